@@ -1,0 +1,127 @@
+"""ctypes view of include/cssm_pf.h and the loader of libcssm_pf.so.
+
+The shared library is the product: hand-written HIP kernels for gfx950 behind a C ABI.  There is
+no CPU fallback -- if the library has not been built (``python -c 'import __graft_entry__ as g;
+g.build()'``) every entry point of this package raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "csrc", "libcssm_pf.so")
+
+# ---- constants (include/cssm_pf.h) ---------------------------------------------------------
+CSSM_OK = 0
+CSSM_EINVAL_DESC = -1
+CSSM_EHIP = -2
+CSSM_ESHARD = -3
+CSSM_ENOMEM = -4
+CSSM_ENONFINITE = -5
+CSSM_EINVAL_ARG = -6
+CSSM_ESTATE = -7
+
+SDE_BROWNIAN, SDE_GEN_BROWNIAN, SDE_OU, SDE_EULER_AFFINE = 0, 1, 2, 3
+F_FIRST, F_SEASONAL = 0, 1
+OBS_POISSON, OBS_GAUSSIAN, OBS_LGCP = 0, 1, 2
+MAX_DIM = 16
+MAX_LEAVES = 16
+
+_dp = C.POINTER(C.c_double)
+
+
+class LeafDesc(C.Structure):
+    _fields_ = [
+        ("sde_kind", C.c_int32), ("dim", C.c_int32), ("f_kind", C.c_int32), ("period", C.c_int32),
+        ("harmonics", C.c_int32), ("has_scale", C.c_int32), ("scale", C.c_double),
+        ("n_m0", C.c_int32), ("n_c0", C.c_int32), ("n_mu", C.c_int32), ("n_phi", C.c_int32),
+        ("n_sigma", C.c_int32), ("reserved", C.c_int32),
+        ("m0", _dp), ("c0", _dp), ("mu", _dp), ("phi", _dp), ("sigma", _dp),
+    ]
+
+
+class ModelDesc(C.Structure):
+    _fields_ = [
+        ("n_leaves", C.c_int32), ("obs_kind", C.c_int32), ("lgcp_precision", C.c_int32),
+        ("reserved", C.c_int32), ("leaves", C.POINTER(LeafDesc)),
+    ]
+
+
+class CssmError(RuntimeError):
+    """Raised for a non-zero status of a cssm_* call (the reference throws from stepFilter)."""
+
+    def __init__(self, code: int, msg: str):
+        super().__init__(f"cssm error {code}: {msg}")
+        self.code = code
+
+
+# Every symbol include/cssm_pf.h declares: (name, restype, argtypes)
+_u64p = C.POINTER(C.c_uint64)
+_i64p = C.POINTER(C.c_int64)
+_i32p = C.POINTER(C.c_int32)
+_u32p = C.POINTER(C.c_uint32)
+_u8p = C.POINTER(C.c_uint8)
+_descp = C.POINTER(ModelDesc)
+_h = C.c_void_p
+
+SYMBOLS = [
+    ("cssm_pf_create", C.c_int, [_descp, C.c_uint64, C.c_uint64, C.c_int, C.POINTER(_h)]),
+    ("cssm_pf_create_shard", C.c_int, [_descp, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64, C.c_int, C.c_void_p, C.POINTER(_h)]),
+    ("cssm_pf_destroy", None, [_h]),
+    ("cssm_pf_set_params", C.c_int, [_h, _descp]),
+    ("cssm_pf_reseed", C.c_int, [_h, C.c_uint64]),
+    ("cssm_pf_init", C.c_int, [_h, C.c_double]),
+    ("cssm_pf_init_from", C.c_int, [_h, C.c_double, _dp]),
+    ("cssm_pf_step", C.c_int, [_h, C.c_double, C.c_double, C.c_int, _dp, _i32p]),
+    ("cssm_pf_ll_filter", C.c_int, [_h, _dp, _dp, _u8p, C.c_size_t, _dp, _dp, _i32p]),
+    ("cssm_pf_filter", C.c_int, [_h, _dp, _dp, _u8p, C.c_size_t, _dp, _dp, _i32p, _dp]),
+    ("cssm_pf_last_loop_ms", C.c_int, [_h, C.POINTER(C.c_float)]),
+    ("cssm_pf_num_particles", C.c_uint64, [_h]),
+    ("cssm_pf_dim", C.c_int32, [_h]),
+    ("cssm_pf_get_particles", C.c_int, [_h, _dp]),
+    ("cssm_pf_get_ancestors", C.c_int, [_h, _u32p]),
+    ("cssm_pf_get_logw", C.c_int, [_h, _dp]),
+    ("cssm_pf_get_proposed", C.c_int, [_h, _dp]),
+    ("cssm_resample_systematic", C.c_int, [_dp, C.c_size_t, C.c_double, _u32p, C.c_int]),
+    ("cssm_pf_shard_init", C.c_int, [_h, C.c_double]),
+    ("cssm_pf_shard_propagate", C.c_int, [_h, C.c_double, C.c_double, C.c_int, C.c_void_p]),
+    ("cssm_pf_shard_sums", C.c_int, [_h, C.c_void_p, C.c_void_p]),
+    ("cssm_pf_shard_offspring", C.c_int, [_h, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    ("cssm_pf_shard_pack", C.c_int, [_h, C.c_int, _i64p, _i64p, C.c_void_p]),
+    ("cssm_pf_shard_adopt", C.c_int, [_h, C.c_void_p, C.c_int64]),
+    ("cssm_pf_shard_result", C.c_int, [_h, _dp, _i32p]),
+    ("cssm_pmmh_run", C.c_int, [_h, _descp, _dp, C.c_size_t, C.c_double, _dp, _dp, _u8p, C.c_size_t,
+                                C.c_uint64, C.c_size_t, _dp, _dp, _i32p, _dp]),
+    ("cssm_desc_flatten", C.c_int, [_descp, _dp, C.c_size_t, C.POINTER(C.c_size_t)]),
+    ("cssm_last_error", C.c_char_p, []),
+    ("cssm_version", C.c_char_p, []),
+]
+
+_lib = None
+
+
+def load_library(path: str | None = None) -> C.CDLL:
+    """dlopen libcssm_pf.so and bind every declared symbol.  Fails loudly if it is missing."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    p = path or LIB_PATH
+    if not os.path.exists(p):
+        raise ImportError(
+            f"{p} not found: the HIP extension is not built. Run `python -c \"import __graft_entry__ "
+            "as g; g.build()\"` (hipcc --offload-arch=gfx950). There is no CPU fallback.")
+    lib = C.CDLL(p, mode=C.RTLD_GLOBAL)
+    for name, res, args in SYMBOLS:
+        fn = getattr(lib, name)  # AttributeError if the library does not export a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    if path is None:
+        _lib = lib
+    return lib
+
+
+def check(rc: int) -> None:
+    if rc != 0:
+        msg = load_library().cssm_last_error()
+        raise CssmError(rc, msg.decode() if msg else "")

@@ -1,0 +1,487 @@
+// cssm_kernels.hip.h -- gfx950 device code of libcssm_pf (included once, by cssm_pf.hip).
+//
+// Data layout in HBM: particles are struct-of-arrays fp64,
+// state[k * stride + i] = latent component k (Tree.flatten order) of particle i, two buffers
+// that ping-pong; logw[N] fp64; endslot[N] u32 (exclusive end of the run of resampling slots
+// particle j owns); anc[N] u32.  Resampling never moves particles: the NEXT propagate kernel
+// reads its input through anc[] (fused gather), so a step costs one read and one write of
+// the cloud.
+//
+// Kernels of one observation (all HBM-bound element-wise / scan work, no MFMA):
+//   k_propagate   gather + exact SDE transition (or Euler-Maruyama) + f + log-density, block
+//                 max -> one integer atomicMax per block             model/ParticleFilter.scala:118,123-124
+//   k_tile_sums   w1 = exp(w - max) in 128-bit fixed point, one (S, S2) per 1024-particle tile   :125
+//   k_scan_tiles  exclusive scan of the tile sums (single block), ll and ess                     :127-128
+//   k_offspring   per tile: LDS scan -> cumulative weight C_j -> end slot cnt(C_j)     model/Resampling.scala:52-58
+//   k_expand      per tile: slots [end_{j-1}, end_j) <- j by binary search in LDS       model/Resampling.scala:36-46,69
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/cssm_numerics.h"
+#include "../../include/cssm_pf.h"
+
+#define CSSM_BLOCK 256
+#define CSSM_ITEMS 4
+#define CSSM_TILE (CSSM_BLOCK * CSSM_ITEMS) /* 1024 particles per tile */
+
+// f-map modes per component (host-built from the leaf list; oracle: gamma_of)
+#define FM_SKIP 0
+#define FM_START 1 /* first used component of a leaf: acc = c*x  */
+#define FM_ADD 2   /* acc += c*x                                 */
+
+// Per-model constants, passed BY VALUE (kernarg -> SGPRs; every branch on them is wave-uniform).
+struct ModelK {
+  int32_t d;
+  int32_t obs_kind;
+  int32_t kind[CSSM_MAX_DIM];    // CSSM_SDE_*
+  int32_t fmode[CSSM_MAX_DIM];   // FM_*
+  int32_t leaf_end[CSSM_MAX_DIM];// 1 if component closes its leaf
+  int32_t first_leaf[CSSM_MAX_DIM]; // 1 if that leaf is the leftmost one
+};
+
+// Per-observation record, built on the host (everything that depends only on (t, y)).
+struct StepRec {
+  double y;       // Poisson: (double)trunc(y); Gaussian: y
+  double aux;     // Poisson: lgamma(k+1); Gaussian: log(sqrt(2 pi) sd)
+  double aux2;    // Gaussian: sd
+  double u;       // the one uniform of systematic resampling
+  double dt;      // time increment (LGCP: the sub-step delta)
+  int32_t has_obs;
+  int32_t n_sub;  // LGCP sub-steps (0: dt == 0, weight 0, state kept)
+  uint32_t pick;  // sampleOne index for `filter`
+  uint32_t step;  // observation index (Philox counter word 2)
+  double coef[CSSM_MAX_DIM][4]; // transition coefficients per component
+  double fco[CSSM_MAX_DIM];     // f coefficients c_k(t)
+};
+
+// Device scalars of a handle.
+struct Scalars {
+  unsigned long long maxkey; // order key of the running max log-weight (atomicMax)
+  uint32_t err;              // bit0: NaN log-weight, bit1: all weights zero / max not finite
+  int32_t ess;
+  double gmax;               // decoded global max of this step
+  double ll;                 // accumulated log-likelihood
+  cssm_u128 S_local, S2_local; // local fixed-point sums (this rank)
+  cssm_u128 S_off;           // sum of the ranks before this one
+  cssm_u128 S_tot, S2_tot;   // global sums
+};
+
+// ------------------------------------------------------------------------------------ helpers
+
+__device__ __forceinline__ double wave_max(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    double o = __shfl_xor(v, off, 64);
+    v = (o > v) ? o : v;
+  }
+  return v;
+}
+
+__device__ __forceinline__ cssm_u128 shfl_up_u128(cssm_u128 v, int off) {
+  cssm_u128 r;
+  r.lo = __shfl_up((unsigned long long)v.lo, off, 64);
+  r.hi = __shfl_up((unsigned long long)v.hi, off, 64);
+  return r;
+}
+__device__ __forceinline__ cssm_u128 shfl_xor_u128(cssm_u128 v, int off) {
+  cssm_u128 r;
+  r.lo = __shfl_xor((unsigned long long)v.lo, off, 64);
+  r.hi = __shfl_xor((unsigned long long)v.hi, off, 64);
+  return r;
+}
+__device__ __forceinline__ cssm_u128 wave_sum_u128(cssm_u128 v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v = cssm_u128_add(v, shfl_xor_u128(v, off));
+  return v;
+}
+// inclusive scan across the 64 lanes (integer adds: any order gives the same bits)
+__device__ __forceinline__ cssm_u128 wave_scan_u128(cssm_u128 v, int lane) {
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    cssm_u128 o = shfl_up_u128(v, off);
+    if (lane >= off) v = cssm_u128_add(v, o);
+  }
+  return v;
+}
+
+// d standard normals of global particle gid (component k = element k&1 of Philox pair k>>1)
+template <int D>
+__device__ __forceinline__ void draw_normals(uint64_t seed, uint64_t gid, uint32_t step, uint32_t tag,
+                                             uint32_t sub, double (&z)[D]) {
+#pragma unroll
+  for (int p = 0; 2 * p < D; ++p) {
+    double z0, z1;
+    cssm_normal_pair(cssm_philox_draw(seed, gid, step, tag, sub, (uint32_t)p), &z0, &z1);
+    z[2 * p] = z0;
+    if (2 * p + 1 < D) z[2 * p + 1] = z1;
+  }
+}
+
+// One transition of all components (model/Sde.scala:86-95,114-123,139-150; :30-43 for Euler).
+template <int D>
+__device__ __forceinline__ void transition(const ModelK& mk, const StepRec* __restrict__ rec, double dt,
+                                           double (&x)[D], const double (&z)[D]) {
+#pragma unroll
+  for (int k = 0; k < D; ++k) {
+    const double p0 = rec->coef[k][0], p1 = rec->coef[k][1], p2 = rec->coef[k][2], p3 = rec->coef[k][3];
+    const int kind = mk.kind[k];
+    if (kind == CSSM_SDE_BROWNIAN) {
+      x[k] = p3 * z[k] + x[k];
+    } else if (kind == CSSM_SDE_GEN_BROWNIAN) {
+      double mean = x[k] + p0;
+      x[k] = p3 * z[k] + mean;
+    } else if (kind == CSSM_SDE_OU) {
+      double mean = p0 + (x[k] - p0) * p1;
+      x[k] = p3 * z[k] + mean;
+    } else {
+      double dW = p3 * z[k];
+      double a = (p0 + p1 * x[k]) * dt;
+      double b = p2 * dW;
+      x[k] = (x[k] + a) + b;
+    }
+  }
+}
+
+// gamma = f(x, t): per-leaf dot product, leaves summed left-nested (model/Model.scala:122-128,217-225,271)
+template <int D>
+__device__ __forceinline__ double gamma_of(const ModelK& mk, const StepRec* __restrict__ rec, const double (&x)[D]) {
+  double g = 0.0, acc = 0.0;
+#pragma unroll
+  for (int k = 0; k < D; ++k) {
+    const int fm = mk.fmode[k];
+    if (fm == FM_START) acc = rec->fco[k] * x[k];
+    else if (fm == FM_ADD) acc = acc + rec->fco[k] * x[k];
+    if (mk.leaf_end[k]) g = mk.first_leaf[k] ? acc : g + acc;
+  }
+  return g;
+}
+
+__device__ __forceinline__ double logdens(const ModelK& mk, const StepRec* __restrict__ rec, double g) {
+  if (mk.obs_kind == CSSM_OBS_POISSON) {
+    // breeze Poisson.logProbabilityOf: -lambda + k log(lambda) - lgamma(k+1), model/Model.scala:273
+    return -cssm_exp(g) + rec->y * g - rec->aux;
+  }
+  // breeze Gaussian.logPdf, model/Model.scala:252-258
+  double dd = (rec->y - g) / rec->aux2;
+  return -(dd * dd) / 2.0 - rec->aux;
+}
+
+// ------------------------------------------------------------------------------------ init
+
+// initialiseState, model/ParticleFilter.scala:105-108: x0 = sqrt(c0) z + m0
+template <int D>
+__global__ __launch_bounds__(CSSM_BLOCK) void k_init(double* __restrict__ dst, size_t stride, uint64_t n,
+                                                     uint64_t gid0, uint64_t seed, const double* __restrict__ m0,
+                                                     const double* __restrict__ sd0) {
+  for (uint64_t i = (uint64_t)blockIdx.x * CSSM_BLOCK + threadIdx.x; i < n; i += (uint64_t)gridDim.x * CSSM_BLOCK) {
+    double z[D];
+    draw_normals<D>(seed, gid0 + i, 0u, CSSM_STREAM_INIT, 0u, z);
+#pragma unroll
+    for (int k = 0; k < D; ++k) dst[(size_t)k * stride + i] = sd0[k] * z[k] + m0[k];
+  }
+}
+
+// FilterInit.initialiseState, model/ParticleFilter.scala:257-260
+__global__ void k_init_from(double* __restrict__ dst, size_t stride, uint64_t n, int d, const double* __restrict__ s) {
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x)
+    for (int k = 0; k < d; ++k) dst[(size_t)k * stride + i] = s[k];
+}
+
+// ------------------------------------------------------------------------------------ propagate + weight
+
+// stepFilter lines :118 and :123-124 fused (LGCP: calcWeight :184-208).  src is read through
+// anc[] when anc != nullptr (the previous step's resampling).
+template <int D, bool LGCP>
+__global__ __launch_bounds__(CSSM_BLOCK) void k_propagate(
+    const double* __restrict__ src, size_t src_stride, const uint32_t* __restrict__ anc,
+    double* __restrict__ dst, size_t dst_stride, double* __restrict__ logw, uint64_t n, uint64_t gid0,
+    uint64_t seed, const StepRec* __restrict__ rec, ModelK mk, Scalars* __restrict__ sc) {
+  __shared__ double s_max[CSSM_BLOCK / 64];
+  const uint32_t step = rec->step;
+  const int has_obs = rec->has_obs;
+  const double dt = rec->dt;
+  double tmax = -cssm_inf();
+  bool bad = false;
+  for (uint64_t i = (uint64_t)blockIdx.x * CSSM_BLOCK + threadIdx.x; i < n; i += (uint64_t)gridDim.x * CSSM_BLOCK) {
+    const size_t j = anc ? (size_t)anc[i] : (size_t)i;
+    double x[D], z[D];
+#pragma unroll
+    for (int k = 0; k < D; ++k) x[k] = src[(size_t)k * src_stride + j];
+    double lw;
+    if (LGCP) {
+      const int nsub = rec->n_sub;
+      if (nsub == 0) {                     // dt == 0: (x, f, f), model/ParticleFilter.scala:212-213
+        double g = gamma_of<D>(mk, rec, x);
+        lw = g - g;
+      } else {
+        double haz = 0.0;
+        for (int s = 0; s < nsub; ++s) {   // simInitStream(...).take(n), :193-194
+          draw_normals<D>(seed, gid0 + i, step, CSSM_STREAM_STEP, (uint32_t)s, z);
+          transition<D>(mk, rec, dt, x, z);
+          haz = haz + cssm_exp(gamma_of<D>(mk, rec, x)) * dt;   // :203-205
+        }
+        lw = gamma_of<D>(mk, rec, x) - haz;                   // :200,:217
+      }
+    } else {
+      draw_normals<D>(seed, gid0 + i, step, CSSM_STREAM_STEP, 0u, z);
+      transition<D>(mk, rec, dt, x, z);
+      lw = has_obs ? logdens(mk, rec, gamma_of<D>(mk, rec, x)) : 0.0;
+    }
+#pragma unroll
+    for (int k = 0; k < D; ++k) dst[(size_t)k * dst_stride + i] = x[k];
+    if (LGCP || has_obs) {
+      if (lw != lw) { bad = true; lw = -cssm_inf(); }
+      logw[i] = lw;
+      tmax = (lw > tmax) ? lw : tmax;
+    }
+  }
+  if (!(LGCP || has_obs)) return;
+  tmax = wave_max(tmax);
+  if ((threadIdx.x & 63) == 0) s_max[threadIdx.x >> 6] = tmax;
+  if (__any(bad) && (threadIdx.x & 63) == 0) atomicOr(&sc->err, 1u);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double m = s_max[0];
+#pragma unroll
+    for (int w = 1; w < CSSM_BLOCK / 64; ++w) m = (s_max[w] > m) ? s_max[w] : m;
+    atomicMax(&sc->maxkey, (unsigned long long)cssm_order_key(m));
+  }
+}
+
+// decode the global max once per step (single GPU); multi-GPU overwrites gmax after its all-reduce
+__global__ void k_decode_max(Scalars* sc) {
+  sc->gmax = cssm_order_unkey(sc->maxkey);
+  sc->maxkey = 0ull;
+}
+
+// ------------------------------------------------------------------------------------ tile sums
+
+// raw != 0: `logw` already holds the weights w1 themselves (stateless Resample[A] entry point,
+// whose second argument is w1 = exp(w - max): model/ParticleFilter.scala:125-126).
+__device__ __forceinline__ void load_tile_weights(const double* __restrict__ logw, uint64_t base, uint64_t n,
+                                                  double gmax, int raw, double (&w1)[CSSM_ITEMS]) {
+  const uint64_t i0 = base + (uint64_t)threadIdx.x * CSSM_ITEMS;
+  double v[CSSM_ITEMS];
+  if (i0 + CSSM_ITEMS <= n) {
+    const double2 a = *reinterpret_cast<const double2*>(logw + i0);
+    const double2 b = *reinterpret_cast<const double2*>(logw + i0 + 2);
+    v[0] = a.x; v[1] = a.y; v[2] = b.x; v[3] = b.y;
+  } else {
+#pragma unroll
+    for (int r = 0; r < CSSM_ITEMS; ++r) v[r] = (i0 + r < n) ? logw[i0 + r] : (raw ? 0.0 : -cssm_inf());
+  }
+#pragma unroll
+  for (int r = 0; r < CSSM_ITEMS; ++r) w1[r] = raw ? v[r] : cssm_exp(v[r] - gmax);
+}
+
+// w1 = exp(w - max) (model/ParticleFilter.scala:125); S = sum w1, S2 = sum w1^2 per tile, fixed point.
+__global__ __launch_bounds__(CSSM_BLOCK) void k_tile_sums(const double* __restrict__ logw, uint64_t n,
+                                                          const Scalars* __restrict__ sc,
+                                                          cssm_u128* __restrict__ tileS, cssm_u128* __restrict__ tileS2,
+                                                          uint32_t ntiles, int raw) {
+  __shared__ cssm_u128 s_a[CSSM_BLOCK / 64], s_b[CSSM_BLOCK / 64];
+  const double gmax = sc->gmax;
+  for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    double w1[CSSM_ITEMS];
+    load_tile_weights(logw, (uint64_t)tile * CSSM_TILE, n, gmax, raw, w1);
+    cssm_u128 a = cssm_u128_zero(), b = cssm_u128_zero();
+#pragma unroll
+    for (int r = 0; r < CSSM_ITEMS; ++r) {
+      a = cssm_u128_add(a, cssm_fix_from_double(w1[r]));
+      b = cssm_u128_add(b, cssm_fix_from_double(w1[r] * w1[r]));
+    }
+    a = wave_sum_u128(a);
+    b = wave_sum_u128(b);
+    if ((threadIdx.x & 63) == 0) { s_a[threadIdx.x >> 6] = a; s_b[threadIdx.x >> 6] = b; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      cssm_u128 ta = s_a[0], tb = s_b[0];
+#pragma unroll
+      for (int w = 1; w < CSSM_BLOCK / 64; ++w) { ta = cssm_u128_add(ta, s_a[w]); tb = cssm_u128_add(tb, s_b[w]); }
+      tileS[tile] = ta; tileS2[tile] = tb;
+    }
+    __syncthreads();
+  }
+}
+
+// ll += max + log(mean(w1)) (:127, :522-524); ess = floor(1 / sum (w1/tot)^2) (:128, :431-434)
+__device__ void finish_step(Scalars* sc, uint64_t n_global) {
+  const double tot = cssm_fix_to_double(sc->S_tot);
+  const double tot2 = cssm_fix_to_double(sc->S2_tot);
+  if (cssm_u128_is_zero(sc->S_tot) || !(sc->gmax > -cssm_inf()) || !(sc->gmax < cssm_inf())) {
+    atomicOr(&sc->err, 2u);
+    return;
+  }
+  sc->ll = sc->ll + sc->gmax + cssm_log(tot / (double)n_global);
+  double e = 1.0 / (tot2 / (tot * tot));
+  double fl = (double)(long long)e;   // e >= 1 here; floor == trunc
+  sc->ess = (e < 2147483647.0) ? (int32_t)fl : 2147483647;
+}
+
+// Exclusive scan of the tile sums in one block; local totals; with world == 1 also the step's ll/ess.
+__global__ __launch_bounds__(1024) void k_scan_tiles(const cssm_u128* __restrict__ tileS, const cssm_u128* __restrict__ tileS2,
+                                                     cssm_u128* __restrict__ tileP, uint32_t ntiles, Scalars* sc,
+                                                     uint64_t n_global, int single) {
+  __shared__ cssm_u128 s_w[16], s_w2[16];
+  __shared__ cssm_u128 s_carry, s_carry2;
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  if (threadIdx.x == 0) { s_carry = cssm_u128_zero(); s_carry2 = cssm_u128_zero(); }
+  __syncthreads();
+  for (uint32_t base = 0; base < ntiles; base += 1024) {
+    const uint32_t t = base + threadIdx.x;
+    cssm_u128 v = (t < ntiles) ? tileS[t] : cssm_u128_zero();
+    cssm_u128 v2 = (t < ntiles) ? tileS2[t] : cssm_u128_zero();
+    cssm_u128 inc = wave_scan_u128(v, lane);
+    cssm_u128 tot2 = wave_sum_u128(v2);
+    if (lane == 63) s_w[wid] = inc;
+    if (lane == 0) s_w2[wid] = tot2;
+    __syncthreads();
+    cssm_u128 off = s_carry;
+    for (int w = 0; w < wid; ++w) off = cssm_u128_add(off, s_w[w]);
+    if (t < ntiles) {
+      // exclusive prefix = off + inc - v  (integers: exact)
+      cssm_u128 ex = cssm_u128_add(off, inc);
+      cssm_u128 r; r.lo = ex.lo - v.lo; r.hi = ex.hi - v.hi - (ex.lo < v.lo ? 1u : 0u);
+      tileP[t] = r;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      cssm_u128 c = s_carry, c2 = s_carry2;
+      for (int w = 0; w < 16; ++w) { c = cssm_u128_add(c, s_w[w]); c2 = cssm_u128_add(c2, s_w2[w]); }
+      s_carry = c; s_carry2 = c2;
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    sc->S_local = s_carry; sc->S2_local = s_carry2;
+    if (single) {
+      sc->S_off = cssm_u128_zero();
+      sc->S_tot = s_carry; sc->S2_tot = s_carry2;
+      finish_step(sc, n_global);
+    }
+  }
+}
+
+// Multi-GPU: after the all-gather of (S.lo, S.hi, S2.lo, S2.hi) per rank.
+__global__ void k_global_sums(const unsigned long long* __restrict__ all4, int rank, int world, Scalars* sc, uint64_t n_global) {
+  cssm_u128 off = cssm_u128_zero(), tot = cssm_u128_zero(), tot2 = cssm_u128_zero();
+  for (int r = 0; r < world; ++r) {
+    cssm_u128 a, b;
+    a.lo = all4[4 * r + 0]; a.hi = all4[4 * r + 1]; b.lo = all4[4 * r + 2]; b.hi = all4[4 * r + 3];
+    if (r < rank) off = cssm_u128_add(off, a);
+    tot = cssm_u128_add(tot, a); tot2 = cssm_u128_add(tot2, b);
+  }
+  sc->S_off = off; sc->S_tot = tot; sc->S2_tot = tot2;
+  finish_step(sc, n_global);
+}
+
+// ------------------------------------------------------------------------------------ offspring (end slots)
+
+// treeEcdf (model/Resampling.scala:52-58): C_j = (sum_{i<=j} w1_i) / (sum_i w1_i), here the
+// correctly rounded quotient of the exact fixed-point sums; end slot of particle j =
+// #{ i : (u+i)/N <= C_j } (the ks of :69 against the keys of the TreeMap).
+__global__ __launch_bounds__(CSSM_BLOCK) void k_offspring(const double* __restrict__ logw, uint64_t n,
+                                                          const Scalars* __restrict__ sc,
+                                                          const cssm_u128* __restrict__ tileP,
+                                                          const StepRec* __restrict__ rec, uint64_t n_global,
+                                                          uint32_t* __restrict__ endslot, uint32_t ntiles, int raw) {
+  __shared__ cssm_u128 s_w[CSSM_BLOCK / 64];
+  const double gmax = sc->gmax;
+  const double u = rec->u;
+  const double totd = cssm_u128_to_double(sc->S_tot);
+  const cssm_u128 S_off = sc->S_off;
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const uint64_t base = (uint64_t)tile * CSSM_TILE;
+    double w1[CSSM_ITEMS];
+    load_tile_weights(logw, base, n, gmax, raw, w1);
+    cssm_u128 q[CSSM_ITEMS];
+    cssm_u128 tsum = cssm_u128_zero();
+#pragma unroll
+    for (int r = 0; r < CSSM_ITEMS; ++r) { q[r] = cssm_fix_from_double(w1[r]); tsum = cssm_u128_add(tsum, q[r]); }
+    cssm_u128 inc = wave_scan_u128(tsum, lane);
+    if (lane == 63) s_w[wid] = inc;
+    __syncthreads();
+    cssm_u128 off = cssm_u128_add(S_off, tileP[tile]);
+    for (int w = 0; w < wid; ++w) off = cssm_u128_add(off, s_w[w]);
+    // exclusive prefix of this thread = off + inc - tsum
+    cssm_u128 run = cssm_u128_add(off, inc);
+    { cssm_u128 r; r.lo = run.lo - tsum.lo; r.hi = run.hi - tsum.hi - (run.lo < tsum.lo ? 1u : 0u); run = r; }
+    uint32_t e[CSSM_ITEMS];
+#pragma unroll
+    for (int r = 0; r < CSSM_ITEMS; ++r) {
+      run = cssm_u128_add(run, q[r]);
+      const double C = cssm_u128_to_double(run) / totd;
+      e[r] = (uint32_t)cssm_sys_count(C, u, n_global);
+    }
+    const uint64_t i0 = base + (uint64_t)threadIdx.x * CSSM_ITEMS;
+    if (i0 + CSSM_ITEMS <= n) {
+      *reinterpret_cast<uint4*>(endslot + i0) = make_uint4(e[0], e[1], e[2], e[3]);
+    } else {
+#pragma unroll
+      for (int r = 0; r < CSSM_ITEMS; ++r) if (i0 + r < n) endslot[i0 + r] = e[r];
+    }
+    __syncthreads();
+  }
+}
+
+// ------------------------------------------------------------------------------------ expand
+
+// findAllInTreeMap (model/Resampling.scala:36-46): slot s copies the first particle j whose end
+// slot exceeds s.  `endslot` holds m candidate particles in global order (single GPU: all N;
+// sharded: the candidates received for this rank); this rank's slots are [slot_lo, slot_hi);
+// anc[s - slot_lo] = index into the candidate array.
+__global__ __launch_bounds__(CSSM_BLOCK) void k_expand(const uint32_t* __restrict__ endslot, uint64_t m,
+                                                       uint64_t slot_lo, uint64_t slot_hi,
+                                                       uint32_t* __restrict__ anc, uint32_t ntiles) {
+  __shared__ uint32_t s_e[CSSM_TILE];
+  for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const uint64_t base = (uint64_t)tile * CSSM_TILE;
+    const uint32_t cnt = (uint32_t)((m - base < CSSM_TILE) ? (m - base) : CSSM_TILE);
+    for (uint32_t r = threadIdx.x; r < cnt; r += CSSM_BLOCK) s_e[r] = endslot[base + r];
+    __syncthreads();
+    uint64_t s_begin = (tile == 0) ? slot_lo : (uint64_t)endslot[base - 1];
+    uint64_t s_end = s_e[cnt - 1];
+    if (s_begin < slot_lo) s_begin = slot_lo;
+    if (s_end > slot_hi) s_end = slot_hi;
+    for (uint64_t s = s_begin + threadIdx.x; s < s_end; s += CSSM_BLOCK) {
+      // first idx in [0, cnt) with s_e[idx] > s (exists: s < s_e[cnt-1])
+      uint32_t lo = 0, hi = cnt - 1;
+      while (lo < hi) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (s_e[mid] > (uint32_t)s) hi = mid; else lo = mid + 1;
+      }
+      anc[s - slot_lo] = (uint32_t)(base + lo);
+    }
+    __syncthreads();
+  }
+}
+
+// ------------------------------------------------------------------------------------ gather / pick
+
+// PfState.particles on demand: out[k][i] = src[k][anc[i]]
+__global__ void k_gather(const double* __restrict__ src, size_t src_stride, const uint32_t* __restrict__ anc,
+                         double* __restrict__ out, size_t out_stride, uint64_t n, int d) {
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+    const size_t j = anc ? (size_t)anc[i] : (size_t)i;
+    for (int k = 0; k < d; ++k) out[(size_t)k * out_stride + i] = src[(size_t)k * src_stride + j];
+  }
+}
+
+// Resampling.sampleOne for `filter` (model/ParticleFilter.scala:157): one particle of the current cloud
+__global__ void k_pick(const double* __restrict__ src, size_t src_stride, const uint32_t* __restrict__ anc,
+                       uint64_t idx, int d, double* __restrict__ out_row) {
+  const int k = threadIdx.x;
+  if (k < d) {
+    const size_t j = anc ? (size_t)anc[idx] : (size_t)idx;
+    out_row[k] = src[(size_t)k * src_stride + j];
+  }
+}
+
+// per-step record of results for the batch drivers
+__global__ void k_record(const Scalars* __restrict__ sc, double* __restrict__ ll_t, int32_t* __restrict__ ess_t, uint32_t s) {
+  ll_t[s] = sc->ll;
+  ess_t[s] = sc->ess;
+}

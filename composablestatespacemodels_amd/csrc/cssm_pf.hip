@@ -1,0 +1,908 @@
+// cssm_pf.hip -- host side of libcssm_pf: the C ABI of include/cssm_pf.h over the gfx950
+// kernels of cssm_kernels.hip.h.  No torch, no CPU compute path: every entry point drives HIP.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "cssm_kernels.hip.h"
+
+// ------------------------------------------------------------------------------------ errors
+
+static thread_local std::string g_err;
+
+static int fail(int code, const char* fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  g_err = buf;
+  return code;
+}
+
+#define HIP_TRY(expr)                                                                         \
+  do {                                                                                        \
+    hipError_t e__ = (expr);                                                                  \
+    if (e__ != hipSuccess) return fail(CSSM_EHIP, "%s: %s (%s:%d)", #expr, hipGetErrorString(e__), __FILE__, __LINE__); \
+  } while (0)
+
+extern "C" const char* cssm_last_error(void) { return g_err.c_str(); }
+extern "C" const char* cssm_version(void) { return "cssm_pf 0.1 (gfx950, numerics contract v1)"; }
+
+// ------------------------------------------------------------------------------------ handle
+
+struct Comp {
+  int kind, leaf, idx, f_kind, period;
+  double m0, c0, mu, phi, sigma;
+};
+
+struct cssm_pf {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  bool own_stream = true;
+  // model
+  int d = 0, n_leaves = 0, obs_kind = 0, precision = 0;
+  double scale_sd = 1.0;
+  Comp comp[CSSM_MAX_DIM];
+  ModelK mk;
+  // sizes
+  uint64_t n_global = 0, first = 0, n = 0, seed = 0;
+  size_t stride = 0;
+  uint32_t ntiles = 0;
+  bool sharded = false;
+  // device memory
+  double* state[2] = {nullptr, nullptr};
+  int cur = 0;                 // state[cur] = propagated cloud of the last step (x1)
+  const double* src = nullptr; // where the next propagate reads (state[cur] or the candidate buffer)
+  size_t src_stride = 0;
+  double* logw = nullptr;
+  uint32_t* endslot = nullptr;
+  uint32_t* anc = nullptr;
+  bool anc_valid = false;
+  cssm_u128 *tileS = nullptr, *tileS2 = nullptr, *tileP = nullptr;
+  Scalars* sc = nullptr;
+  double *d_m0 = nullptr, *d_sd0 = nullptr;
+  StepRec* d_recs = nullptr;
+  size_t recs_cap = 0;
+  double* d_ll_t = nullptr;
+  int32_t* d_ess_t = nullptr;
+  double* d_path = nullptr;
+  size_t path_cap = 0;
+  // sharded extras
+  double* cand = nullptr;      // candidate states received for this rank, SoA [d][cand_cap]
+  uint32_t* cand_end = nullptr;
+  size_t cand_cap = 0;
+  int64_t* d_bounds = nullptr;
+  // host staging (pinned)
+  StepRec* h_recs = nullptr;
+  size_t h_recs_cap = 0;
+  // filter state
+  double t = 0.0;
+  uint32_t step = 0;
+  bool initialised = false;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  float last_ms = 0.f;
+};
+
+static inline int grid_for(uint64_t n, int block, int cap) {
+  uint64_t g = (n + block - 1) / block;
+  if (g > (uint64_t)cap) g = cap;
+  if (g < 1) g = 1;
+  return (int)g;
+}
+
+// ------------------------------------------------------------------------------------ model
+
+static double rep(const double* v, int n, int i) { return v[i % n]; }               // Sde.buildParamRepeat, model/Sde.scala:177-179
+static double logistic(double x) { return 1.0 / (1.0 + cssm_exp(-x)); }              // model/SdeParameters.scala:214-216
+
+// Constraint transforms of the SDE constructors: model/Sde.scala:70-73 (GenBrownian),
+// :99-102 (Brownian), :133-137 (OU, logistic applied to the stored value).
+static int build_model(cssm_pf* pf, const cssm_model_desc* desc) {
+  if (!desc || !desc->leaves) return fail(CSSM_EINVAL_DESC, "null model descriptor");
+  if (desc->n_leaves < 1 || desc->n_leaves > CSSM_MAX_LEAVES) return fail(CSSM_EINVAL_DESC, "n_leaves = %d out of range", desc->n_leaves);
+  int d = 0;
+  for (int l = 0; l < desc->n_leaves; ++l) {
+    const cssm_leaf_desc* L = &desc->leaves[l];
+    if (L->dim < 1 || d + L->dim > CSSM_MAX_DIM) return fail(CSSM_EINVAL_DESC, "leaf %d: dimension %d (total > %d)", l, L->dim, CSSM_MAX_DIM);
+    if (L->n_m0 < 1 || L->n_c0 < 1 || L->n_sigma < 1 || !L->m0 || !L->c0 || !L->sigma)
+      return fail(CSSM_EINVAL_DESC, "leaf %d: m0, c0 and sigma are required", l);
+    const bool need_mu = L->sde_kind == CSSM_SDE_GEN_BROWNIAN || L->sde_kind == CSSM_SDE_OU || L->sde_kind == CSSM_SDE_EULER_AFFINE;
+    const bool need_phi = L->sde_kind == CSSM_SDE_OU || L->sde_kind == CSSM_SDE_EULER_AFFINE;
+    if (L->sde_kind < 0 || L->sde_kind > CSSM_SDE_EULER_AFFINE) return fail(CSSM_EINVAL_DESC, "leaf %d: unknown sde_kind %d", l, L->sde_kind);
+    if (need_mu && (L->n_mu < 1 || !L->mu)) return fail(CSSM_EINVAL_DESC, "leaf %d: mu is required", l);
+    if (need_phi && (L->n_phi < 1 || !L->phi)) return fail(CSSM_EINVAL_DESC, "leaf %d: phi is required", l);
+    if (L->f_kind == CSSM_F_SEASONAL) {
+      if (L->dim != 2 * L->harmonics || L->period < 1) return fail(CSSM_EINVAL_DESC, "leaf %d: seasonal needs dim == 2*harmonics and period >= 1", l);
+      if (desc->obs_kind == CSSM_OBS_LGCP) return fail(CSSM_EINVAL_DESC, "leaf %d: a seasonal leaf under the LGCP filter is not supported", l);
+    } else if (L->f_kind != CSSM_F_FIRST) {
+      return fail(CSSM_EINVAL_DESC, "leaf %d: unknown f_kind %d", l, L->f_kind);
+    }
+    for (int i = 0; i < L->dim; ++i) {
+      Comp& c = pf->comp[d + i];
+      c = Comp{};
+      c.kind = L->sde_kind; c.leaf = l; c.idx = i; c.f_kind = L->f_kind; c.period = L->period;
+      c.m0 = rep(L->m0, L->n_m0, i);
+      c.c0 = cssm_exp(rep(L->c0, L->n_c0, i));
+      switch (L->sde_kind) {
+        case CSSM_SDE_BROWNIAN: c.sigma = cssm_exp(rep(L->sigma, L->n_sigma, i)); break;
+        case CSSM_SDE_GEN_BROWNIAN: c.mu = rep(L->mu, L->n_mu, i); c.sigma = cssm_exp(rep(L->sigma, L->n_sigma, i)); break;
+        case CSSM_SDE_OU:
+          c.phi = logistic(rep(L->phi, L->n_phi, i));
+          c.mu = rep(L->mu, L->n_mu, i);
+          c.sigma = cssm_exp(rep(L->sigma, L->n_sigma, i));
+          break;
+        default: c.mu = rep(L->mu, L->n_mu, i); c.phi = rep(L->phi, L->n_phi, i); c.sigma = rep(L->sigma, L->n_sigma, i); break;
+      }
+    }
+    d += L->dim;
+  }
+  if (pf->d != 0 && pf->d != d) return fail(CSSM_EINVAL_DESC, "set_params: latent dimension changed (%d -> %d)", pf->d, d);
+  pf->d = d;
+  pf->n_leaves = desc->n_leaves;
+  pf->obs_kind = desc->obs_kind;
+  pf->precision = desc->lgcp_precision;
+  if (desc->obs_kind == CSSM_OBS_GAUSSIAN) {
+    if (!desc->leaves[0].has_scale) return fail(CSSM_EINVAL_DESC, "Must provide SD parameter for a Gaussian observation model");
+    pf->scale_sd = cssm_exp(desc->leaves[0].scale);    // model/Model.scala:244
+  } else if (desc->obs_kind != CSSM_OBS_POISSON && desc->obs_kind != CSSM_OBS_LGCP) {
+    return fail(CSSM_EINVAL_DESC, "unknown obs_kind %d", desc->obs_kind);
+  }
+  if (desc->obs_kind == CSSM_OBS_LGCP && (desc->lgcp_precision < 0 || desc->lgcp_precision > 9))
+    return fail(CSSM_EINVAL_DESC, "lgcp_precision %d out of range", desc->lgcp_precision);
+  // kernel-side constants
+  ModelK& mk = pf->mk;
+  memset(&mk, 0, sizeof mk);
+  mk.d = d; mk.obs_kind = desc->obs_kind;
+  for (int k = 0; k < d; ++k) {
+    const Comp& c = pf->comp[k];
+    mk.kind[k] = c.kind;
+    if (c.f_kind == CSSM_F_FIRST) mk.fmode[k] = (c.idx == 0) ? FM_START : FM_SKIP;
+    else mk.fmode[k] = (c.idx == 0) ? FM_START : FM_ADD;
+    mk.leaf_end[k] = (k + 1 == d) || (pf->comp[k + 1].leaf != c.leaf);
+    mk.first_leaf[k] = (c.leaf == 0);
+  }
+  return CSSM_OK;
+}
+
+static int upload_init_params(cssm_pf* pf) {
+  double m0[CSSM_MAX_DIM], sd0[CSSM_MAX_DIM];
+  for (int k = 0; k < pf->d; ++k) { m0[k] = pf->comp[k].m0; sd0[k] = std::sqrt(pf->comp[k].c0); }
+  HIP_TRY(hipMemcpyAsync(pf->d_m0, m0, pf->d * 8, hipMemcpyHostToDevice, pf->stream));
+  HIP_TRY(hipMemcpyAsync(pf->d_sd0, sd0, pf->d * 8, hipMemcpyHostToDevice, pf->stream));
+  HIP_TRY(hipStreamSynchronize(pf->stream));
+  return CSSM_OK;
+}
+
+// Everything of one observation that does not depend on the particle: transition coefficients
+// (model/Sde.scala:88-91,117-119,139-146), F(t) (model/Model.scala:217-223), the observation
+// constants, the resampling uniform (model/Resampling.scala:66) and the sampleOne index (:152).
+static void build_rec(const cssm_pf* pf, double t_prev, double t, double y, int has_obs, uint32_t step, StepRec* r) {
+  memset(r, 0, sizeof *r);
+  double dt = t - t_prev;                                      // model/ParticleFilter.scala:117
+  r->has_obs = has_obs;
+  r->step = step;
+  r->n_sub = 0;
+  if (pf->obs_kind == CSSM_OBS_LGCP) {
+    r->has_obs = 1;                                            // FilterLgcp always weights (:210-226)
+    if (dt == 0) { r->n_sub = 0; }
+    else {
+      const double delta = std::pow(10.0, -pf->precision);     // :190
+      r->n_sub = (int)std::ceil(dt / delta);
+      dt = delta;
+    }
+  }
+  r->dt = dt;
+  for (int k = 0; k < pf->d; ++k) {
+    const Comp& c = pf->comp[k];
+    double* p = r->coef[k];
+    switch (c.kind) {
+      case CSSM_SDE_BROWNIAN: p[3] = std::sqrt(c.sigma * dt); break;
+      case CSSM_SDE_GEN_BROWNIAN: p[0] = c.mu * dt; p[3] = std::sqrt(c.sigma * dt); break;
+      case CSSM_SDE_OU: {
+        const double var = (c.sigma * c.sigma / (c.phi * 2.0)) * (1.0 - cssm_exp(c.phi * -2.0 * dt));
+        p[0] = c.mu; p[1] = cssm_exp(-c.phi * dt); p[3] = std::sqrt(var);
+        break;
+      }
+      default: p[0] = c.mu; p[1] = c.phi; p[2] = c.sigma; p[3] = std::sqrt(dt); break;
+    }
+    if (c.f_kind == CSSM_F_FIRST) {
+      r->fco[k] = (c.idx == 0) ? 1.0 : 0.0;
+    } else {
+      double sn, cs;
+      cssm_sincos2pi(cssm_seasonal_phase((double)(c.idx / 2 + 1), t, (double)c.period), &sn, &cs);
+      r->fco[k] = (c.idx & 1) ? sn : cs;
+    }
+  }
+  if (pf->obs_kind == CSSM_OBS_POISSON) {
+    const long long k = (long long)y;                          // y.toInt
+    r->y = (double)k;
+    r->aux = cssm_lgamma_kp1(k);
+  } else if (pf->obs_kind == CSSM_OBS_GAUSSIAN) {
+    r->y = y;
+    r->aux2 = pf->scale_sd;
+    r->aux = cssm_log(2.5066282746310002 * pf->scale_sd);
+  }
+  const cssm_u32x4 bu = cssm_philox_draw(pf->seed, 0, step, CSSM_STREAM_U, 0, 0);
+  r->u = cssm_u01(bu.v[0], bu.v[1]);
+  const int32_t pr = (int32_t)cssm_philox_draw(pf->seed, 0, step + 1, CSSM_STREAM_PICK, 0, 0).v[0];
+  const uint32_t pa = pr < 0 ? (uint32_t)0 - (uint32_t)pr : (uint32_t)pr;
+  r->pick = (uint32_t)((uint64_t)pa % pf->n_global);
+}
+
+// ------------------------------------------------------------------------------------ create / destroy
+
+static int alloc_handle(cssm_pf* pf) {
+  HIP_TRY(hipSetDevice(pf->device));
+  if (pf->own_stream) HIP_TRY(hipStreamCreateWithFlags(&pf->stream, hipStreamNonBlocking));
+  HIP_TRY(hipEventCreate(&pf->ev0));
+  HIP_TRY(hipEventCreate(&pf->ev1));
+  pf->stride = (size_t)((pf->n + CSSM_TILE - 1) / CSSM_TILE) * CSSM_TILE;   // rows start 16-B aligned
+  pf->ntiles = (uint32_t)((pf->n + CSSM_TILE - 1) / CSSM_TILE);
+  const size_t row = pf->stride * 8;
+  for (int b = 0; b < 2; ++b) {
+    if (hipMalloc(&pf->state[b], row * pf->d) != hipSuccess) return fail(CSSM_ENOMEM, "hipMalloc of %zu bytes failed", row * pf->d);
+    HIP_TRY(hipMemsetAsync(pf->state[b], 0, row * pf->d, pf->stream));
+  }
+  if (hipMalloc(&pf->logw, row) != hipSuccess) return fail(CSSM_ENOMEM, "hipMalloc logw");
+  if (hipMalloc(&pf->endslot, pf->stride * 4) != hipSuccess) return fail(CSSM_ENOMEM, "hipMalloc endslot");
+  if (hipMalloc(&pf->anc, pf->stride * 4) != hipSuccess) return fail(CSSM_ENOMEM, "hipMalloc anc");
+  HIP_TRY(hipMalloc(&pf->tileS, (size_t)pf->ntiles * sizeof(cssm_u128)));
+  HIP_TRY(hipMalloc(&pf->tileS2, (size_t)pf->ntiles * sizeof(cssm_u128)));
+  HIP_TRY(hipMalloc(&pf->tileP, (size_t)pf->ntiles * sizeof(cssm_u128)));
+  HIP_TRY(hipMalloc(&pf->sc, sizeof(Scalars)));
+  HIP_TRY(hipMemsetAsync(pf->sc, 0, sizeof(Scalars), pf->stream));
+  HIP_TRY(hipMalloc(&pf->d_m0, CSSM_MAX_DIM * 8));
+  HIP_TRY(hipMalloc(&pf->d_sd0, CSSM_MAX_DIM * 8));
+  HIP_TRY(hipMalloc(&pf->d_bounds, 64 * 8));
+  return upload_init_params(pf);
+}
+
+static int create_common(const cssm_model_desc* desc, uint64_t n_global, uint64_t first, uint64_t n_local,
+                         uint64_t seed, int device, void* stream, bool sharded, cssm_pf** out) {
+  if (!out) return fail(CSSM_EINVAL_ARG, "out is null");
+  *out = nullptr;
+  if (n_global < 1 || n_global >= 0xffffffffull) return fail(CSSM_EINVAL_ARG, "n_particles must be in [1, 2^32 - 2]");
+  if (n_local < 1 || first + n_local > n_global) return fail(CSSM_ESHARD, "shard [%llu, +%llu) outside [0, %llu)",
+                                                              (unsigned long long)first, (unsigned long long)n_local, (unsigned long long)n_global);
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return fail(CSSM_EHIP, "no HIP device available (this library has no CPU path)");
+  if (device < 0 || device >= ndev) return fail(CSSM_EINVAL_ARG, "device %d out of range (%d devices)", device, ndev);
+  cssm_pf* pf = new cssm_pf();
+  pf->device = device;
+  pf->n_global = n_global; pf->first = first; pf->n = n_local; pf->seed = seed; pf->sharded = sharded;
+  if (stream) { pf->stream = (hipStream_t)stream; pf->own_stream = false; }
+  int rc = build_model(pf, desc);
+  if (rc == CSSM_OK) rc = alloc_handle(pf);
+  if (rc != CSSM_OK) { std::string keep = g_err; cssm_pf_destroy(pf); g_err = keep; return rc; }
+  *out = pf;
+  return CSSM_OK;
+}
+
+extern "C" int cssm_pf_create(const cssm_model_desc* desc, uint64_t n_particles, uint64_t seed, int device, cssm_pf** out) {
+  return create_common(desc, n_particles, 0, n_particles, seed, device, nullptr, false, out);
+}
+
+extern "C" int cssm_pf_create_shard(const cssm_model_desc* desc, uint64_t n_global, uint64_t first, uint64_t n_local,
+                                    uint64_t seed, int device, void* hip_stream, cssm_pf** out) {
+  return create_common(desc, n_global, first, n_local, seed, device, hip_stream, true, out);
+}
+
+extern "C" void cssm_pf_destroy(cssm_pf* pf) {
+  if (!pf) return;
+  (void)hipSetDevice(pf->device);
+  if (pf->stream) (void)hipStreamSynchronize(pf->stream);
+  void* ptrs[] = {pf->state[0], pf->state[1], pf->logw, pf->endslot, pf->anc, pf->tileS, pf->tileS2, pf->tileP, pf->sc,
+                  pf->d_m0, pf->d_sd0, pf->d_recs, pf->d_ll_t, pf->d_ess_t, pf->d_path, pf->cand, pf->cand_end, pf->d_bounds};
+  for (void* p : ptrs) if (p) (void)hipFree(p);
+  if (pf->h_recs) (void)hipHostFree(pf->h_recs);
+  if (pf->ev0) (void)hipEventDestroy(pf->ev0);
+  if (pf->ev1) (void)hipEventDestroy(pf->ev1);
+  if (pf->own_stream && pf->stream) (void)hipStreamDestroy(pf->stream);
+  delete pf;
+}
+
+extern "C" int cssm_pf_set_params(cssm_pf* pf, const cssm_model_desc* desc) {
+  if (!pf) return fail(CSSM_EINVAL_ARG, "null handle");
+  HIP_TRY(hipSetDevice(pf->device));
+  int rc = build_model(pf, desc);
+  if (rc) return rc;
+  return upload_init_params(pf);
+}
+
+extern "C" int cssm_pf_reseed(cssm_pf* pf, uint64_t seed) {
+  if (!pf) return fail(CSSM_EINVAL_ARG, "null handle");
+  pf->seed = seed;
+  return CSSM_OK;
+}
+
+extern "C" uint64_t cssm_pf_num_particles(const cssm_pf* pf) { return pf ? pf->n : 0; }
+extern "C" int32_t cssm_pf_dim(const cssm_pf* pf) { return pf ? pf->d : 0; }
+
+// ------------------------------------------------------------------------------------ launches
+
+#define DISPATCH_D(d, ...)                                                         \
+  switch (d) {                                                                      \
+    case 1: { constexpr int D = 1; __VA_ARGS__; } break;   case 2: { constexpr int D = 2; __VA_ARGS__; } break;   \
+    case 3: { constexpr int D = 3; __VA_ARGS__; } break;   case 4: { constexpr int D = 4; __VA_ARGS__; } break;   \
+    case 5: { constexpr int D = 5; __VA_ARGS__; } break;   case 6: { constexpr int D = 6; __VA_ARGS__; } break;   \
+    case 7: { constexpr int D = 7; __VA_ARGS__; } break;   case 8: { constexpr int D = 8; __VA_ARGS__; } break;   \
+    case 9: { constexpr int D = 9; __VA_ARGS__; } break;   case 10: { constexpr int D = 10; __VA_ARGS__; } break; \
+    case 11: { constexpr int D = 11; __VA_ARGS__; } break; case 12: { constexpr int D = 12; __VA_ARGS__; } break; \
+    case 13: { constexpr int D = 13; __VA_ARGS__; } break; case 14: { constexpr int D = 14; __VA_ARGS__; } break; \
+    case 15: { constexpr int D = 15; __VA_ARGS__; } break; default: { constexpr int D = 16; __VA_ARGS__; } break; \
+  }
+
+static const int kGridCap = 4096;
+
+// ll = 0.0, ess = N: PfState(t0, None, state, 0.0, particles), model/ParticleFilter.scala:107
+static int reset_scalars(cssm_pf* pf) {
+  Scalars h;
+  memset(&h, 0, sizeof h);
+  h.ess = (int32_t)(pf->n_global < 2147483647ull ? pf->n_global : 2147483647ull);
+  // pageable source: the copy is staged before the call returns, so a stack object is safe
+  HIP_TRY(hipMemcpyAsync(pf->sc, &h, sizeof h, hipMemcpyHostToDevice, pf->stream));
+  return CSSM_OK;
+}
+
+static int launch_init(cssm_pf* pf, double t0) {
+  HIP_TRY(hipSetDevice(pf->device));
+  const int grid = grid_for(pf->n, CSSM_BLOCK, kGridCap);
+  DISPATCH_D(pf->d, k_init<D><<<dim3(grid), dim3(CSSM_BLOCK), 0, pf->stream>>>(pf->state[0], pf->stride, pf->n, pf->first,
+                                                                              pf->seed, pf->d_m0, pf->d_sd0));
+  HIP_TRY(hipGetLastError());
+  int rc = reset_scalars(pf);
+  if (rc) return rc;
+  pf->cur = 0; pf->src = pf->state[0]; pf->src_stride = pf->stride; pf->anc_valid = false;
+  pf->t = t0; pf->step = 0; pf->initialised = true;
+  return CSSM_OK;
+}
+
+// propagate + weight of one datum (record already on the device)
+static int launch_propagate(cssm_pf* pf, const StepRec* d_rec) {
+  const int grid = grid_for(pf->n, CSSM_BLOCK, kGridCap);
+  double* dst = pf->state[pf->cur ^ 1];
+  const uint32_t* anc = pf->anc_valid ? pf->anc : nullptr;
+  if (pf->obs_kind == CSSM_OBS_LGCP) {
+    DISPATCH_D(pf->d, k_propagate<D, true><<<dim3(grid), dim3(CSSM_BLOCK), 0, pf->stream>>>(
+                          pf->src, pf->src_stride, anc, dst, pf->stride, pf->logw, pf->n, pf->first, pf->seed, d_rec, pf->mk, pf->sc));
+  } else {
+    DISPATCH_D(pf->d, k_propagate<D, false><<<dim3(grid), dim3(CSSM_BLOCK), 0, pf->stream>>>(
+                          pf->src, pf->src_stride, anc, dst, pf->stride, pf->logw, pf->n, pf->first, pf->seed, d_rec, pf->mk, pf->sc));
+  }
+  HIP_TRY(hipGetLastError());
+  pf->cur ^= 1;
+  pf->src = pf->state[pf->cur]; pf->src_stride = pf->stride; pf->anc_valid = false;
+  return CSSM_OK;
+}
+
+// weights -> sums -> end slots -> ancestors, single GPU
+static int launch_resample(cssm_pf* pf, const StepRec* d_rec) {
+  const int tgrid = grid_for(pf->ntiles, 1, kGridCap);
+  hipLaunchKernelGGL(k_decode_max, dim3(1), dim3(1), 0, pf->stream, pf->sc);
+  hipLaunchKernelGGL(k_tile_sums, dim3(tgrid), dim3(CSSM_BLOCK), 0, pf->stream, pf->logw, pf->n, pf->sc, pf->tileS, pf->tileS2, pf->ntiles, 0);
+  hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(1024), 0, pf->stream, pf->tileS, pf->tileS2, pf->tileP, pf->ntiles, pf->sc, pf->n_global, 1);
+  hipLaunchKernelGGL(k_offspring, dim3(tgrid), dim3(CSSM_BLOCK), 0, pf->stream, pf->logw, pf->n, pf->sc, pf->tileP, d_rec, pf->n_global,
+                     pf->endslot, pf->ntiles, 0);
+  hipLaunchKernelGGL(k_expand, dim3(tgrid), dim3(CSSM_BLOCK), 0, pf->stream, pf->endslot, pf->n, (uint64_t)0, pf->n, pf->anc, pf->ntiles);
+  HIP_TRY(hipGetLastError());
+  pf->anc_valid = true;
+  return CSSM_OK;
+}
+
+static int launch_step(cssm_pf* pf, const StepRec* d_rec, int weighted) {
+  int rc = launch_propagate(pf, d_rec);
+  if (rc) return rc;
+  if (weighted) rc = launch_resample(pf, d_rec);
+  return rc;
+}
+
+static int check_device_err(cssm_pf* pf, const Scalars& h) {
+  if (h.err & 1u) return fail(CSSM_ENONFINITE, "a log-weight is NaN (the reference's breeze distribution constructor would throw)");
+  if (h.err & 2u) return fail(CSSM_ENONFINITE, "all particle weights are zero or the maximum log-weight is not finite");
+  (void)pf;
+  return CSSM_OK;
+}
+
+// ------------------------------------------------------------------------------------ streaming API
+
+static int ensure_recs(cssm_pf* pf, size_t T) {
+  if (pf->h_recs_cap < T) {
+    if (pf->h_recs) (void)hipHostFree(pf->h_recs);
+    pf->h_recs = nullptr;
+    HIP_TRY(hipHostMalloc((void**)&pf->h_recs, T * sizeof(StepRec), hipHostMallocDefault));
+    pf->h_recs_cap = T;
+  }
+  if (pf->recs_cap < T) {
+    if (pf->d_recs) (void)hipFree(pf->d_recs);
+    if (pf->d_ll_t) (void)hipFree(pf->d_ll_t);
+    if (pf->d_ess_t) (void)hipFree(pf->d_ess_t);
+    pf->d_recs = nullptr; pf->d_ll_t = nullptr; pf->d_ess_t = nullptr;
+    HIP_TRY(hipMalloc(&pf->d_recs, T * sizeof(StepRec)));
+    HIP_TRY(hipMalloc(&pf->d_ll_t, T * 8));
+    HIP_TRY(hipMalloc(&pf->d_ess_t, T * 4));
+    pf->recs_cap = T;
+  }
+  return CSSM_OK;
+}
+
+extern "C" int cssm_pf_init(cssm_pf* pf, double t0) {
+  if (!pf) return fail(CSSM_EINVAL_ARG, "null handle");
+  int rc = launch_init(pf, t0);
+  if (rc) return rc;
+  HIP_TRY(hipStreamSynchronize(pf->stream));
+  return CSSM_OK;
+}
+
+extern "C" int cssm_pf_init_from(cssm_pf* pf, double t0, const double* state_d) {
+  if (!pf || !state_d) return fail(CSSM_EINVAL_ARG, "null argument");
+  HIP_TRY(hipSetDevice(pf->device));
+  HIP_TRY(hipMemcpyAsync(pf->d_m0, state_d, pf->d * 8, hipMemcpyHostToDevice, pf->stream));
+  hipLaunchKernelGGL(k_init_from, dim3(grid_for(pf->n, 256, kGridCap)), dim3(256), 0, pf->stream, pf->state[0], pf->stride, pf->n, pf->d, pf->d_m0);
+  HIP_TRY(hipGetLastError());
+  int rc = reset_scalars(pf);
+  if (rc) return rc;
+  HIP_TRY(hipStreamSynchronize(pf->stream));
+  rc = upload_init_params(pf);   // d_m0 was used as scratch
+  if (rc) return rc;
+  pf->cur = 0; pf->src = pf->state[0]; pf->src_stride = pf->stride; pf->anc_valid = false;
+  pf->t = t0; pf->step = 0; pf->initialised = true;
+  return CSSM_OK;
+}
+
+extern "C" int cssm_pf_step(cssm_pf* pf, double t, double obs, int has_obs, double* ll_out, int32_t* ess_out) {
+  if (!pf) return fail(CSSM_EINVAL_ARG, "null handle");
+  if (!pf->initialised) return fail(CSSM_ESTATE, "cssm_pf_step before cssm_pf_init");
+  if (pf->sharded) return fail(CSSM_ESTATE, "a sharded handle is driven through the cssm_pf_shard_* stages");
+  HIP_TRY(hipSetDevice(pf->device));
+  int rc = ensure_recs(pf, 1);
+  if (rc) return rc;
+  build_rec(pf, pf->t, t, obs, has_obs, pf->step, &pf->h_recs[0]);
+  HIP_TRY(hipMemcpyAsync(pf->d_recs, pf->h_recs, sizeof(StepRec), hipMemcpyHostToDevice, pf->stream));
+  const int weighted = pf->h_recs[0].has_obs;
+  rc = launch_step(pf, pf->d_recs, weighted);
+  if (rc) return rc;
+  Scalars h;
+  HIP_TRY(hipMemcpyAsync(&h, pf->sc, sizeof h, hipMemcpyDeviceToHost, pf->stream));
+  HIP_TRY(hipStreamSynchronize(pf->stream));
+  pf->t = t; pf->step++;
+  if (ll_out) *ll_out = h.ll;
+  if (ess_out) *ess_out = h.ess;
+  return check_device_err(pf, h);
+}
+
+// ------------------------------------------------------------------------------------ batch API
+
+static int run_filter(cssm_pf* pf, const double* t, const double* y, const uint8_t* has, size_t T, double* ll_out,
+                      double* ll_t, int32_t* ess_t, double* path) {
+  if (!pf || !t || !y) return fail(CSSM_EINVAL_ARG, "null argument");
+  if (T < 1) return fail(CSSM_EINVAL_ARG, "empty data (the reference's minBy throws on an empty Vector)");
+  if (pf->sharded) return fail(CSSM_ESTATE, "a sharded handle is driven through the cssm_pf_shard_* stages");
+  HIP_TRY(hipSetDevice(pf->device));
+  int rc = ensure_recs(pf, T);
+  if (rc) return rc;
+  double t0 = t[0];
+  for (size_t s = 1; s < T; ++s) if (t[s] < t0) t0 = t[s];     // data.minBy(_.t).t, model/ParticleFilter.scala:138
+  double tp = t0;
+  for (size_t s = 0; s < T; ++s) { build_rec(pf, tp, t[s], y[s], has ? has[s] : 1, (uint32_t)s, &pf->h_recs[s]); tp = t[s]; }
+  HIP_TRY(hipMemcpyAsync(pf->d_recs, pf->h_recs, T * sizeof(StepRec), hipMemcpyHostToDevice, pf->stream));
+  rc = launch_init(pf, t0);
+  if (rc) return rc;
+  const int d = pf->d;
+  if (path) {
+    if (pf->path_cap < (T + 1) * (size_t)d) {
+      if (pf->d_path) (void)hipFree(pf->d_path);
+      pf->d_path = nullptr;
+      HIP_TRY(hipMalloc(&pf->d_path, (T + 1) * (size_t)d * 8));
+      pf->path_cap = (T + 1) * (size_t)d;
+    }
+    const int32_t pr = (int32_t)cssm_philox_draw(pf->seed, 0, 0, CSSM_STREAM_PICK, 0, 0).v[0];
+    const uint32_t pa = pr < 0 ? (uint32_t)0 - (uint32_t)pr : (uint32_t)pr;
+    hipLaunchKernelGGL(k_pick, dim3(1), dim3(64), 0, pf->stream, pf->src, pf->src_stride, (const uint32_t*)nullptr,
+                       (uint64_t)pa % pf->n, d, pf->d_path);
+  }
+  HIP_TRY(hipEventRecord(pf->ev0, pf->stream));
+  for (size_t s = 0; s < T; ++s) {
+    const int weighted = pf->h_recs[s].has_obs;
+    rc = launch_step(pf, pf->d_recs + s, weighted);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_record, dim3(1), dim3(1), 0, pf->stream, pf->sc, pf->d_ll_t, pf->d_ess_t, (uint32_t)s);
+    if (path)
+      hipLaunchKernelGGL(k_pick, dim3(1), dim3(64), 0, pf->stream, pf->src, pf->src_stride,
+                         (const uint32_t*)(pf->anc_valid ? pf->anc : nullptr), (uint64_t)pf->h_recs[s].pick, d,
+                         pf->d_path + (s + 1) * (size_t)d);
+  }
+  HIP_TRY(hipEventRecord(pf->ev1, pf->stream));
+  HIP_TRY(hipGetLastError());
+  Scalars h;
+  HIP_TRY(hipMemcpyAsync(&h, pf->sc, sizeof h, hipMemcpyDeviceToHost, pf->stream));
+  if (ll_t) HIP_TRY(hipMemcpyAsync(ll_t, pf->d_ll_t, T * 8, hipMemcpyDeviceToHost, pf->stream));
+  if (ess_t) HIP_TRY(hipMemcpyAsync(ess_t, pf->d_ess_t, T * 4, hipMemcpyDeviceToHost, pf->stream));
+  if (path) HIP_TRY(hipMemcpyAsync(path, pf->d_path, (T + 1) * (size_t)d * 8, hipMemcpyDeviceToHost, pf->stream));
+  HIP_TRY(hipStreamSynchronize(pf->stream));
+  HIP_TRY(hipEventElapsedTime(&pf->last_ms, pf->ev0, pf->ev1));
+  pf->t = t[T - 1]; pf->step = (uint32_t)T;
+  if (ll_out) *ll_out = h.ll;
+  return check_device_err(pf, h);
+}
+
+extern "C" int cssm_pf_ll_filter(cssm_pf* pf, const double* t, const double* y, const uint8_t* has_obs, size_t T,
+                                 double* ll_out, double* ll_t, int32_t* ess_t) {
+  return run_filter(pf, t, y, has_obs, T, ll_out, ll_t, ess_t, nullptr);
+}
+
+extern "C" int cssm_pf_filter(cssm_pf* pf, const double* t, const double* y, const uint8_t* has_obs, size_t T,
+                              double* ll_out, double* ll_t, int32_t* ess_t, double* path) {
+  if (!path) return fail(CSSM_EINVAL_ARG, "path is null (use cssm_pf_ll_filter)");
+  return run_filter(pf, t, y, has_obs, T, ll_out, ll_t, ess_t, path);
+}
+
+extern "C" int cssm_pf_last_loop_ms(cssm_pf* pf, float* ms_out) {
+  if (!pf || !ms_out) return fail(CSSM_EINVAL_ARG, "null argument");
+  *ms_out = pf->last_ms;
+  return CSSM_OK;
+}
+
+// ------------------------------------------------------------------------------------ inspection
+
+extern "C" int cssm_pf_get_particles(cssm_pf* pf, double* out) {
+  if (!pf || !out) return fail(CSSM_EINVAL_ARG, "null argument");
+  if (!pf->initialised) return fail(CSSM_ESTATE, "not initialised");
+  HIP_TRY(hipSetDevice(pf->device));
+  double* tmp = nullptr;
+  if (hipMalloc(&tmp, pf->n * (size_t)pf->d * 8) != hipSuccess) return fail(CSSM_ENOMEM, "hipMalloc for the gathered cloud");
+  hipLaunchKernelGGL(k_gather, dim3(grid_for(pf->n, 256, kGridCap)), dim3(256), 0, pf->stream, pf->src, pf->src_stride,
+                     (const uint32_t*)(pf->anc_valid ? pf->anc : nullptr), tmp, (size_t)pf->n, pf->n, pf->d);
+  hipError_t e = hipMemcpyAsync(out, tmp, pf->n * (size_t)pf->d * 8, hipMemcpyDeviceToHost, pf->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(pf->stream);
+  (void)hipFree(tmp);
+  if (e != hipSuccess) return fail(CSSM_EHIP, "get_particles: %s", hipGetErrorString(e));
+  return CSSM_OK;
+}
+
+extern "C" int cssm_pf_get_proposed(cssm_pf* pf, double* out) {
+  if (!pf || !out) return fail(CSSM_EINVAL_ARG, "null argument");
+  if (!pf->initialised) return fail(CSSM_ESTATE, "not initialised");
+  HIP_TRY(hipSetDevice(pf->device));
+  HIP_TRY(hipMemcpy2DAsync(out, pf->n * 8, pf->state[pf->cur], pf->stride * 8, pf->n * 8, pf->d, hipMemcpyDeviceToHost, pf->stream));
+  HIP_TRY(hipStreamSynchronize(pf->stream));
+  return CSSM_OK;
+}
+
+extern "C" int cssm_pf_get_ancestors(cssm_pf* pf, uint32_t* out) {
+  if (!pf || !out) return fail(CSSM_EINVAL_ARG, "null argument");
+  HIP_TRY(hipSetDevice(pf->device));
+  if (!pf->anc_valid) { for (uint64_t i = 0; i < pf->n; ++i) out[i] = (uint32_t)i; return CSSM_OK; }
+  HIP_TRY(hipMemcpyAsync(out, pf->anc, pf->n * 4, hipMemcpyDeviceToHost, pf->stream));
+  HIP_TRY(hipStreamSynchronize(pf->stream));
+  return CSSM_OK;
+}
+
+extern "C" int cssm_pf_get_logw(cssm_pf* pf, double* out) {
+  if (!pf || !out) return fail(CSSM_EINVAL_ARG, "null argument");
+  HIP_TRY(hipSetDevice(pf->device));
+  HIP_TRY(hipMemcpyAsync(out, pf->logw, pf->n * 8, hipMemcpyDeviceToHost, pf->stream));
+  HIP_TRY(hipStreamSynchronize(pf->stream));
+  return CSSM_OK;
+}
+
+// ------------------------------------------------------------------------------------ stateless resampler
+
+extern "C" int cssm_resample_systematic(const double* w, size_t n, double u, uint32_t* anc, int device) {
+  if (!w || !anc) return fail(CSSM_EINVAL_ARG, "null argument");
+  if (n < 1 || n >= 0xffffffffull) return fail(CSSM_EINVAL_ARG, "n out of range");
+  if (!(u >= 0.0 && u < 1.0)) return fail(CSSM_EINVAL_ARG, "u must be in [0, 1)");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return fail(CSSM_EHIP, "no HIP device available (this library has no CPU path)");
+  HIP_TRY(hipSetDevice(device));
+  const uint32_t ntiles = (uint32_t)((n + CSSM_TILE - 1) / CSSM_TILE);
+  const size_t stride = (size_t)ntiles * CSSM_TILE;
+  double* d_w = nullptr; uint32_t *d_end = nullptr, *d_anc = nullptr; cssm_u128 *tS = nullptr, *tS2 = nullptr, *tP = nullptr;
+  Scalars* sc = nullptr; StepRec* d_rec = nullptr;
+  hipStream_t st = nullptr;
+  int rc = CSSM_OK;
+  StepRec hrec; memset(&hrec, 0, sizeof hrec); hrec.u = u;
+  Scalars hs;
+#define RS_TRY(expr) do { hipError_t e__ = (expr); if (e__ != hipSuccess) { rc = fail(CSSM_EHIP, "%s: %s", #expr, hipGetErrorString(e__)); goto done; } } while (0)
+  RS_TRY(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+  RS_TRY(hipMalloc(&d_w, stride * 8)); RS_TRY(hipMalloc(&d_end, stride * 4)); RS_TRY(hipMalloc(&d_anc, stride * 4));
+  RS_TRY(hipMalloc(&tS, ntiles * sizeof(cssm_u128))); RS_TRY(hipMalloc(&tS2, ntiles * sizeof(cssm_u128))); RS_TRY(hipMalloc(&tP, ntiles * sizeof(cssm_u128)));
+  RS_TRY(hipMalloc(&sc, sizeof(Scalars))); RS_TRY(hipMalloc(&d_rec, sizeof(StepRec)));
+  RS_TRY(hipMemsetAsync(sc, 0, sizeof(Scalars), st));
+  RS_TRY(hipMemcpyAsync(d_w, w, n * 8, hipMemcpyHostToDevice, st));
+  RS_TRY(hipMemcpyAsync(d_rec, &hrec, sizeof hrec, hipMemcpyHostToDevice, st));
+  {
+    const int tgrid = grid_for(ntiles, 1, kGridCap);
+    hipLaunchKernelGGL(k_tile_sums, dim3(tgrid), dim3(CSSM_BLOCK), 0, st, d_w, (uint64_t)n, sc, tS, tS2, ntiles, 1);
+    hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(1024), 0, st, tS, tS2, tP, ntiles, sc, (uint64_t)n, 1);
+    hipLaunchKernelGGL(k_offspring, dim3(tgrid), dim3(CSSM_BLOCK), 0, st, d_w, (uint64_t)n, sc, tP, d_rec, (uint64_t)n, d_end, ntiles, 1);
+    hipLaunchKernelGGL(k_expand, dim3(tgrid), dim3(CSSM_BLOCK), 0, st, d_end, (uint64_t)n, (uint64_t)0, (uint64_t)n, d_anc, ntiles);
+  }
+  RS_TRY(hipGetLastError());
+  RS_TRY(hipMemcpyAsync(&hs, sc, sizeof hs, hipMemcpyDeviceToHost, st));
+  RS_TRY(hipMemcpyAsync(anc, d_anc, n * 4, hipMemcpyDeviceToHost, st));
+  RS_TRY(hipStreamSynchronize(st));
+  if (hs.S_tot.lo == 0 && hs.S_tot.hi == 0) rc = fail(CSSM_ENONFINITE, "all weights are zero (the reference divides by a zero total)");
+done:
+#undef RS_TRY
+  void* ptrs[] = {d_w, d_end, d_anc, tS, tS2, tP, sc, d_rec};
+  for (void* p : ptrs) if (p) (void)hipFree(p);
+  if (st) (void)hipStreamDestroy(st);
+  return rc;
+}
+
+// ------------------------------------------------------------------------------------ sharded stages
+// One process per GPU; the collectives between the stages belong to the caller (RCCL through
+// torch.distributed).  See include/cssm_pf.h for the sequence.
+
+__global__ void k_export_max(Scalars* sc, double* out) {
+  const double m = cssm_order_unkey(sc->maxkey);
+  sc->maxkey = 0ull;
+  *out = m;
+}
+__global__ void k_import_max(Scalars* sc, const double* gm) { sc->gmax = *gm; }
+__global__ void k_export_sums(const Scalars* sc, unsigned long long* out4) {
+  out4[0] = sc->S_local.lo; out4[1] = sc->S_local.hi; out4[2] = sc->S2_local.lo; out4[3] = sc->S2_local.hi;
+}
+
+// For every destination rank q (owner of slots [q*n_per, min((q+1)*n_per, N))): the contiguous
+// range of LOCAL particles that own at least one of q's slots.  One thread per q.
+__global__ void k_send_ranges(const uint32_t* __restrict__ endslot, uint64_t n_local, const Scalars* __restrict__ sc,
+                              const StepRec* __restrict__ rec, uint64_t n_global, int rank, int world, uint64_t n_per,
+                              long long* __restrict__ first, long long* __restrict__ count) {
+  const int q = blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= world) return;
+  uint64_t b_lo = (uint64_t)q * n_per, b_hi = b_lo + n_per;
+  if (b_lo > n_global) b_lo = n_global;
+  if (b_hi > n_global) b_hi = n_global;
+  uint64_t e_before = 0;   // end slot of the last particle of the previous rank
+  if (rank > 0) e_before = cssm_sys_count(cssm_u128_to_double(sc->S_off) / cssm_u128_to_double(sc->S_tot), rec->u, n_global);
+  // j_lo = first local j with endslot[j] > b_lo
+  uint64_t lo = 0, hi = n_local;
+  while (lo < hi) { const uint64_t mid = (lo + hi) >> 1; if ((uint64_t)endslot[mid] > b_lo) hi = mid; else lo = mid + 1; }
+  const uint64_t j_lo = lo;
+  const uint64_t start = (j_lo == 0) ? e_before : (uint64_t)endslot[j_lo - 1];
+  if (b_lo >= b_hi || j_lo >= n_local || start >= b_hi) { first[q] = 0; count[q] = 0; return; }
+  // j_last = first local j with endslot[j] >= b_hi (it owns slot b_hi - 1), clamped
+  lo = j_lo; hi = n_local;
+  while (lo < hi) { const uint64_t mid = (lo + hi) >> 1; if ((uint64_t)endslot[mid] >= b_hi) hi = mid; else lo = mid + 1; }
+  uint64_t j_last = lo;
+  if (j_last >= n_local) j_last = n_local - 1;
+  first[q] = (long long)j_lo;
+  count[q] = (long long)(j_last - j_lo + 1);
+}
+
+// rows of d+1 doubles: the particle's state and its end slot
+__global__ void k_pack(const double* __restrict__ src, size_t stride, const uint32_t* __restrict__ endslot, int d,
+                       long long j0, long long cnt, double* __restrict__ out) {
+  for (long long r = (long long)blockIdx.x * blockDim.x + threadIdx.x; r < cnt; r += (long long)gridDim.x * blockDim.x) {
+    double* row = out + r * (d + 1);
+    for (int k = 0; k < d; ++k) row[k] = src[(size_t)k * stride + (size_t)(j0 + r)];
+    row[d] = (double)endslot[j0 + r];
+  }
+}
+__global__ void k_adopt(const double* __restrict__ recv, long long m, int d, double* __restrict__ cand, size_t cstride,
+                        uint32_t* __restrict__ cand_end) {
+  for (long long r = (long long)blockIdx.x * blockDim.x + threadIdx.x; r < m; r += (long long)gridDim.x * blockDim.x) {
+    const double* row = recv + r * (d + 1);
+    for (int k = 0; k < d; ++k) cand[(size_t)k * cstride + (size_t)r] = row[k];
+    cand_end[r] = (uint32_t)row[d];
+  }
+}
+
+static int shard_check(cssm_pf* pf) {
+  if (!pf) return fail(CSSM_EINVAL_ARG, "null handle");
+  if (!pf->sharded) return fail(CSSM_ESTATE, "handle was not created with cssm_pf_create_shard");
+  HIP_TRY(hipSetDevice(pf->device));
+  return CSSM_OK;
+}
+
+extern "C" int cssm_pf_shard_init(cssm_pf* pf, double t0) {
+  int rc = shard_check(pf);
+  if (rc) return rc;
+  return launch_init(pf, t0);
+}
+
+extern "C" int cssm_pf_shard_propagate(cssm_pf* pf, double t, double obs, int has_obs, double* local_max_dev) {
+  int rc = shard_check(pf);
+  if (rc) return rc;
+  if (!pf->initialised) return fail(CSSM_ESTATE, "shard_propagate before shard_init");
+  // one record slot per step, round-robin, so that an in-flight step never sees its record overwritten
+  rc = ensure_recs(pf, 64);
+  if (rc) return rc;
+  const size_t slot = pf->step % 64;
+  build_rec(pf, pf->t, t, obs, has_obs, pf->step, &pf->h_recs[slot]);
+  HIP_TRY(hipMemcpyAsync(pf->d_recs + slot, pf->h_recs + slot, sizeof(StepRec), hipMemcpyHostToDevice, pf->stream));
+  rc = launch_propagate(pf, pf->d_recs + slot);
+  if (rc) return rc;
+  if (pf->h_recs[slot].has_obs) {
+    if (!local_max_dev) return fail(CSSM_EINVAL_ARG, "local_max_dev is null");
+    hipLaunchKernelGGL(k_export_max, dim3(1), dim3(1), 0, pf->stream, pf->sc, local_max_dev);
+    HIP_TRY(hipGetLastError());
+  }
+  pf->t = t;
+  pf->step++;
+  return CSSM_OK;
+}
+
+extern "C" int cssm_pf_shard_sums(cssm_pf* pf, const double* global_max_dev, uint64_t* sums4_dev) {
+  int rc = shard_check(pf);
+  if (rc) return rc;
+  if (!global_max_dev || !sums4_dev) return fail(CSSM_EINVAL_ARG, "null argument");
+  const int tgrid = grid_for(pf->ntiles, 1, kGridCap);
+  hipLaunchKernelGGL(k_import_max, dim3(1), dim3(1), 0, pf->stream, pf->sc, global_max_dev);
+  hipLaunchKernelGGL(k_tile_sums, dim3(tgrid), dim3(CSSM_BLOCK), 0, pf->stream, pf->logw, pf->n, pf->sc, pf->tileS, pf->tileS2, pf->ntiles, 0);
+  hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(1024), 0, pf->stream, pf->tileS, pf->tileS2, pf->tileP, pf->ntiles, pf->sc, pf->n_global, 0);
+  hipLaunchKernelGGL(k_export_sums, dim3(1), dim3(1), 0, pf->stream, pf->sc, (unsigned long long*)sums4_dev);
+  HIP_TRY(hipGetLastError());
+  return CSSM_OK;
+}
+
+extern "C" int cssm_pf_shard_offspring(cssm_pf* pf, const uint64_t* all_sums4_dev, int rank, int world,
+                                       int64_t* send_first_dev, int64_t* send_count_dev) {
+  int rc = shard_check(pf);
+  if (rc) return rc;
+  if (!all_sums4_dev || !send_first_dev || !send_count_dev) return fail(CSSM_EINVAL_ARG, "null argument");
+  if (world < 1 || world > 64 || rank < 0 || rank >= world) return fail(CSSM_ESHARD, "rank %d / world %d", rank, world);
+  const uint64_t n_per = (pf->n_global + (uint64_t)world - 1) / (uint64_t)world;
+  if (pf->first != (uint64_t)rank * n_per) return fail(CSSM_ESHARD, "rank %d must own particles from %llu (ceil(N/world) per rank), handle starts at %llu",
+                                                       rank, (unsigned long long)((uint64_t)rank * n_per), (unsigned long long)pf->first);
+  const size_t slot = (pf->step - 1) % 64;   // record of the step propagated last
+  const int tgrid = grid_for(pf->ntiles, 1, kGridCap);
+  hipLaunchKernelGGL(k_global_sums, dim3(1), dim3(1), 0, pf->stream, (const unsigned long long*)all_sums4_dev, rank, world, pf->sc, pf->n_global);
+  hipLaunchKernelGGL(k_offspring, dim3(tgrid), dim3(CSSM_BLOCK), 0, pf->stream, pf->logw, pf->n, pf->sc, pf->tileP, pf->d_recs + slot,
+                     pf->n_global, pf->endslot, pf->ntiles, 0);
+  hipLaunchKernelGGL(k_send_ranges, dim3(1), dim3(64), 0, pf->stream, pf->endslot, pf->n, pf->sc, pf->d_recs + slot, pf->n_global, rank, world,
+                     n_per, (long long*)send_first_dev, (long long*)send_count_dev);
+  HIP_TRY(hipGetLastError());
+  return CSSM_OK;
+}
+
+extern "C" int cssm_pf_shard_pack(cssm_pf* pf, int world, const int64_t* send_first_host, const int64_t* send_count_host,
+                                  double* send_buf_dev) {
+  int rc = shard_check(pf);
+  if (rc) return rc;
+  if (!send_first_host || !send_count_host) return fail(CSSM_EINVAL_ARG, "null argument");
+  int64_t off = 0;
+  for (int q = 0; q < world; ++q) {
+    const int64_t c = send_count_host[q], f = send_first_host[q];
+    if (c < 0 || f < 0 || (uint64_t)(f + c) > pf->n) return fail(CSSM_ESHARD, "send range [%lld, +%lld) outside the shard", (long long)f, (long long)c);
+    if (c > 0) {
+      if (!send_buf_dev) return fail(CSSM_EINVAL_ARG, "send_buf_dev is null");
+      hipLaunchKernelGGL(k_pack, dim3(grid_for((uint64_t)c, 256, kGridCap)), dim3(256), 0, pf->stream, pf->state[pf->cur], pf->stride,
+                         pf->endslot, pf->d, (long long)f, (long long)c, send_buf_dev + off * (pf->d + 1));
+    }
+    off += c;
+  }
+  HIP_TRY(hipGetLastError());
+  return CSSM_OK;
+}
+
+extern "C" int cssm_pf_shard_adopt(cssm_pf* pf, const double* recv_buf_dev, int64_t n_recv) {
+  int rc = shard_check(pf);
+  if (rc) return rc;
+  if (n_recv < 1 || !recv_buf_dev) return fail(CSSM_ESHARD, "a rank must receive at least one candidate particle");
+  if ((size_t)n_recv > pf->cand_cap) {
+    HIP_TRY(hipStreamSynchronize(pf->stream));
+    if (pf->cand) (void)hipFree(pf->cand);
+    if (pf->cand_end) (void)hipFree(pf->cand_end);
+    pf->cand = nullptr; pf->cand_end = nullptr;
+    size_t cap = (size_t)n_recv + (size_t)n_recv / 4 + CSSM_TILE;
+    cap = (cap + CSSM_TILE - 1) / CSSM_TILE * CSSM_TILE;
+    if (hipMalloc(&pf->cand, cap * 8 * pf->d) != hipSuccess) return fail(CSSM_ENOMEM, "hipMalloc candidate buffer (%zu particles)", cap);
+    if (hipMalloc(&pf->cand_end, cap * 4) != hipSuccess) return fail(CSSM_ENOMEM, "hipMalloc candidate end slots");
+    pf->cand_cap = cap;
+  }
+  hipLaunchKernelGGL(k_adopt, dim3(grid_for((uint64_t)n_recv, 256, kGridCap)), dim3(256), 0, pf->stream, recv_buf_dev, (long long)n_recv,
+                     pf->d, pf->cand, pf->cand_cap, pf->cand_end);
+  const uint32_t ct = (uint32_t)(((uint64_t)n_recv + CSSM_TILE - 1) / CSSM_TILE);
+  hipLaunchKernelGGL(k_expand, dim3(grid_for(ct, 1, kGridCap)), dim3(CSSM_BLOCK), 0, pf->stream, pf->cand_end, (uint64_t)n_recv, pf->first,
+                     pf->first + pf->n, pf->anc, ct);
+  HIP_TRY(hipGetLastError());
+  pf->src = pf->cand; pf->src_stride = pf->cand_cap; pf->anc_valid = true;
+  return CSSM_OK;
+}
+
+extern "C" int cssm_pf_shard_result(cssm_pf* pf, double* ll_out, int32_t* ess_out) {
+  int rc = shard_check(pf);
+  if (rc) return rc;
+  Scalars h;
+  HIP_TRY(hipMemcpyAsync(&h, pf->sc, sizeof h, hipMemcpyDeviceToHost, pf->stream));
+  HIP_TRY(hipStreamSynchronize(pf->stream));
+  if (ll_out) *ll_out = h.ll;
+  if (ess_out) *ess_out = h.ess;
+  return check_device_err(pf, h);
+}
+
+// ------------------------------------------------------------------------------------ PMMH host loop
+
+struct OwnedDesc {
+  std::vector<cssm_leaf_desc> leaves;
+  std::vector<std::vector<double>> store;
+  cssm_model_desc desc;
+  std::vector<double*> slots;   // Parameters.flattenParams order, model/Parameters.scala:88-95
+};
+
+static int own_desc(const cssm_model_desc* in, OwnedDesc* o) {
+  if (!in || !in->leaves || in->n_leaves < 1 || in->n_leaves > CSSM_MAX_LEAVES) return fail(CSSM_EINVAL_DESC, "bad descriptor");
+  o->leaves.assign(in->leaves, in->leaves + in->n_leaves);
+  o->store.clear();
+  o->store.reserve((size_t)in->n_leaves * 5);
+  for (auto& L : o->leaves) {
+    auto take = [&](const double*& p, int n) {
+      o->store.emplace_back(p && n > 0 ? std::vector<double>(p, p + n) : std::vector<double>());
+      p = o->store.back().empty() ? nullptr : o->store.back().data();
+    };
+    take(L.m0, L.n_m0); take(L.c0, L.n_c0); take(L.mu, L.n_mu); take(L.phi, L.n_phi); take(L.sigma, L.n_sigma);
+  }
+  o->desc = *in;
+  o->desc.leaves = o->leaves.data();
+  o->slots.clear();
+  for (auto& L : o->leaves) {
+    auto push = [&](const double* p, int n) { for (int i = 0; i < n; ++i) o->slots.push_back(const_cast<double*>(p) + i); };
+    if (L.has_scale) o->slots.push_back(&L.scale);
+    push(L.m0, L.n_m0); push(L.c0, L.n_c0);
+    if (L.sde_kind == CSSM_SDE_GEN_BROWNIAN) push(L.mu, L.n_mu);                                   // m0 ++ c0 ++ mu ++ sigma
+    else if (L.sde_kind == CSSM_SDE_OU || L.sde_kind == CSSM_SDE_EULER_AFFINE) { push(L.phi, L.n_phi); push(L.mu, L.n_mu); }  // m0 ++ c0 ++ phi ++ mu ++ sigma
+    push(L.sigma, L.n_sigma);
+  }
+  return CSSM_OK;
+}
+
+extern "C" int cssm_desc_flatten(const cssm_model_desc* desc, double* theta, size_t cap, size_t* n_theta) {
+  OwnedDesc o;
+  int rc = own_desc(desc, &o);
+  if (rc) return rc;
+  if (n_theta) *n_theta = o.slots.size();
+  if (theta) for (size_t i = 0; i < o.slots.size() && i < cap; ++i) theta[i] = *o.slots[i];
+  return CSSM_OK;
+}
+
+// mhStep, model/PMMH.scala:68-81; init ll = -1e99 (:121); proposal Parameters.perturb(delta),
+// model/Parameters.scala:65-67; the current ll is reused, never re-estimated (:63-66).
+extern "C" int cssm_pmmh_run(cssm_pf* pf, const cssm_model_desc* desc, const double* theta0, size_t n_theta, double delta,
+                             const double* t, const double* y, const uint8_t* has_obs, size_t T, uint64_t seed,
+                             size_t n_iters, double* ll, double* theta, int32_t* accepted, double* last_state) {
+  if (!pf || !theta0 || !ll || !theta || !accepted || !last_state) return fail(CSSM_EINVAL_ARG, "null argument");
+  OwnedDesc o;
+  int rc = own_desc(desc, &o);
+  if (rc) return rc;
+  if (o.slots.size() != n_theta) return fail(CSSM_EINVAL_ARG, "theta0 has %zu entries, the descriptor flattens to %zu", n_theta, o.slots.size());
+  const int d = pf->d;
+  std::vector<double> cur(theta0, theta0 + n_theta), prop(n_theta), path((T + 1) * (size_t)d), cur_state(d, 0.0);
+  double cur_ll = -1e99;
+  int32_t acc = 0;
+  const double sd = std::sqrt(delta);
+  for (size_t it = 0; it < n_iters; ++it) {
+    for (size_t j = 0; j < n_theta; j += 2) {                  // propParams <- proposal(s.params)
+      double z0, z1;
+      cssm_normal_pair(cssm_philox_draw(seed, it, (uint32_t)(j / 2), CSSM_STREAM_HOST, 0, 0), &z0, &z1);
+      prop[j] = cur[j] + sd * z0;
+      if (j + 1 < n_theta) prop[j + 1] = cur[j + 1] + sd * z1;
+    }
+    for (size_t j = 0; j < n_theta; ++j) *o.slots[j] = prop[j];
+    rc = cssm_pf_set_params(pf, &o.desc);
+    if (rc) return rc;
+    cssm_pf_reseed(pf, seed + 1 + it);
+    double pll = 0.0;
+    rc = run_filter(pf, t, y, has_obs, T, &pll, nullptr, nullptr, path.data());   // state = pf(propParams)
+    if (rc == CSSM_ENONFINITE) pll = -cssm_inf();              // a proposal the filter cannot weigh is rejected
+    else if (rc) return rc;
+    const double a = pll - cur_ll;                             // logTransition = prior = 0
+    const cssm_u32x4 b = cssm_philox_draw(seed, it, 0xffffffffu, CSSM_STREAM_HOST, 0, 1);
+    const double uu = cssm_u01_open0(b.v[0], b.v[1]);
+    if (cssm_log(uu) < a) {                                    // :75
+      cur_ll = pll; cur = prop; ++acc;
+      memcpy(cur_state.data(), path.data() + T * (size_t)d, d * 8);
+    }
+    ll[it] = cur_ll; accepted[it] = acc;
+    memcpy(theta + it * n_theta, cur.data(), n_theta * 8);
+    memcpy(last_state + it * (size_t)d, cur_state.data(), d * 8);
+  }
+  return CSSM_OK;
+}

@@ -1,0 +1,302 @@
+"""Host-side mirror of the reference's particle-filter interface over libcssm_pf.
+
+Reference (paths relative to src/main/scala/com/github/jonnylaw/model/):
+
+* ``trait ParticleFilter[S]`` -- ParticleFilter.scala:96-167: ``initialiseState``, ``stepFilter``,
+  ``llFilter``, ``filter``, ``filterStream``.
+* ``Filter(mod, resample)`` :233-246, ``FilterInit(mod, resample, initState)`` :252-271,
+  ``FilterLgcp(mod, resample, precision)`` :169-227.
+* ``object ParticleFilter`` Reader entry points :321-361: ``filter``, ``filterInit``,
+  ``filterLlState``, ``likelihood``; helpers ``effectiveSampleSize`` :431-434, ``mean`` :522-524.
+* ``Resampling.systematicResampling`` -- Resampling.scala:63-72 (type ``Resample[A]``,
+  package.scala:23).
+
+Every computation happens in the HIP library; the particle cloud stays in HBM.  ``PfState`` is an
+immutable value as in the reference (ParticleFilter.scala:32-37) except that ``particles`` is
+fetched from the device on demand and is only available for the handle's CURRENT state.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass, field
+from typing import Callable, Iterable, Iterator, List, Optional, Sequence, Tuple
+
+import numpy as np
+
+from . import _abi
+from .model import Data, Model, TimedObservation, split_data
+
+_dp = C.POINTER(C.c_double)
+
+
+def _p(a, ty=_dp):
+    return a.ctypes.data_as(ty)
+
+
+class NativePf:
+    """Thin RAII wrapper of a ``cssm_pf*`` handle (AutoCloseable on the Scala side)."""
+
+    def __init__(self, model: Model, n: int, seed: int = 20260101, device: int = 0, lgcp_precision: int = 0):
+        self.lib = _abi.load_library()
+        self._desc = model.descriptor(lgcp_precision)
+        self._h = C.c_void_p()
+        _abi.check(self.lib.cssm_pf_create(self._desc.ptr(), int(n), int(seed) & (2**64 - 1), int(device), C.byref(self._h)))
+        self.n = int(n)
+        self.d = int(self.lib.cssm_pf_dim(self._h))
+        self.generation = 0
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            self.lib.cssm_pf_destroy(self._h)
+            self._h = C.c_void_p()
+
+    __del__ = close
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def set_params(self, model: Model, lgcp_precision: int = 0):
+        self._desc = model.descriptor(lgcp_precision)
+        _abi.check(self.lib.cssm_pf_set_params(self._h, self._desc.ptr()))
+
+    def reseed(self, seed: int):
+        _abi.check(self.lib.cssm_pf_reseed(self._h, int(seed) & (2**64 - 1)))
+
+    def init(self, t0: float):
+        _abi.check(self.lib.cssm_pf_init(self._h, float(t0)))
+        self.generation += 1
+
+    def init_from(self, t0: float, state: Sequence[float]):
+        s = np.ascontiguousarray(state, dtype=np.float64)
+        if s.size != self.d:
+            raise ValueError(f"initial state has {s.size} components, the model has {self.d}")
+        _abi.check(self.lib.cssm_pf_init_from(self._h, float(t0), _p(s)))
+        self.generation += 1
+
+    def step(self, t: float, y: Optional[float], has_obs: Optional[bool] = None) -> Tuple[float, int]:
+        if has_obs is None:
+            has_obs = y is not None
+        ll, ess = C.c_double(), C.c_int32()
+        rc = self.lib.cssm_pf_step(self._h, float(t), 0.0 if y is None else float(y), 1 if has_obs else 0,
+                                   C.byref(ll), C.byref(ess))
+        self.generation += 1
+        _abi.check(rc)
+        return ll.value, ess.value
+
+    def run(self, t, y, has=None, want_path: bool = False):
+        t = np.ascontiguousarray(t, dtype=np.float64)
+        y = np.ascontiguousarray(y, dtype=np.float64)
+        T = len(t)
+        hp = None
+        if has is not None:
+            has = np.ascontiguousarray(has, dtype=np.uint8)
+            hp = _p(has, C.POINTER(C.c_uint8))
+        ll = C.c_double()
+        ll_t = np.zeros(T)
+        ess_t = np.zeros(T, dtype=np.int32)
+        path = None
+        if want_path:
+            path = np.zeros((T + 1, self.d))
+            rc = self.lib.cssm_pf_filter(self._h, _p(t), _p(y), hp, T, C.byref(ll), _p(ll_t),
+                                         _p(ess_t, C.POINTER(C.c_int32)), _p(path))
+        else:
+            rc = self.lib.cssm_pf_ll_filter(self._h, _p(t), _p(y), hp, T, C.byref(ll), _p(ll_t),
+                                            _p(ess_t, C.POINTER(C.c_int32)))
+        self.generation += 1
+        _abi.check(rc)
+        return ll.value, ll_t, ess_t, path
+
+    def last_loop_ms(self) -> float:
+        ms = C.c_float()
+        _abi.check(self.lib.cssm_pf_last_loop_ms(self._h, C.byref(ms)))
+        return ms.value
+
+    def particles(self) -> np.ndarray:
+        out = np.zeros((self.d, self.n))
+        _abi.check(self.lib.cssm_pf_get_particles(self._h, _p(out)))
+        return out
+
+    def proposed(self) -> np.ndarray:
+        out = np.zeros((self.d, self.n))
+        _abi.check(self.lib.cssm_pf_get_proposed(self._h, _p(out)))
+        return out
+
+    def logw(self) -> np.ndarray:
+        out = np.zeros(self.n)
+        _abi.check(self.lib.cssm_pf_get_logw(self._h, _p(out)))
+        return out
+
+    def ancestors(self) -> np.ndarray:
+        out = np.zeros(self.n, dtype=np.uint32)
+        _abi.check(self.lib.cssm_pf_get_ancestors(self._h, _p(out, C.POINTER(C.c_uint32))))
+        return out
+
+
+# --------------------------------------------------------------------------- Resample[A]
+class Resampling:
+    """``Resampling.systematicResampling`` (Resampling.scala:63-72) on the GPU.
+
+    Called as a function it is the ``Resample[A]`` of package.scala:23: ``(samples, weights) ->
+    samples`` where ``weights`` are the unnormalised ``w1 = exp(w - max)`` (ParticleFilter.scala:
+    125-126).  Passed to ``Filter`` it only selects the native resampler -- the cloud never
+    leaves the device.
+    """
+
+    @staticmethod
+    def systematicAncestors(weights: Sequence[float], u: float, device: int = 0) -> np.ndarray:
+        w = np.ascontiguousarray(weights, dtype=np.float64)
+        anc = np.zeros(len(w), dtype=np.uint32)
+        _abi.check(_abi.load_library().cssm_resample_systematic(_p(w), len(w), float(u), _p(anc, C.POINTER(C.c_uint32)), device))
+        return anc
+
+    @staticmethod
+    def systematicResampling(particles: Sequence, weights: Sequence[float], u: Optional[float] = None):
+        if len(particles) != len(weights):
+            raise ValueError("particles and weights differ in length")
+        if u is None:  # the reference draws from the unseeded global scala.util.Random (:66)
+            u = float(np.random.default_rng().random())
+        anc = Resampling.systematicAncestors(weights, u)
+        return [particles[int(a)] for a in anc]
+
+
+# --------------------------------------------------------------------------- PfState
+@dataclass(frozen=True)
+class PfState:  # ParticleFilter.scala:32-37
+    t: float
+    observation: Optional[float]
+    ll: float
+    ess: int
+    _owner: Optional[NativePf] = field(default=None, repr=False, compare=False)
+    _generation: int = field(default=-1, repr=False, compare=False)
+
+    @property
+    def particles(self) -> np.ndarray:
+        """The resampled cloud, SoA ``[d, N]`` (row k = component k in Tree.flatten order)."""
+        if self._owner is None or self._owner.generation != self._generation:
+            raise RuntimeError("this PfState is not the handle's current state; its cloud was advanced on the device")
+        return self._owner.particles()
+
+
+@dataclass(frozen=True)
+class StateSpace:  # Sde.scala:170
+    time: float
+    state: np.ndarray
+
+
+# --------------------------------------------------------------------------- filters
+class _FilterBase:
+    lgcp_precision = 0
+
+    def __init__(self, mod: Model, resample, n_particles: Optional[int] = None, seed: int = 20260101, device: int = 0):
+        if resample is not Resampling.systematicResampling:
+            raise NotImplementedError("the native filter implements Resampling.systematicResampling only (SURVEY.md 8f row 3)")
+        self.mod = mod
+        self.resample = resample
+        self.seed = seed
+        self.device = device
+        self._pf: Optional[NativePf] = None
+        if n_particles is not None:
+            self._ensure(n_particles)
+
+    def _ensure(self, n: int) -> NativePf:
+        if self._pf is None or self._pf.n != n:
+            if self._pf is not None:
+                self._pf.close()
+            self._pf = NativePf(self.mod, n, self.seed, self.device, self.lgcp_precision)
+        return self._pf
+
+    def _state(self, t, obs, ll, ess) -> PfState:
+        return PfState(t, obs, ll, ess, self._pf, self._pf.generation)
+
+    # ParticleFilter.scala:105-108
+    def initialiseState(self, particles: int, t0: float) -> PfState:
+        pf = self._ensure(particles)
+        pf.init(t0)
+        return self._state(t0, None, 0.0, particles)
+
+    # ParticleFilter.scala:116-132 (FilterLgcp: :210-226)
+    def stepFilter(self, s: PfState, y: TimedObservation) -> PfState:
+        if s._owner is not self._pf or s._generation != self._pf.generation:
+            raise RuntimeError("stepFilter must be applied to the filter's current PfState")
+        ll, ess = self._pf.step(y.t, y.observation)
+        return self._state(y.t, y.observation, ll, ess)
+
+    # ParticleFilter.scala:137-140
+    def llFilter(self, data: Sequence[TimedObservation], n: int) -> float:
+        t, y, h = split_data(data)
+        return self._ensure(n).run(t, y, h)[0]
+
+    # ParticleFilter.scala:152-158
+    def filter(self, data: Sequence[TimedObservation], particles: int) -> Tuple[float, List[StateSpace]]:
+        t, y, h = split_data(data)
+        ll, _, _, path = self._ensure(particles).run(t, y, h, want_path=True)
+        times = [float(np.min(t))] + [float(v) for v in t]
+        return ll, [StateSpace(tt, path[i].copy()) for i, tt in enumerate(times)]
+
+    # ParticleFilter.scala:163-166: Flow[Data].scan(init)(stepFilter) -- emits init, then one state per datum
+    def filterStream(self, t0: float, particles: int) -> Callable[[Iterable[TimedObservation]], Iterator[PfState]]:
+        def flow(source: Iterable[TimedObservation]) -> Iterator[PfState]:
+            s = self.initialiseState(particles, t0)
+            yield s
+            for y in source:
+                s = self.stepFilter(s, y)
+                yield s
+        return flow
+
+
+class Filter(_FilterBase):
+    """``Filter(mod, resample)``, ParticleFilter.scala:233-246."""
+
+
+class FilterInit(_FilterBase):
+    """``FilterInit(mod, resample, initState)``, ParticleFilter.scala:252-271."""
+
+    def __init__(self, mod: Model, resample, initState: Sequence[float], **kw):
+        super().__init__(mod, resample, **kw)
+        self.initState = np.asarray(initState, dtype=np.float64)
+
+    def initialiseState(self, particles: int, t0: float) -> PfState:
+        pf = self._ensure(particles)
+        pf.init_from(t0, self.initState)
+        return self._state(t0, None, 0.0, particles)
+
+
+class FilterLgcp(_FilterBase):
+    """``FilterLgcp(mod, resample, precision)``, ParticleFilter.scala:169-227."""
+
+    def __init__(self, mod: Model, resample, precision: int, **kw):
+        self.lgcp_precision = int(precision)
+        super().__init__(mod, resample, **kw)
+
+
+class ParticleFilter:
+    """``object ParticleFilter``: Reader-wrapped entry points, ParticleFilter.scala:321-361."""
+
+    @staticmethod
+    def filter(resample, t0: float, n: int, **kw):
+        return lambda mod: Filter(mod, resample, **kw).filterStream(t0, n)
+
+    @staticmethod
+    def filterInit(resample, t0: float, n: int, initState, **kw):
+        return lambda mod: FilterInit(mod, resample, initState, **kw).filterStream(t0, n)
+
+    @staticmethod
+    def filterLlState(data, resample, n: int, **kw):
+        return lambda mod: Filter(mod, resample, **kw).filter(data, n)
+
+    @staticmethod
+    def likelihood(data, resample, n: int, **kw):
+        return lambda mod: Filter(mod, resample, **kw).llFilter(data, n)
+
+    @staticmethod
+    def effectiveSampleSize(weights: Sequence[float]) -> int:  # :431-434 (host helper, tiny inputs)
+        w = np.asarray(weights, dtype=np.float64)
+        nw = w / w.sum()
+        return int(np.floor(1.0 / np.sum(nw * nw)))
+
+    @staticmethod
+    def mean(s: Sequence[float]) -> float:  # :522-524
+        return float(np.sum(s)) / len(s)

@@ -1,0 +1,240 @@
+/*
+ * cssm_pf.h -- C ABI of libcssm_pf, the MI355X (gfx950) bootstrap particle filter.
+ *
+ * The reference (jonnylaw/ComposableStateSpaceModels, Scala/JVM) has no FFI; this header is
+ * the FFI its `ParticleFilter` seam would bind.  Every entry point
+ * cites the reference symbol it replaces as  model/<File>.scala:<lines>  (paths relative to
+ * src/main/scala/com/github/jonnylaw/ of the reference).  The JNI/Scala binding a maintainer
+ * would add is shown in INTEGRATION.md and shipped as source under jvm/.
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes, all floating point is IEEE fp64.
+ *   - Return value 0 (CSSM_OK) or a negative CSSM_E* code; cssm_last_error() returns a
+ *     thread-local message for the last failing call on this thread.  The reference throws
+ *     from inside stepFilter (model/Sde.scala:214, model/Model.scala:150); the JNI glue turns
+ *     a non-zero code into a RuntimeException.
+ *   - The handle owns all device memory, its HIP stream and its graphs; the caller owns every
+ *     host buffer passed in or out.  Pointers documented as "host" must be host memory,
+ *     pointers documented as "device" must be device memory of the handle's GPU.
+ *   - A handle is not re-entrant; distinct handles share nothing mutable and may be driven
+ *     from different threads (two PMMH chains: examples/DetermineParameters.scala:68-69).
+ *     Every entry point selects the handle's device itself, so calls may arrive on any thread
+ *     (Akka dispatcher threads: model/ParticleFilter.scala:163-166).
+ *   - Random numbers and reductions follow include/cssm_numerics.h (the numerics contract).
+ */
+#ifndef CSSM_PF_H
+#define CSSM_PF_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- status codes ---------------------------------------------------------------------- */
+#define CSSM_OK 0
+#define CSSM_EINVAL_DESC (-1) /* malformed model descriptor (reference: Failure(...) at model/Model.scala:44-47) */
+#define CSSM_EHIP (-2)        /* a HIP runtime call failed / no gfx950 device */
+#define CSSM_ESHARD (-3)      /* inconsistent sharding arguments */
+#define CSSM_ENOMEM (-4)
+#define CSSM_ENONFINITE (-5)  /* NaN log-weight or all weights zero (reference: breeze `require` throws) */
+#define CSSM_EINVAL_ARG (-6)
+#define CSSM_ESTATE (-7)      /* call out of sequence (e.g. step before init) */
+
+/* ---- model descriptor ------------------------------------------------------------------- */
+/* Latent SDE of one leaf: model/Sde.scala:98-124 (Brownian), :69-96 (GenBrownian),
+ * :129-163 (OU), :23-43 (trait default Euler-Maruyama, here with affine drift a + b*x and
+ * constant diagonal diffusion g). */
+#define CSSM_SDE_BROWNIAN 0
+#define CSSM_SDE_GEN_BROWNIAN 1
+#define CSSM_SDE_OU 2
+#define CSSM_SDE_EULER_AFFINE 3
+
+/* Linear map f of one leaf: "first component" model/Model.scala:271 (also :153,184,250,296,
+ * 328,347,366) or seasonal model/Model.scala:217-225. */
+#define CSSM_F_FIRST 0
+#define CSSM_F_SEASONAL 1
+
+/* Observation model of the LEFTMOST leaf (model/Model.scala:118-132):
+ * Poisson model/Model.scala:266-274; Gaussian (LinearModel :241-259, SeasonalModel :227-233);
+ * LGCP model/Model.scala:363-369 with the FilterLgcp step model/ParticleFilter.scala:169-227. */
+#define CSSM_OBS_POISSON 0
+#define CSSM_OBS_GAUSSIAN 1
+#define CSSM_OBS_LGCP 2
+
+#define CSSM_MAX_DIM 16     /* total latent dimension d (sum over leaves) */
+#define CSSM_MAX_LEAVES 16
+
+/*
+ * One leaf of the composed model, left-to-right in Tree.flatten order (model/Tree.scala:49-53).
+ * Parameter arrays hold the STORED (unconstrained) values exactly as ParamNode/SdeParameter
+ * hold them (model/SdeParameters.scala:176-205) -- log c0, log sigma, and for OU the value
+ * the reference later passes through `logistic` (model/Sde.scala:136).  The library applies
+ * exp/logistic itself (cssm_exp) and repeats each array cyclically to `dim`
+ * (Sde.buildParamRepeat, model/Sde.scala:177-179).  For CSSM_SDE_EULER_AFFINE mu = a,
+ * phi = b, sigma = g are taken as they are (a user-defined Sde has no stored transform);
+ * c0 is still a log-variance.
+ */
+typedef struct cssm_leaf_desc {
+  int32_t sde_kind;
+  int32_t dim;
+  int32_t f_kind;
+  int32_t period;     /* CSSM_F_SEASONAL: model/Model.scala:205 */
+  int32_t harmonics;  /* CSSM_F_SEASONAL: dim must equal 2*harmonics */
+  int32_t has_scale;  /* ParamNode.scale is Some(_) (model/Parameters.scala:14) */
+  double scale;       /* stored scale; Gaussian uses sd = exp(scale) (model/Model.scala:244) */
+  int32_t n_m0, n_c0, n_mu, n_phi, n_sigma;
+  int32_t reserved;
+  const double* m0;
+  const double* c0;
+  const double* mu;    /* GenBrownian, OU, EulerAffine(a) */
+  const double* phi;   /* OU, EulerAffine(b) */
+  const double* sigma; /* all kinds */
+} cssm_leaf_desc;
+
+typedef struct cssm_model_desc {
+  int32_t n_leaves;
+  int32_t obs_kind;
+  int32_t lgcp_precision; /* FilterLgcp.precision (model/ParticleFilter.scala:172) */
+  int32_t reserved;
+  const cssm_leaf_desc* leaves;
+} cssm_model_desc;
+
+typedef struct cssm_pf cssm_pf; /* opaque handle */
+
+/* ---- lifetime ---------------------------------------------------------------------------- */
+
+/* Build a filter for `n_particles` particles on HIP device `device`.  Replaces the
+ * construction `Filter(mod, resample)` / `FilterLgcp(mod, resample, precision)`
+ * (model/ParticleFilter.scala:233-235, :169-172) with resample = systematicResampling. */
+int cssm_pf_create(const cssm_model_desc* desc, uint64_t n_particles, uint64_t seed, int device,
+                   cssm_pf** out);
+
+/* Same, for one shard of a filter whose N_global particles are split over `world` GPUs (one
+ * process per GPU).  This rank owns global particles and resampling slots
+ * [first, first + n_local).  Random variates are keyed by GLOBAL particle id, so results do
+ * not depend on `world`.  The collectives between the stages are the caller's (torch.distributed
+ * over RCCL): see the cssm_pf_shard_* stage calls below. */
+int cssm_pf_create_shard(const cssm_model_desc* desc, uint64_t n_global, uint64_t first,
+                         uint64_t n_local, uint64_t seed, int device, void* hip_stream,
+                         cssm_pf** out);
+
+void cssm_pf_destroy(cssm_pf* pf);
+
+/* New parameters for the same model structure, without reallocating: one call per PMMH
+ * proposal (model/PMMH.scala:71, `pf(propParams)`). */
+int cssm_pf_set_params(cssm_pf* pf, const cssm_model_desc* desc);
+
+/* New Philox key (a fresh filter run must not reuse variates). */
+int cssm_pf_reseed(cssm_pf* pf, uint64_t seed);
+
+/* ---- streaming mode: one native call per observation -------------------------------------- */
+
+/* initialiseState (model/ParticleFilter.scala:105-108): N draws m0 + sqrt(c0) z; ll = 0,
+ * ess = N, t = t0, step counter = 0. */
+int cssm_pf_init(cssm_pf* pf, double t0);
+
+/* FilterInit.initialiseState (model/ParticleFilter.scala:257-260): replicate one state
+ * (host pointer, d doubles in flatten order) N times. */
+int cssm_pf_init_from(cssm_pf* pf, double t0, const double* state_d);
+
+/* stepFilter (model/ParticleFilter.scala:116-132; LGCP: :210-226).  `has_obs` = 0 is the
+ * `None` branch (:121): propagate only, ll and ess unchanged.  ll_out = accumulated
+ * log-likelihood, ess_out = floor(1 / sum(normalised w^2)) (:431-434). */
+int cssm_pf_step(cssm_pf* pf, double t, double obs, int has_obs, double* ll_out, int32_t* ess_out);
+
+/* ---- batch mode: one native call for all T observations ----------------------------------- */
+
+/* llFilter (model/ParticleFilter.scala:137-140): t0 = min t, init, fold stepFilter over the
+ * data in the order given.  Optional outputs (may be NULL): ll_t[T] running log-likelihood
+ * after each datum, ess_t[T].  No host synchronisation happens inside the loop. */
+int cssm_pf_ll_filter(cssm_pf* pf, const double* t, const double* y, const uint8_t* has_obs,
+                      size_t T, double* ll_out, double* ll_t, int32_t* ess_t);
+
+/* filter (model/ParticleFilter.scala:152-158): as llFilter, and path[(T+1)*d] receives one
+ * uniformly picked particle of the initial cloud and of the cloud after every datum
+ * (Resampling.sampleOne, model/Resampling.scala:151-154), row s = time index, d doubles. */
+int cssm_pf_filter(cssm_pf* pf, const double* t, const double* y, const uint8_t* has_obs, size_t T,
+                   double* ll_out, double* ll_t, int32_t* ess_t, double* path);
+
+/* Device time of the last cssm_pf_ll_filter / cssm_pf_filter loop (HIP events on the
+ * handle's stream around the T steps, init excluded), in milliseconds. */
+int cssm_pf_last_loop_ms(cssm_pf* pf, float* ms_out);
+
+/* ---- inspection (parity tests, `PfState.particles` on demand) ------------------------------ */
+
+uint64_t cssm_pf_num_particles(const cssm_pf* pf); /* local particle count */
+int32_t cssm_pf_dim(const cssm_pf* pf);            /* total latent dimension d */
+
+/* Current cloud, i.e. the RESAMPLED particles of the last step (PfState.particles,
+ * model/ParticleFilter.scala:35), SoA: out[k*N + i] = component k of particle i.  Host ptr. */
+int cssm_pf_get_particles(cssm_pf* pf, double* out_dN);
+/* Ancestor indices of the last resampling (slot i <- particle anc[i]); host pointer, N. */
+int cssm_pf_get_ancestors(cssm_pf* pf, uint32_t* out_N);
+/* Log-weights of the last weighted step, before resampling (model/ParticleFilter.scala:123). */
+int cssm_pf_get_logw(cssm_pf* pf, double* out_N);
+/* Propagated, not yet resampled particles of the last step (x1 at :118), SoA, host pointer. */
+int cssm_pf_get_proposed(cssm_pf* pf, double* out_dN);
+
+/* ---- stateless resampler: the `Resample[A]` seam (model/package.scala:23) ------------------ */
+
+/* Resampling.systematicResampling (model/Resampling.scala:63-72) on host arrays: weights w[n]
+ * (the unnormalised w1 = exp(w - max) the reference passes, :125-126), one uniform u in [0,1),
+ * anc[n] receives the index of the particle that slot i copies.  Runs on `device`. */
+int cssm_resample_systematic(const double* w, size_t n, double u, uint32_t* anc, int device);
+
+/* ---- sharded filter: stage calls between which the caller runs its collectives ------------ */
+/*
+ * One observation on R ranks:
+ *   cssm_pf_shard_propagate     fused propagate + weight on the local shard; local max
+ *   [all-reduce MAX of 1 double]
+ *   cssm_pf_shard_sums          local fixed-point sums of exp(w - gmax): 4 x u64 (S, S2)
+ *   [all-gather of 4 x u64 per rank]
+ *   cssm_pf_shard_offspring     global cumulative weights -> end slot of every local particle;
+ *                               also ll, ess; and for every destination rank q the range of
+ *                               local particles that own at least one slot of q: counts[R]
+ *   [all-gather counts, all-to-all-v of (d+1) doubles per particle]
+ *   cssm_pf_shard_pack / _adopt pack the send ranges; adopt the received candidates and
+ *                               expand them to this rank's N_local slots
+ * All device work is enqueued on the stream given at creation; the only host reads are the
+ * ones whose pointers are documented as host.
+ */
+int cssm_pf_shard_init(cssm_pf* pf, double t0);
+int cssm_pf_shard_propagate(cssm_pf* pf, double t, double obs, int has_obs, double* local_max_dev);
+int cssm_pf_shard_sums(cssm_pf* pf, const double* global_max_dev, uint64_t* sums4_dev);
+int cssm_pf_shard_offspring(cssm_pf* pf, const uint64_t* all_sums4_dev, int rank, int world,
+                            int64_t* send_first_dev, int64_t* send_count_dev);
+int cssm_pf_shard_pack(cssm_pf* pf, int world, const int64_t* send_first_host,
+                       const int64_t* send_count_host, double* send_buf_dev);
+int cssm_pf_shard_adopt(cssm_pf* pf, const double* recv_buf_dev, int64_t n_recv);
+int cssm_pf_shard_result(cssm_pf* pf, double* ll_out, int32_t* ess_out);
+
+/* ---- PMMH host loop ---------------------------------------------------------------------- */
+/*
+ * ParticleMetropolisHastings (model/PMMH.scala:68-81,114-123) with proposal
+ * Parameters.perturb(delta) (model/Parameters.scala:65-67), a symmetric transition (0) and a
+ * flat prior (0), as examples/DetermineParameters.scala:59,73 wires it.  theta0[n_theta] is
+ * the flattened STORED parameter vector in Parameters.flattenParams order
+ * (model/Parameters.scala:88-95: per leaf scale-if-present, then m0, c0, [mu|phi...] in
+ * SdeParameter.flatten order).  Each iteration re-parameterises the handle, reseeds it with
+ * seed + iteration, runs `filter`, and accepts iff log(u) < ll' - ll (initial ll = -1e99).
+ * Outputs, one row per iteration (the stream drops the initial state, :97): ll[n_iters],
+ * theta[n_iters * n_theta], accepted[n_iters] (running count), last_state[n_iters * d].
+ */
+int cssm_pmmh_run(cssm_pf* pf, const cssm_model_desc* desc, const double* theta0, size_t n_theta,
+                  double delta, const double* t, const double* y, const uint8_t* has_obs, size_t T,
+                  uint64_t seed, size_t n_iters, double* ll, double* theta, int32_t* accepted,
+                  double* last_state);
+
+/* Number of stored parameters of a descriptor and their copy-out / copy-in in flatten order. */
+int cssm_desc_flatten(const cssm_model_desc* desc, double* theta, size_t cap, size_t* n_theta);
+
+/* ---- errors / build info ------------------------------------------------------------------ */
+const char* cssm_last_error(void);
+const char* cssm_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CSSM_PF_H */

@@ -1,0 +1,616 @@
+/*
+ * cssm_oracle.c -- CPU restatement of the reference bootstrap particle filter.
+ *
+ * THIS IS TEST INFRASTRUCTURE, NOT PRODUCT CODE.  Only tests/, __graft_entry__.smoke() and
+ * bench.py's cpu_baseline leg may load it; libcssm_pf never links or calls it.
+ *
+ * PARITY STATUS: "parity unpinned by the reference".  The reference
+ * (jonnylaw/ComposableStateSpaceModels, Scala 2.13/JVM) can be neither compiled nor run in
+ * the build image (no JVM, no jars), and its own tests pin no particle-filter number
+ * (SamplingTest.scala:16-18 pins only the output LENGTH of
+ * systematic resampling).  The restatement is therefore pinned by
+ *   - scipy.stats golden vectors for every density (tests/golden/densities.json),
+ *   - closed-form transition moments and the double-logistic OU quirk,
+ *   - hand-worked systematic-resampling examples that follow Resampling.scala:52-72 literally,
+ *   - the exact Kalman-filter log-likelihood for Brownian + Gaussian observation,
+ *   - the reference's own property (output length == input length).
+ *
+ * Each function cites the reference lines it follows as  model/<File>.scala:<lines>
+ * (relative to src/main/scala/com/github/jonnylaw/).  Execution model is the reference's:
+ * one thread, particle by particle, left fold over the data.
+ *
+ * Two arithmetic modes (flags of oracle_pf_create):
+ *   contract (default)  random variates, exp/log/sincos and the weight sums follow
+ *                       include/cssm_numerics.h, so a GPU run is comparable bit for bit.  The
+ *                       fixed-point sums are formed here with the compiler's native
+ *                       unsigned __int128 and long double, NOT with the header's two-limb
+ *                       code, so the two implementations check each other.
+ *   ORACLE_LITERAL_SUMS sums and the cumulative scan are the reference's sequential fp64
+ *                       folds (Resampling.scala:21-24,57; ParticleFilter.scala:431-434,522-524);
+ *   ORACLE_TIE_LAST     TreeMap duplicate-key semantics: on equal cumulative weights the LAST
+ *                       particle wins (Resampling.scala:57, `tree ++ zip`), and a grid point
+ *                       above the last cumulative weight is an error as in :41-42;
+ *   ORACLE_LIBM         glibc exp/log/sin/cos instead of the contract polynomials (bounds the
+ *                       effect of the contract's elementary functions on ll).
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#include <stdio.h>
+
+#include "../include/cssm_numerics.h"
+#include "../include/cssm_pf.h"
+
+#define ORACLE_LITERAL_SUMS 1
+#define ORACLE_TIE_LAST 2
+#define ORACLE_LIBM 4
+
+#define ORACLE_OK 0
+#define ORACLE_EINVAL (-1)
+#define ORACLE_EEMPTY (-8)    /* findAllInTreeMap `.head` on an empty map (Resampling.scala:41-42) */
+#define ORACLE_ENONFINITE (-5)
+
+typedef unsigned __int128 u128;
+
+/* One scalar latent component in Tree.flatten order (model/Tree.scala:49-53). */
+typedef struct {
+  int kind;        /* CSSM_SDE_* */
+  int leaf;        /* leaf index */
+  int idx;         /* index inside the leaf's DenseVector */
+  int f_kind;      /* CSSM_F_* of the leaf */
+  int period;
+  double m0, c0;   /* c0 = exp(stored)            model/Sde.scala:72,101,136 */
+  double mu;
+  double phi;      /* OU: logistic(stored)        model/Sde.scala:136 */
+  double sigma;    /* exp(stored)                 model/Sde.scala:72,101,136 */
+} ocomp;
+
+struct oracle_pf {
+  int d, n_leaves, obs_kind, precision, flags;
+  double scale_sd;       /* Gaussian: exp(scale)  model/Model.scala:244,211 */
+  ocomp comp[CSSM_MAX_DIM];
+  uint64_t n, seed;
+  double t, ll;
+  int32_t ess;
+  uint32_t step;         /* observation index of the NEXT datum */
+  int initialised;
+  double* x;             /* resampled cloud, AoS [n][d]  (PfState.particles) */
+  double* x1;            /* propagated cloud before resampling (x1 at ParticleFilter.scala:118) */
+  double* w;             /* log-weights (ParticleFilter.scala:123) */
+  double* w1;            /* exp(w - max) (:125) */
+  double* C;             /* cumulative normalised weights (Resampling.scala:57) */
+  uint32_t* anc;
+};
+typedef struct oracle_pf oracle_pf;
+
+/* ------------------------------------------------------------------ elementary functions */
+
+static double o_exp(const oracle_pf* pf, double x) { return (pf->flags & ORACLE_LIBM) ? exp(x) : cssm_exp(x); }
+static double o_log(const oracle_pf* pf, double x) { return (pf->flags & ORACLE_LIBM) ? log(x) : cssm_log(x); }
+
+static void o_normal_pair(const oracle_pf* pf, cssm_u32x4 b, double* z0, double* z1) {
+  if (pf->flags & ORACLE_LIBM) {
+    double u1 = cssm_u01_open0(b.v[0], b.v[1]), u2 = cssm_u01(b.v[2], b.v[3]);
+    double r = sqrt(-2.0 * log(u1));
+    *z0 = r * cos(6.283185307179586476925 * u2);
+    *z1 = r * sin(6.283185307179586476925 * u2);
+  } else {
+    cssm_normal_pair(b, z0, z1);
+  }
+}
+
+/* SdeParameter.logistic, model/SdeParameters.scala:214-216 */
+static double o_logistic(const oracle_pf* pf, double x) { return 1.0 / (1.0 + o_exp(pf, -x)); }
+
+/* ------------------------------------------------------------------ model construction */
+
+/* Sde.buildParamRepeat, model/Sde.scala:177-179 */
+static double rep(const double* v, int n, int i) { return v[i % n]; }
+
+static int build_components(oracle_pf* pf, const cssm_model_desc* desc) {
+  if (!desc || desc->n_leaves < 1 || desc->n_leaves > CSSM_MAX_LEAVES || !desc->leaves) return ORACLE_EINVAL;
+  int d = 0;
+  pf->n_leaves = desc->n_leaves;
+  pf->obs_kind = desc->obs_kind;
+  pf->precision = desc->lgcp_precision;
+  for (int l = 0; l < desc->n_leaves; ++l) {
+    const cssm_leaf_desc* L = &desc->leaves[l];
+    if (L->dim < 1 || d + L->dim > CSSM_MAX_DIM) return ORACLE_EINVAL;
+    if (L->n_m0 < 1 || L->n_c0 < 1 || L->n_sigma < 1 || !L->m0 || !L->c0 || !L->sigma) return ORACLE_EINVAL;
+    if ((L->sde_kind == CSSM_SDE_GEN_BROWNIAN || L->sde_kind == CSSM_SDE_OU || L->sde_kind == CSSM_SDE_EULER_AFFINE) &&
+        (L->n_mu < 1 || !L->mu)) return ORACLE_EINVAL;
+    if ((L->sde_kind == CSSM_SDE_OU || L->sde_kind == CSSM_SDE_EULER_AFFINE) && (L->n_phi < 1 || !L->phi)) return ORACLE_EINVAL;
+    if (L->f_kind == CSSM_F_SEASONAL && (L->dim != 2 * L->harmonics || L->period < 1)) return ORACLE_EINVAL;
+    for (int i = 0; i < L->dim; ++i) {
+      ocomp* c = &pf->comp[d + i];
+      memset(c, 0, sizeof *c);
+      c->kind = L->sde_kind; c->leaf = l; c->idx = i; c->f_kind = L->f_kind; c->period = L->period;
+      c->m0 = rep(L->m0, L->n_m0, i);
+      c->c0 = o_exp(pf, rep(L->c0, L->n_c0, i));              /* c.map(exp(_)) */
+      switch (L->sde_kind) {
+        case CSSM_SDE_BROWNIAN:                                /* model/Sde.scala:99-102 */
+          c->sigma = o_exp(pf, rep(L->sigma, L->n_sigma, i));
+          break;
+        case CSSM_SDE_GEN_BROWNIAN:                            /* model/Sde.scala:70-73 */
+          c->mu = rep(L->mu, L->n_mu, i);
+          c->sigma = o_exp(pf, rep(L->sigma, L->n_sigma, i));
+          break;
+        case CSSM_SDE_OU:                                      /* model/Sde.scala:133-137 */
+          c->phi = o_logistic(pf, rep(L->phi, L->n_phi, i));   /* applied to an already-logistic value: the double-logistic quirk */
+          c->mu = rep(L->mu, L->n_mu, i);
+          c->sigma = o_exp(pf, rep(L->sigma, L->n_sigma, i));
+          break;
+        case CSSM_SDE_EULER_AFFINE:                            /* user-defined Sde: raw a, b, g */
+          c->mu = rep(L->mu, L->n_mu, i);
+          c->phi = rep(L->phi, L->n_phi, i);
+          c->sigma = rep(L->sigma, L->n_sigma, i);
+          break;
+        default: return ORACLE_EINVAL;
+      }
+    }
+    d += L->dim;
+  }
+  pf->d = d;
+  /* only the leftmost leaf supplies the observation model, model/Model.scala:118-120,132 */
+  const cssm_leaf_desc* L0 = &desc->leaves[0];
+  if (desc->obs_kind == CSSM_OBS_GAUSSIAN) {
+    if (!L0->has_scale) return ORACLE_EINVAL;                  /* "Must provide SD parameter", model/Model.scala:250 */
+    pf->scale_sd = o_exp(pf, L0->scale);
+  } else if (desc->obs_kind != CSSM_OBS_POISSON && desc->obs_kind != CSSM_OBS_LGCP) {
+    return ORACLE_EINVAL;
+  }
+  return ORACLE_OK;
+}
+
+int oracle_pf_create(const cssm_model_desc* desc, uint64_t n, uint64_t seed, int flags, oracle_pf** out) {
+  if (!out || n < 1 || n >= 0xffffffffULL) return ORACLE_EINVAL;
+  oracle_pf* pf = (oracle_pf*)calloc(1, sizeof *pf);
+  if (!pf) return ORACLE_EINVAL;
+  pf->flags = flags; pf->n = n; pf->seed = seed;
+  int rc = build_components(pf, desc);
+  if (rc) { free(pf); return rc; }
+  size_t nd = (size_t)n * pf->d;
+  pf->x = (double*)malloc(nd * 8); pf->x1 = (double*)malloc(nd * 8);
+  pf->w = (double*)malloc(n * 8); pf->w1 = (double*)malloc(n * 8); pf->C = (double*)malloc(n * 8);
+  pf->anc = (uint32_t*)malloc(n * 4);
+  for (uint64_t i = 0; i < n; ++i) pf->anc[i] = (uint32_t)i;
+  *out = pf;
+  return ORACLE_OK;
+}
+
+void oracle_pf_destroy(oracle_pf* pf) {
+  if (!pf) return;
+  free(pf->x); free(pf->x1); free(pf->w); free(pf->w1); free(pf->C); free(pf->anc); free(pf);
+}
+
+int oracle_pf_set_params(oracle_pf* pf, const cssm_model_desc* desc) {
+  int d0 = pf->d;
+  int rc = build_components(pf, desc);
+  if (rc) return rc;
+  return pf->d == d0 ? ORACLE_OK : ORACLE_EINVAL;
+}
+void oracle_pf_reseed(oracle_pf* pf, uint64_t seed) { pf->seed = seed; }
+
+/* Effective (constrained) per-component parameters, for the K2 tests. out[d][5] = m0,c0,mu,phi,sigma */
+int oracle_pf_components(const oracle_pf* pf, double* out) {
+  for (int k = 0; k < pf->d; ++k) {
+    out[5 * k + 0] = pf->comp[k].m0; out[5 * k + 1] = pf->comp[k].c0; out[5 * k + 2] = pf->comp[k].mu;
+    out[5 * k + 3] = pf->comp[k].phi; out[5 * k + 4] = pf->comp[k].sigma;
+  }
+  return pf->d;
+}
+
+/* ------------------------------------------------------------------ random variates */
+
+/* d standard normals of particle `gid` at (step, tag, substep): component k = element k%2 of
+ * pair k/2 (include/cssm_numerics.h, counter layout). */
+static void draw_normals(const oracle_pf* pf, uint64_t gid, uint32_t step, uint32_t tag, uint32_t sub, double* z) {
+  for (int p = 0; 2 * p < pf->d; ++p) {
+    double z0, z1;
+    o_normal_pair(pf, cssm_philox_draw(pf->seed, gid, step, tag, sub, (uint32_t)p), &z0, &z1);
+    z[2 * p] = z0;
+    if (2 * p + 1 < pf->d) z[2 * p + 1] = z1;
+  }
+}
+
+/* ------------------------------------------------------------------ A1 initial state */
+
+/* initialiseState, model/ParticleFilter.scala:105-108; initialState of the leaves:
+ * Brownian model/Sde.scala:104-108, GenBrownian :75-80, OU :152-156, composed :206-209:
+ * x0 = sqrt(c0) * z + m0 per component. */
+int oracle_pf_init(oracle_pf* pf, double t0) {
+  double z[CSSM_MAX_DIM];
+  for (uint64_t i = 0; i < pf->n; ++i) {
+    draw_normals(pf, i, 0, CSSM_STREAM_INIT, 0, z);
+    for (int k = 0; k < pf->d; ++k) pf->x[i * pf->d + k] = sqrt(pf->comp[k].c0) * z[k] + pf->comp[k].m0;
+  }
+  memcpy(pf->x1, pf->x, (size_t)pf->n * pf->d * 8);
+  for (uint64_t i = 0; i < pf->n; ++i) pf->anc[i] = (uint32_t)i;
+  pf->t = t0; pf->ll = 0.0; pf->ess = (int32_t)pf->n; pf->step = 0; pf->initialised = 1;
+  return ORACLE_OK;
+}
+
+/* FilterInit.initialiseState, model/ParticleFilter.scala:257-260 */
+int oracle_pf_init_from(oracle_pf* pf, double t0, const double* state_d) {
+  for (uint64_t i = 0; i < pf->n; ++i) memcpy(pf->x + i * pf->d, state_d, pf->d * 8);
+  memcpy(pf->x1, pf->x, (size_t)pf->n * pf->d * 8);
+  for (uint64_t i = 0; i < pf->n; ++i) pf->anc[i] = (uint32_t)i;
+  pf->t = t0; pf->ll = 0.0; pf->ess = (int32_t)pf->n; pf->step = 0; pf->initialised = 1;
+  return ORACLE_OK;
+}
+
+/* ------------------------------------------------------------------ A3 transitions */
+
+/* One particle, all leaves left to right (composed stepFunction, model/Sde.scala:223-229). */
+static void transition(const oracle_pf* pf, const double* x, double dt, const double* z, double* out) {
+  for (int k = 0; k < pf->d; ++k) {
+    const ocomp* c = &pf->comp[k];
+    switch (c->kind) {
+      case CSSM_SDE_BROWNIAN: {            /* model/Sde.scala:114-123: sqrt(sigma*dt) * z + x */
+        double sd = sqrt(c->sigma * dt);
+        out[k] = sd * z[k] + x[k];
+        break;
+      }
+      case CSSM_SDE_GEN_BROWNIAN: {        /* model/Sde.scala:86-95: mean = x + mu*dt */
+        double mean = x[k] + c->mu * dt;
+        double sd = sqrt(c->sigma * dt);
+        out[k] = sd * z[k] + mean;
+        break;
+      }
+      case CSSM_SDE_OU: {                  /* model/Sde.scala:139-150 */
+        double var = (c->sigma * c->sigma / (c->phi * 2.0)) * (1.0 - o_exp(pf, c->phi * -2.0 * dt));
+        double mean = c->mu + (x[k] - c->mu) * o_exp(pf, -c->phi * dt);
+        out[k] = sqrt(var) * z[k] + mean;
+        break;
+      }
+      default: {                           /* stepEulerMaruyama, model/Sde.scala:30-43 */
+        double dW = sqrt(dt) * z[k];
+        double a = (c->mu + c->phi * x[k]) * dt;
+        double b = c->sigma * dW;
+        out[k] = (x[k] + a) + b;
+        break;
+      }
+    }
+  }
+}
+
+/* ------------------------------------------------------------------ A4 linear map f */
+
+/* f(s, t): composed sum model/Model.scala:122-128 (left-nested), leaf "first component"
+ * :271, seasonal buildF/f :217-225 with the contract's period reduction. */
+static double gamma_of(const oracle_pf* pf, const double* x, double t) {
+  double g = 0.0, acc = 0.0;
+  int cur = -1, nleaf = 0;
+  for (int k = 0; k < pf->d; ++k) {
+    const ocomp* c = &pf->comp[k];
+    if (c->leaf != cur) {
+      if (cur >= 0) { g = (nleaf == 0) ? acc : g + acc; ++nleaf; }
+      cur = c->leaf; acc = 0.0;
+    }
+    if (c->f_kind == CSSM_F_FIRST) {
+      if (c->idx == 0) acc = x[k];
+    } else {
+      double a = (double)(c->idx / 2 + 1), sn, cs;
+      if (pf->flags & ORACLE_LIBM) {
+        double om = 2.0 * M_PI / c->period;                    /* literal: cos(frequency * a * t) */
+        cs = cos(om * a * t); sn = sin(om * a * t);
+      } else {
+        cssm_sincos2pi(cssm_seasonal_phase(a, t, (double)c->period), &sn, &cs);
+      }
+      double term = ((c->idx & 1) ? sn : cs) * x[k];
+      acc = (c->idx == 0) ? term : acc + term;                 /* F(t) dot x, left to right */
+    }
+  }
+  g = (nleaf == 0) ? acc : g + acc;
+  return g;
+}
+
+/* ------------------------------------------------------------------ A5 observation densities */
+
+/* breeze Poisson(lambda).logProbabilityOf(k) = -lambda + k*log(lambda) - lgamma(k+1) with
+ * lambda = exp(gamma) (model/Model.scala:269,273).  k*log(exp(gamma)) is evaluated as
+ * k*gamma (<= 1 ulp*k apart; no JVM run exists to bit-match). */
+double oracle_logdens_poisson(double gamma, double y) {
+  long long k = (long long)y;                                  /* y.toInt truncation */
+  return -cssm_exp(gamma) + (double)k * gamma - cssm_lgamma_kp1(k);
+}
+/* breeze Gaussian(mu, sd).logPdf(y) = -((y-mu)/sd)^2/2 - log(sqrt(2 pi) * sd), model/Model.scala:252-258 */
+double oracle_logdens_gaussian(double gamma, double y, double sd) {
+  double dd = (y - gamma) / sd;
+  return -(dd * dd) / 2.0 - cssm_log(2.5066282746310002 * sd);
+}
+
+static double logdens(const oracle_pf* pf, double gamma, double y) {
+  if (pf->obs_kind == CSSM_OBS_POISSON) {
+    long long k = (long long)y;
+    return -o_exp(pf, gamma) + (double)k * gamma - cssm_lgamma_kp1(k);
+  }
+  double dd = (y - gamma) / pf->scale_sd;
+  return -(dd * dd) / 2.0 - o_log(pf, 2.5066282746310002 * pf->scale_sd);
+}
+
+/* ------------------------------------------------------------------ A8 systematic resampling */
+
+static u128 fix_from_double(double w) {                         /* floor(w * 2^96), independent of the header */
+  if (!(w > 0.0) || isinf(w)) return 0;
+  long double s = floorl((long double)w * 0x1p96L);             /* 64-bit mantissa: the product is exact */
+  return (u128)s;
+}
+
+/*
+ * Resampling.systematicResampling, model/Resampling.scala:63-72, with treeEcdf :52-58,
+ * normalise :21-24 and findAllInTreeMap :36-46.  `findAllInTreeMap` walks the grid points in
+ * increasing order and takes the first key >= k, which is the two-pointer merge below.
+ */
+int oracle_resample_systematic(const double* w, uint64_t n, double u, uint32_t* anc, double* C_out, int flags) {
+  double* C = C_out ? C_out : (double*)malloc(n * 8);
+  if (flags & ORACLE_LITERAL_SUMS) {
+    double total = 0.0;
+    for (uint64_t i = 0; i < n; ++i) total = total + w[i];     /* prob.foldLeft(0.0)(_ + _) */
+    double acc = 0.0;
+    for (uint64_t i = 0; i < n; ++i) { acc = acc + w[i] / total; C[i] = acc; }  /* scanLeft(0.0)(_ + _).drop(1) */
+  } else {
+    u128 tot = 0, acc = 0;
+    for (uint64_t i = 0; i < n; ++i) tot += fix_from_double(w[i]);
+    double totd = (double)tot;                                  /* compiler's RNE u128 -> double */
+    for (uint64_t i = 0; i < n; ++i) { acc += fix_from_double(w[i]); C[i] = (double)acc / totd; }
+  }
+  int rc = ORACLE_OK;
+  uint64_t j = 0;
+  double nd = (double)n;
+  for (uint64_t i = 0; i < n; ++i) {
+    double k = (u + (double)i) / nd;                            /* ks, Resampling.scala:69 */
+    while (j < n && C[j] < k) ++j;                              /* remMap.from(k) */
+    if (j >= n) {
+      if (flags & ORACLE_TIE_LAST) { rc = ORACLE_EEMPTY; break; }   /* `.head` of an empty map */
+      j = n - 1;                                                /* contract: clamp (cannot occur: C[n-1] == 1) */
+    }
+    uint64_t a = j;
+    if (flags & ORACLE_TIE_LAST) while (a + 1 < n && C[a + 1] == C[a]) ++a;  /* duplicate key: last insert wins */
+    anc[i] = (uint32_t)a;
+  }
+  if (!C_out) free(C);
+  return rc;
+}
+
+/* ------------------------------------------------------------------ A6/A7 sums, ll, ess */
+
+/* Tail of stepFilter after the log-weights exist: model/ParticleFilter.scala:124-130
+ * (and :218-225 for LGCP, same arithmetic). */
+static int weigh_and_resample(oracle_pf* pf) {
+  uint64_t n = pf->n;
+  int d = pf->d;
+  double max = -INFINITY;
+  for (uint64_t i = 0; i < n; ++i) {
+    if (pf->w[i] != pf->w[i]) return ORACLE_ENONFINITE;
+    if (pf->w[i] > max) max = pf->w[i];                         /* w.max */
+  }
+  if (max == -INFINITY || isinf(max)) return ORACLE_ENONFINITE;
+  for (uint64_t i = 0; i < n; ++i) pf->w1[i] = o_exp(pf, pf->w[i] - max);   /* :125 */
+  double u = cssm_u01(cssm_philox_draw(pf->seed, 0, pf->step, CSSM_STREAM_U, 0, 0).v[0],
+                      cssm_philox_draw(pf->seed, 0, pf->step, CSSM_STREAM_U, 0, 0).v[1]);
+  int rc = oracle_resample_systematic(pf->w1, n, u, pf->anc, pf->C, pf->flags);   /* :126 */
+  if (rc) return rc;
+  if (pf->flags & ORACLE_LITERAL_SUMS) {
+    double sum = 0.0;
+    for (uint64_t i = 0; i < n; ++i) sum = sum + pf->w1[i];     /* ParticleFilter.mean, :522-524 */
+    pf->ll = pf->ll + max + o_log(pf, sum / (double)n);         /* :127 */
+    double total = 0.0, s2 = 0.0;
+    for (uint64_t i = 0; i < n; ++i) total = total + pf->w1[i]; /* Resampling.normalise */
+    for (uint64_t i = 0; i < n; ++i) { double q = pf->w1[i] / total; s2 = s2 + q * q; }
+    pf->ess = (int32_t)floor(1.0 / s2);                         /* :431-434 */
+  } else {
+    u128 S = 0, S2 = 0;
+    for (uint64_t i = 0; i < n; ++i) { S += fix_from_double(pf->w1[i]); S2 += fix_from_double(pf->w1[i] * pf->w1[i]); }
+    double tot = (double)S * 0x1p-96, tot2 = (double)S2 * 0x1p-96;
+    pf->ll = pf->ll + max + o_log(pf, tot / (double)n);
+    pf->ess = (int32_t)floor(1.0 / (tot2 / (tot * tot)));
+  }
+  for (uint64_t i = 0; i < n; ++i) memcpy(pf->x + i * d, pf->x1 + (uint64_t)pf->anc[i] * d, d * 8);   /* :130 */
+  return ORACLE_OK;
+}
+
+/* ------------------------------------------------------------------ A2 stepFilter */
+
+/* stepFilter, model/ParticleFilter.scala:116-132 */
+static int step_generic(oracle_pf* pf, double t, double y, int has_obs) {
+  double z[CSSM_MAX_DIM];
+  int d = pf->d;
+  double dt = t - pf->t;                                        /* :117 */
+  for (uint64_t i = 0; i < pf->n; ++i) {                        /* :118 */
+    draw_normals(pf, i, pf->step, CSSM_STREAM_STEP, 0, z);
+    transition(pf, pf->x + i * d, dt, z, pf->x1 + i * d);
+  }
+  if (!has_obs) {                                               /* :121 */
+    memcpy(pf->x, pf->x1, (size_t)pf->n * d * 8);
+    for (uint64_t i = 0; i < pf->n; ++i) pf->anc[i] = (uint32_t)i;
+    pf->t = t; pf->step++;
+    return ORACLE_OK;
+  }
+  for (uint64_t i = 0; i < pf->n; ++i) pf->w[i] = logdens(pf, gamma_of(pf, pf->x1 + i * d, t), y);   /* :123 */
+  int rc = weigh_and_resample(pf);
+  if (rc) return rc;
+  pf->t = t; pf->step++;
+  return ORACLE_OK;
+}
+
+/* ------------------------------------------------------------------ A10 LGCP step */
+
+/* FilterLgcp.stepFilter / calcWeight, model/ParticleFilter.scala:184-226, with
+ * Sde.simInit / simInitStream, model/Sde.scala:57-66. */
+static int step_lgcp(oracle_pf* pf, double t) {
+  double z[CSSM_MAX_DIM], xs[CSSM_MAX_DIM], xn[CSSM_MAX_DIM];
+  int d = pf->d;
+  double dt = t - pf->t;                                        /* :211 */
+  if (dt == 0) {                                                /* :212-213: (x, f, f) -> weight f - f */
+    for (uint64_t i = 0; i < pf->n; ++i) {
+      memcpy(pf->x1 + i * d, pf->x + i * d, d * 8);
+      double g = gamma_of(pf, pf->x + i * d, t);
+      pf->w[i] = g - g;
+    }
+  } else {
+    double delta = pow(10.0, -pf->precision);
+    uint32_t nsub = (uint32_t)ceil(dt / delta);                 /* :190 */
+    for (uint64_t i = 0; i < pf->n; ++i) {
+      memcpy(xs, pf->x + i * d, d * 8);
+      double tau = t, haz = 0.0;                                /* simInit starts the clock at y.t, :194,215 */
+      for (uint32_t k = 0; k < nsub; ++k) {
+        draw_normals(pf, i, pf->step, CSSM_STREAM_STEP, k, z);
+        transition(pf, xs, delta, z, xn);                       /* x <- stepFunction(dt)(s.state), Sde.scala:59 */
+        memcpy(xs, xn, d * 8);
+        tau = tau + delta;                                      /* t = s.time + dt, Sde.scala:60 */
+        haz = haz + o_exp(pf, gamma_of(pf, xs, tau)) * delta;   /* :203-205 */
+      }
+      memcpy(pf->x1 + i * d, xs, d * 8);
+      pf->w[i] = gamma_of(pf, xs, t) - haz;                     /* :200, :217 */
+    }
+  }
+  int rc = weigh_and_resample(pf);                              /* :218-223 */
+  if (rc) return rc;
+  pf->t = t; pf->step++;
+  return ORACLE_OK;
+}
+
+int oracle_pf_step(oracle_pf* pf, double t, double y, int has_obs, double* ll_out, int32_t* ess_out) {
+  if (!pf->initialised) return ORACLE_EINVAL;
+  int rc = (pf->obs_kind == CSSM_OBS_LGCP) ? step_lgcp(pf, t) : step_generic(pf, t, y, has_obs);
+  if (ll_out) *ll_out = pf->ll;
+  if (ess_out) *ess_out = pf->ess;
+  return rc;
+}
+
+/* ------------------------------------------------------------------ A9 drivers */
+
+/* Resampling.sampleOne, model/Resampling.scala:151-154: abs(nextInt) % size */
+static uint64_t pick_index(const oracle_pf* pf, uint32_t s) {
+  int32_t r = (int32_t)cssm_philox_draw(pf->seed, 0, s, CSSM_STREAM_PICK, 0, 0).v[0];
+  uint32_t a = r < 0 ? (uint32_t)0 - (uint32_t)r : (uint32_t)r;
+  return (uint64_t)a % pf->n;
+}
+
+/* llFilter model/ParticleFilter.scala:137-140 and filter :152-158 (path != NULL) */
+int oracle_pf_filter(oracle_pf* pf, const double* t, const double* y, const uint8_t* has, size_t T,
+                     double* ll_out, double* ll_t, int32_t* ess_t, double* path) {
+  double t0 = t[0];
+  for (size_t s = 1; s < T; ++s) if (t[s] < t0) t0 = t[s];      /* data.minBy(_.t).t */
+  int rc = oracle_pf_init(pf, t0);
+  if (rc) return rc;
+  if (path) memcpy(path, pf->x + pick_index(pf, 0) * pf->d, pf->d * 8);
+  for (size_t s = 0; s < T; ++s) {
+    rc = oracle_pf_step(pf, t[s], y[s], has ? has[s] : 1, NULL, NULL);
+    if (rc) return rc;
+    if (ll_t) ll_t[s] = pf->ll;
+    if (ess_t) ess_t[s] = pf->ess;
+    if (path) memcpy(path + (s + 1) * pf->d, pf->x + pick_index(pf, (uint32_t)(s + 1)) * pf->d, pf->d * 8);
+  }
+  if (ll_out) *ll_out = pf->ll;
+  return ORACLE_OK;
+}
+
+/* ------------------------------------------------------------------ getters (SoA out) */
+
+uint64_t oracle_pf_num_particles(const oracle_pf* pf) { return pf->n; }
+int oracle_pf_dim(const oracle_pf* pf) { return pf->d; }
+void oracle_pf_get_particles(const oracle_pf* pf, double* out) {
+  for (uint64_t i = 0; i < pf->n; ++i) for (int k = 0; k < pf->d; ++k) out[(uint64_t)k * pf->n + i] = pf->x[i * pf->d + k];
+}
+void oracle_pf_get_proposed(const oracle_pf* pf, double* out) {
+  for (uint64_t i = 0; i < pf->n; ++i) for (int k = 0; k < pf->d; ++k) out[(uint64_t)k * pf->n + i] = pf->x1[i * pf->d + k];
+}
+void oracle_pf_get_logw(const oracle_pf* pf, double* out) { memcpy(out, pf->w, pf->n * 8); }
+void oracle_pf_get_ancestors(const oracle_pf* pf, uint32_t* out) { memcpy(out, pf->anc, pf->n * 4); }
+void oracle_pf_get_cumw(const oracle_pf* pf, double* out) { memcpy(out, pf->C, pf->n * 8); }
+
+/* ------------------------------------------------------------------ A11 PMMH */
+
+/* Parameters.flattenParams order, model/Parameters.scala:88-95; SdeParameter.flatten,
+ * model/SdeParameters.scala:73,111,153. Returns the count; writes pointers to every stored
+ * scalar of a MUTABLE copy of the descriptor. */
+static size_t theta_slots(cssm_model_desc* desc, double** slots, size_t cap) {
+  size_t n = 0;
+  for (int l = 0; l < desc->n_leaves; ++l) {
+    cssm_leaf_desc* L = (cssm_leaf_desc*)&desc->leaves[l];
+#define PUSH(ptr, cnt) for (int i = 0; i < (cnt); ++i) { if (n < cap) slots[n] = (double*)&(ptr)[i]; ++n; }
+    if (L->has_scale) { if (n < cap) slots[n] = &L->scale; ++n; }
+    PUSH(L->m0, L->n_m0) PUSH(L->c0, L->n_c0)
+    if (L->sde_kind == CSSM_SDE_GEN_BROWNIAN) { PUSH(L->mu, L->n_mu) }
+    else if (L->sde_kind == CSSM_SDE_OU || L->sde_kind == CSSM_SDE_EULER_AFFINE) { PUSH(L->phi, L->n_phi) PUSH(L->mu, L->n_mu) }
+    PUSH(L->sigma, L->n_sigma)
+#undef PUSH
+  }
+  return n;
+}
+
+/* mhStep, model/PMMH.scala:68-81, with init ll = -1e99 (:121), proposal perturb(delta)
+ * (model/Parameters.scala:65-67: Gaussian(theta_k, sqrt(delta)) on every stored scalar),
+ * symmetric transition and flat prior.  The descriptor's parameter arrays are overwritten. */
+int oracle_pmmh_run(oracle_pf* pf, cssm_model_desc* desc, const double* theta0, size_t n_theta, double delta,
+                    const double* t, const double* y, const uint8_t* has, size_t T, uint64_t seed,
+                    size_t n_iters, double* ll, double* theta, int32_t* accepted, double* last_state) {
+  double* slots[1024];
+  if (theta_slots(desc, slots, 1024) != n_theta || n_theta > 1024) return ORACLE_EINVAL;
+  int d = pf->d;
+  double* cur = (double*)malloc(n_theta * 8), *prop = (double*)malloc(n_theta * 8);
+  double* path = (double*)malloc((T + 1) * d * 8), *cur_state = (double*)calloc(d, 8);
+  memcpy(cur, theta0, n_theta * 8);
+  double cur_ll = -1e99;
+  int32_t acc = 0;
+  double sd = sqrt(delta);
+  int rc = ORACLE_OK;
+  for (size_t it = 0; it < n_iters && !rc; ++it) {
+    for (size_t j = 0; j < n_theta; j += 2) {                   /* proposal(s.params) */
+      double z0, z1;
+      cssm_normal_pair(cssm_philox_draw(seed, it, (uint32_t)(j / 2), CSSM_STREAM_HOST, 0, 0), &z0, &z1);
+      prop[j] = cur[j] + sd * z0;
+      if (j + 1 < n_theta) prop[j + 1] = cur[j + 1] + sd * z1;
+    }
+    for (size_t j = 0; j < n_theta; ++j) *slots[j] = prop[j];
+    rc = oracle_pf_set_params(pf, desc);
+    if (rc) break;
+    oracle_pf_reseed(pf, seed + 1 + it);
+    double pll;
+    int frc = oracle_pf_filter(pf, t, y, has, T, &pll, NULL, NULL, path);   /* state = pf(propParams) */
+    if (frc == ORACLE_ENONFINITE) pll = -INFINITY;              /* a proposal the filter cannot weigh is rejected */
+    else if (frc) { rc = frc; break; }
+    double a = pll - cur_ll;                                    /* logTransition = prior = 0 */
+    cssm_u32x4 b = cssm_philox_draw(seed, it, 0xffffffffu, CSSM_STREAM_HOST, 0, 1);
+    double uu = cssm_u01_open0(b.v[0], b.v[1]);
+    if (cssm_log(uu) < a) {                                     /* :75 */
+      cur_ll = pll; memcpy(cur, prop, n_theta * 8); memcpy(cur_state, path + T * d, d * 8); ++acc;
+    }
+    ll[it] = cur_ll; accepted[it] = acc;
+    memcpy(theta + it * n_theta, cur, n_theta * 8);
+    memcpy(last_state + it * d, cur_state, d * 8);
+  }
+  free(cur); free(prop); free(path); free(cur_state);
+  return rc;
+}
+
+/* ------------------------------------------------------------------ contract pass-throughs */
+/* So that tests can pin the numerics contract itself (Philox known answers, ulp bounds). */
+double oracle_c_exp(double x) { return cssm_exp(x); }
+double oracle_c_log(double x) { return cssm_log(x); }
+void oracle_c_sincos2pi(double u, double* s, double* c) { cssm_sincos2pi(u, s, c); }
+void oracle_c_philox(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]) {
+  cssm_u32x4 c; memcpy(c.v, ctr, 16);
+  c = cssm_philox4x32_10(c, key[0], key[1]);
+  memcpy(out, c.v, 16);
+}
+void oracle_c_normals(uint64_t seed, uint64_t gid, uint32_t step, uint32_t tag, uint32_t sub, uint32_t pair, double* z2) {
+  cssm_normal_pair(cssm_philox_draw(seed, gid, step, tag, sub, pair), &z2[0], &z2[1]);
+}
+double oracle_c_lgamma_kp1(long long k) { return cssm_lgamma_kp1(k); }
+uint64_t oracle_c_sys_count(double C, double u, uint64_t n) { return cssm_sys_count(C, u, n); }
+double oracle_c_fix_roundtrip(double w) { return cssm_fix_to_double(cssm_fix_from_double(w)); }
+double oracle_c_u(uint64_t seed, uint32_t step) {
+  cssm_u32x4 b = cssm_philox_draw(seed, 0, step, CSSM_STREAM_U, 0, 0);
+  return cssm_u01(b.v[0], b.v[1]);
+}
+/* vectorised for ulp sweeps */
+void oracle_c_exp_v(const double* x, double* y, size_t n) { for (size_t i = 0; i < n; ++i) y[i] = cssm_exp(x[i]); }
+void oracle_c_log_v(const double* x, double* y, size_t n) { for (size_t i = 0; i < n; ++i) y[i] = cssm_log(x[i]); }
+void oracle_c_sincos2pi_v(const double* u, double* s, double* c, size_t n) { for (size_t i = 0; i < n; ++i) cssm_sincos2pi(u[i], &s[i], &c[i]); }
+void oracle_c_normals_v(uint64_t seed, uint64_t gid0, uint32_t step, uint32_t tag, uint32_t sub, uint32_t pair, double* z, size_t n) {
+  for (size_t i = 0; i < n; ++i) cssm_normal_pair(cssm_philox_draw(seed, gid0 + i, step, tag, sub, pair), &z[2 * i], &z[2 * i + 1]);
+}

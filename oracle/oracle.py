@@ -1,0 +1,214 @@
+"""ctypes wrapper of oracle/liboracle.so -- the CPU restatement of the reference filter.
+
+TEST INFRASTRUCTURE ONLY: importable from tests/, __graft_entry__.smoke() and bench.py's
+cpu_baseline leg; nothing under composablestatespacemodels_amd/ may import this module.
+See the header of cssm_oracle.c for the parity status ("parity unpinned by the reference").
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB = os.path.join(HERE, "liboracle.so")
+
+LITERAL_SUMS = 1
+TIE_LAST = 2
+LIBM = 4
+
+OK, EINVAL, ENONFINITE, EEMPTY = 0, -1, -5, -8
+
+_dp = C.POINTER(C.c_double)
+_u32p = C.POINTER(C.c_uint32)
+_i32p = C.POINTER(C.c_int32)
+_u8p = C.POINTER(C.c_uint8)
+_lib = None
+
+
+def build(force: bool = False) -> str:
+    src = os.path.join(HERE, "cssm_oracle.c")
+    hdrs = [os.path.join(HERE, "..", "include", h) for h in ("cssm_numerics.h", "cssm_pf.h")]
+    stale = force or not os.path.exists(LIB) or any(
+        os.path.exists(s) and os.path.getmtime(s) > os.path.getmtime(LIB) for s in [src] + hdrs)
+    if stale and os.path.exists(src):
+        subprocess.check_call(["make", "-C", HERE, "-s"] + (["-B"] if force else []))
+    return LIB
+
+
+def lib() -> C.CDLL:
+    global _lib
+    if _lib is None:
+        build()
+        L = C.CDLL(LIB)
+        vp = C.c_void_p
+        sig = {
+            "oracle_pf_create": (C.c_int, [vp, C.c_uint64, C.c_uint64, C.c_int, C.POINTER(vp)]),
+            "oracle_pf_destroy": (None, [vp]),
+            "oracle_pf_set_params": (C.c_int, [vp, vp]),
+            "oracle_pf_reseed": (None, [vp, C.c_uint64]),
+            "oracle_pf_components": (C.c_int, [vp, _dp]),
+            "oracle_pf_init": (C.c_int, [vp, C.c_double]),
+            "oracle_pf_init_from": (C.c_int, [vp, C.c_double, _dp]),
+            "oracle_pf_step": (C.c_int, [vp, C.c_double, C.c_double, C.c_int, _dp, _i32p]),
+            "oracle_pf_filter": (C.c_int, [vp, _dp, _dp, _u8p, C.c_size_t, _dp, _dp, _i32p, _dp]),
+            "oracle_pf_num_particles": (C.c_uint64, [vp]),
+            "oracle_pf_dim": (C.c_int, [vp]),
+            "oracle_pf_get_particles": (None, [vp, _dp]),
+            "oracle_pf_get_proposed": (None, [vp, _dp]),
+            "oracle_pf_get_logw": (None, [vp, _dp]),
+            "oracle_pf_get_ancestors": (None, [vp, _u32p]),
+            "oracle_pf_get_cumw": (None, [vp, _dp]),
+            "oracle_resample_systematic": (C.c_int, [_dp, C.c_uint64, C.c_double, _u32p, _dp, C.c_int]),
+            "oracle_logdens_poisson": (C.c_double, [C.c_double, C.c_double]),
+            "oracle_logdens_gaussian": (C.c_double, [C.c_double, C.c_double, C.c_double]),
+            "oracle_pmmh_run": (C.c_int, [vp, vp, _dp, C.c_size_t, C.c_double, _dp, _dp, _u8p, C.c_size_t,
+                                          C.c_uint64, C.c_size_t, _dp, _dp, _i32p, _dp]),
+            "oracle_c_exp": (C.c_double, [C.c_double]),
+            "oracle_c_log": (C.c_double, [C.c_double]),
+            "oracle_c_philox": (None, [_u32p, _u32p, _u32p]),
+            "oracle_c_normals": (None, [C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, _dp]),
+            "oracle_c_lgamma_kp1": (C.c_double, [C.c_longlong]),
+            "oracle_c_sys_count": (C.c_uint64, [C.c_double, C.c_double, C.c_uint64]),
+            "oracle_c_fix_roundtrip": (C.c_double, [C.c_double]),
+            "oracle_c_u": (C.c_double, [C.c_uint64, C.c_uint32]),
+            "oracle_c_exp_v": (None, [_dp, _dp, C.c_size_t]),
+            "oracle_c_log_v": (None, [_dp, _dp, C.c_size_t]),
+            "oracle_c_sincos2pi_v": (None, [_dp, _dp, _dp, C.c_size_t]),
+            "oracle_c_normals_v": (None, [C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, _dp, C.c_size_t]),
+        }
+        for name, (res, args) in sig.items():
+            f = getattr(L, name)
+            f.restype, f.argtypes = res, args
+        _lib = L
+    return _lib
+
+
+def _p(a, ty=_dp):
+    return a.ctypes.data_as(ty)
+
+
+class OracleError(RuntimeError):
+    def __init__(self, code):
+        super().__init__(f"oracle error {code}")
+        self.code = code
+
+
+def _chk(rc):
+    if rc != 0:
+        raise OracleError(rc)
+
+
+class OraclePf:
+    """Sequential CPU filter; the same method names as the native handle wrapper."""
+
+    def __init__(self, descriptor, n: int, seed: int, flags: int = 0):
+        self._d = descriptor  # keeps the ctypes arrays alive
+        self._h = C.c_void_p()
+        _chk(lib().oracle_pf_create(C.cast(descriptor.ptr(), C.c_void_p), n, seed, flags, C.byref(self._h)))
+        self.n = n
+        self.d = lib().oracle_pf_dim(self._h)
+
+    def __del__(self):
+        if getattr(self, "_h", None) and self._h.value:
+            lib().oracle_pf_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def set_params(self, descriptor):
+        self._d = descriptor
+        _chk(lib().oracle_pf_set_params(self._h, C.cast(descriptor.ptr(), C.c_void_p)))
+
+    def reseed(self, seed):
+        lib().oracle_pf_reseed(self._h, seed)
+
+    def components(self):
+        out = np.zeros((self.d, 5))
+        lib().oracle_pf_components(self._h, _p(out))
+        return out
+
+    def init(self, t0):
+        _chk(lib().oracle_pf_init(self._h, t0))
+
+    def init_from(self, t0, state):
+        s = np.ascontiguousarray(state, dtype=np.float64)
+        _chk(lib().oracle_pf_init_from(self._h, t0, _p(s)))
+
+    def step(self, t, y, has_obs=True):
+        ll, ess = C.c_double(), C.c_int32()
+        _chk(lib().oracle_pf_step(self._h, t, 0.0 if y is None else y, 1 if has_obs else 0, C.byref(ll), C.byref(ess)))
+        return ll.value, ess.value
+
+    def filter(self, t, y, has=None, want_path=False):
+        t = np.ascontiguousarray(t, dtype=np.float64); y = np.ascontiguousarray(y, dtype=np.float64)
+        T = len(t)
+        hp = None
+        if has is not None:
+            has = np.ascontiguousarray(has, dtype=np.uint8); hp = _p(has, _u8p)
+        ll = C.c_double(); ll_t = np.zeros(T); ess_t = np.zeros(T, dtype=np.int32)
+        path = np.zeros((T + 1, self.d)) if want_path else None
+        _chk(lib().oracle_pf_filter(self._h, _p(t), _p(y), hp, T, C.byref(ll), _p(ll_t), _p(ess_t, _i32p),
+                                    _p(path) if want_path else None))
+        return ll.value, ll_t, ess_t, path
+
+    def particles(self):
+        out = np.zeros((self.d, self.n)); lib().oracle_pf_get_particles(self._h, _p(out)); return out
+
+    def proposed(self):
+        out = np.zeros((self.d, self.n)); lib().oracle_pf_get_proposed(self._h, _p(out)); return out
+
+    def logw(self):
+        out = np.zeros(self.n); lib().oracle_pf_get_logw(self._h, _p(out)); return out
+
+    def ancestors(self):
+        out = np.zeros(self.n, dtype=np.uint32); lib().oracle_pf_get_ancestors(self._h, _p(out, _u32p)); return out
+
+    def cumw(self):
+        out = np.zeros(self.n); lib().oracle_pf_get_cumw(self._h, _p(out)); return out
+
+    def pmmh(self, descriptor, theta0, delta, t, y, has, seed, n_iters):
+        """descriptor's parameter arrays are overwritten (it is the proposal scratch)."""
+        theta0 = np.ascontiguousarray(theta0, dtype=np.float64)
+        t = np.ascontiguousarray(t, dtype=np.float64); y = np.ascontiguousarray(y, dtype=np.float64)
+        T, nt = len(t), len(theta0)
+        hp = None
+        if has is not None:
+            has = np.ascontiguousarray(has, dtype=np.uint8); hp = _p(has, _u8p)
+        ll = np.zeros(n_iters); th = np.zeros((n_iters, nt)); acc = np.zeros(n_iters, dtype=np.int32)
+        last = np.zeros((n_iters, self.d))
+        self._d = descriptor
+        _chk(lib().oracle_pmmh_run(self._h, C.cast(descriptor.ptr(), C.c_void_p), _p(theta0), nt, delta, _p(t), _p(y),
+                                   hp, T, seed, n_iters, _p(ll), _p(th), _p(acc, _i32p), _p(last)))
+        return ll, th, acc, last
+
+
+def resample_systematic(w, u, flags=0, want_cumw=False):
+    w = np.ascontiguousarray(w, dtype=np.float64)
+    anc = np.zeros(len(w), dtype=np.uint32)
+    Cw = np.zeros(len(w))
+    rc = lib().oracle_resample_systematic(_p(w), len(w), u, _p(anc, _u32p), _p(Cw), flags)
+    _chk(rc)
+    return (anc, Cw) if want_cumw else anc
+
+
+def c_exp(x):
+    x = np.ascontiguousarray(x, dtype=np.float64); y = np.empty_like(x); lib().oracle_c_exp_v(_p(x), _p(y), x.size); return y
+
+
+def c_log(x):
+    x = np.ascontiguousarray(x, dtype=np.float64); y = np.empty_like(x); lib().oracle_c_log_v(_p(x), _p(y), x.size); return y
+
+
+def c_sincos2pi(u):
+    u = np.ascontiguousarray(u, dtype=np.float64); s = np.empty_like(u); c = np.empty_like(u)
+    lib().oracle_c_sincos2pi_v(_p(u), _p(s), _p(c), u.size); return s, c
+
+
+def c_philox(ctr, key):
+    ctr = np.asarray(ctr, dtype=np.uint32); key = np.asarray(key, dtype=np.uint32); out = np.zeros(4, dtype=np.uint32)
+    lib().oracle_c_philox(_p(ctr, _u32p), _p(key, _u32p), _p(out, _u32p)); return out
+
+
+def c_normals(seed, gid0, step, tag, sub, pair, n):
+    z = np.zeros((n, 2)); lib().oracle_c_normals_v(seed, gid0, step, tag, sub, pair, _p(z), n); return z
