@@ -1,0 +1,170 @@
+#!/usr/bin/env python3
+"""bench.py -- particle-steps/second of the bootstrap particle filter on MI355X.
+
+Contract: ``python bench.py --gpus N --steps K --warmup W`` (N > 1 is launched by torchrun, one
+rank per GPU).  A "step" is one stepFilter (model/ParticleFilter.scala:116-132) over the whole
+cloud: propagate + weight + log-sum-exp + systematic resampling for one observation.
+
+Workload: BASELINE.json configs[1] -- seasonal-Poisson with OU latents (d = 3), N = 2^20 particles
+per GPU (weak scaling: the global filter has N_gpus * 2^20 particles), T = K observations, synthetic
+data (tests/cases.py simulator, seed 20260101).  value = N_global * K / wall seconds of the K-step
+loop, with the cloud resident in HBM and the observations (a few KB) already uploaded.
+
+Extra objects on the JSON line (N = 1 only): ``roofline`` for the dominant kernel (k_propagate:
+fused gather + propagate + weight) from HIP events on its launch stream, and ``cpu_baseline``: the
+CPU restatement of the reference path (oracle/, one thread as the reference runs) on a bounded
+sample of the same workload.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy ceiling)
+N_PER_GPU = 1 << 20
+
+
+def build_workload(T):
+    import cases
+    model = cases.c2_model()
+    t, y, has = cases.poisson_counts(T)
+    return model, t, y, has
+
+
+def cpu_baseline(model, t, y, has, budget_s=12.0):
+    """Oracle (CPU restatement of the reference path) on one core, bounded sample."""
+    from oracle import oracle
+    n = 65536
+    o = oracle.OraclePf(model.descriptor(), n, 20260101)
+    T0 = 8
+    t0 = time.perf_counter()
+    o.filter(t[:T0], y[:T0], has[:T0])
+    per = (time.perf_counter() - t0) / (n * T0)
+    Ts = int(max(8, min(len(t), budget_s / (per * n))))
+    t1 = time.perf_counter()
+    ll, _, _, _ = o.filter(t[:Ts], y[:Ts], has[:Ts])
+    dt = time.perf_counter() - t1
+    return {"value": n * Ts / dt, "unit": "particle-steps/s", "cores": 1, "kind": "port",
+            "sample": f"oracle/cssm_oracle.c, same model/data/seed, N={n} particles x T={Ts} observations, {dt:.1f} s on 1 of {os.cpu_count()} host cores",
+            "ll": ll}
+
+
+def run_single(args):
+    from composablestatespacemodels_amd.filter import NativePf
+    K, W = args.steps, args.warmup
+    n = args.particles
+    model, t, y, has = build_workload(max(K, W, 8))
+    pf = NativePf(model, n, 20260101, device=0)
+    d = pf.d
+    if W > 0:
+        pf.run(t[:W], y[:W], has[:W])
+    import torch
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    ll, _, ess_t, _ = pf.run(t[:K], y[:K], has[:K])
+    torch.cuda.synchronize()
+    wall = time.perf_counter() - t0
+    loop_ms = pf.last_loop_ms()
+    # per-kernel durations: HIP events on the launch stream around every kernel (separate pass so
+    # that the event records do not perturb the throughput figure above)
+    pf.profile(True)
+    pf.run(t[:K], y[:K], has[:K])
+    prof = pf.profile_read()
+    pf.profile(False)
+    ms, cnt = prof["k_propagate"]
+    avg_s = ms / max(cnt, 1) * 1e-3
+    alg_bytes = (16 * d + 8) * n  # read 8d + write 8d + write logw per particle-step
+    achieved = alg_bytes / avg_s / 1e9
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
+    if os.path.exists(tpath):
+        try:
+            traffic = json.load(open(tpath)).get("k_propagate_bytes_per_launch")
+        except Exception:
+            traffic = None
+    out = {
+        "metric": "particle-steps/sec (N x T) bootstrap filter", "value": n * K / wall, "unit": "particle-steps/s",
+        "n_gpus": 1, "steps": K, "warmup": W, "ms_per_step": wall * 1e3 / K, "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": "configs[1]: seasonal-Poisson, OU latent (poisson(ou(1)) |+| seasonal(24,1,ou(2)), d=3), "
+                               f"N={n} particles, T={K} observations, systematic resampling every observation",
+                   "particles_per_gpu": n, "observations": K, "latent_dim": d, "seed": 20260101},
+        "roofline": {"bound": "hbm", "kernel": "k_propagate<3,false>", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "algorithmic_bytes_per_launch": alg_bytes,
+                     "avg_launch_us": avg_s * 1e6, "launches": cnt},
+        "kernels_us": {k: (v[0] / max(v[1], 1)) * 1e3 for k, v in prof.items()},
+        "device_loop_ms": loop_ms, "ll": ll, "ess_last": int(ess_t[-1]),
+    }
+    if not args.no_cpu:
+        out["cpu_baseline"] = cpu_baseline(model, t, y, has)
+    pf.close()
+    print(json.dumps(out))
+
+
+def run_multi(args):
+    import torch
+    import torch.distributed as dist
+    from composablestatespacemodels_amd.sharded import DistComm, GpuShard, ShardedFilter
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", str(args.gpus)))
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29511")
+    torch.cuda.set_device(local)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+    K, W = args.steps, args.warmup
+    n_global = args.particles * world
+    model, t, y, has = build_workload(max(K, W, 8))
+    shard = GpuShard(model, n_global, rank, world, 20260101, local)
+    f = ShardedFilter([shard], DistComm())
+    f.init(0.0)
+    for s in range(W):
+        f.step(float(t[s]), float(y[s]), bool(has[s]))
+    f.init(0.0)
+    dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for s in range(K):
+        f.step(float(t[s]), float(y[s]), bool(has[s]))
+    torch.cuda.synchronize()
+    dist.barrier()
+    wall = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device="cuda")
+    dist.all_reduce(wall, op=dist.ReduceOp.MAX)
+    ll, ess = f.result()
+    if rank == 0:
+        w = float(wall.item())
+        print(json.dumps({
+            "metric": "particle-steps/sec (N x T) bootstrap filter", "value": n_global * K / w, "unit": "particle-steps/s",
+            "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": w * 1e3 / K, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "configs[1] sharded: seasonal-Poisson, OU latent (d=3), "
+                                   f"{args.particles} particles per GPU x {world} GPUs = {n_global}, T={K}, global systematic "
+                                   "resampling every observation (all-reduce max, all-gather sums, all-to-all-v particles over RCCL)",
+                       "particles_per_gpu": args.particles, "observations": K, "latent_dim": shard.d, "seed": 20260101},
+            "ll": ll, "ess_last": ess}))
+    dist.destroy_process_group()
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=500)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--particles", type=int, default=N_PER_GPU, help="particles per GPU")
+    ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    args = ap.parse_args()
+    if args.gpus > 1 or int(os.environ.get("WORLD_SIZE", "1")) > 1:
+        run_multi(args)
+    else:
+        run_single(args)
+
+
+if __name__ == "__main__":
+    main()

@@ -57,8 +57,10 @@ struct StepRec {
 };
 
 // Device scalars of a handle.
+#define CSSM_MAXSLOTS 64
+#define CSSM_SLOT_STRIDE 16 /* u64 words: one 128-byte line per slot */
 struct Scalars {
-  unsigned long long maxkey; // order key of the running max log-weight (atomicMax)
+  unsigned long long maxslot[CSSM_MAXSLOTS * CSSM_SLOT_STRIDE]; // sharded order keys of the running max log-weight
   uint32_t err;              // bit0: NaN log-weight, bit1: all weights zero / max not finite
   int32_t ess;
   double gmax;               // decoded global max of this step
@@ -191,9 +193,25 @@ __global__ void k_init_from(double* __restrict__ dst, size_t stride, uint64_t n,
 
 // ------------------------------------------------------------------------------------ propagate + weight
 
+// Particles per thread in k_propagate: all gathers of a thread are issued before its ALU work,
+// and rows are stored as 16-/32-byte vectors.
+template <int D> struct PropItems { static constexpr int value = (D <= 4) ? 4 : (D <= 8 ? 2 : 1); };
+
+// max over the CSSM_MAXSLOTS shards of the running max log-weight
+__device__ __forceinline__ double decode_slots(const Scalars* __restrict__ sc) {
+  unsigned long long k = 0ull;
+#pragma unroll 8
+  for (int s = 0; s < CSSM_MAXSLOTS; ++s) {
+    const unsigned long long v = sc->maxslot[s * CSSM_SLOT_STRIDE];
+    k = (v > k) ? v : k;
+  }
+  return cssm_order_unkey(k);
+}
+
 // stepFilter lines :118 and :123-124 fused (LGCP: calcWeight :184-208).  src is read through
-// anc[] when anc != nullptr (the previous step's resampling).
-template <int D, bool LGCP>
+// anc[] when anc != nullptr (the previous step's resampling).  A thread owns IT consecutive
+// particles; a block owns CSSM_BLOCK*IT consecutive particles per grid-stride iteration.
+template <int D, bool LGCP, int IT>
 __global__ __launch_bounds__(CSSM_BLOCK) void k_propagate(
     const double* __restrict__ src, size_t src_stride, const uint32_t* __restrict__ anc,
     double* __restrict__ dst, size_t dst_stride, double* __restrict__ logw, uint64_t n, uint64_t gid0,
@@ -202,42 +220,92 @@ __global__ __launch_bounds__(CSSM_BLOCK) void k_propagate(
   const uint32_t step = rec->step;
   const int has_obs = rec->has_obs;
   const double dt = rec->dt;
+  const bool weighted = LGCP || has_obs;
   double tmax = -cssm_inf();
   bool bad = false;
-  for (uint64_t i = (uint64_t)blockIdx.x * CSSM_BLOCK + threadIdx.x; i < n; i += (uint64_t)gridDim.x * CSSM_BLOCK) {
-    const size_t j = anc ? (size_t)anc[i] : (size_t)i;
-    double x[D], z[D];
-#pragma unroll
-    for (int k = 0; k < D; ++k) x[k] = src[(size_t)k * src_stride + j];
-    double lw;
-    if (LGCP) {
-      const int nsub = rec->n_sub;
-      if (nsub == 0) {                     // dt == 0: (x, f, f), model/ParticleFilter.scala:212-213
-        double g = gamma_of<D>(mk, rec, x);
-        lw = g - g;
+  const uint64_t per_block = (uint64_t)CSSM_BLOCK * IT;
+  for (uint64_t base = (uint64_t)blockIdx.x * per_block; base < n; base += (uint64_t)gridDim.x * per_block) {
+    const uint64_t i0 = base + (uint64_t)threadIdx.x * IT;
+    if (i0 >= n) continue;
+    const bool full = (i0 + IT <= n);
+    size_t j[IT];
+    if (anc) {
+      if (full && IT == 4) {
+        const uint4 a = *reinterpret_cast<const uint4*>(anc + i0);
+        j[0] = a.x; j[1 % IT] = a.y; j[2 % IT] = a.z; j[3 % IT] = a.w;
+      } else if (full && IT == 2) {
+        const uint2 a = *reinterpret_cast<const uint2*>(anc + i0);
+        j[0] = a.x; j[1 % IT] = a.y;
       } else {
-        double haz = 0.0;
-        for (int s = 0; s < nsub; ++s) {   // simInitStream(...).take(n), :193-194
-          draw_normals<D>(seed, gid0 + i, step, CSSM_STREAM_STEP, (uint32_t)s, z);
-          transition<D>(mk, rec, dt, x, z);
-          haz = haz + cssm_exp(gamma_of<D>(mk, rec, x)) * dt;   // :203-205
-        }
-        lw = gamma_of<D>(mk, rec, x) - haz;                   // :200,:217
+#pragma unroll
+        for (int r = 0; r < IT; ++r) j[r] = (i0 + r < n) ? (size_t)anc[i0 + r] : (size_t)anc[i0];
       }
     } else {
-      draw_normals<D>(seed, gid0 + i, step, CSSM_STREAM_STEP, 0u, z);
-      transition<D>(mk, rec, dt, x, z);
-      lw = has_obs ? logdens(mk, rec, gamma_of<D>(mk, rec, x)) : 0.0;
-    }
 #pragma unroll
-    for (int k = 0; k < D; ++k) dst[(size_t)k * dst_stride + i] = x[k];
-    if (LGCP || has_obs) {
-      if (lw != lw) { bad = true; lw = -cssm_inf(); }
-      logw[i] = lw;
-      tmax = (lw > tmax) ? lw : tmax;
+      for (int r = 0; r < IT; ++r) j[r] = (i0 + r < n) ? (size_t)(i0 + r) : (size_t)i0;
+    }
+    double x[IT][D];
+#pragma unroll
+    for (int r = 0; r < IT; ++r)
+#pragma unroll
+      for (int k = 0; k < D; ++k) x[r][k] = src[(size_t)k * src_stride + j[r]];
+    double lw[IT];
+#pragma unroll
+    for (int r = 0; r < IT; ++r) {
+      double z[D];
+      const uint64_t gid = gid0 + i0 + r;
+      if (LGCP) {
+        const int nsub = rec->n_sub;
+        if (nsub == 0) {                     // dt == 0: (x, f, f), model/ParticleFilter.scala:212-213
+          double g = gamma_of<D>(mk, rec, x[r]);
+          lw[r] = g - g;
+        } else {
+          double haz = 0.0;
+          for (int s = 0; s < nsub; ++s) {   // simInitStream(...).take(n), :193-194
+            draw_normals<D>(seed, gid, step, CSSM_STREAM_STEP, (uint32_t)s, z);
+            transition<D>(mk, rec, dt, x[r], z);
+            haz = haz + cssm_exp(gamma_of<D>(mk, rec, x[r])) * dt;   // :203-205
+          }
+          lw[r] = gamma_of<D>(mk, rec, x[r]) - haz;                // :200,:217
+        }
+      } else {
+        draw_normals<D>(seed, gid, step, CSSM_STREAM_STEP, 0u, z);
+        transition<D>(mk, rec, dt, x[r], z);
+        lw[r] = has_obs ? logdens(mk, rec, gamma_of<D>(mk, rec, x[r])) : 0.0;
+      }
+      if (weighted && i0 + r < n) {
+        if (lw[r] != lw[r]) { bad = true; lw[r] = -cssm_inf(); }
+        tmax = (lw[r] > tmax) ? lw[r] : tmax;
+      }
+    }
+    if (full && IT == 4) {
+#pragma unroll
+      for (int k = 0; k < D; ++k) {
+        double* p = dst + (size_t)k * dst_stride + i0;
+        *reinterpret_cast<double2*>(p) = make_double2(x[0][k], x[1 % IT][k]);
+        *reinterpret_cast<double2*>(p + 2) = make_double2(x[2 % IT][k], x[3 % IT][k]);
+      }
+      if (weighted) {
+        *reinterpret_cast<double2*>(logw + i0) = make_double2(lw[0], lw[1 % IT]);
+        *reinterpret_cast<double2*>(logw + i0 + 2) = make_double2(lw[2 % IT], lw[3 % IT]);
+      }
+    } else if (full && IT == 2) {
+#pragma unroll
+      for (int k = 0; k < D; ++k)
+        *reinterpret_cast<double2*>(dst + (size_t)k * dst_stride + i0) = make_double2(x[0][k], x[1 % IT][k]);
+      if (weighted) *reinterpret_cast<double2*>(logw + i0) = make_double2(lw[0], lw[1 % IT]);
+    } else {
+#pragma unroll
+      for (int r = 0; r < IT; ++r) {
+        if (i0 + r < n) {
+#pragma unroll
+          for (int k = 0; k < D; ++k) dst[(size_t)k * dst_stride + i0 + r] = x[r][k];
+          if (weighted) logw[i0 + r] = lw[r];
+        }
+      }
     }
   }
-  if (!(LGCP || has_obs)) return;
+  if (!weighted) return;
   tmax = wave_max(tmax);
   if ((threadIdx.x & 63) == 0) s_max[threadIdx.x >> 6] = tmax;
   if (__any(bad) && (threadIdx.x & 63) == 0) atomicOr(&sc->err, 1u);
@@ -246,14 +314,10 @@ __global__ __launch_bounds__(CSSM_BLOCK) void k_propagate(
     double m = s_max[0];
 #pragma unroll
     for (int w = 1; w < CSSM_BLOCK / 64; ++w) m = (s_max[w] > m) ? s_max[w] : m;
-    atomicMax(&sc->maxkey, (unsigned long long)cssm_order_key(m));
+    // one integer atomicMax per block, spread over CSSM_MAXSLOTS cache lines: same-address atomics
+    // serialise at ~12 ns each, which at thousands of blocks would cost more than the kernel
+    atomicMax(&sc->maxslot[(blockIdx.x % CSSM_MAXSLOTS) * CSSM_SLOT_STRIDE], (unsigned long long)cssm_order_key(m));
   }
-}
-
-// decode the global max once per step (single GPU); multi-GPU overwrites gmax after its all-reduce
-__global__ void k_decode_max(Scalars* sc) {
-  sc->gmax = cssm_order_unkey(sc->maxkey);
-  sc->maxkey = 0ull;
 }
 
 // ------------------------------------------------------------------------------------ tile sums
@@ -280,9 +344,9 @@ __device__ __forceinline__ void load_tile_weights(const double* __restrict__ log
 __global__ __launch_bounds__(CSSM_BLOCK) void k_tile_sums(const double* __restrict__ logw, uint64_t n,
                                                           const Scalars* __restrict__ sc,
                                                           cssm_u128* __restrict__ tileS, cssm_u128* __restrict__ tileS2,
-                                                          uint32_t ntiles, int raw) {
+                                                          uint32_t ntiles, int raw, int from_slots) {
   __shared__ cssm_u128 s_a[CSSM_BLOCK / 64], s_b[CSSM_BLOCK / 64];
-  const double gmax = sc->gmax;
+  const double gmax = from_slots ? decode_slots(sc) : sc->gmax;
   for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     double w1[CSSM_ITEMS];
     load_tile_weights(logw, (uint64_t)tile * CSSM_TILE, n, gmax, raw, w1);
@@ -323,11 +387,17 @@ __device__ void finish_step(Scalars* sc, uint64_t n_global) {
 // Exclusive scan of the tile sums in one block; local totals; with world == 1 also the step's ll/ess.
 __global__ __launch_bounds__(1024) void k_scan_tiles(const cssm_u128* __restrict__ tileS, const cssm_u128* __restrict__ tileS2,
                                                      cssm_u128* __restrict__ tileP, uint32_t ntiles, Scalars* sc,
-                                                     uint64_t n_global, int single) {
+                                                     uint64_t n_global, int single, int from_slots,
+                                                     double* __restrict__ ll_t, int32_t* __restrict__ ess_t, uint32_t rec_idx) {
   __shared__ cssm_u128 s_w[16], s_w2[16];
   __shared__ cssm_u128 s_carry, s_carry2;
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   if (threadIdx.x == 0) { s_carry = cssm_u128_zero(); s_carry2 = cssm_u128_zero(); }
+  if (from_slots) {   // every k_tile_sums block has decoded the slots already (previous kernel): publish and reset
+    if (threadIdx.x == 0) sc->gmax = decode_slots(sc);
+    __syncthreads();
+    if (threadIdx.x < CSSM_MAXSLOTS) sc->maxslot[threadIdx.x * CSSM_SLOT_STRIDE] = 0ull;
+  }
   __syncthreads();
   for (uint32_t base = 0; base < ntiles; base += 1024) {
     const uint32_t t = base + threadIdx.x;
@@ -360,6 +430,7 @@ __global__ __launch_bounds__(1024) void k_scan_tiles(const cssm_u128* __restrict
       sc->S_off = cssm_u128_zero();
       sc->S_tot = s_carry; sc->S2_tot = s_carry2;
       finish_step(sc, n_global);
+      if (ll_t) { ll_t[rec_idx] = sc->ll; ess_t[rec_idx] = sc->ess; }
     }
   }
 }

@@ -36,6 +36,8 @@ extern "C" const char* cssm_version(void) { return "cssm_pf 0.1 (gfx950, numeric
 
 // ------------------------------------------------------------------------------------ handle
 
+#define CSSM_NKERNELS CSSM_PROFILE_NKERNELS
+
 struct Comp {
   int kind, leaf, idx, f_kind, period;
   double m0, c0, mu, phi, sigma;
@@ -87,7 +89,43 @@ struct cssm_pf {
   bool initialised = false;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   float last_ms = 0.f;
+  // optional per-kernel timing (HIP events on the launch stream around every kernel)
+  bool profile = false;
+  std::vector<hipEvent_t> prof_ev;         // pairs
+  std::vector<int> prof_kind;              // kernel kind of pair i
+  size_t prof_used = 0;
+  double prof_ms[CSSM_NKERNELS] = {0};
+  uint64_t prof_cnt[CSSM_NKERNELS] = {0};
 };
+
+// begin/end of one profiled launch
+static inline void prof_begin(cssm_pf* pf, int kind) {
+  if (!pf->profile) return;
+  if (pf->prof_used * 2 + 2 > pf->prof_ev.size()) {
+    hipEvent_t a, b;
+    if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) { pf->profile = false; return; }
+    pf->prof_ev.push_back(a); pf->prof_ev.push_back(b);
+  }
+  if (pf->prof_kind.size() <= pf->prof_used) pf->prof_kind.resize(pf->prof_used + 1);
+  pf->prof_kind[pf->prof_used] = kind;
+  (void)hipEventRecord(pf->prof_ev[pf->prof_used * 2], pf->stream);
+}
+static inline void prof_end(cssm_pf* pf) {
+  if (!pf->profile) return;
+  (void)hipEventRecord(pf->prof_ev[pf->prof_used * 2 + 1], pf->stream);
+  pf->prof_used++;
+}
+// after a stream synchronise: fold the recorded pairs into per-kind totals
+static void prof_collect(cssm_pf* pf) {
+  for (size_t i = 0; i < pf->prof_used; ++i) {
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, pf->prof_ev[2 * i], pf->prof_ev[2 * i + 1]) == hipSuccess) {
+      pf->prof_ms[pf->prof_kind[i]] += ms;
+      pf->prof_cnt[pf->prof_kind[i]]++;
+    }
+  }
+  pf->prof_used = 0;
+}
 
 static inline int grid_for(uint64_t n, int block, int cap) {
   uint64_t g = (n + block - 1) / block;
@@ -276,7 +314,7 @@ static int create_common(const cssm_model_desc* desc, uint64_t n_global, uint64_
   cssm_pf* pf = new cssm_pf();
   pf->device = device;
   pf->n_global = n_global; pf->first = first; pf->n = n_local; pf->seed = seed; pf->sharded = sharded;
-  if (stream) { pf->stream = (hipStream_t)stream; pf->own_stream = false; }
+  if (sharded) { pf->stream = (hipStream_t)stream; pf->own_stream = false; }  // a null handle is the legacy default stream (torch's default)
   int rc = build_model(pf, desc);
   if (rc == CSSM_OK) rc = alloc_handle(pf);
   if (rc != CSSM_OK) { std::string keep = g_err; cssm_pf_destroy(pf); g_err = keep; return rc; }
@@ -301,6 +339,7 @@ extern "C" void cssm_pf_destroy(cssm_pf* pf) {
                   pf->d_m0, pf->d_sd0, pf->d_recs, pf->d_ll_t, pf->d_ess_t, pf->d_path, pf->cand, pf->cand_end, pf->d_bounds};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   if (pf->h_recs) (void)hipHostFree(pf->h_recs);
+  for (hipEvent_t e : pf->prof_ev) (void)hipEventDestroy(e);
   if (pf->ev0) (void)hipEventDestroy(pf->ev0);
   if (pf->ev1) (void)hipEventDestroy(pf->ev1);
   if (pf->own_stream && pf->stream) (void)hipStreamDestroy(pf->stream);
@@ -339,6 +378,7 @@ extern "C" int32_t cssm_pf_dim(const cssm_pf* pf) { return pf ? pf->d : 0; }
   }
 
 static const int kGridCap = 4096;
+static const int kPropGridCap = 2048;   // 8 blocks of 256 threads per CU; the rest is grid-strided
 
 // ll = 0.0, ess = N: PfState(t0, None, state, 0.0, particles), model/ParticleFilter.scala:107
 static int reset_scalars(cssm_pf* pf) {
@@ -364,17 +404,21 @@ static int launch_init(cssm_pf* pf, double t0) {
 }
 
 // propagate + weight of one datum (record already on the device)
+static int prop_items(int d) { return d <= 4 ? 4 : (d <= 8 ? 2 : 1); }   // PropItems<D>
+
 static int launch_propagate(cssm_pf* pf, const StepRec* d_rec) {
-  const int grid = grid_for(pf->n, CSSM_BLOCK, kGridCap);
+  const int grid = grid_for(pf->n, CSSM_BLOCK * prop_items(pf->d), kPropGridCap);
   double* dst = pf->state[pf->cur ^ 1];
   const uint32_t* anc = pf->anc_valid ? pf->anc : nullptr;
+  prof_begin(pf, CSSM_K_PROPAGATE);
   if (pf->obs_kind == CSSM_OBS_LGCP) {
-    DISPATCH_D(pf->d, k_propagate<D, true><<<dim3(grid), dim3(CSSM_BLOCK), 0, pf->stream>>>(
+    DISPATCH_D(pf->d, k_propagate<D, true, PropItems<D>::value><<<dim3(grid), dim3(CSSM_BLOCK), 0, pf->stream>>>(
                           pf->src, pf->src_stride, anc, dst, pf->stride, pf->logw, pf->n, pf->first, pf->seed, d_rec, pf->mk, pf->sc));
   } else {
-    DISPATCH_D(pf->d, k_propagate<D, false><<<dim3(grid), dim3(CSSM_BLOCK), 0, pf->stream>>>(
+    DISPATCH_D(pf->d, k_propagate<D, false, PropItems<D>::value><<<dim3(grid), dim3(CSSM_BLOCK), 0, pf->stream>>>(
                           pf->src, pf->src_stride, anc, dst, pf->stride, pf->logw, pf->n, pf->first, pf->seed, d_rec, pf->mk, pf->sc));
   }
+  prof_end(pf);
   HIP_TRY(hipGetLastError());
   pf->cur ^= 1;
   pf->src = pf->state[pf->cur]; pf->src_stride = pf->stride; pf->anc_valid = false;
@@ -382,23 +426,32 @@ static int launch_propagate(cssm_pf* pf, const StepRec* d_rec) {
 }
 
 // weights -> sums -> end slots -> ancestors, single GPU
-static int launch_resample(cssm_pf* pf, const StepRec* d_rec) {
+static int launch_resample(cssm_pf* pf, const StepRec* d_rec, double* ll_t = nullptr, int32_t* ess_t = nullptr, uint32_t rec_idx = 0) {
   const int tgrid = grid_for(pf->ntiles, 1, kGridCap);
-  hipLaunchKernelGGL(k_decode_max, dim3(1), dim3(1), 0, pf->stream, pf->sc);
-  hipLaunchKernelGGL(k_tile_sums, dim3(tgrid), dim3(CSSM_BLOCK), 0, pf->stream, pf->logw, pf->n, pf->sc, pf->tileS, pf->tileS2, pf->ntiles, 0);
-  hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(1024), 0, pf->stream, pf->tileS, pf->tileS2, pf->tileP, pf->ntiles, pf->sc, pf->n_global, 1);
+  prof_begin(pf, CSSM_K_TILE_SUMS);
+  hipLaunchKernelGGL(k_tile_sums, dim3(tgrid), dim3(CSSM_BLOCK), 0, pf->stream, pf->logw, pf->n, pf->sc, pf->tileS, pf->tileS2, pf->ntiles, 0, 1);
+  prof_end(pf);
+  prof_begin(pf, CSSM_K_SCAN_TILES);
+  hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(1024), 0, pf->stream, pf->tileS, pf->tileS2, pf->tileP, pf->ntiles, pf->sc, pf->n_global, 1, 1,
+                     ll_t, ess_t, rec_idx);
+  prof_end(pf);
+  prof_begin(pf, CSSM_K_OFFSPRING);
   hipLaunchKernelGGL(k_offspring, dim3(tgrid), dim3(CSSM_BLOCK), 0, pf->stream, pf->logw, pf->n, pf->sc, pf->tileP, d_rec, pf->n_global,
                      pf->endslot, pf->ntiles, 0);
+  prof_end(pf);
+  prof_begin(pf, CSSM_K_EXPAND);
   hipLaunchKernelGGL(k_expand, dim3(tgrid), dim3(CSSM_BLOCK), 0, pf->stream, pf->endslot, pf->n, (uint64_t)0, pf->n, pf->anc, pf->ntiles);
+  prof_end(pf);
   HIP_TRY(hipGetLastError());
   pf->anc_valid = true;
   return CSSM_OK;
 }
 
-static int launch_step(cssm_pf* pf, const StepRec* d_rec, int weighted) {
+static int launch_step(cssm_pf* pf, const StepRec* d_rec, int weighted, double* ll_t = nullptr, int32_t* ess_t = nullptr, uint32_t rec_idx = 0) {
   int rc = launch_propagate(pf, d_rec);
   if (rc) return rc;
-  if (weighted) rc = launch_resample(pf, d_rec);
+  if (weighted) rc = launch_resample(pf, d_rec, ll_t, ess_t, rec_idx);
+  else if (ll_t) hipLaunchKernelGGL(k_record, dim3(1), dim3(1), 0, pf->stream, pf->sc, ll_t, ess_t, rec_idx);
   return rc;
 }
 
@@ -412,6 +465,7 @@ static int check_device_err(cssm_pf* pf, const Scalars& h) {
 // ------------------------------------------------------------------------------------ streaming API
 
 static int ensure_recs(cssm_pf* pf, size_t T) {
+  if (T < 1024) T = 1024;   // one allocation serves every ordinary series length
   if (pf->h_recs_cap < T) {
     if (pf->h_recs) (void)hipHostFree(pf->h_recs);
     pf->h_recs = nullptr;
@@ -509,9 +563,8 @@ static int run_filter(cssm_pf* pf, const double* t, const double* y, const uint8
   HIP_TRY(hipEventRecord(pf->ev0, pf->stream));
   for (size_t s = 0; s < T; ++s) {
     const int weighted = pf->h_recs[s].has_obs;
-    rc = launch_step(pf, pf->d_recs + s, weighted);
+    rc = launch_step(pf, pf->d_recs + s, weighted, pf->d_ll_t, pf->d_ess_t, (uint32_t)s);
     if (rc) return rc;
-    hipLaunchKernelGGL(k_record, dim3(1), dim3(1), 0, pf->stream, pf->sc, pf->d_ll_t, pf->d_ess_t, (uint32_t)s);
     if (path)
       hipLaunchKernelGGL(k_pick, dim3(1), dim3(64), 0, pf->stream, pf->src, pf->src_stride,
                          (const uint32_t*)(pf->anc_valid ? pf->anc : nullptr), (uint64_t)pf->h_recs[s].pick, d,
@@ -526,6 +579,7 @@ static int run_filter(cssm_pf* pf, const double* t, const double* y, const uint8
   if (path) HIP_TRY(hipMemcpyAsync(path, pf->d_path, (T + 1) * (size_t)d * 8, hipMemcpyDeviceToHost, pf->stream));
   HIP_TRY(hipStreamSynchronize(pf->stream));
   HIP_TRY(hipEventElapsedTime(&pf->last_ms, pf->ev0, pf->ev1));
+  prof_collect(pf);
   pf->t = t[T - 1]; pf->step = (uint32_t)T;
   if (ll_out) *ll_out = h.ll;
   return check_device_err(pf, h);
@@ -545,6 +599,20 @@ extern "C" int cssm_pf_filter(cssm_pf* pf, const double* t, const double* y, con
 extern "C" int cssm_pf_last_loop_ms(cssm_pf* pf, float* ms_out) {
   if (!pf || !ms_out) return fail(CSSM_EINVAL_ARG, "null argument");
   *ms_out = pf->last_ms;
+  return CSSM_OK;
+}
+
+extern "C" int cssm_pf_profile(cssm_pf* pf, int enable) {
+  if (!pf) return fail(CSSM_EINVAL_ARG, "null handle");
+  pf->profile = enable != 0;
+  pf->prof_used = 0;
+  for (int k = 0; k < CSSM_NKERNELS; ++k) { pf->prof_ms[k] = 0.0; pf->prof_cnt[k] = 0; }
+  return CSSM_OK;
+}
+
+extern "C" int cssm_pf_profile_read(cssm_pf* pf, double* total_ms, uint64_t* launches) {
+  if (!pf || !total_ms || !launches) return fail(CSSM_EINVAL_ARG, "null argument");
+  for (int k = 0; k < CSSM_NKERNELS; ++k) { total_ms[k] = pf->prof_ms[k]; launches[k] = pf->prof_cnt[k]; }
   return CSSM_OK;
 }
 
@@ -618,8 +686,8 @@ extern "C" int cssm_resample_systematic(const double* w, size_t n, double u, uin
   RS_TRY(hipMemcpyAsync(d_rec, &hrec, sizeof hrec, hipMemcpyHostToDevice, st));
   {
     const int tgrid = grid_for(ntiles, 1, kGridCap);
-    hipLaunchKernelGGL(k_tile_sums, dim3(tgrid), dim3(CSSM_BLOCK), 0, st, d_w, (uint64_t)n, sc, tS, tS2, ntiles, 1);
-    hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(1024), 0, st, tS, tS2, tP, ntiles, sc, (uint64_t)n, 1);
+    hipLaunchKernelGGL(k_tile_sums, dim3(tgrid), dim3(CSSM_BLOCK), 0, st, d_w, (uint64_t)n, sc, tS, tS2, ntiles, 1, 0);
+    hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(1024), 0, st, tS, tS2, tP, ntiles, sc, (uint64_t)n, 1, 0, (double*)nullptr, (int32_t*)nullptr, 0u);
     hipLaunchKernelGGL(k_offspring, dim3(tgrid), dim3(CSSM_BLOCK), 0, st, d_w, (uint64_t)n, sc, tP, d_rec, (uint64_t)n, d_end, ntiles, 1);
     hipLaunchKernelGGL(k_expand, dim3(tgrid), dim3(CSSM_BLOCK), 0, st, d_end, (uint64_t)n, (uint64_t)0, (uint64_t)n, d_anc, ntiles);
   }
@@ -640,10 +708,12 @@ done:
 // One process per GPU; the collectives between the stages belong to the caller (RCCL through
 // torch.distributed).  See include/cssm_pf.h for the sequence.
 
-__global__ void k_export_max(Scalars* sc, double* out) {
-  const double m = cssm_order_unkey(sc->maxkey);
-  sc->maxkey = 0ull;
-  *out = m;
+__global__ void k_export_max(Scalars* sc, double* out) {   // <<<1, CSSM_MAXSLOTS>>>
+  __shared__ double s_m;
+  if (threadIdx.x == 0) s_m = decode_slots(sc);
+  __syncthreads();
+  sc->maxslot[threadIdx.x * CSSM_SLOT_STRIDE] = 0ull;
+  if (threadIdx.x == 0) *out = s_m;
 }
 __global__ void k_import_max(Scalars* sc, const double* gm) { sc->gmax = *gm; }
 __global__ void k_export_sums(const Scalars* sc, unsigned long long* out4) {
@@ -722,7 +792,7 @@ extern "C" int cssm_pf_shard_propagate(cssm_pf* pf, double t, double obs, int ha
   if (rc) return rc;
   if (pf->h_recs[slot].has_obs) {
     if (!local_max_dev) return fail(CSSM_EINVAL_ARG, "local_max_dev is null");
-    hipLaunchKernelGGL(k_export_max, dim3(1), dim3(1), 0, pf->stream, pf->sc, local_max_dev);
+    hipLaunchKernelGGL(k_export_max, dim3(1), dim3(CSSM_MAXSLOTS), 0, pf->stream, pf->sc, local_max_dev);
     HIP_TRY(hipGetLastError());
   }
   pf->t = t;
@@ -736,8 +806,9 @@ extern "C" int cssm_pf_shard_sums(cssm_pf* pf, const double* global_max_dev, uin
   if (!global_max_dev || !sums4_dev) return fail(CSSM_EINVAL_ARG, "null argument");
   const int tgrid = grid_for(pf->ntiles, 1, kGridCap);
   hipLaunchKernelGGL(k_import_max, dim3(1), dim3(1), 0, pf->stream, pf->sc, global_max_dev);
-  hipLaunchKernelGGL(k_tile_sums, dim3(tgrid), dim3(CSSM_BLOCK), 0, pf->stream, pf->logw, pf->n, pf->sc, pf->tileS, pf->tileS2, pf->ntiles, 0);
-  hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(1024), 0, pf->stream, pf->tileS, pf->tileS2, pf->tileP, pf->ntiles, pf->sc, pf->n_global, 0);
+  hipLaunchKernelGGL(k_tile_sums, dim3(tgrid), dim3(CSSM_BLOCK), 0, pf->stream, pf->logw, pf->n, pf->sc, pf->tileS, pf->tileS2, pf->ntiles, 0, 0);
+  hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(1024), 0, pf->stream, pf->tileS, pf->tileS2, pf->tileP, pf->ntiles, pf->sc, pf->n_global, 0, 0,
+                     (double*)nullptr, (int32_t*)nullptr, 0u);
   hipLaunchKernelGGL(k_export_sums, dim3(1), dim3(1), 0, pf->stream, pf->sc, (unsigned long long*)sums4_dev);
   HIP_TRY(hipGetLastError());
   return CSSM_OK;

@@ -114,6 +114,18 @@ class NativePf:
         _abi.check(self.lib.cssm_pf_last_loop_ms(self._h, C.byref(ms)))
         return ms.value
 
+    KERNELS = ("k_propagate", "k_decode_max", "k_tile_sums", "k_scan_tiles", "k_offspring", "k_expand")
+
+    def profile(self, enable: bool):
+        _abi.check(self.lib.cssm_pf_profile(self._h, 1 if enable else 0))
+
+    def profile_read(self):
+        """{kernel: (total_ms, launches)} accumulated since profile(True)."""
+        ms = np.zeros(len(self.KERNELS))
+        cnt = np.zeros(len(self.KERNELS), dtype=np.uint64)
+        _abi.check(self.lib.cssm_pf_profile_read(self._h, _p(ms), _p(cnt, C.POINTER(C.c_uint64))))
+        return {k: (float(ms[i]), int(cnt[i])) for i, k in enumerate(self.KERNELS)}
+
     def particles(self) -> np.ndarray:
         out = np.zeros((self.d, self.n))
         _abi.check(self.lib.cssm_pf_get_particles(self._h, _p(out)))

@@ -1,0 +1,241 @@
+"""Particle filter sharded over the GPUs of one node: one process per GPU, particles split into
+contiguous global ranges, collectives over RCCL (``torch.distributed`` backend "nccl" on ROCm).
+
+Per observation (stage calls of include/cssm_pf.h):
+
+1. ``shard_propagate``  fused propagate + weight on the local shard, local max log-weight
+2. all-reduce MAX of one double                                   (exact, order independent)
+3. ``shard_sums``       local fixed-point sums of exp(w - gmax): 4 x u64
+4. all-gather of 4 x u64 per rank                                 (integers: no rounding)
+5. ``shard_offspring``  global cumulative weights -> end slot of every local particle, ll, ess,
+   and for each destination rank the contiguous range of local particles owning its slots
+6. all-to-all of the range sizes, then all-to-all-v of (d + 1) doubles per candidate particle
+7. ``shard_adopt``      expand the received candidates to this rank's slots
+
+Random variates are keyed by the GLOBAL particle id and every sum is an integer sum, so ll, ess
+and the ancestor arrays are bit-identical for 1, 2, 4 and 8 ranks.
+
+The orchestration is written over a list of local shards and a communicator object so that the
+same code drives (a) one shard per process over RCCL or gloo (``DistComm``) and (b) several
+shards inside one process with the exchanges done by tensor copies (``LocalComm``: how the stage
+kernels are tested for world > 1 on a single GPU).
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import List, Optional, Sequence
+
+import numpy as np
+import torch
+
+from . import _abi
+from .model import Model
+
+
+def shard_bounds(n_global: int, world: int, rank: int):
+    """Rank r owns global particles / slots [r*ceil(N/R), min((r+1)*ceil(N/R), N))."""
+    per = (n_global + world - 1) // world
+    lo = min(rank * per, n_global)
+    hi = min(lo + per, n_global)
+    return lo, hi - lo
+
+
+class GpuShard:
+    """One shard on one GPU, driven through the cssm_pf_shard_* stage calls."""
+
+    def __init__(self, model: Model, n_global: int, rank: int, world: int, seed: int, device: int,
+                 lgcp_precision: int = 0):
+        self.lib = _abi.load_library()
+        self.rank, self.world = rank, world
+        self.first, self.n = shard_bounds(n_global, world, rank)
+        if self.n < 1:
+            raise ValueError("every rank needs at least one particle")
+        self.n_global = n_global
+        self.dev = torch.device("cuda", device)
+        torch.cuda.set_device(self.dev)
+        self._desc = model.descriptor(lgcp_precision)
+        self._h = C.c_void_p()
+        stream = torch.cuda.current_stream(self.dev).cuda_stream
+        _abi.check(self.lib.cssm_pf_create_shard(self._desc.ptr(), n_global, self.first, self.n, seed & (2**64 - 1),
+                                                 device, C.c_void_p(stream), C.byref(self._h)))
+        self.d = int(self.lib.cssm_pf_dim(self._h))
+        kw = dict(device=self.dev)
+        self.local_max = torch.zeros(1, dtype=torch.float64, **kw)
+        self.sums4 = torch.zeros(4, dtype=torch.int64, **kw)
+        self.all_sums = torch.zeros(4 * world, dtype=torch.int64, **kw)
+        self.send_first = torch.zeros(world, dtype=torch.int64, **kw)
+        self.send_count = torch.zeros(world, dtype=torch.int64, **kw)
+        self.recv_count = torch.zeros(world, dtype=torch.int64, **kw)
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            self.lib.cssm_pf_destroy(self._h)
+            self._h = C.c_void_p()
+
+    __del__ = close
+
+    def new_buffer(self, n_doubles: int) -> torch.Tensor:
+        return torch.empty(max(n_doubles, 1), dtype=torch.float64, device=self.dev)
+
+    def init(self, t0: float):
+        _abi.check(self.lib.cssm_pf_shard_init(self._h, float(t0)))
+
+    def propagate(self, t, y, has_obs):
+        _abi.check(self.lib.cssm_pf_shard_propagate(self._h, float(t), float(y), int(has_obs),
+                                                    C.c_void_p(self.local_max.data_ptr())))
+
+    def sums(self):
+        _abi.check(self.lib.cssm_pf_shard_sums(self._h, C.c_void_p(self.local_max.data_ptr()),
+                                               C.c_void_p(self.sums4.data_ptr())))
+
+    def offspring(self):
+        _abi.check(self.lib.cssm_pf_shard_offspring(self._h, C.c_void_p(self.all_sums.data_ptr()), self.rank, self.world,
+                                                    C.c_void_p(self.send_first.data_ptr()),
+                                                    C.c_void_p(self.send_count.data_ptr())))
+
+    def pack(self, first_host: np.ndarray, count_host: np.ndarray, send_buf: torch.Tensor):
+        f = np.ascontiguousarray(first_host, dtype=np.int64)
+        c = np.ascontiguousarray(count_host, dtype=np.int64)
+        _abi.check(self.lib.cssm_pf_shard_pack(self._h, self.world, f.ctypes.data_as(C.POINTER(C.c_int64)),
+                                               c.ctypes.data_as(C.POINTER(C.c_int64)), C.c_void_p(send_buf.data_ptr())))
+
+    def adopt(self, recv_buf: torch.Tensor, n_recv: int):
+        self._recv_keepalive = recv_buf
+        _abi.check(self.lib.cssm_pf_shard_adopt(self._h, C.c_void_p(recv_buf.data_ptr()), int(n_recv)))
+
+    def result(self):
+        ll, ess = C.c_double(), C.c_int32()
+        _abi.check(self.lib.cssm_pf_shard_result(self._h, C.byref(ll), C.byref(ess)))
+        return ll.value, ess.value
+
+    def particles(self) -> np.ndarray:
+        out = np.zeros((self.d, self.n))
+        _abi.check(self.lib.cssm_pf_get_particles(self._h, out.ctypes.data_as(C.POINTER(C.c_double))))
+        return out
+
+    def ancestors_local(self) -> np.ndarray:
+        out = np.zeros(self.n, dtype=np.uint32)
+        _abi.check(self.lib.cssm_pf_get_ancestors(self._h, out.ctypes.data_as(C.POINTER(C.c_uint32))))
+        return out
+
+
+class DistComm:
+    """One shard per process; collectives through torch.distributed (RCCL on GPUs, gloo on CPU)."""
+
+    def __init__(self, group=None):
+        import torch.distributed as dist
+        self.dist = dist
+        self.group = group
+        self.world = dist.get_world_size(group)
+        self.rank = dist.get_rank(group)
+
+    def all_reduce_max(self, xs: List[torch.Tensor]):
+        self.dist.all_reduce(xs[0], op=self.dist.ReduceOp.MAX, group=self.group)
+
+    def all_gather(self, outs: List[torch.Tensor], ins: List[torch.Tensor]):
+        self.dist.all_gather_into_tensor(outs[0], ins[0], group=self.group)
+
+    def all_to_all_counts(self, outs: List[torch.Tensor], ins: List[torch.Tensor]):
+        self.dist.all_to_all_single(outs[0], ins[0], group=self.group)
+
+    def all_to_all_v(self, outs, ins, out_splits, in_splits):
+        self.dist.all_to_all_single(outs[0], ins[0], output_split_sizes=out_splits[0], input_split_sizes=in_splits[0],
+                                    group=self.group)
+
+    def barrier(self):
+        self.dist.barrier(group=self.group)
+
+
+class LocalComm:
+    """All R shards live in this process; the "collectives" are tensor copies.  Test vehicle for the
+    stage kernels at world > 1 on a single GPU -- not a performance path."""
+
+    def __init__(self, world: int):
+        self.world, self.rank = world, 0
+
+    def all_reduce_max(self, xs):
+        m = torch.stack([x.reshape(-1)[0] for x in xs]).max()
+        for x in xs:
+            x.fill_(m)
+
+    def all_gather(self, outs, ins):
+        cat = torch.cat([i.reshape(-1) for i in ins])
+        for o in outs:
+            o.copy_(cat)
+
+    def all_to_all_counts(self, outs, ins):
+        for q, o in enumerate(outs):
+            for r, i in enumerate(ins):
+                o[r] = i[q]
+
+    def all_to_all_v(self, outs, ins, out_splits, in_splits):
+        R = self.world
+        in_off = [np.concatenate([[0], np.cumsum(in_splits[r])]) for r in range(R)]
+        for q in range(R):
+            pos = 0
+            for r in range(R):
+                n = int(in_splits[r][q])
+                assert n == int(out_splits[q][r])
+                if n:
+                    outs[q][pos:pos + n].copy_(ins[r][int(in_off[r][q]):int(in_off[r][q]) + n])
+                pos += n
+
+    def barrier(self):
+        pass
+
+
+class ShardedFilter:
+    """llFilter over sharded particles (ParticleFilter.scala:137-140 on R GPUs).
+
+    ``shards``: the local shards (one under DistComm, R under LocalComm).
+    """
+
+    def __init__(self, shards: Sequence, comm):
+        self.shards = list(shards)
+        self.comm = comm
+        self.d = self.shards[0].d
+
+    def init(self, t0: float):
+        for s in self.shards:
+            s.init(t0)
+
+    def step(self, t: float, y: Optional[float], has_obs: bool = True, lgcp: bool = False):
+        S, comm, d = self.shards, self.comm, self.d
+        yv = 0.0 if y is None else y
+        for s in S:
+            s.propagate(t, yv, 1 if has_obs else 0)
+        if not (has_obs or lgcp):
+            return
+        comm.all_reduce_max([s.local_max for s in S])
+        for s in S:
+            s.sums()
+        comm.all_gather([s.all_sums for s in S], [s.sums4 for s in S])
+        for s in S:
+            s.offspring()
+        comm.all_to_all_counts([s.recv_count for s in S], [s.send_count for s in S])
+        # the one host read of the step: the exchange sizes
+        firsts = [s.send_first.cpu().numpy() for s in S]
+        scount = [s.send_count.cpu().numpy() for s in S]
+        rcount = [s.recv_count.cpu().numpy() for s in S]
+        row = d + 1
+        send_bufs = [s.new_buffer(int(c.sum()) * row) for s, c in zip(S, scount)]
+        recv_bufs = [s.new_buffer(int(c.sum()) * row) for s, c in zip(S, rcount)]
+        for s, f, c, b in zip(S, firsts, scount, send_bufs):
+            s.pack(f, c, b)
+        comm.all_to_all_v([b[: int(c.sum()) * row] for b, c in zip(recv_bufs, rcount)],
+                          [b[: int(c.sum()) * row] for b, c in zip(send_bufs, scount)],
+                          [[int(v) * row for v in c] for c in rcount], [[int(v) * row for v in c] for c in scount])
+        for s, b, c in zip(S, recv_bufs, rcount):
+            s.adopt(b, int(c.sum()))
+
+    def ll_filter(self, t, y, has=None, lgcp: bool = False):
+        t = np.asarray(t, dtype=np.float64)
+        y = np.asarray(y, dtype=np.float64)
+        self.init(float(t.min()))
+        for s in range(len(t)):
+            self.step(float(t[s]), float(y[s]), bool(has[s]) if has is not None else True, lgcp)
+        return self.result()
+
+    def result(self):
+        res = [s.result() for s in self.shards]
+        return res[0]

@@ -162,6 +162,20 @@ int cssm_pf_filter(cssm_pf* pf, const double* t, const double* y, const uint8_t*
  * handle's stream around the T steps, init excluded), in milliseconds. */
 int cssm_pf_last_loop_ms(cssm_pf* pf, float* ms_out);
 
+/* Per-kernel device time, measured with HIP events recorded on the handle's stream directly
+ * before and after every kernel launch of the batch loop (bench.py's `roofline` figure).
+ * Enabling it inserts event records between kernels, so whole-loop throughput is measured with
+ * profiling OFF.  total_ms / launches have CSSM_PROFILE_NKERNELS entries, indexed by CSSM_K_*. */
+#define CSSM_K_PROPAGATE 0   /* fused gather + propagate + weight + block max */
+#define CSSM_K_DECODE_MAX 1
+#define CSSM_K_TILE_SUMS 2   /* exp(w - max), fixed-point tile sums */
+#define CSSM_K_SCAN_TILES 3  /* scan of tile sums, ll, ess */
+#define CSSM_K_OFFSPRING 4   /* cumulative weights -> end slots */
+#define CSSM_K_EXPAND 5      /* end slots -> ancestor indices */
+#define CSSM_PROFILE_NKERNELS 6
+int cssm_pf_profile(cssm_pf* pf, int enable);
+int cssm_pf_profile_read(cssm_pf* pf, double* total_ms, uint64_t* launches);
+
 /* ---- inspection (parity tests, `PfState.particles` on demand) ------------------------------ */
 
 uint64_t cssm_pf_num_particles(const cssm_pf* pf); /* local particle count */

@@ -71,6 +71,7 @@ struct oracle_pf {
   double scale_sd;       /* Gaussian: exp(scale)  model/Model.scala:244,211 */
   ocomp comp[CSSM_MAX_DIM];
   uint64_t n, seed;
+  uint64_t first, n_global; /* shard of a larger filter: global id of particle 0, global particle count */
   double t, ll;
   int32_t ess;
   uint32_t step;         /* observation index of the NEXT datum */
@@ -167,7 +168,7 @@ int oracle_pf_create(const cssm_model_desc* desc, uint64_t n, uint64_t seed, int
   if (!out || n < 1 || n >= 0xffffffffULL) return ORACLE_EINVAL;
   oracle_pf* pf = (oracle_pf*)calloc(1, sizeof *pf);
   if (!pf) return ORACLE_EINVAL;
-  pf->flags = flags; pf->n = n; pf->seed = seed;
+  pf->flags = flags; pf->n = n; pf->seed = seed; pf->first = 0; pf->n_global = n;
   int rc = build_components(pf, desc);
   if (rc) { free(pf); return rc; }
   size_t nd = (size_t)n * pf->d;
@@ -222,7 +223,7 @@ static void draw_normals(const oracle_pf* pf, uint64_t gid, uint32_t step, uint3
 int oracle_pf_init(oracle_pf* pf, double t0) {
   double z[CSSM_MAX_DIM];
   for (uint64_t i = 0; i < pf->n; ++i) {
-    draw_normals(pf, i, 0, CSSM_STREAM_INIT, 0, z);
+    draw_normals(pf, pf->first + i, 0, CSSM_STREAM_INIT, 0, z);
     for (int k = 0; k < pf->d; ++k) pf->x[i * pf->d + k] = sqrt(pf->comp[k].c0) * z[k] + pf->comp[k].m0;
   }
   memcpy(pf->x1, pf->x, (size_t)pf->n * pf->d * 8);
@@ -419,7 +420,7 @@ static int step_generic(oracle_pf* pf, double t, double y, int has_obs) {
   int d = pf->d;
   double dt = t - pf->t;                                        /* :117 */
   for (uint64_t i = 0; i < pf->n; ++i) {                        /* :118 */
-    draw_normals(pf, i, pf->step, CSSM_STREAM_STEP, 0, z);
+    draw_normals(pf, pf->first + i, pf->step, CSSM_STREAM_STEP, 0, z);
     transition(pf, pf->x + i * d, dt, z, pf->x1 + i * d);
   }
   if (!has_obs) {                                               /* :121 */
@@ -456,7 +457,7 @@ static int step_lgcp(oracle_pf* pf, double t) {
       memcpy(xs, pf->x + i * d, d * 8);
       double tau = t, haz = 0.0;                                /* simInit starts the clock at y.t, :194,215 */
       for (uint32_t k = 0; k < nsub; ++k) {
-        draw_normals(pf, i, pf->step, CSSM_STREAM_STEP, k, z);
+        draw_normals(pf, pf->first + i, pf->step, CSSM_STREAM_STEP, k, z);
         transition(pf, xs, delta, z, xn);                       /* x <- stepFunction(dt)(s.state), Sde.scala:59 */
         memcpy(xs, xn, d * 8);
         tau = tau + delta;                                      /* t = s.time + dt, Sde.scala:60 */
@@ -478,6 +479,50 @@ int oracle_pf_step(oracle_pf* pf, double t, double y, int has_obs, double* ll_ou
   if (ll_out) *ll_out = pf->ll;
   if (ess_out) *ess_out = pf->ess;
   return rc;
+}
+
+/* ------------------------------------------------------------------ shard helpers (tests of the multi-rank orchestration) */
+
+/* This handle holds global particles [first, first + n) of an n_global-particle filter: variates
+ * are keyed by the global id.  Only propagate_only / set_particles are meaningful on a shard. */
+void oracle_pf_set_shard(oracle_pf* pf, uint64_t first, uint64_t n_global) { pf->first = first; pf->n_global = n_global; }
+
+/* Lines :118 and :123 of stepFilter only (LGCP: calcWeight): x1 and the log-weights, no resampling. */
+int oracle_pf_propagate_only(oracle_pf* pf, double t, double y, int has_obs) {
+  double z[CSSM_MAX_DIM], xs[CSSM_MAX_DIM], xn[CSSM_MAX_DIM];
+  int d = pf->d;
+  double dt = t - pf->t;
+  if (pf->obs_kind == CSSM_OBS_LGCP) {
+    double delta = pow(10.0, -pf->precision);
+    uint32_t nsub = dt == 0 ? 0 : (uint32_t)ceil(dt / delta);
+    for (uint64_t i = 0; i < pf->n; ++i) {
+      memcpy(xs, pf->x + i * d, d * 8);
+      double tau = t, haz = 0.0;
+      for (uint32_t k = 0; k < nsub; ++k) {
+        draw_normals(pf, pf->first + i, pf->step, CSSM_STREAM_STEP, k, z);
+        transition(pf, xs, delta, z, xn);
+        memcpy(xs, xn, d * 8);
+        tau = tau + delta;
+        haz = haz + o_exp(pf, gamma_of(pf, xs, tau)) * delta;
+      }
+      memcpy(pf->x1 + i * d, xs, d * 8);
+      double g = gamma_of(pf, xs, t);
+      pf->w[i] = nsub ? g - haz : g - g;
+    }
+  } else {
+    for (uint64_t i = 0; i < pf->n; ++i) {
+      draw_normals(pf, pf->first + i, pf->step, CSSM_STREAM_STEP, 0, z);
+      transition(pf, pf->x + i * d, dt, z, pf->x1 + i * d);
+      if (has_obs) pf->w[i] = logdens(pf, gamma_of(pf, pf->x1 + i * d, t), y);
+    }
+  }
+  pf->t = t; pf->step++;
+  return ORACLE_OK;
+}
+
+/* Overwrite the current cloud (SoA in, [d][n]); n may not change. */
+void oracle_pf_set_particles(oracle_pf* pf, const double* soa) {
+  for (uint64_t i = 0; i < pf->n; ++i) for (int k = 0; k < pf->d; ++k) pf->x[i * pf->d + k] = soa[(uint64_t)k * pf->n + i];
 }
 
 /* ------------------------------------------------------------------ A9 drivers */

@@ -54,6 +54,9 @@ def lib() -> C.CDLL:
             "oracle_pf_init_from": (C.c_int, [vp, C.c_double, _dp]),
             "oracle_pf_step": (C.c_int, [vp, C.c_double, C.c_double, C.c_int, _dp, _i32p]),
             "oracle_pf_filter": (C.c_int, [vp, _dp, _dp, _u8p, C.c_size_t, _dp, _dp, _i32p, _dp]),
+            "oracle_pf_set_shard": (None, [vp, C.c_uint64, C.c_uint64]),
+            "oracle_pf_propagate_only": (C.c_int, [vp, C.c_double, C.c_double, C.c_int]),
+            "oracle_pf_set_particles": (None, [vp, _dp]),
             "oracle_pf_num_particles": (C.c_uint64, [vp]),
             "oracle_pf_dim": (C.c_int, [vp]),
             "oracle_pf_get_particles": (None, [vp, _dp]),
@@ -151,6 +154,17 @@ class OraclePf:
         _chk(lib().oracle_pf_filter(self._h, _p(t), _p(y), hp, T, C.byref(ll), _p(ll_t), _p(ess_t, _i32p),
                                     _p(path) if want_path else None))
         return ll.value, ll_t, ess_t, path
+
+    def set_shard(self, first, n_global):
+        lib().oracle_pf_set_shard(self._h, first, n_global)
+
+    def propagate_only(self, t, y, has_obs=True):
+        _chk(lib().oracle_pf_propagate_only(self._h, t, 0.0 if y is None else y, 1 if has_obs else 0))
+
+    def set_particles(self, soa):
+        a = np.ascontiguousarray(soa, dtype=np.float64)
+        assert a.shape == (self.d, self.n)
+        lib().oracle_pf_set_particles(self._h, _p(a))
 
     def particles(self):
         out = np.zeros((self.d, self.n)); lib().oracle_pf_get_particles(self._h, _p(out)); return out

@@ -1,0 +1,93 @@
+"""-m gpu: the sharded (multi-GPU) stage kernels and orchestration, checked bit for bit against the
+single-rank oracle.
+
+One GPU is available, so world > 1 is exercised with all shards in this process and the collectives
+replaced by tensor copies (LocalComm); the RCCL code path itself is exercised at world = 1
+(DistComm over backend "nccl").  The gloo world-size-2 test of the same orchestration is in
+tests/test_sharded_gloo.py (CPU).
+"""
+import os
+
+import numpy as np
+import pytest
+
+import cases
+from oracle import oracle
+
+pytestmark = pytest.mark.gpu
+
+
+def _oracle_run(model, n, t, y, has, lgcp_precision=0):
+    o = oracle.OraclePf(model.descriptor(lgcp_precision), n, cases.SEED)
+    ll, ll_t, ess_t, _ = o.filter(t, y, has)
+    return ll, ess_t, o.particles()
+
+
+@pytest.mark.parametrize("world", [2, 3, 4, 8])
+@pytest.mark.parametrize("name,n", [("c2_model", 6000), ("c1_model", 1000), ("c3_model", 4100)])
+def test_local_shards_match_single_rank_oracle(world, name, n):
+    from composablestatespacemodels_amd.sharded import GpuShard, LocalComm, ShardedFilter
+    model = getattr(cases, name)()
+    t, y, has = cases.poisson_counts(9, missing=0.2)
+    shards = [GpuShard(model, n, r, world, cases.SEED, 0) for r in range(world)]
+    f = ShardedFilter(shards, LocalComm(world))
+    ll, ess = f.ll_filter(t, y, has)
+    oll, oess, opart = _oracle_run(model, n, t, y, has)
+    assert ll == oll
+    assert ess == oess[-1]
+    got = np.concatenate([s.particles() for s in shards], axis=1)
+    np.testing.assert_array_equal(got, opart)
+    for s in shards:
+        assert s.result() == (ll, ess)
+        s.close()
+
+
+def test_local_shards_degenerate_weights():
+    """An informative first observation concentrates the weight on few particles: candidates for a
+    rank then come from other ranks only."""
+    from composablestatespacemodels_amd.sharded import GpuShard, LocalComm, ShardedFilter
+    model = cases.linear_model(obs_sd=0.001)
+    n, world = 4096, 4
+    t = np.array([0.0, 1.0, 2.0]); y = np.array([3.0, 3.1, 2.9]); has = np.ones(3, dtype=np.uint8)
+    shards = [GpuShard(model, n, r, world, cases.SEED, 0) for r in range(world)]
+    f = ShardedFilter(shards, LocalComm(world))
+    ll, ess = f.ll_filter(t, y, has)
+    oll, oess, opart = _oracle_run(model, n, t, y, has)
+    assert (ll, ess) == (oll, oess[-1])
+    np.testing.assert_array_equal(np.concatenate([s.particles() for s in shards], axis=1), opart)
+
+
+def test_local_shards_lgcp():
+    from composablestatespacemodels_amd.sharded import GpuShard, LocalComm, ShardedFilter
+    model = cases.c4_model()
+    n, world = 3000, 2
+    t, y, has = cases.event_times(6)
+    shards = [GpuShard(model, n, r, world, cases.SEED, 0, lgcp_precision=2) for r in range(world)]
+    f = ShardedFilter(shards, LocalComm(world))
+    ll, ess = f.ll_filter(t, y, has, lgcp=True)
+    oll, oess, opart = _oracle_run(model, n, t, y, has, lgcp_precision=2)
+    assert (ll, ess) == (oll, oess[-1])
+    np.testing.assert_array_equal(np.concatenate([s.particles() for s in shards], axis=1), opart)
+
+
+def test_rccl_world1_matches_oracle():
+    import torch
+    import torch.distributed as dist
+    from composablestatespacemodels_amd.sharded import DistComm, GpuShard, ShardedFilter
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29533")
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        model = cases.c2_model()
+        n = 5000
+        t, y, has = cases.poisson_counts(7)
+        shard = GpuShard(model, n, 0, 1, cases.SEED, 0)
+        f = ShardedFilter([shard], DistComm())
+        ll, ess = f.ll_filter(t, y, has)
+        oll, oess, opart = _oracle_run(model, n, t, y, has)
+        assert (ll, ess) == (oll, oess[-1])
+        np.testing.assert_array_equal(shard.particles(), opart)
+        shard.close()
+    finally:
+        dist.destroy_process_group()
