@@ -57,15 +57,16 @@ def cpu_baseline(model, t, y, has, budget_s=12.0):
 
 
 def run_single(args):
+    import torch  # first: its import takes long enough for the GPU clocks to idle down
     from composablestatespacemodels_amd.filter import NativePf
     K, W = args.steps, args.warmup
     n = args.particles
     model, t, y, has = build_workload(max(K, W, 8))
     pf = NativePf(model, n, 20260101, device=0)
     d = pf.d
+    torch.cuda.synchronize()
     if W > 0:
         pf.run(t[:W], y[:W], has[:W])
-    import torch
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     ll, _, ess_t, _ = pf.run(t[:K], y[:K], has[:K])

@@ -340,21 +340,27 @@ __device__ __forceinline__ void load_tile_weights(const double* __restrict__ log
   for (int r = 0; r < CSSM_ITEMS; ++r) w1[r] = raw ? v[r] : cssm_exp(v[r] - gmax);
 }
 
-// w1 = exp(w - max) (model/ParticleFilter.scala:125); S = sum w1, S2 = sum w1^2 per tile, fixed point.
+// w1 = exp(w - max) (model/ParticleFilter.scala:125); S = sum w1, S2 = sum w1^2, fixed point, one pair
+// per UNIT of `sup` consecutive tiles (sup is chosen on the host so that there are ~1K units: the
+// scan over units then fits one pass of one block; integer sums make any grouping give the same bits).
 __global__ __launch_bounds__(CSSM_BLOCK) void k_tile_sums(const double* __restrict__ logw, uint64_t n,
                                                           const Scalars* __restrict__ sc,
-                                                          cssm_u128* __restrict__ tileS, cssm_u128* __restrict__ tileS2,
-                                                          uint32_t ntiles, int raw, int from_slots) {
+                                                          cssm_u128* __restrict__ unitS, cssm_u128* __restrict__ unitS2,
+                                                          uint32_t ntiles, uint32_t sup, uint32_t nunits, int raw, int from_slots) {
   __shared__ cssm_u128 s_a[CSSM_BLOCK / 64], s_b[CSSM_BLOCK / 64];
   const double gmax = from_slots ? decode_slots(sc) : sc->gmax;
-  for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-    double w1[CSSM_ITEMS];
-    load_tile_weights(logw, (uint64_t)tile * CSSM_TILE, n, gmax, raw, w1);
+  for (uint32_t unit = blockIdx.x; unit < nunits; unit += gridDim.x) {
+    const uint32_t t0 = unit * sup;
+    const uint32_t t1 = (t0 + sup < ntiles) ? t0 + sup : ntiles;
     cssm_u128 a = cssm_u128_zero(), b = cssm_u128_zero();
+    for (uint32_t tile = t0; tile < t1; ++tile) {
+      double w1[CSSM_ITEMS];
+      load_tile_weights(logw, (uint64_t)tile * CSSM_TILE, n, gmax, raw, w1);
 #pragma unroll
-    for (int r = 0; r < CSSM_ITEMS; ++r) {
-      a = cssm_u128_add(a, cssm_fix_from_double(w1[r]));
-      b = cssm_u128_add(b, cssm_fix_from_double(w1[r] * w1[r]));
+      for (int r = 0; r < CSSM_ITEMS; ++r) {
+        a = cssm_u128_add(a, cssm_fix_from_double(w1[r]));
+        b = cssm_u128_add(b, cssm_fix_from_double(w1[r] * w1[r]));
+      }
     }
     a = wave_sum_u128(a);
     b = wave_sum_u128(b);
@@ -364,7 +370,7 @@ __global__ __launch_bounds__(CSSM_BLOCK) void k_tile_sums(const double* __restri
       cssm_u128 ta = s_a[0], tb = s_b[0];
 #pragma unroll
       for (int w = 1; w < CSSM_BLOCK / 64; ++w) { ta = cssm_u128_add(ta, s_a[w]); tb = cssm_u128_add(tb, s_b[w]); }
-      tileS[tile] = ta; tileS2[tile] = tb;
+      unitS[unit] = ta; unitS2[unit] = tb;
     }
     __syncthreads();
   }
@@ -384,51 +390,42 @@ __device__ void finish_step(Scalars* sc, uint64_t n_global) {
   sc->ess = (e < 2147483647.0) ? (int32_t)fl : 2147483647;
 }
 
-// Exclusive scan of the tile sums in one block; local totals; with world == 1 also the step's ll/ess.
+// Exclusive scan of the tile sums in one block (thread t owns a contiguous chunk of tiles: sum, block
+// scan of the 1024 chunk sums, then prefix write-back); local totals; with `single` also ll / ess.
 __global__ __launch_bounds__(1024) void k_scan_tiles(const cssm_u128* __restrict__ tileS, const cssm_u128* __restrict__ tileS2,
                                                      cssm_u128* __restrict__ tileP, uint32_t ntiles, Scalars* sc,
                                                      uint64_t n_global, int single, int from_slots,
                                                      double* __restrict__ ll_t, int32_t* __restrict__ ess_t, uint32_t rec_idx) {
   __shared__ cssm_u128 s_w[16], s_w2[16];
-  __shared__ cssm_u128 s_carry, s_carry2;
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-  if (threadIdx.x == 0) { s_carry = cssm_u128_zero(); s_carry2 = cssm_u128_zero(); }
   if (from_slots) {   // every k_tile_sums block has decoded the slots already (previous kernel): publish and reset
     if (threadIdx.x == 0) sc->gmax = decode_slots(sc);
     __syncthreads();
     if (threadIdx.x < CSSM_MAXSLOTS) sc->maxslot[threadIdx.x * CSSM_SLOT_STRIDE] = 0ull;
   }
+  const uint32_t chunk = (ntiles + 1023u) / 1024u;
+  const uint32_t t0 = threadIdx.x * chunk;
+  const uint32_t t1 = (t0 + chunk < ntiles) ? t0 + chunk : ntiles;
+  cssm_u128 v = cssm_u128_zero(), v2 = cssm_u128_zero();
+  for (uint32_t t = t0; t < t1; ++t) { v = cssm_u128_add(v, tileS[t]); v2 = cssm_u128_add(v2, tileS2[t]); }
+  cssm_u128 inc = wave_scan_u128(v, lane);
+  cssm_u128 tot2 = wave_sum_u128(v2);
+  if (lane == 63) s_w[wid] = inc;
+  if (lane == 0) s_w2[wid] = tot2;
   __syncthreads();
-  for (uint32_t base = 0; base < ntiles; base += 1024) {
-    const uint32_t t = base + threadIdx.x;
-    cssm_u128 v = (t < ntiles) ? tileS[t] : cssm_u128_zero();
-    cssm_u128 v2 = (t < ntiles) ? tileS2[t] : cssm_u128_zero();
-    cssm_u128 inc = wave_scan_u128(v, lane);
-    cssm_u128 tot2 = wave_sum_u128(v2);
-    if (lane == 63) s_w[wid] = inc;
-    if (lane == 0) s_w2[wid] = tot2;
-    __syncthreads();
-    cssm_u128 off = s_carry;
-    for (int w = 0; w < wid; ++w) off = cssm_u128_add(off, s_w[w]);
-    if (t < ntiles) {
-      // exclusive prefix = off + inc - v  (integers: exact)
-      cssm_u128 ex = cssm_u128_add(off, inc);
-      cssm_u128 r; r.lo = ex.lo - v.lo; r.hi = ex.hi - v.hi - (ex.lo < v.lo ? 1u : 0u);
-      tileP[t] = r;
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-      cssm_u128 c = s_carry, c2 = s_carry2;
-      for (int w = 0; w < 16; ++w) { c = cssm_u128_add(c, s_w[w]); c2 = cssm_u128_add(c2, s_w2[w]); }
-      s_carry = c; s_carry2 = c2;
-    }
-    __syncthreads();
-  }
+  cssm_u128 off = cssm_u128_zero();
+  for (int w = 0; w < wid; ++w) off = cssm_u128_add(off, s_w[w]);
+  // exclusive prefix of this thread's chunk = off + inc - v (integers: exact)
+  cssm_u128 run = cssm_u128_add(off, inc);
+  { cssm_u128 r; r.lo = run.lo - v.lo; r.hi = run.hi - v.hi - (run.lo < v.lo ? 1u : 0u); run = r; }
+  for (uint32_t t = t0; t < t1; ++t) { tileP[t] = run; run = cssm_u128_add(run, tileS[t]); }
   if (threadIdx.x == 0) {
-    sc->S_local = s_carry; sc->S2_local = s_carry2;
+    cssm_u128 c = cssm_u128_zero(), c2 = cssm_u128_zero();
+    for (int w = 0; w < 16; ++w) { c = cssm_u128_add(c, s_w[w]); c2 = cssm_u128_add(c2, s_w2[w]); }
+    sc->S_local = c; sc->S2_local = c2;
     if (single) {
       sc->S_off = cssm_u128_zero();
-      sc->S_tot = s_carry; sc->S2_tot = s_carry2;
+      sc->S_tot = c; sc->S2_tot = c2;
       finish_step(sc, n_global);
       if (ll_t) { ll_t[rec_idx] = sc->ll; ess_t[rec_idx] = sc->ess; }
     }
@@ -450,51 +447,108 @@ __global__ void k_global_sums(const unsigned long long* __restrict__ all4, int r
 
 // ------------------------------------------------------------------------------------ offspring (end slots)
 
+#define CSSM_RUN_DIRECT 8 /* runs up to this length are written by the owning thread */
+
 // treeEcdf (model/Resampling.scala:52-58): C_j = (sum_{i<=j} w1_i) / (sum_i w1_i), here the
 // correctly rounded quotient of the exact fixed-point sums; end slot of particle j =
 // #{ i : (u+i)/N <= C_j } (the ks of :69 against the keys of the TreeMap).
+// FUSE: also do findAllInTreeMap (:36-46): particle j writes its own run of slots
+// [end_{j-1}, end_j) <- j (runs longer than CSSM_RUN_DIRECT are written by the whole block), so on a
+// single GPU the end slots never travel through HBM.  Otherwise the end slots are stored for the
+// exchange of the sharded filter.  A block walks the tiles of one unit with a running prefix.
+template <bool FUSE>
 __global__ __launch_bounds__(CSSM_BLOCK) void k_offspring(const double* __restrict__ logw, uint64_t n,
                                                           const Scalars* __restrict__ sc,
-                                                          const cssm_u128* __restrict__ tileP,
+                                                          const cssm_u128* __restrict__ unitP,
                                                           const StepRec* __restrict__ rec, uint64_t n_global,
-                                                          uint32_t* __restrict__ endslot, uint32_t ntiles, int raw) {
+                                                          uint32_t* __restrict__ endslot, uint32_t* __restrict__ anc,
+                                                          uint32_t ntiles, uint32_t sup, uint32_t nunits, int raw) {
   __shared__ cssm_u128 s_w[CSSM_BLOCK / 64];
+  __shared__ uint32_t s_last[CSSM_BLOCK / 64];
+  __shared__ uint32_t s_nheavy;
+  __shared__ uint32_t s_hb[FUSE ? CSSM_TILE : 1], s_he[FUSE ? CSSM_TILE : 1], s_hj[FUSE ? CSSM_TILE : 1];
   const double gmax = sc->gmax;
   const double u = rec->u;
   const double totd = cssm_u128_to_double(sc->S_tot);
   const cssm_u128 S_off = sc->S_off;
+  const bool pow2 = (n_global & (n_global - 1)) == 0;
+  const double inv_n = 1.0 / (double)n_global;
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-  for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-    const uint64_t base = (uint64_t)tile * CSSM_TILE;
-    double w1[CSSM_ITEMS];
-    load_tile_weights(logw, base, n, gmax, raw, w1);
-    cssm_u128 q[CSSM_ITEMS];
-    cssm_u128 tsum = cssm_u128_zero();
+  for (uint32_t unit = blockIdx.x; unit < nunits; unit += gridDim.x) {
+    const uint32_t t0 = unit * sup;
+    const uint32_t t1 = (t0 + sup < ntiles) ? t0 + sup : ntiles;
+    cssm_u128 toff = cssm_u128_add(S_off, unitP[unit]);   // cumulative weight before the current tile
+    for (uint32_t tile = t0; tile < t1; ++tile) {
+      const uint64_t base = (uint64_t)tile * CSSM_TILE;
+      double w1[CSSM_ITEMS];
+      load_tile_weights(logw, base, n, gmax, raw, w1);
+      cssm_u128 q[CSSM_ITEMS];
+      cssm_u128 tsum = cssm_u128_zero();
 #pragma unroll
-    for (int r = 0; r < CSSM_ITEMS; ++r) { q[r] = cssm_fix_from_double(w1[r]); tsum = cssm_u128_add(tsum, q[r]); }
-    cssm_u128 inc = wave_scan_u128(tsum, lane);
-    if (lane == 63) s_w[wid] = inc;
-    __syncthreads();
-    cssm_u128 off = cssm_u128_add(S_off, tileP[tile]);
-    for (int w = 0; w < wid; ++w) off = cssm_u128_add(off, s_w[w]);
-    // exclusive prefix of this thread = off + inc - tsum
-    cssm_u128 run = cssm_u128_add(off, inc);
-    { cssm_u128 r; r.lo = run.lo - tsum.lo; r.hi = run.hi - tsum.hi - (run.lo < tsum.lo ? 1u : 0u); run = r; }
-    uint32_t e[CSSM_ITEMS];
+      for (int r = 0; r < CSSM_ITEMS; ++r) { q[r] = cssm_fix_from_double(w1[r]); tsum = cssm_u128_add(tsum, q[r]); }
+      cssm_u128 inc = wave_scan_u128(tsum, lane);
+      if (FUSE && threadIdx.x == 0) s_nheavy = 0;
+      if (lane == 63) s_w[wid] = inc;
+      __syncthreads();
+      cssm_u128 off = toff;
+      for (int w = 0; w < wid; ++w) off = cssm_u128_add(off, s_w[w]);
+      // exclusive prefix of this thread = off + inc - tsum
+      cssm_u128 run = cssm_u128_add(off, inc);
+      { cssm_u128 r; r.lo = run.lo - tsum.lo; r.hi = run.hi - tsum.hi - (run.lo < tsum.lo ? 1u : 0u); run = r; }
+      uint32_t e[CSSM_ITEMS];
 #pragma unroll
-    for (int r = 0; r < CSSM_ITEMS; ++r) {
-      run = cssm_u128_add(run, q[r]);
-      const double C = cssm_u128_to_double(run) / totd;
-      e[r] = (uint32_t)cssm_sys_count(C, u, n_global);
+      for (int r = 0; r < CSSM_ITEMS; ++r) {
+        run = cssm_u128_add(run, q[r]);
+        const double C = cssm_u128_to_double(run) / totd;
+        e[r] = (uint32_t)(pow2 ? cssm_sys_count_pow2(C, u, n_global, inv_n) : cssm_sys_count(C, u, n_global));
+      }
+      const uint64_t i0 = base + (uint64_t)threadIdx.x * CSSM_ITEMS;
+      if (!FUSE) {
+        if (i0 + CSSM_ITEMS <= n) {
+          *reinterpret_cast<uint4*>(endslot + i0) = make_uint4(e[0], e[1], e[2], e[3]);
+        } else {
+#pragma unroll
+          for (int r = 0; r < CSSM_ITEMS; ++r) if (i0 + r < n) endslot[i0 + r] = e[r];
+        }
+      } else {
+        // end slot of the particle before this thread's first one
+        if (lane == 63) s_last[wid] = e[CSSM_ITEMS - 1];
+        uint32_t prev = __shfl_up(e[CSSM_ITEMS - 1], 1, 64);
+        __syncthreads();
+        if (lane == 0) {
+          if (wid > 0) prev = s_last[wid - 1];
+          else if (tile == 0) prev = 0u;
+          else {   // the same formula on the tile's exclusive prefix
+            const double Cp = cssm_u128_to_double(toff) / totd;
+            prev = (uint32_t)(pow2 ? cssm_sys_count_pow2(Cp, u, n_global, inv_n) : cssm_sys_count(Cp, u, n_global));
+          }
+        }
+#pragma unroll
+        for (int r = 0; r < CSSM_ITEMS; ++r) {
+          const uint32_t b = (r == 0) ? prev : e[r - 1];
+          const uint32_t len = e[r] - b;           // 0 for the padding items of a partial tile
+          const uint32_t jj = (uint32_t)(i0 + r);
+          if (len <= CSSM_RUN_DIRECT) {
+            for (uint32_t s = b; s < e[r]; ++s) anc[s] = jj;
+          } else {
+            const uint32_t h = atomicAdd(&s_nheavy, 1u);
+            s_hb[h] = b; s_he[h] = e[r]; s_hj[h] = jj;
+          }
+        }
+        __syncthreads();
+        const uint32_t nh = s_nheavy;
+        for (uint32_t h = 0; h < nh; ++h) {
+          const uint32_t he = s_he[h], hj = s_hj[h];
+          for (uint32_t s = s_hb[h] + threadIdx.x; s < he; s += CSSM_BLOCK) anc[s] = hj;
+        }
+      }
+      // advance the running prefix by this tile's total
+      cssm_u128 ttot = s_w[0];
+#pragma unroll
+      for (int w = 1; w < CSSM_BLOCK / 64; ++w) ttot = cssm_u128_add(ttot, s_w[w]);
+      toff = cssm_u128_add(toff, ttot);
+      __syncthreads();
     }
-    const uint64_t i0 = base + (uint64_t)threadIdx.x * CSSM_ITEMS;
-    if (i0 + CSSM_ITEMS <= n) {
-      *reinterpret_cast<uint4*>(endslot + i0) = make_uint4(e[0], e[1], e[2], e[3]);
-    } else {
-#pragma unroll
-      for (int r = 0; r < CSSM_ITEMS; ++r) if (i0 + r < n) endslot[i0 + r] = e[r];
-    }
-    __syncthreads();
   }
 }
 

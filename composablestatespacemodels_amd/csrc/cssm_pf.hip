@@ -56,6 +56,7 @@ struct cssm_pf {
   uint64_t n_global = 0, first = 0, n = 0, seed = 0;
   size_t stride = 0;
   uint32_t ntiles = 0;
+  uint32_t sup = 1, nunits = 0;   // tiles per scan unit, number of units (<= ~1K)
   bool sharded = false;
   // device memory
   double* state[2] = {nullptr, nullptr};
@@ -282,6 +283,8 @@ static int alloc_handle(cssm_pf* pf) {
   HIP_TRY(hipEventCreate(&pf->ev1));
   pf->stride = (size_t)((pf->n + CSSM_TILE - 1) / CSSM_TILE) * CSSM_TILE;   // rows start 16-B aligned
   pf->ntiles = (uint32_t)((pf->n + CSSM_TILE - 1) / CSSM_TILE);
+  pf->sup = (pf->ntiles + 1023u) / 1024u;
+  pf->nunits = (pf->ntiles + pf->sup - 1) / pf->sup;
   const size_t row = pf->stride * 8;
   for (int b = 0; b < 2; ++b) {
     if (hipMalloc(&pf->state[b], row * pf->d) != hipSuccess) return fail(CSSM_ENOMEM, "hipMalloc of %zu bytes failed", row * pf->d);
@@ -427,20 +430,18 @@ static int launch_propagate(cssm_pf* pf, const StepRec* d_rec) {
 
 // weights -> sums -> end slots -> ancestors, single GPU
 static int launch_resample(cssm_pf* pf, const StepRec* d_rec, double* ll_t = nullptr, int32_t* ess_t = nullptr, uint32_t rec_idx = 0) {
-  const int tgrid = grid_for(pf->ntiles, 1, kGridCap);
+  const int tgrid = (int)pf->nunits;
   prof_begin(pf, CSSM_K_TILE_SUMS);
-  hipLaunchKernelGGL(k_tile_sums, dim3(tgrid), dim3(CSSM_BLOCK), 0, pf->stream, pf->logw, pf->n, pf->sc, pf->tileS, pf->tileS2, pf->ntiles, 0, 1);
+  hipLaunchKernelGGL(k_tile_sums, dim3(tgrid), dim3(CSSM_BLOCK), 0, pf->stream, pf->logw, pf->n, pf->sc, pf->tileS, pf->tileS2, pf->ntiles,
+                     pf->sup, pf->nunits, 0, 1);
   prof_end(pf);
   prof_begin(pf, CSSM_K_SCAN_TILES);
-  hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(1024), 0, pf->stream, pf->tileS, pf->tileS2, pf->tileP, pf->ntiles, pf->sc, pf->n_global, 1, 1,
+  hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(1024), 0, pf->stream, pf->tileS, pf->tileS2, pf->tileP, pf->nunits, pf->sc, pf->n_global, 1, 1,
                      ll_t, ess_t, rec_idx);
   prof_end(pf);
-  prof_begin(pf, CSSM_K_OFFSPRING);
-  hipLaunchKernelGGL(k_offspring, dim3(tgrid), dim3(CSSM_BLOCK), 0, pf->stream, pf->logw, pf->n, pf->sc, pf->tileP, d_rec, pf->n_global,
-                     pf->endslot, pf->ntiles, 0);
-  prof_end(pf);
-  prof_begin(pf, CSSM_K_EXPAND);
-  hipLaunchKernelGGL(k_expand, dim3(tgrid), dim3(CSSM_BLOCK), 0, pf->stream, pf->endslot, pf->n, (uint64_t)0, pf->n, pf->anc, pf->ntiles);
+  prof_begin(pf, CSSM_K_OFFSPRING);   // end slots and their expansion to ancestors in one kernel
+  hipLaunchKernelGGL(k_offspring<true>, dim3(tgrid), dim3(CSSM_BLOCK), 0, pf->stream, pf->logw, pf->n, pf->sc, pf->tileP, d_rec, pf->n_global,
+                     pf->endslot, pf->anc, pf->ntiles, pf->sup, pf->nunits, 0);
   prof_end(pf);
   HIP_TRY(hipGetLastError());
   pf->anc_valid = true;
@@ -669,6 +670,7 @@ extern "C" int cssm_resample_systematic(const double* w, size_t n, double u, uin
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return fail(CSSM_EHIP, "no HIP device available (this library has no CPU path)");
   HIP_TRY(hipSetDevice(device));
   const uint32_t ntiles = (uint32_t)((n + CSSM_TILE - 1) / CSSM_TILE);
+  const uint32_t sup = (ntiles + 1023u) / 1024u, nunits = (ntiles + sup - 1) / sup;
   const size_t stride = (size_t)ntiles * CSSM_TILE;
   double* d_w = nullptr; uint32_t *d_end = nullptr, *d_anc = nullptr; cssm_u128 *tS = nullptr, *tS2 = nullptr, *tP = nullptr;
   Scalars* sc = nullptr; StepRec* d_rec = nullptr;
@@ -685,11 +687,10 @@ extern "C" int cssm_resample_systematic(const double* w, size_t n, double u, uin
   RS_TRY(hipMemcpyAsync(d_w, w, n * 8, hipMemcpyHostToDevice, st));
   RS_TRY(hipMemcpyAsync(d_rec, &hrec, sizeof hrec, hipMemcpyHostToDevice, st));
   {
-    const int tgrid = grid_for(ntiles, 1, kGridCap);
-    hipLaunchKernelGGL(k_tile_sums, dim3(tgrid), dim3(CSSM_BLOCK), 0, st, d_w, (uint64_t)n, sc, tS, tS2, ntiles, 1, 0);
-    hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(1024), 0, st, tS, tS2, tP, ntiles, sc, (uint64_t)n, 1, 0, (double*)nullptr, (int32_t*)nullptr, 0u);
-    hipLaunchKernelGGL(k_offspring, dim3(tgrid), dim3(CSSM_BLOCK), 0, st, d_w, (uint64_t)n, sc, tP, d_rec, (uint64_t)n, d_end, ntiles, 1);
-    hipLaunchKernelGGL(k_expand, dim3(tgrid), dim3(CSSM_BLOCK), 0, st, d_end, (uint64_t)n, (uint64_t)0, (uint64_t)n, d_anc, ntiles);
+    const int tgrid = (int)nunits;
+    hipLaunchKernelGGL(k_tile_sums, dim3(tgrid), dim3(CSSM_BLOCK), 0, st, d_w, (uint64_t)n, sc, tS, tS2, ntiles, sup, nunits, 1, 0);
+    hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(1024), 0, st, tS, tS2, tP, nunits, sc, (uint64_t)n, 1, 0, (double*)nullptr, (int32_t*)nullptr, 0u);
+    hipLaunchKernelGGL(k_offspring<true>, dim3(tgrid), dim3(CSSM_BLOCK), 0, st, d_w, (uint64_t)n, sc, tP, d_rec, (uint64_t)n, d_end, d_anc, ntiles, sup, nunits, 1);
   }
   RS_TRY(hipGetLastError());
   RS_TRY(hipMemcpyAsync(&hs, sc, sizeof hs, hipMemcpyDeviceToHost, st));
@@ -804,10 +805,11 @@ extern "C" int cssm_pf_shard_sums(cssm_pf* pf, const double* global_max_dev, uin
   int rc = shard_check(pf);
   if (rc) return rc;
   if (!global_max_dev || !sums4_dev) return fail(CSSM_EINVAL_ARG, "null argument");
-  const int tgrid = grid_for(pf->ntiles, 1, kGridCap);
+  const int tgrid = (int)pf->nunits;
   hipLaunchKernelGGL(k_import_max, dim3(1), dim3(1), 0, pf->stream, pf->sc, global_max_dev);
-  hipLaunchKernelGGL(k_tile_sums, dim3(tgrid), dim3(CSSM_BLOCK), 0, pf->stream, pf->logw, pf->n, pf->sc, pf->tileS, pf->tileS2, pf->ntiles, 0, 0);
-  hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(1024), 0, pf->stream, pf->tileS, pf->tileS2, pf->tileP, pf->ntiles, pf->sc, pf->n_global, 0, 0,
+  hipLaunchKernelGGL(k_tile_sums, dim3(tgrid), dim3(CSSM_BLOCK), 0, pf->stream, pf->logw, pf->n, pf->sc, pf->tileS, pf->tileS2, pf->ntiles,
+                     pf->sup, pf->nunits, 0, 0);
+  hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(1024), 0, pf->stream, pf->tileS, pf->tileS2, pf->tileP, pf->nunits, pf->sc, pf->n_global, 0, 0,
                      (double*)nullptr, (int32_t*)nullptr, 0u);
   hipLaunchKernelGGL(k_export_sums, dim3(1), dim3(1), 0, pf->stream, pf->sc, (unsigned long long*)sums4_dev);
   HIP_TRY(hipGetLastError());
@@ -824,10 +826,10 @@ extern "C" int cssm_pf_shard_offspring(cssm_pf* pf, const uint64_t* all_sums4_de
   if (pf->first != (uint64_t)rank * n_per) return fail(CSSM_ESHARD, "rank %d must own particles from %llu (ceil(N/world) per rank), handle starts at %llu",
                                                        rank, (unsigned long long)((uint64_t)rank * n_per), (unsigned long long)pf->first);
   const size_t slot = (pf->step - 1) % 64;   // record of the step propagated last
-  const int tgrid = grid_for(pf->ntiles, 1, kGridCap);
+  const int tgrid = (int)pf->nunits;
   hipLaunchKernelGGL(k_global_sums, dim3(1), dim3(1), 0, pf->stream, (const unsigned long long*)all_sums4_dev, rank, world, pf->sc, pf->n_global);
-  hipLaunchKernelGGL(k_offspring, dim3(tgrid), dim3(CSSM_BLOCK), 0, pf->stream, pf->logw, pf->n, pf->sc, pf->tileP, pf->d_recs + slot,
-                     pf->n_global, pf->endslot, pf->ntiles, 0);
+  hipLaunchKernelGGL(k_offspring<false>, dim3(tgrid), dim3(CSSM_BLOCK), 0, pf->stream, pf->logw, pf->n, pf->sc, pf->tileP, pf->d_recs + slot,
+                     pf->n_global, pf->endslot, (uint32_t*)nullptr, pf->ntiles, pf->sup, pf->nunits, 0);
   hipLaunchKernelGGL(k_send_ranges, dim3(1), dim3(64), 0, pf->stream, pf->endslot, pf->n, pf->sc, pf->d_recs + slot, pf->n_global, rank, world,
                      n_per, (long long*)send_first_dev, (long long*)send_count_dev);
   HIP_TRY(hipGetLastError());

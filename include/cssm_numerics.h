@@ -62,6 +62,9 @@ typedef struct { uint32_t v[4]; } cssm_u32x4;
 #define CSSM_PHILOX_W1 0xBB67AE85u
 
 CSSM_HD cssm_u32x4 cssm_philox4x32_10(cssm_u32x4 c, uint32_t k0, uint32_t k1) {
+#if defined(__HIPCC__)
+#pragma unroll
+#endif
   for (int r = 0; r < 10; ++r) {
     uint64_t p0 = (uint64_t)CSSM_PHILOX_M0 * c.v[0];
     uint64_t p1 = (uint64_t)CSSM_PHILOX_M1 * c.v[2];
@@ -102,12 +105,13 @@ CSSM_HD cssm_u32x4 cssm_philox_draw(uint64_t seed, uint64_t gid, uint32_t step, 
 
 /* 53-bit integers from word pairs. */
 CSSM_HD uint64_t cssm_bits53(uint32_t hi, uint32_t lo) { return ((uint64_t)hi << 21) | (lo >> 11); }
-/* [0,1) with 53 bits, as scala.util.Random.nextDouble has. */
-CSSM_HD double cssm_u01(uint32_t hi, uint32_t lo) { return (double)cssm_bits53(hi, lo) * 0x1.0p-53; }
-/* (0,1] with 53 bits (safe argument of log). */
-CSSM_HD double cssm_u01_open0(uint32_t hi, uint32_t lo) {
-  return (double)(cssm_bits53(hi, lo) + 1) * 0x1.0p-53;
+/* [0,1) with 53 bits, as scala.util.Random.nextDouble has: bits53 * 2^-53, formed from two exact
+ * 32-bit conversions (hi * 2^-32 + (lo >> 11) * 2^-53: disjoint bit ranges, 53 bits, no rounding). */
+CSSM_HD double cssm_u01(uint32_t hi, uint32_t lo) {
+  return cssm_fma((double)hi, 0x1.0p-32, (double)(lo >> 11) * 0x1.0p-53);
 }
+/* (0,1] with 53 bits (safe argument of log): (bits53 + 1) * 2^-53, exact. */
+CSSM_HD double cssm_u01_open0(uint32_t hi, uint32_t lo) { return cssm_u01(hi, lo) + 0x1.0p-53; }
 
 /* ------------------------------------------------------------------ exp */
 
@@ -118,16 +122,17 @@ CSSM_HD double cssm_u01_open0(uint32_t hi, uint32_t lo) {
  * subnormal, so the contract does not depend on denormal support); NaN -> NaN.
  */
 CSSM_HD double cssm_exp(double x) {
-  if (x != x) return x;
-  if (x > 709.782712893384) return cssm_inf();
-  if (x < -708.0) return 0.0;
   const double LOG2E = 1.44269504088896338700e+00;
   const double LN2_HI = 6.93147180369123816490e-01; /* 0x3fe62e42fee00000 */
   const double LN2_LO = 1.90821492927058770002e-10; /* 0x3dea39ef35793c76 */
-  double t = x * LOG2E;
+  /* straight-line evaluation on a clamped argument; the edge cases are selected at the end */
+  double xc = (x > 710.0) ? 710.0 : x;
+  xc = (xc < -745.0) ? -745.0 : xc;
+  xc = (x != x) ? 0.0 : xc;
+  double t = xc * LOG2E;
   int k = (int)(t + (t < 0.0 ? -0.5 : 0.5));
   double kd = (double)k;
-  double r = cssm_fma(-kd, LN2_HI, x);
+  double r = cssm_fma(-kd, LN2_HI, xc);
   r = cssm_fma(-kd, LN2_LO, r);
   double p = 1.0 / 6227020800.0; /* 1/13! */
   p = cssm_fma(p, r, 1.0 / 479001600.0);
@@ -145,7 +150,11 @@ CSSM_HD double cssm_exp(double x) {
   p = cssm_fma(p, r, 1.0);
   int k1 = k >> 1;
   int k2 = k - k1;
-  return (p * cssm_pow2i(k1)) * cssm_pow2i(k2);
+  double res = (p * cssm_pow2i(k1)) * cssm_pow2i(k2);
+  res = (x > 709.782712893384) ? cssm_inf() : res;
+  res = (x < -708.0) ? 0.0 : res;
+  res = (x != x) ? x : res;
+  return res;
 }
 
 /* ------------------------------------------------------------------ log */
@@ -176,6 +185,37 @@ CSSM_HD double cssm_log(double x) {
   }
   uint32_t hx = (uint32_t)(ux >> 32);
   k += (int)(hx >> 20) - 1023;
+  hx &= 0x000fffffu;
+  uint32_t i = (hx + 0x95f64u) & 0x100000u;
+  ux = ((uint64_t)(hx | (i ^ 0x3ff00000u)) << 32) | (ux & 0xffffffffULL);
+  k += (int)(i >> 20);
+  double m = cssm_u2d(ux);
+  double f = m - 1.0;
+  double s = f / (2.0 + f);
+  double dk = (double)k;
+  double z = s * s;
+  double w = z * z;
+  double t1 = w * cssm_fma(w, cssm_fma(w, LG6, LG4), LG2);
+  double t2 = z * cssm_fma(w, cssm_fma(w, cssm_fma(w, LG7, LG5), LG3), LG1);
+  double R = t2 + t1;
+  double hfsq = 0.5 * f * f;
+  return dk * LN2_HI - ((hfsq - (s * (hfsq + R) + dk * LN2_LO)) - f);
+}
+
+/*
+ * log(x) for x in [2^-53, 1] -- the Box-Muller argument -- without any special case: the same
+ * algorithm and coefficients as cssm_log, straight-line (x is a positive normal number).
+ */
+CSSM_HD double cssm_log_unit(double x) {
+  const double LN2_HI = 6.93147180369123816490e-01;
+  const double LN2_LO = 1.90821492927058770002e-10;
+  const double LG1 = 6.666666666666735130e-01, LG2 = 3.999999999940941908e-01,
+               LG3 = 2.857142874366239149e-01, LG4 = 2.222219843214978396e-01,
+               LG5 = 1.818357216161805012e-01, LG6 = 1.531383769920937332e-01,
+               LG7 = 1.479819860511658591e-01;
+  uint64_t ux = cssm_d2u(x);
+  uint32_t hx = (uint32_t)(ux >> 32);
+  int k = (int)(hx >> 20) - 1023;
   hx &= 0x000fffffu;
   uint32_t i = (hx + 0x95f64u) & 0x100000u;
   ux = ((uint64_t)(hx | (i ^ 0x3ff00000u)) << 32) | (ux & 0xffffffffULL);
@@ -225,12 +265,12 @@ CSSM_HD void cssm_sincos2pi(double u, double* sn, double* cs) {
   double hz = 0.5 * z;
   double w = 1.0 - hz;
   double c = w + (((1.0 - w) - hz) + (z * rc - xh * xl));
-  switch (q & 3) {
-    case 0: *sn = s; *cs = c; break;
-    case 1: *sn = c; *cs = -s; break;
-    case 2: *sn = -s; *cs = -c; break;
-    default: *sn = -c; *cs = s; break;
-  }
+  /* quadrant rotation without branches: odd q swaps, bit 1 of q (of q+1) negates sin (cos) */
+  const int swap = q & 1;
+  const double ss = swap ? c : s;
+  const double cc = swap ? s : c;
+  *sn = cssm_u2d(cssm_d2u(ss) ^ ((uint64_t)(q & 2) << 62));
+  *cs = cssm_u2d(cssm_d2u(cc) ^ ((uint64_t)((q + 1) & 2) << 62));
 }
 
 /*
@@ -251,7 +291,7 @@ CSSM_HD double cssm_seasonal_phase(double a, double t, double period) {
 CSSM_HD void cssm_normal_pair(cssm_u32x4 b, double* z0, double* z1) {
   double u1 = cssm_u01_open0(b.v[0], b.v[1]);
   double u2 = cssm_u01(b.v[2], b.v[3]);
-  double r = cssm_sqrt(-2.0 * cssm_log(u1));
+  double r = cssm_sqrt(-2.0 * cssm_log_unit(u1));
   double sn, cs;
   cssm_sincos2pi(u2, &sn, &cs);
   *z0 = r * cs;
@@ -293,39 +333,44 @@ CSSM_HD cssm_u128 cssm_u128_add(cssm_u128 a, cssm_u128 b) {
 }
 CSSM_HD int cssm_u128_is_zero(cssm_u128 a) { return (a.lo | a.hi) == 0; }
 
-/* floor(w * 2^96) for finite w >= 0 (w < 2^32); negative, NaN and inf map to 0. */
+/* floor(w * 2^96) for finite 0 <= w < 2^9 (weights are <= 1); negative, NaN, inf and w >= 2^9 map
+ * to 0.  Straight-line: the 53-bit significand m, seen as the 128-bit number m * 2^64, is shifted
+ * right by k = 1043 - biased_exponent. */
 CSSM_HD cssm_u128 cssm_fix_from_double(double w) {
-  cssm_u128 r = cssm_u128_zero();
-  uint64_t u = cssm_d2u(w);
-  if (u >> 63) return r;
-  int e = (int)(u >> 52);
-  if (e == 0 || e == 0x7ff) return r; /* zero/subnormal (< 2^-1022 << 2^-96) or inf/NaN */
-  uint64_t m = (u & 0x000fffffffffffffULL) | 0x0010000000000000ULL;
-  int sh = e - 1075 + CSSM_FIX_FRAC_BITS; /* value = m * 2^(e-1075); place at 2^-96 units */
-  if (sh >= 0) {
-    if (sh >= 75) return r; /* w >= 2^32: outside the contract */
-    if (sh >= 64) { r.hi = m << (sh - 64); }
-    else if (sh == 0) { r.lo = m; }
-    else { r.lo = m << sh; r.hi = m >> (64 - sh); }
-  } else {
-    int rs = -sh;
-    if (rs < 53) r.lo = m >> rs;
-  }
+  cssm_u128 r;
+  const uint64_t u = cssm_d2u(w);
+  const int e = (int)((u >> 52) & 0x7ff);
+  const uint64_t m = (u & 0x000fffffffffffffULL) | 0x0010000000000000ULL;
+  int k = 1043 - e;
+  const int valid = ((u >> 63) == 0) & (e != 0) & (e != 0x7ff) & (k >= 11);
+  k = (k > 127) ? 127 : k;
+  k = (k < 11) ? 11 : k;
+  const int big = k >= 64;
+  const int sft = k & 63;
+  const uint64_t down = m >> sft;
+  const uint64_t up = (m << 1) << (63 - sft); /* m << (64 - sft) without a shift by 64 */
+  r.hi = (valid && !big) ? down : 0;
+  r.lo = valid ? (big ? down : up) : 0;
   return r;
 }
 
 CSSM_HD int cssm_clz64(uint64_t x) { return __builtin_clzll(x); }
 
-/* Correctly rounded (nearest-even) conversion of the 128-bit INTEGER to double. */
+/* Correctly rounded (nearest-even) conversion of the 128-bit INTEGER to double: normalise to 64
+ * significant bits + sticky bit (64 > 53 + 2, so rounding the 64-bit value once is rounding the
+ * exact value once), convert, scale by an exact power of two. */
 CSSM_HD double cssm_u128_to_double(cssm_u128 a) {
-  if (a.hi == 0) return (double)a.lo; /* u64 -> double is round-to-nearest-even on both sides */
-  int lz = cssm_clz64(a.hi);          /* 0..63 */
-  uint64_t top, rest;
-  if (lz == 0) { top = a.hi; rest = a.lo; }
-  else { top = (a.hi << lz) | (a.lo >> (64 - lz)); rest = a.lo << lz; }
-  top |= (rest != 0) ? 1u : 0u;       /* sticky bit: 64 > 53 + 2, so RNE(top) == RNE(exact) */
-  double d = (double)top;             /* in [2^63, 2^64] */
-  return d * cssm_pow2i(64 - lz);     /* exact power-of-two scaling, result < 2^128 */
+  const int zero = (a.hi | a.lo) == 0;
+  const int big = a.hi == 0;                       /* value fits the low word */
+  const uint64_t h2 = big ? a.lo : a.hi;
+  const uint64_t l2 = big ? 0 : a.lo;
+  const int lz = cssm_clz64(h2 | (uint64_t)zero);  /* 0..63 (h2 != 0 unless the value is 0) */
+  uint64_t top = (h2 << lz) | ((l2 >> 1) >> (63 - lz));
+  const uint64_t rest = l2 << lz;
+  top |= (rest != 0) ? 1u : 0u;
+  const double d = (double)top;                    /* in [2^63, 2^64] */
+  const double v = d * cssm_pow2i((big ? 0 : 64) - lz);
+  return zero ? 0.0 : v;
 }
 
 /* Same value scaled back to weight units (exact scaling by 2^-96). */
@@ -344,15 +389,29 @@ CSSM_HD double cssm_sys_grid(double u, uint64_t i, double nd) { return (u + (dou
  * with first-key-wins on equal cumulative weights.
  */
 CSSM_HD uint64_t cssm_sys_count(double C, double u, uint64_t n) {
-  double nd = (double)n;
-  double est = C * nd - u;
-  uint64_t c;
-  if (!(est > -1.0)) c = 0;
-  else if (est >= nd) c = n;
-  else c = (uint64_t)(long long)(est + 1.0);
-  if (c > n) c = n;
-  while (c < n && cssm_sys_grid(u, c, nd) <= C) ++c;
-  while (c > 0 && cssm_sys_grid(u, c - 1, nd) > C) --c;
+  const double nd = (double)n;
+  const uint32_t nn = (uint32_t)n;                 /* n < 2^32 */
+  const double est = C * nd - u;
+  uint32_t c = (est > -1.0) ? ((est >= nd) ? nn : (uint32_t)(est + 1.0)) : 0u;
+  c = (c > nn) ? nn : c;
+  while (c < nn && (u + (double)c) / nd <= C) ++c;
+  while (c > 0 && (u + (double)(c - 1)) / nd > C) --c;
+  return c;
+}
+
+/*
+ * The same count when n is a power of two: (u + i) / n == (u + i) * (1/n) bit for bit (scaling by a
+ * power of two is exact; u + i >= 0 and n < 2^32 keep the product normal or zero), so the
+ * division is replaced by a multiplication.  inv_n = 1.0 / n.
+ */
+CSSM_HD uint64_t cssm_sys_count_pow2(double C, double u, uint64_t n, double inv_n) {
+  const double nd = (double)n;
+  const uint32_t nn = (uint32_t)n;
+  const double est = C * nd - u;
+  uint32_t c = (est > -1.0) ? ((est >= nd) ? nn : (uint32_t)(est + 1.0)) : 0u;
+  c = (c > nn) ? nn : c;
+  while (c < nn && (u + (double)c) * inv_n <= C) ++c;
+  while (c > 0 && (u + (double)(c - 1)) * inv_n > C) --c;
   return c;
 }
 
