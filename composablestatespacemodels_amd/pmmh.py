@@ -1,0 +1,110 @@
+"""Host-side mirror of the reference's PMMH surface (model/PMMH.scala, model/MarkovChain.scala).
+
+The MCMC chain is sequential and stays on the host (BASELINE.json north star); each iteration's
+work is one native filter run.  Two entry points:
+
+* ``MetropolisHastings.pmmhState(initP, proposal, logTransition, prior)(pf)`` -- the generic
+  reference signature (PMMH.scala:161-167): ``pf`` is a ``BootstrapFilter`` (package.scala:24), i.e.
+  a callable ``params -> (ll, path)``; ``proposal(params, rng)`` draws a proposal.  Returns an
+  iterator of ``MetropState`` (the stream drops the initial state, PMMH.scala:97).
+* ``pmmh_native`` -- the wiring of examples/DetermineParameters.scala:58-80 (``perturb(delta)``
+  proposal, symmetric transition, flat prior) executed by ``cssm_pmmh_run`` inside the library with
+  the contract's Philox streams, so a CPU restatement reproduces the chain bit for bit.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from dataclasses import dataclass
+from typing import Callable, Iterator, Optional, Sequence, Tuple
+
+import numpy as np
+
+from . import _abi
+from .filter import NativePf, Resampling
+from .model import Parameters, UnparamModel, split_data
+
+
+@dataclass
+class MetropState:  # PMMH.scala:10-14
+    ll: float
+    params: Parameters
+    sde: object
+    accepted: int
+
+
+class ParametersProposal:
+    """``Parameters.perturb(delta)`` (Parameters.scala:65-67): independent Gaussian(theta_k, sqrt(delta))
+    on every stored scalar, scale included."""
+
+    def __init__(self, delta: float):
+        self.sd = math.sqrt(delta)
+
+    def __call__(self, p: Parameters, rng: np.random.Generator) -> Parameters:
+        theta = np.asarray(p.flattenParams())
+        return p.withFlat(theta + self.sd * rng.standard_normal(theta.size))
+
+
+class MetropolisHastings:
+    @staticmethod
+    def mhStep(s: MetropState, proposal, logTransition, prior, pf, rng) -> MetropState:
+        """PMMH.scala:68-81; the stored ll of the current state is reused, not re-estimated (:63-66)."""
+        prop = proposal(s.params, rng)
+        ll, path = pf(prop)
+        a = ll + logTransition(prop, s.params) + prior(prop) - logTransition(s.params, prop) - s.ll - prior(s.params)
+        u = rng.random()
+        if math.log(u) < a if u > 0.0 else True:
+            return MetropState(ll, prop, path[-1] if len(path) else None, s.accepted + 1)
+        return s
+
+    @staticmethod
+    def pmmhState(initP: Parameters, proposal, logTransition, prior):
+        def run(pf: Callable[[Parameters], Tuple[float, Sequence]], rng: Optional[np.random.Generator] = None,
+                iters: Optional[int] = None) -> Iterator[MetropState]:
+            rng = rng or np.random.default_rng()
+            s = MetropState(-1e99, initP, None, 0)      # PMMH.scala:121
+            k = 0
+            while iters is None or k < iters:
+                s = MetropolisHastings.mhStep(s, proposal, logTransition, prior, pf, rng)
+                k += 1
+                yield s
+        return run
+
+
+def bootstrap_filter(unparam: UnparamModel, data, n: int, seed: int = 20260101, device: int = 0):
+    """``Reader { p => Filter(model.run(p).get, resample).filter(data, n) }`` on one native handle
+    (examples/DetermineParameters.scala:70-72): re-parameterised per call, never re-allocated."""
+    t, y, h = split_data(data)
+    state = {"pf": None, "calls": 0}
+
+    def pf(p: Parameters):
+        model = unparam.run(p)
+        if state["pf"] is None:
+            state["pf"] = NativePf(model, n, seed, device)
+        else:
+            state["pf"].set_params(model)
+        state["pf"].reseed(seed + 1 + state["calls"])
+        state["calls"] += 1
+        ll, _, _, path = state["pf"].run(t, y, h, want_path=True)
+        return ll, path
+    return pf
+
+
+def pmmh_native(unparam: UnparamModel, init: Parameters, data, n: int, delta: float, iters: int,
+                seed: int = 20260101, device: int = 0):
+    """Returns (ll[iters], theta[iters, n_theta], accepted[iters], last_state[iters, d])."""
+    t, y, h = split_data(data)
+    model = unparam.run(init)
+    pf = NativePf(model, n, seed, device)
+    theta0 = np.ascontiguousarray(init.flattenParams(), dtype=np.float64)
+    nt = theta0.size
+    ll = np.zeros(iters); th = np.zeros((iters, nt)); acc = np.zeros(iters, dtype=np.int32); last = np.zeros((iters, pf.d))
+    dp = C.POINTER(C.c_double)
+    desc = model.descriptor()
+    rc = pf.lib.cssm_pmmh_run(pf._h, desc.ptr(), theta0.ctypes.data_as(dp), nt, float(delta), t.ctypes.data_as(dp),
+                              y.ctypes.data_as(dp), h.ctypes.data_as(C.POINTER(C.c_uint8)), len(t), int(seed), int(iters),
+                              ll.ctypes.data_as(dp), th.ctypes.data_as(dp), acc.ctypes.data_as(C.POINTER(C.c_int32)),
+                              last.ctypes.data_as(dp))
+    pf.close()
+    _abi.check(rc)
+    return ll, th, acc, last

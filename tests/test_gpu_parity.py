@@ -86,6 +86,67 @@ def test_batch_ll_filter_matches_oracle(name, n, T):
     g.close()
 
 
+@pytest.mark.parametrize("name", ["c1", "c2", "c3", "c4", "linear"])
+def test_gpu_reproduces_committed_golden_runs(name):
+    """tests/golden/oracle_runs.json was produced in the build container (tests/golden/make_golden.py)."""
+    import json, os
+    g = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "oracle_runs.json")))[name]
+    mk = {"c1": cases.c1_model, "c2": cases.c2_model, "c3": cases.c3_model, "c4": cases.c4_model, "linear": cases.linear_model}[name]
+    if name == "c4":
+        t, y, has = cases.event_times(g["T"])
+    elif name == "linear":
+        t, y, has = cases.gaussian_series(g["T"])
+    else:
+        t, y, has = cases.poisson_counts(g["T"], missing=g["missing"])
+    pf = NativePf(mk(), g["n"], cases.SEED, lgcp_precision=g["lgcp_precision"])
+    ll, ll_t, ess_t, path = pf.run(t, y, has, want_path=True)
+    assert ll == float.fromhex(g["ll"])
+    np.testing.assert_array_equal(ll_t, [float.fromhex(v) for v in g["ll_t"]])
+    np.testing.assert_array_equal(ess_t, g["ess_t"])
+    np.testing.assert_array_equal(pf.ancestors(), g["ancestors_last"])
+    np.testing.assert_array_equal(path, [[float.fromhex(v) for v in row] for row in g["path"]])
+    pf.close()
+
+
+def test_filter_interface_mirrors_the_reference():
+    """Filter(mod, resample).llFilter / filter / filterStream (ParticleFilter.scala:137-166)."""
+    from composablestatespacemodels_amd import Data
+    from composablestatespacemodels_amd.filter import Filter, ParticleFilter
+    model = cases.c2_model()
+    t, y, has = cases.poisson_counts(9, missing=0.2)
+    data = [Data(float(a), float(b) if h else None) for a, b, h in zip(t, y, has)]
+    o = oracle.OraclePf(model.descriptor(), 1000, cases.SEED)
+    oll, oll_t, oess, opath = o.filter(t, y, has, want_path=True)
+    f = Filter(model, Resampling.systematicResampling)
+    assert f.llFilter(data, 1000) == oll
+    ll, states = f.filter(data, 1000)
+    assert ll == oll and len(states) == len(data) + 1 and states[0].time == 0.0
+    np.testing.assert_array_equal(np.array([s.state for s in states]), opath)
+    assert ParticleFilter.likelihood(data, Resampling.systematicResampling, 1000)(model) == oll
+    # filterStream: Flow.scan emits the initial state, then one PfState per datum
+    out = list(f.filterStream(0.0, 1000)(iter(data)))
+    assert len(out) == len(data) + 1 and out[0].ll == 0.0 and out[0].ess == 1000 and out[0].observation is None
+    np.testing.assert_array_equal([s.ll for s in out[1:]], oll_t)
+    np.testing.assert_array_equal([s.ess for s in out[1:]], oess)
+    np.testing.assert_array_equal(out[-1].particles, o.particles())
+    with pytest.raises(RuntimeError):
+        out[0].particles    # an old PfState's cloud no longer exists on the device
+
+
+def test_filter_init_replicates_the_given_state():
+    from composablestatespacemodels_amd.filter import FilterInit
+    model = cases.c2_model()
+    f = FilterInit(model, Resampling.systematicResampling, [0.1, -0.2, 0.3])
+    s = f.initialiseState(500, 2.0)
+    np.testing.assert_array_equal(s.particles, np.tile(np.array([[0.1], [-0.2], [0.3]]), (1, 500)))
+    o = oracle.OraclePf(model.descriptor(), 500, 20260101)
+    o.init_from(2.0, [0.1, -0.2, 0.3])
+    s2 = f.stepFilter(s, __import__("composablestatespacemodels_amd").Data(3.0, 2.0))
+    oll, oess = o.step(3.0, 2.0)
+    assert (s2.ll, s2.ess) == (oll, oess)
+    np.testing.assert_array_equal(s2.particles, o.particles())
+
+
 def test_lgcp_batch_matches_oracle():
     model = cases.c4_model()
     t, y, has = cases.event_times(12)

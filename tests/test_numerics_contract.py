@@ -1,0 +1,100 @@
+"""The numerics contract (include/cssm_numerics.h) pinned on the CPU: Philox known answers,
+elementary functions against glibc/numpy, the fixed-point helpers and the systematic grid count."""
+import math
+
+import numpy as np
+import pytest
+
+from oracle import oracle
+
+
+def ulp_diff(a, b):
+    a = np.asarray(a, dtype=np.float64); b = np.asarray(b, dtype=np.float64)
+    ulp = np.abs(np.nextafter(b, np.inf) - b)
+    return np.abs(a - b) / ulp
+
+
+def test_philox4x32_10_known_answers():
+    # Random123 kat_vectors for philox4x32-10
+    kat = [([0, 0, 0, 0], [0, 0], [0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8]),
+           ([0xffffffff] * 4, [0xffffffff] * 2, [0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd]),
+           ([0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344], [0xa4093822, 0x299f31d0],
+            [0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1])]
+    for ctr, key, want in kat:
+        assert list(oracle.c_philox(ctr, key)) == want
+
+
+def test_exp_within_one_ulp_of_libm_and_edge_cases():
+    rng = np.random.default_rng(1)
+    x = np.concatenate([rng.uniform(-700, 700, 200000), rng.uniform(-50, 0, 200000), rng.normal(0, 1, 100000)])
+    assert ulp_diff(oracle.c_exp(x), np.exp(x)).max() <= 1.0
+    e = oracle.c_exp(np.array([0.0, -708.5, -1e300, 710.0, np.inf, -np.inf, np.nan]))
+    assert e[0] == 1.0 and e[1] == 0.0 and e[2] == 0.0 and e[3] == np.inf and e[4] == np.inf and e[5] == 0.0 and np.isnan(e[6])
+
+
+def test_log_within_one_ulp_of_libm_and_edge_cases():
+    rng = np.random.default_rng(2)
+    x = np.concatenate([np.exp(rng.uniform(-700, 700, 200000)), rng.random(300000) + 2.0**-53, [1.0, 0.5, 2.0**-53]])
+    assert ulp_diff(oracle.c_log(x), np.log(x)).max() <= 1.0
+    l = oracle.c_log(np.array([1.0, 0.0, -1.0, np.inf, np.nan, 5e-324]))
+    assert l[0] == 0.0 and l[1] == -np.inf and np.isnan(l[2]) and l[3] == np.inf and np.isnan(l[4])
+    assert abs(l[5] - math.log(5e-324)) < 1e-12
+
+
+def test_sincos2pi_accuracy_and_exact_points():
+    rng = np.random.default_rng(3)
+    u = rng.random(400000)
+    s, c = oracle.c_sincos2pi(u)
+    a = 2 * np.longdouble("3.14159265358979323846264338327950288") * u.astype(np.longdouble)
+    assert np.abs(s - np.sin(a).astype(np.float64)).max() < 2.3e-16
+    assert np.abs(c - np.cos(a).astype(np.float64)).max() < 2.3e-16
+    s, c = oracle.c_sincos2pi(np.array([0.0, 0.25, 0.5, 0.75, 0.125]))
+    np.testing.assert_array_equal(np.abs(s[:4]), [0, 1, 0, 1])
+    np.testing.assert_array_equal(np.abs(c[:4]), [1, 0, 1, 0])
+    assert s[1] == 1 and c[2] == -1 and s[3] == -1
+    assert abs(s[4] - math.sqrt(0.5)) < 2e-16 and abs(c[4] - math.sqrt(0.5)) < 2e-16
+
+
+def test_normal_pairs_are_standard_normal_and_keyed_by_counter():
+    z = oracle.c_normals(20260101, 0, 3, 0, 0, 0, 400000).ravel()
+    assert abs(z.mean()) < 5e-3 and abs(z.std() - 1) < 5e-3
+    assert abs(np.mean(z**3)) < 2e-2 and abs(np.mean(z**4) - 3) < 5e-2
+    # same counter -> same variate; particle id, step, tag, substep, pair all matter
+    base = oracle.c_normals(7, 100, 3, 0, 0, 0, 4)
+    np.testing.assert_array_equal(base, oracle.c_normals(7, 100, 3, 0, 0, 0, 4))
+    np.testing.assert_array_equal(base[2:], oracle.c_normals(7, 102, 3, 0, 0, 0, 2))  # global id, not local index
+    for other in (oracle.c_normals(8, 100, 3, 0, 0, 0, 4), oracle.c_normals(7, 100, 4, 0, 0, 0, 4),
+                  oracle.c_normals(7, 100, 3, 1, 0, 0, 4), oracle.c_normals(7, 100, 3, 0, 1, 0, 4),
+                  oracle.c_normals(7, 100, 3, 0, 0, 1, 4)):
+        assert not np.array_equal(base, other)
+
+
+def test_uniform_for_resampling_is_in_unit_interval():
+    u = np.array([oracle.lib().oracle_c_u(5, s) for s in range(2000)])
+    assert u.min() >= 0.0 and u.max() < 1.0 and abs(u.mean() - 0.5) < 0.03
+
+
+def test_lgamma_integer():
+    for k in list(range(0, 60)) + [255, 256, 1000, 123456]:
+        assert abs(oracle.lib().oracle_c_lgamma_kp1(k) - math.lgamma(k + 1.0)) <= 2e-14 * max(1.0, math.lgamma(k + 1.0))
+
+
+def test_fixed_point_roundtrip_and_truncation():
+    f = oracle.lib().oracle_c_fix_roundtrip
+    for w in (1.0, 0.5, 0.75, 2.0**-40, 2.0**-96, 1 - 2.0**-53, 0.1):
+        got = f(w)
+        assert got <= w and w - got < 2.0**-96
+    assert f(1.0) == 1.0 and f(2.0**-96) == 2.0**-96
+    assert f(2.0**-97) == 0.0 and f(0.0) == 0.0 and f(-1.0) == 0.0 and f(float("nan")) == 0.0 and f(float("inf")) == 0.0
+
+
+def test_sys_count_matches_brute_force():
+    rng = np.random.default_rng(4)
+    cnt = oracle.lib().oracle_c_sys_count
+    for _ in range(3000):
+        n = int(rng.integers(1, 400))
+        u = float(rng.random())
+        C = float(rng.random() * 1.001)
+        brute = sum(1 for i in range(n) if (u + i) / n <= C)
+        assert cnt(C, u, n) == brute
+    assert cnt(1.0, 0.999, 16) == 16 and cnt(0.0, 0.5, 16) == 0 and cnt(0.0, 0.0, 16) == 1

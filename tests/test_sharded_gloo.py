@@ -1,0 +1,77 @@
+"""World-size-2 (and 3) runs of the sharded-filter orchestration over gloo on CPU.
+
+The orchestration (composablestatespacemodels_amd/sharded.py: stage order, all-reduce / all-gather /
+all-to-all-v, split sizes) is the product's; the per-shard compute here is the test-only OracleShard
+backend.  The result must equal the single-rank oracle bit for bit -- ll, ess and every particle.
+"""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+import cases
+from oracle import oracle
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def _worker(rank, world, port, name, n, T, missing, prec, out_dir):
+    sys.path.insert(0, HERE)
+    sys.path.insert(0, os.path.dirname(HERE))
+    import cases as C
+    from composablestatespacemodels_amd.sharded import DistComm, ShardedFilter
+    from oracle_shard import OracleShard
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        model = getattr(C, name)()
+        if prec:
+            t, y, has = C.event_times(T)
+        else:
+            t, y, has = C.poisson_counts(T, missing=missing)
+        shard = OracleShard(model, n, rank, world, C.SEED, prec)
+        f = ShardedFilter([shard], DistComm())
+        ll, ess = f.ll_filter(t, y, has, lgcp=bool(prec))
+        np.savez(os.path.join(out_dir, f"r{rank}.npz"), ll=ll, ess=ess, part=shard.particles())
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,name,n,T,missing,prec", [
+    (2, "c2_model", 301, 7, 0.2, 0),
+    (3, "c1_model", 200, 6, 0.0, 0),
+    (2, "c4_model", 150, 4, 0.0, 2),
+])
+def test_sharded_orchestration_over_gloo_matches_single_rank(tmp_path, world, name, n, T, missing, prec):
+    port = 29600 + (os.getpid() % 300) + world
+    mp.spawn(_worker, args=(world, port, name, n, T, missing, prec, str(tmp_path)), nprocs=world, join=True)
+    model = getattr(cases, name)()
+    t, y, has = cases.event_times(T) if prec else cases.poisson_counts(T, missing=missing)
+    o = oracle.OraclePf(model.descriptor(prec), n, cases.SEED)
+    ll, _, ess_t, _ = o.filter(t, y, has)
+    parts = []
+    for r in range(world):
+        z = np.load(os.path.join(str(tmp_path), f"r{r}.npz"))
+        assert float(z["ll"]) == ll and int(z["ess"]) == int(ess_t[-1])
+        parts.append(z["part"])
+    np.testing.assert_array_equal(np.concatenate(parts, axis=1), o.particles())
+
+
+def test_local_comm_matches_single_rank_on_cpu():
+    """The single-process multi-shard emulation (LocalComm) used by the GPU tests, here with the oracle backend."""
+    from composablestatespacemodels_amd.sharded import LocalComm, ShardedFilter
+    from oracle_shard import OracleShard
+    model = cases.c2_model()
+    n, world = 257, 4
+    t, y, has = cases.poisson_counts(6, missing=0.2)
+    shards = [OracleShard(model, n, r, world, cases.SEED) for r in range(world)]
+    ll, ess = ShardedFilter(shards, LocalComm(world)).ll_filter(t, y, has)
+    o = oracle.OraclePf(model.descriptor(), n, cases.SEED)
+    oll, _, oess, _ = o.filter(t, y, has)
+    assert (ll, ess) == (oll, int(oess[-1]))
+    np.testing.assert_array_equal(np.concatenate([s.particles() for s in shards], axis=1), o.particles())
