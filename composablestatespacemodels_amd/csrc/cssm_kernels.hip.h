@@ -60,7 +60,9 @@ struct StepRec {
 #define CSSM_MAXSLOTS 64
 #define CSSM_SLOT_STRIDE 16 /* u64 words: one 128-byte line per slot */
 struct Scalars {
-  unsigned long long maxslot[CSSM_MAXSLOTS * CSSM_SLOT_STRIDE]; // sharded order keys of the running max log-weight
+  // Order keys of the running max log-weight, sharded over CSSM_MAXSLOTS cache lines, in two sets:
+  // weighted step s uses set s&1, and its last kernel clears the other set for step s+1.
+  unsigned long long maxslot[2 * CSSM_MAXSLOTS * CSSM_SLOT_STRIDE];
   uint32_t err;              // bit0: NaN log-weight, bit1: all weights zero / max not finite
   int32_t ess;
   double gmax;               // decoded global max of this step
@@ -193,16 +195,35 @@ __global__ void k_init_from(double* __restrict__ dst, size_t stride, uint64_t n,
 
 // ------------------------------------------------------------------------------------ propagate + weight
 
+// Block-cooperative decode of the sharded running max: lane t of wave 0 reads slot t (one load
+// latency instead of 64), wave max, broadcast through LDS.  All threads of the block must call it.
+__device__ __forceinline__ double block_decode_slots(const Scalars* __restrict__ sc, int set) {
+  __shared__ unsigned long long s_key;
+  if (threadIdx.x < 64) {
+    unsigned long long k = (threadIdx.x < CSSM_MAXSLOTS)
+        ? sc->maxslot[((size_t)set * CSSM_MAXSLOTS + threadIdx.x) * CSSM_SLOT_STRIDE] : 0ull;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      const unsigned long long o = __shfl_xor(k, off, 64);
+      k = (o > k) ? o : k;
+    }
+    if (threadIdx.x == 0) s_key = k;
+  }
+  __syncthreads();
+  return cssm_order_unkey(s_key);
+}
+
 // Particles per thread in k_propagate: all gathers of a thread are issued before its ALU work,
 // and rows are stored as 16-/32-byte vectors.
 template <int D> struct PropItems { static constexpr int value = (D <= 4) ? 4 : (D <= 8 ? 2 : 1); };
 
 // max over the CSSM_MAXSLOTS shards of the running max log-weight
-__device__ __forceinline__ double decode_slots(const Scalars* __restrict__ sc) {
+__device__ __forceinline__ double decode_slots(const Scalars* __restrict__ sc, int set) {
   unsigned long long k = 0ull;
+  const unsigned long long* base = sc->maxslot + (size_t)set * CSSM_MAXSLOTS * CSSM_SLOT_STRIDE;
 #pragma unroll 8
   for (int s = 0; s < CSSM_MAXSLOTS; ++s) {
-    const unsigned long long v = sc->maxslot[s * CSSM_SLOT_STRIDE];
+    const unsigned long long v = base[s * CSSM_SLOT_STRIDE];
     k = (v > k) ? v : k;
   }
   return cssm_order_unkey(k);
@@ -215,7 +236,7 @@ template <int D, bool LGCP, int IT>
 __global__ __launch_bounds__(CSSM_BLOCK) void k_propagate(
     const double* __restrict__ src, size_t src_stride, const uint32_t* __restrict__ anc,
     double* __restrict__ dst, size_t dst_stride, double* __restrict__ logw, uint64_t n, uint64_t gid0,
-    uint64_t seed, const StepRec* __restrict__ rec, ModelK mk, Scalars* __restrict__ sc) {
+    uint64_t seed, const StepRec* __restrict__ rec, ModelK mk, Scalars* __restrict__ sc, int slot_set) {
   __shared__ double s_max[CSSM_BLOCK / 64];
   const uint32_t step = rec->step;
   const int has_obs = rec->has_obs;
@@ -316,7 +337,8 @@ __global__ __launch_bounds__(CSSM_BLOCK) void k_propagate(
     for (int w = 1; w < CSSM_BLOCK / 64; ++w) m = (s_max[w] > m) ? s_max[w] : m;
     // one integer atomicMax per block, spread over CSSM_MAXSLOTS cache lines: same-address atomics
     // serialise at ~12 ns each, which at thousands of blocks would cost more than the kernel
-    atomicMax(&sc->maxslot[(blockIdx.x % CSSM_MAXSLOTS) * CSSM_SLOT_STRIDE], (unsigned long long)cssm_order_key(m));
+    atomicMax(&sc->maxslot[((size_t)slot_set * CSSM_MAXSLOTS + blockIdx.x % CSSM_MAXSLOTS) * CSSM_SLOT_STRIDE],
+              (unsigned long long)cssm_order_key(m));
   }
 }
 
@@ -346,9 +368,9 @@ __device__ __forceinline__ void load_tile_weights(const double* __restrict__ log
 __global__ __launch_bounds__(CSSM_BLOCK) void k_tile_sums(const double* __restrict__ logw, uint64_t n,
                                                           const Scalars* __restrict__ sc,
                                                           cssm_u128* __restrict__ unitS, cssm_u128* __restrict__ unitS2,
-                                                          uint32_t ntiles, uint32_t sup, uint32_t nunits, int raw, int from_slots) {
+                                                          uint32_t ntiles, uint32_t sup, uint32_t nunits, int raw, int slot_set) {
   __shared__ cssm_u128 s_a[CSSM_BLOCK / 64], s_b[CSSM_BLOCK / 64];
-  const double gmax = from_slots ? decode_slots(sc) : sc->gmax;
+  const double gmax = (slot_set >= 0) ? block_decode_slots(sc, slot_set) : sc->gmax;   // slot_set < 0: gmax was imported
   for (uint32_t unit = blockIdx.x; unit < nunits; unit += gridDim.x) {
     const uint32_t t0 = unit * sup;
     const uint32_t t1 = (t0 + sup < ntiles) ? t0 + sup : ntiles;
@@ -394,15 +416,10 @@ __device__ void finish_step(Scalars* sc, uint64_t n_global) {
 // scan of the 1024 chunk sums, then prefix write-back); local totals; with `single` also ll / ess.
 __global__ __launch_bounds__(1024) void k_scan_tiles(const cssm_u128* __restrict__ tileS, const cssm_u128* __restrict__ tileS2,
                                                      cssm_u128* __restrict__ tileP, uint32_t ntiles, Scalars* sc,
-                                                     uint64_t n_global, int single, int from_slots,
+                                                     uint64_t n_global, int single,
                                                      double* __restrict__ ll_t, int32_t* __restrict__ ess_t, uint32_t rec_idx) {
   __shared__ cssm_u128 s_w[16], s_w2[16];
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-  if (from_slots) {   // every k_tile_sums block has decoded the slots already (previous kernel): publish and reset
-    if (threadIdx.x == 0) sc->gmax = decode_slots(sc);
-    __syncthreads();
-    if (threadIdx.x < CSSM_MAXSLOTS) sc->maxslot[threadIdx.x * CSSM_SLOT_STRIDE] = 0ull;
-  }
   const uint32_t chunk = (ntiles + 1023u) / 1024u;
   const uint32_t t0 = threadIdx.x * chunk;
   const uint32_t t1 = (t0 + chunk < ntiles) ? t0 + chunk : ntiles;
@@ -456,28 +473,63 @@ __global__ void k_global_sums(const unsigned long long* __restrict__ all4, int r
 // [end_{j-1}, end_j) <- j (runs longer than CSSM_RUN_DIRECT are written by the whole block), so on a
 // single GPU the end slots never travel through HBM.  Otherwise the end slots are stored for the
 // exchange of the sharded filter.  A block walks the tiles of one unit with a running prefix.
-template <bool FUSE>
+// SELF (single GPU): there is no scan kernel.  Every block sums the <= ~1K unit totals itself (integer
+// sums: every block gets the same bits), block 0 publishes max / totals / ll / ess and clears the
+// other max-slot set for the next weighted step.
+template <bool FUSE, bool SELF>
 __global__ __launch_bounds__(CSSM_BLOCK) void k_offspring(const double* __restrict__ logw, uint64_t n,
-                                                          const Scalars* __restrict__ sc,
-                                                          const cssm_u128* __restrict__ unitP,
+                                                          Scalars* __restrict__ sc,
+                                                          const cssm_u128* __restrict__ unitP, const cssm_u128* __restrict__ unitS2,
                                                           const StepRec* __restrict__ rec, uint64_t n_global,
                                                           uint32_t* __restrict__ endslot, uint32_t* __restrict__ anc,
-                                                          uint32_t ntiles, uint32_t sup, uint32_t nunits, int raw) {
+                                                          uint32_t ntiles, uint32_t sup, uint32_t nunits, int raw, int slot_set,
+                                                          double* __restrict__ ll_t, int32_t* __restrict__ ess_t, uint32_t rec_idx) {
   __shared__ cssm_u128 s_w[CSSM_BLOCK / 64];
   __shared__ uint32_t s_last[CSSM_BLOCK / 64];
   __shared__ uint32_t s_nheavy;
   __shared__ uint32_t s_hb[FUSE ? CSSM_TILE : 1], s_he[FUSE ? CSSM_TILE : 1], s_hj[FUSE ? CSSM_TILE : 1];
-  const double gmax = sc->gmax;
+  __shared__ cssm_u128 s_r[3][CSSM_BLOCK / 64];
+  const double gmax = SELF ? block_decode_slots(sc, slot_set) : sc->gmax;
   const double u = rec->u;
-  const double totd = cssm_u128_to_double(sc->S_tot);
-  const cssm_u128 S_off = sc->S_off;
   const bool pow2 = (n_global & (n_global - 1)) == 0;
   const double inv_n = 1.0 / (double)n_global;
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  double totd = SELF ? 0.0 : cssm_u128_to_double(sc->S_tot);
+  const cssm_u128 S_off = SELF ? cssm_u128_zero() : sc->S_off;
   for (uint32_t unit = blockIdx.x; unit < nunits; unit += gridDim.x) {
     const uint32_t t0 = unit * sup;
     const uint32_t t1 = (t0 + sup < ntiles) ? t0 + sup : ntiles;
-    cssm_u128 toff = cssm_u128_add(S_off, unitP[unit]);   // cumulative weight before the current tile
+    cssm_u128 toff;                                        // cumulative weight before the current tile
+    if (SELF) {                                            // here unitP holds the unit SUMS (k_tile_sums output)
+      cssm_u128 pre = cssm_u128_zero(), tot = cssm_u128_zero(), tot2 = cssm_u128_zero();
+      for (uint32_t q = threadIdx.x; q < nunits; q += CSSM_BLOCK) {
+        const cssm_u128 v = unitP[q];
+        if (q < unit) pre = cssm_u128_add(pre, v);
+        tot = cssm_u128_add(tot, v);
+        tot2 = cssm_u128_add(tot2, unitS2[q]);
+      }
+      pre = wave_sum_u128(pre); tot = wave_sum_u128(tot); tot2 = wave_sum_u128(tot2);
+      if (lane == 0) { s_r[0][wid] = pre; s_r[1][wid] = tot; s_r[2][wid] = tot2; }
+      __syncthreads();
+      pre = s_r[0][0]; tot = s_r[1][0]; tot2 = s_r[2][0];
+#pragma unroll
+      for (int w = 1; w < CSSM_BLOCK / 64; ++w) {
+        pre = cssm_u128_add(pre, s_r[0][w]); tot = cssm_u128_add(tot, s_r[1][w]); tot2 = cssm_u128_add(tot2, s_r[2][w]);
+      }
+      toff = pre;
+      totd = cssm_u128_to_double(tot);
+      if (unit == 0 && threadIdx.x == 0) {                 // publish the step's scalars once
+        sc->gmax = gmax; sc->S_off = cssm_u128_zero(); sc->S_local = tot; sc->S2_local = tot2;
+        sc->S_tot = tot; sc->S2_tot = tot2;
+        finish_step(sc, n_global);
+        if (ll_t) { ll_t[rec_idx] = sc->ll; ess_t[rec_idx] = sc->ess; }
+      }
+      if (unit == 0 && threadIdx.x < CSSM_MAXSLOTS)
+        sc->maxslot[((size_t)(slot_set ^ 1) * CSSM_MAXSLOTS + threadIdx.x) * CSSM_SLOT_STRIDE] = 0ull;
+      __syncthreads();
+    } else {
+      toff = cssm_u128_add(S_off, unitP[unit]);
+    }
     for (uint32_t tile = t0; tile < t1; ++tile) {
       const uint64_t base = (uint64_t)tile * CSSM_TILE;
       double w1[CSSM_ITEMS];

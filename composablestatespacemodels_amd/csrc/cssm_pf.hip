@@ -67,6 +67,7 @@ struct cssm_pf {
   uint32_t* endslot = nullptr;
   uint32_t* anc = nullptr;
   bool anc_valid = false;
+  int wparity = 0;             // max-slot set of the next weighted step (single-GPU path)
   cssm_u128 *tileS = nullptr, *tileS2 = nullptr, *tileP = nullptr;
   Scalars* sc = nullptr;
   double *d_m0 = nullptr, *d_sd0 = nullptr;
@@ -402,7 +403,7 @@ static int launch_init(cssm_pf* pf, double t0) {
   int rc = reset_scalars(pf);
   if (rc) return rc;
   pf->cur = 0; pf->src = pf->state[0]; pf->src_stride = pf->stride; pf->anc_valid = false;
-  pf->t = t0; pf->step = 0; pf->initialised = true;
+  pf->t = t0; pf->step = 0; pf->initialised = true; pf->wparity = 0;
   return CSSM_OK;
 }
 
@@ -416,10 +417,12 @@ static int launch_propagate(cssm_pf* pf, const StepRec* d_rec) {
   prof_begin(pf, CSSM_K_PROPAGATE);
   if (pf->obs_kind == CSSM_OBS_LGCP) {
     DISPATCH_D(pf->d, k_propagate<D, true, PropItems<D>::value><<<dim3(grid), dim3(CSSM_BLOCK), 0, pf->stream>>>(
-                          pf->src, pf->src_stride, anc, dst, pf->stride, pf->logw, pf->n, pf->first, pf->seed, d_rec, pf->mk, pf->sc));
+                          pf->src, pf->src_stride, anc, dst, pf->stride, pf->logw, pf->n, pf->first, pf->seed, d_rec, pf->mk, pf->sc,
+                          pf->sharded ? 0 : pf->wparity));
   } else {
     DISPATCH_D(pf->d, k_propagate<D, false, PropItems<D>::value><<<dim3(grid), dim3(CSSM_BLOCK), 0, pf->stream>>>(
-                          pf->src, pf->src_stride, anc, dst, pf->stride, pf->logw, pf->n, pf->first, pf->seed, d_rec, pf->mk, pf->sc));
+                          pf->src, pf->src_stride, anc, dst, pf->stride, pf->logw, pf->n, pf->first, pf->seed, d_rec, pf->mk, pf->sc,
+                          pf->sharded ? 0 : pf->wparity));
   }
   prof_end(pf);
   HIP_TRY(hipGetLastError());
@@ -433,16 +436,14 @@ static int launch_resample(cssm_pf* pf, const StepRec* d_rec, double* ll_t = nul
   const int tgrid = (int)pf->nunits;
   prof_begin(pf, CSSM_K_TILE_SUMS);
   hipLaunchKernelGGL(k_tile_sums, dim3(tgrid), dim3(CSSM_BLOCK), 0, pf->stream, pf->logw, pf->n, pf->sc, pf->tileS, pf->tileS2, pf->ntiles,
-                     pf->sup, pf->nunits, 0, 1);
+                     pf->sup, pf->nunits, 0, pf->wparity);
   prof_end(pf);
-  prof_begin(pf, CSSM_K_SCAN_TILES);
-  hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(1024), 0, pf->stream, pf->tileS, pf->tileS2, pf->tileP, pf->nunits, pf->sc, pf->n_global, 1, 1,
-                     ll_t, ess_t, rec_idx);
+  prof_begin(pf, CSSM_K_OFFSPRING);   // unit prefix, ll/ess, end slots and their expansion to ancestors in one kernel
+  hipLaunchKernelGGL((k_offspring<true, true>), dim3(tgrid), dim3(CSSM_BLOCK), 0, pf->stream, pf->logw, pf->n, pf->sc,
+                     (const cssm_u128*)pf->tileS, (const cssm_u128*)pf->tileS2, d_rec, pf->n_global, pf->endslot, pf->anc, pf->ntiles,
+                     pf->sup, pf->nunits, 0, pf->wparity, ll_t, ess_t, rec_idx);
   prof_end(pf);
-  prof_begin(pf, CSSM_K_OFFSPRING);   // end slots and their expansion to ancestors in one kernel
-  hipLaunchKernelGGL(k_offspring<true>, dim3(tgrid), dim3(CSSM_BLOCK), 0, pf->stream, pf->logw, pf->n, pf->sc, pf->tileP, d_rec, pf->n_global,
-                     pf->endslot, pf->anc, pf->ntiles, pf->sup, pf->nunits, 0);
-  prof_end(pf);
+  pf->wparity ^= 1;
   HIP_TRY(hipGetLastError());
   pf->anc_valid = true;
   return CSSM_OK;
@@ -506,7 +507,7 @@ extern "C" int cssm_pf_init_from(cssm_pf* pf, double t0, const double* state_d) 
   rc = upload_init_params(pf);   // d_m0 was used as scratch
   if (rc) return rc;
   pf->cur = 0; pf->src = pf->state[0]; pf->src_stride = pf->stride; pf->anc_valid = false;
-  pf->t = t0; pf->step = 0; pf->initialised = true;
+  pf->t = t0; pf->step = 0; pf->initialised = true; pf->wparity = 0;
   return CSSM_OK;
 }
 
@@ -688,9 +689,10 @@ extern "C" int cssm_resample_systematic(const double* w, size_t n, double u, uin
   RS_TRY(hipMemcpyAsync(d_rec, &hrec, sizeof hrec, hipMemcpyHostToDevice, st));
   {
     const int tgrid = (int)nunits;
-    hipLaunchKernelGGL(k_tile_sums, dim3(tgrid), dim3(CSSM_BLOCK), 0, st, d_w, (uint64_t)n, sc, tS, tS2, ntiles, sup, nunits, 1, 0);
-    hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(1024), 0, st, tS, tS2, tP, nunits, sc, (uint64_t)n, 1, 0, (double*)nullptr, (int32_t*)nullptr, 0u);
-    hipLaunchKernelGGL(k_offspring<true>, dim3(tgrid), dim3(CSSM_BLOCK), 0, st, d_w, (uint64_t)n, sc, tP, d_rec, (uint64_t)n, d_end, d_anc, ntiles, sup, nunits, 1);
+    hipLaunchKernelGGL(k_tile_sums, dim3(tgrid), dim3(CSSM_BLOCK), 0, st, d_w, (uint64_t)n, sc, tS, tS2, ntiles, sup, nunits, 1, -1);
+    hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(1024), 0, st, tS, tS2, tP, nunits, sc, (uint64_t)n, 1, (double*)nullptr, (int32_t*)nullptr, 0u);
+    hipLaunchKernelGGL((k_offspring<true, false>), dim3(tgrid), dim3(CSSM_BLOCK), 0, st, d_w, (uint64_t)n, sc, (const cssm_u128*)tP,
+                       (const cssm_u128*)tS2, d_rec, (uint64_t)n, d_end, d_anc, ntiles, sup, nunits, 1, 0, (double*)nullptr, (int32_t*)nullptr, 0u);
   }
   RS_TRY(hipGetLastError());
   RS_TRY(hipMemcpyAsync(&hs, sc, sizeof hs, hipMemcpyDeviceToHost, st));
@@ -709,9 +711,9 @@ done:
 // One process per GPU; the collectives between the stages belong to the caller (RCCL through
 // torch.distributed).  See include/cssm_pf.h for the sequence.
 
-__global__ void k_export_max(Scalars* sc, double* out) {   // <<<1, CSSM_MAXSLOTS>>>
+__global__ void k_export_max(Scalars* sc, double* out) {   // <<<1, CSSM_MAXSLOTS>>>; the sharded path uses slot set 0 only
   __shared__ double s_m;
-  if (threadIdx.x == 0) s_m = decode_slots(sc);
+  if (threadIdx.x == 0) s_m = decode_slots(sc, 0);
   __syncthreads();
   sc->maxslot[threadIdx.x * CSSM_SLOT_STRIDE] = 0ull;
   if (threadIdx.x == 0) *out = s_m;
@@ -808,8 +810,8 @@ extern "C" int cssm_pf_shard_sums(cssm_pf* pf, const double* global_max_dev, uin
   const int tgrid = (int)pf->nunits;
   hipLaunchKernelGGL(k_import_max, dim3(1), dim3(1), 0, pf->stream, pf->sc, global_max_dev);
   hipLaunchKernelGGL(k_tile_sums, dim3(tgrid), dim3(CSSM_BLOCK), 0, pf->stream, pf->logw, pf->n, pf->sc, pf->tileS, pf->tileS2, pf->ntiles,
-                     pf->sup, pf->nunits, 0, 0);
-  hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(1024), 0, pf->stream, pf->tileS, pf->tileS2, pf->tileP, pf->nunits, pf->sc, pf->n_global, 0, 0,
+                     pf->sup, pf->nunits, 0, -1);
+  hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(1024), 0, pf->stream, pf->tileS, pf->tileS2, pf->tileP, pf->nunits, pf->sc, pf->n_global, 0,
                      (double*)nullptr, (int32_t*)nullptr, 0u);
   hipLaunchKernelGGL(k_export_sums, dim3(1), dim3(1), 0, pf->stream, pf->sc, (unsigned long long*)sums4_dev);
   HIP_TRY(hipGetLastError());
@@ -828,8 +830,9 @@ extern "C" int cssm_pf_shard_offspring(cssm_pf* pf, const uint64_t* all_sums4_de
   const size_t slot = (pf->step - 1) % 64;   // record of the step propagated last
   const int tgrid = (int)pf->nunits;
   hipLaunchKernelGGL(k_global_sums, dim3(1), dim3(1), 0, pf->stream, (const unsigned long long*)all_sums4_dev, rank, world, pf->sc, pf->n_global);
-  hipLaunchKernelGGL(k_offspring<false>, dim3(tgrid), dim3(CSSM_BLOCK), 0, pf->stream, pf->logw, pf->n, pf->sc, pf->tileP, pf->d_recs + slot,
-                     pf->n_global, pf->endslot, (uint32_t*)nullptr, pf->ntiles, pf->sup, pf->nunits, 0);
+  hipLaunchKernelGGL((k_offspring<false, false>), dim3(tgrid), dim3(CSSM_BLOCK), 0, pf->stream, pf->logw, pf->n, pf->sc,
+                     (const cssm_u128*)pf->tileP, (const cssm_u128*)pf->tileS2, pf->d_recs + slot, pf->n_global, pf->endslot,
+                     (uint32_t*)nullptr, pf->ntiles, pf->sup, pf->nunits, 0, 0, (double*)nullptr, (int32_t*)nullptr, 0u);
   hipLaunchKernelGGL(k_send_ranges, dim3(1), dim3(64), 0, pf->stream, pf->endslot, pf->n, pf->sc, pf->d_recs + slot, pf->n_global, rank, world,
                      n_per, (long long*)send_first_dev, (long long*)send_count_dev);
   HIP_TRY(hipGetLastError());
