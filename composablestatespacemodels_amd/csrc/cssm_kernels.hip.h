@@ -483,7 +483,8 @@ __global__ __launch_bounds__(CSSM_BLOCK) void k_offspring(const double* __restri
                                                           const StepRec* __restrict__ rec, uint64_t n_global,
                                                           uint32_t* __restrict__ endslot, uint32_t* __restrict__ anc,
                                                           uint32_t ntiles, uint32_t sup, uint32_t nunits, int raw, int slot_set,
-                                                          double* __restrict__ ll_t, int32_t* __restrict__ ess_t, uint32_t rec_idx) {
+                                                          double* __restrict__ ll_t, int32_t* __restrict__ ess_t, uint32_t rec_idx,
+                                                          int force_exact) {
   __shared__ cssm_u128 s_w[CSSM_BLOCK / 64];
   __shared__ uint32_t s_last[CSSM_BLOCK / 64];
   __shared__ uint32_t s_nheavy;
@@ -547,12 +548,32 @@ __global__ __launch_bounds__(CSSM_BLOCK) void k_offspring(const double* __restri
       // exclusive prefix of this thread = off + inc - tsum
       cssm_u128 run = cssm_u128_add(off, inc);
       { cssm_u128 r; r.lo = run.lo - tsum.lo; r.hi = run.hi - tsum.hi - (run.lo < tsum.lo ? 1u : 0u); run = r; }
+      // End slot of a particle = cnt(C_j) of the contract.  Fast path: p = S_j/S_tot*N - u evaluated in
+      // fp64 has an absolute error < N*2^-49.5 slots (two conversions, one quotient, one fma), and the
+      // contract's own roundings move a decision by < N*2^-51 slots; whenever p is farther than
+      // eps = N*2^-46 from an integer, floor(p)+1 IS the contract's count.  Otherwise (probability
+      // 2*eps per particle) the exact predicate is evaluated.
+      const double nd = (double)n_global;
+      const double scale = nd / totd;
+      const double eps = nd * 0x1.0p-46;
       uint32_t e[CSSM_ITEMS];
 #pragma unroll
       for (int r = 0; r < CSSM_ITEMS; ++r) {
         run = cssm_u128_add(run, q[r]);
-        const double C = cssm_u128_to_double(run) / totd;
-        e[r] = (uint32_t)(pow2 ? cssm_sys_count_pow2(C, u, n_global, inv_n) : cssm_sys_count(C, u, n_global));
+        const double sd = cssm_fma((double)run.hi, 0x1.0p64, (double)run.lo);
+        const double pp = cssm_fma(sd, scale, -u);
+        const double fl = __builtin_floor(pp);
+        const double fr = pp - fl;
+        double cnt = fl + 1.0;
+        cnt = (cnt < 0.0) ? 0.0 : cnt;
+        cnt = (cnt > nd) ? nd : cnt;
+        const bool safe = (fr > eps) && (fr < 1.0 - eps) && !force_exact;
+        if (safe) {
+          e[r] = (uint32_t)cnt;
+        } else {
+          const double C = cssm_u128_to_double(run) / totd;
+          e[r] = (uint32_t)(pow2 ? cssm_sys_count_pow2(C, u, n_global, inv_n) : cssm_sys_count(C, u, n_global));
+        }
       }
       const uint64_t i0 = base + (uint64_t)threadIdx.x * CSSM_ITEMS;
       if (!FUSE) {

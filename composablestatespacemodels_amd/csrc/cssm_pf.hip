@@ -68,6 +68,7 @@ struct cssm_pf {
   uint32_t* anc = nullptr;
   bool anc_valid = false;
   int wparity = 0;             // max-slot set of the next weighted step (single-GPU path)
+  int opt_exact = 0;           // CSSM_OPT_EXACT_OFFSPRING
   cssm_u128 *tileS = nullptr, *tileS2 = nullptr, *tileP = nullptr;
   Scalars* sc = nullptr;
   double *d_m0 = nullptr, *d_sd0 = nullptr;
@@ -441,7 +442,7 @@ static int launch_resample(cssm_pf* pf, const StepRec* d_rec, double* ll_t = nul
   prof_begin(pf, CSSM_K_OFFSPRING);   // unit prefix, ll/ess, end slots and their expansion to ancestors in one kernel
   hipLaunchKernelGGL((k_offspring<true, true>), dim3(tgrid), dim3(CSSM_BLOCK), 0, pf->stream, pf->logw, pf->n, pf->sc,
                      (const cssm_u128*)pf->tileS, (const cssm_u128*)pf->tileS2, d_rec, pf->n_global, pf->endslot, pf->anc, pf->ntiles,
-                     pf->sup, pf->nunits, 0, pf->wparity, ll_t, ess_t, rec_idx);
+                     pf->sup, pf->nunits, 0, pf->wparity, ll_t, ess_t, rec_idx, pf->opt_exact);
   prof_end(pf);
   pf->wparity ^= 1;
   HIP_TRY(hipGetLastError());
@@ -604,6 +605,12 @@ extern "C" int cssm_pf_last_loop_ms(cssm_pf* pf, float* ms_out) {
   return CSSM_OK;
 }
 
+extern "C" int cssm_pf_set_option(cssm_pf* pf, int option, int value) {
+  if (!pf) return fail(CSSM_EINVAL_ARG, "null handle");
+  if (option == CSSM_OPT_EXACT_OFFSPRING) { pf->opt_exact = value ? 1 : 0; return CSSM_OK; }
+  return fail(CSSM_EINVAL_ARG, "unknown option %d", option);
+}
+
 extern "C" int cssm_pf_profile(cssm_pf* pf, int enable) {
   if (!pf) return fail(CSSM_EINVAL_ARG, "null handle");
   pf->profile = enable != 0;
@@ -692,7 +699,7 @@ extern "C" int cssm_resample_systematic(const double* w, size_t n, double u, uin
     hipLaunchKernelGGL(k_tile_sums, dim3(tgrid), dim3(CSSM_BLOCK), 0, st, d_w, (uint64_t)n, sc, tS, tS2, ntiles, sup, nunits, 1, -1);
     hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(1024), 0, st, tS, tS2, tP, nunits, sc, (uint64_t)n, 1, (double*)nullptr, (int32_t*)nullptr, 0u);
     hipLaunchKernelGGL((k_offspring<true, false>), dim3(tgrid), dim3(CSSM_BLOCK), 0, st, d_w, (uint64_t)n, sc, (const cssm_u128*)tP,
-                       (const cssm_u128*)tS2, d_rec, (uint64_t)n, d_end, d_anc, ntiles, sup, nunits, 1, 0, (double*)nullptr, (int32_t*)nullptr, 0u);
+                       (const cssm_u128*)tS2, d_rec, (uint64_t)n, d_end, d_anc, ntiles, sup, nunits, 1, 0, (double*)nullptr, (int32_t*)nullptr, 0u, 0);
   }
   RS_TRY(hipGetLastError());
   RS_TRY(hipMemcpyAsync(&hs, sc, sizeof hs, hipMemcpyDeviceToHost, st));
@@ -832,7 +839,7 @@ extern "C" int cssm_pf_shard_offspring(cssm_pf* pf, const uint64_t* all_sums4_de
   hipLaunchKernelGGL(k_global_sums, dim3(1), dim3(1), 0, pf->stream, (const unsigned long long*)all_sums4_dev, rank, world, pf->sc, pf->n_global);
   hipLaunchKernelGGL((k_offspring<false, false>), dim3(tgrid), dim3(CSSM_BLOCK), 0, pf->stream, pf->logw, pf->n, pf->sc,
                      (const cssm_u128*)pf->tileP, (const cssm_u128*)pf->tileS2, pf->d_recs + slot, pf->n_global, pf->endslot,
-                     (uint32_t*)nullptr, pf->ntiles, pf->sup, pf->nunits, 0, 0, (double*)nullptr, (int32_t*)nullptr, 0u);
+                     (uint32_t*)nullptr, pf->ntiles, pf->sup, pf->nunits, 0, 0, (double*)nullptr, (int32_t*)nullptr, 0u, pf->opt_exact);
   hipLaunchKernelGGL(k_send_ranges, dim3(1), dim3(64), 0, pf->stream, pf->endslot, pf->n, pf->sc, pf->d_recs + slot, pf->n_global, rank, world,
                      n_per, (long long*)send_first_dev, (long long*)send_count_dev);
   HIP_TRY(hipGetLastError());

@@ -116,6 +116,9 @@ class NativePf:
 
     KERNELS = ("k_propagate", "k_decode_max", "k_tile_sums", "k_scan_tiles", "k_offspring", "k_expand")
 
+    def set_option(self, option: int, value: int):
+        _abi.check(self.lib.cssm_pf_set_option(self._h, int(option), int(value)))
+
     def profile(self, enable: bool):
         _abi.check(self.lib.cssm_pf_profile(self._h, 1 if enable else 0))
 

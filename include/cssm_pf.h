@@ -162,6 +162,12 @@ int cssm_pf_filter(cssm_pf* pf, const double* t, const double* y, const uint8_t*
  * handle's stream around the T steps, init excluded), in milliseconds. */
 int cssm_pf_last_loop_ms(cssm_pf* pf, float* ms_out);
 
+/* Debug/verification options.  CSSM_OPT_EXACT_OFFSPRING = 1 makes the offspring kernel evaluate the
+ * contract's exact predicate for every particle instead of only where its fp64 position estimate is
+ * within the error band of a slot boundary; results are identical by construction (tests compare). */
+#define CSSM_OPT_EXACT_OFFSPRING 1
+int cssm_pf_set_option(cssm_pf* pf, int option, int value);
+
 /* Per-kernel device time, measured with HIP events recorded on the handle's stream directly
  * before and after every kernel launch of the batch loop (bench.py's `roofline` figure).
  * Enabling it inserts event records between kernels, so whole-loop throughput is measured with

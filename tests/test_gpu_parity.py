@@ -202,6 +202,22 @@ def test_full_size_c2_agrees_with_oracle_and_properties():
     g.close()
 
 
+def test_offspring_fast_path_equals_forced_exact_path():
+    """k_offspring decides most end slots from an fp64 position estimate; forcing the exact contract
+    predicate everywhere must give the same ancestors (and both equal the oracle)."""
+    model = cases.c2_model()
+    t, y, has = cases.poisson_counts(10)
+    for n in (5000, 1 << 18):
+        a = NativePf(model, n, cases.SEED); b = NativePf(model, n, cases.SEED)
+        b.set_option(1, 1)
+        ra = a.run(t, y, has); rb = b.run(t, y, has)
+        assert ra[0] == rb[0]
+        np.testing.assert_array_equal(ra[2], rb[2])
+        np.testing.assert_array_equal(a.ancestors(), b.ancestors())
+        np.testing.assert_array_equal(a.particles(), b.particles())
+        a.close(); b.close()
+
+
 def test_errors_are_reported_not_swallowed():
     from composablestatespacemodels_amd import CssmError
     model = cases.linear_model()
