@@ -346,10 +346,9 @@ __global__ __launch_bounds__(CSSM_BLOCK) void k_propagate(
 
 // raw != 0: `logw` already holds the weights w1 themselves (stateless Resample[A] entry point,
 // whose second argument is w1 = exp(w - max): model/ParticleFilter.scala:125-126).
-__device__ __forceinline__ void load_tile_weights(const double* __restrict__ logw, uint64_t base, uint64_t n,
-                                                  double gmax, int raw, double (&w1)[CSSM_ITEMS]) {
+__device__ __forceinline__ void load_tile_raw(const double* __restrict__ logw, uint64_t base, uint64_t n, int raw,
+                                              double (&v)[CSSM_ITEMS]) {
   const uint64_t i0 = base + (uint64_t)threadIdx.x * CSSM_ITEMS;
-  double v[CSSM_ITEMS];
   if (i0 + CSSM_ITEMS <= n) {
     const double2 a = *reinterpret_cast<const double2*>(logw + i0);
     const double2 b = *reinterpret_cast<const double2*>(logw + i0 + 2);
@@ -358,8 +357,16 @@ __device__ __forceinline__ void load_tile_weights(const double* __restrict__ log
 #pragma unroll
     for (int r = 0; r < CSSM_ITEMS; ++r) v[r] = (i0 + r < n) ? logw[i0 + r] : (raw ? 0.0 : -cssm_inf());
   }
+}
+__device__ __forceinline__ void weights_from_raw(const double (&v)[CSSM_ITEMS], double gmax, int raw, double (&w1)[CSSM_ITEMS]) {
 #pragma unroll
   for (int r = 0; r < CSSM_ITEMS; ++r) w1[r] = raw ? v[r] : cssm_exp(v[r] - gmax);
+}
+__device__ __forceinline__ void load_tile_weights(const double* __restrict__ logw, uint64_t base, uint64_t n,
+                                                  double gmax, int raw, double (&w1)[CSSM_ITEMS]) {
+  double v[CSSM_ITEMS];
+  load_tile_raw(logw, base, n, raw, v);
+  weights_from_raw(v, gmax, raw, w1);
 }
 
 // w1 = exp(w - max) (model/ParticleFilter.scala:125); S = sum w1, S2 = sum w1^2, fixed point, one pair
@@ -370,6 +377,8 @@ __global__ __launch_bounds__(CSSM_BLOCK) void k_tile_sums(const double* __restri
                                                           cssm_u128* __restrict__ unitS, cssm_u128* __restrict__ unitS2,
                                                           uint32_t ntiles, uint32_t sup, uint32_t nunits, int raw, int slot_set) {
   __shared__ cssm_u128 s_a[CSSM_BLOCK / 64], s_b[CSSM_BLOCK / 64];
+  double pre[CSSM_ITEMS];   // the block's first tile is requested before the (serial) max decode
+  if (blockIdx.x < nunits) load_tile_raw(logw, (uint64_t)blockIdx.x * sup * CSSM_TILE, n, raw, pre);
   const double gmax = (slot_set >= 0) ? block_decode_slots(sc, slot_set) : sc->gmax;   // slot_set < 0: gmax was imported
   for (uint32_t unit = blockIdx.x; unit < nunits; unit += gridDim.x) {
     const uint32_t t0 = unit * sup;
@@ -377,7 +386,8 @@ __global__ __launch_bounds__(CSSM_BLOCK) void k_tile_sums(const double* __restri
     cssm_u128 a = cssm_u128_zero(), b = cssm_u128_zero();
     for (uint32_t tile = t0; tile < t1; ++tile) {
       double w1[CSSM_ITEMS];
-      load_tile_weights(logw, (uint64_t)tile * CSSM_TILE, n, gmax, raw, w1);
+      if (unit == blockIdx.x && tile == t0) weights_from_raw(pre, gmax, raw, w1);
+      else load_tile_weights(logw, (uint64_t)tile * CSSM_TILE, n, gmax, raw, w1);
 #pragma unroll
       for (int r = 0; r < CSSM_ITEMS; ++r) {
         a = cssm_u128_add(a, cssm_fix_from_double(w1[r]));
@@ -490,6 +500,8 @@ __global__ __launch_bounds__(CSSM_BLOCK) void k_offspring(const double* __restri
   __shared__ uint32_t s_nheavy;
   __shared__ uint32_t s_hb[FUSE ? CSSM_TILE : 1], s_he[FUSE ? CSSM_TILE : 1], s_hj[FUSE ? CSSM_TILE : 1];
   __shared__ cssm_u128 s_r[3][CSSM_BLOCK / 64];
+  double pre_v[CSSM_ITEMS];   // the block's first tile is requested before the serial prologue
+  if (blockIdx.x < nunits) load_tile_raw(logw, (uint64_t)blockIdx.x * sup * CSSM_TILE, n, raw, pre_v);
   const double gmax = SELF ? block_decode_slots(sc, slot_set) : sc->gmax;
   const double u = rec->u;
   const bool pow2 = (n_global & (n_global - 1)) == 0;
@@ -507,9 +519,10 @@ __global__ __launch_bounds__(CSSM_BLOCK) void k_offspring(const double* __restri
         const cssm_u128 v = unitP[q];
         if (q < unit) pre = cssm_u128_add(pre, v);
         tot = cssm_u128_add(tot, v);
-        tot2 = cssm_u128_add(tot2, unitS2[q]);
+        if (unit == 0) tot2 = cssm_u128_add(tot2, unitS2[q]);   // only the publishing block needs sum w^2
       }
-      pre = wave_sum_u128(pre); tot = wave_sum_u128(tot); tot2 = wave_sum_u128(tot2);
+      pre = wave_sum_u128(pre); tot = wave_sum_u128(tot);
+      if (unit == 0) tot2 = wave_sum_u128(tot2);
       if (lane == 0) { s_r[0][wid] = pre; s_r[1][wid] = tot; s_r[2][wid] = tot2; }
       __syncthreads();
       pre = s_r[0][0]; tot = s_r[1][0]; tot2 = s_r[2][0];
@@ -534,7 +547,8 @@ __global__ __launch_bounds__(CSSM_BLOCK) void k_offspring(const double* __restri
     for (uint32_t tile = t0; tile < t1; ++tile) {
       const uint64_t base = (uint64_t)tile * CSSM_TILE;
       double w1[CSSM_ITEMS];
-      load_tile_weights(logw, base, n, gmax, raw, w1);
+      if (unit == blockIdx.x && tile == t0) weights_from_raw(pre_v, gmax, raw, w1);
+      else load_tile_weights(logw, base, n, gmax, raw, w1);
       cssm_u128 q[CSSM_ITEMS];
       cssm_u128 tsum = cssm_u128_zero();
 #pragma unroll
