@@ -236,7 +236,10 @@ template <int D, bool LGCP, int IT>
 __global__ __launch_bounds__(CSSM_BLOCK) void k_propagate(
     const double* __restrict__ src, size_t src_stride, const uint32_t* __restrict__ anc,
     double* __restrict__ dst, size_t dst_stride, double* __restrict__ logw, uint64_t n, uint64_t gid0,
-    uint64_t seed, const StepRec* __restrict__ rec, ModelK mk, Scalars* __restrict__ sc, int slot_set) {
+    uint64_t seed, const StepRec* __restrict__ rec, ModelK mk, Scalars* __restrict__ sc, int slot_set,
+    const double* __restrict__ src2, size_t src2_stride, uint32_t n_split) {
+  // src2 != nullptr (sharded filter): ancestor indices >= n_split address the candidates received from
+  // other ranks, src2[k * src2_stride + (j - n_split)]
   __shared__ double s_max[CSSM_BLOCK / 64];
   const uint32_t step = rec->step;
   const int has_obs = rec->has_obs;
@@ -269,7 +272,8 @@ __global__ __launch_bounds__(CSSM_BLOCK) void k_propagate(
 #pragma unroll
     for (int r = 0; r < IT; ++r)
 #pragma unroll
-      for (int k = 0; k < D; ++k) x[r][k] = src[(size_t)k * src_stride + j[r]];
+      for (int k = 0; k < D; ++k)
+        x[r][k] = (src2 && j[r] >= n_split) ? src2[(size_t)k * src2_stride + (j[r] - n_split)] : src[(size_t)k * src_stride + j[r]];
     double lw[IT];
 #pragma unroll
     for (int r = 0; r < IT; ++r) {
@@ -375,11 +379,13 @@ __device__ __forceinline__ void load_tile_weights(const double* __restrict__ log
 __global__ __launch_bounds__(CSSM_BLOCK) void k_tile_sums(const double* __restrict__ logw, uint64_t n,
                                                           const Scalars* __restrict__ sc,
                                                           cssm_u128* __restrict__ unitS, cssm_u128* __restrict__ unitS2,
-                                                          uint32_t ntiles, uint32_t sup, uint32_t nunits, int raw, int slot_set) {
+                                                          uint32_t ntiles, uint32_t sup, uint32_t nunits, int raw, int slot_set,
+                                                          const double* __restrict__ gmax_in) {
   __shared__ cssm_u128 s_a[CSSM_BLOCK / 64], s_b[CSSM_BLOCK / 64];
   double pre[CSSM_ITEMS];   // the block's first tile is requested before the (serial) max decode
   if (blockIdx.x < nunits) load_tile_raw(logw, (uint64_t)blockIdx.x * sup * CSSM_TILE, n, raw, pre);
-  const double gmax = (slot_set >= 0) ? block_decode_slots(sc, slot_set) : sc->gmax;   // slot_set < 0: gmax was imported
+  // slot_set < 0: the max was agreed elsewhere (sharded: all-reduced value at gmax_in; stateless: sc->gmax)
+  const double gmax = (slot_set >= 0) ? block_decode_slots(sc, slot_set) : (gmax_in ? *gmax_in : sc->gmax);
   for (uint32_t unit = blockIdx.x; unit < nunits; unit += gridDim.x) {
     const uint32_t t0 = unit * sup;
     const uint32_t t1 = (t0 + sup < ntiles) ? t0 + sup : ntiles;
@@ -427,9 +433,11 @@ __device__ void finish_step(Scalars* sc, uint64_t n_global) {
 __global__ __launch_bounds__(1024) void k_scan_tiles(const cssm_u128* __restrict__ tileS, const cssm_u128* __restrict__ tileS2,
                                                      cssm_u128* __restrict__ tileP, uint32_t ntiles, Scalars* sc,
                                                      uint64_t n_global, int single,
-                                                     double* __restrict__ ll_t, int32_t* __restrict__ ess_t, uint32_t rec_idx) {
+                                                     double* __restrict__ ll_t, int32_t* __restrict__ ess_t, uint32_t rec_idx,
+                                                     const double* __restrict__ gmax_in, unsigned long long* __restrict__ sums4_out) {
   __shared__ cssm_u128 s_w[16], s_w2[16];
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  if (gmax_in && threadIdx.x == 0) sc->gmax = *gmax_in;
   const uint32_t chunk = (ntiles + 1023u) / 1024u;
   const uint32_t t0 = threadIdx.x * chunk;
   const uint32_t t1 = (t0 + chunk < ntiles) ? t0 + chunk : ntiles;
@@ -450,6 +458,7 @@ __global__ __launch_bounds__(1024) void k_scan_tiles(const cssm_u128* __restrict
     cssm_u128 c = cssm_u128_zero(), c2 = cssm_u128_zero();
     for (int w = 0; w < 16; ++w) { c = cssm_u128_add(c, s_w[w]); c2 = cssm_u128_add(c2, s_w2[w]); }
     sc->S_local = c; sc->S2_local = c2;
+    if (sums4_out) { sums4_out[0] = c.lo; sums4_out[1] = c.hi; sums4_out[2] = c2.lo; sums4_out[3] = c2.hi; }
     if (single) {
       sc->S_off = cssm_u128_zero();
       sc->S_tot = c; sc->S2_tot = c2;
@@ -494,7 +503,7 @@ __global__ __launch_bounds__(CSSM_BLOCK) void k_offspring(const double* __restri
                                                           uint32_t* __restrict__ endslot, uint32_t* __restrict__ anc,
                                                           uint32_t ntiles, uint32_t sup, uint32_t nunits, int raw, int slot_set,
                                                           double* __restrict__ ll_t, int32_t* __restrict__ ess_t, uint32_t rec_idx,
-                                                          int force_exact) {
+                                                          int force_exact, const unsigned long long* __restrict__ all4, int rank, int world) {
   __shared__ cssm_u128 s_w[CSSM_BLOCK / 64];
   __shared__ uint32_t s_last[CSSM_BLOCK / 64];
   __shared__ uint32_t s_nheavy;
@@ -507,8 +516,27 @@ __global__ __launch_bounds__(CSSM_BLOCK) void k_offspring(const double* __restri
   const bool pow2 = (n_global & (n_global - 1)) == 0;
   const double inv_n = 1.0 / (double)n_global;
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-  double totd = SELF ? 0.0 : cssm_u128_to_double(sc->S_tot);
-  const cssm_u128 S_off = SELF ? cssm_u128_zero() : sc->S_off;
+  double totd = 0.0;
+  cssm_u128 S_off = cssm_u128_zero();
+  if (!SELF) {
+    if (all4) {   // sharded: every block derives this rank's offset and the global totals from the all-gathered sums
+      cssm_u128 tot = cssm_u128_zero(), tot2 = cssm_u128_zero();
+      for (int r = 0; r < world; ++r) {
+        cssm_u128 a, b;
+        a.lo = all4[4 * r + 0]; a.hi = all4[4 * r + 1]; b.lo = all4[4 * r + 2]; b.hi = all4[4 * r + 3];
+        if (r < rank) S_off = cssm_u128_add(S_off, a);
+        tot = cssm_u128_add(tot, a); tot2 = cssm_u128_add(tot2, b);
+      }
+      totd = cssm_u128_to_double(tot);
+      if (blockIdx.x == 0 && threadIdx.x == 0) {
+        sc->S_off = S_off; sc->S_tot = tot; sc->S2_tot = tot2;
+        finish_step(sc, n_global);
+      }
+    } else {
+      totd = cssm_u128_to_double(sc->S_tot);
+      S_off = sc->S_off;
+    }
+  }
   for (uint32_t unit = blockIdx.x; unit < nunits; unit += gridDim.x) {
     const uint32_t t0 = unit * sup;
     const uint32_t t1 = (t0 + sup < ntiles) ? t0 + sup : ntiles;
@@ -641,31 +669,40 @@ __global__ __launch_bounds__(CSSM_BLOCK) void k_offspring(const double* __restri
 
 // ------------------------------------------------------------------------------------ expand
 
-// findAllInTreeMap (model/Resampling.scala:36-46): slot s copies the first particle j whose end
-// slot exceeds s.  `endslot` holds m candidate particles in global order (single GPU: all N;
-// sharded: the candidates received for this rank); this rank's slots are [slot_lo, slot_hi);
-// anc[s - slot_lo] = index into the candidate array.
-__global__ __launch_bounds__(CSSM_BLOCK) void k_expand(const uint32_t* __restrict__ endslot, uint64_t m,
-                                                       uint64_t slot_lo, uint64_t slot_hi,
-                                                       uint32_t* __restrict__ anc, uint32_t ntiles) {
-  __shared__ uint32_t s_e[CSSM_TILE];
-  for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-    const uint64_t base = (uint64_t)tile * CSSM_TILE;
-    const uint32_t cnt = (uint32_t)((m - base < CSSM_TILE) ? (m - base) : CSSM_TILE);
-    for (uint32_t r = threadIdx.x; r < cnt; r += CSSM_BLOCK) s_e[r] = endslot[base + r];
+// findAllInTreeMap (model/Resampling.scala:36-46) on the receiver of the sharded filter: `cand_end`
+// holds the end slots of m candidate particles in global order, `cand_idx` where each candidate's
+// state lives; this rank's slots are [slot_lo, slot_hi).  Candidate j writes its own run
+// [max(end_{j-1}, slot_lo), min(end_j, slot_hi)) <- cand_idx[j]; runs longer than CSSM_RUN_DIRECT are
+// written by the whole block.  The first candidate's run starts at or before slot_lo by construction.
+__global__ __launch_bounds__(CSSM_BLOCK) void k_expand(const uint32_t* __restrict__ cand_end, const uint32_t* __restrict__ cand_idx,
+                                                       uint64_t m, uint64_t slot_lo, uint64_t slot_hi,
+                                                       uint32_t* __restrict__ anc) {
+  __shared__ uint32_t s_nheavy;
+  __shared__ uint32_t s_hb[CSSM_BLOCK], s_he[CSSM_BLOCK], s_hj[CSSM_BLOCK];
+  for (uint64_t base = (uint64_t)blockIdx.x * CSSM_BLOCK; base < m; base += (uint64_t)gridDim.x * CSSM_BLOCK) {
+    if (threadIdx.x == 0) s_nheavy = 0;
     __syncthreads();
-    uint64_t s_begin = (tile == 0) ? slot_lo : (uint64_t)endslot[base - 1];
-    uint64_t s_end = s_e[cnt - 1];
-    if (s_begin < slot_lo) s_begin = slot_lo;
-    if (s_end > slot_hi) s_end = slot_hi;
-    for (uint64_t s = s_begin + threadIdx.x; s < s_end; s += CSSM_BLOCK) {
-      // first idx in [0, cnt) with s_e[idx] > s (exists: s < s_e[cnt-1])
-      uint32_t lo = 0, hi = cnt - 1;
-      while (lo < hi) {
-        const uint32_t mid = (lo + hi) >> 1;
-        if (s_e[mid] > (uint32_t)s) hi = mid; else lo = mid + 1;
+    const uint64_t j = base + threadIdx.x;
+    if (j < m) {
+      uint64_t b = (j == 0) ? slot_lo : (uint64_t)cand_end[j - 1];
+      uint64_t e = cand_end[j];
+      if (b < slot_lo) b = slot_lo;
+      if (e > slot_hi) e = slot_hi;
+      if (e > b) {
+        const uint32_t idx = cand_idx[j];
+        if (e - b <= CSSM_RUN_DIRECT) {
+          for (uint64_t s = b; s < e; ++s) anc[s - slot_lo] = idx;
+        } else {
+          const uint32_t h = atomicAdd(&s_nheavy, 1u);
+          s_hb[h] = (uint32_t)(b - slot_lo); s_he[h] = (uint32_t)(e - slot_lo); s_hj[h] = idx;
+        }
       }
-      anc[s - slot_lo] = (uint32_t)(base + lo);
+    }
+    __syncthreads();
+    const uint32_t nh = s_nheavy;
+    for (uint32_t h = 0; h < nh; ++h) {
+      const uint32_t he = s_he[h], hj = s_hj[h];
+      for (uint32_t s = s_hb[h] + threadIdx.x; s < he; s += CSSM_BLOCK) anc[s] = hj;
     }
     __syncthreads();
   }
@@ -675,10 +712,12 @@ __global__ __launch_bounds__(CSSM_BLOCK) void k_expand(const uint32_t* __restric
 
 // PfState.particles on demand: out[k][i] = src[k][anc[i]]
 __global__ void k_gather(const double* __restrict__ src, size_t src_stride, const uint32_t* __restrict__ anc,
-                         double* __restrict__ out, size_t out_stride, uint64_t n, int d) {
+                         double* __restrict__ out, size_t out_stride, uint64_t n, int d,
+                         const double* __restrict__ src2, size_t src2_stride, uint32_t n_split) {
   for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
     const size_t j = anc ? (size_t)anc[i] : (size_t)i;
-    for (int k = 0; k < d; ++k) out[(size_t)k * out_stride + i] = src[(size_t)k * src_stride + j];
+    for (int k = 0; k < d; ++k)
+      out[(size_t)k * out_stride + i] = (src2 && j >= n_split) ? src2[(size_t)k * src2_stride + (j - n_split)] : src[(size_t)k * src_stride + j];
   }
 }
 

@@ -61,14 +61,18 @@ struct cssm_pf {
   // device memory
   double* state[2] = {nullptr, nullptr};
   int cur = 0;                 // state[cur] = propagated cloud of the last step (x1)
-  const double* src = nullptr; // where the next propagate reads (state[cur] or the candidate buffer)
+  const double* src = nullptr; // where the next propagate reads (state[cur])
   size_t src_stride = 0;
+  const double* src2 = nullptr; // sharded: candidates received from other ranks (indices >= n_split)
+  size_t src2_stride = 0;
+  uint32_t n_split = 0;
   double* logw = nullptr;
   uint32_t* endslot = nullptr;
   uint32_t* anc = nullptr;
   bool anc_valid = false;
   int wparity = 0;             // max-slot set of the next weighted step (single-GPU path)
   int opt_exact = 0;           // CSSM_OPT_EXACT_OFFSPRING
+  const long long *send_first_dev = nullptr, *send_count_dev = nullptr;   // last shard_offspring outputs (device)
   cssm_u128 *tileS = nullptr, *tileS2 = nullptr, *tileP = nullptr;
   Scalars* sc = nullptr;
   double *d_m0 = nullptr, *d_sd0 = nullptr;
@@ -80,8 +84,9 @@ struct cssm_pf {
   size_t path_cap = 0;
   // sharded extras
   double* cand = nullptr;      // candidate states received for this rank, SoA [d][cand_cap]
-  uint32_t* cand_end = nullptr;
   size_t cand_cap = 0;
+  uint32_t *cand_end = nullptr, *cand_idx = nullptr;   // end slot / state index of every candidate, global order
+  size_t cidx_cap = 0;
   int64_t* d_bounds = nullptr;
   // host staging (pinned)
   StepRec* h_recs = nullptr;
@@ -341,7 +346,7 @@ extern "C" void cssm_pf_destroy(cssm_pf* pf) {
   (void)hipSetDevice(pf->device);
   if (pf->stream) (void)hipStreamSynchronize(pf->stream);
   void* ptrs[] = {pf->state[0], pf->state[1], pf->logw, pf->endslot, pf->anc, pf->tileS, pf->tileS2, pf->tileP, pf->sc,
-                  pf->d_m0, pf->d_sd0, pf->d_recs, pf->d_ll_t, pf->d_ess_t, pf->d_path, pf->cand, pf->cand_end, pf->d_bounds};
+                  pf->d_m0, pf->d_sd0, pf->d_recs, pf->d_ll_t, pf->d_ess_t, pf->d_path, pf->cand, pf->cand_end, pf->cand_idx, pf->d_bounds};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   if (pf->h_recs) (void)hipHostFree(pf->h_recs);
   for (hipEvent_t e : pf->prof_ev) (void)hipEventDestroy(e);
@@ -419,16 +424,16 @@ static int launch_propagate(cssm_pf* pf, const StepRec* d_rec) {
   if (pf->obs_kind == CSSM_OBS_LGCP) {
     DISPATCH_D(pf->d, k_propagate<D, true, PropItems<D>::value><<<dim3(grid), dim3(CSSM_BLOCK), 0, pf->stream>>>(
                           pf->src, pf->src_stride, anc, dst, pf->stride, pf->logw, pf->n, pf->first, pf->seed, d_rec, pf->mk, pf->sc,
-                          pf->sharded ? 0 : pf->wparity));
+                          pf->sharded ? 0 : pf->wparity, anc ? pf->src2 : nullptr, pf->src2_stride, pf->n_split));
   } else {
     DISPATCH_D(pf->d, k_propagate<D, false, PropItems<D>::value><<<dim3(grid), dim3(CSSM_BLOCK), 0, pf->stream>>>(
                           pf->src, pf->src_stride, anc, dst, pf->stride, pf->logw, pf->n, pf->first, pf->seed, d_rec, pf->mk, pf->sc,
-                          pf->sharded ? 0 : pf->wparity));
+                          pf->sharded ? 0 : pf->wparity, anc ? pf->src2 : nullptr, pf->src2_stride, pf->n_split));
   }
   prof_end(pf);
   HIP_TRY(hipGetLastError());
   pf->cur ^= 1;
-  pf->src = pf->state[pf->cur]; pf->src_stride = pf->stride; pf->anc_valid = false;
+  pf->src = pf->state[pf->cur]; pf->src_stride = pf->stride; pf->anc_valid = false; pf->src2 = nullptr;
   return CSSM_OK;
 }
 
@@ -437,12 +442,12 @@ static int launch_resample(cssm_pf* pf, const StepRec* d_rec, double* ll_t = nul
   const int tgrid = (int)pf->nunits;
   prof_begin(pf, CSSM_K_TILE_SUMS);
   hipLaunchKernelGGL(k_tile_sums, dim3(tgrid), dim3(CSSM_BLOCK), 0, pf->stream, pf->logw, pf->n, pf->sc, pf->tileS, pf->tileS2, pf->ntiles,
-                     pf->sup, pf->nunits, 0, pf->wparity);
+                     pf->sup, pf->nunits, 0, pf->wparity, (const double*)nullptr);
   prof_end(pf);
   prof_begin(pf, CSSM_K_OFFSPRING);   // unit prefix, ll/ess, end slots and their expansion to ancestors in one kernel
   hipLaunchKernelGGL((k_offspring<true, true>), dim3(tgrid), dim3(CSSM_BLOCK), 0, pf->stream, pf->logw, pf->n, pf->sc,
                      (const cssm_u128*)pf->tileS, (const cssm_u128*)pf->tileS2, d_rec, pf->n_global, pf->endslot, pf->anc, pf->ntiles,
-                     pf->sup, pf->nunits, 0, pf->wparity, ll_t, ess_t, rec_idx, pf->opt_exact);
+                     pf->sup, pf->nunits, 0, pf->wparity, ll_t, ess_t, rec_idx, pf->opt_exact, (const unsigned long long*)nullptr, 0, 1);
   prof_end(pf);
   pf->wparity ^= 1;
   HIP_TRY(hipGetLastError());
@@ -634,7 +639,8 @@ extern "C" int cssm_pf_get_particles(cssm_pf* pf, double* out) {
   double* tmp = nullptr;
   if (hipMalloc(&tmp, pf->n * (size_t)pf->d * 8) != hipSuccess) return fail(CSSM_ENOMEM, "hipMalloc for the gathered cloud");
   hipLaunchKernelGGL(k_gather, dim3(grid_for(pf->n, 256, kGridCap)), dim3(256), 0, pf->stream, pf->src, pf->src_stride,
-                     (const uint32_t*)(pf->anc_valid ? pf->anc : nullptr), tmp, (size_t)pf->n, pf->n, pf->d);
+                     (const uint32_t*)(pf->anc_valid ? pf->anc : nullptr), tmp, (size_t)pf->n, pf->n, pf->d,
+                     pf->anc_valid ? pf->src2 : nullptr, pf->src2_stride, pf->n_split);
   hipError_t e = hipMemcpyAsync(out, tmp, pf->n * (size_t)pf->d * 8, hipMemcpyDeviceToHost, pf->stream);
   if (e == hipSuccess) e = hipStreamSynchronize(pf->stream);
   (void)hipFree(tmp);
@@ -696,10 +702,12 @@ extern "C" int cssm_resample_systematic(const double* w, size_t n, double u, uin
   RS_TRY(hipMemcpyAsync(d_rec, &hrec, sizeof hrec, hipMemcpyHostToDevice, st));
   {
     const int tgrid = (int)nunits;
-    hipLaunchKernelGGL(k_tile_sums, dim3(tgrid), dim3(CSSM_BLOCK), 0, st, d_w, (uint64_t)n, sc, tS, tS2, ntiles, sup, nunits, 1, -1);
-    hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(1024), 0, st, tS, tS2, tP, nunits, sc, (uint64_t)n, 1, (double*)nullptr, (int32_t*)nullptr, 0u);
+    hipLaunchKernelGGL(k_tile_sums, dim3(tgrid), dim3(CSSM_BLOCK), 0, st, d_w, (uint64_t)n, sc, tS, tS2, ntiles, sup, nunits, 1, -1, (const double*)nullptr);
+    hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(1024), 0, st, tS, tS2, tP, nunits, sc, (uint64_t)n, 1, (double*)nullptr, (int32_t*)nullptr, 0u,
+                       (const double*)nullptr, (unsigned long long*)nullptr);
     hipLaunchKernelGGL((k_offspring<true, false>), dim3(tgrid), dim3(CSSM_BLOCK), 0, st, d_w, (uint64_t)n, sc, (const cssm_u128*)tP,
-                       (const cssm_u128*)tS2, d_rec, (uint64_t)n, d_end, d_anc, ntiles, sup, nunits, 1, 0, (double*)nullptr, (int32_t*)nullptr, 0u, 0);
+                       (const cssm_u128*)tS2, d_rec, (uint64_t)n, d_end, d_anc, ntiles, sup, nunits, 1, 0, (double*)nullptr, (int32_t*)nullptr, 0u, 0,
+                       (const unsigned long long*)nullptr, 0, 1);
   }
   RS_TRY(hipGetLastError());
   RS_TRY(hipMemcpyAsync(&hs, sc, sizeof hs, hipMemcpyDeviceToHost, st));
@@ -757,21 +765,46 @@ __global__ void k_send_ranges(const uint32_t* __restrict__ endslot, uint64_t n_l
   count[q] = (long long)(j_last - j_lo + 1);
 }
 
-// rows of d+1 doubles: the particle's state and its end slot
-__global__ void k_pack(const double* __restrict__ src, size_t stride, const uint32_t* __restrict__ endslot, int d,
-                       long long j0, long long cnt, double* __restrict__ out) {
-  for (long long r = (long long)blockIdx.x * blockDim.x + threadIdx.x; r < cnt; r += (long long)gridDim.x * blockDim.x) {
+// rows of d+1 doubles (the particle's state and its end slot) for every destination rank, destinations
+// back to back: row r belongs to the destination q with sum(count[<q]) <= r < sum(count[<=q])
+__global__ void k_pack(const double* __restrict__ src, size_t stride, const uint32_t* __restrict__ endslot, int d, int world,
+                       const long long* __restrict__ first, const long long* __restrict__ count, long long total, int skip,
+                       double* __restrict__ out) {
+  for (long long r = (long long)blockIdx.x * blockDim.x + threadIdx.x; r < total; r += (long long)gridDim.x * blockDim.x) {
+    long long off = 0;
+    int q = 0;
+    for (;;) {   // destination of row r; the rank's own range (`skip`) never travels
+      const long long c = (q == skip) ? 0 : count[q];
+      if (r < off + c || q == world - 1) break;
+      off += c; ++q;
+    }
+    const long long j = first[q] + (r - off);
     double* row = out + r * (d + 1);
-    for (int k = 0; k < d; ++k) row[k] = src[(size_t)k * stride + (size_t)(j0 + r)];
-    row[d] = (double)endslot[j0 + r];
+    for (int k = 0; k < d; ++k) row[k] = src[(size_t)k * stride + (size_t)j];
+    row[d] = (double)endslot[j];
   }
 }
-__global__ void k_adopt(const double* __restrict__ recv, long long m, int d, double* __restrict__ cand, size_t cstride,
-                        uint32_t* __restrict__ cand_end) {
+// Received rows (d+1 doubles: state, end slot) of the ranks below (first n_low rows) and above this one:
+// states go to the SoA candidate buffer, end slots and state indices to their global-order positions
+// around the rank's own range.
+__global__ void k_adopt_remote(const double* __restrict__ recv, long long n_low, long long n_high, long long self_count, int d,
+                               uint32_t n_split, double* __restrict__ cand, size_t cstride,
+                               uint32_t* __restrict__ cand_end, uint32_t* __restrict__ cand_idx) {
+  const long long m = n_low + n_high;
   for (long long r = (long long)blockIdx.x * blockDim.x + threadIdx.x; r < m; r += (long long)gridDim.x * blockDim.x) {
     const double* row = recv + r * (d + 1);
     for (int k = 0; k < d; ++k) cand[(size_t)k * cstride + (size_t)r] = row[k];
-    cand_end[r] = (uint32_t)row[d];
+    const long long p = (r < n_low) ? r : r + self_count;
+    cand_end[p] = (uint32_t)row[d];
+    cand_idx[p] = n_split + (uint32_t)r;
+  }
+}
+// The rank's own candidates stay where they are: only their end slots / indices are listed.
+__global__ void k_adopt_self(const uint32_t* __restrict__ endslot, long long self_first, long long self_count, long long n_low,
+                             uint32_t* __restrict__ cand_end, uint32_t* __restrict__ cand_idx) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < self_count; i += (long long)gridDim.x * blockDim.x) {
+    cand_end[n_low + i] = endslot[self_first + i];
+    cand_idx[n_low + i] = (uint32_t)(self_first + i);
   }
 }
 
@@ -815,12 +848,10 @@ extern "C" int cssm_pf_shard_sums(cssm_pf* pf, const double* global_max_dev, uin
   if (rc) return rc;
   if (!global_max_dev || !sums4_dev) return fail(CSSM_EINVAL_ARG, "null argument");
   const int tgrid = (int)pf->nunits;
-  hipLaunchKernelGGL(k_import_max, dim3(1), dim3(1), 0, pf->stream, pf->sc, global_max_dev);
   hipLaunchKernelGGL(k_tile_sums, dim3(tgrid), dim3(CSSM_BLOCK), 0, pf->stream, pf->logw, pf->n, pf->sc, pf->tileS, pf->tileS2, pf->ntiles,
-                     pf->sup, pf->nunits, 0, -1);
+                     pf->sup, pf->nunits, 0, -1, global_max_dev);
   hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(1024), 0, pf->stream, pf->tileS, pf->tileS2, pf->tileP, pf->nunits, pf->sc, pf->n_global, 0,
-                     (double*)nullptr, (int32_t*)nullptr, 0u);
-  hipLaunchKernelGGL(k_export_sums, dim3(1), dim3(1), 0, pf->stream, pf->sc, (unsigned long long*)sums4_dev);
+                     (double*)nullptr, (int32_t*)nullptr, 0u, global_max_dev, (unsigned long long*)sums4_dev);
   HIP_TRY(hipGetLastError());
   return CSSM_OK;
 }
@@ -836,10 +867,11 @@ extern "C" int cssm_pf_shard_offspring(cssm_pf* pf, const uint64_t* all_sums4_de
                                                        rank, (unsigned long long)((uint64_t)rank * n_per), (unsigned long long)pf->first);
   const size_t slot = (pf->step - 1) % 64;   // record of the step propagated last
   const int tgrid = (int)pf->nunits;
-  hipLaunchKernelGGL(k_global_sums, dim3(1), dim3(1), 0, pf->stream, (const unsigned long long*)all_sums4_dev, rank, world, pf->sc, pf->n_global);
   hipLaunchKernelGGL((k_offspring<false, false>), dim3(tgrid), dim3(CSSM_BLOCK), 0, pf->stream, pf->logw, pf->n, pf->sc,
                      (const cssm_u128*)pf->tileP, (const cssm_u128*)pf->tileS2, pf->d_recs + slot, pf->n_global, pf->endslot,
-                     (uint32_t*)nullptr, pf->ntiles, pf->sup, pf->nunits, 0, 0, (double*)nullptr, (int32_t*)nullptr, 0u, pf->opt_exact);
+                     (uint32_t*)nullptr, pf->ntiles, pf->sup, pf->nunits, 0, 0, (double*)nullptr, (int32_t*)nullptr, 0u, pf->opt_exact,
+                     (const unsigned long long*)all_sums4_dev, rank, world);
+  pf->send_first_dev = (const long long*)send_first_dev; pf->send_count_dev = (const long long*)send_count_dev;
   hipLaunchKernelGGL(k_send_ranges, dim3(1), dim3(64), 0, pf->stream, pf->endslot, pf->n, pf->sc, pf->d_recs + slot, pf->n_global, rank, world,
                      n_per, (long long*)send_first_dev, (long long*)send_count_dev);
   HIP_TRY(hipGetLastError());
@@ -847,47 +879,67 @@ extern "C" int cssm_pf_shard_offspring(cssm_pf* pf, const uint64_t* all_sums4_de
 }
 
 extern "C" int cssm_pf_shard_pack(cssm_pf* pf, int world, const int64_t* send_first_host, const int64_t* send_count_host,
-                                  double* send_buf_dev) {
+                                  int skip_rank, double* send_buf_dev) {
   int rc = shard_check(pf);
   if (rc) return rc;
   if (!send_first_host || !send_count_host) return fail(CSSM_EINVAL_ARG, "null argument");
-  int64_t off = 0;
-  for (int q = 0; q < world; ++q) {
+  if (!pf->send_first_dev) return fail(CSSM_ESTATE, "shard_pack before shard_offspring");
+  int64_t total = 0;
+  for (int q = 0; q < world; ++q) {   // the host copies are only checked; the kernel reads the device originals
     const int64_t c = send_count_host[q], f = send_first_host[q];
     if (c < 0 || f < 0 || (uint64_t)(f + c) > pf->n) return fail(CSSM_ESHARD, "send range [%lld, +%lld) outside the shard", (long long)f, (long long)c);
-    if (c > 0) {
-      if (!send_buf_dev) return fail(CSSM_EINVAL_ARG, "send_buf_dev is null");
-      hipLaunchKernelGGL(k_pack, dim3(grid_for((uint64_t)c, 256, kGridCap)), dim3(256), 0, pf->stream, pf->state[pf->cur], pf->stride,
-                         pf->endslot, pf->d, (long long)f, (long long)c, send_buf_dev + off * (pf->d + 1));
-    }
-    off += c;
+    if (q != skip_rank) total += c;
+  }
+  if (total > 0) {
+    if (!send_buf_dev) return fail(CSSM_EINVAL_ARG, "send_buf_dev is null");
+    hipLaunchKernelGGL(k_pack, dim3(grid_for((uint64_t)total, 256, kGridCap)), dim3(256), 0, pf->stream, pf->state[pf->cur], pf->stride,
+                       pf->endslot, pf->d, world, pf->send_first_dev, pf->send_count_dev, (long long)total, skip_rank, send_buf_dev);
   }
   HIP_TRY(hipGetLastError());
   return CSSM_OK;
 }
 
-extern "C" int cssm_pf_shard_adopt(cssm_pf* pf, const double* recv_buf_dev, int64_t n_recv) {
+extern "C" int cssm_pf_shard_adopt(cssm_pf* pf, const double* recv_buf_dev, int64_t n_low, int64_t n_high, int64_t self_first,
+                                   int64_t self_count) {
   int rc = shard_check(pf);
   if (rc) return rc;
-  if (n_recv < 1 || !recv_buf_dev) return fail(CSSM_ESHARD, "a rank must receive at least one candidate particle");
-  if ((size_t)n_recv > pf->cand_cap) {
+  if (n_low < 0 || n_high < 0 || self_count < 0 || self_first < 0 || (uint64_t)(self_first + self_count) > pf->n)
+    return fail(CSSM_ESHARD, "bad candidate counts");
+  const int64_t n_remote = n_low + n_high, m = n_remote + self_count;
+  if (m < 1) return fail(CSSM_ESHARD, "a rank must have at least one candidate particle");
+  if (n_remote > 0 && !recv_buf_dev) return fail(CSSM_EINVAL_ARG, "recv_buf_dev is null");
+  if ((size_t)n_remote > pf->cand_cap) {
     HIP_TRY(hipStreamSynchronize(pf->stream));
     if (pf->cand) (void)hipFree(pf->cand);
-    if (pf->cand_end) (void)hipFree(pf->cand_end);
-    pf->cand = nullptr; pf->cand_end = nullptr;
-    size_t cap = (size_t)n_recv + (size_t)n_recv / 4 + CSSM_TILE;
+    pf->cand = nullptr;
+    size_t cap = (size_t)n_remote + (size_t)n_remote / 4 + CSSM_TILE;
     cap = (cap + CSSM_TILE - 1) / CSSM_TILE * CSSM_TILE;
     if (hipMalloc(&pf->cand, cap * 8 * pf->d) != hipSuccess) return fail(CSSM_ENOMEM, "hipMalloc candidate buffer (%zu particles)", cap);
-    if (hipMalloc(&pf->cand_end, cap * 4) != hipSuccess) return fail(CSSM_ENOMEM, "hipMalloc candidate end slots");
     pf->cand_cap = cap;
   }
-  hipLaunchKernelGGL(k_adopt, dim3(grid_for((uint64_t)n_recv, 256, kGridCap)), dim3(256), 0, pf->stream, recv_buf_dev, (long long)n_recv,
-                     pf->d, pf->cand, pf->cand_cap, pf->cand_end);
-  const uint32_t ct = (uint32_t)(((uint64_t)n_recv + CSSM_TILE - 1) / CSSM_TILE);
-  hipLaunchKernelGGL(k_expand, dim3(grid_for(ct, 1, kGridCap)), dim3(CSSM_BLOCK), 0, pf->stream, pf->cand_end, (uint64_t)n_recv, pf->first,
-                     pf->first + pf->n, pf->anc, ct);
+  if ((size_t)m > pf->cidx_cap) {
+    HIP_TRY(hipStreamSynchronize(pf->stream));
+    if (pf->cand_end) (void)hipFree(pf->cand_end);
+    if (pf->cand_idx) (void)hipFree(pf->cand_idx);
+    pf->cand_end = pf->cand_idx = nullptr;
+    size_t cap = (size_t)m + (size_t)m / 4 + CSSM_TILE;
+    if (hipMalloc(&pf->cand_end, cap * 4) != hipSuccess || hipMalloc(&pf->cand_idx, cap * 4) != hipSuccess)
+      return fail(CSSM_ENOMEM, "hipMalloc candidate index (%zu entries)", cap);
+    pf->cidx_cap = cap;
+  }
+  const uint32_t n_split = (uint32_t)pf->n;
+  if (n_remote > 0)
+    hipLaunchKernelGGL(k_adopt_remote, dim3(grid_for((uint64_t)n_remote, 256, kGridCap)), dim3(256), 0, pf->stream, recv_buf_dev,
+                       (long long)n_low, (long long)n_high, (long long)self_count, pf->d, n_split, pf->cand, pf->cand_cap, pf->cand_end,
+                       pf->cand_idx);
+  if (self_count > 0)
+    hipLaunchKernelGGL(k_adopt_self, dim3(grid_for((uint64_t)self_count, 256, kGridCap)), dim3(256), 0, pf->stream, pf->endslot,
+                       (long long)self_first, (long long)self_count, (long long)n_low, pf->cand_end, pf->cand_idx);
+  hipLaunchKernelGGL(k_expand, dim3(grid_for((uint64_t)m, CSSM_BLOCK, kGridCap)), dim3(CSSM_BLOCK), 0, pf->stream, pf->cand_end,
+                     pf->cand_idx, (uint64_t)m, pf->first, pf->first + pf->n, pf->anc);
   HIP_TRY(hipGetLastError());
-  pf->src = pf->cand; pf->src_stride = pf->cand_cap; pf->anc_valid = true;
+  pf->src = pf->state[pf->cur]; pf->src_stride = pf->stride;
+  pf->src2 = pf->cand; pf->src2_stride = pf->cand_cap; pf->n_split = n_split; pf->anc_valid = true;
   return CSSM_OK;
 }
 

@@ -63,9 +63,10 @@ class GpuShard:
         self.local_max = torch.zeros(1, dtype=torch.float64, **kw)
         self.sums4 = torch.zeros(4, dtype=torch.int64, **kw)
         self.all_sums = torch.zeros(4 * world, dtype=torch.int64, **kw)
-        self.send_first = torch.zeros(world, dtype=torch.int64, **kw)
-        self.send_count = torch.zeros(world, dtype=torch.int64, **kw)
-        self.recv_count = torch.zeros(world, dtype=torch.int64, **kw)
+        # [send_first | send_count | recv_count], one tensor so that one D2H copy reads all three
+        self.meta = torch.zeros(3 * world, dtype=torch.int64, **kw)
+        self.send_first, self.send_count, self.recv_count = self.meta[:world], self.meta[world:2 * world], self.meta[2 * world:]
+        self._bufs = {}
 
     def close(self):
         if getattr(self, "_h", None) is not None and self._h.value:
@@ -74,8 +75,13 @@ class GpuShard:
 
     __del__ = close
 
-    def new_buffer(self, n_doubles: int) -> torch.Tensor:
-        return torch.empty(max(n_doubles, 1), dtype=torch.float64, device=self.dev)
+    def buffer(self, name: str, n_doubles: int) -> torch.Tensor:
+        """A persistent exchange buffer of at least n_doubles (grown geometrically, never per step)."""
+        b = self._bufs.get(name)
+        if b is None or b.numel() < n_doubles:
+            b = torch.empty(max(int(n_doubles * 1.25) + 1024, 1), dtype=torch.float64, device=self.dev)
+            self._bufs[name] = b
+        return b
 
     def init(self, t0: float):
         _abi.check(self.lib.cssm_pf_shard_init(self._h, float(t0)))
@@ -94,14 +100,16 @@ class GpuShard:
                                                     C.c_void_p(self.send_count.data_ptr())))
 
     def pack(self, first_host: np.ndarray, count_host: np.ndarray, send_buf: torch.Tensor):
+        """Rows for every OTHER rank, destinations back to back (the own range never travels)."""
         f = np.ascontiguousarray(first_host, dtype=np.int64)
         c = np.ascontiguousarray(count_host, dtype=np.int64)
         _abi.check(self.lib.cssm_pf_shard_pack(self._h, self.world, f.ctypes.data_as(C.POINTER(C.c_int64)),
-                                               c.ctypes.data_as(C.POINTER(C.c_int64)), C.c_void_p(send_buf.data_ptr())))
+                                               c.ctypes.data_as(C.POINTER(C.c_int64)), self.rank, C.c_void_p(send_buf.data_ptr())))
 
-    def adopt(self, recv_buf: torch.Tensor, n_recv: int):
+    def adopt(self, recv_buf: torch.Tensor, n_low: int, n_high: int, self_first: int, self_count: int):
         self._recv_keepalive = recv_buf
-        _abi.check(self.lib.cssm_pf_shard_adopt(self._h, C.c_void_p(recv_buf.data_ptr()), int(n_recv)))
+        _abi.check(self.lib.cssm_pf_shard_adopt(self._h, C.c_void_p(recv_buf.data_ptr()), int(n_low), int(n_high),
+                                                int(self_first), int(self_count)))
 
     def result(self):
         ll, ess = C.c_double(), C.c_int32()
@@ -214,19 +222,28 @@ class ShardedFilter:
             s.offspring()
         comm.all_to_all_counts([s.recv_count for s in S], [s.send_count for s in S])
         # the one host read of the step: the exchange sizes
-        firsts = [s.send_first.cpu().numpy() for s in S]
-        scount = [s.send_count.cpu().numpy() for s in S]
-        rcount = [s.recv_count.cpu().numpy() for s in S]
+        W = comm.world
+        metas = [s.meta.cpu().numpy() for s in S]
+        firsts = [m[:W] for m in metas]
+        scount = [m[W:2 * W] for m in metas]
+        rcount = [m[2 * W:] for m in metas]
         row = d + 1
-        send_bufs = [s.new_buffer(int(c.sum()) * row) for s, c in zip(S, scount)]
-        recv_bufs = [s.new_buffer(int(c.sum()) * row) for s, c in zip(S, rcount)]
+        # a rank's own range stays in place: it is excluded from the exchange
+        sx = [c.copy() for c in scount]
+        rx = [c.copy() for c in rcount]
+        for s, a, b in zip(S, sx, rx):
+            a[s.rank] = 0
+            b[s.rank] = 0
+        send_bufs = [s.buffer("send", int(c.sum()) * row) for s, c in zip(S, sx)]
+        recv_bufs = [s.buffer("recv", int(c.sum()) * row) for s, c in zip(S, rx)]
         for s, f, c, b in zip(S, firsts, scount, send_bufs):
             s.pack(f, c, b)
-        comm.all_to_all_v([b[: int(c.sum()) * row] for b, c in zip(recv_bufs, rcount)],
-                          [b[: int(c.sum()) * row] for b, c in zip(send_bufs, scount)],
-                          [[int(v) * row for v in c] for c in rcount], [[int(v) * row for v in c] for c in scount])
-        for s, b, c in zip(S, recv_bufs, rcount):
-            s.adopt(b, int(c.sum()))
+        if W > 1:
+            comm.all_to_all_v([b[: int(c.sum()) * row] for b, c in zip(recv_bufs, rx)],
+                              [b[: int(c.sum()) * row] for b, c in zip(send_bufs, sx)],
+                              [[int(v) * row for v in c] for c in rx], [[int(v) * row for v in c] for c in sx])
+        for s, b, c, f, sc in zip(S, recv_bufs, rx, firsts, scount):
+            s.adopt(b, int(c[: s.rank].sum()), int(c[s.rank + 1:].sum()), int(f[s.rank]), int(sc[s.rank]))
 
     def ll_filter(self, t, y, has=None, lgcp: bool = False):
         t = np.asarray(t, dtype=np.float64)

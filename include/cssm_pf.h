@@ -215,8 +215,9 @@ int cssm_resample_systematic(const double* w, size_t n, double u, uint32_t* anc,
  *                               also ll, ess; and for every destination rank q the range of
  *                               local particles that own at least one slot of q: counts[R]
  *   [all-gather counts, all-to-all-v of (d+1) doubles per particle]
- *   cssm_pf_shard_pack / _adopt pack the send ranges; adopt the received candidates and
- *                               expand them to this rank's N_local slots
+ *   cssm_pf_shard_pack / _adopt pack the send ranges of the OTHER ranks (a rank's own range never
+ *                               travels); adopt the rows received from lower (n_low) and higher
+ *                               (n_high) ranks around the own range and expand to the N_local slots
  * All device work is enqueued on the stream given at creation; the only host reads are the
  * ones whose pointers are documented as host.
  */
@@ -226,8 +227,9 @@ int cssm_pf_shard_sums(cssm_pf* pf, const double* global_max_dev, uint64_t* sums
 int cssm_pf_shard_offspring(cssm_pf* pf, const uint64_t* all_sums4_dev, int rank, int world,
                             int64_t* send_first_dev, int64_t* send_count_dev);
 int cssm_pf_shard_pack(cssm_pf* pf, int world, const int64_t* send_first_host,
-                       const int64_t* send_count_host, double* send_buf_dev);
-int cssm_pf_shard_adopt(cssm_pf* pf, const double* recv_buf_dev, int64_t n_recv);
+                       const int64_t* send_count_host, int skip_rank, double* send_buf_dev);
+int cssm_pf_shard_adopt(cssm_pf* pf, const double* recv_buf_dev, int64_t n_low, int64_t n_high,
+                        int64_t self_first, int64_t self_count);
 int cssm_pf_shard_result(cssm_pf* pf, double* ll_out, int32_t* ess_out);
 
 /* ---- PMMH host loop ---------------------------------------------------------------------- */

@@ -46,12 +46,11 @@ class OracleShard:
         self.local_max = torch.zeros(1, dtype=torch.float64)
         self.sums4 = torch.zeros(4, dtype=torch.int64)
         self.all_sums = torch.zeros(4 * world, dtype=torch.int64)
-        self.send_first = torch.zeros(world, dtype=torch.int64)
-        self.send_count = torch.zeros(world, dtype=torch.int64)
-        self.recv_count = torch.zeros(world, dtype=torch.int64)
+        self.meta = torch.zeros(3 * world, dtype=torch.int64)
+        self.send_first, self.send_count, self.recv_count = self.meta[:world], self.meta[world:2 * world], self.meta[2 * world:]
         self.ll, self.ess, self.step_idx = 0.0, n_global, 0
 
-    def new_buffer(self, n):
+    def buffer(self, name, n):
         return torch.zeros(max(n, 1), dtype=torch.float64)
 
     def init(self, t0):
@@ -113,15 +112,22 @@ class OracleShard:
 
     def pack(self, first, count, buf):
         rows = []
-        for f, c in zip(first, count):
+        for q, (f, c) in enumerate(zip(first, count)):
+            if q == self.rank:
+                continue               # the own range never travels
             for j in range(int(f), int(f) + int(c)):
                 rows.append(np.concatenate([self.x1[:, j], [float(self.E[j])]]))
         if rows:
             flat = np.concatenate(rows)
             buf[: flat.size] = torch.from_numpy(flat)
 
-    def adopt(self, buf, n_recv):
-        rows = buf[: n_recv * (self.d + 1)].numpy().reshape(n_recv, self.d + 1)
+    def adopt(self, buf, n_low, n_high, self_first, self_count):
+        n_rem = n_low + n_high
+        rows = buf[: n_rem * (self.d + 1)].numpy().reshape(n_rem, self.d + 1)
+        own = np.concatenate([self.x1[:, self_first:self_first + self_count].T,
+                              self.E[self_first:self_first + self_count, None].astype(np.float64)], axis=1)
+        rows = np.concatenate([rows[:n_low], own, rows[n_low:]], axis=0)   # global particle order
+        n_recv = rows.shape[0]
         cand, cend = rows[:, : self.d], rows[:, self.d].astype(np.int64)
         slots = np.arange(self.first, self.first + self.n)
         anc = np.searchsorted(cend, slots, side="right")      # first candidate whose end slot exceeds s
