@@ -25,6 +25,7 @@ CSSM_ESTATE = -7
 SDE_BROWNIAN, SDE_GEN_BROWNIAN, SDE_OU, SDE_EULER_AFFINE = 0, 1, 2, 3
 F_FIRST, F_SEASONAL = 0, 1
 OBS_POISSON, OBS_GAUSSIAN, OBS_LGCP = 0, 1, 2
+OBS_NEGBIN, OBS_ZIP, OBS_BERNOULLI, OBS_STUDENT_T, OBS_BETA = 3, 4, 5, 6, 7
 MAX_DIM = 16
 MAX_LEAVES = 16
 
@@ -44,7 +45,7 @@ class LeafDesc(C.Structure):
 class ModelDesc(C.Structure):
     _fields_ = [
         ("n_leaves", C.c_int32), ("obs_kind", C.c_int32), ("lgcp_precision", C.c_int32),
-        ("reserved", C.c_int32), ("leaves", C.POINTER(LeafDesc)),
+        ("obs_df", C.c_int32), ("leaves", C.POINTER(LeafDesc)),
     ]
 
 

@@ -43,9 +43,9 @@ struct ModelK {
 
 // Per-observation record, built on the host (everything that depends only on (t, y)).
 struct StepRec {
-  double y;       // Poisson: (double)trunc(y); Gaussian: y
-  double aux;     // Poisson: lgamma(k+1); Gaussian: log(sqrt(2 pi) sd)
-  double aux2;    // Gaussian: sd
+  double y;       // count models: (double)trunc(y); otherwise y
+  double c[4];    // per-observation constants of the density (see build_rec / logdens)
+  double cdf;     // Student-t: degrees of freedom as double
   double u;       // the one uniform of systematic resampling
   double dt;      // time increment (LGCP: the sub-step delta)
   int32_t has_obs;
@@ -162,14 +162,39 @@ __device__ __forceinline__ double gamma_of(const ModelK& mk, const StepRec* __re
   return g;
 }
 
+// dataLikelihood(gamma, y) of the leftmost leaf; the branch is wave-uniform (mk is a kernel argument).
+// Constants c[] per observation kind are listed in build_rec (cssm_pf.hip); the oracle states the same
+// expressions with the reference's line numbers (oracle/cssm_oracle.c, logdens).
 __device__ __forceinline__ double logdens(const ModelK& mk, const StepRec* __restrict__ rec, double g) {
-  if (mk.obs_kind == CSSM_OBS_POISSON) {
-    // breeze Poisson.logProbabilityOf: -lambda + k log(lambda) - lgamma(k+1), model/Model.scala:273
-    return -cssm_exp(g) + rec->y * g - rec->aux;
+  const double y = rec->y;
+  switch (mk.obs_kind) {
+    case CSSM_OBS_POISSON:   // -lambda + k log(lambda) - lgamma(k+1), model/Model.scala:273
+      return -cssm_exp(g) + y * g - rec->c[0];
+    case CSSM_OBS_GAUSSIAN: {  // breeze Gaussian.logPdf, model/Model.scala:252-258
+      const double dd = (y - g) / rec->c[1];
+      return -(dd * dd) / 2.0 - rec->c[0];
+    }
+    case CSSM_OBS_NEGBIN: {    // model/Model.scala:186-195
+      const double size = rec->c[1], mu = cssm_exp(g);
+      return rec->c[0] + size * cssm_log(size / (mu + size)) + y * cssm_log(mu / (mu + size));
+    }
+    case CSSM_OBS_ZIP: {       // model/Model.scala:298-307
+      if (y == 0.0) return cssm_log(rec->c[0] + (1.0 - rec->c[0]) * cssm_exp(-cssm_exp(g)));
+      return ((rec->c[1] + y * g) - cssm_exp(g)) - rec->c[2];
+    }
+    case CSSM_OBS_BERNOULLI: { // model/Model.scala:318-336
+      const double link = (g > 6.0) ? 1.0 : ((g < -6.0) ? 0.0 : 1.0 / (1.0 + cssm_exp(-g)));
+      if (y == 1.0) return (link == 0.0) ? -1e99 : cssm_log(link);
+      return (link == 1.0) ? -1e99 : cssm_log(1.0 - link);
+    }
+    case CSSM_OBS_STUDENT_T: { // 1/v * StudentsT(df).logPdf((y - eta)/v), model/Model.scala:155-160
+      const double x = (y - g) / rec->c[1];
+      return rec->c[3] * (rec->c[0] - rec->c[2] * cssm_log(1.0 + (x * x) / rec->cdf));
+    }
+    default: {                 // Beta(exp(-gamma), 1).logPdf(y) = (a - 1) log y + log a, model/Model.scala:349-352
+      return (cssm_exp(-g) - 1.0) * rec->c[0] - g;
+    }
   }
-  // breeze Gaussian.logPdf, model/Model.scala:252-258
-  double dd = (rec->y - g) / rec->aux2;
-  return -(dd * dd) / 2.0 - rec->aux;
 }
 
 // ------------------------------------------------------------------------------------ init

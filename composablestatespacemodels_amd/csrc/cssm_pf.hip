@@ -48,8 +48,9 @@ struct cssm_pf {
   hipStream_t stream = nullptr;
   bool own_stream = true;
   // model
-  int d = 0, n_leaves = 0, obs_kind = 0, precision = 0;
-  double scale_sd = 1.0;
+  int d = 0, n_leaves = 0, obs_kind = 0, precision = 0, obs_df = 0;
+  double scale_sd = 1.0;       // exp(scale): Gaussian sd, NegBin size, Student-t v
+  double scale_raw = 0.0;      // ZIP: the stored scale v
   Comp comp[CSSM_MAX_DIM];
   ModelK mk;
   // sizes
@@ -193,12 +194,21 @@ static int build_model(cssm_pf* pf, const cssm_model_desc* desc) {
   pf->n_leaves = desc->n_leaves;
   pf->obs_kind = desc->obs_kind;
   pf->precision = desc->lgcp_precision;
-  if (desc->obs_kind == CSSM_OBS_GAUSSIAN) {
-    if (!desc->leaves[0].has_scale) return fail(CSSM_EINVAL_DESC, "Must provide SD parameter for a Gaussian observation model");
-    pf->scale_sd = cssm_exp(desc->leaves[0].scale);    // model/Model.scala:244
-  } else if (desc->obs_kind != CSSM_OBS_POISSON && desc->obs_kind != CSSM_OBS_LGCP) {
-    return fail(CSSM_EINVAL_DESC, "unknown obs_kind %d", desc->obs_kind);
+  switch (desc->obs_kind) {
+    case CSSM_OBS_GAUSSIAN: case CSSM_OBS_NEGBIN: case CSSM_OBS_STUDENT_T: case CSSM_OBS_ZIP:
+      // "Must provide SD parameter" / "No scale parameter provided", model/Model.scala:150,179,214,250,294
+      if (!desc->leaves[0].has_scale) return fail(CSSM_EINVAL_DESC, "this observation model needs the scale parameter of the leftmost leaf");
+      pf->scale_raw = desc->leaves[0].scale;
+      pf->scale_sd = cssm_exp(desc->leaves[0].scale);  // model/Model.scala:147,171,244
+      if (desc->obs_kind == CSSM_OBS_STUDENT_T && desc->obs_df < 1) return fail(CSSM_EINVAL_DESC, "Student-t needs obs_df >= 1");
+      pf->obs_df = desc->obs_df;
+      break;
+    case CSSM_OBS_POISSON: case CSSM_OBS_LGCP: case CSSM_OBS_BERNOULLI: case CSSM_OBS_BETA: break;
+    default: return fail(CSSM_EINVAL_DESC, "unknown obs_kind %d", desc->obs_kind);
   }
+  if (desc->obs_kind >= CSSM_OBS_NEGBIN)   // these models take f = first component of EVERY leaf (Model.scala:153,184,296,328,347)
+    for (int l = 0; l < desc->n_leaves; ++l)
+      if (l == 0 && desc->leaves[l].f_kind != CSSM_F_FIRST) return fail(CSSM_EINVAL_DESC, "the observing leaf must use the first-component map");
   if (desc->obs_kind == CSSM_OBS_LGCP && (desc->lgcp_precision < 0 || desc->lgcp_precision > 9))
     return fail(CSSM_EINVAL_DESC, "lgcp_precision %d out of range", desc->lgcp_precision);
   // kernel-side constants
@@ -265,14 +275,33 @@ static void build_rec(const cssm_pf* pf, double t_prev, double t, double y, int 
       r->fco[k] = (c.idx & 1) ? sn : cs;
     }
   }
-  if (pf->obs_kind == CSSM_OBS_POISSON) {
-    const long long k = (long long)y;                          // y.toInt
-    r->y = (double)k;
-    r->aux = cssm_lgamma_kp1(k);
-  } else if (pf->obs_kind == CSSM_OBS_GAUSSIAN) {
-    r->y = y;
-    r->aux2 = pf->scale_sd;
-    r->aux = cssm_log(2.5066282746310002 * pf->scale_sd);
+  const long long k = (long long)y;                            // y.toInt
+  r->y = y;
+  switch (pf->obs_kind) {
+    case CSSM_OBS_POISSON:                                     // c0 = lgamma(k+1)
+      r->y = (double)k; r->c[0] = cssm_lgamma_kp1(k); break;
+    case CSSM_OBS_GAUSSIAN:                                    // c0 = log(sqrt(2 pi) sd), c1 = sd
+      r->c[0] = cssm_log(2.5066282746310002 * pf->scale_sd); r->c[1] = pf->scale_sd; break;
+    case CSSM_OBS_NEGBIN: {                                    // c0 = lgamma(size+k) - lgamma(k+1) - lgamma(size), c1 = size
+      const double size = pf->scale_sd;
+      r->y = (double)k;
+      r->c[0] = cssm_lgamma(size + (double)k) - cssm_lgamma_kp1(k) - cssm_lgamma(size); r->c[1] = size;
+      break;
+    }
+    case CSSM_OBS_ZIP: {                                       // c0 = p, c1 = -log(1 + exp(v)), c2 = lgamma(k+1)
+      const double ev = cssm_exp(pf->scale_raw);
+      r->y = (double)k;
+      r->c[0] = ev / (1.0 + ev); r->c[1] = -cssm_log(1.0 + ev); r->c[2] = cssm_lgamma_kp1(k);
+      break;
+    }
+    case CSSM_OBS_STUDENT_T: {                                 // c0 = -logNormalizer, c1 = v, c2 = (df+1)/2, c3 = 1/v
+      const double df = (double)pf->obs_df, v = pf->scale_sd;
+      r->c[0] = cssm_lgamma((df + 1.0) / 2.0) - cssm_lgamma(df / 2.0) - 0.5 * cssm_log(3.14159265358979311600 * df);
+      r->c[1] = v; r->c[2] = (df + 1.0) / 2.0; r->c[3] = 1.0 / v; r->cdf = df;
+      break;
+    }
+    case CSSM_OBS_BETA: r->c[0] = cssm_log(y); break;          // c0 = log(y)
+    default: break;                                            // Bernoulli, LGCP: no constants
   }
   const cssm_u32x4 bu = cssm_philox_draw(pf->seed, 0, step, CSSM_STREAM_U, 0, 0);
   r->u = cssm_u01(bu.v[0], bu.v[1]);

@@ -242,10 +242,11 @@ class Sde:
 # --------------------------------------------------------------------------- models
 @dataclass
 class _LeafSpec:
-    obs: str  # 'poisson' | 'linear' | 'seasonal' | 'lgcp'
+    obs: str  # 'poisson' | 'linear' | 'seasonal' | 'lgcp' | 'negbin' | 'zip' | 'bernoulli' | 'studentt' | 'beta'
     sde: UnparamSde
     period: int = 0
     harmonics: int = 0
+    df: int = 0
 
 
 class UnparamModel:
@@ -285,8 +286,15 @@ class Model:
                 raise ValueError("Must provide SD parameter for LinearModel / SeasonalModel")
         elif first == "lgcp":
             self.obs_kind = _abi.OBS_LGCP
+        elif first in ("negbin", "zip", "studentt"):
+            self.obs_kind = {"negbin": _abi.OBS_NEGBIN, "zip": _abi.OBS_ZIP, "studentt": _abi.OBS_STUDENT_T}[first]
+            if leaves[0][1].scale is None:  # Model.scala:150,179,294
+                raise ValueError("No scale parameter provided to the observation model")
+        elif first in ("bernoulli", "beta"):
+            self.obs_kind = _abi.OBS_BERNOULLI if first == "bernoulli" else _abi.OBS_BETA
         else:
             raise ValueError(f"unknown observation model {first}")
+        self.obs_df = leaves[0][0].df
         self.dimension = sum(l[2].dimension for l in leaves)
         if self.dimension > _abi.MAX_DIM or len(leaves) > _abi.MAX_LEAVES:
             raise ValueError("model too large for the native filter (CSSM_MAX_DIM / CSSM_MAX_LEAVES)")
@@ -307,6 +315,26 @@ class Model:
     @staticmethod
     def lgcp(sde: UnparamSde) -> UnparamModel:
         return UnparamModel([_LeafSpec("lgcp", sde)])
+
+    @staticmethod
+    def negativeBinomial(sde: UnparamSde) -> UnparamModel:  # Model.scala:87-89
+        return UnparamModel([_LeafSpec("negbin", sde)])
+
+    @staticmethod
+    def zeroInflatedPoisson(sde: UnparamSde) -> UnparamModel:  # Model.scala:91-94
+        return UnparamModel([_LeafSpec("zip", sde)])
+
+    @staticmethod
+    def bernoulli(sde: UnparamSde) -> UnparamModel:  # Model.scala:77-80
+        return UnparamModel([_LeafSpec("bernoulli", sde)])
+
+    @staticmethod
+    def studentsT(sde: UnparamSde, df: int) -> UnparamModel:  # Model.scala:72-75
+        return UnparamModel([_LeafSpec("studentt", sde, df=int(df))])
+
+    @staticmethod
+    def beta(sde: UnparamSde) -> UnparamModel:  # Model.scala:50-55
+        return UnparamModel([_LeafSpec("beta", sde)])
 
     def parameters(self) -> Parameters:
         return Parameters([l[1] for l in self.leaves])
@@ -354,6 +382,7 @@ class Descriptor:
         self.desc.n_leaves = n
         self.desc.obs_kind = model.obs_kind
         self.desc.lgcp_precision = lgcp_precision
+        self.desc.obs_df = getattr(model, "obs_df", 0)
         self.desc.leaves = C.cast(self.leaf_array, C.POINTER(_abi.LeafDesc))
 
     def ptr(self):

@@ -318,6 +318,22 @@ CSSM_HD double cssm_lgamma_kp1(long long k) {
   return (n - 0.5) * cssm_log(n) - n + 0.91893853320467274178 + series;
 }
 
+/*
+ * log Gamma(x) for real x > 0 (host-side, once per observation: the constants of the negative
+ * binomial and Student-t densities, model/Model.scala:191,158).  Argument shifted to z >= 24 by the
+ * recurrence, then the Stirling series; ~1e-15 relative.
+ */
+CSSM_HD double cssm_lgamma(double x) {
+  if (!(x > 0.0)) return cssm_nan();
+  double prod = 1.0;   /* x (x+1) ... (z-1) <= 24! : one logarithm instead of a sum of up to 24 */
+  double z = x;
+  while (z < 24.0) { prod *= z; z += 1.0; }
+  const double shift = cssm_log(prod);
+  const double inv = 1.0 / z, inv2 = inv * inv;
+  const double series = inv * (1.0 / 12.0 - inv2 * (1.0 / 360.0 - inv2 * (1.0 / 1260.0 - inv2 * (1.0 / 1680.0 - inv2 * (1.0 / 1188.0)))));
+  return ((z - 0.5) * cssm_log(z) - z + 0.91893853320467274178 + series) - shift;
+}
+
 /* ------------------------------------------------------------------ 128-bit fixed point */
 
 typedef struct { uint64_t lo, hi; } cssm_u128;

@@ -62,6 +62,12 @@ extern "C" {
 #define CSSM_OBS_POISSON 0
 #define CSSM_OBS_GAUSSIAN 1
 #define CSSM_OBS_LGCP 2
+/* "next" rows of SURVEY.md 8f-1, all with f = first component of the leftmost leaf: */
+#define CSSM_OBS_NEGBIN 3     /* NegativeBinomialModel  model/Model.scala:168-196, size = exp(scale)          */
+#define CSSM_OBS_ZIP 4        /* ZeroInflatedPoisson    model/Model.scala:281-309, p = logistic(scale)        */
+#define CSSM_OBS_BERNOULLI 5  /* BernoulliModel         model/Model.scala:315-337 (+-6 clamp, -1e99 floor)    */
+#define CSSM_OBS_STUDENT_T 6  /* StudentsTModel         model/Model.scala:144-161, v = exp(scale), obs_df     */
+#define CSSM_OBS_BETA 7       /* BetaModel              model/Model.scala:339-353, Beta(exp(-gamma), 1)       */
 
 #define CSSM_MAX_DIM 16     /* total latent dimension d (sum over leaves) */
 #define CSSM_MAX_LEAVES 16
@@ -97,7 +103,7 @@ typedef struct cssm_model_desc {
   int32_t n_leaves;
   int32_t obs_kind;
   int32_t lgcp_precision; /* FilterLgcp.precision (model/ParticleFilter.scala:172) */
-  int32_t reserved;
+  int32_t obs_df;         /* CSSM_OBS_STUDENT_T: degrees of freedom (`df: Int`, model/Model.scala:144) */
   const cssm_leaf_desc* leaves;
 } cssm_model_desc;
 

@@ -24,7 +24,7 @@ static void throw_last(JNIEnv* env) {
 
 /*
  * The descriptor arrives flattened from Scala (DescriptorBuilder in FilterGpu.scala):
- *   ints  : [n_leaves, obs_kind, lgcp_precision, then per leaf: sde_kind, dim, f_kind, period, harmonics,
+ *   ints  : [n_leaves, obs_kind, lgcp_precision, obs_df, then per leaf: sde_kind, dim, f_kind, period, harmonics,
  *            has_scale, n_m0, n_c0, n_mu, n_phi, n_sigma]
  *   reals : per leaf: scale, m0[..], c0[..], mu[..], phi[..], sigma[..]   (STORED, unconstrained values)
  */
@@ -37,9 +37,9 @@ static int unpack(JNIEnv* env, jintArray ji, jdoubleArray jd, owned_desc* o) {
   const double* r = o->reals;
   int n = a[0];
   o->leaves = (cssm_leaf_desc*)calloc((size_t)n, sizeof(cssm_leaf_desc));
-  o->desc.n_leaves = n; o->desc.obs_kind = a[1]; o->desc.lgcp_precision = a[2]; o->desc.reserved = 0;
+  o->desc.n_leaves = n; o->desc.obs_kind = a[1]; o->desc.lgcp_precision = a[2]; o->desc.obs_df = a[3];
   o->desc.leaves = o->leaves;
-  a += 3;
+  a += 4;
   for (int l = 0; l < n; ++l, a += 11) {
     cssm_leaf_desc* L = &o->leaves[l];
     L->sde_kind = a[0]; L->dim = a[1]; L->f_kind = a[2]; L->period = a[3]; L->harmonics = a[4]; L->has_scale = a[5];

@@ -34,12 +34,12 @@ object DescriptorBuilder {
     * (obs/f kind, sde kind, dimension, period, harmonics) exactly as the user composed them with |+|. */
   case class LeafSpec(obs: String, sde: Int, dim: Int, period: Int = 0, harmonics: Int = 0)
 
-  def apply(leaves: Seq[LeafSpec], p: Parameters, precision: Int = 0): (Array[Int], Array[Double]) = {
+  def apply(leaves: Seq[LeafSpec], p: Parameters, precision: Int = 0, df: Int = 0): (Array[Int], Array[Double]) = {
     val nodes: Seq[ParamNode] = p.flatten                      // Tree.flatten, Tree.scala:49-53
     require(nodes.size == leaves.size, "parameter tree shape does not match the composed model")
-    val obsKind = leaves.head.obs match { case "poisson" => poisson; case "lgcp" => lgcp; case _ => gaussian }
+    val obsKind = leaves.head.obs match { case "poisson" => poisson; case "lgcp" => lgcp; case "negbin" => 3; case "zip" => 4; case "bernoulli" => 5; case "studentt" => 6; case "beta" => 7; case _ => gaussian }
     val ints = Array.newBuilder[Int]; val reals = Array.newBuilder[Double]
-    ints ++= Seq(leaves.size, obsKind, precision)
+    ints ++= Seq(leaves.size, obsKind, precision, df)
     leaves.zip(nodes).foreach { case (l, node) =>
       val (m0, c0, mu, phi, sigma) = node.sdeParam match {     // STORED values: SdeParameters.scala:176-205
         case BrownianParameter(m, c, s)       => (m, c, DenseVector[Double](), DenseVector[Double](), s)

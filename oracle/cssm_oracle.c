@@ -67,8 +67,9 @@ typedef struct {
 } ocomp;
 
 struct oracle_pf {
-  int d, n_leaves, obs_kind, precision, flags;
-  double scale_sd;       /* Gaussian: exp(scale)  model/Model.scala:244,211 */
+  int d, n_leaves, obs_kind, precision, flags, obs_df;
+  double scale_sd;       /* exp(scale): Gaussian sd, NegBin size, Student-t v   model/Model.scala:147,171,211,244 */
+  double scale_raw;      /* ZIP: the stored scale v                              model/Model.scala:284,300 */
   ocomp comp[CSSM_MAX_DIM];
   uint64_t n, seed;
   uint64_t first, n_global; /* shard of a larger filter: global id of particle 0, global particle count */
@@ -155,11 +156,16 @@ static int build_components(oracle_pf* pf, const cssm_model_desc* desc) {
   pf->d = d;
   /* only the leftmost leaf supplies the observation model, model/Model.scala:118-120,132 */
   const cssm_leaf_desc* L0 = &desc->leaves[0];
-  if (desc->obs_kind == CSSM_OBS_GAUSSIAN) {
-    if (!L0->has_scale) return ORACLE_EINVAL;                  /* "Must provide SD parameter", model/Model.scala:250 */
-    pf->scale_sd = o_exp(pf, L0->scale);
-  } else if (desc->obs_kind != CSSM_OBS_POISSON && desc->obs_kind != CSSM_OBS_LGCP) {
-    return ORACLE_EINVAL;
+  switch (desc->obs_kind) {
+    case CSSM_OBS_GAUSSIAN: case CSSM_OBS_NEGBIN: case CSSM_OBS_STUDENT_T: case CSSM_OBS_ZIP:
+      if (!L0->has_scale) return ORACLE_EINVAL;                /* "Must provide SD parameter" / "No scale parameter", model/Model.scala:150,179,250,294 */
+      pf->scale_raw = L0->scale;
+      pf->scale_sd = o_exp(pf, L0->scale);
+      pf->obs_df = desc->obs_df;
+      if (desc->obs_kind == CSSM_OBS_STUDENT_T && desc->obs_df < 1) return ORACLE_EINVAL;
+      break;
+    case CSSM_OBS_POISSON: case CSSM_OBS_LGCP: case CSSM_OBS_BERNOULLI: case CSSM_OBS_BETA: break;
+    default: return ORACLE_EINVAL;
   }
   return ORACLE_OK;
 }
@@ -322,7 +328,49 @@ double oracle_logdens_gaussian(double gamma, double y, double sd) {
   return -(dd * dd) / 2.0 - cssm_log(2.5066282746310002 * sd);
 }
 
+/* NegativeBinomialModel.dataLikelihood, model/Model.scala:186-195 (size = exp(scale), mu = exp(gamma)) */
+double oracle_logdens_negbin(double gamma, double y, double size) {
+  long long k = (long long)y;
+  double mu = cssm_exp(gamma);
+  return (cssm_lgamma(size + (double)k) - cssm_lgamma_kp1(k) - cssm_lgamma(size)) + size * cssm_log(size / (mu + size)) +
+         (double)k * cssm_log(mu / (mu + size));
+}
+/* ZeroInflatedPoisson.dataLikelihood, model/Model.scala:298-307 (v = stored scale) */
+double oracle_logdens_zip(double gamma, double y, double v) {
+  long long k = (long long)y;
+  double ev = cssm_exp(v);
+  double p = ev / (1.0 + ev);
+  if (k == 0) return cssm_log(p + (1.0 - p) * cssm_exp(-cssm_exp(gamma)));
+  return ((-cssm_log(1.0 + ev) + (double)k * gamma) - cssm_exp(gamma)) - cssm_lgamma_kp1(k);
+}
+/* BernoulliModel.link / dataLikelihood, model/Model.scala:318-336 */
+double oracle_logdens_bernoulli(double gamma, double y) {
+  double link = (gamma > 6.0) ? 1.0 : ((gamma < -6.0) ? 0.0 : 1.0 / (1.0 + cssm_exp(-gamma)));
+  if (y == 1.0) return (link == 0.0) ? -1e99 : cssm_log(link);
+  return (link == 1.0) ? -1e99 : cssm_log(1.0 - link);
+}
+/* StudentsTModel.dataLikelihood, model/Model.scala:155-160: 1/v * StudentsT(df).logPdf((y - eta)/v)
+ * (the 1/v factor multiplies the LOG-pdf, as written); breeze StudentsT.logPdf(x) =
+ * lgamma((df+1)/2) - lgamma(df/2) - log(pi df)/2 - (df+1)/2 log(1 + x^2/df) */
+double oracle_logdens_student_t(double gamma, double y, double v, int df) {
+  double d = (double)df;
+  double x = (y - gamma) / v;
+  double c0 = cssm_lgamma((d + 1.0) / 2.0) - cssm_lgamma(d / 2.0) - 0.5 * cssm_log(3.14159265358979311600 * d);
+  return (1.0 / v) * (c0 - ((d + 1.0) / 2.0) * cssm_log(1.0 + (x * x) / d));
+}
+/* BetaModel.dataLikelihood, model/Model.scala:349-352: Beta(exp(-gamma), 1).logPdf(y) = (a-1) log y - logB(a,1),
+ * and logB(a,1) = lgamma(a) + lgamma(1) - lgamma(a+1) = -log a = gamma: evaluated in that closed form. */
+double oracle_logdens_beta(double gamma, double y) { return (cssm_exp(-gamma) - 1.0) * cssm_log(y) - gamma; }
+
 static double logdens(const oracle_pf* pf, double gamma, double y) {
+  switch (pf->obs_kind) {
+    case CSSM_OBS_NEGBIN: return oracle_logdens_negbin(gamma, y, pf->scale_sd);
+    case CSSM_OBS_ZIP: return oracle_logdens_zip(gamma, y, pf->scale_raw);
+    case CSSM_OBS_BERNOULLI: return oracle_logdens_bernoulli(gamma, y);
+    case CSSM_OBS_STUDENT_T: return oracle_logdens_student_t(gamma, y, pf->scale_sd, pf->obs_df);
+    case CSSM_OBS_BETA: return oracle_logdens_beta(gamma, y);
+    default: break;
+  }
   if (pf->obs_kind == CSSM_OBS_POISSON) {
     long long k = (long long)y;
     return -o_exp(pf, gamma) + (double)k * gamma - cssm_lgamma_kp1(k);
@@ -646,6 +694,7 @@ void oracle_c_normals(uint64_t seed, uint64_t gid, uint32_t step, uint32_t tag, 
   cssm_normal_pair(cssm_philox_draw(seed, gid, step, tag, sub, pair), &z2[0], &z2[1]);
 }
 double oracle_c_lgamma_kp1(long long k) { return cssm_lgamma_kp1(k); }
+double oracle_c_lgamma(double x) { return cssm_lgamma(x); }
 uint64_t oracle_c_sys_count(double C, double u, uint64_t n) { return cssm_sys_count(C, u, n); }
 double oracle_c_fix_roundtrip(double w) { return cssm_fix_to_double(cssm_fix_from_double(w)); }
 double oracle_c_u(uint64_t seed, uint32_t step) {

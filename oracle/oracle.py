@@ -67,6 +67,12 @@ def lib() -> C.CDLL:
             "oracle_resample_systematic": (C.c_int, [_dp, C.c_uint64, C.c_double, _u32p, _dp, C.c_int]),
             "oracle_logdens_poisson": (C.c_double, [C.c_double, C.c_double]),
             "oracle_logdens_gaussian": (C.c_double, [C.c_double, C.c_double, C.c_double]),
+            "oracle_logdens_negbin": (C.c_double, [C.c_double, C.c_double, C.c_double]),
+            "oracle_logdens_zip": (C.c_double, [C.c_double, C.c_double, C.c_double]),
+            "oracle_logdens_bernoulli": (C.c_double, [C.c_double, C.c_double]),
+            "oracle_logdens_student_t": (C.c_double, [C.c_double, C.c_double, C.c_double, C.c_int]),
+            "oracle_logdens_beta": (C.c_double, [C.c_double, C.c_double]),
+            "oracle_c_lgamma": (C.c_double, [C.c_double]),
             "oracle_pmmh_run": (C.c_int, [vp, vp, _dp, C.c_size_t, C.c_double, _dp, _dp, _u8p, C.c_size_t,
                                           C.c_uint64, C.c_size_t, _dp, _dp, _i32p, _dp]),
             "oracle_c_exp": (C.c_double, [C.c_double]),

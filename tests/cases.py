@@ -64,6 +64,53 @@ def euler_model():
     return Model.poisson(Sde.eulerAffine(2)).run(p)
 
 
+def negbin_model():
+    """Model.negativeBinomial(Sde.ouProcess(1)) |+| seasonal: mirrors examples/Simulation.scala:15-28."""
+    p = (Parameters.apply(np.log(3.0), SdeParameter.brownianParameter(0.0, 1.0, 0.01))
+         | Parameters.apply(None, SdeParameter.ouParameter(0.0, 1.0, 0.2, [0.25, -0.25], 0.3)))
+    return (Model.negativeBinomial(Sde.brownianMotion(1)) | Model.seasonal(24, 1, Sde.ouProcess(2))).run(p)
+
+
+def zip_model():
+    p = Parameters.apply(-0.8, SdeParameter.ouParameter(0.5, 1.0, 0.2, 0.5, 0.3))
+    return Model.zeroInflatedPoisson(Sde.ouProcess(1)).run(p)
+
+
+def bernoulli_model():
+    p = Parameters.apply(None, SdeParameter.ouParameter(0.0, 4.0, 0.2, 0.0, 1.5))
+    return Model.bernoulli(Sde.ouProcess(1)).run(p)
+
+
+def studentt_model():
+    p = Parameters.apply(np.log(0.6), SdeParameter.genBrownianParameter(0.5, 2.0, 0.02, 0.3))
+    return Model.studentsT(Sde.genBrownianMotion(1), 5).run(p)
+
+
+def beta_model():
+    p = Parameters.apply(None, SdeParameter.ouParameter(0.5, 0.2, 0.2, 0.5, 0.2))
+    return Model.beta(Sde.ouProcess(1)).run(p)
+
+
+def binary_series(T, seed=SEED):
+    rng = np.random.default_rng(seed)
+    t = np.arange(T, dtype=np.float64)
+    return t, (rng.random(T) < 0.45).astype(np.float64), np.ones(T, dtype=np.uint8)
+
+
+def unit_interval_series(T, seed=SEED):
+    rng = np.random.default_rng(seed)
+    t = np.arange(T, dtype=np.float64)
+    return t, rng.beta(0.7, 1.0, T), np.ones(T, dtype=np.uint8)
+
+
+def counts_with_zeros(T, seed=SEED):
+    rng = np.random.default_rng(seed)
+    t = np.arange(T, dtype=np.float64)
+    y = rng.poisson(1.5, T).astype(np.float64)
+    y[rng.random(T) < 0.4] = 0.0
+    return t, y, np.ones(T, dtype=np.uint8)
+
+
 def poisson_counts(T, seed=SEED, rate=2.0, dt=1.0, missing=0.0):
     """Regular observation times 0, dt, 2dt ... with Poisson counts around a slowly varying rate."""
     rng = np.random.default_rng(seed)
@@ -89,3 +136,25 @@ def event_times(T, seed=SEED, horizon=10.0):
     t = np.sort(rng.random(T) * horizon)
     t = np.round(t, 3)
     return t, np.ones(T), np.ones(T, dtype=np.uint8)
+
+
+GOLDEN_NAMES = ["c1", "c2", "c3", "c4", "linear", "negbin", "zip", "bernoulli", "studentt", "beta"]
+
+
+def golden_case(name, T, missing=0.0):
+    """(model, t, y, has) of a committed run in tests/golden/oracle_runs.json."""
+    mk = {"c1": c1_model, "c2": c2_model, "c3": c3_model, "c4": c4_model, "linear": linear_model, "negbin": negbin_model,
+          "zip": zip_model, "bernoulli": bernoulli_model, "studentt": studentt_model, "beta": beta_model}[name]
+    if name == "c4":
+        data = event_times(T)
+    elif name in ("linear", "studentt"):
+        data = gaussian_series(T)
+    elif name == "zip":
+        data = counts_with_zeros(T)
+    elif name == "bernoulli":
+        data = binary_series(T)
+    elif name == "beta":
+        data = unit_interval_series(T)
+    else:
+        data = poisson_counts(T, missing=missing)
+    return (mk(),) + tuple(data)

@@ -49,6 +49,13 @@ def test_models_streaming_bit_exact(name):
     _compare_streaming(model, 3000, t, y, has)
 
 
+@pytest.mark.parametrize("name", ["negbin", "zip", "bernoulli", "studentt", "beta"])
+def test_next_row_observation_models_streaming_bit_exact(name):
+    """NegBin, ZIP, Bernoulli, Student-t, Beta through the same kernels and boundary."""
+    model, t, y, has = cases.golden_case(name, 9)
+    _compare_streaming(model, 2500, t, y, has)
+
+
 def test_missing_observations_bit_exact():
     t, y, has = cases.poisson_counts(16, missing=0.4)
     assert has.sum() < 16
@@ -86,19 +93,13 @@ def test_batch_ll_filter_matches_oracle(name, n, T):
     g.close()
 
 
-@pytest.mark.parametrize("name", ["c1", "c2", "c3", "c4", "linear"])
+@pytest.mark.parametrize("name", cases.GOLDEN_NAMES)
 def test_gpu_reproduces_committed_golden_runs(name):
     """tests/golden/oracle_runs.json was produced in the build container (tests/golden/make_golden.py)."""
     import json, os
     g = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "oracle_runs.json")))[name]
-    mk = {"c1": cases.c1_model, "c2": cases.c2_model, "c3": cases.c3_model, "c4": cases.c4_model, "linear": cases.linear_model}[name]
-    if name == "c4":
-        t, y, has = cases.event_times(g["T"])
-    elif name == "linear":
-        t, y, has = cases.gaussian_series(g["T"])
-    else:
-        t, y, has = cases.poisson_counts(g["T"], missing=g["missing"])
-    pf = NativePf(mk(), g["n"], cases.SEED, lgcp_precision=g["lgcp_precision"])
+    model, t, y, has = cases.golden_case(name, g["T"], g["missing"])
+    pf = NativePf(model, g["n"], cases.SEED, lgcp_precision=g["lgcp_precision"])
     ll, ll_t, ess_t, path = pf.run(t, y, has, want_path=True)
     assert ll == float.fromhex(g["ll"])
     np.testing.assert_array_equal(ll_t, [float.fromhex(v) for v in g["ll_t"]])

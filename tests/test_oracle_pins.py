@@ -34,6 +34,34 @@ def test_k1_gaussian_density_matches_scipy_golden():
         assert abs(got - r["logpdf"]) <= 1e-12 * max(1.0, abs(r["logpdf"])), r
 
 
+def test_k1_next_row_densities_match_scipy_golden():
+    """NegBin, zero-inflated Poisson, Bernoulli, Student-t (with the reference's 1/v factor on the
+    LOG-pdf, Model.scala:158) and Beta(exp(-gamma), 1): Model.scala:155-160,186-195,298-307,318-336,349-352."""
+    g = json.load(open(os.path.join(GOLD, "densities.json")))
+    L = oracle.lib()
+    tol = lambda ref: 2e-12 * max(1.0, abs(ref))
+    for r in g["negbin"]:
+        assert abs(L.oracle_logdens_negbin(r["gamma"], r["y"], r["size"]) - r["logpmf"]) <= tol(r["logpmf"]), r
+    for r in g["zip"]:
+        assert abs(L.oracle_logdens_zip(r["gamma"], r["y"], r["v"]) - r["logpmf"]) <= tol(r["logpmf"]), r
+    for r in g["bernoulli"]:
+        assert abs(L.oracle_logdens_bernoulli(r["gamma"], r["y"]) - r["logp"]) <= tol(r["logp"]), r
+    for r in g["student_t"]:
+        assert abs(L.oracle_logdens_student_t(r["gamma"], r["y"], r["v"], r["df"]) - r["val"]) <= tol(r["val"]), r
+    for r in g["beta"]:
+        assert abs(L.oracle_logdens_beta(r["gamma"], r["y"]) - r["logpdf"]) <= tol(r["logpdf"]), r
+    # the Bernoulli link's clamp and floor, Model.scala:318-336
+    assert L.oracle_logdens_bernoulli(6.5, 0.0) == -1e99 and L.oracle_logdens_bernoulli(-6.5, 1.0) == -1e99
+    assert L.oracle_logdens_bernoulli(6.5, 1.0) == 0.0 and L.oracle_logdens_bernoulli(-6.5, 0.0) == 0.0
+
+
+def test_lgamma_real_argument():
+    from scipy import special
+    for x in [1e-3, 0.3, 0.5, 1.0, 1.5, 2.0, 2.94, 7.25, 23.9, 24.0, 100.5, 1e4, 1e6]:
+        ref = float(special.gammaln(x))
+        assert abs(oracle.lib().oracle_c_lgamma(x) - ref) <= 3e-14 * max(1.0, abs(ref))
+
+
 # ----------------------------------------------------------------------------- K2 transitions
 def test_k2_double_logistic_on_ou_phi():
     # ouParameter(...)(0.2) stores logistic(0.2); OuProcess applies logistic again (Sde.scala:136)
@@ -198,17 +226,10 @@ def test_k4_particle_filter_likelihood_converges_to_kalman():
 
 
 # ----------------------------------------------------------------------------- K5 committed oracle runs
-@pytest.mark.parametrize("name", ["c1", "c2", "c3", "c4", "linear"])
+@pytest.mark.parametrize("name", cases.GOLDEN_NAMES)
 def test_k5_oracle_reproduces_committed_runs(name):
     g = json.load(open(os.path.join(GOLD, "oracle_runs.json")))[name]
-    mk = {"c1": cases.c1_model, "c2": cases.c2_model, "c3": cases.c3_model, "c4": cases.c4_model, "linear": cases.linear_model}[name]
-    model = mk()
-    if name == "c4":
-        t, y, has = cases.event_times(g["T"])
-    elif name == "linear":
-        t, y, has = cases.gaussian_series(g["T"])
-    else:
-        t, y, has = cases.poisson_counts(g["T"], missing=g["missing"])
+    model, t, y, has = cases.golden_case(name, g["T"], g["missing"])
     o = oracle.OraclePf(model.descriptor(g["lgcp_precision"]), g["n"], cases.SEED)
     ll, ll_t, ess_t, path = o.filter(t, y, has, want_path=True)
     assert ll == float.fromhex(g["ll"])
