@@ -110,14 +110,23 @@ __device__ __forceinline__ cssm_u128 wave_scan_u128(cssm_u128 v, int lane) {
   return v;
 }
 
-// d standard normals of global particle gid (component k = element k&1 of Philox pair k>>1)
+// The contract's log table (include/cssm_numerics.h, CSSM_LOG_TAB) staged in LDS by every kernel that
+// draws normals: `tab_global` is the handle's device copy.  All threads of the block must call it.
+__device__ __forceinline__ const double* stage_log_table(const double* __restrict__ tab_global) {
+  __shared__ double s_logtab[256];
+  for (int i = threadIdx.x; i < 256; i += blockDim.x) s_logtab[i] = tab_global[i];
+  __syncthreads();
+  return s_logtab;
+}
+
+// d standard normals of global particle gid for an ordinary step (normal k = element k&1 of pair k>>1)
 template <int D>
 __device__ __forceinline__ void draw_normals(uint64_t seed, uint64_t gid, uint32_t step, uint32_t tag,
-                                             uint32_t sub, double (&z)[D]) {
+                                             const double* tab, double (&z)[D]) {
 #pragma unroll
   for (int p = 0; 2 * p < D; ++p) {
     double z0, z1;
-    cssm_normal_pair(cssm_philox_draw(seed, gid, step, tag, sub, (uint32_t)p), &z0, &z1);
+    cssm_normal_pair(cssm_philox_draw(seed, gid, step, tag, (uint32_t)p), tab, &z0, &z1);
     z[2 * p] = z0;
     if (2 * p + 1 < D) z[2 * p + 1] = z1;
   }
@@ -203,10 +212,11 @@ __device__ __forceinline__ double logdens(const ModelK& mk, const StepRec* __res
 template <int D>
 __global__ __launch_bounds__(CSSM_BLOCK) void k_init(double* __restrict__ dst, size_t stride, uint64_t n,
                                                      uint64_t gid0, uint64_t seed, const double* __restrict__ m0,
-                                                     const double* __restrict__ sd0) {
+                                                     const double* __restrict__ sd0, const double* __restrict__ logtab) {
+  const double* tab = stage_log_table(logtab);
   for (uint64_t i = (uint64_t)blockIdx.x * CSSM_BLOCK + threadIdx.x; i < n; i += (uint64_t)gridDim.x * CSSM_BLOCK) {
     double z[D];
-    draw_normals<D>(seed, gid0 + i, 0u, CSSM_STREAM_INIT, 0u, z);
+    draw_normals<D>(seed, gid0 + i, 0u, CSSM_STREAM_INIT, tab, z);
 #pragma unroll
     for (int k = 0; k < D; ++k) dst[(size_t)k * stride + i] = sd0[k] * z[k] + m0[k];
   }
@@ -240,7 +250,7 @@ __device__ __forceinline__ double block_decode_slots(const Scalars* __restrict__
 
 // Particles per thread in k_propagate: all gathers of a thread are issued before its ALU work,
 // and rows are stored as 16-/32-byte vectors.
-template <int D> struct PropItems { static constexpr int value = (D <= 4) ? 4 : (D <= 8 ? 2 : 1); };
+template <int D> struct PropItems { static constexpr int value = (D <= 2) ? 4 : (D <= 8 ? 2 : 1); };
 
 // max over the CSSM_MAXSLOTS shards of the running max log-weight
 __device__ __forceinline__ double decode_slots(const Scalars* __restrict__ sc, int set) {
@@ -257,15 +267,20 @@ __device__ __forceinline__ double decode_slots(const Scalars* __restrict__ sc, i
 // stepFilter lines :118 and :123-124 fused (LGCP: calcWeight :184-208).  src is read through
 // anc[] when anc != nullptr (the previous step's resampling).  A thread owns IT consecutive
 // particles; a block owns CSSM_BLOCK*IT consecutive particles per grid-stride iteration.
+// min waves per SIMD asked of the register allocator: 4 for small d (the kernel is VALU-bound and needs
+// the co-resident waves to cover LDS/table and gather latency), 3 beyond
+template <int D> struct PropWaves { static constexpr int value = (D <= 4) ? 4 : 3; };
+
 template <int D, bool LGCP, int IT>
-__global__ __launch_bounds__(CSSM_BLOCK) void k_propagate(
+__global__ __launch_bounds__(CSSM_BLOCK, PropWaves<D>::value) void k_propagate(
     const double* __restrict__ src, size_t src_stride, const uint32_t* __restrict__ anc,
     double* __restrict__ dst, size_t dst_stride, double* __restrict__ logw, uint64_t n, uint64_t gid0,
     uint64_t seed, const StepRec* __restrict__ rec, ModelK mk, Scalars* __restrict__ sc, int slot_set,
-    const double* __restrict__ src2, size_t src2_stride, uint32_t n_split) {
+    const double* __restrict__ src2, size_t src2_stride, uint32_t n_split, const double* __restrict__ logtab) {
   // src2 != nullptr (sharded filter): ancestor indices >= n_split address the candidates received from
   // other ranks, src2[k * src2_stride + (j - n_split)]
   __shared__ double s_max[CSSM_BLOCK / 64];
+  const double* tab = stage_log_table(logtab);
   const uint32_t step = rec->step;
   const int has_obs = rec->has_obs;
   const double dt = rec->dt;
@@ -273,32 +288,53 @@ __global__ __launch_bounds__(CSSM_BLOCK) void k_propagate(
   double tmax = -cssm_inf();
   bool bad = false;
   const uint64_t per_block = (uint64_t)CSSM_BLOCK * IT;
-  for (uint64_t base = (uint64_t)blockIdx.x * per_block; base < n; base += (uint64_t)gridDim.x * per_block) {
+  const uint64_t stride = (uint64_t)gridDim.x * per_block;
+  // Optional software pipeline over the block's tiles: ancestor indices two tiles ahead, gathered states
+  // one tile ahead of the tile being computed.  MEASURED SLOWER on MI355X (N = 2^24, d = 3: 320 us with
+  // the pipeline at 4 waves/SIMD + spills, 337 us at 3 waves, 280 us without), so it is compiled out:
+  // the extra live registers cost more occupancy than the overlap returns.
+  constexpr bool PF = false;
+  // indices of this thread's IT particles of the tile at `base`, clamped into range (stores are predicated)
+  auto load_idx = [&](uint64_t base, size_t (&j)[IT]) {
     const uint64_t i0 = base + (uint64_t)threadIdx.x * IT;
-    if (i0 >= n) continue;
-    const bool full = (i0 + IT <= n);
-    size_t j[IT];
     if (anc) {
-      if (full && IT == 4) {
-        const uint4 a = *reinterpret_cast<const uint4*>(anc + i0);
-        j[0] = a.x; j[1 % IT] = a.y; j[2 % IT] = a.z; j[3 % IT] = a.w;
-      } else if (full && IT == 2) {
-        const uint2 a = *reinterpret_cast<const uint2*>(anc + i0);
-        j[0] = a.x; j[1 % IT] = a.y;
+      if (i0 + IT <= n && IT == 4) {
+        const uint4 a4 = *reinterpret_cast<const uint4*>(anc + i0);
+        j[0] = a4.x; j[1 % IT] = a4.y; j[2 % IT] = a4.z; j[3 % IT] = a4.w;
+      } else if (i0 + IT <= n && IT == 2) {
+        const uint2 a2 = *reinterpret_cast<const uint2*>(anc + i0);
+        j[0] = a2.x; j[1 % IT] = a2.y;
       } else {
 #pragma unroll
-        for (int r = 0; r < IT; ++r) j[r] = (i0 + r < n) ? (size_t)anc[i0 + r] : (size_t)anc[i0];
+        for (int r = 0; r < IT; ++r) j[r] = (size_t)anc[(i0 + r < n) ? i0 + r : n - 1];
       }
     } else {
 #pragma unroll
-      for (int r = 0; r < IT; ++r) j[r] = (i0 + r < n) ? (size_t)(i0 + r) : (size_t)i0;
+      for (int r = 0; r < IT; ++r) j[r] = (size_t)((i0 + r < n) ? i0 + r : n - 1);
     }
-    double x[IT][D];
+  };
+  auto gather = [&](const size_t (&j)[IT], double (&x)[IT][D]) {
 #pragma unroll
     for (int r = 0; r < IT; ++r)
 #pragma unroll
       for (int k = 0; k < D; ++k)
         x[r][k] = (src2 && j[r] >= n_split) ? src2[(size_t)k * src2_stride + (j[r] - n_split)] : src[(size_t)k * src_stride + j[r]];
+  };
+  uint64_t base = (uint64_t)blockIdx.x * per_block;
+  size_t jn[IT], jnn[IT];
+  double x[IT][D], xn[IT][D];
+  if (base < n) {
+    load_idx(base, jn);
+    gather(jn, x);
+    if (PF && base + stride < n) load_idx(base + stride, jn);
+  }
+  for (; base < n; base += stride) {
+    const uint64_t i0 = base + (uint64_t)threadIdx.x * IT;
+    const bool full = (i0 + IT <= n);
+    if (PF) {
+      if (base + stride < n) gather(jn, xn);                       // next tile's states
+      if (base + 2 * stride < n) load_idx(base + 2 * stride, jnn); // indices of the tile after it
+    }
     double lw[IT];
 #pragma unroll
     for (int r = 0; r < IT; ++r) {
@@ -310,16 +346,27 @@ __global__ __launch_bounds__(CSSM_BLOCK) void k_propagate(
           double g = gamma_of<D>(mk, rec, x[r]);
           lw[r] = g - g;
         } else {
-          double haz = 0.0;
+          double haz = 0.0, carry = 0.0;
           for (int s = 0; s < nsub; ++s) {   // simInitStream(...).take(n), :193-194
-            draw_normals<D>(seed, gid, step, CSSM_STREAM_STEP, (uint32_t)s, z);
+            // normal number q = s*D + k: even q opens Box-Muller pair q>>1 (second element kept for q+1)
+#pragma unroll
+            for (int k = 0; k < D; ++k) {
+              const uint32_t q = (uint32_t)s * D + k;
+              if ((q & 1u) == 0u) {
+                double z0, z1;
+                cssm_normal_pair(cssm_philox_draw(seed, gid, step, CSSM_STREAM_STEP, q >> 1), tab, &z0, &z1);
+                z[k] = z0; carry = z1;
+              } else {
+                z[k] = carry;
+              }
+            }
             transition<D>(mk, rec, dt, x[r], z);
             haz = haz + cssm_exp(gamma_of<D>(mk, rec, x[r])) * dt;   // :203-205
           }
           lw[r] = gamma_of<D>(mk, rec, x[r]) - haz;                // :200,:217
         }
       } else {
-        draw_normals<D>(seed, gid, step, CSSM_STREAM_STEP, 0u, z);
+        draw_normals<D>(seed, gid, step, CSSM_STREAM_STEP, tab, z);
         transition<D>(mk, rec, dt, x[r], z);
         lw[r] = has_obs ? logdens(mk, rec, gamma_of<D>(mk, rec, x[r])) : 0.0;
       }
@@ -353,6 +400,20 @@ __global__ __launch_bounds__(CSSM_BLOCK) void k_propagate(
           if (weighted) logw[i0 + r] = lw[r];
         }
       }
+    }
+    // advance the pipeline
+    if (PF) {
+      if (base + stride < n) {
+#pragma unroll
+        for (int r = 0; r < IT; ++r)
+#pragma unroll
+          for (int k = 0; k < D; ++k) x[r][k] = xn[r][k];
+      }
+#pragma unroll
+      for (int r = 0; r < IT; ++r) jn[r] = jnn[r];
+    } else if (base + stride < n) {
+      load_idx(base + stride, jn);
+      gather(jn, x);
     }
   }
   if (!weighted) return;

@@ -2,6 +2,7 @@
 // kernels of cssm_kernels.hip.h.  No torch, no CPU compute path: every entry point drives HIP.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -76,7 +77,7 @@ struct cssm_pf {
   const long long *send_first_dev = nullptr, *send_count_dev = nullptr;   // last shard_offspring outputs (device)
   cssm_u128 *tileS = nullptr, *tileS2 = nullptr, *tileP = nullptr;
   Scalars* sc = nullptr;
-  double *d_m0 = nullptr, *d_sd0 = nullptr;
+  double *d_m0 = nullptr, *d_sd0 = nullptr, *d_logtab = nullptr;
   StepRec* d_recs = nullptr;
   size_t recs_cap = 0;
   double* d_ll_t = nullptr;
@@ -303,9 +304,9 @@ static void build_rec(const cssm_pf* pf, double t_prev, double t, double y, int 
     case CSSM_OBS_BETA: r->c[0] = cssm_log(y); break;          // c0 = log(y)
     default: break;                                            // Bernoulli, LGCP: no constants
   }
-  const cssm_u32x4 bu = cssm_philox_draw(pf->seed, 0, step, CSSM_STREAM_U, 0, 0);
+  const cssm_u32x4 bu = cssm_philox_draw(pf->seed, 0, step, CSSM_STREAM_U, 0);
   r->u = cssm_u01(bu.v[0], bu.v[1]);
-  const int32_t pr = (int32_t)cssm_philox_draw(pf->seed, 0, step + 1, CSSM_STREAM_PICK, 0, 0).v[0];
+  const int32_t pr = (int32_t)cssm_philox_draw(pf->seed, 0, step + 1, CSSM_STREAM_PICK, 0).v[0];
   const uint32_t pa = pr < 0 ? (uint32_t)0 - (uint32_t)pr : (uint32_t)pr;
   r->pick = (uint32_t)((uint64_t)pa % pf->n_global);
 }
@@ -337,6 +338,8 @@ static int alloc_handle(cssm_pf* pf) {
   HIP_TRY(hipMalloc(&pf->d_m0, CSSM_MAX_DIM * 8));
   HIP_TRY(hipMalloc(&pf->d_sd0, CSSM_MAX_DIM * 8));
   HIP_TRY(hipMalloc(&pf->d_bounds, 64 * 8));
+  HIP_TRY(hipMalloc(&pf->d_logtab, sizeof(CSSM_LOG_TAB)));
+  HIP_TRY(hipMemcpyAsync(pf->d_logtab, CSSM_LOG_TAB, sizeof(CSSM_LOG_TAB), hipMemcpyHostToDevice, pf->stream));
   return upload_init_params(pf);
 }
 
@@ -375,7 +378,7 @@ extern "C" void cssm_pf_destroy(cssm_pf* pf) {
   (void)hipSetDevice(pf->device);
   if (pf->stream) (void)hipStreamSynchronize(pf->stream);
   void* ptrs[] = {pf->state[0], pf->state[1], pf->logw, pf->endslot, pf->anc, pf->tileS, pf->tileS2, pf->tileP, pf->sc,
-                  pf->d_m0, pf->d_sd0, pf->d_recs, pf->d_ll_t, pf->d_ess_t, pf->d_path, pf->cand, pf->cand_end, pf->cand_idx, pf->d_bounds};
+                  pf->d_m0, pf->d_sd0, pf->d_logtab, pf->d_recs, pf->d_ll_t, pf->d_ess_t, pf->d_path, pf->cand, pf->cand_end, pf->cand_idx, pf->d_bounds};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   if (pf->h_recs) (void)hipHostFree(pf->h_recs);
   for (hipEvent_t e : pf->prof_ev) (void)hipEventDestroy(e);
@@ -433,7 +436,7 @@ static int launch_init(cssm_pf* pf, double t0) {
   HIP_TRY(hipSetDevice(pf->device));
   const int grid = grid_for(pf->n, CSSM_BLOCK, kGridCap);
   DISPATCH_D(pf->d, k_init<D><<<dim3(grid), dim3(CSSM_BLOCK), 0, pf->stream>>>(pf->state[0], pf->stride, pf->n, pf->first,
-                                                                              pf->seed, pf->d_m0, pf->d_sd0));
+                                                                              pf->seed, pf->d_m0, pf->d_sd0, pf->d_logtab));
   HIP_TRY(hipGetLastError());
   int rc = reset_scalars(pf);
   if (rc) return rc;
@@ -443,7 +446,7 @@ static int launch_init(cssm_pf* pf, double t0) {
 }
 
 // propagate + weight of one datum (record already on the device)
-static int prop_items(int d) { return d <= 4 ? 4 : (d <= 8 ? 2 : 1); }   // PropItems<D>
+static int prop_items(int d) { return d <= 2 ? 4 : (d <= 8 ? 2 : 1); }   // PropItems<D>
 
 static int launch_propagate(cssm_pf* pf, const StepRec* d_rec) {
   const int grid = grid_for(pf->n, CSSM_BLOCK * prop_items(pf->d), kPropGridCap);
@@ -453,11 +456,11 @@ static int launch_propagate(cssm_pf* pf, const StepRec* d_rec) {
   if (pf->obs_kind == CSSM_OBS_LGCP) {
     DISPATCH_D(pf->d, k_propagate<D, true, PropItems<D>::value><<<dim3(grid), dim3(CSSM_BLOCK), 0, pf->stream>>>(
                           pf->src, pf->src_stride, anc, dst, pf->stride, pf->logw, pf->n, pf->first, pf->seed, d_rec, pf->mk, pf->sc,
-                          pf->sharded ? 0 : pf->wparity, anc ? pf->src2 : nullptr, pf->src2_stride, pf->n_split));
+                          pf->sharded ? 0 : pf->wparity, anc ? pf->src2 : nullptr, pf->src2_stride, pf->n_split, pf->d_logtab));
   } else {
     DISPATCH_D(pf->d, k_propagate<D, false, PropItems<D>::value><<<dim3(grid), dim3(CSSM_BLOCK), 0, pf->stream>>>(
                           pf->src, pf->src_stride, anc, dst, pf->stride, pf->logw, pf->n, pf->first, pf->seed, d_rec, pf->mk, pf->sc,
-                          pf->sharded ? 0 : pf->wparity, anc ? pf->src2 : nullptr, pf->src2_stride, pf->n_split));
+                          pf->sharded ? 0 : pf->wparity, anc ? pf->src2 : nullptr, pf->src2_stride, pf->n_split, pf->d_logtab));
   }
   prof_end(pf);
   HIP_TRY(hipGetLastError());
@@ -592,7 +595,7 @@ static int run_filter(cssm_pf* pf, const double* t, const double* y, const uint8
       HIP_TRY(hipMalloc(&pf->d_path, (T + 1) * (size_t)d * 8));
       pf->path_cap = (T + 1) * (size_t)d;
     }
-    const int32_t pr = (int32_t)cssm_philox_draw(pf->seed, 0, 0, CSSM_STREAM_PICK, 0, 0).v[0];
+    const int32_t pr = (int32_t)cssm_philox_draw(pf->seed, 0, 0, CSSM_STREAM_PICK, 0).v[0];
     const uint32_t pa = pr < 0 ? (uint32_t)0 - (uint32_t)pr : (uint32_t)pr;
     hipLaunchKernelGGL(k_pick, dim3(1), dim3(64), 0, pf->stream, pf->src, pf->src_stride, (const uint32_t*)nullptr,
                        (uint64_t)pa % pf->n, d, pf->d_path);
@@ -1045,7 +1048,7 @@ extern "C" int cssm_pmmh_run(cssm_pf* pf, const cssm_model_desc* desc, const dou
   for (size_t it = 0; it < n_iters; ++it) {
     for (size_t j = 0; j < n_theta; j += 2) {                  // propParams <- proposal(s.params)
       double z0, z1;
-      cssm_normal_pair(cssm_philox_draw(seed, it, (uint32_t)(j / 2), CSSM_STREAM_HOST, 0, 0), &z0, &z1);
+      cssm_normal_pair(cssm_philox_draw(seed, it, (uint32_t)(j / 2), CSSM_STREAM_HOST, 0), CSSM_LOG_TAB, &z0, &z1);
       prop[j] = cur[j] + sd * z0;
       if (j + 1 < n_theta) prop[j + 1] = cur[j + 1] + sd * z1;
     }
@@ -1058,7 +1061,7 @@ extern "C" int cssm_pmmh_run(cssm_pf* pf, const cssm_model_desc* desc, const dou
     if (rc == CSSM_ENONFINITE) pll = -cssm_inf();              // a proposal the filter cannot weigh is rejected
     else if (rc) return rc;
     const double a = pll - cur_ll;                             // logTransition = prior = 0
-    const cssm_u32x4 b = cssm_philox_draw(seed, it, 0xffffffffu, CSSM_STREAM_HOST, 0, 1);
+    const cssm_u32x4 b = cssm_philox_draw(seed, it, 0xffffffffu, CSSM_STREAM_HOST, 1);
     const double uu = cssm_u01_open0(b.v[0], b.v[1]);
     if (cssm_log(uu) < a) {                                    // :75
       cur_ll = pll; cur = prop; ++acc;

@@ -90,16 +90,17 @@ CSSM_HD cssm_u32x4 cssm_philox4x32_10(cssm_u32x4 c, uint32_t k0, uint32_t k1) {
 /*
  * Counter layout: word0/1 = GLOBAL particle id (so results do not depend on how particles
  * are sharded over GPUs), word2 = step (observation index, 0-based; 0 for init),
- * word3 = tag<<28 | substep<<8 | pair.  `pair` p serves latent components 2p and 2p+1;
- * `substep` is the LGCP sub-step (0 for ordinary steps).  Key = the 64-bit seed.
+ * word3 = tag<<28 | pair.  One Philox block yields one Box-Muller PAIR of normals; the normals a
+ * particle consumes within one step are numbered q = substep * d + k (k = latent component in
+ * Tree.flatten order, substep = LGCP sub-step, 0 otherwise) and normal q is element q&1 of pair
+ * q>>1, so no variate is generated twice and at most one is unused.  Key = the 64-bit seed.
  */
-CSSM_HD cssm_u32x4 cssm_philox_draw(uint64_t seed, uint64_t gid, uint32_t step, uint32_t tag,
-                                    uint32_t substep, uint32_t pair) {
+CSSM_HD cssm_u32x4 cssm_philox_draw(uint64_t seed, uint64_t gid, uint32_t step, uint32_t tag, uint32_t pair) {
   cssm_u32x4 c;
   c.v[0] = (uint32_t)gid;
   c.v[1] = (uint32_t)(gid >> 32);
   c.v[2] = step;
-  c.v[3] = (tag << 28) | ((substep & 0xFFFFFu) << 8) | (pair & 0xFFu);
+  c.v[3] = (tag << 28) | (pair & 0x0FFFFFFFu);
   return cssm_philox4x32_10(c, (uint32_t)seed, (uint32_t)(seed >> 32));
 }
 
@@ -203,47 +204,179 @@ CSSM_HD double cssm_log(double x) {
 }
 
 /*
- * log(x) for x in [2^-53, 1] -- the Box-Muller argument -- without any special case: the same
- * algorithm and coefficients as cssm_log, straight-line (x is a positive normal number).
+ * log(x) for x in [2^-53, 1] -- the Box-Muller argument -- without a division and without special
+ * cases.  x = 2^e * f, f in [1,2); j = top 7 mantissa bits of f.  j < 64: m = f, k = e; j >= 64:
+ * m = f/2 in [0.75, 1), k = e + 1.  Table entry j holds invc = RN(1/c_j) and logc = RN(-log(invc)) for
+ * the centre c_j of m's interval (c = 1 exactly for the two intervals touching 1, so log is exact-ish
+ * and never positive near x = 1).  r = m*invc - 1 (one fma), |r| <= 2^-7,
+ * log(x) = (k ln2_hi + logc) + (r + r^2 P(r) + k ln2_lo), P = degree-6 Taylor tail of log1p.
+ * The table (2 KiB) is passed by pointer: the host uses CSSM_LOG_TAB, kernels stage it in LDS.
+ * Generated with 80-digit decimal arithmetic (tests/golden/make_golden.py documents the recipe).
  */
-CSSM_HD double cssm_log_unit(double x) {
+static const double CSSM_LOG_TAB[256] = {
+  0x1.0000000000000p+0, 0x0.0p+0,
+  0x1.fa11caa01fa12p-1, 0x1.7dc475f810a69p-7,
+  0x1.f6310aca0dbb5p-1, 0x1.3cea44346a584p-6,
+  0x1.f25f644230ab5p-1, 0x1.b9fc027af919ap-6,
+  0x1.ee9c7f8458e02p-1, 0x1.1b0d98923d97fp-5,
+  0x1.eae807aba01ebp-1, 0x1.58a5bafc8e4d3p-5,
+  0x1.e741aa59750e4p-1, 0x1.95c830ec8e3f2p-5,
+  0x1.e3a9179dc1a73p-1, 0x1.d276b8adb0b56p-5,
+  0x1.e01e01e01e01ep-1, 0x1.075983598e471p-4,
+  0x1.dca01dca01dcap-1, 0x1.253f62f0a1417p-4,
+  0x1.d92f2231e7f8ap-1, 0x1.42edcbea646eep-4,
+  0x1.d5cac807572b2p-1, 0x1.60658a93750c4p-4,
+  0x1.d272ca3fc5b1ap-1, 0x1.7da766d7b12d0p-4,
+  0x1.cf26e5c44bfc6p-1, 0x1.9ab42462033aep-4,
+  0x1.cbe6d9601cbe7p-1, 0x1.b78c82bb0eda0p-4,
+  0x1.c8b265afb8a42p-1, 0x1.d4313d66cb35dp-4,
+  0x1.c5894d10d4986p-1, 0x1.f0a30c01162a4p-4,
+  0x1.c26b5392ea01cp-1, 0x1.0671512ca596fp-3,
+  0x1.bf583ee868d8bp-1, 0x1.14785846742acp-3,
+  0x1.bc4fd65883e7bp-1, 0x1.2266f190a5acdp-3,
+  0x1.b951e2b18ff23p-1, 0x1.303d718e47fd5p-3,
+  0x1.b65e2e3beee05p-1, 0x1.3dfc2b0ecc62ap-3,
+  0x1.b37484ad806cep-1, 0x1.4ba36f39a55e5p-3,
+  0x1.b094b31d922a4p-1, 0x1.59338d9982085p-3,
+  0x1.adbe87f94905ep-1, 0x1.66acd4272ad51p-3,
+  0x1.aaf1d2f87ebfdp-1, 0x1.740f8f54037a3p-3,
+  0x1.a82e65130e159p-1, 0x1.815c0a14357e9p-3,
+  0x1.a574107688a4ap-1, 0x1.8e928de886d41p-3,
+  0x1.a2c2a87c51ca0p-1, 0x1.9bb362e7dfb85p-3,
+  0x1.a01a01a01a01ap-1, 0x1.a8becfc882f19p-3,
+  0x1.9d79f176b682dp-1, 0x1.b5b519e8fb5a6p-3,
+  0x1.9ae24ea5510dap-1, 0x1.c2968558c18c2p-3,
+  0x1.9852f0d8ec0ffp-1, 0x1.cf6354e09c5ddp-3,
+  0x1.95cbb0be377aep-1, 0x1.dc1bca0abec7bp-3,
+  0x1.934c67f9b2ce6p-1, 0x1.e8c0252aa5a60p-3,
+  0x1.90d4f120190d5p-1, 0x1.f550a564b7b37p-3,
+  0x1.8e6527af1373fp-1, 0x1.00e6c45ad501dp-2,
+  0x1.8bfce8062ff3ap-1, 0x1.071b85fcd590dp-2,
+  0x1.899c0f601899cp-1, 0x1.0d46b579ab74bp-2,
+  0x1.87427bcc092b9p-1, 0x1.136870293a8b0p-2,
+  0x1.84f00c2780614p-1, 0x1.1980d2dd4236fp-2,
+  0x1.82a4a0182a4a0p-1, 0x1.1f8ff9e48a2f3p-2,
+  0x1.8060180601806p-1, 0x1.2596010df763ap-2,
+  0x1.7e225515a4f1dp-1, 0x1.2b9303ab89d25p-2,
+  0x1.7beb3922e017cp-1, 0x1.31871c9544185p-2,
+  0x1.79baa6bb6398bp-1, 0x1.3772662bfd85cp-2,
+  0x1.77908119ac60dp-1, 0x1.3d54fa5c1f710p-2,
+  0x1.756cac201756dp-1, 0x1.432ef2a04e813p-2,
+  0x1.734f0c541fe8dp-1, 0x1.49006804009d0p-2,
+  0x1.713786d9c7c09p-1, 0x1.4ec9732600269p-2,
+  0x1.6f26016f26017p-1, 0x1.548a2c3add263p-2,
+  0x1.6d1a62681c861p-1, 0x1.5a42ab0f4cfe2p-2,
+  0x1.6b1490aa31a3dp-1, 0x1.5ff3070a793d4p-2,
+  0x1.691473a88d0c0p-1, 0x1.659b57303e1f2p-2,
+  0x1.6719f3601671ap-1, 0x1.6b3bb2235943dp-2,
+  0x1.6524f853b4aa3p-1, 0x1.70d42e2789236p-2,
+  0x1.63356b88ac0dep-1, 0x1.7664e1239dbcfp-2,
+  0x1.614b36831ae94p-1, 0x1.7bede0a37afbfp-2,
+  0x1.5f66434292dfcp-1, 0x1.816f41da0d495p-2,
+  0x1.5d867c3ece2a5p-1, 0x1.86e919a330ba1p-2,
+  0x1.5babcc647fa91p-1, 0x1.8c5b7c858b48bp-2,
+  0x1.59d61f123ccaap-1, 0x1.91c67eb45a83ep-2,
+  0x1.5805601580560p-1, 0x1.972a341135159p-2,
+  0x1.56397ba7c52e2p-1, 0x1.9c86b02dc0862p-2,
+  0x1.54725e6bb82fep+0, -0x1.23ec5991eba49p-2,
+  0x1.52aff56a8054bp+0, -0x1.1e9e1678899f5p-2,
+  0x1.50f22e111c4c5p+0, -0x1.1956d3b9bc2f9p-2,
+  0x1.4f38f62dd4c9bp+0, -0x1.14167ef367784p-2,
+  0x1.4d843bedc2c4cp+0, -0x1.0edd060b78082p-2,
+  0x1.4bd3edda68fe1p+0, -0x1.09aa572e6c6d4p-2,
+  0x1.4a27fad76014ap+0, -0x1.047e60cde83b7p-2,
+  0x1.4880522014880p+0, -0x1.feb2233ea07cbp-3,
+  0x1.46dce34596066p+0, -0x1.f474b134df228p-3,
+  0x1.453d9e2c776cap+0, -0x1.ea4449f04aaf5p-3,
+  0x1.43a2730abee4dp+0, -0x1.e020cc6235ab5p-3,
+  0x1.420b5265e5951p+0, -0x1.d60a17f903514p-3,
+  0x1.40782d10e6566p+0, -0x1.cc000c9db3c52p-3,
+  0x1.3ee8f42a5af07p+0, -0x1.c2028ab17f9b5p-3,
+  0x1.3d5d991aa75c6p+0, -0x1.b811730b823d4p-3,
+  0x1.3bd60d9232955p+0, -0x1.ae2ca6f672bd8p-3,
+  0x1.3a524387ac822p+0, -0x1.a454082e6ab03p-3,
+  0x1.38d22d366088ep+0, -0x1.9a8778debaa3ap-3,
+  0x1.3755bd1c945eep+0, -0x1.90c6db9fcbcdbp-3,
+  0x1.35dce5f9f2af8p+0, -0x1.871213750e994p-3,
+  0x1.34679ace01346p+0, -0x1.7d6903caf5acdp-3,
+  0x1.32f5ced6a1dfap+0, -0x1.73cb9074fd14dp-3,
+  0x1.3187758e9ebb6p+0, -0x1.6a399dabbd383p-3,
+  0x1.301c82ac40260p+0, -0x1.60b3100b09474p-3,
+  0x1.2eb4ea1fed14bp+0, -0x1.5737cc9018cddp-3,
+  0x1.2d50a012d50a0p+0, -0x1.4dc7b897bc1c7p-3,
+  0x1.2bef98e5a3711p+0, -0x1.4462b9dc9b3dcp-3,
+  0x1.2a91c92f3c105p+0, -0x1.3b08b6757f2a7p-3,
+  0x1.293725bb804a5p+0, -0x1.31b994d3a4f86p-3,
+  0x1.27dfa38a1ce4dp+0, -0x1.28753bc11aba2p-3,
+  0x1.268b37cd60127p+0, -0x1.1f3b925f25d44p-3,
+  0x1.2539d7e9177b2p+0, -0x1.160c8024b27b0p-3,
+  0x1.23eb79717605bp+0, -0x1.0ce7ecdccc28bp-3,
+  0x1.22a0122a0122ap+0, -0x1.03cdc0a51ec0dp-3,
+  0x1.21579804855e6p+0, -0x1.f57bc7d9005dbp-4,
+  0x1.2012012012012p+0, -0x1.e3707ee30487bp-4,
+  0x1.1ecf43c7fb84cp+0, -0x1.d179788219362p-4,
+  0x1.1d8f5672e4abdp+0, -0x1.bf968769fca18p-4,
+  0x1.1c522fc1ce059p+0, -0x1.adc77ee5aea8ep-4,
+  0x1.1b17c67f2bae3p+0, -0x1.9c0c32d4d254dp-4,
+  0x1.19e0119e0119ep+0, -0x1.8a6477a91dc29p-4,
+  0x1.18ab083902bdbp+0, -0x1.78d02263d82d7p-4,
+  0x1.1778a191bd684p+0, -0x1.674f089365a78p-4,
+  0x1.1648d50fc3201p+0, -0x1.55e10050e0382p-4,
+  0x1.151b9a3fdd5c9p+0, -0x1.4485e03dbdfb0p-4,
+  0x1.13f0e8d344724p+0, -0x1.333d7f8183f4ap-4,
+  0x1.12c8b89edc0acp+0, -0x1.2207b5c7854a1p-4,
+  0x1.11a3019a74826p+0, -0x1.10e45b3cae829p-4,
+  0x1.107fbbe011080p+0, -0x1.ffa6911ab9309p-5,
+  0x1.0f5edfab325a2p+0, -0x1.dda8adc67ee59p-5,
+  0x1.0e40655826011p+0, -0x1.bbcebfc68f424p-5,
+  0x1.0d24456359e3ap+0, -0x1.9a187b573de81p-5,
+  0x1.0c0a7868b4171p+0, -0x1.788595a3577c8p-5,
+  0x1.0af2f722eecb5p+0, -0x1.5715c4c03cee1p-5,
+  0x1.09ddba6af8360p+0, -0x1.35c8bfaa13069p-5,
+  0x1.08cabb37565e2p+0, -0x1.149e3e4005a8dp-5,
+  0x1.07b9f29b8eae2p+0, -0x1.e72bf2813ce6ap-6,
+  0x1.06ab59c7912fbp+0, -0x1.a55f548c5c427p-6,
+  0x1.059eea0727586p+0, -0x1.63d6178690bbep-6,
+  0x1.04949cc1664c5p+0, -0x1.228fb1fea2e0ap-6,
+  0x1.038c6b78247fcp+0, -0x1.c317384c75f0dp-7,
+  0x1.02864fc7729e9p+0, -0x1.41929f968330cp-7,
+  0x1.0182436517a37p+0, -0x1.8121214586b02p-8,
+  0x1.0000000000000p+0, 0x0.0p+0,
+};
+
+CSSM_HD double cssm_log_unit(double x, const double* tab) {
   const double LN2_HI = 6.93147180369123816490e-01;
   const double LN2_LO = 1.90821492927058770002e-10;
-  const double LG1 = 6.666666666666735130e-01, LG2 = 3.999999999940941908e-01,
-               LG3 = 2.857142874366239149e-01, LG4 = 2.222219843214978396e-01,
-               LG5 = 1.818357216161805012e-01, LG6 = 1.531383769920937332e-01,
-               LG7 = 1.479819860511658591e-01;
-  uint64_t ux = cssm_d2u(x);
-  uint32_t hx = (uint32_t)(ux >> 32);
-  int k = (int)(hx >> 20) - 1023;
-  hx &= 0x000fffffu;
-  uint32_t i = (hx + 0x95f64u) & 0x100000u;
-  ux = ((uint64_t)(hx | (i ^ 0x3ff00000u)) << 32) | (ux & 0xffffffffULL);
-  k += (int)(i >> 20);
-  double m = cssm_u2d(ux);
-  double f = m - 1.0;
-  double s = f / (2.0 + f);
-  double dk = (double)k;
-  double z = s * s;
-  double w = z * z;
-  double t1 = w * cssm_fma(w, cssm_fma(w, LG6, LG4), LG2);
-  double t2 = z * cssm_fma(w, cssm_fma(w, cssm_fma(w, LG7, LG5), LG3), LG1);
-  double R = t2 + t1;
-  double hfsq = 0.5 * f * f;
-  return dk * LN2_HI - ((hfsq - (s * (hfsq + R) + dk * LN2_LO)) - f);
+  const uint64_t ux = cssm_d2u(x);
+  const int e = (int)(ux >> 52) - 1023;
+  const uint32_t j = (uint32_t)(ux >> 45) & 127u;
+  const int up = (int)(j >> 6);
+  const double m = cssm_u2d((ux & 0x000fffffffffffffULL) | ((uint64_t)(0x3ff - up) << 52));
+  const double kd = (double)(e + up);
+  const double invc = tab[2 * j], logc = tab[2 * j + 1];
+  const double r = cssm_fma(m, invc, -1.0);
+  double p = -1.0 / 8.0;
+  p = cssm_fma(p, r, 1.0 / 7.0);
+  p = cssm_fma(p, r, -1.0 / 6.0);
+  p = cssm_fma(p, r, 1.0 / 5.0);
+  p = cssm_fma(p, r, -1.0 / 4.0);
+  p = cssm_fma(p, r, 1.0 / 3.0);
+  p = cssm_fma(p, r, -0.5);
+  const double hi = cssm_fma(kd, LN2_HI, logc);
+  const double lo = cssm_fma(r * r, p, kd * LN2_LO);
+  return hi + (r + lo);
 }
 
 /* ------------------------------------------------------------------ sin/cos of 2*pi*u */
 
 /*
  * (sin, cos)(2*pi*u) for u in [0,1).  4u is split EXACTLY into a quadrant q = round(4u) and
- * r in [-1/2,1/2]; x = r*pi/2 is formed as a double-double and fed to the fdlibm kernels.
+ * r in [-1/2,1/2]; x = RN(r*pi/2) is fed to the fdlibm kernel polynomials (< 2 ulp overall).
  * No large-argument reduction exists, so there is nothing to get wrong at large t: seasonal
  * phases (model/Model.scala:217-223) are reduced as frac(a*t/P) first, see cssm_seasonal_phase.
  */
 CSSM_HD void cssm_sincos2pi(double u, double* sn, double* cs) {
   const double PIO2_HI = 1.57079632679489655800e+00; /* 0x3FF921FB54442D18 */
-  const double PIO2_LO = 6.12323399573676603587e-17; /* 0x3C91A62633145C07 */
   const double S1 = -1.66666666666666324348e-01, S2 = 8.33333333332248946124e-03,
                S3 = -1.98412698298579493134e-04, S4 = 2.75573137070700676789e-06,
                S5 = -2.50507602534068634195e-08, S6 = 1.58969099521155010221e-10;
@@ -253,18 +386,16 @@ CSSM_HD void cssm_sincos2pi(double u, double* sn, double* cs) {
   double t = 4.0 * u;
   int q = (int)(t + 0.5);
   double r = t - (double)q;
-  double xh = r * PIO2_HI;
-  double xl = cssm_fma(r, PIO2_HI, -xh) + r * PIO2_LO;
-  double z = xh * xh;
-  /* sin kernel */
-  double v = z * xh;
-  double rs = cssm_fma(z, cssm_fma(z, cssm_fma(z, cssm_fma(z, S6, S5), S4), S3), S2);
-  double s = xh - ((z * (0.5 * xl - v * rs) - xl) - v * S1);
-  /* cos kernel */
-  double rc = z * cssm_fma(z, cssm_fma(z, cssm_fma(z, cssm_fma(z, cssm_fma(z, C6, C5), C4), C3), C2), C1);
-  double hz = 0.5 * z;
-  double w = 1.0 - hz;
-  double c = w + (((1.0 - w) - hz) + (z * rc - xh * xl));
+  const double x = r * PIO2_HI; /* the angle, rounded once: |error| < 1.2e-16 * |x| */
+  const double z = x * x;
+  /* sin kernel: x + x^3 (S1 + z (S2 + ...)) */
+  const double rs = cssm_fma(z, cssm_fma(z, cssm_fma(z, cssm_fma(z, cssm_fma(z, S6, S5), S4), S3), S2), S1);
+  const double s = cssm_fma(z * x, rs, x);
+  /* cos kernel: 1 - z/2 + z^2 (C1 + z (C2 + ...)) */
+  const double rc = cssm_fma(z, cssm_fma(z, cssm_fma(z, cssm_fma(z, cssm_fma(z, C6, C5), C4), C3), C2), C1);
+  const double hz = 0.5 * z;
+  const double w = 1.0 - hz;
+  const double c = w + (((1.0 - w) - hz) + (z * z) * rc);
   /* quadrant rotation without branches: odd q swaps, bit 1 of q (of q+1) negates sin (cos) */
   const int swap = q & 1;
   const double ss = swap ? c : s;
@@ -287,11 +418,14 @@ CSSM_HD double cssm_seasonal_phase(double a, double t, double period) {
 
 /* ------------------------------------------------------------------ Box-Muller */
 
-/* Two standard normals from one Philox block: r = sqrt(-2 log u1), (r cos, r sin)(2 pi u2). */
-CSSM_HD void cssm_normal_pair(cssm_u32x4 b, double* z0, double* z1) {
+/* Two standard normals from one Philox block: r = sqrt(-2 log u1), (r cos, r sin)(2 pi u2).
+ * `tab` = CSSM_LOG_TAB (host) or its copy in LDS (kernels). */
+CSSM_HD void cssm_normal_pair(cssm_u32x4 b, const double* tab, double* z0, double* z1) {
   double u1 = cssm_u01_open0(b.v[0], b.v[1]);
   double u2 = cssm_u01(b.v[2], b.v[3]);
-  double r = cssm_sqrt(-2.0 * cssm_log_unit(u1));
+  double t = -2.0 * cssm_log_unit(u1, tab);
+  t = (t < 0.0) ? 0.0 : t; /* log_unit(x <= 1) <= 0 by construction; the clamp documents it */
+  double r = cssm_sqrt(t);
   double sn, cs;
   cssm_sincos2pi(u2, &sn, &cs);
   *z0 = r * cs;

@@ -98,7 +98,7 @@ static void o_normal_pair(const oracle_pf* pf, cssm_u32x4 b, double* z0, double*
     *z0 = r * cos(6.283185307179586476925 * u2);
     *z1 = r * sin(6.283185307179586476925 * u2);
   } else {
-    cssm_normal_pair(b, z0, z1);
+    cssm_normal_pair(b, CSSM_LOG_TAB, z0, z1);
   }
 }
 
@@ -210,14 +210,14 @@ int oracle_pf_components(const oracle_pf* pf, double* out) {
 
 /* ------------------------------------------------------------------ random variates */
 
-/* d standard normals of particle `gid` at (step, tag, substep): component k = element k%2 of
- * pair k/2 (include/cssm_numerics.h, counter layout). */
+/* d standard normals of particle `gid` at (step, tag, substep): normal number q = substep*d + k is
+ * element q&1 of Box-Muller pair q>>1 (include/cssm_numerics.h, counter layout). */
 static void draw_normals(const oracle_pf* pf, uint64_t gid, uint32_t step, uint32_t tag, uint32_t sub, double* z) {
-  for (int p = 0; 2 * p < pf->d; ++p) {
+  for (int k = 0; k < pf->d; ++k) {
+    uint32_t q = sub * (uint32_t)pf->d + (uint32_t)k;
     double z0, z1;
-    o_normal_pair(pf, cssm_philox_draw(pf->seed, gid, step, tag, sub, (uint32_t)p), &z0, &z1);
-    z[2 * p] = z0;
-    if (2 * p + 1 < pf->d) z[2 * p + 1] = z1;
+    o_normal_pair(pf, cssm_philox_draw(pf->seed, gid, step, tag, q >> 1), &z0, &z1);
+    z[k] = (q & 1u) ? z1 : z0;
   }
 }
 
@@ -437,8 +437,8 @@ static int weigh_and_resample(oracle_pf* pf) {
   }
   if (max == -INFINITY || isinf(max)) return ORACLE_ENONFINITE;
   for (uint64_t i = 0; i < n; ++i) pf->w1[i] = o_exp(pf, pf->w[i] - max);   /* :125 */
-  double u = cssm_u01(cssm_philox_draw(pf->seed, 0, pf->step, CSSM_STREAM_U, 0, 0).v[0],
-                      cssm_philox_draw(pf->seed, 0, pf->step, CSSM_STREAM_U, 0, 0).v[1]);
+  const cssm_u32x4 bu = cssm_philox_draw(pf->seed, 0, pf->step, CSSM_STREAM_U, 0);
+  double u = cssm_u01(bu.v[0], bu.v[1]);
   int rc = oracle_resample_systematic(pf->w1, n, u, pf->anc, pf->C, pf->flags);   /* :126 */
   if (rc) return rc;
   if (pf->flags & ORACLE_LITERAL_SUMS) {
@@ -577,7 +577,7 @@ void oracle_pf_set_particles(oracle_pf* pf, const double* soa) {
 
 /* Resampling.sampleOne, model/Resampling.scala:151-154: abs(nextInt) % size */
 static uint64_t pick_index(const oracle_pf* pf, uint32_t s) {
-  int32_t r = (int32_t)cssm_philox_draw(pf->seed, 0, s, CSSM_STREAM_PICK, 0, 0).v[0];
+  int32_t r = (int32_t)cssm_philox_draw(pf->seed, 0, s, CSSM_STREAM_PICK, 0).v[0];
   uint32_t a = r < 0 ? (uint32_t)0 - (uint32_t)r : (uint32_t)r;
   return (uint64_t)a % pf->n;
 }
@@ -654,7 +654,7 @@ int oracle_pmmh_run(oracle_pf* pf, cssm_model_desc* desc, const double* theta0, 
   for (size_t it = 0; it < n_iters && !rc; ++it) {
     for (size_t j = 0; j < n_theta; j += 2) {                   /* proposal(s.params) */
       double z0, z1;
-      cssm_normal_pair(cssm_philox_draw(seed, it, (uint32_t)(j / 2), CSSM_STREAM_HOST, 0, 0), &z0, &z1);
+      cssm_normal_pair(cssm_philox_draw(seed, it, (uint32_t)(j / 2), CSSM_STREAM_HOST, 0), CSSM_LOG_TAB, &z0, &z1);
       prop[j] = cur[j] + sd * z0;
       if (j + 1 < n_theta) prop[j + 1] = cur[j + 1] + sd * z1;
     }
@@ -667,7 +667,7 @@ int oracle_pmmh_run(oracle_pf* pf, cssm_model_desc* desc, const double* theta0, 
     if (frc == ORACLE_ENONFINITE) pll = -INFINITY;              /* a proposal the filter cannot weigh is rejected */
     else if (frc) { rc = frc; break; }
     double a = pll - cur_ll;                                    /* logTransition = prior = 0 */
-    cssm_u32x4 b = cssm_philox_draw(seed, it, 0xffffffffu, CSSM_STREAM_HOST, 0, 1);
+    cssm_u32x4 b = cssm_philox_draw(seed, it, 0xffffffffu, CSSM_STREAM_HOST, 1);
     double uu = cssm_u01_open0(b.v[0], b.v[1]);
     if (cssm_log(uu) < a) {                                     /* :75 */
       cur_ll = pll; memcpy(cur, prop, n_theta * 8); memcpy(cur_state, path + T * d, d * 8); ++acc;
@@ -690,21 +690,22 @@ void oracle_c_philox(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[
   c = cssm_philox4x32_10(c, key[0], key[1]);
   memcpy(out, c.v, 16);
 }
-void oracle_c_normals(uint64_t seed, uint64_t gid, uint32_t step, uint32_t tag, uint32_t sub, uint32_t pair, double* z2) {
-  cssm_normal_pair(cssm_philox_draw(seed, gid, step, tag, sub, pair), &z2[0], &z2[1]);
+void oracle_c_normals(uint64_t seed, uint64_t gid, uint32_t step, uint32_t tag, uint32_t pair, double* z2) {
+  cssm_normal_pair(cssm_philox_draw(seed, gid, step, tag, pair), CSSM_LOG_TAB, &z2[0], &z2[1]);
 }
+void oracle_c_log_unit_v(const double* x, double* y, size_t n) { for (size_t i = 0; i < n; ++i) y[i] = cssm_log_unit(x[i], CSSM_LOG_TAB); }
 double oracle_c_lgamma_kp1(long long k) { return cssm_lgamma_kp1(k); }
 double oracle_c_lgamma(double x) { return cssm_lgamma(x); }
 uint64_t oracle_c_sys_count(double C, double u, uint64_t n) { return cssm_sys_count(C, u, n); }
 double oracle_c_fix_roundtrip(double w) { return cssm_fix_to_double(cssm_fix_from_double(w)); }
 double oracle_c_u(uint64_t seed, uint32_t step) {
-  cssm_u32x4 b = cssm_philox_draw(seed, 0, step, CSSM_STREAM_U, 0, 0);
+  cssm_u32x4 b = cssm_philox_draw(seed, 0, step, CSSM_STREAM_U, 0);
   return cssm_u01(b.v[0], b.v[1]);
 }
 /* vectorised for ulp sweeps */
 void oracle_c_exp_v(const double* x, double* y, size_t n) { for (size_t i = 0; i < n; ++i) y[i] = cssm_exp(x[i]); }
 void oracle_c_log_v(const double* x, double* y, size_t n) { for (size_t i = 0; i < n; ++i) y[i] = cssm_log(x[i]); }
 void oracle_c_sincos2pi_v(const double* u, double* s, double* c, size_t n) { for (size_t i = 0; i < n; ++i) cssm_sincos2pi(u[i], &s[i], &c[i]); }
-void oracle_c_normals_v(uint64_t seed, uint64_t gid0, uint32_t step, uint32_t tag, uint32_t sub, uint32_t pair, double* z, size_t n) {
-  for (size_t i = 0; i < n; ++i) cssm_normal_pair(cssm_philox_draw(seed, gid0 + i, step, tag, sub, pair), &z[2 * i], &z[2 * i + 1]);
+void oracle_c_normals_v(uint64_t seed, uint64_t gid0, uint32_t step, uint32_t tag, uint32_t pair, double* z, size_t n) {
+  for (size_t i = 0; i < n; ++i) cssm_normal_pair(cssm_philox_draw(seed, gid0 + i, step, tag, pair), CSSM_LOG_TAB, &z[2 * i], &z[2 * i + 1]);
 }

@@ -78,7 +78,8 @@ def lib() -> C.CDLL:
             "oracle_c_exp": (C.c_double, [C.c_double]),
             "oracle_c_log": (C.c_double, [C.c_double]),
             "oracle_c_philox": (None, [_u32p, _u32p, _u32p]),
-            "oracle_c_normals": (None, [C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, _dp]),
+            "oracle_c_normals": (None, [C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, _dp]),
+            "oracle_c_log_unit_v": (None, [_dp, _dp, C.c_size_t]),
             "oracle_c_lgamma_kp1": (C.c_double, [C.c_longlong]),
             "oracle_c_sys_count": (C.c_uint64, [C.c_double, C.c_double, C.c_uint64]),
             "oracle_c_fix_roundtrip": (C.c_double, [C.c_double]),
@@ -86,7 +87,7 @@ def lib() -> C.CDLL:
             "oracle_c_exp_v": (None, [_dp, _dp, C.c_size_t]),
             "oracle_c_log_v": (None, [_dp, _dp, C.c_size_t]),
             "oracle_c_sincos2pi_v": (None, [_dp, _dp, _dp, C.c_size_t]),
-            "oracle_c_normals_v": (None, [C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, _dp, C.c_size_t]),
+            "oracle_c_normals_v": (None, [C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, _dp, C.c_size_t]),
         }
         for name, (res, args) in sig.items():
             f = getattr(L, name)
@@ -230,5 +231,9 @@ def c_philox(ctr, key):
     lib().oracle_c_philox(_p(ctr, _u32p), _p(key, _u32p), _p(out, _u32p)); return out
 
 
-def c_normals(seed, gid0, step, tag, sub, pair, n):
-    z = np.zeros((n, 2)); lib().oracle_c_normals_v(seed, gid0, step, tag, sub, pair, _p(z), n); return z
+def c_normals(seed, gid0, step, tag, pair, n):
+    z = np.zeros((n, 2)); lib().oracle_c_normals_v(seed, gid0, step, tag, pair, _p(z), n); return z
+
+
+def c_log_unit(x):
+    x = np.ascontiguousarray(x, dtype=np.float64); y = np.empty_like(x); lib().oracle_c_log_unit_v(_p(x), _p(y), x.size); return y

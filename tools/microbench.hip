@@ -11,17 +11,20 @@
 #define CHECK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); return 1; } } while (0)
 
 template <int MODE>
-__global__ __launch_bounds__(256) void k_piece(double* __restrict__ out, uint64_t n, uint64_t seed, uint32_t step) {
+__global__ __launch_bounds__(256) void k_piece(double* __restrict__ out, uint64_t n, uint64_t seed, uint32_t step, const double* __restrict__ gtab) {
+  __shared__ double tab[256];
+  tab[threadIdx.x] = gtab[threadIdx.x];
+  __syncthreads();
   for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (uint64_t)gridDim.x * 256) {
     double acc = 0.0;
 #pragma unroll
     for (int p = 0; p < 2; ++p) {
       cssm_u32x4 b;
       if (MODE == 0) { b.v[0] = (uint32_t)i * 2654435761u + p; b.v[1] = (uint32_t)(i >> 3) ^ 0x9E3779B9u; b.v[2] = b.v[0] ^ step; b.v[3] = b.v[1] + p; }
-      else b = cssm_philox_draw(seed, i, step, 0, 0, p);
+      else b = cssm_philox_draw(seed, i, step, 0, p);
       double u1 = cssm_u01_open0(b.v[0], b.v[1]), u2 = cssm_u01(b.v[2], b.v[3]);
       if (MODE <= 1) { acc += u1 + u2; continue; }
-      double l = cssm_log(u1);
+      double l = cssm_log_unit(u1, tab);
       if (MODE == 2) { acc += l + u2; continue; }
       double r = cssm_sqrt(-2.0 * l);
       if (MODE == 3) { acc += r + u2; continue; }
@@ -57,18 +60,19 @@ static float time_it(F launch, int reps) {
 int main() {
   const uint64_t sizes[] = {1ull << 20, 1ull << 22, 1ull << 24};
   for (uint64_t n : sizes) {
-    double *out, *src, *dst;
+    double *out, *src, *dst, *gtab;
+    CHECK(hipMalloc(&gtab, sizeof(CSSM_LOG_TAB))); CHECK(hipMemcpy(gtab, CSSM_LOG_TAB, sizeof(CSSM_LOG_TAB), hipMemcpyHostToDevice));
     CHECK(hipMalloc(&out, n * 8)); CHECK(hipMalloc(&src, n * 8 * 3)); CHECK(hipMalloc(&dst, n * 8 * 4));
     CHECK(hipMemset(src, 0, n * 8 * 3));
     for (int grid : {1024, 2048, 4096, 8192}) {
       if ((uint64_t)grid * 256 > n) continue;
       printf("N=%llu grid=%d:", (unsigned long long)n, grid);
-      printf(" nophilox %.1f", time_it([&] { k_piece<0><<<grid, 256>>>(out, n, 1, 2); }, 20));
-      printf(" philox %.1f", time_it([&] { k_piece<1><<<grid, 256>>>(out, n, 1, 2); }, 20));
-      printf(" +log %.1f", time_it([&] { k_piece<2><<<grid, 256>>>(out, n, 1, 2); }, 20));
-      printf(" +sqrt %.1f", time_it([&] { k_piece<3><<<grid, 256>>>(out, n, 1, 2); }, 20));
-      printf(" +sincos %.1f", time_it([&] { k_piece<4><<<grid, 256>>>(out, n, 1, 2); }, 20));
-      printf(" +exp %.1f", time_it([&] { k_piece<5><<<grid, 256>>>(out, n, 1, 2); }, 20));
+      printf(" nophilox %.1f", time_it([&] { k_piece<0><<<grid, 256>>>(out, n, 1, 2, gtab); }, 20));
+      printf(" philox %.1f", time_it([&] { k_piece<1><<<grid, 256>>>(out, n, 1, 2, gtab); }, 20));
+      printf(" +log %.1f", time_it([&] { k_piece<2><<<grid, 256>>>(out, n, 1, 2, gtab); }, 20));
+      printf(" +sqrt %.1f", time_it([&] { k_piece<3><<<grid, 256>>>(out, n, 1, 2, gtab); }, 20));
+      printf(" +sincos %.1f", time_it([&] { k_piece<4><<<grid, 256>>>(out, n, 1, 2, gtab); }, 20));
+      printf(" +exp %.1f", time_it([&] { k_piece<5><<<grid, 256>>>(out, n, 1, 2, gtab); }, 20));
       printf(" | stream(56B) %.1f us\n", time_it([&] { k_stream<<<grid, 256>>>(src, dst, n, n); }, 20));
     }
     hipFree(out); hipFree(src); hipFree(dst);
