@@ -32,13 +32,18 @@
 #define FM_ADD 2   /* acc += c*x                                 */
 
 // Per-model constants, passed BY VALUE (kernarg -> SGPRs; every branch on them is wave-uniform).
+// One byte per latent component: bits 0-1 CSSM_SDE_*, bits 2-3 FM_*, bit 4 closes its leaf, bit 5 leaf is
+// the leftmost one.  Packed four to a word so that the whole struct costs 6 SGPRs (66 unpacked made the
+// kernel spill scalars through v_writelane/v_readlane).
 struct ModelK {
   int32_t d;
   int32_t obs_kind;
-  int32_t kind[CSSM_MAX_DIM];    // CSSM_SDE_*
-  int32_t fmode[CSSM_MAX_DIM];   // FM_*
-  int32_t leaf_end[CSSM_MAX_DIM];// 1 if component closes its leaf
-  int32_t first_leaf[CSSM_MAX_DIM]; // 1 if that leaf is the leftmost one
+  uint32_t comp[CSSM_MAX_DIM / 4];
+  __host__ __device__ __forceinline__ uint32_t byte(int k) const { return (comp[k >> 2] >> ((k & 3) * 8)) & 0xffu; }
+  __host__ __device__ __forceinline__ int kind(int k) const { return (int)(byte(k) & 3u); }
+  __host__ __device__ __forceinline__ int fmode(int k) const { return (int)((byte(k) >> 2) & 3u); }
+  __host__ __device__ __forceinline__ bool leaf_end(int k) const { return (byte(k) >> 4) & 1u; }
+  __host__ __device__ __forceinline__ bool first_leaf(int k) const { return (byte(k) >> 5) & 1u; }
 };
 
 // Per-observation record, built on the host (everything that depends only on (t, y)).
@@ -139,7 +144,7 @@ __device__ __forceinline__ void transition(const ModelK& mk, const StepRec* __re
 #pragma unroll
   for (int k = 0; k < D; ++k) {
     const double p0 = rec->coef[k][0], p1 = rec->coef[k][1], p2 = rec->coef[k][2], p3 = rec->coef[k][3];
-    const int kind = mk.kind[k];
+    const int kind = mk.kind(k);
     if (kind == CSSM_SDE_BROWNIAN) {
       x[k] = p3 * z[k] + x[k];
     } else if (kind == CSSM_SDE_GEN_BROWNIAN) {
@@ -163,10 +168,10 @@ __device__ __forceinline__ double gamma_of(const ModelK& mk, const StepRec* __re
   double g = 0.0, acc = 0.0;
 #pragma unroll
   for (int k = 0; k < D; ++k) {
-    const int fm = mk.fmode[k];
+    const int fm = mk.fmode(k);
     if (fm == FM_START) acc = rec->fco[k] * x[k];
     else if (fm == FM_ADD) acc = acc + rec->fco[k] * x[k];
-    if (mk.leaf_end[k]) g = mk.first_leaf[k] ? acc : g + acc;
+    if (mk.leaf_end(k)) g = mk.first_leaf(k) ? acc : g + acc;
   }
   return g;
 }
@@ -250,7 +255,10 @@ __device__ __forceinline__ double block_decode_slots(const Scalars* __restrict__
 
 // Particles per thread in k_propagate: all gathers of a thread are issued before its ALU work,
 // and rows are stored as 16-/32-byte vectors.
-template <int D> struct PropItems { static constexpr int value = (D <= 2) ? 4 : (D <= 8 ? 2 : 1); };
+#ifndef CSSM_PROP_IT_MID
+#define CSSM_PROP_IT_MID 2
+#endif
+template <int D> struct PropItems { static constexpr int value = (D <= 2) ? 4 : (D <= 8 ? CSSM_PROP_IT_MID : 1); };
 
 // max over the CSSM_MAXSLOTS shards of the running max log-weight
 __device__ __forceinline__ double decode_slots(const Scalars* __restrict__ sc, int set) {

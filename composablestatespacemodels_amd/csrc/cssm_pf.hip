@@ -218,11 +218,13 @@ static int build_model(cssm_pf* pf, const cssm_model_desc* desc) {
   mk.d = d; mk.obs_kind = desc->obs_kind;
   for (int k = 0; k < d; ++k) {
     const Comp& c = pf->comp[k];
-    mk.kind[k] = c.kind;
-    if (c.f_kind == CSSM_F_FIRST) mk.fmode[k] = (c.idx == 0) ? FM_START : FM_SKIP;
-    else mk.fmode[k] = (c.idx == 0) ? FM_START : FM_ADD;
-    mk.leaf_end[k] = (k + 1 == d) || (pf->comp[k + 1].leaf != c.leaf);
-    mk.first_leaf[k] = (c.leaf == 0);
+    uint32_t fm;
+    if (c.f_kind == CSSM_F_FIRST) fm = (c.idx == 0) ? FM_START : FM_SKIP;
+    else fm = (c.idx == 0) ? FM_START : FM_ADD;
+    const uint32_t leaf_end = (k + 1 == d) || (pf->comp[k + 1].leaf != c.leaf);
+    const uint32_t first_leaf = (c.leaf == 0);
+    const uint32_t b = ((uint32_t)c.kind & 3u) | (fm << 2) | (leaf_end << 4) | (first_leaf << 5);
+    mk.comp[k >> 2] |= b << ((k & 3) * 8);
   }
   return CSSM_OK;
 }
@@ -446,7 +448,7 @@ static int launch_init(cssm_pf* pf, double t0) {
 }
 
 // propagate + weight of one datum (record already on the device)
-static int prop_items(int d) { return d <= 2 ? 4 : (d <= 8 ? 2 : 1); }   // PropItems<D>
+static int prop_items(int d) { return d <= 2 ? 4 : (d <= 8 ? CSSM_PROP_IT_MID : 1); }   // PropItems<D>
 
 static int launch_propagate(cssm_pf* pf, const StepRec* d_rec) {
   const int grid = grid_for(pf->n, CSSM_BLOCK * prop_items(pf->d), kPropGridCap);

@@ -62,8 +62,10 @@ typedef struct { uint32_t v[4]; } cssm_u32x4;
 #define CSSM_PHILOX_W1 0xBB67AE85u
 
 CSSM_HD cssm_u32x4 cssm_philox4x32_10(cssm_u32x4 c, uint32_t k0, uint32_t k1) {
-#if defined(__HIPCC__)
+#if defined(__HIPCC__) && !defined(CSSM_PHILOX_NO_UNROLL)
 #pragma unroll
+#elif defined(__HIPCC__)
+#pragma unroll 1
 #endif
   for (int r = 0; r < 10; ++r) {
     uint64_t p0 = (uint64_t)CSSM_PHILOX_M0 * c.v[0];
