@@ -830,3 +830,109 @@ __global__ void k_record(const Scalars* __restrict__ sc, double* __restrict__ ll
   ll_t[s] = sc->ll;
   ess_t[s] = sc->ess;
 }
+
+// ------------------------------------------------------------------------------------ cloud summaries
+// getIntervals (model/ParticleFilter.scala:415-424): meanState (:465-479), getallCredibleIntervals
+// (:488-512) and getOrderStatistic (:455-460) of the CURRENT (resampled) cloud, on the device.
+
+// link of the observing leaf (model/Model.scala:24,183,269,296,318-326,345)
+__device__ __forceinline__ double link_of(int obs_kind, double g) {
+  switch (obs_kind) {
+    case CSSM_OBS_POISSON: case CSSM_OBS_NEGBIN: case CSSM_OBS_ZIP: return cssm_exp(g);
+    case CSSM_OBS_BERNOULLI: return (g > 6.0) ? 1.0 : ((g < -6.0) ? 0.0 : 1.0 / (1.0 + cssm_exp(-g)));
+    case CSSM_OBS_BETA: return cssm_exp(-g);
+    default: return g;
+  }
+}
+
+// rows 0..d-1: the resampled state components, row d: eta = link(f(x, t)); stored as order-preserving keys
+template <int D>
+__global__ __launch_bounds__(CSSM_BLOCK) void k_summary_fill(const double* __restrict__ src, size_t src_stride,
+                                                             const uint32_t* __restrict__ anc, const double* __restrict__ src2,
+                                                             size_t src2_stride, uint32_t n_split, uint64_t n,
+                                                             const StepRec* __restrict__ rec, ModelK mk,
+                                                             unsigned long long* __restrict__ keys, size_t kstride,
+                                                             double* __restrict__ partial /*[gridDim.x][D]*/) {
+  __shared__ double s_p[CSSM_BLOCK / 64][D];
+  double acc[D];
+#pragma unroll
+  for (int k = 0; k < D; ++k) acc[k] = 0.0;
+  for (uint64_t i = (uint64_t)blockIdx.x * CSSM_BLOCK + threadIdx.x; i < n; i += (uint64_t)gridDim.x * CSSM_BLOCK) {
+    const size_t j = anc ? (size_t)anc[i] : (size_t)i;
+    double x[D];
+#pragma unroll
+    for (int k = 0; k < D; ++k) {
+      x[k] = (src2 && j >= n_split) ? src2[(size_t)k * src2_stride + (j - n_split)] : src[(size_t)k * src_stride + j];
+      keys[(size_t)k * kstride + i] = cssm_order_key(x[k]);
+      acc[k] += x[k];
+    }
+    keys[(size_t)D * kstride + i] = cssm_order_key(link_of(mk.obs_kind, gamma_of<D>(mk, rec, x)));
+  }
+#pragma unroll
+  for (int k = 0; k < D; ++k) {
+    double v = acc[k];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    if ((threadIdx.x & 63) == 0) s_p[threadIdx.x >> 6][k] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x < D) {
+    double v = 0.0;
+    for (int w = 0; w < CSSM_BLOCK / 64; ++w) v += s_p[w][threadIdx.x];
+    partial[(size_t)blockIdx.x * D + threadIdx.x] = v;
+  }
+}
+
+// Radix select, most significant byte first, two targets (lower / upper order statistic) per row.
+struct SelState { unsigned long long prefix[2]; unsigned long long rank[2]; };
+
+__global__ __launch_bounds__(CSSM_BLOCK) void k_sel_hist(const unsigned long long* __restrict__ keys, size_t kstride, uint64_t n,
+                                                         const SelState* __restrict__ st, int shift, uint32_t* __restrict__ hist) {
+  __shared__ uint32_t s_h[2][256];
+  const int row = blockIdx.y;
+  for (int i = threadIdx.x; i < 512; i += CSSM_BLOCK) (&s_h[0][0])[i] = 0;
+  __syncthreads();
+  const unsigned long long p0 = st[row].prefix[0], p1 = st[row].prefix[1];
+  const unsigned long long hm = (shift >= 56) ? 0ull : (~0ull << (shift + 8));   // bits above the current byte
+  const unsigned long long* kr = keys + (size_t)row * kstride;
+  for (uint64_t i = (uint64_t)blockIdx.x * CSSM_BLOCK + threadIdx.x; i < n; i += (uint64_t)gridDim.x * CSSM_BLOCK) {
+    const unsigned long long k = kr[i];
+    const uint32_t b = (uint32_t)(k >> shift) & 255u;
+    if ((k & hm) == (p0 & hm)) atomicAdd(&s_h[0][b], 1u);
+    if ((k & hm) == (p1 & hm)) atomicAdd(&s_h[1][b], 1u);
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 512; i += CSSM_BLOCK) {
+    const uint32_t v = (&s_h[0][0])[i];
+    if (v) atomicAdd(&hist[(size_t)row * 512 + i], v);
+  }
+}
+
+__global__ void k_sel_pick(SelState* __restrict__ st, int shift, uint32_t* __restrict__ hist) {   // <<<rows, 2>>>
+  const int row = blockIdx.x, t = threadIdx.x;
+  uint32_t* h = hist + (size_t)row * 512 + t * 256;
+  unsigned long long r = st[row].rank[t], cum = 0;
+  int b = 0;
+  for (; b < 255; ++b) {
+    if (cum + h[b] > r) break;
+    cum += h[b];
+  }
+  st[row].prefix[t] |= (unsigned long long)b << shift;
+  st[row].rank[t] = r - cum;
+  for (int i = 0; i < 256; ++i) h[i] = 0;
+}
+
+__global__ void k_summary_finish(const SelState* __restrict__ st, const double* __restrict__ partial, int nblocks, int d, uint64_t n,
+                                 double* __restrict__ out /*[3][d+1]: mean, lower, upper*/) {
+  const int k = threadIdx.x;
+  if (k > d) return;
+  if (k < d) {
+    double s = 0.0;
+    for (int b = 0; b < nblocks; ++b) s += partial[(size_t)b * d + k];
+    out[k] = s / (double)n;
+  } else {
+    out[k] = 0.0;   // eta of the mean state is formed on the host: link(f(mean, t))
+  }
+  out[(d + 1) + k] = cssm_order_unkey(st[k].prefix[0]);
+  out[2 * (d + 1) + k] = cssm_order_unkey(st[k].prefix[1]);
+}

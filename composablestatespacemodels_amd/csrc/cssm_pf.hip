@@ -708,6 +708,84 @@ extern "C" int cssm_pf_get_logw(cssm_pf* pf, double* out) {
   return CSSM_OK;
 }
 
+// getIntervals (model/ParticleFilter.scala:415-424) on the device; see include/cssm_pf.h
+static double host_link(int obs_kind, double g) {
+  switch (obs_kind) {
+    case CSSM_OBS_POISSON: case CSSM_OBS_NEGBIN: case CSSM_OBS_ZIP: return cssm_exp(g);
+    case CSSM_OBS_BERNOULLI: return (g > 6.0) ? 1.0 : ((g < -6.0) ? 0.0 : 1.0 / (1.0 + cssm_exp(-g)));
+    case CSSM_OBS_BETA: return cssm_exp(-g);
+    default: return g;
+  }
+}
+
+extern "C" int cssm_pf_summary(cssm_pf* pf, double interval, double* state_mean, double* state_lower, double* state_upper,
+                               double* eta_of_mean, double* eta_lower, double* eta_upper) {
+  if (!pf) return fail(CSSM_EINVAL_ARG, "null handle");
+  if (!pf->initialised) return fail(CSSM_ESTATE, "not initialised");
+  if (!(interval > 0.0 && interval <= 1.0)) return fail(CSSM_EINVAL_ARG, "interval must be in (0, 1]");
+  HIP_TRY(hipSetDevice(pf->device));
+  const int d = pf->d, rows = d + 1;
+  const uint64_t n = pf->n;
+  const int nblocks = grid_for(n, CSSM_BLOCK, 1024);
+  unsigned long long* keys = nullptr; double* partial = nullptr; SelState* st = nullptr; uint32_t* hist = nullptr; double* out = nullptr;
+  StepRec* drec = nullptr;
+  std::vector<SelState> hst(rows);
+  std::vector<double> hout(3 * rows);
+  StepRec hrec;
+  int rc = CSSM_OK;
+  // ranks, 0-based in ascending order: getCredibleInterval (:488-502) uses (N - index - 1, index - 1) with
+  // index = floor(interval * N); getOrderStatistic (:455-460) uses (N - index, index) -- both reproduced
+  const long long idx = (long long)std::floor(interval * (double)n);
+  auto clampr = [&](long long r) { return (unsigned long long)std::min<long long>(std::max<long long>(r, 0), (long long)n - 1); };
+  for (int k = 0; k < rows; ++k) {
+    hst[k].prefix[0] = hst[k].prefix[1] = 0;
+    hst[k].rank[0] = clampr(k < d ? (long long)n - idx - 1 : (long long)n - idx);
+    hst[k].rank[1] = clampr(k < d ? idx - 1 : idx);
+  }
+  build_rec(pf, pf->t, pf->t, 0.0, 0, pf->step, &hrec);   // F(t) of the current time for f(x, t)
+#define SM_TRY(expr) do { hipError_t e__ = (expr); if (e__ != hipSuccess) { rc = fail(CSSM_EHIP, "%s: %s", #expr, hipGetErrorString(e__)); goto done; } } while (0)
+  SM_TRY(hipMalloc(&keys, (size_t)rows * n * 8)); SM_TRY(hipMalloc(&partial, (size_t)nblocks * d * 8));
+  SM_TRY(hipMalloc(&st, rows * sizeof(SelState))); SM_TRY(hipMalloc(&hist, (size_t)rows * 512 * 4)); SM_TRY(hipMalloc(&out, 3 * rows * 8));
+  SM_TRY(hipMalloc(&drec, sizeof(StepRec)));
+  SM_TRY(hipMemcpyAsync(st, hst.data(), rows * sizeof(SelState), hipMemcpyHostToDevice, pf->stream));
+  SM_TRY(hipMemcpyAsync(drec, &hrec, sizeof hrec, hipMemcpyHostToDevice, pf->stream));
+  SM_TRY(hipMemsetAsync(hist, 0, (size_t)rows * 512 * 4, pf->stream));
+  {
+    const uint32_t* anc = pf->anc_valid ? pf->anc : nullptr;
+    DISPATCH_D(d, k_summary_fill<D><<<dim3(nblocks), dim3(CSSM_BLOCK), 0, pf->stream>>>(
+                      pf->src, pf->src_stride, anc, anc ? pf->src2 : nullptr, pf->src2_stride, pf->n_split, n, drec, pf->mk, keys, (size_t)n,
+                      partial));
+    for (int shift = 56; shift >= 0; shift -= 8) {
+      hipLaunchKernelGGL(k_sel_hist, dim3(nblocks, rows), dim3(CSSM_BLOCK), 0, pf->stream, keys, (size_t)n, n, st, shift, hist);
+      hipLaunchKernelGGL(k_sel_pick, dim3(rows), dim3(2), 0, pf->stream, st, shift, hist);
+    }
+    hipLaunchKernelGGL(k_summary_finish, dim3(1), dim3(64), 0, pf->stream, st, partial, nblocks, d, n, out);
+  }
+  SM_TRY(hipGetLastError());
+  SM_TRY(hipMemcpyAsync(hout.data(), out, 3 * rows * 8, hipMemcpyDeviceToHost, pf->stream));
+  SM_TRY(hipStreamSynchronize(pf->stream));
+  for (int k = 0; k < d; ++k) {
+    if (state_mean) state_mean[k] = hout[k];
+    if (state_lower) state_lower[k] = hout[rows + k];
+    if (state_upper) state_upper[k] = hout[2 * rows + k];
+  }
+  if (eta_lower) *eta_lower = hout[rows + d];
+  if (eta_upper) *eta_upper = hout[2 * rows + d];
+  if (eta_of_mean) {   // meanEta = link(f(stateMean, t)), :420
+    double g = 0.0, acc = 0.0;
+    for (int k = 0; k < d; ++k) {
+      const int fm = pf->mk.fmode(k);
+      if (fm == FM_START) acc = hrec.fco[k] * hout[k]; else if (fm == FM_ADD) acc = acc + hrec.fco[k] * hout[k];
+      if (pf->mk.leaf_end(k)) g = pf->mk.first_leaf(k) ? acc : g + acc;
+    }
+    *eta_of_mean = host_link(pf->obs_kind, g);
+  }
+done:
+#undef SM_TRY
+  { void* ptrs[] = {keys, partial, st, hist, out, drec}; for (void* q : ptrs) if (q) (void)hipFree(q); }
+  return rc;
+}
+
 // ------------------------------------------------------------------------------------ stateless resampler
 
 extern "C" int cssm_resample_systematic(const double* w, size_t n, double u, uint32_t* anc, int device) {

@@ -129,6 +129,13 @@ class NativePf:
         _abi.check(self.lib.cssm_pf_profile_read(self._h, _p(ms), _p(cnt, C.POINTER(C.c_uint64))))
         return {k: (float(ms[i]), int(cnt[i])) for i, k in enumerate(self.KERNELS)}
 
+    def summary(self, interval: float = 0.975):
+        """(state_mean[d], state_lower[d], state_upper[d], eta_of_mean, eta_lower, eta_upper) of the current cloud."""
+        m, lo, hi = np.zeros(self.d), np.zeros(self.d), np.zeros(self.d)
+        em, el, eu = C.c_double(), C.c_double(), C.c_double()
+        _abi.check(self.lib.cssm_pf_summary(self._h, float(interval), _p(m), _p(lo), _p(hi), C.byref(em), C.byref(el), C.byref(eu)))
+        return m, lo, hi, em.value, el.value, eu.value
+
     def particles(self) -> np.ndarray:
         out = np.zeros((self.d, self.n))
         _abi.check(self.lib.cssm_pf_get_particles(self._h, _p(out)))
@@ -193,6 +200,22 @@ class PfState:  # ParticleFilter.scala:32-37
         if self._owner is None or self._owner.generation != self._generation:
             raise RuntimeError("this PfState is not the handle's current state; its cloud was advanced on the device")
         return self._owner.particles()
+
+
+@dataclass(frozen=True)
+class CredibleInterval:  # ParticleFilter.scala:14
+    lower: float
+    upper: float
+
+
+@dataclass(frozen=True)
+class PfOut:  # ParticleFilter.scala:20-26
+    time: float
+    observation: Optional[float]
+    eta: float
+    etaIntervals: CredibleInterval
+    state: np.ndarray
+    stateIntervals: List[CredibleInterval]
 
 
 @dataclass(frozen=True)
@@ -305,6 +328,14 @@ class ParticleFilter:
     @staticmethod
     def likelihood(data, resample, n: int, **kw):
         return lambda mod: Filter(mod, resample, **kw).llFilter(data, n)
+
+    @staticmethod
+    def getIntervals(model: Model, s: "PfState") -> PfOut:
+        """ParticleFilter.getIntervals (:415-424), evaluated on the device for the handle's current state."""
+        if s._owner is None or s._owner.generation != s._generation:
+            raise RuntimeError("getIntervals needs the filter's current PfState")
+        m, lo, hi, em, el, eu = s._owner.summary(0.975)
+        return PfOut(s.t, s.observation, em, CredibleInterval(el, eu), m, [CredibleInterval(a, b) for a, b in zip(lo, hi)])
 
     @staticmethod
     def effectiveSampleSize(weights: Sequence[float]) -> int:  # :431-434 (host helper, tiny inputs)

@@ -203,6 +203,17 @@ int cssm_pf_get_logw(cssm_pf* pf, double* out_N);
 /* Propagated, not yet resampled particles of the last step (x1 at :118), SoA, host pointer. */
 int cssm_pf_get_proposed(cssm_pf* pf, double* out_dN);
 
+/* getIntervals (model/ParticleFilter.scala:415-424) of the current cloud, computed on the device so that
+ * the streaming consumer (examples/Filtering.scala:29) never copies N particles back: per latent
+ * component the mean (meanState, :465-479) and the two order statistics of getCredibleInterval
+ * (:488-502: sorted(N - index - 1), sorted(index - 1), index = floor(interval*N)); for
+ * eta = link(f(x, t)) the order statistics of getOrderStatistic (:455-460: sorted(N - index),
+ * sorted(index)) and eta_of_mean = link(f(stateMean, t)) (:420).  Host pointers, d doubles each for the
+ * state outputs; any may be NULL.  Order statistics are exact (radix selection); the means are plain
+ * fp64 sums (agreement with the reference's sequential sum: ~1e-13 relative). */
+int cssm_pf_summary(cssm_pf* pf, double interval, double* state_mean, double* state_lower, double* state_upper,
+                    double* eta_of_mean, double* eta_lower, double* eta_upper);
+
 /* ---- stateless resampler: the `Resample[A]` seam (model/package.scala:23) ------------------ */
 
 /* Resampling.systematicResampling (model/Resampling.scala:63-72) on host arrays: weights w[n]

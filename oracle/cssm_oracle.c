@@ -615,6 +615,48 @@ void oracle_pf_get_logw(const oracle_pf* pf, double* out) { memcpy(out, pf->w, p
 void oracle_pf_get_ancestors(const oracle_pf* pf, uint32_t* out) { memcpy(out, pf->anc, pf->n * 4); }
 void oracle_pf_get_cumw(const oracle_pf* pf, double* out) { memcpy(out, pf->C, pf->n * 8); }
 
+/* ------------------------------------------------------------------ cloud summaries */
+
+/* link of the observing leaf: model/Model.scala:24 (identity), :183,269,296 (exp), :318-326 (Bernoulli), :345 (Beta) */
+static double o_link(const oracle_pf* pf, double g) {
+  switch (pf->obs_kind) {
+    case CSSM_OBS_POISSON: case CSSM_OBS_NEGBIN: case CSSM_OBS_ZIP: return cssm_exp(g);
+    case CSSM_OBS_BERNOULLI: return (g > 6.0) ? 1.0 : ((g < -6.0) ? 0.0 : 1.0 / (1.0 + cssm_exp(-g)));
+    case CSSM_OBS_BETA: return cssm_exp(-g);
+    default: return g;
+  }
+}
+static int cmp_double(const void* a, const void* b) { double x = *(const double*)a, y = *(const double*)b; return (x > y) - (x < y); }
+
+/* getIntervals, model/ParticleFilter.scala:415-424: meanState (:465-479, weights 1/N), getallCredibleIntervals
+ * (:488-512: sorted(N - index - 1), sorted(index - 1)), getOrderStatistic of eta (:455-460: sorted(N - index),
+ * sorted(index)), meanEta = link(f(stateMean, t)). */
+int oracle_pf_summary(const oracle_pf* pf, double interval, double* mean, double* lower, double* upper,
+                      double* eta_of_mean, double* eta_lower, double* eta_upper) {
+  uint64_t n = pf->n;
+  int d = pf->d;
+  double* col = (double*)malloc(n * 8);
+  double w = 1.0 / (double)n;                                   /* normalisedWeights = w / w.sum */
+  long long idx = (long long)floor(interval * (double)n);
+  for (int k = 0; k < d; ++k) {
+    double acc = 0.0;
+    for (uint64_t i = 0; i < n; ++i) { col[i] = pf->x[i * d + k]; acc = acc + col[i] * w; }
+    mean[k] = acc;
+    qsort(col, n, 8, cmp_double);
+    long long lo = (long long)n - idx - 1, hi = idx - 1;
+    if (lo < 0) lo = 0; if (hi < 0) hi = 0; if (lo > (long long)n - 1) lo = n - 1; if (hi > (long long)n - 1) hi = n - 1;
+    lower[k] = col[lo]; upper[k] = col[hi];
+  }
+  for (uint64_t i = 0; i < n; ++i) col[i] = o_link(pf, gamma_of(pf, pf->x + i * d, pf->t));
+  qsort(col, n, 8, cmp_double);
+  long long lo = (long long)n - idx, hi = idx;
+  if (lo < 0) lo = 0; if (hi < 0) hi = 0; if (lo > (long long)n - 1) lo = n - 1; if (hi > (long long)n - 1) hi = n - 1;
+  *eta_lower = col[lo]; *eta_upper = col[hi];
+  *eta_of_mean = o_link(pf, gamma_of(pf, mean, pf->t));
+  free(col);
+  return ORACLE_OK;
+}
+
 /* ------------------------------------------------------------------ A11 PMMH */
 
 /* Parameters.flattenParams order, model/Parameters.scala:88-95; SdeParameter.flatten,

@@ -64,6 +64,7 @@ def lib() -> C.CDLL:
             "oracle_pf_get_logw": (None, [vp, _dp]),
             "oracle_pf_get_ancestors": (None, [vp, _u32p]),
             "oracle_pf_get_cumw": (None, [vp, _dp]),
+            "oracle_pf_summary": (C.c_int, [vp, C.c_double, _dp, _dp, _dp, _dp, _dp, _dp]),
             "oracle_resample_systematic": (C.c_int, [_dp, C.c_uint64, C.c_double, _u32p, _dp, C.c_int]),
             "oracle_logdens_poisson": (C.c_double, [C.c_double, C.c_double]),
             "oracle_logdens_gaussian": (C.c_double, [C.c_double, C.c_double, C.c_double]),
@@ -172,6 +173,12 @@ class OraclePf:
         a = np.ascontiguousarray(soa, dtype=np.float64)
         assert a.shape == (self.d, self.n)
         lib().oracle_pf_set_particles(self._h, _p(a))
+
+    def summary(self, interval=0.975):
+        m, lo, hi = np.zeros(self.d), np.zeros(self.d), np.zeros(self.d)
+        em, el, eu = C.c_double(), C.c_double(), C.c_double()
+        _chk(lib().oracle_pf_summary(self._h, interval, _p(m), _p(lo), _p(hi), C.byref(em), C.byref(el), C.byref(eu)))
+        return m, lo, hi, em.value, el.value, eu.value
 
     def particles(self):
         out = np.zeros((self.d, self.n)); lib().oracle_pf_get_particles(self._h, _p(out)); return out

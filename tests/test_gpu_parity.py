@@ -219,6 +219,39 @@ def test_offspring_fast_path_equals_forced_exact_path():
         a.close(); b.close()
 
 
+@pytest.mark.parametrize("name,n", [("c2_model", 20000), ("c3_model", 5000), ("bernoulli_model", 3000), ("linear_model", 1 << 18)])
+def test_device_summaries_match_oracle(name, n):
+    """cssm_pf_summary == getIntervals (ParticleFilter.scala:415-424): order statistics exact, means to 1e-12."""
+    model = getattr(cases, name)()
+    t, y, has = {"bernoulli_model": cases.binary_series, "linear_model": cases.gaussian_series}.get(name, cases.poisson_counts)(6)
+    g = NativePf(model, n, cases.SEED)
+    o = oracle.OraclePf(model.descriptor(), n, cases.SEED)
+    g.init(0.0); o.init(0.0)
+    for s in range(6):
+        g.step(t[s], y[s], bool(has[s])); o.step(t[s], y[s], bool(has[s]))
+        gm, glo, ghi, gem, gel, geu = g.summary(0.975)
+        om, olo, ohi, oem, oel, oeu = o.summary(0.975)
+        np.testing.assert_array_equal(glo, olo)
+        np.testing.assert_array_equal(ghi, ohi)
+        assert (gel, geu) == (oel, oeu)
+        np.testing.assert_allclose(gm, om, rtol=1e-12, atol=1e-13)
+        assert abs(gem - oem) <= 1e-12 * max(1.0, abs(oem))
+    g.close()
+
+
+def test_get_intervals_mirror():
+    from composablestatespacemodels_amd import Data
+    from composablestatespacemodels_amd.filter import Filter, ParticleFilter
+    model = cases.c2_model()
+    f = Filter(model, Resampling.systematicResampling)
+    s = f.initialiseState(4000, 0.0)
+    s = f.stepFilter(s, Data(1.0, 3.0))
+    out = ParticleFilter.getIntervals(model, s)
+    assert out.time == 1.0 and out.observation == 3.0 and len(out.stateIntervals) == 3
+    assert all(ci.lower < m < ci.upper for ci, m in zip(out.stateIntervals, out.state))
+    assert out.etaIntervals.lower < out.eta < out.etaIntervals.upper
+
+
 def test_errors_are_reported_not_swallowed():
     from composablestatespacemodels_amd import CssmError
     model = cases.linear_model()

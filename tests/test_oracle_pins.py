@@ -280,3 +280,26 @@ def test_nonfinite_weights_are_an_error():
     with pytest.raises(oracle.OracleError) as e:
         o.step(1.0, float("nan"))
     assert e.value.code == oracle.ENONFINITE
+
+
+# ----------------------------------------------------------------------------- cloud summaries
+def test_summary_follows_the_reference_index_conventions():
+    """getCredibleInterval uses sorted(N - index - 1), sorted(index - 1); getOrderStatistic uses sorted(N - index),
+    sorted(index) (ParticleFilter.scala:455-460,488-502) -- both off-by-one conventions are reproduced."""
+    model = cases.c2_model()
+    n = 1000
+    o = oracle.OraclePf(model.descriptor(), n, 3)
+    o.init(0.0)
+    o.step(1.0, 2.0)
+    x = o.particles()
+    m, lo, hi, em, el, eu = o.summary(0.975)
+    idx = int(np.floor(0.975 * n))
+    for k in range(3):
+        srt = np.sort(x[k])
+        assert lo[k] == srt[n - idx - 1] and hi[k] == srt[idx - 1]
+        assert abs(m[k] - x[k].mean()) < 1e-13
+    t = 1.0
+    eta = np.exp(x[0] + np.cos(2 * np.pi * t / 24) * x[1] + np.sin(2 * np.pi * t / 24) * x[2])
+    srt = np.sort(eta)
+    assert abs(el - srt[n - idx]) <= 1e-15 * abs(el) * 4 and abs(eu - srt[idx]) <= 1e-15 * abs(eu) * 4
+    assert abs(em - np.exp(m[0] + np.cos(2 * np.pi * t / 24) * m[1] + np.sin(2 * np.pi * t / 24) * m[2])) < 1e-12
