@@ -158,3 +158,21 @@ def golden_case(name, T, missing=0.0):
     else:
         data = poisson_counts(T, missing=missing)
     return (mk(),) + tuple(data)
+
+
+def max_dim_model():
+    """d = CSSM_MAX_DIM = 16 in one composition: poisson(brownian 2) |+| seasonal(12, 3, ou 6) |+| linear-leaf(genBrownian 8)."""
+    p = (Parameters.apply(None, SdeParameter.brownianParameter([0.0, 0.1], 1.0, [0.01, 0.02]))
+         | Parameters.apply(None, SdeParameter.ouParameter(0.0, 0.5, 0.2, [0.1, -0.1, 0.0], 0.2))
+         | Parameters.apply(0.0, SdeParameter.genBrownianParameter(0.0, 0.3, [0.01, -0.01], 0.05)))
+    return (Model.poisson(Sde.brownianMotion(2)) | Model.seasonal(12, 3, Sde.ouProcess(6)) | Model.linear(Sde.genBrownianMotion(8))).run(p)
+
+
+def many_leaves_model(n_leaves=16):
+    """CSSM_MAX_LEAVES one-dimensional leaves."""
+    ps = Parameters.apply(None, SdeParameter.ouParameter(0.0, 0.3, 0.2, 0.05, 0.1))
+    um = Model.poisson(Sde.ouProcess(1))
+    for i in range(n_leaves - 1):
+        ps = ps | Parameters.apply(None, SdeParameter.brownianParameter(0.0, 0.05, 0.001 * (i + 1)))
+        um = um | Model.poisson(Sde.brownianMotion(1))
+    return um.run(ps)

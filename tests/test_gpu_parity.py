@@ -56,6 +56,45 @@ def test_next_row_observation_models_streaming_bit_exact(name):
     _compare_streaming(model, 2500, t, y, has)
 
 
+def test_maximum_dimension_and_leaf_count():
+    """d = 16 (CSSM_MAX_DIM) over three leaves, and 16 leaves (CSSM_MAX_LEAVES)."""
+    t, y, has = cases.poisson_counts(6)
+    _compare_streaming(cases.max_dim_model(), 1500, t, y, has)
+    _compare_streaming(cases.many_leaves_model(), 1200, t, y, has)
+
+
+def test_single_datum_all_missing_and_empty_series():
+    from composablestatespacemodels_amd import CssmError
+    model = cases.c2_model()
+    g = NativePf(model, 700, cases.SEED)
+    o = oracle.OraclePf(model.descriptor(), 700, cases.SEED)
+    # T = 1: the first datum has dt = 0 (t0 = min t), ParticleFilter.scala:138
+    assert g.run(np.array([3.0]), np.array([2.0]))[0] == o.filter(np.array([3.0]), np.array([2.0]))[0]
+    # every observation missing: particles are only propagated, ll stays 0 and ess stays N (:121)
+    t = np.arange(5.0); y = np.zeros(5); has = np.zeros(5, dtype=np.uint8)
+    ll, ll_t, ess_t, _ = g.run(t, y, has)
+    oll, oll_t, oess_t, _ = o.filter(t, y, has)
+    assert ll == 0.0 == oll and list(ess_t) == [700] * 5 == list(oess_t)
+    np.testing.assert_array_equal(g.particles(), o.particles())
+    np.testing.assert_array_equal(g.ancestors(), np.arange(700))
+    # empty data: the reference's minBy throws on an empty Vector
+    with pytest.raises(CssmError) as e:
+        g.run(np.array([]), np.array([]))
+    assert e.value.code == -6
+    g.close()
+
+
+def test_decreasing_time_is_reported_as_nonfinite():
+    """A negative dt makes sqrt(sigma*dt) NaN in the reference too (Sde.scala:117); here it is an error code."""
+    from composablestatespacemodels_amd import CssmError
+    g = NativePf(cases.c1_model(), 256, 1)
+    g.init(5.0)
+    with pytest.raises(CssmError) as e:
+        g.step(4.0, 1.0)
+    assert e.value.code == -5
+    g.close()
+
+
 def test_missing_observations_bit_exact():
     t, y, has = cases.poisson_counts(16, missing=0.4)
     assert has.sum() < 16
