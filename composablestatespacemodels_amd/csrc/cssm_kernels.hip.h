@@ -597,7 +597,8 @@ __global__ __launch_bounds__(CSSM_BLOCK) void k_offspring(const double* __restri
                                                           uint32_t* __restrict__ endslot, uint32_t* __restrict__ anc,
                                                           uint32_t ntiles, uint32_t sup, uint32_t nunits, int raw, int slot_set,
                                                           double* __restrict__ ll_t, int32_t* __restrict__ ess_t, uint32_t rec_idx,
-                                                          int force_exact, const unsigned long long* __restrict__ all4, int rank, int world) {
+                                                          int force_exact, const unsigned long long* __restrict__ all4, int rank, int world,
+                                                          int resampler, uint64_t seed, double* __restrict__ cum_out) {
   __shared__ cssm_u128 s_w[CSSM_BLOCK / 64];
   __shared__ uint32_t s_last[CSSM_BLOCK / 64];
   __shared__ uint32_t s_nheavy;
@@ -703,12 +704,20 @@ __global__ __launch_bounds__(CSSM_BLOCK) void k_offspring(const double* __restri
         double cnt = fl + 1.0;
         cnt = (cnt < 0.0) ? 0.0 : cnt;
         cnt = (cnt > nd) ? nd : cnt;
-        const bool safe = (fr > eps) && (fr < 1.0 - eps) && !force_exact;
+        const bool safe = (fr > eps) && (fr < 1.0 - eps) && !force_exact && resampler == CSSM_RESAMPLE_SYSTEMATIC;
         if (safe) {
           e[r] = (uint32_t)cnt;
         } else {
           const double C = cssm_u128_to_double(run) / totd;
-          e[r] = (uint32_t)(pow2 ? cssm_sys_count_pow2(C, u, n_global, inv_n) : cssm_sys_count(C, u, n_global));
+          if (resampler == CSSM_RESAMPLE_SYSTEMATIC) {
+            e[r] = (uint32_t)(pow2 ? cssm_sys_count_pow2(C, u, n_global, inv_n) : cssm_sys_count(C, u, n_global));
+          } else if (resampler == CSSM_RESAMPLE_STRATIFIED) {   // one uniform per slot, model/Resampling.scala:82-83
+            e[r] = (uint32_t)cssm_strat_count(C, seed, rec->step, n_global);
+          } else {                                              // multinomial: the draws are searched in C afterwards
+            const uint64_t ii = base + (uint64_t)threadIdx.x * CSSM_ITEMS + r;
+            if (ii < n) cum_out[ii] = C;
+            e[r] = 0;
+          }
         }
       }
       const uint64_t i0 = base + (uint64_t)threadIdx.x * CSSM_ITEMS;
@@ -719,7 +728,7 @@ __global__ __launch_bounds__(CSSM_BLOCK) void k_offspring(const double* __restri
 #pragma unroll
           for (int r = 0; r < CSSM_ITEMS; ++r) if (i0 + r < n) endslot[i0 + r] = e[r];
         }
-      } else {
+      } else if (resampler != CSSM_RESAMPLE_MULTINOMIAL) {
         // end slot of the particle before this thread's first one
         if (lane == 63) s_last[wid] = e[CSSM_ITEMS - 1];
         uint32_t prev = __shfl_up(e[CSSM_ITEMS - 1], 1, 64);
@@ -729,7 +738,9 @@ __global__ __launch_bounds__(CSSM_BLOCK) void k_offspring(const double* __restri
           else if (tile == 0) prev = 0u;
           else {   // the same formula on the tile's exclusive prefix
             const double Cp = cssm_u128_to_double(toff) / totd;
-            prev = (uint32_t)(pow2 ? cssm_sys_count_pow2(Cp, u, n_global, inv_n) : cssm_sys_count(Cp, u, n_global));
+            prev = (resampler == CSSM_RESAMPLE_STRATIFIED)
+                       ? (uint32_t)cssm_strat_count(Cp, seed, rec->step, n_global)
+                       : (uint32_t)(pow2 ? cssm_sys_count_pow2(Cp, u, n_global, inv_n) : cssm_sys_count(Cp, u, n_global));
           }
         }
 #pragma unroll
@@ -799,6 +810,21 @@ __global__ __launch_bounds__(CSSM_BLOCK) void k_expand(const uint32_t* __restric
       for (uint32_t s = s_hb[h] + threadIdx.x; s < he; s += CSSM_BLOCK) anc[s] = hj;
     }
     __syncthreads();
+  }
+}
+
+// Resampling.multinomialResampling (model/Resampling.scala:92-96): slot i draws its own uniform and takes the
+// first particle whose cumulative normalised weight reaches it (breeze Multinomial.draw); the output is in
+// draw order, not sorted.  `cum` is non-decreasing and ends at exactly 1.0.
+__global__ void k_multinomial(const double* __restrict__ cum, uint64_t n, uint64_t seed, uint32_t step, uint32_t* __restrict__ anc) {
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+    const double ui = cssm_multi_uniform(seed, step, i);
+    uint64_t lo = 0, hi = n - 1;      // first j with cum[j] >= ui (exists: cum[n-1] == 1 > ui)
+    while (lo < hi) {
+      const uint64_t mid = (lo + hi) >> 1;
+      if (cum[mid] >= ui) hi = mid; else lo = mid + 1;
+    }
+    anc[i] = (uint32_t)lo;
   }
 }
 

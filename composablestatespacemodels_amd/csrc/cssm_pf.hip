@@ -74,6 +74,8 @@ struct cssm_pf {
   bool anc_valid = false;
   int wparity = 0;             // max-slot set of the next weighted step (single-GPU path)
   int opt_exact = 0;           // CSSM_OPT_EXACT_OFFSPRING
+  int resampler = CSSM_RESAMPLE_SYSTEMATIC;
+  double* cum = nullptr;       // multinomial: cumulative normalised weights
   const long long *send_first_dev = nullptr, *send_count_dev = nullptr;   // last shard_offspring outputs (device)
   cssm_u128 *tileS = nullptr, *tileS2 = nullptr, *tileP = nullptr;
   Scalars* sc = nullptr;
@@ -96,6 +98,7 @@ struct cssm_pf {
   // filter state
   double t = 0.0;
   uint32_t step = 0;
+  uint32_t h_step_for_resample = 0;   // observation index of the step being resampled (Philox counter word)
   bool initialised = false;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   float last_ms = 0.f;
@@ -380,7 +383,7 @@ extern "C" void cssm_pf_destroy(cssm_pf* pf) {
   (void)hipSetDevice(pf->device);
   if (pf->stream) (void)hipStreamSynchronize(pf->stream);
   void* ptrs[] = {pf->state[0], pf->state[1], pf->logw, pf->endslot, pf->anc, pf->tileS, pf->tileS2, pf->tileP, pf->sc,
-                  pf->d_m0, pf->d_sd0, pf->d_logtab, pf->d_recs, pf->d_ll_t, pf->d_ess_t, pf->d_path, pf->cand, pf->cand_end, pf->cand_idx, pf->d_bounds};
+                  pf->d_m0, pf->d_sd0, pf->d_logtab, pf->cum, pf->d_recs, pf->d_ll_t, pf->d_ess_t, pf->d_path, pf->cand, pf->cand_end, pf->cand_idx, pf->d_bounds};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   if (pf->h_recs) (void)hipHostFree(pf->h_recs);
   for (hipEvent_t e : pf->prof_ev) (void)hipEventDestroy(e);
@@ -473,6 +476,9 @@ static int launch_propagate(cssm_pf* pf, const StepRec* d_rec) {
 
 // weights -> sums -> end slots -> ancestors, single GPU
 static int launch_resample(cssm_pf* pf, const StepRec* d_rec, double* ll_t = nullptr, int32_t* ess_t = nullptr, uint32_t rec_idx = 0) {
+  if (pf->resampler == CSSM_RESAMPLE_MULTINOMIAL && !pf->cum) {
+    if (hipMalloc(&pf->cum, pf->stride * 8) != hipSuccess) return fail(CSSM_ENOMEM, "hipMalloc cumulative weights");
+  }
   const int tgrid = (int)pf->nunits;
   prof_begin(pf, CSSM_K_TILE_SUMS);
   hipLaunchKernelGGL(k_tile_sums, dim3(tgrid), dim3(CSSM_BLOCK), 0, pf->stream, pf->logw, pf->n, pf->sc, pf->tileS, pf->tileS2, pf->ntiles,
@@ -481,7 +487,11 @@ static int launch_resample(cssm_pf* pf, const StepRec* d_rec, double* ll_t = nul
   prof_begin(pf, CSSM_K_OFFSPRING);   // unit prefix, ll/ess, end slots and their expansion to ancestors in one kernel
   hipLaunchKernelGGL((k_offspring<true, true>), dim3(tgrid), dim3(CSSM_BLOCK), 0, pf->stream, pf->logw, pf->n, pf->sc,
                      (const cssm_u128*)pf->tileS, (const cssm_u128*)pf->tileS2, d_rec, pf->n_global, pf->endslot, pf->anc, pf->ntiles,
-                     pf->sup, pf->nunits, 0, pf->wparity, ll_t, ess_t, rec_idx, pf->opt_exact, (const unsigned long long*)nullptr, 0, 1);
+                     pf->sup, pf->nunits, 0, pf->wparity, ll_t, ess_t, rec_idx, pf->opt_exact, (const unsigned long long*)nullptr, 0, 1,
+                     pf->resampler, pf->seed, pf->cum);
+  if (pf->resampler == CSSM_RESAMPLE_MULTINOMIAL)
+    hipLaunchKernelGGL(k_multinomial, dim3(grid_for(pf->n, 256, kGridCap)), dim3(256), 0, pf->stream, pf->cum, pf->n, pf->seed,
+                       pf->h_step_for_resample, pf->anc);
   prof_end(pf);
   pf->wparity ^= 1;
   HIP_TRY(hipGetLastError());
@@ -489,7 +499,9 @@ static int launch_resample(cssm_pf* pf, const StepRec* d_rec, double* ll_t = nul
   return CSSM_OK;
 }
 
-static int launch_step(cssm_pf* pf, const StepRec* d_rec, int weighted, double* ll_t = nullptr, int32_t* ess_t = nullptr, uint32_t rec_idx = 0) {
+static int launch_step(cssm_pf* pf, const StepRec* d_rec, int weighted, uint32_t step_index, double* ll_t = nullptr, int32_t* ess_t = nullptr,
+                       uint32_t rec_idx = 0) {
+  pf->h_step_for_resample = step_index;
   int rc = launch_propagate(pf, d_rec);
   if (rc) return rc;
   if (weighted) rc = launch_resample(pf, d_rec, ll_t, ess_t, rec_idx);
@@ -561,7 +573,7 @@ extern "C" int cssm_pf_step(cssm_pf* pf, double t, double obs, int has_obs, doub
   build_rec(pf, pf->t, t, obs, has_obs, pf->step, &pf->h_recs[0]);
   HIP_TRY(hipMemcpyAsync(pf->d_recs, pf->h_recs, sizeof(StepRec), hipMemcpyHostToDevice, pf->stream));
   const int weighted = pf->h_recs[0].has_obs;
-  rc = launch_step(pf, pf->d_recs, weighted);
+  rc = launch_step(pf, pf->d_recs, weighted, pf->step);
   if (rc) return rc;
   Scalars h;
   HIP_TRY(hipMemcpyAsync(&h, pf->sc, sizeof h, hipMemcpyDeviceToHost, pf->stream));
@@ -605,7 +617,7 @@ static int run_filter(cssm_pf* pf, const double* t, const double* y, const uint8
   HIP_TRY(hipEventRecord(pf->ev0, pf->stream));
   for (size_t s = 0; s < T; ++s) {
     const int weighted = pf->h_recs[s].has_obs;
-    rc = launch_step(pf, pf->d_recs + s, weighted, pf->d_ll_t, pf->d_ess_t, (uint32_t)s);
+    rc = launch_step(pf, pf->d_recs + s, weighted, (uint32_t)s, pf->d_ll_t, pf->d_ess_t, (uint32_t)s);
     if (rc) return rc;
     if (path)
       hipLaunchKernelGGL(k_pick, dim3(1), dim3(64), 0, pf->stream, pf->src, pf->src_stride,
@@ -647,6 +659,12 @@ extern "C" int cssm_pf_last_loop_ms(cssm_pf* pf, float* ms_out) {
 extern "C" int cssm_pf_set_option(cssm_pf* pf, int option, int value) {
   if (!pf) return fail(CSSM_EINVAL_ARG, "null handle");
   if (option == CSSM_OPT_EXACT_OFFSPRING) { pf->opt_exact = value ? 1 : 0; return CSSM_OK; }
+  if (option == CSSM_OPT_RESAMPLER) {
+    if (value < CSSM_RESAMPLE_SYSTEMATIC || value > CSSM_RESAMPLE_MULTINOMIAL) return fail(CSSM_EINVAL_ARG, "unknown resampler %d", value);
+    if (pf->sharded && value != CSSM_RESAMPLE_SYSTEMATIC) return fail(CSSM_ESTATE, "sharded handles resample systematically");
+    pf->resampler = value;
+    return CSSM_OK;
+  }
   return fail(CSSM_EINVAL_ARG, "unknown option %d", option);
 }
 
@@ -819,7 +837,7 @@ extern "C" int cssm_resample_systematic(const double* w, size_t n, double u, uin
                        (const double*)nullptr, (unsigned long long*)nullptr);
     hipLaunchKernelGGL((k_offspring<true, false>), dim3(tgrid), dim3(CSSM_BLOCK), 0, st, d_w, (uint64_t)n, sc, (const cssm_u128*)tP,
                        (const cssm_u128*)tS2, d_rec, (uint64_t)n, d_end, d_anc, ntiles, sup, nunits, 1, 0, (double*)nullptr, (int32_t*)nullptr, 0u, 0,
-                       (const unsigned long long*)nullptr, 0, 1);
+                       (const unsigned long long*)nullptr, 0, 1, CSSM_RESAMPLE_SYSTEMATIC, (uint64_t)0, (double*)nullptr);
   }
   RS_TRY(hipGetLastError());
   RS_TRY(hipMemcpyAsync(&hs, sc, sizeof hs, hipMemcpyDeviceToHost, st));
@@ -982,7 +1000,7 @@ extern "C" int cssm_pf_shard_offspring(cssm_pf* pf, const uint64_t* all_sums4_de
   hipLaunchKernelGGL((k_offspring<false, false>), dim3(tgrid), dim3(CSSM_BLOCK), 0, pf->stream, pf->logw, pf->n, pf->sc,
                      (const cssm_u128*)pf->tileP, (const cssm_u128*)pf->tileS2, pf->d_recs + slot, pf->n_global, pf->endslot,
                      (uint32_t*)nullptr, pf->ntiles, pf->sup, pf->nunits, 0, 0, (double*)nullptr, (int32_t*)nullptr, 0u, pf->opt_exact,
-                     (const unsigned long long*)all_sums4_dev, rank, world);
+                     (const unsigned long long*)all_sums4_dev, rank, world, CSSM_RESAMPLE_SYSTEMATIC, pf->seed, (double*)nullptr);
   pf->send_first_dev = (const long long*)send_first_dev; pf->send_count_dev = (const long long*)send_count_dev;
   hipLaunchKernelGGL(k_send_ranges, dim3(1), dim3(64), 0, pf->stream, pf->endslot, pf->n, pf->sc, pf->d_recs + slot, pf->n_global, rank, world,
                      n_per, (long long*)send_first_dev, (long long*)send_count_dev);

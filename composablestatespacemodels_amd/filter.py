@@ -175,6 +175,16 @@ class Resampling:
         return anc
 
     @staticmethod
+    def stratifiedResampling(particles: Sequence, weights: Sequence[float]):
+        """Resampling.scala:78-86.  As a ``Filter`` argument it selects the native stratified resampler."""
+        raise NotImplementedError("stratified resampling is native inside Filter only (no stateless entry point yet)")
+
+    @staticmethod
+    def multinomialResampling(particles: Sequence, weights: Sequence[float]):
+        """Resampling.scala:92-96.  As a ``Filter`` argument it selects the native multinomial resampler."""
+        raise NotImplementedError("multinomial resampling is native inside Filter only (no stateless entry point yet)")
+
+    @staticmethod
     def systematicResampling(particles: Sequence, weights: Sequence[float], u: Optional[float] = None):
         if len(particles) != len(weights):
             raise ValueError("particles and weights differ in length")
@@ -229,8 +239,11 @@ class _FilterBase:
     lgcp_precision = 0
 
     def __init__(self, mod: Model, resample, n_particles: Optional[int] = None, seed: int = 20260101, device: int = 0):
-        if resample is not Resampling.systematicResampling:
-            raise NotImplementedError("the native filter implements Resampling.systematicResampling only (SURVEY.md 8f row 3)")
+        kinds = {Resampling.systematicResampling: 0, Resampling.stratifiedResampling: 1, Resampling.multinomialResampling: 2}
+        if resample not in kinds:
+            raise NotImplementedError("native resamplers: Resampling.systematicResampling, .stratifiedResampling, "
+                                      ".multinomialResampling (the reference's residualResampling cannot run as written)")
+        self._resampler = kinds[resample]
         self.mod = mod
         self.resample = resample
         self.seed = seed
@@ -244,6 +257,8 @@ class _FilterBase:
             if self._pf is not None:
                 self._pf.close()
             self._pf = NativePf(self.mod, n, self.seed, self.device, self.lgcp_precision)
+            if self._resampler:
+                self._pf.set_option(2, self._resampler)   # CSSM_OPT_RESAMPLER
         return self._pf
 
     def _state(self, t, obs, ll, ess) -> PfState:

@@ -88,6 +88,8 @@ CSSM_HD cssm_u32x4 cssm_philox4x32_10(cssm_u32x4 c, uint32_t k0, uint32_t k1) {
 #define CSSM_STREAM_U 2u      /* the ONE uniform of systematic resampling (Resampling.scala:66) */
 #define CSSM_STREAM_PICK 3u   /* sampleOne index of `filter` (Resampling.scala:151-154)     */
 #define CSSM_STREAM_HOST 4u   /* host-side PMMH proposal / accept draws (PMMH.scala:70,74)  */
+#define CSSM_STREAM_STRAT 5u  /* the N uniforms of stratified resampling (Resampling.scala:83), counter id = slot */
+#define CSSM_STREAM_MULTI 6u  /* the N uniforms of multinomial resampling (Resampling.scala:93), counter id = slot */
 
 /*
  * Counter layout: word0/1 = GLOBAL particle id (so results do not depend on how particles
@@ -565,6 +567,29 @@ CSSM_HD uint64_t cssm_sys_count_pow2(double C, double u, uint64_t n, double inv_
   while (c < nn && (u + (double)c) * inv_n <= C) ++c;
   while (c > 0 && (u + (double)(c - 1)) * inv_n > C) --c;
   return c;
+}
+
+/* Stratified grid, model/Resampling.scala:82-83: k_i = (i + u_i) / n with one uniform per slot,
+ * u_i = cssm_u01 of Philox(seed, id = i, step, CSSM_STREAM_STRAT).  k_i is strictly increasing in i. */
+CSSM_HD double cssm_strat_grid(uint64_t seed, uint32_t step, uint64_t i, double nd) {
+  const cssm_u32x4 b = cssm_philox_draw(seed, i, step, CSSM_STREAM_STRAT, 0);
+  return ((double)i + cssm_u01(b.v[0], b.v[1])) / nd;
+}
+/* #{ i in [0,n) : k_i <= C } for the stratified grid (same role as cssm_sys_count). */
+CSSM_HD uint64_t cssm_strat_count(double C, uint64_t seed, uint32_t step, uint64_t n) {
+  const double nd = (double)n;
+  const uint32_t nn = (uint32_t)n;
+  const double est = C * nd;
+  uint32_t c = (est > 0.0) ? ((est >= nd) ? nn : (uint32_t)est) : 0u;
+  while (c < nn && cssm_strat_grid(seed, step, c, nd) <= C) ++c;
+  while (c > 0 && cssm_strat_grid(seed, step, c - 1, nd) > C) --c;
+  return c;
+}
+/* The uniform of multinomial draw i (breeze Multinomial.draw: the first index whose cumulative weight
+ * reaches u * sum, model/Resampling.scala:92-96). */
+CSSM_HD double cssm_multi_uniform(uint64_t seed, uint32_t step, uint64_t i) {
+  const cssm_u32x4 b = cssm_philox_draw(seed, i, step, CSSM_STREAM_MULTI, 0);
+  return cssm_u01(b.v[0], b.v[1]);
 }
 
 /* ------------------------------------------------------------------ order-preserving key */

@@ -172,6 +172,14 @@ int cssm_pf_last_loop_ms(cssm_pf* pf, float* ms_out);
  * contract's exact predicate for every particle instead of only where its fp64 position estimate is
  * within the error band of a slot boundary; results are identical by construction (tests compare). */
 #define CSSM_OPT_EXACT_OFFSPRING 1
+/* CSSM_OPT_RESAMPLER selects the `Resample[A]` the filter was constructed with (model/ParticleFilter.scala:
+ * 233-235): systematic (model/Resampling.scala:63-72, default), stratified (:78-86) or multinomial (:92-96).
+ * The reference's residualResampling (:130-146) indexes `Vector.range(1, m)` with draws from [0, n) and cannot
+ * run as written; it is not offered.  Sharded handles support systematic resampling only. */
+#define CSSM_OPT_RESAMPLER 2
+#define CSSM_RESAMPLE_SYSTEMATIC 0
+#define CSSM_RESAMPLE_STRATIFIED 1
+#define CSSM_RESAMPLE_MULTINOMIAL 2
 int cssm_pf_set_option(cssm_pf* pf, int option, int value);
 
 /* Per-kernel device time, measured with HIP events recorded on the handle's stream directly

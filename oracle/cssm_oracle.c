@@ -45,6 +45,8 @@
 #define ORACLE_LITERAL_SUMS 1
 #define ORACLE_TIE_LAST 2
 #define ORACLE_LIBM 4
+#define ORACLE_RESAMPLE_STRATIFIED 8    /* Resampling.stratifiedResampling, model/Resampling.scala:78-86 */
+#define ORACLE_RESAMPLE_MULTINOMIAL 16  /* Resampling.multinomialResampling, model/Resampling.scala:92-96 */
 
 #define ORACLE_OK 0
 #define ORACLE_EINVAL (-1)
@@ -423,6 +425,45 @@ int oracle_resample_systematic(const double* w, uint64_t n, double u, uint32_t* 
   return rc;
 }
 
+/* Contract cumulative weights C_j = RN(RN(S_j)/RN(S_tot)) of the fixed-point sums. */
+static void contract_cumw(const double* w, uint64_t n, double* C) {
+  u128 tot = 0, acc = 0;
+  for (uint64_t i = 0; i < n; ++i) tot += fix_from_double(w[i]);
+  double totd = (double)tot;
+  for (uint64_t i = 0; i < n; ++i) { acc += fix_from_double(w[i]); C[i] = (double)acc / totd; }
+}
+
+/* Resampling.stratifiedResampling, model/Resampling.scala:78-86: ks_i = (i + nextDouble)/n, one uniform per slot
+ * (ordered, so findAllInTreeMap is again the two-pointer merge). */
+int oracle_resample_stratified(const double* w, uint64_t n, uint64_t seed, uint32_t step, uint32_t* anc, double* C_out) {
+  double* C = C_out ? C_out : (double*)malloc(n * 8);
+  contract_cumw(w, n, C);
+  uint64_t j = 0;
+  double nd = (double)n;
+  for (uint64_t i = 0; i < n; ++i) {
+    double k = cssm_strat_grid(seed, step, i, nd);
+    while (j < n - 1 && C[j] < k) ++j;
+    anc[i] = (uint32_t)j;
+  }
+  if (!C_out) free(C);
+  return ORACLE_OK;
+}
+
+/* Resampling.multinomialResampling, model/Resampling.scala:92-96: n independent draws of breeze Multinomial(weights),
+ * each the first index whose cumulative weight reaches u * sum; output in draw order. */
+int oracle_resample_multinomial(const double* w, uint64_t n, uint64_t seed, uint32_t step, uint32_t* anc, double* C_out) {
+  double* C = C_out ? C_out : (double*)malloc(n * 8);
+  contract_cumw(w, n, C);
+  for (uint64_t i = 0; i < n; ++i) {
+    double ui = cssm_multi_uniform(seed, step, i);
+    uint64_t j = 0;
+    while (j < n - 1 && C[j] < ui) ++j;                      /* linear, as Multinomial.draw scans */
+    anc[i] = (uint32_t)j;
+  }
+  if (!C_out) free(C);
+  return ORACLE_OK;
+}
+
 /* ------------------------------------------------------------------ A6/A7 sums, ll, ess */
 
 /* Tail of stepFilter after the log-weights exist: model/ParticleFilter.scala:124-130
@@ -439,7 +480,10 @@ static int weigh_and_resample(oracle_pf* pf) {
   for (uint64_t i = 0; i < n; ++i) pf->w1[i] = o_exp(pf, pf->w[i] - max);   /* :125 */
   const cssm_u32x4 bu = cssm_philox_draw(pf->seed, 0, pf->step, CSSM_STREAM_U, 0);
   double u = cssm_u01(bu.v[0], bu.v[1]);
-  int rc = oracle_resample_systematic(pf->w1, n, u, pf->anc, pf->C, pf->flags);   /* :126 */
+  int rc;
+  if (pf->flags & ORACLE_RESAMPLE_STRATIFIED) rc = oracle_resample_stratified(pf->w1, n, pf->seed, pf->step, pf->anc, pf->C);
+  else if (pf->flags & ORACLE_RESAMPLE_MULTINOMIAL) rc = oracle_resample_multinomial(pf->w1, n, pf->seed, pf->step, pf->anc, pf->C);
+  else rc = oracle_resample_systematic(pf->w1, n, u, pf->anc, pf->C, pf->flags);   /* :126 */
   if (rc) return rc;
   if (pf->flags & ORACLE_LITERAL_SUMS) {
     double sum = 0.0;
@@ -626,6 +670,7 @@ static double o_link(const oracle_pf* pf, double g) {
     default: return g;
   }
 }
+static long long clamp_rank(long long r, uint64_t n) { return r < 0 ? 0 : (r > (long long)n - 1 ? (long long)n - 1 : r); }
 static int cmp_double(const void* a, const void* b) { double x = *(const double*)a, y = *(const double*)b; return (x > y) - (x < y); }
 
 /* getIntervals, model/ParticleFilter.scala:415-424: meanState (:465-479, weights 1/N), getallCredibleIntervals
@@ -643,15 +688,13 @@ int oracle_pf_summary(const oracle_pf* pf, double interval, double* mean, double
     for (uint64_t i = 0; i < n; ++i) { col[i] = pf->x[i * d + k]; acc = acc + col[i] * w; }
     mean[k] = acc;
     qsort(col, n, 8, cmp_double);
-    long long lo = (long long)n - idx - 1, hi = idx - 1;
-    if (lo < 0) lo = 0; if (hi < 0) hi = 0; if (lo > (long long)n - 1) lo = n - 1; if (hi > (long long)n - 1) hi = n - 1;
-    lower[k] = col[lo]; upper[k] = col[hi];
+    lower[k] = col[clamp_rank((long long)n - idx - 1, n)];
+    upper[k] = col[clamp_rank(idx - 1, n)];
   }
   for (uint64_t i = 0; i < n; ++i) col[i] = o_link(pf, gamma_of(pf, pf->x + i * d, pf->t));
   qsort(col, n, 8, cmp_double);
-  long long lo = (long long)n - idx, hi = idx;
-  if (lo < 0) lo = 0; if (hi < 0) hi = 0; if (lo > (long long)n - 1) lo = n - 1; if (hi > (long long)n - 1) hi = n - 1;
-  *eta_lower = col[lo]; *eta_upper = col[hi];
+  *eta_lower = col[clamp_rank((long long)n - idx, n)];
+  *eta_upper = col[clamp_rank(idx, n)];
   *eta_of_mean = o_link(pf, gamma_of(pf, mean, pf->t));
   free(col);
   return ORACLE_OK;

@@ -18,6 +18,8 @@ LIB = os.path.join(HERE, "liboracle.so")
 LITERAL_SUMS = 1
 TIE_LAST = 2
 LIBM = 4
+RESAMPLE_STRATIFIED = 8
+RESAMPLE_MULTINOMIAL = 16
 
 OK, EINVAL, ENONFINITE, EEMPTY = 0, -1, -5, -8
 
@@ -66,6 +68,8 @@ def lib() -> C.CDLL:
             "oracle_pf_get_cumw": (None, [vp, _dp]),
             "oracle_pf_summary": (C.c_int, [vp, C.c_double, _dp, _dp, _dp, _dp, _dp, _dp]),
             "oracle_resample_systematic": (C.c_int, [_dp, C.c_uint64, C.c_double, _u32p, _dp, C.c_int]),
+            "oracle_resample_stratified": (C.c_int, [_dp, C.c_uint64, C.c_uint64, C.c_uint32, _u32p, _dp]),
+            "oracle_resample_multinomial": (C.c_int, [_dp, C.c_uint64, C.c_uint64, C.c_uint32, _u32p, _dp]),
             "oracle_logdens_poisson": (C.c_double, [C.c_double, C.c_double]),
             "oracle_logdens_gaussian": (C.c_double, [C.c_double, C.c_double, C.c_double]),
             "oracle_logdens_negbin": (C.c_double, [C.c_double, C.c_double, C.c_double]),
@@ -218,6 +222,16 @@ def resample_systematic(w, u, flags=0, want_cumw=False):
     rc = lib().oracle_resample_systematic(_p(w), len(w), u, _p(anc, _u32p), _p(Cw), flags)
     _chk(rc)
     return (anc, Cw) if want_cumw else anc
+
+
+def resample_stratified(w, seed, step=0):
+    w = np.ascontiguousarray(w, dtype=np.float64); anc = np.zeros(len(w), dtype=np.uint32)
+    _chk(lib().oracle_resample_stratified(_p(w), len(w), seed, step, _p(anc, _u32p), None)); return anc
+
+
+def resample_multinomial(w, seed, step=0):
+    w = np.ascontiguousarray(w, dtype=np.float64); anc = np.zeros(len(w), dtype=np.uint32)
+    _chk(lib().oracle_resample_multinomial(_p(w), len(w), seed, step, _p(anc, _u32p), None)); return anc
 
 
 def c_exp(x):

@@ -109,7 +109,7 @@ def test_composition_is_left_nested_and_leftmost_model_observes():
     assert g.parameters().add([1.0] * len(theta)).flattenParams() == [v + 1.0 for v in theta]
 
 
-def test_only_systematic_resampling_is_native():
+def test_only_the_reference_resamplers_are_accepted():
     with pytest.raises(NotImplementedError):
         Filter(cases.c1_model(), lambda p, w: p)
     assert ParticleFilter.effectiveSampleSize([1.0, 1.0, 1.0, 1.0]) == 4      # ParticleFilter.scala:431-434

@@ -303,3 +303,32 @@ def test_summary_follows_the_reference_index_conventions():
     srt = np.sort(eta)
     assert abs(el - srt[n - idx]) <= 1e-15 * abs(el) * 4 and abs(eu - srt[idx]) <= 1e-15 * abs(eu) * 4
     assert abs(em - np.exp(m[0] + np.cos(2 * np.pi * t / 24) * m[1] + np.sin(2 * np.pi * t / 24) * m[2])) < 1e-12
+
+
+# ----------------------------------------------------------------------------- other resamplers
+def test_stratified_and_multinomial_properties():
+    rng = np.random.default_rng(21)
+    n = 4000
+    w = rng.random(n); w[rng.random(n) < 0.3] = 0.0
+    a = oracle.resample_stratified(w, 5, 7)
+    assert len(a) == n and np.all(np.diff(a.astype(np.int64)) >= 0)      # ordered grid -> monotone ancestors
+    counts = np.bincount(a, minlength=n)
+    expect = n * w / w.sum()
+    assert np.all(counts[w == 0] == 0) and np.all(np.abs(counts - expect) < 2.0)   # stratified: |count - N w| < 2
+    np.testing.assert_array_equal(oracle.resample_stratified(np.ones(64), 1), np.arange(64))
+    m = oracle.resample_multinomial(w, 5, 7)
+    assert len(m) == n and np.all(w[m] > 0)                                # zero-weight particles are never drawn
+    assert not np.all(np.diff(m.astype(np.int64)) >= 0)                    # draw order, not sorted
+    big = oracle.resample_multinomial(np.array([0.1, 0.2, 0.3, 0.4]), 3)
+    cnt = np.bincount(oracle.resample_multinomial(np.tile([0.1, 0.2, 0.3, 0.4], 5000), 9) % 4, minlength=4) / 20000.0
+    assert np.all(np.abs(cnt - [0.1, 0.2, 0.3, 0.4]) < 0.02) and len(big) == 4
+
+
+def test_filters_with_other_resamplers_estimate_the_same_likelihood():
+    model = cases.linear_model()
+    t, y, has = cases.gaussian_series(30)
+    from test_oracle_pins import kalman_ll
+    exact = kalman_ll(t, y, 0.5, 2.0, 0.3, 0.5)
+    for flag in (oracle.RESAMPLE_STRATIFIED, oracle.RESAMPLE_MULTINOMIAL):
+        lls = [oracle.OraclePf(model.descriptor(), 20000, 50 + r, flag).filter(t, y, has)[0] for r in range(4)]
+        assert abs(np.mean(lls) - exact) < 0.1
