@@ -179,9 +179,12 @@ __device__ __forceinline__ double gamma_of(const ModelK& mk, const StepRec* __re
 // dataLikelihood(gamma, y) of the leftmost leaf; the branch is wave-uniform (mk is a kernel argument).
 // Constants c[] per observation kind are listed in build_rec (cssm_pf.hip); the oracle states the same
 // expressions with the reference's line numbers (oracle/cssm_oracle.c, logdens).
-__device__ __forceinline__ double logdens(const ModelK& mk, const StepRec* __restrict__ rec, double g) {
+// OBS >= 0: the observation kind is a compile-time constant (the common Poisson / Gaussian kernels carry only
+// their own density: the generic body is ~2.5x larger and spills out of the instruction cache); OBS < 0: runtime.
+template <int OBS>
+__device__ __forceinline__ double logdens(const ModelK& mk, const StepRec* __restrict__ rec, double g, const double* tab) {
   const double y = rec->y;
-  switch (mk.obs_kind) {
+  switch (OBS >= 0 ? OBS : mk.obs_kind) {
     case CSSM_OBS_POISSON:   // -lambda + k log(lambda) - lgamma(k+1), model/Model.scala:273
       return -cssm_exp(g) + y * g - rec->c[0];
     case CSSM_OBS_GAUSSIAN: {  // breeze Gaussian.logPdf, model/Model.scala:252-258
@@ -279,7 +282,7 @@ __device__ __forceinline__ double decode_slots(const Scalars* __restrict__ sc, i
 // the co-resident waves to cover LDS/table and gather latency), 3 beyond
 template <int D> struct PropWaves { static constexpr int value = (D <= 4) ? 4 : 3; };
 
-template <int D, bool LGCP, int IT>
+template <int D, bool LGCP, int IT, int OBS>
 __global__ __launch_bounds__(CSSM_BLOCK, PropWaves<D>::value) void k_propagate(
     const double* __restrict__ src, size_t src_stride, const uint32_t* __restrict__ anc,
     double* __restrict__ dst, size_t dst_stride, double* __restrict__ logw, uint64_t n, uint64_t gid0,
@@ -376,7 +379,7 @@ __global__ __launch_bounds__(CSSM_BLOCK, PropWaves<D>::value) void k_propagate(
       } else {
         draw_normals<D>(seed, gid, step, CSSM_STREAM_STEP, tab, z);
         transition<D>(mk, rec, dt, x[r], z);
-        lw[r] = has_obs ? logdens(mk, rec, gamma_of<D>(mk, rec, x[r])) : 0.0;
+        lw[r] = has_obs ? logdens<OBS>(mk, rec, gamma_of<D>(mk, rec, x[r]), tab) : 0.0;
       }
       if (weighted && i0 + r < n) {
         if (lw[r] != lw[r]) { bad = true; lw[r] = -cssm_inf(); }
@@ -456,15 +459,16 @@ __device__ __forceinline__ void load_tile_raw(const double* __restrict__ logw, u
     for (int r = 0; r < CSSM_ITEMS; ++r) v[r] = (i0 + r < n) ? logw[i0 + r] : (raw ? 0.0 : -cssm_inf());
   }
 }
-__device__ __forceinline__ void weights_from_raw(const double (&v)[CSSM_ITEMS], double gmax, int raw, double (&w1)[CSSM_ITEMS]) {
+__device__ __forceinline__ void weights_from_raw(const double (&v)[CSSM_ITEMS], double gmax, int raw, double (&w1)[CSSM_ITEMS],
+                                                 const double* tab) {
 #pragma unroll
   for (int r = 0; r < CSSM_ITEMS; ++r) w1[r] = raw ? v[r] : cssm_exp(v[r] - gmax);
 }
 __device__ __forceinline__ void load_tile_weights(const double* __restrict__ logw, uint64_t base, uint64_t n,
-                                                  double gmax, int raw, double (&w1)[CSSM_ITEMS]) {
+                                                  double gmax, int raw, double (&w1)[CSSM_ITEMS], const double* tab) {
   double v[CSSM_ITEMS];
   load_tile_raw(logw, base, n, raw, v);
-  weights_from_raw(v, gmax, raw, w1);
+  weights_from_raw(v, gmax, raw, w1, tab);
 }
 
 // w1 = exp(w - max) (model/ParticleFilter.scala:125); S = sum w1, S2 = sum w1^2, fixed point, one pair
@@ -474,8 +478,9 @@ __global__ __launch_bounds__(CSSM_BLOCK) void k_tile_sums(const double* __restri
                                                           const Scalars* __restrict__ sc,
                                                           cssm_u128* __restrict__ unitS, cssm_u128* __restrict__ unitS2,
                                                           uint32_t ntiles, uint32_t sup, uint32_t nunits, int raw, int slot_set,
-                                                          const double* __restrict__ gmax_in) {
+                                                          const double* __restrict__ gmax_in, const double* __restrict__ logtab) {
   __shared__ cssm_u128 s_a[CSSM_BLOCK / 64], s_b[CSSM_BLOCK / 64];
+  const double* tab = nullptr; (void)logtab;   // literal constants measured faster than an LDS constant table
   double pre[CSSM_ITEMS];   // the block's first tile is requested before the (serial) max decode
   if (blockIdx.x < nunits) load_tile_raw(logw, (uint64_t)blockIdx.x * sup * CSSM_TILE, n, raw, pre);
   // slot_set < 0: the max was agreed elsewhere (sharded: all-reduced value at gmax_in; stateless: sc->gmax)
@@ -486,8 +491,8 @@ __global__ __launch_bounds__(CSSM_BLOCK) void k_tile_sums(const double* __restri
     cssm_u128 a = cssm_u128_zero(), b = cssm_u128_zero();
     for (uint32_t tile = t0; tile < t1; ++tile) {
       double w1[CSSM_ITEMS];
-      if (unit == blockIdx.x && tile == t0) weights_from_raw(pre, gmax, raw, w1);
-      else load_tile_weights(logw, (uint64_t)tile * CSSM_TILE, n, gmax, raw, w1);
+      if (unit == blockIdx.x && tile == t0) weights_from_raw(pre, gmax, raw, w1, tab);
+      else load_tile_weights(logw, (uint64_t)tile * CSSM_TILE, n, gmax, raw, w1, tab);
 #pragma unroll
       for (int r = 0; r < CSSM_ITEMS; ++r) {
         a = cssm_u128_add(a, cssm_fix_from_double(w1[r]));
@@ -589,8 +594,10 @@ __global__ void k_global_sums(const unsigned long long* __restrict__ all4, int r
 // SELF (single GPU): there is no scan kernel.  Every block sums the <= ~1K unit totals itself (integer
 // sums: every block gets the same bits), block 0 publishes max / totals / ll / ess and clears the
 // other max-slot set for the next weighted step.
-template <bool FUSE, bool SELF>
-__global__ __launch_bounds__(CSSM_BLOCK) void k_offspring(const double* __restrict__ logw, uint64_t n,
+// RS = CSSM_RESAMPLE_* at compile time: the systematic kernel must not carry the stratified path's Philox code
+// (it cost 40 VGPRs and a wave of occupancy when the kind was a runtime argument).
+template <bool FUSE, bool SELF, int RS>
+__global__ __launch_bounds__(CSSM_BLOCK, 3) void k_offspring(const double* __restrict__ logw, uint64_t n,
                                                           Scalars* __restrict__ sc,
                                                           const cssm_u128* __restrict__ unitP, const cssm_u128* __restrict__ unitS2,
                                                           const StepRec* __restrict__ rec, uint64_t n_global,
@@ -598,7 +605,11 @@ __global__ __launch_bounds__(CSSM_BLOCK) void k_offspring(const double* __restri
                                                           uint32_t ntiles, uint32_t sup, uint32_t nunits, int raw, int slot_set,
                                                           double* __restrict__ ll_t, int32_t* __restrict__ ess_t, uint32_t rec_idx,
                                                           int force_exact, const unsigned long long* __restrict__ all4, int rank, int world,
-                                                          int resampler, uint64_t seed, double* __restrict__ cum_out) {
+                                                          int resampler_unused, uint64_t seed, double* __restrict__ cum_out,
+                                                          const double* __restrict__ logtab) {
+  constexpr int resampler = RS;
+  (void)resampler_unused;
+  const double* tab = nullptr; (void)logtab;
   __shared__ cssm_u128 s_w[CSSM_BLOCK / 64];
   __shared__ uint32_t s_last[CSSM_BLOCK / 64];
   __shared__ uint32_t s_nheavy;
@@ -670,8 +681,8 @@ __global__ __launch_bounds__(CSSM_BLOCK) void k_offspring(const double* __restri
     for (uint32_t tile = t0; tile < t1; ++tile) {
       const uint64_t base = (uint64_t)tile * CSSM_TILE;
       double w1[CSSM_ITEMS];
-      if (unit == blockIdx.x && tile == t0) weights_from_raw(pre_v, gmax, raw, w1);
-      else load_tile_weights(logw, base, n, gmax, raw, w1);
+      if (unit == blockIdx.x && tile == t0) weights_from_raw(pre_v, gmax, raw, w1, tab);
+      else load_tile_weights(logw, base, n, gmax, raw, w1, tab);
       cssm_u128 q[CSSM_ITEMS];
       cssm_u128 tsum = cssm_u128_zero();
 #pragma unroll

@@ -343,8 +343,8 @@ static int alloc_handle(cssm_pf* pf) {
   HIP_TRY(hipMalloc(&pf->d_m0, CSSM_MAX_DIM * 8));
   HIP_TRY(hipMalloc(&pf->d_sd0, CSSM_MAX_DIM * 8));
   HIP_TRY(hipMalloc(&pf->d_bounds, 64 * 8));
-  HIP_TRY(hipMalloc(&pf->d_logtab, sizeof(CSSM_LOG_TAB)));
-  HIP_TRY(hipMemcpyAsync(pf->d_logtab, CSSM_LOG_TAB, sizeof(CSSM_LOG_TAB), hipMemcpyHostToDevice, pf->stream));
+  HIP_TRY(hipMalloc(&pf->d_logtab, sizeof(CSSM_TAB)));
+  HIP_TRY(hipMemcpyAsync(pf->d_logtab, CSSM_TAB, sizeof(CSSM_TAB), hipMemcpyHostToDevice, pf->stream));
   return upload_init_params(pf);
 }
 
@@ -459,11 +459,19 @@ static int launch_propagate(cssm_pf* pf, const StepRec* d_rec) {
   const uint32_t* anc = pf->anc_valid ? pf->anc : nullptr;
   prof_begin(pf, CSSM_K_PROPAGATE);
   if (pf->obs_kind == CSSM_OBS_LGCP) {
-    DISPATCH_D(pf->d, k_propagate<D, true, PropItems<D>::value><<<dim3(grid), dim3(CSSM_BLOCK), 0, pf->stream>>>(
+    DISPATCH_D(pf->d, k_propagate<D, true, PropItems<D>::value, -1><<<dim3(grid), dim3(CSSM_BLOCK), 0, pf->stream>>>(
+                          pf->src, pf->src_stride, anc, dst, pf->stride, pf->logw, pf->n, pf->first, pf->seed, d_rec, pf->mk, pf->sc,
+                          pf->sharded ? 0 : pf->wparity, anc ? pf->src2 : nullptr, pf->src2_stride, pf->n_split, pf->d_logtab));
+  } else if (pf->obs_kind == CSSM_OBS_POISSON) {
+    DISPATCH_D(pf->d, k_propagate<D, false, PropItems<D>::value, CSSM_OBS_POISSON><<<dim3(grid), dim3(CSSM_BLOCK), 0, pf->stream>>>(
+                          pf->src, pf->src_stride, anc, dst, pf->stride, pf->logw, pf->n, pf->first, pf->seed, d_rec, pf->mk, pf->sc,
+                          pf->sharded ? 0 : pf->wparity, anc ? pf->src2 : nullptr, pf->src2_stride, pf->n_split, pf->d_logtab));
+  } else if (pf->obs_kind == CSSM_OBS_GAUSSIAN) {
+    DISPATCH_D(pf->d, k_propagate<D, false, PropItems<D>::value, CSSM_OBS_GAUSSIAN><<<dim3(grid), dim3(CSSM_BLOCK), 0, pf->stream>>>(
                           pf->src, pf->src_stride, anc, dst, pf->stride, pf->logw, pf->n, pf->first, pf->seed, d_rec, pf->mk, pf->sc,
                           pf->sharded ? 0 : pf->wparity, anc ? pf->src2 : nullptr, pf->src2_stride, pf->n_split, pf->d_logtab));
   } else {
-    DISPATCH_D(pf->d, k_propagate<D, false, PropItems<D>::value><<<dim3(grid), dim3(CSSM_BLOCK), 0, pf->stream>>>(
+    DISPATCH_D(pf->d, k_propagate<D, false, PropItems<D>::value, -1><<<dim3(grid), dim3(CSSM_BLOCK), 0, pf->stream>>>(
                           pf->src, pf->src_stride, anc, dst, pf->stride, pf->logw, pf->n, pf->first, pf->seed, d_rec, pf->mk, pf->sc,
                           pf->sharded ? 0 : pf->wparity, anc ? pf->src2 : nullptr, pf->src2_stride, pf->n_split, pf->d_logtab));
   }
@@ -482,13 +490,24 @@ static int launch_resample(cssm_pf* pf, const StepRec* d_rec, double* ll_t = nul
   const int tgrid = (int)pf->nunits;
   prof_begin(pf, CSSM_K_TILE_SUMS);
   hipLaunchKernelGGL(k_tile_sums, dim3(tgrid), dim3(CSSM_BLOCK), 0, pf->stream, pf->logw, pf->n, pf->sc, pf->tileS, pf->tileS2, pf->ntiles,
-                     pf->sup, pf->nunits, 0, pf->wparity, (const double*)nullptr);
+                     pf->sup, pf->nunits, 0, pf->wparity, (const double*)nullptr, pf->d_logtab);
   prof_end(pf);
   prof_begin(pf, CSSM_K_OFFSPRING);   // unit prefix, ll/ess, end slots and their expansion to ancestors in one kernel
-  hipLaunchKernelGGL((k_offspring<true, true>), dim3(tgrid), dim3(CSSM_BLOCK), 0, pf->stream, pf->logw, pf->n, pf->sc,
+  if (pf->resampler == CSSM_RESAMPLE_STRATIFIED)
+    hipLaunchKernelGGL((k_offspring<true, true, CSSM_RESAMPLE_STRATIFIED>), dim3(tgrid), dim3(CSSM_BLOCK), 0, pf->stream, pf->logw, pf->n, pf->sc,
                      (const cssm_u128*)pf->tileS, (const cssm_u128*)pf->tileS2, d_rec, pf->n_global, pf->endslot, pf->anc, pf->ntiles,
                      pf->sup, pf->nunits, 0, pf->wparity, ll_t, ess_t, rec_idx, pf->opt_exact, (const unsigned long long*)nullptr, 0, 1,
-                     pf->resampler, pf->seed, pf->cum);
+                     pf->resampler, pf->seed, pf->cum, pf->d_logtab);
+  else if (pf->resampler == CSSM_RESAMPLE_MULTINOMIAL)
+    hipLaunchKernelGGL((k_offspring<true, true, CSSM_RESAMPLE_MULTINOMIAL>), dim3(tgrid), dim3(CSSM_BLOCK), 0, pf->stream, pf->logw, pf->n, pf->sc,
+                     (const cssm_u128*)pf->tileS, (const cssm_u128*)pf->tileS2, d_rec, pf->n_global, pf->endslot, pf->anc, pf->ntiles,
+                     pf->sup, pf->nunits, 0, pf->wparity, ll_t, ess_t, rec_idx, pf->opt_exact, (const unsigned long long*)nullptr, 0, 1,
+                     pf->resampler, pf->seed, pf->cum, pf->d_logtab);
+  else
+    hipLaunchKernelGGL((k_offspring<true, true, CSSM_RESAMPLE_SYSTEMATIC>), dim3(tgrid), dim3(CSSM_BLOCK), 0, pf->stream, pf->logw, pf->n, pf->sc,
+                     (const cssm_u128*)pf->tileS, (const cssm_u128*)pf->tileS2, d_rec, pf->n_global, pf->endslot, pf->anc, pf->ntiles,
+                     pf->sup, pf->nunits, 0, pf->wparity, ll_t, ess_t, rec_idx, pf->opt_exact, (const unsigned long long*)nullptr, 0, 1,
+                     pf->resampler, pf->seed, pf->cum, pf->d_logtab);
   if (pf->resampler == CSSM_RESAMPLE_MULTINOMIAL)
     hipLaunchKernelGGL(k_multinomial, dim3(grid_for(pf->n, 256, kGridCap)), dim3(256), 0, pf->stream, pf->cum, pf->n, pf->seed,
                        pf->h_step_for_resample, pf->anc);
@@ -817,7 +836,7 @@ extern "C" int cssm_resample_systematic(const double* w, size_t n, double u, uin
   const uint32_t sup = (ntiles + 1023u) / 1024u, nunits = (ntiles + sup - 1) / sup;
   const size_t stride = (size_t)ntiles * CSSM_TILE;
   double* d_w = nullptr; uint32_t *d_end = nullptr, *d_anc = nullptr; cssm_u128 *tS = nullptr, *tS2 = nullptr, *tP = nullptr;
-  Scalars* sc = nullptr; StepRec* d_rec = nullptr;
+  Scalars* sc = nullptr; StepRec* d_rec = nullptr; double* d_tab = nullptr;
   hipStream_t st = nullptr;
   int rc = CSSM_OK;
   StepRec hrec; memset(&hrec, 0, sizeof hrec); hrec.u = u;
@@ -826,18 +845,19 @@ extern "C" int cssm_resample_systematic(const double* w, size_t n, double u, uin
   RS_TRY(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
   RS_TRY(hipMalloc(&d_w, stride * 8)); RS_TRY(hipMalloc(&d_end, stride * 4)); RS_TRY(hipMalloc(&d_anc, stride * 4));
   RS_TRY(hipMalloc(&tS, ntiles * sizeof(cssm_u128))); RS_TRY(hipMalloc(&tS2, ntiles * sizeof(cssm_u128))); RS_TRY(hipMalloc(&tP, ntiles * sizeof(cssm_u128)));
-  RS_TRY(hipMalloc(&sc, sizeof(Scalars))); RS_TRY(hipMalloc(&d_rec, sizeof(StepRec)));
+  RS_TRY(hipMalloc(&sc, sizeof(Scalars))); RS_TRY(hipMalloc(&d_rec, sizeof(StepRec))); RS_TRY(hipMalloc(&d_tab, sizeof(CSSM_TAB)));
+  RS_TRY(hipMemcpyAsync(d_tab, CSSM_TAB, sizeof(CSSM_TAB), hipMemcpyHostToDevice, st));
   RS_TRY(hipMemsetAsync(sc, 0, sizeof(Scalars), st));
   RS_TRY(hipMemcpyAsync(d_w, w, n * 8, hipMemcpyHostToDevice, st));
   RS_TRY(hipMemcpyAsync(d_rec, &hrec, sizeof hrec, hipMemcpyHostToDevice, st));
   {
     const int tgrid = (int)nunits;
-    hipLaunchKernelGGL(k_tile_sums, dim3(tgrid), dim3(CSSM_BLOCK), 0, st, d_w, (uint64_t)n, sc, tS, tS2, ntiles, sup, nunits, 1, -1, (const double*)nullptr);
+    hipLaunchKernelGGL(k_tile_sums, dim3(tgrid), dim3(CSSM_BLOCK), 0, st, d_w, (uint64_t)n, sc, tS, tS2, ntiles, sup, nunits, 1, -1, (const double*)nullptr, d_tab);
     hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(1024), 0, st, tS, tS2, tP, nunits, sc, (uint64_t)n, 1, (double*)nullptr, (int32_t*)nullptr, 0u,
                        (const double*)nullptr, (unsigned long long*)nullptr);
-    hipLaunchKernelGGL((k_offspring<true, false>), dim3(tgrid), dim3(CSSM_BLOCK), 0, st, d_w, (uint64_t)n, sc, (const cssm_u128*)tP,
+    hipLaunchKernelGGL((k_offspring<true, false, CSSM_RESAMPLE_SYSTEMATIC>), dim3(tgrid), dim3(CSSM_BLOCK), 0, st, d_w, (uint64_t)n, sc, (const cssm_u128*)tP,
                        (const cssm_u128*)tS2, d_rec, (uint64_t)n, d_end, d_anc, ntiles, sup, nunits, 1, 0, (double*)nullptr, (int32_t*)nullptr, 0u, 0,
-                       (const unsigned long long*)nullptr, 0, 1, CSSM_RESAMPLE_SYSTEMATIC, (uint64_t)0, (double*)nullptr);
+                       (const unsigned long long*)nullptr, 0, 1, CSSM_RESAMPLE_SYSTEMATIC, (uint64_t)0, (double*)nullptr, d_tab);
   }
   RS_TRY(hipGetLastError());
   RS_TRY(hipMemcpyAsync(&hs, sc, sizeof hs, hipMemcpyDeviceToHost, st));
@@ -846,7 +866,7 @@ extern "C" int cssm_resample_systematic(const double* w, size_t n, double u, uin
   if (hs.S_tot.lo == 0 && hs.S_tot.hi == 0) rc = fail(CSSM_ENONFINITE, "all weights are zero (the reference divides by a zero total)");
 done:
 #undef RS_TRY
-  void* ptrs[] = {d_w, d_end, d_anc, tS, tS2, tP, sc, d_rec};
+  void* ptrs[] = {d_w, d_end, d_anc, tS, tS2, tP, sc, d_rec, d_tab};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   if (st) (void)hipStreamDestroy(st);
   return rc;
@@ -979,7 +999,7 @@ extern "C" int cssm_pf_shard_sums(cssm_pf* pf, const double* global_max_dev, uin
   if (!global_max_dev || !sums4_dev) return fail(CSSM_EINVAL_ARG, "null argument");
   const int tgrid = (int)pf->nunits;
   hipLaunchKernelGGL(k_tile_sums, dim3(tgrid), dim3(CSSM_BLOCK), 0, pf->stream, pf->logw, pf->n, pf->sc, pf->tileS, pf->tileS2, pf->ntiles,
-                     pf->sup, pf->nunits, 0, -1, global_max_dev);
+                     pf->sup, pf->nunits, 0, -1, global_max_dev, pf->d_logtab);
   hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(1024), 0, pf->stream, pf->tileS, pf->tileS2, pf->tileP, pf->nunits, pf->sc, pf->n_global, 0,
                      (double*)nullptr, (int32_t*)nullptr, 0u, global_max_dev, (unsigned long long*)sums4_dev);
   HIP_TRY(hipGetLastError());
@@ -997,10 +1017,10 @@ extern "C" int cssm_pf_shard_offspring(cssm_pf* pf, const uint64_t* all_sums4_de
                                                        rank, (unsigned long long)((uint64_t)rank * n_per), (unsigned long long)pf->first);
   const size_t slot = (pf->step - 1) % 64;   // record of the step propagated last
   const int tgrid = (int)pf->nunits;
-  hipLaunchKernelGGL((k_offspring<false, false>), dim3(tgrid), dim3(CSSM_BLOCK), 0, pf->stream, pf->logw, pf->n, pf->sc,
+  hipLaunchKernelGGL((k_offspring<false, false, CSSM_RESAMPLE_SYSTEMATIC>), dim3(tgrid), dim3(CSSM_BLOCK), 0, pf->stream, pf->logw, pf->n, pf->sc,
                      (const cssm_u128*)pf->tileP, (const cssm_u128*)pf->tileS2, pf->d_recs + slot, pf->n_global, pf->endslot,
                      (uint32_t*)nullptr, pf->ntiles, pf->sup, pf->nunits, 0, 0, (double*)nullptr, (int32_t*)nullptr, 0u, pf->opt_exact,
-                     (const unsigned long long*)all_sums4_dev, rank, world, CSSM_RESAMPLE_SYSTEMATIC, pf->seed, (double*)nullptr);
+                     (const unsigned long long*)all_sums4_dev, rank, world, CSSM_RESAMPLE_SYSTEMATIC, pf->seed, (double*)nullptr, pf->d_logtab);
   pf->send_first_dev = (const long long*)send_first_dev; pf->send_count_dev = (const long long*)send_count_dev;
   hipLaunchKernelGGL(k_send_ranges, dim3(1), dim3(64), 0, pf->stream, pf->endslot, pf->n, pf->sc, pf->d_recs + slot, pf->n_global, rank, world,
                      n_per, (long long*)send_first_dev, (long long*)send_count_dev);

@@ -118,106 +118,56 @@ CSSM_HD double cssm_u01(uint32_t hi, uint32_t lo) {
 /* (0,1] with 53 bits (safe argument of log): (bits53 + 1) * 2^-53, exact. */
 CSSM_HD double cssm_u01_open0(uint32_t hi, uint32_t lo) { return cssm_u01(hi, lo) + 0x1.0p-53; }
 
-/* ------------------------------------------------------------------ exp */
+/* ------------------------------------------------------------------ constant table */
 
-/*
- * exp(x): k = round(x/ln2), r = x - k*ln2 (two-constant Cody-Waite with fma), degree-13
- * Taylor polynomial on |r| <= ln2/2 (truncation 4e-18 relative), scaled by 2^k in two exact
- * steps.  Contract edge cases: x > 709.78 -> +inf; x < -708 -> +0 (results are never
- * subnormal, so the contract does not depend on denormal support); NaN -> NaN.
- */
-CSSM_HD double cssm_exp(double x) {
-  const double LOG2E = 1.44269504088896338700e+00;
-  const double LN2_HI = 6.93147180369123816490e-01; /* 0x3fe62e42fee00000 */
-  const double LN2_LO = 1.90821492927058770002e-10; /* 0x3dea39ef35793c76 */
-  /* straight-line evaluation on a clamped argument; the edge cases are selected at the end */
-  double xc = (x > 710.0) ? 710.0 : x;
-  xc = (xc < -745.0) ? -745.0 : xc;
-  xc = (x != x) ? 0.0 : xc;
-  double t = xc * LOG2E;
-  int k = (int)(t + (t < 0.0 ? -0.5 : 0.5));
-  double kd = (double)k;
-  double r = cssm_fma(-kd, LN2_HI, xc);
-  r = cssm_fma(-kd, LN2_LO, r);
-  double p = 1.0 / 6227020800.0; /* 1/13! */
-  p = cssm_fma(p, r, 1.0 / 479001600.0);
-  p = cssm_fma(p, r, 1.0 / 39916800.0);
-  p = cssm_fma(p, r, 1.0 / 3628800.0);
-  p = cssm_fma(p, r, 1.0 / 362880.0);
-  p = cssm_fma(p, r, 1.0 / 40320.0);
-  p = cssm_fma(p, r, 1.0 / 5040.0);
-  p = cssm_fma(p, r, 1.0 / 720.0);
-  p = cssm_fma(p, r, 1.0 / 120.0);
-  p = cssm_fma(p, r, 1.0 / 24.0);
-  p = cssm_fma(p, r, 1.0 / 6.0);
-  p = cssm_fma(p, r, 0.5);
-  p = cssm_fma(p, r, 1.0);
-  p = cssm_fma(p, r, 1.0);
-  int k1 = k >> 1;
-  int k2 = k - k1;
-  double res = (p * cssm_pow2i(k1)) * cssm_pow2i(k2);
-  res = (x > 709.782712893384) ? cssm_inf() : res;
-  res = (x < -708.0) ? 0.0 : res;
-  res = (x != x) ? x : res;
-  return res;
-}
-
-/* ------------------------------------------------------------------ log */
-
-/*
- * log(x), the fdlibm e_log algorithm without its short-cut branches: x = 2^k * m,
- * m in [sqrt(1/2), sqrt(2)), f = m-1, s = f/(2+f), log(m) = f - (f^2/2 - s*(f^2/2 + R(s^2))).
- * One IEEE division (correctly rounded on x86 and in hipcc's default fp64 lowering).
- * x = 0 -> -inf, x < 0 -> NaN, +inf -> +inf, NaN -> NaN; subnormals are scaled by 2^54.
- */
-CSSM_HD double cssm_log(double x) {
-  const double LN2_HI = 6.93147180369123816490e-01;
-  const double LN2_LO = 1.90821492927058770002e-10;
-  const double LG1 = 6.666666666666735130e-01, LG2 = 3.999999999940941908e-01,
-               LG3 = 2.857142874366239149e-01, LG4 = 2.222219843214978396e-01,
-               LG5 = 1.818357216161805012e-01, LG6 = 1.531383769920937332e-01,
-               LG7 = 1.479819860511658591e-01;
-  uint64_t ux = cssm_d2u(x);
-  int k = 0;
-  if (x != x) return x;
-  if (ux >> 63) return ((ux << 1) == 0) ? -cssm_inf() : cssm_nan();
-  if (ux == 0) return -cssm_inf();
-  if (ux == 0x7ff0000000000000ULL) return x;
-  if ((ux >> 52) == 0) { /* subnormal */
-    x *= 0x1.0p54;
-    ux = cssm_d2u(x);
-    k -= 54;
-  }
-  uint32_t hx = (uint32_t)(ux >> 32);
-  k += (int)(hx >> 20) - 1023;
-  hx &= 0x000fffffu;
-  uint32_t i = (hx + 0x95f64u) & 0x100000u;
-  ux = ((uint64_t)(hx | (i ^ 0x3ff00000u)) << 32) | (ux & 0xffffffffULL);
-  k += (int)(i >> 20);
-  double m = cssm_u2d(ux);
-  double f = m - 1.0;
-  double s = f / (2.0 + f);
-  double dk = (double)k;
-  double z = s * s;
-  double w = z * z;
-  double t1 = w * cssm_fma(w, cssm_fma(w, LG6, LG4), LG2);
-  double t2 = z * cssm_fma(w, cssm_fma(w, cssm_fma(w, LG7, LG5), LG3), LG1);
-  double R = t2 + t1;
-  double hfsq = 0.5 * f * f;
-  return dk * LN2_HI - ((hfsq - (s * (hfsq + R) + dk * LN2_LO)) - f);
-}
-
-/*
- * log(x) for x in [2^-53, 1] -- the Box-Muller argument -- without a division and without special
- * cases.  x = 2^e * f, f in [1,2); j = top 7 mantissa bits of f.  j < 64: m = f, k = e; j >= 64:
- * m = f/2 in [0.75, 1), k = e + 1.  Table entry j holds invc = RN(1/c_j) and logc = RN(-log(invc)) for
- * the centre c_j of m's interval (c = 1 exactly for the two intervals touching 1, so log is exact-ish
- * and never positive near x = 1).  r = m*invc - 1 (one fma), |r| <= 2^-7,
- * log(x) = (k ln2_hi + logc) + (r + r^2 P(r) + k ln2_lo), P = degree-6 Taylor tail of log1p.
- * The table (2 KiB) is passed by pointer: the host uses CSSM_LOG_TAB, kernels stage it in LDS.
- * Generated with 80-digit decimal arithmetic (tests/golden/make_golden.py documents the recipe).
- */
-static const double CSSM_LOG_TAB[256] = {
+/* CSSM_TAB[0..255]: the log table (invc, logc pairs) of cssm_log_unit; CSSM_TAB[256..]: the other constants of
+ * the hot functions.  The _t functions read their constants from a table pointer (an LDS copy on the GPU); the
+ * plain functions use the same constants as literals and give the same bits (tests compare).  On MI355X the
+ * literal forms measured FASTER (k_propagate 266 us vs 309 us at N = 2^24: table constants occupy VGPRs), so the
+ * kernels use the literal forms; only the log table itself is staged in LDS. */
+enum {
+  CSSM_KI_LOG2E = 256,
+  CSSM_KI_LN2_HI = 257,
+  CSSM_KI_LN2_LO = 258,
+  CSSM_KI_XMAX = 259,
+  CSSM_KI_XMIN = 260,
+  CSSM_KI_OVF = 261,
+  CSSM_KI_UNF = 262,
+  CSSM_KI_E13 = 263,
+  CSSM_KI_E12 = 264,
+  CSSM_KI_E11 = 265,
+  CSSM_KI_E10 = 266,
+  CSSM_KI_E9 = 267,
+  CSSM_KI_E8 = 268,
+  CSSM_KI_E7 = 269,
+  CSSM_KI_E6 = 270,
+  CSSM_KI_E5 = 271,
+  CSSM_KI_E4 = 272,
+  CSSM_KI_E3 = 273,
+  CSSM_KI_P8 = 274,
+  CSSM_KI_P7 = 275,
+  CSSM_KI_P6 = 276,
+  CSSM_KI_P5 = 277,
+  CSSM_KI_P4 = 278,
+  CSSM_KI_P3 = 279,
+  CSSM_KI_PIO2 = 280,
+  CSSM_KI_S1 = 281,
+  CSSM_KI_S2 = 282,
+  CSSM_KI_S3 = 283,
+  CSSM_KI_S4 = 284,
+  CSSM_KI_S5 = 285,
+  CSSM_KI_S6 = 286,
+  CSSM_KI_C1 = 287,
+  CSSM_KI_C2 = 288,
+  CSSM_KI_C3 = 289,
+  CSSM_KI_C4 = 290,
+  CSSM_KI_C5 = 291,
+  CSSM_KI_C6 = 292,
+  CSSM_KI_TWOM32 = 293,
+  CSSM_KI_TWOM53 = 294,
+  CSSM_TAB_SIZE = 320
+};
+static const double CSSM_TAB[CSSM_TAB_SIZE] = {
   0x1.0000000000000p+0, 0x0.0p+0,
   0x1.fa11caa01fa12p-1, 0x1.7dc475f810a69p-7,
   0x1.f6310aca0dbb5p-1, 0x1.3cea44346a584p-6,
@@ -346,7 +296,206 @@ static const double CSSM_LOG_TAB[256] = {
   0x1.02864fc7729e9p+0, -0x1.41929f968330cp-7,
   0x1.0182436517a37p+0, -0x1.8121214586b02p-8,
   0x1.0000000000000p+0, 0x0.0p+0,
+  1.44269504088896338700e+00,
+  6.93147180369123816490e-01,
+  1.90821492927058770002e-10,
+  710.0,
+  -745.0,
+  709.782712893384,
+  -708.0,
+  1.0 / 6227020800.0,
+  1.0 / 479001600.0,
+  1.0 / 39916800.0,
+  1.0 / 3628800.0,
+  1.0 / 362880.0,
+  1.0 / 40320.0,
+  1.0 / 5040.0,
+  1.0 / 720.0,
+  1.0 / 120.0,
+  1.0 / 24.0,
+  1.0 / 6.0,
+  -1.0 / 8.0,
+  1.0 / 7.0,
+  -1.0 / 6.0,
+  1.0 / 5.0,
+  -1.0 / 4.0,
+  1.0 / 3.0,
+  1.57079632679489655800e+00,
+  -1.66666666666666324348e-01,
+  8.33333333332248946124e-03,
+  -1.98412698298579493134e-04,
+  2.75573137070700676789e-06,
+  -2.50507602534068634195e-08,
+  1.58969099521155010221e-10,
+  4.16666666666666019037e-02,
+  -1.38888888888741095749e-03,
+  2.48015872894767294178e-05,
+  -2.75573143513906633035e-07,
+  2.08757232129817482790e-09,
+  -1.13596475577881948265e-11,
+  0x1.0p-32,
+  0x1.0p-53,
+  0.0,
+  0.0,
+  0.0,
+  0.0,
+  0.0,
+  0.0,
+  0.0,
+  0.0,
+  0.0,
+  0.0,
+  0.0,
+  0.0,
+  0.0,
+  0.0,
+  0.0,
+  0.0,
+  0.0,
+  0.0,
+  0.0,
+  0.0,
+  0.0,
+  0.0,
+  0.0,
+  0.0,
+  0.0
 };
+#define CSSM_LOG_TAB CSSM_TAB
+
+/* ------------------------------------------------------------------ exp */
+
+/*
+ * exp(x): k = round(x/ln2), r = x - k*ln2 (two-constant Cody-Waite with fma), degree-13
+ * Taylor polynomial on |r| <= ln2/2 (truncation 4e-18 relative), scaled by 2^k in two exact
+ * steps.  Contract edge cases: x > 709.78 -> +inf; x < -708 -> +0 (results are never
+ * subnormal, so the contract does not depend on denormal support); NaN -> NaN.
+ */
+CSSM_HD double cssm_exp(double x) {
+  const double LOG2E = 1.44269504088896338700e+00;
+  const double LN2_HI = 6.93147180369123816490e-01; /* 0x3fe62e42fee00000 */
+  const double LN2_LO = 1.90821492927058770002e-10; /* 0x3dea39ef35793c76 */
+  /* straight-line evaluation on a clamped argument; the edge cases are selected at the end */
+  double xc = (x > 710.0) ? 710.0 : x;
+  xc = (xc < -745.0) ? -745.0 : xc;
+  xc = (x != x) ? 0.0 : xc;
+  double t = xc * LOG2E;
+  int k = (int)(t + (t < 0.0 ? -0.5 : 0.5));
+  double kd = (double)k;
+  double r = cssm_fma(-kd, LN2_HI, xc);
+  r = cssm_fma(-kd, LN2_LO, r);
+  double p = 1.0 / 6227020800.0; /* 1/13! */
+  p = cssm_fma(p, r, 1.0 / 479001600.0);
+  p = cssm_fma(p, r, 1.0 / 39916800.0);
+  p = cssm_fma(p, r, 1.0 / 3628800.0);
+  p = cssm_fma(p, r, 1.0 / 362880.0);
+  p = cssm_fma(p, r, 1.0 / 40320.0);
+  p = cssm_fma(p, r, 1.0 / 5040.0);
+  p = cssm_fma(p, r, 1.0 / 720.0);
+  p = cssm_fma(p, r, 1.0 / 120.0);
+  p = cssm_fma(p, r, 1.0 / 24.0);
+  p = cssm_fma(p, r, 1.0 / 6.0);
+  p = cssm_fma(p, r, 0.5);
+  p = cssm_fma(p, r, 1.0);
+  p = cssm_fma(p, r, 1.0);
+  int k1 = k >> 1;
+  int k2 = k - k1;
+  double res = (p * cssm_pow2i(k1)) * cssm_pow2i(k2);
+  res = (x > 709.782712893384) ? cssm_inf() : res;
+  res = (x < -708.0) ? 0.0 : res;
+  res = (x != x) ? x : res;
+  return res;
+}
+
+/* cssm_exp with its constants read from `tab` (CSSM_TAB or an LDS copy): the same operations in the same order. */
+CSSM_HD double cssm_exp_t(double x, const double* tab) {
+  double xc = (x > tab[CSSM_KI_XMAX]) ? tab[CSSM_KI_XMAX] : x;
+  xc = (xc < tab[CSSM_KI_XMIN]) ? tab[CSSM_KI_XMIN] : xc;
+  xc = (x != x) ? 0.0 : xc;
+  double t = xc * tab[CSSM_KI_LOG2E];
+  int k = (int)(t + (t < 0.0 ? -0.5 : 0.5));
+  double kd = (double)k;
+  double r = cssm_fma(-kd, tab[CSSM_KI_LN2_HI], xc);
+  r = cssm_fma(-kd, tab[CSSM_KI_LN2_LO], r);
+  double p = tab[CSSM_KI_E13];
+  p = cssm_fma(p, r, tab[CSSM_KI_E12]);
+  p = cssm_fma(p, r, tab[CSSM_KI_E11]);
+  p = cssm_fma(p, r, tab[CSSM_KI_E10]);
+  p = cssm_fma(p, r, tab[CSSM_KI_E9]);
+  p = cssm_fma(p, r, tab[CSSM_KI_E8]);
+  p = cssm_fma(p, r, tab[CSSM_KI_E7]);
+  p = cssm_fma(p, r, tab[CSSM_KI_E6]);
+  p = cssm_fma(p, r, tab[CSSM_KI_E5]);
+  p = cssm_fma(p, r, tab[CSSM_KI_E4]);
+  p = cssm_fma(p, r, tab[CSSM_KI_E3]);
+  p = cssm_fma(p, r, 0.5);
+  p = cssm_fma(p, r, 1.0);
+  p = cssm_fma(p, r, 1.0);
+  int k1 = k >> 1;
+  int k2 = k - k1;
+  double res = (p * cssm_pow2i(k1)) * cssm_pow2i(k2);
+  res = (x > tab[CSSM_KI_OVF]) ? cssm_inf() : res;
+  res = (x < tab[CSSM_KI_UNF]) ? 0.0 : res;
+  res = (x != x) ? x : res;
+  return res;
+}
+
+/* ------------------------------------------------------------------ log */
+
+/*
+ * log(x), the fdlibm e_log algorithm without its short-cut branches: x = 2^k * m,
+ * m in [sqrt(1/2), sqrt(2)), f = m-1, s = f/(2+f), log(m) = f - (f^2/2 - s*(f^2/2 + R(s^2))).
+ * One IEEE division (correctly rounded on x86 and in hipcc's default fp64 lowering).
+ * x = 0 -> -inf, x < 0 -> NaN, +inf -> +inf, NaN -> NaN; subnormals are scaled by 2^54.
+ */
+CSSM_HD double cssm_log(double x) {
+  const double LN2_HI = 6.93147180369123816490e-01;
+  const double LN2_LO = 1.90821492927058770002e-10;
+  const double LG1 = 6.666666666666735130e-01, LG2 = 3.999999999940941908e-01,
+               LG3 = 2.857142874366239149e-01, LG4 = 2.222219843214978396e-01,
+               LG5 = 1.818357216161805012e-01, LG6 = 1.531383769920937332e-01,
+               LG7 = 1.479819860511658591e-01;
+  uint64_t ux = cssm_d2u(x);
+  int k = 0;
+  if (x != x) return x;
+  if (ux >> 63) return ((ux << 1) == 0) ? -cssm_inf() : cssm_nan();
+  if (ux == 0) return -cssm_inf();
+  if (ux == 0x7ff0000000000000ULL) return x;
+  if ((ux >> 52) == 0) { /* subnormal */
+    x *= 0x1.0p54;
+    ux = cssm_d2u(x);
+    k -= 54;
+  }
+  uint32_t hx = (uint32_t)(ux >> 32);
+  k += (int)(hx >> 20) - 1023;
+  hx &= 0x000fffffu;
+  uint32_t i = (hx + 0x95f64u) & 0x100000u;
+  ux = ((uint64_t)(hx | (i ^ 0x3ff00000u)) << 32) | (ux & 0xffffffffULL);
+  k += (int)(i >> 20);
+  double m = cssm_u2d(ux);
+  double f = m - 1.0;
+  double s = f / (2.0 + f);
+  double dk = (double)k;
+  double z = s * s;
+  double w = z * z;
+  double t1 = w * cssm_fma(w, cssm_fma(w, LG6, LG4), LG2);
+  double t2 = z * cssm_fma(w, cssm_fma(w, cssm_fma(w, LG7, LG5), LG3), LG1);
+  double R = t2 + t1;
+  double hfsq = 0.5 * f * f;
+  return dk * LN2_HI - ((hfsq - (s * (hfsq + R) + dk * LN2_LO)) - f);
+}
+
+/*
+ * log(x) for x in [2^-53, 1] -- the Box-Muller argument -- without a division and without special
+ * cases.  x = 2^e * f, f in [1,2); j = top 7 mantissa bits of f.  j < 64: m = f, k = e; j >= 64:
+ * m = f/2 in [0.75, 1), k = e + 1.  Table entry j holds invc = RN(1/c_j) and logc = RN(-log(invc)) for
+ * the centre c_j of m's interval (c = 1 exactly for the two intervals touching 1, so log is exact-ish
+ * and never positive near x = 1).  r = m*invc - 1 (one fma), |r| <= 2^-7,
+ * log(x) = (k ln2_hi + logc) + (r + r^2 P(r) + k ln2_lo), P = degree-6 Taylor tail of log1p.
+ * The table (2 KiB) is passed by pointer: the host uses CSSM_LOG_TAB, kernels stage it in LDS.
+ * Generated with 80-digit decimal arithmetic (tests/golden/make_golden.py documents the recipe).
+ */
+
 
 CSSM_HD double cssm_log_unit(double x, const double* tab) {
   const double LN2_HI = 6.93147180369123816490e-01;
@@ -401,6 +550,28 @@ CSSM_HD void cssm_sincos2pi(double u, double* sn, double* cs) {
   const double w = 1.0 - hz;
   const double c = w + (((1.0 - w) - hz) + (z * z) * rc);
   /* quadrant rotation without branches: odd q swaps, bit 1 of q (of q+1) negates sin (cos) */
+  const int swap = q & 1;
+  const double ss = swap ? c : s;
+  const double cc = swap ? s : c;
+  *sn = cssm_u2d(cssm_d2u(ss) ^ ((uint64_t)(q & 2) << 62));
+  *cs = cssm_u2d(cssm_d2u(cc) ^ ((uint64_t)((q + 1) & 2) << 62));
+}
+
+/* cssm_sincos2pi with its constants read from `tab`: the same operations in the same order. */
+CSSM_HD void cssm_sincos2pi_t(double u, const double* tab, double* sn, double* cs) {
+  double t = 4.0 * u;
+  int q = (int)(t + 0.5);
+  double r = t - (double)q;
+  const double x = r * tab[CSSM_KI_PIO2];
+  const double z = x * x;
+  const double rs = cssm_fma(z, cssm_fma(z, cssm_fma(z, cssm_fma(z, cssm_fma(z, tab[CSSM_KI_S6], tab[CSSM_KI_S5]), tab[CSSM_KI_S4]),
+                                                 tab[CSSM_KI_S3]), tab[CSSM_KI_S2]), tab[CSSM_KI_S1]);
+  const double s = cssm_fma(z * x, rs, x);
+  const double rc = cssm_fma(z, cssm_fma(z, cssm_fma(z, cssm_fma(z, cssm_fma(z, tab[CSSM_KI_C6], tab[CSSM_KI_C5]), tab[CSSM_KI_C4]),
+                                                 tab[CSSM_KI_C3]), tab[CSSM_KI_C2]), tab[CSSM_KI_C1]);
+  const double hz = 0.5 * z;
+  const double w = 1.0 - hz;
+  const double c = w + (((1.0 - w) - hz) + (z * z) * rc);
   const int swap = q & 1;
   const double ss = swap ? c : s;
   const double cc = swap ? s : c;

@@ -778,6 +778,8 @@ void oracle_c_philox(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[
 void oracle_c_normals(uint64_t seed, uint64_t gid, uint32_t step, uint32_t tag, uint32_t pair, double* z2) {
   cssm_normal_pair(cssm_philox_draw(seed, gid, step, tag, pair), CSSM_LOG_TAB, &z2[0], &z2[1]);
 }
+void oracle_c_exp_t_v(const double* x, double* y, size_t n) { for (size_t i = 0; i < n; ++i) y[i] = cssm_exp_t(x[i], CSSM_TAB); }
+void oracle_c_sincos2pi_t_v(const double* u, double* s, double* c, size_t n) { for (size_t i = 0; i < n; ++i) cssm_sincos2pi_t(u[i], CSSM_TAB, &s[i], &c[i]); }
 void oracle_c_log_unit_v(const double* x, double* y, size_t n) { for (size_t i = 0; i < n; ++i) y[i] = cssm_log_unit(x[i], CSSM_LOG_TAB); }
 double oracle_c_lgamma_kp1(long long k) { return cssm_lgamma_kp1(k); }
 double oracle_c_lgamma(double x) { return cssm_lgamma(x); }

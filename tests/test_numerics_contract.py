@@ -108,3 +108,12 @@ def test_sys_count_matches_brute_force():
         brute = sum(1 for i in range(n) if (u + i) / n <= C)
         assert cnt(C, u, n) == brute
     assert cnt(1.0, 0.999, 16) == 16 and cnt(0.0, 0.5, 16) == 0 and cnt(0.0, 0.0, 16) == 1
+
+
+def test_table_driven_variants_are_bit_identical_to_the_literal_forms():
+    rng = np.random.default_rng(12)
+    x = np.concatenate([rng.uniform(-760, 720, 300000), rng.normal(0, 3, 100000), [0.0, np.nan, np.inf, -np.inf, 709.9, -708.5]])
+    assert np.array_equal(oracle.c_exp(x), oracle.c_exp_t(x), equal_nan=True)
+    u = rng.random(300000)
+    s1, c1 = oracle.c_sincos2pi(u); s2, c2 = oracle.c_sincos2pi_t(u)
+    assert np.array_equal(s1, s2) and np.array_equal(c1, c2)

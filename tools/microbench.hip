@@ -12,8 +12,8 @@
 
 template <int MODE>
 __global__ __launch_bounds__(256) void k_piece(double* __restrict__ out, uint64_t n, uint64_t seed, uint32_t step, const double* __restrict__ gtab) {
-  __shared__ double tab[256];
-  tab[threadIdx.x] = gtab[threadIdx.x];
+  __shared__ double tab[CSSM_TAB_SIZE];
+  for (int i = threadIdx.x; i < CSSM_TAB_SIZE; i += 256) tab[i] = gtab[i];
   __syncthreads();
   for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (uint64_t)gridDim.x * 256) {
     double acc = 0.0;
@@ -61,7 +61,7 @@ int main() {
   const uint64_t sizes[] = {1ull << 20, 1ull << 22, 1ull << 24};
   for (uint64_t n : sizes) {
     double *out, *src, *dst, *gtab;
-    CHECK(hipMalloc(&gtab, sizeof(CSSM_LOG_TAB))); CHECK(hipMemcpy(gtab, CSSM_LOG_TAB, sizeof(CSSM_LOG_TAB), hipMemcpyHostToDevice));
+    CHECK(hipMalloc(&gtab, sizeof(CSSM_TAB))); CHECK(hipMemcpy(gtab, CSSM_TAB, sizeof(CSSM_TAB), hipMemcpyHostToDevice));
     CHECK(hipMalloc(&out, n * 8)); CHECK(hipMalloc(&src, n * 8 * 3)); CHECK(hipMalloc(&dst, n * 8 * 4));
     CHECK(hipMemset(src, 0, n * 8 * 3));
     for (int grid : {1024, 2048, 4096, 8192}) {
