@@ -321,6 +321,24 @@ def test_filter_accepts_the_three_resamplers():
     assert len(set(lls)) == 3 and max(lls) - min(lls) < 1.0
 
 
+def test_cpp_host_mirror_matches_python_binding_and_oracle(tmp_path):
+    """include/cssm_pf.hpp (C++ mirror of Filter/llFilter/filter/stepFilter) compiled with g++ and run here."""
+    import os, subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "test_hpp")
+    lib = os.path.join(root, "composablestatespacemodels_amd", "csrc")
+    subprocess.check_call(["g++", "-std=c++17", "-O2", "-I" + os.path.join(root, "include"), os.path.join(root, "tests", "cpp", "test_hpp.cpp"),
+                           "-L" + lib, "-lcssm_pf", "-Wl,-rpath," + lib, "-o", exe])
+    out = subprocess.run([exe, "4096"], capture_output=True, text=True, check=True).stdout
+    kv = dict(line.split(" ", 1) for line in out.strip().splitlines())
+    model = cases.c2_model()
+    t = np.arange(8.0); y = np.array([2, 1, 4, 0, 3, 2, 5, 1.0]); has = np.ones(8, dtype=np.uint8); has[3] = 0
+    o = oracle.OraclePf(model.descriptor(), 4096, cases.SEED)
+    oll, _, oess, _ = o.filter(t, y, has)
+    assert float.fromhex(kv["ll"]) == oll and float.fromhex(kv["ll_filter"]) == oll and float.fromhex(kv["ll_stream"]) == oll
+    assert int(kv["path_len"]) == 9 and int(kv["ess"]) == oess[-1] and int(kv["error_code"]) == -1
+
+
 def test_errors_are_reported_not_swallowed():
     from composablestatespacemodels_amd import CssmError
     model = cases.linear_model()
