@@ -755,12 +755,10 @@ static double host_link(int obs_kind, double g) {
   }
 }
 
-extern "C" int cssm_pf_summary(cssm_pf* pf, double interval, double* state_mean, double* state_lower, double* state_upper,
-                               double* eta_of_mean, double* eta_lower, double* eta_upper) {
-  if (!pf) return fail(CSSM_EINVAL_ARG, "null handle");
-  if (!pf->initialised) return fail(CSSM_ESTATE, "not initialised");
-  if (!(interval > 0.0 && interval <= 1.0)) return fail(CSSM_EINVAL_ARG, "interval must be in (0, 1]");
-  HIP_TRY(hipSetDevice(pf->device));
+// Summary of the cloud { src[:, idx[i]] : i < n } at time `time` (idx == nullptr: identity); see cssm_pf_summary.
+static int summary_impl(cssm_pf* pf, const double* src, size_t src_stride, const uint32_t* idx, const double* src2, size_t src2_stride,
+                        uint32_t n_split, double time, double interval, double* state_mean, double* state_lower, double* state_upper,
+                        double* eta_of_mean, double* eta_lower, double* eta_upper) {
   const int d = pf->d, rows = d + 1;
   const uint64_t n = pf->n;
   const int nblocks = grid_for(n, CSSM_BLOCK, 1024);
@@ -772,14 +770,14 @@ extern "C" int cssm_pf_summary(cssm_pf* pf, double interval, double* state_mean,
   int rc = CSSM_OK;
   // ranks, 0-based in ascending order: getCredibleInterval (:488-502) uses (N - index - 1, index - 1) with
   // index = floor(interval * N); getOrderStatistic (:455-460) uses (N - index, index) -- both reproduced
-  const long long idx = (long long)std::floor(interval * (double)n);
+  const long long idxr = (long long)std::floor(interval * (double)n);
   auto clampr = [&](long long r) { return (unsigned long long)std::min<long long>(std::max<long long>(r, 0), (long long)n - 1); };
   for (int k = 0; k < rows; ++k) {
     hst[k].prefix[0] = hst[k].prefix[1] = 0;
-    hst[k].rank[0] = clampr(k < d ? (long long)n - idx - 1 : (long long)n - idx);
-    hst[k].rank[1] = clampr(k < d ? idx - 1 : idx);
+    hst[k].rank[0] = clampr(k < d ? (long long)n - idxr - 1 : (long long)n - idxr);
+    hst[k].rank[1] = clampr(k < d ? idxr - 1 : idxr);
   }
-  build_rec(pf, pf->t, pf->t, 0.0, 0, pf->step, &hrec);   // F(t) of the current time for f(x, t)
+  build_rec(pf, time, time, 0.0, 0, pf->step, &hrec);   // F(t) of the requested time for f(x, t)
 #define SM_TRY(expr) do { hipError_t e__ = (expr); if (e__ != hipSuccess) { rc = fail(CSSM_EHIP, "%s: %s", #expr, hipGetErrorString(e__)); goto done; } } while (0)
   SM_TRY(hipMalloc(&keys, (size_t)rows * n * 8)); SM_TRY(hipMalloc(&partial, (size_t)nblocks * d * 8));
   SM_TRY(hipMalloc(&st, rows * sizeof(SelState))); SM_TRY(hipMalloc(&hist, (size_t)rows * 512 * 4)); SM_TRY(hipMalloc(&out, 3 * rows * 8));
@@ -788,10 +786,8 @@ extern "C" int cssm_pf_summary(cssm_pf* pf, double interval, double* state_mean,
   SM_TRY(hipMemcpyAsync(drec, &hrec, sizeof hrec, hipMemcpyHostToDevice, pf->stream));
   SM_TRY(hipMemsetAsync(hist, 0, (size_t)rows * 512 * 4, pf->stream));
   {
-    const uint32_t* anc = pf->anc_valid ? pf->anc : nullptr;
     DISPATCH_D(d, k_summary_fill<D><<<dim3(nblocks), dim3(CSSM_BLOCK), 0, pf->stream>>>(
-                      pf->src, pf->src_stride, anc, anc ? pf->src2 : nullptr, pf->src2_stride, pf->n_split, n, drec, pf->mk, keys, (size_t)n,
-                      partial));
+                      src, src_stride, idx, idx ? src2 : nullptr, src2_stride, n_split, n, drec, pf->mk, keys, (size_t)n, partial));
     for (int shift = 56; shift >= 0; shift -= 8) {
       hipLaunchKernelGGL(k_sel_hist, dim3(nblocks, rows), dim3(CSSM_BLOCK), 0, pf->stream, keys, (size_t)n, n, st, shift, hist);
       hipLaunchKernelGGL(k_sel_pick, dim3(rows), dim3(2), 0, pf->stream, st, shift, hist);
@@ -820,6 +816,104 @@ extern "C" int cssm_pf_summary(cssm_pf* pf, double interval, double* state_mean,
 done:
 #undef SM_TRY
   { void* ptrs[] = {keys, partial, st, hist, out, drec}; for (void* q : ptrs) if (q) (void)hipFree(q); }
+  return rc;
+}
+
+extern "C" int cssm_pf_summary(cssm_pf* pf, double interval, double* state_mean, double* state_lower, double* state_upper,
+                               double* eta_of_mean, double* eta_lower, double* eta_upper) {
+  if (!pf) return fail(CSSM_EINVAL_ARG, "null handle");
+  if (!pf->initialised) return fail(CSSM_ESTATE, "not initialised");
+  if (!(interval > 0.0 && interval <= 1.0)) return fail(CSSM_EINVAL_ARG, "interval must be in (0, 1]");
+  HIP_TRY(hipSetDevice(pf->device));
+  return summary_impl(pf, pf->src, pf->src_stride, pf->anc_valid ? pf->anc : nullptr, pf->src2, pf->src2_stride, pf->n_split, pf->t,
+                      interval, state_mean, state_lower, state_upper, eta_of_mean, eta_lower, eta_upper);
+}
+
+// ------------------------------------------------------------------------------------ FilterInterpolate
+// FilterInterpolate.stepInterpolate / filterInterpolate (model/ParticleFilter.scala:273-311): particles are whole
+// paths (x_t :: x_{t-1} :: ...), and a weighted step resamples the PATHS.  Here the forward pass keeps every
+// propagated cloud and ancestor array in a history slab (the kernels write straight into it), and the paths that
+// survive to the end are recovered by composing the ancestor arrays backwards: the state at time index s of final
+// path i is X1_s[b_s(i)], b_T = anc_T, b_{s-1} = anc_{s-1}[b_s].  Output: per time index the summary
+// examples/Interpolate.scala:42-44 computes from the transposed paths (getIntervals of the surviving lineages).
+
+__global__ void k_compose(const uint32_t* __restrict__ anc, uint32_t* __restrict__ b, uint64_t n) {
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) b[i] = anc[b[i]];
+}
+__global__ void k_iota(uint32_t* __restrict__ b, uint64_t n) {
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) b[i] = (uint32_t)i;
+}
+
+extern "C" int cssm_pf_interpolate(cssm_pf* pf, const double* t, const double* y, const uint8_t* has, size_t T, double interval,
+                                   int flags, double* ll_out, double* state_mean, double* state_lower, double* state_upper,
+                                   double* eta_of_mean, double* eta_lower, double* eta_upper) {
+  if (!pf || !t || !y) return fail(CSSM_EINVAL_ARG, "null argument");
+  if (T < 1) return fail(CSSM_EINVAL_ARG, "empty data");
+  if (pf->sharded) return fail(CSSM_ESTATE, "interpolation runs on a single-GPU handle");
+  if (pf->obs_kind == CSSM_OBS_LGCP) return fail(CSSM_EINVAL_ARG, "FilterInterpolate weighs with dataLikelihood; the LGCP filter has no path variant");
+  if (!(interval > 0.0 && interval <= 1.0)) return fail(CSSM_EINVAL_ARG, "interval must be in (0, 1]");
+  HIP_TRY(hipSetDevice(pf->device));
+  int rc = ensure_recs(pf, T);
+  if (rc) return rc;
+  const int d = pf->d;
+  const size_t slab = pf->stride * (size_t)d;
+  double* hx = nullptr; uint32_t *hanc = nullptr, *bidx = nullptr;
+  std::vector<uint8_t> weighted(T + 1, 0);
+  double* save_state[2] = {pf->state[0], pf->state[1]};
+  uint32_t* save_anc = pf->anc;
+  if (hipMalloc(&hx, (T + 1) * slab * 8) != hipSuccess) return fail(CSSM_ENOMEM, "history of %zu clouds does not fit (%zu bytes)", T + 1, (T + 1) * slab * 8);
+  if (hipMalloc(&hanc, (T + 1) * pf->stride * 4) != hipSuccess || hipMalloc(&bidx, pf->stride * 4) != hipSuccess) {
+    (void)hipFree(hx); if (hanc) (void)hipFree(hanc);
+    return fail(CSSM_ENOMEM, "ancestor history does not fit");
+  }
+  double t0 = t[0];
+  for (size_t s = 1; s < T; ++s) if (t[s] < t0) t0 = t[s];
+  double tp = t0;
+  for (size_t s = 0; s < T; ++s) { build_rec(pf, tp, t[s], y[s], has ? has[s] : 1, (uint32_t)s, &pf->h_recs[s]); tp = t[s]; }
+  rc = (hipMemcpyAsync(pf->d_recs, pf->h_recs, T * sizeof(StepRec), hipMemcpyHostToDevice, pf->stream) == hipSuccess) ? CSSM_OK : fail(CSSM_EHIP, "record upload");
+  if (!rc) {
+    pf->state[0] = hx;                                   // X1_0 = the initial cloud
+    rc = launch_init(pf, t0);
+  }
+  for (size_t s = 0; s < T && !rc; ++s) {
+    // step s+1 reads X1_s through anc_s (launch_propagate uses pf->anc / pf->anc_valid) and writes X1_{s+1}
+    pf->state[pf->cur ^ 1] = hx + (s + 1) * slab;
+    pf->anc = hanc + s * pf->stride;
+    const int w = pf->h_recs[s].has_obs;
+    pf->h_step_for_resample = (uint32_t)s;
+    rc = launch_propagate(pf, pf->d_recs + s);
+    if (!rc && w) {
+      pf->anc = hanc + (s + 1) * pf->stride;
+      rc = launch_resample(pf, pf->d_recs + s);
+      weighted[s + 1] = 1;
+    }
+  }
+  Scalars h;
+  if (!rc && hipMemcpyAsync(&h, pf->sc, sizeof h, hipMemcpyDeviceToHost, pf->stream) != hipSuccess) rc = fail(CSSM_EHIP, "scalars");
+  if (!rc && hipStreamSynchronize(pf->stream) != hipSuccess) rc = fail(CSSM_EHIP, "forward pass");
+  if (!rc) rc = check_device_err(pf, h);
+  if (!rc && ll_out) *ll_out = h.ll;
+  // backward: compose the genealogy and summarise every time index
+  if (!rc) {
+    hipLaunchKernelGGL(k_iota, dim3(grid_for(pf->n, 256, kGridCap)), dim3(256), 0, pf->stream, bidx, pf->n);
+    for (size_t s = T + 1; s-- > 0 && !rc;) {
+      if (weighted[s])
+        hipLaunchKernelGGL(k_compose, dim3(grid_for(pf->n, 256, kGridCap)), dim3(256), 0, pf->stream, hanc + s * pf->stride, bidx, pf->n);
+      // output entry o pairs the cloud of time index s with the time of index o (o = T - s reproduces the zipped
+      // pairing of examples/Interpolate.scala:42, whose transposed paths run newest-first)
+      const size_t o = (flags & CSSM_INTERP_REFERENCE_PAIRING) ? T - s : s;
+      const double time = (o == 0) ? t0 : t[o - 1];
+      rc = summary_impl(pf, hx + s * slab, pf->stride, bidx, nullptr, 0, 0, time, interval,
+                        state_mean ? state_mean + o * d : nullptr, state_lower ? state_lower + o * d : nullptr,
+                        state_upper ? state_upper + o * d : nullptr, eta_of_mean ? eta_of_mean + o : nullptr,
+                        eta_lower ? eta_lower + o : nullptr, eta_upper ? eta_upper + o : nullptr);
+    }
+  }
+  (void)hipStreamSynchronize(pf->stream);
+  pf->state[0] = save_state[0]; pf->state[1] = save_state[1]; pf->anc = save_anc;
+  pf->initialised = false;                               // the handle's own buffers hold no cloud now
+  (void)hipFree(hx); (void)hipFree(hanc); (void)hipFree(bidx);
+  pf->t = t[T - 1]; pf->step = (uint32_t)T;
   return rc;
 }
 

@@ -136,6 +136,24 @@ class NativePf:
         _abi.check(self.lib.cssm_pf_summary(self._h, float(interval), _p(m), _p(lo), _p(hi), C.byref(em), C.byref(el), C.byref(eu)))
         return m, lo, hi, em.value, el.value, eu.value
 
+    def interpolate(self, t, y, has=None, interval: float = 0.975, reference_pairing: bool = False):
+        """cssm_pf_interpolate: (ll, mean[T+1,d], lower, upper, eta_of_mean[T+1], eta_lower, eta_upper)."""
+        t = np.ascontiguousarray(t, dtype=np.float64)
+        y = np.ascontiguousarray(y, dtype=np.float64)
+        T = len(t)
+        hp = None
+        if has is not None:
+            has = np.ascontiguousarray(has, dtype=np.uint8)
+            hp = _p(has, C.POINTER(C.c_uint8))
+        m, lo, hi = (np.zeros((T + 1, self.d)) for _ in range(3))
+        em, el, eu = (np.zeros(T + 1) for _ in range(3))
+        ll = C.c_double()
+        rc = self.lib.cssm_pf_interpolate(self._h, _p(t), _p(y), hp, T, float(interval), 1 if reference_pairing else 0,
+                                          C.byref(ll), _p(m), _p(lo), _p(hi), _p(em), _p(el), _p(eu))
+        self.generation += 1
+        _abi.check(rc)
+        return ll.value, m, lo, hi, em, el, eu
+
     def particles(self) -> np.ndarray:
         out = np.zeros((self.d, self.n))
         _abi.check(self.lib.cssm_pf_get_particles(self._h, _p(out)))
@@ -325,6 +343,26 @@ class FilterLgcp(_FilterBase):
         super().__init__(mod, resample, **kw)
 
 
+class FilterInterpolate(_FilterBase):
+    """``FilterInterpolate(mod, resample)``, ParticleFilter.scala:273-311: particles are whole paths and a weighted
+    step resamples the paths.  The reference's only consumer (examples/Interpolate.scala:34-44) runs the stream to
+    the end and summarises the LAST state's transposed paths; ``interpolate`` returns exactly that list of ``PfOut``
+    (one per emitted state: the initial one and one per datum), formed on the device from the ancestor history.
+
+    ``reference_pairing=True`` reproduces the example's ``zipped`` literally: the transposed paths run newest-first,
+    so entry k carries the time/observation of index k but the states of index T-k; the default pairs them
+    chronologically, which is what the example means to plot."""
+
+    def interpolate(self, data: Sequence[TimedObservation], particles: int, interval: float = 0.975,
+                    reference_pairing: bool = False) -> Tuple[float, List[PfOut]]:
+        t, y, h = split_data(data)
+        ll, m, lo, hi, em, el, eu = self._ensure(particles).interpolate(t, y, h, interval, reference_pairing)
+        times = [float(np.min(t))] + [float(v) for v in t]
+        obs = [None] + [d.observation for d in data]
+        return ll, [PfOut(times[k], obs[k], float(em[k]), CredibleInterval(float(el[k]), float(eu[k])), m[k].copy(),
+                          [CredibleInterval(float(a), float(b)) for a, b in zip(lo[k], hi[k])]) for k in range(len(times))]
+
+
 class ParticleFilter:
     """``object ParticleFilter``: Reader-wrapped entry points, ParticleFilter.scala:321-361."""
 
@@ -335,6 +373,10 @@ class ParticleFilter:
     @staticmethod
     def filterInit(resample, t0: float, n: int, initState, **kw):
         return lambda mod: FilterInit(mod, resample, initState, **kw).filterStream(t0, n)
+
+    @staticmethod
+    def interpolate(resample, t0: float, particles: int, **kw):   # :335-337 (t0 is re-derived from the data as minSink does)
+        return lambda mod: (lambda data: FilterInterpolate(mod, resample, **kw).interpolate(list(data), particles))
 
     @staticmethod
     def filterLlState(data, resample, n: int, **kw):

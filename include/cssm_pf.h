@@ -222,6 +222,21 @@ int cssm_pf_get_proposed(cssm_pf* pf, double* out_dN);
 int cssm_pf_summary(cssm_pf* pf, double interval, double* state_mean, double* state_lower, double* state_upper,
                     double* eta_of_mean, double* eta_lower, double* eta_upper);
 
+/* FilterInterpolate (model/ParticleFilter.scala:273-311, ParticleFilter.interpolate :335-337): the filter whose
+ * particles are whole paths, so that a weighted step resamples the paths and missing observations are
+ * interpolated by the surviving lineages.  The forward pass keeps the history of clouds and ancestor arrays on the
+ * device ((T+1) * N * (8 d + 4) bytes); the output is, for every time index s = 0..T (0 = initial cloud), the
+ * summary examples/Interpolate.scala:42-44 forms from the transposed paths of the LAST state: mean, the
+ * getCredibleInterval order statistics and eta (see cssm_pf_summary).  Arrays: (T+1)*d doubles (state_*),
+ * T+1 doubles (eta_*); any may be NULL.  The handle must be re-initialised before further streaming calls.
+ * flags: CSSM_INTERP_REFERENCE_PAIRING pairs output entry k with the cloud of time index T - k (evaluated with
+ * the time of index k): what the example's `(interpolated, interpolated.last.particles.transpose).zipped` really
+ * does, since the transposed paths run newest-first; 0 gives the chronological pairing the example intends. */
+#define CSSM_INTERP_REFERENCE_PAIRING 1
+int cssm_pf_interpolate(cssm_pf* pf, const double* t, const double* y, const uint8_t* has_obs, size_t T, double interval,
+                        int flags, double* ll_out, double* state_mean, double* state_lower, double* state_upper,
+                        double* eta_of_mean, double* eta_lower, double* eta_upper);
+
 /* ---- stateless resampler: the `Resample[A]` seam (model/package.scala:23) ------------------ */
 
 /* Resampling.systematicResampling (model/Resampling.scala:63-72) on host arrays: weights w[n]

@@ -676,7 +676,7 @@ static int cmp_double(const void* a, const void* b) { double x = *(const double*
 /* getIntervals, model/ParticleFilter.scala:415-424: meanState (:465-479, weights 1/N), getallCredibleIntervals
  * (:488-512: sorted(N - index - 1), sorted(index - 1)), getOrderStatistic of eta (:455-460: sorted(N - index),
  * sorted(index)), meanEta = link(f(stateMean, t)). */
-int oracle_pf_summary(const oracle_pf* pf, double interval, double* mean, double* lower, double* upper,
+static int summary_of(const oracle_pf* pf, const double* x, double time, double interval, double* mean, double* lower, double* upper,
                       double* eta_of_mean, double* eta_lower, double* eta_upper) {
   uint64_t n = pf->n;
   int d = pf->d;
@@ -685,19 +685,69 @@ int oracle_pf_summary(const oracle_pf* pf, double interval, double* mean, double
   long long idx = (long long)floor(interval * (double)n);
   for (int k = 0; k < d; ++k) {
     double acc = 0.0;
-    for (uint64_t i = 0; i < n; ++i) { col[i] = pf->x[i * d + k]; acc = acc + col[i] * w; }
+    for (uint64_t i = 0; i < n; ++i) { col[i] = x[i * d + k]; acc = acc + col[i] * w; }
     mean[k] = acc;
     qsort(col, n, 8, cmp_double);
     lower[k] = col[clamp_rank((long long)n - idx - 1, n)];
     upper[k] = col[clamp_rank(idx - 1, n)];
   }
-  for (uint64_t i = 0; i < n; ++i) col[i] = o_link(pf, gamma_of(pf, pf->x + i * d, pf->t));
+  for (uint64_t i = 0; i < n; ++i) col[i] = o_link(pf, gamma_of(pf, x + i * d, time));
   qsort(col, n, 8, cmp_double);
   *eta_lower = col[clamp_rank((long long)n - idx, n)];
   *eta_upper = col[clamp_rank(idx, n)];
-  *eta_of_mean = o_link(pf, gamma_of(pf, mean, pf->t));
+  *eta_of_mean = o_link(pf, gamma_of(pf, mean, time));
   free(col);
   return ORACLE_OK;
+}
+
+int oracle_pf_summary(const oracle_pf* pf, double interval, double* mean, double* lower, double* upper,
+                      double* eta_of_mean, double* eta_lower, double* eta_upper) {
+  return summary_of(pf, pf->x, pf->t, interval, mean, lower, upper, eta_of_mean, eta_lower, eta_upper);
+}
+
+/* ------------------------------------------------------------------ FilterInterpolate */
+
+/* FilterInterpolate.stepInterpolate / filterInterpolate, model/ParticleFilter.scala:273-311, followed by the
+ * summary of examples/Interpolate.scala:42-44.  Literal: every particle IS its path (newest state first in the
+ * reference's List; here oldest first in an array), a weighted step copies whole paths by the resampled indices.
+ * Output entry k (k = 0..T): getIntervals of { path_i[src] : i } where src = k, evaluated with the time of index k
+ * -- or, with reference_pairing != 0, src = T - k: what `(interpolated, interpolated.last.particles.transpose)
+ * .zipped` really pairs, because the transposed paths run newest-first (an evident slip of the example that
+ * only a drop-in needs to reproduce). */
+int oracle_pf_interpolate(oracle_pf* pf, const double* t, const double* y, const uint8_t* has, size_t T, double interval,
+                          int reference_pairing, double* ll_out, double* mean, double* lower, double* upper,
+                          double* eta_of_mean, double* eta_lower, double* eta_upper) {
+  if (pf->obs_kind == CSSM_OBS_LGCP) return ORACLE_EINVAL;
+  uint64_t n = pf->n;
+  int d = pf->d;
+  size_t L = (T + 1) * (size_t)d;
+  double t0 = t[0];
+  for (size_t s = 1; s < T; ++s) if (t[s] < t0) t0 = t[s];
+  int rc = oracle_pf_init(pf, t0);                               /* x0 = initialState.sample(particles) map (_ :: Nil) */
+  if (rc) return rc;
+  double* paths = (double*)calloc(n * L, 8), *next = (double*)calloc(n * L, 8), *cloud = (double*)malloc(n * d * 8);
+  for (uint64_t i = 0; i < n; ++i) memcpy(paths + i * L, pf->x + i * d, d * 8);
+  for (size_t s = 0; s < T && !rc; ++s) {
+    rc = oracle_pf_step(pf, t[s], y[s], has ? has[s] : 1, NULL, NULL);
+    if (rc) break;
+    /* x1 = step(x.head) :: x, then resample(x1, w1): path i becomes (path anc[i]) ++ x1[anc[i]]; pf->x[i] = x1[anc[i]] */
+    for (uint64_t i = 0; i < n; ++i) {
+      memcpy(next + i * L, paths + (uint64_t)pf->anc[i] * L, (s + 1) * d * 8);
+      memcpy(next + i * L + (s + 1) * d, pf->x + i * d, d * 8);
+    }
+    double* sw = paths; paths = next; next = sw;
+  }
+  if (!rc) {
+    if (ll_out) *ll_out = pf->ll;
+    for (size_t k = 0; k <= T; ++k) {
+      size_t src = reference_pairing ? T - k : k;
+      double time = k == 0 ? t0 : t[k - 1];
+      for (uint64_t i = 0; i < n; ++i) memcpy(cloud + i * d, paths + i * L + src * d, d * 8);
+      summary_of(pf, cloud, time, interval, mean + k * d, lower + k * d, upper + k * d, eta_of_mean + k, eta_lower + k, eta_upper + k);
+    }
+  }
+  free(paths); free(next); free(cloud);
+  return rc;
 }
 
 /* ------------------------------------------------------------------ A11 PMMH */

@@ -67,6 +67,7 @@ def lib() -> C.CDLL:
             "oracle_pf_get_ancestors": (None, [vp, _u32p]),
             "oracle_pf_get_cumw": (None, [vp, _dp]),
             "oracle_pf_summary": (C.c_int, [vp, C.c_double, _dp, _dp, _dp, _dp, _dp, _dp]),
+            "oracle_pf_interpolate": (C.c_int, [vp, _dp, _dp, _u8p, C.c_size_t, C.c_double, C.c_int, _dp, _dp, _dp, _dp, _dp, _dp, _dp]),
             "oracle_resample_systematic": (C.c_int, [_dp, C.c_uint64, C.c_double, _u32p, _dp, C.c_int]),
             "oracle_resample_stratified": (C.c_int, [_dp, C.c_uint64, C.c_uint64, C.c_uint32, _u32p, _dp]),
             "oracle_resample_multinomial": (C.c_int, [_dp, C.c_uint64, C.c_uint64, C.c_uint32, _u32p, _dp]),
@@ -185,6 +186,17 @@ class OraclePf:
         em, el, eu = C.c_double(), C.c_double(), C.c_double()
         _chk(lib().oracle_pf_summary(self._h, interval, _p(m), _p(lo), _p(hi), C.byref(em), C.byref(el), C.byref(eu)))
         return m, lo, hi, em.value, el.value, eu.value
+
+    def interpolate(self, t, y, has=None, interval=0.975, reference_pairing=False):
+        t = np.ascontiguousarray(t, dtype=np.float64); y = np.ascontiguousarray(y, dtype=np.float64)
+        T = len(t)
+        hasa = np.ones(T, dtype=np.uint8) if has is None else np.ascontiguousarray(has, dtype=np.uint8)
+        m, lo, hi = (np.zeros((T + 1, self.d)) for _ in range(3))
+        em, el, eu = (np.zeros(T + 1) for _ in range(3))
+        ll = np.zeros(1)
+        _chk(lib().oracle_pf_interpolate(self._h, _p(t), _p(y), _p(hasa, _u8p), T, interval, int(reference_pairing), _p(ll),
+                                         _p(m), _p(lo), _p(hi), _p(em), _p(el), _p(eu)))
+        return float(ll[0]), m, lo, hi, em, el, eu
 
     def particles(self):
         out = np.zeros((self.d, self.n)); lib().oracle_pf_get_particles(self._h, _p(out)); return out
