@@ -92,8 +92,8 @@ SYMBOLS = [
     ("cssm_resample_systematic", C.c_int, [_dp, C.c_size_t, C.c_double, _u32p, C.c_int]),
     ("cssm_pf_shard_init", C.c_int, [_h, C.c_double]),
     ("cssm_pf_shard_propagate", C.c_int, [_h, C.c_double, C.c_double, C.c_int, C.c_void_p]),
-    ("cssm_pf_shard_sums", C.c_int, [_h, C.c_void_p, C.c_void_p]),
-    ("cssm_pf_shard_offspring", C.c_int, [_h, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    ("cssm_pf_shard_sums", C.c_int, [_h, C.c_void_p, C.c_int, C.c_void_p]),
+    ("cssm_pf_shard_offspring", C.c_int, [_h, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     ("cssm_pf_shard_pack", C.c_int, [_h, C.c_int, _i64p, _i64p, C.c_int, C.c_void_p]),
     ("cssm_pf_shard_adopt", C.c_int, [_h, C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_int64]),
     ("cssm_pf_shard_result", C.c_int, [_h, _dp, _i32p]),

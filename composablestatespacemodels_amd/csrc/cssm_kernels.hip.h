@@ -53,6 +53,7 @@ struct StepRec {
   double cdf;     // Student-t: degrees of freedom as double
   double u;       // the one uniform of systematic resampling
   double dt;      // time increment (LGCP: the sub-step delta)
+  double ref;     // reference level of the observation (cssm_ref_level; NaN: always rescale by the max)
   int32_t has_obs;
   int32_t n_sub;  // LGCP sub-steps (0: dt == 0, weight 0, state kept)
   uint32_t pick;  // sampleOne index for `filter`
@@ -68,9 +69,11 @@ struct Scalars {
   // Order keys of the running max log-weight, sharded over CSSM_MAXSLOTS cache lines, in two sets:
   // weighted step s uses set s&1, and its last kernel clears the other set for step s+1.
   unsigned long long maxslot[2 * CSSM_MAXSLOTS * CSSM_SLOT_STRIDE];
-  uint32_t err;              // bit0: NaN log-weight, bit1: all weights zero / max not finite
+  uint32_t err;              // bit0: NaN log-weight, bit1: all weights zero / max not finite,
+                             // bit2: the reference level was unusable and the sums must be formed again (host retries)
   int32_t ess;
   double gmax;               // decoded global max of this step
+  double ref;                // level the weights of this step were rescaled by (cssm_ref_choose)
   double ll;                 // accumulated log-likelihood
   cssm_u128 S_local, S2_local; // local fixed-point sums (this rank)
   cssm_u128 S_off;           // sum of the ranks before this one
@@ -282,12 +285,18 @@ __device__ __forceinline__ double decode_slots(const Scalars* __restrict__ sc, i
 // the co-resident waves to cover LDS/table and gather latency), 3 beyond
 template <int D> struct PropWaves { static constexpr int value = (D <= 4) ? 4 : 3; };
 
+//
+// A block owns the CONTIGUOUS range [blockIdx.x * chunk, +chunk) (chunk a multiple of CSSM_BLOCK*IT, chosen on the
+// host so that a whole number of blocks makes one scan unit of k_offspring).  With do_sums the block also forms
+// S = sum exp(w - c), S2 = sum exp(w - c)^2 in fixed point for its range, c = rec->ref being known before any
+// weight is (include/cssm_numerics.h, "reference level"): the log-sum-exp of :125-127 then needs no pass of its own.
 template <int D, bool LGCP, int IT, int OBS>
 __global__ __launch_bounds__(CSSM_BLOCK, PropWaves<D>::value) void k_propagate(
     const double* __restrict__ src, size_t src_stride, const uint32_t* __restrict__ anc,
     double* __restrict__ dst, size_t dst_stride, double* __restrict__ logw, uint64_t n, uint64_t gid0,
     uint64_t seed, const StepRec* __restrict__ rec, ModelK mk, Scalars* __restrict__ sc, int slot_set,
-    const double* __restrict__ src2, size_t src2_stride, uint32_t n_split, const double* __restrict__ logtab) {
+    const double* __restrict__ src2, size_t src2_stride, uint32_t n_split, const double* __restrict__ logtab,
+    uint64_t chunk, int do_sums_arg, cssm_u128* __restrict__ subS, cssm_u128* __restrict__ subS2) {
   // src2 != nullptr (sharded filter): ancestor indices >= n_split address the candidates received from
   // other ranks, src2[k * src2_stride + (j - n_split)]
   __shared__ double s_max[CSSM_BLOCK / 64];
@@ -296,10 +305,16 @@ __global__ __launch_bounds__(CSSM_BLOCK, PropWaves<D>::value) void k_propagate(
   const int has_obs = rec->has_obs;
   const double dt = rec->dt;
   const bool weighted = LGCP || has_obs;
+  const bool do_sums = !LGCP && do_sums_arg && has_obs;
+  const double cref = rec->ref;
+  cssm_u128 accS = cssm_u128_zero(), accS2 = cssm_u128_zero();
   double tmax = -cssm_inf();
   bool bad = false;
   const uint64_t per_block = (uint64_t)CSSM_BLOCK * IT;
-  const uint64_t stride = (uint64_t)gridDim.x * per_block;
+  const uint64_t stride = per_block;
+  const uint64_t range_lo = (uint64_t)blockIdx.x * chunk;
+  const uint64_t n_all = n;
+  { const uint64_t range_hi = range_lo + chunk; n = (range_hi < n) ? range_hi : n; }   // this block's range ends at n
   // Optional software pipeline over the block's tiles: ancestor indices two tiles ahead, gathered states
   // one tile ahead of the tile being computed.  MEASURED SLOWER on MI355X (N = 2^24, d = 3: 320 us with
   // the pipeline at 4 waves/SIMD + spills, 337 us at 3 waves, 280 us without), so it is compiled out:
@@ -331,7 +346,7 @@ __global__ __launch_bounds__(CSSM_BLOCK, PropWaves<D>::value) void k_propagate(
       for (int k = 0; k < D; ++k)
         x[r][k] = (src2 && j[r] >= n_split) ? src2[(size_t)k * src2_stride + (j[r] - n_split)] : src[(size_t)k * src_stride + j[r]];
   };
-  uint64_t base = (uint64_t)blockIdx.x * per_block;
+  uint64_t base = range_lo;
   size_t jn[IT], jnn[IT];
   double x[IT][D], xn[IT][D];
   if (base < n) {
@@ -384,6 +399,14 @@ __global__ __launch_bounds__(CSSM_BLOCK, PropWaves<D>::value) void k_propagate(
       if (weighted && i0 + r < n) {
         if (lw[r] != lw[r]) { bad = true; lw[r] = -cssm_inf(); }
         tmax = (lw[r] > tmax) ? lw[r] : tmax;
+        if (!LGCP && do_sums) {
+          // beyond c + CSSM_REF_BELOW the step is redone with the max anyway: keep the conversion in range
+          double a = lw[r] - cref;
+          a = (a > CSSM_REF_BELOW) ? CSSM_REF_BELOW : a;
+          const double w1 = cssm_exp(a);
+          accS = cssm_u128_add(accS, cssm_fix_from_double(w1));
+          accS2 = cssm_u128_add(accS2, cssm_fix_from_double(w1 * w1));
+        }
       }
     }
     if (full && IT == 4) {
@@ -427,11 +450,26 @@ __global__ __launch_bounds__(CSSM_BLOCK, PropWaves<D>::value) void k_propagate(
       gather(jn, x);
     }
   }
+  (void)n_all;
   if (!weighted) return;
   tmax = wave_max(tmax);
   if ((threadIdx.x & 63) == 0) s_max[threadIdx.x >> 6] = tmax;
   if (__any(bad) && (threadIdx.x & 63) == 0) atomicOr(&sc->err, 1u);
-  __syncthreads();
+  if (!LGCP && do_sums) {
+    __shared__ cssm_u128 s_sa[CSSM_BLOCK / 64], s_sb[CSSM_BLOCK / 64];
+    accS = wave_sum_u128(accS);
+    accS2 = wave_sum_u128(accS2);
+    if ((threadIdx.x & 63) == 0) { s_sa[threadIdx.x >> 6] = accS; s_sb[threadIdx.x >> 6] = accS2; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      cssm_u128 ta = s_sa[0], tb = s_sb[0];
+#pragma unroll
+      for (int w = 1; w < CSSM_BLOCK / 64; ++w) { ta = cssm_u128_add(ta, s_sa[w]); tb = cssm_u128_add(tb, s_sb[w]); }
+      subS[blockIdx.x] = ta; subS2[blockIdx.x] = tb;
+    }
+  } else {
+    __syncthreads();
+  }
   if (threadIdx.x == 0) {
     double m = s_max[0];
 #pragma unroll
@@ -478,13 +516,16 @@ __global__ __launch_bounds__(CSSM_BLOCK) void k_tile_sums(const double* __restri
                                                           const Scalars* __restrict__ sc,
                                                           cssm_u128* __restrict__ unitS, cssm_u128* __restrict__ unitS2,
                                                           uint32_t ntiles, uint32_t sup, uint32_t nunits, int raw, int slot_set,
-                                                          const double* __restrict__ gmax_in, const double* __restrict__ logtab) {
+                                                          const double* __restrict__ gmax_in, const double* __restrict__ logtab,
+                                                          const StepRec* __restrict__ rec) {
   __shared__ cssm_u128 s_a[CSSM_BLOCK / 64], s_b[CSSM_BLOCK / 64];
   const double* tab = nullptr; (void)logtab;   // literal constants measured faster than an LDS constant table
   double pre[CSSM_ITEMS];   // the block's first tile is requested before the (serial) max decode
   if (blockIdx.x < nunits) load_tile_raw(logw, (uint64_t)blockIdx.x * sup * CSSM_TILE, n, raw, pre);
   // slot_set < 0: the max was agreed elsewhere (sharded: all-reduced value at gmax_in; stateless: sc->gmax)
-  const double gmax = (slot_set >= 0) ? block_decode_slots(sc, slot_set) : (gmax_in ? *gmax_in : sc->gmax);
+  const double gmax_dec = (slot_set >= 0) ? block_decode_slots(sc, slot_set) : (gmax_in ? *gmax_in : sc->gmax);
+  // the level every kernel of the step agrees on: the observation's reference level when the max allows it
+  const double gmax = raw ? gmax_dec : cssm_ref_choose(rec->ref, gmax_dec);
   for (uint32_t unit = blockIdx.x; unit < nunits; unit += gridDim.x) {
     const uint32_t t0 = unit * sup;
     const uint32_t t1 = (t0 + sup < ntiles) ? t0 + sup : ntiles;
@@ -521,7 +562,7 @@ __device__ void finish_step(Scalars* sc, uint64_t n_global) {
     atomicOr(&sc->err, 2u);
     return;
   }
-  sc->ll = sc->ll + sc->gmax + cssm_log(tot / (double)n_global);
+  sc->ll = sc->ll + sc->ref + cssm_log(tot / (double)n_global);
   double e = 1.0 / (tot2 / (tot * tot));
   double fl = (double)(long long)e;   // e >= 1 here; floor == trunc
   sc->ess = (e < 2147483647.0) ? (int32_t)fl : 2147483647;
@@ -533,10 +574,21 @@ __global__ __launch_bounds__(1024) void k_scan_tiles(const cssm_u128* __restrict
                                                      cssm_u128* __restrict__ tileP, uint32_t ntiles, Scalars* sc,
                                                      uint64_t n_global, int single,
                                                      double* __restrict__ ll_t, int32_t* __restrict__ ess_t, uint32_t rec_idx,
-                                                     const double* __restrict__ gmax_in, unsigned long long* __restrict__ sums4_out) {
+                                                     const double* __restrict__ gmax_in, unsigned long long* __restrict__ sums4_out,
+                                                     int export_max) {
   __shared__ cssm_u128 s_w[16], s_w2[16];
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-  if (gmax_in && threadIdx.x == 0) sc->gmax = *gmax_in;
+  if (gmax_in && threadIdx.x == 0) { sc->gmax = *gmax_in; sc->ref = *gmax_in; }
+  if (export_max && threadIdx.x < 64) {   // sharded: word 4 = order key of the local max (slot set 0), slots cleared for the next step
+    unsigned long long k = 0ull;
+    if (threadIdx.x < CSSM_MAXSLOTS) {
+      k = sc->maxslot[(size_t)threadIdx.x * CSSM_SLOT_STRIDE];
+      sc->maxslot[(size_t)threadIdx.x * CSSM_SLOT_STRIDE] = 0ull;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) { const unsigned long long o = __shfl_xor(k, off, 64); k = (o > k) ? o : k; }
+    if (threadIdx.x == 0) sums4_out[4] = k;
+  }
   const uint32_t chunk = (ntiles + 1023u) / 1024u;
   const uint32_t t0 = threadIdx.x * chunk;
   const uint32_t t1 = (t0 + chunk < ntiles) ? t0 + chunk : ntiles;
@@ -604,11 +656,15 @@ __global__ __launch_bounds__(CSSM_BLOCK, 3) void k_offspring(const double* __res
                                                           uint32_t* __restrict__ endslot, uint32_t* __restrict__ anc,
                                                           uint32_t ntiles, uint32_t sup, uint32_t nunits, int raw, int slot_set,
                                                           double* __restrict__ ll_t, int32_t* __restrict__ ess_t, uint32_t rec_idx,
-                                                          int force_exact, const unsigned long long* __restrict__ all4, int rank, int world,
-                                                          int resampler_unused, uint64_t seed, double* __restrict__ cum_out,
-                                                          const double* __restrict__ logtab) {
+                                                          int force_exact, const unsigned long long* __restrict__ all5, int rank, int world,
+                                                          int split, uint64_t seed, double* __restrict__ cum_out,
+                                                          const double* __restrict__ logtab, int optimistic,
+                                                          unsigned long long* __restrict__ flag_out) {
+  // unitP holds `split` entries per unit (k_propagate's blocks are sub-units); all5: 5 words per rank
+  // (S.lo, S.hi, S2.lo, S2.hi, order key of the rank's max); optimistic: the sums were formed relative to the
+  // observation's reference level before the max was known -- if the max rules that level out, nothing is
+  // resampled and the host is told to form the sums again (err bit 2 / *flag_out).
   constexpr int resampler = RS;
-  (void)resampler_unused;
   const double* tab = nullptr; (void)logtab;
   __shared__ cssm_u128 s_w[CSSM_BLOCK / 64];
   __shared__ uint32_t s_last[CSSM_BLOCK / 64];
@@ -617,7 +673,37 @@ __global__ __launch_bounds__(CSSM_BLOCK, 3) void k_offspring(const double* __res
   __shared__ cssm_u128 s_r[3][CSSM_BLOCK / 64];
   double pre_v[CSSM_ITEMS];   // the block's first tile is requested before the serial prologue
   if (blockIdx.x < nunits) load_tile_raw(logw, (uint64_t)blockIdx.x * sup * CSSM_TILE, n, raw, pre_v);
-  const double gmax = SELF ? block_decode_slots(sc, slot_set) : sc->gmax;
+  double gmax_dec;
+  if (SELF) {
+    gmax_dec = block_decode_slots(sc, slot_set);
+  } else if (all5) {
+    unsigned long long key = 0ull;
+    for (int r = 0; r < world; ++r) { const unsigned long long k = all5[5 * r + 4]; key = (k > key) ? k : key; }
+    gmax_dec = cssm_order_unkey(key);
+  } else {
+    gmax_dec = sc->gmax;
+  }
+  const double gmax = raw ? gmax_dec : cssm_ref_choose(rec->ref, gmax_dec);   // the level of this step
+  if (!raw && optimistic && !(gmax == rec->ref)) {
+    if (SELF) {
+      if (FUSE && anc) {   // keep the ancestor array addressable for the steps already enqueued behind this one
+        for (uint32_t unit = blockIdx.x; unit < nunits; unit += gridDim.x) {
+          const uint64_t lo = (uint64_t)unit * sup * CSSM_TILE;
+          uint64_t hi = lo + (uint64_t)sup * CSSM_TILE;
+          hi = (hi < n) ? hi : n;
+          for (uint64_t i = lo + threadIdx.x; i < hi; i += CSSM_BLOCK) anc[i] = (uint32_t)i;
+        }
+      }
+      if (blockIdx.x == 0) {
+        if (threadIdx.x == 0) { sc->gmax = gmax_dec; atomicOr(&sc->err, 4u); }
+        if (threadIdx.x < CSSM_MAXSLOTS) sc->maxslot[((size_t)(slot_set ^ 1) * CSSM_MAXSLOTS + threadIdx.x) * CSSM_SLOT_STRIDE] = 0ull;
+      }
+    } else if (blockIdx.x == 0 && threadIdx.x == 0 && flag_out) {
+      *flag_out = 1ull;
+    }
+    return;
+  }
+  if (!SELF && flag_out && blockIdx.x == 0 && threadIdx.x == 0) *flag_out = 0ull;
   const double u = rec->u;
   const bool pow2 = (n_global & (n_global - 1)) == 0;
   const double inv_n = 1.0 / (double)n_global;
@@ -625,16 +711,17 @@ __global__ __launch_bounds__(CSSM_BLOCK, 3) void k_offspring(const double* __res
   double totd = 0.0;
   cssm_u128 S_off = cssm_u128_zero();
   if (!SELF) {
-    if (all4) {   // sharded: every block derives this rank's offset and the global totals from the all-gathered sums
+    if (all5) {   // sharded: every block derives this rank's offset and the global totals from the all-gathered sums
       cssm_u128 tot = cssm_u128_zero(), tot2 = cssm_u128_zero();
       for (int r = 0; r < world; ++r) {
         cssm_u128 a, b;
-        a.lo = all4[4 * r + 0]; a.hi = all4[4 * r + 1]; b.lo = all4[4 * r + 2]; b.hi = all4[4 * r + 3];
+        a.lo = all5[5 * r + 0]; a.hi = all5[5 * r + 1]; b.lo = all5[5 * r + 2]; b.hi = all5[5 * r + 3];
         if (r < rank) S_off = cssm_u128_add(S_off, a);
         tot = cssm_u128_add(tot, a); tot2 = cssm_u128_add(tot2, b);
       }
       totd = cssm_u128_to_double(tot);
       if (blockIdx.x == 0 && threadIdx.x == 0) {
+        sc->gmax = gmax_dec; sc->ref = gmax;
         sc->S_off = S_off; sc->S_tot = tot; sc->S2_tot = tot2;
         finish_step(sc, n_global);
       }
@@ -649,9 +736,10 @@ __global__ __launch_bounds__(CSSM_BLOCK, 3) void k_offspring(const double* __res
     cssm_u128 toff;                                        // cumulative weight before the current tile
     if (SELF) {                                            // here unitP holds the unit SUMS (k_tile_sums output)
       cssm_u128 pre = cssm_u128_zero(), tot = cssm_u128_zero(), tot2 = cssm_u128_zero();
-      for (uint32_t q = threadIdx.x; q < nunits; q += CSSM_BLOCK) {
+      const uint32_t nsub = nunits * (uint32_t)split, qlim = unit * (uint32_t)split;
+      for (uint32_t q = threadIdx.x; q < nsub; q += CSSM_BLOCK) {
         const cssm_u128 v = unitP[q];
-        if (q < unit) pre = cssm_u128_add(pre, v);
+        if (q < qlim) pre = cssm_u128_add(pre, v);
         tot = cssm_u128_add(tot, v);
         if (unit == 0) tot2 = cssm_u128_add(tot2, unitS2[q]);   // only the publishing block needs sum w^2
       }
@@ -667,7 +755,7 @@ __global__ __launch_bounds__(CSSM_BLOCK, 3) void k_offspring(const double* __res
       toff = pre;
       totd = cssm_u128_to_double(tot);
       if (unit == 0 && threadIdx.x == 0) {                 // publish the step's scalars once
-        sc->gmax = gmax; sc->S_off = cssm_u128_zero(); sc->S_local = tot; sc->S2_local = tot2;
+        sc->gmax = gmax_dec; sc->ref = gmax; sc->S_off = cssm_u128_zero(); sc->S_local = tot; sc->S2_local = tot2;
         sc->S_tot = tot; sc->S2_tot = tot2;
         finish_step(sc, n_global);
         if (ll_t) { ll_t[rec_idx] = sc->ll; ess_t[rec_idx] = sc->ess; }
@@ -676,7 +764,7 @@ __global__ __launch_bounds__(CSSM_BLOCK, 3) void k_offspring(const double* __res
         sc->maxslot[((size_t)(slot_set ^ 1) * CSSM_MAXSLOTS + threadIdx.x) * CSSM_SLOT_STRIDE] = 0ull;
       __syncthreads();
     } else {
-      toff = cssm_u128_add(S_off, unitP[unit]);
+      toff = cssm_u128_add(S_off, unitP[(size_t)unit * split]);
     }
     for (uint32_t tile = t0; tile < t1; ++tile) {
       const uint64_t base = (uint64_t)tile * CSSM_TILE;

@@ -59,6 +59,10 @@ struct cssm_pf {
   size_t stride = 0;
   uint32_t ntiles = 0;
   uint32_t sup = 1, nunits = 0;   // tiles per scan unit, number of units (<= ~1K)
+  uint32_t split = 1;             // k_propagate blocks per unit (each owns a contiguous sub-unit and its sums)
+  bool safe_sums = false;         // form the sums in their own pass after the max is known (retry of a step whose
+                                  // reference level was ruled out by the max; always for LGCP)
+  bool last_optimistic = false;   // the last launch_propagate formed the sums itself
   bool sharded = false;
   // device memory
   double* state[2] = {nullptr, nullptr};
@@ -309,6 +313,8 @@ static void build_rec(const cssm_pf* pf, double t_prev, double t, double y, int 
     case CSSM_OBS_BETA: r->c[0] = cssm_log(y); break;          // c0 = log(y)
     default: break;                                            // Bernoulli, LGCP: no constants
   }
+  // reference level of the step's weights (include/cssm_numerics.h); NaN = rescale by the max
+  r->ref = (pf->obs_kind == CSSM_OBS_LGCP) ? cssm_nan() : cssm_ref_level(pf->obs_kind, y, pf->scale_sd, (double)pf->obs_df);
   const cssm_u32x4 bu = cssm_philox_draw(pf->seed, 0, step, CSSM_STREAM_U, 0);
   r->u = cssm_u01(bu.v[0], bu.v[1]);
   const int32_t pr = (int32_t)cssm_philox_draw(pf->seed, 0, step + 1, CSSM_STREAM_PICK, 0).v[0];
@@ -317,6 +323,8 @@ static void build_rec(const cssm_pf* pf, double t_prev, double t, double y, int 
 }
 
 // ------------------------------------------------------------------------------------ create / destroy
+
+static int prop_items(int d) { return d <= 2 ? 4 : (d <= 8 ? CSSM_PROP_IT_MID : 1); }   // PropItems<D>
 
 static int alloc_handle(cssm_pf* pf) {
   HIP_TRY(hipSetDevice(pf->device));
@@ -327,6 +335,11 @@ static int alloc_handle(cssm_pf* pf) {
   pf->ntiles = (uint32_t)((pf->n + CSSM_TILE - 1) / CSSM_TILE);
   pf->sup = (pf->ntiles + 1023u) / 1024u;
   pf->nunits = (pf->ntiles + pf->sup - 1) / pf->sup;
+  {   // k_propagate: a block owns unit/split particles, a multiple of its CSSM_BLOCK * IT particles per iteration
+    const uint32_t per_block = (uint32_t)(CSSM_BLOCK * prop_items(pf->d));
+    pf->split = (per_block >= (uint32_t)CSSM_TILE) ? 1u : 2u;
+  }
+  const size_t nsums = (size_t)(pf->ntiles > 2 * pf->nunits ? pf->ntiles : 2 * pf->nunits);
   const size_t row = pf->stride * 8;
   for (int b = 0; b < 2; ++b) {
     if (hipMalloc(&pf->state[b], row * pf->d) != hipSuccess) return fail(CSSM_ENOMEM, "hipMalloc of %zu bytes failed", row * pf->d);
@@ -335,9 +348,13 @@ static int alloc_handle(cssm_pf* pf) {
   if (hipMalloc(&pf->logw, row) != hipSuccess) return fail(CSSM_ENOMEM, "hipMalloc logw");
   if (hipMalloc(&pf->endslot, pf->stride * 4) != hipSuccess) return fail(CSSM_ENOMEM, "hipMalloc endslot");
   if (hipMalloc(&pf->anc, pf->stride * 4) != hipSuccess) return fail(CSSM_ENOMEM, "hipMalloc anc");
-  HIP_TRY(hipMalloc(&pf->tileS, (size_t)pf->ntiles * sizeof(cssm_u128)));
-  HIP_TRY(hipMalloc(&pf->tileS2, (size_t)pf->ntiles * sizeof(cssm_u128)));
-  HIP_TRY(hipMalloc(&pf->tileP, (size_t)pf->ntiles * sizeof(cssm_u128)));
+  HIP_TRY(hipMalloc(&pf->tileS, nsums * sizeof(cssm_u128)));
+  HIP_TRY(hipMalloc(&pf->tileS2, nsums * sizeof(cssm_u128)));
+  HIP_TRY(hipMalloc(&pf->tileP, nsums * sizeof(cssm_u128)));
+  // sub-unit entries past the last k_propagate block are never written and must read as zero sums
+  HIP_TRY(hipMemsetAsync(pf->tileS, 0, nsums * sizeof(cssm_u128), pf->stream));
+  HIP_TRY(hipMemsetAsync(pf->tileS2, 0, nsums * sizeof(cssm_u128), pf->stream));
+  HIP_TRY(hipMemsetAsync(pf->tileP, 0, nsums * sizeof(cssm_u128), pf->stream));
   HIP_TRY(hipMalloc(&pf->sc, sizeof(Scalars)));
   HIP_TRY(hipMemsetAsync(pf->sc, 0, sizeof(Scalars), pf->stream));
   HIP_TRY(hipMalloc(&pf->d_m0, CSSM_MAX_DIM * 8));
@@ -425,7 +442,6 @@ extern "C" int32_t cssm_pf_dim(const cssm_pf* pf) { return pf ? pf->d : 0; }
   }
 
 static const int kGridCap = 4096;
-static const int kPropGridCap = 2048;   // 8 blocks of 256 threads per CU; the rest is grid-strided
 
 // ll = 0.0, ess = N: PfState(t0, None, state, 0.0, particles), model/ParticleFilter.scala:107
 static int reset_scalars(cssm_pf* pf) {
@@ -451,30 +467,30 @@ static int launch_init(cssm_pf* pf, double t0) {
 }
 
 // propagate + weight of one datum (record already on the device)
-static int prop_items(int d) { return d <= 2 ? 4 : (d <= 8 ? CSSM_PROP_IT_MID : 1); }   // PropItems<D>
 
 static int launch_propagate(cssm_pf* pf, const StepRec* d_rec) {
-  const int grid = grid_for(pf->n, CSSM_BLOCK * prop_items(pf->d), kPropGridCap);
+  // one block per sub-unit: contiguous ranges, so that (with do_sums) the block's fixed-point sums are the
+  // sub-unit sums k_offspring scans
+  const uint64_t chunk = (uint64_t)pf->sup * CSSM_TILE / pf->split;
+  const int grid = (int)((pf->n + chunk - 1) / chunk);
   double* dst = pf->state[pf->cur ^ 1];
   const uint32_t* anc = pf->anc_valid ? pf->anc : nullptr;
+  const int do_sums = (!pf->safe_sums && pf->obs_kind != CSSM_OBS_LGCP && pf->resampler != CSSM_RESAMPLE_MULTINOMIAL) ? 1 : 0;
+  pf->last_optimistic = do_sums != 0;
   prof_begin(pf, CSSM_K_PROPAGATE);
+#define PROP_ARGS pf->src, pf->src_stride, anc, dst, pf->stride, pf->logw, pf->n, pf->first, pf->seed, d_rec, pf->mk, pf->sc, \
+                  pf->sharded ? 0 : pf->wparity, anc ? pf->src2 : nullptr, pf->src2_stride, pf->n_split, pf->d_logtab, chunk, do_sums, \
+                  pf->tileS, pf->tileS2
   if (pf->obs_kind == CSSM_OBS_LGCP) {
-    DISPATCH_D(pf->d, k_propagate<D, true, PropItems<D>::value, -1><<<dim3(grid), dim3(CSSM_BLOCK), 0, pf->stream>>>(
-                          pf->src, pf->src_stride, anc, dst, pf->stride, pf->logw, pf->n, pf->first, pf->seed, d_rec, pf->mk, pf->sc,
-                          pf->sharded ? 0 : pf->wparity, anc ? pf->src2 : nullptr, pf->src2_stride, pf->n_split, pf->d_logtab));
+    DISPATCH_D(pf->d, k_propagate<D, true, PropItems<D>::value, -1><<<dim3(grid), dim3(CSSM_BLOCK), 0, pf->stream>>>(PROP_ARGS));
   } else if (pf->obs_kind == CSSM_OBS_POISSON) {
-    DISPATCH_D(pf->d, k_propagate<D, false, PropItems<D>::value, CSSM_OBS_POISSON><<<dim3(grid), dim3(CSSM_BLOCK), 0, pf->stream>>>(
-                          pf->src, pf->src_stride, anc, dst, pf->stride, pf->logw, pf->n, pf->first, pf->seed, d_rec, pf->mk, pf->sc,
-                          pf->sharded ? 0 : pf->wparity, anc ? pf->src2 : nullptr, pf->src2_stride, pf->n_split, pf->d_logtab));
+    DISPATCH_D(pf->d, k_propagate<D, false, PropItems<D>::value, CSSM_OBS_POISSON><<<dim3(grid), dim3(CSSM_BLOCK), 0, pf->stream>>>(PROP_ARGS));
   } else if (pf->obs_kind == CSSM_OBS_GAUSSIAN) {
-    DISPATCH_D(pf->d, k_propagate<D, false, PropItems<D>::value, CSSM_OBS_GAUSSIAN><<<dim3(grid), dim3(CSSM_BLOCK), 0, pf->stream>>>(
-                          pf->src, pf->src_stride, anc, dst, pf->stride, pf->logw, pf->n, pf->first, pf->seed, d_rec, pf->mk, pf->sc,
-                          pf->sharded ? 0 : pf->wparity, anc ? pf->src2 : nullptr, pf->src2_stride, pf->n_split, pf->d_logtab));
+    DISPATCH_D(pf->d, k_propagate<D, false, PropItems<D>::value, CSSM_OBS_GAUSSIAN><<<dim3(grid), dim3(CSSM_BLOCK), 0, pf->stream>>>(PROP_ARGS));
   } else {
-    DISPATCH_D(pf->d, k_propagate<D, false, PropItems<D>::value, -1><<<dim3(grid), dim3(CSSM_BLOCK), 0, pf->stream>>>(
-                          pf->src, pf->src_stride, anc, dst, pf->stride, pf->logw, pf->n, pf->first, pf->seed, d_rec, pf->mk, pf->sc,
-                          pf->sharded ? 0 : pf->wparity, anc ? pf->src2 : nullptr, pf->src2_stride, pf->n_split, pf->d_logtab));
+    DISPATCH_D(pf->d, k_propagate<D, false, PropItems<D>::value, -1><<<dim3(grid), dim3(CSSM_BLOCK), 0, pf->stream>>>(PROP_ARGS));
   }
+#undef PROP_ARGS
   prof_end(pf);
   HIP_TRY(hipGetLastError());
   pf->cur ^= 1;
@@ -482,32 +498,34 @@ static int launch_propagate(cssm_pf* pf, const StepRec* d_rec) {
   return CSSM_OK;
 }
 
-// weights -> sums -> end slots -> ancestors, single GPU
-static int launch_resample(cssm_pf* pf, const StepRec* d_rec, double* ll_t = nullptr, int32_t* ess_t = nullptr, uint32_t rec_idx = 0) {
+// sums (unless k_propagate formed them) -> end slots -> ancestors, single GPU.  `redo`: second attempt at the step
+// whose reference level the max ruled out -- same max-slot set, sums formed by k_tile_sums with the agreed level.
+static int launch_resample(cssm_pf* pf, const StepRec* d_rec, double* ll_t = nullptr, int32_t* ess_t = nullptr, uint32_t rec_idx = 0,
+                           bool redo = false) {
   if (pf->resampler == CSSM_RESAMPLE_MULTINOMIAL && !pf->cum) {
     if (hipMalloc(&pf->cum, pf->stride * 8) != hipSuccess) return fail(CSSM_ENOMEM, "hipMalloc cumulative weights");
   }
+  if (redo) pf->wparity ^= 1;
+  const bool optimistic = pf->last_optimistic && !redo;
   const int tgrid = (int)pf->nunits;
-  prof_begin(pf, CSSM_K_TILE_SUMS);
-  hipLaunchKernelGGL(k_tile_sums, dim3(tgrid), dim3(CSSM_BLOCK), 0, pf->stream, pf->logw, pf->n, pf->sc, pf->tileS, pf->tileS2, pf->ntiles,
-                     pf->sup, pf->nunits, 0, pf->wparity, (const double*)nullptr, pf->d_logtab);
-  prof_end(pf);
+  const int split = optimistic ? (int)pf->split : 1;
+  if (!optimistic) {
+    prof_begin(pf, CSSM_K_TILE_SUMS);
+    hipLaunchKernelGGL(k_tile_sums, dim3(tgrid), dim3(CSSM_BLOCK), 0, pf->stream, pf->logw, pf->n, pf->sc, pf->tileS, pf->tileS2, pf->ntiles,
+                       pf->sup, pf->nunits, 0, pf->wparity, (const double*)nullptr, pf->d_logtab, d_rec);
+    prof_end(pf);
+  }
   prof_begin(pf, CSSM_K_OFFSPRING);   // unit prefix, ll/ess, end slots and their expansion to ancestors in one kernel
+#define OFF_ARGS pf->logw, pf->n, pf->sc, (const cssm_u128*)pf->tileS, (const cssm_u128*)pf->tileS2, d_rec, pf->n_global, pf->endslot, pf->anc, \
+                 pf->ntiles, pf->sup, pf->nunits, 0, pf->wparity, ll_t, ess_t, rec_idx, pf->opt_exact, (const unsigned long long*)nullptr, 0, 1, \
+                 split, pf->seed, pf->cum, pf->d_logtab, optimistic ? 1 : 0, (unsigned long long*)nullptr
   if (pf->resampler == CSSM_RESAMPLE_STRATIFIED)
-    hipLaunchKernelGGL((k_offspring<true, true, CSSM_RESAMPLE_STRATIFIED>), dim3(tgrid), dim3(CSSM_BLOCK), 0, pf->stream, pf->logw, pf->n, pf->sc,
-                     (const cssm_u128*)pf->tileS, (const cssm_u128*)pf->tileS2, d_rec, pf->n_global, pf->endslot, pf->anc, pf->ntiles,
-                     pf->sup, pf->nunits, 0, pf->wparity, ll_t, ess_t, rec_idx, pf->opt_exact, (const unsigned long long*)nullptr, 0, 1,
-                     pf->resampler, pf->seed, pf->cum, pf->d_logtab);
+    hipLaunchKernelGGL((k_offspring<true, true, CSSM_RESAMPLE_STRATIFIED>), dim3(tgrid), dim3(CSSM_BLOCK), 0, pf->stream, OFF_ARGS);
   else if (pf->resampler == CSSM_RESAMPLE_MULTINOMIAL)
-    hipLaunchKernelGGL((k_offspring<true, true, CSSM_RESAMPLE_MULTINOMIAL>), dim3(tgrid), dim3(CSSM_BLOCK), 0, pf->stream, pf->logw, pf->n, pf->sc,
-                     (const cssm_u128*)pf->tileS, (const cssm_u128*)pf->tileS2, d_rec, pf->n_global, pf->endslot, pf->anc, pf->ntiles,
-                     pf->sup, pf->nunits, 0, pf->wparity, ll_t, ess_t, rec_idx, pf->opt_exact, (const unsigned long long*)nullptr, 0, 1,
-                     pf->resampler, pf->seed, pf->cum, pf->d_logtab);
+    hipLaunchKernelGGL((k_offspring<true, true, CSSM_RESAMPLE_MULTINOMIAL>), dim3(tgrid), dim3(CSSM_BLOCK), 0, pf->stream, OFF_ARGS);
   else
-    hipLaunchKernelGGL((k_offspring<true, true, CSSM_RESAMPLE_SYSTEMATIC>), dim3(tgrid), dim3(CSSM_BLOCK), 0, pf->stream, pf->logw, pf->n, pf->sc,
-                     (const cssm_u128*)pf->tileS, (const cssm_u128*)pf->tileS2, d_rec, pf->n_global, pf->endslot, pf->anc, pf->ntiles,
-                     pf->sup, pf->nunits, 0, pf->wparity, ll_t, ess_t, rec_idx, pf->opt_exact, (const unsigned long long*)nullptr, 0, 1,
-                     pf->resampler, pf->seed, pf->cum, pf->d_logtab);
+    hipLaunchKernelGGL((k_offspring<true, true, CSSM_RESAMPLE_SYSTEMATIC>), dim3(tgrid), dim3(CSSM_BLOCK), 0, pf->stream, OFF_ARGS);
+#undef OFF_ARGS
   if (pf->resampler == CSSM_RESAMPLE_MULTINOMIAL)
     hipLaunchKernelGGL(k_multinomial, dim3(grid_for(pf->n, 256, kGridCap)), dim3(256), 0, pf->stream, pf->cum, pf->n, pf->seed,
                        pf->h_step_for_resample, pf->anc);
@@ -597,6 +615,13 @@ extern "C" int cssm_pf_step(cssm_pf* pf, double t, double obs, int has_obs, doub
   Scalars h;
   HIP_TRY(hipMemcpyAsync(&h, pf->sc, sizeof h, hipMemcpyDeviceToHost, pf->stream));
   HIP_TRY(hipStreamSynchronize(pf->stream));
+  if (h.err == 4u) {   // the max ruled the reference level out: the log-weights are in place, form the sums again
+    HIP_TRY(hipMemsetAsync(&pf->sc->err, 0, sizeof(uint32_t), pf->stream));
+    rc = launch_resample(pf, pf->d_recs, nullptr, nullptr, 0, /*redo=*/true);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(&h, pf->sc, sizeof h, hipMemcpyDeviceToHost, pf->stream));
+    HIP_TRY(hipStreamSynchronize(pf->stream));
+  }
   pf->t = t; pf->step++;
   if (ll_out) *ll_out = h.ll;
   if (ess_out) *ess_out = h.ess;
@@ -605,8 +630,28 @@ extern "C" int cssm_pf_step(cssm_pf* pf, double t, double obs, int has_obs, doub
 
 // ------------------------------------------------------------------------------------ batch API
 
+static int run_filter_once(cssm_pf* pf, const double* t, const double* y, const uint8_t* has, size_t T, double* ll_out,
+                           double* ll_t, int32_t* ess_t, double* path, bool* retry);
+
+// The series is enqueued without a host round trip per step, with the sums formed inside k_propagate relative to
+// each observation's reference level.  If the max of some step rules its level out (err bit 2; an outlying
+// observation), the series is run again with the sums in their own pass: every step then applies the same rule
+// (cssm_ref_choose), so both runs define the same result and only the second one can compute it.
 static int run_filter(cssm_pf* pf, const double* t, const double* y, const uint8_t* has, size_t T, double* ll_out,
                       double* ll_t, int32_t* ess_t, double* path) {
+  bool retry = false;
+  int rc = run_filter_once(pf, t, y, has, T, ll_out, ll_t, ess_t, path, &retry);
+  if (rc == CSSM_OK && retry) {
+    pf->safe_sums = true;
+    rc = run_filter_once(pf, t, y, has, T, ll_out, ll_t, ess_t, path, &retry);
+    pf->safe_sums = false;
+  }
+  return rc;
+}
+
+static int run_filter_once(cssm_pf* pf, const double* t, const double* y, const uint8_t* has, size_t T, double* ll_out,
+                           double* ll_t, int32_t* ess_t, double* path, bool* retry) {
+  *retry = false;
   if (!pf || !t || !y) return fail(CSSM_EINVAL_ARG, "null argument");
   if (T < 1) return fail(CSSM_EINVAL_ARG, "empty data (the reference's minBy throws on an empty Vector)");
   if (pf->sharded) return fail(CSSM_ESTATE, "a sharded handle is driven through the cssm_pf_shard_* stages");
@@ -654,6 +699,7 @@ static int run_filter(cssm_pf* pf, const double* t, const double* y, const uint8
   HIP_TRY(hipEventElapsedTime(&pf->last_ms, pf->ev0, pf->ev1));
   prof_collect(pf);
   pf->t = t[T - 1]; pf->step = (uint32_t)T;
+  if ((h.err & 4u) && !(h.err & 1u) && !pf->safe_sums) { *retry = true; return CSSM_OK; }
   if (ll_out) *ll_out = h.ll;
   return check_device_err(pf, h);
 }
@@ -871,26 +917,29 @@ extern "C" int cssm_pf_interpolate(cssm_pf* pf, const double* t, const double* y
   double tp = t0;
   for (size_t s = 0; s < T; ++s) { build_rec(pf, tp, t[s], y[s], has ? has[s] : 1, (uint32_t)s, &pf->h_recs[s]); tp = t[s]; }
   rc = (hipMemcpyAsync(pf->d_recs, pf->h_recs, T * sizeof(StepRec), hipMemcpyHostToDevice, pf->stream) == hipSuccess) ? CSSM_OK : fail(CSSM_EHIP, "record upload");
-  if (!rc) {
+  Scalars h;
+  for (int attempt = 0; attempt < 2 && !rc; ++attempt) {   // second attempt: see run_filter
+    pf->safe_sums = (attempt == 1);
     pf->state[0] = hx;                                   // X1_0 = the initial cloud
     rc = launch_init(pf, t0);
-  }
-  for (size_t s = 0; s < T && !rc; ++s) {
-    // step s+1 reads X1_s through anc_s (launch_propagate uses pf->anc / pf->anc_valid) and writes X1_{s+1}
-    pf->state[pf->cur ^ 1] = hx + (s + 1) * slab;
-    pf->anc = hanc + s * pf->stride;
-    const int w = pf->h_recs[s].has_obs;
-    pf->h_step_for_resample = (uint32_t)s;
-    rc = launch_propagate(pf, pf->d_recs + s);
-    if (!rc && w) {
-      pf->anc = hanc + (s + 1) * pf->stride;
-      rc = launch_resample(pf, pf->d_recs + s);
-      weighted[s + 1] = 1;
+    for (size_t s = 0; s < T && !rc; ++s) {
+      // step s+1 reads X1_s through anc_s (launch_propagate uses pf->anc / pf->anc_valid) and writes X1_{s+1}
+      pf->state[pf->cur ^ 1] = hx + (s + 1) * slab;
+      pf->anc = hanc + s * pf->stride;
+      const int w = pf->h_recs[s].has_obs;
+      pf->h_step_for_resample = (uint32_t)s;
+      rc = launch_propagate(pf, pf->d_recs + s);
+      if (!rc && w) {
+        pf->anc = hanc + (s + 1) * pf->stride;
+        rc = launch_resample(pf, pf->d_recs + s);
+        weighted[s + 1] = 1;
+      }
     }
+    if (!rc && hipMemcpyAsync(&h, pf->sc, sizeof h, hipMemcpyDeviceToHost, pf->stream) != hipSuccess) rc = fail(CSSM_EHIP, "scalars");
+    if (!rc && hipStreamSynchronize(pf->stream) != hipSuccess) rc = fail(CSSM_EHIP, "forward pass");
+    if (rc || !(h.err & 4u) || (h.err & 1u)) break;
   }
-  Scalars h;
-  if (!rc && hipMemcpyAsync(&h, pf->sc, sizeof h, hipMemcpyDeviceToHost, pf->stream) != hipSuccess) rc = fail(CSSM_EHIP, "scalars");
-  if (!rc && hipStreamSynchronize(pf->stream) != hipSuccess) rc = fail(CSSM_EHIP, "forward pass");
+  pf->safe_sums = false;
   if (!rc) rc = check_device_err(pf, h);
   if (!rc && ll_out) *ll_out = h.ll;
   // backward: compose the genealogy and summarise every time index
@@ -946,12 +995,13 @@ extern "C" int cssm_resample_systematic(const double* w, size_t n, double u, uin
   RS_TRY(hipMemcpyAsync(d_rec, &hrec, sizeof hrec, hipMemcpyHostToDevice, st));
   {
     const int tgrid = (int)nunits;
-    hipLaunchKernelGGL(k_tile_sums, dim3(tgrid), dim3(CSSM_BLOCK), 0, st, d_w, (uint64_t)n, sc, tS, tS2, ntiles, sup, nunits, 1, -1, (const double*)nullptr, d_tab);
+    hipLaunchKernelGGL(k_tile_sums, dim3(tgrid), dim3(CSSM_BLOCK), 0, st, d_w, (uint64_t)n, sc, tS, tS2, ntiles, sup, nunits, 1, -1, (const double*)nullptr, d_tab,
+                       (const StepRec*)d_rec);
     hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(1024), 0, st, tS, tS2, tP, nunits, sc, (uint64_t)n, 1, (double*)nullptr, (int32_t*)nullptr, 0u,
-                       (const double*)nullptr, (unsigned long long*)nullptr);
+                       (const double*)nullptr, (unsigned long long*)nullptr, 0);
     hipLaunchKernelGGL((k_offspring<true, false, CSSM_RESAMPLE_SYSTEMATIC>), dim3(tgrid), dim3(CSSM_BLOCK), 0, st, d_w, (uint64_t)n, sc, (const cssm_u128*)tP,
                        (const cssm_u128*)tS2, d_rec, (uint64_t)n, d_end, d_anc, ntiles, sup, nunits, 1, 0, (double*)nullptr, (int32_t*)nullptr, 0u, 0,
-                       (const unsigned long long*)nullptr, 0, 1, CSSM_RESAMPLE_SYSTEMATIC, (uint64_t)0, (double*)nullptr, d_tab);
+                       (const unsigned long long*)nullptr, 0, 1, 1, (uint64_t)0, (double*)nullptr, d_tab, 0, (unsigned long long*)nullptr);
   }
   RS_TRY(hipGetLastError());
   RS_TRY(hipMemcpyAsync(&hs, sc, sizeof hs, hipMemcpyDeviceToHost, st));
@@ -970,16 +1020,11 @@ done:
 // One process per GPU; the collectives between the stages belong to the caller (RCCL through
 // torch.distributed).  See include/cssm_pf.h for the sequence.
 
-__global__ void k_export_max(Scalars* sc, double* out) {   // <<<1, CSSM_MAXSLOTS>>>; the sharded path uses slot set 0 only
-  __shared__ double s_m;
-  if (threadIdx.x == 0) s_m = decode_slots(sc, 0);
-  __syncthreads();
-  sc->maxslot[threadIdx.x * CSSM_SLOT_STRIDE] = 0ull;
-  if (threadIdx.x == 0) *out = s_m;
-}
-__global__ void k_import_max(Scalars* sc, const double* gm) { sc->gmax = *gm; }
-__global__ void k_export_sums(const Scalars* sc, unsigned long long* out4) {
-  out4[0] = sc->S_local.lo; out4[1] = sc->S_local.hi; out4[2] = sc->S2_local.lo; out4[3] = sc->S2_local.hi;
+// level of the step from the all-gathered order keys (word 4 of every rank's 5 words)
+__global__ void k_import_level(Scalars* sc, const unsigned long long* __restrict__ all5, int world) {
+  unsigned long long key = 0ull;
+  for (int r = 0; r < world; ++r) { const unsigned long long k = all5[5 * r + 4]; key = (k > key) ? k : key; }
+  sc->gmax = cssm_order_unkey(key);
 }
 
 // For every destination rank q (owner of slots [q*n_per, min((q+1)*n_per, N))): the contiguous
@@ -1065,7 +1110,7 @@ extern "C" int cssm_pf_shard_init(cssm_pf* pf, double t0) {
   return launch_init(pf, t0);
 }
 
-extern "C" int cssm_pf_shard_propagate(cssm_pf* pf, double t, double obs, int has_obs, double* local_max_dev) {
+extern "C" int cssm_pf_shard_propagate(cssm_pf* pf, double t, double obs, int has_obs, uint64_t* sums5_dev) {
   int rc = shard_check(pf);
   if (rc) return rc;
   if (!pf->initialised) return fail(CSSM_ESTATE, "shard_propagate before shard_init");
@@ -1078,8 +1123,13 @@ extern "C" int cssm_pf_shard_propagate(cssm_pf* pf, double t, double obs, int ha
   rc = launch_propagate(pf, pf->d_recs + slot);
   if (rc) return rc;
   if (pf->h_recs[slot].has_obs) {
-    if (!local_max_dev) return fail(CSSM_EINVAL_ARG, "local_max_dev is null");
-    hipLaunchKernelGGL(k_export_max, dim3(1), dim3(CSSM_MAXSLOTS), 0, pf->stream, pf->sc, local_max_dev);
+    if (!sums5_dev) return fail(CSSM_EINVAL_ARG, "sums5_dev is null");
+    // prefix of the sub-unit sums k_propagate formed, the rank's totals and the order key of its max -> 5 words
+    const uint32_t nsub = (uint32_t)((pf->n + (uint64_t)pf->sup * CSSM_TILE / pf->split - 1) / ((uint64_t)pf->sup * CSSM_TILE / pf->split));
+    if (!pf->last_optimistic) HIP_TRY(hipMemsetAsync(pf->tileS, 0, (size_t)nsub * sizeof(cssm_u128), pf->stream));   // LGCP: only the max travels
+    if (!pf->last_optimistic) HIP_TRY(hipMemsetAsync(pf->tileS2, 0, (size_t)nsub * sizeof(cssm_u128), pf->stream));
+    hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(1024), 0, pf->stream, pf->tileS, pf->tileS2, pf->tileP, nsub, pf->sc, pf->n_global, 0,
+                       (double*)nullptr, (int32_t*)nullptr, 0u, (const double*)nullptr, (unsigned long long*)sums5_dev, 1);
     HIP_TRY(hipGetLastError());
   }
   pf->t = t;
@@ -1087,34 +1137,41 @@ extern "C" int cssm_pf_shard_propagate(cssm_pf* pf, double t, double obs, int ha
   return CSSM_OK;
 }
 
-extern "C" int cssm_pf_shard_sums(cssm_pf* pf, const double* global_max_dev, uint64_t* sums4_dev) {
+extern "C" int cssm_pf_shard_sums(cssm_pf* pf, const uint64_t* all_sums5_dev, int world, uint64_t* sums5_dev) {
   int rc = shard_check(pf);
   if (rc) return rc;
-  if (!global_max_dev || !sums4_dev) return fail(CSSM_EINVAL_ARG, "null argument");
+  if (!all_sums5_dev || !sums5_dev) return fail(CSSM_EINVAL_ARG, "null argument");
+  if (world < 1 || world > 64) return fail(CSSM_ESHARD, "world %d", world);
+  const size_t slot = (pf->step - 1) % 64;
   const int tgrid = (int)pf->nunits;
+  hipLaunchKernelGGL(k_import_level, dim3(1), dim3(1), 0, pf->stream, pf->sc, (const unsigned long long*)all_sums5_dev, world);
   hipLaunchKernelGGL(k_tile_sums, dim3(tgrid), dim3(CSSM_BLOCK), 0, pf->stream, pf->logw, pf->n, pf->sc, pf->tileS, pf->tileS2, pf->ntiles,
-                     pf->sup, pf->nunits, 0, -1, global_max_dev, pf->d_logtab);
+                     pf->sup, pf->nunits, 0, -1, (const double*)nullptr, pf->d_logtab, (const StepRec*)(pf->d_recs + slot));
+  // word 4 (the max key) of sums5_dev is left as shard_propagate wrote it
   hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(1024), 0, pf->stream, pf->tileS, pf->tileS2, pf->tileP, pf->nunits, pf->sc, pf->n_global, 0,
-                     (double*)nullptr, (int32_t*)nullptr, 0u, global_max_dev, (unsigned long long*)sums4_dev);
+                     (double*)nullptr, (int32_t*)nullptr, 0u, (const double*)nullptr, (unsigned long long*)sums5_dev, 0);
   HIP_TRY(hipGetLastError());
+  pf->last_optimistic = false;
   return CSSM_OK;
 }
 
-extern "C" int cssm_pf_shard_offspring(cssm_pf* pf, const uint64_t* all_sums4_dev, int rank, int world,
-                                       int64_t* send_first_dev, int64_t* send_count_dev) {
+extern "C" int cssm_pf_shard_offspring(cssm_pf* pf, const uint64_t* all_sums5_dev, int rank, int world,
+                                       int64_t* send_first_dev, int64_t* send_count_dev, uint64_t* redo_flag_dev) {
   int rc = shard_check(pf);
   if (rc) return rc;
-  if (!all_sums4_dev || !send_first_dev || !send_count_dev) return fail(CSSM_EINVAL_ARG, "null argument");
+  if (!all_sums5_dev || !send_first_dev || !send_count_dev || !redo_flag_dev) return fail(CSSM_EINVAL_ARG, "null argument");
   if (world < 1 || world > 64 || rank < 0 || rank >= world) return fail(CSSM_ESHARD, "rank %d / world %d", rank, world);
   const uint64_t n_per = (pf->n_global + (uint64_t)world - 1) / (uint64_t)world;
   if (pf->first != (uint64_t)rank * n_per) return fail(CSSM_ESHARD, "rank %d must own particles from %llu (ceil(N/world) per rank), handle starts at %llu",
                                                        rank, (unsigned long long)((uint64_t)rank * n_per), (unsigned long long)pf->first);
   const size_t slot = (pf->step - 1) % 64;   // record of the step propagated last
   const int tgrid = (int)pf->nunits;
+  const int optimistic = pf->last_optimistic ? 1 : 0;
   hipLaunchKernelGGL((k_offspring<false, false, CSSM_RESAMPLE_SYSTEMATIC>), dim3(tgrid), dim3(CSSM_BLOCK), 0, pf->stream, pf->logw, pf->n, pf->sc,
                      (const cssm_u128*)pf->tileP, (const cssm_u128*)pf->tileS2, pf->d_recs + slot, pf->n_global, pf->endslot,
                      (uint32_t*)nullptr, pf->ntiles, pf->sup, pf->nunits, 0, 0, (double*)nullptr, (int32_t*)nullptr, 0u, pf->opt_exact,
-                     (const unsigned long long*)all_sums4_dev, rank, world, CSSM_RESAMPLE_SYSTEMATIC, pf->seed, (double*)nullptr, pf->d_logtab);
+                     (const unsigned long long*)all_sums5_dev, rank, world, optimistic ? (int)pf->split : 1, pf->seed, (double*)nullptr, pf->d_logtab,
+                     optimistic, (unsigned long long*)redo_flag_dev);
   pf->send_first_dev = (const long long*)send_first_dev; pf->send_count_dev = (const long long*)send_count_dev;
   hipLaunchKernelGGL(k_send_ranges, dim3(1), dim3(64), 0, pf->stream, pf->endslot, pf->n, pf->sc, pf->d_recs + slot, pf->n_global, rank, world,
                      n_per, (long long*)send_first_dev, (long long*)send_count_dev);

@@ -3,14 +3,15 @@ contiguous global ranges, collectives over RCCL (``torch.distributed`` backend "
 
 Per observation (stage calls of include/cssm_pf.h):
 
-1. ``shard_propagate``  fused propagate + weight on the local shard, local max log-weight
-2. all-reduce MAX of one double                                   (exact, order independent)
-3. ``shard_sums``       local fixed-point sums of exp(w - gmax): 4 x u64
-4. all-gather of 4 x u64 per rank                                 (integers: no rounding)
-5. ``shard_offspring``  global cumulative weights -> end slot of every local particle, ll, ess,
-   and for each destination rank the contiguous range of local particles owning its slots
-6. all-to-all of the range sizes, then all-to-all-v of (d + 1) doubles per candidate particle
-7. ``shard_adopt``      expand the received candidates to this rank's slots
+1. ``shard_propagate``  fused propagate + weight + local fixed-point sums of exp(w - c), c being the
+   observation's reference level (known without an exchange): 5 x u64 = S, S2, order key of the local max
+2. all-gather of 5 x u64 per rank                                 (integers: no rounding)
+3. ``shard_offspring``  global max -> c usable?  then global cumulative weights -> end slot of every local
+   particle, ll, ess, and for each destination rank the contiguous range of local particles owning its slots
+   (c unusable -- an outlying observation, or LGCP: ``shard_sums`` relative to the max, all-gather and
+   ``shard_offspring`` once more)
+4. all-to-all of the range sizes, then all-to-all-v of (d + 1) doubles per candidate particle
+5. ``shard_adopt``      expand the received candidates to this rank's slots
 
 Random variates are keyed by the GLOBAL particle id and every sum is an integer sum, so ll, ess
 and the ancestor arrays are bit-identical for 1, 2, 4 and 8 ranks.
@@ -60,12 +61,12 @@ class GpuShard:
                                                  device, C.c_void_p(stream), C.byref(self._h)))
         self.d = int(self.lib.cssm_pf_dim(self._h))
         kw = dict(device=self.dev)
-        self.local_max = torch.zeros(1, dtype=torch.float64, **kw)
-        self.sums4 = torch.zeros(4, dtype=torch.int64, **kw)
-        self.all_sums = torch.zeros(4 * world, dtype=torch.int64, **kw)
-        # [send_first | send_count | recv_count], one tensor so that one D2H copy reads all three
-        self.meta = torch.zeros(3 * world, dtype=torch.int64, **kw)
-        self.send_first, self.send_count, self.recv_count = self.meta[:world], self.meta[world:2 * world], self.meta[2 * world:]
+        self.sums5 = torch.zeros(5, dtype=torch.int64, **kw)
+        self.all_sums = torch.zeros(5 * world, dtype=torch.int64, **kw)
+        # [send_first | send_count | recv_count | redo flag], one tensor so that one D2H copy reads all of them
+        self.meta = torch.zeros(3 * world + 1, dtype=torch.int64, **kw)
+        self.send_first, self.send_count = self.meta[:world], self.meta[world:2 * world]
+        self.recv_count, self.redo_flag = self.meta[2 * world:3 * world], self.meta[3 * world:]
         self._bufs = {}
 
     def close(self):
@@ -88,16 +89,17 @@ class GpuShard:
 
     def propagate(self, t, y, has_obs):
         _abi.check(self.lib.cssm_pf_shard_propagate(self._h, float(t), float(y), int(has_obs),
-                                                    C.c_void_p(self.local_max.data_ptr())))
+                                                    C.c_void_p(self.sums5.data_ptr())))
 
     def sums(self):
-        _abi.check(self.lib.cssm_pf_shard_sums(self._h, C.c_void_p(self.local_max.data_ptr()),
-                                               C.c_void_p(self.sums4.data_ptr())))
+        _abi.check(self.lib.cssm_pf_shard_sums(self._h, C.c_void_p(self.all_sums.data_ptr()), self.world,
+                                               C.c_void_p(self.sums5.data_ptr())))
 
     def offspring(self):
         _abi.check(self.lib.cssm_pf_shard_offspring(self._h, C.c_void_p(self.all_sums.data_ptr()), self.rank, self.world,
                                                     C.c_void_p(self.send_first.data_ptr()),
-                                                    C.c_void_p(self.send_count.data_ptr())))
+                                                    C.c_void_p(self.send_count.data_ptr()),
+                                                    C.c_void_p(self.redo_flag.data_ptr())))
 
     def pack(self, first_host: np.ndarray, count_host: np.ndarray, send_buf: torch.Tensor):
         """Rows for every OTHER rank, destinations back to back (the own range never travels)."""
@@ -137,9 +139,6 @@ class DistComm:
         self.world = dist.get_world_size(group)
         self.rank = dist.get_rank(group)
 
-    def all_reduce_max(self, xs: List[torch.Tensor]):
-        self.dist.all_reduce(xs[0], op=self.dist.ReduceOp.MAX, group=self.group)
-
     def all_gather(self, outs: List[torch.Tensor], ins: List[torch.Tensor]):
         self.dist.all_gather_into_tensor(outs[0], ins[0], group=self.group)
 
@@ -160,11 +159,6 @@ class LocalComm:
 
     def __init__(self, world: int):
         self.world, self.rank = world, 0
-
-    def all_reduce_max(self, xs):
-        m = torch.stack([x.reshape(-1)[0] for x in xs]).max()
-        for x in xs:
-            x.fill_(m)
 
     def all_gather(self, outs, ins):
         cat = torch.cat([i.reshape(-1) for i in ins])
@@ -214,19 +208,26 @@ class ShardedFilter:
             s.propagate(t, yv, 1 if has_obs else 0)
         if not (has_obs or lgcp):
             return
-        comm.all_reduce_max([s.local_max for s in S])
-        for s in S:
-            s.sums()
-        comm.all_gather([s.all_sums for s in S], [s.sums4 for s in S])
-        for s in S:
-            s.offspring()
-        comm.all_to_all_counts([s.recv_count for s in S], [s.send_count for s in S])
-        # the one host read of the step: the exchange sizes
         W = comm.world
-        metas = [s.meta.cpu().numpy() for s in S]
+
+        def resample_stage():
+            comm.all_gather([s.all_sums for s in S], [s.sums5 for s in S])
+            for s in S:
+                s.offspring()
+            comm.all_to_all_counts([s.recv_count for s in S], [s.send_count for s in S])
+            return [s.meta.cpu().numpy() for s in S]   # the one host read of the step: exchange sizes + redo flag
+
+        metas = None if lgcp else resample_stage()
+        if metas is None or any(int(m[3 * W]) for m in metas):
+            # the max ruled the reference level out (every rank sees the same gathered words, so all agree): sums again
+            if metas is None:
+                comm.all_gather([s.all_sums for s in S], [s.sums5 for s in S])   # LGCP: only the max keys matter
+            for s in S:
+                s.sums()
+            metas = resample_stage()
         firsts = [m[:W] for m in metas]
         scount = [m[W:2 * W] for m in metas]
-        rcount = [m[2 * W:] for m in metas]
+        rcount = [m[2 * W:3 * W] for m in metas]
         row = d + 1
         # a rank's own range stays in place: it is excluded from the exchange
         sx = [c.copy() for c in scount]

@@ -774,6 +774,50 @@ CSSM_HD double cssm_order_unkey(uint64_t k) {
   return cssm_u2d((k >> 63) ? (k & 0x7fffffffffffffffULL) : ~k);
 }
 
+/* ------------------------------------------------------------------ reference level of a weighted step */
+
+/* The reference's stepFilter rescales the log-weights by their maximum, w1 = exp(w - max)
+ * (model/ParticleFilter.scala:124-125), which on a GPU costs a grid-wide dependency (and on several GPUs a
+ * collective) between the log-densities and their sums.  The contract instead rescales by a level c that is
+ * known BEFORE any particle is weighted: an upper bound of the observation log-density over gamma (its
+ * supremum where that is simple), a function of the observation and the observation parameters alone.  The max
+ * is still found (an integer atomicMax on the side) and decides afterwards whether c was usable:
+ *
+ *     ref = c   if  -CSSM_REF_BELOW <= c - max <= CSSM_REF_ABOVE      (every w1 < 2^9, top weight keeps > 50 bits)
+ *         = max otherwise (outlying observation, LGCP, non-finite c): the sums are then formed again with max.
+ *
+ * ll += ref + log(mean(exp(w - ref))) is the same quantity for either level; only roundings differ.
+ * kinds: the CSSM_OBS_* numbers of cssm_pf.h; p = the observation parameter as the density uses it (Gaussian
+ * sd, Student-t v); df = Student-t degrees of freedom. */
+#define CSSM_REF_BELOW 6.0
+#define CSSM_REF_ABOVE 32.0
+CSSM_HD double cssm_ref_level(int kind, double y, double p, double df) {
+  switch (kind) {
+    case 0: case 3: case 4: {   /* Poisson (sup at lambda = k); NegBin and ZIP (k > 0) are mixtures/multiples of it */
+      const long long k = (long long)y;
+      if (k < 1) return 0.0;
+      const double kd = (double)k;
+      return (kd * cssm_log(kd) - kd) - cssm_lgamma_kp1(k);
+    }
+    case 1: return -cssm_log(2.5066282746310002 * p);                       /* Gaussian at gamma = y */
+    case 5: return 0.0;                                                      /* Bernoulli: log-probabilities */
+    case 6:                                                                  /* Student-t at gamma = y: (1/v) * -logNormalizer */
+      return ((cssm_lgamma((df + 1.0) / 2.0) - cssm_lgamma(df / 2.0)) - 0.5 * cssm_log(3.14159265358979311600 * df)) / p;
+    case 7: {                                                                /* Beta(a, 1): sup over a at a = -1/log y */
+      if (!(y > 0.0 && y < 1.0)) return 0.0;
+      const double L = cssm_log(y);
+      return (-1.0 - L) + cssm_log(-1.0 / L);
+    }
+    default: return cssm_nan();                                              /* LGCP: gamma - hazard is unbounded */
+  }
+}
+/* The level actually used, given the maximum log-weight of the step. */
+CSSM_HD double cssm_ref_choose(double c, double max) {
+  const double gap = c - max;
+  const int ok = (gap >= -CSSM_REF_BELOW) && (gap <= CSSM_REF_ABOVE);       /* false for NaN */
+  return ok ? c : max;
+}
+
 #ifdef __cplusplus
 }
 #endif

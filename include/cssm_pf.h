@@ -247,25 +247,28 @@ int cssm_resample_systematic(const double* w, size_t n, double u, uint32_t* anc,
 /* ---- sharded filter: stage calls between which the caller runs its collectives ------------ */
 /*
  * One observation on R ranks:
- *   cssm_pf_shard_propagate     fused propagate + weight on the local shard; local max
- *   [all-reduce MAX of 1 double]
- *   cssm_pf_shard_sums          local fixed-point sums of exp(w - gmax): 4 x u64 (S, S2)
- *   [all-gather of 4 x u64 per rank]
- *   cssm_pf_shard_offspring     global cumulative weights -> end slot of every local particle;
- *                               also ll, ess; and for every destination rank q the range of
- *                               local particles that own at least one slot of q: counts[R]
- *   [all-gather counts, all-to-all-v of (d+1) doubles per particle]
+ *   cssm_pf_shard_propagate     fused propagate + weight + fixed-point sums of exp(w - c) on the local shard, c being
+ *                               the observation's reference level (cssm_numerics.h: known without any exchange);
+ *                               5 x u64 out: S, S2 (2 words each), order key of the local max log-weight
+ *   [all-gather of 5 x u64 per rank -- the only collective before the resampling exchange]
+ *   cssm_pf_shard_offspring     global max -> was c usable?  If so: global cumulative weights -> end slot of every
+ *                               local particle; ll, ess; for every destination rank q the range of local particles
+ *                               that own at least one slot of q: first[R], count[R]; *redo_flag = 0.
+ *                               If not (outlying observation; always for LGCP): *redo_flag = 1 and the caller runs
+ *   cssm_pf_shard_sums          local sums again, relative to the max taken from the gathered words: 5 x u64
+ *   [all-gather of 5 x u64 per rank]  and cssm_pf_shard_offspring once more
+ *   [all-to-all of count[R], all-to-all-v of (d+1) doubles per particle]
  *   cssm_pf_shard_pack / _adopt pack the send ranges of the OTHER ranks (a rank's own range never
  *                               travels); adopt the rows received from lower (n_low) and higher
  *                               (n_high) ranks around the own range and expand to the N_local slots
  * All device work is enqueued on the stream given at creation; the only host reads are the
- * ones whose pointers are documented as host.
+ * ones whose pointers are documented as host (the caller reads count[R] and the flag in one copy).
  */
 int cssm_pf_shard_init(cssm_pf* pf, double t0);
-int cssm_pf_shard_propagate(cssm_pf* pf, double t, double obs, int has_obs, double* local_max_dev);
-int cssm_pf_shard_sums(cssm_pf* pf, const double* global_max_dev, uint64_t* sums4_dev);
-int cssm_pf_shard_offspring(cssm_pf* pf, const uint64_t* all_sums4_dev, int rank, int world,
-                            int64_t* send_first_dev, int64_t* send_count_dev);
+int cssm_pf_shard_propagate(cssm_pf* pf, double t, double obs, int has_obs, uint64_t* sums5_dev);
+int cssm_pf_shard_sums(cssm_pf* pf, const uint64_t* all_sums5_dev, int world, uint64_t* sums5_dev);
+int cssm_pf_shard_offspring(cssm_pf* pf, const uint64_t* all_sums5_dev, int rank, int world,
+                            int64_t* send_first_dev, int64_t* send_count_dev, uint64_t* redo_flag_dev);
 int cssm_pf_shard_pack(cssm_pf* pf, int world, const int64_t* send_first_host,
                        const int64_t* send_count_host, int skip_rank, double* send_buf_dev);
 int cssm_pf_shard_adopt(cssm_pf* pf, const double* recv_buf_dev, int64_t n_low, int64_t n_high,

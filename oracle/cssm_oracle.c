@@ -71,6 +71,7 @@ typedef struct {
 struct oracle_pf {
   int d, n_leaves, obs_kind, precision, flags, obs_df;
   double scale_sd;       /* exp(scale): Gaussian sd, NegBin size, Student-t v   model/Model.scala:147,171,211,244 */
+  double ref_last, gmax_last; /* rescaling level and max log-weight of the last weighted step */
   double scale_raw;      /* ZIP: the stored scale v                              model/Model.scala:284,300 */
   ocomp comp[CSSM_MAX_DIM];
   uint64_t n, seed;
@@ -468,7 +469,7 @@ int oracle_resample_multinomial(const double* w, uint64_t n, uint64_t seed, uint
 
 /* Tail of stepFilter after the log-weights exist: model/ParticleFilter.scala:124-130
  * (and :218-225 for LGCP, same arithmetic). */
-static int weigh_and_resample(oracle_pf* pf) {
+static int weigh_and_resample(oracle_pf* pf, double y) {
   uint64_t n = pf->n;
   int d = pf->d;
   double max = -INFINITY;
@@ -477,6 +478,14 @@ static int weigh_and_resample(oracle_pf* pf) {
     if (pf->w[i] > max) max = pf->w[i];                         /* w.max */
   }
   if (max == -INFINITY || isinf(max)) return ORACLE_ENONFINITE;
+  /* The contract rescales by the reference level of the observation when the max allows it (cssm_numerics.h,
+   * cssm_ref_level / cssm_ref_choose); ORACLE_LITERAL_SUMS keeps the reference's own w - max. */
+  if (!(pf->flags & ORACLE_LITERAL_SUMS)) {
+    double c = (pf->obs_kind == CSSM_OBS_LGCP) ? cssm_nan() : cssm_ref_level(pf->obs_kind, y, pf->scale_sd, (double)pf->obs_df);
+    pf->gmax_last = max;
+    max = cssm_ref_choose(c, max);
+  }
+  pf->ref_last = max;
   for (uint64_t i = 0; i < n; ++i) pf->w1[i] = o_exp(pf, pf->w[i] - max);   /* :125 */
   const cssm_u32x4 bu = cssm_philox_draw(pf->seed, 0, pf->step, CSSM_STREAM_U, 0);
   double u = cssm_u01(bu.v[0], bu.v[1]);
@@ -522,7 +531,7 @@ static int step_generic(oracle_pf* pf, double t, double y, int has_obs) {
     return ORACLE_OK;
   }
   for (uint64_t i = 0; i < pf->n; ++i) pf->w[i] = logdens(pf, gamma_of(pf, pf->x1 + i * d, t), y);   /* :123 */
-  int rc = weigh_and_resample(pf);
+  int rc = weigh_and_resample(pf, y);
   if (rc) return rc;
   pf->t = t; pf->step++;
   return ORACLE_OK;
@@ -559,7 +568,7 @@ static int step_lgcp(oracle_pf* pf, double t) {
       pf->w[i] = gamma_of(pf, xs, t) - haz;                     /* :200, :217 */
     }
   }
-  int rc = weigh_and_resample(pf);                              /* :218-223 */
+  int rc = weigh_and_resample(pf, 0.0);                         /* :218-223 */
   if (rc) return rc;
   pf->t = t; pf->step++;
   return ORACLE_OK;
@@ -658,6 +667,14 @@ void oracle_pf_get_proposed(const oracle_pf* pf, double* out) {
 void oracle_pf_get_logw(const oracle_pf* pf, double* out) { memcpy(out, pf->w, pf->n * 8); }
 void oracle_pf_get_ancestors(const oracle_pf* pf, uint32_t* out) { memcpy(out, pf->anc, pf->n * 4); }
 void oracle_pf_get_cumw(const oracle_pf* pf, double* out) { memcpy(out, pf->C, pf->n * 8); }
+/* contract pass-throughs for the shard test double */
+double oracle_pf_ref_level(const oracle_pf* pf, double y) {
+  return (pf->obs_kind == CSSM_OBS_LGCP) ? cssm_nan() : cssm_ref_level(pf->obs_kind, y, pf->scale_sd, (double)pf->obs_df);
+}
+double oracle_c_ref_choose(double c, double max) { return cssm_ref_choose(c, max); }
+uint64_t oracle_c_order_key(double x) { return cssm_order_key(x); }
+double oracle_c_order_unkey(uint64_t k) { return cssm_order_unkey(k); }
+void oracle_pf_get_ref(const oracle_pf* pf, double* ref, double* gmax) { *ref = pf->ref_last; *gmax = pf->gmax_last; }
 
 /* ------------------------------------------------------------------ cloud summaries */
 

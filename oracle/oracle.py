@@ -66,6 +66,11 @@ def lib() -> C.CDLL:
             "oracle_pf_get_logw": (None, [vp, _dp]),
             "oracle_pf_get_ancestors": (None, [vp, _u32p]),
             "oracle_pf_get_cumw": (None, [vp, _dp]),
+            "oracle_pf_get_ref": (None, [vp, _dp, _dp]),
+            "oracle_pf_ref_level": (C.c_double, [vp, C.c_double]),
+            "oracle_c_ref_choose": (C.c_double, [C.c_double, C.c_double]),
+            "oracle_c_order_key": (C.c_uint64, [C.c_double]),
+            "oracle_c_order_unkey": (C.c_double, [C.c_uint64]),
             "oracle_pf_summary": (C.c_int, [vp, C.c_double, _dp, _dp, _dp, _dp, _dp, _dp]),
             "oracle_pf_interpolate": (C.c_int, [vp, _dp, _dp, _u8p, C.c_size_t, C.c_double, C.c_int, _dp, _dp, _dp, _dp, _dp, _dp, _dp]),
             "oracle_resample_systematic": (C.c_int, [_dp, C.c_uint64, C.c_double, _u32p, _dp, C.c_int]),
@@ -209,6 +214,15 @@ class OraclePf:
 
     def ancestors(self):
         out = np.zeros(self.n, dtype=np.uint32); lib().oracle_pf_get_ancestors(self._h, _p(out, _u32p)); return out
+
+    def ref_level(self, y):
+        return float(lib().oracle_pf_ref_level(self._h, float(y)))
+
+    def ref(self):
+        """(rescaling level, max log-weight) of the last weighted step."""
+        r, g = np.zeros(1), np.zeros(1)
+        lib().oracle_pf_get_ref(self._h, _p(r), _p(g))
+        return float(r[0]), float(g[0])
 
     def cumw(self):
         out = np.zeros(self.n); lib().oracle_pf_get_cumw(self._h, _p(out)); return out

@@ -43,11 +43,12 @@ class OracleShard:
         self.o.set_shard(self.first, n_global)
         self.d = self.o.d
         self.seed = seed
-        self.local_max = torch.zeros(1, dtype=torch.float64)
-        self.sums4 = torch.zeros(4, dtype=torch.int64)
-        self.all_sums = torch.zeros(4 * world, dtype=torch.int64)
-        self.meta = torch.zeros(3 * world, dtype=torch.int64)
-        self.send_first, self.send_count, self.recv_count = self.meta[:world], self.meta[world:2 * world], self.meta[2 * world:]
+        self.sums5 = torch.zeros(5, dtype=torch.int64)
+        self.all_sums = torch.zeros(5 * world, dtype=torch.int64)
+        self.meta = torch.zeros(3 * world + 1, dtype=torch.int64)
+        self.send_first, self.send_count = self.meta[:world], self.meta[world:2 * world]
+        self.recv_count, self.redo_flag = self.meta[2 * world:3 * world], self.meta[3 * world:]
+        self.redone = 0
         self.ll, self.ess, self.step_idx = 0.0, n_global, 0
 
     def buffer(self, name, n):
@@ -62,7 +63,14 @@ class OracleShard:
         self.x1 = self.o.proposed()
         if has_obs or self.o_is_lgcp():
             self.logw = self.o.logw()
-            self.local_max[0] = float(self.logw.max())
+            self.c = self.o.ref_level(y)                       # known without any exchange
+            self.optimistic = not self.o_is_lgcp()
+            key = int(oracle.lib().oracle_c_order_key(float(self.logw.max())))
+            if self.optimistic:
+                self._local_sums(self.c, clamp=True)
+            else:
+                self.sums5[:4] = 0
+            self.sums5[4] = key - 2**64 if key >= 2**63 else key
         else:
             self.o.set_particles(self.x1)
         self.step_idx += 1
@@ -70,24 +78,41 @@ class OracleShard:
     def o_is_lgcp(self):
         return self.o._d.desc.obs_kind == 2
 
-    def sums(self):
-        self.gmax = float(self.local_max[0])
-        self.w1 = oracle.c_exp(self.logw - self.gmax)
+    def _local_sums(self, level, clamp):
+        a = self.logw - level
+        self.w1 = oracle.c_exp(np.minimum(a, 6.0) if clamp else a)   # k_propagate clamps: beyond c + 6 the step is redone anyway
         self.q = [fix(float(w)) for w in self.w1]
         S = sum(self.q); S2 = sum(fix(float(w * w)) for w in self.w1)
         a, b = _split64(S); c, d = _split64(S2)
-        self.sums4[:] = torch.tensor([a, b, c, d], dtype=torch.int64)
+        self.sums5[:4] = torch.tensor([a, b, c, d], dtype=torch.int64)
+
+    def _global_max(self):
+        v = [int(x) for x in self.all_sums.tolist()]
+        key = max(v[5 * r + 4] & (2**64 - 1) for r in range(self.world))
+        return float(oracle.lib().oracle_c_order_unkey(key))
+
+    def sums(self):
+        """Second attempt: sums relative to the level chosen with the gathered max."""
+        self.optimistic = False
+        self.redone += 1
+        self._local_sums(float(oracle.lib().oracle_c_ref_choose(self.c, self._global_max())), clamp=False)
 
     def offspring(self):
+        gmax = self._global_max()
+        self.level = float(oracle.lib().oracle_c_ref_choose(self.c, gmax))
+        if self.optimistic and not (self.level == self.c):
+            self.redo_flag[0] = 1
+            return
+        self.redo_flag[0] = 0
         v = [int(x) for x in self.all_sums.tolist()]
         S_off = S_tot = S2_tot = 0
         for r in range(self.world):
-            S = _join64(v[4 * r], v[4 * r + 1]); S2 = _join64(v[4 * r + 2], v[4 * r + 3])
+            S = _join64(v[5 * r], v[5 * r + 1]); S2 = _join64(v[5 * r + 2], v[5 * r + 3])
             if r < self.rank:
                 S_off += S
             S_tot += S; S2_tot += S2
         tot = float(S_tot) * 2.0**-96; tot2 = float(S2_tot) * 2.0**-96
-        self.ll = self.ll + self.gmax + float(oracle.c_log(np.array([tot / self.n_global]))[0])
+        self.ll = self.ll + self.level + float(oracle.c_log(np.array([tot / self.n_global]))[0])
         self.ess = int(np.floor(1.0 / (tot2 / (tot * tot))))
         u = oracle.lib().oracle_c_u(self.seed, self.step_idx - 1)
         totd = float(S_tot)

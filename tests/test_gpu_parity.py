@@ -350,3 +350,58 @@ def test_errors_are_reported_not_swallowed():
         g.step(1.0, float("nan"))  # NaN log-weights: breeze's Gaussian/Poisson would throw
     assert e.value.code == -5
     g.close()
+
+
+def _outlier_series(T=10, where=(4,)):
+    t, y, has = cases.poisson_counts(T)
+    y = y.copy()
+    for s in where:
+        y[s] = 60.0            # log p(60 | lambda ~ 2) is ~70 below the Poisson supremum: the reference level is ruled out
+    return t, y, has
+
+
+@pytest.mark.parametrize("n", [1000, 1 << 16])
+def test_outlying_observation_falls_back_to_the_max_streaming(n):
+    """cssm_ref_choose: a step whose max log-weight is > 32 below the observation's reference level is rescaled by
+    the max (second attempt on the device), exactly as the oracle decides."""
+    model = cases.c2_model()
+    t, y, has = _outlier_series()
+    o = oracle.OraclePf(model.descriptor(), n, cases.SEED)
+    o.init(0.0)
+    levels = []
+    for s in range(len(t)):
+        o.step(t[s], y[s], True)
+        levels.append(o.ref())
+    assert levels[4][0] == levels[4][1] and levels[3][0] != levels[3][1]   # max used at the outlier only
+    _compare_streaming(model, n, t, y, has)
+
+
+@pytest.mark.parametrize("name,where", [("c2_model", (4,)), ("c2_model", (0, 9)), ("c3_model", (7,))])
+def test_outlying_observation_batch_rerun_matches_oracle(name, where):
+    model = getattr(cases, name)()
+    n = 5000
+    t, y, has = _outlier_series(10, where)
+    g = NativePf(model, n, cases.SEED)
+    gl, gll, gess, gpath = g.run(t, y, has, want_path=True)
+    o = oracle.OraclePf(model.descriptor(), n, cases.SEED)
+    ol, oll, oess, opath = o.filter(t, y, has, want_path=True)
+    assert gl == ol
+    np.testing.assert_array_equal(gll, oll)
+    np.testing.assert_array_equal(gess, oess)
+    np.testing.assert_array_equal(gpath, opath)
+    np.testing.assert_array_equal(g.particles(), o.particles())
+    # the handle is back in its ordinary mode afterwards
+    t2, y2, has2 = cases.poisson_counts(10)
+    assert g.run(t2, y2, has2)[0] == oracle.OraclePf(model.descriptor(), n, cases.SEED).filter(t2, y2, has2)[0]
+    g.close()
+
+
+def test_outlying_gaussian_observation_and_pmmh_path():
+    model = cases.linear_model()
+    n = 4096
+    t, y, has = cases.gaussian_series(8)
+    y = y.copy(); y[3] = 40.0           # ~80 sd away from every particle
+    g = NativePf(model, n, cases.SEED)
+    o = oracle.OraclePf(model.descriptor(), n, cases.SEED)
+    assert g.run(t, y, has)[0] == o.filter(t, y, has)[0]
+    g.close()

@@ -91,3 +91,21 @@ def test_rccl_world1_matches_oracle():
         shard.close()
     finally:
         dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_local_shards_outlying_observation_second_attempt(world):
+    """The gathered max rules the reference level out at one step: shard_sums + a second all-gather, same bits."""
+    from composablestatespacemodels_amd.sharded import GpuShard, LocalComm, ShardedFilter
+    model = cases.c2_model()
+    n = 5000
+    t, y, has = cases.poisson_counts(8)
+    y = y.copy(); y[3] = 60.0
+    shards = [GpuShard(model, n, r, world, cases.SEED, 0) for r in range(world)]
+    f = ShardedFilter(shards, LocalComm(world))
+    ll, ess = f.ll_filter(t, y, has)
+    oll, oess, opart = _oracle_run(model, n, t, y, has)
+    assert (ll, ess) == (oll, oess[-1])
+    np.testing.assert_array_equal(np.concatenate([s.particles() for s in shards], axis=1), opart)
+    for s in shards:
+        s.close()

@@ -121,3 +121,19 @@ def test_gpu_interpolate_mirror_and_errors():
     with pytest.raises(CssmError):
         l.interpolate(tt, yy, hh)
     l.close()
+
+
+@pytest.mark.gpu
+def test_gpu_interpolate_with_outlying_observation():
+    from composablestatespacemodels_amd.filter import NativePf
+    model = cases.c2_model()
+    n, T = 3000, 12
+    t, y, has = _series("c2_model", T)
+    y = y.copy(); y[1] = 60.0
+    g = NativePf(model, n, cases.SEED)
+    got = g.interpolate(t, y, has)
+    want = oracle.OraclePf(model.descriptor(), n, cases.SEED).interpolate(t, y, has)
+    assert got[0] == want[0]
+    for k in (2, 3, 5, 6):
+        np.testing.assert_array_equal(got[k], want[k])
+    g.close()

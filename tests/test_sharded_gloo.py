@@ -19,6 +19,15 @@ from oracle import oracle
 HERE = os.path.dirname(os.path.abspath(__file__))
 
 
+def _series(C, T, missing, prec):
+    if prec:
+        return C.event_times(T)
+    t, y, has = C.poisson_counts(T, missing=abs(missing))
+    if missing < 0:            # negative `missing`: plant an outlying count, whose reference level the max rules out
+        y = y.copy(); y[T // 2] = 60.0; has = has.copy(); has[T // 2] = 1
+    return t, y, has
+
+
 def _worker(rank, world, port, name, n, T, missing, prec, out_dir):
     sys.path.insert(0, HERE)
     sys.path.insert(0, os.path.dirname(HERE))
@@ -30,14 +39,11 @@ def _worker(rank, world, port, name, n, T, missing, prec, out_dir):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         model = getattr(C, name)()
-        if prec:
-            t, y, has = C.event_times(T)
-        else:
-            t, y, has = C.poisson_counts(T, missing=missing)
+        t, y, has = _series(C, T, missing, prec)
         shard = OracleShard(model, n, rank, world, C.SEED, prec)
         f = ShardedFilter([shard], DistComm())
         ll, ess = f.ll_filter(t, y, has, lgcp=bool(prec))
-        np.savez(os.path.join(out_dir, f"r{rank}.npz"), ll=ll, ess=ess, part=shard.particles())
+        np.savez(os.path.join(out_dir, f"r{rank}.npz"), ll=ll, ess=ess, part=shard.particles(), redone=shard.redone)
     finally:
         dist.destroy_process_group()
 
@@ -46,17 +52,20 @@ def _worker(rank, world, port, name, n, T, missing, prec, out_dir):
     (2, "c2_model", 301, 7, 0.2, 0),
     (3, "c1_model", 200, 6, 0.0, 0),
     (2, "c4_model", 150, 4, 0.0, 2),
+    (2, "c2_model", 256, 6, -0.1, 0),
 ])
 def test_sharded_orchestration_over_gloo_matches_single_rank(tmp_path, world, name, n, T, missing, prec):
     port = 29600 + (os.getpid() % 300) + world
     mp.spawn(_worker, args=(world, port, name, n, T, missing, prec, str(tmp_path)), nprocs=world, join=True)
     model = getattr(cases, name)()
-    t, y, has = cases.event_times(T) if prec else cases.poisson_counts(T, missing=missing)
+    t, y, has = _series(cases, T, missing, prec)
     o = oracle.OraclePf(model.descriptor(prec), n, cases.SEED)
     ll, _, ess_t, _ = o.filter(t, y, has)
     parts = []
     for r in range(world):
         z = np.load(os.path.join(str(tmp_path), f"r{r}.npz"))
+        # the second attempt runs exactly for the steps whose level the max rules out (LGCP: every step)
+        assert int(z["redone"]) == (T if prec else (1 if missing < 0 else 0))
         assert float(z["ll"]) == ll and int(z["ess"]) == int(ess_t[-1])
         parts.append(z["part"])
     np.testing.assert_array_equal(np.concatenate(parts, axis=1), o.particles())
