@@ -63,6 +63,8 @@ def run_single(args):
     n = args.particles
     model, t, y, has = build_workload(max(K, W, 8))
     pf = NativePf(model, n, 20260101, device=0)
+    if args.fused is not None:
+        pf.set_option(3, args.fused)   # CSSM_OPT_FUSED_SUMS (experiment switch; the default is the library's)
     d = pf.d
     torch.cuda.synchronize()
     if W > 0:
@@ -124,21 +126,17 @@ def run_multi(args):
     n_global = args.particles * world
     model, t, y, has = build_workload(max(K, W, 8))
     shard = GpuShard(model, n_global, rank, world, 20260101, local)
-    f = ShardedFilter([shard], DistComm())
-    f.init(0.0)
-    for s in range(W):
-        f.step(float(t[s]), float(y[s]), bool(has[s]))
-    f.init(0.0)
+    f = ShardedFilter([shard], DistComm(device=torch.device("cuda", local)))
+    if W > 0:
+        f.ll_filter(t[:W], y[:W], has[:W])          # warm-up: allocations, RCCL channels, clocks
     dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for s in range(K):
-        f.step(float(t[s]), float(y[s]), bool(has[s]))
+    ll, ess = f.ll_filter(t[:K], y[:K], has[:K])    # the K timed observations: one series, read back once at its end
     torch.cuda.synchronize()
     dist.barrier()
     wall = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device="cuda")
     dist.all_reduce(wall, op=dist.ReduceOp.MAX)
-    ll, ess = f.result()
     if rank == 0:
         w = float(wall.item())
         print(json.dumps({
@@ -147,9 +145,11 @@ def run_multi(args):
             "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": "configs[1] sharded: seasonal-Poisson, OU latent (d=3), "
                                    f"{args.particles} particles per GPU x {world} GPUs = {n_global}, T={K}, global systematic "
-                                   "resampling every observation (all-reduce max, all-gather sums, all-to-all-v particles over RCCL)",
+                                   "resampling every observation (per observation over RCCL: all-gather of 5 words per rank, one equal-split "
+                                   f"all-to-all of boundary particles, capacity {f.last_cap} rows per pair; the first {f.EXACT_STEPS} observations "
+                                   "use the exact all-to-all-v exchange)",
                        "particles_per_gpu": args.particles, "observations": K, "latent_dim": shard.d, "seed": 20260101},
-            "ll": ll, "ess_last": ess}))
+            "exchange": {"capacity_rows": f.last_cap, "attempts": f.last_attempts}, "ll": ll, "ess_last": ess}))
     dist.destroy_process_group()
 
 
@@ -160,6 +160,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--particles", type=int, default=N_PER_GPU, help="particles per GPU")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--fused", type=int, default=None, help="CSSM_OPT_FUSED_SUMS override (single GPU)")
     args = ap.parse_args()
     if args.gpus > 1 or int(os.environ.get("WORLD_SIZE", "1")) > 1:
         run_multi(args)

@@ -659,7 +659,9 @@ __global__ __launch_bounds__(CSSM_BLOCK, 3) void k_offspring(const double* __res
                                                           int force_exact, const unsigned long long* __restrict__ all5, int rank, int world,
                                                           int split, uint64_t seed, double* __restrict__ cum_out,
                                                           const double* __restrict__ logtab, int optimistic,
-                                                          unsigned long long* __restrict__ flag_out) {
+                                                          unsigned long long* __restrict__ flag_out,
+                                                          uint32_t slot_lo, uint32_t slot_hi) {
+  // !SELF && FUSE (sharded, stateless): only the slots [slot_lo, slot_hi) are this rank's; anc is indexed from slot_lo.
   // unitP holds `split` entries per unit (k_propagate's blocks are sub-units); all5: 5 words per rank
   // (S.lo, S.hi, S2.lo, S2.hi, order key of the rank's max); optimistic: the sums were formed relative to the
   // observation's reference level before the max was known -- if the max rules that level out, nothing is
@@ -820,21 +822,23 @@ __global__ __launch_bounds__(CSSM_BLOCK, 3) void k_offspring(const double* __res
         }
       }
       const uint64_t i0 = base + (uint64_t)threadIdx.x * CSSM_ITEMS;
-      if (!FUSE) {
+      constexpr bool CLIP = !SELF;
+      if (!FUSE || (CLIP && all5 != nullptr)) {   // the exchange of the sharded filter needs the end slots themselves
         if (i0 + CSSM_ITEMS <= n) {
           *reinterpret_cast<uint4*>(endslot + i0) = make_uint4(e[0], e[1], e[2], e[3]);
         } else {
 #pragma unroll
           for (int r = 0; r < CSSM_ITEMS; ++r) if (i0 + r < n) endslot[i0 + r] = e[r];
         }
-      } else if (resampler != CSSM_RESAMPLE_MULTINOMIAL) {
+      }
+      if (FUSE && resampler != CSSM_RESAMPLE_MULTINOMIAL) {
         // end slot of the particle before this thread's first one
         if (lane == 63) s_last[wid] = e[CSSM_ITEMS - 1];
         uint32_t prev = __shfl_up(e[CSSM_ITEMS - 1], 1, 64);
         __syncthreads();
         if (lane == 0) {
           if (wid > 0) prev = s_last[wid - 1];
-          else if (tile == 0) prev = 0u;
+          else if (tile == 0 && (SELF || all5 == nullptr || rank == 0)) prev = 0u;   // the globally first particle
           else {   // the same formula on the tile's exclusive prefix
             const double Cp = cssm_u128_to_double(toff) / totd;
             prev = (resampler == CSSM_RESAMPLE_STRATIFIED)
@@ -844,14 +848,21 @@ __global__ __launch_bounds__(CSSM_BLOCK, 3) void k_offspring(const double* __res
         }
 #pragma unroll
         for (int r = 0; r < CSSM_ITEMS; ++r) {
-          const uint32_t b = (r == 0) ? prev : e[r - 1];
-          const uint32_t len = e[r] - b;           // 0 for the padding items of a partial tile
+          uint32_t b = (r == 0) ? prev : e[r - 1];
+          uint32_t ee = e[r];
+          if (CLIP) {                               // keep the part of the run inside this rank's slots
+            b = (b < slot_lo) ? slot_lo : b;
+            ee = (ee > slot_hi) ? slot_hi : ee;
+            ee = (ee < b) ? b : ee;
+            b -= slot_lo; ee -= slot_lo;
+          }
+          const uint32_t len = ee - b;             // 0 for the padding items of a partial tile
           const uint32_t jj = (uint32_t)(i0 + r);
           if (len <= CSSM_RUN_DIRECT) {
-            for (uint32_t s = b; s < e[r]; ++s) anc[s] = jj;
+            for (uint32_t s = b; s < ee; ++s) anc[s] = jj;
           } else {
             const uint32_t h = atomicAdd(&s_nheavy, 1u);
-            s_hb[h] = b; s_he[h] = e[r]; s_hj[h] = jj;
+            s_hb[h] = b; s_he[h] = ee; s_hj[h] = jj;
           }
         }
         __syncthreads();
@@ -873,14 +884,16 @@ __global__ __launch_bounds__(CSSM_BLOCK, 3) void k_offspring(const double* __res
 
 // ------------------------------------------------------------------------------------ expand
 
-// findAllInTreeMap (model/Resampling.scala:36-46) on the receiver of the sharded filter: `cand_end`
-// holds the end slots of m candidate particles in global order, `cand_idx` where each candidate's
-// state lives; this rank's slots are [slot_lo, slot_hi).  Candidate j writes its own run
-// [max(end_{j-1}, slot_lo), min(end_j, slot_hi)) <- cand_idx[j]; runs longer than CSSM_RUN_DIRECT are
-// written by the whole block.  The first candidate's run starts at or before slot_lo by construction.
-__global__ __launch_bounds__(CSSM_BLOCK) void k_expand(const uint32_t* __restrict__ cand_end, const uint32_t* __restrict__ cand_idx,
-                                                       uint64_t m, uint64_t slot_lo, uint64_t slot_hi,
-                                                       uint32_t* __restrict__ anc) {
+// findAllInTreeMap (model/Resampling.scala:36-46) on the receiver of the sharded filter, for the slots of this rank
+// [slot_lo, slot_hi) that belong to OTHER ranks' particles (the own particles wrote their runs in k_offspring).
+// `cand_end` holds the end slots of the m received candidates in global particle order -- n_low from lower ranks,
+// then those from higher ranks -- and `cand_idx` where each candidate's state lives.  Candidate j writes its run
+// [max(start_j, slot_lo), min(end_j, slot_hi)) <- cand_idx[j], start_j = end_{j-1}; the first candidate from below
+// starts at or before slot_lo by construction, the first one from above at the own last end slot.  Runs longer
+// than CSSM_RUN_DIRECT are written by the whole block.
+__device__ __forceinline__ void expand_body(const uint32_t* __restrict__ cand_end, const uint32_t* __restrict__ cand_idx,
+                                            uint64_t m, uint64_t n_low, uint64_t slot_lo, uint64_t slot_hi,
+                                            uint32_t* __restrict__ anc, const uint32_t* __restrict__ own_last_end) {
   __shared__ uint32_t s_nheavy;
   __shared__ uint32_t s_hb[CSSM_BLOCK], s_he[CSSM_BLOCK], s_hj[CSSM_BLOCK];
   for (uint64_t base = (uint64_t)blockIdx.x * CSSM_BLOCK; base < m; base += (uint64_t)gridDim.x * CSSM_BLOCK) {
@@ -888,7 +901,7 @@ __global__ __launch_bounds__(CSSM_BLOCK) void k_expand(const uint32_t* __restric
     __syncthreads();
     const uint64_t j = base + threadIdx.x;
     if (j < m) {
-      uint64_t b = (j == 0) ? slot_lo : (uint64_t)cand_end[j - 1];
+      uint64_t b = (j == n_low) ? (uint64_t)*own_last_end : ((j == 0) ? slot_lo : (uint64_t)cand_end[j - 1]);
       uint64_t e = cand_end[j];
       if (b < slot_lo) b = slot_lo;
       if (e > slot_hi) e = slot_hi;
@@ -910,6 +923,17 @@ __global__ __launch_bounds__(CSSM_BLOCK) void k_expand(const uint32_t* __restric
     }
     __syncthreads();
   }
+}
+__global__ __launch_bounds__(CSSM_BLOCK) void k_expand(const uint32_t* __restrict__ cand_end, const uint32_t* __restrict__ cand_idx,
+                                                       uint64_t m, uint64_t n_low, uint64_t slot_lo, uint64_t slot_hi,
+                                                       uint32_t* __restrict__ anc, const uint32_t* __restrict__ own_last_end) {
+  expand_body(cand_end, cand_idx, m, n_low, slot_lo, slot_hi, anc, own_last_end);
+}
+// counts on the device (fixed-capacity exchange: the host never learns them): nlh = {n_low, n_high}
+__global__ __launch_bounds__(CSSM_BLOCK) void k_expand_dev(const uint32_t* __restrict__ cand_end, const uint32_t* __restrict__ cand_idx,
+                                                           const long long* __restrict__ nlh, uint64_t slot_lo, uint64_t slot_hi,
+                                                           uint32_t* __restrict__ anc, const uint32_t* __restrict__ own_last_end) {
+  expand_body(cand_end, cand_idx, (uint64_t)(nlh[0] + nlh[1]), (uint64_t)nlh[0], slot_lo, slot_hi, anc, own_last_end);
 }
 
 // Resampling.multinomialResampling (model/Resampling.scala:92-96): slot i draws its own uniform and takes the

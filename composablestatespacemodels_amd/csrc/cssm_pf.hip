@@ -78,6 +78,7 @@ struct cssm_pf {
   bool anc_valid = false;
   int wparity = 0;             // max-slot set of the next weighted step (single-GPU path)
   int opt_exact = 0;           // CSSM_OPT_EXACT_OFFSPRING
+  int opt_fused = 0;           // CSSM_OPT_FUSED_SUMS (set to 1 for sharded handles at creation)
   int resampler = CSSM_RESAMPLE_SYSTEMATIC;
   double* cum = nullptr;       // multinomial: cumulative normalised weights
   const long long *send_first_dev = nullptr, *send_count_dev = nullptr;   // last shard_offspring outputs (device)
@@ -96,6 +97,11 @@ struct cssm_pf {
   uint32_t *cand_end = nullptr, *cand_idx = nullptr;   // end slot / state index of every candidate, global order
   size_t cidx_cap = 0;
   int64_t* d_bounds = nullptr;
+  // fixed-capacity (host-read-free) exchange
+  int64_t* d_xch = nullptr;    // [0..63] send first, [64..127] send count, [128] redo flag of the step, [129..130] n_low, n_high
+  uint32_t* d_need = nullptr;  // per step: the largest send count of this rank (how much capacity the step needed)
+  size_t need_cap = 0;
+  bool series = false;         // records of a whole series are resident (cssm_pf_shard_begin)
   // host staging (pinned)
   StepRec* h_recs = nullptr;
   size_t h_recs_cap = 0;
@@ -360,6 +366,9 @@ static int alloc_handle(cssm_pf* pf) {
   HIP_TRY(hipMalloc(&pf->d_m0, CSSM_MAX_DIM * 8));
   HIP_TRY(hipMalloc(&pf->d_sd0, CSSM_MAX_DIM * 8));
   HIP_TRY(hipMalloc(&pf->d_bounds, 64 * 8));
+  HIP_TRY(hipMalloc(&pf->d_xch, 136 * 8));
+  HIP_TRY(hipMemsetAsync(pf->d_xch, 0, 136 * 8, pf->stream));
+  HIP_TRY(hipMemsetAsync(pf->anc, 0, pf->stride * 4, pf->stream));   // always addressable, also before the first resampling
   HIP_TRY(hipMalloc(&pf->d_logtab, sizeof(CSSM_TAB)));
   HIP_TRY(hipMemcpyAsync(pf->d_logtab, CSSM_TAB, sizeof(CSSM_TAB), hipMemcpyHostToDevice, pf->stream));
   return upload_init_params(pf);
@@ -378,7 +387,7 @@ static int create_common(const cssm_model_desc* desc, uint64_t n_global, uint64_
   cssm_pf* pf = new cssm_pf();
   pf->device = device;
   pf->n_global = n_global; pf->first = first; pf->n = n_local; pf->seed = seed; pf->sharded = sharded;
-  if (sharded) { pf->stream = (hipStream_t)stream; pf->own_stream = false; }  // a null handle is the legacy default stream (torch's default)
+  if (sharded) { pf->stream = (hipStream_t)stream; pf->own_stream = false; pf->opt_fused = 1; }  // a null handle is the legacy default stream (torch's default)
   int rc = build_model(pf, desc);
   if (rc == CSSM_OK) rc = alloc_handle(pf);
   if (rc != CSSM_OK) { std::string keep = g_err; cssm_pf_destroy(pf); g_err = keep; return rc; }
@@ -400,7 +409,7 @@ extern "C" void cssm_pf_destroy(cssm_pf* pf) {
   (void)hipSetDevice(pf->device);
   if (pf->stream) (void)hipStreamSynchronize(pf->stream);
   void* ptrs[] = {pf->state[0], pf->state[1], pf->logw, pf->endslot, pf->anc, pf->tileS, pf->tileS2, pf->tileP, pf->sc,
-                  pf->d_m0, pf->d_sd0, pf->d_logtab, pf->cum, pf->d_recs, pf->d_ll_t, pf->d_ess_t, pf->d_path, pf->cand, pf->cand_end, pf->cand_idx, pf->d_bounds};
+                  pf->d_m0, pf->d_sd0, pf->d_logtab, pf->cum, pf->d_recs, pf->d_ll_t, pf->d_ess_t, pf->d_path, pf->cand, pf->cand_end, pf->cand_idx, pf->d_bounds, pf->d_xch, pf->d_need};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   if (pf->h_recs) (void)hipHostFree(pf->h_recs);
   for (hipEvent_t e : pf->prof_ev) (void)hipEventDestroy(e);
@@ -475,7 +484,7 @@ static int launch_propagate(cssm_pf* pf, const StepRec* d_rec) {
   const int grid = (int)((pf->n + chunk - 1) / chunk);
   double* dst = pf->state[pf->cur ^ 1];
   const uint32_t* anc = pf->anc_valid ? pf->anc : nullptr;
-  const int do_sums = (!pf->safe_sums && pf->obs_kind != CSSM_OBS_LGCP && pf->resampler != CSSM_RESAMPLE_MULTINOMIAL) ? 1 : 0;
+  const int do_sums = (pf->opt_fused && !pf->safe_sums && pf->obs_kind != CSSM_OBS_LGCP && pf->resampler != CSSM_RESAMPLE_MULTINOMIAL) ? 1 : 0;
   pf->last_optimistic = do_sums != 0;
   prof_begin(pf, CSSM_K_PROPAGATE);
 #define PROP_ARGS pf->src, pf->src_stride, anc, dst, pf->stride, pf->logw, pf->n, pf->first, pf->seed, d_rec, pf->mk, pf->sc, \
@@ -518,7 +527,7 @@ static int launch_resample(cssm_pf* pf, const StepRec* d_rec, double* ll_t = nul
   prof_begin(pf, CSSM_K_OFFSPRING);   // unit prefix, ll/ess, end slots and their expansion to ancestors in one kernel
 #define OFF_ARGS pf->logw, pf->n, pf->sc, (const cssm_u128*)pf->tileS, (const cssm_u128*)pf->tileS2, d_rec, pf->n_global, pf->endslot, pf->anc, \
                  pf->ntiles, pf->sup, pf->nunits, 0, pf->wparity, ll_t, ess_t, rec_idx, pf->opt_exact, (const unsigned long long*)nullptr, 0, 1, \
-                 split, pf->seed, pf->cum, pf->d_logtab, optimistic ? 1 : 0, (unsigned long long*)nullptr
+                 split, pf->seed, pf->cum, pf->d_logtab, optimistic ? 1 : 0, (unsigned long long*)nullptr, 0u, (uint32_t)pf->n_global
   if (pf->resampler == CSSM_RESAMPLE_STRATIFIED)
     hipLaunchKernelGGL((k_offspring<true, true, CSSM_RESAMPLE_STRATIFIED>), dim3(tgrid), dim3(CSSM_BLOCK), 0, pf->stream, OFF_ARGS);
   else if (pf->resampler == CSSM_RESAMPLE_MULTINOMIAL)
@@ -724,6 +733,7 @@ extern "C" int cssm_pf_last_loop_ms(cssm_pf* pf, float* ms_out) {
 extern "C" int cssm_pf_set_option(cssm_pf* pf, int option, int value) {
   if (!pf) return fail(CSSM_EINVAL_ARG, "null handle");
   if (option == CSSM_OPT_EXACT_OFFSPRING) { pf->opt_exact = value ? 1 : 0; return CSSM_OK; }
+  if (option == CSSM_OPT_FUSED_SUMS) { pf->opt_fused = value ? 1 : 0; return CSSM_OK; }
   if (option == CSSM_OPT_RESAMPLER) {
     if (value < CSSM_RESAMPLE_SYSTEMATIC || value > CSSM_RESAMPLE_MULTINOMIAL) return fail(CSSM_EINVAL_ARG, "unknown resampler %d", value);
     if (pf->sharded && value != CSSM_RESAMPLE_SYSTEMATIC) return fail(CSSM_ESTATE, "sharded handles resample systematically");
@@ -1001,7 +1011,8 @@ extern "C" int cssm_resample_systematic(const double* w, size_t n, double u, uin
                        (const double*)nullptr, (unsigned long long*)nullptr, 0);
     hipLaunchKernelGGL((k_offspring<true, false, CSSM_RESAMPLE_SYSTEMATIC>), dim3(tgrid), dim3(CSSM_BLOCK), 0, st, d_w, (uint64_t)n, sc, (const cssm_u128*)tP,
                        (const cssm_u128*)tS2, d_rec, (uint64_t)n, d_end, d_anc, ntiles, sup, nunits, 1, 0, (double*)nullptr, (int32_t*)nullptr, 0u, 0,
-                       (const unsigned long long*)nullptr, 0, 1, 1, (uint64_t)0, (double*)nullptr, d_tab, 0, (unsigned long long*)nullptr);
+                       (const unsigned long long*)nullptr, 0, 1, 1, (uint64_t)0, (double*)nullptr, d_tab, 0, (unsigned long long*)nullptr,
+                       0u, (uint32_t)n);
   }
   RS_TRY(hipGetLastError());
   RS_TRY(hipMemcpyAsync(&hs, sc, sizeof hs, hipMemcpyDeviceToHost, st));
@@ -1073,29 +1084,22 @@ __global__ void k_pack(const double* __restrict__ src, size_t stride, const uint
     row[d] = (double)endslot[j];
   }
 }
-// Received rows (d+1 doubles: state, end slot) of the ranks below (first n_low rows) and above this one:
-// states go to the SoA candidate buffer, end slots and state indices to their global-order positions
-// around the rank's own range.
-__global__ void k_adopt_remote(const double* __restrict__ recv, long long n_low, long long n_high, long long self_count, int d,
+// Received rows (d+1 doubles: state, end slot) of the ranks below (first n_low rows) and above this one, in global
+// particle order: states go to the SoA candidate buffer, end slots and state indices to the candidate lists.
+__global__ void k_adopt_remote(const double* __restrict__ recv, long long m, int d,
                                uint32_t n_split, double* __restrict__ cand, size_t cstride,
                                uint32_t* __restrict__ cand_end, uint32_t* __restrict__ cand_idx) {
-  const long long m = n_low + n_high;
   for (long long r = (long long)blockIdx.x * blockDim.x + threadIdx.x; r < m; r += (long long)gridDim.x * blockDim.x) {
     const double* row = recv + r * (d + 1);
     for (int k = 0; k < d; ++k) cand[(size_t)k * cstride + (size_t)r] = row[k];
-    const long long p = (r < n_low) ? r : r + self_count;
-    cand_end[p] = (uint32_t)row[d];
-    cand_idx[p] = n_split + (uint32_t)r;
+    cand_end[r] = (uint32_t)row[d];
+    cand_idx[r] = n_split + (uint32_t)r;
   }
 }
-// The rank's own candidates stay where they are: only their end slots / indices are listed.
-__global__ void k_adopt_self(const uint32_t* __restrict__ endslot, long long self_first, long long self_count, long long n_low,
-                             uint32_t* __restrict__ cand_end, uint32_t* __restrict__ cand_idx) {
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < self_count; i += (long long)gridDim.x * blockDim.x) {
-    cand_end[n_low + i] = endslot[self_first + i];
-    cand_idx[n_low + i] = (uint32_t)(self_first + i);
-  }
-}
+
+static int shard_prepare_step(cssm_pf* pf, const StepRec* d_rec, int weighted, uint64_t* sums5_dev);
+// record of the step propagated last: a ring of 64 for streaming steps, the whole series after shard_begin
+static size_t last_rec_slot(const cssm_pf* pf) { return pf->series ? (size_t)(pf->step - 1) : (size_t)((pf->step - 1) % 64); }
 
 static int shard_check(cssm_pf* pf) {
   if (!pf) return fail(CSSM_EINVAL_ARG, "null handle");
@@ -1107,6 +1111,7 @@ static int shard_check(cssm_pf* pf) {
 extern "C" int cssm_pf_shard_init(cssm_pf* pf, double t0) {
   int rc = shard_check(pf);
   if (rc) return rc;
+  pf->series = false;
   return launch_init(pf, t0);
 }
 
@@ -1120,18 +1125,9 @@ extern "C" int cssm_pf_shard_propagate(cssm_pf* pf, double t, double obs, int ha
   const size_t slot = pf->step % 64;
   build_rec(pf, pf->t, t, obs, has_obs, pf->step, &pf->h_recs[slot]);
   HIP_TRY(hipMemcpyAsync(pf->d_recs + slot, pf->h_recs + slot, sizeof(StepRec), hipMemcpyHostToDevice, pf->stream));
-  rc = launch_propagate(pf, pf->d_recs + slot);
+  if (pf->series) return fail(CSSM_ESTATE, "a series begun with shard_begin is stepped with shard_propagate_at");
+  rc = shard_prepare_step(pf, pf->d_recs + slot, pf->h_recs[slot].has_obs, sums5_dev);
   if (rc) return rc;
-  if (pf->h_recs[slot].has_obs) {
-    if (!sums5_dev) return fail(CSSM_EINVAL_ARG, "sums5_dev is null");
-    // prefix of the sub-unit sums k_propagate formed, the rank's totals and the order key of its max -> 5 words
-    const uint32_t nsub = (uint32_t)((pf->n + (uint64_t)pf->sup * CSSM_TILE / pf->split - 1) / ((uint64_t)pf->sup * CSSM_TILE / pf->split));
-    if (!pf->last_optimistic) HIP_TRY(hipMemsetAsync(pf->tileS, 0, (size_t)nsub * sizeof(cssm_u128), pf->stream));   // LGCP: only the max travels
-    if (!pf->last_optimistic) HIP_TRY(hipMemsetAsync(pf->tileS2, 0, (size_t)nsub * sizeof(cssm_u128), pf->stream));
-    hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(1024), 0, pf->stream, pf->tileS, pf->tileS2, pf->tileP, nsub, pf->sc, pf->n_global, 0,
-                       (double*)nullptr, (int32_t*)nullptr, 0u, (const double*)nullptr, (unsigned long long*)sums5_dev, 1);
-    HIP_TRY(hipGetLastError());
-  }
   pf->t = t;
   pf->step++;
   return CSSM_OK;
@@ -1142,7 +1138,7 @@ extern "C" int cssm_pf_shard_sums(cssm_pf* pf, const uint64_t* all_sums5_dev, in
   if (rc) return rc;
   if (!all_sums5_dev || !sums5_dev) return fail(CSSM_EINVAL_ARG, "null argument");
   if (world < 1 || world > 64) return fail(CSSM_ESHARD, "world %d", world);
-  const size_t slot = (pf->step - 1) % 64;
+  const size_t slot = last_rec_slot(pf);
   const int tgrid = (int)pf->nunits;
   hipLaunchKernelGGL(k_import_level, dim3(1), dim3(1), 0, pf->stream, pf->sc, (const unsigned long long*)all_sums5_dev, world);
   hipLaunchKernelGGL(k_tile_sums, dim3(tgrid), dim3(CSSM_BLOCK), 0, pf->stream, pf->logw, pf->n, pf->sc, pf->tileS, pf->tileS2, pf->ntiles,
@@ -1164,19 +1160,207 @@ extern "C" int cssm_pf_shard_offspring(cssm_pf* pf, const uint64_t* all_sums5_de
   const uint64_t n_per = (pf->n_global + (uint64_t)world - 1) / (uint64_t)world;
   if (pf->first != (uint64_t)rank * n_per) return fail(CSSM_ESHARD, "rank %d must own particles from %llu (ceil(N/world) per rank), handle starts at %llu",
                                                        rank, (unsigned long long)((uint64_t)rank * n_per), (unsigned long long)pf->first);
-  const size_t slot = (pf->step - 1) % 64;   // record of the step propagated last
+  const size_t slot = last_rec_slot(pf);
   const int tgrid = (int)pf->nunits;
   const int optimistic = pf->last_optimistic ? 1 : 0;
-  hipLaunchKernelGGL((k_offspring<false, false, CSSM_RESAMPLE_SYSTEMATIC>), dim3(tgrid), dim3(CSSM_BLOCK), 0, pf->stream, pf->logw, pf->n, pf->sc,
+  // the rank's own particles write their runs inside the rank's slots straight into anc (indexed from the first
+  // own slot); the end slots are kept for the send ranges; slots owned by other ranks' particles are filled by adopt
+  hipLaunchKernelGGL((k_offspring<true, false, CSSM_RESAMPLE_SYSTEMATIC>), dim3(tgrid), dim3(CSSM_BLOCK), 0, pf->stream, pf->logw, pf->n, pf->sc,
                      (const cssm_u128*)pf->tileP, (const cssm_u128*)pf->tileS2, pf->d_recs + slot, pf->n_global, pf->endslot,
-                     (uint32_t*)nullptr, pf->ntiles, pf->sup, pf->nunits, 0, 0, (double*)nullptr, (int32_t*)nullptr, 0u, pf->opt_exact,
+                     pf->anc, pf->ntiles, pf->sup, pf->nunits, 0, 0, (double*)nullptr, (int32_t*)nullptr, 0u, pf->opt_exact,
                      (const unsigned long long*)all_sums5_dev, rank, world, optimistic ? (int)pf->split : 1, pf->seed, (double*)nullptr, pf->d_logtab,
-                     optimistic, (unsigned long long*)redo_flag_dev);
+                     optimistic, (unsigned long long*)redo_flag_dev, (uint32_t)pf->first, (uint32_t)(pf->first + pf->n));
   pf->send_first_dev = (const long long*)send_first_dev; pf->send_count_dev = (const long long*)send_count_dev;
   hipLaunchKernelGGL(k_send_ranges, dim3(1), dim3(64), 0, pf->stream, pf->endslot, pf->n, pf->sc, pf->d_recs + slot, pf->n_global, rank, world,
                      n_per, (long long*)send_first_dev, (long long*)send_count_dev);
   HIP_TRY(hipGetLastError());
   return CSSM_OK;
+}
+
+// ---- fixed-capacity exchange: no host read between the kernels of a step ------------------------------------
+// Send buffer: one segment per destination rank, (cap + 1) rows of (d + 1) doubles; row 0 is a header whose first
+// double is the number of candidate rows that follow (0 for the rank itself: the own range never travels), rows
+// 1..count are (state, end slot).  An all-to-all with EQUAL splits moves segment q of every rank to rank q, so the
+// receiver learns the counts from the headers and the host never does.  count > cap sets the sticky err bit 3 (the
+// caller repeats the series with a larger cap or with the exact, host-read exchange).
+__global__ void k_pack_fixed(const double* __restrict__ src, size_t stride, const uint32_t* __restrict__ endslot, int d, int world, int rank,
+                             const long long* __restrict__ first, const long long* __restrict__ count, long long cap,
+                             double* __restrict__ out, Scalars* __restrict__ sc, const long long* __restrict__ redo_flag,
+                             uint32_t* __restrict__ need_out) {
+  const long long seg = cap + 1, total = (long long)world * seg;
+  for (long long row = (long long)blockIdx.x * blockDim.x + threadIdx.x; row < total; row += (long long)gridDim.x * blockDim.x) {
+    const int q = (int)(row / seg);
+    const long long i = row - (long long)q * seg;
+    const long long c = (q == rank) ? 0 : count[q];
+    double* o = out + row * (d + 1);
+    if (i == 0) {
+      o[0] = (double)c;
+      if (c > cap) atomicOr(&sc->err, 8u);
+    } else if (i - 1 < c && i - 1 < cap) {
+      const long long j = first[q] + (i - 1);
+      for (int k = 0; k < d; ++k) o[k] = src[(size_t)k * stride + (size_t)j];
+      o[d] = (double)endslot[j];
+    }
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    if (*redo_flag) atomicOr(&sc->err, 4u);   // the max ruled the reference level out: this series needs the exact path
+    long long mx = 0;
+    for (int q = 0; q < world; ++q) if (q != rank && count[q] > mx) mx = count[q];
+    if (need_out) *need_out = (uint32_t)mx;
+  }
+}
+// Receive buffer: segment r came from rank r.  Candidates in global particle order = segments in rank order.
+__global__ __launch_bounds__(CSSM_BLOCK) void k_adopt_fixed(const double* __restrict__ recv, int world, int rank, long long cap, int d,
+                                                            uint32_t n_split, double* __restrict__ cand, size_t cstride,
+                                                            uint32_t* __restrict__ cand_end, uint32_t* __restrict__ cand_idx,
+                                                            long long* __restrict__ nlh, Scalars* __restrict__ sc) {
+  __shared__ long long s_cnt[64], s_off[64];
+  const long long seg = cap + 1;
+  if (threadIdx.x < 64) {
+    long long c = 0;
+    if ((int)threadIdx.x < world && (int)threadIdx.x != rank) {
+      c = (long long)recv[(size_t)threadIdx.x * seg * (d + 1)];
+      if (c > cap && blockIdx.x == 0) atomicOr(&sc->err, 8u);   // the sender had more than fits (it raised the bit too)
+      c = (c < 0) ? 0 : ((c > cap) ? cap : c);
+    }
+    s_cnt[threadIdx.x] = c;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    long long off = 0, lo = 0;
+    for (int r = 0; r < world; ++r) { s_off[r] = off; off += s_cnt[r]; if (r < rank) lo += s_cnt[r]; }
+    if (blockIdx.x == 0) { nlh[0] = lo; nlh[1] = off - lo; }
+  }
+  __syncthreads();
+  const long long total = (long long)world * seg;
+  for (long long row = (long long)blockIdx.x * CSSM_BLOCK + threadIdx.x; row < total; row += (long long)gridDim.x * CSSM_BLOCK) {
+    const int r = (int)(row / seg);
+    const long long i = row - (long long)r * seg;
+    if (i == 0 || i - 1 >= s_cnt[r]) continue;
+    const long long p = s_off[r] + (i - 1);
+    const double* src = recv + row * (d + 1);
+    for (int k = 0; k < d; ++k) cand[(size_t)k * cstride + (size_t)p] = src[k];
+    cand_end[p] = (uint32_t)src[d];
+    cand_idx[p] = n_split + (uint32_t)p;
+  }
+}
+
+static int shard_prepare_step(cssm_pf* pf, const StepRec* d_rec, int weighted, uint64_t* sums5_dev) {
+  int rc = launch_propagate(pf, d_rec);
+  if (rc) return rc;
+  if (weighted) {
+    if (!sums5_dev) return fail(CSSM_EINVAL_ARG, "sums5_dev is null");
+    // prefix of the sub-unit sums k_propagate formed, the rank's totals and the order key of its max -> 5 words
+    const uint64_t chunk = (uint64_t)pf->sup * CSSM_TILE / pf->split;
+    const uint32_t nsub = (uint32_t)((pf->n + chunk - 1) / chunk);
+    if (!pf->last_optimistic) {   // LGCP: only the max travels
+      HIP_TRY(hipMemsetAsync(pf->tileS, 0, (size_t)nsub * sizeof(cssm_u128), pf->stream));
+      HIP_TRY(hipMemsetAsync(pf->tileS2, 0, (size_t)nsub * sizeof(cssm_u128), pf->stream));
+    }
+    hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(1024), 0, pf->stream, pf->tileS, pf->tileS2, pf->tileP, nsub, pf->sc, pf->n_global, 0,
+                       (double*)nullptr, (int32_t*)nullptr, 0u, (const double*)nullptr, (unsigned long long*)sums5_dev, 1);
+    HIP_TRY(hipGetLastError());
+  }
+  return CSSM_OK;
+}
+
+extern "C" int cssm_pf_shard_begin(cssm_pf* pf, const double* t, const double* y, const uint8_t* has_obs, size_t T) {
+  int rc = shard_check(pf);
+  if (rc) return rc;
+  if (!t || !y) return fail(CSSM_EINVAL_ARG, "null argument");
+  if (T < 1) return fail(CSSM_EINVAL_ARG, "empty data");
+  rc = ensure_recs(pf, T);
+  if (rc) return rc;
+  if (pf->need_cap < T) {
+    if (pf->d_need) (void)hipFree(pf->d_need);
+    pf->d_need = nullptr;
+    HIP_TRY(hipMalloc(&pf->d_need, T * 4));
+    pf->need_cap = T;
+  }
+  HIP_TRY(hipMemsetAsync(pf->d_need, 0, T * 4, pf->stream));
+  double t0 = t[0];
+  for (size_t s = 1; s < T; ++s) if (t[s] < t0) t0 = t[s];
+  double tp = t0;
+  for (size_t s = 0; s < T; ++s) { build_rec(pf, tp, t[s], y[s], has_obs ? has_obs[s] : 1, (uint32_t)s, &pf->h_recs[s]); tp = t[s]; }
+  HIP_TRY(hipMemcpyAsync(pf->d_recs, pf->h_recs, T * sizeof(StepRec), hipMemcpyHostToDevice, pf->stream));
+  rc = launch_init(pf, t0);
+  if (rc) return rc;
+  pf->series = true;
+  return CSSM_OK;
+}
+
+extern "C" int cssm_pf_shard_propagate_at(cssm_pf* pf, size_t s, uint64_t* sums5_dev) {
+  int rc = shard_check(pf);
+  if (rc) return rc;
+  if (!pf->series || !pf->initialised) return fail(CSSM_ESTATE, "shard_propagate_at before shard_begin");
+  if (s >= pf->h_recs_cap || s != pf->step) return fail(CSSM_ESTATE, "steps of a series run in order (expected %u)", pf->step);
+  rc = shard_prepare_step(pf, pf->d_recs + s, pf->h_recs[s].has_obs, sums5_dev);
+  if (rc) return rc;
+  pf->step++;
+  return CSSM_OK;
+}
+
+extern "C" int cssm_pf_shard_offspring_pack(cssm_pf* pf, const uint64_t* all_sums5_dev, int rank, int world, int64_t cap,
+                                            double* send_buf_dev) {
+  if (!pf || !send_buf_dev) return fail(CSSM_EINVAL_ARG, "null argument");
+  if (cap < 1) return fail(CSSM_EINVAL_ARG, "cap must be positive");
+  int rc = cssm_pf_shard_offspring(pf, all_sums5_dev, rank, world, pf->d_xch, pf->d_xch + 64, (uint64_t*)(pf->d_xch + 128));
+  if (rc) return rc;
+  const long long total = (long long)world * (cap + 1);
+  uint32_t* need = (pf->d_need && pf->step >= 1 && (size_t)(pf->step - 1) < pf->need_cap) ? pf->d_need + (pf->step - 1) : nullptr;
+  hipLaunchKernelGGL(k_pack_fixed, dim3(grid_for((uint64_t)total, 256, kGridCap)), dim3(256), 0, pf->stream, pf->state[pf->cur], pf->stride,
+                     pf->endslot, pf->d, world, rank, (const long long*)pf->d_xch, (const long long*)(pf->d_xch + 64), (long long)cap,
+                     send_buf_dev, pf->sc, (const long long*)(pf->d_xch + 128), need);
+  HIP_TRY(hipGetLastError());
+  return CSSM_OK;
+}
+
+extern "C" int cssm_pf_shard_adopt_fixed(cssm_pf* pf, const double* recv_buf_dev, int rank, int world, int64_t cap) {
+  int rc = shard_check(pf);
+  if (rc) return rc;
+  if (!recv_buf_dev) return fail(CSSM_EINVAL_ARG, "recv_buf_dev is null");
+  if (cap < 1 || world < 1 || world > 64 || rank < 0 || rank >= world) return fail(CSSM_ESHARD, "rank %d / world %d / cap %lld", rank, world, (long long)cap);
+  const size_t need = (size_t)world * (size_t)cap;
+  if (need > pf->cand_cap) {
+    HIP_TRY(hipStreamSynchronize(pf->stream));
+    if (pf->cand) (void)hipFree(pf->cand);
+    if (pf->cand_end) (void)hipFree(pf->cand_end);
+    if (pf->cand_idx) (void)hipFree(pf->cand_idx);
+    pf->cand = nullptr; pf->cand_end = pf->cand_idx = nullptr;
+    const size_t cap2 = (need + CSSM_TILE - 1) / CSSM_TILE * CSSM_TILE;
+    if (hipMalloc(&pf->cand, cap2 * 8 * pf->d) != hipSuccess || hipMalloc(&pf->cand_end, cap2 * 4) != hipSuccess ||
+        hipMalloc(&pf->cand_idx, cap2 * 4) != hipSuccess)
+      return fail(CSSM_ENOMEM, "hipMalloc candidate buffers (%zu particles)", cap2);
+    pf->cand_cap = cap2;
+  }
+  const uint32_t n_split = (uint32_t)pf->n;
+  const long long total = (long long)world * (cap + 1);
+  hipLaunchKernelGGL(k_adopt_fixed, dim3(grid_for((uint64_t)total, CSSM_BLOCK, 1024)), dim3(CSSM_BLOCK), 0, pf->stream, recv_buf_dev, world, rank,
+                     (long long)cap, pf->d, n_split, pf->cand, pf->cand_cap, pf->cand_end, pf->cand_idx, (long long*)(pf->d_xch + 129), pf->sc);
+  hipLaunchKernelGGL(k_expand_dev, dim3(grid_for((uint64_t)need, CSSM_BLOCK, 1024)), dim3(CSSM_BLOCK), 0, pf->stream, pf->cand_end, pf->cand_idx,
+                     (const long long*)(pf->d_xch + 129), pf->first, pf->first + pf->n, pf->anc, (const uint32_t*)(pf->endslot + (pf->n - 1)));
+  HIP_TRY(hipGetLastError());
+  pf->src = pf->state[pf->cur]; pf->src_stride = pf->stride;
+  pf->src2 = pf->cand; pf->src2_stride = pf->cand_cap; pf->n_split = n_split; pf->anc_valid = true;
+  return CSSM_OK;
+}
+
+// ll, ess and the sticky bits of a series run with the fixed-capacity exchange: bit 2 (value 4) = some step's
+// reference level was ruled out by the max, bit 3 (value 8) = some send count exceeded the capacity.  Either bit
+// means the numbers are not the filter's; `need` (optional, T entries) receives the capacity every step needed
+// (exact up to the first overflowing step).
+extern "C" int cssm_pf_shard_status(cssm_pf* pf, double* ll_out, int32_t* ess_out, uint32_t* bits_out, uint32_t* need, size_t T) {
+  int rc = shard_check(pf);
+  if (rc) return rc;
+  Scalars h;
+  HIP_TRY(hipMemcpyAsync(&h, pf->sc, sizeof h, hipMemcpyDeviceToHost, pf->stream));
+  if (need && pf->d_need && T <= pf->need_cap) HIP_TRY(hipMemcpyAsync(need, pf->d_need, T * 4, hipMemcpyDeviceToHost, pf->stream));
+  HIP_TRY(hipStreamSynchronize(pf->stream));
+  if (ll_out) *ll_out = h.ll;
+  if (ess_out) *ess_out = h.ess;
+  if (bits_out) *bits_out = h.err & 12u;
+  h.err &= ~12u;
+  return check_device_err(pf, h);
 }
 
 extern "C" int cssm_pf_shard_pack(cssm_pf* pf, int world, const int64_t* send_first_host, const int64_t* send_count_host,
@@ -1206,38 +1390,33 @@ extern "C" int cssm_pf_shard_adopt(cssm_pf* pf, const double* recv_buf_dev, int6
   if (rc) return rc;
   if (n_low < 0 || n_high < 0 || self_count < 0 || self_first < 0 || (uint64_t)(self_first + self_count) > pf->n)
     return fail(CSSM_ESHARD, "bad candidate counts");
-  const int64_t n_remote = n_low + n_high, m = n_remote + self_count;
-  if (m < 1) return fail(CSSM_ESHARD, "a rank must have at least one candidate particle");
+  const int64_t n_remote = n_low + n_high;
+  if (n_remote + self_count < 1) return fail(CSSM_ESHARD, "a rank must have at least one candidate particle");
   if (n_remote > 0 && !recv_buf_dev) return fail(CSSM_EINVAL_ARG, "recv_buf_dev is null");
   if ((size_t)n_remote > pf->cand_cap) {
     HIP_TRY(hipStreamSynchronize(pf->stream));
     if (pf->cand) (void)hipFree(pf->cand);
-    pf->cand = nullptr;
-    size_t cap = (size_t)n_remote + (size_t)n_remote / 4 + CSSM_TILE;
-    cap = (cap + CSSM_TILE - 1) / CSSM_TILE * CSSM_TILE;
-    if (hipMalloc(&pf->cand, cap * 8 * pf->d) != hipSuccess) return fail(CSSM_ENOMEM, "hipMalloc candidate buffer (%zu particles)", cap);
-    pf->cand_cap = cap;
-  }
-  if ((size_t)m > pf->cidx_cap) {
-    HIP_TRY(hipStreamSynchronize(pf->stream));
     if (pf->cand_end) (void)hipFree(pf->cand_end);
     if (pf->cand_idx) (void)hipFree(pf->cand_idx);
-    pf->cand_end = pf->cand_idx = nullptr;
-    size_t cap = (size_t)m + (size_t)m / 4 + CSSM_TILE;
-    if (hipMalloc(&pf->cand_end, cap * 4) != hipSuccess || hipMalloc(&pf->cand_idx, cap * 4) != hipSuccess)
-      return fail(CSSM_ENOMEM, "hipMalloc candidate index (%zu entries)", cap);
-    pf->cidx_cap = cap;
+    pf->cand = nullptr; pf->cand_end = pf->cand_idx = nullptr;
+    size_t cap = (size_t)n_remote + (size_t)n_remote / 4 + CSSM_TILE;
+    cap = (cap + CSSM_TILE - 1) / CSSM_TILE * CSSM_TILE;
+    if (hipMalloc(&pf->cand, cap * 8 * pf->d) != hipSuccess || hipMalloc(&pf->cand_end, cap * 4) != hipSuccess ||
+        hipMalloc(&pf->cand_idx, cap * 4) != hipSuccess)
+      return fail(CSSM_ENOMEM, "hipMalloc candidate buffers (%zu particles)", cap);
+    pf->cand_cap = cap;
   }
+  // The own particles' runs are already in anc (shard_offspring).  Candidates of lower ranks fill the slots below the
+  // first own run (their last end slot is where it starts), candidates of higher ranks the slots from the last own
+  // end slot upwards.
   const uint32_t n_split = (uint32_t)pf->n;
   if (n_remote > 0)
     hipLaunchKernelGGL(k_adopt_remote, dim3(grid_for((uint64_t)n_remote, 256, kGridCap)), dim3(256), 0, pf->stream, recv_buf_dev,
-                       (long long)n_low, (long long)n_high, (long long)self_count, pf->d, n_split, pf->cand, pf->cand_cap, pf->cand_end,
-                       pf->cand_idx);
-  if (self_count > 0)
-    hipLaunchKernelGGL(k_adopt_self, dim3(grid_for((uint64_t)self_count, 256, kGridCap)), dim3(256), 0, pf->stream, pf->endslot,
-                       (long long)self_first, (long long)self_count, (long long)n_low, pf->cand_end, pf->cand_idx);
-  hipLaunchKernelGGL(k_expand, dim3(grid_for((uint64_t)m, CSSM_BLOCK, kGridCap)), dim3(CSSM_BLOCK), 0, pf->stream, pf->cand_end,
-                     pf->cand_idx, (uint64_t)m, pf->first, pf->first + pf->n, pf->anc);
+                       (long long)n_remote, pf->d, n_split, pf->cand, pf->cand_cap, pf->cand_end, pf->cand_idx);
+  if (n_remote > 0)
+    hipLaunchKernelGGL(k_expand, dim3(grid_for((uint64_t)n_remote, CSSM_BLOCK, kGridCap)), dim3(CSSM_BLOCK), 0, pf->stream, pf->cand_end,
+                       pf->cand_idx, (uint64_t)n_remote, (uint64_t)n_low, pf->first, pf->first + pf->n, pf->anc,
+                       (const uint32_t*)(pf->endslot + (pf->n - 1)));
   HIP_TRY(hipGetLastError());
   pf->src = pf->state[pf->cur]; pf->src_stride = pf->stride;
   pf->src2 = pf->cand; pf->src2_stride = pf->cand_cap; pf->n_split = n_split; pf->anc_valid = true;

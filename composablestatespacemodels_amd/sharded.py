@@ -16,6 +16,15 @@ Per observation (stage calls of include/cssm_pf.h):
 Random variates are keyed by the GLOBAL particle id and every sum is an integer sum, so ll, ess
 and the ancestor arrays are bit-identical for 1, 2, 4 and 8 ranks.
 
+Step 4 as written needs the exchange sizes on the host (all-to-all-v split sizes): one blocking device-to-host read
+per observation, which costs far more than the kernels once the wait is long enough for the runtime to sleep
+(measured at world = 1: 795 -> 479 us per observation at N = 2^24, 130 -> 89 us at N = 2^20).  ``ll_filter`` therefore
+runs a series with the FIXED-CAPACITY exchange after its first observations: every rank sends every other rank a
+segment of ``cap`` rows preceded by a header row holding the real count (``shard_offspring_pack``), one all-to-all
+with equal splits moves them, and ``shard_adopt_fixed`` reads the counts on the device.  The host never waits; a
+count above ``cap`` (or a reference level ruled out by the max) raises a sticky bit that is read once at the end,
+and the series is then repeated with the exact exchange -- same seed, same result, only slower.
+
 The orchestration is written over a list of local shards and a communicator object so that the
 same code drives (a) one shard per process over RCCL or gloo (``DistComm``) and (b) several
 shards inside one process with the exchanges done by tensor copies (``LocalComm``: how the stage
@@ -87,6 +96,34 @@ class GpuShard:
     def init(self, t0: float):
         _abi.check(self.lib.cssm_pf_shard_init(self._h, float(t0)))
 
+    # ---- a whole series, records resident on the device
+    def begin(self, t, y, has):
+        t = np.ascontiguousarray(t, dtype=np.float64)
+        y = np.ascontiguousarray(y, dtype=np.float64)
+        h = np.ones(len(t), dtype=np.uint8) if has is None else np.ascontiguousarray(has, dtype=np.uint8)
+        dp = C.POINTER(C.c_double)
+        _abi.check(self.lib.cssm_pf_shard_begin(self._h, t.ctypes.data_as(dp), y.ctypes.data_as(dp),
+                                                h.ctypes.data_as(C.POINTER(C.c_uint8)), len(t)))
+
+    def propagate_at(self, s: int):
+        _abi.check(self.lib.cssm_pf_shard_propagate_at(self._h, int(s), C.c_void_p(self.sums5.data_ptr())))
+
+    def offspring_pack(self, cap: int, send_buf: torch.Tensor):
+        _abi.check(self.lib.cssm_pf_shard_offspring_pack(self._h, C.c_void_p(self.all_sums.data_ptr()), self.rank, self.world,
+                                                         int(cap), C.c_void_p(send_buf.data_ptr())))
+
+    def adopt_fixed(self, recv_buf: torch.Tensor, cap: int):
+        self._recv_keepalive = recv_buf
+        _abi.check(self.lib.cssm_pf_shard_adopt_fixed(self._h, C.c_void_p(recv_buf.data_ptr()), self.rank, self.world, int(cap)))
+
+    def status(self, T: int):
+        """(ll, ess, sticky bits, capacity needed per step) of the series just run."""
+        ll, ess, bits = C.c_double(), C.c_int32(), C.c_uint32()
+        need = np.zeros(T, dtype=np.uint32)
+        _abi.check(self.lib.cssm_pf_shard_status(self._h, C.byref(ll), C.byref(ess), C.byref(bits),
+                                                 need.ctypes.data_as(C.POINTER(C.c_uint32)), T))
+        return ll.value, ess.value, bits.value, need
+
     def propagate(self, t, y, has_obs):
         _abi.check(self.lib.cssm_pf_shard_propagate(self._h, float(t), float(y), int(has_obs),
                                                     C.c_void_p(self.sums5.data_ptr())))
@@ -132,12 +169,13 @@ class GpuShard:
 class DistComm:
     """One shard per process; collectives through torch.distributed (RCCL on GPUs, gloo on CPU)."""
 
-    def __init__(self, group=None):
+    def __init__(self, group=None, device=None):
         import torch.distributed as dist
         self.dist = dist
         self.group = group
         self.world = dist.get_world_size(group)
         self.rank = dist.get_rank(group)
+        self.device = device   # where the small agreement tensors live (the GPU under RCCL, None = CPU under gloo)
 
     def all_gather(self, outs: List[torch.Tensor], ins: List[torch.Tensor]):
         self.dist.all_gather_into_tensor(outs[0], ins[0], group=self.group)
@@ -148,6 +186,15 @@ class DistComm:
     def all_to_all_v(self, outs, ins, out_splits, in_splits):
         self.dist.all_to_all_single(outs[0], ins[0], output_split_sizes=out_splits[0], input_split_sizes=in_splits[0],
                                     group=self.group)
+
+    def all_to_all_equal(self, outs, ins):
+        self.dist.all_to_all_single(outs[0], ins[0], group=self.group)
+
+    def agree_max(self, values: List[int]) -> int:
+        """Max over all ranks of a host integer (a decision every rank must take alike)."""
+        x = torch.tensor([int(values[0])], dtype=torch.int64, device=self.device if self.device is not None else "cpu")
+        self.dist.all_reduce(x, op=self.dist.ReduceOp.MAX, group=self.group)
+        return int(x.item())
 
     def barrier(self):
         self.dist.barrier(group=self.group)
@@ -182,6 +229,16 @@ class LocalComm:
                     outs[q][pos:pos + n].copy_(ins[r][int(in_off[r][q]):int(in_off[r][q]) + n])
                 pos += n
 
+    def all_to_all_equal(self, outs, ins):
+        R = self.world
+        seg = ins[0].numel() // R
+        for q in range(R):
+            for r in range(R):
+                outs[q][r * seg:(r + 1) * seg].copy_(ins[r][q * seg:(q + 1) * seg])
+
+    def agree_max(self, values):
+        return max(int(v) for v in values)
+
     def barrier(self):
         pass
 
@@ -202,12 +259,16 @@ class ShardedFilter:
             s.init(t0)
 
     def step(self, t: float, y: Optional[float], has_obs: bool = True, lgcp: bool = False):
-        S, comm, d = self.shards, self.comm, self.d
+        """One observation with the exact (host-read) exchange."""
         yv = 0.0 if y is None else y
-        for s in S:
+        for s in self.shards:
             s.propagate(t, yv, 1 if has_obs else 0)
-        if not (has_obs or lgcp):
-            return
+        if has_obs or lgcp:
+            self._resample_exact(lgcp)
+
+    def _resample_exact(self, lgcp: bool = False) -> int:
+        """Stages after propagate with the host read of the exchange sizes; returns the largest send count."""
+        S, comm, d = self.shards, self.comm, self.d
         W = comm.world
 
         def resample_stage():
@@ -245,14 +306,58 @@ class ShardedFilter:
                               [[int(v) * row for v in c] for c in rx], [[int(v) * row for v in c] for c in sx])
         for s, b, c, f, sc in zip(S, recv_bufs, rx, firsts, scount):
             s.adopt(b, int(c[: s.rank].sum()), int(c[s.rank + 1:].sum()), int(f[s.rank]), int(sc[s.rank]))
+        return max([int(c.max()) for c in sx] + [0])
 
-    def ll_filter(self, t, y, has=None, lgcp: bool = False):
+    def _resample_fixed(self, cap: int):
+        """Stages after propagate with the fixed-capacity exchange: nothing is read by the host."""
+        S, comm = self.shards, self.comm
+        n = comm.world * (cap + 1) * (self.d + 1)
+        comm.all_gather([s.all_sums for s in S], [s.sums5 for s in S])
+        send = [s.buffer("send_fixed", n)[:n] for s in S]
+        recv = [s.buffer("recv_fixed", n)[:n] for s in S]
+        for s, b in zip(S, send):
+            s.offspring_pack(cap, b)
+        comm.all_to_all_equal(recv, send)
+        for s, b in zip(S, recv):
+            s.adopt_fixed(b, cap)
+
+    # A series is begun with the exact exchange (the first observations of a filter are where the weights are most
+    # uneven and the exchange largest), which also tells how much capacity the fixed exchange needs afterwards.
+    EXACT_STEPS = 4
+    MIN_CAP = 1024
+    CAP_HEADROOM = 4      # capacity = CAP_HEADROOM x the largest exchange seen during the exact steps
+
+    def ll_filter(self, t, y, has=None, lgcp: bool = False, exact: bool = False):
         t = np.asarray(t, dtype=np.float64)
         y = np.asarray(y, dtype=np.float64)
-        self.init(float(t.min()))
-        for s in range(len(t)):
-            self.step(float(t[s]), float(y[s]), bool(has[s]) if has is not None else True, lgcp)
-        return self.result()
+        T = len(t)
+        weighted = np.ones(T, dtype=bool) if (has is None or lgcp) else np.asarray(has, dtype=bool)
+        S, comm = self.shards, self.comm
+        n_max = -(-S[0].n_global // comm.world)   # ceil(N / world): the same on every rank, and no count can exceed it
+        for attempt in range(2):
+            all_exact = exact or lgcp or attempt == 1
+            for s in S:
+                s.begin(t, y, has)
+            cap, seen, done_exact = None, 0, 0
+            for k in range(T):
+                for s in S:
+                    s.propagate_at(k)
+                if not weighted[k]:
+                    continue
+                if all_exact or done_exact < self.EXACT_STEPS:
+                    seen = max(seen, self._resample_exact(lgcp))
+                    done_exact += 1
+                    continue
+                if cap is None:   # every rank must use the same capacity: agree on the largest count seen so far
+                    cap = min(max(self.MIN_CAP, self.CAP_HEADROOM * comm.agree_max([seen] * len(S))), n_max)
+                self._resample_fixed(cap)
+            res = [s.status(T) for s in S]
+            # bits 4 and 8 both mean "again, exactly"; any rank may have raised one, every rank must repeat
+            bits = comm.agree_max([max(r[2] for r in res)] * len(S))
+            if bits == 0:
+                self.last_cap, self.last_attempts = cap, attempt + 1
+                return res[0][0], res[0][1]
+        raise RuntimeError("the exact exchange cannot raise a sticky bit")
 
     def result(self):
         res = [s.result() for s in self.shards]

@@ -180,6 +180,13 @@ int cssm_pf_last_loop_ms(cssm_pf* pf, float* ms_out);
 #define CSSM_RESAMPLE_SYSTEMATIC 0
 #define CSSM_RESAMPLE_STRATIFIED 1
 #define CSSM_RESAMPLE_MULTINOMIAL 2
+/* CSSM_OPT_FUSED_SUMS: 1 = k_propagate also forms the fixed-point sums of exp(w - c) (c = the observation's
+ * reference level, cssm_numerics.h), 2 kernels per observation, and a second attempt when the max rules c out;
+ * 0 = the sums are a pass of their own after the max is known, 3 kernels per observation.  Identical results
+ * (both apply cssm_ref_choose).  Default: 1 on sharded handles, where it saves a collective per observation;
+ * 0 on single-GPU handles, where the extra exp in the VALU-bound propagate kernel was measured to cost what the
+ * separate pass costs. */
+#define CSSM_OPT_FUSED_SUMS 3
 int cssm_pf_set_option(cssm_pf* pf, int option, int value);
 
 /* Per-kernel device time, measured with HIP events recorded on the handle's stream directly
@@ -269,6 +276,24 @@ int cssm_pf_shard_propagate(cssm_pf* pf, double t, double obs, int has_obs, uint
 int cssm_pf_shard_sums(cssm_pf* pf, const uint64_t* all_sums5_dev, int world, uint64_t* sums5_dev);
 int cssm_pf_shard_offspring(cssm_pf* pf, const uint64_t* all_sums5_dev, int rank, int world,
                             int64_t* send_first_dev, int64_t* send_count_dev, uint64_t* redo_flag_dev);
+/* The same observation WITHOUT a host read (the exchange sizes stay on the device), for a series known in advance:
+ *   cssm_pf_shard_begin           records of all T observations uploaded once; initial cloud
+ *   cssm_pf_shard_propagate_at    step s (in order): as cssm_pf_shard_propagate
+ *   [all-gather of 5 x u64 per rank]
+ *   cssm_pf_shard_offspring_pack  offspring as above, then the send ranges packed into a FIXED layout: one segment of
+ *                                 (cap + 1) rows of (d + 1) doubles per destination, row 0 = header (row count)
+ *   [all-to-all with equal splits of (cap + 1) * (d + 1) doubles]
+ *   cssm_pf_shard_adopt_fixed     counts from the headers; candidates expanded to the slots the own particles left
+ *   cssm_pf_shard_status          at the end: ll, ess and two sticky bits -- 4: the max ruled some step's reference
+ *                                 level out, 8: some send count exceeded cap.  Either means the series has to be run
+ *                                 again (larger cap, or the host-read stages above); need[s] = capacity step s needed.
+ * Nothing here blocks the host, so the kernels and collectives of consecutive observations queue back to back. */
+int cssm_pf_shard_begin(cssm_pf* pf, const double* t, const double* y, const uint8_t* has_obs, size_t T);
+int cssm_pf_shard_propagate_at(cssm_pf* pf, size_t s, uint64_t* sums5_dev);
+int cssm_pf_shard_offspring_pack(cssm_pf* pf, const uint64_t* all_sums5_dev, int rank, int world, int64_t cap,
+                                 double* send_buf_dev);
+int cssm_pf_shard_adopt_fixed(cssm_pf* pf, const double* recv_buf_dev, int rank, int world, int64_t cap);
+int cssm_pf_shard_status(cssm_pf* pf, double* ll_out, int32_t* ess_out, uint32_t* bits_out, uint32_t* need, size_t T);
 int cssm_pf_shard_pack(cssm_pf* pf, int world, const int64_t* send_first_host,
                        const int64_t* send_count_host, int skip_rank, double* send_buf_dev);
 int cssm_pf_shard_adopt(cssm_pf* pf, const double* recv_buf_dev, int64_t n_low, int64_t n_high,

@@ -14,8 +14,9 @@ from oracle import oracle
 pytestmark = pytest.mark.gpu
 
 
-def _compare_streaming(model, n, t, y, has, seed=cases.SEED, lgcp_precision=0):
+def _compare_streaming(model, n, t, y, has, seed=cases.SEED, lgcp_precision=0, fused=0):
     g = NativePf(model, n, seed, lgcp_precision=lgcp_precision)
+    g.set_option(3, fused)      # CSSM_OPT_FUSED_SUMS
     o = oracle.OraclePf(model.descriptor(lgcp_precision), n, seed)
     t0 = float(np.min(t))
     g.init(t0); o.init(t0)
@@ -360,8 +361,9 @@ def _outlier_series(T=10, where=(4,)):
     return t, y, has
 
 
+@pytest.mark.parametrize("fused", [0, 1])
 @pytest.mark.parametrize("n", [1000, 1 << 16])
-def test_outlying_observation_falls_back_to_the_max_streaming(n):
+def test_outlying_observation_falls_back_to_the_max_streaming(n, fused):
     """cssm_ref_choose: a step whose max log-weight is > 32 below the observation's reference level is rescaled by
     the max (second attempt on the device), exactly as the oracle decides."""
     model = cases.c2_model()
@@ -373,15 +375,17 @@ def test_outlying_observation_falls_back_to_the_max_streaming(n):
         o.step(t[s], y[s], True)
         levels.append(o.ref())
     assert levels[4][0] == levels[4][1] and levels[3][0] != levels[3][1]   # max used at the outlier only
-    _compare_streaming(model, n, t, y, has)
+    _compare_streaming(model, n, t, y, has, fused=fused)
 
 
+@pytest.mark.parametrize("fused", [0, 1])
 @pytest.mark.parametrize("name,where", [("c2_model", (4,)), ("c2_model", (0, 9)), ("c3_model", (7,))])
-def test_outlying_observation_batch_rerun_matches_oracle(name, where):
+def test_outlying_observation_batch_rerun_matches_oracle(name, where, fused):
     model = getattr(cases, name)()
     n = 5000
     t, y, has = _outlier_series(10, where)
     g = NativePf(model, n, cases.SEED)
+    g.set_option(3, fused)
     gl, gll, gess, gpath = g.run(t, y, has, want_path=True)
     o = oracle.OraclePf(model.descriptor(), n, cases.SEED)
     ol, oll, oess, opath = o.filter(t, y, has, want_path=True)
@@ -401,7 +405,32 @@ def test_outlying_gaussian_observation_and_pmmh_path():
     n = 4096
     t, y, has = cases.gaussian_series(8)
     y = y.copy(); y[3] = 40.0           # ~80 sd away from every particle
-    g = NativePf(model, n, cases.SEED)
     o = oracle.OraclePf(model.descriptor(), n, cases.SEED)
-    assert g.run(t, y, has)[0] == o.filter(t, y, has)[0]
-    g.close()
+    want = o.filter(t, y, has)[0]
+    for fused in (0, 1):
+        g = NativePf(model, n, cases.SEED)
+        g.set_option(3, fused)
+        assert g.run(t, y, has)[0] == want
+        g.close()
+
+
+@pytest.mark.parametrize("name", ["c1_model", "c2_model", "c3_model", "linear_model", "negbin_model", "max_dim_model"])
+@pytest.mark.parametrize("n", [2500, 1 << 17])
+def test_fused_sums_equal_separate_pass(name, n):
+    """CSSM_OPT_FUSED_SUMS: k_propagate forming the sums relative to the reference level (2 kernels per observation)
+    gives the bits of the separate pass (3 kernels), streaming and batch, and both equal the oracle."""
+    model = getattr(cases, name)()
+    t, y, has = (cases.gaussian_series(7) if name == "linear_model" else cases.poisson_counts(7, missing=0.15))
+    if n <= 4096:
+        _compare_streaming(model, n, t, y, has, fused=1)
+    runs = []
+    for fused in (0, 1):
+        g = NativePf(model, n, cases.SEED)
+        g.set_option(3, fused)
+        ll, ll_t, ess_t, _ = g.run(t, y, has)
+        runs.append((ll, ll_t.copy(), ess_t.copy(), g.ancestors(), g.particles()))
+        g.close()
+    assert runs[0][0] == runs[1][0]
+    for a, b in zip(runs[0][1:], runs[1][1:]):
+        np.testing.assert_array_equal(a, b)
+    assert runs[0][0] == oracle.OraclePf(model.descriptor(), n, cases.SEED).filter(t, y, has)[0]

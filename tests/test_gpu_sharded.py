@@ -81,13 +81,14 @@ def test_rccl_world1_matches_oracle():
     try:
         model = cases.c2_model()
         n = 5000
-        t, y, has = cases.poisson_counts(7)
+        t, y, has = cases.poisson_counts(15)
         shard = GpuShard(model, n, 0, 1, cases.SEED, 0)
-        f = ShardedFilter([shard], DistComm())
-        ll, ess = f.ll_filter(t, y, has)
+        f = ShardedFilter([shard], DistComm(device=torch.device("cuda", 0)))
         oll, oess, opart = _oracle_run(model, n, t, y, has)
-        assert (ll, ess) == (oll, oess[-1])
-        np.testing.assert_array_equal(shard.particles(), opart)
+        for exact in (False, True):          # fixed-capacity exchange (equal-split all-to-all) and exact exchange over RCCL
+            ll, ess = f.ll_filter(t, y, has, exact=exact)
+            assert (ll, ess) == (oll, oess[-1])
+            np.testing.assert_array_equal(shard.particles(), opart)
         shard.close()
     finally:
         dist.destroy_process_group()
@@ -104,6 +105,51 @@ def test_local_shards_outlying_observation_second_attempt(world):
     shards = [GpuShard(model, n, r, world, cases.SEED, 0) for r in range(world)]
     f = ShardedFilter(shards, LocalComm(world))
     ll, ess = f.ll_filter(t, y, has)
+    oll, oess, opart = _oracle_run(model, n, t, y, has)
+    assert (ll, ess) == (oll, oess[-1])
+    np.testing.assert_array_equal(np.concatenate([s.particles() for s in shards], axis=1), opart)
+    for s in shards:
+        s.close()
+
+
+@pytest.mark.parametrize("world", [2, 4, 8])
+@pytest.mark.parametrize("name,n,T", [("c2_model", 20000, 30), ("c3_model", 9000, 16)])
+def test_fixed_capacity_series_matches_oracle(world, name, n, T):
+    """ll_filter: exact exchange for the first observations, then the host-read-free fixed-capacity exchange."""
+    from composablestatespacemodels_amd.sharded import GpuShard, LocalComm, ShardedFilter
+    model = getattr(cases, name)()
+    t, y, has = cases.poisson_counts(T, missing=0.1)
+    shards = [GpuShard(model, n, r, world, cases.SEED, 0) for r in range(world)]
+    f = ShardedFilter(shards, LocalComm(world))
+    ll, ess = f.ll_filter(t, y, has)
+    assert f.last_attempts == 1 and f.last_cap is not None
+    oll, oess, opart = _oracle_run(model, n, t, y, has)
+    assert (ll, ess) == (oll, oess[-1])
+    np.testing.assert_array_equal(np.concatenate([s.particles() for s in shards], axis=1), opart)
+    # the same handles run another series (records, capacity buffers and sticky bits start afresh)
+    t2, y2, has2 = cases.poisson_counts(12, seed=7)
+    ll2, ess2 = f.ll_filter(t2, y2, has2)
+    oll2, oess2, _ = _oracle_run(model, n, t2, y2, has2)
+    assert (ll2, ess2) == (oll2, oess2[-1])
+    for s in shards:
+        s.close()
+
+
+@pytest.mark.parametrize("why", ["capacity", "outlier"])
+def test_fixed_capacity_series_is_repeated_exactly_when_voided(why):
+    from composablestatespacemodels_amd.sharded import GpuShard, LocalComm, ShardedFilter
+    model = cases.c2_model()
+    n, world, T = 12000, 4, 14
+    t, y, has = cases.poisson_counts(T)
+    if why == "outlier":
+        y = y.copy(); y[9] = 60.0          # in the fixed-capacity part: the max rules the reference level out (sticky bit 4)
+    shards = [GpuShard(model, n, r, world, cases.SEED, 0) for r in range(world)]
+    f = ShardedFilter(shards, LocalComm(world))
+    f.EXACT_STEPS = 1
+    if why == "capacity":
+        f.MIN_CAP, f.CAP_HEADROOM = 1, 0    # one row per pair cannot hold the exchange (sticky bit 8)
+    ll, ess = f.ll_filter(t, y, has)
+    assert f.last_attempts == 2
     oll, oess, opart = _oracle_run(model, n, t, y, has)
     assert (ll, ess) == (oll, oess[-1])
     np.testing.assert_array_equal(np.concatenate([s.particles() for s in shards], axis=1), opart)

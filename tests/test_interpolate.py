@@ -130,10 +130,12 @@ def test_gpu_interpolate_with_outlying_observation():
     n, T = 3000, 12
     t, y, has = _series("c2_model", T)
     y = y.copy(); y[1] = 60.0
-    g = NativePf(model, n, cases.SEED)
-    got = g.interpolate(t, y, has)
     want = oracle.OraclePf(model.descriptor(), n, cases.SEED).interpolate(t, y, has)
-    assert got[0] == want[0]
-    for k in (2, 3, 5, 6):
-        np.testing.assert_array_equal(got[k], want[k])
-    g.close()
+    for fused in (0, 1):
+        g = NativePf(model, n, cases.SEED)
+        g.set_option(3, fused)
+        got = g.interpolate(t, y, has)
+        assert got[0] == want[0]
+        for k in (2, 3, 5, 6):
+            np.testing.assert_array_equal(got[k], want[k])
+        g.close()

@@ -42,8 +42,13 @@ def _worker(rank, world, port, name, n, T, missing, prec, out_dir):
         t, y, has = _series(C, T, missing, prec)
         shard = OracleShard(model, n, rank, world, C.SEED, prec)
         f = ShardedFilter([shard], DistComm())
+        if missing == -0.2:        # the outlier falls into the fixed-capacity part of the series
+            f.EXACT_STEPS = 1
+        if missing == 0.05:        # capacity too small for what the exchange needs: the series is repeated exactly
+            f.EXACT_STEPS, f.MIN_CAP, f.CAP_HEADROOM = 1, 1, 0
         ll, ess = f.ll_filter(t, y, has, lgcp=bool(prec))
-        np.savez(os.path.join(out_dir, f"r{rank}.npz"), ll=ll, ess=ess, part=shard.particles(), redone=shard.redone)
+        np.savez(os.path.join(out_dir, f"r{rank}.npz"), ll=ll, ess=ess, part=shard.particles(), redone=shard.redone,
+                 attempts=f.last_attempts, cap=-1 if f.last_cap is None else f.last_cap)
     finally:
         dist.destroy_process_group()
 
@@ -53,6 +58,9 @@ def _worker(rank, world, port, name, n, T, missing, prec, out_dir):
     (3, "c1_model", 200, 6, 0.0, 0),
     (2, "c4_model", 150, 4, 0.0, 2),
     (2, "c2_model", 256, 6, -0.1, 0),
+    (2, "c2_model", 256, 12, -0.2, 0),
+    (3, "c2_model", 300, 12, 0.05, 0),
+    (2, "c3_model", 200, 14, 0.0, 0),
 ])
 def test_sharded_orchestration_over_gloo_matches_single_rank(tmp_path, world, name, n, T, missing, prec):
     port = 29600 + (os.getpid() % 300) + world
@@ -66,6 +74,10 @@ def test_sharded_orchestration_over_gloo_matches_single_rank(tmp_path, world, na
         z = np.load(os.path.join(str(tmp_path), f"r{r}.npz"))
         # the second attempt runs exactly for the steps whose level the max rules out (LGCP: every step)
         assert int(z["redone"]) == (T if prec else (1 if missing < 0 else 0))
+        # a series is run once unless a sticky bit (level ruled out / capacity exceeded in its fixed-capacity part) voids it
+        assert int(z["attempts"]) == (2 if missing in (-0.2, 0.05) else 1)
+        if T > 8 and missing == 0.0:
+            assert int(z["cap"]) >= 1             # the fixed-capacity exchange did run
         assert float(z["ll"]) == ll and int(z["ess"]) == int(ess_t[-1])
         parts.append(z["part"])
     np.testing.assert_array_equal(np.concatenate(parts, axis=1), o.particles())

@@ -10,12 +10,13 @@ dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cu
 model = cases.c2_model(); t, y, has = cases.poisson_counts(220)
 for n in (1 << 20, 1 << 24):
     shard = GpuShard(model, n, 0, 1, cases.SEED, 0)
-    f = ShardedFilter([shard], DistComm())
-    f.init(0.0)
-    for s in range(20): f.step(float(t[s]), float(y[s]), True)
-    torch.cuda.synchronize(); t0 = time.perf_counter()
-    for s in range(20, 220): f.step(float(t[s]), float(y[s]), True)
-    torch.cuda.synchronize(); w = time.perf_counter() - t0
-    print(f"sharded RCCL path, world=1, N={n}: {w/200*1e6:.1f} us/step, {n*200/w/1e9:.2f} G particle-steps/s", flush=True)
+    f = ShardedFilter([shard], DistComm(device=torch.device("cuda", 0)))
+    for exact in (True, False):
+        f.ll_filter(t[:20], y[:20], has[:20], exact=exact)
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        ll, ess = f.ll_filter(t[:200], y[:200], has[:200], exact=exact)
+        torch.cuda.synchronize(); w = time.perf_counter() - t0
+        print(f"sharded RCCL path, world=1, N={n}, {'exact (host-read)' if exact else 'fixed-capacity'} exchange: {w/200*1e6:.1f} us/step, "
+              f"{n*200/w/1e9:.2f} G particle-steps/s  cap={f.last_cap} attempts={f.last_attempts} ll={ll:.6f}", flush=True)
     shard.close()
 dist.destroy_process_group()

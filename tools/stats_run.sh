@@ -1,0 +1,20 @@
+#!/bin/bash
+# rocprofv3 kernel-trace statistics of bench.py at two sizes (run on the GPU box from the repo root).
+# usage: tools/stats_run.sh <tag>
+TAG=${1:-r01}
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+export TMPDIR=/tmp
+cd /tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/stats_${TAG}_1M -- python3 $R/bench.py --steps 500 --warmup 20 --no-cpu > $R/gpurun_out/stats_${TAG}_1M.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/stats_${TAG}_16M -- python3 $R/bench.py --steps 100 --warmup 5 --no-cpu --particles 16777216 > $R/gpurun_out/stats_${TAG}_16M.log 2>&1
+cd $R
+for s in 1M 16M; do
+  f=$(find gpurun_out/stats_${TAG}_$s -name '*kernel_stats.csv' | head -1)
+  echo "== $s: $f"; python3 - "$f" <<'PY'
+import csv, sys
+for row in csv.DictReader(open(sys.argv[1])):
+    if float(row['Percentage']) > 0.5:
+        print(f"{row['Name'][:60]:60s} calls {row['Calls']:>5s} avg {float(row['AverageNs'])/1e3:8.1f} us min {float(row['MinNs'])/1e3:8.1f}")
+PY
+  tail -1 gpurun_out/stats_${TAG}_$s.log | python3 -c "import sys,json; d=json.loads(sys.stdin.read()); print('ms_per_step', d['ms_per_step'], 'value', d['value'])"
+done
