@@ -297,6 +297,9 @@ __global__ __launch_bounds__(CSSM_BLOCK, PropWaves<D>::value) void k_propagate(
     uint64_t seed, const StepRec* __restrict__ rec, ModelK mk, Scalars* __restrict__ sc, int slot_set,
     const double* __restrict__ src2, size_t src2_stride, uint32_t n_split, const double* __restrict__ logtab,
     uint64_t chunk, int do_sums_arg, cssm_u128* __restrict__ subS, cssm_u128* __restrict__ subS2) {
+  // (Totalling the sub-unit sums in the block that finishes last -- the threadfence-reduction idiom -- was measured
+  // and rejected: on this multi-XCD part every block's device-scope release fence writes the L2's dirty lines back,
+  // which in a kernel that streams hundreds of MB of stores cost 130 us at N = 2^24.  k_scan_tiles does it instead.)
   // src2 != nullptr (sharded filter): ancestor indices >= n_split address the candidates received from
   // other ranks, src2[k * src2_stride + (j - n_split)]
   __shared__ double s_max[CSSM_BLOCK / 64];
@@ -339,12 +342,18 @@ __global__ __launch_bounds__(CSSM_BLOCK, PropWaves<D>::value) void k_propagate(
       for (int r = 0; r < IT; ++r) j[r] = (size_t)((i0 + r < n) ? i0 + r : n - 1);
     }
   };
+  // src2_stride == 0: the candidates are rows of (D + 1) doubles (state, end slot) exactly as they were received
+  // (fixed-capacity exchange: the receive buffer is read in place); otherwise struct-of-arrays with that stride
   auto gather = [&](const size_t (&j)[IT], double (&x)[IT][D]) {
 #pragma unroll
     for (int r = 0; r < IT; ++r)
 #pragma unroll
-      for (int k = 0; k < D; ++k)
-        x[r][k] = (src2 && j[r] >= n_split) ? src2[(size_t)k * src2_stride + (j[r] - n_split)] : src[(size_t)k * src_stride + j[r]];
+      for (int k = 0; k < D; ++k) {
+        if (src2 && j[r] >= n_split)
+          x[r][k] = (src2_stride == 0) ? src2[(j[r] - n_split) * (size_t)(D + 1) + k] : src2[(size_t)k * src2_stride + (j[r] - n_split)];
+        else
+          x[r][k] = src[(size_t)k * src_stride + j[r]];
+      }
   };
   uint64_t base = range_lo;
   size_t jn[IT], jnn[IT];
@@ -736,7 +745,19 @@ __global__ __launch_bounds__(CSSM_BLOCK, 3) void k_offspring(const double* __res
     const uint32_t t0 = unit * sup;
     const uint32_t t1 = (t0 + sup < ntiles) ? t0 + sup : ntiles;
     cssm_u128 toff;                                        // cumulative weight before the current tile
-    if (SELF) {                                            // here unitP holds the unit SUMS (k_tile_sums output)
+    if (!SELF && all5) {                                   // sharded: unitP holds the (sub-)unit SUMS; the totals came with all5
+      cssm_u128 pre = cssm_u128_zero();
+      const uint32_t qlim = unit * (uint32_t)split;
+      for (uint32_t q = threadIdx.x; q < qlim; q += CSSM_BLOCK) pre = cssm_u128_add(pre, unitP[q]);
+      pre = wave_sum_u128(pre);
+      if (lane == 0) s_r[0][wid] = pre;
+      __syncthreads();
+      pre = s_r[0][0];
+#pragma unroll
+      for (int w = 1; w < CSSM_BLOCK / 64; ++w) pre = cssm_u128_add(pre, s_r[0][w]);
+      toff = cssm_u128_add(S_off, pre);
+      __syncthreads();
+    } else if (SELF) {                                     // here unitP holds the unit SUMS (k_tile_sums output)
       cssm_u128 pre = cssm_u128_zero(), tot = cssm_u128_zero(), tot2 = cssm_u128_zero();
       const uint32_t nsub = nunits * (uint32_t)split, qlim = unit * (uint32_t)split;
       for (uint32_t q = threadIdx.x; q < nsub; q += CSSM_BLOCK) {
@@ -924,6 +945,72 @@ __device__ __forceinline__ void expand_body(const uint32_t* __restrict__ cand_en
     __syncthreads();
   }
 }
+// The same on the receive buffer of the fixed-capacity exchange, in place: segment r = (cap + 1) rows of (d + 1)
+// doubles from rank r, row 0 a header with the row count, the rest (state, end slot).  Candidate = row; its ancestor
+// index is n_split + row number, which k_propagate resolves against the same buffer.  The predecessor of a
+// segment's first row is the last row of the nearest non-empty segment below it -- or, crossing this rank's own
+// position, the own last end slot; at the very bottom the run starts at slot_lo.
+__global__ __launch_bounds__(CSSM_BLOCK) void k_expand_fixed(const double* __restrict__ recv, int world, int rank, long long cap, int d,
+                                                             uint32_t n_split, uint64_t slot_lo, uint64_t slot_hi,
+                                                             uint32_t* __restrict__ anc, const uint32_t* __restrict__ own_last_end,
+                                                             Scalars* __restrict__ sc) {
+  __shared__ long long s_cnt[64];
+  __shared__ uint32_t s_nheavy;
+  __shared__ uint32_t s_hb[CSSM_BLOCK], s_he[CSSM_BLOCK], s_hj[CSSM_BLOCK];
+  const long long seg = cap + 1, rowlen = d + 1;
+  if (threadIdx.x < 64) {
+    long long c = 0;
+    if ((int)threadIdx.x < world && (int)threadIdx.x != rank) {
+      c = (long long)recv[(size_t)threadIdx.x * seg * rowlen];
+      if (c > cap && blockIdx.x == 0) atomicOr(&sc->err, 8u);   // the sender had more than fits (it raised the bit too)
+      c = (c < 0) ? 0 : ((c > cap) ? cap : c);
+    }
+    s_cnt[threadIdx.x] = c;
+  }
+  __syncthreads();
+  const long long total = (long long)world * seg;
+  for (long long base = (long long)blockIdx.x * CSSM_BLOCK; base < total; base += (long long)gridDim.x * CSSM_BLOCK) {
+    if (threadIdx.x == 0) s_nheavy = 0;
+    __syncthreads();
+    const long long row = base + threadIdx.x;
+    if (row < total) {
+      const int r = (int)(row / seg);
+      const long long i = row - (long long)r * seg;
+      if (i >= 1 && i - 1 < s_cnt[r]) {
+        uint64_t b;
+        if (i > 1) {
+          b = (uint64_t)recv[(row - 1) * rowlen + d];
+        } else {
+          int rp = r - 1;
+          while (rp >= 0 && (rp == rank || s_cnt[rp] == 0)) { if (rp == rank) break; --rp; }
+          if (rp < 0) b = slot_lo;
+          else if (rp == rank) b = (uint64_t)*own_last_end;
+          else b = (uint64_t)recv[((long long)rp * seg + s_cnt[rp]) * rowlen + d];
+        }
+        uint64_t e = (uint64_t)recv[row * rowlen + d];
+        if (b < slot_lo) b = slot_lo;
+        if (e > slot_hi) e = slot_hi;
+        if (e > b) {
+          const uint32_t idx = n_split + (uint32_t)row;
+          if (e - b <= CSSM_RUN_DIRECT) {
+            for (uint64_t sl = b; sl < e; ++sl) anc[sl - slot_lo] = idx;
+          } else {
+            const uint32_t h = atomicAdd(&s_nheavy, 1u);
+            s_hb[h] = (uint32_t)(b - slot_lo); s_he[h] = (uint32_t)(e - slot_lo); s_hj[h] = idx;
+          }
+        }
+      }
+    }
+    __syncthreads();
+    const uint32_t nh = s_nheavy;
+    for (uint32_t h = 0; h < nh; ++h) {
+      const uint32_t he = s_he[h], hj = s_hj[h];
+      for (uint32_t sl = s_hb[h] + threadIdx.x; sl < he; sl += CSSM_BLOCK) anc[sl] = hj;
+    }
+    __syncthreads();
+  }
+}
+
 __global__ __launch_bounds__(CSSM_BLOCK) void k_expand(const uint32_t* __restrict__ cand_end, const uint32_t* __restrict__ cand_idx,
                                                        uint64_t m, uint64_t n_low, uint64_t slot_lo, uint64_t slot_hi,
                                                        uint32_t* __restrict__ anc, const uint32_t* __restrict__ own_last_end) {
@@ -960,7 +1047,9 @@ __global__ void k_gather(const double* __restrict__ src, size_t src_stride, cons
   for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
     const size_t j = anc ? (size_t)anc[i] : (size_t)i;
     for (int k = 0; k < d; ++k)
-      out[(size_t)k * out_stride + i] = (src2 && j >= n_split) ? src2[(size_t)k * src2_stride + (j - n_split)] : src[(size_t)k * src_stride + j];
+      out[(size_t)k * out_stride + i] = (src2 && j >= n_split)
+          ? (src2_stride == 0 ? src2[(size_t)(j - n_split) * (size_t)(d + 1) + k] : src2[(size_t)k * src2_stride + (j - n_split)])
+          : src[(size_t)k * src_stride + j];
   }
 }
 
@@ -1011,7 +1100,9 @@ __global__ __launch_bounds__(CSSM_BLOCK) void k_summary_fill(const double* __res
     double x[D];
 #pragma unroll
     for (int k = 0; k < D; ++k) {
-      x[k] = (src2 && j >= n_split) ? src2[(size_t)k * src2_stride + (j - n_split)] : src[(size_t)k * src_stride + j];
+      x[k] = (src2 && j >= n_split)
+          ? (src2_stride == 0 ? src2[(size_t)(j - n_split) * (size_t)(D + 1) + k] : src2[(size_t)k * src2_stride + (j - n_split)])
+          : src[(size_t)k * src_stride + j];
       keys[(size_t)k * kstride + i] = cssm_order_key(x[k]);
       acc[k] += x[k];
     }

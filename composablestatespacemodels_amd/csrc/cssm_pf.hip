@@ -1166,7 +1166,7 @@ extern "C" int cssm_pf_shard_offspring(cssm_pf* pf, const uint64_t* all_sums5_de
   // the rank's own particles write their runs inside the rank's slots straight into anc (indexed from the first
   // own slot); the end slots are kept for the send ranges; slots owned by other ranks' particles are filled by adopt
   hipLaunchKernelGGL((k_offspring<true, false, CSSM_RESAMPLE_SYSTEMATIC>), dim3(tgrid), dim3(CSSM_BLOCK), 0, pf->stream, pf->logw, pf->n, pf->sc,
-                     (const cssm_u128*)pf->tileP, (const cssm_u128*)pf->tileS2, pf->d_recs + slot, pf->n_global, pf->endslot,
+                     (const cssm_u128*)pf->tileS, (const cssm_u128*)pf->tileS2, pf->d_recs + slot, pf->n_global, pf->endslot,
                      pf->anc, pf->ntiles, pf->sup, pf->nunits, 0, 0, (double*)nullptr, (int32_t*)nullptr, 0u, pf->opt_exact,
                      (const unsigned long long*)all_sums5_dev, rank, world, optimistic ? (int)pf->split : 1, pf->seed, (double*)nullptr, pf->d_logtab,
                      optimistic, (unsigned long long*)redo_flag_dev, (uint32_t)pf->first, (uint32_t)(pf->first + pf->n));
@@ -1183,74 +1183,83 @@ extern "C" int cssm_pf_shard_offspring(cssm_pf* pf, const uint64_t* all_sums5_de
 // 1..count are (state, end slot).  An all-to-all with EQUAL splits moves segment q of every rank to rank q, so the
 // receiver learns the counts from the headers and the host never does.  count > cap sets the sticky err bit 3 (the
 // caller repeats the series with a larger cap or with the exact, host-read exchange).
-__global__ void k_pack_fixed(const double* __restrict__ src, size_t stride, const uint32_t* __restrict__ endslot, int d, int world, int rank,
-                             const long long* __restrict__ first, const long long* __restrict__ count, long long cap,
-                             double* __restrict__ out, Scalars* __restrict__ sc, const long long* __restrict__ redo_flag,
-                             uint32_t* __restrict__ need_out) {
-  const long long seg = cap + 1, total = (long long)world * seg;
-  for (long long row = (long long)blockIdx.x * blockDim.x + threadIdx.x; row < total; row += (long long)gridDim.x * blockDim.x) {
-    const int q = (int)(row / seg);
-    const long long i = row - (long long)q * seg;
-    const long long c = (q == rank) ? 0 : count[q];
-    double* o = out + row * (d + 1);
+// first j in [0, n) with endslot[j] > bound (strict) or >= bound, n if there is none; endslot is non-decreasing.
+// All 64 lanes of a wave call it: every round probes 64 equally spaced positions of the bracket (4 rounds for 2^24).
+__device__ __forceinline__ uint64_t wave_search_first(const uint32_t* __restrict__ endslot, uint64_t n, uint64_t bound, bool strict) {
+  const int lane = threadIdx.x & 63;
+  uint64_t lo = 0, hi = n;                                // the answer is in [lo, hi]
+  while (hi > lo) {
+    const uint64_t width = hi - lo;
+    const uint64_t step = (width + 63) / 64;
+    const uint64_t idx = lo + (uint64_t)lane * step;      // lane l probes the first element of its sub-range
+    bool t = false;
+    if (idx < hi) { const uint64_t v = endslot[idx]; t = strict ? (v > bound) : (v >= bound); }
+    else t = true;                                        // beyond the bracket counts as "true" (hi itself is the fallback answer)
+    const unsigned long long m = __ballot(t);
+    const int f = m ? (__ffsll((long long)m) - 1) : 64;   // first lane whose probe is true
+    if (f == 0) { hi = lo; break; }                       // the very first element of the bracket satisfies it
+    // the probe of lane f-1 is false, the probe of lane f is true: the answer is in (idx_{f-1}, idx_f]
+    const uint64_t new_lo = lo + (uint64_t)(f - 1) * step + 1;
+    const uint64_t new_hi = (f < 64 && lo + (uint64_t)f * step < hi) ? lo + (uint64_t)f * step : hi;
+    lo = new_lo; hi = new_hi;
+    if (step == 1) { lo = hi = new_hi; break; }           // sub-ranges were single elements: idx_f (or hi) is the answer
+  }
+  return hi;
+}
+
+// Blocks (x = chunk of rows, y = destination rank q).  Wave 0 of every block first finds the contiguous range of
+// local particles owning at least one slot of q (the searches k_send_ranges does with one thread per destination).
+__global__ __launch_bounds__(256) void k_pack_fixed(const double* __restrict__ src, size_t stride, const uint32_t* __restrict__ endslot,
+                             uint64_t n_local, int d, int world, int rank, uint64_t n_global, uint64_t n_per, long long cap,
+                             const StepRec* __restrict__ rec, double* __restrict__ out, Scalars* __restrict__ sc,
+                             const long long* __restrict__ redo_flag, uint32_t* __restrict__ need_out) {
+  __shared__ long long s_first, s_count;
+  const int q = blockIdx.y;
+  const long long seg = cap + 1;
+  if (threadIdx.x < 64) {
+    long long first = 0, count = 0;
+    if (q != rank) {
+      uint64_t b_lo = (uint64_t)q * n_per, b_hi = b_lo + n_per;
+      if (b_lo > n_global) b_lo = n_global;
+      if (b_hi > n_global) b_hi = n_global;
+      uint64_t e_before = 0;   // end slot of the last particle of the previous rank
+      if (rank > 0) e_before = cssm_sys_count(cssm_u128_to_double(sc->S_off) / cssm_u128_to_double(sc->S_tot), rec->u, n_global);
+      const uint64_t j_lo = wave_search_first(endslot, n_local, b_lo, true);
+      if (b_lo < b_hi && j_lo < n_local) {
+        const uint64_t start = (j_lo == 0) ? e_before : (uint64_t)endslot[j_lo - 1];
+        if (start < b_hi) {
+          uint64_t j_last = wave_search_first(endslot, n_local, b_hi, false);   // it owns slot b_hi - 1
+          if (j_last >= n_local) j_last = n_local - 1;
+          first = (long long)j_lo; count = (long long)(j_last - j_lo + 1);
+        }
+      }
+    }
+    if (threadIdx.x == 0) { s_first = first; s_count = count; }
+  }
+  __syncthreads();
+  const long long first = s_first, c = s_count;
+  double* oseg = out + (size_t)q * seg * (d + 1);
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < seg; i += (long long)gridDim.x * blockDim.x) {
+    double* o = oseg + i * (d + 1);
     if (i == 0) {
       o[0] = (double)c;
       if (c > cap) atomicOr(&sc->err, 8u);
+      if (need_out) atomicMax(need_out, (uint32_t)c);
     } else if (i - 1 < c && i - 1 < cap) {
-      const long long j = first[q] + (i - 1);
+      const long long j = first + (i - 1);
       for (int k = 0; k < d; ++k) o[k] = src[(size_t)k * stride + (size_t)j];
       o[d] = (double)endslot[j];
     }
   }
-  if (blockIdx.x == 0 && threadIdx.x == 0) {
-    if (*redo_flag) atomicOr(&sc->err, 4u);   // the max ruled the reference level out: this series needs the exact path
-    long long mx = 0;
-    for (int q = 0; q < world; ++q) if (q != rank && count[q] > mx) mx = count[q];
-    if (need_out) *need_out = (uint32_t)mx;
-  }
+  // the max ruled the reference level out: this series needs the exact path
+  if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0 && *redo_flag) atomicOr(&sc->err, 4u);
 }
-// Receive buffer: segment r came from rank r.  Candidates in global particle order = segments in rank order.
-__global__ __launch_bounds__(CSSM_BLOCK) void k_adopt_fixed(const double* __restrict__ recv, int world, int rank, long long cap, int d,
-                                                            uint32_t n_split, double* __restrict__ cand, size_t cstride,
-                                                            uint32_t* __restrict__ cand_end, uint32_t* __restrict__ cand_idx,
-                                                            long long* __restrict__ nlh, Scalars* __restrict__ sc) {
-  __shared__ long long s_cnt[64], s_off[64];
-  const long long seg = cap + 1;
-  if (threadIdx.x < 64) {
-    long long c = 0;
-    if ((int)threadIdx.x < world && (int)threadIdx.x != rank) {
-      c = (long long)recv[(size_t)threadIdx.x * seg * (d + 1)];
-      if (c > cap && blockIdx.x == 0) atomicOr(&sc->err, 8u);   // the sender had more than fits (it raised the bit too)
-      c = (c < 0) ? 0 : ((c > cap) ? cap : c);
-    }
-    s_cnt[threadIdx.x] = c;
-  }
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    long long off = 0, lo = 0;
-    for (int r = 0; r < world; ++r) { s_off[r] = off; off += s_cnt[r]; if (r < rank) lo += s_cnt[r]; }
-    if (blockIdx.x == 0) { nlh[0] = lo; nlh[1] = off - lo; }
-  }
-  __syncthreads();
-  const long long total = (long long)world * seg;
-  for (long long row = (long long)blockIdx.x * CSSM_BLOCK + threadIdx.x; row < total; row += (long long)gridDim.x * CSSM_BLOCK) {
-    const int r = (int)(row / seg);
-    const long long i = row - (long long)r * seg;
-    if (i == 0 || i - 1 >= s_cnt[r]) continue;
-    const long long p = s_off[r] + (i - 1);
-    const double* src = recv + row * (d + 1);
-    for (int k = 0; k < d; ++k) cand[(size_t)k * cstride + (size_t)p] = src[k];
-    cand_end[p] = (uint32_t)src[d];
-    cand_idx[p] = n_split + (uint32_t)p;
-  }
-}
-
 static int shard_prepare_step(cssm_pf* pf, const StepRec* d_rec, int weighted, uint64_t* sums5_dev) {
   int rc = launch_propagate(pf, d_rec);
   if (rc) return rc;
   if (weighted) {
     if (!sums5_dev) return fail(CSSM_EINVAL_ARG, "sums5_dev is null");
-    // prefix of the sub-unit sums k_propagate formed, the rank's totals and the order key of its max -> 5 words
+    // the rank's totals of the sub-unit sums k_propagate formed and the order key of its max -> 5 words for the all-gather
     const uint64_t chunk = (uint64_t)pf->sup * CSSM_TILE / pf->split;
     const uint32_t nsub = (uint32_t)((pf->n + chunk - 1) / chunk);
     if (!pf->last_optimistic) {   // LGCP: only the max travels
@@ -1304,13 +1313,26 @@ extern "C" int cssm_pf_shard_offspring_pack(cssm_pf* pf, const uint64_t* all_sum
                                             double* send_buf_dev) {
   if (!pf || !send_buf_dev) return fail(CSSM_EINVAL_ARG, "null argument");
   if (cap < 1) return fail(CSSM_EINVAL_ARG, "cap must be positive");
-  int rc = cssm_pf_shard_offspring(pf, all_sums5_dev, rank, world, pf->d_xch, pf->d_xch + 64, (uint64_t*)(pf->d_xch + 128));
+  int rc = shard_check(pf);
   if (rc) return rc;
-  const long long total = (long long)world * (cap + 1);
+  if (!all_sums5_dev) return fail(CSSM_EINVAL_ARG, "null argument");
+  if (world < 1 || world > 64 || rank < 0 || rank >= world) return fail(CSSM_ESHARD, "rank %d / world %d", rank, world);
+  const uint64_t n_per = (pf->n_global + (uint64_t)world - 1) / (uint64_t)world;
+  if (pf->first != (uint64_t)rank * n_per) return fail(CSSM_ESHARD, "rank %d must own particles from %llu, handle starts at %llu",
+                                                       rank, (unsigned long long)((uint64_t)rank * n_per), (unsigned long long)pf->first);
+  const size_t slot = last_rec_slot(pf);
+  const int tgrid = (int)pf->nunits;
+  const int optimistic = pf->last_optimistic ? 1 : 0;
+  hipLaunchKernelGGL((k_offspring<true, false, CSSM_RESAMPLE_SYSTEMATIC>), dim3(tgrid), dim3(CSSM_BLOCK), 0, pf->stream, pf->logw, pf->n, pf->sc,
+                     (const cssm_u128*)pf->tileS, (const cssm_u128*)pf->tileS2, pf->d_recs + slot, pf->n_global, pf->endslot,
+                     pf->anc, pf->ntiles, pf->sup, pf->nunits, 0, 0, (double*)nullptr, (int32_t*)nullptr, 0u, pf->opt_exact,
+                     (const unsigned long long*)all_sums5_dev, rank, world, optimistic ? (int)pf->split : 1, pf->seed, (double*)nullptr, pf->d_logtab,
+                     optimistic, (unsigned long long*)(pf->d_xch + 128), (uint32_t)pf->first, (uint32_t)(pf->first + pf->n));
   uint32_t* need = (pf->d_need && pf->step >= 1 && (size_t)(pf->step - 1) < pf->need_cap) ? pf->d_need + (pf->step - 1) : nullptr;
-  hipLaunchKernelGGL(k_pack_fixed, dim3(grid_for((uint64_t)total, 256, kGridCap)), dim3(256), 0, pf->stream, pf->state[pf->cur], pf->stride,
-                     pf->endslot, pf->d, world, rank, (const long long*)pf->d_xch, (const long long*)(pf->d_xch + 64), (long long)cap,
-                     send_buf_dev, pf->sc, (const long long*)(pf->d_xch + 128), need);
+  const int xblocks = (int)std::min<long long>((cap + 1 + 255) / 256, 64);
+  hipLaunchKernelGGL(k_pack_fixed, dim3(xblocks, world), dim3(256), 0, pf->stream, pf->state[pf->cur], pf->stride, pf->endslot, pf->n, pf->d,
+                     world, rank, pf->n_global, n_per, (long long)cap, pf->d_recs + slot, send_buf_dev, pf->sc,
+                     (const long long*)(pf->d_xch + 128), need);
   HIP_TRY(hipGetLastError());
   return CSSM_OK;
 }
@@ -1320,28 +1342,15 @@ extern "C" int cssm_pf_shard_adopt_fixed(cssm_pf* pf, const double* recv_buf_dev
   if (rc) return rc;
   if (!recv_buf_dev) return fail(CSSM_EINVAL_ARG, "recv_buf_dev is null");
   if (cap < 1 || world < 1 || world > 64 || rank < 0 || rank >= world) return fail(CSSM_ESHARD, "rank %d / world %d / cap %lld", rank, world, (long long)cap);
-  const size_t need = (size_t)world * (size_t)cap;
-  if (need > pf->cand_cap) {
-    HIP_TRY(hipStreamSynchronize(pf->stream));
-    if (pf->cand) (void)hipFree(pf->cand);
-    if (pf->cand_end) (void)hipFree(pf->cand_end);
-    if (pf->cand_idx) (void)hipFree(pf->cand_idx);
-    pf->cand = nullptr; pf->cand_end = pf->cand_idx = nullptr;
-    const size_t cap2 = (need + CSSM_TILE - 1) / CSSM_TILE * CSSM_TILE;
-    if (hipMalloc(&pf->cand, cap2 * 8 * pf->d) != hipSuccess || hipMalloc(&pf->cand_end, cap2 * 4) != hipSuccess ||
-        hipMalloc(&pf->cand_idx, cap2 * 4) != hipSuccess)
-      return fail(CSSM_ENOMEM, "hipMalloc candidate buffers (%zu particles)", cap2);
-    pf->cand_cap = cap2;
-  }
+  // The receive buffer is used in place (it must stay untouched until the next cssm_pf_shard_propagate* has run):
+  // ancestors of the slots the own particles left open point at its rows.
   const uint32_t n_split = (uint32_t)pf->n;
   const long long total = (long long)world * (cap + 1);
-  hipLaunchKernelGGL(k_adopt_fixed, dim3(grid_for((uint64_t)total, CSSM_BLOCK, 1024)), dim3(CSSM_BLOCK), 0, pf->stream, recv_buf_dev, world, rank,
-                     (long long)cap, pf->d, n_split, pf->cand, pf->cand_cap, pf->cand_end, pf->cand_idx, (long long*)(pf->d_xch + 129), pf->sc);
-  hipLaunchKernelGGL(k_expand_dev, dim3(grid_for((uint64_t)need, CSSM_BLOCK, 1024)), dim3(CSSM_BLOCK), 0, pf->stream, pf->cand_end, pf->cand_idx,
-                     (const long long*)(pf->d_xch + 129), pf->first, pf->first + pf->n, pf->anc, (const uint32_t*)(pf->endslot + (pf->n - 1)));
+  hipLaunchKernelGGL(k_expand_fixed, dim3(grid_for((uint64_t)total, CSSM_BLOCK, 1024)), dim3(CSSM_BLOCK), 0, pf->stream, recv_buf_dev, world, rank,
+                     (long long)cap, pf->d, n_split, pf->first, pf->first + pf->n, pf->anc, (const uint32_t*)(pf->endslot + (pf->n - 1)), pf->sc);
   HIP_TRY(hipGetLastError());
   pf->src = pf->state[pf->cur]; pf->src_stride = pf->stride;
-  pf->src2 = pf->cand; pf->src2_stride = pf->cand_cap; pf->n_split = n_split; pf->anc_valid = true;
+  pf->src2 = recv_buf_dev; pf->src2_stride = 0; pf->n_split = n_split; pf->anc_valid = true;   // stride 0 = rows of d + 1
   return CSSM_OK;
 }
 
