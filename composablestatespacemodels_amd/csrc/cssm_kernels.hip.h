@@ -82,41 +82,64 @@ struct Scalars {
 
 // ------------------------------------------------------------------------------------ helpers
 
-__device__ __forceinline__ double wave_max(double v) {
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) {
-    double o = __shfl_xor(v, off, 64);
-    v = (o > v) ? o : v;
-  }
-  return v;
+// Cross-lane traffic goes through DPP (data-parallel primitives: a VALU move whose source lane is a fixed
+// pattern), not through ds_bpermute (__shfl*): measured on MI355X (tools/instr_rate.hip) a DPP move issues in ~5
+// cycles per wave, a ds_bpermute_b32 in ~25, and a 128-bit scan needs 24 of either.
+//   row_shr:n   lane i of each row of 16 reads lane i-n of its row (lanes without a source keep `old` = 0)
+//   row_bcast15 lane 15 of every row -> all lanes of the NEXT row (row_mask 0xa: rows 1 and 3 take it)
+//   row_bcast31 lane 31 -> all lanes of rows 2 and 3 (row_mask 0xc)
+// After the six steps lane i holds the inclusive prefix over lanes 0..i, lane 63 the wave total.
+#define CSSM_DPP_ROW_SHR(n) (0x110 + (n))
+#define CSSM_DPP_BCAST15 0x142
+#define CSSM_DPP_BCAST31 0x143
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ uint32_t dpp0(uint32_t v) {   // lanes that receive nothing read 0
+  return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROW_MASK, 0xf, false);
+}
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ uint64_t dpp0_u64(uint64_t v) {
+  return (uint64_t)dpp0<CTRL, ROW_MASK>((uint32_t)v) | ((uint64_t)dpp0<CTRL, ROW_MASK>((uint32_t)(v >> 32)) << 32);
+}
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ cssm_u128 dpp0_u128(cssm_u128 v) {
+  cssm_u128 r;
+  r.lo = dpp0_u64<CTRL, ROW_MASK>(v.lo);
+  r.hi = dpp0_u64<CTRL, ROW_MASK>(v.hi);
+  return r;
+}
+__device__ __forceinline__ uint64_t readlane_u64(uint64_t v, int lane) {
+  return (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, lane) |
+         ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), lane) << 32);
 }
 
-__device__ __forceinline__ cssm_u128 shfl_up_u128(cssm_u128 v, int off) {
-  cssm_u128 r;
-  r.lo = __shfl_up((unsigned long long)v.lo, off, 64);
-  r.hi = __shfl_up((unsigned long long)v.hi, off, 64);
-  return r;
-}
-__device__ __forceinline__ cssm_u128 shfl_xor_u128(cssm_u128 v, int off) {
-  cssm_u128 r;
-  r.lo = __shfl_xor((unsigned long long)v.lo, off, 64);
-  r.hi = __shfl_xor((unsigned long long)v.hi, off, 64);
-  return r;
-}
-__device__ __forceinline__ cssm_u128 wave_sum_u128(cssm_u128 v) {
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) v = cssm_u128_add(v, shfl_xor_u128(v, off));
-  return v;
-}
 // inclusive scan across the 64 lanes (integer adds: any order gives the same bits)
 __device__ __forceinline__ cssm_u128 wave_scan_u128(cssm_u128 v, int lane) {
-#pragma unroll
-  for (int off = 1; off < 64; off <<= 1) {
-    cssm_u128 o = shfl_up_u128(v, off);
-    if (lane >= off) v = cssm_u128_add(v, o);
-  }
+  (void)lane;
+  v = cssm_u128_add(v, dpp0_u128<CSSM_DPP_ROW_SHR(1), 0xf>(v));
+  v = cssm_u128_add(v, dpp0_u128<CSSM_DPP_ROW_SHR(2), 0xf>(v));
+  v = cssm_u128_add(v, dpp0_u128<CSSM_DPP_ROW_SHR(4), 0xf>(v));
+  v = cssm_u128_add(v, dpp0_u128<CSSM_DPP_ROW_SHR(8), 0xf>(v));
+  v = cssm_u128_add(v, dpp0_u128<CSSM_DPP_BCAST15, 0xa>(v));
+  v = cssm_u128_add(v, dpp0_u128<CSSM_DPP_BCAST31, 0xc>(v));
   return v;
 }
+// wave total, uniform (it is read from lane 63 into scalar registers)
+__device__ __forceinline__ cssm_u128 wave_sum_u128(cssm_u128 v) {
+  v = wave_scan_u128(v, 0);
+  cssm_u128 r;
+  r.lo = readlane_u64(v.lo, 63);
+  r.hi = readlane_u64(v.hi, 63);
+  return r;
+}
+__device__ __forceinline__ uint64_t wave_max_u64(uint64_t k) {   // uniform
+#define CSSM_MAX_STEP(CTRL, RM) { const uint64_t o = dpp0_u64<CTRL, RM>(k); k = (o > k) ? o : k; }
+  CSSM_MAX_STEP(CSSM_DPP_ROW_SHR(1), 0xf) CSSM_MAX_STEP(CSSM_DPP_ROW_SHR(2), 0xf) CSSM_MAX_STEP(CSSM_DPP_ROW_SHR(4), 0xf)
+  CSSM_MAX_STEP(CSSM_DPP_ROW_SHR(8), 0xf) CSSM_MAX_STEP(CSSM_DPP_BCAST15, 0xa) CSSM_MAX_STEP(CSSM_DPP_BCAST31, 0xc)
+#undef CSSM_MAX_STEP
+  return readlane_u64(k, 63);
+}
+// max of doubles through their order-preserving keys (a missing DPP source reads key 0, below every real key)
+__device__ __forceinline__ double wave_max(double v) { return cssm_order_unkey(wave_max_u64(cssm_order_key(v))); }
 
 // The contract's log table (include/cssm_numerics.h, CSSM_LOG_TAB) staged in LDS by every kernel that
 // draws normals: `tab_global` is the handle's device copy.  All threads of the block must call it.
@@ -248,11 +271,7 @@ __device__ __forceinline__ double block_decode_slots(const Scalars* __restrict__
   if (threadIdx.x < 64) {
     unsigned long long k = (threadIdx.x < CSSM_MAXSLOTS)
         ? sc->maxslot[((size_t)set * CSSM_MAXSLOTS + threadIdx.x) * CSSM_SLOT_STRIDE] : 0ull;
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-      const unsigned long long o = __shfl_xor(k, off, 64);
-      k = (o > k) ? o : k;
-    }
+    k = wave_max_u64(k);
     if (threadIdx.x == 0) s_key = k;
   }
   __syncthreads();
@@ -594,8 +613,7 @@ __global__ __launch_bounds__(1024) void k_scan_tiles(const cssm_u128* __restrict
       k = sc->maxslot[(size_t)threadIdx.x * CSSM_SLOT_STRIDE];
       sc->maxslot[(size_t)threadIdx.x * CSSM_SLOT_STRIDE] = 0ull;
     }
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) { const unsigned long long o = __shfl_xor(k, off, 64); k = (o > k) ? o : k; }
+    k = wave_max_u64(k);
     if (threadIdx.x == 0) sums4_out[4] = k;
   }
   const uint32_t chunk = (ntiles + 1023u) / 1024u;
@@ -657,8 +675,11 @@ __global__ void k_global_sums(const unsigned long long* __restrict__ all4, int r
 // other max-slot set for the next weighted step.
 // RS = CSSM_RESAMPLE_* at compile time: the systematic kernel must not carry the stratified path's Philox code
 // (it cost 40 VGPRs and a wave of occupancy when the kind was a runtime argument).
+#ifndef CSSM_OFF_WAVES
+#define CSSM_OFF_WAVES 4
+#endif
 template <bool FUSE, bool SELF, int RS>
-__global__ __launch_bounds__(CSSM_BLOCK, 3) void k_offspring(const double* __restrict__ logw, uint64_t n,
+__global__ __launch_bounds__(CSSM_BLOCK, CSSM_OFF_WAVES) void k_offspring(const double* __restrict__ logw, uint64_t n,
                                                           Scalars* __restrict__ sc,
                                                           const cssm_u128* __restrict__ unitP, const cssm_u128* __restrict__ unitS2,
                                                           const StepRec* __restrict__ rec, uint64_t n_global,
@@ -855,7 +876,7 @@ __global__ __launch_bounds__(CSSM_BLOCK, 3) void k_offspring(const double* __res
       if (FUSE && resampler != CSSM_RESAMPLE_MULTINOMIAL) {
         // end slot of the particle before this thread's first one
         if (lane == 63) s_last[wid] = e[CSSM_ITEMS - 1];
-        uint32_t prev = __shfl_up(e[CSSM_ITEMS - 1], 1, 64);
+        uint32_t prev = dpp0<0x138 /* wave_shr:1 */, 0xf>(e[CSSM_ITEMS - 1]);
         __syncthreads();
         if (lane == 0) {
           if (wid > 0) prev = s_last[wid - 1];
