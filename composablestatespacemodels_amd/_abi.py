@@ -104,6 +104,7 @@ SYMBOLS = [
     ("cssm_pf_shard_result", C.c_int, [_h, _dp, _i32p]),
     ("cssm_pmmh_run", C.c_int, [_h, _descp, _dp, C.c_size_t, C.c_double, _dp, _dp, _u8p, C.c_size_t,
                                 C.c_uint64, C.c_size_t, _dp, _dp, _i32p, _dp]),
+    ("cssm_contract_eval", C.c_int, [C.c_int, C.c_int, _dp, C.c_size_t, _dp, C.c_size_t]),
     ("cssm_desc_flatten", C.c_int, [_descp, _dp, C.c_size_t, C.POINTER(C.c_size_t)]),
     ("cssm_last_error", C.c_char_p, []),
     ("cssm_version", C.c_char_p, []),

@@ -150,40 +150,95 @@ __device__ __forceinline__ const double* stage_log_table(const double* __restric
   return s_logtab;
 }
 
-// d standard normals of global particle gid for an ordinary step (normal k = element k&1 of pair k>>1)
+// The d standard normals of global particle gid for an ordinary step or the initial draw (include/cssm_numerics.h,
+// counter layout): particles 2m and 2m+1 share stream m, particle gid owns its normals q = (gid & 1) * D + k, normal q
+// = element q&1 of block q>>1.  A particle touches ceil(D/2) blocks starting at b0; for odd D an odd particle starts
+// on the SECOND element of its first block.  Branch-free in gid, so neighbouring lanes do not diverge.
 template <int D>
 __device__ __forceinline__ void draw_normals(uint64_t seed, uint64_t gid, uint32_t step, uint32_t tag,
                                              const double* tab, double (&z)[D]) {
+  constexpr int NB = (D + 1) / 2;
+  const bool odd = (gid & 1u) != 0u;
+  const uint32_t b0 = ((uint32_t)(gid & 1u) * (uint32_t)D) >> 1;
+  const uint64_t stream = cssm_pair_stream(gid);
+  double pe1 = 0.0;
 #pragma unroll
-  for (int p = 0; 2 * p < D; ++p) {
-    double z0, z1;
-    cssm_normal_pair(cssm_philox_draw(seed, gid, step, tag, (uint32_t)p), tab, &z0, &z1);
-    z[2 * p] = z0;
-    if (2 * p + 1 < D) z[2 * p + 1] = z1;
+  for (int p = 0; p < NB; ++p) {
+    double e0, e1;
+    cssm_normal_pair(cssm_philox_draw(seed, stream, step, tag, b0 + (uint32_t)p), tab, &e0, &e1);
+    if (D % 2 == 0) {
+      z[2 * p] = e0; z[(2 * p + 1) % D] = e1;
+    } else {   // even particle: element j of its blocks is component j; odd particle: component j - 1
+      if (p > 0) z[(2 * p - 1 + D) % D] = odd ? e0 : pe1;
+      z[2 * p] = odd ? e1 : e0;
+      pe1 = e1;
+    }
   }
 }
 
-// One transition of all components (model/Sde.scala:86-95,114-123,139-150; :30-43 for Euler).
+// One transition of component k (model/Sde.scala:86-95,114-123,139-150; :30-43 for Euler); components are independent.
+template <int D>
+__device__ __forceinline__ void transition_one(const ModelK& mk, const StepRec* __restrict__ rec, double dt, int k, double& xk, double zk) {
+  const double p0 = rec->coef[k][0], p1 = rec->coef[k][1], p2 = rec->coef[k][2], p3 = rec->coef[k][3];
+  const int kind = mk.kind(k);
+  if (kind == CSSM_SDE_BROWNIAN) {
+    xk = p3 * zk + xk;
+  } else if (kind == CSSM_SDE_GEN_BROWNIAN) {
+    double mean = xk + p0;
+    xk = p3 * zk + mean;
+  } else if (kind == CSSM_SDE_OU) {
+    double mean = p0 + (xk - p0) * p1;
+    xk = p3 * zk + mean;
+  } else {
+    double dW = p3 * zk;
+    double a = (p0 + p1 * xk) * dt;
+    double b = p2 * dW;
+    xk = (xk + a) + b;
+  }
+}
 template <int D>
 __device__ __forceinline__ void transition(const ModelK& mk, const StepRec* __restrict__ rec, double dt,
                                            double (&x)[D], const double (&z)[D]) {
 #pragma unroll
-  for (int k = 0; k < D; ++k) {
-    const double p0 = rec->coef[k][0], p1 = rec->coef[k][1], p2 = rec->coef[k][2], p3 = rec->coef[k][3];
-    const int kind = mk.kind(k);
-    if (kind == CSSM_SDE_BROWNIAN) {
-      x[k] = p3 * z[k] + x[k];
-    } else if (kind == CSSM_SDE_GEN_BROWNIAN) {
-      double mean = x[k] + p0;
-      x[k] = p3 * z[k] + mean;
-    } else if (kind == CSSM_SDE_OU) {
-      double mean = p0 + (x[k] - p0) * p1;
-      x[k] = p3 * z[k] + mean;
+  for (int k = 0; k < D; ++k) transition_one<D>(mk, rec, dt, k, x[k], z[k]);
+}
+
+// Ordinary step of the two particles of a pair (2m, 2m+1): D Philox blocks + Box-Muller pairs give their 2 D normals,
+// each fed to its component as soon as it exists (normal q -> particle q / D, component q % D).
+template <int D>
+__device__ __forceinline__ void propagate_pair(const ModelK& mk, const StepRec* __restrict__ rec, double dt, uint64_t seed,
+                                               uint64_t gid_even, uint32_t step, const double* tab, double (&xa)[D], double (&xb)[D]) {
+  const uint64_t stream = cssm_pair_stream(gid_even);
+#pragma unroll
+  for (int p = 0; p < D; ++p) {
+    double e0, e1;
+    cssm_normal_pair(cssm_philox_draw(seed, stream, step, CSSM_STREAM_STEP, (uint32_t)p), tab, &e0, &e1);
+    if (2 * p < D) transition_one<D>(mk, rec, dt, 2 * p, xa[(2 * p) % D], e0);
+    else transition_one<D>(mk, rec, dt, 2 * p - D, xb[(2 * p - D + D) % D], e0);
+    if (2 * p + 1 < D) transition_one<D>(mk, rec, dt, 2 * p + 1, xa[(2 * p + 1) % D], e1);
+    else transition_one<D>(mk, rec, dt, 2 * p + 1 - D, xb[(2 * p + 1 - D + D) % D], e1);
+  }
+}
+// The same for ONE particle of either parity (threads that do not own whole pairs): ceil(D/2) blocks.
+template <int D>
+__device__ __forceinline__ void propagate_one(const ModelK& mk, const StepRec* __restrict__ rec, double dt, uint64_t seed,
+                                              uint64_t gid, uint32_t step, const double* tab, double (&x)[D]) {
+  constexpr int NB = (D + 1) / 2;
+  const bool odd = (gid & 1u) != 0u;
+  const uint32_t b0 = ((uint32_t)(gid & 1u) * (uint32_t)D) >> 1;
+  const uint64_t stream = cssm_pair_stream(gid);
+  double pe1 = 0.0;
+#pragma unroll
+  for (int p = 0; p < NB; ++p) {
+    double e0, e1;
+    cssm_normal_pair(cssm_philox_draw(seed, stream, step, CSSM_STREAM_STEP, b0 + (uint32_t)p), tab, &e0, &e1);
+    if (D % 2 == 0) {
+      transition_one<D>(mk, rec, dt, 2 * p, x[2 * p], e0);
+      transition_one<D>(mk, rec, dt, (2 * p + 1) % D, x[(2 * p + 1) % D], e1);
     } else {
-      double dW = p3 * z[k];
-      double a = (p0 + p1 * x[k]) * dt;
-      double b = p2 * dW;
-      x[k] = (x[k] + a) + b;
+      if (p > 0) transition_one<D>(mk, rec, dt, (2 * p - 1 + D) % D, x[(2 * p - 1 + D) % D], odd ? e0 : pe1);
+      transition_one<D>(mk, rec, dt, 2 * p, x[2 * p], odd ? e1 : e0);
+      pe1 = e1;
     }
   }
 }
@@ -278,6 +333,22 @@ __device__ __forceinline__ double block_decode_slots(const Scalars* __restrict__
   return cssm_order_unkey(s_key);
 }
 
+// Asynchronous 16-byte-per-lane copy global -> LDS (gfx950: global_load_lds_dwordx4): lane l fetches the 16 bytes at
+// its own address g into LDS bytes [lds_base + 16 l, +16); lds_base is wave-uniform and travels in M0.  Issued through
+// inline assembly ON PURPOSE: for the builtin form the compiler, unable to prove that later LDS reads (the log table)
+// do not touch the destination, inserts s_waitcnt vmcnt(0) before the first LDS read that follows, i.e. it waits for
+// the very prefetch that is meant to overlap the computation.  An operation the compiler does not count only makes its
+// own counted waits more conservative (VMEM operations retire in order), never wrong; completion is awaited explicitly
+// (s_waitcnt vmcnt(0)) before the wave reads the region back.  M0 has no other use in these kernels.
+__device__ __forceinline__ void lds_dma16(const double* g, uint32_t lds_base) {
+  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(g), "s"(lds_base) : "memory");
+}
+// The same with 4 bytes per lane (lane l -> LDS bytes [lds_base + 4 l, +4)): a double travels as two of these, low and
+// high word into two 256-byte regions, where LDS is too small for 16 bytes per element.
+__device__ __forceinline__ void lds_dma4(const void* g, uint32_t lds_base) {
+  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %0, off" : : "v"(g), "s"(lds_base) : "memory");
+}
+
 // Particles per thread in k_propagate: all gathers of a thread are issued before its ALU work,
 // and rows are stored as 16-/32-byte vectors.
 #ifndef CSSM_PROP_IT_MID
@@ -302,17 +373,20 @@ __device__ __forceinline__ double decode_slots(const Scalars* __restrict__ sc, i
 // particles; a block owns CSSM_BLOCK*IT consecutive particles per grid-stride iteration.
 // min waves per SIMD asked of the register allocator: 4 for small d (the kernel is VALU-bound and needs
 // the co-resident waves to cover LDS/table and gather latency), 3 beyond
-template <int D> struct PropWaves { static constexpr int value = (D <= 4) ? 4 : 3; };
+#ifndef CSSM_PROP_WAVES_LO
+#define CSSM_PROP_WAVES_LO 4
+#endif
+template <int D> struct PropWaves { static constexpr int value = (D <= 4) ? CSSM_PROP_WAVES_LO : 3; };
 
 //
 // A block owns the CONTIGUOUS range [blockIdx.x * chunk, +chunk) (chunk a multiple of CSSM_BLOCK*IT, chosen on the
 // host so that a whole number of blocks makes one scan unit of k_offspring).  With do_sums the block also forms
 // S = sum exp(w - c), S2 = sum exp(w - c)^2 in fixed point for its range, c = rec->ref being known before any
 // weight is (include/cssm_numerics.h, "reference level"): the log-sum-exp of :125-127 then needs no pass of its own.
-template <int D, bool LGCP, int IT, int OBS>
+template <int D, bool LGCP, int IT, int OBS, bool SUMS>
 __global__ __launch_bounds__(CSSM_BLOCK, PropWaves<D>::value) void k_propagate(
     const double* __restrict__ src, size_t src_stride, const uint32_t* __restrict__ anc,
-    double* __restrict__ dst, size_t dst_stride, double* __restrict__ logw, uint64_t n, uint64_t gid0,
+    double* __restrict__ dst, size_t dst_stride, double* __restrict__ logw, uint64_t n_arg, uint64_t gid0,
     uint64_t seed, const StepRec* __restrict__ rec, ModelK mk, Scalars* __restrict__ sc, int slot_set,
     const double* __restrict__ src2, size_t src2_stride, uint32_t n_split, const double* __restrict__ logtab,
     uint64_t chunk, int do_sums_arg, cssm_u128* __restrict__ subS, cssm_u128* __restrict__ subS2) {
@@ -327,74 +401,158 @@ __global__ __launch_bounds__(CSSM_BLOCK, PropWaves<D>::value) void k_propagate(
   const int has_obs = rec->has_obs;
   const double dt = rec->dt;
   const bool weighted = LGCP || has_obs;
-  const bool do_sums = !LGCP && do_sums_arg && has_obs;
+  // every thread's first particle has an even global id (gid0 even; chunk, tile and IT even): whole pairs per thread
+  const bool pair_ok = (gid0 & 1ull) == 0ull;
+  // SUMS (compile time: its accumulators would otherwise hold 8 VGPRs in every kernel): the block also forms the sums
+  const bool do_sums = SUMS && !LGCP && do_sums_arg && has_obs;
   const double cref = rec->ref;
   cssm_u128 accS = cssm_u128_zero(), accS2 = cssm_u128_zero();
   double tmax = -cssm_inf();
   bool bad = false;
-  const uint64_t per_block = (uint64_t)CSSM_BLOCK * IT;
-  const uint64_t stride = per_block;
-  const uint64_t range_lo = (uint64_t)blockIdx.x * chunk;
-  const uint64_t n_all = n;
-  { const uint64_t range_hi = range_lo + chunk; n = (range_hi < n) ? range_hi : n; }   // this block's range ends at n
-  // Optional software pipeline over the block's tiles: ancestor indices two tiles ahead, gathered states
-  // one tile ahead of the tile being computed.  MEASURED SLOWER on MI355X (N = 2^24, d = 3: 320 us with
-  // the pipeline at 4 waves/SIMD + spills, 337 us at 3 waves, 280 us without), so it is compiled out:
-  // the extra live registers cost more occupancy than the overlap returns.
-  constexpr bool PF = false;
+  // tile indices are 32-bit (the library admits n <= 2^32 - 2^16 particles per handle): half the VALU work of 64-bit
+  constexpr uint32_t stride = (uint32_t)CSSM_BLOCK * IT;      // particles per tile
+  const uint32_t range_lo = blockIdx.x * (uint32_t)chunk;
+  uint32_t n;                                                 // this block's range ends at n
+  { const uint64_t range_hi = (uint64_t)range_lo + chunk; n = (uint32_t)((range_hi < n_arg) ? range_hi : n_arg); }
+  // Software pipeline over the block's tiles WITHOUT spending registers on it.  With 4 waves per SIMD the two
+  // dependent memory round trips of a tile (ancestor index -> gathered state) are exposed: a model with that
+  // latency reproduces the 3.3 TB/s the un-pipelined kernel reached for every d, and holding the next tile in VGPRs
+  // costs a wave of occupancy (measured: slower).  Instead the NEXT tile's states are fetched by asynchronous
+  // global -> LDS loads (global_load_lds_dwordx4, a gfx950 instruction: each lane fetches the 16 bytes at its own
+  // address into slot lane * 16 of a 1 KiB LDS region, no VGPR is written) while the current tile is computed, and the
+  // ancestor indices of the tile after that are fetched into the IT index registers.  A wave reads back only what it
+  // loaded itself, so no block barrier is involved.  Per wave: IT * D regions of 1 KiB.
+  // Bytes per lane and element: 16 (one dwordx4 fetch, of which the first 8 bytes are the element) while 4 blocks of
+  // that fit the CU's 160 KiB of LDS, else 8 (two dword fetches: low and high word).
+  constexpr bool STAGE = true;
+  constexpr int ES = (IT * D <= 9) ? 16 : 8;
+  constexpr int WAVE_STAGE = IT * D * 64 * ES;
+  __shared__ __attribute__((aligned(16))) unsigned char s_stage[(CSSM_BLOCK / 64) * WAVE_STAGE];
+  unsigned char* const wstage = s_stage + (size_t)(threadIdx.x >> 6) * WAVE_STAGE;
+  const uint32_t wstage_lds = __builtin_amdgcn_readfirstlane((uint32_t)(size_t)(__attribute__((address_space(3))) void*)wstage);
+  const uint32_t n_last = n - 1u;
   // indices of this thread's IT particles of the tile at `base`, clamped into range (stores are predicated)
-  auto load_idx = [&](uint64_t base, size_t (&j)[IT]) {
-    const uint64_t i0 = base + (uint64_t)threadIdx.x * IT;
+  // One vector load for every thread (anc has `stride` >= n entries rounded up to a tile, so the load of a partial or
+  // empty thread stays inside the buffer).  The indices stay PACKED two to a 64-bit register exactly as they were
+  // loaded, and nothing touches them until they are consumed: any operation on them next to the load -- even the
+  // register copy that unpacking a vector load can need -- makes the compiler wait for the load right there.
+  constexpr int NJ = (IT + 1) / 2;
+  auto load_idx = [&](uint32_t base, unsigned long long (&jp)[NJ]) {
+    const uint32_t i0 = base + threadIdx.x * IT;
     if (anc) {
-      if (i0 + IT <= n && IT == 4) {
-        const uint4 a4 = *reinterpret_cast<const uint4*>(anc + i0);
-        j[0] = a4.x; j[1 % IT] = a4.y; j[2 % IT] = a4.z; j[3 % IT] = a4.w;
-      } else if (i0 + IT <= n && IT == 2) {
-        const uint2 a2 = *reinterpret_cast<const uint2*>(anc + i0);
-        j[0] = a2.x; j[1 % IT] = a2.y;
+      if (IT == 4) {
+        const ulonglong2 a = *reinterpret_cast<const ulonglong2*>(anc + i0);
+        jp[0] = a.x; jp[NJ - 1] = a.y;
+      } else if (IT == 2) {
+        jp[0] = *reinterpret_cast<const unsigned long long*>(anc + i0);
       } else {
-#pragma unroll
-        for (int r = 0; r < IT; ++r) j[r] = (size_t)anc[(i0 + r < n) ? i0 + r : n - 1];
+        jp[0] = anc[i0];
       }
     } else {
 #pragma unroll
-      for (int r = 0; r < IT; ++r) j[r] = (size_t)((i0 + r < n) ? i0 + r : n - 1);
+      for (int q = 0; q < NJ; ++q) jp[q] = (unsigned long long)(uint32_t)(i0 + 2 * q) | ((unsigned long long)(uint32_t)(i0 + 2 * q + 1) << 32);
+    }
+  };
+  // unpacked where they are consumed; what a partial thread read beyond n is replaced by a valid index
+  auto unpack_idx = [&](uint32_t base, const unsigned long long (&jp)[NJ], uint32_t (&j)[IT]) {
+    const uint32_t i0 = base + threadIdx.x * IT;
+#pragma unroll
+    for (int r = 0; r < IT; ++r) {
+      const uint32_t v = (uint32_t)(jp[r / 2] >> (32 * (r & 1)));
+      j[r] = (i0 + r < n) ? v : n_last;
     }
   };
   // src2_stride == 0: the candidates are rows of (D + 1) doubles (state, end slot) exactly as they were received
   // (fixed-capacity exchange: the receive buffer is read in place); otherwise struct-of-arrays with that stride
-  auto gather = [&](const size_t (&j)[IT], double (&x)[IT][D]) {
+  auto ptr_of = [&](uint32_t j, int k) -> const double* {
+    if (src2 && j >= n_split)
+      return (src2_stride == 0) ? src2 + (size_t)(j - n_split) * (size_t)(D + 1) + k : src2 + (size_t)k * src2_stride + (j - n_split);
+    return src + (size_t)k * src_stride + j;
+  };
+  auto gather = [&](const uint32_t (&j)[IT], double (&x)[IT][D]) {
+#pragma unroll
+    for (int r = 0; r < IT; ++r)
+#pragma unroll
+      for (int k = 0; k < D; ++k) x[r][k] = *ptr_of(j[r], k);
+  };
+  // (every gather source is allocated with 16 spare bytes: the 16-byte fetch of the last element of a buffer stays inside it)
+  auto stage_issue = [&](const uint32_t (&j)[IT]) {
 #pragma unroll
     for (int r = 0; r < IT; ++r)
 #pragma unroll
       for (int k = 0; k < D; ++k) {
-        if (src2 && j[r] >= n_split)
-          x[r][k] = (src2_stride == 0) ? src2[(j[r] - n_split) * (size_t)(D + 1) + k] : src2[(size_t)k * src2_stride + (j[r] - n_split)];
-        else
-          x[r][k] = src[(size_t)k * src_stride + j[r]];
+        // (src2 == nullptr is uniform: without candidates from other ranks the row base stays in scalar registers)
+        const double* g = (src2 == nullptr) ? src + (size_t)k * src_stride + j[r] : ptr_of(j[r], k);
+        const uint32_t slot = wstage_lds + (uint32_t)((r * D + k) * 64 * ES);
+        if (ES == 16) {
+          lds_dma16(g, slot);
+        } else {
+          lds_dma4(g, slot);
+          lds_dma4(reinterpret_cast<const unsigned char*>(g) + 4, slot + 256u);
+        }
       }
   };
-  uint64_t base = range_lo;
-  size_t jn[IT], jnn[IT];
-  double x[IT][D], xn[IT][D];
+  auto stage_read = [&](double (&x)[IT][D]) {
+    const uint32_t lane = threadIdx.x & 63;
+#pragma unroll
+    for (int r = 0; r < IT; ++r)
+#pragma unroll
+      for (int k = 0; k < D; ++k) {
+        const unsigned char* slot = wstage + (r * D + k) * 64 * ES;
+        if (ES == 16) {
+          x[r][k] = *reinterpret_cast<const double*>(slot + lane * 16);
+        } else {
+          const uint32_t lo = *reinterpret_cast<const uint32_t*>(slot + lane * 4);
+          const uint32_t hi = *reinterpret_cast<const uint32_t*>(slot + 256 + lane * 4);
+          x[r][k] = cssm_u2d((uint64_t)lo | ((uint64_t)hi << 32));
+        }
+      }
+  };
+  uint32_t base = range_lo;
+  unsigned long long jp[NJ];
+  uint32_t jn[IT];
+  double x[IT][D];
   if (base < n) {
-    load_idx(base, jn);
-    gather(jn, x);
-    if (PF && base + stride < n) load_idx(base + stride, jn);
+    load_idx(base, jp);
+    unpack_idx(base, jp, jn);
+    if (STAGE) {
+      stage_issue(jn);                                            // tile 0 (needs its indices: the one exposed latency)
+      if (base + stride < n) load_idx(base + stride, jp);         // indices of tile 1
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      stage_read(x);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // the region is free again
+      if (base + stride < n) {
+        unpack_idx(base + stride, jp, jn);
+        stage_issue(jn);                                          // tile 1 lands while tile 0 is computed
+        if (base + 2 * stride < n) load_idx(base + 2 * stride, jp);
+      }
+    } else {
+      gather(jn, x);
+    }
   }
   for (; base < n; base += stride) {
-    const uint64_t i0 = base + (uint64_t)threadIdx.x * IT;
+    const uint32_t i0 = base + threadIdx.x * IT;
     const bool full = (i0 + IT <= n);
-    if (PF) {
-      if (base + stride < n) gather(jn, xn);                       // next tile's states
-      if (base + 2 * stride < n) load_idx(base + 2 * stride, jnn); // indices of the tile after it
-    }
     double lw[IT];
+    // weight of particle r once its state is propagated: NaN check, running max, optional fused sums
+    auto account = [&](int r) {
+      if (weighted && i0 + r < n) {
+        if (lw[r] != lw[r]) { bad = true; lw[r] = -cssm_inf(); }
+        tmax = (lw[r] > tmax) ? lw[r] : tmax;
+        if (SUMS && !LGCP && do_sums) {
+          // beyond c + CSSM_REF_BELOW the step is redone with the max anyway: keep the conversion in range
+          const double a = cssm_min_c(lw[r] - cref, CSSM_REF_BELOW);
+          const double w1 = cssm_exp(a);
+          accS = cssm_u128_add(accS, cssm_fix_from_double(w1));
+          accS2 = cssm_u128_add(accS2, cssm_fix_from_double(w1 * w1));
+        }
+      }
+    };
+    if (LGCP) {
 #pragma unroll
-    for (int r = 0; r < IT; ++r) {
-      double z[D];
-      const uint64_t gid = gid0 + i0 + r;
-      if (LGCP) {
+      for (int r = 0; r < IT; ++r) {
+        double z[D];
+        const uint64_t gid = gid0 + i0 + r;
         const int nsub = rec->n_sub;
         if (nsub == 0) {                     // dt == 0: (x, f, f), model/ParticleFilter.scala:212-213
           double g = gamma_of<D>(mk, rec, x[r]);
@@ -419,23 +577,34 @@ __global__ __launch_bounds__(CSSM_BLOCK, PropWaves<D>::value) void k_propagate(
           }
           lw[r] = gamma_of<D>(mk, rec, x[r]) - haz;                // :200,:217
         }
-      } else {
-        draw_normals<D>(seed, gid, step, CSSM_STREAM_STEP, tab, z);
-        transition<D>(mk, rec, dt, x[r], z);
+        account(r);
+      }
+    } else if (IT % 2 == 0 && pair_ok) {
+      // the thread's particles are whole pairs (2m, 2m+1): D Philox blocks + Box-Muller pairs per two particles
+#pragma unroll
+      for (int r = 0; r + 1 < IT; r += 2) {
+        propagate_pair<D>(mk, rec, dt, seed, gid0 + i0 + r, step, tab, x[r], x[(r + 1) % IT]);
         lw[r] = has_obs ? logdens<OBS>(mk, rec, gamma_of<D>(mk, rec, x[r]), tab) : 0.0;
+        account(r);
+        lw[(r + 1) % IT] = has_obs ? logdens<OBS>(mk, rec, gamma_of<D>(mk, rec, x[(r + 1) % IT]), tab) : 0.0;
+        account((r + 1) % IT);
       }
-      if (weighted && i0 + r < n) {
-        if (lw[r] != lw[r]) { bad = true; lw[r] = -cssm_inf(); }
-        tmax = (lw[r] > tmax) ? lw[r] : tmax;
-        if (!LGCP && do_sums) {
-          // beyond c + CSSM_REF_BELOW the step is redone with the max anyway: keep the conversion in range
-          double a = lw[r] - cref;
-          a = (a > CSSM_REF_BELOW) ? CSSM_REF_BELOW : a;
-          const double w1 = cssm_exp(a);
-          accS = cssm_u128_add(accS, cssm_fix_from_double(w1));
-          accS2 = cssm_u128_add(accS2, cssm_fix_from_double(w1 * w1));
-        }
+    } else {
+#pragma unroll
+      for (int r = 0; r < IT; ++r) {
+        propagate_one<D>(mk, rec, dt, seed, gid0 + i0 + r, step, tab, x[r]);
+        lw[r] = has_obs ? logdens<OBS>(mk, rec, gamma_of<D>(mk, rec, x[r]), tab) : 0.0;
+        account(r);
       }
+    }
+    // everything older is complete by now without having been waited for: the next tile's states (issued one tile of
+    // compute ago), the indices of the tile after it, and the previous tile's stores
+    if (STAGE) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      // the index registers are complete as well: tell the compiler here, or it waits for them (and with them for the
+      // stores below) where the next tile's loads are issued
+#pragma unroll
+      for (int q = 0; q < NJ; ++q) asm volatile("" : "+v"(jp[q]));
     }
     if (full && IT == 4) {
 #pragma unroll
@@ -464,26 +633,27 @@ __global__ __launch_bounds__(CSSM_BLOCK, PropWaves<D>::value) void k_propagate(
       }
     }
     // advance the pipeline
-    if (PF) {
+    if (STAGE) {
       if (base + stride < n) {
-#pragma unroll
-        for (int r = 0; r < IT; ++r)
-#pragma unroll
-          for (int k = 0; k < D; ++k) x[r][k] = xn[r][k];
+        stage_read(x);                                            // tile i + 1
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (base + 2 * stride < n) {
+          unpack_idx(base + 2 * stride, jp, jn);
+          stage_issue(jn);                                        // tile i + 2
+          if (base + 3 * stride < n) load_idx(base + 3 * stride, jp);
+        }
       }
-#pragma unroll
-      for (int r = 0; r < IT; ++r) jn[r] = jnn[r];
     } else if (base + stride < n) {
-      load_idx(base + stride, jn);
+      load_idx(base + stride, jp);
+      unpack_idx(base + stride, jp, jn);
       gather(jn, x);
     }
   }
-  (void)n_all;
   if (!weighted) return;
   tmax = wave_max(tmax);
   if ((threadIdx.x & 63) == 0) s_max[threadIdx.x >> 6] = tmax;
   if (__any(bad) && (threadIdx.x & 63) == 0) atomicOr(&sc->err, 1u);
-  if (!LGCP && do_sums) {
+  if (SUMS && !LGCP && do_sums) {
     __shared__ cssm_u128 s_sa[CSSM_BLOCK / 64], s_sb[CSSM_BLOCK / 64];
     accS = wave_sum_u128(accS);
     accS2 = wave_sum_u128(accS2);

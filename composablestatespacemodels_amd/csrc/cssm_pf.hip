@@ -33,7 +33,7 @@ static int fail(int code, const char* fmt, ...) {
   } while (0)
 
 extern "C" const char* cssm_last_error(void) { return g_err.c_str(); }
-extern "C" const char* cssm_version(void) { return "cssm_pf 0.1 (gfx950, numerics contract v1)"; }
+extern "C" const char* cssm_version(void) { return "cssm_pf 0.2 (gfx950, numerics contract v4)"; }
 
 // ------------------------------------------------------------------------------------ handle
 
@@ -342,13 +342,14 @@ static int alloc_handle(cssm_pf* pf) {
   pf->sup = (pf->ntiles + 1023u) / 1024u;
   pf->nunits = (pf->ntiles + pf->sup - 1) / pf->sup;
   {   // k_propagate: a block owns unit/split particles, a multiple of its CSSM_BLOCK * IT particles per iteration
-    const uint32_t per_block = (uint32_t)(CSSM_BLOCK * prop_items(pf->d));
-    pf->split = (per_block >= (uint32_t)CSSM_TILE) ? 1u : 2u;
+    // (the kernel pipelines its tiles through LDS and wants several of them: one block per unit)
+    pf->split = 1u;
   }
   const size_t nsums = (size_t)(pf->ntiles > 2 * pf->nunits ? pf->ntiles : 2 * pf->nunits);
   const size_t row = pf->stride * 8;
   for (int b = 0; b < 2; ++b) {
-    if (hipMalloc(&pf->state[b], row * pf->d) != hipSuccess) return fail(CSSM_ENOMEM, "hipMalloc of %zu bytes failed", row * pf->d);
+    if (hipMalloc(&pf->state[b], row * pf->d + 64) != hipSuccess)   // + spare bytes: k_propagate fetches 16 bytes per element
+      return fail(CSSM_ENOMEM, "hipMalloc of %zu bytes failed", row * pf->d);
     HIP_TRY(hipMemsetAsync(pf->state[b], 0, row * pf->d, pf->stream));
   }
   if (hipMalloc(&pf->logw, row) != hipSuccess) return fail(CSSM_ENOMEM, "hipMalloc logw");
@@ -378,7 +379,7 @@ static int create_common(const cssm_model_desc* desc, uint64_t n_global, uint64_
                          uint64_t seed, int device, void* stream, bool sharded, cssm_pf** out) {
   if (!out) return fail(CSSM_EINVAL_ARG, "out is null");
   *out = nullptr;
-  if (n_global < 1 || n_global >= 0xffffffffull) return fail(CSSM_EINVAL_ARG, "n_particles must be in [1, 2^32 - 2]");
+  if (n_global < 1 || n_global > 0xffff0000ull) return fail(CSSM_EINVAL_ARG, "n_particles must be in [1, 2^32 - 2^16]");
   if (n_local < 1 || first + n_local > n_global) return fail(CSSM_ESHARD, "shard [%llu, +%llu) outside [0, %llu)",
                                                               (unsigned long long)first, (unsigned long long)n_local, (unsigned long long)n_global);
   int ndev = 0;
@@ -490,15 +491,17 @@ static int launch_propagate(cssm_pf* pf, const StepRec* d_rec) {
 #define PROP_ARGS pf->src, pf->src_stride, anc, dst, pf->stride, pf->logw, pf->n, pf->first, pf->seed, d_rec, pf->mk, pf->sc, \
                   pf->sharded ? 0 : pf->wparity, anc ? pf->src2 : nullptr, pf->src2_stride, pf->n_split, pf->d_logtab, chunk, do_sums, \
                   pf->tileS, pf->tileS2
+#define PROP_LAUNCH(LG, OB, SM) DISPATCH_D(pf->d, k_propagate<D, LG, PropItems<D>::value, OB, SM><<<dim3(grid), dim3(CSSM_BLOCK), 0, pf->stream>>>(PROP_ARGS))
   if (pf->obs_kind == CSSM_OBS_LGCP) {
-    DISPATCH_D(pf->d, k_propagate<D, true, PropItems<D>::value, -1><<<dim3(grid), dim3(CSSM_BLOCK), 0, pf->stream>>>(PROP_ARGS));
+    PROP_LAUNCH(true, -1, false);
   } else if (pf->obs_kind == CSSM_OBS_POISSON) {
-    DISPATCH_D(pf->d, k_propagate<D, false, PropItems<D>::value, CSSM_OBS_POISSON><<<dim3(grid), dim3(CSSM_BLOCK), 0, pf->stream>>>(PROP_ARGS));
+    if (do_sums) { PROP_LAUNCH(false, CSSM_OBS_POISSON, true); } else { PROP_LAUNCH(false, CSSM_OBS_POISSON, false); }
   } else if (pf->obs_kind == CSSM_OBS_GAUSSIAN) {
-    DISPATCH_D(pf->d, k_propagate<D, false, PropItems<D>::value, CSSM_OBS_GAUSSIAN><<<dim3(grid), dim3(CSSM_BLOCK), 0, pf->stream>>>(PROP_ARGS));
+    if (do_sums) { PROP_LAUNCH(false, CSSM_OBS_GAUSSIAN, true); } else { PROP_LAUNCH(false, CSSM_OBS_GAUSSIAN, false); }
   } else {
-    DISPATCH_D(pf->d, k_propagate<D, false, PropItems<D>::value, -1><<<dim3(grid), dim3(CSSM_BLOCK), 0, pf->stream>>>(PROP_ARGS));
+    if (do_sums) { PROP_LAUNCH(false, -1, true); } else { PROP_LAUNCH(false, -1, false); }
   }
+#undef PROP_LAUNCH
 #undef PROP_ARGS
   prof_end(pf);
   HIP_TRY(hipGetLastError());
@@ -724,6 +727,70 @@ extern "C" int cssm_pf_filter(cssm_pf* pf, const double* t, const double* y, con
   return run_filter(pf, t, y, has_obs, T, ll_out, ll_t, ess_t, path);
 }
 
+// ------------------------------------------------------------------------------------ contract diagnostics
+
+__global__ void k_contract_eval(int fn, const double* __restrict__ x, size_t n, double* __restrict__ out, const double* __restrict__ logtab) {
+  const double* tab = stage_log_table(logtab);
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const double v = x[i];
+    if (fn == CSSM_FN_EXP) out[i] = cssm_exp(v);
+    else if (fn == CSSM_FN_LOG) out[i] = cssm_log(v);
+    else if (fn == CSSM_FN_LOG_UNIT) out[i] = cssm_log_unit(v, tab);
+    else if (fn == CSSM_FN_SINCOS2PI) { double sn, cs; cssm_sincos2pi(v, &sn, &cs); out[2 * i] = sn; out[2 * i + 1] = cs; }
+    else { const cssm_u128 q = cssm_fix_from_double(v); out[2 * i] = cssm_u2d(q.lo); out[2 * i + 1] = cssm_u2d(q.hi); }
+  }
+}
+template <int D>
+__global__ void k_contract_normals(uint64_t seed, uint64_t first, uint32_t step, uint32_t tag, size_t n, double* __restrict__ out,
+                                   const double* __restrict__ logtab) {
+  const double* tab = stage_log_table(logtab);
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    double z[D];
+    draw_normals<D>(seed, first + i, step, tag, tab, z);
+#pragma unroll
+    for (int k = 0; k < D; ++k) out[i * D + k] = z[k];
+  }
+}
+
+extern "C" int cssm_contract_eval(int device, int fn, const double* x, size_t n, double* out, size_t n_out) {
+  if (!x || !out || n < 1) return fail(CSSM_EINVAL_ARG, "null argument");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return fail(CSSM_EHIP, "no HIP device available (this library has no CPU path)");
+  if (device < 0 || device >= ndev) return fail(CSSM_EINVAL_ARG, "device %d out of range", device);
+  HIP_TRY(hipSetDevice(device));
+  size_t need = n, d = 0, np = 0;
+  if (fn == CSSM_FN_SINCOS2PI || fn == CSSM_FN_FIX) need = 2 * n;
+  else if (fn == CSSM_FN_PAIRED_NORMALS) {
+    if (n < 5) return fail(CSSM_EINVAL_ARG, "paired normals take {seed, first, step, tag, d}");
+    d = (size_t)x[4];
+    if (d < 1 || d > CSSM_MAX_DIM) return fail(CSSM_EINVAL_ARG, "d out of range");
+    np = n_out / d; need = np * d;
+    if (np < 1) return fail(CSSM_EINVAL_ARG, "out is too small");
+  } else if (fn < CSSM_FN_EXP || fn > CSSM_FN_FIX) return fail(CSSM_EINVAL_ARG, "unknown contract function %d", fn);
+  if (n_out < need) return fail(CSSM_EINVAL_ARG, "out holds %zu doubles, %zu needed", n_out, need);
+  double *dx = nullptr, *dout = nullptr, *dtab = nullptr;
+  int rc = CSSM_OK;
+  if (hipMalloc(&dx, n * 8) != hipSuccess || hipMalloc(&dout, need * 8) != hipSuccess || hipMalloc(&dtab, sizeof(CSSM_TAB)) != hipSuccess)
+    rc = fail(CSSM_ENOMEM, "hipMalloc");
+  if (!rc && (hipMemcpy(dx, x, n * 8, hipMemcpyHostToDevice) != hipSuccess || hipMemcpy(dtab, CSSM_TAB, sizeof(CSSM_TAB), hipMemcpyHostToDevice) != hipSuccess))
+    rc = fail(CSSM_EHIP, "upload");
+  if (!rc) {
+    if (fn == CSSM_FN_PAIRED_NORMALS) {
+      const uint64_t seed = (uint64_t)x[0], first = (uint64_t)x[1];
+      const uint32_t step = (uint32_t)x[2], tag = (uint32_t)x[3];
+      DISPATCH_D((int)d, k_contract_normals<D><<<dim3(grid_for(np, 256, 1024)), dim3(256)>>>(seed, first, step, tag, np, dout, dtab));
+    } else {
+      hipLaunchKernelGGL(k_contract_eval, dim3(grid_for(n, 256, 1024)), dim3(256), 0, 0, fn, dx, n, dout, dtab);
+    }
+    if (hipGetLastError() != hipSuccess || hipDeviceSynchronize() != hipSuccess) rc = fail(CSSM_EHIP, "contract kernel");
+  }
+  if (!rc && hipMemcpy(out, dout, need * 8, hipMemcpyDeviceToHost) != hipSuccess) rc = fail(CSSM_EHIP, "download");
+  if (dx) (void)hipFree(dx);
+  if (dout) (void)hipFree(dout);
+  if (dtab) (void)hipFree(dtab);
+  return rc;
+}
+
 extern "C" int cssm_pf_last_loop_ms(cssm_pf* pf, float* ms_out) {
   if (!pf || !ms_out) return fail(CSSM_EINVAL_ARG, "null argument");
   *ms_out = pf->last_ms;
@@ -917,7 +984,7 @@ extern "C" int cssm_pf_interpolate(cssm_pf* pf, const double* t, const double* y
   std::vector<uint8_t> weighted(T + 1, 0);
   double* save_state[2] = {pf->state[0], pf->state[1]};
   uint32_t* save_anc = pf->anc;
-  if (hipMalloc(&hx, (T + 1) * slab * 8) != hipSuccess) return fail(CSSM_ENOMEM, "history of %zu clouds does not fit (%zu bytes)", T + 1, (T + 1) * slab * 8);
+  if (hipMalloc(&hx, (T + 1) * slab * 8 + 64) != hipSuccess) return fail(CSSM_ENOMEM, "history of %zu clouds does not fit (%zu bytes)", T + 1, (T + 1) * slab * 8);
   if (hipMalloc(&hanc, (T + 1) * pf->stride * 4) != hipSuccess || hipMalloc(&bidx, pf->stride * 4) != hipSuccess) {
     (void)hipFree(hx); if (hanc) (void)hipFree(hanc);
     return fail(CSSM_ENOMEM, "ancestor history does not fit");
@@ -1410,7 +1477,7 @@ extern "C" int cssm_pf_shard_adopt(cssm_pf* pf, const double* recv_buf_dev, int6
     pf->cand = nullptr; pf->cand_end = pf->cand_idx = nullptr;
     size_t cap = (size_t)n_remote + (size_t)n_remote / 4 + CSSM_TILE;
     cap = (cap + CSSM_TILE - 1) / CSSM_TILE * CSSM_TILE;
-    if (hipMalloc(&pf->cand, cap * 8 * pf->d) != hipSuccess || hipMalloc(&pf->cand_end, cap * 4) != hipSuccess ||
+    if (hipMalloc(&pf->cand, cap * 8 * pf->d + 64) != hipSuccess || hipMalloc(&pf->cand_end, cap * 4) != hipSuccess ||
         hipMalloc(&pf->cand_idx, cap * 4) != hipSuccess)
       return fail(CSSM_ENOMEM, "hipMalloc candidate buffers (%zu particles)", cap);
     pf->cand_cap = cap;

@@ -52,6 +52,46 @@ CSSM_HD double cssm_nan(void) { return cssm_u2d(0x7ff8000000000000ULL); }
 /* 2^k for k in [-1022, 1023] */
 CSSM_HD double cssm_pow2i(int k) { return cssm_u2d((uint64_t)(k + 1023) << 52); }
 
+/*
+ * Primitives that have a one-instruction form on gfx950 and a portable form on the host.  Each pair returns the
+ * SAME value for every argument the contract functions pass (stated per primitive), so the contract stays one
+ * definition; tests/test_gpu_parity.py::test_contract_functions_on_the_device_match_the_host compares the two
+ * builds function by function on dense and edge-case samples.
+ */
+#if defined(__HIP_DEVICE_COMPILE__)
+#define CSSM_DEVICE_FORM 1
+#else
+#define CSSM_DEVICE_FORM 0
+#endif
+/* max(x, c) and min(x, c) against a finite non-zero constant c; a NaN x gives c (IEEE maxNum / minNum). */
+CSSM_HD double cssm_max_c(double x, double c) {
+#if CSSM_DEVICE_FORM
+  return __builtin_fmax(x, c);   /* v_max_f64 */
+#else
+  return (x > c) ? x : c;
+#endif
+}
+CSSM_HD double cssm_min_c(double x, double c) {
+#if CSSM_DEVICE_FORM
+  return __builtin_fmin(x, c);   /* v_min_f64 */
+#else
+  return (x < c) ? x : c;
+#endif
+}
+/* p * 2^k for p in [0.5, 2) and k in [-1100, 1100], identical WHEREVER THE RESULT IS NORMAL OR OVERFLOWS (exact
+ * scaling, +inf); the two forms may round a subnormal result differently, and cssm_exp discards those. */
+CSSM_HD double cssm_scale2(double p, int k) {
+#if CSSM_DEVICE_FORM
+  return __builtin_ldexp(p, k);  /* v_ldexp_f64 */
+#else
+  const int k1 = k >> 1, k2 = k - k1;
+  return (p * cssm_pow2i(k1)) * cssm_pow2i(k2);
+#endif
+}
+/* Round-to-nearest-even of t (|t| < 2^31) by the shifter trick: adding 1.5 * 2^52 leaves the integer in the low
+ * mantissa bits (ulp = 1), in two's complement.  Plain IEEE additions: the same on every machine. */
+#define CSSM_SHIFTER 0x1.8p52
+
 /* ------------------------------------------------------------------ Philox4x32-10 */
 
 typedef struct { uint32_t v[4]; } cssm_u32x4;
@@ -92,13 +132,19 @@ CSSM_HD cssm_u32x4 cssm_philox4x32_10(cssm_u32x4 c, uint32_t k0, uint32_t k1) {
 #define CSSM_STREAM_MULTI 6u  /* the N uniforms of multinomial resampling (Resampling.scala:93), counter id = slot */
 
 /*
- * Counter layout: word0/1 = GLOBAL particle id (so results do not depend on how particles
- * are sharded over GPUs), word2 = step (observation index, 0-based; 0 for init),
- * word3 = tag<<28 | pair.  One Philox block yields one Box-Muller PAIR of normals; the normals a
- * particle consumes within one step are numbered q = substep * d + k (k = latent component in
- * Tree.flatten order, substep = LGCP sub-step, 0 otherwise) and normal q is element q&1 of pair
- * q>>1, so no variate is generated twice and at most one is unused.  Key = the 64-bit seed.
+ * Counter layout: word0/1 = stream id, word2 = step (observation index, 0-based; 0 for init),
+ * word3 = tag<<28 | block.  One Philox block yields one Box-Muller PAIR of normals.  Key = the 64-bit seed.
+ * Stream ids are GLOBAL, so results do not depend on how particles are sharded over GPUs:
+ *   - ordinary filter steps (CSSM_STREAM_STEP) and the initial draw (CSSM_STREAM_INIT): the two particles 2m and
+ *     2m+1 share stream m = gid >> 1; of its normals, particle gid owns numbers q = (gid & 1) * d + k
+ *     (k = latent component in Tree.flatten order) and normal q is element q&1 of block q>>1 -- no variate is
+ *     generated twice and at most one per PAIR OF PARTICLES is unused (a thread that owns both particles of a pair
+ *     evaluates d blocks for them; a model of odd dimension d would otherwise waste one normal per particle);
+ *   - LGCP steps: stream id = gid, normal number q = substep * d + k, element q&1 of block q>>1;
+ *   - resampling uniforms, sampleOne, host-side PMMH draws: see the stream tags above.
  */
+CSSM_HD uint64_t cssm_pair_stream(uint64_t gid) { return gid >> 1; }
+CSSM_HD uint32_t cssm_pair_first(uint64_t gid, int d) { return (uint32_t)(gid & 1u) * (uint32_t)d; } /* q of component 0 */
 CSSM_HD cssm_u32x4 cssm_philox_draw(uint64_t seed, uint64_t gid, uint32_t step, uint32_t tag, uint32_t pair) {
   cssm_u32x4 c;
   c.v[0] = (uint32_t)gid;
@@ -120,53 +166,10 @@ CSSM_HD double cssm_u01_open0(uint32_t hi, uint32_t lo) { return cssm_u01(hi, lo
 
 /* ------------------------------------------------------------------ constant table */
 
-/* CSSM_TAB[0..255]: the log table (invc, logc pairs) of cssm_log_unit; CSSM_TAB[256..]: the other constants of
- * the hot functions.  The _t functions read their constants from a table pointer (an LDS copy on the GPU); the
- * plain functions use the same constants as literals and give the same bits (tests compare).  On MI355X the
- * literal forms measured FASTER (k_propagate 266 us vs 309 us at N = 2^24: table constants occupy VGPRs), so the
- * kernels use the literal forms; only the log table itself is staged in LDS. */
-enum {
-  CSSM_KI_LOG2E = 256,
-  CSSM_KI_LN2_HI = 257,
-  CSSM_KI_LN2_LO = 258,
-  CSSM_KI_XMAX = 259,
-  CSSM_KI_XMIN = 260,
-  CSSM_KI_OVF = 261,
-  CSSM_KI_UNF = 262,
-  CSSM_KI_E13 = 263,
-  CSSM_KI_E12 = 264,
-  CSSM_KI_E11 = 265,
-  CSSM_KI_E10 = 266,
-  CSSM_KI_E9 = 267,
-  CSSM_KI_E8 = 268,
-  CSSM_KI_E7 = 269,
-  CSSM_KI_E6 = 270,
-  CSSM_KI_E5 = 271,
-  CSSM_KI_E4 = 272,
-  CSSM_KI_E3 = 273,
-  CSSM_KI_P8 = 274,
-  CSSM_KI_P7 = 275,
-  CSSM_KI_P6 = 276,
-  CSSM_KI_P5 = 277,
-  CSSM_KI_P4 = 278,
-  CSSM_KI_P3 = 279,
-  CSSM_KI_PIO2 = 280,
-  CSSM_KI_S1 = 281,
-  CSSM_KI_S2 = 282,
-  CSSM_KI_S3 = 283,
-  CSSM_KI_S4 = 284,
-  CSSM_KI_S5 = 285,
-  CSSM_KI_S6 = 286,
-  CSSM_KI_C1 = 287,
-  CSSM_KI_C2 = 288,
-  CSSM_KI_C3 = 289,
-  CSSM_KI_C4 = 290,
-  CSSM_KI_C5 = 291,
-  CSSM_KI_C6 = 292,
-  CSSM_KI_TWOM32 = 293,
-  CSSM_KI_TWOM53 = 294,
-  CSSM_TAB_SIZE = 320
-};
+/* CSSM_TAB: the log table of cssm_log_unit, 128 (invc, logc) pairs; kernels stage it in LDS.  (All other constants
+ * of the hot functions are literals: an LDS constant table measured slower on MI355X -- k_propagate 309 us vs 266 us
+ * at N = 2^24 -- because table constants occupy VGPRs.) */
+enum { CSSM_TAB_SIZE = 256 };
 static const double CSSM_TAB[CSSM_TAB_SIZE] = {
   0x1.0000000000000p+0, 0x0.0p+0,
   0x1.fa11caa01fa12p-1, 0x1.7dc475f810a69p-7,
@@ -296,70 +299,6 @@ static const double CSSM_TAB[CSSM_TAB_SIZE] = {
   0x1.02864fc7729e9p+0, -0x1.41929f968330cp-7,
   0x1.0182436517a37p+0, -0x1.8121214586b02p-8,
   0x1.0000000000000p+0, 0x0.0p+0,
-  1.44269504088896338700e+00,
-  6.93147180369123816490e-01,
-  1.90821492927058770002e-10,
-  710.0,
-  -745.0,
-  709.782712893384,
-  -708.0,
-  1.0 / 6227020800.0,
-  1.0 / 479001600.0,
-  1.0 / 39916800.0,
-  1.0 / 3628800.0,
-  1.0 / 362880.0,
-  1.0 / 40320.0,
-  1.0 / 5040.0,
-  1.0 / 720.0,
-  1.0 / 120.0,
-  1.0 / 24.0,
-  1.0 / 6.0,
-  -1.0 / 8.0,
-  1.0 / 7.0,
-  -1.0 / 6.0,
-  1.0 / 5.0,
-  -1.0 / 4.0,
-  1.0 / 3.0,
-  1.57079632679489655800e+00,
-  -1.66666666666666324348e-01,
-  8.33333333332248946124e-03,
-  -1.98412698298579493134e-04,
-  2.75573137070700676789e-06,
-  -2.50507602534068634195e-08,
-  1.58969099521155010221e-10,
-  4.16666666666666019037e-02,
-  -1.38888888888741095749e-03,
-  2.48015872894767294178e-05,
-  -2.75573143513906633035e-07,
-  2.08757232129817482790e-09,
-  -1.13596475577881948265e-11,
-  0x1.0p-32,
-  0x1.0p-53,
-  0.0,
-  0.0,
-  0.0,
-  0.0,
-  0.0,
-  0.0,
-  0.0,
-  0.0,
-  0.0,
-  0.0,
-  0.0,
-  0.0,
-  0.0,
-  0.0,
-  0.0,
-  0.0,
-  0.0,
-  0.0,
-  0.0,
-  0.0,
-  0.0,
-  0.0,
-  0.0,
-  0.0,
-  0.0
 };
 #define CSSM_LOG_TAB CSSM_TAB
 
@@ -375,13 +314,11 @@ CSSM_HD double cssm_exp(double x) {
   const double LOG2E = 1.44269504088896338700e+00;
   const double LN2_HI = 6.93147180369123816490e-01; /* 0x3fe62e42fee00000 */
   const double LN2_LO = 1.90821492927058770002e-10; /* 0x3dea39ef35793c76 */
-  /* straight-line evaluation on a clamped argument; the edge cases are selected at the end */
-  double xc = (x > 710.0) ? 710.0 : x;
-  xc = (xc < -745.0) ? -745.0 : xc;
-  xc = (x != x) ? 0.0 : xc;
-  double t = xc * LOG2E;
-  int k = (int)(t + (t < 0.0 ? -0.5 : 0.5));
-  double kd = (double)k;
+  /* straight-line evaluation on a clamped argument (a NaN is clamped to -745 here); edge cases selected at the end */
+  const double xc = cssm_min_c(cssm_max_c(x, -745.0), 710.0);
+  const double ts = cssm_fma(xc, LOG2E, CSSM_SHIFTER); /* k = the integer nearest xc * log2(e), ties to even */
+  const double kd = ts - CSSM_SHIFTER;
+  const int k = (int)(uint32_t)cssm_d2u(ts);
   double r = cssm_fma(-kd, LN2_HI, xc);
   r = cssm_fma(-kd, LN2_LO, r);
   double p = 1.0 / 6227020800.0; /* 1/13! */
@@ -398,44 +335,9 @@ CSSM_HD double cssm_exp(double x) {
   p = cssm_fma(p, r, 0.5);
   p = cssm_fma(p, r, 1.0);
   p = cssm_fma(p, r, 1.0);
-  int k1 = k >> 1;
-  int k2 = k - k1;
-  double res = (p * cssm_pow2i(k1)) * cssm_pow2i(k2);
+  double res = cssm_scale2(p, k);
   res = (x > 709.782712893384) ? cssm_inf() : res;
   res = (x < -708.0) ? 0.0 : res;
-  res = (x != x) ? x : res;
-  return res;
-}
-
-/* cssm_exp with its constants read from `tab` (CSSM_TAB or an LDS copy): the same operations in the same order. */
-CSSM_HD double cssm_exp_t(double x, const double* tab) {
-  double xc = (x > tab[CSSM_KI_XMAX]) ? tab[CSSM_KI_XMAX] : x;
-  xc = (xc < tab[CSSM_KI_XMIN]) ? tab[CSSM_KI_XMIN] : xc;
-  xc = (x != x) ? 0.0 : xc;
-  double t = xc * tab[CSSM_KI_LOG2E];
-  int k = (int)(t + (t < 0.0 ? -0.5 : 0.5));
-  double kd = (double)k;
-  double r = cssm_fma(-kd, tab[CSSM_KI_LN2_HI], xc);
-  r = cssm_fma(-kd, tab[CSSM_KI_LN2_LO], r);
-  double p = tab[CSSM_KI_E13];
-  p = cssm_fma(p, r, tab[CSSM_KI_E12]);
-  p = cssm_fma(p, r, tab[CSSM_KI_E11]);
-  p = cssm_fma(p, r, tab[CSSM_KI_E10]);
-  p = cssm_fma(p, r, tab[CSSM_KI_E9]);
-  p = cssm_fma(p, r, tab[CSSM_KI_E8]);
-  p = cssm_fma(p, r, tab[CSSM_KI_E7]);
-  p = cssm_fma(p, r, tab[CSSM_KI_E6]);
-  p = cssm_fma(p, r, tab[CSSM_KI_E5]);
-  p = cssm_fma(p, r, tab[CSSM_KI_E4]);
-  p = cssm_fma(p, r, tab[CSSM_KI_E3]);
-  p = cssm_fma(p, r, 0.5);
-  p = cssm_fma(p, r, 1.0);
-  p = cssm_fma(p, r, 1.0);
-  int k1 = k >> 1;
-  int k2 = k - k1;
-  double res = (p * cssm_pow2i(k1)) * cssm_pow2i(k2);
-  res = (x > tab[CSSM_KI_OVF]) ? cssm_inf() : res;
-  res = (x < tab[CSSM_KI_UNF]) ? 0.0 : res;
   res = (x != x) ? x : res;
   return res;
 }
@@ -557,28 +459,6 @@ CSSM_HD void cssm_sincos2pi(double u, double* sn, double* cs) {
   *cs = cssm_u2d(cssm_d2u(cc) ^ ((uint64_t)((q + 1) & 2) << 62));
 }
 
-/* cssm_sincos2pi with its constants read from `tab`: the same operations in the same order. */
-CSSM_HD void cssm_sincos2pi_t(double u, const double* tab, double* sn, double* cs) {
-  double t = 4.0 * u;
-  int q = (int)(t + 0.5);
-  double r = t - (double)q;
-  const double x = r * tab[CSSM_KI_PIO2];
-  const double z = x * x;
-  const double rs = cssm_fma(z, cssm_fma(z, cssm_fma(z, cssm_fma(z, cssm_fma(z, tab[CSSM_KI_S6], tab[CSSM_KI_S5]), tab[CSSM_KI_S4]),
-                                                 tab[CSSM_KI_S3]), tab[CSSM_KI_S2]), tab[CSSM_KI_S1]);
-  const double s = cssm_fma(z * x, rs, x);
-  const double rc = cssm_fma(z, cssm_fma(z, cssm_fma(z, cssm_fma(z, cssm_fma(z, tab[CSSM_KI_C6], tab[CSSM_KI_C5]), tab[CSSM_KI_C4]),
-                                                 tab[CSSM_KI_C3]), tab[CSSM_KI_C2]), tab[CSSM_KI_C1]);
-  const double hz = 0.5 * z;
-  const double w = 1.0 - hz;
-  const double c = w + (((1.0 - w) - hz) + (z * z) * rc);
-  const int swap = q & 1;
-  const double ss = swap ? c : s;
-  const double cc = swap ? s : c;
-  *sn = cssm_u2d(cssm_d2u(ss) ^ ((uint64_t)(q & 2) << 62));
-  *cs = cssm_u2d(cssm_d2u(cc) ^ ((uint64_t)((q + 1) & 2) << 62));
-}
-
 /*
  * Seasonal phase: the reference evaluates cos(2*pi/P * a * t) (model/Model.scala:218-221).
  * The contract evaluates cos(2*pi*frac(a*t/P)) -- the same angle with exact period
@@ -658,24 +538,22 @@ CSSM_HD cssm_u128 cssm_u128_add(cssm_u128 a, cssm_u128 b) {
 }
 CSSM_HD int cssm_u128_is_zero(cssm_u128 a) { return (a.lo | a.hi) == 0; }
 
-/* floor(w * 2^96) for finite 0 <= w < 2^9 (weights are <= 1); negative, NaN, inf and w >= 2^9 map
- * to 0.  Straight-line: the 53-bit significand m, seen as the 128-bit number m * 2^64, is shifted
- * right by k = 1043 - biased_exponent. */
+/* floor(w * 2^96) for finite 0 <= w < 2^9 (weights are <= 1); negative, NaN, inf and w >= 2^9 map to 0.
+ * Four 32-bit digits peeled off by truncation: every subtraction and every scaling by 2^32 is exact in fp64 (the
+ * operand is a non-negative double below 2^32 and its integer part), so no rounding occurs anywhere. */
 CSSM_HD cssm_u128 cssm_fix_from_double(double w) {
   cssm_u128 r;
-  const uint64_t u = cssm_d2u(w);
-  const int e = (int)((u >> 52) & 0x7ff);
-  const uint64_t m = (u & 0x000fffffffffffffULL) | 0x0010000000000000ULL;
-  int k = 1043 - e;
-  const int valid = ((u >> 63) == 0) & (e != 0) & (e != 0x7ff) & (k >= 11);
-  k = (k > 127) ? 127 : k;
-  k = (k < 11) ? 11 : k;
-  const int big = k >= 64;
-  const int sft = k & 63;
-  const uint64_t down = m >> sft;
-  const uint64_t up = (m << 1) << (63 - sft); /* m << (64 - sft) without a shift by 64 */
-  r.hi = (valid && !big) ? down : 0;
-  r.lo = valid ? (big ? down : up) : 0;
+  const int valid = (w >= 0.0) & (w < 512.0);            /* false for NaN */
+  const double x = valid ? w : 0.0;
+  const uint32_t d3 = (uint32_t)x;                        /* integer part */
+  double t = (x - (double)d3) * 0x1.0p32;
+  const uint32_t d2 = (uint32_t)t;
+  t = (t - (double)d2) * 0x1.0p32;
+  const uint32_t d1 = (uint32_t)t;
+  t = (t - (double)d1) * 0x1.0p32;
+  const uint32_t d0 = (uint32_t)t;
+  r.hi = ((uint64_t)d3 << 32) | d2;
+  r.lo = ((uint64_t)d1 << 32) | d0;
   return r;
 }
 

@@ -203,6 +203,24 @@ int cssm_pf_set_option(cssm_pf* pf, int option, int value);
 int cssm_pf_profile(cssm_pf* pf, int enable);
 int cssm_pf_profile_read(cssm_pf* pf, double* total_ms, uint64_t* launches);
 
+/* ---- diagnostics of the numerics contract --------------------------------------------------- */
+
+/* Evaluates one function of include/cssm_numerics.h ON THE DEVICE for n arguments (so that a caller holding the host
+ * build of the same header can check that both builds agree bit for bit; the parity tests do).
+ *   CSSM_FN_EXP / CSSM_FN_LOG / CSSM_FN_LOG_UNIT: out[i] = f(x[i])
+ *   CSSM_FN_SINCOS2PI: out[2i] = sin, out[2i+1] = cos of 2 pi x[i]
+ *   CSSM_FN_FIX: out holds 2 n 64-bit words (lo, hi) of cssm_fix_from_double(x[i]), written as raw bits
+ *   CSSM_FN_PAIRED_NORMALS: x = {seed, first global particle id, step, tag, d} as doubles (n = 5 is ignored: n_out
+ *                           particles are drawn); out[i * d + k] = normal k of particle first + i
+ * n_out = number of doubles `out` can hold. */
+#define CSSM_FN_EXP 0
+#define CSSM_FN_LOG 1
+#define CSSM_FN_LOG_UNIT 2
+#define CSSM_FN_SINCOS2PI 3
+#define CSSM_FN_FIX 4
+#define CSSM_FN_PAIRED_NORMALS 5
+int cssm_contract_eval(int device, int fn, const double* x, size_t n, double* out, size_t n_out);
+
 /* ---- inspection (parity tests, `PfState.particles` on demand) ------------------------------ */
 
 uint64_t cssm_pf_num_particles(const cssm_pf* pf); /* local particle count */

@@ -224,6 +224,18 @@ static void draw_normals(const oracle_pf* pf, uint64_t gid, uint32_t step, uint3
   }
 }
 
+/* The same for an ordinary step or the initial draw, where particles 2m and 2m+1 share stream m: particle gid owns
+ * the normals q = (gid & 1) * d + k of that stream (include/cssm_numerics.h, counter layout). */
+static void draw_normals_paired(const oracle_pf* pf, uint64_t gid, uint32_t step, uint32_t tag, double* z) {
+  const uint32_t q0 = cssm_pair_first(gid, pf->d);
+  for (int k = 0; k < pf->d; ++k) {
+    uint32_t q = q0 + (uint32_t)k;
+    double z0, z1;
+    o_normal_pair(pf, cssm_philox_draw(pf->seed, cssm_pair_stream(gid), step, tag, q >> 1), &z0, &z1);
+    z[k] = (q & 1u) ? z1 : z0;
+  }
+}
+
 /* ------------------------------------------------------------------ A1 initial state */
 
 /* initialiseState, model/ParticleFilter.scala:105-108; initialState of the leaves:
@@ -232,7 +244,7 @@ static void draw_normals(const oracle_pf* pf, uint64_t gid, uint32_t step, uint3
 int oracle_pf_init(oracle_pf* pf, double t0) {
   double z[CSSM_MAX_DIM];
   for (uint64_t i = 0; i < pf->n; ++i) {
-    draw_normals(pf, pf->first + i, 0, CSSM_STREAM_INIT, 0, z);
+    draw_normals_paired(pf, pf->first + i, 0, CSSM_STREAM_INIT, z);
     for (int k = 0; k < pf->d; ++k) pf->x[i * pf->d + k] = sqrt(pf->comp[k].c0) * z[k] + pf->comp[k].m0;
   }
   memcpy(pf->x1, pf->x, (size_t)pf->n * pf->d * 8);
@@ -521,7 +533,7 @@ static int step_generic(oracle_pf* pf, double t, double y, int has_obs) {
   int d = pf->d;
   double dt = t - pf->t;                                        /* :117 */
   for (uint64_t i = 0; i < pf->n; ++i) {                        /* :118 */
-    draw_normals(pf, pf->first + i, pf->step, CSSM_STREAM_STEP, 0, z);
+    draw_normals_paired(pf, pf->first + i, pf->step, CSSM_STREAM_STEP, z);
     transition(pf, pf->x + i * d, dt, z, pf->x1 + i * d);
   }
   if (!has_obs) {                                               /* :121 */
@@ -612,7 +624,7 @@ int oracle_pf_propagate_only(oracle_pf* pf, double t, double y, int has_obs) {
     }
   } else {
     for (uint64_t i = 0; i < pf->n; ++i) {
-      draw_normals(pf, pf->first + i, pf->step, CSSM_STREAM_STEP, 0, z);
+      draw_normals_paired(pf, pf->first + i, pf->step, CSSM_STREAM_STEP, z);
       transition(pf, pf->x + i * d, dt, z, pf->x1 + i * d);
       if (has_obs) pf->w[i] = logdens(pf, gamma_of(pf, pf->x1 + i * d, t), y);
     }
@@ -845,8 +857,6 @@ void oracle_c_philox(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[
 void oracle_c_normals(uint64_t seed, uint64_t gid, uint32_t step, uint32_t tag, uint32_t pair, double* z2) {
   cssm_normal_pair(cssm_philox_draw(seed, gid, step, tag, pair), CSSM_LOG_TAB, &z2[0], &z2[1]);
 }
-void oracle_c_exp_t_v(const double* x, double* y, size_t n) { for (size_t i = 0; i < n; ++i) y[i] = cssm_exp_t(x[i], CSSM_TAB); }
-void oracle_c_sincos2pi_t_v(const double* u, double* s, double* c, size_t n) { for (size_t i = 0; i < n; ++i) cssm_sincos2pi_t(u[i], CSSM_TAB, &s[i], &c[i]); }
 void oracle_c_log_unit_v(const double* x, double* y, size_t n) { for (size_t i = 0; i < n; ++i) y[i] = cssm_log_unit(x[i], CSSM_LOG_TAB); }
 double oracle_c_lgamma_kp1(long long k) { return cssm_lgamma_kp1(k); }
 double oracle_c_lgamma(double x) { return cssm_lgamma(x); }
@@ -858,6 +868,21 @@ double oracle_c_u(uint64_t seed, uint32_t step) {
 }
 /* vectorised for ulp sweeps */
 void oracle_c_exp_v(const double* x, double* y, size_t n) { for (size_t i = 0; i < n; ++i) y[i] = cssm_exp(x[i]); }
+void oracle_c_fix_v(const double* w, uint64_t* out, size_t n) {
+  for (size_t i = 0; i < n; ++i) { cssm_u128 q = cssm_fix_from_double(w[i]); out[2 * i] = q.lo; out[2 * i + 1] = q.hi; }
+}
+/* the d normals of particles gid0 .. gid0+n-1 of an ordinary step / the initial draw (pair streams) */
+void oracle_c_paired_normals_v(uint64_t seed, uint64_t gid0, uint32_t step, uint32_t tag, int d, double* z, size_t n) {
+  for (size_t i = 0; i < n; ++i) {
+    const uint64_t gid = gid0 + i;
+    const uint32_t q0 = cssm_pair_first(gid, d);
+    for (int k = 0; k < d; ++k) {
+      double z0, z1;
+      cssm_normal_pair(cssm_philox_draw(seed, cssm_pair_stream(gid), step, tag, (q0 + (uint32_t)k) >> 1), CSSM_LOG_TAB, &z0, &z1);
+      z[i * (size_t)d + k] = ((q0 + (uint32_t)k) & 1u) ? z1 : z0;
+    }
+  }
+}
 void oracle_c_log_v(const double* x, double* y, size_t n) { for (size_t i = 0; i < n; ++i) y[i] = cssm_log(x[i]); }
 void oracle_c_sincos2pi_v(const double* u, double* s, double* c, size_t n) { for (size_t i = 0; i < n; ++i) cssm_sincos2pi(u[i], &s[i], &c[i]); }
 void oracle_c_normals_v(uint64_t seed, uint64_t gid0, uint32_t step, uint32_t tag, uint32_t pair, double* z, size_t n) {

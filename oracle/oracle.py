@@ -91,8 +91,8 @@ def lib() -> C.CDLL:
             "oracle_c_philox": (None, [_u32p, _u32p, _u32p]),
             "oracle_c_normals": (None, [C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, _dp]),
             "oracle_c_log_unit_v": (None, [_dp, _dp, C.c_size_t]),
-            "oracle_c_exp_t_v": (None, [_dp, _dp, C.c_size_t]),
-            "oracle_c_sincos2pi_t_v": (None, [_dp, _dp, _dp, C.c_size_t]),
+            "oracle_c_fix_v": (None, [_dp, C.POINTER(C.c_uint64), C.c_size_t]),
+            "oracle_c_paired_normals_v": (None, [C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32, C.c_int, _dp, C.c_size_t]),
             "oracle_c_lgamma_kp1": (C.c_double, [C.c_longlong]),
             "oracle_c_sys_count": (C.c_uint64, [C.c_double, C.c_double, C.c_uint64]),
             "oracle_c_fix_roundtrip": (C.c_double, [C.c_double]),
@@ -284,13 +284,15 @@ def c_normals(seed, gid0, step, tag, pair, n):
     z = np.zeros((n, 2)); lib().oracle_c_normals_v(seed, gid0, step, tag, pair, _p(z), n); return z
 
 
-def c_exp_t(x):
-    x = np.ascontiguousarray(x, dtype=np.float64); y = np.empty_like(x); lib().oracle_c_exp_t_v(_p(x), _p(y), x.size); return y
+def c_fix(w):
+    """cssm_fix_from_double: (lo, hi) 64-bit words per input."""
+    w = np.ascontiguousarray(w, dtype=np.float64); out = np.zeros((w.size, 2), dtype=np.uint64)
+    lib().oracle_c_fix_v(_p(w), _p(out, C.POINTER(C.c_uint64)), w.size); return out
 
 
-def c_sincos2pi_t(u):
-    u = np.ascontiguousarray(u, dtype=np.float64); s = np.empty_like(u); c = np.empty_like(u)
-    lib().oracle_c_sincos2pi_t_v(_p(u), _p(s), _p(c), u.size); return s, c
+def c_paired_normals(seed, gid0, step, tag, d, n):
+    """The d normals of each of the particles gid0 .. gid0+n-1 of an ordinary step / the initial draw (pair streams)."""
+    z = np.zeros((n, d)); lib().oracle_c_paired_normals_v(seed, gid0, step, tag, d, _p(z), n); return z
 
 
 def c_log_unit(x):

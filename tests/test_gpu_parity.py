@@ -434,3 +434,40 @@ def test_fused_sums_equal_separate_pass(name, n):
     for a, b in zip(runs[0][1:], runs[1][1:]):
         np.testing.assert_array_equal(a, b)
     assert runs[0][0] == oracle.OraclePf(model.descriptor(), n, cases.SEED).filter(t, y, has)[0]
+
+
+def _contract_eval(fn, x, n_out):
+    import ctypes as C
+    from composablestatespacemodels_amd import _abi
+    lib = _abi.load_library()
+    x = np.ascontiguousarray(x, dtype=np.float64); out = np.zeros(n_out)
+    dp = C.POINTER(C.c_double)
+    _abi.check(lib.cssm_contract_eval(0, fn, x.ctypes.data_as(dp), x.size, out.ctypes.data_as(dp), out.size))
+    return out
+
+
+def test_contract_functions_on_the_device_match_the_host():
+    """include/cssm_numerics.h compiled by hipcc for gfx950 (one-instruction min/max/ldexp forms) and by gcc for the
+    host (portable forms) must agree bit for bit, function by function, on dense samples and on the edge cases."""
+    rng = np.random.default_rng(2026)
+    edge = np.array([0.0, -0.0, np.inf, -np.inf, np.nan, 710.0, 709.782712893384, np.nextafter(709.782712893384, 1e9), 709.9, -708.0,
+                     np.nextafter(-708.0, -1e9), -745.0, -745.2, 1e300, -1e300, 0.5 * np.log(2.0), 1.5 * np.log(2.0), 5e-324, 1.0, -1.0])
+    x = np.concatenate([rng.uniform(-760, 720, 400000), rng.normal(0, 3, 400000), 709.782712893384 + rng.uniform(-1e-9, 1e-9, 20000),
+                        -708.0 + rng.uniform(-1e-9, 1e-9, 20000), edge])
+    assert np.array_equal(_contract_eval(0, x, x.size), oracle.c_exp(x), equal_nan=True)
+    xl = np.concatenate([np.exp(rng.uniform(-700, 700, 300000)), rng.random(100000), [0.0, 1.0, np.inf, 5e-324, 2.2250738585072014e-308, -1.0, np.nan]])
+    assert np.array_equal(_contract_eval(1, xl, xl.size), oracle.c_log(xl), equal_nan=True)
+    u = np.concatenate([(rng.integers(0, 2 ** 53, 300000).astype(np.float64) + 1.0) * 2.0 ** -53, [2.0 ** -53, 1.0, 0.5, 0.75, np.nextafter(1.0, 0)]])
+    assert np.array_equal(_contract_eval(2, u, u.size), oracle.c_log_unit(u))
+    v = np.concatenate([rng.random(300000), [0.0, 0.125, 0.25, 0.375, 0.5, 0.625, 0.75, 0.875, np.nextafter(1.0, 0)]])
+    sc = _contract_eval(3, v, 2 * v.size).reshape(-1, 2)
+    s_h, c_h = oracle.c_sincos2pi(v)
+    assert np.array_equal(sc[:, 0], s_h) and np.array_equal(sc[:, 1], c_h)
+    w = np.concatenate([rng.random(200000), rng.random(200000) * 2.0 ** -rng.integers(0, 1100, 200000), rng.random(1000) * 520, -rng.random(100),
+                        [0.0, 1.0, 2.0 ** -96, 2.0 ** -97, 5e-324, 511.99999999999994, 512.0, np.inf, np.nan, 403.4287934927351]])
+    fx = _contract_eval(4, w, 2 * w.size).view(np.uint64).reshape(-1, 2)
+    assert np.array_equal(fx, oracle.c_fix(w))
+    for d in (1, 2, 3, 4, 9, 16):
+        for first in (0, 7):   # even and odd first particle: both parities of the pair streams
+            z = _contract_eval(5, np.array([cases.SEED, first, 3, 0, d], dtype=np.float64), 1001 * d).reshape(-1, d)
+            np.testing.assert_array_equal(z, oracle.c_paired_normals(cases.SEED, first, 3, 0, d, 1001))

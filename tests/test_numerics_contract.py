@@ -110,10 +110,27 @@ def test_sys_count_matches_brute_force():
     assert cnt(1.0, 0.999, 16) == 16 and cnt(0.0, 0.5, 16) == 0 and cnt(0.0, 0.0, 16) == 1
 
 
-def test_table_driven_variants_are_bit_identical_to_the_literal_forms():
+def test_fixed_point_conversion_is_the_exact_floor():
+    """cssm_fix_from_double(w) = floor(w * 2^96) for finite 0 <= w < 2^9, else 0 -- against Python integers."""
+    from fractions import Fraction
     rng = np.random.default_rng(12)
-    x = np.concatenate([rng.uniform(-760, 720, 300000), rng.normal(0, 3, 100000), [0.0, np.nan, np.inf, -np.inf, 709.9, -708.5]])
-    assert np.array_equal(oracle.c_exp(x), oracle.c_exp_t(x), equal_nan=True)
-    u = rng.random(300000)
-    s1, c1 = oracle.c_sincos2pi(u); s2, c2 = oracle.c_sincos2pi_t(u)
-    assert np.array_equal(s1, s2) and np.array_equal(c1, c2)
+    w = np.concatenate([rng.random(2000), rng.random(2000) * 2.0 ** -rng.integers(0, 1100, 2000), rng.random(300) * 511.9,
+                        [0.0, 1.0, 2.0 ** -96, 2.0 ** -97, 2.0 ** -1074, 511.99999999999994, 512.0, 600.0, -1.0, np.inf, np.nan]])
+    out = oracle.c_fix(w)
+    for x, (lo, hi) in zip(w, out):
+        want = int(Fraction(x) * 2 ** 96) if (np.isfinite(x) and 0 <= x < 512) else 0
+        assert (int(hi) << 64) | int(lo) == want, x
+
+
+def test_paired_streams_share_blocks_without_reuse():
+    """Ordinary steps / initial draw: particles 2m and 2m+1 share stream m; particle gid owns normals (gid&1)*d + k of it."""
+    seed, step, tag = 99, 7, 0
+    for d in (1, 2, 3, 4, 9):
+        z = oracle.c_paired_normals(seed, 10, step, tag, d, 6)          # particles 10..15 = pairs 5, 6, 7
+        blocks = oracle.c_normals(seed, 5, step, tag, 0, 3)             # block 0 of streams 5, 6, 7
+        for m in range(3):
+            flat = np.concatenate([oracle.c_normals(seed, 5 + m, step, tag, b, 1)[0] for b in range(d)])   # blocks 0..d-1 of stream 5+m
+            np.testing.assert_array_equal(z[2 * m], flat[:d])
+            np.testing.assert_array_equal(z[2 * m + 1], flat[d:2 * d])
+        assert blocks.shape == (3, 2)
+        assert len(np.unique(z)) == z.size                              # nothing drawn twice

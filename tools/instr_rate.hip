@@ -149,9 +149,10 @@ int main() {
             {"v_readlane_b32", k_readlane}, {"v_floor_f64", k_floor_f64}, {"v_cvt_i32_f64", k_cvt_i32_f64}, {"v_div_scale_f64", k_div_scale_f64},
             {"v_div_fmas_f64", k_div_fmas_f64}, {"v_div_fixup_f64", k_div_fixup_f64}, {"ds_read_b64", k_ds_read_b64}};
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-  for (int waves = 1; waves <= 4; waves *= 4) {
+  for (int waves : {1, 2, 3, 4, 6, 8}) {
     printf("-- %d wave(s) per SIMD\n", waves);
     for (auto& k : ks) {
+      if (waves != 1 && waves != 4 && k.k != (kern_t)k_fma_f64 && k.k != (kern_t)k_xor_b32 && k.k != (kern_t)k_mad_u64_u32) continue;
       const int grid = p.multiProcessorCount * waves;   // blocks of 256 threads = 4 waves = one per SIMD
       hipLaunchKernelGGL(k.k, dim3(grid), dim3(256), 0, 0, out, 10);
       hipDeviceSynchronize();
