@@ -102,6 +102,12 @@ SYMBOLS = [
     ("cssm_pf_shard_pack", C.c_int, [_h, C.c_int, _i64p, _i64p, C.c_int, C.c_void_p]),
     ("cssm_pf_shard_adopt", C.c_int, [_h, C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_int64]),
     ("cssm_pf_shard_result", C.c_int, [_h, _dp, _i32p]),
+    ("cssm_rccl_available", C.c_int, []),
+    ("cssm_rccl_unique_id", C.c_int, [C.c_void_p]),
+    ("cssm_rccl_comm_create", C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
+    ("cssm_rccl_comm_destroy", None, [C.c_void_p]),
+    ("cssm_pf_shard_series_rccl", C.c_int, [_h, C.c_void_p, C.c_int, C.c_int, C.c_size_t, C.c_size_t, _u8p, C.c_int64,
+                                            C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     ("cssm_pmmh_run", C.c_int, [_h, _descp, _dp, C.c_size_t, C.c_double, _dp, _dp, _u8p, C.c_size_t,
                                 C.c_uint64, C.c_size_t, _dp, _dp, _i32p, _dp]),
     ("cssm_contract_eval", C.c_int, [C.c_int, C.c_int, _dp, C.c_size_t, _dp, C.c_size_t]),

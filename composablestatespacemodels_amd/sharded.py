@@ -116,6 +116,16 @@ class GpuShard:
         self._recv_keepalive = recv_buf
         _abi.check(self.lib.cssm_pf_shard_adopt_fixed(self._h, C.c_void_p(recv_buf.data_ptr()), self.rank, self.world, int(cap)))
 
+    def series_native(self, comm_handle, s_begin: int, s_end: int, weighted: np.ndarray, cap: int,
+                      send_buf: torch.Tensor, recv_buf: torch.Tensor):
+        """Observations [s_begin, s_end) with the collectives issued by the library itself (cssm_pf_shard_series_rccl)."""
+        self._recv_keepalive = recv_buf
+        w = np.ascontiguousarray(weighted, dtype=np.uint8)
+        _abi.check(self.lib.cssm_pf_shard_series_rccl(self._h, comm_handle, self.rank, self.world, int(s_begin), int(s_end),
+                                                      w.ctypes.data_as(C.POINTER(C.c_uint8)), int(cap),
+                                                      C.c_void_p(self.sums5.data_ptr()), C.c_void_p(self.all_sums.data_ptr()),
+                                                      C.c_void_p(send_buf.data_ptr()), C.c_void_p(recv_buf.data_ptr())))
+
     def status(self, T: int):
         """(ll, ess, sticky bits, capacity needed per step) of the series just run."""
         ll, ess, bits = C.c_double(), C.c_int32(), C.c_uint32()
@@ -195,6 +205,39 @@ class DistComm:
         x = torch.tensor([int(values[0])], dtype=torch.int64, device=self.device if self.device is not None else "cpu")
         self.dist.all_reduce(x, op=self.dist.ReduceOp.MAX, group=self.group)
         return int(x.item())
+
+    def native_comm(self):
+        """An RCCL communicator owned by libcssm_pf (its series loop issues the collectives itself), or None.
+
+        Only under the RCCL backend with one GPU per rank.  Rank 0 creates the id; it travels by object broadcast.
+        Set CSSM_SHARD_NATIVE=0 to stay on the torch.distributed collectives."""
+        import os
+        if getattr(self, "_native", False) is not False:
+            return self._native
+        self._native = None
+        if self.device is None or self.dist.get_backend(self.group) != "nccl" or os.environ.get("CSSM_SHARD_NATIVE", "1") == "0":
+            return None
+        lib = _abi.load_library()
+        ok = torch.tensor([1 if lib.cssm_rccl_available() else 0], dtype=torch.int64, device=self.device)
+        self.dist.all_reduce(ok, op=self.dist.ReduceOp.MIN, group=self.group)
+        if int(ok.item()) == 0:
+            return None
+        ident = C.create_string_buffer(128)
+        if self.rank == 0:
+            _abi.check(lib.cssm_rccl_unique_id(ident))
+        box = [ident.raw if self.rank == 0 else None]
+        self.dist.broadcast_object_list(box, src=self.dist.get_global_rank(self.group, 0) if self.group is not None else 0, group=self.group)
+        ident = C.create_string_buffer(box[0], 128)
+        h = C.c_void_p()
+        rc = lib.cssm_rccl_comm_create(ident, self.world, self.rank, self.device.index, C.byref(h))
+        good = torch.tensor([1 if rc == 0 else 0], dtype=torch.int64, device=self.device)
+        self.dist.all_reduce(good, op=self.dist.ReduceOp.MIN, group=self.group)
+        if int(good.item()) == 0:      # some rank failed: every rank falls back to the torch.distributed collectives
+            if rc == 0:
+                lib.cssm_rccl_comm_destroy(h)
+            return None
+        self._native = h
+        return h
 
     def barrier(self):
         self.dist.barrier(group=self.group)
@@ -338,7 +381,7 @@ class ShardedFilter:
             all_exact = exact or lgcp or attempt == 1
             for s in S:
                 s.begin(t, y, has)
-            cap, seen, done_exact = None, 0, 0
+            cap, seen, done_exact, native = None, 0, 0, None
             for k in range(T):
                 for s in S:
                     s.propagate_at(k)
@@ -350,7 +393,16 @@ class ShardedFilter:
                     continue
                 if cap is None:   # every rank must use the same capacity: agree on the largest count seen so far
                     cap = min(max(self.MIN_CAP, self.CAP_HEADROOM * comm.agree_max([seen] * len(S))), n_max)
+                    native = comm.native_comm() if (len(S) == 1 and hasattr(comm, "native_comm")) else None
                 self._resample_fixed(cap)
+                if native is not None and k + 1 < T:
+                    # the rest of the series is enqueued by the library itself: kernels and RCCL collectives on one
+                    # stream, no host-language call per observation (cssm_pf_shard_series_rccl)
+                    nb = comm.world * (cap + 1) * (self.d + 1)
+                    S[0].series_native(native, k + 1, T, weighted, cap, S[0].buffer("send_fixed", nb)[:nb],
+                                       S[0].buffer("recv_fixed", nb)[:nb])
+                    break
+            self.last_native = native is not None
             res = [s.status(T) for s in S]
             # bits 4 and 8 both mean "again, exactly"; any rank may have raised one, every rank must repeat
             bits = comm.agree_max([max(r[2] for r in res)] * len(S))

@@ -41,6 +41,7 @@ extern "C" {
 #define CSSM_ENONFINITE (-5)  /* NaN log-weight or all weights zero (reference: breeze `require` throws) */
 #define CSSM_EINVAL_ARG (-6)
 #define CSSM_ESTATE (-7)      /* call out of sequence (e.g. step before init) */
+#define CSSM_ERCCL (-8)       /* librccl.so could not be loaded, or an RCCL call failed */
 
 /* ---- model descriptor ------------------------------------------------------------------- */
 /* Latent SDE of one leaf: model/Sde.scala:98-124 (Brownian), :69-96 (GenBrownian),
@@ -317,6 +318,23 @@ int cssm_pf_shard_pack(cssm_pf* pf, int world, const int64_t* send_first_host,
 int cssm_pf_shard_adopt(cssm_pf* pf, const double* recv_buf_dev, int64_t n_low, int64_t n_high,
                         int64_t self_first, int64_t self_count);
 int cssm_pf_shard_result(cssm_pf* pf, double* ll_out, int32_t* ess_out);
+
+/* The fixed-capacity series with its collectives driven from INSIDE the library (RCCL over xGMI, resolved at run time
+ * with dlopen: the copy already in the process, else librccl.so of the ROCm installation).  Per weighted observation
+ * s in [s_begin, s_end): cssm_pf_shard_propagate_at -> ncclAllGather of 5 words per rank -> cssm_pf_shard_offspring_pack
+ * -> ncclAllToAll of (cap + 1) rows of (d + 1) doubles per pair of ranks -> cssm_pf_shard_adopt_fixed, everything
+ * enqueued on the handle's stream, no host wait.  The communicator is made from an id that rank 0 creates and hands to
+ * the other ranks by whatever channel the host has (bench.py: torch.distributed's object broadcast).
+ * weighted[s] != 0: observation s resamples.  Buffers (device): sums5 5 words, all_sums5 5 * world words, send / recv
+ * world * (cap + 1) * (d + 1) doubles each; recv must stay untouched until the next propagate has run. */
+typedef struct { char internal[128]; } cssm_rccl_id;   /* ncclUniqueId */
+int cssm_rccl_available(void);
+int cssm_rccl_unique_id(cssm_rccl_id* id_out);
+int cssm_rccl_comm_create(const cssm_rccl_id* id, int world, int rank, int device, void** comm_out);
+void cssm_rccl_comm_destroy(void* comm);
+int cssm_pf_shard_series_rccl(cssm_pf* pf, void* comm, int rank, int world, size_t s_begin, size_t s_end,
+                              const uint8_t* weighted, int64_t cap, uint64_t* sums5_dev, uint64_t* all_sums5_dev,
+                              double* send_buf_dev, double* recv_buf_dev);
 
 /* ---- PMMH host loop ---------------------------------------------------------------------- */
 /*

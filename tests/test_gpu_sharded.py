@@ -89,6 +89,17 @@ def test_rccl_world1_matches_oracle():
             ll, ess = f.ll_filter(t, y, has, exact=exact)
             assert (ll, ess) == (oll, oess[-1])
             np.testing.assert_array_equal(shard.particles(), opart)
+            if not exact:                    # the library drove the collectives of the series itself (cssm_pf_shard_series_rccl)
+                assert f.last_native, "the native RCCL series loop was not taken"
+        # the same series with the collectives issued through torch.distributed: identical bits
+        os.environ["CSSM_SHARD_NATIVE"] = "0"
+        try:
+            f2 = ShardedFilter([shard], DistComm(device=torch.device("cuda", 0)))
+            ll, ess = f2.ll_filter(t, y, has)
+            assert not f2.last_native and (ll, ess) == (oll, oess[-1])
+            np.testing.assert_array_equal(shard.particles(), opart)
+        finally:
+            del os.environ["CSSM_SHARD_NATIVE"]
         shard.close()
     finally:
         dist.destroy_process_group()
