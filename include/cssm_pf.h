@@ -193,9 +193,11 @@ int cssm_pf_set_option(cssm_pf* pf, int option, int value);
 /* Per-kernel device time, measured with HIP events recorded on the handle's stream directly
  * before and after every kernel launch of the batch loop (bench.py's `roofline` figure).
  * Enabling it inserts event records between kernels, so whole-loop throughput is measured with
- * profiling OFF.  total_ms / launches have CSSM_PROFILE_NKERNELS entries, indexed by CSSM_K_*. */
+ * profiling OFF.  The event packets themselves take time on the queue (about 2 us per bracketed launch on MI355X): the
+ * caller can calibrate that in place as (loop time with profiling - loop time without) / bracketed launches, both loop
+ * times from cssm_pf_last_loop_ms (bench.py does, and its figure then agrees with rocprofv3's kernel trace). */
 #define CSSM_K_PROPAGATE 0   /* fused gather + propagate + weight + block max */
-#define CSSM_K_DECODE_MAX 1
+#define CSSM_K_RESERVED 1
 #define CSSM_K_TILE_SUMS 2   /* exp(w - max), fixed-point tile sums */
 #define CSSM_K_SCAN_TILES 3  /* scan of tile sums, ll, ess */
 #define CSSM_K_OFFSPRING 4   /* cumulative weights -> end slots */

@@ -8,7 +8,7 @@ OUT=$R/gpurun_out/ab_${TAG}.log
 for v in "$@"; do
   for sz in "--steps 500 --warmup 20" "--steps 100 --warmup 5 --particles 16777216"; do
     echo "## $v $sz" >> $OUT
-    timeout -k 10 300 python3 $R/bench.py --no-cpu $sz $v 2>&1 | tail -1 | python3 -c "
+    timeout -k 10 300 python3 $R/bench.py --no-cpu $sz $v 2>/dev/null | tail -1 | python3 -c "
 import sys, json
 try:
     d = json.loads(sys.stdin.read())

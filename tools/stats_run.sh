@@ -16,5 +16,5 @@ for row in csv.DictReader(open(sys.argv[1])):
     if float(row['Percentage']) > 0.5:
         print(f"{row['Name'][:60]:60s} calls {row['Calls']:>5s} avg {float(row['AverageNs'])/1e3:8.1f} us min {float(row['MinNs'])/1e3:8.1f}")
 PY
-  tail -1 gpurun_out/stats_${TAG}_$s.log | python3 -c "import sys,json; d=json.loads(sys.stdin.read()); print('ms_per_step', d['ms_per_step'], 'value', d['value'])"
+  grep '^{' gpurun_out/stats_${TAG}_$s.log | tail -1 | python3 -c "import sys,json; d=json.loads(sys.stdin.read()); print('ms_per_step', d['ms_per_step'], 'value', d['value'], 'k_propagate_us(events)', d['roofline']['avg_launch_us'])"
 done
