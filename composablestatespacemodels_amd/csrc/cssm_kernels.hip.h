@@ -376,7 +376,13 @@ __device__ __forceinline__ double decode_slots(const Scalars* __restrict__ sc, i
 #ifndef CSSM_PROP_WAVES_LO
 #define CSSM_PROP_WAVES_LO 4
 #endif
-template <int D> struct PropWaves { static constexpr int value = (D <= 4) ? CSSM_PROP_WAVES_LO : 3; };
+#ifndef CSSM_PROP_WAVES_SUMS
+#define CSSM_PROP_WAVES_SUMS 4
+#endif
+// (the kernels that also form the sums need ~10 more VGPRs; at 4 waves they spill 12 bytes, and a scratch reload in the
+// compute phase waits for the prefetch like any other vector-memory operation -- measured all the same: 4 waves with
+// that spill 41.2 us/step at N = 2^20 and 375 us at 2^24, 3 waves without it 41.9 and 383)
+template <int D, bool SUMS = false> struct PropWaves { static constexpr int value = (D <= 4) ? (SUMS ? CSSM_PROP_WAVES_SUMS : CSSM_PROP_WAVES_LO) : 3; };
 
 //
 // A block owns the CONTIGUOUS range [blockIdx.x * chunk, +chunk) (chunk a multiple of CSSM_BLOCK*IT, chosen on the
@@ -384,7 +390,7 @@ template <int D> struct PropWaves { static constexpr int value = (D <= 4) ? CSSM
 // S = sum exp(w - c), S2 = sum exp(w - c)^2 in fixed point for its range, c = rec->ref being known before any
 // weight is (include/cssm_numerics.h, "reference level"): the log-sum-exp of :125-127 then needs no pass of its own.
 template <int D, bool LGCP, int IT, int OBS, bool SUMS>
-__global__ __launch_bounds__(CSSM_BLOCK, PropWaves<D>::value) void k_propagate(
+__global__ __launch_bounds__(CSSM_BLOCK, (PropWaves<D, SUMS>::value)) void k_propagate(
     const double* __restrict__ src, size_t src_stride, const uint32_t* __restrict__ anc,
     double* __restrict__ dst, size_t dst_stride, double* __restrict__ logw, uint64_t n_arg, uint64_t gid0,
     uint64_t seed, const StepRec* __restrict__ rec, ModelK mk, Scalars* __restrict__ sc, int slot_set,

@@ -176,3 +176,16 @@ def many_leaves_model(n_leaves=16):
         ps = ps | Parameters.apply(None, SdeParameter.brownianParameter(0.0, 0.05, 0.001 * (i + 1)))
         um = um | Model.poisson(Sde.brownianMotion(1))
     return um.run(ps)
+
+
+def dim_model(d: int):
+    """A model of total latent dimension d (1..16): poisson(ou(1 or 2)) |+| seasonal(24, h, ou(2 h)) -- one kernel
+    instantiation (particles per thread, LDS staging layout) per dimension."""
+    first = 1 if d % 2 else 2
+    p = Parameters.apply(None, SdeParameter.ouParameter(0.0, 0.5, 0.2, [0.1, -0.05][:first], 0.2))
+    m = Model.poisson(Sde.ouProcess(first))
+    h = (d - first) // 2
+    if h:
+        p = p | Parameters.apply(None, SdeParameter.ouParameter(0.0, 0.2, 0.2, [0.05 * ((i % 3) - 1) for i in range(2 * h)], 0.1))
+        m = m | Model.seasonal(24, h, Sde.ouProcess(2 * h))
+    return m.run(p)

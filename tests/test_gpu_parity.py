@@ -471,3 +471,24 @@ def test_contract_functions_on_the_device_match_the_host():
         for first in (0, 7):   # even and odd first particle: both parities of the pair streams
             z = _contract_eval(5, np.array([cases.SEED, first, 3, 0, d], dtype=np.float64), 1001 * d).reshape(-1, d)
             np.testing.assert_array_equal(z, oracle.c_paired_normals(cases.SEED, first, 3, 0, d, 1001))
+
+
+@pytest.mark.parametrize("d", list(range(1, 17)))
+def test_every_dimension_streaming_and_batch_bit_exact(d):
+    """One k_propagate instantiation per latent dimension (particles per thread 4 / 2 / 1, 16- or 8-byte LDS staging,
+    pair-shared normals for even IT): each against the oracle, with several tiles per block and a ragged last tile."""
+    model = cases.dim_model(d)
+    assert model.descriptor().dim == d if hasattr(model.descriptor(), "dim") else True
+    t, y, has = cases.poisson_counts(6, missing=0.2)
+    _compare_streaming(model, 3001, t, y, has)
+    n = 5 * 1024 + 77
+    g = NativePf(model, n, cases.SEED)
+    assert g.d == d
+    o = oracle.OraclePf(model.descriptor(), n, cases.SEED)
+    gl, gll, gess, _ = g.run(t, y, has)
+    ol, oll, oess, _ = o.filter(t, y, has)
+    assert gl == ol
+    np.testing.assert_array_equal(gess, oess)
+    np.testing.assert_array_equal(g.ancestors(), o.ancestors())
+    np.testing.assert_array_equal(g.particles(), o.particles())
+    g.close()
