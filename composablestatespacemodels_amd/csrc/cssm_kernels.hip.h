@@ -395,14 +395,17 @@ __global__ __launch_bounds__(CSSM_BLOCK, (PropWaves<D, SUMS>::value)) void k_pro
     double* __restrict__ dst, size_t dst_stride, double* __restrict__ logw, uint64_t n_arg, uint64_t gid0,
     uint64_t seed, const StepRec* __restrict__ rec, ModelK mk, Scalars* __restrict__ sc, int slot_set,
     const double* __restrict__ src2, size_t src2_stride, uint32_t n_split, const double* __restrict__ logtab,
-    uint64_t chunk, int do_sums_arg, cssm_u128* __restrict__ subS, cssm_u128* __restrict__ subS2) {
+    uint64_t chunk, int do_sums_arg, cssm_u128* __restrict__ subS, cssm_u128* __restrict__ subS2,
+    double* __restrict__ pick_out, uint32_t pick_slot) {
+  // pick_out != nullptr (`filter`, model/ParticleFilter.scala:157): the thread that gathers slot pick_slot holds the
+  // resampled state sampleOne chose after the PREVIOUS observation, before its transition: it records it (a launch of
+  // its own per observation would cost more than the whole sums pass at small N)
   // (Totalling the sub-unit sums in the block that finishes last -- the threadfence-reduction idiom -- was measured
   // and rejected: on this multi-XCD part every block's device-scope release fence writes the L2's dirty lines back,
   // which in a kernel that streams hundreds of MB of stores cost 130 us at N = 2^24.  k_scan_tiles does it instead.)
   // src2 != nullptr (sharded filter): ancestor indices >= n_split address the candidates received from
   // other ranks, src2[k * src2_stride + (j - n_split)]
   __shared__ double s_max[CSSM_BLOCK / 64];
-  const double* tab = stage_log_table(logtab);
   const uint32_t step = rec->step;
   const int has_obs = rec->has_obs;
   const double dt = rec->dt;
@@ -518,6 +521,7 @@ __global__ __launch_bounds__(CSSM_BLOCK, (PropWaves<D, SUMS>::value)) void k_pro
   unsigned long long jp[NJ];
   uint32_t jn[IT];
   double x[IT][D];
+  const double* tab = stage_log_table(logtab);   // (issuing the first index load before this was measured: no change)
   if (base < n) {
     load_idx(base, jp);
     unpack_idx(base, jp, jn);
@@ -539,6 +543,14 @@ __global__ __launch_bounds__(CSSM_BLOCK, (PropWaves<D, SUMS>::value)) void k_pro
   for (; base < n; base += stride) {
     const uint32_t i0 = base + threadIdx.x * IT;
     const bool full = (i0 + IT <= n);
+    if (pick_out != nullptr) {
+#pragma unroll
+      for (int r = 0; r < IT; ++r)
+        if (i0 + r == pick_slot) {
+#pragma unroll
+          for (int k = 0; k < D; ++k) pick_out[k] = x[r][k];
+        }
+    }
     double lw[IT];
     // weight of particle r once its state is propagated: NaN check, running max, optional fused sums
     auto account = [&](int r) {

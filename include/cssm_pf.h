@@ -184,9 +184,10 @@ int cssm_pf_last_loop_ms(cssm_pf* pf, float* ms_out);
 /* CSSM_OPT_FUSED_SUMS: 1 = k_propagate also forms the fixed-point sums of exp(w - c) (c = the observation's
  * reference level, cssm_numerics.h), 2 kernels per observation, and a second attempt when the max rules c out;
  * 0 = the sums are a pass of their own after the max is known, 3 kernels per observation.  Identical results
- * (both apply cssm_ref_choose).  Default: 1 on sharded handles, where it saves a collective per observation;
- * 0 on single-GPU handles, where the extra exp in the VALU-bound propagate kernel was measured to cost what the
- * separate pass costs. */
+ * (both apply cssm_ref_choose).  Default: 1 on sharded handles, where it saves a collective per observation, and on
+ * handles of at most 2^18 particles, where a step is launch-latency bound and two launches beat three (20.0 vs 21.4 us
+ * per observation at N = 100 000); 0 otherwise: at N = 2^20 both paths take the same time (within 2 %) and the lean
+ * propagate kernel is the one the roofline figure is quoted on. */
 #define CSSM_OPT_FUSED_SUMS 3
 int cssm_pf_set_option(cssm_pf* pf, int option, int value);
 
