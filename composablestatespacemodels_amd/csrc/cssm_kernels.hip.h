@@ -2,18 +2,22 @@
 //
 // Data layout in HBM: particles are struct-of-arrays fp64,
 // state[k * stride + i] = latent component k (Tree.flatten order) of particle i, two buffers
-// that ping-pong; logw[N] fp64; endslot[N] u32 (exclusive end of the run of resampling slots
-// particle j owns); anc[N] u32.  Resampling never moves particles: the NEXT propagate kernel
-// reads its input through anc[] (fused gather), so a step costs one read and one write of
-// the cloud.
+// that ping-pong; logw[N] fp64; anc[stride] u32; endslot[N] u32 (sharded filter only: exclusive end of the
+// run of resampling slots particle j owns).  Resampling never moves particles: the NEXT propagate kernel
+// reads its input through anc[] (fused gather), so a step costs one read and one write of the cloud.
 //
-// Kernels of one observation (all HBM-bound element-wise / scan work, no MFMA):
-//   k_propagate   gather + exact SDE transition (or Euler-Maruyama) + f + log-density, block
-//                 max -> one integer atomicMax per block             model/ParticleFilter.scala:118,123-124
-//   k_tile_sums   w1 = exp(w - max) in 128-bit fixed point, one (S, S2) per 1024-particle tile   :125
-//   k_scan_tiles  exclusive scan of the tile sums (single block), ll and ess                     :127-128
-//   k_offspring   per tile: LDS scan -> cumulative weight C_j -> end slot cnt(C_j)     model/Resampling.scala:52-58
-//   k_expand      per tile: slots [end_{j-1}, end_j) <- j by binary search in LDS       model/Resampling.scala:36-46,69
+// Kernels of one observation (element-wise / scan work, no MFMA):
+//   k_propagate   gather + exact SDE transition (or Euler-Maruyama) + f + log-density, block max -> one integer
+//                 atomicMax per block; the next tile's states are prefetched by asynchronous global -> LDS loads
+//                 (global_load_lds_dwordx4), the indices of the tile after it into registers; optionally (SUMS)
+//                 the fixed-point sums of exp(w - c) as well                       model/ParticleFilter.scala:118,123-124
+//   k_tile_sums   w1 = exp(w - level) in 128-bit fixed point, one (S, S2) per unit of tiles                        :125
+//   k_offspring   unit prefix + totals (every block sums the <= 1K unit sums itself), ll and ess (:127-128), per tile
+//                 a DPP wave scan -> cumulative weight C_j -> end slot cnt(C_j); every particle writes its own run of
+//                 slots into anc (single GPU), or the end slots are kept for the exchange   model/Resampling.scala:36-58,69
+//   sharded only  k_scan_tiles / k_global_sums (exact exchange), k_pack_fixed + k_expand_fixed (fixed-capacity
+//                 exchange), k_expand (candidates -> slots)
+// Cross-lane traffic is DPP, not ds_bpermute (5 vs 25 cycles per move on MI355X, tools/instr_rate.hip).
 #pragma once
 
 #include <hip/hip_runtime.h>
