@@ -401,7 +401,7 @@ __global__ __launch_bounds__(CSSM_BLOCK, (PropWaves<D, SUMS>::value)) void k_pro
     const double* __restrict__ src2, size_t src2_stride, uint32_t n_split, const double* __restrict__ logtab,
     uint64_t chunk, int do_sums_arg, cssm_u128* __restrict__ subS, cssm_u128* __restrict__ subS2,
     double* __restrict__ pick_out, uint32_t pick_slot) {
-  // pick_out != nullptr (`filter`, model/ParticleFilter.scala:157): the thread that gathers slot pick_slot holds the
+  // SUMS && pick_out != nullptr (`filter`, model/ParticleFilter.scala:157): the thread that gathers slot pick_slot holds the
   // resampled state sampleOne chose after the PREVIOUS observation, before its transition: it records it (a launch of
   // its own per observation would cost more than the whole sums pass at small N)
   // (Totalling the sub-unit sums in the block that finishes last -- the threadfence-reduction idiom -- was measured
@@ -547,7 +547,7 @@ __global__ __launch_bounds__(CSSM_BLOCK, (PropWaves<D, SUMS>::value)) void k_pro
   for (; base < n; base += stride) {
     const uint32_t i0 = base + threadIdx.x * IT;
     const bool full = (i0 + IT <= n);
-    if (pick_out != nullptr) {
+    if (SUMS && pick_out != nullptr) {   // (only the SUMS kernels carry this: it costs the lean kernel 2 % for nothing)
 #pragma unroll
       for (int r = 0; r < IT; ++r)
         if (i0 + r == pick_slot) {

@@ -479,6 +479,11 @@ static int launch_init(cssm_pf* pf, double t0) {
 
 // propagate + weight of one datum (record already on the device)
 
+// whether launch_propagate will use the kernels that also form the sums (and can record sampleOne's pick on the way)
+static bool uses_sums_kernel(const cssm_pf* pf) {
+  return pf->opt_fused && !pf->safe_sums && pf->obs_kind != CSSM_OBS_LGCP && pf->resampler != CSSM_RESAMPLE_MULTINOMIAL;
+}
+
 static int launch_propagate(cssm_pf* pf, const StepRec* d_rec, double* pick_out = nullptr, uint32_t pick_slot = 0) {
   // one block per sub-unit: contiguous ranges, so that (with do_sums) the block's fixed-point sums are the
   // sub-unit sums k_offspring scans
@@ -486,7 +491,7 @@ static int launch_propagate(cssm_pf* pf, const StepRec* d_rec, double* pick_out 
   const int grid = (int)((pf->n + chunk - 1) / chunk);
   double* dst = pf->state[pf->cur ^ 1];
   const uint32_t* anc = pf->anc_valid ? pf->anc : nullptr;
-  const int do_sums = (pf->opt_fused && !pf->safe_sums && pf->obs_kind != CSSM_OBS_LGCP && pf->resampler != CSSM_RESAMPLE_MULTINOMIAL) ? 1 : 0;
+  const int do_sums = uses_sums_kernel(pf) ? 1 : 0;
   pf->last_optimistic = do_sums != 0;
   prof_begin(pf, CSSM_K_PROPAGATE);
 #define PROP_ARGS pf->src, pf->src_stride, anc, dst, pf->stride, pf->logw, pf->n, pf->first, pf->seed, d_rec, pf->mk, pf->sc, \
@@ -692,19 +697,21 @@ static int run_filter_once(cssm_pf* pf, const double* t, const double* y, const 
                        (uint64_t)pa % pf->n, d, pf->d_path);
   }
   HIP_TRY(hipEventRecord(pf->ev0, pf->stream));
+  // path entry s + 1 = the resampled state sampleOne picks after observation s.  With the kernels that also form the
+  // sums (small handles: the PMMH case) the k_propagate of observation s + 1, which gathers exactly that state into the
+  // thread of slot pick_s, records it on the way; otherwise a one-block launch per observation does.
+  const bool fold = path && uses_sums_kernel(pf);
   for (size_t s = 0; s < T; ++s) {
     const int weighted = pf->h_recs[s].has_obs;
-    // path entry s (s >= 1) = the resampled state sampleOne picked after observation s - 1: the k_propagate of
-    // observation s gathers exactly that state into the thread of slot pick_{s-1} and records it on the way
-    double* pick_out = (path && s >= 1) ? pf->d_path + s * (size_t)d : nullptr;
+    double* pick_out = (fold && s >= 1) ? pf->d_path + s * (size_t)d : nullptr;
     rc = launch_step(pf, pf->d_recs + s, weighted, (uint32_t)s, pf->d_ll_t, pf->d_ess_t, (uint32_t)s, pick_out,
                      s >= 1 ? pf->h_recs[s - 1].pick : 0u);
     if (rc) return rc;
+    if (path && (!fold || s + 1 == T))   // (folded: only the last entry has no following propagate)
+      hipLaunchKernelGGL(k_pick, dim3(1), dim3(64), 0, pf->stream, pf->src, pf->src_stride,
+                         (const uint32_t*)(pf->anc_valid ? pf->anc : nullptr), (uint64_t)pf->h_recs[s].pick, d,
+                         pf->d_path + (s + 1) * (size_t)d);
   }
-  if (path)   // the last entry has no following propagate
-    hipLaunchKernelGGL(k_pick, dim3(1), dim3(64), 0, pf->stream, pf->src, pf->src_stride,
-                       (const uint32_t*)(pf->anc_valid ? pf->anc : nullptr), (uint64_t)pf->h_recs[T - 1].pick, d,
-                       pf->d_path + T * (size_t)d);
   HIP_TRY(hipEventRecord(pf->ev1, pf->stream));
   HIP_TRY(hipGetLastError());
   Scalars h;
