@@ -166,3 +166,24 @@ def test_fixed_capacity_series_is_repeated_exactly_when_voided(why):
     np.testing.assert_array_equal(np.concatenate([s.particles() for s in shards], axis=1), opart)
     for s in shards:
         s.close()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("d,n,T", [(2, 4099, 12), (4, 5001, 12), (6, 4100, 12), (8, 3073, 12), (16, 4097, 12)])
+def test_local_shards_every_staging_layout_with_remote_candidates(world, d, n, T):
+    """k_propagate stages the next tile through LDS with 16 bytes per element (IT * d <= 9) or 8 bytes (two dword
+    fetches); in the sharded filter part of the gathered states are candidates received from other ranks (second
+    source, rows of d + 1 doubles in the fixed-capacity series).  Odd shard starts also exercise the unpaired
+    normal streams.  Both exchanges (the first observations exact, the rest fixed-capacity) against the oracle."""
+    from composablestatespacemodels_amd.sharded import GpuShard, LocalComm, ShardedFilter
+    model = cases.dim_model(d)
+    t, y, has = cases.poisson_counts(T, missing=0.15)
+    shards = [GpuShard(model, n, r, world, cases.SEED, 0) for r in range(world)]
+    f = ShardedFilter(shards, LocalComm(world))
+    oll, oess, opart = _oracle_run(model, n, t, y, has)
+    for exact in (False, True):
+        ll, ess = f.ll_filter(t, y, has, exact=exact)
+        assert (ll, ess) == (oll, oess[-1])
+        np.testing.assert_array_equal(np.concatenate([s.particles() for s in shards], axis=1), opart)
+    for s in shards:
+        s.close()
