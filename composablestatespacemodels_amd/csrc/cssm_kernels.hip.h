@@ -882,7 +882,9 @@ __global__ __launch_bounds__(CSSM_BLOCK, CSSM_OFF_WAVES) void k_offspring(const 
                                                           int split, uint64_t seed, double* __restrict__ cum_out,
                                                           const double* __restrict__ logtab, int optimistic,
                                                           unsigned long long* __restrict__ flag_out,
-                                                          uint32_t slot_lo, uint32_t slot_hi) {
+                                                          uint32_t slot_lo, uint32_t slot_hi, uint32_t all5_stride = 5) {
+  // all5_stride: distance in words between the 5 words of consecutive ranks (5: the all-gathered array; the segment
+  // length when the words are read from the headers of the single-collective exchange, see k_boundary_pack)
   // !SELF && FUSE (sharded, stateless): only the slots [slot_lo, slot_hi) are this rank's; anc is indexed from slot_lo.
   // unitP holds `split` entries per unit (k_propagate's blocks are sub-units); all5: 5 words per rank
   // (S.lo, S.hi, S2.lo, S2.hi, order key of the rank's max); optimistic: the sums were formed relative to the
@@ -902,7 +904,7 @@ __global__ __launch_bounds__(CSSM_BLOCK, CSSM_OFF_WAVES) void k_offspring(const 
     gmax_dec = block_decode_slots(sc, slot_set);
   } else if (all5) {
     unsigned long long key = 0ull;
-    for (int r = 0; r < world; ++r) { const unsigned long long k = all5[5 * r + 4]; key = (k > key) ? k : key; }
+    for (int r = 0; r < world; ++r) { const unsigned long long k = all5[(size_t)all5_stride * r + 4]; key = (k > key) ? k : key; }
     gmax_dec = cssm_order_unkey(key);
   } else {
     gmax_dec = sc->gmax;
@@ -939,7 +941,8 @@ __global__ __launch_bounds__(CSSM_BLOCK, CSSM_OFF_WAVES) void k_offspring(const 
       cssm_u128 tot = cssm_u128_zero(), tot2 = cssm_u128_zero();
       for (int r = 0; r < world; ++r) {
         cssm_u128 a, b;
-        a.lo = all5[5 * r + 0]; a.hi = all5[5 * r + 1]; b.lo = all5[5 * r + 2]; b.hi = all5[5 * r + 3];
+        const unsigned long long* w5 = all5 + (size_t)all5_stride * r;
+        a.lo = w5[0]; a.hi = w5[1]; b.lo = w5[2]; b.hi = w5[3];
         if (r < rank) S_off = cssm_u128_add(S_off, a);
         tot = cssm_u128_add(tot, a); tot2 = cssm_u128_add(tot2, b);
       }
@@ -1219,6 +1222,236 @@ __global__ __launch_bounds__(CSSM_BLOCK) void k_expand_fixed(const double* __res
     for (uint32_t h = 0; h < nh; ++h) {
       const uint32_t he = s_he[h], hj = s_hj[h];
       for (uint32_t sl = s_hb[h] + threadIdx.x; sl < he; sl += CSSM_BLOCK) anc[sl] = hj;
+    }
+    __syncthreads();
+  }
+}
+
+// ------------------------------------------------------------------------------------ single-collective exchange
+//
+// One all-to-all per observation carries BOTH the rank's 5 sum words and its boundary particles:
+// segment r -> q of R-double rows (R = d + 1), laid out as
+//   [0, HD)                header: [0] row count, [1..5] S.lo S.hi S2.lo S2.hi max-key (raw bits), [6..7] base (u128 raw bits)
+//   [HD, HD + cap R)       rows: (state d, low word of P_j)      P_j = inclusive prefix of the fixed-point weights
+//   [HD + cap R, + capP)   high words of P_j                            WITHIN the block of particles the segment carries
+// q < r receives the rank's FIRST cap particles (base = 0), q > r its LAST cap particles (base = S_local - P_total), q = r
+// the header only (the all-to-all's own segment delivers every rank its own sums too).  The receiver knows all sums after
+// the exchange and turns base + P_j into global cumulative weights and end slots itself (k_expand_spec).
+__host__ __device__ __forceinline__ long long spec_hdr(int d) { return (long long)(d + 1) * ((8 + d) / (d + 1)); }
+__host__ __device__ __forceinline__ long long spec_capP(int d, long long cap) { return (long long)(d + 1) * ((cap + d) / (d + 1)); }
+__host__ __device__ __forceinline__ long long spec_seg(int d, long long cap) { return spec_hdr(d) + cap * (d + 1) + spec_capP(d, cap); }
+
+// grid (tiles of the block, destination rank); the weights are those k_propagate<SUMS> summed: exp(min(w - c, REF_BELOW))
+__global__ __launch_bounds__(CSSM_BLOCK) void k_boundary_pack(const double* __restrict__ src, size_t stride, const double* __restrict__ logw,
+                                                              uint64_t n_local, int d, int world, int rank, long long cap,
+                                                              const StepRec* __restrict__ rec, const cssm_u128* __restrict__ subS,
+                                                              const cssm_u128* __restrict__ subS2, uint32_t nsub,
+                                                              const Scalars* __restrict__ sc, double* __restrict__ out) {
+  __shared__ cssm_u128 s_w[CSSM_BLOCK / 64], s_r[2][CSSM_BLOCK / 64];
+  const int q = blockIdx.y;
+  const long long R = d + 1, HD = spec_hdr(d), seg = spec_seg(d, cap);
+  double* oseg = out + (size_t)q * seg;
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const long long cnt = (q == rank) ? 0 : ((long long)n_local < cap ? (long long)n_local : cap);
+  const uint64_t first = (q < rank) ? 0 : n_local - (uint64_t)cnt;     // first particle of the block the segment carries
+  const double cref = rec->ref;
+  auto tile_weights = [&](uint64_t base, cssm_u128 (&qq)[CSSM_ITEMS]) {   // particles first + base + 4 tid .. of the block
+#pragma unroll
+    for (int r = 0; r < CSSM_ITEMS; ++r) {
+      const uint64_t i = base + (uint64_t)threadIdx.x * CSSM_ITEMS + r;
+      qq[r] = (i < (uint64_t)cnt) ? cssm_fix_from_double(cssm_exp(cssm_min_c(logw[first + i] - cref, CSSM_REF_BELOW))) : cssm_u128_zero();
+    }
+  };
+  auto block_total = [&](cssm_u128 v) -> cssm_u128 {   // sum over the block's threads (uniform result)
+    v = wave_sum_u128(v);
+    __syncthreads();
+    if (lane == 0) s_w[wid] = v;
+    __syncthreads();
+    cssm_u128 t = s_w[0];
+#pragma unroll
+    for (int w = 1; w < CSSM_BLOCK / 64; ++w) t = cssm_u128_add(t, s_w[w]);
+    return t;
+  };
+  // prefix of the tiles before this block's tile
+  cssm_u128 toff = cssm_u128_zero();
+  for (uint32_t t = 0; t < blockIdx.x; ++t) {
+    cssm_u128 qq[CSSM_ITEMS];
+    tile_weights((uint64_t)t * CSSM_TILE, qq);
+    cssm_u128 a = cssm_u128_zero();
+#pragma unroll
+    for (int r = 0; r < CSSM_ITEMS; ++r) a = cssm_u128_add(a, qq[r]);
+    toff = cssm_u128_add(toff, block_total(a));
+  }
+  // this tile: inclusive prefixes, rows
+  const uint64_t base = (uint64_t)blockIdx.x * CSSM_TILE;
+  cssm_u128 qq[CSSM_ITEMS];
+  tile_weights(base, qq);
+  cssm_u128 tsum = cssm_u128_zero();
+#pragma unroll
+  for (int r = 0; r < CSSM_ITEMS; ++r) tsum = cssm_u128_add(tsum, qq[r]);
+  const cssm_u128 inc = wave_scan_u128(tsum, lane);
+  __syncthreads();
+  if (lane == 63) s_w[wid] = inc;
+  __syncthreads();
+  cssm_u128 run = toff;
+  for (int w = 0; w < wid; ++w) run = cssm_u128_add(run, s_w[w]);
+  run = cssm_u128_add(run, inc);
+  { cssm_u128 t; t.lo = run.lo - tsum.lo; t.hi = run.hi - tsum.hi - (run.lo < tsum.lo ? 1u : 0u); run = t; }   // exclusive prefix of the thread
+#pragma unroll
+  for (int r = 0; r < CSSM_ITEMS; ++r) {
+    run = cssm_u128_add(run, qq[r]);
+    const uint64_t i = base + (uint64_t)threadIdx.x * CSSM_ITEMS + r;
+    if (i < (uint64_t)cnt) {
+      double* o = oseg + HD + (long long)i * R;
+      for (int k = 0; k < d; ++k) o[k] = src[(size_t)k * stride + (size_t)(first + i)];
+      o[d] = cssm_u2d(run.lo);
+      oseg[HD + cap * R + (long long)i] = cssm_u2d(run.hi);
+    }
+  }
+  if (blockIdx.x != 0) return;
+  // header (the block of tile 0): the rank's totals of the sub-unit sums k_propagate formed, the key of its max, base
+  cssm_u128 a = cssm_u128_zero(), b = cssm_u128_zero();
+  for (uint32_t i = threadIdx.x; i < nsub; i += CSSM_BLOCK) { a = cssm_u128_add(a, subS[i]); b = cssm_u128_add(b, subS2[i]); }
+  a = wave_sum_u128(a); b = wave_sum_u128(b);
+  __syncthreads();
+  if (lane == 0) { s_r[0][wid] = a; s_r[1][wid] = b; }
+  __syncthreads();
+  unsigned long long key = 0ull;
+  if (threadIdx.x < 64) {
+    key = (threadIdx.x < CSSM_MAXSLOTS) ? sc->maxslot[(size_t)threadIdx.x * CSSM_SLOT_STRIDE] : 0ull;   // slot set 0 (sharded handles)
+    key = wave_max_u64(key);
+  }
+  // total weight of the whole block of cnt particles (for the base of a LAST block)
+  cssm_u128 ptot = cssm_u128_zero();
+  const uint32_t ntile = (uint32_t)((cnt + CSSM_TILE - 1) / CSSM_TILE);
+  if (q > rank) {
+    for (uint32_t t = 0; t < ntile; ++t) {
+      cssm_u128 q2[CSSM_ITEMS];
+      tile_weights((uint64_t)t * CSSM_TILE, q2);
+      cssm_u128 c = cssm_u128_zero();
+#pragma unroll
+      for (int r = 0; r < CSSM_ITEMS; ++r) c = cssm_u128_add(c, q2[r]);
+      ptot = cssm_u128_add(ptot, block_total(c));
+    }
+  }
+  if (threadIdx.x == 0) {
+    cssm_u128 S = s_r[0][0], S2 = s_r[1][0];
+#pragma unroll
+    for (int w = 1; w < CSSM_BLOCK / 64; ++w) { S = cssm_u128_add(S, s_r[0][w]); S2 = cssm_u128_add(S2, s_r[1][w]); }
+    cssm_u128 bs = cssm_u128_zero();
+    if (q > rank) { bs.lo = S.lo - ptot.lo; bs.hi = S.hi - ptot.hi - (S.lo < ptot.lo ? 1u : 0u); }
+    oseg[0] = (double)cnt;
+    oseg[1] = cssm_u2d(S.lo); oseg[2] = cssm_u2d(S.hi); oseg[3] = cssm_u2d(S2.lo); oseg[4] = cssm_u2d(S2.hi);
+    oseg[5] = cssm_u2d(key);
+    oseg[6] = cssm_u2d(bs.lo); oseg[7] = cssm_u2d(bs.hi);
+  }
+}
+
+// After the all-to-all: every segment's rows -> the slots of this rank they own.  Global cumulative weight of row i of
+// segment s = S_off(s) + base(s) + P_i; end slot = cnt of the contract (the sender's k_offspring arrives at the same
+// number for the same particle: its fast path equals the contract's count by construction).  Ancestor index of a slot
+// = n_split + row number in the receive buffer (in R-double rows), which k_propagate resolves in place.
+// Also: slots of this rank that neither its own particles nor the received rows own -> err bit 3 (8): exact exchange.
+__global__ __launch_bounds__(CSSM_BLOCK) void k_expand_spec(const double* __restrict__ recv, int world, int rank, long long cap, int d,
+                                                            uint32_t n_split, uint64_t slot_lo, uint64_t slot_hi, uint64_t n_global,
+                                                            const StepRec* __restrict__ rec, uint32_t* __restrict__ anc,
+                                                            Scalars* __restrict__ sc, const unsigned long long* __restrict__ redo_flag) {
+  __shared__ cssm_u128 s_S[64], s_off[64], s_base[64];
+  __shared__ long long s_cnt[64];
+  __shared__ cssm_u128 s_tot;
+  __shared__ uint32_t s_nheavy;
+  __shared__ uint32_t s_hb[CSSM_BLOCK], s_he[CSSM_BLOCK], s_hj[CSSM_BLOCK];
+  const long long R = d + 1, HD = spec_hdr(d), seg = spec_seg(d, cap);
+  if (threadIdx.x < 64) {
+    cssm_u128 S = cssm_u128_zero(), bs = cssm_u128_zero();
+    long long c = 0;
+    if ((int)threadIdx.x < world) {
+      const double* h = recv + (size_t)threadIdx.x * seg;
+      S.lo = cssm_d2u(h[1]); S.hi = cssm_d2u(h[2]); bs.lo = cssm_d2u(h[6]); bs.hi = cssm_d2u(h[7]);
+      c = (long long)h[0];
+      c = (c < 0) ? 0 : ((c > cap) ? cap : c);
+    }
+    s_S[threadIdx.x] = S; s_base[threadIdx.x] = bs; s_cnt[threadIdx.x] = c;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    cssm_u128 run = cssm_u128_zero();
+    for (int r = 0; r < world; ++r) { s_off[r] = run; run = cssm_u128_add(run, s_S[r]); }
+    s_tot = run;
+  }
+  __syncthreads();
+  const double totd = cssm_u128_to_double(s_tot);
+  const double u = rec->u;
+  const bool pow2 = (n_global & (n_global - 1)) == 0;
+  const double inv_n = 1.0 / (double)n_global;
+  auto count_of = [&](cssm_u128 G) -> uint64_t {
+    const double C = cssm_u128_to_double(G) / totd;
+    return pow2 ? cssm_sys_count_pow2(C, u, n_global, inv_n) : cssm_sys_count(C, u, n_global);
+  };
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    if (*redo_flag) atomicOr(&sc->err, 4u);        // the max ruled the reference level out: this series needs the exact path
+    // coverage of this rank's slots by its own particles and the adjacent ranks' boundary blocks
+    const uint64_t own_begin = (rank == 0) ? 0 : count_of(s_off[rank]);
+    const uint64_t own_end = count_of(cssm_u128_add(s_off[rank], s_S[rank]));
+    bool ok = true;
+    if (slot_lo < own_begin && slot_lo < slot_hi) {
+      if (rank == 0) ok = false;
+      else ok = (s_cnt[rank - 1] > 0) && count_of(cssm_u128_add(s_off[rank - 1], s_base[rank - 1])) <= slot_lo;
+    }
+    if (own_end < slot_hi && slot_lo < slot_hi) {
+      if (rank == world - 1) ok = false;           // cannot happen: the last cumulative weight is exactly 1
+      else {
+        const int s = rank + 1;
+        bool up = s_cnt[s] > 0;
+        if (up) {
+          const double* h = recv + (size_t)s * seg;
+          cssm_u128 P; P.lo = cssm_d2u(h[HD + (s_cnt[s] - 1) * R + d]); P.hi = cssm_d2u(h[HD + cap * R + (s_cnt[s] - 1)]);
+          up = count_of(cssm_u128_add(s_off[s], cssm_u128_add(s_base[s], P))) >= slot_hi;
+        }
+        ok = ok && up;
+      }
+    }
+    if (!ok) atomicOr(&sc->err, 8u);
+  }
+  if (blockIdx.x == 0 && threadIdx.x < CSSM_MAXSLOTS) sc->maxslot[(size_t)threadIdx.x * CSSM_SLOT_STRIDE] = 0ull;   // set 0 for the next step
+  const long long total = (long long)world * cap;
+  for (long long base = (long long)blockIdx.x * CSSM_BLOCK; base < total; base += (long long)gridDim.x * CSSM_BLOCK) {
+    if (threadIdx.x == 0) s_nheavy = 0;
+    __syncthreads();
+    const long long idx = base + threadIdx.x;
+    if (idx < total) {
+      const int s = (int)(idx / cap);
+      const long long i = idx - (long long)s * cap;
+      if (s != rank && i < s_cnt[s]) {
+        const double* h = recv + (size_t)s * seg;
+        const cssm_u128 off = cssm_u128_add(s_off[s], s_base[s]);
+        cssm_u128 P; P.lo = cssm_d2u(h[HD + i * R + d]); P.hi = cssm_d2u(h[HD + cap * R + i]);
+        uint64_t e = count_of(cssm_u128_add(off, P));
+        uint64_t b;
+        if (i == 0) {
+          b = cssm_u128_is_zero(off) ? 0 : count_of(off);   // (the globally first particle starts at slot 0, as in k_offspring)
+        } else {
+          cssm_u128 Pp; Pp.lo = cssm_d2u(h[HD + (i - 1) * R + d]); Pp.hi = cssm_d2u(h[HD + cap * R + (i - 1)]);
+          b = count_of(cssm_u128_add(off, Pp));
+        }
+        if (b < slot_lo) b = slot_lo;
+        if (e > slot_hi) e = slot_hi;
+        if (e > b) {
+          const uint32_t row = n_split + (uint32_t)(((long long)s * seg + HD) / R + i);
+          if (e - b <= CSSM_RUN_DIRECT) {
+            for (uint64_t sl = b; sl < e; ++sl) anc[sl - slot_lo] = row;
+          } else {
+            const uint32_t hh = atomicAdd(&s_nheavy, 1u);
+            s_hb[hh] = (uint32_t)(b - slot_lo); s_he[hh] = (uint32_t)(e - slot_lo); s_hj[hh] = row;
+          }
+        }
+      }
+    }
+    __syncthreads();
+    const uint32_t nh = s_nheavy;
+    for (uint32_t hh = 0; hh < nh; ++hh) {
+      const uint32_t he = s_he[hh], hj = s_hj[hh];
+      for (uint32_t sl = s_hb[hh] + threadIdx.x; sl < he; sl += CSSM_BLOCK) anc[sl] = hj;
     }
     __syncthreads();
   }

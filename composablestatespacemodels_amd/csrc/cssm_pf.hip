@@ -1336,8 +1336,7 @@ __global__ __launch_bounds__(256) void k_pack_fixed(const double* __restrict__ s
 static int shard_prepare_step(cssm_pf* pf, const StepRec* d_rec, int weighted, uint64_t* sums5_dev) {
   int rc = launch_propagate(pf, d_rec);
   if (rc) return rc;
-  if (weighted) {
-    if (!sums5_dev) return fail(CSSM_EINVAL_ARG, "sums5_dev is null");
+  if (weighted && sums5_dev) {   // (sums5_dev == nullptr: the single-collective exchange totals the sums in k_boundary_pack)
     // the rank's totals of the sub-unit sums k_propagate formed and the order key of its max -> 5 words for the all-gather
     const uint64_t chunk = (uint64_t)pf->sup * CSSM_TILE / pf->split;
     const uint32_t nsub = (uint32_t)((pf->n + chunk - 1) / chunk);
@@ -1427,6 +1426,58 @@ extern "C" int cssm_pf_shard_adopt_fixed(cssm_pf* pf, const double* recv_buf_dev
   const long long total = (long long)world * (cap + 1);
   hipLaunchKernelGGL(k_expand_fixed, dim3(grid_for((uint64_t)total, CSSM_BLOCK, 1024)), dim3(CSSM_BLOCK), 0, pf->stream, recv_buf_dev, world, rank,
                      (long long)cap, pf->d, n_split, pf->first, pf->first + pf->n, pf->anc, (const uint32_t*)(pf->endslot + (pf->n - 1)), pf->sc);
+  HIP_TRY(hipGetLastError());
+  pf->src = pf->state[pf->cur]; pf->src_stride = pf->stride;
+  pf->src2 = recv_buf_dev; pf->src2_stride = 0; pf->n_split = n_split; pf->anc_valid = true;   // stride 0 = rows of d + 1
+  return CSSM_OK;
+}
+
+// ---- single-collective exchange (k_boundary_pack / k_expand_spec in cssm_kernels.hip.h)
+
+extern "C" int64_t cssm_pf_shard_spec_segment(const cssm_pf* pf, int64_t cap) {
+  return (pf && cap >= 1) ? (int64_t)spec_seg(pf->d, (long long)cap) : 0;
+}
+
+extern "C" int cssm_pf_shard_boundary_pack(cssm_pf* pf, int rank, int world, int64_t cap, double* send_buf_dev) {
+  int rc = shard_check(pf);
+  if (rc) return rc;
+  if (!send_buf_dev) return fail(CSSM_EINVAL_ARG, "null argument");
+  if (cap < 1 || world < 1 || world > 64 || rank < 0 || rank >= world) return fail(CSSM_ESHARD, "rank %d / world %d / cap %lld", rank, world, (long long)cap);
+  if (!pf->last_optimistic) return fail(CSSM_ESTATE, "the single-collective exchange needs the sums k_propagate forms (not LGCP, not the second attempt)");
+  const size_t slot = last_rec_slot(pf);
+  const uint64_t chunk = (uint64_t)pf->sup * CSSM_TILE / pf->split;
+  const uint32_t nsub = (uint32_t)((pf->n + chunk - 1) / chunk);
+  const long long cnt = std::min<long long>((long long)pf->n, (long long)cap);
+  const int tiles = (int)((cnt + CSSM_TILE - 1) / CSSM_TILE);
+  hipLaunchKernelGGL(k_boundary_pack, dim3(tiles, world), dim3(CSSM_BLOCK), 0, pf->stream, pf->state[pf->cur], pf->stride, pf->logw, pf->n, pf->d,
+                     world, rank, (long long)cap, pf->d_recs + slot, (const cssm_u128*)pf->tileS, (const cssm_u128*)pf->tileS2, nsub,
+                     (const Scalars*)pf->sc, send_buf_dev);
+  HIP_TRY(hipGetLastError());
+  return CSSM_OK;
+}
+
+extern "C" int cssm_pf_shard_adopt_spec(cssm_pf* pf, const double* recv_buf_dev, int rank, int world, int64_t cap) {
+  int rc = shard_check(pf);
+  if (rc) return rc;
+  if (!recv_buf_dev) return fail(CSSM_EINVAL_ARG, "recv_buf_dev is null");
+  if (cap < 1 || world < 1 || world > 64 || rank < 0 || rank >= world) return fail(CSSM_ESHARD, "rank %d / world %d / cap %lld", rank, world, (long long)cap);
+  const uint64_t n_per = (pf->n_global + (uint64_t)world - 1) / (uint64_t)world;
+  if (pf->first != (uint64_t)rank * n_per) return fail(CSSM_ESHARD, "rank %d must own particles from %llu", rank, (unsigned long long)((uint64_t)rank * n_per));
+  const size_t slot = last_rec_slot(pf);
+  const int tgrid = (int)pf->nunits;
+  const long long seg = spec_seg(pf->d, (long long)cap);
+  // the 5 words of every rank are the header words 1..5 of its segment (the all-to-all delivered this rank's own too)
+  const unsigned long long* all5 = reinterpret_cast<const unsigned long long*>(recv_buf_dev) + 1;
+  hipLaunchKernelGGL((k_offspring<true, false, CSSM_RESAMPLE_SYSTEMATIC>), dim3(tgrid), dim3(CSSM_BLOCK), 0, pf->stream, pf->logw, pf->n, pf->sc,
+                     (const cssm_u128*)pf->tileS, (const cssm_u128*)pf->tileS2, pf->d_recs + slot, pf->n_global, pf->endslot,
+                     pf->anc, pf->ntiles, pf->sup, pf->nunits, 0, 0, (double*)nullptr, (int32_t*)nullptr, 0u, pf->opt_exact,
+                     all5, rank, world, (int)pf->split, pf->seed, (double*)nullptr, pf->d_logtab,
+                     1, (unsigned long long*)(pf->d_xch + 128), (uint32_t)pf->first, (uint32_t)(pf->first + pf->n), (uint32_t)seg);
+  const uint32_t n_split = (uint32_t)pf->n;
+  const long long total = (long long)world * cap;
+  hipLaunchKernelGGL(k_expand_spec, dim3(grid_for((uint64_t)total, CSSM_BLOCK, 1024)), dim3(CSSM_BLOCK), 0, pf->stream, recv_buf_dev, world, rank,
+                     (long long)cap, pf->d, n_split, pf->first, pf->first + pf->n, pf->n_global, pf->d_recs + slot, pf->anc, pf->sc,
+                     (const unsigned long long*)(pf->d_xch + 128));
   HIP_TRY(hipGetLastError());
   pf->src = pf->state[pf->cur]; pf->src_stride = pf->stride;
   pf->src2 = recv_buf_dev; pf->src2_stride = 0; pf->n_split = n_split; pf->anc_valid = true;   // stride 0 = rows of d + 1
@@ -1527,13 +1578,28 @@ extern "C" void cssm_rccl_comm_destroy(void* comm) {
 
 extern "C" int cssm_pf_shard_series_rccl(cssm_pf* pf, void* comm, int rank, int world, size_t s_begin, size_t s_end,
                                          const uint8_t* weighted, int64_t cap, uint64_t* sums5_dev, uint64_t* all_sums5_dev,
-                                         double* send_buf_dev, double* recv_buf_dev) {
+                                         double* send_buf_dev, double* recv_buf_dev, int single_collective) {
   int rc = shard_check(pf);
   if (rc) return rc;
   if (!comm || !weighted || !sums5_dev || !all_sums5_dev || !send_buf_dev || !recv_buf_dev) return fail(CSSM_EINVAL_ARG, "null argument");
   RcclApi* a = rccl_api();
   if (!a) return fail(CSSM_ERCCL, "librccl.so could not be loaded");
   const size_t seg = (size_t)(cap + 1) * (size_t)(pf->d + 1);   // doubles per pair of ranks
+  if (single_collective) {   // sums and boundary particles in ONE all-to-all per observation (k_boundary_pack / k_expand_spec)
+    const size_t sseg = (size_t)spec_seg(pf->d, (long long)cap);
+    for (size_t s = s_begin; s < s_end; ++s) {
+      rc = cssm_pf_shard_propagate_at(pf, s, nullptr);
+      if (rc) return rc;
+      if (!weighted[s]) continue;
+      rc = cssm_pf_shard_boundary_pack(pf, rank, world, cap, send_buf_dev);
+      if (rc) return rc;
+      const int r = a->AllToAll(send_buf_dev, recv_buf_dev, sseg, kNcclFloat64, comm, pf->stream);
+      if (r) return rccl_fail(a, "ncclAllToAll", r);
+      rc = cssm_pf_shard_adopt_spec(pf, recv_buf_dev, rank, world, cap);
+      if (rc) return rc;
+    }
+    return CSSM_OK;
+  }
   for (size_t s = s_begin; s < s_end; ++s) {
     rc = cssm_pf_shard_propagate_at(pf, s, sums5_dev);
     if (rc) return rc;

@@ -1,17 +1,19 @@
 """Particle filter sharded over the GPUs of one node: one process per GPU, particles split into
 contiguous global ranges, collectives over RCCL (``torch.distributed`` backend "nccl" on ROCm).
 
-Per observation (stage calls of include/cssm_pf.h):
+Per observation (stage calls of include/cssm_pf.h), after the first observations of a series:
 
-1. ``shard_propagate``  fused propagate + weight + local fixed-point sums of exp(w - c), c being the
-   observation's reference level (known without an exchange): 5 x u64 = S, S2, order key of the local max
-2. all-gather of 5 x u64 per rank                                 (integers: no rounding)
-3. ``shard_offspring``  global max -> c usable?  then global cumulative weights -> end slot of every local
-   particle, ll, ess, and for each destination rank the contiguous range of local particles owning its slots
-   (c unusable -- an outlying observation, or LGCP: ``shard_sums`` relative to the max, all-gather and
-   ``shard_offspring`` once more)
-4. all-to-all of the range sizes, then all-to-all-v of (d + 1) doubles per candidate particle
-5. ``shard_adopt``      expand the received candidates to this rank's slots
+1. ``shard_propagate_at``   fused propagate + weight + local fixed-point sums of exp(w - c), c being the
+   observation's reference level (known without an exchange)
+2. ``shard_boundary_pack``  for every peer one segment: header = the rank's 5 words (S, S2, order key of the local max),
+   rows = its first (for lower ranks) or last (for higher ranks) ``cap`` particles with their cumulative weights
+3. ONE equal-split all-to-all
+4. ``shard_adopt_spec``     global max -> c usable?  global cumulative weights -> ll, ess, end slots and runs of the own
+   particles; the received rows expanded to the slots the own particles left open; coverage check
+
+(``CSSM_SHARD_SINGLE=0``: the earlier exchange -- all-gather of 5 words, ``shard_offspring_pack``, all-to-all,
+``shard_adopt_fixed``.)  The first observations use the exact exchange: all-gather, ``shard_offspring``, all-to-all of
+the range sizes, all-to-all-v of (d + 1) doubles per candidate, ``shard_adopt`` -- with a host read of the sizes.
 
 Random variates are keyed by the GLOBAL particle id and every sum is an integer sum, so ll, ess
 and the ancestor arrays are bit-identical for 1, 2, 4 and 8 ranks.
@@ -105,8 +107,20 @@ class GpuShard:
         _abi.check(self.lib.cssm_pf_shard_begin(self._h, t.ctypes.data_as(dp), y.ctypes.data_as(dp),
                                                 h.ctypes.data_as(C.POINTER(C.c_uint8)), len(t)))
 
-    def propagate_at(self, s: int):
-        _abi.check(self.lib.cssm_pf_shard_propagate_at(self._h, int(s), C.c_void_p(self.sums5.data_ptr())))
+    def propagate_at(self, s: int, with_sums: bool = True):
+        """with_sums=False: the single-collective exchange totals the sums itself (boundary_pack)."""
+        _abi.check(self.lib.cssm_pf_shard_propagate_at(self._h, int(s), C.c_void_p(self.sums5.data_ptr()) if with_sums else None))
+
+    # ---- single-collective exchange: sums and boundary particles in one all-to-all
+    def spec_segment(self, cap: int) -> int:
+        return int(self.lib.cssm_pf_shard_spec_segment(self._h, int(cap)))
+
+    def boundary_pack(self, cap: int, send_buf: torch.Tensor):
+        _abi.check(self.lib.cssm_pf_shard_boundary_pack(self._h, self.rank, self.world, int(cap), C.c_void_p(send_buf.data_ptr())))
+
+    def adopt_spec(self, recv_buf: torch.Tensor, cap: int):
+        self._recv_keepalive = recv_buf
+        _abi.check(self.lib.cssm_pf_shard_adopt_spec(self._h, C.c_void_p(recv_buf.data_ptr()), self.rank, self.world, int(cap)))
 
     def offspring_pack(self, cap: int, send_buf: torch.Tensor):
         _abi.check(self.lib.cssm_pf_shard_offspring_pack(self._h, C.c_void_p(self.all_sums.data_ptr()), self.rank, self.world,
@@ -117,14 +131,15 @@ class GpuShard:
         _abi.check(self.lib.cssm_pf_shard_adopt_fixed(self._h, C.c_void_p(recv_buf.data_ptr()), self.rank, self.world, int(cap)))
 
     def series_native(self, comm_handle, s_begin: int, s_end: int, weighted: np.ndarray, cap: int,
-                      send_buf: torch.Tensor, recv_buf: torch.Tensor):
+                      send_buf: torch.Tensor, recv_buf: torch.Tensor, single_collective: bool = False):
         """Observations [s_begin, s_end) with the collectives issued by the library itself (cssm_pf_shard_series_rccl)."""
         self._recv_keepalive = recv_buf
         w = np.ascontiguousarray(weighted, dtype=np.uint8)
         _abi.check(self.lib.cssm_pf_shard_series_rccl(self._h, comm_handle, self.rank, self.world, int(s_begin), int(s_end),
                                                       w.ctypes.data_as(C.POINTER(C.c_uint8)), int(cap),
                                                       C.c_void_p(self.sums5.data_ptr()), C.c_void_p(self.all_sums.data_ptr()),
-                                                      C.c_void_p(send_buf.data_ptr()), C.c_void_p(recv_buf.data_ptr())))
+                                                      C.c_void_p(send_buf.data_ptr()), C.c_void_p(recv_buf.data_ptr()),
+                                                      1 if single_collective else 0))
 
     def status(self, T: int):
         """(ll, ess, sticky bits, capacity needed per step) of the series just run."""
@@ -364,6 +379,19 @@ class ShardedFilter:
         for s, b in zip(S, recv):
             s.adopt_fixed(b, cap)
 
+    def _resample_spec(self, cap: int):
+        """Stages after propagate with the single-collective exchange: sums (segment headers) and boundary particles
+        travel in ONE equal-split all-to-all; nothing is read by the host."""
+        S, comm = self.shards, self.comm
+        n = comm.world * S[0].spec_segment(cap)
+        send = [s.buffer("send_spec", n)[:n] for s in S]
+        recv = [s.buffer("recv_spec", n)[:n] for s in S]
+        for s, b in zip(S, send):
+            s.boundary_pack(cap, b)
+        comm.all_to_all_equal(recv, send)
+        for s, b in zip(S, recv):
+            s.adopt_spec(b, cap)
+
     # A series is begun with the exact exchange (the first observations of a filter are where the weights are most
     # uneven and the exchange largest), which also tells how much capacity the fixed exchange needs afterwards.
     EXACT_STEPS = 4
@@ -382,26 +410,43 @@ class ShardedFilter:
             for s in S:
                 s.begin(t, y, has)
             cap, seen, done_exact, native = None, 0, 0, None
+            import os
+            single = (not lgcp) and all(hasattr(s, "boundary_pack") for s in S) and os.environ.get("CSSM_SHARD_SINGLE", "1") != "0"
             for k in range(T):
+                exact_k = bool(weighted[k]) and (all_exact or done_exact < self.EXACT_STEPS)
+                if weighted[k] and not exact_k and cap is None:
+                    # every rank must use the same capacity: agree on the largest count seen so far
+                    cap = min(max(self.MIN_CAP, self.CAP_HEADROOM * comm.agree_max([seen] * len(S))), n_max)
+                    native = comm.native_comm() if (len(S) == 1 and hasattr(comm, "native_comm")) else None
+                spec_k = bool(weighted[k]) and not exact_k and single
                 for s in S:
-                    s.propagate_at(k)
+                    if spec_k:
+                        s.propagate_at(k, with_sums=False)
+                    else:
+                        s.propagate_at(k)
                 if not weighted[k]:
                     continue
-                if all_exact or done_exact < self.EXACT_STEPS:
+                if exact_k:
                     seen = max(seen, self._resample_exact(lgcp))
                     done_exact += 1
                     continue
-                if cap is None:   # every rank must use the same capacity: agree on the largest count seen so far
-                    cap = min(max(self.MIN_CAP, self.CAP_HEADROOM * comm.agree_max([seen] * len(S))), n_max)
-                    native = comm.native_comm() if (len(S) == 1 and hasattr(comm, "native_comm")) else None
-                self._resample_fixed(cap)
+                if spec_k:
+                    self._resample_spec(cap)
+                else:
+                    self._resample_fixed(cap)
                 if native is not None and k + 1 < T:
                     # the rest of the series is enqueued by the library itself: kernels and RCCL collectives on one
                     # stream, no host-language call per observation (cssm_pf_shard_series_rccl)
-                    nb = comm.world * (cap + 1) * (self.d + 1)
-                    S[0].series_native(native, k + 1, T, weighted, cap, S[0].buffer("send_fixed", nb)[:nb],
-                                       S[0].buffer("recv_fixed", nb)[:nb])
+                    if single:
+                        nb = comm.world * S[0].spec_segment(cap)
+                        S[0].series_native(native, k + 1, T, weighted, cap, S[0].buffer("send_spec", nb)[:nb],
+                                           S[0].buffer("recv_spec", nb)[:nb], single_collective=True)
+                    else:
+                        nb = comm.world * (cap + 1) * (self.d + 1)
+                        S[0].series_native(native, k + 1, T, weighted, cap, S[0].buffer("send_fixed", nb)[:nb],
+                                           S[0].buffer("recv_fixed", nb)[:nb])
                     break
+            self.last_single = single
             self.last_native = native is not None
             res = [s.status(T) for s in S]
             # bits 4 and 8 both mean "again, exactly"; any rank may have raised one, every rank must repeat

@@ -329,7 +329,8 @@ int cssm_pf_shard_result(cssm_pf* pf, double* ll_out, int32_t* ess_out);
  * enqueued on the handle's stream, no host wait.  The communicator is made from an id that rank 0 creates and hands to
  * the other ranks by whatever channel the host has (bench.py: torch.distributed's object broadcast).
  * weighted[s] != 0: observation s resamples.  Buffers (device): sums5 5 words, all_sums5 5 * world words, send / recv
- * world * (cap + 1) * (d + 1) doubles each; recv must stay untouched until the next propagate has run. */
+ * world * (cap + 1) * (d + 1) doubles each (single_collective: world * cssm_pf_shard_spec_segment doubles); recv must stay
+ * untouched until the next propagate has run. */
 typedef struct { char internal[128]; } cssm_rccl_id;   /* ncclUniqueId */
 int cssm_rccl_available(void);
 int cssm_rccl_unique_id(cssm_rccl_id* id_out);
@@ -337,7 +338,22 @@ int cssm_rccl_comm_create(const cssm_rccl_id* id, int world, int rank, int devic
 void cssm_rccl_comm_destroy(void* comm);
 int cssm_pf_shard_series_rccl(cssm_pf* pf, void* comm, int rank, int world, size_t s_begin, size_t s_end,
                               const uint8_t* weighted, int64_t cap, uint64_t* sums5_dev, uint64_t* all_sums5_dev,
-                              double* send_buf_dev, double* recv_buf_dev);
+                              double* send_buf_dev, double* recv_buf_dev, int single_collective);
+
+/* The single-collective exchange (single_collective != 0 above; stage calls for hosts that issue the collective themselves):
+ * ONE equal-split all-to-all per observation carries the rank's 5 sum words (segment header) AND its boundary particles
+ * -- to every lower rank its first `cap` particles, to every higher rank its last `cap`, each with the inclusive prefix
+ * of its fixed-point weight within that block -- so no all-gather precedes it.  The receiver, holding every rank's sums
+ * after the exchange, turns the prefixes into global end slots itself.  Slots of a rank owned neither by its own particles
+ * nor by the adjacent ranks' boundary blocks raise the same sticky bit 8 as a count above `cap` does (exact exchange).
+ *   cssm_pf_shard_spec_segment    doubles per pair of ranks for capacity `cap` (send / recv buffers: world segments)
+ *   cssm_pf_shard_propagate_at    with sums5_dev = NULL (the totals are formed by the next call)
+ *   cssm_pf_shard_boundary_pack   header + boundary rows for every destination
+ *   (all-to-all of cssm_pf_shard_spec_segment doubles per pair)
+ *   cssm_pf_shard_adopt_spec      offspring of the own particles, expansion of the received rows, coverage check */
+int64_t cssm_pf_shard_spec_segment(const cssm_pf* pf, int64_t cap);
+int cssm_pf_shard_boundary_pack(cssm_pf* pf, int rank, int world, int64_t cap, double* send_buf_dev);
+int cssm_pf_shard_adopt_spec(cssm_pf* pf, const double* recv_buf_dev, int rank, int world, int64_t cap);
 
 /* ---- PMMH host loop ---------------------------------------------------------------------- */
 /*
