@@ -871,7 +871,7 @@ __global__ void k_global_sums(const unsigned long long* __restrict__ all4, int r
 #define CSSM_OFF_WAVES 4
 #endif
 template <bool FUSE, bool SELF, int RS>
-__global__ __launch_bounds__(CSSM_BLOCK, CSSM_OFF_WAVES) void k_offspring(const double* __restrict__ logw, uint64_t n,
+__device__ __forceinline__ void offspring_body(const double* __restrict__ logw, uint64_t n,
                                                           Scalars* __restrict__ sc,
                                                           const cssm_u128* __restrict__ unitP, const cssm_u128* __restrict__ unitS2,
                                                           const StepRec* __restrict__ rec, uint64_t n_global,
@@ -882,7 +882,7 @@ __global__ __launch_bounds__(CSSM_BLOCK, CSSM_OFF_WAVES) void k_offspring(const 
                                                           int split, uint64_t seed, double* __restrict__ cum_out,
                                                           const double* __restrict__ logtab, int optimistic,
                                                           unsigned long long* __restrict__ flag_out,
-                                                          uint32_t slot_lo, uint32_t slot_hi, uint32_t all5_stride = 5) {
+                                                          uint32_t slot_lo, uint32_t slot_hi, uint32_t all5_stride) {
   // all5_stride: distance in words between the 5 words of consecutive ranks (5: the all-gathered array; the segment
   // length when the words are read from the headers of the single-collective exchange, see k_boundary_pack)
   // !SELF && FUSE (sharded, stateless): only the slots [slot_lo, slot_hi) are this rank's; anc is indexed from slot_lo.
@@ -924,8 +924,9 @@ __global__ __launch_bounds__(CSSM_BLOCK, CSSM_OFF_WAVES) void k_offspring(const 
         if (threadIdx.x == 0) { sc->gmax = gmax_dec; atomicOr(&sc->err, 4u); }
         if (threadIdx.x < CSSM_MAXSLOTS) sc->maxslot[((size_t)(slot_set ^ 1) * CSSM_MAXSLOTS + threadIdx.x) * CSSM_SLOT_STRIDE] = 0ull;
       }
-    } else if (blockIdx.x == 0 && threadIdx.x == 0 && flag_out) {
-      *flag_out = 1ull;
+    } else if (blockIdx.x == 0 && threadIdx.x == 0) {
+      if (flag_out) *flag_out = 1ull;
+      if (optimistic == 2) atomicOr(&sc->err, 4u);   // (merged with the expansion: no later kernel reads the flag)
     }
     return;
   }
@@ -1117,6 +1118,22 @@ __global__ __launch_bounds__(CSSM_BLOCK, CSSM_OFF_WAVES) void k_offspring(const 
       __syncthreads();
     }
   }
+}
+
+#define CSSM_OFFSPRING_PARAMS                                                                                              \
+  const double* __restrict__ logw, uint64_t n, Scalars* __restrict__ sc, const cssm_u128* __restrict__ unitP,              \
+  const cssm_u128* __restrict__ unitS2, const StepRec* __restrict__ rec, uint64_t n_global, uint32_t* __restrict__ endslot, \
+  uint32_t* __restrict__ anc, uint32_t ntiles, uint32_t sup, uint32_t nunits, int raw, int slot_set,                        \
+  double* __restrict__ ll_t, int32_t* __restrict__ ess_t, uint32_t rec_idx, int force_exact,                                \
+  const unsigned long long* __restrict__ all5, int rank, int world, int split, uint64_t seed, double* __restrict__ cum_out, \
+  const double* __restrict__ logtab, int optimistic, unsigned long long* __restrict__ flag_out, uint32_t slot_lo, uint32_t slot_hi
+#define CSSM_OFFSPRING_FWD                                                                                                   \
+  logw, n, sc, unitP, unitS2, rec, n_global, endslot, anc, ntiles, sup, nunits, raw, slot_set, ll_t, ess_t, rec_idx,       \
+  force_exact, all5, rank, world, split, seed, cum_out, logtab, optimistic, flag_out, slot_lo, slot_hi
+
+template <bool FUSE, bool SELF, int RS>
+__global__ __launch_bounds__(CSSM_BLOCK, CSSM_OFF_WAVES) void k_offspring(CSSM_OFFSPRING_PARAMS, uint32_t all5_stride = 5) {
+  offspring_body<FUSE, SELF, RS>(CSSM_OFFSPRING_FWD, all5_stride);
 }
 
 // ------------------------------------------------------------------------------------ expand
@@ -1352,10 +1369,10 @@ __global__ __launch_bounds__(CSSM_BLOCK) void k_boundary_pack(const double* __re
 // number for the same particle: its fast path equals the contract's count by construction).  Ancestor index of a slot
 // = n_split + row number in the receive buffer (in R-double rows), which k_propagate resolves in place.
 // Also: slots of this rank that neither its own particles nor the received rows own -> err bit 3 (8): exact exchange.
-__global__ __launch_bounds__(CSSM_BLOCK) void k_expand_spec(const double* __restrict__ recv, int world, int rank, long long cap, int d,
-                                                            uint32_t n_split, uint64_t slot_lo, uint64_t slot_hi, uint64_t n_global,
-                                                            const StepRec* __restrict__ rec, uint32_t* __restrict__ anc,
-                                                            Scalars* __restrict__ sc, const unsigned long long* __restrict__ redo_flag) {
+__device__ __forceinline__ void expand_spec_body(uint32_t bid, uint32_t nblk, const double* __restrict__ recv, int world, int rank, long long cap, int d,
+                                                 uint32_t n_split, uint64_t slot_lo, uint64_t slot_hi, uint64_t n_global,
+                                                 const StepRec* __restrict__ rec, uint32_t* __restrict__ anc,
+                                                 Scalars* __restrict__ sc, const unsigned long long* __restrict__ redo_flag) {
   __shared__ cssm_u128 s_S[64], s_off[64], s_base[64];
   __shared__ long long s_cnt[64];
   __shared__ cssm_u128 s_tot;
@@ -1388,8 +1405,8 @@ __global__ __launch_bounds__(CSSM_BLOCK) void k_expand_spec(const double* __rest
     const double C = cssm_u128_to_double(G) / totd;
     return pow2 ? cssm_sys_count_pow2(C, u, n_global, inv_n) : cssm_sys_count(C, u, n_global);
   };
-  if (blockIdx.x == 0 && threadIdx.x == 0) {
-    if (*redo_flag) atomicOr(&sc->err, 4u);        // the max ruled the reference level out: this series needs the exact path
+  if (bid == 0 && threadIdx.x == 0) {
+    if (redo_flag && *redo_flag) atomicOr(&sc->err, 4u);        // the max ruled the reference level out: this series needs the exact path
     // coverage of this rank's slots by its own particles and the adjacent ranks' boundary blocks
     const uint64_t own_begin = (rank == 0) ? 0 : count_of(s_off[rank]);
     const uint64_t own_end = count_of(cssm_u128_add(s_off[rank], s_S[rank]));
@@ -1413,9 +1430,9 @@ __global__ __launch_bounds__(CSSM_BLOCK) void k_expand_spec(const double* __rest
     }
     if (!ok) atomicOr(&sc->err, 8u);
   }
-  if (blockIdx.x == 0 && threadIdx.x < CSSM_MAXSLOTS) sc->maxslot[(size_t)threadIdx.x * CSSM_SLOT_STRIDE] = 0ull;   // set 0 for the next step
+  if (bid == 0 && threadIdx.x < CSSM_MAXSLOTS) sc->maxslot[(size_t)threadIdx.x * CSSM_SLOT_STRIDE] = 0ull;   // set 0 for the next step
   const long long total = (long long)world * cap;
-  for (long long base = (long long)blockIdx.x * CSSM_BLOCK; base < total; base += (long long)gridDim.x * CSSM_BLOCK) {
+  for (long long base = (long long)bid * CSSM_BLOCK; base < total; base += (long long)nblk * CSSM_BLOCK) {
     if (threadIdx.x == 0) s_nheavy = 0;
     __syncthreads();
     const long long idx = base + threadIdx.x;
@@ -1454,6 +1471,26 @@ __global__ __launch_bounds__(CSSM_BLOCK) void k_expand_spec(const double* __rest
       for (uint32_t sl = s_hb[hh] + threadIdx.x; sl < he; sl += CSSM_BLOCK) anc[sl] = hj;
     }
     __syncthreads();
+  }
+}
+
+__global__ __launch_bounds__(CSSM_BLOCK) void k_expand_spec(const double* __restrict__ recv, int world, int rank, long long cap, int d,
+                                                            uint32_t n_split, uint64_t slot_lo, uint64_t slot_hi, uint64_t n_global,
+                                                            const StepRec* __restrict__ rec, uint32_t* __restrict__ anc,
+                                                            Scalars* __restrict__ sc, const unsigned long long* __restrict__ redo_flag) {
+  expand_spec_body(blockIdx.x, gridDim.x, recv, world, rank, cap, d, n_split, slot_lo, slot_hi, n_global, rec, anc, sc, redo_flag);
+}
+// Offspring of the own particles and expansion of the received rows in ONE launch: the two are independent once the
+// exchange is done (disjoint slots; both read only the segment headers), and a launch costs ~5 us of latency.  Blocks
+// [0, nunits) are k_offspring's, the rest k_expand_spec's; `optimistic` = 2 makes the offspring side raise err bit 2
+// itself (no later kernel reads the flag).
+__global__ __launch_bounds__(CSSM_BLOCK, CSSM_OFF_WAVES) void k_offspring_expand_spec(
+    CSSM_OFFSPRING_PARAMS, uint32_t all5_stride, const double* __restrict__ recv, long long cap, int d, uint32_t n_split) {
+  if (blockIdx.x < nunits) {
+    offspring_body<true, false, CSSM_RESAMPLE_SYSTEMATIC>(CSSM_OFFSPRING_FWD, all5_stride);
+  } else {
+    expand_spec_body(blockIdx.x - nunits, gridDim.x - nunits, recv, world, rank, cap, d, n_split, (uint64_t)slot_lo, (uint64_t)slot_hi,
+                     n_global, rec, anc, sc, nullptr);
   }
 }
 

@@ -1468,16 +1468,16 @@ extern "C" int cssm_pf_shard_adopt_spec(cssm_pf* pf, const double* recv_buf_dev,
   const long long seg = spec_seg(pf->d, (long long)cap);
   // the 5 words of every rank are the header words 1..5 of its segment (the all-to-all delivered this rank's own too)
   const unsigned long long* all5 = reinterpret_cast<const unsigned long long*>(recv_buf_dev) + 1;
-  hipLaunchKernelGGL((k_offspring<true, false, CSSM_RESAMPLE_SYSTEMATIC>), dim3(tgrid), dim3(CSSM_BLOCK), 0, pf->stream, pf->logw, pf->n, pf->sc,
-                     (const cssm_u128*)pf->tileS, (const cssm_u128*)pf->tileS2, pf->d_recs + slot, pf->n_global, pf->endslot,
-                     pf->anc, pf->ntiles, pf->sup, pf->nunits, 0, 0, (double*)nullptr, (int32_t*)nullptr, 0u, pf->opt_exact,
-                     all5, rank, world, (int)pf->split, pf->seed, (double*)nullptr, pf->d_logtab,
-                     1, (unsigned long long*)(pf->d_xch + 128), (uint32_t)pf->first, (uint32_t)(pf->first + pf->n), (uint32_t)seg);
   const uint32_t n_split = (uint32_t)pf->n;
   const long long total = (long long)world * cap;
-  hipLaunchKernelGGL(k_expand_spec, dim3(grid_for((uint64_t)total, CSSM_BLOCK, 1024)), dim3(CSSM_BLOCK), 0, pf->stream, recv_buf_dev, world, rank,
-                     (long long)cap, pf->d, n_split, pf->first, pf->first + pf->n, pf->n_global, pf->d_recs + slot, pf->anc, pf->sc,
-                     (const unsigned long long*)(pf->d_xch + 128));
+  const int xgrid = grid_for((uint64_t)total, CSSM_BLOCK, 256);
+  // one launch: blocks [0, nunits) = offspring of the own particles, the rest = expansion of the received rows
+  hipLaunchKernelGGL(k_offspring_expand_spec, dim3(tgrid + xgrid), dim3(CSSM_BLOCK), 0, pf->stream, pf->logw, pf->n, pf->sc,
+                     (const cssm_u128*)pf->tileS, (const cssm_u128*)pf->tileS2, (const StepRec*)(pf->d_recs + slot), pf->n_global, pf->endslot,
+                     pf->anc, pf->ntiles, pf->sup, pf->nunits, 0, 0, (double*)nullptr, (int32_t*)nullptr, 0u, pf->opt_exact,
+                     all5, rank, world, (int)pf->split, pf->seed, (double*)nullptr, (const double*)pf->d_logtab,
+                     2, (unsigned long long*)(pf->d_xch + 128), (uint32_t)pf->first, (uint32_t)(pf->first + pf->n), (uint32_t)seg,
+                     recv_buf_dev, (long long)cap, pf->d, n_split);
   HIP_TRY(hipGetLastError());
   pf->src = pf->state[pf->cur]; pf->src_stride = pf->stride;
   pf->src2 = recv_buf_dev; pf->src2_stride = 0; pf->n_split = n_split; pf->anc_valid = true;   // stride 0 = rows of d + 1
