@@ -1258,7 +1258,8 @@ __host__ __device__ __forceinline__ long long spec_hdr(int d) { return (long lon
 __host__ __device__ __forceinline__ long long spec_capP(int d, long long cap) { return (long long)(d + 1) * ((cap + d) / (d + 1)); }
 __host__ __device__ __forceinline__ long long spec_seg(int d, long long cap) { return spec_hdr(d) + cap * (d + 1) + spec_capP(d, cap); }
 
-// grid (tiles of the block, destination rank); the weights are those k_propagate<SUMS> summed: exp(min(w - c, REF_BELOW))
+// grid (tiles of the block + 1 for the header, destination rank); the weights are those k_propagate<SUMS> summed:
+// exp(min(w - c, REF_BELOW))
 __global__ __launch_bounds__(CSSM_BLOCK) void k_boundary_pack(const double* __restrict__ src, size_t stride, const double* __restrict__ logw,
                                                               uint64_t n_local, int d, int world, int rank, long long cap,
                                                               const StepRec* __restrict__ rec, const cssm_u128* __restrict__ subS,
@@ -1289,6 +1290,8 @@ __global__ __launch_bounds__(CSSM_BLOCK) void k_boundary_pack(const double* __re
     for (int w = 1; w < CSSM_BLOCK / 64; ++w) t = cssm_u128_add(t, s_w[w]);
     return t;
   };
+  const bool header_block = (blockIdx.x == gridDim.x - 1);   // grid.x = tiles of the block + 1: the header has a block of its own
+  if (!header_block) {
   // prefix of the tiles before this block's tile
   cssm_u128 toff = cssm_u128_zero();
   for (uint32_t t = 0; t < blockIdx.x; ++t) {
@@ -1325,8 +1328,9 @@ __global__ __launch_bounds__(CSSM_BLOCK) void k_boundary_pack(const double* __re
       oseg[HD + cap * R + (long long)i] = cssm_u2d(run.hi);
     }
   }
-  if (blockIdx.x != 0) return;
-  // header (the block of tile 0): the rank's totals of the sub-unit sums k_propagate formed, the key of its max, base
+  return;
+  }
+  // header: the rank's totals of the sub-unit sums k_propagate formed, the key of its max, base
   cssm_u128 a = cssm_u128_zero(), b = cssm_u128_zero();
   for (uint32_t i = threadIdx.x; i < nsub; i += CSSM_BLOCK) { a = cssm_u128_add(a, subS[i]); b = cssm_u128_add(b, subS2[i]); }
   a = wave_sum_u128(a); b = wave_sum_u128(b);

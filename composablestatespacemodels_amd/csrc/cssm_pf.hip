@@ -1449,7 +1449,7 @@ extern "C" int cssm_pf_shard_boundary_pack(cssm_pf* pf, int rank, int world, int
   const uint32_t nsub = (uint32_t)((pf->n + chunk - 1) / chunk);
   const long long cnt = std::min<long long>((long long)pf->n, (long long)cap);
   const int tiles = (int)((cnt + CSSM_TILE - 1) / CSSM_TILE);
-  hipLaunchKernelGGL(k_boundary_pack, dim3(tiles, world), dim3(CSSM_BLOCK), 0, pf->stream, pf->state[pf->cur], pf->stride, pf->logw, pf->n, pf->d,
+  hipLaunchKernelGGL(k_boundary_pack, dim3(tiles + 1, world), dim3(CSSM_BLOCK), 0, pf->stream, pf->state[pf->cur], pf->stride, pf->logw, pf->n, pf->d,
                      world, rank, (long long)cap, pf->d_recs + slot, (const cssm_u128*)pf->tileS, (const cssm_u128*)pf->tileS2, nsub,
                      (const Scalars*)pf->sc, send_buf_dev);
   HIP_TRY(hipGetLastError());
