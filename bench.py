@@ -156,12 +156,14 @@ def run_multi(args):
             "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": "configs[1] sharded: seasonal-Poisson, OU latent (d=3), "
                                    f"{args.particles} particles per GPU x {world} GPUs = {n_global}, T={K}, global systematic "
-                                   "resampling every observation (per observation over RCCL, enqueued by the library itself: all-gather of 5 words per rank, one equal-split "
-                                   f"all-to-all of boundary particles, capacity {f.last_cap} rows per pair; the first {f.EXACT_STEPS} observations "
-                                   "use the exact all-to-all-v exchange)",
+                                   "resampling every observation (per observation over RCCL, enqueued by the library itself: one equal-split all-to-all "
+                                   f"carrying every rank's 5 sum words and its boundary particles, capacity {f.last_cap} rows per pair; the first "
+                                   f"{f.EXACT_STEPS} observations use the exact all-to-all-v exchange)",
                        "particles_per_gpu": args.particles, "observations": K, "latent_dim": shard.d, "seed": 20260101},
             "exchange": {"capacity_rows": f.last_cap, "attempts": f.last_attempts,
-                         "collectives_issued_by": "libcssm_pf (cssm_pf_shard_series_rccl)" if getattr(f, "last_native", False) else "torch.distributed"},
+                         "collectives_issued_by": "libcssm_pf (cssm_pf_shard_series_rccl)" if getattr(f, "last_native", False) else "torch.distributed",
+                         "collectives_per_observation": 1 if getattr(f, "last_single", False) else 2,
+                         "rccl": shard.lib.cssm_rccl_library().decode()},
             "ll": ll, "ess_last": ess}))
     dist.destroy_process_group()
 

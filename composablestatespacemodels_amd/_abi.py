@@ -103,6 +103,7 @@ SYMBOLS = [
     ("cssm_pf_shard_adopt", C.c_int, [_h, C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_int64]),
     ("cssm_pf_shard_result", C.c_int, [_h, _dp, _i32p]),
     ("cssm_rccl_available", C.c_int, []),
+    ("cssm_rccl_library", C.c_char_p, []),
     ("cssm_rccl_unique_id", C.c_int, [C.c_void_p]),
     ("cssm_rccl_comm_create", C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
     ("cssm_rccl_comm_destroy", None, [C.c_void_p]),

@@ -1514,6 +1514,7 @@ extern "C" int cssm_pf_shard_status(cssm_pf* pf, double* ll_out, int32_t* ess_ou
 namespace {
 struct RcclApi {
   void* lib = nullptr;
+  std::string path;
   int (*GetUniqueId)(void*) = nullptr;
   int (*CommInitRank)(void**, int, cssm_rccl_id, int) = nullptr;
   int (*CommDestroy)(void*) = nullptr;
@@ -1527,10 +1528,24 @@ RcclApi* rccl_api() {
   static bool tried = false;
   if (tried) return api.ok ? &api : nullptr;
   tried = true;
+  // the copy already mapped into this process (the host's framework usually brings one: two RCCL instances side by side
+  // would each keep their own topology and IPC state), else the ROCm installation's
+  if (FILE* maps = fopen("/proc/self/maps", "r")) {
+    char line[4096];
+    while (!api.lib && fgets(line, sizeof line, maps)) {
+      char* path = strchr(line, '/');
+      if (!path || !strstr(path, "librccl.so")) continue;
+      path[strcspn(path, "\n")] = 0;
+      api.lib = dlopen(path, RTLD_NOW | RTLD_LOCAL | RTLD_NOLOAD);
+      if (api.lib) api.path = path;
+    }
+    fclose(maps);
+  }
   const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so"};
   for (const char* nm : names) {
-    api.lib = dlopen(nm, RTLD_NOW | RTLD_LOCAL);
     if (api.lib) break;
+    api.lib = dlopen(nm, RTLD_NOW | RTLD_LOCAL);
+    if (api.lib) api.path = nm;
   }
   if (!api.lib) return nullptr;
   api.GetUniqueId = (int (*)(void*))dlsym(api.lib, "ncclGetUniqueId");
@@ -1549,6 +1564,7 @@ int rccl_fail(RcclApi* a, const char* what, int r) {
 }  // namespace
 
 extern "C" int cssm_rccl_available(void) { return rccl_api() ? 1 : 0; }
+extern "C" const char* cssm_rccl_library(void) { RcclApi* a = rccl_api(); return a ? a->path.c_str() : ""; }
 
 extern "C" int cssm_rccl_unique_id(cssm_rccl_id* id_out) {
   if (!id_out) return fail(CSSM_EINVAL_ARG, "null argument");

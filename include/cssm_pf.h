@@ -333,6 +333,7 @@ int cssm_pf_shard_result(cssm_pf* pf, double* ll_out, int32_t* ess_out);
  * untouched until the next propagate has run. */
 typedef struct { char internal[128]; } cssm_rccl_id;   /* ncclUniqueId */
 int cssm_rccl_available(void);
+const char* cssm_rccl_library(void);   /* which librccl.so the library bound to (diagnostics) */
 int cssm_rccl_unique_id(cssm_rccl_id* id_out);
 int cssm_rccl_comm_create(const cssm_rccl_id* id, int world, int rank, int device, void** comm_out);
 void cssm_rccl_comm_destroy(void* comm);
