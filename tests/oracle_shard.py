@@ -166,8 +166,95 @@ class OracleShard:
         self.bits, self.need = 0, np.zeros(len(self._t), dtype=np.uint32)
         self.init(float(self._t.min()))
 
-    def propagate_at(self, k):
+    def propagate_at(self, k, with_sums=True):
         self.propagate(float(self._t[k]), float(self._y[k]), bool(self._has[k]) or self.o_is_lgcp())
+
+    # ---- the single-collective exchange of GpuShard (k_boundary_pack / k_offspring_expand_spec), restated
+    def spec_segment(self, cap):
+        R = self.d + 1
+        return R * ((8 + self.d) // R) + cap * R + R * ((cap + self.d) // R)
+
+    def boundary_pack(self, cap, send_buf):
+        R, seg = self.d + 1, self.spec_segment(cap)
+        HD = R * ((8 + self.d) // R)
+        buf = send_buf.numpy()
+        bits = buf.view(np.uint64)
+        buf[: self.world * seg] = 0.0
+        S = sum(self.q)
+        words = [int(x) & (2**64 - 1) for x in self.sums5.tolist()]
+        for qd in range(self.world):
+            o = qd * seg
+            cnt = 0 if qd == self.rank else min(self.n, cap)
+            first = 0 if qd < self.rank else self.n - cnt
+            P, run = [], 0
+            for j in range(first, first + cnt):
+                run += self.q[j]
+                P.append(run)
+            base = 0 if qd < self.rank else S - run          # a LAST block starts at S_local - P_total
+            if qd == self.rank:
+                base = 0
+            buf[o] = float(cnt)
+            for i, w in enumerate(words):
+                bits[o + 1 + i] = w
+            bits[o + 6] = base & (2**64 - 1); bits[o + 7] = base >> 64
+            for i in range(cnt):
+                buf[o + HD + i * R: o + HD + i * R + self.d] = self.x1[:, first + i]
+                bits[o + HD + i * R + self.d] = P[i] & (2**64 - 1)
+                bits[o + HD + cap * R + i] = P[i] >> 64
+
+    def adopt_spec(self, recv_buf, cap):
+        R, seg = self.d + 1, self.spec_segment(cap)
+        HD = R * ((8 + self.d) // R)
+        buf = recv_buf.numpy()
+        bits = buf.view(np.uint64)
+        to_i64 = lambda x: x - 2**64 if x >= 2**63 else x
+        for r in range(self.world):                       # every rank's 5 words are in the segment headers
+            for i in range(5):
+                self.all_sums[5 * r + i] = to_i64(int(bits[r * seg + 1 + i]))
+        self.offspring()                                   # own particles: level, ll, ess, end slots E
+        if int(self.redo_flag[0]):
+            self.bits |= 4
+            return
+        v = [int(x) for x in self.all_sums.tolist()]
+        S = [_join64(v[5 * r], v[5 * r + 1]) for r in range(self.world)]
+        off = [sum(S[:r]) for r in range(self.world)]
+        totd = float(sum(S))
+        u = oracle.lib().oracle_c_u(self.seed, self.step_idx - 1)
+        cnt_of = lambda G: int(oracle.lib().oracle_c_sys_count(float(G) / totd, u, self.n_global))
+        cands = {}
+        for sdr in range(self.world):
+            if sdr == self.rank:
+                continue
+            o = sdr * seg
+            c = min(max(int(buf[o]), 0), cap)
+            base = int(bits[o + 6]) | (int(bits[o + 7]) << 64)
+            rows = []
+            for i in range(c):
+                P = int(bits[o + HD + i * R + self.d]) | (int(bits[o + HD + cap * R + i]) << 64)
+                rows.append((buf[o + HD + i * R: o + HD + i * R + self.d].copy(), cnt_of(off[sdr] + base + P)))
+            begin = 0 if (off[sdr] + base) == 0 else cnt_of(off[sdr] + base)
+            cands[sdr] = (begin, rows)
+        slot_lo, slot_hi = self.first, self.first + self.n
+        own_begin = 0 if self.rank == 0 else cnt_of(off[self.rank])
+        own_end = cnt_of(off[self.rank] + S[self.rank])
+        ok = True
+        if slot_lo < own_begin:
+            ok = self.rank > 0 and len(cands[self.rank - 1][1]) > 0 and cands[self.rank - 1][0] <= slot_lo
+        if own_end < slot_hi:
+            up = self.rank < self.world - 1 and len(cands[self.rank + 1][1]) > 0 and cands[self.rank + 1][1][-1][1] >= slot_hi
+            ok = ok and up
+        if not ok:
+            self.bits |= 8
+            return
+        low = [row for sdr in range(self.rank) for row in cands[sdr][1]]
+        high = [row for sdr in range(self.rank + 1, self.world) for row in cands[sdr][1]]
+        own = [(self.x1[:, j], int(self.E[j])) for j in range(self.n)]
+        allc = low + own + high                            # global particle order: end slots are non-decreasing
+        cend = np.array([e for _, e in allc], dtype=np.int64)
+        slots = np.arange(slot_lo, slot_hi)
+        anc = np.searchsorted(cend, slots, side="right")
+        assert anc.max() < len(allc)
+        self.o.set_particles(np.ascontiguousarray(np.stack([allc[a][0] for a in anc], axis=1)))
 
     def offspring_pack(self, cap, send_buf):
         row, seg = self.d + 1, (cap + 1) * (self.d + 1)

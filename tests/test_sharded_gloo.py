@@ -28,7 +28,7 @@ def _series(C, T, missing, prec):
     return t, y, has
 
 
-def _worker(rank, world, port, name, n, T, missing, prec, out_dir):
+def _worker(rank, world, port, name, n, T, missing, prec, out_dir, single):
     sys.path.insert(0, HERE)
     sys.path.insert(0, os.path.dirname(HERE))
     import cases as C
@@ -36,6 +36,7 @@ def _worker(rank, world, port, name, n, T, missing, prec, out_dir):
     from oracle_shard import OracleShard
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
+    os.environ["CSSM_SHARD_SINGLE"] = single
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         model = getattr(C, name)()
@@ -48,7 +49,7 @@ def _worker(rank, world, port, name, n, T, missing, prec, out_dir):
             f.EXACT_STEPS, f.MIN_CAP, f.CAP_HEADROOM = 1, 1, 0
         ll, ess = f.ll_filter(t, y, has, lgcp=bool(prec))
         np.savez(os.path.join(out_dir, f"r{rank}.npz"), ll=ll, ess=ess, part=shard.particles(), redone=shard.redone,
-                 attempts=f.last_attempts, cap=-1 if f.last_cap is None else f.last_cap)
+                 attempts=f.last_attempts, cap=-1 if f.last_cap is None else f.last_cap, single=int(f.last_single))
     finally:
         dist.destroy_process_group()
 
@@ -62,9 +63,14 @@ def _worker(rank, world, port, name, n, T, missing, prec, out_dir):
     (3, "c2_model", 300, 12, 0.05, 0),
     (2, "c3_model", 200, 14, 0.0, 0),
 ])
-def test_sharded_orchestration_over_gloo_matches_single_rank(tmp_path, world, name, n, T, missing, prec):
-    port = 29600 + (os.getpid() % 300) + world
-    mp.spawn(_worker, args=(world, port, name, n, T, missing, prec, str(tmp_path)), nprocs=world, join=True)
+@pytest.mark.parametrize("single", ["1", "0"])
+def test_sharded_orchestration_over_gloo_matches_single_rank(tmp_path, world, name, n, T, missing, prec, single):
+    """single = 1: ONE all-to-all per observation carries sums and boundary particles (the default); single = 0:
+    all-gather of the sums, then the all-to-all of the packed ranges."""
+    if single == "0" and (prec or T <= 8):
+        pytest.skip("the series never leaves the exact exchange: nothing differs between the two modes")
+    port = 29600 + (os.getpid() % 300) + world + (40 if single == "0" else 0)
+    mp.spawn(_worker, args=(world, port, name, n, T, missing, prec, str(tmp_path), single), nprocs=world, join=True)
     model = getattr(cases, name)()
     t, y, has = _series(cases, T, missing, prec)
     o = oracle.OraclePf(model.descriptor(prec), n, cases.SEED)
@@ -78,6 +84,7 @@ def test_sharded_orchestration_over_gloo_matches_single_rank(tmp_path, world, na
         assert int(z["attempts"]) == (2 if missing in (-0.2, 0.05) else 1)
         if T > 8 and missing == 0.0:
             assert int(z["cap"]) >= 1             # the fixed-capacity exchange did run
+        assert int(z["single"]) == (0 if prec else int(single))
         assert float(z["ll"]) == ll and int(z["ess"]) == int(ess_t[-1])
         parts.append(z["part"])
     np.testing.assert_array_equal(np.concatenate(parts, axis=1), o.particles())
