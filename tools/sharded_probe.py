@@ -8,10 +8,10 @@ os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = "29544"
 torch.cuda.set_device(0)
 dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
 model = cases.c2_model(); t, y, has = cases.poisson_counts(220)
-for n in (1 << 20, 1 << 24):
+for n in ([int(a) for a in sys.argv[1:]] or [1 << 20, 1 << 24]):
     shard = GpuShard(model, n, 0, 1, cases.SEED, 0)
     f = ShardedFilter([shard], DistComm(device=torch.device("cuda", 0)))
-    for exact in (True, False):
+    for exact in ((False,) if os.environ.get("PROBE_FIXED_ONLY") else (True, False)):
         f.ll_filter(t[:20], y[:20], has[:20], exact=exact)
         torch.cuda.synchronize(); t0 = time.perf_counter()
         ll, ess = f.ll_filter(t[:200], y[:200], has[:200], exact=exact)
