@@ -56,7 +56,7 @@ def cpu_baseline(model, t, y, has, budget_s=12.0):
             "ll": ll}
 
 
-def run_single(args):
+def run_single(args, emit=print):
     import torch  # first: its import takes long enough for the GPU clocks to idle down
     from composablestatespacemodels_amd.filter import NativePf
     K, W = args.steps, args.warmup
@@ -119,10 +119,10 @@ def run_single(args):
     if not args.no_cpu:
         out["cpu_baseline"] = cpu_baseline(model, t, y, has)
     pf.close()
-    print(json.dumps(out))
+    emit(json.dumps(out))
 
 
-def run_multi(args):
+def run_multi(args, emit=print):
     import torch
     import torch.distributed as dist
     from composablestatespacemodels_amd.sharded import DistComm, GpuShard, ShardedFilter
@@ -138,8 +138,12 @@ def run_multi(args):
     model, t, y, has = build_workload(max(K, W, 8))
     shard = GpuShard(model, n_global, rank, world, 20260101, local)
     f = ShardedFilter([shard], DistComm(device=torch.device("cuda", local)))
-    if W > 0:
-        f.ll_filter(t[:W], y[:W], has[:W])          # warm-up: allocations, RCCL channels, clocks
+    # warm-up: allocations, RCCL channels, clocks.  At least 8 observations whatever W is: the first 4 of a series use the
+    # exact exchange, and the library's own RCCL communicator and the capacity buffers are created at the first
+    # observation after them -- that must not happen inside the timed region
+    Wn = max(W, 8)
+    tw, yw, hw = build_workload(Wn)[1:]
+    f.ll_filter(tw[:Wn], yw[:Wn], hw[:Wn])
     dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -150,7 +154,7 @@ def run_multi(args):
     dist.all_reduce(wall, op=dist.ReduceOp.MAX)
     if rank == 0:
         w = float(wall.item())
-        print(json.dumps({
+        emit(json.dumps({
             "metric": "particle-steps/sec (N x T) bootstrap filter", "value": n_global * K / w, "unit": "particle-steps/s",
             "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": w * 1e3 / K, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
@@ -165,7 +169,32 @@ def run_multi(args):
                          "collectives_per_observation": 1 if getattr(f, "last_single", False) else 2,
                          "rccl": shard.lib.cssm_rccl_library().decode()},
             "ll": ll, "ess_last": ess}))
+    shard.close()
+    f.comm.close()
     dist.destroy_process_group()
+
+
+class _QuietStdout:
+    """Everything written to file descriptor 1 while the benchmark runs (RCCL prints a version banner there when a
+    communicator is created) goes to stderr; the descriptor is restored for the one JSON line."""
+
+    def __enter__(self):
+        sys.stdout.flush()
+        self._saved = os.dup(1)
+        os.dup2(2, 1)
+        return self
+
+    def emit(self, line: str):
+        sys.stdout.flush()
+        os.dup2(self._saved, 1)
+        print(line, flush=True)
+        os.dup2(2, 1)
+
+    def __exit__(self, *exc):
+        sys.stdout.flush()
+        os.dup2(self._saved, 1)
+        os.close(self._saved)
+        return False
 
 
 def main():
@@ -177,10 +206,11 @@ def main():
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--fused", type=int, default=None, help="CSSM_OPT_FUSED_SUMS override (single GPU)")
     args = ap.parse_args()
-    if args.gpus > 1 or int(os.environ.get("WORLD_SIZE", "1")) > 1:
-        run_multi(args)
-    else:
-        run_single(args)
+    with _QuietStdout() as out:
+        if args.gpus > 1 or int(os.environ.get("WORLD_SIZE", "1")) > 1:
+            run_multi(args, out.emit)
+        else:
+            run_single(args, out.emit)
 
 
 if __name__ == "__main__":

@@ -257,6 +257,13 @@ class DistComm:
     def barrier(self):
         self.dist.barrier(group=self.group)
 
+    def close(self):
+        """Destroy the library-owned RCCL communicator (if one was made); call before destroy_process_group."""
+        h = getattr(self, "_native", None)
+        if h:
+            _abi.load_library().cssm_rccl_comm_destroy(h)
+        self._native = None
+
 
 class LocalComm:
     """All R shards live in this process; the "collectives" are tensor copies.  Test vehicle for the

@@ -111,6 +111,7 @@ def test_rccl_world1_matches_oracle():
         finally:
             del os.environ["CSSM_SHARD_NATIVE"]
         shard.close()
+        f.comm.close()
     finally:
         dist.destroy_process_group()
 
