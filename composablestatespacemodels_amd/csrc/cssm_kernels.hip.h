@@ -1264,7 +1264,9 @@ __global__ __launch_bounds__(CSSM_BLOCK) void k_boundary_pack(const double* __re
                                                               uint64_t n_local, int d, int world, int rank, long long cap,
                                                               const StepRec* __restrict__ rec, const cssm_u128* __restrict__ subS,
                                                               const cssm_u128* __restrict__ subS2, uint32_t nsub,
-                                                              const Scalars* __restrict__ sc, double* __restrict__ out) {
+                                                              const Scalars* __restrict__ sc, double* __restrict__ out, uint64_t chunk) {
+  // chunk = particles per sub-unit sum of k_propagate (subS): when the tiles of the carried block coincide with
+  // sub-units, the prefix of the tiles before a block's own is read from subS instead of being recomputed
   __shared__ cssm_u128 s_w[CSSM_BLOCK / 64], s_r[2][CSSM_BLOCK / 64];
   const int q = blockIdx.y;
   const long long R = d + 1, HD = spec_hdr(d), seg = spec_seg(d, cap);
@@ -1294,7 +1296,12 @@ __global__ __launch_bounds__(CSSM_BLOCK) void k_boundary_pack(const double* __re
   if (!header_block) {
   // prefix of the tiles before this block's tile
   cssm_u128 toff = cssm_u128_zero();
-  for (uint32_t t = 0; t < blockIdx.x; ++t) {
+  const bool aligned = (chunk == (uint64_t)CSSM_TILE) && (first % (uint64_t)CSSM_TILE == 0);
+  if (aligned) {
+    const uint32_t b0 = (uint32_t)(first / CSSM_TILE);
+    for (uint32_t t = 0; t < blockIdx.x; ++t) toff = cssm_u128_add(toff, subS[b0 + t]);
+  }
+  for (uint32_t t = 0; !aligned && t < blockIdx.x; ++t) {
     cssm_u128 qq[CSSM_ITEMS];
     tile_weights((uint64_t)t * CSSM_TILE, qq);
     cssm_u128 a = cssm_u128_zero();

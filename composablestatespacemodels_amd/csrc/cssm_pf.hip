@@ -1451,7 +1451,7 @@ extern "C" int cssm_pf_shard_boundary_pack(cssm_pf* pf, int rank, int world, int
   const int tiles = (int)((cnt + CSSM_TILE - 1) / CSSM_TILE);
   hipLaunchKernelGGL(k_boundary_pack, dim3(tiles + 1, world), dim3(CSSM_BLOCK), 0, pf->stream, pf->state[pf->cur], pf->stride, pf->logw, pf->n, pf->d,
                      world, rank, (long long)cap, pf->d_recs + slot, (const cssm_u128*)pf->tileS, (const cssm_u128*)pf->tileS2, nsub,
-                     (const Scalars*)pf->sc, send_buf_dev);
+                     (const Scalars*)pf->sc, send_buf_dev, chunk);
   HIP_TRY(hipGetLastError());
   return CSSM_OK;
 }

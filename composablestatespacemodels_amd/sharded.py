@@ -424,6 +424,8 @@ class ShardedFilter:
                 if weighted[k] and not exact_k and cap is None:
                     # every rank must use the same capacity: agree on the largest count seen so far
                     cap = min(max(self.MIN_CAP, self.CAP_HEADROOM * comm.agree_max([seen] * len(S))), n_max)
+                    if cap >= 1024:
+                        cap = min(-(-cap // 1024) * 1024, n_max)   # whole tiles: the boundary blocks then line up with k_propagate's sums
                     native = comm.native_comm() if (len(S) == 1 and hasattr(comm, "native_comm")) else None
                 spec_k = bool(weighted[k]) and not exact_k and single
                 for s in S:

@@ -205,3 +205,22 @@ def test_local_shards_every_staging_layout_with_remote_candidates(world, d, n, T
         np.testing.assert_array_equal(np.concatenate([s.particles() for s in shards], axis=1), opart)
     for s in shards:
         s.close()
+
+
+@pytest.mark.parametrize("n,world", [(8 * 4096, 2), (8 * 4096 + 555, 2), (3 * 5000, 3)])
+def test_single_collective_with_boundary_blocks_of_several_tiles(n, world):
+    """Capacity of several tiles per boundary block: the prefix of the tiles before a block's own comes from
+    k_propagate's sub-unit sums when the block is tile-aligned, else it is recomputed -- same bits either way."""
+    from composablestatespacemodels_amd.sharded import GpuShard, LocalComm, ShardedFilter
+    model = cases.c2_model()
+    t, y, has = cases.poisson_counts(14, missing=0.1)
+    shards = [GpuShard(model, n, r, world, cases.SEED, 0) for r in range(world)]
+    f = ShardedFilter(shards, LocalComm(world))
+    f.MIN_CAP = 3500                      # rounded up to 4096 = 4 tiles
+    ll, ess = f.ll_filter(t, y, has)
+    assert f.last_single and f.last_attempts == 1 and f.last_cap >= 3500
+    oll, oess, opart = _oracle_run(model, n, t, y, has)
+    assert (ll, ess) == (oll, oess[-1])
+    np.testing.assert_array_equal(np.concatenate([s.particles() for s in shards], axis=1), opart)
+    for s in shards:
+        s.close()
