@@ -88,6 +88,35 @@ CSSM_HD double cssm_scale2(double p, int k) {
   return (p * cssm_pow2i(k1)) * cssm_pow2i(k2);
 #endif
 }
+/* fma(a, b, k) with a CONSTANT addend k (the Horner steps of the polynomials below).  The same IEEE operation on both
+ * sides and at every level of the build knob CSSM_ASM_FMA_LEVEL (0: nowhere -- the default, 1: exp, 2: exp, log_unit,
+ * sincos), which pins the device form to one v_fma_f64 with k in a scalar register pair.  Left to itself the compiler
+ * (in the large kernels, not in small ones) keeps k in a vector register and emits v_mov_b64 + v_fmac_f64 per step.
+ * Measured on MI355X, same box, us per observation (separate sums / fused sums): N = 2^20: level 0 40.2 / 39.0,
+ * level 1 40.8 / 38.9, level 2 41.1 / 39.1; N = 2^24: 368 / 364, 357 / 356, 357 / 352.  Pinning frees 15-30 VGPRs and
+ * gains 3 % at 2^24 but costs scalar-register pressure that loses 2 % at the size the benchmark is quoted on. */
+#ifndef CSSM_ASM_FMA_LEVEL
+#define CSSM_ASM_FMA_LEVEL 0
+#endif
+CSSM_HD double cssm_fma_k2(double a, double b, double k) {
+#if CSSM_DEVICE_FORM && CSSM_ASM_FMA_LEVEL >= 2
+  double d;
+  __asm__("v_fma_f64 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "s"(k));
+  return d;
+#else
+  return __builtin_fma(a, b, k);
+#endif
+}
+CSSM_HD double cssm_fma_k(double a, double b, double k) {
+#if CSSM_DEVICE_FORM && CSSM_ASM_FMA_LEVEL >= 1
+  double d;
+  __asm__("v_fma_f64 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "s"(k));
+  return d;
+#else
+  return __builtin_fma(a, b, k);
+#endif
+}
+
 /* Round-to-nearest-even of t (|t| < 2^31) by the shifter trick: adding 1.5 * 2^52 leaves the integer in the low
  * mantissa bits (ulp = 1), in two's complement.  Plain IEEE additions: the same on every machine. */
 #define CSSM_SHIFTER 0x1.8p52
@@ -322,16 +351,16 @@ CSSM_HD double cssm_exp(double x) {
   double r = cssm_fma(-kd, LN2_HI, xc);
   r = cssm_fma(-kd, LN2_LO, r);
   double p = 1.0 / 6227020800.0; /* 1/13! */
-  p = cssm_fma(p, r, 1.0 / 479001600.0);
-  p = cssm_fma(p, r, 1.0 / 39916800.0);
-  p = cssm_fma(p, r, 1.0 / 3628800.0);
-  p = cssm_fma(p, r, 1.0 / 362880.0);
-  p = cssm_fma(p, r, 1.0 / 40320.0);
-  p = cssm_fma(p, r, 1.0 / 5040.0);
-  p = cssm_fma(p, r, 1.0 / 720.0);
-  p = cssm_fma(p, r, 1.0 / 120.0);
-  p = cssm_fma(p, r, 1.0 / 24.0);
-  p = cssm_fma(p, r, 1.0 / 6.0);
+  p = cssm_fma_k(p, r, 1.0 / 479001600.0);
+  p = cssm_fma_k(p, r, 1.0 / 39916800.0);
+  p = cssm_fma_k(p, r, 1.0 / 3628800.0);
+  p = cssm_fma_k(p, r, 1.0 / 362880.0);
+  p = cssm_fma_k(p, r, 1.0 / 40320.0);
+  p = cssm_fma_k(p, r, 1.0 / 5040.0);
+  p = cssm_fma_k(p, r, 1.0 / 720.0);
+  p = cssm_fma_k(p, r, 1.0 / 120.0);
+  p = cssm_fma_k(p, r, 1.0 / 24.0);
+  p = cssm_fma_k(p, r, 1.0 / 6.0);
   p = cssm_fma(p, r, 0.5);
   p = cssm_fma(p, r, 1.0);
   p = cssm_fma(p, r, 1.0);
@@ -411,11 +440,11 @@ CSSM_HD double cssm_log_unit(double x, const double* tab) {
   const double invc = tab[2 * j], logc = tab[2 * j + 1];
   const double r = cssm_fma(m, invc, -1.0);
   double p = -1.0 / 8.0;
-  p = cssm_fma(p, r, 1.0 / 7.0);
-  p = cssm_fma(p, r, -1.0 / 6.0);
-  p = cssm_fma(p, r, 1.0 / 5.0);
+  p = cssm_fma_k2(p, r, 1.0 / 7.0);
+  p = cssm_fma_k2(p, r, -1.0 / 6.0);
+  p = cssm_fma_k2(p, r, 1.0 / 5.0);
   p = cssm_fma(p, r, -1.0 / 4.0);
-  p = cssm_fma(p, r, 1.0 / 3.0);
+  p = cssm_fma_k2(p, r, 1.0 / 3.0);
   p = cssm_fma(p, r, -0.5);
   const double hi = cssm_fma(kd, LN2_HI, logc);
   const double lo = cssm_fma(r * r, p, kd * LN2_LO);
@@ -444,10 +473,10 @@ CSSM_HD void cssm_sincos2pi(double u, double* sn, double* cs) {
   const double x = r * PIO2_HI; /* the angle, rounded once: |error| < 1.2e-16 * |x| */
   const double z = x * x;
   /* sin kernel: x + x^3 (S1 + z (S2 + ...)) */
-  const double rs = cssm_fma(z, cssm_fma(z, cssm_fma(z, cssm_fma(z, cssm_fma(z, S6, S5), S4), S3), S2), S1);
+  const double rs = cssm_fma_k2(z, cssm_fma_k2(z, cssm_fma_k2(z, cssm_fma_k2(z, cssm_fma_k2(z, S6, S5), S4), S3), S2), S1);
   const double s = cssm_fma(z * x, rs, x);
   /* cos kernel: 1 - z/2 + z^2 (C1 + z (C2 + ...)) */
-  const double rc = cssm_fma(z, cssm_fma(z, cssm_fma(z, cssm_fma(z, cssm_fma(z, C6, C5), C4), C3), C2), C1);
+  const double rc = cssm_fma_k2(z, cssm_fma_k2(z, cssm_fma_k2(z, cssm_fma_k2(z, cssm_fma_k2(z, C6, C5), C4), C3), C2), C1);
   const double hz = 0.5 * z;
   const double w = 1.0 - hz;
   const double c = w + (((1.0 - w) - hz) + (z * z) * rc);
