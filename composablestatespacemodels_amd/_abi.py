@@ -112,6 +112,7 @@ SYMBOLS = [
     ("cssm_pf_shard_spec_segment", C.c_int64, [_h, C.c_int64]),
     ("cssm_pf_shard_boundary_pack", C.c_int, [_h, C.c_int, C.c_int, C.c_int64, C.c_void_p]),
     ("cssm_pf_shard_adopt_spec", C.c_int, [_h, C.c_void_p, C.c_int, C.c_int, C.c_int64]),
+    ("cssm_pf_shard_resume", C.c_int, [_h, C.POINTER(C.c_uint32)]),
     ("cssm_pmmh_run", C.c_int, [_h, _descp, _dp, C.c_size_t, C.c_double, _dp, _dp, _u8p, C.c_size_t,
                                 C.c_uint64, C.c_size_t, _dp, _dp, _i32p, _dp]),
     ("cssm_contract_eval", C.c_int, [C.c_int, C.c_int, _dp, C.c_size_t, _dp, C.c_size_t]),

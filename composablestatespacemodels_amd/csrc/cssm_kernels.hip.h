@@ -75,7 +75,10 @@ struct Scalars {
   unsigned long long maxslot[2 * CSSM_MAXSLOTS * CSSM_SLOT_STRIDE];
   uint32_t err;              // bit0: NaN log-weight, bit1: all weights zero / max not finite,
                              // bit2: the reference level was unusable and the sums must be formed again (host retries)
+                             // bit3: (sharded) the exchange capacity did not cover some rank's slots at step fail_step
   int32_t ess;
+  uint32_t fail_step;        // first observation whose exchange did not fit (0xffffffff: none); see k_offspring_expand_spec
+  uint32_t pad_;
   double gmax;               // decoded global max of this step
   double ref;                // level the weights of this step were rescaled by (cssm_ref_choose)
   double ll;                 // accumulated log-likelihood
@@ -410,6 +413,9 @@ __global__ __launch_bounds__(CSSM_BLOCK, (PropWaves<D, SUMS>::value)) void k_pro
   // src2 != nullptr (sharded filter): ancestor indices >= n_split address the candidates received from
   // other ranks, src2[k * src2_stride + (j - n_split)]
   __shared__ double s_max[CSSM_BLOCK / 64];
+  // (sharded series) the exchange of an earlier observation did not fit: the series is on hold and nothing may change
+  // until the host resumes it (cssm_pf_shard_resume)
+  if (sc->err & 8u) return;   // (bit 3 is only ever raised by the sharded exchange)
   const uint32_t step = rec->step;
   const int has_obs = rec->has_obs;
   const double dt = rec->dt;
@@ -1248,13 +1254,15 @@ __global__ __launch_bounds__(CSSM_BLOCK) void k_expand_fixed(const double* __res
 //
 // One all-to-all per observation carries BOTH the rank's 5 sum words and its boundary particles:
 // segment r -> q of R-double rows (R = d + 1), laid out as
-//   [0, HD)                header: [0] row count, [1..5] S.lo S.hi S2.lo S2.hi max-key (raw bits), [6..7] base (u128 raw bits)
+//   [0, HD)                header: [0] row count, [1..5] S.lo S.hi S2.lo S2.hi max-key (raw bits), [6..7] base (u128 raw bits),
+//                          [8..9] total weight of the rank's FIRST-cap block, [10..11] of its LAST-cap block (every header carries
+//                          both: with them EVERY rank can tell from the headers alone whether EVERY rank's slots are covered)
 //   [HD, HD + cap R)       rows: (state d, low word of P_j)      P_j = inclusive prefix of the fixed-point weights
 //   [HD + cap R, + capP)   high words of P_j                            WITHIN the block of particles the segment carries
 // q < r receives the rank's FIRST cap particles (base = 0), q > r its LAST cap particles (base = S_local - P_total), q = r
 // the header only (the all-to-all's own segment delivers every rank its own sums too).  The receiver knows all sums after
 // the exchange and turns base + P_j into global cumulative weights and end slots itself (k_expand_spec).
-__host__ __device__ __forceinline__ long long spec_hdr(int d) { return (long long)(d + 1) * ((8 + d) / (d + 1)); }
+__host__ __device__ __forceinline__ long long spec_hdr(int d) { return (long long)(d + 1) * ((12 + d) / (d + 1)); }
 __host__ __device__ __forceinline__ long long spec_capP(int d, long long cap) { return (long long)(d + 1) * ((cap + d) / (d + 1)); }
 __host__ __device__ __forceinline__ long long spec_seg(int d, long long cap) { return spec_hdr(d) + cap * (d + 1) + spec_capP(d, cap); }
 
@@ -1268,6 +1276,7 @@ __global__ __launch_bounds__(CSSM_BLOCK) void k_boundary_pack(const double* __re
   // chunk = particles per sub-unit sum of k_propagate (subS): when the tiles of the carried block coincide with
   // sub-units, the prefix of the tiles before a block's own is read from subS instead of being recomputed
   __shared__ cssm_u128 s_w[CSSM_BLOCK / 64], s_r[2][CSSM_BLOCK / 64];
+  if (sc->err & 8u) return;   // the series is on hold (capacity miss): nothing may change until the host resumes it
   const int q = blockIdx.y;
   const long long R = d + 1, HD = spec_hdr(d), seg = spec_seg(d, cap);
   double* oseg = out + (size_t)q * seg;
@@ -1349,29 +1358,46 @@ __global__ __launch_bounds__(CSSM_BLOCK) void k_boundary_pack(const double* __re
     key = (threadIdx.x < CSSM_MAXSLOTS) ? sc->maxslot[(size_t)threadIdx.x * CSSM_SLOT_STRIDE] : 0ull;   // slot set 0 (sharded handles)
     key = wave_max_u64(key);
   }
-  // total weight of the whole block of cnt particles (for the base of a LAST block)
-  cssm_u128 ptot = cssm_u128_zero();
-  const uint32_t ntile = (uint32_t)((cnt + CSSM_TILE - 1) / CSSM_TILE);
-  if (q > rank) {
-    for (uint32_t t = 0; t < ntile; ++t) {
-      cssm_u128 q2[CSSM_ITEMS];
-      tile_weights((uint64_t)t * CSSM_TILE, q2);
-      cssm_u128 c = cssm_u128_zero();
+  // total weights of the rank's FIRST-cap and LAST-cap blocks (both travel in every header; the LAST one gives the base)
+  const long long cnt_all = ((long long)n_local < cap) ? (long long)n_local : cap;
+  const uint32_t ntile = (uint32_t)((cnt_all + CSSM_TILE - 1) / CSSM_TILE);
+  cssm_u128 ptot[2];
 #pragma unroll
-      for (int r = 0; r < CSSM_ITEMS; ++r) c = cssm_u128_add(c, q2[r]);
-      ptot = cssm_u128_add(ptot, block_total(c));
+  for (int which = 0; which < 2; ++which) {
+    const uint64_t bfirst = which ? n_local - (uint64_t)cnt_all : 0;
+    const bool al = (chunk == (uint64_t)CSSM_TILE) && (bfirst % (uint64_t)CSSM_TILE == 0) && ((uint64_t)cnt_all % CSSM_TILE == 0);
+    cssm_u128 acc = cssm_u128_zero();
+    if (al) {   // whole sub-units: their sums are k_propagate's
+      const uint32_t b0 = (uint32_t)(bfirst / CSSM_TILE);
+      cssm_u128 c = cssm_u128_zero();
+      for (uint32_t t = threadIdx.x; t < ntile; t += CSSM_BLOCK) c = cssm_u128_add(c, subS[b0 + t]);
+      acc = block_total(c);
+    } else {
+      for (uint32_t t = 0; t < ntile; ++t) {
+        cssm_u128 c = cssm_u128_zero();
+#pragma unroll
+        for (int r = 0; r < CSSM_ITEMS; ++r) {
+          const uint64_t i = (uint64_t)t * CSSM_TILE + (uint64_t)threadIdx.x * CSSM_ITEMS + r;
+          if (i < (uint64_t)cnt_all)
+            c = cssm_u128_add(c, cssm_fix_from_double(cssm_exp(cssm_min_c(logw[bfirst + i] - cref, CSSM_REF_BELOW))));
+        }
+        acc = cssm_u128_add(acc, block_total(c));
+      }
     }
+    ptot[which] = acc;
   }
   if (threadIdx.x == 0) {
     cssm_u128 S = s_r[0][0], S2 = s_r[1][0];
 #pragma unroll
     for (int w = 1; w < CSSM_BLOCK / 64; ++w) { S = cssm_u128_add(S, s_r[0][w]); S2 = cssm_u128_add(S2, s_r[1][w]); }
     cssm_u128 bs = cssm_u128_zero();
-    if (q > rank) { bs.lo = S.lo - ptot.lo; bs.hi = S.hi - ptot.hi - (S.lo < ptot.lo ? 1u : 0u); }
+    if (q > rank) { bs.lo = S.lo - ptot[1].lo; bs.hi = S.hi - ptot[1].hi - (S.lo < ptot[1].lo ? 1u : 0u); }
     oseg[0] = (double)cnt;
     oseg[1] = cssm_u2d(S.lo); oseg[2] = cssm_u2d(S.hi); oseg[3] = cssm_u2d(S2.lo); oseg[4] = cssm_u2d(S2.hi);
     oseg[5] = cssm_u2d(key);
     oseg[6] = cssm_u2d(bs.lo); oseg[7] = cssm_u2d(bs.hi);
+    oseg[8] = cssm_u2d(ptot[0].lo); oseg[9] = cssm_u2d(ptot[0].hi);
+    oseg[10] = cssm_u2d(ptot[1].lo); oseg[11] = cssm_u2d(ptot[1].hi);
   }
 }
 
@@ -1380,67 +1406,91 @@ __global__ __launch_bounds__(CSSM_BLOCK) void k_boundary_pack(const double* __re
 // number for the same particle: its fast path equals the contract's count by construction).  Ancestor index of a slot
 // = n_split + row number in the receive buffer (in R-double rows), which k_propagate resolves in place.
 // Also: slots of this rank that neither its own particles nor the received rows own -> err bit 3 (8): exact exchange.
-__device__ __forceinline__ void expand_spec_body(uint32_t bid, uint32_t nblk, const double* __restrict__ recv, int world, int rank, long long cap, int d,
-                                                 uint32_t n_split, uint64_t slot_lo, uint64_t slot_hi, uint64_t n_global,
-                                                 const StepRec* __restrict__ rec, uint32_t* __restrict__ anc,
-                                                 Scalars* __restrict__ sc, const unsigned long long* __restrict__ redo_flag) {
-  __shared__ cssm_u128 s_S[64], s_off[64], s_base[64];
-  __shared__ long long s_cnt[64];
-  __shared__ cssm_u128 s_tot;
-  __shared__ uint32_t s_nheavy;
-  __shared__ uint32_t s_hb[CSSM_BLOCK], s_he[CSSM_BLOCK], s_hj[CSSM_BLOCK];
-  const long long R = d + 1, HD = spec_hdr(d), seg = spec_seg(d, cap);
+// What every block of the launch does first: the headers of all segments -> per-rank sums, offsets, block totals, and the
+// verdict "every rank's slots are covered by its own particles plus its neighbours' boundary blocks".  The verdict is a
+// function of the headers alone, and every rank holds every header: all ranks arrive at the same verdict without talking.
+struct SpecHeaders {
+  cssm_u128 S[64], off[64], base[64], plow[64], phigh[64];
+  long long cnt[64];
+  cssm_u128 tot;
+  int all_ok;
+};
+__device__ __forceinline__ bool spec_read_headers(SpecHeaders& H, const double* __restrict__ recv, int world, int rank, long long cap, int d,
+                                                  uint64_t n_local, uint64_t n_global, const StepRec* __restrict__ rec) {
+  const long long seg = spec_seg(d, cap);
   if (threadIdx.x < 64) {
-    cssm_u128 S = cssm_u128_zero(), bs = cssm_u128_zero();
+    cssm_u128 S = cssm_u128_zero(), bs = cssm_u128_zero(), pl = cssm_u128_zero(), ph = cssm_u128_zero();
     long long c = 0;
     if ((int)threadIdx.x < world) {
       const double* h = recv + (size_t)threadIdx.x * seg;
       S.lo = cssm_d2u(h[1]); S.hi = cssm_d2u(h[2]); bs.lo = cssm_d2u(h[6]); bs.hi = cssm_d2u(h[7]);
+      pl.lo = cssm_d2u(h[8]); pl.hi = cssm_d2u(h[9]); ph.lo = cssm_d2u(h[10]); ph.hi = cssm_d2u(h[11]);
       c = (long long)h[0];
       c = (c < 0) ? 0 : ((c > cap) ? cap : c);
     }
-    s_S[threadIdx.x] = S; s_base[threadIdx.x] = bs; s_cnt[threadIdx.x] = c;
+    H.S[threadIdx.x] = S; H.base[threadIdx.x] = bs; H.plow[threadIdx.x] = pl; H.phigh[threadIdx.x] = ph; H.cnt[threadIdx.x] = c;
   }
   __syncthreads();
   if (threadIdx.x == 0) {
     cssm_u128 run = cssm_u128_zero();
-    for (int r = 0; r < world; ++r) { s_off[r] = run; run = cssm_u128_add(run, s_S[r]); }
-    s_tot = run;
+    for (int r = 0; r < world; ++r) { H.off[r] = run; run = cssm_u128_add(run, H.S[r]); }
+    H.tot = run;
+    H.all_ok = 1;
   }
   __syncthreads();
-  const double totd = cssm_u128_to_double(s_tot);
+  const double totd = cssm_u128_to_double(H.tot);
   const double u = rec->u;
   const bool pow2 = (n_global & (n_global - 1)) == 0;
   const double inv_n = 1.0 / (double)n_global;
   auto count_of = [&](cssm_u128 G) -> uint64_t {
+    if (cssm_u128_is_zero(G)) return 0;   // (the globally first particle starts at slot 0, as in k_offspring)
     const double C = cssm_u128_to_double(G) / totd;
     return pow2 ? cssm_sys_count_pow2(C, u, n_global, inv_n) : cssm_sys_count(C, u, n_global);
   };
-  if (bid == 0 && threadIdx.x == 0) {
-    if (redo_flag && *redo_flag) atomicOr(&sc->err, 4u);        // the max ruled the reference level out: this series needs the exact path
-    // coverage of this rank's slots by its own particles and the adjacent ranks' boundary blocks
-    const uint64_t own_begin = (rank == 0) ? 0 : count_of(s_off[rank]);
-    const uint64_t own_end = count_of(cssm_u128_add(s_off[rank], s_S[rank]));
+  if ((int)threadIdx.x < world) {
+    const int r = (int)threadIdx.x;
+    const uint64_t n_per = (n_global + (uint64_t)world - 1) / (uint64_t)world;
+    uint64_t lo = (uint64_t)r * n_per; lo = (lo < n_global) ? lo : n_global;
+    uint64_t hi = lo + n_per; hi = (hi < n_global) ? hi : n_global;
     bool ok = true;
-    if (slot_lo < own_begin && slot_lo < slot_hi) {
-      if (rank == 0) ok = false;
-      else ok = (s_cnt[rank - 1] > 0) && count_of(cssm_u128_add(s_off[rank - 1], s_base[rank - 1])) <= slot_lo;
-    }
-    if (own_end < slot_hi && slot_lo < slot_hi) {
-      if (rank == world - 1) ok = false;           // cannot happen: the last cumulative weight is exactly 1
-      else {
-        const int s = rank + 1;
-        bool up = s_cnt[s] > 0;
-        if (up) {
-          const double* h = recv + (size_t)s * seg;
-          cssm_u128 P; P.lo = cssm_d2u(h[HD + (s_cnt[s] - 1) * R + d]); P.hi = cssm_d2u(h[HD + cap * R + (s_cnt[s] - 1)]);
-          up = count_of(cssm_u128_add(s_off[s], cssm_u128_add(s_base[s], P))) >= slot_hi;
+    if (lo < hi) {
+      const uint64_t own_begin = count_of(H.off[r]);
+      const uint64_t own_end = count_of(cssm_u128_add(H.off[r], H.S[r]));
+      if (lo < own_begin) {    // the last-cap block of rank r - 1 must reach down to lo (its end is own_begin by construction)
+        if (r == 0) ok = false;
+        else {
+          const cssm_u128 Sp = H.S[r - 1], Pp = H.phigh[r - 1];
+          cssm_u128 bse; bse.lo = Sp.lo - Pp.lo; bse.hi = Sp.hi - Pp.hi - (Sp.lo < Pp.lo ? 1u : 0u);
+          ok = count_of(cssm_u128_add(H.off[r - 1], bse)) <= lo && !cssm_u128_is_zero(Pp);
         }
-        ok = ok && up;
+      }
+      if (own_end < hi) {      // the first-cap block of rank r + 1 must reach up to hi
+        if (r == world - 1) ok = false;   // cannot happen: the last cumulative weight is exactly 1
+        else ok = ok && count_of(cssm_u128_add(H.off[r + 1], H.plow[r + 1])) >= hi;
       }
     }
-    if (!ok) atomicOr(&sc->err, 8u);
+    if (!ok) H.all_ok = 0;
   }
+  __syncthreads();
+  (void)rank; (void)n_local;
+  return H.all_ok != 0;
+}
+
+__device__ __forceinline__ void expand_spec_body(SpecHeaders& H, uint32_t bid, uint32_t nblk, const double* __restrict__ recv, int world, int rank,
+                                                 long long cap, int d, uint32_t n_split, uint64_t slot_lo, uint64_t slot_hi, uint64_t n_global,
+                                                 const StepRec* __restrict__ rec, uint32_t* __restrict__ anc, Scalars* __restrict__ sc) {
+  __shared__ uint32_t s_nheavy;
+  __shared__ uint32_t s_hb[CSSM_BLOCK], s_he[CSSM_BLOCK], s_hj[CSSM_BLOCK];
+  const long long R = d + 1, HD = spec_hdr(d), seg = spec_seg(d, cap);
+  const double totd = cssm_u128_to_double(H.tot);
+  const double u = rec->u;
+  const bool pow2 = (n_global & (n_global - 1)) == 0;
+  const double inv_n = 1.0 / (double)n_global;
+  auto count_of = [&](cssm_u128 G) -> uint64_t {
+    if (cssm_u128_is_zero(G)) return 0;
+    const double C = cssm_u128_to_double(G) / totd;
+    return pow2 ? cssm_sys_count_pow2(C, u, n_global, inv_n) : cssm_sys_count(C, u, n_global);
+  };
   if (bid == 0 && threadIdx.x < CSSM_MAXSLOTS) sc->maxslot[(size_t)threadIdx.x * CSSM_SLOT_STRIDE] = 0ull;   // set 0 for the next step
   const long long total = (long long)world * cap;
   for (long long base = (long long)bid * CSSM_BLOCK; base < total; base += (long long)nblk * CSSM_BLOCK) {
@@ -1450,14 +1500,14 @@ __device__ __forceinline__ void expand_spec_body(uint32_t bid, uint32_t nblk, co
     if (idx < total) {
       const int s = (int)(idx / cap);
       const long long i = idx - (long long)s * cap;
-      if (s != rank && i < s_cnt[s]) {
+      if (s != rank && i < H.cnt[s]) {
         const double* h = recv + (size_t)s * seg;
-        const cssm_u128 off = cssm_u128_add(s_off[s], s_base[s]);
+        const cssm_u128 off = cssm_u128_add(H.off[s], H.base[s]);
         cssm_u128 P; P.lo = cssm_d2u(h[HD + i * R + d]); P.hi = cssm_d2u(h[HD + cap * R + i]);
         uint64_t e = count_of(cssm_u128_add(off, P));
         uint64_t b;
         if (i == 0) {
-          b = cssm_u128_is_zero(off) ? 0 : count_of(off);   // (the globally first particle starts at slot 0, as in k_offspring)
+          b = count_of(off);
         } else {
           cssm_u128 Pp; Pp.lo = cssm_d2u(h[HD + (i - 1) * R + d]); Pp.hi = cssm_d2u(h[HD + cap * R + (i - 1)]);
           b = count_of(cssm_u128_add(off, Pp));
@@ -1484,24 +1534,27 @@ __device__ __forceinline__ void expand_spec_body(uint32_t bid, uint32_t nblk, co
     __syncthreads();
   }
 }
-
-__global__ __launch_bounds__(CSSM_BLOCK) void k_expand_spec(const double* __restrict__ recv, int world, int rank, long long cap, int d,
-                                                            uint32_t n_split, uint64_t slot_lo, uint64_t slot_hi, uint64_t n_global,
-                                                            const StepRec* __restrict__ rec, uint32_t* __restrict__ anc,
-                                                            Scalars* __restrict__ sc, const unsigned long long* __restrict__ redo_flag) {
-  expand_spec_body(blockIdx.x, gridDim.x, recv, world, rank, cap, d, n_split, slot_lo, slot_hi, n_global, rec, anc, sc, redo_flag);
-}
 // Offspring of the own particles and expansion of the received rows in ONE launch: the two are independent once the
 // exchange is done (disjoint slots; both read only the segment headers), and a launch costs ~5 us of latency.  Blocks
-// [0, nunits) are k_offspring's, the rest k_expand_spec's; `optimistic` = 2 makes the offspring side raise err bit 2
+// [0, nunits) are k_offspring's, the rest expand the rows; `optimistic` = 2 makes the offspring side raise err bit 2
 // itself (no later kernel reads the flag).
+// EVERY block first takes the verdict of spec_read_headers.  If some rank's slots are not covered, the whole launch
+// does NOTHING on every rank except recording err bit 3 and the observation index: the state is exactly as the
+// propagate of this observation left it, every later kernel of the series returns at once (they test the bit), and
+// the host redoes this observation's exchange with a larger capacity and carries on (cssm_pf_shard_resume).
 __global__ __launch_bounds__(CSSM_BLOCK, CSSM_OFF_WAVES) void k_offspring_expand_spec(
     CSSM_OFFSPRING_PARAMS, uint32_t all5_stride, const double* __restrict__ recv, long long cap, int d, uint32_t n_split) {
+  __shared__ SpecHeaders H;
+  if (sc->err & 8u) return;
+  if (!spec_read_headers(H, recv, world, rank, cap, d, n, n_global, rec)) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) { atomicOr(&sc->err, 8u); atomicMin(&sc->fail_step, rec->step); }
+    return;
+  }
   if (blockIdx.x < nunits) {
     offspring_body<true, false, CSSM_RESAMPLE_SYSTEMATIC>(CSSM_OFFSPRING_FWD, all5_stride);
   } else {
-    expand_spec_body(blockIdx.x - nunits, gridDim.x - nunits, recv, world, rank, cap, d, n_split, (uint64_t)slot_lo, (uint64_t)slot_hi,
-                     n_global, rec, anc, sc, nullptr);
+    expand_spec_body(H, blockIdx.x - nunits, gridDim.x - nunits, recv, world, rank, cap, d, n_split, (uint64_t)slot_lo, (uint64_t)slot_hi,
+                     n_global, rec, anc, sc);
   }
 }
 

@@ -102,6 +102,8 @@ struct cssm_pf {
   uint32_t* d_need = nullptr;  // per step: the largest send count of this rank (how much capacity the step needed)
   size_t need_cap = 0;
   bool series = false;         // records of a whole series are resident (cssm_pf_shard_begin)
+  struct Snap { int cur; const double* src; size_t src_stride; const double* src2; size_t src2_stride; uint32_t n_split; bool anc_valid, last_optimistic; uint32_t step; double t; };
+  std::vector<Snap> snaps;     // host-side state right after the propagate of every observation of the series (cssm_pf_shard_resume)
   // host staging (pinned)
   StepRec* h_recs = nullptr;
   size_t h_recs_cap = 0;
@@ -459,6 +461,7 @@ static int reset_scalars(cssm_pf* pf) {
   Scalars h;
   memset(&h, 0, sizeof h);
   h.ess = (int32_t)(pf->n_global < 2147483647ull ? pf->n_global : 2147483647ull);
+  h.fail_step = 0xffffffffu;
   // pageable source: the copy is staged before the call returns, so a stack object is safe
   HIP_TRY(hipMemcpyAsync(pf->sc, &h, sizeof h, hipMemcpyHostToDevice, pf->stream));
   return CSSM_OK;
@@ -1384,6 +1387,36 @@ extern "C" int cssm_pf_shard_propagate_at(cssm_pf* pf, size_t s, uint64_t* sums5
   rc = shard_prepare_step(pf, pf->d_recs + s, pf->h_recs[s].has_obs, sums5_dev);
   if (rc) return rc;
   pf->step++;
+  if (pf->snaps.size() <= s) pf->snaps.resize(s + 1);
+  pf->snaps[s] = {pf->cur, pf->src, pf->src_stride, pf->src2, pf->src2_stride, pf->n_split, pf->anc_valid, pf->last_optimistic, pf->step, pf->t};
+  return CSSM_OK;
+}
+
+// A capacity miss of the single-collective series is not the end of the series.  k_offspring_expand_spec of the observation
+// that missed did nothing (on every rank alike: the verdict is a function of the segment headers), recorded the observation
+// index, and every later kernel returned at once.  This call reads that index, clears the bit and rewinds the host-side
+// state to "observation fail_step propagated, not yet resampled": the host then redoes that observation's exchange with
+// a larger capacity (boundary_pack, all-to-all, adopt_spec) and continues the series after it.
+extern "C" int cssm_pf_shard_resume(cssm_pf* pf, uint32_t* fail_step_out) {
+  int rc = shard_check(pf);
+  if (rc) return rc;
+  if (!fail_step_out) return fail(CSSM_EINVAL_ARG, "null argument");
+  Scalars h;
+  HIP_TRY(hipMemcpyAsync(&h, pf->sc, sizeof h, hipMemcpyDeviceToHost, pf->stream));
+  HIP_TRY(hipStreamSynchronize(pf->stream));
+  if (!(h.err & 8u) || h.fail_step == 0xffffffffu || h.fail_step >= pf->snaps.size())
+    return fail(CSSM_ESTATE, "no resumable capacity miss is recorded");
+  if (h.err & 7u) return fail(CSSM_ESTATE, "the series has other errors (bits %u)", h.err);
+  const uint32_t s = h.fail_step;
+  h.err &= ~8u; h.fail_step = 0xffffffffu;
+  // only err and fail_step change on the device (ll, ess, sums stay what the last completed observation left)
+  HIP_TRY(hipMemcpyAsync(&pf->sc->err, &h.err, sizeof(uint32_t), hipMemcpyHostToDevice, pf->stream));
+  HIP_TRY(hipMemcpyAsync(&pf->sc->fail_step, &h.fail_step, sizeof(uint32_t), hipMemcpyHostToDevice, pf->stream));
+  HIP_TRY(hipStreamSynchronize(pf->stream));
+  const cssm_pf::Snap& q = pf->snaps[s];
+  pf->cur = q.cur; pf->src = q.src; pf->src_stride = q.src_stride; pf->src2 = q.src2; pf->src2_stride = q.src2_stride;
+  pf->n_split = q.n_split; pf->anc_valid = q.anc_valid; pf->last_optimistic = q.last_optimistic; pf->step = q.step; pf->t = q.t;
+  *fail_step_out = s;
   return CSSM_OK;
 }
 

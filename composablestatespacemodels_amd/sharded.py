@@ -141,6 +141,13 @@ class GpuShard:
                                                       C.c_void_p(send_buf.data_ptr()), C.c_void_p(recv_buf.data_ptr()),
                                                       1 if single_collective else 0))
 
+    def resume(self) -> int:
+        """After a capacity miss of the single-collective series: the observation that missed (its propagate is done,
+        its resampling is not); the sticky bit is cleared and the handle rewound to that point."""
+        k = C.c_uint32()
+        _abi.check(self.lib.cssm_pf_shard_resume(self._h, C.byref(k)))
+        return int(k.value)
+
     def status(self, T: int):
         """(ll, ess, sticky bits, capacity needed per step) of the series just run."""
         ll, ess, bits = C.c_double(), C.c_int32(), C.c_uint32()
@@ -403,7 +410,15 @@ class ShardedFilter:
     # uneven and the exchange largest), which also tells how much capacity the fixed exchange needs afterwards.
     EXACT_STEPS = 4
     MIN_CAP = 1024
-    CAP_HEADROOM = 4      # capacity = CAP_HEADROOM x the largest exchange seen during the exact steps
+    CAP_HEADROOM = 2      # capacity >= CAP_HEADROOM x the largest exchange seen during the exact steps
+    # ... and >= CAP_SQRT x sqrt(N_global): the number of particles whose runs cross a rank boundary is the deviation of a
+    # cumulative weight from its mean, ~ sqrt(N x (N/ESS - 1)); the first observations do not show how uneven the weights
+    # of a later, more informative observation will be (bench workload, 2^20 particles per rank: median 660 rows, maximum
+    # 6237 / 9879 / 14184 at world 2 / 4 / 8 = 4.3 .. 4.9 sqrt(N), tools/need_probe.py).  A series that needs more is
+    # still computed correctly: it is repeated with the exact exchange.
+    CAP_SQRT = 6.0
+    NATIVE_STRETCH = 128  # observations the library enqueues between two looks at the sticky bits
+    last_resumes = 0
 
     def ll_filter(self, t, y, has=None, lgcp: bool = False, exact: bool = False):
         t = np.asarray(t, dtype=np.float64)
@@ -419,42 +434,75 @@ class ShardedFilter:
             cap, seen, done_exact, native = None, 0, 0, None
             import os
             single = (not lgcp) and all(hasattr(s, "boundary_pack") for s in S) and os.environ.get("CSSM_SHARD_SINGLE", "1") != "0"
-            for k in range(T):
+            k, resumes, redo_exchange, redo_cap, escalated = 0, 0, False, 0, {}
+            while k < T:
                 exact_k = bool(weighted[k]) and (all_exact or done_exact < self.EXACT_STEPS)
                 if weighted[k] and not exact_k and cap is None:
                     # every rank must use the same capacity: agree on the largest count seen so far
-                    cap = min(max(self.MIN_CAP, self.CAP_HEADROOM * comm.agree_max([seen] * len(S))), n_max)
+                    cap = min(max(self.MIN_CAP, self.CAP_HEADROOM * comm.agree_max([seen] * len(S)),
+                                  int(self.CAP_SQRT * S[0].n_global ** 0.5)), n_max)
                     if cap >= 1024:
                         cap = min(-(-cap // 1024) * 1024, n_max)   # whole tiles: the boundary blocks then line up with k_propagate's sums
                     native = comm.native_comm() if (len(S) == 1 and hasattr(comm, "native_comm")) else None
                 spec_k = bool(weighted[k]) and not exact_k and single
-                for s in S:
-                    if spec_k:
-                        s.propagate_at(k, with_sums=False)
-                    else:
-                        s.propagate_at(k)
+                if not redo_exchange:               # (after a resume the observation is already propagated)
+                    for s in S:
+                        if spec_k:
+                            s.propagate_at(k, with_sums=False)
+                        else:
+                            s.propagate_at(k)
+                redo_exchange = False
                 if not weighted[k]:
+                    k += 1
                     continue
                 if exact_k:
                     seen = max(seen, self._resample_exact(lgcp))
                     done_exact += 1
+                    k += 1
                     continue
                 if spec_k:
-                    self._resample_spec(cap)
+                    self._resample_spec(redo_cap if redo_cap else cap)   # (a resumed observation: with its enlarged capacity only)
                 else:
                     self._resample_fixed(cap)
-                if native is not None and k + 1 < T:
-                    # the rest of the series is enqueued by the library itself: kernels and RCCL collectives on one
-                    # stream, no host-language call per observation (cssm_pf_shard_series_rccl)
+                redo_cap = 0
+                k += 1
+                stretch_end = False
+                if native is not None and k < T:
+                    # the series behind this observation is enqueued by the library itself: kernels and RCCL collectives on
+                    # one stream, no host-language call per observation (cssm_pf_shard_series_rccl) -- in stretches of
+                    # NATIVE_STRETCH observations, so that a capacity miss is noticed (one status read per stretch) before
+                    # the whole tail has been enqueued in vain
+                    kend = min(k + self.NATIVE_STRETCH, T) if single else T
                     if single:
                         nb = comm.world * S[0].spec_segment(cap)
-                        S[0].series_native(native, k + 1, T, weighted, cap, S[0].buffer("send_spec", nb)[:nb],
+                        S[0].series_native(native, k, kend, weighted, cap, S[0].buffer("send_spec", nb)[:nb],
                                            S[0].buffer("recv_spec", nb)[:nb], single_collective=True)
                     else:
                         nb = comm.world * (cap + 1) * (self.d + 1)
-                        S[0].series_native(native, k + 1, T, weighted, cap, S[0].buffer("send_fixed", nb)[:nb],
+                        S[0].series_native(native, k, kend, weighted, cap, S[0].buffer("send_fixed", nb)[:nb],
                                            S[0].buffer("recv_fixed", nb)[:nb])
-                    break
+                    k = kend
+                    stretch_end = True
+                if (k == T or stretch_end) and single and cap < n_max and resumes < 64:
+                    # A capacity miss of the single-collective exchange is resumable: the observation that missed was left
+                    # untouched on every rank (all reach the same verdict from the segment headers, so bit 8 needs no
+                    # agreement) and every kernel behind it returned at once.  Redo its exchange with four times the
+                    # capacity and carry on behind it.
+                    bits = max(s.status(T)[2] for s in S)
+                    if bits == 8:
+                        ks = [s.resume() for s in S]
+                        k = comm.agree_max([max(ks)] * len(S))
+                        if any(v != k for v in ks):
+                            raise RuntimeError("ranks disagree on the observation whose exchange did not fit")
+                        # four times the capacity for THAT observation (again four times if it missed before); the series
+                        # behind it goes on with the ordinary capacity
+                        escalated[k] = min(escalated.get(k, cap) * 4, n_max)
+                        redo_cap = escalated[k]
+                        if redo_cap >= 1024:
+                            redo_cap = min(-(-redo_cap // 1024) * 1024, n_max)
+                        resumes += 1
+                        redo_exchange = True
+            self.last_resumes = resumes
             self.last_single = single
             self.last_native = native is not None
             res = [s.status(T) for s in S]

@@ -355,6 +355,12 @@ int cssm_pf_shard_series_rccl(cssm_pf* pf, void* comm, int rank, int world, size
 int64_t cssm_pf_shard_spec_segment(const cssm_pf* pf, int64_t cap);
 int cssm_pf_shard_boundary_pack(cssm_pf* pf, int rank, int world, int64_t cap, double* send_buf_dev);
 int cssm_pf_shard_adopt_spec(cssm_pf* pf, const double* recv_buf_dev, int rank, int world, int64_t cap);
+/* A capacity miss of the single-collective series is resumable.  The launch that found some rank's slots uncovered did
+ * nothing on any rank (every rank reaches the same verdict from the segment headers), recorded the observation index and
+ * sticky bit 8, and every later kernel of the series returned at once.  cssm_pf_shard_resume returns that index, clears
+ * the bit and rewinds the handle to "that observation propagated, not yet resampled"; the host redoes its exchange with a
+ * larger capacity (boundary_pack, all-to-all, adopt_spec) and continues the series behind it. */
+int cssm_pf_shard_resume(cssm_pf* pf, uint32_t* fail_step_out);
 
 /* ---- PMMH host loop ---------------------------------------------------------------------- */
 /*

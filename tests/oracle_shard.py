@@ -49,6 +49,7 @@ class OracleShard:
         self.send_first, self.send_count = self.meta[:world], self.meta[world:2 * world]
         self.recv_count, self.redo_flag = self.meta[2 * world:3 * world], self.meta[3 * world:]
         self.redone = 0
+        self.bits, self.fail_step = 0, None
         self.ll, self.ess, self.step_idx = 0.0, n_global, 0
 
     def buffer(self, name, n):
@@ -163,20 +164,33 @@ class OracleShard:
     def begin(self, t, y, has):
         self._t = np.asarray(t, dtype=np.float64); self._y = np.asarray(y, dtype=np.float64)
         self._has = np.ones(len(self._t), dtype=np.uint8) if has is None else np.asarray(has)
-        self.bits, self.need = 0, np.zeros(len(self._t), dtype=np.uint32)
+        self.bits, self.need, self.fail_step = 0, np.zeros(len(self._t), dtype=np.uint32), None
         self.init(float(self._t.min()))
 
     def propagate_at(self, k, with_sums=True):
+        if self.bits & 8:
+            return                                   # on hold after a capacity miss: nothing may change until resume()
         self.propagate(float(self._t[k]), float(self._y[k]), bool(self._has[k]) or self.o_is_lgcp())
+
+    def resume(self):
+        """The observation whose exchange did not fit (its propagate is done); the hold is lifted."""
+        assert self.bits & 8 and self.fail_step is not None
+        self.bits &= ~8
+        k, self.fail_step = self.fail_step, None
+        return k
 
     # ---- the single-collective exchange of GpuShard (k_boundary_pack / k_offspring_expand_spec), restated
     def spec_segment(self, cap):
         R = self.d + 1
-        return R * ((8 + self.d) // R) + cap * R + R * ((cap + self.d) // R)
+        return R * ((12 + self.d) // R) + cap * R + R * ((cap + self.d) // R)
 
     def boundary_pack(self, cap, send_buf):
+        if self.bits & 8:
+            return
         R, seg = self.d + 1, self.spec_segment(cap)
-        HD = R * ((8 + self.d) // R)
+        HD = R * ((12 + self.d) // R)
+        cnt_all = min(self.n, cap)
+        plow, phigh = sum(self.q[:cnt_all]), sum(self.q[self.n - cnt_all:])
         buf = send_buf.numpy()
         bits = buf.view(np.uint64)
         buf[: self.world * seg] = 0.0
@@ -197,30 +211,52 @@ class OracleShard:
             for i, w in enumerate(words):
                 bits[o + 1 + i] = w
             bits[o + 6] = base & (2**64 - 1); bits[o + 7] = base >> 64
+            bits[o + 8] = plow & (2**64 - 1); bits[o + 9] = plow >> 64
+            bits[o + 10] = phigh & (2**64 - 1); bits[o + 11] = phigh >> 64
             for i in range(cnt):
                 buf[o + HD + i * R: o + HD + i * R + self.d] = self.x1[:, first + i]
                 bits[o + HD + i * R + self.d] = P[i] & (2**64 - 1)
                 bits[o + HD + cap * R + i] = P[i] >> 64
 
     def adopt_spec(self, recv_buf, cap):
+        if self.bits & 8:
+            return
         R, seg = self.d + 1, self.spec_segment(cap)
-        HD = R * ((8 + self.d) // R)
+        HD = R * ((12 + self.d) // R)
         buf = recv_buf.numpy()
         bits = buf.view(np.uint64)
         to_i64 = lambda x: x - 2**64 if x >= 2**63 else x
         for r in range(self.world):                       # every rank's 5 words are in the segment headers
             for i in range(5):
                 self.all_sums[5 * r + i] = to_i64(int(bits[r * seg + 1 + i]))
-        self.offspring()                                   # own particles: level, ll, ess, end slots E
-        if int(self.redo_flag[0]):
-            self.bits |= 4
-            return
         v = [int(x) for x in self.all_sums.tolist()]
         S = [_join64(v[5 * r], v[5 * r + 1]) for r in range(self.world)]
         off = [sum(S[:r]) for r in range(self.world)]
         totd = float(sum(S))
         u = oracle.lib().oracle_c_u(self.seed, self.step_idx - 1)
-        cnt_of = lambda G: int(oracle.lib().oracle_c_sys_count(float(G) / totd, u, self.n_global))
+        cnt_of = lambda G: 0 if G == 0 else int(oracle.lib().oracle_c_sys_count(float(G) / totd, u, self.n_global))
+        # the verdict every rank reaches from the headers alone: are EVERY rank's slots covered?
+        plow = [int(bits[r * seg + 8]) | (int(bits[r * seg + 9]) << 64) for r in range(self.world)]
+        phigh = [int(bits[r * seg + 10]) | (int(bits[r * seg + 11]) << 64) for r in range(self.world)]
+        per = (self.n_global + self.world - 1) // self.world
+        all_ok = True
+        for r in range(self.world):
+            lo = min(r * per, self.n_global); hi = min(lo + per, self.n_global)
+            if lo >= hi:
+                continue
+            own_begin, own_end = cnt_of(off[r]), cnt_of(off[r] + S[r])
+            if lo < own_begin:
+                all_ok &= r > 0 and phigh[r - 1] > 0 and cnt_of(off[r - 1] + S[r - 1] - phigh[r - 1]) <= lo
+            if own_end < hi:
+                all_ok &= r < self.world - 1 and cnt_of(off[r + 1] + plow[r + 1]) >= hi
+        if not all_ok:
+            self.bits |= 8                                  # nothing is touched: the host resumes this observation with more capacity
+            self.fail_step = self.step_idx - 1 if self.fail_step is None else min(self.fail_step, self.step_idx - 1)
+            return
+        self.offspring()                                   # own particles: level, ll, ess, end slots E
+        if int(self.redo_flag[0]):
+            self.bits |= 4
+            return
         cands = {}
         for sdr in range(self.world):
             if sdr == self.rank:
@@ -235,17 +271,6 @@ class OracleShard:
             begin = 0 if (off[sdr] + base) == 0 else cnt_of(off[sdr] + base)
             cands[sdr] = (begin, rows)
         slot_lo, slot_hi = self.first, self.first + self.n
-        own_begin = 0 if self.rank == 0 else cnt_of(off[self.rank])
-        own_end = cnt_of(off[self.rank] + S[self.rank])
-        ok = True
-        if slot_lo < own_begin:
-            ok = self.rank > 0 and len(cands[self.rank - 1][1]) > 0 and cands[self.rank - 1][0] <= slot_lo
-        if own_end < slot_hi:
-            up = self.rank < self.world - 1 and len(cands[self.rank + 1][1]) > 0 and cands[self.rank + 1][1][-1][1] >= slot_hi
-            ok = ok and up
-        if not ok:
-            self.bits |= 8
-            return
         low = [row for sdr in range(self.rank) for row in cands[sdr][1]]
         high = [row for sdr in range(self.rank + 1, self.world) for row in cands[sdr][1]]
         own = [(self.x1[:, j], int(self.E[j])) for j in range(self.n)]

@@ -46,10 +46,10 @@ def _worker(rank, world, port, name, n, T, missing, prec, out_dir, single):
         if missing == -0.2:        # the outlier falls into the fixed-capacity part of the series
             f.EXACT_STEPS = 1
         if missing == 0.05:        # capacity too small for what the exchange needs: the series is repeated exactly
-            f.EXACT_STEPS, f.MIN_CAP, f.CAP_HEADROOM = 1, 1, 0
+            f.EXACT_STEPS, f.MIN_CAP, f.CAP_HEADROOM, f.CAP_SQRT = 1, 1, 0, 0.0
         ll, ess = f.ll_filter(t, y, has, lgcp=bool(prec))
         np.savez(os.path.join(out_dir, f"r{rank}.npz"), ll=ll, ess=ess, part=shard.particles(), redone=shard.redone,
-                 attempts=f.last_attempts, cap=-1 if f.last_cap is None else f.last_cap, single=int(f.last_single))
+                 attempts=f.last_attempts, cap=-1 if f.last_cap is None else f.last_cap, single=int(f.last_single), resumes=int(f.last_resumes))
     finally:
         dist.destroy_process_group()
 
@@ -81,7 +81,9 @@ def test_sharded_orchestration_over_gloo_matches_single_rank(tmp_path, world, na
         # the second attempt runs exactly for the steps whose level the max rules out (LGCP: every step)
         assert int(z["redone"]) == (T if prec else (1 if missing < 0 else 0))
         # a series is run once unless a sticky bit (level ruled out / capacity exceeded in its fixed-capacity part) voids it
-        assert int(z["attempts"]) == (2 if missing in (-0.2, 0.05) else 1)
+        resumed = (missing == 0.05 and single == "1")     # a capacity miss of the single-collective exchange is resumed, not repeated
+        assert int(z["attempts"]) == (1 if resumed else (2 if missing in (-0.2, 0.05) else 1))
+        assert (int(z["resumes"]) >= 1) == resumed
         if T > 8 and missing == 0.0:
             assert int(z["cap"]) >= 1             # the fixed-capacity exchange did run
         assert int(z["single"]) == (0 if prec else int(single))
