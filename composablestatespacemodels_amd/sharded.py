@@ -466,8 +466,30 @@ class ShardedFilter:
                     self._resample_fixed(cap)
                 redo_cap = 0
                 k += 1
-                stretch_end = False
-                if native is not None and k < T:
+                def look_for_a_miss():
+                    """A capacity miss of the single-collective exchange is resumable: the observation that missed was left
+                    untouched on every rank (all reach the same verdict from the segment headers, so bit 8 needs no
+                    agreement) and every kernel behind it returned at once.  Its exchange is redone with four times the
+                    capacity (again four times if it missed before); the series behind it keeps the ordinary capacity."""
+                    nonlocal k, resumes, redo_exchange, redo_cap
+                    if not (single and cap < n_max and resumes < 64):
+                        return False
+                    if max(s.status(T)[2] for s in S) != 8:
+                        return False
+                    ks = [s.resume() for s in S]
+                    k = comm.agree_max([max(ks)] * len(S))
+                    if any(v != k for v in ks):
+                        raise RuntimeError("ranks disagree on the observation whose exchange did not fit")
+                    escalated[k] = min(escalated.get(k, cap) * 4, n_max)
+                    redo_cap = escalated[k]
+                    if redo_cap >= 1024:
+                        redo_cap = min(-(-redo_cap // 1024) * 1024, n_max)
+                    resumes += 1
+                    redo_exchange = True
+                    return True
+
+                missed = False
+                while native is not None and k < T and not missed:
                     # the series behind this observation is enqueued by the library itself: kernels and RCCL collectives on
                     # one stream, no host-language call per observation (cssm_pf_shard_series_rccl) -- in stretches of
                     # NATIVE_STRETCH observations, so that a capacity miss is noticed (one status read per stretch) before
@@ -482,26 +504,9 @@ class ShardedFilter:
                         S[0].series_native(native, k, kend, weighted, cap, S[0].buffer("send_fixed", nb)[:nb],
                                            S[0].buffer("recv_fixed", nb)[:nb])
                     k = kend
-                    stretch_end = True
-                if (k == T or stretch_end) and single and cap < n_max and resumes < 64:
-                    # A capacity miss of the single-collective exchange is resumable: the observation that missed was left
-                    # untouched on every rank (all reach the same verdict from the segment headers, so bit 8 needs no
-                    # agreement) and every kernel behind it returned at once.  Redo its exchange with four times the
-                    # capacity and carry on behind it.
-                    bits = max(s.status(T)[2] for s in S)
-                    if bits == 8:
-                        ks = [s.resume() for s in S]
-                        k = comm.agree_max([max(ks)] * len(S))
-                        if any(v != k for v in ks):
-                            raise RuntimeError("ranks disagree on the observation whose exchange did not fit")
-                        # four times the capacity for THAT observation (again four times if it missed before); the series
-                        # behind it goes on with the ordinary capacity
-                        escalated[k] = min(escalated.get(k, cap) * 4, n_max)
-                        redo_cap = escalated[k]
-                        if redo_cap >= 1024:
-                            redo_cap = min(-(-redo_cap // 1024) * 1024, n_max)
-                        resumes += 1
-                        redo_exchange = True
+                    missed = look_for_a_miss()
+                if native is None and k == T:
+                    look_for_a_miss()                # host-driven series: one look at its end
             self.last_resumes = resumes
             self.last_single = single
             self.last_native = native is not None
