@@ -1412,6 +1412,7 @@ __global__ __launch_bounds__(CSSM_BLOCK) void k_boundary_pack(const double* __re
 struct SpecHeaders {
   cssm_u128 S[64], off[64], base[64], plow[64], phigh[64];
   long long cnt[64];
+  unsigned long long cnts[64][4];
   cssm_u128 tot;
   int all_ok;
 };
@@ -1447,6 +1448,23 @@ __device__ __forceinline__ bool spec_read_headers(SpecHeaders& H, const double* 
     const double C = cssm_u128_to_double(G) / totd;
     return pow2 ? cssm_sys_count_pow2(C, u, n_global, inv_n) : cssm_sys_count(C, u, n_global);
   };
+  // four slot counts per rank (own begin / end, reach of the lower neighbour's last block / of the upper neighbour's first
+  // block), one thread each: the verdict is on every block's critical path
+  if ((int)threadIdx.x < 4 * world) {
+    const int r = (int)(threadIdx.x >> 2), which = (int)(threadIdx.x & 3);
+    uint64_t v = 0;
+    if (which == 0) v = count_of(H.off[r]);
+    else if (which == 1) v = count_of(cssm_u128_add(H.off[r], H.S[r]));
+    else if (which == 2) {
+      if (r > 0) {
+        const cssm_u128 Sp = H.S[r - 1], Pp = H.phigh[r - 1];
+        cssm_u128 bse; bse.lo = Sp.lo - Pp.lo; bse.hi = Sp.hi - Pp.hi - (Sp.lo < Pp.lo ? 1u : 0u);
+        v = count_of(cssm_u128_add(H.off[r - 1], bse));
+      }
+    } else if (r + 1 < world) v = count_of(cssm_u128_add(H.off[r + 1], H.plow[r + 1]));
+    H.cnts[r][which] = v;
+  }
+  __syncthreads();
   if ((int)threadIdx.x < world) {
     const int r = (int)threadIdx.x;
     const uint64_t n_per = (n_global + (uint64_t)world - 1) / (uint64_t)world;
@@ -1454,20 +1472,11 @@ __device__ __forceinline__ bool spec_read_headers(SpecHeaders& H, const double* 
     uint64_t hi = lo + n_per; hi = (hi < n_global) ? hi : n_global;
     bool ok = true;
     if (lo < hi) {
-      const uint64_t own_begin = count_of(H.off[r]);
-      const uint64_t own_end = count_of(cssm_u128_add(H.off[r], H.S[r]));
-      if (lo < own_begin) {    // the last-cap block of rank r - 1 must reach down to lo (its end is own_begin by construction)
-        if (r == 0) ok = false;
-        else {
-          const cssm_u128 Sp = H.S[r - 1], Pp = H.phigh[r - 1];
-          cssm_u128 bse; bse.lo = Sp.lo - Pp.lo; bse.hi = Sp.hi - Pp.hi - (Sp.lo < Pp.lo ? 1u : 0u);
-          ok = count_of(cssm_u128_add(H.off[r - 1], bse)) <= lo && !cssm_u128_is_zero(Pp);
-        }
-      }
-      if (own_end < hi) {      // the first-cap block of rank r + 1 must reach up to hi
-        if (r == world - 1) ok = false;   // cannot happen: the last cumulative weight is exactly 1
-        else ok = ok && count_of(cssm_u128_add(H.off[r + 1], H.plow[r + 1])) >= hi;
-      }
+      const uint64_t own_begin = H.cnts[r][0], own_end = H.cnts[r][1];
+      if (lo < own_begin)      // the last-cap block of rank r - 1 must reach down to lo (its end is own_begin by construction)
+        ok = (r > 0) && H.cnts[r][2] <= lo && !cssm_u128_is_zero(H.phigh[r - 1]);
+      if (own_end < hi)        // the first-cap block of rank r + 1 must reach up to hi (r = world - 1 cannot get here:
+        ok = ok && (r + 1 < world) && H.cnts[r][3] >= hi;   //  the last cumulative weight is exactly 1)
     }
     if (!ok) H.all_ok = 0;
   }
