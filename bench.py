@@ -138,9 +138,9 @@ def run_multi(args, emit=print):
     model, t, y, has = build_workload(max(K, W, 8))
     shard = GpuShard(model, n_global, rank, world, 20260101, local)
     f = ShardedFilter([shard], DistComm(device=torch.device("cuda", local)))
-    # warm-up: allocations, RCCL channels, clocks.  At least 8 observations whatever W is: the first 4 of a series use the
-    # exact exchange, and the library's own RCCL communicator and the capacity buffers are created at the first
-    # observation after them -- that must not happen inside the timed region
+    # warm-up: allocations, RCCL channels, clocks.  At least 8 observations whatever W is: the library's own RCCL
+    # communicator and the exchange buffers are created at the first observation of the first series -- that must not
+    # happen inside the timed region
     Wn = max(W, 8)
     tw, yw, hw = build_workload(Wn)[1:]
     f.ll_filter(tw[:Wn], yw[:Wn], hw[:Wn])
@@ -161,8 +161,8 @@ def run_multi(args, emit=print):
             "config": {"workload": "configs[1] sharded: seasonal-Poisson, OU latent (d=3), "
                                    f"{args.particles} particles per GPU x {world} GPUs = {n_global}, T={K}, global systematic "
                                    "resampling every observation (per observation over RCCL, enqueued by the library itself: one equal-split all-to-all "
-                                   f"carrying every rank's 5 sum words and its boundary particles, capacity {f.last_cap} rows per pair; the first "
-                                   f"{f.EXACT_STEPS} observations use the exact all-to-all-v exchange)",
+                                   f"carrying every rank's 5 sum words and its boundary particles, capacity {f.last_cap} rows per pair, "
+                                   f"{getattr(f, 'last_resumes', 0)} resumed capacity misses)",
                        "particles_per_gpu": args.particles, "observations": K, "latent_dim": shard.d, "seed": 20260101},
             "exchange": {"capacity_rows": f.last_cap, "attempts": f.last_attempts,
                          "collectives_issued_by": "libcssm_pf (cssm_pf_shard_series_rccl)" if getattr(f, "last_native", False) else "torch.distributed",

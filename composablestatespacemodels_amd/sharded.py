@@ -12,8 +12,10 @@ Per observation (stage calls of include/cssm_pf.h), after the firs
    particles; the received rows expanded to the slots the own particles left open; coverage check
 
 (``CSSM_SHARD_SINGLE=0``: the earlier exchange -- all-gather of 5 words, ``shard_offspring_pack``, all-to-all,
-``shard_adopt_fixed``.)  The first observations use the exact exchange: all-gather, ``shard_offspring``, all-to-all of
-the range sizes, all-to-all-v of (d + 1) doubles per candidate, ``shard_adopt`` -- with a host read of the sizes.
+``shard_adopt_fixed``.)  The exact exchange -- all-gather, ``shard_offspring``, all-to-all of the range sizes, all-to-all-v
+of (d + 1) doubles per candidate, ``shard_adopt``, with a host read of the sizes -- serves LGCP series and the repetition
+of a series whose reference level an outlying observation ruled out.  A capacity miss of the single-collective exchange
+is resumed in place (``shard_resume``).
 
 Random variates are keyed by the GLOBAL particle id and every sum is an integer sum, so ll, ess
 and the ancestor arrays are bit-identical for 1, 2, 4 and 8 ranks.
@@ -408,7 +410,7 @@ class ShardedFilter:
 
     # A series is begun with the exact exchange (the first observations of a filter are where the weights are most
     # uneven and the exchange largest), which also tells how much capacity the fixed exchange needs afterwards.
-    EXACT_STEPS = 4
+    EXACT_STEPS = 0       # (observations run with the exact, host-read exchange before the capacity is fixed; kept for experiments)
     MIN_CAP = 1024
     CAP_HEADROOM = 2      # capacity >= CAP_HEADROOM x the largest exchange seen during the exact steps
     # ... and >= CAP_SQRT x sqrt(N_global): the number of particles whose runs cross a rank boundary is the deviation of a

@@ -43,6 +43,8 @@ def _worker(rank, world, port, name, n, T, missing, prec, out_dir, single):
         t, y, has = _series(C, T, missing, prec)
         shard = OracleShard(model, n, rank, world, C.SEED, prec)
         f = ShardedFilter([shard], DistComm())
+        if missing == -0.1:        # the outlier falls into a prefix run with the exact exchange (sums formed again for that step)
+            f.EXACT_STEPS = 4
         if missing == -0.2:        # the outlier falls into the fixed-capacity part of the series
             f.EXACT_STEPS = 1
         if missing == 0.05:        # capacity too small for what the exchange needs: the series is repeated exactly
