@@ -1501,15 +1501,17 @@ __device__ __forceinline__ void expand_spec_body(SpecHeaders& H, uint32_t bid, u
     return pow2 ? cssm_sys_count_pow2(C, u, n_global, inv_n) : cssm_sys_count(C, u, n_global);
   };
   if (bid == 0 && threadIdx.x < CSSM_MAXSLOTS) sc->maxslot[(size_t)threadIdx.x * CSSM_SLOT_STRIDE] = 0ull;   // set 0 for the next step
-  const long long total = (long long)world * cap;
+  // Only the two adjacent ranks' rows can own slots of this rank: the verdict established that its slots below the own
+  // particles' first one all belong to the last-cap block of rank - 1 and those above to the first-cap block of rank + 1.
+  const long long total = 2 * cap;
   for (long long base = (long long)bid * CSSM_BLOCK; base < total; base += (long long)nblk * CSSM_BLOCK) {
     if (threadIdx.x == 0) s_nheavy = 0;
     __syncthreads();
     const long long idx = base + threadIdx.x;
     if (idx < total) {
-      const int s = (int)(idx / cap);
-      const long long i = idx - (long long)s * cap;
-      if (s != rank && i < H.cnt[s]) {
+      const int s = (idx < cap) ? rank - 1 : rank + 1;
+      const long long i = (idx < cap) ? idx : idx - cap;
+      if (s >= 0 && s < world && i < H.cnt[s]) {
         const double* h = recv + (size_t)s * seg;
         const cssm_u128 off = cssm_u128_add(H.off[s], H.base[s]);
         cssm_u128 P; P.lo = cssm_d2u(h[HD + i * R + d]); P.hi = cssm_d2u(h[HD + cap * R + i]);
