@@ -1503,12 +1503,16 @@ __device__ __forceinline__ void expand_spec_body(SpecHeaders& H, uint32_t bid, u
   if (bid == 0 && threadIdx.x < CSSM_MAXSLOTS) sc->maxslot[(size_t)threadIdx.x * CSSM_SLOT_STRIDE] = 0ull;   // set 0 for the next step
   // Only the two adjacent ranks' rows can own slots of this rank: the verdict established that its slots below the own
   // particles' first one all belong to the last-cap block of rank - 1 and those above to the first-cap block of rank + 1.
+  // The rows are spread evenly over ALL blocks of the launch (a share of ceil(2 cap / blocks) each, done after the
+  // block's own tile): extra blocks for them would start a second, nearly empty round on a chip the offspring blocks fill.
   const long long total = 2 * cap;
-  for (long long base = (long long)bid * CSSM_BLOCK; base < total; base += (long long)nblk * CSSM_BLOCK) {
+  const long long per = (total + nblk - 1) / nblk;
+  const long long row_lo = (long long)bid * per, row_hi = (row_lo + per < total) ? row_lo + per : total;
+  for (long long base = row_lo; base < row_hi; base += CSSM_BLOCK) {
     if (threadIdx.x == 0) s_nheavy = 0;
     __syncthreads();
     const long long idx = base + threadIdx.x;
-    if (idx < total) {
+    if (idx < row_hi) {
       const int s = (idx < cap) ? rank - 1 : rank + 1;
       const long long i = (idx < cap) ? idx : idx - cap;
       if (s >= 0 && s < world && i < H.cnt[s]) {
@@ -1546,9 +1550,9 @@ __device__ __forceinline__ void expand_spec_body(SpecHeaders& H, uint32_t bid, u
   }
 }
 // Offspring of the own particles and expansion of the received rows in ONE launch: the two are independent once the
-// exchange is done (disjoint slots; both read only the segment headers), and a launch costs ~5 us of latency.  Blocks
-// [0, nunits) are k_offspring's, the rest expand the rows; `optimistic` = 2 makes the offspring side raise err bit 2
-// itself (no later kernel reads the flag).
+// exchange is done (disjoint slots; both read only the segment headers), and a launch costs ~5 us of latency.  Every block
+// is a k_offspring block first and then expands its share of the received rows; `optimistic` = 2 makes the offspring
+// side raise err bit 2 itself (no later kernel reads the flag).
 // EVERY block first takes the verdict of spec_read_headers.  If some rank's slots are not covered, the whole launch
 // does NOTHING on every rank except recording err bit 3 and the observation index: the state is exactly as the
 // propagate of this observation left it, every later kernel of the series returns at once (they test the bit), and
@@ -1561,12 +1565,8 @@ __global__ __launch_bounds__(CSSM_BLOCK, CSSM_OFF_WAVES) void k_offspring_expand
     if (blockIdx.x == 0 && threadIdx.x == 0) { atomicOr(&sc->err, 8u); atomicMin(&sc->fail_step, rec->step); }
     return;
   }
-  if (blockIdx.x < nunits) {
-    offspring_body<true, false, CSSM_RESAMPLE_SYSTEMATIC>(CSSM_OFFSPRING_FWD, all5_stride);
-  } else {
-    expand_spec_body(H, blockIdx.x - nunits, gridDim.x - nunits, recv, world, rank, cap, d, n_split, (uint64_t)slot_lo, (uint64_t)slot_hi,
-                     n_global, rec, anc, sc);
-  }
+  offspring_body<true, false, CSSM_RESAMPLE_SYSTEMATIC>(CSSM_OFFSPRING_FWD, all5_stride);
+  expand_spec_body(H, blockIdx.x, gridDim.x, recv, world, rank, cap, d, n_split, (uint64_t)slot_lo, (uint64_t)slot_hi, n_global, rec, anc, sc);
 }
 
 __global__ __launch_bounds__(CSSM_BLOCK) void k_expand(const uint32_t* __restrict__ cand_end, const uint32_t* __restrict__ cand_idx,

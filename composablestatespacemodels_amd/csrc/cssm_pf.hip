@@ -1502,10 +1502,7 @@ extern "C" int cssm_pf_shard_adopt_spec(cssm_pf* pf, const double* recv_buf_dev,
   // the 5 words of every rank are the header words 1..5 of its segment (the all-to-all delivered this rank's own too)
   const unsigned long long* all5 = reinterpret_cast<const unsigned long long*>(recv_buf_dev) + 1;
   const uint32_t n_split = (uint32_t)pf->n;
-  const long long total = 2 * (long long)cap;   // rows of the two adjacent ranks
-  const int xgrid = grid_for((uint64_t)total, CSSM_BLOCK, 256);
-  // one launch: blocks [0, nunits) = offspring of the own particles, the rest = expansion of the received rows
-  hipLaunchKernelGGL(k_offspring_expand_spec, dim3(tgrid + xgrid), dim3(CSSM_BLOCK), 0, pf->stream, pf->logw, pf->n, pf->sc,
+  hipLaunchKernelGGL(k_offspring_expand_spec, dim3(tgrid), dim3(CSSM_BLOCK), 0, pf->stream, pf->logw, pf->n, pf->sc,
                      (const cssm_u128*)pf->tileS, (const cssm_u128*)pf->tileS2, (const StepRec*)(pf->d_recs + slot), pf->n_global, pf->endslot,
                      pf->anc, pf->ntiles, pf->sup, pf->nunits, 0, 0, (double*)nullptr, (int32_t*)nullptr, 0u, pf->opt_exact,
                      all5, rank, world, (int)pf->split, pf->seed, (double*)nullptr, (const double*)pf->d_logtab,
