@@ -160,13 +160,17 @@ def run_multi(args, emit=print):
             "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": "configs[1] sharded: seasonal-Poisson, OU latent (d=3), "
                                    f"{args.particles} particles per GPU x {world} GPUs = {n_global}, T={K}, global systematic "
-                                   "resampling every observation (per observation over RCCL, enqueued by the library itself: one equal-split all-to-all "
-                                   f"carrying every rank's 5 sum words and its boundary particles, capacity {f.last_cap} rows per pair, "
+                                   "resampling every observation (per observation over RCCL, enqueued by the library itself: one all-to-all "
+                                   f"carrying every rank's 5 sum words and, between adjacent ranks, its boundary particles, capacity {f.last_cap} rows per pair, "
                                    f"{getattr(f, 'last_resumes', 0)} resumed capacity misses)",
                        "particles_per_gpu": args.particles, "observations": K, "latent_dim": shard.d, "seed": 20260101},
             "exchange": {"capacity_rows": f.last_cap, "attempts": f.last_attempts,
                          "collectives_issued_by": "libcssm_pf (cssm_pf_shard_series_rccl)" if getattr(f, "last_native", False) else "torch.distributed",
                          "collectives_per_observation": 1 if getattr(f, "last_single", False) else 2,
+                         "all_to_all": ("ncclAllToAllv: whole segments between adjacent ranks, 12 header words between the others"
+                                        if (getattr(f, "last_native", False) and getattr(f, "last_single", False) and world > 2
+                                            and f.SINGLE_MODE == 2 and os.environ.get("CSSM_SHARD_TRIM", "1") != "0")
+                                        else "equal split"),
                          "rccl": shard.lib.cssm_rccl_library().decode()},
             "ll": ll, "ess_last": ess}))
     shard.close()

@@ -1259,9 +1259,10 @@ __global__ __launch_bounds__(CSSM_BLOCK) void k_expand_fixed(const double* __res
 //                          both: with them EVERY rank can tell from the headers alone whether EVERY rank's slots are covered)
 //   [HD, HD + cap R)       rows: (state d, low word of P_j)      P_j = inclusive prefix of the fixed-point weights
 //   [HD + cap R, + capP)   high words of P_j                            WITHIN the block of particles the segment carries
-// q < r receives the rank's FIRST cap particles (base = 0), q > r its LAST cap particles (base = S_local - P_total), q = r
-// the header only (the all-to-all's own segment delivers every rank its own sums too).  The receiver knows all sums after
+// q = r - 1 receives the rank's FIRST cap particles (base = 0), q = r + 1 its LAST cap particles (base = S_local - P_total),
+// every other q (q = r included: the all-to-all's own segment delivers every rank its own sums too) the header only.  The receiver knows all sums after
 // the exchange and turns base + P_j into global cumulative weights and end slots itself (k_expand_spec).
+constexpr int kSpecHeaderWords = 12;   // what a header-only segment carries
 __host__ __device__ __forceinline__ long long spec_hdr(int d) { return (long long)(d + 1) * ((12 + d) / (d + 1)); }
 __host__ __device__ __forceinline__ long long spec_capP(int d, long long cap) { return (long long)(d + 1) * ((cap + d) / (d + 1)); }
 __host__ __device__ __forceinline__ long long spec_seg(int d, long long cap) { return spec_hdr(d) + cap * (d + 1) + spec_capP(d, cap); }
@@ -1281,7 +1282,9 @@ __global__ __launch_bounds__(CSSM_BLOCK) void k_boundary_pack(const double* __re
   const long long R = d + 1, HD = spec_hdr(d), seg = spec_seg(d, cap);
   double* oseg = out + (size_t)q * seg;
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-  const long long cnt = (q == rank) ? 0 : ((long long)n_local < cap ? (long long)n_local : cap);
+  // only the two adjacent ranks can own slots of this rank's boundary particles (k_offspring_expand_spec's verdict refuses
+  // anything else), so only their segments carry rows; every other segment is its header
+  const long long cnt = (q == rank + 1 || q == rank - 1) ? ((long long)n_local < cap ? (long long)n_local : cap) : 0;
   const uint64_t first = (q < rank) ? 0 : n_local - (uint64_t)cnt;     // first particle of the block the segment carries
   const double cref = rec->ref;
   auto tile_weights = [&](uint64_t base, cssm_u128 (&qq)[CSSM_ITEMS]) {   // particles first + base + 4 tid .. of the block
@@ -1303,6 +1306,7 @@ __global__ __launch_bounds__(CSSM_BLOCK) void k_boundary_pack(const double* __re
   };
   const bool header_block = (blockIdx.x == gridDim.x - 1);   // grid.x = tiles of the block + 1: the header has a block of its own
   if (!header_block) {
+  if (cnt == 0) return;
   // prefix of the tiles before this block's tile
   cssm_u128 toff = cssm_u128_zero();
   const bool aligned = (chunk == (uint64_t)CSSM_TILE) && (first % (uint64_t)CSSM_TILE == 0);

@@ -1550,6 +1550,7 @@ struct RcclApi {
   int (*CommDestroy)(void*) = nullptr;
   int (*AllGather)(const void*, void*, size_t, int, void*, hipStream_t) = nullptr;
   int (*AllToAll)(const void*, void*, size_t, int, void*, hipStream_t) = nullptr;
+  int (*AllToAllv)(const void*, const size_t*, const size_t*, void*, const size_t*, const size_t*, int, void*, hipStream_t) = nullptr;
   const char* (*GetErrorString)(int) = nullptr;
   bool ok = false;
 };
@@ -1583,6 +1584,7 @@ RcclApi* rccl_api() {
   api.CommDestroy = (int (*)(void*))dlsym(api.lib, "ncclCommDestroy");
   api.AllGather = (int (*)(const void*, void*, size_t, int, void*, hipStream_t))dlsym(api.lib, "ncclAllGather");
   api.AllToAll = (int (*)(const void*, void*, size_t, int, void*, hipStream_t))dlsym(api.lib, "ncclAllToAll");
+  api.AllToAllv = (int (*)(const void*, const size_t*, const size_t*, void*, const size_t*, const size_t*, int, void*, hipStream_t))dlsym(api.lib, "ncclAllToAllv");   // optional
   api.GetErrorString = (const char* (*)(int))dlsym(api.lib, "ncclGetErrorString");
   api.ok = api.GetUniqueId && api.CommInitRank && api.CommDestroy && api.AllGather && api.AllToAll;
   return api.ok ? &api : nullptr;
@@ -1633,14 +1635,27 @@ extern "C" int cssm_pf_shard_series_rccl(cssm_pf* pf, void* comm, int rank, int 
   const size_t seg = (size_t)(cap + 1) * (size_t)(pf->d + 1);   // doubles per pair of ranks
   if (single_collective) {   // sums and boundary particles in ONE all-to-all per observation (k_boundary_pack / k_expand_spec)
     const size_t sseg = (size_t)spec_seg(pf->d, (long long)cap);
+    // single_collective == 2: only the two adjacent ranks get (and send) whole segments, every other pair exchanges the
+    // 12-word segment header alone -- k_offspring_expand_spec reads nothing else of them (its verdict, formed from the
+    // headers, rules out that a non-adjacent rank owns slots here).  Same call count, (world - 3) segments fewer on the
+    // links per rank and observation.  Counts are a function of |rank - peer| only, so both ends of a pair agree.
+    if (single_collective == 3 && !a->AllToAllv) return fail(CSSM_ERCCL, "this RCCL has no ncclAllToAllv");
+    const bool trimmed = (single_collective == 3) || (single_collective == 2 && a->AllToAllv && world > 2);   // 3: tests (any world)
+    std::vector<size_t> counts((size_t)world), displs((size_t)world);
+    for (int q = 0; q < world; ++q) {
+      counts[(size_t)q] = (q == rank + 1 || q == rank - 1) ? sseg : (size_t)kSpecHeaderWords;
+      displs[(size_t)q] = (size_t)q * sseg;
+    }
     for (size_t s = s_begin; s < s_end; ++s) {
       rc = cssm_pf_shard_propagate_at(pf, s, nullptr);
       if (rc) return rc;
       if (!weighted[s]) continue;
       rc = cssm_pf_shard_boundary_pack(pf, rank, world, cap, send_buf_dev);
       if (rc) return rc;
-      const int r = a->AllToAll(send_buf_dev, recv_buf_dev, sseg, kNcclFloat64, comm, pf->stream);
-      if (r) return rccl_fail(a, "ncclAllToAll", r);
+      const int r = trimmed ? a->AllToAllv(send_buf_dev, counts.data(), displs.data(), recv_buf_dev, counts.data(), displs.data(), kNcclFloat64,
+                                           comm, pf->stream)
+                            : a->AllToAll(send_buf_dev, recv_buf_dev, sseg, kNcclFloat64, comm, pf->stream);
+      if (r) return rccl_fail(a, trimmed ? "ncclAllToAllv" : "ncclAllToAll", r);
       rc = cssm_pf_shard_adopt_spec(pf, recv_buf_dev, rank, world, cap);
       if (rc) return rc;
     }

@@ -133,15 +133,17 @@ class GpuShard:
         _abi.check(self.lib.cssm_pf_shard_adopt_fixed(self._h, C.c_void_p(recv_buf.data_ptr()), self.rank, self.world, int(cap)))
 
     def series_native(self, comm_handle, s_begin: int, s_end: int, weighted: np.ndarray, cap: int,
-                      send_buf: torch.Tensor, recv_buf: torch.Tensor, single_collective: bool = False):
-        """Observations [s_begin, s_end) with the collectives issued by the library itself (cssm_pf_shard_series_rccl)."""
+                      send_buf: torch.Tensor, recv_buf: torch.Tensor, single_collective: int = 0):
+        """Observations [s_begin, s_end) with the collectives issued by the library itself (cssm_pf_shard_series_rccl).
+        single_collective: 0 = all-gather + all-to-all, 1 = one equal-split all-to-all, 2 = one all-to-all-v (whole
+        segments between adjacent ranks only, headers otherwise)."""
         self._recv_keepalive = recv_buf
         w = np.ascontiguousarray(weighted, dtype=np.uint8)
         _abi.check(self.lib.cssm_pf_shard_series_rccl(self._h, comm_handle, self.rank, self.world, int(s_begin), int(s_end),
                                                       w.ctypes.data_as(C.POINTER(C.c_uint8)), int(cap),
                                                       C.c_void_p(self.sums5.data_ptr()), C.c_void_p(self.all_sums.data_ptr()),
                                                       C.c_void_p(send_buf.data_ptr()), C.c_void_p(recv_buf.data_ptr()),
-                                                      1 if single_collective else 0))
+                                                      int(single_collective)))
 
     def resume(self) -> int:
         """After a capacity miss of the single-collective series: the observation that missed (its propagate is done,
@@ -419,7 +421,8 @@ class ShardedFilter:
     # 6237 / 9879 / 14184 at world 2 / 4 / 8 = 4.3 .. 4.9 sqrt(N), tools/need_probe.py).  A series that needs more is
     # still computed correctly: it is repeated with the exact exchange.
     CAP_SQRT = 6.0
-    NATIVE_STRETCH = 128  # observations the library enqueues between two looks at the sticky bits
+    NATIVE_STRETCH = 128     # observations the library enqueues between two looks at the sticky bits
+    SINGLE_MODE = 2          # library-driven single-collective series: 2 = all-to-all-v trimmed to the adjacent ranks, 1 = equal split
     last_resumes = 0
 
     def ll_filter(self, t, y, has=None, lgcp: bool = False, exact: bool = False):
@@ -500,7 +503,7 @@ class ShardedFilter:
                     if single:
                         nb = comm.world * S[0].spec_segment(cap)
                         S[0].series_native(native, k, kend, weighted, cap, S[0].buffer("send_spec", nb)[:nb],
-                                           S[0].buffer("recv_spec", nb)[:nb], single_collective=True)
+                                           S[0].buffer("recv_spec", nb)[:nb], single_collective=1 if os.environ.get("CSSM_SHARD_TRIM", "1") == "0" else self.SINGLE_MODE)
                     else:
                         nb = comm.world * (cap + 1) * (self.d + 1)
                         S[0].series_native(native, k, kend, weighted, cap, S[0].buffer("send_fixed", nb)[:nb],

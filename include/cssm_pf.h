@@ -342,14 +342,17 @@ int cssm_pf_shard_series_rccl(cssm_pf* pf, void* comm, int rank, int world, size
                               double* send_buf_dev, double* recv_buf_dev, int single_collective);
 
 /* The single-collective exchange (single_collective != 0 above; stage calls for hosts that issue the collective themselves):
- * ONE equal-split all-to-all per observation carries the rank's 5 sum words (segment header) AND its boundary particles
- * -- to every lower rank its first `cap` particles, to every higher rank its last `cap`, each with the inclusive prefix
- * of its fixed-point weight within that block -- so no all-gather precedes it.  The receiver, holding every rank's sums
+ * ONE all-to-all per observation carries the rank's 5 sum words (segment header, to every rank) AND its boundary
+ * particles -- to the rank below its first `cap` particles, to the rank above its last `cap`, each with the inclusive
+ * prefix of its fixed-point weight within that block -- so no all-gather precedes it.  single_collective = 1: equal-split
+ * ncclAllToAll of whole segments; 2: ncclAllToAllv in which only the adjacent pairs exchange whole segments and every
+ * other pair the 12 header words (nothing else of those segments is ever read; falls back to 1 when world <= 2 or the
+ * RCCL copy has no ncclAllToAllv; 3 = the same for any world, an error without ncclAllToAllv: tests).  The receiver, holding every rank's sums
  * after the exchange, turns the prefixes into global end slots itself.  Slots of a rank owned neither by its own particles
  * nor by the adjacent ranks' boundary blocks raise the same sticky bit 8 as a count above `cap` does (exact exchange).
  *   cssm_pf_shard_spec_segment    doubles per pair of ranks for capacity `cap` (send / recv buffers: world segments)
  *   cssm_pf_shard_propagate_at    with sums5_dev = NULL (the totals are formed by the next call)
- *   cssm_pf_shard_boundary_pack   header + boundary rows for every destination
+ *   cssm_pf_shard_boundary_pack   a header for every destination, boundary rows for the two adjacent ranks
  *   (all-to-all of cssm_pf_shard_spec_segment doubles per pair)
  *   cssm_pf_shard_adopt_spec      offspring of the own particles, expansion of the received rows, coverage check */
 int64_t cssm_pf_shard_spec_segment(const cssm_pf* pf, int64_t cap);

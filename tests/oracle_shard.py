@@ -198,15 +198,13 @@ class OracleShard:
         words = [int(x) & (2**64 - 1) for x in self.sums5.tolist()]
         for qd in range(self.world):
             o = qd * seg
-            cnt = 0 if qd == self.rank else min(self.n, cap)
+            cnt = min(self.n, cap) if abs(qd - self.rank) == 1 else 0      # rows travel to the two adjacent ranks only
             first = 0 if qd < self.rank else self.n - cnt
             P, run = [], 0
             for j in range(first, first + cnt):
                 run += self.q[j]
                 P.append(run)
-            base = 0 if qd < self.rank else S - run          # a LAST block starts at S_local - P_total
-            if qd == self.rank:
-                base = 0
+            base = 0 if qd <= self.rank else S - phigh        # a LAST block starts at S_local - P_total
             buf[o] = float(cnt)
             for i, w in enumerate(words):
                 bits[o + 1 + i] = w

@@ -92,6 +92,14 @@ def test_rccl_world1_matches_oracle():
             if not exact:                    # the library drove the collectives of the series itself (cssm_pf_shard_series_rccl)
                 assert f.last_native, "the native RCCL series loop was not taken"
         assert f.last_single
+        # ... with the all-to-all-v of the library's trimmed exchange (mode 3 forces it at any world size; at world 1 it
+        # carries the rank's own header)
+        f4 = ShardedFilter([shard], DistComm(device=torch.device("cuda", 0)))
+        f4.SINGLE_MODE = 3
+        ll, ess = f4.ll_filter(t, y, has)
+        assert f4.last_native and f4.last_single and (ll, ess) == (oll, oess[-1])
+        np.testing.assert_array_equal(shard.particles(), opart)
+        f4.comm.close()
         # ... with all-gather + all-to-all instead of the single all-to-all, still issued by the library
         os.environ["CSSM_SHARD_SINGLE"] = "0"
         try:
