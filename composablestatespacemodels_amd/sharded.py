@@ -5,9 +5,11 @@ Per observation (stage calls of include/cssm_pf.h), after the firs
 
 1. ``shard_propagate_at``   fused propagate + weight + local fixed-point sums of exp(w - c), c being the
    observation's reference level (known without an exchange)
-2. ``shard_boundary_pack``  for every peer one segment: header = the rank's 5 words (S, S2, order key of the local max),
-   rows = its first (for lower ranks) or last (for higher ranks) ``cap`` particles with their cumulative weights
-3. ONE equal-split all-to-all
+2. ``shard_boundary_pack``  for every peer one segment: header = the rank's 5 words (S, S2, order key of the local max)
+   and the totals of its boundary blocks; for the two adjacent ranks also rows = its first (rank below) or last (rank
+   above) ``cap`` particles with their cumulative weights
+3. ONE all-to-all (library-driven series: all-to-all-v, whole segments between adjacent ranks and headers between the
+   others; otherwise equal splits)
 4. ``shard_adopt_spec``     global max -> c usable?  global cumulative weights -> ll, ess, end slots and runs of the own
    particles; the received rows expanded to the slots the own particles left open; coverage check
 
@@ -399,7 +401,7 @@ class ShardedFilter:
 
     def _resample_spec(self, cap: int):
         """Stages after propagate with the single-collective exchange: sums (segment headers) and boundary particles
-        travel in ONE equal-split all-to-all; nothing is read by the host."""
+        travel in ONE all-to-all; nothing is read by the host."""
         S, comm = self.shards, self.comm
         n = comm.world * S[0].spec_segment(cap)
         send = [s.buffer("send_spec", n)[:n] for s in S]
