@@ -243,6 +243,39 @@ def test_full_size_c2_agrees_with_oracle_and_properties():
     g.close()
 
 
+@pytest.mark.parametrize("name,n,T,lgcp", [("c3_model", 1 << 22, 5, 0), ("c4_model", 1 << 24, 4, 2)])
+def test_full_size_c3_c4_size_independent_properties(name, n, T, lgcp):
+    """BASELINE configs 3 (d = 9, N = 2^22) and 4 (LGCP, N = 2^24) at their full particle counts, where the one-thread
+    oracle no longer finishes in seconds: properties that hold at any size.  Batch == streaming bit for bit, a second
+    run reproduces the first, ancestors are non-decreasing, and every particle's offspring count is floor or ceil of
+    N w_i / sum(w) (systematic resampling, Resampling.scala:63-72)."""
+    model = getattr(cases, name)()
+    t, y, has = (cases.event_times(T) if lgcp else cases.poisson_counts(T))
+    a = NativePf(model, n, cases.SEED, lgcp_precision=lgcp)
+    ll_a, llt_a, ess_a, _ = a.run(t, y, has)
+    b = NativePf(model, n, cases.SEED, lgcp_precision=lgcp)
+    b.init(float(np.min(t)))
+    for s in range(T):
+        ll_b, ess_b = b.step(t[s], y[s], bool(has[s]))
+        assert ess_b == ess_a[s]
+    assert ll_b == ll_a and np.isfinite(ll_a)
+    assert 1 <= ess_a.min() and ess_a.max() <= n
+    anc = a.ancestors()
+    np.testing.assert_array_equal(anc, b.ancestors())
+    assert np.all(np.diff(anc.astype(np.int64)) >= 0)
+    lw = a.logw().astype(np.longdouble)
+    w = np.exp(lw - lw.max())
+    expect = (w * (np.longdouble(n) / w.sum())).astype(np.float64)
+    counts = np.bincount(anc, minlength=n).astype(np.float64)
+    assert counts.sum() == n
+    assert np.max(np.abs(counts - expect)) < 1.0 + 1e-6
+    # the same series on the same handle again: identical (re-initialised state, same seed)
+    ll_c, _, ess_c, _ = a.run(t, y, has)
+    assert ll_c == ll_a
+    np.testing.assert_array_equal(ess_c, ess_a)
+    a.close(); b.close()
+
+
 def test_offspring_fast_path_equals_forced_exact_path():
     """k_offspring decides most end slots from an fp64 position estimate; forcing the exact contract
     predicate everywhere must give the same ancestors (and both equal the oracle)."""

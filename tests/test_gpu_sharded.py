@@ -70,6 +70,27 @@ def test_local_shards_lgcp():
     np.testing.assert_array_equal(np.concatenate([s.particles() for s in shards], axis=1), opart)
 
 
+@pytest.mark.parametrize("world", [2, 8])
+def test_full_size_local_shards_equal_single_gpu(world):
+    """BASELINE config 2 at its full size (N = 2^20), split into 2 and 8 local shards: ll, ess and the particles equal the
+    single-GPU filter of the same N bit for bit (the shard count is not allowed to show in any result)."""
+    from composablestatespacemodels_amd.filter import NativePf
+    from composablestatespacemodels_amd.sharded import GpuShard, LocalComm, ShardedFilter
+    model = cases.c2_model()
+    n, T = 1 << 20, 24
+    t, y, has = cases.poisson_counts(T)
+    g = NativePf(model, n, cases.SEED)
+    ll1, _, ess1, _ = g.run(t, y, has)
+    shards = [GpuShard(model, n, r, world, cases.SEED, 0) for r in range(world)]
+    f = ShardedFilter(shards, LocalComm(world))
+    ll, ess = f.ll_filter(t, y, has)
+    assert (ll, ess) == (ll1, int(ess1[-1]))
+    np.testing.assert_array_equal(np.concatenate([s.particles() for s in shards], axis=1), g.particles())
+    for s in shards:
+        s.close()
+    g.close()
+
+
 def test_rccl_world1_matches_oracle():
     import torch
     import torch.distributed as dist
