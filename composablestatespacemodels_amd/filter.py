@@ -389,10 +389,35 @@ class ParticleFilter:
     @staticmethod
     def getIntervals(model: Model, s: "PfState") -> PfOut:
         """ParticleFilter.getIntervals (:415-424), evaluated on the device for the handle's current state."""
-        if s._owner is None or s._owner.generation != s._generation:
-            raise RuntimeError("getIntervals needs the filter's current PfState")
-        m, lo, hi, em, el, eu = s._owner.summary(0.975)
+        m, lo, hi, em, el, eu = ParticleFilter._current(s).summary(0.975)
         return PfOut(s.t, s.observation, em, CredibleInterval(el, eu), m, [CredibleInterval(a, b) for a, b in zip(lo, hi)])
+
+    @staticmethod
+    def _current(s: "PfState") -> NativePf:
+        if s._owner is None or s._owner.generation != s._generation:
+            raise RuntimeError("the cloud summaries need the filter's current PfState (the cloud lives on the device)")
+        return s._owner
+
+    @staticmethod
+    def meanState(s: "PfState") -> np.ndarray:
+        """ParticleFilter.meanState (:475-477) of the state's cloud: per-component means, formed on the device."""
+        return ParticleFilter._current(s).summary(0.975)[0]
+
+    @staticmethod
+    def getallCredibleIntervals(s: "PfState", interval: float) -> List[CredibleInterval]:
+        """ParticleFilter.getallCredibleIntervals (:510-512, getCredibleInterval :488-502) of the state's cloud: per component
+        the order statistics sorted(n - index - 1) and sorted(index - 1), index = floor(interval n), selected on the device."""
+        _, lo, hi, _, _, _ = ParticleFilter._current(s).summary(float(interval))
+        return [CredibleInterval(a, b) for a, b in zip(lo, hi)]
+
+    @staticmethod
+    def getOrderStatistic(samples: Sequence[float], interval: float) -> CredibleInterval:
+        """ParticleFilter.getOrderStatistic (:455-460) for a vector the caller already holds on the host:
+        CredibleInterval(sorted(n - index), sorted(index)), index = floor(n interval).  (The eta intervals of a cloud come
+        from getIntervals, which selects them on the device.)"""
+        a = np.sort(np.asarray(samples, dtype=np.float64))
+        index = int(np.floor(a.size * interval))
+        return CredibleInterval(float(a[a.size - index]), float(a[index]))
 
     @staticmethod
     def effectiveSampleSize(weights: Sequence[float]) -> int:  # :431-434 (host helper, tiny inputs)

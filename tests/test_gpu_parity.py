@@ -323,6 +323,18 @@ def test_get_intervals_mirror():
     assert out.time == 1.0 and out.observation == 3.0 and len(out.stateIntervals) == 3
     assert all(ci.lower < m < ci.upper for ci, m in zip(out.stateIntervals, out.state))
     assert out.etaIntervals.lower < out.eta < out.etaIntervals.upper
+    # the named helpers of the reference (ParticleFilter.scala:455-512) against a host evaluation of the downloaded cloud
+    x = s.particles
+    np.testing.assert_allclose(ParticleFilter.meanState(s), x.mean(axis=1), rtol=1e-12)
+    for interval in (0.975, 0.9):
+        cis = ParticleFilter.getallCredibleIntervals(s, interval)
+        n = x.shape[1]; index = int(np.floor(interval * n))
+        for k, ci in enumerate(cis):
+            srt = np.sort(x[k])
+            assert (ci.lower, ci.upper) == (srt[n - index - 1], srt[index - 1])
+    ci = ParticleFilter.getOrderStatistic(list(x[0]), 0.975)
+    srt = np.sort(x[0]); index = int(np.floor(0.975 * len(srt)))
+    assert (ci.lower, ci.upper) == (srt[len(srt) - index], srt[index])
 
 
 @pytest.mark.parametrize("kind,flag", [(1, oracle.RESAMPLE_STRATIFIED), (2, oracle.RESAMPLE_MULTINOMIAL)])
