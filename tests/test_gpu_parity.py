@@ -64,6 +64,52 @@ def test_maximum_dimension_and_leaf_count():
     _compare_streaming(cases.many_leaves_model(), 1200, t, y, has)
 
 
+def test_independent_handles_driven_concurrently_and_one_handle_from_several_threads():
+    """SURVEY.md 8b, threading: Akka calls stepFilter one at a time but from different dispatcher threads, and independent
+    handles run side by side (two PMMH chains under mapAsync(2), examples/DetermineParameters.scala:68-69).  Three
+    handles with different models and sizes are driven from three threads at once (ctypes releases the GIL: the calls
+    really overlap), each alternating batch and streaming calls; then one handle is stepped from a fresh thread per
+    observation.  Everything must equal what the same calls give one after the other."""
+    import threading
+    jobs = [(cases.c2_model(), 40000, cases.poisson_counts(30), 11), (cases.c3_model(), 20000, cases.poisson_counts(25), 12),
+            (cases.c1_model(), 100000, cases.poisson_counts(35), 13)]
+
+    def work(model, n, data, seed, out):
+        t, y, has = data
+        pf = NativePf(model, n, seed)
+        res = []
+        for rep in range(3):
+            res.append(pf.run(t, y, has)[0])
+            pf.init(float(t[0]))
+            for s in range(len(t)):
+                ll, ess = pf.step(t[s], y[s], bool(has[s]))
+            res.append((ll, ess))
+        res.append(pf.particles().copy())
+        pf.close()
+        out.append(res)
+
+    serial = []
+    for j in jobs:
+        o = []; work(*j, o); serial.append(o[0])
+    outs = [[] for _ in jobs]
+    threads = [threading.Thread(target=work, args=(*j, o)) for j, o in zip(jobs, outs)]
+    for th in threads: th.start()
+    for th in threads: th.join()
+    for o, ref in zip(outs, serial):
+        assert len(o) == 1, "a worker thread raised"
+        assert o[0][:-1] == ref[:-1]
+        np.testing.assert_array_equal(o[0][-1], ref[-1])
+    # one handle, a different thread for every call
+    model, n, (t, y, has), seed = jobs[0]
+    a = NativePf(model, n, seed); a.init(float(t[0]))
+    got = []
+    for s in range(len(t)):
+        th = threading.Thread(target=lambda s=s: got.append(a.step(t[s], y[s], bool(has[s]))))
+        th.start(); th.join()
+    assert got[-1] == serial[0][1]
+    a.close()
+
+
 def test_single_datum_all_missing_and_empty_series():
     from composablestatespacemodels_amd import CssmError
     model = cases.c2_model()
