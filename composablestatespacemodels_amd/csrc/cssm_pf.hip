@@ -1061,8 +1061,16 @@ extern "C" int cssm_pf_interpolate(cssm_pf* pf, const double* t, const double* y
 // ------------------------------------------------------------------------------------ stateless resampler
 
 extern "C" int cssm_resample_systematic(const double* w, size_t n, double u, uint32_t* anc, int device) {
+  return cssm_resample(CSSM_RESAMPLE_SYSTEMATIC, w, n, u, 0, 0, anc, device);
+}
+
+// kind = CSSM_RESAMPLE_*: systematic reads u; stratified and multinomial draw their per-slot uniforms from the Philox
+// streams of (seed, step) exactly as the filter's resamplers do at observation `step`
+extern "C" int cssm_resample(int kind, const double* w, size_t n, double u, uint64_t seed, uint32_t step, uint32_t* anc, int device) {
   if (!w || !anc) return fail(CSSM_EINVAL_ARG, "null argument");
   if (n < 1 || n >= 0xffffffffull) return fail(CSSM_EINVAL_ARG, "n out of range");
+  if (kind < CSSM_RESAMPLE_SYSTEMATIC || kind > CSSM_RESAMPLE_MULTINOMIAL) return fail(CSSM_EINVAL_ARG, "unknown resampler %d", kind);
+  if (kind != CSSM_RESAMPLE_SYSTEMATIC) u = 0.0;
   if (!(u >= 0.0 && u < 1.0)) return fail(CSSM_EINVAL_ARG, "u must be in [0, 1)");
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return fail(CSSM_EHIP, "no HIP device available (this library has no CPU path)");
@@ -1071,16 +1079,17 @@ extern "C" int cssm_resample_systematic(const double* w, size_t n, double u, uin
   const uint32_t sup = (ntiles + 1023u) / 1024u, nunits = (ntiles + sup - 1) / sup;
   const size_t stride = (size_t)ntiles * CSSM_TILE;
   double* d_w = nullptr; uint32_t *d_end = nullptr, *d_anc = nullptr; cssm_u128 *tS = nullptr, *tS2 = nullptr, *tP = nullptr;
-  Scalars* sc = nullptr; StepRec* d_rec = nullptr; double* d_tab = nullptr;
+  Scalars* sc = nullptr; StepRec* d_rec = nullptr; double* d_tab = nullptr; double* d_cum = nullptr;
   hipStream_t st = nullptr;
   int rc = CSSM_OK;
-  StepRec hrec; memset(&hrec, 0, sizeof hrec); hrec.u = u;
+  StepRec hrec; memset(&hrec, 0, sizeof hrec); hrec.u = u; hrec.step = step;
   Scalars hs;
 #define RS_TRY(expr) do { hipError_t e__ = (expr); if (e__ != hipSuccess) { rc = fail(CSSM_EHIP, "%s: %s", #expr, hipGetErrorString(e__)); goto done; } } while (0)
   RS_TRY(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
   RS_TRY(hipMalloc(&d_w, stride * 8)); RS_TRY(hipMalloc(&d_end, stride * 4)); RS_TRY(hipMalloc(&d_anc, stride * 4));
   RS_TRY(hipMalloc(&tS, ntiles * sizeof(cssm_u128))); RS_TRY(hipMalloc(&tS2, ntiles * sizeof(cssm_u128))); RS_TRY(hipMalloc(&tP, ntiles * sizeof(cssm_u128)));
   RS_TRY(hipMalloc(&sc, sizeof(Scalars))); RS_TRY(hipMalloc(&d_rec, sizeof(StepRec))); RS_TRY(hipMalloc(&d_tab, sizeof(CSSM_TAB)));
+  if (kind == CSSM_RESAMPLE_MULTINOMIAL) RS_TRY(hipMalloc(&d_cum, stride * 8));
   RS_TRY(hipMemcpyAsync(d_tab, CSSM_TAB, sizeof(CSSM_TAB), hipMemcpyHostToDevice, st));
   RS_TRY(hipMemsetAsync(sc, 0, sizeof(Scalars), st));
   RS_TRY(hipMemcpyAsync(d_w, w, n * 8, hipMemcpyHostToDevice, st));
@@ -1091,10 +1100,18 @@ extern "C" int cssm_resample_systematic(const double* w, size_t n, double u, uin
                        (const StepRec*)d_rec);
     hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(1024), 0, st, tS, tS2, tP, nunits, sc, (uint64_t)n, 1, (double*)nullptr, (int32_t*)nullptr, 0u,
                        (const double*)nullptr, (unsigned long long*)nullptr, 0);
-    hipLaunchKernelGGL((k_offspring<true, false, CSSM_RESAMPLE_SYSTEMATIC>), dim3(tgrid), dim3(CSSM_BLOCK), 0, st, d_w, (uint64_t)n, sc, (const cssm_u128*)tP,
-                       (const cssm_u128*)tS2, d_rec, (uint64_t)n, d_end, d_anc, ntiles, sup, nunits, 1, 0, (double*)nullptr, (int32_t*)nullptr, 0u, 0,
-                       (const unsigned long long*)nullptr, 0, 1, 1, (uint64_t)0, (double*)nullptr, d_tab, 0, (unsigned long long*)nullptr,
-                       0u, (uint32_t)n);
+#define RS_OFF_ARGS d_w, (uint64_t)n, sc, (const cssm_u128*)tP, (const cssm_u128*)tS2, d_rec, (uint64_t)n, d_end, d_anc, ntiles, sup, nunits, 1, 0, \
+                    (double*)nullptr, (int32_t*)nullptr, 0u, 0, (const unsigned long long*)nullptr, 0, 1, 1, seed, d_cum, d_tab, 0,                \
+                    (unsigned long long*)nullptr, 0u, (uint32_t)n
+    if (kind == CSSM_RESAMPLE_STRATIFIED)
+      hipLaunchKernelGGL((k_offspring<true, false, CSSM_RESAMPLE_STRATIFIED>), dim3(tgrid), dim3(CSSM_BLOCK), 0, st, RS_OFF_ARGS);
+    else if (kind == CSSM_RESAMPLE_MULTINOMIAL)
+      hipLaunchKernelGGL((k_offspring<true, false, CSSM_RESAMPLE_MULTINOMIAL>), dim3(tgrid), dim3(CSSM_BLOCK), 0, st, RS_OFF_ARGS);
+    else
+      hipLaunchKernelGGL((k_offspring<true, false, CSSM_RESAMPLE_SYSTEMATIC>), dim3(tgrid), dim3(CSSM_BLOCK), 0, st, RS_OFF_ARGS);
+#undef RS_OFF_ARGS
+    if (kind == CSSM_RESAMPLE_MULTINOMIAL)
+      hipLaunchKernelGGL(k_multinomial, dim3(grid_for(n, 256, kGridCap)), dim3(256), 0, st, d_cum, (uint64_t)n, seed, step, d_anc);
   }
   RS_TRY(hipGetLastError());
   RS_TRY(hipMemcpyAsync(&hs, sc, sizeof hs, hipMemcpyDeviceToHost, st));
@@ -1103,7 +1120,7 @@ extern "C" int cssm_resample_systematic(const double* w, size_t n, double u, uin
   if (hs.S_tot.lo == 0 && hs.S_tot.hi == 0) rc = fail(CSSM_ENONFINITE, "all weights are zero (the reference divides by a zero total)");
 done:
 #undef RS_TRY
-  void* ptrs[] = {d_w, d_end, d_anc, tS, tS2, tP, sc, d_rec, d_tab};
+  void* ptrs[] = {d_w, d_end, d_anc, tS, tS2, tP, sc, d_rec, d_tab, d_cum};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   if (st) (void)hipStreamDestroy(st);
   return rc;

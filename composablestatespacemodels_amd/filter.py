@@ -193,14 +193,37 @@ class Resampling:
         return anc
 
     @staticmethod
-    def stratifiedResampling(particles: Sequence, weights: Sequence[float]):
-        """Resampling.scala:78-86.  As a ``Filter`` argument it selects the native stratified resampler."""
-        raise NotImplementedError("stratified resampling is native inside Filter only (no stateless entry point yet)")
+    def ancestors(kind: int, weights: Sequence[float], u: float = 0.0, seed: int = 0, step: int = 0, device: int = 0) -> np.ndarray:
+        """cssm_resample: the ancestor indices of resampler ``kind`` (0 systematic, 1 stratified, 2 multinomial)."""
+        w = np.ascontiguousarray(weights, dtype=np.float64)
+        anc = np.zeros(len(w), dtype=np.uint32)
+        _abi.check(_abi.load_library().cssm_resample(int(kind), _p(w), len(w), float(u), int(seed), int(step),
+                                                     _p(anc, C.POINTER(C.c_uint32)), device))
+        return anc
 
     @staticmethod
-    def multinomialResampling(particles: Sequence, weights: Sequence[float]):
-        """Resampling.scala:92-96.  As a ``Filter`` argument it selects the native multinomial resampler."""
-        raise NotImplementedError("multinomial resampling is native inside Filter only (no stateless entry point yet)")
+    def _seeded(kind: int, particles: Sequence, weights: Sequence[float], seed: Optional[int], step: int):
+        if len(particles) != len(weights):
+            raise ValueError("particles and weights differ in length")
+        if seed is None:   # the reference draws from unseeded global generators (:83, :93)
+            seed = int(np.random.default_rng().integers(0, 2**63))
+        return [particles[int(a)] for a in Resampling.ancestors(kind, weights, 0.0, seed, step)]
+
+    @staticmethod
+    def stratifiedResampling(particles: Sequence, weights: Sequence[float], seed: Optional[int] = None, step: int = 0):
+        """Resampling.scala:78-86 as a ``Resample[A]``; as a ``Filter`` argument it selects the native stratified resampler."""
+        return Resampling._seeded(1, particles, weights, seed, step)
+
+    @staticmethod
+    def multinomialResampling(particles: Sequence, weights: Sequence[float], seed: Optional[int] = None, step: int = 0):
+        """Resampling.scala:92-96 as a ``Resample[A]``; as a ``Filter`` argument it selects the native multinomial resampler."""
+        return Resampling._seeded(2, particles, weights, seed, step)
+
+    @staticmethod
+    def residualResampling(particles: Sequence, weights: Sequence[float]):
+        """Resampling.scala:130-146 cannot run as written (it hands ``Vector.range(1, m)`` with n weights to the multinomial
+        resampler and then indexes the particles with the result, :144-145): not offered, see DESIGN.md section 9."""
+        raise NotImplementedError("the reference's residualResampling fails as written (model/Resampling.scala:144-145)")
 
     @staticmethod
     def systematicResampling(particles: Sequence, weights: Sequence[float], u: Optional[float] = None):

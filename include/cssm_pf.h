@@ -272,6 +272,11 @@ int cssm_pf_interpolate(cssm_pf* pf, const double* t, const double* y, const uin
  * (the unnormalised w1 = exp(w - max) the reference passes, :125-126), one uniform u in [0,1),
  * anc[n] receives the index of the particle that slot i copies.  Runs on `device`. */
 int cssm_resample_systematic(const double* w, size_t n, double u, uint32_t* anc, int device);
+/* The same seam for every resampler the library has: kind = CSSM_RESAMPLE_SYSTEMATIC (reads u; seed and step unused),
+ * CSSM_RESAMPLE_STRATIFIED (model/Resampling.scala:78-86) or CSSM_RESAMPLE_MULTINOMIAL (:92-96), whose per-slot uniforms
+ * come from the Philox streams of (seed, step) -- the ancestors a filter with that seed selects at observation `step`
+ * for the same weights (u unused).  The reference draws them from unseeded global generators (:66, :83, :93). */
+int cssm_resample(int kind, const double* w, size_t n, double u, uint64_t seed, uint32_t step, uint32_t* anc, int device);
 
 /* ---- sharded filter: stage calls between which the caller runs its collectives ------------ */
 /*

@@ -264,6 +264,27 @@ def test_stateless_resampler_matches_oracle(n):
             np.testing.assert_array_equal(Resampling.systematicAncestors(w, u), oracle.resample_systematic(w, u))
 
 
+@pytest.mark.parametrize("n", [1, 7, 1000, 1024, 4097, 200000])
+def test_stateless_stratified_and_multinomial_match_oracle(n):
+    """The `Resample[A]` seam for the other two resamplers (Resampling.scala:78-96): same ancestors as the oracle for the
+    same (seed, step), and as the filter's own resampling step selects (tested through the filters elsewhere)."""
+    rng = np.random.default_rng(n + 1)
+    for case in range(3):
+        w = rng.random(n) if case == 0 else np.exp(-rng.exponential(8.0, n))
+        if case == 2:
+            w[rng.random(n) < 0.5] = 0.0; w[rng.integers(n)] = 0.25
+        for seed, step in ((cases.SEED, 0), (12345, 17)):
+            np.testing.assert_array_equal(Resampling.ancestors(1, w, seed=seed, step=step), oracle.resample_stratified(w, seed, step))
+            if n <= 20000:   # (the oracle scans linearly per draw, as Multinomial.draw does)
+                np.testing.assert_array_equal(Resampling.ancestors(2, w, seed=seed, step=step), oracle.resample_multinomial(w, seed, step))
+    out = Resampling.stratifiedResampling(list(range(n)), list(w), seed=3)
+    assert len(out) == n and all(w[i] > 0 for i in out)
+    out = Resampling.multinomialResampling(list(range(n)), list(w))
+    assert len(out) == n and all(w[i] > 0 for i in out)
+    with pytest.raises(NotImplementedError):
+        Resampling.residualResampling([1, 2], [0.5, 0.5])
+
+
 def test_resample_seam_returns_same_length():
     # the reference's own property: SamplingTest.scala:16-18
     w = np.random.default_rng(5).random(777)
