@@ -33,6 +33,13 @@ class MetropState:  # PMMH.scala:10-14
     accepted: int
 
 
+@dataclass
+class ParamsState:  # PMMH.scala:17 (what `params` emits: the chain without the sampled state)
+    ll: float
+    params: Parameters
+    accepted: int
+
+
 class ParametersProposal:
     """``Parameters.perturb(delta)`` (Parameters.scala:65-67): independent Gaussian(theta_k, sqrt(delta))
     on every stored scalar, scale included."""
@@ -69,6 +76,50 @@ class MetropolisHastings:
                 k += 1
                 yield s
         return run
+
+
+    @staticmethod
+    def approxMhStep(s: MetropState, proposal, logTransition, prior, pf, rng) -> MetropState:
+        """ApproxPMMH.mhStep (PMMH.scala:138-152): the likelihood of the CURRENT parameters is estimated again in every
+        step (two filter runs per iteration: the proposal's first, then the current one's), and a rejected step carries
+        that fresh estimate and its last sampled state."""
+        prop = proposal(s.params, rng)
+        ll, path = pf(prop)
+        old_ll, old_path = pf(s.params)
+        a = ll + logTransition(prop, s.params) + prior(prop) - logTransition(s.params, prop) - old_ll - prior(s.params)
+        u = rng.random()
+        if math.log(u) < a if u > 0.0 else True:
+            return MetropState(ll, prop, path[-1] if len(path) else None, s.accepted + 1)
+        return MetropState(old_ll, s.params, old_path[-1] if len(old_path) else None, s.accepted)
+
+    @staticmethod
+    def approxPmmh(initP: Parameters, proposal, logTransition, prior):
+        """MetropolisHastings.approxPmmh (PMMH.scala:169-175): as pmmhState with ApproxPMMH's step."""
+        def run(pf: Callable[[Parameters], Tuple[float, Sequence]], rng: Optional[np.random.Generator] = None,
+                iters: Optional[int] = None) -> Iterator[MetropState]:
+            rng = rng or np.random.default_rng()
+            s = MetropState(-1e99, initP, None, 0)      # PMMH.scala:135
+            k = 0
+            while iters is None or k < iters:
+                s = MetropolisHastings.approxMhStep(s, proposal, logTransition, prior, pf, rng)
+                k += 1
+                yield s
+        return run
+
+    @staticmethod
+    def params(chain: Iterator[MetropState]) -> Iterator[ParamsState]:
+        """MetropolisHastings.params (PMMH.scala:89-93): the chain's (ll, params, accepted)."""
+        for s in chain:
+            yield ParamsState(s.ll, s.params, s.accepted)
+
+    @staticmethod
+    def pmmhStep(pos: Callable, proposal: Callable, s: Tuple[float, object], rng) -> Tuple[float, object]:
+        """MetropolisHastings.pmmhStep (PMMH.scala:177-191): Metropolis step on a (log-posterior, parameter) pair with a
+        symmetric proposal; `pos` returns the log-posterior estimate of a proposal."""
+        prop = proposal(s[1], rng)
+        ll = pos(prop)
+        u = rng.random()
+        return (ll, prop) if (u <= 0.0 or math.log(u) < ll - s[0]) else s
 
 
 def bootstrap_filter(unparam: UnparamModel, data, n: int, seed: int = 20260101, device: int = 0):

@@ -42,6 +42,41 @@ def test_k6_mh_step_accept_reject_sequence_with_stub_filter():
     assert out == [(-50.0, 1), (-50.0, 1), (-49.5, 2), (-49.5, 2), (-70.0, 3)]
 
 
+def test_approx_pmmh_reestimates_the_current_likelihood_every_step():
+    """ApproxPMMH (PMMH.scala:128-152): two filter runs per iteration, proposal first; a rejected step keeps the fresh
+    estimate of the current parameters, not the stored one."""
+    init = cases.c2_params()
+    nt = len(init.flattenParams())
+    calls = []
+    lls = iter([-50.0, -1e9,      # it 1: proposal -50, "current" (initial params) -1e9 -> accept
+                -60.0, -50.5,     # it 2: proposal -60, current re-estimated -50.5: log(.5) < -9.5 false -> reject, ll becomes -50.5
+                -49.0, -50.2])    # it 3: proposal -49, current -50.2: a = 1.2 -> accept
+    def pf(p):
+        calls.append(tuple(p.flattenParams()))
+        return next(lls), [np.full(3, len(calls))]
+    rng = FixedStream(np.ones(nt * 3), [0.5, 0.5, 0.5])
+    chain = MetropolisHastings.approxPmmh(init, ParametersProposal(0.04), lambda a, b: 0.0, lambda p: 0.0)(pf, rng, iters=3)
+    out = list(chain)
+    assert [(s.ll, s.accepted) for s in out] == [(-50.0, 1), (-50.5, 1), (-49.0, 2)]
+    assert len(calls) == 6 and calls[1] == tuple(init.flattenParams()) and calls[3] == calls[0]   # current = the accepted proposal
+    assert out[1].sde[0] == 4                     # the rejected step carries the state of the re-run (4th filter call)
+    ps = list(MetropolisHastings.params(iter(out)))
+    assert [(q.ll, q.accepted) for q in ps] == [(-50.0, 1), (-50.5, 1), (-49.0, 2)] and ps[2].params is out[2].params
+
+
+def test_pmmh_step_on_a_log_posterior_pair():
+    """MetropolisHastings.pmmhStep (PMMH.scala:177-191)."""
+    rng = FixedStream([0.0] * 3, [0.5, 0.5, 1e-9])
+    pos = iter([-10.0, -12.0, -30.0])
+    s = (-1e99, 0.0)
+    out = []
+    for _ in range(3):
+        s = MetropolisHastings.pmmhStep(lambda p: next(pos), lambda p, r: p + 1.0 + r.standard_normal(1)[0], s, rng)
+        out.append(s)
+    # accept (from -1e99); log(.5) < -2 false -> stay; log(1e-9) = -20.7 < -20 -> accept
+    assert out == [(-10.0, 1.0), (-10.0, 1.0), (-30.0, 2.0)]
+
+
 def test_perturb_proposal_moments_and_shape():
     p = cases.c2_params()
     rng = np.random.default_rng(0)
