@@ -137,6 +137,39 @@ using Data = TimedObservation;
 struct PfState { double t; std::optional<double> observation; double ll; int ess; };   // ParticleFilter.scala:32-37 (cloud stays on the device)
 struct StateSpace { double time; Vec state; };
 
+// object Resampling (model/Resampling.scala): the `Resample[A]` of package.scala:23 on host vectors -- the ancestor indices
+// come from the GPU (cssm_resample), the gather of the caller's `A`s happens here.  `weights` are the unnormalised
+// w1 = exp(w - max) the reference passes (ParticleFilter.scala:125-126).  The reference draws u / the per-slot uniforms
+// from unseeded global generators (:66, :83, :93); here the caller passes u, or (seed, step) of the contract's streams.
+struct Resampling {
+  static std::vector<uint32_t> ancestors(int kind, const Vec& weights, double u = 0.0, uint64_t seed = 0, uint32_t step = 0, int device = 0) {
+    std::vector<uint32_t> anc(weights.size());
+    check(cssm_resample(kind, weights.data(), weights.size(), u, seed, step, anc.data(), device));
+    return anc;
+  }
+  template <class A>
+  static std::vector<A> gather(const std::vector<A>& particles, const std::vector<uint32_t>& anc) {
+    std::vector<A> out; out.reserve(anc.size());
+    for (uint32_t a : anc) out.push_back(particles[a]);
+    return out;
+  }
+  template <class A>
+  static std::vector<A> systematicResampling(const std::vector<A>& particles, const Vec& weights, double u, int device = 0) {   // :63-72
+    if (particles.size() != weights.size()) throw Error(CSSM_EINVAL_ARG, "particles and weights differ in length");
+    return gather(particles, ancestors(CSSM_RESAMPLE_SYSTEMATIC, weights, u, 0, 0, device));
+  }
+  template <class A>
+  static std::vector<A> stratifiedResampling(const std::vector<A>& particles, const Vec& weights, uint64_t seed, uint32_t step = 0, int device = 0) {   // :78-86
+    if (particles.size() != weights.size()) throw Error(CSSM_EINVAL_ARG, "particles and weights differ in length");
+    return gather(particles, ancestors(CSSM_RESAMPLE_STRATIFIED, weights, 0.0, seed, step, device));
+  }
+  template <class A>
+  static std::vector<A> multinomialResampling(const std::vector<A>& particles, const Vec& weights, uint64_t seed, uint32_t step = 0, int device = 0) {   // :92-96
+    if (particles.size() != weights.size()) throw Error(CSSM_EINVAL_ARG, "particles and weights differ in length");
+    return gather(particles, ancestors(CSSM_RESAMPLE_MULTINOMIAL, weights, 0.0, seed, step, device));
+  }
+};
+
 // Filter(mod, resample) with resample = Resampling.systematicResampling (or CSSM_RESAMPLE_* through `resampler`)
 class Filter {
  public:

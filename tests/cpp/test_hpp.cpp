@@ -23,6 +23,17 @@ int main(int argc, char** argv) {
     PfState s = f.initialiseState(0.0);
     for (auto& d : data) s = f.stepFilter(s, d);
     std::printf("ll %a\nll_filter %a\nll_stream %a\npath_len %zu\ness %d\n", ll, ll2, s.ll, path.size(), s.ess);
+    // the Resample[A] seam (package.scala:23) on host vectors: systematic with a given u, stratified / multinomial by (seed, step)
+    {
+      Vec w; std::vector<int> ids;
+      for (int i = 0; i < 1000; ++i) { w.push_back((i * 37 % 101) / 101.0 + (i == 500 ? 5.0 : 0.0)); ids.push_back(i); }
+      auto a = Resampling::systematicResampling(ids, w, 0.25);
+      auto b = Resampling::stratifiedResampling(ids, w, 20260101, 3);
+      auto c = Resampling::multinomialResampling(ids, w, 20260101, 3);
+      unsigned long long ha = 0, hb = 0, hc = 0;
+      for (size_t i = 0; i < a.size(); ++i) { ha = ha * 1000003ull + a[i]; hb = hb * 1000003ull + b[i]; hc = hc * 1000003ull + c[i]; }
+      std::printf("resample_len %zu\nresample_sys %llu\nresample_strat %llu\nresample_multi %llu\n", a.size(), ha, hb, hc);
+    }
     // error path: a Gaussian model without its scale parameter must throw (Model.scala:250)
     try {
       ParamModel bad(Model::linear(Sde::brownianMotion(1)), Parameters{{std::nullopt, SdeParameter::brownianParameter({0.0}, {1.0}, {1.0})}});

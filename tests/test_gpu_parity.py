@@ -450,6 +450,17 @@ def test_cpp_host_mirror_matches_python_binding_and_oracle(tmp_path):
     oll, _, oess, _ = o.filter(t, y, has)
     assert float.fromhex(kv["ll"]) == oll and float.fromhex(kv["ll_filter"]) == oll and float.fromhex(kv["ll_stream"]) == oll
     assert int(kv["path_len"]) == 9 and int(kv["ess"]) == oess[-1] and int(kv["error_code"]) == -1
+    # cssm::Resampling (the Resample[A] seam) against the oracle's ancestors for the same weights
+    w = np.array([(i * 37 % 101) / 101.0 + (5.0 if i == 500 else 0.0) for i in range(1000)])
+    def h(anc):
+        v = 0
+        for a in anc:
+            v = (v * 1000003 + int(a)) % (1 << 64)
+        return v
+    assert int(kv["resample_len"]) == 1000
+    assert int(kv["resample_sys"]) == h(oracle.resample_systematic(w, 0.25))
+    assert int(kv["resample_strat"]) == h(oracle.resample_stratified(w, 20260101, 3))
+    assert int(kv["resample_multi"]) == h(oracle.resample_multinomial(w, 20260101, 3))
 
 
 def test_errors_are_reported_not_swallowed():
