@@ -128,6 +128,18 @@ JNIEXPORT void JNICALL Java_com_github_jonnylaw_model_CssmNative_particles(JNIEn
   if (rc) throw_last(env);
 }
 
+/* Resample[A] shim for the other resamplers (kind = CSSM_RESAMPLE_*; uniforms from the Philox streams of (seed, step)) */
+JNIEXPORT void JNICALL Java_com_github_jonnylaw_model_CssmNative_resample(JNIEnv* env, jclass c, jint kind, jdoubleArray jw, jdouble u,
+                                                                          jlong seed, jint step, jintArray janc, jint device) {
+  jsize n = (*env)->GetArrayLength(env, jw);
+  jdouble* w = (*env)->GetDoubleArrayElements(env, jw, NULL);
+  jint* a = (*env)->GetIntArrayElements(env, janc, NULL);
+  int rc = cssm_resample(kind, w, (size_t)n, u, (uint64_t)seed, (uint32_t)step, (uint32_t*)a, device);
+  (*env)->ReleaseDoubleArrayElements(env, jw, w, JNI_ABORT);
+  (*env)->ReleaseIntArrayElements(env, janc, a, 0);
+  if (rc) throw_last(env);
+}
+
 /* Resample[A] shim: ancestor indices for host-side weights */
 JNIEXPORT void JNICALL Java_com_github_jonnylaw_model_CssmNative_resampleSystematic(JNIEnv* env, jclass c, jdoubleArray jw,
                                                                                     jdouble u, jintArray janc, jint device) {

@@ -22,6 +22,7 @@ object CssmNative {
   @native def filter(handle: Long, t: Array[Double], y: Array[Double], has: Array[Byte], path: Array[Double]): Double
   @native def particles(handle: Long, out: Array[Double]): Unit
   @native def resampleSystematic(w: Array[Double], u: Double, anc: Array[Int], device: Int): Unit
+  @native def resample(kind: Int, w: Array[Double], u: Double, seed: Long, step: Int, anc: Array[Int], device: Int): Unit
 }
 
 /** Flattens a parameterised composed model into the cssm_model_desc wire form (see cssm_jni.c). */
@@ -128,6 +129,15 @@ object GpuResample {
     CssmNative.resampleSystematic(weights.toArray, scala.util.Random.nextDouble, anc, device)   // u: Resampling.scala:66
     anc.toVector.map(particles(_))
   }
+  /** Resampling.stratifiedResampling (:78-86) / multinomialResampling (:92-96): kind 1 / 2 of cssm_resample; the per-slot
+    * uniforms come from the library's Philox streams, keyed by a seed drawn where the reference draws its uniforms. */
+  private def seeded[A](kind: Int, device: Int): Resample[A] = (particles: Vector[A], weights: Vector[LogLikelihood]) => {
+    val anc = new Array[Int](weights.size)
+    CssmNative.resample(kind, weights.toArray, 0.0, scala.util.Random.nextLong, 0, anc, device)
+    anc.toVector.map(particles(_))
+  }
+  def stratified[A](device: Int = 0): Resample[A] = seeded(1, device)
+  def multinomial[A](device: Int = 0): Resample[A] = seeded(2, device)
 }
 
 /** BootstrapFilter for PMMH (package.scala:24; examples/DetermineParameters.scala:70-75): drops into
