@@ -356,6 +356,34 @@ __device__ __forceinline__ void lds_dma4(const void* g, uint32_t lds_base) {
   asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %0, off" : : "v"(g), "s"(lds_base) : "memory");
 }
 
+// How k_propagate's two-particles-per-thread instantiations (d = 3 .. 8) store their bulk outputs (state rows,
+// log-weights), one 16-byte store per lane and row, contiguous across the wave.  0: plain stores (dirty lines stay in
+// the L2 and are written back when the kernel ends); 1: non-temporal; 2: write-through at agent scope (sc1); 3: sc0 sc1.
+// Measured per step at N = 2^20 / 2^24 (d = 3, separate sums): 40.7 / 368 us plain, 39.8 / 374 nt, 37.9 / 366 sc1,
+// 37.9 / 366 sc0 sc1 -- the write-back of a launch's last dirty lines is on its critical path, a write-through store is
+// not (tools/sc1_stream_bench.hip shows the same on a bare stream).  Only where a wave's store instruction fills whole
+// lines: the four-particles-per-thread layout (d <= 2: two 16-byte stores per lane, 32 bytes apart) loses the L2's
+// write combining with sc1 (k_propagate<1> 129 -> 190 us at N = 2^24), so do the 4-byte run writes of k_offspring
+// (106 -> 165 us); one particle per thread (d >= 9, 8-byte stores) is neutral (191.6 vs 192.1 us).  Those stay plain.
+#ifndef CSSM_ST_MODE
+#define CSSM_ST_MODE 2
+#endif
+typedef double cssm_dbl2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void bulk_store2(double* p, double a, double b) {
+#if CSSM_ST_MODE == 1
+  cssm_dbl2 v; v.x = a; v.y = b;
+  __builtin_nontemporal_store(v, reinterpret_cast<cssm_dbl2*>(p));
+#elif CSSM_ST_MODE == 2
+  cssm_dbl2 v; v.x = a; v.y = b;
+  asm volatile("global_store_dwordx4 %0, %1, off sc1" : : "v"(p), "v"(v) : "memory");
+#elif CSSM_ST_MODE == 3
+  cssm_dbl2 v; v.x = a; v.y = b;
+  asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" : : "v"(p), "v"(v) : "memory");
+#else
+  *reinterpret_cast<double2*>(p) = make_double2(a, b);
+#endif
+}
+
 // Particles per thread in k_propagate: all gathers of a thread are issued before its ALU work,
 // and rows are stored as 16-/32-byte vectors.
 #ifndef CSSM_PROP_IT_MID
@@ -648,8 +676,8 @@ __global__ __launch_bounds__(CSSM_BLOCK, (PropWaves<D, SUMS>::value)) void k_pro
     } else if (full && IT == 2) {
 #pragma unroll
       for (int k = 0; k < D; ++k)
-        *reinterpret_cast<double2*>(dst + (size_t)k * dst_stride + i0) = make_double2(x[0][k], x[1 % IT][k]);
-      if (weighted) *reinterpret_cast<double2*>(logw + i0) = make_double2(lw[0], lw[1 % IT]);
+        bulk_store2(dst + (size_t)k * dst_stride + i0, x[0][k], x[1 % IT][k]);
+      if (weighted) bulk_store2(logw + i0, lw[0], lw[1 % IT]);
     } else {
 #pragma unroll
       for (int r = 0; r < IT; ++r) {

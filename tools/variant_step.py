@@ -15,8 +15,10 @@ for n in (1 << 20, 1 << 24):
     for fused in (0, 1):
         pf = NativePf(m, n, 1); pf.set_option(3, fused); T = 300 if n < (1 << 22) else 60
         pf.run(t[:20], y[:20], has[:20])
-        best = min((pf.run(t[:T], y[:T], has[:T]), pf.last_loop_ms())[1] for _ in range(4)) / T * 1e3
-        out.append("N=2^%%d %%s %%.1f" %% (n.bit_length() - 1, "fused" if fused else "separate", best)); pf.close()
+        best = 1e9
+        for _ in range(4):
+            ll = pf.run(t[:T], y[:T], has[:T])[0]; best = min(best, pf.last_loop_ms() / T * 1e3)
+        out.append("N=2^%%d %%s %%.1f (ll %%r)" %% (n.bit_length() - 1, "fused" if fused else "separate", best, ll)); pf.close()
 print(os.path.basename(%r), " | ".join(out), flush=True)
 '''
 for rep in range(2):
