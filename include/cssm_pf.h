@@ -186,8 +186,9 @@ int cssm_pf_last_loop_ms(cssm_pf* pf, float* ms_out);
  * 0 = the sums are a pass of their own after the max is known, 3 kernels per observation.  Identical results
  * (both apply cssm_ref_choose).  Default: 1 on sharded handles, where it saves a collective per observation, and on
  * handles of at most 2^18 particles, where a step is launch-latency bound and two launches beat three (20.0 vs 21.4 us
- * per observation at N = 100 000); 0 otherwise: at N = 2^20 both paths take the same time (within 2 %) and the lean
- * propagate kernel is the one the roofline figure is quoted on. */
+ * per observation at N = 100 000); 0 otherwise: at N = 2^20 the fused path is 2 % faster (37.4 vs 38.3 us of device time
+ * per observation, 363 vs 366 us at 2^24) but a series with an outlying observation runs twice, and the lean propagate
+ * kernel is the one the roofline figure is quoted on. */
 #define CSSM_OPT_FUSED_SUMS 3
 int cssm_pf_set_option(cssm_pf* pf, int option, int value);
 
