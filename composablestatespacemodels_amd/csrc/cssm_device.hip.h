@@ -1,0 +1,382 @@
+// cssm_device.hip.h -- gfx950 device-side building blocks of libcssm_pf shared by every translation unit: record and
+// scalar layouts, DPP scans, the contract's variate streams, transitions, f, log-densities, LDS DMA, bulk stores.
+// Only inline device functions and templates live here (safe to include from several .hip files); the kernels are in
+// cssm_propagate.hip.h (k_propagate, one translation unit per latent dimension) and cssm_kernels.hip.h (all others).
+//
+// Data layout in HBM: particles are struct-of-arrays fp64,
+// state[k * stride + i] = latent component k (Tree.flatten order) of particle i, two buffers
+// that ping-pong; logw[N] fp64; anc[stride] u32; endslot[N] u32 (sharded filter only: exclusive end of the
+// run of resampling slots particle j owns).  Resampling never moves particles: the NEXT propagate kernel
+// reads its input through anc[] (fused gather), so a step costs one read and one write of the cloud.
+//
+// Kernels of one observation (element-wise / scan work, no MFMA):
+//   k_propagate   gather + exact SDE transition (or Euler-Maruyama) + f + log-density, block max -> one integer
+//                 atomicMax per block; the next tile's states are prefetched by asynchronous global -> LDS loads
+//                 (global_load_lds_dwordx4), the indices of the tile after it into registers; optionally (SUMS)
+//                 the fixed-point sums of exp(w - c) as well                       model/ParticleFilter.scala:118,123-124
+//   k_tile_sums   w1 = exp(w - level) in 128-bit fixed point, one (S, S2) per unit of tiles                        :125
+//   k_offspring   unit prefix + totals (every block sums the <= 1K unit sums itself), ll and ess (:127-128), per tile
+//                 a DPP wave scan -> cumulative weight C_j -> end slot cnt(C_j); every particle writes its own run of
+//                 slots into anc (single GPU), or the end slots are kept for the exchange   model/Resampling.scala:36-58,69
+//   sharded only  k_scan_tiles / k_global_sums (exact exchange), k_pack_fixed + k_expand_fixed (fixed-capacity
+//                 exchange), k_expand (candidates -> slots)
+// Cross-lane traffic is DPP, not ds_bpermute (5 vs 25 cycles per move on MI355X, tools/instr_rate.hip).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/cssm_numerics.h"
+#include "../../include/cssm_pf.h"
+
+#define CSSM_BLOCK 256
+#ifndef CSSM_PROP_IT_MID
+#define CSSM_PROP_IT_MID 2 /* particles per thread of k_propagate for d = 3 .. 8 (PropItems) */
+#endif
+#define CSSM_ITEMS 4
+#define CSSM_TILE (CSSM_BLOCK * CSSM_ITEMS) /* 1024 particles per tile */
+
+// f-map modes per component (host-built from the leaf list; oracle: gamma_of)
+#define FM_SKIP 0
+#define FM_START 1 /* first used component of a leaf: acc = c*x  */
+#define FM_ADD 2   /* acc += c*x                                 */
+
+// Per-model constants, passed BY VALUE (kernarg -> SGPRs; every branch on them is wave-uniform).
+// One byte per latent component: bits 0-1 CSSM_SDE_*, bits 2-3 FM_*, bit 4 closes its leaf, bit 5 leaf is
+// the leftmost one.  Packed four to a word so that the whole struct costs 6 SGPRs (66 unpacked made the
+// kernel spill scalars through v_writelane/v_readlane).
+struct ModelK {
+  int32_t d;
+  int32_t obs_kind;
+  uint32_t comp[CSSM_MAX_DIM / 4];
+  __host__ __device__ __forceinline__ uint32_t byte(int k) const { return (comp[k >> 2] >> ((k & 3) * 8)) & 0xffu; }
+  __host__ __device__ __forceinline__ int kind(int k) const { return (int)(byte(k) & 3u); }
+  __host__ __device__ __forceinline__ int fmode(int k) const { return (int)((byte(k) >> 2) & 3u); }
+  __host__ __device__ __forceinline__ bool leaf_end(int k) const { return (byte(k) >> 4) & 1u; }
+  __host__ __device__ __forceinline__ bool first_leaf(int k) const { return (byte(k) >> 5) & 1u; }
+};
+
+// Per-observation record, built on the host (everything that depends only on (t, y)).
+struct StepRec {
+  double y;       // count models: (double)trunc(y); otherwise y
+  double c[4];    // per-observation constants of the density (see build_rec / logdens)
+  double cdf;     // Student-t: degrees of freedom as double
+  double u;       // the one uniform of systematic resampling
+  double dt;      // time increment (LGCP: the sub-step delta)
+  double ref;     // reference level of the observation (cssm_ref_level; NaN: always rescale by the max)
+  int32_t has_obs;
+  int32_t n_sub;  // LGCP sub-steps (0: dt == 0, weight 0, state kept)
+  uint32_t pick;  // sampleOne index for `filter`
+  uint32_t step;  // observation index (Philox counter word 2)
+  double coef[CSSM_MAX_DIM][4]; // transition coefficients per component
+  double fco[CSSM_MAX_DIM];     // f coefficients c_k(t)
+};
+
+// Device scalars of a handle.
+#define CSSM_MAXSLOTS 64
+#define CSSM_SLOT_STRIDE 16 /* u64 words: one 128-byte line per slot */
+struct Scalars {
+  // Order keys of the running max log-weight, sharded over CSSM_MAXSLOTS cache lines, in two sets:
+  // weighted step s uses set s&1, and its last kernel clears the other set for step s+1.
+  unsigned long long maxslot[2 * CSSM_MAXSLOTS * CSSM_SLOT_STRIDE];
+  uint32_t err;              // bit0: NaN log-weight, bit1: all weights zero / max not finite,
+                             // bit2: the reference level was unusable and the sums must be formed again (host retries)
+                             // bit3: (sharded) the exchange capacity did not cover some rank's slots at step fail_step
+  int32_t ess;
+  uint32_t fail_step;        // first observation whose exchange did not fit (0xffffffff: none); see k_offspring_expand_spec
+  uint32_t pad_;
+  double gmax;               // decoded global max of this step
+  double ref;                // level the weights of this step were rescaled by (cssm_ref_choose)
+  double ll;                 // accumulated log-likelihood
+  cssm_u128 S_local, S2_local; // local fixed-point sums (this rank)
+  cssm_u128 S_off;           // sum of the ranks before this one
+  cssm_u128 S_tot, S2_tot;   // global sums
+};
+
+// ------------------------------------------------------------------------------------ helpers
+
+// Cross-lane traffic goes through DPP (data-parallel primitives: a VALU move whose source lane is a fixed
+// pattern), not through ds_bpermute (__shfl*): measured on MI355X (tools/instr_rate.hip) a DPP move issues in ~5
+// cycles per wave, a ds_bpermute_b32 in ~25, and a 128-bit scan needs 24 of either.
+//   row_shr:n   lane i of each row of 16 reads lane i-n of its row (lanes without a source keep `old` = 0)
+//   row_bcast15 lane 15 of every row -> all lanes of the NEXT row (row_mask 0xa: rows 1 and 3 take it)
+//   row_bcast31 lane 31 -> all lanes of rows 2 and 3 (row_mask 0xc)
+// After the six steps lane i holds the inclusive prefix over lanes 0..i, lane 63 the wave total.
+#define CSSM_DPP_ROW_SHR(n) (0x110 + (n))
+#define CSSM_DPP_BCAST15 0x142
+#define CSSM_DPP_BCAST31 0x143
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ uint32_t dpp0(uint32_t v) {   // lanes that receive nothing read 0
+  return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROW_MASK, 0xf, false);
+}
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ uint64_t dpp0_u64(uint64_t v) {
+  return (uint64_t)dpp0<CTRL, ROW_MASK>((uint32_t)v) | ((uint64_t)dpp0<CTRL, ROW_MASK>((uint32_t)(v >> 32)) << 32);
+}
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ cssm_u128 dpp0_u128(cssm_u128 v) {
+  cssm_u128 r;
+  r.lo = dpp0_u64<CTRL, ROW_MASK>(v.lo);
+  r.hi = dpp0_u64<CTRL, ROW_MASK>(v.hi);
+  return r;
+}
+__device__ __forceinline__ uint64_t readlane_u64(uint64_t v, int lane) {
+  return (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, lane) |
+         ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), lane) << 32);
+}
+
+// inclusive scan across the 64 lanes (integer adds: any order gives the same bits)
+__device__ __forceinline__ cssm_u128 wave_scan_u128(cssm_u128 v, int lane) {
+  (void)lane;
+  v = cssm_u128_add(v, dpp0_u128<CSSM_DPP_ROW_SHR(1), 0xf>(v));
+  v = cssm_u128_add(v, dpp0_u128<CSSM_DPP_ROW_SHR(2), 0xf>(v));
+  v = cssm_u128_add(v, dpp0_u128<CSSM_DPP_ROW_SHR(4), 0xf>(v));
+  v = cssm_u128_add(v, dpp0_u128<CSSM_DPP_ROW_SHR(8), 0xf>(v));
+  v = cssm_u128_add(v, dpp0_u128<CSSM_DPP_BCAST15, 0xa>(v));
+  v = cssm_u128_add(v, dpp0_u128<CSSM_DPP_BCAST31, 0xc>(v));
+  return v;
+}
+// wave total, uniform (it is read from lane 63 into scalar registers)
+__device__ __forceinline__ cssm_u128 wave_sum_u128(cssm_u128 v) {
+  v = wave_scan_u128(v, 0);
+  cssm_u128 r;
+  r.lo = readlane_u64(v.lo, 63);
+  r.hi = readlane_u64(v.hi, 63);
+  return r;
+}
+__device__ __forceinline__ uint64_t wave_max_u64(uint64_t k) {   // uniform
+#define CSSM_MAX_STEP(CTRL, RM) { const uint64_t o = dpp0_u64<CTRL, RM>(k); k = (o > k) ? o : k; }
+  CSSM_MAX_STEP(CSSM_DPP_ROW_SHR(1), 0xf) CSSM_MAX_STEP(CSSM_DPP_ROW_SHR(2), 0xf) CSSM_MAX_STEP(CSSM_DPP_ROW_SHR(4), 0xf)
+  CSSM_MAX_STEP(CSSM_DPP_ROW_SHR(8), 0xf) CSSM_MAX_STEP(CSSM_DPP_BCAST15, 0xa) CSSM_MAX_STEP(CSSM_DPP_BCAST31, 0xc)
+#undef CSSM_MAX_STEP
+  return readlane_u64(k, 63);
+}
+// max of doubles through their order-preserving keys (a missing DPP source reads key 0, below every real key)
+__device__ __forceinline__ double wave_max(double v) { return cssm_order_unkey(wave_max_u64(cssm_order_key(v))); }
+
+// The contract's log table (include/cssm_numerics.h, CSSM_LOG_TAB) staged in LDS by every kernel that
+// draws normals: `tab_global` is the handle's device copy.  All threads of the block must call it.
+__device__ __forceinline__ const double* stage_log_table(const double* __restrict__ tab_global) {
+  __shared__ double s_logtab[256];
+  for (int i = threadIdx.x; i < 256; i += blockDim.x) s_logtab[i] = tab_global[i];
+  __syncthreads();
+  return s_logtab;
+}
+
+// The d standard normals of global particle gid for an ordinary step or the initial draw (include/cssm_numerics.h,
+// counter layout): particles 2m and 2m+1 share stream m, particle gid owns its normals q = (gid & 1) * D + k, normal q
+// = element q&1 of block q>>1.  A particle touches ceil(D/2) blocks starting at b0; for odd D an odd particle starts
+// on the SECOND element of its first block.  Branch-free in gid, so neighbouring lanes do not diverge.
+template <int D>
+__device__ __forceinline__ void draw_normals(uint64_t seed, uint64_t gid, uint32_t step, uint32_t tag,
+                                             const double* tab, double (&z)[D]) {
+  constexpr int NB = (D + 1) / 2;
+  const bool odd = (gid & 1u) != 0u;
+  const uint32_t b0 = ((uint32_t)(gid & 1u) * (uint32_t)D) >> 1;
+  const uint64_t stream = cssm_pair_stream(gid);
+  double pe1 = 0.0;
+#pragma unroll
+  for (int p = 0; p < NB; ++p) {
+    double e0, e1;
+    cssm_normal_pair(cssm_philox_draw(seed, stream, step, tag, b0 + (uint32_t)p), tab, &e0, &e1);
+    if (D % 2 == 0) {
+      z[2 * p] = e0; z[(2 * p + 1) % D] = e1;
+    } else {   // even particle: element j of its blocks is component j; odd particle: component j - 1
+      if (p > 0) z[(2 * p - 1 + D) % D] = odd ? e0 : pe1;
+      z[2 * p] = odd ? e1 : e0;
+      pe1 = e1;
+    }
+  }
+}
+
+// One transition of component k (model/Sde.scala:86-95,114-123,139-150; :30-43 for Euler); components are independent.
+template <int D>
+__device__ __forceinline__ void transition_one(const ModelK& mk, const StepRec* __restrict__ rec, double dt, int k, double& xk, double zk) {
+  const double p0 = rec->coef[k][0], p1 = rec->coef[k][1], p2 = rec->coef[k][2], p3 = rec->coef[k][3];
+  const int kind = mk.kind(k);
+  if (kind == CSSM_SDE_BROWNIAN) {
+    xk = p3 * zk + xk;
+  } else if (kind == CSSM_SDE_GEN_BROWNIAN) {
+    double mean = xk + p0;
+    xk = p3 * zk + mean;
+  } else if (kind == CSSM_SDE_OU) {
+    double mean = p0 + (xk - p0) * p1;
+    xk = p3 * zk + mean;
+  } else {
+    double dW = p3 * zk;
+    double a = (p0 + p1 * xk) * dt;
+    double b = p2 * dW;
+    xk = (xk + a) + b;
+  }
+}
+template <int D>
+__device__ __forceinline__ void transition(const ModelK& mk, const StepRec* __restrict__ rec, double dt,
+                                           double (&x)[D], const double (&z)[D]) {
+#pragma unroll
+  for (int k = 0; k < D; ++k) transition_one<D>(mk, rec, dt, k, x[k], z[k]);
+}
+
+// Ordinary step of the two particles of a pair (2m, 2m+1): D Philox blocks + Box-Muller pairs give their 2 D normals,
+// each fed to its component as soon as it exists (normal q -> particle q / D, component q % D).
+template <int D>
+__device__ __forceinline__ void propagate_pair(const ModelK& mk, const StepRec* __restrict__ rec, double dt, uint64_t seed,
+                                               uint64_t gid_even, uint32_t step, const double* tab, double (&xa)[D], double (&xb)[D]) {
+  const uint64_t stream = cssm_pair_stream(gid_even);
+#pragma unroll
+  for (int p = 0; p < D; ++p) {
+    double e0, e1;
+    cssm_normal_pair(cssm_philox_draw(seed, stream, step, CSSM_STREAM_STEP, (uint32_t)p), tab, &e0, &e1);
+    if (2 * p < D) transition_one<D>(mk, rec, dt, 2 * p, xa[(2 * p) % D], e0);
+    else transition_one<D>(mk, rec, dt, 2 * p - D, xb[(2 * p - D + D) % D], e0);
+    if (2 * p + 1 < D) transition_one<D>(mk, rec, dt, 2 * p + 1, xa[(2 * p + 1) % D], e1);
+    else transition_one<D>(mk, rec, dt, 2 * p + 1 - D, xb[(2 * p + 1 - D + D) % D], e1);
+  }
+}
+// The same for ONE particle of either parity (threads that do not own whole pairs): ceil(D/2) blocks.
+template <int D>
+__device__ __forceinline__ void propagate_one(const ModelK& mk, const StepRec* __restrict__ rec, double dt, uint64_t seed,
+                                              uint64_t gid, uint32_t step, const double* tab, double (&x)[D]) {
+  constexpr int NB = (D + 1) / 2;
+  const bool odd = (gid & 1u) != 0u;
+  const uint32_t b0 = ((uint32_t)(gid & 1u) * (uint32_t)D) >> 1;
+  const uint64_t stream = cssm_pair_stream(gid);
+  double pe1 = 0.0;
+#pragma unroll
+  for (int p = 0; p < NB; ++p) {
+    double e0, e1;
+    cssm_normal_pair(cssm_philox_draw(seed, stream, step, CSSM_STREAM_STEP, b0 + (uint32_t)p), tab, &e0, &e1);
+    if (D % 2 == 0) {
+      transition_one<D>(mk, rec, dt, 2 * p, x[2 * p], e0);
+      transition_one<D>(mk, rec, dt, (2 * p + 1) % D, x[(2 * p + 1) % D], e1);
+    } else {
+      if (p > 0) transition_one<D>(mk, rec, dt, (2 * p - 1 + D) % D, x[(2 * p - 1 + D) % D], odd ? e0 : pe1);
+      transition_one<D>(mk, rec, dt, 2 * p, x[2 * p], odd ? e1 : e0);
+      pe1 = e1;
+    }
+  }
+}
+
+// gamma = f(x, t): per-leaf dot product, leaves summed left-nested (model/Model.scala:122-128,217-225,271)
+template <int D>
+__device__ __forceinline__ double gamma_of(const ModelK& mk, const StepRec* __restrict__ rec, const double (&x)[D]) {
+  double g = 0.0, acc = 0.0;
+#pragma unroll
+  for (int k = 0; k < D; ++k) {
+    const int fm = mk.fmode(k);
+    if (fm == FM_START) acc = rec->fco[k] * x[k];
+    else if (fm == FM_ADD) acc = acc + rec->fco[k] * x[k];
+    if (mk.leaf_end(k)) g = mk.first_leaf(k) ? acc : g + acc;
+  }
+  return g;
+}
+
+// dataLikelihood(gamma, y) of the leftmost leaf; the branch is wave-uniform (mk is a kernel argument).
+// Constants c[] per observation kind are listed in build_rec (cssm_pf.hip); the oracle states the same
+// expressions with the reference's line numbers (oracle/cssm_oracle.c, logdens).
+// OBS >= 0: the observation kind is a compile-time constant (the common Poisson / Gaussian kernels carry only
+// their own density: the generic body is ~2.5x larger and spills out of the instruction cache); OBS < 0: runtime.
+template <int OBS>
+__device__ __forceinline__ double logdens(const ModelK& mk, const StepRec* __restrict__ rec, double g, const double* tab) {
+  const double y = rec->y;
+  switch (OBS >= 0 ? OBS : mk.obs_kind) {
+    case CSSM_OBS_POISSON:   // -lambda + k log(lambda) - lgamma(k+1), model/Model.scala:273
+      return -cssm_exp(g) + y * g - rec->c[0];
+    case CSSM_OBS_GAUSSIAN: {  // breeze Gaussian.logPdf, model/Model.scala:252-258
+      const double dd = (y - g) / rec->c[1];
+      return -(dd * dd) / 2.0 - rec->c[0];
+    }
+    case CSSM_OBS_NEGBIN: {    // model/Model.scala:186-195
+      const double size = rec->c[1], mu = cssm_exp(g);
+      return rec->c[0] + size * cssm_log(size / (mu + size)) + y * cssm_log(mu / (mu + size));
+    }
+    case CSSM_OBS_ZIP: {       // model/Model.scala:298-307
+      if (y == 0.0) return cssm_log(rec->c[0] + (1.0 - rec->c[0]) * cssm_exp(-cssm_exp(g)));
+      return ((rec->c[1] + y * g) - cssm_exp(g)) - rec->c[2];
+    }
+    case CSSM_OBS_BERNOULLI: { // model/Model.scala:318-336
+      const double link = (g > 6.0) ? 1.0 : ((g < -6.0) ? 0.0 : 1.0 / (1.0 + cssm_exp(-g)));
+      if (y == 1.0) return (link == 0.0) ? -1e99 : cssm_log(link);
+      return (link == 1.0) ? -1e99 : cssm_log(1.0 - link);
+    }
+    case CSSM_OBS_STUDENT_T: { // 1/v * StudentsT(df).logPdf((y - eta)/v), model/Model.scala:155-160
+      const double x = (y - g) / rec->c[1];
+      return rec->c[3] * (rec->c[0] - rec->c[2] * cssm_log(1.0 + (x * x) / rec->cdf));
+    }
+    default: {                 // Beta(exp(-gamma), 1).logPdf(y) = (a - 1) log y + log a, model/Model.scala:349-352
+      return (cssm_exp(-g) - 1.0) * rec->c[0] - g;
+    }
+  }
+}
+
+
+// ------------------------------------------------------------------------------------ propagate + weight
+
+// Block-cooperative decode of the sharded running max: lane t of wave 0 reads slot t (one load
+// latency instead of 64), wave max, broadcast through LDS.  All threads of the block must call it.
+__device__ __forceinline__ double block_decode_slots(const Scalars* __restrict__ sc, int set) {
+  __shared__ unsigned long long s_key;
+  if (threadIdx.x < 64) {
+    unsigned long long k = (threadIdx.x < CSSM_MAXSLOTS)
+        ? sc->maxslot[((size_t)set * CSSM_MAXSLOTS + threadIdx.x) * CSSM_SLOT_STRIDE] : 0ull;
+    k = wave_max_u64(k);
+    if (threadIdx.x == 0) s_key = k;
+  }
+  __syncthreads();
+  return cssm_order_unkey(s_key);
+}
+
+// Asynchronous 16-byte-per-lane copy global -> LDS (gfx950: global_load_lds_dwordx4): lane l fetches the 16 bytes at
+// its own address g into LDS bytes [lds_base + 16 l, +16); lds_base is wave-uniform and travels in M0.  Issued through
+// inline assembly ON PURPOSE: for the builtin form the compiler, unable to prove that later LDS reads (the log table)
+// do not touch the destination, inserts s_waitcnt vmcnt(0) before the first LDS read that follows, i.e. it waits for
+// the very prefetch that is meant to overlap the computation.  An operation the compiler does not count only makes its
+// own counted waits more conservative (VMEM operations retire in order), never wrong; completion is awaited explicitly
+// (s_waitcnt vmcnt(0)) before the wave reads the region back.  M0 has no other use in these kernels.
+__device__ __forceinline__ void lds_dma16(const double* g, uint32_t lds_base) {
+  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(g), "s"(lds_base) : "memory");
+}
+// The same with 4 bytes per lane (lane l -> LDS bytes [lds_base + 4 l, +4)): a double travels as two of these, low and
+// high word into two 256-byte regions, where LDS is too small for 16 bytes per element.
+__device__ __forceinline__ void lds_dma4(const void* g, uint32_t lds_base) {
+  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %0, off" : : "v"(g), "s"(lds_base) : "memory");
+}
+
+// How k_propagate's two-particles-per-thread instantiations (d = 3 .. 8) store their bulk outputs (state rows,
+// log-weights), one 16-byte store per lane and row, contiguous across the wave.  0: plain stores (dirty lines stay in
+// the L2 and are written back when the kernel ends); 1: non-temporal; 2: write-through at agent scope (sc1); 3: sc0 sc1.
+// Measured per step at N = 2^20 / 2^24 (d = 3, separate sums): 40.7 / 368 us plain, 39.8 / 374 nt, 37.9 / 366 sc1,
+// 37.9 / 366 sc0 sc1 -- the write-back of a launch's last dirty lines is on its critical path, a write-through store is
+// not (tools/sc1_stream_bench.hip shows the same on a bare stream).  Only where a wave's store instruction fills whole
+// lines: the four-particles-per-thread layout (d <= 2: two 16-byte stores per lane, 32 bytes apart) loses the L2's
+// write combining with sc1 (k_propagate<1> 129 -> 190 us at N = 2^24), so do the 4-byte run writes of k_offspring
+// (106 -> 165 us); one particle per thread (d >= 9, 8-byte stores) is neutral (191.6 vs 192.1 us).  Those stay plain.
+#ifndef CSSM_ST_MODE
+#define CSSM_ST_MODE 2
+#endif
+typedef double cssm_dbl2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void bulk_store2(double* p, double a, double b) {
+#if CSSM_ST_MODE == 1
+  cssm_dbl2 v; v.x = a; v.y = b;
+  __builtin_nontemporal_store(v, reinterpret_cast<cssm_dbl2*>(p));
+#elif CSSM_ST_MODE == 2
+  cssm_dbl2 v; v.x = a; v.y = b;
+  asm volatile("global_store_dwordx4 %0, %1, off sc1" : : "v"(p), "v"(v) : "memory");
+#elif CSSM_ST_MODE == 3
+  cssm_dbl2 v; v.x = a; v.y = b;
+  asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" : : "v"(p), "v"(v) : "memory");
+#else
+  *reinterpret_cast<double2*>(p) = make_double2(a, b);
+#endif
+}
+
+// max over the CSSM_MAXSLOTS shards of the running max log-weight
+__device__ __forceinline__ double decode_slots(const Scalars* __restrict__ sc, int set) {
+  unsigned long long k = 0ull;
+  const unsigned long long* base = sc->maxslot + (size_t)set * CSSM_MAXSLOTS * CSSM_SLOT_STRIDE;
+#pragma unroll 8
+  for (int s = 0; s < CSSM_MAXSLOTS; ++s) {
+    const unsigned long long v = base[s * CSSM_SLOT_STRIDE];
+    k = (v > k) ? v : k;
+  }
+  return cssm_order_unkey(k);
+}

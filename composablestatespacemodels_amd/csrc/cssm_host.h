@@ -1,0 +1,28 @@
+// cssm_host.h -- what the translation units of libcssm_pf share on the host side (not part of the C ABI).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "cssm_device.hip.h"
+
+// Everything one k_propagate launch needs.  cssm_pf.hip fills it, the per-dimension translation unit that owns the
+// instantiation (cssm_prop.hip compiled with -DCSSM_PROP_D=<d>) launches it.
+struct PropLaunch {
+  int grid;
+  hipStream_t stream;
+  int lgcp;            // k_propagate<D, true, ...>
+  int obs;             // CSSM_OBS_POISSON / CSSM_OBS_GAUSSIAN compiled in, -1 = runtime observation kind
+  int sums;            // the kernel also forms the fixed-point sums of exp(w - c)
+  const double* src; size_t src_stride; const uint32_t* anc;
+  double* dst; size_t dst_stride; double* logw; uint64_t n; uint64_t gid0; uint64_t seed;
+  const StepRec* rec; ModelK mk; Scalars* sc; int slot_set;
+  const double* src2; size_t src2_stride; uint32_t n_split; const double* logtab;
+  uint64_t chunk; int do_sums; cssm_u128* subS; cssm_u128* subS2; double* pick_out; uint32_t pick_slot;
+};
+
+// one per latent dimension, defined in cssm_prop.hip
+#define CSSM_DECL_PROP(D) void cssm_prop_launch_d##D(const PropLaunch& a);
+CSSM_DECL_PROP(1) CSSM_DECL_PROP(2) CSSM_DECL_PROP(3) CSSM_DECL_PROP(4) CSSM_DECL_PROP(5) CSSM_DECL_PROP(6) CSSM_DECL_PROP(7) CSSM_DECL_PROP(8)
+CSSM_DECL_PROP(9) CSSM_DECL_PROP(10) CSSM_DECL_PROP(11) CSSM_DECL_PROP(12) CSSM_DECL_PROP(13) CSSM_DECL_PROP(14) CSSM_DECL_PROP(15) CSSM_DECL_PROP(16)
+#undef CSSM_DECL_PROP

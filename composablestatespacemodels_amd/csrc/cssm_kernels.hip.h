@@ -1,306 +1,7 @@
-// cssm_kernels.hip.h -- gfx950 device code of libcssm_pf (included once, by cssm_pf.hip).
-//
-// Data layout in HBM: particles are struct-of-arrays fp64,
-// state[k * stride + i] = latent component k (Tree.flatten order) of particle i, two buffers
-// that ping-pong; logw[N] fp64; anc[stride] u32; endslot[N] u32 (sharded filter only: exclusive end of the
-// run of resampling slots particle j owns).  Resampling never moves particles: the NEXT propagate kernel
-// reads its input through anc[] (fused gather), so a step costs one read and one write of the cloud.
-//
-// Kernels of one observation (element-wise / scan work, no MFMA):
-//   k_propagate   gather + exact SDE transition (or Euler-Maruyama) + f + log-density, block max -> one integer
-//                 atomicMax per block; the next tile's states are prefetched by asynchronous global -> LDS loads
-//                 (global_load_lds_dwordx4), the indices of the tile after it into registers; optionally (SUMS)
-//                 the fixed-point sums of exp(w - c) as well                       model/ParticleFilter.scala:118,123-124
-//   k_tile_sums   w1 = exp(w - level) in 128-bit fixed point, one (S, S2) per unit of tiles                        :125
-//   k_offspring   unit prefix + totals (every block sums the <= 1K unit sums itself), ll and ess (:127-128), per tile
-//                 a DPP wave scan -> cumulative weight C_j -> end slot cnt(C_j); every particle writes its own run of
-//                 slots into anc (single GPU), or the end slots are kept for the exchange   model/Resampling.scala:36-58,69
-//   sharded only  k_scan_tiles / k_global_sums (exact exchange), k_pack_fixed + k_expand_fixed (fixed-capacity
-//                 exchange), k_expand (candidates -> slots)
-// Cross-lane traffic is DPP, not ds_bpermute (5 vs 25 cycles per move on MI355X, tools/instr_rate.hip).
+// cssm_kernels.hip.h -- every kernel of libcssm_pf except k_propagate (cssm_propagate.hip.h); included once, by cssm_pf.hip.
 #pragma once
 
-#include <hip/hip_runtime.h>
-#include <stdint.h>
-
-#include "../../include/cssm_numerics.h"
-#include "../../include/cssm_pf.h"
-
-#define CSSM_BLOCK 256
-#define CSSM_ITEMS 4
-#define CSSM_TILE (CSSM_BLOCK * CSSM_ITEMS) /* 1024 particles per tile */
-
-// f-map modes per component (host-built from the leaf list; oracle: gamma_of)
-#define FM_SKIP 0
-#define FM_START 1 /* first used component of a leaf: acc = c*x  */
-#define FM_ADD 2   /* acc += c*x                                 */
-
-// Per-model constants, passed BY VALUE (kernarg -> SGPRs; every branch on them is wave-uniform).
-// One byte per latent component: bits 0-1 CSSM_SDE_*, bits 2-3 FM_*, bit 4 closes its leaf, bit 5 leaf is
-// the leftmost one.  Packed four to a word so that the whole struct costs 6 SGPRs (66 unpacked made the
-// kernel spill scalars through v_writelane/v_readlane).
-struct ModelK {
-  int32_t d;
-  int32_t obs_kind;
-  uint32_t comp[CSSM_MAX_DIM / 4];
-  __host__ __device__ __forceinline__ uint32_t byte(int k) const { return (comp[k >> 2] >> ((k & 3) * 8)) & 0xffu; }
-  __host__ __device__ __forceinline__ int kind(int k) const { return (int)(byte(k) & 3u); }
-  __host__ __device__ __forceinline__ int fmode(int k) const { return (int)((byte(k) >> 2) & 3u); }
-  __host__ __device__ __forceinline__ bool leaf_end(int k) const { return (byte(k) >> 4) & 1u; }
-  __host__ __device__ __forceinline__ bool first_leaf(int k) const { return (byte(k) >> 5) & 1u; }
-};
-
-// Per-observation record, built on the host (everything that depends only on (t, y)).
-struct StepRec {
-  double y;       // count models: (double)trunc(y); otherwise y
-  double c[4];    // per-observation constants of the density (see build_rec / logdens)
-  double cdf;     // Student-t: degrees of freedom as double
-  double u;       // the one uniform of systematic resampling
-  double dt;      // time increment (LGCP: the sub-step delta)
-  double ref;     // reference level of the observation (cssm_ref_level; NaN: always rescale by the max)
-  int32_t has_obs;
-  int32_t n_sub;  // LGCP sub-steps (0: dt == 0, weight 0, state kept)
-  uint32_t pick;  // sampleOne index for `filter`
-  uint32_t step;  // observation index (Philox counter word 2)
-  double coef[CSSM_MAX_DIM][4]; // transition coefficients per component
-  double fco[CSSM_MAX_DIM];     // f coefficients c_k(t)
-};
-
-// Device scalars of a handle.
-#define CSSM_MAXSLOTS 64
-#define CSSM_SLOT_STRIDE 16 /* u64 words: one 128-byte line per slot */
-struct Scalars {
-  // Order keys of the running max log-weight, sharded over CSSM_MAXSLOTS cache lines, in two sets:
-  // weighted step s uses set s&1, and its last kernel clears the other set for step s+1.
-  unsigned long long maxslot[2 * CSSM_MAXSLOTS * CSSM_SLOT_STRIDE];
-  uint32_t err;              // bit0: NaN log-weight, bit1: all weights zero / max not finite,
-                             // bit2: the reference level was unusable and the sums must be formed again (host retries)
-                             // bit3: (sharded) the exchange capacity did not cover some rank's slots at step fail_step
-  int32_t ess;
-  uint32_t fail_step;        // first observation whose exchange did not fit (0xffffffff: none); see k_offspring_expand_spec
-  uint32_t pad_;
-  double gmax;               // decoded global max of this step
-  double ref;                // level the weights of this step were rescaled by (cssm_ref_choose)
-  double ll;                 // accumulated log-likelihood
-  cssm_u128 S_local, S2_local; // local fixed-point sums (this rank)
-  cssm_u128 S_off;           // sum of the ranks before this one
-  cssm_u128 S_tot, S2_tot;   // global sums
-};
-
-// ------------------------------------------------------------------------------------ helpers
-
-// Cross-lane traffic goes through DPP (data-parallel primitives: a VALU move whose source lane is a fixed
-// pattern), not through ds_bpermute (__shfl*): measured on MI355X (tools/instr_rate.hip) a DPP move issues in ~5
-// cycles per wave, a ds_bpermute_b32 in ~25, and a 128-bit scan needs 24 of either.
-//   row_shr:n   lane i of each row of 16 reads lane i-n of its row (lanes without a source keep `old` = 0)
-//   row_bcast15 lane 15 of every row -> all lanes of the NEXT row (row_mask 0xa: rows 1 and 3 take it)
-//   row_bcast31 lane 31 -> all lanes of rows 2 and 3 (row_mask 0xc)
-// After the six steps lane i holds the inclusive prefix over lanes 0..i, lane 63 the wave total.
-#define CSSM_DPP_ROW_SHR(n) (0x110 + (n))
-#define CSSM_DPP_BCAST15 0x142
-#define CSSM_DPP_BCAST31 0x143
-template <int CTRL, int ROW_MASK>
-__device__ __forceinline__ uint32_t dpp0(uint32_t v) {   // lanes that receive nothing read 0
-  return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROW_MASK, 0xf, false);
-}
-template <int CTRL, int ROW_MASK>
-__device__ __forceinline__ uint64_t dpp0_u64(uint64_t v) {
-  return (uint64_t)dpp0<CTRL, ROW_MASK>((uint32_t)v) | ((uint64_t)dpp0<CTRL, ROW_MASK>((uint32_t)(v >> 32)) << 32);
-}
-template <int CTRL, int ROW_MASK>
-__device__ __forceinline__ cssm_u128 dpp0_u128(cssm_u128 v) {
-  cssm_u128 r;
-  r.lo = dpp0_u64<CTRL, ROW_MASK>(v.lo);
-  r.hi = dpp0_u64<CTRL, ROW_MASK>(v.hi);
-  return r;
-}
-__device__ __forceinline__ uint64_t readlane_u64(uint64_t v, int lane) {
-  return (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, lane) |
-         ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), lane) << 32);
-}
-
-// inclusive scan across the 64 lanes (integer adds: any order gives the same bits)
-__device__ __forceinline__ cssm_u128 wave_scan_u128(cssm_u128 v, int lane) {
-  (void)lane;
-  v = cssm_u128_add(v, dpp0_u128<CSSM_DPP_ROW_SHR(1), 0xf>(v));
-  v = cssm_u128_add(v, dpp0_u128<CSSM_DPP_ROW_SHR(2), 0xf>(v));
-  v = cssm_u128_add(v, dpp0_u128<CSSM_DPP_ROW_SHR(4), 0xf>(v));
-  v = cssm_u128_add(v, dpp0_u128<CSSM_DPP_ROW_SHR(8), 0xf>(v));
-  v = cssm_u128_add(v, dpp0_u128<CSSM_DPP_BCAST15, 0xa>(v));
-  v = cssm_u128_add(v, dpp0_u128<CSSM_DPP_BCAST31, 0xc>(v));
-  return v;
-}
-// wave total, uniform (it is read from lane 63 into scalar registers)
-__device__ __forceinline__ cssm_u128 wave_sum_u128(cssm_u128 v) {
-  v = wave_scan_u128(v, 0);
-  cssm_u128 r;
-  r.lo = readlane_u64(v.lo, 63);
-  r.hi = readlane_u64(v.hi, 63);
-  return r;
-}
-__device__ __forceinline__ uint64_t wave_max_u64(uint64_t k) {   // uniform
-#define CSSM_MAX_STEP(CTRL, RM) { const uint64_t o = dpp0_u64<CTRL, RM>(k); k = (o > k) ? o : k; }
-  CSSM_MAX_STEP(CSSM_DPP_ROW_SHR(1), 0xf) CSSM_MAX_STEP(CSSM_DPP_ROW_SHR(2), 0xf) CSSM_MAX_STEP(CSSM_DPP_ROW_SHR(4), 0xf)
-  CSSM_MAX_STEP(CSSM_DPP_ROW_SHR(8), 0xf) CSSM_MAX_STEP(CSSM_DPP_BCAST15, 0xa) CSSM_MAX_STEP(CSSM_DPP_BCAST31, 0xc)
-#undef CSSM_MAX_STEP
-  return readlane_u64(k, 63);
-}
-// max of doubles through their order-preserving keys (a missing DPP source reads key 0, below every real key)
-__device__ __forceinline__ double wave_max(double v) { return cssm_order_unkey(wave_max_u64(cssm_order_key(v))); }
-
-// The contract's log table (include/cssm_numerics.h, CSSM_LOG_TAB) staged in LDS by every kernel that
-// draws normals: `tab_global` is the handle's device copy.  All threads of the block must call it.
-__device__ __forceinline__ const double* stage_log_table(const double* __restrict__ tab_global) {
-  __shared__ double s_logtab[256];
-  for (int i = threadIdx.x; i < 256; i += blockDim.x) s_logtab[i] = tab_global[i];
-  __syncthreads();
-  return s_logtab;
-}
-
-// The d standard normals of global particle gid for an ordinary step or the initial draw (include/cssm_numerics.h,
-// counter layout): particles 2m and 2m+1 share stream m, particle gid owns its normals q = (gid & 1) * D + k, normal q
-// = element q&1 of block q>>1.  A particle touches ceil(D/2) blocks starting at b0; for odd D an odd particle starts
-// on the SECOND element of its first block.  Branch-free in gid, so neighbouring lanes do not diverge.
-template <int D>
-__device__ __forceinline__ void draw_normals(uint64_t seed, uint64_t gid, uint32_t step, uint32_t tag,
-                                             const double* tab, double (&z)[D]) {
-  constexpr int NB = (D + 1) / 2;
-  const bool odd = (gid & 1u) != 0u;
-  const uint32_t b0 = ((uint32_t)(gid & 1u) * (uint32_t)D) >> 1;
-  const uint64_t stream = cssm_pair_stream(gid);
-  double pe1 = 0.0;
-#pragma unroll
-  for (int p = 0; p < NB; ++p) {
-    double e0, e1;
-    cssm_normal_pair(cssm_philox_draw(seed, stream, step, tag, b0 + (uint32_t)p), tab, &e0, &e1);
-    if (D % 2 == 0) {
-      z[2 * p] = e0; z[(2 * p + 1) % D] = e1;
-    } else {   // even particle: element j of its blocks is component j; odd particle: component j - 1
-      if (p > 0) z[(2 * p - 1 + D) % D] = odd ? e0 : pe1;
-      z[2 * p] = odd ? e1 : e0;
-      pe1 = e1;
-    }
-  }
-}
-
-// One transition of component k (model/Sde.scala:86-95,114-123,139-150; :30-43 for Euler); components are independent.
-template <int D>
-__device__ __forceinline__ void transition_one(const ModelK& mk, const StepRec* __restrict__ rec, double dt, int k, double& xk, double zk) {
-  const double p0 = rec->coef[k][0], p1 = rec->coef[k][1], p2 = rec->coef[k][2], p3 = rec->coef[k][3];
-  const int kind = mk.kind(k);
-  if (kind == CSSM_SDE_BROWNIAN) {
-    xk = p3 * zk + xk;
-  } else if (kind == CSSM_SDE_GEN_BROWNIAN) {
-    double mean = xk + p0;
-    xk = p3 * zk + mean;
-  } else if (kind == CSSM_SDE_OU) {
-    double mean = p0 + (xk - p0) * p1;
-    xk = p3 * zk + mean;
-  } else {
-    double dW = p3 * zk;
-    double a = (p0 + p1 * xk) * dt;
-    double b = p2 * dW;
-    xk = (xk + a) + b;
-  }
-}
-template <int D>
-__device__ __forceinline__ void transition(const ModelK& mk, const StepRec* __restrict__ rec, double dt,
-                                           double (&x)[D], const double (&z)[D]) {
-#pragma unroll
-  for (int k = 0; k < D; ++k) transition_one<D>(mk, rec, dt, k, x[k], z[k]);
-}
-
-// Ordinary step of the two particles of a pair (2m, 2m+1): D Philox blocks + Box-Muller pairs give their 2 D normals,
-// each fed to its component as soon as it exists (normal q -> particle q / D, component q % D).
-template <int D>
-__device__ __forceinline__ void propagate_pair(const ModelK& mk, const StepRec* __restrict__ rec, double dt, uint64_t seed,
-                                               uint64_t gid_even, uint32_t step, const double* tab, double (&xa)[D], double (&xb)[D]) {
-  const uint64_t stream = cssm_pair_stream(gid_even);
-#pragma unroll
-  for (int p = 0; p < D; ++p) {
-    double e0, e1;
-    cssm_normal_pair(cssm_philox_draw(seed, stream, step, CSSM_STREAM_STEP, (uint32_t)p), tab, &e0, &e1);
-    if (2 * p < D) transition_one<D>(mk, rec, dt, 2 * p, xa[(2 * p) % D], e0);
-    else transition_one<D>(mk, rec, dt, 2 * p - D, xb[(2 * p - D + D) % D], e0);
-    if (2 * p + 1 < D) transition_one<D>(mk, rec, dt, 2 * p + 1, xa[(2 * p + 1) % D], e1);
-    else transition_one<D>(mk, rec, dt, 2 * p + 1 - D, xb[(2 * p + 1 - D + D) % D], e1);
-  }
-}
-// The same for ONE particle of either parity (threads that do not own whole pairs): ceil(D/2) blocks.
-template <int D>
-__device__ __forceinline__ void propagate_one(const ModelK& mk, const StepRec* __restrict__ rec, double dt, uint64_t seed,
-                                              uint64_t gid, uint32_t step, const double* tab, double (&x)[D]) {
-  constexpr int NB = (D + 1) / 2;
-  const bool odd = (gid & 1u) != 0u;
-  const uint32_t b0 = ((uint32_t)(gid & 1u) * (uint32_t)D) >> 1;
-  const uint64_t stream = cssm_pair_stream(gid);
-  double pe1 = 0.0;
-#pragma unroll
-  for (int p = 0; p < NB; ++p) {
-    double e0, e1;
-    cssm_normal_pair(cssm_philox_draw(seed, stream, step, CSSM_STREAM_STEP, b0 + (uint32_t)p), tab, &e0, &e1);
-    if (D % 2 == 0) {
-      transition_one<D>(mk, rec, dt, 2 * p, x[2 * p], e0);
-      transition_one<D>(mk, rec, dt, (2 * p + 1) % D, x[(2 * p + 1) % D], e1);
-    } else {
-      if (p > 0) transition_one<D>(mk, rec, dt, (2 * p - 1 + D) % D, x[(2 * p - 1 + D) % D], odd ? e0 : pe1);
-      transition_one<D>(mk, rec, dt, 2 * p, x[2 * p], odd ? e1 : e0);
-      pe1 = e1;
-    }
-  }
-}
-
-// gamma = f(x, t): per-leaf dot product, leaves summed left-nested (model/Model.scala:122-128,217-225,271)
-template <int D>
-__device__ __forceinline__ double gamma_of(const ModelK& mk, const StepRec* __restrict__ rec, const double (&x)[D]) {
-  double g = 0.0, acc = 0.0;
-#pragma unroll
-  for (int k = 0; k < D; ++k) {
-    const int fm = mk.fmode(k);
-    if (fm == FM_START) acc = rec->fco[k] * x[k];
-    else if (fm == FM_ADD) acc = acc + rec->fco[k] * x[k];
-    if (mk.leaf_end(k)) g = mk.first_leaf(k) ? acc : g + acc;
-  }
-  return g;
-}
-
-// dataLikelihood(gamma, y) of the leftmost leaf; the branch is wave-uniform (mk is a kernel argument).
-// Constants c[] per observation kind are listed in build_rec (cssm_pf.hip); the oracle states the same
-// expressions with the reference's line numbers (oracle/cssm_oracle.c, logdens).
-// OBS >= 0: the observation kind is a compile-time constant (the common Poisson / Gaussian kernels carry only
-// their own density: the generic body is ~2.5x larger and spills out of the instruction cache); OBS < 0: runtime.
-template <int OBS>
-__device__ __forceinline__ double logdens(const ModelK& mk, const StepRec* __restrict__ rec, double g, const double* tab) {
-  const double y = rec->y;
-  switch (OBS >= 0 ? OBS : mk.obs_kind) {
-    case CSSM_OBS_POISSON:   // -lambda + k log(lambda) - lgamma(k+1), model/Model.scala:273
-      return -cssm_exp(g) + y * g - rec->c[0];
-    case CSSM_OBS_GAUSSIAN: {  // breeze Gaussian.logPdf, model/Model.scala:252-258
-      const double dd = (y - g) / rec->c[1];
-      return -(dd * dd) / 2.0 - rec->c[0];
-    }
-    case CSSM_OBS_NEGBIN: {    // model/Model.scala:186-195
-      const double size = rec->c[1], mu = cssm_exp(g);
-      return rec->c[0] + size * cssm_log(size / (mu + size)) + y * cssm_log(mu / (mu + size));
-    }
-    case CSSM_OBS_ZIP: {       // model/Model.scala:298-307
-      if (y == 0.0) return cssm_log(rec->c[0] + (1.0 - rec->c[0]) * cssm_exp(-cssm_exp(g)));
-      return ((rec->c[1] + y * g) - cssm_exp(g)) - rec->c[2];
-    }
-    case CSSM_OBS_BERNOULLI: { // model/Model.scala:318-336
-      const double link = (g > 6.0) ? 1.0 : ((g < -6.0) ? 0.0 : 1.0 / (1.0 + cssm_exp(-g)));
-      if (y == 1.0) return (link == 0.0) ? -1e99 : cssm_log(link);
-      return (link == 1.0) ? -1e99 : cssm_log(1.0 - link);
-    }
-    case CSSM_OBS_STUDENT_T: { // 1/v * StudentsT(df).logPdf((y - eta)/v), model/Model.scala:155-160
-      const double x = (y - g) / rec->c[1];
-      return rec->c[3] * (rec->c[0] - rec->c[2] * cssm_log(1.0 + (x * x) / rec->cdf));
-    }
-    default: {                 // Beta(exp(-gamma), 1).logPdf(y) = (a - 1) log y + log a, model/Model.scala:349-352
-      return (cssm_exp(-g) - 1.0) * rec->c[0] - g;
-    }
-  }
-}
+#include "cssm_device.hip.h"
 
 // ------------------------------------------------------------------------------------ init
 
@@ -322,417 +23,6 @@ __global__ __launch_bounds__(CSSM_BLOCK) void k_init(double* __restrict__ dst, s
 __global__ void k_init_from(double* __restrict__ dst, size_t stride, uint64_t n, int d, const double* __restrict__ s) {
   for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x)
     for (int k = 0; k < d; ++k) dst[(size_t)k * stride + i] = s[k];
-}
-
-// ------------------------------------------------------------------------------------ propagate + weight
-
-// Block-cooperative decode of the sharded running max: lane t of wave 0 reads slot t (one load
-// latency instead of 64), wave max, broadcast through LDS.  All threads of the block must call it.
-__device__ __forceinline__ double block_decode_slots(const Scalars* __restrict__ sc, int set) {
-  __shared__ unsigned long long s_key;
-  if (threadIdx.x < 64) {
-    unsigned long long k = (threadIdx.x < CSSM_MAXSLOTS)
-        ? sc->maxslot[((size_t)set * CSSM_MAXSLOTS + threadIdx.x) * CSSM_SLOT_STRIDE] : 0ull;
-    k = wave_max_u64(k);
-    if (threadIdx.x == 0) s_key = k;
-  }
-  __syncthreads();
-  return cssm_order_unkey(s_key);
-}
-
-// Asynchronous 16-byte-per-lane copy global -> LDS (gfx950: global_load_lds_dwordx4): lane l fetches the 16 bytes at
-// its own address g into LDS bytes [lds_base + 16 l, +16); lds_base is wave-uniform and travels in M0.  Issued through
-// inline assembly ON PURPOSE: for the builtin form the compiler, unable to prove that later LDS reads (the log table)
-// do not touch the destination, inserts s_waitcnt vmcnt(0) before the first LDS read that follows, i.e. it waits for
-// the very prefetch that is meant to overlap the computation.  An operation the compiler does not count only makes its
-// own counted waits more conservative (VMEM operations retire in order), never wrong; completion is awaited explicitly
-// (s_waitcnt vmcnt(0)) before the wave reads the region back.  M0 has no other use in these kernels.
-__device__ __forceinline__ void lds_dma16(const double* g, uint32_t lds_base) {
-  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(g), "s"(lds_base) : "memory");
-}
-// The same with 4 bytes per lane (lane l -> LDS bytes [lds_base + 4 l, +4)): a double travels as two of these, low and
-// high word into two 256-byte regions, where LDS is too small for 16 bytes per element.
-__device__ __forceinline__ void lds_dma4(const void* g, uint32_t lds_base) {
-  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %0, off" : : "v"(g), "s"(lds_base) : "memory");
-}
-
-// How k_propagate's two-particles-per-thread instantiations (d = 3 .. 8) store their bulk outputs (state rows,
-// log-weights), one 16-byte store per lane and row, contiguous across the wave.  0: plain stores (dirty lines stay in
-// the L2 and are written back when the kernel ends); 1: non-temporal; 2: write-through at agent scope (sc1); 3: sc0 sc1.
-// Measured per step at N = 2^20 / 2^24 (d = 3, separate sums): 40.7 / 368 us plain, 39.8 / 374 nt, 37.9 / 366 sc1,
-// 37.9 / 366 sc0 sc1 -- the write-back of a launch's last dirty lines is on its critical path, a write-through store is
-// not (tools/sc1_stream_bench.hip shows the same on a bare stream).  Only where a wave's store instruction fills whole
-// lines: the four-particles-per-thread layout (d <= 2: two 16-byte stores per lane, 32 bytes apart) loses the L2's
-// write combining with sc1 (k_propagate<1> 129 -> 190 us at N = 2^24), so do the 4-byte run writes of k_offspring
-// (106 -> 165 us); one particle per thread (d >= 9, 8-byte stores) is neutral (191.6 vs 192.1 us).  Those stay plain.
-#ifndef CSSM_ST_MODE
-#define CSSM_ST_MODE 2
-#endif
-typedef double cssm_dbl2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ void bulk_store2(double* p, double a, double b) {
-#if CSSM_ST_MODE == 1
-  cssm_dbl2 v; v.x = a; v.y = b;
-  __builtin_nontemporal_store(v, reinterpret_cast<cssm_dbl2*>(p));
-#elif CSSM_ST_MODE == 2
-  cssm_dbl2 v; v.x = a; v.y = b;
-  asm volatile("global_store_dwordx4 %0, %1, off sc1" : : "v"(p), "v"(v) : "memory");
-#elif CSSM_ST_MODE == 3
-  cssm_dbl2 v; v.x = a; v.y = b;
-  asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" : : "v"(p), "v"(v) : "memory");
-#else
-  *reinterpret_cast<double2*>(p) = make_double2(a, b);
-#endif
-}
-
-// Particles per thread in k_propagate: all gathers of a thread are issued before its ALU work,
-// and rows are stored as 16-/32-byte vectors.
-#ifndef CSSM_PROP_IT_MID
-#define CSSM_PROP_IT_MID 2
-#endif
-template <int D> struct PropItems { static constexpr int value = (D <= 2) ? 4 : (D <= 8 ? CSSM_PROP_IT_MID : 1); };
-
-// max over the CSSM_MAXSLOTS shards of the running max log-weight
-__device__ __forceinline__ double decode_slots(const Scalars* __restrict__ sc, int set) {
-  unsigned long long k = 0ull;
-  const unsigned long long* base = sc->maxslot + (size_t)set * CSSM_MAXSLOTS * CSSM_SLOT_STRIDE;
-#pragma unroll 8
-  for (int s = 0; s < CSSM_MAXSLOTS; ++s) {
-    const unsigned long long v = base[s * CSSM_SLOT_STRIDE];
-    k = (v > k) ? v : k;
-  }
-  return cssm_order_unkey(k);
-}
-
-// stepFilter lines :118 and :123-124 fused (LGCP: calcWeight :184-208).  src is read through
-// anc[] when anc != nullptr (the previous step's resampling).  A thread owns IT consecutive
-// particles; a block owns CSSM_BLOCK*IT consecutive particles per grid-stride iteration.
-// min waves per SIMD asked of the register allocator: 4 for small d (the kernel is VALU-bound and needs
-// the co-resident waves to cover LDS/table and gather latency), 3 beyond
-#ifndef CSSM_PROP_WAVES_LO
-#define CSSM_PROP_WAVES_LO 4
-#endif
-#ifndef CSSM_PROP_WAVES_SUMS
-#define CSSM_PROP_WAVES_SUMS 4
-#endif
-// (the kernels that also form the sums need ~10 more VGPRs; at 4 waves they spill 12 bytes, and a scratch reload in the
-// compute phase waits for the prefetch like any other vector-memory operation -- measured all the same: 4 waves with
-// that spill 41.2 us/step at N = 2^20 and 375 us at 2^24, 3 waves without it 41.9 and 383)
-template <int D, bool SUMS = false> struct PropWaves { static constexpr int value = (D <= 4) ? (SUMS ? CSSM_PROP_WAVES_SUMS : CSSM_PROP_WAVES_LO) : 3; };
-
-//
-// A block owns the CONTIGUOUS range [blockIdx.x * chunk, +chunk) (chunk a multiple of CSSM_BLOCK*IT, chosen on the
-// host so that a whole number of blocks makes one scan unit of k_offspring).  With do_sums the block also forms
-// S = sum exp(w - c), S2 = sum exp(w - c)^2 in fixed point for its range, c = rec->ref being known before any
-// weight is (include/cssm_numerics.h, "reference level"): the log-sum-exp of :125-127 then needs no pass of its own.
-template <int D, bool LGCP, int IT, int OBS, bool SUMS>
-__global__ __launch_bounds__(CSSM_BLOCK, (PropWaves<D, SUMS>::value)) void k_propagate(
-    const double* __restrict__ src, size_t src_stride, const uint32_t* __restrict__ anc,
-    double* __restrict__ dst, size_t dst_stride, double* __restrict__ logw, uint64_t n_arg, uint64_t gid0,
-    uint64_t seed, const StepRec* __restrict__ rec, ModelK mk, Scalars* __restrict__ sc, int slot_set,
-    const double* __restrict__ src2, size_t src2_stride, uint32_t n_split, const double* __restrict__ logtab,
-    uint64_t chunk, int do_sums_arg, cssm_u128* __restrict__ subS, cssm_u128* __restrict__ subS2,
-    double* __restrict__ pick_out, uint32_t pick_slot) {
-  // SUMS && pick_out != nullptr (`filter`, model/ParticleFilter.scala:157): the thread that gathers slot pick_slot holds the
-  // resampled state sampleOne chose after the PREVIOUS observation, before its transition: it records it (a launch of
-  // its own per observation would cost more than the whole sums pass at small N)
-  // (Totalling the sub-unit sums in the block that finishes last -- the threadfence-reduction idiom -- was measured
-  // and rejected: on this multi-XCD part every block's device-scope release fence writes the L2's dirty lines back,
-  // which in a kernel that streams hundreds of MB of stores cost 130 us at N = 2^24.  k_scan_tiles does it instead.)
-  // src2 != nullptr (sharded filter): ancestor indices >= n_split address the candidates received from
-  // other ranks, src2[k * src2_stride + (j - n_split)]
-  __shared__ double s_max[CSSM_BLOCK / 64];
-  // (sharded series) the exchange of an earlier observation did not fit: the series is on hold and nothing may change
-  // until the host resumes it (cssm_pf_shard_resume)
-  if (sc->err & 8u) return;   // (bit 3 is only ever raised by the sharded exchange)
-  const uint32_t step = rec->step;
-  const int has_obs = rec->has_obs;
-  const double dt = rec->dt;
-  const bool weighted = LGCP || has_obs;
-  // every thread's first particle has an even global id (gid0 even; chunk, tile and IT even): whole pairs per thread
-  const bool pair_ok = (gid0 & 1ull) == 0ull;
-  // SUMS (compile time: its accumulators would otherwise hold 8 VGPRs in every kernel): the block also forms the sums
-  const bool do_sums = SUMS && !LGCP && do_sums_arg && has_obs;
-  const double cref = rec->ref;
-  cssm_u128 accS = cssm_u128_zero(), accS2 = cssm_u128_zero();
-  double tmax = -cssm_inf();
-  bool bad = false;
-  // tile indices are 32-bit (the library admits n <= 2^32 - 2^16 particles per handle): half the VALU work of 64-bit
-  constexpr uint32_t stride = (uint32_t)CSSM_BLOCK * IT;      // particles per tile
-  const uint32_t range_lo = blockIdx.x * (uint32_t)chunk;
-  uint32_t n;                                                 // this block's range ends at n
-  { const uint64_t range_hi = (uint64_t)range_lo + chunk; n = (uint32_t)((range_hi < n_arg) ? range_hi : n_arg); }
-  // Software pipeline over the block's tiles WITHOUT spending registers on it.  With 4 waves per SIMD the two
-  // dependent memory round trips of a tile (ancestor index -> gathered state) are exposed: a model with that
-  // latency reproduces the 3.3 TB/s the un-pipelined kernel reached for every d, and holding the next tile in VGPRs
-  // costs a wave of occupancy (measured: slower).  Instead the NEXT tile's states are fetched by asynchronous
-  // global -> LDS loads (global_load_lds_dwordx4, a gfx950 instruction: each lane fetches the 16 bytes at its own
-  // address into slot lane * 16 of a 1 KiB LDS region, no VGPR is written) while the current tile is computed, and the
-  // ancestor indices of the tile after that are fetched into the IT index registers.  A wave reads back only what it
-  // loaded itself, so no block barrier is involved.  Per wave: IT * D regions of 1 KiB.
-  // Bytes per lane and element: 16 (one dwordx4 fetch, of which the first 8 bytes are the element) while 4 blocks of
-  // that fit the CU's 160 KiB of LDS, else 8 (two dword fetches: low and high word).
-  constexpr bool STAGE = true;
-  constexpr int ES = (IT * D <= 9) ? 16 : 8;
-  constexpr int WAVE_STAGE = IT * D * 64 * ES;
-  __shared__ __attribute__((aligned(16))) unsigned char s_stage[(CSSM_BLOCK / 64) * WAVE_STAGE];
-  unsigned char* const wstage = s_stage + (size_t)(threadIdx.x >> 6) * WAVE_STAGE;
-  const uint32_t wstage_lds = __builtin_amdgcn_readfirstlane((uint32_t)(size_t)(__attribute__((address_space(3))) void*)wstage);
-  const uint32_t n_last = n - 1u;
-  // indices of this thread's IT particles of the tile at `base`, clamped into range (stores are predicated)
-  // One vector load for every thread (anc has `stride` >= n entries rounded up to a tile, so the load of a partial or
-  // empty thread stays inside the buffer).  The indices stay PACKED two to a 64-bit register exactly as they were
-  // loaded, and nothing touches them until they are consumed: any operation on them next to the load -- even the
-  // register copy that unpacking a vector load can need -- makes the compiler wait for the load right there.
-  constexpr int NJ = (IT + 1) / 2;
-  auto load_idx = [&](uint32_t base, unsigned long long (&jp)[NJ]) {
-    const uint32_t i0 = base + threadIdx.x * IT;
-    if (anc) {
-      if (IT == 4) {
-        const ulonglong2 a = *reinterpret_cast<const ulonglong2*>(anc + i0);
-        jp[0] = a.x; jp[NJ - 1] = a.y;
-      } else if (IT == 2) {
-        jp[0] = *reinterpret_cast<const unsigned long long*>(anc + i0);
-      } else {
-        jp[0] = anc[i0];
-      }
-    } else {
-#pragma unroll
-      for (int q = 0; q < NJ; ++q) jp[q] = (unsigned long long)(uint32_t)(i0 + 2 * q) | ((unsigned long long)(uint32_t)(i0 + 2 * q + 1) << 32);
-    }
-  };
-  // unpacked where they are consumed; what a partial thread read beyond n is replaced by a valid index
-  auto unpack_idx = [&](uint32_t base, const unsigned long long (&jp)[NJ], uint32_t (&j)[IT]) {
-    const uint32_t i0 = base + threadIdx.x * IT;
-#pragma unroll
-    for (int r = 0; r < IT; ++r) {
-      const uint32_t v = (uint32_t)(jp[r / 2] >> (32 * (r & 1)));
-      j[r] = (i0 + r < n) ? v : n_last;
-    }
-  };
-  // src2_stride == 0: the candidates are rows of (D + 1) doubles (state, end slot) exactly as they were received
-  // (fixed-capacity exchange: the receive buffer is read in place); otherwise struct-of-arrays with that stride
-  auto ptr_of = [&](uint32_t j, int k) -> const double* {
-    if (src2 && j >= n_split)
-      return (src2_stride == 0) ? src2 + (size_t)(j - n_split) * (size_t)(D + 1) + k : src2 + (size_t)k * src2_stride + (j - n_split);
-    return src + (size_t)k * src_stride + j;
-  };
-  auto gather = [&](const uint32_t (&j)[IT], double (&x)[IT][D]) {
-#pragma unroll
-    for (int r = 0; r < IT; ++r)
-#pragma unroll
-      for (int k = 0; k < D; ++k) x[r][k] = *ptr_of(j[r], k);
-  };
-  // (every gather source is allocated with 16 spare bytes: the 16-byte fetch of the last element of a buffer stays inside it)
-  auto stage_issue = [&](const uint32_t (&j)[IT]) {
-#pragma unroll
-    for (int r = 0; r < IT; ++r)
-#pragma unroll
-      for (int k = 0; k < D; ++k) {
-        // (src2 == nullptr is uniform: without candidates from other ranks the row base stays in scalar registers)
-        const double* g = (src2 == nullptr) ? src + (size_t)k * src_stride + j[r] : ptr_of(j[r], k);
-        const uint32_t slot = wstage_lds + (uint32_t)((r * D + k) * 64 * ES);
-        if (ES == 16) {
-          lds_dma16(g, slot);
-        } else {
-          lds_dma4(g, slot);
-          lds_dma4(reinterpret_cast<const unsigned char*>(g) + 4, slot + 256u);
-        }
-      }
-  };
-  auto stage_read = [&](double (&x)[IT][D]) {
-    const uint32_t lane = threadIdx.x & 63;
-#pragma unroll
-    for (int r = 0; r < IT; ++r)
-#pragma unroll
-      for (int k = 0; k < D; ++k) {
-        const unsigned char* slot = wstage + (r * D + k) * 64 * ES;
-        if (ES == 16) {
-          x[r][k] = *reinterpret_cast<const double*>(slot + lane * 16);
-        } else {
-          const uint32_t lo = *reinterpret_cast<const uint32_t*>(slot + lane * 4);
-          const uint32_t hi = *reinterpret_cast<const uint32_t*>(slot + 256 + lane * 4);
-          x[r][k] = cssm_u2d((uint64_t)lo | ((uint64_t)hi << 32));
-        }
-      }
-  };
-  uint32_t base = range_lo;
-  unsigned long long jp[NJ];
-  uint32_t jn[IT];
-  double x[IT][D];
-  const double* tab = stage_log_table(logtab);   // (issuing the first index load before this was measured: no change)
-  if (base < n) {
-    load_idx(base, jp);
-    unpack_idx(base, jp, jn);
-    if (STAGE) {
-      stage_issue(jn);                                            // tile 0 (needs its indices: the one exposed latency)
-      if (base + stride < n) load_idx(base + stride, jp);         // indices of tile 1
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      stage_read(x);
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // the region is free again
-      if (base + stride < n) {
-        unpack_idx(base + stride, jp, jn);
-        stage_issue(jn);                                          // tile 1 lands while tile 0 is computed
-        if (base + 2 * stride < n) load_idx(base + 2 * stride, jp);
-      }
-    } else {
-      gather(jn, x);
-    }
-  }
-  for (; base < n; base += stride) {
-    const uint32_t i0 = base + threadIdx.x * IT;
-    const bool full = (i0 + IT <= n);
-    if (SUMS && pick_out != nullptr) {   // (only the SUMS kernels carry this: it costs the lean kernel 2 % for nothing)
-#pragma unroll
-      for (int r = 0; r < IT; ++r)
-        if (i0 + r == pick_slot) {
-#pragma unroll
-          for (int k = 0; k < D; ++k) pick_out[k] = x[r][k];
-        }
-    }
-    double lw[IT];
-    // weight of particle r once its state is propagated: NaN check, running max, optional fused sums
-    auto account = [&](int r) {
-      if (weighted && i0 + r < n) {
-        if (lw[r] != lw[r]) { bad = true; lw[r] = -cssm_inf(); }
-        tmax = (lw[r] > tmax) ? lw[r] : tmax;
-        if (SUMS && !LGCP && do_sums) {
-          // beyond c + CSSM_REF_BELOW the step is redone with the max anyway: keep the conversion in range
-          const double a = cssm_min_c(lw[r] - cref, CSSM_REF_BELOW);
-          const double w1 = cssm_exp(a);
-          accS = cssm_u128_add(accS, cssm_fix_from_double(w1));
-          accS2 = cssm_u128_add(accS2, cssm_fix_from_double(w1 * w1));
-        }
-      }
-    };
-    if (LGCP) {
-#pragma unroll
-      for (int r = 0; r < IT; ++r) {
-        double z[D];
-        const uint64_t gid = gid0 + i0 + r;
-        const int nsub = rec->n_sub;
-        if (nsub == 0) {                     // dt == 0: (x, f, f), model/ParticleFilter.scala:212-213
-          double g = gamma_of<D>(mk, rec, x[r]);
-          lw[r] = g - g;
-        } else {
-          double haz = 0.0, carry = 0.0;
-          for (int s = 0; s < nsub; ++s) {   // simInitStream(...).take(n), :193-194
-            // normal number q = s*D + k: even q opens Box-Muller pair q>>1 (second element kept for q+1)
-#pragma unroll
-            for (int k = 0; k < D; ++k) {
-              const uint32_t q = (uint32_t)s * D + k;
-              if ((q & 1u) == 0u) {
-                double z0, z1;
-                cssm_normal_pair(cssm_philox_draw(seed, gid, step, CSSM_STREAM_STEP, q >> 1), tab, &z0, &z1);
-                z[k] = z0; carry = z1;
-              } else {
-                z[k] = carry;
-              }
-            }
-            transition<D>(mk, rec, dt, x[r], z);
-            haz = haz + cssm_exp(gamma_of<D>(mk, rec, x[r])) * dt;   // :203-205
-          }
-          lw[r] = gamma_of<D>(mk, rec, x[r]) - haz;                // :200,:217
-        }
-        account(r);
-      }
-    } else if (IT % 2 == 0 && pair_ok) {
-      // the thread's particles are whole pairs (2m, 2m+1): D Philox blocks + Box-Muller pairs per two particles
-#pragma unroll
-      for (int r = 0; r + 1 < IT; r += 2) {
-        propagate_pair<D>(mk, rec, dt, seed, gid0 + i0 + r, step, tab, x[r], x[(r + 1) % IT]);
-        lw[r] = has_obs ? logdens<OBS>(mk, rec, gamma_of<D>(mk, rec, x[r]), tab) : 0.0;
-        account(r);
-        lw[(r + 1) % IT] = has_obs ? logdens<OBS>(mk, rec, gamma_of<D>(mk, rec, x[(r + 1) % IT]), tab) : 0.0;
-        account((r + 1) % IT);
-      }
-    } else {
-#pragma unroll
-      for (int r = 0; r < IT; ++r) {
-        propagate_one<D>(mk, rec, dt, seed, gid0 + i0 + r, step, tab, x[r]);
-        lw[r] = has_obs ? logdens<OBS>(mk, rec, gamma_of<D>(mk, rec, x[r]), tab) : 0.0;
-        account(r);
-      }
-    }
-    // everything older is complete by now without having been waited for: the next tile's states (issued one tile of
-    // compute ago), the indices of the tile after it, and the previous tile's stores
-    if (STAGE) {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      // the index registers are complete as well: tell the compiler here, or it waits for them (and with them for the
-      // stores below) where the next tile's loads are issued
-#pragma unroll
-      for (int q = 0; q < NJ; ++q) asm volatile("" : "+v"(jp[q]));
-    }
-    if (full && IT == 4) {
-#pragma unroll
-      for (int k = 0; k < D; ++k) {
-        double* p = dst + (size_t)k * dst_stride + i0;
-        *reinterpret_cast<double2*>(p) = make_double2(x[0][k], x[1 % IT][k]);
-        *reinterpret_cast<double2*>(p + 2) = make_double2(x[2 % IT][k], x[3 % IT][k]);
-      }
-      if (weighted) {
-        *reinterpret_cast<double2*>(logw + i0) = make_double2(lw[0], lw[1 % IT]);
-        *reinterpret_cast<double2*>(logw + i0 + 2) = make_double2(lw[2 % IT], lw[3 % IT]);
-      }
-    } else if (full && IT == 2) {
-#pragma unroll
-      for (int k = 0; k < D; ++k)
-        bulk_store2(dst + (size_t)k * dst_stride + i0, x[0][k], x[1 % IT][k]);
-      if (weighted) bulk_store2(logw + i0, lw[0], lw[1 % IT]);
-    } else {
-#pragma unroll
-      for (int r = 0; r < IT; ++r) {
-        if (i0 + r < n) {
-#pragma unroll
-          for (int k = 0; k < D; ++k) dst[(size_t)k * dst_stride + i0 + r] = x[r][k];
-          if (weighted) logw[i0 + r] = lw[r];
-        }
-      }
-    }
-    // advance the pipeline
-    if (STAGE) {
-      if (base + stride < n) {
-        stage_read(x);                                            // tile i + 1
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        if (base + 2 * stride < n) {
-          unpack_idx(base + 2 * stride, jp, jn);
-          stage_issue(jn);                                        // tile i + 2
-          if (base + 3 * stride < n) load_idx(base + 3 * stride, jp);
-        }
-      }
-    } else if (base + stride < n) {
-      load_idx(base + stride, jp);
-      unpack_idx(base + stride, jp, jn);
-      gather(jn, x);
-    }
-  }
-  if (!weighted) return;
-  tmax = wave_max(tmax);
-  if ((threadIdx.x & 63) == 0) s_max[threadIdx.x >> 6] = tmax;
-  if (__any(bad) && (threadIdx.x & 63) == 0) atomicOr(&sc->err, 1u);
-  if (SUMS && !LGCP && do_sums) {
-    __shared__ cssm_u128 s_sa[CSSM_BLOCK / 64], s_sb[CSSM_BLOCK / 64];
-    accS = wave_sum_u128(accS);
-    accS2 = wave_sum_u128(accS2);
-    if ((threadIdx.x & 63) == 0) { s_sa[threadIdx.x >> 6] = accS; s_sb[threadIdx.x >> 6] = accS2; }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-      cssm_u128 ta = s_sa[0], tb = s_sb[0];
-#pragma unroll
-      for (int w = 1; w < CSSM_BLOCK / 64; ++w) { ta = cssm_u128_add(ta, s_sa[w]); tb = cssm_u128_add(tb, s_sb[w]); }
-      subS[blockIdx.x] = ta; subS2[blockIdx.x] = tb;
-    }
-  } else {
-    __syncthreads();
-  }
-  if (threadIdx.x == 0) {
-    double m = s_max[0];
-#pragma unroll
-    for (int w = 1; w < CSSM_BLOCK / 64; ++w) m = (s_max[w] > m) ? s_max[w] : m;
-    // one integer atomicMax per block, spread over CSSM_MAXSLOTS cache lines: same-address atomics
-    // serialise at ~12 ns each, which at thousands of blocks would cost more than the kernel
-    atomicMax(&sc->maxslot[((size_t)slot_set * CSSM_MAXSLOTS + blockIdx.x % CSSM_MAXSLOTS) * CSSM_SLOT_STRIDE],
-              (unsigned long long)cssm_order_key(m));
-  }
 }
 
 // ------------------------------------------------------------------------------------ tile sums

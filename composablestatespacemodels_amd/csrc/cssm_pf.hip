@@ -10,6 +10,7 @@
 #include <string>
 #include <vector>
 
+#include "cssm_host.h"
 #include "cssm_kernels.hip.h"
 
 // ------------------------------------------------------------------------------------ errors
@@ -497,21 +498,23 @@ static int launch_propagate(cssm_pf* pf, const StepRec* d_rec, double* pick_out 
   const int do_sums = uses_sums_kernel(pf) ? 1 : 0;
   pf->last_optimistic = do_sums != 0;
   prof_begin(pf, CSSM_K_PROPAGATE);
-#define PROP_ARGS pf->src, pf->src_stride, anc, dst, pf->stride, pf->logw, pf->n, pf->first, pf->seed, d_rec, pf->mk, pf->sc, \
-                  pf->sharded ? 0 : pf->wparity, anc ? pf->src2 : nullptr, pf->src2_stride, pf->n_split, pf->d_logtab, chunk, do_sums, \
-                  pf->tileS, pf->tileS2, pick_out, pick_slot
-#define PROP_LAUNCH(LG, OB, SM) DISPATCH_D(pf->d, k_propagate<D, LG, PropItems<D>::value, OB, SM><<<dim3(grid), dim3(CSSM_BLOCK), 0, pf->stream>>>(PROP_ARGS))
-  if (pf->obs_kind == CSSM_OBS_LGCP) {
-    PROP_LAUNCH(true, -1, false);
-  } else if (pf->obs_kind == CSSM_OBS_POISSON) {
-    if (do_sums) { PROP_LAUNCH(false, CSSM_OBS_POISSON, true); } else { PROP_LAUNCH(false, CSSM_OBS_POISSON, false); }
-  } else if (pf->obs_kind == CSSM_OBS_GAUSSIAN) {
-    if (do_sums) { PROP_LAUNCH(false, CSSM_OBS_GAUSSIAN, true); } else { PROP_LAUNCH(false, CSSM_OBS_GAUSSIAN, false); }
-  } else {
-    if (do_sums) { PROP_LAUNCH(false, -1, true); } else { PROP_LAUNCH(false, -1, false); }
+  PropLaunch a;
+  a.grid = grid; a.stream = pf->stream;
+  a.lgcp = pf->obs_kind == CSSM_OBS_LGCP;
+  a.obs = (pf->obs_kind == CSSM_OBS_POISSON || pf->obs_kind == CSSM_OBS_GAUSSIAN) ? pf->obs_kind : -1;
+  a.sums = do_sums;
+  a.src = pf->src; a.src_stride = pf->src_stride; a.anc = anc; a.dst = dst; a.dst_stride = pf->stride; a.logw = pf->logw;
+  a.n = pf->n; a.gid0 = pf->first; a.seed = pf->seed; a.rec = d_rec; a.mk = pf->mk; a.sc = pf->sc;
+  a.slot_set = pf->sharded ? 0 : pf->wparity;
+  a.src2 = anc ? pf->src2 : nullptr; a.src2_stride = pf->src2_stride; a.n_split = pf->n_split; a.logtab = pf->d_logtab;
+  a.chunk = chunk; a.do_sums = do_sums; a.subS = pf->tileS; a.subS2 = pf->tileS2; a.pick_out = pick_out; a.pick_slot = pick_slot;
+  switch (pf->d) {
+#define CSSM_CASE_PROP(D) case D: cssm_prop_launch_d##D(a); break;
+    CSSM_CASE_PROP(1) CSSM_CASE_PROP(2) CSSM_CASE_PROP(3) CSSM_CASE_PROP(4) CSSM_CASE_PROP(5) CSSM_CASE_PROP(6) CSSM_CASE_PROP(7) CSSM_CASE_PROP(8)
+    CSSM_CASE_PROP(9) CSSM_CASE_PROP(10) CSSM_CASE_PROP(11) CSSM_CASE_PROP(12) CSSM_CASE_PROP(13) CSSM_CASE_PROP(14) CSSM_CASE_PROP(15)
+    default: cssm_prop_launch_d16(a); break;
+#undef CSSM_CASE_PROP
   }
-#undef PROP_LAUNCH
-#undef PROP_ARGS
   prof_end(pf);
   HIP_TRY(hipGetLastError());
   pf->cur ^= 1;

@@ -1,0 +1,30 @@
+// cssm_prop.hip -- the k_propagate instantiations of ONE latent dimension (compile with -DCSSM_PROP_D=<d>); the
+// Makefile builds the 16 objects in parallel.
+#include "cssm_host.h"
+#include "cssm_propagate.hip.h"
+
+#ifndef CSSM_PROP_D
+#error "compile with -DCSSM_PROP_D=<latent dimension>"
+#endif
+
+#define CSSM_CAT2(a, b) a##b
+#define CSSM_CAT(a, b) CSSM_CAT2(a, b)
+
+void CSSM_CAT(cssm_prop_launch_d, CSSM_PROP_D)(const PropLaunch& a) {
+  constexpr int D = CSSM_PROP_D;
+  constexpr int IT = PropItems<D>::value;
+#define PROP_GO(LG, OB, SM)                                                                                               \
+  k_propagate<D, LG, IT, OB, SM><<<dim3(a.grid), dim3(CSSM_BLOCK), 0, a.stream>>>(                                        \
+      a.src, a.src_stride, a.anc, a.dst, a.dst_stride, a.logw, a.n, a.gid0, a.seed, a.rec, a.mk, a.sc, a.slot_set, a.src2, \
+      a.src2_stride, a.n_split, a.logtab, a.chunk, a.do_sums, a.subS, a.subS2, a.pick_out, a.pick_slot)
+  if (a.lgcp) {
+    PROP_GO(true, -1, false);
+  } else if (a.obs == CSSM_OBS_POISSON) {
+    if (a.sums) PROP_GO(false, CSSM_OBS_POISSON, true); else PROP_GO(false, CSSM_OBS_POISSON, false);
+  } else if (a.obs == CSSM_OBS_GAUSSIAN) {
+    if (a.sums) PROP_GO(false, CSSM_OBS_GAUSSIAN, true); else PROP_GO(false, CSSM_OBS_GAUSSIAN, false);
+  } else {
+    if (a.sums) PROP_GO(false, -1, true); else PROP_GO(false, -1, false);
+  }
+#undef PROP_GO
+}

@@ -1,0 +1,342 @@
+// cssm_propagate.hip.h -- k_propagate, the fused gather + propagate + weight kernel.  Included by
+// cssm_prop.hip, which is compiled once per latent dimension D (the 112 instantiations built in parallel).
+#pragma once
+
+#include "cssm_device.hip.h"
+
+// Particles per thread in k_propagate: all gathers of a thread are issued before its ALU work,
+// and rows are stored as 16-/32-byte vectors.
+template <int D> struct PropItems { static constexpr int value = (D <= 2) ? 4 : (D <= 8 ? CSSM_PROP_IT_MID : 1); };
+
+
+// stepFilter lines :118 and :123-124 fused (LGCP: calcWeight :184-208).  src is read through
+// anc[] when anc != nullptr (the previous step's resampling).  A thread owns IT consecutive
+// particles; a block owns CSSM_BLOCK*IT consecutive particles per grid-stride iteration.
+// min waves per SIMD asked of the register allocator: 4 for small d (the kernel is VALU-bound and needs
+// the co-resident waves to cover LDS/table and gather latency), 3 beyond
+#ifndef CSSM_PROP_WAVES_LO
+#define CSSM_PROP_WAVES_LO 4
+#endif
+#ifndef CSSM_PROP_WAVES_SUMS
+#define CSSM_PROP_WAVES_SUMS 4
+#endif
+// (the kernels that also form the sums need ~10 more VGPRs; at 4 waves they spill 12 bytes, and a scratch reload in the
+// compute phase waits for the prefetch like any other vector-memory operation -- measured all the same: 4 waves with
+// that spill 41.2 us/step at N = 2^20 and 375 us at 2^24, 3 waves without it 41.9 and 383)
+template <int D, bool SUMS = false> struct PropWaves { static constexpr int value = (D <= 4) ? (SUMS ? CSSM_PROP_WAVES_SUMS : CSSM_PROP_WAVES_LO) : 3; };
+
+//
+// A block owns the CONTIGUOUS range [blockIdx.x * chunk, +chunk) (chunk a multiple of CSSM_BLOCK*IT, chosen on the
+// host so that a whole number of blocks makes one scan unit of k_offspring).  With do_sums the block also forms
+// S = sum exp(w - c), S2 = sum exp(w - c)^2 in fixed point for its range, c = rec->ref being known before any
+// weight is (include/cssm_numerics.h, "reference level"): the log-sum-exp of :125-127 then needs no pass of its own.
+template <int D, bool LGCP, int IT, int OBS, bool SUMS>
+__global__ __launch_bounds__(CSSM_BLOCK, (PropWaves<D, SUMS>::value)) void k_propagate(
+    const double* __restrict__ src, size_t src_stride, const uint32_t* __restrict__ anc,
+    double* __restrict__ dst, size_t dst_stride, double* __restrict__ logw, uint64_t n_arg, uint64_t gid0,
+    uint64_t seed, const StepRec* __restrict__ rec, ModelK mk, Scalars* __restrict__ sc, int slot_set,
+    const double* __restrict__ src2, size_t src2_stride, uint32_t n_split, const double* __restrict__ logtab,
+    uint64_t chunk, int do_sums_arg, cssm_u128* __restrict__ subS, cssm_u128* __restrict__ subS2,
+    double* __restrict__ pick_out, uint32_t pick_slot) {
+  // SUMS && pick_out != nullptr (`filter`, model/ParticleFilter.scala:157): the thread that gathers slot pick_slot holds the
+  // resampled state sampleOne chose after the PREVIOUS observation, before its transition: it records it (a launch of
+  // its own per observation would cost more than the whole sums pass at small N)
+  // (Totalling the sub-unit sums in the block that finishes last -- the threadfence-reduction idiom -- was measured
+  // and rejected: on this multi-XCD part every block's device-scope release fence writes the L2's dirty lines back,
+  // which in a kernel that streams hundreds of MB of stores cost 130 us at N = 2^24.  k_scan_tiles does it instead.)
+  // src2 != nullptr (sharded filter): ancestor indices >= n_split address the candidates received from
+  // other ranks, src2[k * src2_stride + (j - n_split)]
+  __shared__ double s_max[CSSM_BLOCK / 64];
+  // (sharded series) the exchange of an earlier observation did not fit: the series is on hold and nothing may change
+  // until the host resumes it (cssm_pf_shard_resume)
+  if (sc->err & 8u) return;   // (bit 3 is only ever raised by the sharded exchange)
+  const uint32_t step = rec->step;
+  const int has_obs = rec->has_obs;
+  const double dt = rec->dt;
+  const bool weighted = LGCP || has_obs;
+  // every thread's first particle has an even global id (gid0 even; chunk, tile and IT even): whole pairs per thread
+  const bool pair_ok = (gid0 & 1ull) == 0ull;
+  // SUMS (compile time: its accumulators would otherwise hold 8 VGPRs in every kernel): the block also forms the sums
+  const bool do_sums = SUMS && !LGCP && do_sums_arg && has_obs;
+  const double cref = rec->ref;
+  cssm_u128 accS = cssm_u128_zero(), accS2 = cssm_u128_zero();
+  double tmax = -cssm_inf();
+  bool bad = false;
+  // tile indices are 32-bit (the library admits n <= 2^32 - 2^16 particles per handle): half the VALU work of 64-bit
+  constexpr uint32_t stride = (uint32_t)CSSM_BLOCK * IT;      // particles per tile
+  const uint32_t range_lo = blockIdx.x * (uint32_t)chunk;
+  uint32_t n;                                                 // this block's range ends at n
+  { const uint64_t range_hi = (uint64_t)range_lo + chunk; n = (uint32_t)((range_hi < n_arg) ? range_hi : n_arg); }
+  // Software pipeline over the block's tiles WITHOUT spending registers on it.  With 4 waves per SIMD the two
+  // dependent memory round trips of a tile (ancestor index -> gathered state) are exposed: a model with that
+  // latency reproduces the 3.3 TB/s the un-pipelined kernel reached for every d, and holding the next tile in VGPRs
+  // costs a wave of occupancy (measured: slower).  Instead the NEXT tile's states are fetched by asynchronous
+  // global -> LDS loads (global_load_lds_dwordx4, a gfx950 instruction: each lane fetches the 16 bytes at its own
+  // address into slot lane * 16 of a 1 KiB LDS region, no VGPR is written) while the current tile is computed, and the
+  // ancestor indices of the tile after that are fetched into the IT index registers.  A wave reads back only what it
+  // loaded itself, so no block barrier is involved.  Per wave: IT * D regions of 1 KiB.
+  // Bytes per lane and element: 16 (one dwordx4 fetch, of which the first 8 bytes are the element) while 4 blocks of
+  // that fit the CU's 160 KiB of LDS, else 8 (two dword fetches: low and high word).
+  constexpr bool STAGE = true;
+  constexpr int ES = (IT * D <= 9) ? 16 : 8;
+  constexpr int WAVE_STAGE = IT * D * 64 * ES;
+  __shared__ __attribute__((aligned(16))) unsigned char s_stage[(CSSM_BLOCK / 64) * WAVE_STAGE];
+  unsigned char* const wstage = s_stage + (size_t)(threadIdx.x >> 6) * WAVE_STAGE;
+  const uint32_t wstage_lds = __builtin_amdgcn_readfirstlane((uint32_t)(size_t)(__attribute__((address_space(3))) void*)wstage);
+  const uint32_t n_last = n - 1u;
+  // indices of this thread's IT particles of the tile at `base`, clamped into range (stores are predicated)
+  // One vector load for every thread (anc has `stride` >= n entries rounded up to a tile, so the load of a partial or
+  // empty thread stays inside the buffer).  The indices stay PACKED two to a 64-bit register exactly as they were
+  // loaded, and nothing touches them until they are consumed: any operation on them next to the load -- even the
+  // register copy that unpacking a vector load can need -- makes the compiler wait for the load right there.
+  constexpr int NJ = (IT + 1) / 2;
+  auto load_idx = [&](uint32_t base, unsigned long long (&jp)[NJ]) {
+    const uint32_t i0 = base + threadIdx.x * IT;
+    if (anc) {
+      if (IT == 4) {
+        const ulonglong2 a = *reinterpret_cast<const ulonglong2*>(anc + i0);
+        jp[0] = a.x; jp[NJ - 1] = a.y;
+      } else if (IT == 2) {
+        jp[0] = *reinterpret_cast<const unsigned long long*>(anc + i0);
+      } else {
+        jp[0] = anc[i0];
+      }
+    } else {
+#pragma unroll
+      for (int q = 0; q < NJ; ++q) jp[q] = (unsigned long long)(uint32_t)(i0 + 2 * q) | ((unsigned long long)(uint32_t)(i0 + 2 * q + 1) << 32);
+    }
+  };
+  // unpacked where they are consumed; what a partial thread read beyond n is replaced by a valid index
+  auto unpack_idx = [&](uint32_t base, const unsigned long long (&jp)[NJ], uint32_t (&j)[IT]) {
+    const uint32_t i0 = base + threadIdx.x * IT;
+#pragma unroll
+    for (int r = 0; r < IT; ++r) {
+      const uint32_t v = (uint32_t)(jp[r / 2] >> (32 * (r & 1)));
+      j[r] = (i0 + r < n) ? v : n_last;
+    }
+  };
+  // src2_stride == 0: the candidates are rows of (D + 1) doubles (state, end slot) exactly as they were received
+  // (fixed-capacity exchange: the receive buffer is read in place); otherwise struct-of-arrays with that stride
+  auto ptr_of = [&](uint32_t j, int k) -> const double* {
+    if (src2 && j >= n_split)
+      return (src2_stride == 0) ? src2 + (size_t)(j - n_split) * (size_t)(D + 1) + k : src2 + (size_t)k * src2_stride + (j - n_split);
+    return src + (size_t)k * src_stride + j;
+  };
+  auto gather = [&](const uint32_t (&j)[IT], double (&x)[IT][D]) {
+#pragma unroll
+    for (int r = 0; r < IT; ++r)
+#pragma unroll
+      for (int k = 0; k < D; ++k) x[r][k] = *ptr_of(j[r], k);
+  };
+  // (every gather source is allocated with 16 spare bytes: the 16-byte fetch of the last element of a buffer stays inside it)
+  auto stage_issue = [&](const uint32_t (&j)[IT]) {
+#pragma unroll
+    for (int r = 0; r < IT; ++r)
+#pragma unroll
+      for (int k = 0; k < D; ++k) {
+        // (src2 == nullptr is uniform: without candidates from other ranks the row base stays in scalar registers)
+        const double* g = (src2 == nullptr) ? src + (size_t)k * src_stride + j[r] : ptr_of(j[r], k);
+        const uint32_t slot = wstage_lds + (uint32_t)((r * D + k) * 64 * ES);
+        if (ES == 16) {
+          lds_dma16(g, slot);
+        } else {
+          lds_dma4(g, slot);
+          lds_dma4(reinterpret_cast<const unsigned char*>(g) + 4, slot + 256u);
+        }
+      }
+  };
+  auto stage_read = [&](double (&x)[IT][D]) {
+    const uint32_t lane = threadIdx.x & 63;
+#pragma unroll
+    for (int r = 0; r < IT; ++r)
+#pragma unroll
+      for (int k = 0; k < D; ++k) {
+        const unsigned char* slot = wstage + (r * D + k) * 64 * ES;
+        if (ES == 16) {
+          x[r][k] = *reinterpret_cast<const double*>(slot + lane * 16);
+        } else {
+          const uint32_t lo = *reinterpret_cast<const uint32_t*>(slot + lane * 4);
+          const uint32_t hi = *reinterpret_cast<const uint32_t*>(slot + 256 + lane * 4);
+          x[r][k] = cssm_u2d((uint64_t)lo | ((uint64_t)hi << 32));
+        }
+      }
+  };
+  uint32_t base = range_lo;
+  unsigned long long jp[NJ];
+  uint32_t jn[IT];
+  double x[IT][D];
+  const double* tab = stage_log_table(logtab);   // (issuing the first index load before this was measured: no change)
+  if (base < n) {
+    load_idx(base, jp);
+    unpack_idx(base, jp, jn);
+    if (STAGE) {
+      stage_issue(jn);                                            // tile 0 (needs its indices: the one exposed latency)
+      if (base + stride < n) load_idx(base + stride, jp);         // indices of tile 1
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      stage_read(x);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // the region is free again
+      if (base + stride < n) {
+        unpack_idx(base + stride, jp, jn);
+        stage_issue(jn);                                          // tile 1 lands while tile 0 is computed
+        if (base + 2 * stride < n) load_idx(base + 2 * stride, jp);
+      }
+    } else {
+      gather(jn, x);
+    }
+  }
+  for (; base < n; base += stride) {
+    const uint32_t i0 = base + threadIdx.x * IT;
+    const bool full = (i0 + IT <= n);
+    if (SUMS && pick_out != nullptr) {   // (only the SUMS kernels carry this: it costs the lean kernel 2 % for nothing)
+#pragma unroll
+      for (int r = 0; r < IT; ++r)
+        if (i0 + r == pick_slot) {
+#pragma unroll
+          for (int k = 0; k < D; ++k) pick_out[k] = x[r][k];
+        }
+    }
+    double lw[IT];
+    // weight of particle r once its state is propagated: NaN check, running max, optional fused sums
+    auto account = [&](int r) {
+      if (weighted && i0 + r < n) {
+        if (lw[r] != lw[r]) { bad = true; lw[r] = -cssm_inf(); }
+        tmax = (lw[r] > tmax) ? lw[r] : tmax;
+        if (SUMS && !LGCP && do_sums) {
+          // beyond c + CSSM_REF_BELOW the step is redone with the max anyway: keep the conversion in range
+          const double a = cssm_min_c(lw[r] - cref, CSSM_REF_BELOW);
+          const double w1 = cssm_exp(a);
+          accS = cssm_u128_add(accS, cssm_fix_from_double(w1));
+          accS2 = cssm_u128_add(accS2, cssm_fix_from_double(w1 * w1));
+        }
+      }
+    };
+    if (LGCP) {
+#pragma unroll
+      for (int r = 0; r < IT; ++r) {
+        double z[D];
+        const uint64_t gid = gid0 + i0 + r;
+        const int nsub = rec->n_sub;
+        if (nsub == 0) {                     // dt == 0: (x, f, f), model/ParticleFilter.scala:212-213
+          double g = gamma_of<D>(mk, rec, x[r]);
+          lw[r] = g - g;
+        } else {
+          double haz = 0.0, carry = 0.0;
+          for (int s = 0; s < nsub; ++s) {   // simInitStream(...).take(n), :193-194
+            // normal number q = s*D + k: even q opens Box-Muller pair q>>1 (second element kept for q+1)
+#pragma unroll
+            for (int k = 0; k < D; ++k) {
+              const uint32_t q = (uint32_t)s * D + k;
+              if ((q & 1u) == 0u) {
+                double z0, z1;
+                cssm_normal_pair(cssm_philox_draw(seed, gid, step, CSSM_STREAM_STEP, q >> 1), tab, &z0, &z1);
+                z[k] = z0; carry = z1;
+              } else {
+                z[k] = carry;
+              }
+            }
+            transition<D>(mk, rec, dt, x[r], z);
+            haz = haz + cssm_exp(gamma_of<D>(mk, rec, x[r])) * dt;   // :203-205
+          }
+          lw[r] = gamma_of<D>(mk, rec, x[r]) - haz;                // :200,:217
+        }
+        account(r);
+      }
+    } else if (IT % 2 == 0 && pair_ok) {
+      // the thread's particles are whole pairs (2m, 2m+1): D Philox blocks + Box-Muller pairs per two particles
+#pragma unroll
+      for (int r = 0; r + 1 < IT; r += 2) {
+        propagate_pair<D>(mk, rec, dt, seed, gid0 + i0 + r, step, tab, x[r], x[(r + 1) % IT]);
+        lw[r] = has_obs ? logdens<OBS>(mk, rec, gamma_of<D>(mk, rec, x[r]), tab) : 0.0;
+        account(r);
+        lw[(r + 1) % IT] = has_obs ? logdens<OBS>(mk, rec, gamma_of<D>(mk, rec, x[(r + 1) % IT]), tab) : 0.0;
+        account((r + 1) % IT);
+      }
+    } else {
+#pragma unroll
+      for (int r = 0; r < IT; ++r) {
+        propagate_one<D>(mk, rec, dt, seed, gid0 + i0 + r, step, tab, x[r]);
+        lw[r] = has_obs ? logdens<OBS>(mk, rec, gamma_of<D>(mk, rec, x[r]), tab) : 0.0;
+        account(r);
+      }
+    }
+    // everything older is complete by now without having been waited for: the next tile's states (issued one tile of
+    // compute ago), the indices of the tile after it, and the previous tile's stores
+    if (STAGE) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      // the index registers are complete as well: tell the compiler here, or it waits for them (and with them for the
+      // stores below) where the next tile's loads are issued
+#pragma unroll
+      for (int q = 0; q < NJ; ++q) asm volatile("" : "+v"(jp[q]));
+    }
+    if (full && IT == 4) {
+#pragma unroll
+      for (int k = 0; k < D; ++k) {
+        double* p = dst + (size_t)k * dst_stride + i0;
+        *reinterpret_cast<double2*>(p) = make_double2(x[0][k], x[1 % IT][k]);
+        *reinterpret_cast<double2*>(p + 2) = make_double2(x[2 % IT][k], x[3 % IT][k]);
+      }
+      if (weighted) {
+        *reinterpret_cast<double2*>(logw + i0) = make_double2(lw[0], lw[1 % IT]);
+        *reinterpret_cast<double2*>(logw + i0 + 2) = make_double2(lw[2 % IT], lw[3 % IT]);
+      }
+    } else if (full && IT == 2) {
+#pragma unroll
+      for (int k = 0; k < D; ++k)
+        bulk_store2(dst + (size_t)k * dst_stride + i0, x[0][k], x[1 % IT][k]);
+      if (weighted) bulk_store2(logw + i0, lw[0], lw[1 % IT]);
+    } else {
+#pragma unroll
+      for (int r = 0; r < IT; ++r) {
+        if (i0 + r < n) {
+#pragma unroll
+          for (int k = 0; k < D; ++k) dst[(size_t)k * dst_stride + i0 + r] = x[r][k];
+          if (weighted) logw[i0 + r] = lw[r];
+        }
+      }
+    }
+    // advance the pipeline
+    if (STAGE) {
+      if (base + stride < n) {
+        stage_read(x);                                            // tile i + 1
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (base + 2 * stride < n) {
+          unpack_idx(base + 2 * stride, jp, jn);
+          stage_issue(jn);                                        // tile i + 2
+          if (base + 3 * stride < n) load_idx(base + 3 * stride, jp);
+        }
+      }
+    } else if (base + stride < n) {
+      load_idx(base + stride, jp);
+      unpack_idx(base + stride, jp, jn);
+      gather(jn, x);
+    }
+  }
+  if (!weighted) return;
+  tmax = wave_max(tmax);
+  if ((threadIdx.x & 63) == 0) s_max[threadIdx.x >> 6] = tmax;
+  if (__any(bad) && (threadIdx.x & 63) == 0) atomicOr(&sc->err, 1u);
+  if (SUMS && !LGCP && do_sums) {
+    __shared__ cssm_u128 s_sa[CSSM_BLOCK / 64], s_sb[CSSM_BLOCK / 64];
+    accS = wave_sum_u128(accS);
+    accS2 = wave_sum_u128(accS2);
+    if ((threadIdx.x & 63) == 0) { s_sa[threadIdx.x >> 6] = accS; s_sb[threadIdx.x >> 6] = accS2; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      cssm_u128 ta = s_sa[0], tb = s_sb[0];
+#pragma unroll
+      for (int w = 1; w < CSSM_BLOCK / 64; ++w) { ta = cssm_u128_add(ta, s_sa[w]); tb = cssm_u128_add(tb, s_sb[w]); }
+      subS[blockIdx.x] = ta; subS2[blockIdx.x] = tb;
+    }
+  } else {
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    double m = s_max[0];
+#pragma unroll
+    for (int w = 1; w < CSSM_BLOCK / 64; ++w) m = (s_max[w] > m) ? s_max[w] : m;
+    // one integer atomicMax per block, spread over CSSM_MAXSLOTS cache lines: same-address atomics
+    // serialise at ~12 ns each, which at thousands of blocks would cost more than the kernel
+    atomicMax(&sc->maxslot[((size_t)slot_set * CSSM_MAXSLOTS + blockIdx.x % CSSM_MAXSLOTS) * CSSM_SLOT_STRIDE],
+              (unsigned long long)cssm_order_key(m));
+  }
+}
