@@ -72,6 +72,7 @@ SYMBOLS = [
     ("cssm_pf_destroy", None, [_h]),
     ("cssm_pf_set_params", C.c_int, [_h, _descp]),
     ("cssm_pf_reseed", C.c_int, [_h, C.c_uint64]),
+    ("cssm_pf_run_key", C.c_uint64, [C.c_uint64, C.c_uint64]),
     ("cssm_pf_init", C.c_int, [_h, C.c_double]),
     ("cssm_pf_init_from", C.c_int, [_h, C.c_double, _dp]),
     ("cssm_pf_step", C.c_int, [_h, C.c_double, C.c_double, C.c_int, _dp, _i32p]),
@@ -116,6 +117,7 @@ SYMBOLS = [
     ("cssm_pf_shard_resume", C.c_int, [_h, C.POINTER(C.c_uint32)]),
     ("cssm_pmmh_run", C.c_int, [_h, _descp, _dp, C.c_size_t, C.c_double, _dp, _dp, _u8p, C.c_size_t,
                                 C.c_uint64, C.c_size_t, _dp, _dp, _i32p, _dp]),
+    ("cssm_diag_copy_ceiling", C.c_int, [C.c_int, C.c_size_t, C.c_int, _dp]),
     ("cssm_contract_eval", C.c_int, [C.c_int, C.c_int, _dp, C.c_size_t, _dp, C.c_size_t]),
     ("cssm_desc_flatten", C.c_int, [_descp, _dp, C.c_size_t, C.POINTER(C.c_size_t)]),
     ("cssm_last_error", C.c_char_p, []),

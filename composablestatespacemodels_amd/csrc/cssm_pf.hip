@@ -7,6 +7,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -167,7 +168,34 @@ static double logistic(double x) { return 1.0 / (1.0 + cssm_exp(-x)); }         
 
 // Constraint transforms of the SDE constructors: model/Sde.scala:70-73 (GenBrownian),
 // :99-102 (Brownian), :133-137 (OU, logistic applied to the stored value).
-static int build_model(cssm_pf* pf, const cssm_model_desc* desc) {
+static int build_model_into(cssm_pf* pf, const cssm_model_desc* desc);
+
+// Validate and translate the descriptor into a scratch handle first; the real handle changes only when everything
+// checked out (a failing cssm_pf_set_params leaves the previous parameters in force, whole).  `update`: the call
+// re-parameterises an existing handle -- the STRUCTURE (leaves, dimensions, SDE kinds, f kinds, periods, observation
+// model, LGCP precision, Student-t df) must be the one the handle was created with: kernels, buffers and the sharding of
+// work were sized for it.
+static int build_model(cssm_pf* pf, const cssm_model_desc* desc, bool update) {
+  cssm_pf tmp;
+  int rc = build_model_into(&tmp, desc);
+  if (rc) return rc;
+  if (update) {
+    bool same = tmp.d == pf->d && tmp.n_leaves == pf->n_leaves && tmp.obs_kind == pf->obs_kind && tmp.precision == pf->precision &&
+                tmp.obs_df == pf->obs_df;
+    for (int k = 0; same && k < tmp.d; ++k) {
+      const Comp &a = tmp.comp[k], &b = pf->comp[k];
+      same = a.kind == b.kind && a.leaf == b.leaf && a.idx == b.idx && a.f_kind == b.f_kind && a.period == b.period;
+    }
+    if (!same) return fail(CSSM_EINVAL_DESC, "set_params: the model structure differs from the one the handle was created with "
+                                             "(only parameter values may change; create a new handle for another model)");
+  }
+  pf->d = tmp.d; pf->n_leaves = tmp.n_leaves; pf->obs_kind = tmp.obs_kind; pf->precision = tmp.precision; pf->obs_df = tmp.obs_df;
+  pf->scale_sd = tmp.scale_sd; pf->scale_raw = tmp.scale_raw; pf->mk = tmp.mk;
+  for (int k = 0; k < tmp.d; ++k) pf->comp[k] = tmp.comp[k];
+  return CSSM_OK;
+}
+
+static int build_model_into(cssm_pf* pf, const cssm_model_desc* desc) {
   if (!desc || !desc->leaves) return fail(CSSM_EINVAL_DESC, "null model descriptor");
   if (desc->n_leaves < 1 || desc->n_leaves > CSSM_MAX_LEAVES) return fail(CSSM_EINVAL_DESC, "n_leaves = %d out of range", desc->n_leaves);
   int d = 0;
@@ -206,7 +234,6 @@ static int build_model(cssm_pf* pf, const cssm_model_desc* desc) {
     }
     d += L->dim;
   }
-  if (pf->d != 0 && pf->d != d) return fail(CSSM_EINVAL_DESC, "set_params: latent dimension changed (%d -> %d)", pf->d, d);
   pf->d = d;
   pf->n_leaves = desc->n_leaves;
   pf->obs_kind = desc->obs_kind;
@@ -393,7 +420,7 @@ static int create_common(const cssm_model_desc* desc, uint64_t n_global, uint64_
   pf->n_global = n_global; pf->first = first; pf->n = n_local; pf->seed = seed; pf->sharded = sharded;
   if (sharded) { pf->stream = (hipStream_t)stream; pf->own_stream = false; pf->opt_fused = 1; }
   else if (n_local <= (1ull << 18)) pf->opt_fused = 1;   // launch-latency-bound sizes: two launches per observation beat three (measured: 21.4 -> 20.0 us)  // a null handle is the legacy default stream (torch's default)
-  int rc = build_model(pf, desc);
+  int rc = build_model(pf, desc, false);
   if (rc == CSSM_OK) rc = alloc_handle(pf);
   if (rc != CSSM_OK) { std::string keep = g_err; cssm_pf_destroy(pf); g_err = keep; return rc; }
   *out = pf;
@@ -427,7 +454,7 @@ extern "C" void cssm_pf_destroy(cssm_pf* pf) {
 extern "C" int cssm_pf_set_params(cssm_pf* pf, const cssm_model_desc* desc) {
   if (!pf) return fail(CSSM_EINVAL_ARG, "null handle");
   HIP_TRY(hipSetDevice(pf->device));
-  int rc = build_model(pf, desc);
+  int rc = build_model(pf, desc, true);
   if (rc) return rc;
   return upload_init_params(pf);
 }
@@ -437,6 +464,8 @@ extern "C" int cssm_pf_reseed(cssm_pf* pf, uint64_t seed) {
   pf->seed = seed;
   return CSSM_OK;
 }
+
+extern "C" uint64_t cssm_pf_run_key(uint64_t seed, uint64_t run) { return cssm_derive_key(seed, run); }
 
 extern "C" uint64_t cssm_pf_num_particles(const cssm_pf* pf) { return pf ? pf->n : 0; }
 extern "C" int32_t cssm_pf_dim(const cssm_pf* pf) { return pf ? pf->d : 0; }
@@ -806,6 +835,41 @@ extern "C" int cssm_contract_eval(int device, int fn, const double* x, size_t n,
   if (dx) (void)hipFree(dx);
   if (dout) (void)hipFree(dout);
   if (dtab) (void)hipFree(dtab);
+  return rc;
+}
+
+// ---- on-box streaming ceiling (bench.py: roofline.copy_ceiling) ---------------------------------------------------
+// A plain 16-bytes-per-lane copy of `bytes` bytes (read + write = 2 * bytes of HBM traffic), timed with HIP events over
+// `reps` launches after one warm-up launch: what this GPU streams when nothing but loads and stores is in the way.
+__global__ __launch_bounds__(256) void k_diag_copy(const uint4* __restrict__ src, uint4* __restrict__ dst, size_t n16) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (size_t)gridDim.x * 256) dst[i] = src[i];
+}
+extern "C" int cssm_diag_copy_ceiling(int device, size_t bytes, int reps, double* gbps_out) {
+  if (!gbps_out || bytes < (1u << 20) || reps < 1) return fail(CSSM_EINVAL_ARG, "bytes >= 1 MiB, reps >= 1 and an output pointer are required");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return fail(CSSM_EHIP, "no HIP device available (this library has no CPU path)");
+  if (device < 0 || device >= ndev) return fail(CSSM_EINVAL_ARG, "device %d out of range", device);
+  HIP_TRY(hipSetDevice(device));
+  const size_t n16 = bytes / 16;
+  uint4 *a = nullptr, *b = nullptr;
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  int rc = CSSM_OK;
+  if (hipMalloc(&a, n16 * 16) != hipSuccess || hipMalloc(&b, n16 * 16) != hipSuccess) rc = fail(CSSM_ENOMEM, "hipMalloc of 2 x %zu bytes", n16 * 16);
+  if (!rc && (hipMemset(a, 1, n16 * 16) != hipSuccess || hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess)) rc = fail(CSSM_EHIP, "setup");
+  if (!rc) {
+    const int grid = 256 * 16;   // 16 blocks of 4 waves per CU
+    hipLaunchKernelGGL(k_diag_copy, dim3(grid), dim3(256), 0, 0, a, b, n16);
+    (void)hipEventRecord(e0, 0);
+    for (int r = 0; r < reps; ++r) hipLaunchKernelGGL(k_diag_copy, dim3(grid), dim3(256), 0, 0, (r & 1) ? b : a, (r & 1) ? a : b, n16);
+    (void)hipEventRecord(e1, 0);
+    float ms = 0.f;
+    if (hipEventSynchronize(e1) != hipSuccess || hipEventElapsedTime(&ms, e0, e1) != hipSuccess || hipGetLastError() != hipSuccess) rc = fail(CSSM_EHIP, "copy kernel");
+    else *gbps_out = 2.0 * (double)(n16 * 16) * reps / ((double)ms * 1e-3) / 1e9;
+  }
+  if (e0) (void)hipEventDestroy(e0);
+  if (e1) (void)hipEventDestroy(e1);
+  if (a) (void)hipFree(a);
+  if (b) (void)hipFree(b);
   return rc;
 }
 
@@ -1574,11 +1638,15 @@ struct RcclApi {
   const char* (*GetErrorString)(int) = nullptr;
   bool ok = false;
 };
-RcclApi* rccl_api() {
+static RcclApi* rccl_api_load();
+RcclApi* rccl_api() {   // (distinct handles may be driven from different threads: the first calls must not race on dlopen)
+  static std::once_flag once;
+  static RcclApi* loaded = nullptr;
+  std::call_once(once, [] { loaded = rccl_api_load(); });
+  return loaded;
+}
+static RcclApi* rccl_api_load() {
   static RcclApi api;
-  static bool tried = false;
-  if (tried) return api.ok ? &api : nullptr;
-  tried = true;
   // the copy already mapped into this process (the host's framework usually brings one: two RCCL instances side by side
   // would each keep their own topology and IPC state), else the ROCm installation's
   if (FILE* maps = fopen("/proc/self/maps", "r")) {
@@ -1837,7 +1905,7 @@ extern "C" int cssm_pmmh_run(cssm_pf* pf, const cssm_model_desc* desc, const dou
     for (size_t j = 0; j < n_theta; ++j) *o.slots[j] = prop[j];
     rc = cssm_pf_set_params(pf, &o.desc);
     if (rc) return rc;
-    cssm_pf_reseed(pf, seed + 1 + it);
+    cssm_pf_reseed(pf, cssm_derive_key(seed, (uint64_t)it + 1));   // (never seed + it: include/cssm_numerics.h)
     double pll = 0.0;
     rc = run_filter(pf, t, y, has_obs, T, &pll, nullptr, nullptr, path.data());   // state = pf(propParams)
     if (rc == CSSM_ENONFINITE) pll = -cssm_inf();              // a proposal the filter cannot weigh is rejected

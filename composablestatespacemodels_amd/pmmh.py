@@ -134,7 +134,7 @@ def bootstrap_filter(unparam: UnparamModel, data, n: int, seed: int = 20260101, 
             state["pf"] = NativePf(model, n, seed, device)
         else:
             state["pf"].set_params(model)
-        state["pf"].reseed(seed + 1 + state["calls"])
+        state["pf"].reseed(state["pf"].lib.cssm_pf_run_key(seed & (2**64 - 1), 1 + state["calls"]))   # a PRF of (seed, call), never seed + call
         state["calls"] += 1
         ll, _, _, path = state["pf"].run(t, y, h, want_path=True)
         return ll, path

@@ -321,6 +321,26 @@ class LocalComm:
         pass
 
 
+class LocalCommTrimmed(LocalComm):
+    """LocalComm whose equal-split all-to-all moves only what the trimmed all-to-all-v of the library would move (whole
+    segments between adjacent ranks, ``header_words`` doubles between every other pair and to oneself) and fills the rest
+    of every receive segment with NaN: a kernel that read anything else of a non-adjacent segment could not produce the
+    oracle's bits.  Test vehicle (tests/test_gpu_sharded.py), world >= 3."""
+
+    def __init__(self, world: int, header_words: int = 12):
+        super().__init__(world)
+        self.header_words = header_words
+
+    def all_to_all_equal(self, outs, ins):
+        R = self.world
+        seg = ins[0].numel() // R
+        for q in range(R):
+            outs[q].fill_(float("nan"))
+            for r in range(R):
+                n = seg if abs(q - r) == 1 else min(self.header_words, seg)
+                outs[q][r * seg:r * seg + n].copy_(ins[r][q * seg:q * seg + n])
+
+
 class ShardedFilter:
     """llFilter over sharded particles (ParticleFilter.scala:137-140 on R GPUs).
 
@@ -424,8 +444,14 @@ class ShardedFilter:
     # still computed correctly: it is repeated with the exact exchange.
     CAP_SQRT = 6.0
     NATIVE_STRETCH = 128     # observations the library enqueues between two looks at the sticky bits
-    SINGLE_MODE = 2          # library-driven single-collective series: 2 = all-to-all-v trimmed to the adjacent ranks, 1 = equal split
+    # library-driven single-collective series: 1 = equal-split all-to-all of whole segments (default), 2 = all-to-all-v trimmed to
+    # what is read (whole segments between adjacent ranks, the 12 header words between all other pairs).  Mode 2 moves
+    # (world - 3) segments fewer per rank and observation but has never run on more than one real GPU: it is opt-in
+    # (CSSM_SHARD_TRIM=1) until it has; LocalCommTrimmed (below) checks its claim -- nothing but the header of a
+    # non-adjacent segment is ever read -- on one GPU.
+    SINGLE_MODE = 1
     last_resumes = 0
+    last_all_to_all = "equal split"
 
     def ll_filter(self, t, y, has=None, lgcp: bool = False, exact: bool = False):
         t = np.asarray(t, dtype=np.float64)
@@ -504,8 +530,11 @@ class ShardedFilter:
                     kend = min(k + self.NATIVE_STRETCH, T) if single else T
                     if single:
                         nb = comm.world * S[0].spec_segment(cap)
+                        mode = 2 if (self.SINGLE_MODE == 1 and os.environ.get("CSSM_SHARD_TRIM", "0") == "1") else self.SINGLE_MODE
                         S[0].series_native(native, k, kend, weighted, cap, S[0].buffer("send_spec", nb)[:nb],
-                                           S[0].buffer("recv_spec", nb)[:nb], single_collective=1 if os.environ.get("CSSM_SHARD_TRIM", "1") == "0" else self.SINGLE_MODE)
+                                           S[0].buffer("recv_spec", nb)[:nb], single_collective=mode)
+                        self.last_all_to_all = ("ncclAllToAllv: whole segments between adjacent ranks, 12 header words between the others"
+                                                if (mode == 3 or (mode == 2 and comm.world > 2)) else "ncclAllToAll, equal split of whole segments")
                     else:
                         nb = comm.world * (cap + 1) * (self.d + 1)
                         S[0].series_native(native, k, kend, weighted, cap, S[0].buffer("send_fixed", nb)[:nb],

@@ -159,6 +159,7 @@ CSSM_HD cssm_u32x4 cssm_philox4x32_10(cssm_u32x4 c, uint32_t k0, uint32_t k1) {
 #define CSSM_STREAM_HOST 4u   /* host-side PMMH proposal / accept draws (PMMH.scala:70,74)  */
 #define CSSM_STREAM_STRAT 5u  /* the N uniforms of stratified resampling (Resampling.scala:83), counter id = slot */
 #define CSSM_STREAM_MULTI 6u  /* the N uniforms of multinomial resampling (Resampling.scala:93), counter id = slot */
+#define CSSM_STREAM_KEY 7u    /* key derivation: the Philox key of filter run number `run` under user seed `seed` (cssm_derive_key) */
 
 /*
  * Counter layout: word0/1 = stream id, word2 = step (observation index, 0-based; 0 for init),
@@ -181,6 +182,15 @@ CSSM_HD cssm_u32x4 cssm_philox_draw(uint64_t seed, uint64_t gid, uint32_t step, 
   c.v[2] = step;
   c.v[3] = (tag << 28) | (pair & 0x0FFFFFFFu);
   return cssm_philox4x32_10(c, (uint32_t)seed, (uint32_t)(seed >> 32));
+}
+
+/* The Philox key of the `run`-th filter run a driver makes under one user seed (PMMH: one run per MCMC iteration,
+ * model/PMMH.scala:71).  A PRF of (seed, run), NOT seed + run: chains started with adjacent seeds s and s + 1 would
+ * otherwise replay each other's filter randomness shifted by one iteration (the reference's chains draw from
+ * independent generator state, examples/DetermineParameters.scala:68-69). */
+CSSM_HD uint64_t cssm_derive_key(uint64_t seed, uint64_t run) {
+  const cssm_u32x4 b = cssm_philox_draw(seed, run, 0u, CSSM_STREAM_KEY, 0u);
+  return (uint64_t)b.v[0] | ((uint64_t)b.v[1] << 32);
 }
 
 /* 53-bit integers from word pairs. */
@@ -690,13 +700,17 @@ CSSM_HD double cssm_order_unkey(uint64_t k) {
  * supremum where that is simple), a function of the observation and the observation parameters alone.  The max
  * is still found (an integer atomicMax on the side) and decides afterwards whether c was usable:
  *
- *     ref = c   if  -CSSM_REF_BELOW <= c - max <= CSSM_REF_ABOVE      (every w1 < 2^9, top weight keeps > 50 bits)
+ *     ref = c   if  -CSSM_REF_BELOW <= c - max <= CSSM_REF_ABOVE      (every w1 <= 1 + 2^-20, top weight keeps > 50 bits)
  *         = max otherwise (outlying observation, LGCP, non-finite c): the sums are then formed again with max.
  *
  * ll += ref + log(mean(exp(w - ref))) is the same quantity for either level; only roundings differ.
  * kinds: the CSSM_OBS_* numbers of cssm_pf.h; p = the observation parameter as the density uses it (Gaussian
  * sd, Student-t v); df = Student-t degrees of freedom. */
-#define CSSM_REF_BELOW 6.0
+/* c is an upper bound of every log-weight, so the max can exceed it by rounding only: BELOW is a rounding allowance, not a
+ * range.  It bounds every w1 by exp(2^-20), hence S and S2 by N (1 + 2^-20) < 2^32 for every admissible N (<= 2^32 - 2^16):
+ * the 32 integer bits of the fixed-point sums cannot overflow.  (It was 6.0, which admitted w1 up to 403 and so, in
+ * principle, a silent wrap of S beyond N = 2^23.) */
+#define CSSM_REF_BELOW 0x1.0p-20
 #define CSSM_REF_ABOVE 32.0
 CSSM_HD double cssm_ref_level(int kind, double y, double p, double df) {
   switch (kind) {

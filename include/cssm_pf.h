@@ -13,7 +13,7 @@
  *     thread-local message for the last failing call on this thread.  The reference throws
  *     from inside stepFilter (model/Sde.scala:214, model/Model.scala:150); the JNI glue turns
  *     a non-zero code into a RuntimeException.
- *   - The handle owns all device memory, its HIP stream and its graphs; the caller owns every
+ *   - The handle owns all device memory and its HIP stream; the caller owns every
  *     host buffer passed in or out.  Pointers documented as "host" must be host memory,
  *     pointers documented as "device" must be device memory of the handle's GPU.
  *   - A handle is not re-entrant; distinct handles share nothing mutable and may be driven
@@ -21,6 +21,11 @@
  *     Every entry point selects the handle's device itself, so calls may arrive on any thread
  *     (Akka dispatcher threads: model/ParticleFilter.scala:163-166).
  *   - Random numbers and reductions follow include/cssm_numerics.h (the numerics contract).
+ *   - Stated fp64 tolerance to the reference's literal arithmetic (sequential fp64 sums and cumulative weights, platform
+ *     libm, rescaling by the max, TreeMap last-wins ties -- model/ParticleFilter.scala:124-128, model/Resampling.scala:
+ *     21-24,57) under the same variates:  |ll - ll_literal| <= 1e-9 * T  for a series of T observations, and at most a
+ *     fraction 1e-4 of the ancestor indices of the first weighted observation differ.  Against the CPU restatement that
+ *     shares the contract (oracle/), everything is bit-identical.  tests/test_gpu_parity.py asserts both on the GPU.
  */
 #ifndef CSSM_PF_H
 #define CSSM_PF_H
@@ -135,6 +140,10 @@ int cssm_pf_set_params(cssm_pf* pf, const cssm_model_desc* desc);
 
 /* New Philox key (a fresh filter run must not reuse variates). */
 int cssm_pf_reseed(cssm_pf* pf, uint64_t seed);
+/* The key a driver should hand to cssm_pf_reseed for its `run`-th filter run under one user seed: a PRF of (seed, run)
+ * (include/cssm_numerics.h, cssm_derive_key), never seed + run -- chains seeded s and s + 1 would otherwise replay each
+ * other's filter randomness one iteration apart.  cssm_pmmh_run uses run = iteration + 1. */
+uint64_t cssm_pf_run_key(uint64_t seed, uint64_t run);
 
 /* ---- streaming mode: one native call per observation -------------------------------------- */
 
@@ -225,6 +234,11 @@ int cssm_pf_profile_read(cssm_pf* pf, double* total_ms, uint64_t* launches);
 #define CSSM_FN_FIX 4
 #define CSSM_FN_PAIRED_NORMALS 5
 int cssm_contract_eval(int device, int fn, const double* x, size_t n, double* out, size_t n_out);
+
+/* On-box streaming ceiling: GB/s (read + write) of a plain 16-bytes-per-lane device-to-device copy of `bytes` bytes,
+ * HIP-event timed over `reps` launches.  bench.py reports k_propagate's rate against it beside the 8 TB/s specification
+ * ("measure an on-box copy ceiling too and report both fractions"). */
+int cssm_diag_copy_ceiling(int device, size_t bytes, int reps, double* gbps_out);
 
 /* ---- inspection (parity tests, `PfState.particles` on demand) ------------------------------ */
 
@@ -379,7 +393,7 @@ int cssm_pf_shard_resume(cssm_pf* pf, uint32_t* fail_step_out);
  * the flattened STORED parameter vector in Parameters.flattenParams order
  * (model/Parameters.scala:88-95: per leaf scale-if-present, then m0, c0, [mu|phi...] in
  * SdeParameter.flatten order).  Each iteration re-parameterises the handle, reseeds it with
- * seed + iteration, runs `filter`, and accepts iff log(u) < ll' - ll (initial ll = -1e99).
+ * cssm_pf_run_key(seed, iteration + 1), runs `filter`, and accepts iff log(u) < ll' - ll (initial ll = -1e99).
  * Outputs, one row per iteration (the stream drops the initial state, :97): ll[n_iters],
  * theta[n_iters * n_theta], accepted[n_iters] (running count), last_state[n_iters * d].
  */

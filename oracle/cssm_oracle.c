@@ -825,7 +825,7 @@ int oracle_pmmh_run(oracle_pf* pf, cssm_model_desc* desc, const double* theta0, 
     for (size_t j = 0; j < n_theta; ++j) *slots[j] = prop[j];
     rc = oracle_pf_set_params(pf, desc);
     if (rc) break;
-    oracle_pf_reseed(pf, seed + 1 + it);
+    oracle_pf_reseed(pf, cssm_derive_key(seed, (uint64_t)it + 1));
     double pll;
     int frc = oracle_pf_filter(pf, t, y, has, T, &pll, NULL, NULL, path);   /* state = pf(propParams) */
     if (frc == ORACLE_ENONFINITE) pll = -INFINITY;              /* a proposal the filter cannot weigh is rejected */

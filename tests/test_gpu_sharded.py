@@ -257,3 +257,24 @@ def test_single_collective_with_boundary_blocks_of_several_tiles(n, world):
     np.testing.assert_array_equal(np.concatenate([s.particles() for s in shards], axis=1), opart)
     for s in shards:
         s.close()
+
+
+@pytest.mark.parametrize("world", [3, 4, 8])
+@pytest.mark.parametrize("name,n,T", [("c2_model", 20000, 30), ("c3_model", 9000, 16)])
+def test_trimmed_exchange_reads_only_headers_of_non_adjacent_segments(world, name, n, T):
+    """The library's all-to-all-v (single_collective = 2) moves whole segments between adjacent ranks only and 12 header
+    words between every other pair.  LocalCommTrimmed moves exactly that and fills the rest of every receive segment
+    with NaN: if k_offspring_expand_spec (or the next k_propagate) read anything else, the oracle's bits could not
+    come out."""
+    from composablestatespacemodels_amd.sharded import GpuShard, LocalCommTrimmed, ShardedFilter
+    model = getattr(cases, name)()
+    t, y, has = cases.poisson_counts(T, missing=0.1)
+    shards = [GpuShard(model, n, r, world, cases.SEED, 0) for r in range(world)]
+    f = ShardedFilter(shards, LocalCommTrimmed(world))
+    ll, ess = f.ll_filter(t, y, has)
+    assert f.last_single and f.last_attempts == 1
+    oll, oess, opart = _oracle_run(model, n, t, y, has)
+    assert (ll, ess) == (oll, oess[-1])
+    np.testing.assert_array_equal(np.concatenate([s.particles() for s in shards], axis=1), opart)
+    for s in shards:
+        s.close()

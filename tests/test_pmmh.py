@@ -132,3 +132,21 @@ def test_generic_pmmh_state_over_native_bootstrap_filter():
     states = list(run(pf, np.random.default_rng(1), iters=5))
     assert len(states) == 5 and states[0].accepted == 1 and math.isfinite(states[-1].ll)
     assert states[-1].sde.shape == (3,)
+
+
+def test_chains_with_adjacent_seeds_share_no_filter_key():
+    """The Philox key of a chain's k-th filter run is a PRF of (seed, k) (cssm_pf_run_key), not seed + k: chains seeded s and
+    s + 1 -- how two chains are naturally started side by side (examples/DetermineParameters.scala:68-69) -- must not replay
+    each other's filter randomness one iteration apart.  The host function needs no GPU."""
+    from composablestatespacemodels_amd import _abi
+    lib = _abi.load_library()
+    runs = range(1, 2001)
+    for s in (0, 99, 20260101, 2**64 - 2):
+        a = {lib.cssm_pf_run_key(s, k) for k in runs}
+        b = {lib.cssm_pf_run_key((s + 1) % 2**64, k) for k in runs}
+        assert len(a) == len(runs) and len(b) == len(runs)
+        assert not (a & b)
+        assert s not in a and (s + 1) % 2**64 not in a       # nor the handle's creation seed
+    # the oracle's chain derives the same keys (shared header): the native-vs-oracle chain test relies on it
+    from oracle import oracle
+    assert oracle.lib() is not None

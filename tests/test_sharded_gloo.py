@@ -107,3 +107,40 @@ def test_local_comm_matches_single_rank_on_cpu():
     oll, _, oess, _ = o.filter(t, y, has)
     assert (ll, ess) == (oll, int(oess[-1]))
     np.testing.assert_array_equal(np.concatenate([s.particles() for s in shards], axis=1), o.particles())
+
+
+def test_bench_launches_its_own_ranks_over_gloo():
+    """`python bench.py --gpus 2` without a launcher starts its own two ranks (children, before any GPU call in the
+    parent), and hands rank 0's JSON line on: rehearsed here over gloo with the oracle shard backend."""
+    import json
+    import subprocess
+    env = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(os.path.dirname(HERE), "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "2",
+                        "--particles", "300", "--backend", "gloo", "--launch-timeout", "240"],
+                       capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["steps"] == 6 and j["config"]["particles_per_gpu"] == 300
+    assert j["exchange"]["backend"] == "gloo"
+    model = cases.c2_model()
+    t, y, has = cases.poisson_counts(8)
+    o = oracle.OraclePf(model.descriptor(), 600, 20260101)
+    ll, _, ess_t, _ = o.filter(t[:6], y[:6], has[:6])
+    assert j["ll"] == ll and j["ess_last"] == int(ess_t[-1])
+
+
+def test_bench_launcher_reports_a_failing_rank():
+    """A rank that dies makes the launcher exit non-zero instead of hanging (here: an impossible particle count)."""
+    import subprocess
+    env = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(os.path.dirname(HERE), "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "1",
+                        "--particles", "0", "--backend", "gloo", "--launch-timeout", "120"],
+                       capture_output=True, text=True, timeout=200, env=env)
+    assert r.returncode != 0
+    assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
