@@ -619,10 +619,18 @@ def test_every_dimension_streaming_and_batch_bit_exact(d):
 
 # ----------------------------------------------------------------------------- tolerance to the reference's literal arithmetic
 # The north star asks for the marginal log-likelihood "to a stated fp64 tolerance" of the reference CPU filter.  The closest
-# executable form of the reference's own arithmetic is the oracle in LITERAL_SUMS | LIBM | TIE_LAST mode: sequential fp64
-# sums and cumulative weights (Seq.sum / scanLeft, model/ParticleFilter.scala:124-128, model/Resampling.scala:21-24,57), the
-# platform libm instead of the contract's elementary functions, TreeMap last-wins ties (:57), rescaling by the max.  The
-# stated tolerance (include/cssm_pf.h):  |ll_HIP - ll_literal| <= LL_TOL_PER_OBS * T.
+# executable form of the reference's own arithmetic is the oracle in LITERAL_SUMS | LIBM mode: sequential fp64 sums and
+# cumulative weights (Seq.sum / scanLeft, model/ParticleFilter.scala:124-128, model/Resampling.scala:21-24,57), the platform
+# libm instead of the contract's elementary functions, rescaling by the max.  The stated tolerance (DESIGN.md section 2,
+# include/cssm_pf.h):  |ll_HIP - ll_literal| <= LL_TOL_PER_OBS * T, and no more than FLIPPED_ANCESTORS_MAX of the ancestor
+# indices of the first weighted observation differ (measured: none).
+# TIE_LAST adds the TreeMap quirk (:57: equal consecutive cumulative weights are ONE key whose value is the LAST particle
+# inserted).  At large N that is no corner case: a weight below half an ulp of the running cumulative sum leaves the sum
+# unchanged, so a particle of negligible weight takes the slot of the heavy particle before it (0.4 % of the slots at
+# N = 2^16 on the bench model).  The contract keeps the first particle (deviation D3) -- the one that owns the probability
+# mass.  One such swap changes the later cumulative weights by O(1/N), i.e. by a fraction of a slot, so from the next
+# observation on the two runs are different realisations of the same estimator: the test pins (i) that EVERY differing
+# ancestor of the first weighted observation is such a swap and (ii) agreement of ll within Monte-Carlo error.
 LL_TOL_PER_OBS = 1e-9
 FLIPPED_ANCESTORS_MAX = 1e-4     # fraction of slots whose ancestor may differ after the FIRST weighted observation
 
@@ -631,26 +639,41 @@ FLIPPED_ANCESTORS_MAX = 1e-4     # fraction of slots whose ancestor may differ a
 def test_hip_likelihood_within_stated_tolerance_of_literal_reference_arithmetic(name, n, T):
     model = getattr(cases, name)()
     t, y, has = cases.poisson_counts(T)
-    flags = oracle.LITERAL_SUMS | oracle.LIBM | oracle.TIE_LAST
-    # whole series: marginal log-likelihood
     g = NativePf(model, n, cases.SEED)
     gl, gl_t, gess, _ = g.run(t, y, has)
-    o = oracle.OraclePf(model.descriptor(), n, cases.SEED, flags)
-    ol, ol_t, oess, _ = o.filter(t, y, has)
+    t0 = float(np.min(t))
+    s0 = int(np.argmax(has))
+
+    def first_weighted_step(flags):
+        g.init(t0)
+        o = oracle.OraclePf(model.descriptor(), n, cases.SEED, flags)
+        o.init(t0)
+        for s in range(s0 + 1):
+            g.step(t[s], y[s], bool(has[s])); o.step(t[s], y[s], bool(has[s]))
+        return g.ancestors().astype(np.int64), o.ancestors().astype(np.int64), o.logw()
+
+    # (a) literal sums + libm: the stated tolerance
+    flags = oracle.LITERAL_SUMS | oracle.LIBM
+    ol, ol_t, oess, _ = oracle.OraclePf(model.descriptor(), n, cases.SEED, flags).filter(t, y, has)
     assert abs(gl - ol) <= LL_TOL_PER_OBS * T, (gl, ol)
     assert np.max(np.abs(gl_t - ol_t)) <= LL_TOL_PER_OBS * T
-    assert np.max(np.abs(gess.astype(np.int64) - oess.astype(np.int64))) <= max(2, n // 10000)
-    # first weighted observation, before trajectories can diverge: ancestors
-    t0 = float(np.min(t))
-    g.init(t0)
-    o2 = oracle.OraclePf(model.descriptor(), n, cases.SEED, flags)
-    o2.init(t0)
-    s0 = int(np.argmax(has))
-    for s in range(s0 + 1):
-        g.step(t[s], y[s], bool(has[s])); o2.step(t[s], y[s], bool(has[s]))
-    flipped = float(np.mean(g.ancestors() != o2.ancestors()))
-    print(f"{name} N={n} T={T}: |dll| = {abs(gl - ol):.3e} (tolerance {LL_TOL_PER_OBS * T:.1e}), flipped ancestors at step {s0}: {flipped:.2e}")
+    assert np.max(np.abs(gess.astype(np.int64) - oess.astype(np.int64))) <= 1
+    ga, oa, _ = first_weighted_step(flags)
+    flipped = float(np.mean(ga != oa))
     assert flipped <= FLIPPED_ANCESTORS_MAX
+    # (b) ... + the TreeMap duplicate-key quirk
+    flags |= oracle.TIE_LAST
+    tl = oracle.OraclePf(model.descriptor(), n, cases.SEED, flags).filter(t, y, has)[0]
+    ga, oa, lw = first_weighted_step(flags)
+    diff = np.nonzero(ga != oa)[0]
+    w1 = np.exp(lw - lw.max())
+    rel = w1 / w1.sum()
+    for i in diff:
+        assert oa[i] > ga[i]                                   # the reference's key maps to a LATER particle ...
+        assert rel[ga[i] + 1:oa[i] + 1].max() <= 2.0 ** -52    # ... and everything up to it is too light to move the cumulative sum
+    assert abs(gl - tl) <= 0.25                                # different realisations from here on: Monte-Carlo agreement only
+    print(f"{name} N={n} T={T}: |dll| literal+libm = {abs(gl - ol):.3e} (tolerance {LL_TOL_PER_OBS * T:.1e}), flipped ancestors {flipped:.1e}; "
+          f"with TreeMap last-wins ties: {len(diff) / n:.2e} of the first observation's slots swap to a negligible particle, |dll| = {abs(gl - tl):.3e}")
     g.close()
 
 
