@@ -341,6 +341,14 @@ __device__ __forceinline__ void lds_dma4(const void* g, uint32_t lds_base) {
   asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %0, off" : : "v"(g), "s"(lds_base) : "memory");
 }
 
+// The same with agent scope (sc1): the source was written by another block earlier in the same launch (series kernel).
+__device__ __forceinline__ void lds_dma16_sc1(const double* g, uint32_t lds_base) {
+  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off sc1" : : "v"(g), "s"(lds_base) : "memory");
+}
+__device__ __forceinline__ void lds_dma4_sc1(const void* g, uint32_t lds_base) {
+  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %0, off sc1" : : "v"(g), "s"(lds_base) : "memory");
+}
+
 // How k_propagate's two-particles-per-thread instantiations (d = 3 .. 8) store their bulk outputs (state rows,
 // log-weights), one 16-byte store per lane and row, contiguous across the wave.  0: plain stores (dirty lines stay in
 // the L2 and are written back when the kernel ends); 1: non-temporal; 2: write-through at agent scope (sc1); 3: sc0 sc1.
@@ -380,3 +388,18 @@ __device__ __forceinline__ double decode_slots(const Scalars* __restrict__ sc, i
   }
   return cssm_order_unkey(k);
 }
+
+// ll += max + log(mean(w1)) (:127, :522-524); ess = floor(1 / sum (w1/tot)^2) (:128, :431-434)
+__device__ __forceinline__ void finish_step(Scalars* sc, uint64_t n_global) {
+  const double tot = cssm_fix_to_double(sc->S_tot);
+  const double tot2 = cssm_fix_to_double(sc->S2_tot);
+  if (cssm_u128_is_zero(sc->S_tot) || !(sc->gmax > -cssm_inf()) || !(sc->gmax < cssm_inf())) {
+    atomicOr(&sc->err, 2u);
+    return;
+  }
+  sc->ll = sc->ll + sc->ref + cssm_log(tot / (double)n_global);
+  double e = 1.0 / (tot2 / (tot * tot));
+  double fl = (double)(long long)e;   // e >= 1 here; floor == trunc
+  sc->ess = (e < 2147483647.0) ? (int32_t)fl : 2147483647;
+}
+

@@ -98,20 +98,6 @@ __global__ __launch_bounds__(CSSM_BLOCK) void k_tile_sums(const double* __restri
   }
 }
 
-// ll += max + log(mean(w1)) (:127, :522-524); ess = floor(1 / sum (w1/tot)^2) (:128, :431-434)
-__device__ void finish_step(Scalars* sc, uint64_t n_global) {
-  const double tot = cssm_fix_to_double(sc->S_tot);
-  const double tot2 = cssm_fix_to_double(sc->S2_tot);
-  if (cssm_u128_is_zero(sc->S_tot) || !(sc->gmax > -cssm_inf()) || !(sc->gmax < cssm_inf())) {
-    atomicOr(&sc->err, 2u);
-    return;
-  }
-  sc->ll = sc->ll + sc->ref + cssm_log(tot / (double)n_global);
-  double e = 1.0 / (tot2 / (tot * tot));
-  double fl = (double)(long long)e;   // e >= 1 here; floor == trunc
-  sc->ess = (e < 2147483647.0) ? (int32_t)fl : 2147483647;
-}
-
 // Exclusive scan of the tile sums in one block (thread t owns a contiguous chunk of tiles: sum, block
 // scan of the 1024 chunk sums, then prefix write-back); local totals; with `single` also ll / ess.
 __global__ __launch_bounds__(1024) void k_scan_tiles(const cssm_u128* __restrict__ tileS, const cssm_u128* __restrict__ tileS2,

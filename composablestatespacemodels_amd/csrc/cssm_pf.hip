@@ -13,6 +13,7 @@
 
 #include "cssm_host.h"
 #include "cssm_kernels.hip.h"
+#include "cssm_series_abi.h"
 
 // ------------------------------------------------------------------------------------ errors
 
@@ -81,6 +82,15 @@ struct cssm_pf {
   int wparity = 0;             // max-slot set of the next weighted step (single-GPU path)
   int opt_exact = 0;           // CSSM_OPT_EXACT_OFFSPRING
   int opt_fused = 0;           // CSSM_OPT_FUSED_SUMS (set to 1 for sharded handles at creation)
+  int opt_series = 1;          // CSSM_OPT_SERIES_KERNEL: batch drivers run the persistent series kernel when the handle is eligible
+  // persistent series kernel (cssm_series.hip.h)
+  void* d_sync = nullptr;      // SeriesSync
+  int ser_blocks_max = -1;     // co-resident blocks the kernel may use (-1: not asked yet, 0: not available)
+  unsigned long long* d_ts = nullptr;   // profiling: block 0's timestamps, 5 per observation
+  size_t ts_cap = 0;
+  bool last_series = false;    // the last batch run used the series kernel
+  double ser_phase_us[4] = {0, 0, 0, 0};   // profiling: average phase P / exchange / phase O / closing barrier of the weighted steps
+  uint64_t ser_phase_steps = 0;
   int resampler = CSSM_RESAMPLE_SYSTEMATIC;
   double* cum = nullptr;       // multinomial: cumulative normalised weights
   const long long *send_first_dev = nullptr, *send_count_dev = nullptr;   // last shard_offspring outputs (device)
@@ -441,7 +451,7 @@ extern "C" void cssm_pf_destroy(cssm_pf* pf) {
   (void)hipSetDevice(pf->device);
   if (pf->stream) (void)hipStreamSynchronize(pf->stream);
   void* ptrs[] = {pf->state[0], pf->state[1], pf->logw, pf->endslot, pf->anc, pf->tileS, pf->tileS2, pf->tileP, pf->sc,
-                  pf->d_m0, pf->d_sd0, pf->d_logtab, pf->cum, pf->d_recs, pf->d_ll_t, pf->d_ess_t, pf->d_path, pf->cand, pf->cand_end, pf->cand_idx, pf->d_bounds, pf->d_xch, pf->d_need};
+                  pf->d_m0, pf->d_sd0, pf->d_logtab, pf->d_sync, pf->d_ts, pf->cum, pf->d_recs, pf->d_ll_t, pf->d_ess_t, pf->d_path, pf->cand, pf->cand_end, pf->cand_idx, pf->d_bounds, pf->d_xch, pf->d_need};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   if (pf->h_recs) (void)hipHostFree(pf->h_recs);
   for (hipEvent_t e : pf->prof_ev) (void)hipEventDestroy(e);
@@ -681,6 +691,104 @@ extern "C" int cssm_pf_step(cssm_pf* pf, double t, double obs, int has_obs, doub
   return check_device_err(pf, h);
 }
 
+// ------------------------------------------------------------------------------------ persistent series kernel
+
+static int series_items(int d) { return d <= 8 ? 2 : 1; }   // SeriesItems<D>
+
+#define CSSM_SER_DISPATCH(fn, d, ...)                                                                       \
+  switch (d) {                                                                                               \
+    case 1: e = fn##1(__VA_ARGS__); break;   case 2: e = fn##2(__VA_ARGS__); break;   case 3: e = fn##3(__VA_ARGS__); break;   \
+    case 4: e = fn##4(__VA_ARGS__); break;   case 5: e = fn##5(__VA_ARGS__); break;   case 6: e = fn##6(__VA_ARGS__); break;   \
+    case 7: e = fn##7(__VA_ARGS__); break;   case 8: e = fn##8(__VA_ARGS__); break;   case 9: e = fn##9(__VA_ARGS__); break;   \
+    case 10: e = fn##10(__VA_ARGS__); break; case 11: e = fn##11(__VA_ARGS__); break; case 12: e = fn##12(__VA_ARGS__); break; \
+    case 13: e = fn##13(__VA_ARGS__); break; case 14: e = fn##14(__VA_ARGS__); break; case 15: e = fn##15(__VA_ARGS__); break; \
+    default: e = fn##16(__VA_ARGS__); break;                                                                 \
+  }
+
+// How the series kernel would run this handle: `grid` blocks of `per_block` consecutive particles each, or not at all
+// (false): LGCP, other resamplers and sharded handles use the per-observation kernels; a block must be able to keep its
+// particles' log-weights in LDS (per_block <= CSSM_SER_LW_CAP); all blocks must be resident together.
+struct SeriesPlan { int grid; uint32_t per_block; size_t smem; };
+static bool series_plan(cssm_pf* pf, SeriesPlan* plan) {
+  if (!pf->opt_series || pf->sharded || pf->obs_kind == CSSM_OBS_LGCP || pf->resampler != CSSM_RESAMPLE_SYSTEMATIC) return false;
+  if (pf->first != 0 || pf->n != pf->n_global || pf->n < 1) return false;
+  const int obs = (pf->obs_kind == CSSM_OBS_POISSON || pf->obs_kind == CSSM_OBS_GAUSSIAN) ? pf->obs_kind : -1;
+  const uint64_t tile = (uint64_t)CSSM_BLOCK * series_items(pf->d);
+  if (pf->ser_blocks_max < 0) {   // asked once per handle: co-resident blocks at the largest LDS footprint a launch can have
+    pf->ser_blocks_max = 0;
+    int per_cu = 0, cus = 0, coop = 0;
+    hipError_t e = hipSuccess;
+    CSSM_SER_DISPATCH(cssm_series_occupancy_d, pf->d, obs, (size_t)CSSM_SER_LW_CAP * 8, &per_cu);
+    if (e == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, pf->device) == hipSuccess &&
+        hipDeviceGetAttribute(&coop, hipDeviceAttributeCooperativeLaunch, pf->device) == hipSuccess && coop && per_cu > 0 && cus > 0) {
+      long long b = (long long)per_cu * cus;
+      pf->ser_blocks_max = (int)(b > CSSM_SER_MAXBLOCKS ? CSSM_SER_MAXBLOCKS : b);
+    }
+    (void)hipGetLastError();
+  }
+  if (pf->ser_blocks_max < 1) return false;
+  uint64_t g = (pf->n + tile - 1) / tile;
+  if (g > (uint64_t)pf->ser_blocks_max) g = (uint64_t)pf->ser_blocks_max;
+  uint64_t per = (pf->n + g - 1) / g;
+  per = (per + tile - 1) / tile * tile;
+  if (per > CSSM_SER_LW_CAP) return false;
+  plan->per_block = (uint32_t)per;
+  plan->grid = (int)((pf->n + per - 1) / per);
+  plan->smem = (size_t)per * 8;
+  return true;
+}
+
+// One cooperative launch for observations [0, T) (records already on the device, cloud initialised in state[0]).
+static int launch_series(cssm_pf* pf, const SeriesPlan& plan, size_t T, double* d_path) {
+  if (!pf->d_sync) HIP_TRY(hipMalloc(&pf->d_sync, cssm_series_sync_bytes()));
+  HIP_TRY(hipMemsetAsync(pf->d_sync, 0, cssm_series_sync_bytes(), pf->stream));
+  unsigned long long* ts = nullptr;
+  if (pf->profile) {
+    if (pf->ts_cap < T) {
+      if (pf->d_ts) (void)hipFree(pf->d_ts);
+      pf->d_ts = nullptr; pf->ts_cap = 0;
+      HIP_TRY(hipMalloc(&pf->d_ts, T * CSSM_SER_TS_PER_STEP * 8));
+      pf->ts_cap = T;
+    }
+    ts = pf->d_ts;
+  }
+  SeriesLaunch a;
+  a.grid = plan.grid; a.stream = pf->stream; a.smem = plan.smem;
+  a.obs = (pf->obs_kind == CSSM_OBS_POISSON || pf->obs_kind == CSSM_OBS_GAUSSIAN) ? pf->obs_kind : -1;
+  a.state0 = pf->state[0]; a.state1 = pf->state[1]; a.stride = pf->stride; a.anc = pf->anc; a.logw = pf->logw;
+  a.n = pf->n; a.seed = pf->seed; a.recs = pf->d_recs; a.T = (uint32_t)T; a.mk = pf->mk; a.sc = pf->sc; a.sync = pf->d_sync;
+  a.logtab = pf->d_logtab; a.per_block = plan.per_block; a.cur0 = pf->cur; a.force_exact = pf->opt_exact;
+  a.ll_t = pf->d_ll_t; a.ess_t = pf->d_ess_t; a.path = d_path; a.ts = ts;
+  prof_begin(pf, CSSM_K_SERIES);
+  hipError_t e = hipSuccess;
+  CSSM_SER_DISPATCH(cssm_series_launch_d, pf->d, a);
+  prof_end(pf);
+  if (e != hipSuccess) return fail(CSSM_EHIP, "cooperative launch of the series kernel (%d blocks): %s", plan.grid, hipGetErrorString(e));
+  // host-side mirror of what the kernel did: T propagates, the last resampling (if any) valid
+  pf->cur = (pf->cur + (int)(T & 1)) & 1;
+  pf->src = pf->state[pf->cur]; pf->src_stride = pf->stride; pf->src2 = nullptr;
+  pf->anc_valid = pf->h_recs[T - 1].has_obs != 0;
+  pf->last_optimistic = true;
+  return CSSM_OK;
+}
+
+// profiling: block 0's timestamps -> average duration of the four stretches of a weighted observation
+static int series_collect_phases(cssm_pf* pf, size_t T) {
+  std::vector<unsigned long long> h(T * CSSM_SER_TS_PER_STEP);
+  HIP_TRY(hipMemcpy(h.data(), pf->d_ts, h.size() * 8, hipMemcpyDeviceToHost));
+  double acc[4] = {0, 0, 0, 0};
+  uint64_t cnt = 0;
+  for (size_t s = 0; s < T; ++s) {
+    if (!pf->h_recs[s].has_obs) continue;
+    const unsigned long long* q = &h[s * CSSM_SER_TS_PER_STEP];
+    for (int k = 0; k < 4; ++k) acc[k] += (double)(q[k + 1] - q[k]) * 0.01;   // 100 MHz ticks -> us
+    ++cnt;
+  }
+  for (int k = 0; k < 4; ++k) pf->ser_phase_us[k] = cnt ? acc[k] / (double)cnt : 0.0;
+  pf->ser_phase_steps = cnt;
+  return CSSM_OK;
+}
+
 // ------------------------------------------------------------------------------------ batch API
 
 static int run_filter_once(cssm_pf* pf, const double* t, const double* y, const uint8_t* has, size_t T, double* ll_out,
@@ -732,11 +840,23 @@ static int run_filter_once(cssm_pf* pf, const double* t, const double* y, const 
                        (uint64_t)pa % pf->n, d, pf->d_path);
   }
   HIP_TRY(hipEventRecord(pf->ev0, pf->stream));
+  SeriesPlan plan;
+  pf->last_series = series_plan(pf, &plan);
+  if (pf->last_series) {
+    // all T observations in one cooperative launch (cssm_series.hip.h); path entries 1 .. T-1 are recorded inside it, the
+    // last one (no following propagate) by k_pick
+    rc = launch_series(pf, plan, T, path ? pf->d_path : nullptr);
+    if (rc) return rc;
+    if (path)
+      hipLaunchKernelGGL(k_pick, dim3(1), dim3(64), 0, pf->stream, pf->src, pf->src_stride,
+                         (const uint32_t*)(pf->anc_valid ? pf->anc : nullptr), (uint64_t)pf->h_recs[T - 1].pick, d,
+                         pf->d_path + T * (size_t)d);
+  }
   // path entry s + 1 = the resampled state sampleOne picks after observation s.  With the kernels that also form the
   // sums (small handles: the PMMH case) the k_propagate of observation s + 1, which gathers exactly that state into the
   // thread of slot pick_s, records it on the way; otherwise a one-block launch per observation does.
   const bool fold = path && uses_sums_kernel(pf);
-  for (size_t s = 0; s < T; ++s) {
+  for (size_t s = 0; s < T && !pf->last_series; ++s) {
     const int weighted = pf->h_recs[s].has_obs;
     double* pick_out = (fold && s >= 1) ? pf->d_path + s * (size_t)d : nullptr;
     rc = launch_step(pf, pf->d_recs + s, weighted, (uint32_t)s, pf->d_ll_t, pf->d_ess_t, (uint32_t)s, pick_out,
@@ -757,7 +877,9 @@ static int run_filter_once(cssm_pf* pf, const double* t, const double* y, const 
   HIP_TRY(hipStreamSynchronize(pf->stream));
   HIP_TRY(hipEventElapsedTime(&pf->last_ms, pf->ev0, pf->ev1));
   prof_collect(pf);
+  if (pf->last_series && pf->profile && pf->d_ts) { rc = series_collect_phases(pf, T); if (rc) return rc; }
   pf->t = t[T - 1]; pf->step = (uint32_t)T;
+  if (h.err & 16u) return fail(CSSM_EHIP, "the grid barrier of the series kernel timed out (a block did not arrive); the series was abandoned");
   if ((h.err & 4u) && !(h.err & 1u) && !pf->safe_sums) { *retry = true; return CSSM_OK; }
   if (ll_out) *ll_out = h.ll;
   return check_device_err(pf, h);
@@ -883,6 +1005,7 @@ extern "C" int cssm_pf_set_option(cssm_pf* pf, int option, int value) {
   if (!pf) return fail(CSSM_EINVAL_ARG, "null handle");
   if (option == CSSM_OPT_EXACT_OFFSPRING) { pf->opt_exact = value ? 1 : 0; return CSSM_OK; }
   if (option == CSSM_OPT_FUSED_SUMS) { pf->opt_fused = value ? 1 : 0; return CSSM_OK; }
+  if (option == CSSM_OPT_SERIES_KERNEL) { pf->opt_series = value ? 1 : 0; return CSSM_OK; }
   if (option == CSSM_OPT_RESAMPLER) {
     if (value < CSSM_RESAMPLE_SYSTEMATIC || value > CSSM_RESAMPLE_MULTINOMIAL) return fail(CSSM_EINVAL_ARG, "unknown resampler %d", value);
     if (pf->sharded && value != CSSM_RESAMPLE_SYSTEMATIC) return fail(CSSM_ESTATE, "sharded handles resample systematically");
@@ -903,6 +1026,14 @@ extern "C" int cssm_pf_profile(cssm_pf* pf, int enable) {
 extern "C" int cssm_pf_profile_read(cssm_pf* pf, double* total_ms, uint64_t* launches) {
   if (!pf || !total_ms || !launches) return fail(CSSM_EINVAL_ARG, "null argument");
   for (int k = 0; k < CSSM_NKERNELS; ++k) { total_ms[k] = pf->prof_ms[k]; launches[k] = pf->prof_cnt[k]; }
+  return CSSM_OK;
+}
+
+extern "C" int cssm_pf_series_phases(cssm_pf* pf, int* used_series, double* phase_us, uint64_t* weighted_steps) {
+  if (!pf) return fail(CSSM_EINVAL_ARG, "null handle");
+  if (used_series) *used_series = pf->last_series ? 1 : 0;
+  if (phase_us) for (int k = 0; k < 4; ++k) phase_us[k] = pf->ser_phase_us[k];
+  if (weighted_steps) *weighted_steps = pf->ser_phase_steps;
   return CSSM_OK;
 }
 

@@ -25,19 +25,37 @@ template <int D> struct PropItems { static constexpr int value = (D <= 2) ? 4 : 
 // that spill 41.2 us/step at N = 2^20 and 375 us at 2^24, 3 waves without it 41.9 and 383)
 template <int D, bool SUMS = false> struct PropWaves { static constexpr int value = (D <= 4) ? (SUMS ? CSSM_PROP_WAVES_SUMS : CSSM_PROP_WAVES_LO) : 3; };
 
-//
-// A block owns the CONTIGUOUS range [blockIdx.x * chunk, +chunk) (chunk a multiple of CSSM_BLOCK*IT, chosen on the
-// host so that a whole number of blocks makes one scan unit of k_offspring).  With do_sums the block also forms
-// S = sum exp(w - c), S2 = sum exp(w - c)^2 in fixed point for its range, c = rec->ref being known before any
-// weight is (include/cssm_numerics.h, "reference level"): the log-sum-exp of :125-127 then needs no pass of its own.
-template <int D, bool LGCP, int IT, int OBS, bool SUMS>
-__global__ __launch_bounds__(CSSM_BLOCK, (PropWaves<D, SUMS>::value)) void k_propagate(
+// LDS staging area of propagate_range: per wave IT * D regions of 64 lanes x ES bytes (ES = 16: one dwordx4 fetch per lane and
+// element, of which the first 8 bytes are the element, while 4 blocks of that fit the CU's 160 KiB; else 8: two dword fetches).
+template <int D, int IT> struct PropStage {
+  static constexpr int ES = (IT * D <= 9) ? 16 : 8;
+  static constexpr int wave_bytes = IT * D * 64 * ES;
+  static constexpr int bytes = (CSSM_BLOCK / 64) * wave_bytes;
+};
+
+// Thread-local results of propagate_range, reduced over the block by its caller.
+struct PropAcc {
+  cssm_u128 S, S2;   // fixed-point sums of exp(w - c), exp(w - c)^2 over the thread's particles (SUMS)
+  double tmax;       // largest log-weight seen
+  bool bad;          // a log-weight was NaN
+};
+
+// The body shared by k_propagate (one launch per observation) and the persistent series kernel (cssm_series.hip.h): the
+// block's particles [range_lo, n) of one observation.  COH (series kernel): everything another block wrote earlier in
+// the SAME launch -- ancestor indices, state rows -- is read with agent-scope (sc1) loads and everything another block
+// will read is stored write-through (sc1), because the 8 XCDs' L2s are not coherent with each other inside a kernel;
+// lw_lds != nullptr: the log-weights of the range also go to LDS (lw_lds[i - range_lo]) for the offspring phase.
+// `tab`: the contract's log table, staged in LDS by the caller (stage_log_table).
+template <int D, bool LGCP, int IT, int OBS, bool SUMS, bool COH>
+__device__ __forceinline__ void propagate_range(
     const double* __restrict__ src, size_t src_stride, const uint32_t* __restrict__ anc,
-    double* __restrict__ dst, size_t dst_stride, double* __restrict__ logw, uint64_t n_arg, uint64_t gid0,
-    uint64_t seed, const StepRec* __restrict__ rec, ModelK mk, Scalars* __restrict__ sc, int slot_set,
-    const double* __restrict__ src2, size_t src2_stride, uint32_t n_split, const double* __restrict__ logtab,
-    uint64_t chunk, int do_sums_arg, cssm_u128* __restrict__ subS, cssm_u128* __restrict__ subS2,
-    double* __restrict__ pick_out, uint32_t pick_slot) {
+    double* __restrict__ dst, size_t dst_stride, double* __restrict__ logw, uint64_t gid0,
+    uint64_t seed, const StepRec* __restrict__ rec, const ModelK& mk,
+    const double* __restrict__ src2, size_t src2_stride, uint32_t n_split, const double* tab,
+    const uint32_t range_lo, const uint32_t n, int do_sums_arg,
+    double* __restrict__ pick_out, uint32_t pick_slot, double* lw_lds, unsigned char* s_stage, PropAcc& acc) {
+  // s_stage: PropStage<D, IT>::bytes bytes of LDS (16-byte aligned) owned by the caller -- the series kernel reuses them
+  // for its offspring phase
   // SUMS && pick_out != nullptr (`filter`, model/ParticleFilter.scala:157): the thread that gathers slot pick_slot holds the
   // resampled state sampleOne chose after the PREVIOUS observation, before its transition: it records it (a launch of
   // its own per observation would cost more than the whole sums pass at small N)
@@ -46,10 +64,6 @@ __global__ __launch_bounds__(CSSM_BLOCK, (PropWaves<D, SUMS>::value)) void k_pro
   // which in a kernel that streams hundreds of MB of stores cost 130 us at N = 2^24.  k_scan_tiles does it instead.)
   // src2 != nullptr (sharded filter): ancestor indices >= n_split address the candidates received from
   // other ranks, src2[k * src2_stride + (j - n_split)]
-  __shared__ double s_max[CSSM_BLOCK / 64];
-  // (sharded series) the exchange of an earlier observation did not fit: the series is on hold and nothing may change
-  // until the host resumes it (cssm_pf_shard_resume)
-  if (sc->err & 8u) return;   // (bit 3 is only ever raised by the sharded exchange)
   const uint32_t step = rec->step;
   const int has_obs = rec->has_obs;
   const double dt = rec->dt;
@@ -62,11 +76,9 @@ __global__ __launch_bounds__(CSSM_BLOCK, (PropWaves<D, SUMS>::value)) void k_pro
   cssm_u128 accS = cssm_u128_zero(), accS2 = cssm_u128_zero();
   double tmax = -cssm_inf();
   bool bad = false;
+  static_assert(!COH || IT <= 2, "the series kernel runs one or two particles per thread (wave-contiguous write-through stores)");
   // tile indices are 32-bit (the library admits n <= 2^32 - 2^16 particles per handle): half the VALU work of 64-bit
   constexpr uint32_t stride = (uint32_t)CSSM_BLOCK * IT;      // particles per tile
-  const uint32_t range_lo = blockIdx.x * (uint32_t)chunk;
-  uint32_t n;                                                 // this block's range ends at n
-  { const uint64_t range_hi = (uint64_t)range_lo + chunk; n = (uint32_t)((range_hi < n_arg) ? range_hi : n_arg); }
   // Software pipeline over the block's tiles WITHOUT spending registers on it.  With 4 waves per SIMD the two
   // dependent memory round trips of a tile (ancestor index -> gathered state) are exposed: a model with that
   // latency reproduces the 3.3 TB/s the un-pipelined kernel reached for every d, and holding the next tile in VGPRs
@@ -80,7 +92,6 @@ __global__ __launch_bounds__(CSSM_BLOCK, (PropWaves<D, SUMS>::value)) void k_pro
   constexpr bool STAGE = true;
   constexpr int ES = (IT * D <= 9) ? 16 : 8;
   constexpr int WAVE_STAGE = IT * D * 64 * ES;
-  __shared__ __attribute__((aligned(16))) unsigned char s_stage[(CSSM_BLOCK / 64) * WAVE_STAGE];
   unsigned char* const wstage = s_stage + (size_t)(threadIdx.x >> 6) * WAVE_STAGE;
   const uint32_t wstage_lds = __builtin_amdgcn_readfirstlane((uint32_t)(size_t)(__attribute__((address_space(3))) void*)wstage);
   const uint32_t n_last = n - 1u;
@@ -93,7 +104,17 @@ __global__ __launch_bounds__(CSSM_BLOCK, (PropWaves<D, SUMS>::value)) void k_pro
   auto load_idx = [&](uint32_t base, unsigned long long (&jp)[NJ]) {
     const uint32_t i0 = base + threadIdx.x * IT;
     if (anc) {
-      if (IT == 4) {
+      if (COH) {   // written by other blocks earlier in this launch: agent-scope loads (global_load ... sc1)
+        const unsigned long long* a64 = reinterpret_cast<const unsigned long long*>(anc + i0);
+        if (IT == 4) {
+          jp[0] = __hip_atomic_load(a64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          jp[NJ - 1] = __hip_atomic_load(a64 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else if (IT == 2) {
+          jp[0] = __hip_atomic_load(a64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+          jp[0] = __hip_atomic_load(anc + i0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+      } else if (IT == 4) {
         const ulonglong2 a = *reinterpret_cast<const ulonglong2*>(anc + i0);
         jp[0] = a.x; jp[NJ - 1] = a.y;
       } else if (IT == 2) {
@@ -138,7 +159,10 @@ __global__ __launch_bounds__(CSSM_BLOCK, (PropWaves<D, SUMS>::value)) void k_pro
         const double* g = (src2 == nullptr) ? src + (size_t)k * src_stride + j[r] : ptr_of(j[r], k);
         const uint32_t slot = wstage_lds + (uint32_t)((r * D + k) * 64 * ES);
         if (ES == 16) {
-          lds_dma16(g, slot);
+          if (COH) lds_dma16_sc1(g, slot); else lds_dma16(g, slot);
+        } else if (COH) {
+          lds_dma4_sc1(g, slot);
+          lds_dma4_sc1(reinterpret_cast<const unsigned char*>(g) + 4, slot + 256u);
         } else {
           lds_dma4(g, slot);
           lds_dma4(reinterpret_cast<const unsigned char*>(g) + 4, slot + 256u);
@@ -165,7 +189,6 @@ __global__ __launch_bounds__(CSSM_BLOCK, (PropWaves<D, SUMS>::value)) void k_pro
   unsigned long long jp[NJ];
   uint32_t jn[IT];
   double x[IT][D];
-  const double* tab = stage_log_table(logtab);   // (issuing the first index load before this was measured: no change)
   if (base < n) {
     load_idx(base, jp);
     unpack_idx(base, jp, jn);
@@ -283,16 +306,25 @@ __global__ __launch_bounds__(CSSM_BLOCK, (PropWaves<D, SUMS>::value)) void k_pro
 #pragma unroll
       for (int k = 0; k < D; ++k)
         bulk_store2(dst + (size_t)k * dst_stride + i0, x[0][k], x[1 % IT][k]);
-      if (weighted) bulk_store2(logw + i0, lw[0], lw[1 % IT]);
+      if (weighted && logw) bulk_store2(logw + i0, lw[0], lw[1 % IT]);
     } else {
 #pragma unroll
       for (int r = 0; r < IT; ++r) {
         if (i0 + r < n) {
 #pragma unroll
-          for (int k = 0; k < D; ++k) dst[(size_t)k * dst_stride + i0 + r] = x[r][k];
-          if (weighted) logw[i0 + r] = lw[r];
+          for (int k = 0; k < D; ++k) {
+            if (COH) __hip_atomic_store(reinterpret_cast<unsigned long long*>(dst + (size_t)k * dst_stride + i0 + r),
+                                        (unsigned long long)cssm_d2u(x[r][k]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            else dst[(size_t)k * dst_stride + i0 + r] = x[r][k];
+          }
+          if (weighted && logw) logw[i0 + r] = lw[r];
         }
       }
+    }
+    if (COH && weighted && lw_lds != nullptr) {   // the offspring phase of the same launch reads them back from LDS
+#pragma unroll
+      for (int r = 0; r < IT; ++r)
+        if (i0 + r < n) lw_lds[i0 + r - range_lo] = lw[r];
     }
     // advance the pipeline
     if (STAGE) {
@@ -311,6 +343,39 @@ __global__ __launch_bounds__(CSSM_BLOCK, (PropWaves<D, SUMS>::value)) void k_pro
       gather(jn, x);
     }
   }
+  acc.S = accS; acc.S2 = accS2; acc.tmax = tmax; acc.bad = bad;
+}
+
+//
+// A block owns the CONTIGUOUS range [blockIdx.x * chunk, +chunk) (chunk a multiple of CSSM_BLOCK*IT, chosen on the
+// host so that a whole number of blocks makes one scan unit of k_offspring).  With do_sums the block also forms
+// S = sum exp(w - c), S2 = sum exp(w - c)^2 in fixed point for its range, c = rec->ref being known before any
+// weight is (include/cssm_numerics.h, "reference level"): the log-sum-exp of :125-127 then needs no pass of its own.
+template <int D, bool LGCP, int IT, int OBS, bool SUMS>
+__global__ __launch_bounds__(CSSM_BLOCK, (PropWaves<D, SUMS>::value)) void k_propagate(
+    const double* __restrict__ src, size_t src_stride, const uint32_t* __restrict__ anc,
+    double* __restrict__ dst, size_t dst_stride, double* __restrict__ logw, uint64_t n_arg, uint64_t gid0,
+    uint64_t seed, const StepRec* __restrict__ rec, ModelK mk, Scalars* __restrict__ sc, int slot_set,
+    const double* __restrict__ src2, size_t src2_stride, uint32_t n_split, const double* __restrict__ logtab,
+    uint64_t chunk, int do_sums_arg, cssm_u128* __restrict__ subS, cssm_u128* __restrict__ subS2,
+    double* __restrict__ pick_out, uint32_t pick_slot) {
+  __shared__ double s_max[CSSM_BLOCK / 64];
+  // (sharded series) the exchange of an earlier observation did not fit: the series is on hold and nothing may change
+  // until the host resumes it (cssm_pf_shard_resume)
+  if (sc->err & 8u) return;   // (bit 3 is only ever raised by the sharded exchange)
+  const uint32_t range_lo = blockIdx.x * (uint32_t)chunk;
+  uint32_t n;                                                 // this block's range ends at n
+  { const uint64_t range_hi = (uint64_t)range_lo + chunk; n = (uint32_t)((range_hi < n_arg) ? range_hi : n_arg); }
+  const double* tab = stage_log_table(logtab);
+  __shared__ __attribute__((aligned(16))) unsigned char s_stage[PropStage<D, IT>::bytes];
+  PropAcc acc;
+  propagate_range<D, LGCP, IT, OBS, SUMS, false>(src, src_stride, anc, dst, dst_stride, logw, gid0, seed, rec, mk, src2, src2_stride,
+                                                 n_split, tab, range_lo, n, do_sums_arg, pick_out, pick_slot, nullptr, s_stage, acc);
+  const bool weighted = LGCP || rec->has_obs;
+  const bool do_sums = SUMS && !LGCP && do_sums_arg && rec->has_obs;
+  cssm_u128 accS = acc.S, accS2 = acc.S2;
+  double tmax = acc.tmax;
+  const bool bad = acc.bad;
   if (!weighted) return;
   tmax = wave_max(tmax);
   if ((threadIdx.x & 63) == 0) s_max[threadIdx.x >> 6] = tmax;

@@ -203,6 +203,13 @@ int cssm_pf_last_loop_ms(cssm_pf* pf, float* ms_out);
  * per observation, 363 vs 366 us at 2^24) but a series with an outlying observation runs twice, and the lean propagate
  * kernel is the one the roofline figure is quoted on. */
 #define CSSM_OPT_FUSED_SUMS 3
+/* CSSM_OPT_SERIES_KERNEL (default 1): the batch drivers (cssm_pf_ll_filter, cssm_pf_filter, cssm_pmmh_run) run all T
+ * observations in ONE cooperative launch of a persistent kernel -- propagate + weight + sums, a grid barrier that also
+ * reduces the sums, offspring + ancestors, a second grid barrier, per observation; log-weights stay in LDS -- whenever the
+ * handle is eligible: systematic resampling, not LGCP, not sharded, at most 2048 particles per co-resident block (N <= 2^21
+ * on MI355X).  0 = always the per-observation kernels (identical results; the tested fallback, and what streaming
+ * cssm_pf_step always uses).  A step boundary then costs a barrier (~3 us) instead of a kernel launch (~5-10 us). */
+#define CSSM_OPT_SERIES_KERNEL 4
 int cssm_pf_set_option(cssm_pf* pf, int option, int value);
 
 /* Per-kernel device time, measured with HIP events recorded on the handle's stream directly
@@ -217,9 +224,15 @@ int cssm_pf_set_option(cssm_pf* pf, int option, int value);
 #define CSSM_K_SCAN_TILES 3  /* scan of tile sums, ll, ess */
 #define CSSM_K_OFFSPRING 4   /* cumulative weights -> end slots */
 #define CSSM_K_EXPAND 5      /* end slots -> ancestor indices */
-#define CSSM_PROFILE_NKERNELS 6
+#define CSSM_K_SERIES 6      /* the persistent series kernel: ONE launch for all T observations of a batch run */
+#define CSSM_PROFILE_NKERNELS 7
 int cssm_pf_profile(cssm_pf* pf, int enable);
 int cssm_pf_profile_read(cssm_pf* pf, double* total_ms, uint64_t* launches);
+/* Whether the last batch run used the persistent series kernel and, if profiling was on, how its weighted observations
+ * spent their time on average, from timestamps block 0 takes inside the kernel (constant 100 MHz counter):
+ * phase_us[0] = propagate + weight + sums, [1] = exchange (barrier + reduction of the sums), [2] = offspring + ancestors,
+ * [3] = closing barrier.  Any pointer may be NULL. */
+int cssm_pf_series_phases(cssm_pf* pf, int* used_series, double* phase_us, uint64_t* weighted_steps);
 
 /* ---- diagnostics of the numerics contract --------------------------------------------------- */
 

@@ -6,9 +6,10 @@ import sys
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-SRC = os.path.join(HERE, "..", "composablestatespacemodels_amd", "csrc", "cssm_pf.hip")
+# usage: kernel_resources.py [name-filter] [source.hip] [extra hipcc flags, e.g. -DCSSM_PROP_D=3]
+SRC = os.path.join(HERE, "..", "composablestatespacemodels_amd", "csrc", sys.argv[2] if len(sys.argv) > 2 else "cssm_pf.hip")
 cmd = ["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "-ffp-contract=off", "-mfma", "--offload-arch=gfx950",
-       "-Rpass-analysis=kernel-resource-usage", "-c", SRC, "-o", "/dev/null"]
+       "-Rpass-analysis=kernel-resource-usage", "-c", SRC, "-o", "/dev/null"] + sys.argv[3:]
 out = subprocess.run(cmd, capture_output=True, text=True).stderr
 rows, cur = {}, None
 for line in out.splitlines():
