@@ -333,20 +333,20 @@ __device__ __forceinline__ double block_decode_slots(const Scalars* __restrict__
 // own counted waits more conservative (VMEM operations retire in order), never wrong; completion is awaited explicitly
 // (s_waitcnt vmcnt(0)) before the wave reads the region back.  M0 has no other use in these kernels.
 __device__ __forceinline__ void lds_dma16(const double* g, uint32_t lds_base) {
-  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(g), "s"(lds_base) : "memory");
+  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(g), "s"(lds_base) : "memory", "m0");
 }
 // The same with 4 bytes per lane (lane l -> LDS bytes [lds_base + 4 l, +4)): a double travels as two of these, low and
 // high word into two 256-byte regions, where LDS is too small for 16 bytes per element.
 __device__ __forceinline__ void lds_dma4(const void* g, uint32_t lds_base) {
-  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %0, off" : : "v"(g), "s"(lds_base) : "memory");
+  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %0, off" : : "v"(g), "s"(lds_base) : "memory", "m0");
 }
 
 // The same with agent scope (sc1): the source was written by another block earlier in the same launch (series kernel).
 __device__ __forceinline__ void lds_dma16_sc1(const double* g, uint32_t lds_base) {
-  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off sc1" : : "v"(g), "s"(lds_base) : "memory");
+  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off sc1" : : "v"(g), "s"(lds_base) : "memory", "m0");
 }
 __device__ __forceinline__ void lds_dma4_sc1(const void* g, uint32_t lds_base) {
-  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %0, off sc1" : : "v"(g), "s"(lds_base) : "memory");
+  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %0, off sc1" : : "v"(g), "s"(lds_base) : "memory", "m0");
 }
 
 // How k_propagate's two-particles-per-thread instantiations (d = 3 .. 8) store their bulk outputs (state rows,
@@ -358,6 +358,11 @@ __device__ __forceinline__ void lds_dma4_sc1(const void* g, uint32_t lds_base) {
 // lines: the four-particles-per-thread layout (d <= 2: two 16-byte stores per lane, 32 bytes apart) loses the L2's
 // write combining with sc1 (k_propagate<1> 129 -> 190 us at N = 2^24), so do the 4-byte run writes of k_offspring
 // (106 -> 165 us); one particle per thread (d >= 9, 8-byte stores) is neutral (191.6 vs 192.1 us).  Those stay plain.
+// HAZARD: a vector-memory store of more than 64 bits reads its data registers over several cycles, and a VALU instruction
+// that overwrites them in the next wait states corrupts what is stored (gfx9 "VMEM store data hazard").  The compiler
+// pads its own stores; it cannot see into inline assembly, so every 128-bit store issued from inline assembly carries
+// its own `s_nop 1` (found the hard way: ancestor indices came out as halves of the NEXT store's address in exactly
+// those instantiations whose schedule happened to put the address arithmetic right behind the store).
 #ifndef CSSM_ST_MODE
 #define CSSM_ST_MODE 2
 #endif
@@ -368,10 +373,10 @@ __device__ __forceinline__ void bulk_store2(double* p, double a, double b) {
   __builtin_nontemporal_store(v, reinterpret_cast<cssm_dbl2*>(p));
 #elif CSSM_ST_MODE == 2
   cssm_dbl2 v; v.x = a; v.y = b;
-  asm volatile("global_store_dwordx4 %0, %1, off sc1" : : "v"(p), "v"(v) : "memory");
+  asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" : : "v"(p), "v"(v) : "memory");   // s_nop: see CSSM_ST_MODE
 #elif CSSM_ST_MODE == 3
   cssm_dbl2 v; v.x = a; v.y = b;
-  asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" : : "v"(p), "v"(v) : "memory");
+  asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" : : "v"(p), "v"(v) : "memory");
 #else
   *reinterpret_cast<double2*>(p) = make_double2(a, b);
 #endif

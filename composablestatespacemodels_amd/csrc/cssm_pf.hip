@@ -879,6 +879,7 @@ static int run_filter_once(cssm_pf* pf, const double* t, const double* y, const 
   prof_collect(pf);
   if (pf->last_series && pf->profile && pf->d_ts) { rc = series_collect_phases(pf, T); if (rc) return rc; }
   pf->t = t[T - 1]; pf->step = (uint32_t)T;
+  if (h.err & 32u) return fail(CSSM_EHIP, "the series kernel met an ancestor index beyond the cloud (clamped, not dereferenced): internal error");
   if (h.err & 16u) return fail(CSSM_EHIP, "the grid barrier of the series kernel timed out (a block did not arrive); the series was abandoned");
   if ((h.err & 4u) && !(h.err & 1u) && !pf->safe_sums) { *retry = true; return CSSM_OK; }
   if (ll_out) *ll_out = h.ll;

@@ -53,7 +53,11 @@ __device__ __forceinline__ void propagate_range(
     uint64_t seed, const StepRec* __restrict__ rec, const ModelK& mk,
     const double* __restrict__ src2, size_t src2_stride, uint32_t n_split, const double* tab,
     const uint32_t range_lo, const uint32_t n, int do_sums_arg,
-    double* __restrict__ pick_out, uint32_t pick_slot, double* lw_lds, unsigned char* s_stage, PropAcc& acc) {
+    double* __restrict__ pick_out, uint32_t pick_slot, double* lw_lds, unsigned char* s_stage, PropAcc& acc,
+    const uint32_t idx_max = 0xffffffffu, uint32_t* __restrict__ err_word = nullptr) {
+  // idx_max / err_word (COH): ancestor indices above idx_max -- impossible by construction -- are clamped and reported
+  // (err bit 5) instead of being dereferenced: the ancestor array is the only data-dependent address of the path, and a
+  // wild gather inside a kernel that the whole grid waits on must not be able to fault the GPU
   // s_stage: PropStage<D, IT>::bytes bytes of LDS (16-byte aligned) owned by the caller -- the series kernel reuses them
   // for its offspring phase
   // SUMS && pick_out != nullptr (`filter`, model/ParticleFilter.scala:157): the thread that gathers slot pick_slot holds the
@@ -132,7 +136,8 @@ __device__ __forceinline__ void propagate_range(
     const uint32_t i0 = base + threadIdx.x * IT;
 #pragma unroll
     for (int r = 0; r < IT; ++r) {
-      const uint32_t v = (uint32_t)(jp[r / 2] >> (32 * (r & 1)));
+      uint32_t v = (uint32_t)(jp[r / 2] >> (32 * (r & 1)));
+      if (COH && v > idx_max) { v = idx_max; if (i0 + r < n) atomicOr(err_word, 32u); }
       j[r] = (i0 + r < n) ? v : n_last;
     }
   };

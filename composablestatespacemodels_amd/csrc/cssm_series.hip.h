@@ -165,7 +165,7 @@ __device__ __forceinline__ uint32_t wave_scan_max_u32(uint32_t v) {
 typedef uint32_t cssm_u32x4v __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void ser_store_anc4(uint32_t* p, uint32_t a, uint32_t b, uint32_t c, uint32_t d) {
   cssm_u32x4v v; v.x = a; v.y = b; v.z = c; v.w = d;
-  asm volatile("global_store_dwordx4 %0, %1, off sc1" : : "v"(p), "v"(v) : "memory");
+  asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" : : "v"(p), "v"(v) : "memory");   // s_nop: store-data hazard, see CSSM_ST_MODE
 }
 
 // Phase O of one weighted observation for the block's particles [range_lo, range_lo + cnt): log-weights in s_lw.
@@ -345,7 +345,7 @@ __global__ __launch_bounds__(CSSM_BLOCK, CSSM_SER_WAVES) void k_series(
     // (logw: only the last observation's log-weights go to memory, for cssm_pf_get_logw)
     propagate_range<D, false, IT, OBS, true, true>(src, stride, via_anc ? anc : nullptr, dst, stride, (s + 1 == T) ? logw : nullptr, 0ull, seed,
                                                    rec, mk, nullptr, 0, 0u, tab, range_lo, range_hi, 1, pick_out,
-                                                   s >= 1 ? recs[s - 1].pick : 0u, s_lw, s_buf, acc);
+                                                   s >= 1 ? recs[s - 1].pick : 0u, s_lw, s_buf, acc, n - 1u, &sc->err);
     cur ^= 1;
     if (!has_obs) {               // model/ParticleFilter.scala:121: propagated cloud, ll and ess unchanged
       if (blockIdx.x == 0 && threadIdx.x == 0 && ll_t) { ll_t[s] = sc->ll; ess_t[s] = sc->ess; }
