@@ -85,7 +85,8 @@ struct cssm_pf {
   int opt_series = 1;          // CSSM_OPT_SERIES_KERNEL: batch drivers run the persistent series kernel when the handle is eligible
   // persistent series kernel (cssm_series.hip.h)
   void* d_sync = nullptr;      // SeriesSync
-  int ser_blocks_max = -1;     // co-resident blocks the kernel may use (-1: not asked yet, 0: not available)
+  int ser_blocks_max = -1;     // CUs of a device that can launch cooperatively (-1: not asked yet, 0: it cannot)
+  std::vector<int> ser_occ;    // resident blocks per CU by particles per block / tile (-1: not asked yet)
   unsigned long long* d_ts = nullptr;   // profiling: block 0's timestamps, 5 per observation
   size_t ts_cap = 0;
   bool last_series = false;    // the last batch run used the series kernel
@@ -714,23 +715,33 @@ static bool series_plan(cssm_pf* pf, SeriesPlan* plan) {
   if (pf->first != 0 || pf->n != pf->n_global || pf->n < 1) return false;
   const int obs = (pf->obs_kind == CSSM_OBS_POISSON || pf->obs_kind == CSSM_OBS_GAUSSIAN) ? pf->obs_kind : -1;
   const uint64_t tile = (uint64_t)CSSM_BLOCK * series_items(pf->d);
-  if (pf->ser_blocks_max < 0) {   // asked once per handle: co-resident blocks at the largest LDS footprint a launch can have
+  if (pf->ser_blocks_max < 0) {   // asked once per handle: can this device launch cooperatively at all
     pf->ser_blocks_max = 0;
-    int per_cu = 0, cus = 0, coop = 0;
-    hipError_t e = hipSuccess;
-    CSSM_SER_DISPATCH(cssm_series_occupancy_d, pf->d, obs, (size_t)CSSM_SER_LW_CAP * 8, &per_cu);
-    if (e == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, pf->device) == hipSuccess &&
-        hipDeviceGetAttribute(&coop, hipDeviceAttributeCooperativeLaunch, pf->device) == hipSuccess && coop && per_cu > 0 && cus > 0) {
-      long long b = (long long)per_cu * cus;
-      pf->ser_blocks_max = (int)(b > CSSM_SER_MAXBLOCKS ? CSSM_SER_MAXBLOCKS : b);
-    }
+    int cus = 0, coop = 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, pf->device) == hipSuccess &&
+        hipDeviceGetAttribute(&coop, hipDeviceAttributeCooperativeLaunch, pf->device) == hipSuccess && coop && cus > 0)
+      pf->ser_blocks_max = cus;   // (holds the CU count; blocks per CU depend on the LDS a launch asks for, below)
     (void)hipGetLastError();
   }
   if (pf->ser_blocks_max < 1) return false;
-  uint64_t g = (pf->n + tile - 1) / tile;
-  if (g > (uint64_t)pf->ser_blocks_max) g = (uint64_t)pf->ser_blocks_max;
-  uint64_t per = (pf->n + g - 1) / g;
+  // the fewest particles per block that CSSM_SER_MAXBLOCKS blocks can cover, then upwards until the blocks that size needs
+  // are resident together (more log-weights in LDS per block = fewer blocks per CU)
+  uint64_t per = (pf->n + CSSM_SER_MAXBLOCKS - 1) / CSSM_SER_MAXBLOCKS;
   per = (per + tile - 1) / tile * tile;
+  for (; per <= CSSM_SER_LW_CAP; per += tile) {
+    const size_t idx = (size_t)(per / tile);
+    if (pf->ser_occ.size() <= idx) pf->ser_occ.resize(idx + 1, -1);
+    if (pf->ser_occ[idx] < 0) {
+      int per_cu = 0;
+      hipError_t e = hipSuccess;
+      CSSM_SER_DISPATCH(cssm_series_occupancy_d, pf->d, obs, (size_t)per * 8, &per_cu);
+      pf->ser_occ[idx] = (e == hipSuccess && per_cu > 0) ? per_cu : 0;
+      (void)hipGetLastError();
+    }
+    long long resident = (long long)pf->ser_occ[idx] * pf->ser_blocks_max;
+    if (resident > CSSM_SER_MAXBLOCKS) resident = CSSM_SER_MAXBLOCKS;
+    if ((long long)((pf->n + per - 1) / per) <= resident) break;
+  }
   if (per > CSSM_SER_LW_CAP) return false;
   plan->per_block = (uint32_t)per;
   plan->grid = (int)((pf->n + per - 1) / per);

@@ -69,11 +69,12 @@ def test_series_kernel_every_dimension(d):
 
 
 def test_series_kernel_full_bench_size_and_beyond_its_range():
-    """N = 2^20 (1024 blocks of 1024 particles: the bench configuration) and N = 2^21 (2048 per block, the most a block keeps
-    in LDS) run the series kernel; N = 2^21 + 1 is beyond it and silently takes the per-observation kernels."""
+    """N = 2^20 (1024 blocks of 1024 particles: the bench configuration) and N = 3 * 2^19 (1536 per block: the most 1024
+    co-resident blocks of this model can keep in LDS) run the series kernel; N = 2^21 + 1 is beyond it and silently takes
+    the per-observation kernels."""
     model = cases.c2_model()
     t, y, has = cases.poisson_counts(10, missing=0.1)
-    for n, expect in ((1 << 20, True), (1 << 21, True), ((1 << 21) + 1, False)):
+    for n, expect in ((1 << 20, True), (3 << 19, True), ((1 << 21) + 1, False)):
         a = _run(model, n, t, y, has, series=1, want_path=(n == 1 << 20))
         assert a["used"] == expect
         b = _run(model, n, t, y, has, series=0, want_path=(n == 1 << 20))
