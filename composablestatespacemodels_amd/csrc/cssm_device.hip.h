@@ -82,6 +82,8 @@ struct Scalars {
   uint32_t err;              // bit0: NaN log-weight, bit1: all weights zero / max not finite,
                              // bit2: the reference level was unusable and the sums must be formed again (host retries)
                              // bit3: (sharded) the exchange capacity did not cover some rank's slots at step fail_step
+                             // bit4: series kernel: grid barrier timed out; bit5: series kernel: wild ancestor index (clamped)
+                             // bit6: batch series on hold at fail_step: its reference level was ruled out, the host redoes its sums
   int32_t ess;
   uint32_t fail_step;        // first observation whose exchange did not fit (0xffffffff: none); see k_offspring_expand_spec
   uint32_t pad_;
@@ -333,20 +335,20 @@ __device__ __forceinline__ double block_decode_slots(const Scalars* __restrict__
 // own counted waits more conservative (VMEM operations retire in order), never wrong; completion is awaited explicitly
 // (s_waitcnt vmcnt(0)) before the wave reads the region back.  M0 has no other use in these kernels.
 __device__ __forceinline__ void lds_dma16(const double* g, uint32_t lds_base) {
-  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(g), "s"(lds_base) : "memory", "m0");
+  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(g), "s"(lds_base) : "memory");
 }
 // The same with 4 bytes per lane (lane l -> LDS bytes [lds_base + 4 l, +4)): a double travels as two of these, low and
 // high word into two 256-byte regions, where LDS is too small for 16 bytes per element.
 __device__ __forceinline__ void lds_dma4(const void* g, uint32_t lds_base) {
-  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %0, off" : : "v"(g), "s"(lds_base) : "memory", "m0");
+  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %0, off" : : "v"(g), "s"(lds_base) : "memory");
 }
 
 // The same with agent scope (sc1): the source was written by another block earlier in the same launch (series kernel).
 __device__ __forceinline__ void lds_dma16_sc1(const double* g, uint32_t lds_base) {
-  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off sc1" : : "v"(g), "s"(lds_base) : "memory", "m0");
+  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off sc1" : : "v"(g), "s"(lds_base) : "memory");
 }
 __device__ __forceinline__ void lds_dma4_sc1(const void* g, uint32_t lds_base) {
-  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %0, off sc1" : : "v"(g), "s"(lds_base) : "memory", "m0");
+  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %0, off sc1" : : "v"(g), "s"(lds_base) : "memory");
 }
 
 // How k_propagate's two-particles-per-thread instantiations (d = 3 .. 8) store their bulk outputs (state rows,

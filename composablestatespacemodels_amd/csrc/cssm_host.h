@@ -32,7 +32,7 @@ struct SeriesLaunch {
   int grid; hipStream_t stream; int obs; size_t smem;
   double* state0; double* state1; size_t stride; uint32_t* anc; double* logw; uint64_t n; uint64_t seed;
   const StepRec* recs; uint32_t T; ModelK mk; Scalars* sc; void* sync; const double* logtab; uint32_t per_block; int cur0;
-  int force_exact; double* ll_t; int32_t* ess_t; double* path; unsigned long long* ts;
+  int force_exact; double* ll_t; int32_t* ess_t; double* path; unsigned long long* ts; uint32_t ts_blocks;
 };
 #define CSSM_DECL_SER(D) hipError_t cssm_series_launch_d##D(const SeriesLaunch& a); \
                          hipError_t cssm_series_occupancy_d##D(int obs, size_t smem, int* blocks_per_cu);

@@ -207,6 +207,9 @@ __device__ __forceinline__ void offspring_body(const double* __restrict__ logw, 
   __shared__ uint32_t s_nheavy;
   __shared__ uint32_t s_hb[FUSE ? CSSM_TILE : 1], s_he[FUSE ? CSSM_TILE : 1], s_hj[FUSE ? CSSM_TILE : 1];
   __shared__ cssm_u128 s_r[3][CSSM_BLOCK / 64];
+  // (batch series, single GPU) an earlier observation's reference level was ruled out by its max: the series is on hold at
+  // that observation until the host has redone its sums (run_filter_once); nothing may change meanwhile
+  if (SELF && (sc->err & 64u)) return;
   double pre_v[CSSM_ITEMS];   // the block's first tile is requested before the serial prologue
   if (blockIdx.x < nunits) load_tile_raw(logw, (uint64_t)blockIdx.x * sup * CSSM_TILE, n, raw, pre_v);
   double gmax_dec;
@@ -221,7 +224,11 @@ __device__ __forceinline__ void offspring_body(const double* __restrict__ logw, 
   }
   const double gmax = raw ? gmax_dec : cssm_ref_choose(rec->ref, gmax_dec);   // the level of this step
   if (!raw && optimistic && !(gmax == rec->ref)) {
-    if (SELF) {
+    if (SELF && optimistic == 3) {
+      // batch series: put the series on hold AT this observation (its propagate is done, its log-weights are in place); every
+      // kernel enqueued behind returns at once, the host redoes this observation's sums relative to the max and carries on
+      if (blockIdx.x == 0 && threadIdx.x == 0) { sc->gmax = gmax_dec; atomicMin(&sc->fail_step, rec->step); atomicOr(&sc->err, 64u); }
+    } else if (SELF) {
       if (FUSE && anc) {   // keep the ancestor array addressable for the steps already enqueued behind this one
         for (uint32_t unit = blockIdx.x; unit < nunits; unit += gridDim.x) {
           const uint64_t lo = (uint64_t)unit * sup * CSSM_TILE;

@@ -66,6 +66,7 @@ struct cssm_pf {
   bool safe_sums = false;         // form the sums in their own pass after the max is known (retry of a step whose
                                   // reference level was ruled out by the max; always for LGCP)
   bool last_optimistic = false;   // the last launch_propagate formed the sums itself
+  bool batch_hold = false;        // batch drivers: an outlying observation puts the series on hold (err bit 6) instead of voiding it
   bool sharded = false;
   // device memory
   double* state[2] = {nullptr, nullptr};
@@ -89,6 +90,8 @@ struct cssm_pf {
   std::vector<int> ser_occ;    // resident blocks per CU by particles per block / tile (-1: not asked yet)
   unsigned long long* d_ts = nullptr;   // profiling: block 0's timestamps, 5 per observation
   size_t ts_cap = 0;
+  int profile_level = 0;       // 2: every block of the series kernel stamps its phases (cssm_pf_series_stamps)
+  uint32_t ts_blocks = 0; size_t ts_T = 0;
   bool last_series = false;    // the last batch run used the series kernel
   double ser_phase_us[4] = {0, 0, 0, 0};   // profiling: average phase P / exchange / phase O / closing barrier of the weighted steps
   uint64_t ser_phase_steps = 0;
@@ -430,7 +433,7 @@ static int create_common(const cssm_model_desc* desc, uint64_t n_global, uint64_
   pf->device = device;
   pf->n_global = n_global; pf->first = first; pf->n = n_local; pf->seed = seed; pf->sharded = sharded;
   if (sharded) { pf->stream = (hipStream_t)stream; pf->own_stream = false; pf->opt_fused = 1; }
-  else if (n_local <= (1ull << 18)) pf->opt_fused = 1;   // launch-latency-bound sizes: two launches per observation beat three (measured: 21.4 -> 20.0 us)  // a null handle is the legacy default stream (torch's default)
+  else pf->opt_fused = 1;   // two launches per observation at every size: an outlying observation is redone in place (run_filter_once)
   int rc = build_model(pf, desc, false);
   if (rc == CSSM_OK) rc = alloc_handle(pf);
   if (rc != CSSM_OK) { std::string keep = g_err; cssm_pf_destroy(pf); g_err = keep; return rc; }
@@ -582,7 +585,7 @@ static int launch_resample(cssm_pf* pf, const StepRec* d_rec, double* ll_t = nul
   prof_begin(pf, CSSM_K_OFFSPRING);   // unit prefix, ll/ess, end slots and their expansion to ancestors in one kernel
 #define OFF_ARGS pf->logw, pf->n, pf->sc, (const cssm_u128*)pf->tileS, (const cssm_u128*)pf->tileS2, d_rec, pf->n_global, pf->endslot, pf->anc, \
                  pf->ntiles, pf->sup, pf->nunits, 0, pf->wparity, ll_t, ess_t, rec_idx, pf->opt_exact, (const unsigned long long*)nullptr, 0, 1, \
-                 split, pf->seed, pf->cum, pf->d_logtab, optimistic ? 1 : 0, (unsigned long long*)nullptr, 0u, (uint32_t)pf->n_global
+                 split, pf->seed, pf->cum, pf->d_logtab, optimistic ? (pf->batch_hold ? 3 : 1) : 0, (unsigned long long*)nullptr, 0u, (uint32_t)pf->n_global
   if (pf->resampler == CSSM_RESAMPLE_STRATIFIED)
     hipLaunchKernelGGL((k_offspring<true, true, CSSM_RESAMPLE_STRATIFIED>), dim3(tgrid), dim3(CSSM_BLOCK), 0, pf->stream, OFF_ARGS);
   else if (pf->resampler == CSSM_RESAMPLE_MULTINOMIAL)
@@ -754,22 +757,25 @@ static int launch_series(cssm_pf* pf, const SeriesPlan& plan, size_t T, double* 
   if (!pf->d_sync) HIP_TRY(hipMalloc(&pf->d_sync, cssm_series_sync_bytes()));
   HIP_TRY(hipMemsetAsync(pf->d_sync, 0, cssm_series_sync_bytes(), pf->stream));
   unsigned long long* ts = nullptr;
+  const uint32_t ts_blocks = (pf->profile_level >= 2) ? (uint32_t)plan.grid : 1u;
   if (pf->profile) {
-    if (pf->ts_cap < T) {
+    const size_t need = (size_t)ts_blocks * T;
+    if (pf->ts_cap < need) {
       if (pf->d_ts) (void)hipFree(pf->d_ts);
       pf->d_ts = nullptr; pf->ts_cap = 0;
-      HIP_TRY(hipMalloc(&pf->d_ts, T * CSSM_SER_TS_PER_STEP * 8));
-      pf->ts_cap = T;
+      HIP_TRY(hipMalloc(&pf->d_ts, need * CSSM_SER_TS_PER_STEP * 8));
+      pf->ts_cap = need;
     }
     ts = pf->d_ts;
   }
+  pf->ts_blocks = ts_blocks; pf->ts_T = T;
   SeriesLaunch a;
   a.grid = plan.grid; a.stream = pf->stream; a.smem = plan.smem;
   a.obs = (pf->obs_kind == CSSM_OBS_POISSON || pf->obs_kind == CSSM_OBS_GAUSSIAN) ? pf->obs_kind : -1;
   a.state0 = pf->state[0]; a.state1 = pf->state[1]; a.stride = pf->stride; a.anc = pf->anc; a.logw = pf->logw;
   a.n = pf->n; a.seed = pf->seed; a.recs = pf->d_recs; a.T = (uint32_t)T; a.mk = pf->mk; a.sc = pf->sc; a.sync = pf->d_sync;
   a.logtab = pf->d_logtab; a.per_block = plan.per_block; a.cur0 = pf->cur; a.force_exact = pf->opt_exact;
-  a.ll_t = pf->d_ll_t; a.ess_t = pf->d_ess_t; a.path = d_path; a.ts = ts;
+  a.ll_t = pf->d_ll_t; a.ess_t = pf->d_ess_t; a.path = d_path; a.ts = ts; a.ts_blocks = ts_blocks;
   prof_begin(pf, CSSM_K_SERIES);
   hipError_t e = hipSuccess;
   CSSM_SER_DISPATCH(cssm_series_launch_d, pf->d, a);
@@ -867,16 +873,53 @@ static int run_filter_once(cssm_pf* pf, const double* t, const double* y, const 
   // sums (small handles: the PMMH case) the k_propagate of observation s + 1, which gathers exactly that state into the
   // thread of slot pick_s, records it on the way; otherwise a one-block launch per observation does.
   const bool fold = path && uses_sums_kernel(pf);
-  for (size_t s = 0; s < T && !pf->last_series; ++s) {
-    const int weighted = pf->h_recs[s].has_obs;
-    double* pick_out = (fold && s >= 1) ? pf->d_path + s * (size_t)d : nullptr;
-    rc = launch_step(pf, pf->d_recs + s, weighted, (uint32_t)s, pf->d_ll_t, pf->d_ess_t, (uint32_t)s, pick_out,
-                     s >= 1 ? pf->h_recs[s - 1].pick : 0u);
+  // Per-observation kernels, enqueued without a host round trip.  With the sums formed inside k_propagate (relative to each
+  // observation's reference level), an observation whose max rules its level out puts the series ON HOLD at that
+  // observation (err bit 6: every kernel behind it returns at once); the host then redoes that one observation's sums
+  // relative to the max (k_tile_sums + k_offspring, the log-weights are in place) and enqueues the rest again.
+  size_t s_from = 0;
+  while (!pf->last_series) {
+    pf->batch_hold = uses_sums_kernel(pf);
+    for (size_t s = s_from; s < T; ++s) {
+      const int weighted = pf->h_recs[s].has_obs;
+      double* pick_out = (fold && s >= 1) ? pf->d_path + s * (size_t)d : nullptr;
+      rc = launch_step(pf, pf->d_recs + s, weighted, (uint32_t)s, pf->d_ll_t, pf->d_ess_t, (uint32_t)s, pick_out,
+                       s >= 1 ? pf->h_recs[s - 1].pick : 0u);
+      if (rc) { pf->batch_hold = false; return rc; }
+      if (path && (!fold || s + 1 == T))   // (folded: only the last entry has no following propagate)
+        hipLaunchKernelGGL(k_pick, dim3(1), dim3(64), 0, pf->stream, pf->src, pf->src_stride,
+                           (const uint32_t*)(pf->anc_valid ? pf->anc : nullptr), (uint64_t)pf->h_recs[s].pick, d,
+                           pf->d_path + (s + 1) * (size_t)d);
+    }
+    const bool may_hold = pf->batch_hold;
+    pf->batch_hold = false;
+    if (!may_hold) break;
+    Scalars hh;
+    HIP_TRY(hipMemcpyAsync(&hh, pf->sc, sizeof hh, hipMemcpyDeviceToHost, pf->stream));
+    HIP_TRY(hipStreamSynchronize(pf->stream));
+    if (!(hh.err & 64u)) break;
+    if (hh.err & 3u) break;            // NaN / unusable weights: reported below
+    const size_t sf = hh.fail_step;
+    if (sf >= T) return fail(CSSM_ESTATE, "held series reports observation %zu of %zu", sf, T);
+    hh.err &= ~64u; hh.fail_step = 0xffffffffu;
+    HIP_TRY(hipMemcpyAsync(&pf->sc->err, &hh.err, sizeof(uint32_t), hipMemcpyHostToDevice, pf->stream));
+    HIP_TRY(hipMemcpyAsync(&pf->sc->fail_step, &hh.fail_step, sizeof(uint32_t), hipMemcpyHostToDevice, pf->stream));
+    // host-side state right after the propagate of observation sf (launch_init: cur = 0, wparity = 0; every propagate
+    // flips cur, every weighted observation flips wparity)
+    pf->cur = (int)((sf + 1) & 1);
+    pf->src = pf->state[pf->cur]; pf->src_stride = pf->stride; pf->anc_valid = false; pf->src2 = nullptr;
+    int wp = 0;
+    for (size_t q = 0; q < sf; ++q) wp ^= (pf->h_recs[q].has_obs ? 1 : 0);
+    pf->wparity = wp ^ 1;              // launch_resample(redo) flips it back to the set the step's k_propagate used
+    pf->last_optimistic = true;
+    pf->h_step_for_resample = (uint32_t)sf;
+    rc = launch_resample(pf, pf->d_recs + sf, pf->d_ll_t, pf->d_ess_t, (uint32_t)sf, /*redo=*/true);
     if (rc) return rc;
-    if (path && (!fold || s + 1 == T))   // (folded: only the last entry has no following propagate)
-      hipLaunchKernelGGL(k_pick, dim3(1), dim3(64), 0, pf->stream, pf->src, pf->src_stride,
-                         (const uint32_t*)(pf->anc_valid ? pf->anc : nullptr), (uint64_t)pf->h_recs[s].pick, d,
-                         pf->d_path + (s + 1) * (size_t)d);
+    if (path && (!fold || sf + 1 == T))
+      hipLaunchKernelGGL(k_pick, dim3(1), dim3(64), 0, pf->stream, pf->src, pf->src_stride, (const uint32_t*)pf->anc,
+                         (uint64_t)pf->h_recs[sf].pick, d, pf->d_path + (sf + 1) * (size_t)d);
+    s_from = sf + 1;
+    if (s_from >= T) break;
   }
   HIP_TRY(hipEventRecord(pf->ev1, pf->stream));
   HIP_TRY(hipGetLastError());
@@ -1030,6 +1073,7 @@ extern "C" int cssm_pf_set_option(cssm_pf* pf, int option, int value) {
 extern "C" int cssm_pf_profile(cssm_pf* pf, int enable) {
   if (!pf) return fail(CSSM_EINVAL_ARG, "null handle");
   pf->profile = enable != 0;
+  pf->profile_level = enable;
   pf->prof_used = 0;
   for (int k = 0; k < CSSM_NKERNELS; ++k) { pf->prof_ms[k] = 0.0; pf->prof_cnt[k] = 0; }
   return CSSM_OK;
@@ -1046,6 +1090,18 @@ extern "C" int cssm_pf_series_phases(cssm_pf* pf, int* used_series, double* phas
   if (used_series) *used_series = pf->last_series ? 1 : 0;
   if (phase_us) for (int k = 0; k < 4; ++k) phase_us[k] = pf->ser_phase_us[k];
   if (weighted_steps) *weighted_steps = pf->ser_phase_steps;
+  return CSSM_OK;
+}
+
+extern "C" int cssm_pf_series_stamps(cssm_pf* pf, uint64_t* out, size_t cap, uint32_t* blocks, uint32_t* steps) {
+  if (!pf) return fail(CSSM_EINVAL_ARG, "null handle");
+  if (blocks) *blocks = pf->ts_blocks;
+  if (steps) *steps = (uint32_t)pf->ts_T;
+  const size_t n = (size_t)pf->ts_blocks * pf->ts_T * CSSM_SER_TS_PER_STEP;
+  if (out) {
+    if (!pf->d_ts || !pf->last_series || cap < n) return fail(CSSM_ESTATE, "no stamps of a profiled series run (or the buffer is too small: %zu words)", n);
+    HIP_TRY(hipMemcpy(out, pf->d_ts, n * 8, hipMemcpyDeviceToHost));
+  }
   return CSSM_OK;
 }
 

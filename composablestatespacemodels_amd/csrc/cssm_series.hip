@@ -29,7 +29,7 @@ hipError_t CSSM_CAT(cssm_series_launch_d, CSSM_SER_D)(const SeriesLaunch& a) {
   uint64_t n = a.n, seed = a.seed;
   void* args[] = {(void*)&a.state0, (void*)&a.state1, (void*)&a.stride, (void*)&a.anc, (void*)&a.logw, (void*)&n, (void*)&seed,
                   (void*)&a.recs, (void*)&a.T, (void*)&a.mk, (void*)&a.sc, (void*)&sy, (void*)&a.logtab, (void*)&a.per_block,
-                  (void*)&a.cur0, (void*)&a.force_exact, (void*)&a.ll_t, (void*)&a.ess_t, (void*)&a.path, (void*)&a.ts};
+                  (void*)&a.cur0, (void*)&a.force_exact, (void*)&a.ll_t, (void*)&a.ess_t, (void*)&a.path, (void*)&a.ts, (void*)&a.ts_blocks};
   // cooperative: the runtime guarantees that all blocks are resident together (they spin on each other)
   return hipLaunchCooperativeKernel(series_kernel(a.obs), dim3(a.grid), dim3(CSSM_BLOCK), args, (unsigned)a.smem, a.stream);
 }

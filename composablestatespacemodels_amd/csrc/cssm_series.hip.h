@@ -318,7 +318,8 @@ __global__ __launch_bounds__(CSSM_BLOCK, CSSM_SER_WAVES) void k_series(
     double* __restrict__ state0, double* __restrict__ state1, size_t stride, uint32_t* __restrict__ anc, double* __restrict__ logw,
     uint64_t n_arg, uint64_t seed, const StepRec* __restrict__ recs, uint32_t T, ModelK mk, Scalars* __restrict__ sc,
     SeriesSync* __restrict__ sy, const double* __restrict__ logtab, uint32_t per_block, int cur0, int force_exact,
-    double* __restrict__ ll_t, int32_t* __restrict__ ess_t, double* __restrict__ path, unsigned long long* __restrict__ ts) {
+    double* __restrict__ ll_t, int32_t* __restrict__ ess_t, double* __restrict__ path, unsigned long long* __restrict__ ts_arg,
+    uint32_t ts_blocks) {
   constexpr int IT = SeriesItems<D>::value;
   constexpr int STAGE_BYTES = PropStage<D, IT>::bytes;
   constexpr int BUF_BYTES = STAGE_BYTES > CSSM_SER_CHUNK * 4 ? STAGE_BYTES : CSSM_SER_CHUNK * 4;
@@ -332,7 +333,9 @@ __global__ __launch_bounds__(CSSM_BLOCK, CSSM_SER_WAVES) void k_series(
   unsigned round = 0, xpar = 0;
   int cur = cur0;                 // state buffer holding the cloud the next observation reads
   bool via_anc = false;           // ... through the ancestor indices of the previous observation's resampling
-  const bool stamp = (ts != nullptr) && blockIdx.x == 0 && threadIdx.x == 0;
+  // profiling: thread 0 of the first ts_blocks blocks stamps its own row of T x 5 ticks (block 0 alone: the phase averages)
+  const bool stamp = (ts_arg != nullptr) && blockIdx.x < ts_blocks && threadIdx.x == 0;
+  unsigned long long* const ts = ts_arg + (size_t)blockIdx.x * T * CSSM_SER_TS_PER_STEP;
   for (uint32_t s = 0; s < T; ++s) {
     const StepRec* rec = recs + s;
     const int has_obs = rec->has_obs;

@@ -233,6 +233,9 @@ int cssm_pf_profile_read(cssm_pf* pf, double* total_ms, uint64_t* launches);
  * phase_us[0] = propagate + weight + sums, [1] = exchange (barrier + reduction of the sums), [2] = offspring + ancestors,
  * [3] = closing barrier.  Any pointer may be NULL. */
 int cssm_pf_series_phases(cssm_pf* pf, int* used_series, double* phase_us, uint64_t* weighted_steps);
+/* The raw stamps (cssm_pf_profile(pf, 2): every block stamps): out[(block * steps + s) * 5 + q], q = start, end of phase P, end
+ * of the exchange, end of phase O, end of the closing barrier; ticks of 10 ns.  out may be NULL to ask for the sizes. */
+int cssm_pf_series_stamps(cssm_pf* pf, uint64_t* out, size_t cap, uint32_t* blocks, uint32_t* steps);
 
 /* ---- diagnostics of the numerics contract --------------------------------------------------- */
 
