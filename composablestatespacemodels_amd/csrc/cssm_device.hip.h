@@ -410,3 +410,86 @@ __device__ __forceinline__ void finish_step(Scalars* sc, uint64_t n_global) {
   sc->ess = (e < 2147483647.0) ? (int32_t)fl : 2147483647;
 }
 
+// inclusive max-scan across the 64 lanes (values >= 0; a lane without a DPP source reads 0)
+__device__ __forceinline__ uint32_t wave_scan_max_u32(uint32_t v) {
+#define CSSM_MX(CTRL, RM) { const uint32_t o = dpp0<CTRL, RM>(v); v = (o > v) ? o : v; }
+  CSSM_MX(CSSM_DPP_ROW_SHR(1), 0xf) CSSM_MX(CSSM_DPP_ROW_SHR(2), 0xf) CSSM_MX(CSSM_DPP_ROW_SHR(4), 0xf)
+  CSSM_MX(CSSM_DPP_ROW_SHR(8), 0xf) CSSM_MX(CSSM_DPP_BCAST15, 0xa) CSSM_MX(CSSM_DPP_BCAST31, 0xc)
+#undef CSSM_MX
+  return v;
+}
+
+typedef uint32_t cssm_u32x4v __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void store_anc4_sc1(uint32_t* p, uint32_t a, uint32_t b, uint32_t c, uint32_t d) {
+  cssm_u32x4v v; v.x = a; v.y = b; v.z = c; v.w = d;
+  asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" : : "v"(p), "v"(v) : "memory");   // s_nop: store-data hazard, see CSSM_ST_MODE
+}
+
+
+#define CSSM_RUN_CHUNK 2048   /* resampling slots assembled in LDS at a time (8 KiB) */
+
+// findAllInTreeMap (model/Resampling.scala:36-46) for one tile of CSSM_TILE particles: thread t holds the end slots e[0..3]
+// of its four consecutive particles first_idx .. first_idx + 3 and the end slot `prev` of the particle before them; the
+// tile's particles own the slots [lo, hi) (uniform; already clipped to what this launch may write).  The ancestor indices
+// of those slots are assembled in LDS, 2048 at a time -- every particle drops its index + 1 at the first slot of its run,
+// an inclusive max-scan fills the runs (indices grow with the slots) -- and leave as 32 contiguous bytes per thread
+// (256-byte aligned chunks), so that HBM sees whole lines instead of one 4-byte write per slot (round 1: 1.38x the
+// algorithmic write traffic).  SC1: write-through stores (another block, or the next kernel's first wave, reads them).
+// anc is indexed by slot - slot_off; values are clamped to idx_max.  s_slot: CSSM_RUN_CHUNK words of LDS.  All threads call.
+template <bool SC1>
+__device__ __forceinline__ void fill_runs_tile(uint32_t prev, const uint32_t (&e)[CSSM_ITEMS], uint32_t first_idx, uint32_t lo, uint32_t hi,
+                                               uint32_t* __restrict__ anc, uint32_t slot_off, uint32_t idx_max, uint32_t* __restrict__ s_slot) {
+  __shared__ uint32_t s_wmax[CSSM_BLOCK / 64];
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  for (uint32_t c0 = lo & ~63u; c0 < hi; c0 += CSSM_RUN_CHUNK) {
+    uint4* z = reinterpret_cast<uint4*>(s_slot + threadIdx.x * 8);
+    z[0] = make_uint4(0u, 0u, 0u, 0u); z[1] = make_uint4(0u, 0u, 0u, 0u);
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < CSSM_ITEMS; ++r) {
+      uint32_t rb = (r == 0) ? prev : e[r - 1];
+      uint32_t re = e[r];
+      rb = (rb < lo) ? lo : rb;
+      re = (re > hi) ? hi : re;
+      if (re > rb && re > c0 && rb < c0 + CSSM_RUN_CHUNK) {
+        const uint32_t pos = ((rb > c0) ? rb : c0) - c0;
+        s_slot[pos] = first_idx + r + 1u;                 // index + 1 (0 = no run starts here)
+      }
+    }
+    __syncthreads();
+    const uint4 a = z[0], bq = z[1];
+    uint32_t v[8] = {a.x, a.y, a.z, a.w, bq.x, bq.y, bq.z, bq.w};
+#pragma unroll
+    for (int k = 1; k < 8; ++k) v[k] = (v[k - 1] > v[k]) ? v[k - 1] : v[k];
+    const uint32_t incl = wave_scan_max_u32(v[7]);
+    if (lane == 63) s_wmax[wid] = incl;
+    uint32_t carry = dpp0<0x138 /* wave_shr:1 */, 0xf>(incl);   // exclusive: max over the lanes before this one (lane 0: 0)
+    __syncthreads();
+    for (int w = 0; w < wid; ++w) carry = (s_wmax[w] > carry) ? s_wmax[w] : carry;
+    const uint32_t s0 = c0 + threadIdx.x * 8;              // first slot of this thread's piece
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      uint32_t x = (v[k] > carry) ? v[k] : carry;
+      x = (x > 0u) ? x - 1u : 0u;                           // (0 cannot occur inside [lo, hi): every slot there belongs to a run)
+      v[k] = (x > idx_max) ? idx_max : x;
+    }
+    uint32_t* dst = anc + (s0 - slot_off);                  // (only dereferenced for slots inside [lo, hi), lo >= slot_off)
+    if (s0 >= lo && s0 + 8 <= hi && ((s0 - slot_off) & 3u) == 0u) {
+      if (SC1) {
+        store_anc4_sc1(dst, v[0], v[1], v[2], v[3]);
+        store_anc4_sc1(dst + 4, v[4], v[5], v[6], v[7]);
+      } else {
+        *reinterpret_cast<uint4*>(dst) = make_uint4(v[0], v[1], v[2], v[3]);
+        *reinterpret_cast<uint4*>(dst + 4) = make_uint4(v[4], v[5], v[6], v[7]);
+      }
+    } else {
+#pragma unroll
+      for (int k = 0; k < 8; ++k)
+        if (s0 + k >= lo && s0 + k < hi) {
+          if (SC1) __hip_atomic_store(dst + k, v[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          else dst[k] = v[k];
+        }
+    }
+    __syncthreads();                                        // s_slot / s_wmax are rewritten by the next chunk
+  }
+}

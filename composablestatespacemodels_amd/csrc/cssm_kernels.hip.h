@@ -180,6 +180,10 @@ __global__ void k_global_sums(const unsigned long long* __restrict__ all4, int r
 #ifndef CSSM_OFF_WAVES
 #define CSSM_OFF_WAVES 4
 #endif
+// k_offspring's ancestor lines: 1 = write-through (sc1) stores, 0 = plain stores (dirty lines written back when the kernel ends)
+#ifndef CSSM_OFF_SC1
+#define CSSM_OFF_SC1 1
+#endif
 template <bool FUSE, bool SELF, int RS>
 __device__ __forceinline__ void offspring_body(const double* __restrict__ logw, uint64_t n,
                                                           Scalars* __restrict__ sc,
@@ -204,8 +208,8 @@ __device__ __forceinline__ void offspring_body(const double* __restrict__ logw, 
   const double* tab = nullptr; (void)logtab;
   __shared__ cssm_u128 s_w[CSSM_BLOCK / 64];
   __shared__ uint32_t s_last[CSSM_BLOCK / 64];
-  __shared__ uint32_t s_nheavy;
-  __shared__ uint32_t s_hb[FUSE ? CSSM_TILE : 1], s_he[FUSE ? CSSM_TILE : 1], s_hj[FUSE ? CSSM_TILE : 1];
+  __shared__ uint32_t s_tile_b;
+  __shared__ __attribute__((aligned(16))) uint32_t s_slot[FUSE ? CSSM_RUN_CHUNK : 4];
   __shared__ cssm_u128 s_r[3][CSSM_BLOCK / 64];
   // (batch series, single GPU) an earlier observation's reference level was ruled out by its max: the series is on hold at
   // that observation until the host has redone its sums (run_filter_once); nothing may change meanwhile
@@ -333,7 +337,6 @@ __device__ __forceinline__ void offspring_body(const double* __restrict__ logw, 
 #pragma unroll
       for (int r = 0; r < CSSM_ITEMS; ++r) { q[r] = cssm_fix_from_double(w1[r]); tsum = cssm_u128_add(tsum, q[r]); }
       cssm_u128 inc = wave_scan_u128(tsum, lane);
-      if (FUSE && threadIdx.x == 0) s_nheavy = 0;
       if (lane == 63) s_w[wid] = inc;
       __syncthreads();
       cssm_u128 off = toff;
@@ -400,32 +403,16 @@ __device__ __forceinline__ void offspring_body(const double* __restrict__ logw, 
                        ? (uint32_t)cssm_strat_count(Cp, seed, rec->step, n_global)
                        : (uint32_t)(pow2 ? cssm_sys_count_pow2(Cp, u, n_global, inv_n) : cssm_sys_count(Cp, u, n_global));
           }
-        }
-#pragma unroll
-        for (int r = 0; r < CSSM_ITEMS; ++r) {
-          uint32_t b = (r == 0) ? prev : e[r - 1];
-          uint32_t ee = e[r];
-          if (CLIP) {                               // keep the part of the run inside this rank's slots
-            b = (b < slot_lo) ? slot_lo : b;
-            ee = (ee > slot_hi) ? slot_hi : ee;
-            ee = (ee < b) ? b : ee;
-            b -= slot_lo; ee -= slot_lo;
-          }
-          const uint32_t len = ee - b;             // 0 for the padding items of a partial tile
-          const uint32_t jj = (uint32_t)(i0 + r);
-          if (len <= CSSM_RUN_DIRECT) {
-            for (uint32_t s = b; s < ee; ++s) anc[s] = jj;
-          } else {
-            const uint32_t h = atomicAdd(&s_nheavy, 1u);
-            s_hb[h] = b; s_he[h] = ee; s_hj[h] = jj;
-          }
+          if (wid == 0) s_tile_b = prev;
         }
         __syncthreads();
-        const uint32_t nh = s_nheavy;
-        for (uint32_t h = 0; h < nh; ++h) {
-          const uint32_t he = s_he[h], hj = s_hj[h];
-          for (uint32_t s = s_hb[h] + threadIdx.x; s < he; s += CSSM_BLOCK) anc[s] = hj;
-        }
+        // the slots the tile's particles own: [start of its first particle's run, end of its last particle's run), clipped
+        // to this launch's slots; their ancestors are assembled in LDS and written as whole lines (fill_runs_tile)
+        uint32_t tb = s_tile_b, te = s_last[CSSM_BLOCK / 64 - 1];
+        if (CLIP) { tb = (tb < slot_lo) ? slot_lo : tb; te = (te > slot_hi) ? slot_hi : te; }
+        te = (te > (uint32_t)n_global) ? (uint32_t)n_global : te;
+        tb = (tb > te) ? te : tb;
+        fill_runs_tile<CSSM_OFF_SC1 != 0>(prev, e, (uint32_t)i0, tb, te, anc, CLIP ? slot_lo : 0u, (uint32_t)(n - 1), s_slot);
       }
       // advance the running prefix by this tile's total
       cssm_u128 ttot = s_w[0];

@@ -153,33 +153,17 @@ __device__ __forceinline__ bool ser_sync(SeriesSync* __restrict__ sy, unsigned& 
   return ok;
 }
 
-// inclusive max-scan across the 64 lanes (values >= 0; a lane without a DPP source reads 0)
-__device__ __forceinline__ uint32_t wave_scan_max_u32(uint32_t v) {
-#define CSSM_MX(CTRL, RM) { const uint32_t o = dpp0<CTRL, RM>(v); v = (o > v) ? o : v; }
-  CSSM_MX(CSSM_DPP_ROW_SHR(1), 0xf) CSSM_MX(CSSM_DPP_ROW_SHR(2), 0xf) CSSM_MX(CSSM_DPP_ROW_SHR(4), 0xf)
-  CSSM_MX(CSSM_DPP_ROW_SHR(8), 0xf) CSSM_MX(CSSM_DPP_BCAST15, 0xa) CSSM_MX(CSSM_DPP_BCAST31, 0xc)
-#undef CSSM_MX
-  return v;
-}
-
-typedef uint32_t cssm_u32x4v __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ void ser_store_anc4(uint32_t* p, uint32_t a, uint32_t b, uint32_t c, uint32_t d) {
-  cssm_u32x4v v; v.x = a; v.y = b; v.z = c; v.w = d;
-  asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" : : "v"(p), "v"(v) : "memory");   // s_nop: store-data hazard, see CSSM_ST_MODE
-}
-
 // Phase O of one weighted observation for the block's particles [range_lo, range_lo + cnt): log-weights in s_lw.
 // treeEcdf + findAllInTreeMap of model/Resampling.scala:36-58,69 exactly as k_offspring computes them (same contract
 // functions, same fast path for the end slot); the ancestor indices of the slots the block's particles own are assembled
 // in LDS -- every particle drops its index + 1 at the first slot of its run, an inclusive max-scan fills the runs (indices
 // grow with the slots) -- and leave as whole 32-byte pieces per thread, write-through.
-// s_slot: CSSM_SER_CHUNK words of LDS.
+// s_slot: CSSM_RUN_CHUNK words of LDS.
 __device__ __forceinline__ void series_offspring(const double* __restrict__ s_lw, uint32_t range_lo, uint32_t cnt, double level,
                                                  cssm_u128 pre, cssm_u128 tot, double u, uint64_t n_global, uint32_t* __restrict__ anc,
                                                  int force_exact, uint32_t* __restrict__ s_slot) {
   __shared__ cssm_u128 s_w[CSSM_BLOCK / 64];
   __shared__ uint32_t s_last[CSSM_BLOCK / 64];
-  __shared__ uint32_t s_wmax[CSSM_BLOCK / 64];
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   const bool pow2 = (n_global & (n_global - 1)) == 0;
   const double inv_n = 1.0 / (double)n_global;
@@ -234,49 +218,7 @@ __device__ __forceinline__ void series_offspring(const double* __restrict__ s_lw
     // defensive bounds (a NaN total or a broken invariant must never become a wild store): slots live in [0, N]
     tile_e = (tile_e > (uint32_t)n_global) ? (uint32_t)n_global : tile_e;
     tile_b = (tile_b > tile_e) ? tile_e : tile_b;
-    // ---- the runs, chunk by chunk: chunk = slots [c0, c0 + CSSM_SER_CHUNK), c0 a multiple of 64 (256-byte lines)
-    for (uint32_t c0 = tile_b & ~63u; c0 < tile_e; c0 += CSSM_SER_CHUNK) {
-      uint4* z = reinterpret_cast<uint4*>(s_slot + threadIdx.x * 8);
-      z[0] = make_uint4(0u, 0u, 0u, 0u); z[1] = make_uint4(0u, 0u, 0u, 0u);
-      __syncthreads();
-#pragma unroll
-      for (int r = 0; r < CSSM_ITEMS; ++r) {
-        uint32_t rb = (r == 0) ? prev : e[r - 1];
-        uint32_t re = e[r];
-        rb = (rb < tile_b) ? tile_b : rb;
-        re = (re > tile_e) ? tile_e : re;
-        if (re > rb && re > c0 && rb < c0 + CSSM_SER_CHUNK) {
-          const uint32_t pos = ((rb > c0) ? rb : c0) - c0;
-          s_slot[pos] = range_lo + p0 + r + 1u;            // index + 1 (0 = no run starts here)
-        }
-      }
-      __syncthreads();
-      uint4 a = z[0], bq = z[1];
-      uint32_t v[8] = {a.x, a.y, a.z, a.w, bq.x, bq.y, bq.z, bq.w};
-#pragma unroll
-      for (int k = 1; k < 8; ++k) v[k] = (v[k - 1] > v[k]) ? v[k - 1] : v[k];
-      const uint32_t incl = wave_scan_max_u32(v[7]);
-      if (lane == 63) s_wmax[wid] = incl;
-      uint32_t carry = dpp0<0x138 /* wave_shr:1 */, 0xf>(incl);   // exclusive: max over the lanes before this one (lane 0: 0)
-      __syncthreads();
-      for (int w = 0; w < wid; ++w) carry = (s_wmax[w] > carry) ? s_wmax[w] : carry;
-      const uint32_t s0 = c0 + threadIdx.x * 8;            // first slot of this thread's piece
-#pragma unroll
-      for (int k = 0; k < 8; ++k) {
-        uint32_t x = (v[k] > carry) ? v[k] : carry;
-        x = (x > 0u) ? x - 1u : 0u;                         // (0 cannot occur inside [tile_b, tile_e); see "defensive" above)
-        v[k] = (x > n_last) ? n_last : x;
-      }
-      if (s0 >= tile_b && s0 + 8 <= tile_e) {
-        ser_store_anc4(anc + s0, v[0], v[1], v[2], v[3]);
-        ser_store_anc4(anc + s0 + 4, v[4], v[5], v[6], v[7]);
-      } else {
-#pragma unroll
-        for (int k = 0; k < 8; ++k)
-          if (s0 + k >= tile_b && s0 + k < tile_e) __hip_atomic_store(anc + s0 + k, v[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      }
-      __syncthreads();                                      // s_slot / s_wmax are rewritten by the next chunk
-    }
+    fill_runs_tile<true>(prev, e, range_lo + p0, tile_b, tile_e, anc, 0u, n_last, s_slot);
     // ---- next tile
     cssm_u128 ttot = s_w[0];
 #pragma unroll
@@ -322,7 +264,7 @@ __global__ __launch_bounds__(CSSM_BLOCK, CSSM_SER_WAVES) void k_series(
     uint32_t ts_blocks) {
   constexpr int IT = SeriesItems<D>::value;
   constexpr int STAGE_BYTES = PropStage<D, IT>::bytes;
-  constexpr int BUF_BYTES = STAGE_BYTES > CSSM_SER_CHUNK * 4 ? STAGE_BYTES : CSSM_SER_CHUNK * 4;
+  constexpr int BUF_BYTES = STAGE_BYTES > CSSM_RUN_CHUNK * 4 ? STAGE_BYTES : CSSM_RUN_CHUNK * 4;
   __shared__ __attribute__((aligned(16))) unsigned char s_buf[BUF_BYTES];   // phase P: LDS staging; phase O: slot chunk
   extern __shared__ __attribute__((aligned(16))) double s_lw[];             // per_block log-weights
   const double* tab = stage_log_table(logtab);
