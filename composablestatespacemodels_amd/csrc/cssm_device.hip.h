@@ -473,7 +473,9 @@ __device__ __forceinline__ void fill_runs_tile(uint32_t prev, const uint32_t (&e
       x = (x > 0u) ? x - 1u : 0u;                           // (0 cannot occur inside [lo, hi): every slot there belongs to a run)
       v[k] = (x > idx_max) ? idx_max : x;
     }
-    uint32_t* dst = anc + (s0 - slot_off);                  // (only dereferenced for slots inside [lo, hi), lo >= slot_off)
+    // (signed: a chunk starts on a 64-slot boundary at or below lo, which can lie below slot_off; only slots inside
+    //  [lo, hi), lo >= slot_off, are dereferenced)
+    uint32_t* dst = anc + ((long long)s0 - (long long)slot_off);
     if (s0 >= lo && s0 + 8 <= hi && ((s0 - slot_off) & 3u) == 0u) {
       if (SC1) {
         store_anc4_sc1(dst, v[0], v[1], v[2], v[3]);
