@@ -10,7 +10,7 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "csrc", "libcssm_pf.so")
+LIB_PATH = os.environ.get("CSSM_PF_LIB") or os.path.join(HERE, "csrc", "libcssm_pf.so")   # (CSSM_PF_LIB: an experiment build, tools/)
 
 # ---- constants (include/cssm_pf.h) ---------------------------------------------------------
 CSSM_OK = 0

@@ -184,6 +184,10 @@ __global__ void k_global_sums(const unsigned long long* __restrict__ all4, int r
 #ifndef CSSM_OFF_SC1
 #define CSSM_OFF_SC1 1
 #endif
+// 1: a tile's ancestor runs are assembled in LDS and written as whole lines; 0: every particle writes its own run
+#ifndef CSSM_OFF_LINES
+#define CSSM_OFF_LINES 1
+#endif
 template <bool FUSE, bool SELF, int RS>
 __device__ __forceinline__ void offspring_body(const double* __restrict__ logw, uint64_t n,
                                                           Scalars* __restrict__ sc,
@@ -209,7 +213,8 @@ __device__ __forceinline__ void offspring_body(const double* __restrict__ logw, 
   __shared__ cssm_u128 s_w[CSSM_BLOCK / 64];
   __shared__ uint32_t s_last[CSSM_BLOCK / 64];
   __shared__ uint32_t s_tile_b;
-  __shared__ __attribute__((aligned(16))) uint32_t s_slot[FUSE ? CSSM_RUN_CHUNK : 4];
+  __shared__ uint32_t s_nheavy;
+  __shared__ __attribute__((aligned(16))) uint32_t s_slot[FUSE ? 3 * CSSM_TILE : 4];   // a 2048-slot chunk / up to 1024 long runs
   __shared__ cssm_u128 s_r[3][CSSM_BLOCK / 64];
   // (batch series, single GPU) an earlier observation's reference level was ruled out by its max: the series is on hold at
   // that observation until the host has redone its sums (run_filter_once); nothing may change meanwhile
@@ -406,6 +411,7 @@ __device__ __forceinline__ void offspring_body(const double* __restrict__ logw, 
           if (wid == 0) s_tile_b = prev;
         }
         __syncthreads();
+#if CSSM_OFF_LINES
         // the slots the tile's particles own: [start of its first particle's run, end of its last particle's run), clipped
         // to this launch's slots; their ancestors are assembled in LDS and written as whole lines (fill_runs_tile)
         uint32_t tb = s_tile_b, te = s_last[CSSM_BLOCK / 64 - 1];
@@ -413,6 +419,36 @@ __device__ __forceinline__ void offspring_body(const double* __restrict__ logw, 
         te = (te > (uint32_t)n_global) ? (uint32_t)n_global : te;
         tb = (tb > te) ? te : tb;
         fill_runs_tile<CSSM_OFF_SC1 != 0>(prev, e, (uint32_t)i0, tb, te, anc, CLIP ? slot_lo : 0u, (uint32_t)(n - 1), s_slot);
+#else
+        // every particle writes its own run of slots (runs longer than CSSM_RUN_DIRECT: the whole block)
+        if (threadIdx.x == 0) s_nheavy = 0;
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < CSSM_ITEMS; ++r) {
+          uint32_t b = (r == 0) ? prev : e[r - 1];
+          uint32_t ee = e[r];
+          if (CLIP) {                               // keep the part of the run inside this rank's slots
+            b = (b < slot_lo) ? slot_lo : b;
+            ee = (ee > slot_hi) ? slot_hi : ee;
+            ee = (ee < b) ? b : ee;
+            b -= slot_lo; ee -= slot_lo;
+          }
+          const uint32_t len = ee - b;             // 0 for the padding items of a partial tile
+          const uint32_t jj = (uint32_t)(i0 + r);
+          if (len <= CSSM_RUN_DIRECT) {
+            for (uint32_t s = b; s < ee; ++s) anc[s] = jj;
+          } else {
+            const uint32_t h = atomicAdd(&s_nheavy, 1u);
+            s_slot[3 * h] = b; s_slot[3 * h + 1] = ee; s_slot[3 * h + 2] = jj;
+          }
+        }
+        __syncthreads();
+        const uint32_t nh = s_nheavy;
+        for (uint32_t h = 0; h < nh; ++h) {
+          const uint32_t he = s_slot[3 * h + 1], hj = s_slot[3 * h + 2];
+          for (uint32_t s = s_slot[3 * h] + threadIdx.x; s < he; s += CSSM_BLOCK) anc[s] = hj;
+        }
+#endif
       }
       // advance the running prefix by this tile's total
       cssm_u128 ttot = s_w[0];

@@ -36,7 +36,7 @@ static int fail(int code, const char* fmt, ...) {
   } while (0)
 
 extern "C" const char* cssm_last_error(void) { return g_err.c_str(); }
-extern "C" const char* cssm_version(void) { return "cssm_pf 0.2 (gfx950, numerics contract v4)"; }
+extern "C" const char* cssm_version(void) { return "cssm_pf 0.3 (gfx950, numerics contract v5)"; }
 
 // ------------------------------------------------------------------------------------ handle
 
@@ -83,7 +83,7 @@ struct cssm_pf {
   int wparity = 0;             // max-slot set of the next weighted step (single-GPU path)
   int opt_exact = 0;           // CSSM_OPT_EXACT_OFFSPRING
   int opt_fused = 0;           // CSSM_OPT_FUSED_SUMS (set to 1 for sharded handles at creation)
-  int opt_series = 1;          // CSSM_OPT_SERIES_KERNEL: batch drivers run the persistent series kernel when the handle is eligible
+  int opt_series = 0;          // CSSM_OPT_SERIES_KERNEL: 1 = batch drivers run the persistent series kernel when the handle is eligible (opt-in, see cssm_pf.h)
   // persistent series kernel (cssm_series.hip.h)
   void* d_sync = nullptr;      // SeriesSync
   int ser_blocks_max = -1;     // CUs of a device that can launch cooperatively (-1: not asked yet, 0: it cannot)
@@ -433,7 +433,8 @@ static int create_common(const cssm_model_desc* desc, uint64_t n_global, uint64_
   pf->device = device;
   pf->n_global = n_global; pf->first = first; pf->n = n_local; pf->seed = seed; pf->sharded = sharded;
   if (sharded) { pf->stream = (hipStream_t)stream; pf->own_stream = false; pf->opt_fused = 1; }
-  else pf->opt_fused = 1;   // two launches per observation at every size: an outlying observation is redone in place (run_filter_once)
+  else if (n_local <= (1ull << 18)) pf->opt_fused = 1;   // launch-latency-bound sizes: two launches per observation beat three (20.8 vs 21.7 us at N = 100 000); at 2^20
+                                                          // both cost 38.7 us and at 2^24 the lean kernels win (413 vs 441 us): k_propagate is VALU-bound, the sums are not free in it
   int rc = build_model(pf, desc, false);
   if (rc == CSSM_OK) rc = alloc_handle(pf);
   if (rc != CSSM_OK) { std::string keep = g_err; cssm_pf_destroy(pf); g_err = keep; return rc; }

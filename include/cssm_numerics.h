@@ -14,7 +14,7 @@
  * section 7 ("hard parts") names this; the contract removes it.
  *
  * What the contract fixes:
- *   1. Philox4x32-10 (Salmon et al., SC'11), counter layout cssm_philox_ctr() below.  It
+ *   1. Philox4x32-7 (Salmon et al., SC'11; seven rounds since contract v5), counter layout cssm_philox_ctr() below.  It
  *      replaces the reference's unseeded global generators (breeze Rand at
  *      model/Sde.scala:13, scala.util.Random at model/Resampling.scala:66,152).
  *   2. cssm_exp / cssm_log / cssm_sincos2pi / Box-Muller: fixed polynomial evaluations
@@ -121,7 +121,7 @@ CSSM_HD double cssm_fma_k(double a, double b, double k) {
  * mantissa bits (ulp = 1), in two's complement.  Plain IEEE additions: the same on every machine. */
 #define CSSM_SHIFTER 0x1.8p52
 
-/* ------------------------------------------------------------------ Philox4x32-10 */
+/* ------------------------------------------------------------------ Philox4x32 (7 rounds; contract v5) */
 
 typedef struct { uint32_t v[4]; } cssm_u32x4;
 
@@ -130,26 +130,38 @@ typedef struct { uint32_t v[4]; } cssm_u32x4;
 #define CSSM_PHILOX_W0 0x9E3779B9u
 #define CSSM_PHILOX_W1 0xBB67AE85u
 
-CSSM_HD cssm_u32x4 cssm_philox4x32_10(cssm_u32x4 c, uint32_t k0, uint32_t k1) {
+/* R rounds of Philox4x32 (Salmon et al., SC'11; the Random123 round function and Weyl key schedule). */
 #if defined(__HIPCC__) && !defined(CSSM_PHILOX_NO_UNROLL)
-#pragma unroll
+#define CSSM_PHILOX_UNROLL _Pragma("unroll")
 #elif defined(__HIPCC__)
-#pragma unroll 1
+#define CSSM_PHILOX_UNROLL _Pragma("unroll 1")
+#else
+#define CSSM_PHILOX_UNROLL
 #endif
-  for (int r = 0; r < 10; ++r) {
-    uint64_t p0 = (uint64_t)CSSM_PHILOX_M0 * c.v[0];
-    uint64_t p1 = (uint64_t)CSSM_PHILOX_M1 * c.v[2];
-    cssm_u32x4 n;
-    n.v[0] = (uint32_t)(p1 >> 32) ^ c.v[1] ^ k0;
-    n.v[1] = (uint32_t)p1;
-    n.v[2] = (uint32_t)(p0 >> 32) ^ c.v[3] ^ k1;
-    n.v[3] = (uint32_t)p0;
-    c = n;
-    k0 += CSSM_PHILOX_W0;
-    k1 += CSSM_PHILOX_W1;
-  }
+#define CSSM_PHILOX_BODY(R)                                                    \
+  CSSM_PHILOX_UNROLL                                                           \
+  for (int r = 0; r < (R); ++r) {                                              \
+    uint64_t p0 = (uint64_t)CSSM_PHILOX_M0 * c.v[0];                           \
+    uint64_t p1 = (uint64_t)CSSM_PHILOX_M1 * c.v[2];                           \
+    cssm_u32x4 n;                                                              \
+    n.v[0] = (uint32_t)(p1 >> 32) ^ c.v[1] ^ k0;                               \
+    n.v[1] = (uint32_t)p1;                                                     \
+    n.v[2] = (uint32_t)(p0 >> 32) ^ c.v[3] ^ k1;                               \
+    n.v[3] = (uint32_t)p0;                                                     \
+    c = n;                                                                     \
+    k0 += CSSM_PHILOX_W0;                                                      \
+    k1 += CSSM_PHILOX_W1;                                                      \
+  }                                                                            \
   return c;
-}
+/* the 10-round generator of the Random123 known-answer vectors (tests: the round function and key schedule are right) */
+CSSM_HD cssm_u32x4 cssm_philox4x32_10(cssm_u32x4 c, uint32_t k0, uint32_t k1) { CSSM_PHILOX_BODY(10) }
+/* The generator of the contract (v5): SEVEN rounds.  Philox4x32-7 is the smallest round count the Random123 authors report as
+ * passing BigCrush ("Crush-resistant"; 10 is their default for margin); every variate of the filter comes from it.  The
+ * fused kernel is VALU-bound and Philox is its largest single item: three rounds fewer are 18 of ~60 VALU instructions
+ * per block, 1.5 blocks per particle-step at d = 3.  (Contract v4 used 10 rounds; any fixed seed defines one realisation
+ * of the same algorithm under either.) */
+#define CSSM_PHILOX_ROUNDS 7
+CSSM_HD cssm_u32x4 cssm_philox4x32(cssm_u32x4 c, uint32_t k0, uint32_t k1) { CSSM_PHILOX_BODY(CSSM_PHILOX_ROUNDS) }
 
 /* Stream tags (bits 28..31 of counter word 3). */
 #define CSSM_STREAM_STEP 0u   /* transition noise of filter step `step` (observation index) */
@@ -181,7 +193,7 @@ CSSM_HD cssm_u32x4 cssm_philox_draw(uint64_t seed, uint64_t gid, uint32_t step, 
   c.v[1] = (uint32_t)(gid >> 32);
   c.v[2] = step;
   c.v[3] = (tag << 28) | (pair & 0x0FFFFFFFu);
-  return cssm_philox4x32_10(c, (uint32_t)seed, (uint32_t)(seed >> 32));
+  return cssm_philox4x32(c, (uint32_t)seed, (uint32_t)(seed >> 32));
 }
 
 /* The Philox key of the `run`-th filter run a driver makes under one user seed (PMMH: one run per MCMC iteration,

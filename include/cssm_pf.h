@@ -203,12 +203,16 @@ int cssm_pf_last_loop_ms(cssm_pf* pf, float* ms_out);
  * per observation, 363 vs 366 us at 2^24) but a series with an outlying observation runs twice, and the lean propagate
  * kernel is the one the roofline figure is quoted on. */
 #define CSSM_OPT_FUSED_SUMS 3
-/* CSSM_OPT_SERIES_KERNEL (default 1): the batch drivers (cssm_pf_ll_filter, cssm_pf_filter, cssm_pmmh_run) run all T
+/* CSSM_OPT_SERIES_KERNEL (default 0): 1 = the batch drivers (cssm_pf_ll_filter, cssm_pf_filter, cssm_pmmh_run) run all T
  * observations in ONE cooperative launch of a persistent kernel -- propagate + weight + sums, a grid barrier that also
  * reduces the sums, offspring + ancestors, a second grid barrier, per observation; log-weights stay in LDS -- whenever the
- * handle is eligible: systematic resampling, not LGCP, not sharded, at most 2048 particles per co-resident block (N <= 2^21
- * on MI355X).  0 = always the per-observation kernels (identical results; the tested fallback, and what streaming
- * cssm_pf_step always uses).  A step boundary then costs a barrier (~3 us) instead of a kernel launch (~5-10 us). */
+ * handle is eligible: systematic resampling, not LGCP, not sharded, at most 1024 co-resident blocks of at most 2048
+ * particles (N <= 1.5 M for d = 3 on MI355X).  Identical results (tests/test_gpu_series.py).  Opt-in because it does not pay
+ * on MI355X as measured: a step boundary costs grid barriers instead of launches, but every datum
+ * that crosses blocks inside a kernel has to bypass the per-XCD L2 (sc1) at ~0.8 us per dependent round trip, 16 of them
+ * per observation: 19.8 vs 20.8 us per observation at N = 100 000 and 45.4 vs 38.7 us at N = 2^20, where the resident
+ * waves' fixed ages also skew the propagate phase (13 us for a CU's oldest block, 28 us for its youngest).  A cooperative
+ * launch also has the GPU to itself: two chains on two streams no longer overlap. */
 #define CSSM_OPT_SERIES_KERNEL 4
 int cssm_pf_set_option(cssm_pf* pf, int option, int value);
 

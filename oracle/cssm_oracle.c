@@ -854,6 +854,11 @@ void oracle_c_philox(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[
   c = cssm_philox4x32_10(c, key[0], key[1]);
   memcpy(out, c.v, 16);
 }
+void oracle_c_philox_contract(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]) {   /* the contract's round count */
+  cssm_u32x4 c; memcpy(c.v, ctr, 16);
+  c = cssm_philox4x32(c, key[0], key[1]);
+  memcpy(out, c.v, 16);
+}
 void oracle_c_normals(uint64_t seed, uint64_t gid, uint32_t step, uint32_t tag, uint32_t pair, double* z2) {
   cssm_normal_pair(cssm_philox_draw(seed, gid, step, tag, pair), CSSM_LOG_TAB, &z2[0], &z2[1]);
 }

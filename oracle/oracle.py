@@ -89,6 +89,7 @@ def lib() -> C.CDLL:
             "oracle_c_exp": (C.c_double, [C.c_double]),
             "oracle_c_log": (C.c_double, [C.c_double]),
             "oracle_c_philox": (None, [_u32p, _u32p, _u32p]),
+            "oracle_c_philox_contract": (None, [_u32p, _u32p, _u32p]),
             "oracle_c_normals": (None, [C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, _dp]),
             "oracle_c_log_unit_v": (None, [_dp, _dp, C.c_size_t]),
             "oracle_c_fix_v": (None, [_dp, C.POINTER(C.c_uint64), C.c_size_t]),
@@ -278,6 +279,12 @@ def c_sincos2pi(u):
 def c_philox(ctr, key):
     ctr = np.asarray(ctr, dtype=np.uint32); key = np.asarray(key, dtype=np.uint32); out = np.zeros(4, dtype=np.uint32)
     lib().oracle_c_philox(_p(ctr, _u32p), _p(key, _u32p), _p(out, _u32p)); return out
+
+
+def c_philox_contract(ctr, key):
+    """The generator every variate of the contract comes from (Philox4x32 with CSSM_PHILOX_ROUNDS = 7 rounds)."""
+    ctr = np.asarray(ctr, dtype=np.uint32); key = np.asarray(key, dtype=np.uint32); out = np.zeros(4, dtype=np.uint32)
+    lib().oracle_c_philox_contract(_p(ctr, _u32p), _p(key, _u32p), _p(out, _u32p)); return out
 
 
 def c_normals(seed, gid0, step, tag, pair, n):

@@ -1,5 +1,5 @@
-"""-m gpu: the persistent series kernel (one cooperative launch per batch run, cssm_series.hip.h) against the oracle AND
-against the per-observation kernels it replaces (CSSM_OPT_SERIES_KERNEL = 0, the tested fallback): ll, ll_t, ess_t, the
+"""-m gpu: the persistent series kernel (one cooperative launch per batch run, cssm_series.hip.h; opt-in through
+CSSM_OPT_SERIES_KERNEL = 1) against the oracle AND against the per-observation kernels (the default): ll, ll_t, ess_t, the
 sampled path, the final ancestors, log-weights and cloud must be identical bit for bit.
 """
 import numpy as np
@@ -113,6 +113,7 @@ def test_series_kernel_forced_exact_offspring_and_reuse_of_a_handle():
     t, y, has = cases.poisson_counts(12, missing=0.1)
     n = 50_000
     g = NativePf(model, n, cases.SEED)
+    g.set_option(OPT_SERIES, 1)
     r1 = g.run(t, y, has)
     g.set_option(1, 1)                       # CSSM_OPT_EXACT_OFFSPRING: the contract's exact count for every particle
     r2 = g.run(t, y, has)
@@ -133,6 +134,7 @@ def test_series_kernel_then_streaming_continues_the_same_filter():
     t, y, has = cases.poisson_counts(10)
     n = 20_000
     g = NativePf(model, n, cases.SEED)
+    g.set_option(OPT_SERIES, 1)
     g.run(t[:6], y[:6], has[:6])
     assert g.series_phases()[0]
     o = oracle.OraclePf(model.descriptor(), n, cases.SEED)
@@ -149,6 +151,7 @@ def test_series_kernel_phase_timestamps():
     model = cases.c2_model()
     t, y, has = cases.poisson_counts(30)
     g = NativePf(model, 1 << 18, cases.SEED)
+    g.set_option(OPT_SERIES, 1)
     g.profile(True)
     g.run(t, y, has)
     used, ph, steps = g.series_phases()
