@@ -49,7 +49,11 @@ struct ModelK {
   int32_t d;
   int32_t obs_kind;
   uint32_t comp[CSSM_MAX_DIM / 4];
+#ifdef CSSM_EXPERIMENT_FIXED_C2   /* experiment: the bench model's per-component flags as compile-time constants */
+  __host__ __device__ __forceinline__ uint32_t byte(int k) const { return k == 0 ? 0x36u : (k == 1 ? 0x06u : 0x1au); }
+#else
   __host__ __device__ __forceinline__ uint32_t byte(int k) const { return (comp[k >> 2] >> ((k & 3) * 8)) & 0xffu; }
+#endif
   __host__ __device__ __forceinline__ int kind(int k) const { return (int)(byte(k) & 3u); }
   __host__ __device__ __forceinline__ int fmode(int k) const { return (int)((byte(k) >> 2) & 3u); }
   __host__ __device__ __forceinline__ bool leaf_end(int k) const { return (byte(k) >> 4) & 1u; }

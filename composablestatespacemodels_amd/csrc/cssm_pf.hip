@@ -374,7 +374,10 @@ static void build_rec(const cssm_pf* pf, double t_prev, double t, double y, int 
 
 // ------------------------------------------------------------------------------------ create / destroy
 
-static int prop_items(int d) { return d <= 2 ? 4 : (d <= 8 ? CSSM_PROP_IT_MID : 1); }   // PropItems<D>
+#ifndef CSSM_PROP_IT_LO
+#define CSSM_PROP_IT_LO 2
+#endif
+static int prop_items(int d) { return d <= 2 ? CSSM_PROP_IT_LO : (d <= 8 ? CSSM_PROP_IT_MID : 1); }   // PropItems<D>
 
 static int alloc_handle(cssm_pf* pf) {
   HIP_TRY(hipSetDevice(pf->device));

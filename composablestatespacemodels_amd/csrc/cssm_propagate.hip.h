@@ -4,9 +4,16 @@
 
 #include "cssm_device.hip.h"
 
-// Particles per thread in k_propagate: all gathers of a thread are issued before its ALU work,
-// and rows are stored as 16-/32-byte vectors.
-template <int D> struct PropItems { static constexpr int value = (D <= 2) ? 4 : (D <= 8 ? CSSM_PROP_IT_MID : 1); };
+// Particles per thread in k_propagate: all gathers of a thread are issued before its ALU work, and rows are stored as
+// 16-byte vectors.  Two per thread for every d <= 8: a wave's store instruction then covers 1 KiB contiguously, which is
+// what the write-through (sc1) stores need -- with four per thread (round 1's layout for d <= 2: two 16-byte stores per
+// lane, 32 bytes apart) they lost the L2's write combining and the plain stores that layout fell back to left the
+// launch's dirty lines to its end: k_propagate<1> 115 -> 93 us at N = 2^24 (0.43 -> 0.54 of the HBM peak), 13.8 -> 11.8 us
+// at 2^20.
+#ifndef CSSM_PROP_IT_LO
+#define CSSM_PROP_IT_LO 2
+#endif
+template <int D> struct PropItems { static constexpr int value = (D <= 2) ? CSSM_PROP_IT_LO : (D <= 8 ? CSSM_PROP_IT_MID : 1); };
 
 
 // stepFilter lines :118 and :123-124 fused (LGCP: calcWeight :184-208).  src is read through

@@ -7,12 +7,12 @@ import subprocess
 import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-SRC = os.path.join(HERE, "..", "composablestatespacemodels_amd", "csrc", "cssm_pf.hip")
+SRC = os.path.join(HERE, "..", "composablestatespacemodels_amd", "csrc", os.environ.get("ISA_SRC", "cssm_pf.hip"))
 OUT = "/tmp/cssm_isa"
 os.makedirs(OUT, exist_ok=True)
 subprocess.run(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "-ffp-contract=off", "-mfma", "--offload-arch=gfx950",
                 "-save-temps=obj", *sys.argv[4:], "-c", SRC, "-o", os.path.join(OUT, "x.o")], capture_output=True)
-s = open(os.path.join(OUT, "cssm_pf-hip-amdgcn-amd-amdhsa-gfx950.s")).read()
+s = open(os.path.join(OUT, os.path.splitext(os.environ.get("ISA_SRC", "cssm_pf.hip"))[0] + "-hip-amdgcn-amd-amdhsa-gfx950.s")).read()
 want = sys.argv[1] if len(sys.argv) > 1 else "k_propagate<3, false>"
 for m in re.finditer(r"^(_Z\w+):[^\n]*\n(.*?)^\.Lfunc_end", s, re.S | re.M):
     name = subprocess.run(["c++filt", m.group(1)], capture_output=True, text=True).stdout.strip()
