@@ -74,6 +74,9 @@ struct StepRec {
   uint32_t step;  // observation index (Philox counter word 2)
   double coef[CSSM_MAX_DIM][4]; // transition coefficients per component
   double fco[CSSM_MAX_DIM];     // f coefficients c_k(t)
+  double t_obs;                 // the observation's time (LGCP with a time-dependent f: the sub-step clock starts here)
+  uint32_t fsub_off;            // LGCP with a time-dependent f: where this observation's n_sub x d coefficients c_k(tau_s) start
+  uint32_t pad2_;               //   in the handle's sub-step table (doubles)
 };
 
 // Device scalars of a handle.
@@ -264,16 +267,20 @@ __device__ __forceinline__ void propagate_one(const ModelK& mk, const StepRec* _
 
 // gamma = f(x, t): per-leaf dot product, leaves summed left-nested (model/Model.scala:122-128,217-225,271)
 template <int D>
-__device__ __forceinline__ double gamma_of(const ModelK& mk, const StepRec* __restrict__ rec, const double (&x)[D]) {
+__device__ __forceinline__ double gamma_coef(const ModelK& mk, const double* __restrict__ fco, const double (&x)[D]) {
   double g = 0.0, acc = 0.0;
 #pragma unroll
   for (int k = 0; k < D; ++k) {
     const int fm = mk.fmode(k);
-    if (fm == FM_START) acc = rec->fco[k] * x[k];
-    else if (fm == FM_ADD) acc = acc + rec->fco[k] * x[k];
+    if (fm == FM_START) acc = fco[k] * x[k];
+    else if (fm == FM_ADD) acc = acc + fco[k] * x[k];
     if (mk.leaf_end(k)) g = mk.first_leaf(k) ? acc : g + acc;
   }
   return g;
+}
+template <int D>
+__device__ __forceinline__ double gamma_of(const ModelK& mk, const StepRec* __restrict__ rec, const double (&x)[D]) {
+  return gamma_coef<D>(mk, rec->fco, x);
 }
 
 // dataLikelihood(gamma, y) of the leftmost leaf; the branch is wave-uniform (mk is a kernel argument).

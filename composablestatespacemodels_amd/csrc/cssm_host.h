@@ -19,6 +19,7 @@ struct PropLaunch {
   const StepRec* rec; ModelK mk; Scalars* sc; int slot_set;
   const double* src2; size_t src2_stride; uint32_t n_split; const double* logtab;
   uint64_t chunk; int do_sums; cssm_u128* subS; cssm_u128* subS2; double* pick_out; uint32_t pick_slot;
+  const double* fsub;  // LGCP with a time-dependent f: the sub-step coefficient table (else nullptr)
 };
 
 // one per latent dimension, defined in cssm_prop.hip

@@ -213,7 +213,9 @@ __device__ __forceinline__ void offspring_body(const double* __restrict__ logw, 
   __shared__ cssm_u128 s_w[CSSM_BLOCK / 64];
   __shared__ uint32_t s_last[CSSM_BLOCK / 64];
   __shared__ uint32_t s_tile_b;
+#if !CSSM_OFF_LINES
   __shared__ uint32_t s_nheavy;
+#endif
   __shared__ __attribute__((aligned(16))) uint32_t s_slot[FUSE ? 3 * CSSM_TILE : 4];   // a 2048-slot chunk / up to 1024 long runs
   __shared__ cssm_u128 s_r[3][CSSM_BLOCK / 64];
   // (batch series, single GPU) an earlier observation's reference level was ruled out by its max: the series is on hold at

@@ -66,6 +66,9 @@ struct cssm_pf {
   bool safe_sums = false;         // form the sums in their own pass after the max is known (retry of a step whose
                                   // reference level was ruled out by the max; always for LGCP)
   bool last_optimistic = false;   // the last launch_propagate formed the sums itself
+  bool lgcp_tdep = false;         // LGCP whose f depends on time (a seasonal leaf): f is evaluated at every sub-step time (d_fsub)
+  std::vector<double> h_fsub;     // host copy of the sub-step coefficient table of the records last built
+  double* d_fsub = nullptr; size_t fsub_cap = 0;
   bool batch_hold = false;        // batch drivers: an outlying observation puts the series on hold (err bit 6) instead of voiding it
   bool sharded = false;
   // device memory
@@ -205,6 +208,8 @@ static int build_model(cssm_pf* pf, const cssm_model_desc* desc, bool update) {
   }
   pf->d = tmp.d; pf->n_leaves = tmp.n_leaves; pf->obs_kind = tmp.obs_kind; pf->precision = tmp.precision; pf->obs_df = tmp.obs_df;
   pf->scale_sd = tmp.scale_sd; pf->scale_raw = tmp.scale_raw; pf->mk = tmp.mk;
+  pf->lgcp_tdep = false;
+  if (tmp.obs_kind == CSSM_OBS_LGCP) for (int k = 0; k < tmp.d; ++k) if (tmp.comp[k].f_kind == CSSM_F_SEASONAL) pf->lgcp_tdep = true;
   for (int k = 0; k < tmp.d; ++k) pf->comp[k] = tmp.comp[k];
   return CSSM_OK;
 }
@@ -225,7 +230,6 @@ static int build_model_into(cssm_pf* pf, const cssm_model_desc* desc) {
     if (need_phi && (L->n_phi < 1 || !L->phi)) return fail(CSSM_EINVAL_DESC, "leaf %d: phi is required", l);
     if (L->f_kind == CSSM_F_SEASONAL) {
       if (L->dim != 2 * L->harmonics || L->period < 1) return fail(CSSM_EINVAL_DESC, "leaf %d: seasonal needs dim == 2*harmonics and period >= 1", l);
-      if (desc->obs_kind == CSSM_OBS_LGCP) return fail(CSSM_EINVAL_DESC, "leaf %d: a seasonal leaf under the LGCP filter is not supported", l);
     } else if (L->f_kind != CSSM_F_FIRST) {
       return fail(CSSM_EINVAL_DESC, "leaf %d: unknown f_kind %d", l, L->f_kind);
     }
@@ -304,6 +308,7 @@ static void build_rec(const cssm_pf* pf, double t_prev, double t, double y, int 
   r->has_obs = has_obs;
   r->step = step;
   r->n_sub = 0;
+  r->t_obs = t;
   if (pf->obs_kind == CSSM_OBS_LGCP) {
     r->has_obs = 1;                                            // FilterLgcp always weights (:210-226)
     if (dt == 0) { r->n_sub = 0; }
@@ -370,6 +375,54 @@ static void build_rec(const cssm_pf* pf, double t_prev, double t, double y, int 
   const int32_t pr = (int32_t)cssm_philox_draw(pf->seed, 0, step + 1, CSSM_STREAM_PICK, 0).v[0];
   const uint32_t pa = pr < 0 ? (uint32_t)0 - (uint32_t)pr : (uint32_t)pr;
   r->pick = (uint32_t)((uint64_t)pa % pf->n_global);
+}
+
+// FilterLgcp.calcWeight evaluates f at EVERY simulated time tau_s = t + s delta, the clock starting at the observation's
+// time (model/ParticleFilter.scala:193-205, :215; model/Sde.scala:57-66 -- a reference quirk that only shows when f depends
+// on time, i.e. with a seasonal leaf).  For such models the coefficients c_k(tau_s) of records [first, first + count) are
+// tabulated here (they depend on (t, s) only; tau is accumulated by repeated addition exactly as the oracle does) and
+// uploaded behind the records; the kernel reads row s of its observation.  `reset`: the records start a new table.
+static int build_fsub(cssm_pf* pf, size_t first, size_t count, bool reset) {
+  if (!pf->lgcp_tdep) return CSSM_OK;
+  if (reset) pf->h_fsub.clear();
+  const int d = pf->d;
+  for (size_t q = first; q < first + count; ++q) {
+    StepRec* r = &pf->h_recs[q];
+    r->fsub_off = 0;
+    if (r->n_sub <= 0) continue;
+    if (pf->h_fsub.size() + (size_t)r->n_sub * d > ((size_t)1 << 27))
+      return fail(CSSM_ENOMEM, "the sub-step table of a time-dependent LGCP model would exceed 1 GiB (%d sub-steps at observation %zu)", r->n_sub, q);
+    r->fsub_off = (uint32_t)pf->h_fsub.size();
+    double tau = r->t_obs;
+    for (int sidx = 0; sidx < r->n_sub; ++sidx) {
+      tau = tau + r->dt;                                   // t = s.time + dt, model/Sde.scala:60 (r->dt is delta for LGCP)
+      for (int k = 0; k < d; ++k) {
+        const Comp& c = pf->comp[k];
+        double v;
+        if (c.f_kind == CSSM_F_FIRST) v = (c.idx == 0) ? 1.0 : 0.0;
+        else {
+          double sn, cs;
+          cssm_sincos2pi(cssm_seasonal_phase((double)(c.idx / 2 + 1), tau, (double)c.period), &sn, &cs);
+          v = (c.idx & 1) ? sn : cs;
+        }
+        pf->h_fsub.push_back(v);
+      }
+    }
+  }
+  if (pf->h_fsub.empty()) return CSSM_OK;
+  if (pf->fsub_cap < pf->h_fsub.size()) {
+    HIP_TRY(hipStreamSynchronize(pf->stream));
+    if (pf->d_fsub) (void)hipFree(pf->d_fsub);
+    pf->d_fsub = nullptr; pf->fsub_cap = 0;
+    const size_t cap = pf->h_fsub.size() + pf->h_fsub.size() / 2 + 1024;
+    HIP_TRY(hipMalloc(&pf->d_fsub, cap * 8));
+    pf->fsub_cap = cap;
+  }
+  // (synchronous: the source is an ordinary vector that the next call may rewrite; this happens once per series, or once
+  //  per observation in the streaming calls, which wait for the device per observation anyway)
+  HIP_TRY(hipStreamSynchronize(pf->stream));
+  HIP_TRY(hipMemcpy(pf->d_fsub, pf->h_fsub.data(), pf->h_fsub.size() * 8, hipMemcpyHostToDevice));
+  return CSSM_OK;
 }
 
 // ------------------------------------------------------------------------------------ create / destroy
@@ -459,7 +512,7 @@ extern "C" void cssm_pf_destroy(cssm_pf* pf) {
   (void)hipSetDevice(pf->device);
   if (pf->stream) (void)hipStreamSynchronize(pf->stream);
   void* ptrs[] = {pf->state[0], pf->state[1], pf->logw, pf->endslot, pf->anc, pf->tileS, pf->tileS2, pf->tileP, pf->sc,
-                  pf->d_m0, pf->d_sd0, pf->d_logtab, pf->d_sync, pf->d_ts, pf->cum, pf->d_recs, pf->d_ll_t, pf->d_ess_t, pf->d_path, pf->cand, pf->cand_end, pf->cand_idx, pf->d_bounds, pf->d_xch, pf->d_need};
+                  pf->d_m0, pf->d_sd0, pf->d_logtab, pf->d_sync, pf->d_ts, pf->d_fsub, pf->cum, pf->d_recs, pf->d_ll_t, pf->d_ess_t, pf->d_path, pf->cand, pf->cand_end, pf->cand_idx, pf->d_bounds, pf->d_xch, pf->d_need};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   if (pf->h_recs) (void)hipHostFree(pf->h_recs);
   for (hipEvent_t e : pf->prof_ev) (void)hipEventDestroy(e);
@@ -555,6 +608,7 @@ static int launch_propagate(cssm_pf* pf, const StepRec* d_rec, double* pick_out 
   a.slot_set = pf->sharded ? 0 : pf->wparity;
   a.src2 = anc ? pf->src2 : nullptr; a.src2_stride = pf->src2_stride; a.n_split = pf->n_split; a.logtab = pf->d_logtab;
   a.chunk = chunk; a.do_sums = do_sums; a.subS = pf->tileS; a.subS2 = pf->tileS2; a.pick_out = pick_out; a.pick_slot = pick_slot;
+  a.fsub = pf->lgcp_tdep ? pf->d_fsub : nullptr;
   switch (pf->d) {
 #define CSSM_CASE_PROP(D) case D: cssm_prop_launch_d##D(a); break;
     CSSM_CASE_PROP(1) CSSM_CASE_PROP(2) CSSM_CASE_PROP(3) CSSM_CASE_PROP(4) CSSM_CASE_PROP(5) CSSM_CASE_PROP(6) CSSM_CASE_PROP(7) CSSM_CASE_PROP(8)
@@ -679,6 +733,8 @@ extern "C" int cssm_pf_step(cssm_pf* pf, double t, double obs, int has_obs, doub
   int rc = ensure_recs(pf, 1);
   if (rc) return rc;
   build_rec(pf, pf->t, t, obs, has_obs, pf->step, &pf->h_recs[0]);
+  rc = build_fsub(pf, 0, 1, true);
+  if (rc) return rc;
   HIP_TRY(hipMemcpyAsync(pf->d_recs, pf->h_recs, sizeof(StepRec), hipMemcpyHostToDevice, pf->stream));
   const int weighted = pf->h_recs[0].has_obs;
   rc = launch_step(pf, pf->d_recs, weighted, pf->step);
@@ -844,6 +900,8 @@ static int run_filter_once(cssm_pf* pf, const double* t, const double* y, const 
   for (size_t s = 1; s < T; ++s) if (t[s] < t0) t0 = t[s];     // data.minBy(_.t).t, model/ParticleFilter.scala:138
   double tp = t0;
   for (size_t s = 0; s < T; ++s) { build_rec(pf, tp, t[s], y[s], has ? has[s] : 1, (uint32_t)s, &pf->h_recs[s]); tp = t[s]; }
+  rc = build_fsub(pf, 0, T, true);
+  if (rc) return rc;
   HIP_TRY(hipMemcpyAsync(pf->d_recs, pf->h_recs, T * sizeof(StepRec), hipMemcpyHostToDevice, pf->stream));
   rc = launch_init(pf, t0);
   if (rc) return rc;
@@ -1278,6 +1336,8 @@ extern "C" int cssm_pf_interpolate(cssm_pf* pf, const double* t, const double* y
   for (size_t s = 1; s < T; ++s) if (t[s] < t0) t0 = t[s];
   double tp = t0;
   for (size_t s = 0; s < T; ++s) { build_rec(pf, tp, t[s], y[s], has ? has[s] : 1, (uint32_t)s, &pf->h_recs[s]); tp = t[s]; }
+  rc = build_fsub(pf, 0, T, true);
+  if (rc) return rc;
   rc = (hipMemcpyAsync(pf->d_recs, pf->h_recs, T * sizeof(StepRec), hipMemcpyHostToDevice, pf->stream) == hipSuccess) ? CSSM_OK : fail(CSSM_EHIP, "record upload");
   Scalars h;
   for (int attempt = 0; attempt < 2 && !rc; ++attempt) {   // second attempt: see run_filter
@@ -1493,6 +1553,8 @@ extern "C" int cssm_pf_shard_propagate(cssm_pf* pf, double t, double obs, int ha
   if (rc) return rc;
   const size_t slot = pf->step % 64;
   build_rec(pf, pf->t, t, obs, has_obs, pf->step, &pf->h_recs[slot]);
+  rc = build_fsub(pf, slot, 1, true);
+  if (rc) return rc;
   HIP_TRY(hipMemcpyAsync(pf->d_recs + slot, pf->h_recs + slot, sizeof(StepRec), hipMemcpyHostToDevice, pf->stream));
   if (pf->series) return fail(CSSM_ESTATE, "a series begun with shard_begin is stepped with shard_propagate_at");
   rc = shard_prepare_step(pf, pf->d_recs + slot, pf->h_recs[slot].has_obs, sums5_dev);
@@ -1659,6 +1721,8 @@ extern "C" int cssm_pf_shard_begin(cssm_pf* pf, const double* t, const double* y
   for (size_t s = 1; s < T; ++s) if (t[s] < t0) t0 = t[s];
   double tp = t0;
   for (size_t s = 0; s < T; ++s) { build_rec(pf, tp, t[s], y[s], has_obs ? has_obs[s] : 1, (uint32_t)s, &pf->h_recs[s]); tp = t[s]; }
+  rc = build_fsub(pf, 0, T, true);
+  if (rc) return rc;
   HIP_TRY(hipMemcpyAsync(pf->d_recs, pf->h_recs, T * sizeof(StepRec), hipMemcpyHostToDevice, pf->stream));
   rc = launch_init(pf, t0);
   if (rc) return rc;

@@ -61,7 +61,10 @@ __device__ __forceinline__ void propagate_range(
     const double* __restrict__ src2, size_t src2_stride, uint32_t n_split, const double* tab,
     const uint32_t range_lo, const uint32_t n, int do_sums_arg,
     double* __restrict__ pick_out, uint32_t pick_slot, double* lw_lds, unsigned char* s_stage, PropAcc& acc,
-    const uint32_t idx_max = 0xffffffffu, uint32_t* __restrict__ err_word = nullptr) {
+    const uint32_t idx_max = 0xffffffffu, uint32_t* __restrict__ err_word = nullptr, const double* __restrict__ fsub = nullptr) {
+  // fsub (LGCP with a time-dependent f, e.g. a seasonal leaf): the handle's table of f coefficients at the sub-step times
+  // tau_s = t + s delta (FilterLgcp.calcWeight evaluates mod.f(a.state, a.time) at every simulated time,
+  // model/ParticleFilter.scala:193-205; model/Sde.scala:57-66); this observation's rows start at rec->fsub_off
   // idx_max / err_word (COH): ancestor indices above idx_max -- impossible by construction -- are clamped and reported
   // (err bit 5) instead of being dereferenced: the ancestor array is the only data-dependent address of the path, and a
   // wild gather inside a kernel that the whole grid waits on must not be able to fault the GPU
@@ -256,6 +259,7 @@ __device__ __forceinline__ void propagate_range(
           lw[r] = g - g;
         } else {
           double haz = 0.0, carry = 0.0;
+          const double* fsub_obs = (fsub != nullptr) ? fsub + rec->fsub_off : nullptr;
           for (int s = 0; s < nsub; ++s) {   // simInitStream(...).take(n), :193-194
             // normal number q = s*D + k: even q opens Box-Muller pair q>>1 (second element kept for q+1)
 #pragma unroll
@@ -270,7 +274,8 @@ __device__ __forceinline__ void propagate_range(
               }
             }
             transition<D>(mk, rec, dt, x[r], z);
-            haz = haz + cssm_exp(gamma_of<D>(mk, rec, x[r])) * dt;   // :203-205
+            const double* fc = (fsub_obs != nullptr) ? fsub_obs + (size_t)s * D : rec->fco;   // f at tau_s (uniform)
+            haz = haz + cssm_exp(gamma_coef<D>(mk, fc, x[r])) * dt;   // :203-205
           }
           lw[r] = gamma_of<D>(mk, rec, x[r]) - haz;                // :200,:217
         }
@@ -370,7 +375,7 @@ __global__ __launch_bounds__(CSSM_BLOCK, (PropWaves<D, SUMS>::value)) void k_pro
     uint64_t seed, const StepRec* __restrict__ rec, ModelK mk, Scalars* __restrict__ sc, int slot_set,
     const double* __restrict__ src2, size_t src2_stride, uint32_t n_split, const double* __restrict__ logtab,
     uint64_t chunk, int do_sums_arg, cssm_u128* __restrict__ subS, cssm_u128* __restrict__ subS2,
-    double* __restrict__ pick_out, uint32_t pick_slot) {
+    double* __restrict__ pick_out, uint32_t pick_slot, const double* __restrict__ fsub) {
   __shared__ double s_max[CSSM_BLOCK / 64];
   // (sharded series) the exchange of an earlier observation did not fit: the series is on hold and nothing may change
   // until the host resumes it (cssm_pf_shard_resume)
@@ -382,7 +387,8 @@ __global__ __launch_bounds__(CSSM_BLOCK, (PropWaves<D, SUMS>::value)) void k_pro
   __shared__ __attribute__((aligned(16))) unsigned char s_stage[PropStage<D, IT>::bytes];
   PropAcc acc;
   propagate_range<D, LGCP, IT, OBS, SUMS, false>(src, src_stride, anc, dst, dst_stride, logw, gid0, seed, rec, mk, src2, src2_stride,
-                                                 n_split, tab, range_lo, n, do_sums_arg, pick_out, pick_slot, nullptr, s_stage, acc);
+                                                 n_split, tab, range_lo, n, do_sums_arg, pick_out, pick_slot, nullptr, s_stage, acc,
+                                                 0xffffffffu, nullptr, LGCP ? fsub : nullptr);
   const bool weighted = LGCP || rec->has_obs;
   const bool do_sums = SUMS && !LGCP && do_sums_arg && rec->has_obs;
   cssm_u128 accS = acc.S, accS2 = acc.S2;

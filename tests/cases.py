@@ -45,6 +45,14 @@ def c4_model():
     return Model.lgcp(Sde.ouProcess(1)).run(p)
 
 
+def lgcp_seasonal_model():
+    """Model.lgcp(Sde.ouProcess(1)) |+| Model.seasonal(24, 1, Sde.ouProcess(2)): a log-Gaussian Cox process whose intensity has a
+    daily cycle -- f depends on time, so FilterLgcp evaluates it at every sub-step time (model/ParticleFilter.scala:193-205)."""
+    p = (Parameters.apply(None, SdeParameter.ouParameter(0.1, 0.5, 0.4, 0.1, 0.5))
+         | Parameters.apply(None, SdeParameter.ouParameter(0.0, 0.3, 0.2, [0.3, -0.2], 0.2)))
+    return (Model.lgcp(Sde.ouProcess(1)) | Model.seasonal(24, 1, Sde.ouProcess(2))).run(p)
+
+
 def linear_model(sigma=0.3, obs_sd=0.5, m0=0.5, c0=2.0):
     """Model.linear(Sde.brownianMotion(1)): Kalman-tractable (docs/particle_filter.md:8-18)."""
     p = Parameters.apply(np.log(obs_sd), SdeParameter.brownianParameter(m0, c0, sigma))

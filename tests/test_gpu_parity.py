@@ -246,6 +246,30 @@ def test_lgcp_batch_matches_oracle():
     g.close()
 
 
+@pytest.mark.parametrize("precision", [1, 2])
+def test_lgcp_with_time_dependent_f_matches_oracle(precision):
+    """Model.lgcp(...) |+| Model.seasonal(...): FilterLgcp.calcWeight evaluates f(x_k, tau_k) at every simulated time tau_k =
+    t + k delta, the clock starting at the observation's time (model/ParticleFilter.scala:193-205,:215; model/Sde.scala:57-66).
+    The kernel reads the seasonal coefficients of every sub-step from a per-observation table; streaming and batch, bit for
+    bit against the oracle (oracle/cssm_oracle.c, step_lgcp)."""
+    model = cases.lgcp_seasonal_model()
+    t, y, has = cases.event_times(9, horizon=30.0)
+    _compare_streaming(model, 3000, t, y, has, lgcp_precision=precision)
+    g = NativePf(model, 5000, cases.SEED, lgcp_precision=precision)
+    o = oracle.OraclePf(model.descriptor(precision), 5000, cases.SEED)
+    gl, gll, gess, _ = g.run(t, y, has)
+    ol, oll, oess, _ = o.filter(t, y, has)
+    assert gl == ol
+    np.testing.assert_array_equal(gll, oll)
+    np.testing.assert_array_equal(gess, oess)
+    np.testing.assert_array_equal(g.particles(), o.particles())
+    # the cycle matters: the same series through a model without the seasonal leaf's time dependence differs
+    flat = NativePf(cases.c4_model(), 5000, cases.SEED, lgcp_precision=precision)
+    assert flat.run(t, y, has)[0] != gl
+    flat.close()
+    g.close()
+
+
 @pytest.mark.parametrize("n", [1, 7, 1024, 1500, 100_000])
 def test_stateless_resampler_matches_oracle(n):
     rng = np.random.default_rng(n)
