@@ -18,8 +18,8 @@
 //   k_offspring   unit prefix + totals (every block sums the <= 1K unit sums itself), ll and ess (:127-128), per tile
 //                 a DPP wave scan -> cumulative weight C_j -> end slot cnt(C_j); every particle writes its own run of
 //                 slots into anc (single GPU), or the end slots are kept for the exchange   model/Resampling.scala:36-58,69
-//   sharded only  k_scan_tiles / k_global_sums (exact exchange), k_pack_fixed + k_expand_fixed (fixed-capacity
-//                 exchange), k_expand (candidates -> slots)
+//   sharded only  k_boundary_pack + k_offspring_expand_spec (single-collective exchange); k_scan_tiles / k_global_sums,
+//                 k_pack, k_expand (exact exchange: candidates -> slots)
 // Cross-lane traffic is DPP, not ds_bpermute (5 vs 25 cycles per move on MI355X, tools/instr_rate.hip).
 #pragma once
 

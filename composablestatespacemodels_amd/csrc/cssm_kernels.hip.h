@@ -520,72 +520,6 @@ __device__ __forceinline__ void expand_body(const uint32_t* __restrict__ cand_en
     __syncthreads();
   }
 }
-// The same on the receive buffer of the fixed-capacity exchange, in place: segment r = (cap + 1) rows of (d + 1)
-// doubles from rank r, row 0 a header with the row count, the rest (state, end slot).  Candidate = row; its ancestor
-// index is n_split + row number, which k_propagate resolves against the same buffer.  The predecessor of a
-// segment's first row is the last row of the nearest non-empty segment below it -- or, crossing this rank's own
-// position, the own last end slot; at the very bottom the run starts at slot_lo.
-__global__ __launch_bounds__(CSSM_BLOCK) void k_expand_fixed(const double* __restrict__ recv, int world, int rank, long long cap, int d,
-                                                             uint32_t n_split, uint64_t slot_lo, uint64_t slot_hi,
-                                                             uint32_t* __restrict__ anc, const uint32_t* __restrict__ own_last_end,
-                                                             Scalars* __restrict__ sc) {
-  __shared__ long long s_cnt[64];
-  __shared__ uint32_t s_nheavy;
-  __shared__ uint32_t s_hb[CSSM_BLOCK], s_he[CSSM_BLOCK], s_hj[CSSM_BLOCK];
-  const long long seg = cap + 1, rowlen = d + 1;
-  if (threadIdx.x < 64) {
-    long long c = 0;
-    if ((int)threadIdx.x < world && (int)threadIdx.x != rank) {
-      c = (long long)recv[(size_t)threadIdx.x * seg * rowlen];
-      if (c > cap && blockIdx.x == 0) atomicOr(&sc->err, 8u);   // the sender had more than fits (it raised the bit too)
-      c = (c < 0) ? 0 : ((c > cap) ? cap : c);
-    }
-    s_cnt[threadIdx.x] = c;
-  }
-  __syncthreads();
-  const long long total = (long long)world * seg;
-  for (long long base = (long long)blockIdx.x * CSSM_BLOCK; base < total; base += (long long)gridDim.x * CSSM_BLOCK) {
-    if (threadIdx.x == 0) s_nheavy = 0;
-    __syncthreads();
-    const long long row = base + threadIdx.x;
-    if (row < total) {
-      const int r = (int)(row / seg);
-      const long long i = row - (long long)r * seg;
-      if (i >= 1 && i - 1 < s_cnt[r]) {
-        uint64_t b;
-        if (i > 1) {
-          b = (uint64_t)recv[(row - 1) * rowlen + d];
-        } else {
-          int rp = r - 1;
-          while (rp >= 0 && (rp == rank || s_cnt[rp] == 0)) { if (rp == rank) break; --rp; }
-          if (rp < 0) b = slot_lo;
-          else if (rp == rank) b = (uint64_t)*own_last_end;
-          else b = (uint64_t)recv[((long long)rp * seg + s_cnt[rp]) * rowlen + d];
-        }
-        uint64_t e = (uint64_t)recv[row * rowlen + d];
-        if (b < slot_lo) b = slot_lo;
-        if (e > slot_hi) e = slot_hi;
-        if (e > b) {
-          const uint32_t idx = n_split + (uint32_t)row;
-          if (e - b <= CSSM_RUN_DIRECT) {
-            for (uint64_t sl = b; sl < e; ++sl) anc[sl - slot_lo] = idx;
-          } else {
-            const uint32_t h = atomicAdd(&s_nheavy, 1u);
-            s_hb[h] = (uint32_t)(b - slot_lo); s_he[h] = (uint32_t)(e - slot_lo); s_hj[h] = idx;
-          }
-        }
-      }
-    }
-    __syncthreads();
-    const uint32_t nh = s_nheavy;
-    for (uint32_t h = 0; h < nh; ++h) {
-      const uint32_t he = s_he[h], hj = s_hj[h];
-      for (uint32_t sl = s_hb[h] + threadIdx.x; sl < he; sl += CSSM_BLOCK) anc[sl] = hj;
-    }
-    __syncthreads();
-  }
-}
-
 // ------------------------------------------------------------------------------------ single-collective exchange
 //
 // One all-to-all per observation carries BOTH the rank's 5 sum words and its boundary particles:
@@ -914,13 +848,6 @@ __global__ __launch_bounds__(CSSM_BLOCK) void k_expand(const uint32_t* __restric
                                                        uint32_t* __restrict__ anc, const uint32_t* __restrict__ own_last_end) {
   expand_body(cand_end, cand_idx, m, n_low, slot_lo, slot_hi, anc, own_last_end);
 }
-// counts on the device (fixed-capacity exchange: the host never learns them): nlh = {n_low, n_high}
-__global__ __launch_bounds__(CSSM_BLOCK) void k_expand_dev(const uint32_t* __restrict__ cand_end, const uint32_t* __restrict__ cand_idx,
-                                                           const long long* __restrict__ nlh, uint64_t slot_lo, uint64_t slot_hi,
-                                                           uint32_t* __restrict__ anc, const uint32_t* __restrict__ own_last_end) {
-  expand_body(cand_end, cand_idx, (uint64_t)(nlh[0] + nlh[1]), (uint64_t)nlh[0], slot_lo, slot_hi, anc, own_last_end);
-}
-
 // Resampling.multinomialResampling (model/Resampling.scala:92-96): slot i draws its own uniform and takes the
 // first particle whose cumulative normalised weight reaches it (breeze Multinomial.draw); the output is in
 // draw order, not sorted.  `cum` is non-decreasing and ends at exactly 1.0.

@@ -7,7 +7,10 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <chrono>
+#include <cstdlib>
 #include <mutex>
+#include <thread>
 #include <string>
 #include <vector>
 
@@ -66,6 +69,7 @@ struct cssm_pf {
   bool safe_sums = false;         // form the sums in their own pass after the max is known (retry of a step whose
                                   // reference level was ruled out by the max; always for LGCP)
   bool last_optimistic = false;   // the last launch_propagate formed the sums itself
+  void* last_comm = nullptr;      // RCCL communicator the library last enqueued collectives on (bounded_sync)
   bool lgcp_tdep = false;         // LGCP whose f depends on time (a seasonal leaf): f is evaluated at every sub-step time (d_fsub)
   std::vector<double> h_fsub;     // host copy of the sub-step coefficient table of the records last built
   double* d_fsub = nullptr; size_t fsub_cap = 0;
@@ -1527,6 +1531,7 @@ __global__ void k_adopt_remote(const double* __restrict__ recv, long long m, int
 }
 
 static int shard_prepare_step(cssm_pf* pf, const StepRec* d_rec, int weighted, uint64_t* sums5_dev);
+static int bounded_sync(cssm_pf* pf);
 // record of the step propagated last: a ring of 64 for streaming steps, the whole series after shard_begin
 static size_t last_rec_slot(const cssm_pf* pf) { return pf->series ? (size_t)(pf->step - 1) : (size_t)((pf->step - 1) % 64); }
 
@@ -1638,53 +1643,6 @@ __device__ __forceinline__ uint64_t wave_search_first(const uint32_t* __restrict
   return hi;
 }
 
-// Blocks (x = chunk of rows, y = destination rank q).  Wave 0 of every block first finds the contiguous range of
-// local particles owning at least one slot of q (the searches k_send_ranges does with one thread per destination).
-__global__ __launch_bounds__(256) void k_pack_fixed(const double* __restrict__ src, size_t stride, const uint32_t* __restrict__ endslot,
-                             uint64_t n_local, int d, int world, int rank, uint64_t n_global, uint64_t n_per, long long cap,
-                             const StepRec* __restrict__ rec, double* __restrict__ out, Scalars* __restrict__ sc,
-                             const long long* __restrict__ redo_flag, uint32_t* __restrict__ need_out) {
-  __shared__ long long s_first, s_count;
-  const int q = blockIdx.y;
-  const long long seg = cap + 1;
-  if (threadIdx.x < 64) {
-    long long first = 0, count = 0;
-    if (q != rank) {
-      uint64_t b_lo = (uint64_t)q * n_per, b_hi = b_lo + n_per;
-      if (b_lo > n_global) b_lo = n_global;
-      if (b_hi > n_global) b_hi = n_global;
-      uint64_t e_before = 0;   // end slot of the last particle of the previous rank
-      if (rank > 0) e_before = cssm_sys_count(cssm_u128_to_double(sc->S_off) / cssm_u128_to_double(sc->S_tot), rec->u, n_global);
-      const uint64_t j_lo = wave_search_first(endslot, n_local, b_lo, true);
-      if (b_lo < b_hi && j_lo < n_local) {
-        const uint64_t start = (j_lo == 0) ? e_before : (uint64_t)endslot[j_lo - 1];
-        if (start < b_hi) {
-          uint64_t j_last = wave_search_first(endslot, n_local, b_hi, false);   // it owns slot b_hi - 1
-          if (j_last >= n_local) j_last = n_local - 1;
-          first = (long long)j_lo; count = (long long)(j_last - j_lo + 1);
-        }
-      }
-    }
-    if (threadIdx.x == 0) { s_first = first; s_count = count; }
-  }
-  __syncthreads();
-  const long long first = s_first, c = s_count;
-  double* oseg = out + (size_t)q * seg * (d + 1);
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < seg; i += (long long)gridDim.x * blockDim.x) {
-    double* o = oseg + i * (d + 1);
-    if (i == 0) {
-      o[0] = (double)c;
-      if (c > cap) atomicOr(&sc->err, 8u);
-      if (need_out) atomicMax(need_out, (uint32_t)c);
-    } else if (i - 1 < c && i - 1 < cap) {
-      const long long j = first + (i - 1);
-      for (int k = 0; k < d; ++k) o[k] = src[(size_t)k * stride + (size_t)j];
-      o[d] = (double)endslot[j];
-    }
-  }
-  // the max ruled the reference level out: this series needs the exact path
-  if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0 && *redo_flag) atomicOr(&sc->err, 4u);
-}
 static int shard_prepare_step(cssm_pf* pf, const StepRec* d_rec, int weighted, uint64_t* sums5_dev) {
   int rc = launch_propagate(pf, d_rec);
   if (rc) return rc;
@@ -1752,6 +1710,8 @@ extern "C" int cssm_pf_shard_resume(cssm_pf* pf, uint32_t* fail_step_out) {
   int rc = shard_check(pf);
   if (rc) return rc;
   if (!fail_step_out) return fail(CSSM_EINVAL_ARG, "null argument");
+  rc = bounded_sync(pf);   // (first: a copy into pageable memory would wait for the stream without a bound)
+  if (rc) return rc;
   Scalars h;
   HIP_TRY(hipMemcpyAsync(&h, pf->sc, sizeof h, hipMemcpyDeviceToHost, pf->stream));
   HIP_TRY(hipStreamSynchronize(pf->stream));
@@ -1768,51 +1728,6 @@ extern "C" int cssm_pf_shard_resume(cssm_pf* pf, uint32_t* fail_step_out) {
   pf->cur = q.cur; pf->src = q.src; pf->src_stride = q.src_stride; pf->src2 = q.src2; pf->src2_stride = q.src2_stride;
   pf->n_split = q.n_split; pf->anc_valid = q.anc_valid; pf->last_optimistic = q.last_optimistic; pf->step = q.step; pf->t = q.t;
   *fail_step_out = s;
-  return CSSM_OK;
-}
-
-extern "C" int cssm_pf_shard_offspring_pack(cssm_pf* pf, const uint64_t* all_sums5_dev, int rank, int world, int64_t cap,
-                                            double* send_buf_dev) {
-  if (!pf || !send_buf_dev) return fail(CSSM_EINVAL_ARG, "null argument");
-  if (cap < 1) return fail(CSSM_EINVAL_ARG, "cap must be positive");
-  int rc = shard_check(pf);
-  if (rc) return rc;
-  if (!all_sums5_dev) return fail(CSSM_EINVAL_ARG, "null argument");
-  if (world < 1 || world > 64 || rank < 0 || rank >= world) return fail(CSSM_ESHARD, "rank %d / world %d", rank, world);
-  const uint64_t n_per = (pf->n_global + (uint64_t)world - 1) / (uint64_t)world;
-  if (pf->first != (uint64_t)rank * n_per) return fail(CSSM_ESHARD, "rank %d must own particles from %llu, handle starts at %llu",
-                                                       rank, (unsigned long long)((uint64_t)rank * n_per), (unsigned long long)pf->first);
-  const size_t slot = last_rec_slot(pf);
-  const int tgrid = (int)pf->nunits;
-  const int optimistic = pf->last_optimistic ? 1 : 0;
-  hipLaunchKernelGGL((k_offspring<true, false, CSSM_RESAMPLE_SYSTEMATIC>), dim3(tgrid), dim3(CSSM_BLOCK), 0, pf->stream, pf->logw, pf->n, pf->sc,
-                     (const cssm_u128*)pf->tileS, (const cssm_u128*)pf->tileS2, pf->d_recs + slot, pf->n_global, pf->endslot,
-                     pf->anc, pf->ntiles, pf->sup, pf->nunits, 0, 0, (double*)nullptr, (int32_t*)nullptr, 0u, pf->opt_exact,
-                     (const unsigned long long*)all_sums5_dev, rank, world, optimistic ? (int)pf->split : 1, pf->seed, (double*)nullptr, pf->d_logtab,
-                     optimistic, (unsigned long long*)(pf->d_xch + 128), (uint32_t)pf->first, (uint32_t)(pf->first + pf->n));
-  uint32_t* need = (pf->d_need && pf->step >= 1 && (size_t)(pf->step - 1) < pf->need_cap) ? pf->d_need + (pf->step - 1) : nullptr;
-  const int xblocks = (int)std::min<long long>((cap + 1 + 255) / 256, 64);
-  hipLaunchKernelGGL(k_pack_fixed, dim3(xblocks, world), dim3(256), 0, pf->stream, pf->state[pf->cur], pf->stride, pf->endslot, pf->n, pf->d,
-                     world, rank, pf->n_global, n_per, (long long)cap, pf->d_recs + slot, send_buf_dev, pf->sc,
-                     (const long long*)(pf->d_xch + 128), need);
-  HIP_TRY(hipGetLastError());
-  return CSSM_OK;
-}
-
-extern "C" int cssm_pf_shard_adopt_fixed(cssm_pf* pf, const double* recv_buf_dev, int rank, int world, int64_t cap) {
-  int rc = shard_check(pf);
-  if (rc) return rc;
-  if (!recv_buf_dev) return fail(CSSM_EINVAL_ARG, "recv_buf_dev is null");
-  if (cap < 1 || world < 1 || world > 64 || rank < 0 || rank >= world) return fail(CSSM_ESHARD, "rank %d / world %d / cap %lld", rank, world, (long long)cap);
-  // The receive buffer is used in place (it must stay untouched until the next cssm_pf_shard_propagate* has run):
-  // ancestors of the slots the own particles left open point at its rows.
-  const uint32_t n_split = (uint32_t)pf->n;
-  const long long total = (long long)world * (cap + 1);
-  hipLaunchKernelGGL(k_expand_fixed, dim3(grid_for((uint64_t)total, CSSM_BLOCK, 1024)), dim3(CSSM_BLOCK), 0, pf->stream, recv_buf_dev, world, rank,
-                     (long long)cap, pf->d, n_split, pf->first, pf->first + pf->n, pf->anc, (const uint32_t*)(pf->endslot + (pf->n - 1)), pf->sc);
-  HIP_TRY(hipGetLastError());
-  pf->src = pf->state[pf->cur]; pf->src_stride = pf->stride;
-  pf->src2 = recv_buf_dev; pf->src2_stride = 0; pf->n_split = n_split; pf->anc_valid = true;   // stride 0 = rows of d + 1
   return CSSM_OK;
 }
 
@@ -1872,6 +1787,8 @@ extern "C" int cssm_pf_shard_adopt_spec(cssm_pf* pf, const double* recv_buf_dev,
 extern "C" int cssm_pf_shard_status(cssm_pf* pf, double* ll_out, int32_t* ess_out, uint32_t* bits_out, uint32_t* need, size_t T) {
   int rc = shard_check(pf);
   if (rc) return rc;
+  rc = bounded_sync(pf);   // (first: a copy into pageable memory would wait for the stream without a bound)
+  if (rc) return rc;
   Scalars h;
   HIP_TRY(hipMemcpyAsync(&h, pf->sc, sizeof h, hipMemcpyDeviceToHost, pf->stream));
   if (need && pf->d_need && T <= pf->need_cap) HIP_TRY(hipMemcpyAsync(need, pf->d_need, T * 4, hipMemcpyDeviceToHost, pf->stream));
@@ -1885,12 +1802,14 @@ extern "C" int cssm_pf_shard_status(cssm_pf* pf, double* ll_out, int32_t* ess_ou
 
 // ------------------------------------------------------------------------------------ series loop over RCCL, in the library
 //
-// The collectives of the fixed-capacity series can be driven from here instead of from the host language: per
-// weighted observation  k_propagate -> ncclAllGather(5 words per rank) -> k_offspring + k_pack_fixed ->
-// ncclAllToAll((cap + 1) rows per pair) -> k_expand_fixed, all enqueued on the handle's stream without a host wait
-// (through torch.distributed the same sequence costs seven host-language calls per observation, which at 2^20 particles
-// per GPU is longer than the kernels).  RCCL is resolved at run time -- the copy already loaded in the process (e.g.
-// torch's) or librccl.so from the ROCm installation -- so the library itself links nothing but the HIP runtime.
+// The collectives of a single-collective series are driven from here instead of from the host language: per weighted
+// observation  k_propagate<SUMS> -> k_boundary_pack -> ONE all-to-all -> k_offspring_expand_spec, all enqueued on the
+// handle's stream without a host wait (through torch.distributed the same sequence costs several host-language calls per
+// observation, which at 2^20 particles per GPU is longer than the kernels).  RCCL is resolved at run time -- the copy
+// already loaded in the process (e.g. torch's) or librccl.so from the ROCm installation -- so the library itself links
+// nothing but the HIP runtime.  Every wait for a stretch of the series is bounded (bounded_sync): a rank that never
+// joins a collective, or an asynchronous RCCL error, aborts the communicator and surfaces as CSSM_ERCCL on this rank
+// instead of hanging it.
 #include <dlfcn.h>
 namespace {
 struct RcclApi {
@@ -1902,6 +1821,8 @@ struct RcclApi {
   int (*AllGather)(const void*, void*, size_t, int, void*, hipStream_t) = nullptr;
   int (*AllToAll)(const void*, void*, size_t, int, void*, hipStream_t) = nullptr;
   int (*AllToAllv)(const void*, const size_t*, const size_t*, void*, const size_t*, const size_t*, int, void*, hipStream_t) = nullptr;
+  int (*CommAbort)(void*) = nullptr;                 // optional
+  int (*CommGetAsyncError)(void*, int*) = nullptr;   // optional
   const char* (*GetErrorString)(int) = nullptr;
   bool ok = false;
 };
@@ -1941,14 +1862,45 @@ static RcclApi* rccl_api_load() {
   api.AllToAll = (int (*)(const void*, void*, size_t, int, void*, hipStream_t))dlsym(api.lib, "ncclAllToAll");
   api.AllToAllv = (int (*)(const void*, const size_t*, const size_t*, void*, const size_t*, const size_t*, int, void*, hipStream_t))dlsym(api.lib, "ncclAllToAllv");   // optional
   api.GetErrorString = (const char* (*)(int))dlsym(api.lib, "ncclGetErrorString");
-  api.ok = api.GetUniqueId && api.CommInitRank && api.CommDestroy && api.AllGather && api.AllToAll;
+  api.CommAbort = (int (*)(void*))dlsym(api.lib, "ncclCommAbort");
+  api.CommGetAsyncError = (int (*)(void*, int*))dlsym(api.lib, "ncclCommGetAsyncError");
+  api.ok = api.GetUniqueId && api.CommInitRank && api.CommDestroy && api.AllToAll;
   return api.ok ? &api : nullptr;
 }
-const int kNcclUint64 = 5, kNcclFloat64 = 8;   // ncclDataType_t (rccl.h)
+const int kNcclFloat64 = 8;   // ncclDataType_t (rccl.h)
 int rccl_fail(RcclApi* a, const char* what, int r) {
   return fail(CSSM_ERCCL, "%s: %s", what, (a && a->GetErrorString) ? a->GetErrorString(r) : "RCCL error");
 }
 }  // namespace
+
+// Wait for the handle's stream, but not forever once the library has put RCCL collectives on it: the wait polls, watches the
+// communicator for asynchronous errors, and after CSSM_SHARD_TIMEOUT_S seconds (default 600) aborts the communicator --
+// which ends the pending collectives on this rank -- and reports CSSM_ERCCL.  (Another rank died, or returned with an error
+// before joining a collective: without this every surviving rank would sit in that collective for ever.)
+static int bounded_sync(cssm_pf* pf) {
+  if (!pf->last_comm) { HIP_TRY(hipStreamSynchronize(pf->stream)); return CSSM_OK; }
+  RcclApi* a = rccl_api();
+  double limit = 600.0;
+  if (const char* e = getenv("CSSM_SHARD_TIMEOUT_S")) { const double v = atof(e); if (v > 0.0) limit = v; }
+  const auto t0 = std::chrono::steady_clock::now();
+  for (unsigned spin = 0;; ++spin) {
+    const hipError_t e = hipStreamQuery(pf->stream);
+    if (e == hipSuccess) return CSSM_OK;
+    if (e != hipErrorNotReady) return fail(CSSM_EHIP, "hipStreamQuery: %s", hipGetErrorString(e));
+    int async_err = 0;
+    const bool failed = a && a->CommGetAsyncError && a->CommGetAsyncError(pf->last_comm, &async_err) == 0 && async_err != 0;
+    const double waited = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    if (failed || waited > limit) {
+      if (a && a->CommAbort) (void)a->CommAbort(pf->last_comm);
+      pf->last_comm = nullptr;
+      (void)hipStreamSynchronize(pf->stream);
+      return failed ? rccl_fail(a, "asynchronous RCCL error in the sharded series", async_err)
+                    : fail(CSSM_ERCCL, "a collective of the sharded series did not complete within %.0f s (a rank that never joined it?); "
+                                       "the communicator was aborted", limit);
+    }
+    if (spin > 200) std::this_thread::sleep_for(std::chrono::microseconds(50));   // (the first polls spin: a stretch takes a few ms)
+  }
+}
 
 extern "C" int cssm_rccl_available(void) { return rccl_api() ? 1 : 0; }
 extern "C" const char* cssm_rccl_library(void) { RcclApi* a = rccl_api(); return a ? a->path.c_str() : ""; }
@@ -1987,7 +1939,7 @@ extern "C" int cssm_pf_shard_series_rccl(cssm_pf* pf, void* comm, int rank, int 
   if (!comm || !weighted || !sums5_dev || !all_sums5_dev || !send_buf_dev || !recv_buf_dev) return fail(CSSM_EINVAL_ARG, "null argument");
   RcclApi* a = rccl_api();
   if (!a) return fail(CSSM_ERCCL, "librccl.so could not be loaded");
-  const size_t seg = (size_t)(cap + 1) * (size_t)(pf->d + 1);   // doubles per pair of ranks
+  pf->last_comm = comm;
   if (single_collective) {   // sums and boundary particles in ONE all-to-all per observation (k_boundary_pack / k_expand_spec)
     const size_t sseg = (size_t)spec_seg(pf->d, (long long)cap);
     // single_collective == 2: only the two adjacent ranks get (and send) whole segments, every other pair exchanges the
@@ -2010,26 +1962,17 @@ extern "C" int cssm_pf_shard_series_rccl(cssm_pf* pf, void* comm, int rank, int 
       const int r = trimmed ? a->AllToAllv(send_buf_dev, counts.data(), displs.data(), recv_buf_dev, counts.data(), displs.data(), kNcclFloat64,
                                            comm, pf->stream)
                             : a->AllToAll(send_buf_dev, recv_buf_dev, sseg, kNcclFloat64, comm, pf->stream);
-      if (r) return rccl_fail(a, trimmed ? "ncclAllToAllv" : "ncclAllToAll", r);
+      if (r) {   // this rank will not enqueue the rest: end the collectives its peers may already wait in
+        if (a->CommAbort) (void)a->CommAbort(comm);
+        pf->last_comm = nullptr;
+        return rccl_fail(a, trimmed ? "ncclAllToAllv" : "ncclAllToAll", r);
+      }
       rc = cssm_pf_shard_adopt_spec(pf, recv_buf_dev, rank, world, cap);
       if (rc) return rc;
     }
     return CSSM_OK;
   }
-  for (size_t s = s_begin; s < s_end; ++s) {
-    rc = cssm_pf_shard_propagate_at(pf, s, sums5_dev);
-    if (rc) return rc;
-    if (!weighted[s]) continue;
-    int r = a->AllGather(sums5_dev, all_sums5_dev, 5, kNcclUint64, comm, pf->stream);
-    if (r) return rccl_fail(a, "ncclAllGather", r);
-    rc = cssm_pf_shard_offspring_pack(pf, all_sums5_dev, rank, world, cap, send_buf_dev);
-    if (rc) return rc;
-    r = a->AllToAll(send_buf_dev, recv_buf_dev, seg, kNcclFloat64, comm, pf->stream);
-    if (r) return rccl_fail(a, "ncclAllToAll", r);
-    rc = cssm_pf_shard_adopt_fixed(pf, recv_buf_dev, rank, world, cap);
-    if (rc) return rc;
-  }
-  return CSSM_OK;
+  return fail(CSSM_EINVAL_ARG, "single_collective must be 1, 2 or 3");
 }
 
 extern "C" int cssm_pf_shard_pack(cssm_pf* pf, int world, const int64_t* send_first_host, const int64_t* send_count_host,

@@ -114,7 +114,7 @@ class NativePf:
         _abi.check(self.lib.cssm_pf_last_loop_ms(self._h, C.byref(ms)))
         return ms.value
 
-    KERNELS = ("k_propagate", "reserved", "k_tile_sums", "k_scan_tiles", "k_offspring", "k_expand", "k_series")
+    KERNELS = ("k_propagate", "k_tile_sums", "k_offspring", "k_series")
 
     def set_option(self, option: int, value: int):
         _abi.check(self.lib.cssm_pf_set_option(self._h, int(option), int(value)))

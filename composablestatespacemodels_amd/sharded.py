@@ -1,35 +1,31 @@
 """Particle filter sharded over the GPUs of one node: one process per GPU, particles split into
 contiguous global ranges, collectives over RCCL (``torch.distributed`` backend "nccl" on ROCm).
 
-Per observation (stage calls of include/cssm_pf.h), after the first observations of a series:
+Two exchanges exist (stage calls of include/cssm_pf.h):
+
+**Single-collective exchange** -- every weighted observation of an ordinary series:
 
 1. ``shard_propagate_at``   fused propagate + weight + local fixed-point sums of exp(w - c), c being the
    observation's reference level (known without an exchange)
 2. ``shard_boundary_pack``  for every peer one segment: header = the rank's 5 words (S, S2, order key of the local max)
    and the totals of its boundary blocks; for the two adjacent ranks also rows = its first (rank below) or last (rank
    above) ``cap`` particles with their cumulative weights
-3. ONE all-to-all (library-driven series: all-to-all-v, whole segments between adjacent ranks and headers between the
-   others; otherwise equal splits)
+3. ONE all-to-all (equal split; opt-in: all-to-all-v trimmed to what is read)
 4. ``shard_adopt_spec``     global max -> c usable?  global cumulative weights -> ll, ess, end slots and runs of the own
    particles; the received rows expanded to the slots the own particles left open; coverage check
 
-(``CSSM_SHARD_SINGLE=0``: the earlier exchange -- all-gather of 5 words, ``shard_offspring_pack``, all-to-all,
-``shard_adopt_fixed``.)  The exact exchange -- all-gather, ``shard_offspring``, all-to-all of the range sizes, all-to-all-v
-of (d + 1) doubles per candidate, ``shard_adopt``, with a host read of the sizes -- serves LGCP series and the repetition
-of a series whose reference level an outlying observation ruled out.  A capacity miss of the single-collective exchange
-is resumed in place (``shard_resume``).
+Nothing is read by the host per observation.  A capacity miss is resumed in place (``shard_resume``: that observation's
+exchange is redone with four times the capacity, the series carries on); a reference level ruled out by the max
+(an outlying observation) repeats the series with the exact exchange.  With ``DistComm`` over RCCL the library enqueues
+kernels AND collectives itself (``cssm_pf_shard_series_rccl``), in stretches after each of which one status word is
+read, bounded by a timeout (a rank that never joins a collective surfaces as an RCCL error on every rank, not a hang).
+
+**Exact exchange** -- LGCP series (their level is the max, which needs an exchange of its own), forced (``exact=True``),
+or the repetition just mentioned: all-gather of the sums, ``shard_offspring``, all-to-all of the range sizes, ONE host
+read of those sizes, all-to-all-v of (d + 1) doubles per candidate, ``shard_adopt``.
 
 Random variates are keyed by the GLOBAL particle id and every sum is an integer sum, so ll, ess
 and the ancestor arrays are bit-identical for 1, 2, 4 and 8 ranks.
-
-Step 4 as written needs the exchange sizes on the host (all-to-all-v split sizes): one blocking device-to-host read
-per observation, which costs far more than the kernels once the wait is long enough for the runtime to sleep
-(measured at world = 1: 795 -> 479 us per observation at N = 2^24, 130 -> 89 us at N = 2^20).  ``ll_filter`` therefore
-runs a series with the FIXED-CAPACITY exchange after its first observations: every rank sends every other rank a
-segment of ``cap`` rows preceded by a header row holding the real count (``shard_offspring_pack``), one all-to-all
-with equal splits moves them, and ``shard_adopt_fixed`` reads the counts on the device.  The host never waits; a
-count above ``cap`` (or a reference level ruled out by the max) raises a sticky bit that is read once at the end,
-and the series is then repeated with the exact exchange -- same seed, same result, only slower.
 
 The orchestration is written over a list of local shards and a communicator object so that the
 same code drives (a) one shard per process over RCCL or gloo (``DistComm``) and (b) several
@@ -126,19 +122,11 @@ class GpuShard:
         self._recv_keepalive = recv_buf
         _abi.check(self.lib.cssm_pf_shard_adopt_spec(self._h, C.c_void_p(recv_buf.data_ptr()), self.rank, self.world, int(cap)))
 
-    def offspring_pack(self, cap: int, send_buf: torch.Tensor):
-        _abi.check(self.lib.cssm_pf_shard_offspring_pack(self._h, C.c_void_p(self.all_sums.data_ptr()), self.rank, self.world,
-                                                         int(cap), C.c_void_p(send_buf.data_ptr())))
-
-    def adopt_fixed(self, recv_buf: torch.Tensor, cap: int):
-        self._recv_keepalive = recv_buf
-        _abi.check(self.lib.cssm_pf_shard_adopt_fixed(self._h, C.c_void_p(recv_buf.data_ptr()), self.rank, self.world, int(cap)))
-
     def series_native(self, comm_handle, s_begin: int, s_end: int, weighted: np.ndarray, cap: int,
-                      send_buf: torch.Tensor, recv_buf: torch.Tensor, single_collective: int = 0):
+                      send_buf: torch.Tensor, recv_buf: torch.Tensor, single_collective: int = 1):
         """Observations [s_begin, s_end) with the collectives issued by the library itself (cssm_pf_shard_series_rccl).
-        single_collective: 0 = all-gather + all-to-all, 1 = one equal-split all-to-all, 2 = one all-to-all-v (whole
-        segments between adjacent ranks only, headers otherwise)."""
+        single_collective: 1 = one equal-split all-to-all, 2 = one all-to-all-v (whole segments between adjacent ranks
+        only, headers otherwise; world > 2), 3 = the same at any world size (tests)."""
         self._recv_keepalive = recv_buf
         w = np.ascontiguousarray(weighted, dtype=np.uint8)
         _abi.check(self.lib.cssm_pf_shard_series_rccl(self._h, comm_handle, self.rank, self.world, int(s_begin), int(s_end),
@@ -406,19 +394,6 @@ class ShardedFilter:
             s.adopt(b, int(c[: s.rank].sum()), int(c[s.rank + 1:].sum()), int(f[s.rank]), int(sc[s.rank]))
         return max([int(c.max()) for c in sx] + [0])
 
-    def _resample_fixed(self, cap: int):
-        """Stages after propagate with the fixed-capacity exchange: nothing is read by the host."""
-        S, comm = self.shards, self.comm
-        n = comm.world * (cap + 1) * (self.d + 1)
-        comm.all_gather([s.all_sums for s in S], [s.sums5 for s in S])
-        send = [s.buffer("send_fixed", n)[:n] for s in S]
-        recv = [s.buffer("recv_fixed", n)[:n] for s in S]
-        for s, b in zip(S, send):
-            s.offspring_pack(cap, b)
-        comm.all_to_all_equal(recv, send)
-        for s, b in zip(S, recv):
-            s.adopt_fixed(b, cap)
-
     def _resample_spec(self, cap: int):
         """Stages after propagate with the single-collective exchange: sums (segment headers) and boundary particles
         travel in ONE all-to-all; nothing is read by the host."""
@@ -432,122 +407,104 @@ class ShardedFilter:
         for s, b in zip(S, recv):
             s.adopt_spec(b, cap)
 
-    # A series is begun with the exact exchange (the first observations of a filter are where the weights are most
-    # uneven and the exchange largest), which also tells how much capacity the fixed exchange needs afterwards.
-    EXACT_STEPS = 0       # (observations run with the exact, host-read exchange before the capacity is fixed; kept for experiments)
     MIN_CAP = 1024
-    CAP_HEADROOM = 2      # capacity >= CAP_HEADROOM x the largest exchange seen during the exact steps
-    # ... and >= CAP_SQRT x sqrt(N_global): the number of particles whose runs cross a rank boundary is the deviation of a
-    # cumulative weight from its mean, ~ sqrt(N x (N/ESS - 1)); the first observations do not show how uneven the weights
-    # of a later, more informative observation will be (bench workload, 2^20 particles per rank: median 660 rows, maximum
-    # 6237 / 9879 / 14184 at world 2 / 4 / 8 = 4.3 .. 4.9 sqrt(N), tools/need_probe.py).  A series that needs more is
-    # still computed correctly: it is repeated with the exact exchange.
+    # capacity >= CAP_SQRT x sqrt(N_global): the number of particles whose runs cross a rank boundary is the deviation of a
+    # cumulative weight from its mean, ~ sqrt(N x (N/ESS - 1)) (bench workload, 2^20 particles per rank: median 660 rows,
+    # maximum 6237 / 9879 / 14184 at world 2 / 4 / 8 = 4.3 .. 4.9 sqrt(N), tools/need_probe.py).  An observation that needs
+    # more is resumed with four times as much.
     CAP_SQRT = 6.0
     NATIVE_STRETCH = 128     # observations the library enqueues between two looks at the sticky bits
-    # library-driven single-collective series: 1 = equal-split all-to-all of whole segments (default), 2 = all-to-all-v trimmed to
-    # what is read (whole segments between adjacent ranks, the 12 header words between all other pairs).  Mode 2 moves
-    # (world - 3) segments fewer per rank and observation but has never run on more than one real GPU: it is opt-in
-    # (CSSM_SHARD_TRIM=1) until it has; LocalCommTrimmed (below) checks its claim -- nothing but the header of a
-    # non-adjacent segment is ever read -- on one GPU.
+    # library-driven series: 1 = equal-split all-to-all of whole segments (default), 2 = all-to-all-v trimmed to what is read
+    # (whole segments between adjacent ranks, the 12 header words between all other pairs).  Mode 2 moves (world - 3) segments
+    # fewer per rank and observation but has never run on more than one real GPU: it is opt-in (CSSM_SHARD_TRIM=1) until
+    # it has; LocalCommTrimmed (above) checks its claim -- nothing but the header of a non-adjacent segment is ever
+    # read -- on one GPU.
     SINGLE_MODE = 1
     last_resumes = 0
     last_all_to_all = "equal split"
 
+    def _capacity(self) -> int:
+        S, comm = self.shards, self.comm
+        n_max = -(-S[0].n_global // comm.world)   # ceil(N / world): the same on every rank, and no count can exceed it
+        cap = min(max(self.MIN_CAP, int(self.CAP_SQRT * S[0].n_global ** 0.5)), n_max)
+        if cap >= 1024:
+            cap = min(-(-cap // 1024) * 1024, n_max)   # whole tiles: the boundary blocks then line up with k_propagate's sums
+        return cap
+
     def ll_filter(self, t, y, has=None, lgcp: bool = False, exact: bool = False):
+        import os
         t = np.asarray(t, dtype=np.float64)
         y = np.asarray(y, dtype=np.float64)
         T = len(t)
         weighted = np.ones(T, dtype=bool) if (has is None or lgcp) else np.asarray(has, dtype=bool)
         S, comm = self.shards, self.comm
-        n_max = -(-S[0].n_global // comm.world)   # ceil(N / world): the same on every rank, and no count can exceed it
+        n_max = -(-S[0].n_global // comm.world)
         for attempt in range(2):
-            all_exact = exact or lgcp or attempt == 1
+            # attempt 1: the single-collective exchange; attempt 2 (an outlying observation voided it): the exact exchange
+            all_exact = exact or lgcp or attempt == 1 or not all(hasattr(s, "boundary_pack") for s in S)
             for s in S:
                 s.begin(t, y, has)
-            cap, seen, done_exact, native = None, 0, 0, None
-            import os
-            single = (not lgcp) and all(hasattr(s, "boundary_pack") for s in S) and os.environ.get("CSSM_SHARD_SINGLE", "1") != "0"
+            cap = None if all_exact else self._capacity()
+            native = None
+            if not all_exact and len(S) == 1 and hasattr(comm, "native_comm"):
+                native = comm.native_comm()
+            mode = 2 if (self.SINGLE_MODE == 1 and os.environ.get("CSSM_SHARD_TRIM", "0") == "1") else self.SINGLE_MODE
             k, resumes, redo_exchange, redo_cap, escalated = 0, 0, False, 0, {}
+
+            def look_for_a_miss():
+                """A capacity miss is resumable: the observation that missed was left untouched on every rank (all reach the
+                same verdict from the segment headers, so bit 8 needs no agreement) and every kernel behind it returned at
+                once.  Its exchange is redone with four times the capacity (again four times if it missed before); the
+                series behind it keeps the ordinary capacity."""
+                nonlocal k, resumes, redo_exchange, redo_cap
+                if all_exact or cap >= n_max or resumes >= 64:
+                    return False
+                if max(s.status(T)[2] for s in S) != 8:
+                    return False
+                ks = [s.resume() for s in S]
+                k = comm.agree_max([max(ks)] * len(S))
+                if any(v != k for v in ks):
+                    raise RuntimeError("ranks disagree on the observation whose exchange did not fit")
+                escalated[k] = min(escalated.get(k, cap) * 4, n_max)
+                redo_cap = escalated[k]
+                if redo_cap >= 1024:
+                    redo_cap = min(-(-redo_cap // 1024) * 1024, n_max)
+                resumes += 1
+                redo_exchange = True
+                return True
+
             while k < T:
-                exact_k = bool(weighted[k]) and (all_exact or done_exact < self.EXACT_STEPS)
-                if weighted[k] and not exact_k and cap is None:
-                    # every rank must use the same capacity: agree on the largest count seen so far
-                    cap = min(max(self.MIN_CAP, self.CAP_HEADROOM * comm.agree_max([seen] * len(S)),
-                                  int(self.CAP_SQRT * S[0].n_global ** 0.5)), n_max)
-                    if cap >= 1024:
-                        cap = min(-(-cap // 1024) * 1024, n_max)   # whole tiles: the boundary blocks then line up with k_propagate's sums
-                    native = comm.native_comm() if (len(S) == 1 and hasattr(comm, "native_comm")) else None
-                spec_k = bool(weighted[k]) and not exact_k and single
+                if native is not None and not redo_exchange:
+                    # the library enqueues kernels and RCCL collectives itself, one stream, no host-language call per
+                    # observation -- in stretches, so that a capacity miss is noticed (one status read per stretch) before
+                    # the whole tail has been enqueued in vain
+                    kend = min(k + self.NATIVE_STRETCH, T)
+                    nb = comm.world * S[0].spec_segment(cap)
+                    S[0].series_native(native, k, kend, weighted, cap, S[0].buffer("send_spec", nb)[:nb],
+                                       S[0].buffer("recv_spec", nb)[:nb], single_collective=mode)
+                    self.last_all_to_all = ("ncclAllToAllv: whole segments between adjacent ranks, 12 header words between the others"
+                                            if (mode == 3 or (mode == 2 and comm.world > 2)) else "ncclAllToAll, equal split of whole segments")
+                    k = kend
+                    look_for_a_miss()
+                    continue
                 if not redo_exchange:               # (after a resume the observation is already propagated)
                     for s in S:
-                        if spec_k:
-                            s.propagate_at(k, with_sums=False)
-                        else:
-                            s.propagate_at(k)
-                redo_exchange = False
-                if not weighted[k]:
-                    k += 1
-                    continue
-                if exact_k:
-                    seen = max(seen, self._resample_exact(lgcp))
-                    done_exact += 1
-                    k += 1
-                    continue
-                if spec_k:
-                    self._resample_spec(redo_cap if redo_cap else cap)   # (a resumed observation: with its enlarged capacity only)
-                else:
-                    self._resample_fixed(cap)
-                redo_cap = 0
-                k += 1
-                def look_for_a_miss():
-                    """A capacity miss of the single-collective exchange is resumable: the observation that missed was left
-                    untouched on every rank (all reach the same verdict from the segment headers, so bit 8 needs no
-                    agreement) and every kernel behind it returned at once.  Its exchange is redone with four times the
-                    capacity (again four times if it missed before); the series behind it keeps the ordinary capacity."""
-                    nonlocal k, resumes, redo_exchange, redo_cap
-                    if not (single and cap < n_max and resumes < 64):
-                        return False
-                    if max(s.status(T)[2] for s in S) != 8:
-                        return False
-                    ks = [s.resume() for s in S]
-                    k = comm.agree_max([max(ks)] * len(S))
-                    if any(v != k for v in ks):
-                        raise RuntimeError("ranks disagree on the observation whose exchange did not fit")
-                    escalated[k] = min(escalated.get(k, cap) * 4, n_max)
-                    redo_cap = escalated[k]
-                    if redo_cap >= 1024:
-                        redo_cap = min(-(-redo_cap // 1024) * 1024, n_max)
-                    resumes += 1
-                    redo_exchange = True
-                    return True
-
-                missed = False
-                while native is not None and k < T and not missed:
-                    # the series behind this observation is enqueued by the library itself: kernels and RCCL collectives on
-                    # one stream, no host-language call per observation (cssm_pf_shard_series_rccl) -- in stretches of
-                    # NATIVE_STRETCH observations, so that a capacity miss is noticed (one status read per stretch) before
-                    # the whole tail has been enqueued in vain
-                    kend = min(k + self.NATIVE_STRETCH, T) if single else T
-                    if single:
-                        nb = comm.world * S[0].spec_segment(cap)
-                        mode = 2 if (self.SINGLE_MODE == 1 and os.environ.get("CSSM_SHARD_TRIM", "0") == "1") else self.SINGLE_MODE
-                        S[0].series_native(native, k, kend, weighted, cap, S[0].buffer("send_spec", nb)[:nb],
-                                           S[0].buffer("recv_spec", nb)[:nb], single_collective=mode)
-                        self.last_all_to_all = ("ncclAllToAllv: whole segments between adjacent ranks, 12 header words between the others"
-                                                if (mode == 3 or (mode == 2 and comm.world > 2)) else "ncclAllToAll, equal split of whole segments")
+                        s.propagate_at(k) if all_exact else s.propagate_at(k, with_sums=False)
+                if weighted[k]:
+                    if all_exact:
+                        self._resample_exact(lgcp)
                     else:
-                        nb = comm.world * (cap + 1) * (self.d + 1)
-                        S[0].series_native(native, k, kend, weighted, cap, S[0].buffer("send_fixed", nb)[:nb],
-                                           S[0].buffer("recv_fixed", nb)[:nb])
-                    k = kend
-                    missed = look_for_a_miss()
+                        self._resample_spec(redo_cap if redo_exchange else cap)   # (a resumed observation: its enlarged capacity)
+                redo_exchange, redo_cap = False, 0
+                k += 1
                 if native is None and k == T:
                     look_for_a_miss()                # host-driven series: one look at its end
             self.last_resumes = resumes
-            self.last_single = single
+            self.last_single = not all_exact
             self.last_native = native is not None
             res = [s.status(T) for s in S]
-            # bits 4 and 8 both mean "again, exactly"; any rank may have raised one, every rank must repeat
+            # bit 4 (an observation's reference level was ruled out by the max) means "again, exactly"; any rank may have
+            # raised it, every rank must repeat
             bits = comm.agree_max([max(r[2] for r in res)] * len(S))
             if bits == 0:
                 self.last_cap, self.last_attempts = cap, attempt + 1

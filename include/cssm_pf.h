@@ -222,14 +222,11 @@ int cssm_pf_set_option(cssm_pf* pf, int option, int value);
  * profiling OFF.  The event packets themselves take time on the queue (about 2 us per bracketed launch on MI355X): the
  * caller can calibrate that in place as (loop time with profiling - loop time without) / bracketed launches, both loop
  * times from cssm_pf_last_loop_ms (bench.py does, and its figure then agrees with rocprofv3's kernel trace). */
-#define CSSM_K_PROPAGATE 0   /* fused gather + propagate + weight + block max */
-#define CSSM_K_RESERVED 1
-#define CSSM_K_TILE_SUMS 2   /* exp(w - max), fixed-point tile sums */
-#define CSSM_K_SCAN_TILES 3  /* scan of tile sums, ll, ess */
-#define CSSM_K_OFFSPRING 4   /* cumulative weights -> end slots */
-#define CSSM_K_EXPAND 5      /* end slots -> ancestor indices */
-#define CSSM_K_SERIES 6      /* the persistent series kernel: ONE launch for all T observations of a batch run */
-#define CSSM_PROFILE_NKERNELS 7
+#define CSSM_K_PROPAGATE 0   /* fused gather + propagate + weight + block max (+ fixed-point sums with CSSM_OPT_FUSED_SUMS) */
+#define CSSM_K_TILE_SUMS 1   /* exp(w - level), fixed-point unit sums */
+#define CSSM_K_OFFSPRING 2   /* unit prefix, ll / ess, cumulative weights -> end slots -> ancestor indices */
+#define CSSM_K_SERIES 3      /* the persistent series kernel: ONE launch for all T observations of a batch run */
+#define CSSM_PROFILE_NKERNELS 4
 int cssm_pf_profile(cssm_pf* pf, int enable);
 int cssm_pf_profile_read(cssm_pf* pf, double* total_ms, uint64_t* launches);
 /* Whether the last batch run used the persistent series kernel and, if profiling was on, how its weighted observations
@@ -319,7 +316,8 @@ int cssm_resample(int kind, const double* w, size_t n, double u, uint64_t seed, 
 
 /* ---- sharded filter: stage calls between which the caller runs its collectives ------------ */
 /*
- * One observation on R ranks:
+ * EXACT exchange, one observation on R ranks -- LGCP series, forced, or the repetition of a series an
+ * outlying observation voided:
  *   cssm_pf_shard_propagate     fused propagate + weight + fixed-point sums of exp(w - c) on the local shard, c being
  *                               the observation's reference level (cssm_numerics.h: known without any exchange);
  *                               5 x u64 out: S, S2 (2 words each), order key of the local max log-weight
@@ -342,39 +340,57 @@ int cssm_pf_shard_propagate(cssm_pf* pf, double t, double obs, int has_obs, uint
 int cssm_pf_shard_sums(cssm_pf* pf, const uint64_t* all_sums5_dev, int world, uint64_t* sums5_dev);
 int cssm_pf_shard_offspring(cssm_pf* pf, const uint64_t* all_sums5_dev, int rank, int world,
                             int64_t* send_first_dev, int64_t* send_count_dev, uint64_t* redo_flag_dev);
-/* The same observation WITHOUT a host read (the exchange sizes stay on the device), for a series known in advance:
- *   cssm_pf_shard_begin           records of all T observations uploaded once; initial cloud
- *   cssm_pf_shard_propagate_at    step s (in order): as cssm_pf_shard_propagate
- *   [all-gather of 5 x u64 per rank]
- *   cssm_pf_shard_offspring_pack  offspring as above, then the send ranges packed into a FIXED layout: one segment of
- *                                 (cap + 1) rows of (d + 1) doubles per destination, row 0 = header (row count)
- *   [all-to-all with equal splits of (cap + 1) * (d + 1) doubles]
- *   cssm_pf_shard_adopt_fixed     counts from the headers; candidates expanded to the slots the own particles left
- *   cssm_pf_shard_status          at the end: ll, ess and two sticky bits -- 4: the max ruled some step's reference
- *                                 level out, 8: some send count exceeded cap.  Either means the series has to be run
- *                                 again (larger cap, or the host-read stages above); need[s] = capacity step s needed.
- * Nothing here blocks the host, so the kernels and collectives of consecutive observations queue back to back. */
-int cssm_pf_shard_begin(cssm_pf* pf, const double* t, const double* y, const uint8_t* has_obs, size_t T);
-int cssm_pf_shard_propagate_at(cssm_pf* pf, size_t s, uint64_t* sums5_dev);
-int cssm_pf_shard_offspring_pack(cssm_pf* pf, const uint64_t* all_sums5_dev, int rank, int world, int64_t cap,
-                                 double* send_buf_dev);
-int cssm_pf_shard_adopt_fixed(cssm_pf* pf, const double* recv_buf_dev, int rank, int world, int64_t cap);
-int cssm_pf_shard_status(cssm_pf* pf, double* ll_out, int32_t* ess_out, uint32_t* bits_out, uint32_t* need, size_t T);
 int cssm_pf_shard_pack(cssm_pf* pf, int world, const int64_t* send_first_host,
                        const int64_t* send_count_host, int skip_rank, double* send_buf_dev);
 int cssm_pf_shard_adopt(cssm_pf* pf, const double* recv_buf_dev, int64_t n_low, int64_t n_high,
                         int64_t self_first, int64_t self_count);
 int cssm_pf_shard_result(cssm_pf* pf, double* ll_out, int32_t* ess_out);
 
-/* The fixed-capacity series with its collectives driven from INSIDE the library (RCCL over xGMI, resolved at run time
- * with dlopen: the copy already in the process, else librccl.so of the ROCm installation).  Per weighted observation
- * s in [s_begin, s_end): cssm_pf_shard_propagate_at -> ncclAllGather of 5 words per rank -> cssm_pf_shard_offspring_pack
- * -> ncclAllToAll of (cap + 1) rows of (d + 1) doubles per pair of ranks -> cssm_pf_shard_adopt_fixed, everything
- * enqueued on the handle's stream, no host wait.  The communicator is made from an id that rank 0 creates and hands to
- * the other ranks by whatever channel the host has (bench.py: torch.distributed's object broadcast).
- * weighted[s] != 0: observation s resamples.  Buffers (device): sums5 5 words, all_sums5 5 * world words, send / recv
- * world * (cap + 1) * (d + 1) doubles each (single_collective: world * cssm_pf_shard_spec_segment doubles); recv must stay
- * untouched until the next propagate has run. */
+/* A series known in advance: the records of all T observations are uploaded once (cssm_pf_shard_begin) and observation s is
+ * propagated by cssm_pf_shard_propagate_at(s) (in order; sums5_dev as above, or NULL when the single-collective exchange
+ * totals the sums itself).  cssm_pf_shard_status at the end: ll, ess and the sticky bits -- 4: the max ruled some
+ * observation's reference level out (run the series again with the exact exchange), 8: a capacity miss that was not resumed;
+ * need[s] = rows observation s needed (diagnostics). */
+int cssm_pf_shard_begin(cssm_pf* pf, const double* t, const double* y, const uint8_t* has_obs, size_t T);
+int cssm_pf_shard_propagate_at(cssm_pf* pf, size_t s, uint64_t* sums5_dev);
+int cssm_pf_shard_status(cssm_pf* pf, double* ll_out, int32_t* ess_out, uint32_t* bits_out, uint32_t* need, size_t T);
+
+/* SINGLE-COLLECTIVE exchange (every weighted observation of an ordinary series): ONE all-to-all per observation carries
+ * the rank's 5 sum words (segment header, to every rank) AND its boundary particles -- to the rank below its first `cap`
+ * particles, to the rank above its last `cap`, each with the inclusive prefix of its fixed-point weight within that block --
+ * so no all-gather precedes it and the host reads nothing.  The receiver, holding every rank's sums after the exchange,
+ * turns the prefixes into global end slots itself.  Slots of a rank owned neither by its own particles nor by the adjacent
+ * ranks' boundary blocks raise sticky bit 8 (a capacity miss).
+ *   cssm_pf_shard_spec_segment    doubles per pair of ranks for capacity `cap` (send / recv buffers: world segments)
+ *   cssm_pf_shard_propagate_at    with sums5_dev = NULL
+ *   cssm_pf_shard_boundary_pack   a header for every destination, boundary rows for the two adjacent ranks
+ *   (all-to-all of cssm_pf_shard_spec_segment doubles per pair)
+ *   cssm_pf_shard_adopt_spec      offspring of the own particles, expansion of the received rows, coverage check
+ * recv_buf_dev must stay untouched until the next propagate has run (ancestors point into it). */
+int64_t cssm_pf_shard_spec_segment(const cssm_pf* pf, int64_t cap);
+int cssm_pf_shard_boundary_pack(cssm_pf* pf, int rank, int world, int64_t cap, double* send_buf_dev);
+int cssm_pf_shard_adopt_spec(cssm_pf* pf, const double* recv_buf_dev, int rank, int world, int64_t cap);
+/* A capacity miss is resumable.  The launch that found some rank's slots uncovered did nothing on any rank (every rank
+ * reaches the same verdict from the segment headers), recorded the observation index and sticky bit 8, and every later
+ * kernel of the series returned at once.  cssm_pf_shard_resume returns that index, clears the bit and rewinds the handle to
+ * "that observation propagated, not yet resampled"; the host redoes its exchange with a larger capacity (boundary_pack,
+ * all-to-all, adopt_spec) and continues the series behind it. */
+int cssm_pf_shard_resume(cssm_pf* pf, uint32_t* fail_step_out);
+
+/* The single-collective series with its collectives driven from INSIDE the library (RCCL over xGMI, resolved at run time
+ * with dlopen: the copy already in the process, else librccl.so of the ROCm installation).  Per weighted observation s in
+ * [s_begin, s_end): propagate_at -> boundary_pack -> ONE RCCL all-to-all -> adopt_spec, everything enqueued on the handle's
+ * stream, no host wait.  single_collective = 1: equal-split ncclAllToAll of whole segments; 2: ncclAllToAllv in which only
+ * the adjacent pairs exchange whole segments and every other pair the 12 header words (nothing else of those segments is
+ * ever read; falls back to 1 when world <= 2 or the RCCL copy has no ncclAllToAllv); 3 = the same for any world, an error
+ * without ncclAllToAllv (tests).  The communicator is made from an id that rank 0 creates and hands to the other ranks by
+ * whatever channel the host has (bench.py: torch.distributed's object broadcast).  weighted[s] != 0: observation s
+ * resamples.  Buffers (device): send / recv world * cssm_pf_shard_spec_segment doubles each; sums5 / all_sums5 are not used
+ * by this exchange (kept in the signature for the stage-call hosts).
+ * The library never waits without a bound for work that contains its collectives: cssm_pf_shard_status / _resume poll the
+ * stream, watch the communicator's asynchronous error state and after CSSM_SHARD_TIMEOUT_S seconds (environment; default
+ * 600) abort the communicator and return CSSM_ERCCL -- a rank that died or returned early surfaces as an error on every
+ * rank instead of a hang.  A rank whose own RCCL call fails aborts the communicator before returning, for the same reason. */
 typedef struct { char internal[128]; } cssm_rccl_id;   /* ncclUniqueId */
 int cssm_rccl_available(void);
 const char* cssm_rccl_library(void);   /* which librccl.so the library bound to (diagnostics) */
@@ -384,30 +400,6 @@ void cssm_rccl_comm_destroy(void* comm);
 int cssm_pf_shard_series_rccl(cssm_pf* pf, void* comm, int rank, int world, size_t s_begin, size_t s_end,
                               const uint8_t* weighted, int64_t cap, uint64_t* sums5_dev, uint64_t* all_sums5_dev,
                               double* send_buf_dev, double* recv_buf_dev, int single_collective);
-
-/* The single-collective exchange (single_collective != 0 above; stage calls for hosts that issue the collective themselves):
- * ONE all-to-all per observation carries the rank's 5 sum words (segment header, to every rank) AND its boundary
- * particles -- to the rank below its first `cap` particles, to the rank above its last `cap`, each with the inclusive
- * prefix of its fixed-point weight within that block -- so no all-gather precedes it.  single_collective = 1: equal-split
- * ncclAllToAll of whole segments; 2: ncclAllToAllv in which only the adjacent pairs exchange whole segments and every
- * other pair the 12 header words (nothing else of those segments is ever read; falls back to 1 when world <= 2 or the
- * RCCL copy has no ncclAllToAllv; 3 = the same for any world, an error without ncclAllToAllv: tests).  The receiver, holding every rank's sums
- * after the exchange, turns the prefixes into global end slots itself.  Slots of a rank owned neither by its own particles
- * nor by the adjacent ranks' boundary blocks raise the same sticky bit 8 as a count above `cap` does (exact exchange).
- *   cssm_pf_shard_spec_segment    doubles per pair of ranks for capacity `cap` (send / recv buffers: world segments)
- *   cssm_pf_shard_propagate_at    with sums5_dev = NULL (the totals are formed by the next call)
- *   cssm_pf_shard_boundary_pack   a header for every destination, boundary rows for the two adjacent ranks
- *   (all-to-all of cssm_pf_shard_spec_segment doubles per pair)
- *   cssm_pf_shard_adopt_spec      offspring of the own particles, expansion of the received rows, coverage check */
-int64_t cssm_pf_shard_spec_segment(const cssm_pf* pf, int64_t cap);
-int cssm_pf_shard_boundary_pack(cssm_pf* pf, int rank, int world, int64_t cap, double* send_buf_dev);
-int cssm_pf_shard_adopt_spec(cssm_pf* pf, const double* recv_buf_dev, int rank, int world, int64_t cap);
-/* A capacity miss of the single-collective series is resumable.  The launch that found some rank's slots uncovered did
- * nothing on any rank (every rank reaches the same verdict from the segment headers), recorded the observation index and
- * sticky bit 8, and every later kernel of the series returned at once.  cssm_pf_shard_resume returns that index, clears
- * the bit and rewinds the handle to "that observation propagated, not yet resampled"; the host redoes its exchange with a
- * larger capacity (boundary_pack, all-to-all, adopt_spec) and continues the series behind it. */
-int cssm_pf_shard_resume(cssm_pf* pf, uint32_t* fail_step_out);
 
 /* ---- PMMH host loop ---------------------------------------------------------------------- */
 /*

@@ -279,46 +279,6 @@ class OracleShard:
         assert anc.max() < len(allc)
         self.o.set_particles(np.ascontiguousarray(np.stack([allc[a][0] for a in anc], axis=1)))
 
-    def offspring_pack(self, cap, send_buf):
-        row, seg = self.d + 1, (cap + 1) * (self.d + 1)
-        send_buf[: self.world * seg] = 0
-        self.offspring()
-        if int(self.redo_flag[0]):
-            self.bits |= 4
-            return
-        self.need[self.step_idx - 1] = max([int(self.send_count[q]) for q in range(self.world) if q != self.rank] + [0])
-        for q in range(self.world):
-            c = 0 if q == self.rank else int(self.send_count[q])
-            send_buf[q * seg] = float(c)
-            if c > cap:
-                self.bits |= 8
-            f = int(self.send_first[q])
-            for i in range(min(c, cap)):
-                j = f + i
-                send_buf[q * seg + (i + 1) * row: q * seg + (i + 2) * row] = torch.from_numpy(
-                    np.concatenate([self.x1[:, j], [float(self.E[j])]]))
-
-    def adopt_fixed(self, recv_buf, cap):
-        if self.bits & 4:
-            return                                   # the series is void; GpuShard keeps running on stale but addressable data
-        row, seg = self.d + 1, (cap + 1) * (self.d + 1)
-        rows, n_low, n_high = [], 0, 0
-        for r in range(self.world):
-            if r == self.rank:
-                continue
-            if int(recv_buf[r * seg]) > cap:
-                self.bits |= 8                       # the sender had more than fits: the receiver sees it in the header too
-            c = min(int(recv_buf[r * seg]), cap)
-            rows.append(recv_buf[r * seg + row: r * seg + (c + 1) * row])
-            if r < self.rank:
-                n_low += c
-            else:
-                n_high += c
-        flat = torch.cat(rows) if rows else torch.zeros(0, dtype=torch.float64)
-        if self.bits & 8:
-            return
-        self.adopt(flat, n_low, n_high, int(self.send_first[self.rank]), int(self.send_count[self.rank]))
-
     def status(self, T):
         return self.ll, self.ess, self.bits, self.need[:T]
 

@@ -106,13 +106,13 @@ def test_rccl_world1_matches_oracle():
         shard = GpuShard(model, n, 0, 1, cases.SEED, 0)
         f = ShardedFilter([shard], DistComm(device=torch.device("cuda", 0)))
         oll, oess, opart = _oracle_run(model, n, t, y, has)
-        for exact in (False, True):          # fixed-capacity exchange (equal-split all-to-all) and exact exchange over RCCL
+        for exact in (False, True):          # single-collective exchange (equal-split all-to-all) and exact exchange over RCCL
             ll, ess = f.ll_filter(t, y, has, exact=exact)
             assert (ll, ess) == (oll, oess[-1])
             np.testing.assert_array_equal(shard.particles(), opart)
             if not exact:                    # the library drove the collectives of the series itself (cssm_pf_shard_series_rccl)
                 assert f.last_native, "the native RCCL series loop was not taken"
-        assert f.last_single
+                assert f.last_single
         # ... with the all-to-all-v of the library's trimmed exchange (mode 3 forces it at any world size; at world 1 it
         # carries the rank's own header)
         f4 = ShardedFilter([shard], DistComm(device=torch.device("cuda", 0)))
@@ -121,15 +121,6 @@ def test_rccl_world1_matches_oracle():
         assert f4.last_native and f4.last_single and (ll, ess) == (oll, oess[-1])
         np.testing.assert_array_equal(shard.particles(), opart)
         f4.comm.close()
-        # ... with all-gather + all-to-all instead of the single all-to-all, still issued by the library
-        os.environ["CSSM_SHARD_SINGLE"] = "0"
-        try:
-            f3 = ShardedFilter([shard], DistComm(device=torch.device("cuda", 0)))
-            ll, ess = f3.ll_filter(t, y, has)
-            assert f3.last_native and not f3.last_single and (ll, ess) == (oll, oess[-1])
-            np.testing.assert_array_equal(shard.particles(), opart)
-        finally:
-            del os.environ["CSSM_SHARD_SINGLE"]
         # the same series with the collectives issued through torch.distributed: identical bits
         os.environ["CSSM_SHARD_NATIVE"] = "0"
         try:
@@ -163,20 +154,17 @@ def test_local_shards_outlying_observation_second_attempt(world):
         s.close()
 
 
-@pytest.mark.parametrize("single", ["1", "0"])
 @pytest.mark.parametrize("world", [2, 4, 8])
 @pytest.mark.parametrize("name,n,T", [("c2_model", 20000, 30), ("c3_model", 9000, 16)])
-def test_fixed_capacity_series_matches_oracle(world, name, n, T, single, monkeypatch):
-    """ll_filter: exact exchange for the first observations, then the host-read-free exchange -- with ONE all-to-all per
-    observation carrying sums and boundary particles (single = 1, the default) or all-gather + all-to-all (single = 0)."""
+def test_single_collective_series_matches_oracle(world, name, n, T):
+    """ll_filter: the host-read-free exchange -- ONE all-to-all per observation carrying sums and boundary particles."""
     from composablestatespacemodels_amd.sharded import GpuShard, LocalComm, ShardedFilter
-    monkeypatch.setenv("CSSM_SHARD_SINGLE", single)
     model = getattr(cases, name)()
     t, y, has = cases.poisson_counts(T, missing=0.1)
     shards = [GpuShard(model, n, r, world, cases.SEED, 0) for r in range(world)]
     f = ShardedFilter(shards, LocalComm(world))
     ll, ess = f.ll_filter(t, y, has)
-    assert f.last_attempts == 1 and f.last_cap is not None and f.last_single == (single == "1")
+    assert f.last_attempts == 1 and f.last_cap is not None and f.last_single
     oll, oess, opart = _oracle_run(model, n, t, y, has)
     assert (ll, ess) == (oll, oess[-1])
     np.testing.assert_array_equal(np.concatenate([s.particles() for s in shards], axis=1), opart)
@@ -189,24 +177,20 @@ def test_fixed_capacity_series_matches_oracle(world, name, n, T, single, monkeyp
         s.close()
 
 
-@pytest.mark.parametrize("single", ["1", "0"])
 @pytest.mark.parametrize("why", ["capacity", "outlier"])
-def test_fixed_capacity_series_is_repeated_exactly_when_voided(why, single, monkeypatch):
+def test_series_resumes_a_capacity_miss_and_repeats_after_an_outlying_observation(why):
     from composablestatespacemodels_amd.sharded import GpuShard, LocalComm, ShardedFilter
-    monkeypatch.setenv("CSSM_SHARD_SINGLE", single)
     model = cases.c2_model()
     n, world, T = 12000, 4, 14
     t, y, has = cases.poisson_counts(T)
     if why == "outlier":
-        y = y.copy(); y[9] = 60.0          # in the fixed-capacity part: the max rules the reference level out (sticky bit 4)
+        y = y.copy(); y[9] = 60.0          # the max rules the reference level out (sticky bit 4): repeated with the exact exchange
     shards = [GpuShard(model, n, r, world, cases.SEED, 0) for r in range(world)]
     f = ShardedFilter(shards, LocalComm(world))
-    f.EXACT_STEPS = 1
     if why == "capacity":
-        f.MIN_CAP, f.CAP_HEADROOM, f.CAP_SQRT = 1, 0, 0.0    # one row per pair cannot hold the exchange (sticky bit 8)
+        f.MIN_CAP, f.CAP_SQRT = 1, 0.0     # one row per pair cannot hold the exchange (sticky bit 8): resumed with more
     ll, ess = f.ll_filter(t, y, has)
-    if why == "capacity" and single == "1":
-        # a capacity miss of the single-collective exchange is resumed with more capacity, not repeated from the start
+    if why == "capacity":
         assert f.last_attempts == 1 and f.last_resumes >= 1
     else:
         assert f.last_attempts == 2
@@ -217,16 +201,14 @@ def test_fixed_capacity_series_is_repeated_exactly_when_voided(why, single, monk
         s.close()
 
 
-@pytest.mark.parametrize("single", ["1", "0"])
 @pytest.mark.parametrize("world", [2, 3])
 @pytest.mark.parametrize("d,n,T", [(1, 3000, 12), (2, 4099, 12), (4, 5001, 12), (6, 4100, 12), (8, 3073, 12), (16, 4097, 12)])
-def test_local_shards_every_staging_layout_with_remote_candidates(world, d, n, T, single, monkeypatch):
+def test_local_shards_every_staging_layout_with_remote_candidates(world, d, n, T):
     """k_propagate stages the next tile through LDS with 16 bytes per element (IT * d <= 9) or 8 bytes (two dword
     fetches); in the sharded filter part of the gathered states are candidates received from other ranks (second
-    source, rows of d + 1 doubles in the fixed-capacity series).  Odd shard starts also exercise the unpaired
-    normal streams.  Both exchanges (the first observations exact, the rest fixed-capacity) against the oracle."""
+    source, rows of d + 1 doubles in the single-collective series).  Odd shard starts also exercise the unpaired
+    normal streams.  Both exchanges against the oracle."""
     from composablestatespacemodels_amd.sharded import GpuShard, LocalComm, ShardedFilter
-    monkeypatch.setenv("CSSM_SHARD_SINGLE", single)
     model = cases.dim_model(d)
     t, y, has = cases.poisson_counts(T, missing=0.15)
     shards = [GpuShard(model, n, r, world, cases.SEED, 0) for r in range(world)]

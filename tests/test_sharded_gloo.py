@@ -28,7 +28,7 @@ def _series(C, T, missing, prec):
     return t, y, has
 
 
-def _worker(rank, world, port, name, n, T, missing, prec, out_dir, single):
+def _worker(rank, world, port, name, n, T, missing, prec, out_dir):
     sys.path.insert(0, HERE)
     sys.path.insert(0, os.path.dirname(HERE))
     import cases as C
@@ -36,20 +36,15 @@ def _worker(rank, world, port, name, n, T, missing, prec, out_dir, single):
     from oracle_shard import OracleShard
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
-    os.environ["CSSM_SHARD_SINGLE"] = single
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         model = getattr(C, name)()
         t, y, has = _series(C, T, missing, prec)
         shard = OracleShard(model, n, rank, world, C.SEED, prec)
         f = ShardedFilter([shard], DistComm())
-        if missing == -0.1:        # the outlier falls into a prefix run with the exact exchange (sums formed again for that step)
-            f.EXACT_STEPS = 4
-        if missing == -0.2:        # the outlier falls into the fixed-capacity part of the series
-            f.EXACT_STEPS = 1
-        if missing == 0.05:        # capacity too small for what the exchange needs: the series is repeated exactly
-            f.EXACT_STEPS, f.MIN_CAP, f.CAP_HEADROOM, f.CAP_SQRT = 1, 1, 0, 0.0
-        ll, ess = f.ll_filter(t, y, has, lgcp=bool(prec))
+        if missing == 0.05:        # capacity too small for what the exchange needs: the observations that miss are resumed
+            f.MIN_CAP, f.CAP_SQRT = 1, 0.0
+        ll, ess = f.ll_filter(t, y, has, lgcp=bool(prec), exact=(missing == -0.1))
         np.savez(os.path.join(out_dir, f"r{rank}.npz"), ll=ll, ess=ess, part=shard.particles(), redone=shard.redone,
                  attempts=f.last_attempts, cap=-1 if f.last_cap is None else f.last_cap, single=int(f.last_single), resumes=int(f.last_resumes))
     finally:
@@ -59,20 +54,17 @@ def _worker(rank, world, port, name, n, T, missing, prec, out_dir, single):
 @pytest.mark.parametrize("world,name,n,T,missing,prec", [
     (2, "c2_model", 301, 7, 0.2, 0),
     (3, "c1_model", 200, 6, 0.0, 0),
-    (2, "c4_model", 150, 4, 0.0, 2),
-    (2, "c2_model", 256, 6, -0.1, 0),
-    (2, "c2_model", 256, 12, -0.2, 0),
-    (3, "c2_model", 300, 12, 0.05, 0),
+    (2, "c4_model", 150, 4, 0.0, 2),       # LGCP: the exact exchange (its level is the max)
+    (2, "c2_model", 256, 6, -0.1, 0),      # an outlying observation inside a series forced onto the exact exchange
+    (2, "c2_model", 256, 12, -0.2, 0),     # ... inside a single-collective series: voided, repeated exactly
+    (3, "c2_model", 300, 12, 0.05, 0),     # capacity misses: resumed in place
     (2, "c3_model", 200, 14, 0.0, 0),
 ])
-@pytest.mark.parametrize("single", ["1", "0"])
-def test_sharded_orchestration_over_gloo_matches_single_rank(tmp_path, world, name, n, T, missing, prec, single):
-    """single = 1: ONE all-to-all per observation carries sums and boundary particles (the default); single = 0:
-    all-gather of the sums, then the all-to-all of the packed ranges."""
-    if single == "0" and (prec or T <= 8):
-        pytest.skip("the series never leaves the exact exchange: nothing differs between the two modes")
-    port = 29600 + (os.getpid() % 300) + world + (40 if single == "0" else 0)
-    mp.spawn(_worker, args=(world, port, name, n, T, missing, prec, str(tmp_path), single), nprocs=world, join=True)
+def test_sharded_orchestration_over_gloo_matches_single_rank(tmp_path, world, name, n, T, missing, prec):
+    """ONE all-to-all per observation carries sums and boundary particles (ordinary series); all-gather + host-read sizes +
+    all-to-all-v (LGCP, forced, or the repetition after an outlying observation)."""
+    port = 29600 + (os.getpid() % 300) + world
+    mp.spawn(_worker, args=(world, port, name, n, T, missing, prec, str(tmp_path)), nprocs=world, join=True)
     model = getattr(cases, name)()
     t, y, has = _series(cases, T, missing, prec)
     o = oracle.OraclePf(model.descriptor(prec), n, cases.SEED)
@@ -80,15 +72,12 @@ def test_sharded_orchestration_over_gloo_matches_single_rank(tmp_path, world, na
     parts = []
     for r in range(world):
         z = np.load(os.path.join(str(tmp_path), f"r{r}.npz"))
-        # the second attempt runs exactly for the steps whose level the max rules out (LGCP: every step)
+        # sums are formed a second time exactly for the observations whose level the max rules out (LGCP: every one)
         assert int(z["redone"]) == (T if prec else (1 if missing < 0 else 0))
-        # a series is run once unless a sticky bit (level ruled out / capacity exceeded in its fixed-capacity part) voids it
-        resumed = (missing == 0.05 and single == "1")     # a capacity miss of the single-collective exchange is resumed, not repeated
-        assert int(z["attempts"]) == (1 if resumed else (2 if missing in (-0.2, 0.05) else 1))
+        resumed = missing == 0.05                       # capacity misses are resumed, not repeated from the start
+        assert int(z["attempts"]) == (2 if missing == -0.2 else 1)
         assert (int(z["resumes"]) >= 1) == resumed
-        if T > 8 and missing == 0.0:
-            assert int(z["cap"]) >= 1             # the fixed-capacity exchange did run
-        assert int(z["single"]) == (0 if prec else int(single))
+        assert int(z["single"]) == (0 if (prec or missing < 0) else 1)
         assert float(z["ll"]) == ll and int(z["ess"]) == int(ess_t[-1])
         parts.append(z["part"])
     np.testing.assert_array_equal(np.concatenate(parts, axis=1), o.particles())
