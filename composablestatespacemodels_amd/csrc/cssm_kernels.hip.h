@@ -543,7 +543,11 @@ __global__ __launch_bounds__(CSSM_BLOCK) void k_boundary_pack(const double* __re
                                                               uint64_t n_local, int d, int world, int rank, long long cap,
                                                               const StepRec* __restrict__ rec, const cssm_u128* __restrict__ subS,
                                                               const cssm_u128* __restrict__ subS2, uint32_t nsub,
-                                                              const Scalars* __restrict__ sc, double* __restrict__ out, uint64_t chunk) {
+                                                              const Scalars* __restrict__ sc, double* __restrict__ out, uint64_t chunk,
+                                                              int level_from_max) {
+  // level_from_max: the sums (subS) were formed relative to the level chosen with the GLOBAL max after an all-gather of the
+  // local maxima (cssm_pf_shard_sums: LGCP series, whose level is the max; the repetition of a series an outlying observation
+  // voided) -- the weights of the rows are then relative to sc->ref and the header carries the global max
   // chunk = particles per sub-unit sum of k_propagate (subS): when the tiles of the carried block coincide with
   // sub-units, the prefix of the tiles before a block's own is read from subS instead of being recomputed
   __shared__ cssm_u128 s_w[CSSM_BLOCK / 64], s_r[2][CSSM_BLOCK / 64];
@@ -556,7 +560,7 @@ __global__ __launch_bounds__(CSSM_BLOCK) void k_boundary_pack(const double* __re
   // anything else), so only their segments carry rows; every other segment is its header
   const long long cnt = (q == rank + 1 || q == rank - 1) ? ((long long)n_local < cap ? (long long)n_local : cap) : 0;
   const uint64_t first = (q < rank) ? 0 : n_local - (uint64_t)cnt;     // first particle of the block the segment carries
-  const double cref = rec->ref;
+  const double cref = level_from_max ? sc->ref : rec->ref;
   auto tile_weights = [&](uint64_t base, cssm_u128 (&qq)[CSSM_ITEMS]) {   // particles first + base + 4 tid .. of the block
 #pragma unroll
     for (int r = 0; r < CSSM_ITEMS; ++r) {
@@ -628,7 +632,9 @@ __global__ __launch_bounds__(CSSM_BLOCK) void k_boundary_pack(const double* __re
   if (lane == 0) { s_r[0][wid] = a; s_r[1][wid] = b; }
   __syncthreads();
   unsigned long long key = 0ull;
-  if (threadIdx.x < 64) {
+  if (level_from_max) {
+    key = cssm_order_key(sc->gmax);                    // (the slots were exported and cleared before the all-gather)
+  } else if (threadIdx.x < 64) {
     key = (threadIdx.x < CSSM_MAXSLOTS) ? sc->maxslot[(size_t)threadIdx.x * CSSM_SLOT_STRIDE] : 0ull;   // slot set 0 (sharded handles)
     key = wave_max_u64(key);
   }

@@ -1465,10 +1465,11 @@ done:
 // torch.distributed).  See include/cssm_pf.h for the sequence.
 
 // level of the step from the all-gathered order keys (word 4 of every rank's 5 words)
-__global__ void k_import_level(Scalars* sc, const unsigned long long* __restrict__ all5, int world) {
+__global__ void k_import_level(Scalars* sc, const unsigned long long* __restrict__ all5, int world, const StepRec* __restrict__ rec) {
   unsigned long long key = 0ull;
   for (int r = 0; r < world; ++r) { const unsigned long long k = all5[5 * r + 4]; key = (k > key) ? k : key; }
   sc->gmax = cssm_order_unkey(key);
+  sc->ref = cssm_ref_choose(rec->ref, sc->gmax);   // the level every kernel of the step agrees on (k_tile_sums applies the same rule)
 }
 
 // For every destination rank q (owner of slots [q*n_per, min((q+1)*n_per, N))): the contiguous
@@ -1576,7 +1577,8 @@ extern "C" int cssm_pf_shard_sums(cssm_pf* pf, const uint64_t* all_sums5_dev, in
   if (world < 1 || world > 64) return fail(CSSM_ESHARD, "world %d", world);
   const size_t slot = last_rec_slot(pf);
   const int tgrid = (int)pf->nunits;
-  hipLaunchKernelGGL(k_import_level, dim3(1), dim3(1), 0, pf->stream, pf->sc, (const unsigned long long*)all_sums5_dev, world);
+  hipLaunchKernelGGL(k_import_level, dim3(1), dim3(1), 0, pf->stream, pf->sc, (const unsigned long long*)all_sums5_dev, world,
+                     (const StepRec*)(pf->d_recs + slot));
   hipLaunchKernelGGL(k_tile_sums, dim3(tgrid), dim3(CSSM_BLOCK), 0, pf->stream, pf->logw, pf->n, pf->sc, pf->tileS, pf->tileS2, pf->ntiles,
                      pf->sup, pf->nunits, 0, -1, (const double*)nullptr, pf->d_logtab, (const StepRec*)(pf->d_recs + slot));
   // word 4 (the max key) of sums5_dev is left as shard_propagate wrote it
@@ -1742,7 +1744,7 @@ extern "C" int cssm_pf_shard_boundary_pack(cssm_pf* pf, int rank, int world, int
   if (rc) return rc;
   if (!send_buf_dev) return fail(CSSM_EINVAL_ARG, "null argument");
   if (cap < 1 || world < 1 || world > 64 || rank < 0 || rank >= world) return fail(CSSM_ESHARD, "rank %d / world %d / cap %lld", rank, world, (long long)cap);
-  if (!pf->last_optimistic) return fail(CSSM_ESTATE, "the single-collective exchange needs the sums k_propagate forms (not LGCP, not the second attempt)");
+  // !last_optimistic: the sums were formed by cssm_pf_shard_sums relative to the level chosen with the all-gathered max
   const size_t slot = last_rec_slot(pf);
   const uint64_t chunk = (uint64_t)pf->sup * CSSM_TILE / pf->split;
   const uint32_t nsub = (uint32_t)((pf->n + chunk - 1) / chunk);
@@ -1750,7 +1752,7 @@ extern "C" int cssm_pf_shard_boundary_pack(cssm_pf* pf, int rank, int world, int
   const int tiles = (int)((cnt + CSSM_TILE - 1) / CSSM_TILE);
   hipLaunchKernelGGL(k_boundary_pack, dim3(tiles + 1, world), dim3(CSSM_BLOCK), 0, pf->stream, pf->state[pf->cur], pf->stride, pf->logw, pf->n, pf->d,
                      world, rank, (long long)cap, pf->d_recs + slot, (const cssm_u128*)pf->tileS, (const cssm_u128*)pf->tileS2, nsub,
-                     (const Scalars*)pf->sc, send_buf_dev, chunk);
+                     (const Scalars*)pf->sc, send_buf_dev, chunk, pf->last_optimistic ? 0 : 1);
   HIP_TRY(hipGetLastError());
   return CSSM_OK;
 }
@@ -1772,7 +1774,7 @@ extern "C" int cssm_pf_shard_adopt_spec(cssm_pf* pf, const double* recv_buf_dev,
                      (const cssm_u128*)pf->tileS, (const cssm_u128*)pf->tileS2, (const StepRec*)(pf->d_recs + slot), pf->n_global, pf->endslot,
                      pf->anc, pf->ntiles, pf->sup, pf->nunits, 0, 0, (double*)nullptr, (int32_t*)nullptr, 0u, pf->opt_exact,
                      all5, rank, world, (int)pf->split, pf->seed, (double*)nullptr, (const double*)pf->d_logtab,
-                     2, (unsigned long long*)(pf->d_xch + 128), (uint32_t)pf->first, (uint32_t)(pf->first + pf->n), (uint32_t)seg,
+                     pf->last_optimistic ? 2 : 0, (unsigned long long*)(pf->d_xch + 128), (uint32_t)pf->first, (uint32_t)(pf->first + pf->n), (uint32_t)seg,
                      recv_buf_dev, (long long)cap, pf->d, n_split);
   HIP_TRY(hipGetLastError());
   pf->src = pf->state[pf->cur]; pf->src_stride = pf->stride;
@@ -1867,7 +1869,7 @@ static RcclApi* rccl_api_load() {
   api.ok = api.GetUniqueId && api.CommInitRank && api.CommDestroy && api.AllToAll;
   return api.ok ? &api : nullptr;
 }
-const int kNcclFloat64 = 8;   // ncclDataType_t (rccl.h)
+const int kNcclUint64 = 5, kNcclFloat64 = 8;   // ncclDataType_t (rccl.h)
 int rccl_fail(RcclApi* a, const char* what, int r) {
   return fail(CSSM_ERCCL, "%s: %s", what, (a && a->GetErrorString) ? a->GetErrorString(r) : "RCCL error");
 }
@@ -1940,6 +1942,12 @@ extern "C" int cssm_pf_shard_series_rccl(cssm_pf* pf, void* comm, int rank, int 
   RcclApi* a = rccl_api();
   if (!a) return fail(CSSM_ERCCL, "librccl.so could not be loaded");
   pf->last_comm = comm;
+  // single_collective & 4: the level comes from the GLOBAL max (LGCP; the repetition of a series an outlying observation
+  // voided): an all-gather of the ranks' 5 words (only the max key matters) and cssm_pf_shard_sums precede the all-to-all
+  const bool level_from_max = (single_collective & 4) != 0;
+  single_collective &= 3;
+  if (level_from_max && single_collective == 0) single_collective = 1;
+  if (level_from_max && !a->AllGather) return fail(CSSM_ERCCL, "this RCCL has no ncclAllGather");
   if (single_collective) {   // sums and boundary particles in ONE all-to-all per observation (k_boundary_pack / k_expand_spec)
     const size_t sseg = (size_t)spec_seg(pf->d, (long long)cap);
     // single_collective == 2: only the two adjacent ranks get (and send) whole segments, every other pair exchanges the
@@ -1954,9 +1962,15 @@ extern "C" int cssm_pf_shard_series_rccl(cssm_pf* pf, void* comm, int rank, int 
       displs[(size_t)q] = (size_t)q * sseg;
     }
     for (size_t s = s_begin; s < s_end; ++s) {
-      rc = cssm_pf_shard_propagate_at(pf, s, nullptr);
+      rc = cssm_pf_shard_propagate_at(pf, s, level_from_max ? sums5_dev : nullptr);
       if (rc) return rc;
       if (!weighted[s]) continue;
+      if (level_from_max) {
+        const int rg = a->AllGather(sums5_dev, all_sums5_dev, 5, kNcclUint64, comm, pf->stream);
+        if (rg) { if (a->CommAbort) (void)a->CommAbort(comm); pf->last_comm = nullptr; return rccl_fail(a, "ncclAllGather", rg); }
+        rc = cssm_pf_shard_sums(pf, all_sums5_dev, world, sums5_dev);
+        if (rc) return rc;
+      }
       rc = cssm_pf_shard_boundary_pack(pf, rank, world, cap, send_buf_dev);
       if (rc) return rc;
       const int r = trimmed ? a->AllToAllv(send_buf_dev, counts.data(), displs.data(), recv_buf_dev, counts.data(), displs.data(), kNcclFloat64,
@@ -1972,7 +1986,7 @@ extern "C" int cssm_pf_shard_series_rccl(cssm_pf* pf, void* comm, int rank, int 
     }
     return CSSM_OK;
   }
-  return fail(CSSM_EINVAL_ARG, "single_collective must be 1, 2 or 3");
+  return fail(CSSM_EINVAL_ARG, "single_collective must be 1, 2 or 3 (+ 4: level from the all-gathered max)");
 }
 
 extern "C" int cssm_pf_shard_pack(cssm_pf* pf, int world, const int64_t* send_first_host, const int64_t* send_count_host,

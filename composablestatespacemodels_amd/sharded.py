@@ -16,13 +16,17 @@ Two exchanges exist (stage calls of include/cssm_pf.h):
 
 Nothing is read by the host per observation.  A capacity miss is resumed in place (``shard_resume``: that observation's
 exchange is redone with four times the capacity, the series carries on); a reference level ruled out by the max
-(an outlying observation) repeats the series with the exact exchange.  With ``DistComm`` over RCCL the library enqueues
+(an outlying observation) repeats the series with every level taken from the global max (below).  With ``DistComm`` over RCCL the library enqueues
 kernels AND collectives itself (``cssm_pf_shard_series_rccl``), in stretches after each of which one status word is
 read, bounded by a timeout (a rank that never joins a collective surfaces as an RCCL error on every rank, not a hang).
 
-**Exact exchange** -- LGCP series (their level is the max, which needs an exchange of its own), forced (``exact=True``),
-or the repetition just mentioned: all-gather of the sums, ``shard_offspring``, all-to-all of the range sizes, ONE host
-read of those sizes, all-to-all-v of (d + 1) doubles per candidate, ``shard_adopt``.
+LGCP series (their level IS the max) and the repetition just mentioned run the same exchange with the level taken from
+the GLOBAL max: an all-gather of the ranks' 5 words and ``shard_sums`` (sums relative to the level the gathered max
+selects) precede the all-to-all -- two collectives per observation, still nothing read by the host.
+
+**Exact exchange** -- forced (``exact=True``; tests, and the stage calls a host may drive itself): all-gather of the sums,
+``shard_offspring``, all-to-all of the range sizes, ONE host read of those sizes, all-to-all-v of (d + 1) doubles per
+candidate, ``shard_adopt``.
 
 Random variates are keyed by the GLOBAL particle id and every sum is an integer sum, so ll, ess
 and the ancestor arrays are bit-identical for 1, 2, 4 and 8 ranks.
@@ -440,8 +444,11 @@ class ShardedFilter:
         S, comm = self.shards, self.comm
         n_max = -(-S[0].n_global // comm.world)
         for attempt in range(2):
-            # attempt 1: the single-collective exchange; attempt 2 (an outlying observation voided it): the exact exchange
-            all_exact = exact or lgcp or attempt == 1 or not all(hasattr(s, "boundary_pack") for s in S)
+            # attempt 1: the single-collective exchange, every observation's level being its reference level.  LGCP (the
+            # level IS the max) and attempt 2 (an outlying observation voided attempt 1): the level comes from the global
+            # max -- an all-gather of the local maxima and shard_sums precede the all-to-all; still nothing is read by the host.
+            all_exact = exact or not all(hasattr(s, "boundary_pack") for s in S)
+            from_max = (not all_exact) and (lgcp or attempt == 1)
             for s in S:
                 s.begin(t, y, has)
             cap = None if all_exact else self._capacity()
@@ -481,7 +488,7 @@ class ShardedFilter:
                     kend = min(k + self.NATIVE_STRETCH, T)
                     nb = comm.world * S[0].spec_segment(cap)
                     S[0].series_native(native, k, kend, weighted, cap, S[0].buffer("send_spec", nb)[:nb],
-                                       S[0].buffer("recv_spec", nb)[:nb], single_collective=mode)
+                                       S[0].buffer("recv_spec", nb)[:nb], single_collective=mode + (4 if from_max else 0))
                     self.last_all_to_all = ("ncclAllToAllv: whole segments between adjacent ranks, 12 header words between the others"
                                             if (mode == 3 or (mode == 2 and comm.world > 2)) else "ncclAllToAll, equal split of whole segments")
                     k = kend
@@ -489,7 +496,11 @@ class ShardedFilter:
                     continue
                 if not redo_exchange:               # (after a resume the observation is already propagated)
                     for s in S:
-                        s.propagate_at(k) if all_exact else s.propagate_at(k, with_sums=False)
+                        s.propagate_at(k) if (all_exact or from_max) else s.propagate_at(k, with_sums=False)
+                    if from_max and weighted[k]:
+                        comm.all_gather([s.all_sums for s in S], [s.sums5 for s in S])   # only the max keys matter
+                        for s in S:
+                            s.sums()                # the sums, relative to the level the gathered max selects
                 if weighted[k]:
                     if all_exact:
                         self._resample_exact(lgcp)
@@ -501,6 +512,7 @@ class ShardedFilter:
                     look_for_a_miss()                # host-driven series: one look at its end
             self.last_resumes = resumes
             self.last_single = not all_exact
+            self.last_from_max = from_max
             self.last_native = native is not None
             res = [s.status(T) for s in S]
             # bit 4 (an observation's reference level was ruled out by the max) means "again, exactly"; any rank may have

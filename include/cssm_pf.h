@@ -363,6 +363,8 @@ int cssm_pf_shard_status(cssm_pf* pf, double* ll_out, int32_t* ess_out, uint32_t
  * ranks' boundary blocks raise sticky bit 8 (a capacity miss).
  *   cssm_pf_shard_spec_segment    doubles per pair of ranks for capacity `cap` (send / recv buffers: world segments)
  *   cssm_pf_shard_propagate_at    with sums5_dev = NULL
+ *   [level from the global max instead (LGCP; repetition after an outlying observation): propagate_at with sums5_dev,
+ *    all-gather of the 5 words, cssm_pf_shard_sums -- the sums are then relative to the level the gathered max selects]
  *   cssm_pf_shard_boundary_pack   a header for every destination, boundary rows for the two adjacent ranks
  *   (all-to-all of cssm_pf_shard_spec_segment doubles per pair)
  *   cssm_pf_shard_adopt_spec      offspring of the own particles, expansion of the received rows, coverage check
@@ -383,10 +385,13 @@ int cssm_pf_shard_resume(cssm_pf* pf, uint32_t* fail_step_out);
  * stream, no host wait.  single_collective = 1: equal-split ncclAllToAll of whole segments; 2: ncclAllToAllv in which only
  * the adjacent pairs exchange whole segments and every other pair the 12 header words (nothing else of those segments is
  * ever read; falls back to 1 when world <= 2 or the RCCL copy has no ncclAllToAllv); 3 = the same for any world, an error
- * without ncclAllToAllv (tests).  The communicator is made from an id that rank 0 creates and hands to the other ranks by
+ * without ncclAllToAllv (tests); + 4 (i.e. 5, 6, 7): the level of every observation comes from the GLOBAL max -- an
+ * ncclAllGather of the ranks' 5 words and cssm_pf_shard_sums precede the all-to-all (LGCP series, whose level IS the max;
+ * the repetition of a series an outlying observation voided): 2 collectives per observation, still no host read.
+ * The communicator is made from an id that rank 0 creates and hands to the other ranks by
  * whatever channel the host has (bench.py: torch.distributed's object broadcast).  weighted[s] != 0: observation s
- * resamples.  Buffers (device): send / recv world * cssm_pf_shard_spec_segment doubles each; sums5 / all_sums5 are not used
- * by this exchange (kept in the signature for the stage-call hosts).
+ * resamples.  Buffers (device): send / recv world * cssm_pf_shard_spec_segment doubles each; sums5 (5 words) / all_sums5
+ * (5 * world words) are used by the + 4 modes only.
  * The library never waits without a bound for work that contains its collectives: cssm_pf_shard_status / _resume poll the
  * stream, watch the communicator's asynchronous error state and after CSSM_SHARD_TIMEOUT_S seconds (environment; default
  * 600) abort the communicator and return CSSM_ERCCL -- a rank that died or returned early surfaces as an error on every

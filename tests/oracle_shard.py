@@ -81,7 +81,7 @@ class OracleShard:
 
     def _local_sums(self, level, clamp):
         a = self.logw - level
-        self.w1 = oracle.c_exp(np.minimum(a, 6.0) if clamp else a)   # k_propagate clamps: beyond c + 6 the step is redone anyway
+        self.w1 = oracle.c_exp(np.minimum(a, 2.0**-20) if clamp else a)   # k_propagate clamps at CSSM_REF_BELOW: beyond it the step is redone anyway
         self.q = [fix(float(w)) for w in self.w1]
         S = sum(self.q); S2 = sum(fix(float(w * w)) for w in self.w1)
         a, b = _split64(S); c, d = _split64(S2)

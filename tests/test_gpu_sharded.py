@@ -57,17 +57,25 @@ def test_local_shards_degenerate_weights():
     np.testing.assert_array_equal(np.concatenate([s.particles() for s in shards], axis=1), opart)
 
 
-def test_local_shards_lgcp():
+@pytest.mark.parametrize("world,n", [(2, 3000), (4, 9000), (8, 20000)])
+@pytest.mark.parametrize("name", ["c4_model", "lgcp_seasonal_model"])
+def test_local_shards_lgcp(world, n, name):
+    """LGCP series (BASELINE config 4 is the 8-GPU one): the level of every observation is the global max, so an all-gather of
+    the local maxima and the sums relative to it precede the single all-to-all -- two collectives per observation, nothing
+    read by the host; bit-identical to the single-rank oracle for 2, 4 and 8 shards.  Also through the exact exchange."""
     from composablestatespacemodels_amd.sharded import GpuShard, LocalComm, ShardedFilter
-    model = cases.c4_model()
-    n, world = 3000, 2
-    t, y, has = cases.event_times(6)
+    model = getattr(cases, name)()
+    t, y, has = cases.event_times(7, horizon=12.0)
     shards = [GpuShard(model, n, r, world, cases.SEED, 0, lgcp_precision=2) for r in range(world)]
     f = ShardedFilter(shards, LocalComm(world))
-    ll, ess = f.ll_filter(t, y, has, lgcp=True)
     oll, oess, opart = _oracle_run(model, n, t, y, has, lgcp_precision=2)
-    assert (ll, ess) == (oll, oess[-1])
-    np.testing.assert_array_equal(np.concatenate([s.particles() for s in shards], axis=1), opart)
+    for exact in (False, True):
+        ll, ess = f.ll_filter(t, y, has, lgcp=True, exact=exact)
+        assert f.last_single == (not exact) and f.last_from_max == (not exact) and f.last_attempts == 1
+        assert (ll, ess) == (oll, oess[-1])
+        np.testing.assert_array_equal(np.concatenate([s.particles() for s in shards], axis=1), opart)
+    for s in shards:
+        s.close()
 
 
 @pytest.mark.parametrize("world", [2, 8])
@@ -121,6 +129,17 @@ def test_rccl_world1_matches_oracle():
         assert f4.last_native and f4.last_single and (ll, ess) == (oll, oess[-1])
         np.testing.assert_array_equal(shard.particles(), opart)
         f4.comm.close()
+        # an LGCP series with the library's own loop: all-gather of the maxima + all-to-all per observation (mode 1 + 4)
+        lm = cases.c4_model()
+        lt, ly, lh = cases.event_times(9)
+        lshard = GpuShard(lm, 6000, 0, 1, cases.SEED, 0, lgcp_precision=2)
+        fl = ShardedFilter([lshard], DistComm(device=torch.device("cuda", 0)))
+        ll, ess = fl.ll_filter(lt, ly, lh, lgcp=True)
+        lo = _oracle_run(lm, 6000, lt, ly, lh, lgcp_precision=2)
+        assert fl.last_native and fl.last_single and fl.last_from_max and (ll, ess) == (lo[0], lo[1][-1])
+        np.testing.assert_array_equal(lshard.particles(), lo[2])
+        lshard.close()
+        fl.comm.close()
         # the same series with the collectives issued through torch.distributed: identical bits
         os.environ["CSSM_SHARD_NATIVE"] = "0"
         try:
@@ -193,7 +212,7 @@ def test_series_resumes_a_capacity_miss_and_repeats_after_an_outlying_observatio
     if why == "capacity":
         assert f.last_attempts == 1 and f.last_resumes >= 1
     else:
-        assert f.last_attempts == 2
+        assert f.last_attempts == 2 and f.last_single and f.last_from_max   # repeated with every level taken from the global max
     oll, oess, opart = _oracle_run(model, n, t, y, has)
     assert (ll, ess) == (oll, oess[-1])
     np.testing.assert_array_equal(np.concatenate([s.particles() for s in shards], axis=1), opart)

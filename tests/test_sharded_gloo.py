@@ -46,7 +46,7 @@ def _worker(rank, world, port, name, n, T, missing, prec, out_dir):
             f.MIN_CAP, f.CAP_SQRT = 1, 0.0
         ll, ess = f.ll_filter(t, y, has, lgcp=bool(prec), exact=(missing == -0.1))
         np.savez(os.path.join(out_dir, f"r{rank}.npz"), ll=ll, ess=ess, part=shard.particles(), redone=shard.redone,
-                 attempts=f.last_attempts, cap=-1 if f.last_cap is None else f.last_cap, single=int(f.last_single), resumes=int(f.last_resumes))
+                 attempts=f.last_attempts, cap=-1 if f.last_cap is None else f.last_cap, single=int(f.last_single), resumes=int(f.last_resumes), from_max=int(f.last_from_max))
     finally:
         dist.destroy_process_group()
 
@@ -54,9 +54,10 @@ def _worker(rank, world, port, name, n, T, missing, prec, out_dir):
 @pytest.mark.parametrize("world,name,n,T,missing,prec", [
     (2, "c2_model", 301, 7, 0.2, 0),
     (3, "c1_model", 200, 6, 0.0, 0),
-    (2, "c4_model", 150, 4, 0.0, 2),       # LGCP: the exact exchange (its level is the max)
+    (2, "c4_model", 150, 4, 0.0, 2),       # LGCP: the level is the global max (all-gather + sums before the all-to-all)
+    (3, "c4_model", 200, 5, 0.0, 1),
     (2, "c2_model", 256, 6, -0.1, 0),      # an outlying observation inside a series forced onto the exact exchange
-    (2, "c2_model", 256, 12, -0.2, 0),     # ... inside a single-collective series: voided, repeated exactly
+    (2, "c2_model", 256, 12, -0.2, 0),     # ... inside a single-collective series: voided, repeated with levels from the max
     (3, "c2_model", 300, 12, 0.05, 0),     # capacity misses: resumed in place
     (2, "c3_model", 200, 14, 0.0, 0),
 ])
@@ -72,12 +73,15 @@ def test_sharded_orchestration_over_gloo_matches_single_rank(tmp_path, world, na
     parts = []
     for r in range(world):
         z = np.load(os.path.join(str(tmp_path), f"r{r}.npz"))
-        # sums are formed a second time exactly for the observations whose level the max rules out (LGCP: every one)
-        assert int(z["redone"]) == (T if prec else (1 if missing < 0 else 0))
+        # sums are formed a second time for the observations whose level the max selects: every one of an LGCP series and of
+        # the repetition after an outlying observation; that observation alone under the exact exchange; else none
+        weighted = int(np.sum(has)) if not prec else T
+        assert int(z["redone"]) == (T if prec else (weighted if missing == -0.2 else (1 if missing == -0.1 else 0)))
         resumed = missing == 0.05                       # capacity misses are resumed, not repeated from the start
         assert int(z["attempts"]) == (2 if missing == -0.2 else 1)
         assert (int(z["resumes"]) >= 1) == resumed
-        assert int(z["single"]) == (0 if (prec or missing < 0) else 1)
+        assert int(z["single"]) == (0 if missing == -0.1 else 1)
+        assert int(z["from_max"]) == (1 if (prec or missing == -0.2) else 0)
         assert float(z["ll"]) == ll and int(z["ess"]) == int(ess_t[-1])
         parts.append(z["part"])
     np.testing.assert_array_equal(np.concatenate(parts, axis=1), o.particles())
