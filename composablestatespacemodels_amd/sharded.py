@@ -443,12 +443,21 @@ class ShardedFilter:
         weighted = np.ones(T, dtype=bool) if (has is None or lgcp) else np.asarray(has, dtype=bool)
         S, comm = self.shards, self.comm
         n_max = -(-S[0].n_global // comm.world)
-        for attempt in range(2):
-            # attempt 1: the single-collective exchange, every observation's level being its reference level.  LGCP (the
-            # level IS the max) and attempt 2 (an outlying observation voided attempt 1): the level comes from the global
-            # max -- an all-gather of the local maxima and shard_sums precede the all-to-all; still nothing is read by the host.
-            all_exact = exact or not all(hasattr(s, "boundary_pack") for s in S)
-            from_max = (not all_exact) and (lgcp or attempt == 1)
+        # Plans, tried in this order until one completes without a sticky bit:
+        #   "ref"   the single-collective exchange, every observation's level being its reference level
+        #   "max"   the same exchange with every level taken from the GLOBAL max (an all-gather of the local maxima and
+        #           shard_sums precede the all-to-all): LGCP series start here (their level IS the max); others get here
+        #           when an outlying observation voided "ref" (bit 4)
+        #   "exact" the host-read exchange: slots owned by particles of NON-adjacent ranks (weights so degenerate that no
+        #           capacity covers them: bit 8 survives the resumes), or forced
+        can_single = all(hasattr(s, "boundary_pack") for s in S)
+        plans = ["exact"] if (exact or not can_single) else (["max", "exact"] if lgcp else ["ref", "max", "exact"])
+        attempt = 0
+        while plans:
+            plan = plans.pop(0)
+            attempt += 1
+            all_exact = plan == "exact"
+            from_max = plan == "max"
             for s in S:
                 s.begin(t, y, has)
             cap = None if all_exact else self._capacity()
@@ -456,22 +465,26 @@ class ShardedFilter:
             if not all_exact and len(S) == 1 and hasattr(comm, "native_comm"):
                 native = comm.native_comm()
             mode = 2 if (self.SINGLE_MODE == 1 and os.environ.get("CSSM_SHARD_TRIM", "0") == "1") else self.SINGLE_MODE
-            k, resumes, redo_exchange, redo_cap, escalated = 0, 0, False, 0, {}
+            k, resumes, redo_exchange, redo_cap, escalated, give_up = 0, 0, False, 0, {}, False
 
             def look_for_a_miss():
                 """A capacity miss is resumable: the observation that missed was left untouched on every rank (all reach the
                 same verdict from the segment headers, so bit 8 needs no agreement) and every kernel behind it returned at
                 once.  Its exchange is redone with four times the capacity (again four times if it missed before); the
                 series behind it keeps the ordinary capacity."""
-                nonlocal k, resumes, redo_exchange, redo_cap
+                nonlocal k, resumes, redo_exchange, redo_cap, give_up
                 if all_exact or cap >= n_max or resumes >= 64:
                     return False
                 if max(s.status(T)[2] for s in S) != 8:
                     return False
                 ks = [s.resume() for s in S]
-                k = comm.agree_max([max(ks)] * len(S))
-                if any(v != k for v in ks):
+                kf = comm.agree_max([max(ks)] * len(S))
+                if any(v != kf for v in ks):
                     raise RuntimeError("ranks disagree on the observation whose exchange did not fit")
+                if escalated.get(kf, 0) >= n_max:
+                    give_up = True                   # even whole shards as boundary blocks do not cover it: the exact exchange
+                    return False
+                k = kf
                 escalated[k] = min(escalated.get(k, cap) * 4, n_max)
                 redo_cap = escalated[k]
                 if redo_cap >= 1024:
@@ -480,7 +493,7 @@ class ShardedFilter:
                 redo_exchange = True
                 return True
 
-            while k < T:
+            while k < T and not give_up:
                 if native is not None and not redo_exchange:
                     # the library enqueues kernels and RCCL collectives itself, one stream, no host-language call per
                     # observation -- in stretches, so that a capacity miss is noticed (one status read per stretch) before
@@ -514,13 +527,18 @@ class ShardedFilter:
             self.last_single = not all_exact
             self.last_from_max = from_max
             self.last_native = native is not None
+            if give_up:
+                plans = ["exact"]
+                continue
             res = [s.status(T) for s in S]
             # bit 4 (an observation's reference level was ruled out by the max) means "again, exactly"; any rank may have
             # raised it, every rank must repeat
             bits = comm.agree_max([max(r[2] for r in res)] * len(S))
             if bits == 0:
-                self.last_cap, self.last_attempts = cap, attempt + 1
+                self.last_cap, self.last_attempts = cap, attempt
                 return res[0][0], res[0][1]
+            if bits & 8:
+                plans = ["exact"]                    # (a level problem alone moves on to "max")
         raise RuntimeError("the exact exchange cannot raise a sticky bit")
 
     def result(self):
