@@ -551,7 +551,7 @@ __global__ __launch_bounds__(CSSM_BLOCK) void k_boundary_pack(const double* __re
   // chunk = particles per sub-unit sum of k_propagate (subS): when the tiles of the carried block coincide with
   // sub-units, the prefix of the tiles before a block's own is read from subS instead of being recomputed
   __shared__ cssm_u128 s_w[CSSM_BLOCK / 64], s_r[2][CSSM_BLOCK / 64];
-  if (sc->err & 8u) return;   // the series is on hold (capacity miss): nothing may change until the host resumes it
+  if (sc->err & (4u | 8u)) return;   // the series is on hold (capacity miss) or void (level ruled out): nothing may change
   const int q = blockIdx.y;
   const long long R = d + 1, HD = spec_hdr(d), seg = spec_seg(d, cap);
   double* oseg = out + (size_t)q * seg;
@@ -840,7 +840,18 @@ __device__ __forceinline__ void expand_spec_body(SpecHeaders& H, uint32_t bid, u
 __global__ __launch_bounds__(CSSM_BLOCK, CSSM_OFF_WAVES) void k_offspring_expand_spec(
     CSSM_OFFSPRING_PARAMS, uint32_t all5_stride, const double* __restrict__ recv, long long cap, int d, uint32_t n_split) {
   __shared__ SpecHeaders H;
-  if (sc->err & 8u) return;
+  if (sc->err & (4u | 8u)) return;
+  if (optimistic) {
+    // the level first: sums formed relative to a reference level that the global max rules out (an outlying observation) say
+    // nothing about coverage either.  Sticky bit 2 (4): every later kernel of the series returns at once, the host runs
+    // the series again with the levels taken from the global max.
+    unsigned long long key = 0ull;
+    for (int r = 0; r < world; ++r) { const unsigned long long k = all5[(size_t)all5_stride * r + 4]; key = (k > key) ? k : key; }
+    if (!(cssm_ref_choose(rec->ref, cssm_order_unkey(key)) == rec->ref)) {
+      if (blockIdx.x == 0 && threadIdx.x == 0) atomicOr(&sc->err, 4u);
+      return;
+    }
+  }
   if (!spec_read_headers(H, recv, world, rank, cap, d, n, n_global, rec)) {
     if (blockIdx.x == 0 && threadIdx.x == 0) { atomicOr(&sc->err, 8u); atomicMin(&sc->fail_step, rec->step); }
     return;

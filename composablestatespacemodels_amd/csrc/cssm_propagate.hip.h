@@ -379,7 +379,9 @@ __global__ __launch_bounds__(CSSM_BLOCK, (PropWaves<D, SUMS>::value)) void k_pro
   __shared__ double s_max[CSSM_BLOCK / 64];
   // (sharded series) the exchange of an earlier observation did not fit: the series is on hold and nothing may change
   // until the host resumes it (cssm_pf_shard_resume)
-  if (sc->err & (8u | 64u)) return;   // (bit 3: sharded exchange; bit 6: a single-GPU batch series waits for the redo of an outlying observation)
+  // bit 3: a sharded series is on hold (capacity miss); bit 6: a single-GPU batch series waits for the redo of an outlying
+  // observation; bit 2: a series enqueued ahead is void (its level was ruled out: the host repeats it) -- nothing to do
+  if (sc->err & (4u | 8u | 64u)) return;
   const uint32_t range_lo = blockIdx.x * (uint32_t)chunk;
   uint32_t n;                                                 // this block's range ends at n
   { const uint64_t range_hi = (uint64_t)range_lo + chunk; n = (uint32_t)((range_hi < n_arg) ? range_hi : n_arg); }

@@ -537,8 +537,8 @@ class ShardedFilter:
             if bits == 0:
                 self.last_cap, self.last_attempts = cap, attempt
                 return res[0][0], res[0][1]
-            if bits & 8:
-                plans = ["exact"]                    # (a level problem alone moves on to "max")
+            if (bits & 8) and not (bits & 4):
+                plans = ["exact"]                    # (a level problem moves on to "max")
         raise RuntimeError("the exact exchange cannot raise a sticky bit")
 
     def result(self):

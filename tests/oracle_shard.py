@@ -168,8 +168,8 @@ class OracleShard:
         self.init(float(self._t.min()))
 
     def propagate_at(self, k, with_sums=True):
-        if self.bits & 8:
-            return                                   # on hold after a capacity miss: nothing may change until resume()
+        if self.bits & 12:
+            return                                   # on hold after a capacity miss (8) or void (4: level ruled out): nothing may change
         self.propagate(float(self._t[k]), float(self._y[k]), bool(self._has[k]) or self.o_is_lgcp())
 
     def resume(self):
@@ -185,7 +185,7 @@ class OracleShard:
         return R * ((12 + self.d) // R) + cap * R + R * ((cap + self.d) // R)
 
     def boundary_pack(self, cap, send_buf):
-        if self.bits & 8:
+        if self.bits & 12:
             return
         R, seg = self.d + 1, self.spec_segment(cap)
         HD = R * ((12 + self.d) // R)
@@ -217,7 +217,7 @@ class OracleShard:
                 bits[o + HD + cap * R + i] = P[i] >> 64
 
     def adopt_spec(self, recv_buf, cap):
-        if self.bits & 8:
+        if self.bits & 12:
             return
         R, seg = self.d + 1, self.spec_segment(cap)
         HD = R * ((12 + self.d) // R)
@@ -227,6 +227,9 @@ class OracleShard:
         for r in range(self.world):                       # every rank's 5 words are in the segment headers
             for i in range(5):
                 self.all_sums[5 * r + i] = to_i64(int(bits[r * seg + 1 + i]))
+        if self.optimistic and not (float(oracle.lib().oracle_c_ref_choose(self.c, self._global_max())) == self.c):
+            self.bits |= 4                                  # the level first: the max rules the reference level out, the series is void
+            return
         v = [int(x) for x in self.all_sums.tolist()]
         S = [_join64(v[5 * r], v[5 * r + 1]) for r in range(self.world)]
         off = [sum(S[:r]) for r in range(self.world)]
