@@ -212,7 +212,9 @@ def test_series_resumes_a_capacity_miss_and_repeats_after_an_outlying_observatio
     if why == "capacity":
         assert f.last_attempts == 1 and f.last_resumes >= 1
     else:
-        assert f.last_attempts == 2 and f.last_single and f.last_from_max   # repeated with every level taken from the global max
+        # repeated with every level taken from the global max; a count of 60 also concentrates the weight on so few particles
+        # that slots of a rank can belong to particles of NON-adjacent ranks, which no capacity covers: then the exact exchange
+        assert (f.last_attempts == 2 and f.last_single and f.last_from_max) or (f.last_attempts == 3 and not f.last_single)
     oll, oess, opart = _oracle_run(model, n, t, y, has)
     assert (ll, ess) == (oll, oess[-1])
     np.testing.assert_array_equal(np.concatenate([s.particles() for s in shards], axis=1), opart)
