@@ -151,3 +151,13 @@ JNIEXPORT void JNICALL Java_com_github_jonnylaw_model_CssmNative_resampleSystema
   (*env)->ReleaseIntArrayElements(env, janc, a, 0);
   if (rc) throw_last(env);
 }
+
+/* The Philox key of the run-th filter run under one user seed (a PRF of (seed, run); include/cssm_numerics.h) */
+JNIEXPORT jlong JNICALL Java_com_github_jonnylaw_model_CssmNative_runKey(JNIEnv* env, jclass c, jlong seed, jlong run) {
+  return (jlong)cssm_pf_run_key((uint64_t)seed, (uint64_t)run);
+}
+
+/* Filter(mod, resample): the resampler of the device path (CSSM_OPT_RESAMPLER) */
+JNIEXPORT void JNICALL Java_com_github_jonnylaw_model_CssmNative_setResampler(JNIEnv* env, jclass c, jlong h, jint kind) {
+  if (cssm_pf_set_option((cssm_pf*)(intptr_t)h, CSSM_OPT_RESAMPLER, kind)) throw_last(env);
+}

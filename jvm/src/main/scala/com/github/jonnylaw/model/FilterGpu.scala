@@ -23,6 +23,10 @@ object CssmNative {
   @native def particles(handle: Long, out: Array[Double]): Unit
   @native def resampleSystematic(w: Array[Double], u: Double, anc: Array[Int], device: Int): Unit
   @native def resample(kind: Int, w: Array[Double], u: Double, seed: Long, step: Int, anc: Array[Int], device: Int): Unit
+  /** cssm_pf_run_key: the Philox key of the `run`-th filter run under one user seed -- a PRF of (seed, run), never seed + run. */
+  @native def runKey(seed: Long, run: Long): Long
+  /** cssm_pf_set_option(handle, CSSM_OPT_RESAMPLER, kind). */
+  @native def setResampler(handle: Long, kind: Int): Unit
 }
 
 /** Flattens a parameterised composed model into the cssm_model_desc wire form (see cssm_jni.c). */
@@ -31,9 +35,10 @@ object DescriptorBuilder {
   private val (fFirst, fSeasonal) = (0, 1)
   private val (poisson, gaussian, lgcp) = (0, 1, 2)
 
-  /** (unparameterised leaf kinds, parameters) => (ints, reals).  `leaves` lists, left to right,
-    * (obs/f kind, sde kind, dimension, period, harmonics) exactly as the user composed them with |+|. */
-  case class LeafSpec(obs: String, sde: Int, dim: Int, period: Int = 0, harmonics: Int = 0)
+  /** One leaf of the composition, left to right: (obs/f kind, sde kind, dimension, period, harmonics).  Users never write
+    * these: they come from LeafSpecs.ofModel (a single leaf model, by matching the private case classes) or from the
+    * structure-carrying constructors of GpuModel (a composition). */
+  case class LeafSpec(obs: String, sde: Int, dim: Int, period: Int = 0, harmonics: Int = 0, df: Int = 0)
 
   def apply(leaves: Seq[LeafSpec], p: Parameters, precision: Int = 0, df: Int = 0): (Array[Int], Array[Double]) = {
     val nodes: Seq[ParamNode] = p.flatten                      // Tree.flatten, Tree.scala:49-53
@@ -56,23 +61,118 @@ object DescriptorBuilder {
   }
 }
 
+/** The leaf structure of a parameterised model, recovered inside package `model` where the case classes are visible
+  * (Model.scala:144,168,204,241,266,281,315,339,363; Sde.scala:69,98,129). */
+object LeafSpecs {
+  import DescriptorBuilder.LeafSpec
+  def ofSde(s: Sde): (Int, Int) = s match {
+    case BrownianMotion(_, d)    => (0, d)
+    case GenBrownianMotion(_, d) => (1, d)
+    case OuProcess(_, d)         => (2, d)
+    case other => throw new IllegalArgumentException(s"the GPU filter serves the built-in SDEs; got $other")
+  }
+  /** Some(leaf) for a single-leaf model.  A COMPOSED model is an anonymous `new Model { ... }` closure (Model.compose,
+    * Model.scala:110-136): its leaves cannot be recovered from the value -- compose with GpuModel instead, which
+    * carries the structure alongside the reference's own UnparamModel. */
+  def ofModel(m: Model): Option[Seq[LeafSpec]] = {
+    def leaf(obs: String, sde: Sde, period: Int = 0, harmonics: Int = 0, df: Int = 0) = {
+      val (k, d) = ofSde(sde); Some(Seq(LeafSpec(obs, k, d, period, harmonics, df)))
+    }
+    m match {
+      case PoissonModel(sde, _)             => leaf("poisson", sde)
+      case SeasonalModel(p, h, sde, _)      => leaf("seasonal", sde, p, h)
+      case LinearModel(sde, _)              => leaf("linear", sde)
+      case StudentsTModel(sde, df, _)       => leaf("studentt", sde, df = df)
+      case NegativeBinomialModel(sde, _)    => leaf("negbin", sde)
+      case ZeroInflatedPoisson(sde, _)      => leaf("zip", sde)
+      case BernoulliModel(sde, _)           => leaf("bernoulli", sde)
+      case BetaModel(sde, _)                => leaf("beta", sde)
+      case LogGaussianCox(sde, _)           => leaf("lgcp", sde)
+      case _                                => None
+    }
+  }
+}
+
+/** Composition that keeps its structure: the reference's constructors (Model.poisson, Model.seasonal, ... Model.scala:44-92)
+  * and `|+|` (Model.scala:96-100), with the leaf list carried beside the UnparamModel they build.  A call site changes
+  * one identifier:  `GpuModel.poisson(Sde.ouProcess(1)) |+| GpuModel.seasonal(24, 1, Sde.ouProcess(2))`. */
+case class GpuUnparam(unparam: UnparamModel, leaves: Seq[DescriptorBuilder.LeafSpec]) {
+  def |+|(that: GpuUnparam): GpuUnparam = GpuUnparam(Model.compose(unparam, that.unparam), leaves ++ that.leaves)
+}
+object GpuModel {
+  import DescriptorBuilder.LeafSpec
+  /** kind and dimension of an unparameterised SDE: Sde.brownianMotion(d) etc. are Readers of the parameter leaf, so the
+    * structure is read off a run with a neutral parameter of the matching constructor. */
+  private def kindOf(sde: UnparamSde): (Int, Int) = {
+    val z = breeze.linalg.DenseVector(0.0)
+    val probes = Seq[SdeParameter](BrownianParameter(z, z, z), GenBrownianParameter(z, z, z, z), OuParameter(z, z, z, z, z))
+    probes.view.flatMap(p => sde.run(p).toOption).headOption.map(LeafSpecs.ofSde)
+      .getOrElse(throw new IllegalArgumentException("the GPU filter serves the built-in SDEs"))
+  }
+  private def leaf(obs: String, u: UnparamModel, sde: UnparamSde, period: Int = 0, harmonics: Int = 0, df: Int = 0) = {
+    val (k, d) = kindOf(sde); GpuUnparam(u, Seq(LeafSpec(obs, k, d, period, harmonics, df)))
+  }
+  def poisson(sde: UnparamSde)                       = leaf("poisson", Model.poisson(sde), sde)
+  def seasonal(period: Int, h: Int, sde: UnparamSde) = leaf("seasonal", Model.seasonal(period, h, sde), sde, period, h)
+  def linear(sde: UnparamSde)                        = leaf("linear", Model.linear(sde), sde)
+  def studentsT(sde: UnparamSde, df: Int)            = leaf("studentt", Model.studentsT(sde, df), sde, df = df)
+  def negativeBinomial(sde: UnparamSde)              = leaf("negbin", Model.negativeBinomial(sde), sde)
+  def zeroInflatedPoisson(sde: UnparamSde)           = leaf("zip", Model.zeroInflatedPoisson(sde), sde)
+  def bernoulli(sde: UnparamSde)                     = leaf("bernoulli", Model.bernoulli(sde), sde)
+  def beta(sde: UnparamSde)                          = leaf("beta", Model.beta(sde), sde)
+  def lgcp(sde: UnparamSde)                          = leaf("lgcp", Model.lgcp(sde), sde)
+}
+
+/** `Resample[A]` (package.scala:23) values the native filter understands: as a function they are the parity shim (ancestor
+  * indices via JNI, gather on the JVM); handed to FilterGpu they only select the resampler of the device path
+  * (CSSM_OPT_RESAMPLER) -- the cloud never leaves HBM.  Resampling.scala:63-72 (systematic), :78-86, :92-96. */
+sealed abstract class GpuResampler[A](val kind: Int, device: Int) extends ((Vector[A], Vector[LogLikelihood]) => Vector[A]) {
+  def apply(particles: Vector[A], weights: Vector[LogLikelihood]): Vector[A] = {
+    val anc = new Array[Int](weights.size)
+    if (kind == 0) CssmNative.resampleSystematic(weights.toArray, scala.util.Random.nextDouble, anc, device)   // u: Resampling.scala:66
+    else CssmNative.resample(kind, weights.toArray, 0.0, scala.util.Random.nextLong, 0, anc, device)           // keyed where the reference draws
+    anc.toVector.map(particles(_))
+  }
+}
+object GpuResample {
+  def systematic[A](device: Int = 0): GpuResampler[A]  = new GpuResampler[A](0, device) {}
+  def stratified[A](device: Int = 0): GpuResampler[A]  = new GpuResampler[A](1, device) {}
+  def multinomial[A](device: Int = 0): GpuResampler[A] = new GpuResampler[A](2, device) {}
+}
+
 /**
-  * The GPU particle filter behind the reference's own trait (ParticleFilter.scala:96-167): overrides
-  * initialiseState / stepFilter / llFilter / filter wholesale, as FilterLgcp already overrides
-  * stepFilter (:210).  The cloud stays in HBM: `PfState.particles` is downloaded only on demand via
+  * The GPU particle filter behind the reference's own trait (ParticleFilter.scala:96-167), with the constructor shape of
+  * `Filter(mod, resample)` (:233-235): overrides initialiseState / stepFilter / llFilter / filter wholesale, as FilterLgcp
+  * already overrides stepFilter (:210).  The cloud stays in HBM: `PfState.particles` is downloaded only on demand via
   * `currentParticles`; the PfState values returned here carry an empty Vector.
+  *
+  * `leaves`: for a single-leaf model they are derived from `mod` itself; for a composition pass `gpuUnparam.leaves`
+  * (see GpuModel) -- FilterGpu.of does both.
   */
 case class FilterGpu(
-  leaves: Seq[DescriptorBuilder.LeafSpec],
-  params: Parameters,
   mod: Model,
+  resample: Resample[State],
+  params: Parameters,
   particles: Int,
+  leaves: Seq[DescriptorBuilder.LeafSpec] = Nil,
   seed: Long = 20260101L,
   device: Int = 0,
   precision: Int = 0) extends ParticleFilter[State] with AutoCloseable {
 
-  private val (ints, reals) = DescriptorBuilder(leaves, params, precision)
+  private val structure: Seq[DescriptorBuilder.LeafSpec] =
+    if (leaves.nonEmpty) leaves
+    else LeafSpecs.ofModel(mod).getOrElse(throw new IllegalArgumentException(
+      "a composed model does not reveal its leaves (Model.compose builds a closure): compose with GpuModel and pass its `leaves`"))
+  private val df = structure.head.df                                     // StudentsTModel.df (Model.scala:144)
+  private val resamplerKind = resample match {
+    case g: GpuResampler[_] => g.kind
+    case _ => throw new IllegalArgumentException("the device path resamples with GpuResample.systematic / stratified / multinomial")
+  }
+  private val (ints, reals) = DescriptorBuilder(structure, params, precision, df)
   private val handle = CssmNative.create(ints, reals, particles.toLong, seed, device)
+  if (resamplerKind != 0) CssmNative.setResampler(handle, resamplerKind)
+  /** the handle's clock: the time of the last state it produced (the handle is mutable, PfState values are not) */
+  private var clock: Double = Double.NaN
   def close(): Unit = CssmNative.destroy(handle)
 
   // the abstract members exist for source compatibility; the native path never calls them
@@ -80,29 +180,38 @@ case class FilterGpu(
   def stepFunction(dt: TimeIncrement)(s: State) = mod.sde.stepFunction(dt)(s)
   def initialState = mod.sde.initialState
   def f(s: State, t: Time): Gamma = mod.f(s, t)
-  def resample: Resample[State] = GpuResample.systematic(device)
 
   override def initialiseState(n: Int, t0: Time): PfState[State] = {
     require(n == particles, "the handle was created for a fixed particle count")
     CssmNative.init(handle, t0)
+    clock = t0
     PfState(t0, None, Vector.empty, 0.0, n)
   }
 
   override def stepFilter(s: PfState[State], y: Data): PfState[State] = {
+    // the state argument is a value, the cloud behind it is the handle's: a replayed or branched stream that hands in an
+    // OLDER state would otherwise be stepped from the wrong cloud without a word
+    if (s.t != clock) throw new IllegalStateException(
+      s"stepFilter on a state of time ${s.t}, but the device cloud is at $clock: a FilterGpu advances one stream; re-initialise to branch")
     val out = new Array[Double](2)
     CssmNative.step(handle, y.t, y.observation.getOrElse(0.0), y.observation.isDefined, out)
+    clock = y.t
     PfState(y.t, y.observation, Vector.empty, out(0), out(1).toInt)
   }
 
-  override def llFilter(data: Vector[Data], n: Int): LogLikelihood =
-    CssmNative.filter(handle, data.map(_.t).toArray, data.map(_.observation.getOrElse(0.0)).toArray,
-                      data.map(d => (if (d.observation.isDefined) 1 else 0).toByte).toArray, null)
+  override def llFilter(data: Vector[Data], n: Int): LogLikelihood = {
+    val ll = CssmNative.filter(handle, data.map(_.t).toArray, data.map(_.observation.getOrElse(0.0)).toArray,
+                               data.map(d => (if (d.observation.isDefined) 1 else 0).toByte).toArray, null)
+    clock = data.last.t
+    ll
+  }
 
   override def filter(data: Vector[Data], n: Int): (LogLikelihood, Vector[StateSpace[State]]) = {
     val d = mod.sde.dimension
     val path = new Array[Double]((data.size + 1) * d)
     val ll = CssmNative.filter(handle, data.map(_.t).toArray, data.map(_.observation.getOrElse(0.0)).toArray,
                                data.map(x => (if (x.observation.isDefined) 1 else 0).toByte).toArray, path)
+    clock = data.last.t
     val times = data.minBy(_.t).t +: data.map(_.t)
     (ll, times.zipWithIndex.map { case (t, i) => StateSpace[State](t, Tree.leaf(DenseVector(path.slice(i * d, (i + 1) * d)))) })
   }
@@ -115,38 +224,28 @@ case class FilterGpu(
     val out = new Array[Double](mod.sde.dimension * particles); CssmNative.particles(handle, out); out
   }
 
-  /** New parameters for the same model: one call per PMMH proposal (PMMH.scala:71). */
-  def reparameterise(p: Parameters, newSeed: Long): Unit = {
-    val (i, r) = DescriptorBuilder(leaves, p, precision); CssmNative.setParams(handle, i, r, newSeed)
+  /** New parameters for the same model: one call per PMMH proposal (PMMH.scala:71).  `key`: CssmNative.runKey(seed, run). */
+  def reparameterise(p: Parameters, key: Long): Unit = {
+    val (i, r) = DescriptorBuilder(structure, p, precision, df); CssmNative.setParams(handle, i, r, key)
   }
 }
 
-/** `Resample[A]` (package.scala:23) on the GPU: ancestor indices via JNI, gather on the JVM.  A parity
-  * shim -- it leaves the cloud on the heap; FilterGpu is the production path. */
-object GpuResample {
-  def systematic[A](device: Int = 0): Resample[A] = (particles: Vector[A], weights: Vector[LogLikelihood]) => {
-    val anc = new Array[Int](weights.size)
-    CssmNative.resampleSystematic(weights.toArray, scala.util.Random.nextDouble, anc, device)   // u: Resampling.scala:66
-    anc.toVector.map(particles(_))
-  }
-  /** Resampling.stratifiedResampling (:78-86) / multinomialResampling (:92-96): kind 1 / 2 of cssm_resample; the per-slot
-    * uniforms come from the library's Philox streams, keyed by a seed drawn where the reference draws its uniforms. */
-  private def seeded[A](kind: Int, device: Int): Resample[A] = (particles: Vector[A], weights: Vector[LogLikelihood]) => {
-    val anc = new Array[Int](weights.size)
-    CssmNative.resample(kind, weights.toArray, 0.0, scala.util.Random.nextLong, 0, anc, device)
-    anc.toVector.map(particles(_))
-  }
-  def stratified[A](device: Int = 0): Resample[A] = seeded(1, device)
-  def multinomial[A](device: Int = 0): Resample[A] = seeded(2, device)
+object FilterGpu {
+  /** `Filter(unparam.run(p).get, resample)` for a structure-carrying composition. */
+  def of(g: GpuUnparam, p: Parameters, resample: Resample[State], particles: Int, seed: Long = 20260101L, device: Int = 0,
+         precision: Int = 0): FilterGpu =
+    FilterGpu(g.unparam.run(p).get, resample, p, particles, g.leaves, seed, device, precision)
 }
 
 /** BootstrapFilter for PMMH (package.scala:24; examples/DetermineParameters.scala:70-75): drops into
   * MetropolisHastings.pmmhState(...) unchanged. */
 object GpuBootstrap {
-  def apply(leaves: Seq[DescriptorBuilder.LeafSpec], unparam: UnparamModel, init: Parameters, data: Vector[Data], n: Int,
+  def apply(g: GpuUnparam, init: Parameters, data: Vector[Data], n: Int,
             seed: Long = 20260101L): BootstrapFilter[Parameters, StateSpace[State]] = {
-    val gpu = FilterGpu(leaves, init, unparam.run(init).get, n, seed)
+    val gpu = FilterGpu.of(g, init, GpuResample.systematic[State](), n, seed)
     var calls = 0L
-    Reader { (p: Parameters) => calls += 1; gpu.reparameterise(p, seed + calls); gpu.filter(data, n) }
+    // every filter run gets its own Philox key, a PRF of (seed, run) -- never seed + run: chains seeded s and s + 1 would
+    // replay each other's filter randomness one iteration apart
+    Reader { (p: Parameters) => calls += 1; gpu.reparameterise(p, CssmNative.runKey(seed, calls)); gpu.filter(data, n) }
   }
 }
