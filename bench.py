@@ -131,7 +131,7 @@ def run_single(args, emit=print):
     from composablestatespacemodels_amd.filter import NativePf
     K, W = args.steps, args.warmup
     n = args.particles
-    model, t, y, has = build_workload(max(K, W, 8))
+    model, t, y, has = build_workload(max(K, W, 8), args.model)
     pf = NativePf(model, n, 20260101, device=0)
     if args.fused is not None:
         pf.set_option(3, args.fused)   # CSSM_OPT_FUSED_SUMS (experiment switch; the default is the library's)
@@ -208,7 +208,8 @@ def run_single(args, emit=print):
         "metric": METRIC, "value": n * K / wall, "unit": "particle-steps/s",
         "n_gpus": 1, "steps": K, "warmup": W, "ms_per_step": wall * 1e3 / K, "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-        "config": {"workload": "configs[1]: seasonal-Poisson, OU latent (poisson(ou(1)) |+| seasonal(24,1,ou(2)), d=3), "
+        "config": {"workload": ("configs[1]: seasonal-Poisson, OU latent (poisson(ou(1)) |+| seasonal(24,1,ou(2)), d=3), " if args.model == "c2"
+                                else "configs[0] model at bench size: poisson(brownianMotion(1)), d=1, ") +
                                f"N={n} particles, T={K} observations, systematic resampling every observation",
                    "particles_per_gpu": n, "observations": K, "latent_dim": d, "seed": 20260101},
         "repeats": R, "value_is": "median over `repeats` timed K-step series", "wall_ms_each": [w * 1e3 for w in walls],
@@ -386,6 +387,7 @@ def main():
     ap.add_argument("--no-16m", action="store_true", help="skip the roofline_16m leg")
     ap.add_argument("--fused", type=int, default=None, help="CSSM_OPT_FUSED_SUMS override (single GPU)")
     ap.add_argument("--series", type=int, default=None, help="CSSM_OPT_SERIES_KERNEL override (single GPU): 0 = per-observation kernels")
+    ap.add_argument("--model", default="c2", choices=["c2", "c1"], help="c2: the bench workload (BASELINE configs[1], d = 3); c1: Poisson-Brownian (configs[0], d = 1) -- profiling runs only")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="gloo: CPU rehearsal of the N-rank path with the test-only oracle shard")
     ap.add_argument("--launch-timeout", type=float, default=1500.0, help="seconds the self-launched ranks may take")
     args = ap.parse_args()
