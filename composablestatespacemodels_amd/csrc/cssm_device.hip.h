@@ -477,31 +477,37 @@ __device__ __forceinline__ void fill_runs_tile(uint32_t prev, const uint32_t (&e
     uint32_t carry = dpp0<0x138 /* wave_shr:1 */, 0xf>(incl);   // exclusive: max over the lanes before this one (lane 0: 0)
     __syncthreads();
     for (int w = 0; w < wid; ++w) carry = (s_wmax[w] > carry) ? s_wmax[w] : carry;
-    const uint32_t s0 = c0 + threadIdx.x * 8;              // first slot of this thread's piece
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
       uint32_t x = (v[k] > carry) ? v[k] : carry;
       x = (x > 0u) ? x - 1u : 0u;                           // (0 cannot occur inside [lo, hi): every slot there belongs to a run)
       v[k] = (x > idx_max) ? idx_max : x;
     }
-    // (signed: a chunk starts on a 64-slot boundary at or below lo, which can lie below slot_off; only slots inside
-    //  [lo, hi), lo >= slot_off, are dereferenced)
-    uint32_t* dst = anc + ((long long)s0 - (long long)slot_off);
-    if (s0 >= lo && s0 + 8 <= hi && ((s0 - slot_off) & 3u) == 0u) {
-      if (SC1) {
-        store_anc4_sc1(dst, v[0], v[1], v[2], v[3]);
-        store_anc4_sc1(dst + 4, v[4], v[5], v[6], v[7]);
-      } else {
-        *reinterpret_cast<uint4*>(dst) = make_uint4(v[0], v[1], v[2], v[3]);
-        *reinterpret_cast<uint4*>(dst + 4) = make_uint4(v[4], v[5], v[6], v[7]);
-      }
-    } else {
+    // Back through LDS so that every store INSTRUCTION of a wave covers 1 KiB contiguously (thread t: slots 4t .. 4t+3 of
+    // the chunk's first half, then of its second half): a thread's own 8 slots are two 16-byte stores 32 bytes apart, and
+    // write-through stores of that shape write every line twice, half at a time (PMC: 12.5 MB for 4 MB of ancestors).
+    z[0] = make_uint4(v[0], v[1], v[2], v[3]); z[1] = make_uint4(v[4], v[5], v[6], v[7]);
+    __syncthreads();
 #pragma unroll
-      for (int k = 0; k < 8; ++k)
-        if (s0 + k >= lo && s0 + k < hi) {
-          if (SC1) __hip_atomic_store(dst + k, v[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          else dst[k] = v[k];
-        }
+    for (int half = 0; half < 2; ++half) {
+      const uint32_t p = half * (CSSM_RUN_CHUNK / 2) + threadIdx.x * 4;     // position in the chunk
+      const uint4 w = *reinterpret_cast<const uint4*>(s_slot + p);
+      const uint32_t s0 = c0 + p;
+      // (signed: a chunk starts on a 64-slot boundary at or below lo, which can lie below slot_off; only slots inside
+      //  [lo, hi), lo >= slot_off, are dereferenced)
+      uint32_t* dst = anc + ((long long)s0 - (long long)slot_off);
+      if (s0 >= lo && s0 + 4 <= hi && ((s0 - slot_off) & 3u) == 0u) {
+        if (SC1) store_anc4_sc1(dst, w.x, w.y, w.z, w.w);
+        else *reinterpret_cast<uint4*>(dst) = w;
+      } else {
+        const uint32_t wv[4] = {w.x, w.y, w.z, w.w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+          if (s0 + k >= lo && s0 + k < hi) {
+            if (SC1) __hip_atomic_store(dst + k, wv[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            else dst[k] = wv[k];
+          }
+      }
     }
     __syncthreads();                                        // s_slot / s_wmax are rewritten by the next chunk
   }
