@@ -478,6 +478,19 @@ __global__ __launch_bounds__(CSSM_BLOCK, CSSM_OFF_WAVES) void k_offspring(CSSM_O
   offspring_body<FUSE, SELF, RS>(CSSM_OFFSPRING_FWD, all5_stride);
 }
 
+// The single-GPU filter's launch: only the arguments that path uses (the generic kernel above carries ~30, most of them the
+// sharded filter's; their scalar registers spilled into vector registers and those into scratch -- 28 bytes per thread,
+// i.e. 7 MB of scratch write-back per launch at N = 2^20, which the PMC counters showed as "wasted" write traffic).
+template <int RS>
+__global__ __launch_bounds__(CSSM_BLOCK, CSSM_OFF_WAVES) void k_offspring_self(
+    const double* __restrict__ logw, uint64_t n, Scalars* __restrict__ sc, const cssm_u128* __restrict__ unitP,
+    const cssm_u128* __restrict__ unitS2, const StepRec* __restrict__ rec, uint32_t* __restrict__ anc, uint32_t ntiles, uint32_t sup,
+    uint32_t nunits, int slot_set, double* __restrict__ ll_t, int32_t* __restrict__ ess_t, uint32_t rec_idx, int force_exact, int split,
+    uint64_t seed, double* __restrict__ cum_out, int optimistic) {
+  offspring_body<true, true, RS>(logw, n, sc, unitP, unitS2, rec, n, nullptr, anc, ntiles, sup, nunits, 0, slot_set, ll_t, ess_t, rec_idx,
+                                 force_exact, nullptr, 0, 1, split, seed, cum_out, nullptr, optimistic, nullptr, 0u, (uint32_t)n, 5u);
+}
+
 // ------------------------------------------------------------------------------------ expand
 
 // findAllInTreeMap (model/Resampling.scala:36-46) on the receiver of the sharded filter, for the slots of this rank

@@ -645,15 +645,14 @@ static int launch_resample(cssm_pf* pf, const StepRec* d_rec, double* ll_t = nul
     prof_end(pf);
   }
   prof_begin(pf, CSSM_K_OFFSPRING);   // unit prefix, ll/ess, end slots and their expansion to ancestors in one kernel
-#define OFF_ARGS pf->logw, pf->n, pf->sc, (const cssm_u128*)pf->tileS, (const cssm_u128*)pf->tileS2, d_rec, pf->n_global, pf->endslot, pf->anc, \
-                 pf->ntiles, pf->sup, pf->nunits, 0, pf->wparity, ll_t, ess_t, rec_idx, pf->opt_exact, (const unsigned long long*)nullptr, 0, 1, \
-                 split, pf->seed, pf->cum, pf->d_logtab, optimistic ? (pf->batch_hold ? 3 : 1) : 0, (unsigned long long*)nullptr, 0u, (uint32_t)pf->n_global
+#define OFF_ARGS pf->logw, pf->n, pf->sc, (const cssm_u128*)pf->tileS, (const cssm_u128*)pf->tileS2, d_rec, pf->anc, pf->ntiles, pf->sup, pf->nunits, \
+                 pf->wparity, ll_t, ess_t, rec_idx, pf->opt_exact, split, pf->seed, pf->cum, optimistic ? (pf->batch_hold ? 3 : 1) : 0
   if (pf->resampler == CSSM_RESAMPLE_STRATIFIED)
-    hipLaunchKernelGGL((k_offspring<true, true, CSSM_RESAMPLE_STRATIFIED>), dim3(tgrid), dim3(CSSM_BLOCK), 0, pf->stream, OFF_ARGS);
+    hipLaunchKernelGGL((k_offspring_self<CSSM_RESAMPLE_STRATIFIED>), dim3(tgrid), dim3(CSSM_BLOCK), 0, pf->stream, OFF_ARGS);
   else if (pf->resampler == CSSM_RESAMPLE_MULTINOMIAL)
-    hipLaunchKernelGGL((k_offspring<true, true, CSSM_RESAMPLE_MULTINOMIAL>), dim3(tgrid), dim3(CSSM_BLOCK), 0, pf->stream, OFF_ARGS);
+    hipLaunchKernelGGL((k_offspring_self<CSSM_RESAMPLE_MULTINOMIAL>), dim3(tgrid), dim3(CSSM_BLOCK), 0, pf->stream, OFF_ARGS);
   else
-    hipLaunchKernelGGL((k_offspring<true, true, CSSM_RESAMPLE_SYSTEMATIC>), dim3(tgrid), dim3(CSSM_BLOCK), 0, pf->stream, OFF_ARGS);
+    hipLaunchKernelGGL((k_offspring_self<CSSM_RESAMPLE_SYSTEMATIC>), dim3(tgrid), dim3(CSSM_BLOCK), 0, pf->stream, OFF_ARGS);
 #undef OFF_ARGS
   if (pf->resampler == CSSM_RESAMPLE_MULTINOMIAL)
     hipLaunchKernelGGL(k_multinomial, dim3(grid_for(pf->n, 256, kGridCap)), dim3(256), 0, pf->stream, pf->cum, pf->n, pf->seed,
