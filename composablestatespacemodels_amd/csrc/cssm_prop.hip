@@ -7,6 +7,9 @@
 #error "compile with -DCSSM_PROP_D=<latent dimension>"
 #endif
 
+#ifndef CSSM_PROP_SELF
+#define CSSM_PROP_SELF 1   /* 0: always the generic kernel (experiments) */
+#endif
 #define CSSM_CAT2(a, b) a##b
 #define CSSM_CAT(a, b) CSSM_CAT2(a, b)
 
@@ -17,7 +20,16 @@ void CSSM_CAT(cssm_prop_launch_d, CSSM_PROP_D)(const PropLaunch& a) {
   k_propagate<D, LG, IT, OB, SM><<<dim3(a.grid), dim3(CSSM_BLOCK), 0, a.stream>>>(                                        \
       a.src, a.src_stride, a.anc, a.dst, a.dst_stride, a.logw, a.n, a.gid0, a.seed, a.rec, a.mk, a.sc, a.slot_set, a.src2, \
       a.src2_stride, a.n_split, a.logtab, a.chunk, a.do_sums, a.subS, a.subS2, a.pick_out, a.pick_slot, a.fsub)
-  if (a.lgcp) {
+  // the single-GPU lean launch: nothing of the sharded filter, no fused sums, no pick, first global id 0
+  const bool self = !a.lgcp && !a.sums && a.src2 == nullptr && a.gid0 == 0 && a.pick_out == nullptr && a.fsub == nullptr;
+#define PROP_SELF(OB)                                                                                                       \
+  k_propagate_self<D, IT, OB><<<dim3(a.grid), dim3(CSSM_BLOCK), 0, a.stream>>>(a.src, a.src_stride, a.anc, a.dst, a.dst_stride, \
+      a.logw, a.n, a.seed, a.rec, a.mk, a.sc, a.slot_set, a.logtab, a.chunk)
+  if (self && CSSM_PROP_SELF) {
+    if (a.obs == CSSM_OBS_POISSON) PROP_SELF(CSSM_OBS_POISSON);
+    else if (a.obs == CSSM_OBS_GAUSSIAN) PROP_SELF(CSSM_OBS_GAUSSIAN);
+    else PROP_SELF(-1);
+  } else if (a.lgcp) {
     PROP_GO(true, -1, false);
   } else if (a.obs == CSSM_OBS_POISSON) {
     if (a.sums) PROP_GO(false, CSSM_OBS_POISSON, true); else PROP_GO(false, CSSM_OBS_POISSON, false);
@@ -27,4 +39,5 @@ void CSSM_CAT(cssm_prop_launch_d, CSSM_PROP_D)(const PropLaunch& a) {
     if (a.sums) PROP_GO(false, -1, true); else PROP_GO(false, -1, false);
   }
 #undef PROP_GO
+#undef PROP_SELF
 }

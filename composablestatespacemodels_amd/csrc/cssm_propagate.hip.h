@@ -425,3 +425,36 @@ __global__ __launch_bounds__(CSSM_BLOCK, (PropWaves<D, SUMS>::value)) void k_pro
               (unsigned long long)cssm_order_key(m));
   }
 }
+
+// The single-GPU filter's launch of the lean kernel (no fused sums, not LGCP): only the arguments that path uses, and what
+// it knows at compile time -- the first particle's global id is 0 (every thread owns whole pairs: the unpaired variant of
+// the transition code is not even compiled), no second gather source, no sub-step table, no pick.  The generic kernel's
+// ~24 arguments overflow the scalar registers into vector-register lanes (88 v_readlane per tile).
+template <int D, int IT, int OBS>
+__global__ __launch_bounds__(CSSM_BLOCK, (PropWaves<D, false>::value)) void k_propagate_self(
+    const double* __restrict__ src, size_t src_stride, const uint32_t* __restrict__ anc, double* __restrict__ dst, size_t dst_stride,
+    double* __restrict__ logw, uint64_t n_arg, uint64_t seed, const StepRec* __restrict__ rec, ModelK mk, Scalars* __restrict__ sc,
+    int slot_set, const double* __restrict__ logtab, uint64_t chunk) {
+  __shared__ double s_max[CSSM_BLOCK / 64];
+  if (sc->err & (4u | 8u | 64u)) return;
+  const uint32_t range_lo = blockIdx.x * (uint32_t)chunk;
+  uint32_t n;
+  { const uint64_t range_hi = (uint64_t)range_lo + chunk; n = (uint32_t)((range_hi < n_arg) ? range_hi : n_arg); }
+  const double* tab = stage_log_table(logtab);
+  __shared__ __attribute__((aligned(16))) unsigned char s_stage[PropStage<D, IT>::bytes];
+  PropAcc acc;
+  propagate_range<D, false, IT, OBS, false, false>(src, src_stride, anc, dst, dst_stride, logw, 0ull, seed, rec, mk, nullptr, 0, 0u, tab,
+                                                   range_lo, n, 0, nullptr, 0u, nullptr, s_stage, acc);
+  if (!rec->has_obs) return;
+  double tmax = wave_max(acc.tmax);
+  if ((threadIdx.x & 63) == 0) s_max[threadIdx.x >> 6] = tmax;
+  if (__any(acc.bad) && (threadIdx.x & 63) == 0) atomicOr(&sc->err, 1u);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double m = s_max[0];
+#pragma unroll
+    for (int w = 1; w < CSSM_BLOCK / 64; ++w) m = (s_max[w] > m) ? s_max[w] : m;
+    atomicMax(&sc->maxslot[((size_t)slot_set * CSSM_MAXSLOTS + blockIdx.x % CSSM_MAXSLOTS) * CSSM_SLOT_STRIDE],
+              (unsigned long long)cssm_order_key(m));
+  }
+}
