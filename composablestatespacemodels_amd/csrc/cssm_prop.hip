@@ -21,14 +21,14 @@ void CSSM_CAT(cssm_prop_launch_d, CSSM_PROP_D)(const PropLaunch& a) {
       a.src, a.src_stride, a.anc, a.dst, a.dst_stride, a.logw, a.n, a.gid0, a.seed, a.rec, a.mk, a.sc, a.slot_set, a.src2, \
       a.src2_stride, a.n_split, a.logtab, a.chunk, a.do_sums, a.subS, a.subS2, a.pick_out, a.pick_slot, a.fsub)
   // the single-GPU lean launch: nothing of the sharded filter, no fused sums, no pick, first global id 0
-  const bool self = !a.lgcp && !a.sums && a.src2 == nullptr && a.gid0 == 0 && a.pick_out == nullptr && a.fsub == nullptr;
-#define PROP_SELF(OB)                                                                                                       \
-  k_propagate_self<D, IT, OB><<<dim3(a.grid), dim3(CSSM_BLOCK), 0, a.stream>>>(a.src, a.src_stride, a.anc, a.dst, a.dst_stride, \
-      a.logw, a.n, a.seed, a.rec, a.mk, a.sc, a.slot_set, a.logtab, a.chunk)
+  const bool self = !a.lgcp && a.src2 == nullptr && a.gid0 == 0 && a.fsub == nullptr && (a.sums || a.pick_out == nullptr) && (!a.sums || a.do_sums);
+#define PROP_SELF(OB, SM)                                                                                                   \
+  k_propagate_self<D, IT, OB, SM><<<dim3(a.grid), dim3(CSSM_BLOCK), 0, a.stream>>>(a.src, a.src_stride, a.anc, a.dst, a.dst_stride, \
+      a.logw, a.n, a.seed, a.rec, a.mk, a.sc, a.slot_set, a.logtab, a.chunk, a.subS, a.subS2, a.pick_out, a.pick_slot)
   if (self && CSSM_PROP_SELF) {
-    if (a.obs == CSSM_OBS_POISSON) PROP_SELF(CSSM_OBS_POISSON);
-    else if (a.obs == CSSM_OBS_GAUSSIAN) PROP_SELF(CSSM_OBS_GAUSSIAN);
-    else PROP_SELF(-1);
+    if (a.obs == CSSM_OBS_POISSON) { if (a.sums) PROP_SELF(CSSM_OBS_POISSON, true); else PROP_SELF(CSSM_OBS_POISSON, false); }
+    else if (a.obs == CSSM_OBS_GAUSSIAN) { if (a.sums) PROP_SELF(CSSM_OBS_GAUSSIAN, true); else PROP_SELF(CSSM_OBS_GAUSSIAN, false); }
+    else { if (a.sums) PROP_SELF(-1, true); else PROP_SELF(-1, false); }
   } else if (a.lgcp) {
     PROP_GO(true, -1, false);
   } else if (a.obs == CSSM_OBS_POISSON) {

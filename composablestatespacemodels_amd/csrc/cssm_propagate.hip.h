@@ -430,11 +430,14 @@ __global__ __launch_bounds__(CSSM_BLOCK, (PropWaves<D, SUMS>::value)) void k_pro
 // it knows at compile time -- the first particle's global id is 0 (every thread owns whole pairs: the unpaired variant of
 // the transition code is not even compiled), no second gather source, no sub-step table, no pick.  The generic kernel's
 // ~24 arguments overflow the scalar registers into vector-register lanes (88 v_readlane per tile).
-template <int D, int IT, int OBS>
-__global__ __launch_bounds__(CSSM_BLOCK, (PropWaves<D, false>::value)) void k_propagate_self(
+template <int D, int IT, int OBS, bool SUMS>
+__global__ __launch_bounds__(CSSM_BLOCK, (PropWaves<D, SUMS>::value)) void k_propagate_self(
     const double* __restrict__ src, size_t src_stride, const uint32_t* __restrict__ anc, double* __restrict__ dst, size_t dst_stride,
     double* __restrict__ logw, uint64_t n_arg, uint64_t seed, const StepRec* __restrict__ rec, ModelK mk, Scalars* __restrict__ sc,
-    int slot_set, const double* __restrict__ logtab, uint64_t chunk) {
+    int slot_set, const double* __restrict__ logtab, uint64_t chunk,
+    cssm_u128* __restrict__ subS, cssm_u128* __restrict__ subS2, double* __restrict__ pick_out, uint32_t pick_slot) {
+  // SUMS: the block also forms its fixed-point sums of exp(w - c) (subS / subS2, one entry per block) and, for `filter`,
+  // records the state sampleOne picked after the previous observation (pick_out / pick_slot; see k_propagate)
   __shared__ double s_max[CSSM_BLOCK / 64];
   if (sc->err & (4u | 8u | 64u)) return;
   const uint32_t range_lo = blockIdx.x * (uint32_t)chunk;
@@ -443,13 +446,26 @@ __global__ __launch_bounds__(CSSM_BLOCK, (PropWaves<D, false>::value)) void k_pr
   const double* tab = stage_log_table(logtab);
   __shared__ __attribute__((aligned(16))) unsigned char s_stage[PropStage<D, IT>::bytes];
   PropAcc acc;
-  propagate_range<D, false, IT, OBS, false, false>(src, src_stride, anc, dst, dst_stride, logw, 0ull, seed, rec, mk, nullptr, 0, 0u, tab,
-                                                   range_lo, n, 0, nullptr, 0u, nullptr, s_stage, acc);
+  propagate_range<D, false, IT, OBS, SUMS, false>(src, src_stride, anc, dst, dst_stride, logw, 0ull, seed, rec, mk, nullptr, 0, 0u, tab,
+                                                  range_lo, n, SUMS ? 1 : 0, SUMS ? pick_out : nullptr, pick_slot, nullptr, s_stage, acc);
   if (!rec->has_obs) return;
   double tmax = wave_max(acc.tmax);
   if ((threadIdx.x & 63) == 0) s_max[threadIdx.x >> 6] = tmax;
   if (__any(acc.bad) && (threadIdx.x & 63) == 0) atomicOr(&sc->err, 1u);
-  __syncthreads();
+  if (SUMS) {
+    __shared__ cssm_u128 s_sa[CSSM_BLOCK / 64], s_sb[CSSM_BLOCK / 64];
+    const cssm_u128 accS = wave_sum_u128(acc.S), accS2 = wave_sum_u128(acc.S2);
+    if ((threadIdx.x & 63) == 0) { s_sa[threadIdx.x >> 6] = accS; s_sb[threadIdx.x >> 6] = accS2; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      cssm_u128 ta = s_sa[0], tb = s_sb[0];
+#pragma unroll
+      for (int w = 1; w < CSSM_BLOCK / 64; ++w) { ta = cssm_u128_add(ta, s_sa[w]); tb = cssm_u128_add(tb, s_sb[w]); }
+      subS[blockIdx.x] = ta; subS2[blockIdx.x] = tb;
+    }
+  } else {
+    __syncthreads();
+  }
   if (threadIdx.x == 0) {
     double m = s_max[0];
 #pragma unroll
