@@ -493,8 +493,8 @@ static int create_common(const cssm_model_desc* desc, uint64_t n_global, uint64_
   pf->device = device;
   pf->n_global = n_global; pf->first = first; pf->n = n_local; pf->seed = seed; pf->sharded = sharded;
   if (sharded) { pf->stream = (hipStream_t)stream; pf->own_stream = false; pf->opt_fused = 1; }
-  else if (n_local <= (1ull << 18)) pf->opt_fused = 1;   // launch-latency-bound sizes: two launches per observation beat three (20.8 vs 21.7 us at N = 100 000); at 2^20
-                                                          // both cost 38.7 us and at 2^24 the lean kernels win (413 vs 441 us): k_propagate is VALU-bound, the sums are not free in it
+  else pf->opt_fused = 1;   // two launches per observation at every size (measured with the slim single-GPU kernels: 18.7 vs 20.0 us at
+                            // N = 100 000, 34.0 vs 35.4 at 2^20, 336 vs 356 at 2^24); an outlying observation is redone in place
   int rc = build_model(pf, desc, false);
   if (rc == CSSM_OK) rc = alloc_handle(pf);
   if (rc != CSSM_OK) { std::string keep = g_err; cssm_pf_destroy(pf); g_err = keep; return rc; }

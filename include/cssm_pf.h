@@ -194,14 +194,13 @@ int cssm_pf_last_loop_ms(cssm_pf* pf, float* ms_out);
 #define CSSM_RESAMPLE_SYSTEMATIC 0
 #define CSSM_RESAMPLE_STRATIFIED 1
 #define CSSM_RESAMPLE_MULTINOMIAL 2
-/* CSSM_OPT_FUSED_SUMS: 1 = k_propagate also forms the fixed-point sums of exp(w - c) (c = the observation's
- * reference level, cssm_numerics.h), 2 kernels per observation, and a second attempt when the max rules c out;
- * 0 = the sums are a pass of their own after the max is known, 3 kernels per observation.  Identical results
- * (both apply cssm_ref_choose).  Default: 1 on sharded handles, where it saves a collective per observation, and on
- * handles of at most 2^18 particles, where a step is launch-latency bound and two launches beat three (20.0 vs 21.4 us
- * per observation at N = 100 000); 0 otherwise: at N = 2^20 the fused path is 2 % faster (37.4 vs 38.3 us of device time
- * per observation, 363 vs 366 us at 2^24) but a series with an outlying observation runs twice, and the lean propagate
- * kernel is the one the roofline figure is quoted on. */
+/* CSSM_OPT_FUSED_SUMS (default 1): k_propagate also forms the fixed-point sums of exp(w - c) (c = the observation's reference
+ * level, cssm_numerics.h) -- the log-sum-exp normalisation inside the fused kernel: 2 kernels per observation.  When the max
+ * rules c out (an outlying observation) the batch drivers put the series on hold at that observation, redo its sums relative
+ * to the max (k_tile_sums + k_offspring; the log-weights are in place) and carry on; streaming cssm_pf_step does the same
+ * within the call.  0 = the sums are a pass of their own after the max is known (k_tile_sums), 3 kernels per observation.
+ * Identical results (both apply cssm_ref_choose).  Measured per observation, fused vs separate: 18.7 vs 20.0 us at
+ * N = 100 000, 34.0 vs 35.4 us at 2^20, 336 vs 356 us at 2^24. */
 #define CSSM_OPT_FUSED_SUMS 3
 /* CSSM_OPT_SERIES_KERNEL (default 0): 1 = the batch drivers (cssm_pf_ll_filter, cssm_pf_filter, cssm_pmmh_run) run all T
  * observations in ONE cooperative launch of a persistent kernel -- propagate + weight + sums, a grid barrier that also
