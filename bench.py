@@ -198,7 +198,7 @@ def run_single(args, emit=print):
         kernels_us = {"k_series_per_observation": launch_s * 1e6 / K}
     else:
         avg_s, cnt, raw_s = per["k_propagate"]
-        roof = _roofline(f"k_propagate<{d},...> (gather + propagate + weight), N={n}", d, n, avg_s, cnt, raw_s, pair_s, copy_gbs)
+        roof = _roofline(f"k_propagate<{d},...> (gather + propagate + weight + log-sum-exp sums), N={n}", d, n, avg_s, cnt, raw_s, pair_s, copy_gbs)
         roof["timing"] = ("HIP events on the launch stream around every k_propagate launch of a K-step series, minus what a bracketing "
                           "event pair adds: (sum of all bracketed kernel times - device time of the same loop without brackets) / brackets")
         kernels_us = {k: v[0] * 1e6 for k, v in per.items()}
@@ -225,25 +225,29 @@ def run_single(args, emit=print):
 
 
 def roofline_16m(NativePf, copy_gbs, fused=None, K=24):
-    """The fused propagate+weight kernel at the north-star size N = 2^24, driver-timed: the bench model (d = 3, 56 B per
-    particle) and Poisson-Brownian (d = 1, 24 B per particle: SURVEY.md 8d's reading of the target)."""
+    """The fused kernel at the north-star size N = 2^24, driver-timed: the bench model (d = 3, 56 B per particle) and
+    Poisson-Brownian (d = 1, 24 B per particle: SURVEY.md 8d's reading of the target).  Two variants each:
+    the DEFAULT kernel -- gather + propagate + weight + the log-sum-exp sums (SURVEY 8d's K_fused; CSSM_OPT_FUSED_SUMS = 1) --
+    and, under ``*_lean``, the same kernel without the sums (CSSM_OPT_FUSED_SUMS = 0: they are then a pass of their own,
+    k_tile_sums), which is the kernel round 1 quoted.  Same algorithmic bytes (the sums add none), more arithmetic."""
     res = {}
     for key, which in (("c2_d3", "c2"), ("c1_d1", "c1")):
         model, t, y, has = build_workload(K, which)
-        pf = NativePf(model, N_16M, 20260101, device=0)
-        if fused is not None:
-            pf.set_option(3, fused)
-        pf.run(t[:8], y[:8], has[:8])
-        pf.run(t[:K], y[:K], has[:K])
-        loop_ms = pf.last_loop_ms()
-        per, pair_s, _ = _kernel_profile(pf, t, y, has, K, loop_ms)
-        avg_s, cnt, raw_s = per["k_propagate"]
-        r = _roofline(f"k_propagate<{pf.d},...>, N={N_16M}", pf.d, N_16M, avg_s, cnt, raw_s, pair_s, copy_gbs)
-        r["step_us"] = loop_ms * 1e3 / K
-        r["particle_steps_per_s"] = N_16M * K / (loop_ms * 1e-3)
-        r["kernels_us"] = {k: v[0] * 1e6 for k, v in per.items()}
-        res[key] = r
-        pf.close()
+        for variant, fz in (("", 1 if fused is None else fused), ("_lean", 0)):
+            pf = NativePf(model, N_16M, 20260101, device=0)
+            pf.set_option(3, fz)
+            pf.run(t[:8], y[:8], has[:8])
+            pf.run(t[:K], y[:K], has[:K])
+            loop_ms = pf.last_loop_ms()
+            per, pair_s, _ = _kernel_profile(pf, t, y, has, K, loop_ms)
+            avg_s, cnt, raw_s = per["k_propagate"]
+            r = _roofline(f"k_propagate<{pf.d},...> {'with' if fz else 'without'} the fused sums, N={N_16M}", pf.d, N_16M, avg_s, cnt, raw_s, pair_s, copy_gbs)
+            r["fused_sums"] = bool(fz)
+            r["step_us"] = loop_ms * 1e3 / K
+            r["particle_steps_per_s"] = N_16M * K / (loop_ms * 1e-3)
+            r["kernels_us"] = {k: v[0] * 1e6 for k, v in per.items()}
+            res[key + variant] = r
+            pf.close()
     return res
 
 
