@@ -869,6 +869,48 @@ static int series_collect_phases(cssm_pf* pf, size_t T) {
   return CSSM_OK;
 }
 
+// ---- an arbitrary Resample[A] on the host (model/package.scala:23): the step split at the resampler ----------------------
+// cssm_pf_propagate = lines :117-124 of stepFilter (propagate, weigh); the caller fetches the proposed cloud and the
+// log-weights (cssm_pf_get_proposed / cssm_pf_get_logw), applies ITS resampler to them and hands the result back with
+// cssm_pf_adopt (:126-130).  A parity path -- the cloud crosses PCIe twice per observation -- for resamplers the library
+// does not have natively (Resampling.indentity :29, user functions).
+extern "C" int cssm_pf_propagate(cssm_pf* pf, double t, double obs, int has_obs) {
+  if (!pf) return fail(CSSM_EINVAL_ARG, "null handle");
+  if (!pf->initialised) return fail(CSSM_ESTATE, "cssm_pf_propagate before cssm_pf_init");
+  if (pf->sharded) return fail(CSSM_ESTATE, "a sharded handle is driven through the cssm_pf_shard_* stages");
+  HIP_TRY(hipSetDevice(pf->device));
+  int rc = ensure_recs(pf, 1);
+  if (rc) return rc;
+  build_rec(pf, pf->t, t, obs, has_obs, pf->step, &pf->h_recs[0]);
+  rc = build_fsub(pf, 0, 1, true);
+  if (rc) return rc;
+  HIP_TRY(hipMemcpyAsync(pf->d_recs, pf->h_recs, sizeof(StepRec), hipMemcpyHostToDevice, pf->stream));
+  rc = launch_propagate(pf, pf->d_recs);
+  if (rc) return rc;
+  // nobody decodes this step's running max on the device: clear both slot sets for the next weighted step
+  HIP_TRY(hipMemsetAsync(pf->sc->maxslot, 0, sizeof(pf->sc->maxslot), pf->stream));
+  Scalars h;
+  HIP_TRY(hipMemcpyAsync(&h, pf->sc, sizeof h, hipMemcpyDeviceToHost, pf->stream));
+  HIP_TRY(hipStreamSynchronize(pf->stream));
+  pf->wparity = 0;
+  pf->t = t; pf->step++;
+  return check_device_err(pf, h);
+}
+
+extern "C" int cssm_pf_adopt(cssm_pf* pf, const double* state_dN, double ll, int32_t ess) {
+  if (!pf || !state_dN) return fail(CSSM_EINVAL_ARG, "null argument");
+  if (!pf->initialised) return fail(CSSM_ESTATE, "cssm_pf_adopt before cssm_pf_init");
+  if (pf->sharded) return fail(CSSM_ESTATE, "a sharded handle is driven through the cssm_pf_shard_* stages");
+  HIP_TRY(hipSetDevice(pf->device));
+  // the resampled cloud becomes the current one, in place of the proposed cloud (the next propagate reads it directly)
+  HIP_TRY(hipMemcpy2DAsync(pf->state[pf->cur], pf->stride * 8, state_dN, pf->n * 8, pf->n * 8, pf->d, hipMemcpyHostToDevice, pf->stream));
+  HIP_TRY(hipMemcpyAsync(&pf->sc->ll, &ll, sizeof(double), hipMemcpyHostToDevice, pf->stream));
+  HIP_TRY(hipMemcpyAsync(&pf->sc->ess, &ess, sizeof(int32_t), hipMemcpyHostToDevice, pf->stream));
+  HIP_TRY(hipStreamSynchronize(pf->stream));
+  pf->src = pf->state[pf->cur]; pf->src_stride = pf->stride; pf->src2 = nullptr; pf->anc_valid = false;
+  return CSSM_OK;
+}
+
 // ------------------------------------------------------------------------------------ batch API
 
 static int run_filter_once(cssm_pf* pf, const double* t, const double* y, const uint8_t* has, size_t T, double* ll_out,

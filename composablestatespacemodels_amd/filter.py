@@ -18,6 +18,7 @@ fetched from the device on demand and is only available for the handle's CURRENT
 from __future__ import annotations
 
 import ctypes as C
+import math
 from dataclasses import dataclass, field
 from typing import Callable, Iterable, Iterator, List, Optional, Sequence, Tuple
 
@@ -85,6 +86,21 @@ class NativePf:
         self.generation += 1
         _abi.check(rc)
         return ll.value, ess.value
+
+    def propagate(self, t: float, y: Optional[float], has_obs: Optional[bool] = None):
+        """cssm_pf_propagate: stepFilter up to the weights (the caller resamples: see _FilterBase with a host function)."""
+        if has_obs is None:
+            has_obs = y is not None
+        rc = self.lib.cssm_pf_propagate(self._h, float(t), 0.0 if y is None else float(y), 1 if has_obs else 0)
+        self.generation += 1
+        _abi.check(rc)
+
+    def adopt(self, state: np.ndarray, ll: float, ess: int):
+        s = np.ascontiguousarray(state, dtype=np.float64)
+        if s.shape != (self.d, self.n):
+            raise ValueError(f"the resampled cloud must be [{self.d}, {self.n}], got {s.shape}")
+        _abi.check(self.lib.cssm_pf_adopt(self._h, _p(s), float(ll), int(ess)))
+        self.generation += 1
 
     def run(self, t, y, has=None, want_path: bool = False):
         t = np.ascontiguousarray(t, dtype=np.float64)
@@ -193,6 +209,11 @@ class Resampling:
     """
 
     @staticmethod
+    def indentity(samples: Sequence, weights: Sequence[float]):
+        """Resampling.indentity (sic), model/Resampling.scala:29: the samples as they are."""
+        return samples
+
+    @staticmethod
     def systematicAncestors(weights: Sequence[float], u: float, device: int = 0) -> np.ndarray:
         w = np.ascontiguousarray(weights, dtype=np.float64)
         anc = np.zeros(len(w), dtype=np.uint32)
@@ -288,10 +309,15 @@ class _FilterBase:
 
     def __init__(self, mod: Model, resample, n_particles: Optional[int] = None, seed: int = 20260101, device: int = 0):
         kinds = {Resampling.systematicResampling: 0, Resampling.stratifiedResampling: 1, Resampling.multinomialResampling: 2}
-        if resample not in kinds:
-            raise NotImplementedError("native resamplers: Resampling.systematicResampling, .stratifiedResampling, "
-                                      ".multinomialResampling (the reference's residualResampling cannot run as written)")
-        self._resampler = kinds[resample]
+        if resample is Resampling.residualResampling:
+            raise NotImplementedError("the reference's residualResampling cannot run as written (model/Resampling.scala:144-145)")
+        if not callable(resample):
+            raise TypeError("resample must be a Resample[A]: (samples, weights) -> samples")
+        # one of the three native resamplers: the whole step stays on the device.  Any OTHER function is a host Resample[A]
+        # (model/package.scala:23): the step is split at the resampler (cssm_pf_propagate / cssm_pf_adopt) and the function
+        # is applied to the cloud's columns exactly as the reference applies it to its Vector[State] -- a parity path.
+        self._resampler = kinds.get(resample, 0)
+        self._host_resample = None if resample in kinds else resample
         self.mod = mod
         self.resample = resample
         self.seed = seed
@@ -322,16 +348,54 @@ class _FilterBase:
     def stepFilter(self, s: PfState, y: TimedObservation) -> PfState:
         if s._owner is not self._pf or s._generation != self._pf.generation:
             raise RuntimeError("stepFilter must be applied to the filter's current PfState")
+        if self._host_resample is not None:
+            return self._step_with_host_resampler(s, y)
         ll, ess = self._pf.step(y.t, y.observation)
+        return self._state(y.t, y.observation, ll, ess)
+
+    def _step_with_host_resampler(self, s: PfState, y: TimedObservation) -> PfState:
+        """stepFilter with the user's Resample[A], line by line (ParticleFilter.scala:116-132): the device propagates and
+        weighs, the host rescales by the max, resamples with the given function and computes ll and ess."""
+        pf = self._pf
+        weighted = y.observation is not None or self.lgcp_precision > 0
+        pf.propagate(y.t, y.observation)
+        if not weighted:                                   # :121
+            return self._state(y.t, y.observation, s.ll, s.ess)
+        w = pf.logw()                                      # :123
+        x1 = pf.proposed()
+        mx = float(np.max(w))                              # :124
+        w1 = np.exp(w - mx)                                # :125
+        cols = [x1[:, i] for i in range(pf.n)]
+        new = self._host_resample(cols, w1)                # :126
+        if len(new) != pf.n:
+            raise ValueError("the resampler must return as many particles as it was given")
+        ll = s.ll + mx + math.log(float(np.sum(w1)) / pf.n)   # :127
+        nw = w1 / np.sum(w1)
+        ess = int(math.floor(1.0 / float(np.sum(nw * nw))))   # :128
+        pf.adopt(np.stack(new, axis=1), ll, ess)
         return self._state(y.t, y.observation, ll, ess)
 
     # ParticleFilter.scala:137-140
     def llFilter(self, data: Sequence[TimedObservation], n: int) -> float:
+        if self._host_resample is not None:                # fold stepFilter over the data (:137-140)
+            st = self.initialiseState(n, min(d.t for d in data))
+            for d in data:
+                st = self.stepFilter(st, d)
+            return st.ll
         t, y, h = split_data(data)
         return self._ensure(n).run(t, y, h)[0]
 
     # ParticleFilter.scala:152-158
     def filter(self, data: Sequence[TimedObservation], particles: int) -> Tuple[float, List[StateSpace]]:
+        if self._host_resample is not None:                # scan stepFilter, one uniformly picked particle per state (:152-158)
+            rng = np.random.default_rng(self.seed)
+            t0 = min(d.t for d in data)
+            st = self.initialiseState(particles, t0)
+            out = [StateSpace(t0, self._pf.particles()[:, int(rng.integers(particles))].copy())]
+            for d in data:
+                st = self.stepFilter(st, d)
+                out.append(StateSpace(d.t, self._pf.particles()[:, int(rng.integers(particles))].copy()))
+            return st.ll, out
         t, y, h = split_data(data)
         ll, _, _, path = self._ensure(particles).run(t, y, h, want_path=True)
         times = [float(np.min(t))] + [float(v) for v in t]

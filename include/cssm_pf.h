@@ -164,6 +164,15 @@ int cssm_pf_init_from(cssm_pf* pf, double t0, const double* state_d);
  * log-likelihood, ess_out = floor(1 / sum(normalised w^2)) (:431-434). */
 int cssm_pf_step(cssm_pf* pf, double t, double obs, int has_obs, double* ll_out, int32_t* ess_out);
 
+/* stepFilter split at the resampler, for a `Resample[A]` the library does not have natively (any host function:
+ * model/package.scala:23; Resampling.indentity, model/Resampling.scala:29).  cssm_pf_propagate does :117-124 (propagate the
+ * cloud to t, weigh it; `has_obs` = 0: propagate only); the host reads the proposed cloud and the log-weights
+ * (cssm_pf_get_proposed, cssm_pf_get_logw), forms w1 = exp(w - max), applies its resampler, and hands the resampled cloud
+ * (SoA, d x N, host) back with cssm_pf_adopt together with the new ll and ess (:126-130).  A parity path: the cloud crosses
+ * PCIe twice per observation.  After cssm_pf_propagate without cssm_pf_adopt the proposed cloud is the current one. */
+int cssm_pf_propagate(cssm_pf* pf, double t, double obs, int has_obs);
+int cssm_pf_adopt(cssm_pf* pf, const double* state_dN, double ll, int32_t ess);
+
 /* ---- batch mode: one native call for all T observations ----------------------------------- */
 
 /* llFilter (model/ParticleFilter.scala:137-140): t0 = min t, init, fold stepFilter over the

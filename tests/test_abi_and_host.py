@@ -109,9 +109,16 @@ def test_composition_is_left_nested_and_leftmost_model_observes():
     assert g.parameters().add([1.0] * len(theta)).flattenParams() == [v + 1.0 for v in theta]
 
 
-def test_only_the_reference_resamplers_are_accepted():
+def test_filter_accepts_any_resample_function_except_the_broken_residual():
+    """`Resample[A]` is a function type (model/package.scala:23): the three native resamplers keep the step on the device, any
+    other function is applied on the host (cssm_pf_propagate / cssm_pf_adopt); the reference's residualResampling cannot run as
+    written (model/Resampling.scala:144-145) and is refused."""
+    f = Filter(cases.c1_model(), lambda p, w: p)
+    assert f._host_resample is not None and Filter(cases.c1_model(), Resampling.systematicResampling)._host_resample is None
     with pytest.raises(NotImplementedError):
-        Filter(cases.c1_model(), lambda p, w: p)
+        Filter(cases.c1_model(), Resampling.residualResampling)
+    with pytest.raises(TypeError):
+        Filter(cases.c1_model(), 3)
     assert ParticleFilter.effectiveSampleSize([1.0, 1.0, 1.0, 1.0]) == 4      # ParticleFilter.scala:431-434
     assert ParticleFilter.effectiveSampleSize([1.0, 0.0, 0.0, 0.0]) == 1
     assert ParticleFilter.mean([1.0, 2.0, 3.0]) == 2.0

@@ -718,3 +718,44 @@ def test_set_params_is_transactional_and_keeps_the_structure():
     g.set_params(cases.c2_model())                # the same structure is accepted
     assert g.run(t, y, has)[0] == ll0
     g.close()
+
+
+def test_filter_with_a_host_resample_function():
+    """`Filter(mod, f)` for an arbitrary `Resample[A]` (model/package.scala:23): the device propagates and weighs, the function
+    resamples on the host.  (i) a host restatement of systematic resampling driven by the contract's own uniform reproduces
+    the native filter bit for bit -- particles, ess; ll to the last bits (the host sums in plain fp64); (ii) Resampling.indentity
+    (model/Resampling.scala:29) leaves the cloud unresampled: ll and ess still follow :127-128."""
+    from composablestatespacemodels_amd.filter import Filter
+    from composablestatespacemodels_amd.model import TimedObservation
+    model = cases.c2_model()
+    n, T = 4000, 6
+    t, y, has = cases.poisson_counts(T, missing=0.2)
+    data = [TimedObservation(float(a), float(b) if h else None) for a, b, h in zip(t, y, has)]
+    step = {"s": 0}
+
+    def host_systematic(particles, w1):
+        # the contract's ancestors for these weights and this observation's uniform (cssm_resample_systematic with the
+        # same u the native filter draws: stream U, observation index)
+        u = float(oracle.lib().oracle_c_u(cases.SEED, step["s"]))
+        anc = Resampling.systematicAncestors(w1, u)
+        return [particles[int(a)] for a in anc]
+
+    f = Filter(model, host_systematic, seed=cases.SEED)
+    g = Filter(model, Resampling.systematicResampling, seed=cases.SEED)
+    sf, sg = f.initialiseState(n, 0.0), g.initialiseState(n, 0.0)
+    for k, d in enumerate(data):
+        step["s"] = k
+        sf, sg = f.stepFilter(sf, d), g.stepFilter(sg, d)
+        np.testing.assert_array_equal(sf.particles, sg.particles)
+        assert sf.ess == sg.ess and abs(sf.ll - sg.ll) < 1e-9
+    # identity: no resampling at all
+    fi = Filter(model, Resampling.indentity, seed=cases.SEED)
+    si = fi.initialiseState(n, 0.0)
+    o = oracle.OraclePf(model.descriptor(), n, cases.SEED)
+    o.init(0.0)
+    o.propagate_only(data[0].t, data[0].observation, True)
+    si = fi.stepFilter(si, data[0])
+    np.testing.assert_array_equal(si.particles, o.proposed())          # the proposed cloud, unresampled
+    w = o.logw(); w1 = np.exp(w - w.max())
+    assert abs(si.ll - (w.max() + np.log(w1.sum() / n))) < 1e-12 and si.ess == int(np.floor(1.0 / np.sum((w1 / w1.sum()) ** 2)))
+    assert fi.llFilter(data, n) == fi.llFilter(data, n)                # deterministic under the handle's seed
