@@ -759,3 +759,38 @@ def test_filter_with_a_host_resample_function():
     w = o.logw(); w1 = np.exp(w - w.max())
     assert abs(si.ll - (w.max() + np.log(w1.sum() / n))) < 1e-12 and si.ess == int(np.floor(1.0 / np.sum((w1 / w1.sum()) ** 2)))
     assert fi.llFilter(data, n) == fi.llFilter(data, n)                # deterministic under the handle's seed
+
+
+@pytest.mark.parametrize("name,n,T,lgcp", [("c3_model", 1 << 22, 4, 0), ("c4_model", 1 << 24, 3, 2), ("c2_model", 100_000, 6, 0)])
+def test_full_size_configs_oracle_checked_on_slices(name, n, T, lgcp):
+    """BASELINE configs 3 (d = 9, N = 2^22), 4 (LGCP, N = 2^24) and 5's filter (N = 100 000) at their FULL particle counts, checked
+    against the oracle where the one-thread oracle can go: slices of the cloud.  Variates are keyed by the global particle id,
+    so an oracle shard [first, first + m) of an N-particle filter, handed the GPU's resampled cloud of its slice, must
+    reproduce the GPU's propagated particles and log-weights of that slice bit for bit at every observation (the initial
+    cloud included) -- three slices per configuration, one with an odd start (unpaired normal streams).  The resampling
+    in between is global; the offspring-count property of test_full_size_c3_c4_size_independent_properties pins it."""
+    model = getattr(cases, name)()
+    t, y, has = (cases.event_times(T) if lgcp else cases.poisson_counts(T, missing=0.25))
+    g = NativePf(model, n, cases.SEED, lgcp_precision=lgcp)
+    t0 = float(np.min(t))
+    g.init(t0)
+    slices = [(0, 4096), (n // 2 - 1001, 4097), (n - 3000, 3000)]
+    shards = []
+    cloud = g.particles()
+    for first, m in slices:
+        o = oracle.OraclePf(model.descriptor(lgcp), m, cases.SEED)
+        o.set_shard(first, n)
+        o.init(t0)
+        np.testing.assert_array_equal(o.particles(), cloud[:, first:first + m], err_msg=f"initial cloud, slice at {first}")
+        shards.append(o)
+    for s in range(T):
+        g.step(t[s], y[s], bool(has[s]))
+        prop, lw = g.proposed(), g.logw()
+        for (first, m), o in zip(slices, shards):
+            o.set_particles(np.ascontiguousarray(cloud[:, first:first + m]))
+            o.propagate_only(float(t[s]), float(y[s]), bool(has[s]))
+            np.testing.assert_array_equal(o.proposed(), prop[:, first:first + m], err_msg=f"step {s}, slice at {first}: propagated cloud")
+            if has[s] or lgcp:
+                np.testing.assert_array_equal(o.logw(), lw[first:first + m], err_msg=f"step {s}, slice at {first}: log-weights")
+        cloud = g.particles()
+    g.close()

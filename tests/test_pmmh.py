@@ -122,6 +122,26 @@ def test_native_pmmh_chain_matches_oracle_bit_for_bit():
 
 
 @pytest.mark.gpu
+def test_native_pmmh_chain_at_the_full_c5_size_matches_oracle():
+    """BASELINE config 5 at its full size -- N = 100 000 particles, T = 500 observations -- for the two iterations the
+    one-thread oracle can afford (2 x 5e7 particle-steps): log-likelihoods, parameters, acceptances and the sampled states of
+    the native chain equal the oracle's bit for bit."""
+    from composablestatespacemodels_amd.pmmh import pmmh_native
+    from composablestatespacemodels_amd import Data
+    model = cases.c2_model()
+    t, y, has = cases.poisson_counts(500)
+    data = [Data(float(a), float(b) if h else None) for a, b, h in zip(t, y, has)]
+    init = model.parameters()
+    ll, th, acc, last = pmmh_native(cases.c2_unparam(), init, data, 100_000, 0.05, 2, seed=7)
+    o = oracle.OraclePf(model.descriptor(), 100_000, 1)
+    oll, oth, oacc, olast = o.pmmh(model.descriptor(), np.array(init.flattenParams()), 0.05, t, y, has, seed=7, n_iters=2)
+    np.testing.assert_array_equal(ll, oll)
+    np.testing.assert_array_equal(th, oth)
+    np.testing.assert_array_equal(acc, oacc)
+    np.testing.assert_array_equal(last, olast)
+
+
+@pytest.mark.gpu
 def test_generic_pmmh_state_over_native_bootstrap_filter():
     from composablestatespacemodels_amd.pmmh import bootstrap_filter
     from composablestatespacemodels_amd import Data
