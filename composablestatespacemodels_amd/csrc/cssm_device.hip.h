@@ -512,3 +512,71 @@ __device__ __forceinline__ void fill_runs_tile(uint32_t prev, const uint32_t (&e
     __syncthreads();                                        // s_slot / s_wmax are rewritten by the next chunk
   }
 }
+
+#define CSSM_WAVE_CHUNK 512   /* resampling slots one WAVE assembles in LDS at a time (2 KiB per wave) */
+
+// The same for ONE WAVE's 256 particles, with no block barrier at all: lane l holds the end slots e[0..3] of its four
+// consecutive particles first_idx .. first_idx + 3 and `prev`; the wave's particles own the slots [lo, hi) (wave-uniform;
+// already clipped).  A wave's LDS operations execute in program order, so markers written by some lanes are visible to
+// the reads of others without s_barrier -- the compiler is held to that order by wave_barrier + an explicit lgkmcnt wait.
+// k_offspring spent half its wave cycles waiting (PMC SQ_WAIT_ANY 51 %): eight block barriers per tile of 1024 particles,
+// five of them in the block-wide version of this function.  s_wave: CSSM_WAVE_CHUNK words of LDS owned by this wave.
+template <bool SC1>
+__device__ __forceinline__ void fill_runs_wave(uint32_t prev, const uint32_t (&e)[CSSM_ITEMS], uint32_t first_idx, uint32_t lo, uint32_t hi,
+                                               uint32_t* __restrict__ anc, uint32_t slot_off, uint32_t idx_max, uint32_t* __restrict__ s_wave) {
+  const uint32_t lane = threadIdx.x & 63u;
+  auto lds_order = [] { __builtin_amdgcn_wave_barrier(); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_wave_barrier(); };
+  for (uint32_t c0 = lo & ~63u; c0 < hi; c0 += CSSM_WAVE_CHUNK) {
+    uint4* z = reinterpret_cast<uint4*>(s_wave + lane * 8);
+    z[0] = make_uint4(0u, 0u, 0u, 0u); z[1] = make_uint4(0u, 0u, 0u, 0u);
+    lds_order();
+#pragma unroll
+    for (int r = 0; r < CSSM_ITEMS; ++r) {
+      uint32_t rb = (r == 0) ? prev : e[r - 1];
+      uint32_t re = e[r];
+      rb = (rb < lo) ? lo : rb;
+      re = (re > hi) ? hi : re;
+      if (re > rb && re > c0 && rb < c0 + CSSM_WAVE_CHUNK) {
+        const uint32_t pos = ((rb > c0) ? rb : c0) - c0;
+        s_wave[pos] = first_idx + r + 1u;                  // index + 1 (0 = no run starts here)
+      }
+    }
+    lds_order();
+    const uint4 a = z[0], bq = z[1];
+    uint32_t v[8] = {a.x, a.y, a.z, a.w, bq.x, bq.y, bq.z, bq.w};
+#pragma unroll
+    for (int k = 1; k < 8; ++k) v[k] = (v[k - 1] > v[k]) ? v[k - 1] : v[k];
+    const uint32_t incl = wave_scan_max_u32(v[7]);
+    const uint32_t carry = dpp0<0x138 /* wave_shr:1 */, 0xf>(incl);   // exclusive: max over the lanes before this one (lane 0: 0)
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      uint32_t x = (v[k] > carry) ? v[k] : carry;
+      x = (x > 0u) ? x - 1u : 0u;                           // (0 cannot occur inside [lo, hi): every slot there belongs to a run)
+      v[k] = (x > idx_max) ? idx_max : x;
+    }
+    // back through LDS so that each of the two store instructions of the wave covers 1 KiB contiguously
+    lds_order();
+    z[0] = make_uint4(v[0], v[1], v[2], v[3]); z[1] = make_uint4(v[4], v[5], v[6], v[7]);
+    lds_order();
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+      const uint32_t p = half * (CSSM_WAVE_CHUNK / 2) + lane * 4;
+      const uint4 w = *reinterpret_cast<const uint4*>(s_wave + p);
+      const uint32_t s0 = c0 + p;
+      uint32_t* dst = anc + ((long long)s0 - (long long)slot_off);   // (signed: see fill_runs_tile)
+      if (s0 >= lo && s0 + 4 <= hi && ((s0 - slot_off) & 3u) == 0u) {
+        if (SC1) store_anc4_sc1(dst, w.x, w.y, w.z, w.w);
+        else *reinterpret_cast<uint4*>(dst) = w;
+      } else {
+        const uint32_t wv[4] = {w.x, w.y, w.z, w.w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+          if (s0 + k >= lo && s0 + k < hi) {
+            if (SC1) __hip_atomic_store(dst + k, wv[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            else dst[k] = wv[k];
+          }
+      }
+    }
+    lds_order();                                            // the region is rewritten by the next chunk
+  }
+}

@@ -212,7 +212,6 @@ __device__ __forceinline__ void offspring_body(const double* __restrict__ logw, 
   const double* tab = nullptr; (void)logtab;
   __shared__ cssm_u128 s_w[CSSM_BLOCK / 64];
   __shared__ uint32_t s_last[CSSM_BLOCK / 64];
-  __shared__ uint32_t s_tile_b;
 #if !CSSM_OFF_LINES
   __shared__ uint32_t s_nheavy;
 #endif
@@ -410,17 +409,18 @@ __device__ __forceinline__ void offspring_body(const double* __restrict__ logw, 
                        ? (uint32_t)cssm_strat_count(Cp, seed, rec->step, n_global)
                        : (uint32_t)(pow2 ? cssm_sys_count_pow2(Cp, u, n_global, inv_n) : cssm_sys_count(Cp, u, n_global));
           }
-          if (wid == 0) s_tile_b = prev;
         }
-        __syncthreads();
 #if CSSM_OFF_LINES
-        // the slots the tile's particles own: [start of its first particle's run, end of its last particle's run), clipped
-        // to this launch's slots; their ancestors are assembled in LDS and written as whole lines (fill_runs_tile)
-        uint32_t tb = s_tile_b, te = s_last[CSSM_BLOCK / 64 - 1];
-        if (CLIP) { tb = (tb < slot_lo) ? slot_lo : tb; te = (te > slot_hi) ? slot_hi : te; }
-        te = (te > (uint32_t)n_global) ? (uint32_t)n_global : te;
-        tb = (tb > te) ? te : tb;
-        fill_runs_tile<CSSM_OFF_SC1 != 0>(prev, e, (uint32_t)i0, tb, te, anc, CLIP ? slot_lo : 0u, (uint32_t)(n - 1), s_slot);
+        // the slots this WAVE's 256 particles own: [start of its first particle's run, end of its last particle's run), clipped
+        // to this launch's slots; their ancestors are assembled in the wave's LDS region and written as whole lines, with no
+        // block barrier (fill_runs_wave)
+        uint32_t wb = (uint32_t)__builtin_amdgcn_readfirstlane((int)prev);
+        uint32_t we = (uint32_t)__builtin_amdgcn_readlane((int)e[CSSM_ITEMS - 1], 63);
+        if (CLIP) { wb = (wb < slot_lo) ? slot_lo : wb; we = (we > slot_hi) ? slot_hi : we; }
+        we = (we > (uint32_t)n_global) ? (uint32_t)n_global : we;
+        wb = (wb > we) ? we : wb;
+        fill_runs_wave<CSSM_OFF_SC1 != 0>(prev, e, (uint32_t)i0, wb, we, anc, CLIP ? slot_lo : 0u, (uint32_t)(n - 1),
+                                          s_slot + wid * CSSM_WAVE_CHUNK);
 #else
         // every particle writes its own run of slots (runs longer than CSSM_RUN_DIRECT: the whole block)
         if (threadIdx.x == 0) s_nheavy = 0;

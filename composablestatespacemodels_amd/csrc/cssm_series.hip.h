@@ -218,7 +218,12 @@ __device__ __forceinline__ void series_offspring(const double* __restrict__ s_lw
     // defensive bounds (a NaN total or a broken invariant must never become a wild store): slots live in [0, N]
     tile_e = (tile_e > (uint32_t)n_global) ? (uint32_t)n_global : tile_e;
     tile_b = (tile_b > tile_e) ? tile_e : tile_b;
-    fill_runs_tile<true>(prev, e, range_lo + p0, tile_b, tile_e, anc, 0u, n_last, s_slot);
+    {   // this wave's slot range, clipped to the tile's (defensive) bounds
+      uint32_t wb = (uint32_t)__builtin_amdgcn_readfirstlane((int)prev);
+      uint32_t we = (uint32_t)__builtin_amdgcn_readlane((int)e[CSSM_ITEMS - 1], 63);
+      wb = (wb < tile_b) ? tile_b : wb; we = (we > tile_e) ? tile_e : we; wb = (wb > we) ? we : wb;
+      fill_runs_wave<true>(prev, e, range_lo + p0, wb, we, anc, 0u, n_last, s_slot + wid * CSSM_WAVE_CHUNK);
+    }
     // ---- next tile
     cssm_u128 ttot = s_w[0];
 #pragma unroll
