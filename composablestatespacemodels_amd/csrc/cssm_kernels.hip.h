@@ -222,6 +222,17 @@ __device__ __forceinline__ void offspring_body(const double* __restrict__ logw, 
   if (SELF && (sc->err & 64u)) return;
   double pre_v[CSSM_ITEMS];   // the block's first tile is requested before the serial prologue
   if (blockIdx.x < nunits) load_tile_raw(logw, (uint64_t)blockIdx.x * sup * CSSM_TILE, n, raw, pre_v);
+  // ... and (single GPU) so are the unit sums every block totals: up to 1024 of them, 4 per thread, in flight while the max
+  // is decoded -- one dependent round trip less on the kernel's critical path, which at N = 2^20 is all it has
+  constexpr int UPRE = 4;
+  cssm_u128 upre[UPRE];
+  if (SELF) {
+#pragma unroll
+    for (int k = 0; k < UPRE; ++k) {
+      const uint32_t q = threadIdx.x + (uint32_t)k * CSSM_BLOCK;
+      upre[k] = (q < nunits * (uint32_t)split) ? unitP[q] : cssm_u128_zero();
+    }
+  }
   double gmax_dec;
   if (SELF) {
     gmax_dec = block_decode_slots(sc, slot_set);
@@ -285,7 +296,10 @@ __device__ __forceinline__ void offspring_body(const double* __restrict__ logw, 
       S_off = sc->S_off;
     }
   }
-  for (uint32_t unit = blockIdx.x; unit < nunits; unit += gridDim.x) {
+  // (SELF: the single-GPU launch has exactly one block per unit -- no loop, so that what was prefetched above does not
+  //  have to stay live around a back edge)
+  uint32_t unit = blockIdx.x;
+  if (unit < nunits) do {
     const uint32_t t0 = unit * sup;
     const uint32_t t1 = (t0 + sup < ntiles) ? t0 + sup : ntiles;
     cssm_u128 toff;                                        // cumulative weight before the current tile
@@ -304,11 +318,18 @@ __device__ __forceinline__ void offspring_body(const double* __restrict__ logw, 
     } else if (SELF) {                                     // here unitP holds the unit SUMS (k_tile_sums output)
       cssm_u128 pre = cssm_u128_zero(), tot = cssm_u128_zero(), tot2 = cssm_u128_zero();
       const uint32_t nsub = nunits * (uint32_t)split, qlim = unit * (uint32_t)split;
-      for (uint32_t q = threadIdx.x; q < nsub; q += CSSM_BLOCK) {
+#pragma unroll
+      for (int k = 0; k < UPRE; ++k) {     // (requested before the max was decoded; upre[k] is zero beyond nsub)
+        const uint32_t q = threadIdx.x + (uint32_t)k * CSSM_BLOCK;
+        if (q < qlim) pre = cssm_u128_add(pre, upre[k]);
+        tot = cssm_u128_add(tot, upre[k]);
+        if (unit == 0 && q < nsub) tot2 = cssm_u128_add(tot2, unitS2[q]);   // only the publishing block needs sum w^2
+      }
+      for (uint32_t q = threadIdx.x + UPRE * CSSM_BLOCK; q < nsub; q += CSSM_BLOCK) {
         const cssm_u128 v = unitP[q];
         if (q < qlim) pre = cssm_u128_add(pre, v);
         tot = cssm_u128_add(tot, v);
-        if (unit == 0) tot2 = cssm_u128_add(tot2, unitS2[q]);   // only the publishing block needs sum w^2
+        if (unit == 0) tot2 = cssm_u128_add(tot2, unitS2[q]);
       }
       pre = wave_sum_u128(pre); tot = wave_sum_u128(tot);
       if (unit == 0) tot2 = wave_sum_u128(tot2);
@@ -459,7 +480,7 @@ __device__ __forceinline__ void offspring_body(const double* __restrict__ logw, 
       toff = cssm_u128_add(toff, ttot);
       __syncthreads();
     }
-  }
+  } while (!SELF && (unit += gridDim.x) < nunits);
 }
 
 #define CSSM_OFFSPRING_PARAMS                                                                                              \
