@@ -219,7 +219,8 @@ __device__ __forceinline__ void offspring_body(const double* __restrict__ logw, 
   __shared__ cssm_u128 s_r[3][CSSM_BLOCK / 64];
   // (batch series, single GPU) an earlier observation's reference level was ruled out by its max: the series is on hold at
   // that observation until the host has redone its sums (run_filter_once); nothing may change meanwhile
-  if (SELF && (sc->err & 64u)) return;
+  // (the test sits behind the prefetches below: a dependent round trip at the very top of the kernel otherwise)
+  const uint32_t held = SELF ? sc->err : 0u;
   double pre_v[CSSM_ITEMS];   // the block's first tile is requested before the serial prologue
   if (blockIdx.x < nunits) load_tile_raw(logw, (uint64_t)blockIdx.x * sup * CSSM_TILE, n, raw, pre_v);
   // ... and (single GPU) so are the unit sums every block totals: up to 1024 of them, 4 per thread, in flight while the max
@@ -236,6 +237,7 @@ __device__ __forceinline__ void offspring_body(const double* __restrict__ logw, 
   double gmax_dec;
   if (SELF) {
     gmax_dec = block_decode_slots(sc, slot_set);
+    if (held & 64u) return;
   } else if (all5) {
     unsigned long long key = 0ull;
     for (int r = 0; r < world; ++r) { const unsigned long long k = all5[(size_t)all5_stride * r + 4]; key = (k > key) ? k : key; }

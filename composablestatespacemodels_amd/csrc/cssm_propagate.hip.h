@@ -439,11 +439,12 @@ __global__ __launch_bounds__(CSSM_BLOCK, (PropWaves<D, SUMS>::value)) void k_pro
   // SUMS: the block also forms its fixed-point sums of exp(w - c) (subS / subS2, one entry per block) and, for `filter`,
   // records the state sampleOne picked after the previous observation (pick_out / pick_slot; see k_propagate)
   __shared__ double s_max[CSSM_BLOCK / 64];
-  if (sc->err & (4u | 8u | 64u)) return;
+  const uint32_t held = sc->err;          // (tested behind the table staging: its load then overlaps the table's)
   const uint32_t range_lo = blockIdx.x * (uint32_t)chunk;
   uint32_t n;
   { const uint64_t range_hi = (uint64_t)range_lo + chunk; n = (uint32_t)((range_hi < n_arg) ? range_hi : n_arg); }
   const double* tab = stage_log_table(logtab);
+  if (held & (4u | 8u | 64u)) return;
   __shared__ __attribute__((aligned(16))) unsigned char s_stage[PropStage<D, IT>::bytes];
   PropAcc acc;
   propagate_range<D, false, IT, OBS, SUMS, false>(src, src_stride, anc, dst, dst_stride, logw, 0ull, seed, rec, mk, nullptr, 0, 0u, tab,
