@@ -120,10 +120,9 @@ struct cssm_pf {
   uint32_t *cand_end = nullptr, *cand_idx = nullptr;   // end slot / state index of every candidate, global order
   size_t cidx_cap = 0;
   int64_t* d_bounds = nullptr;
-  // fixed-capacity (host-read-free) exchange
-  int64_t* d_xch = nullptr;    // [0..63] send first, [64..127] send count, [128] redo flag of the step, [129..130] n_low, n_high
-  uint32_t* d_need = nullptr;  // per step: the largest send count of this rank (how much capacity the step needed)
-  size_t need_cap = 0;
+  int64_t* d_xch = nullptr;    // exact exchange: [0..63] send first, [64..127] send count; [128] the redo flag k_offspring_expand_spec writes
+  uint32_t* d_need = nullptr;  // per observation: rows the exchange needed (diagnostics of cssm_pf_shard_status; zero since the
+  size_t need_cap = 0;         //   two-collective exchange that recorded them was removed)
   bool series = false;         // records of a whole series are resident (cssm_pf_shard_begin)
   struct Snap { int cur; const double* src; size_t src_stride; const double* src2; size_t src2_stride; uint32_t n_split; bool anc_valid, last_optimistic; uint32_t step; double t; };
   std::vector<Snap> snaps;     // host-side state right after the propagate of every observation of the series (cssm_pf_shard_resume)
@@ -1656,12 +1655,7 @@ extern "C" int cssm_pf_shard_offspring(cssm_pf* pf, const uint64_t* all_sums5_de
   return CSSM_OK;
 }
 
-// ---- fixed-capacity exchange: no host read between the kernels of a step ------------------------------------
-// Send buffer: one segment per destination rank, (cap + 1) rows of (d + 1) doubles; row 0 is a header whose first
-// double is the number of candidate rows that follow (0 for the rank itself: the own range never travels), rows
-// 1..count are (state, end slot).  An all-to-all with EQUAL splits moves segment q of every rank to rank q, so the
-// receiver learns the counts from the headers and the host never does.  count > cap sets the sticky err bit 3 (the
-// caller repeats the series with a larger cap or with the exact, host-read exchange).
+// ---- a series known in advance: records resident on the device, observations propagated by index ----------------
 // first j in [0, n) with endslot[j] > bound (strict) or >= bound, n if there is none; endslot is non-decreasing.
 // All 64 lanes of a wave call it: every round probes 64 equally spaced positions of the bracket (4 rounds for 2^24).
 __device__ __forceinline__ uint64_t wave_search_first(const uint32_t* __restrict__ endslot, uint64_t n, uint64_t bound, bool strict) {
@@ -1823,10 +1817,9 @@ extern "C" int cssm_pf_shard_adopt_spec(cssm_pf* pf, const double* recv_buf_dev,
   return CSSM_OK;
 }
 
-// ll, ess and the sticky bits of a series run with the fixed-capacity exchange: bit 2 (value 4) = some step's
-// reference level was ruled out by the max, bit 3 (value 8) = some send count exceeded the capacity.  Either bit
-// means the numbers are not the filter's; `need` (optional, T entries) receives the capacity every step needed
-// (exact up to the first overflowing step).
+// ll, ess and the sticky bits of a series run with the single-collective exchange: bit 2 (value 4) = some observation's
+// reference level was ruled out by the max, bit 3 (value 8) = a capacity miss that was not resumed.  Either bit means the
+// numbers are not the filter's (ShardedFilter moves on to its next plan); `need` (optional, T entries): diagnostics.
 extern "C" int cssm_pf_shard_status(cssm_pf* pf, double* ll_out, int32_t* ess_out, uint32_t* bits_out, uint32_t* need, size_t T) {
   int rc = shard_check(pf);
   if (rc) return rc;

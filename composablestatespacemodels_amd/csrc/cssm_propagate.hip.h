@@ -152,7 +152,7 @@ __device__ __forceinline__ void propagate_range(
     }
   };
   // src2_stride == 0: the candidates are rows of (D + 1) doubles (state, end slot) exactly as they were received
-  // (fixed-capacity exchange: the receive buffer is read in place); otherwise struct-of-arrays with that stride
+  // (single-collective exchange: the receive buffer is read in place); otherwise struct-of-arrays with that stride
   auto ptr_of = [&](uint32_t j, int k) -> const double* {
     if (src2 && j >= n_split)
       return (src2_stride == 0) ? src2 + (size_t)(j - n_split) * (size_t)(D + 1) + k : src2 + (size_t)k * src2_stride + (j - n_split);

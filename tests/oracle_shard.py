@@ -160,7 +160,7 @@ class OracleShard:
         assert anc.max() < n_recv
         self.o.set_particles(np.ascontiguousarray(cand[anc].T))
 
-    # ---- the fixed-capacity (host-read-free) series API of GpuShard, restated
+    # ---- the series API of GpuShard (records resident, observations by index), restated
     def begin(self, t, y, has):
         self._t = np.asarray(t, dtype=np.float64); self._y = np.asarray(y, dtype=np.float64)
         self._has = np.ones(len(self._t), dtype=np.uint8) if has is None else np.asarray(has)

@@ -16,7 +16,7 @@ for n in ([int(a) for a in sys.argv[1:]] or [1 << 20, 1 << 24]):
         torch.cuda.synchronize(); t0 = time.perf_counter()
         ll, ess = f.ll_filter(t[:200], y[:200], has[:200], exact=exact)
         torch.cuda.synchronize(); w = time.perf_counter() - t0
-        print(f"sharded RCCL path, world=1, N={n}, {'exact (host-read)' if exact else 'fixed-capacity'} exchange: {w/200*1e6:.1f} us/step, "
+        print(f"sharded RCCL path, world=1, N={n}, {'exact (host-read)' if exact else 'single-collective'} exchange: {w/200*1e6:.1f} us/step, "
               f"{n*200/w/1e9:.2f} G particle-steps/s  cap={f.last_cap} attempts={f.last_attempts} ll={ll:.6f}", flush=True)
     shard.close()
 dist.destroy_process_group()
