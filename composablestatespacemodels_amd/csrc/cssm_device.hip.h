@@ -82,10 +82,13 @@ struct StepRec {
 // Device scalars of a handle.
 #define CSSM_MAXSLOTS 64
 #define CSSM_SLOT_STRIDE 16 /* u64 words: one 128-byte line per slot */
+#define CSSM_MAXSETS 3
+#define CSSM_STEP_UNITS 1024 /* unit sums one block of k_step scans (four per thread) */
 struct Scalars {
-  // Order keys of the running max log-weight, sharded over CSSM_MAXSLOTS cache lines, in two sets:
-  // weighted step s uses set s&1, and its last kernel clears the other set for step s+1.
-  unsigned long long maxslot[2 * CSSM_MAXSLOTS * CSSM_SLOT_STRIDE];
+  // Order keys of the running max log-weight, sharded over CSSM_MAXSLOTS cache lines, in three sets: weighted
+  // observation s uses set s % 3; the kernel that resamples it clears the sets it neither reads nor has written into
+  // (k_offspring: both others; k_step, which reads set s and collects the max of observation s + 1 in set s + 1: the third).
+  unsigned long long maxslot[CSSM_MAXSETS * CSSM_MAXSLOTS * CSSM_SLOT_STRIDE];
   uint32_t err;              // bit0: NaN log-weight, bit1: all weights zero / max not finite,
                              // bit2: the reference level was unusable and the sums must be formed again (host retries)
                              // bit3: (sharded) the exchange capacity did not cover some rank's slots at step fail_step
@@ -419,6 +422,65 @@ __device__ __forceinline__ void finish_step(Scalars* sc, uint64_t n_global) {
   double e = 1.0 / (tot2 / (tot * tot));
   double fl = (double)(long long)e;   // e >= 1 here; floor == trunc
   sc->ess = (e < 2147483647.0) ? (int32_t)fl : 2147483647;
+}
+
+
+// ------------------------------------------------------------------------------------ weights of a tile, end slots
+
+// raw != 0: `logw` already holds the weights w1 themselves (stateless Resample[A] entry point,
+// whose second argument is w1 = exp(w - max): model/ParticleFilter.scala:125-126).
+__device__ __forceinline__ void load_tile_raw(const double* __restrict__ logw, uint64_t base, uint64_t n, int raw,
+                                              double (&v)[CSSM_ITEMS]) {
+  const uint64_t i0 = base + (uint64_t)threadIdx.x * CSSM_ITEMS;
+  if (i0 + CSSM_ITEMS <= n) {
+    const double2 a = *reinterpret_cast<const double2*>(logw + i0);
+    const double2 b = *reinterpret_cast<const double2*>(logw + i0 + 2);
+    v[0] = a.x; v[1] = a.y; v[2] = b.x; v[3] = b.y;
+  } else {
+#pragma unroll
+    for (int r = 0; r < CSSM_ITEMS; ++r) v[r] = (i0 + r < n) ? logw[i0 + r] : (raw ? 0.0 : -cssm_inf());
+  }
+}
+__device__ __forceinline__ void weights_from_raw(const double (&v)[CSSM_ITEMS], double gmax, int raw, double (&w1)[CSSM_ITEMS],
+                                                 const double* tab) {
+#pragma unroll
+  for (int r = 0; r < CSSM_ITEMS; ++r) w1[r] = raw ? v[r] : cssm_exp(v[r] - gmax);
+}
+__device__ __forceinline__ void load_tile_weights(const double* __restrict__ logw, uint64_t base, uint64_t n,
+                                                  double gmax, int raw, double (&w1)[CSSM_ITEMS], const double* tab) {
+  double v[CSSM_ITEMS];
+  load_tile_raw(logw, base, n, raw, v);
+  weights_from_raw(v, gmax, raw, w1, tab);
+}
+
+// End slot of a particle under systematic resampling = cnt(C_j) of the contract, C_j = `run` / total (treeEcdf,
+// model/Resampling.scala:52-58,69).  Fast path: p = S_j / S_tot * N - u evaluated in fp64 has an absolute error
+// < N * 2^-49.5 slots (two conversions, one quotient, one fma), and the contract's own roundings move a decision by
+// < N * 2^-51 slots; whenever p is farther than eps = N * 2^-46 from an integer, floor(p) + 1 IS the contract's count.
+// Otherwise (probability 2 eps per particle) the exact predicate is evaluated.  (k_offspring's loop states the same
+// expressions; k_step uses this function for the unit boundaries and for the particles.)
+struct SlotMap {
+  double totd, scale, u, nd, eps, inv_n;
+  uint64_t n;
+  bool pow2;
+  int force_exact;
+  __device__ __forceinline__ void set(const cssm_u128& tot, double u_, uint64_t n_, int force) {
+    totd = cssm_u128_to_double(tot); n = n_; nd = (double)n_; scale = nd / totd; eps = nd * 0x1.0p-46; u = u_;
+    inv_n = 1.0 / (double)n_; pow2 = (n_ & (n_ - 1)) == 0; force_exact = force;
+  }
+};
+__device__ __forceinline__ uint32_t sys_end_slot(const cssm_u128& run, const SlotMap& m) {
+  const double sd = cssm_fma((double)run.hi, 0x1.0p64, (double)run.lo);
+  const double pp = cssm_fma(sd, m.scale, -m.u);
+  const double fl = __builtin_floor(pp);
+  const double fr = pp - fl;
+  double cnt = fl + 1.0;
+  cnt = (cnt < 0.0) ? 0.0 : cnt;
+  cnt = (cnt > m.nd) ? m.nd : cnt;
+  const bool safe = (fr > m.eps) && (fr < 1.0 - m.eps) && !m.force_exact;
+  if (safe) return (uint32_t)cnt;
+  const double C = cssm_u128_to_double(run) / m.totd;
+  return (uint32_t)(m.pow2 ? cssm_sys_count_pow2(C, m.u, m.n, m.inv_n) : cssm_sys_count(C, m.u, m.n));
 }
 
 // inclusive max-scan across the 64 lanes (values >= 0; a lane without a DPP source reads 0)

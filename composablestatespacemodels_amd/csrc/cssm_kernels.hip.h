@@ -27,31 +27,7 @@ __global__ void k_init_from(double* __restrict__ dst, size_t stride, uint64_t n,
 
 // ------------------------------------------------------------------------------------ tile sums
 
-// raw != 0: `logw` already holds the weights w1 themselves (stateless Resample[A] entry point,
-// whose second argument is w1 = exp(w - max): model/ParticleFilter.scala:125-126).
-__device__ __forceinline__ void load_tile_raw(const double* __restrict__ logw, uint64_t base, uint64_t n, int raw,
-                                              double (&v)[CSSM_ITEMS]) {
-  const uint64_t i0 = base + (uint64_t)threadIdx.x * CSSM_ITEMS;
-  if (i0 + CSSM_ITEMS <= n) {
-    const double2 a = *reinterpret_cast<const double2*>(logw + i0);
-    const double2 b = *reinterpret_cast<const double2*>(logw + i0 + 2);
-    v[0] = a.x; v[1] = a.y; v[2] = b.x; v[3] = b.y;
-  } else {
-#pragma unroll
-    for (int r = 0; r < CSSM_ITEMS; ++r) v[r] = (i0 + r < n) ? logw[i0 + r] : (raw ? 0.0 : -cssm_inf());
-  }
-}
-__device__ __forceinline__ void weights_from_raw(const double (&v)[CSSM_ITEMS], double gmax, int raw, double (&w1)[CSSM_ITEMS],
-                                                 const double* tab) {
-#pragma unroll
-  for (int r = 0; r < CSSM_ITEMS; ++r) w1[r] = raw ? v[r] : cssm_exp(v[r] - gmax);
-}
-__device__ __forceinline__ void load_tile_weights(const double* __restrict__ logw, uint64_t base, uint64_t n,
-                                                  double gmax, int raw, double (&w1)[CSSM_ITEMS], const double* tab) {
-  double v[CSSM_ITEMS];
-  load_tile_raw(logw, base, n, raw, v);
-  weights_from_raw(v, gmax, raw, w1, tab);
-}
+// (load_tile_raw / weights_from_raw / load_tile_weights: cssm_device.hip.h)
 
 // w1 = exp(w - max) (model/ParticleFilter.scala:125); S = sum w1, S2 = sum w1^2, fixed point, one pair
 // per UNIT of `sup` consecutive tiles (sup is chosen on the host so that there are ~1K units: the
@@ -174,7 +150,7 @@ __global__ void k_global_sums(const unsigned long long* __restrict__ all4, int r
 // exchange of the sharded filter.  A block walks the tiles of one unit with a running prefix.
 // SELF (single GPU): there is no scan kernel.  Every block sums the <= ~1K unit totals itself (integer
 // sums: every block gets the same bits), block 0 publishes max / totals / ll / ess and clears the
-// other max-slot set for the next weighted step.
+// other max-slot sets for the next weighted steps.
 // RS = CSSM_RESAMPLE_* at compile time: the systematic kernel must not carry the stratified path's Philox code
 // (it cost 40 VGPRs and a wave of occupancy when the kind was a runtime argument).
 #ifndef CSSM_OFF_WAVES
@@ -262,7 +238,8 @@ __device__ __forceinline__ void offspring_body(const double* __restrict__ logw, 
       }
       if (blockIdx.x == 0) {
         if (threadIdx.x == 0) { sc->gmax = gmax_dec; atomicOr(&sc->err, 4u); }
-        if (threadIdx.x < CSSM_MAXSLOTS) sc->maxslot[((size_t)(slot_set ^ 1) * CSSM_MAXSLOTS + threadIdx.x) * CSSM_SLOT_STRIDE] = 0ull;
+        if (threadIdx.x < 2 * CSSM_MAXSLOTS)
+          sc->maxslot[((size_t)((slot_set + 1 + (int)(threadIdx.x / CSSM_MAXSLOTS)) % CSSM_MAXSETS) * CSSM_MAXSLOTS + threadIdx.x % CSSM_MAXSLOTS) * CSSM_SLOT_STRIDE] = 0ull;
       }
     } else if (blockIdx.x == 0 && threadIdx.x == 0) {
       if (flag_out) *flag_out = 1ull;
@@ -299,8 +276,53 @@ __device__ __forceinline__ void offspring_body(const double* __restrict__ logw, 
     }
   }
   // (SELF: the single-GPU launch has exactly one block per unit -- no loop, so that what was prefetched above does not
-  //  have to stay live around a back edge)
+  //  have to stay live around a back edge -- plus ONE more block, the publisher: it totals the sums like every block and
+  //  then publishes the observation's scalars (ll, ess: a logarithm and two divisions in one thread) instead of working on
+  //  a unit.  With block 0 doing both, that serial tail was on the critical path of a launch that at small N has nothing
+  //  but its critical path.)
   uint32_t unit = blockIdx.x;
+  cssm_u128 toff_self = cssm_u128_zero();
+  if (SELF) {                                              // here unitP holds the unit SUMS (k_propagate / k_tile_sums output)
+    const bool pub = (blockIdx.x == nunits);
+    cssm_u128 pre = cssm_u128_zero(), tot = cssm_u128_zero(), tot2 = cssm_u128_zero();
+    const uint32_t nsub = nunits * (uint32_t)split, qlim = unit * (uint32_t)split;
+#pragma unroll
+    for (int k = 0; k < UPRE; ++k) {     // (requested before the max was decoded; upre[k] is zero beyond nsub)
+      const uint32_t q = threadIdx.x + (uint32_t)k * CSSM_BLOCK;
+      if (q < qlim) pre = cssm_u128_add(pre, upre[k]);
+      tot = cssm_u128_add(tot, upre[k]);
+      if (pub && q < nsub) tot2 = cssm_u128_add(tot2, unitS2[q]);   // only the publishing block needs sum w^2
+    }
+    for (uint32_t q = threadIdx.x + UPRE * CSSM_BLOCK; q < nsub; q += CSSM_BLOCK) {
+      const cssm_u128 v = unitP[q];
+      if (q < qlim) pre = cssm_u128_add(pre, v);
+      tot = cssm_u128_add(tot, v);
+      if (pub) tot2 = cssm_u128_add(tot2, unitS2[q]);
+    }
+    pre = wave_sum_u128(pre); tot = wave_sum_u128(tot);
+    if (pub) tot2 = wave_sum_u128(tot2);
+    if (lane == 0) { s_r[0][wid] = pre; s_r[1][wid] = tot; s_r[2][wid] = tot2; }
+    __syncthreads();
+    pre = s_r[0][0]; tot = s_r[1][0]; tot2 = s_r[2][0];
+#pragma unroll
+    for (int w = 1; w < CSSM_BLOCK / 64; ++w) {
+      pre = cssm_u128_add(pre, s_r[0][w]); tot = cssm_u128_add(tot, s_r[1][w]); tot2 = cssm_u128_add(tot2, s_r[2][w]);
+    }
+    toff_self = pre;
+    totd = cssm_u128_to_double(tot);
+    if (pub) {
+      if (threadIdx.x == 0) {                              // publish the step's scalars once
+        sc->gmax = gmax_dec; sc->ref = gmax; sc->S_off = cssm_u128_zero(); sc->S_local = tot; sc->S2_local = tot2;
+        sc->S_tot = tot; sc->S2_tot = tot2;
+        finish_step(sc, n_global);
+        if (ll_t) { ll_t[rec_idx] = sc->ll; ess_t[rec_idx] = sc->ess; }
+      }
+      if (threadIdx.x < 2 * CSSM_MAXSLOTS)   // the two sets this observation did not use
+        sc->maxslot[((size_t)((slot_set + 1 + (int)(threadIdx.x / CSSM_MAXSLOTS)) % CSSM_MAXSETS) * CSSM_MAXSLOTS + threadIdx.x % CSSM_MAXSLOTS) * CSSM_SLOT_STRIDE] = 0ull;
+      return;
+    }
+    __syncthreads();
+  }
   if (unit < nunits) do {
     const uint32_t t0 = unit * sup;
     const uint32_t t1 = (t0 + sup < ntiles) ? t0 + sup : ntiles;
@@ -317,42 +339,8 @@ __device__ __forceinline__ void offspring_body(const double* __restrict__ logw, 
       for (int w = 1; w < CSSM_BLOCK / 64; ++w) pre = cssm_u128_add(pre, s_r[0][w]);
       toff = cssm_u128_add(S_off, pre);
       __syncthreads();
-    } else if (SELF) {                                     // here unitP holds the unit SUMS (k_tile_sums output)
-      cssm_u128 pre = cssm_u128_zero(), tot = cssm_u128_zero(), tot2 = cssm_u128_zero();
-      const uint32_t nsub = nunits * (uint32_t)split, qlim = unit * (uint32_t)split;
-#pragma unroll
-      for (int k = 0; k < UPRE; ++k) {     // (requested before the max was decoded; upre[k] is zero beyond nsub)
-        const uint32_t q = threadIdx.x + (uint32_t)k * CSSM_BLOCK;
-        if (q < qlim) pre = cssm_u128_add(pre, upre[k]);
-        tot = cssm_u128_add(tot, upre[k]);
-        if (unit == 0 && q < nsub) tot2 = cssm_u128_add(tot2, unitS2[q]);   // only the publishing block needs sum w^2
-      }
-      for (uint32_t q = threadIdx.x + UPRE * CSSM_BLOCK; q < nsub; q += CSSM_BLOCK) {
-        const cssm_u128 v = unitP[q];
-        if (q < qlim) pre = cssm_u128_add(pre, v);
-        tot = cssm_u128_add(tot, v);
-        if (unit == 0) tot2 = cssm_u128_add(tot2, unitS2[q]);
-      }
-      pre = wave_sum_u128(pre); tot = wave_sum_u128(tot);
-      if (unit == 0) tot2 = wave_sum_u128(tot2);
-      if (lane == 0) { s_r[0][wid] = pre; s_r[1][wid] = tot; s_r[2][wid] = tot2; }
-      __syncthreads();
-      pre = s_r[0][0]; tot = s_r[1][0]; tot2 = s_r[2][0];
-#pragma unroll
-      for (int w = 1; w < CSSM_BLOCK / 64; ++w) {
-        pre = cssm_u128_add(pre, s_r[0][w]); tot = cssm_u128_add(tot, s_r[1][w]); tot2 = cssm_u128_add(tot2, s_r[2][w]);
-      }
-      toff = pre;
-      totd = cssm_u128_to_double(tot);
-      if (unit == 0 && threadIdx.x == 0) {                 // publish the step's scalars once
-        sc->gmax = gmax_dec; sc->ref = gmax; sc->S_off = cssm_u128_zero(); sc->S_local = tot; sc->S2_local = tot2;
-        sc->S_tot = tot; sc->S2_tot = tot2;
-        finish_step(sc, n_global);
-        if (ll_t) { ll_t[rec_idx] = sc->ll; ess_t[rec_idx] = sc->ess; }
-      }
-      if (unit == 0 && threadIdx.x < CSSM_MAXSLOTS)
-        sc->maxslot[((size_t)(slot_set ^ 1) * CSSM_MAXSLOTS + threadIdx.x) * CSSM_SLOT_STRIDE] = 0ull;
-      __syncthreads();
+    } else if (SELF) {
+      toff = toff_self;
     } else {
       toff = cssm_u128_add(S_off, unitP[(size_t)unit * split]);
     }

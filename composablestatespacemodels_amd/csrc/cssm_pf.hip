@@ -87,9 +87,14 @@ struct cssm_pf {
   uint32_t* endslot = nullptr;
   uint32_t* anc = nullptr;
   bool anc_valid = false;
-  int wparity = 0;             // max-slot set of the next weighted step (single-GPU path)
+  int wparity = 0;             // max-slot set (0 .. CSSM_MAXSETS - 1) of the next weighted step (single-GPU path)
   int opt_exact = 0;           // CSSM_OPT_EXACT_OFFSPRING
   int opt_fused = 0;           // CSSM_OPT_FUSED_SUMS (set to 1 for sharded handles at creation)
+  int opt_step = 0;            // CSSM_OPT_ONE_LAUNCH: 0 = never (default: measured no faster), 1 = whenever eligible, -1 = for clouds up to CSSM_STEP_MAX_N
+  double* logw_alt = nullptr;  // k_step reads the log-weights / unit sums of observation s - 1 and writes those of s: two sets,
+  cssm_u128 *tileS_alt = nullptr, *tileS2_alt = nullptr;   //   logw / tileS / tileS2 always being the set written last
+  int pp = 0;                  // how often the sets were swapped since launch_init, mod 2
+  std::vector<uint8_t> pp_after;   // pp right after the propagate of every observation of the batch run (restored when a series is put on hold)
   int opt_series = 0;          // CSSM_OPT_SERIES_KERNEL: 1 = batch drivers run the persistent series kernel when the handle is eligible (opt-in, see cssm_pf.h)
   // persistent series kernel (cssm_series.hip.h)
   void* d_sync = nullptr;      // SeriesSync
@@ -433,6 +438,9 @@ static int build_fsub(cssm_pf* pf, size_t first, size_t count, bool reset) {
 #ifndef CSSM_PROP_IT_LO
 #define CSSM_PROP_IT_LO 2
 #endif
+#ifndef CSSM_SPLIT_MAX_N
+#define CSSM_SPLIT_MAX_N (1u << 18)
+#endif
 static int prop_items(int d) { return d <= 2 ? CSSM_PROP_IT_LO : (d <= 8 ? CSSM_PROP_IT_MID : 1); }   // PropItems<D>
 
 static int alloc_handle(cssm_pf* pf) {
@@ -446,7 +454,11 @@ static int alloc_handle(cssm_pf* pf) {
   pf->nunits = (pf->ntiles + pf->sup - 1) / pf->sup;
   {   // k_propagate: a block owns unit/split particles, a multiple of its CSSM_BLOCK * IT particles per iteration
     // (the kernel pipelines its tiles through LDS and wants several of them: one block per unit)
-    pf->split = 1u;
+    // Small clouds on one GPU: HALF a tile per block.  Below ~2^18 particles every SIMD holds at most one or two waves and a
+    // kernel's duration is the length of ONE wave's dependent instruction stream (~3 ns per instruction, tools/launch_floor.hip;
+    // the launch itself is 3.1 us): one pair of particles per thread instead of two -- k_propagate 10.8 -> 8.2 us at
+    // N = 100 000, the step 17.7 -> 15.3 us; from 2^19 particles on the machine is full and whole tiles are faster.
+    pf->split = (!pf->sharded && pf->n <= CSSM_SPLIT_MAX_N) ? 2u : 1u;
   }
   const size_t nsums = (size_t)(pf->ntiles > 2 * pf->nunits ? pf->ntiles : 2 * pf->nunits);
   const size_t row = pf->stride * 8;
@@ -514,7 +526,7 @@ extern "C" void cssm_pf_destroy(cssm_pf* pf) {
   if (!pf) return;
   (void)hipSetDevice(pf->device);
   if (pf->stream) (void)hipStreamSynchronize(pf->stream);
-  void* ptrs[] = {pf->state[0], pf->state[1], pf->logw, pf->endslot, pf->anc, pf->tileS, pf->tileS2, pf->tileP, pf->sc,
+  void* ptrs[] = {pf->logw_alt, pf->tileS_alt, pf->tileS2_alt, pf->state[0], pf->state[1], pf->logw, pf->endslot, pf->anc, pf->tileS, pf->tileS2, pf->tileP, pf->sc,
                   pf->d_m0, pf->d_sd0, pf->d_logtab, pf->d_sync, pf->d_ts, pf->d_fsub, pf->cum, pf->d_recs, pf->d_ll_t, pf->d_ess_t, pf->d_path, pf->cand, pf->cand_end, pf->cand_idx, pf->d_bounds, pf->d_xch, pf->d_need};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   if (pf->h_recs) (void)hipHostFree(pf->h_recs);
@@ -633,7 +645,7 @@ static int launch_resample(cssm_pf* pf, const StepRec* d_rec, double* ll_t = nul
   if (pf->resampler == CSSM_RESAMPLE_MULTINOMIAL && !pf->cum) {
     if (hipMalloc(&pf->cum, pf->stride * 8) != hipSuccess) return fail(CSSM_ENOMEM, "hipMalloc cumulative weights");
   }
-  if (redo) pf->wparity ^= 1;
+  if (redo) pf->wparity = (pf->wparity + CSSM_MAXSETS - 1) % CSSM_MAXSETS;
   const bool optimistic = pf->last_optimistic && !redo;
   const int tgrid = (int)pf->nunits;
   const int split = optimistic ? (int)pf->split : 1;
@@ -643,23 +655,79 @@ static int launch_resample(cssm_pf* pf, const StepRec* d_rec, double* ll_t = nul
                        pf->sup, pf->nunits, 0, pf->wparity, (const double*)nullptr, pf->d_logtab, d_rec);
     prof_end(pf);
   }
-  prof_begin(pf, CSSM_K_OFFSPRING);   // unit prefix, ll/ess, end slots and their expansion to ancestors in one kernel
+  prof_begin(pf, CSSM_K_OFFSPRING);   // unit prefix, ll/ess, end slots and their expansion to ancestors in one kernel (one block per unit + the publisher)
 #define OFF_ARGS pf->logw, pf->n, pf->sc, (const cssm_u128*)pf->tileS, (const cssm_u128*)pf->tileS2, d_rec, pf->anc, pf->ntiles, pf->sup, pf->nunits, \
                  pf->wparity, ll_t, ess_t, rec_idx, pf->opt_exact, split, pf->seed, pf->cum, optimistic ? (pf->batch_hold ? 3 : 1) : 0
   if (pf->resampler == CSSM_RESAMPLE_STRATIFIED)
-    hipLaunchKernelGGL((k_offspring_self<CSSM_RESAMPLE_STRATIFIED>), dim3(tgrid), dim3(CSSM_BLOCK), 0, pf->stream, OFF_ARGS);
+    hipLaunchKernelGGL((k_offspring_self<CSSM_RESAMPLE_STRATIFIED>), dim3(tgrid + 1), dim3(CSSM_BLOCK), 0, pf->stream, OFF_ARGS);
   else if (pf->resampler == CSSM_RESAMPLE_MULTINOMIAL)
-    hipLaunchKernelGGL((k_offspring_self<CSSM_RESAMPLE_MULTINOMIAL>), dim3(tgrid), dim3(CSSM_BLOCK), 0, pf->stream, OFF_ARGS);
+    hipLaunchKernelGGL((k_offspring_self<CSSM_RESAMPLE_MULTINOMIAL>), dim3(tgrid + 1), dim3(CSSM_BLOCK), 0, pf->stream, OFF_ARGS);
   else
-    hipLaunchKernelGGL((k_offspring_self<CSSM_RESAMPLE_SYSTEMATIC>), dim3(tgrid), dim3(CSSM_BLOCK), 0, pf->stream, OFF_ARGS);
+    hipLaunchKernelGGL((k_offspring_self<CSSM_RESAMPLE_SYSTEMATIC>), dim3(tgrid + 1), dim3(CSSM_BLOCK), 0, pf->stream, OFF_ARGS);
 #undef OFF_ARGS
   if (pf->resampler == CSSM_RESAMPLE_MULTINOMIAL)
     hipLaunchKernelGGL(k_multinomial, dim3(grid_for(pf->n, 256, kGridCap)), dim3(256), 0, pf->stream, pf->cum, pf->n, pf->seed,
                        pf->h_step_for_resample, pf->anc);
   prof_end(pf);
-  pf->wparity ^= 1;
+  pf->wparity = (pf->wparity + 1) % CSSM_MAXSETS;
   HIP_TRY(hipGetLastError());
   pf->anc_valid = true;
+  return CSSM_OK;
+}
+
+// ---- one launch per observation (k_step, cssm_propagate.hip.h) ---------------------------------------------------------
+#ifndef CSSM_STEP_MAX_N
+#define CSSM_STEP_MAX_N (1u << 18)   /* CSSM_OPT_ONE_LAUNCH = -1: up to here the one-launch path is within 5 % of the two-launch path */
+#endif
+static void swap_sets(cssm_pf* pf) {
+  std::swap(pf->logw, pf->logw_alt); std::swap(pf->tileS, pf->tileS_alt); std::swap(pf->tileS2, pf->tileS2_alt);
+  pf->pp ^= 1;
+}
+// whether the batch drivers may merge the resampling of one observation with the propagate of the next
+static bool step_eligible(const cssm_pf* pf) {
+  if (pf->opt_step == 0 || !uses_sums_kernel(pf) || pf->sharded || pf->resampler != CSSM_RESAMPLE_SYSTEMATIC) return false;
+  if (pf->first != 0 || pf->n != pf->n_global || pf->sup != 1 || pf->split > 2) return false;
+  if ((pf->n + CSSM_TILE / pf->split - 1) / (CSSM_TILE / pf->split) > CSSM_STEP_UNITS) return false;   // the unit sums a block scans
+  return pf->opt_step > 0 || pf->n <= CSSM_STEP_MAX_N;
+}
+static int ensure_step_sets(cssm_pf* pf) {
+  if (pf->logw_alt) return CSSM_OK;
+  const size_t nsums = (size_t)(pf->ntiles > 2 * pf->nunits ? pf->ntiles : 2 * pf->nunits);
+  if (hipMalloc(&pf->logw_alt, pf->stride * 8) != hipSuccess) return fail(CSSM_ENOMEM, "hipMalloc of the second set of log-weights");
+  HIP_TRY(hipMalloc(&pf->tileS_alt, nsums * sizeof(cssm_u128)));
+  HIP_TRY(hipMalloc(&pf->tileS2_alt, nsums * sizeof(cssm_u128)));
+  HIP_TRY(hipMemsetAsync(pf->tileS_alt, 0, nsums * sizeof(cssm_u128), pf->stream));
+  HIP_TRY(hipMemsetAsync(pf->tileS2_alt, 0, nsums * sizeof(cssm_u128), pf->stream));
+  return CSSM_OK;
+}
+// resampling of the observation before d_rec (not launched by its own step: deferred) + propagate and weight of d_rec
+static int launch_merged_step(cssm_pf* pf, const StepRec* d_rec, double* ll_t, int32_t* ess_t, double* pick_out, uint32_t pick_slot) {
+  int rc = ensure_step_sets(pf);
+  if (rc) return rc;
+  StepLaunch a;
+  a.chunk = (uint32_t)CSSM_TILE / pf->split;
+  a.grid = (int)((pf->n + a.chunk - 1) / a.chunk); a.stream = pf->stream;
+  a.obs = (pf->obs_kind == CSSM_OBS_POISSON || pf->obs_kind == CSSM_OBS_GAUSSIAN) ? pf->obs_kind : -1;
+  a.src = pf->src; a.src_stride = pf->src_stride; a.dst = pf->state[pf->cur ^ 1]; a.dst_stride = pf->stride;
+  a.logw_in = pf->logw; a.logw_out = pf->logw_alt; a.n = (uint32_t)pf->n; a.seed = pf->seed; a.rec = d_rec; a.mk = pf->mk; a.sc = pf->sc;
+  a.set_in = pf->wparity; a.logtab = pf->d_logtab;
+  a.inS = pf->tileS; a.inS2 = pf->tileS2; a.outS = pf->tileS_alt; a.outS2 = pf->tileS2_alt; a.nunits = (uint32_t)a.grid;
+  a.ll_t = ll_t; a.ess_t = ess_t; a.force_exact = pf->opt_exact; a.pick_out = pick_out; a.pick_slot = pick_slot;
+  prof_begin(pf, CSSM_K_STEP);
+  switch (pf->d) {
+#define CSSM_CASE_STEP(D) case D: cssm_step_launch_d##D(a); break;
+    CSSM_CASE_STEP(1) CSSM_CASE_STEP(2) CSSM_CASE_STEP(3) CSSM_CASE_STEP(4) CSSM_CASE_STEP(5) CSSM_CASE_STEP(6) CSSM_CASE_STEP(7) CSSM_CASE_STEP(8)
+    CSSM_CASE_STEP(9) CSSM_CASE_STEP(10) CSSM_CASE_STEP(11) CSSM_CASE_STEP(12) CSSM_CASE_STEP(13) CSSM_CASE_STEP(14) CSSM_CASE_STEP(15)
+    default: cssm_step_launch_d16(a); break;
+#undef CSSM_CASE_STEP
+  }
+  prof_end(pf);
+  HIP_TRY(hipGetLastError());
+  swap_sets(pf);
+  pf->wparity = (pf->wparity + 1) % CSSM_MAXSETS;
+  pf->cur ^= 1;
+  pf->src = pf->state[pf->cur]; pf->src_stride = pf->stride; pf->anc_valid = false; pf->src2 = nullptr;
+  pf->last_optimistic = true;
   return CSSM_OK;
 }
 
@@ -986,11 +1054,25 @@ static int run_filter_once(cssm_pf* pf, const double* t, const double* y, const 
   size_t s_from = 0;
   while (!pf->last_series) {
     pf->batch_hold = uses_sums_kernel(pf);
+    // (small clouds) the resampling of a weighted observation that another weighted observation follows is not launched:
+    // the next observation's k_step does it on the way -- one launch per observation instead of two
+    const bool merge = step_eligible(pf) && (!path || fold);
+    bool deferred = false;
+    if (pf->pp_after.size() < T) pf->pp_after.resize(T);
     for (size_t s = s_from; s < T; ++s) {
       const int weighted = pf->h_recs[s].has_obs;
       double* pick_out = (fold && s >= 1) ? pf->d_path + s * (size_t)d : nullptr;
-      rc = launch_step(pf, pf->d_recs + s, weighted, (uint32_t)s, pf->d_ll_t, pf->d_ess_t, (uint32_t)s, pick_out,
-                       s >= 1 ? pf->h_recs[s - 1].pick : 0u);
+      const uint32_t pick_slot = s >= 1 ? pf->h_recs[s - 1].pick : 0u;
+      const bool defer_next = merge && weighted && s + 1 < T && pf->h_recs[s + 1].has_obs;
+      pf->h_step_for_resample = (uint32_t)s;
+      if (deferred) rc = launch_merged_step(pf, pf->d_recs + s, pf->d_ll_t, pf->d_ess_t, pick_out, pick_slot);
+      else rc = launch_propagate(pf, pf->d_recs + s, pick_out, pick_slot);
+      pf->pp_after[s] = (uint8_t)pf->pp;
+      if (!rc && !defer_next) {
+        if (weighted) rc = launch_resample(pf, pf->d_recs + s, pf->d_ll_t, pf->d_ess_t, (uint32_t)s);
+        else hipLaunchKernelGGL(k_record, dim3(1), dim3(1), 0, pf->stream, pf->sc, pf->d_ll_t, pf->d_ess_t, (uint32_t)s);
+      }
+      deferred = defer_next;
       if (rc) { pf->batch_hold = false; return rc; }
       if (path && (!fold || s + 1 == T))   // (folded: only the last entry has no following propagate)
         hipLaunchKernelGGL(k_pick, dim3(1), dim3(64), 0, pf->stream, pf->src, pf->src_stride,
@@ -1011,12 +1093,13 @@ static int run_filter_once(cssm_pf* pf, const double* t, const double* y, const 
     HIP_TRY(hipMemcpyAsync(&pf->sc->err, &hh.err, sizeof(uint32_t), hipMemcpyHostToDevice, pf->stream));
     HIP_TRY(hipMemcpyAsync(&pf->sc->fail_step, &hh.fail_step, sizeof(uint32_t), hipMemcpyHostToDevice, pf->stream));
     // host-side state right after the propagate of observation sf (launch_init: cur = 0, wparity = 0; every propagate
-    // flips cur, every weighted observation flips wparity)
+    // flips cur, every weighted observation advances wparity)
     pf->cur = (int)((sf + 1) & 1);
     pf->src = pf->state[pf->cur]; pf->src_stride = pf->stride; pf->anc_valid = false; pf->src2 = nullptr;
     int wp = 0;
-    for (size_t q = 0; q < sf; ++q) wp ^= (pf->h_recs[q].has_obs ? 1 : 0);
-    pf->wparity = wp ^ 1;              // launch_resample(redo) flips it back to the set the step's k_propagate used
+    for (size_t q = 0; q < sf; ++q) wp = (wp + (pf->h_recs[q].has_obs ? 1 : 0)) % CSSM_MAXSETS;
+    pf->wparity = (wp + 1) % CSSM_MAXSETS;   // launch_resample(redo) steps it back to the set the observation's propagate used
+    if (sf < pf->pp_after.size() && pf->pp != (int)pf->pp_after[sf]) swap_sets(pf);   // ... and the log-weights / unit sums it wrote
     pf->last_optimistic = true;
     pf->h_step_for_resample = (uint32_t)sf;
     rc = launch_resample(pf, pf->d_recs + sf, pf->d_ll_t, pf->d_ess_t, (uint32_t)sf, /*redo=*/true);
@@ -1167,6 +1250,7 @@ extern "C" int cssm_pf_set_option(cssm_pf* pf, int option, int value) {
   if (option == CSSM_OPT_EXACT_OFFSPRING) { pf->opt_exact = value ? 1 : 0; return CSSM_OK; }
   if (option == CSSM_OPT_FUSED_SUMS) { pf->opt_fused = value ? 1 : 0; return CSSM_OK; }
   if (option == CSSM_OPT_SERIES_KERNEL) { pf->opt_series = value ? 1 : 0; return CSSM_OK; }
+  if (option == CSSM_OPT_ONE_LAUNCH) { pf->opt_step = value < 0 ? -1 : (value ? 1 : 0); return CSSM_OK; }
   if (option == CSSM_OPT_RESAMPLER) {
     if (value < CSSM_RESAMPLE_SYSTEMATIC || value > CSSM_RESAMPLE_MULTINOMIAL) return fail(CSSM_EINVAL_ARG, "unknown resampler %d", value);
     if (pf->sharded && value != CSSM_RESAMPLE_SYSTEMATIC) return fail(CSSM_ESTATE, "sharded handles resample systematically");

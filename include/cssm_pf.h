@@ -222,6 +222,14 @@ int cssm_pf_last_loop_ms(cssm_pf* pf, float* ms_out);
  * waves' fixed ages also skew the propagate phase (13 us for a CU's oldest block, 28 us for its youngest).  A cooperative
  * launch also has the GPU to itself: two chains on two streams no longer overlap. */
 #define CSSM_OPT_SERIES_KERNEL 4
+/* CSSM_OPT_ONE_LAUNCH (default 0; opt-in like the series kernel): 1 = the batch drivers merge the resampling of a weighted
+ * observation with the propagate of the weighted observation that follows it into ONE kernel launch (k_step: a block finds
+ * the parents of its own resampling slots from the unit sums, rebuilds their end slots and keeps the ancestor indices in
+ * LDS) wherever the handle is eligible: one GPU, systematic resampling, fused sums, not LGCP, at most 1024 units of sums
+ * (N <= 2^20; 2^19 for the half-tile units of small clouds); -1 = only for clouds of up to 2^18 particles.  Results are
+ * bit-identical either way.  Measured: NOT faster than two launches (14.9 vs 14.4 us per observation at N = 100 000, 34.0
+ * vs 32.5 at 2^20) -- a launch costs 3.1 us, the parents' end slots a block has to rebuild cost as much; see DESIGN.md 5c. */
+#define CSSM_OPT_ONE_LAUNCH 5
 int cssm_pf_set_option(cssm_pf* pf, int option, int value);
 
 /* Per-kernel device time, measured with HIP events recorded on the handle's stream directly
@@ -234,7 +242,8 @@ int cssm_pf_set_option(cssm_pf* pf, int option, int value);
 #define CSSM_K_TILE_SUMS 1   /* exp(w - level), fixed-point unit sums */
 #define CSSM_K_OFFSPRING 2   /* unit prefix, ll / ess, cumulative weights -> end slots -> ancestor indices */
 #define CSSM_K_SERIES 3      /* the persistent series kernel: ONE launch for all T observations of a batch run */
-#define CSSM_PROFILE_NKERNELS 4
+#define CSSM_K_STEP 4        /* k_step: resampling of the previous observation + propagate and weight of this one (CSSM_OPT_ONE_LAUNCH) */
+#define CSSM_PROFILE_NKERNELS 5
 int cssm_pf_profile(cssm_pf* pf, int enable);
 int cssm_pf_profile_read(cssm_pf* pf, double* total_ms, uint64_t* launches);
 /* Whether the last batch run used the persistent series kernel and, if profiling was on, how its weighted observations
