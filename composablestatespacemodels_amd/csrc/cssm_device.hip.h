@@ -244,6 +244,16 @@ __device__ __forceinline__ void propagate_pair(const ModelK& mk, const StepRec* 
     else transition_one<D>(mk, rec, dt, 2 * p + 1 - D, xb[(2 * p + 1 - D + D) % D], e1);
   }
 }
+// The pair's normals on their own (k_propagate's single-tile instantiations draw them while the gathered rows travel):
+// half H = 0 / 1 of the pair's D Philox blocks, z[2 p] / z[2 p + 1] = the elements of block p -- normal q of the pair goes
+// to particle q / D, component q % D, exactly as in propagate_pair.
+template <int D, int H>
+__device__ __forceinline__ void normals_pair_half(uint64_t seed, uint64_t gid_even, uint32_t step, const double* tab, double* z) {
+  const uint64_t stream = cssm_pair_stream(gid_even);
+  constexpr int P0 = H == 0 ? 0 : D / 2, P1 = H == 0 ? D / 2 : D;   // (the gathered rows take longer than the indices: the larger half)
+#pragma unroll
+  for (int p = P0; p < P1; ++p) cssm_normal_pair(cssm_philox_draw(seed, stream, step, CSSM_STREAM_STEP, (uint32_t)p), tab, &z[2 * p], &z[2 * p + 1]);
+}
 // The same for ONE particle of either parity (threads that do not own whole pairs): ceil(D/2) blocks.
 template <int D>
 __device__ __forceinline__ void propagate_one(const ModelK& mk, const StepRec* __restrict__ rec, double dt, uint64_t seed,

@@ -13,6 +13,20 @@
 #define CSSM_CAT2(a, b) a##b
 #define CSSM_CAT(a, b) CSSM_CAT2(a, b)
 
+// k_propagate_self<D, 2, OBS, true, ONE = true> exists for the two-particles-per-thread dimensions only
+template <int D, int IT> struct OneTile { static void go(const PropLaunch&) {} };
+template <int D> struct OneTile<D, 2> {
+  static void go(const PropLaunch& a) {
+#define PROP_ONE(OB)                                                                                                              \
+  k_propagate_self<D, 2, OB, true, true><<<dim3(a.grid), dim3(CSSM_BLOCK), 0, a.stream>>>(a.src, a.src_stride, a.anc, a.dst, a.dst_stride, \
+      a.logw, a.n, a.seed, a.rec, a.mk, a.sc, a.slot_set, a.logtab, a.chunk, a.subS, a.subS2, a.pick_out, a.pick_slot)
+    if (a.obs == CSSM_OBS_POISSON) PROP_ONE(CSSM_OBS_POISSON);
+    else if (a.obs == CSSM_OBS_GAUSSIAN) PROP_ONE(CSSM_OBS_GAUSSIAN);
+    else PROP_ONE(-1);
+#undef PROP_ONE
+  }
+};
+
 void CSSM_CAT(cssm_prop_launch_d, CSSM_PROP_D)(const PropLaunch& a) {
   constexpr int D = CSSM_PROP_D;
   constexpr int IT = PropItems<D>::value;
@@ -25,7 +39,10 @@ void CSSM_CAT(cssm_prop_launch_d, CSSM_PROP_D)(const PropLaunch& a) {
 #define PROP_SELF(OB, SM)                                                                                                   \
   k_propagate_self<D, IT, OB, SM><<<dim3(a.grid), dim3(CSSM_BLOCK), 0, a.stream>>>(a.src, a.src_stride, a.anc, a.dst, a.dst_stride, \
       a.logw, a.n, a.seed, a.rec, a.mk, a.sc, a.slot_set, a.logtab, a.chunk, a.subS, a.subS2, a.pick_out, a.pick_slot)
-  if (self && CSSM_PROP_SELF) {
+  // small clouds: half a tile per block = one tile of the two-particles-per-thread kernels (d <= 8): the ONE instantiation
+  if (self && CSSM_PROP_SELF && a.sums && IT == 2 && a.chunk == (uint64_t)CSSM_BLOCK * IT) {
+    OneTile<D, IT>::go(a);
+  } else if (self && CSSM_PROP_SELF) {
     if (a.obs == CSSM_OBS_POISSON) { if (a.sums) PROP_SELF(CSSM_OBS_POISSON, true); else PROP_SELF(CSSM_OBS_POISSON, false); }
     else if (a.obs == CSSM_OBS_GAUSSIAN) { if (a.sums) PROP_SELF(CSSM_OBS_GAUSSIAN, true); else PROP_SELF(CSSM_OBS_GAUSSIAN, false); }
     else { if (a.sums) PROP_SELF(-1, true); else PROP_SELF(-1, false); }

@@ -54,7 +54,10 @@ struct PropAcc {
 // lw_lds != nullptr: the log-weights of the range also go to LDS (lw_lds[i - range_lo]) for the offspring phase.
 // `tab`: the contract's log table, staged in LDS by the caller (stage_log_table).
 // LANC (k_step): `anc` points into LDS and holds the ancestors of the block's own range, anc[i - range_lo].
-template <int D, bool LGCP, int IT, int OBS, bool SUMS, bool COH, bool LANC = false>
+// ONE (small clouds): the range is a single tile, and the tile's normal variates -- which depend on nothing but (seed, particle,
+// observation) -- are drawn WHILE the ancestor indices and the gathered rows are on their way: with one wave per SIMD nobody
+// else hides those two round trips (~1.7 us of a kernel whose whole body takes ~5).  Same arithmetic, another order.
+template <int D, bool LGCP, int IT, int OBS, bool SUMS, bool COH, bool LANC = false, bool ONE = false>
 __device__ __forceinline__ void propagate_range(
     const double* __restrict__ src, size_t src_stride, const uint32_t* __restrict__ anc,
     double* __restrict__ dst, size_t dst_stride, double* __restrict__ logw, uint64_t gid0,
@@ -209,16 +212,31 @@ __device__ __forceinline__ void propagate_range(
   unsigned long long jp[NJ];
   uint32_t jn[IT];
   double x[IT][D];
+  static_assert(!ONE || (IT == 2 && !LGCP && !COH), "ONE: one pair per thread, ordinary step");
+  double zz[ONE ? 2 * D : 1];                                     // ONE: the pair's 2 D normals (normal q -> particle q / D, component q % D)
   if (base < n) {
     load_idx(base, jp);
+    if (ONE) {                                                    // (while the indices travel)
+      normals_pair_half<D, 0>(seed, gid0 + base + threadIdx.x * IT, step, tab, zz);
+      // the indices are consumed BEHIND these normals: an empty asm that takes both pins the order (the compiler otherwise
+      // hoists the address arithmetic, and with it the wait for the load, above the Philox rounds)
+#pragma unroll
+      for (int q = 0; q < 2 * (D / 2); ++q) asm volatile("" : "+v"(zz[q % (ONE ? 2 * D : 1)]), "+v"(jp[0]));
+      if (D / 2 == 0) asm volatile("" : "+v"(jp[0]));
+    }
     unpack_idx(base, jp, jn);
     if (STAGE) {
       stage_issue(jn);                                            // tile 0 (needs its indices: the one exposed latency)
-      if (base + stride < n) load_idx(base + stride, jp);         // indices of tile 1
+      if (!ONE && base + stride < n) load_idx(base + stride, jp);         // indices of tile 1
+      if (ONE) {                                                  // (while the rows travel)
+        normals_pair_half<D, 1>(seed, gid0 + base + threadIdx.x * IT, step, tab, zz);
+#pragma unroll
+        for (int q = 2 * (D / 2); q < 2 * D; ++q) asm volatile("" : "+v"(zz[q % (ONE ? 2 * D : 1)]));
+      }
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       stage_read(x);
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // the region is free again
-      if (base + stride < n) {
+      if (!ONE && base + stride < n) {
         unpack_idx(base + stride, jp, jn);
         stage_issue(jn);                                          // tile 1 lands while tile 0 is computed
         if (base + 2 * stride < n) load_idx(base + 2 * stride, jp);
@@ -286,6 +304,14 @@ __device__ __forceinline__ void propagate_range(
         }
         account(r);
       }
+    } else if (ONE) {
+      // (gid0 is even for every caller of this instantiation: whole pairs)
+#pragma unroll
+      for (int q = 0; q < 2 * D; ++q) transition_one<D>(mk, rec, dt, q % D, x[(q / D) % IT][q % D], zz[q % (ONE ? 2 * D : 1)]);
+      lw[0] = has_obs ? logdens<OBS>(mk, rec, gamma_of<D>(mk, rec, x[0]), tab) : 0.0;
+      account(0);
+      lw[1 % IT] = has_obs ? logdens<OBS>(mk, rec, gamma_of<D>(mk, rec, x[1 % IT]), tab) : 0.0;
+      account(1 % IT);
     } else if (IT % 2 == 0 && pair_ok) {
       // the thread's particles are whole pairs (2m, 2m+1): D Philox blocks + Box-Muller pairs per two particles
 #pragma unroll
@@ -348,6 +374,7 @@ __device__ __forceinline__ void propagate_range(
       for (int r = 0; r < IT; ++r)
         if (i0 + r < n) lw_lds[i0 + r - range_lo] = lw[r];
     }
+    if (ONE) break;                                               // (the range is this one tile)
     // advance the pipeline
     if (STAGE) {
       if (base + stride < n) {
@@ -435,8 +462,9 @@ __global__ __launch_bounds__(CSSM_BLOCK, (PropWaves<D, SUMS>::value)) void k_pro
 // it knows at compile time -- the first particle's global id is 0 (every thread owns whole pairs: the unpaired variant of
 // the transition code is not even compiled), no second gather source, no sub-step table, no pick.  The generic kernel's
 // ~24 arguments overflow the scalar registers into vector-register lanes (88 v_readlane per tile).
-template <int D, int IT, int OBS, bool SUMS>
-__global__ __launch_bounds__(CSSM_BLOCK, (PropWaves<D, SUMS>::value)) void k_propagate_self(
+// ONE: the block's range is one tile (small clouds, half a tile per block): see propagate_range
+template <int D, int IT, int OBS, bool SUMS, bool ONE = false>
+__global__ __launch_bounds__(CSSM_BLOCK, (ONE ? 2 : PropWaves<D, SUMS>::value)) void k_propagate_self(
     const double* __restrict__ src, size_t src_stride, const uint32_t* __restrict__ anc, double* __restrict__ dst, size_t dst_stride,
     double* __restrict__ logw, uint64_t n_arg, uint64_t seed, const StepRec* __restrict__ rec, ModelK mk, Scalars* __restrict__ sc,
     int slot_set, const double* __restrict__ logtab, uint64_t chunk,
@@ -452,8 +480,8 @@ __global__ __launch_bounds__(CSSM_BLOCK, (PropWaves<D, SUMS>::value)) void k_pro
   if (held & (4u | 8u | 64u)) return;
   __shared__ __attribute__((aligned(16))) unsigned char s_stage[PropStage<D, IT>::bytes];
   PropAcc acc;
-  propagate_range<D, false, IT, OBS, SUMS, false>(src, src_stride, anc, dst, dst_stride, logw, 0ull, seed, rec, mk, nullptr, 0, 0u, tab,
-                                                  range_lo, n, SUMS ? 1 : 0, SUMS ? pick_out : nullptr, pick_slot, nullptr, s_stage, acc);
+  propagate_range<D, false, IT, OBS, SUMS, false, false, ONE>(src, src_stride, anc, dst, dst_stride, logw, 0ull, seed, rec, mk, nullptr, 0, 0u, tab,
+                                                              range_lo, n, SUMS ? 1 : 0, SUMS ? pick_out : nullptr, pick_slot, nullptr, s_stage, acc);
   if (!rec->has_obs) return;
   double tmax = wave_max(acc.tmax);
   if ((threadIdx.x & 63) == 0) s_max[threadIdx.x >> 6] = tmax;
