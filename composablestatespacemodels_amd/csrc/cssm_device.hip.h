@@ -174,6 +174,14 @@ __device__ __forceinline__ const double* stage_log_table(const double* __restric
   __syncthreads();
   return s_logtab;
 }
+// The same in two halves for blocks of exactly 256 threads (the small-cloud kernels): the load is issued by the caller, next to
+// its other first loads (`v` = tab_global[threadIdx.x]), and lands in LDS here.
+__device__ __forceinline__ const double* stage_log_table_finish(double v) {
+  __shared__ double s_logtab2[256];
+  s_logtab2[threadIdx.x] = v;
+  __syncthreads();
+  return s_logtab2;
+}
 
 // The d standard normals of global particle gid for an ordinary step or the initial draw (include/cssm_numerics.h,
 // counter layout): particles 2m and 2m+1 share stream m, particle gid owns its normals q = (gid & 1) * D + k, normal q

@@ -65,7 +65,10 @@ __device__ __forceinline__ void propagate_range(
     const double* __restrict__ src2, size_t src2_stride, uint32_t n_split, const double* tab,
     const uint32_t range_lo, const uint32_t n, int do_sums_arg,
     double* __restrict__ pick_out, uint32_t pick_slot, double* lw_lds, unsigned char* s_stage, PropAcc& acc,
-    const uint32_t idx_max = 0xffffffffu, uint32_t* __restrict__ err_word = nullptr, const double* __restrict__ fsub = nullptr) {
+    const uint32_t idx_max = 0xffffffffu, uint32_t* __restrict__ err_word = nullptr, const double* __restrict__ fsub = nullptr,
+    const unsigned long long* pre_jp = nullptr) {
+  // pre_jp (ONE): the tile's packed ancestor indices, already requested by the caller (before it staged the log table: one
+  // dependent round trip less)
   // fsub (LGCP with a time-dependent f, e.g. a seasonal leaf): the handle's table of f coefficients at the sub-step times
   // tau_s = t + s delta (FilterLgcp.calcWeight evaluates mod.f(a.state, a.time) at every simulated time,
   // model/ParticleFilter.scala:193-205; model/Sde.scala:57-66); this observation's rows start at rec->fsub_off
@@ -215,8 +218,8 @@ __device__ __forceinline__ void propagate_range(
   static_assert(!ONE || (IT == 2 && !LGCP && !COH), "ONE: one pair per thread, ordinary step");
   double zz[ONE ? 2 * D : 1];                                     // ONE: the pair's 2 D normals (normal q -> particle q / D, component q % D)
   if (base < n) {
-    load_idx(base, jp);
-    if (ONE) {                                                    // (while the indices travel)
+    if (ONE && pre_jp != nullptr) jp[0] = *pre_jp; else load_idx(base, jp);
+    if (ONE && pre_jp == nullptr) {                               // (while the indices travel)
       normals_pair_half<D, 0>(seed, gid0 + base + threadIdx.x * IT, step, tab, zz);
       // the indices are consumed BEHIND these normals: an empty asm that takes both pins the order (the compiler otherwise
       // hoists the address arithmetic, and with it the wait for the load, above the Philox rounds)
@@ -229,9 +232,10 @@ __device__ __forceinline__ void propagate_range(
       stage_issue(jn);                                            // tile 0 (needs its indices: the one exposed latency)
       if (!ONE && base + stride < n) load_idx(base + stride, jp);         // indices of tile 1
       if (ONE) {                                                  // (while the rows travel)
+        if (pre_jp != nullptr) normals_pair_half<D, 0>(seed, gid0 + base + threadIdx.x * IT, step, tab, zz);
         normals_pair_half<D, 1>(seed, gid0 + base + threadIdx.x * IT, step, tab, zz);
 #pragma unroll
-        for (int q = 2 * (D / 2); q < 2 * D; ++q) asm volatile("" : "+v"(zz[q % (ONE ? 2 * D : 1)]));
+        for (int q = (pre_jp != nullptr) ? 0 : 2 * (D / 2); q < 2 * D; ++q) asm volatile("" : "+v"(zz[q % (ONE ? 2 * D : 1)]));
       }
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       stage_read(x);
@@ -476,12 +480,37 @@ __global__ __launch_bounds__(CSSM_BLOCK, (ONE ? 2 : PropWaves<D, SUMS>::value)) 
   const uint32_t range_lo = blockIdx.x * (uint32_t)chunk;
   uint32_t n;
   { const uint64_t range_hi = (uint64_t)range_lo + chunk; n = (uint32_t)((range_hi < n_arg) ? range_hi : n_arg); }
-  const double* tab = stage_log_table(logtab);
+  // ONE: the tile's ancestor indices are requested together with the log table -- they depend on nothing but the thread's
+  // position (anc holds a whole number of tiles: a partial thread's pair stays inside it)
+  unsigned long long jp_early = 0ull;
+  if (ONE) {
+    const uint32_t i0 = range_lo + threadIdx.x * IT;
+    jp_early = anc ? *reinterpret_cast<const unsigned long long*>(anc + i0) : ((unsigned long long)i0 | ((unsigned long long)(i0 + 1u) << 32));
+  }
+  // ... and so are the thread's entry of the log table and the lines of the observation's record the kernel will read: behind
+  // the table's barrier the record's lines are hits in the scalar cache instead of a first touch on the critical path.  (The
+  // comparison cannot be true and cannot be folded: it keeps the loads alive and in place without an asm statement, which
+  // would cost the record its scalar loads altogether.)
+  const double* tab;
+  if (ONE) {
+    static_assert(CSSM_BLOCK == 256, "one table entry per thread");
+    const double tv = logtab[threadIdx.x];
+    const uint32_t* w = reinterpret_cast<const uint32_t*>(rec);
+    uint32_t probe = w[0];
+#pragma unroll
+    for (int o = 16; o < (int)(sizeof(StepRec) / 4); o += 16)
+      if (o * 4 < 88 + D * 32 + 64 || (o * 4 + 64 > 88 + CSSM_MAX_DIM * 32 && o * 4 < 88 + CSSM_MAX_DIM * 32 + D * 8 + 64)) probe |= w[o];
+    if ((probe == 0x9e3779b9u) & (blockIdx.x > 0x7ffffff0u)) atomicOr(&sc->err, 128u);
+    tab = stage_log_table_finish(tv);
+  } else {
+    tab = stage_log_table(logtab);
+  }
   if (held & (4u | 8u | 64u)) return;
   __shared__ __attribute__((aligned(16))) unsigned char s_stage[PropStage<D, IT>::bytes];
   PropAcc acc;
   propagate_range<D, false, IT, OBS, SUMS, false, false, ONE>(src, src_stride, anc, dst, dst_stride, logw, 0ull, seed, rec, mk, nullptr, 0, 0u, tab,
-                                                              range_lo, n, SUMS ? 1 : 0, SUMS ? pick_out : nullptr, pick_slot, nullptr, s_stage, acc);
+                                                              range_lo, n, SUMS ? 1 : 0, SUMS ? pick_out : nullptr, pick_slot, nullptr, s_stage, acc,
+                                                              0xffffffffu, nullptr, nullptr, ONE ? &jp_early : nullptr);
   if (!rec->has_obs) return;
   double tmax = wave_max(acc.tmax);
   if ((threadIdx.x & 63) == 0) s_max[threadIdx.x >> 6] = tmax;
