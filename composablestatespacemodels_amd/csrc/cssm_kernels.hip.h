@@ -196,6 +196,10 @@ __device__ __forceinline__ void offspring_body(const double* __restrict__ logw, 
   // (batch series, single GPU) an earlier observation's reference level was ruled out by its max: the series is on hold at
   // that observation until the host has redone its sums (run_filter_once); nothing may change meanwhile
   // (the test sits behind the prefetches below: a dependent round trip at the very top of the kernel otherwise)
+#ifdef CSSM_OFF_STAMPS
+  const unsigned long long os0 = wall_clock64();
+  unsigned long long os1 = 0, os2 = 0, os3 = 0, os4 = 0;
+#endif
   const uint32_t held = SELF ? sc->err : 0u;
   double pre_v[CSSM_ITEMS];   // the block's first tile is requested before the serial prologue
   if (blockIdx.x < nunits) load_tile_raw(logw, (uint64_t)blockIdx.x * sup * CSSM_TILE, n, raw, pre_v);
@@ -213,6 +217,9 @@ __device__ __forceinline__ void offspring_body(const double* __restrict__ logw, 
   double gmax_dec;
   if (SELF) {
     gmax_dec = block_decode_slots(sc, slot_set);
+#ifdef CSSM_OFF_STAMPS
+    os1 = wall_clock64();
+#endif
     if (held & 64u) return;
   } else if (all5) {
     unsigned long long key = 0ull;
@@ -315,7 +322,9 @@ __device__ __forceinline__ void offspring_body(const double* __restrict__ logw, 
         sc->gmax = gmax_dec; sc->ref = gmax; sc->S_off = cssm_u128_zero(); sc->S_local = tot; sc->S2_local = tot2;
         sc->S_tot = tot; sc->S2_tot = tot2;
         finish_step(sc, n_global);
+#ifndef CSSM_OFF_STAMPS
         if (ll_t) { ll_t[rec_idx] = sc->ll; ess_t[rec_idx] = sc->ess; }
+#endif
       }
       if (threadIdx.x < 2 * CSSM_MAXSLOTS)   // the two sets this observation did not use
         sc->maxslot[((size_t)((slot_set + 1 + (int)(threadIdx.x / CSSM_MAXSLOTS)) % CSSM_MAXSETS) * CSSM_MAXSLOTS + threadIdx.x % CSSM_MAXSLOTS) * CSSM_SLOT_STRIDE] = 0ull;
@@ -323,6 +332,9 @@ __device__ __forceinline__ void offspring_body(const double* __restrict__ logw, 
     }
     __syncthreads();
   }
+#ifdef CSSM_OFF_STAMPS
+  os2 = wall_clock64();
+#endif
   if (unit < nunits) do {
     const uint32_t t0 = unit * sup;
     const uint32_t t1 = (t0 + sup < ntiles) ? t0 + sup : ntiles;
@@ -396,6 +408,9 @@ __device__ __forceinline__ void offspring_body(const double* __restrict__ logw, 
           }
         }
       }
+#ifdef CSSM_OFF_STAMPS
+      os3 = wall_clock64();
+#endif
       const uint64_t i0 = base + (uint64_t)threadIdx.x * CSSM_ITEMS;
       constexpr bool CLIP = !SELF;
       if (!FUSE || (CLIP && all5 != nullptr)) {   // the exchange of the sharded filter needs the end slots themselves
@@ -471,6 +486,13 @@ __device__ __forceinline__ void offspring_body(const double* __restrict__ logw, 
       __syncthreads();
     }
   } while (!SELF && (unit += gridDim.x) < nunits);
+#ifdef CSSM_OFF_STAMPS
+  if (SELF && blockIdx.x == 0 && threadIdx.x == 0 && ll_t) {
+    os4 = wall_clock64();
+    auto c3 = [](unsigned long long a) { return (double)(a > 999ull ? 999ull : a); };
+    ll_t[rec_idx] = c3(os1 - os0) + 1e3 * c3(os2 - os1) + 1e6 * c3(os3 - os2) + 1e9 * c3(os4 - os3);
+  }
+#endif
 }
 
 #define CSSM_OFFSPRING_PARAMS                                                                                              \
