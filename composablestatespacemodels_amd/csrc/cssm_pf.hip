@@ -439,7 +439,7 @@ static int build_fsub(cssm_pf* pf, size_t first, size_t count, bool reset) {
 #define CSSM_PROP_IT_LO 2
 #endif
 #ifndef CSSM_SPLIT_MAX_N
-#define CSSM_SPLIT_MAX_N (1u << 18)
+#define CSSM_SPLIT_MAX_N ((1u << 20) - 1u)
 #endif
 static int prop_items(int d) { return d <= 2 ? CSSM_PROP_IT_LO : (d <= 8 ? CSSM_PROP_IT_MID : 1); }   // PropItems<D>
 
@@ -454,13 +454,16 @@ static int alloc_handle(cssm_pf* pf) {
   pf->nunits = (pf->ntiles + pf->sup - 1) / pf->sup;
   {   // k_propagate: a block owns unit/split particles, a multiple of its CSSM_BLOCK * IT particles per iteration
     // (the kernel pipelines its tiles through LDS and wants several of them: one block per unit)
-    // Small clouds on one GPU: HALF a tile per block.  Below ~2^18 particles every SIMD holds at most one or two waves and a
-    // kernel's duration is the length of ONE wave's dependent instruction stream (~3 ns per instruction, tools/launch_floor.hip;
-    // the launch itself is 3.1 us): one pair of particles per thread instead of two -- k_propagate 10.8 -> 8.2 us at
-    // N = 100 000, the step 17.7 -> 15.3 us; from 2^19 particles on the machine is full and whole tiles are faster.
-    pf->split = (!pf->sharded && pf->n <= CSSM_SPLIT_MAX_N) ? 2u : 1u;
+    // Clouds below 2^20 particles on one GPU: HALF a tile per block.  Up to ~2^18 particles every SIMD holds at most one or
+    // two waves and a kernel's duration is the length of ONE wave's dependent instruction stream (~3 ns per instruction,
+    // tools/launch_floor.hip; the launch itself is 3.1 us): one pair of particles per thread instead of two, in the single-tile
+    // instantiation k_propagate_self<..., ONE> (d <= 8) that draws its normals while the gathered rows travel.  Per observation,
+    // bench model: 17.7 -> 12.8 us at N = 100 000, 21.2 -> 18.9 at 2^19, 27.1 -> 24.8 at 3 * 2^18; a tie at 2^20 (32.1 vs 32.3),
+    // from where on whole tiles and the software-pipelined kernel run.
+    // (d >= 9: one particle per thread, so one tile of the kernel is a QUARTER of 1024)
+    pf->split = (!pf->sharded && pf->n <= CSSM_SPLIT_MAX_N) ? (prop_items(pf->d) == 1 ? 4u : 2u) : 1u;
   }
-  const size_t nsums = (size_t)(pf->ntiles > 2 * pf->nunits ? pf->ntiles : 2 * pf->nunits);
+  const size_t nsums = (size_t)(pf->ntiles > 4 * pf->nunits ? pf->ntiles : 4 * pf->nunits);   // (up to four sub-units per unit)
   const size_t row = pf->stride * 8;
   for (int b = 0; b < 2; ++b) {
     if (hipMalloc(&pf->state[b], row * pf->d + 64) != hipSuccess)   // + spare bytes: k_propagate fetches 16 bytes per element
@@ -686,13 +689,14 @@ static void swap_sets(cssm_pf* pf) {
 // whether the batch drivers may merge the resampling of one observation with the propagate of the next
 static bool step_eligible(const cssm_pf* pf) {
   if (pf->opt_step == 0 || !uses_sums_kernel(pf) || pf->sharded || pf->resampler != CSSM_RESAMPLE_SYSTEMATIC) return false;
-  if (pf->first != 0 || pf->n != pf->n_global || pf->sup != 1 || pf->split > 2) return false;
+  if (pf->first != 0 || pf->n != pf->n_global || pf->sup != 1) return false;
+  if (pf->split != 1 && (uint32_t)CSSM_TILE / pf->split != (uint32_t)(CSSM_BLOCK * prop_items(pf->d))) return false;   // whole tiles, or one tile of the kernel
   if ((pf->n + CSSM_TILE / pf->split - 1) / (CSSM_TILE / pf->split) > CSSM_STEP_UNITS) return false;   // the unit sums a block scans
   return pf->opt_step > 0 || pf->n <= CSSM_STEP_MAX_N;
 }
 static int ensure_step_sets(cssm_pf* pf) {
   if (pf->logw_alt) return CSSM_OK;
-  const size_t nsums = (size_t)(pf->ntiles > 2 * pf->nunits ? pf->ntiles : 2 * pf->nunits);
+  const size_t nsums = (size_t)(pf->ntiles > 4 * pf->nunits ? pf->ntiles : 4 * pf->nunits);
   if (hipMalloc(&pf->logw_alt, pf->stride * 8) != hipSuccess) return fail(CSSM_ENOMEM, "hipMalloc of the second set of log-weights");
   HIP_TRY(hipMalloc(&pf->tileS_alt, nsums * sizeof(cssm_u128)));
   HIP_TRY(hipMalloc(&pf->tileS2_alt, nsums * sizeof(cssm_u128)));

@@ -13,12 +13,11 @@
 #define CSSM_CAT2(a, b) a##b
 #define CSSM_CAT(a, b) CSSM_CAT2(a, b)
 
-// k_propagate_self<D, 2, OBS, true, ONE = true> exists for the two-particles-per-thread dimensions only
-template <int D, int IT> struct OneTile { static void go(const PropLaunch&) {} };
-template <int D> struct OneTile<D, 2> {
+// the single-tile instantiation of the small clouds (one pair per thread for d <= 8, one particle for d >= 9)
+template <int D, int IT> struct OneTile {
   static void go(const PropLaunch& a) {
 #define PROP_ONE(OB)                                                                                                              \
-  k_propagate_self<D, 2, OB, true, true><<<dim3(a.grid), dim3(CSSM_BLOCK), 0, a.stream>>>(a.src, a.src_stride, a.anc, a.dst, a.dst_stride, \
+  k_propagate_self<D, IT, OB, true, true><<<dim3(a.grid), dim3(CSSM_BLOCK), 0, a.stream>>>(a.src, a.src_stride, a.anc, a.dst, a.dst_stride, \
       a.logw, a.n, a.seed, a.rec, a.mk, a.sc, a.slot_set, a.logtab, a.chunk, a.subS, a.subS2, a.pick_out, a.pick_slot)
     if (a.obs == CSSM_OBS_POISSON) PROP_ONE(CSSM_OBS_POISSON);
     else if (a.obs == CSSM_OBS_GAUSSIAN) PROP_ONE(CSSM_OBS_GAUSSIAN);
@@ -39,8 +38,8 @@ void CSSM_CAT(cssm_prop_launch_d, CSSM_PROP_D)(const PropLaunch& a) {
 #define PROP_SELF(OB, SM)                                                                                                   \
   k_propagate_self<D, IT, OB, SM><<<dim3(a.grid), dim3(CSSM_BLOCK), 0, a.stream>>>(a.src, a.src_stride, a.anc, a.dst, a.dst_stride, \
       a.logw, a.n, a.seed, a.rec, a.mk, a.sc, a.slot_set, a.logtab, a.chunk, a.subS, a.subS2, a.pick_out, a.pick_slot)
-  // small clouds: half a tile per block = one tile of the two-particles-per-thread kernels (d <= 8): the ONE instantiation
-  if (self && CSSM_PROP_SELF && a.sums && IT == 2 && a.chunk == (uint64_t)CSSM_BLOCK * IT) {
+  // small clouds: one tile of the kernel per block (half a tile of 1024 for d <= 8, a quarter for d >= 9): the ONE instantiation
+  if (self && CSSM_PROP_SELF && a.sums && a.chunk == (uint64_t)CSSM_BLOCK * IT) {
     OneTile<D, IT>::go(a);
   } else if (self && CSSM_PROP_SELF) {
     if (a.obs == CSSM_OBS_POISSON) { if (a.sums) PROP_SELF(CSSM_OBS_POISSON, true); else PROP_SELF(CSSM_OBS_POISSON, false); }
@@ -70,10 +69,10 @@ void CSSM_CAT(cssm_step_launch_d, CSSM_PROP_D)(const StepLaunch& a) {
     if (a.obs == CSSM_OBS_POISSON) STEP_GO(CSSM_OBS_POISSON, CSSM_TILE);
     else if (a.obs == CSSM_OBS_GAUSSIAN) STEP_GO(CSSM_OBS_GAUSSIAN, CSSM_TILE);
     else STEP_GO(-1, CSSM_TILE);
-  } else {
-    if (a.obs == CSSM_OBS_POISSON) STEP_GO(CSSM_OBS_POISSON, CSSM_TILE / 2);
-    else if (a.obs == CSSM_OBS_GAUSSIAN) STEP_GO(CSSM_OBS_GAUSSIAN, CSSM_TILE / 2);
-    else STEP_GO(-1, CSSM_TILE / 2);
+  } else {   // clouds below 2^20 particles: one tile of the propagate kernel per block
+    if (a.obs == CSSM_OBS_POISSON) STEP_GO(CSSM_OBS_POISSON, CSSM_BLOCK * IT);
+    else if (a.obs == CSSM_OBS_GAUSSIAN) STEP_GO(CSSM_OBS_GAUSSIAN, CSSM_BLOCK * IT);
+    else STEP_GO(-1, CSSM_BLOCK * IT);
   }
 #undef STEP_GO
 }

@@ -215,27 +215,32 @@ __device__ __forceinline__ void propagate_range(
   unsigned long long jp[NJ];
   uint32_t jn[IT];
   double x[IT][D];
-  static_assert(!ONE || (IT == 2 && !LGCP && !COH), "ONE: one pair per thread, ordinary step");
-  double zz[ONE ? 2 * D : 1];                                     // ONE: the pair's 2 D normals (normal q -> particle q / D, component q % D)
+  static_assert(!ONE || (IT <= 2 && !LGCP && !COH), "ONE: one pair (d <= 8) or one particle (d >= 9) per thread, ordinary step");
+  double zz[ONE ? IT * D : 1];                                    // ONE: the thread's IT * D normals (normal q -> particle q / D, component q % D)
   if (base < n) {
     if (ONE && pre_jp != nullptr) jp[0] = *pre_jp; else load_idx(base, jp);
-    if (ONE && pre_jp == nullptr) {                               // (while the indices travel)
+    if (ONE && IT == 2 && pre_jp == nullptr) {                    // (while the indices travel)
       normals_pair_half<D, 0>(seed, gid0 + base + threadIdx.x * IT, step, tab, zz);
       // the indices are consumed BEHIND these normals: an empty asm that takes both pins the order (the compiler otherwise
       // hoists the address arithmetic, and with it the wait for the load, above the Philox rounds)
 #pragma unroll
-      for (int q = 0; q < 2 * (D / 2); ++q) asm volatile("" : "+v"(zz[q % (ONE ? 2 * D : 1)]), "+v"(jp[0]));
+      for (int q = 0; q < 2 * (D / 2); ++q) asm volatile("" : "+v"(zz[q % (ONE ? IT * D : 1)]), "+v"(jp[0]));
       if (D / 2 == 0) asm volatile("" : "+v"(jp[0]));
     }
     unpack_idx(base, jp, jn);
     if (STAGE) {
       stage_issue(jn);                                            // tile 0 (needs its indices: the one exposed latency)
       if (!ONE && base + stride < n) load_idx(base + stride, jp);         // indices of tile 1
-      if (ONE) {                                                  // (while the rows travel)
+      if (ONE && IT == 2) {                                       // (while the rows travel)
         if (pre_jp != nullptr) normals_pair_half<D, 0>(seed, gid0 + base + threadIdx.x * IT, step, tab, zz);
         normals_pair_half<D, 1>(seed, gid0 + base + threadIdx.x * IT, step, tab, zz);
 #pragma unroll
-        for (int q = (pre_jp != nullptr) ? 0 : 2 * (D / 2); q < 2 * D; ++q) asm volatile("" : "+v"(zz[q % (ONE ? 2 * D : 1)]));
+        for (int q = (pre_jp != nullptr) ? 0 : 2 * (D / 2); q < 2 * D; ++q) asm volatile("" : "+v"(zz[q % (ONE ? IT * D : 1)]));
+      } else if (ONE) {                                           // one particle per thread: its D normals
+        double z1[D];
+        draw_normals<D>(seed, gid0 + base + threadIdx.x, step, CSSM_STREAM_STEP, tab, z1);
+#pragma unroll
+        for (int q = 0; q < D; ++q) { zz[q % (ONE ? IT * D : 1)] = z1[q]; asm volatile("" : "+v"(zz[q % (ONE ? IT * D : 1)])); }
       }
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       stage_read(x);
@@ -311,11 +316,12 @@ __device__ __forceinline__ void propagate_range(
     } else if (ONE) {
       // (gid0 is even for every caller of this instantiation: whole pairs)
 #pragma unroll
-      for (int q = 0; q < 2 * D; ++q) transition_one<D>(mk, rec, dt, q % D, x[(q / D) % IT][q % D], zz[q % (ONE ? 2 * D : 1)]);
-      lw[0] = has_obs ? logdens<OBS>(mk, rec, gamma_of<D>(mk, rec, x[0]), tab) : 0.0;
-      account(0);
-      lw[1 % IT] = has_obs ? logdens<OBS>(mk, rec, gamma_of<D>(mk, rec, x[1 % IT]), tab) : 0.0;
-      account(1 % IT);
+      for (int q = 0; q < IT * D; ++q) transition_one<D>(mk, rec, dt, q % D, x[(q / D) % IT][q % D], zz[q % (ONE ? IT * D : 1)]);
+#pragma unroll
+      for (int r = 0; r < IT; ++r) {
+        lw[r] = has_obs ? logdens<OBS>(mk, rec, gamma_of<D>(mk, rec, x[r]), tab) : 0.0;
+        account(r);
+      }
     } else if (IT % 2 == 0 && pair_ok) {
       // the thread's particles are whole pairs (2m, 2m+1): D Philox blocks + Box-Muller pairs per two particles
 #pragma unroll
@@ -485,7 +491,8 @@ __global__ __launch_bounds__(CSSM_BLOCK, (ONE ? 2 : PropWaves<D, SUMS>::value)) 
   unsigned long long jp_early = 0ull;
   if (ONE) {
     const uint32_t i0 = range_lo + threadIdx.x * IT;
-    jp_early = anc ? *reinterpret_cast<const unsigned long long*>(anc + i0) : ((unsigned long long)i0 | ((unsigned long long)(i0 + 1u) << 32));
+    if (IT == 2) jp_early = anc ? *reinterpret_cast<const unsigned long long*>(anc + i0) : ((unsigned long long)i0 | ((unsigned long long)(i0 + 1u) << 32));
+    else jp_early = anc ? (unsigned long long)anc[i0] : (unsigned long long)i0;
   }
   // ... and so are the thread's entry of the log table and the lines of the observation's record the kernel will read: behind
   // the table's barrier the record's lines are hits in the scalar cache instead of a first touch on the critical path.  (The
@@ -571,7 +578,7 @@ __global__ __launch_bounds__(CSSM_BLOCK, (D <= 3 ? 4 : 3)) void k_step_self(
     uint32_t nunits, double* __restrict__ ll_t, int32_t* __restrict__ ess_t, int force_exact,
     double* __restrict__ pick_out, uint32_t pick_slot) {
   static_assert(CSSM_BLOCK == 256 && CSSM_ITEMS == 4, "k_step: four waves, four units per thread");
-  static_assert(CH % (CSSM_BLOCK * IT) == 0 && CH <= CSSM_TILE && CH >= 2 * CSSM_BLOCK, "whole propagate tiles per block");
+  static_assert(CH % (CSSM_BLOCK * IT) == 0 && CH <= CSSM_TILE && CH >= CSSM_BLOCK, "whole propagate tiles per block");
   constexpr int PI = CH / CSSM_BLOCK;                                      // parents per thread and unit; slots per thread
   constexpr int NW = CSSM_BLOCK / 64;
   __shared__ double s_max[NW];
@@ -691,9 +698,9 @@ __global__ __launch_bounds__(CSSM_BLOCK, (D <= 3 ? 4 : 3)) void k_step_self(
       const uint32_t base = q * (uint32_t)CH;
       const uint32_t i0 = base + tid * PI;
       double v[PI];
-      if (i0 + PI <= n) {
+      if (PI >= 2 && i0 + PI <= n) {
 #pragma unroll
-        for (int r = 0; r < PI; r += 2) { const double2 a = *reinterpret_cast<const double2*>(logw_in + i0 + r); v[r] = a.x; v[r + 1] = a.y; }
+        for (int r = 0; r + 1 < PI; r += 2) { const double2 a = *reinterpret_cast<const double2*>(logw_in + i0 + r); v[r] = a.x; v[(r + 1) % PI] = a.y; }
       } else {
 #pragma unroll
         for (int r = 0; r < PI; ++r) v[r] = (i0 + r < n) ? logw_in[i0 + r] : -cssm_inf();

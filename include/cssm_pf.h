@@ -226,7 +226,7 @@ int cssm_pf_last_loop_ms(cssm_pf* pf, float* ms_out);
  * observation with the propagate of the weighted observation that follows it into ONE kernel launch (k_step: a block finds
  * the parents of its own resampling slots from the unit sums, rebuilds their end slots and keeps the ancestor indices in
  * LDS) wherever the handle is eligible: one GPU, systematic resampling, fused sums, not LGCP, at most 1024 units of sums
- * (N <= 2^20; 2^19 for the half-tile units of small clouds); -1 = only for clouds of up to 2^18 particles.  Results are
+ * (N <= 2^19 with the half-tile units of clouds below 2^20, and N = 2^20 itself); -1 = only for clouds of up to 2^18 particles.  Results are
  * bit-identical either way.  Measured: NOT faster than two launches (14.9 vs 14.4 us per observation at N = 100 000, 34.0
  * vs 32.5 at 2^20) -- a launch costs 3.1 us, the parents' end slots a block has to rebuild cost as much; see DESIGN.md 5c. */
 #define CSSM_OPT_ONE_LAUNCH 5

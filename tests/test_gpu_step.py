@@ -80,12 +80,12 @@ def test_one_launch_every_dimension(d):
 
 
 def test_one_launch_range_and_full_bench_size():
-    """Not taken unless asked for; -1 = clouds of up to 2^18 particles (half-tile units); 1 = whenever eligible: N = 2^20 (1024
-    units: the most a block scans) is, N = 2^20 + 1 is not."""
+    """Not taken unless asked for; -1 = clouds of up to 2^18 particles; 1 = whenever eligible = at most 1024 units of sums: up to
+    2^19 with the half-tile units of clouds below 2^20, N = 2^20 itself (whole tiles), not 2^20 + 1."""
     model = cases.c2_model()
     t, y, has = cases.poisson_counts(8, missing=0.1)
     for n, opt, expect in ((50_000, 0, False), (50_000, -1, True), (1 << 18, -1, True), ((1 << 18) + 1, -1, False), (1 << 19, 1, True),
-                           (1 << 20, 1, True), ((1 << 20) + 1, 1, False)):
+                           ((1 << 19) + 1, 1, False), (1 << 20, 1, True), ((1 << 20) + 1, 1, False)):
         a = _run(model, n, t, y, has, opt, want_path=False)
         assert (a["merged"] > 0) == expect, (n, opt, a["merged"])
         if expect:
