@@ -443,6 +443,11 @@ static int build_fsub(cssm_pf* pf, size_t first, size_t count, bool reset) {
 #endif
 static int prop_items(int d) { return d <= 2 ? CSSM_PROP_IT_LO : (d <= 8 ? CSSM_PROP_IT_MID : 1); }   // PropItems<D>
 
+// k_propagate blocks per 1024-particle unit on a single-GPU handle: one tile of the kernel per block below 2^20 particles
+static uint32_t auto_split(const cssm_pf* pf) {
+  return (!pf->sharded && pf->sup == 1 && pf->n <= CSSM_SPLIT_MAX_N) ? (prop_items(pf->d) == 1 ? 4u : 2u) : 1u;
+}
+
 static int alloc_handle(cssm_pf* pf) {
   HIP_TRY(hipSetDevice(pf->device));
   if (pf->own_stream) HIP_TRY(hipStreamCreateWithFlags(&pf->stream, hipStreamNonBlocking));
@@ -461,7 +466,7 @@ static int alloc_handle(cssm_pf* pf) {
     // bench model: 17.7 -> 12.8 us at N = 100 000, 21.2 -> 18.9 at 2^19, 27.1 -> 24.8 at 3 * 2^18; a tie at 2^20 (32.1 vs 32.3),
     // from where on whole tiles and the software-pipelined kernel run.
     // (d >= 9: one particle per thread, so one tile of the kernel is a QUARTER of 1024)
-    pf->split = (!pf->sharded && pf->n <= CSSM_SPLIT_MAX_N) ? (prop_items(pf->d) == 1 ? 4u : 2u) : 1u;
+    pf->split = auto_split(pf);
   }
   const size_t nsums = (size_t)(pf->ntiles > 4 * pf->nunits ? pf->ntiles : 4 * pf->nunits);   // (up to four sub-units per unit)
   const size_t row = pf->stride * 8;
@@ -1255,6 +1260,11 @@ extern "C" int cssm_pf_set_option(cssm_pf* pf, int option, int value) {
   if (option == CSSM_OPT_FUSED_SUMS) { pf->opt_fused = value ? 1 : 0; return CSSM_OK; }
   if (option == CSSM_OPT_SERIES_KERNEL) { pf->opt_series = value ? 1 : 0; return CSSM_OK; }
   if (option == CSSM_OPT_ONE_LAUNCH) { pf->opt_step = value < 0 ? -1 : (value ? 1 : 0); return CSSM_OK; }
+  if (option == CSSM_OPT_WHOLE_TILES) {   // launch geometry only: the arrays hold up to four sub-units per unit either way
+    if (pf->sharded) return fail(CSSM_ESTATE, "sharded handles always run whole tiles");
+    pf->split = value ? 1u : auto_split(pf);
+    return CSSM_OK;
+  }
   if (option == CSSM_OPT_RESAMPLER) {
     if (value < CSSM_RESAMPLE_SYSTEMATIC || value > CSSM_RESAMPLE_MULTINOMIAL) return fail(CSSM_EINVAL_ARG, "unknown resampler %d", value);
     if (pf->sharded && value != CSSM_RESAMPLE_SYSTEMATIC) return fail(CSSM_ESTATE, "sharded handles resample systematically");

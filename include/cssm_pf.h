@@ -230,6 +230,12 @@ int cssm_pf_last_loop_ms(cssm_pf* pf, float* ms_out);
  * bit-identical either way.  Measured: NOT faster than two launches (14.9 vs 14.4 us per observation at N = 100 000, 34.0
  * vs 32.5 at 2^20) -- a launch costs 3.1 us, the parents' end slots a block has to rebuild cost as much; see DESIGN.md 5c. */
 #define CSSM_OPT_ONE_LAUNCH 5
+/* CSSM_OPT_WHOLE_TILES (default 0): clouds below 2^20 particles on one GPU run ONE tile of the propagate kernel per block
+ * (512 particles for d <= 8, 256 for d >= 9: the single-tile kernels that request everything position-dependent in their first
+ * round of loads and draw the normals while the gathered rows travel) instead of whole 1024-particle tiles and the software-
+ * pipelined kernels that larger clouds run.  1 = whole tiles at every size: a verification switch -- it lets the kernels of
+ * the large clouds be checked against the oracle at sizes the oracle finishes in seconds.  Results are bit-identical. */
+#define CSSM_OPT_WHOLE_TILES 6
 int cssm_pf_set_option(cssm_pf* pf, int option, int value);
 
 /* Per-kernel device time, measured with HIP events recorded on the handle's stream directly

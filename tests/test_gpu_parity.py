@@ -620,25 +620,59 @@ def test_contract_functions_on_the_device_match_the_host():
             np.testing.assert_array_equal(z, oracle.c_paired_normals(cases.SEED, first, 3, 0, d, 1001))
 
 
+OPT_WHOLE_TILES = 6   # CSSM_OPT_WHOLE_TILES: the launch geometry and kernels of clouds of 2^20 particles and more, at any size
+
+
 @pytest.mark.parametrize("d", list(range(1, 17)))
 def test_every_dimension_streaming_and_batch_bit_exact(d):
-    """One k_propagate instantiation per latent dimension (particles per thread 4 / 2 / 1, 16- or 8-byte LDS staging,
-    pair-shared normals for even IT): each against the oracle, with several tiles per block and a ragged last tile."""
+    """One k_propagate instantiation per latent dimension (particles per thread 2 / 1, 16- or 8-byte LDS staging, pair-shared
+    normals for even IT) and launch geometry -- one tile per block with the single-tile kernels (clouds below 2^20), whole
+    1024-particle tiles with the software-pipelined kernels (larger clouds; forced here) -- each against the oracle, with a
+    ragged last tile."""
     model = cases.dim_model(d)
     assert model.descriptor().dim == d if hasattr(model.descriptor(), "dim") else True
     t, y, has = cases.poisson_counts(6, missing=0.2)
     _compare_streaming(model, 3001, t, y, has)
     n = 5 * 1024 + 77
-    g = NativePf(model, n, cases.SEED)
-    assert g.d == d
     o = oracle.OraclePf(model.descriptor(), n, cases.SEED)
-    gl, gll, gess, _ = g.run(t, y, has)
+    ol, oll, oess, opath = o.filter(t, y, has, want_path=True)
+    for whole in (0, 1):
+        g = NativePf(model, n, cases.SEED)
+        g.set_option(OPT_WHOLE_TILES, whole)
+        assert g.d == d
+        gl, gll, gess, gpath = g.run(t, y, has, want_path=True)
+        assert gl == ol, (whole, gl, ol)
+        np.testing.assert_array_equal(gess, oess)
+        np.testing.assert_array_equal(gpath, opath)
+        np.testing.assert_array_equal(g.ancestors(), o.ancestors())
+        np.testing.assert_array_equal(g.particles(), o.particles())
+        np.testing.assert_array_equal(g.proposed(), o.proposed())
+        g.close()
+
+
+@pytest.mark.parametrize("name", ["c1", "c2", "c3", "linear", "negbin", "zip", "bernoulli", "studentt", "beta"])
+def test_whole_tile_kernels_at_test_sizes(name):
+    """The kernels large clouds run (CSSM_OPT_WHOLE_TILES = 1), every observation density, batch and streaming, with outliers
+    absent and a missing observation -- against the oracle AND against the default single-tile path."""
+    model, t, y, has = cases.golden_case(name, 12, missing=0.1)
+    n = 3 * 1024 + 5
+    o = oracle.OraclePf(model.descriptor(), n, cases.SEED)
     ol, oll, oess, _ = o.filter(t, y, has)
-    assert gl == ol
-    np.testing.assert_array_equal(gess, oess)
-    np.testing.assert_array_equal(g.ancestors(), o.ancestors())
-    np.testing.assert_array_equal(g.particles(), o.particles())
-    g.close()
+    for whole in (1, 0):
+        g = NativePf(model, n, cases.SEED)
+        g.set_option(OPT_WHOLE_TILES, whole)
+        gl, gll, gess, _ = g.run(t, y, has)
+        assert gl == ol, (name, whole)
+        np.testing.assert_array_equal(gll, oll)
+        np.testing.assert_array_equal(gess, oess)
+        np.testing.assert_array_equal(g.ancestors(), o.ancestors())
+        np.testing.assert_array_equal(g.logw(), o.logw()) if has[-1] else None
+        g.init(float(np.min(t)))                       # the same handle, streaming, same geometry
+        o2 = oracle.OraclePf(model.descriptor(), n, cases.SEED); o2.init(float(np.min(t)))
+        for s in range(4):
+            assert g.step(t[s], y[s], bool(has[s])) == o2.step(t[s], y[s], bool(has[s]))
+        np.testing.assert_array_equal(g.particles(), o2.particles())
+        g.close()
 
 
 # ----------------------------------------------------------------------------- tolerance to the reference's literal arithmetic
