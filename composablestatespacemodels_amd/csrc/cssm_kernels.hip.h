@@ -74,6 +74,27 @@ __global__ __launch_bounds__(CSSM_BLOCK) void k_tile_sums(const double* __restri
   }
 }
 
+// Large clouds run k_propagate's single-tile kernel -- many blocks per unit of sums -- and this kernel folds the blocks' sums
+// into the units' (one WAVE per unit: lane l adds the entries l, l + 64, ... of its unit; integer sums: any grouping gives the
+// same bits), so that k_offspring reads <= 1024 unit sums whatever the cloud's size.  ~5 us per weighted observation; what the
+// single-tile kernel saves grows with the latent dimension (cssm_pf.hip, uses_fine: d >= 4).
+__global__ __launch_bounds__(CSSM_BLOCK) void k_reduce_units(const cssm_u128* __restrict__ blockS, const cssm_u128* __restrict__ blockS2,
+                                                             uint32_t nblocks, uint32_t blocks_per_unit, uint32_t nunits,
+                                                             cssm_u128* __restrict__ unitS, cssm_u128* __restrict__ unitS2,
+                                                             const Scalars* __restrict__ sc, const StepRec* __restrict__ rec) {
+  if (!rec->has_obs || (sc->err & (4u | 8u | 64u))) return;   // (nothing was formed: an unweighted observation, a series on hold)
+  const uint32_t unit = blockIdx.x * (CSSM_BLOCK / 64) + (threadIdx.x >> 6);
+  if (unit >= nunits) return;
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint32_t b0 = unit * blocks_per_unit;
+  uint32_t b1 = b0 + blocks_per_unit;
+  b1 = (b1 < nblocks) ? b1 : nblocks;
+  cssm_u128 a = cssm_u128_zero(), b = cssm_u128_zero();
+  for (uint32_t q = b0 + lane; q < b1; q += 64u) { a = cssm_u128_add(a, blockS[q]); b = cssm_u128_add(b, blockS2[q]); }
+  a = wave_sum_u128(a); b = wave_sum_u128(b);
+  if (lane == 0u) { unitS[unit] = a; unitS2[unit] = b; }
+}
+
 // Exclusive scan of the tile sums in one block (thread t owns a contiguous chunk of tiles: sum, block
 // scan of the 1024 chunk sums, then prefix write-back); local totals; with `single` also ll / ess.
 __global__ __launch_bounds__(1024) void k_scan_tiles(const cssm_u128* __restrict__ tileS, const cssm_u128* __restrict__ tileS2,

@@ -94,6 +94,10 @@ struct cssm_pf {
   double* logw_alt = nullptr;  // k_step reads the log-weights / unit sums of observation s - 1 and writes those of s: two sets,
   cssm_u128 *tileS_alt = nullptr, *tileS2_alt = nullptr;   //   logw / tileS / tileS2 always being the set written last
   int pp = 0;                  // how often the sets were swapped since launch_init, mod 2
+  cssm_u128 *fineS = nullptr, *fineS2 = nullptr;   // large clouds: the sums of k_propagate's single-tile blocks (k_reduce_units folds them into tileS / tileS2)
+  size_t fine_cap = 0;
+  bool no_fine = false;        // (k_step in use: no extra launch between the kernels it merges)
+  int opt_whole = 0;           // CSSM_OPT_WHOLE_TILES
   std::vector<uint8_t> pp_after;   // pp right after the propagate of every observation of the batch run (restored when a series is put on hold)
   int opt_series = 0;          // CSSM_OPT_SERIES_KERNEL: 1 = batch drivers run the persistent series kernel when the handle is eligible (opt-in, see cssm_pf.h)
   // persistent series kernel (cssm_series.hip.h)
@@ -534,7 +538,7 @@ extern "C" void cssm_pf_destroy(cssm_pf* pf) {
   if (!pf) return;
   (void)hipSetDevice(pf->device);
   if (pf->stream) (void)hipStreamSynchronize(pf->stream);
-  void* ptrs[] = {pf->logw_alt, pf->tileS_alt, pf->tileS2_alt, pf->state[0], pf->state[1], pf->logw, pf->endslot, pf->anc, pf->tileS, pf->tileS2, pf->tileP, pf->sc,
+  void* ptrs[] = {pf->fineS, pf->fineS2, pf->logw_alt, pf->tileS_alt, pf->tileS2_alt, pf->state[0], pf->state[1], pf->logw, pf->endslot, pf->anc, pf->tileS, pf->tileS2, pf->tileP, pf->sc,
                   pf->d_m0, pf->d_sd0, pf->d_logtab, pf->d_sync, pf->d_ts, pf->d_fsub, pf->cum, pf->d_recs, pf->d_ll_t, pf->d_ess_t, pf->d_path, pf->cand, pf->cand_end, pf->cand_idx, pf->d_bounds, pf->d_xch, pf->d_need};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   if (pf->h_recs) (void)hipHostFree(pf->h_recs);
@@ -611,15 +615,44 @@ static bool uses_sums_kernel(const cssm_pf* pf) {
   return pf->opt_fused && !pf->safe_sums && pf->obs_kind != CSSM_OBS_LGCP && pf->resampler != CSSM_RESAMPLE_MULTINOMIAL;
 }
 
+// Whether k_propagate runs its single-tile kernel on a cloud of 2^20 particles and more (one tile per block, k_reduce_units
+// behind it).  The single-tile kernel carries no software-pipeline state -- no spill, 5-6 waves per SIMD instead of 3-4 -- and
+// the wider the state the more that is worth; the reduce launch costs ~5 us per weighted observation.  In-process A/B
+// (tools/ab_fine.py, per observation, single-tile vs software-pipelined): d = 3: 33.6 vs 34.7 us at 2^20, 92.6 vs 93.0 at 2^22,
+// 336 vs 332 at 2^24 (a tie: the bench model keeps two launches); d = 4: 36.8 vs 38.9, 110.5 vs 111.8, 399 vs 402; d = 5:
+// 39.4 vs 44.7 at 2^20, 121 vs 137 at 2^22; d = 6: 42.8 vs 49.2; d = 8: 168 vs 200 at 2^22; d = 9 (C3): 194 vs 203 at 2^22, 57.3 vs
+// 61.7 at 2^20; d = 16: 287 vs 343.  At d <= 2 the software-pipelined kernel keeps a few per cent (d = 2, 2^22: 75.8 vs 77.2).
+// (Timings taken on different boxes differ by +-5 %: a first comparison across boxes had promised 13 % at d = 3.)
+#ifndef CSSM_FINE_MIN_D
+#define CSSM_FINE_MIN_D 4
+#endif
+static bool uses_fine(const cssm_pf* pf) {
+  if (pf->sharded || pf->split != 1 || pf->no_fine || pf->opt_whole == 2 || pf->first != 0 || pf->n != pf->n_global) return false;
+  if (pf->resampler == CSSM_RESAMPLE_MULTINOMIAL) return false;
+  return pf->opt_whole == 1 ? pf->d >= 3 : pf->d >= CSSM_FINE_MIN_D;
+}
+
 static int launch_propagate(cssm_pf* pf, const StepRec* d_rec, double* pick_out = nullptr, uint32_t pick_slot = 0) {
   // one block per sub-unit: contiguous ranges, so that (with do_sums) the block's fixed-point sums are the
   // sub-unit sums k_offspring scans
-  const uint64_t chunk = (uint64_t)pf->sup * CSSM_TILE / pf->split;
-  const int grid = (int)((pf->n + chunk - 1) / chunk);
+  uint64_t chunk = (uint64_t)pf->sup * CSSM_TILE / pf->split;
   double* dst = pf->state[pf->cur ^ 1];
   const uint32_t* anc = pf->anc_valid ? pf->anc : nullptr;
   const int do_sums = uses_sums_kernel(pf) ? 1 : 0;
   pf->last_optimistic = do_sums != 0;
+  const bool fine = do_sums && uses_fine(pf);
+  const uint64_t unit_particles = (uint64_t)pf->sup * CSSM_TILE;
+  if (fine) chunk = (uint64_t)CSSM_BLOCK * prop_items(pf->d);   // (divides the unit: 1024 * sup)
+  const int grid = (int)((pf->n + chunk - 1) / chunk);
+  if (fine && pf->fine_cap < (size_t)grid) {
+    HIP_TRY(hipStreamSynchronize(pf->stream));
+    if (pf->fineS) (void)hipFree(pf->fineS);
+    if (pf->fineS2) (void)hipFree(pf->fineS2);
+    pf->fineS = pf->fineS2 = nullptr; pf->fine_cap = 0;
+    if (hipMalloc(&pf->fineS, (size_t)grid * sizeof(cssm_u128)) != hipSuccess || hipMalloc(&pf->fineS2, (size_t)grid * sizeof(cssm_u128)) != hipSuccess)
+      return fail(CSSM_ENOMEM, "hipMalloc of the per-block sums (%d blocks)", grid);
+    pf->fine_cap = (size_t)grid;
+  }
   prof_begin(pf, CSSM_K_PROPAGATE);
   PropLaunch a;
   a.grid = grid; a.stream = pf->stream;
@@ -630,7 +663,8 @@ static int launch_propagate(cssm_pf* pf, const StepRec* d_rec, double* pick_out 
   a.n = pf->n; a.gid0 = pf->first; a.seed = pf->seed; a.rec = d_rec; a.mk = pf->mk; a.sc = pf->sc;
   a.slot_set = pf->sharded ? 0 : pf->wparity;
   a.src2 = anc ? pf->src2 : nullptr; a.src2_stride = pf->src2_stride; a.n_split = pf->n_split; a.logtab = pf->d_logtab;
-  a.chunk = chunk; a.do_sums = do_sums; a.subS = pf->tileS; a.subS2 = pf->tileS2; a.pick_out = pick_out; a.pick_slot = pick_slot;
+  a.chunk = chunk; a.do_sums = do_sums; a.subS = fine ? pf->fineS : pf->tileS; a.subS2 = fine ? pf->fineS2 : pf->tileS2;
+  a.pick_out = pick_out; a.pick_slot = pick_slot;
   a.fsub = pf->lgcp_tdep ? pf->d_fsub : nullptr;
   switch (pf->d) {
 #define CSSM_CASE_PROP(D) case D: cssm_prop_launch_d##D(a); break;
@@ -640,6 +674,13 @@ static int launch_propagate(cssm_pf* pf, const StepRec* d_rec, double* pick_out 
 #undef CSSM_CASE_PROP
   }
   prof_end(pf);
+  if (fine) {   // the blocks' sums -> the units' (the kernel itself skips unweighted observations and series on hold)
+    prof_begin(pf, CSSM_K_REDUCE);
+    hipLaunchKernelGGL(k_reduce_units, dim3((pf->nunits + CSSM_BLOCK / 64 - 1) / (CSSM_BLOCK / 64)), dim3(CSSM_BLOCK), 0, pf->stream,
+                       (const cssm_u128*)pf->fineS, (const cssm_u128*)pf->fineS2, (uint32_t)grid, (uint32_t)(unit_particles / chunk), pf->nunits,
+                       pf->tileS, pf->tileS2, (const Scalars*)pf->sc, d_rec);
+    prof_end(pf);
+  }
   HIP_TRY(hipGetLastError());
   pf->cur ^= 1;
   pf->src = pf->state[pf->cur]; pf->src_stride = pf->stride; pf->anc_valid = false; pf->src2 = nullptr;
@@ -1066,6 +1107,7 @@ static int run_filter_once(cssm_pf* pf, const double* t, const double* y, const 
     // (small clouds) the resampling of a weighted observation that another weighted observation follows is not launched:
     // the next observation's k_step does it on the way -- one launch per observation instead of two
     const bool merge = step_eligible(pf) && (!path || fold);
+    pf->no_fine = merge;   // (k_step consumes the propagate kernel's own unit sums)
     bool deferred = false;
     if (pf->pp_after.size() < T) pf->pp_after.resize(T);
     for (size_t s = s_from; s < T; ++s) {
@@ -1262,6 +1304,7 @@ extern "C" int cssm_pf_set_option(cssm_pf* pf, int option, int value) {
   if (option == CSSM_OPT_ONE_LAUNCH) { pf->opt_step = value < 0 ? -1 : (value ? 1 : 0); return CSSM_OK; }
   if (option == CSSM_OPT_WHOLE_TILES) {   // launch geometry only: the arrays hold up to four sub-units per unit either way
     if (pf->sharded) return fail(CSSM_ESTATE, "sharded handles always run whole tiles");
+    pf->opt_whole = value < 0 ? 0 : (value > 2 ? 2 : value);
     pf->split = value ? 1u : auto_split(pf);
     return CSSM_OK;
   }

@@ -130,7 +130,7 @@ class NativePf:
         _abi.check(self.lib.cssm_pf_last_loop_ms(self._h, C.byref(ms)))
         return ms.value
 
-    KERNELS = ("k_propagate", "k_tile_sums", "k_offspring", "k_series", "k_step")
+    KERNELS = ("k_propagate", "k_tile_sums", "k_offspring", "k_series", "k_step", "k_reduce_units")
 
     def set_option(self, option: int, value: int):
         _abi.check(self.lib.cssm_pf_set_option(self._h, int(option), int(value)))

@@ -230,11 +230,14 @@ int cssm_pf_last_loop_ms(cssm_pf* pf, float* ms_out);
  * bit-identical either way.  Measured: NOT faster than two launches (14.9 vs 14.4 us per observation at N = 100 000, 34.0
  * vs 32.5 at 2^20) -- a launch costs 3.1 us, the parents' end slots a block has to rebuild cost as much; see DESIGN.md 5c. */
 #define CSSM_OPT_ONE_LAUNCH 5
-/* CSSM_OPT_WHOLE_TILES (default 0): clouds below 2^20 particles on one GPU run ONE tile of the propagate kernel per block
- * (512 particles for d <= 8, 256 for d >= 9: the single-tile kernels that request everything position-dependent in their first
- * round of loads and draw the normals while the gathered rows travel) instead of whole 1024-particle tiles and the software-
- * pipelined kernels that larger clouds run.  1 = whole tiles at every size: a verification switch -- it lets the kernels of
- * the large clouds be checked against the oracle at sizes the oracle finishes in seconds.  Results are bit-identical. */
+/* CSSM_OPT_WHOLE_TILES (default 0): a verification switch over the launch geometry (results are bit-identical in every setting).
+ * By default the propagate kernel is the single-tile kernel (one tile -- 512 particles for d <= 8, 256 for d >= 9 -- per block;
+ * everything position-dependent requested in the first round of loads, the normals drawn while the gathered rows travel) for
+ * clouds below 2^20 particles, where k_offspring reads one pair of sums per block, and for larger clouds of latent dimension
+ * d >= 4, where k_reduce_units folds the blocks' sums into <= 1024 unit sums; larger clouds with d <= 3 run whole units of
+ * 1024 * k particles per block and the software-pipelined kernel (a tie at d = 3, a few per cent better at d <= 2).
+ * 1 = the geometry of the large clouds (single-tile kernel + k_reduce_units for d >= 3) at every size: lets it be checked
+ * against the oracle at sizes the oracle finishes in seconds; 2 = whole units and the software-pipelined kernels for every d. */
 #define CSSM_OPT_WHOLE_TILES 6
 int cssm_pf_set_option(cssm_pf* pf, int option, int value);
 
@@ -249,7 +252,8 @@ int cssm_pf_set_option(cssm_pf* pf, int option, int value);
 #define CSSM_K_OFFSPRING 2   /* unit prefix, ll / ess, cumulative weights -> end slots -> ancestor indices */
 #define CSSM_K_SERIES 3      /* the persistent series kernel: ONE launch for all T observations of a batch run */
 #define CSSM_K_STEP 4        /* k_step: resampling of the previous observation + propagate and weight of this one (CSSM_OPT_ONE_LAUNCH) */
-#define CSSM_PROFILE_NKERNELS 5
+#define CSSM_K_REDUCE 5      /* k_reduce_units: the sums of k_propagate's single-tile blocks -> unit sums (large clouds) */
+#define CSSM_PROFILE_NKERNELS 6
 int cssm_pf_profile(cssm_pf* pf, int enable);
 int cssm_pf_profile_read(cssm_pf* pf, double* total_ms, uint64_t* launches);
 /* Whether the last batch run used the persistent series kernel and, if profiling was on, how its weighted observations
