@@ -5,11 +5,11 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, ROOT + "/tests")
 import numpy as np, cases
 from composablestatespacemodels_amd.filter import NativePf
-which, n = sys.argv[1], int(sys.argv[2]); T = int(sys.argv[3]) if len(sys.argv) > 3 else 40
+which, n = sys.argv[1], int(sys.argv[2]); T = int(sys.argv[3]) if len(sys.argv) > 3 else (40 if n >= (1 << 20) else 200)
 model = cases.c2_model() if which == "c2" else (cases.c1_model() if which == "c1" else cases.dim_model(int(which[1:])))
 t, y, has = cases.poisson_counts(T)
 hs = {}
-for name, whole in (("fine", 1), ("pipelined", 2)):
+for name, whole in (("fine", 1 if n >= (1 << 20) else 0), ("pipelined", 2)):   # below 2^20 the default geometry IS the single-tile kernel
     g = NativePf(model, n, cases.SEED); g.set_option(6, whole); g.run(t[:10], y[:10], has[:10]); hs[name] = g
 res = {k: {"loop": [], "prop": [], "off": [], "red": []} for k in hs}
 for rep in range(4):
