@@ -1,5 +1,6 @@
 """A/B in one process: the single-tile propagate kernel + k_reduce_units (default for large clouds) against whole units and the
-software-pipelined kernel (CSSM_OPT_WHOLE_TILES = 2).  usage: ab_fine.py model N [T=40]  (model: c2 | c1 | d<k>)"""
+software-pipelined kernel (CSSM_OPT_WHOLE_TILES = 2).  usage: ab_fine.py model N [T=40] [optA optB]  (model: c2 | c1 | d<k>; opt = CSSM_OPT_WHOLE_TILES value: 0 default, 1 single-tile,
+2 whole units + software-pipelined kernel, one block per unit)"""
 import sys, os
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, ROOT + "/tests")
@@ -9,7 +10,9 @@ which, n = sys.argv[1], int(sys.argv[2]); T = int(sys.argv[3]) if len(sys.argv) 
 model = cases.c2_model() if which == "c2" else (cases.c1_model() if which == "c1" else cases.dim_model(int(which[1:])))
 t, y, has = cases.poisson_counts(T)
 hs = {}
-for name, whole in (("fine", 1 if n >= (1 << 20) else 0), ("pipelined", 2)):   # below 2^20 the default geometry IS the single-tile kernel
+opts = [int(v) for v in sys.argv[4:6]] if len(sys.argv) > 5 else [1 if n >= (1 << 20) else 0, 2]   # below 2^20 the default geometry IS the single-tile kernel
+labels = {0: "default", 1: "fine", 2: "pipelined"}
+for name, whole in ((labels[opts[0]], opts[0]), (labels[opts[1]], opts[1])):
     g = NativePf(model, n, cases.SEED); g.set_option(6, whole); g.run(t[:10], y[:10], has[:10]); hs[name] = g
 res = {k: {"loop": [], "prop": [], "off": [], "red": []} for k in hs}
 for rep in range(4):
