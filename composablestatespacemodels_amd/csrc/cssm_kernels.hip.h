@@ -177,6 +177,10 @@ __global__ void k_global_sums(const unsigned long long* __restrict__ all4, int r
 #ifndef CSSM_OFF_WAVES
 #define CSSM_OFF_WAVES 4
 #endif
+// unit sums every block of k_offspring_self requests before anything else, per thread (x 256 threads); the rest in a loop
+#ifndef CSSM_OFF_UPRE
+#define CSSM_OFF_UPRE 8   /* 2048 entries: every sub-unit sum of a cloud of up to 2^20 particles run on half tiles is in flight at once */
+#endif
 // k_offspring's ancestor lines: 1 = write-through (sc1) stores, 0 = plain stores (dirty lines written back when the kernel ends)
 #ifndef CSSM_OFF_SC1
 #define CSSM_OFF_SC1 1
@@ -224,9 +228,9 @@ __device__ __forceinline__ void offspring_body(const double* __restrict__ logw, 
   const uint32_t held = SELF ? sc->err : 0u;
   double pre_v[CSSM_ITEMS];   // the block's first tile is requested before the serial prologue
   if (blockIdx.x < nunits) load_tile_raw(logw, (uint64_t)blockIdx.x * sup * CSSM_TILE, n, raw, pre_v);
-  // ... and (single GPU) so are the unit sums every block totals: up to 1024 of them, 4 per thread, in flight while the max
+  // ... and (single GPU) so are the unit sums every block totals: up to 2048 of them, CSSM_OFF_UPRE per thread, in flight while the max
   // is decoded -- one dependent round trip less on the kernel's critical path, which at N = 2^20 is all it has
-  constexpr int UPRE = 4;
+  constexpr int UPRE = CSSM_OFF_UPRE;
   cssm_u128 upre[UPRE];
   if (SELF) {
 #pragma unroll

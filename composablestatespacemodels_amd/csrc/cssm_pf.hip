@@ -443,13 +443,18 @@ static int build_fsub(cssm_pf* pf, size_t first, size_t count, bool reset) {
 #define CSSM_PROP_IT_LO 2
 #endif
 #ifndef CSSM_SPLIT_MAX_N
-#define CSSM_SPLIT_MAX_N ((1u << 20) - 1u)
+#define CSSM_SPLIT_MAX_N (1u << 20)
 #endif
 static int prop_items(int d) { return d <= 2 ? CSSM_PROP_IT_LO : (d <= 8 ? CSSM_PROP_IT_MID : 1); }   // PropItems<D>
 
 // k_propagate blocks per 1024-particle unit on a single-GPU handle: one tile of the kernel per block below 2^20 particles
 static uint32_t auto_split(const cssm_pf* pf) {
-  return (!pf->sharded && pf->sup == 1 && pf->n <= CSSM_SPLIT_MAX_N) ? (prop_items(pf->d) == 1 ? 4u : 2u) : 1u;
+  if (pf->sharded || pf->sup != 1) return 1u;
+  // two particles per thread (d <= 8): half tiles up to 2^20 particles inclusive (2048 sub-unit sums, all requested up front by
+  // k_offspring: 32.8 vs 34.2 us per observation at 2^20, d = 3, same process); one particle per thread (d >= 9): quarter tiles
+  // below 2^20 (at 2^20 itself 4096 sub-unit sums cost k_offspring more than the reduce launch of the large clouds: 61.7 vs 57.3)
+  if (prop_items(pf->d) == 1) return pf->n < CSSM_SPLIT_MAX_N ? 4u : 1u;
+  return pf->n <= CSSM_SPLIT_MAX_N ? 2u : 1u;
 }
 
 static int alloc_handle(cssm_pf* pf) {
@@ -463,13 +468,12 @@ static int alloc_handle(cssm_pf* pf) {
   pf->nunits = (pf->ntiles + pf->sup - 1) / pf->sup;
   {   // k_propagate: a block owns unit/split particles, a multiple of its CSSM_BLOCK * IT particles per iteration
     // (the kernel pipelines its tiles through LDS and wants several of them: one block per unit)
-    // Clouds below 2^20 particles on one GPU: HALF a tile per block.  Up to ~2^18 particles every SIMD holds at most one or
-    // two waves and a kernel's duration is the length of ONE wave's dependent instruction stream (~3 ns per instruction,
-    // tools/launch_floor.hip; the launch itself is 3.1 us): one pair of particles per thread instead of two, in the single-tile
-    // instantiation k_propagate_self<..., ONE> (d <= 8) that draws its normals while the gathered rows travel.  Per observation,
-    // bench model: 17.7 -> 12.8 us at N = 100 000, 21.2 -> 18.9 at 2^19, 27.1 -> 24.8 at 3 * 2^18; a tie at 2^20 (32.1 vs 32.3),
-    // from where on whole tiles and the software-pipelined kernel run.
-    // (d >= 9: one particle per thread, so one tile of the kernel is a QUARTER of 1024)
+    // Clouds of up to 2^20 particles on one GPU: one tile of the kernel per block.  Up to ~2^18 particles every SIMD holds at
+    // most one or two waves and a kernel's duration is the length of ONE wave's dependent instruction stream (~3 ns per
+    // instruction, tools/launch_floor.hip; the launch itself is 3.1 us): one pair of particles per thread instead of two, in the
+    // single-tile instantiation k_propagate_self<..., ONE> that requests everything position-dependent in its first round of
+    // loads and draws its normals while the gathered rows travel.  Per observation, bench model, same process (tools/ab_fine.py):
+    // 17.1 -> 12.6 us at N = 100 000, 21.9 -> 19.3 at 2^19, 28.1 -> 25.8 at 3 * 2^18, 34.2 -> 32.8 at 2^20.
     pf->split = auto_split(pf);
   }
   const size_t nsums = (size_t)(pf->ntiles > 4 * pf->nunits ? pf->ntiles : 4 * pf->nunits);   // (up to four sub-units per unit)

@@ -14,8 +14,9 @@ pytestmark = pytest.mark.gpu
 OPT_ONE_LAUNCH = 5
 
 
-def _run(model, n, t, y, has, one_launch, want_path=True, seed=cases.SEED, exact=0):
+def _run(model, n, t, y, has, one_launch, want_path=True, seed=cases.SEED, exact=0, whole=0):
     g = NativePf(model, n, seed)
+    g.set_option(6, whole)                   # CSSM_OPT_WHOLE_TILES
     g.set_option(OPT_ONE_LAUNCH, one_launch)
     if exact:
         g.set_option(1, 1)
@@ -81,19 +82,21 @@ def test_one_launch_every_dimension(d):
 
 def test_one_launch_range_and_full_bench_size():
     """Not taken unless asked for; -1 = clouds of up to 2^18 particles; 1 = whenever eligible = at most 1024 units of sums: up to
-    2^19 with the half-tile units of clouds below 2^20, N = 2^20 itself (whole tiles), not 2^20 + 1."""
+    2^19 particles with the half-tile units of the default geometry, 2^20 with whole units (CSSM_OPT_WHOLE_TILES = 2), never beyond."""
     model = cases.c2_model()
     t, y, has = cases.poisson_counts(8, missing=0.1)
-    for n, opt, expect in ((50_000, 0, False), (50_000, -1, True), (1 << 18, -1, True), ((1 << 18) + 1, -1, False), (1 << 19, 1, True),
-                           ((1 << 19) + 1, 1, False), (1 << 20, 1, True), ((1 << 20) + 1, 1, False)):
-        a = _run(model, n, t, y, has, opt, want_path=False)
-        assert (a["merged"] > 0) == expect, (n, opt, a["merged"])
+    for n, opt, whole, expect in ((50_000, 0, 0, False), (50_000, -1, 0, True), (1 << 18, -1, 0, True), ((1 << 18) + 1, -1, 0, False),
+                                  (1 << 19, 1, 0, True), ((1 << 19) + 1, 1, 0, False), (1 << 20, 1, 0, False), (1 << 20, 1, 2, True),
+                                  ((1 << 20) + 1, 1, 2, False)):
+        a = _run(model, n, t, y, has, opt, want_path=False, whole=whole)
+        assert (a["merged"] > 0) == expect, (n, opt, whole, a["merged"])
         if expect:
             assert a["merged"] == _pairs(has)
             b = _run(model, n, t, y, has, 0, want_path=False)
             _same(a, b, f"N = {n}")
     o = _oracle(model, 1 << 20, t[:4], y[:4], has[:4])
-    a = _run(model, 1 << 20, t[:4], y[:4], has[:4], 1)
+    a = _run(model, 1 << 20, t[:4], y[:4], has[:4], 1, whole=2)
+    assert a["merged"] == _pairs(has[:4])
     _same(a, o, "N = 2^20 vs oracle")
 
 
