@@ -17,7 +17,8 @@ def digest(*arrs):
 
 bad = 0
 t, y, has = cases.poisson_counts(300, missing=0.05)
-for name, n, fused in (("c2_model", (1 << 22) + 333, 0), ("c2_model", 1 << 22, 1), ("c1_model", 1 << 23, 0), ("c3_model", 1 << 21, 0), ("max_dim_model", 1 << 19, 1)):
+for name, n, fused in (("c2_model", (1 << 22) + 333, 0), ("c2_model", 1 << 22, 1), ("c1_model", 1 << 23, 0), ("c3_model", 1 << 21, 0), ("max_dim_model", 1 << 19, 1),
+                       ("c2_model", 100_000, 1), ("c2_model", (1 << 20) - 5, 1), ("c3_model", (1 << 21) + 7, 1), ("max_dim_model", (1 << 20) + 1, 1)):   # single-tile kernels: half / quarter tiles, k_reduce_units
     model = getattr(cases, name)()
     ds = []
     for rep in range(4):
