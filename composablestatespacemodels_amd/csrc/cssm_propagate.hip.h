@@ -2,6 +2,8 @@
 // cssm_prop.hip, which is compiled once per latent dimension D (the 112 instantiations built in parallel).
 #pragma once
 
+#include <cstddef>
+
 #include "cssm_device.hip.h"
 
 // Particles per thread in k_propagate: all gathers of a thread are issued before its ALU work, and rows are stored as
@@ -506,7 +508,9 @@ __global__ __launch_bounds__(CSSM_BLOCK, (ONE ? 2 : PropWaves<D, SUMS>::value)) 
     uint32_t probe = w[0];
 #pragma unroll
     for (int o = 16; o < (int)(sizeof(StepRec) / 4); o += 16)
-      if (o * 4 < 88 + D * 32 + 64 || (o * 4 + 64 > 88 + CSSM_MAX_DIM * 32 && o * 4 < 88 + CSSM_MAX_DIM * 32 + D * 8 + 64)) probe |= w[o];
+      // (one word of every 64-byte line that holds the scalars, the first D rows of coef[] or the first D entries of fco[])
+      if (o * 4 < (int)(offsetof(StepRec, coef) + D * sizeof(double[4]) + 64) ||
+          (o * 4 + 64 > (int)offsetof(StepRec, fco) && o * 4 < (int)(offsetof(StepRec, fco) + D * sizeof(double) + 64))) probe |= w[o];
     if ((probe == 0x9e3779b9u) & (blockIdx.x > 0x7ffffff0u)) atomicOr(&sc->err, 128u);
     tab = stage_log_table_finish(tv);
   } else {
