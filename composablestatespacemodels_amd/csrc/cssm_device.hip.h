@@ -18,6 +18,12 @@
 //   k_offspring   unit prefix + totals (every block sums the <= 1K unit sums itself), ll and ess (:127-128), per tile
 //                 a DPP wave scan -> cumulative weight C_j -> end slot cnt(C_j); every particle writes its own run of
 //                 slots into anc (single GPU), or the end slots are kept for the exchange   model/Resampling.scala:36-58,69
+//   launch geometry (single GPU): clouds of up to 2^20 particles (d >= 9: below 2^20) and larger clouds of
+//                 d >= 4 run k_propagate_self<..., ONE> -- ONE tile per block, everything position-dependent requested in the
+//                 first round of loads, the normals drawn while the gathered rows travel; the former store one pair of sums per
+//                 block (k_offspring totals up to 2048 of them), the latter are followed by k_reduce_units (blocks' sums ->
+//                 <= 1024 unit sums); other large clouds run whole units per block and the software-pipelined kernel
+//   k_step        (opt-in) k_offspring for the block's own slots + k_propagate in one launch
 //   sharded only  k_boundary_pack + k_offspring_expand_spec (single-collective exchange); k_scan_tiles / k_global_sums,
 //                 k_pack, k_expand (exact exchange: candidates -> slots)
 // Cross-lane traffic is DPP, not ds_bpermute (5 vs 25 cycles per move on MI355X, tools/instr_rate.hip).

@@ -596,7 +596,7 @@ __global__ __launch_bounds__(CSSM_BLOCK, (D <= 3 ? 4 : 3)) void k_step_self(
   const int lane = (int)(tid & 63u), wid = (int)(tid >> 6);
   // ---- A: everything the prologue needs is requested before anything is waited for
 #ifdef CSSM_STEP_STAMPS
-  const unsigned long long ts0 = __builtin_readcyclecounter() * 0 + wall_clock64();
+  const unsigned long long ts0 = wall_clock64();
 #endif
   const uint32_t held = sc->err;
   cssm_u128 us[CSSM_ITEMS];

@@ -1,5 +1,7 @@
+"""Host time of one batch run beyond its device time (records built, uploaded, results read back): usage host_overhead.py"""
 import sys, os, time
-sys.path.insert(0, "/root/repo"); sys.path.insert(0, "/root/repo/tests")
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, ROOT + "/tests")
 import numpy as np, cases
 from composablestatespacemodels_amd.filter import NativePf
 t, y, has = cases.poisson_counts(500)
