@@ -12,8 +12,9 @@ non-zero if any rank failed.
 
 Workload: BASELINE.json configs[1] -- seasonal-Poisson with OU latents (d = 3), N = 2^20 particles per GPU (weak
 scaling: the global filter has N_gpus * 2^20 particles), T = K observations, synthetic data (tests/cases.py
-simulator, seed 20260101).  value = N_global * K / wall seconds of a K-step series (median of ``repeats`` series),
-with the cloud resident in HBM and the observations (a few KB) already uploaded.
+simulator, seed 20260101).  N = 1: the W warm-up steps start the filter and the timed legs CONTINUE it -- value =
+N * K / wall seconds of K more steps (cssm_pf_ll_filter_more; median of ``repeats`` legs), the cloud resident in HBM, the
+K observations' records built and uploaded inside the timed call.  N > 1: a K-step series of the sharded filter.
 
 Extra objects on the JSON line (N = 1 only): ``roofline`` for the dominant kernel from HIP events on its launch
 stream, ``roofline_16m`` the same kernel at N = 2^24 (the north-star size) for the bench model (d = 3) and for
@@ -131,7 +132,9 @@ def run_single(args, emit=print):
     from composablestatespacemodels_amd.filter import NativePf
     K, W = args.steps, args.warmup
     n = args.particles
-    model, t, y, has = build_workload(max(K, W, 8), args.model)
+    R = args.repeats if args.repeats > 0 else (3 if K >= 200 else 7)
+    W = max(W, 1)                      # (the filter has to be running before K more steps can be timed)
+    model, t, y, has = build_workload(W + R * K + 8, args.model)
     pf = NativePf(model, n, 20260101, device=0)
     if args.fused is not None:
         pf.set_option(3, args.fused)   # CSSM_OPT_FUSED_SUMS (experiment switch; the default is the library's)
@@ -139,17 +142,19 @@ def run_single(args, emit=print):
         pf.set_option(4, args.series)  # CSSM_OPT_SERIES_KERNEL
     d = pf.d
     torch.cuda.synchronize()
-    if W > 0:
-        pf.run(t[:W], y[:W], has[:W])
-    # the timed leg: R series of exactly K steps each, every one bracketed by a device synchronisation on both sides;
-    # the figure is the MEDIAN series (a short series on a fresh box is otherwise at the mercy of one hiccup)
-    R = args.repeats if args.repeats > 0 else (3 if K >= 200 else 7)
+    # W untimed warm-up steps start the filter (initial cloud, allocations, clocks) ...
+    pf.run(t[:W], y[:W], has[:W])
+    # ... and the timed leg CONTINUES it: R legs of exactly K more steps each (cssm_pf_ll_filter_more: no new cloud, the series
+    # goes on), every leg bracketed by a device synchronisation on both sides; the figure is the MEDIAN leg (a short leg on a
+    # fresh box is otherwise at the mercy of one hiccup).  A leg is the whole host call: records built and uploaded, 2 K
+    # launches enqueued, ll / ess read back.
     walls, loops = [], []
     ll = ess_t = None
-    for _ in range(R):
+    for r in range(R):
+        lo = W + r * K
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        ll, _, ess_t, _ = pf.run(t[:K], y[:K], has[:K])
+        ll, _, ess_t = pf.run_more(t[lo:lo + K], y[lo:lo + K], has[lo:lo + K])
         torch.cuda.synchronize()
         walls.append(time.perf_counter() - t0)
         loops.append(pf.last_loop_ms())
@@ -212,7 +217,7 @@ def run_single(args, emit=print):
                                 else "configs[0] model at bench size: poisson(brownianMotion(1)), d=1, ") +
                                f"N={n} particles, T={K} observations, systematic resampling every observation",
                    "particles_per_gpu": n, "observations": K, "latent_dim": d, "seed": 20260101},
-        "repeats": R, "value_is": "median over `repeats` timed K-step series", "wall_ms_each": [w * 1e3 for w in walls],
+        "repeats": R, "value_is": "median over `repeats` timed legs of K steps each, continuing the filter the warm-up steps started (cssm_pf_ll_filter_more)", "wall_ms_each": [w * 1e3 for w in walls],
         "roofline": roof,
         "kernels_us": kernels_us,
         "device_loop_ms": loop_ms, "ll": ll, "ess_last": int(ess_t[-1]),

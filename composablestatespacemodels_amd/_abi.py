@@ -79,6 +79,7 @@ SYMBOLS = [
     ("cssm_pf_propagate", C.c_int, [_h, C.c_double, C.c_double, C.c_int]),
     ("cssm_pf_adopt", C.c_int, [_h, _dp, C.c_double, C.c_int32]),
     ("cssm_pf_ll_filter", C.c_int, [_h, _dp, _dp, _u8p, C.c_size_t, _dp, _dp, _i32p]),
+    ("cssm_pf_ll_filter_more", C.c_int, [_h, _dp, _dp, _u8p, C.c_size_t, _dp, _dp, _i32p]),
     ("cssm_pf_filter", C.c_int, [_h, _dp, _dp, _u8p, C.c_size_t, _dp, _dp, _i32p, _dp]),
     ("cssm_pf_last_loop_ms", C.c_int, [_h, C.POINTER(C.c_float)]),
     ("cssm_pf_set_option", C.c_int, [_h, C.c_int, C.c_int]),

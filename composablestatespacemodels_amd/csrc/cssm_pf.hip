@@ -1035,7 +1035,7 @@ extern "C" int cssm_pf_adopt(cssm_pf* pf, const double* state_dN, double ll, int
 // ------------------------------------------------------------------------------------ batch API
 
 static int run_filter_once(cssm_pf* pf, const double* t, const double* y, const uint8_t* has, size_t T, double* ll_out,
-                           double* ll_t, int32_t* ess_t, double* path, bool* retry);
+                           double* ll_t, int32_t* ess_t, double* path, bool* retry, bool cont = false);
 
 // The series is enqueued without a host round trip per step, with the sums formed inside k_propagate relative to
 // each observation's reference level.  If the max of some step rules its level out (err bit 2; an outlying
@@ -1053,8 +1053,10 @@ static int run_filter(cssm_pf* pf, const double* t, const double* y, const uint8
   return rc;
 }
 
+// cont: the observations CONTINUE the filter from its current state (cssm_pf_ll_filter_more): no initial cloud is drawn, the
+// first time increment is taken from the handle's clock, observation s of this call is observation pf->step + s of the filter.
 static int run_filter_once(cssm_pf* pf, const double* t, const double* y, const uint8_t* has, size_t T, double* ll_out,
-                           double* ll_t, int32_t* ess_t, double* path, bool* retry) {
+                           double* ll_t, int32_t* ess_t, double* path, bool* retry, bool cont) {
   *retry = false;
   if (!pf || !t || !y) return fail(CSSM_EINVAL_ARG, "null argument");
   if (T < 1) return fail(CSSM_EINVAL_ARG, "empty data (the reference's minBy throws on an empty Vector)");
@@ -1062,15 +1064,21 @@ static int run_filter_once(cssm_pf* pf, const double* t, const double* y, const 
   HIP_TRY(hipSetDevice(pf->device));
   int rc = ensure_recs(pf, T);
   if (rc) return rc;
+  if (cont && (!pf->initialised || path)) return fail(CSSM_ESTATE, "continuing a filter needs an initialised handle (and records no path)");
   double t0 = t[0];
   for (size_t s = 1; s < T; ++s) if (t[s] < t0) t0 = t[s];     // data.minBy(_.t).t, model/ParticleFilter.scala:138
-  double tp = t0;
-  for (size_t s = 0; s < T; ++s) { build_rec(pf, tp, t[s], y[s], has ? has[s] : 1, (uint32_t)s, &pf->h_recs[s]); tp = t[s]; }
+  const uint32_t base = cont ? pf->step : 0u;                  // index of this call's first observation in the filter's series
+  double tp = cont ? pf->t : t0;
+  for (size_t s = 0; s < T; ++s) { build_rec(pf, tp, t[s], y[s], has ? has[s] : 1, base + (uint32_t)s, &pf->h_recs[s]); tp = t[s]; }
   rc = build_fsub(pf, 0, T, true);
   if (rc) return rc;
   HIP_TRY(hipMemcpyAsync(pf->d_recs, pf->h_recs, T * sizeof(StepRec), hipMemcpyHostToDevice, pf->stream));
-  rc = launch_init(pf, t0);
-  if (rc) return rc;
+  if (!cont) {
+    rc = launch_init(pf, t0);
+    if (rc) return rc;
+  }
+  // host-side state at the first observation of this call (launch_init: cur = 0, wparity = 0)
+  const int cur0 = pf->cur, wpar0 = pf->wparity;
   const int d = pf->d;
   if (path) {
     if (pf->path_cap < (T + 1) * (size_t)d) {
@@ -1086,7 +1094,7 @@ static int run_filter_once(cssm_pf* pf, const double* t, const double* y, const 
   }
   HIP_TRY(hipEventRecord(pf->ev0, pf->stream));
   SeriesPlan plan;
-  pf->last_series = series_plan(pf, &plan);
+  pf->last_series = !cont && series_plan(pf, &plan);
   if (pf->last_series) {
     // all T observations in one cooperative launch (cssm_series.hip.h); path entries 1 .. T-1 are recorded inside it, the
     // last one (no following propagate) by k_pick
@@ -1110,7 +1118,7 @@ static int run_filter_once(cssm_pf* pf, const double* t, const double* y, const 
     pf->batch_hold = uses_sums_kernel(pf);
     // (small clouds) the resampling of a weighted observation that another weighted observation follows is not launched:
     // the next observation's k_step does it on the way -- one launch per observation instead of two
-    const bool merge = step_eligible(pf) && (!path || fold);
+    const bool merge = !cont && step_eligible(pf) && (!path || fold);   // (k_step indexes ll_t by the observation's index in the filter's series)
     pf->no_fine = merge;   // (k_step consumes the propagate kernel's own unit sums)
     bool deferred = false;
     if (pf->pp_after.size() < T) pf->pp_after.resize(T);
@@ -1119,7 +1127,7 @@ static int run_filter_once(cssm_pf* pf, const double* t, const double* y, const 
       double* pick_out = (fold && s >= 1) ? pf->d_path + s * (size_t)d : nullptr;
       const uint32_t pick_slot = s >= 1 ? pf->h_recs[s - 1].pick : 0u;
       const bool defer_next = merge && weighted && s + 1 < T && pf->h_recs[s + 1].has_obs;
-      pf->h_step_for_resample = (uint32_t)s;
+      pf->h_step_for_resample = base + (uint32_t)s;
       if (deferred) rc = launch_merged_step(pf, pf->d_recs + s, pf->d_ll_t, pf->d_ess_t, pick_out, pick_slot);
       else rc = launch_propagate(pf, pf->d_recs + s, pick_out, pick_slot);
       pf->pp_after[s] = (uint8_t)pf->pp;
@@ -1142,21 +1150,21 @@ static int run_filter_once(cssm_pf* pf, const double* t, const double* y, const 
     HIP_TRY(hipStreamSynchronize(pf->stream));
     if (!(hh.err & 64u)) break;
     if (hh.err & 3u) break;            // NaN / unusable weights: reported below
-    const size_t sf = hh.fail_step;
-    if (sf >= T) return fail(CSSM_ESTATE, "held series reports observation %zu of %zu", sf, T);
+    const size_t sf = (size_t)hh.fail_step - base;              // (the record's index in this call)
+    if (hh.fail_step < base || sf >= T) return fail(CSSM_ESTATE, "held series reports observation %u; this call holds %u .. %zu", hh.fail_step, base, base + T - 1);
     hh.err &= ~64u; hh.fail_step = 0xffffffffu;
     HIP_TRY(hipMemcpyAsync(&pf->sc->err, &hh.err, sizeof(uint32_t), hipMemcpyHostToDevice, pf->stream));
     HIP_TRY(hipMemcpyAsync(&pf->sc->fail_step, &hh.fail_step, sizeof(uint32_t), hipMemcpyHostToDevice, pf->stream));
-    // host-side state right after the propagate of observation sf (launch_init: cur = 0, wparity = 0; every propagate
-    // flips cur, every weighted observation advances wparity)
-    pf->cur = (int)((sf + 1) & 1);
+    // host-side state right after the propagate of observation sf (every propagate flips cur, every weighted observation
+    // advances wparity)
+    pf->cur = (int)(((size_t)cur0 + sf + 1) & 1);
     pf->src = pf->state[pf->cur]; pf->src_stride = pf->stride; pf->anc_valid = false; pf->src2 = nullptr;
-    int wp = 0;
+    int wp = wpar0;
     for (size_t q = 0; q < sf; ++q) wp = (wp + (pf->h_recs[q].has_obs ? 1 : 0)) % CSSM_MAXSETS;
     pf->wparity = (wp + 1) % CSSM_MAXSETS;   // launch_resample(redo) steps it back to the set the observation's propagate used
     if (sf < pf->pp_after.size() && pf->pp != (int)pf->pp_after[sf]) swap_sets(pf);   // ... and the log-weights / unit sums it wrote
     pf->last_optimistic = true;
-    pf->h_step_for_resample = (uint32_t)sf;
+    pf->h_step_for_resample = base + (uint32_t)sf;
     rc = launch_resample(pf, pf->d_recs + sf, pf->d_ll_t, pf->d_ess_t, (uint32_t)sf, /*redo=*/true);
     if (rc) return rc;
     if (path && (!fold || sf + 1 == T))
@@ -1176,7 +1184,7 @@ static int run_filter_once(cssm_pf* pf, const double* t, const double* y, const 
   HIP_TRY(hipEventElapsedTime(&pf->last_ms, pf->ev0, pf->ev1));
   prof_collect(pf);
   if (pf->last_series && pf->profile && pf->d_ts) { rc = series_collect_phases(pf, T); if (rc) return rc; }
-  pf->t = t[T - 1]; pf->step = (uint32_t)T;
+  pf->t = t[T - 1]; pf->step = base + (uint32_t)T;
   if (h.err & 32u) return fail(CSSM_EHIP, "the series kernel met an ancestor index beyond the cloud (clamped, not dereferenced): internal error");
   if (h.err & 16u) return fail(CSSM_EHIP, "the grid barrier of the series kernel timed out (a block did not arrive); the series was abandoned");
   if ((h.err & 4u) && !(h.err & 1u) && !pf->safe_sums) { *retry = true; return CSSM_OK; }
@@ -1187,6 +1195,14 @@ static int run_filter_once(cssm_pf* pf, const double* t, const double* y, const 
 extern "C" int cssm_pf_ll_filter(cssm_pf* pf, const double* t, const double* y, const uint8_t* has_obs, size_t T,
                                  double* ll_out, double* ll_t, int32_t* ess_t) {
   return run_filter(pf, t, y, has_obs, T, ll_out, ll_t, ess_t, nullptr);
+}
+
+extern "C" int cssm_pf_ll_filter_more(cssm_pf* pf, const double* t, const double* y, const uint8_t* has_obs, size_t T,
+                                      double* ll_out, double* ll_t, int32_t* ess_t) {
+  bool retry = false;
+  int rc = run_filter_once(pf, t, y, has_obs, T, ll_out, ll_t, ess_t, nullptr, &retry, /*cont=*/true);
+  if (rc == CSSM_OK && retry) return fail(CSSM_ESTATE, "a continued series cannot be repeated from its start");   // (not reached: batch series are held in place)
+  return rc;
 }
 
 extern "C" int cssm_pf_filter(cssm_pf* pf, const double* t, const double* y, const uint8_t* has_obs, size_t T,

@@ -125,6 +125,24 @@ class NativePf:
         _abi.check(rc)
         return ll.value, ll_t, ess_t, path
 
+    def run_more(self, t, y, has=None):
+        """T MORE observations of the running filter (cssm_pf_ll_filter_more): no new cloud, the clock and the observation count
+        go on; returns (ll accumulated since initialisation, ll_t, ess_t) of this call's observations."""
+        t = np.ascontiguousarray(t, dtype=np.float64)
+        y = np.ascontiguousarray(y, dtype=np.float64)
+        T = len(t)
+        hp = None
+        if has is not None:
+            has = np.ascontiguousarray(has, dtype=np.uint8)
+            hp = _p(has, C.POINTER(C.c_uint8))
+        ll = C.c_double()
+        ll_t = np.zeros(T)
+        ess_t = np.zeros(T, dtype=np.int32)
+        rc = self.lib.cssm_pf_ll_filter_more(self._h, _p(t), _p(y), hp, T, C.byref(ll), _p(ll_t), _p(ess_t, C.POINTER(C.c_int32)))
+        self.generation += 1
+        _abi.check(rc)
+        return ll.value, ll_t, ess_t
+
     def last_loop_ms(self) -> float:
         ms = C.c_float()
         _abi.check(self.lib.cssm_pf_last_loop_ms(self._h, C.byref(ms)))

@@ -180,6 +180,15 @@ int cssm_pf_adopt(cssm_pf* pf, const double* state_dN, double ll, int32_t ess);
  * after each datum, ess_t[T].  No host synchronisation happens inside the loop. */
 int cssm_pf_ll_filter(cssm_pf* pf, const double* t, const double* y, const uint8_t* has_obs,
                       size_t T, double* ll_out, double* ll_t, int32_t* ess_t);
+/* The same for T MORE observations of a filter that is already running (initialised by cssm_pf_init / _init_from, or left
+ * behind by a batch run or by streaming steps): no initial cloud is drawn, the first time increment is taken from the
+ * handle's clock, and observation s of this call is observation (steps so far + s) of the filter -- what Flow.scan(init)
+ * (stepFilter) does with the next T elements of the stream (model/ParticleFilter.scala:163-166), without a host round trip
+ * per element.  *ll_out = the log-likelihood accumulated since the filter was initialised; ll_t / ess_t: this call's
+ * observations.  cssm_pf_ll_filter(t[0..a)) followed by cssm_pf_ll_filter_more(t[a..T)) leaves the same bits as
+ * cssm_pf_ll_filter(t[0..T)). */
+int cssm_pf_ll_filter_more(cssm_pf* pf, const double* t, const double* y, const uint8_t* has_obs, size_t T,
+                           double* ll_out, double* ll_t, int32_t* ess_t);
 
 /* filter (model/ParticleFilter.scala:152-158): as llFilter, and path[(T+1)*d] receives one
  * uniformly picked particle of the initial cloud and of the cloud after every datum

@@ -828,3 +828,48 @@ def test_full_size_configs_oracle_checked_on_slices(name, n, T, lgcp):
                 np.testing.assert_array_equal(o.logw(), lw[first:first + m], err_msg=f"step {s}, slice at {first}: log-weights")
         cloud = g.particles()
     g.close()
+
+
+# ----------------------------------------------------------------------------- continuing a batch run
+@pytest.mark.parametrize("name,n,whole,kind", [("c2_model", 3000, 0, 0), ("c2_model", 5 * 1024 + 3, 1, 0), ("c3_model", 4096, 0, 0),
+                                               ("c3_model", 3 * 1024, 1, 0), ("c1_model", 1000, 2, 0), ("linear_model", 2500, 0, 0),
+                                               ("c2_model", 2500, 0, 1), ("c2_model", 2500, 0, 2)])
+def test_ll_filter_more_continues_the_series_bit_for_bit(name, n, whole, kind):
+    """cssm_pf_ll_filter(t[:a]) then cssm_pf_ll_filter_more(t[a:b]), (t[b:]) = cssm_pf_ll_filter(t) = the oracle: ll, ll_t, ess_t,
+    ancestors, clouds -- with missing observations, outlying observations in the continued parts (held and redone with the
+    call's own record indices), in every launch geometry and with every native resampler (whose per-observation variates are
+    keyed by the observation's index in the FILTER's series)."""
+    model = getattr(cases, name)()
+    t, y, has = cases.poisson_counts(26, missing=0.15)
+    y = y.copy()
+    if name != "linear_model":
+        y[11] = 70.0; y[12] = 85.0; y[25] = 95.0; has[11] = has[12] = has[25] = 1
+    a, b = 9, 12
+    g = NativePf(model, n, cases.SEED); g.set_option(OPT_WHOLE_TILES, whole); g.set_option(2, kind)
+    g.run(t[:a], y[:a], has[:a])
+    l1 = g.run_more(t[a:b], y[a:b], has[a:b])
+    l2 = g.run_more(t[b:], y[b:], has[b:])
+    f = NativePf(model, n, cases.SEED); f.set_option(OPT_WHOLE_TILES, whole); f.set_option(2, kind)
+    fl, fll, fess, _ = f.run(t, y, has)
+    assert l2[0] == fl
+    np.testing.assert_array_equal(np.concatenate([l1[1], l2[1]]), fll[a:])
+    np.testing.assert_array_equal(np.concatenate([l1[2], l2[2]]), fess[a:])
+    np.testing.assert_array_equal(g.ancestors(), f.ancestors())
+    np.testing.assert_array_equal(g.particles(), f.particles())
+    np.testing.assert_array_equal(g.proposed(), f.proposed())
+    if kind == 0:
+        o = oracle.OraclePf(model.descriptor(), n, cases.SEED)
+        ol = o.filter(t, y, has)[0]
+        assert l2[0] == ol
+        np.testing.assert_array_equal(g.particles(), o.particles())
+    # ... and streaming steps continue from there
+    gs = g.step(27.0, 3.0, True); fs = f.step(27.0, 3.0, True)
+    assert gs == fs
+    g.close(); f.close()
+
+
+def test_ll_filter_more_needs_a_running_filter():
+    g = NativePf(cases.c1_model(), 100, 1)
+    with pytest.raises(Exception):
+        g.run_more(np.array([1.0]), np.array([1.0]))
+    g.close()
