@@ -1,6 +1,7 @@
 // cssm_pf.hip -- host side of libcssm_pf: the C ABI of include/cssm_pf.h over the gfx950
 // kernels of cssm_kernels.hip.h.  No torch, no CPU compute path: every entry point drives HIP.
 #include <hip/hip_runtime.h>
+#include <cstddef>
 
 #include <algorithm>
 #include <cmath>
@@ -795,6 +796,11 @@ static int launch_step(cssm_pf* pf, const StepRec* d_rec, int weighted, uint32_t
   return rc;
 }
 
+// The host reads the scalars BEHIND the max slots (err, ess, fail_step, gmax, ref, ll, the sums: ~120 bytes, not the 24 KiB of
+// slot lines in front of them -- that copy to pageable memory cost ~15 us per streaming step and per batch call).
+#define CSSM_SC_TAIL_OFF offsetof(Scalars, err)
+#define CSSM_SC_TAIL_ARGS(hp, scp) reinterpret_cast<char*>(hp) + CSSM_SC_TAIL_OFF, reinterpret_cast<const char*>(scp) + CSSM_SC_TAIL_OFF, sizeof(Scalars) - CSSM_SC_TAIL_OFF
+
 static int check_device_err(cssm_pf* pf, const Scalars& h) {
   if (h.err & 1u) return fail(CSSM_ENONFINITE, "a log-weight is NaN (the reference's breeze distribution constructor would throw)");
   if (h.err & 2u) return fail(CSSM_ENONFINITE, "all particle weights are zero or the maximum log-weight is not finite");
@@ -864,13 +870,13 @@ extern "C" int cssm_pf_step(cssm_pf* pf, double t, double obs, int has_obs, doub
   rc = launch_step(pf, pf->d_recs, weighted, pf->step);
   if (rc) return rc;
   Scalars h;
-  HIP_TRY(hipMemcpyAsync(&h, pf->sc, sizeof h, hipMemcpyDeviceToHost, pf->stream));
+  HIP_TRY(hipMemcpyAsync(CSSM_SC_TAIL_ARGS(&h, pf->sc), hipMemcpyDeviceToHost, pf->stream));
   HIP_TRY(hipStreamSynchronize(pf->stream));
   if (h.err == 4u) {   // the max ruled the reference level out: the log-weights are in place, form the sums again
     HIP_TRY(hipMemsetAsync(&pf->sc->err, 0, sizeof(uint32_t), pf->stream));
     rc = launch_resample(pf, pf->d_recs, nullptr, nullptr, 0, /*redo=*/true);
     if (rc) return rc;
-    HIP_TRY(hipMemcpyAsync(&h, pf->sc, sizeof h, hipMemcpyDeviceToHost, pf->stream));
+    HIP_TRY(hipMemcpyAsync(CSSM_SC_TAIL_ARGS(&h, pf->sc), hipMemcpyDeviceToHost, pf->stream));
     HIP_TRY(hipStreamSynchronize(pf->stream));
   }
   pf->t = t; pf->step++;
@@ -1011,7 +1017,7 @@ extern "C" int cssm_pf_propagate(cssm_pf* pf, double t, double obs, int has_obs)
   // nobody decodes this step's running max on the device: clear both slot sets for the next weighted step
   HIP_TRY(hipMemsetAsync(pf->sc->maxslot, 0, sizeof(pf->sc->maxslot), pf->stream));
   Scalars h;
-  HIP_TRY(hipMemcpyAsync(&h, pf->sc, sizeof h, hipMemcpyDeviceToHost, pf->stream));
+  HIP_TRY(hipMemcpyAsync(CSSM_SC_TAIL_ARGS(&h, pf->sc), hipMemcpyDeviceToHost, pf->stream));
   HIP_TRY(hipStreamSynchronize(pf->stream));
   pf->wparity = 0;
   pf->t = t; pf->step++;
@@ -1146,7 +1152,7 @@ static int run_filter_once(cssm_pf* pf, const double* t, const double* y, const 
     pf->batch_hold = false;
     if (!may_hold) break;
     Scalars hh;
-    HIP_TRY(hipMemcpyAsync(&hh, pf->sc, sizeof hh, hipMemcpyDeviceToHost, pf->stream));
+    HIP_TRY(hipMemcpyAsync(CSSM_SC_TAIL_ARGS(&hh, pf->sc), hipMemcpyDeviceToHost, pf->stream));
     HIP_TRY(hipStreamSynchronize(pf->stream));
     if (!(hh.err & 64u)) break;
     if (hh.err & 3u) break;            // NaN / unusable weights: reported below
@@ -1176,7 +1182,7 @@ static int run_filter_once(cssm_pf* pf, const double* t, const double* y, const 
   HIP_TRY(hipEventRecord(pf->ev1, pf->stream));
   HIP_TRY(hipGetLastError());
   Scalars h;
-  HIP_TRY(hipMemcpyAsync(&h, pf->sc, sizeof h, hipMemcpyDeviceToHost, pf->stream));
+  HIP_TRY(hipMemcpyAsync(CSSM_SC_TAIL_ARGS(&h, pf->sc), hipMemcpyDeviceToHost, pf->stream));
   if (ll_t) HIP_TRY(hipMemcpyAsync(ll_t, pf->d_ll_t, T * 8, hipMemcpyDeviceToHost, pf->stream));
   if (ess_t) HIP_TRY(hipMemcpyAsync(ess_t, pf->d_ess_t, T * 4, hipMemcpyDeviceToHost, pf->stream));
   if (path) HIP_TRY(hipMemcpyAsync(path, pf->d_path, (T + 1) * (size_t)d * 8, hipMemcpyDeviceToHost, pf->stream));
@@ -1562,7 +1568,7 @@ extern "C" int cssm_pf_interpolate(cssm_pf* pf, const double* t, const double* y
         weighted[s + 1] = 1;
       }
     }
-    if (!rc && hipMemcpyAsync(&h, pf->sc, sizeof h, hipMemcpyDeviceToHost, pf->stream) != hipSuccess) rc = fail(CSSM_EHIP, "scalars");
+    if (!rc && hipMemcpyAsync(CSSM_SC_TAIL_ARGS(&h, pf->sc), hipMemcpyDeviceToHost, pf->stream) != hipSuccess) rc = fail(CSSM_EHIP, "scalars");
     if (!rc && hipStreamSynchronize(pf->stream) != hipSuccess) rc = fail(CSSM_EHIP, "forward pass");
     if (rc || !(h.err & 4u) || (h.err & 1u)) break;
   }
@@ -1649,7 +1655,7 @@ extern "C" int cssm_resample(int kind, const double* w, size_t n, double u, uint
       hipLaunchKernelGGL(k_multinomial, dim3(grid_for(n, 256, kGridCap)), dim3(256), 0, st, d_cum, (uint64_t)n, seed, step, d_anc);
   }
   RS_TRY(hipGetLastError());
-  RS_TRY(hipMemcpyAsync(&hs, sc, sizeof hs, hipMemcpyDeviceToHost, st));
+  RS_TRY(hipMemcpyAsync(CSSM_SC_TAIL_ARGS(&hs, sc), hipMemcpyDeviceToHost, st));
   RS_TRY(hipMemcpyAsync(anc, d_anc, n * 4, hipMemcpyDeviceToHost, st));
   RS_TRY(hipStreamSynchronize(st));
   if (hs.S_tot.lo == 0 && hs.S_tot.hi == 0) rc = fail(CSSM_ENONFINITE, "all weights are zero (the reference divides by a zero total)");
@@ -1911,7 +1917,7 @@ extern "C" int cssm_pf_shard_resume(cssm_pf* pf, uint32_t* fail_step_out) {
   rc = bounded_sync(pf);   // (first: a copy into pageable memory would wait for the stream without a bound)
   if (rc) return rc;
   Scalars h;
-  HIP_TRY(hipMemcpyAsync(&h, pf->sc, sizeof h, hipMemcpyDeviceToHost, pf->stream));
+  HIP_TRY(hipMemcpyAsync(CSSM_SC_TAIL_ARGS(&h, pf->sc), hipMemcpyDeviceToHost, pf->stream));
   HIP_TRY(hipStreamSynchronize(pf->stream));
   if (!(h.err & 8u) || h.fail_step == 0xffffffffu || h.fail_step >= pf->snaps.size())
     return fail(CSSM_ESTATE, "no resumable capacity miss is recorded");
@@ -1987,7 +1993,7 @@ extern "C" int cssm_pf_shard_status(cssm_pf* pf, double* ll_out, int32_t* ess_ou
   rc = bounded_sync(pf);   // (first: a copy into pageable memory would wait for the stream without a bound)
   if (rc) return rc;
   Scalars h;
-  HIP_TRY(hipMemcpyAsync(&h, pf->sc, sizeof h, hipMemcpyDeviceToHost, pf->stream));
+  HIP_TRY(hipMemcpyAsync(CSSM_SC_TAIL_ARGS(&h, pf->sc), hipMemcpyDeviceToHost, pf->stream));
   if (need && pf->d_need && T <= pf->need_cap) HIP_TRY(hipMemcpyAsync(need, pf->d_need, T * 4, hipMemcpyDeviceToHost, pf->stream));
   HIP_TRY(hipStreamSynchronize(pf->stream));
   if (ll_out) *ll_out = h.ll;
@@ -2248,7 +2254,7 @@ extern "C" int cssm_pf_shard_result(cssm_pf* pf, double* ll_out, int32_t* ess_ou
   int rc = shard_check(pf);
   if (rc) return rc;
   Scalars h;
-  HIP_TRY(hipMemcpyAsync(&h, pf->sc, sizeof h, hipMemcpyDeviceToHost, pf->stream));
+  HIP_TRY(hipMemcpyAsync(CSSM_SC_TAIL_ARGS(&h, pf->sc), hipMemcpyDeviceToHost, pf->stream));
   HIP_TRY(hipStreamSynchronize(pf->stream));
   if (ll_out) *ll_out = h.ll;
   if (ess_out) *ess_out = h.ess;
