@@ -139,6 +139,7 @@ struct cssm_pf {
   // host staging (pinned)
   StepRec* h_recs = nullptr;
   size_t h_recs_cap = 0;
+  Scalars* h_sc = nullptr;     // pinned: the streaming step's scalars land here without a staging copy
   // filter state
   double t = 0.0;
   uint32_t step = 0;
@@ -547,6 +548,7 @@ extern "C" void cssm_pf_destroy(cssm_pf* pf) {
                   pf->d_m0, pf->d_sd0, pf->d_logtab, pf->d_sync, pf->d_ts, pf->d_fsub, pf->cum, pf->d_recs, pf->d_ll_t, pf->d_ess_t, pf->d_path, pf->cand, pf->cand_end, pf->cand_idx, pf->d_bounds, pf->d_xch, pf->d_need};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   if (pf->h_recs) (void)hipHostFree(pf->h_recs);
+  if (pf->h_sc) (void)hipHostFree(pf->h_sc);
   for (hipEvent_t e : pf->prof_ev) (void)hipEventDestroy(e);
   if (pf->ev0) (void)hipEventDestroy(pf->ev0);
   if (pf->ev1) (void)hipEventDestroy(pf->ev1);
@@ -869,7 +871,8 @@ extern "C" int cssm_pf_step(cssm_pf* pf, double t, double obs, int has_obs, doub
   const int weighted = pf->h_recs[0].has_obs;
   rc = launch_step(pf, pf->d_recs, weighted, pf->step);
   if (rc) return rc;
-  Scalars h;
+  if (!pf->h_sc) HIP_TRY(hipHostMalloc((void**)&pf->h_sc, sizeof(Scalars), hipHostMallocDefault));
+  Scalars& h = *pf->h_sc;
   HIP_TRY(hipMemcpyAsync(CSSM_SC_TAIL_ARGS(&h, pf->sc), hipMemcpyDeviceToHost, pf->stream));
   HIP_TRY(hipStreamSynchronize(pf->stream));
   if (h.err == 4u) {   // the max ruled the reference level out: the log-weights are in place, form the sums again
@@ -1181,7 +1184,8 @@ static int run_filter_once(cssm_pf* pf, const double* t, const double* y, const 
   }
   HIP_TRY(hipEventRecord(pf->ev1, pf->stream));
   HIP_TRY(hipGetLastError());
-  Scalars h;
+  if (!pf->h_sc) HIP_TRY(hipHostMalloc((void**)&pf->h_sc, sizeof(Scalars), hipHostMallocDefault));
+  Scalars& h = *pf->h_sc;
   HIP_TRY(hipMemcpyAsync(CSSM_SC_TAIL_ARGS(&h, pf->sc), hipMemcpyDeviceToHost, pf->stream));
   if (ll_t) HIP_TRY(hipMemcpyAsync(ll_t, pf->d_ll_t, T * 8, hipMemcpyDeviceToHost, pf->stream));
   if (ess_t) HIP_TRY(hipMemcpyAsync(ess_t, pf->d_ess_t, T * 4, hipMemcpyDeviceToHost, pf->stream));
