@@ -451,12 +451,8 @@ static int prop_items(int d) { return d <= 2 ? CSSM_PROP_IT_LO : (d <= 8 ? CSSM_
 
 // k_propagate blocks per 1024-particle unit on a single-GPU handle: one tile of the kernel per block below 2^20 particles
 static uint32_t auto_split(const cssm_pf* pf) {
-  if (pf->sharded || pf->sup != 1) return 1u;
-  // two particles per thread (d <= 8): half tiles up to 2^20 particles inclusive (2048 sub-unit sums, all requested up front by
-  // k_offspring: 32.8 vs 34.2 us per observation at 2^20, d = 3, same process); one particle per thread (d >= 9): quarter tiles
-  // below 2^20 (at 2^20 itself 4096 sub-unit sums cost k_offspring more than the reduce launch of the large clouds: 61.7 vs 57.3)
-  if (prop_items(pf->d) == 1) return pf->n < CSSM_SPLIT_MAX_N ? 4u : 1u;
-  return pf->n <= CSSM_SPLIT_MAX_N ? 2u : 1u;
+  if (pf->sharded || pf->sup != 1 || pf->n >= CSSM_SPLIT_MAX_N) return 1u;
+  return prop_items(pf->d) == 1 ? 4u : 2u;   // one tile of the kernel: half of 1024 (two particles per thread), a quarter (one)
 }
 
 static int alloc_handle(cssm_pf* pf) {
@@ -470,12 +466,13 @@ static int alloc_handle(cssm_pf* pf) {
   pf->nunits = (pf->ntiles + pf->sup - 1) / pf->sup;
   {   // k_propagate: a block owns unit/split particles, a multiple of its CSSM_BLOCK * IT particles per iteration
     // (the kernel pipelines its tiles through LDS and wants several of them: one block per unit)
-    // Clouds of up to 2^20 particles on one GPU: one tile of the kernel per block.  Up to ~2^18 particles every SIMD holds at
+    // Clouds below 2^20 particles on one GPU: one tile of the kernel per block.  Up to ~2^18 particles every SIMD holds at
     // most one or two waves and a kernel's duration is the length of ONE wave's dependent instruction stream (~3 ns per
     // instruction, tools/launch_floor.hip; the launch itself is 3.1 us): one pair of particles per thread instead of two, in the
     // single-tile instantiation k_propagate_self<..., ONE> that requests everything position-dependent in its first round of
     // loads and draws its normals while the gathered rows travel.  Per observation, bench model, same process (tools/ab_fine.py):
-    // 17.1 -> 12.6 us at N = 100 000, 21.9 -> 19.3 at 2^19, 28.1 -> 25.8 at 3 * 2^18, 34.2 -> 32.8 at 2^20.
+    // 17.1 -> 12.6 us at N = 100 000, 21.9 -> 19.3 at 2^19, 28.1 -> 25.8 at 3 * 2^18.  From 2^20 particles on: whole units per
+    // block (launch_propagate).
     pf->split = auto_split(pf);
   }
   const size_t nsums = (size_t)(pf->ntiles > 4 * pf->nunits ? pf->ntiles : 4 * pf->nunits);   // (up to four sub-units per unit)
@@ -622,21 +619,31 @@ static bool uses_sums_kernel(const cssm_pf* pf) {
   return pf->opt_fused && !pf->safe_sums && pf->obs_kind != CSSM_OBS_LGCP && pf->resampler != CSSM_RESAMPLE_MULTINOMIAL;
 }
 
-// Whether k_propagate runs its single-tile kernel on a cloud of 2^20 particles and more (one tile per block, k_reduce_units
-// behind it).  The single-tile kernel carries no software-pipeline state -- no spill, 5-6 waves per SIMD instead of 3-4 -- and
-// the wider the state the more that is worth; the reduce launch costs ~5 us per weighted observation.  In-process A/B
-// (tools/ab_fine.py, per observation, single-tile vs software-pipelined): d = 3: 33.6 vs 34.7 us at 2^20, 92.6 vs 93.0 at 2^22,
-// 336 vs 332 at 2^24 (a tie: the bench model keeps two launches); d = 4: 36.8 vs 38.9, 110.5 vs 111.8, 399 vs 402; d = 5:
-// 39.4 vs 44.7 at 2^20, 121 vs 137 at 2^22; d = 6: 42.8 vs 49.2; d = 8: 168 vs 200 at 2^22; d = 9 (C3): 194 vs 203 at 2^22, 57.3 vs
-// 61.7 at 2^20; d = 16: 287 vs 343.  At d <= 2 the software-pipelined kernel keeps a few per cent (d = 2, 2^22: 75.8 vs 77.2).
-// (Timings taken on different boxes differ by +-5 %: a first comparison across boxes had promised 13 % at d = 3.)
+// Launch geometry of the sums kernels on clouds of 2^20 particles and more (one GPU; whole units of 1024 * sup particles).
+// In-process A/B (tools/ab_opt.py option 6, tools/ab_fine.py; per observation; boxes of this pool differ by +-5 %, only runs of
+// one process compare):
+//   LOOP    one block per unit running the single-tile-style kernel tile after tile (k_propagate_self<..., ONE>: no software-
+//           pipeline state, no spill, 5-6 waves per SIMD; co-resident waves cover the round trips).  While a block has at most
+//           CSSM_LOOP_MAX_TILES tiles it beats everything else: d = 3: 31.0 vs 33.2 (half tiles) / 32.5 (pipelined) us at 2^20,
+//           50.7 vs 53.3 at 2^21, 90.0 vs 93.0 at 2^22, a tie at 2^23, 376 vs 368 at 2^24; d = 1: 23.6 vs 26.9 at 2^20, a tie at 2^22,
+//           252 vs 241 at 2^24; d = 4: 108 vs 120 at 2^22; d = 9: 57.6 vs 63.4 at 2^20, 105 vs 114 at 2^21; d = 16 at 2^22 (16 tiles): 329 vs 313.
+//   FINE    one tile per block + k_reduce_units (~5 us): larger clouds of d >= 4 (d = 9: 194 vs 203 us pipelined at 2^22; d = 16: 287 vs 343)
+//   PIPE    one block per unit, the software-pipelined kernel: larger clouds of d <= 3 (a tie with FINE at d = 3, a few per cent better at d <= 2)
 #ifndef CSSM_FINE_MIN_D
 #define CSSM_FINE_MIN_D 4
 #endif
-static bool uses_fine(const cssm_pf* pf) {
-  if (pf->sharded || pf->split != 1 || pf->no_fine || pf->opt_whole == 2 || pf->first != 0 || pf->n != pf->n_global) return false;
-  if (pf->resampler == CSSM_RESAMPLE_MULTINOMIAL) return false;
-  return pf->opt_whole == 1 ? pf->d >= 3 : pf->d >= CSSM_FINE_MIN_D;
+#ifndef CSSM_LOOP_MAX_TILES
+#define CSSM_LOOP_MAX_TILES 8
+#endif
+enum { GEO_PIPE = 0, GEO_LOOP = 1, GEO_FINE = 2 };
+static int large_geometry(const cssm_pf* pf) {
+  if (pf->sharded || pf->split != 1 || pf->first != 0 || pf->n != pf->n_global || pf->resampler == CSSM_RESAMPLE_MULTINOMIAL) return GEO_PIPE;
+  if (pf->opt_whole == 1) return GEO_LOOP;
+  if (pf->opt_whole == 2) return GEO_PIPE;
+  if (pf->opt_whole == 3) return pf->no_fine ? GEO_LOOP : GEO_FINE;
+  const uint32_t tiles = pf->sup * (uint32_t)CSSM_TILE / (uint32_t)(CSSM_BLOCK * prop_items(pf->d));
+  if (tiles <= CSSM_LOOP_MAX_TILES) return GEO_LOOP;
+  return (pf->d >= CSSM_FINE_MIN_D && !pf->no_fine) ? GEO_FINE : GEO_PIPE;
 }
 
 static int launch_propagate(cssm_pf* pf, const StepRec* d_rec, double* pick_out = nullptr, uint32_t pick_slot = 0) {
@@ -647,7 +654,8 @@ static int launch_propagate(cssm_pf* pf, const StepRec* d_rec, double* pick_out 
   const uint32_t* anc = pf->anc_valid ? pf->anc : nullptr;
   const int do_sums = uses_sums_kernel(pf) ? 1 : 0;
   pf->last_optimistic = do_sums != 0;
-  const bool fine = do_sums && uses_fine(pf);
+  const int geo = do_sums ? large_geometry(pf) : GEO_PIPE;
+  const bool fine = geo == GEO_FINE;
   const uint64_t unit_particles = (uint64_t)pf->sup * CSSM_TILE;
   if (fine) chunk = (uint64_t)CSSM_BLOCK * prop_items(pf->d);   // (divides the unit: 1024 * sup)
   const int grid = (int)((pf->n + chunk - 1) / chunk);
@@ -673,6 +681,7 @@ static int launch_propagate(cssm_pf* pf, const StepRec* d_rec, double* pick_out 
   a.chunk = chunk; a.do_sums = do_sums; a.subS = fine ? pf->fineS : pf->tileS; a.subS2 = fine ? pf->fineS2 : pf->tileS2;
   a.pick_out = pick_out; a.pick_slot = pick_slot;
   a.fsub = pf->lgcp_tdep ? pf->d_fsub : nullptr;
+  a.one = (chunk == (uint64_t)CSSM_BLOCK * prop_items(pf->d)) || geo == GEO_LOOP;
   switch (pf->d) {
 #define CSSM_CASE_PROP(D) case D: cssm_prop_launch_d##D(a); break;
     CSSM_CASE_PROP(1) CSSM_CASE_PROP(2) CSSM_CASE_PROP(3) CSSM_CASE_PROP(4) CSSM_CASE_PROP(5) CSSM_CASE_PROP(6) CSSM_CASE_PROP(7) CSSM_CASE_PROP(8)
@@ -1334,7 +1343,7 @@ extern "C" int cssm_pf_set_option(cssm_pf* pf, int option, int value) {
   if (option == CSSM_OPT_ONE_LAUNCH) { pf->opt_step = value < 0 ? -1 : (value ? 1 : 0); return CSSM_OK; }
   if (option == CSSM_OPT_WHOLE_TILES) {   // launch geometry only: the arrays hold up to four sub-units per unit either way
     if (pf->sharded) return fail(CSSM_ESTATE, "sharded handles always run whole tiles");
-    pf->opt_whole = value < 0 ? 0 : (value > 2 ? 2 : value);
+    pf->opt_whole = value < 0 ? 0 : (value > 3 ? 3 : value);
     pf->split = value ? 1u : auto_split(pf);
     return CSSM_OK;
   }

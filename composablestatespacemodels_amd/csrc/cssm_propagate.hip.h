@@ -386,7 +386,29 @@ __device__ __forceinline__ void propagate_range(
       for (int r = 0; r < IT; ++r)
         if (i0 + r < n) lw_lds[i0 + r - range_lo] = lw[r];
     }
-    if (ONE) break;                                               // (the range is this one tile)
+    if (ONE) {   // further tiles of the range in the same way: no software pipeline, co-resident waves cover the round trips
+      const uint32_t nb = base + stride;
+      if (nb < n) {
+        load_idx(nb, jp);
+        unpack_idx(nb, jp, jn);
+        stage_issue(jn);
+        if (IT == 2) {
+          normals_pair_half<D, 0>(seed, gid0 + nb + threadIdx.x * IT, step, tab, zz);
+          normals_pair_half<D, 1>(seed, gid0 + nb + threadIdx.x * IT, step, tab, zz);
+        } else {
+          double z1[D];
+          draw_normals<D>(seed, gid0 + nb + threadIdx.x, step, CSSM_STREAM_STEP, tab, z1);
+#pragma unroll
+          for (int q = 0; q < D; ++q) zz[q % (ONE ? IT * D : 1)] = z1[q];
+        }
+#pragma unroll
+        for (int q = 0; q < IT * D; ++q) asm volatile("" : "+v"(zz[q % (ONE ? IT * D : 1)]));
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        stage_read(x);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      }
+      continue;
+    }
     // advance the pipeline
     if (STAGE) {
       if (base + stride < n) {

@@ -239,14 +239,14 @@ int cssm_pf_last_loop_ms(cssm_pf* pf, float* ms_out);
  * bit-identical either way.  Measured: NOT faster than two launches (14.9 vs 14.4 us per observation at N = 100 000, 34.0
  * vs 32.5 at 2^20) -- a launch costs 3.1 us, the parents' end slots a block has to rebuild cost as much; see DESIGN.md 5c. */
 #define CSSM_OPT_ONE_LAUNCH 5
-/* CSSM_OPT_WHOLE_TILES (default 0): a verification switch over the launch geometry (results are bit-identical in every setting).
- * By default the propagate kernel is the single-tile kernel (one tile -- 512 particles for d <= 8, 256 for d >= 9 -- per block;
- * everything position-dependent requested in the first round of loads, the normals drawn while the gathered rows travel) for
- * clouds below 2^20 particles, where k_offspring reads one pair of sums per block, and for larger clouds of latent dimension
- * d >= 4, where k_reduce_units folds the blocks' sums into <= 1024 unit sums; larger clouds with d <= 3 run whole units of
- * 1024 * k particles per block and the software-pipelined kernel (a tie at d = 3, a few per cent better at d <= 2).
- * 1 = the geometry of the large clouds (single-tile kernel + k_reduce_units for d >= 3) at every size: lets it be checked
- * against the oracle at sizes the oracle finishes in seconds; 2 = whole units and the software-pipelined kernels for every d. */
+/* CSSM_OPT_WHOLE_TILES (default 0): a verification switch over the launch geometry of the propagate kernel (results are
+ * bit-identical in every setting).  Automatic (0): clouds below 2^20 particles run ONE tile of the kernel per block (512
+ * particles for d <= 8, 256 for d >= 9: the single-tile kernel requests everything position-dependent in its first round of
+ * loads and draws the normals while the gathered rows travel; k_offspring totals one pair of sums per block); from 2^20 on a
+ * block owns a whole unit of 1024 * k particles and runs (1) the same kernel tile after tile while a unit has at most 8
+ * tiles, else (2) the software-pipelined kernel (d <= 3) or (3) one tile per block again with k_reduce_units folding the
+ * blocks' sums into <= 1024 unit sums (d >= 4).  1 / 2 / 3 force that geometry at every size: the kernels of the large
+ * clouds can then be checked against the oracle at sizes the oracle finishes in seconds. */
 #define CSSM_OPT_WHOLE_TILES 6
 int cssm_pf_set_option(cssm_pf* pf, int option, int value);
 

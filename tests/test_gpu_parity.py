@@ -620,15 +620,15 @@ def test_contract_functions_on_the_device_match_the_host():
             np.testing.assert_array_equal(z, oracle.c_paired_normals(cases.SEED, first, 3, 0, d, 1001))
 
 
-OPT_WHOLE_TILES = 6   # CSSM_OPT_WHOLE_TILES: the launch geometry and kernels of clouds of 2^20 particles and more, at any size
+OPT_WHOLE_TILES = 6   # CSSM_OPT_WHOLE_TILES: 1 / 2 / 3 = the launch geometries and kernels of clouds of 2^20 particles and more, at any size
 
 
 @pytest.mark.parametrize("d", list(range(1, 17)))
 def test_every_dimension_streaming_and_batch_bit_exact(d):
     """One k_propagate instantiation per latent dimension (particles per thread 2 / 1, 16- or 8-byte LDS staging, pair-shared
-    normals for even IT) and launch geometry -- one tile per block with the single-tile kernels (clouds below 2^20), whole
-    1024-particle tiles with the software-pipelined kernels (larger clouds; forced here) -- each against the oracle, with a
-    ragged last tile."""
+    normals for even IT) and launch geometry -- one tile per block (clouds below 2^20) and the three geometries of larger clouds,
+    forced here: whole units with the single-tile-style kernel looping over their tiles, whole units with the software-pipelined
+    kernel, one tile per block + k_reduce_units -- each against the oracle, with a ragged last tile."""
     model = cases.dim_model(d)
     assert model.descriptor().dim == d if hasattr(model.descriptor(), "dim") else True
     t, y, has = cases.poisson_counts(6, missing=0.2)
@@ -636,7 +636,7 @@ def test_every_dimension_streaming_and_batch_bit_exact(d):
     n = 5 * 1024 + 77
     o = oracle.OraclePf(model.descriptor(), n, cases.SEED)
     ol, oll, oess, opath = o.filter(t, y, has, want_path=True)
-    for whole in (0, 1):
+    for whole in (0, 1, 2, 3):
         g = NativePf(model, n, cases.SEED)
         g.set_option(OPT_WHOLE_TILES, whole)
         assert g.d == d
@@ -652,13 +652,13 @@ def test_every_dimension_streaming_and_batch_bit_exact(d):
 
 @pytest.mark.parametrize("name", ["c1", "c2", "c3", "linear", "negbin", "zip", "bernoulli", "studentt", "beta"])
 def test_whole_tile_kernels_at_test_sizes(name):
-    """The kernels large clouds run (CSSM_OPT_WHOLE_TILES = 1), every observation density, batch and streaming, with outliers
-    absent and a missing observation -- against the oracle AND against the default single-tile path."""
+    """The kernels large clouds run (CSSM_OPT_WHOLE_TILES = 1, 2, 3), every observation density, batch and streaming, with
+    outliers absent and a missing observation -- against the oracle AND against the default single-tile path."""
     model, t, y, has = cases.golden_case(name, 12, missing=0.1)
     n = 3 * 1024 + 5
     o = oracle.OraclePf(model.descriptor(), n, cases.SEED)
     ol, oll, oess, _ = o.filter(t, y, has)
-    for whole in (1, 0):
+    for whole in (1, 2, 3, 0):
         g = NativePf(model, n, cases.SEED)
         g.set_option(OPT_WHOLE_TILES, whole)
         gl, gll, gess, _ = g.run(t, y, has)
@@ -833,7 +833,7 @@ def test_full_size_configs_oracle_checked_on_slices(name, n, T, lgcp):
 # ----------------------------------------------------------------------------- continuing a batch run
 @pytest.mark.parametrize("name,n,whole,kind", [("c2_model", 3000, 0, 0), ("c2_model", 5 * 1024 + 3, 1, 0), ("c3_model", 4096, 0, 0),
                                                ("c3_model", 3 * 1024, 1, 0), ("c1_model", 1000, 2, 0), ("linear_model", 2500, 0, 0),
-                                               ("c2_model", 2500, 0, 1), ("c2_model", 2500, 0, 2)])
+                                               ("c2_model", 2500, 0, 1), ("c2_model", 2500, 0, 2), ("c3_model", 5 * 1024 + 9, 3, 0), ("c2_model", 4 * 1024 + 1, 3, 0)])
 def test_ll_filter_more_continues_the_series_bit_for_bit(name, n, whole, kind):
     """cssm_pf_ll_filter(t[:a]) then cssm_pf_ll_filter_more(t[a:b]), (t[b:]) = cssm_pf_ll_filter(t) = the oracle: ll, ll_t, ess_t,
     ancestors, clouds -- with missing observations, outlying observations in the continued parts (held and redone with the

@@ -82,11 +82,11 @@ def test_one_launch_every_dimension(d):
 
 def test_one_launch_range_and_full_bench_size():
     """Not taken unless asked for; -1 = clouds of up to 2^18 particles; 1 = whenever eligible = at most 1024 units of sums: up to
-    2^19 particles with the half-tile units of the default geometry, 2^20 with whole units (CSSM_OPT_WHOLE_TILES = 2), never beyond."""
+    2^19 particles with the half-tile units of clouds below 2^20, and 2^20 itself (whole units: 1024 of them), never beyond."""
     model = cases.c2_model()
     t, y, has = cases.poisson_counts(8, missing=0.1)
     for n, opt, whole, expect in ((50_000, 0, 0, False), (50_000, -1, 0, True), (1 << 18, -1, 0, True), ((1 << 18) + 1, -1, 0, False),
-                                  (1 << 19, 1, 0, True), ((1 << 19) + 1, 1, 0, False), (1 << 20, 1, 0, False), (1 << 20, 1, 2, True),
+                                  (1 << 19, 1, 0, True), ((1 << 19) + 1, 1, 0, False), (1 << 20, 1, 0, True), (1 << 20, 1, 2, True),
                                   ((1 << 20) + 1, 1, 2, False)):
         a = _run(model, n, t, y, has, opt, want_path=False, whole=whole)
         assert (a["merged"] > 0) == expect, (n, opt, whole, a["merged"])
