@@ -681,7 +681,7 @@ static int launch_propagate(cssm_pf* pf, const StepRec* d_rec, double* pick_out 
   a.chunk = chunk; a.do_sums = do_sums; a.subS = fine ? pf->fineS : pf->tileS; a.subS2 = fine ? pf->fineS2 : pf->tileS2;
   a.pick_out = pick_out; a.pick_slot = pick_slot;
   a.fsub = pf->lgcp_tdep ? pf->d_fsub : nullptr;
-  a.one = (chunk == (uint64_t)CSSM_BLOCK * prop_items(pf->d)) || geo == GEO_LOOP;
+  a.one = (chunk == (uint64_t)CSSM_BLOCK * prop_items(pf->d)) ? 1 : (geo == GEO_LOOP ? 2 : 0);
   switch (pf->d) {
 #define CSSM_CASE_PROP(D) case D: cssm_prop_launch_d##D(a); break;
     CSSM_CASE_PROP(1) CSSM_CASE_PROP(2) CSSM_CASE_PROP(3) CSSM_CASE_PROP(4) CSSM_CASE_PROP(5) CSSM_CASE_PROP(6) CSSM_CASE_PROP(7) CSSM_CASE_PROP(8)

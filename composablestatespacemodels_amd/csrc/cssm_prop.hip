@@ -16,12 +16,18 @@
 // the single-tile instantiation of the small clouds (one pair per thread for d <= 8, one particle for d >= 9)
 template <int D, int IT> struct OneTile {
   static void go(const PropLaunch& a) {
-#define PROP_ONE(OB)                                                                                                              \
-  k_propagate_self<D, IT, OB, true, true><<<dim3(a.grid), dim3(CSSM_BLOCK), 0, a.stream>>>(a.src, a.src_stride, a.anc, a.dst, a.dst_stride, \
+#define PROP_ONE(OB, ONEV)                                                                                                        \
+  k_propagate_self<D, IT, OB, true, ONEV><<<dim3(a.grid), dim3(CSSM_BLOCK), 0, a.stream>>>(a.src, a.src_stride, a.anc, a.dst, a.dst_stride, \
       a.logw, a.n, a.seed, a.rec, a.mk, a.sc, a.slot_set, a.logtab, a.chunk, a.subS, a.subS2, a.pick_out, a.pick_slot)
-    if (a.obs == CSSM_OBS_POISSON) PROP_ONE(CSSM_OBS_POISSON);
-    else if (a.obs == CSSM_OBS_GAUSSIAN) PROP_ONE(CSSM_OBS_GAUSSIAN);
-    else PROP_ONE(-1);
+    if (a.one == 1) {          // the block's range is one tile
+      if (a.obs == CSSM_OBS_POISSON) PROP_ONE(CSSM_OBS_POISSON, 1);
+      else if (a.obs == CSSM_OBS_GAUSSIAN) PROP_ONE(CSSM_OBS_GAUSSIAN, 1);
+      else PROP_ONE(-1, 1);
+    } else {                   // tile after tile
+      if (a.obs == CSSM_OBS_POISSON) PROP_ONE(CSSM_OBS_POISSON, 2);
+      else if (a.obs == CSSM_OBS_GAUSSIAN) PROP_ONE(CSSM_OBS_GAUSSIAN, 2);
+      else PROP_ONE(-1, 2);
+    }
 #undef PROP_ONE
   }
 };

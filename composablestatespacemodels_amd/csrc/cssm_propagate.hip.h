@@ -59,7 +59,9 @@ struct PropAcc {
 // ONE (small clouds): the range is a single tile, and the tile's normal variates -- which depend on nothing but (seed, particle,
 // observation) -- are drawn WHILE the ancestor indices and the gathered rows are on their way: with one wave per SIMD nobody
 // else hides those two round trips (~1.7 us of a kernel whose whole body takes ~5).  Same arithmetic, another order.
-template <int D, bool LGCP, int IT, int OBS, bool SUMS, bool COH, bool LANC = false, bool ONE = false>
+// (ONE = 1: the range is a single tile; ONE = 2: the same body tile after tile -- a separate instantiation: folding the loop into
+// the single-tile kernel cost it 18 VGPRs and 10 % at d = 9)
+template <int D, bool LGCP, int IT, int OBS, bool SUMS, bool COH, bool LANC = false, int ONE = 0>
 __device__ __forceinline__ void propagate_range(
     const double* __restrict__ src, size_t src_stride, const uint32_t* __restrict__ anc,
     double* __restrict__ dst, size_t dst_stride, double* __restrict__ logw, uint64_t gid0,
@@ -386,7 +388,8 @@ __device__ __forceinline__ void propagate_range(
       for (int r = 0; r < IT; ++r)
         if (i0 + r < n) lw_lds[i0 + r - range_lo] = lw[r];
     }
-    if (ONE) {   // further tiles of the range in the same way: no software pipeline, co-resident waves cover the round trips
+    if (ONE == 1) break;                                          // (the range is this one tile)
+    if (ONE == 2) {   // further tiles of the range in the same way: no software pipeline, co-resident waves cover the round trips
       const uint32_t nb = base + stride;
       if (nb < n) {
         load_idx(nb, jp);
@@ -497,7 +500,7 @@ __global__ __launch_bounds__(CSSM_BLOCK, (PropWaves<D, SUMS>::value)) void k_pro
 // the transition code is not even compiled), no second gather source, no sub-step table, no pick.  The generic kernel's
 // ~24 arguments overflow the scalar registers into vector-register lanes (88 v_readlane per tile).
 // ONE: the block's range is one tile (small clouds, half a tile per block): see propagate_range
-template <int D, int IT, int OBS, bool SUMS, bool ONE = false>
+template <int D, int IT, int OBS, bool SUMS, int ONE = 0>
 __global__ __launch_bounds__(CSSM_BLOCK, (ONE ? 2 : PropWaves<D, SUMS>::value)) void k_propagate_self(
     const double* __restrict__ src, size_t src_stride, const uint32_t* __restrict__ anc, double* __restrict__ dst, size_t dst_stride,
     double* __restrict__ logw, uint64_t n_arg, uint64_t seed, const StepRec* __restrict__ rec, ModelK mk, Scalars* __restrict__ sc,
