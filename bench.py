@@ -175,7 +175,7 @@ def run_single(args, emit=print):
     if os.path.exists(tpath):
         try:
             tj = json.load(open(tpath))
-            traffic = tj.get("k_propagate_bytes_per_launch")
+            traffic = tj.get("k_propagate_bytes_per_launch", tj.get("k_propagate_self_bytes_per_launch"))
             traffic_source = ("NOT measured in this run: copied from profiles/traffic_latest.json (rocprofv3 --pmc passes of "
                               + str(tj.get("date", "an earlier session")) + ", " + str(tj.get("source", "profiles/")) + ")")
         except Exception:
