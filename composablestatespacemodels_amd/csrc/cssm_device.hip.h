@@ -18,11 +18,12 @@
 //   k_offspring   unit prefix + totals (every block sums the <= 1K unit sums itself), ll and ess (:127-128), per tile
 //                 a DPP wave scan -> cumulative weight C_j -> end slot cnt(C_j); every particle writes its own run of
 //                 slots into anc (single GPU), or the end slots are kept for the exchange   model/Resampling.scala:36-58,69
-//   launch geometry (single GPU): clouds of up to 2^20 particles (d >= 9: below 2^20) and larger clouds of
-//                 d >= 4 run k_propagate_self<..., ONE> -- ONE tile per block, everything position-dependent requested in the
-//                 first round of loads, the normals drawn while the gathered rows travel; the former store one pair of sums per
-//                 block (k_offspring totals up to 2048 of them), the latter are followed by k_reduce_units (blocks' sums ->
-//                 <= 1024 unit sums); other large clouds run whole units per block and the software-pipelined kernel
+//   launch geometry (single GPU): k_propagate_self<..., ONE> has no software pipeline -- everything
+//                 position-dependent requested in the first round of loads, the normals drawn while the gathered rows travel.
+//                 Clouds below 2^20 particles: ONE = 1, one tile per block, one pair of sums per block (k_offspring totals up to
+//                 4096 of them); from 2^20 on a block owns a whole unit of 1024 * k particles and runs the same body tile after
+//                 tile (ONE = 2) while a unit has at most 8 tiles; beyond that the software-pipelined kernel (ONE = 0, d <= 3) or
+//                 one tile per block again with k_reduce_units behind it (blocks' sums -> <= 1024 unit sums, d >= 4)
 //   k_step        (opt-in) k_offspring for the block's own slots + k_propagate in one launch
 //   sharded only  k_boundary_pack + k_offspring_expand_spec (single-collective exchange); k_scan_tiles / k_global_sums,
 //                 k_pack, k_expand (exact exchange: candidates -> slots)
