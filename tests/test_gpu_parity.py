@@ -795,7 +795,12 @@ def test_filter_with_a_host_resample_function():
     assert fi.llFilter(data, n) == fi.llFilter(data, n)                # deterministic under the handle's seed
 
 
-@pytest.mark.parametrize("name,n,T,lgcp", [("c3_model", 1 << 22, 4, 0), ("c4_model", 1 << 24, 3, 2), ("c2_model", 100_000, 6, 0)])
+@pytest.mark.parametrize("name,n,T,lgcp", [("c3_model", 1 << 22, 4, 0), ("c4_model", 1 << 24, 3, 2), ("c2_model", 100_000, 6, 0),
+                                           # the launch geometries of the large clouds at sizes where they are the default: whole units of
+                                           # 3 and 4 tiles of 1024 looped over (odd unit size; the 8-tile limit), the software-pipelined
+                                           # kernel beyond it (ragged N), one tile per block + k_reduce_units for a wide state (ragged N)
+                                           ("c2_model", 3 << 20, 3, 0), ("c2_model", 1 << 22, 3, 0), ("c1_model", (1 << 23) + 5, 3, 0),
+                                           ("max_dim_model", (1 << 21) + 77, 3, 0)])
 def test_full_size_configs_oracle_checked_on_slices(name, n, T, lgcp):
     """BASELINE configs 3 (d = 9, N = 2^22), 4 (LGCP, N = 2^24) and 5's filter (N = 100 000) at their FULL particle counts, checked
     against the oracle where the one-thread oracle can go: slices of the cloud.  Variates are keyed by the global particle id,
