@@ -51,6 +51,17 @@ void CSSM_CAT(cssm_prop_launch_d, CSSM_PROP_D)(const PropLaunch& a) {
     if (a.obs == CSSM_OBS_POISSON) { if (a.sums) PROP_SELF(CSSM_OBS_POISSON, true); else PROP_SELF(CSSM_OBS_POISSON, false); }
     else if (a.obs == CSSM_OBS_GAUSSIAN) { if (a.sums) PROP_SELF(CSSM_OBS_GAUSSIAN, true); else PROP_SELF(CSSM_OBS_GAUSSIAN, false); }
     else { if (a.sums) PROP_SELF(-1, true); else PROP_SELF(-1, false); }
+  } else if (!a.lgcp && CSSM_PROP_SELF && a.sums && a.do_sums && a.shard_slim) {
+    // the sharded filter (single-collective exchange): the slim launch; tile after tile while a unit has few tiles
+#define PROP_SHARD(OB, ONEV)                                                                                               \
+  k_propagate_shard<D, IT, OB, ONEV><<<dim3(a.grid), dim3(CSSM_BLOCK), 0, a.stream>>>(a.src, a.src_stride, a.anc, a.dst, a.dst_stride, a.logw, \
+      a.n, a.gid0, a.seed, a.rec, a.mk, a.sc, a.src2, a.n_split, a.logtab, a.chunk, a.subS, a.subS2)
+    if (a.one == 2) {
+      if (a.obs == CSSM_OBS_POISSON) PROP_SHARD(CSSM_OBS_POISSON, 2); else if (a.obs == CSSM_OBS_GAUSSIAN) PROP_SHARD(CSSM_OBS_GAUSSIAN, 2); else PROP_SHARD(-1, 2);
+    } else {
+      if (a.obs == CSSM_OBS_POISSON) PROP_SHARD(CSSM_OBS_POISSON, 0); else if (a.obs == CSSM_OBS_GAUSSIAN) PROP_SHARD(CSSM_OBS_GAUSSIAN, 0); else PROP_SHARD(-1, 0);
+    }
+#undef PROP_SHARD
   } else if (a.lgcp) {
     PROP_GO(true, -1, false);
   } else if (a.obs == CSSM_OBS_POISSON) {

@@ -500,12 +500,15 @@ __global__ __launch_bounds__(CSSM_BLOCK, (PropWaves<D, SUMS>::value)) void k_pro
 // the transition code is not even compiled), no second gather source, no sub-step table, no pick.  The generic kernel's
 // ~24 arguments overflow the scalar registers into vector-register lanes (88 v_readlane per tile).
 // ONE: the block's range is one tile (small clouds, half a tile per block): see propagate_range
-template <int D, int IT, int OBS, bool SUMS, int ONE = 0>
-__global__ __launch_bounds__(CSSM_BLOCK, (ONE ? 2 : PropWaves<D, SUMS>::value)) void k_propagate_self(
+// (the body, shared with the sharded filter's slim launch k_propagate_shard: gid0 = the rank's first global particle, src2 /
+//  n_split = the rows received from the neighbouring ranks; both compile-time constants -- 0, nullptr -- in k_propagate_self)
+template <int D, int IT, int OBS, bool SUMS, int ONE>
+__device__ __forceinline__ void propagate_block(
     const double* __restrict__ src, size_t src_stride, const uint32_t* __restrict__ anc, double* __restrict__ dst, size_t dst_stride,
-    double* __restrict__ logw, uint64_t n_arg, uint64_t seed, const StepRec* __restrict__ rec, ModelK mk, Scalars* __restrict__ sc,
+    double* __restrict__ logw, uint64_t n_arg, uint64_t seed, const StepRec* __restrict__ rec, const ModelK& mk, Scalars* __restrict__ sc,
     int slot_set, const double* __restrict__ logtab, uint64_t chunk,
-    cssm_u128* __restrict__ subS, cssm_u128* __restrict__ subS2, double* __restrict__ pick_out, uint32_t pick_slot) {
+    cssm_u128* __restrict__ subS, cssm_u128* __restrict__ subS2, double* __restrict__ pick_out, uint32_t pick_slot,
+    const uint64_t gid0, const double* __restrict__ src2, const uint32_t n_split) {
   // SUMS: the block also forms its fixed-point sums of exp(w - c) (subS / subS2, one entry per block) and, for `filter`,
   // records the state sampleOne picked after the previous observation (pick_out / pick_slot; see k_propagate)
   __shared__ double s_max[CSSM_BLOCK / 64];
@@ -544,7 +547,7 @@ __global__ __launch_bounds__(CSSM_BLOCK, (ONE ? 2 : PropWaves<D, SUMS>::value)) 
   if (held & (4u | 8u | 64u)) return;
   __shared__ __attribute__((aligned(16))) unsigned char s_stage[PropStage<D, IT>::bytes];
   PropAcc acc;
-  propagate_range<D, false, IT, OBS, SUMS, false, false, ONE>(src, src_stride, anc, dst, dst_stride, logw, 0ull, seed, rec, mk, nullptr, 0, 0u, tab,
+  propagate_range<D, false, IT, OBS, SUMS, false, false, ONE>(src, src_stride, anc, dst, dst_stride, logw, gid0, seed, rec, mk, src2, 0, n_split, tab,
                                                               range_lo, n, SUMS ? 1 : 0, SUMS ? pick_out : nullptr, pick_slot, nullptr, s_stage, acc,
                                                               0xffffffffu, nullptr, nullptr, ONE ? &jp_early : nullptr);
   if (!rec->has_obs) return;
@@ -572,6 +575,30 @@ __global__ __launch_bounds__(CSSM_BLOCK, (ONE ? 2 : PropWaves<D, SUMS>::value)) 
     atomicMax(&sc->maxslot[((size_t)slot_set * CSSM_MAXSLOTS + blockIdx.x % CSSM_MAXSLOTS) * CSSM_SLOT_STRIDE],
               (unsigned long long)cssm_order_key(m));
   }
+}
+
+template <int D, int IT, int OBS, bool SUMS, int ONE = 0>
+__global__ __launch_bounds__(CSSM_BLOCK, (ONE ? 2 : PropWaves<D, SUMS>::value)) void k_propagate_self(
+    const double* __restrict__ src, size_t src_stride, const uint32_t* __restrict__ anc, double* __restrict__ dst, size_t dst_stride,
+    double* __restrict__ logw, uint64_t n_arg, uint64_t seed, const StepRec* __restrict__ rec, ModelK mk, Scalars* __restrict__ sc,
+    int slot_set, const double* __restrict__ logtab, uint64_t chunk,
+    cssm_u128* __restrict__ subS, cssm_u128* __restrict__ subS2, double* __restrict__ pick_out, uint32_t pick_slot) {
+  propagate_block<D, IT, OBS, SUMS, ONE>(src, src_stride, anc, dst, dst_stride, logw, n_arg, seed, rec, mk, sc, slot_set, logtab, chunk, subS, subS2,
+                                         pick_out, pick_slot, 0ull, nullptr, 0u);
+}
+
+// The sharded filter's slim launch (single-collective exchange: the sums are always formed, the rows received from the two
+// neighbouring ranks are read in place -- src2 = the receive buffer, rows of D + 1 doubles, indices >= n_split --, max-slot set
+// 0, an even first global particle: whole pairs per thread): the same body behind 18 arguments instead of the generic
+// kernel's 24.  ONE = 2: tile after tile (units of at most CSSM_LOOP_MAX_TILES tiles); ONE = 0: software-pipelined.
+template <int D, int IT, int OBS, int ONE>
+__global__ __launch_bounds__(CSSM_BLOCK, (ONE ? 2 : PropWaves<D, true>::value)) void k_propagate_shard(
+    const double* __restrict__ src, size_t src_stride, const uint32_t* __restrict__ anc, double* __restrict__ dst, size_t dst_stride,
+    double* __restrict__ logw, uint64_t n_arg, uint64_t gid0, uint64_t seed, const StepRec* __restrict__ rec, ModelK mk,
+    Scalars* __restrict__ sc, const double* __restrict__ src2, uint32_t n_split, const double* __restrict__ logtab, uint64_t chunk,
+    cssm_u128* __restrict__ subS, cssm_u128* __restrict__ subS2) {
+  propagate_block<D, IT, OBS, true, ONE>(src, src_stride, anc, dst, dst_stride, logw, n_arg, seed, rec, mk, sc, 0, logtab, chunk, subS, subS2,
+                                         nullptr, 0u, gid0, src2, n_split);
 }
 
 // ------------------------------------------------------------------------------------ one launch per observation
