@@ -683,10 +683,10 @@ static int launch_propagate(cssm_pf* pf, const StepRec* d_rec, double* pick_out 
   a.fsub = pf->lgcp_tdep ? pf->d_fsub : nullptr;
   a.one = (chunk == (uint64_t)CSSM_BLOCK * prop_items(pf->d)) ? 1 : (geo == GEO_LOOP ? 2 : 0);
   // sharded handle on the single-collective exchange (received rows read in place: src2_stride == 0) or before its first exchange:
-  // slim launch, tile after tile while a unit has at most CSSM_LOOP_MAX_TILES tiles; whole pairs per thread need an even first id
+  // slim launch, tile after tile while a unit has at most CSSM_LOOP_MAX_TILES tiles; whole pairs per thread (d <= 8) need an even first id
   a.shard_slim = pf->sharded && do_sums && !a.lgcp && (a.src2 == nullptr || a.src2_stride == 0) && a.fsub == nullptr && pick_out == nullptr &&
-                 (pf->first & 1ull) == 0ull && a.slot_set == 0 && prop_items(pf->d) == 2;
-  if (a.shard_slim && pf->sup * (uint32_t)CSSM_TILE / (uint32_t)(CSSM_BLOCK * 2) <= CSSM_LOOP_MAX_TILES) a.one = 2;
+                 ((pf->first & 1ull) == 0ull || prop_items(pf->d) == 1) && a.slot_set == 0;
+  if (a.shard_slim && pf->sup * (uint32_t)CSSM_TILE / (uint32_t)(CSSM_BLOCK * prop_items(pf->d)) <= CSSM_LOOP_MAX_TILES) a.one = 2;
   switch (pf->d) {
 #define CSSM_CASE_PROP(D) case D: cssm_prop_launch_d##D(a); break;
     CSSM_CASE_PROP(1) CSSM_CASE_PROP(2) CSSM_CASE_PROP(3) CSSM_CASE_PROP(4) CSSM_CASE_PROP(5) CSSM_CASE_PROP(6) CSSM_CASE_PROP(7) CSSM_CASE_PROP(8)
