@@ -138,8 +138,6 @@ def run_single(args, emit=print):
     pf = NativePf(model, n, 20260101, device=0)
     if args.fused is not None:
         pf.set_option(3, args.fused)   # CSSM_OPT_FUSED_SUMS (experiment switch; the default is the library's)
-    if args.series is not None:
-        pf.set_option(4, args.series)  # CSSM_OPT_SERIES_KERNEL
     d = pf.d
     torch.cuda.synchronize()
     # W untimed warm-up steps start the filter (initial cloud, allocations, clocks) ...
@@ -161,7 +159,6 @@ def run_single(args, emit=print):
     wall = float(np.median(walls))
     loop_ms = float(np.median(loops))
     per, pair_s, prof_raw = _kernel_profile(pf, t, y, has, K, loop_ms)
-    used_series, phases, _ = pf.series_phases()
     lib = pf.lib
     pf.close()
     # on-box streaming ceiling (plain 16-byte-per-lane copy, 1 GiB each way: far beyond the 256 MB Infinity Cache)
@@ -180,33 +177,11 @@ def run_single(args, emit=print):
                               + str(tj.get("date", "an earlier session")) + ", " + str(tj.get("source", "profiles/")) + ")")
         except Exception:
             traffic = None
-    if used_series:
-        # ONE launch ran the whole series: the dominant kernel is k_series, a launch processes N x K particle-steps, and the
-        # algorithmic bytes of a particle-step are the whole step's (32 d + 24 -- gather + propagate + weight
-        # 16 d + 8, resample 12, gather 16 d + 4; the kernel itself moves less: log-weights never leave the CU)
-        ms, cnt = prof_raw["k_series"]
-        launch_s = ms / max(cnt, 1) * 1e-3
-        alg = (32 * d + 24) * n * K
-        roof = {"bound": "hbm", "kernel": f"k_series<{d},POISSON> (persistent: all {K} observations in one cooperative launch), N={n}",
-                "achieved": alg / launch_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": alg / launch_s / 1e9 / HBM_PEAK_GBS,
-                "algorithmic_bytes_per_launch": alg, "algorithmic_bytes_per_particle_step": 32 * d + 24,
-                "particle_steps_per_launch": n * K, "avg_launch_us": launch_s * 1e6, "launches": cnt,
-                "timing": "HIP events on the launch stream around the k_series launch of a K-step series (a pass of its own, profiling on)"}
-        if copy_gbs:
-            roof["copy_ceiling"] = copy_gbs
-            roof["frac_of_copy_ceiling"] = roof["achieved"] / copy_gbs
-        pP, pX, pO, pB = [float(v) for v in phases]
-        roof["phases_us"] = {"propagate_weight_sums": pP, "exchange_barrier": pX, "offspring_ancestors": pO, "closing_barrier": pB,
-                             "source": "timestamps of block 0 inside the kernel (100 MHz counter), average over the weighted observations"}
-        roof["phase_propagate"] = {"algorithmic_bytes_per_particle": 16 * d + 8, "achieved": (16 * d + 8) * n / (pP * 1e-6) / 1e9,
-                                   "frac": (16 * d + 8) * n / (pP * 1e-6) / 1e9 / HBM_PEAK_GBS, "unit": "GB/s"}
-        kernels_us = {"k_series_per_observation": launch_s * 1e6 / K}
-    else:
-        avg_s, cnt, raw_s = per["k_propagate"]
-        roof = _roofline(f"k_propagate<{d},...> (gather + propagate + weight + log-sum-exp sums), N={n}", d, n, avg_s, cnt, raw_s, pair_s, copy_gbs)
-        roof["timing"] = ("HIP events on the launch stream around every k_propagate launch of a K-step series, minus what a bracketing "
-                          "event pair adds: (sum of all bracketed kernel times - device time of the same loop without brackets) / brackets")
-        kernels_us = {k: v[0] * 1e6 for k, v in per.items()}
+    avg_s, cnt, raw_s = per["k_propagate"]
+    roof = _roofline(f"k_propagate<{d},...> (gather + propagate + weight + log-sum-exp sums), N={n}", d, n, avg_s, cnt, raw_s, pair_s, copy_gbs)
+    roof["timing"] = ("HIP events on the launch stream around every k_propagate launch of a K-step series, minus what a bracketing "
+                      "event pair adds: (sum of all bracketed kernel times - device time of the same loop without brackets) / brackets")
+    kernels_us = {k: v[0] * 1e6 for k, v in per.items()}
     roof["traffic"] = traffic
     roof["traffic_source"] = traffic_source
     out = {
@@ -397,7 +372,6 @@ def main():
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-16m", action="store_true", help="skip the roofline_16m leg")
     ap.add_argument("--fused", type=int, default=None, help="CSSM_OPT_FUSED_SUMS override (single GPU)")
-    ap.add_argument("--series", type=int, default=None, help="CSSM_OPT_SERIES_KERNEL override (single GPU): 0 = per-observation kernels")
     ap.add_argument("--model", default="c2", choices=["c2", "c1"], help="c2: the bench workload (BASELINE configs[1], d = 3); c1: Poisson-Brownian (configs[0], d = 1) -- profiling runs only")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="gloo: CPU rehearsal of the N-rank path with the test-only oracle shard")
     ap.add_argument("--launch-timeout", type=float, default=1500.0, help="seconds the self-launched ranks may take")

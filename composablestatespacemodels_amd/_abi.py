@@ -85,8 +85,6 @@ SYMBOLS = [
     ("cssm_pf_set_option", C.c_int, [_h, C.c_int, C.c_int]),
     ("cssm_pf_profile", C.c_int, [_h, C.c_int]),
     ("cssm_pf_profile_read", C.c_int, [_h, _dp, _u64p]),
-    ("cssm_pf_series_phases", C.c_int, [_h, C.POINTER(C.c_int), _dp, _u64p]),
-    ("cssm_pf_series_stamps", C.c_int, [_h, _u64p, C.c_size_t, _u32p, _u32p]),
     ("cssm_pf_num_particles", C.c_uint64, [_h]),
     ("cssm_pf_dim", C.c_int32, [_h]),
     ("cssm_pf_get_particles", C.c_int, [_h, _dp]),

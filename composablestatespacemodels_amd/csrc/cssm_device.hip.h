@@ -24,7 +24,6 @@
 //                 4096 of them); from 2^20 on a block owns a whole unit of 1024 * k particles and runs the same body tile after
 //                 tile (ONE = 2) while a unit has at most 8 tiles; beyond that the software-pipelined kernel (ONE = 0, d <= 3) or
 //                 one tile per block again with k_reduce_units behind it (blocks' sums -> <= 1024 unit sums, d >= 4)
-//   k_step        (opt-in) k_offspring for the block's own slots + k_propagate in one launch
 //   sharded only  k_boundary_pack + k_offspring_expand_spec (single-collective exchange); k_scan_tiles / k_global_sums,
 //                 k_pack, k_expand (exact exchange: candidates -> slots)
 // Cross-lane traffic is DPP, not ds_bpermute (5 vs 25 cycles per move on MI355X, tools/instr_rate.hip).
@@ -33,8 +32,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
-#include "../../include/cssm_numerics.h"
-#include "../../include/cssm_pf.h"
+#include "cssm_records.h"
 
 #define CSSM_BLOCK 256
 #ifndef CSSM_PROP_IT_MID
@@ -43,63 +41,18 @@
 #define CSSM_ITEMS 4
 #define CSSM_TILE (CSSM_BLOCK * CSSM_ITEMS) /* 1024 particles per tile */
 
-// f-map modes per component (host-built from the leaf list; oracle: gamma_of)
-#define FM_SKIP 0
-#define FM_START 1 /* first used component of a leaf: acc = c*x  */
-#define FM_ADD 2   /* acc += c*x                                 */
-
-// Per-model constants, passed BY VALUE (kernarg -> SGPRs; every branch on them is wave-uniform).
-// One byte per latent component: bits 0-1 CSSM_SDE_*, bits 2-3 FM_*, bit 4 closes its leaf, bit 5 leaf is
-// the leftmost one.  Packed four to a word so that the whole struct costs 6 SGPRs (66 unpacked made the
-// kernel spill scalars through v_writelane/v_readlane).
-struct ModelK {
-  int32_t d;
-  int32_t obs_kind;
-  uint32_t comp[CSSM_MAX_DIM / 4];
-#ifdef CSSM_EXPERIMENT_FIXED_C2   /* experiment: the bench model's per-component flags as compile-time constants */
-  __host__ __device__ __forceinline__ uint32_t byte(int k) const { return k == 0 ? 0x36u : (k == 1 ? 0x06u : 0x1au); }
-#else
-  __host__ __device__ __forceinline__ uint32_t byte(int k) const { return (comp[k >> 2] >> ((k & 3) * 8)) & 0xffu; }
-#endif
-  __host__ __device__ __forceinline__ int kind(int k) const { return (int)(byte(k) & 3u); }
-  __host__ __device__ __forceinline__ int fmode(int k) const { return (int)((byte(k) >> 2) & 3u); }
-  __host__ __device__ __forceinline__ bool leaf_end(int k) const { return (byte(k) >> 4) & 1u; }
-  __host__ __device__ __forceinline__ bool first_leaf(int k) const { return (byte(k) >> 5) & 1u; }
-};
-
-// Per-observation record, built on the host (everything that depends only on (t, y)).
-struct StepRec {
-  double y;       // count models: (double)trunc(y); otherwise y
-  double c[4];    // per-observation constants of the density (see build_rec / logdens)
-  double cdf;     // Student-t: degrees of freedom as double
-  double u;       // the one uniform of systematic resampling
-  double dt;      // time increment (LGCP: the sub-step delta)
-  double ref;     // reference level of the observation (cssm_ref_level; NaN: always rescale by the max)
-  int32_t has_obs;
-  int32_t n_sub;  // LGCP sub-steps (0: dt == 0, weight 0, state kept)
-  uint32_t pick;  // sampleOne index for `filter`
-  uint32_t step;  // observation index (Philox counter word 2)
-  double coef[CSSM_MAX_DIM][4]; // transition coefficients per component
-  double fco[CSSM_MAX_DIM];     // f coefficients c_k(t)
-  double t_obs;                 // the observation's time (LGCP with a time-dependent f: the sub-step clock starts here)
-  uint32_t fsub_off;            // LGCP with a time-dependent f: where this observation's n_sub x d coefficients c_k(tau_s) start
-  uint32_t pad2_;               //   in the handle's sub-step table (doubles)
-};
-
 // Device scalars of a handle.
 #define CSSM_MAXSLOTS 64
 #define CSSM_SLOT_STRIDE 16 /* u64 words: one 128-byte line per slot */
 #define CSSM_MAXSETS 3
-#define CSSM_STEP_UNITS 1024 /* unit sums one block of k_step scans (four per thread) */
 struct Scalars {
   // Order keys of the running max log-weight, sharded over CSSM_MAXSLOTS cache lines, in three sets: weighted
-  // observation s uses set s % 3; the kernel that resamples it clears the sets it neither reads nor has written into
-  // (k_offspring: both others; k_step, which reads set s and collects the max of observation s + 1 in set s + 1: the third).
+  // observation s uses set s % 3; the kernel that resamples it (k_offspring) clears the other two, so no reset kernel exists.
   unsigned long long maxslot[CSSM_MAXSETS * CSSM_MAXSLOTS * CSSM_SLOT_STRIDE];
   uint32_t err;              // bit0: NaN log-weight, bit1: all weights zero / max not finite,
                              // bit2: the reference level was unusable and the sums must be formed again (host retries)
                              // bit3: (sharded) the exchange capacity did not cover some rank's slots at step fail_step
-                             // bit4: series kernel: grid barrier timed out; bit5: series kernel: wild ancestor index (clamped)
+                             // (bits 4, 5: unused)
                              // bit6: batch series on hold at fail_step: its reference level was ruled out, the host redoes its sums
   int32_t ess;
   uint32_t fail_step;        // first observation whose exchange did not fit (0xffffffff: none); see k_offspring_expand_spec
@@ -382,14 +335,6 @@ __device__ __forceinline__ void lds_dma4(const void* g, uint32_t lds_base) {
   asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %0, off" : : "v"(g), "s"(lds_base) : "memory");
 }
 
-// The same with agent scope (sc1): the source was written by another block earlier in the same launch (series kernel).
-__device__ __forceinline__ void lds_dma16_sc1(const double* g, uint32_t lds_base) {
-  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off sc1" : : "v"(g), "s"(lds_base) : "memory");
-}
-__device__ __forceinline__ void lds_dma4_sc1(const void* g, uint32_t lds_base) {
-  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %0, off sc1" : : "v"(g), "s"(lds_base) : "memory");
-}
-
 // How k_propagate's two-particles-per-thread instantiations (d = 3 .. 8) store their bulk outputs (state rows,
 // log-weights), one 16-byte store per lane and row, contiguous across the wave.  0: plain stores (dirty lines stay in
 // the L2 and are written back when the kernel ends); 1: non-temporal; 2: write-through at agent scope (sc1); 3: sc0 sc1.
@@ -421,18 +366,6 @@ __device__ __forceinline__ void bulk_store2(double* p, double a, double b) {
 #else
   *reinterpret_cast<double2*>(p) = make_double2(a, b);
 #endif
-}
-
-// max over the CSSM_MAXSLOTS shards of the running max log-weight
-__device__ __forceinline__ double decode_slots(const Scalars* __restrict__ sc, int set) {
-  unsigned long long k = 0ull;
-  const unsigned long long* base = sc->maxslot + (size_t)set * CSSM_MAXSLOTS * CSSM_SLOT_STRIDE;
-#pragma unroll 8
-  for (int s = 0; s < CSSM_MAXSLOTS; ++s) {
-    const unsigned long long v = base[s * CSSM_SLOT_STRIDE];
-    k = (v > k) ? v : k;
-  }
-  return cssm_order_unkey(k);
 }
 
 // ll += max + log(mean(w1)) (:127, :522-524); ess = floor(1 / sum (w1/tot)^2) (:128, :431-434)
@@ -478,36 +411,6 @@ __device__ __forceinline__ void load_tile_weights(const double* __restrict__ log
   weights_from_raw(v, gmax, raw, w1, tab);
 }
 
-// End slot of a particle under systematic resampling = cnt(C_j) of the contract, C_j = `run` / total (treeEcdf,
-// model/Resampling.scala:52-58,69).  Fast path: p = S_j / S_tot * N - u evaluated in fp64 has an absolute error
-// < N * 2^-49.5 slots (two conversions, one quotient, one fma), and the contract's own roundings move a decision by
-// < N * 2^-51 slots; whenever p is farther than eps = N * 2^-46 from an integer, floor(p) + 1 IS the contract's count.
-// Otherwise (probability 2 eps per particle) the exact predicate is evaluated.  (k_offspring's loop states the same
-// expressions; k_step uses this function for the unit boundaries and for the particles.)
-struct SlotMap {
-  double totd, scale, u, nd, eps, inv_n;
-  uint64_t n;
-  bool pow2;
-  int force_exact;
-  __device__ __forceinline__ void set(const cssm_u128& tot, double u_, uint64_t n_, int force) {
-    totd = cssm_u128_to_double(tot); n = n_; nd = (double)n_; scale = nd / totd; eps = nd * 0x1.0p-46; u = u_;
-    inv_n = 1.0 / (double)n_; pow2 = (n_ & (n_ - 1)) == 0; force_exact = force;
-  }
-};
-__device__ __forceinline__ uint32_t sys_end_slot(const cssm_u128& run, const SlotMap& m) {
-  const double sd = cssm_fma((double)run.hi, 0x1.0p64, (double)run.lo);
-  const double pp = cssm_fma(sd, m.scale, -m.u);
-  const double fl = __builtin_floor(pp);
-  const double fr = pp - fl;
-  double cnt = fl + 1.0;
-  cnt = (cnt < 0.0) ? 0.0 : cnt;
-  cnt = (cnt > m.nd) ? m.nd : cnt;
-  const bool safe = (fr > m.eps) && (fr < 1.0 - m.eps) && !m.force_exact;
-  if (safe) return (uint32_t)cnt;
-  const double C = cssm_u128_to_double(run) / m.totd;
-  return (uint32_t)(m.pow2 ? cssm_sys_count_pow2(C, m.u, m.n, m.inv_n) : cssm_sys_count(C, m.u, m.n));
-}
-
 // inclusive max-scan across the 64 lanes (values >= 0; a lane without a DPP source reads 0)
 __device__ __forceinline__ uint32_t wave_scan_max_u32(uint32_t v) {
 #define CSSM_MX(CTRL, RM) { const uint32_t o = dpp0<CTRL, RM>(v); v = (o > v) ? o : v; }
@@ -524,87 +427,16 @@ __device__ __forceinline__ void store_anc4_sc1(uint32_t* p, uint32_t a, uint32_t
 }
 
 
-#define CSSM_RUN_CHUNK 2048   /* resampling slots assembled in LDS at a time (8 KiB) */
-
-// findAllInTreeMap (model/Resampling.scala:36-46) for one tile of CSSM_TILE particles: thread t holds the end slots e[0..3]
-// of its four consecutive particles first_idx .. first_idx + 3 and the end slot `prev` of the particle before them; the
-// tile's particles own the slots [lo, hi) (uniform; already clipped to what this launch may write).  The ancestor indices
-// of those slots are assembled in LDS, 2048 at a time -- every particle drops its index + 1 at the first slot of its run,
-// an inclusive max-scan fills the runs (indices grow with the slots) -- and leave as 32 contiguous bytes per thread
-// (256-byte aligned chunks), so that HBM sees whole lines instead of one 4-byte write per slot (round 1: 1.38x the
-// algorithmic write traffic).  SC1: write-through stores (another block, or the next kernel's first wave, reads them).
-// anc is indexed by slot - slot_off; values are clamped to idx_max.  s_slot: CSSM_RUN_CHUNK words of LDS.  All threads call.
-template <bool SC1>
-__device__ __forceinline__ void fill_runs_tile(uint32_t prev, const uint32_t (&e)[CSSM_ITEMS], uint32_t first_idx, uint32_t lo, uint32_t hi,
-                                               uint32_t* __restrict__ anc, uint32_t slot_off, uint32_t idx_max, uint32_t* __restrict__ s_slot) {
-  __shared__ uint32_t s_wmax[CSSM_BLOCK / 64];
-  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-  for (uint32_t c0 = lo & ~63u; c0 < hi; c0 += CSSM_RUN_CHUNK) {
-    uint4* z = reinterpret_cast<uint4*>(s_slot + threadIdx.x * 8);
-    z[0] = make_uint4(0u, 0u, 0u, 0u); z[1] = make_uint4(0u, 0u, 0u, 0u);
-    __syncthreads();
-#pragma unroll
-    for (int r = 0; r < CSSM_ITEMS; ++r) {
-      uint32_t rb = (r == 0) ? prev : e[r - 1];
-      uint32_t re = e[r];
-      rb = (rb < lo) ? lo : rb;
-      re = (re > hi) ? hi : re;
-      if (re > rb && re > c0 && rb < c0 + CSSM_RUN_CHUNK) {
-        const uint32_t pos = ((rb > c0) ? rb : c0) - c0;
-        s_slot[pos] = first_idx + r + 1u;                 // index + 1 (0 = no run starts here)
-      }
-    }
-    __syncthreads();
-    const uint4 a = z[0], bq = z[1];
-    uint32_t v[8] = {a.x, a.y, a.z, a.w, bq.x, bq.y, bq.z, bq.w};
-#pragma unroll
-    for (int k = 1; k < 8; ++k) v[k] = (v[k - 1] > v[k]) ? v[k - 1] : v[k];
-    const uint32_t incl = wave_scan_max_u32(v[7]);
-    if (lane == 63) s_wmax[wid] = incl;
-    uint32_t carry = dpp0<0x138 /* wave_shr:1 */, 0xf>(incl);   // exclusive: max over the lanes before this one (lane 0: 0)
-    __syncthreads();
-    for (int w = 0; w < wid; ++w) carry = (s_wmax[w] > carry) ? s_wmax[w] : carry;
-#pragma unroll
-    for (int k = 0; k < 8; ++k) {
-      uint32_t x = (v[k] > carry) ? v[k] : carry;
-      x = (x > 0u) ? x - 1u : 0u;                           // (0 cannot occur inside [lo, hi): every slot there belongs to a run)
-      v[k] = (x > idx_max) ? idx_max : x;
-    }
-    // Back through LDS so that every store INSTRUCTION of a wave covers 1 KiB contiguously (thread t: slots 4t .. 4t+3 of
-    // the chunk's first half, then of its second half): a thread's own 8 slots are two 16-byte stores 32 bytes apart, and
-    // write-through stores of that shape write every line twice, half at a time (PMC: 12.5 MB for 4 MB of ancestors).
-    z[0] = make_uint4(v[0], v[1], v[2], v[3]); z[1] = make_uint4(v[4], v[5], v[6], v[7]);
-    __syncthreads();
-#pragma unroll
-    for (int half = 0; half < 2; ++half) {
-      const uint32_t p = half * (CSSM_RUN_CHUNK / 2) + threadIdx.x * 4;     // position in the chunk
-      const uint4 w = *reinterpret_cast<const uint4*>(s_slot + p);
-      const uint32_t s0 = c0 + p;
-      // (signed: a chunk starts on a 64-slot boundary at or below lo, which can lie below slot_off; only slots inside
-      //  [lo, hi), lo >= slot_off, are dereferenced)
-      uint32_t* dst = anc + ((long long)s0 - (long long)slot_off);
-      if (s0 >= lo && s0 + 4 <= hi && ((s0 - slot_off) & 3u) == 0u) {
-        if (SC1) store_anc4_sc1(dst, w.x, w.y, w.z, w.w);
-        else *reinterpret_cast<uint4*>(dst) = w;
-      } else {
-        const uint32_t wv[4] = {w.x, w.y, w.z, w.w};
-#pragma unroll
-        for (int k = 0; k < 4; ++k)
-          if (s0 + k >= lo && s0 + k < hi) {
-            if (SC1) __hip_atomic_store(dst + k, wv[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            else dst[k] = wv[k];
-          }
-      }
-    }
-    __syncthreads();                                        // s_slot / s_wmax are rewritten by the next chunk
-  }
-}
-
 #define CSSM_WAVE_CHUNK 512   /* resampling slots one WAVE assembles in LDS at a time (2 KiB per wave) */
 
-// The same for ONE WAVE's 256 particles, with no block barrier at all: lane l holds the end slots e[0..3] of its four
-// consecutive particles first_idx .. first_idx + 3 and `prev`; the wave's particles own the slots [lo, hi) (wave-uniform;
-// already clipped).  A wave's LDS operations execute in program order, so markers written by some lanes are visible to
+// findAllInTreeMap (model/Resampling.scala:36-46) for ONE WAVE's 256 particles, with no block barrier at all: lane l holds the
+// end slots e[0..3] of its four consecutive particles first_idx .. first_idx + 3 and the end slot `prev` of the particle before
+// them; the wave's particles own the slots [lo, hi) (wave-uniform; already clipped to what this launch may write).  The ancestor
+// indices of those slots are assembled in LDS, 512 at a time -- every particle drops its index + 1 at the first slot of its run,
+// an inclusive max-scan fills the runs (indices grow with the slots) -- and leave as whole lines (round 1 wrote 4 bytes per slot:
+// 1.38x the algorithmic write traffic).  SC1: write-through stores.  anc is indexed by slot - slot_off (signed arithmetic: a
+// chunk starts on a 64-slot boundary at or below lo, which can lie below slot_off; only slots inside [lo, hi) are dereferenced);
+// values are clamped to idx_max.  A wave's LDS operations execute in program order, so markers written by some lanes are visible to
 // the reads of others without s_barrier -- the compiler is held to that order by wave_barrier + an explicit lgkmcnt wait.
 // k_offspring spent half its wave cycles waiting (PMC SQ_WAIT_ANY 51 %): eight block barriers per tile of 1024 particles,
 // five of them in the block-wide version of this function.  s_wave: CSSM_WAVE_CHUNK words of LDS owned by this wave.
@@ -650,7 +482,7 @@ __device__ __forceinline__ void fill_runs_wave(uint32_t prev, const uint32_t (&e
       const uint32_t p = half * (CSSM_WAVE_CHUNK / 2) + lane * 4;
       const uint4 w = *reinterpret_cast<const uint4*>(s_wave + p);
       const uint32_t s0 = c0 + p;
-      uint32_t* dst = anc + ((long long)s0 - (long long)slot_off);   // (signed: see fill_runs_tile)
+      uint32_t* dst = anc + ((long long)s0 - (long long)slot_off);
       if (s0 >= lo && s0 + 4 <= hi && ((s0 - slot_off) & 3u) == 0u) {
         if (SC1) store_anc4_sc1(dst, w.x, w.y, w.z, w.w);
         else *reinterpret_cast<uint4*>(dst) = w;

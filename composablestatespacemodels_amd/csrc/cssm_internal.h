@@ -1,0 +1,165 @@
+// cssm_internal.h -- what the HIP translation units of libcssm_pf share: the handle, error plumbing and the launch helpers
+// that both the single-GPU drivers (cssm_pf.hip) and the sharded stages (cssm_shard.hip) use.  Not part of the C ABI.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstddef>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "cssm_host.h"
+
+#define fail cssm_fail
+#define HIP_TRY(expr)                                                                         \
+  do {                                                                                        \
+    hipError_t e__ = (expr);                                                                  \
+    if (e__ != hipSuccess) return fail(CSSM_EHIP, "%s: %s (%s:%d)", #expr, hipGetErrorString(e__), __FILE__, __LINE__); \
+  } while (0)
+
+#define CSSM_NKERNELS CSSM_PROFILE_NKERNELS
+
+
+struct cssm_pf : HostModel {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  bool own_stream = true;
+  // sizes
+  uint64_t first = 0, n = 0;   // (n_global, seed: HostModel)
+  size_t stride = 0;
+  uint32_t ntiles = 0;
+  uint32_t sup = 1, nunits = 0;   // tiles per scan unit, number of units (<= ~1K)
+  uint32_t split = 1;             // k_propagate blocks per unit (each owns a contiguous sub-unit and its sums)
+  bool safe_sums = false;         // form the sums in their own pass after the max is known (retry of a step whose
+                                  // reference level was ruled out by the max; always for LGCP)
+  bool last_optimistic = false;   // the last launch_propagate formed the sums itself
+  void* last_comm = nullptr;      // RCCL communicator the library last enqueued collectives on (bounded_sync)
+  std::vector<double> h_fsub;     // host copy of the sub-step coefficient table of the records last built
+  double* d_fsub = nullptr; size_t fsub_cap = 0;
+  bool batch_hold = false;        // batch drivers: an outlying observation puts the series on hold (err bit 6) instead of voiding it
+  bool sharded = false;
+  // device memory
+  double* state[2] = {nullptr, nullptr};
+  int cur = 0;                 // state[cur] = propagated cloud of the last step (x1)
+  const double* src = nullptr; // where the next propagate reads (state[cur])
+  size_t src_stride = 0;
+  const double* src2 = nullptr; // sharded: candidates received from other ranks (indices >= n_split)
+  size_t src2_stride = 0;
+  uint32_t n_split = 0;
+  double* logw = nullptr;
+  uint32_t* endslot = nullptr;
+  uint32_t* anc = nullptr;
+  bool anc_valid = false;
+  int wparity = 0;             // max-slot set (0 .. CSSM_MAXSETS - 1) of the next weighted step (single-GPU path)
+  int opt_exact = 0;           // CSSM_OPT_EXACT_OFFSPRING
+  int opt_fused = 0;           // CSSM_OPT_FUSED_SUMS (set to 1 for sharded handles at creation)
+  cssm_u128 *fineS = nullptr, *fineS2 = nullptr;   // large clouds: the sums of k_propagate's single-tile blocks (k_reduce_units folds them into tileS / tileS2)
+  size_t fine_cap = 0;
+  int opt_whole = 0;           // CSSM_OPT_WHOLE_TILES
+  int resampler = CSSM_RESAMPLE_SYSTEMATIC;
+  double* cum = nullptr;       // multinomial: cumulative normalised weights
+  const long long *send_first_dev = nullptr, *send_count_dev = nullptr;   // last shard_offspring outputs (device)
+  cssm_u128 *tileS = nullptr, *tileS2 = nullptr, *tileP = nullptr;
+  Scalars* sc = nullptr;
+  double *d_m0 = nullptr, *d_sd0 = nullptr, *d_logtab = nullptr;
+  StepRec* d_recs = nullptr;
+  size_t recs_cap = 0;
+  double* d_ll_t = nullptr;
+  int32_t* d_ess_t = nullptr;
+  double* d_path = nullptr;
+  size_t path_cap = 0;
+  // sharded extras
+  double* cand = nullptr;      // candidate states received for this rank, SoA [d][cand_cap]
+  size_t cand_cap = 0;
+  uint32_t *cand_end = nullptr, *cand_idx = nullptr;   // end slot / state index of every candidate, global order
+  size_t cidx_cap = 0;
+  int64_t* d_bounds = nullptr;
+  int64_t* d_xch = nullptr;    // exact exchange: [0..63] send first, [64..127] send count; [128] the redo flag k_offspring_expand_spec writes
+  uint32_t* d_need = nullptr;  // per observation: rows the exchange needed (diagnostics of cssm_pf_shard_status; zero since the
+  size_t need_cap = 0;         //   two-collective exchange that recorded them was removed)
+  bool series = false;         // records of a whole series are resident (cssm_pf_shard_begin)
+  struct Snap { int cur; const double* src; size_t src_stride; const double* src2; size_t src2_stride; uint32_t n_split; bool anc_valid, last_optimistic; uint32_t step; double t; };
+  std::vector<Snap> snaps;     // host-side state right after the propagate of every observation of the series (cssm_pf_shard_resume)
+  // host staging (pinned)
+  StepRec* h_recs = nullptr;
+  size_t h_recs_cap = 0;
+  Scalars* h_sc = nullptr;     // pinned: the streaming step's scalars land here without a staging copy
+  // filter state
+  double t = 0.0;
+  uint32_t step = 0;
+  uint32_t h_step_for_resample = 0;   // observation index of the step being resampled (Philox counter word)
+  bool initialised = false;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  float last_ms = 0.f;
+  // optional per-kernel timing (HIP events on the launch stream around every kernel)
+  bool profile = false;
+  std::vector<hipEvent_t> prof_ev;         // pairs
+  std::vector<int> prof_kind;              // kernel kind of pair i
+  size_t prof_used = 0;
+  double prof_ms[CSSM_NKERNELS] = {0};
+  uint64_t prof_cnt[CSSM_NKERNELS] = {0};
+};
+
+// begin/end of one profiled launch
+static inline void prof_begin(cssm_pf* pf, int kind) {
+  if (!pf->profile) return;
+  if (pf->prof_used * 2 + 2 > pf->prof_ev.size()) {
+    hipEvent_t a, b;
+    if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) { pf->profile = false; return; }
+    pf->prof_ev.push_back(a); pf->prof_ev.push_back(b);
+  }
+  if (pf->prof_kind.size() <= pf->prof_used) pf->prof_kind.resize(pf->prof_used + 1);
+  pf->prof_kind[pf->prof_used] = kind;
+  (void)hipEventRecord(pf->prof_ev[pf->prof_used * 2], pf->stream);
+}
+static inline void prof_end(cssm_pf* pf) {
+  if (!pf->profile) return;
+  (void)hipEventRecord(pf->prof_ev[pf->prof_used * 2 + 1], pf->stream);
+  pf->prof_used++;
+}
+// after a stream synchronise: fold the recorded pairs into per-kind totals
+static inline void prof_collect(cssm_pf* pf) {
+  for (size_t i = 0; i < pf->prof_used; ++i) {
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, pf->prof_ev[2 * i], pf->prof_ev[2 * i + 1]) == hipSuccess) {
+      pf->prof_ms[pf->prof_kind[i]] += ms;
+      pf->prof_cnt[pf->prof_kind[i]]++;
+    }
+  }
+  pf->prof_used = 0;
+}
+
+static inline int grid_for(uint64_t n, int block, int cap) {
+  uint64_t g = (n + block - 1) / block;
+  if (g > (uint64_t)cap) g = cap;
+  if (g < 1) g = 1;
+  return (int)g;
+}
+
+// The host reads the scalars BEHIND the max slots (err, ess, fail_step, gmax, ref, ll, the sums: ~120 bytes, not the 24 KiB of
+// slot lines in front of them -- that copy to pageable memory cost ~15 us per streaming step and per batch call).
+#define CSSM_SC_TAIL_OFF offsetof(Scalars, err)
+#define CSSM_SC_TAIL_ARGS(hp, scp) reinterpret_cast<char*>(hp) + CSSM_SC_TAIL_OFF, reinterpret_cast<const char*>(scp) + CSSM_SC_TAIL_OFF, sizeof(Scalars) - CSSM_SC_TAIL_OFF
+
+static const int kGridCap = 4096;
+
+#define DISPATCH_D(d, ...)                                                         \
+  switch (d) {                                                                      \
+    case 1: { constexpr int D = 1; __VA_ARGS__; } break;   case 2: { constexpr int D = 2; __VA_ARGS__; } break;   \
+    case 3: { constexpr int D = 3; __VA_ARGS__; } break;   case 4: { constexpr int D = 4; __VA_ARGS__; } break;   \
+    case 5: { constexpr int D = 5; __VA_ARGS__; } break;   case 6: { constexpr int D = 6; __VA_ARGS__; } break;   \
+    case 7: { constexpr int D = 7; __VA_ARGS__; } break;   case 8: { constexpr int D = 8; __VA_ARGS__; } break;   \
+    case 9: { constexpr int D = 9; __VA_ARGS__; } break;   case 10: { constexpr int D = 10; __VA_ARGS__; } break; \
+    case 11: { constexpr int D = 11; __VA_ARGS__; } break; case 12: { constexpr int D = 12; __VA_ARGS__; } break; \
+    case 13: { constexpr int D = 13; __VA_ARGS__; } break; case 14: { constexpr int D = 14; __VA_ARGS__; } break; \
+    case 15: { constexpr int D = 15; __VA_ARGS__; } break; default: { constexpr int D = 16; __VA_ARGS__; } break; \
+  }
+
+// ---- defined in cssm_pf.hip, used by cssm_shard.hip as well
+int cssm_build_fsub(cssm_pf* pf, size_t first, size_t count, bool reset);   // sub-step table of records [first, +count) -> device
+int cssm_ensure_recs(cssm_pf* pf, size_t T);
+int cssm_launch_init(cssm_pf* pf, double t0);
+int cssm_launch_propagate(cssm_pf* pf, const StepRec* d_rec, double* pick_out = nullptr, uint32_t pick_slot = 0);
+int cssm_check_device_err(cssm_pf* pf, const Scalars& h);
+int cssm_prop_items(int d);   // PropItems<D>

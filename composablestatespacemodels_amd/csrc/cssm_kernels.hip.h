@@ -1,4 +1,6 @@
-// cssm_kernels.hip.h -- every kernel of libcssm_pf except k_propagate (cssm_propagate.hip.h); included once, by cssm_pf.hip.
+// cssm_kernels.hip.h -- the kernels of libcssm_pf other than k_propagate (cssm_propagate.hip.h) that the single-GPU drivers use, and
+// the bodies they share with the sharded stages (cssm_shard_kernels.hip.h).  Non-template kernels have internal linkage: the
+// header is included by cssm_pf.hip and cssm_shard.hip.
 #pragma once
 
 #include "cssm_device.hip.h"
@@ -20,7 +22,7 @@ __global__ __launch_bounds__(CSSM_BLOCK) void k_init(double* __restrict__ dst, s
 }
 
 // FilterInit.initialiseState, model/ParticleFilter.scala:257-260
-__global__ void k_init_from(double* __restrict__ dst, size_t stride, uint64_t n, int d, const double* __restrict__ s) {
+static __global__ void k_init_from(double* __restrict__ dst, size_t stride, uint64_t n, int d, const double* __restrict__ s) {
   for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x)
     for (int k = 0; k < d; ++k) dst[(size_t)k * stride + i] = s[k];
 }
@@ -32,7 +34,7 @@ __global__ void k_init_from(double* __restrict__ dst, size_t stride, uint64_t n,
 // w1 = exp(w - max) (model/ParticleFilter.scala:125); S = sum w1, S2 = sum w1^2, fixed point, one pair
 // per UNIT of `sup` consecutive tiles (sup is chosen on the host so that there are ~1K units: the
 // scan over units then fits one pass of one block; integer sums make any grouping give the same bits).
-__global__ __launch_bounds__(CSSM_BLOCK) void k_tile_sums(const double* __restrict__ logw, uint64_t n,
+static __global__ __launch_bounds__(CSSM_BLOCK) void k_tile_sums(const double* __restrict__ logw, uint64_t n,
                                                           const Scalars* __restrict__ sc,
                                                           cssm_u128* __restrict__ unitS, cssm_u128* __restrict__ unitS2,
                                                           uint32_t ntiles, uint32_t sup, uint32_t nunits, int raw, int slot_set,
@@ -78,7 +80,7 @@ __global__ __launch_bounds__(CSSM_BLOCK) void k_tile_sums(const double* __restri
 // into the units' (one WAVE per unit: lane l adds the entries l, l + 64, ... of its unit; integer sums: any grouping gives the
 // same bits), so that k_offspring reads <= 1024 unit sums whatever the cloud's size.  ~5 us per weighted observation; what the
 // single-tile kernel saves grows with the latent dimension (cssm_pf.hip, uses_fine: d >= 4).
-__global__ __launch_bounds__(CSSM_BLOCK) void k_reduce_units(const cssm_u128* __restrict__ blockS, const cssm_u128* __restrict__ blockS2,
+static __global__ __launch_bounds__(CSSM_BLOCK) void k_reduce_units(const cssm_u128* __restrict__ blockS, const cssm_u128* __restrict__ blockS2,
                                                              uint32_t nblocks, uint32_t blocks_per_unit, uint32_t nunits,
                                                              cssm_u128* __restrict__ unitS, cssm_u128* __restrict__ unitS2,
                                                              const Scalars* __restrict__ sc, const StepRec* __restrict__ rec) {
@@ -97,7 +99,7 @@ __global__ __launch_bounds__(CSSM_BLOCK) void k_reduce_units(const cssm_u128* __
 
 // Exclusive scan of the tile sums in one block (thread t owns a contiguous chunk of tiles: sum, block
 // scan of the 1024 chunk sums, then prefix write-back); local totals; with `single` also ll / ess.
-__global__ __launch_bounds__(1024) void k_scan_tiles(const cssm_u128* __restrict__ tileS, const cssm_u128* __restrict__ tileS2,
+static __global__ __launch_bounds__(1024) void k_scan_tiles(const cssm_u128* __restrict__ tileS, const cssm_u128* __restrict__ tileS2,
                                                      cssm_u128* __restrict__ tileP, uint32_t ntiles, Scalars* sc,
                                                      uint64_t n_global, int single,
                                                      double* __restrict__ ll_t, int32_t* __restrict__ ess_t, uint32_t rec_idx,
@@ -143,19 +145,6 @@ __global__ __launch_bounds__(1024) void k_scan_tiles(const cssm_u128* __restrict
       if (ll_t) { ll_t[rec_idx] = sc->ll; ess_t[rec_idx] = sc->ess; }
     }
   }
-}
-
-// Multi-GPU: after the all-gather of (S.lo, S.hi, S2.lo, S2.hi) per rank.
-__global__ void k_global_sums(const unsigned long long* __restrict__ all4, int rank, int world, Scalars* sc, uint64_t n_global) {
-  cssm_u128 off = cssm_u128_zero(), tot = cssm_u128_zero(), tot2 = cssm_u128_zero();
-  for (int r = 0; r < world; ++r) {
-    cssm_u128 a, b;
-    a.lo = all4[4 * r + 0]; a.hi = all4[4 * r + 1]; b.lo = all4[4 * r + 2]; b.hi = all4[4 * r + 3];
-    if (r < rank) off = cssm_u128_add(off, a);
-    tot = cssm_u128_add(tot, a); tot2 = cssm_u128_add(tot2, b);
-  }
-  sc->S_off = off; sc->S_tot = tot; sc->S2_tot = tot2;
-  finish_step(sc, n_global);
 }
 
 // ------------------------------------------------------------------------------------ offspring (end slots)
@@ -549,397 +538,10 @@ __global__ __launch_bounds__(CSSM_BLOCK, CSSM_OFF_WAVES) void k_offspring_self(
                                  force_exact, nullptr, 0, 1, split, seed, cum_out, nullptr, optimistic, nullptr, 0u, (uint32_t)n, 5u);
 }
 
-// ------------------------------------------------------------------------------------ expand
-
-// findAllInTreeMap (model/Resampling.scala:36-46) on the receiver of the sharded filter, for the slots of this rank
-// [slot_lo, slot_hi) that belong to OTHER ranks' particles (the own particles wrote their runs in k_offspring).
-// `cand_end` holds the end slots of the m received candidates in global particle order -- n_low from lower ranks,
-// then those from higher ranks -- and `cand_idx` where each candidate's state lives.  Candidate j writes its run
-// [max(start_j, slot_lo), min(end_j, slot_hi)) <- cand_idx[j], start_j = end_{j-1}; the first candidate from below
-// starts at or before slot_lo by construction, the first one from above at the own last end slot.  Runs longer
-// than CSSM_RUN_DIRECT are written by the whole block.
-__device__ __forceinline__ void expand_body(const uint32_t* __restrict__ cand_end, const uint32_t* __restrict__ cand_idx,
-                                            uint64_t m, uint64_t n_low, uint64_t slot_lo, uint64_t slot_hi,
-                                            uint32_t* __restrict__ anc, const uint32_t* __restrict__ own_last_end) {
-  __shared__ uint32_t s_nheavy;
-  __shared__ uint32_t s_hb[CSSM_BLOCK], s_he[CSSM_BLOCK], s_hj[CSSM_BLOCK];
-  for (uint64_t base = (uint64_t)blockIdx.x * CSSM_BLOCK; base < m; base += (uint64_t)gridDim.x * CSSM_BLOCK) {
-    if (threadIdx.x == 0) s_nheavy = 0;
-    __syncthreads();
-    const uint64_t j = base + threadIdx.x;
-    if (j < m) {
-      uint64_t b = (j == n_low) ? (uint64_t)*own_last_end : ((j == 0) ? slot_lo : (uint64_t)cand_end[j - 1]);
-      uint64_t e = cand_end[j];
-      if (b < slot_lo) b = slot_lo;
-      if (e > slot_hi) e = slot_hi;
-      if (e > b) {
-        const uint32_t idx = cand_idx[j];
-        if (e - b <= CSSM_RUN_DIRECT) {
-          for (uint64_t s = b; s < e; ++s) anc[s - slot_lo] = idx;
-        } else {
-          const uint32_t h = atomicAdd(&s_nheavy, 1u);
-          s_hb[h] = (uint32_t)(b - slot_lo); s_he[h] = (uint32_t)(e - slot_lo); s_hj[h] = idx;
-        }
-      }
-    }
-    __syncthreads();
-    const uint32_t nh = s_nheavy;
-    for (uint32_t h = 0; h < nh; ++h) {
-      const uint32_t he = s_he[h], hj = s_hj[h];
-      for (uint32_t s = s_hb[h] + threadIdx.x; s < he; s += CSSM_BLOCK) anc[s] = hj;
-    }
-    __syncthreads();
-  }
-}
-// ------------------------------------------------------------------------------------ single-collective exchange
-//
-// One all-to-all per observation carries BOTH the rank's 5 sum words and its boundary particles:
-// segment r -> q of R-double rows (R = d + 1), laid out as
-//   [0, HD)                header: [0] row count, [1..5] S.lo S.hi S2.lo S2.hi max-key (raw bits), [6..7] base (u128 raw bits),
-//                          [8..9] total weight of the rank's FIRST-cap block, [10..11] of its LAST-cap block (every header carries
-//                          both: with them EVERY rank can tell from the headers alone whether EVERY rank's slots are covered)
-//   [HD, HD + cap R)       rows: (state d, low word of P_j)      P_j = inclusive prefix of the fixed-point weights
-//   [HD + cap R, + capP)   high words of P_j                            WITHIN the block of particles the segment carries
-// q = r - 1 receives the rank's FIRST cap particles (base = 0), q = r + 1 its LAST cap particles (base = S_local - P_total),
-// every other q (q = r included: the all-to-all's own segment delivers every rank its own sums too) the header only.  The receiver knows all sums after
-// the exchange and turns base + P_j into global cumulative weights and end slots itself (k_expand_spec).
-constexpr int kSpecHeaderWords = 12;   // what a header-only segment carries
-__host__ __device__ __forceinline__ long long spec_hdr(int d) { return (long long)(d + 1) * ((12 + d) / (d + 1)); }
-__host__ __device__ __forceinline__ long long spec_capP(int d, long long cap) { return (long long)(d + 1) * ((cap + d) / (d + 1)); }
-__host__ __device__ __forceinline__ long long spec_seg(int d, long long cap) { return spec_hdr(d) + cap * (d + 1) + spec_capP(d, cap); }
-
-// grid (tiles of the block + 1 for the header, destination rank); the weights are those k_propagate<SUMS> summed:
-// exp(min(w - c, REF_BELOW))
-__global__ __launch_bounds__(CSSM_BLOCK) void k_boundary_pack(const double* __restrict__ src, size_t stride, const double* __restrict__ logw,
-                                                              uint64_t n_local, int d, int world, int rank, long long cap,
-                                                              const StepRec* __restrict__ rec, const cssm_u128* __restrict__ subS,
-                                                              const cssm_u128* __restrict__ subS2, uint32_t nsub,
-                                                              const Scalars* __restrict__ sc, double* __restrict__ out, uint64_t chunk,
-                                                              int level_from_max) {
-  // level_from_max: the sums (subS) were formed relative to the level chosen with the GLOBAL max after an all-gather of the
-  // local maxima (cssm_pf_shard_sums: LGCP series, whose level is the max; the repetition of a series an outlying observation
-  // voided) -- the weights of the rows are then relative to sc->ref and the header carries the global max
-  // chunk = particles per sub-unit sum of k_propagate (subS): when the tiles of the carried block coincide with
-  // sub-units, the prefix of the tiles before a block's own is read from subS instead of being recomputed
-  __shared__ cssm_u128 s_w[CSSM_BLOCK / 64], s_r[2][CSSM_BLOCK / 64];
-  if (sc->err & (4u | 8u)) return;   // the series is on hold (capacity miss) or void (level ruled out): nothing may change
-  const int q = blockIdx.y;
-  const long long R = d + 1, HD = spec_hdr(d), seg = spec_seg(d, cap);
-  double* oseg = out + (size_t)q * seg;
-  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-  // only the two adjacent ranks can own slots of this rank's boundary particles (k_offspring_expand_spec's verdict refuses
-  // anything else), so only their segments carry rows; every other segment is its header
-  const long long cnt = (q == rank + 1 || q == rank - 1) ? ((long long)n_local < cap ? (long long)n_local : cap) : 0;
-  const uint64_t first = (q < rank) ? 0 : n_local - (uint64_t)cnt;     // first particle of the block the segment carries
-  const double cref = level_from_max ? sc->ref : rec->ref;
-  auto tile_weights = [&](uint64_t base, cssm_u128 (&qq)[CSSM_ITEMS]) {   // particles first + base + 4 tid .. of the block
-#pragma unroll
-    for (int r = 0; r < CSSM_ITEMS; ++r) {
-      const uint64_t i = base + (uint64_t)threadIdx.x * CSSM_ITEMS + r;
-      qq[r] = (i < (uint64_t)cnt) ? cssm_fix_from_double(cssm_exp(cssm_min_c(logw[first + i] - cref, CSSM_REF_BELOW))) : cssm_u128_zero();
-    }
-  };
-  auto block_total = [&](cssm_u128 v) -> cssm_u128 {   // sum over the block's threads (uniform result)
-    v = wave_sum_u128(v);
-    __syncthreads();
-    if (lane == 0) s_w[wid] = v;
-    __syncthreads();
-    cssm_u128 t = s_w[0];
-#pragma unroll
-    for (int w = 1; w < CSSM_BLOCK / 64; ++w) t = cssm_u128_add(t, s_w[w]);
-    return t;
-  };
-  const bool header_block = (blockIdx.x == gridDim.x - 1);   // grid.x = tiles of the block + 1: the header has a block of its own
-  if (!header_block) {
-  if (cnt == 0) return;
-  // prefix of the tiles before this block's tile
-  cssm_u128 toff = cssm_u128_zero();
-  const bool aligned = (chunk == (uint64_t)CSSM_TILE) && (first % (uint64_t)CSSM_TILE == 0);
-  if (aligned) {
-    const uint32_t b0 = (uint32_t)(first / CSSM_TILE);
-    for (uint32_t t = 0; t < blockIdx.x; ++t) toff = cssm_u128_add(toff, subS[b0 + t]);
-  }
-  for (uint32_t t = 0; !aligned && t < blockIdx.x; ++t) {
-    cssm_u128 qq[CSSM_ITEMS];
-    tile_weights((uint64_t)t * CSSM_TILE, qq);
-    cssm_u128 a = cssm_u128_zero();
-#pragma unroll
-    for (int r = 0; r < CSSM_ITEMS; ++r) a = cssm_u128_add(a, qq[r]);
-    toff = cssm_u128_add(toff, block_total(a));
-  }
-  // this tile: inclusive prefixes, rows
-  const uint64_t base = (uint64_t)blockIdx.x * CSSM_TILE;
-  cssm_u128 qq[CSSM_ITEMS];
-  tile_weights(base, qq);
-  cssm_u128 tsum = cssm_u128_zero();
-#pragma unroll
-  for (int r = 0; r < CSSM_ITEMS; ++r) tsum = cssm_u128_add(tsum, qq[r]);
-  const cssm_u128 inc = wave_scan_u128(tsum, lane);
-  __syncthreads();
-  if (lane == 63) s_w[wid] = inc;
-  __syncthreads();
-  cssm_u128 run = toff;
-  for (int w = 0; w < wid; ++w) run = cssm_u128_add(run, s_w[w]);
-  run = cssm_u128_add(run, inc);
-  { cssm_u128 t; t.lo = run.lo - tsum.lo; t.hi = run.hi - tsum.hi - (run.lo < tsum.lo ? 1u : 0u); run = t; }   // exclusive prefix of the thread
-#pragma unroll
-  for (int r = 0; r < CSSM_ITEMS; ++r) {
-    run = cssm_u128_add(run, qq[r]);
-    const uint64_t i = base + (uint64_t)threadIdx.x * CSSM_ITEMS + r;
-    if (i < (uint64_t)cnt) {
-      double* o = oseg + HD + (long long)i * R;
-      for (int k = 0; k < d; ++k) o[k] = src[(size_t)k * stride + (size_t)(first + i)];
-      o[d] = cssm_u2d(run.lo);
-      oseg[HD + cap * R + (long long)i] = cssm_u2d(run.hi);
-    }
-  }
-  return;
-  }
-  // header: the rank's totals of the sub-unit sums k_propagate formed, the key of its max, base
-  cssm_u128 a = cssm_u128_zero(), b = cssm_u128_zero();
-  for (uint32_t i = threadIdx.x; i < nsub; i += CSSM_BLOCK) { a = cssm_u128_add(a, subS[i]); b = cssm_u128_add(b, subS2[i]); }
-  a = wave_sum_u128(a); b = wave_sum_u128(b);
-  __syncthreads();
-  if (lane == 0) { s_r[0][wid] = a; s_r[1][wid] = b; }
-  __syncthreads();
-  unsigned long long key = 0ull;
-  if (level_from_max) {
-    key = cssm_order_key(sc->gmax);                    // (the slots were exported and cleared before the all-gather)
-  } else if (threadIdx.x < 64) {
-    key = (threadIdx.x < CSSM_MAXSLOTS) ? sc->maxslot[(size_t)threadIdx.x * CSSM_SLOT_STRIDE] : 0ull;   // slot set 0 (sharded handles)
-    key = wave_max_u64(key);
-  }
-  // total weights of the rank's FIRST-cap and LAST-cap blocks (both travel in every header; the LAST one gives the base)
-  const long long cnt_all = ((long long)n_local < cap) ? (long long)n_local : cap;
-  const uint32_t ntile = (uint32_t)((cnt_all + CSSM_TILE - 1) / CSSM_TILE);
-  cssm_u128 ptot[2];
-#pragma unroll
-  for (int which = 0; which < 2; ++which) {
-    const uint64_t bfirst = which ? n_local - (uint64_t)cnt_all : 0;
-    const bool al = (chunk == (uint64_t)CSSM_TILE) && (bfirst % (uint64_t)CSSM_TILE == 0) && ((uint64_t)cnt_all % CSSM_TILE == 0);
-    cssm_u128 acc = cssm_u128_zero();
-    if (al) {   // whole sub-units: their sums are k_propagate's
-      const uint32_t b0 = (uint32_t)(bfirst / CSSM_TILE);
-      cssm_u128 c = cssm_u128_zero();
-      for (uint32_t t = threadIdx.x; t < ntile; t += CSSM_BLOCK) c = cssm_u128_add(c, subS[b0 + t]);
-      acc = block_total(c);
-    } else {
-      for (uint32_t t = 0; t < ntile; ++t) {
-        cssm_u128 c = cssm_u128_zero();
-#pragma unroll
-        for (int r = 0; r < CSSM_ITEMS; ++r) {
-          const uint64_t i = (uint64_t)t * CSSM_TILE + (uint64_t)threadIdx.x * CSSM_ITEMS + r;
-          if (i < (uint64_t)cnt_all)
-            c = cssm_u128_add(c, cssm_fix_from_double(cssm_exp(cssm_min_c(logw[bfirst + i] - cref, CSSM_REF_BELOW))));
-        }
-        acc = cssm_u128_add(acc, block_total(c));
-      }
-    }
-    ptot[which] = acc;
-  }
-  if (threadIdx.x == 0) {
-    cssm_u128 S = s_r[0][0], S2 = s_r[1][0];
-#pragma unroll
-    for (int w = 1; w < CSSM_BLOCK / 64; ++w) { S = cssm_u128_add(S, s_r[0][w]); S2 = cssm_u128_add(S2, s_r[1][w]); }
-    cssm_u128 bs = cssm_u128_zero();
-    if (q > rank) { bs.lo = S.lo - ptot[1].lo; bs.hi = S.hi - ptot[1].hi - (S.lo < ptot[1].lo ? 1u : 0u); }
-    oseg[0] = (double)cnt;
-    oseg[1] = cssm_u2d(S.lo); oseg[2] = cssm_u2d(S.hi); oseg[3] = cssm_u2d(S2.lo); oseg[4] = cssm_u2d(S2.hi);
-    oseg[5] = cssm_u2d(key);
-    oseg[6] = cssm_u2d(bs.lo); oseg[7] = cssm_u2d(bs.hi);
-    oseg[8] = cssm_u2d(ptot[0].lo); oseg[9] = cssm_u2d(ptot[0].hi);
-    oseg[10] = cssm_u2d(ptot[1].lo); oseg[11] = cssm_u2d(ptot[1].hi);
-  }
-}
-
-// After the all-to-all: every segment's rows -> the slots of this rank they own.  Global cumulative weight of row i of
-// segment s = S_off(s) + base(s) + P_i; end slot = cnt of the contract (the sender's k_offspring arrives at the same
-// number for the same particle: its fast path equals the contract's count by construction).  Ancestor index of a slot
-// = n_split + row number in the receive buffer (in R-double rows), which k_propagate resolves in place.
-// Also: slots of this rank that neither its own particles nor the received rows own -> err bit 3 (8): exact exchange.
-// What every block of the launch does first: the headers of all segments -> per-rank sums, offsets, block totals, and the
-// verdict "every rank's slots are covered by its own particles plus its neighbours' boundary blocks".  The verdict is a
-// function of the headers alone, and every rank holds every header: all ranks arrive at the same verdict without talking.
-struct SpecHeaders {
-  cssm_u128 S[64], off[64], base[64], plow[64], phigh[64];
-  long long cnt[64];
-  unsigned long long cnts[64][4];
-  cssm_u128 tot;
-  int all_ok;
-};
-__device__ __forceinline__ bool spec_read_headers(SpecHeaders& H, const double* __restrict__ recv, int world, int rank, long long cap, int d,
-                                                  uint64_t n_local, uint64_t n_global, const StepRec* __restrict__ rec) {
-  const long long seg = spec_seg(d, cap);
-  if (threadIdx.x < 64) {
-    cssm_u128 S = cssm_u128_zero(), bs = cssm_u128_zero(), pl = cssm_u128_zero(), ph = cssm_u128_zero();
-    long long c = 0;
-    if ((int)threadIdx.x < world) {
-      const double* h = recv + (size_t)threadIdx.x * seg;
-      S.lo = cssm_d2u(h[1]); S.hi = cssm_d2u(h[2]); bs.lo = cssm_d2u(h[6]); bs.hi = cssm_d2u(h[7]);
-      pl.lo = cssm_d2u(h[8]); pl.hi = cssm_d2u(h[9]); ph.lo = cssm_d2u(h[10]); ph.hi = cssm_d2u(h[11]);
-      c = (long long)h[0];
-      c = (c < 0) ? 0 : ((c > cap) ? cap : c);
-    }
-    H.S[threadIdx.x] = S; H.base[threadIdx.x] = bs; H.plow[threadIdx.x] = pl; H.phigh[threadIdx.x] = ph; H.cnt[threadIdx.x] = c;
-  }
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    cssm_u128 run = cssm_u128_zero();
-    for (int r = 0; r < world; ++r) { H.off[r] = run; run = cssm_u128_add(run, H.S[r]); }
-    H.tot = run;
-    H.all_ok = 1;
-  }
-  __syncthreads();
-  const double totd = cssm_u128_to_double(H.tot);
-  const double u = rec->u;
-  const bool pow2 = (n_global & (n_global - 1)) == 0;
-  const double inv_n = 1.0 / (double)n_global;
-  auto count_of = [&](cssm_u128 G) -> uint64_t {
-    if (cssm_u128_is_zero(G)) return 0;   // (the globally first particle starts at slot 0, as in k_offspring)
-    const double C = cssm_u128_to_double(G) / totd;
-    return pow2 ? cssm_sys_count_pow2(C, u, n_global, inv_n) : cssm_sys_count(C, u, n_global);
-  };
-  // four slot counts per rank (own begin / end, reach of the lower neighbour's last block / of the upper neighbour's first
-  // block), one thread each: the verdict is on every block's critical path
-  if ((int)threadIdx.x < 4 * world) {
-    const int r = (int)(threadIdx.x >> 2), which = (int)(threadIdx.x & 3);
-    uint64_t v = 0;
-    if (which == 0) v = count_of(H.off[r]);
-    else if (which == 1) v = count_of(cssm_u128_add(H.off[r], H.S[r]));
-    else if (which == 2) {
-      if (r > 0) {
-        const cssm_u128 Sp = H.S[r - 1], Pp = H.phigh[r - 1];
-        cssm_u128 bse; bse.lo = Sp.lo - Pp.lo; bse.hi = Sp.hi - Pp.hi - (Sp.lo < Pp.lo ? 1u : 0u);
-        v = count_of(cssm_u128_add(H.off[r - 1], bse));
-      }
-    } else if (r + 1 < world) v = count_of(cssm_u128_add(H.off[r + 1], H.plow[r + 1]));
-    H.cnts[r][which] = v;
-  }
-  __syncthreads();
-  if ((int)threadIdx.x < world) {
-    const int r = (int)threadIdx.x;
-    const uint64_t n_per = (n_global + (uint64_t)world - 1) / (uint64_t)world;
-    uint64_t lo = (uint64_t)r * n_per; lo = (lo < n_global) ? lo : n_global;
-    uint64_t hi = lo + n_per; hi = (hi < n_global) ? hi : n_global;
-    bool ok = true;
-    if (lo < hi) {
-      const uint64_t own_begin = H.cnts[r][0], own_end = H.cnts[r][1];
-      if (lo < own_begin)      // the last-cap block of rank r - 1 must reach down to lo (its end is own_begin by construction)
-        ok = (r > 0) && H.cnts[r][2] <= lo && !cssm_u128_is_zero(H.phigh[r - 1]);
-      if (own_end < hi)        // the first-cap block of rank r + 1 must reach up to hi (r = world - 1 cannot get here:
-        ok = ok && (r + 1 < world) && H.cnts[r][3] >= hi;   //  the last cumulative weight is exactly 1)
-    }
-    if (!ok) H.all_ok = 0;
-  }
-  __syncthreads();
-  (void)rank; (void)n_local;
-  return H.all_ok != 0;
-}
-
-__device__ __forceinline__ void expand_spec_body(SpecHeaders& H, uint32_t bid, uint32_t nblk, const double* __restrict__ recv, int world, int rank,
-                                                 long long cap, int d, uint32_t n_split, uint64_t slot_lo, uint64_t slot_hi, uint64_t n_global,
-                                                 const StepRec* __restrict__ rec, uint32_t* __restrict__ anc, Scalars* __restrict__ sc) {
-  __shared__ uint32_t s_nheavy;
-  __shared__ uint32_t s_hb[CSSM_BLOCK], s_he[CSSM_BLOCK], s_hj[CSSM_BLOCK];
-  const long long R = d + 1, HD = spec_hdr(d), seg = spec_seg(d, cap);
-  const double totd = cssm_u128_to_double(H.tot);
-  const double u = rec->u;
-  const bool pow2 = (n_global & (n_global - 1)) == 0;
-  const double inv_n = 1.0 / (double)n_global;
-  auto count_of = [&](cssm_u128 G) -> uint64_t {
-    if (cssm_u128_is_zero(G)) return 0;
-    const double C = cssm_u128_to_double(G) / totd;
-    return pow2 ? cssm_sys_count_pow2(C, u, n_global, inv_n) : cssm_sys_count(C, u, n_global);
-  };
-  if (bid == 0 && threadIdx.x < CSSM_MAXSLOTS) sc->maxslot[(size_t)threadIdx.x * CSSM_SLOT_STRIDE] = 0ull;   // set 0 for the next step
-  // Only the two adjacent ranks' rows can own slots of this rank: the verdict established that its slots below the own
-  // particles' first one all belong to the last-cap block of rank - 1 and those above to the first-cap block of rank + 1.
-  // The rows are spread evenly over ALL blocks of the launch (a share of ceil(2 cap / blocks) each, done after the
-  // block's own tile): extra blocks for them would start a second, nearly empty round on a chip the offspring blocks fill.
-  const long long total = 2 * cap;
-  const long long per = (total + nblk - 1) / nblk;
-  const long long row_lo = (long long)bid * per, row_hi = (row_lo + per < total) ? row_lo + per : total;
-  for (long long base = row_lo; base < row_hi; base += CSSM_BLOCK) {
-    if (threadIdx.x == 0) s_nheavy = 0;
-    __syncthreads();
-    const long long idx = base + threadIdx.x;
-    if (idx < row_hi) {
-      const int s = (idx < cap) ? rank - 1 : rank + 1;
-      const long long i = (idx < cap) ? idx : idx - cap;
-      if (s >= 0 && s < world && i < H.cnt[s]) {
-        const double* h = recv + (size_t)s * seg;
-        const cssm_u128 off = cssm_u128_add(H.off[s], H.base[s]);
-        cssm_u128 P; P.lo = cssm_d2u(h[HD + i * R + d]); P.hi = cssm_d2u(h[HD + cap * R + i]);
-        uint64_t e = count_of(cssm_u128_add(off, P));
-        uint64_t b;
-        if (i == 0) {
-          b = count_of(off);
-        } else {
-          cssm_u128 Pp; Pp.lo = cssm_d2u(h[HD + (i - 1) * R + d]); Pp.hi = cssm_d2u(h[HD + cap * R + (i - 1)]);
-          b = count_of(cssm_u128_add(off, Pp));
-        }
-        if (b < slot_lo) b = slot_lo;
-        if (e > slot_hi) e = slot_hi;
-        if (e > b) {
-          const uint32_t row = n_split + (uint32_t)(((long long)s * seg + HD) / R + i);
-          if (e - b <= CSSM_RUN_DIRECT) {
-            for (uint64_t sl = b; sl < e; ++sl) anc[sl - slot_lo] = row;
-          } else {
-            const uint32_t hh = atomicAdd(&s_nheavy, 1u);
-            s_hb[hh] = (uint32_t)(b - slot_lo); s_he[hh] = (uint32_t)(e - slot_lo); s_hj[hh] = row;
-          }
-        }
-      }
-    }
-    __syncthreads();
-    const uint32_t nh = s_nheavy;
-    for (uint32_t hh = 0; hh < nh; ++hh) {
-      const uint32_t he = s_he[hh], hj = s_hj[hh];
-      for (uint32_t sl = s_hb[hh] + threadIdx.x; sl < he; sl += CSSM_BLOCK) anc[sl] = hj;
-    }
-    __syncthreads();
-  }
-}
-// Offspring of the own particles and expansion of the received rows in ONE launch: the two are independent once the
-// exchange is done (disjoint slots; both read only the segment headers), and a launch costs ~5 us of latency.  Every block
-// is a k_offspring block first and then expands its share of the received rows; `optimistic` = 2 makes the offspring
-// side raise err bit 2 itself (no later kernel reads the flag).
-// EVERY block first takes the verdict of spec_read_headers.  If some rank's slots are not covered, the whole launch
-// does NOTHING on every rank except recording err bit 3 and the observation index: the state is exactly as the
-// propagate of this observation left it, every later kernel of the series returns at once (they test the bit), and
-// the host redoes this observation's exchange with a larger capacity and carries on (cssm_pf_shard_resume).
-__global__ __launch_bounds__(CSSM_BLOCK, CSSM_OFF_WAVES) void k_offspring_expand_spec(
-    CSSM_OFFSPRING_PARAMS, uint32_t all5_stride, const double* __restrict__ recv, long long cap, int d, uint32_t n_split) {
-  __shared__ SpecHeaders H;
-  if (sc->err & (4u | 8u)) return;
-  if (optimistic) {
-    // the level first: sums formed relative to a reference level that the global max rules out (an outlying observation) say
-    // nothing about coverage either.  Sticky bit 2 (4): every later kernel of the series returns at once, the host runs
-    // the series again with the levels taken from the global max.
-    unsigned long long key = 0ull;
-    for (int r = 0; r < world; ++r) { const unsigned long long k = all5[(size_t)all5_stride * r + 4]; key = (k > key) ? k : key; }
-    if (!(cssm_ref_choose(rec->ref, cssm_order_unkey(key)) == rec->ref)) {
-      if (blockIdx.x == 0 && threadIdx.x == 0) atomicOr(&sc->err, 4u);
-      return;
-    }
-  }
-  if (!spec_read_headers(H, recv, world, rank, cap, d, n, n_global, rec)) {
-    if (blockIdx.x == 0 && threadIdx.x == 0) { atomicOr(&sc->err, 8u); atomicMin(&sc->fail_step, rec->step); }
-    return;
-  }
-  offspring_body<true, false, CSSM_RESAMPLE_SYSTEMATIC>(CSSM_OFFSPRING_FWD, all5_stride);
-  expand_spec_body(H, blockIdx.x, gridDim.x, recv, world, rank, cap, d, n_split, (uint64_t)slot_lo, (uint64_t)slot_hi, n_global, rec, anc, sc);
-}
-
-__global__ __launch_bounds__(CSSM_BLOCK) void k_expand(const uint32_t* __restrict__ cand_end, const uint32_t* __restrict__ cand_idx,
-                                                       uint64_t m, uint64_t n_low, uint64_t slot_lo, uint64_t slot_hi,
-                                                       uint32_t* __restrict__ anc, const uint32_t* __restrict__ own_last_end) {
-  expand_body(cand_end, cand_idx, m, n_low, slot_lo, slot_hi, anc, own_last_end);
-}
 // Resampling.multinomialResampling (model/Resampling.scala:92-96): slot i draws its own uniform and takes the
 // first particle whose cumulative normalised weight reaches it (breeze Multinomial.draw); the output is in
 // draw order, not sorted.  `cum` is non-decreasing and ends at exactly 1.0.
-__global__ void k_multinomial(const double* __restrict__ cum, uint64_t n, uint64_t seed, uint32_t step, uint32_t* __restrict__ anc) {
+static __global__ void k_multinomial(const double* __restrict__ cum, uint64_t n, uint64_t seed, uint32_t step, uint32_t* __restrict__ anc) {
   for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
     const double ui = cssm_multi_uniform(seed, step, i);
     uint64_t lo = 0, hi = n - 1;      // first j with cum[j] >= ui (exists: cum[n-1] == 1 > ui)
@@ -954,7 +556,7 @@ __global__ void k_multinomial(const double* __restrict__ cum, uint64_t n, uint64
 // ------------------------------------------------------------------------------------ gather / pick
 
 // PfState.particles on demand: out[k][i] = src[k][anc[i]]
-__global__ void k_gather(const double* __restrict__ src, size_t src_stride, const uint32_t* __restrict__ anc,
+static __global__ void k_gather(const double* __restrict__ src, size_t src_stride, const uint32_t* __restrict__ anc,
                          double* __restrict__ out, size_t out_stride, uint64_t n, int d,
                          const double* __restrict__ src2, size_t src2_stride, uint32_t n_split) {
   for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
@@ -967,7 +569,7 @@ __global__ void k_gather(const double* __restrict__ src, size_t src_stride, cons
 }
 
 // Resampling.sampleOne for `filter` (model/ParticleFilter.scala:157): one particle of the current cloud
-__global__ void k_pick(const double* __restrict__ src, size_t src_stride, const uint32_t* __restrict__ anc,
+static __global__ void k_pick(const double* __restrict__ src, size_t src_stride, const uint32_t* __restrict__ anc,
                        uint64_t idx, int d, double* __restrict__ out_row) {
   const int k = threadIdx.x;
   if (k < d) {
@@ -977,7 +579,7 @@ __global__ void k_pick(const double* __restrict__ src, size_t src_stride, const 
 }
 
 // per-step record of results for the batch drivers
-__global__ void k_record(const Scalars* __restrict__ sc, double* __restrict__ ll_t, int32_t* __restrict__ ess_t, uint32_t s) {
+static __global__ void k_record(const Scalars* __restrict__ sc, double* __restrict__ ll_t, int32_t* __restrict__ ess_t, uint32_t s) {
   ll_t[s] = sc->ll;
   ess_t[s] = sc->ess;
 }
@@ -1039,7 +641,7 @@ __global__ __launch_bounds__(CSSM_BLOCK) void k_summary_fill(const double* __res
 // Radix select, most significant byte first, two targets (lower / upper order statistic) per row.
 struct SelState { unsigned long long prefix[2]; unsigned long long rank[2]; };
 
-__global__ __launch_bounds__(CSSM_BLOCK) void k_sel_hist(const unsigned long long* __restrict__ keys, size_t kstride, uint64_t n,
+static __global__ __launch_bounds__(CSSM_BLOCK) void k_sel_hist(const unsigned long long* __restrict__ keys, size_t kstride, uint64_t n,
                                                          const SelState* __restrict__ st, int shift, uint32_t* __restrict__ hist) {
   __shared__ uint32_t s_h[2][256];
   const int row = blockIdx.y;
@@ -1061,7 +663,7 @@ __global__ __launch_bounds__(CSSM_BLOCK) void k_sel_hist(const unsigned long lon
   }
 }
 
-__global__ void k_sel_pick(SelState* __restrict__ st, int shift, uint32_t* __restrict__ hist) {   // <<<rows, 2>>>
+static __global__ void k_sel_pick(SelState* __restrict__ st, int shift, uint32_t* __restrict__ hist) {   // <<<rows, 2>>>
   const int row = blockIdx.x, t = threadIdx.x;
   uint32_t* h = hist + (size_t)row * 512 + t * 256;
   unsigned long long r = st[row].rank[t], cum = 0;
@@ -1075,7 +677,7 @@ __global__ void k_sel_pick(SelState* __restrict__ st, int shift, uint32_t* __res
   for (int i = 0; i < 256; ++i) h[i] = 0;
 }
 
-__global__ void k_summary_finish(const SelState* __restrict__ st, const double* __restrict__ partial, int nblocks, int d, uint64_t n,
+static __global__ void k_summary_finish(const SelState* __restrict__ st, const double* __restrict__ partial, int nblocks, int d, uint64_t n,
                                  double* __restrict__ out /*[3][d+1]: mean, lower, upper*/) {
   const int k = threadIdx.x;
   if (k > d) return;

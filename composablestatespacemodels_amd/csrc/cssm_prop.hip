@@ -74,22 +74,3 @@ void CSSM_CAT(cssm_prop_launch_d, CSSM_PROP_D)(const PropLaunch& a) {
 #undef PROP_GO
 #undef PROP_SELF
 }
-
-void CSSM_CAT(cssm_step_launch_d, CSSM_PROP_D)(const StepLaunch& a) {
-  constexpr int D = CSSM_PROP_D;
-  constexpr int IT = PropItems<D>::value;
-#define STEP_GO(OB, CHV)                                                                                                          \
-  k_step_self<D, IT, OB, CHV><<<dim3(a.grid), dim3(CSSM_BLOCK), 0, a.stream>>>(a.src, a.src_stride, a.dst, a.dst_stride, a.logw_in, a.logw_out, \
-      a.n, a.seed, a.rec, a.mk, a.sc, a.set_in, a.logtab, a.inS, a.inS2, a.outS, a.outS2, a.nunits, a.ll_t, a.ess_t, a.force_exact,    \
-      a.pick_out, a.pick_slot)
-  if (a.chunk == CSSM_TILE) {
-    if (a.obs == CSSM_OBS_POISSON) STEP_GO(CSSM_OBS_POISSON, CSSM_TILE);
-    else if (a.obs == CSSM_OBS_GAUSSIAN) STEP_GO(CSSM_OBS_GAUSSIAN, CSSM_TILE);
-    else STEP_GO(-1, CSSM_TILE);
-  } else {   // clouds below 2^20 particles: one tile of the propagate kernel per block
-    if (a.obs == CSSM_OBS_POISSON) STEP_GO(CSSM_OBS_POISSON, CSSM_BLOCK * IT);
-    else if (a.obs == CSSM_OBS_GAUSSIAN) STEP_GO(CSSM_OBS_GAUSSIAN, CSSM_BLOCK * IT);
-    else STEP_GO(-1, CSSM_BLOCK * IT);
-  }
-#undef STEP_GO
-}

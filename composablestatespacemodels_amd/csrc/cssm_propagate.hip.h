@@ -49,38 +49,28 @@ struct PropAcc {
   bool bad;          // a log-weight was NaN
 };
 
-// The body shared by k_propagate (one launch per observation) and the persistent series kernel (cssm_series.hip.h): the
-// block's particles [range_lo, n) of one observation.  COH (series kernel): everything another block wrote earlier in
-// the SAME launch -- ancestor indices, state rows -- is read with agent-scope (sc1) loads and everything another block
-// will read is stored write-through (sc1), because the 8 XCDs' L2s are not coherent with each other inside a kernel;
-// lw_lds != nullptr: the log-weights of the range also go to LDS (lw_lds[i - range_lo]) for the offspring phase.
+// The body of every k_propagate launch: the block's particles [range_lo, n) of one observation.
 // `tab`: the contract's log table, staged in LDS by the caller (stage_log_table).
-// LANC (k_step): `anc` points into LDS and holds the ancestors of the block's own range, anc[i - range_lo].
 // ONE (small clouds): the range is a single tile, and the tile's normal variates -- which depend on nothing but (seed, particle,
 // observation) -- are drawn WHILE the ancestor indices and the gathered rows are on their way: with one wave per SIMD nobody
 // else hides those two round trips (~1.7 us of a kernel whose whole body takes ~5).  Same arithmetic, another order.
 // (ONE = 1: the range is a single tile; ONE = 2: the same body tile after tile -- a separate instantiation: folding the loop into
 // the single-tile kernel cost it 18 VGPRs and 10 % at d = 9)
-template <int D, bool LGCP, int IT, int OBS, bool SUMS, bool COH, bool LANC = false, int ONE = 0>
+template <int D, bool LGCP, int IT, int OBS, bool SUMS, int ONE = 0>
 __device__ __forceinline__ void propagate_range(
     const double* __restrict__ src, size_t src_stride, const uint32_t* __restrict__ anc,
     double* __restrict__ dst, size_t dst_stride, double* __restrict__ logw, uint64_t gid0,
     uint64_t seed, const StepRec* __restrict__ rec, const ModelK& mk,
     const double* __restrict__ src2, size_t src2_stride, uint32_t n_split, const double* tab,
     const uint32_t range_lo, const uint32_t n, int do_sums_arg,
-    double* __restrict__ pick_out, uint32_t pick_slot, double* lw_lds, unsigned char* s_stage, PropAcc& acc,
-    const uint32_t idx_max = 0xffffffffu, uint32_t* __restrict__ err_word = nullptr, const double* __restrict__ fsub = nullptr,
-    const unsigned long long* pre_jp = nullptr) {
+    double* __restrict__ pick_out, uint32_t pick_slot, unsigned char* s_stage, PropAcc& acc,
+    const double* __restrict__ fsub = nullptr, const unsigned long long* pre_jp = nullptr) {
   // pre_jp (ONE): the tile's packed ancestor indices, already requested by the caller (before it staged the log table: one
   // dependent round trip less)
   // fsub (LGCP with a time-dependent f, e.g. a seasonal leaf): the handle's table of f coefficients at the sub-step times
   // tau_s = t + s delta (FilterLgcp.calcWeight evaluates mod.f(a.state, a.time) at every simulated time,
   // model/ParticleFilter.scala:193-205; model/Sde.scala:57-66); this observation's rows start at rec->fsub_off
-  // idx_max / err_word (COH): ancestor indices above idx_max -- impossible by construction -- are clamped and reported
-  // (err bit 5) instead of being dereferenced: the ancestor array is the only data-dependent address of the path, and a
-  // wild gather inside a kernel that the whole grid waits on must not be able to fault the GPU
-  // s_stage: PropStage<D, IT>::bytes bytes of LDS (16-byte aligned) owned by the caller -- the series kernel reuses them
-  // for its offspring phase
+  // s_stage: PropStage<D, IT>::bytes bytes of LDS (16-byte aligned) owned by the caller
   // SUMS && pick_out != nullptr (`filter`, model/ParticleFilter.scala:157): the thread that gathers slot pick_slot holds the
   // resampled state sampleOne chose after the PREVIOUS observation, before its transition: it records it (a launch of
   // its own per observation would cost more than the whole sums pass at small N)
@@ -101,7 +91,6 @@ __device__ __forceinline__ void propagate_range(
   cssm_u128 accS = cssm_u128_zero(), accS2 = cssm_u128_zero();
   double tmax = -cssm_inf();
   bool bad = false;
-  static_assert(!COH || IT <= 2, "the series kernel runs one or two particles per thread (wave-contiguous write-through stores)");
   // tile indices are 32-bit (the library admits n <= 2^32 - 2^16 particles per handle): half the VALU work of 64-bit
   constexpr uint32_t stride = (uint32_t)CSSM_BLOCK * IT;      // particles per tile
   // Software pipeline over the block's tiles WITHOUT spending registers on it.  With 4 waves per SIMD the two
@@ -128,22 +117,8 @@ __device__ __forceinline__ void propagate_range(
   constexpr int NJ = (IT + 1) / 2;
   auto load_idx = [&](uint32_t base, unsigned long long (&jp)[NJ]) {
     const uint32_t i0 = base + threadIdx.x * IT;
-    if (LANC) {
-      static_assert(!LANC || IT <= 2, "k_step runs one or two particles per thread");
-      if (IT == 2) jp[0] = *reinterpret_cast<const unsigned long long*>(anc + (i0 - range_lo));
-      else jp[0] = anc[i0 - range_lo];
-    } else if (anc) {
-      if (COH) {   // written by other blocks earlier in this launch: agent-scope loads (global_load ... sc1)
-        const unsigned long long* a64 = reinterpret_cast<const unsigned long long*>(anc + i0);
-        if (IT == 4) {
-          jp[0] = __hip_atomic_load(a64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          jp[NJ - 1] = __hip_atomic_load(a64 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        } else if (IT == 2) {
-          jp[0] = __hip_atomic_load(a64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        } else {
-          jp[0] = __hip_atomic_load(anc + i0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-      } else if (IT == 4) {
+    if (anc) {
+      if (IT == 4) {
         const ulonglong2 a = *reinterpret_cast<const ulonglong2*>(anc + i0);
         jp[0] = a.x; jp[NJ - 1] = a.y;
       } else if (IT == 2) {
@@ -161,8 +136,7 @@ __device__ __forceinline__ void propagate_range(
     const uint32_t i0 = base + threadIdx.x * IT;
 #pragma unroll
     for (int r = 0; r < IT; ++r) {
-      uint32_t v = (uint32_t)(jp[r / 2] >> (32 * (r & 1)));
-      if (COH && v > idx_max) { v = idx_max; if (i0 + r < n) atomicOr(err_word, 32u); }
+      const uint32_t v = (uint32_t)(jp[r / 2] >> (32 * (r & 1)));
       j[r] = (i0 + r < n) ? v : n_last;
     }
   };
@@ -189,10 +163,7 @@ __device__ __forceinline__ void propagate_range(
         const double* g = (src2 == nullptr) ? src + (size_t)k * src_stride + j[r] : ptr_of(j[r], k);
         const uint32_t slot = wstage_lds + (uint32_t)((r * D + k) * 64 * ES);
         if (ES == 16) {
-          if (COH) lds_dma16_sc1(g, slot); else lds_dma16(g, slot);
-        } else if (COH) {
-          lds_dma4_sc1(g, slot);
-          lds_dma4_sc1(reinterpret_cast<const unsigned char*>(g) + 4, slot + 256u);
+          lds_dma16(g, slot);
         } else {
           lds_dma4(g, slot);
           lds_dma4(reinterpret_cast<const unsigned char*>(g) + 4, slot + 256u);
@@ -219,7 +190,7 @@ __device__ __forceinline__ void propagate_range(
   unsigned long long jp[NJ];
   uint32_t jn[IT];
   double x[IT][D];
-  static_assert(!ONE || (IT <= 2 && !LGCP && !COH), "ONE: one pair (d <= 8) or one particle (d >= 9) per thread, ordinary step");
+  static_assert(!ONE || (IT <= 2 && !LGCP), "ONE: one pair (d <= 8) or one particle (d >= 9) per thread, ordinary step");
   double zz[ONE ? IT * D : 1];                                    // ONE: the thread's IT * D normals (normal q -> particle q / D, component q % D)
   if (base < n) {
     if (ONE && pre_jp != nullptr) jp[0] = *pre_jp; else load_idx(base, jp);
@@ -374,19 +345,10 @@ __device__ __forceinline__ void propagate_range(
       for (int r = 0; r < IT; ++r) {
         if (i0 + r < n) {
 #pragma unroll
-          for (int k = 0; k < D; ++k) {
-            if (COH) __hip_atomic_store(reinterpret_cast<unsigned long long*>(dst + (size_t)k * dst_stride + i0 + r),
-                                        (unsigned long long)cssm_d2u(x[r][k]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            else dst[(size_t)k * dst_stride + i0 + r] = x[r][k];
-          }
+          for (int k = 0; k < D; ++k) dst[(size_t)k * dst_stride + i0 + r] = x[r][k];
           if (weighted && logw) logw[i0 + r] = lw[r];
         }
       }
-    }
-    if (COH && weighted && lw_lds != nullptr) {   // the offspring phase of the same launch reads them back from LDS
-#pragma unroll
-      for (int r = 0; r < IT; ++r)
-        if (i0 + r < n) lw_lds[i0 + r - range_lo] = lw[r];
     }
     if (ONE == 1) break;                                          // (the range is this one tile)
     if (ONE == 2) {   // further tiles of the range in the same way: no software pipeline, co-resident waves cover the round trips
@@ -457,9 +419,8 @@ __global__ __launch_bounds__(CSSM_BLOCK, (PropWaves<D, SUMS>::value)) void k_pro
   const double* tab = stage_log_table(logtab);
   __shared__ __attribute__((aligned(16))) unsigned char s_stage[PropStage<D, IT>::bytes];
   PropAcc acc;
-  propagate_range<D, LGCP, IT, OBS, SUMS, false>(src, src_stride, anc, dst, dst_stride, logw, gid0, seed, rec, mk, src2, src2_stride,
-                                                 n_split, tab, range_lo, n, do_sums_arg, pick_out, pick_slot, nullptr, s_stage, acc,
-                                                 0xffffffffu, nullptr, LGCP ? fsub : nullptr);
+  propagate_range<D, LGCP, IT, OBS, SUMS>(src, src_stride, anc, dst, dst_stride, logw, gid0, seed, rec, mk, src2, src2_stride,
+                                          n_split, tab, range_lo, n, do_sums_arg, pick_out, pick_slot, s_stage, acc, LGCP ? fsub : nullptr);
   const bool weighted = LGCP || rec->has_obs;
   const bool do_sums = SUMS && !LGCP && do_sums_arg && rec->has_obs;
   cssm_u128 accS = acc.S, accS2 = acc.S2;
@@ -547,9 +508,9 @@ __device__ __forceinline__ void propagate_block(
   if (held & (4u | 8u | 64u)) return;
   __shared__ __attribute__((aligned(16))) unsigned char s_stage[PropStage<D, IT>::bytes];
   PropAcc acc;
-  propagate_range<D, false, IT, OBS, SUMS, false, false, ONE>(src, src_stride, anc, dst, dst_stride, logw, gid0, seed, rec, mk, src2, 0, n_split, tab,
-                                                              range_lo, n, SUMS ? 1 : 0, SUMS ? pick_out : nullptr, pick_slot, nullptr, s_stage, acc,
-                                                              0xffffffffu, nullptr, nullptr, ONE ? &jp_early : nullptr);
+  propagate_range<D, false, IT, OBS, SUMS, ONE>(src, src_stride, anc, dst, dst_stride, logw, gid0, seed, rec, mk, src2, 0, n_split, tab,
+                                                range_lo, n, SUMS ? 1 : 0, SUMS ? pick_out : nullptr, pick_slot, s_stage, acc,
+                                                nullptr, ONE ? &jp_early : nullptr);
   if (!rec->has_obs) return;
   double tmax = wave_max(acc.tmax);
   if ((threadIdx.x & 63) == 0) s_max[threadIdx.x >> 6] = tmax;
@@ -599,265 +560,4 @@ __global__ __launch_bounds__(CSSM_BLOCK, (ONE ? 2 : PropWaves<D, true>::value)) 
     cssm_u128* __restrict__ subS, cssm_u128* __restrict__ subS2) {
   propagate_block<D, IT, OBS, true, ONE>(src, src_stride, anc, dst, dst_stride, logw, n_arg, seed, rec, mk, sc, 0, logtab, chunk, subS, subS2,
                                          nullptr, 0u, gid0, src2, n_split);
-}
-
-// ------------------------------------------------------------------------------------ one launch per observation
-//
-// k_step = the resampling of observation s - 1 and the propagate + weight of observation s in ONE launch (single GPU,
-// systematic resampling, sums formed relative to the reference level).  The two launches per
-// observation of the default path are each a chain of dependent memory round trips behind a dispatch -- ~8 us however few
-// particles there are -- and the resampling is the part that cannot be fused into the kernel BEFORE it (it needs the
-// total of all weights).  It can be fused into the kernel AFTER it when that is organised by CHILDREN: block b owns the
-// resampling slots [b * 1024, (b + 1) * 1024) = the particles it is about to propagate.
-//   A  every block reads the <= 1024 unit sums of observation s - 1 (unit = 1024 consecutive particles = one block of the
-//      previous launch), scans them (integer sums: every block gets the same bits) and evaluates the contract's end slot
-//      at every unit boundary: which units hold the parents of its slots is then a comparison;
-//   B  for those units (two or three when the weights are even; units without offspring are skipped) it recomputes
-//      exp(w - c) in fixed point from the log-weights, scans, and gets every parent's end slot exactly as k_offspring
-//      does; a parent whose run of slots meets the block's range drops its index at the run's first slot, in LDS;
-//   C  a max-scan over the 1024 slots fills the runs (findAllInTreeMap, model/Resampling.scala:36-46): the ancestors of the
-//      block's particles, in LDS -- they never travel through HBM;
-//   D  propagate_range gathers through them, as k_propagate does through anc[];
-//   E  the block's sums and max of observation s go to the OTHER set of unit sums / log-weights (blocks of this launch still
-//      read the previous set) and to max-slot set s % 3.
-// Block 0 also publishes ll / ess of observation s - 1.  Work that k_offspring does once per particle is done ~2.3 times
-// here (a block's parents straddle unit boundaries), which is why this is the path of small clouds (N <= CSSM_STEP_MAX_N,
-// cssm_pf.hip) where a launch costs more than its arithmetic.  An observation whose max rules its reference level out
-// is found in phase A of the NEXT launch: the series goes on hold exactly as with k_offspring (err bit 6).
-// CH = particles per block = particles per unit of sums (CSSM_TILE, or half of it for small clouds: pf->split = 2)
-template <int D, int IT, int OBS, int CH>
-__global__ __launch_bounds__(CSSM_BLOCK, (D <= 3 ? 4 : 3)) void k_step_self(
-    const double* __restrict__ src, size_t src_stride, double* __restrict__ dst, size_t dst_stride,
-    const double* __restrict__ logw_in, double* __restrict__ logw_out, uint32_t n, uint64_t seed,
-    const StepRec* __restrict__ rec, ModelK mk, Scalars* __restrict__ sc, int set_in, const double* __restrict__ logtab,
-    const cssm_u128* __restrict__ inS, const cssm_u128* __restrict__ inS2, cssm_u128* __restrict__ outS, cssm_u128* __restrict__ outS2,
-    uint32_t nunits, double* __restrict__ ll_t, int32_t* __restrict__ ess_t, int force_exact,
-    double* __restrict__ pick_out, uint32_t pick_slot) {
-  static_assert(CSSM_BLOCK == 256 && CSSM_ITEMS == 4, "k_step: four waves, four units per thread");
-  static_assert(CH % (CSSM_BLOCK * IT) == 0 && CH <= CSSM_TILE && CH >= CSSM_BLOCK, "whole propagate tiles per block");
-  constexpr int PI = CH / CSSM_BLOCK;                                      // parents per thread and unit; slots per thread
-  constexpr int NW = CSSM_BLOCK / 64;
-  __shared__ double s_max[NW];
-  __shared__ cssm_u128 s_w[NW], s_t2[NW], s_toff;
-  __shared__ uint32_t s_last[NW], s_q[2];
-  __shared__ uint32_t s_eu[CSSM_STEP_UNITS + 1];                           // end slot before unit q (s_eu[0] = 0) ... after the last
-  __shared__ __attribute__((aligned(16))) uint32_t s_anc[CH];
-  __shared__ __attribute__((aligned(16))) unsigned char s_stage[PropStage<D, IT>::bytes];
-  const StepRec* const recp = rec - 1;                                     // the observation being resampled
-  const uint32_t tid = threadIdx.x;
-  const int lane = (int)(tid & 63u), wid = (int)(tid >> 6);
-  // ---- A: everything the prologue needs is requested before anything is waited for
-#ifdef CSSM_STEP_STAMPS
-  const unsigned long long ts0 = wall_clock64();
-#endif
-  const uint32_t held = sc->err;
-  cssm_u128 us[CSSM_ITEMS];
-#pragma unroll
-  for (int k = 0; k < CSSM_ITEMS; ++k) {
-    const uint32_t q = tid * CSSM_ITEMS + (uint32_t)k;
-    us[k] = (q < nunits) ? inS[q] : cssm_u128_zero();
-  }
-  cssm_u128 t2 = cssm_u128_zero();
-  if (blockIdx.x == 0) {
-#pragma unroll
-    for (int k = 0; k < CSSM_ITEMS; ++k) {
-      const uint32_t q = tid * CSSM_ITEMS + (uint32_t)k;
-      if (q < nunits) t2 = cssm_u128_add(t2, inS2[q]);
-    }
-  }
-  if (tid == 0) { s_q[0] = 0xffffffffu; s_q[1] = 0u; s_eu[0] = 0u; }
-  const double gmax_dec = block_decode_slots(sc, set_in);
-#if CSSM_STEP_STAMPS == 2
-  const unsigned long long ta1 = wall_clock64();
-#endif
-  const double* tab = stage_log_table(logtab);
-#if CSSM_STEP_STAMPS == 2
-  const unsigned long long ta2 = wall_clock64();
-#endif
-  if (held & (4u | 8u | 64u)) return;
-  const double cref = recp->ref;
-  if (!(cssm_ref_choose(cref, gmax_dec) == cref)) {   // the max rules the level out: hold the series at observation s - 1
-    if (blockIdx.x == 0 && tid == 0) { sc->gmax = gmax_dec; atomicMin(&sc->fail_step, recp->step); atomicOr(&sc->err, 64u); }
-    return;
-  }
-  // inclusive prefix of the unit sums: in the thread, across the wave (DPP), across the waves (LDS)
-  cssm_u128 inc[CSSM_ITEMS];
-  inc[0] = us[0];
-#pragma unroll
-  for (int k = 1; k < CSSM_ITEMS; ++k) inc[k] = cssm_u128_add(inc[k - 1], us[k]);
-  const cssm_u128 wsum = wave_scan_u128(inc[CSSM_ITEMS - 1], lane);
-  if (lane == 63) s_w[wid] = wsum;
-  if (blockIdx.x == 0) { t2 = wave_sum_u128(t2); if (lane == 0) s_t2[wid] = t2; }
-  __syncthreads();
-#if CSSM_STEP_STAMPS == 2
-  const unsigned long long ta3 = wall_clock64();
-#endif
-  cssm_u128 excl = cssm_u128_zero(), tot = s_w[0];
-#pragma unroll
-  for (int w = 0; w < NW; ++w) {
-    if (w < wid) excl = cssm_u128_add(excl, s_w[w]);
-    if (w > 0) tot = cssm_u128_add(tot, s_w[w]);
-  }
-  {   // exclusive prefix of this thread's first unit = waves before + lanes before
-    const cssm_u128 a = cssm_u128_add(excl, wsum), b = inc[CSSM_ITEMS - 1];
-    excl.lo = a.lo - b.lo; excl.hi = a.hi - b.hi - (a.lo < b.lo ? 1u : 0u);
-  }
-  SlotMap sm;
-  sm.set(tot, recp->u, (uint64_t)n, force_exact);
-#pragma unroll
-  for (int k = 0; k < CSSM_ITEMS; ++k) {
-    const uint32_t q = tid * CSSM_ITEMS + (uint32_t)k;
-    if (q < nunits) s_eu[q + 1] = sys_end_slot(cssm_u128_add(excl, inc[k]), sm);
-  }
-  if (blockIdx.x == 0) {
-    if (tid == 0) {                                       // publish observation s - 1's scalars once
-      cssm_u128 tot2 = s_t2[0];
-#pragma unroll
-      for (int w = 1; w < NW; ++w) tot2 = cssm_u128_add(tot2, s_t2[w]);
-      sc->gmax = gmax_dec; sc->ref = cref; sc->S_off = cssm_u128_zero(); sc->S_local = tot; sc->S2_local = tot2;
-      sc->S_tot = tot; sc->S2_tot = tot2;
-      finish_step(sc, (uint64_t)n);
-      if (ll_t) { ll_t[recp->step] = sc->ll; ess_t[recp->step] = sc->ess; }
-    }
-    if (tid < CSSM_MAXSLOTS)                               // the set observation s + 1 will collect its max in
-      sc->maxslot[((size_t)((set_in + 2) % CSSM_MAXSETS) * CSSM_MAXSLOTS + tid) * CSSM_SLOT_STRIDE] = 0ull;
-  }
-  __syncthreads();
-#if CSSM_STEP_STAMPS == 2
-  const unsigned long long ta4 = wall_clock64();
-#endif
-  const uint32_t lo = blockIdx.x * (uint32_t)CH;
-  const uint32_t hi = (n - lo < (uint32_t)CH) ? n : lo + (uint32_t)CH;
-  // the units whose particles own slots of [lo, hi): a contiguous range (end slots grow with the particles)
-#pragma unroll
-  for (int k = 0; k < CSSM_ITEMS; ++k) {
-    const uint32_t q = tid * CSSM_ITEMS + (uint32_t)k;
-    if (q < nunits && s_eu[q] < hi && s_eu[q + 1] > lo) { atomicMin(&s_q[0], q); atomicMax(&s_q[1], q); }
-  }
-#pragma unroll
-  for (int k = 0; k < PI; ++k) s_anc[tid * PI + k] = 0u;
-  __syncthreads();
-  const uint32_t q_lo = s_q[0], q_hi = s_q[1];
-#pragma unroll
-  for (int k = 0; k < CSSM_ITEMS; ++k)                     // cumulative weight before unit q_lo (static indices: no scratch)
-    if (tid * CSSM_ITEMS + (uint32_t)k == q_lo) s_toff = (k == 0) ? excl : cssm_u128_add(excl, inc[(k + CSSM_ITEMS - 1) % CSSM_ITEMS]);
-  __syncthreads();
-#ifdef CSSM_STEP_STAMPS
-  const unsigned long long ts1 = wall_clock64();
-#endif
-  // ---- B: the parents' end slots; run heads into LDS.  (No unit covers the range only when the weights are unusable --
-  // all zero: err bit 1 is up -- and then the ancestors are whatever in-range indices phase C makes of an empty table.)
-  if (q_lo <= q_hi && q_hi < nunits) {
-    cssm_u128 toff = s_toff;
-    for (uint32_t q = q_lo; q <= q_hi; ++q) {
-      if (s_eu[q] == s_eu[q + 1]) { toff = cssm_u128_add(toff, inS[q]); continue; }   // a unit without offspring (uniform)
-      const uint32_t base = q * (uint32_t)CH;
-      const uint32_t i0 = base + tid * PI;
-      double v[PI];
-      if (PI >= 2 && i0 + PI <= n) {
-#pragma unroll
-        for (int r = 0; r + 1 < PI; r += 2) { const double2 a = *reinterpret_cast<const double2*>(logw_in + i0 + r); v[r] = a.x; v[(r + 1) % PI] = a.y; }
-      } else {
-#pragma unroll
-        for (int r = 0; r < PI; ++r) v[r] = (i0 + r < n) ? logw_in[i0 + r] : -cssm_inf();
-      }
-      cssm_u128 fx[PI];
-      cssm_u128 tsum = cssm_u128_zero();
-#pragma unroll
-      for (int r = 0; r < PI; ++r) { fx[r] = cssm_fix_from_double(cssm_exp(v[r] - cref)); tsum = cssm_u128_add(tsum, fx[r]); }
-      const cssm_u128 incw = wave_scan_u128(tsum, lane);
-      if (lane == 63) s_w[wid] = incw;
-      __syncthreads();
-      cssm_u128 run = toff;
-#pragma unroll
-      for (int w = 0; w < NW; ++w) if (w < wid) run = cssm_u128_add(run, s_w[w]);
-      run = cssm_u128_add(run, incw);
-      { cssm_u128 r; r.lo = run.lo - tsum.lo; r.hi = run.hi - tsum.hi - (run.lo < tsum.lo ? 1u : 0u); run = r; }
-      uint32_t e[PI];
-#pragma unroll
-      for (int r = 0; r < PI; ++r) { run = cssm_u128_add(run, fx[r]); e[r] = sys_end_slot(run, sm); }
-      if (lane == 63) s_last[wid] = e[PI - 1];
-      uint32_t prev = dpp0<0x138 /* wave_shr:1 */, 0xf>(e[PI - 1]);
-      __syncthreads();
-      if (lane == 0) prev = (wid > 0) ? s_last[wid - 1] : s_eu[q];   // (the globally first particle's run starts at slot 0 = s_eu[0])
-#pragma unroll
-      for (int r = 0; r < PI; ++r) {
-        uint32_t b = (r == 0) ? prev : e[(r + PI - 1) % PI];
-        uint32_t ee = e[r];
-        b = (b < lo) ? lo : b;
-        ee = (ee > hi) ? hi : ee;
-        if (ee > b) s_anc[b - lo] = i0 + (uint32_t)r + 1u;      // index + 1 at the first slot of the run (0 = no run starts here)
-      }
-      cssm_u128 ttot = s_w[0];
-#pragma unroll
-      for (int w = 1; w < NW; ++w) ttot = cssm_u128_add(ttot, s_w[w]);
-      toff = cssm_u128_add(toff, ttot);
-      __syncthreads();                                            // s_w / s_last are rewritten by the next unit
-    }
-  }
-#ifdef CSSM_STEP_STAMPS
-  const unsigned long long ts2 = wall_clock64();
-#endif
-  // ---- C: fill the runs
-  {
-    uint32_t vv[PI];
-#pragma unroll
-    for (int k = 0; k < PI; ++k) vv[k] = s_anc[tid * PI + k];
-#pragma unroll
-    for (int k = 1; k < PI; ++k) vv[k] = (vv[k - 1] > vv[k]) ? vv[k - 1] : vv[k];
-    const uint32_t incl = wave_scan_max_u32(vv[PI - 1]);
-    if (lane == 63) s_last[wid] = incl;
-    uint32_t carry = dpp0<0x138 /* wave_shr:1 */, 0xf>(incl);
-    __syncthreads();
-#pragma unroll
-    for (int w = 0; w < NW; ++w) if (w < wid) carry = (s_last[w] > carry) ? s_last[w] : carry;
-    const uint32_t n_last = n - 1u;
-#pragma unroll
-    for (int k = 0; k < PI; ++k) {
-      uint32_t x = (vv[k] > carry) ? vv[k] : carry;
-      x = (x > 0u) ? x - 1u : 0u;
-      vv[k] = (x > n_last) ? n_last : x;                          // (never: the only data-dependent address of the path stays in range)
-    }
-#pragma unroll
-    for (int k = 0; k < PI; ++k) s_anc[tid * PI + k] = vv[k];
-    __syncthreads();
-  }
-#ifdef CSSM_STEP_STAMPS
-  const unsigned long long ts3 = wall_clock64();
-#endif
-  // ---- D: gather through the ancestors in LDS, transition, weigh, sums
-  PropAcc acc;
-  propagate_range<D, false, IT, OBS, true, false, true>(src, src_stride, s_anc, dst, dst_stride, logw_out, 0ull, seed, rec, mk, nullptr, 0, 0u, tab,
-                                                        lo, hi, 1, pick_out, pick_slot, nullptr, s_stage, acc);
-#ifdef CSSM_STEP_STAMPS
-  const unsigned long long ts4 = wall_clock64();
-#endif
-  // ---- E
-  double tmax = wave_max(acc.tmax);
-  if (lane == 0) s_max[wid] = tmax;
-  if (__any(acc.bad) && lane == 0) atomicOr(&sc->err, 1u);
-  const cssm_u128 accS = wave_sum_u128(acc.S), accS2 = wave_sum_u128(acc.S2);
-  if (lane == 0) { s_w[wid] = accS; s_t2[wid] = accS2; }
-  __syncthreads();
-  if (tid == 0) {
-    cssm_u128 ta = s_w[0], tb = s_t2[0];
-    double m = s_max[0];
-#pragma unroll
-    for (int w = 1; w < NW; ++w) { ta = cssm_u128_add(ta, s_w[w]); tb = cssm_u128_add(tb, s_t2[w]); m = (s_max[w] > m) ? s_max[w] : m; }
-    outS[blockIdx.x] = ta; outS2[blockIdx.x] = tb;
-    atomicMax(&sc->maxslot[((size_t)((set_in + 1) % CSSM_MAXSETS) * CSSM_MAXSLOTS + blockIdx.x % CSSM_MAXSLOTS) * CSSM_SLOT_STRIDE],
-              (unsigned long long)cssm_order_key(m));
-  }
-#ifdef CSSM_STEP_STAMPS
-  // (experiment) block 0 replaces ll_t of the resampled observation by its own phase durations, in ticks of 10 ns, three digits each
-  if (blockIdx.x == 0 && tid == 0 && ll_t) {
-    const unsigned long long ts5 = wall_clock64();
-    auto c3 = [](unsigned long long a) { return (double)(a > 999ull ? 999ull : a); };
-#if CSSM_STEP_STAMPS == 2
-    ll_t[recp->step] = c3(ta1 - ts0) + 1e3 * c3(ta2 - ta1) + 1e6 * c3(ta3 - ta2) + 1e9 * c3(ta4 - ta3) + 1e12 * c3(ts1 - ta4);
-#else
-    ll_t[recp->step] = c3(ts1 - ts0) + 1e3 * c3(ts2 - ts1) + 1e6 * c3(ts3 - ts2) + 1e9 * c3(ts4 - ts3) + 1e12 * c3(ts5 - ts4);
-#endif
-  }
-#endif
 }

@@ -1,0 +1,86 @@
+// cssm_records.h -- the records that cross from the host model code to the kernels: per-model constants (ModelK) and the
+// per-observation record (StepRec).  Plain C++ (no HIP): cssm_model.cpp -- descriptor validation, build_rec, the PMMH loop --
+// compiles with any host compiler (and under sanitizers: oracle/Makefile, target `san`), the kernels include it through
+// cssm_device.hip.h.
+#pragma once
+
+#include <stdint.h>
+
+#include <vector>
+
+#include "../../include/cssm_numerics.h"
+#include "../../include/cssm_pf.h"
+
+#if defined(__HIPCC__)
+#define CSSM_HDM __host__ __device__ __forceinline__
+#else
+#define CSSM_HDM inline
+#endif
+
+// f-map modes per component (host-built from the leaf list; oracle: gamma_of)
+#define FM_SKIP 0
+#define FM_START 1 /* first used component of a leaf: acc = c*x  */
+#define FM_ADD 2   /* acc += c*x                                 */
+
+// Per-model constants, passed BY VALUE (kernarg -> SGPRs; every branch on them is wave-uniform).
+// One byte per latent component: bits 0-1 CSSM_SDE_*, bits 2-3 FM_*, bit 4 closes its leaf, bit 5 leaf is
+// the leftmost one.  Packed four to a word so that the whole struct costs 6 SGPRs (66 unpacked made the
+// kernel spill scalars through v_writelane/v_readlane).
+struct ModelK {
+  int32_t d;
+  int32_t obs_kind;
+  uint32_t comp[CSSM_MAX_DIM / 4];
+  CSSM_HDM uint32_t byte(int k) const { return (comp[k >> 2] >> ((k & 3) * 8)) & 0xffu; }
+  CSSM_HDM int kind(int k) const { return (int)(byte(k) & 3u); }
+  CSSM_HDM int fmode(int k) const { return (int)((byte(k) >> 2) & 3u); }
+  CSSM_HDM bool leaf_end(int k) const { return (byte(k) >> 4) & 1u; }
+  CSSM_HDM bool first_leaf(int k) const { return (byte(k) >> 5) & 1u; }
+};
+
+// Per-observation record, built on the host (everything that depends only on (t, y)): build_rec, cssm_model.cpp.
+struct StepRec {
+  double y;       // count models: (double)trunc(y); otherwise y
+  double c[4];    // per-observation constants of the density (see build_rec / logdens)
+  double cdf;     // Student-t: degrees of freedom as double
+  double u;       // the one uniform of systematic resampling
+  double dt;      // time increment (LGCP: the sub-step delta)
+  double ref;     // reference level of the observation (cssm_ref_level; NaN: always rescale by the max)
+  int32_t has_obs;
+  int32_t n_sub;  // LGCP sub-steps (0: dt == 0, weight 0, state kept)
+  uint32_t pick;  // sampleOne index for `filter`
+  uint32_t step;  // observation index (Philox counter word 2)
+  double coef[CSSM_MAX_DIM][4]; // transition coefficients per component
+  double fco[CSSM_MAX_DIM];     // f coefficients c_k(t)
+  double t_obs;                 // the observation's time (LGCP with a time-dependent f: the sub-step clock starts here)
+  uint32_t fsub_off;            // LGCP with a time-dependent f: where this observation's n_sub x d coefficients c_k(tau_s) start
+  uint32_t pad2_;               //   in the handle's sub-step table (doubles)
+};
+
+// One latent component of the composed model, constraint transforms applied (model/Sde.scala:70-73,99-102,133-137).
+struct Comp {
+  int kind, leaf, idx, f_kind, period;
+  double m0, c0, mu, phi, sigma;
+};
+
+// The model as the host sees it: what descriptor validation produces and build_rec consumes.  cssm_pf (cssm_internal.h)
+// derives from it; nothing here touches a device.
+struct HostModel {
+  int d = 0, n_leaves = 0, obs_kind = 0, precision = 0, obs_df = 0;
+  double scale_sd = 1.0;       // exp(scale): Gaussian sd, NegBin size, Student-t v
+  double scale_raw = 0.0;      // ZIP: the stored scale v
+  Comp comp[CSSM_MAX_DIM];
+  ModelK mk;
+  bool lgcp_tdep = false;      // LGCP whose f depends on time (a seasonal leaf): f is evaluated at every sub-step time
+  uint64_t n_global = 0, seed = 0;   // (build_rec: sampleOne's index, the Philox key of the resampling uniform)
+};
+
+// ---- cssm_model.cpp (host only) ----
+int cssm_fail(int code, const char* fmt, ...);   // sets the thread-local message of cssm_last_error(), returns code
+// Validate and translate a descriptor; `update`: re-parameterise -- the STRUCTURE must be the one `m` already has.
+int cssm_build_model(HostModel* m, const cssm_model_desc* desc, bool update);
+// Everything of one observation that does not depend on the particle (records for the kernels).
+void cssm_build_rec(const HostModel* m, double t_prev, double t, double y, int has_obs, uint32_t step, StepRec* r);
+// LGCP with a time-dependent f (FilterLgcp.calcWeight evaluates f at every simulated time, model/ParticleFilter.scala:193-205):
+// append the n_sub x d coefficient rows of records recs[first .. first + count) to `table` and set their fsub_off;
+// CSSM_ENOMEM if the table would exceed 1 GiB.  No-op for every other model.
+int cssm_build_fsub_table(const HostModel* m, StepRec* recs, size_t first, size_t count, std::vector<double>& table);

@@ -1,0 +1,607 @@
+// cssm_shard.hip -- the sharded filter of libcssm_pf: the cssm_pf_shard_* stage calls between which the caller runs its
+// collectives, and the series loop in which the library issues them itself (RCCL over xGMI, resolved at run time).
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <mutex>
+#include <thread>
+
+#include "cssm_internal.h"
+#include "cssm_shard_kernels.hip.h"
+
+// ------------------------------------------------------------------------------------ sharded stages
+// One process per GPU; the collectives between the stages belong to the caller (RCCL through
+// torch.distributed).  See include/cssm_pf.h for the sequence.
+
+// level of the step from the all-gathered order keys (word 4 of every rank's 5 words)
+__global__ void k_import_level(Scalars* sc, const unsigned long long* __restrict__ all5, int world, const StepRec* __restrict__ rec) {
+  unsigned long long key = 0ull;
+  for (int r = 0; r < world; ++r) { const unsigned long long k = all5[5 * r + 4]; key = (k > key) ? k : key; }
+  sc->gmax = cssm_order_unkey(key);
+  sc->ref = cssm_ref_choose(rec->ref, sc->gmax);   // the level every kernel of the step agrees on (k_tile_sums applies the same rule)
+}
+
+// For every destination rank q (owner of slots [q*n_per, min((q+1)*n_per, N))): the contiguous
+// range of LOCAL particles that own at least one of q's slots.  One thread per q.
+__global__ void k_send_ranges(const uint32_t* __restrict__ endslot, uint64_t n_local, const Scalars* __restrict__ sc,
+                              const StepRec* __restrict__ rec, uint64_t n_global, int rank, int world, uint64_t n_per,
+                              long long* __restrict__ first, long long* __restrict__ count) {
+  const int q = blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= world) return;
+  uint64_t b_lo = (uint64_t)q * n_per, b_hi = b_lo + n_per;
+  if (b_lo > n_global) b_lo = n_global;
+  if (b_hi > n_global) b_hi = n_global;
+  uint64_t e_before = 0;   // end slot of the last particle of the previous rank
+  if (rank > 0) e_before = cssm_sys_count(cssm_u128_to_double(sc->S_off) / cssm_u128_to_double(sc->S_tot), rec->u, n_global);
+  // j_lo = first local j with endslot[j] > b_lo
+  uint64_t lo = 0, hi = n_local;
+  while (lo < hi) { const uint64_t mid = (lo + hi) >> 1; if ((uint64_t)endslot[mid] > b_lo) hi = mid; else lo = mid + 1; }
+  const uint64_t j_lo = lo;
+  const uint64_t start = (j_lo == 0) ? e_before : (uint64_t)endslot[j_lo - 1];
+  if (b_lo >= b_hi || j_lo >= n_local || start >= b_hi) { first[q] = 0; count[q] = 0; return; }
+  // j_last = first local j with endslot[j] >= b_hi (it owns slot b_hi - 1), clamped
+  lo = j_lo; hi = n_local;
+  while (lo < hi) { const uint64_t mid = (lo + hi) >> 1; if ((uint64_t)endslot[mid] >= b_hi) hi = mid; else lo = mid + 1; }
+  uint64_t j_last = lo;
+  if (j_last >= n_local) j_last = n_local - 1;
+  first[q] = (long long)j_lo;
+  count[q] = (long long)(j_last - j_lo + 1);
+}
+
+// rows of d+1 doubles (the particle's state and its end slot) for every destination rank, destinations
+// back to back: row r belongs to the destination q with sum(count[<q]) <= r < sum(count[<=q])
+__global__ void k_pack(const double* __restrict__ src, size_t stride, const uint32_t* __restrict__ endslot, int d, int world,
+                       const long long* __restrict__ first, const long long* __restrict__ count, long long total, int skip,
+                       double* __restrict__ out) {
+  for (long long r = (long long)blockIdx.x * blockDim.x + threadIdx.x; r < total; r += (long long)gridDim.x * blockDim.x) {
+    long long off = 0;
+    int q = 0;
+    for (;;) {   // destination of row r; the rank's own range (`skip`) never travels
+      const long long c = (q == skip) ? 0 : count[q];
+      if (r < off + c || q == world - 1) break;
+      off += c; ++q;
+    }
+    const long long j = first[q] + (r - off);
+    double* row = out + r * (d + 1);
+    for (int k = 0; k < d; ++k) row[k] = src[(size_t)k * stride + (size_t)j];
+    row[d] = (double)endslot[j];
+  }
+}
+// Received rows (d+1 doubles: state, end slot) of the ranks below (first n_low rows) and above this one, in global
+// particle order: states go to the SoA candidate buffer, end slots and state indices to the candidate lists.
+__global__ void k_adopt_remote(const double* __restrict__ recv, long long m, int d,
+                               uint32_t n_split, double* __restrict__ cand, size_t cstride,
+                               uint32_t* __restrict__ cand_end, uint32_t* __restrict__ cand_idx) {
+  for (long long r = (long long)blockIdx.x * blockDim.x + threadIdx.x; r < m; r += (long long)gridDim.x * blockDim.x) {
+    const double* row = recv + r * (d + 1);
+    for (int k = 0; k < d; ++k) cand[(size_t)k * cstride + (size_t)r] = row[k];
+    cand_end[r] = (uint32_t)row[d];
+    cand_idx[r] = n_split + (uint32_t)r;
+  }
+}
+
+static int shard_prepare_step(cssm_pf* pf, const StepRec* d_rec, int weighted, uint64_t* sums5_dev);
+static int bounded_sync(cssm_pf* pf);
+// record of the step propagated last: a ring of 64 for streaming steps, the whole series after shard_begin
+static size_t last_rec_slot(const cssm_pf* pf) { return pf->series ? (size_t)(pf->step - 1) : (size_t)((pf->step - 1) % 64); }
+
+static int shard_check(cssm_pf* pf) {
+  if (!pf) return fail(CSSM_EINVAL_ARG, "null handle");
+  if (!pf->sharded) return fail(CSSM_ESTATE, "handle was not created with cssm_pf_create_shard");
+  HIP_TRY(hipSetDevice(pf->device));
+  return CSSM_OK;
+}
+
+extern "C" int cssm_pf_shard_init(cssm_pf* pf, double t0) {
+  int rc = shard_check(pf);
+  if (rc) return rc;
+  pf->series = false;
+  return cssm_launch_init(pf, t0);
+}
+
+extern "C" int cssm_pf_shard_propagate(cssm_pf* pf, double t, double obs, int has_obs, uint64_t* sums5_dev) {
+  int rc = shard_check(pf);
+  if (rc) return rc;
+  if (!pf->initialised) return fail(CSSM_ESTATE, "shard_propagate before shard_init");
+  // one record slot per step, round-robin, so that an in-flight step never sees its record overwritten
+  rc = cssm_ensure_recs(pf, 64);
+  if (rc) return rc;
+  const size_t slot = pf->step % 64;
+  cssm_build_rec(pf, pf->t, t, obs, has_obs, pf->step, &pf->h_recs[slot]);
+  rc = cssm_build_fsub(pf, slot, 1, true);
+  if (rc) return rc;
+  HIP_TRY(hipMemcpyAsync(pf->d_recs + slot, pf->h_recs + slot, sizeof(StepRec), hipMemcpyHostToDevice, pf->stream));
+  if (pf->series) return fail(CSSM_ESTATE, "a series begun with shard_begin is stepped with shard_propagate_at");
+  rc = shard_prepare_step(pf, pf->d_recs + slot, pf->h_recs[slot].has_obs, sums5_dev);
+  if (rc) return rc;
+  pf->t = t;
+  pf->step++;
+  return CSSM_OK;
+}
+
+extern "C" int cssm_pf_shard_sums(cssm_pf* pf, const uint64_t* all_sums5_dev, int world, uint64_t* sums5_dev) {
+  int rc = shard_check(pf);
+  if (rc) return rc;
+  if (!all_sums5_dev || !sums5_dev) return fail(CSSM_EINVAL_ARG, "null argument");
+  if (world < 1 || world > 64) return fail(CSSM_ESHARD, "world %d", world);
+  const size_t slot = last_rec_slot(pf);
+  const int tgrid = (int)pf->nunits;
+  hipLaunchKernelGGL(k_import_level, dim3(1), dim3(1), 0, pf->stream, pf->sc, (const unsigned long long*)all_sums5_dev, world,
+                     (const StepRec*)(pf->d_recs + slot));
+  hipLaunchKernelGGL(k_tile_sums, dim3(tgrid), dim3(CSSM_BLOCK), 0, pf->stream, pf->logw, pf->n, pf->sc, pf->tileS, pf->tileS2, pf->ntiles,
+                     pf->sup, pf->nunits, 0, -1, (const double*)nullptr, pf->d_logtab, (const StepRec*)(pf->d_recs + slot));
+  // word 4 (the max key) of sums5_dev is left as shard_propagate wrote it
+  hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(1024), 0, pf->stream, pf->tileS, pf->tileS2, pf->tileP, pf->nunits, pf->sc, pf->n_global, 0,
+                     (double*)nullptr, (int32_t*)nullptr, 0u, (const double*)nullptr, (unsigned long long*)sums5_dev, 0);
+  HIP_TRY(hipGetLastError());
+  pf->last_optimistic = false;
+  return CSSM_OK;
+}
+
+extern "C" int cssm_pf_shard_offspring(cssm_pf* pf, const uint64_t* all_sums5_dev, int rank, int world,
+                                       int64_t* send_first_dev, int64_t* send_count_dev, uint64_t* redo_flag_dev) {
+  int rc = shard_check(pf);
+  if (rc) return rc;
+  if (!all_sums5_dev || !send_first_dev || !send_count_dev || !redo_flag_dev) return fail(CSSM_EINVAL_ARG, "null argument");
+  if (world < 1 || world > 64 || rank < 0 || rank >= world) return fail(CSSM_ESHARD, "rank %d / world %d", rank, world);
+  const uint64_t n_per = (pf->n_global + (uint64_t)world - 1) / (uint64_t)world;
+  if (pf->first != (uint64_t)rank * n_per) return fail(CSSM_ESHARD, "rank %d must own particles from %llu (ceil(N/world) per rank), handle starts at %llu",
+                                                       rank, (unsigned long long)((uint64_t)rank * n_per), (unsigned long long)pf->first);
+  const size_t slot = last_rec_slot(pf);
+  const int tgrid = (int)pf->nunits;
+  const int optimistic = pf->last_optimistic ? 1 : 0;
+  // the rank's own particles write their runs inside the rank's slots straight into anc (indexed from the first
+  // own slot); the end slots are kept for the send ranges; slots owned by other ranks' particles are filled by adopt
+  hipLaunchKernelGGL((k_offspring<true, false, CSSM_RESAMPLE_SYSTEMATIC>), dim3(tgrid), dim3(CSSM_BLOCK), 0, pf->stream, pf->logw, pf->n, pf->sc,
+                     (const cssm_u128*)pf->tileS, (const cssm_u128*)pf->tileS2, pf->d_recs + slot, pf->n_global, pf->endslot,
+                     pf->anc, pf->ntiles, pf->sup, pf->nunits, 0, 0, (double*)nullptr, (int32_t*)nullptr, 0u, pf->opt_exact,
+                     (const unsigned long long*)all_sums5_dev, rank, world, optimistic ? (int)pf->split : 1, pf->seed, (double*)nullptr, pf->d_logtab,
+                     optimistic, (unsigned long long*)redo_flag_dev, (uint32_t)pf->first, (uint32_t)(pf->first + pf->n));
+  pf->send_first_dev = (const long long*)send_first_dev; pf->send_count_dev = (const long long*)send_count_dev;
+  hipLaunchKernelGGL(k_send_ranges, dim3(1), dim3(64), 0, pf->stream, pf->endslot, pf->n, pf->sc, pf->d_recs + slot, pf->n_global, rank, world,
+                     n_per, (long long*)send_first_dev, (long long*)send_count_dev);
+  HIP_TRY(hipGetLastError());
+  return CSSM_OK;
+}
+
+// ---- a series known in advance: records resident on the device, observations propagated by index ----------------
+// first j in [0, n) with endslot[j] > bound (strict) or >= bound, n if there is none; endslot is non-decreasing.
+// All 64 lanes of a wave call it: every round probes 64 equally spaced positions of the bracket (4 rounds for 2^24).
+__device__ __forceinline__ uint64_t wave_search_first(const uint32_t* __restrict__ endslot, uint64_t n, uint64_t bound, bool strict) {
+  const int lane = threadIdx.x & 63;
+  uint64_t lo = 0, hi = n;                                // the answer is in [lo, hi]
+  while (hi > lo) {
+    const uint64_t width = hi - lo;
+    const uint64_t step = (width + 63) / 64;
+    const uint64_t idx = lo + (uint64_t)lane * step;      // lane l probes the first element of its sub-range
+    bool t = false;
+    if (idx < hi) { const uint64_t v = endslot[idx]; t = strict ? (v > bound) : (v >= bound); }
+    else t = true;                                        // beyond the bracket counts as "true" (hi itself is the fallback answer)
+    const unsigned long long m = __ballot(t);
+    const int f = m ? (__ffsll((long long)m) - 1) : 64;   // first lane whose probe is true
+    if (f == 0) { hi = lo; break; }                       // the very first element of the bracket satisfies it
+    // the probe of lane f-1 is false, the probe of lane f is true: the answer is in (idx_{f-1}, idx_f]
+    const uint64_t new_lo = lo + (uint64_t)(f - 1) * step + 1;
+    const uint64_t new_hi = (f < 64 && lo + (uint64_t)f * step < hi) ? lo + (uint64_t)f * step : hi;
+    lo = new_lo; hi = new_hi;
+    if (step == 1) { lo = hi = new_hi; break; }           // sub-ranges were single elements: idx_f (or hi) is the answer
+  }
+  return hi;
+}
+
+static int shard_prepare_step(cssm_pf* pf, const StepRec* d_rec, int weighted, uint64_t* sums5_dev) {
+  int rc = cssm_launch_propagate(pf, d_rec);
+  if (rc) return rc;
+  if (weighted && sums5_dev) {   // (sums5_dev == nullptr: the single-collective exchange totals the sums in k_boundary_pack)
+    // the rank's totals of the sub-unit sums k_propagate formed and the order key of its max -> 5 words for the all-gather
+    const uint64_t chunk = (uint64_t)pf->sup * CSSM_TILE / pf->split;
+    const uint32_t nsub = (uint32_t)((pf->n + chunk - 1) / chunk);
+    if (!pf->last_optimistic) {   // LGCP: only the max travels
+      HIP_TRY(hipMemsetAsync(pf->tileS, 0, (size_t)nsub * sizeof(cssm_u128), pf->stream));
+      HIP_TRY(hipMemsetAsync(pf->tileS2, 0, (size_t)nsub * sizeof(cssm_u128), pf->stream));
+    }
+    hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(1024), 0, pf->stream, pf->tileS, pf->tileS2, pf->tileP, nsub, pf->sc, pf->n_global, 0,
+                       (double*)nullptr, (int32_t*)nullptr, 0u, (const double*)nullptr, (unsigned long long*)sums5_dev, 1);
+    HIP_TRY(hipGetLastError());
+  }
+  return CSSM_OK;
+}
+
+extern "C" int cssm_pf_shard_begin(cssm_pf* pf, const double* t, const double* y, const uint8_t* has_obs, size_t T) {
+  int rc = shard_check(pf);
+  if (rc) return rc;
+  if (!t || !y) return fail(CSSM_EINVAL_ARG, "null argument");
+  if (T < 1) return fail(CSSM_EINVAL_ARG, "empty data");
+  rc = cssm_ensure_recs(pf, T);
+  if (rc) return rc;
+  if (pf->need_cap < T) {
+    if (pf->d_need) (void)hipFree(pf->d_need);
+    pf->d_need = nullptr;
+    HIP_TRY(hipMalloc(&pf->d_need, T * 4));
+    pf->need_cap = T;
+  }
+  HIP_TRY(hipMemsetAsync(pf->d_need, 0, T * 4, pf->stream));
+  double t0 = t[0];
+  for (size_t s = 1; s < T; ++s) if (t[s] < t0) t0 = t[s];
+  double tp = t0;
+  for (size_t s = 0; s < T; ++s) { cssm_build_rec(pf, tp, t[s], y[s], has_obs ? has_obs[s] : 1, (uint32_t)s, &pf->h_recs[s]); tp = t[s]; }
+  rc = cssm_build_fsub(pf, 0, T, true);
+  if (rc) return rc;
+  HIP_TRY(hipMemcpyAsync(pf->d_recs, pf->h_recs, T * sizeof(StepRec), hipMemcpyHostToDevice, pf->stream));
+  rc = cssm_launch_init(pf, t0);
+  if (rc) return rc;
+  pf->series = true;
+  return CSSM_OK;
+}
+
+extern "C" int cssm_pf_shard_propagate_at(cssm_pf* pf, size_t s, uint64_t* sums5_dev) {
+  int rc = shard_check(pf);
+  if (rc) return rc;
+  if (!pf->series || !pf->initialised) return fail(CSSM_ESTATE, "shard_propagate_at before shard_begin");
+  if (s >= pf->h_recs_cap || s != pf->step) return fail(CSSM_ESTATE, "steps of a series run in order (expected %u)", pf->step);
+  rc = shard_prepare_step(pf, pf->d_recs + s, pf->h_recs[s].has_obs, sums5_dev);
+  if (rc) return rc;
+  pf->step++;
+  if (pf->snaps.size() <= s) pf->snaps.resize(s + 1);
+  pf->snaps[s] = {pf->cur, pf->src, pf->src_stride, pf->src2, pf->src2_stride, pf->n_split, pf->anc_valid, pf->last_optimistic, pf->step, pf->t};
+  return CSSM_OK;
+}
+
+// A capacity miss of the single-collective series is not the end of the series.  k_offspring_expand_spec of the observation
+// that missed did nothing (on every rank alike: the verdict is a function of the segment headers), recorded the observation
+// index, and every later kernel returned at once.  This call reads that index, clears the bit and rewinds the host-side
+// state to "observation fail_step propagated, not yet resampled": the host then redoes that observation's exchange with
+// a larger capacity (boundary_pack, all-to-all, adopt_spec) and continues the series after it.
+extern "C" int cssm_pf_shard_resume(cssm_pf* pf, uint32_t* fail_step_out) {
+  int rc = shard_check(pf);
+  if (rc) return rc;
+  if (!fail_step_out) return fail(CSSM_EINVAL_ARG, "null argument");
+  rc = bounded_sync(pf);   // (first: a copy into pageable memory would wait for the stream without a bound)
+  if (rc) return rc;
+  Scalars h;
+  HIP_TRY(hipMemcpyAsync(CSSM_SC_TAIL_ARGS(&h, pf->sc), hipMemcpyDeviceToHost, pf->stream));
+  HIP_TRY(hipStreamSynchronize(pf->stream));
+  if (!(h.err & 8u) || h.fail_step == 0xffffffffu || h.fail_step >= pf->snaps.size())
+    return fail(CSSM_ESTATE, "no resumable capacity miss is recorded");
+  if (h.err & 7u) return fail(CSSM_ESTATE, "the series has other errors (bits %u)", h.err);
+  const uint32_t s = h.fail_step;
+  h.err &= ~8u; h.fail_step = 0xffffffffu;
+  // only err and fail_step change on the device (ll, ess, sums stay what the last completed observation left)
+  HIP_TRY(hipMemcpyAsync(&pf->sc->err, &h.err, sizeof(uint32_t), hipMemcpyHostToDevice, pf->stream));
+  HIP_TRY(hipMemcpyAsync(&pf->sc->fail_step, &h.fail_step, sizeof(uint32_t), hipMemcpyHostToDevice, pf->stream));
+  HIP_TRY(hipStreamSynchronize(pf->stream));
+  const cssm_pf::Snap& q = pf->snaps[s];
+  pf->cur = q.cur; pf->src = q.src; pf->src_stride = q.src_stride; pf->src2 = q.src2; pf->src2_stride = q.src2_stride;
+  pf->n_split = q.n_split; pf->anc_valid = q.anc_valid; pf->last_optimistic = q.last_optimistic; pf->step = q.step; pf->t = q.t;
+  *fail_step_out = s;
+  return CSSM_OK;
+}
+
+// ---- single-collective exchange (k_boundary_pack / k_expand_spec in cssm_kernels.hip.h)
+
+extern "C" int64_t cssm_pf_shard_spec_segment(const cssm_pf* pf, int64_t cap) {
+  return (pf && cap >= 1) ? (int64_t)spec_seg(pf->d, (long long)cap) : 0;
+}
+
+extern "C" int cssm_pf_shard_boundary_pack(cssm_pf* pf, int rank, int world, int64_t cap, double* send_buf_dev) {
+  int rc = shard_check(pf);
+  if (rc) return rc;
+  if (!send_buf_dev) return fail(CSSM_EINVAL_ARG, "null argument");
+  if (cap < 1 || world < 1 || world > 64 || rank < 0 || rank >= world) return fail(CSSM_ESHARD, "rank %d / world %d / cap %lld", rank, world, (long long)cap);
+  // !last_optimistic: the sums were formed by cssm_pf_shard_sums relative to the level chosen with the all-gathered max
+  const size_t slot = last_rec_slot(pf);
+  const uint64_t chunk = (uint64_t)pf->sup * CSSM_TILE / pf->split;
+  const uint32_t nsub = (uint32_t)((pf->n + chunk - 1) / chunk);
+  const long long cnt = std::min<long long>((long long)pf->n, (long long)cap);
+  const int tiles = (int)((cnt + CSSM_TILE - 1) / CSSM_TILE);
+  hipLaunchKernelGGL(k_boundary_pack, dim3(tiles + 1, world), dim3(CSSM_BLOCK), 0, pf->stream, pf->state[pf->cur], pf->stride, pf->logw, pf->n, pf->d,
+                     world, rank, (long long)cap, pf->d_recs + slot, (const cssm_u128*)pf->tileS, (const cssm_u128*)pf->tileS2, nsub,
+                     (const Scalars*)pf->sc, send_buf_dev, chunk, pf->last_optimistic ? 0 : 1);
+  HIP_TRY(hipGetLastError());
+  return CSSM_OK;
+}
+
+extern "C" int cssm_pf_shard_adopt_spec(cssm_pf* pf, const double* recv_buf_dev, int rank, int world, int64_t cap) {
+  int rc = shard_check(pf);
+  if (rc) return rc;
+  if (!recv_buf_dev) return fail(CSSM_EINVAL_ARG, "recv_buf_dev is null");
+  if (cap < 1 || world < 1 || world > 64 || rank < 0 || rank >= world) return fail(CSSM_ESHARD, "rank %d / world %d / cap %lld", rank, world, (long long)cap);
+  const uint64_t n_per = (pf->n_global + (uint64_t)world - 1) / (uint64_t)world;
+  if (pf->first != (uint64_t)rank * n_per) return fail(CSSM_ESHARD, "rank %d must own particles from %llu", rank, (unsigned long long)((uint64_t)rank * n_per));
+  const size_t slot = last_rec_slot(pf);
+  const int tgrid = (int)pf->nunits;
+  const long long seg = spec_seg(pf->d, (long long)cap);
+  // the 5 words of every rank are the header words 1..5 of its segment (the all-to-all delivered this rank's own too)
+  const unsigned long long* all5 = reinterpret_cast<const unsigned long long*>(recv_buf_dev) + 1;
+  const uint32_t n_split = (uint32_t)pf->n;
+  hipLaunchKernelGGL(k_offspring_expand_spec, dim3(tgrid), dim3(CSSM_BLOCK), 0, pf->stream, pf->logw, pf->n, pf->sc,
+                     (const cssm_u128*)pf->tileS, (const cssm_u128*)pf->tileS2, (const StepRec*)(pf->d_recs + slot), pf->n_global, pf->endslot,
+                     pf->anc, pf->ntiles, pf->sup, pf->nunits, 0, 0, (double*)nullptr, (int32_t*)nullptr, 0u, pf->opt_exact,
+                     all5, rank, world, (int)pf->split, pf->seed, (double*)nullptr, (const double*)pf->d_logtab,
+                     pf->last_optimistic ? 2 : 0, (unsigned long long*)(pf->d_xch + 128), (uint32_t)pf->first, (uint32_t)(pf->first + pf->n), (uint32_t)seg,
+                     recv_buf_dev, (long long)cap, pf->d, n_split);
+  HIP_TRY(hipGetLastError());
+  pf->src = pf->state[pf->cur]; pf->src_stride = pf->stride;
+  pf->src2 = recv_buf_dev; pf->src2_stride = 0; pf->n_split = n_split; pf->anc_valid = true;   // stride 0 = rows of d + 1
+  return CSSM_OK;
+}
+
+// ll, ess and the sticky bits of a series run with the single-collective exchange: bit 2 (value 4) = some observation's
+// reference level was ruled out by the max, bit 3 (value 8) = a capacity miss that was not resumed.  Either bit means the
+// numbers are not the filter's (ShardedFilter moves on to its next plan); `need` (optional, T entries): diagnostics.
+extern "C" int cssm_pf_shard_status(cssm_pf* pf, double* ll_out, int32_t* ess_out, uint32_t* bits_out, uint32_t* need, size_t T) {
+  int rc = shard_check(pf);
+  if (rc) return rc;
+  rc = bounded_sync(pf);   // (first: a copy into pageable memory would wait for the stream without a bound)
+  if (rc) return rc;
+  Scalars h;
+  HIP_TRY(hipMemcpyAsync(CSSM_SC_TAIL_ARGS(&h, pf->sc), hipMemcpyDeviceToHost, pf->stream));
+  if (need && pf->d_need && T <= pf->need_cap) HIP_TRY(hipMemcpyAsync(need, pf->d_need, T * 4, hipMemcpyDeviceToHost, pf->stream));
+  HIP_TRY(hipStreamSynchronize(pf->stream));
+  if (ll_out) *ll_out = h.ll;
+  if (ess_out) *ess_out = h.ess;
+  if (bits_out) *bits_out = h.err & 12u;
+  h.err &= ~12u;
+  return cssm_check_device_err(pf, h);
+}
+
+// ------------------------------------------------------------------------------------ series loop over RCCL, in the library
+//
+// The collectives of a single-collective series are driven from here instead of from the host language: per weighted
+// observation  k_propagate<SUMS> -> k_boundary_pack -> ONE all-to-all -> k_offspring_expand_spec, all enqueued on the
+// handle's stream without a host wait (through torch.distributed the same sequence costs several host-language calls per
+// observation, which at 2^20 particles per GPU is longer than the kernels).  RCCL is resolved at run time -- the copy
+// already loaded in the process (e.g. torch's) or librccl.so from the ROCm installation -- so the library itself links
+// nothing but the HIP runtime.  Every wait for a stretch of the series is bounded (bounded_sync): a rank that never
+// joins a collective, or an asynchronous RCCL error, aborts the communicator and surfaces as CSSM_ERCCL on this rank
+// instead of hanging it.
+#include <dlfcn.h>
+namespace {
+struct RcclApi {
+  void* lib = nullptr;
+  std::string path;
+  int (*GetUniqueId)(void*) = nullptr;
+  int (*CommInitRank)(void**, int, cssm_rccl_id, int) = nullptr;
+  int (*CommDestroy)(void*) = nullptr;
+  int (*AllGather)(const void*, void*, size_t, int, void*, hipStream_t) = nullptr;
+  int (*AllToAll)(const void*, void*, size_t, int, void*, hipStream_t) = nullptr;
+  int (*AllToAllv)(const void*, const size_t*, const size_t*, void*, const size_t*, const size_t*, int, void*, hipStream_t) = nullptr;
+  int (*CommAbort)(void*) = nullptr;                 // optional
+  int (*CommGetAsyncError)(void*, int*) = nullptr;   // optional
+  const char* (*GetErrorString)(int) = nullptr;
+  bool ok = false;
+};
+static RcclApi* rccl_api_load();
+RcclApi* rccl_api() {   // (distinct handles may be driven from different threads: the first calls must not race on dlopen)
+  static std::once_flag once;
+  static RcclApi* loaded = nullptr;
+  std::call_once(once, [] { loaded = rccl_api_load(); });
+  return loaded;
+}
+static RcclApi* rccl_api_load() {
+  static RcclApi api;
+  // the copy already mapped into this process (the host's framework usually brings one: two RCCL instances side by side
+  // would each keep their own topology and IPC state), else the ROCm installation's
+  if (FILE* maps = fopen("/proc/self/maps", "r")) {
+    char line[4096];
+    while (!api.lib && fgets(line, sizeof line, maps)) {
+      char* path = strchr(line, '/');
+      if (!path || !strstr(path, "librccl.so")) continue;
+      path[strcspn(path, "\n")] = 0;
+      api.lib = dlopen(path, RTLD_NOW | RTLD_LOCAL | RTLD_NOLOAD);
+      if (api.lib) api.path = path;
+    }
+    fclose(maps);
+  }
+  const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so"};
+  for (const char* nm : names) {
+    if (api.lib) break;
+    api.lib = dlopen(nm, RTLD_NOW | RTLD_LOCAL);
+    if (api.lib) api.path = nm;
+  }
+  if (!api.lib) return nullptr;
+  api.GetUniqueId = (int (*)(void*))dlsym(api.lib, "ncclGetUniqueId");
+  api.CommInitRank = (int (*)(void**, int, cssm_rccl_id, int))dlsym(api.lib, "ncclCommInitRank");
+  api.CommDestroy = (int (*)(void*))dlsym(api.lib, "ncclCommDestroy");
+  api.AllGather = (int (*)(const void*, void*, size_t, int, void*, hipStream_t))dlsym(api.lib, "ncclAllGather");
+  api.AllToAll = (int (*)(const void*, void*, size_t, int, void*, hipStream_t))dlsym(api.lib, "ncclAllToAll");
+  api.AllToAllv = (int (*)(const void*, const size_t*, const size_t*, void*, const size_t*, const size_t*, int, void*, hipStream_t))dlsym(api.lib, "ncclAllToAllv");   // optional
+  api.GetErrorString = (const char* (*)(int))dlsym(api.lib, "ncclGetErrorString");
+  api.CommAbort = (int (*)(void*))dlsym(api.lib, "ncclCommAbort");
+  api.CommGetAsyncError = (int (*)(void*, int*))dlsym(api.lib, "ncclCommGetAsyncError");
+  api.ok = api.GetUniqueId && api.CommInitRank && api.CommDestroy && api.AllToAll;
+  return api.ok ? &api : nullptr;
+}
+const int kNcclUint64 = 5, kNcclFloat64 = 8;   // ncclDataType_t (rccl.h)
+int rccl_fail(RcclApi* a, const char* what, int r) {
+  return fail(CSSM_ERCCL, "%s: %s", what, (a && a->GetErrorString) ? a->GetErrorString(r) : "RCCL error");
+}
+}  // namespace
+
+// Wait for the handle's stream, but not forever once the library has put RCCL collectives on it: the wait polls, watches the
+// communicator for asynchronous errors, and after CSSM_SHARD_TIMEOUT_S seconds (default 600) aborts the communicator --
+// which ends the pending collectives on this rank -- and reports CSSM_ERCCL.  (Another rank died, or returned with an error
+// before joining a collective: without this every surviving rank would sit in that collective for ever.)
+static int bounded_sync(cssm_pf* pf) {
+  if (!pf->last_comm) { HIP_TRY(hipStreamSynchronize(pf->stream)); return CSSM_OK; }
+  RcclApi* a = rccl_api();
+  double limit = 600.0;
+  if (const char* e = getenv("CSSM_SHARD_TIMEOUT_S")) { const double v = atof(e); if (v > 0.0) limit = v; }
+  const auto t0 = std::chrono::steady_clock::now();
+  for (unsigned spin = 0;; ++spin) {
+    const hipError_t e = hipStreamQuery(pf->stream);
+    if (e == hipSuccess) return CSSM_OK;
+    if (e != hipErrorNotReady) return fail(CSSM_EHIP, "hipStreamQuery: %s", hipGetErrorString(e));
+    int async_err = 0;
+    const bool failed = a && a->CommGetAsyncError && a->CommGetAsyncError(pf->last_comm, &async_err) == 0 && async_err != 0;
+    const double waited = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    if (failed || waited > limit) {
+      if (a && a->CommAbort) (void)a->CommAbort(pf->last_comm);
+      pf->last_comm = nullptr;
+      (void)hipStreamSynchronize(pf->stream);
+      return failed ? rccl_fail(a, "asynchronous RCCL error in the sharded series", async_err)
+                    : fail(CSSM_ERCCL, "a collective of the sharded series did not complete within %.0f s (a rank that never joined it?); "
+                                       "the communicator was aborted", limit);
+    }
+    if (spin > 200) std::this_thread::sleep_for(std::chrono::microseconds(50));   // (the first polls spin: a stretch takes a few ms)
+  }
+}
+
+extern "C" int cssm_rccl_available(void) { return rccl_api() ? 1 : 0; }
+extern "C" const char* cssm_rccl_library(void) { RcclApi* a = rccl_api(); return a ? a->path.c_str() : ""; }
+
+extern "C" int cssm_rccl_unique_id(cssm_rccl_id* id_out) {
+  if (!id_out) return fail(CSSM_EINVAL_ARG, "null argument");
+  RcclApi* a = rccl_api();
+  if (!a) return fail(CSSM_ERCCL, "librccl.so could not be loaded");
+  const int r = a->GetUniqueId(id_out);
+  return r ? rccl_fail(a, "ncclGetUniqueId", r) : CSSM_OK;
+}
+
+extern "C" int cssm_rccl_comm_create(const cssm_rccl_id* id, int world, int rank, int device, void** comm_out) {
+  if (!id || !comm_out) return fail(CSSM_EINVAL_ARG, "null argument");
+  if (world < 1 || world > 64 || rank < 0 || rank >= world) return fail(CSSM_ESHARD, "rank %d / world %d", rank, world);
+  RcclApi* a = rccl_api();
+  if (!a) return fail(CSSM_ERCCL, "librccl.so could not be loaded");
+  HIP_TRY(hipSetDevice(device));
+  void* comm = nullptr;
+  const int r = a->CommInitRank(&comm, world, *id, rank);
+  if (r) return rccl_fail(a, "ncclCommInitRank", r);
+  *comm_out = comm;
+  return CSSM_OK;
+}
+
+extern "C" void cssm_rccl_comm_destroy(void* comm) {
+  RcclApi* a = rccl_api();
+  if (a && comm) (void)a->CommDestroy(comm);
+}
+
+extern "C" int cssm_pf_shard_series_rccl(cssm_pf* pf, void* comm, int rank, int world, size_t s_begin, size_t s_end,
+                                         const uint8_t* weighted, int64_t cap, uint64_t* sums5_dev, uint64_t* all_sums5_dev,
+                                         double* send_buf_dev, double* recv_buf_dev, int single_collective) {
+  int rc = shard_check(pf);
+  if (rc) return rc;
+  if (!comm || !weighted || !sums5_dev || !all_sums5_dev || !send_buf_dev || !recv_buf_dev) return fail(CSSM_EINVAL_ARG, "null argument");
+  RcclApi* a = rccl_api();
+  if (!a) return fail(CSSM_ERCCL, "librccl.so could not be loaded");
+  pf->last_comm = comm;
+  // single_collective & 4: the level comes from the GLOBAL max (LGCP; the repetition of a series an outlying observation
+  // voided): an all-gather of the ranks' 5 words (only the max key matters) and cssm_pf_shard_sums precede the all-to-all
+  const bool level_from_max = (single_collective & 4) != 0;
+  single_collective &= 3;
+  if (level_from_max && single_collective == 0) single_collective = 1;
+  if (level_from_max && !a->AllGather) return fail(CSSM_ERCCL, "this RCCL has no ncclAllGather");
+  if (single_collective) {   // sums and boundary particles in ONE all-to-all per observation (k_boundary_pack / k_expand_spec)
+    const size_t sseg = (size_t)spec_seg(pf->d, (long long)cap);
+    // single_collective == 2: only the two adjacent ranks get (and send) whole segments, every other pair exchanges the
+    // 12-word segment header alone -- k_offspring_expand_spec reads nothing else of them (its verdict, formed from the
+    // headers, rules out that a non-adjacent rank owns slots here).  Same call count, (world - 3) segments fewer on the
+    // links per rank and observation.  Counts are a function of |rank - peer| only, so both ends of a pair agree.
+    if (single_collective == 3 && !a->AllToAllv) return fail(CSSM_ERCCL, "this RCCL has no ncclAllToAllv");
+    const bool trimmed = (single_collective == 3) || (single_collective == 2 && a->AllToAllv && world > 2);   // 3: tests (any world)
+    std::vector<size_t> counts((size_t)world), displs((size_t)world);
+    for (int q = 0; q < world; ++q) {
+      counts[(size_t)q] = (q == rank + 1 || q == rank - 1) ? sseg : (size_t)kSpecHeaderWords;
+      displs[(size_t)q] = (size_t)q * sseg;
+    }
+    for (size_t s = s_begin; s < s_end; ++s) {
+      rc = cssm_pf_shard_propagate_at(pf, s, level_from_max ? sums5_dev : nullptr);
+      if (rc) return rc;
+      if (!weighted[s]) continue;
+      if (level_from_max) {
+        const int rg = a->AllGather(sums5_dev, all_sums5_dev, 5, kNcclUint64, comm, pf->stream);
+        if (rg) { if (a->CommAbort) (void)a->CommAbort(comm); pf->last_comm = nullptr; return rccl_fail(a, "ncclAllGather", rg); }
+        rc = cssm_pf_shard_sums(pf, all_sums5_dev, world, sums5_dev);
+        if (rc) return rc;
+      }
+      rc = cssm_pf_shard_boundary_pack(pf, rank, world, cap, send_buf_dev);
+      if (rc) return rc;
+      const int r = trimmed ? a->AllToAllv(send_buf_dev, counts.data(), displs.data(), recv_buf_dev, counts.data(), displs.data(), kNcclFloat64,
+                                           comm, pf->stream)
+                            : a->AllToAll(send_buf_dev, recv_buf_dev, sseg, kNcclFloat64, comm, pf->stream);
+      if (r) {   // this rank will not enqueue the rest: end the collectives its peers may already wait in
+        if (a->CommAbort) (void)a->CommAbort(comm);
+        pf->last_comm = nullptr;
+        return rccl_fail(a, trimmed ? "ncclAllToAllv" : "ncclAllToAll", r);
+      }
+      rc = cssm_pf_shard_adopt_spec(pf, recv_buf_dev, rank, world, cap);
+      if (rc) return rc;
+    }
+    return CSSM_OK;
+  }
+  return fail(CSSM_EINVAL_ARG, "single_collective must be 1, 2 or 3 (+ 4: level from the all-gathered max)");
+}
+
+extern "C" int cssm_pf_shard_pack(cssm_pf* pf, int world, const int64_t* send_first_host, const int64_t* send_count_host,
+                                  int skip_rank, double* send_buf_dev) {
+  int rc = shard_check(pf);
+  if (rc) return rc;
+  if (!send_first_host || !send_count_host) return fail(CSSM_EINVAL_ARG, "null argument");
+  if (!pf->send_first_dev) return fail(CSSM_ESTATE, "shard_pack before shard_offspring");
+  int64_t total = 0;
+  for (int q = 0; q < world; ++q) {   // the host copies are only checked; the kernel reads the device originals
+    const int64_t c = send_count_host[q], f = send_first_host[q];
+    if (c < 0 || f < 0 || (uint64_t)(f + c) > pf->n) return fail(CSSM_ESHARD, "send range [%lld, +%lld) outside the shard", (long long)f, (long long)c);
+    if (q != skip_rank) total += c;
+  }
+  if (total > 0) {
+    if (!send_buf_dev) return fail(CSSM_EINVAL_ARG, "send_buf_dev is null");
+    hipLaunchKernelGGL(k_pack, dim3(grid_for((uint64_t)total, 256, kGridCap)), dim3(256), 0, pf->stream, pf->state[pf->cur], pf->stride,
+                       pf->endslot, pf->d, world, pf->send_first_dev, pf->send_count_dev, (long long)total, skip_rank, send_buf_dev);
+  }
+  HIP_TRY(hipGetLastError());
+  return CSSM_OK;
+}
+
+extern "C" int cssm_pf_shard_adopt(cssm_pf* pf, const double* recv_buf_dev, int64_t n_low, int64_t n_high, int64_t self_first,
+                                   int64_t self_count) {
+  int rc = shard_check(pf);
+  if (rc) return rc;
+  if (n_low < 0 || n_high < 0 || self_count < 0 || self_first < 0 || (uint64_t)(self_first + self_count) > pf->n)
+    return fail(CSSM_ESHARD, "bad candidate counts");
+  const int64_t n_remote = n_low + n_high;
+  if (n_remote + self_count < 1) return fail(CSSM_ESHARD, "a rank must have at least one candidate particle");
+  if (n_remote > 0 && !recv_buf_dev) return fail(CSSM_EINVAL_ARG, "recv_buf_dev is null");
+  if ((size_t)n_remote > pf->cand_cap) {
+    HIP_TRY(hipStreamSynchronize(pf->stream));
+    if (pf->cand) (void)hipFree(pf->cand);
+    if (pf->cand_end) (void)hipFree(pf->cand_end);
+    if (pf->cand_idx) (void)hipFree(pf->cand_idx);
+    pf->cand = nullptr; pf->cand_end = pf->cand_idx = nullptr;
+    size_t cap = (size_t)n_remote + (size_t)n_remote / 4 + CSSM_TILE;
+    cap = (cap + CSSM_TILE - 1) / CSSM_TILE * CSSM_TILE;
+    if (hipMalloc(&pf->cand, cap * 8 * pf->d + 64) != hipSuccess || hipMalloc(&pf->cand_end, cap * 4) != hipSuccess ||
+        hipMalloc(&pf->cand_idx, cap * 4) != hipSuccess)
+      return fail(CSSM_ENOMEM, "hipMalloc candidate buffers (%zu particles)", cap);
+    pf->cand_cap = cap;
+  }
+  // The own particles' runs are already in anc (shard_offspring).  Candidates of lower ranks fill the slots below the
+  // first own run (their last end slot is where it starts), candidates of higher ranks the slots from the last own
+  // end slot upwards.
+  const uint32_t n_split = (uint32_t)pf->n;
+  if (n_remote > 0)
+    hipLaunchKernelGGL(k_adopt_remote, dim3(grid_for((uint64_t)n_remote, 256, kGridCap)), dim3(256), 0, pf->stream, recv_buf_dev,
+                       (long long)n_remote, pf->d, n_split, pf->cand, pf->cand_cap, pf->cand_end, pf->cand_idx);
+  if (n_remote > 0)
+    hipLaunchKernelGGL(k_expand, dim3(grid_for((uint64_t)n_remote, CSSM_BLOCK, kGridCap)), dim3(CSSM_BLOCK), 0, pf->stream, pf->cand_end,
+                       pf->cand_idx, (uint64_t)n_remote, (uint64_t)n_low, pf->first, pf->first + pf->n, pf->anc,
+                       (const uint32_t*)(pf->endslot + (pf->n - 1)));
+  HIP_TRY(hipGetLastError());
+  pf->src = pf->state[pf->cur]; pf->src_stride = pf->stride;
+  pf->src2 = pf->cand; pf->src2_stride = pf->cand_cap; pf->n_split = n_split; pf->anc_valid = true;
+  return CSSM_OK;
+}
+
+extern "C" int cssm_pf_shard_result(cssm_pf* pf, double* ll_out, int32_t* ess_out) {
+  int rc = shard_check(pf);
+  if (rc) return rc;
+  Scalars h;
+  HIP_TRY(hipMemcpyAsync(CSSM_SC_TAIL_ARGS(&h, pf->sc), hipMemcpyDeviceToHost, pf->stream));
+  HIP_TRY(hipStreamSynchronize(pf->stream));
+  if (ll_out) *ll_out = h.ll;
+  if (ess_out) *ess_out = h.ess;
+  return cssm_check_device_err(pf, h);
+}

@@ -148,7 +148,7 @@ class NativePf:
         _abi.check(self.lib.cssm_pf_last_loop_ms(self._h, C.byref(ms)))
         return ms.value
 
-    KERNELS = ("k_propagate", "k_tile_sums", "k_offspring", "k_series", "k_step", "k_reduce_units")
+    KERNELS = ("k_propagate", "k_tile_sums", "k_offspring", "k_reduce_units", "k_boundary_pack", "k_offspring_expand_spec", "collective")
 
     def set_option(self, option: int, value: int):
         _abi.check(self.lib.cssm_pf_set_option(self._h, int(option), int(value)))
@@ -162,13 +162,6 @@ class NativePf:
         cnt = np.zeros(len(self.KERNELS), dtype=np.uint64)
         _abi.check(self.lib.cssm_pf_profile_read(self._h, _p(ms), _p(cnt, C.POINTER(C.c_uint64))))
         return {k: (float(ms[i]), int(cnt[i])) for i, k in enumerate(self.KERNELS)}
-
-    def series_phases(self):
-        """(used_series, [phase P, exchange, phase O, closing barrier] average us, weighted steps) of the last batch run."""
-        used, steps = C.c_int(), C.c_uint64()
-        ph = np.zeros(4)
-        _abi.check(self.lib.cssm_pf_series_phases(self._h, C.byref(used), _p(ph), C.byref(steps)))
-        return bool(used.value), ph, int(steps.value)
 
     def summary(self, interval: float = 0.975):
         """(state_mean[d], state_lower[d], state_upper[d], eta_of_mean, eta_lower, eta_upper) of the current cloud."""

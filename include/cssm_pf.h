@@ -212,33 +212,14 @@ int cssm_pf_last_loop_ms(cssm_pf* pf, float* ms_out);
 #define CSSM_RESAMPLE_SYSTEMATIC 0
 #define CSSM_RESAMPLE_STRATIFIED 1
 #define CSSM_RESAMPLE_MULTINOMIAL 2
-/* CSSM_OPT_FUSED_SUMS (default 1): k_propagate also forms the fixed-point sums of exp(w - c) (c = the observation's reference
- * level, cssm_numerics.h) -- the log-sum-exp normalisation inside the fused kernel: 2 kernels per observation.  When the max
- * rules c out (an outlying observation) the batch drivers put the series on hold at that observation, redo its sums relative
- * to the max (k_tile_sums + k_offspring; the log-weights are in place) and carry on; streaming cssm_pf_step does the same
- * within the call.  0 = the sums are a pass of their own after the max is known (k_tile_sums), 3 kernels per observation.
- * Identical results (both apply cssm_ref_choose).  Measured per observation, fused vs separate: 18.7 vs 20.0 us at
- * N = 100 000, 34.0 vs 35.4 us at 2^20, 336 vs 356 us at 2^24. */
+/* CSSM_OPT_FUSED_SUMS (default 1; a verification switch like CSSM_OPT_WHOLE_TILES -- results are identical, both settings apply
+ * cssm_ref_choose): k_propagate also forms the fixed-point sums of exp(w - c) (c = the observation's reference level,
+ * cssm_numerics.h) -- the log-sum-exp normalisation inside the fused kernel: 2 kernels per observation.  When the max rules c
+ * out (an outlying observation) the batch drivers put the series on hold at that observation, redo its sums relative to the
+ * max and carry on; streaming cssm_pf_step does the same within the call.  0 = the sums are always a pass of their own after
+ * the max is known (k_tile_sums, 3 kernels per observation) -- the path LGCP, the multinomial resampler and a redone observation
+ * run anyway; measured slower at every size (20.0 vs 18.7 us at N = 100 000, 35.4 vs 34.0 at 2^20, 356 vs 336 at 2^24). */
 #define CSSM_OPT_FUSED_SUMS 3
-/* CSSM_OPT_SERIES_KERNEL (default 0): 1 = the batch drivers (cssm_pf_ll_filter, cssm_pf_filter, cssm_pmmh_run) run all T
- * observations in ONE cooperative launch of a persistent kernel -- propagate + weight + sums, a grid barrier that also
- * reduces the sums, offspring + ancestors, a second grid barrier, per observation; log-weights stay in LDS -- whenever the
- * handle is eligible: systematic resampling, not LGCP, not sharded, at most 1024 co-resident blocks of at most 2048
- * particles (N <= 1.5 M for d = 3 on MI355X).  Identical results (tests/test_gpu_series.py).  Opt-in because it does not pay
- * on MI355X as measured: a step boundary costs grid barriers instead of launches, but every datum
- * that crosses blocks inside a kernel has to bypass the per-XCD L2 (sc1) at ~0.8 us per dependent round trip, 16 of them
- * per observation: 19.8 vs 20.8 us per observation at N = 100 000 and 45.4 vs 38.7 us at N = 2^20, where the resident
- * waves' fixed ages also skew the propagate phase (13 us for a CU's oldest block, 28 us for its youngest).  A cooperative
- * launch also has the GPU to itself: two chains on two streams no longer overlap. */
-#define CSSM_OPT_SERIES_KERNEL 4
-/* CSSM_OPT_ONE_LAUNCH (default 0; opt-in like the series kernel): 1 = the batch drivers merge the resampling of a weighted
- * observation with the propagate of the weighted observation that follows it into ONE kernel launch (k_step: a block finds
- * the parents of its own resampling slots from the unit sums, rebuilds their end slots and keeps the ancestor indices in
- * LDS) wherever the handle is eligible: one GPU, systematic resampling, fused sums, not LGCP, at most 1024 units of sums
- * (N <= 2^19 with the half-tile units of clouds below 2^20, and N = 2^20 itself); -1 = only for clouds of up to 2^18 particles.  Results are
- * bit-identical either way.  Measured: NOT faster than two launches (14.9 vs 14.4 us per observation at N = 100 000, 34.0
- * vs 32.5 at 2^20) -- a launch costs 3.1 us, the parents' end slots a block has to rebuild cost as much; see DESIGN.md 5c. */
-#define CSSM_OPT_ONE_LAUNCH 5
 /* CSSM_OPT_WHOLE_TILES (default 0): a verification switch over the launch geometry of the propagate kernel (results are
  * bit-identical in every setting).  Automatic (0): clouds below 2^20 particles run ONE tile of the kernel per block (512
  * particles for d <= 8, 256 for d >= 9: the single-tile kernel requests everything position-dependent in its first round of
@@ -246,7 +227,10 @@ int cssm_pf_last_loop_ms(cssm_pf* pf, float* ms_out);
  * block owns a whole unit of 1024 * k particles and runs (1) the same kernel tile after tile while a unit has at most 8
  * tiles, else (2) the software-pipelined kernel (d <= 3) or (3) one tile per block again with k_reduce_units folding the
  * blocks' sums into <= 1024 unit sums (d >= 4).  1 / 2 / 3 force that geometry at every size: the kernels of the large
- * clouds can then be checked against the oracle at sizes the oracle finishes in seconds. */
+ * clouds can then be checked against the oracle at sizes the oracle finishes in seconds.
+ * (Options 4 and 5 of rounds 1-2 -- a persistent one-launch-per-series kernel and a one-launch-per-observation kernel, both
+ * bit-identical and both measured slower than two launches per observation -- were removed in round 3; DESIGN.md 5b-5c keep
+ * the record, git history the code.) */
 #define CSSM_OPT_WHOLE_TILES 6
 int cssm_pf_set_option(cssm_pf* pf, int option, int value);
 
@@ -259,21 +243,13 @@ int cssm_pf_set_option(cssm_pf* pf, int option, int value);
 #define CSSM_K_PROPAGATE 0   /* fused gather + propagate + weight + block max (+ fixed-point sums with CSSM_OPT_FUSED_SUMS) */
 #define CSSM_K_TILE_SUMS 1   /* exp(w - level), fixed-point unit sums */
 #define CSSM_K_OFFSPRING 2   /* unit prefix, ll / ess, cumulative weights -> end slots -> ancestor indices */
-#define CSSM_K_SERIES 3      /* the persistent series kernel: ONE launch for all T observations of a batch run */
-#define CSSM_K_STEP 4        /* k_step: resampling of the previous observation + propagate and weight of this one (CSSM_OPT_ONE_LAUNCH) */
-#define CSSM_K_REDUCE 5      /* k_reduce_units: the sums of k_propagate's single-tile blocks -> unit sums (large clouds) */
-#define CSSM_PROFILE_NKERNELS 6
+#define CSSM_K_REDUCE 3      /* k_reduce_units: the sums of k_propagate's single-tile blocks -> unit sums (large clouds) */
+#define CSSM_K_PACK 4        /* sharded: k_boundary_pack (segment headers + boundary rows of the single-collective exchange) */
+#define CSSM_K_EXPAND 5      /* sharded: k_offspring_expand_spec (offspring of the own particles + expansion of the received rows) */
+#define CSSM_K_COLLECTIVE 6  /* sharded, collectives issued by the library: the RCCL kernel(s) of one observation's exchange */
+#define CSSM_PROFILE_NKERNELS 7
 int cssm_pf_profile(cssm_pf* pf, int enable);
 int cssm_pf_profile_read(cssm_pf* pf, double* total_ms, uint64_t* launches);
-/* Whether the last batch run used the persistent series kernel and, if profiling was on, how its weighted observations
- * spent their time on average, from timestamps block 0 takes inside the kernel (constant 100 MHz counter):
- * phase_us[0] = propagate + weight + sums, [1] = exchange (barrier + reduction of the sums), [2] = offspring + ancestors,
- * [3] = closing barrier.  Any pointer may be NULL. */
-int cssm_pf_series_phases(cssm_pf* pf, int* used_series, double* phase_us, uint64_t* weighted_steps);
-/* The raw stamps (cssm_pf_profile(pf, 2): every block stamps): out[(block * steps + s) * 5 + q], q = start, end of phase P, end
- * of the exchange, end of phase O, end of the closing barrier; ticks of 10 ns.  out may be NULL to ask for the sizes. */
-int cssm_pf_series_stamps(cssm_pf* pf, uint64_t* out, size_t cap, uint32_t* blocks, uint32_t* steps);
-
 /* ---- diagnostics of the numerics contract --------------------------------------------------- */
 
 /* Evaluates one function of include/cssm_numerics.h ON THE DEVICE for n arguments (so that a caller holding the host

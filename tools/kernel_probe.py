@@ -11,7 +11,7 @@ model = cases.c2_model() if which == "c2" else cases.c1_model()
 for n in sizes:
     T = 200 if n <= (1 << 20) else 24
     t, y, has = cases.poisson_counts(T)
-    g = NativePf(model, n, cases.SEED); g.set_option(3, fused); g.set_option(4, 0)
+    g = NativePf(model, n, cases.SEED); g.set_option(3, fused)
     g.run(t[:20], y[:20], has[:20])
     best = min((g.run(t, y, has), g.last_loop_ms())[1] for _ in range(3)) * 1e3 / T
     g.profile(True); g.run(t, y, has); prof = g.profile_read(); g.profile(False)
