@@ -1,9 +1,9 @@
 /*
  * cssm_jni.c -- JNI glue between com.github.jonnylaw.model.CssmNative and libcssm_pf.
  *
- * SOURCE ONLY: neither the build image nor the GPU box has a JDK (no jni.h), so this file is not
- * compiled or tested here.  It is deliberately thin: every line of logic lives behind the C ABI of
- * include/cssm_pf.h, which the ctypes harness exercises.
+ * The build image has no JDK (no jni.h); tests/test_jvm_binding.py probes for one on the GPU box and, where it finds
+ * javac + jni.h, compiles this file with CssmNative.java and a small Java harness and compares what they return with the
+ * ctypes path.  It is deliberately thin: every line of logic lives behind the C ABI of include/cssm_pf.h.
  *
  *   gcc -shared -fPIC -I$JAVA_HOME/include -I$JAVA_HOME/include/linux -I../../../../include \
  *       cssm_jni.c -L<dir of libcssm_pf.so> -lcssm_pf -o libcssm_jni.so

@@ -1,6 +1,7 @@
 package com.github.jonnylaw.model
 
-// SOURCE ONLY (no JDK/sbt in the build image): the Scala side of the drop-in boundary.
+// The Scala side of the drop-in boundary (no Scala compiler in the build image: source; the JNI layer below it is compiled
+// and driven wherever a JDK exists -- tests/test_jvm_binding.py).
 // It lives in package com.github.jonnylaw.model because the model case classes it pattern-matches
 // (PoissonModel, SeasonalModel, LinearModel, LogGaussianCox, BrownianMotion, GenBrownianMotion,
 // OuProcess) are `private final` there (Model.scala:144-363, Sde.scala:69,98,129).
@@ -10,24 +11,8 @@ import akka.stream.scaladsl.Flow
 import breeze.linalg.DenseVector
 import cats.data.Reader
 
-/** JNI entry points of libcssm_jni.so (jvm/src/main/c/cssm_jni.c) over include/cssm_pf.h. */
-object CssmNative {
-  System.loadLibrary("cssm_jni")
-  @native def create(ints: Array[Int], reals: Array[Double], n: Long, seed: Long, device: Int): Long
-  @native def destroy(handle: Long): Unit
-  @native def setParams(handle: Long, ints: Array[Int], reals: Array[Double], seed: Long): Unit
-  @native def init(handle: Long, t0: Double): Unit
-  @native def initFrom(handle: Long, t0: Double, state: Array[Double]): Unit
-  @native def step(handle: Long, t: Double, y: Double, hasObs: Boolean, out: Array[Double]): Unit
-  @native def filter(handle: Long, t: Array[Double], y: Array[Double], has: Array[Byte], path: Array[Double]): Double
-  @native def particles(handle: Long, out: Array[Double]): Unit
-  @native def resampleSystematic(w: Array[Double], u: Double, anc: Array[Int], device: Int): Unit
-  @native def resample(kind: Int, w: Array[Double], u: Double, seed: Long, step: Int, anc: Array[Int], device: Int): Unit
-  /** cssm_pf_run_key: the Philox key of the `run`-th filter run under one user seed -- a PRF of (seed, run), never seed + run. */
-  @native def runKey(seed: Long, run: Long): Long
-  /** cssm_pf_set_option(handle, CSSM_OPT_RESAMPLER, kind). */
-  @native def setResampler(handle: Long, kind: Int): Unit
-}
+// CssmNative -- the JNI entry points -- is a Java class with static natives (jvm/src/main/java/.../CssmNative.java): the glue's
+// symbols take a jclass, which a Scala `object` with @native methods (natives on the module class CssmNative$) would not match.
 
 /** Flattens a parameterised composed model into the cssm_model_desc wire form (see cssm_jni.c). */
 object DescriptorBuilder {
@@ -106,7 +91,9 @@ object GpuModel {
   private def kindOf(sde: UnparamSde): (Int, Int) = {
     val z = breeze.linalg.DenseVector(0.0)
     val probes = Seq[SdeParameter](BrownianParameter(z, z, z), GenBrownianParameter(z, z, z, z), OuParameter(z, z, z, z, z))
-    probes.view.flatMap(p => sde.run(p).toOption).headOption.map(LeafSpecs.ofSde)
+    // (the reference's mismatch branch is `Failure(throw new Exception(...))` -- Sde.scala:183,188,201: the throw is evaluated
+    //  eagerly, so run() THROWS on a parameter of another SDE instead of returning the Failure; Try catches it)
+    probes.view.flatMap(p => scala.util.Try(sde.run(p)).flatten.toOption).headOption.map(LeafSpecs.ofSde)
       .getOrElse(throw new IllegalArgumentException("the GPU filter serves the built-in SDEs"))
   }
   private def leaf(obs: String, u: UnparamModel, sde: UnparamSde, period: Int = 0, harmonics: Int = 0, df: Int = 0) = {
@@ -213,7 +200,24 @@ case class FilterGpu(
                                data.map(x => (if (x.observation.isDefined) 1 else 0).toByte).toArray, path)
     clock = data.last.t
     val times = data.minBy(_.t).t +: data.map(_.t)
-    (ll, times.zipWithIndex.map { case (t, i) => StateSpace[State](t, Tree.leaf(DenseVector(path.slice(i * d, (i + 1) * d)))) })
+    (ll, times.zipWithIndex.map { case (t, i) => StateSpace[State](t, toState(path, i * d)) })
+  }
+
+  /** One device row (d doubles, Tree.flatten order) as the State the reference's own SDE would hold: one Leaf per composed
+    * sub-model, LEFT-nested -- `(a |+| b) |+| c` is Branch(Branch(a, b), c) (Tree.scala:18-20; Sde.scala:206-209 builds the
+    * composed initial state that way).  A flat Leaf would type-check and be WRONG: Model.compose's `f` on a Leaf evaluates
+    * model1.f only (Model.scala:122-128), silently dropping every other leaf's contribution. */
+  private def toState(row: Array[Double], off: Int): State = {
+    var o = off
+    val leaves = structure.map { l => val v = DenseVector(row.slice(o, o + l.dim)); o += l.dim; Tree.leaf(v) }
+    leaves.reduceLeft((acc, leaf) => Tree.branch(acc, leaf))
+  }
+
+  /** The current cloud as the reference's `PfState.particles` would hold it (Vector[State], length N) -- a download of
+    * d x N doubles: for inspection and for consumers of `mod.f(state, t)`, not for the per-step path. */
+  def currentStates: Vector[State] = {
+    val soa = currentParticles; val d = mod.sde.dimension
+    Vector.tabulate(particles) { i => val row = Array.tabulate(d)(k => soa(k * particles + i)); toState(row, 0) }
   }
 
   override def filterStream(t0: Time, n: Int): Flow[Data, PfState[State], NotUsed] =
