@@ -39,7 +39,11 @@ static __global__ __launch_bounds__(CSSM_BLOCK) void k_tile_sums(const double* _
                                                           cssm_u128* __restrict__ unitS, cssm_u128* __restrict__ unitS2,
                                                           uint32_t ntiles, uint32_t sup, uint32_t nunits, int raw, int slot_set,
                                                           const double* __restrict__ gmax_in, const double* __restrict__ logtab,
-                                                          const StepRec* __restrict__ rec) {
+                                                          const StepRec* __restrict__ rec, uint32_t hold_mask) {
+  // hold_mask (sharded series, level from the all-gathered max): while the series is on hold after a capacity miss (err bit 3)
+  // or void (bit 2) the sums of the observation it holds at must survive the observations enqueued behind it -- the host
+  // resumes exactly there (cssm_pf_shard_resume)
+  if (hold_mask && (sc->err & hold_mask)) return;
   __shared__ cssm_u128 s_a[CSSM_BLOCK / 64], s_b[CSSM_BLOCK / 64];
   const double* tab = nullptr; (void)logtab;   // literal constants measured faster than an LDS constant table
   double pre[CSSM_ITEMS];   // the block's first tile is requested before the (serial) max decode
@@ -104,7 +108,10 @@ static __global__ __launch_bounds__(1024) void k_scan_tiles(const cssm_u128* __r
                                                      uint64_t n_global, int single,
                                                      double* __restrict__ ll_t, int32_t* __restrict__ ess_t, uint32_t rec_idx,
                                                      const double* __restrict__ gmax_in, unsigned long long* __restrict__ sums4_out,
-                                                     int export_max) {
+                                                     int export_max, uint32_t hold_mask, int sums_valid) {
+  // hold_mask: see k_tile_sums (neither the exported words nor the max slots may change while a sharded series is on hold);
+  // sums_valid = 0: only the max travels (an LGCP observation before its level is known) -- the sums read as zero
+  if (hold_mask && (sc->err & hold_mask)) return;
   __shared__ cssm_u128 s_w[16], s_w2[16];
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   if (gmax_in && threadIdx.x == 0) { sc->gmax = *gmax_in; sc->ref = *gmax_in; }
@@ -121,7 +128,7 @@ static __global__ __launch_bounds__(1024) void k_scan_tiles(const cssm_u128* __r
   const uint32_t t0 = threadIdx.x * chunk;
   const uint32_t t1 = (t0 + chunk < ntiles) ? t0 + chunk : ntiles;
   cssm_u128 v = cssm_u128_zero(), v2 = cssm_u128_zero();
-  for (uint32_t t = t0; t < t1; ++t) { v = cssm_u128_add(v, tileS[t]); v2 = cssm_u128_add(v2, tileS2[t]); }
+  if (sums_valid) for (uint32_t t = t0; t < t1; ++t) { v = cssm_u128_add(v, tileS[t]); v2 = cssm_u128_add(v2, tileS2[t]); }
   cssm_u128 inc = wave_scan_u128(v, lane);
   cssm_u128 tot2 = wave_sum_u128(v2);
   if (lane == 63) s_w[wid] = inc;
@@ -132,7 +139,7 @@ static __global__ __launch_bounds__(1024) void k_scan_tiles(const cssm_u128* __r
   // exclusive prefix of this thread's chunk = off + inc - v (integers: exact)
   cssm_u128 run = cssm_u128_add(off, inc);
   { cssm_u128 r; r.lo = run.lo - v.lo; r.hi = run.hi - v.hi - (run.lo < v.lo ? 1u : 0u); run = r; }
-  for (uint32_t t = t0; t < t1; ++t) { tileP[t] = run; run = cssm_u128_add(run, tileS[t]); }
+  if (sums_valid) for (uint32_t t = t0; t < t1; ++t) { tileP[t] = run; run = cssm_u128_add(run, tileS[t]); }
   if (threadIdx.x == 0) {
     cssm_u128 c = cssm_u128_zero(), c2 = cssm_u128_zero();
     for (int w = 0; w < 16; ++w) { c = cssm_u128_add(c, s_w[w]); c2 = cssm_u128_add(c2, s_w2[w]); }

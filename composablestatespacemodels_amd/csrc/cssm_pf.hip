@@ -312,7 +312,7 @@ static int launch_resample(cssm_pf* pf, const StepRec* d_rec, double* ll_t = nul
   if (!optimistic) {
     prof_begin(pf, CSSM_K_TILE_SUMS);
     hipLaunchKernelGGL(k_tile_sums, dim3(tgrid), dim3(CSSM_BLOCK), 0, pf->stream, pf->logw, pf->n, pf->sc, pf->tileS, pf->tileS2, pf->ntiles,
-                       pf->sup, pf->nunits, 0, pf->wparity, (const double*)nullptr, pf->d_logtab, d_rec);
+                       pf->sup, pf->nunits, 0, pf->wparity, (const double*)nullptr, pf->d_logtab, d_rec, 0u);
     prof_end(pf);
   }
   prof_begin(pf, CSSM_K_OFFSPRING);   // unit prefix, ll/ess, end slots and their expansion to ancestors in one kernel (one block per unit + the publisher)
@@ -1019,9 +1019,9 @@ extern "C" int cssm_resample(int kind, const double* w, size_t n, double u, uint
   {
     const int tgrid = (int)nunits;
     hipLaunchKernelGGL(k_tile_sums, dim3(tgrid), dim3(CSSM_BLOCK), 0, st, d_w, (uint64_t)n, sc, tS, tS2, ntiles, sup, nunits, 1, -1, (const double*)nullptr, d_tab,
-                       (const StepRec*)d_rec);
+                       (const StepRec*)d_rec, 0u);
     hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(1024), 0, st, tS, tS2, tP, nunits, sc, (uint64_t)n, 1, (double*)nullptr, (int32_t*)nullptr, 0u,
-                       (const double*)nullptr, (unsigned long long*)nullptr, 0);
+                       (const double*)nullptr, (unsigned long long*)nullptr, 0, 0u, 1);
 #define RS_OFF_ARGS d_w, (uint64_t)n, sc, (const cssm_u128*)tP, (const cssm_u128*)tS2, d_rec, (uint64_t)n, d_end, d_anc, ntiles, sup, nunits, 1, 0, \
                     (double*)nullptr, (int32_t*)nullptr, 0u, 0, (const unsigned long long*)nullptr, 0, 1, 1, seed, d_cum, d_tab, 0,                \
                     (unsigned long long*)nullptr, 0u, (uint32_t)n

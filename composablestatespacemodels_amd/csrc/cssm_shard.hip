@@ -18,6 +18,7 @@
 
 // level of the step from the all-gathered order keys (word 4 of every rank's 5 words)
 __global__ void k_import_level(Scalars* sc, const unsigned long long* __restrict__ all5, int world, const StepRec* __restrict__ rec) {
+  if (sc->err & (4u | 8u)) return;   // on hold / void: the level of the observation the series holds at stays in place
   unsigned long long key = 0ull;
   for (int r = 0; r < world; ++r) { const unsigned long long k = all5[5 * r + 4]; key = (k > key) ? k : key; }
   sc->gmax = cssm_order_unkey(key);
@@ -131,13 +132,17 @@ extern "C" int cssm_pf_shard_sums(cssm_pf* pf, const uint64_t* all_sums5_dev, in
   const int tgrid = (int)pf->nunits;
   hipLaunchKernelGGL(k_import_level, dim3(1), dim3(1), 0, pf->stream, pf->sc, (const unsigned long long*)all_sums5_dev, world,
                      (const StepRec*)(pf->d_recs + slot));
+  // (every kernel here returns at once while the series is on hold after a capacity miss or void: the level, the unit sums
+  //  and the exported words of the observation it holds at are what cssm_pf_shard_resume's caller continues from)
   hipLaunchKernelGGL(k_tile_sums, dim3(tgrid), dim3(CSSM_BLOCK), 0, pf->stream, pf->logw, pf->n, pf->sc, pf->tileS, pf->tileS2, pf->ntiles,
-                     pf->sup, pf->nunits, 0, -1, (const double*)nullptr, pf->d_logtab, (const StepRec*)(pf->d_recs + slot));
+                     pf->sup, pf->nunits, 0, -1, (const double*)nullptr, pf->d_logtab, (const StepRec*)(pf->d_recs + slot), 12u);
   // word 4 (the max key) of sums5_dev is left as shard_propagate wrote it
   hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(1024), 0, pf->stream, pf->tileS, pf->tileS2, pf->tileP, pf->nunits, pf->sc, pf->n_global, 0,
-                     (double*)nullptr, (int32_t*)nullptr, 0u, (const double*)nullptr, (unsigned long long*)sums5_dev, 0);
+                     (double*)nullptr, (int32_t*)nullptr, 0u, (const double*)nullptr, (unsigned long long*)sums5_dev, 0, 12u, 1);
   HIP_TRY(hipGetLastError());
   pf->last_optimistic = false;
+  // the snapshot a resume restores was taken right after the propagate: the sums it describes are these now
+  if (pf->series && pf->step >= 1 && pf->snaps.size() >= pf->step) pf->snaps[pf->step - 1].last_optimistic = false;
   return CSSM_OK;
 }
 
@@ -199,12 +204,11 @@ static int shard_prepare_step(cssm_pf* pf, const StepRec* d_rec, int weighted, u
     // the rank's totals of the sub-unit sums k_propagate formed and the order key of its max -> 5 words for the all-gather
     const uint64_t chunk = (uint64_t)pf->sup * CSSM_TILE / pf->split;
     const uint32_t nsub = (uint32_t)((pf->n + chunk - 1) / chunk);
-    if (!pf->last_optimistic) {   // LGCP: only the max travels
-      HIP_TRY(hipMemsetAsync(pf->tileS, 0, (size_t)nsub * sizeof(cssm_u128), pf->stream));
-      HIP_TRY(hipMemsetAsync(pf->tileS2, 0, (size_t)nsub * sizeof(cssm_u128), pf->stream));
-    }
+    // (LGCP -- !last_optimistic -- forms no sums in k_propagate: only the max travels, the sums read as zero.  On hold the
+    //  kernel does nothing: the max slots were exported and cleared by the observation the series holds at.)
     hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(1024), 0, pf->stream, pf->tileS, pf->tileS2, pf->tileP, nsub, pf->sc, pf->n_global, 0,
-                       (double*)nullptr, (int32_t*)nullptr, 0u, (const double*)nullptr, (unsigned long long*)sums5_dev, 1);
+                       (double*)nullptr, (int32_t*)nullptr, 0u, (const double*)nullptr, (unsigned long long*)sums5_dev, 1, 12u,
+                       pf->last_optimistic ? 1 : 0);
     HIP_TRY(hipGetLastError());
   }
   return CSSM_OK;
@@ -507,28 +511,27 @@ extern "C" int cssm_pf_shard_series_rccl(cssm_pf* pf, void* comm, int rank, int 
       counts[(size_t)q] = (q == rank + 1 || q == rank - 1) ? sseg : (size_t)kSpecHeaderWords;
       displs[(size_t)q] = (size_t)q * sseg;
     }
+    // A rank that stops enqueueing -- an RCCL call failed, or one of its own stages did -- must end the collectives its peers
+    // may already wait in: abort the communicator before returning (the peers' bounded waits then see an error, not a hang).
+    auto bail = [&](int code) { if (a->CommAbort) (void)a->CommAbort(comm); pf->last_comm = nullptr; return code; };
     for (size_t s = s_begin; s < s_end; ++s) {
       rc = cssm_pf_shard_propagate_at(pf, s, level_from_max ? sums5_dev : nullptr);
-      if (rc) return rc;
+      if (rc) return bail(rc);
       if (!weighted[s]) continue;
       if (level_from_max) {
         const int rg = a->AllGather(sums5_dev, all_sums5_dev, 5, kNcclUint64, comm, pf->stream);
-        if (rg) { if (a->CommAbort) (void)a->CommAbort(comm); pf->last_comm = nullptr; return rccl_fail(a, "ncclAllGather", rg); }
+        if (rg) return bail(rccl_fail(a, "ncclAllGather", rg));
         rc = cssm_pf_shard_sums(pf, all_sums5_dev, world, sums5_dev);
-        if (rc) return rc;
+        if (rc) return bail(rc);
       }
       rc = cssm_pf_shard_boundary_pack(pf, rank, world, cap, send_buf_dev);
-      if (rc) return rc;
+      if (rc) return bail(rc);
       const int r = trimmed ? a->AllToAllv(send_buf_dev, counts.data(), displs.data(), recv_buf_dev, counts.data(), displs.data(), kNcclFloat64,
                                            comm, pf->stream)
                             : a->AllToAll(send_buf_dev, recv_buf_dev, sseg, kNcclFloat64, comm, pf->stream);
-      if (r) {   // this rank will not enqueue the rest: end the collectives its peers may already wait in
-        if (a->CommAbort) (void)a->CommAbort(comm);
-        pf->last_comm = nullptr;
-        return rccl_fail(a, trimmed ? "ncclAllToAllv" : "ncclAllToAll", r);
-      }
+      if (r) return bail(rccl_fail(a, trimmed ? "ncclAllToAllv" : "ncclAllToAll", r));
       rc = cssm_pf_shard_adopt_spec(pf, recv_buf_dev, rank, world, cap);
-      if (rc) return rc;
+      if (rc) return bail(rc);
     }
     return CSSM_OK;
   }

@@ -196,26 +196,71 @@ def test_single_collective_series_matches_oracle(world, name, n, T):
         s.close()
 
 
-@pytest.mark.parametrize("why", ["capacity", "outlier"])
+def _mirror_plan(model, n, world, t, y, has, lgcp=False, prec=0, min_cap=None, cap_sqrt=None):
+    """What the orchestration does with this series -- (attempts, resumes, single, from_max) -- found by running the SAME
+    ShardedFilter over the CPU stand-in (tests/oracle_shard.py; every verdict there is a function of the same bits): the GPU
+    run must take exactly that path, not merely arrive at the right numbers by some path."""
+    from composablestatespacemodels_amd.sharded import LocalComm, ShardedFilter
+    from oracle_shard import OracleShard
+    shards = [OracleShard(model, n, r, world, cases.SEED, prec) for r in range(world)]
+    f = ShardedFilter(shards, LocalComm(world))
+    if min_cap is not None:
+        f.MIN_CAP, f.CAP_SQRT = min_cap, cap_sqrt
+    ll, ess = f.ll_filter(t, y, has, lgcp=lgcp)
+    return (f.last_attempts, f.last_resumes, f.last_single, f.last_from_max), (ll, ess)
+
+
+@pytest.mark.parametrize("why", ["capacity", "outlier", "outlier+capacity"])
 def test_series_resumes_a_capacity_miss_and_repeats_after_an_outlying_observation(why):
+    """capacity: one row per pair cannot hold the exchange (sticky bit 8): the observations that miss are resumed in place.
+    outlier: the max rules a reference level out (bit 4): the series is repeated with every level from the global max.
+    outlier+capacity: both -- the repetition (plan "max": all-gather + shard_sums before the all-to-all) ALSO misses its
+    capacity and is resumed: the level, the unit sums and the exported words of the observation the series holds at must
+    survive the observations enqueued behind it (round 2 lost them: NaN levels for LGCP, a spurious third attempt here)."""
     from composablestatespacemodels_amd.sharded import GpuShard, LocalComm, ShardedFilter
     model = cases.c2_model()
-    n, world, T = 12000, 4, 14
+    # (a count of 60 also concentrates the weight on very few particles: at world 2 every rank is adjacent to the other, so
+    #  boundary blocks -- whole shards if need be -- always cover; at world 4 such a step ends on the exact exchange)
+    n, world, T = 12000, (4 if why == "capacity" else 2), 14
     t, y, has = cases.poisson_counts(T)
-    if why == "outlier":
-        y = y.copy(); y[9] = 60.0          # the max rules the reference level out (sticky bit 4): repeated with the exact exchange
+    if why != "capacity":
+        y = y.copy(); y[9] = 60.0
+    tiny = why != "outlier"
     shards = [GpuShard(model, n, r, world, cases.SEED, 0) for r in range(world)]
     f = ShardedFilter(shards, LocalComm(world))
-    if why == "capacity":
-        f.MIN_CAP, f.CAP_SQRT = 1, 0.0     # one row per pair cannot hold the exchange (sticky bit 8): resumed with more
+    if tiny:
+        f.MIN_CAP, f.CAP_SQRT = 1, 0.0
     ll, ess = f.ll_filter(t, y, has)
+    plan, _ = _mirror_plan(model, n, world, t, y, has, min_cap=1 if tiny else None, cap_sqrt=0.0 if tiny else None)
+    assert (f.last_attempts, f.last_resumes, f.last_single, f.last_from_max) == plan
     if why == "capacity":
-        assert f.last_attempts == 1 and f.last_resumes >= 1
+        assert plan[0] == 1 and plan[1] >= 1
+    elif why == "outlier":
+        assert plan[0] == 2 and plan[2] and plan[3]
     else:
-        # repeated with every level taken from the global max; a count of 60 also concentrates the weight on so few particles
-        # that slots of a rank can belong to particles of NON-adjacent ranks, which no capacity covers: then the exact exchange
-        assert (f.last_attempts == 2 and f.last_single and f.last_from_max) or (f.last_attempts == 3 and not f.last_single)
+        assert plan[0] == 2 and plan[1] >= 1 and plan[2] and plan[3]      # resumed INSIDE the "max" plan
     oll, oess, opart = _oracle_run(model, n, t, y, has)
+    assert (ll, ess) == (oll, oess[-1])
+    np.testing.assert_array_equal(np.concatenate([s.particles() for s in shards], axis=1), opart)
+    for s in shards:
+        s.close()
+
+
+@pytest.mark.parametrize("world,n", [(2, 3000), (4, 9000)])
+def test_lgcp_series_resumes_a_capacity_miss(world, n):
+    """An LGCP series runs on the "max" plan from the start (its level IS the max).  With one row per pair its exchanges
+    miss and are resumed in place: ONE attempt, at least one resume, the oracle's bits."""
+    from composablestatespacemodels_amd.sharded import GpuShard, LocalComm, ShardedFilter
+    model = cases.c4_model()
+    t, y, has = cases.event_times(8, horizon=12.0)
+    shards = [GpuShard(model, n, r, world, cases.SEED, 0, lgcp_precision=2) for r in range(world)]
+    f = ShardedFilter(shards, LocalComm(world))
+    f.MIN_CAP, f.CAP_SQRT = 1, 0.0
+    ll, ess = f.ll_filter(t, y, has, lgcp=True)
+    plan, _ = _mirror_plan(model, n, world, t, y, has, lgcp=True, prec=2, min_cap=1, cap_sqrt=0.0)
+    assert (f.last_attempts, f.last_resumes, f.last_single, f.last_from_max) == plan
+    assert plan[0] == 1 and plan[1] >= 1 and plan[2] and plan[3]
+    oll, oess, opart = _oracle_run(model, n, t, y, has, lgcp_precision=2)
     assert (ll, ess) == (oll, oess[-1])
     np.testing.assert_array_equal(np.concatenate([s.particles() for s in shards], axis=1), opart)
     for s in shards:
