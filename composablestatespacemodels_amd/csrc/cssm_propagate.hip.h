@@ -248,10 +248,11 @@ __device__ __forceinline__ void propagate_range(
         tmax = (lw[r] > tmax) ? lw[r] : tmax;
         if (SUMS && !LGCP && do_sums) {
           // beyond c + CSSM_REF_BELOW the step is redone with the max anyway: keep the conversion in range
+          // (a <= 2^-20 and never NaN: the cheaper forms of exp and of the fixed-point conversion return the same values)
           const double a = cssm_min_c(lw[r] - cref, CSSM_REF_BELOW);
-          const double w1 = cssm_exp(a);
-          accS = cssm_u128_add(accS, cssm_fix_from_double(w1));
-          accS2 = cssm_u128_add(accS2, cssm_fix_from_double(w1 * w1));
+          const double w1 = cssm_exp_le0(a);
+          accS = cssm_u128_add(accS, cssm_fix_from_unit(w1));
+          accS2 = cssm_u128_add(accS2, cssm_fix_from_unit(w1 * w1));
         }
       }
     };

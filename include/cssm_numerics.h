@@ -393,6 +393,49 @@ CSSM_HD double cssm_exp(double x) {
   return res;
 }
 
+/* exp(a) for an argument KNOWN to be at most CSSM_REF_BELOW and not NaN (-inf allowed): the weight w1 = exp(w - level) of a
+ * particle whose log-weight was already checked for NaN and clamped at the level.  The value of cssm_exp(a) for every such a;
+ * what is left out are the selects that cannot fire (overflow, NaN, the upper clamp).  Device form: the Horner steps are
+ * pinned to one three-address v_fma_f64 each with the coefficient in a vector register -- in the fused kernel the compiler
+ * otherwise emits v_mov_b64 + v_fmac_f64 per step for THIS call (ten copies per weight; the exp of the Poisson density a few
+ * lines earlier, same source, gets plain v_fma_f64). */
+CSSM_HD double cssm_fma_kv(double a, double b, double k) {
+#if CSSM_DEVICE_FORM
+  double d;
+  __asm__("v_fma_f64 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(k));
+  return d;
+#else
+  return __builtin_fma(a, b, k);
+#endif
+}
+CSSM_HD double cssm_exp_le0(double a) {
+  const double LOG2E = 1.44269504088896338700e+00;
+  const double LN2_HI = 6.93147180369123816490e-01;
+  const double LN2_LO = 1.90821492927058770002e-10;
+  const double xc = cssm_max_c(a, -745.0);
+  const double ts = cssm_fma(xc, LOG2E, CSSM_SHIFTER);
+  const double kd = ts - CSSM_SHIFTER;
+  const int k = (int)(uint32_t)cssm_d2u(ts);
+  double r = cssm_fma(-kd, LN2_HI, xc);
+  r = cssm_fma(-kd, LN2_LO, r);
+  double p = 1.0 / 6227020800.0;
+  p = cssm_fma_kv(p, r, 1.0 / 479001600.0);
+  p = cssm_fma_kv(p, r, 1.0 / 39916800.0);
+  p = cssm_fma_kv(p, r, 1.0 / 3628800.0);
+  p = cssm_fma_kv(p, r, 1.0 / 362880.0);
+  p = cssm_fma_kv(p, r, 1.0 / 40320.0);
+  p = cssm_fma_kv(p, r, 1.0 / 5040.0);
+  p = cssm_fma_kv(p, r, 1.0 / 720.0);
+  p = cssm_fma_kv(p, r, 1.0 / 120.0);
+  p = cssm_fma_kv(p, r, 1.0 / 24.0);
+  p = cssm_fma_kv(p, r, 1.0 / 6.0);
+  p = cssm_fma(p, r, 0.5);
+  p = cssm_fma(p, r, 1.0);
+  p = cssm_fma(p, r, 1.0);
+  const double res = cssm_scale2(p, k);
+  return (a < -708.0) ? 0.0 : res;
+}
+
 /* ------------------------------------------------------------------ log */
 
 /*
@@ -581,17 +624,48 @@ typedef struct { uint64_t lo, hi; } cssm_u128;
 #define CSSM_FIX_FRAC_BITS 96 /* 1.0 == {lo = 0, hi = 1<<32}; 32 integer bits => N < 2^32 */
 
 CSSM_HD cssm_u128 cssm_u128_zero(void) { cssm_u128 r; r.lo = 0; r.hi = 0; return r; }
+/* a + b mod 2^128.  Device form: the four-instruction carry chain.  Left to itself the compiler (ROCm 7.2) lowers the portable
+ * form -- and unsigned __int128, and __builtin_addcll -- to two or three 64-bit adds plus a 64-bit compare and a select per
+ * 128-bit add: 5-8 instructions at the 64-bit rate (~5 cycles per wave each on MI355X, tools/instr_rate.hip) instead of 4 at
+ * the 32-bit carry rate (~2.4).  The fused kernel makes two such adds per particle, a wave scan six per lane. */
 CSSM_HD cssm_u128 cssm_u128_add(cssm_u128 a, cssm_u128 b) {
+#if CSSM_DEVICE_FORM
+  uint32_t a0 = (uint32_t)a.lo, a1 = (uint32_t)(a.lo >> 32), a2 = (uint32_t)a.hi, a3 = (uint32_t)(a.hi >> 32);
+  const uint32_t b0 = (uint32_t)b.lo, b1 = (uint32_t)(b.lo >> 32), b2 = (uint32_t)b.hi, b3 = (uint32_t)(b.hi >> 32);
+  __asm__("v_add_co_u32 %0, vcc, %0, %4\n\tv_addc_co_u32 %1, vcc, %1, %5, vcc\n\tv_addc_co_u32 %2, vcc, %2, %6, vcc\n\t"
+          "v_addc_co_u32 %3, vcc, %3, %7, vcc"
+          : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(b0), "v"(b1), "v"(b2), "v"(b3) : "vcc");
+  cssm_u128 r;
+  r.lo = (uint64_t)a0 | ((uint64_t)a1 << 32);
+  r.hi = (uint64_t)a2 | ((uint64_t)a3 << 32);
+  return r;
+#else
   cssm_u128 r;
   r.lo = a.lo + b.lo;
   r.hi = a.hi + b.hi + (r.lo < a.lo ? 1u : 0u);
   return r;
+#endif
 }
 CSSM_HD int cssm_u128_is_zero(cssm_u128 a) { return (a.lo | a.hi) == 0; }
 
 /* floor(w * 2^96) for finite 0 <= w < 2^9 (weights are <= 1); negative, NaN, inf and w >= 2^9 map to 0.
  * Four 32-bit digits peeled off by truncation: every subtraction and every scaling by 2^32 is exact in fp64 (the
  * operand is a non-negative double below 2^32 and its integer part), so no rounding occurs anywhere. */
+/* ... the digits themselves, for an argument KNOWN to be finite and in [0, 2^32) (the weights a kernel has just formed as
+ * exp of a clamped non-positive number): the same value as cssm_fix_from_double without its range selects. */
+CSSM_HD cssm_u128 cssm_fix_from_unit(double x) {
+  cssm_u128 r;
+  const uint32_t d3 = (uint32_t)x;                        /* integer part */
+  double t = (x - (double)d3) * 0x1.0p32;
+  const uint32_t d2 = (uint32_t)t;
+  t = (t - (double)d2) * 0x1.0p32;
+  const uint32_t d1 = (uint32_t)t;
+  t = (t - (double)d1) * 0x1.0p32;
+  const uint32_t d0 = (uint32_t)t;
+  r.hi = ((uint64_t)d3 << 32) | d2;
+  r.lo = ((uint64_t)d1 << 32) | d0;
+  return r;
+}
 CSSM_HD cssm_u128 cssm_fix_from_double(double w) {
   cssm_u128 r;
   const int valid = (w >= 0.0) & (w < 512.0);            /* false for NaN */
