@@ -73,6 +73,7 @@ SYMBOLS = [
     ("cssm_pf_set_params", C.c_int, [_h, _descp]),
     ("cssm_pf_reseed", C.c_int, [_h, C.c_uint64]),
     ("cssm_pf_run_key", C.c_uint64, [C.c_uint64, C.c_uint64]),
+    ("cssm_pf_get_weights", C.c_int, [_h, _dp, _dp]),
     ("cssm_pf_init", C.c_int, [_h, C.c_double]),
     ("cssm_pf_init_from", C.c_int, [_h, C.c_double, _dp]),
     ("cssm_pf_step", C.c_int, [_h, C.c_double, C.c_double, C.c_int, _dp, _i32p]),

@@ -63,6 +63,12 @@ struct Scalars {
   cssm_u128 S_local, S2_local; // local fixed-point sums (this rank)
   cssm_u128 S_off;           // sum of the ranks before this one
   cssm_u128 S_tot, S2_tot;   // global sums
+  // ESS pending (single GPU, weights kept in place of log-weights): the sum of squared weights of the last weighted
+  // observation was formed by k_offspring's blocks -- one partial per block in s2[pend_buf][0 .. pend_n) -- and nobody has
+  // totalled it yet: the NEXT weighted observation's publisher block does (and files the value under ess_t[pend_idx] if the
+  // batch call of generation pend_gen is still the one running), or the host when a call ends (cssm_ess_of, same arithmetic).
+  uint32_t pend, pend_buf, pend_n, pend_idx, pend_gen, pad3_;
+  cssm_u128 pend_S;          // S_tot of that observation
 };
 
 // ------------------------------------------------------------------------------------ helpers
@@ -368,25 +374,35 @@ __device__ __forceinline__ void bulk_store2(double* p, double a, double b) {
 #endif
 }
 
-// ll += max + log(mean(w1)) (:127, :522-524); ess = floor(1 / sum (w1/tot)^2) (:128, :431-434)
-__device__ __forceinline__ void finish_step(Scalars* sc, uint64_t n_global) {
-  const double tot = cssm_fix_to_double(sc->S_tot);
-  const double tot2 = cssm_fix_to_double(sc->S2_tot);
+// ess = floor(1 / sum (w1/tot)^2) (model/ParticleFilter.scala:128, :431-434) from the fixed-point sums; IEEE operations only:
+// the host evaluates the same function when it totals a pending observation's squares itself
+__host__ __device__ __forceinline__ int32_t cssm_ess_of(cssm_u128 S, cssm_u128 S2) {
+  const double tot = cssm_fix_to_double(S);
+  const double tot2 = cssm_fix_to_double(S2);
+  const double e = 1.0 / (tot2 / (tot * tot));
+  const double fl = (double)(long long)e;   // e >= 1 here; floor == trunc
+  return (e < 2147483647.0) ? (int32_t)fl : 2147483647;
+}
+// ll += level + log(mean(w1)) (:127, :522-524) from sc->S_tot; false (and err bit 1) when no weight is left
+__device__ __forceinline__ bool finish_ll(Scalars* sc, uint64_t n_global) {
   if (cssm_u128_is_zero(sc->S_tot) || !(sc->gmax > -cssm_inf()) || !(sc->gmax < cssm_inf())) {
     atomicOr(&sc->err, 2u);
-    return;
+    return false;
   }
-  sc->ll = sc->ll + sc->ref + cssm_log(tot / (double)n_global);
-  double e = 1.0 / (tot2 / (tot * tot));
-  double fl = (double)(long long)e;   // e >= 1 here; floor == trunc
-  sc->ess = (e < 2147483647.0) ? (int32_t)fl : 2147483647;
+  sc->ll = sc->ll + sc->ref + cssm_log(cssm_fix_to_double(sc->S_tot) / (double)n_global);
+  return true;
+}
+// ... and the ESS with it, when the sum of squares is at hand (sc->S2_tot)
+__device__ __forceinline__ void finish_step(Scalars* sc, uint64_t n_global) {
+  if (finish_ll(sc, n_global)) sc->ess = cssm_ess_of(sc->S_tot, sc->S2_tot);
 }
 
 
 // ------------------------------------------------------------------------------------ weights of a tile, end slots
 
-// raw != 0: `logw` already holds the weights w1 themselves (stateless Resample[A] entry point,
-// whose second argument is w1 = exp(w - max): model/ParticleFilter.scala:125-126).
+// raw != 0: `logw` already holds the weights w1 themselves -- 1: the stateless Resample[A] entry point, whose second argument is
+// w1 = exp(w - max) (model/ParticleFilter.scala:125-126; arbitrary host doubles); 2: k_propagate<SUMS> stored
+// exp(min(w - c, 2^-20)) in place of the log-weights (in [0, 1 + 2^-20]: cssm_fix_from_unit applies).
 __device__ __forceinline__ void load_tile_raw(const double* __restrict__ logw, uint64_t base, uint64_t n, int raw,
                                               double (&v)[CSSM_ITEMS]) {
   const uint64_t i0 = base + (uint64_t)threadIdx.x * CSSM_ITEMS;
@@ -402,7 +418,7 @@ __device__ __forceinline__ void load_tile_raw(const double* __restrict__ logw, u
 __device__ __forceinline__ void weights_from_raw(const double (&v)[CSSM_ITEMS], double gmax, int raw, double (&w1)[CSSM_ITEMS],
                                                  const double* tab) {
 #pragma unroll
-  for (int r = 0; r < CSSM_ITEMS; ++r) w1[r] = raw ? v[r] : cssm_exp(v[r] - gmax);
+  for (int r = 0; r < CSSM_ITEMS; ++r) w1[r] = raw ? v[r] : cssm_exp_le0(v[r] - gmax);   // (w - level <= 2^-20, never NaN: k_propagate)
 }
 __device__ __forceinline__ void load_tile_weights(const double* __restrict__ logw, uint64_t base, uint64_t n,
                                                   double gmax, int raw, double (&w1)[CSSM_ITEMS], const double* tab) {

@@ -20,6 +20,8 @@ struct PropLaunch {
   const double* src2; size_t src2_stride; uint32_t n_split; const double* logtab;
   uint64_t chunk; int do_sums; cssm_u128* subS; cssm_u128* subS2; double* pick_out; uint32_t pick_slot;
   const double* fsub;  // LGCP with a time-dependent f: the sub-step coefficient table (else nullptr)
+  int sharded;         // a shard's launch: both sums (S and S2) travel in the exchange -- never the single-GPU _self kernels, which
+                       //   leave the sum of squares to k_offspring
   int shard_slim;      // the sharded filter's slim launch k_propagate_shard applies (cssm_pf.hip decides)
   int one;             // k_propagate_self<..., ONE>: 1 = the block's range is one tile, 2 = the same body tile after tile, 0 = software-pipelined
 };

@@ -33,11 +33,21 @@ struct cssm_pf : HostModel {
   uint32_t split = 1;             // k_propagate blocks per unit (each owns a contiguous sub-unit and its sums)
   bool safe_sums = false;         // form the sums in their own pass after the max is known (retry of a step whose
                                   // reference level was ruled out by the max; always for LGCP)
-  bool last_optimistic = false;   // the last launch_propagate formed the sums itself
+  bool last_optimistic = false;   // the last launch_propagate formed the sums itself (and stored weights in place of log-weights)
+  bool wmode = false;             // the log-weight buffer holds the WEIGHTS exp(min(w - c, 2^-20)) of the last weighted observation
+  bool sums_ready = false;        // sharded: the unit sums of the last propagated observation exist (k_propagate<SUMS> or cssm_pf_shard_sums)
+  // ESS pending (Scalars::pend): k_offspring's blocks leave partial sums of squared weights in s2buf[par * s2_stride + block]
+  cssm_u128* s2buf = nullptr;     // 2 x s2_stride entries
+  cssm_u128* h_s2 = nullptr;      // pinned: the partials of the last enqueued weighted observation, read with the scalars
+  uint32_t s2_stride = 0;
+  int s2_par = 0;                 // buffer the next weighted observation's k_offspring writes
+  uint32_t gen = 0;               // generation of the batch call / streaming step that owns d_ess_t
+  bool pend_host = false;         // the last ENQUEUED weighted observation leaves its ESS pending, partials in buffer pend_par_host
+  int pend_par_host = 0;
+  int32_t ess_host = 0;           // ESS of the last completed observation as the host knows it
   void* last_comm = nullptr;      // RCCL communicator the library last enqueued collectives on (bounded_sync)
   std::vector<double> h_fsub;     // host copy of the sub-step coefficient table of the records last built
   double* d_fsub = nullptr; size_t fsub_cap = 0;
-  bool batch_hold = false;        // batch drivers: an outlying observation puts the series on hold (err bit 6) instead of voiding it
   bool sharded = false;
   // device memory
   double* state[2] = {nullptr, nullptr};

@@ -62,8 +62,13 @@ static __global__ __launch_bounds__(CSSM_BLOCK) void k_tile_sums(const double* _
       else load_tile_weights(logw, (uint64_t)tile * CSSM_TILE, n, gmax, raw, w1, tab);
 #pragma unroll
       for (int r = 0; r < CSSM_ITEMS; ++r) {
-        a = cssm_u128_add(a, cssm_fix_from_double(w1[r]));
-        b = cssm_u128_add(b, cssm_fix_from_double(w1[r] * w1[r]));
+        if (raw) {   // (the stateless entry point: arbitrary host doubles, range-checked)
+          a = cssm_u128_add(a, cssm_fix_from_double(w1[r]));
+          b = cssm_u128_add(b, cssm_fix_from_double(w1[r] * w1[r]));
+        } else {
+          a = cssm_u128_add(a, cssm_fix_from_unit(w1[r]));
+          b = cssm_u128_add(b, cssm_fix_from_unit(w1[r] * w1[r]));
+        }
       }
     }
     a = wave_sum_u128(a);
@@ -96,9 +101,11 @@ static __global__ __launch_bounds__(CSSM_BLOCK) void k_reduce_units(const cssm_u
   uint32_t b1 = b0 + blocks_per_unit;
   b1 = (b1 < nblocks) ? b1 : nblocks;
   cssm_u128 a = cssm_u128_zero(), b = cssm_u128_zero();
-  for (uint32_t q = b0 + lane; q < b1; q += 64u) { a = cssm_u128_add(a, blockS[q]); b = cssm_u128_add(b, blockS2[q]); }
-  a = wave_sum_u128(a); b = wave_sum_u128(b);
-  if (lane == 0u) { unitS[unit] = a; unitS2[unit] = b; }
+  // blockS2 == nullptr: the blocks formed no sums of squares (single GPU: k_offspring forms them)
+  for (uint32_t q = b0 + lane; q < b1; q += 64u) { a = cssm_u128_add(a, blockS[q]); if (blockS2) b = cssm_u128_add(b, blockS2[q]); }
+  a = wave_sum_u128(a);
+  if (blockS2) b = wave_sum_u128(b);
+  if (lane == 0u) { unitS[unit] = a; if (blockS2) unitS2[unit] = b; }
 }
 
 // Exclusive scan of the tile sums in one block (thread t owns a contiguous chunk of tiles: sum, block
@@ -175,72 +182,86 @@ static __global__ __launch_bounds__(1024) void k_scan_tiles(const cssm_u128* __r
 #endif
 // unit sums every block of k_offspring_self requests before anything else, per thread (x 256 threads); the rest in a loop
 #ifndef CSSM_OFF_UPRE
-#define CSSM_OFF_UPRE 8   /* 2048 entries: every sub-unit sum of a cloud of up to 2^20 particles run on half tiles is in flight at once */
+#define CSSM_OFF_UPRE 4   /* 1024 entries (every cloud from 2^20 particles on) in flight at once; smaller clouds on half / quarter tiles: a loop for the rest */
 #endif
 // k_offspring's ancestor lines: 1 = write-through (sc1) stores, 0 = plain stores (dirty lines written back when the kernel ends)
 #ifndef CSSM_OFF_SC1
 #define CSSM_OFF_SC1 1
 #endif
-// 1: a tile's ancestor runs are assembled in LDS and written as whole lines; 0: every particle writes its own run
-#ifndef CSSM_OFF_LINES
-#define CSSM_OFF_LINES 1
-#endif
-template <bool FUSE, bool SELF, int RS>
+// sum over the block's threads, the same value in every thread (s_red: CSSM_BLOCK / 64 entries of LDS; all threads call)
+__device__ __forceinline__ cssm_u128 block_sum_u128(cssm_u128 v, cssm_u128* s_red) {
+  v = wave_sum_u128(v);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  cssm_u128 t = s_red[0];
+#pragma unroll
+  for (int w = 1; w < CSSM_BLOCK / 64; ++w) t = cssm_u128_add(t, s_red[w]);
+  return t;
+}
+
+template <bool FUSE, bool SELF, int RS, int RAWC = -1>
 __device__ __forceinline__ void offspring_body(const double* __restrict__ logw, uint64_t n,
                                                           Scalars* __restrict__ sc,
                                                           const cssm_u128* __restrict__ unitP, const cssm_u128* __restrict__ unitS2,
                                                           const StepRec* __restrict__ rec, uint64_t n_global,
                                                           uint32_t* __restrict__ endslot, uint32_t* __restrict__ anc,
-                                                          uint32_t ntiles, uint32_t sup, uint32_t nunits, int raw, int slot_set,
+                                                          uint32_t ntiles, uint32_t sup, uint32_t nunits, int raw_arg, int slot_set,
                                                           double* __restrict__ ll_t, int32_t* __restrict__ ess_t, uint32_t rec_idx,
                                                           int force_exact, const unsigned long long* __restrict__ all5, int rank, int world,
                                                           int split, uint64_t seed, double* __restrict__ cum_out,
                                                           const double* __restrict__ logtab, int optimistic,
                                                           unsigned long long* __restrict__ flag_out,
-                                                          uint32_t slot_lo, uint32_t slot_hi, uint32_t all5_stride) {
+                                                          uint32_t slot_lo, uint32_t slot_hi, uint32_t all5_stride,
+                                                          cssm_u128* __restrict__ s2buf = nullptr, uint32_t s2_stride = 0, int s2_par_arg = -1,
+                                                          uint32_t gen = 0) {
+  // RAWC >= 0 (the single-GPU launches): the weight-input mode is a compile-time constant -- 2 goes with the pending ESS
+  // (s2_par >= 0), 0 with the sums of squares at hand; the kernel had run out of scalar and vector registers otherwise
+  const int raw = (RAWC >= 0) ? RAWC : raw_arg;
+  const int s2_par = (RAWC == 0) ? -1 : s2_par_arg;
+  // raw: 0 = `logw` holds log-weights, rescaled here by the step's level; 1 = weights as given (stateless Resample[A]);
+  //      2 = the weights exp(min(w - c, 2^-20)) k_propagate<SUMS> stored in place of the log-weights (c = rec->ref): no exp
+  //      here, and the conversion is the one k_propagate formed the unit sums with
   // all5_stride: distance in words between the 5 words of consecutive ranks (5: the all-gathered array; the segment
   // length when the words are read from the headers of the single-collective exchange, see k_boundary_pack)
   // !SELF && FUSE (sharded, stateless): only the slots [slot_lo, slot_hi) are this rank's; anc is indexed from slot_lo.
   // unitP holds `split` entries per unit (k_propagate's blocks are sub-units); all5: 5 words per rank
   // (S.lo, S.hi, S2.lo, S2.hi, order key of the rank's max); optimistic: the sums were formed relative to the
   // observation's reference level before the max was known -- if the max rules that level out, nothing is
-  // resampled and the host is told to form the sums again (err bit 2 / *flag_out).
+  // resampled and the host is told to form the sums again (SELF: err bit 6, the series is on hold; else err bit 2 / *flag_out).
+  // s2buf / s2_stride / s2_par / gen (SELF): two arrays of per-block partial sums of squared weights.  s2_par >= 0: this
+  // launch forms the observation's sum of squares ITSELF -- block b's partial goes to s2buf[s2_par * s2_stride + b] -- and its
+  // ESS stays pending (Scalars::pend) until the next weighted observation's publisher, or the host, totals the partials.
+  // s2_par < 0: the sum of squares is at hand (unitS2: k_tile_sums formed it): the ESS is published with ll.
   constexpr int resampler = RS;
   const double* tab = nullptr; (void)logtab;
   __shared__ cssm_u128 s_w[CSSM_BLOCK / 64];
   __shared__ uint32_t s_last[CSSM_BLOCK / 64];
-#if !CSSM_OFF_LINES
-  __shared__ uint32_t s_nheavy;
-#endif
-  __shared__ __attribute__((aligned(16))) uint32_t s_slot[FUSE ? 3 * CSSM_TILE : 4];   // a 2048-slot chunk / up to 1024 long runs
+  __shared__ __attribute__((aligned(16))) uint32_t s_slot[FUSE ? (CSSM_BLOCK / 64) * CSSM_WAVE_CHUNK : 4];   // per wave: a 512-slot chunk of ancestor runs
   __shared__ cssm_u128 s_r[3][CSSM_BLOCK / 64];
+  __shared__ cssm_u128 s_pre[2];
   // (batch series, single GPU) an earlier observation's reference level was ruled out by its max: the series is on hold at
-  // that observation until the host has redone its sums (run_filter_once); nothing may change meanwhile
+  // that observation until the host has redone it (run_filter_once); nothing may change meanwhile
   // (the test sits behind the prefetches below: a dependent round trip at the very top of the kernel otherwise)
-#ifdef CSSM_OFF_STAMPS
-  const unsigned long long os0 = wall_clock64();
-  unsigned long long os1 = 0, os2 = 0, os3 = 0, os4 = 0;
-#endif
   const uint32_t held = SELF ? sc->err : 0u;
   double pre_v[CSSM_ITEMS];   // the block's first tile is requested before the serial prologue
   if (blockIdx.x < nunits) load_tile_raw(logw, (uint64_t)blockIdx.x * sup * CSSM_TILE, n, raw, pre_v);
-  // ... and (single GPU) so are the unit sums every block totals: up to 2048 of them, CSSM_OFF_UPRE per thread, in flight while the max
-  // is decoded -- one dependent round trip less on the kernel's critical path, which at N = 2^20 is all it has
+  // ... and (single GPU) so are the unit sums every block totals: thread t owns the E = ceil(nsub / 256) consecutive entries
+  // from t E on (up to UPRE of them in flight while the max is decoded; a loop for more)
   constexpr int UPRE = CSSM_OFF_UPRE;
   cssm_u128 upre[UPRE];
+  const uint32_t nsub = SELF ? nunits * (uint32_t)split : 0u;
+  const uint32_t E = (nsub + CSSM_BLOCK - 1) / CSSM_BLOCK;
   if (SELF) {
 #pragma unroll
     for (int k = 0; k < UPRE; ++k) {
-      const uint32_t q = threadIdx.x + (uint32_t)k * CSSM_BLOCK;
-      upre[k] = (q < nunits * (uint32_t)split) ? unitP[q] : cssm_u128_zero();
+      const uint32_t q = threadIdx.x * E + (uint32_t)k;
+      upre[k] = ((uint32_t)k < E && q < nsub) ? unitP[q] : cssm_u128_zero();
     }
   }
   double gmax_dec;
   if (SELF) {
     gmax_dec = block_decode_slots(sc, slot_set);
-#ifdef CSSM_OFF_STAMPS
-    os1 = wall_clock64();
-#endif
     if (held & 64u) return;
   } else if (all5) {
     unsigned long long key = 0ull;
@@ -249,26 +270,13 @@ __device__ __forceinline__ void offspring_body(const double* __restrict__ logw, 
   } else {
     gmax_dec = sc->gmax;
   }
-  const double gmax = raw ? gmax_dec : cssm_ref_choose(rec->ref, gmax_dec);   // the level of this step
-  if (!raw && optimistic && !(gmax == rec->ref)) {
-    if (SELF && optimistic == 3) {
-      // batch series: put the series on hold AT this observation (its propagate is done, its log-weights are in place); every
-      // kernel enqueued behind returns at once, the host redoes this observation's sums relative to the max and carries on
+  const double gmax = (raw == 1) ? gmax_dec : cssm_ref_choose(rec->ref, gmax_dec);   // the level of this step
+  if (raw != 1 && optimistic && !(gmax == rec->ref)) {
+    if (SELF) {
+      // put the series on hold AT this observation (its propagate is done: the cloud is in place, the previous ancestors are
+      // untouched); every kernel enqueued behind returns at once, the host redoes this observation -- its weights again, as
+      // log-weights, and its sums relative to the max -- and carries on
       if (blockIdx.x == 0 && threadIdx.x == 0) { sc->gmax = gmax_dec; atomicMin(&sc->fail_step, rec->step); atomicOr(&sc->err, 64u); }
-    } else if (SELF) {
-      if (FUSE && anc) {   // keep the ancestor array addressable for the steps already enqueued behind this one
-        for (uint32_t unit = blockIdx.x; unit < nunits; unit += gridDim.x) {
-          const uint64_t lo = (uint64_t)unit * sup * CSSM_TILE;
-          uint64_t hi = lo + (uint64_t)sup * CSSM_TILE;
-          hi = (hi < n) ? hi : n;
-          for (uint64_t i = lo + threadIdx.x; i < hi; i += CSSM_BLOCK) anc[i] = (uint32_t)i;
-        }
-      }
-      if (blockIdx.x == 0) {
-        if (threadIdx.x == 0) { sc->gmax = gmax_dec; atomicOr(&sc->err, 4u); }
-        if (threadIdx.x < 2 * CSSM_MAXSLOTS)
-          sc->maxslot[((size_t)((slot_set + 1 + (int)(threadIdx.x / CSSM_MAXSLOTS)) % CSSM_MAXSETS) * CSSM_MAXSLOTS + threadIdx.x % CSSM_MAXSLOTS) * CSSM_SLOT_STRIDE] = 0ull;
-      }
     } else if (blockIdx.x == 0 && threadIdx.x == 0) {
       if (flag_out) *flag_out = 1ull;
       if (optimistic == 2) atomicOr(&sc->err, 4u);   // (merged with the expansion: no later kernel reads the flag)
@@ -305,57 +313,100 @@ __device__ __forceinline__ void offspring_body(const double* __restrict__ logw, 
   }
   // (SELF: the single-GPU launch has exactly one block per unit -- no loop, so that what was prefetched above does not
   //  have to stay live around a back edge -- plus ONE more block, the publisher: it totals the sums like every block and
-  //  then publishes the observation's scalars (ll, ess: a logarithm and two divisions in one thread) instead of working on
+  //  then publishes the observation's scalars (ll; ess: a logarithm and two divisions in one thread) instead of working on
   //  a unit.  With block 0 doing both, that serial tail was on the critical path of a launch that at small N has nothing
   //  but its critical path.)
   uint32_t unit = blockIdx.x;
   cssm_u128 toff_self = cssm_u128_zero();
   if (SELF) {                                              // here unitP holds the unit SUMS (k_propagate / k_tile_sums output)
     const bool pub = (blockIdx.x == nunits);
-    cssm_u128 pre = cssm_u128_zero(), tot = cssm_u128_zero(), tot2 = cssm_u128_zero();
-    const uint32_t nsub = nunits * (uint32_t)split, qlim = unit * (uint32_t)split;
+    // ONE wave scan of the threads' own sums gives both the total and the prefix of the entries below this block's first
+    // (qlim): that prefix = inclusive scan at thread tq - 1 + the first qlim - tq E entries of thread tq, tq = qlim / E.
+    // (Round 2 took two block-wide sums with eight masked 128-bit adds per thread each: a third of the kernel's
+    //  instructions at N = 2^20, where a block has one tile.)
+    const uint32_t qlim = unit * (uint32_t)split;
+    const uint32_t tq = E ? qlim / E : 0u, rq = E ? qlim - tq * E : 0u;     // (uniform)
+    cssm_u128 own = cssm_u128_zero(), part = cssm_u128_zero();
 #pragma unroll
-    for (int k = 0; k < UPRE; ++k) {     // (requested before the max was decoded; upre[k] is zero beyond nsub)
-      const uint32_t q = threadIdx.x + (uint32_t)k * CSSM_BLOCK;
-      if (q < qlim) pre = cssm_u128_add(pre, upre[k]);
-      tot = cssm_u128_add(tot, upre[k]);
-      if (pub && q < nsub) tot2 = cssm_u128_add(tot2, unitS2[q]);   // only the publishing block needs sum w^2
+    for (int k = 0; k < UPRE; ++k) {     // (upre[k] is zero beyond E and beyond nsub)
+      own = cssm_u128_add(own, upre[k]);
+      if ((uint32_t)k + 1u == rq) part = own;               // the first rq entries of a thread (kept by thread tq only)
     }
-    for (uint32_t q = threadIdx.x + UPRE * CSSM_BLOCK; q < nsub; q += CSSM_BLOCK) {
-      const cssm_u128 v = unitP[q];
-      if (q < qlim) pre = cssm_u128_add(pre, v);
-      tot = cssm_u128_add(tot, v);
-      if (pub) tot2 = cssm_u128_add(tot2, unitS2[q]);
+    for (uint32_t k = UPRE; k < E; ++k) {
+      const uint32_t q = threadIdx.x * E + k;
+      if (q < nsub) own = cssm_u128_add(own, unitP[q]);
+      if (k + 1u == rq) part = own;
     }
-    pre = wave_sum_u128(pre); tot = wave_sum_u128(tot);
-    if (pub) tot2 = wave_sum_u128(tot2);
-    if (lane == 0) { s_r[0][wid] = pre; s_r[1][wid] = tot; s_r[2][wid] = tot2; }
+    const cssm_u128 inc = wave_scan_u128(own, lane);
+    if (lane == 63) s_r[1][wid] = inc;
+    if (threadIdx.x + 1u == tq) s_pre[0] = inc;             // inclusive scan at thread tq - 1, within its wave
+    if (threadIdx.x == tq) s_pre[1] = part;                 // (tq <= 255: qlim < nsub <= 256 E)
+    cssm_u128 tot2 = cssm_u128_zero();
+    // the publisher also totals what it publishes an ESS from: the unit sums of squares when they are at hand ...
+    uint32_t p_pend = 0, p_buf = 0, p_n = 0;
+    cssm_u128 pt2 = cssm_u128_zero();
+    if (pub) {
+      // ... and the squares of the PREVIOUS weighted observation if its ESS is still pending.  Its partials are requested
+      // before the record that says so has arrived (it is on the publisher's critical path, which at N = 2^20 is a round
+      // of its own behind 1024 resident blocks): the other buffer than this launch's, one entry per unit -- what is
+      // pending whenever the previous weighted observation ran this kernel; anything else is read again below.
+      const uint32_t hint_buf = (s2_par >= 0) ? (uint32_t)(s2_par ^ 1) : 0u;
+      {
+        const cssm_u128* hb = s2buf + (size_t)hint_buf * s2_stride;
+        for (uint32_t q = threadIdx.x; q < nunits; q += CSSM_BLOCK) pt2 = cssm_u128_add(pt2, hb[q]);
+      }
+      if (s2_par < 0) {
+        cssm_u128 t2 = cssm_u128_zero();
+        for (uint32_t q = threadIdx.x; q < nsub; q += CSSM_BLOCK) t2 = cssm_u128_add(t2, unitS2[q]);
+        tot2 = block_sum_u128(t2, s_r[2]);
+      }
+      p_pend = sc->pend; p_buf = sc->pend_buf; p_n = sc->pend_n;
+      if (p_pend && (p_buf != hint_buf || p_n != nunits)) {   // (uniform) not what was prefetched
+        pt2 = cssm_u128_zero();
+        const cssm_u128* pb = s2buf + (size_t)p_buf * s2_stride;
+        for (uint32_t q = threadIdx.x; q < p_n; q += CSSM_BLOCK) pt2 = cssm_u128_add(pt2, pb[q]);
+      }
+    }
     __syncthreads();
-    pre = s_r[0][0]; tot = s_r[1][0]; tot2 = s_r[2][0];
+    cssm_u128 tot = s_r[1][0];
 #pragma unroll
-    for (int w = 1; w < CSSM_BLOCK / 64; ++w) {
-      pre = cssm_u128_add(pre, s_r[0][w]); tot = cssm_u128_add(tot, s_r[1][w]); tot2 = cssm_u128_add(tot2, s_r[2][w]);
+    for (int w = 1; w < CSSM_BLOCK / 64; ++w) tot = cssm_u128_add(tot, s_r[1][w]);
+    cssm_u128 pre = (rq > 0u) ? s_pre[1] : cssm_u128_zero();
+    if (tq > 0u) {
+      pre = cssm_u128_add(pre, s_pre[0]);
+      const uint32_t wq = (tq - 1u) >> 6;                   // waves wholly before thread tq - 1's
+#pragma unroll
+      for (int w = 0; w < CSSM_BLOCK / 64 - 1; ++w) if ((uint32_t)w < wq) pre = cssm_u128_add(pre, s_r[1][w]);
     }
     toff_self = pre;
     totd = cssm_u128_to_double(tot);
     if (pub) {
+      cssm_u128 ptot2 = cssm_u128_zero();
+      if (p_pend) ptot2 = block_sum_u128(pt2, s_r[2]);
       if (threadIdx.x == 0) {                              // publish the step's scalars once
-        sc->gmax = gmax_dec; sc->ref = gmax; sc->S_off = cssm_u128_zero(); sc->S_local = tot; sc->S2_local = tot2;
-        sc->S_tot = tot; sc->S2_tot = tot2;
-        finish_step(sc, n_global);
-#ifndef CSSM_OFF_STAMPS
-        if (ll_t) { ll_t[rec_idx] = sc->ll; ess_t[rec_idx] = sc->ess; }
-#endif
+        if (p_pend) {
+          const int32_t pe = cssm_ess_of(sc->pend_S, ptot2);
+          sc->ess = pe;
+          if (ess_t && sc->pend_gen == gen) ess_t[sc->pend_idx] = pe;
+        }
+        sc->gmax = gmax_dec; sc->ref = gmax; sc->S_off = cssm_u128_zero(); sc->S_local = tot; sc->S_tot = tot;
+        if (s2_par < 0) {
+          sc->S2_local = tot2; sc->S2_tot = tot2; sc->pend = 0u;
+          finish_step(sc, n_global);
+          if (ll_t) { ll_t[rec_idx] = sc->ll; ess_t[rec_idx] = sc->ess; }
+        } else {
+          sc->pend = 1u; sc->pend_buf = (uint32_t)s2_par; sc->pend_n = nunits; sc->pend_idx = rec_idx; sc->pend_gen = gen;
+          sc->pend_S = tot;
+          (void)finish_ll(sc, n_global);
+          if (ll_t) ll_t[rec_idx] = sc->ll;
+        }
       }
       if (threadIdx.x < 2 * CSSM_MAXSLOTS)   // the two sets this observation did not use
         sc->maxslot[((size_t)((slot_set + 1 + (int)(threadIdx.x / CSSM_MAXSLOTS)) % CSSM_MAXSETS) * CSSM_MAXSLOTS + threadIdx.x % CSSM_MAXSLOTS) * CSSM_SLOT_STRIDE] = 0ull;
       return;
     }
-    __syncthreads();
   }
-#ifdef CSSM_OFF_STAMPS
-  os2 = wall_clock64();
-#endif
+  cssm_u128 acc2 = cssm_u128_zero();                       // SELF, s2_par >= 0: the thread's sum of squared weights
   if (unit < nunits) do {
     const uint32_t t0 = unit * sup;
     const uint32_t t1 = (t0 + sup < ntiles) ? t0 + sup : ntiles;
@@ -364,12 +415,7 @@ __device__ __forceinline__ void offspring_body(const double* __restrict__ logw, 
       cssm_u128 pre = cssm_u128_zero();
       const uint32_t qlim = unit * (uint32_t)split;
       for (uint32_t q = threadIdx.x; q < qlim; q += CSSM_BLOCK) pre = cssm_u128_add(pre, unitP[q]);
-      pre = wave_sum_u128(pre);
-      if (lane == 0) s_r[0][wid] = pre;
-      __syncthreads();
-      pre = s_r[0][0];
-#pragma unroll
-      for (int w = 1; w < CSSM_BLOCK / 64; ++w) pre = cssm_u128_add(pre, s_r[0][w]);
+      pre = block_sum_u128(pre, s_r[0]);
       toff = cssm_u128_add(S_off, pre);
       __syncthreads();
     } else if (SELF) {
@@ -385,7 +431,12 @@ __device__ __forceinline__ void offspring_body(const double* __restrict__ logw, 
       cssm_u128 q[CSSM_ITEMS];
       cssm_u128 tsum = cssm_u128_zero();
 #pragma unroll
-      for (int r = 0; r < CSSM_ITEMS; ++r) { q[r] = cssm_fix_from_double(w1[r]); tsum = cssm_u128_add(tsum, q[r]); }
+      for (int r = 0; r < CSSM_ITEMS; ++r) {
+        // (raw == 1: arbitrary host doubles, range-checked; else the weight is exp of a clamped non-positive number)
+        q[r] = (raw == 1) ? cssm_fix_from_double(w1[r]) : cssm_fix_from_unit(w1[r]);
+        tsum = cssm_u128_add(tsum, q[r]);
+        if (SELF && s2_par >= 0) acc2 = cssm_u128_add(acc2, cssm_fix_from_unit(w1[r] * w1[r]));
+      }
       cssm_u128 inc = wave_scan_u128(tsum, lane);
       if (lane == 63) s_w[wid] = inc;
       __syncthreads();
@@ -429,9 +480,6 @@ __device__ __forceinline__ void offspring_body(const double* __restrict__ logw, 
           }
         }
       }
-#ifdef CSSM_OFF_STAMPS
-      os3 = wall_clock64();
-#endif
       const uint64_t i0 = base + (uint64_t)threadIdx.x * CSSM_ITEMS;
       constexpr bool CLIP = !SELF;
       if (!FUSE || (CLIP && all5 != nullptr)) {   // the exchange of the sharded filter needs the end slots themselves
@@ -457,7 +505,6 @@ __device__ __forceinline__ void offspring_body(const double* __restrict__ logw, 
                        : (uint32_t)(pow2 ? cssm_sys_count_pow2(Cp, u, n_global, inv_n) : cssm_sys_count(Cp, u, n_global));
           }
         }
-#if CSSM_OFF_LINES
         // the slots this WAVE's 256 particles own: [start of its first particle's run, end of its last particle's run), clipped
         // to this launch's slots; their ancestors are assembled in the wave's LDS region and written as whole lines, with no
         // block barrier (fill_runs_wave)
@@ -468,36 +515,6 @@ __device__ __forceinline__ void offspring_body(const double* __restrict__ logw, 
         wb = (wb > we) ? we : wb;
         fill_runs_wave<CSSM_OFF_SC1 != 0>(prev, e, (uint32_t)i0, wb, we, anc, CLIP ? slot_lo : 0u, (uint32_t)(n - 1),
                                           s_slot + wid * CSSM_WAVE_CHUNK);
-#else
-        // every particle writes its own run of slots (runs longer than CSSM_RUN_DIRECT: the whole block)
-        if (threadIdx.x == 0) s_nheavy = 0;
-        __syncthreads();
-#pragma unroll
-        for (int r = 0; r < CSSM_ITEMS; ++r) {
-          uint32_t b = (r == 0) ? prev : e[r - 1];
-          uint32_t ee = e[r];
-          if (CLIP) {                               // keep the part of the run inside this rank's slots
-            b = (b < slot_lo) ? slot_lo : b;
-            ee = (ee > slot_hi) ? slot_hi : ee;
-            ee = (ee < b) ? b : ee;
-            b -= slot_lo; ee -= slot_lo;
-          }
-          const uint32_t len = ee - b;             // 0 for the padding items of a partial tile
-          const uint32_t jj = (uint32_t)(i0 + r);
-          if (len <= CSSM_RUN_DIRECT) {
-            for (uint32_t s = b; s < ee; ++s) anc[s] = jj;
-          } else {
-            const uint32_t h = atomicAdd(&s_nheavy, 1u);
-            s_slot[3 * h] = b; s_slot[3 * h + 1] = ee; s_slot[3 * h + 2] = jj;
-          }
-        }
-        __syncthreads();
-        const uint32_t nh = s_nheavy;
-        for (uint32_t h = 0; h < nh; ++h) {
-          const uint32_t he = s_slot[3 * h + 1], hj = s_slot[3 * h + 2];
-          for (uint32_t s = s_slot[3 * h] + threadIdx.x; s < he; s += CSSM_BLOCK) anc[s] = hj;
-        }
-#endif
       }
       // advance the running prefix by this tile's total
       cssm_u128 ttot = s_w[0];
@@ -507,13 +524,10 @@ __device__ __forceinline__ void offspring_body(const double* __restrict__ logw, 
       __syncthreads();
     }
   } while (!SELF && (unit += gridDim.x) < nunits);
-#ifdef CSSM_OFF_STAMPS
-  if (SELF && blockIdx.x == 0 && threadIdx.x == 0 && ll_t) {
-    os4 = wall_clock64();
-    auto c3 = [](unsigned long long a) { return (double)(a > 999ull ? 999ull : a); };
-    ll_t[rec_idx] = c3(os1 - os0) + 1e3 * c3(os2 - os1) + 1e6 * c3(os3 - os2) + 1e9 * c3(os4 - os3);
+  if (SELF && s2_par >= 0 && blockIdx.x < nunits) {        // the block's partial sum of squares (its ESS is formed later)
+    const cssm_u128 b2 = block_sum_u128(acc2, s_r[2]);
+    if (threadIdx.x == 0) s2buf[(size_t)s2_par * s2_stride + blockIdx.x] = b2;
   }
-#endif
 }
 
 #define CSSM_OFFSPRING_PARAMS                                                                                              \
@@ -535,14 +549,17 @@ __global__ __launch_bounds__(CSSM_BLOCK, CSSM_OFF_WAVES) void k_offspring(CSSM_O
 // The single-GPU filter's launch: only the arguments that path uses (the generic kernel above carries ~30, most of them the
 // sharded filter's; their scalar registers spilled into vector registers and those into scratch -- 28 bytes per thread,
 // i.e. 7 MB of scratch write-back per launch at N = 2^20, which the PMC counters showed as "wasted" write traffic).
-template <int RS>
+template <int RS, int RAWC>
 __global__ __launch_bounds__(CSSM_BLOCK, CSSM_OFF_WAVES) void k_offspring_self(
     const double* __restrict__ logw, uint64_t n, Scalars* __restrict__ sc, const cssm_u128* __restrict__ unitP,
     const cssm_u128* __restrict__ unitS2, const StepRec* __restrict__ rec, uint32_t* __restrict__ anc, uint32_t ntiles, uint32_t sup,
     uint32_t nunits, int slot_set, double* __restrict__ ll_t, int32_t* __restrict__ ess_t, uint32_t rec_idx, int force_exact, int split,
-    uint64_t seed, double* __restrict__ cum_out, int optimistic) {
-  offspring_body<true, true, RS>(logw, n, sc, unitP, unitS2, rec, n, nullptr, anc, ntiles, sup, nunits, 0, slot_set, ll_t, ess_t, rec_idx,
-                                 force_exact, nullptr, 0, 1, split, seed, cum_out, nullptr, optimistic, nullptr, 0u, (uint32_t)n, 5u);
+    uint64_t seed, double* __restrict__ cum_out, cssm_u128* __restrict__ s2buf, uint32_t s2_stride, int s2_par, uint32_t gen) {
+  // RAWC = 2: behind k_propagate<SUMS> (weights in place of log-weights, sums relative to the reference level: `optimistic`,
+  // the ESS stays pending); 0: behind k_tile_sums (log-weights, both sums at hand)
+  offspring_body<true, true, RS, RAWC>(logw, n, sc, unitP, unitS2, rec, n, nullptr, anc, ntiles, sup, nunits, RAWC, slot_set, ll_t, ess_t, rec_idx,
+                                       force_exact, nullptr, 0, 1, split, seed, cum_out, nullptr, RAWC == 2 ? 1 : 0, nullptr, 0u, (uint32_t)n, 5u,
+                                       s2buf, s2_stride, s2_par, gen);
 }
 
 // Resampling.multinomialResampling (model/Resampling.scala:92-96): slot i draws its own uniform and takes the

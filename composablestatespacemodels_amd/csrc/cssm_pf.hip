@@ -93,6 +93,11 @@ static int alloc_handle(cssm_pf* pf) {
   HIP_TRY(hipMalloc(&pf->tileS, nsums * sizeof(cssm_u128)));
   HIP_TRY(hipMalloc(&pf->tileS2, nsums * sizeof(cssm_u128)));
   HIP_TRY(hipMalloc(&pf->tileP, nsums * sizeof(cssm_u128)));
+  pf->s2_stride = (uint32_t)nsums;
+  HIP_TRY(hipMalloc(&pf->s2buf, 2 * nsums * sizeof(cssm_u128)));
+  HIP_TRY(hipMemsetAsync(pf->s2buf, 0, 2 * nsums * sizeof(cssm_u128), pf->stream));
+  HIP_TRY(hipHostMalloc((void**)&pf->h_s2, nsums * sizeof(cssm_u128), hipHostMallocDefault));
+  HIP_TRY(hipHostMalloc((void**)&pf->h_sc, sizeof(Scalars), hipHostMallocDefault));
   // sub-unit entries past the last k_propagate block are never written and must read as zero sums
   HIP_TRY(hipMemsetAsync(pf->tileS, 0, nsums * sizeof(cssm_u128), pf->stream));
   HIP_TRY(hipMemsetAsync(pf->tileS2, 0, nsums * sizeof(cssm_u128), pf->stream));
@@ -146,11 +151,12 @@ extern "C" void cssm_pf_destroy(cssm_pf* pf) {
   if (!pf) return;
   (void)hipSetDevice(pf->device);
   if (pf->stream) (void)hipStreamSynchronize(pf->stream);
-  void* ptrs[] = {pf->fineS, pf->fineS2, pf->state[0], pf->state[1], pf->logw, pf->endslot, pf->anc, pf->tileS, pf->tileS2, pf->tileP, pf->sc,
+  void* ptrs[] = {pf->s2buf, pf->fineS, pf->fineS2, pf->state[0], pf->state[1], pf->logw, pf->endslot, pf->anc, pf->tileS, pf->tileS2, pf->tileP, pf->sc,
                   pf->d_m0, pf->d_sd0, pf->d_logtab, pf->d_fsub, pf->cum, pf->d_recs, pf->d_ll_t, pf->d_ess_t, pf->d_path, pf->cand, pf->cand_end, pf->cand_idx, pf->d_bounds, pf->d_xch, pf->d_need};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   if (pf->h_recs) (void)hipHostFree(pf->h_recs);
   if (pf->h_sc) (void)hipHostFree(pf->h_sc);
+  if (pf->h_s2) (void)hipHostFree(pf->h_s2);
   for (hipEvent_t e : pf->prof_ev) (void)hipEventDestroy(e);
   if (pf->ev0) (void)hipEventDestroy(pf->ev0);
   if (pf->ev1) (void)hipEventDestroy(pf->ev1);
@@ -199,6 +205,8 @@ int cssm_launch_init(cssm_pf* pf, double t0) {
   if (rc) return rc;
   pf->cur = 0; pf->src = pf->state[0]; pf->src_stride = pf->stride; pf->anc_valid = false;
   pf->t = t0; pf->step = 0; pf->initialised = true; pf->wparity = 0;
+  pf->wmode = false; pf->pend_host = false; pf->sums_ready = false;   // (reset_scalars cleared Scalars::pend)
+  pf->ess_host = (int32_t)(pf->n_global < 2147483647ull ? pf->n_global : 2147483647ull);
   return CSSM_OK;
 }
 
@@ -262,6 +270,7 @@ int cssm_launch_propagate(cssm_pf* pf, const StepRec* d_rec, double* pick_out, u
   PropLaunch a;
   a.grid = grid; a.stream = pf->stream;
   a.lgcp = pf->obs_kind == CSSM_OBS_LGCP;
+  a.sharded = pf->sharded ? 1 : 0;
   a.obs = (pf->obs_kind == CSSM_OBS_POISSON || pf->obs_kind == CSSM_OBS_GAUSSIAN) ? pf->obs_kind : -1;
   a.sums = do_sums;
   a.src = pf->src; a.src_stride = pf->src_stride; a.anc = anc; a.dst = dst; a.dst_stride = pf->stride; a.logw = pf->logw;
@@ -288,8 +297,8 @@ int cssm_launch_propagate(cssm_pf* pf, const StepRec* d_rec, double* pick_out, u
   if (fine) {   // the blocks' sums -> the units' (the kernel itself skips unweighted observations and series on hold)
     prof_begin(pf, CSSM_K_REDUCE);
     hipLaunchKernelGGL(k_reduce_units, dim3((pf->nunits + CSSM_BLOCK / 64 - 1) / (CSSM_BLOCK / 64)), dim3(CSSM_BLOCK), 0, pf->stream,
-                       (const cssm_u128*)pf->fineS, (const cssm_u128*)pf->fineS2, (uint32_t)grid, (uint32_t)(unit_particles / chunk), pf->nunits,
-                       pf->tileS, pf->tileS2, (const Scalars*)pf->sc, d_rec);
+                       (const cssm_u128*)pf->fineS, (const cssm_u128*)nullptr, (uint32_t)grid, (uint32_t)(unit_particles / chunk), pf->nunits,
+                       pf->tileS, pf->tileS2, (const Scalars*)pf->sc, d_rec);   // (single GPU: the squares are k_offspring's)
     prof_end(pf);
   }
   HIP_TRY(hipGetLastError());
@@ -298,15 +307,14 @@ int cssm_launch_propagate(cssm_pf* pf, const StepRec* d_rec, double* pick_out, u
   return CSSM_OK;
 }
 
-// sums (unless k_propagate formed them) -> end slots -> ancestors, single GPU.  `redo`: second attempt at the step
-// whose reference level the max ruled out -- same max-slot set, sums formed by k_tile_sums with the agreed level.
-static int launch_resample(cssm_pf* pf, const StepRec* d_rec, double* ll_t = nullptr, int32_t* ess_t = nullptr, uint32_t rec_idx = 0,
-                           bool redo = false) {
+// sums (unless k_propagate formed them) -> end slots -> ancestors, single GPU.  After a k_propagate<SUMS> the buffer holds the
+// weights themselves (raw = 2) and k_offspring forms the sum of squares on the way: that observation's ESS stays pending until
+// the next weighted observation's publisher block, or the host at the end of the call, totals the blocks' partials.
+static int launch_resample(cssm_pf* pf, const StepRec* d_rec, double* ll_t = nullptr, int32_t* ess_t = nullptr, uint32_t rec_idx = 0) {
   if (pf->resampler == CSSM_RESAMPLE_MULTINOMIAL && !pf->cum) {
     if (hipMalloc(&pf->cum, pf->stride * 8) != hipSuccess) return fail(CSSM_ENOMEM, "hipMalloc cumulative weights");
   }
-  if (redo) pf->wparity = (pf->wparity + CSSM_MAXSETS - 1) % CSSM_MAXSETS;
-  const bool optimistic = pf->last_optimistic && !redo;
+  const bool optimistic = pf->last_optimistic;
   const int tgrid = (int)pf->nunits;
   const int split = optimistic ? (int)pf->split : 1;
   if (!optimistic) {
@@ -315,15 +323,16 @@ static int launch_resample(cssm_pf* pf, const StepRec* d_rec, double* ll_t = nul
                        pf->sup, pf->nunits, 0, pf->wparity, (const double*)nullptr, pf->d_logtab, d_rec, 0u);
     prof_end(pf);
   }
-  prof_begin(pf, CSSM_K_OFFSPRING);   // unit prefix, ll/ess, end slots and their expansion to ancestors in one kernel (one block per unit + the publisher)
+  const int s2_par = optimistic ? pf->s2_par : -1;
+  prof_begin(pf, CSSM_K_OFFSPRING);   // unit prefix, ll (ess), end slots and their expansion to ancestors in one kernel (one block per unit + the publisher)
 #define OFF_ARGS pf->logw, pf->n, pf->sc, (const cssm_u128*)pf->tileS, (const cssm_u128*)pf->tileS2, d_rec, pf->anc, pf->ntiles, pf->sup, pf->nunits, \
-                 pf->wparity, ll_t, ess_t, rec_idx, pf->opt_exact, split, pf->seed, pf->cum, optimistic ? (pf->batch_hold ? 3 : 1) : 0
-  if (pf->resampler == CSSM_RESAMPLE_STRATIFIED)
-    hipLaunchKernelGGL((k_offspring_self<CSSM_RESAMPLE_STRATIFIED>), dim3(tgrid + 1), dim3(CSSM_BLOCK), 0, pf->stream, OFF_ARGS);
-  else if (pf->resampler == CSSM_RESAMPLE_MULTINOMIAL)
-    hipLaunchKernelGGL((k_offspring_self<CSSM_RESAMPLE_MULTINOMIAL>), dim3(tgrid + 1), dim3(CSSM_BLOCK), 0, pf->stream, OFF_ARGS);
-  else
-    hipLaunchKernelGGL((k_offspring_self<CSSM_RESAMPLE_SYSTEMATIC>), dim3(tgrid + 1), dim3(CSSM_BLOCK), 0, pf->stream, OFF_ARGS);
+                 pf->wparity, ll_t, ess_t, rec_idx, pf->opt_exact, split, pf->seed, pf->cum, pf->s2buf, pf->s2_stride, s2_par, pf->gen
+#define OFF_GO(RS) do { if (optimistic) hipLaunchKernelGGL((k_offspring_self<RS, 2>), dim3(tgrid + 1), dim3(CSSM_BLOCK), 0, pf->stream, OFF_ARGS); \
+                        else hipLaunchKernelGGL((k_offspring_self<RS, 0>), dim3(tgrid + 1), dim3(CSSM_BLOCK), 0, pf->stream, OFF_ARGS); } while (0)
+  if (pf->resampler == CSSM_RESAMPLE_STRATIFIED) OFF_GO(CSSM_RESAMPLE_STRATIFIED);
+  else if (pf->resampler == CSSM_RESAMPLE_MULTINOMIAL) OFF_GO(CSSM_RESAMPLE_MULTINOMIAL);
+  else OFF_GO(CSSM_RESAMPLE_SYSTEMATIC);
+#undef OFF_GO
 #undef OFF_ARGS
   if (pf->resampler == CSSM_RESAMPLE_MULTINOMIAL)
     hipLaunchKernelGGL(k_multinomial, dim3(grid_for(pf->n, 256, kGridCap)), dim3(256), 0, pf->stream, pf->cum, pf->n, pf->seed,
@@ -332,6 +341,9 @@ static int launch_resample(cssm_pf* pf, const StepRec* d_rec, double* ll_t = nul
   pf->wparity = (pf->wparity + 1) % CSSM_MAXSETS;
   HIP_TRY(hipGetLastError());
   pf->anc_valid = true;
+  pf->wmode = optimistic;
+  pf->pend_host = optimistic;
+  if (optimistic) { pf->pend_par_host = s2_par; pf->s2_par ^= 1; }
   return CSSM_OK;
 }
 static int launch_step(cssm_pf* pf, const StepRec* d_rec, int weighted, uint32_t step_index, double* ll_t = nullptr, int32_t* ess_t = nullptr,
@@ -350,6 +362,45 @@ int cssm_check_device_err(cssm_pf* pf, const Scalars& h) {
   (void)pf;
   return CSSM_OK;
 }
+// The handle's scalars -> *pf->h_sc (pinned), one synchronisation.  If the last enqueued weighted observation left its ESS
+// pending, the partial sums of squares of its blocks travel in the same round trip and the host totals them: the value of
+// cssm_ess_of is the one the next publisher block would compute (IEEE operations on exact integer sums).
+static int read_scalars(cssm_pf* pf) {
+  Scalars& h = *pf->h_sc;
+  HIP_TRY(hipMemcpyAsync(CSSM_SC_TAIL_ARGS(&h, pf->sc), hipMemcpyDeviceToHost, pf->stream));
+  const uint32_t n_host = pf->nunits;
+  if (pf->pend_host)
+    HIP_TRY(hipMemcpyAsync(pf->h_s2, pf->s2buf + (size_t)pf->pend_par_host * pf->s2_stride, (size_t)n_host * sizeof(cssm_u128), hipMemcpyDeviceToHost, pf->stream));
+  HIP_TRY(hipStreamSynchronize(pf->stream));
+  if (h.pend) {
+    if (h.pend_n > pf->s2_stride || h.pend_buf > 1u) return fail(CSSM_ESTATE, "pending ESS record is corrupt (n = %u, buffer = %u)", h.pend_n, h.pend_buf);
+    if (!pf->pend_host || (int)h.pend_buf != pf->pend_par_host || h.pend_n != n_host) {   // (a series that ended on hold: the pending observation is an earlier one)
+      HIP_TRY(hipMemcpyAsync(pf->h_s2, pf->s2buf + (size_t)h.pend_buf * pf->s2_stride, (size_t)h.pend_n * sizeof(cssm_u128), hipMemcpyDeviceToHost, pf->stream));
+      HIP_TRY(hipStreamSynchronize(pf->stream));
+    }
+    cssm_u128 t2 = cssm_u128_zero();
+    for (uint32_t q = 0; q < h.pend_n; ++q) t2 = cssm_u128_add(t2, pf->h_s2[q]);
+    if (!(h.err & 3u) && !cssm_u128_is_zero(h.pend_S)) h.ess = cssm_ess_of(h.pend_S, t2);
+  }
+  pf->ess_host = h.ess;
+  return CSSM_OK;
+}
+
+// Host-side state of a single-GPU handle right before a propagate: what redoing that observation starts from.
+struct PreState { int cur; const double* src; size_t src_stride; bool anc_valid; int wparity; };
+static inline PreState pre_state(const cssm_pf* pf) { return {pf->cur, pf->src, pf->src_stride, pf->anc_valid, pf->wparity}; }
+// An observation whose reference level the max ruled out (err bit 6: k_offspring put the series on hold AT it; its propagate
+// is done, the cloud it read and the previous ancestors are untouched) is done AGAIN: the same propagate with log-weights
+// stored (the weights relative to the level it first assumed are useless), sums relative to the max (k_tile_sums), resampling.
+static int redo_observation(cssm_pf* pf, const PreState& q, const StepRec* d_rec, double* ll_t, int32_t* ess_t, uint32_t rec_idx) {
+  pf->cur = q.cur; pf->src = q.src; pf->src_stride = q.src_stride; pf->src2 = nullptr; pf->anc_valid = q.anc_valid; pf->wparity = q.wparity;
+  pf->safe_sums = true;
+  int rc = cssm_launch_propagate(pf, d_rec, nullptr, 0);
+  pf->safe_sums = false;
+  if (rc) return rc;
+  return launch_resample(pf, d_rec, ll_t, ess_t, rec_idx);
+}
+
 // ------------------------------------------------------------------------------------ streaming API
 
 int cssm_ensure_recs(cssm_pf* pf, size_t T) {
@@ -409,18 +460,21 @@ extern "C" int cssm_pf_step(cssm_pf* pf, double t, double obs, int has_obs, doub
   if (rc) return rc;
   HIP_TRY(hipMemcpyAsync(pf->d_recs, pf->h_recs, sizeof(StepRec), hipMemcpyHostToDevice, pf->stream));
   const int weighted = pf->h_recs[0].has_obs;
+  const PreState before = pre_state(pf);
+  pf->gen++;
   rc = launch_step(pf, pf->d_recs, weighted, pf->step);
   if (rc) return rc;
-  if (!pf->h_sc) HIP_TRY(hipHostMalloc((void**)&pf->h_sc, sizeof(Scalars), hipHostMallocDefault));
   Scalars& h = *pf->h_sc;
-  HIP_TRY(hipMemcpyAsync(CSSM_SC_TAIL_ARGS(&h, pf->sc), hipMemcpyDeviceToHost, pf->stream));
-  HIP_TRY(hipStreamSynchronize(pf->stream));
-  if (h.err == 4u) {   // the max ruled the reference level out: the log-weights are in place, form the sums again
-    HIP_TRY(hipMemsetAsync(&pf->sc->err, 0, sizeof(uint32_t), pf->stream));
-    rc = launch_resample(pf, pf->d_recs, nullptr, nullptr, 0, /*redo=*/true);
+  rc = read_scalars(pf);
+  if (rc) return rc;
+  if ((h.err & 64u) && !(h.err & 3u)) {   // the max ruled the reference level out: this observation again, relative to the max
+    const uint32_t cleared = h.err & ~64u, none = 0xffffffffu;
+    HIP_TRY(hipMemcpyAsync(&pf->sc->err, &cleared, sizeof(uint32_t), hipMemcpyHostToDevice, pf->stream));
+    HIP_TRY(hipMemcpyAsync(&pf->sc->fail_step, &none, sizeof(uint32_t), hipMemcpyHostToDevice, pf->stream));
+    rc = redo_observation(pf, before, pf->d_recs, nullptr, nullptr, 0);
     if (rc) return rc;
-    HIP_TRY(hipMemcpyAsync(CSSM_SC_TAIL_ARGS(&h, pf->sc), hipMemcpyDeviceToHost, pf->stream));
-    HIP_TRY(hipStreamSynchronize(pf->stream));
+    rc = read_scalars(pf);
+    if (rc) return rc;
   }
   pf->t = t; pf->step++;
   if (ll_out) *ll_out = h.ll;
@@ -443,8 +497,11 @@ extern "C" int cssm_pf_propagate(cssm_pf* pf, double t, double obs, int has_obs)
   rc = cssm_build_fsub(pf, 0, 1, true);
   if (rc) return rc;
   HIP_TRY(hipMemcpyAsync(pf->d_recs, pf->h_recs, sizeof(StepRec), hipMemcpyHostToDevice, pf->stream));
+  pf->safe_sums = true;        // the host resampler wants the log-weights themselves (:123): the kernel that stores them
   rc = cssm_launch_propagate(pf, pf->d_recs);
+  pf->safe_sums = false;
   if (rc) return rc;
+  pf->wmode = false;
   // nobody decodes this step's running max on the device: clear both slot sets for the next weighted step
   HIP_TRY(hipMemsetAsync(pf->sc->maxslot, 0, sizeof(pf->sc->maxslot), pf->stream));
   Scalars h;
@@ -464,6 +521,9 @@ extern "C" int cssm_pf_adopt(cssm_pf* pf, const double* state_dN, double ll, int
   HIP_TRY(hipMemcpy2DAsync(pf->state[pf->cur], pf->stride * 8, state_dN, pf->n * 8, pf->n * 8, pf->d, hipMemcpyHostToDevice, pf->stream));
   HIP_TRY(hipMemcpyAsync(&pf->sc->ll, &ll, sizeof(double), hipMemcpyHostToDevice, pf->stream));
   HIP_TRY(hipMemcpyAsync(&pf->sc->ess, &ess, sizeof(int32_t), hipMemcpyHostToDevice, pf->stream));
+  const uint32_t no_pend = 0u;   // (an ESS still pending from an earlier native step is superseded by the caller's)
+  HIP_TRY(hipMemcpyAsync(&pf->sc->pend, &no_pend, sizeof(uint32_t), hipMemcpyHostToDevice, pf->stream));
+  pf->pend_host = false; pf->ess_host = ess;
   HIP_TRY(hipStreamSynchronize(pf->stream));
   pf->src = pf->state[pf->cur]; pf->src_stride = pf->stride; pf->src2 = nullptr; pf->anc_valid = false;
   return CSSM_OK;
@@ -515,6 +575,9 @@ static int run_filter_once(cssm_pf* pf, const double* t, const double* y, const 
   }
   // host-side state at the first observation of this call (launch_init: cur = 0, wparity = 0)
   const int cur0 = pf->cur, wpar0 = pf->wparity;
+  const bool anc_valid0 = pf->anc_valid;
+  const int32_t ess0 = pf->ess_host;      // what an unweighted first observation reports (ll and ess unchanged, :121)
+  pf->gen++;
   const int d = pf->d;
   if (path) {
     if (pf->path_cap < (T + 1) * (size_t)d) {
@@ -535,11 +598,11 @@ static int run_filter_once(cssm_pf* pf, const double* t, const double* y, const 
   const bool fold = path && uses_sums_kernel(pf);
   // Per-observation kernels, enqueued without a host round trip.  With the sums formed inside k_propagate (relative to each
   // observation's reference level), an observation whose max rules its level out puts the series ON HOLD at that
-  // observation (err bit 6: every kernel behind it returns at once); the host then redoes that one observation's sums
-  // relative to the max (k_tile_sums + k_offspring, the log-weights are in place) and enqueues the rest again.
+  // observation (err bit 6: every kernel behind it returns at once); the host then redoes that one observation (its
+  // propagate again, storing log-weights; sums relative to the max: k_tile_sums + k_offspring) and enqueues the rest again.
   size_t s_from = 0;
   for (;;) {
-    pf->batch_hold = uses_sums_kernel(pf);
+    const bool may_hold = uses_sums_kernel(pf);
     for (size_t s = s_from; s < T; ++s) {
       const int weighted = pf->h_recs[s].has_obs;
       double* pick_out = (fold && s >= 1) ? pf->d_path + s * (size_t)d : nullptr;
@@ -550,51 +613,51 @@ static int run_filter_once(cssm_pf* pf, const double* t, const double* y, const 
         if (weighted) rc = launch_resample(pf, pf->d_recs + s, pf->d_ll_t, pf->d_ess_t, (uint32_t)s);
         else hipLaunchKernelGGL(k_record, dim3(1), dim3(1), 0, pf->stream, pf->sc, pf->d_ll_t, pf->d_ess_t, (uint32_t)s);
       }
-      if (rc) { pf->batch_hold = false; return rc; }
+      if (rc) return rc;
       if (path && (!fold || s + 1 == T))   // (folded: only the last entry has no following propagate)
         hipLaunchKernelGGL(k_pick, dim3(1), dim3(64), 0, pf->stream, pf->src, pf->src_stride,
                            (const uint32_t*)(pf->anc_valid ? pf->anc : nullptr), (uint64_t)pf->h_recs[s].pick, d,
                            pf->d_path + (s + 1) * (size_t)d);
     }
-    const bool may_hold = pf->batch_hold;
-    pf->batch_hold = false;
-    if (!may_hold) break;
-    Scalars hh;
-    HIP_TRY(hipMemcpyAsync(CSSM_SC_TAIL_ARGS(&hh, pf->sc), hipMemcpyDeviceToHost, pf->stream));
-    HIP_TRY(hipStreamSynchronize(pf->stream));
-    if (!(hh.err & 64u)) break;
-    if (hh.err & 3u) break;            // NaN / unusable weights: reported below
+    // the call's ONE synchronisation when no observation was held: results and scalars travel together
+    HIP_TRY(hipEventRecord(pf->ev1, pf->stream));
+    HIP_TRY(hipGetLastError());
+    if (ll_t) HIP_TRY(hipMemcpyAsync(ll_t, pf->d_ll_t, T * 8, hipMemcpyDeviceToHost, pf->stream));
+    if (ess_t) HIP_TRY(hipMemcpyAsync(ess_t, pf->d_ess_t, T * 4, hipMemcpyDeviceToHost, pf->stream));
+    if (path) HIP_TRY(hipMemcpyAsync(path, pf->d_path, (T + 1) * (size_t)d * 8, hipMemcpyDeviceToHost, pf->stream));
+    rc = read_scalars(pf);       // (totals a pending ESS on the host)
+    if (rc) return rc;
+    const Scalars& hh = *pf->h_sc;
+    if (!may_hold || !(hh.err & 64u) || (hh.err & 3u)) break;   // (NaN / unusable weights: reported below)
     const size_t sf = (size_t)hh.fail_step - base;              // (the record's index in this call)
     if (hh.fail_step < base || sf >= T) return fail(CSSM_ESTATE, "held series reports observation %u; this call holds %u .. %zu", hh.fail_step, base, base + T - 1);
-    hh.err &= ~64u; hh.fail_step = 0xffffffffu;
-    HIP_TRY(hipMemcpyAsync(&pf->sc->err, &hh.err, sizeof(uint32_t), hipMemcpyHostToDevice, pf->stream));
-    HIP_TRY(hipMemcpyAsync(&pf->sc->fail_step, &hh.fail_step, sizeof(uint32_t), hipMemcpyHostToDevice, pf->stream));
-    // host-side state right after the propagate of observation sf (every propagate flips cur, every weighted observation
-    // advances wparity)
-    pf->cur = (int)(((size_t)cur0 + sf + 1) & 1);
-    pf->src = pf->state[pf->cur]; pf->src_stride = pf->stride; pf->anc_valid = false; pf->src2 = nullptr;
+    const uint32_t cleared = hh.err & ~64u, none = 0xffffffffu;
+    HIP_TRY(hipMemcpyAsync(&pf->sc->err, &cleared, sizeof(uint32_t), hipMemcpyHostToDevice, pf->stream));
+    HIP_TRY(hipMemcpyAsync(&pf->sc->fail_step, &none, sizeof(uint32_t), hipMemcpyHostToDevice, pf->stream));
+    // host-side state right BEFORE the propagate of observation sf (every propagate flips cur, every weighted observation
+    // advances the max-slot set; the ancestors are those of the observation before it, if that one resampled)
+    PreState before;
+    before.cur = (int)(((size_t)cur0 + sf) & 1);
+    before.src = pf->state[before.cur]; before.src_stride = pf->stride;
+    before.anc_valid = sf == 0 ? anc_valid0 : (pf->h_recs[sf - 1].has_obs != 0);
     int wp = wpar0;
     for (size_t q = 0; q < sf; ++q) wp = (wp + (pf->h_recs[q].has_obs ? 1 : 0)) % CSSM_MAXSETS;
-    pf->wparity = (wp + 1) % CSSM_MAXSETS;   // launch_resample(redo) steps it back to the set the observation's propagate used
-    pf->last_optimistic = true;
+    before.wparity = wp;
     pf->h_step_for_resample = base + (uint32_t)sf;
-    rc = launch_resample(pf, pf->d_recs + sf, pf->d_ll_t, pf->d_ess_t, (uint32_t)sf, /*redo=*/true);
+    rc = redo_observation(pf, before, pf->d_recs + sf, pf->d_ll_t, pf->d_ess_t, (uint32_t)sf);
     if (rc) return rc;
     if (path && (!fold || sf + 1 == T))
       hipLaunchKernelGGL(k_pick, dim3(1), dim3(64), 0, pf->stream, pf->src, pf->src_stride, (const uint32_t*)pf->anc,
                          (uint64_t)pf->h_recs[sf].pick, d, pf->d_path + (sf + 1) * (size_t)d);
-    s_from = sf + 1;
-    if (s_from >= T) break;
+    s_from = sf + 1;             // (s_from == T: the loop only reads the results again)
   }
-  HIP_TRY(hipEventRecord(pf->ev1, pf->stream));
-  HIP_TRY(hipGetLastError());
-  if (!pf->h_sc) HIP_TRY(hipHostMalloc((void**)&pf->h_sc, sizeof(Scalars), hipHostMallocDefault));
   Scalars& h = *pf->h_sc;
-  HIP_TRY(hipMemcpyAsync(CSSM_SC_TAIL_ARGS(&h, pf->sc), hipMemcpyDeviceToHost, pf->stream));
-  if (ll_t) HIP_TRY(hipMemcpyAsync(ll_t, pf->d_ll_t, T * 8, hipMemcpyDeviceToHost, pf->stream));
-  if (ess_t) HIP_TRY(hipMemcpyAsync(ess_t, pf->d_ess_t, T * 4, hipMemcpyDeviceToHost, pf->stream));
-  if (path) HIP_TRY(hipMemcpyAsync(path, pf->d_path, (T + 1) * (size_t)d * 8, hipMemcpyDeviceToHost, pf->stream));
-  HIP_TRY(hipStreamSynchronize(pf->stream));
+  if (ess_t) {
+    // the last weighted observation's ESS was still pending when the series ended (nobody after it to total its squares) ...
+    if (h.pend && h.pend_gen == pf->gen && h.pend_idx < T) ess_t[h.pend_idx] = h.ess;
+    // ... and an observation without a datum reports the ESS before it (:121), which a kernel could not know yet
+    for (size_t s = 0; s < T; ++s) if (!pf->h_recs[s].has_obs) ess_t[s] = s ? ess_t[s - 1] : ess0;
+  }
   HIP_TRY(hipEventElapsedTime(&pf->last_ms, pf->ev0, pf->ev1));
   prof_collect(pf);
   pf->t = t[T - 1]; pf->step = base + (uint32_t)T;
@@ -795,8 +858,22 @@ extern "C" int cssm_pf_get_ancestors(cssm_pf* pf, uint32_t* out) {
   return CSSM_OK;
 }
 
+extern "C" int cssm_pf_get_weights(cssm_pf* pf, double* out, double* level_out) {
+  if (!pf || !out) return fail(CSSM_EINVAL_ARG, "null argument");
+  if (!pf->wmode) return fail(CSSM_ESTATE, "the last weighted step kept log-weights (cssm_pf_get_logw), not weights");
+  HIP_TRY(hipSetDevice(pf->device));
+  Scalars h;
+  HIP_TRY(hipMemcpyAsync(out, pf->logw, pf->n * 8, hipMemcpyDeviceToHost, pf->stream));
+  HIP_TRY(hipMemcpyAsync(CSSM_SC_TAIL_ARGS(&h, pf->sc), hipMemcpyDeviceToHost, pf->stream));
+  HIP_TRY(hipStreamSynchronize(pf->stream));
+  if (level_out) *level_out = h.ref;
+  return CSSM_OK;
+}
+
 extern "C" int cssm_pf_get_logw(cssm_pf* pf, double* out) {
   if (!pf || !out) return fail(CSSM_EINVAL_ARG, "null argument");
+  if (pf->wmode) return fail(CSSM_ESTATE, "the fused kernel keeps the weights exp(w - c) in place of the log-weights (cssm_pf_get_weights); "
+                                          "CSSM_OPT_FUSED_SUMS = 0 keeps log-weights");
   HIP_TRY(hipSetDevice(pf->device));
   HIP_TRY(hipMemcpyAsync(out, pf->logw, pf->n * 8, hipMemcpyDeviceToHost, pf->stream));
   HIP_TRY(hipStreamSynchronize(pf->stream));
@@ -951,7 +1028,7 @@ extern "C" int cssm_pf_interpolate(cssm_pf* pf, const double* t, const double* y
     }
     if (!rc && hipMemcpyAsync(CSSM_SC_TAIL_ARGS(&h, pf->sc), hipMemcpyDeviceToHost, pf->stream) != hipSuccess) rc = fail(CSSM_EHIP, "scalars");
     if (!rc && hipStreamSynchronize(pf->stream) != hipSuccess) rc = fail(CSSM_EHIP, "forward pass");
-    if (rc || !(h.err & 4u) || (h.err & 1u)) break;
+    if (rc || !(h.err & 64u) || (h.err & 3u)) break;   // (bit 6: some observation's level was ruled out -- again, sums in their own pass)
   }
   pf->safe_sums = false;
   if (!rc) rc = cssm_check_device_err(pf, h);

@@ -17,7 +17,7 @@
 template <int D, int IT> struct OneTile {
   static void go(const PropLaunch& a) {
 #define PROP_ONE(OB, ONEV)                                                                                                        \
-  k_propagate_self<D, IT, OB, true, ONEV><<<dim3(a.grid), dim3(CSSM_BLOCK), 0, a.stream>>>(a.src, a.src_stride, a.anc, a.dst, a.dst_stride, \
+  k_propagate_self<D, IT, OB, 1, ONEV><<<dim3(a.grid), dim3(CSSM_BLOCK), 0, a.stream>>>(a.src, a.src_stride, a.anc, a.dst, a.dst_stride, \
       a.logw, a.n, a.seed, a.rec, a.mk, a.sc, a.slot_set, a.logtab, a.chunk, a.subS, a.subS2, a.pick_out, a.pick_slot)
     if (a.one == 1) {          // the block's range is one tile
       if (a.obs == CSSM_OBS_POISSON) PROP_ONE(CSSM_OBS_POISSON, 1);
@@ -40,7 +40,7 @@ void CSSM_CAT(cssm_prop_launch_d, CSSM_PROP_D)(const PropLaunch& a) {
       a.src, a.src_stride, a.anc, a.dst, a.dst_stride, a.logw, a.n, a.gid0, a.seed, a.rec, a.mk, a.sc, a.slot_set, a.src2, \
       a.src2_stride, a.n_split, a.logtab, a.chunk, a.do_sums, a.subS, a.subS2, a.pick_out, a.pick_slot, a.fsub)
   // the single-GPU lean launch: nothing of the sharded filter, no fused sums, no pick, first global id 0
-  const bool self = !a.lgcp && a.src2 == nullptr && a.gid0 == 0 && a.fsub == nullptr && (a.sums || a.pick_out == nullptr) && (!a.sums || a.do_sums);
+  const bool self = (!a.sharded || !a.sums) && !a.lgcp && a.src2 == nullptr && a.gid0 == 0 && a.fsub == nullptr && (a.sums || a.pick_out == nullptr) && (!a.sums || a.do_sums);
 #define PROP_SELF(OB, SM)                                                                                                   \
   k_propagate_self<D, IT, OB, SM><<<dim3(a.grid), dim3(CSSM_BLOCK), 0, a.stream>>>(a.src, a.src_stride, a.anc, a.dst, a.dst_stride, \
       a.logw, a.n, a.seed, a.rec, a.mk, a.sc, a.slot_set, a.logtab, a.chunk, a.subS, a.subS2, a.pick_out, a.pick_slot)
@@ -48,9 +48,9 @@ void CSSM_CAT(cssm_prop_launch_d, CSSM_PROP_D)(const PropLaunch& a) {
   if (self && CSSM_PROP_SELF && a.sums && a.one) {
     OneTile<D, IT>::go(a);
   } else if (self && CSSM_PROP_SELF) {
-    if (a.obs == CSSM_OBS_POISSON) { if (a.sums) PROP_SELF(CSSM_OBS_POISSON, true); else PROP_SELF(CSSM_OBS_POISSON, false); }
-    else if (a.obs == CSSM_OBS_GAUSSIAN) { if (a.sums) PROP_SELF(CSSM_OBS_GAUSSIAN, true); else PROP_SELF(CSSM_OBS_GAUSSIAN, false); }
-    else { if (a.sums) PROP_SELF(-1, true); else PROP_SELF(-1, false); }
+    if (a.obs == CSSM_OBS_POISSON) { if (a.sums) PROP_SELF(CSSM_OBS_POISSON, 1); else PROP_SELF(CSSM_OBS_POISSON, 0); }
+    else if (a.obs == CSSM_OBS_GAUSSIAN) { if (a.sums) PROP_SELF(CSSM_OBS_GAUSSIAN, 1); else PROP_SELF(CSSM_OBS_GAUSSIAN, 0); }
+    else { if (a.sums) PROP_SELF(-1, 1); else PROP_SELF(-1, 0); }
   } else if (!a.lgcp && CSSM_PROP_SELF && a.sums && a.do_sums && a.shard_slim) {
     // the sharded filter (single-collective exchange): the slim launch; tile after tile while a unit has few tiles
 #define PROP_SHARD(OB, ONEV)                                                                                               \
@@ -63,13 +63,13 @@ void CSSM_CAT(cssm_prop_launch_d, CSSM_PROP_D)(const PropLaunch& a) {
     }
 #undef PROP_SHARD
   } else if (a.lgcp) {
-    PROP_GO(true, -1, false);
-  } else if (a.obs == CSSM_OBS_POISSON) {
-    if (a.sums) PROP_GO(false, CSSM_OBS_POISSON, true); else PROP_GO(false, CSSM_OBS_POISSON, false);
+    PROP_GO(true, -1, 0);
+  } else if (a.obs == CSSM_OBS_POISSON) {   // (the generic kernel with sums serves sharded handles only: both sums, SUMS = 2)
+    if (a.sums) PROP_GO(false, CSSM_OBS_POISSON, 2); else PROP_GO(false, CSSM_OBS_POISSON, 0);
   } else if (a.obs == CSSM_OBS_GAUSSIAN) {
-    if (a.sums) PROP_GO(false, CSSM_OBS_GAUSSIAN, true); else PROP_GO(false, CSSM_OBS_GAUSSIAN, false);
+    if (a.sums) PROP_GO(false, CSSM_OBS_GAUSSIAN, 2); else PROP_GO(false, CSSM_OBS_GAUSSIAN, 0);
   } else {
-    if (a.sums) PROP_GO(false, -1, true); else PROP_GO(false, -1, false);
+    if (a.sums) PROP_GO(false, -1, 2); else PROP_GO(false, -1, 0);
   }
 #undef PROP_GO
 #undef PROP_SELF

@@ -32,7 +32,7 @@ template <int D> struct PropItems { static constexpr int value = (D <= 2) ? CSSM
 // (the kernels that also form the sums need ~10 more VGPRs; at 4 waves they spill 12 bytes, and a scratch reload in the
 // compute phase waits for the prefetch like any other vector-memory operation -- measured all the same: 4 waves with
 // that spill 41.2 us/step at N = 2^20 and 375 us at 2^24, 3 waves without it 41.9 and 383)
-template <int D, bool SUMS = false> struct PropWaves { static constexpr int value = (D <= 4) ? (SUMS ? CSSM_PROP_WAVES_SUMS : CSSM_PROP_WAVES_LO) : 3; };
+template <int D, int SUMS = 0> struct PropWaves { static constexpr int value = (D <= 4) ? (SUMS ? CSSM_PROP_WAVES_SUMS : CSSM_PROP_WAVES_LO) : 3; };
 
 // LDS staging area of propagate_range: per wave IT * D regions of 64 lanes x ES bytes (ES = 16: one dwordx4 fetch per lane and
 // element, of which the first 8 bytes are the element, while 4 blocks of that fit the CU's 160 KiB; else 8: two dword fetches).
@@ -44,19 +44,26 @@ template <int D, int IT> struct PropStage {
 
 // Thread-local results of propagate_range, reduced over the block by its caller.
 struct PropAcc {
-  cssm_u128 S, S2;   // fixed-point sums of exp(w - c), exp(w - c)^2 over the thread's particles (SUMS)
+  cssm_u128 S, S2;   // fixed-point sums of exp(w - c) (SUMS >= 1) and of exp(w - c)^2 (SUMS == 2) over the thread's particles
   double tmax;       // largest log-weight seen
   bool bad;          // a log-weight was NaN
 };
 
 // The body of every k_propagate launch: the block's particles [range_lo, n) of one observation.
+// SUMS: what the kernel does with a weighted particle's log-weight w --
+//   0  stores w (LGCP, whose level is the max; the multinomial resampler; an observation that is redone: the sums are then
+//      a pass of their own, k_tile_sums);
+//   1  forms w1 = exp(min(w - c, 2^-20)) relative to the observation's reference level c, adds it to the block's fixed-point
+//      sum S and stores W1 IN PLACE OF w (same 8 bytes): k_offspring then needs no exp, only the conversion the sum was
+//      formed with.  Sum of squares: k_offspring's business (nothing on the device depends on the ESS).  Single GPU;
+//   2  the same, and also S2 = sum w1^2 (the sharded exchange ships both sums in its segment headers).
 // `tab`: the contract's log table, staged in LDS by the caller (stage_log_table).
 // ONE (small clouds): the range is a single tile, and the tile's normal variates -- which depend on nothing but (seed, particle,
 // observation) -- are drawn WHILE the ancestor indices and the gathered rows are on their way: with one wave per SIMD nobody
 // else hides those two round trips (~1.7 us of a kernel whose whole body takes ~5).  Same arithmetic, another order.
 // (ONE = 1: the range is a single tile; ONE = 2: the same body tile after tile -- a separate instantiation: folding the loop into
 // the single-tile kernel cost it 18 VGPRs and 10 % at d = 9)
-template <int D, bool LGCP, int IT, int OBS, bool SUMS, int ONE = 0>
+template <int D, bool LGCP, int IT, int OBS, int SUMS, int ONE = 0>
 __device__ __forceinline__ void propagate_range(
     const double* __restrict__ src, size_t src_stride, const uint32_t* __restrict__ anc,
     double* __restrict__ dst, size_t dst_stride, double* __restrict__ logw, uint64_t gid0,
@@ -86,7 +93,7 @@ __device__ __forceinline__ void propagate_range(
   // every thread's first particle has an even global id (gid0 even; chunk, tile and IT even): whole pairs per thread
   const bool pair_ok = (gid0 & 1ull) == 0ull;
   // SUMS (compile time: its accumulators would otherwise hold 8 VGPRs in every kernel): the block also forms the sums
-  const bool do_sums = SUMS && !LGCP && do_sums_arg && has_obs;
+  const bool do_sums = SUMS && !LGCP && do_sums_arg && has_obs;   // (do_sums_arg is 1 for every SUMS instantiation)
   const double cref = rec->ref;
   cssm_u128 accS = cssm_u128_zero(), accS2 = cssm_u128_zero();
   double tmax = -cssm_inf();
@@ -252,7 +259,8 @@ __device__ __forceinline__ void propagate_range(
           const double a = cssm_min_c(lw[r] - cref, CSSM_REF_BELOW);
           const double w1 = cssm_exp_le0(a);
           accS = cssm_u128_add(accS, cssm_fix_from_unit(w1));
-          accS2 = cssm_u128_add(accS2, cssm_fix_from_unit(w1 * w1));
+          if (SUMS == 2) accS2 = cssm_u128_add(accS2, cssm_fix_from_unit(w1 * w1));
+          lw[r] = w1;                            // what is stored: the weight, not its logarithm
         }
       }
     };
@@ -400,7 +408,7 @@ __device__ __forceinline__ void propagate_range(
 // host so that a whole number of blocks makes one scan unit of k_offspring).  With do_sums the block also forms
 // S = sum exp(w - c), S2 = sum exp(w - c)^2 in fixed point for its range, c = rec->ref being known before any
 // weight is (include/cssm_numerics.h, "reference level"): the log-sum-exp of :125-127 then needs no pass of its own.
-template <int D, bool LGCP, int IT, int OBS, bool SUMS>
+template <int D, bool LGCP, int IT, int OBS, int SUMS>
 __global__ __launch_bounds__(CSSM_BLOCK, (PropWaves<D, SUMS>::value)) void k_propagate(
     const double* __restrict__ src, size_t src_stride, const uint32_t* __restrict__ anc,
     double* __restrict__ dst, size_t dst_stride, double* __restrict__ logw, uint64_t n_arg, uint64_t gid0,
@@ -434,14 +442,15 @@ __global__ __launch_bounds__(CSSM_BLOCK, (PropWaves<D, SUMS>::value)) void k_pro
   if (SUMS && !LGCP && do_sums) {
     __shared__ cssm_u128 s_sa[CSSM_BLOCK / 64], s_sb[CSSM_BLOCK / 64];
     accS = wave_sum_u128(accS);
-    accS2 = wave_sum_u128(accS2);
-    if ((threadIdx.x & 63) == 0) { s_sa[threadIdx.x >> 6] = accS; s_sb[threadIdx.x >> 6] = accS2; }
+    if (SUMS == 2) accS2 = wave_sum_u128(accS2);
+    if ((threadIdx.x & 63) == 0) { s_sa[threadIdx.x >> 6] = accS; if (SUMS == 2) s_sb[threadIdx.x >> 6] = accS2; }
     __syncthreads();
     if (threadIdx.x == 0) {
-      cssm_u128 ta = s_sa[0], tb = s_sb[0];
+      cssm_u128 ta = s_sa[0], tb = (SUMS == 2) ? s_sb[0] : cssm_u128_zero();
 #pragma unroll
-      for (int w = 1; w < CSSM_BLOCK / 64; ++w) { ta = cssm_u128_add(ta, s_sa[w]); tb = cssm_u128_add(tb, s_sb[w]); }
-      subS[blockIdx.x] = ta; subS2[blockIdx.x] = tb;
+      for (int w = 1; w < CSSM_BLOCK / 64; ++w) { ta = cssm_u128_add(ta, s_sa[w]); if (SUMS == 2) tb = cssm_u128_add(tb, s_sb[w]); }
+      subS[blockIdx.x] = ta;
+      if (SUMS == 2) subS2[blockIdx.x] = tb;
     }
   } else {
     __syncthreads();
@@ -464,7 +473,7 @@ __global__ __launch_bounds__(CSSM_BLOCK, (PropWaves<D, SUMS>::value)) void k_pro
 // ONE: the block's range is one tile (small clouds, half a tile per block): see propagate_range
 // (the body, shared with the sharded filter's slim launch k_propagate_shard: gid0 = the rank's first global particle, src2 /
 //  n_split = the rows received from the neighbouring ranks; both compile-time constants -- 0, nullptr -- in k_propagate_self)
-template <int D, int IT, int OBS, bool SUMS, int ONE>
+template <int D, int IT, int OBS, int SUMS, int ONE>
 __device__ __forceinline__ void propagate_block(
     const double* __restrict__ src, size_t src_stride, const uint32_t* __restrict__ anc, double* __restrict__ dst, size_t dst_stride,
     double* __restrict__ logw, uint64_t n_arg, uint64_t seed, const StepRec* __restrict__ rec, const ModelK& mk, Scalars* __restrict__ sc,
@@ -518,14 +527,15 @@ __device__ __forceinline__ void propagate_block(
   if (__any(acc.bad) && (threadIdx.x & 63) == 0) atomicOr(&sc->err, 1u);
   if (SUMS) {
     __shared__ cssm_u128 s_sa[CSSM_BLOCK / 64], s_sb[CSSM_BLOCK / 64];
-    const cssm_u128 accS = wave_sum_u128(acc.S), accS2 = wave_sum_u128(acc.S2);
-    if ((threadIdx.x & 63) == 0) { s_sa[threadIdx.x >> 6] = accS; s_sb[threadIdx.x >> 6] = accS2; }
+    const cssm_u128 accS = wave_sum_u128(acc.S), accS2 = (SUMS == 2) ? wave_sum_u128(acc.S2) : cssm_u128_zero();
+    if ((threadIdx.x & 63) == 0) { s_sa[threadIdx.x >> 6] = accS; if (SUMS == 2) s_sb[threadIdx.x >> 6] = accS2; }
     __syncthreads();
     if (threadIdx.x == 0) {
-      cssm_u128 ta = s_sa[0], tb = s_sb[0];
+      cssm_u128 ta = s_sa[0], tb = (SUMS == 2) ? s_sb[0] : cssm_u128_zero();
 #pragma unroll
-      for (int w = 1; w < CSSM_BLOCK / 64; ++w) { ta = cssm_u128_add(ta, s_sa[w]); tb = cssm_u128_add(tb, s_sb[w]); }
-      subS[blockIdx.x] = ta; subS2[blockIdx.x] = tb;
+      for (int w = 1; w < CSSM_BLOCK / 64; ++w) { ta = cssm_u128_add(ta, s_sa[w]); if (SUMS == 2) tb = cssm_u128_add(tb, s_sb[w]); }
+      subS[blockIdx.x] = ta;
+      if (SUMS == 2) subS2[blockIdx.x] = tb;
     }
   } else {
     __syncthreads();
@@ -539,7 +549,7 @@ __device__ __forceinline__ void propagate_block(
   }
 }
 
-template <int D, int IT, int OBS, bool SUMS, int ONE = 0>
+template <int D, int IT, int OBS, int SUMS, int ONE = 0>
 __global__ __launch_bounds__(CSSM_BLOCK, (ONE ? 2 : PropWaves<D, SUMS>::value)) void k_propagate_self(
     const double* __restrict__ src, size_t src_stride, const uint32_t* __restrict__ anc, double* __restrict__ dst, size_t dst_stride,
     double* __restrict__ logw, uint64_t n_arg, uint64_t seed, const StepRec* __restrict__ rec, ModelK mk, Scalars* __restrict__ sc,
@@ -554,11 +564,11 @@ __global__ __launch_bounds__(CSSM_BLOCK, (ONE ? 2 : PropWaves<D, SUMS>::value)) 
 // 0, an even first global particle: whole pairs per thread): the same body behind 18 arguments instead of the generic
 // kernel's 24.  ONE = 2: tile after tile (units of at most CSSM_LOOP_MAX_TILES tiles); ONE = 0: software-pipelined.
 template <int D, int IT, int OBS, int ONE>
-__global__ __launch_bounds__(CSSM_BLOCK, (ONE ? 2 : PropWaves<D, true>::value)) void k_propagate_shard(
+__global__ __launch_bounds__(CSSM_BLOCK, (ONE ? 2 : PropWaves<D, 2>::value)) void k_propagate_shard(
     const double* __restrict__ src, size_t src_stride, const uint32_t* __restrict__ anc, double* __restrict__ dst, size_t dst_stride,
     double* __restrict__ logw, uint64_t n_arg, uint64_t gid0, uint64_t seed, const StepRec* __restrict__ rec, ModelK mk,
     Scalars* __restrict__ sc, const double* __restrict__ src2, uint32_t n_split, const double* __restrict__ logtab, uint64_t chunk,
     cssm_u128* __restrict__ subS, cssm_u128* __restrict__ subS2) {
-  propagate_block<D, IT, OBS, true, ONE>(src, src_stride, anc, dst, dst_stride, logw, n_arg, seed, rec, mk, sc, 0, logtab, chunk, subS, subS2,
-                                         nullptr, 0u, gid0, src2, n_split);
+  propagate_block<D, IT, OBS, 2, ONE>(src, src_stride, anc, dst, dst_stride, logw, n_arg, seed, rec, mk, sc, 0, logtab, chunk, subS, subS2,
+                                      nullptr, 0u, gid0, src2, n_split);
 }

@@ -141,6 +141,7 @@ extern "C" int cssm_pf_shard_sums(cssm_pf* pf, const uint64_t* all_sums5_dev, in
                      (double*)nullptr, (int32_t*)nullptr, 0u, (const double*)nullptr, (unsigned long long*)sums5_dev, 0, 12u, 1);
   HIP_TRY(hipGetLastError());
   pf->last_optimistic = false;
+  pf->sums_ready = true;
   // the snapshot a resume restores was taken right after the propagate: the sums it describes are these now
   if (pf->series && pf->step >= 1 && pf->snaps.size() >= pf->step) pf->snaps[pf->step - 1].last_optimistic = false;
   return CSSM_OK;
@@ -155,6 +156,8 @@ extern "C" int cssm_pf_shard_offspring(cssm_pf* pf, const uint64_t* all_sums5_de
   const uint64_t n_per = (pf->n_global + (uint64_t)world - 1) / (uint64_t)world;
   if (pf->first != (uint64_t)rank * n_per) return fail(CSSM_ESHARD, "rank %d must own particles from %llu (ceil(N/world) per rank), handle starts at %llu",
                                                        rank, (unsigned long long)((uint64_t)rank * n_per), (unsigned long long)pf->first);
+  if (!pf->sums_ready) return fail(CSSM_ESTATE, "the exact exchange forms its sums with cssm_pf_shard_sums first (all-gather of the maxima, "
+                                                "sums relative to the level they select, all-gather of the sums)");
   const size_t slot = last_rec_slot(pf);
   const int tgrid = (int)pf->nunits;
   const int optimistic = pf->last_optimistic ? 1 : 0;
@@ -162,7 +165,7 @@ extern "C" int cssm_pf_shard_offspring(cssm_pf* pf, const uint64_t* all_sums5_de
   // own slot); the end slots are kept for the send ranges; slots owned by other ranks' particles are filled by adopt
   hipLaunchKernelGGL((k_offspring<true, false, CSSM_RESAMPLE_SYSTEMATIC>), dim3(tgrid), dim3(CSSM_BLOCK), 0, pf->stream, pf->logw, pf->n, pf->sc,
                      (const cssm_u128*)pf->tileS, (const cssm_u128*)pf->tileS2, pf->d_recs + slot, pf->n_global, pf->endslot,
-                     pf->anc, pf->ntiles, pf->sup, pf->nunits, 0, 0, (double*)nullptr, (int32_t*)nullptr, 0u, pf->opt_exact,
+                     pf->anc, pf->ntiles, pf->sup, pf->nunits, optimistic ? 2 : 0, 0, (double*)nullptr, (int32_t*)nullptr, 0u, pf->opt_exact,
                      (const unsigned long long*)all_sums5_dev, rank, world, optimistic ? (int)pf->split : 1, pf->seed, (double*)nullptr, pf->d_logtab,
                      optimistic, (unsigned long long*)redo_flag_dev, (uint32_t)pf->first, (uint32_t)(pf->first + pf->n));
   pf->send_first_dev = (const long long*)send_first_dev; pf->send_count_dev = (const long long*)send_count_dev;
@@ -198,8 +201,15 @@ __device__ __forceinline__ uint64_t wave_search_first(const uint32_t* __restrict
 }
 
 static int shard_prepare_step(cssm_pf* pf, const StepRec* d_rec, int weighted, uint64_t* sums5_dev) {
+  // sums5_dev != nullptr: the level of the observation will come from the GLOBAL max (exact exchange; the "max" plan of a
+  // series): only the local max is exported now and the sums are a pass of their own once the level is known
+  // (cssm_pf_shard_sums), so the kernel that stores LOG-weights runs.  nullptr (single-collective exchange at every
+  // observation's reference level): k_propagate<SUMS> forms the sums and stores the weights in place of the log-weights.
+  pf->safe_sums = sums5_dev != nullptr;
   int rc = cssm_launch_propagate(pf, d_rec);
+  pf->safe_sums = false;
   if (rc) return rc;
+  pf->sums_ready = pf->last_optimistic;
   if (weighted && sums5_dev) {   // (sums5_dev == nullptr: the single-collective exchange totals the sums in k_boundary_pack)
     // the rank's totals of the sub-unit sums k_propagate formed and the order key of its max -> 5 words for the all-gather
     const uint64_t chunk = (uint64_t)pf->sup * CSSM_TILE / pf->split;
@@ -280,6 +290,7 @@ extern "C" int cssm_pf_shard_resume(cssm_pf* pf, uint32_t* fail_step_out) {
   const cssm_pf::Snap& q = pf->snaps[s];
   pf->cur = q.cur; pf->src = q.src; pf->src_stride = q.src_stride; pf->src2 = q.src2; pf->src2_stride = q.src2_stride;
   pf->n_split = q.n_split; pf->anc_valid = q.anc_valid; pf->last_optimistic = q.last_optimistic; pf->step = q.step; pf->t = q.t;
+  pf->sums_ready = true;   // (the exchange that missed ran behind them)
   *fail_step_out = s;
   return CSSM_OK;
 }
@@ -323,13 +334,14 @@ extern "C" int cssm_pf_shard_adopt_spec(cssm_pf* pf, const double* recv_buf_dev,
   const uint32_t n_split = (uint32_t)pf->n;
   hipLaunchKernelGGL(k_offspring_expand_spec, dim3(tgrid), dim3(CSSM_BLOCK), 0, pf->stream, pf->logw, pf->n, pf->sc,
                      (const cssm_u128*)pf->tileS, (const cssm_u128*)pf->tileS2, (const StepRec*)(pf->d_recs + slot), pf->n_global, pf->endslot,
-                     pf->anc, pf->ntiles, pf->sup, pf->nunits, 0, 0, (double*)nullptr, (int32_t*)nullptr, 0u, pf->opt_exact,
+                     pf->anc, pf->ntiles, pf->sup, pf->nunits, pf->last_optimistic ? 2 : 0, 0, (double*)nullptr, (int32_t*)nullptr, 0u, pf->opt_exact,
                      all5, rank, world, (int)pf->split, pf->seed, (double*)nullptr, (const double*)pf->d_logtab,
                      pf->last_optimistic ? 2 : 0, (unsigned long long*)(pf->d_xch + 128), (uint32_t)pf->first, (uint32_t)(pf->first + pf->n), (uint32_t)seg,
                      recv_buf_dev, (long long)cap, pf->d, n_split);
   HIP_TRY(hipGetLastError());
   pf->src = pf->state[pf->cur]; pf->src_stride = pf->stride;
   pf->src2 = recv_buf_dev; pf->src2_stride = 0; pf->n_split = n_split; pf->anc_valid = true;   // stride 0 = rows of d + 1
+  pf->wmode = pf->last_optimistic;
   return CSSM_OK;
 }
 

@@ -63,8 +63,8 @@ __host__ __device__ __forceinline__ long long spec_hdr(int d) { return (long lon
 __host__ __device__ __forceinline__ long long spec_capP(int d, long long cap) { return (long long)(d + 1) * ((cap + d) / (d + 1)); }
 __host__ __device__ __forceinline__ long long spec_seg(int d, long long cap) { return spec_hdr(d) + cap * (d + 1) + spec_capP(d, cap); }
 
-// grid (tiles of the block + 1 for the header, destination rank); the weights are those k_propagate<SUMS> summed:
-// exp(min(w - c, REF_BELOW))
+// grid (tiles of the block + 1 for the header, destination rank); the weights are those k_propagate<SUMS> summed and stored,
+// exp(min(w - c, REF_BELOW)) -- or, with the level taken from the global max, exp(w - level) of the stored log-weights
 __global__ __launch_bounds__(CSSM_BLOCK) void k_boundary_pack(const double* __restrict__ src, size_t stride, const double* __restrict__ logw,
                                                               uint64_t n_local, int d, int world, int rank, long long cap,
                                                               const StepRec* __restrict__ rec, const cssm_u128* __restrict__ subS,
@@ -91,7 +91,8 @@ __global__ __launch_bounds__(CSSM_BLOCK) void k_boundary_pack(const double* __re
 #pragma unroll
     for (int r = 0; r < CSSM_ITEMS; ++r) {
       const uint64_t i = base + (uint64_t)threadIdx.x * CSSM_ITEMS + r;
-      qq[r] = (i < (uint64_t)cnt) ? cssm_fix_from_double(cssm_exp(cssm_min_c(logw[first + i] - cref, CSSM_REF_BELOW))) : cssm_u128_zero();
+      // level_from_max: log-weights, rescaled as k_tile_sums does; else the weights k_propagate<SUMS> stored in their place
+      qq[r] = (i < (uint64_t)cnt) ? cssm_fix_from_unit(level_from_max ? cssm_exp_le0(logw[first + i] - cref) : logw[first + i]) : cssm_u128_zero();
     }
   };
   auto block_total = [&](cssm_u128 v) -> cssm_u128 {   // sum over the block's threads (uniform result)
@@ -185,7 +186,7 @@ __global__ __launch_bounds__(CSSM_BLOCK) void k_boundary_pack(const double* __re
         for (int r = 0; r < CSSM_ITEMS; ++r) {
           const uint64_t i = (uint64_t)t * CSSM_TILE + (uint64_t)threadIdx.x * CSSM_ITEMS + r;
           if (i < (uint64_t)cnt_all)
-            c = cssm_u128_add(c, cssm_fix_from_double(cssm_exp(cssm_min_c(logw[bfirst + i] - cref, CSSM_REF_BELOW))));
+            c = cssm_u128_add(c, cssm_fix_from_unit(level_from_max ? cssm_exp_le0(logw[bfirst + i] - cref) : logw[bfirst + i]));
         }
         acc = cssm_u128_add(acc, block_total(c));
       }

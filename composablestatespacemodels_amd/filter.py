@@ -198,6 +198,17 @@ class NativePf:
         _abi.check(self.lib.cssm_pf_get_proposed(self._h, _p(out)))
         return out
 
+    def weights(self):
+        """(w1, c): the weights exp(min(w - c, 2^-20)) of the last weighted step and the level c they are relative to -- what the
+        fused kernel keeps in place of the log-weights; None where the handle keeps log-weights (see ``logw``)."""
+        out = np.zeros(self.n)
+        level = C.c_double()
+        rc = self.lib.cssm_pf_get_weights(self._h, _p(out), C.byref(level))
+        if rc == -7:       # CSSM_ESTATE: log-weights are kept
+            return None
+        _abi.check(rc)
+        return out, level.value
+
     def logw(self) -> np.ndarray:
         out = np.zeros(self.n)
         _abi.check(self.lib.cssm_pf_get_logw(self._h, _p(out)))

@@ -368,14 +368,17 @@ class ShardedFilter:
             comm.all_to_all_counts([s.recv_count for s in S], [s.send_count for s in S])
             return [s.meta.cpu().numpy() for s in S]   # the one host read of the step: exchange sizes + redo flag
 
-        metas = None if lgcp else resample_stage()
-        if metas is None or any(int(m[3 * W]) for m in metas):
-            # the max ruled the reference level out (every rank sees the same gathered words, so all agree): sums again
-            if metas is None:
-                comm.all_gather([s.all_sums for s in S], [s.sums5 for s in S])   # LGCP: only the max keys matter
-            for s in S:
-                s.sums()
-            metas = resample_stage()
+        # the level of the observation comes from the GLOBAL max: an all-gather of the local maxima (only the max keys of the 5
+        # words matter), the sums relative to the level it selects, then the ordinary stage.  (Rounds 1-2 first tried the
+        # observation's reference level for non-LGCP models and formed the sums again when the max ruled it out; the kernels
+        # that form sums relative to the reference level now keep the weights in place of the log-weights, so the exchange
+        # whose level is unknown in advance runs the log-weight kernels throughout.)
+        comm.all_gather([s.all_sums for s in S], [s.sums5 for s in S])
+        for s in S:
+            s.sums()
+        metas = resample_stage()
+        if any(int(m[3 * W]) for m in metas):
+            raise RuntimeError("the exact exchange cannot ask for its sums again")
         firsts = [m[:W] for m in metas]
         scount = [m[W:2 * W] for m in metas]
         rcount = [m[2 * W:3 * W] for m in metas]

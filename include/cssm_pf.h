@@ -283,8 +283,14 @@ int32_t cssm_pf_dim(const cssm_pf* pf);            /* total latent dimension d *
 int cssm_pf_get_particles(cssm_pf* pf, double* out_dN);
 /* Ancestor indices of the last resampling (slot i <- particle anc[i]); host pointer, N. */
 int cssm_pf_get_ancestors(cssm_pf* pf, uint32_t* out_N);
-/* Log-weights of the last weighted step, before resampling (model/ParticleFilter.scala:123). */
+/* Log-weights of the last weighted step, before resampling (model/ParticleFilter.scala:123) -- where the handle keeps them: LGCP
+ * filters, the multinomial resampler, cssm_pf_propagate, CSSM_OPT_FUSED_SUMS = 0, an observation that was redone relative to
+ * the max.  Otherwise CSSM_ESTATE: the fused kernel stores the WEIGHTS in their place, see cssm_pf_get_weights. */
 int cssm_pf_get_logw(cssm_pf* pf, double* out_N);
+/* The weights w1_i = exp(min(w_i - c, 2^-20)) of the last weighted step -- what stepFilter hands its resampler as the second
+ * argument, rescaled by the observation's reference level c instead of the max (model/ParticleFilter.scala:125-126;
+ * include/cssm_numerics.h, "reference level") -- and *level_out = c (may be NULL).  CSSM_ESTATE where log-weights are kept. */
+int cssm_pf_get_weights(cssm_pf* pf, double* out_N, double* level_out);
 /* Propagated, not yet resampled particles of the last step (x1 at :118), SoA, host pointer. */
 int cssm_pf_get_proposed(cssm_pf* pf, double* out_dN);
 

@@ -14,6 +14,22 @@ from oracle import oracle
 pytestmark = pytest.mark.gpu
 
 
+def _assert_weights_match(g, o_logw, o=None, err_msg=""):
+    """The handle keeps either the log-weights of the last weighted step or -- the fused kernel -- the weights
+    w1 = exp(min(w - c, 2^-20)) relative to the observation's reference level c in their place (what stepFilter hands its
+    resampler, ParticleFilter.scala:125-126, rescaled by c instead of the max).  Whichever it keeps must equal what the oracle's
+    log-weights give, bit for bit; with the whole-cloud oracle at hand the level must be the oracle's too."""
+    w = g.weights()
+    if w is None:
+        np.testing.assert_array_equal(g.logw(), o_logw, err_msg="log-weights: " + err_msg)
+        return
+    w1, c = w
+    if o is not None:
+        assert c == o.ref()[0], (c, o.ref(), err_msg)
+    lw = np.where(np.isnan(o_logw), -np.inf, o_logw)
+    np.testing.assert_array_equal(w1, oracle.c_exp(np.minimum(lw - c, 2.0 ** -20)), err_msg="weights: " + err_msg)
+
+
 def _compare_streaming(model, n, t, y, has, seed=cases.SEED, lgcp_precision=0, fused=0):
     g = NativePf(model, n, seed, lgcp_precision=lgcp_precision)
     g.set_option(3, fused)      # CSSM_OPT_FUSED_SUMS
@@ -26,7 +42,7 @@ def _compare_streaming(model, n, t, y, has, seed=cases.SEED, lgcp_precision=0, f
         ol, oe = o.step(t[s], y[s], bool(has[s]))
         np.testing.assert_array_equal(g.proposed(), o.proposed(), err_msg=f"propagated cloud differs at step {s}")
         if has[s] or lgcp_precision:
-            np.testing.assert_array_equal(g.logw(), o.logw(), err_msg=f"log-weights differ at step {s}")
+            _assert_weights_match(g, o.logw(), o, err_msg=f"step {s}")
             np.testing.assert_array_equal(g.ancestors(), o.ancestors(), err_msg=f"ancestors differ at step {s}")
         np.testing.assert_array_equal(g.particles(), o.particles(), err_msg=f"resampled cloud differs at step {s}")
         assert gl == ol, f"ll differs at step {s}: {gl!r} vs {ol!r}"
@@ -354,8 +370,12 @@ def test_full_size_c3_c4_size_independent_properties(name, n, T, lgcp):
     anc = a.ancestors()
     np.testing.assert_array_equal(anc, b.ancestors())
     assert np.all(np.diff(anc.astype(np.int64)) >= 0)
-    lw = a.logw().astype(np.longdouble)
-    w = np.exp(lw - lw.max())
+    kept = a.weights()                              # (weights relative to the reference level, or log-weights: LGCP)
+    if kept is None:
+        lw = a.logw().astype(np.longdouble)
+        w = np.exp(lw - lw.max())
+    else:
+        w = kept[0].astype(np.longdouble)
     expect = (w * (np.longdouble(n) / w.sum())).astype(np.float64)
     counts = np.bincount(anc, minlength=n).astype(np.float64)
     assert counts.sum() == n
@@ -666,7 +686,7 @@ def test_whole_tile_kernels_at_test_sizes(name):
         np.testing.assert_array_equal(gll, oll)
         np.testing.assert_array_equal(gess, oess)
         np.testing.assert_array_equal(g.ancestors(), o.ancestors())
-        np.testing.assert_array_equal(g.logw(), o.logw()) if has[-1] else None
+        _assert_weights_match(g, o.logw(), o) if has[-1] else None
         g.init(float(np.min(t)))                       # the same handle, streaming, same geometry
         o2 = oracle.OraclePf(model.descriptor(), n, cases.SEED); o2.init(float(np.min(t)))
         for s in range(4):
@@ -824,13 +844,19 @@ def test_full_size_configs_oracle_checked_on_slices(name, n, T, lgcp):
         shards.append(o)
     for s in range(T):
         g.step(t[s], y[s], bool(has[s]))
-        prop, lw = g.proposed(), g.logw()
+        prop = g.proposed()
         for (first, m), o in zip(slices, shards):
             o.set_particles(np.ascontiguousarray(cloud[:, first:first + m]))
             o.propagate_only(float(t[s]), float(y[s]), bool(has[s]))
             np.testing.assert_array_equal(o.proposed(), prop[:, first:first + m], err_msg=f"step {s}, slice at {first}: propagated cloud")
             if has[s] or lgcp:
-                np.testing.assert_array_equal(o.logw(), lw[first:first + m], err_msg=f"step {s}, slice at {first}: log-weights")
+                kept = g.weights()
+                if kept is None:
+                    np.testing.assert_array_equal(o.logw(), g.logw()[first:first + m], err_msg=f"step {s}, slice at {first}: log-weights")
+                else:
+                    olw = np.where(np.isnan(o.logw()), -np.inf, o.logw())
+                    np.testing.assert_array_equal(oracle.c_exp(np.minimum(olw - kept[1], 2.0 ** -20)), kept[0][first:first + m],
+                                                  err_msg=f"step {s}, slice at {first}: weights")
         cloud = g.particles()
     g.close()
 
