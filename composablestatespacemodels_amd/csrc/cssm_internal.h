@@ -23,6 +23,7 @@
 
 struct cssm_pf : HostModel {
   int device = 0;
+  int n_cus = 256;             // compute units of the device (launch geometry decisions)
   hipStream_t stream = nullptr;
   bool own_stream = true;
   // sizes

@@ -315,7 +315,9 @@ __device__ __forceinline__ void offspring_body(const double* __restrict__ logw, 
   //  have to stay live around a back edge -- plus ONE more block, the publisher: it totals the sums like every block and
   //  then publishes the observation's scalars (ll; ess: a logarithm and two divisions in one thread) instead of working on
   //  a unit.  With block 0 doing both, that serial tail was on the critical path of a launch that at small N has nothing
-  //  but its critical path.)
+  //  but its critical path.  Measured and dropped in round 3: letting the LAST unit's block publish when nunits + 1 blocks
+  //  exceed the 4 x 256 resident slots (N = 2^20: 1024 units) -- 12.8 vs 12.0 us: blocks do not finish in lockstep, the extra
+  //  block slips into the first free slot long before the grid drains.)
   uint32_t unit = blockIdx.x;
   cssm_u128 toff_self = cssm_u128_zero();
   if (SELF) {                                              // here unitP holds the unit SUMS (k_propagate / k_tile_sums output)

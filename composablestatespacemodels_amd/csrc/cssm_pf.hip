@@ -65,6 +65,7 @@ static int alloc_handle(cssm_pf* pf) {
   if (pf->own_stream) HIP_TRY(hipStreamCreateWithFlags(&pf->stream, hipStreamNonBlocking));
   HIP_TRY(hipEventCreate(&pf->ev0));
   HIP_TRY(hipEventCreate(&pf->ev1));
+  HIP_TRY(hipDeviceGetAttribute(&pf->n_cus, hipDeviceAttributeMultiprocessorCount, pf->device));
   pf->stride = (size_t)((pf->n + CSSM_TILE - 1) / CSSM_TILE) * CSSM_TILE;   // rows start 16-B aligned
   pf->ntiles = (uint32_t)((pf->n + CSSM_TILE - 1) / CSSM_TILE);
   pf->sup = (pf->ntiles + 1023u) / 1024u;
@@ -327,8 +328,9 @@ static int launch_resample(cssm_pf* pf, const StepRec* d_rec, double* ll_t = nul
   prof_begin(pf, CSSM_K_OFFSPRING);   // unit prefix, ll (ess), end slots and their expansion to ancestors in one kernel (one block per unit + the publisher)
 #define OFF_ARGS pf->logw, pf->n, pf->sc, (const cssm_u128*)pf->tileS, (const cssm_u128*)pf->tileS2, d_rec, pf->anc, pf->ntiles, pf->sup, pf->nunits, \
                  pf->wparity, ll_t, ess_t, rec_idx, pf->opt_exact, split, pf->seed, pf->cum, pf->s2buf, pf->s2_stride, s2_par, pf->gen
-#define OFF_GO(RS) do { if (optimistic) hipLaunchKernelGGL((k_offspring_self<RS, 2>), dim3(tgrid + 1), dim3(CSSM_BLOCK), 0, pf->stream, OFF_ARGS); \
-                        else hipLaunchKernelGGL((k_offspring_self<RS, 0>), dim3(tgrid + 1), dim3(CSSM_BLOCK), 0, pf->stream, OFF_ARGS); } while (0)
+  const int ogrid = tgrid + 1;   // one block per unit + the publisher
+#define OFF_GO(RS) do { if (optimistic) hipLaunchKernelGGL((k_offspring_self<RS, 2>), dim3(ogrid), dim3(CSSM_BLOCK), 0, pf->stream, OFF_ARGS); \
+                        else hipLaunchKernelGGL((k_offspring_self<RS, 0>), dim3(ogrid), dim3(CSSM_BLOCK), 0, pf->stream, OFF_ARGS); } while (0)
   if (pf->resampler == CSSM_RESAMPLE_STRATIFIED) OFF_GO(CSSM_RESAMPLE_STRATIFIED);
   else if (pf->resampler == CSSM_RESAMPLE_MULTINOMIAL) OFF_GO(CSSM_RESAMPLE_MULTINOMIAL);
   else OFF_GO(CSSM_RESAMPLE_SYSTEMATIC);

@@ -99,6 +99,49 @@ def test_full_size_local_shards_equal_single_gpu(world):
     g.close()
 
 
+def test_full_size_lgcp_in_its_sharded_shape_equals_single_gpu():
+    """BASELINE configs[3] as BASELINE shapes it -- a log-Gaussian Cox process, N = 2^24 particles over 8 shards of 2^21
+    (FilterLgcp, ParticleFilter.scala:184-226; precision 2) -- on one GPU with the collectives as tensor copies: every level
+    is the global max (plan "max": all-gather of the maxima + all-to-all per event), and ll, ess and every particle equal the
+    single-GPU handle of the same N bit for bit."""
+    from composablestatespacemodels_amd.filter import NativePf
+    from composablestatespacemodels_amd.sharded import GpuShard, LocalComm, ShardedFilter
+    model = cases.c4_model()
+    n, world, T = 1 << 24, 8, 3
+    t, y, has = cases.event_times(T)
+    g = NativePf(model, n, cases.SEED, lgcp_precision=2)
+    ll1, _, ess1, _ = g.run(t, y, has)
+    ref = g.particles()
+    g.close()
+    shards = [GpuShard(model, n, r, world, cases.SEED, 0, lgcp_precision=2) for r in range(world)]
+    f = ShardedFilter(shards, LocalComm(world))
+    ll, ess = f.ll_filter(t, y, has, lgcp=True)
+    assert f.last_single and f.last_from_max and f.last_attempts == 1
+    assert (ll, ess) == (ll1, int(ess1[-1]))
+    for r, s in enumerate(shards):
+        lo, m = s.first, s.n
+        np.testing.assert_array_equal(s.particles(), ref[:, lo:lo + m], err_msg=f"shard {r}")
+        s.close()
+
+
+def test_trimmed_exchange_lgcp_world8():
+    """The same plan through the trimmed exchange (whole segments between adjacent ranks, 12 header words otherwise; the rest
+    of every receive segment NaN): 8 shards, against the oracle."""
+    from composablestatespacemodels_amd.sharded import GpuShard, LocalCommTrimmed, ShardedFilter
+    model = cases.c4_model()
+    n, world = 24000, 8
+    t, y, has = cases.event_times(7, horizon=12.0)
+    shards = [GpuShard(model, n, r, world, cases.SEED, 0, lgcp_precision=2) for r in range(world)]
+    f = ShardedFilter(shards, LocalCommTrimmed(world))
+    ll, ess = f.ll_filter(t, y, has, lgcp=True)
+    assert f.last_single and f.last_from_max and f.last_attempts == 1
+    oll, oess, opart = _oracle_run(model, n, t, y, has, lgcp_precision=2)
+    assert (ll, ess) == (oll, oess[-1])
+    np.testing.assert_array_equal(np.concatenate([s.particles() for s in shards], axis=1), opart)
+    for s in shards:
+        s.close()
+
+
 def test_rccl_world1_matches_oracle():
     import torch
     import torch.distributed as dist
