@@ -10,11 +10,14 @@ one rank; launched bare (``python bench.py --gpus 8``) it starts the N ranks its
 anything in this process has touched a GPU -- waits a bounded time, forwards rank 0's JSON line and exits
 non-zero if any rank failed.
 
-Workload: BASELINE.json configs[1] -- seasonal-Poisson with OU latents (d = 3), N = 2^20 particles per GPU (weak
-scaling: the global filter has N_gpus * 2^20 particles), T = K observations, synthetic data (tests/cases.py
-simulator, seed 20260101).  N = 1: the W warm-up steps start the filter and the timed legs CONTINUE it -- value =
-N * K / wall seconds of K more steps (cssm_pf_ll_filter_more; median of ``repeats`` legs), the cloud resident in HBM, the
-K observations' records built and uploaded inside the timed call.  N > 1: a K-step series of the sharded filter.
+Workload (default, ``--model c2``): BASELINE.json configs[1] -- seasonal-Poisson with OU latents (d = 3), N = 2^20 particles
+per GPU (weak scaling: the global filter has N_gpus * 2^20 particles), T = K observations, synthetic data (tests/cases.py
+simulator, seed 20260101).  ``--model c4``: configs[3] -- a log-Gaussian Cox process (FilterLgcp, precision 2, ~10 sub-steps per
+event), N = 2^24 particles IN TOTAL (strong scaling: 2^24 / N_gpus per GPU; ``--particles`` overrides the total).
+At every N the W warm-up steps start the filter and the timed legs CONTINUE it -- value = particles * K / wall seconds of K
+more steps (cssm_pf_ll_filter_more / its sharded form; median of ``repeats`` legs, max over ranks per leg), the cloud resident
+in HBM, the K observations' records built and uploaded inside the timed call.  N > 1: plus a profiled pass whose per-rank
+kernel / collective times, plan and resumes go into the line (``per_rank``).
 
 Extra objects on the JSON line (N = 1 only): ``roofline`` for the dominant kernel from HIP events on its launch
 stream, ``roofline_16m`` the same kernel at N = 2^24 (the north-star size) for the bench model (d = 3) and for
@@ -45,11 +48,30 @@ N_16M = 1 << 24
 METRIC = "particle-steps/sec (N x T) bootstrap filter"
 
 
+LGCP_PRECISION = 2
+
+
 def build_workload(T, which="c2"):
+    """(model, t, y, has) of T observations.  c4: T events on [0, T / 10] (what thinning a log-Gaussian Cox process yields:
+    irregular increments, ~10 sub-steps of 10^-2 each)."""
     import cases
+    if which == "c4":
+        t, y, has = cases.event_times(T, horizon=0.1 * T)
+        return cases.c4_model(), t, y, has
     model = cases.c2_model() if which == "c2" else cases.c1_model()
     t, y, has = cases.poisson_counts(T)
     return model, t, y, has
+
+
+def workload_text(which, n_total, K, per_gpu=None, world=1):
+    if which == "c4":
+        s = (f"configs[3]: log-Gaussian Cox process (lgcp(ouProcess(1)), precision {LGCP_PRECISION}, ~10 sub-steps per event, d=1), "
+             f"N={n_total} particles in total")
+        return s + (f" over {world} GPUs (strong scaling: {per_gpu} per GPU)" if world > 1 else "") + f", T={K} events, systematic resampling every event"
+    head = ("configs[1]: seasonal-Poisson, OU latent (poisson(ou(1)) |+| seasonal(24,1,ou(2)), d=3), " if which == "c2"
+            else "configs[0] model at bench size: poisson(brownianMotion(1)), d=1, ")
+    size = f"N={n_total} particles" if world == 1 else f"{per_gpu} particles per GPU x {world} GPUs = {n_total} (weak scaling)"
+    return head + size + f", T={K} observations, systematic resampling every observation"
 
 
 # ------------------------------------------------------------------------------------------------ CPU baseline
@@ -131,11 +153,12 @@ def run_single(args, emit=print):
     import torch  # first: its import takes long enough for the GPU clocks to idle down
     from composablestatespacemodels_amd.filter import NativePf
     K, W = args.steps, args.warmup
-    n = args.particles
+    lgcp = args.model == "c4"
+    n = args.particles if args.particles > 0 else (N_16M if lgcp else N_PER_GPU)
     R = args.repeats if args.repeats > 0 else (3 if K >= 200 else 7)
     W = max(W, 1)                      # (the filter has to be running before K more steps can be timed)
     model, t, y, has = build_workload(W + R * K + 8, args.model)
-    pf = NativePf(model, n, 20260101, device=0)
+    pf = NativePf(model, n, 20260101, device=0, lgcp_precision=LGCP_PRECISION if lgcp else 0)
     if args.fused is not None:
         pf.set_option(3, args.fused)   # CSSM_OPT_FUSED_SUMS (experiment switch; the default is the library's)
     d = pf.d
@@ -188,16 +211,17 @@ def run_single(args, emit=print):
         "metric": METRIC, "value": n * K / wall, "unit": "particle-steps/s",
         "n_gpus": 1, "steps": K, "warmup": W, "ms_per_step": wall * 1e3 / K, "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-        "config": {"workload": ("configs[1]: seasonal-Poisson, OU latent (poisson(ou(1)) |+| seasonal(24,1,ou(2)), d=3), " if args.model == "c2"
-                                else "configs[0] model at bench size: poisson(brownianMotion(1)), d=1, ") +
-                               f"N={n} particles, T={K} observations, systematic resampling every observation",
+        "config": {"workload": workload_text(args.model, n, K),
                    "particles_per_gpu": n, "observations": K, "latent_dim": d, "seed": 20260101},
         "repeats": R, "value_is": "median over `repeats` timed legs of K steps each, continuing the filter the warm-up steps started (cssm_pf_ll_filter_more)", "wall_ms_each": [w * 1e3 for w in walls],
         "roofline": roof,
         "kernels_us": kernels_us,
         "device_loop_ms": loop_ms, "ll": ll, "ess_last": int(ess_t[-1]),
     }
-    if not args.no_16m:
+    if lgcp:
+        roof["note"] = ("an LGCP step runs its ~10 sub-steps of Philox + Box-Muller + exp per particle in registers: the kernel is compute-bound by "
+                        "design (SURVEY.md 8d); the HBM fraction is reported for completeness")
+    if not args.no_16m and not lgcp:
         out["roofline_16m"] = roofline_16m(NativePf, copy_gbs, args.fused)
     if not args.no_cpu:
         out["cpu_baseline"] = cpu_baseline()
@@ -250,50 +274,84 @@ def run_multi(args, emit=print):
     else:   # rehearsal of the launcher and of the orchestration on CPU (tests): gloo + the test-only oracle shard
         dist.init_process_group("gloo", rank=rank, world_size=world)
     K, W = args.steps, args.warmup
-    n_global = args.particles * world
-    model, t, y, has = build_workload(max(K, W, 8))
+    lgcp = args.model == "c4"
+    if lgcp:      # configs[3]: a fixed cloud split over the GPUs (strong scaling)
+        n_global = args.particles if args.particles > 0 else N_16M
+        per_gpu = -(-n_global // world)
+    else:         # configs[1]: a fixed cloud per GPU (weak scaling)
+        per_gpu = args.particles if args.particles > 0 else N_PER_GPU
+        n_global = per_gpu * world
+    R = args.repeats if args.repeats > 0 else (3 if K >= 200 else 7)
+    # warm-up: allocations, RCCL channels, clocks.  At least 8 observations whatever W is: the library's own RCCL communicator and
+    # the exchange buffers are created at the first observation of the first series -- that must not happen inside a timed leg
+    Wn = max(W, 8) if gpu else max(W, 1)
+    model, t, y, has = build_workload(Wn + (R + 1) * K, args.model)
+    prec = LGCP_PRECISION if lgcp else 0
     if gpu:
         from composablestatespacemodels_amd.sharded import GpuShard
-        shard = GpuShard(model, n_global, rank, world, 20260101, local)
+        shard = GpuShard(model, n_global, rank, world, 20260101, local, lgcp_precision=prec)
         f = ShardedFilter([shard], DistComm(device=torch.device("cuda", local)))
     else:
         from oracle_shard import OracleShard
-        shard = OracleShard(model, n_global, rank, world, 20260101)
+        shard = OracleShard(model, n_global, rank, world, 20260101, prec)
         f = ShardedFilter([shard], DistComm())
     sync = torch.cuda.synchronize if gpu else (lambda: None)
-    # warm-up: allocations, RCCL channels, clocks.  At least 8 observations whatever W is: the library's own RCCL
-    # communicator and the exchange buffers are created at the first observation of the first series -- that must not
-    # happen inside the timed region
-    Wn = max(W, 8) if gpu else max(W, 1)
-    tw, yw, hw = build_workload(Wn)[1:]
-    f.ll_filter(tw[:Wn], yw[:Wn], hw[:Wn])
-    dist.barrier()
-    sync()
-    t0 = time.perf_counter()
-    ll, ess = f.ll_filter(t[:K], y[:K], has[:K])    # the K timed observations: one series, read back once at its end
-    sync()
-    dist.barrier()
-    wall = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device="cuda" if gpu else "cpu")
-    dist.all_reduce(wall, op=dist.ReduceOp.MAX)
+    dev = "cuda" if gpu else "cpu"
+    # the W warm-up observations START the sharded filter ...
+    f.ll_filter(t[:Wn], y[:Wn], has[:Wn], lgcp=lgcp)
+    # ... and every timed leg CONTINUES it with exactly K more (the sharded cssm_pf_ll_filter_more: records built and uploaded,
+    # kernels and collectives enqueued by the library, one status read per stretch, ll / ess read back -- no new cloud, no k_init),
+    # bracketed by a barrier + device synchronisation on both sides; a leg's time is the MAX over the ranks, the figure the
+    # MEDIAN leg
+    walls, plans = [], []
+    ll = ess = None
+    for r in range(R):
+        lo = Wn + r * K
+        dist.barrier()
+        sync()
+        t0 = time.perf_counter()
+        ll, ess = f.ll_filter_more(t[lo:lo + K], y[lo:lo + K], has[lo:lo + K], lgcp=lgcp)
+        sync()
+        dist.barrier()
+        wall = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
+        dist.all_reduce(wall, op=dist.ReduceOp.MAX)
+        walls.append(float(wall.item()))
+        plans.append({"plan": "max" if f.last_from_max else ("ref" if f.last_single else "exact"), "resumes": int(f.last_resumes),
+                      "capacity_rows": f.last_cap})
+    # a pass of its own with HIP events around every kernel and every library-issued collective of this rank's stream (the
+    # event records perturb the throughput figure): what a step is made of, per rank
+    mine = {"rank": rank, "legs": plans}
+    if gpu:
+        lo = Wn + R * K
+        shard.profile(True)
+        f.ll_filter_more(t[lo:lo + K], y[lo:lo + K], has[lo:lo + K], lgcp=lgcp)
+        prof = shard.profile_read()
+        shard.profile(False)
+        mine["kernels_us"] = {k: round(v[0] / v[1] * 1e3, 2) for k, v in prof.items() if v[1] and k != "collective"}
+        mine["collective_us"] = round(prof["collective"][0] / prof["collective"][1] * 1e3, 2) if prof["collective"][1] else None
+        mine["collectives_per_observation"] = round(prof["collective"][1] / max(prof["k_propagate"][1], 1), 2)
+        mine["note"] = "bracketed event times include ~2 us of event-record overhead per launch; a collective's time includes waiting for the slowest peer"
+    every = [None] * world
+    dist.all_gather_object(every, mine)
     if rank == 0:
-        w = float(wall.item())
+        w = float(np.median(walls))
         native = bool(getattr(f, "last_native", False))
         emit(json.dumps({
             "metric": METRIC, "value": n_global * K / w, "unit": "particle-steps/s",
             "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": w * 1e3 / K, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "configs[1] sharded: seasonal-Poisson, OU latent (d=3), "
-                                   f"{args.particles} particles per GPU x {world} GPUs = {n_global}, T={K}, global systematic "
-                                   "resampling every observation (one all-to-all per observation carrying every rank's sum words and, "
-                                   f"between adjacent ranks, its boundary particles; capacity {f.last_cap} rows per pair, "
-                                   f"{getattr(f, 'last_resumes', 0)} resumed capacity misses)",
-                       "particles_per_gpu": args.particles, "observations": K, "latent_dim": shard.d, "seed": 20260101},
-            "exchange": {"capacity_rows": f.last_cap, "attempts": f.last_attempts, "backend": args.backend,
+            "scaling": "strong" if lgcp else "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": workload_text(args.model, n_global, K, per_gpu, world) +
+                                   " (global systematic resampling: one all-to-all per observation carrying every rank's sum words and, between "
+                                   "adjacent ranks, its boundary particles" + ("; LGCP: preceded by an all-gather of the ranks' maxima" if lgcp else "") + ")",
+                       "particles_per_gpu": per_gpu, "particles_total": n_global, "observations": K, "latent_dim": shard.d, "seed": 20260101},
+            "repeats": R, "value_is": "median over `repeats` timed legs of K steps each (max over ranks per leg), continuing the sharded filter the warm-up "
+                                      "steps started (cssm_pf_shard_continue)", "wall_ms_each": [x * 1e3 for x in walls],
+            "exchange": {"backend": args.backend,
                          "shard_backend": "libcssm_pf (HIP)" if gpu else "oracle (CPU rehearsal, not a measurement)",
                          "collectives_issued_by": "libcssm_pf (cssm_pf_shard_series_rccl)" if native else "torch.distributed",
-                         "collectives_per_observation": 1 if getattr(f, "last_single", False) else 2,
                          "all_to_all": getattr(f, "last_all_to_all", "equal split"),
                          "rccl": shard.lib.cssm_rccl_library().decode() if gpu else None},
+            "per_rank": every,
             "ll": ll, "ess_last": ess}))
     if gpu:
         shard.close()
@@ -367,20 +425,21 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=500)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--particles", type=int, default=N_PER_GPU, help="particles per GPU")
+    ap.add_argument("--particles", type=int, default=0, help="particles per GPU (c2 / c1: default 2^20) or in total (c4: default 2^24)")
     ap.add_argument("--repeats", type=int, default=0, help="timed K-step series (0: 3 for K >= 200, else 7); the median is reported")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-16m", action="store_true", help="skip the roofline_16m leg")
     ap.add_argument("--fused", type=int, default=None, help="CSSM_OPT_FUSED_SUMS override (single GPU)")
-    ap.add_argument("--model", default="c2", choices=["c2", "c1"], help="c2: the bench workload (BASELINE configs[1], d = 3); c1: Poisson-Brownian (configs[0], d = 1) -- profiling runs only")
+    ap.add_argument("--model", default="c2", choices=["c2", "c1", "c4"], help="c2: the bench workload (BASELINE configs[1], d = 3, weak scaling); c4: BASELINE configs[3], the log-Gaussian Cox process at N = 2^24 in total (strong scaling); c1: Poisson-Brownian (configs[0], d = 1) -- profiling runs only")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="gloo: CPU rehearsal of the N-rank path with the test-only oracle shard")
     ap.add_argument("--launch-timeout", type=float, default=1500.0, help="seconds the self-launched ranks may take")
+    ap.add_argument("--sharded", action="store_true", help="diagnostic: with --gpus 1, run the SHARDED code path at world = 1 over RCCL (its kernels, its collective) instead of the single-GPU filter")
     args = ap.parse_args()
     in_launcher = "WORLD_SIZE" in os.environ and "RANK" in os.environ
     if args.gpus > 1 and not in_launcher:
         sys.exit(launch_ranks(args, sys.argv[1:]))
     with _QuietStdout() as out:
-        if int(os.environ.get("WORLD_SIZE", "1")) > 1:
+        if int(os.environ.get("WORLD_SIZE", "1")) > 1 or args.sharded:
             run_multi(args, out.emit)
         elif args.backend == "gloo":
             run_multi(args, out.emit)

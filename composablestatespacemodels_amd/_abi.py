@@ -101,6 +101,7 @@ SYMBOLS = [
     ("cssm_pf_shard_sums", C.c_int, [_h, C.c_void_p, C.c_int, C.c_void_p]),
     ("cssm_pf_shard_offspring", C.c_int, [_h, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     ("cssm_pf_shard_begin", C.c_int, [_h, _dp, _dp, _u8p, C.c_size_t]),
+    ("cssm_pf_shard_continue", C.c_int, [_h, _dp, _dp, _u8p, C.c_size_t]),
     ("cssm_pf_shard_propagate_at", C.c_int, [_h, C.c_size_t, C.c_void_p]),
     ("cssm_pf_shard_status", C.c_int, [_h, _dp, _i32p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.c_size_t]),
     ("cssm_pf_shard_pack", C.c_int, [_h, C.c_int, _i64p, _i64p, C.c_int, C.c_void_p]),
@@ -114,6 +115,7 @@ SYMBOLS = [
     ("cssm_pf_shard_series_rccl", C.c_int, [_h, C.c_void_p, C.c_int, C.c_int, C.c_size_t, C.c_size_t, _u8p, C.c_int64,
                                             C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]),
     ("cssm_pf_shard_spec_segment", C.c_int64, [_h, C.c_int64]),
+    ("cssm_pf_shard_unit", C.c_int64, [_h]),
     ("cssm_pf_shard_boundary_pack", C.c_int, [_h, C.c_int, C.c_int, C.c_int64, C.c_void_p]),
     ("cssm_pf_shard_adopt_spec", C.c_int, [_h, C.c_void_p, C.c_int, C.c_int, C.c_int64]),
     ("cssm_pf_shard_resume", C.c_int, [_h, C.POINTER(C.c_uint32)]),

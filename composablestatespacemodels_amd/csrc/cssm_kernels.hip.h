@@ -35,11 +35,15 @@ static __global__ void k_init_from(double* __restrict__ dst, size_t stride, uint
 // per UNIT of `sup` consecutive tiles (sup is chosen on the host so that there are ~1K units: the
 // scan over units then fits one pass of one block; integer sums make any grouping give the same bits).
 static __global__ __launch_bounds__(CSSM_BLOCK) void k_tile_sums(const double* __restrict__ logw, uint64_t n,
-                                                          const Scalars* __restrict__ sc,
+                                                          Scalars* __restrict__ sc,
                                                           cssm_u128* __restrict__ unitS, cssm_u128* __restrict__ unitS2,
                                                           uint32_t ntiles, uint32_t sup, uint32_t nunits, int raw, int slot_set,
                                                           const double* __restrict__ gmax_in, const double* __restrict__ logtab,
-                                                          const StepRec* __restrict__ rec, uint32_t hold_mask) {
+                                                          const StepRec* __restrict__ rec, uint32_t hold_mask,
+                                                          const unsigned long long* __restrict__ all5 = nullptr, int world = 0) {
+  // all5 != nullptr (sharded series whose levels come from the global max, collectives issued by the library): the max is the
+  // largest of the ranks' order keys (word 4 of each rank's 5 all-gathered words) -- every block decodes it itself, block 0
+  // publishes it with the level it selects (k_boundary_pack and the status read find them in Scalars)
   // hold_mask (sharded series, level from the all-gathered max): while the series is on hold after a capacity miss (err bit 3)
   // or void (bit 2) the sums of the observation it holds at must survive the observations enqueued behind it -- the host
   // resumes exactly there (cssm_pf_shard_resume)
@@ -49,7 +53,15 @@ static __global__ __launch_bounds__(CSSM_BLOCK) void k_tile_sums(const double* _
   double pre[CSSM_ITEMS];   // the block's first tile is requested before the (serial) max decode
   if (blockIdx.x < nunits) load_tile_raw(logw, (uint64_t)blockIdx.x * sup * CSSM_TILE, n, raw, pre);
   // slot_set < 0: the max was agreed elsewhere (sharded: all-reduced value at gmax_in; stateless: sc->gmax)
-  const double gmax_dec = (slot_set >= 0) ? block_decode_slots(sc, slot_set) : (gmax_in ? *gmax_in : sc->gmax);
+  double gmax_dec;
+  if (all5) {
+    unsigned long long key = 0ull;
+    for (int r = 0; r < world; ++r) { const unsigned long long k = all5[5 * r + 4]; key = (k > key) ? k : key; }
+    gmax_dec = cssm_order_unkey(key);
+    if (blockIdx.x == 0 && threadIdx.x == 0) { sc->gmax = gmax_dec; sc->ref = cssm_ref_choose(rec->ref, gmax_dec); }
+  } else {
+    gmax_dec = (slot_set >= 0) ? block_decode_slots(sc, slot_set) : (gmax_in ? *gmax_in : sc->gmax);
+  }
   // the level every kernel of the step agrees on: the observation's reference level when the max allows it
   const double gmax = raw ? gmax_dec : cssm_ref_choose(rec->ref, gmax_dec);
   for (uint32_t unit = blockIdx.x; unit < nunits; unit += gridDim.x) {

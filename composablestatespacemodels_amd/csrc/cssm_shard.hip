@@ -87,7 +87,7 @@ __global__ void k_adopt_remote(const double* __restrict__ recv, long long m, int
 static int shard_prepare_step(cssm_pf* pf, const StepRec* d_rec, int weighted, uint64_t* sums5_dev);
 static int bounded_sync(cssm_pf* pf);
 // record of the step propagated last: a ring of 64 for streaming steps, the whole series after shard_begin
-static size_t last_rec_slot(const cssm_pf* pf) { return pf->series ? (size_t)(pf->step - 1) : (size_t)((pf->step - 1) % 64); }
+static size_t last_rec_slot(const cssm_pf* pf) { return pf->series ? (size_t)(pf->step - 1 - pf->rec_base) : (size_t)((pf->step - 1) % 64); }
 
 static int shard_check(cssm_pf* pf) {
   if (!pf) return fail(CSSM_EINVAL_ARG, "null handle");
@@ -123,13 +123,32 @@ extern "C" int cssm_pf_shard_propagate(cssm_pf* pf, double t, double obs, int ha
   return CSSM_OK;
 }
 
+// sums5_dev == nullptr (the library's own series loop): nobody gathers the sums again -- the single-collective exchange totals
+// the unit sums in k_boundary_pack -- so ONE kernel does: k_tile_sums, which decodes the level from the gathered keys itself.
+static int shard_sums_impl(cssm_pf* pf, const uint64_t* all_sums5_dev, int world, uint64_t* sums5_dev);
 extern "C" int cssm_pf_shard_sums(cssm_pf* pf, const uint64_t* all_sums5_dev, int world, uint64_t* sums5_dev) {
   int rc = shard_check(pf);
   if (rc) return rc;
   if (!all_sums5_dev || !sums5_dev) return fail(CSSM_EINVAL_ARG, "null argument");
+  return shard_sums_impl(pf, all_sums5_dev, world, sums5_dev);
+}
+static int shard_sums_impl(cssm_pf* pf, const uint64_t* all_sums5_dev, int world, uint64_t* sums5_dev) {
   if (world < 1 || world > 64) return fail(CSSM_ESHARD, "world %d", world);
   const size_t slot = last_rec_slot(pf);
   const int tgrid = (int)pf->nunits;
+  if (!sums5_dev) {
+    prof_begin(pf, CSSM_K_TILE_SUMS);
+    hipLaunchKernelGGL(k_tile_sums, dim3(tgrid), dim3(CSSM_BLOCK), 0, pf->stream, pf->logw, pf->n, pf->sc, pf->tileS, pf->tileS2, pf->ntiles,
+                       pf->sup, pf->nunits, 0, -1, (const double*)nullptr, pf->d_logtab, (const StepRec*)(pf->d_recs + slot), 12u,
+                       (const unsigned long long*)all_sums5_dev, world);
+    prof_end(pf);
+    HIP_TRY(hipGetLastError());
+    pf->last_optimistic = false;
+    pf->sums_ready = true;
+    if (pf->series && pf->step > pf->rec_base && pf->snaps.size() >= pf->step - pf->rec_base) pf->snaps[pf->step - 1 - pf->rec_base].last_optimistic = false;
+    return CSSM_OK;
+  }
+  prof_begin(pf, CSSM_K_TILE_SUMS);
   hipLaunchKernelGGL(k_import_level, dim3(1), dim3(1), 0, pf->stream, pf->sc, (const unsigned long long*)all_sums5_dev, world,
                      (const StepRec*)(pf->d_recs + slot));
   // (every kernel here returns at once while the series is on hold after a capacity miss or void: the level, the unit sums
@@ -139,11 +158,12 @@ extern "C" int cssm_pf_shard_sums(cssm_pf* pf, const uint64_t* all_sums5_dev, in
   // word 4 (the max key) of sums5_dev is left as shard_propagate wrote it
   hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(1024), 0, pf->stream, pf->tileS, pf->tileS2, pf->tileP, pf->nunits, pf->sc, pf->n_global, 0,
                      (double*)nullptr, (int32_t*)nullptr, 0u, (const double*)nullptr, (unsigned long long*)sums5_dev, 0, 12u, 1);
+  prof_end(pf);
   HIP_TRY(hipGetLastError());
   pf->last_optimistic = false;
   pf->sums_ready = true;
   // the snapshot a resume restores was taken right after the propagate: the sums it describes are these now
-  if (pf->series && pf->step >= 1 && pf->snaps.size() >= pf->step) pf->snaps[pf->step - 1].last_optimistic = false;
+  if (pf->series && pf->step > pf->rec_base && pf->snaps.size() >= pf->step - pf->rec_base) pf->snaps[pf->step - 1 - pf->rec_base].last_optimistic = false;
   return CSSM_OK;
 }
 
@@ -248,6 +268,39 @@ extern "C" int cssm_pf_shard_begin(cssm_pf* pf, const double* t, const double* y
   rc = cssm_launch_init(pf, t0);
   if (rc) return rc;
   pf->series = true;
+  pf->rec_base = 0;
+  return CSSM_OK;
+}
+
+// T MORE observations of the sharded filter that is already running (what cssm_pf_ll_filter_more is to a single-GPU handle;
+// Flow.scan(init)(stepFilter) handed the next T elements, model/ParticleFilter.scala:163-166): no new cloud, the first time
+// increment from the handle's clock, record s of the call = observation (observations so far + s) of the filter (its Philox
+// counter word).  Steps, exchanges, status and resume then work on the call's records exactly as after cssm_pf_shard_begin.
+extern "C" int cssm_pf_shard_continue(cssm_pf* pf, const double* t, const double* y, const uint8_t* has_obs, size_t T) {
+  int rc = shard_check(pf);
+  if (rc) return rc;
+  if (!t || !y) return fail(CSSM_EINVAL_ARG, "null argument");
+  if (T < 1) return fail(CSSM_EINVAL_ARG, "empty data");
+  if (!pf->initialised) return fail(CSSM_ESTATE, "cssm_pf_shard_continue before cssm_pf_shard_begin / _init");
+  rc = bounded_sync(pf);   // (the records of the series before are rewritten)
+  if (rc) return rc;
+  rc = cssm_ensure_recs(pf, T);
+  if (rc) return rc;
+  if (pf->need_cap < T) {
+    if (pf->d_need) (void)hipFree(pf->d_need);
+    pf->d_need = nullptr;
+    HIP_TRY(hipMalloc(&pf->d_need, T * 4));
+    pf->need_cap = T;
+  }
+  HIP_TRY(hipMemsetAsync(pf->d_need, 0, T * 4, pf->stream));
+  double tp = pf->t;
+  for (size_t s = 0; s < T; ++s) { cssm_build_rec(pf, tp, t[s], y[s], has_obs ? has_obs[s] : 1, pf->step + (uint32_t)s, &pf->h_recs[s]); tp = t[s]; }
+  rc = cssm_build_fsub(pf, 0, T, true);
+  if (rc) return rc;
+  HIP_TRY(hipMemcpyAsync(pf->d_recs, pf->h_recs, T * sizeof(StepRec), hipMemcpyHostToDevice, pf->stream));
+  pf->series = true;
+  pf->rec_base = pf->step;
+  pf->snaps.clear();
   return CSSM_OK;
 }
 
@@ -255,10 +308,11 @@ extern "C" int cssm_pf_shard_propagate_at(cssm_pf* pf, size_t s, uint64_t* sums5
   int rc = shard_check(pf);
   if (rc) return rc;
   if (!pf->series || !pf->initialised) return fail(CSSM_ESTATE, "shard_propagate_at before shard_begin");
-  if (s >= pf->h_recs_cap || s != pf->step) return fail(CSSM_ESTATE, "steps of a series run in order (expected %u)", pf->step);
+  if (s >= pf->h_recs_cap || s + pf->rec_base != pf->step) return fail(CSSM_ESTATE, "steps of a series run in order (expected %u)", pf->step - pf->rec_base);
   rc = shard_prepare_step(pf, pf->d_recs + s, pf->h_recs[s].has_obs, sums5_dev);
   if (rc) return rc;
   pf->step++;
+  pf->t = pf->h_recs[s].t_obs;
   if (pf->snaps.size() <= s) pf->snaps.resize(s + 1);
   pf->snaps[s] = {pf->cur, pf->src, pf->src_stride, pf->src2, pf->src2_stride, pf->n_split, pf->anc_valid, pf->last_optimistic, pf->step, pf->t};
   return CSSM_OK;
@@ -278,10 +332,10 @@ extern "C" int cssm_pf_shard_resume(cssm_pf* pf, uint32_t* fail_step_out) {
   Scalars h;
   HIP_TRY(hipMemcpyAsync(CSSM_SC_TAIL_ARGS(&h, pf->sc), hipMemcpyDeviceToHost, pf->stream));
   HIP_TRY(hipStreamSynchronize(pf->stream));
-  if (!(h.err & 8u) || h.fail_step == 0xffffffffu || h.fail_step >= pf->snaps.size())
+  if (!(h.err & 8u) || h.fail_step == 0xffffffffu || h.fail_step < pf->rec_base || h.fail_step - pf->rec_base >= pf->snaps.size())
     return fail(CSSM_ESTATE, "no resumable capacity miss is recorded");
   if (h.err & 7u) return fail(CSSM_ESTATE, "the series has other errors (bits %u)", h.err);
-  const uint32_t s = h.fail_step;
+  const uint32_t s = h.fail_step - pf->rec_base;      // (the record's index in the resident series)
   h.err &= ~8u; h.fail_step = 0xffffffffu;
   // only err and fail_step change on the device (ll, ess, sums stay what the last completed observation left)
   HIP_TRY(hipMemcpyAsync(&pf->sc->err, &h.err, sizeof(uint32_t), hipMemcpyHostToDevice, pf->stream));
@@ -296,6 +350,10 @@ extern "C" int cssm_pf_shard_resume(cssm_pf* pf, uint32_t* fail_step_out) {
 }
 
 // ---- single-collective exchange (k_boundary_pack / k_expand_spec in cssm_kernels.hip.h)
+
+extern "C" int64_t cssm_pf_shard_unit(const cssm_pf* pf) {
+  return pf ? (int64_t)((uint64_t)pf->sup * CSSM_TILE / pf->split) : 0;
+}
 
 extern "C" int64_t cssm_pf_shard_spec_segment(const cssm_pf* pf, int64_t cap) {
   return (pf && cap >= 1) ? (int64_t)spec_seg(pf->d, (long long)cap) : 0;
@@ -312,9 +370,11 @@ extern "C" int cssm_pf_shard_boundary_pack(cssm_pf* pf, int rank, int world, int
   const uint32_t nsub = (uint32_t)((pf->n + chunk - 1) / chunk);
   const long long cnt = std::min<long long>((long long)pf->n, (long long)cap);
   const int tiles = (int)((cnt + CSSM_TILE - 1) / CSSM_TILE);
+  prof_begin(pf, CSSM_K_PACK);
   hipLaunchKernelGGL(k_boundary_pack, dim3(tiles + 1, world), dim3(CSSM_BLOCK), 0, pf->stream, pf->state[pf->cur], pf->stride, pf->logw, pf->n, pf->d,
                      world, rank, (long long)cap, pf->d_recs + slot, (const cssm_u128*)pf->tileS, (const cssm_u128*)pf->tileS2, nsub,
                      (const Scalars*)pf->sc, send_buf_dev, chunk, pf->last_optimistic ? 0 : 1);
+  prof_end(pf);
   HIP_TRY(hipGetLastError());
   return CSSM_OK;
 }
@@ -332,12 +392,14 @@ extern "C" int cssm_pf_shard_adopt_spec(cssm_pf* pf, const double* recv_buf_dev,
   // the 5 words of every rank are the header words 1..5 of its segment (the all-to-all delivered this rank's own too)
   const unsigned long long* all5 = reinterpret_cast<const unsigned long long*>(recv_buf_dev) + 1;
   const uint32_t n_split = (uint32_t)pf->n;
+  prof_begin(pf, CSSM_K_EXPAND);
   hipLaunchKernelGGL(k_offspring_expand_spec, dim3(tgrid), dim3(CSSM_BLOCK), 0, pf->stream, pf->logw, pf->n, pf->sc,
                      (const cssm_u128*)pf->tileS, (const cssm_u128*)pf->tileS2, (const StepRec*)(pf->d_recs + slot), pf->n_global, pf->endslot,
                      pf->anc, pf->ntiles, pf->sup, pf->nunits, pf->last_optimistic ? 2 : 0, 0, (double*)nullptr, (int32_t*)nullptr, 0u, pf->opt_exact,
                      all5, rank, world, (int)pf->split, pf->seed, (double*)nullptr, (const double*)pf->d_logtab,
                      pf->last_optimistic ? 2 : 0, (unsigned long long*)(pf->d_xch + 128), (uint32_t)pf->first, (uint32_t)(pf->first + pf->n), (uint32_t)seg,
                      recv_buf_dev, (long long)cap, pf->d, n_split);
+  prof_end(pf);
   HIP_TRY(hipGetLastError());
   pf->src = pf->state[pf->cur]; pf->src_stride = pf->stride;
   pf->src2 = recv_buf_dev; pf->src2_stride = 0; pf->n_split = n_split; pf->anc_valid = true;   // stride 0 = rows of d + 1
@@ -357,6 +419,7 @@ extern "C" int cssm_pf_shard_status(cssm_pf* pf, double* ll_out, int32_t* ess_ou
   HIP_TRY(hipMemcpyAsync(CSSM_SC_TAIL_ARGS(&h, pf->sc), hipMemcpyDeviceToHost, pf->stream));
   if (need && pf->d_need && T <= pf->need_cap) HIP_TRY(hipMemcpyAsync(need, pf->d_need, T * 4, hipMemcpyDeviceToHost, pf->stream));
   HIP_TRY(hipStreamSynchronize(pf->stream));
+  prof_collect(pf);
   if (ll_out) *ll_out = h.ll;
   if (ess_out) *ess_out = h.ess;
   if (bits_out) *bits_out = h.err & 12u;
@@ -531,16 +594,20 @@ extern "C" int cssm_pf_shard_series_rccl(cssm_pf* pf, void* comm, int rank, int 
       if (rc) return bail(rc);
       if (!weighted[s]) continue;
       if (level_from_max) {
+        prof_begin(pf, CSSM_K_COLLECTIVE);
         const int rg = a->AllGather(sums5_dev, all_sums5_dev, 5, kNcclUint64, comm, pf->stream);
+        prof_end(pf);
         if (rg) return bail(rccl_fail(a, "ncclAllGather", rg));
-        rc = cssm_pf_shard_sums(pf, all_sums5_dev, world, sums5_dev);
+        rc = shard_sums_impl(pf, all_sums5_dev, world, nullptr);
         if (rc) return bail(rc);
       }
       rc = cssm_pf_shard_boundary_pack(pf, rank, world, cap, send_buf_dev);
       if (rc) return bail(rc);
+      prof_begin(pf, CSSM_K_COLLECTIVE);
       const int r = trimmed ? a->AllToAllv(send_buf_dev, counts.data(), displs.data(), recv_buf_dev, counts.data(), displs.data(), kNcclFloat64,
                                            comm, pf->stream)
                             : a->AllToAll(send_buf_dev, recv_buf_dev, sseg, kNcclFloat64, comm, pf->stream);
+      prof_end(pf);
       if (r) return bail(rccl_fail(a, trimmed ? "ncclAllToAllv" : "ncclAllToAll", r));
       rc = cssm_pf_shard_adopt_spec(pf, recv_buf_dev, rank, world, cap);
       if (rc) return bail(rc);

@@ -110,12 +110,19 @@ __global__ __launch_bounds__(CSSM_BLOCK) void k_boundary_pack(const double* __re
   if (cnt == 0) return;
   // prefix of the tiles before this block's tile
   cssm_u128 toff = cssm_u128_zero();
-  const bool aligned = (chunk == (uint64_t)CSSM_TILE) && (first % (uint64_t)CSSM_TILE == 0);
+  // The carried block starts on a boundary of the sub-units whose sums k_propagate (or k_tile_sums) formed -- chunk particles
+  // each, a whole number of tiles: the sub-units wholly before this tile come from subS, at most chunk / 1024 - 1 tiles of the
+  // tile's own sub-unit are formed again.  (Round 2 recognised alignment only for chunk = one tile and otherwise formed EVERY
+  // tile before its own again, in every block: quadratic in the capacity -- 29 us per observation for an LGCP shard of 2^21.)
+  const bool aligned = (chunk % (uint64_t)CSSM_TILE == 0) && (first % chunk == 0);
+  uint32_t t_begin = 0;
   if (aligned) {
-    const uint32_t b0 = (uint32_t)(first / CSSM_TILE);
-    for (uint32_t t = 0; t < blockIdx.x; ++t) toff = cssm_u128_add(toff, subS[b0 + t]);
+    const uint32_t per = (uint32_t)(chunk / CSSM_TILE);               // tiles per sub-unit
+    const uint32_t c0 = (uint32_t)(first / chunk), nc = blockIdx.x / per;   // sub-units wholly before this tile
+    for (uint32_t c = 0; c < nc; ++c) toff = cssm_u128_add(toff, subS[c0 + c]);
+    t_begin = nc * per;
   }
-  for (uint32_t t = 0; !aligned && t < blockIdx.x; ++t) {
+  for (uint32_t t = t_begin; t < blockIdx.x; ++t) {
     cssm_u128 qq[CSSM_ITEMS];
     tile_weights((uint64_t)t * CSSM_TILE, qq);
     cssm_u128 a = cssm_u128_zero();
@@ -172,12 +179,12 @@ __global__ __launch_bounds__(CSSM_BLOCK) void k_boundary_pack(const double* __re
 #pragma unroll
   for (int which = 0; which < 2; ++which) {
     const uint64_t bfirst = which ? n_local - (uint64_t)cnt_all : 0;
-    const bool al = (chunk == (uint64_t)CSSM_TILE) && (bfirst % (uint64_t)CSSM_TILE == 0) && ((uint64_t)cnt_all % CSSM_TILE == 0);
+    const bool al = (chunk % (uint64_t)CSSM_TILE == 0) && (bfirst % chunk == 0) && ((uint64_t)cnt_all % chunk == 0);
     cssm_u128 acc = cssm_u128_zero();
-    if (al) {   // whole sub-units: their sums are k_propagate's
-      const uint32_t b0 = (uint32_t)(bfirst / CSSM_TILE);
+    if (al) {   // whole sub-units: their sums are k_propagate's (k_tile_sums')
+      const uint32_t b0 = (uint32_t)(bfirst / chunk), nch = (uint32_t)((uint64_t)cnt_all / chunk);
       cssm_u128 c = cssm_u128_zero();
-      for (uint32_t t = threadIdx.x; t < ntile; t += CSSM_BLOCK) c = cssm_u128_add(c, subS[b0 + t]);
+      for (uint32_t t = threadIdx.x; t < nch; t += CSSM_BLOCK) c = cssm_u128_add(c, subS[b0 + t]);
       acc = block_total(c);
     } else {
       for (uint32_t t = 0; t < ntile; ++t) {

@@ -111,6 +111,28 @@ class GpuShard:
         _abi.check(self.lib.cssm_pf_shard_begin(self._h, t.ctypes.data_as(dp), y.ctypes.data_as(dp),
                                                 h.ctypes.data_as(C.POINTER(C.c_uint8)), len(t)))
 
+    def begin_more(self, t, y, has):
+        """T MORE observations of the running sharded filter (cssm_pf_shard_continue): no new cloud, the series goes on."""
+        t = np.ascontiguousarray(t, dtype=np.float64)
+        y = np.ascontiguousarray(y, dtype=np.float64)
+        h = np.ones(len(t), dtype=np.uint8) if has is None else np.ascontiguousarray(has, dtype=np.uint8)
+        dp = C.POINTER(C.c_double)
+        _abi.check(self.lib.cssm_pf_shard_continue(self._h, t.ctypes.data_as(dp), y.ctypes.data_as(dp),
+                                                   h.ctypes.data_as(C.POINTER(C.c_uint8)), len(t)))
+
+    KERNELS = ("k_propagate", "k_tile_sums", "k_offspring", "k_reduce_units", "k_boundary_pack", "k_offspring_expand_spec", "collective")
+
+    def profile(self, enable: bool):
+        """HIP events around every kernel and every library-issued collective of the shard's stream (a pass of its own: the
+        event records perturb the throughput figure)."""
+        _abi.check(self.lib.cssm_pf_profile(self._h, 1 if enable else 0))
+
+    def profile_read(self):
+        ms = np.zeros(len(self.KERNELS))
+        cnt = np.zeros(len(self.KERNELS), dtype=np.uint64)
+        _abi.check(self.lib.cssm_pf_profile_read(self._h, ms.ctypes.data_as(C.POINTER(C.c_double)), cnt.ctypes.data_as(C.POINTER(C.c_uint64))))
+        return {k: (float(ms[i]), int(cnt[i])) for i, k in enumerate(self.KERNELS)}
+
     def propagate_at(self, s: int, with_sums: bool = True):
         """with_sums=False: the single-collective exchange totals the sums itself (boundary_pack)."""
         _abi.check(self.lib.cssm_pf_shard_propagate_at(self._h, int(s), C.c_void_p(self.sums5.data_ptr()) if with_sums else None))
@@ -118,6 +140,10 @@ class GpuShard:
     # ---- single-collective exchange: sums and boundary particles in one all-to-all
     def spec_segment(self, cap: int) -> int:
         return int(self.lib.cssm_pf_shard_spec_segment(self._h, int(cap)))
+
+    def unit_particles(self) -> int:
+        """Particles per unit sum (cssm_pf_shard_unit): capacities are rounded up to a multiple of it."""
+        return int(self.lib.cssm_pf_shard_unit(self._h))
 
     def boundary_pack(self, cap: int, send_buf: torch.Tensor):
         _abi.check(self.lib.cssm_pf_shard_boundary_pack(self._h, self.rank, self.world, int(cap), C.c_void_p(send_buf.data_ptr())))
@@ -434,11 +460,25 @@ class ShardedFilter:
         S, comm = self.shards, self.comm
         n_max = -(-S[0].n_global // comm.world)   # ceil(N / world): the same on every rank, and no count can exceed it
         cap = min(max(self.MIN_CAP, int(self.CAP_SQRT * S[0].n_global ** 0.5)), n_max)
-        if cap >= 1024:
-            cap = min(-(-cap // 1024) * 1024, n_max)   # whole tiles: the boundary blocks then line up with k_propagate's sums
-        return cap
+        return self._round_cap(cap, n_max)
 
-    def ll_filter(self, t, y, has=None, lgcp: bool = False, exact: bool = False):
+    def _round_cap(self, cap: int, n_max: int) -> int:
+        """Whole units of sums (1024 particles, or a multiple for large shards): the boundary blocks then line up with the sums
+        k_propagate / k_tile_sums formed, and k_boundary_pack takes their totals and prefixes from there."""
+        # (derived from n_max, which every rank knows, not asked of the local shard: the LAST rank's shard may be smaller and
+        #  split into finer units, and all ranks must arrive at the same capacity.  A unit = ceil(tiles / 1024) tiles of 1024.)
+        tiles = -(-n_max // 1024)
+        unit = 1024 * (-(-tiles // 1024))
+        return min(-(-cap // unit) * unit, n_max) if cap >= 1024 else cap
+
+    def ll_filter_more(self, t, y, has=None, lgcp: bool = False):
+        """T MORE observations of the filter ``ll_filter`` (or an earlier ``ll_filter_more``) left running: the sharded
+        cssm_pf_ll_filter_more.  Capacity misses are resumed in place as ever; an observation whose reference level the max
+        rules out cannot be handled by repeating the series (its start is gone): RuntimeError -- run such data through
+        ``ll_filter`` or as an LGCP-style series (``lgcp=True``: every level from the global max)."""
+        return self.ll_filter(t, y, has, lgcp=lgcp, cont=True)
+
+    def ll_filter(self, t, y, has=None, lgcp: bool = False, exact: bool = False, cont: bool = False):
         import os
         t = np.asarray(t, dtype=np.float64)
         y = np.asarray(y, dtype=np.float64)
@@ -455,6 +495,8 @@ class ShardedFilter:
         #           capacity covers them: bit 8 survives the resumes), or forced
         can_single = all(hasattr(s, "boundary_pack") for s in S)
         plans = ["exact"] if (exact or not can_single) else (["max", "exact"] if lgcp else ["ref", "max", "exact"])
+        if cont:
+            plans = plans[:1]   # (a continued series cannot be repeated from its start)
         attempt = 0
         while plans:
             plan = plans.pop(0)
@@ -462,7 +504,7 @@ class ShardedFilter:
             all_exact = plan == "exact"
             from_max = plan == "max"
             for s in S:
-                s.begin(t, y, has)
+                s.begin_more(t, y, has) if cont else s.begin(t, y, has)
             cap = None if all_exact else self._capacity()
             native = None
             if not all_exact and len(S) == 1 and hasattr(comm, "native_comm"):
@@ -489,9 +531,7 @@ class ShardedFilter:
                     return False
                 k = kf
                 escalated[k] = min(escalated.get(k, cap) * 4, n_max)
-                redo_cap = escalated[k]
-                if redo_cap >= 1024:
-                    redo_cap = min(-(-redo_cap // 1024) * 1024, n_max)
+                redo_cap = self._round_cap(escalated[k], n_max)
                 resumes += 1
                 redo_exchange = True
                 return True
@@ -540,6 +580,9 @@ class ShardedFilter:
             if bits == 0:
                 self.last_cap, self.last_attempts = cap, attempt
                 return res[0][0], res[0][1]
+            if cont:
+                raise RuntimeError(f"a continued sharded series cannot be repeated under another plan (sticky bits {bits}: "
+                                   "4 = an observation's reference level was ruled out by the max, 8 = slots owned by non-adjacent ranks)")
             if (bits & 8) and not (bits & 4):
                 plans = ["exact"]                    # (a level problem moves on to "max")
         raise RuntimeError("the exact exchange cannot raise a sticky bit")

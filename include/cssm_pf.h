@@ -370,6 +370,11 @@ int cssm_pf_shard_result(cssm_pf* pf, double* ll_out, int32_t* ess_out);
  * observation's reference level out (run the series again with the exact exchange), 8: a capacity miss that was not resumed;
  * need[s] = rows observation s needed (diagnostics). */
 int cssm_pf_shard_begin(cssm_pf* pf, const double* t, const double* y, const uint8_t* has_obs, size_t T);
+/* T MORE observations of the sharded filter that is already running -- what cssm_pf_ll_filter_more is to a single-GPU handle
+ * (Flow.scan(init)(stepFilter) handed the next T elements, model/ParticleFilter.scala:163-166): no new cloud, the first time
+ * increment from the handle's clock, record s of the call = observation (observations so far + s) of the filter.  Steps,
+ * exchanges, cssm_pf_shard_status and cssm_pf_shard_resume then address the call's records 0 .. T-1 as after _begin. */
+int cssm_pf_shard_continue(cssm_pf* pf, const double* t, const double* y, const uint8_t* has_obs, size_t T);
 int cssm_pf_shard_propagate_at(cssm_pf* pf, size_t s, uint64_t* sums5_dev);
 int cssm_pf_shard_status(cssm_pf* pf, double* ll_out, int32_t* ess_out, uint32_t* bits_out, uint32_t* need, size_t T);
 
@@ -388,6 +393,10 @@ int cssm_pf_shard_status(cssm_pf* pf, double* ll_out, int32_t* ess_out, uint32_t
  *   cssm_pf_shard_adopt_spec      offspring of the own particles, expansion of the received rows, coverage check
  * recv_buf_dev must stay untouched until the next propagate has run (ancestors point into it). */
 int64_t cssm_pf_shard_spec_segment(const cssm_pf* pf, int64_t cap);
+/* Particles per unit sum of this shard (a whole number of 1024-particle tiles).  A capacity that is a multiple of it lets
+ * cssm_pf_shard_boundary_pack take the totals and prefixes of the boundary blocks from the unit sums instead of forming them
+ * again (any capacity is correct; ShardedFilter rounds up to it). */
+int64_t cssm_pf_shard_unit(const cssm_pf* pf);
 int cssm_pf_shard_boundary_pack(cssm_pf* pf, int rank, int world, int64_t cap, double* send_buf_dev);
 int cssm_pf_shard_adopt_spec(cssm_pf* pf, const double* recv_buf_dev, int rank, int world, int64_t cap);
 /* A capacity miss is resumable.  The launch that found some rank's slots uncovered did nothing on any rank (every rank

@@ -166,6 +166,14 @@ class OracleShard:
         self._has = np.ones(len(self._t), dtype=np.uint8) if has is None else np.asarray(has)
         self.bits, self.need, self.fail_step = 0, np.zeros(len(self._t), dtype=np.uint32), None
         self.init(float(self._t.min()))
+        self._base = 0
+
+    def begin_more(self, t, y, has):
+        """T more observations of the running filter: the clock, ll, ess and the observation count go on."""
+        self._t = np.asarray(t, dtype=np.float64); self._y = np.asarray(y, dtype=np.float64)
+        self._has = np.ones(len(self._t), dtype=np.uint8) if has is None else np.asarray(has)
+        self.bits, self.need, self.fail_step = 0, np.zeros(len(self._t), dtype=np.uint32), None
+        self._base = self.step_idx
 
     def propagate_at(self, k, with_sums=True):
         if self.bits & 12:
@@ -177,7 +185,7 @@ class OracleShard:
         assert self.bits & 8 and self.fail_step is not None
         self.bits &= ~8
         k, self.fail_step = self.fail_step, None
-        return k
+        return k - self._base                        # (the record's index in the resident series)
 
     # ---- the single-collective exchange of GpuShard (k_boundary_pack / k_offspring_expand_spec), restated
     def spec_segment(self, cap):

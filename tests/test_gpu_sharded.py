@@ -142,6 +142,32 @@ def test_trimmed_exchange_lgcp_world8():
         s.close()
 
 
+@pytest.mark.parametrize("name,prec,n,world", [("c2_model", 0, 9000, 4), ("c3_model", 0, 5000, 2), ("c4_model", 2, 6000, 3)])
+def test_continued_sharded_series_equals_the_whole_series(name, prec, n, world):
+    """ll_filter(t[:a]) + ll_filter_more(t[a:]) leaves the bits of ll_filter(t): the sharded cssm_pf_ll_filter_more
+    (cssm_pf_shard_continue: no new cloud, the clock and the observation count go on; Flow.scan handed the next elements,
+    ParticleFilter.scala:163-166) -- with the ordinary capacity and with one row per pair (misses resumed inside the continued
+    part, whose records are addressed from 0 again)."""
+    from composablestatespacemodels_amd.sharded import GpuShard, LocalComm, ShardedFilter
+    model = getattr(cases, name)()
+    T, a = 13, 5
+    t, y, has = cases.event_times(T, horizon=12.0) if prec else cases.poisson_counts(T, missing=0.1)
+    oll, oess, opart = _oracle_run(model, n, t, y, has, lgcp_precision=prec)
+    for tiny in (False, True):
+        shards = [GpuShard(model, n, r, world, cases.SEED, 0, lgcp_precision=prec) for r in range(world)]
+        f = ShardedFilter(shards, LocalComm(world))
+        if tiny:
+            f.MIN_CAP, f.CAP_SQRT = 1, 0.0
+        f.ll_filter(t[:a], y[:a], has[:a], lgcp=bool(prec))
+        ll, ess = f.ll_filter_more(t[a:a + 4], y[a:a + 4], has[a:a + 4], lgcp=bool(prec))
+        ll, ess = f.ll_filter_more(t[a + 4:], y[a + 4:], has[a + 4:], lgcp=bool(prec))
+        assert (ll, ess) == (oll, oess[-1]), (tiny, f.last_resumes)
+        assert f.last_attempts == 1
+        np.testing.assert_array_equal(np.concatenate([s.particles() for s in shards], axis=1), opart)
+        for s in shards:
+            s.close()
+
+
 def test_rccl_world1_matches_oracle():
     import torch
     import torch.distributed as dist
@@ -164,6 +190,18 @@ def test_rccl_world1_matches_oracle():
             if not exact:                    # the library drove the collectives of the series itself (cssm_pf_shard_series_rccl)
                 assert f.last_native, "the native RCCL series loop was not taken"
                 assert f.last_single
+        # the library's loop continues a running filter (cssm_pf_shard_continue) with the same bits, and its event brackets see
+        # every kernel and the collective of every weighted observation
+        f.ll_filter(t[:6], y[:6], has[:6])
+        shard.profile(True)
+        ll, ess = f.ll_filter_more(t[6:], y[6:], has[6:])
+        prof = shard.profile_read()
+        shard.profile(False)
+        assert f.last_native and (ll, ess) == (oll, oess[-1])
+        np.testing.assert_array_equal(shard.particles(), opart)
+        nw = int(np.sum(has[6:]))
+        assert prof["k_propagate"][1] == len(t) - 6 and prof["collective"][1] == nw
+        assert prof["k_boundary_pack"][1] == nw and prof["k_offspring_expand_spec"][1] == nw
         # ... with the all-to-all-v of the library's trimmed exchange (mode 3 forces it at any world size; at world 1 it
         # carries the rank's own header)
         f4 = ShardedFilter([shard], DistComm(device=torch.device("cuda", 0)))

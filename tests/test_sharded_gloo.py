@@ -102,27 +102,39 @@ def test_local_comm_matches_single_rank_on_cpu():
     np.testing.assert_array_equal(np.concatenate([s.particles() for s in shards], axis=1), o.particles())
 
 
-def test_bench_launches_its_own_ranks_over_gloo():
+@pytest.mark.parametrize("which", ["c2", "c4"])
+def test_bench_launches_its_own_ranks_over_gloo(which):
     """`python bench.py --gpus 2` without a launcher starts its own two ranks (children, before any GPU call in the
-    parent), and hands rank 0's JSON line on: rehearsed here over gloo with the oracle shard backend."""
+    parent), and hands rank 0's JSON line on: rehearsed here over gloo with the oracle shard backend.  The warm-up
+    observations start the sharded filter, every timed leg continues it (the sharded ll_filter_more); c2 = BASELINE
+    configs[1] weak-scaled, c4 = configs[3] (LGCP, every level from the global max) strong-scaled."""
     import json
     import subprocess
     env = dict(os.environ)
     for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
-    r = subprocess.run([sys.executable, os.path.join(os.path.dirname(HERE), "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "2",
-                        "--particles", "300", "--backend", "gloo", "--launch-timeout", "240"],
+    K, W, R = 5, 2, 2
+    n_arg = 300 if which == "c2" else 400           # c2: per GPU; c4: in total
+    r = subprocess.run([sys.executable, os.path.join(os.path.dirname(HERE), "bench.py"), "--gpus", "2", "--steps", str(K), "--warmup", str(W),
+                        "--repeats", str(R), "--particles", str(n_arg), "--model", which, "--backend", "gloo", "--launch-timeout", "240"],
                        capture_output=True, text=True, timeout=300, env=env)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1
     j = json.loads(lines[0])
-    assert j["n_gpus"] == 2 and j["steps"] == 6 and j["config"]["particles_per_gpu"] == 300
+    n_total = 600 if which == "c2" else 400
+    assert j["n_gpus"] == 2 and j["steps"] == K and j["repeats"] == R and len(j["wall_ms_each"]) == R
+    assert j["config"]["particles_total"] == n_total and j["config"]["particles_per_gpu"] == n_total // 2
+    assert j["scaling"] == ("weak" if which == "c2" else "strong")
     assert j["exchange"]["backend"] == "gloo"
-    model = cases.c2_model()
-    t, y, has = cases.poisson_counts(8)
-    o = oracle.OraclePf(model.descriptor(), 600, 20260101)
-    ll, _, ess_t, _ = o.filter(t[:6], y[:6], has[:6])
+    assert [p["rank"] for p in j["per_rank"]] == [0, 1]
+    assert all(len(p["legs"]) == R and p["legs"][0]["plan"] == ("ref" if which == "c2" else "max") for p in j["per_rank"])
+    sys.path.insert(0, os.path.dirname(HERE))
+    import bench
+    model, t, y, has = bench.build_workload(W + (R + 1) * K, which)
+    o = oracle.OraclePf(model.descriptor(2 if which == "c4" else 0), n_total, 20260101)
+    T = W + R * K                                    # the line reports the filter after its last timed leg
+    ll, _, ess_t, _ = o.filter(t[:T], y[:T], has[:T])
     assert j["ll"] == ll and j["ess_last"] == int(ess_t[-1])
 
 
@@ -137,3 +149,25 @@ def test_bench_launcher_reports_a_failing_rank():
                        capture_output=True, text=True, timeout=200, env=env)
     assert r.returncode != 0
     assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+
+
+def test_continued_sharded_series_equals_the_whole_series_on_cpu():
+    """ll_filter(t[:a]) + ll_filter_more(t[a:]) = ll_filter(t): the sharded cssm_pf_ll_filter_more, here through the CPU stand-in
+    (LocalComm; capacity misses resumed inside the continued part) -- tests/test_gpu_sharded.py runs the same on the GPU."""
+    from composablestatespacemodels_amd.sharded import LocalComm, ShardedFilter
+    from oracle_shard import OracleShard
+    model = cases.c2_model()
+    n, world, T, a = 300, 3, 12, 5
+    t, y, has = cases.poisson_counts(T, missing=0.1)
+    o = oracle.OraclePf(model.descriptor(), n, cases.SEED)
+    oll, _, oess, _ = o.filter(t, y, has)
+    for tiny in (False, True):
+        shards = [OracleShard(model, n, r, world, cases.SEED) for r in range(world)]
+        f = ShardedFilter(shards, LocalComm(world))
+        if tiny:
+            f.MIN_CAP, f.CAP_SQRT = 1, 0.0
+        f.ll_filter(t[:a], y[:a], has[:a])
+        ll, ess = f.ll_filter_more(t[a:], y[a:], has[a:])
+        assert (ll, ess) == (oll, int(oess[-1]))
+        assert (f.last_resumes >= 1) == tiny
+        np.testing.assert_array_equal(np.concatenate([s.particles() for s in shards], axis=1), o.particles())
