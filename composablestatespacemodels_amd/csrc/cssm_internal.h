@@ -39,12 +39,9 @@ struct cssm_pf : HostModel {
   bool sums_ready = false;        // sharded: the unit sums of the last propagated observation exist (k_propagate<SUMS> or cssm_pf_shard_sums)
   // ESS pending (Scalars::pend): k_offspring's blocks leave partial sums of squared weights in s2buf[par * s2_stride + block]
   cssm_u128* s2buf = nullptr;     // 2 x s2_stride entries
-  cssm_u128* h_s2 = nullptr;      // pinned: the partials of the last enqueued weighted observation, read with the scalars
   uint32_t s2_stride = 0;
   int s2_par = 0;                 // buffer the next weighted observation's k_offspring writes
   uint32_t gen = 0;               // generation of the batch call / streaming step that owns d_ess_t
-  bool pend_host = false;         // the last ENQUEUED weighted observation leaves its ESS pending, partials in buffer pend_par_host
-  int pend_par_host = 0;
   int32_t ess_host = 0;           // ESS of the last completed observation as the host knows it
   void* last_comm = nullptr;      // RCCL communicator the library last enqueued collectives on (bounded_sync)
   std::vector<double> h_fsub;     // host copy of the sub-step coefficient table of the records last built
@@ -78,6 +75,10 @@ struct cssm_pf : HostModel {
   size_t recs_cap = 0;
   double* d_ll_t = nullptr;
   int32_t* d_ess_t = nullptr;
+  // host-mapped mirrors k_finish writes at the end of a call (the host synchronises the stream and reads them: no D2H copy)
+  double* h_ll_t = nullptr; double* hd_ll_t = nullptr;       // host pointer / the same memory as the device sees it
+  int32_t* h_ess_t = nullptr; int32_t* hd_ess_t = nullptr;
+  Scalars* hd_sc = nullptr;                                   // device view of h_sc
   double* d_path = nullptr;
   size_t path_cap = 0;
   // sharded extras

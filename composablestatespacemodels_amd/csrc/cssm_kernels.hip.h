@@ -616,6 +616,43 @@ static __global__ void k_pick(const double* __restrict__ src, size_t src_stride,
   }
 }
 
+// The end of a call, instead of device-to-host copies: (1) an ESS still pending (Scalars::pend: the last weighted observation's
+// blocks left partial sums of squared weights, nobody after it totalled them) is formed and filed; (2) the call's per-observation
+// results and the scalars the host reads (Scalars from `err` on) are written straight into host-mapped memory.  One block; the
+// host only synchronises the stream.  (Four small hipMemcpyAsync D2H behind a K = 20 series cost ~45 us, this kernel ~4.)
+static __global__ __launch_bounds__(CSSM_BLOCK) void k_finish(Scalars* __restrict__ sc, const cssm_u128* __restrict__ s2buf, uint32_t s2_stride,
+                                                              double* __restrict__ ll_t, int32_t* __restrict__ ess_t, uint32_t T, uint32_t gen,
+                                                              Scalars* __restrict__ host_sc, double* __restrict__ host_ll_t, int32_t* __restrict__ host_ess_t) {
+  __shared__ cssm_u128 s_red[CSSM_BLOCK / 64];
+  __shared__ int32_t s_ess;
+  const uint32_t pend = sc->pend, p_buf = sc->pend_buf, p_n = sc->pend_n, p_idx = sc->pend_idx, p_gen = sc->pend_gen, err = sc->err;
+  const cssm_u128 p_S = sc->pend_S;
+  int32_t ess = sc->ess;
+  if (pend && p_buf < 2u && p_n <= s2_stride) {           // (uniform)
+    cssm_u128 t2 = cssm_u128_zero();
+    const cssm_u128* pb = s2buf + (size_t)p_buf * s2_stride;
+    for (uint32_t q = threadIdx.x; q < p_n; q += CSSM_BLOCK) t2 = cssm_u128_add(t2, pb[q]);
+    t2 = block_sum_u128(t2, s_red);
+    if (threadIdx.x == 0) {
+      if (!(err & 3u) && !cssm_u128_is_zero(p_S)) ess = cssm_ess_of(p_S, t2);
+      sc->ess = ess; sc->pend = 0u;
+      if (ess_t && p_gen == gen && p_idx < T) ess_t[p_idx] = ess;
+      s_ess = ess;
+    }
+    __syncthreads();
+    ess = s_ess;
+  }
+  // per-observation results of the call (device arrays, written by the publisher blocks / k_record) -> the host's mirrors
+  if (host_ll_t) for (uint32_t s = threadIdx.x; s < T; s += CSSM_BLOCK) host_ll_t[s] = ll_t[s];
+  if (host_ess_t) for (uint32_t s = threadIdx.x; s < T; s += CSSM_BLOCK) host_ess_t[s] = (pend && p_gen == gen && s == p_idx) ? ess : ess_t[s];
+  // the scalars from `err` on, word for word; ess and pend as just settled
+  constexpr uint32_t W0 = (uint32_t)(offsetof(Scalars, err) / 4), W1 = (uint32_t)(sizeof(Scalars) / 4);
+  constexpr uint32_t WE = (uint32_t)(offsetof(Scalars, ess) / 4), WP = (uint32_t)(offsetof(Scalars, pend) / 4);
+  const uint32_t* src = reinterpret_cast<const uint32_t*>(sc);
+  uint32_t* dst = reinterpret_cast<uint32_t*>(host_sc);
+  for (uint32_t w = W0 + threadIdx.x; w < W1; w += CSSM_BLOCK) dst[w] = (w == WE) ? (uint32_t)ess : ((w == WP) ? 0u : src[w]);
+}
+
 // per-step record of results for the batch drivers
 static __global__ void k_record(const Scalars* __restrict__ sc, double* __restrict__ ll_t, int32_t* __restrict__ ess_t, uint32_t s) {
   ll_t[s] = sc->ll;

@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -97,8 +98,9 @@ static int alloc_handle(cssm_pf* pf) {
   pf->s2_stride = (uint32_t)nsums;
   HIP_TRY(hipMalloc(&pf->s2buf, 2 * nsums * sizeof(cssm_u128)));
   HIP_TRY(hipMemsetAsync(pf->s2buf, 0, 2 * nsums * sizeof(cssm_u128), pf->stream));
-  HIP_TRY(hipHostMalloc((void**)&pf->h_s2, nsums * sizeof(cssm_u128), hipHostMallocDefault));
-  HIP_TRY(hipHostMalloc((void**)&pf->h_sc, sizeof(Scalars), hipHostMallocDefault));
+  HIP_TRY(hipHostMalloc((void**)&pf->h_sc, sizeof(Scalars), hipHostMallocMapped));
+  memset(pf->h_sc, 0, sizeof(Scalars));
+  HIP_TRY(hipHostGetDevicePointer((void**)&pf->hd_sc, pf->h_sc, 0));
   // sub-unit entries past the last k_propagate block are never written and must read as zero sums
   HIP_TRY(hipMemsetAsync(pf->tileS, 0, nsums * sizeof(cssm_u128), pf->stream));
   HIP_TRY(hipMemsetAsync(pf->tileS2, 0, nsums * sizeof(cssm_u128), pf->stream));
@@ -157,7 +159,8 @@ extern "C" void cssm_pf_destroy(cssm_pf* pf) {
   for (void* p : ptrs) if (p) (void)hipFree(p);
   if (pf->h_recs) (void)hipHostFree(pf->h_recs);
   if (pf->h_sc) (void)hipHostFree(pf->h_sc);
-  if (pf->h_s2) (void)hipHostFree(pf->h_s2);
+  if (pf->h_ll_t) (void)hipHostFree(pf->h_ll_t);
+  if (pf->h_ess_t) (void)hipHostFree(pf->h_ess_t);
   for (hipEvent_t e : pf->prof_ev) (void)hipEventDestroy(e);
   if (pf->ev0) (void)hipEventDestroy(pf->ev0);
   if (pf->ev1) (void)hipEventDestroy(pf->ev1);
@@ -206,7 +209,7 @@ int cssm_launch_init(cssm_pf* pf, double t0) {
   if (rc) return rc;
   pf->cur = 0; pf->src = pf->state[0]; pf->src_stride = pf->stride; pf->anc_valid = false;
   pf->t = t0; pf->step = 0; pf->initialised = true; pf->wparity = 0;
-  pf->wmode = false; pf->pend_host = false; pf->sums_ready = false;   // (reset_scalars cleared Scalars::pend)
+  pf->wmode = false; pf->sums_ready = false;   // (reset_scalars cleared Scalars::pend)
   pf->ess_host = (int32_t)(pf->n_global < 2147483647ull ? pf->n_global : 2147483647ull);
   return CSSM_OK;
 }
@@ -344,8 +347,7 @@ static int launch_resample(cssm_pf* pf, const StepRec* d_rec, double* ll_t = nul
   HIP_TRY(hipGetLastError());
   pf->anc_valid = true;
   pf->wmode = optimistic;
-  pf->pend_host = optimistic;
-  if (optimistic) { pf->pend_par_host = s2_par; pf->s2_par ^= 1; }
+  if (optimistic) pf->s2_par ^= 1;
   return CSSM_OK;
 }
 static int launch_step(cssm_pf* pf, const StepRec* d_rec, int weighted, uint32_t step_index, double* ll_t = nullptr, int32_t* ess_t = nullptr,
@@ -364,27 +366,15 @@ int cssm_check_device_err(cssm_pf* pf, const Scalars& h) {
   (void)pf;
   return CSSM_OK;
 }
-// The handle's scalars -> *pf->h_sc (pinned), one synchronisation.  If the last enqueued weighted observation left its ESS
-// pending, the partial sums of squares of its blocks travel in the same round trip and the host totals them: the value of
-// cssm_ess_of is the one the next publisher block would compute (IEEE operations on exact integer sums).
-static int read_scalars(cssm_pf* pf) {
-  Scalars& h = *pf->h_sc;
-  HIP_TRY(hipMemcpyAsync(CSSM_SC_TAIL_ARGS(&h, pf->sc), hipMemcpyDeviceToHost, pf->stream));
-  const uint32_t n_host = pf->nunits;
-  if (pf->pend_host)
-    HIP_TRY(hipMemcpyAsync(pf->h_s2, pf->s2buf + (size_t)pf->pend_par_host * pf->s2_stride, (size_t)n_host * sizeof(cssm_u128), hipMemcpyDeviceToHost, pf->stream));
+// The end of a call: k_finish forms an ESS that is still pending, and writes the scalars the host reads (and, with T > 0, the
+// call's ll_t / ess_t) into host-mapped memory; the host synchronises the stream -- no device-to-host copy.  *pf->h_sc is valid
+// from `err` on afterwards.
+static int read_scalars(cssm_pf* pf, uint32_t T = 0, bool want_ll_t = false, bool want_ess_t = false) {
+  hipLaunchKernelGGL(k_finish, dim3(1), dim3(CSSM_BLOCK), 0, pf->stream, pf->sc, (const cssm_u128*)pf->s2buf, pf->s2_stride, pf->d_ll_t, pf->d_ess_t, T,
+                     pf->gen, pf->hd_sc, want_ll_t ? pf->hd_ll_t : (double*)nullptr, want_ess_t ? pf->hd_ess_t : (int32_t*)nullptr);
+  HIP_TRY(hipGetLastError());
   HIP_TRY(hipStreamSynchronize(pf->stream));
-  if (h.pend) {
-    if (h.pend_n > pf->s2_stride || h.pend_buf > 1u) return fail(CSSM_ESTATE, "pending ESS record is corrupt (n = %u, buffer = %u)", h.pend_n, h.pend_buf);
-    if (!pf->pend_host || (int)h.pend_buf != pf->pend_par_host || h.pend_n != n_host) {   // (a series that ended on hold: the pending observation is an earlier one)
-      HIP_TRY(hipMemcpyAsync(pf->h_s2, pf->s2buf + (size_t)h.pend_buf * pf->s2_stride, (size_t)h.pend_n * sizeof(cssm_u128), hipMemcpyDeviceToHost, pf->stream));
-      HIP_TRY(hipStreamSynchronize(pf->stream));
-    }
-    cssm_u128 t2 = cssm_u128_zero();
-    for (uint32_t q = 0; q < h.pend_n; ++q) t2 = cssm_u128_add(t2, pf->h_s2[q]);
-    if (!(h.err & 3u) && !cssm_u128_is_zero(h.pend_S)) h.ess = cssm_ess_of(h.pend_S, t2);
-  }
-  pf->ess_host = h.ess;
+  pf->ess_host = pf->h_sc->ess;
   return CSSM_OK;
 }
 
@@ -417,10 +407,16 @@ int cssm_ensure_recs(cssm_pf* pf, size_t T) {
     if (pf->d_recs) (void)hipFree(pf->d_recs);
     if (pf->d_ll_t) (void)hipFree(pf->d_ll_t);
     if (pf->d_ess_t) (void)hipFree(pf->d_ess_t);
-    pf->d_recs = nullptr; pf->d_ll_t = nullptr; pf->d_ess_t = nullptr;
+    if (pf->h_ll_t) (void)hipHostFree(pf->h_ll_t);
+    if (pf->h_ess_t) (void)hipHostFree(pf->h_ess_t);
+    pf->d_recs = nullptr; pf->d_ll_t = nullptr; pf->d_ess_t = nullptr; pf->h_ll_t = pf->hd_ll_t = nullptr; pf->h_ess_t = pf->hd_ess_t = nullptr;
     HIP_TRY(hipMalloc(&pf->d_recs, T * sizeof(StepRec)));
     HIP_TRY(hipMalloc(&pf->d_ll_t, T * 8));
     HIP_TRY(hipMalloc(&pf->d_ess_t, T * 4));
+    HIP_TRY(hipHostMalloc((void**)&pf->h_ll_t, T * 8, hipHostMallocMapped));
+    HIP_TRY(hipHostMalloc((void**)&pf->h_ess_t, T * 4, hipHostMallocMapped));
+    HIP_TRY(hipHostGetDevicePointer((void**)&pf->hd_ll_t, pf->h_ll_t, 0));
+    HIP_TRY(hipHostGetDevicePointer((void**)&pf->hd_ess_t, pf->h_ess_t, 0));
     pf->recs_cap = T;
   }
   return CSSM_OK;
@@ -525,7 +521,7 @@ extern "C" int cssm_pf_adopt(cssm_pf* pf, const double* state_dN, double ll, int
   HIP_TRY(hipMemcpyAsync(&pf->sc->ess, &ess, sizeof(int32_t), hipMemcpyHostToDevice, pf->stream));
   const uint32_t no_pend = 0u;   // (an ESS still pending from an earlier native step is superseded by the caller's)
   HIP_TRY(hipMemcpyAsync(&pf->sc->pend, &no_pend, sizeof(uint32_t), hipMemcpyHostToDevice, pf->stream));
-  pf->pend_host = false; pf->ess_host = ess;
+  pf->ess_host = ess;
   HIP_TRY(hipStreamSynchronize(pf->stream));
   pf->src = pf->state[pf->cur]; pf->src_stride = pf->stride; pf->src2 = nullptr; pf->anc_valid = false;
   return CSSM_OK;
@@ -558,6 +554,11 @@ static int run_filter_once(cssm_pf* pf, const double* t, const double* y, const 
   *retry = false;
   if (!pf || !t || !y) return fail(CSSM_EINVAL_ARG, "null argument");
   if (T < 1) return fail(CSSM_EINVAL_ARG, "empty data (the reference's minBy throws on an empty Vector)");
+  // CSSM_CALL_TIMING=1: host-side phases of the call on stderr (tools/leg_overhead.py)
+  static const bool timing = getenv("CSSM_CALL_TIMING") != nullptr;
+  const auto tp0 = std::chrono::steady_clock::now();
+  auto since = [&](std::chrono::steady_clock::time_point a) { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - a).count(); };
+  double ph_rec = 0, ph_up = 0, ph_enq = 0;
   if (pf->sharded) return fail(CSSM_ESTATE, "a sharded handle is driven through the cssm_pf_shard_* stages");
   HIP_TRY(hipSetDevice(pf->device));
   int rc = cssm_ensure_recs(pf, T);
@@ -570,7 +571,9 @@ static int run_filter_once(cssm_pf* pf, const double* t, const double* y, const 
   for (size_t s = 0; s < T; ++s) { cssm_build_rec(pf, tp, t[s], y[s], has ? has[s] : 1, base + (uint32_t)s, &pf->h_recs[s]); tp = t[s]; }
   rc = cssm_build_fsub(pf, 0, T, true);
   if (rc) return rc;
+  ph_rec = since(tp0);
   HIP_TRY(hipMemcpyAsync(pf->d_recs, pf->h_recs, T * sizeof(StepRec), hipMemcpyHostToDevice, pf->stream));
+  ph_up = since(tp0);
   if (!cont) {
     rc = cssm_launch_init(pf, t0);
     if (rc) return rc;
@@ -622,12 +625,11 @@ static int run_filter_once(cssm_pf* pf, const double* t, const double* y, const 
                            pf->d_path + (s + 1) * (size_t)d);
     }
     // the call's ONE synchronisation when no observation was held: results and scalars travel together
+    ph_enq = since(tp0);
     HIP_TRY(hipEventRecord(pf->ev1, pf->stream));
     HIP_TRY(hipGetLastError());
-    if (ll_t) HIP_TRY(hipMemcpyAsync(ll_t, pf->d_ll_t, T * 8, hipMemcpyDeviceToHost, pf->stream));
-    if (ess_t) HIP_TRY(hipMemcpyAsync(ess_t, pf->d_ess_t, T * 4, hipMemcpyDeviceToHost, pf->stream));
     if (path) HIP_TRY(hipMemcpyAsync(path, pf->d_path, (T + 1) * (size_t)d * 8, hipMemcpyDeviceToHost, pf->stream));
-    rc = read_scalars(pf);       // (totals a pending ESS on the host)
+    rc = read_scalars(pf, (uint32_t)T, ll_t != nullptr, ess_t != nullptr);   // (k_finish: a pending ESS formed, results into host-mapped memory)
     if (rc) return rc;
     const Scalars& hh = *pf->h_sc;
     if (!may_hold || !(hh.err & 64u) || (hh.err & 3u)) break;   // (NaN / unusable weights: reported below)
@@ -654,14 +656,17 @@ static int run_filter_once(cssm_pf* pf, const double* t, const double* y, const 
     s_from = sf + 1;             // (s_from == T: the loop only reads the results again)
   }
   Scalars& h = *pf->h_sc;
+  if (ll_t) memcpy(ll_t, pf->h_ll_t, T * 8);
   if (ess_t) {
-    // the last weighted observation's ESS was still pending when the series ended (nobody after it to total its squares) ...
-    if (h.pend && h.pend_gen == pf->gen && h.pend_idx < T) ess_t[h.pend_idx] = h.ess;
-    // ... and an observation without a datum reports the ESS before it (:121), which a kernel could not know yet
+    memcpy(ess_t, pf->h_ess_t, T * 4);
+    // an observation without a datum reports the ESS before it (:121), which a kernel could not know yet (the ESS of the
+    // weighted observation before it was still pending when k_record ran)
     for (size_t s = 0; s < T; ++s) if (!pf->h_recs[s].has_obs) ess_t[s] = s ? ess_t[s - 1] : ess0;
   }
   HIP_TRY(hipEventElapsedTime(&pf->last_ms, pf->ev0, pf->ev1));
   prof_collect(pf);
+  if (timing) fprintf(stderr, "cssm call T=%zu: records built %.1f us, upload enqueued %.1f, %zu steps enqueued %.1f, results back %.1f (device loop %.1f us)\n",
+                      T, ph_rec, ph_up, T, ph_enq, since(tp0), pf->last_ms * 1e3);
   pf->t = t[T - 1]; pf->step = base + (uint32_t)T;
   if ((h.err & 4u) && !(h.err & 1u) && !pf->safe_sums) { *retry = true; return CSSM_OK; }
   if (ll_out) *ll_out = h.ll;

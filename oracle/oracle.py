@@ -13,7 +13,8 @@ import subprocess
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB = os.path.join(HERE, "liboracle.so")
+# CSSM_ORACLE_LIB: another build of the same source (the sanitizer job loads oracle/liboracle_san.so, tests/test_sanitizers.py)
+LIB = os.environ.get("CSSM_ORACLE_LIB") or os.path.join(HERE, "liboracle.so")
 
 LITERAL_SUMS = 1
 TIE_LAST = 2
@@ -33,6 +34,8 @@ _lib = None
 def build(force: bool = False) -> str:
     src = os.path.join(HERE, "cssm_oracle.c")
     hdrs = [os.path.join(HERE, "..", "include", h) for h in ("cssm_numerics.h", "cssm_pf.h")]
+    if os.environ.get("CSSM_ORACLE_LIB"):
+        return LIB
     stale = force or not os.path.exists(LIB) or any(
         os.path.exists(s) and os.path.getmtime(s) > os.path.getmtime(LIB) for s in [src] + hdrs)
     if stale and os.path.exists(src):
