@@ -149,30 +149,34 @@ __device__ __forceinline__ const double* stage_log_table_finish(double v) {
   return s_logtab2;
 }
 
-// The d standard normals of global particle gid for an ordinary step or the initial draw (include/cssm_numerics.h,
-// counter layout): particles 2m and 2m+1 share stream m, particle gid owns its normals q = (gid & 1) * D + k, normal q
-// = element q&1 of block q>>1.  A particle touches ceil(D/2) blocks starting at b0; for odd D an odd particle starts
-// on the SECOND element of its first block.  Branch-free in gid, so neighbouring lanes do not diverge.
+// Normals of a stream by blocks (include/cssm_numerics.h, counter layout, contract v6): one Philox block = two Box-Muller
+// pairs = four normals; E[m] = normal m of the stream counted from block b0 on, NP pairs evaluated.
+template <int NP>
+__device__ __forceinline__ void stream_normals(uint64_t seed, uint64_t stream, uint32_t step, uint32_t tag, uint32_t b0, const double* tab,
+                                               double (&E)[2 * NP]) {
+#pragma unroll
+  for (int B = 0; B < (NP + 1) / 2; ++B) {
+    const cssm_u32x4 blk = cssm_philox_draw(seed, stream, step, tag, b0 + (uint32_t)B);
+    cssm_normal_pair64(blk.v[0], blk.v[1], tab, &E[(4 * B) % (2 * NP)], &E[(4 * B + 1) % (2 * NP)]);
+    if (2 * B + 1 < NP) cssm_normal_pair64(blk.v[2], blk.v[3], tab, &E[(4 * B + 2) % (2 * NP)], &E[(4 * B + 3) % (2 * NP)]);
+  }
+}
+
+// The d standard normals of global particle gid for an ordinary step or the initial draw: particles 2m and 2m+1 share
+// stream m, particle gid owns its normals q = (gid & 1) * D + k.  An even particle reads normals 0 .. D-1 from block 0 on; an
+// odd one normals D .. 2D-1, i.e. from block D >> 2 on with an offset of D & 3 normals into it -- a compile-time shift, so the
+// choice between the two is one select per component and neighbouring lanes do not diverge.
 template <int D>
 __device__ __forceinline__ void draw_normals(uint64_t seed, uint64_t gid, uint32_t step, uint32_t tag,
                                              const double* tab, double (&z)[D]) {
-  constexpr int NB = (D + 1) / 2;
+  constexpr int S = D & 3;                       // offset of an odd particle's first normal inside its first block
+  constexpr int NP = (D + S + 1) / 2;            // pairs that cover normals 0 .. D - 1 + S
   const bool odd = (gid & 1u) != 0u;
-  const uint32_t b0 = ((uint32_t)(gid & 1u) * (uint32_t)D) >> 1;
-  const uint64_t stream = cssm_pair_stream(gid);
-  double pe1 = 0.0;
+  const uint32_t b0 = odd ? (uint32_t)(D >> 2) : 0u;
+  double E[2 * NP];
+  stream_normals<NP>(seed, cssm_pair_stream(gid), step, tag, b0, tab, E);
 #pragma unroll
-  for (int p = 0; p < NB; ++p) {
-    double e0, e1;
-    cssm_normal_pair(cssm_philox_draw(seed, stream, step, tag, b0 + (uint32_t)p), tab, &e0, &e1);
-    if (D % 2 == 0) {
-      z[2 * p] = e0; z[(2 * p + 1) % D] = e1;
-    } else {   // even particle: element j of its blocks is component j; odd particle: component j - 1
-      if (p > 0) z[(2 * p - 1 + D) % D] = odd ? e0 : pe1;
-      z[2 * p] = odd ? e1 : e0;
-      pe1 = e1;
-    }
-  }
+  for (int k = 0; k < D; ++k) z[k] = odd ? E[k + S] : E[k];
 }
 
 // One transition of component k (model/Sde.scala:86-95,114-123,139-150; :30-43 for Euler); components are independent.
@@ -202,54 +206,54 @@ __device__ __forceinline__ void transition(const ModelK& mk, const StepRec* __re
   for (int k = 0; k < D; ++k) transition_one<D>(mk, rec, dt, k, x[k], z[k]);
 }
 
-// Ordinary step of the two particles of a pair (2m, 2m+1): D Philox blocks + Box-Muller pairs give their 2 D normals,
-// each fed to its component as soon as it exists (normal q -> particle q / D, component q % D).
+// Ordinary step of the two particles of a pair (2m, 2m+1): ceil(D / 2) Philox blocks give their 2 D normals, each fed to
+// its component as soon as it exists (normal q -> particle q / D, component q % D).
 template <int D>
 __device__ __forceinline__ void propagate_pair(const ModelK& mk, const StepRec* __restrict__ rec, double dt, uint64_t seed,
                                                uint64_t gid_even, uint32_t step, const double* tab, double (&xa)[D], double (&xb)[D]) {
   const uint64_t stream = cssm_pair_stream(gid_even);
+  auto feed = [&](int q, double e) {            // (q is a compile-time constant wherever this is called)
+    if (q < D) transition_one<D>(mk, rec, dt, q, xa[q % D], e);
+    else if (q < 2 * D) transition_one<D>(mk, rec, dt, q - D, xb[(q - D + D) % D], e);
+  };
 #pragma unroll
-  for (int p = 0; p < D; ++p) {
+  for (int B = 0; B < (D + 1) / 2; ++B) {
+    const cssm_u32x4 blk = cssm_philox_draw(seed, stream, step, CSSM_STREAM_STEP, (uint32_t)B);
     double e0, e1;
-    cssm_normal_pair(cssm_philox_draw(seed, stream, step, CSSM_STREAM_STEP, (uint32_t)p), tab, &e0, &e1);
-    if (2 * p < D) transition_one<D>(mk, rec, dt, 2 * p, xa[(2 * p) % D], e0);
-    else transition_one<D>(mk, rec, dt, 2 * p - D, xb[(2 * p - D + D) % D], e0);
-    if (2 * p + 1 < D) transition_one<D>(mk, rec, dt, 2 * p + 1, xa[(2 * p + 1) % D], e1);
-    else transition_one<D>(mk, rec, dt, 2 * p + 1 - D, xb[(2 * p + 1 - D + D) % D], e1);
+    cssm_normal_pair64(blk.v[0], blk.v[1], tab, &e0, &e1);
+    feed(4 * B, e0); feed(4 * B + 1, e1);
+    if (2 * B + 1 < D) {
+      cssm_normal_pair64(blk.v[2], blk.v[3], tab, &e0, &e1);
+      feed(4 * B + 2, e0); feed(4 * B + 3, e1);
+    }
   }
 }
-// The pair's normals on their own (k_propagate's single-tile instantiations draw them while the gathered rows travel):
-// half H = 0 / 1 of the pair's D Philox blocks, z[2 p] / z[2 p + 1] = the elements of block p -- normal q of the pair goes
-// to particle q / D, component q % D, exactly as in propagate_pair.
+// The pair's normals on their own (k_propagate's single-tile instantiations draw them while the gathered rows travel): half
+// H = 0 / 1 of the pair's ceil(D / 2) Philox blocks, z[q] = normal q of the pair (-> particle q / D, component q % D, exactly as in
+// propagate_pair).  PairHalf<D>::n0 normals come with half 0.
+template <int D> struct PairHalf {
+  static constexpr int nblk = (D + 1) / 2;                       // blocks of the pair
+  static constexpr int b_split = nblk / 2;                       // half 0 = blocks [0, b_split), half 1 = [b_split, nblk)
+  static constexpr int n0 = (4 * b_split < 2 * D) ? 4 * b_split : 2 * D;
+};
 template <int D, int H>
 __device__ __forceinline__ void normals_pair_half(uint64_t seed, uint64_t gid_even, uint32_t step, const double* tab, double* z) {
   const uint64_t stream = cssm_pair_stream(gid_even);
-  constexpr int P0 = H == 0 ? 0 : D / 2, P1 = H == 0 ? D / 2 : D;   // (the gathered rows take longer than the indices: the larger half)
+  constexpr int B0 = H == 0 ? 0 : PairHalf<D>::b_split, B1 = H == 0 ? PairHalf<D>::b_split : PairHalf<D>::nblk;
 #pragma unroll
-  for (int p = P0; p < P1; ++p) cssm_normal_pair(cssm_philox_draw(seed, stream, step, CSSM_STREAM_STEP, (uint32_t)p), tab, &z[2 * p], &z[2 * p + 1]);
+  for (int B = B0; B < B1; ++B) {
+    const cssm_u32x4 blk = cssm_philox_draw(seed, stream, step, CSSM_STREAM_STEP, (uint32_t)B);
+    cssm_normal_pair64(blk.v[0], blk.v[1], tab, &z[4 * B], &z[4 * B + 1]);
+    if (2 * B + 1 < D) cssm_normal_pair64(blk.v[2], blk.v[3], tab, &z[4 * B + 2], &z[4 * B + 3]);
+  }
 }
-// The same for ONE particle of either parity (threads that do not own whole pairs): ceil(D/2) blocks.
+// The same for ONE particle of either parity (threads that do not own whole pairs)
 template <int D>
 __device__ __forceinline__ void propagate_one(const ModelK& mk, const StepRec* __restrict__ rec, double dt, uint64_t seed,
                                               uint64_t gid, uint32_t step, const double* tab, double (&x)[D]) {
-  constexpr int NB = (D + 1) / 2;
-  const bool odd = (gid & 1u) != 0u;
-  const uint32_t b0 = ((uint32_t)(gid & 1u) * (uint32_t)D) >> 1;
-  const uint64_t stream = cssm_pair_stream(gid);
-  double pe1 = 0.0;
-#pragma unroll
-  for (int p = 0; p < NB; ++p) {
-    double e0, e1;
-    cssm_normal_pair(cssm_philox_draw(seed, stream, step, CSSM_STREAM_STEP, b0 + (uint32_t)p), tab, &e0, &e1);
-    if (D % 2 == 0) {
-      transition_one<D>(mk, rec, dt, 2 * p, x[2 * p], e0);
-      transition_one<D>(mk, rec, dt, (2 * p + 1) % D, x[(2 * p + 1) % D], e1);
-    } else {
-      if (p > 0) transition_one<D>(mk, rec, dt, (2 * p - 1 + D) % D, x[(2 * p - 1 + D) % D], odd ? e0 : pe1);
-      transition_one<D>(mk, rec, dt, 2 * p, x[2 * p], odd ? e1 : e0);
-      pe1 = e1;
-    }
-  }
+  double z[D];
+  draw_normals<D>(seed, gid, step, CSSM_STREAM_STEP, tab, z);
+  transition<D>(mk, rec, dt, x, z);
 }
 
 // gamma = f(x, t): per-leaf dot product, leaves summed left-nested (model/Model.scala:122-128,217-225,271)

@@ -28,7 +28,7 @@ int cssm_fail(int code, const char* fmt, ...) {
 #define fail cssm_fail
 
 extern "C" const char* cssm_last_error(void) { return g_err.c_str(); }
-extern "C" const char* cssm_version(void) { return "cssm_pf 0.4 (gfx950, numerics contract v5)"; }
+extern "C" const char* cssm_version(void) { return "cssm_pf 0.4 (gfx950, numerics contract v6)"; }
 
 // ------------------------------------------------------------------------------------ model
 
@@ -316,7 +316,7 @@ extern "C" int cssm_pmmh_run(cssm_pf* pf, const cssm_model_desc* desc, const dou
   for (size_t it = 0; it < n_iters; ++it) {
     for (size_t j = 0; j < n_theta; j += 2) {                  // propParams <- proposal(s.params)
       double z0, z1;
-      cssm_normal_pair(cssm_philox_draw(seed, it, (uint32_t)(j / 2), CSSM_STREAM_HOST, 0), CSSM_LOG_TAB, &z0, &z1);
+      cssm_normal_pair_of(seed, it, (uint32_t)(j / 2), CSSM_STREAM_HOST, 0, CSSM_LOG_TAB, &z0, &z1);
       prop[j] = cur[j] + sd * z0;
       if (j + 1 < n_theta) prop[j + 1] = cur[j + 1] + sd * z1;
     }

@@ -206,8 +206,8 @@ __device__ __forceinline__ void propagate_range(
       // the indices are consumed BEHIND these normals: an empty asm that takes both pins the order (the compiler otherwise
       // hoists the address arithmetic, and with it the wait for the load, above the Philox rounds)
 #pragma unroll
-      for (int q = 0; q < 2 * (D / 2); ++q) asm volatile("" : "+v"(zz[q % (ONE ? IT * D : 1)]), "+v"(jp[0]));
-      if (D / 2 == 0) asm volatile("" : "+v"(jp[0]));
+      for (int q = 0; q < PairHalf<D>::n0; ++q) asm volatile("" : "+v"(zz[q % (ONE ? IT * D : 1)]), "+v"(jp[0]));
+      if (PairHalf<D>::n0 == 0) asm volatile("" : "+v"(jp[0]));
     }
     unpack_idx(base, jp, jn);
     if (STAGE) {
@@ -217,7 +217,7 @@ __device__ __forceinline__ void propagate_range(
         if (pre_jp != nullptr) normals_pair_half<D, 0>(seed, gid0 + base + threadIdx.x * IT, step, tab, zz);
         normals_pair_half<D, 1>(seed, gid0 + base + threadIdx.x * IT, step, tab, zz);
 #pragma unroll
-        for (int q = (pre_jp != nullptr) ? 0 : 2 * (D / 2); q < 2 * D; ++q) asm volatile("" : "+v"(zz[q % (ONE ? IT * D : 1)]));
+        for (int q = (pre_jp != nullptr) ? 0 : PairHalf<D>::n0; q < 2 * D; ++q) asm volatile("" : "+v"(zz[q % (ONE ? IT * D : 1)]));
       } else if (ONE) {                                           // one particle per thread: its D normals
         double z1[D];
         draw_normals<D>(seed, gid0 + base + threadIdx.x, step, CSSM_STREAM_STEP, tab, z1);
@@ -275,15 +275,23 @@ __device__ __forceinline__ void propagate_range(
           lw[r] = g - g;
         } else {
           double haz = 0.0, carry = 0.0;
+          uint32_t held_a = 0u, held_b = 0u;     // the second half of the Philox block in use (contract v6: a block = two pairs)
           const double* fsub_obs = (fsub != nullptr) ? fsub + rec->fsub_off : nullptr;
           for (int s = 0; s < nsub; ++s) {   // simInitStream(...).take(n), :193-194
-            // normal number q = s*D + k: even q opens Box-Muller pair q>>1 (second element kept for q+1)
+            // normal number q = s*D + k: even q opens Box-Muller pair q>>1 (second element kept for q+1); pair P is half P & 1
+            // of Philox block P >> 1: q = 0 mod 4 draws a block, q = 2 mod 4 uses the half it kept
 #pragma unroll
             for (int k = 0; k < D; ++k) {
               const uint32_t q = (uint32_t)s * D + k;
               if ((q & 1u) == 0u) {
                 double z0, z1;
-                cssm_normal_pair(cssm_philox_draw(seed, gid, step, CSSM_STREAM_STEP, q >> 1), tab, &z0, &z1);
+                if ((q & 2u) == 0u) {
+                  const cssm_u32x4 blk = cssm_philox_draw(seed, gid, step, CSSM_STREAM_STEP, q >> 2);
+                  held_a = blk.v[2]; held_b = blk.v[3];
+                  cssm_normal_pair64(blk.v[0], blk.v[1], tab, &z0, &z1);
+                } else {
+                  cssm_normal_pair64(held_a, held_b, tab, &z0, &z1);
+                }
                 z[k] = z0; carry = z1;
               } else {
                 z[k] = carry;

@@ -14,7 +14,8 @@
  * section 7 ("hard parts") names this; the contract removes it.
  *
  * What the contract fixes:
- *   1. Philox4x32-7 (Salmon et al., SC'11; seven rounds since contract v5), counter layout cssm_philox_ctr() below.  It
+ *   1. Philox4x32-7 (Salmon et al., SC'11; seven rounds since contract v5; since v6 one block yields TWO Box-Muller pairs),
+ *      counter layout below.  It
  *      replaces the reference's unseeded global generators (breeze Rand at
  *      model/Sde.scala:13, scala.util.Random at model/Resampling.scala:66,152).
  *   2. cssm_exp / cssm_log / cssm_sincos2pi / Box-Muller: fixed polynomial evaluations
@@ -175,24 +176,27 @@ CSSM_HD cssm_u32x4 cssm_philox4x32(cssm_u32x4 c, uint32_t k0, uint32_t k1) { CSS
 
 /*
  * Counter layout: word0/1 = stream id, word2 = step (observation index, 0-based; 0 for init),
- * word3 = tag<<28 | block.  One Philox block yields one Box-Muller PAIR of normals.  Key = the 64-bit seed.
+ * word3 = tag<<28 | block.  Key = the 64-bit seed.  One Philox block yields TWO Box-Muller pairs (contract v6: pair P of a
+ * stream is half P & 1 of its block P >> 1 -- words 0, 1 or words 2, 3; cssm_normal_pair64), i.e. four normals: normal q of
+ * a stream is element q & 1 of pair q >> 1.  (Up to v5 a block fed one pair: 53 + 53 of its 128 bits.  Philox is a quarter
+ * of the fused kernel's instructions; a pair now takes 40 + 24 bits, see cssm_normal_pair64.)
  * Stream ids are GLOBAL, so results do not depend on how particles are sharded over GPUs:
  *   - ordinary filter steps (CSSM_STREAM_STEP) and the initial draw (CSSM_STREAM_INIT): the two particles 2m and
  *     2m+1 share stream m = gid >> 1; of its normals, particle gid owns numbers q = (gid & 1) * d + k
- *     (k = latent component in Tree.flatten order) and normal q is element q&1 of block q>>1 -- no variate is
- *     generated twice and at most one per PAIR OF PARTICLES is unused (a thread that owns both particles of a pair
- *     evaluates d blocks for them; a model of odd dimension d would otherwise waste one normal per particle);
- *   - LGCP steps: stream id = gid, normal number q = substep * d + k, element q&1 of block q>>1;
- *   - resampling uniforms, sampleOne, host-side PMMH draws: see the stream tags above.
+ *     (k = latent component in Tree.flatten order) -- no variate is generated twice (a thread that owns both particles
+ *     of a pair evaluates ceil(d / 2) blocks for their 2 d normals);
+ *   - LGCP steps: stream id = gid, normal number q = substep * d + k;
+ *   - resampling uniforms, sampleOne, host-side PMMH draws: see the stream tags above (PMMH proposal pair j of
+ *     iteration `it`: half 0 of the block of (stream it, step j)).
  */
 CSSM_HD uint64_t cssm_pair_stream(uint64_t gid) { return gid >> 1; }
 CSSM_HD uint32_t cssm_pair_first(uint64_t gid, int d) { return (uint32_t)(gid & 1u) * (uint32_t)d; } /* q of component 0 */
-CSSM_HD cssm_u32x4 cssm_philox_draw(uint64_t seed, uint64_t gid, uint32_t step, uint32_t tag, uint32_t pair) {
+CSSM_HD cssm_u32x4 cssm_philox_draw(uint64_t seed, uint64_t gid, uint32_t step, uint32_t tag, uint32_t block) {
   cssm_u32x4 c;
   c.v[0] = (uint32_t)gid;
   c.v[1] = (uint32_t)(gid >> 32);
   c.v[2] = step;
-  c.v[3] = (tag << 28) | (pair & 0x0FFFFFFFu);
+  c.v[3] = (tag << 28) | (block & 0x0FFFFFFFu);
   return cssm_philox4x32(c, (uint32_t)seed, (uint32_t)(seed >> 32));
 }
 
@@ -567,11 +571,15 @@ CSSM_HD double cssm_seasonal_phase(double a, double t, double period) {
 
 /* ------------------------------------------------------------------ Box-Muller */
 
-/* Two standard normals from one Philox block: r = sqrt(-2 log u1), (r cos, r sin)(2 pi u2).
- * `tab` = CSSM_LOG_TAB (host) or its copy in LDS (kernels). */
-CSSM_HD void cssm_normal_pair(cssm_u32x4 b, const double* tab, double* z0, double* z1) {
-  double u1 = cssm_u01_open0(b.v[0], b.v[1]);
-  double u2 = cssm_u01(b.v[2], b.v[3]);
+/* Two standard normals from HALF a Philox block (two 32-bit words a, b): r = sqrt(-2 log u1), (r cos, r sin)(2 pi u2).
+ *   u1 = (a * 2^8 + (b & 255) + 1) * 2^-40 in (0, 1]: 40 bits for the radius -- the largest |z| is sqrt(80 ln 2) = 7.45
+ *        (a 53-bit uniform reaches 8.57; the tail beyond 7.45 has probability 9e-14 per variate: one in ~400 series of
+ *        2^24 particles x 500 observations x 3 components would have drawn a single such value);
+ *   u2 = (b >> 8) * 2^-24 in [0, 1): 24 bits for the angle (1.7e7 directions).
+ * Both conversions are exact.  `tab` = CSSM_LOG_TAB (host) or its copy in LDS (kernels). */
+CSSM_HD void cssm_normal_pair64(uint32_t a, uint32_t b, const double* tab, double* z0, double* z1) {
+  const double u1 = cssm_fma((double)a, 0x1.0p-32, (double)((b & 255u) + 1u) * 0x1.0p-40);
+  const double u2 = (double)(b >> 8) * 0x1.0p-24;
   double t = -2.0 * cssm_log_unit(u1, tab);
   t = (t < 0.0) ? 0.0 : t; /* log_unit(x <= 1) <= 0 by construction; the clamp documents it */
   double r = cssm_sqrt(t);
@@ -579,6 +587,15 @@ CSSM_HD void cssm_normal_pair(cssm_u32x4 b, const double* tab, double* z0, doubl
   cssm_sincos2pi(u2, &sn, &cs);
   *z0 = r * cs;
   *z1 = r * sn;
+}
+/* pair `half` (0 / 1) of a block, and pair number `pair` of a stream (host code, the oracle; kernels evaluate a block once
+ * for both of its pairs) */
+CSSM_HD void cssm_normal_pair_half(cssm_u32x4 blk, int half, const double* tab, double* z0, double* z1) {
+  cssm_normal_pair64(half ? blk.v[2] : blk.v[0], half ? blk.v[3] : blk.v[1], tab, z0, z1);
+}
+CSSM_HD void cssm_normal_pair_of(uint64_t seed, uint64_t stream, uint32_t step, uint32_t tag, uint32_t pair, const double* tab,
+                                 double* z0, double* z1) {
+  cssm_normal_pair_half(cssm_philox_draw(seed, stream, step, tag, pair >> 1), (int)(pair & 1u), tab, z0, z1);
 }
 
 /* ------------------------------------------------------------------ lgamma(k+1), integer k */

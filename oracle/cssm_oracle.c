@@ -94,14 +94,17 @@ typedef struct oracle_pf oracle_pf;
 static double o_exp(const oracle_pf* pf, double x) { return (pf->flags & ORACLE_LIBM) ? exp(x) : cssm_exp(x); }
 static double o_log(const oracle_pf* pf, double x) { return (pf->flags & ORACLE_LIBM) ? log(x) : cssm_log(x); }
 
-static void o_normal_pair(const oracle_pf* pf, cssm_u32x4 b, double* z0, double* z1) {
+/* pair number `pair` of stream (gid, step, tag): half pair & 1 of block pair >> 1 (include/cssm_numerics.h, counter layout) */
+static void o_normal_pair(const oracle_pf* pf, uint64_t gid, uint32_t step, uint32_t tag, uint32_t pair, double* z0, double* z1) {
   if (pf->flags & ORACLE_LIBM) {
-    double u1 = cssm_u01_open0(b.v[0], b.v[1]), u2 = cssm_u01(b.v[2], b.v[3]);
+    const cssm_u32x4 blk = cssm_philox_draw(pf->seed, gid, step, tag, pair >> 1);
+    const uint32_t a = (pair & 1u) ? blk.v[2] : blk.v[0], b = (pair & 1u) ? blk.v[3] : blk.v[1];
+    double u1 = cssm_fma((double)a, 0x1.0p-32, (double)((b & 255u) + 1u) * 0x1.0p-40), u2 = (double)(b >> 8) * 0x1.0p-24;
     double r = sqrt(-2.0 * log(u1));
     *z0 = r * cos(6.283185307179586476925 * u2);
     *z1 = r * sin(6.283185307179586476925 * u2);
   } else {
-    cssm_normal_pair(b, CSSM_LOG_TAB, z0, z1);
+    cssm_normal_pair_of(pf->seed, gid, step, tag, pair, CSSM_LOG_TAB, z0, z1);
   }
 }
 
@@ -219,7 +222,7 @@ static void draw_normals(const oracle_pf* pf, uint64_t gid, uint32_t step, uint3
   for (int k = 0; k < pf->d; ++k) {
     uint32_t q = sub * (uint32_t)pf->d + (uint32_t)k;
     double z0, z1;
-    o_normal_pair(pf, cssm_philox_draw(pf->seed, gid, step, tag, q >> 1), &z0, &z1);
+    o_normal_pair(pf, gid, step, tag, q >> 1, &z0, &z1);
     z[k] = (q & 1u) ? z1 : z0;
   }
 }
@@ -231,7 +234,7 @@ static void draw_normals_paired(const oracle_pf* pf, uint64_t gid, uint32_t step
   for (int k = 0; k < pf->d; ++k) {
     uint32_t q = q0 + (uint32_t)k;
     double z0, z1;
-    o_normal_pair(pf, cssm_philox_draw(pf->seed, cssm_pair_stream(gid), step, tag, q >> 1), &z0, &z1);
+    o_normal_pair(pf, cssm_pair_stream(gid), step, tag, q >> 1, &z0, &z1);
     z[k] = (q & 1u) ? z1 : z0;
   }
 }
@@ -818,7 +821,7 @@ int oracle_pmmh_run(oracle_pf* pf, cssm_model_desc* desc, const double* theta0, 
   for (size_t it = 0; it < n_iters && !rc; ++it) {
     for (size_t j = 0; j < n_theta; j += 2) {                   /* proposal(s.params) */
       double z0, z1;
-      cssm_normal_pair(cssm_philox_draw(seed, it, (uint32_t)(j / 2), CSSM_STREAM_HOST, 0), CSSM_LOG_TAB, &z0, &z1);
+      cssm_normal_pair_of(seed, it, (uint32_t)(j / 2), CSSM_STREAM_HOST, 0, CSSM_LOG_TAB, &z0, &z1);
       prop[j] = cur[j] + sd * z0;
       if (j + 1 < n_theta) prop[j + 1] = cur[j + 1] + sd * z1;
     }
@@ -860,7 +863,7 @@ void oracle_c_philox_contract(const uint32_t ctr[4], const uint32_t key[2], uint
   memcpy(out, c.v, 16);
 }
 void oracle_c_normals(uint64_t seed, uint64_t gid, uint32_t step, uint32_t tag, uint32_t pair, double* z2) {
-  cssm_normal_pair(cssm_philox_draw(seed, gid, step, tag, pair), CSSM_LOG_TAB, &z2[0], &z2[1]);
+  cssm_normal_pair_of(seed, gid, step, tag, pair, CSSM_LOG_TAB, &z2[0], &z2[1]);
 }
 void oracle_c_log_unit_v(const double* x, double* y, size_t n) { for (size_t i = 0; i < n; ++i) y[i] = cssm_log_unit(x[i], CSSM_LOG_TAB); }
 double oracle_c_lgamma_kp1(long long k) { return cssm_lgamma_kp1(k); }
@@ -883,7 +886,7 @@ void oracle_c_paired_normals_v(uint64_t seed, uint64_t gid0, uint32_t step, uint
     const uint32_t q0 = cssm_pair_first(gid, d);
     for (int k = 0; k < d; ++k) {
       double z0, z1;
-      cssm_normal_pair(cssm_philox_draw(seed, cssm_pair_stream(gid), step, tag, (q0 + (uint32_t)k) >> 1), CSSM_LOG_TAB, &z0, &z1);
+      cssm_normal_pair_of(seed, cssm_pair_stream(gid), step, tag, (q0 + (uint32_t)k) >> 1, CSSM_LOG_TAB, &z0, &z1);
       z[i * (size_t)d + k] = ((q0 + (uint32_t)k) & 1u) ? z1 : z0;
     }
   }
@@ -891,5 +894,5 @@ void oracle_c_paired_normals_v(uint64_t seed, uint64_t gid0, uint32_t step, uint
 void oracle_c_log_v(const double* x, double* y, size_t n) { for (size_t i = 0; i < n; ++i) y[i] = cssm_log(x[i]); }
 void oracle_c_sincos2pi_v(const double* u, double* s, double* c, size_t n) { for (size_t i = 0; i < n; ++i) cssm_sincos2pi(u[i], &s[i], &c[i]); }
 void oracle_c_normals_v(uint64_t seed, uint64_t gid0, uint32_t step, uint32_t tag, uint32_t pair, double* z, size_t n) {
-  for (size_t i = 0; i < n; ++i) cssm_normal_pair(cssm_philox_draw(seed, gid0 + i, step, tag, pair), CSSM_LOG_TAB, &z[2 * i], &z[2 * i + 1]);
+  for (size_t i = 0; i < n; ++i) cssm_normal_pair_of(seed, gid0 + i, step, tag, pair, CSSM_LOG_TAB, &z[2 * i], &z[2 * i + 1]);
 }
