@@ -118,6 +118,19 @@ CSSM_HD double cssm_fma_k(double a, double b, double k) {
 #endif
 }
 
+/* fma(a, b, k) pinned, on the device, to ONE three-address v_fma_f64 with the coefficient k in a vector register: for some call
+ * sites inside the fused kernel the compiler otherwise emits v_mov_b64 + v_fmac_f64 per Horner step (the two-address form needs
+ * the addend in the destination, and the coefficient is still live).  The same IEEE operation everywhere. */
+CSSM_HD double cssm_fma_kv(double a, double b, double k) {
+#if CSSM_DEVICE_FORM
+  double d;
+  __asm__("v_fma_f64 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(k));
+  return d;
+#else
+  return __builtin_fma(a, b, k);
+#endif
+}
+
 /* Round-to-nearest-even of t (|t| < 2^31) by the shifter trick: adding 1.5 * 2^52 leaves the integer in the low
  * mantissa bits (ulp = 1), in two's complement.  Plain IEEE additions: the same on every machine. */
 #define CSSM_SHIFTER 0x1.8p52
@@ -377,21 +390,22 @@ CSSM_HD double cssm_exp(double x) {
   double r = cssm_fma(-kd, LN2_HI, xc);
   r = cssm_fma(-kd, LN2_LO, r);
   double p = 1.0 / 6227020800.0; /* 1/13! */
-  p = cssm_fma_k(p, r, 1.0 / 479001600.0);
-  p = cssm_fma_k(p, r, 1.0 / 39916800.0);
-  p = cssm_fma_k(p, r, 1.0 / 3628800.0);
-  p = cssm_fma_k(p, r, 1.0 / 362880.0);
-  p = cssm_fma_k(p, r, 1.0 / 40320.0);
-  p = cssm_fma_k(p, r, 1.0 / 5040.0);
-  p = cssm_fma_k(p, r, 1.0 / 720.0);
-  p = cssm_fma_k(p, r, 1.0 / 120.0);
-  p = cssm_fma_k(p, r, 1.0 / 24.0);
-  p = cssm_fma_k(p, r, 1.0 / 6.0);
+  p = cssm_fma_kv(p, r, 1.0 / 479001600.0);
+  p = cssm_fma_kv(p, r, 1.0 / 39916800.0);
+  p = cssm_fma_kv(p, r, 1.0 / 3628800.0);
+  p = cssm_fma_kv(p, r, 1.0 / 362880.0);
+  p = cssm_fma_kv(p, r, 1.0 / 40320.0);
+  p = cssm_fma_kv(p, r, 1.0 / 5040.0);
+  p = cssm_fma_kv(p, r, 1.0 / 720.0);
+  p = cssm_fma_kv(p, r, 1.0 / 120.0);
+  p = cssm_fma_kv(p, r, 1.0 / 24.0);
+  p = cssm_fma_kv(p, r, 1.0 / 6.0);
   p = cssm_fma(p, r, 0.5);
   p = cssm_fma(p, r, 1.0);
   p = cssm_fma(p, r, 1.0);
+  /* x > 709.782712893384 (= 1024 ln 2): k = 1024 and r >= 0, so p >= 1 and the scaling overflows to +inf by itself in both
+   * forms of cssm_scale2 -- no select needed (there was one until round 3; it never changed a value) */
   double res = cssm_scale2(p, k);
-  res = (x > 709.782712893384) ? cssm_inf() : res;
   res = (x < -708.0) ? 0.0 : res;
   res = (x != x) ? x : res;
   return res;
@@ -403,15 +417,6 @@ CSSM_HD double cssm_exp(double x) {
  * pinned to one three-address v_fma_f64 each with the coefficient in a vector register -- in the fused kernel the compiler
  * otherwise emits v_mov_b64 + v_fmac_f64 per step for THIS call (ten copies per weight; the exp of the Poisson density a few
  * lines earlier, same source, gets plain v_fma_f64). */
-CSSM_HD double cssm_fma_kv(double a, double b, double k) {
-#if CSSM_DEVICE_FORM
-  double d;
-  __asm__("v_fma_f64 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(k));
-  return d;
-#else
-  return __builtin_fma(a, b, k);
-#endif
-}
 CSSM_HD double cssm_exp_le0(double a) {
   const double LOG2E = 1.44269504088896338700e+00;
   const double LN2_HI = 6.93147180369123816490e-01;
