@@ -91,6 +91,7 @@ struct cssm_pf : HostModel {
   uint32_t* d_need = nullptr;  // per observation: rows the exchange needed (diagnostics of cssm_pf_shard_status; zero since the
   size_t need_cap = 0;         //   two-collective exchange that recorded them was removed)
   bool series = false;         // records of a whole series are resident (cssm_pf_shard_begin / _continue)
+  bool want_path = false;      // sharded `filter`: record sampleOne's pick after every observation whose slot this rank owns
   uint32_t rec_base = 0;       // observation index (pf->step) of the resident series' first record: 0 after _begin, the filter's
                                //   observation count so far after _continue
   struct Snap { int cur; const double* src; size_t src_stride; const double* src2; size_t src2_stride; uint32_t n_split; bool anc_valid, last_optimistic; uint32_t step; double t; };

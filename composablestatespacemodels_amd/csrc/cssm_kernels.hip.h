@@ -339,7 +339,8 @@ __device__ __forceinline__ void offspring_body(const double* __restrict__ logw, 
     // (Round 2 took two block-wide sums with eight masked 128-bit adds per thread each: a third of the kernel's
     //  instructions at N = 2^20, where a block has one tile.)
     const uint32_t qlim = unit * (uint32_t)split;
-    const uint32_t tq = E ? qlim / E : 0u, rq = E ? qlim - tq * E : 0u;     // (uniform)
+    const uint32_t Ed = E ? E : 1u;                                          // (E >= 1 here: SELF; the guard is for the other instantiations)
+    const uint32_t tq = qlim / Ed, rq = qlim - tq * Ed;                      // (uniform)
     cssm_u128 own = cssm_u128_zero(), part = cssm_u128_zero();
 #pragma unroll
     for (int k = 0; k < UPRE; ++k) {     // (upre[k] is zero beyond E and beyond nsub)

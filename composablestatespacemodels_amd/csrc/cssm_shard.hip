@@ -86,6 +86,60 @@ __global__ void k_adopt_remote(const double* __restrict__ recv, long long m, int
 
 static int shard_prepare_step(cssm_pf* pf, const StepRec* d_rec, int weighted, uint64_t* sums5_dev);
 static int bounded_sync(cssm_pf* pf);
+static int shard_check(cssm_pf* pf);
+
+// ---- `filter` on shards (model/ParticleFilter.scala:152-158): after every observation sampleOne picks ONE particle of the
+// whole cloud, uniformly by GLOBAL slot (Resampling.scala:151-154; the index is a function of seed and observation: every rank
+// computes the same one) -- the rank that owns the slot records the state it holds, rows of the others stay zero, and the
+// caller combines the ranks' paths (exactly one of them is non-zero per row).
+__global__ void k_pick_shard(const double* __restrict__ src, size_t src_stride, const uint32_t* __restrict__ anc, const double* __restrict__ src2,
+                             size_t src2_stride, uint32_t n_split, uint64_t idx, int d, double* __restrict__ out_row) {
+  const int k = threadIdx.x;
+  if (k >= d) return;
+  const size_t j = anc ? (size_t)anc[idx] : (size_t)idx;
+  out_row[k] = (src2 && j >= n_split)
+      ? (src2_stride == 0 ? src2[(size_t)(j - n_split) * (size_t)(d + 1) + k] : src2[(size_t)k * src2_stride + (j - n_split)])
+      : src[(size_t)k * src_stride + j];
+}
+static int path_prepare(cssm_pf* pf, size_t T) {
+  if (!pf->want_path) return CSSM_OK;
+  const size_t need = (T + 1) * (size_t)pf->d;
+  if (pf->path_cap < need) {
+    HIP_TRY(hipStreamSynchronize(pf->stream));
+    if (pf->d_path) (void)hipFree(pf->d_path);
+    pf->d_path = nullptr; pf->path_cap = 0;
+    HIP_TRY(hipMalloc(&pf->d_path, need * 8));
+    pf->path_cap = need;
+  }
+  HIP_TRY(hipMemsetAsync(pf->d_path, 0, need * 8, pf->stream));
+  return CSSM_OK;
+}
+// row `row` of the path <- the current cloud's particle at GLOBAL slot `slot`, if this rank owns it
+static void path_record(cssm_pf* pf, size_t row, uint64_t slot) {
+  if (!pf->want_path || !pf->d_path || slot < pf->first || slot >= pf->first + pf->n) return;
+  hipLaunchKernelGGL(k_pick_shard, dim3(1), dim3(64), 0, pf->stream, pf->src, pf->src_stride, (const uint32_t*)(pf->anc_valid ? pf->anc : nullptr),
+                     pf->anc_valid ? pf->src2 : (const double*)nullptr, pf->src2_stride, pf->n_split, slot - pf->first, pf->d, pf->d_path + row * (size_t)pf->d);
+}
+// after observation (record) s of the resident series has been propagated and, if weighted, resampled
+static void path_after(cssm_pf* pf, size_t s) { if (pf->want_path) path_record(pf, s + 1, (uint64_t)pf->h_recs[s].pick); }
+
+extern "C" int cssm_pf_shard_want_path(cssm_pf* pf, int on) {
+  int rc = shard_check(pf);
+  if (rc) return rc;
+  pf->want_path = on != 0;
+  return CSSM_OK;
+}
+extern "C" int cssm_pf_shard_get_path(cssm_pf* pf, double* out_host, size_t T) {
+  int rc = shard_check(pf);
+  if (rc) return rc;
+  if (!out_host) return fail(CSSM_EINVAL_ARG, "null argument");
+  if (!pf->want_path || !pf->d_path || (T + 1) * (size_t)pf->d > pf->path_cap) return fail(CSSM_ESTATE, "no path of %zu observations was recorded (cssm_pf_shard_want_path before the series)", T);
+  rc = bounded_sync(pf);
+  if (rc) return rc;
+  HIP_TRY(hipMemcpy(out_host, pf->d_path, (T + 1) * (size_t)pf->d * 8, hipMemcpyDeviceToHost));
+  return CSSM_OK;
+}
+static int bounded_sync(cssm_pf* pf);
 // record of the step propagated last: a ring of 64 for streaming steps, the whole series after shard_begin
 static size_t last_rec_slot(const cssm_pf* pf) { return pf->series ? (size_t)(pf->step - 1 - pf->rec_base) : (size_t)((pf->step - 1) % 64); }
 
@@ -269,6 +323,13 @@ extern "C" int cssm_pf_shard_begin(cssm_pf* pf, const double* t, const double* y
   if (rc) return rc;
   pf->series = true;
   pf->rec_base = 0;
+  rc = path_prepare(pf, T);
+  if (rc) return rc;
+  if (pf->want_path) {   // row 0: one particle of the initial cloud (:154)
+    const int32_t pr = (int32_t)cssm_philox_draw(pf->seed, 0, 0, CSSM_STREAM_PICK, 0).v[0];
+    const uint32_t pa = pr < 0 ? (uint32_t)0 - (uint32_t)pr : (uint32_t)pr;
+    path_record(pf, 0, (uint64_t)pa % pf->n_global);
+  }
   return CSSM_OK;
 }
 
@@ -301,7 +362,7 @@ extern "C" int cssm_pf_shard_continue(cssm_pf* pf, const double* t, const double
   pf->series = true;
   pf->rec_base = pf->step;
   pf->snaps.clear();
-  return CSSM_OK;
+  return path_prepare(pf, T);   // (row 0 of a continued call's path stays zero: the state before its first observation belongs to the call before)
 }
 
 extern "C" int cssm_pf_shard_propagate_at(cssm_pf* pf, size_t s, uint64_t* sums5_dev) {
@@ -313,6 +374,7 @@ extern "C" int cssm_pf_shard_propagate_at(cssm_pf* pf, size_t s, uint64_t* sums5
   if (rc) return rc;
   pf->step++;
   pf->t = pf->h_recs[s].t_obs;
+  if (!pf->h_recs[s].has_obs) path_after(pf, s);   // (a weighted observation: behind its resampling, cssm_pf_shard_adopt_spec / _adopt)
   if (pf->snaps.size() <= s) pf->snaps.resize(s + 1);
   pf->snaps[s] = {pf->cur, pf->src, pf->src_stride, pf->src2, pf->src2_stride, pf->n_split, pf->anc_valid, pf->last_optimistic, pf->step, pf->t};
   return CSSM_OK;
@@ -404,6 +466,7 @@ extern "C" int cssm_pf_shard_adopt_spec(cssm_pf* pf, const double* recv_buf_dev,
   pf->src = pf->state[pf->cur]; pf->src_stride = pf->stride;
   pf->src2 = recv_buf_dev; pf->src2_stride = 0; pf->n_split = n_split; pf->anc_valid = true;   // stride 0 = rows of d + 1
   pf->wmode = pf->last_optimistic;
+  if (pf->series) path_after(pf, slot);   // (on hold after a capacity miss the slot index of a wrong row is overwritten when the observation is redone)
   return CSSM_OK;
 }
 
@@ -674,6 +737,7 @@ extern "C" int cssm_pf_shard_adopt(cssm_pf* pf, const double* recv_buf_dev, int6
   HIP_TRY(hipGetLastError());
   pf->src = pf->state[pf->cur]; pf->src_stride = pf->stride;
   pf->src2 = pf->cand; pf->src2_stride = pf->cand_cap; pf->n_split = n_split; pf->anc_valid = true;
+  if (pf->series) path_after(pf, last_rec_slot(pf));
   return CSSM_OK;
 }
 

@@ -180,6 +180,15 @@ class GpuShard:
                                                  need.ctypes.data_as(C.POINTER(C.c_uint32)), T))
         return ll.value, ess.value, bits.value, need
 
+    def want_path(self, on: bool):
+        _abi.check(self.lib.cssm_pf_shard_want_path(self._h, 1 if on else 0))
+
+    def get_path(self, T: int) -> np.ndarray:
+        """This rank's (T + 1) x d rows of `filter`'s path: the rows whose picked slot it owns, zero bits elsewhere."""
+        out = np.zeros((T + 1, self.d))
+        _abi.check(self.lib.cssm_pf_shard_get_path(self._h, out.ctypes.data_as(C.POINTER(C.c_double)), T))
+        return out
+
     def propagate(self, t, y, has_obs):
         _abi.check(self.lib.cssm_pf_shard_propagate(self._h, float(t), float(y), int(has_obs),
                                                     C.c_void_p(self.sums5.data_ptr())))
@@ -251,6 +260,16 @@ class DistComm:
         x = torch.tensor([int(values[0])], dtype=torch.int64, device=self.device if self.device is not None else "cpu")
         self.dist.all_reduce(x, op=self.dist.ReduceOp.MAX, group=self.group)
         return int(x.item())
+
+    def combine_rows(self, arrays: List[np.ndarray]) -> np.ndarray:
+        """Rows of which exactly one rank holds non-zero bits -> the same array on every rank, bit for bit: the 32-bit halves of
+        the bit patterns are summed (RCCL has no bitwise OR; a sum of doubles could turn -0.0 into +0.0)."""
+        bits = np.ascontiguousarray(arrays[0]).view(np.uint64)
+        halves = np.stack([(bits >> np.uint64(32)).astype(np.int64), (bits & np.uint64(0xffffffff)).astype(np.int64)])
+        x = torch.from_numpy(halves).to(self.device if self.device is not None else "cpu")
+        self.dist.all_reduce(x, op=self.dist.ReduceOp.SUM, group=self.group)
+        h = x.cpu().numpy().astype(np.uint64)
+        return ((h[0] << np.uint64(32)) | h[1]).view(np.float64).reshape(arrays[0].shape)
 
     def native_comm(self):
         """An RCCL communicator owned by libcssm_pf (its series loop issues the collectives itself), or None.
@@ -334,6 +353,12 @@ class LocalComm:
 
     def agree_max(self, values):
         return max(int(v) for v in values)
+
+    def combine_rows(self, arrays):
+        out = np.zeros(arrays[0].shape, dtype=np.uint64)
+        for a in arrays:
+            out |= np.ascontiguousarray(a).view(np.uint64).reshape(out.shape)
+        return out.view(np.float64)
 
     def barrier(self):
         pass
@@ -470,6 +495,21 @@ class ShardedFilter:
         tiles = -(-n_max // 1024)
         unit = 1024 * (-(-tiles // 1024))
         return min(-(-cap // unit) * unit, n_max) if cap >= 1024 else cap
+
+    def filter(self, t, y, has=None, lgcp: bool = False):
+        """(ll, path): `filter` of ParticleFilter.scala:152-158 over the shards -- the log-likelihood and, for the initial cloud
+        and after every observation, ONE uniformly picked particle (Resampling.sampleOne; row s + 1 = after observation s).  The
+        rank that owns the picked global slot records the state; the ranks' rows are combined once, at the end of the series.
+        This is what a BootstrapFilter over several GPUs returns (model/package.scala:24; PMMH, model/PMMH.scala:71)."""
+        for s in self.shards:
+            s.want_path(True)
+        try:
+            ll, ess = self.ll_filter(t, y, has, lgcp=lgcp)
+            path = self.comm.combine_rows([s.get_path(len(t)) for s in self.shards])
+        finally:
+            for s in self.shards:
+                s.want_path(False)
+        return ll, path
 
     def ll_filter_more(self, t, y, has=None, lgcp: bool = False):
         """T MORE observations of the filter ``ll_filter`` (or an earlier ``ll_filter_more``) left running: the sharded

@@ -377,6 +377,14 @@ int cssm_pf_shard_begin(cssm_pf* pf, const double* t, const double* y, const uin
 int cssm_pf_shard_continue(cssm_pf* pf, const double* t, const double* y, const uint8_t* has_obs, size_t T);
 int cssm_pf_shard_propagate_at(cssm_pf* pf, size_t s, uint64_t* sums5_dev);
 int cssm_pf_shard_status(cssm_pf* pf, double* ll_out, int32_t* ess_out, uint32_t* bits_out, uint32_t* need, size_t T);
+/* `filter` on shards (model/ParticleFilter.scala:152-158): with cssm_pf_shard_want_path(pf, 1) set BEFORE cssm_pf_shard_begin /
+ * _continue, the rank that owns the GLOBAL slot sampleOne picks after an observation (Resampling.scala:151-154; the index is a
+ * function of seed and observation, the same on every rank) records the state in that slot.  cssm_pf_shard_get_path copies
+ * this rank's (T + 1) x d rows to the host: row s + 1 = the pick after observation s of the series (row 0: of the initial cloud;
+ * all zero after _continue), rows of slots other ranks own are all-zero bits -- the caller combines the ranks' paths (exactly
+ * one is non-zero per row; ShardedFilter.filter sums the 32-bit halves of the bit patterns). */
+int cssm_pf_shard_want_path(cssm_pf* pf, int on);
+int cssm_pf_shard_get_path(cssm_pf* pf, double* out_host, size_t T);
 
 /* SINGLE-COLLECTIVE exchange (every weighted observation of an ordinary series): ONE all-to-all per observation carries
  * the rank's 5 sum words (segment header, to every rank) AND its boundary particles -- to the rank below its first `cap`

@@ -650,6 +650,13 @@ static uint64_t pick_index(const oracle_pf* pf, uint32_t s) {
   return (uint64_t)a % pf->n;
 }
 
+/* the same index for a cloud of n particles under `seed` (tests/oracle_shard.py: which rank owns the pick) */
+uint64_t oracle_c_pick(uint64_t seed, uint32_t s, uint64_t n) {
+  int32_t r = (int32_t)cssm_philox_draw(seed, 0, s, CSSM_STREAM_PICK, 0).v[0];
+  uint32_t a = r < 0 ? (uint32_t)0 - (uint32_t)r : (uint32_t)r;
+  return (uint64_t)a % n;
+}
+
 /* llFilter model/ParticleFilter.scala:137-140 and filter :152-158 (path != NULL) */
 int oracle_pf_filter(oracle_pf* pf, const double* t, const double* y, const uint8_t* has, size_t T,
                      double* ll_out, double* ll_t, int32_t* ess_t, double* path) {

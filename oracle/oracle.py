@@ -93,6 +93,7 @@ def lib() -> C.CDLL:
             "oracle_c_log": (C.c_double, [C.c_double]),
             "oracle_c_philox": (None, [_u32p, _u32p, _u32p]),
             "oracle_c_philox_contract": (None, [_u32p, _u32p, _u32p]),
+            "oracle_c_pick": (C.c_uint64, [C.c_uint64, C.c_uint32, C.c_uint64]),
             "oracle_c_normals": (None, [C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, _dp]),
             "oracle_c_log_unit_v": (None, [_dp, _dp, C.c_size_t]),
             "oracle_c_fix_v": (None, [_dp, C.POINTER(C.c_uint64), C.c_size_t]),

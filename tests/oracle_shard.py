@@ -159,6 +159,8 @@ class OracleShard:
         anc = np.searchsorted(cend, slots, side="right")      # first candidate whose end slot exceeds s
         assert anc.max() < n_recv
         self.o.set_particles(np.ascontiguousarray(cand[anc].T))
+        if hasattr(self, "_t"):
+            self._record(self.step_idx - self._base, self.step_idx)
 
     # ---- the series API of GpuShard (records resident, observations by index), restated
     def begin(self, t, y, has):
@@ -167,6 +169,22 @@ class OracleShard:
         self.bits, self.need, self.fail_step = 0, np.zeros(len(self._t), dtype=np.uint32), None
         self.init(float(self._t.min()))
         self._base = 0
+        self._path = np.zeros((len(self._t) + 1, self.d))
+        self._record(0, 0)
+
+    def want_path(self, on):
+        self._want_path = bool(on)
+
+    def get_path(self, T):
+        return self._path[: T + 1].copy()
+
+    def _record(self, row, step_for_pick):
+        """row of the path <- the current cloud's particle at the global slot sampleOne picks (if this rank owns it)"""
+        if not getattr(self, "_want_path", False):
+            return
+        slot = int(oracle.lib().oracle_c_pick(self.seed, step_for_pick, self.n_global))
+        if self.first <= slot < self.first + self.n:
+            self._path[row] = self.o.particles()[:, slot - self.first]
 
     def begin_more(self, t, y, has):
         """T more observations of the running filter: the clock, ll, ess and the observation count go on."""
@@ -179,6 +197,8 @@ class OracleShard:
         if self.bits & 12:
             return                                   # on hold after a capacity miss (8) or void (4: level ruled out): nothing may change
         self.propagate(float(self._t[k]), float(self._y[k]), bool(self._has[k]) or self.o_is_lgcp())
+        if not (bool(self._has[k]) or self.o_is_lgcp()):
+            self._record(k + 1, self.step_idx)        # (a weighted observation: behind its resampling)
 
     def resume(self):
         """The observation whose exchange did not fit (its propagate is done); the hold is lifted."""
@@ -289,6 +309,7 @@ class OracleShard:
         anc = np.searchsorted(cend, slots, side="right")
         assert anc.max() < len(allc)
         self.o.set_particles(np.ascontiguousarray(np.stack([allc[a][0] for a in anc], axis=1)))
+        self._record(self.step_idx - self._base, self.step_idx)
 
     def status(self, T):
         return self.ll, self.ess, self.bits, self.need[:T]

@@ -168,6 +168,30 @@ def test_continued_sharded_series_equals_the_whole_series(name, prec, n, world):
             s.close()
 
 
+@pytest.mark.parametrize("name,prec,n,world,tiny", [("c2_model", 0, 9000, 4, False), ("c2_model", 0, 9000, 4, True), ("c3_model", 0, 5000, 2, False),
+                                                    ("c4_model", 2, 6000, 3, False)])
+def test_sharded_filter_returns_the_sampled_path(name, prec, n, world, tiny):
+    """ShardedFilter.filter = `filter` (ParticleFilter.scala:152-158) over shards -- what a BootstrapFilter over several GPUs hands
+    PMMH (package.scala:24): ll and one uniformly picked particle of the initial cloud and of the cloud after every observation
+    (Resampling.sampleOne on the GLOBAL slot index; the owning rank records it, also when the slot's ancestor is a row received
+    from a neighbour, also through resumed capacity misses) equal the single-rank oracle's path bit for bit."""
+    from composablestatespacemodels_amd.sharded import GpuShard, LocalComm, ShardedFilter
+    model = getattr(cases, name)()
+    T = 11
+    t, y, has = cases.event_times(T, horizon=12.0) if prec else cases.poisson_counts(T, missing=0.2)
+    o = oracle.OraclePf(model.descriptor(prec), n, cases.SEED)
+    oll, _, _, opath = o.filter(t, y, has, want_path=True)
+    shards = [GpuShard(model, n, r, world, cases.SEED, 0, lgcp_precision=prec) for r in range(world)]
+    f = ShardedFilter(shards, LocalComm(world))
+    if tiny:
+        f.MIN_CAP, f.CAP_SQRT = 1, 0.0
+    ll, path = f.filter(t, y, has, lgcp=bool(prec))
+    assert ll == oll and (f.last_resumes >= 1) == tiny
+    np.testing.assert_array_equal(path, opath)
+    for s in shards:
+        s.close()
+
+
 def test_rccl_world1_matches_oracle():
     import torch
     import torch.distributed as dist
@@ -202,6 +226,11 @@ def test_rccl_world1_matches_oracle():
         nw = int(np.sum(has[6:]))
         assert prof["k_propagate"][1] == len(t) - 6 and prof["collective"][1] == nw
         assert prof["k_boundary_pack"][1] == nw and prof["k_offspring_expand_spec"][1] == nw
+        # `filter` through the library's loop: the path rows are recorded on the stream, combined with one all-reduce at the end
+        ll, path = f.filter(t, y, has)
+        opath = oracle.OraclePf(model.descriptor(), n, cases.SEED).filter(t, y, has, want_path=True)[3]
+        assert f.last_native and ll == oll
+        np.testing.assert_array_equal(path, opath)
         # ... with the all-to-all-v of the library's trimmed exchange (mode 3 forces it at any world size; at world 1 it
         # carries the rank's own header)
         f4 = ShardedFilter([shard], DistComm(device=torch.device("cuda", 0)))

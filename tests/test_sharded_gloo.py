@@ -171,3 +171,19 @@ def test_continued_sharded_series_equals_the_whole_series_on_cpu():
         assert (ll, ess) == (oll, int(oess[-1]))
         assert (f.last_resumes >= 1) == tiny
         np.testing.assert_array_equal(np.concatenate([s.particles() for s in shards], axis=1), o.particles())
+
+
+def test_sharded_filter_returns_the_sampled_path_on_cpu():
+    """ShardedFilter.filter = `filter` of ParticleFilter.scala:152-158 over shards: ll and the path of uniformly picked particles
+    (row 0: of the initial cloud; the rank that owns the picked global slot records it) equal the single-rank oracle's."""
+    from composablestatespacemodels_amd.sharded import LocalComm, ShardedFilter
+    from oracle_shard import OracleShard
+    model = cases.c2_model()
+    n, world, T = 300, 3, 9
+    t, y, has = cases.poisson_counts(T, missing=0.2)
+    o = oracle.OraclePf(model.descriptor(), n, cases.SEED)
+    oll, _, _, opath = o.filter(t, y, has, want_path=True)
+    shards = [OracleShard(model, n, r, world, cases.SEED) for r in range(world)]
+    ll, path = ShardedFilter(shards, LocalComm(world)).filter(t, y, has)
+    assert ll == oll
+    np.testing.assert_array_equal(path, opath)
