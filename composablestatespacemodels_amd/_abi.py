@@ -106,6 +106,10 @@ SYMBOLS = [
     ("cssm_pf_shard_status", C.c_int, [_h, _dp, _i32p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.c_size_t]),
     ("cssm_pf_shard_want_path", C.c_int, [_h, C.c_int]),
     ("cssm_pf_shard_get_path", C.c_int, [_h, _dp, C.c_size_t]),
+    ("cssm_pf_shard_summary_begin", C.c_int, [_h, C.c_double, C.c_void_p, C.c_void_p]),
+    ("cssm_pf_shard_summary_hist", C.c_int, [_h, C.c_int, C.c_void_p]),
+    ("cssm_pf_shard_summary_pick", C.c_int, [_h, C.c_int, C.c_void_p]),
+    ("cssm_pf_shard_summary_finish", C.c_int, [_h, C.c_void_p, _dp, _dp, _dp, _dp, _dp, _dp]),
     ("cssm_pf_shard_pack", C.c_int, [_h, C.c_int, _i64p, _i64p, C.c_int, C.c_void_p]),
     ("cssm_pf_shard_adopt", C.c_int, [_h, C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_int64]),
     ("cssm_pf_shard_result", C.c_int, [_h, _dp, _i32p]),

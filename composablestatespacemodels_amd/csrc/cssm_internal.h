@@ -91,6 +91,9 @@ struct cssm_pf : HostModel {
   uint32_t* d_need = nullptr;  // per observation: rows the exchange needed (diagnostics of cssm_pf_shard_status; zero since the
   size_t need_cap = 0;         //   two-collective exchange that recorded them was removed)
   bool series = false;         // records of a whole series are resident (cssm_pf_shard_begin / _continue)
+  // sharded cloud summaries (cssm_pf_shard_summary_*): keys of the local cloud, block partial sums, the two radix-select states per row
+  unsigned long long* sm_keys = nullptr; double* sm_partial = nullptr; void* sm_st = nullptr; StepRec* sm_rec = nullptr;
+  size_t sm_cap = 0; int sm_blocks = 0; double sm_time = 0.0;
   bool want_path = false;      // sharded `filter`: record sampleOne's pick after every observation whose slot this rank owns
   uint32_t rec_base = 0;       // observation index (pf->step) of the resident series' first record: 0 after _begin, the filter's
                                //   observation count so far after _continue
@@ -178,3 +181,4 @@ int cssm_launch_init(cssm_pf* pf, double t0);
 int cssm_launch_propagate(cssm_pf* pf, const StepRec* d_rec, double* pick_out = nullptr, uint32_t pick_slot = 0);
 int cssm_check_device_err(cssm_pf* pf, const Scalars& h);
 int cssm_prop_items(int d);   // PropItems<D>
+double cssm_eta_of_mean(const cssm_pf* pf, const StepRec& rec, const double* mean);   // link(f(stateMean, t)), ParticleFilter.scala:420

@@ -154,7 +154,7 @@ extern "C" void cssm_pf_destroy(cssm_pf* pf) {
   if (!pf) return;
   (void)hipSetDevice(pf->device);
   if (pf->stream) (void)hipStreamSynchronize(pf->stream);
-  void* ptrs[] = {pf->s2buf, pf->fineS, pf->fineS2, pf->state[0], pf->state[1], pf->logw, pf->endslot, pf->anc, pf->tileS, pf->tileS2, pf->tileP, pf->sc,
+  void* ptrs[] = {pf->sm_keys, pf->sm_partial, pf->sm_st, pf->sm_rec, pf->s2buf, pf->fineS, pf->fineS2, pf->state[0], pf->state[1], pf->logw, pf->endslot, pf->anc, pf->tileS, pf->tileS2, pf->tileP, pf->sc,
                   pf->d_m0, pf->d_sd0, pf->d_logtab, pf->d_fsub, pf->cum, pf->d_recs, pf->d_ll_t, pf->d_ess_t, pf->d_path, pf->cand, pf->cand_end, pf->cand_idx, pf->d_bounds, pf->d_xch, pf->d_need};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   if (pf->h_recs) (void)hipHostFree(pf->h_recs);
@@ -897,6 +897,16 @@ static double host_link(int obs_kind, double g) {
   }
 }
 
+double cssm_eta_of_mean(const cssm_pf* pf, const StepRec& rec, const double* mean) {
+  double g = 0.0, acc = 0.0;
+  for (int k = 0; k < pf->d; ++k) {
+    const int fm = pf->mk.fmode(k);
+    if (fm == FM_START) acc = rec.fco[k] * mean[k]; else if (fm == FM_ADD) acc = acc + rec.fco[k] * mean[k];
+    if (pf->mk.leaf_end(k)) g = pf->mk.first_leaf(k) ? acc : g + acc;
+  }
+  return host_link(pf->obs_kind, g);
+}
+
 // Summary of the cloud { src[:, idx[i]] : i < n } at time `time` (idx == nullptr: identity); see cssm_pf_summary.
 static int summary_impl(cssm_pf* pf, const double* src, size_t src_stride, const uint32_t* idx, const double* src2, size_t src2_stride,
                         uint32_t n_split, double time, double interval, double* state_mean, double* state_lower, double* state_upper,
@@ -946,15 +956,7 @@ static int summary_impl(cssm_pf* pf, const double* src, size_t src_stride, const
   }
   if (eta_lower) *eta_lower = hout[rows + d];
   if (eta_upper) *eta_upper = hout[2 * rows + d];
-  if (eta_of_mean) {   // meanEta = link(f(stateMean, t)), :420
-    double g = 0.0, acc = 0.0;
-    for (int k = 0; k < d; ++k) {
-      const int fm = pf->mk.fmode(k);
-      if (fm == FM_START) acc = hrec.fco[k] * hout[k]; else if (fm == FM_ADD) acc = acc + hrec.fco[k] * hout[k];
-      if (pf->mk.leaf_end(k)) g = pf->mk.first_leaf(k) ? acc : g + acc;
-    }
-    *eta_of_mean = host_link(pf->obs_kind, g);
-  }
+  if (eta_of_mean) *eta_of_mean = cssm_eta_of_mean(pf, hrec, hout.data());   // meanEta = link(f(stateMean, t)), :420
 done:
 #undef SM_TRY
   { void* ptrs[] = {keys, partial, st, hist, out, drec}; for (void* q : ptrs) if (q) (void)hipFree(q); }

@@ -4,6 +4,8 @@
 
 #include <algorithm>
 #include <chrono>
+#include <cmath>
+#include <vector>
 #include <cstdio>
 #include <cstdlib>
 #include <mutex>
@@ -738,6 +740,111 @@ extern "C" int cssm_pf_shard_adopt(cssm_pf* pf, const double* recv_buf_dev, int6
   pf->src = pf->state[pf->cur]; pf->src_stride = pf->stride;
   pf->src2 = pf->cand; pf->src2_stride = pf->cand_cap; pf->n_split = n_split; pf->anc_valid = true;
   if (pf->series) path_after(pf, last_rec_slot(pf));
+  return CSSM_OK;
+}
+
+// ------------------------------------------------------------------------------------ cloud summaries over shards
+// getIntervals (model/ParticleFilter.scala:415-424) of the SHARDED cloud: the order statistics are global ranks, so every
+// radix-select pass totals the ranks' byte histograms with one all-reduce (the caller's) before every rank picks the same byte;
+// the means are the all-reduced local sums over N_global.  Stage calls (ShardedFilter.summary drives them):
+//   cssm_pf_shard_summary_begin   keys of the local resampled cloud (d state rows + eta = link(f(x, t))), local sums of the
+//                                 state components -> sums_dev[d]; select states for the global ranks; hist_dev zeroed
+//   8 x { cssm_pf_shard_summary_hist(shift) -> [all-reduce SUM of hist_dev: (d + 1) * 512 u32] -> cssm_pf_shard_summary_pick(shift) }
+//   [all-reduce SUM of sums_dev]  cssm_pf_shard_summary_finish   means, order statistics, eta of the mean -> host
+__global__ void k_partial_sums(const double* __restrict__ partial, int nblocks, int d, double* __restrict__ out) {
+  const int k = threadIdx.x;
+  if (k >= d) return;
+  double s = 0.0;
+  for (int b = 0; b < nblocks; ++b) s += partial[(size_t)b * d + k];
+  out[k] = s;
+}
+extern "C" int cssm_pf_shard_summary_begin(cssm_pf* pf, double interval, double* sums_dev, uint32_t* hist_dev) {
+  int rc = shard_check(pf);
+  if (rc) return rc;
+  if (!sums_dev || !hist_dev) return fail(CSSM_EINVAL_ARG, "null argument");
+  if (!pf->initialised) return fail(CSSM_ESTATE, "not initialised");
+  if (!(interval > 0.0 && interval <= 1.0)) return fail(CSSM_EINVAL_ARG, "interval must be in (0, 1]");
+  const int d = pf->d, rows = d + 1;
+  const uint64_t n = pf->n, ng = pf->n_global;
+  const int nblocks = grid_for(n, CSSM_BLOCK, 1024);
+  if (pf->sm_cap < (size_t)n) {
+    HIP_TRY(hipStreamSynchronize(pf->stream));
+    void* old[] = {pf->sm_keys, pf->sm_partial, pf->sm_st, pf->sm_rec};
+    for (void* q : old) if (q) (void)hipFree(q);
+    pf->sm_keys = nullptr; pf->sm_partial = nullptr; pf->sm_st = nullptr; pf->sm_rec = nullptr; pf->sm_cap = 0;
+    HIP_TRY(hipMalloc(&pf->sm_keys, (size_t)rows * n * 8));
+    HIP_TRY(hipMalloc(&pf->sm_partial, (size_t)1024 * d * 8));
+    HIP_TRY(hipMalloc(&pf->sm_st, rows * sizeof(SelState)));
+    HIP_TRY(hipMalloc(&pf->sm_rec, sizeof(StepRec)));
+    pf->sm_cap = (size_t)n;
+  }
+  pf->sm_blocks = nblocks; pf->sm_time = pf->t;
+  // ranks, 0-based in ascending order, of the GLOBAL cloud: getCredibleInterval (:488-502) uses (N - index - 1, index - 1) with
+  // index = floor(interval * N); getOrderStatistic (:455-460) uses (N - index, index)
+  std::vector<SelState> hst(rows);
+  const long long idxr = (long long)std::floor(interval * (double)ng);
+  auto clampr = [&](long long r) { return (unsigned long long)std::min<long long>(std::max<long long>(r, 0), (long long)ng - 1); };
+  for (int k = 0; k < rows; ++k) {
+    hst[k].prefix[0] = hst[k].prefix[1] = 0;
+    hst[k].rank[0] = clampr(k < d ? (long long)ng - idxr - 1 : (long long)ng - idxr);
+    hst[k].rank[1] = clampr(k < d ? idxr - 1 : idxr);
+  }
+  StepRec hrec;
+  cssm_build_rec(pf, pf->t, pf->t, 0.0, 0, pf->step, &hrec);   // F(t) of the cloud's time for f(x, t)
+  HIP_TRY(hipMemcpyAsync(pf->sm_st, hst.data(), rows * sizeof(SelState), hipMemcpyHostToDevice, pf->stream));
+  HIP_TRY(hipMemcpyAsync(pf->sm_rec, &hrec, sizeof hrec, hipMemcpyHostToDevice, pf->stream));
+  HIP_TRY(hipStreamSynchronize(pf->stream));   // (the sources are stack objects)
+  HIP_TRY(hipMemsetAsync(hist_dev, 0, (size_t)rows * 512 * 4, pf->stream));
+  const uint32_t* idx = pf->anc_valid ? pf->anc : nullptr;
+  DISPATCH_D(d, k_summary_fill<D><<<dim3(nblocks), dim3(CSSM_BLOCK), 0, pf->stream>>>(
+                    pf->src, pf->src_stride, idx, idx ? pf->src2 : nullptr, pf->src2_stride, pf->n_split, n, (const StepRec*)pf->sm_rec, pf->mk,
+                    pf->sm_keys, (size_t)n, pf->sm_partial));
+  hipLaunchKernelGGL(k_partial_sums, dim3(1), dim3(64), 0, pf->stream, (const double*)pf->sm_partial, nblocks, d, sums_dev);
+  HIP_TRY(hipGetLastError());
+  return CSSM_OK;
+}
+extern "C" int cssm_pf_shard_summary_hist(cssm_pf* pf, int shift, uint32_t* hist_dev) {
+  int rc = shard_check(pf);
+  if (rc) return rc;
+  if (!hist_dev || !pf->sm_keys || shift < 0 || shift > 56 || (shift & 7)) return fail(CSSM_EINVAL_ARG, "summary_hist: begin first; shift in {56, 48, ..., 0}");
+  hipLaunchKernelGGL(k_sel_hist, dim3(pf->sm_blocks, pf->d + 1), dim3(CSSM_BLOCK), 0, pf->stream, (const unsigned long long*)pf->sm_keys, (size_t)pf->n, pf->n,
+                     (const SelState*)pf->sm_st, shift, hist_dev);
+  HIP_TRY(hipGetLastError());
+  return CSSM_OK;
+}
+extern "C" int cssm_pf_shard_summary_pick(cssm_pf* pf, int shift, uint32_t* hist_dev) {
+  int rc = shard_check(pf);
+  if (rc) return rc;
+  if (!hist_dev || !pf->sm_st) return fail(CSSM_EINVAL_ARG, "summary_pick: begin first");
+  hipLaunchKernelGGL(k_sel_pick, dim3(pf->d + 1), dim3(2), 0, pf->stream, (SelState*)pf->sm_st, shift, hist_dev);   // (zeroes the histogram for the next pass)
+  HIP_TRY(hipGetLastError());
+  return CSSM_OK;
+}
+extern "C" int cssm_pf_shard_summary_finish(cssm_pf* pf, const double* sums_global_dev, double* state_mean, double* state_lower, double* state_upper,
+                                            double* eta_of_mean, double* eta_lower, double* eta_upper) {
+  int rc = shard_check(pf);
+  if (rc) return rc;
+  if (!sums_global_dev || !pf->sm_st) return fail(CSSM_EINVAL_ARG, "summary_finish: begin first");
+  const int d = pf->d, rows = d + 1;
+  std::vector<SelState> hst(rows);
+  std::vector<double> sums(d), mean(d);
+  rc = bounded_sync(pf);
+  if (rc) return rc;
+  HIP_TRY(hipMemcpy(hst.data(), pf->sm_st, rows * sizeof(SelState), hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(sums.data(), sums_global_dev, d * 8, hipMemcpyDeviceToHost));
+  for (int k = 0; k < d; ++k) {
+    mean[k] = sums[k] / (double)pf->n_global;
+    if (state_mean) state_mean[k] = mean[k];
+    if (state_lower) state_lower[k] = cssm_order_unkey(hst[k].prefix[0]);
+    if (state_upper) state_upper[k] = cssm_order_unkey(hst[k].prefix[1]);
+  }
+  if (eta_lower) *eta_lower = cssm_order_unkey(hst[d].prefix[0]);
+  if (eta_upper) *eta_upper = cssm_order_unkey(hst[d].prefix[1]);
+  if (eta_of_mean) {
+    StepRec hrec;
+    cssm_build_rec(pf, pf->sm_time, pf->sm_time, 0.0, 0, pf->step, &hrec);
+    *eta_of_mean = cssm_eta_of_mean(pf, hrec, mean.data());
+  }
   return CSSM_OK;
 }
 

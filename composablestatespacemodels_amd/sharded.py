@@ -189,6 +189,29 @@ class GpuShard:
         _abi.check(self.lib.cssm_pf_shard_get_path(self._h, out.ctypes.data_as(C.POINTER(C.c_double)), T))
         return out
 
+    # -- getIntervals over the shards (cssm_pf_shard_summary_*): the collectives between the stages are the caller's
+    def summary_begin(self, interval: float):
+        if not hasattr(self, "sm_sums"):
+            self.sm_sums = torch.zeros(self.d, dtype=torch.float64, device=self.dev)
+            self.sm_hist = torch.zeros((self.d + 1) * 512, dtype=torch.int32, device=self.dev)
+        _abi.check(self.lib.cssm_pf_shard_summary_begin(self._h, float(interval), C.c_void_p(self.sm_sums.data_ptr()),
+                                                        C.c_void_p(self.sm_hist.data_ptr())))
+
+    def summary_hist(self, shift: int):
+        _abi.check(self.lib.cssm_pf_shard_summary_hist(self._h, int(shift), C.c_void_p(self.sm_hist.data_ptr())))
+
+    def summary_pick(self, shift: int):
+        _abi.check(self.lib.cssm_pf_shard_summary_pick(self._h, int(shift), C.c_void_p(self.sm_hist.data_ptr())))
+
+    def summary_finish(self) -> dict:
+        d = self.d
+        m, lo, hi = np.zeros(d), np.zeros(d), np.zeros(d)
+        em, el, eu = C.c_double(), C.c_double(), C.c_double()
+        _p = lambda a: a.ctypes.data_as(C.POINTER(C.c_double))
+        _abi.check(self.lib.cssm_pf_shard_summary_finish(self._h, C.c_void_p(self.sm_sums.data_ptr()), _p(m), _p(lo), _p(hi),
+                                                         C.byref(em), C.byref(el), C.byref(eu)))
+        return dict(state_mean=m, state_lower=lo, state_upper=hi, eta_of_mean=em.value, eta_lower=el.value, eta_upper=eu.value)
+
     def propagate(self, t, y, has_obs):
         _abi.check(self.lib.cssm_pf_shard_propagate(self._h, float(t), float(y), int(has_obs),
                                                     C.c_void_p(self.sums5.data_ptr())))
@@ -254,6 +277,9 @@ class DistComm:
 
     def all_to_all_equal(self, outs, ins):
         self.dist.all_to_all_single(outs[0], ins[0], group=self.group)
+
+    def all_reduce_sum(self, tensors: List[torch.Tensor]):
+        self.dist.all_reduce(tensors[0], op=self.dist.ReduceOp.SUM, group=self.group)
 
     def agree_max(self, values: List[int]) -> int:
         """Max over all ranks of a host integer (a decision every rank must take alike)."""
@@ -350,6 +376,13 @@ class LocalComm:
         for q in range(R):
             for r in range(R):
                 outs[q][r * seg:(r + 1) * seg].copy_(ins[r][q * seg:(q + 1) * seg])
+
+    def all_reduce_sum(self, tensors):
+        total = tensors[0].clone()
+        for x in tensors[1:]:
+            total += x.to(total.device)
+        for x in tensors:
+            x.copy_(total)
 
     def agree_max(self, values):
         return max(int(v) for v in values)
@@ -510,6 +543,24 @@ class ShardedFilter:
             for s in self.shards:
                 s.want_path(False)
         return ll, path
+
+    def summary(self, interval: float = 0.975) -> dict:
+        """getIntervals (model/ParticleFilter.scala:415-424) of the sharded cloud as it stands (after ``ll_filter`` / ``filter`` /
+        ``ll_filter_more``): what NativePf.summary returns for the single-GPU cloud of the same N_global -- the order statistics
+        bit for bit, the means to ~1e-13.  Eight radix-selection passes, each one all-reduce of (d + 1) x 512 counters, plus one
+        all-reduce of d sums: nothing of the cloud leaves its rank."""
+        S, comm = self.shards, self.comm
+        for s in S:
+            s.summary_begin(interval)
+        comm.all_reduce_sum([s.sm_sums for s in S])
+        for shift in range(56, -8, -8):
+            for s in S:
+                s.summary_hist(shift)
+            comm.all_reduce_sum([s.sm_hist for s in S])
+            for s in S:
+                s.summary_pick(shift)
+        out = [s.summary_finish() for s in S]
+        return out[0]
 
     def ll_filter_more(self, t, y, has=None, lgcp: bool = False):
         """T MORE observations of the filter ``ll_filter`` (or an earlier ``ll_filter_more``) left running: the sharded

@@ -386,6 +386,26 @@ int cssm_pf_shard_status(cssm_pf* pf, double* ll_out, int32_t* ess_out, uint32_t
 int cssm_pf_shard_want_path(cssm_pf* pf, int on);
 int cssm_pf_shard_get_path(cssm_pf* pf, double* out_host, size_t T);
 
+/* getIntervals (model/ParticleFilter.scala:415-424; cssm_pf_summary above) of the SHARDED cloud.  The order statistics are
+ * ranks in the global cloud of n_global particles, so every radix-selection pass totals the ranks' byte histograms with one
+ * all-reduce; the means are the all-reduced local sums over n_global.  Stage calls, the same on every rank:
+ *   cssm_pf_shard_summary_begin(pf, interval, sums_dev, hist_dev)   keys of this rank's resampled cloud (d state rows +
+ *                           eta = link(f(x, t))); sums_dev[d] <- local sums of the state components; hist_dev zeroed
+ *   for shift = 56, 48, ..., 0:
+ *     cssm_pf_shard_summary_hist(pf, shift, hist_dev)               local byte histograms of the still-matching keys
+ *     [caller: all-reduce SUM of hist_dev, (d + 1) * 512 uint32]
+ *     cssm_pf_shard_summary_pick(pf, shift, hist_dev)               every rank picks the same byte; hist_dev zeroed again
+ *   [caller: all-reduce SUM of sums_dev]
+ *   cssm_pf_shard_summary_finish(pf, sums_dev, ...)                 outputs as cssm_pf_summary (host pointers, may be NULL)
+ * sums_dev (d doubles) and hist_dev ((d + 1) * 512 uint32) are DEVICE buffers of the caller (the ones its collective
+ * works on); all launches go to the handle's stream.  Order statistics are exact (equal to the single-GPU filter's
+ * over the concatenated shards); the means agree with it to ~1e-13 relative (another order of summation). */
+int cssm_pf_shard_summary_begin(cssm_pf* pf, double interval, double* sums_dev, uint32_t* hist_dev);
+int cssm_pf_shard_summary_hist(cssm_pf* pf, int shift, uint32_t* hist_dev);
+int cssm_pf_shard_summary_pick(cssm_pf* pf, int shift, uint32_t* hist_dev);
+int cssm_pf_shard_summary_finish(cssm_pf* pf, const double* sums_global_dev, double* state_mean, double* state_lower, double* state_upper,
+                                 double* eta_of_mean, double* eta_lower, double* eta_upper);
+
 /* SINGLE-COLLECTIVE exchange (every weighted observation of an ordinary series): ONE all-to-all per observation carries
  * the rank's 5 sum words (segment header, to every rank) AND its boundary particles -- to the rank below its first `cap`
  * particles, to the rank above its last `cap`, each with the inclusive prefix of its fixed-point weight within that block --

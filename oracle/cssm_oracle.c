@@ -744,6 +744,13 @@ int oracle_pf_summary(const oracle_pf* pf, double interval, double* mean, double
   return summary_of(pf, pf->x, pf->t, interval, mean, lower, upper, eta_of_mean, eta_lower, eta_upper);
 }
 
+/* eta = link(f(x, t)) of every particle of the current cloud (out[n]) and of one given state: the pieces of summary_of a
+ * sharded summary needs separately (tests/oracle_shard.py: the order statistics are global ranks, found over the shards). */
+void oracle_pf_eta(const oracle_pf* pf, double* out) {
+  for (uint64_t i = 0; i < pf->n; ++i) out[i] = o_link(pf, gamma_of(pf, pf->x + i * pf->d, pf->t));
+}
+double oracle_pf_eta_of(const oracle_pf* pf, const double* state) { return o_link(pf, gamma_of(pf, state, pf->t)); }
+
 /* ------------------------------------------------------------------ FilterInterpolate */
 
 /* FilterInterpolate.stepInterpolate / filterInterpolate, model/ParticleFilter.scala:273-311, followed by the

@@ -67,6 +67,8 @@ def lib() -> C.CDLL:
             "oracle_pf_get_particles": (None, [vp, _dp]),
             "oracle_pf_get_proposed": (None, [vp, _dp]),
             "oracle_pf_get_logw": (None, [vp, _dp]),
+            "oracle_pf_eta": (None, [vp, _dp]),
+            "oracle_pf_eta_of": (C.c_double, [vp, _dp]),
             "oracle_pf_get_ancestors": (None, [vp, _u32p]),
             "oracle_pf_get_cumw": (None, [vp, _dp]),
             "oracle_pf_get_ref": (None, [vp, _dp, _dp]),
@@ -196,6 +198,13 @@ class OraclePf:
         em, el, eu = C.c_double(), C.c_double(), C.c_double()
         _chk(lib().oracle_pf_summary(self._h, interval, _p(m), _p(lo), _p(hi), C.byref(em), C.byref(el), C.byref(eu)))
         return m, lo, hi, em.value, el.value, eu.value
+
+    def eta(self):
+        out = np.zeros(self.n); lib().oracle_pf_eta(self._h, _p(out)); return out
+
+    def eta_of(self, state):
+        s = np.ascontiguousarray(state, dtype=np.float64)
+        return float(lib().oracle_pf_eta_of(self._h, _p(s)))
 
     def interpolate(self, t, y, has=None, interval=0.975, reference_pairing=False):
         t = np.ascontiguousarray(t, dtype=np.float64); y = np.ascontiguousarray(y, dtype=np.float64)

@@ -175,6 +175,48 @@ class OracleShard:
     def want_path(self, on):
         self._want_path = bool(on)
 
+    # -- getIntervals over the shards: the mirror of cssm_pf_shard_summary_* (include/cssm_pf.h), histogram layout included
+    def summary_begin(self, interval):
+        x = self.o.particles()                                             # (d, n) resampled local cloud
+        rows = np.vstack([x, self.o.eta()[None, :]])
+        u = np.ascontiguousarray(rows).view(np.uint64)
+        self._sm_keys = np.where(u >> np.uint64(63) != 0, ~u, u | np.uint64(1 << 63))   # cssm_order_key
+        self.sm_sums = torch.from_numpy(x.sum(axis=1))
+        self.sm_hist = torch.zeros((self.d + 1) * 512, dtype=torch.int32)
+        ng = self.n_global
+        idx = int(np.floor(interval * ng))
+        cl = lambda r: min(max(r, 0), ng - 1)
+        self._sm_rank = [[cl(ng - idx - 1), cl(idx - 1)] for _ in range(self.d)] + [[cl(ng - idx), cl(idx)]]
+        self._sm_prefix = np.zeros((self.d + 1, 2), dtype=np.uint64)
+
+    def summary_hist(self, shift):
+        h = self.sm_hist.numpy().reshape(self.d + 1, 2, 256)
+        hm = np.uint64(0) if shift >= 56 else np.uint64((~0 << (shift + 8)) & (2**64 - 1))
+        for row in range(self.d + 1):
+            k = self._sm_keys[row]
+            b = ((k >> np.uint64(shift)) & np.uint64(255)).astype(np.int64)
+            for j in range(2):
+                sel = (k & hm) == (self._sm_prefix[row, j] & hm)
+                h[row, j] += np.bincount(b[sel], minlength=256).astype(np.int32)
+
+    def summary_pick(self, shift):
+        h = self.sm_hist.numpy().reshape(self.d + 1, 2, 256)
+        for row in range(self.d + 1):
+            for j in range(2):
+                r, cum, b = self._sm_rank[row][j], 0, 0
+                while b < 255 and cum + int(h[row, j, b]) <= r:
+                    cum += int(h[row, j, b]); b += 1
+                self._sm_prefix[row, j] |= np.uint64(b << shift)
+                self._sm_rank[row][j] = r - cum
+        h[:] = 0
+
+    def summary_finish(self):
+        k = self._sm_prefix
+        val = np.where(k >> np.uint64(63) != 0, k & np.uint64((1 << 63) - 1), ~k).view(np.float64)   # cssm_order_unkey
+        mean = self.sm_sums.numpy() / float(self.n_global)
+        return dict(state_mean=mean, state_lower=val[:self.d, 0].copy(), state_upper=val[:self.d, 1].copy(),
+                    eta_of_mean=self.o.eta_of(mean), eta_lower=float(val[self.d, 0]), eta_upper=float(val[self.d, 1]))
+
     def get_path(self, T):
         return self._path[: T + 1].copy()
 

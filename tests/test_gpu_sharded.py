@@ -192,6 +192,47 @@ def test_sharded_filter_returns_the_sampled_path(name, prec, n, world, tiny):
         s.close()
 
 
+def _assert_summary_matches(got, want):
+    m, lo, hi, em, el, eu = want
+    np.testing.assert_array_equal(got["state_lower"], lo)        # order statistics: exact
+    np.testing.assert_array_equal(got["state_upper"], hi)
+    assert got["eta_lower"] == el and got["eta_upper"] == eu
+    np.testing.assert_allclose(got["state_mean"], m, rtol=1e-12, atol=0)   # fp64 sums in another order
+    np.testing.assert_allclose(got["eta_of_mean"], em, rtol=1e-12, atol=0)
+
+
+@pytest.mark.parametrize("name,prec,n,world,interval", [("c2_model", 0, 9001, 4, 0.975), ("c2_model", 0, 9001, 2, 0.5), ("c1_model", 0, 3000, 3, 0.99),
+                                                         ("c3_model", 0, 5000, 2, 0.975), ("gen_brownian_seasonal_gaussian", 0, 4100, 8, 0.9), ("c4_model", 2, 6000, 3, 0.975)])
+def test_sharded_summary_equals_the_single_rank_summary(name, prec, n, world, interval):
+    """ShardedFilter.summary = getIntervals (ParticleFilter.scala:415-424) of the sharded cloud: credible-interval order statistics
+    of every latent component and of eta are GLOBAL ranks (one all-reduce of the byte histograms per radix pass), equal to the
+    oracle's over the single-rank cloud bit for bit; the means agree to the order of summation."""
+    from composablestatespacemodels_amd.sharded import GpuShard, LocalComm, ShardedFilter
+    model = getattr(cases, name)()
+    T = 9
+    t, y, has = cases.event_times(T, horizon=12.0) if prec else cases.poisson_counts(T, missing=0.2)
+    o = oracle.OraclePf(model.descriptor(prec), n, cases.SEED)
+    oll = o.filter(t, y, has)[0]
+    shards = [GpuShard(model, n, r, world, cases.SEED, 0, lgcp_precision=prec) for r in range(world)]
+    f = ShardedFilter(shards, LocalComm(world))
+    ll, _ = f.ll_filter(t, y, has, lgcp=bool(prec))
+    assert ll == oll
+    _assert_summary_matches(f.summary(interval), o.summary(interval))
+    # a second summary of the same cloud (buffers reused), and one after more observations
+    _assert_summary_matches(f.summary(0.6), o.summary(0.6))
+    t2 = t[-1] + np.arange(1, 4) * 0.7
+    y2 = np.ascontiguousarray(y[-3:][::-1])   # (values of the series' own scale: a continued series cannot change plan)
+    if prec:
+        f.ll_filter_more(t2, y2, lgcp=True)
+    else:
+        f.ll_filter_more(t2, y2)
+    for a, b in zip(t2, y2):
+        o.step(a, b)
+    _assert_summary_matches(f.summary(interval), o.summary(interval))
+    for s in shards:
+        s.close()
+
+
 def test_rccl_world1_matches_oracle():
     import torch
     import torch.distributed as dist
@@ -231,6 +272,10 @@ def test_rccl_world1_matches_oracle():
         opath = oracle.OraclePf(model.descriptor(), n, cases.SEED).filter(t, y, has, want_path=True)[3]
         assert f.last_native and ll == oll
         np.testing.assert_array_equal(path, opath)
+        # getIntervals of the sharded cloud: the histogram all-reduces run over RCCL
+        osum = oracle.OraclePf(model.descriptor(), n, cases.SEED)
+        osum.filter(t, y, has)
+        _assert_summary_matches(f.summary(0.975), osum.summary(0.975))
         # ... with the all-to-all-v of the library's trimmed exchange (mode 3 forces it at any world size; at world 1 it
         # carries the rank's own header)
         f4 = ShardedFilter([shard], DistComm(device=torch.device("cuda", 0)))

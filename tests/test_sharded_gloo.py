@@ -45,6 +45,8 @@ def _worker(rank, world, port, name, n, T, missing, prec, out_dir):
         if missing == 0.05:        # capacity too small for what the exchange needs: the observations that miss are resumed
             f.MIN_CAP, f.CAP_SQRT = 1, 0.0
         ll, ess = f.ll_filter(t, y, has, lgcp=bool(prec), exact=(missing == -0.1))
+        sm = f.summary(0.9)     # getIntervals over the shards: eight histogram all-reduces + one of the sums, over gloo
+        np.savez(os.path.join(out_dir, f"s{rank}.npz"), **sm)
         np.savez(os.path.join(out_dir, f"r{rank}.npz"), ll=ll, ess=ess, part=shard.particles(), redone=shard.redone,
                  attempts=f.last_attempts, cap=-1 if f.last_cap is None else f.last_cap, single=int(f.last_single), resumes=int(f.last_resumes), from_max=int(f.last_from_max))
     finally:
@@ -71,7 +73,14 @@ def test_sharded_orchestration_over_gloo_matches_single_rank(tmp_path, world, na
     o = oracle.OraclePf(model.descriptor(prec), n, cases.SEED)
     ll, _, ess_t, _ = o.filter(t, y, has)
     parts = []
+    om, olo, ohi, oem, oel, oeu = o.summary(0.9)
     for r in range(world):
+        sm = np.load(os.path.join(str(tmp_path), f"s{r}.npz"))
+        np.testing.assert_array_equal(sm["state_lower"], olo)
+        np.testing.assert_array_equal(sm["state_upper"], ohi)
+        assert float(sm["eta_lower"]) == oel and float(sm["eta_upper"]) == oeu
+        np.testing.assert_allclose(sm["state_mean"], om, rtol=1e-12)
+        np.testing.assert_allclose(float(sm["eta_of_mean"]), oem, rtol=1e-12)
         z = np.load(os.path.join(str(tmp_path), f"r{r}.npz"))
         # sums are a pass of their own (cssm_pf_shard_sums) wherever the level comes from the global max: every observation of an
         # LGCP series, of the repetition after an outlying observation, and of a series on the exact exchange; else none
@@ -100,6 +109,11 @@ def test_local_comm_matches_single_rank_on_cpu():
     oll, _, oess, _ = o.filter(t, y, has)
     assert (ll, ess) == (oll, int(oess[-1]))
     np.testing.assert_array_equal(np.concatenate([s.particles() for s in shards], axis=1), o.particles())
+    sm, (om, olo, ohi, oem, oel, oeu) = ShardedFilter(shards, LocalComm(world)).summary(0.975), o.summary(0.975)
+    np.testing.assert_array_equal(sm["state_lower"], olo)
+    np.testing.assert_array_equal(sm["state_upper"], ohi)
+    assert (sm["eta_lower"], sm["eta_upper"]) == (oel, oeu)
+    np.testing.assert_allclose(sm["state_mean"], om, rtol=1e-12)
 
 
 @pytest.mark.parametrize("which", ["c2", "c4"])
