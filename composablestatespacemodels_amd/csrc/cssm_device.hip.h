@@ -104,15 +104,34 @@ __device__ __forceinline__ uint64_t readlane_u64(uint64_t v, int lane) {
 }
 
 // inclusive scan across the 64 lanes (integer adds: any order gives the same bits)
+// The DPP read is folded into the adds of the carry chain (v_add_co_u32_dpp / v_addc_co_u32_dpp: src0 comes from the other lane,
+// a lane without a source adds 0; rows masked off by row_mask keep their value): 24 instructions per scan instead of the 48 of
+// v_mov_b32_dpp + add (the compiler does not fold a DPP move into an add that is itself inline assembly, and without the
+// assembly it does not keep the four limbs on one carry chain).  k_offspring scans once per tile of 1024 particles and once
+// more per block: a tenth of its instructions at N = 2^20.  The leading s_nop covers the VALU-write -> DPP-read hazard
+// (2 wait states) against whatever instruction the compiler placed before the block; inside it every DPP operand was written
+// at least 3 instructions earlier.  All 64 lanes must be active.
+#define CSSM_SCAN_STEP(CTRL)                                  \
+  "v_add_co_u32_dpp %0, vcc, %0, %0 " CTRL "\n\t"              \
+  "v_addc_co_u32_dpp %1, vcc, %1, %1, vcc " CTRL "\n\t"        \
+  "v_addc_co_u32_dpp %2, vcc, %2, %2, vcc " CTRL "\n\t"        \
+  "v_addc_co_u32_dpp %3, vcc, %3, %3, vcc " CTRL "\n\t"
 __device__ __forceinline__ cssm_u128 wave_scan_u128(cssm_u128 v, int lane) {
   (void)lane;
-  v = cssm_u128_add(v, dpp0_u128<CSSM_DPP_ROW_SHR(1), 0xf>(v));
-  v = cssm_u128_add(v, dpp0_u128<CSSM_DPP_ROW_SHR(2), 0xf>(v));
-  v = cssm_u128_add(v, dpp0_u128<CSSM_DPP_ROW_SHR(4), 0xf>(v));
-  v = cssm_u128_add(v, dpp0_u128<CSSM_DPP_ROW_SHR(8), 0xf>(v));
-  v = cssm_u128_add(v, dpp0_u128<CSSM_DPP_BCAST15, 0xa>(v));
-  v = cssm_u128_add(v, dpp0_u128<CSSM_DPP_BCAST31, 0xc>(v));
-  return v;
+  uint32_t a0 = (uint32_t)v.lo, a1 = (uint32_t)(v.lo >> 32), a2 = (uint32_t)v.hi, a3 = (uint32_t)(v.hi >> 32);
+  asm volatile("s_nop 1\n\t"
+               CSSM_SCAN_STEP("row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0")
+               CSSM_SCAN_STEP("row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:0")
+               CSSM_SCAN_STEP("row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:0")
+               CSSM_SCAN_STEP("row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:0")
+               CSSM_SCAN_STEP("row_bcast:15 row_mask:0xa bank_mask:0xf")
+               CSSM_SCAN_STEP("row_bcast:31 row_mask:0xc bank_mask:0xf")
+               "s_nop 0"
+               : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : : "vcc");
+  cssm_u128 r;
+  r.lo = (uint64_t)a0 | ((uint64_t)a1 << 32);
+  r.hi = (uint64_t)a2 | ((uint64_t)a3 << 32);
+  return r;
 }
 // wave total, uniform (it is read from lane 63 into scalar registers)
 __device__ __forceinline__ cssm_u128 wave_sum_u128(cssm_u128 v) {
@@ -460,7 +479,7 @@ __device__ __forceinline__ void store_anc4_sc1(uint32_t* p, uint32_t a, uint32_t
 // the reads of others without s_barrier -- the compiler is held to that order by wave_barrier + an explicit lgkmcnt wait.
 // k_offspring spent half its wave cycles waiting (PMC SQ_WAIT_ANY 51 %): eight block barriers per tile of 1024 particles,
 // five of them in the block-wide version of this function.  s_wave: CSSM_WAVE_CHUNK words of LDS owned by this wave.
-template <bool SC1>
+template <bool SC1, bool CLIP = true>
 __device__ __forceinline__ void fill_runs_wave(uint32_t prev, const uint32_t (&e)[CSSM_ITEMS], uint32_t first_idx, uint32_t lo, uint32_t hi,
                                                uint32_t* __restrict__ anc, uint32_t slot_off, uint32_t idx_max, uint32_t* __restrict__ s_wave) {
   const uint32_t lane = threadIdx.x & 63u;
@@ -469,15 +488,25 @@ __device__ __forceinline__ void fill_runs_wave(uint32_t prev, const uint32_t (&e
     uint4* z = reinterpret_cast<uint4*>(s_wave + lane * 8);
     z[0] = make_uint4(0u, 0u, 0u, 0u); z[1] = make_uint4(0u, 0u, 0u, 0u);
     lds_order();
+    if (!CLIP && c0 <= lo && hi - c0 <= CSSM_WAVE_CHUNK) {
+      // (uniform) !CLIP: [lo, hi) is exactly the union of this wave's runs, and here all of it lies in this chunk: no run
+      // needs clipping -- the common case (a wave's 256 particles own 256 slots on average, the chunk holds 512)
 #pragma unroll
-    for (int r = 0; r < CSSM_ITEMS; ++r) {
-      uint32_t rb = (r == 0) ? prev : e[r - 1];
-      uint32_t re = e[r];
-      rb = (rb < lo) ? lo : rb;
-      re = (re > hi) ? hi : re;
-      if (re > rb && re > c0 && rb < c0 + CSSM_WAVE_CHUNK) {
-        const uint32_t pos = ((rb > c0) ? rb : c0) - c0;
-        s_wave[pos] = first_idx + r + 1u;                  // index + 1 (0 = no run starts here)
+      for (int r = 0; r < CSSM_ITEMS; ++r) {
+        const uint32_t rb = (r == 0) ? prev : e[r - 1];
+        if (e[r] > rb) s_wave[rb - c0] = first_idx + r + 1u;
+      }
+    } else {
+#pragma unroll
+      for (int r = 0; r < CSSM_ITEMS; ++r) {
+        uint32_t rb = (r == 0) ? prev : e[r - 1];
+        uint32_t re = e[r];
+        rb = (rb < lo) ? lo : rb;
+        re = (re > hi) ? hi : re;
+        if (re > rb && re > c0 && rb < c0 + CSSM_WAVE_CHUNK) {
+          const uint32_t pos = ((rb > c0) ? rb : c0) - c0;
+          s_wave[pos] = first_idx + r + 1u;                  // index + 1 (0 = no run starts here)
+        }
       }
     }
     lds_order();
@@ -489,8 +518,9 @@ __device__ __forceinline__ void fill_runs_wave(uint32_t prev, const uint32_t (&e
     const uint32_t carry = dpp0<0x138 /* wave_shr:1 */, 0xf>(incl);   // exclusive: max over the lanes before this one (lane 0: 0)
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
-      uint32_t x = (v[k] > carry) ? v[k] : carry;
-      x = (x > 0u) ? x - 1u : 0u;                           // (0 cannot occur inside [lo, hi): every slot there belongs to a run)
+      // (0 cannot occur inside [lo, hi): every slot there belongs to a run; outside it nothing is stored, and 0 - 1 wraps to
+      //  what the clamp turns into idx_max)
+      const uint32_t x = ((v[k] > carry) ? v[k] : carry) - 1u;
       v[k] = (x > idx_max) ? idx_max : x;
     }
     // back through LDS so that each of the two store instructions of the wave covers 1 KiB contiguously

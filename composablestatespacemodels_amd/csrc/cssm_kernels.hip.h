@@ -425,6 +425,7 @@ __device__ __forceinline__ void offspring_body(const double* __restrict__ logw, 
   if (unit < nunits) do {
     const uint32_t t0 = unit * sup;
     const uint32_t t1 = (t0 + sup < ntiles) ? t0 + sup : ntiles;
+    uint32_t tile_last = 0u;                               // (wave 0, lane 0) end slot of the previous tile's last particle
     cssm_u128 toff;                                        // cumulative weight before the current tile
     if (!SELF && all5) {                                   // sharded: unitP holds the (sub-)unit SUMS; the totals came with all5
       cssm_u128 pre = cssm_u128_zero();
@@ -460,29 +461,46 @@ __device__ __forceinline__ void offspring_body(const double* __restrict__ logw, 
       // exclusive prefix of this thread = off + inc - tsum
       cssm_u128 run = cssm_u128_add(off, inc);
       { cssm_u128 r; r.lo = run.lo - tsum.lo; r.hi = run.hi - tsum.hi - (run.lo < tsum.lo ? 1u : 0u); run = r; }
-      // End slot of a particle = cnt(C_j) of the contract.  Fast path: p = S_j/S_tot*N - u evaluated in
-      // fp64 has an absolute error < N*2^-49.5 slots (two conversions, one quotient, one fma), and the
-      // contract's own roundings move a decision by < N*2^-51 slots; whenever p is farther than
-      // eps = N*2^-46 from an integer, floor(p)+1 IS the contract's count.  Otherwise (probability
-      // 2*eps per particle) the exact predicate is evaluated.
+      // End slot of a particle = cnt(C_j) of the contract.  Fast path: p = S_j/S_tot*N - u evaluated in fp64; whenever p is
+      // farther than eps = N*2^-44 from an integer, floor(p)+1 IS the contract's count.  Otherwise (probability 2*eps per
+      // particle) the exact predicate is evaluated on the exact 128-bit prefix.  Error budget of the fast path, in slots:
+      //   S_j as a double: the thread's exclusive prefix is converted once (two conversions: < N*2^-52), then every particle adds
+      //     its weight IN FLOATING POINT, sd += w1 * 2^96 (<= 4 roundings: < N*2^-51) -- the weight as a double, not its
+      //     truncation to the 2^-96 grid: the drift is < 4 * 2^-96 / S_tot, and S_tot >= the largest weight >= exp(-32) > 2^-46.2
+      //     (cssm_ref_choose admits a level at most CSSM_REF_ABOVE = 32 above the max; a level from the max itself gives 1):
+      //     < N*2^-47.8.  (Round 2 converted the exact 128-bit running sum per particle: 13 instructions against 1.)
+      //   quotient N / S_tot, the fma: < N*2^-51; the contract's own roundings move a decision by < N*2^-51.
+      // Total < N*2^-47.2, a factor 9 inside eps.  raw == 1 (stateless resampling of arbitrary host weights: no lower bound on
+      // S_tot) keeps the exact running sum.
       const double nd = (double)n_global;
       const double scale = nd / totd;
-      const double eps = nd * 0x1.0p-46;
+      const double eps = nd * 0x1.0p-44;
       uint32_t e[CSSM_ITEMS];
+      const cssm_u128 run0 = run;
+      double sd = cssm_fma((double)run.hi, 0x1.0p64, (double)run.lo);
 #pragma unroll
       for (int r = 0; r < CSSM_ITEMS; ++r) {
-        run = cssm_u128_add(run, q[r]);
-        const double sd = cssm_fma((double)run.hi, 0x1.0p64, (double)run.lo);
+        if (raw == 1) {
+          run = cssm_u128_add(run, q[r]);
+          sd = cssm_fma((double)run.hi, 0x1.0p64, (double)run.lo);
+        } else {
+          sd = cssm_fma(w1[r], 0x1.0p96, sd);
+        }
         const double pp = cssm_fma(sd, scale, -u);
         const double fl = __builtin_floor(pp);
         const double fr = pp - fl;
-        double cnt = fl + 1.0;
-        cnt = (cnt < 0.0) ? 0.0 : cnt;
-        cnt = (cnt > nd) ? nd : cnt;
         const bool safe = (fr > eps) && (fr < 1.0 - eps) && !force_exact && resampler == CSSM_RESAMPLE_SYSTEMATIC;
         if (safe) {
-          e[r] = (uint32_t)cnt;
+          // (sd >= 0 and u < 1: p > -1, the count is non-negative; it cannot exceed N either -- the min is a guard for the
+          //  ancestor writes below, not part of the arithmetic)
+          const uint32_t c32 = (uint32_t)(fl + 1.0);
+          e[r] = (c32 > (uint32_t)n_global) ? (uint32_t)n_global : c32;
         } else {
+          if (raw != 1) {                                      // the exact prefix, formed only here
+            run = run0;
+#pragma unroll
+            for (int k = 0; k < CSSM_ITEMS; ++k) if (k <= r) run = cssm_u128_add(run, q[k]);
+          }
           const double C = cssm_u128_to_double(run) / totd;
           if (resampler == CSSM_RESAMPLE_SYSTEMATIC) {
             e[r] = (uint32_t)(pow2 ? cssm_sys_count_pow2(C, u, n_global, inv_n) : cssm_sys_count(C, u, n_global));
@@ -513,12 +531,23 @@ __device__ __forceinline__ void offspring_body(const double* __restrict__ logw, 
         if (lane == 0) {
           if (wid > 0) prev = s_last[wid - 1];
           else if (tile == 0 && (SELF || all5 == nullptr || rank == 0)) prev = 0u;   // the globally first particle
-          else {   // the same formula on the tile's exclusive prefix
-            const double Cp = cssm_u128_to_double(toff) / totd;
-            prev = (resampler == CSSM_RESAMPLE_STRATIFIED)
-                       ? (uint32_t)cssm_strat_count(Cp, seed, rec->step, n_global)
-                       : (uint32_t)(pow2 ? cssm_sys_count_pow2(Cp, u, n_global, inv_n) : cssm_sys_count(Cp, u, n_global));
+          else if (tile != t0) prev = tile_last;               // the previous tile of this unit ended there
+          else {   // the same formula on the unit's exclusive prefix: the fast path of the end slots above, else the exact one
+            const double sdp = cssm_fma((double)toff.hi, 0x1.0p64, (double)toff.lo);
+            const double ppp = cssm_fma(sdp, scale, -u);
+            const double flp = __builtin_floor(ppp);
+            const double frp = ppp - flp;
+            if ((frp > eps) && (frp < 1.0 - eps) && !force_exact && resampler == CSSM_RESAMPLE_SYSTEMATIC) {
+              const uint32_t c32 = (uint32_t)(flp + 1.0);
+              prev = (c32 > (uint32_t)n_global) ? (uint32_t)n_global : c32;
+            } else {
+              const double Cp = cssm_u128_to_double(toff) / totd;
+              prev = (resampler == CSSM_RESAMPLE_STRATIFIED)
+                         ? (uint32_t)cssm_strat_count(Cp, seed, rec->step, n_global)
+                         : (uint32_t)(pow2 ? cssm_sys_count_pow2(Cp, u, n_global, inv_n) : cssm_sys_count(Cp, u, n_global));
+            }
           }
+          if (wid == 0) tile_last = s_last[CSSM_BLOCK / 64 - 1];   // (read before the tile's last barrier, rewritten after it)
         }
         // the slots this WAVE's 256 particles own: [start of its first particle's run, end of its last particle's run), clipped
         // to this launch's slots; their ancestors are assembled in the wave's LDS region and written as whole lines, with no
@@ -528,8 +557,8 @@ __device__ __forceinline__ void offspring_body(const double* __restrict__ logw, 
         if (CLIP) { wb = (wb < slot_lo) ? slot_lo : wb; we = (we > slot_hi) ? slot_hi : we; }
         we = (we > (uint32_t)n_global) ? (uint32_t)n_global : we;
         wb = (wb > we) ? we : wb;
-        fill_runs_wave<CSSM_OFF_SC1 != 0>(prev, e, (uint32_t)i0, wb, we, anc, CLIP ? slot_lo : 0u, (uint32_t)(n - 1),
-                                          s_slot + wid * CSSM_WAVE_CHUNK);
+        fill_runs_wave<CSSM_OFF_SC1 != 0, CLIP>(prev, e, (uint32_t)i0, wb, we, anc, CLIP ? slot_lo : 0u, (uint32_t)(n - 1),
+                                                s_slot + wid * CSSM_WAVE_CHUNK);
       }
       // advance the running prefix by this tile's total
       cssm_u128 ttot = s_w[0];

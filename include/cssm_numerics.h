@@ -677,6 +677,20 @@ CSSM_HD int cssm_u128_is_zero(cssm_u128 a) { return (a.lo | a.hi) == 0; }
  * exp of a clamped non-positive number): the same value as cssm_fix_from_double without its range selects. */
 CSSM_HD cssm_u128 cssm_fix_from_unit(double x) {
   cssm_u128 r;
+#if CSSM_DEVICE_FORM
+  /* v_fract_f64 = t - floor(t): for a non-negative t below 2^32 exactly the t - (double)(uint32_t)t of the portable form
+   * (dropping integer bits never rounds), one instruction instead of two per digit */
+  const uint32_t f3 = (uint32_t)x;
+  double tf = __builtin_amdgcn_fract(x) * 0x1.0p32;
+  const uint32_t f2 = (uint32_t)tf;
+  tf = __builtin_amdgcn_fract(tf) * 0x1.0p32;
+  const uint32_t f1 = (uint32_t)tf;
+  tf = __builtin_amdgcn_fract(tf) * 0x1.0p32;
+  const uint32_t f0 = (uint32_t)tf;
+  r.hi = ((uint64_t)f3 << 32) | f2;
+  r.lo = ((uint64_t)f1 << 32) | f0;
+  return r;
+#endif
   const uint32_t d3 = (uint32_t)x;                        /* integer part */
   double t = (x - (double)d3) * 0x1.0p32;
   const uint32_t d2 = (uint32_t)t;
