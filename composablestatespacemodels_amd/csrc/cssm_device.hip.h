@@ -133,6 +133,26 @@ __device__ __forceinline__ cssm_u128 wave_scan_u128(cssm_u128 v, int lane) {
   r.hi = (uint64_t)a2 | ((uint64_t)a3 << 32);
   return r;
 }
+// off + (the value `inc` holds in the lane before; lane 0: 0): the exclusive prefix from an inclusive scan, one carry chain whose
+// first operand is read through DPP wave_shr:1
+__device__ __forceinline__ cssm_u128 wave_excl_add_u128(cssm_u128 inc, cssm_u128 off) {
+  uint32_t a0 = (uint32_t)inc.lo, a1 = (uint32_t)(inc.lo >> 32), a2 = (uint32_t)inc.hi, a3 = (uint32_t)(inc.hi >> 32);
+  const uint32_t b0 = (uint32_t)off.lo, b1 = (uint32_t)(off.lo >> 32), b2 = (uint32_t)off.hi, b3 = (uint32_t)(off.hi >> 32);
+  uint32_t r0, r1, r2, r3;
+  asm volatile("s_nop 1\n\t"
+               "v_add_co_u32_dpp %0, vcc, %4, %8 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
+               "v_addc_co_u32_dpp %1, vcc, %5, %9, vcc wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
+               "v_addc_co_u32_dpp %2, vcc, %6, %10, vcc wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
+               "v_addc_co_u32_dpp %3, vcc, %7, %11, vcc wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0"
+               : "=&v"(r0), "=&v"(r1), "=&v"(r2), "=&v"(r3)
+               : "v"(a0), "v"(a1), "v"(a2), "v"(a3), "v"(b0), "v"(b1), "v"(b2), "v"(b3) : "vcc");
+  cssm_u128 r;
+  r.lo = (uint64_t)r0 | ((uint64_t)r1 << 32);
+  r.hi = (uint64_t)r2 | ((uint64_t)r3 << 32);
+  return r;
+}
+// x - floor(x) of a non-negative finite x (v_fract_f64)
+__device__ __forceinline__ double cssm_fract_pos(double x) { return __builtin_amdgcn_fract(x); }
 // wave total, uniform (it is read from lane 63 into scalar registers)
 __device__ __forceinline__ cssm_u128 wave_sum_u128(cssm_u128 v) {
   v = wave_scan_u128(v, 0);
@@ -471,11 +491,11 @@ __device__ __forceinline__ void store_anc4_sc1(uint32_t* p, uint32_t a, uint32_t
 // findAllInTreeMap (model/Resampling.scala:36-46) for ONE WAVE's 256 particles, with no block barrier at all: lane l holds the
 // end slots e[0..3] of its four consecutive particles first_idx .. first_idx + 3 and the end slot `prev` of the particle before
 // them; the wave's particles own the slots [lo, hi) (wave-uniform; already clipped to what this launch may write).  The ancestor
-// indices of those slots are assembled in LDS, 512 at a time -- every particle drops its index + 1 at the first slot of its run,
+// indices of those slots are assembled in LDS, 512 at a time -- every particle drops its index at the first slot of its run,
 // an inclusive max-scan fills the runs (indices grow with the slots) -- and leave as whole lines (round 1 wrote 4 bytes per slot:
 // 1.38x the algorithmic write traffic).  SC1: write-through stores.  anc is indexed by slot - slot_off (signed arithmetic: a
 // chunk starts on a 64-slot boundary at or below lo, which can lie below slot_off; only slots inside [lo, hi) are dereferenced);
-// values are clamped to idx_max.  A wave's LDS operations execute in program order, so markers written by some lanes are visible to
+// idx_max: unused since the markers are the indices themselves (it clamped index + 1 - 1).  A wave's LDS operations execute in program order, so markers written by some lanes are visible to
 // the reads of others without s_barrier -- the compiler is held to that order by wave_barrier + an explicit lgkmcnt wait.
 // k_offspring spent half its wave cycles waiting (PMC SQ_WAIT_ANY 51 %): eight block barriers per tile of 1024 particles,
 // five of them in the block-wide version of this function.  s_wave: CSSM_WAVE_CHUNK words of LDS owned by this wave.
@@ -483,6 +503,7 @@ template <bool SC1, bool CLIP = true>
 __device__ __forceinline__ void fill_runs_wave(uint32_t prev, const uint32_t (&e)[CSSM_ITEMS], uint32_t first_idx, uint32_t lo, uint32_t hi,
                                                uint32_t* __restrict__ anc, uint32_t slot_off, uint32_t idx_max, uint32_t* __restrict__ s_wave) {
   const uint32_t lane = threadIdx.x & 63u;
+  (void)idx_max;
   auto lds_order = [] { __builtin_amdgcn_wave_barrier(); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_wave_barrier(); };
   for (uint32_t c0 = lo & ~63u; c0 < hi; c0 += CSSM_WAVE_CHUNK) {
     uint4* z = reinterpret_cast<uint4*>(s_wave + lane * 8);
@@ -494,7 +515,7 @@ __device__ __forceinline__ void fill_runs_wave(uint32_t prev, const uint32_t (&e
 #pragma unroll
       for (int r = 0; r < CSSM_ITEMS; ++r) {
         const uint32_t rb = (r == 0) ? prev : e[r - 1];
-        if (e[r] > rb) s_wave[rb - c0] = first_idx + r + 1u;
+        if (e[r] > rb) s_wave[rb - c0] = first_idx + r;
       }
     } else {
 #pragma unroll
@@ -505,7 +526,7 @@ __device__ __forceinline__ void fill_runs_wave(uint32_t prev, const uint32_t (&e
         re = (re > hi) ? hi : re;
         if (re > rb && re > c0 && rb < c0 + CSSM_WAVE_CHUNK) {
           const uint32_t pos = ((rb > c0) ? rb : c0) - c0;
-          s_wave[pos] = first_idx + r + 1u;                  // index + 1 (0 = no run starts here)
+          s_wave[pos] = first_idx + r;                       // 0 = no run starts here, or particle 0's (see below)
         }
       }
     }
@@ -518,10 +539,10 @@ __device__ __forceinline__ void fill_runs_wave(uint32_t prev, const uint32_t (&e
     const uint32_t carry = dpp0<0x138 /* wave_shr:1 */, 0xf>(incl);   // exclusive: max over the lanes before this one (lane 0: 0)
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
-      // (0 cannot occur inside [lo, hi): every slot there belongs to a run; outside it nothing is stored, and 0 - 1 wraps to
-      //  what the clamp turns into idx_max)
-      const uint32_t x = ((v[k] > carry) ? v[k] : carry) - 1u;
-      v[k] = (x > idx_max) ? idx_max : x;
+      // (a marker is the index of the particle whose run starts at the slot; an empty slot reads 0, which is also particle 0's
+      //  marker: the slots of [lo, hi) before every other marker can only be particle 0's run -- the cloud's first slots -- so the
+      //  running max is the ancestor as it stands.  Every marker is a particle index of this tile: <= idx_max.)
+      v[k] = (v[k] > carry) ? v[k] : carry;
     }
     // back through LDS so that each of the two store instructions of the wave covers 1 KiB contiguously
     lds_order();

@@ -458,9 +458,8 @@ __device__ __forceinline__ void offspring_body(const double* __restrict__ logw, 
       __syncthreads();
       cssm_u128 off = toff;
       for (int w = 0; w < wid; ++w) off = cssm_u128_add(off, s_w[w]);
-      // exclusive prefix of this thread = off + inc - tsum
-      cssm_u128 run = cssm_u128_add(off, inc);
-      { cssm_u128 r; r.lo = run.lo - tsum.lo; r.hi = run.hi - tsum.hi - (run.lo < tsum.lo ? 1u : 0u); run = r; }
+      // exclusive prefix of this thread = off + the inclusive scan of the lane before (lane 0: + 0)
+      cssm_u128 run = wave_excl_add_u128(inc, off);
       // End slot of a particle = cnt(C_j) of the contract.  Fast path: p = S_j/S_tot*N - u evaluated in fp64; whenever p is
       // farther than eps = N*2^-44 from an integer, floor(p)+1 IS the contract's count.  Otherwise (probability 2*eps per
       // particle) the exact predicate is evaluated on the exact 128-bit prefix.  Error budget of the fast path, in slots:
@@ -475,6 +474,7 @@ __device__ __forceinline__ void offspring_body(const double* __restrict__ logw, 
       const double nd = (double)n_global;
       const double scale = nd / totd;
       const double eps = nd * 0x1.0p-44;
+      const double one_minus_u = 1.0 - u;
       uint32_t e[CSSM_ITEMS];
       const cssm_u128 run0 = run;
       double sd = cssm_fma((double)run.hi, 0x1.0p64, (double)run.lo);
@@ -486,14 +486,14 @@ __device__ __forceinline__ void offspring_body(const double* __restrict__ logw, 
         } else {
           sd = cssm_fma(w1[r], 0x1.0p96, sd);
         }
-        const double pp = cssm_fma(sd, scale, -u);
-        const double fl = __builtin_floor(pp);
-        const double fr = pp - fl;
+        // p + 1 = S_j/S_tot*N + (1 - u) > 0 (1 - u is exact: u is a multiple of 2^-53 in [0, 1)): its integer part is the count,
+        // its fraction (v_fract_f64) the distance test
+        const double pp1 = cssm_fma(sd, scale, one_minus_u);
+        const double fr = cssm_fract_pos(pp1);
         const bool safe = (fr > eps) && (fr < 1.0 - eps) && !force_exact && resampler == CSSM_RESAMPLE_SYSTEMATIC;
         if (safe) {
-          // (sd >= 0 and u < 1: p > -1, the count is non-negative; it cannot exceed N either -- the min is a guard for the
-          //  ancestor writes below, not part of the arithmetic)
-          const uint32_t c32 = (uint32_t)(fl + 1.0);
+          // (the count cannot exceed N -- the min is a guard for the ancestor writes below, not part of the arithmetic)
+          const uint32_t c32 = (uint32_t)pp1;
           e[r] = (c32 > (uint32_t)n_global) ? (uint32_t)n_global : c32;
         } else {
           if (raw != 1) {                                      // the exact prefix, formed only here
@@ -534,11 +534,10 @@ __device__ __forceinline__ void offspring_body(const double* __restrict__ logw, 
           else if (tile != t0) prev = tile_last;               // the previous tile of this unit ended there
           else {   // the same formula on the unit's exclusive prefix: the fast path of the end slots above, else the exact one
             const double sdp = cssm_fma((double)toff.hi, 0x1.0p64, (double)toff.lo);
-            const double ppp = cssm_fma(sdp, scale, -u);
-            const double flp = __builtin_floor(ppp);
-            const double frp = ppp - flp;
+            const double ppp = cssm_fma(sdp, scale, one_minus_u);
+            const double frp = cssm_fract_pos(ppp);
             if ((frp > eps) && (frp < 1.0 - eps) && !force_exact && resampler == CSSM_RESAMPLE_SYSTEMATIC) {
-              const uint32_t c32 = (uint32_t)(flp + 1.0);
+              const uint32_t c32 = (uint32_t)ppp;
               prev = (c32 > (uint32_t)n_global) ? (uint32_t)n_global : c32;
             } else {
               const double Cp = cssm_u128_to_double(toff) / totd;
