@@ -151,6 +151,19 @@ __device__ __forceinline__ cssm_u128 wave_excl_add_u128(cssm_u128 inc, cssm_u128
   r.hi = (uint64_t)r2 | ((uint64_t)r3 << 32);
   return r;
 }
+// A wave-uniform value the VALU produced, moved into scalar registers (v_readfirstlane_b32): it stops occupying vector registers
+// for as long as it lives.  k_offspring_self's tile loop keeps ~12 such words (the running prefix, N / S_tot, the distance bound).
+__device__ __forceinline__ double uniform_f64(double x) {
+  const uint64_t b = cssm_d2u(x);
+  const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)b), hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(b >> 32));
+  return cssm_u2d((uint64_t)lo | ((uint64_t)hi << 32));
+}
+__device__ __forceinline__ cssm_u128 uniform_u128(cssm_u128 v) {
+  cssm_u128 r;
+  r.lo = (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v.lo) | ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v.lo >> 32)) << 32);
+  r.hi = (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v.hi) | ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v.hi >> 32)) << 32);
+  return r;
+}
 // x - floor(x) of a non-negative finite x (v_fract_f64)
 __device__ __forceinline__ double cssm_fract_pos(double x) { return __builtin_amdgcn_fract(x); }
 // wave total, uniform (it is read from lane 63 into scalar registers)

@@ -212,6 +212,32 @@ __device__ __forceinline__ cssm_u128 block_sum_u128(cssm_u128 v, cssm_u128* s_re
   return t;
 }
 
+// The exact predicate of the systematic end slots for the single-GPU kernel: taken for about N * 2^-43 of the particles.  Inlined
+// once per particle of a thread, inside the loop over them, it was 60 % of the kernel's code and what its registers were sized by
+// (values spilled to scratch on the hot path, ahead of the branch; as a real call the spills of the caller-saved registers were
+// hoisted to the hot path just the same).  It is one rolled loop BEHIND the thread's particles instead, where little is live.
+// run0 + the first k + 1 weights (on the 2^-96 grid) = the exact prefix of particle k; bit k of `mask` asks for its count.
+#ifndef CSSM_OFF_SELF_WAVES
+#define CSSM_OFF_SELF_WAVES 5
+#endif
+__device__ __forceinline__ void offspring_exact_counts(cssm_u128 run0, const double (&w)[4], uint32_t mask, cssm_u128 tot, double u, uint64_t n_global,
+                                                       uint32_t (&e)[4]) {
+  const double totd = cssm_u128_to_double(tot);
+  const bool pow2 = (n_global & (n_global - 1)) == 0;
+  const double inv_n = 1.0 / (double)n_global;
+  cssm_u128 run = run0;
+#pragma unroll 1
+  for (int k = 0; k < 4; ++k) {
+    const double wk = (k == 0) ? w[0] : ((k == 1) ? w[1] : ((k == 2) ? w[2] : w[3]));
+    run = cssm_u128_add(run, cssm_fix_from_unit(wk));
+    if ((mask >> k) & 1u) {
+      const double C = cssm_u128_to_double(run) / totd;
+      const uint32_t c = (uint32_t)(pow2 ? cssm_sys_count_pow2(C, u, n_global, inv_n) : cssm_sys_count(C, u, n_global));
+      e[0] = (k == 0) ? c : e[0]; e[1] = (k == 1) ? c : e[1]; e[2] = (k == 2) ? c : e[2]; e[3] = (k == 3) ? c : e[3];
+    }
+  }
+}
+
 template <bool FUSE, bool SELF, int RS, int RAWC = -1>
 __device__ __forceinline__ void offspring_body(const double* __restrict__ logw, uint64_t n,
                                                           Scalars* __restrict__ sc,
@@ -271,34 +297,53 @@ __device__ __forceinline__ void offspring_body(const double* __restrict__ logw, 
       upre[k] = ((uint32_t)k < E && q < nsub) ? unitP[q] : cssm_u128_zero();
     }
   }
-  double gmax_dec;
-  if (SELF) {
-    gmax_dec = block_decode_slots(sc, slot_set);
-    if (held & 64u) return;
-  } else if (all5) {
-    unsigned long long key = 0ull;
-    for (int r = 0; r < world; ++r) { const unsigned long long k = all5[(size_t)all5_stride * r + 4]; key = (k > key) ? k : key; }
-    gmax_dec = cssm_order_unkey(key);
-  } else {
-    gmax_dec = sc->gmax;
-  }
-  const double gmax = (raw == 1) ? gmax_dec : cssm_ref_choose(rec->ref, gmax_dec);   // the level of this step
-  if (raw != 1 && optimistic && !(gmax == rec->ref)) {
-    if (SELF) {
-      // put the series on hold AT this observation (its propagate is done: the cloud is in place, the previous ancestors are
-      // untouched); every kernel enqueued behind returns at once, the host redoes this observation -- its weights again, as
-      // log-weights, and its sums relative to the max -- and carries on
-      if (blockIdx.x == 0 && threadIdx.x == 0) { sc->gmax = gmax_dec; atomicMin(&sc->fail_step, rec->step); atomicOr(&sc->err, 64u); }
-    } else if (blockIdx.x == 0 && threadIdx.x == 0) {
-      if (flag_out) *flag_out = 1ull;
-      if (optimistic == 2) atomicOr(&sc->err, 4u);   // (merged with the expansion: no later kernel reads the flag)
+  // the record's scalars are requested here, with everything else the kernel starts from (behind the max decode they were a
+  // round trip of their own)
+  const double rec_ref = rec->ref, u = rec->u;
+  const uint32_t rec_step = rec->step;
+  __shared__ unsigned long long s_key;
+  double gmax_dec = 0.0, gmax = 0.0;
+  // the level of this step, once the max is known; false: the level the sums were formed with is ruled out -- nothing may be
+  // resampled (uniform: every block takes the same decision from the same words)
+  auto level_known = [&]() -> bool {
+    gmax = (raw == 1) ? gmax_dec : cssm_ref_choose(rec_ref, gmax_dec);
+    if (raw != 1 && optimistic && !(gmax == rec_ref)) {
+      if (SELF) {
+        // put the series on hold AT this observation (its propagate is done: the cloud is in place, the previous ancestors are
+        // untouched); every kernel enqueued behind returns at once, the host redoes this observation -- its weights again, as
+        // log-weights, and its sums relative to the max -- and carries on
+        if (blockIdx.x == 0 && threadIdx.x == 0) { sc->gmax = gmax_dec; atomicMin(&sc->fail_step, rec_step); atomicOr(&sc->err, 64u); }
+      } else if (blockIdx.x == 0 && threadIdx.x == 0) {
+        if (flag_out) *flag_out = 1ull;
+        if (optimistic == 2) atomicOr(&sc->err, 4u);   // (merged with the expansion: no later kernel reads the flag)
+      }
+      return false;
     }
-    return;
+    return true;
+  };
+  if (SELF) {
+    // wave 0 decodes the running max (lane t reads slot t) and leaves its key in LDS; the block reads it behind the barrier of
+    // the unit-sum scan below (round 2: block_decode_slots, a block barrier of its own at the head of the kernel)
+    if (threadIdx.x < 64) {
+      unsigned long long k = (threadIdx.x < CSSM_MAXSLOTS)
+          ? sc->maxslot[((size_t)slot_set * CSSM_MAXSLOTS + threadIdx.x) * CSSM_SLOT_STRIDE] : 0ull;
+      k = wave_max_u64(k);
+      if (threadIdx.x == 0) s_key = k;
+    }
+    if (held & 64u) return;
+  } else {
+    if (all5) {
+      unsigned long long key = 0ull;
+      for (int r = 0; r < world; ++r) { const unsigned long long k = all5[(size_t)all5_stride * r + 4]; key = (k > key) ? k : key; }
+      gmax_dec = cssm_order_unkey(key);
+    } else {
+      gmax_dec = sc->gmax;
+    }
+    if (!level_known()) return;
   }
   if (!SELF && flag_out && blockIdx.x == 0 && threadIdx.x == 0) *flag_out = 0ull;
-  const double u = rec->u;
   const bool pow2 = (n_global & (n_global - 1)) == 0;
-  const double inv_n = 1.0 / (double)n_global;
+  // (1 / N is formed where the exact predicate is evaluated: a division and two registers in every thread otherwise)
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   double totd = 0.0;
   cssm_u128 S_off = cssm_u128_zero();
@@ -332,8 +377,16 @@ __device__ __forceinline__ void offspring_body(const double* __restrict__ logw, 
   //  block slips into the first free slot long before the grid drains.)
   uint32_t unit = blockIdx.x;
   cssm_u128 toff_self = cssm_u128_zero();
+  double scale_self = 0.0;
+  // SELF: the exact S_tot as a double, from the waves' sums the prologue left in LDS (s_r[1] is not written again)
+  auto totd_exact = [&]() -> double {
+    if (!SELF) return totd;
+    cssm_u128 t = s_r[1][0];
+#pragma unroll
+    for (int w = 1; w < CSSM_BLOCK / 64; ++w) t = cssm_u128_add(t, s_r[1][w]);
+    return cssm_u128_to_double(t);
+  };
   if (SELF) {                                              // here unitP holds the unit SUMS (k_propagate / k_tile_sums output)
-    const bool pub = (blockIdx.x == nunits);
     // ONE wave scan of the threads' own sums gives both the total and the prefix of the entries below this block's first
     // (qlim): that prefix = inclusive scan at thread tq - 1 + the first qlim - tq E entries of thread tq, tq = qlim / E.
     // (Round 2 took two block-wide sums with eight masked 128-bit adds per thread each: a third of the kernel's
@@ -341,30 +394,43 @@ __device__ __forceinline__ void offspring_body(const double* __restrict__ logw, 
     const uint32_t qlim = unit * (uint32_t)split;
     const uint32_t Ed = E ? E : 1u;                                          // (E >= 1 here: SELF; the guard is for the other instantiations)
     const uint32_t tq = qlim / Ed, rq = qlim - tq * Ed;                      // (uniform)
-    cssm_u128 own = cssm_u128_zero(), part = cssm_u128_zero();
+    auto scan_units = [&](cssm_u128& tot, cssm_u128& pre) {   // (contains one block barrier)
+      cssm_u128 own = cssm_u128_zero(), part = cssm_u128_zero();
 #pragma unroll
-    for (int k = 0; k < UPRE; ++k) {     // (upre[k] is zero beyond E and beyond nsub)
-      own = cssm_u128_add(own, upre[k]);
-      if ((uint32_t)k + 1u == rq) part = own;               // the first rq entries of a thread (kept by thread tq only)
-    }
-    for (uint32_t k = UPRE; k < E; ++k) {
-      const uint32_t q = threadIdx.x * E + k;
-      if (q < nsub) own = cssm_u128_add(own, unitP[q]);
-      if (k + 1u == rq) part = own;
-    }
-    const cssm_u128 inc = wave_scan_u128(own, lane);
-    if (lane == 63) s_r[1][wid] = inc;
-    if (threadIdx.x + 1u == tq) s_pre[0] = inc;             // inclusive scan at thread tq - 1, within its wave
-    if (threadIdx.x == tq) s_pre[1] = part;                 // (tq <= 255: qlim < nsub <= 256 E)
-    cssm_u128 tot2 = cssm_u128_zero();
-    // the publisher also totals what it publishes an ESS from: the unit sums of squares when they are at hand ...
-    uint32_t p_pend = 0, p_buf = 0, p_n = 0;
-    cssm_u128 pt2 = cssm_u128_zero();
-    if (pub) {
-      // ... and the squares of the PREVIOUS weighted observation if its ESS is still pending.  Its partials are requested
-      // before the record that says so has arrived (it is on the publisher's critical path, which at N = 2^20 is a round
-      // of its own behind 1024 resident blocks): the other buffer than this launch's, one entry per unit -- what is
-      // pending whenever the previous weighted observation ran this kernel; anything else is read again below.
+      for (int k = 0; k < UPRE; ++k) {     // (upre[k] is zero beyond E and beyond nsub)
+        own = cssm_u128_add(own, upre[k]);
+        if ((uint32_t)k + 1u == rq) part = own;               // the first rq entries of a thread (kept by thread tq only)
+      }
+      for (uint32_t k = UPRE; k < E; ++k) {
+        const uint32_t q = threadIdx.x * E + k;
+        if (q < nsub) own = cssm_u128_add(own, unitP[q]);
+        if (k + 1u == rq) part = own;
+      }
+      const cssm_u128 inc = wave_scan_u128(own, lane);
+      if (lane == 63) s_r[1][wid] = inc;
+      if (threadIdx.x + 1u == tq) s_pre[0] = inc;             // inclusive scan at thread tq - 1, within its wave
+      if (threadIdx.x == tq) s_pre[1] = part;                 // (tq <= 255: qlim < nsub <= 256 E)
+      __syncthreads();
+      tot = s_r[1][0];
+#pragma unroll
+      for (int w = 1; w < CSSM_BLOCK / 64; ++w) tot = cssm_u128_add(tot, s_r[1][w]);
+      pre = (rq > 0u) ? s_pre[1] : cssm_u128_zero();
+      if (tq > 0u) {
+        pre = cssm_u128_add(pre, s_pre[0]);
+        const uint32_t wq = (tq - 1u) >> 6;                   // waves wholly before thread tq - 1's
+#pragma unroll
+        for (int w = 0; w < CSSM_BLOCK / 64 - 1; ++w) if ((uint32_t)w < wq) pre = cssm_u128_add(pre, s_r[1][w]);
+      }
+    };
+    if (blockIdx.x == nunits) {
+      // ---- the publisher: a path of its own that ends here (sharing the scan with the unit blocks kept its partial sums
+      //      alive across their whole tile loop -- 28 bytes of scratch per thread in every block)
+      // It also totals what it publishes an ESS from: the unit sums of squares when they are at hand, and the squares of the
+      // PREVIOUS weighted observation if its ESS is still pending.  Those partials are requested before the record that says
+      // so has arrived (it is on the publisher's critical path, which at N = 2^20 is a round of its own behind 1024 resident
+      // blocks): the other buffer than this launch's, one entry per unit -- what is pending whenever the previous weighted
+      // observation ran this kernel; anything else is read again below.
+      cssm_u128 tot2 = cssm_u128_zero(), pt2 = cssm_u128_zero();
       const uint32_t hint_buf = (s2_par >= 0) ? (uint32_t)(s2_par ^ 1) : 0u;
       {
         const cssm_u128* hb = s2buf + (size_t)hint_buf * s2_stride;
@@ -375,27 +441,16 @@ __device__ __forceinline__ void offspring_body(const double* __restrict__ logw, 
         for (uint32_t q = threadIdx.x; q < nsub; q += CSSM_BLOCK) t2 = cssm_u128_add(t2, unitS2[q]);
         tot2 = block_sum_u128(t2, s_r[2]);
       }
-      p_pend = sc->pend; p_buf = sc->pend_buf; p_n = sc->pend_n;
+      const uint32_t p_pend = sc->pend, p_buf = sc->pend_buf, p_n = sc->pend_n;
       if (p_pend && (p_buf != hint_buf || p_n != nunits)) {   // (uniform) not what was prefetched
         pt2 = cssm_u128_zero();
         const cssm_u128* pb = s2buf + (size_t)p_buf * s2_stride;
         for (uint32_t q = threadIdx.x; q < p_n; q += CSSM_BLOCK) pt2 = cssm_u128_add(pt2, pb[q]);
       }
-    }
-    __syncthreads();
-    cssm_u128 tot = s_r[1][0];
-#pragma unroll
-    for (int w = 1; w < CSSM_BLOCK / 64; ++w) tot = cssm_u128_add(tot, s_r[1][w]);
-    cssm_u128 pre = (rq > 0u) ? s_pre[1] : cssm_u128_zero();
-    if (tq > 0u) {
-      pre = cssm_u128_add(pre, s_pre[0]);
-      const uint32_t wq = (tq - 1u) >> 6;                   // waves wholly before thread tq - 1's
-#pragma unroll
-      for (int w = 0; w < CSSM_BLOCK / 64 - 1; ++w) if ((uint32_t)w < wq) pre = cssm_u128_add(pre, s_r[1][w]);
-    }
-    toff_self = pre;
-    totd = cssm_u128_to_double(tot);
-    if (pub) {
+      cssm_u128 tot, pre_unused;
+      scan_units(tot, pre_unused);
+      gmax_dec = cssm_order_unkey(s_key);
+      if (!level_known()) return;
       cssm_u128 ptot2 = cssm_u128_zero();
       if (p_pend) ptot2 = block_sum_u128(pt2, s_r[2]);
       if (threadIdx.x == 0) {                              // publish the step's scalars once
@@ -420,6 +475,21 @@ __device__ __forceinline__ void offspring_body(const double* __restrict__ logw, 
         sc->maxslot[((size_t)((slot_set + 1 + (int)(threadIdx.x / CSSM_MAXSLOTS)) % CSSM_MAXSETS) * CSSM_MAXSLOTS + threadIdx.x % CSSM_MAXSLOTS) * CSSM_SLOT_STRIDE] = 0ull;
       return;
     }
+    cssm_u128 tot;
+    scan_units(tot, toff_self);
+    gmax_dec = cssm_order_unkey(s_key);
+    if (!level_known()) return;
+    // N / S_tot for the fast path of the end slots: S_tot through two conversions and an fma, its reciprocal by v_rcp_f64 and two
+    // Newton steps (what the division's own expansion starts with): relative error < 2^-50, inside the budget stated below.  The
+    // correctly rounded S_tot of the contract (a normalisation with a leading-zero count: ~35 instructions, and a full division:
+    // ~30, in every thread of every block) is formed only where the exact predicate is evaluated.
+    {
+      const double tf = cssm_fma((double)tot.hi, 0x1.0p64, (double)tot.lo);
+      double rinv = __builtin_amdgcn_rcp(tf);
+      rinv = cssm_fma(cssm_fma(-tf, rinv, 1.0), rinv, rinv);
+      rinv = cssm_fma(cssm_fma(-tf, rinv, 1.0), rinv, rinv);
+      scale_self = uniform_f64((double)n_global * rinv);
+    }
   }
   cssm_u128 acc2 = cssm_u128_zero();                       // SELF, s2_par >= 0: the thread's sum of squared weights
   if (unit < nunits) do {
@@ -435,7 +505,7 @@ __device__ __forceinline__ void offspring_body(const double* __restrict__ logw, 
       toff = cssm_u128_add(S_off, pre);
       __syncthreads();
     } else if (SELF) {
-      toff = toff_self;
+      toff = uniform_u128(toff_self);
     } else {
       toff = cssm_u128_add(S_off, unitP[(size_t)unit * split]);
     }
@@ -444,13 +514,13 @@ __device__ __forceinline__ void offspring_body(const double* __restrict__ logw, 
       double w1[CSSM_ITEMS];
       if (unit == blockIdx.x && tile == t0) weights_from_raw(pre_v, gmax, raw, w1, tab);
       else load_tile_weights(logw, base, n, gmax, raw, w1, tab);
-      cssm_u128 q[CSSM_ITEMS];
+      // the weight on the 2^-96 grid (raw == 1: arbitrary host doubles, range-checked; else exp of a clamped non-positive number).
+      // Not kept: the rare exact path below forms it again from w1 (16 registers live across the whole tile otherwise).
+      auto fixw = [&](double w) { return (raw == 1) ? cssm_fix_from_double(w) : cssm_fix_from_unit(w); };
       cssm_u128 tsum = cssm_u128_zero();
 #pragma unroll
       for (int r = 0; r < CSSM_ITEMS; ++r) {
-        // (raw == 1: arbitrary host doubles, range-checked; else the weight is exp of a clamped non-positive number)
-        q[r] = (raw == 1) ? cssm_fix_from_double(w1[r]) : cssm_fix_from_unit(w1[r]);
-        tsum = cssm_u128_add(tsum, q[r]);
+        tsum = cssm_u128_add(tsum, fixw(w1[r]));
         if (SELF && s2_par >= 0) acc2 = cssm_u128_add(acc2, cssm_fix_from_unit(w1[r] * w1[r]));
       }
       cssm_u128 inc = wave_scan_u128(tsum, lane);
@@ -472,16 +542,19 @@ __device__ __forceinline__ void offspring_body(const double* __restrict__ logw, 
       // Total < N*2^-47.2, a factor 9 inside eps.  raw == 1 (stateless resampling of arbitrary host weights: no lower bound on
       // S_tot) keeps the exact running sum.
       const double nd = (double)n_global;
-      const double scale = nd / totd;
-      const double eps = nd * 0x1.0p-44;
+      const double scale = SELF ? scale_self : nd / totd;
+      const double eps = SELF ? uniform_f64(nd * 0x1.0p-44) : nd * 0x1.0p-44;
+      const double one_minus_eps = SELF ? uniform_f64(1.0 - eps) : 1.0 - eps;
       const double one_minus_u = 1.0 - u;
       uint32_t e[CSSM_ITEMS];
+      constexpr bool OUTLINED = SELF && RS == CSSM_RESAMPLE_SYSTEMATIC && (RAWC == 0 || RAWC == 2) && CSSM_ITEMS == 4;
+      uint32_t unsafe = 0u;                                   // OUTLINED: the particles whose count the exact predicate decides
       const cssm_u128 run0 = run;
       double sd = cssm_fma((double)run.hi, 0x1.0p64, (double)run.lo);
 #pragma unroll
       for (int r = 0; r < CSSM_ITEMS; ++r) {
         if (raw == 1) {
-          run = cssm_u128_add(run, q[r]);
+          run = cssm_u128_add(run, fixw(w1[r]));
           sd = cssm_fma((double)run.hi, 0x1.0p64, (double)run.lo);
         } else {
           sd = cssm_fma(w1[r], 0x1.0p96, sd);
@@ -490,28 +563,37 @@ __device__ __forceinline__ void offspring_body(const double* __restrict__ logw, 
         // its fraction (v_fract_f64) the distance test
         const double pp1 = cssm_fma(sd, scale, one_minus_u);
         const double fr = cssm_fract_pos(pp1);
-        const bool safe = (fr > eps) && (fr < 1.0 - eps) && !force_exact && resampler == CSSM_RESAMPLE_SYSTEMATIC;
+        const bool safe = (fr > eps) && (fr < one_minus_eps) && !force_exact && resampler == CSSM_RESAMPLE_SYSTEMATIC;
         if (safe) {
           // (the count cannot exceed N -- the min is a guard for the ancestor writes below, not part of the arithmetic)
           const uint32_t c32 = (uint32_t)pp1;
           e[r] = (c32 > (uint32_t)n_global) ? (uint32_t)n_global : c32;
+        } else if constexpr (OUTLINED) {
+          e[r] = 0u;
+          unsafe |= 1u << r;
         } else {
           if (raw != 1) {                                      // the exact prefix, formed only here
             run = run0;
 #pragma unroll
-            for (int k = 0; k < CSSM_ITEMS; ++k) if (k <= r) run = cssm_u128_add(run, q[k]);
+            for (int k = 0; k < CSSM_ITEMS; ++k) if (k <= r) run = cssm_u128_add(run, fixw(w1[k]));
           }
-          const double C = cssm_u128_to_double(run) / totd;
+          const double C = cssm_u128_to_double(run) / totd_exact();
           if (resampler == CSSM_RESAMPLE_SYSTEMATIC) {
-            e[r] = (uint32_t)(pow2 ? cssm_sys_count_pow2(C, u, n_global, inv_n) : cssm_sys_count(C, u, n_global));
+            e[r] = (uint32_t)(pow2 ? cssm_sys_count_pow2(C, u, n_global, 1.0 / (double)n_global) : cssm_sys_count(C, u, n_global));
           } else if (resampler == CSSM_RESAMPLE_STRATIFIED) {   // one uniform per slot, model/Resampling.scala:82-83
-            e[r] = (uint32_t)cssm_strat_count(C, seed, rec->step, n_global);
+            e[r] = (uint32_t)cssm_strat_count(C, seed, rec_step, n_global);
           } else {                                              // multinomial: the draws are searched in C afterwards
             const uint64_t ii = base + (uint64_t)threadIdx.x * CSSM_ITEMS + r;
             if (ii < n) cum_out[ii] = C;
             e[r] = 0;
           }
         }
+      }
+      if constexpr (OUTLINED) if (unsafe) {
+        cssm_u128 t = s_r[1][0];                               // S_tot: the waves' sums the prologue left in LDS
+#pragma unroll
+        for (int w = 1; w < CSSM_BLOCK / 64; ++w) t = cssm_u128_add(t, s_r[1][w]);
+        offspring_exact_counts(run0, w1, unsafe, t, u, n_global, e);
       }
       const uint64_t i0 = base + (uint64_t)threadIdx.x * CSSM_ITEMS;
       constexpr bool CLIP = !SELF;
@@ -536,14 +618,22 @@ __device__ __forceinline__ void offspring_body(const double* __restrict__ logw, 
             const double sdp = cssm_fma((double)toff.hi, 0x1.0p64, (double)toff.lo);
             const double ppp = cssm_fma(sdp, scale, one_minus_u);
             const double frp = cssm_fract_pos(ppp);
-            if ((frp > eps) && (frp < 1.0 - eps) && !force_exact && resampler == CSSM_RESAMPLE_SYSTEMATIC) {
+            if ((frp > eps) && (frp < one_minus_eps) && !force_exact && resampler == CSSM_RESAMPLE_SYSTEMATIC) {
               const uint32_t c32 = (uint32_t)ppp;
               prev = (c32 > (uint32_t)n_global) ? (uint32_t)n_global : c32;
+            } else if constexpr (OUTLINED) {
+              cssm_u128 t = s_r[1][0];
+#pragma unroll
+              for (int w = 1; w < CSSM_BLOCK / 64; ++w) t = cssm_u128_add(t, s_r[1][w]);
+              const double z4[4] = {0.0, 0.0, 0.0, 0.0};
+              uint32_t p4[4] = {0u, 0u, 0u, 0u};
+              offspring_exact_counts(toff, z4, 1u, t, u, n_global, p4);
+              prev = p4[0];
             } else {
-              const double Cp = cssm_u128_to_double(toff) / totd;
+              const double Cp = cssm_u128_to_double(toff) / totd_exact();
               prev = (resampler == CSSM_RESAMPLE_STRATIFIED)
-                         ? (uint32_t)cssm_strat_count(Cp, seed, rec->step, n_global)
-                         : (uint32_t)(pow2 ? cssm_sys_count_pow2(Cp, u, n_global, inv_n) : cssm_sys_count(Cp, u, n_global));
+                         ? (uint32_t)cssm_strat_count(Cp, seed, rec_step, n_global)
+                         : (uint32_t)(pow2 ? cssm_sys_count_pow2(Cp, u, n_global, 1.0 / (double)n_global) : cssm_sys_count(Cp, u, n_global));
             }
           }
           if (wid == 0) tile_last = s_last[CSSM_BLOCK / 64 - 1];   // (read before the tile's last barrier, rewritten after it)
@@ -563,11 +653,13 @@ __device__ __forceinline__ void offspring_body(const double* __restrict__ logw, 
       cssm_u128 ttot = s_w[0];
 #pragma unroll
       for (int w = 1; w < CSSM_BLOCK / 64; ++w) ttot = cssm_u128_add(ttot, s_w[w]);
-      toff = cssm_u128_add(toff, ttot);
+      toff = SELF ? uniform_u128(cssm_u128_add(toff, ttot)) : cssm_u128_add(toff, ttot);
       __syncthreads();
     }
   } while (!SELF && (unit += gridDim.x) < nunits);
   if (SELF && s2_par >= 0 && blockIdx.x < nunits) {        // the block's partial sum of squares (its ESS is formed later)
+    // (measured and dropped: one partial per WAVE, no block barrier here -- the publisher, a round of its own behind the 1024
+    //  resident blocks at N = 2^20, then reads four times the entries: 11.1 -> 14.2 us)
     const cssm_u128 b2 = block_sum_u128(acc2, s_r[2]);
     if (threadIdx.x == 0) s2buf[(size_t)s2_par * s2_stride + blockIdx.x] = b2;
   }
@@ -593,7 +685,8 @@ __global__ __launch_bounds__(CSSM_BLOCK, CSSM_OFF_WAVES) void k_offspring(CSSM_O
 // sharded filter's; their scalar registers spilled into vector registers and those into scratch -- 28 bytes per thread,
 // i.e. 7 MB of scratch write-back per launch at N = 2^20, which the PMC counters showed as "wasted" write traffic).
 template <int RS, int RAWC>
-__global__ __launch_bounds__(CSSM_BLOCK, CSSM_OFF_WAVES) void k_offspring_self(
+__global__ __attribute__((amdgpu_flat_work_group_size(CSSM_BLOCK, CSSM_BLOCK),
+                          amdgpu_waves_per_eu((RS == CSSM_RESAMPLE_SYSTEMATIC && RAWC == 2) ? CSSM_OFF_SELF_WAVES : CSSM_OFF_WAVES, 8))) void k_offspring_self(
     const double* __restrict__ logw, uint64_t n, Scalars* __restrict__ sc, const cssm_u128* __restrict__ unitP,
     const cssm_u128* __restrict__ unitS2, const StepRec* __restrict__ rec, uint32_t* __restrict__ anc, uint32_t ntiles, uint32_t sup,
     uint32_t nunits, int slot_set, double* __restrict__ ll_t, int32_t* __restrict__ ess_t, uint32_t rec_idx, int force_exact, int split,
