@@ -238,6 +238,13 @@ __device__ __forceinline__ void offspring_exact_counts(cssm_u128 run0, const dou
   }
 }
 
+// Diagnostic build only (-DCSSM_OFF_STAMPS, tools/offspring_stamps.py): thread 0 of every block of k_offspring_self leaves the
+// constant 100 MHz clock at eight points of the kernel in the (otherwise unused) cumulative-weights buffer.
+#ifdef CSSM_OFF_STAMPS
+#define CSSM_STAMP(k) do { if (SELF && threadIdx.x == 0 && cum_out) reinterpret_cast<unsigned long long*>(cum_out)[(size_t)(is_pub ? gridDim.x - 1u : ublk) * 8 + (k)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define CSSM_STAMP(k) do { } while (0)
+#endif
 template <bool FUSE, bool SELF, int RS, int RAWC = -1>
 __device__ __forceinline__ void offspring_body(const double* __restrict__ logw, uint64_t n,
                                                           Scalars* __restrict__ sc,
@@ -274,16 +281,22 @@ __device__ __forceinline__ void offspring_body(const double* __restrict__ logw, 
   constexpr int resampler = RS;
   const double* tab = nullptr; (void)logtab;
   __shared__ cssm_u128 s_w[CSSM_BLOCK / 64];
-  __shared__ uint32_t s_last[CSSM_BLOCK / 64];
   __shared__ __attribute__((aligned(16))) uint32_t s_slot[FUSE ? (CSSM_BLOCK / 64) * CSSM_WAVE_CHUNK : 4];   // per wave: a 512-slot chunk of ancestor runs
   __shared__ cssm_u128 s_r[3][CSSM_BLOCK / 64];
   __shared__ cssm_u128 s_pre[2];
   // (batch series, single GPU) an earlier observation's reference level was ruled out by its max: the series is on hold at
   // that observation until the host has redone it (run_filter_once); nothing may change meanwhile
   // (the test sits behind the prefetches below: a dependent round trip at the very top of the kernel otherwise)
+  // The single-GPU launch has one block more than units: the publisher.  Where all nunits + 1 <= 1025 blocks are resident at once
+  // (the default kernel: five blocks per CU) it is block 0 -- the oldest wave of its CU, served first -- and block b + 1 works on
+  // unit b; the other instantiations (four blocks per CU) keep it last, where it slips into the first slot a unit block frees.
+  constexpr bool PUB_FIRST = SELF && RS == CSSM_RESAMPLE_SYSTEMATIC && RAWC == 2;
+  const uint32_t ublk = PUB_FIRST ? blockIdx.x - 1u : blockIdx.x;
+  const bool is_pub = SELF && (PUB_FIRST ? blockIdx.x == 0u : blockIdx.x == nunits);
+  CSSM_STAMP(0);
   const uint32_t held = SELF ? sc->err : 0u;
   double pre_v[CSSM_ITEMS];   // the block's first tile is requested before the serial prologue
-  if (blockIdx.x < nunits) load_tile_raw(logw, (uint64_t)blockIdx.x * sup * CSSM_TILE, n, raw, pre_v);
+  if (ublk < nunits) load_tile_raw(logw, (uint64_t)ublk * sup * CSSM_TILE, n, raw, pre_v);
   // ... and (single GPU) so are the unit sums every block totals: thread t owns the E = ceil(nsub / 256) consecutive entries
   // from t E on (up to UPRE of them in flight while the max is decoded; a loop for more)
   constexpr int UPRE = CSSM_OFF_UPRE;
@@ -324,11 +337,13 @@ __device__ __forceinline__ void offspring_body(const double* __restrict__ logw, 
   if (SELF) {
     // wave 0 decodes the running max (lane t reads slot t) and leaves its key in LDS; the block reads it behind the barrier of
     // the unit-sum scan below (round 2: block_decode_slots, a block barrier of its own at the head of the kernel)
-    if (threadIdx.x < 64) {
-      unsigned long long k = (threadIdx.x < CSSM_MAXSLOTS)
-          ? sc->maxslot[((size_t)slot_set * CSSM_MAXSLOTS + threadIdx.x) * CSSM_SLOT_STRIDE] : 0ull;
+    // (which wave: round-robin over the blocks -- a block's wave w runs on SIMD w, and one SIMD of every CU carrying all
+    //  the decodes delayed each CU's youngest blocks at N = 2^20)
+    if ((threadIdx.x >> 6) == (blockIdx.x & (CSSM_BLOCK / 64 - 1))) {
+      const uint32_t l = threadIdx.x & 63u;
+      unsigned long long k = (l < CSSM_MAXSLOTS) ? sc->maxslot[((size_t)slot_set * CSSM_MAXSLOTS + l) * CSSM_SLOT_STRIDE] : 0ull;
       k = wave_max_u64(k);
-      if (threadIdx.x == 0) s_key = k;
+      if (l == 0u) s_key = k;
     }
     if (held & 64u) return;
   } else {
@@ -371,11 +386,11 @@ __device__ __forceinline__ void offspring_body(const double* __restrict__ logw, 
   // (SELF: the single-GPU launch has exactly one block per unit -- no loop, so that what was prefetched above does not
   //  have to stay live around a back edge -- plus ONE more block, the publisher: it totals the sums like every block and
   //  then publishes the observation's scalars (ll; ess: a logarithm and two divisions in one thread) instead of working on
-  //  a unit.  With block 0 doing both, that serial tail was on the critical path of a launch that at small N has nothing
+  //  a unit.  With one block doing both, that serial tail was on the critical path of a launch that at small N has nothing
   //  but its critical path.  Measured and dropped in round 3: letting the LAST unit's block publish when nunits + 1 blocks
   //  exceed the 4 x 256 resident slots (N = 2^20: 1024 units) -- 12.8 vs 12.0 us: blocks do not finish in lockstep, the extra
   //  block slips into the first free slot long before the grid drains.)
-  uint32_t unit = blockIdx.x;
+  uint32_t unit = ublk;
   cssm_u128 toff_self = cssm_u128_zero();
   double scale_self = 0.0;
   // SELF: the exact S_tot as a double, from the waves' sums the prologue left in LDS (s_r[1] is not written again)
@@ -391,9 +406,10 @@ __device__ __forceinline__ void offspring_body(const double* __restrict__ logw, 
     // (qlim): that prefix = inclusive scan at thread tq - 1 + the first qlim - tq E entries of thread tq, tq = qlim / E.
     // (Round 2 took two block-wide sums with eight masked 128-bit adds per thread each: a third of the kernel's
     //  instructions at N = 2^20, where a block has one tile.)
-    const uint32_t qlim = unit * (uint32_t)split;
+    const uint32_t qlim = (is_pub ? 0u : unit) * (uint32_t)split;    // (the publisher needs no prefix)
     const uint32_t Ed = E ? E : 1u;                                          // (E >= 1 here: SELF; the guard is for the other instantiations)
-    const uint32_t tq = qlim / Ed, rq = qlim - tq * Ed;                      // (uniform)
+    // (uniform; E is a power of two for every cloud of a power-of-two size: a shift instead of the division's ~25 instructions)
+    const uint32_t tq = ((Ed & (Ed - 1u)) == 0u) ? (qlim >> (31 - __builtin_clz(Ed))) : qlim / Ed, rq = qlim - tq * Ed;
     auto scan_units = [&](cssm_u128& tot, cssm_u128& pre) {   // (contains one block barrier)
       cssm_u128 own = cssm_u128_zero(), part = cssm_u128_zero();
 #pragma unroll
@@ -422,7 +438,7 @@ __device__ __forceinline__ void offspring_body(const double* __restrict__ logw, 
         for (int w = 0; w < CSSM_BLOCK / 64 - 1; ++w) if ((uint32_t)w < wq) pre = cssm_u128_add(pre, s_r[1][w]);
       }
     };
-    if (blockIdx.x == nunits) {
+    if (is_pub) {
       // ---- the publisher: a path of its own that ends here (sharing the scan with the unit blocks kept its partial sums
       //      alive across their whole tile loop -- 28 bytes of scratch per thread in every block)
       // It also totals what it publishes an ESS from: the unit sums of squares when they are at hand, and the squares of the
@@ -449,6 +465,7 @@ __device__ __forceinline__ void offspring_body(const double* __restrict__ logw, 
       }
       cssm_u128 tot, pre_unused;
       scan_units(tot, pre_unused);
+      CSSM_STAMP(1);
       gmax_dec = cssm_order_unkey(s_key);
       if (!level_known()) return;
       cssm_u128 ptot2 = cssm_u128_zero();
@@ -471,12 +488,14 @@ __device__ __forceinline__ void offspring_body(const double* __restrict__ logw, 
           if (ll_t) ll_t[rec_idx] = sc->ll;
         }
       }
+      CSSM_STAMP(7);
       if (threadIdx.x < 2 * CSSM_MAXSLOTS)   // the two sets this observation did not use
         sc->maxslot[((size_t)((slot_set + 1 + (int)(threadIdx.x / CSSM_MAXSLOTS)) % CSSM_MAXSETS) * CSSM_MAXSLOTS + threadIdx.x % CSSM_MAXSLOTS) * CSSM_SLOT_STRIDE] = 0ull;
       return;
     }
     cssm_u128 tot;
     scan_units(tot, toff_self);
+    CSSM_STAMP(1);
     gmax_dec = cssm_order_unkey(s_key);
     if (!level_known()) return;
     // N / S_tot for the fast path of the end slots: S_tot through two conversions and an fma, its reciprocal by v_rcp_f64 and two
@@ -495,7 +514,6 @@ __device__ __forceinline__ void offspring_body(const double* __restrict__ logw, 
   if (unit < nunits) do {
     const uint32_t t0 = unit * sup;
     const uint32_t t1 = (t0 + sup < ntiles) ? t0 + sup : ntiles;
-    uint32_t tile_last = 0u;                               // (wave 0, lane 0) end slot of the previous tile's last particle
     cssm_u128 toff;                                        // cumulative weight before the current tile
     if (!SELF && all5) {                                   // sharded: unitP holds the (sub-)unit SUMS; the totals came with all5
       cssm_u128 pre = cssm_u128_zero();
@@ -512,7 +530,7 @@ __device__ __forceinline__ void offspring_body(const double* __restrict__ logw, 
     for (uint32_t tile = t0; tile < t1; ++tile) {
       const uint64_t base = (uint64_t)tile * CSSM_TILE;
       double w1[CSSM_ITEMS];
-      if (unit == blockIdx.x && tile == t0) weights_from_raw(pre_v, gmax, raw, w1, tab);
+      if (unit == ublk && tile == t0) weights_from_raw(pre_v, gmax, raw, w1, tab);
       else load_tile_weights(logw, base, n, gmax, raw, w1, tab);
       // the weight on the 2^-96 grid (raw == 1: arbitrary host doubles, range-checked; else exp of a clamped non-positive number).
       // Not kept: the rare exact path below forms it again from w1 (16 registers live across the whole tile otherwise).
@@ -525,7 +543,22 @@ __device__ __forceinline__ void offspring_body(const double* __restrict__ logw, 
       }
       cssm_u128 inc = wave_scan_u128(tsum, lane);
       if (lane == 63) s_w[wid] = inc;
+      // (single GPU) the unit's last tile: the waves' sums of squared weights ride on this barrier -- the block's partial leaves
+      // behind it, its ESS is formed later (a block-wide sum of its own at the end of the kernel cost two more barriers)
+      CSSM_STAMP(2);
+      const bool s2_now = SELF && s2_par >= 0 && tile + 1 == t1;
+      if (s2_now) {
+        const cssm_u128 w2 = wave_scan_u128(acc2, lane);
+        if (lane == 63) s_r[2][wid] = w2;
+      }
       __syncthreads();
+      if (s2_now && threadIdx.x == 0) {
+        cssm_u128 b2 = s_r[2][0];
+#pragma unroll
+        for (int w = 1; w < CSSM_BLOCK / 64; ++w) b2 = cssm_u128_add(b2, s_r[2][w]);
+        s2buf[(size_t)s2_par * s2_stride + ublk] = b2;
+      }
+      CSSM_STAMP(3);
       cssm_u128 off = toff;
       for (int w = 0; w < wid; ++w) off = cssm_u128_add(off, s_w[w]);
       // exclusive prefix of this thread = off + the inclusive scan of the lane before (lane 0: + 0)
@@ -605,16 +638,16 @@ __device__ __forceinline__ void offspring_body(const double* __restrict__ logw, 
           for (int r = 0; r < CSSM_ITEMS; ++r) if (i0 + r < n) endslot[i0 + r] = e[r];
         }
       }
+      CSSM_STAMP(4);
       if (FUSE && resampler != CSSM_RESAMPLE_MULTINOMIAL) {
-        // end slot of the particle before this thread's first one
-        if (lane == 63) s_last[wid] = e[CSSM_ITEMS - 1];
+        // end slot of the particle before this thread's first one: the lane before holds it; lane 0 of every wave evaluates
+        // the count on its wave's exclusive prefix `off` -- the very sum the particle before was counted on in another wave,
+        // tile or block, so the same count (round 2 passed it between the waves through LDS: one more block barrier per tile)
         uint32_t prev = dpp0<0x138 /* wave_shr:1 */, 0xf>(e[CSSM_ITEMS - 1]);
-        __syncthreads();
         if (lane == 0) {
-          if (wid > 0) prev = s_last[wid - 1];
-          else if (tile == 0 && (SELF || all5 == nullptr || rank == 0)) prev = 0u;   // the globally first particle
-          else if (tile != t0) prev = tile_last;               // the previous tile of this unit ended there
-          else {   // the same formula on the unit's exclusive prefix: the fast path of the end slots above, else the exact one
+          if (tile == 0 && wid == 0 && (SELF || all5 == nullptr || rank == 0)) prev = 0u;   // the globally first particle
+          else {   // the fast path of the end slots above, else the exact predicate
+            const cssm_u128 toff = off;
             const double sdp = cssm_fma((double)toff.hi, 0x1.0p64, (double)toff.lo);
             const double ppp = cssm_fma(sdp, scale, one_minus_u);
             const double frp = cssm_fract_pos(ppp);
@@ -636,7 +669,6 @@ __device__ __forceinline__ void offspring_body(const double* __restrict__ logw, 
                          : (uint32_t)(pow2 ? cssm_sys_count_pow2(Cp, u, n_global, 1.0 / (double)n_global) : cssm_sys_count(Cp, u, n_global));
             }
           }
-          if (wid == 0) tile_last = s_last[CSSM_BLOCK / 64 - 1];   // (read before the tile's last barrier, rewritten after it)
         }
         // the slots this WAVE's 256 particles own: [start of its first particle's run, end of its last particle's run), clipped
         // to this launch's slots; their ancestors are assembled in the wave's LDS region and written as whole lines, with no
@@ -649,20 +681,15 @@ __device__ __forceinline__ void offspring_body(const double* __restrict__ logw, 
         fill_runs_wave<CSSM_OFF_SC1 != 0, CLIP>(prev, e, (uint32_t)i0, wb, we, anc, CLIP ? slot_lo : 0u, (uint32_t)(n - 1),
                                                 s_slot + wid * CSSM_WAVE_CHUNK);
       }
+      CSSM_STAMP(5);
       // advance the running prefix by this tile's total
       cssm_u128 ttot = s_w[0];
 #pragma unroll
       for (int w = 1; w < CSSM_BLOCK / 64; ++w) ttot = cssm_u128_add(ttot, s_w[w]);
       toff = SELF ? uniform_u128(cssm_u128_add(toff, ttot)) : cssm_u128_add(toff, ttot);
-      __syncthreads();
+      if (!SELF || tile + 1 < t1) __syncthreads();             // (s_w is rewritten by the next tile / the next unit)
     }
   } while (!SELF && (unit += gridDim.x) < nunits);
-  if (SELF && s2_par >= 0 && blockIdx.x < nunits) {        // the block's partial sum of squares (its ESS is formed later)
-    // (measured and dropped: one partial per WAVE, no block barrier here -- the publisher, a round of its own behind the 1024
-    //  resident blocks at N = 2^20, then reads four times the entries: 11.1 -> 14.2 us)
-    const cssm_u128 b2 = block_sum_u128(acc2, s_r[2]);
-    if (threadIdx.x == 0) s2buf[(size_t)s2_par * s2_stride + blockIdx.x] = b2;
-  }
 }
 
 #define CSSM_OFFSPRING_PARAMS                                                                                              \

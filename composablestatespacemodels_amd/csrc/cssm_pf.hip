@@ -315,6 +315,9 @@ int cssm_launch_propagate(cssm_pf* pf, const StepRec* d_rec, double* pick_out, u
 // weights themselves (raw = 2) and k_offspring forms the sum of squares on the way: that observation's ESS stays pending until
 // the next weighted observation's publisher block, or the host at the end of the call, totals the blocks' partials.
 static int launch_resample(cssm_pf* pf, const StepRec* d_rec, double* ll_t = nullptr, int32_t* ess_t = nullptr, uint32_t rec_idx = 0) {
+#ifdef CSSM_OFF_STAMPS
+  if (!pf->cum) { HIP_TRY(hipMalloc(&pf->cum, pf->stride * 8 + (1u << 20))); HIP_TRY(hipMemsetAsync(pf->cum, 0, 1u << 20, pf->stream)); }
+#endif
   if (pf->resampler == CSSM_RESAMPLE_MULTINOMIAL && !pf->cum) {
     if (hipMalloc(&pf->cum, pf->stride * 8) != hipSuccess) return fail(CSSM_ENOMEM, "hipMalloc cumulative weights");
   }
@@ -1133,3 +1136,13 @@ done:
   if (st) (void)hipStreamDestroy(st);
   return rc;
 }
+
+#ifdef CSSM_OFF_STAMPS
+// diagnostic build: the stamps k_offspring_self's blocks left (8 words per block)
+extern "C" int cssm_pf_debug_stamps(cssm_pf* pf, unsigned long long* out, size_t nwords) {
+  if (!pf || !pf->cum || nwords * 8 > (1u << 20)) return CSSM_EINVAL_ARG;
+  HIP_TRY(hipStreamSynchronize(pf->stream));
+  HIP_TRY(hipMemcpy(out, pf->cum, nwords * 8, hipMemcpyDeviceToHost));
+  return CSSM_OK;
+}
+#endif
