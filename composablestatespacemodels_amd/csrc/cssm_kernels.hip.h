@@ -304,10 +304,15 @@ __device__ __forceinline__ void offspring_body(const double* __restrict__ logw, 
   const uint32_t nsub = SELF ? nunits * (uint32_t)split : 0u;
   const uint32_t E = (nsub + CSSM_BLOCK - 1) / CSSM_BLOCK;
   if (SELF) {
+    if (nsub == UPRE * CSSM_BLOCK) {   // (uniform) every cloud of 2^20 particles or more: UPRE entries per thread, none out of range
 #pragma unroll
-    for (int k = 0; k < UPRE; ++k) {
-      const uint32_t q = threadIdx.x * E + (uint32_t)k;
-      upre[k] = ((uint32_t)k < E && q < nsub) ? unitP[q] : cssm_u128_zero();
+      for (int k = 0; k < UPRE; ++k) upre[k] = unitP[threadIdx.x * UPRE + (uint32_t)k];
+    } else {
+#pragma unroll
+      for (int k = 0; k < UPRE; ++k) {
+        const uint32_t q = threadIdx.x * E + (uint32_t)k;
+        upre[k] = ((uint32_t)k < E && q < nsub) ? unitP[q] : cssm_u128_zero();
+      }
     }
   }
   // the record's scalars are requested here, with everything else the kernel starts from (behind the max decode they were a
@@ -414,9 +419,10 @@ __device__ __forceinline__ void offspring_body(const double* __restrict__ logw, 
       cssm_u128 own = cssm_u128_zero(), part = cssm_u128_zero();
 #pragma unroll
       for (int k = 0; k < UPRE; ++k) {     // (upre[k] is zero beyond E and beyond nsub)
+        if ((uint32_t)k == rq && rq < (uint32_t)UPRE) part = own;   // the first rq entries of a thread (kept by thread tq only; rq is uniform)
         own = cssm_u128_add(own, upre[k]);
-        if ((uint32_t)k + 1u == rq) part = own;               // the first rq entries of a thread (kept by thread tq only)
       }
+      if (rq == (uint32_t)UPRE) part = own;
       for (uint32_t k = UPRE; k < E; ++k) {
         const uint32_t q = threadIdx.x * E + k;
         if (q < nsub) own = cssm_u128_add(own, unitP[q]);
@@ -682,12 +688,14 @@ __device__ __forceinline__ void offspring_body(const double* __restrict__ logw, 
                                                 s_slot + wid * CSSM_WAVE_CHUNK);
       }
       CSSM_STAMP(5);
-      // advance the running prefix by this tile's total
-      cssm_u128 ttot = s_w[0];
+      // advance the running prefix by this tile's total (not behind a unit's last tile on the single GPU: nothing follows)
+      if (!SELF || tile + 1 < t1) {
+        cssm_u128 ttot = s_w[0];
 #pragma unroll
-      for (int w = 1; w < CSSM_BLOCK / 64; ++w) ttot = cssm_u128_add(ttot, s_w[w]);
-      toff = SELF ? uniform_u128(cssm_u128_add(toff, ttot)) : cssm_u128_add(toff, ttot);
-      if (!SELF || tile + 1 < t1) __syncthreads();             // (s_w is rewritten by the next tile / the next unit)
+        for (int w = 1; w < CSSM_BLOCK / 64; ++w) ttot = cssm_u128_add(ttot, s_w[w]);
+        toff = SELF ? uniform_u128(cssm_u128_add(toff, ttot)) : cssm_u128_add(toff, ttot);
+        __syncthreads();                                       // (s_w is rewritten by the next tile / the next unit)
+      }
     }
   } while (!SELF && (unit += gridDim.x) < nunits);
 }
