@@ -220,16 +220,15 @@ __device__ __forceinline__ cssm_u128 block_sum_u128(cssm_u128 v, cssm_u128* s_re
 #ifndef CSSM_OFF_SELF_WAVES
 #define CSSM_OFF_SELF_WAVES 5
 #endif
-__device__ __forceinline__ void offspring_exact_counts(cssm_u128 run0, const double (&w)[4], uint32_t mask, cssm_u128 tot, double u, uint64_t n_global,
-                                                       uint32_t (&e)[4]) {
-  const double totd = cssm_u128_to_double(tot);
+__device__ __forceinline__ void offspring_exact_counts(cssm_u128 run0, const double (&w)[4], uint32_t mask, double totd, double u, uint64_t n_global,
+                                                       uint32_t (&e)[4], bool host_weights = false) {
   const bool pow2 = (n_global & (n_global - 1)) == 0;
   const double inv_n = 1.0 / (double)n_global;
   cssm_u128 run = run0;
 #pragma unroll 1
   for (int k = 0; k < 4; ++k) {
     const double wk = (k == 0) ? w[0] : ((k == 1) ? w[1] : ((k == 2) ? w[2] : w[3]));
-    run = cssm_u128_add(run, cssm_fix_from_unit(wk));
+    run = cssm_u128_add(run, host_weights ? cssm_fix_from_double(wk) : cssm_fix_from_unit(wk));
     if ((mask >> k) & 1u) {
       const double C = cssm_u128_to_double(run) / totd;
       const uint32_t c = (uint32_t)(pow2 ? cssm_sys_count_pow2(C, u, n_global, inv_n) : cssm_sys_count(C, u, n_global));
@@ -586,7 +585,7 @@ __device__ __forceinline__ void offspring_body(const double* __restrict__ logw, 
       const double one_minus_eps = SELF ? uniform_f64(1.0 - eps) : 1.0 - eps;
       const double one_minus_u = 1.0 - u;
       uint32_t e[CSSM_ITEMS];
-      constexpr bool OUTLINED = SELF && RS == CSSM_RESAMPLE_SYSTEMATIC && (RAWC == 0 || RAWC == 2) && CSSM_ITEMS == 4;
+      constexpr bool OUTLINED = RS == CSSM_RESAMPLE_SYSTEMATIC && CSSM_ITEMS == 4;   // (every systematic instantiation)
       uint32_t unsafe = 0u;                                   // OUTLINED: the particles whose count the exact predicate decides
       const cssm_u128 run0 = run;
       double sd = cssm_fma((double)run.hi, 0x1.0p64, (double)run.lo);
@@ -628,12 +627,7 @@ __device__ __forceinline__ void offspring_body(const double* __restrict__ logw, 
           }
         }
       }
-      if constexpr (OUTLINED) if (unsafe) {
-        cssm_u128 t = s_r[1][0];                               // S_tot: the waves' sums the prologue left in LDS
-#pragma unroll
-        for (int w = 1; w < CSSM_BLOCK / 64; ++w) t = cssm_u128_add(t, s_r[1][w]);
-        offspring_exact_counts(run0, w1, unsafe, t, u, n_global, e);
-      }
+      if constexpr (OUTLINED) if (unsafe) offspring_exact_counts(run0, w1, unsafe, totd_exact(), u, n_global, e, raw == 1);
       const uint64_t i0 = base + (uint64_t)threadIdx.x * CSSM_ITEMS;
       constexpr bool CLIP = !SELF;
       if (!FUSE || (CLIP && all5 != nullptr)) {   // the exchange of the sharded filter needs the end slots themselves
@@ -661,12 +655,9 @@ __device__ __forceinline__ void offspring_body(const double* __restrict__ logw, 
               const uint32_t c32 = (uint32_t)ppp;
               prev = (c32 > (uint32_t)n_global) ? (uint32_t)n_global : c32;
             } else if constexpr (OUTLINED) {
-              cssm_u128 t = s_r[1][0];
-#pragma unroll
-              for (int w = 1; w < CSSM_BLOCK / 64; ++w) t = cssm_u128_add(t, s_r[1][w]);
               const double z4[4] = {0.0, 0.0, 0.0, 0.0};
               uint32_t p4[4] = {0u, 0u, 0u, 0u};
-              offspring_exact_counts(toff, z4, 1u, t, u, n_global, p4);
+              offspring_exact_counts(toff, z4, 1u, totd_exact(), u, n_global, p4);
               prev = p4[0];
             } else {
               const double Cp = cssm_u128_to_double(toff) / totd_exact();
