@@ -535,6 +535,8 @@ __device__ __forceinline__ void offspring_body(const double* __restrict__ logw, 
     for (uint32_t tile = t0; tile < t1; ++tile) {
       const uint64_t base = (uint64_t)tile * CSSM_TILE;
       double w1[CSSM_ITEMS];
+      // (measured and dropped: requesting the NEXT tile's weights here, a register pipeline over the 16 tiles a block of the
+      //  2^24 cloud walks -- 71.4 vs 71.7 us: the CU's other blocks already cover the round trip)
       if (unit == ublk && tile == t0) weights_from_raw(pre_v, gmax, raw, w1, tab);
       else load_tile_weights(logw, base, n, gmax, raw, w1, tab);
       // the weight on the 2^-96 grid (raw == 1: arbitrary host doubles, range-checked; else exp of a clamped non-positive number).
