@@ -274,6 +274,8 @@ def run_multi(args, emit=print):
     else:   # rehearsal of the launcher and of the orchestration on CPU (tests): gloo + the test-only oracle shard
         dist.init_process_group("gloo", rank=rank, world_size=world)
     K, W = args.steps, args.warmup
+    if args.particles < 0:
+        raise SystemExit("--particles must be positive (0: the configuration's default)")
     lgcp = args.model == "c4"
     if lgcp:      # configs[3]: a fixed cloud split over the GPUs (strong scaling)
         n_global = args.particles if args.particles > 0 else N_16M

@@ -159,7 +159,7 @@ def test_bench_launcher_reports_a_failing_rank():
     for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
         env.pop(k, None)
     r = subprocess.run([sys.executable, os.path.join(os.path.dirname(HERE), "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "1",
-                        "--particles", "0", "--backend", "gloo", "--launch-timeout", "120"],
+                        "--particles", "-1", "--backend", "gloo", "--launch-timeout", "120"],
                        capture_output=True, text=True, timeout=200, env=env)
     assert r.returncode != 0
     assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
