@@ -112,6 +112,7 @@ struct cssm_pf : HostModel {
   float last_ms = 0.f;
   // optional per-kernel timing (HIP events on the launch stream around every kernel)
   bool profile = false;
+  uint32_t* h_done = nullptr; uint32_t* hd_done = nullptr; uint32_t done_seq = 0;   // k_finish's completion word (host-mapped), read_scalars polls it
   std::vector<hipEvent_t> prof_ev;         // pairs
   std::vector<int> prof_kind;              // kernel kind of pair i
   size_t prof_used = 0;

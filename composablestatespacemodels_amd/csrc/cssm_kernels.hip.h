@@ -772,7 +772,8 @@ static __global__ void k_pick(const double* __restrict__ src, size_t src_stride,
 // host only synchronises the stream.  (Four small hipMemcpyAsync D2H behind a K = 20 series cost ~45 us, this kernel ~4.)
 static __global__ __launch_bounds__(CSSM_BLOCK) void k_finish(Scalars* __restrict__ sc, const cssm_u128* __restrict__ s2buf, uint32_t s2_stride,
                                                               double* __restrict__ ll_t, int32_t* __restrict__ ess_t, uint32_t T, uint32_t gen,
-                                                              Scalars* __restrict__ host_sc, double* __restrict__ host_ll_t, int32_t* __restrict__ host_ess_t) {
+                                                              Scalars* __restrict__ host_sc, double* __restrict__ host_ll_t, int32_t* __restrict__ host_ess_t,
+                                                              uint32_t* __restrict__ host_done = nullptr, uint32_t done_seq = 0u) {
   __shared__ cssm_u128 s_red[CSSM_BLOCK / 64];
   __shared__ int32_t s_ess;
   const uint32_t pend = sc->pend, p_buf = sc->pend_buf, p_n = sc->pend_n, p_idx = sc->pend_idx, p_gen = sc->pend_gen, err = sc->err;
@@ -801,6 +802,12 @@ static __global__ __launch_bounds__(CSSM_BLOCK) void k_finish(Scalars* __restric
   const uint32_t* src = reinterpret_cast<const uint32_t*>(sc);
   uint32_t* dst = reinterpret_cast<uint32_t*>(host_sc);
   for (uint32_t w = W0 + threadIdx.x; w < W1; w += CSSM_BLOCK) dst[w] = (w == WE) ? (uint32_t)ess : ((w == WP) ? 0u : src[w]);
+  // the call's completion word, behind everything above: the host polls it instead of waiting for the stream (read_scalars)
+  if (host_done) {
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_store(host_done, done_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
 }
 
 // per-step record of results for the batch drivers

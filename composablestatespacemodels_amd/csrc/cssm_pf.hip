@@ -101,6 +101,9 @@ static int alloc_handle(cssm_pf* pf) {
   HIP_TRY(hipHostMalloc((void**)&pf->h_sc, sizeof(Scalars), hipHostMallocMapped));
   memset(pf->h_sc, 0, sizeof(Scalars));
   HIP_TRY(hipHostGetDevicePointer((void**)&pf->hd_sc, pf->h_sc, 0));
+  HIP_TRY(hipHostMalloc((void**)&pf->h_done, 64, hipHostMallocMapped));
+  memset(pf->h_done, 0, 64);
+  HIP_TRY(hipHostGetDevicePointer((void**)&pf->hd_done, pf->h_done, 0));
   // sub-unit entries past the last k_propagate block are never written and must read as zero sums
   HIP_TRY(hipMemsetAsync(pf->tileS, 0, nsums * sizeof(cssm_u128), pf->stream));
   HIP_TRY(hipMemsetAsync(pf->tileS2, 0, nsums * sizeof(cssm_u128), pf->stream));
@@ -159,6 +162,7 @@ extern "C" void cssm_pf_destroy(cssm_pf* pf) {
   for (void* p : ptrs) if (p) (void)hipFree(p);
   if (pf->h_recs) (void)hipHostFree(pf->h_recs);
   if (pf->h_sc) (void)hipHostFree(pf->h_sc);
+  if (pf->h_done) (void)hipHostFree(pf->h_done);
   if (pf->h_ll_t) (void)hipHostFree(pf->h_ll_t);
   if (pf->h_ess_t) (void)hipHostFree(pf->h_ess_t);
   for (hipEvent_t e : pf->prof_ev) (void)hipEventDestroy(e);
@@ -372,11 +376,33 @@ int cssm_check_device_err(cssm_pf* pf, const Scalars& h) {
 // The end of a call: k_finish forms an ESS that is still pending, and writes the scalars the host reads (and, with T > 0, the
 // call's ll_t / ess_t) into host-mapped memory; the host synchronises the stream -- no device-to-host copy.  *pf->h_sc is valid
 // from `err` on afterwards.
-static int read_scalars(cssm_pf* pf, uint32_t T = 0, bool want_ll_t = false, bool want_ess_t = false) {
+// poll = true (the batch drivers without a path copy, not while profiling): the host does not wait for the STREAM but for the word
+// k_finish stores last (system-scope release behind its other stores into host-mapped memory) -- the runtime's wait returned
+// ~10 us behind the kernel's end, a short continued leg (bench.py --steps 20) pays that once per 20 observations.  The stream is
+// queried now and then: a faulted or vanished kernel must not leave the host spinning.
+static int read_scalars(cssm_pf* pf, uint32_t T = 0, bool want_ll_t = false, bool want_ess_t = false, bool poll = false) {
+  const uint32_t seq = ++pf->done_seq;
   hipLaunchKernelGGL(k_finish, dim3(1), dim3(CSSM_BLOCK), 0, pf->stream, pf->sc, (const cssm_u128*)pf->s2buf, pf->s2_stride, pf->d_ll_t, pf->d_ess_t, T,
-                     pf->gen, pf->hd_sc, want_ll_t ? pf->hd_ll_t : (double*)nullptr, want_ess_t ? pf->hd_ess_t : (int32_t*)nullptr);
+                     pf->gen, pf->hd_sc, want_ll_t ? pf->hd_ll_t : (double*)nullptr, want_ess_t ? pf->hd_ess_t : (int32_t*)nullptr,
+                     pf->hd_done, seq);
   HIP_TRY(hipGetLastError());
-  HIP_TRY(hipStreamSynchronize(pf->stream));
+  static const bool no_poll = getenv("CSSM_NO_POLL") != nullptr;
+  if (poll && !no_poll && !pf->profile) {
+    volatile uint32_t* flag = pf->h_done;
+    for (uint64_t spins = 1;; ++spins) {
+      if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) == seq) break;
+      if ((spins & 0x3fffu) == 0u) {             // every ~16 K polls (tens of microseconds): is the stream still alive?
+        const hipError_t q = hipStreamQuery(pf->stream);
+        if (q == hipSuccess) {                    // drained: the word must be there (else the kernel did not run to its end)
+          if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) == seq) break;
+          return fail(CSSM_EHIP, "the stream drained without k_finish's completion word");
+        }
+        if (q != hipErrorNotReady) return fail(CSSM_EHIP, "HIP error while waiting for the series: %s", hipGetErrorString(q));
+      }
+    }
+  } else {
+    HIP_TRY(hipStreamSynchronize(pf->stream));
+  }
   pf->ess_host = pf->h_sc->ess;
   return CSSM_OK;
 }
@@ -632,7 +658,7 @@ static int run_filter_once(cssm_pf* pf, const double* t, const double* y, const 
     HIP_TRY(hipEventRecord(pf->ev1, pf->stream));
     HIP_TRY(hipGetLastError());
     if (path) HIP_TRY(hipMemcpyAsync(path, pf->d_path, (T + 1) * (size_t)d * 8, hipMemcpyDeviceToHost, pf->stream));
-    rc = read_scalars(pf, (uint32_t)T, ll_t != nullptr, ess_t != nullptr);   // (k_finish: a pending ESS formed, results into host-mapped memory)
+    rc = read_scalars(pf, (uint32_t)T, ll_t != nullptr, ess_t != nullptr, /*poll=*/path == nullptr);   // (k_finish: a pending ESS formed, results into host-mapped memory)
     if (rc) return rc;
     const Scalars& hh = *pf->h_sc;
     if (!may_hold || !(hh.err & 64u) || (hh.err & 3u)) break;   // (NaN / unusable weights: reported below)
@@ -666,7 +692,8 @@ static int run_filter_once(cssm_pf* pf, const double* t, const double* y, const 
     // weighted observation before it was still pending when k_record ran)
     for (size_t s = 0; s < T; ++s) if (!pf->h_recs[s].has_obs) ess_t[s] = s ? ess_t[s - 1] : ess0;
   }
-  HIP_TRY(hipEventElapsedTime(&pf->last_ms, pf->ev0, pf->ev1));
+  pf->last_ms = -1.f;            // (the event pair is read when somebody asks: cssm_pf_last_loop_ms; a query per call cost ~3 us)
+  if (timing) { HIP_TRY(hipEventSynchronize(pf->ev1)); HIP_TRY(hipEventElapsedTime(&pf->last_ms, pf->ev0, pf->ev1)); }
   prof_collect(pf);
   if (timing) fprintf(stderr, "cssm call T=%zu: records built %.1f us, upload enqueued %.1f, %zu steps enqueued %.1f, results back %.1f (device loop %.1f us)\n",
                       T, ph_rec, ph_up, T, ph_enq, since(tp0), pf->last_ms * 1e3);
@@ -795,6 +822,11 @@ extern "C" int cssm_diag_copy_ceiling(int device, size_t bytes, int reps, double
 
 extern "C" int cssm_pf_last_loop_ms(cssm_pf* pf, float* ms_out) {
   if (!pf || !ms_out) return fail(CSSM_EINVAL_ARG, "null argument");
+  if (pf->last_ms < 0.f) {       // the batch drivers leave the event pair of their device loop unread
+    HIP_TRY(hipSetDevice(pf->device));
+    HIP_TRY(hipEventSynchronize(pf->ev1));   // (the call returned on k_finish's completion word, not on the stream)
+    HIP_TRY(hipEventElapsedTime(&pf->last_ms, pf->ev0, pf->ev1));
+  }
   *ms_out = pf->last_ms;
   return CSSM_OK;
 }

@@ -45,6 +45,9 @@ class NativePf:
         self.n = int(n)
         self.d = int(self.lib.cssm_pf_dim(self._h))
         self.generation = 0
+        # the same entry point bound once more with untyped pointers: run_more hands it raw array addresses
+        self._ll_filter_more_raw = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_double),
+                                               C.c_void_p, C.c_void_p)(("cssm_pf_ll_filter_more", self.lib))
 
     def close(self):
         if getattr(self, "_h", None) is not None and self._h.value:
@@ -128,17 +131,22 @@ class NativePf:
     def run_more(self, t, y, has=None):
         """T MORE observations of the running filter (cssm_pf_ll_filter_more): no new cloud, the clock and the observation count
         go on; returns (ll accumulated since initialisation, ll_t, ess_t) of this call's observations."""
-        t = np.ascontiguousarray(t, dtype=np.float64)
-        y = np.ascontiguousarray(y, dtype=np.float64)
+        # (a short continued leg pays for every microsecond here: no copies of arrays that already are what the ABI takes, raw
+        #  addresses instead of typed ctypes pointers)
+        if not (type(t) is np.ndarray and t.dtype == np.float64 and t.flags.c_contiguous):
+            t = np.ascontiguousarray(t, dtype=np.float64)
+        if not (type(y) is np.ndarray and y.dtype == np.float64 and y.flags.c_contiguous):
+            y = np.ascontiguousarray(y, dtype=np.float64)
         T = len(t)
         hp = None
         if has is not None:
-            has = np.ascontiguousarray(has, dtype=np.uint8)
-            hp = _p(has, C.POINTER(C.c_uint8))
+            if not (type(has) is np.ndarray and has.dtype == np.uint8 and has.flags.c_contiguous):
+                has = np.ascontiguousarray(has, dtype=np.uint8)
+            hp = has.ctypes.data
         ll = C.c_double()
-        ll_t = np.zeros(T)
-        ess_t = np.zeros(T, dtype=np.int32)
-        rc = self.lib.cssm_pf_ll_filter_more(self._h, _p(t), _p(y), hp, T, C.byref(ll), _p(ll_t), _p(ess_t, C.POINTER(C.c_int32)))
+        ll_t = np.empty(T)
+        ess_t = np.empty(T, dtype=np.int32)
+        rc = self._ll_filter_more_raw(self._h, t.ctypes.data, y.ctypes.data, hp, T, C.byref(ll), ll_t.ctypes.data, ess_t.ctypes.data)
         self.generation += 1
         _abi.check(rc)
         return ll.value, ll_t, ess_t
