@@ -116,15 +116,23 @@ def cpu_baseline(budget_s=12.0, all_cores=True):
 
 
 # ------------------------------------------------------------------------------------------------ single GPU
-def _kernel_profile(pf, t, y, has, K, loop_ms_plain):
+def _kernel_profile(pf, t, y, has, K, loop_ms_plain, legs=None):
     """Per-kernel durations of one K-step series: HIP events on the launch stream around every kernel (a pass of its
     own, so that the event records do not perturb the throughput figure), minus what a bracketing event pair adds.
     The event packets sit on the queue and inflate every bracketed launch; calibrated in place: the bracketed durations
     of all kernels of the series add up to more than the same loop takes without brackets, and the excess, split evenly
     over the brackets, is what one bracket adds (idle gaps of the plain loop stay inside the kernels' figures: the
     estimate errs on the long side)."""
+    # legs: [(lo, hi), ...] -- the pass CONTINUES the running filter leg by leg, the very shape of the timed region (as many legs
+    # of as many steps: with the driver's --steps 20 that is 140 launches per kernel to average over instead of 20, and every
+    # leg's first, slower launch weighs as it does in the timed legs); None: one fresh series of K steps
     pf.profile(True)
-    pf.run(t[:K], y[:K], has[:K])
+    if legs:
+        for lo, hi in legs:
+            pf.run_more(t[lo:hi], y[lo:hi], has[lo:hi])
+        loop_ms_plain = loop_ms_plain * len(legs)
+    else:
+        pf.run(t[:K], y[:K], has[:K])
     prof = pf.profile_read()
     pf.profile(False)
     pairs = sum(v[1] for v in prof.values())
@@ -157,7 +165,7 @@ def run_single(args, emit=print):
     n = args.particles if args.particles > 0 else (N_16M if lgcp else N_PER_GPU)
     R = args.repeats if args.repeats > 0 else (3 if K >= 200 else 7)
     W = max(W, 1)                      # (the filter has to be running before K more steps can be timed)
-    model, t, y, has = build_workload(W + R * K + 8, args.model)
+    model, t, y, has = build_workload(W + 2 * R * K + 8, args.model)
     pf = NativePf(model, n, 20260101, device=0, lgcp_precision=LGCP_PRECISION if lgcp else 0)
     if args.fused is not None:
         pf.set_option(3, args.fused)   # CSSM_OPT_FUSED_SUMS (experiment switch; the default is the library's)
@@ -181,7 +189,8 @@ def run_single(args, emit=print):
         loops.append(pf.last_loop_ms())
     wall = float(np.median(walls))
     loop_ms = float(np.median(loops))
-    per, pair_s, prof_raw = _kernel_profile(pf, t, y, has, K, loop_ms)
+    per, pair_s, prof_raw = _kernel_profile(pf, t, y, has, K, loop_ms,
+                                            legs=[(W + (R + r) * K, W + (R + r + 1) * K) for r in range(R)])
     lib = pf.lib
     pf.close()
     # on-box streaming ceiling (plain 16-byte-per-lane copy, 1 GiB each way: far beyond the 256 MB Infinity Cache)
@@ -202,8 +211,9 @@ def run_single(args, emit=print):
             traffic = None
     avg_s, cnt, raw_s = per["k_propagate"]
     roof = _roofline(f"k_propagate<{d},...> (gather + propagate + weight + log-sum-exp sums), N={n}", d, n, avg_s, cnt, raw_s, pair_s, copy_gbs)
-    roof["timing"] = ("HIP events on the launch stream around every k_propagate launch of a K-step series, minus what a bracketing "
-                      "event pair adds: (sum of all bracketed kernel times - device time of the same loop without brackets) / brackets")
+    roof["timing"] = ("HIP events on the launch stream around every k_propagate launch of `repeats` more legs of K steps each "
+                      "(the timed region's shape, continued), minus what a bracketing event pair adds: (sum of all bracketed "
+                      "kernel times - device time of the same legs without brackets) / brackets")
     kernels_us = {k: v[0] * 1e6 for k, v in per.items()}
     roof["traffic"] = traffic
     roof["traffic_source"] = traffic_source
