@@ -119,7 +119,14 @@ __global__ __launch_bounds__(CSSM_BLOCK) void k_boundary_pack(const double* __re
   if (aligned) {
     const uint32_t per = (uint32_t)(chunk / CSSM_TILE);               // tiles per sub-unit
     const uint32_t c0 = (uint32_t)(first / chunk), nc = blockIdx.x / per;   // sub-units wholly before this tile
-    for (uint32_t c = 0; c < nc; ++c) toff = cssm_u128_add(toff, subS[c0 + c]);
+    // (the kernel is one latency chain after another at the sizes it runs at -- a capacity of a few thousand rows: what can be
+    //  requested together is: up to 8 sums in flight, the rest in a loop)
+    cssm_u128 pre8[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) pre8[c] = ((uint32_t)c < nc) ? subS[c0 + (uint32_t)c] : cssm_u128_zero();
+#pragma unroll
+    for (int c = 0; c < 8; ++c) toff = cssm_u128_add(toff, pre8[c]);
+    for (uint32_t c = 8; c < nc; ++c) toff = cssm_u128_add(toff, subS[c0 + c]);
     t_begin = nc * per;
   }
   for (uint32_t t = t_begin; t < blockIdx.x; ++t) {
@@ -158,33 +165,55 @@ __global__ __launch_bounds__(CSSM_BLOCK) void k_boundary_pack(const double* __re
   }
   return;
   }
-  // header: the rank's totals of the sub-unit sums k_propagate formed, the key of its max, base
-  cssm_u128 a = cssm_u128_zero(), b = cssm_u128_zero();
-  for (uint32_t i = threadIdx.x; i < nsub; i += CSSM_BLOCK) { a = cssm_u128_add(a, subS[i]); b = cssm_u128_add(b, subS2[i]); }
-  a = wave_sum_u128(a); b = wave_sum_u128(b);
-  __syncthreads();
-  if (lane == 0) { s_r[0][wid] = a; s_r[1][wid] = b; }
-  __syncthreads();
+  // header: the rank's totals of the sub-unit sums k_propagate formed, the key of its max, base.  Everything it reads is
+  // requested before anything is summed: up to 4 sums and 4 sums of squares per thread (1024 sub-units), the max slots, the
+  // boundary blocks' sub-unit sums (below).
   unsigned long long key = 0ull;
   if (level_from_max) {
     key = cssm_order_key(sc->gmax);                    // (the slots were exported and cleared before the all-gather)
   } else if (threadIdx.x < 64) {
     key = (threadIdx.x < CSSM_MAXSLOTS) ? sc->maxslot[(size_t)threadIdx.x * CSSM_SLOT_STRIDE] : 0ull;   // slot set 0 (sharded handles)
-    key = wave_max_u64(key);
   }
-  // total weights of the rank's FIRST-cap and LAST-cap blocks (both travel in every header; the LAST one gives the base)
+  cssm_u128 a4[4], b4[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const uint32_t i = threadIdx.x + (uint32_t)k * CSSM_BLOCK;
+    a4[k] = (i < nsub) ? subS[i] : cssm_u128_zero();
+    b4[k] = (i < nsub) ? subS2[i] : cssm_u128_zero();
+  }
   const long long cnt_all = ((long long)n_local < cap) ? (long long)n_local : cap;
+  cssm_u128 p2[2] = {cssm_u128_zero(), cssm_u128_zero()};
+  bool al2[2];
+#pragma unroll
+  for (int which = 0; which < 2; ++which) {
+    const uint64_t bfirst = which ? n_local - (uint64_t)cnt_all : 0;
+    al2[which] = (chunk % (uint64_t)CSSM_TILE == 0) && (bfirst % chunk == 0) && ((uint64_t)cnt_all % chunk == 0);
+    if (al2[which]) {
+      const uint32_t b0 = (uint32_t)(bfirst / chunk), nch = (uint32_t)((uint64_t)cnt_all / chunk);
+      if (threadIdx.x < nch) p2[which] = subS[b0 + threadIdx.x];            // (the first 256 of them; a loop for more below)
+    }
+  }
+  cssm_u128 a = cssm_u128_zero(), b = cssm_u128_zero();
+#pragma unroll
+  for (int k = 0; k < 4; ++k) { a = cssm_u128_add(a, a4[k]); b = cssm_u128_add(b, b4[k]); }
+  for (uint32_t i = threadIdx.x + 4u * CSSM_BLOCK; i < nsub; i += CSSM_BLOCK) { a = cssm_u128_add(a, subS[i]); b = cssm_u128_add(b, subS2[i]); }
+  a = wave_sum_u128(a); b = wave_sum_u128(b);
+  __syncthreads();
+  if (lane == 0) { s_r[0][wid] = a; s_r[1][wid] = b; }
+  __syncthreads();
+  if (!level_from_max && threadIdx.x < 64) key = wave_max_u64(key);
+  // total weights of the rank's FIRST-cap and LAST-cap blocks (both travel in every header; the LAST one gives the base)
   const uint32_t ntile = (uint32_t)((cnt_all + CSSM_TILE - 1) / CSSM_TILE);
   cssm_u128 ptot[2];
 #pragma unroll
   for (int which = 0; which < 2; ++which) {
     const uint64_t bfirst = which ? n_local - (uint64_t)cnt_all : 0;
-    const bool al = (chunk % (uint64_t)CSSM_TILE == 0) && (bfirst % chunk == 0) && ((uint64_t)cnt_all % chunk == 0);
+    const bool al = al2[which];
     cssm_u128 acc = cssm_u128_zero();
     if (al) {   // whole sub-units: their sums are k_propagate's (k_tile_sums')
       const uint32_t b0 = (uint32_t)(bfirst / chunk), nch = (uint32_t)((uint64_t)cnt_all / chunk);
-      cssm_u128 c = cssm_u128_zero();
-      for (uint32_t t = threadIdx.x; t < nch; t += CSSM_BLOCK) c = cssm_u128_add(c, subS[b0 + t]);
+      cssm_u128 c = p2[which];
+      for (uint32_t t = threadIdx.x + CSSM_BLOCK; t < nch; t += CSSM_BLOCK) c = cssm_u128_add(c, subS[b0 + t]);
       acc = block_total(c);
     } else {
       for (uint32_t t = 0; t < ntile; ++t) {
