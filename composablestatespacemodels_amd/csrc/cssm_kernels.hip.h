@@ -632,7 +632,9 @@ __device__ __forceinline__ void offspring_body(const double* __restrict__ logw, 
       if constexpr (OUTLINED) if (unsafe) offspring_exact_counts(run0, w1, unsafe, totd_exact(), u, n_global, e, raw == 1);
       const uint64_t i0 = base + (uint64_t)threadIdx.x * CSSM_ITEMS;
       constexpr bool CLIP = !SELF;
-      if (!FUSE || (CLIP && all5 != nullptr)) {   // the exchange of the sharded filter needs the end slots themselves
+      // the EXACT exchange of the sharded filter needs the end slots themselves (k_send_ranges, k_pack); the single-collective
+      // launch passes endslot = nullptr -- nobody reads them there, and 4 bytes per particle are a third of this kernel's writes
+      if ((!FUSE || (CLIP && all5 != nullptr)) && endslot != nullptr) {
         if (i0 + CSSM_ITEMS <= n) {
           *reinterpret_cast<uint4*>(endslot + i0) = make_uint4(e[0], e[1], e[2], e[3]);
         } else {

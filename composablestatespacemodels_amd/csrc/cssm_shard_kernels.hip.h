@@ -419,7 +419,10 @@ __global__ __launch_bounds__(CSSM_BLOCK, CSSM_OFF_WAVES) void k_offspring_expand
     if (blockIdx.x == 0 && threadIdx.x == 0) { atomicOr(&sc->err, 8u); atomicMin(&sc->fail_step, rec->step); }
     return;
   }
-  offspring_body<true, false, CSSM_RESAMPLE_SYSTEMATIC>(CSSM_OFFSPRING_FWD, all5_stride);
+  // (the arguments the single-collective launch has no use for are constants here: the compiler drops what hangs on them)
+  offspring_body<true, false, CSSM_RESAMPLE_SYSTEMATIC>(logw, n, sc, unitP, unitS2, rec, n_global, /*endslot=*/nullptr, anc, ntiles, sup, nunits, raw, slot_set,
+                                                        /*ll_t=*/nullptr, /*ess_t=*/nullptr, 0u, force_exact, all5, rank, world, split, /*seed=*/0ull,
+                                                        /*cum_out=*/nullptr, /*logtab=*/nullptr, optimistic, flag_out, slot_lo, slot_hi, all5_stride);
   expand_spec_body(H, blockIdx.x, gridDim.x, recv, world, rank, cap, d, n_split, (uint64_t)slot_lo, (uint64_t)slot_hi, n_global, rec, anc, sc);
 }
 
