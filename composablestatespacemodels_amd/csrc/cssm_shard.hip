@@ -858,3 +858,13 @@ extern "C" int cssm_pf_shard_result(cssm_pf* pf, double* ll_out, int32_t* ess_ou
   if (ess_out) *ess_out = h.ess;
   return cssm_check_device_err(pf, h);
 }
+
+#ifdef CSSM_OFF_STAMPS
+// diagnostic build: the stamps k_offspring_expand_spec's blocks left (8 words per block)
+extern "C" int cssm_pf_debug_spec_stamps(cssm_pf* pf, unsigned long long* out, size_t nwords) {
+  if (!pf || nwords > 2048 * 8) return CSSM_EINVAL_ARG;
+  HIP_TRY(hipStreamSynchronize(pf->stream));
+  HIP_TRY(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_spec_stamps), nwords * 8));
+  return CSSM_OK;
+}
+#endif

@@ -259,17 +259,29 @@ struct SpecHeaders {
   cssm_u128 tot;
   int all_ok;
 };
-__device__ __forceinline__ bool spec_read_headers(SpecHeaders& H, const double* __restrict__ recv, int world, int rank, long long cap, int d,
-                                                  uint64_t n_local, uint64_t n_global, const StepRec* __restrict__ rec) {
-  const long long seg = spec_seg(d, cap);
+// (the header words of rank threadIdx.x, requested by the kernel together with everything else it starts from: the verdict
+//  used to begin with three round trips one behind the other -- the sticky bits, the max keys, the headers -- and a fourth
+//  for the record's u in its middle: 3 us before a block had so much as asked for its weights)
+struct SpecHdrRegs { double w[9]; };
+__device__ __forceinline__ SpecHdrRegs spec_load_headers(const double* __restrict__ recv, int world, long long cap, int d) {
+  SpecHdrRegs g;
+#pragma unroll
+  for (int k = 0; k < 9; ++k) g.w[k] = 0.0;
+  if ((int)threadIdx.x < world) {
+    const double* h = recv + (size_t)threadIdx.x * spec_seg(d, cap);
+    g.w[0] = h[0]; g.w[1] = h[1]; g.w[2] = h[2]; g.w[3] = h[6]; g.w[4] = h[7]; g.w[5] = h[8]; g.w[6] = h[9]; g.w[7] = h[10]; g.w[8] = h[11];
+  }
+  return g;
+}
+__device__ __forceinline__ bool spec_read_headers(SpecHeaders& H, const SpecHdrRegs& g, int world, int rank, long long cap, int d,
+                                                  uint64_t n_local, uint64_t n_global, const double u) {
   if (threadIdx.x < 64) {
     cssm_u128 S = cssm_u128_zero(), bs = cssm_u128_zero(), pl = cssm_u128_zero(), ph = cssm_u128_zero();
     long long c = 0;
     if ((int)threadIdx.x < world) {
-      const double* h = recv + (size_t)threadIdx.x * seg;
-      S.lo = cssm_d2u(h[1]); S.hi = cssm_d2u(h[2]); bs.lo = cssm_d2u(h[6]); bs.hi = cssm_d2u(h[7]);
-      pl.lo = cssm_d2u(h[8]); pl.hi = cssm_d2u(h[9]); ph.lo = cssm_d2u(h[10]); ph.hi = cssm_d2u(h[11]);
-      c = (long long)h[0];
+      S.lo = cssm_d2u(g.w[1]); S.hi = cssm_d2u(g.w[2]); bs.lo = cssm_d2u(g.w[3]); bs.hi = cssm_d2u(g.w[4]);
+      pl.lo = cssm_d2u(g.w[5]); pl.hi = cssm_d2u(g.w[6]); ph.lo = cssm_d2u(g.w[7]); ph.hi = cssm_d2u(g.w[8]);
+      c = (long long)g.w[0];
       c = (c < 0) ? 0 : ((c > cap) ? cap : c);
     }
     H.S[threadIdx.x] = S; H.base[threadIdx.x] = bs; H.plow[threadIdx.x] = pl; H.phigh[threadIdx.x] = ph; H.cnt[threadIdx.x] = c;
@@ -283,7 +295,6 @@ __device__ __forceinline__ bool spec_read_headers(SpecHeaders& H, const double* 
   }
   __syncthreads();
   const double totd = cssm_u128_to_double(H.tot);
-  const double u = rec->u;
   const bool pow2 = (n_global & (n_global - 1)) == 0;
   const double inv_n = 1.0 / (double)n_global;
   auto count_of = [&](cssm_u128 G) -> uint64_t {
@@ -400,30 +411,44 @@ __device__ __forceinline__ void expand_spec_body(SpecHeaders& H, uint32_t bid, u
 // does NOTHING on every rank except recording err bit 3 and the observation index: the state is exactly as the
 // propagate of this observation left it, every later kernel of the series returns at once (they test the bit), and
 // the host redoes this observation's exchange with a larger capacity and carries on (cssm_pf_shard_resume).
+#ifdef CSSM_OFF_STAMPS
+__device__ unsigned long long g_spec_stamps[2048 * 8];   // diagnostic build: clock stamps of k_offspring_expand_spec's blocks
+#define CSSM_SPEC_STAMP(k) do { if (threadIdx.x == 0 && blockIdx.x < 2048) g_spec_stamps[blockIdx.x * 8 + (k)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define CSSM_SPEC_STAMP(k) do { } while (0)
+#endif
 __global__ __launch_bounds__(CSSM_BLOCK, CSSM_OFF_WAVES) void k_offspring_expand_spec(
     CSSM_OFFSPRING_PARAMS, uint32_t all5_stride, const double* __restrict__ recv, long long cap, int d, uint32_t n_split) {
   __shared__ SpecHeaders H;
-  if (sc->err & (4u | 8u)) return;
+  CSSM_SPEC_STAMP(0);
+  // everything the verdict starts from is requested first, tested afterwards
+  const uint32_t held = sc->err;
+  const double rec_ref = rec->ref, rec_u = rec->u;
+  unsigned long long key = 0ull;
+  if (optimistic) for (int r = 0; r < world; ++r) { const unsigned long long k = all5[(size_t)all5_stride * r + 4]; key = (k > key) ? k : key; }
+  const SpecHdrRegs hregs = spec_load_headers(recv, world, cap, d);
+  if (held & (4u | 8u)) return;
   if (optimistic) {
     // the level first: sums formed relative to a reference level that the global max rules out (an outlying observation) say
     // nothing about coverage either.  Sticky bit 2 (4): every later kernel of the series returns at once, the host runs
     // the series again with the levels taken from the global max.
-    unsigned long long key = 0ull;
-    for (int r = 0; r < world; ++r) { const unsigned long long k = all5[(size_t)all5_stride * r + 4]; key = (k > key) ? k : key; }
-    if (!(cssm_ref_choose(rec->ref, cssm_order_unkey(key)) == rec->ref)) {
+    if (!(cssm_ref_choose(rec_ref, cssm_order_unkey(key)) == rec_ref)) {
       if (blockIdx.x == 0 && threadIdx.x == 0) atomicOr(&sc->err, 4u);
       return;
     }
   }
-  if (!spec_read_headers(H, recv, world, rank, cap, d, n, n_global, rec)) {
+  if (!spec_read_headers(H, hregs, world, rank, cap, d, n, n_global, rec_u)) {
     if (blockIdx.x == 0 && threadIdx.x == 0) { atomicOr(&sc->err, 8u); atomicMin(&sc->fail_step, rec->step); }
     return;
   }
+  CSSM_SPEC_STAMP(1);
   // (the arguments the single-collective launch has no use for are constants here: the compiler drops what hangs on them)
   offspring_body<true, false, CSSM_RESAMPLE_SYSTEMATIC>(logw, n, sc, unitP, unitS2, rec, n_global, /*endslot=*/nullptr, anc, ntiles, sup, nunits, raw, slot_set,
                                                         /*ll_t=*/nullptr, /*ess_t=*/nullptr, 0u, force_exact, all5, rank, world, split, /*seed=*/0ull,
                                                         /*cum_out=*/nullptr, /*logtab=*/nullptr, optimistic, flag_out, slot_lo, slot_hi, all5_stride);
+  CSSM_SPEC_STAMP(2);
   expand_spec_body(H, blockIdx.x, gridDim.x, recv, world, rank, cap, d, n_split, (uint64_t)slot_lo, (uint64_t)slot_hi, n_global, rec, anc, sc);
+  CSSM_SPEC_STAMP(3);
 }
 
 __global__ __launch_bounds__(CSSM_BLOCK) void k_expand(const uint32_t* __restrict__ cand_end, const uint32_t* __restrict__ cand_idx,
