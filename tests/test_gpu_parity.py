@@ -392,7 +392,9 @@ def test_offspring_fast_path_equals_forced_exact_path():
     predicate everywhere must give the same ancestors (and both equal the oracle)."""
     model = cases.c2_model()
     t, y, has = cases.poisson_counts(10)
-    for n in (5000, 1 << 18):
+    # 2^20: one tile per block, all 1025 blocks resident, the publisher first; 3 * 2^20 + 777: several tiles per block, a ragged
+    # last tile (the rolled exact loop takes over every particle when forced, single particles otherwise)
+    for n in (5000, 1 << 18, 1 << 20, (3 << 20) + 777):
         a = NativePf(model, n, cases.SEED); b = NativePf(model, n, cases.SEED)
         b.set_option(1, 1)
         ra = a.run(t, y, has); rb = b.run(t, y, has)
