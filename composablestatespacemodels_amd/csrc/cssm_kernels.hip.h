@@ -603,7 +603,8 @@ __device__ __forceinline__ void offspring_body(const double* __restrict__ logw, 
         // its fraction (v_fract_f64) the distance test
         const double pp1 = cssm_fma(sd, scale, one_minus_u);
         const double fr = cssm_fract_pos(pp1);
-        const bool safe = (fr > eps) && (fr < one_minus_eps) && !force_exact && resampler == CSSM_RESAMPLE_SYSTEMATIC;
+        // (OUTLINED: a forced exact evaluation does not touch this path -- the particles it names join `unsafe` behind the loop)
+        const bool safe = (fr > eps) && (fr < one_minus_eps) && (OUTLINED || !force_exact) && resampler == CSSM_RESAMPLE_SYSTEMATIC;
         if (safe) {
           // (the count cannot exceed N -- the min is a guard for the ancestor writes below, not part of the arithmetic)
           const uint32_t c32 = (uint32_t)pp1;
@@ -629,7 +630,19 @@ __device__ __forceinline__ void offspring_body(const double* __restrict__ logw, 
           }
         }
       }
-      if constexpr (OUTLINED) if (unsafe) offspring_exact_counts(run0, w1, unsafe, totd_exact(), u, n_global, e, raw == 1);
+      if constexpr (OUTLINED) {
+        // CSSM_OPT_EXACT_OFFSPRING (verification): 1 = every particle through the exact predicate, 2 = every third one -- threads
+        // then hold mixed masks, as they do when the fast path hands over a single particle
+        if (force_exact) {   // (uniform)
+          uint32_t fm = 0xfu;
+          if (force_exact == 2) {
+            const uint32_t j0 = (uint32_t)base + threadIdx.x * CSSM_ITEMS;
+            fm = ((j0 % 3u == 0u) ? 1u : 0u) | (((j0 + 1u) % 3u == 0u) ? 2u : 0u) | (((j0 + 2u) % 3u == 0u) ? 4u : 0u) | (((j0 + 3u) % 3u == 0u) ? 8u : 0u);
+          }
+          unsafe |= fm;
+        }
+        if (unsafe) offspring_exact_counts(run0, w1, unsafe, totd_exact(), u, n_global, e, raw == 1);
+      }
       const uint64_t i0 = base + (uint64_t)threadIdx.x * CSSM_ITEMS;
       constexpr bool CLIP = !SELF;
       // the EXACT exchange of the sharded filter needs the end slots themselves (k_send_ranges, k_pack); the single-collective

@@ -833,7 +833,7 @@ extern "C" int cssm_pf_last_loop_ms(cssm_pf* pf, float* ms_out) {
 
 extern "C" int cssm_pf_set_option(cssm_pf* pf, int option, int value) {
   if (!pf) return fail(CSSM_EINVAL_ARG, "null handle");
-  if (option == CSSM_OPT_EXACT_OFFSPRING) { pf->opt_exact = value ? 1 : 0; return CSSM_OK; }
+  if (option == CSSM_OPT_EXACT_OFFSPRING) { pf->opt_exact = (value == 2) ? 2 : (value ? 1 : 0); return CSSM_OK; }
   if (option == CSSM_OPT_FUSED_SUMS) { pf->opt_fused = value ? 1 : 0; return CSSM_OK; }
   if (option == CSSM_OPT_WHOLE_TILES) {   // launch geometry only: the arrays hold up to four sub-units per unit either way
     if (pf->sharded) return fail(CSSM_ESTATE, "sharded handles always run whole tiles");

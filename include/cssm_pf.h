@@ -202,7 +202,9 @@ int cssm_pf_last_loop_ms(cssm_pf* pf, float* ms_out);
 
 /* Debug/verification options.  CSSM_OPT_EXACT_OFFSPRING = 1 makes the offspring kernel evaluate the
  * contract's exact predicate for every particle instead of only where its fp64 position estimate is
- * within the error band of a slot boundary; results are identical by construction (tests compare). */
+ * within the error band of a slot boundary; results are identical by construction (tests compare).
+ * Value 2 (systematic resampling): every third particle only -- threads then hand over single particles, as the
+ * fast path does when one of them is close to a boundary. */
 #define CSSM_OPT_EXACT_OFFSPRING 1
 /* CSSM_OPT_RESAMPLER selects the `Resample[A]` the filter was constructed with (model/ParticleFilter.scala:
  * 233-235): systematic (model/Resampling.scala:63-72, default), stratified (:78-86) or multinomial (:92-96).

@@ -395,14 +395,18 @@ def test_offspring_fast_path_equals_forced_exact_path():
     # 2^20: one tile per block, all 1025 blocks resident, the publisher first; 3 * 2^20 + 777: several tiles per block, a ragged
     # last tile (the rolled exact loop takes over every particle when forced, single particles otherwise)
     for n in (5000, 1 << 18, 1 << 20, (3 << 20) + 777):
-        a = NativePf(model, n, cases.SEED); b = NativePf(model, n, cases.SEED)
-        b.set_option(1, 1)
-        ra = a.run(t, y, has); rb = b.run(t, y, has)
-        assert ra[0] == rb[0]
-        np.testing.assert_array_equal(ra[2], rb[2])
-        np.testing.assert_array_equal(a.ancestors(), b.ancestors())
-        np.testing.assert_array_equal(a.particles(), b.particles())
-        a.close(); b.close()
+        a = NativePf(model, n, cases.SEED)
+        ra = a.run(t, y, has)
+        for mode in (1, 2):     # every particle / every third particle (mixed masks per thread) through the exact predicate
+            b = NativePf(model, n, cases.SEED)
+            b.set_option(1, mode)
+            rb = b.run(t, y, has)
+            assert ra[0] == rb[0]
+            np.testing.assert_array_equal(ra[2], rb[2])
+            np.testing.assert_array_equal(a.ancestors(), b.ancestors())
+            np.testing.assert_array_equal(a.particles(), b.particles())
+            b.close()
+        a.close()
 
 
 @pytest.mark.parametrize("name,n", [("c2_model", 20000), ("c3_model", 5000), ("bernoulli_model", 3000), ("linear_model", 1 << 18)])
