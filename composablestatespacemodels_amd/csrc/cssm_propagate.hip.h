@@ -557,12 +557,20 @@ __device__ __forceinline__ void propagate_block(
   }
 }
 
-template <int D, int IT, int OBS, int SUMS, int ONE = 0>
+// MKW != 0 (d <= 12): the model's structure -- per component its SDE, its place in the f map, where its leaf ends: ModelK::comp[0..2]
+// -- at COMPILE time.  The reference composes its models at compile time too; here the structure is data, and every
+// transition and every term of f branches on it (wave-uniform scalar branches, ~60 per tile of a d = 3 model).  The structures
+// of the reference's example models at d <= 4 have instantiations of their own (cssm_prop.hip: KnownStructures); the host
+// launches one only when the handle's ModelK::comp[0] IS that word, so the constant is the value the argument holds anyway.
+// Bench model: k_propagate 18.4 -> 17.7 us event-bracketed at N = 2^20.
+template <int D, int IT, int OBS, int SUMS, int ONE = 0, uint32_t MKW = 0u, uint32_t MKW1 = 0u, uint32_t MKW2 = 0u>
 __global__ __launch_bounds__(CSSM_BLOCK, (ONE ? 2 : PropWaves<D, SUMS>::value)) void k_propagate_self(
     const double* __restrict__ src, size_t src_stride, const uint32_t* __restrict__ anc, double* __restrict__ dst, size_t dst_stride,
     double* __restrict__ logw, uint64_t n_arg, uint64_t seed, const StepRec* __restrict__ rec, ModelK mk, Scalars* __restrict__ sc,
     int slot_set, const double* __restrict__ logtab, uint64_t chunk,
     cssm_u128* __restrict__ subS, cssm_u128* __restrict__ subS2, double* __restrict__ pick_out, uint32_t pick_slot) {
+  static_assert(MKW == 0u || D <= 12, "three structure words cover twelve components");
+  if (MKW != 0u) { mk.comp[0] = MKW; mk.comp[1] = MKW1; mk.comp[2] = MKW2; }
   propagate_block<D, IT, OBS, SUMS, ONE>(src, src_stride, anc, dst, dst_stride, logw, n_arg, seed, rec, mk, sc, slot_set, logtab, chunk, subS, subS2,
                                          pick_out, pick_slot, 0ull, nullptr, 0u);
 }
@@ -571,12 +579,14 @@ __global__ __launch_bounds__(CSSM_BLOCK, (ONE ? 2 : PropWaves<D, SUMS>::value)) 
 // neighbouring ranks are read in place -- src2 = the receive buffer, rows of D + 1 doubles, indices >= n_split --, max-slot set
 // 0, an even first global particle: whole pairs per thread): the same body behind 18 arguments instead of the generic
 // kernel's 24.  ONE = 2: tile after tile (units of at most CSSM_LOOP_MAX_TILES tiles); ONE = 0: software-pipelined.
-template <int D, int IT, int OBS, int ONE>
+// MKW..: a known structure at compile time, as in k_propagate_self.
+template <int D, int IT, int OBS, int ONE, uint32_t MKW = 0u, uint32_t MKW1 = 0u, uint32_t MKW2 = 0u>
 __global__ __launch_bounds__(CSSM_BLOCK, (ONE ? 2 : PropWaves<D, 2>::value)) void k_propagate_shard(
     const double* __restrict__ src, size_t src_stride, const uint32_t* __restrict__ anc, double* __restrict__ dst, size_t dst_stride,
     double* __restrict__ logw, uint64_t n_arg, uint64_t gid0, uint64_t seed, const StepRec* __restrict__ rec, ModelK mk,
     Scalars* __restrict__ sc, const double* __restrict__ src2, uint32_t n_split, const double* __restrict__ logtab, uint64_t chunk,
     cssm_u128* __restrict__ subS, cssm_u128* __restrict__ subS2) {
+  if (MKW != 0u) { mk.comp[0] = MKW; mk.comp[1] = MKW1; mk.comp[2] = MKW2; }
   propagate_block<D, IT, OBS, 2, ONE>(src, src_stride, anc, dst, dst_stride, logw, n_arg, seed, rec, mk, sc, 0, logtab, chunk, subS, subS2,
                                       nullptr, 0u, gid0, src2, n_split);
 }
