@@ -106,6 +106,13 @@ void CSSM_CAT(cssm_prop_launch_d, CSSM_PROP_D)(const PropLaunch& a) {
     }
 #undef PROP_SHARD
   } else if (a.lgcp) {
+    // the log-Gaussian Cox process on one OU component (configs[3]): its structure at compile time (the sub-step loop branches
+    // on it once per sub-step and particle)
+    if (D == 1 && a.mk.comp[0] == 0x36u)
+      k_propagate<D, true, IT, -1, 0, (D == 1 ? 0x36u : 0u)><<<dim3(a.grid), dim3(CSSM_BLOCK), 0, a.stream>>>(
+          a.src, a.src_stride, a.anc, a.dst, a.dst_stride, a.logw, a.n, a.gid0, a.seed, a.rec, a.mk, a.sc, a.slot_set, a.src2,
+          a.src2_stride, a.n_split, a.logtab, a.chunk, a.do_sums, a.subS, a.subS2, a.pick_out, a.pick_slot, a.fsub);
+    else
     PROP_GO(true, -1, 0);
   } else if (a.obs == CSSM_OBS_POISSON) {   // (the generic kernel with sums serves sharded handles only: both sums, SUMS = 2)
     if (a.sums) PROP_GO(false, CSSM_OBS_POISSON, 2); else PROP_GO(false, CSSM_OBS_POISSON, 0);

@@ -416,7 +416,7 @@ __device__ __forceinline__ void propagate_range(
 // host so that a whole number of blocks makes one scan unit of k_offspring).  With do_sums the block also forms
 // S = sum exp(w - c), S2 = sum exp(w - c)^2 in fixed point for its range, c = rec->ref being known before any
 // weight is (include/cssm_numerics.h, "reference level"): the log-sum-exp of :125-127 then needs no pass of its own.
-template <int D, bool LGCP, int IT, int OBS, int SUMS>
+template <int D, bool LGCP, int IT, int OBS, int SUMS, uint32_t MKW = 0u, uint32_t MKW1 = 0u, uint32_t MKW2 = 0u>
 __global__ __launch_bounds__(CSSM_BLOCK, (PropWaves<D, SUMS>::value)) void k_propagate(
     const double* __restrict__ src, size_t src_stride, const uint32_t* __restrict__ anc,
     double* __restrict__ dst, size_t dst_stride, double* __restrict__ logw, uint64_t n_arg, uint64_t gid0,
@@ -425,6 +425,7 @@ __global__ __launch_bounds__(CSSM_BLOCK, (PropWaves<D, SUMS>::value)) void k_pro
     uint64_t chunk, int do_sums_arg, cssm_u128* __restrict__ subS, cssm_u128* __restrict__ subS2,
     double* __restrict__ pick_out, uint32_t pick_slot, const double* __restrict__ fsub) {
   __shared__ double s_max[CSSM_BLOCK / 64];
+  if (MKW != 0u) { mk.comp[0] = MKW; mk.comp[1] = MKW1; mk.comp[2] = MKW2; }   // (a known structure at compile time: k_propagate_self)
   // (sharded series) the exchange of an earlier observation did not fit: the series is on hold and nothing may change
   // until the host resumes it (cssm_pf_shard_resume)
   // bit 3: a sharded series is on hold (capacity miss); bit 6: a single-GPU batch series waits for the redo of an outlying
