@@ -15,7 +15,7 @@
 
 // Structures with instantiations of their own (k_propagate_self / k_propagate_shard<..., MKW, MKW1, MKW2>): ModelK::comp[0..2] of the
 // reference's example models -- byte per component = SDE kind | FM_* << 2 | leaf ends << 4 | leftmost leaf << 5 (cssm_model.cpp).
-// Poisson observation, fused sums (the batch drivers' default kernels).
+// Poisson observation (d = 1: also Gaussian -- Model.linear), fused sums (the batch drivers' default kernels).
 //   d = 1: one leaf on Brownian motion (configs[0]), generalised Brownian motion, an OU process
 //   d = 3: poisson(ou(1)) |+| seasonal(24, 1, ou(2))                      (configs[1], the bench model)
 //   d = 9: poisson(brownianMotion(1)) |+| seasonal(24, 4, ouProcess(8))   (configs[2])
@@ -26,7 +26,7 @@ template <> struct KnownStructures<9> { static constexpr int n = 1; static const
 
 // the fused-sums Poisson kernel of a known structure (ONEV as in OneTile; 0: the pipelined kernel; SHARD: the sharded slim
 // launch): true if one was launched
-template <int D, int IT, int ONEV, bool SHARD, int I> struct TryKnown {
+template <int D, int IT, int ONEV, bool SHARD, int OB, int I> struct TryKnown {
   static bool go(const PropLaunch& a) {
     if constexpr (I >= KnownStructures<D>::n) {
       return false;
@@ -34,22 +34,24 @@ template <int D, int IT, int ONEV, bool SHARD, int I> struct TryKnown {
       constexpr uint32_t W0 = KnownStructures<D>::w[I][0], W1 = KnownStructures<D>::w[I][1], W2 = KnownStructures<D>::w[I][2];
       if (a.mk.comp[0] == W0 && a.mk.comp[1] == W1 && a.mk.comp[2] == W2) {
         if constexpr (SHARD)
-          k_propagate_shard<D, IT, CSSM_OBS_POISSON, ONEV, W0, W1, W2><<<dim3(a.grid), dim3(CSSM_BLOCK), 0, a.stream>>>(
+          k_propagate_shard<D, IT, OB, ONEV, W0, W1, W2><<<dim3(a.grid), dim3(CSSM_BLOCK), 0, a.stream>>>(
               a.src, a.src_stride, a.anc, a.dst, a.dst_stride, a.logw, a.n, a.gid0, a.seed, a.rec, a.mk, a.sc, a.src2, a.n_split, a.logtab, a.chunk,
               a.subS, a.subS2);
         else
-          k_propagate_self<D, IT, CSSM_OBS_POISSON, 1, ONEV, W0, W1, W2><<<dim3(a.grid), dim3(CSSM_BLOCK), 0, a.stream>>>(
+          k_propagate_self<D, IT, OB, 1, ONEV, W0, W1, W2><<<dim3(a.grid), dim3(CSSM_BLOCK), 0, a.stream>>>(
               a.src, a.src_stride, a.anc, a.dst, a.dst_stride, a.logw, a.n, a.seed, a.rec, a.mk, a.sc, a.slot_set, a.logtab, a.chunk, a.subS, a.subS2,
               a.pick_out, a.pick_slot);
         return true;
       }
-      return TryKnown<D, IT, ONEV, SHARD, I + 1>::go(a);
+      return TryKnown<D, IT, ONEV, SHARD, OB, I + 1>::go(a);
     }
   }
 };
 template <int D, int IT, int ONEV, bool SHARD = false> static bool launch_known(const PropLaunch& a) {
   if (D > 12 || a.mk.d != D) return false;
-  return TryKnown<D, IT, ONEV, SHARD, 0>::go(a);
+  if (a.obs == CSSM_OBS_POISSON) return TryKnown<D, IT, ONEV, SHARD, CSSM_OBS_POISSON, 0>::go(a);
+  if constexpr (D == 1) { if (a.obs == CSSM_OBS_GAUSSIAN) return TryKnown<D, IT, ONEV, SHARD, CSSM_OBS_GAUSSIAN, 0>::go(a); }   // (Model.linear on one component)
+  return false;
 }
 
 // the single-tile instantiation of the small clouds (one pair per thread for d <= 8, one particle for d >= 9)
@@ -58,7 +60,7 @@ template <int D, int IT> struct OneTile {
 #define PROP_ONE(OB, ONEV)                                                                                                        \
   k_propagate_self<D, IT, OB, 1, ONEV><<<dim3(a.grid), dim3(CSSM_BLOCK), 0, a.stream>>>(a.src, a.src_stride, a.anc, a.dst, a.dst_stride, \
       a.logw, a.n, a.seed, a.rec, a.mk, a.sc, a.slot_set, a.logtab, a.chunk, a.subS, a.subS2, a.pick_out, a.pick_slot)
-    if (a.obs == CSSM_OBS_POISSON && (a.one == 1 ? launch_known<D, IT, 1>(a) : launch_known<D, IT, 2>(a))) return;
+    if (a.one == 1 ? launch_known<D, IT, 1>(a) : launch_known<D, IT, 2>(a)) return;
     if (a.one == 1) {          // the block's range is one tile
       if (a.obs == CSSM_OBS_POISSON) PROP_ONE(CSSM_OBS_POISSON, 1);
       else if (a.obs == CSSM_OBS_GAUSSIAN) PROP_ONE(CSSM_OBS_GAUSSIAN, 1);
@@ -88,7 +90,7 @@ void CSSM_CAT(cssm_prop_launch_d, CSSM_PROP_D)(const PropLaunch& a) {
   if (self && CSSM_PROP_SELF && a.sums && a.one) {
     OneTile<D, IT>::go(a);
   } else if (self && CSSM_PROP_SELF) {
-    if (a.obs == CSSM_OBS_POISSON && a.sums && launch_known<D, IT, 0>(a)) { /* a known structure's own instantiation */ }
+    if (a.sums && launch_known<D, IT, 0>(a)) { /* a known structure's own instantiation */ }
     else if (a.obs == CSSM_OBS_POISSON) { if (a.sums) PROP_SELF(CSSM_OBS_POISSON, 1); else PROP_SELF(CSSM_OBS_POISSON, 0); }
     else if (a.obs == CSSM_OBS_GAUSSIAN) { if (a.sums) PROP_SELF(CSSM_OBS_GAUSSIAN, 1); else PROP_SELF(CSSM_OBS_GAUSSIAN, 0); }
     else { if (a.sums) PROP_SELF(-1, 1); else PROP_SELF(-1, 0); }
@@ -97,7 +99,7 @@ void CSSM_CAT(cssm_prop_launch_d, CSSM_PROP_D)(const PropLaunch& a) {
 #define PROP_SHARD(OB, ONEV)                                                                                               \
   k_propagate_shard<D, IT, OB, ONEV><<<dim3(a.grid), dim3(CSSM_BLOCK), 0, a.stream>>>(a.src, a.src_stride, a.anc, a.dst, a.dst_stride, a.logw, \
       a.n, a.gid0, a.seed, a.rec, a.mk, a.sc, a.src2, a.n_split, a.logtab, a.chunk, a.subS, a.subS2)
-    if (a.obs == CSSM_OBS_POISSON && (a.one == 2 ? launch_known<D, IT, 2, true>(a) : launch_known<D, IT, 0, true>(a))) {
+    if (a.one == 2 ? launch_known<D, IT, 2, true>(a) : launch_known<D, IT, 0, true>(a)) {
       /* a known structure's own instantiation */
     } else if (a.one == 2) {
       if (a.obs == CSSM_OBS_POISSON) PROP_SHARD(CSSM_OBS_POISSON, 2); else if (a.obs == CSSM_OBS_GAUSSIAN) PROP_SHARD(CSSM_OBS_GAUSSIAN, 2); else PROP_SHARD(-1, 2);
