@@ -106,6 +106,7 @@ SYMBOLS = [
     ("cssm_pf_shard_status", C.c_int, [_h, _dp, _i32p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.c_size_t]),
     ("cssm_pf_shard_want_path", C.c_int, [_h, C.c_int]),
     ("cssm_pf_shard_get_path", C.c_int, [_h, _dp, C.c_size_t]),
+    ("cssm_model_structure", C.c_int, [_descp, C.POINTER(C.c_uint32), C.POINTER(C.c_int32)]),
     ("cssm_pf_shard_summary_begin", C.c_int, [_h, C.c_double, C.c_void_p, C.c_void_p]),
     ("cssm_pf_shard_summary_hist", C.c_int, [_h, C.c_int, C.c_void_p]),
     ("cssm_pf_shard_summary_pick", C.c_int, [_h, C.c_int, C.c_void_p]),

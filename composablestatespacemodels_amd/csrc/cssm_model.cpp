@@ -289,6 +289,16 @@ static int own_desc(const cssm_model_desc* in, OwnedDesc* o) {
   return CSSM_OK;
 }
 
+extern "C" int cssm_model_structure(const cssm_model_desc* desc, uint32_t* words_out, int32_t* d_out) {
+  if (!desc || !words_out) return fail(CSSM_EINVAL_ARG, "null argument");
+  HostModel tmp;
+  int rc = build_model_into(&tmp, desc);
+  if (rc) return rc;
+  for (int i = 0; i < CSSM_MAX_DIM / 4; ++i) words_out[i] = tmp.mk.comp[i];
+  if (d_out) *d_out = tmp.d;
+  return CSSM_OK;
+}
+
 extern "C" int cssm_desc_flatten(const cssm_model_desc* desc, double* theta, size_t cap, size_t* n_theta) {
   OwnedDesc o;
   int rc = own_desc(desc, &o);

@@ -483,6 +483,11 @@ int cssm_pmmh_run(cssm_pf* pf, const cssm_model_desc* desc, const double* theta0
 /* Number of stored parameters of a descriptor and their copy-out / copy-in in flatten order. */
 int cssm_desc_flatten(const cssm_model_desc* desc, double* theta, size_t cap, size_t* n_theta);
 
+/* Diagnostic: the structure words the kernels branch on (one byte per latent component: SDE kind | place in the f map << 2 |
+ * leaf ends << 4 | leftmost leaf << 5; four components per word, CSSM_MAX_DIM / 4 words) and the latent dimension.  The models
+ * whose words are listed in csrc/cssm_prop.hip (KnownStructures) run kernels that hold them at compile time. */
+int cssm_model_structure(const cssm_model_desc* desc, uint32_t* words_out, int32_t* d_out);
+
 /* ---- errors / build info ------------------------------------------------------------------ */
 const char* cssm_last_error(void);
 const char* cssm_version(void);

@@ -122,3 +122,30 @@ def test_filter_accepts_any_resample_function_except_the_broken_residual():
     assert ParticleFilter.effectiveSampleSize([1.0, 1.0, 1.0, 1.0]) == 4      # ParticleFilter.scala:431-434
     assert ParticleFilter.effectiveSampleSize([1.0, 0.0, 0.0, 0.0]) == 1
     assert ParticleFilter.mean([1.0, 2.0, 3.0]) == 2.0
+
+
+def test_known_model_structures_are_the_words_the_kernels_hold_at_compile_time():
+    """csrc/cssm_prop.hip launches k_propagate instantiations that hold a model's structure words at compile time when the handle's
+    words ARE those constants (KnownStructures; the LGCP launch's 0x36).  If the packing of ModelK::comp ever changes, the table
+    would silently stop matching -- a performance loss no parity test sees: the reference's example models must still map to it."""
+    import re
+    lib = _abi.load_library()
+    src = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "composablestatespacemodels_amd", "csrc", "cssm_prop.hip")).read()
+    table = {}
+    for dm, body in re.findall(r"template <> struct KnownStructures<(\d+)> \{[^\n]*w\[\d+\]\[3\] = \{(.*)\}; \};", src):
+        table[int(dm)] = [tuple(int(x.rstrip("u"), 16) for x in grp.split(",")) for grp in re.findall(r"\{([^{}]*)\}", body)]
+    assert set(table) == {1, 3, 9}, table
+
+    def words(model, prec=0):
+        w = (C.c_uint32 * 4)()
+        d = C.c_int32()
+        assert lib.cssm_model_structure(model.descriptor(prec).ptr(), w, C.byref(d)) == 0
+        return d.value, tuple(w)[:3]
+
+    for model, prec in ((cases.c1_model(), 0), (cases.c2_model(), 0), (cases.c3_model(), 0), (cases.linear_model(), 0)):
+        d, w = words(model, prec)
+        assert w in table[d], (d, [hex(x) for x in w])
+    d, w = words(cases.c4_model(), 2)            # configs[3]: the LGCP launch compares comp[0] with 0x36
+    assert (d, w[0]) == (1, 0x36) and "a.mk.comp[0] == 0x36u" in src
+    d, w = words(cases.lgcp_seasonal_model(), 1)  # (a structure outside the table keeps the generic kernels)
+    assert w not in table.get(d, [])
