@@ -147,5 +147,5 @@ def test_known_model_structures_are_the_words_the_kernels_hold_at_compile_time()
         assert w in table[d], (d, [hex(x) for x in w])
     d, w = words(cases.c4_model(), 2)            # configs[3]: the LGCP launch compares comp[0] with 0x36
     assert (d, w[0]) == (1, 0x36) and "a.mk.comp[0] == 0x36u" in src
-    d, w = words(cases.lgcp_seasonal_model(), 1)  # (a structure outside the table keeps the generic kernels)
+    d, w = words(cases.dim_model(2))              # (a structure outside the table keeps the generic kernels)
     assert w not in table.get(d, [])
