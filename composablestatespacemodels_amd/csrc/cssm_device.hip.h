@@ -186,17 +186,19 @@ __device__ __forceinline__ double wave_max(double v) { return cssm_order_unkey(w
 
 // The contract's log table (include/cssm_numerics.h, CSSM_LOG_TAB) staged in LDS by every kernel that
 // draws normals: `tab_global` is the handle's device copy.  All threads of the block must call it.
+// (contract v7: the table also holds the 256 (sin, cos) pairs of cssm_sincos_u24 -- 768 doubles, 6 KiB)
 __device__ __forceinline__ const double* stage_log_table(const double* __restrict__ tab_global) {
-  __shared__ double s_logtab[256];
-  for (int i = threadIdx.x; i < 256; i += blockDim.x) s_logtab[i] = tab_global[i];
+  __shared__ double s_logtab[CSSM_TAB_SIZE];
+  for (int i = threadIdx.x; i < CSSM_TAB_SIZE; i += blockDim.x) s_logtab[i] = tab_global[i];
   __syncthreads();
   return s_logtab;
 }
 // The same in two halves for blocks of exactly 256 threads (the small-cloud kernels): the load is issued by the caller, next to
 // its other first loads (`v` = tab_global[threadIdx.x]), and lands in LDS here.
-__device__ __forceinline__ const double* stage_log_table_finish(double v) {
-  __shared__ double s_logtab2[256];
-  s_logtab2[threadIdx.x] = v;
+__device__ __forceinline__ const double* stage_log_table_finish(double v, double v1, double v2) {
+  static_assert(CSSM_TAB_SIZE == 3 * 256, "three table entries per thread of a 256-thread block");
+  __shared__ double s_logtab2[CSSM_TAB_SIZE];
+  s_logtab2[threadIdx.x] = v; s_logtab2[256 + threadIdx.x] = v1; s_logtab2[512 + threadIdx.x] = v2;
   __syncthreads();
   return s_logtab2;
 }

@@ -28,7 +28,7 @@ int cssm_fail(int code, const char* fmt, ...) {
 #define fail cssm_fail
 
 extern "C" const char* cssm_last_error(void) { return g_err.c_str(); }
-extern "C" const char* cssm_version(void) { return "cssm_pf 0.4 (gfx950, numerics contract v6)"; }
+extern "C" const char* cssm_version(void) { return "cssm_pf 0.5 (gfx950, numerics contract v7)"; }
 
 // ------------------------------------------------------------------------------------ model
 

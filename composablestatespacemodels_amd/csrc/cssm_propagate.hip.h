@@ -511,7 +511,7 @@ __device__ __forceinline__ void propagate_block(
   const double* tab;
   if (ONE) {
     static_assert(CSSM_BLOCK == 256, "one table entry per thread");
-    const double tv = logtab[threadIdx.x];
+    const double tv = logtab[threadIdx.x], tv1 = logtab[256 + threadIdx.x], tv2 = logtab[512 + threadIdx.x];
     const uint32_t* w = reinterpret_cast<const uint32_t*>(rec);
     uint32_t probe = w[0];
 #pragma unroll
@@ -520,7 +520,7 @@ __device__ __forceinline__ void propagate_block(
       if (o * 4 < (int)(offsetof(StepRec, coef) + D * sizeof(double[4]) + 64) ||
           (o * 4 + 64 > (int)offsetof(StepRec, fco) && o * 4 < (int)(offsetof(StepRec, fco) + D * sizeof(double) + 64))) probe |= w[o];
     if ((probe == 0x9e3779b9u) & (blockIdx.x > 0x7ffffff0u)) atomicOr(&sc->err, 128u);
-    tab = stage_log_table_finish(tv);
+    tab = stage_log_table_finish(tv, tv1, tv2);
   } else {
     tab = stage_log_table(logtab);
   }

@@ -234,10 +234,12 @@ CSSM_HD double cssm_u01_open0(uint32_t hi, uint32_t lo) { return cssm_u01(hi, lo
 
 /* ------------------------------------------------------------------ constant table */
 
-/* CSSM_TAB: the log table of cssm_log_unit, 128 (invc, logc) pairs; kernels stage it in LDS.  (All other constants
+/* CSSM_TAB: [0, 256) the log table of cssm_log_unit, 128 (invc, logc) pairs; [256, 768) the (sin, cos)(2 pi h / 256), h < 256, of
+ * cssm_sincos_u24 (contract v7), each the correctly rounded double of the exact value (generated with rational arithmetic:
+ * the angle reduced to the first octant exactly, Taylor series to 1e-70).  Kernels stage the table in LDS.  (All other constants
  * of the hot functions are literals: an LDS constant table measured slower on MI355X -- k_propagate 309 us vs 266 us
  * at N = 2^24 -- because table constants occupy VGPRs.) */
-enum { CSSM_TAB_SIZE = 256 };
+enum { CSSM_TAB_SIZE = 768, CSSM_TAB_SINCOS = 256 };
 static const double CSSM_TAB[CSSM_TAB_SIZE] = {
   0x1.0000000000000p+0, 0x0.0p+0,
   0x1.fa11caa01fa12p-1, 0x1.7dc475f810a69p-7,
@@ -367,6 +369,263 @@ static const double CSSM_TAB[CSSM_TAB_SIZE] = {
   0x1.02864fc7729e9p+0, -0x1.41929f968330cp-7,
   0x1.0182436517a37p+0, -0x1.8121214586b02p-8,
   0x1.0000000000000p+0, 0x0.0p+0,
+  /* (sin, cos)(2 pi h / 256), h = 0 .. 255 */
+  0x0.0p+0, 0x1.0000000000000p+0,
+  0x1.92155f7a3667ep-6, 0x1.ffd886084cd0dp-1,
+  0x1.91f65f10dd814p-5, 0x1.ff621e3796d7ep-1,
+  0x1.2d52092ce19f6p-4, 0x1.fe9cdad01883ap-1,
+  0x1.917a6bc29b42cp-4, 0x1.fd88da3d12526p-1,
+  0x1.f564e56a9730ep-4, 0x1.fc26470e19fd3p-1,
+  0x1.2c8106e8e613ap-3, 0x1.fa7557f08a517p-1,
+  0x1.5e214448b3fc6p-3, 0x1.f8764fa714ba9p-1,
+  0x1.8f8b83c69a60bp-3, 0x1.f6297cff75cb0p-1,
+  0x1.c0b826a7e4f63p-3, 0x1.f38f3ac64e589p-1,
+  0x1.f19f97b215f1bp-3, 0x1.f0a7efb9230d7p-1,
+  0x1.111d262b1f677p-2, 0x1.ed740e7684963p-1,
+  0x1.294062ed59f06p-2, 0x1.e9f4156c62ddap-1,
+  0x1.4135c94176601p-2, 0x1.e6288ec48e112p-1,
+  0x1.58f9a75ab1fddp-2, 0x1.e212104f686e5p-1,
+  0x1.7088530fa459fp-2, 0x1.ddb13b6ccc23cp-1,
+  0x1.87de2a6aea963p-2, 0x1.d906bcf328d46p-1,
+  0x1.9ef7943a8ed8ap-2, 0x1.d4134d14dc93ap-1,
+  0x1.b5d1009e15cc0p-2, 0x1.ced7af43cc773p-1,
+  0x1.cc66e9931c45ep-2, 0x1.c954b213411f5p-1,
+  0x1.e2b5d3806f63bp-2, 0x1.c38b2f180bdb1p-1,
+  0x1.f8ba4dbf89abap-2, 0x1.bd7c0ac6f952ap-1,
+  0x1.073879922ffeep-1, 0x1.b728345196e3ep-1,
+  0x1.11eb3541b4b23p-1, 0x1.b090a58150200p-1,
+  0x1.1c73b39ae68c8p-1, 0x1.a9b66290ea1a3p-1,
+  0x1.26d054cdd12dfp-1, 0x1.a29a7a0462782p-1,
+  0x1.30ff7fce17035p-1, 0x1.9b3e047f38741p-1,
+  0x1.3affa292050b9p-1, 0x1.93a22499263fbp-1,
+  0x1.44cf325091dd6p-1, 0x1.8bc806b151741p-1,
+  0x1.4e6cabbe3e5e9p-1, 0x1.83b0e0bff976ep-1,
+  0x1.57d69348ceca0p-1, 0x1.7b5df226aafafp-1,
+  0x1.610b7551d2cdfp-1, 0x1.72d0837efff96p-1,
+  0x1.6a09e667f3bcdp-1, 0x1.6a09e667f3bcdp-1,
+  0x1.72d0837efff96p-1, 0x1.610b7551d2cdfp-1,
+  0x1.7b5df226aafafp-1, 0x1.57d69348ceca0p-1,
+  0x1.83b0e0bff976ep-1, 0x1.4e6cabbe3e5e9p-1,
+  0x1.8bc806b151741p-1, 0x1.44cf325091dd6p-1,
+  0x1.93a22499263fbp-1, 0x1.3affa292050b9p-1,
+  0x1.9b3e047f38741p-1, 0x1.30ff7fce17035p-1,
+  0x1.a29a7a0462782p-1, 0x1.26d054cdd12dfp-1,
+  0x1.a9b66290ea1a3p-1, 0x1.1c73b39ae68c8p-1,
+  0x1.b090a58150200p-1, 0x1.11eb3541b4b23p-1,
+  0x1.b728345196e3ep-1, 0x1.073879922ffeep-1,
+  0x1.bd7c0ac6f952ap-1, 0x1.f8ba4dbf89abap-2,
+  0x1.c38b2f180bdb1p-1, 0x1.e2b5d3806f63bp-2,
+  0x1.c954b213411f5p-1, 0x1.cc66e9931c45ep-2,
+  0x1.ced7af43cc773p-1, 0x1.b5d1009e15cc0p-2,
+  0x1.d4134d14dc93ap-1, 0x1.9ef7943a8ed8ap-2,
+  0x1.d906bcf328d46p-1, 0x1.87de2a6aea963p-2,
+  0x1.ddb13b6ccc23cp-1, 0x1.7088530fa459fp-2,
+  0x1.e212104f686e5p-1, 0x1.58f9a75ab1fddp-2,
+  0x1.e6288ec48e112p-1, 0x1.4135c94176601p-2,
+  0x1.e9f4156c62ddap-1, 0x1.294062ed59f06p-2,
+  0x1.ed740e7684963p-1, 0x1.111d262b1f677p-2,
+  0x1.f0a7efb9230d7p-1, 0x1.f19f97b215f1bp-3,
+  0x1.f38f3ac64e589p-1, 0x1.c0b826a7e4f63p-3,
+  0x1.f6297cff75cb0p-1, 0x1.8f8b83c69a60bp-3,
+  0x1.f8764fa714ba9p-1, 0x1.5e214448b3fc6p-3,
+  0x1.fa7557f08a517p-1, 0x1.2c8106e8e613ap-3,
+  0x1.fc26470e19fd3p-1, 0x1.f564e56a9730ep-4,
+  0x1.fd88da3d12526p-1, 0x1.917a6bc29b42cp-4,
+  0x1.fe9cdad01883ap-1, 0x1.2d52092ce19f6p-4,
+  0x1.ff621e3796d7ep-1, 0x1.91f65f10dd814p-5,
+  0x1.ffd886084cd0dp-1, 0x1.92155f7a3667ep-6,
+  0x1.0000000000000p+0, 0x0.0p+0,
+  0x1.ffd886084cd0dp-1, -0x1.92155f7a3667ep-6,
+  0x1.ff621e3796d7ep-1, -0x1.91f65f10dd814p-5,
+  0x1.fe9cdad01883ap-1, -0x1.2d52092ce19f6p-4,
+  0x1.fd88da3d12526p-1, -0x1.917a6bc29b42cp-4,
+  0x1.fc26470e19fd3p-1, -0x1.f564e56a9730ep-4,
+  0x1.fa7557f08a517p-1, -0x1.2c8106e8e613ap-3,
+  0x1.f8764fa714ba9p-1, -0x1.5e214448b3fc6p-3,
+  0x1.f6297cff75cb0p-1, -0x1.8f8b83c69a60bp-3,
+  0x1.f38f3ac64e589p-1, -0x1.c0b826a7e4f63p-3,
+  0x1.f0a7efb9230d7p-1, -0x1.f19f97b215f1bp-3,
+  0x1.ed740e7684963p-1, -0x1.111d262b1f677p-2,
+  0x1.e9f4156c62ddap-1, -0x1.294062ed59f06p-2,
+  0x1.e6288ec48e112p-1, -0x1.4135c94176601p-2,
+  0x1.e212104f686e5p-1, -0x1.58f9a75ab1fddp-2,
+  0x1.ddb13b6ccc23cp-1, -0x1.7088530fa459fp-2,
+  0x1.d906bcf328d46p-1, -0x1.87de2a6aea963p-2,
+  0x1.d4134d14dc93ap-1, -0x1.9ef7943a8ed8ap-2,
+  0x1.ced7af43cc773p-1, -0x1.b5d1009e15cc0p-2,
+  0x1.c954b213411f5p-1, -0x1.cc66e9931c45ep-2,
+  0x1.c38b2f180bdb1p-1, -0x1.e2b5d3806f63bp-2,
+  0x1.bd7c0ac6f952ap-1, -0x1.f8ba4dbf89abap-2,
+  0x1.b728345196e3ep-1, -0x1.073879922ffeep-1,
+  0x1.b090a58150200p-1, -0x1.11eb3541b4b23p-1,
+  0x1.a9b66290ea1a3p-1, -0x1.1c73b39ae68c8p-1,
+  0x1.a29a7a0462782p-1, -0x1.26d054cdd12dfp-1,
+  0x1.9b3e047f38741p-1, -0x1.30ff7fce17035p-1,
+  0x1.93a22499263fbp-1, -0x1.3affa292050b9p-1,
+  0x1.8bc806b151741p-1, -0x1.44cf325091dd6p-1,
+  0x1.83b0e0bff976ep-1, -0x1.4e6cabbe3e5e9p-1,
+  0x1.7b5df226aafafp-1, -0x1.57d69348ceca0p-1,
+  0x1.72d0837efff96p-1, -0x1.610b7551d2cdfp-1,
+  0x1.6a09e667f3bcdp-1, -0x1.6a09e667f3bcdp-1,
+  0x1.610b7551d2cdfp-1, -0x1.72d0837efff96p-1,
+  0x1.57d69348ceca0p-1, -0x1.7b5df226aafafp-1,
+  0x1.4e6cabbe3e5e9p-1, -0x1.83b0e0bff976ep-1,
+  0x1.44cf325091dd6p-1, -0x1.8bc806b151741p-1,
+  0x1.3affa292050b9p-1, -0x1.93a22499263fbp-1,
+  0x1.30ff7fce17035p-1, -0x1.9b3e047f38741p-1,
+  0x1.26d054cdd12dfp-1, -0x1.a29a7a0462782p-1,
+  0x1.1c73b39ae68c8p-1, -0x1.a9b66290ea1a3p-1,
+  0x1.11eb3541b4b23p-1, -0x1.b090a58150200p-1,
+  0x1.073879922ffeep-1, -0x1.b728345196e3ep-1,
+  0x1.f8ba4dbf89abap-2, -0x1.bd7c0ac6f952ap-1,
+  0x1.e2b5d3806f63bp-2, -0x1.c38b2f180bdb1p-1,
+  0x1.cc66e9931c45ep-2, -0x1.c954b213411f5p-1,
+  0x1.b5d1009e15cc0p-2, -0x1.ced7af43cc773p-1,
+  0x1.9ef7943a8ed8ap-2, -0x1.d4134d14dc93ap-1,
+  0x1.87de2a6aea963p-2, -0x1.d906bcf328d46p-1,
+  0x1.7088530fa459fp-2, -0x1.ddb13b6ccc23cp-1,
+  0x1.58f9a75ab1fddp-2, -0x1.e212104f686e5p-1,
+  0x1.4135c94176601p-2, -0x1.e6288ec48e112p-1,
+  0x1.294062ed59f06p-2, -0x1.e9f4156c62ddap-1,
+  0x1.111d262b1f677p-2, -0x1.ed740e7684963p-1,
+  0x1.f19f97b215f1bp-3, -0x1.f0a7efb9230d7p-1,
+  0x1.c0b826a7e4f63p-3, -0x1.f38f3ac64e589p-1,
+  0x1.8f8b83c69a60bp-3, -0x1.f6297cff75cb0p-1,
+  0x1.5e214448b3fc6p-3, -0x1.f8764fa714ba9p-1,
+  0x1.2c8106e8e613ap-3, -0x1.fa7557f08a517p-1,
+  0x1.f564e56a9730ep-4, -0x1.fc26470e19fd3p-1,
+  0x1.917a6bc29b42cp-4, -0x1.fd88da3d12526p-1,
+  0x1.2d52092ce19f6p-4, -0x1.fe9cdad01883ap-1,
+  0x1.91f65f10dd814p-5, -0x1.ff621e3796d7ep-1,
+  0x1.92155f7a3667ep-6, -0x1.ffd886084cd0dp-1,
+  0x0.0p+0, -0x1.0000000000000p+0,
+  -0x1.92155f7a3667ep-6, -0x1.ffd886084cd0dp-1,
+  -0x1.91f65f10dd814p-5, -0x1.ff621e3796d7ep-1,
+  -0x1.2d52092ce19f6p-4, -0x1.fe9cdad01883ap-1,
+  -0x1.917a6bc29b42cp-4, -0x1.fd88da3d12526p-1,
+  -0x1.f564e56a9730ep-4, -0x1.fc26470e19fd3p-1,
+  -0x1.2c8106e8e613ap-3, -0x1.fa7557f08a517p-1,
+  -0x1.5e214448b3fc6p-3, -0x1.f8764fa714ba9p-1,
+  -0x1.8f8b83c69a60bp-3, -0x1.f6297cff75cb0p-1,
+  -0x1.c0b826a7e4f63p-3, -0x1.f38f3ac64e589p-1,
+  -0x1.f19f97b215f1bp-3, -0x1.f0a7efb9230d7p-1,
+  -0x1.111d262b1f677p-2, -0x1.ed740e7684963p-1,
+  -0x1.294062ed59f06p-2, -0x1.e9f4156c62ddap-1,
+  -0x1.4135c94176601p-2, -0x1.e6288ec48e112p-1,
+  -0x1.58f9a75ab1fddp-2, -0x1.e212104f686e5p-1,
+  -0x1.7088530fa459fp-2, -0x1.ddb13b6ccc23cp-1,
+  -0x1.87de2a6aea963p-2, -0x1.d906bcf328d46p-1,
+  -0x1.9ef7943a8ed8ap-2, -0x1.d4134d14dc93ap-1,
+  -0x1.b5d1009e15cc0p-2, -0x1.ced7af43cc773p-1,
+  -0x1.cc66e9931c45ep-2, -0x1.c954b213411f5p-1,
+  -0x1.e2b5d3806f63bp-2, -0x1.c38b2f180bdb1p-1,
+  -0x1.f8ba4dbf89abap-2, -0x1.bd7c0ac6f952ap-1,
+  -0x1.073879922ffeep-1, -0x1.b728345196e3ep-1,
+  -0x1.11eb3541b4b23p-1, -0x1.b090a58150200p-1,
+  -0x1.1c73b39ae68c8p-1, -0x1.a9b66290ea1a3p-1,
+  -0x1.26d054cdd12dfp-1, -0x1.a29a7a0462782p-1,
+  -0x1.30ff7fce17035p-1, -0x1.9b3e047f38741p-1,
+  -0x1.3affa292050b9p-1, -0x1.93a22499263fbp-1,
+  -0x1.44cf325091dd6p-1, -0x1.8bc806b151741p-1,
+  -0x1.4e6cabbe3e5e9p-1, -0x1.83b0e0bff976ep-1,
+  -0x1.57d69348ceca0p-1, -0x1.7b5df226aafafp-1,
+  -0x1.610b7551d2cdfp-1, -0x1.72d0837efff96p-1,
+  -0x1.6a09e667f3bcdp-1, -0x1.6a09e667f3bcdp-1,
+  -0x1.72d0837efff96p-1, -0x1.610b7551d2cdfp-1,
+  -0x1.7b5df226aafafp-1, -0x1.57d69348ceca0p-1,
+  -0x1.83b0e0bff976ep-1, -0x1.4e6cabbe3e5e9p-1,
+  -0x1.8bc806b151741p-1, -0x1.44cf325091dd6p-1,
+  -0x1.93a22499263fbp-1, -0x1.3affa292050b9p-1,
+  -0x1.9b3e047f38741p-1, -0x1.30ff7fce17035p-1,
+  -0x1.a29a7a0462782p-1, -0x1.26d054cdd12dfp-1,
+  -0x1.a9b66290ea1a3p-1, -0x1.1c73b39ae68c8p-1,
+  -0x1.b090a58150200p-1, -0x1.11eb3541b4b23p-1,
+  -0x1.b728345196e3ep-1, -0x1.073879922ffeep-1,
+  -0x1.bd7c0ac6f952ap-1, -0x1.f8ba4dbf89abap-2,
+  -0x1.c38b2f180bdb1p-1, -0x1.e2b5d3806f63bp-2,
+  -0x1.c954b213411f5p-1, -0x1.cc66e9931c45ep-2,
+  -0x1.ced7af43cc773p-1, -0x1.b5d1009e15cc0p-2,
+  -0x1.d4134d14dc93ap-1, -0x1.9ef7943a8ed8ap-2,
+  -0x1.d906bcf328d46p-1, -0x1.87de2a6aea963p-2,
+  -0x1.ddb13b6ccc23cp-1, -0x1.7088530fa459fp-2,
+  -0x1.e212104f686e5p-1, -0x1.58f9a75ab1fddp-2,
+  -0x1.e6288ec48e112p-1, -0x1.4135c94176601p-2,
+  -0x1.e9f4156c62ddap-1, -0x1.294062ed59f06p-2,
+  -0x1.ed740e7684963p-1, -0x1.111d262b1f677p-2,
+  -0x1.f0a7efb9230d7p-1, -0x1.f19f97b215f1bp-3,
+  -0x1.f38f3ac64e589p-1, -0x1.c0b826a7e4f63p-3,
+  -0x1.f6297cff75cb0p-1, -0x1.8f8b83c69a60bp-3,
+  -0x1.f8764fa714ba9p-1, -0x1.5e214448b3fc6p-3,
+  -0x1.fa7557f08a517p-1, -0x1.2c8106e8e613ap-3,
+  -0x1.fc26470e19fd3p-1, -0x1.f564e56a9730ep-4,
+  -0x1.fd88da3d12526p-1, -0x1.917a6bc29b42cp-4,
+  -0x1.fe9cdad01883ap-1, -0x1.2d52092ce19f6p-4,
+  -0x1.ff621e3796d7ep-1, -0x1.91f65f10dd814p-5,
+  -0x1.ffd886084cd0dp-1, -0x1.92155f7a3667ep-6,
+  -0x1.0000000000000p+0, 0x0.0p+0,
+  -0x1.ffd886084cd0dp-1, 0x1.92155f7a3667ep-6,
+  -0x1.ff621e3796d7ep-1, 0x1.91f65f10dd814p-5,
+  -0x1.fe9cdad01883ap-1, 0x1.2d52092ce19f6p-4,
+  -0x1.fd88da3d12526p-1, 0x1.917a6bc29b42cp-4,
+  -0x1.fc26470e19fd3p-1, 0x1.f564e56a9730ep-4,
+  -0x1.fa7557f08a517p-1, 0x1.2c8106e8e613ap-3,
+  -0x1.f8764fa714ba9p-1, 0x1.5e214448b3fc6p-3,
+  -0x1.f6297cff75cb0p-1, 0x1.8f8b83c69a60bp-3,
+  -0x1.f38f3ac64e589p-1, 0x1.c0b826a7e4f63p-3,
+  -0x1.f0a7efb9230d7p-1, 0x1.f19f97b215f1bp-3,
+  -0x1.ed740e7684963p-1, 0x1.111d262b1f677p-2,
+  -0x1.e9f4156c62ddap-1, 0x1.294062ed59f06p-2,
+  -0x1.e6288ec48e112p-1, 0x1.4135c94176601p-2,
+  -0x1.e212104f686e5p-1, 0x1.58f9a75ab1fddp-2,
+  -0x1.ddb13b6ccc23cp-1, 0x1.7088530fa459fp-2,
+  -0x1.d906bcf328d46p-1, 0x1.87de2a6aea963p-2,
+  -0x1.d4134d14dc93ap-1, 0x1.9ef7943a8ed8ap-2,
+  -0x1.ced7af43cc773p-1, 0x1.b5d1009e15cc0p-2,
+  -0x1.c954b213411f5p-1, 0x1.cc66e9931c45ep-2,
+  -0x1.c38b2f180bdb1p-1, 0x1.e2b5d3806f63bp-2,
+  -0x1.bd7c0ac6f952ap-1, 0x1.f8ba4dbf89abap-2,
+  -0x1.b728345196e3ep-1, 0x1.073879922ffeep-1,
+  -0x1.b090a58150200p-1, 0x1.11eb3541b4b23p-1,
+  -0x1.a9b66290ea1a3p-1, 0x1.1c73b39ae68c8p-1,
+  -0x1.a29a7a0462782p-1, 0x1.26d054cdd12dfp-1,
+  -0x1.9b3e047f38741p-1, 0x1.30ff7fce17035p-1,
+  -0x1.93a22499263fbp-1, 0x1.3affa292050b9p-1,
+  -0x1.8bc806b151741p-1, 0x1.44cf325091dd6p-1,
+  -0x1.83b0e0bff976ep-1, 0x1.4e6cabbe3e5e9p-1,
+  -0x1.7b5df226aafafp-1, 0x1.57d69348ceca0p-1,
+  -0x1.72d0837efff96p-1, 0x1.610b7551d2cdfp-1,
+  -0x1.6a09e667f3bcdp-1, 0x1.6a09e667f3bcdp-1,
+  -0x1.610b7551d2cdfp-1, 0x1.72d0837efff96p-1,
+  -0x1.57d69348ceca0p-1, 0x1.7b5df226aafafp-1,
+  -0x1.4e6cabbe3e5e9p-1, 0x1.83b0e0bff976ep-1,
+  -0x1.44cf325091dd6p-1, 0x1.8bc806b151741p-1,
+  -0x1.3affa292050b9p-1, 0x1.93a22499263fbp-1,
+  -0x1.30ff7fce17035p-1, 0x1.9b3e047f38741p-1,
+  -0x1.26d054cdd12dfp-1, 0x1.a29a7a0462782p-1,
+  -0x1.1c73b39ae68c8p-1, 0x1.a9b66290ea1a3p-1,
+  -0x1.11eb3541b4b23p-1, 0x1.b090a58150200p-1,
+  -0x1.073879922ffeep-1, 0x1.b728345196e3ep-1,
+  -0x1.f8ba4dbf89abap-2, 0x1.bd7c0ac6f952ap-1,
+  -0x1.e2b5d3806f63bp-2, 0x1.c38b2f180bdb1p-1,
+  -0x1.cc66e9931c45ep-2, 0x1.c954b213411f5p-1,
+  -0x1.b5d1009e15cc0p-2, 0x1.ced7af43cc773p-1,
+  -0x1.9ef7943a8ed8ap-2, 0x1.d4134d14dc93ap-1,
+  -0x1.87de2a6aea963p-2, 0x1.d906bcf328d46p-1,
+  -0x1.7088530fa459fp-2, 0x1.ddb13b6ccc23cp-1,
+  -0x1.58f9a75ab1fddp-2, 0x1.e212104f686e5p-1,
+  -0x1.4135c94176601p-2, 0x1.e6288ec48e112p-1,
+  -0x1.294062ed59f06p-2, 0x1.e9f4156c62ddap-1,
+  -0x1.111d262b1f677p-2, 0x1.ed740e7684963p-1,
+  -0x1.f19f97b215f1bp-3, 0x1.f0a7efb9230d7p-1,
+  -0x1.c0b826a7e4f63p-3, 0x1.f38f3ac64e589p-1,
+  -0x1.8f8b83c69a60bp-3, 0x1.f6297cff75cb0p-1,
+  -0x1.5e214448b3fc6p-3, 0x1.f8764fa714ba9p-1,
+  -0x1.2c8106e8e613ap-3, 0x1.fa7557f08a517p-1,
+  -0x1.f564e56a9730ep-4, 0x1.fc26470e19fd3p-1,
+  -0x1.917a6bc29b42cp-4, 0x1.fd88da3d12526p-1,
+  -0x1.2d52092ce19f6p-4, 0x1.fe9cdad01883ap-1,
+  -0x1.91f65f10dd814p-5, 0x1.ff621e3796d7ep-1,
+  -0x1.92155f7a3667ep-6, 0x1.ffd886084cd0dp-1,
 };
 #define CSSM_LOG_TAB CSSM_TAB
 
@@ -574,6 +833,25 @@ CSSM_HD double cssm_seasonal_phase(double a, double t, double period) {
   return x - fl;
 }
 
+/*
+ * sin and cos of the angle 2 pi k / 2^24, k < 2^24 (the 24 angle bits of a Box-Muller pair): the high 8 bits of k pick
+ * (sin a, cos a), a = 2 pi h / 256, from the table; the low 16 bits are a rotation by delta = 2 pi l / 2^24 < 2 pi / 256 = 0.0246,
+ * whose sine and cosine need three Taylor terms each (truncation < 4e-19 / 4e-18 relative); sin(a + delta) = sin a cos delta +
+ * cos a sin delta.  Absolute error < 2^-52 (what a normal variate needs: the relative error of a value near a zero crossing is
+ * larger -- the two products cancel there).  20 instructions against the 40 of the full-range cssm_sincos2pi, which stays for
+ * arguments that are not 24-bit fractions (the seasonal phase).
+ */
+CSSM_HD void cssm_sincos_u24(uint32_t k, const double* tab, double* sn, double* cs) {
+  const uint32_t h = (k >> 16) & 255u, l = k & 0xffffu;
+  const double sa = tab[CSSM_TAB_SINCOS + 2u * h], ca = tab[CSSM_TAB_SINCOS + 2u * h + 1u];
+  const double dl = (double)l * 0x1.921fb54442d18p-22; /* l * (2 pi * 2^-24), 2 pi = 0x1.921fb54442d18p+2 */
+  const double z = dl * dl;
+  const double sd = cssm_fma(dl * z, cssm_fma_k2(z, cssm_fma_k2(z, -0x1.a01a01a01a01ap-13, 0x1.1111111111111p-7), -0x1.5555555555555p-3), dl);
+  const double cd = cssm_fma_k2(z, cssm_fma_k2(z, cssm_fma_k2(z, -0x1.6c16c16c16c17p-10, 0x1.5555555555555p-5), -0.5), 1.0);
+  *sn = cssm_fma(ca, sd, sa * cd);
+  *cs = cssm_fma(-sa, sd, ca * cd);
+}
+
 /* ------------------------------------------------------------------ Box-Muller */
 
 /* Two standard normals from HALF a Philox block (two 32-bit words a, b): r = sqrt(-2 log u1), (r cos, r sin)(2 pi u2).
@@ -584,12 +862,11 @@ CSSM_HD double cssm_seasonal_phase(double a, double t, double period) {
  * Both conversions are exact.  `tab` = CSSM_LOG_TAB (host) or its copy in LDS (kernels). */
 CSSM_HD void cssm_normal_pair64(uint32_t a, uint32_t b, const double* tab, double* z0, double* z1) {
   const double u1 = cssm_fma((double)a, 0x1.0p-32, (double)((b & 255u) + 1u) * 0x1.0p-40);
-  const double u2 = (double)(b >> 8) * 0x1.0p-24;
   double t = -2.0 * cssm_log_unit(u1, tab);
   t = (t < 0.0) ? 0.0 : t; /* log_unit(x <= 1) <= 0 by construction; the clamp documents it */
   double r = cssm_sqrt(t);
   double sn, cs;
-  cssm_sincos2pi(u2, &sn, &cs);
+  cssm_sincos_u24(b >> 8, tab, &sn, &cs);
   *z0 = r * cs;
   *z1 = r * sn;
 }

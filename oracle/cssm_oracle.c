@@ -906,6 +906,7 @@ void oracle_c_paired_normals_v(uint64_t seed, uint64_t gid0, uint32_t step, uint
   }
 }
 void oracle_c_log_v(const double* x, double* y, size_t n) { for (size_t i = 0; i < n; ++i) y[i] = cssm_log(x[i]); }
+void oracle_c_sincos_u24_v(const uint32_t* k, double* s, double* c, size_t n) { for (size_t i = 0; i < n; ++i) cssm_sincos_u24(k[i], CSSM_LOG_TAB, &s[i], &c[i]); }
 void oracle_c_sincos2pi_v(const double* u, double* s, double* c, size_t n) { for (size_t i = 0; i < n; ++i) cssm_sincos2pi(u[i], &s[i], &c[i]); }
 void oracle_c_normals_v(uint64_t seed, uint64_t gid0, uint32_t step, uint32_t tag, uint32_t pair, double* z, size_t n) {
   for (size_t i = 0; i < n; ++i) cssm_normal_pair_of(seed, gid0 + i, step, tag, pair, CSSM_LOG_TAB, &z[2 * i], &z[2 * i + 1]);

@@ -107,6 +107,7 @@ def lib() -> C.CDLL:
             "oracle_c_exp_v": (None, [_dp, _dp, C.c_size_t]),
             "oracle_c_log_v": (None, [_dp, _dp, C.c_size_t]),
             "oracle_c_sincos2pi_v": (None, [_dp, _dp, _dp, C.c_size_t]),
+            "oracle_c_sincos_u24_v": (None, [C.POINTER(C.c_uint32), _dp, _dp, C.c_size_t]),
             "oracle_c_normals_v": (None, [C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, _dp, C.c_size_t]),
         }
         for name, (res, args) in sig.items():
@@ -287,6 +288,11 @@ def c_log(x):
 def c_sincos2pi(u):
     u = np.ascontiguousarray(u, dtype=np.float64); s = np.empty_like(u); c = np.empty_like(u)
     lib().oracle_c_sincos2pi_v(_p(u), _p(s), _p(c), u.size); return s, c
+
+
+def c_sincos_u24(k):
+    k = np.ascontiguousarray(k, dtype=np.uint32); s = np.empty(k.size); c = np.empty(k.size)
+    lib().oracle_c_sincos_u24_v(k.ctypes.data_as(C.POINTER(C.c_uint32)), _p(s), _p(c), k.size); return s, c
 
 
 def c_philox(ctr, key):

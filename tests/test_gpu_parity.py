@@ -636,6 +636,10 @@ def test_contract_functions_on_the_device_match_the_host():
     sc = _contract_eval(3, v, 2 * v.size).reshape(-1, 2)
     s_h, c_h = oracle.c_sincos2pi(v)
     assert np.array_equal(sc[:, 0], s_h) and np.array_equal(sc[:, 1], c_h)
+    k24 = np.concatenate([rng.integers(0, 1 << 24, 400000), np.arange(0, 1 << 24, 1 << 16), np.arange(0, 1 << 24, 1 << 16) + 65535, [1, 2, (1 << 24) - 1]])
+    sc = _contract_eval(6, k24.astype(np.float64), 2 * k24.size).reshape(-1, 2)
+    s_h, c_h = oracle.c_sincos_u24(k24)
+    assert np.array_equal(sc[:, 0], s_h) and np.array_equal(sc[:, 1], c_h)
     w = np.concatenate([rng.random(200000), rng.random(200000) * 2.0 ** -rng.integers(0, 1100, 200000), rng.random(1000) * 520, -rng.random(100),
                         [0.0, 1.0, 2.0 ** -96, 2.0 ** -97, 5e-324, 511.99999999999994, 512.0, np.inf, np.nan, 403.4287934927351]])
     fx = _contract_eval(4, w, 2 * w.size).view(np.uint64).reshape(-1, 2)

@@ -76,6 +76,23 @@ def test_sincos2pi_accuracy_and_exact_points():
     assert abs(s[4] - math.sqrt(0.5)) < 2e-16 and abs(c[4] - math.sqrt(0.5)) < 2e-16
 
 
+def test_sincos_u24_table_and_rotation_accuracy():
+    """cssm_sincos_u24 (contract v7: the Box-Muller angle has 24 bits): table entry of the high 8 bits rotated by the low 16 --
+    absolute error <= 2^-52 for EVERY one of the 2^24 angles, the table's own points exact, sin^2 + cos^2 = 1 to 2^-51."""
+    k = np.arange(1 << 24, dtype=np.uint32)
+    s, c = oracle.c_sincos_u24(k)
+    a = 2 * np.longdouble("3.14159265358979323846264338327950288") * (k.astype(np.longdouble) / np.longdouble(1 << 24))
+    assert np.abs(s - np.sin(a).astype(np.float64)).max() <= 2.0 ** -52   # (measured: exactly 2^-52 at the worst angle)
+    assert np.abs(c - np.cos(a).astype(np.float64)).max() <= 2.0 ** -52
+    assert np.abs(s * s + c * c - 1.0).max() <= 2.0 ** -51
+    q = 1 << 22                                   # quarter turns: table entries 0, 64, 128, 192 hold exact values
+    assert (s[0], c[0]) == (0.0, 1.0) and (s[q], c[q]) == (1.0, 0.0) and (s[2 * q], c[2 * q]) == (0.0, -1.0) and (s[3 * q], c[3 * q]) == (-1.0, 0.0)
+    # every table point is the correctly rounded value (k = h * 2^16: no rotation, cos delta = 1, sin delta = 0)
+    h = np.arange(256, dtype=np.uint32) << 16
+    ah = 2 * np.longdouble("3.14159265358979323846264338327950288") * (np.arange(256).astype(np.longdouble) / 256)
+    assert np.abs(s[h] - np.sin(ah).astype(np.float64)).max() < 1.2e-16 and np.abs(c[h] - np.cos(ah).astype(np.float64)).max() < 1.2e-16
+
+
 def test_normal_pairs_are_standard_normal_and_keyed_by_counter():
     z = oracle.c_normals(20260101, 0, 3, 0, 0, 400000).ravel()
     assert abs(z.mean()) < 5e-3 and abs(z.std() - 1) < 5e-3
