@@ -19,7 +19,8 @@
  *      replaces the reference's unseeded global generators (breeze Rand at
  *      model/Sde.scala:13, scala.util.Random at model/Resampling.scala:66,152).
  *   2. cssm_exp / cssm_log / cssm_sincos2pi / Box-Muller: fixed polynomial evaluations
- *      (fdlibm-derived coefficients), < 2 ulp from the correctly rounded result.
+ *      (fdlibm-derived coefficients), < 2 ulp from the correctly rounded result.  Since contract v7 the Box-Muller angle -- 24 bits --
+ *      goes through cssm_sincos_u24: a 256-entry (sin, cos) table rotated by the low 16 bits (absolute error <= 2^-52).
  *   3. Weight sums and the cumulative weight scan are accumulated in 128-bit FIXED POINT
  *      (96 fractional bits).  Integer addition is associative, so the sum and every prefix
  *      are independent of tile size, wave scan order, block order and GPU count, and the
