@@ -732,6 +732,7 @@ __global__ void k_contract_eval(int fn, const double* __restrict__ x, size_t n, 
     else if (fn == CSSM_FN_LOG_UNIT) out[i] = cssm_log_unit(v, tab);
     else if (fn == CSSM_FN_SINCOS2PI) { double sn, cs; cssm_sincos2pi(v, &sn, &cs); out[2 * i] = sn; out[2 * i + 1] = cs; }
     else if (fn == CSSM_FN_SINCOS_U24) { double sn, cs; cssm_sincos_u24((uint32_t)v, tab, &sn, &cs); out[2 * i] = sn; out[2 * i + 1] = cs; }
+    else if (fn == CSSM_FN_SQRT_RADIUS) out[i] = cssm_sqrt_radius(v);
     else { const cssm_u128 q = cssm_fix_from_double(v); out[2 * i] = cssm_u2d(q.lo); out[2 * i + 1] = cssm_u2d(q.hi); }
   }
 }
@@ -761,7 +762,7 @@ extern "C" int cssm_contract_eval(int device, int fn, const double* x, size_t n,
     if (d < 1 || d > CSSM_MAX_DIM) return fail(CSSM_EINVAL_ARG, "d out of range");
     np = n_out / d; need = np * d;
     if (np < 1) return fail(CSSM_EINVAL_ARG, "out is too small");
-  } else if ((fn < CSSM_FN_EXP || fn > CSSM_FN_FIX) && fn != CSSM_FN_SINCOS_U24) return fail(CSSM_EINVAL_ARG, "unknown contract function %d", fn);
+  } else if ((fn < CSSM_FN_EXP || fn > CSSM_FN_FIX) && fn != CSSM_FN_SINCOS_U24 && fn != CSSM_FN_SQRT_RADIUS) return fail(CSSM_EINVAL_ARG, "unknown contract function %d", fn);
   if (n_out < need) return fail(CSSM_EINVAL_ARG, "out holds %zu doubles, %zu needed", n_out, need);
   double *dx = nullptr, *dout = nullptr, *dtab = nullptr;
   int rc = CSSM_OK;

@@ -855,6 +855,29 @@ CSSM_HD void cssm_sincos_u24(uint32_t k, const double* tab, double* sn, double* 
 
 /* ------------------------------------------------------------------ Box-Muller */
 
+/* sqrt of the Box-Muller radius argument t = -2 log u1: +-0 or a number in [2^-39, 55.5] (u1 = m * 2^-40, 1 <= m <= 2^40).  The
+ * correctly rounded value on both sides.  Device: the compiler's own expansion of an IEEE double-precision sqrt -- v_rsq_f64, two
+ * coupled Newton steps on (g, h) = (t y, y / 2), two residual corrections -- WITHOUT what that expansion spends on arguments
+ * this one never sees: the rescaling of inputs below 2^-767 (a compare, two selects, two ldexp) and the pass-through of
+ * infinities and NaNs.  Over the stated range the two are the same instruction sequence, hence the same bits
+ * (tests/test_gpu_parity.py::test_contract_functions_on_the_device_match_the_host compares them with the host's sqrt). */
+CSSM_HD double cssm_sqrt_radius(double t) {
+#if CSSM_DEVICE_FORM
+  const double y = __builtin_amdgcn_rsq(t);
+  double g = t * y, h = 0.5 * y;
+  const double r = __builtin_fma(-h, g, 0.5);
+  g = __builtin_fma(g, r, g);
+  h = __builtin_fma(h, r, h);
+  double d = __builtin_fma(-g, g, t);
+  g = __builtin_fma(d, h, g);
+  d = __builtin_fma(-g, g, t);
+  g = __builtin_fma(d, h, g);
+  return (t == 0.0) ? t : g;
+#else
+  return __builtin_sqrt(t);
+#endif
+}
+
 /* Two standard normals from HALF a Philox block (two 32-bit words a, b): r = sqrt(-2 log u1), (r cos, r sin)(2 pi u2).
  *   u1 = (a * 2^8 + (b & 255) + 1) * 2^-40 in (0, 1]: 40 bits for the radius -- the largest |z| is sqrt(80 ln 2) = 7.45
  *        (a 53-bit uniform reaches 8.57; the tail beyond 7.45 has probability 9e-14 per variate: one in ~400 series of
@@ -863,9 +886,8 @@ CSSM_HD void cssm_sincos_u24(uint32_t k, const double* tab, double* sn, double* 
  * Both conversions are exact.  `tab` = CSSM_LOG_TAB (host) or its copy in LDS (kernels). */
 CSSM_HD void cssm_normal_pair64(uint32_t a, uint32_t b, const double* tab, double* z0, double* z1) {
   const double u1 = cssm_fma((double)a, 0x1.0p-32, (double)((b & 255u) + 1u) * 0x1.0p-40);
-  double t = -2.0 * cssm_log_unit(u1, tab);
-  t = (t < 0.0) ? 0.0 : t; /* log_unit(x <= 1) <= 0 by construction; the clamp documents it */
-  double r = cssm_sqrt(t);
+  const double t = -2.0 * cssm_log_unit(u1, tab); /* log_unit(x <= 1) <= 0 by construction (tests/test_numerics_contract.py): t >= 0 */
+  const double r = cssm_sqrt_radius(t);
   double sn, cs;
   cssm_sincos_u24(b >> 8, tab, &sn, &cs);
   *z0 = r * cs;

@@ -269,6 +269,7 @@ int cssm_pf_profile_read(cssm_pf* pf, double* total_ms, uint64_t* launches);
 #define CSSM_FN_FIX 4
 #define CSSM_FN_PAIRED_NORMALS 5
 #define CSSM_FN_SINCOS_U24 6   /* out[2i] = sin, out[2i+1] = cos of 2 pi k / 2^24, k = (uint32_t)x[i] < 2^24 (cssm_sincos_u24) */
+#define CSSM_FN_SQRT_RADIUS 7  /* out[i] = cssm_sqrt_radius(x[i]), x[i] = +-0 or in [2^-39, 55.5] */
 int cssm_contract_eval(int device, int fn, const double* x, size_t n, double* out, size_t n_out);
 
 /* On-box streaming ceiling: GB/s (read + write) of a plain 16-bytes-per-lane device-to-device copy of `bytes` bytes,

@@ -640,6 +640,14 @@ def test_contract_functions_on_the_device_match_the_host():
     sc = _contract_eval(6, k24.astype(np.float64), 2 * k24.size).reshape(-1, 2)
     s_h, c_h = oracle.c_sincos_u24(k24)
     assert np.array_equal(sc[:, 0], s_h) and np.array_equal(sc[:, 1], c_h)
+    # the Box-Muller radius: the device's sqrt without the range handling its argument never needs == the host's IEEE sqrt, on
+    # the arguments Box-Muller really produces (t = -2 log u1 over dense and extreme u1) and on dense samples of their range
+    u1 = np.concatenate([(rng.integers(1, 2 ** 40, 2000000).astype(np.float64)) * 2.0 ** -40, np.arange(1, 200001) * 2.0 ** -40,
+                         1.0 - np.arange(0, 200000) * 2.0 ** -40, [1.0, 2.0 ** -40]])
+    tr = np.concatenate([-2.0 * oracle.c_log_unit(u1), np.exp(rng.uniform(np.log(2.0 ** -39), np.log(55.5), 2000000)), rng.uniform(0, 55.5, 1000000),
+                         [0.0, -0.0, 2.0 ** -39, 55.5, 1.0, 4.0, 2.0, 0.25]])
+    got = _contract_eval(7, tr, tr.size)
+    assert np.array_equal(got.view(np.uint64), np.sqrt(tr).view(np.uint64))
     w = np.concatenate([rng.random(200000), rng.random(200000) * 2.0 ** -rng.integers(0, 1100, 200000), rng.random(1000) * 520, -rng.random(100),
                         [0.0, 1.0, 2.0 ** -96, 2.0 ** -97, 5e-324, 511.99999999999994, 512.0, np.inf, np.nan, 403.4287934927351]])
     fx = _contract_eval(4, w, 2 * w.size).view(np.uint64).reshape(-1, 2)
