@@ -37,7 +37,7 @@ template <int D, int SUMS = 0> struct PropWaves { static constexpr int value = (
 // LDS staging area of propagate_range: per wave IT * D regions of 64 lanes x ES bytes (ES = 16: one dwordx4 fetch per lane and
 // element, of which the first 8 bytes are the element, while 4 blocks of that fit the CU's 160 KiB; else 8: two dword fetches).
 template <int D, int IT> struct PropStage {
-  static constexpr int ES = (IT * D <= 9) ? 16 : 8;
+  static constexpr int ES = (IT * D <= 8) ? 16 : 8;
   static constexpr int wave_bytes = IT * D * 64 * ES;
   static constexpr int bytes = (CSSM_BLOCK / 64) * wave_bytes;
 };
@@ -109,9 +109,10 @@ __device__ __forceinline__ void propagate_range(
   // ancestor indices of the tile after that are fetched into the IT index registers.  A wave reads back only what it
   // loaded itself, so no block barrier is involved.  Per wave: IT * D regions of 1 KiB.
   // Bytes per lane and element: 16 (one dwordx4 fetch, of which the first 8 bytes are the element) while 4 blocks of
-  // that fit the CU's 160 KiB of LDS, else 8 (two dword fetches: low and high word).
+  // that fit the CU's 160 KiB of LDS next to the 6 KiB contract table (v7: d = 9 no longer does), else 8 (two dword fetches:
+  // low and high word).
   constexpr bool STAGE = true;
-  constexpr int ES = (IT * D <= 9) ? 16 : 8;
+  constexpr int ES = (IT * D <= 8) ? 16 : 8;
   constexpr int WAVE_STAGE = IT * D * 64 * ES;
   unsigned char* const wstage = s_stage + (size_t)(threadIdx.x >> 6) * WAVE_STAGE;
   const uint32_t wstage_lds = __builtin_amdgcn_readfirstlane((uint32_t)(size_t)(__attribute__((address_space(3))) void*)wstage);
