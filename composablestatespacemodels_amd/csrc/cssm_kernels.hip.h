@@ -180,12 +180,12 @@ static __global__ __launch_bounds__(1024) void k_scan_tiles(const cssm_u128* __r
 // treeEcdf (model/Resampling.scala:52-58): C_j = (sum_{i<=j} w1_i) / (sum_i w1_i), here the
 // correctly rounded quotient of the exact fixed-point sums; end slot of particle j =
 // #{ i : (u+i)/N <= C_j } (the ks of :69 against the keys of the TreeMap).
-// FUSE: also do findAllInTreeMap (:36-46): particle j writes its own run of slots
-// [end_{j-1}, end_j) <- j (runs longer than CSSM_RUN_DIRECT are written by the whole block), so on a
-// single GPU the end slots never travel through HBM.  Otherwise the end slots are stored for the
-// exchange of the sharded filter.  A block walks the tiles of one unit with a running prefix.
+// FUSE: also do findAllInTreeMap (:36-46): the ancestors of the slots a wave's 256 particles own -- the runs
+// [end_{j-1}, end_j) <- j -- are assembled in the wave's LDS region and written as whole lines (fill_runs_wave), so on a
+// single GPU the end slots never travel through HBM.  The exact exchange of the sharded filter has the end slots
+// stored as well.  A block walks the tiles of one unit with a running prefix.
 // SELF (single GPU): there is no scan kernel.  Every block sums the <= ~1K unit totals itself (integer
-// sums: every block gets the same bits), block 0 publishes max / totals / ll / ess and clears the
+// sums: every block gets the same bits); one more block, the publisher, files max / totals / ll / ess and clears the
 // other max-slot sets for the next weighted steps.
 // RS = CSSM_RESAMPLE_* at compile time: the systematic kernel must not carry the stratified path's Philox code
 // (it cost 40 VGPRs and a wave of occupancy when the kind was a runtime argument).
