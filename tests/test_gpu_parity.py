@@ -658,6 +658,36 @@ def test_contract_functions_on_the_device_match_the_host():
             np.testing.assert_array_equal(z, oracle.c_paired_normals(cases.SEED, first, 3, 0, d, 1001))
 
 
+@pytest.mark.parametrize("sde", ["brownian", "gen_brownian", "ou"])
+@pytest.mark.parametrize("obs", ["poisson", "linear"])
+@pytest.mark.parametrize("n", [3000, (1 << 20) + 77])
+def test_one_component_models_of_every_kind_bit_exact(sde, obs, n):
+    """The six one-component structures k_propagate holds at compile time (cssm_prop.hip: KnownStructures<1> x Poisson / Gaussian
+    observation), each in the single-tile kernel of a small cloud and in the whole-unit kernels of a large one, against the oracle
+    (batch, with missing observations)."""
+    from composablestatespacemodels_amd import Model, Parameters, Sde, SdeParameter
+    sp = {"brownian": (Sde.brownianMotion(1), SdeParameter.brownianParameter(0.1, 1.0, 0.05)),
+          "gen_brownian": (Sde.genBrownianMotion(1), SdeParameter.genBrownianParameter(0.1, 1.0, 0.02, 0.05)),
+          "ou": (Sde.ouProcess(1), SdeParameter.ouParameter(0.1, 1.0, 0.3, 0.2, 0.2))}[sde]
+    if obs == "poisson":
+        model = Model.poisson(sp[0]).run(Parameters.apply(None, sp[1]))
+        t, y, has = cases.poisson_counts(9, missing=0.2)
+    else:
+        model = Model.linear(sp[0]).run(Parameters.apply(np.log(0.5), sp[1]))
+        t, y, has = cases.gaussian_series(9)
+        has = np.ones(len(t), dtype=np.uint8); has[4] = 0
+    g = NativePf(model, n, cases.SEED)
+    o = oracle.OraclePf(model.descriptor(), n, cases.SEED)
+    ll, ll_t, ess_t, _ = g.run(t, y, has)
+    oll, oll_t, oess_t, _ = o.filter(t, y, has)
+    assert ll == oll
+    np.testing.assert_array_equal(ll_t, oll_t)
+    np.testing.assert_array_equal(ess_t, oess_t)
+    np.testing.assert_array_equal(g.particles(), o.particles())
+    np.testing.assert_array_equal(g.ancestors(), o.ancestors())
+    g.close()
+
+
 OPT_WHOLE_TILES = 6   # CSSM_OPT_WHOLE_TILES: 1 / 2 / 3 = the launch geometries and kernels of clouds of 2^20 particles and more, at any size
 
 
