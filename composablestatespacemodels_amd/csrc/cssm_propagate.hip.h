@@ -266,6 +266,8 @@ __device__ __forceinline__ void propagate_range(
       }
     };
     if (LGCP) {
+      // (measured and dropped: the thread's particles walking the sub-steps side by side -- loop over s outside -- for
+      //  instruction-level parallelism between their dependent chains: 459 vs 463 us at N = 2^24, five more registers)
 #pragma unroll
       for (int r = 0; r < IT; ++r) {
         double z[D];
