@@ -417,6 +417,9 @@ __device__ unsigned long long g_spec_stamps[2048 * 8];   // diagnostic build: cl
 #else
 #define CSSM_SPEC_STAMP(k) do { } while (0)
 #endif
+// RAWC: how the weights are stored, at compile time (2: the weights k_propagate_shard formed relative to the reference level; 0:
+// log-weights, rescaled by the level the global max gave -- LGCP, a series repeated after an outlying observation)
+template <int RAWC>
 __global__ __launch_bounds__(CSSM_BLOCK, CSSM_OFF_WAVES) void k_offspring_expand_spec(
     CSSM_OFFSPRING_PARAMS, uint32_t all5_stride, const double* __restrict__ recv, long long cap, int d, uint32_t n_split) {
   __shared__ SpecHeaders H;
@@ -443,7 +446,8 @@ __global__ __launch_bounds__(CSSM_BLOCK, CSSM_OFF_WAVES) void k_offspring_expand
   }
   CSSM_SPEC_STAMP(1);
   // (the arguments the single-collective launch has no use for are constants here: the compiler drops what hangs on them)
-  offspring_body<true, false, CSSM_RESAMPLE_SYSTEMATIC>(logw, n, sc, unitP, unitS2, rec, n_global, /*endslot=*/nullptr, anc, ntiles, sup, nunits, raw, slot_set,
+  (void)raw;
+  offspring_body<true, false, CSSM_RESAMPLE_SYSTEMATIC, RAWC>(logw, n, sc, unitP, unitS2, rec, n_global, /*endslot=*/nullptr, anc, ntiles, sup, nunits, RAWC, slot_set,
                                                         /*ll_t=*/nullptr, /*ess_t=*/nullptr, 0u, force_exact, all5, rank, world, split, /*seed=*/0ull,
                                                         /*cum_out=*/nullptr, /*logtab=*/nullptr, optimistic, flag_out, slot_lo, slot_hi, all5_stride);
   CSSM_SPEC_STAMP(2);
