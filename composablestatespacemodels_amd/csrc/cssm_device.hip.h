@@ -174,12 +174,21 @@ __device__ __forceinline__ cssm_u128 wave_sum_u128(cssm_u128 v) {
   r.hi = readlane_u64(v.hi, 63);
   return r;
 }
-__device__ __forceinline__ uint64_t wave_max_u64(uint64_t k) {   // uniform
-#define CSSM_MAX_STEP(CTRL, RM) { const uint64_t o = dpp0_u64<CTRL, RM>(k); k = (o > k) ? o : k; }
+// (a missing DPP source reads 0, the identity of an unsigned max: the compiler folds the read into v_max_u32_dpp)
+__device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {   // uniform
+#define CSSM_MAX_STEP(CTRL, RM) { const uint32_t o = dpp0<CTRL, RM>(v); v = (o > v) ? o : v; }
   CSSM_MAX_STEP(CSSM_DPP_ROW_SHR(1), 0xf) CSSM_MAX_STEP(CSSM_DPP_ROW_SHR(2), 0xf) CSSM_MAX_STEP(CSSM_DPP_ROW_SHR(4), 0xf)
   CSSM_MAX_STEP(CSSM_DPP_ROW_SHR(8), 0xf) CSSM_MAX_STEP(CSSM_DPP_BCAST15, 0xa) CSSM_MAX_STEP(CSSM_DPP_BCAST31, 0xc)
 #undef CSSM_MAX_STEP
-  return readlane_u64(k, 63);
+  return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+}
+// 64-bit keys as two 32-bit reductions -- the high words, then the low words of the lanes that hold the winning high word:
+// 14 + 2 instructions instead of six rounds of two DPP moves, a 64-bit compare and two selects
+__device__ __forceinline__ uint64_t wave_max_u64(uint64_t k) {   // uniform
+  const uint32_t hi = (uint32_t)(k >> 32);
+  const uint32_t mh = wave_max_u32(hi);
+  const uint32_t ml = wave_max_u32((hi == mh) ? (uint32_t)k : 0u);
+  return ((uint64_t)mh << 32) | (uint64_t)ml;
 }
 // max of doubles through their order-preserving keys (a missing DPP source reads key 0, below every real key)
 __device__ __forceinline__ double wave_max(double v) { return cssm_order_unkey(wave_max_u64(cssm_order_key(v))); }
