@@ -240,6 +240,9 @@ __device__ __forceinline__ void propagate_range(
   for (; base < n; base += stride) {
     const uint32_t i0 = base + threadIdx.x * IT;
     const bool full = (i0 + IT <= n);
+    // (tile after tile: the NEXT tile's ancestor indices travel while this one is computed -- one of the two dependent round trips
+    //  at the tile boundary; two registers)
+    if (ONE == 2 && base + stride < n) load_idx(base + stride, jp);
     if (SUMS && pick_out != nullptr) {   // (only the SUMS kernels carry this: it costs the lean kernel 2 % for nothing)
 #pragma unroll
       for (int r = 0; r < IT; ++r)
@@ -374,7 +377,6 @@ __device__ __forceinline__ void propagate_range(
     if (ONE == 2) {   // further tiles of the range in the same way: no software pipeline, co-resident waves cover the round trips
       const uint32_t nb = base + stride;
       if (nb < n) {
-        load_idx(nb, jp);
         unpack_idx(nb, jp, jn);
         stage_issue(jn);
         if (IT == 2) {
