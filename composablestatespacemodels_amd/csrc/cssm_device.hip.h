@@ -310,6 +310,16 @@ __device__ __forceinline__ void normals_pair_half(uint64_t seed, uint64_t gid_ev
     if (2 * B + 1 < D) cssm_normal_pair64(blk.v[2], blk.v[3], tab, &z[4 * B + 2], &z[4 * B + 3]);
   }
 }
+// ... and from Philox blocks drawn beforehand (blk[B] = block B of the pair's stream: k_propagate's single-tile instantiations draw
+// the first tile's blocks while their first loads -- ancestor indices, the contract's table -- are still on their way)
+template <int D>
+__device__ __forceinline__ void normals_pair_from_blocks(const cssm_u32x4* blk, const double* tab, double* z) {
+#pragma unroll
+  for (int B = 0; B < PairHalf<D>::nblk; ++B) {
+    cssm_normal_pair64(blk[B].v[0], blk[B].v[1], tab, &z[4 * B], &z[4 * B + 1]);
+    if (2 * B + 1 < D) cssm_normal_pair64(blk[B].v[2], blk[B].v[3], tab, &z[4 * B + 2], &z[4 * B + 3]);
+  }
+}
 // The same for ONE particle of either parity (threads that do not own whole pairs)
 template <int D>
 __device__ __forceinline__ void propagate_one(const ModelK& mk, const StepRec* __restrict__ rec, double dt, uint64_t seed,

@@ -23,6 +23,7 @@ struct PropLaunch {
   int sharded;         // a shard's launch: both sums (S and S2) travel in the exchange -- never the single-GPU _self kernels, which
                        //   leave the sum of squares to k_offspring
   int shard_slim;      // the sharded filter's slim launch k_propagate_shard applies (cssm_pf.hip decides)
+  uint32_t step;       // the observation's index (= rec->step, read from the host copy of the record: k_propagate_self / _shard use it before any load lands)
   int one;             // k_propagate_self<..., ONE>: 1 = the block's range is one tile, 2 = the same body tile after tile, 0 = software-pipelined
 };
 

@@ -287,6 +287,11 @@ int cssm_launch_propagate(cssm_pf* pf, const StepRec* d_rec, double* pick_out, u
   a.src2 = anc ? pf->src2 : nullptr; a.src2_stride = pf->src2_stride; a.n_split = pf->n_split; a.logtab = pf->d_logtab;
   a.chunk = chunk; a.do_sums = do_sums; a.subS = fine ? pf->fineS : pf->tileS; a.subS2 = fine ? pf->fineS2 : pf->tileS2;
   a.pick_out = pick_out; a.pick_slot = pick_slot;
+  // the observation's index as a kernel argument: every record a propagate is launched on lives in the handle's record buffer,
+  // whose host copy was built (and its upload enqueued) before this launch
+  if (!pf->h_recs || d_rec < pf->d_recs || d_rec >= pf->d_recs + pf->h_recs_cap)
+    return fail(CSSM_ESTATE, "propagate launched on a record outside the handle's record buffer");
+  a.step = pf->h_recs[d_rec - pf->d_recs].step;
   a.fsub = pf->lgcp_tdep ? pf->d_fsub : nullptr;
   a.one = (chunk == (uint64_t)CSSM_BLOCK * cssm_prop_items(pf->d)) ? 1 : (geo == GEO_LOOP ? 2 : 0);
   // sharded handle on the single-collective exchange (received rows read in place: src2_stride == 0) or before its first exchange:

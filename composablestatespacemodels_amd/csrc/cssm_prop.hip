@@ -36,11 +36,11 @@ template <int D, int IT, int ONEV, bool SHARD, int OB, int I> struct TryKnown {
         if constexpr (SHARD)
           k_propagate_shard<D, IT, OB, ONEV, W0, W1, W2><<<dim3(a.grid), dim3(CSSM_BLOCK), 0, a.stream>>>(
               a.src, a.src_stride, a.anc, a.dst, a.dst_stride, a.logw, a.n, a.gid0, a.seed, a.rec, a.mk, a.sc, a.src2, a.n_split, a.logtab, a.chunk,
-              a.subS, a.subS2);
+              a.subS, a.subS2, a.step);
         else
           k_propagate_self<D, IT, OB, 1, ONEV, W0, W1, W2><<<dim3(a.grid), dim3(CSSM_BLOCK), 0, a.stream>>>(
               a.src, a.src_stride, a.anc, a.dst, a.dst_stride, a.logw, a.n, a.seed, a.rec, a.mk, a.sc, a.slot_set, a.logtab, a.chunk, a.subS, a.subS2,
-              a.pick_out, a.pick_slot);
+              a.pick_out, a.pick_slot, a.step);
         return true;
       }
       return TryKnown<D, IT, ONEV, SHARD, OB, I + 1>::go(a);
@@ -59,7 +59,7 @@ template <int D, int IT> struct OneTile {
   static void go(const PropLaunch& a) {
 #define PROP_ONE(OB, ONEV)                                                                                                        \
   k_propagate_self<D, IT, OB, 1, ONEV><<<dim3(a.grid), dim3(CSSM_BLOCK), 0, a.stream>>>(a.src, a.src_stride, a.anc, a.dst, a.dst_stride, \
-      a.logw, a.n, a.seed, a.rec, a.mk, a.sc, a.slot_set, a.logtab, a.chunk, a.subS, a.subS2, a.pick_out, a.pick_slot)
+      a.logw, a.n, a.seed, a.rec, a.mk, a.sc, a.slot_set, a.logtab, a.chunk, a.subS, a.subS2, a.pick_out, a.pick_slot, a.step)
     if (a.one == 1 ? launch_known<D, IT, 1>(a) : launch_known<D, IT, 2>(a)) return;
     if (a.one == 1) {          // the block's range is one tile
       if (a.obs == CSSM_OBS_POISSON) PROP_ONE(CSSM_OBS_POISSON, 1);
@@ -85,7 +85,7 @@ void CSSM_CAT(cssm_prop_launch_d, CSSM_PROP_D)(const PropLaunch& a) {
   const bool self = (!a.sharded || !a.sums) && !a.lgcp && a.src2 == nullptr && a.gid0 == 0 && a.fsub == nullptr && (a.sums || a.pick_out == nullptr) && (!a.sums || a.do_sums);
 #define PROP_SELF(OB, SM)                                                                                                   \
   k_propagate_self<D, IT, OB, SM><<<dim3(a.grid), dim3(CSSM_BLOCK), 0, a.stream>>>(a.src, a.src_stride, a.anc, a.dst, a.dst_stride, \
-      a.logw, a.n, a.seed, a.rec, a.mk, a.sc, a.slot_set, a.logtab, a.chunk, a.subS, a.subS2, a.pick_out, a.pick_slot)
+      a.logw, a.n, a.seed, a.rec, a.mk, a.sc, a.slot_set, a.logtab, a.chunk, a.subS, a.subS2, a.pick_out, a.pick_slot, a.step)
   // small clouds: one tile of the kernel per block (half a tile of 1024 for d <= 8, a quarter for d >= 9): the ONE instantiation
   if (self && CSSM_PROP_SELF && a.sums && a.one) {
     OneTile<D, IT>::go(a);
@@ -98,7 +98,7 @@ void CSSM_CAT(cssm_prop_launch_d, CSSM_PROP_D)(const PropLaunch& a) {
     // the sharded filter (single-collective exchange): the slim launch; tile after tile while a unit has few tiles
 #define PROP_SHARD(OB, ONEV)                                                                                               \
   k_propagate_shard<D, IT, OB, ONEV><<<dim3(a.grid), dim3(CSSM_BLOCK), 0, a.stream>>>(a.src, a.src_stride, a.anc, a.dst, a.dst_stride, a.logw, \
-      a.n, a.gid0, a.seed, a.rec, a.mk, a.sc, a.src2, a.n_split, a.logtab, a.chunk, a.subS, a.subS2)
+      a.n, a.gid0, a.seed, a.rec, a.mk, a.sc, a.src2, a.n_split, a.logtab, a.chunk, a.subS, a.subS2, a.step)
     if (a.one == 2 ? launch_known<D, IT, 2, true>(a) : launch_known<D, IT, 0, true>(a)) {
       /* a known structure's own instantiation */
     } else if (a.one == 2) {

@@ -71,9 +71,12 @@ __device__ __forceinline__ void propagate_range(
     const double* __restrict__ src2, size_t src2_stride, uint32_t n_split, const double* tab,
     const uint32_t range_lo, const uint32_t n, int do_sums_arg,
     double* __restrict__ pick_out, uint32_t pick_slot, unsigned char* s_stage, PropAcc& acc,
-    const double* __restrict__ fsub = nullptr, const unsigned long long* pre_jp = nullptr) {
+    const double* __restrict__ fsub = nullptr, const unsigned long long* pre_jp = nullptr, const cssm_u32x4* pre_blk = nullptr,
+    const uint32_t step_now = 0u) {
   // pre_jp (ONE): the tile's packed ancestor indices, already requested by the caller (before it staged the log table: one
   // dependent round trip less)
+  // pre_blk (ONE, pairs): the Philox blocks of the first tile's pairs, drawn by the caller while those first loads travelled
+  // (step_now = the observation's index as the HOST passed it: rec->step is itself a first load)
   // fsub (LGCP with a time-dependent f, e.g. a seasonal leaf): the handle's table of f coefficients at the sub-step times
   // tau_s = t + s delta (FilterLgcp.calcWeight evaluates mod.f(a.state, a.time) at every simulated time,
   // model/ParticleFilter.scala:193-205; model/Sde.scala:57-66); this observation's rows start at rec->fsub_off
@@ -86,7 +89,7 @@ __device__ __forceinline__ void propagate_range(
   // which in a kernel that streams hundreds of MB of stores cost 130 us at N = 2^24.  k_scan_tiles does it instead.)
   // src2 != nullptr (sharded filter): ancestor indices >= n_split address the candidates received from
   // other ranks, src2[k * src2_stride + (j - n_split)]
-  const uint32_t step = rec->step;
+  const uint32_t step = (pre_blk != nullptr) ? step_now : rec->step;
   const int has_obs = rec->has_obs;
   const double dt = rec->dt;
   const bool weighted = LGCP || has_obs;
@@ -215,8 +218,12 @@ __device__ __forceinline__ void propagate_range(
       stage_issue(jn);                                            // tile 0 (needs its indices: the one exposed latency)
       if (!ONE && base + stride < n) load_idx(base + stride, jp);         // indices of tile 1
       if (ONE && IT == 2) {                                       // (while the rows travel)
-        if (pre_jp != nullptr) normals_pair_half<D, 0>(seed, gid0 + base + threadIdx.x * IT, step, tab, zz);
-        normals_pair_half<D, 1>(seed, gid0 + base + threadIdx.x * IT, step, tab, zz);
+        if (pre_blk != nullptr) {
+          normals_pair_from_blocks<D>(pre_blk, tab, zz);
+        } else {
+          if (pre_jp != nullptr) normals_pair_half<D, 0>(seed, gid0 + base + threadIdx.x * IT, step, tab, zz);
+          normals_pair_half<D, 1>(seed, gid0 + base + threadIdx.x * IT, step, tab, zz);
+        }
 #pragma unroll
         for (int q = (pre_jp != nullptr) ? 0 : PairHalf<D>::n0; q < 2 * D; ++q) asm volatile("" : "+v"(zz[q % (ONE ? IT * D : 1)]));
       } else if (ONE) {                                           // one particle per thread: its D normals
@@ -493,10 +500,14 @@ __device__ __forceinline__ void propagate_block(
     double* __restrict__ logw, uint64_t n_arg, uint64_t seed, const StepRec* __restrict__ rec, const ModelK& mk, Scalars* __restrict__ sc,
     int slot_set, const double* __restrict__ logtab, uint64_t chunk,
     cssm_u128* __restrict__ subS, cssm_u128* __restrict__ subS2, double* __restrict__ pick_out, uint32_t pick_slot,
-    const uint64_t gid0, const double* __restrict__ src2, const uint32_t n_split) {
+    const uint64_t gid0, const double* __restrict__ src2, const uint32_t n_split, const uint32_t step_now) {
   // SUMS: the block also forms its fixed-point sums of exp(w - c) (subS / subS2, one entry per block) and, for `filter`,
   // records the state sampleOne picked after the previous observation (pick_out / pick_slot; see k_propagate)
   __shared__ double s_max[CSSM_BLOCK / 64];
+  // (ONE, pairs: the Philox key and the observation's index are wanted BEFORE the first loads from memory are waited for -- scalar
+  //  loads return out of order, one wait covers all of them -- so they are fetched with the kernel's first arguments)
+  uint32_t key_lo = (uint32_t)seed, key_hi = (uint32_t)(seed >> 32), step_k = step_now;
+  if (ONE != 0 && IT == 2) asm volatile("" : "+s"(key_lo), "+s"(key_hi), "+s"(step_k));
   const uint32_t held = sc->err;          // (tested behind the table staging: its load then overlaps the table's)
   const uint32_t range_lo = blockIdx.x * (uint32_t)chunk;
   uint32_t n;
@@ -514,16 +525,40 @@ __device__ __forceinline__ void propagate_block(
   // comparison cannot be true and cannot be folded: it keeps the loads alive and in place without an asm statement, which
   // would cost the record its scalar loads altogether.)
   const double* tab;
+  constexpr bool EARLY = ONE != 0 && IT == 2;
+  cssm_u32x4 blk_early[EARLY ? PairHalf<D>::nblk : 1];
   if (ONE) {
     static_assert(CSSM_BLOCK == 256, "one table entry per thread");
-    const double tv = logtab[threadIdx.x], tv1 = logtab[256 + threadIdx.x], tv2 = logtab[512 + threadIdx.x];
+    double tv = logtab[threadIdx.x], tv1 = logtab[256 + threadIdx.x], tv2 = logtab[512 + threadIdx.x];
     const uint32_t* w = reinterpret_cast<const uint32_t*>(rec);
-    uint32_t probe = w[0];
+    // (one word of every 64-byte line that holds the scalars, the first D rows of coef[] or the first D entries of fco[])
+    constexpr int NLINES = (int)((sizeof(StepRec) + 63) / 64);
+    auto line_wanted = [](int i) {
+      const int o = i * 16;
+      return i == 0 || (o * 4 + 4 <= (int)sizeof(StepRec) &&
+                        (o * 4 < (int)(offsetof(StepRec, coef) + D * sizeof(double[4]) + 64) ||
+                         (o * 4 + 64 > (int)offsetof(StepRec, fco) && o * 4 < (int)(offsetof(StepRec, fco) + D * sizeof(double) + 64))));
+    };
+    uint32_t pw[NLINES];
 #pragma unroll
-    for (int o = 16; o < (int)(sizeof(StepRec) / 4); o += 16)
-      // (one word of every 64-byte line that holds the scalars, the first D rows of coef[] or the first D entries of fco[])
-      if (o * 4 < (int)(offsetof(StepRec, coef) + D * sizeof(double[4]) + 64) ||
-          (o * 4 + 64 > (int)offsetof(StepRec, fco) && o * 4 < (int)(offsetof(StepRec, fco) + D * sizeof(double) + 64))) probe |= w[o];
+    for (int i = 0; i < NLINES; ++i) pw[i] = line_wanted(i) ? w[i * 16] : 0u;
+    if (EARLY) __builtin_amdgcn_sched_barrier(0);   // (the loads above are issued HERE: the scheduler otherwise sinks them below the rounds)
+    // ... and while all of that travels, the Philox blocks of the tile's pairs: they depend on nothing but (seed, pair, observation)
+    // -- the observation's index as a kernel argument, rec->step being one of the loads.  (The empty asm statements take a block
+    // and a loaded value: the rounds cannot sink below them, the waits for the loads cannot rise above them -- scalar loads return
+    // out of order, so a wait for any of them is a wait for all.)
+    if (EARLY) {
+      const uint64_t stream = cssm_pair_stream(gid0 + range_lo + threadIdx.x * IT);
+#pragma unroll
+      for (int B = 0; B < PairHalf<D>::nblk; ++B) {
+        blk_early[B] = cssm_philox_draw((uint64_t)key_lo | ((uint64_t)key_hi << 32), stream, step_k, CSSM_STREAM_STEP, (uint32_t)B);
+        asm volatile("" : "+v"(blk_early[B].v[0]), "+v"(blk_early[B].v[1]), "+v"(blk_early[B].v[2]), "+v"(blk_early[B].v[3]), "+v"(tv));
+      }
+      __builtin_amdgcn_sched_barrier(0);              // (... and consumed behind them)
+    }
+    uint32_t probe = 0u;
+#pragma unroll
+    for (int i = 0; i < NLINES; ++i) probe |= pw[i];
     if ((probe == 0x9e3779b9u) & (blockIdx.x > 0x7ffffff0u)) atomicOr(&sc->err, 128u);
     tab = stage_log_table_finish(tv, tv1, tv2);
   } else {
@@ -534,7 +569,7 @@ __device__ __forceinline__ void propagate_block(
   PropAcc acc;
   propagate_range<D, false, IT, OBS, SUMS, ONE>(src, src_stride, anc, dst, dst_stride, logw, gid0, seed, rec, mk, src2, 0, n_split, tab,
                                                 range_lo, n, SUMS ? 1 : 0, SUMS ? pick_out : nullptr, pick_slot, s_stage, acc,
-                                                nullptr, ONE ? &jp_early : nullptr);
+                                                nullptr, ONE ? &jp_early : nullptr, EARLY ? blk_early : nullptr, step_now);
   if (!rec->has_obs) return;
   double tmax = wave_max(acc.tmax);
   if ((threadIdx.x & 63) == 0) s_max[threadIdx.x >> 6] = tmax;
@@ -574,11 +609,12 @@ __global__ __launch_bounds__(CSSM_BLOCK, (ONE ? 2 : PropWaves<D, SUMS>::value)) 
     const double* __restrict__ src, size_t src_stride, const uint32_t* __restrict__ anc, double* __restrict__ dst, size_t dst_stride,
     double* __restrict__ logw, uint64_t n_arg, uint64_t seed, const StepRec* __restrict__ rec, ModelK mk, Scalars* __restrict__ sc,
     int slot_set, const double* __restrict__ logtab, uint64_t chunk,
-    cssm_u128* __restrict__ subS, cssm_u128* __restrict__ subS2, double* __restrict__ pick_out, uint32_t pick_slot) {
+    cssm_u128* __restrict__ subS, cssm_u128* __restrict__ subS2, double* __restrict__ pick_out, uint32_t pick_slot, uint32_t step_now) {
+  // (step_now: the observation's index = rec->step, passed by the host so that the ONE instantiations can use it before any load lands)
   static_assert(MKW == 0u || D <= 12, "three structure words cover twelve components");
   if (MKW != 0u) { mk.comp[0] = MKW; mk.comp[1] = MKW1; mk.comp[2] = MKW2; }
   propagate_block<D, IT, OBS, SUMS, ONE>(src, src_stride, anc, dst, dst_stride, logw, n_arg, seed, rec, mk, sc, slot_set, logtab, chunk, subS, subS2,
-                                         pick_out, pick_slot, 0ull, nullptr, 0u);
+                                         pick_out, pick_slot, 0ull, nullptr, 0u, step_now);
 }
 
 // The sharded filter's slim launch (single-collective exchange: the sums are always formed, the rows received from the two
@@ -591,8 +627,8 @@ __global__ __launch_bounds__(CSSM_BLOCK, (ONE ? 2 : PropWaves<D, 2>::value)) voi
     const double* __restrict__ src, size_t src_stride, const uint32_t* __restrict__ anc, double* __restrict__ dst, size_t dst_stride,
     double* __restrict__ logw, uint64_t n_arg, uint64_t gid0, uint64_t seed, const StepRec* __restrict__ rec, ModelK mk,
     Scalars* __restrict__ sc, const double* __restrict__ src2, uint32_t n_split, const double* __restrict__ logtab, uint64_t chunk,
-    cssm_u128* __restrict__ subS, cssm_u128* __restrict__ subS2) {
+    cssm_u128* __restrict__ subS, cssm_u128* __restrict__ subS2, uint32_t step_now) {
   if (MKW != 0u) { mk.comp[0] = MKW; mk.comp[1] = MKW1; mk.comp[2] = MKW2; }
   propagate_block<D, IT, OBS, 2, ONE>(src, src_stride, anc, dst, dst_stride, logw, n_arg, seed, rec, mk, sc, 0, logtab, chunk, subS, subS2,
-                                      nullptr, 0u, gid0, src2, n_split);
+                                      nullptr, 0u, gid0, src2, n_split, step_now);
 }
