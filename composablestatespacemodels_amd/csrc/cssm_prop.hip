@@ -126,3 +126,11 @@ void CSSM_CAT(cssm_prop_launch_d, CSSM_PROP_D)(const PropLaunch& a) {
 #undef PROP_GO
 #undef PROP_SELF
 }
+
+#if defined(CSSM_PROP_STAMPS)
+// diagnostic build: the stamps the slim kernels' blocks of THIS dimension left
+extern "C" int CSSM_CAT(cssm_prop_debug_stamps_d, CSSM_PROP_D)(unsigned long long* out, size_t nwords) {
+  if (nwords > 8192 * 8) nwords = 8192 * 8;
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_prop_stamps), nwords * 8) == hipSuccess ? 0 : 1;
+}
+#endif

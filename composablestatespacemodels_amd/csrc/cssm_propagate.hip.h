@@ -34,6 +34,18 @@ template <int D> struct PropItems { static constexpr int value = (D <= 2) ? CSSM
 // that spill 41.2 us/step at N = 2^20 and 375 us at 2^24, 3 waves without it 41.9 and 383)
 template <int D, int SUMS = 0> struct PropWaves { static constexpr int value = (D <= 4) ? (SUMS ? CSSM_PROP_WAVES_SUMS : CSSM_PROP_WAVES_LO) : 3; };
 
+// Diagnostic build only (-DCSSM_PROP_STAMPS, tools/propagate_stamps.py): lane 0 of wave 0 of every block of the slim kernels leaves the
+// 100 MHz clock at the points marked PSTAMP (8 words per block).
+// (Measured with these stamps and dropped: s_setprio by phase -- first tile's normals 3, its arithmetic 2, second tile's normals 1, the
+//  rest 0 -- so that the waves of a SIMD, which the arbiter otherwise serves oldest first, progress together: they do (blocks done
+//  at 9.3 .. 12.9 us instead of 6.4 .. 12.5), and the kernel is 0.4 us SLOWER: the pipe was busy either way.)
+#ifdef CSSM_PROP_STAMPS
+static __device__ unsigned long long g_prop_stamps[8192 * 8];
+#define PSTAMP(k) do { if (threadIdx.x == 0 && blockIdx.x < 8192) g_prop_stamps[blockIdx.x * 8 + (k)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define PSTAMP(k) do { } while (0)
+#endif
+
 // LDS staging area of propagate_range: per wave IT * D regions of 64 lanes x ES bytes (ES = 16: one dwordx4 fetch per lane and
 // element, of which the first 8 bytes are the element, while 4 blocks of that fit the CU's 160 KiB; else 8: two dword fetches).
 template <int D, int IT> struct PropStage {
@@ -232,9 +244,11 @@ __device__ __forceinline__ void propagate_range(
 #pragma unroll
         for (int q = 0; q < D; ++q) { zz[q % (ONE ? IT * D : 1)] = z1[q]; asm volatile("" : "+v"(zz[q % (ONE ? IT * D : 1)])); }
       }
+      if (ONE) PSTAMP(2);                                         // (normals drawn)
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       stage_read(x);
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // the region is free again
+      if (ONE) PSTAMP(3);                                         // (rows landed)
       if (!ONE && base + stride < n) {
         unpack_idx(base + stride, jp, jn);
         stage_issue(jn);                                          // tile 1 lands while tile 0 is computed
@@ -380,6 +394,7 @@ __device__ __forceinline__ void propagate_range(
         }
       }
     }
+    if (ONE && base == range_lo) PSTAMP(4);                      // (first tile computed, stores issued)
     if (ONE == 1) break;                                          // (the range is this one tile)
     if (ONE == 2) {   // further tiles of the range in the same way: no software pipeline, co-resident waves cover the round trips
       const uint32_t nb = base + stride;
@@ -400,6 +415,7 @@ __device__ __forceinline__ void propagate_range(
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         stage_read(x);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (base == range_lo) PSTAMP(5);                         // (second tile's rows landed)
       }
       continue;
     }
@@ -508,6 +524,7 @@ __device__ __forceinline__ void propagate_block(
   //  loads return out of order, one wait covers all of them -- so they are fetched with the kernel's first arguments)
   uint32_t key_lo = (uint32_t)seed, key_hi = (uint32_t)(seed >> 32), step_k = step_now;
   if (ONE != 0 && IT == 2) asm volatile("" : "+s"(key_lo), "+s"(key_hi), "+s"(step_k));
+  PSTAMP(0);
   const uint32_t held = sc->err;          // (tested behind the table staging: its load then overlaps the table's)
   const uint32_t range_lo = blockIdx.x * (uint32_t)chunk;
   uint32_t n;
@@ -561,6 +578,7 @@ __device__ __forceinline__ void propagate_block(
     for (int i = 0; i < NLINES; ++i) probe |= pw[i];
     if ((probe == 0x9e3779b9u) & (blockIdx.x > 0x7ffffff0u)) atomicOr(&sc->err, 128u);
     tab = stage_log_table_finish(tv, tv1, tv2);
+    PSTAMP(1);
   } else {
     tab = stage_log_table(logtab);
   }
@@ -570,6 +588,7 @@ __device__ __forceinline__ void propagate_block(
   propagate_range<D, false, IT, OBS, SUMS, ONE>(src, src_stride, anc, dst, dst_stride, logw, gid0, seed, rec, mk, src2, 0, n_split, tab,
                                                 range_lo, n, SUMS ? 1 : 0, SUMS ? pick_out : nullptr, pick_slot, s_stage, acc,
                                                 nullptr, ONE ? &jp_early : nullptr, EARLY ? blk_early : nullptr, step_now);
+  PSTAMP(6);
   if (!rec->has_obs) return;
   double tmax = wave_max(acc.tmax);
   if ((threadIdx.x & 63) == 0) s_max[threadIdx.x >> 6] = tmax;
@@ -596,6 +615,7 @@ __device__ __forceinline__ void propagate_block(
     atomicMax(&sc->maxslot[((size_t)slot_set * CSSM_MAXSLOTS + blockIdx.x % CSSM_MAXSLOTS) * CSSM_SLOT_STRIDE],
               (unsigned long long)cssm_order_key(m));
   }
+  PSTAMP(7);
 }
 
 // MKW != 0 (d <= 12): the model's structure -- per component its SDE, its place in the f map, where its leaf ends: ModelK::comp[0..2]
