@@ -45,10 +45,21 @@
 #define CSSM_MAXSLOTS 64
 #define CSSM_SLOT_STRIDE 16 /* u64 words: one 128-byte line per slot */
 #define CSSM_MAXSETS 3
+#define CSSM_GRP_UNITS 32 /* units per group */
+#define CSSM_GRP_MAX 32   /* groups: 1024 units */
+#define CSSM_GRP_LIMB 56  /* bits of the low limb */
+#define CSSM_GRP_MAX_UNIT (1u << 15) /* particles per unit: sum < 2^(15 + 96 + 1) = 2^112 = two 56-bit limbs */
 struct Scalars {
   // Order keys of the running max log-weight, sharded over CSSM_MAXSLOTS cache lines, in three sets: weighted
   // observation s uses set s % 3; the kernel that resamples it (k_offspring) clears the other two, so no reset kernel exists.
   unsigned long long maxslot[CSSM_MAXSETS * CSSM_MAXSLOTS * CSSM_SLOT_STRIDE];
+  // Sums of GROUPS of CSSM_GRP_UNITS consecutive units (single GPU, fused sums, one k_propagate block per unit), in the same three
+  // sets: every k_propagate block adds the two 56-bit limbs of its unit sum (< 2^112: units of at most 2^15 particles... the host
+  // checks) to two 64-bit words, each on a cache line of its own (non-returning atomics; 32 blocks x 2^56 cannot overflow a word;
+  // integer sums: any order, the same bits).  k_offspring's blocks then read 32 group sums + the 32 unit sums of their own group
+  // instead of all 1024 unit sums (16 KiB per block, 16 MiB per launch through the L2s: doubling that traffic cost the kernel
+  // 1.35 us at N = 2^20).  Cleared with the max slots.  Index: ((set * 2 + limb) * CSSM_GRP_MAX + group) * CSSM_SLOT_STRIDE.
+  unsigned long long grp[CSSM_MAXSETS * 2 * CSSM_GRP_MAX * CSSM_SLOT_STRIDE];
   uint32_t err;              // bit0: NaN log-weight, bit1: all weights zero / max not finite,
                              // bit2: the reference level was unusable and the sums must be formed again (host retries)
                              // bit3: (sharded) the exchange capacity did not cover some rank's slots at step fail_step

@@ -65,6 +65,8 @@ struct cssm_pf : HostModel {
   cssm_u128 *fineS = nullptr, *fineS2 = nullptr;   // large clouds: the sums of k_propagate's single-tile blocks (k_reduce_units folds them into tileS / tileS2)
   size_t fine_cap = 0;
   int opt_whole = 0;           // CSSM_OPT_WHOLE_TILES
+  int opt_grp = 1;             // CSSM_OPT_GROUP_SUMS
+  bool last_grp = false;       // the last launch_propagate's blocks accumulated the sums of groups of units (Scalars::grp)
   int resampler = CSSM_RESAMPLE_SYSTEMATIC;
   double* cum = nullptr;       // multinomial: cumulative normalised weights
   const long long *send_first_dev = nullptr, *send_count_dev = nullptr;   // last shard_offspring outputs (device)

@@ -258,7 +258,8 @@ __device__ __forceinline__ void offspring_body(const double* __restrict__ logw, 
                                                           unsigned long long* __restrict__ flag_out,
                                                           uint32_t slot_lo, uint32_t slot_hi, uint32_t all5_stride,
                                                           cssm_u128* __restrict__ s2buf = nullptr, uint32_t s2_stride = 0, int s2_par_arg = -1,
-                                                          uint32_t gen = 0) {
+                                                          uint32_t gen = 0, const bool grp_on = false) {
+  // grp_on (SELF, behind a k_propagate whose blocks accumulated them): the sums of groups of 32 units are at hand (Scalars::grp)
   // RAWC >= 0 (the single-GPU launches): the weight-input mode is a compile-time constant -- 2 goes with the pending ESS
   // (s2_par >= 0), 0 with the sums of squares at hand; the kernel had run out of scalar and vector registers otherwise
   const int raw = (RAWC >= 0) ? RAWC : raw_arg;
@@ -302,7 +303,24 @@ __device__ __forceinline__ void offspring_body(const double* __restrict__ logw, 
   cssm_u128 upre[UPRE];
   const uint32_t nsub = SELF ? nunits * (uint32_t)split : 0u;
   const uint32_t E = (nsub + CSSM_BLOCK - 1) / CSSM_BLOCK;
-  if (SELF) {
+  // grp_on: ONE wave (not the one that decodes the max) totals 32 group sums + the 32 unit sums of the block's own group: lane l < 32
+  // holds group l (four 64-bit words of 32-bit limb sums), lane 32 + j unit j of the own group
+  const uint32_t wsum = (blockIdx.x + 1u) & 3u;
+  const uint32_t grp_unit = is_pub ? 0u : ublk;
+  if (SELF && grp_on) {
+#pragma unroll
+    for (int k = 0; k < UPRE; ++k) upre[k] = cssm_u128_zero();
+    if ((threadIdx.x >> 6) == wsum) {
+      const uint32_t l = threadIdx.x & 63u;
+      if (l < (uint32_t)CSSM_GRP_MAX) {
+        const unsigned long long* g = &sc->grp[((size_t)slot_set * 2 * CSSM_GRP_MAX + l) * CSSM_SLOT_STRIDE];
+        upre[0].lo = g[0]; upre[0].hi = g[(size_t)CSSM_GRP_MAX * CSSM_SLOT_STRIDE];   // the two limb sums
+      } else {
+        const uint32_t q = (grp_unit / CSSM_GRP_UNITS) * CSSM_GRP_UNITS + (l - (uint32_t)CSSM_GRP_MAX);
+        if (q < nunits) upre[0] = unitP[q];
+      }
+    }
+  } else if (SELF) {
     if (nsub == UPRE * CSSM_BLOCK) {   // (uniform) every cloud of 2^20 particles or more: UPRE entries per thread, none out of range
 #pragma unroll
       for (int k = 0; k < UPRE; ++k) upre[k] = unitP[threadIdx.x * UPRE + (uint32_t)k];
@@ -415,6 +433,37 @@ __device__ __forceinline__ void offspring_body(const double* __restrict__ logw, 
     // (uniform; E is a power of two for every cloud of a power-of-two size: a shift instead of the division's ~25 instructions)
     const uint32_t tq = ((Ed & (Ed - 1u)) == 0u) ? (qlim >> (31 - __builtin_clz(Ed))) : qlim / Ed, rq = qlim - tq * Ed;
     auto scan_units = [&](cssm_u128& tot, cssm_u128& pre) {   // (contains one block barrier)
+      if (grp_on) {                                             // (uniform) one wave, one scan: groups in lanes 0..31, own group's units behind
+        static_assert(CSSM_GRP_MAX == 32 && CSSM_GRP_UNITS == 32, "one wave holds the groups and one group's units");
+        if (wid == wsum) {
+          cssm_u128 v = upre[0];
+          if (lane < 32u) {   // the two limb sums a0, a1 (< 2^61 each) -> a0 + a1 2^56
+            cssm_u128 x, y;
+            x.lo = upre[0].lo; x.hi = 0ull;
+            y.lo = upre[0].hi << CSSM_GRP_LIMB; y.hi = upre[0].hi >> (64 - CSSM_GRP_LIMB);
+            v = cssm_u128_add(x, y);
+          }
+          const cssm_u128 inc = wave_scan_u128(v, lane);
+          const uint32_t G = grp_unit / CSSM_GRP_UNITS, r = grp_unit % CSSM_GRP_UNITS;   // (uniform)
+          cssm_u128 t, pg = cssm_u128_zero(), pu = cssm_u128_zero();
+          t.lo = readlane_u64(inc.lo, 31); t.hi = readlane_u64(inc.hi, 31);
+          if (G > 0u) { pg.lo = readlane_u64(inc.lo, (int)G - 1); pg.hi = readlane_u64(inc.hi, (int)G - 1); }
+          if (r > 0u) {
+            cssm_u128 e; e.lo = readlane_u64(inc.lo, 31 + (int)r); e.hi = readlane_u64(inc.hi, 31 + (int)r);
+            pu.lo = e.lo - t.lo; pu.hi = e.hi - t.hi - (e.lo < t.lo ? 1ull : 0ull);
+          }
+          if (lane == 0u) {
+            s_r[1][0] = t;
+#pragma unroll
+            for (int w = 1; w < CSSM_BLOCK / 64; ++w) s_r[1][w] = cssm_u128_zero();
+            s_pre[0] = cssm_u128_add(pg, pu);
+          }
+        }
+        __syncthreads();
+        tot = s_r[1][0];
+        pre = s_pre[0];
+        return;
+      }
       cssm_u128 own = cssm_u128_zero(), part = cssm_u128_zero();
 #pragma unroll
       for (int k = 0; k < UPRE; ++k) {     // (upre[k] is zero beyond E and beyond nsub)
@@ -494,6 +543,10 @@ __device__ __forceinline__ void offspring_body(const double* __restrict__ logw, 
         }
       }
       CSSM_STAMP(7);
+      if (threadIdx.x < 2 * 2 * CSSM_GRP_MAX) {   // ... and their group sums (two sets x two limbs x 32 groups)
+        const uint32_t tq2 = threadIdx.x;
+        sc->grp[((size_t)((slot_set + 1 + (int)(tq2 / (2 * CSSM_GRP_MAX))) % CSSM_MAXSETS) * 2 * CSSM_GRP_MAX + tq2 % (2 * CSSM_GRP_MAX)) * CSSM_SLOT_STRIDE] = 0ull;
+      }
       if (threadIdx.x < 2 * CSSM_MAXSLOTS)   // the two sets this observation did not use
         sc->maxslot[((size_t)((slot_set + 1 + (int)(threadIdx.x / CSSM_MAXSLOTS)) % CSSM_MAXSETS) * CSSM_MAXSLOTS + threadIdx.x % CSSM_MAXSLOTS) * CSSM_SLOT_STRIDE] = 0ull;
       return;
@@ -736,9 +789,10 @@ __global__ __attribute__((amdgpu_flat_work_group_size(CSSM_BLOCK, CSSM_BLOCK),
     uint64_t seed, double* __restrict__ cum_out, cssm_u128* __restrict__ s2buf, uint32_t s2_stride, int s2_par, uint32_t gen) {
   // RAWC = 2: behind k_propagate<SUMS> (weights in place of log-weights, sums relative to the reference level: `optimistic`,
   // the ESS stays pending); 0: behind k_tile_sums (log-weights, both sums at hand)
-  offspring_body<true, true, RS, RAWC>(logw, n, sc, unitP, unitS2, rec, n, nullptr, anc, ntiles, sup, nunits, RAWC, slot_set, ll_t, ess_t, rec_idx,
+  // (slot_set bit 8: the propagate behind this launch accumulated the sums of groups of units, Scalars::grp)
+  offspring_body<true, true, RS, RAWC>(logw, n, sc, unitP, unitS2, rec, n, nullptr, anc, ntiles, sup, nunits, RAWC, slot_set & 0xff, ll_t, ess_t, rec_idx,
                                        force_exact, nullptr, 0, 1, split, seed, cum_out, nullptr, RAWC == 2 ? 1 : 0, nullptr, 0u, (uint32_t)n, 5u,
-                                       s2buf, s2_stride, s2_par, gen);
+                                       s2buf, s2_stride, s2_par, gen, RAWC == 2 && (slot_set & 0x100) != 0);
 }
 
 // Resampling.multinomialResampling (model/Resampling.scala:92-96): slot i draws its own uniform and takes the

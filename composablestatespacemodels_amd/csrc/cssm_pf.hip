@@ -284,6 +284,11 @@ int cssm_launch_propagate(cssm_pf* pf, const StepRec* d_rec, double* pick_out, u
   a.src = pf->src; a.src_stride = pf->src_stride; a.anc = anc; a.dst = dst; a.dst_stride = pf->stride; a.logw = pf->logw;
   a.n = pf->n; a.gid0 = pf->first; a.seed = pf->seed; a.rec = d_rec; a.mk = pf->mk; a.sc = pf->sc;
   a.slot_set = pf->sharded ? 0 : pf->wparity;
+  // one fused-sums block per unit of a single-GPU cloud: the blocks also accumulate the sums of groups of 32 units (Scalars::grp,
+  // bit 8 of the set argument of k_propagate_self and k_offspring_self), which k_offspring then reads instead of every unit sum
+  pf->last_grp = !pf->sharded && do_sums && !fine && pf->split == 1 && chunk == unit_particles && pf->first == 0 && pf->n == pf->n_global &&
+                 pf->nunits >= 2u * CSSM_GRP_UNITS && pf->nunits <= (uint32_t)(CSSM_GRP_MAX * CSSM_GRP_UNITS) && unit_particles <= CSSM_GRP_MAX_UNIT && pf->opt_grp;
+  if (pf->last_grp) a.slot_set |= 0x100;
   a.src2 = anc ? pf->src2 : nullptr; a.src2_stride = pf->src2_stride; a.n_split = pf->n_split; a.logtab = pf->d_logtab;
   a.chunk = chunk; a.do_sums = do_sums; a.subS = fine ? pf->fineS : pf->tileS; a.subS2 = fine ? pf->fineS2 : pf->tileS2;
   a.pick_out = pick_out; a.pick_slot = pick_slot;
@@ -342,7 +347,7 @@ static int launch_resample(cssm_pf* pf, const StepRec* d_rec, double* ll_t = nul
   const int s2_par = optimistic ? pf->s2_par : -1;
   prof_begin(pf, CSSM_K_OFFSPRING);   // unit prefix, ll (ess), end slots and their expansion to ancestors in one kernel (one block per unit + the publisher)
 #define OFF_ARGS pf->logw, pf->n, pf->sc, (const cssm_u128*)pf->tileS, (const cssm_u128*)pf->tileS2, d_rec, pf->anc, pf->ntiles, pf->sup, pf->nunits, \
-                 pf->wparity, ll_t, ess_t, rec_idx, pf->opt_exact, split, pf->seed, pf->cum, pf->s2buf, pf->s2_stride, s2_par, pf->gen
+                 pf->wparity | ((optimistic && pf->last_grp) ? 0x100 : 0), ll_t, ess_t, rec_idx, pf->opt_exact, split, pf->seed, pf->cum, pf->s2buf, pf->s2_stride, s2_par, pf->gen
   const int ogrid = tgrid + 1;   // one block per unit + the publisher
 #define OFF_GO(RS) do { if (optimistic) hipLaunchKernelGGL((k_offspring_self<RS, 2>), dim3(ogrid), dim3(CSSM_BLOCK), 0, pf->stream, OFF_ARGS); \
                         else hipLaunchKernelGGL((k_offspring_self<RS, 0>), dim3(ogrid), dim3(CSSM_BLOCK), 0, pf->stream, OFF_ARGS); } while (0)
@@ -842,6 +847,7 @@ extern "C" int cssm_pf_set_option(cssm_pf* pf, int option, int value) {
   if (!pf) return fail(CSSM_EINVAL_ARG, "null handle");
   if (option == CSSM_OPT_EXACT_OFFSPRING) { pf->opt_exact = (value == 2) ? 2 : (value ? 1 : 0); return CSSM_OK; }
   if (option == CSSM_OPT_FUSED_SUMS) { pf->opt_fused = value ? 1 : 0; return CSSM_OK; }
+  if (option == CSSM_OPT_GROUP_SUMS) { pf->opt_grp = value ? 1 : 0; return CSSM_OK; }
   if (option == CSSM_OPT_WHOLE_TILES) {   // launch geometry only: the arrays hold up to four sub-units per unit either way
     if (pf->sharded) return fail(CSSM_ESTATE, "sharded handles always run whole tiles");
     pf->opt_whole = value < 0 ? 0 : (value > 3 ? 3 : value);

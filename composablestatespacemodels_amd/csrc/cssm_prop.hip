@@ -79,7 +79,7 @@ void CSSM_CAT(cssm_prop_launch_d, CSSM_PROP_D)(const PropLaunch& a) {
   constexpr int IT = PropItems<D>::value;
 #define PROP_GO(LG, OB, SM)                                                                                               \
   k_propagate<D, LG, IT, OB, SM><<<dim3(a.grid), dim3(CSSM_BLOCK), 0, a.stream>>>(                                        \
-      a.src, a.src_stride, a.anc, a.dst, a.dst_stride, a.logw, a.n, a.gid0, a.seed, a.rec, a.mk, a.sc, a.slot_set, a.src2, \
+      a.src, a.src_stride, a.anc, a.dst, a.dst_stride, a.logw, a.n, a.gid0, a.seed, a.rec, a.mk, a.sc, a.slot_set & 0xff, a.src2, \
       a.src2_stride, a.n_split, a.logtab, a.chunk, a.do_sums, a.subS, a.subS2, a.pick_out, a.pick_slot, a.fsub)
   // the single-GPU lean launch: nothing of the sharded filter, no fused sums, no pick, first global id 0
   const bool self = (!a.sharded || !a.sums) && !a.lgcp && a.src2 == nullptr && a.gid0 == 0 && a.fsub == nullptr && (a.sums || a.pick_out == nullptr) && (!a.sums || a.do_sums);
@@ -112,7 +112,7 @@ void CSSM_CAT(cssm_prop_launch_d, CSSM_PROP_D)(const PropLaunch& a) {
     // on it once per sub-step and particle)
     if (D == 1 && a.mk.comp[0] == 0x36u)
       k_propagate<D, true, IT, -1, 0, (D == 1 ? 0x36u : 0u)><<<dim3(a.grid), dim3(CSSM_BLOCK), 0, a.stream>>>(
-          a.src, a.src_stride, a.anc, a.dst, a.dst_stride, a.logw, a.n, a.gid0, a.seed, a.rec, a.mk, a.sc, a.slot_set, a.src2,
+          a.src, a.src_stride, a.anc, a.dst, a.dst_stride, a.logw, a.n, a.gid0, a.seed, a.rec, a.mk, a.sc, a.slot_set & 0xff, a.src2,
           a.src2_stride, a.n_split, a.logtab, a.chunk, a.do_sums, a.subS, a.subS2, a.pick_out, a.pick_slot, a.fsub);
     else
     PROP_GO(true, -1, 0);

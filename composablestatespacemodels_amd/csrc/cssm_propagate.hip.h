@@ -514,9 +514,13 @@ template <int D, int IT, int OBS, int SUMS, int ONE>
 __device__ __forceinline__ void propagate_block(
     const double* __restrict__ src, size_t src_stride, const uint32_t* __restrict__ anc, double* __restrict__ dst, size_t dst_stride,
     double* __restrict__ logw, uint64_t n_arg, uint64_t seed, const StepRec* __restrict__ rec, const ModelK& mk, Scalars* __restrict__ sc,
-    int slot_set, const double* __restrict__ logtab, uint64_t chunk,
+    int slot_set_arg, const double* __restrict__ logtab, uint64_t chunk,
     cssm_u128* __restrict__ subS, cssm_u128* __restrict__ subS2, double* __restrict__ pick_out, uint32_t pick_slot,
     const uint64_t gid0, const double* __restrict__ src2, const uint32_t n_split, const uint32_t step_now) {
+  // slot_set_arg: bits 0-7 the set of max slots (and of group sums); bit 8: this launch has one block per unit of a single-GPU
+  // cloud -- the blocks also accumulate the sums of groups of units (Scalars::grp)
+  const int slot_set = slot_set_arg & 0xff;
+  const bool grp_on = (slot_set_arg & 0x100) != 0;
   // SUMS: the block also forms its fixed-point sums of exp(w - c) (subS / subS2, one entry per block) and, for `filter`,
   // records the state sampleOne picked after the previous observation (pick_out / pick_slot; see k_propagate)
   __shared__ double s_max[CSSM_BLOCK / 64];
@@ -604,6 +608,11 @@ __device__ __forceinline__ void propagate_block(
       for (int w = 1; w < CSSM_BLOCK / 64; ++w) { ta = cssm_u128_add(ta, s_sa[w]); if (SUMS == 2) tb = cssm_u128_add(tb, s_sb[w]); }
       subS[blockIdx.x] = ta;
       if (SUMS == 2) subS2[blockIdx.x] = tb;
+      if (SUMS == 1 && grp_on) {   // (uniform) the group's sum: Scalars::grp
+        unsigned long long* g = &sc->grp[((size_t)slot_set * 2 * CSSM_GRP_MAX + blockIdx.x / CSSM_GRP_UNITS) * CSSM_SLOT_STRIDE];
+        atomicAdd(g, ta.lo & ((1ull << CSSM_GRP_LIMB) - 1ull));
+        atomicAdd(g + (size_t)CSSM_GRP_MAX * CSSM_SLOT_STRIDE, (ta.lo >> CSSM_GRP_LIMB) | (ta.hi << (64 - CSSM_GRP_LIMB)));
+      }
     }
   } else {
     __syncthreads();

@@ -234,6 +234,12 @@ int cssm_pf_last_loop_ms(cssm_pf* pf, float* ms_out);
  * bit-identical and both measured slower than two launches per observation -- were removed in round 3; DESIGN.md 5b-5c keep
  * the record, git history the code.) */
 #define CSSM_OPT_WHOLE_TILES 6
+/* CSSM_OPT_GROUP_SUMS (default 1; a verification switch: results are bit-identical either way).  Where k_propagate runs one
+ * fused-sums block per unit of a single-GPU cloud (every cloud of 2^20 particles or more that is not on geometry 3; smaller ones
+ * under CSSM_OPT_WHOLE_TILES = 1 or 2 from 64 units on) its blocks also add their unit sums, limb by limb, to the sums of groups
+ * of 32 units, and k_offspring's blocks read 32 group sums + the 32 unit sums of their own group instead of all 1024 unit sums
+ * (16 KiB per block through the L2s).  0 = every block totals every unit sum, as before. */
+#define CSSM_OPT_GROUP_SUMS 7
 int cssm_pf_set_option(cssm_pf* pf, int option, int value);
 
 /* Per-kernel device time, measured with HIP events recorded on the handle's stream directly

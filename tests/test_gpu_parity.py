@@ -718,6 +718,59 @@ def test_every_dimension_streaming_and_batch_bit_exact(d):
         g.close()
 
 
+OPT_GROUP_SUMS = 7    # CSSM_OPT_GROUP_SUMS: k_propagate's blocks also accumulate the sums of groups of 32 units, k_offspring reads those
+
+
+@pytest.mark.parametrize("name,n,whole", [("c2_model", 100_000, 1), ("c2_model", 1 << 17, 2), ("c1_model", 65 * 1024 + 3, 1),
+                                          ("c3_model", 64 * 1024, 1), ("c2_model", 70_001, 2)])
+def test_group_sums_match_the_oracle_at_test_sizes(name, n, whole):
+    """Scalars::grp (single GPU, one fused-sums block per unit, 64 units or more): k_propagate's blocks add the limbs of their unit
+    sums to the sums of groups of 32 units with atomics, and every k_offspring block reads 32 group sums + the 32 unit sums of its
+    own group instead of all unit sums.  Forced here at sizes the oracle finishes in seconds (whole units of 1024 particles: 64 to
+    128 units, a partial last group, a ragged last unit), batch -- with a missing observation and, for c2, an outlying one that is
+    redone relative to the max while the group sums of its first attempt stay behind -- and streaming, bit for bit; and the
+    same handle with the option off."""
+    model = getattr(cases, name)()
+    t, y, has = cases.poisson_counts(9, missing=0.15)
+    y = y.copy()
+    if name == "c2_model":
+        y[4] = 60.0; has[4] = 1      # an outlying observation (as _outlier_series): its reference level is ruled out by the max (redo_observation)
+    o = oracle.OraclePf(model.descriptor(), n, cases.SEED)
+    ol, oll, oess, _ = o.filter(t, y, has)
+    for grp in (1, 0):
+        g = NativePf(model, n, cases.SEED)
+        g.set_option(OPT_WHOLE_TILES, whole); g.set_option(OPT_GROUP_SUMS, grp)
+        for rep in range(2):                           # (the second run starts from the sets the first one left)
+            gl, gll, gess, _ = g.run(t, y, has)
+            assert gl == ol, (name, grp, rep, gl, ol)
+            np.testing.assert_array_equal(gll, oll)
+            np.testing.assert_array_equal(gess, oess)
+            np.testing.assert_array_equal(g.ancestors(), o.ancestors())
+            np.testing.assert_array_equal(g.particles(), o.particles())
+        g.init(float(np.min(t)))
+        o2 = oracle.OraclePf(model.descriptor(), n, cases.SEED); o2.init(float(np.min(t)))
+        for s in range(6):
+            assert g.step(t[s], y[s], bool(has[s])) == o2.step(t[s], y[s], bool(has[s])), (name, grp, s)
+        np.testing.assert_array_equal(g.ancestors(), o2.ancestors())
+        g.close()
+
+
+@pytest.mark.parametrize("n", [1 << 20, (1 << 20) + 4097, 3 << 20, (1 << 23) + 5])
+def test_group_sums_on_and_off_agree_at_full_size(n):
+    """The same at the sizes where the group sums are the default (1024 units of 1024 .. 8192 particles, a ragged cloud whose last
+    groups are short or empty): both settings of CSSM_OPT_GROUP_SUMS, bit for bit, over a series with a missing observation."""
+    model = cases.c2_model() if n != (1 << 23) + 5 else cases.c1_model()
+    t, y, has = cases.poisson_counts(7, missing=0.2)
+    out = []
+    for grp in (1, 0):
+        g = NativePf(model, n, cases.SEED); g.set_option(OPT_GROUP_SUMS, grp)
+        ll, llt, ess, _ = g.run(t, y, has)
+        out.append((ll, llt, ess, g.ancestors(), g.particles())); g.close()
+    assert out[0][0] == out[1][0]
+    for a, b in zip(out[0][1:], out[1][1:]):
+        np.testing.assert_array_equal(a, b)
+
+
 @pytest.mark.parametrize("name", ["c1", "c2", "c3", "linear", "negbin", "zip", "bernoulli", "studentt", "beta"])
 def test_whole_tile_kernels_at_test_sizes(name):
     """The kernels large clouds run (CSSM_OPT_WHOLE_TILES = 1, 2, 3), every observation density, batch and streaming, with
