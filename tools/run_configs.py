@@ -50,6 +50,7 @@ run("C4 LGCP precision 2, N=2^24 on ONE GPU, 100 events", m, 1 << 24, t, y, has,
 t, y, has = cases.poisson_counts(500)
 data = [Data(float(a), float(b)) for a, b in zip(t, y)]
 for n in (100000, 131072):
+    pmmh_native(cases.c2_unparam(), cases.c2_params(), data, n, 0.05, 2, seed=7)   # (untimed: the first call of a process loads the code objects)
     t0 = time.perf_counter(); ll, th, acc, last = pmmh_native(cases.c2_unparam(), cases.c2_params(), data, n, 0.05, 20, seed=7)
     dt = time.perf_counter() - t0
     row = {"config": f"C5 PMMH seasonal model N={n} T=500", "iters_run": 20, "s_per_iter": dt / 20, "projected_10k_iters_s": dt / 20 * 10000,
