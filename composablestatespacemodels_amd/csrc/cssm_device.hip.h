@@ -54,8 +54,8 @@ struct Scalars {
   // observation s uses set s % 3; the kernel that resamples it (k_offspring) clears the other two, so no reset kernel exists.
   unsigned long long maxslot[CSSM_MAXSETS * CSSM_MAXSLOTS * CSSM_SLOT_STRIDE];
   // Sums of GROUPS of CSSM_GRP_UNITS consecutive units (single GPU, fused sums, one k_propagate block per unit), in the same three
-  // sets: every k_propagate block adds the two 56-bit limbs of its unit sum (< 2^112: units of at most 2^15 particles... the host
-  // checks) to two 64-bit words, each on a cache line of its own (non-returning atomics; 32 blocks x 2^56 cannot overflow a word;
+  // sets: every k_propagate block adds the two 56-bit limbs of its unit sum (< 2^112: the host turns the group sums on for units of
+  // at most CSSM_GRP_MAX_UNIT particles, every weight being at most exp(2^-20)) to two 64-bit words, each on a cache line of its own (non-returning atomics; 32 blocks x 2^56 cannot overflow a word;
   // integer sums: any order, the same bits).  k_offspring's blocks then read 32 group sums + the 32 unit sums of their own group
   // instead of all 1024 unit sums (16 KiB per block, 16 MiB per launch through the L2s: doubling that traffic cost the kernel
   // 1.35 us at N = 2^20).  Cleared with the max slots.  Index: ((set * 2 + limb) * CSSM_GRP_MAX + group) * CSSM_SLOT_STRIDE.
