@@ -244,7 +244,7 @@ __device__ __forceinline__ void offspring_exact_counts(cssm_u128 run0, const dou
 #else
 #define CSSM_STAMP(k) do { } while (0)
 #endif
-template <bool FUSE, bool SELF, int RS, int RAWC = -1>
+template <bool FUSE, bool SELF, int RS, int RAWC = -1, bool GRP = false>
 __device__ __forceinline__ void offspring_body(const double* __restrict__ logw, uint64_t n,
                                                           Scalars* __restrict__ sc,
                                                           const cssm_u128* __restrict__ unitP, const cssm_u128* __restrict__ unitS2,
@@ -258,8 +258,12 @@ __device__ __forceinline__ void offspring_body(const double* __restrict__ logw, 
                                                           unsigned long long* __restrict__ flag_out,
                                                           uint32_t slot_lo, uint32_t slot_hi, uint32_t all5_stride,
                                                           cssm_u128* __restrict__ s2buf = nullptr, uint32_t s2_stride = 0, int s2_par_arg = -1,
-                                                          uint32_t gen = 0, const bool grp_on = false) {
-  // grp_on (SELF, behind a k_propagate whose blocks accumulated them): the sums of groups of 32 units are at hand (Scalars::grp)
+                                                          uint32_t gen = 0) {
+  // GRP (SELF, RAWC == 2, behind a k_propagate whose blocks accumulated them): the sums of groups of 32 units are at hand
+  // (Scalars::grp) -- an instantiation of its own: it keeps ONE unit-sum entry per lane of one wave in flight instead of UPRE per
+  // thread, and the registers that frees let the block's first tile be converted and scanned BEFORE the sums' barrier
+  constexpr bool grp_on = GRP;
+  static_assert(!GRP || (SELF && RAWC == 2), "group sums: the single-GPU launch behind a fused-sums propagate");
   // RAWC >= 0 (the single-GPU launches): the weight-input mode is a compile-time constant -- 2 goes with the pending ESS
   // (s2_par >= 0), 0 with the sums of squares at hand; the kernel had run out of scalar and vector registers otherwise
   const int raw = (RAWC >= 0) ? RAWC : raw_arg;
@@ -423,6 +427,36 @@ __device__ __forceinline__ void offspring_body(const double* __restrict__ logw, 
     for (int w = 1; w < CSSM_BLOCK / 64; ++w) t = cssm_u128_add(t, s_r[1][w]);
     return cssm_u128_to_double(t);
   };
+  cssm_u128 acc2 = cssm_u128_zero();                       // SELF, s2_par >= 0: the thread's sum of squared weights
+  // the weight on the 2^-96 grid (raw == 1: arbitrary host doubles, range-checked; else exp of a clamped non-positive number).
+  // Not kept: the rare exact path below forms it again from w1 (16 registers live across the whole tile otherwise).
+  auto fixw = [&](double w) { return (raw == 1) ? cssm_fix_from_double(w) : cssm_fix_from_unit(w); };
+  // (GRP instantiation) A tile up to its block barrier: the weights, their sum on the grid, the wave scan of the threads' sums (s_w[wave] = the wave's
+  // total) and, behind a unit's last tile on the single GPU, the waves' sums of squared weights (s_r[2]: they ride on that barrier
+  // -- the block's partial leaves behind it, its ESS is formed later; a block-wide sum of its own at the end of the kernel cost two
+  // more barriers)
+  auto tile_front = [&](uint32_t tile, bool first, double (&w1)[CSSM_ITEMS], bool s2_now) __attribute__((always_inline)) -> cssm_u128 {
+    // (measured and dropped: requesting the NEXT tile's weights here, a register pipeline over the 16 tiles a block of the
+    //  2^24 cloud walks -- 71.4 vs 71.7 us: the CU's other blocks already cover the round trip)
+    if (first) weights_from_raw(pre_v, gmax, raw, w1, tab);
+    else load_tile_weights(logw, (uint64_t)tile * CSSM_TILE, n, gmax, raw, w1, tab);
+    cssm_u128 tsum = cssm_u128_zero();
+#pragma unroll
+    for (int r = 0; r < CSSM_ITEMS; ++r) {
+      tsum = cssm_u128_add(tsum, fixw(w1[r]));
+      if (SELF && s2_par >= 0) acc2 = cssm_u128_add(acc2, cssm_fix_from_unit(w1[r] * w1[r]));
+    }
+    const cssm_u128 inc = wave_scan_u128(tsum, lane);
+    if (lane == 63) s_w[wid] = inc;
+    CSSM_STAMP(2);
+    if (s2_now) {
+      const cssm_u128 w2 = wave_scan_u128(acc2, lane);
+      if (lane == 63) s_r[2][wid] = w2;
+    }
+    return inc;
+  };
+  double w1_first[CSSM_ITEMS];                             // GRP: the first tile, converted ahead of the sums' barrier
+  cssm_u128 inc_first = cssm_u128_zero();
   if (SELF) {                                              // here unitP holds the unit SUMS (k_propagate / k_tile_sums output)
     // ONE wave scan of the threads' own sums gives both the total and the prefix of the entries below this block's first
     // (qlim): that prefix = inclusive scan at thread tq - 1 + the first qlim - tq E entries of thread tq, tq = qlim / E.
@@ -460,8 +494,8 @@ __device__ __forceinline__ void offspring_body(const double* __restrict__ logw, 
           }
         }
         __syncthreads();
-        tot = s_r[1][0];
-        pre = s_pre[0];
+        tot.lo = s_r[1][0].lo; tot.hi = s_r[1][0].hi;     // (member by member: a struct copy here stays a memcpy through a private
+        pre.lo = s_pre[0].lo; pre.hi = s_pre[0].hi;       //  object, which the back end then parks in LDS: 16 bytes per thread)
         return;
       }
       cssm_u128 own = cssm_u128_zero(), part = cssm_u128_zero();
@@ -551,6 +585,12 @@ __device__ __forceinline__ void offspring_body(const double* __restrict__ logw, 
         sc->maxslot[((size_t)((slot_set + 1 + (int)(threadIdx.x / CSSM_MAXSLOTS)) % CSSM_MAXSETS) * CSSM_MAXSLOTS + threadIdx.x % CSSM_MAXSLOTS) * CSSM_SLOT_STRIDE] = 0ull;
       return;
     }
+    // GRP: the first tile's weights on the grid and their wave scan while the sums' wave is at work -- nothing of that depends on
+    // the sums (RAWC == 2: the weights are stored as they are used); its results go through the SAME barrier (tile_front below)
+    if constexpr (GRP) {
+      const uint32_t t0h = ublk * sup;
+      inc_first = tile_front(t0h, true, w1_first, t0h + 1u == ((t0h + sup < ntiles) ? t0h + sup : ntiles));
+    }
     cssm_u128 tot;
     scan_units(tot, toff_self);
     CSSM_STAMP(1);
@@ -568,7 +608,6 @@ __device__ __forceinline__ void offspring_body(const double* __restrict__ logw, 
       scale_self = uniform_f64((double)n_global * rinv);
     }
   }
-  cssm_u128 acc2 = cssm_u128_zero();                       // SELF, s2_par >= 0: the thread's sum of squared weights
   if (unit < nunits) do {
     const uint32_t t0 = unit * sup;
     const uint32_t t1 = (t0 + sup < ntiles) ? t0 + sup : ntiles;
@@ -588,30 +627,39 @@ __device__ __forceinline__ void offspring_body(const double* __restrict__ logw, 
     for (uint32_t tile = t0; tile < t1; ++tile) {
       const uint64_t base = (uint64_t)tile * CSSM_TILE;
       double w1[CSSM_ITEMS];
-      // (measured and dropped: requesting the NEXT tile's weights here, a register pipeline over the 16 tiles a block of the
-      //  2^24 cloud walks -- 71.4 vs 71.7 us: the CU's other blocks already cover the round trip)
-      if (unit == ublk && tile == t0) weights_from_raw(pre_v, gmax, raw, w1, tab);
-      else load_tile_weights(logw, base, n, gmax, raw, w1, tab);
-      // the weight on the 2^-96 grid (raw == 1: arbitrary host doubles, range-checked; else exp of a clamped non-positive number).
-      // Not kept: the rare exact path below forms it again from w1 (16 registers live across the whole tile otherwise).
-      auto fixw = [&](double w) { return (raw == 1) ? cssm_fix_from_double(w) : cssm_fix_from_unit(w); };
-      cssm_u128 tsum = cssm_u128_zero();
-#pragma unroll
-      for (int r = 0; r < CSSM_ITEMS; ++r) {
-        tsum = cssm_u128_add(tsum, fixw(w1[r]));
-        if (SELF && s2_par >= 0) acc2 = cssm_u128_add(acc2, cssm_fix_from_unit(w1[r] * w1[r]));
-      }
-      cssm_u128 inc = wave_scan_u128(tsum, lane);
-      if (lane == 63) s_w[wid] = inc;
-      // (single GPU) the unit's last tile: the waves' sums of squared weights ride on this barrier -- the block's partial leaves
-      // behind it, its ESS is formed later (a block-wide sum of its own at the end of the kernel cost two more barriers)
-      CSSM_STAMP(2);
+      cssm_u128 inc;
       const bool s2_now = SELF && s2_par >= 0 && tile + 1 == t1;
-      if (s2_now) {
-        const cssm_u128 w2 = wave_scan_u128(acc2, lane);
-        if (lane == 63) s_r[2][wid] = w2;
+      if constexpr (GRP) {
+        if (tile == t0) {                                    // (converted and scanned ahead of the sums' barrier, which covered s_w too)
+#pragma unroll
+          for (int r = 0; r < CSSM_ITEMS; ++r) w1[r] = w1_first[r];
+          inc = inc_first;
+        } else {
+          inc = tile_front(tile, false, w1, s2_now);
+          __syncthreads();
+        }
+      } else {
+        // (measured and dropped: requesting the NEXT tile's weights here, a register pipeline over the 16 tiles a block of the
+        //  2^24 cloud walks -- 71.4 vs 71.7 us: the CU's other blocks already cover the round trip)
+        if (unit == ublk && tile == t0) weights_from_raw(pre_v, gmax, raw, w1, tab);
+        else load_tile_weights(logw, base, n, gmax, raw, w1, tab);
+        cssm_u128 tsum = cssm_u128_zero();
+#pragma unroll
+        for (int r = 0; r < CSSM_ITEMS; ++r) {
+          tsum = cssm_u128_add(tsum, fixw(w1[r]));
+          if (SELF && s2_par >= 0) acc2 = cssm_u128_add(acc2, cssm_fix_from_unit(w1[r] * w1[r]));
+        }
+        inc = wave_scan_u128(tsum, lane);
+        if (lane == 63) s_w[wid] = inc;
+        // (single GPU) the unit's last tile: the waves' sums of squared weights ride on this barrier -- the block's partial leaves
+        // behind it, its ESS is formed later (a block-wide sum of its own at the end of the kernel cost two more barriers)
+        CSSM_STAMP(2);
+        if (s2_now) {
+          const cssm_u128 w2 = wave_scan_u128(acc2, lane);
+          if (lane == 63) s_r[2][wid] = w2;
+        }
+        __syncthreads();
       }
-      __syncthreads();
       if (s2_now && threadIdx.x == 0) {
         cssm_u128 b2 = s_r[2][0];
 #pragma unroll
@@ -780,7 +828,7 @@ __global__ __launch_bounds__(CSSM_BLOCK, CSSM_OFF_WAVES) void k_offspring(CSSM_O
 // The single-GPU filter's launch: only the arguments that path uses (the generic kernel above carries ~30, most of them the
 // sharded filter's; their scalar registers spilled into vector registers and those into scratch -- 28 bytes per thread,
 // i.e. 7 MB of scratch write-back per launch at N = 2^20, which the PMC counters showed as "wasted" write traffic).
-template <int RS, int RAWC>
+template <int RS, int RAWC, bool GRP = false>
 __global__ __attribute__((amdgpu_flat_work_group_size(CSSM_BLOCK, CSSM_BLOCK),
                           amdgpu_waves_per_eu((RS == CSSM_RESAMPLE_SYSTEMATIC && RAWC == 2) ? CSSM_OFF_SELF_WAVES : CSSM_OFF_WAVES, 8))) void k_offspring_self(
     const double* __restrict__ logw, uint64_t n, Scalars* __restrict__ sc, const cssm_u128* __restrict__ unitP,
@@ -789,10 +837,10 @@ __global__ __attribute__((amdgpu_flat_work_group_size(CSSM_BLOCK, CSSM_BLOCK),
     uint64_t seed, double* __restrict__ cum_out, cssm_u128* __restrict__ s2buf, uint32_t s2_stride, int s2_par, uint32_t gen) {
   // RAWC = 2: behind k_propagate<SUMS> (weights in place of log-weights, sums relative to the reference level: `optimistic`,
   // the ESS stays pending); 0: behind k_tile_sums (log-weights, both sums at hand)
-  // (slot_set bit 8: the propagate behind this launch accumulated the sums of groups of units, Scalars::grp)
-  offspring_body<true, true, RS, RAWC>(logw, n, sc, unitP, unitS2, rec, n, nullptr, anc, ntiles, sup, nunits, RAWC, slot_set & 0xff, ll_t, ess_t, rec_idx,
-                                       force_exact, nullptr, 0, 1, split, seed, cum_out, nullptr, RAWC == 2 ? 1 : 0, nullptr, 0u, (uint32_t)n, 5u,
-                                       s2buf, s2_stride, s2_par, gen, RAWC == 2 && (slot_set & 0x100) != 0);
+  // GRP: the propagate behind this launch accumulated the sums of groups of units (Scalars::grp)
+  offspring_body<true, true, RS, RAWC, GRP>(logw, n, sc, unitP, unitS2, rec, n, nullptr, anc, ntiles, sup, nunits, RAWC, slot_set, ll_t, ess_t, rec_idx,
+                                            force_exact, nullptr, 0, 1, split, seed, cum_out, nullptr, RAWC == 2 ? 1 : 0, nullptr, 0u, (uint32_t)n, 5u,
+                                            s2buf, s2_stride, s2_par, gen);
 }
 
 // Resampling.multinomialResampling (model/Resampling.scala:92-96): slot i draws its own uniform and takes the

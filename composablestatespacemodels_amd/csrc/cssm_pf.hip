@@ -347,9 +347,11 @@ static int launch_resample(cssm_pf* pf, const StepRec* d_rec, double* ll_t = nul
   const int s2_par = optimistic ? pf->s2_par : -1;
   prof_begin(pf, CSSM_K_OFFSPRING);   // unit prefix, ll (ess), end slots and their expansion to ancestors in one kernel (one block per unit + the publisher)
 #define OFF_ARGS pf->logw, pf->n, pf->sc, (const cssm_u128*)pf->tileS, (const cssm_u128*)pf->tileS2, d_rec, pf->anc, pf->ntiles, pf->sup, pf->nunits, \
-                 pf->wparity | ((optimistic && pf->last_grp) ? 0x100 : 0), ll_t, ess_t, rec_idx, pf->opt_exact, split, pf->seed, pf->cum, pf->s2buf, pf->s2_stride, s2_par, pf->gen
+                 pf->wparity, ll_t, ess_t, rec_idx, pf->opt_exact, split, pf->seed, pf->cum, pf->s2buf, pf->s2_stride, s2_par, pf->gen
   const int ogrid = tgrid + 1;   // one block per unit + the publisher
-#define OFF_GO(RS) do { if (optimistic) hipLaunchKernelGGL((k_offspring_self<RS, 2>), dim3(ogrid), dim3(CSSM_BLOCK), 0, pf->stream, OFF_ARGS); \
+#define OFF_GO(RS) do { if (optimistic && pf->last_grp && RS == CSSM_RESAMPLE_SYSTEMATIC) \
+                          hipLaunchKernelGGL((k_offspring_self<CSSM_RESAMPLE_SYSTEMATIC, 2, true>), dim3(ogrid), dim3(CSSM_BLOCK), 0, pf->stream, OFF_ARGS); \
+                        else if (optimistic) hipLaunchKernelGGL((k_offspring_self<RS, 2>), dim3(ogrid), dim3(CSSM_BLOCK), 0, pf->stream, OFF_ARGS); \
                         else hipLaunchKernelGGL((k_offspring_self<RS, 0>), dim3(ogrid), dim3(CSSM_BLOCK), 0, pf->stream, OFF_ARGS); } while (0)
   if (pf->resampler == CSSM_RESAMPLE_STRATIFIED) OFF_GO(CSSM_RESAMPLE_STRATIFIED);
   else if (pf->resampler == CSSM_RESAMPLE_MULTINOMIAL) OFF_GO(CSSM_RESAMPLE_MULTINOMIAL);
