@@ -288,6 +288,7 @@ __device__ __forceinline__ void offspring_body(const double* __restrict__ logw, 
   __shared__ __attribute__((aligned(16))) uint32_t s_slot[FUSE ? (CSSM_BLOCK / 64) * CSSM_WAVE_CHUNK : 4];   // per wave: a 512-slot chunk of ancestor runs
   __shared__ cssm_u128 s_r[3][CSSM_BLOCK / 64];
   __shared__ cssm_u128 s_pre[2];
+  __shared__ double s_scale;                               // (GRP) N / S_tot, see scan_units
   // (batch series, single GPU) an earlier observation's reference level was ruled out by its max: the series is on hold at
   // that observation until the host has redone it (run_filter_once); nothing may change meanwhile
   // (the test sits behind the prefetches below: a dependent round trip at the very top of the kernel otherwise)
@@ -491,6 +492,12 @@ __device__ __forceinline__ void offspring_body(const double* __restrict__ logw, 
 #pragma unroll
             for (int w = 1; w < CSSM_BLOCK / 64; ++w) s_r[1][w] = cssm_u128_zero();
             s_pre[0] = cssm_u128_add(pg, pu);
+            // N / S_tot of the end slots' fast path (see below), once per block instead of once per thread behind the barrier
+            const double tf = cssm_fma((double)t.hi, 0x1.0p64, (double)t.lo);
+            double rinv = __builtin_amdgcn_rcp(tf);
+            rinv = cssm_fma(cssm_fma(-tf, rinv, 1.0), rinv, rinv);
+            rinv = cssm_fma(cssm_fma(-tf, rinv, 1.0), rinv, rinv);
+            s_scale = (double)n_global * rinv;
           }
         }
         __syncthreads();
@@ -600,7 +607,9 @@ __device__ __forceinline__ void offspring_body(const double* __restrict__ logw, 
     // Newton steps (what the division's own expansion starts with): relative error < 2^-50, inside the budget stated below.  The
     // correctly rounded S_tot of the contract (a normalisation with a leading-zero count: ~35 instructions, and a full division:
     // ~30, in every thread of every block) is formed only where the exact predicate is evaluated.
-    {
+    if constexpr (GRP) {
+      scale_self = uniform_f64(s_scale);                   // (formed by the wave that totalled the sums, ahead of the barrier)
+    } else {
       const double tf = cssm_fma((double)tot.hi, 0x1.0p64, (double)tot.lo);
       double rinv = __builtin_amdgcn_rcp(tf);
       rinv = cssm_fma(cssm_fma(-tf, rinv, 1.0), rinv, rinv);
