@@ -71,6 +71,8 @@ struct cssm_pf : HostModel {
   double* cum = nullptr;       // multinomial: cumulative normalised weights
   const long long *send_first_dev = nullptr, *send_count_dev = nullptr;   // last shard_offspring outputs (device)
   cssm_u128 *tileS = nullptr, *tileS2 = nullptr, *tileP = nullptr;
+  cssm_u128* unitPre = nullptr;   // sharded, single-collective exchange: exclusive prefixes of the unit sums (k_boundary_pack -> k_offspring_expand_spec)
+  bool spec_pre = false;          // ... written by the last cssm_pf_shard_boundary_pack
   Scalars* sc = nullptr;
   double *d_m0 = nullptr, *d_sd0 = nullptr, *d_logtab = nullptr;
   StepRec* d_recs = nullptr;

@@ -258,7 +258,8 @@ __device__ __forceinline__ void offspring_body(const double* __restrict__ logw, 
                                                           unsigned long long* __restrict__ flag_out,
                                                           uint32_t slot_lo, uint32_t slot_hi, uint32_t all5_stride,
                                                           cssm_u128* __restrict__ s2buf = nullptr, uint32_t s2_stride = 0, int s2_par_arg = -1,
-                                                          uint32_t gen = 0) {
+                                                          uint32_t gen = 0, const cssm_u128* __restrict__ unit_pre = nullptr) {
+  // unit_pre (sharded, single-collective exchange; or nullptr): exclusive prefixes of the (sub-)unit sums, from k_boundary_pack
   // GRP (SELF, RAWC == 2, behind a k_propagate whose blocks accumulated them): the sums of groups of 32 units are at hand
   // (Scalars::grp) -- an instantiation of its own: it keeps ONE unit-sum entry per lane of one wave in flight instead of UPRE per
   // thread, and the registers that frees let the block's first tile be converted and scanned BEFORE the sums' barrier
@@ -621,7 +622,9 @@ __device__ __forceinline__ void offspring_body(const double* __restrict__ logw, 
     const uint32_t t0 = unit * sup;
     const uint32_t t1 = (t0 + sup < ntiles) ? t0 + sup : ntiles;
     cssm_u128 toff;                                        // cumulative weight before the current tile
-    if (!SELF && all5) {                                   // sharded: unitP holds the (sub-)unit SUMS; the totals came with all5
+    if (!SELF && all5 && unit_pre != nullptr) {            // sharded, the prefixes of the unit sums at hand (k_boundary_pack's header block)
+      toff = cssm_u128_add(S_off, unit_pre[(size_t)unit * split]);
+    } else if (!SELF && all5) {                            // sharded: unitP holds the (sub-)unit SUMS; the totals came with all5
       cssm_u128 pre = cssm_u128_zero();
       const uint32_t qlim = unit * (uint32_t)split;
       for (uint32_t q = threadIdx.x; q < qlim; q += CSSM_BLOCK) pre = cssm_u128_add(pre, unitP[q]);

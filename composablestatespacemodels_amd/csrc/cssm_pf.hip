@@ -95,6 +95,7 @@ static int alloc_handle(cssm_pf* pf) {
   HIP_TRY(hipMalloc(&pf->tileS, nsums * sizeof(cssm_u128)));
   HIP_TRY(hipMalloc(&pf->tileS2, nsums * sizeof(cssm_u128)));
   HIP_TRY(hipMalloc(&pf->tileP, nsums * sizeof(cssm_u128)));
+  HIP_TRY(hipMalloc(&pf->unitPre, nsums * sizeof(cssm_u128)));
   pf->s2_stride = (uint32_t)nsums;
   HIP_TRY(hipMalloc(&pf->s2buf, 2 * nsums * sizeof(cssm_u128)));
   HIP_TRY(hipMemsetAsync(pf->s2buf, 0, 2 * nsums * sizeof(cssm_u128), pf->stream));
@@ -157,7 +158,7 @@ extern "C" void cssm_pf_destroy(cssm_pf* pf) {
   if (!pf) return;
   (void)hipSetDevice(pf->device);
   if (pf->stream) (void)hipStreamSynchronize(pf->stream);
-  void* ptrs[] = {pf->sm_keys, pf->sm_partial, pf->sm_st, pf->sm_rec, pf->s2buf, pf->fineS, pf->fineS2, pf->state[0], pf->state[1], pf->logw, pf->endslot, pf->anc, pf->tileS, pf->tileS2, pf->tileP, pf->sc,
+  void* ptrs[] = {pf->sm_keys, pf->sm_partial, pf->sm_st, pf->sm_rec, pf->s2buf, pf->fineS, pf->fineS2, pf->state[0], pf->state[1], pf->logw, pf->endslot, pf->anc, pf->tileS, pf->tileS2, pf->tileP, pf->unitPre, pf->sc,
                   pf->d_m0, pf->d_sd0, pf->d_logtab, pf->d_fsub, pf->cum, pf->d_recs, pf->d_ll_t, pf->d_ess_t, pf->d_path, pf->cand, pf->cand_end, pf->cand_idx, pf->d_bounds, pf->d_xch, pf->d_need};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   if (pf->h_recs) (void)hipHostFree(pf->h_recs);

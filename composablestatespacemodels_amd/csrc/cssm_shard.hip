@@ -435,9 +435,11 @@ extern "C" int cssm_pf_shard_boundary_pack(cssm_pf* pf, int rank, int world, int
   const long long cnt = std::min<long long>((long long)pf->n, (long long)cap);
   const int tiles = (int)((cnt + CSSM_TILE - 1) / CSSM_TILE);
   prof_begin(pf, CSSM_K_PACK);
-  hipLaunchKernelGGL(k_boundary_pack, dim3(tiles + 1, world), dim3(CSSM_BLOCK), 0, pf->stream, pf->state[pf->cur], pf->stride, pf->logw, pf->n, pf->d,
+  hipLaunchKernelGGL(k_boundary_pack, dim3(tiles + 2, world), dim3(CSSM_BLOCK), 0, pf->stream, pf->state[pf->cur], pf->stride, pf->logw, pf->n, pf->d,
                      world, rank, (long long)cap, pf->d_recs + slot, (const cssm_u128*)pf->tileS, (const cssm_u128*)pf->tileS2, nsub,
-                     (const Scalars*)pf->sc, send_buf_dev, chunk, pf->last_optimistic ? 0 : 1);
+                     (const Scalars*)pf->sc, send_buf_dev, chunk, pf->last_optimistic ? 0 : 1,
+                     (pf->split == 1 && nsub <= 4u * CSSM_BLOCK) ? pf->unitPre : (cssm_u128*)nullptr);
+  pf->spec_pre = (pf->split == 1 && nsub <= 4u * CSSM_BLOCK);   // (k_offspring_expand_spec reads them: cssm_pf_shard_adopt_spec)
   prof_end(pf);
   HIP_TRY(hipGetLastError());
   return CSSM_OK;
@@ -463,14 +465,14 @@ extern "C" int cssm_pf_shard_adopt_spec(cssm_pf* pf, const double* recv_buf_dev,
                      pf->anc, pf->ntiles, pf->sup, pf->nunits, pf->last_optimistic ? 2 : 0, 0, (double*)nullptr, (int32_t*)nullptr, 0u, pf->opt_exact,
                      all5, rank, world, (int)pf->split, pf->seed, (double*)nullptr, (const double*)pf->d_logtab,
                      pf->last_optimistic ? 2 : 0, (unsigned long long*)(pf->d_xch + 128), (uint32_t)pf->first, (uint32_t)(pf->first + pf->n), (uint32_t)seg,
-                     recv_buf_dev, (long long)cap, pf->d, n_split);
+                     recv_buf_dev, (long long)cap, pf->d, n_split, pf->spec_pre ? (const cssm_u128*)pf->unitPre : (const cssm_u128*)nullptr);
   } else {
     hipLaunchKernelGGL(k_offspring_expand_spec<0>, dim3(tgrid), dim3(CSSM_BLOCK), 0, pf->stream, pf->logw, pf->n, pf->sc,
                      (const cssm_u128*)pf->tileS, (const cssm_u128*)pf->tileS2, (const StepRec*)(pf->d_recs + slot), pf->n_global, pf->endslot,
                      pf->anc, pf->ntiles, pf->sup, pf->nunits, pf->last_optimistic ? 2 : 0, 0, (double*)nullptr, (int32_t*)nullptr, 0u, pf->opt_exact,
                      all5, rank, world, (int)pf->split, pf->seed, (double*)nullptr, (const double*)pf->d_logtab,
                      pf->last_optimistic ? 2 : 0, (unsigned long long*)(pf->d_xch + 128), (uint32_t)pf->first, (uint32_t)(pf->first + pf->n), (uint32_t)seg,
-                     recv_buf_dev, (long long)cap, pf->d, n_split);
+                     recv_buf_dev, (long long)cap, pf->d, n_split, pf->spec_pre ? (const cssm_u128*)pf->unitPre : (const cssm_u128*)nullptr);
   }
   prof_end(pf);
   HIP_TRY(hipGetLastError());

@@ -70,7 +70,10 @@ __global__ __launch_bounds__(CSSM_BLOCK) void k_boundary_pack(const double* __re
                                                               const StepRec* __restrict__ rec, const cssm_u128* __restrict__ subS,
                                                               const cssm_u128* __restrict__ subS2, uint32_t nsub,
                                                               const Scalars* __restrict__ sc, double* __restrict__ out, uint64_t chunk,
-                                                              int level_from_max) {
+                                                              int level_from_max, cssm_u128* __restrict__ pre_out) {
+  // pre_out (nsub <= 4 * CSSM_BLOCK, else nullptr): the header block of segment 0 also writes the EXCLUSIVE prefix of the sub-unit
+  // sums -- pre_out[j] = subS[0] + .. + subS[j - 1] -- which k_offspring_expand_spec's block j then reads as one word instead of
+  // summing j entries itself (on average 8 KiB per block and a block-wide sum with two barriers)
   // level_from_max: the sums (subS) were formed relative to the level chosen with the GLOBAL max after an all-gather of the
   // local maxima (cssm_pf_shard_sums: LGCP series, whose level is the max; the repetition of a series an outlying observation
   // voided) -- the weights of the rows are then relative to sc->ref and the header carries the global max
@@ -105,7 +108,29 @@ __global__ __launch_bounds__(CSSM_BLOCK) void k_boundary_pack(const double* __re
     for (int w = 1; w < CSSM_BLOCK / 64; ++w) t = cssm_u128_add(t, s_w[w]);
     return t;
   };
-  const bool header_block = (blockIdx.x == gridDim.x - 1);   // grid.x = tiles of the block + 1: the header has a block of its own
+  // grid.x = tiles of the block + 2: the header has a block of its own, and so have the prefixes of the sub-unit sums (pre_out; in the
+  // header block they lengthened the launch's longest latency chain by 1.6 us)
+  if (blockIdx.x == gridDim.x - 1) {   // the prefix block: thread t owns the entries 4 t .. 4 t + 3
+    if (pre_out == nullptr || blockIdx.y != 0) return;
+    __shared__ cssm_u128 s_p[CSSM_BLOCK / 64];
+    cssm_u128 v[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { const uint32_t i = threadIdx.x * 4u + (uint32_t)k; v[k] = (i < nsub) ? subS[i] : cssm_u128_zero(); }
+    const cssm_u128 e1 = v[0], e2 = cssm_u128_add(e1, v[1]), e3 = cssm_u128_add(e2, v[2]), own = cssm_u128_add(e3, v[3]);
+    const cssm_u128 inc = wave_scan_u128(own, lane);
+    if (lane == 63) s_p[wid] = inc;
+    __syncthreads();
+    cssm_u128 ex = inc;                                  // exclusive prefix of the thread's first entry: inc - own + the waves before
+    ex.hi = inc.hi - own.hi - (inc.lo < own.lo ? 1ull : 0ull); ex.lo = inc.lo - own.lo;
+    for (int w = 0; w < wid; ++w) ex = cssm_u128_add(ex, s_p[w]);
+    const uint32_t i0 = threadIdx.x * 4u;
+    if (i0 < nsub) pre_out[i0] = ex;
+    if (i0 + 1u < nsub) pre_out[i0 + 1u] = cssm_u128_add(ex, e1);
+    if (i0 + 2u < nsub) pre_out[i0 + 2u] = cssm_u128_add(ex, e2);
+    if (i0 + 3u < nsub) pre_out[i0 + 3u] = cssm_u128_add(ex, e3);
+    return;
+  }
+  const bool header_block = (blockIdx.x == gridDim.x - 2);
   if (!header_block) {
   if (cnt == 0) return;
   // prefix of the tiles before this block's tile
@@ -421,7 +446,9 @@ __device__ unsigned long long g_spec_stamps[2048 * 8];   // diagnostic build: cl
 // log-weights, rescaled by the level the global max gave -- LGCP, a series repeated after an outlying observation)
 template <int RAWC>
 __global__ __launch_bounds__(CSSM_BLOCK, CSSM_OFF_WAVES) void k_offspring_expand_spec(
-    CSSM_OFFSPRING_PARAMS, uint32_t all5_stride, const double* __restrict__ recv, long long cap, int d, uint32_t n_split) {
+    CSSM_OFFSPRING_PARAMS, uint32_t all5_stride, const double* __restrict__ recv, long long cap, int d, uint32_t n_split,
+    const cssm_u128* __restrict__ unit_pre) {
+  // unit_pre (or nullptr): the exclusive prefixes of the unit sums k_boundary_pack's header block left (its pre_out)
   __shared__ SpecHeaders H;
   CSSM_SPEC_STAMP(0);
   // everything the verdict starts from is requested first, tested afterwards
@@ -449,7 +476,8 @@ __global__ __launch_bounds__(CSSM_BLOCK, CSSM_OFF_WAVES) void k_offspring_expand
   (void)raw;
   offspring_body<true, false, CSSM_RESAMPLE_SYSTEMATIC, RAWC>(logw, n, sc, unitP, unitS2, rec, n_global, /*endslot=*/nullptr, anc, ntiles, sup, nunits, RAWC, slot_set,
                                                         /*ll_t=*/nullptr, /*ess_t=*/nullptr, 0u, force_exact, all5, rank, world, split, /*seed=*/0ull,
-                                                        /*cum_out=*/nullptr, /*logtab=*/nullptr, optimistic, flag_out, slot_lo, slot_hi, all5_stride);
+                                                        /*cum_out=*/nullptr, /*logtab=*/nullptr, optimistic, flag_out, slot_lo, slot_hi, all5_stride,
+                                                        /*s2buf=*/nullptr, 0u, -1, 0u, unit_pre);
   CSSM_SPEC_STAMP(2);
   expand_spec_body(H, blockIdx.x, gridDim.x, recv, world, rank, cap, d, n_split, (uint64_t)slot_lo, (uint64_t)slot_hi, n_global, rec, anc, sc);
   CSSM_SPEC_STAMP(3);
