@@ -457,6 +457,8 @@ __global__ __launch_bounds__(CSSM_BLOCK, CSSM_OFF_WAVES) void k_offspring_expand
   unsigned long long key = 0ull;
   if (optimistic) for (int r = 0; r < world; ++r) { const unsigned long long k = all5[(size_t)all5_stride * r + 4]; key = (k > key) ? k : key; }
   const SpecHdrRegs hregs = spec_load_headers(recv, world, cap, d);
+  // (measured and dropped: the weights of the block's first tile requested here as well, ahead of the verdict -- 11.8 -> 12.3 us at
+  //  2^20 per rank, eight more registers live across the verdict)
   if (held & (4u | 8u)) return;
   if (optimistic) {
     // the level first: sums formed relative to a reference level that the global max rules out (an outlying observation) say
