@@ -295,7 +295,7 @@ int cssm_launch_propagate(cssm_pf* pf, const StepRec* d_rec, double* pick_out, u
   a.pick_out = pick_out; a.pick_slot = pick_slot;
   // the observation's index as a kernel argument: every record a propagate is launched on lives in the handle's record buffer,
   // whose host copy was built (and its upload enqueued) before this launch
-  if (!pf->h_recs || d_rec < pf->d_recs || d_rec >= pf->d_recs + pf->h_recs_cap)
+  if (!pf->h_recs || d_rec < pf->d_recs || d_rec >= pf->d_recs + std::min(pf->h_recs_cap, pf->recs_cap))
     return fail(CSSM_ESTATE, "propagate launched on a record outside the handle's record buffer");
   a.step = pf->h_recs[d_rec - pf->d_recs].step;
   a.fsub = pf->lgcp_tdep ? pf->d_fsub : nullptr;
