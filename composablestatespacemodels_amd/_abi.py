@@ -158,6 +158,11 @@ def load_library(path: str | None = None) -> C.CDLL:
     return lib
 
 
+def last_error() -> str:
+    msg = load_library().cssm_last_error()
+    return msg.decode() if msg else ""
+
+
 def check(rc: int) -> None:
     if rc != 0:
         msg = load_library().cssm_last_error()

@@ -27,8 +27,9 @@ struct PropLaunch {
   int one;             // k_propagate_self<..., ONE>: 1 = the block's range is one tile, 2 = the same body tile after tile, 0 = software-pipelined
 };
 
-// one per latent dimension, defined in cssm_prop.hip
-#define CSSM_DECL_PROP(D) void cssm_prop_launch_d##D(const PropLaunch& a);
+// one per latent dimension, defined in cssm_prop.hip; returns what the kernel it chose does beyond the propagate itself
+#define CSSM_PROP_LAUNCHED_GRP 1   /* its blocks accumulate the sums of groups of units (Scalars::grp; asked for by bit 8 of slot_set) */
+#define CSSM_DECL_PROP(D) int cssm_prop_launch_d##D(const PropLaunch& a);
 CSSM_DECL_PROP(1) CSSM_DECL_PROP(2) CSSM_DECL_PROP(3) CSSM_DECL_PROP(4) CSSM_DECL_PROP(5) CSSM_DECL_PROP(6) CSSM_DECL_PROP(7) CSSM_DECL_PROP(8)
 CSSM_DECL_PROP(9) CSSM_DECL_PROP(10) CSSM_DECL_PROP(11) CSSM_DECL_PROP(12) CSSM_DECL_PROP(13) CSSM_DECL_PROP(14) CSSM_DECL_PROP(15) CSSM_DECL_PROP(16)
 #undef CSSM_DECL_PROP

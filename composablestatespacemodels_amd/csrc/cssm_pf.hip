@@ -204,6 +204,15 @@ static int reset_scalars(cssm_pf* pf) {
   return CSSM_OK;
 }
 
+// host-side state of a handle whose cloud has just been drawn (or replicated) into state[0]: what cssm_launch_init and
+// cssm_pf_init_from share (reset_scalars cleared the device side, Scalars::pend included)
+static void fresh_host_state(cssm_pf* pf, double t0) {
+  pf->cur = 0; pf->src = pf->state[0]; pf->src_stride = pf->stride; pf->src2 = nullptr; pf->anc_valid = false;
+  pf->t = t0; pf->step = 0; pf->initialised = true; pf->wparity = 0;
+  pf->wmode = false; pf->sums_ready = false; pf->last_optimistic = false; pf->last_grp = false;
+  pf->ess_host = (int32_t)(pf->n_global < 2147483647ull ? pf->n_global : 2147483647ull);
+}
+
 int cssm_launch_init(cssm_pf* pf, double t0) {
   HIP_TRY(hipSetDevice(pf->device));
   const int grid = grid_for(pf->n, CSSM_BLOCK, kGridCap);
@@ -212,10 +221,7 @@ int cssm_launch_init(cssm_pf* pf, double t0) {
   HIP_TRY(hipGetLastError());
   int rc = reset_scalars(pf);
   if (rc) return rc;
-  pf->cur = 0; pf->src = pf->state[0]; pf->src_stride = pf->stride; pf->anc_valid = false;
-  pf->t = t0; pf->step = 0; pf->initialised = true; pf->wparity = 0;
-  pf->wmode = false; pf->sums_ready = false;   // (reset_scalars cleared Scalars::pend)
-  pf->ess_host = (int32_t)(pf->n_global < 2147483647ull ? pf->n_global : 2147483647ull);
+  fresh_host_state(pf, t0);
   return CSSM_OK;
 }
 
@@ -254,6 +260,14 @@ static int large_geometry(const cssm_pf* pf) {
 }
 
 int cssm_launch_propagate(cssm_pf* pf, const StepRec* d_rec, double* pick_out, uint32_t pick_slot) {
+  // The observation's index travels as a kernel argument (the slim kernels use it before any load lands): every record a
+  // propagate is launched on lives in the handle's record buffer, and the HOST copy of that record -- h_recs mirrors d_recs from
+  // the moment a record is built until the launch that consumes it: every caller builds the record, enqueues its upload and
+  // launches, in that order, and never rewrites a slot with launches on it still to come -- supplies the index.  Checked before
+  // anything of the handle changes: a refused launch leaves no trace.
+  if (!pf->h_recs || d_rec < pf->d_recs || d_rec >= pf->d_recs + std::min(pf->h_recs_cap, pf->recs_cap))
+    return fail(CSSM_ESTATE, "propagate launched on a record outside the handle's record buffer");
+  const uint32_t rec_step = pf->h_recs[d_rec - pf->d_recs].step;
   // one block per sub-unit: contiguous ranges, so that (with do_sums) the block's fixed-point sums are the
   // sub-unit sums k_offspring scans
   uint64_t chunk = (uint64_t)pf->sup * CSSM_TILE / pf->split;
@@ -289,15 +303,12 @@ int cssm_launch_propagate(cssm_pf* pf, const StepRec* d_rec, double* pick_out, u
   // bit 8 of the set argument of k_propagate_self and k_offspring_self), which k_offspring then reads instead of every unit sum
   pf->last_grp = !pf->sharded && do_sums && !fine && pf->split == 1 && chunk == unit_particles && pf->first == 0 && pf->n == pf->n_global &&
                  pf->nunits >= 2u * CSSM_GRP_UNITS && pf->nunits <= (uint32_t)(CSSM_GRP_MAX * CSSM_GRP_UNITS) && unit_particles <= CSSM_GRP_MAX_UNIT && pf->opt_grp;
-  if (pf->last_grp) a.slot_set |= 0x100;
+  const bool want_grp = pf->last_grp;
+  if (want_grp) a.slot_set |= 0x100;
   a.src2 = anc ? pf->src2 : nullptr; a.src2_stride = pf->src2_stride; a.n_split = pf->n_split; a.logtab = pf->d_logtab;
   a.chunk = chunk; a.do_sums = do_sums; a.subS = fine ? pf->fineS : pf->tileS; a.subS2 = fine ? pf->fineS2 : pf->tileS2;
   a.pick_out = pick_out; a.pick_slot = pick_slot;
-  // the observation's index as a kernel argument: every record a propagate is launched on lives in the handle's record buffer,
-  // whose host copy was built (and its upload enqueued) before this launch
-  if (!pf->h_recs || d_rec < pf->d_recs || d_rec >= pf->d_recs + std::min(pf->h_recs_cap, pf->recs_cap))
-    return fail(CSSM_ESTATE, "propagate launched on a record outside the handle's record buffer");
-  a.step = pf->h_recs[d_rec - pf->d_recs].step;
+  a.step = rec_step;
   a.fsub = pf->lgcp_tdep ? pf->d_fsub : nullptr;
   a.one = (chunk == (uint64_t)CSSM_BLOCK * cssm_prop_items(pf->d)) ? 1 : (geo == GEO_LOOP ? 2 : 0);
   // sharded handle on the single-collective exchange (received rows read in place: src2_stride == 0) or before its first exchange:
@@ -305,13 +316,16 @@ int cssm_launch_propagate(cssm_pf* pf, const StepRec* d_rec, double* pick_out, u
   a.shard_slim = pf->sharded && do_sums && !a.lgcp && (a.src2 == nullptr || a.src2_stride == 0) && a.fsub == nullptr && pick_out == nullptr &&
                  ((pf->first & 1ull) == 0ull || cssm_prop_items(pf->d) == 1) && a.slot_set == 0;
   if (a.shard_slim && pf->sup * (uint32_t)CSSM_TILE / (uint32_t)(CSSM_BLOCK * cssm_prop_items(pf->d)) <= CSSM_LOOP_MAX_TILES) a.one = 2;
+  int launched = 0;   // CSSM_PROP_LAUNCHED_* of the kernel the dispatcher chose
   switch (pf->d) {
-#define CSSM_CASE_PROP(D) case D: cssm_prop_launch_d##D(a); break;
+#define CSSM_CASE_PROP(D) case D: launched = cssm_prop_launch_d##D(a); break;
     CSSM_CASE_PROP(1) CSSM_CASE_PROP(2) CSSM_CASE_PROP(3) CSSM_CASE_PROP(4) CSSM_CASE_PROP(5) CSSM_CASE_PROP(6) CSSM_CASE_PROP(7) CSSM_CASE_PROP(8)
     CSSM_CASE_PROP(9) CSSM_CASE_PROP(10) CSSM_CASE_PROP(11) CSSM_CASE_PROP(12) CSSM_CASE_PROP(13) CSSM_CASE_PROP(14) CSSM_CASE_PROP(15)
-    default: cssm_prop_launch_d16(a); break;
+    default: launched = cssm_prop_launch_d16(a); break;
 #undef CSSM_CASE_PROP
   }
+  // k_offspring reads the group sums only where the kernel that ran accumulated them (the unit sums exist either way)
+  pf->last_grp = want_grp && (launched & CSSM_PROP_LAUNCHED_GRP) != 0;
   prof_end(pf);
   if (fine) {   // the blocks' sums -> the units' (the kernel itself skips unweighted observations and series on hold)
     prof_begin(pf, CSSM_K_REDUCE);
@@ -483,8 +497,7 @@ extern "C" int cssm_pf_init_from(cssm_pf* pf, double t0, const double* state_d) 
   HIP_TRY(hipStreamSynchronize(pf->stream));
   rc = upload_init_params(pf);   // d_m0 was used as scratch
   if (rc) return rc;
-  pf->cur = 0; pf->src = pf->state[0]; pf->src_stride = pf->stride; pf->anc_valid = false;
-  pf->t = t0; pf->step = 0; pf->initialised = true; pf->wparity = 0;
+  fresh_host_state(pf, t0);
   return CSSM_OK;
 }
 
@@ -542,8 +555,11 @@ extern "C" int cssm_pf_propagate(cssm_pf* pf, double t, double obs, int has_obs)
   pf->safe_sums = false;
   if (rc) return rc;
   pf->wmode = false;
-  // nobody decodes this step's running max on the device: clear both slot sets for the next weighted step
-  HIP_TRY(hipMemsetAsync(pf->sc->maxslot, 0, sizeof(pf->sc->maxslot), pf->stream));
+  // nobody decodes this step's running max on the device: clear every set of max slots AND of group sums for the next weighted
+  // step (wparity restarts at 0 below: a native fused step that ran on set 0 before this call left its group sums there, and
+  // k_offspring's publisher clears only the two sets it does not use -- the next native step would add onto them)
+  static_assert(offsetof(Scalars, maxslot) == 0 && offsetof(Scalars, grp) == sizeof(Scalars::maxslot), "maxslot and grp are contiguous at the head of Scalars");
+  HIP_TRY(hipMemsetAsync(pf->sc, 0, offsetof(Scalars, err), pf->stream));
   Scalars h;
   HIP_TRY(hipMemcpyAsync(CSSM_SC_TAIL_ARGS(&h, pf->sc), hipMemcpyDeviceToHost, pf->stream));
   HIP_TRY(hipStreamSynchronize(pf->stream));

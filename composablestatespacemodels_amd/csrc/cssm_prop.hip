@@ -74,7 +74,7 @@ template <int D, int IT> struct OneTile {
   }
 };
 
-void CSSM_CAT(cssm_prop_launch_d, CSSM_PROP_D)(const PropLaunch& a) {
+int CSSM_CAT(cssm_prop_launch_d, CSSM_PROP_D)(const PropLaunch& a) {
   constexpr int D = CSSM_PROP_D;
   constexpr int IT = PropItems<D>::value;
 #define PROP_GO(LG, OB, SM)                                                                                               \
@@ -87,6 +87,8 @@ void CSSM_CAT(cssm_prop_launch_d, CSSM_PROP_D)(const PropLaunch& a) {
   k_propagate_self<D, IT, OB, SM><<<dim3(a.grid), dim3(CSSM_BLOCK), 0, a.stream>>>(a.src, a.src_stride, a.anc, a.dst, a.dst_stride, \
       a.logw, a.n, a.seed, a.rec, a.mk, a.sc, a.slot_set, a.logtab, a.chunk, a.subS, a.subS2, a.pick_out, a.pick_slot, a.step)
   // small clouds: one tile of the kernel per block (half a tile of 1024 for d <= 8, a quarter for d >= 9): the ONE instantiation
+  // only propagate_block with SUMS == 1 (k_propagate_self<..., 1, ...>) adds to the group sums
+  const int grp = (self && CSSM_PROP_SELF && a.sums && (a.slot_set & 0x100)) ? CSSM_PROP_LAUNCHED_GRP : 0;
   if (self && CSSM_PROP_SELF && a.sums && a.one) {
     OneTile<D, IT>::go(a);
   } else if (self && CSSM_PROP_SELF) {
@@ -125,6 +127,7 @@ void CSSM_CAT(cssm_prop_launch_d, CSSM_PROP_D)(const PropLaunch& a) {
   }
 #undef PROP_GO
 #undef PROP_SELF
+  return grp;
 }
 
 #if defined(CSSM_PROP_STAMPS)

@@ -163,6 +163,7 @@ extern "C" int cssm_pf_shard_propagate(cssm_pf* pf, double t, double obs, int ha
   int rc = shard_check(pf);
   if (rc) return rc;
   if (!pf->initialised) return fail(CSSM_ESTATE, "shard_propagate before shard_init");
+  if (pf->series) return fail(CSSM_ESTATE, "a series begun with shard_begin is stepped with shard_propagate_at");   // (before any record is touched)
   // one record slot per step, round-robin, so that an in-flight step never sees its record overwritten
   rc = cssm_ensure_recs(pf, 64);
   if (rc) return rc;
@@ -171,7 +172,6 @@ extern "C" int cssm_pf_shard_propagate(cssm_pf* pf, double t, double obs, int ha
   rc = cssm_build_fsub(pf, slot, 1, true);
   if (rc) return rc;
   HIP_TRY(hipMemcpyAsync(pf->d_recs + slot, pf->h_recs + slot, sizeof(StepRec), hipMemcpyHostToDevice, pf->stream));
-  if (pf->series) return fail(CSSM_ESTATE, "a series begun with shard_begin is stepped with shard_propagate_at");
   rc = shard_prepare_step(pf, pf->d_recs + slot, pf->h_recs[slot].has_obs, sums5_dev);
   if (rc) return rc;
   pf->t = t;

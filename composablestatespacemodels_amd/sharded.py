@@ -33,8 +33,8 @@ and the ancestor arrays are bit-identical for 1, 2, 4 and 8 ranks.
 
 The orchestration is written over a list of local shards and a communicator object so that the
 same code drives (a) one shard per process over RCCL or gloo (``DistComm``) and (b) several
-shards inside one process with the exchanges done by tensor copies (``LocalComm``: how the stage
-kernels are tested for world > 1 on a single GPU).
+shards inside one process with the exchanges done by tensor copies (``tests/local_comm.py``: how the stage
+kernels are tested for world > 1 on a single GPU; test infrastructure, not part of the package).
 """
 from __future__ import annotations
 
@@ -312,7 +312,8 @@ class DistComm:
         ok = torch.tensor([1 if lib.cssm_rccl_available() else 0], dtype=torch.int64, device=self.device)
         self.dist.all_reduce(ok, op=self.dist.ReduceOp.MIN, group=self.group)
         if int(ok.item()) == 0:
-            return None
+            raise RuntimeError("librccl.so could not be loaded by libcssm_pf on some rank; set CSSM_SHARD_NATIVE=0 to run the collectives "
+                               "through torch.distributed instead")
         ident = C.create_string_buffer(128)
         if self.rank == 0:
             _abi.check(lib.cssm_rccl_unique_id(ident))
@@ -321,12 +322,16 @@ class DistComm:
         ident = C.create_string_buffer(box[0], 128)
         h = C.c_void_p()
         rc = lib.cssm_rccl_comm_create(ident, self.world, self.rank, self.device.index, C.byref(h))
+        why = _abi.last_error() if rc != 0 else ""
         good = torch.tensor([1 if rc == 0 else 0], dtype=torch.int64, device=self.device)
         self.dist.all_reduce(good, op=self.dist.ReduceOp.MIN, group=self.group)
-        if int(good.item()) == 0:      # some rank failed: every rank falls back to the torch.distributed collectives
+        if int(good.item()) == 0:
+            # No silent change of protocol: the torch.distributed collectives cost several host-language calls per observation
+            # (a different performance regime), so they are chosen explicitly (CSSM_SHARD_NATIVE=0), never fallen back to.
             if rc == 0:
                 lib.cssm_rccl_comm_destroy(h)
-            return None
+            raise RuntimeError("libcssm_pf could not create its RCCL communicator on every rank (rank %d: %s); set CSSM_SHARD_NATIVE=0 to "
+                               "run the collectives through torch.distributed instead" % (self.rank, why or "ok here, failed on a peer"))
         self._native = h
         return h
 
@@ -339,82 +344,6 @@ class DistComm:
         if h:
             _abi.load_library().cssm_rccl_comm_destroy(h)
         self._native = None
-
-
-class LocalComm:
-    """All R shards live in this process; the "collectives" are tensor copies.  Test vehicle for the
-    stage kernels at world > 1 on a single GPU -- not a performance path."""
-
-    def __init__(self, world: int):
-        self.world, self.rank = world, 0
-
-    def all_gather(self, outs, ins):
-        cat = torch.cat([i.reshape(-1) for i in ins])
-        for o in outs:
-            o.copy_(cat)
-
-    def all_to_all_counts(self, outs, ins):
-        for q, o in enumerate(outs):
-            for r, i in enumerate(ins):
-                o[r] = i[q]
-
-    def all_to_all_v(self, outs, ins, out_splits, in_splits):
-        R = self.world
-        in_off = [np.concatenate([[0], np.cumsum(in_splits[r])]) for r in range(R)]
-        for q in range(R):
-            pos = 0
-            for r in range(R):
-                n = int(in_splits[r][q])
-                assert n == int(out_splits[q][r])
-                if n:
-                    outs[q][pos:pos + n].copy_(ins[r][int(in_off[r][q]):int(in_off[r][q]) + n])
-                pos += n
-
-    def all_to_all_equal(self, outs, ins):
-        R = self.world
-        seg = ins[0].numel() // R
-        for q in range(R):
-            for r in range(R):
-                outs[q][r * seg:(r + 1) * seg].copy_(ins[r][q * seg:(q + 1) * seg])
-
-    def all_reduce_sum(self, tensors):
-        total = tensors[0].clone()
-        for x in tensors[1:]:
-            total += x.to(total.device)
-        for x in tensors:
-            x.copy_(total)
-
-    def agree_max(self, values):
-        return max(int(v) for v in values)
-
-    def combine_rows(self, arrays):
-        out = np.zeros(arrays[0].shape, dtype=np.uint64)
-        for a in arrays:
-            out |= np.ascontiguousarray(a).view(np.uint64).reshape(out.shape)
-        return out.view(np.float64)
-
-    def barrier(self):
-        pass
-
-
-class LocalCommTrimmed(LocalComm):
-    """LocalComm whose equal-split all-to-all moves only what the trimmed all-to-all-v of the library would move (whole
-    segments between adjacent ranks, ``header_words`` doubles between every other pair and to oneself) and fills the rest
-    of every receive segment with NaN: a kernel that read anything else of a non-adjacent segment could not produce the
-    oracle's bits.  Test vehicle (tests/test_gpu_sharded.py), world >= 3."""
-
-    def __init__(self, world: int, header_words: int = 12):
-        super().__init__(world)
-        self.header_words = header_words
-
-    def all_to_all_equal(self, outs, ins):
-        R = self.world
-        seg = ins[0].numel() // R
-        for q in range(R):
-            outs[q].fill_(float("nan"))
-            for r in range(R):
-                n = seg if abs(q - r) == 1 else min(self.header_words, seg)
-                outs[q][r * seg:r * seg + n].copy_(ins[r][q * seg:q * seg + n])
 
 
 class ShardedFilter:

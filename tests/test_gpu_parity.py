@@ -755,6 +755,42 @@ def test_group_sums_match_the_oracle_at_test_sizes(name, n, whole):
         g.close()
 
 
+@pytest.mark.parametrize("native_before", [1, 2, 4])
+def test_group_sums_survive_a_host_resampled_step_in_between(native_before):
+    """cssm_pf_propagate / cssm_pf_adopt (the host `Resample[A]` seam) between native fused steps: the seam restarts the rotation
+    of max-slot / group-sum sets at 0, so it must leave every set clean -- with 1 (mod 3) native weighted steps before it, set 0
+    still held the group sums of the last native step, and the next native step added its own on top (round 3's advisor:
+    wrong S_tot and prefixes, silently).  70 units of 1024 particles, the group sums forced on; the host resampler hands back
+    the oracle's resampled cloud, ll and ess, so every later native step must equal the oracle's bit for bit."""
+    model = cases.c2_model()
+    n = 70 * 1024 + 5
+    T = native_before + 4
+    t, y, has = cases.poisson_counts(T)
+    g = NativePf(model, n, cases.SEED)
+    g.set_option(OPT_WHOLE_TILES, 1); g.set_option(OPT_GROUP_SUMS, 1)
+    o = oracle.OraclePf(model.descriptor(), n, cases.SEED)
+    g.init(0.0); o.init(0.0)
+    for s in range(T):
+        ol, oe = o.step(t[s], y[s], True)
+        if s in (native_before, native_before + 2):       # twice: the second time after two more native steps
+            g.propagate(t[s], y[s], True)
+            np.testing.assert_array_equal(g.proposed(), o.proposed())
+            np.testing.assert_array_equal(g.logw(), o.logw())
+            g.adopt(o.particles(), ol, oe)
+        else:
+            assert g.step(t[s], y[s], True) == (ol, oe), (native_before, s)
+            np.testing.assert_array_equal(g.ancestors(), o.ancestors(), err_msg=f"step {s}")
+        np.testing.assert_array_equal(g.particles(), o.particles(), err_msg=f"step {s}")
+    # ... and a continued batch leg behind the seam (cssm_pf_ll_filter_more reads the same sets)
+    t2, y2, has2 = cases.poisson_counts(T + 5)
+    gl = g.run_more(t2[T:], y2[T:], has2[T:])[0]
+    for s in range(T, T + 5):
+        ol, oe = o.step(t2[s], y2[s], bool(has2[s]))
+    assert gl == ol
+    np.testing.assert_array_equal(g.ancestors(), o.ancestors())
+    g.close()
+
+
 @pytest.mark.parametrize("n", [1 << 20, (1 << 20) + 4097, 3 << 20, (1 << 23) + 5])
 def test_group_sums_on_and_off_agree_at_full_size(n):
     """The same at the sizes where the group sums are the default (1024 units of 1024 .. 8192 particles, a ragged cloud whose last

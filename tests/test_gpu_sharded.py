@@ -26,7 +26,8 @@ def _oracle_run(model, n, t, y, has, lgcp_precision=0):
 @pytest.mark.parametrize("world", [2, 3, 4, 8])
 @pytest.mark.parametrize("name,n", [("c2_model", 6000), ("c1_model", 1000), ("c3_model", 4100)])
 def test_local_shards_match_single_rank_oracle(world, name, n):
-    from composablestatespacemodels_amd.sharded import GpuShard, LocalComm, ShardedFilter
+    from composablestatespacemodels_amd.sharded import GpuShard, ShardedFilter
+    from local_comm import LocalComm
     model = getattr(cases, name)()
     t, y, has = cases.poisson_counts(9, missing=0.2)
     shards = [GpuShard(model, n, r, world, cases.SEED, 0) for r in range(world)]
@@ -45,7 +46,8 @@ def test_local_shards_match_single_rank_oracle(world, name, n):
 def test_local_shards_degenerate_weights():
     """An informative first observation concentrates the weight on few particles: candidates for a
     rank then come from other ranks only."""
-    from composablestatespacemodels_amd.sharded import GpuShard, LocalComm, ShardedFilter
+    from composablestatespacemodels_amd.sharded import GpuShard, ShardedFilter
+    from local_comm import LocalComm
     model = cases.linear_model(obs_sd=0.001)
     n, world = 4096, 4
     t = np.array([0.0, 1.0, 2.0]); y = np.array([3.0, 3.1, 2.9]); has = np.ones(3, dtype=np.uint8)
@@ -63,7 +65,8 @@ def test_local_shards_lgcp(world, n, name):
     """LGCP series (BASELINE config 4 is the 8-GPU one): the level of every observation is the global max, so an all-gather of
     the local maxima and the sums relative to it precede the single all-to-all -- two collectives per observation, nothing
     read by the host; bit-identical to the single-rank oracle for 2, 4 and 8 shards.  Also through the exact exchange."""
-    from composablestatespacemodels_amd.sharded import GpuShard, LocalComm, ShardedFilter
+    from composablestatespacemodels_amd.sharded import GpuShard, ShardedFilter
+    from local_comm import LocalComm
     model = getattr(cases, name)()
     t, y, has = cases.event_times(7, horizon=12.0)
     shards = [GpuShard(model, n, r, world, cases.SEED, 0, lgcp_precision=2) for r in range(world)]
@@ -83,7 +86,8 @@ def test_full_size_local_shards_equal_single_gpu(world):
     """BASELINE config 2 at its full size (N = 2^20), split into 2 and 8 local shards: ll, ess and the particles equal the
     single-GPU filter of the same N bit for bit (the shard count is not allowed to show in any result)."""
     from composablestatespacemodels_amd.filter import NativePf
-    from composablestatespacemodels_amd.sharded import GpuShard, LocalComm, ShardedFilter
+    from composablestatespacemodels_amd.sharded import GpuShard, ShardedFilter
+    from local_comm import LocalComm
     model = cases.c2_model()
     n, T = 1 << 20, 24
     t, y, has = cases.poisson_counts(T)
@@ -105,7 +109,8 @@ def test_full_size_lgcp_in_its_sharded_shape_equals_single_gpu():
     is the global max (plan "max": all-gather of the maxima + all-to-all per event), and ll, ess and every particle equal the
     single-GPU handle of the same N bit for bit."""
     from composablestatespacemodels_amd.filter import NativePf
-    from composablestatespacemodels_amd.sharded import GpuShard, LocalComm, ShardedFilter
+    from composablestatespacemodels_amd.sharded import GpuShard, ShardedFilter
+    from local_comm import LocalComm
     model = cases.c4_model()
     n, world, T = 1 << 24, 8, 3
     t, y, has = cases.event_times(T)
@@ -127,7 +132,8 @@ def test_full_size_lgcp_in_its_sharded_shape_equals_single_gpu():
 def test_trimmed_exchange_lgcp_world8():
     """The same plan through the trimmed exchange (whole segments between adjacent ranks, 12 header words otherwise; the rest
     of every receive segment NaN): 8 shards, against the oracle."""
-    from composablestatespacemodels_amd.sharded import GpuShard, LocalCommTrimmed, ShardedFilter
+    from composablestatespacemodels_amd.sharded import GpuShard, ShardedFilter
+    from local_comm import LocalCommTrimmed
     model = cases.c4_model()
     n, world = 24000, 8
     t, y, has = cases.event_times(7, horizon=12.0)
@@ -148,7 +154,8 @@ def test_continued_sharded_series_equals_the_whole_series(name, prec, n, world):
     (cssm_pf_shard_continue: no new cloud, the clock and the observation count go on; Flow.scan handed the next elements,
     ParticleFilter.scala:163-166) -- with the ordinary capacity and with one row per pair (misses resumed inside the continued
     part, whose records are addressed from 0 again)."""
-    from composablestatespacemodels_amd.sharded import GpuShard, LocalComm, ShardedFilter
+    from composablestatespacemodels_amd.sharded import GpuShard, ShardedFilter
+    from local_comm import LocalComm
     model = getattr(cases, name)()
     T, a = 13, 5
     t, y, has = cases.event_times(T, horizon=12.0) if prec else cases.poisson_counts(T, missing=0.1)
@@ -175,7 +182,8 @@ def test_sharded_filter_returns_the_sampled_path(name, prec, n, world, tiny):
     PMMH (package.scala:24): ll and one uniformly picked particle of the initial cloud and of the cloud after every observation
     (Resampling.sampleOne on the GLOBAL slot index; the owning rank records it, also when the slot's ancestor is a row received
     from a neighbour, also through resumed capacity misses) equal the single-rank oracle's path bit for bit."""
-    from composablestatespacemodels_amd.sharded import GpuShard, LocalComm, ShardedFilter
+    from composablestatespacemodels_amd.sharded import GpuShard, ShardedFilter
+    from local_comm import LocalComm
     model = getattr(cases, name)()
     T = 11
     t, y, has = cases.event_times(T, horizon=12.0) if prec else cases.poisson_counts(T, missing=0.2)
@@ -207,7 +215,8 @@ def test_sharded_summary_equals_the_single_rank_summary(name, prec, n, world, in
     """ShardedFilter.summary = getIntervals (ParticleFilter.scala:415-424) of the sharded cloud: credible-interval order statistics
     of every latent component and of eta are GLOBAL ranks (one all-reduce of the byte histograms per radix pass), equal to the
     oracle's over the single-rank cloud bit for bit; the means agree to the order of summation."""
-    from composablestatespacemodels_amd.sharded import GpuShard, LocalComm, ShardedFilter
+    from composablestatespacemodels_amd.sharded import GpuShard, ShardedFilter
+    from local_comm import LocalComm
     model = getattr(cases, name)()
     T = 9
     t, y, has = cases.event_times(T, horizon=12.0) if prec else cases.poisson_counts(T, missing=0.2)
@@ -313,7 +322,8 @@ def test_rccl_world1_matches_oracle():
 @pytest.mark.parametrize("world", [2, 4])
 def test_local_shards_outlying_observation_second_attempt(world):
     """The gathered max rules the reference level out at one step: shard_sums + a second all-gather, same bits."""
-    from composablestatespacemodels_amd.sharded import GpuShard, LocalComm, ShardedFilter
+    from composablestatespacemodels_amd.sharded import GpuShard, ShardedFilter
+    from local_comm import LocalComm
     model = cases.c2_model()
     n = 5000
     t, y, has = cases.poisson_counts(8)
@@ -332,7 +342,8 @@ def test_local_shards_outlying_observation_second_attempt(world):
 @pytest.mark.parametrize("name,n,T", [("c2_model", 20000, 30), ("c3_model", 9000, 16)])
 def test_single_collective_series_matches_oracle(world, name, n, T):
     """ll_filter: the host-read-free exchange -- ONE all-to-all per observation carrying sums and boundary particles."""
-    from composablestatespacemodels_amd.sharded import GpuShard, LocalComm, ShardedFilter
+    from composablestatespacemodels_amd.sharded import GpuShard, ShardedFilter
+    from local_comm import LocalComm
     model = getattr(cases, name)()
     t, y, has = cases.poisson_counts(T, missing=0.1)
     shards = [GpuShard(model, n, r, world, cases.SEED, 0) for r in range(world)]
@@ -355,7 +366,8 @@ def _mirror_plan(model, n, world, t, y, has, lgcp=False, prec=0, min_cap=None, c
     """What the orchestration does with this series -- (attempts, resumes, single, from_max) -- found by running the SAME
     ShardedFilter over the CPU stand-in (tests/oracle_shard.py; every verdict there is a function of the same bits): the GPU
     run must take exactly that path, not merely arrive at the right numbers by some path."""
-    from composablestatespacemodels_amd.sharded import LocalComm, ShardedFilter
+    from composablestatespacemodels_amd.sharded import ShardedFilter
+    from local_comm import LocalComm
     from oracle_shard import OracleShard
     shards = [OracleShard(model, n, r, world, cases.SEED, prec) for r in range(world)]
     f = ShardedFilter(shards, LocalComm(world))
@@ -372,7 +384,8 @@ def test_series_resumes_a_capacity_miss_and_repeats_after_an_outlying_observatio
     outlier+capacity: both -- the repetition (plan "max": all-gather + shard_sums before the all-to-all) ALSO misses its
     capacity and is resumed: the level, the unit sums and the exported words of the observation the series holds at must
     survive the observations enqueued behind it (round 2 lost them: NaN levels for LGCP, a spurious third attempt here)."""
-    from composablestatespacemodels_amd.sharded import GpuShard, LocalComm, ShardedFilter
+    from composablestatespacemodels_amd.sharded import GpuShard, ShardedFilter
+    from local_comm import LocalComm
     model = cases.c2_model()
     # (a count of 60 also concentrates the weight on very few particles: at world 2 every rank is adjacent to the other, so
     #  boundary blocks -- whole shards if need be -- always cover; at world 4 such a step ends on the exact exchange)
@@ -405,7 +418,8 @@ def test_series_resumes_a_capacity_miss_and_repeats_after_an_outlying_observatio
 def test_lgcp_series_resumes_a_capacity_miss(world, n):
     """An LGCP series runs on the "max" plan from the start (its level IS the max).  With one row per pair its exchanges
     miss and are resumed in place: ONE attempt, at least one resume, the oracle's bits."""
-    from composablestatespacemodels_amd.sharded import GpuShard, LocalComm, ShardedFilter
+    from composablestatespacemodels_amd.sharded import GpuShard, ShardedFilter
+    from local_comm import LocalComm
     model = cases.c4_model()
     t, y, has = cases.event_times(8, horizon=12.0)
     shards = [GpuShard(model, n, r, world, cases.SEED, 0, lgcp_precision=2) for r in range(world)]
@@ -429,7 +443,8 @@ def test_local_shards_every_staging_layout_with_remote_candidates(world, d, n, T
     fetches); in the sharded filter part of the gathered states are candidates received from other ranks (second
     source, rows of d + 1 doubles in the single-collective series).  Odd shard starts also exercise the unpaired
     normal streams.  Both exchanges against the oracle."""
-    from composablestatespacemodels_amd.sharded import GpuShard, LocalComm, ShardedFilter
+    from composablestatespacemodels_amd.sharded import GpuShard, ShardedFilter
+    from local_comm import LocalComm
     model = cases.dim_model(d)
     t, y, has = cases.poisson_counts(T, missing=0.15)
     shards = [GpuShard(model, n, r, world, cases.SEED, 0) for r in range(world)]
@@ -447,7 +462,8 @@ def test_local_shards_every_staging_layout_with_remote_candidates(world, d, n, T
 def test_single_collective_with_boundary_blocks_of_several_tiles(n, world):
     """Capacity of several tiles per boundary block: the prefix of the tiles before a block's own comes from
     k_propagate's sub-unit sums when the block is tile-aligned, else it is recomputed -- same bits either way."""
-    from composablestatespacemodels_amd.sharded import GpuShard, LocalComm, ShardedFilter
+    from composablestatespacemodels_amd.sharded import GpuShard, ShardedFilter
+    from local_comm import LocalComm
     model = cases.c2_model()
     t, y, has = cases.poisson_counts(14, missing=0.1)
     shards = [GpuShard(model, n, r, world, cases.SEED, 0) for r in range(world)]
@@ -469,7 +485,8 @@ def test_trimmed_exchange_reads_only_headers_of_non_adjacent_segments(world, nam
     words between every other pair.  LocalCommTrimmed moves exactly that and fills the rest of every receive segment
     with NaN: if k_offspring_expand_spec (or the next k_propagate) read anything else, the oracle's bits could not
     come out."""
-    from composablestatespacemodels_amd.sharded import GpuShard, LocalCommTrimmed, ShardedFilter
+    from composablestatespacemodels_amd.sharded import GpuShard, ShardedFilter
+    from local_comm import LocalCommTrimmed
     model = getattr(cases, name)()
     t, y, has = cases.poisson_counts(T, missing=0.1)
     shards = [GpuShard(model, n, r, world, cases.SEED, 0) for r in range(world)]

@@ -98,7 +98,8 @@ def test_sharded_orchestration_over_gloo_matches_single_rank(tmp_path, world, na
 
 def test_local_comm_matches_single_rank_on_cpu():
     """The single-process multi-shard emulation (LocalComm) used by the GPU tests, here with the oracle backend."""
-    from composablestatespacemodels_amd.sharded import LocalComm, ShardedFilter
+    from composablestatespacemodels_amd.sharded import ShardedFilter
+    from local_comm import LocalComm
     from oracle_shard import OracleShard
     model = cases.c2_model()
     n, world = 257, 4
@@ -168,7 +169,8 @@ def test_bench_launcher_reports_a_failing_rank():
 def test_continued_sharded_series_equals_the_whole_series_on_cpu():
     """ll_filter(t[:a]) + ll_filter_more(t[a:]) = ll_filter(t): the sharded cssm_pf_ll_filter_more, here through the CPU stand-in
     (LocalComm; capacity misses resumed inside the continued part) -- tests/test_gpu_sharded.py runs the same on the GPU."""
-    from composablestatespacemodels_amd.sharded import LocalComm, ShardedFilter
+    from composablestatespacemodels_amd.sharded import ShardedFilter
+    from local_comm import LocalComm
     from oracle_shard import OracleShard
     model = cases.c2_model()
     n, world, T, a = 300, 3, 12, 5
@@ -190,7 +192,8 @@ def test_continued_sharded_series_equals_the_whole_series_on_cpu():
 def test_sharded_filter_returns_the_sampled_path_on_cpu():
     """ShardedFilter.filter = `filter` of ParticleFilter.scala:152-158 over shards: ll and the path of uniformly picked particles
     (row 0: of the initial cloud; the rank that owns the picked global slot records it) equal the single-rank oracle's."""
-    from composablestatespacemodels_amd.sharded import LocalComm, ShardedFilter
+    from composablestatespacemodels_amd.sharded import ShardedFilter
+    from local_comm import LocalComm
     from oracle_shard import OracleShard
     model = cases.c2_model()
     n, world, T = 300, 3, 9

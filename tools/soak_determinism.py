@@ -7,7 +7,9 @@ sys.path.insert(0, R); sys.path.insert(0, os.path.join(R, "tests"))
 import numpy as np
 import cases
 from composablestatespacemodels_amd.filter import NativePf
-from composablestatespacemodels_amd.sharded import GpuShard, LocalComm, ShardedFilter
+from composablestatespacemodels_amd.sharded import GpuShard, ShardedFilter
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests"))
+from local_comm import LocalComm
 
 def digest(*arrs):
     h = hashlib.sha256()
