@@ -354,7 +354,7 @@ def run_multi(args, emit=print):
             "scaling": "strong" if lgcp else "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": workload_text(args.model, n_global, K, per_gpu, world) +
                                    " (global systematic resampling: one all-to-all per observation carrying every rank's sum words and, between "
-                                   "adjacent ranks, its boundary particles" + ("; LGCP: preceded by an all-gather of the ranks' maxima" if lgcp else "") + ")",
+                                   "adjacent ranks, its boundary particles" + ("; LGCP: every event's level predicted from the max of the event before (numerics contract v8)" if lgcp else "") + ")",
                        "particles_per_gpu": per_gpu, "particles_total": n_global, "observations": K, "latent_dim": shard.d, "seed": 20260101},
             "repeats": R, "value_is": "median over `repeats` timed legs of K steps each (max over ranks per leg), continuing the sharded filter the warm-up "
                                       "steps started (cssm_pf_shard_continue)", "wall_ms_each": [x * 1e3 for x in walls],

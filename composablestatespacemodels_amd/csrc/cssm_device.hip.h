@@ -70,6 +70,8 @@ struct Scalars {
   uint32_t pad_;
   double gmax;               // decoded global max of this step
   double ref;                // level the weights of this step were rescaled by (cssm_ref_choose)
+  double next_ref;           // LGCP (StepRec::predict): the level predicted for the NEXT weighted observation, cssm_ref_predict(gmax) -- NaN
+                             // while no weighted observation has run since the cloud was drawn / handed back by a host resampler
   double ll;                 // accumulated log-likelihood
   cssm_u128 S_local, S2_local; // local fixed-point sums (this rank)
   cssm_u128 S_off;           // sum of the ranks before this one
@@ -470,6 +472,17 @@ __host__ __device__ __forceinline__ int32_t cssm_ess_of(cssm_u128 S, cssm_u128 S
   const double e = 1.0 / (tot2 / (tot * tot));
   const double fl = (double)(long long)e;   // e >= 1 here; floor == trunc
   return (e < 2147483647.0) ? (int32_t)fl : 2147483647;
+}
+// The kernel that publishes a weighted observation's scalars also hands the NEXT weighted observation its level where that is
+// predicted from this one's max (LGCP, contract v8): into the record behind this one -- the records of a call are consecutive,
+// and the buffer holds one spare record behind the last -- and into Scalars::next_ref, from where the host chains the first
+// record of the next call (k_chain_level).  One thread calls it.
+__device__ __forceinline__ void publish_next_level(Scalars* __restrict__ sc, const StepRec* __restrict__ rec, double gmax_dec) {
+  if (rec->predict) {
+    const double c = cssm_ref_predict(gmax_dec);
+    sc->next_ref = c;
+    const_cast<StepRec*>(rec + 1)->ref = c;
+  }
 }
 // ll += level + log(mean(w1)) (:127, :522-524) from sc->S_tot; false (and err bit 1) when no weight is left
 __device__ __forceinline__ bool finish_ll(Scalars* sc, uint64_t n_global) {

@@ -36,6 +36,8 @@ struct cssm_pf : HostModel {
                                   // reference level was ruled out by the max; always for LGCP)
   bool last_optimistic = false;   // the last launch_propagate formed the sums itself (and stored weights in place of log-weights)
   bool wmode = false;             // the log-weight buffer holds the WEIGHTS exp(min(w - c, 2^-20)) of the last weighted observation
+  bool have_level = false;        // LGCP (contract v8): a weighted observation has run natively since the cloud was drawn / adopted -- its
+                                  //   publisher left the next observation's predicted level (Scalars::next_ref), so the propagate may form the sums
   bool sums_ready = false;        // sharded: the unit sums of the last propagated observation exist (k_propagate<SUMS> or cssm_pf_shard_sums)
   // ESS pending (Scalars::pend): k_offspring's blocks leave partial sums of squared weights in s2buf[par * s2_stride + block]
   cssm_u128* s2buf = nullptr;     // 2 x s2_stride entries
@@ -101,7 +103,7 @@ struct cssm_pf : HostModel {
   bool want_path = false;      // sharded `filter`: record sampleOne's pick after every observation whose slot this rank owns
   uint32_t rec_base = 0;       // observation index (pf->step) of the resident series' first record: 0 after _begin, the filter's
                                //   observation count so far after _continue
-  struct Snap { int cur; const double* src; size_t src_stride; const double* src2; size_t src2_stride; uint32_t n_split; bool anc_valid, last_optimistic; uint32_t step; double t; };
+  struct Snap { int cur; const double* src; size_t src_stride; const double* src2; size_t src2_stride; uint32_t n_split; bool anc_valid, last_optimistic; uint32_t step; double t; bool have_level; };
   std::vector<Snap> snaps;     // host-side state right after the propagate of every observation of the series (cssm_pf_shard_resume)
   // host staging (pinned)
   StepRec* h_recs = nullptr;
@@ -182,6 +184,7 @@ static const int kGridCap = 4096;
 // ---- defined in cssm_pf.hip, used by cssm_shard.hip as well
 int cssm_build_fsub(cssm_pf* pf, size_t first, size_t count, bool reset);   // sub-step table of records [first, +count) -> device
 int cssm_ensure_recs(cssm_pf* pf, size_t T);
+int cssm_upload_recs(cssm_pf* pf, size_t first, size_t count, bool chain);   // records -> device (+ the predicted level of the first one: LGCP)
 int cssm_launch_init(cssm_pf* pf, double t0);
 int cssm_launch_propagate(cssm_pf* pf, const StepRec* d_rec, double* pick_out = nullptr, uint32_t pick_slot = 0);
 int cssm_check_device_err(cssm_pf* pf, const Scalars& h);

@@ -405,6 +405,7 @@ __device__ __forceinline__ void offspring_body(const double* __restrict__ logw, 
         sc->gmax = gmax_dec; sc->ref = gmax;
         sc->S_off = S_off; sc->S_tot = tot; sc->S2_tot = tot2;
         finish_step(sc, n_global);
+        publish_next_level(sc, rec, gmax_dec);
       }
     } else {
       totd = cssm_u128_to_double(sc->S_tot);
@@ -573,6 +574,7 @@ __device__ __forceinline__ void offspring_body(const double* __restrict__ logw, 
           if (ess_t && sc->pend_gen == gen) ess_t[sc->pend_idx] = pe;
         }
         sc->gmax = gmax_dec; sc->ref = gmax; sc->S_off = cssm_u128_zero(); sc->S_local = tot; sc->S_tot = tot;
+        publish_next_level(sc, rec, gmax_dec);
         if (s2_par < 0) {
           sc->S2_local = tot2; sc->S2_tot = tot2; sc->pend = 0u;
           finish_step(sc, n_global);
@@ -938,6 +940,10 @@ static __global__ __launch_bounds__(CSSM_BLOCK) void k_finish(Scalars* __restric
     if (threadIdx.x == 0) __hip_atomic_store(host_done, done_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
   }
 }
+
+// The first record of a call that CONTINUES a filter whose levels are predicted (LGCP): its level is what the last weighted
+// observation before the call published (Scalars::next_ref) -- on the stream, the host never learns it.
+static __global__ void k_chain_level(StepRec* __restrict__ rec, const Scalars* __restrict__ sc) { rec->ref = sc->next_ref; }
 
 // per-step record of results for the batch drivers
 static __global__ void k_record(const Scalars* __restrict__ sc, double* __restrict__ ll_t, int32_t* __restrict__ ess_t, uint32_t s) {

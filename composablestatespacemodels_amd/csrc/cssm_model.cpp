@@ -28,7 +28,7 @@ int cssm_fail(int code, const char* fmt, ...) {
 #define fail cssm_fail
 
 extern "C" const char* cssm_last_error(void) { return g_err.c_str(); }
-extern "C" const char* cssm_version(void) { return "cssm_pf 0.5 (gfx950, numerics contract v7)"; }
+extern "C" const char* cssm_version(void) { return "cssm_pf 0.5 (gfx950, numerics contract v8)"; }
 
 // ------------------------------------------------------------------------------------ model
 
@@ -212,7 +212,9 @@ void cssm_build_rec(const HostModel* pf, double t_prev, double t, double y, int 
     default: break;                                            // Bernoulli, LGCP: no constants
   }
   // reference level of the step's weights (include/cssm_numerics.h); NaN = rescale by the max
+  // (LGCP: predicted on the device from the previous weighted observation's max -- StepRec::predict; NaN until it is)
   r->ref = (pf->obs_kind == CSSM_OBS_LGCP) ? cssm_nan() : cssm_ref_level(pf->obs_kind, y, pf->scale_sd, (double)pf->obs_df);
+  r->predict = (pf->obs_kind == CSSM_OBS_LGCP) ? 1u : 0u;
   const cssm_u32x4 bu = cssm_philox_draw(pf->seed, 0, step, CSSM_STREAM_U, 0);
   r->u = cssm_u01(bu.v[0], bu.v[1]);
   const int32_t pr = (int32_t)cssm_philox_draw(pf->seed, 0, step + 1, CSSM_STREAM_PICK, 0).v[0];

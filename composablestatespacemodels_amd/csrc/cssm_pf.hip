@@ -199,6 +199,7 @@ static int reset_scalars(cssm_pf* pf) {
   memset(&h, 0, sizeof h);
   h.ess = (int32_t)(pf->n_global < 2147483647ull ? pf->n_global : 2147483647ull);
   h.fail_step = 0xffffffffu;
+  h.next_ref = cssm_nan();      // (LGCP: no weighted observation yet whose max could predict a level)
   // pageable source: the copy is staged before the call returns, so a stack object is safe
   HIP_TRY(hipMemcpyAsync(pf->sc, &h, sizeof h, hipMemcpyHostToDevice, pf->stream));
   return CSSM_OK;
@@ -209,7 +210,7 @@ static int reset_scalars(cssm_pf* pf) {
 static void fresh_host_state(cssm_pf* pf, double t0) {
   pf->cur = 0; pf->src = pf->state[0]; pf->src_stride = pf->stride; pf->src2 = nullptr; pf->anc_valid = false;
   pf->t = t0; pf->step = 0; pf->initialised = true; pf->wparity = 0;
-  pf->wmode = false; pf->sums_ready = false; pf->last_optimistic = false; pf->last_grp = false;
+  pf->wmode = false; pf->sums_ready = false; pf->last_optimistic = false; pf->last_grp = false; pf->have_level = false;
   pf->ess_host = (int32_t)(pf->n_global < 2147483647ull ? pf->n_global : 2147483647ull);
 }
 
@@ -228,8 +229,26 @@ int cssm_launch_init(cssm_pf* pf, double t0) {
 // propagate + weight of one datum (record already on the device)
 
 // whether launch_propagate will use the kernels that also form the sums (and can record sampleOne's pick on the way)
+// (LGCP, contract v8: once a weighted observation has run natively its max predicts the next one's level -- Scalars::next_ref --
+//  and the sums are formed inside the propagate like everybody else's; the first observation's level is its max)
 static bool uses_sums_kernel(const cssm_pf* pf) {
-  return pf->opt_fused && !pf->safe_sums && pf->obs_kind != CSSM_OBS_LGCP && pf->resampler != CSSM_RESAMPLE_MULTINOMIAL;
+  return pf->opt_fused && !pf->safe_sums && (pf->obs_kind != CSSM_OBS_LGCP || pf->have_level) && pf->resampler != CSSM_RESAMPLE_MULTINOMIAL;
+}
+// ... ever, in the series that is being enqueued (whether an observation can put it on hold)
+static bool may_use_sums_kernel(const cssm_pf* pf) {
+  return pf->opt_fused && !pf->safe_sums && pf->resampler != CSSM_RESAMPLE_MULTINOMIAL;
+}
+
+// Records [first, first + count) of the handle's host buffer -> the device.  chain (the records CONTINUE a running filter): where
+// the level is predicted from the observation before (LGCP: StepRec::predict) the first record's comes from Scalars::next_ref,
+// on the stream; later records of the call get theirs from the kernels that publish their predecessors (publish_next_level).
+int cssm_upload_recs(cssm_pf* pf, size_t first, size_t count, bool chain) {
+  HIP_TRY(hipMemcpyAsync(pf->d_recs + first, pf->h_recs + first, count * sizeof(StepRec), hipMemcpyHostToDevice, pf->stream));
+  if (chain && pf->obs_kind == CSSM_OBS_LGCP) {
+    hipLaunchKernelGGL(k_chain_level, dim3(1), dim3(1), 0, pf->stream, pf->d_recs + first, (const Scalars*)pf->sc);
+    HIP_TRY(hipGetLastError());
+  }
+  return CSSM_OK;
 }
 
 // Launch geometry of the sums kernels on clouds of 2^20 particles and more (one GPU; whole units of 1024 * sup particles).
@@ -381,6 +400,7 @@ static int launch_resample(cssm_pf* pf, const StepRec* d_rec, double* ll_t = nul
   HIP_TRY(hipGetLastError());
   pf->anc_valid = true;
   pf->wmode = optimistic;
+  pf->have_level = true;        // (the publisher of this launch leaves the next observation's predicted level: LGCP)
   if (optimistic) pf->s2_par ^= 1;
   return CSSM_OK;
 }
@@ -466,7 +486,7 @@ int cssm_ensure_recs(cssm_pf* pf, size_t T) {
     if (pf->h_ll_t) (void)hipHostFree(pf->h_ll_t);
     if (pf->h_ess_t) (void)hipHostFree(pf->h_ess_t);
     pf->d_recs = nullptr; pf->d_ll_t = nullptr; pf->d_ess_t = nullptr; pf->h_ll_t = pf->hd_ll_t = nullptr; pf->h_ess_t = pf->hd_ess_t = nullptr;
-    HIP_TRY(hipMalloc(&pf->d_recs, T * sizeof(StepRec)));
+    HIP_TRY(hipMalloc(&pf->d_recs, (T + 1) * sizeof(StepRec)));   // (+ 1: publish_next_level writes the level of the record BEHIND the one it publishes)
     HIP_TRY(hipMalloc(&pf->d_ll_t, T * 8));
     HIP_TRY(hipMalloc(&pf->d_ess_t, T * 4));
     HIP_TRY(hipHostMalloc((void**)&pf->h_ll_t, T * 8, hipHostMallocMapped));
@@ -511,7 +531,8 @@ extern "C" int cssm_pf_step(cssm_pf* pf, double t, double obs, int has_obs, doub
   cssm_build_rec(pf, pf->t, t, obs, has_obs, pf->step, &pf->h_recs[0]);
   rc = cssm_build_fsub(pf, 0, 1, true);
   if (rc) return rc;
-  HIP_TRY(hipMemcpyAsync(pf->d_recs, pf->h_recs, sizeof(StepRec), hipMemcpyHostToDevice, pf->stream));
+  rc = cssm_upload_recs(pf, 0, 1, true);
+  if (rc) return rc;
   const int weighted = pf->h_recs[0].has_obs;
   const PreState before = pre_state(pf);
   pf->gen++;
@@ -549,7 +570,8 @@ extern "C" int cssm_pf_propagate(cssm_pf* pf, double t, double obs, int has_obs)
   cssm_build_rec(pf, pf->t, t, obs, has_obs, pf->step, &pf->h_recs[0]);
   rc = cssm_build_fsub(pf, 0, 1, true);
   if (rc) return rc;
-  HIP_TRY(hipMemcpyAsync(pf->d_recs, pf->h_recs, sizeof(StepRec), hipMemcpyHostToDevice, pf->stream));
+  rc = cssm_upload_recs(pf, 0, 1, false);   // (the level of this observation is the host's business)
+  if (rc) return rc;
   pf->safe_sums = true;        // the host resampler wants the log-weights themselves (:123): the kernel that stores them
   rc = cssm_launch_propagate(pf, pf->d_recs);
   pf->safe_sums = false;
@@ -560,6 +582,10 @@ extern "C" int cssm_pf_propagate(cssm_pf* pf, double t, double obs, int has_obs)
   // k_offspring's publisher clears only the two sets it does not use -- the next native step would add onto them)
   static_assert(offsetof(Scalars, maxslot) == 0 && offsetof(Scalars, grp) == sizeof(Scalars::maxslot), "maxslot and grp are contiguous at the head of Scalars");
   HIP_TRY(hipMemsetAsync(pf->sc, 0, offsetof(Scalars, err), pf->stream));
+  // ... and no kernel publishes this observation's max: the next native observation's level cannot be predicted from it (LGCP)
+  static const double kNoLevel = cssm_nan();
+  HIP_TRY(hipMemcpyAsync(&pf->sc->next_ref, &kNoLevel, sizeof(double), hipMemcpyHostToDevice, pf->stream));
+  pf->have_level = false;
   Scalars h;
   HIP_TRY(hipMemcpyAsync(CSSM_SC_TAIL_ARGS(&h, pf->sc), hipMemcpyDeviceToHost, pf->stream));
   HIP_TRY(hipStreamSynchronize(pf->stream));
@@ -630,7 +656,8 @@ static int run_filter_once(cssm_pf* pf, const double* t, const double* y, const 
   rc = cssm_build_fsub(pf, 0, T, true);
   if (rc) return rc;
   ph_rec = since(tp0);
-  HIP_TRY(hipMemcpyAsync(pf->d_recs, pf->h_recs, T * sizeof(StepRec), hipMemcpyHostToDevice, pf->stream));
+  rc = cssm_upload_recs(pf, 0, T, cont);
+  if (rc) return rc;
   ph_up = since(tp0);
   if (!cont) {
     rc = cssm_launch_init(pf, t0);
@@ -658,17 +685,19 @@ static int run_filter_once(cssm_pf* pf, const double* t, const double* y, const 
   // path entry s + 1 = the resampled state sampleOne picks after observation s.  With the kernels that also form the
   // sums (small handles: the PMMH case) the k_propagate of observation s + 1, which gathers exactly that state into the
   // thread of slot pick_s, records it on the way; otherwise a one-block launch per observation does.
-  const bool fold = path && uses_sums_kernel(pf);
+  // (whether an observation's propagate is such a kernel is decided observation by observation: an LGCP series starts with one
+  //  whose level is its max -- `folded` = the propagate of the NEXT observation will record the pick after the current one)
+  bool folded = false;
   // Per-observation kernels, enqueued without a host round trip.  With the sums formed inside k_propagate (relative to each
   // observation's reference level), an observation whose max rules its level out puts the series ON HOLD at that
   // observation (err bit 6: every kernel behind it returns at once); the host then redoes that one observation (its
   // propagate again, storing log-weights; sums relative to the max: k_tile_sums + k_offspring) and enqueues the rest again.
   size_t s_from = 0;
   for (;;) {
-    const bool may_hold = uses_sums_kernel(pf);
+    const bool may_hold = may_use_sums_kernel(pf);
     for (size_t s = s_from; s < T; ++s) {
       const int weighted = pf->h_recs[s].has_obs;
-      double* pick_out = (fold && s >= 1) ? pf->d_path + s * (size_t)d : nullptr;
+      double* pick_out = (folded && s >= 1) ? pf->d_path + s * (size_t)d : nullptr;
       const uint32_t pick_slot = s >= 1 ? pf->h_recs[s - 1].pick : 0u;
       pf->h_step_for_resample = base + (uint32_t)s;
       rc = cssm_launch_propagate(pf, pf->d_recs + s, pick_out, pick_slot);
@@ -677,7 +706,8 @@ static int run_filter_once(cssm_pf* pf, const double* t, const double* y, const 
         else hipLaunchKernelGGL(k_record, dim3(1), dim3(1), 0, pf->stream, pf->sc, pf->d_ll_t, pf->d_ess_t, (uint32_t)s);
       }
       if (rc) return rc;
-      if (path && (!fold || s + 1 == T))   // (folded: only the last entry has no following propagate)
+      folded = path && s + 1 < T && uses_sums_kernel(pf);   // (the last entry has no following propagate)
+      if (path && !folded)
         hipLaunchKernelGGL(k_pick, dim3(1), dim3(64), 0, pf->stream, pf->src, pf->src_stride,
                            (const uint32_t*)(pf->anc_valid ? pf->anc : nullptr), (uint64_t)pf->h_recs[s].pick, d,
                            pf->d_path + (s + 1) * (size_t)d);
@@ -708,7 +738,8 @@ static int run_filter_once(cssm_pf* pf, const double* t, const double* y, const 
     pf->h_step_for_resample = base + (uint32_t)sf;
     rc = redo_observation(pf, before, pf->d_recs + sf, pf->d_ll_t, pf->d_ess_t, (uint32_t)sf);
     if (rc) return rc;
-    if (path && (!fold || sf + 1 == T))
+    folded = path && sf + 1 < T && uses_sums_kernel(pf);
+    if (path && !folded)
       hipLaunchKernelGGL(k_pick, dim3(1), dim3(64), 0, pf->stream, pf->src, pf->src_stride, (const uint32_t*)pf->anc,
                          (uint64_t)pf->h_recs[sf].pick, d, pf->d_path + (sf + 1) * (size_t)d);
     s_from = sf + 1;             // (s_from == T: the loop only reads the results again)
@@ -1083,7 +1114,7 @@ extern "C" int cssm_pf_interpolate(cssm_pf* pf, const double* t, const double* y
   for (size_t s = 0; s < T; ++s) { cssm_build_rec(pf, tp, t[s], y[s], has ? has[s] : 1, (uint32_t)s, &pf->h_recs[s]); tp = t[s]; }
   rc = cssm_build_fsub(pf, 0, T, true);
   if (rc) return rc;
-  rc = (hipMemcpyAsync(pf->d_recs, pf->h_recs, T * sizeof(StepRec), hipMemcpyHostToDevice, pf->stream) == hipSuccess) ? CSSM_OK : fail(CSSM_EHIP, "record upload");
+  rc = cssm_upload_recs(pf, 0, T, false);
   Scalars h;
   for (int attempt = 0; attempt < 2 && !rc; ++attempt) {   // second attempt: see run_filter
     pf->safe_sums = (attempt == 1);

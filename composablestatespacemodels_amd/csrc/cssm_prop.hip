@@ -112,12 +112,19 @@ int CSSM_CAT(cssm_prop_launch_d, CSSM_PROP_D)(const PropLaunch& a) {
   } else if (a.lgcp) {
     // the log-Gaussian Cox process on one OU component (configs[3]): its structure at compile time (the sub-step loop branches
     // on it once per sub-step and particle)
-    if (D == 1 && a.mk.comp[0] == 0x36u)
-      k_propagate<D, true, IT, -1, 0, (D == 1 ? 0x36u : 0u)><<<dim3(a.grid), dim3(CSSM_BLOCK), 0, a.stream>>>(
-          a.src, a.src_stride, a.anc, a.dst, a.dst_stride, a.logw, a.n, a.gid0, a.seed, a.rec, a.mk, a.sc, a.slot_set & 0xff, a.src2,
-          a.src2_stride, a.n_split, a.logtab, a.chunk, a.do_sums, a.subS, a.subS2, a.pick_out, a.pick_slot, a.fsub);
-    else
-    PROP_GO(true, -1, 0);
+    // SM: 0 = log-weights stored (the level is the max: the first event of a series, a redone one, the multinomial resampler);
+    // 1 / 2 = the sums formed relative to the PREDICTED level (contract v8) and the weights stored -- one GPU / a shard (both sums)
+#define PROP_LGCP(SM)                                                                                                          \
+    do {                                                                                                                       \
+      if (D == 1 && a.mk.comp[0] == 0x36u)                                                                                     \
+        k_propagate<D, true, IT, -1, SM, (D == 1 ? 0x36u : 0u)><<<dim3(a.grid), dim3(CSSM_BLOCK), 0, a.stream>>>(              \
+            a.src, a.src_stride, a.anc, a.dst, a.dst_stride, a.logw, a.n, a.gid0, a.seed, a.rec, a.mk, a.sc, a.slot_set & 0xff, a.src2, \
+            a.src2_stride, a.n_split, a.logtab, a.chunk, a.do_sums, a.subS, a.subS2, a.pick_out, a.pick_slot, a.fsub);         \
+      else                                                                                                                     \
+        PROP_GO(true, -1, SM);                                                                                                 \
+    } while (0)
+    if (!a.sums) PROP_LGCP(0); else if (a.sharded) PROP_LGCP(2); else PROP_LGCP(1);
+#undef PROP_LGCP
   } else if (a.obs == CSSM_OBS_POISSON) {   // (the generic kernel with sums serves sharded handles only: both sums, SUMS = 2)
     if (a.sums) PROP_GO(false, CSSM_OBS_POISSON, 2); else PROP_GO(false, CSSM_OBS_POISSON, 0);
   } else if (a.obs == CSSM_OBS_GAUSSIAN) {

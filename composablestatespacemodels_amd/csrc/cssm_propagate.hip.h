@@ -63,8 +63,8 @@ struct PropAcc {
 
 // The body of every k_propagate launch: the block's particles [range_lo, n) of one observation.
 // SUMS: what the kernel does with a weighted particle's log-weight w --
-//   0  stores w (LGCP, whose level is the max; the multinomial resampler; an observation that is redone: the sums are then
-//      a pass of their own, k_tile_sums);
+//   0  stores w (the multinomial resampler; an observation that is redone; the first event of an LGCP series, whose level is its
+//      max: the sums are then a pass of their own, k_tile_sums);
 //   1  forms w1 = exp(min(w - c, 2^-20)) relative to the observation's reference level c, adds it to the block's fixed-point
 //      sum S and stores W1 IN PLACE OF w (same 8 bytes): k_offspring then needs no exp, only the conversion the sum was
 //      formed with.  Sum of squares: k_offspring's business (nothing on the device depends on the ESS).  Single GPU;
@@ -108,7 +108,7 @@ __device__ __forceinline__ void propagate_range(
   // every thread's first particle has an even global id (gid0 even; chunk, tile and IT even): whole pairs per thread
   const bool pair_ok = (gid0 & 1ull) == 0ull;
   // SUMS (compile time: its accumulators would otherwise hold 8 VGPRs in every kernel): the block also forms the sums
-  const bool do_sums = SUMS && !LGCP && do_sums_arg && has_obs;   // (do_sums_arg is 1 for every SUMS instantiation)
+  const bool do_sums = SUMS && do_sums_arg && weighted;   // (do_sums_arg is 1 for every SUMS instantiation; LGCP: the level is predicted, contract v8)
   const double cref = rec->ref;
   cssm_u128 accS = cssm_u128_zero(), accS2 = cssm_u128_zero();
   double tmax = -cssm_inf();
@@ -278,7 +278,7 @@ __device__ __forceinline__ void propagate_range(
       if (weighted && i0 + r < n) {
         if (lw[r] != lw[r]) { bad = true; lw[r] = -cssm_inf(); }
         tmax = (lw[r] > tmax) ? lw[r] : tmax;
-        if (SUMS && !LGCP && do_sums) {
+        if (SUMS && do_sums) {
           // beyond c + CSSM_REF_BELOW the step is redone with the max anyway: keep the conversion in range
           // (a <= 2^-20 and never NaN: the cheaper forms of exp and of the fixed-point conversion return the same values)
           const double a = cssm_min_c(lw[r] - cref, CSSM_REF_BELOW);
@@ -468,7 +468,7 @@ __global__ __launch_bounds__(CSSM_BLOCK, (PropWaves<D, SUMS>::value)) void k_pro
   propagate_range<D, LGCP, IT, OBS, SUMS>(src, src_stride, anc, dst, dst_stride, logw, gid0, seed, rec, mk, src2, src2_stride,
                                           n_split, tab, range_lo, n, do_sums_arg, pick_out, pick_slot, s_stage, acc, LGCP ? fsub : nullptr);
   const bool weighted = LGCP || rec->has_obs;
-  const bool do_sums = SUMS && !LGCP && do_sums_arg && rec->has_obs;
+  const bool do_sums = SUMS && do_sums_arg && weighted;
   cssm_u128 accS = acc.S, accS2 = acc.S2;
   double tmax = acc.tmax;
   const bool bad = acc.bad;
@@ -476,7 +476,7 @@ __global__ __launch_bounds__(CSSM_BLOCK, (PropWaves<D, SUMS>::value)) void k_pro
   tmax = wave_max(tmax);
   if ((threadIdx.x & 63) == 0) s_max[threadIdx.x >> 6] = tmax;
   if (__any(bad) && (threadIdx.x & 63) == 0) atomicOr(&sc->err, 1u);
-  if (SUMS && !LGCP && do_sums) {
+  if (SUMS && do_sums) {
     __shared__ cssm_u128 s_sa[CSSM_BLOCK / 64], s_sb[CSSM_BLOCK / 64];
     accS = wave_sum_u128(accS);
     if (SUMS == 2) accS2 = wave_sum_u128(accS2);

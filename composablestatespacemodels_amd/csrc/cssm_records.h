@@ -53,7 +53,11 @@ struct StepRec {
   double fco[CSSM_MAX_DIM];     // f coefficients c_k(t)
   double t_obs;                 // the observation's time (LGCP with a time-dependent f: the sub-step clock starts here)
   uint32_t fsub_off;            // LGCP with a time-dependent f: where this observation's n_sub x d coefficients c_k(tau_s) start
-  uint32_t pad2_;               //   in the handle's sub-step table (doubles)
+                                //   in the handle's sub-step table (doubles)
+  uint32_t predict;             // 1 (LGCP): `ref` is not a function of the observation -- it is the level PREDICTED from the max of the weighted
+                                //   observation before (cssm_ref_predict), which the kernel that publishes that observation's scalars writes into
+                                //   the NEXT record (rec[1].ref) and into Scalars::next_ref; the host uploads NaN and chains the first record of a
+                                //   call from Scalars::next_ref on the stream (cssm_upload_recs).  0: ref = cssm_ref_level of the observation.
 };
 
 // One latent component of the composed model, constraint transforms applied (model/Sde.scala:70-73,99-102,133-137).

@@ -171,7 +171,8 @@ extern "C" int cssm_pf_shard_propagate(cssm_pf* pf, double t, double obs, int ha
   cssm_build_rec(pf, pf->t, t, obs, has_obs, pf->step, &pf->h_recs[slot]);
   rc = cssm_build_fsub(pf, slot, 1, true);
   if (rc) return rc;
-  HIP_TRY(hipMemcpyAsync(pf->d_recs + slot, pf->h_recs + slot, sizeof(StepRec), hipMemcpyHostToDevice, pf->stream));
+  rc = cssm_upload_recs(pf, slot, 1, true);
+  if (rc) return rc;
   rc = shard_prepare_step(pf, pf->d_recs + slot, pf->h_recs[slot].has_obs, sums5_dev);
   if (rc) return rc;
   pf->t = t;
@@ -244,6 +245,7 @@ extern "C" int cssm_pf_shard_offspring(cssm_pf* pf, const uint64_t* all_sums5_de
                      pf->anc, pf->ntiles, pf->sup, pf->nunits, optimistic ? 2 : 0, 0, (double*)nullptr, (int32_t*)nullptr, 0u, pf->opt_exact,
                      (const unsigned long long*)all_sums5_dev, rank, world, optimistic ? (int)pf->split : 1, pf->seed, (double*)nullptr, pf->d_logtab,
                      optimistic, (unsigned long long*)redo_flag_dev, (uint32_t)pf->first, (uint32_t)(pf->first + pf->n));
+  pf->have_level = true;
   pf->send_first_dev = (const long long*)send_first_dev; pf->send_count_dev = (const long long*)send_count_dev;
   hipLaunchKernelGGL(k_send_ranges, dim3(1), dim3(64), 0, pf->stream, pf->endslot, pf->n, pf->sc, pf->d_recs + slot, pf->n_global, rank, world,
                      n_per, (long long*)send_first_dev, (long long*)send_count_dev);
@@ -281,6 +283,10 @@ static int shard_prepare_step(cssm_pf* pf, const StepRec* d_rec, int weighted, u
   // series): only the local max is exported now and the sums are a pass of their own once the level is known
   // (cssm_pf_shard_sums), so the kernel that stores LOG-weights runs.  nullptr (single-collective exchange at every
   // observation's reference level): k_propagate<SUMS> forms the sums and stores the weights in place of the log-weights.
+  // (LGCP, contract v8: the level is predicted from the weighted observation before -- the first event of a series has none and
+  //  takes its level from the global max like an exact exchange: the caller must gather the maxima for it)
+  if (weighted && sums5_dev == nullptr && pf->obs_kind == CSSM_OBS_LGCP && !pf->have_level)
+    return fail(CSSM_ESTATE, "the first LGCP event of a series has no predicted level: its level comes from the all-gathered max (pass sums5_dev)");
   pf->safe_sums = sums5_dev != nullptr;
   int rc = cssm_launch_propagate(pf, d_rec);
   pf->safe_sums = false;
@@ -320,7 +326,8 @@ extern "C" int cssm_pf_shard_begin(cssm_pf* pf, const double* t, const double* y
   for (size_t s = 0; s < T; ++s) { cssm_build_rec(pf, tp, t[s], y[s], has_obs ? has_obs[s] : 1, (uint32_t)s, &pf->h_recs[s]); tp = t[s]; }
   rc = cssm_build_fsub(pf, 0, T, true);
   if (rc) return rc;
-  HIP_TRY(hipMemcpyAsync(pf->d_recs, pf->h_recs, T * sizeof(StepRec), hipMemcpyHostToDevice, pf->stream));
+  rc = cssm_upload_recs(pf, 0, T, false);   // (a new cloud: no observation precedes the first record)
+  if (rc) return rc;
   rc = cssm_launch_init(pf, t0);
   if (rc) return rc;
   pf->series = true;
@@ -360,7 +367,8 @@ extern "C" int cssm_pf_shard_continue(cssm_pf* pf, const double* t, const double
   for (size_t s = 0; s < T; ++s) { cssm_build_rec(pf, tp, t[s], y[s], has_obs ? has_obs[s] : 1, pf->step + (uint32_t)s, &pf->h_recs[s]); tp = t[s]; }
   rc = cssm_build_fsub(pf, 0, T, true);
   if (rc) return rc;
-  HIP_TRY(hipMemcpyAsync(pf->d_recs, pf->h_recs, T * sizeof(StepRec), hipMemcpyHostToDevice, pf->stream));
+  rc = cssm_upload_recs(pf, 0, T, true);
+  if (rc) return rc;
   pf->series = true;
   pf->rec_base = pf->step;
   pf->snaps.clear();
@@ -378,7 +386,7 @@ extern "C" int cssm_pf_shard_propagate_at(cssm_pf* pf, size_t s, uint64_t* sums5
   pf->t = pf->h_recs[s].t_obs;
   if (!pf->h_recs[s].has_obs) path_after(pf, s);   // (a weighted observation: behind its resampling, cssm_pf_shard_adopt_spec / _adopt)
   if (pf->snaps.size() <= s) pf->snaps.resize(s + 1);
-  pf->snaps[s] = {pf->cur, pf->src, pf->src_stride, pf->src2, pf->src2_stride, pf->n_split, pf->anc_valid, pf->last_optimistic, pf->step, pf->t};
+  pf->snaps[s] = {pf->cur, pf->src, pf->src_stride, pf->src2, pf->src2_stride, pf->n_split, pf->anc_valid, pf->last_optimistic, pf->step, pf->t, pf->have_level};
   return CSSM_OK;
 }
 
@@ -408,6 +416,7 @@ extern "C" int cssm_pf_shard_resume(cssm_pf* pf, uint32_t* fail_step_out) {
   const cssm_pf::Snap& q = pf->snaps[s];
   pf->cur = q.cur; pf->src = q.src; pf->src_stride = q.src_stride; pf->src2 = q.src2; pf->src2_stride = q.src2_stride;
   pf->n_split = q.n_split; pf->anc_valid = q.anc_valid; pf->last_optimistic = q.last_optimistic; pf->step = q.step; pf->t = q.t;
+  pf->have_level = q.have_level;
   pf->sums_ready = true;   // (the exchange that missed ran behind them)
   *fail_step_out = s;
   return CSSM_OK;
@@ -479,6 +488,7 @@ extern "C" int cssm_pf_shard_adopt_spec(cssm_pf* pf, const double* recv_buf_dev,
   pf->src = pf->state[pf->cur]; pf->src_stride = pf->stride;
   pf->src2 = recv_buf_dev; pf->src2_stride = 0; pf->n_split = n_split; pf->anc_valid = true;   // stride 0 = rows of d + 1
   pf->wmode = pf->last_optimistic;
+  pf->have_level = true;        // (its block 0 published the next observation's predicted level: LGCP)
   if (pf->series) path_after(pf, slot);   // (on hold after a capacity miss the slot index of a wrong row is overwritten when the observation is redone)
   return CSSM_OK;
 }

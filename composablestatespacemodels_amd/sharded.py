@@ -20,9 +20,10 @@ exchange is redone with four times the capacity, the series carries on); a refer
 kernels AND collectives itself (``cssm_pf_shard_series_rccl``), in stretches after each of which one status word is
 read, bounded by a timeout (a rank that never joins a collective surfaces as an RCCL error on every rank, not a hang).
 
-LGCP series (their level IS the max) and the repetition just mentioned run the same exchange with the level taken from
-the GLOBAL max: an all-gather of the ranks' 5 words and ``shard_sums`` (sums relative to the level the gathered max
-selects) precede the all-to-all -- two collectives per observation, still nothing read by the host.
+The repetition just mentioned (and the first event of an LGCP series, which has no predecessor to predict its level from --
+numerics contract v8) run the same exchange with the level taken from the GLOBAL max: an all-gather of the ranks' 5 words and
+``shard_sums`` (sums relative to the level the gathered max selects) precede the all-to-all -- two collectives per
+observation, still nothing read by the host.
 
 **Exact exchange** -- forced (``exact=True``; tests, and the stage calls a host may drive itself): all-gather of the sums,
 ``shard_offspring``, all-to-all of the range sizes, ONE host read of those sizes, all-to-all-v of (d + 1) doubles per
@@ -514,15 +515,20 @@ class ShardedFilter:
         #   "exact" the host-read exchange: slots owned by particles of NON-adjacent ranks (weights so degenerate that no
         #           capacity covers them: bit 8 survives the resumes), or forced
         can_single = all(hasattr(s, "boundary_pack") for s in S)
-        plans = ["exact"] if (exact or not can_single) else (["max", "exact"] if lgcp else ["ref", "max", "exact"])
+        plans = ["exact"] if (exact or not can_single) else ["ref", "max", "exact"]
         if cont:
             plans = plans[:1]   # (a continued series cannot be repeated from its start)
+        # LGCP (numerics contract v8): the level of an event is predicted from the max of the weighted observation before it, so an
+        # LGCP series runs the "ref" plan like any other -- except its FIRST event when nothing precedes it (a new cloud): that one
+        # takes its level from the global max (all-gather + shard_sums ahead of its all-to-all), whatever the plan.
+        have_level0 = bool(getattr(self, "_have_level", False)) if cont else False
         attempt = 0
         while plans:
             plan = plans.pop(0)
             attempt += 1
             all_exact = plan == "exact"
             from_max = plan == "max"
+            first_from_max = lgcp and not have_level0 and not all_exact and not from_max
             for s in S:
                 s.begin_more(t, y, has) if cont else s.begin(t, y, has)
             cap = None if all_exact else self._capacity()
@@ -561,19 +567,21 @@ class ShardedFilter:
                     # the library enqueues kernels and RCCL collectives itself, one stream, no host-language call per
                     # observation -- in stretches, so that a capacity miss is noticed (one status read per stretch) before
                     # the whole tail has been enqueued in vain
-                    kend = min(k + self.NATIVE_STRETCH, T)
+                    fm = from_max or (first_from_max and k == 0)
+                    kend = 1 if (first_from_max and k == 0) else min(k + self.NATIVE_STRETCH, T)
                     nb = comm.world * S[0].spec_segment(cap)
                     S[0].series_native(native, k, kend, weighted, cap, S[0].buffer("send_spec", nb)[:nb],
-                                       S[0].buffer("recv_spec", nb)[:nb], single_collective=mode + (4 if from_max else 0))
+                                       S[0].buffer("recv_spec", nb)[:nb], single_collective=mode + (4 if fm else 0))
                     self.last_all_to_all = ("ncclAllToAllv: whole segments between adjacent ranks, 12 header words between the others"
                                             if (mode == 3 or (mode == 2 and comm.world > 2)) else "ncclAllToAll, equal split of whole segments")
                     k = kend
                     look_for_a_miss()
                     continue
+                fm = from_max or (first_from_max and k == 0)
                 if not redo_exchange:               # (after a resume the observation is already propagated)
                     for s in S:
-                        s.propagate_at(k) if (all_exact or from_max) else s.propagate_at(k, with_sums=False)
-                    if from_max and weighted[k]:
+                        s.propagate_at(k) if (all_exact or fm) else s.propagate_at(k, with_sums=False)
+                    if fm and weighted[k]:
                         comm.all_gather([s.all_sums for s in S], [s.sums5 for s in S])   # only the max keys matter
                         for s in S:
                             s.sums()                # the sums, relative to the level the gathered max selects
@@ -599,6 +607,7 @@ class ShardedFilter:
             bits = comm.agree_max([max(r[2] for r in res)] * len(S))
             if bits == 0:
                 self.last_cap, self.last_attempts = cap, attempt
+                self._have_level = have_level0 or bool(np.any(weighted))
                 return res[0][0], res[0][1]
             if cont:
                 raise RuntimeError(f"a continued sharded series cannot be repeated under another plan (sticky bits {bits}: "

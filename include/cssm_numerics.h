@@ -1125,7 +1125,8 @@ CSSM_HD double cssm_order_unkey(uint64_t k) {
  * is still found (an integer atomicMax on the side) and decides afterwards whether c was usable:
  *
  *     ref = c   if  -CSSM_REF_BELOW <= c - max <= CSSM_REF_ABOVE      (every w1 <= 1 + 2^-20, top weight keeps > 50 bits)
- *         = max otherwise (outlying observation, LGCP, non-finite c): the sums are then formed again with max.
+ *         = max otherwise (outlying observation, non-finite c): the sums are then formed again with max.
+ *     (LGCP: c is predicted from the previous event's max, see cssm_ref_predict below.)
  *
  * ll += ref + log(mean(exp(w - ref))) is the same quantity for either level; only roundings differ.
  * kinds: the CSSM_OBS_* numbers of cssm_pf.h; p = the observation parameter as the density uses it (Gaussian
@@ -1156,6 +1157,21 @@ CSSM_HD double cssm_ref_level(int kind, double y, double p, double df) {
     default: return cssm_nan();                                              /* LGCP: gamma - hazard is unbounded */
   }
 }
+/* LGCP (contract v8).  gamma - hazard has no bound that depends on the observation alone, so up to v7 every LGCP event was
+ * rescaled by its max -- a grid-wide dependency between the weights and their sums on one GPU (a pass of its own over the
+ * log-weights), and on several GPUs an all-gather of the maxima ahead of the resampling exchange.  Since v8 the level of an
+ * event is PREDICTED from the max of the weighted observation before it in the same filter:
+ *
+ *     c_s = cssm_ref_predict(max_{s-1}) = max_{s-1} + CSSM_REF_PREDICT_MARGIN,      ref_s = cssm_ref_choose(c_s, max_s)
+ *
+ * and NaN (always the max) where no weighted observation precedes -- the first one after the cloud was initialised or handed
+ * back by a host resampler.  The max of an LGCP event moves by a few units between events (the bench workload: at most
+ * +-2.5), so the prediction stands practically always and the weights' sums are formed inside the propagate kernel as for
+ * every other observation model; a prediction the max rules out (cssm_ref_choose) is an outlying observation like any other:
+ * its sums are formed again relative to the max.  The margin keeps the top weight at exp(-margin) ~ 2^-11.5 of the level: 84 of
+ * the 96 fractional bits remain below it. */
+#define CSSM_REF_PREDICT_MARGIN 8.0
+CSSM_HD double cssm_ref_predict(double prev_max) { return prev_max + CSSM_REF_PREDICT_MARGIN; }   /* NaN in, NaN out */
 /* The level actually used, given the maximum log-weight of the step. */
 CSSM_HD double cssm_ref_choose(double c, double max) {
   const double gap = c - max;

@@ -72,6 +72,8 @@ struct oracle_pf {
   int d, n_leaves, obs_kind, precision, flags, obs_df;
   double scale_sd;       /* exp(scale): Gaussian sd, NegBin size, Student-t v   model/Model.scala:147,171,211,244 */
   double ref_last, gmax_last; /* rescaling level and max log-weight of the last weighted step */
+  double next_ref;       /* LGCP (contract v8, cssm_ref_predict): the level predicted for the NEXT weighted observation from the max of
+                            the last one; NaN while none has run since the cloud was drawn or handed in (oracle_pf_set_particles) */
   double scale_raw;      /* ZIP: the stored scale v                              model/Model.scala:284,300 */
   ocomp comp[CSSM_MAX_DIM];
   uint64_t n, seed;
@@ -252,7 +254,7 @@ int oracle_pf_init(oracle_pf* pf, double t0) {
   }
   memcpy(pf->x1, pf->x, (size_t)pf->n * pf->d * 8);
   for (uint64_t i = 0; i < pf->n; ++i) pf->anc[i] = (uint32_t)i;
-  pf->t = t0; pf->ll = 0.0; pf->ess = (int32_t)pf->n; pf->step = 0; pf->initialised = 1;
+  pf->t = t0; pf->ll = 0.0; pf->ess = (int32_t)pf->n; pf->step = 0; pf->initialised = 1; pf->next_ref = cssm_nan();
   return ORACLE_OK;
 }
 
@@ -261,7 +263,7 @@ int oracle_pf_init_from(oracle_pf* pf, double t0, const double* state_d) {
   for (uint64_t i = 0; i < pf->n; ++i) memcpy(pf->x + i * pf->d, state_d, pf->d * 8);
   memcpy(pf->x1, pf->x, (size_t)pf->n * pf->d * 8);
   for (uint64_t i = 0; i < pf->n; ++i) pf->anc[i] = (uint32_t)i;
-  pf->t = t0; pf->ll = 0.0; pf->ess = (int32_t)pf->n; pf->step = 0; pf->initialised = 1;
+  pf->t = t0; pf->ll = 0.0; pf->ess = (int32_t)pf->n; pf->step = 0; pf->initialised = 1; pf->next_ref = cssm_nan();
   return ORACLE_OK;
 }
 
@@ -496,8 +498,11 @@ static int weigh_and_resample(oracle_pf* pf, double y) {
   /* The contract rescales by the reference level of the observation when the max allows it (cssm_numerics.h,
    * cssm_ref_level / cssm_ref_choose); ORACLE_LITERAL_SUMS keeps the reference's own w - max. */
   if (!(pf->flags & ORACLE_LITERAL_SUMS)) {
-    double c = (pf->obs_kind == CSSM_OBS_LGCP) ? cssm_nan() : cssm_ref_level(pf->obs_kind, y, pf->scale_sd, (double)pf->obs_df);
+    /* LGCP: gamma - hazard has no bound known in advance; its level is predicted from the max of the weighted observation
+     * before (cssm_ref_predict), NaN -- i.e. the max -- where there is none */
+    double c = (pf->obs_kind == CSSM_OBS_LGCP) ? pf->next_ref : cssm_ref_level(pf->obs_kind, y, pf->scale_sd, (double)pf->obs_df);
     pf->gmax_last = max;
+    pf->next_ref = cssm_ref_predict(max);
     max = cssm_ref_choose(c, max);
   }
   pf->ref_last = max;
@@ -638,6 +643,7 @@ int oracle_pf_propagate_only(oracle_pf* pf, double t, double y, int has_obs) {
 
 /* Overwrite the current cloud (SoA in, [d][n]); n may not change. */
 void oracle_pf_set_particles(oracle_pf* pf, const double* soa) {
+  pf->next_ref = cssm_nan();   /* (a host resampler's cloud: no native observation whose max could predict the next level) */
   for (uint64_t i = 0; i < pf->n; ++i) for (int k = 0; k < pf->d; ++k) pf->x[i * pf->d + k] = soa[(uint64_t)k * pf->n + i];
 }
 
@@ -691,9 +697,10 @@ void oracle_pf_get_ancestors(const oracle_pf* pf, uint32_t* out) { memcpy(out, p
 void oracle_pf_get_cumw(const oracle_pf* pf, double* out) { memcpy(out, pf->C, pf->n * 8); }
 /* contract pass-throughs for the shard test double */
 double oracle_pf_ref_level(const oracle_pf* pf, double y) {
-  return (pf->obs_kind == CSSM_OBS_LGCP) ? cssm_nan() : cssm_ref_level(pf->obs_kind, y, pf->scale_sd, (double)pf->obs_df);
+  return (pf->obs_kind == CSSM_OBS_LGCP) ? pf->next_ref : cssm_ref_level(pf->obs_kind, y, pf->scale_sd, (double)pf->obs_df);
 }
 double oracle_c_ref_choose(double c, double max) { return cssm_ref_choose(c, max); }
+double oracle_c_ref_predict(double prev_max) { return cssm_ref_predict(prev_max); }
 uint64_t oracle_c_order_key(double x) { return cssm_order_key(x); }
 double oracle_c_order_unkey(uint64_t k) { return cssm_order_unkey(k); }
 void oracle_pf_get_ref(const oracle_pf* pf, double* ref, double* gmax) { *ref = pf->ref_last; *gmax = pf->gmax_last; }

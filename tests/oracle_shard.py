@@ -58,14 +58,17 @@ class OracleShard:
     def init(self, t0):
         self.o.init(t0)
         self.ll, self.ess, self.step_idx = 0.0, self.n_global, 0
+        self.next_ref = float("nan")     # LGCP (contract v8): the level predicted from the previous weighted observation's max
 
     def propagate(self, t, y, has_obs):
         self.o.propagate_only(t, y, bool(has_obs))
         self.x1 = self.o.proposed()
         if has_obs or self.o_is_lgcp():
             self.logw = self.o.logw()
-            self.c = self.o.ref_level(y)                       # known without any exchange
-            self.optimistic = not self.o_is_lgcp()
+            # known without any exchange: a function of the observation -- or, LGCP, predicted from the GLOBAL max of the weighted
+            # observation before (every rank holds it after that observation's exchange); NaN for the first event of a series
+            self.c = self.next_ref if self.o_is_lgcp() else self.o.ref_level(y)
+            self.optimistic = not np.isnan(self.c)
             key = int(oracle.lib().oracle_c_order_key(float(self.logw.max())))
             if self.optimistic:
                 self._local_sums(self.c, clamp=True)
@@ -105,6 +108,8 @@ class OracleShard:
             self.redo_flag[0] = 1
             return
         self.redo_flag[0] = 0
+        if self.o_is_lgcp():
+            self.next_ref = float(oracle.lib().oracle_c_ref_predict(gmax))
         v = [int(x) for x in self.all_sums.tolist()]
         S_off = S_tot = S2_tot = 0
         for r in range(self.world):

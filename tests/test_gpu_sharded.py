@@ -62,9 +62,10 @@ def test_local_shards_degenerate_weights():
 @pytest.mark.parametrize("world,n", [(2, 3000), (4, 9000), (8, 20000)])
 @pytest.mark.parametrize("name", ["c4_model", "lgcp_seasonal_model"])
 def test_local_shards_lgcp(world, n, name):
-    """LGCP series (BASELINE config 4 is the 8-GPU one): the level of every observation is the global max, so an all-gather of
-    the local maxima and the sums relative to it precede the single all-to-all -- two collectives per observation, nothing
-    read by the host; bit-identical to the single-rank oracle for 2, 4 and 8 shards.  Also through the exact exchange."""
+    """LGCP series (BASELINE config 4 is the 8-GPU one).  Numerics contract v8: the level of an event is predicted from the max
+    of the event before, so the series runs the "ref" plan -- ONE all-to-all per event, the sums formed inside the propagate --
+    except its first event (nothing precedes it: all-gather of the maxima + sums relative to the max ahead of the all-to-all);
+    nothing read by the host; bit-identical to the single-rank oracle for 2, 4 and 8 shards.  Also through the exact exchange."""
     from composablestatespacemodels_amd.sharded import GpuShard, ShardedFilter
     from local_comm import LocalComm
     model = getattr(cases, name)()
@@ -74,7 +75,7 @@ def test_local_shards_lgcp(world, n, name):
     oll, oess, opart = _oracle_run(model, n, t, y, has, lgcp_precision=2)
     for exact in (False, True):
         ll, ess = f.ll_filter(t, y, has, lgcp=True, exact=exact)
-        assert f.last_single == (not exact) and f.last_from_max == (not exact) and f.last_attempts == 1
+        assert f.last_single == (not exact) and not f.last_from_max and f.last_attempts == 1
         assert (ll, ess) == (oll, oess[-1])
         np.testing.assert_array_equal(np.concatenate([s.particles() for s in shards], axis=1), opart)
     for s in shards:
@@ -105,9 +106,9 @@ def test_full_size_local_shards_equal_single_gpu(world):
 
 def test_full_size_lgcp_in_its_sharded_shape_equals_single_gpu():
     """BASELINE configs[3] as BASELINE shapes it -- a log-Gaussian Cox process, N = 2^24 particles over 8 shards of 2^21
-    (FilterLgcp, ParticleFilter.scala:184-226; precision 2) -- on one GPU with the collectives as tensor copies: every level
-    is the global max (plan "max": all-gather of the maxima + all-to-all per event), and ll, ess and every particle equal the
-    single-GPU handle of the same N bit for bit."""
+    (FilterLgcp, ParticleFilter.scala:184-226; precision 2) -- on one GPU with the collectives as tensor copies: the levels are
+    predicted (plan "ref": one all-to-all per event; the first event's level is the all-gathered max), and ll, ess and every
+    particle equal the single-GPU handle of the same N bit for bit."""
     from composablestatespacemodels_amd.filter import NativePf
     from composablestatespacemodels_amd.sharded import GpuShard, ShardedFilter
     from local_comm import LocalComm
@@ -121,7 +122,7 @@ def test_full_size_lgcp_in_its_sharded_shape_equals_single_gpu():
     shards = [GpuShard(model, n, r, world, cases.SEED, 0, lgcp_precision=2) for r in range(world)]
     f = ShardedFilter(shards, LocalComm(world))
     ll, ess = f.ll_filter(t, y, has, lgcp=True)
-    assert f.last_single and f.last_from_max and f.last_attempts == 1
+    assert f.last_single and not f.last_from_max and f.last_attempts == 1
     assert (ll, ess) == (ll1, int(ess1[-1]))
     for r, s in enumerate(shards):
         lo, m = s.first, s.n
@@ -140,7 +141,7 @@ def test_trimmed_exchange_lgcp_world8():
     shards = [GpuShard(model, n, r, world, cases.SEED, 0, lgcp_precision=2) for r in range(world)]
     f = ShardedFilter(shards, LocalCommTrimmed(world))
     ll, ess = f.ll_filter(t, y, has, lgcp=True)
-    assert f.last_single and f.last_from_max and f.last_attempts == 1
+    assert f.last_single and not f.last_from_max and f.last_attempts == 1
     oll, oess, opart = _oracle_run(model, n, t, y, has, lgcp_precision=2)
     assert (ll, ess) == (oll, oess[-1])
     np.testing.assert_array_equal(np.concatenate([s.particles() for s in shards], axis=1), opart)
@@ -293,14 +294,15 @@ def test_rccl_world1_matches_oracle():
         assert f4.last_native and f4.last_single and (ll, ess) == (oll, oess[-1])
         np.testing.assert_array_equal(shard.particles(), opart)
         f4.comm.close()
-        # an LGCP series with the library's own loop: all-gather of the maxima + all-to-all per observation (mode 1 + 4)
+        # an LGCP series with the library's own loop: the first event with an all-gather of the maxima ahead of its all-to-all (mode 1 + 4),
+        # every later one on its predicted level (mode 1)
         lm = cases.c4_model()
         lt, ly, lh = cases.event_times(9)
         lshard = GpuShard(lm, 6000, 0, 1, cases.SEED, 0, lgcp_precision=2)
         fl = ShardedFilter([lshard], DistComm(device=torch.device("cuda", 0)))
         ll, ess = fl.ll_filter(lt, ly, lh, lgcp=True)
         lo = _oracle_run(lm, 6000, lt, ly, lh, lgcp_precision=2)
-        assert fl.last_native and fl.last_single and fl.last_from_max and (ll, ess) == (lo[0], lo[1][-1])
+        assert fl.last_native and fl.last_single and not fl.last_from_max and (ll, ess) == (lo[0], lo[1][-1])
         np.testing.assert_array_equal(lshard.particles(), lo[2])
         lshard.close()
         fl.comm.close()
@@ -416,8 +418,8 @@ def test_series_resumes_a_capacity_miss_and_repeats_after_an_outlying_observatio
 
 @pytest.mark.parametrize("world,n", [(2, 3000), (4, 9000)])
 def test_lgcp_series_resumes_a_capacity_miss(world, n):
-    """An LGCP series runs on the "max" plan from the start (its level IS the max).  With one row per pair its exchanges
-    miss and are resumed in place: ONE attempt, at least one resume, the oracle's bits."""
+    """An LGCP series (plan "ref" on predicted levels, its first event on the all-gathered max): with one row per pair its
+    exchanges miss and are resumed in place: ONE attempt, at least one resume, the oracle's bits."""
     from composablestatespacemodels_amd.sharded import GpuShard, ShardedFilter
     from local_comm import LocalComm
     model = cases.c4_model()
@@ -428,7 +430,7 @@ def test_lgcp_series_resumes_a_capacity_miss(world, n):
     ll, ess = f.ll_filter(t, y, has, lgcp=True)
     plan, _ = _mirror_plan(model, n, world, t, y, has, lgcp=True, prec=2, min_cap=1, cap_sqrt=0.0)
     assert (f.last_attempts, f.last_resumes, f.last_single, f.last_from_max) == plan
-    assert plan[0] == 1 and plan[1] >= 1 and plan[2] and plan[3]
+    assert plan[0] == 1 and plan[1] >= 1 and plan[2] and not plan[3]
     oll, oess, opart = _oracle_run(model, n, t, y, has, lgcp_precision=2)
     assert (ll, ess) == (oll, oess[-1])
     np.testing.assert_array_equal(np.concatenate([s.particles() for s in shards], axis=1), opart)

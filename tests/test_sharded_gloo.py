@@ -82,15 +82,16 @@ def test_sharded_orchestration_over_gloo_matches_single_rank(tmp_path, world, na
         np.testing.assert_allclose(sm["state_mean"], om, rtol=1e-12)
         np.testing.assert_allclose(float(sm["eta_of_mean"]), oem, rtol=1e-12)
         z = np.load(os.path.join(str(tmp_path), f"r{r}.npz"))
-        # sums are a pass of their own (cssm_pf_shard_sums) wherever the level comes from the global max: every observation of an
-        # LGCP series, of the repetition after an outlying observation, and of a series on the exact exchange; else none
+        # sums are a pass of their own (cssm_pf_shard_sums) wherever the level comes from the global max: the FIRST event of an
+        # LGCP series (contract v8: every later one predicts its level from the event before), every observation of the
+        # repetition after an outlying observation and of a series on the exact exchange; else none
         weighted = int(np.sum(has)) if not prec else T
-        assert int(z["redone"]) == (T if prec else (weighted if missing in (-0.2, -0.1) else 0))
+        assert int(z["redone"]) == (1 if prec else (weighted if missing in (-0.2, -0.1) else 0))
         resumed = missing == 0.05                       # capacity misses are resumed, not repeated from the start
         assert int(z["attempts"]) == (2 if missing == -0.2 else 1)
         assert (int(z["resumes"]) >= 1) == resumed
         assert int(z["single"]) == (0 if missing == -0.1 else 1)
-        assert int(z["from_max"]) == (1 if (prec or missing == -0.2) else 0)
+        assert int(z["from_max"]) == (1 if missing == -0.2 else 0)      # (an LGCP series runs the "ref" plan)
         assert float(z["ll"]) == ll and int(z["ess"]) == int(ess_t[-1])
         parts.append(z["part"])
     np.testing.assert_array_equal(np.concatenate(parts, axis=1), o.particles())
@@ -143,7 +144,7 @@ def test_bench_launches_its_own_ranks_over_gloo(which):
     assert j["scaling"] == ("weak" if which == "c2" else "strong")
     assert j["exchange"]["backend"] == "gloo"
     assert [p["rank"] for p in j["per_rank"]] == [0, 1]
-    assert all(len(p["legs"]) == R and p["legs"][0]["plan"] == ("ref" if which == "c2" else "max") for p in j["per_rank"])
+    assert all(len(p["legs"]) == R and p["legs"][0]["plan"] == "ref" for p in j["per_rank"])
     sys.path.insert(0, os.path.dirname(HERE))
     import bench
     model, t, y, has = bench.build_workload(W + (R + 1) * K, which)
