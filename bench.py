@@ -348,6 +348,7 @@ def run_multi(args, emit=print):
     if rank == 0:
         w = float(np.median(walls))
         native = bool(getattr(f, "last_native", False))
+        peer = bool(getattr(f, "last_peer", False))
         emit(json.dumps({
             "metric": METRIC, "value": n_global * K / w, "unit": "particle-steps/s",
             "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": w * 1e3 / K, "higher_is_better": True,
@@ -360,7 +361,10 @@ def run_multi(args, emit=print):
                                       "steps started (cssm_pf_shard_continue)", "wall_ms_each": [x * 1e3 for x in walls],
             "exchange": {"backend": args.backend,
                          "shard_backend": "libcssm_pf (HIP)" if gpu else "oracle (CPU rehearsal, not a measurement)",
-                         "collectives_issued_by": "libcssm_pf (cssm_pf_shard_series_rccl)" if native else "torch.distributed",
+                         "protocol": ("peer-written: every rank writes its segments into the other ranks' receive windows (hipIpc-mapped device memory) and "
+                                      "sets a flag; no collective per observation (cssm_pf_shard_series_peer)") if peer else "collective: one all-to-all per observation",
+                         "collectives_issued_by": ("none per observation" if peer else
+                                                   ("libcssm_pf (cssm_pf_shard_series_rccl)" if native else "torch.distributed")),
                          "all_to_all": getattr(f, "last_all_to_all", "equal split"),
                          "rccl": shard.lib.cssm_rccl_library().decode() if gpu else None},
             "per_rank": every,

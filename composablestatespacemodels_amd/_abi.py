@@ -49,6 +49,12 @@ class ModelDesc(C.Structure):
     ]
 
 
+class PeerHandle(C.Structure):
+    """cssm_peer_handle: what a rank hands the others so that they can map its receive windows (peer-written exchange)."""
+    _fields_ = [("ipc", C.c_char * 64), ("pid", C.c_uint64), ("local_ptr", C.c_uint64), ("bytes", C.c_uint64),
+                ("device", C.c_int32), ("has_ipc", C.c_int32)]
+
+
 class CssmError(RuntimeError):
     """Raised for a non-zero status of a cssm_* call (the reference throws from stepFilter)."""
 
@@ -126,6 +132,12 @@ SYMBOLS = [
     ("cssm_pf_shard_boundary_pack", C.c_int, [_h, C.c_int, C.c_int, C.c_int64, C.c_void_p]),
     ("cssm_pf_shard_adopt_spec", C.c_int, [_h, C.c_void_p, C.c_int, C.c_int, C.c_int64]),
     ("cssm_pf_shard_resume", C.c_int, [_h, C.POINTER(C.c_uint32)]),
+    ("cssm_pf_shard_peer_setup", C.c_int, [_h, C.c_int, C.c_int, C.c_int64, C.POINTER(PeerHandle)]),
+    ("cssm_pf_shard_peer_connect", C.c_int, [_h, C.POINTER(PeerHandle), C.c_int]),
+    ("cssm_pf_shard_peer_close", None, [_h]),
+    ("cssm_pf_shard_pack_peer", C.c_int, [_h, C.c_int, C.c_int, C.c_int64]),
+    ("cssm_pf_shard_adopt_peer", C.c_int, [_h, C.c_int, C.c_int, C.c_int64]),
+    ("cssm_pf_shard_series_peer", C.c_int, [_h, C.c_int, C.c_int, C.c_size_t, C.c_size_t, _u8p, C.c_int64]),
     ("cssm_pmmh_run", C.c_int, [_h, _descp, _dp, C.c_size_t, C.c_double, _dp, _dp, _u8p, C.c_size_t,
                                 C.c_uint64, C.c_size_t, _dp, _dp, _i32p, _dp]),
     ("cssm_diag_copy_ceiling", C.c_int, [C.c_int, C.c_size_t, C.c_int, _dp]),

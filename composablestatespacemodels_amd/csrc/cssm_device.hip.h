@@ -63,7 +63,8 @@ struct Scalars {
   uint32_t err;              // bit0: NaN log-weight, bit1: all weights zero / max not finite,
                              // bit2: the reference level was unusable and the sums must be formed again (host retries)
                              // bit3: (sharded) the exchange capacity did not cover some rank's slots at step fail_step
-                             // (bits 4, 5: unused)
+                             // bit4: (sharded, peer-written exchange) a rank's segment did not arrive within the wait bound
+                             // (bit 5: unused)
                              // bit6: batch series on hold at fail_step: its reference level was ruled out, the host redoes its sums
   int32_t ess;
   uint32_t fail_step;        // first observation whose exchange did not fit (0xffffffff: none); see k_offspring_expand_spec
@@ -164,6 +165,13 @@ __device__ __forceinline__ cssm_u128 wave_excl_add_u128(cssm_u128 inc, cssm_u128
   r.hi = (uint64_t)r2 | ((uint64_t)r3 << 32);
   return r;
 }
+// Loads of data another GPU (or another process on this one) wrote while this kernel runs -- the receive windows of the peer-written
+// exchange, read behind their flags: system-scope loads (sc0 sc1) that no cache level of this GPU answers from a stale line.  NOT an
+// acquire fence: a system-scope fence is an L2 invalidate per wave, and k_offspring_expand_spec's 1024 blocks queueing for it cost
+// 34 us per launch (measured); the handful of loads per block that read a window bypass the caches instead.
+__device__ __forceinline__ unsigned long long ld_sys_u64(const unsigned long long* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+__device__ __forceinline__ double ld_sys_f64(const double* p) { return cssm_u2d(ld_sys_u64(reinterpret_cast<const unsigned long long*>(p))); }
+
 // A wave-uniform value the VALU produced, moved into scalar registers (v_readfirstlane_b32): it stops occupying vector registers
 // for as long as it lives.  k_offspring_self's tile loop keeps ~12 such words (the running prefix, N / S_tot, the distance bound).
 __device__ __forceinline__ double uniform_f64(double x) {

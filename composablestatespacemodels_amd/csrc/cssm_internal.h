@@ -100,6 +100,10 @@ struct cssm_pf : HostModel {
   // sharded cloud summaries (cssm_pf_shard_summary_*): keys of the local cloud, block partial sums, the two radix-select states per row
   unsigned long long* sm_keys = nullptr; double* sm_partial = nullptr; void* sm_st = nullptr; StepRec* sm_rec = nullptr;
   size_t sm_cap = 0; int sm_blocks = 0; double sm_time = 0.0;
+  // peer-written exchange (cssm_shard.hip: PeerState; the device table and the ticket counters k_boundary_pack uses)
+  void* peer = nullptr; void* peer_tab = nullptr; unsigned int* peer_tickets = nullptr;
+  uint32_t peer_seq = 0;       // number of the last exchange enqueued on the peer windows (window = seq & 1; the flags carry it)
+  bool peer_packed = false;    // cssm_pf_shard_pack_peer ran, cssm_pf_shard_adopt_peer has not yet
   bool want_path = false;      // sharded `filter`: record sampleOne's pick after every observation whose slot this rank owns
   uint32_t rec_base = 0;       // observation index (pf->step) of the resident series' first record: 0 after _begin, the filter's
                                //   observation count so far after _continue
@@ -189,4 +193,5 @@ int cssm_launch_init(cssm_pf* pf, double t0);
 int cssm_launch_propagate(cssm_pf* pf, const StepRec* d_rec, double* pick_out = nullptr, uint32_t pick_slot = 0);
 int cssm_check_device_err(cssm_pf* pf, const Scalars& h);
 int cssm_prop_items(int d);   // PropItems<D>
-double cssm_eta_of_mean(const cssm_pf* pf, const StepRec& rec, const double* mean);   // link(f(stateMean, t)), ParticleFilter.scala:420
+double cssm_eta_of_mean(const cssm_pf* pf, const StepRec& rec, const double* mean);
+void cssm_peer_free(cssm_pf* pf);   // cssm_shard.hip: the peer-written exchange's windows, mappings and device table   // link(f(stateMean, t)), ParticleFilter.scala:420

@@ -105,7 +105,7 @@ static __global__ __launch_bounds__(CSSM_BLOCK) void k_reduce_units(const cssm_u
                                                              uint32_t nblocks, uint32_t blocks_per_unit, uint32_t nunits,
                                                              cssm_u128* __restrict__ unitS, cssm_u128* __restrict__ unitS2,
                                                              const Scalars* __restrict__ sc, const StepRec* __restrict__ rec) {
-  if (!rec->has_obs || (sc->err & (4u | 8u | 64u))) return;   // (nothing was formed: an unweighted observation, a series on hold)
+  if (!rec->has_obs || (sc->err & (4u | 8u | 16u | 64u))) return;   // (nothing was formed: an unweighted observation, a series on hold)
   const uint32_t unit = blockIdx.x * (CSSM_BLOCK / 64) + (threadIdx.x >> 6);
   if (unit >= nunits) return;
   const uint32_t lane = threadIdx.x & 63u;
@@ -377,7 +377,7 @@ __device__ __forceinline__ void offspring_body(const double* __restrict__ logw, 
   } else {
     if (all5) {
       unsigned long long key = 0ull;
-      for (int r = 0; r < world; ++r) { const unsigned long long k = all5[(size_t)all5_stride * r + 4]; key = (k > key) ? k : key; }
+      for (int r = 0; r < world; ++r) { const unsigned long long k = ld_sys_u64(all5 + (size_t)all5_stride * r + 4); key = (k > key) ? k : key; }
       gmax_dec = cssm_order_unkey(key);
     } else {
       gmax_dec = sc->gmax;
@@ -395,8 +395,8 @@ __device__ __forceinline__ void offspring_body(const double* __restrict__ logw, 
       cssm_u128 tot = cssm_u128_zero(), tot2 = cssm_u128_zero();
       for (int r = 0; r < world; ++r) {
         cssm_u128 a, b;
-        const unsigned long long* w5 = all5 + (size_t)all5_stride * r;
-        a.lo = w5[0]; a.hi = w5[1]; b.lo = w5[2]; b.hi = w5[3];
+        const unsigned long long* w5 = all5 + (size_t)all5_stride * r;   // (possibly a peer-written window: ld_sys)
+        a.lo = ld_sys_u64(w5); a.hi = ld_sys_u64(w5 + 1); b.lo = ld_sys_u64(w5 + 2); b.hi = ld_sys_u64(w5 + 3);
         if (r < rank) S_off = cssm_u128_add(S_off, a);
         tot = cssm_u128_add(tot, a); tot2 = cssm_u128_add(tot2, b);
       }

@@ -158,6 +158,7 @@ extern "C" void cssm_pf_destroy(cssm_pf* pf) {
   if (!pf) return;
   (void)hipSetDevice(pf->device);
   if (pf->stream) (void)hipStreamSynchronize(pf->stream);
+  cssm_peer_free(pf);
   void* ptrs[] = {pf->sm_keys, pf->sm_partial, pf->sm_st, pf->sm_rec, pf->s2buf, pf->fineS, pf->fineS2, pf->state[0], pf->state[1], pf->logw, pf->endslot, pf->anc, pf->tileS, pf->tileS2, pf->tileP, pf->unitPre, pf->sc,
                   pf->d_m0, pf->d_sd0, pf->d_logtab, pf->d_fsub, pf->cum, pf->d_recs, pf->d_ll_t, pf->d_ess_t, pf->d_path, pf->cand, pf->cand_end, pf->cand_idx, pf->d_bounds, pf->d_xch, pf->d_need};
   for (void* p : ptrs) if (p) (void)hipFree(p);
@@ -417,6 +418,7 @@ static int launch_step(cssm_pf* pf, const StepRec* d_rec, int weighted, uint32_t
 int cssm_check_device_err(cssm_pf* pf, const Scalars& h) {
   if (h.err & 1u) return fail(CSSM_ENONFINITE, "a log-weight is NaN (the reference's breeze distribution constructor would throw)");
   if (h.err & 2u) return fail(CSSM_ENONFINITE, "all particle weights are zero or the maximum log-weight is not finite");
+  if (h.err & 16u) return fail(CSSM_ESHARD, "peer-written exchange: a rank's segment did not arrive within the wait bound");
   (void)pf;
   return CSSM_OK;
 }

@@ -458,7 +458,7 @@ __global__ __launch_bounds__(CSSM_BLOCK, (PropWaves<D, SUMS>::value)) void k_pro
   // until the host resumes it (cssm_pf_shard_resume)
   // bit 3: a sharded series is on hold (capacity miss); bit 6: a single-GPU batch series waits for the redo of an outlying
   // observation; bit 2: a series enqueued ahead is void (its level was ruled out: the host repeats it) -- nothing to do
-  if (sc->err & (4u | 8u | 64u)) return;
+  if (sc->err & (4u | 8u | 16u | 64u)) return;
   const uint32_t range_lo = blockIdx.x * (uint32_t)chunk;
   uint32_t n;                                                 // this block's range ends at n
   { const uint64_t range_hi = (uint64_t)range_lo + chunk; n = (uint32_t)((range_hi < n_arg) ? range_hi : n_arg); }
@@ -586,7 +586,7 @@ __device__ __forceinline__ void propagate_block(
   } else {
     tab = stage_log_table(logtab);
   }
-  if (held & (4u | 8u | 64u)) return;
+  if (held & (4u | 8u | 16u | 64u)) return;
   __shared__ __attribute__((aligned(16))) unsigned char s_stage[PropStage<D, IT>::bytes];
   PropAcc acc;
   propagate_range<D, false, IT, OBS, SUMS, ONE>(src, src_stride, anc, dst, dst_stride, logw, gid0, seed, rec, mk, src2, 0, n_split, tab,

@@ -10,6 +10,7 @@
 #include <cstdlib>
 #include <mutex>
 #include <thread>
+#include <unistd.h>
 
 #include "cssm_internal.h"
 #include "cssm_shard_kernels.hip.h"
@@ -20,7 +21,7 @@
 
 // level of the step from the all-gathered order keys (word 4 of every rank's 5 words)
 __global__ void k_import_level(Scalars* sc, const unsigned long long* __restrict__ all5, int world, const StepRec* __restrict__ rec) {
-  if (sc->err & (4u | 8u)) return;   // on hold / void: the level of the observation the series holds at stays in place
+  if (sc->err & (4u | 8u | 16u)) return;   // on hold / void: the level of the observation the series holds at stays in place
   unsigned long long key = 0ull;
   for (int r = 0; r < world; ++r) { const unsigned long long k = all5[5 * r + 4]; key = (k > key) ? k : key; }
   sc->gmax = cssm_order_unkey(key);
@@ -196,7 +197,7 @@ static int shard_sums_impl(cssm_pf* pf, const uint64_t* all_sums5_dev, int world
   if (!sums5_dev) {
     prof_begin(pf, CSSM_K_TILE_SUMS);
     hipLaunchKernelGGL(k_tile_sums, dim3(tgrid), dim3(CSSM_BLOCK), 0, pf->stream, pf->logw, pf->n, pf->sc, pf->tileS, pf->tileS2, pf->ntiles,
-                       pf->sup, pf->nunits, 0, -1, (const double*)nullptr, pf->d_logtab, (const StepRec*)(pf->d_recs + slot), 12u,
+                       pf->sup, pf->nunits, 0, -1, (const double*)nullptr, pf->d_logtab, (const StepRec*)(pf->d_recs + slot), 28u,
                        (const unsigned long long*)all_sums5_dev, world);
     prof_end(pf);
     HIP_TRY(hipGetLastError());
@@ -211,10 +212,10 @@ static int shard_sums_impl(cssm_pf* pf, const uint64_t* all_sums5_dev, int world
   // (every kernel here returns at once while the series is on hold after a capacity miss or void: the level, the unit sums
   //  and the exported words of the observation it holds at are what cssm_pf_shard_resume's caller continues from)
   hipLaunchKernelGGL(k_tile_sums, dim3(tgrid), dim3(CSSM_BLOCK), 0, pf->stream, pf->logw, pf->n, pf->sc, pf->tileS, pf->tileS2, pf->ntiles,
-                     pf->sup, pf->nunits, 0, -1, (const double*)nullptr, pf->d_logtab, (const StepRec*)(pf->d_recs + slot), 12u);
+                     pf->sup, pf->nunits, 0, -1, (const double*)nullptr, pf->d_logtab, (const StepRec*)(pf->d_recs + slot), 28u);
   // word 4 (the max key) of sums5_dev is left as shard_propagate wrote it
   hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(1024), 0, pf->stream, pf->tileS, pf->tileS2, pf->tileP, pf->nunits, pf->sc, pf->n_global, 0,
-                     (double*)nullptr, (int32_t*)nullptr, 0u, (const double*)nullptr, (unsigned long long*)sums5_dev, 0, 12u, 1);
+                     (double*)nullptr, (int32_t*)nullptr, 0u, (const double*)nullptr, (unsigned long long*)sums5_dev, 0, 28u, 1);
   prof_end(pf);
   HIP_TRY(hipGetLastError());
   pf->last_optimistic = false;
@@ -299,7 +300,7 @@ static int shard_prepare_step(cssm_pf* pf, const StepRec* d_rec, int weighted, u
     // (LGCP -- !last_optimistic -- forms no sums in k_propagate: only the max travels, the sums read as zero.  On hold the
     //  kernel does nothing: the max slots were exported and cleared by the observation the series holds at.)
     hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(1024), 0, pf->stream, pf->tileS, pf->tileS2, pf->tileP, nsub, pf->sc, pf->n_global, 0,
-                       (double*)nullptr, (int32_t*)nullptr, 0u, (const double*)nullptr, (unsigned long long*)sums5_dev, 1, 12u,
+                       (double*)nullptr, (int32_t*)nullptr, 0u, (const double*)nullptr, (unsigned long long*)sums5_dev, 1, 28u,
                        pf->last_optimistic ? 1 : 0);
     HIP_TRY(hipGetLastError());
   }
@@ -432,10 +433,14 @@ extern "C" int64_t cssm_pf_shard_spec_segment(const cssm_pf* pf, int64_t cap) {
   return (pf && cap >= 1) ? (int64_t)spec_seg(pf->d, (long long)cap) : 0;
 }
 
+static int boundary_pack_impl(cssm_pf* pf, int rank, int world, int64_t cap, double* send_buf_dev, bool peer);
 extern "C" int cssm_pf_shard_boundary_pack(cssm_pf* pf, int rank, int world, int64_t cap, double* send_buf_dev) {
   int rc = shard_check(pf);
   if (rc) return rc;
   if (!send_buf_dev) return fail(CSSM_EINVAL_ARG, "null argument");
+  return boundary_pack_impl(pf, rank, world, cap, send_buf_dev, false);
+}
+static int boundary_pack_impl(cssm_pf* pf, int rank, int world, int64_t cap, double* send_buf_dev, bool peer) {
   if (cap < 1 || world < 1 || world > 64 || rank < 0 || rank >= world) return fail(CSSM_ESHARD, "rank %d / world %d / cap %lld", rank, world, (long long)cap);
   // !last_optimistic: the sums were formed by cssm_pf_shard_sums relative to the level chosen with the all-gathered max
   const size_t slot = last_rec_slot(pf);
@@ -447,17 +452,22 @@ extern "C" int cssm_pf_shard_boundary_pack(cssm_pf* pf, int rank, int world, int
   hipLaunchKernelGGL(k_boundary_pack, dim3(tiles + 2, world), dim3(CSSM_BLOCK), 0, pf->stream, pf->state[pf->cur], pf->stride, pf->logw, pf->n, pf->d,
                      world, rank, (long long)cap, pf->d_recs + slot, (const cssm_u128*)pf->tileS, (const cssm_u128*)pf->tileS2, nsub,
                      (const Scalars*)pf->sc, send_buf_dev, chunk, pf->last_optimistic ? 0 : 1,
-                     (pf->split == 1 && nsub <= 4u * CSSM_BLOCK) ? pf->unitPre : (cssm_u128*)nullptr);
+                     (pf->split == 1 && nsub <= 4u * CSSM_BLOCK) ? pf->unitPre : (cssm_u128*)nullptr,
+                     peer ? (const PeerTable*)pf->peer_tab : (const PeerTable*)nullptr, (int)(pf->peer_seq & 1u), pf->peer_seq, pf->peer_tickets);
   pf->spec_pre = (pf->split == 1 && nsub <= 4u * CSSM_BLOCK);   // (k_offspring_expand_spec reads them: cssm_pf_shard_adopt_spec)
   prof_end(pf);
   HIP_TRY(hipGetLastError());
   return CSSM_OK;
 }
 
+static int adopt_spec_impl(cssm_pf* pf, const double* recv_buf_dev, int rank, int world, int64_t cap, const unsigned int* peer_flags, uint32_t peer_seq);
 extern "C" int cssm_pf_shard_adopt_spec(cssm_pf* pf, const double* recv_buf_dev, int rank, int world, int64_t cap) {
   int rc = shard_check(pf);
   if (rc) return rc;
   if (!recv_buf_dev) return fail(CSSM_EINVAL_ARG, "recv_buf_dev is null");
+  return adopt_spec_impl(pf, recv_buf_dev, rank, world, cap, nullptr, 0u);
+}
+static int adopt_spec_impl(cssm_pf* pf, const double* recv_buf_dev, int rank, int world, int64_t cap, const unsigned int* peer_flags, uint32_t peer_seq) {
   if (cap < 1 || world < 1 || world > 64 || rank < 0 || rank >= world) return fail(CSSM_ESHARD, "rank %d / world %d / cap %lld", rank, world, (long long)cap);
   const uint64_t n_per = (pf->n_global + (uint64_t)world - 1) / (uint64_t)world;
   if (pf->first != (uint64_t)rank * n_per) return fail(CSSM_ESHARD, "rank %d must own particles from %llu", rank, (unsigned long long)((uint64_t)rank * n_per));
@@ -474,14 +484,16 @@ extern "C" int cssm_pf_shard_adopt_spec(cssm_pf* pf, const double* recv_buf_dev,
                      pf->anc, pf->ntiles, pf->sup, pf->nunits, pf->last_optimistic ? 2 : 0, 0, (double*)nullptr, (int32_t*)nullptr, 0u, pf->opt_exact,
                      all5, rank, world, (int)pf->split, pf->seed, (double*)nullptr, (const double*)pf->d_logtab,
                      pf->last_optimistic ? 2 : 0, (unsigned long long*)(pf->d_xch + 128), (uint32_t)pf->first, (uint32_t)(pf->first + pf->n), (uint32_t)seg,
-                     recv_buf_dev, (long long)cap, pf->d, n_split, pf->spec_pre ? (const cssm_u128*)pf->unitPre : (const cssm_u128*)nullptr);
+                     recv_buf_dev, (long long)cap, pf->d, n_split, pf->spec_pre ? (const cssm_u128*)pf->unitPre : (const cssm_u128*)nullptr,
+                     peer_flags, peer_seq);
   } else {
     hipLaunchKernelGGL(k_offspring_expand_spec<0>, dim3(tgrid), dim3(CSSM_BLOCK), 0, pf->stream, pf->logw, pf->n, pf->sc,
                      (const cssm_u128*)pf->tileS, (const cssm_u128*)pf->tileS2, (const StepRec*)(pf->d_recs + slot), pf->n_global, pf->endslot,
                      pf->anc, pf->ntiles, pf->sup, pf->nunits, pf->last_optimistic ? 2 : 0, 0, (double*)nullptr, (int32_t*)nullptr, 0u, pf->opt_exact,
                      all5, rank, world, (int)pf->split, pf->seed, (double*)nullptr, (const double*)pf->d_logtab,
                      pf->last_optimistic ? 2 : 0, (unsigned long long*)(pf->d_xch + 128), (uint32_t)pf->first, (uint32_t)(pf->first + pf->n), (uint32_t)seg,
-                     recv_buf_dev, (long long)cap, pf->d, n_split, pf->spec_pre ? (const cssm_u128*)pf->unitPre : (const cssm_u128*)nullptr);
+                     recv_buf_dev, (long long)cap, pf->d, n_split, pf->spec_pre ? (const cssm_u128*)pf->unitPre : (const cssm_u128*)nullptr,
+                     peer_flags, peer_seq);
   }
   prof_end(pf);
   HIP_TRY(hipGetLastError());
@@ -510,7 +522,170 @@ extern "C" int cssm_pf_shard_status(cssm_pf* pf, double* ll_out, int32_t* ess_ou
   if (ess_out) *ess_out = h.ess;
   if (bits_out) *bits_out = h.err & 12u;
   h.err &= ~12u;
+  if (h.err & 16u) return fail(CSSM_ESHARD, "peer-written exchange: a rank's segment of observation %u did not arrive within the wait bound "
+                                            "(a peer that died, or never enqueued its series?)", h.fail_step);
   return cssm_check_device_err(pf, h);
+}
+
+// ------------------------------------------------------------------------------------ peer-written exchange
+// (kernel side and protocol: PeerTable in cssm_shard_kernels.hip.h.)  Every rank allocates ONE slab -- two receive windows of
+// `world` segments each, then two sets of flags -- and hands out a cssm_peer_handle for it; cssm_pf_shard_peer_connect maps the
+// other ranks' slabs (hipIpcOpenMemHandle; the plain pointer where the owner lives in this process: several shards of one
+// process, or the rank itself) and fills the device table the pack kernel reads.
+struct PeerState {
+  int world = 0, rank = 0;
+  int64_t cap = 0;
+  size_t seg = 0, win_bytes = 0, slab_bytes = 0;
+  void* slab = nullptr;                 // own: [window 0 | window 1 | flags 0 | flags 1]
+  bool slab_fine = false;
+  void* mapped[64] = {nullptr};         // peers' slabs as this process sees them
+  bool opened[64] = {false};            // ... through hipIpcOpenMemHandle (to be closed)
+  bool connected = false;
+};
+static size_t peer_flags_bytes(int world) { return (size_t)world * CSSM_PEER_FLAG_STRIDE * sizeof(unsigned int); }
+static double* peer_window(const PeerState* ps, void* slab, int p) { return reinterpret_cast<double*>(static_cast<char*>(slab) + (size_t)p * ps->win_bytes); }
+static unsigned int* peer_flagset(const PeerState* ps, void* slab, int p) {
+  return reinterpret_cast<unsigned int*>(static_cast<char*>(slab) + 2 * ps->win_bytes + (size_t)p * peer_flags_bytes(ps->world));
+}
+void cssm_peer_free(cssm_pf* pf) {
+  PeerState* ps = static_cast<PeerState*>(pf->peer);
+  if (!ps) return;
+  for (int q = 0; q < 64; ++q) if (ps->opened[q] && ps->mapped[q]) (void)hipIpcCloseMemHandle(ps->mapped[q]);
+  if (ps->slab) (void)hipFree(ps->slab);
+  if (pf->peer_tab) (void)hipFree(pf->peer_tab);
+  if (pf->peer_tickets) (void)hipFree(pf->peer_tickets);
+  pf->peer_tab = nullptr; pf->peer_tickets = nullptr;
+  delete ps;
+  pf->peer = nullptr;
+}
+
+extern "C" int cssm_pf_shard_peer_setup(cssm_pf* pf, int rank, int world, int64_t cap, cssm_peer_handle* mine_out) {
+  int rc = shard_check(pf);
+  if (rc) return rc;
+  if (!mine_out) return fail(CSSM_EINVAL_ARG, "null argument");
+  if (cap < 1 || world < 1 || world > 64 || rank < 0 || rank >= world) return fail(CSSM_ESHARD, "rank %d / world %d / cap %lld", rank, world, (long long)cap);
+  rc = bounded_sync(pf);   // (windows of an earlier setup may still be gathered from)
+  if (rc) return rc;
+  if (pf->src2 && pf->peer && static_cast<PeerState*>(pf->peer)->slab) {
+    // the current cloud may still point into the old windows (ancestors of the last exchange): materialise nothing, refuse
+    const PeerState* old = static_cast<PeerState*>(pf->peer);
+    const char* a = static_cast<const char*>(old->slab);
+    if (reinterpret_cast<const char*>(pf->src2) >= a && reinterpret_cast<const char*>(pf->src2) < a + old->slab_bytes)
+      return fail(CSSM_ESTATE, "the cloud still reads rows of the current peer windows: set the windows up before the series (or with the same capacity)");
+  }
+  cssm_peer_free(pf);
+  PeerState* ps = new PeerState();
+  pf->peer = ps;
+  ps->world = world; ps->rank = rank; ps->cap = cap;
+  ps->seg = (size_t)spec_seg(pf->d, (long long)cap);
+  ps->win_bytes = ((size_t)world * ps->seg * sizeof(double) + 255) / 256 * 256;
+  ps->slab_bytes = 2 * ps->win_bytes + 2 * peer_flags_bytes(world);
+  // fine-grained device memory (visible to peers while a kernel runs; not held in this GPU's L2 across the peers' writes);
+  // plain device memory if the runtime refuses (single-GPU use is indifferent)
+  static const bool coarse = getenv("CSSM_PEER_COARSE") != nullptr;
+  if (!coarse && hipExtMallocWithFlags(&ps->slab, ps->slab_bytes, hipDeviceMallocFinegrained) == hipSuccess) ps->slab_fine = true;
+  else { (void)hipGetLastError(); if (hipMalloc(&ps->slab, ps->slab_bytes) != hipSuccess) { ps->slab = nullptr; cssm_peer_free(pf); return fail(CSSM_ENOMEM, "peer windows (%zu bytes)", ps->slab_bytes); } }
+  HIP_TRY(hipMemsetAsync(ps->slab, 0, ps->slab_bytes, pf->stream));
+  HIP_TRY(hipMalloc(&pf->peer_tab, sizeof(PeerTable)));
+  HIP_TRY(hipMalloc(&pf->peer_tickets, 64 * sizeof(unsigned int)));
+  HIP_TRY(hipMemsetAsync(pf->peer_tickets, 0, 64 * sizeof(unsigned int), pf->stream));
+  HIP_TRY(hipStreamSynchronize(pf->stream));
+  memset(mine_out, 0, sizeof *mine_out);
+  mine_out->pid = (uint64_t)getpid();
+  mine_out->local_ptr = (uint64_t)(uintptr_t)ps->slab;
+  mine_out->bytes = (uint64_t)ps->slab_bytes;
+  mine_out->device = pf->device;
+  hipIpcMemHandle_t h;
+  if (hipIpcGetMemHandle(&h, ps->slab) == hipSuccess) { memcpy(mine_out->ipc, &h, sizeof h); mine_out->has_ipc = 1; }
+  else { (void)hipGetLastError(); mine_out->has_ipc = 0; }   // (usable inside this process only)
+  return CSSM_OK;
+}
+
+extern "C" int cssm_pf_shard_peer_connect(cssm_pf* pf, const cssm_peer_handle* all, int world) {
+  int rc = shard_check(pf);
+  if (rc) return rc;
+  PeerState* ps = static_cast<PeerState*>(pf->peer);
+  if (!ps || !ps->slab) return fail(CSSM_ESTATE, "cssm_pf_shard_peer_connect before cssm_pf_shard_peer_setup");
+  if (!all || world != ps->world) return fail(CSSM_ESHARD, "peer handles of %d ranks expected", ps->world);
+  const uint64_t me = (uint64_t)getpid();
+  PeerTable tab;
+  memset(&tab, 0, sizeof tab);
+  for (int q = 0; q < world; ++q) {
+    if (all[q].bytes != (uint64_t)ps->slab_bytes) return fail(CSSM_ESHARD, "rank %d set its windows up for another capacity or world (%llu bytes, %zu here)", q, (unsigned long long)all[q].bytes, ps->slab_bytes);
+    void* base = nullptr;
+    if (q == ps->rank) base = ps->slab;
+    else if (all[q].pid == me) base = (void*)(uintptr_t)all[q].local_ptr;       // a shard of this process
+    else {
+      if (!all[q].has_ipc) return fail(CSSM_ESHARD, "rank %d exported no IPC handle for its windows", q);
+      hipIpcMemHandle_t h;
+      memcpy(&h, all[q].ipc, sizeof h);
+      const hipError_t e = hipIpcOpenMemHandle(&base, h, hipIpcMemLazyEnablePeerAccess);
+      if (e != hipSuccess) { (void)hipGetLastError(); return fail(CSSM_EHIP, "hipIpcOpenMemHandle of rank %d's windows: %s", q, hipGetErrorString(e)); }
+      ps->opened[q] = true;
+    }
+    ps->mapped[q] = base;
+    for (int p = 0; p < 2; ++p) { tab.win[p][q] = peer_window(ps, base, p); tab.flag[p][q] = peer_flagset(ps, base, p); }
+  }
+  HIP_TRY(hipMemcpy(pf->peer_tab, &tab, sizeof tab, hipMemcpyHostToDevice));
+  ps->connected = true;
+  return CSSM_OK;
+}
+
+extern "C" void cssm_pf_shard_peer_close(cssm_pf* pf) {
+  if (!pf) return;
+  (void)hipSetDevice(pf->device);
+  if (pf->stream) (void)hipStreamSynchronize(pf->stream);
+  if (pf->peer && pf->src2) {   // the cloud must not keep pointing into windows that are about to go
+    const PeerState* ps = static_cast<PeerState*>(pf->peer);
+    const char* a = static_cast<const char*>(ps->slab);
+    if (a && reinterpret_cast<const char*>(pf->src2) >= a && reinterpret_cast<const char*>(pf->src2) < a + ps->slab_bytes) pf->initialised = false;
+  }
+  cssm_peer_free(pf);
+}
+
+// Stage calls of the peer-written exchange (the library's own loop below, and a host that drives several shards of one process):
+// cssm_pf_shard_pack_peer = k_boundary_pack writing into the peers' windows + flags; cssm_pf_shard_adopt_peer = k_offspring_expand_spec
+// on this rank's window of the same exchange, behind the flags.  Both use the handle's exchange counter: one pack, then one
+// adopt, per weighted observation, on every rank alike.
+extern "C" int cssm_pf_shard_pack_peer(cssm_pf* pf, int rank, int world, int64_t cap) {
+  int rc = shard_check(pf);
+  if (rc) return rc;
+  PeerState* ps = static_cast<PeerState*>(pf->peer);
+  if (!ps || !ps->connected) return fail(CSSM_ESTATE, "peer windows are not set up (cssm_pf_shard_peer_setup / _connect)");
+  if (rank != ps->rank || world != ps->world || cap != ps->cap) return fail(CSSM_ESHARD, "peer windows were set up for rank %d / world %d / cap %lld", ps->rank, ps->world, (long long)ps->cap);
+  if (pf->peer_packed) return fail(CSSM_ESTATE, "cssm_pf_shard_pack_peer twice without cssm_pf_shard_adopt_peer");
+  pf->peer_seq++;
+  pf->peer_packed = true;
+  return boundary_pack_impl(pf, rank, world, cap, nullptr, true);
+}
+extern "C" int cssm_pf_shard_adopt_peer(cssm_pf* pf, int rank, int world, int64_t cap) {
+  int rc = shard_check(pf);
+  if (rc) return rc;
+  PeerState* ps = static_cast<PeerState*>(pf->peer);
+  if (!ps || !ps->connected) return fail(CSSM_ESTATE, "peer windows are not set up (cssm_pf_shard_peer_setup / _connect)");
+  if (rank != ps->rank || world != ps->world || cap != ps->cap) return fail(CSSM_ESHARD, "peer windows were set up for rank %d / world %d / cap %lld", ps->rank, ps->world, (long long)ps->cap);
+  if (!pf->peer_packed) return fail(CSSM_ESTATE, "cssm_pf_shard_adopt_peer without cssm_pf_shard_pack_peer");
+  pf->peer_packed = false;
+  const int p = (int)(pf->peer_seq & 1u);
+  return adopt_spec_impl(pf, peer_window(ps, ps->slab, p), rank, world, cap, peer_flagset(ps, ps->slab, p), pf->peer_seq);
+}
+// The series loop on the peer-written exchange: per weighted observation propagate -> pack into the peers' windows -> offspring +
+// expansion behind the flags; three launches, no collective, no host wait.  (Observations whose level comes from the global max --
+// the first event of an LGCP series, a repeated series -- and resumed exchanges go through the RCCL / host-driven exchange.)
+extern "C" int cssm_pf_shard_series_peer(cssm_pf* pf, int rank, int world, size_t s_begin, size_t s_end, const uint8_t* weighted, int64_t cap) {
+  int rc = shard_check(pf);
+  if (rc) return rc;
+  if (!weighted) return fail(CSSM_EINVAL_ARG, "null argument");
+  for (size_t s = s_begin; s < s_end; ++s) {
+    rc = cssm_pf_shard_propagate_at(pf, s, nullptr);
+    if (rc) return rc;
+    if (!weighted[s]) continue;
+    rc = cssm_pf_shard_pack_peer(pf, rank, world, cap);
+    if (rc) return rc;
+    rc = cssm_pf_shard_adopt_peer(pf, rank, world, cap);
+    if (rc) return rc;
+  }
+  return CSSM_OK;
 }
 
 // ------------------------------------------------------------------------------------ series loop over RCCL, in the library

@@ -63,14 +63,34 @@ __host__ __device__ __forceinline__ long long spec_hdr(int d) { return (long lon
 __host__ __device__ __forceinline__ long long spec_capP(int d, long long cap) { return (long long)(d + 1) * ((cap + d) / (d + 1)); }
 __host__ __device__ __forceinline__ long long spec_seg(int d, long long cap) { return spec_hdr(d) + cap * (d + 1) + spec_capP(d, cap); }
 
+// PEER-WRITTEN exchange: instead of filling a send buffer for an all-to-all, the segments are written
+// straight into the DESTINATION ranks' receive windows -- peer-mapped device memory (hipIpcOpenMemHandle across processes; plain
+// pointers where the shards share a process) -- and a flag per (window, source rank) tells the destination's
+// k_offspring_expand_spec that the segment is complete: no collective launch per observation.  Two windows alternate by exchange
+// number (the rows of exchange e are gathered from by the propagate of the NEXT observation while exchange e + 1 is written).
+// Protocol, per destination q: every block that wrote part of segment rank -> q makes its stores visible at SYSTEM scope
+// (__threadfence_system by every thread, then the block barrier), takes a ticket on a LOCAL counter, and the block that takes the last one
+// stores the exchange number into q's flag with system-scope release.  The reader polls with system-scope loads, bounded, and
+// reads the window with system-scope loads as well (ld_sys: no fence -- an L2 invalidate per wave of a 1024-block kernel cost 34 us).
+struct PeerTable {
+  double* win[2][64];              // win[p][q]: base of rank q's receive window p (world segments; segment r = what rank r wrote)
+  unsigned int* flag[2][64];       // flag[p][q]: rank q's flags of window p, one 64-byte line per source rank
+};
+#define CSSM_PEER_FLAG_STRIDE 16   /* uint32 words between the flags of consecutive source ranks (one line each) */
+#define CSSM_PEER_SPIN_LIMIT (1u << 22)   /* polls (~1 us each) before a reader gives up: err bit 4 (16) */
+
 // grid (tiles of the block + 1 for the header, destination rank); the weights are those k_propagate<SUMS> summed and stored,
 // exp(min(w - c, REF_BELOW)) -- or, with the level taken from the global max, exp(w - level) of the stored log-weights
+// peer != nullptr: the peer-written exchange -- `out` unused, segment rank -> q lands in peer->win[parity][q] + rank * seg,
+// tickets[q] counts the finished blocks of destination q (left at zero again by the block that takes the last ticket)
 __global__ __launch_bounds__(CSSM_BLOCK) void k_boundary_pack(const double* __restrict__ src, size_t stride, const double* __restrict__ logw,
                                                               uint64_t n_local, int d, int world, int rank, long long cap,
                                                               const StepRec* __restrict__ rec, const cssm_u128* __restrict__ subS,
                                                               const cssm_u128* __restrict__ subS2, uint32_t nsub,
                                                               const Scalars* __restrict__ sc, double* __restrict__ out, uint64_t chunk,
-                                                              int level_from_max, cssm_u128* __restrict__ pre_out) {
+                                                              int level_from_max, cssm_u128* __restrict__ pre_out,
+                                                              const PeerTable* __restrict__ peer = nullptr, int parity = 0, uint32_t seq = 0u,
+                                                              unsigned int* __restrict__ tickets = nullptr) {
   // pre_out (nsub <= 4 * CSSM_BLOCK, else nullptr): the header block of segment 0 also writes the EXCLUSIVE prefix of the sub-unit
   // sums -- pre_out[j] = subS[0] + .. + subS[j - 1] -- which k_offspring_expand_spec's block j then reads as one word instead of
   // summing j entries itself (on average 8 KiB per block and a block-wide sum with two barriers)
@@ -80,11 +100,26 @@ __global__ __launch_bounds__(CSSM_BLOCK) void k_boundary_pack(const double* __re
   // chunk = particles per sub-unit sum of k_propagate (subS): when the tiles of the carried block coincide with
   // sub-units, the prefix of the tiles before a block's own is read from subS instead of being recomputed
   __shared__ cssm_u128 s_w[CSSM_BLOCK / 64], s_r[2][CSSM_BLOCK / 64];
-  if (sc->err & (4u | 8u)) return;   // the series is on hold (capacity miss) or void (level ruled out): nothing may change
+  if (sc->err & (4u | 8u | 16u)) return;   // the series is on hold (capacity miss) or void (level ruled out): nothing may change
   const int q = blockIdx.y;
   const long long R = d + 1, HD = spec_hdr(d), seg = spec_seg(d, cap);
-  double* oseg = out + (size_t)q * seg;
+  double* oseg = peer ? peer->win[parity][q] + (size_t)rank * seg : out + (size_t)q * seg;
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  // peer-written exchange: this block's part of segment rank -> q is done (all threads call; see PeerTable)
+  auto peer_done = [&]() {
+    if (peer == nullptr) return;
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      const unsigned int nblk = gridDim.x - 1u;          // (every block of this destination but the prefix block)
+      const unsigned int t = atomicAdd(&tickets[q], 1u);
+      if (t + 1u == nblk) {
+        tickets[q] = 0u;                                  // (the next launch on this stream starts from zero)
+        __threadfence_system();
+        __hip_atomic_store(peer->flag[parity][q] + (size_t)rank * CSSM_PEER_FLAG_STRIDE, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+      }
+    }
+  };
   // only the two adjacent ranks can own slots of this rank's boundary particles (k_offspring_expand_spec's verdict refuses
   // anything else), so only their segments carry rows; every other segment is its header
   const long long cnt = (q == rank + 1 || q == rank - 1) ? ((long long)n_local < cap ? (long long)n_local : cap) : 0;
@@ -132,7 +167,7 @@ __global__ __launch_bounds__(CSSM_BLOCK) void k_boundary_pack(const double* __re
   }
   const bool header_block = (blockIdx.x == gridDim.x - 2);
   if (!header_block) {
-  if (cnt == 0) return;
+  if (cnt == 0) { peer_done(); return; }
   // prefix of the tiles before this block's tile
   cssm_u128 toff = cssm_u128_zero();
   // The carried block starts on a boundary of the sub-units whose sums k_propagate (or k_tile_sums) formed -- chunk particles
@@ -188,6 +223,7 @@ __global__ __launch_bounds__(CSSM_BLOCK) void k_boundary_pack(const double* __re
       oseg[HD + cap * R + (long long)i] = cssm_u2d(run.hi);
     }
   }
+  peer_done();
   return;
   }
   // header: the rank's totals of the sub-unit sums k_propagate formed, the key of its max, base.  Everything it reads is
@@ -267,6 +303,7 @@ __global__ __launch_bounds__(CSSM_BLOCK) void k_boundary_pack(const double* __re
     oseg[8] = cssm_u2d(ptot[0].lo); oseg[9] = cssm_u2d(ptot[0].hi);
     oseg[10] = cssm_u2d(ptot[1].lo); oseg[11] = cssm_u2d(ptot[1].hi);
   }
+  peer_done();
 }
 
 // After the all-to-all: every segment's rows -> the slots of this rank they own.  Global cumulative weight of row i of
@@ -294,7 +331,8 @@ __device__ __forceinline__ SpecHdrRegs spec_load_headers(const double* __restric
   for (int k = 0; k < 9; ++k) g.w[k] = 0.0;
   if ((int)threadIdx.x < world) {
     const double* h = recv + (size_t)threadIdx.x * spec_seg(d, cap);
-    g.w[0] = h[0]; g.w[1] = h[1]; g.w[2] = h[2]; g.w[3] = h[6]; g.w[4] = h[7]; g.w[5] = h[8]; g.w[6] = h[9]; g.w[7] = h[10]; g.w[8] = h[11];
+    g.w[0] = ld_sys_f64(h); g.w[1] = ld_sys_f64(h + 1); g.w[2] = ld_sys_f64(h + 2); g.w[3] = ld_sys_f64(h + 6); g.w[4] = ld_sys_f64(h + 7);
+    g.w[5] = ld_sys_f64(h + 8); g.w[6] = ld_sys_f64(h + 9); g.w[7] = ld_sys_f64(h + 10); g.w[8] = ld_sys_f64(h + 11);
   }
   return g;
 }
@@ -397,13 +435,13 @@ __device__ __forceinline__ void expand_spec_body(SpecHeaders& H, uint32_t bid, u
       if (s >= 0 && s < world && i < H.cnt[s]) {
         const double* h = recv + (size_t)s * seg;
         const cssm_u128 off = cssm_u128_add(H.off[s], H.base[s]);
-        cssm_u128 P; P.lo = cssm_d2u(h[HD + i * R + d]); P.hi = cssm_d2u(h[HD + cap * R + i]);
+        cssm_u128 P; P.lo = cssm_d2u(ld_sys_f64(h + HD + i * R + d)); P.hi = cssm_d2u(ld_sys_f64(h + HD + cap * R + i));
         uint64_t e = count_of(cssm_u128_add(off, P));
         uint64_t b;
         if (i == 0) {
           b = count_of(off);
         } else {
-          cssm_u128 Pp; Pp.lo = cssm_d2u(h[HD + (i - 1) * R + d]); Pp.hi = cssm_d2u(h[HD + cap * R + (i - 1)]);
+          cssm_u128 Pp; Pp.lo = cssm_d2u(ld_sys_f64(h + HD + (i - 1) * R + d)); Pp.hi = cssm_d2u(ld_sys_f64(h + HD + cap * R + (i - 1)));
           b = count_of(cssm_u128_add(off, Pp));
         }
         if (b < slot_lo) b = slot_lo;
@@ -447,19 +485,44 @@ __device__ unsigned long long g_spec_stamps[2048 * 8];   // diagnostic build: cl
 template <int RAWC>
 __global__ __launch_bounds__(CSSM_BLOCK, CSSM_OFF_WAVES) void k_offspring_expand_spec(
     CSSM_OFFSPRING_PARAMS, uint32_t all5_stride, const double* __restrict__ recv, long long cap, int d, uint32_t n_split,
-    const cssm_u128* __restrict__ unit_pre) {
+    const cssm_u128* __restrict__ unit_pre, const unsigned int* __restrict__ peer_flags = nullptr, uint32_t peer_seq = 0u) {
   // unit_pre (or nullptr): the exclusive prefixes of the unit sums k_boundary_pack's header block left (its pre_out)
+  // peer_flags (peer-written exchange; else nullptr): this rank's flags of the window `recv` is -- one line per source rank; the
+  // segment of rank r is complete once its flag holds peer_seq (PeerTable).  Every block waits for every rank's flag (thread r
+  // polls rank r's, system-scope acquire, bounded): a rank that never delivers raises err bit 4 (16) here instead of hanging the
+  // GPU, and the series ends like one on hold.
   __shared__ SpecHeaders H;
   CSSM_SPEC_STAMP(0);
+  if (peer_flags != nullptr) {
+    __shared__ unsigned int s_late;
+    if (sc->err & (4u | 8u | 16u)) return;   // (on hold / void / a peer missing: nobody delivers, nobody waits)
+    if (threadIdx.x == 0) s_late = 0u;
+    __syncthreads();
+    if ((int)threadIdx.x < world) {
+      const unsigned int* f = peer_flags + (size_t)threadIdx.x * CSSM_PEER_FLAG_STRIDE;
+      unsigned int spins = 0u;
+      // (relaxed system-scope loads: each one reads the flag at the point of coherence; the window itself is read with such loads
+      //  too -- ld_sys, no fence: see there -- and the next kernel's gathers start behind a kernel boundary)
+      while (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != peer_seq) {
+        if (++spins > CSSM_PEER_SPIN_LIMIT) { s_late = 1u; break; }
+        __builtin_amdgcn_s_sleep(8);
+      }
+    }
+    __syncthreads();
+    if (s_late) {
+      if (threadIdx.x == 0) { atomicOr(&sc->err, 16u); atomicMin(&sc->fail_step, rec->step); }
+      return;
+    }
+  }
   // everything the verdict starts from is requested first, tested afterwards
   const uint32_t held = sc->err;
   const double rec_ref = rec->ref, rec_u = rec->u;
   unsigned long long key = 0ull;
-  if (optimistic) for (int r = 0; r < world; ++r) { const unsigned long long k = all5[(size_t)all5_stride * r + 4]; key = (k > key) ? k : key; }
+  if (optimistic) for (int r = 0; r < world; ++r) { const unsigned long long k = ld_sys_u64(all5 + (size_t)all5_stride * r + 4); key = (k > key) ? k : key; }
   const SpecHdrRegs hregs = spec_load_headers(recv, world, cap, d);
   // (measured and dropped: the weights of the block's first tile requested here as well, ahead of the verdict -- 11.8 -> 12.3 us at
   //  2^20 per rank, eight more registers live across the verdict)
-  if (held & (4u | 8u)) return;
+  if (held & (4u | 8u | 16u)) return;
   if (optimistic) {
     // the level first: sums formed relative to a reference level that the global max rules out (an outlying observation) say
     // nothing about coverage either.  Sticky bit 2 (4): every later kernel of the series returns at once, the host runs

@@ -166,6 +166,37 @@ class GpuShard:
                                                       C.c_void_p(send_buf.data_ptr()), C.c_void_p(recv_buf.data_ptr()),
                                                       int(single_collective)))
 
+    # ---- peer-written exchange (cssm_pf_shard_peer_*): segments written straight into the other ranks' receive windows
+    def peer_setup(self, cap: int) -> "_abi.PeerHandle":
+        h = _abi.PeerHandle()
+        _abi.check(self.lib.cssm_pf_shard_peer_setup(self._h, self.rank, self.world, int(cap), C.byref(h)))
+        self._peer_cap = int(cap)
+        return h
+
+    def peer_connect(self, handles: Sequence["_abi.PeerHandle"]):
+        arr = (_abi.PeerHandle * len(handles))(*handles)
+        _abi.check(self.lib.cssm_pf_shard_peer_connect(self._h, arr, len(handles)))
+        self._peer_ready = True
+
+    def peer_ready(self, cap: int) -> bool:
+        return bool(getattr(self, "_peer_ready", False)) and getattr(self, "_peer_cap", None) == int(cap)
+
+    def peer_close(self):
+        self.lib.cssm_pf_shard_peer_close(self._h)
+        self._peer_ready = False
+
+    def pack_peer(self, cap: int):
+        _abi.check(self.lib.cssm_pf_shard_pack_peer(self._h, self.rank, self.world, int(cap)))
+
+    def adopt_peer(self, cap: int):
+        _abi.check(self.lib.cssm_pf_shard_adopt_peer(self._h, self.rank, self.world, int(cap)))
+
+    def series_peer(self, s_begin: int, s_end: int, weighted: np.ndarray, cap: int):
+        """Observations [s_begin, s_end) on the peer-written exchange, enqueued by the library (cssm_pf_shard_series_peer)."""
+        w = np.ascontiguousarray(weighted, dtype=np.uint8)
+        _abi.check(self.lib.cssm_pf_shard_series_peer(self._h, self.rank, self.world, int(s_begin), int(s_end),
+                                                      w.ctypes.data_as(C.POINTER(C.c_uint8)), int(cap)))
+
     def resume(self) -> int:
         """After a capacity miss of the single-collective series: the observation that missed (its propagate is done,
         its resampling is not); the sticky bit is cleared and the handle rewound to that point."""
@@ -265,6 +296,19 @@ class DistComm:
         self.world = dist.get_world_size(group)
         self.rank = dist.get_rank(group)
         self.device = device   # where the small agreement tensors live (the GPU under RCCL, None = CPU under gloo)
+
+    @property
+    def peer(self) -> bool:
+        """Whether the ordinary exchanges of a series run on the peer-written protocol (no collective per observation).  GPU ranks
+        only; CSSM_SHARD_PEER=0 keeps every exchange on the collectives (RCCL issued by the library, or torch.distributed)."""
+        import os
+        return self.device is not None and os.environ.get("CSSM_SHARD_PEER", "1") != "0"
+
+    def exchange_handles(self, handles: List) -> List:
+        """Every rank's peer handle (bytes), in rank order, on every rank."""
+        box = [None] * self.world
+        self.dist.all_gather_object(box, bytes(handles[0]), group=self.group)
+        return [_abi.PeerHandle.from_buffer_copy(b) for b in box]
 
     def all_gather(self, outs: List[torch.Tensor], ins: List[torch.Tensor]):
         self.dist.all_gather_into_tensor(outs[0], ins[0], group=self.group)
@@ -428,6 +472,29 @@ class ShardedFilter:
         for s, b in zip(S, recv):
             s.adopt_spec(b, cap)
 
+    def _resample_peer(self, cap: int):
+        """The same exchange on the peer-written protocol: every shard writes its segments into the other shards' windows, then
+        every shard resamples behind the flags (shards of ONE process share a stream: the order of the launches is the order
+        of the protocol; one shard per process: the flags are)."""
+        for s in self.shards:
+            s.pack_peer(cap)
+        for s in self.shards:
+            s.adopt_peer(cap)
+
+    def _ensure_peer(self, cap: int) -> bool:
+        """Windows of every local shard set up for `cap` and every rank's mapped by every other (once per capacity)."""
+        S, comm = self.shards, self.comm
+        if not all(hasattr(s, "peer_setup") for s in S):
+            return False
+        if all(s.peer_ready(cap) for s in S):
+            return True
+        mine = [s.peer_setup(cap) for s in S]
+        every = comm.exchange_handles(mine)
+        for s in S:
+            s.peer_connect(every)
+        comm.barrier()
+        return True
+
     MIN_CAP = 1024
     # capacity >= CAP_SQRT x sqrt(N_global): the number of particles whose runs cross a rank boundary is the deviation of a
     # cumulative weight from its mean, ~ sqrt(N x (N/ESS - 1)) (bench workload, 2^20 particles per rank: median 660 rows,
@@ -532,8 +599,11 @@ class ShardedFilter:
             for s in S:
                 s.begin_more(t, y, has) if cont else s.begin(t, y, has)
             cap = None if all_exact else self._capacity()
+            # the ordinary exchanges of the "ref" plan: peer-written where the communicator offers it (no collective at all), else
+            # the collectives -- issued by the library itself over RCCL where it can
+            peer = (plan == "ref") and bool(getattr(comm, "peer", False)) and self._ensure_peer(cap)
             native = None
-            if not all_exact and len(S) == 1 and hasattr(comm, "native_comm"):
+            if not all_exact and not peer and len(S) == 1 and hasattr(comm, "native_comm"):
                 native = comm.native_comm()
             mode = 2 if (self.SINGLE_MODE == 1 and os.environ.get("CSSM_SHARD_TRIM", "0") == "1") else self.SINGLE_MODE
             k, resumes, redo_exchange, redo_cap, escalated, give_up = 0, 0, False, 0, {}, False
@@ -563,6 +633,14 @@ class ShardedFilter:
                 return True
 
             while k < T and not give_up:
+                if peer and len(S) == 1 and hasattr(comm, "dist") and not redo_exchange and not (first_from_max and k == 0):
+                    # one shard per process: the library enqueues propagate, pack and offspring + expansion of a whole stretch
+                    kend = min(k + self.NATIVE_STRETCH, T)
+                    S[0].series_peer(k, kend, weighted, cap)
+                    self.last_all_to_all = "none: segments written into the peers' windows (peer-written exchange)"
+                    k = kend
+                    look_for_a_miss()
+                    continue
                 if native is not None and not redo_exchange:
                     # the library enqueues kernels and RCCL collectives itself, one stream, no host-language call per
                     # observation -- in stretches, so that a capacity miss is noticed (one status read per stretch) before
@@ -588,6 +666,8 @@ class ShardedFilter:
                 if weighted[k]:
                     if all_exact:
                         self._resample_exact(lgcp)
+                    elif peer and not redo_exchange and not fm:
+                        self._resample_peer(cap)
                     else:
                         self._resample_spec(redo_cap if redo_exchange else cap)   # (a resumed observation: its enlarged capacity)
                 redo_exchange, redo_cap = False, 0
@@ -598,6 +678,7 @@ class ShardedFilter:
             self.last_single = not all_exact
             self.last_from_max = from_max
             self.last_native = native is not None
+            self.last_peer = bool(peer)
             if give_up:
                 plans = ["exact"]
                 continue

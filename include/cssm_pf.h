@@ -471,6 +471,37 @@ int cssm_pf_shard_series_rccl(cssm_pf* pf, void* comm, int rank, int world, size
                               const uint8_t* weighted, int64_t cap, uint64_t* sums5_dev, uint64_t* all_sums5_dev,
                               double* send_buf_dev, double* recv_buf_dev, int single_collective);
 
+/* PEER-WRITTEN exchange: the same single-collective protocol without a collective.  Every rank owns two receive windows (they
+ * alternate by exchange) and a flag per (window, source rank) in ONE slab of device memory that the other ranks map
+ * (hipIpcOpenMemHandle across processes -- one process per GPU over xGMI peer access; the plain pointer where several shards share
+ * a process, and for the rank itself).  k_boundary_pack writes segment (rank -> q) -- header, and for the two adjacent ranks the
+ * boundary rows -- straight into q's window and, when the last of its blocks has made its stores visible at system scope, stores the
+ * exchange number into q's flag (release); q's k_offspring_expand_spec polls the flags of all ranks (acquire, bounded: a rank that
+ * never delivers raises a device error instead of hanging the GPU) before it reads a header.  Three launches per weighted
+ * observation -- propagate, pack, offspring + expansion -- and nothing else: no RCCL launch, no host wait.  The windows hold the
+ * capacity they were set up for; an exchange that is resumed with a larger capacity, and observations whose level comes from the
+ * global max, go through the collective exchange above (the two share every kernel and produce the same bits).
+ *   cssm_pf_shard_peer_setup    allocate this rank's slab for (world, cap); *mine_out = what the other ranks need to map it
+ *   [the host exchanges the handles: every rank receives all `world` of them, in rank order]
+ *   cssm_pf_shard_peer_connect  map them, build the device table
+ *   cssm_pf_shard_series_peer   observations [s_begin, s_end) of the resident series (cssm_pf_shard_begin / _continue), or stage
+ *                               by stage: cssm_pf_shard_propagate_at(s, NULL), cssm_pf_shard_pack_peer, cssm_pf_shard_adopt_peer
+ *   cssm_pf_shard_peer_close    unmap and free (also done by cssm_pf_destroy)
+ * model/ParticleFilter.scala:116-132 is the step whose resampling this exchange completes across GPUs. */
+typedef struct cssm_peer_handle {
+  char ipc[64];          /* hipIpcMemHandle_t of the slab (valid if has_ipc) */
+  uint64_t pid;          /* owner process: a rank of the same process uses local_ptr instead of the IPC handle */
+  uint64_t local_ptr;    /* the slab's address in the owner's process */
+  uint64_t bytes;        /* size of the slab: equal on all ranks (same world, capacity and latent dimension) */
+  int32_t device, has_ipc;
+} cssm_peer_handle;
+int cssm_pf_shard_peer_setup(cssm_pf* pf, int rank, int world, int64_t cap, cssm_peer_handle* mine_out);
+int cssm_pf_shard_peer_connect(cssm_pf* pf, const cssm_peer_handle* all_handles, int world);
+void cssm_pf_shard_peer_close(cssm_pf* pf);
+int cssm_pf_shard_pack_peer(cssm_pf* pf, int rank, int world, int64_t cap);
+int cssm_pf_shard_adopt_peer(cssm_pf* pf, int rank, int world, int64_t cap);
+int cssm_pf_shard_series_peer(cssm_pf* pf, int rank, int world, size_t s_begin, size_t s_end, const uint8_t* weighted, int64_t cap);
+
 /* ---- PMMH host loop ---------------------------------------------------------------------- */
 /*
  * ParticleMetropolisHastings (model/PMMH.scala:68-81,114-123) with proposal

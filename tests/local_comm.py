@@ -79,3 +79,14 @@ class LocalCommTrimmed(LocalComm):
             for r in range(R):
                 n = seg if abs(q - r) == 1 else min(self.header_words, seg)
                 outs[q][r * seg:r * seg + n].copy_(ins[r][q * seg:q * seg + n])
+
+
+class LocalCommPeer(LocalComm):
+    """LocalComm on the PEER-WRITTEN exchange: the shards of this process map each other's receive windows by plain pointers
+    (cssm_peer_handle.local_ptr) and the ordinary exchanges of a series are k_boundary_pack writing into them + flags --
+    protocol, flags, window alternation and bits as on real peers; what one GPU cannot show is visibility across xGMI."""
+    peer = True
+
+    def exchange_handles(self, handles):
+        return list(handles)
+

@@ -1,0 +1,202 @@
+"""-m gpu: the PEER-WRITTEN exchange of the sharded filter (include/cssm_pf.h, cssm_pf_shard_peer_*): k_boundary_pack writes every
+segment straight into the destination rank's receive window and sets a flag; k_offspring_expand_spec polls the flags -- no
+collective per observation.  On one GPU the protocol runs (a) between the shards of one process (tests/local_comm.py:
+LocalCommPeer -- windows mapped by plain pointers), (b) on a rank's own windows at world 1 under torch.distributed, and (c)
+between PROCESSES that share the GPU and map each other's windows through hipIpc handles (control plane over gloo).  Every case
+must give the bits of the single-rank CPU oracle -- the bits the collective exchange gives (tests/test_gpu_sharded.py)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+import cases
+from oracle import oracle
+
+pytestmark = pytest.mark.gpu
+
+
+def _oracle_run(model, n, t, y, has, lgcp_precision=0):
+    o = oracle.OraclePf(model.descriptor(lgcp_precision), n, cases.SEED)
+    ll, ll_t, ess_t, _ = o.filter(t, y, has)
+    return ll, ess_t, o.particles()
+
+
+def _peer_filter(model, n, world, lgcp_precision=0):
+    from composablestatespacemodels_amd.sharded import GpuShard, ShardedFilter
+    from local_comm import LocalCommPeer
+    shards = [GpuShard(model, n, r, world, cases.SEED, 0, lgcp_precision=lgcp_precision) for r in range(world)]
+    return shards, ShardedFilter(shards, LocalCommPeer(world))
+
+
+@pytest.mark.parametrize("world", [2, 3, 4, 8])
+@pytest.mark.parametrize("name,n", [("c2_model", 6000), ("c1_model", 1000), ("c3_model", 4100)])
+def test_peer_exchange_local_shards_match_single_rank_oracle(world, name, n):
+    model = getattr(cases, name)()
+    t, y, has = cases.poisson_counts(11, missing=0.2)
+    shards, f = _peer_filter(model, n, world)
+    ll, ess = f.ll_filter(t, y, has)
+    assert f.last_peer and f.last_single and not f.last_from_max and f.last_attempts == 1
+    oll, oess, opart = _oracle_run(model, n, t, y, has)
+    assert (ll, ess) == (oll, oess[-1])
+    np.testing.assert_array_equal(np.concatenate([s.particles() for s in shards], axis=1), opart)
+    # a second series on the same windows (the exchange counter and the window alternation go on), then a continued one
+    ll2, ess2 = f.ll_filter(t[:7], y[:7], has[:7])
+    ll3, ess3 = f.ll_filter_more(t[7:], y[7:], has[7:])
+    assert (ll3, ess3) == (oll, oess[-1]) and f.last_peer
+    np.testing.assert_array_equal(np.concatenate([s.particles() for s in shards], axis=1), opart)
+    for s in shards:
+        s.close()
+
+
+@pytest.mark.parametrize("world,n", [(2, 3000), (4, 9000), (8, 20000)])
+@pytest.mark.parametrize("name", ["c4_model", "lgcp_seasonal_model"])
+def test_peer_exchange_lgcp(world, n, name):
+    """LGCP (numerics contract v8): the first event's level is the all-gathered max (collective exchange), every later event's
+    is predicted and its exchange peer-written."""
+    model = getattr(cases, name)()
+    t, y, has = cases.event_times(8, horizon=12.0)
+    shards, f = _peer_filter(model, n, world, lgcp_precision=2)
+    ll, ess = f.ll_filter(t, y, has, lgcp=True)
+    assert f.last_peer and not f.last_from_max and f.last_attempts == 1
+    oll, oess, opart = _oracle_run(model, n, t, y, has, lgcp_precision=2)
+    assert (ll, ess) == (oll, oess[-1])
+    np.testing.assert_array_equal(np.concatenate([s.particles() for s in shards], axis=1), opart)
+    for s in shards:
+        s.close()
+
+
+@pytest.mark.parametrize("world", [2, 3, 4])
+def test_peer_exchange_resumes_capacity_misses_and_falls_back_on_an_outlier(world):
+    """One row per pair: the exchanges miss and are resumed -- each redone through the collective exchange with a larger capacity
+    while the kernels enqueued behind it (their packs and polls included) returned at once -- and the series goes on peer-written:
+    the exchange counter has moved on by the skipped exchanges, on every rank alike.  An outlying observation voids the plan
+    and the series is repeated with every level from the global max (collective exchange)."""
+    model = cases.c2_model()
+    n = 3000 * world
+    t, y, has = cases.poisson_counts(12, missing=0.1)
+    shards, f = _peer_filter(model, n, world)
+    f.MIN_CAP, f.CAP_SQRT = 1, 0.0
+    ll, ess = f.ll_filter(t, y, has)
+    assert f.last_peer and f.last_resumes >= 1 and f.last_attempts == 1
+    oll, oess, opart = _oracle_run(model, n, t, y, has)
+    assert (ll, ess) == (oll, oess[-1])
+    np.testing.assert_array_equal(np.concatenate([s.particles() for s in shards], axis=1), opart)
+    y2 = y.copy(); y2[5] = 60.0; has2 = has.copy(); has2[5] = 1
+    f.MIN_CAP, f.CAP_SQRT = 1024, 6.0
+    ll, ess = f.ll_filter(t, y2, has2)
+    assert f.last_attempts >= 2 and not f.last_peer      # ("max", or on to "exact" where the outlier leaves whole ranks without weight)
+    oll, oess, opart = _oracle_run(model, n, t, y2, has2)
+    assert (ll, ess) == (oll, oess[-1])
+    np.testing.assert_array_equal(np.concatenate([s.particles() for s in shards], axis=1), opart)
+    # ... and back on the peer windows afterwards
+    ll, ess = f.ll_filter(t, y, has)
+    oll, oess, opart = _oracle_run(model, n, t, y, has)
+    assert f.last_peer and (ll, ess) == (oll, oess[-1])
+    np.testing.assert_array_equal(np.concatenate([s.particles() for s in shards], axis=1), opart)
+    for s in shards:
+        s.close()
+
+
+def test_peer_exchange_at_full_size_equals_single_gpu():
+    """BASELINE configs[1] at 2^20 particles over 8 shards and configs[3]'s shape (LGCP, 8 x 2^18 here) -- the sizes at which a unit of
+    sums has several tiles and a boundary block several units -- equal the single-GPU handle bit for bit."""
+    from composablestatespacemodels_amd.filter import NativePf
+    for model, n, T, prec, data in ((cases.c2_model(), 1 << 20, 10, 0, cases.poisson_counts), (cases.c4_model(), 1 << 21, 4, 2, cases.event_times)):
+        t, y, has = data(T)
+        g = NativePf(model, n, cases.SEED, lgcp_precision=prec)
+        ll1, _, ess1, _ = g.run(t, y, has)
+        ref = g.particles()
+        g.close()
+        shards, f = _peer_filter(model, n, 8, lgcp_precision=prec)
+        ll, ess = f.ll_filter(t, y, has, lgcp=bool(prec))
+        assert f.last_peer and (ll, ess) == (ll1, int(ess1[-1]))
+        for s in shards:
+            np.testing.assert_array_equal(s.particles(), ref[:, s.first:s.first + s.n])
+            s.close()
+
+
+def test_peer_exchange_world1_under_torch_distributed():
+    """One shard per process as bench.py --sharded runs it: the library's own loop (cssm_pf_shard_series_peer), the rank's windows
+    being its own peer; no RCCL communicator is created for the series."""
+    import torch
+    import torch.distributed as dist
+    from composablestatespacemodels_amd.sharded import DistComm, GpuShard, ShardedFilter
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29537")
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        for model, n, prec, data in ((cases.c2_model(), 5000, 0, cases.poisson_counts), (cases.c4_model(), 6000, 2, cases.event_times)):
+            t, y, has = data(14)
+            shard = GpuShard(model, n, 0, 1, cases.SEED, 0, lgcp_precision=prec)
+            f = ShardedFilter([shard], DistComm(device=torch.device("cuda", 0)))
+            oll, oess, opart = _oracle_run(model, n, t, y, has, lgcp_precision=prec)
+            ll, ess = f.ll_filter(t, y, has, lgcp=bool(prec))
+            assert f.last_peer and not f.last_native and (ll, ess) == (oll, oess[-1])
+            np.testing.assert_array_equal(shard.particles(), opart)
+            f.ll_filter(t[:5], y[:5], has[:5], lgcp=bool(prec))
+            shard.profile(True)
+            ll, ess = f.ll_filter_more(t[5:], y[5:], has[5:], lgcp=bool(prec))
+            prof = shard.profile_read()
+            shard.profile(False)
+            assert f.last_peer and (ll, ess) == (oll, oess[-1])
+            nw = int(np.sum(has[5:])) if not prec else len(t) - 5
+            assert prof["collective"][1] == 0 and prof["k_boundary_pack"][1] == nw and prof["k_offspring_expand_spec"][1] == nw
+            shard.close()
+            f.comm.close()
+    finally:
+        dist.destroy_process_group()
+
+
+def _ipc_rank(rank, world, port, n, T, outdir):
+    """One rank of test_peer_exchange_between_processes_sharing_the_gpu (spawned; every rank on cuda:0)."""
+    import torch
+    import torch.distributed as dist
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import cases as cs
+    from composablestatespacemodels_amd.sharded import DistComm, GpuShard, ShardedFilter
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+
+    class GlooPeerComm(DistComm):          # control plane on the CPU (gloo), windows on the GPU (IPC)
+        peer = True
+
+    torch.cuda.set_device(0)
+    model = cs.c2_model()
+    t, y, has = cs.poisson_counts(T, missing=0.1)
+    shard = GpuShard(model, n, rank, world, cs.SEED, 0)
+    f = ShardedFilter([shard], GlooPeerComm())
+    ll, ess = f.ll_filter(t, y, has)
+    ll2, ess2 = f.ll_filter_more(t[-3:] + T, y[-3:], has[-3:])
+    np.savez(os.path.join(outdir, f"r{rank}.npz"), ll=ll, ess=ess, ll2=ll2, ess2=ess2, part=shard.particles(), peer=int(f.last_peer),
+             resumes=int(f.last_resumes))
+    shard.close()
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_peer_exchange_between_processes_sharing_the_gpu(tmp_path, world):
+    """`world` PROCESSES, all on this GPU, each mapping the others' windows through hipIpcOpenMemHandle: the handles, the
+    device table, the flags and the window alternation as across GPUs (what one GPU cannot show is xGMI visibility).  Small
+    clouds, so that the processes' kernels fit the GPU side by side."""
+    import torch.multiprocessing as mp
+    n, T = 4096 * world, 9
+    port = 29700 + (os.getpid() % 200) + world
+    mp.spawn(_ipc_rank, args=(world, port, n, T, str(tmp_path)), nprocs=world, join=True)
+    model = cases.c2_model()
+    t, y, has = cases.poisson_counts(T, missing=0.1)
+    o = oracle.OraclePf(model.descriptor(), n, cases.SEED)
+    ll, _, ess_t, _ = o.filter(t, y, has)
+    for a, b, h in zip(t[-3:] + T, y[-3:], has[-3:]):
+        ll2, ess2 = o.step(a, b, bool(h))
+    parts = []
+    for r in range(world):
+        z = np.load(os.path.join(str(tmp_path), f"r{r}.npz"))
+        assert int(z["peer"]) == 1
+        assert float(z["ll"]) == ll and int(z["ess"]) == int(ess_t[-1])
+        assert float(z["ll2"]) == ll2 and int(z["ess2"]) == ess2
+        parts.append(z["part"])
+    np.testing.assert_array_equal(np.concatenate(parts, axis=1), o.particles())

@@ -243,10 +243,13 @@ def test_sharded_summary_equals_the_single_rank_summary(name, prec, n, world, in
         s.close()
 
 
-def test_rccl_world1_matches_oracle():
+def test_rccl_world1_matches_oracle(monkeypatch):
+    """The COLLECTIVE exchange over RCCL (CSSM_SHARD_PEER=0: the peer-written exchange is the default where the communicator
+    offers it, tests/test_gpu_peer.py), the library issuing the collectives itself."""
     import torch
     import torch.distributed as dist
     from composablestatespacemodels_amd.sharded import DistComm, GpuShard, ShardedFilter
+    monkeypatch.setenv("CSSM_SHARD_PEER", "0")
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("MASTER_PORT", "29533")
     torch.cuda.set_device(0)
