@@ -137,6 +137,7 @@ SYMBOLS = [
     ("cssm_pf_shard_peer_close", None, [_h]),
     ("cssm_pf_shard_pack_peer", C.c_int, [_h, C.c_int, C.c_int, C.c_int64]),
     ("cssm_pf_shard_adopt_peer", C.c_int, [_h, C.c_int, C.c_int, C.c_int64]),
+    ("cssm_pf_shard_exchange_peer", C.c_int, [_h, C.c_int, C.c_int, C.c_int64]),
     ("cssm_pf_shard_series_peer", C.c_int, [_h, C.c_int, C.c_int, C.c_size_t, C.c_size_t, _u8p, C.c_int64]),
     ("cssm_pmmh_run", C.c_int, [_h, _descp, _dp, C.c_size_t, C.c_double, _dp, _dp, _u8p, C.c_size_t,
                                 C.c_uint64, C.c_size_t, _dp, _dp, _i32p, _dp]),

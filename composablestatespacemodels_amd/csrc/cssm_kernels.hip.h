@@ -244,6 +244,10 @@ __device__ __forceinline__ void offspring_exact_counts(cssm_u128 run0, const dou
 #else
 #define CSSM_STAMP(k) do { } while (0)
 #endif
+// What a sharded launch that has already read every rank's 5 words hands the body (k_offspring_expand_spec: one thread per rank
+// loads a header, the totals go through LDS -- the body's own loops over all5 are world x 5 loads in EVERY thread, and on the
+// peer-written windows each of those is a system-scope load past the caches)
+struct SpecTotals { cssm_u128 S_off, tot, tot2; double gmax; };
 template <bool FUSE, bool SELF, int RS, int RAWC = -1, bool GRP = false>
 __device__ __forceinline__ void offspring_body(const double* __restrict__ logw, uint64_t n,
                                                           Scalars* __restrict__ sc,
@@ -258,7 +262,13 @@ __device__ __forceinline__ void offspring_body(const double* __restrict__ logw, 
                                                           unsigned long long* __restrict__ flag_out,
                                                           uint32_t slot_lo, uint32_t slot_hi, uint32_t all5_stride,
                                                           cssm_u128* __restrict__ s2buf = nullptr, uint32_t s2_stride = 0, int s2_par_arg = -1,
-                                                          uint32_t gen = 0, const cssm_u128* __restrict__ unit_pre = nullptr) {
+                                                          uint32_t gen = 0, const cssm_u128* __restrict__ unit_pre = nullptr, const uint32_t blk0 = 0u,
+                                                          const double* pre_in = nullptr, const SpecTotals* tt = nullptr) {
+  // pre_in (or nullptr): the weights of the block's first tile, requested by the caller (the merged exchange kernel asks for them
+  // BEFORE it waits for the peers' flags: the wait covers their round trip)
+  // blk0: blocks [0, blk0) of the launch are somebody else's (the pack blocks of the merged exchange + offspring kernel of the
+  // peer-written exchange): this body runs in blocks blk0 .. gridDim.x - 1, numbered from 0
+  const uint32_t bidx = blockIdx.x - blk0, nblk = gridDim.x - blk0;
   // unit_pre (sharded, single-collective exchange; or nullptr): exclusive prefixes of the (sub-)unit sums, from k_boundary_pack
   // GRP (SELF, RAWC == 2, behind a k_propagate whose blocks accumulated them): the sums of groups of 32 units are at hand
   // (Scalars::grp) -- an instantiation of its own: it keeps ONE unit-sum entry per lane of one wave in flight instead of UPRE per
@@ -297,12 +307,15 @@ __device__ __forceinline__ void offspring_body(const double* __restrict__ logw, 
   // (the default kernel: five blocks per CU) it is block 0 -- the oldest wave of its CU, served first -- and block b + 1 works on
   // unit b; the other instantiations (four blocks per CU) keep it last, where it slips into the first slot a unit block frees.
   constexpr bool PUB_FIRST = SELF && RS == CSSM_RESAMPLE_SYSTEMATIC && RAWC == 2;
-  const uint32_t ublk = PUB_FIRST ? blockIdx.x - 1u : blockIdx.x;
-  const bool is_pub = SELF && (PUB_FIRST ? blockIdx.x == 0u : blockIdx.x == nunits);
+  const uint32_t ublk = PUB_FIRST ? bidx - 1u : bidx;
+  const bool is_pub = SELF && (PUB_FIRST ? bidx == 0u : bidx == nunits);
   CSSM_STAMP(0);
   const uint32_t held = SELF ? sc->err : 0u;
   double pre_v[CSSM_ITEMS];   // the block's first tile is requested before the serial prologue
-  if (ublk < nunits) load_tile_raw(logw, (uint64_t)ublk * sup * CSSM_TILE, n, raw, pre_v);
+  if (pre_in != nullptr) {
+#pragma unroll
+    for (int r = 0; r < CSSM_ITEMS; ++r) pre_v[r] = pre_in[r];
+  } else if (ublk < nunits) load_tile_raw(logw, (uint64_t)ublk * sup * CSSM_TILE, n, raw, pre_v);
   // ... and (single GPU) so are the unit sums every block totals: thread t owns the E = ceil(nsub / 256) consecutive entries
   // from t E on (up to UPRE of them in flight while the max is decoded; a loop for more)
   constexpr int UPRE = CSSM_OFF_UPRE;
@@ -311,7 +324,7 @@ __device__ __forceinline__ void offspring_body(const double* __restrict__ logw, 
   const uint32_t E = (nsub + CSSM_BLOCK - 1) / CSSM_BLOCK;
   // grp_on: ONE wave (not the one that decodes the max) totals 32 group sums + the 32 unit sums of the block's own group: lane l < 32
   // holds group l (four 64-bit words of 32-bit limb sums), lane 32 + j unit j of the own group
-  const uint32_t wsum = (blockIdx.x + 1u) & 3u;
+  const uint32_t wsum = (bidx + 1u) & 3u;
   const uint32_t grp_unit = is_pub ? 0u : ublk;
   if (SELF && grp_on) {
 #pragma unroll
@@ -353,8 +366,8 @@ __device__ __forceinline__ void offspring_body(const double* __restrict__ logw, 
         // put the series on hold AT this observation (its propagate is done: the cloud is in place, the previous ancestors are
         // untouched); every kernel enqueued behind returns at once, the host redoes this observation -- its weights again, as
         // log-weights, and its sums relative to the max -- and carries on
-        if (blockIdx.x == 0 && threadIdx.x == 0) { sc->gmax = gmax_dec; atomicMin(&sc->fail_step, rec_step); atomicOr(&sc->err, 64u); }
-      } else if (blockIdx.x == 0 && threadIdx.x == 0) {
+        if (bidx == 0 && threadIdx.x == 0) { sc->gmax = gmax_dec; atomicMin(&sc->fail_step, rec_step); atomicOr(&sc->err, 64u); }
+      } else if (bidx == 0 && threadIdx.x == 0) {
         if (flag_out) *flag_out = 1ull;
         if (optimistic == 2) atomicOr(&sc->err, 4u);   // (merged with the expansion: no later kernel reads the flag)
       }
@@ -367,7 +380,7 @@ __device__ __forceinline__ void offspring_body(const double* __restrict__ logw, 
     // the unit-sum scan below (round 2: block_decode_slots, a block barrier of its own at the head of the kernel)
     // (which wave: round-robin over the blocks -- a block's wave w runs on SIMD w, and one SIMD of every CU carrying all
     //  the decodes delayed each CU's youngest blocks at N = 2^20)
-    if ((threadIdx.x >> 6) == (blockIdx.x & (CSSM_BLOCK / 64 - 1))) {
+    if ((threadIdx.x >> 6) == (bidx & (CSSM_BLOCK / 64 - 1))) {
       const uint32_t l = threadIdx.x & 63u;
       unsigned long long k = (l < CSSM_MAXSLOTS) ? sc->maxslot[((size_t)slot_set * CSSM_MAXSLOTS + l) * CSSM_SLOT_STRIDE] : 0ull;
       k = wave_max_u64(k);
@@ -375,7 +388,9 @@ __device__ __forceinline__ void offspring_body(const double* __restrict__ logw, 
     }
     if (held & 64u) return;
   } else {
-    if (all5) {
+    if (tt != nullptr) {
+      gmax_dec = tt->gmax;
+    } else if (all5) {
       unsigned long long key = 0ull;
       for (int r = 0; r < world; ++r) { const unsigned long long k = ld_sys_u64(all5 + (size_t)all5_stride * r + 4); key = (k > key) ? k : key; }
       gmax_dec = cssm_order_unkey(key);
@@ -384,7 +399,7 @@ __device__ __forceinline__ void offspring_body(const double* __restrict__ logw, 
     }
     if (!level_known()) return;
   }
-  if (!SELF && flag_out && blockIdx.x == 0 && threadIdx.x == 0) *flag_out = 0ull;
+  if (!SELF && flag_out && bidx == 0 && threadIdx.x == 0) *flag_out = 0ull;
   const bool pow2 = (n_global & (n_global - 1)) == 0;
   // (1 / N is formed where the exact predicate is evaluated: a division and two registers in every thread otherwise)
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
@@ -393,6 +408,9 @@ __device__ __forceinline__ void offspring_body(const double* __restrict__ logw, 
   if (!SELF) {
     if (all5) {   // sharded: every block derives this rank's offset and the global totals from the all-gathered sums
       cssm_u128 tot = cssm_u128_zero(), tot2 = cssm_u128_zero();
+      if (tt != nullptr) {
+        S_off = tt->S_off; tot = tt->tot; tot2 = tt->tot2;
+      } else
       for (int r = 0; r < world; ++r) {
         cssm_u128 a, b;
         const unsigned long long* w5 = all5 + (size_t)all5_stride * r;   // (possibly a peer-written window: ld_sys)
@@ -401,7 +419,7 @@ __device__ __forceinline__ void offspring_body(const double* __restrict__ logw, 
         tot = cssm_u128_add(tot, a); tot2 = cssm_u128_add(tot2, b);
       }
       totd = cssm_u128_to_double(tot);
-      if (blockIdx.x == 0 && threadIdx.x == 0) {
+      if (bidx == 0 && threadIdx.x == 0) {
         sc->gmax = gmax_dec; sc->ref = gmax;
         sc->S_off = S_off; sc->S_tot = tot; sc->S2_tot = tot2;
         finish_step(sc, n_global);
@@ -625,7 +643,10 @@ __device__ __forceinline__ void offspring_body(const double* __restrict__ logw, 
     const uint32_t t1 = (t0 + sup < ntiles) ? t0 + sup : ntiles;
     cssm_u128 toff;                                        // cumulative weight before the current tile
     if (!SELF && all5 && unit_pre != nullptr) {            // sharded, the prefixes of the unit sums at hand (k_boundary_pack's header block)
-      toff = cssm_u128_add(S_off, unit_pre[(size_t)unit * split]);
+      // (the merged kernel's prefix block wrote them while this launch ran: system-scope loads, behind its flag)
+      cssm_u128 up; const unsigned long long* upw = reinterpret_cast<const unsigned long long*>(unit_pre + (size_t)unit * split);
+      up.lo = ld_sys_u64(upw); up.hi = ld_sys_u64(upw + 1);
+      toff = cssm_u128_add(S_off, up);
     } else if (!SELF && all5) {                            // sharded: unitP holds the (sub-)unit SUMS; the totals came with all5
       cssm_u128 pre = cssm_u128_zero();
       const uint32_t qlim = unit * (uint32_t)split;
@@ -820,7 +841,7 @@ __device__ __forceinline__ void offspring_body(const double* __restrict__ logw, 
         __syncthreads();                                       // (s_w is rewritten by the next tile / the next unit)
       }
     }
-  } while (!SELF && (unit += gridDim.x) < nunits);
+  } while (!SELF && (unit += nblk) < nunits);
 }
 
 #define CSSM_OFFSPRING_PARAMS                                                                                              \

@@ -460,14 +460,17 @@ static int boundary_pack_impl(cssm_pf* pf, int rank, int world, int64_t cap, dou
   return CSSM_OK;
 }
 
-static int adopt_spec_impl(cssm_pf* pf, const double* recv_buf_dev, int rank, int world, int64_t cap, const unsigned int* peer_flags, uint32_t peer_seq);
+static int adopt_spec_impl(cssm_pf* pf, const double* recv_buf_dev, int rank, int world, int64_t cap, const unsigned int* peer_flags, uint32_t peer_seq,
+                           bool merged = false);
 extern "C" int cssm_pf_shard_adopt_spec(cssm_pf* pf, const double* recv_buf_dev, int rank, int world, int64_t cap) {
   int rc = shard_check(pf);
   if (rc) return rc;
   if (!recv_buf_dev) return fail(CSSM_EINVAL_ARG, "recv_buf_dev is null");
   return adopt_spec_impl(pf, recv_buf_dev, rank, world, cap, nullptr, 0u);
 }
-static int adopt_spec_impl(cssm_pf* pf, const double* recv_buf_dev, int rank, int world, int64_t cap, const unsigned int* peer_flags, uint32_t peer_seq) {
+static int adopt_spec_impl(cssm_pf* pf, const double* recv_buf_dev, int rank, int world, int64_t cap, const unsigned int* peer_flags, uint32_t peer_seq,
+                           bool merged) {
+  // merged (peer-written exchange, one shard per stream): the pack blocks ride at the head of the same launch (k_exchange_offspring)
   if (cap < 1 || world < 1 || world > 64 || rank < 0 || rank >= world) return fail(CSSM_ESHARD, "rank %d / world %d / cap %lld", rank, world, (long long)cap);
   const uint64_t n_per = (pf->n_global + (uint64_t)world - 1) / (uint64_t)world;
   if (pf->first != (uint64_t)rank * n_per) return fail(CSSM_ESHARD, "rank %d must own particles from %llu", rank, (unsigned long long)((uint64_t)rank * n_per));
@@ -478,7 +481,27 @@ static int adopt_spec_impl(cssm_pf* pf, const double* recv_buf_dev, int rank, in
   const unsigned long long* all5 = reinterpret_cast<const unsigned long long*>(recv_buf_dev) + 1;
   const uint32_t n_split = (uint32_t)pf->n;
   prof_begin(pf, CSSM_K_EXPAND);
-  if (pf->last_optimistic) {
+  if (merged) {
+    if (!pf->last_optimistic) return fail(CSSM_ESTATE, "the merged peer exchange serves the propagate that formed the sums (levels known in advance)");
+    const uint64_t chunk = (uint64_t)pf->sup * CSSM_TILE / pf->split;
+    const uint32_t nsub = (uint32_t)((pf->n + chunk - 1) / chunk);
+    const long long cnt = std::min<long long>((long long)pf->n, (long long)cap);
+    const bool pre = (pf->split == 1 && nsub <= 4u * CSSM_BLOCK);
+    PackArgs pk;
+    pk.src = pf->state[pf->cur]; pk.stride = pf->stride; pk.nsub = nsub; pk.chunk = chunk;
+    pk.pre_out = pre ? pf->unitPre : (cssm_u128*)nullptr;
+    pk.peer = (const PeerTable*)pf->peer_tab; pk.parity = (int)(peer_seq & 1u); pk.tickets = pf->peer_tickets;
+    pk.pre_flag = pre ? pf->peer_tickets + 64 : (unsigned int*)nullptr;
+    pk.pack_gx = (uint32_t)((cnt + CSSM_TILE - 1) / CSSM_TILE) + 2u;
+    pf->spec_pre = pre;
+    hipLaunchKernelGGL(k_exchange_offspring<2>, dim3(tgrid + (int)(pk.pack_gx * (uint32_t)world)), dim3(CSSM_BLOCK), 0, pf->stream, pf->logw, pf->n, pf->sc,
+                     (const cssm_u128*)pf->tileS, (const cssm_u128*)pf->tileS2, (const StepRec*)(pf->d_recs + slot), pf->n_global, pf->endslot,
+                     pf->anc, pf->ntiles, pf->sup, pf->nunits, 2, 0, (double*)nullptr, (int32_t*)nullptr, 0u, pf->opt_exact,
+                     all5, rank, world, (int)pf->split, pf->seed, (double*)nullptr, (const double*)pf->d_logtab,
+                     2, (unsigned long long*)(pf->d_xch + 128), (uint32_t)pf->first, (uint32_t)(pf->first + pf->n), (uint32_t)seg,
+                     recv_buf_dev, (long long)cap, pf->d, n_split, pre ? (const cssm_u128*)pf->unitPre : (const cssm_u128*)nullptr,
+                     peer_flags, peer_seq, pk);
+  } else if (pf->last_optimistic) {
     hipLaunchKernelGGL(k_offspring_expand_spec<2>, dim3(tgrid), dim3(CSSM_BLOCK), 0, pf->stream, pf->logw, pf->n, pf->sc,
                      (const cssm_u128*)pf->tileS, (const cssm_u128*)pf->tileS2, (const StepRec*)(pf->d_recs + slot), pf->n_global, pf->endslot,
                      pf->anc, pf->ntiles, pf->sup, pf->nunits, pf->last_optimistic ? 2 : 0, 0, (double*)nullptr, (int32_t*)nullptr, 0u, pf->opt_exact,
@@ -587,8 +610,8 @@ extern "C" int cssm_pf_shard_peer_setup(cssm_pf* pf, int rank, int world, int64_
   else { (void)hipGetLastError(); if (hipMalloc(&ps->slab, ps->slab_bytes) != hipSuccess) { ps->slab = nullptr; cssm_peer_free(pf); return fail(CSSM_ENOMEM, "peer windows (%zu bytes)", ps->slab_bytes); } }
   HIP_TRY(hipMemsetAsync(ps->slab, 0, ps->slab_bytes, pf->stream));
   HIP_TRY(hipMalloc(&pf->peer_tab, sizeof(PeerTable)));
-  HIP_TRY(hipMalloc(&pf->peer_tickets, 64 * sizeof(unsigned int)));
-  HIP_TRY(hipMemsetAsync(pf->peer_tickets, 0, 64 * sizeof(unsigned int), pf->stream));
+  HIP_TRY(hipMalloc(&pf->peer_tickets, 128 * sizeof(unsigned int)));   // [0, 64): tickets per destination; [64]: the flag of the unit-sum prefixes (merged kernel)
+  HIP_TRY(hipMemsetAsync(pf->peer_tickets, 0, 128 * sizeof(unsigned int), pf->stream));
   HIP_TRY(hipStreamSynchronize(pf->stream));
   memset(mine_out, 0, sizeof *mine_out);
   mine_out->pid = (uint64_t)getpid();
@@ -669,8 +692,23 @@ extern "C" int cssm_pf_shard_adopt_peer(cssm_pf* pf, int rank, int world, int64_
   const int p = (int)(pf->peer_seq & 1u);
   return adopt_spec_impl(pf, peer_window(ps, ps->slab, p), rank, world, cap, peer_flagset(ps, ps->slab, p), pf->peer_seq);
 }
-// The series loop on the peer-written exchange: per weighted observation propagate -> pack into the peers' windows -> offspring +
-// expansion behind the flags; three launches, no collective, no host wait.  (Observations whose level comes from the global max --
+// Pack and adopt in ONE launch (k_exchange_offspring): for a rank that has its stream to itself -- one process per GPU.  Several
+// shards driven on one stream must use the two stage calls above, all packs before any adopt: a shard's pollers would wait for
+// segments that a launch BEHIND them on the same stream is to write.
+extern "C" int cssm_pf_shard_exchange_peer(cssm_pf* pf, int rank, int world, int64_t cap) {
+  int rc = shard_check(pf);
+  if (rc) return rc;
+  PeerState* ps = static_cast<PeerState*>(pf->peer);
+  if (!ps || !ps->connected) return fail(CSSM_ESTATE, "peer windows are not set up (cssm_pf_shard_peer_setup / _connect)");
+  if (rank != ps->rank || world != ps->world || cap != ps->cap) return fail(CSSM_ESHARD, "peer windows were set up for rank %d / world %d / cap %lld", ps->rank, ps->world, (long long)ps->cap);
+  if (pf->peer_packed) return fail(CSSM_ESTATE, "cssm_pf_shard_exchange_peer between cssm_pf_shard_pack_peer and cssm_pf_shard_adopt_peer");
+  pf->peer_seq++;
+  const int p = (int)(pf->peer_seq & 1u);
+  return adopt_spec_impl(pf, peer_window(ps, ps->slab, p), rank, world, cap, peer_flagset(ps, ps->slab, p), pf->peer_seq, /*merged=*/true);
+}
+
+// The series loop on the peer-written exchange: per weighted observation propagate -> [pack into the peers' windows | offspring +
+// expansion behind the flags] -- two launches, no collective, no host wait.  (Observations whose level comes from the global max --
 // the first event of an LGCP series, a repeated series -- and resumed exchanges go through the RCCL / host-driven exchange.)
 extern "C" int cssm_pf_shard_series_peer(cssm_pf* pf, int rank, int world, size_t s_begin, size_t s_end, const uint8_t* weighted, int64_t cap) {
   int rc = shard_check(pf);
@@ -680,9 +718,14 @@ extern "C" int cssm_pf_shard_series_peer(cssm_pf* pf, int rank, int world, size_
     rc = cssm_pf_shard_propagate_at(pf, s, nullptr);
     if (rc) return rc;
     if (!weighted[s]) continue;
-    rc = cssm_pf_shard_pack_peer(pf, rank, world, cap);
-    if (rc) return rc;
-    rc = cssm_pf_shard_adopt_peer(pf, rank, world, cap);
+    static const bool two_launches = getenv("CSSM_PEER_TWO_LAUNCHES") != nullptr;   // (A/B: pack and adopt as launches of their own)
+    if (two_launches) {
+      rc = cssm_pf_shard_pack_peer(pf, rank, world, cap);
+      if (rc) return rc;
+      rc = cssm_pf_shard_adopt_peer(pf, rank, world, cap);
+    } else {
+      rc = cssm_pf_shard_exchange_peer(pf, rank, world, cap);
+    }
     if (rc) return rc;
   }
   return CSSM_OK;

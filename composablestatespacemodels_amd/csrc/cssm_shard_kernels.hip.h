@@ -68,29 +68,37 @@ __host__ __device__ __forceinline__ long long spec_seg(int d, long long cap) { r
 // pointers where the shards share a process) -- and a flag per (window, source rank) tells the destination's
 // k_offspring_expand_spec that the segment is complete: no collective launch per observation.  Two windows alternate by exchange
 // number (the rows of exchange e are gathered from by the propagate of the NEXT observation while exchange e + 1 is written).
-// Protocol, per destination q: every block that wrote part of segment rank -> q makes its stores visible at SYSTEM scope
-// (__threadfence_system by every thread, then the block barrier), takes a ticket on a LOCAL counter, and the block that takes the last one
-// stores the exchange number into q's flag with system-scope release.  The reader polls with system-scope loads, bounded, and
+// Protocol, per destination q, two flags per source rank: [0] the HEADER is complete -- the one block that writes it makes its stores
+// visible at SYSTEM scope (__threadfence_system by every thread, then the block barrier) and stores the exchange number with
+// system-scope release: everything a reader needs before it can resample its own particles, and the only flag on its critical
+// path; [1] the ROWS are complete -- every block that wrote rows does the same fence, takes a ticket on a LOCAL counter, and the
+// block that takes the last one stores the number: read only where the received rows are expanded, behind the reader's own
+// particles, by when it has long been set.  The reader polls with system-scope loads, bounded, and
 // reads the window with system-scope loads as well (ld_sys: no fence -- an L2 invalidate per wave of a 1024-block kernel cost 34 us).
 struct PeerTable {
   double* win[2][64];              // win[p][q]: base of rank q's receive window p (world segments; segment r = what rank r wrote)
-  unsigned int* flag[2][64];       // flag[p][q]: rank q's flags of window p, one 64-byte line per source rank
+  unsigned int* flag[2][64];       // flag[p][q]: rank q's flags of window p, two 64-byte lines per source rank: header, rows
 };
-#define CSSM_PEER_FLAG_STRIDE 16   /* uint32 words between the flags of consecutive source ranks (one line each) */
+#define CSSM_PEER_FLAG_STRIDE 32   /* uint32 words between the flags of consecutive source ranks (header flag at 0, rows flag at 16) */
+#define CSSM_PEER_FLAG_ROWS 16
 #define CSSM_PEER_SPIN_LIMIT (1u << 22)   /* polls (~1 us each) before a reader gives up: err bit 4 (16) */
 
 // grid (tiles of the block + 1 for the header, destination rank); the weights are those k_propagate<SUMS> summed and stored,
 // exp(min(w - c, REF_BELOW)) -- or, with the level taken from the global max, exp(w - level) of the stored log-weights
 // peer != nullptr: the peer-written exchange -- `out` unused, segment rank -> q lands in peer->win[parity][q] + rank * seg,
 // tickets[q] counts the finished blocks of destination q (left at zero again by the block that takes the last ticket)
-__global__ __launch_bounds__(CSSM_BLOCK) void k_boundary_pack(const double* __restrict__ src, size_t stride, const double* __restrict__ logw,
+__device__ __forceinline__ void boundary_pack_block(const uint32_t bx, const uint32_t gx, const int q,
+                                                              const double* __restrict__ src, size_t stride, const double* __restrict__ logw,
                                                               uint64_t n_local, int d, int world, int rank, long long cap,
                                                               const StepRec* __restrict__ rec, const cssm_u128* __restrict__ subS,
                                                               const cssm_u128* __restrict__ subS2, uint32_t nsub,
                                                               const Scalars* __restrict__ sc, double* __restrict__ out, uint64_t chunk,
                                                               int level_from_max, cssm_u128* __restrict__ pre_out,
-                                                              const PeerTable* __restrict__ peer = nullptr, int parity = 0, uint32_t seq = 0u,
-                                                              unsigned int* __restrict__ tickets = nullptr) {
+                                                              const PeerTable* __restrict__ peer, int parity, uint32_t seq,
+                                                              unsigned int* __restrict__ tickets, unsigned int* __restrict__ pre_flag) {
+  // bx / gx / q: the block's place in a (gx, world) grid -- blockIdx.x, gridDim.x, blockIdx.y of k_boundary_pack; the merged
+  // exchange + offspring kernel of the peer-written exchange hands its first gx * world blocks through here
+  // pre_flag (merged kernel; else nullptr): the prefix block announces pre_out with the exchange number (agent-scope release)
   // pre_out (nsub <= 4 * CSSM_BLOCK, else nullptr): the header block of segment 0 also writes the EXCLUSIVE prefix of the sub-unit
   // sums -- pre_out[j] = subS[0] + .. + subS[j - 1] -- which k_offspring_expand_spec's block j then reads as one word instead of
   // summing j entries itself (on average 8 KiB per block and a block-wide sum with two barriers)
@@ -100,23 +108,33 @@ __global__ __launch_bounds__(CSSM_BLOCK) void k_boundary_pack(const double* __re
   // chunk = particles per sub-unit sum of k_propagate (subS): when the tiles of the carried block coincide with
   // sub-units, the prefix of the tiles before a block's own is read from subS instead of being recomputed
   __shared__ cssm_u128 s_w[CSSM_BLOCK / 64], s_r[2][CSSM_BLOCK / 64];
-  if (sc->err & (4u | 8u | 16u)) return;   // the series is on hold (capacity miss) or void (level ruled out): nothing may change
-  const int q = blockIdx.y;
+  // the series is on hold (capacity miss), void (level ruled out) or a peer is missing: nothing may change -- tested where a block is
+  // about to store (everything before is loads and arithmetic: at the head of the block the test was a round trip of its own in a
+  // kernel that is one latency chain, and in the merged kernel the pollers of every rank wait for that chain)
+  const uint32_t held = sc->err & (4u | 8u | 16u);
   const long long R = d + 1, HD = spec_hdr(d), seg = spec_seg(d, cap);
   double* oseg = peer ? peer->win[parity][q] + (size_t)rank * seg : out + (size_t)q * seg;
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   // peer-written exchange: this block's part of segment rank -> q is done (all threads call; see PeerTable)
-  auto peer_done = [&]() {
+  auto peer_done = [&](bool header) {
     if (peer == nullptr) return;
+    if (header) {   // (thread 0 alone wrote the header: its release orders those stores before the flag)
+      if (threadIdx.x == 0)
+        __hip_atomic_store(peer->flag[parity][q] + (size_t)rank * CSSM_PEER_FLAG_STRIDE, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+      return;
+    }
     __threadfence_system();
     __syncthreads();
     if (threadIdx.x == 0) {
-      const unsigned int nblk = gridDim.x - 1u;          // (every block of this destination but the prefix block)
-      const unsigned int t = atomicAdd(&tickets[q], 1u);
-      if (t + 1u == nblk) {
-        tickets[q] = 0u;                                  // (the next launch on this stream starts from zero)
-        __threadfence_system();
-        __hip_atomic_store(peer->flag[parity][q] + (size_t)rank * CSSM_PEER_FLAG_STRIDE, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+      unsigned int* f = peer->flag[parity][q] + (size_t)rank * CSSM_PEER_FLAG_STRIDE;
+      {
+        const unsigned int nblk = gx - 2u;                // (the row blocks of this destination)
+        const unsigned int t = atomicAdd(&tickets[q], 1u);
+        if (t + 1u == nblk) {
+          tickets[q] = 0u;                                // (the next launch on this stream starts from zero)
+          __threadfence_system();
+          __hip_atomic_store(f + CSSM_PEER_FLAG_ROWS, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
       }
     }
   };
@@ -145,8 +163,9 @@ __global__ __launch_bounds__(CSSM_BLOCK) void k_boundary_pack(const double* __re
   };
   // grid.x = tiles of the block + 2: the header has a block of its own, and so have the prefixes of the sub-unit sums (pre_out; in the
   // header block they lengthened the launch's longest latency chain by 1.6 us)
-  if (blockIdx.x == gridDim.x - 1) {   // the prefix block: thread t owns the entries 4 t .. 4 t + 3
-    if (pre_out == nullptr || blockIdx.y != 0) return;
+  if (bx == gx - 1) {   // the prefix block: thread t owns the entries 4 t .. 4 t + 3
+    if (pre_out == nullptr || q != 0) return;
+    // (the entries are requested ahead of the hold test)
     __shared__ cssm_u128 s_p[CSSM_BLOCK / 64];
     cssm_u128 v[4];
 #pragma unroll
@@ -159,15 +178,21 @@ __global__ __launch_bounds__(CSSM_BLOCK) void k_boundary_pack(const double* __re
     ex.hi = inc.hi - own.hi - (inc.lo < own.lo ? 1ull : 0ull); ex.lo = inc.lo - own.lo;
     for (int w = 0; w < wid; ++w) ex = cssm_u128_add(ex, s_p[w]);
     const uint32_t i0 = threadIdx.x * 4u;
+    if (held) return;
     if (i0 < nsub) pre_out[i0] = ex;
     if (i0 + 1u < nsub) pre_out[i0 + 1u] = cssm_u128_add(ex, e1);
     if (i0 + 2u < nsub) pre_out[i0 + 2u] = cssm_u128_add(ex, e2);
     if (i0 + 3u < nsub) pre_out[i0 + 3u] = cssm_u128_add(ex, e3);
+    if (pre_flag != nullptr) {   // (merged kernel: the offspring blocks of this very launch read them, behind this flag)
+      __threadfence();
+      __syncthreads();
+      if (threadIdx.x == 0) __hip_atomic_store(pre_flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    }
     return;
   }
-  const bool header_block = (blockIdx.x == gridDim.x - 2);
+  const bool header_block = (bx == gx - 2);
   if (!header_block) {
-  if (cnt == 0) { peer_done(); return; }
+  if (cnt == 0) { if (held) return; peer_done(false); return; }
   // prefix of the tiles before this block's tile
   cssm_u128 toff = cssm_u128_zero();
   // The carried block starts on a boundary of the sub-units whose sums k_propagate (or k_tile_sums) formed -- chunk particles
@@ -178,7 +203,7 @@ __global__ __launch_bounds__(CSSM_BLOCK) void k_boundary_pack(const double* __re
   uint32_t t_begin = 0;
   if (aligned) {
     const uint32_t per = (uint32_t)(chunk / CSSM_TILE);               // tiles per sub-unit
-    const uint32_t c0 = (uint32_t)(first / chunk), nc = blockIdx.x / per;   // sub-units wholly before this tile
+    const uint32_t c0 = (uint32_t)(first / chunk), nc = bx / per;   // sub-units wholly before this tile
     // (the kernel is one latency chain after another at the sizes it runs at -- a capacity of a few thousand rows: what can be
     //  requested together is: up to 8 sums in flight, the rest in a loop)
     cssm_u128 pre8[8];
@@ -189,7 +214,7 @@ __global__ __launch_bounds__(CSSM_BLOCK) void k_boundary_pack(const double* __re
     for (uint32_t c = 8; c < nc; ++c) toff = cssm_u128_add(toff, subS[c0 + c]);
     t_begin = nc * per;
   }
-  for (uint32_t t = t_begin; t < blockIdx.x; ++t) {
+  for (uint32_t t = t_begin; t < bx; ++t) {
     cssm_u128 qq[CSSM_ITEMS];
     tile_weights((uint64_t)t * CSSM_TILE, qq);
     cssm_u128 a = cssm_u128_zero();
@@ -198,7 +223,7 @@ __global__ __launch_bounds__(CSSM_BLOCK) void k_boundary_pack(const double* __re
     toff = cssm_u128_add(toff, block_total(a));
   }
   // this tile: inclusive prefixes, rows
-  const uint64_t base = (uint64_t)blockIdx.x * CSSM_TILE;
+  const uint64_t base = (uint64_t)bx * CSSM_TILE;
   cssm_u128 qq[CSSM_ITEMS];
   tile_weights(base, qq);
   cssm_u128 tsum = cssm_u128_zero();
@@ -212,6 +237,7 @@ __global__ __launch_bounds__(CSSM_BLOCK) void k_boundary_pack(const double* __re
   for (int w = 0; w < wid; ++w) run = cssm_u128_add(run, s_w[w]);
   run = cssm_u128_add(run, inc);
   { cssm_u128 t; t.lo = run.lo - tsum.lo; t.hi = run.hi - tsum.hi - (run.lo < tsum.lo ? 1u : 0u); run = t; }   // exclusive prefix of the thread
+  if (held) return;
 #pragma unroll
   for (int r = 0; r < CSSM_ITEMS; ++r) {
     run = cssm_u128_add(run, qq[r]);
@@ -223,7 +249,7 @@ __global__ __launch_bounds__(CSSM_BLOCK) void k_boundary_pack(const double* __re
       oseg[HD + cap * R + (long long)i] = cssm_u2d(run.hi);
     }
   }
-  peer_done();
+  peer_done(false);
   return;
   }
   // header: the rank's totals of the sub-unit sums k_propagate formed, the key of its max, base.  Everything it reads is
@@ -290,6 +316,7 @@ __global__ __launch_bounds__(CSSM_BLOCK) void k_boundary_pack(const double* __re
     }
     ptot[which] = acc;
   }
+  if (held) return;
   if (threadIdx.x == 0) {
     cssm_u128 S = s_r[0][0], S2 = s_r[1][0];
 #pragma unroll
@@ -303,7 +330,19 @@ __global__ __launch_bounds__(CSSM_BLOCK) void k_boundary_pack(const double* __re
     oseg[8] = cssm_u2d(ptot[0].lo); oseg[9] = cssm_u2d(ptot[0].hi);
     oseg[10] = cssm_u2d(ptot[1].lo); oseg[11] = cssm_u2d(ptot[1].hi);
   }
-  peer_done();
+  peer_done(true);
+}
+
+__global__ __launch_bounds__(CSSM_BLOCK) void k_boundary_pack(const double* __restrict__ src, size_t stride, const double* __restrict__ logw,
+                                                              uint64_t n_local, int d, int world, int rank, long long cap,
+                                                              const StepRec* __restrict__ rec, const cssm_u128* __restrict__ subS,
+                                                              const cssm_u128* __restrict__ subS2, uint32_t nsub,
+                                                              const Scalars* __restrict__ sc, double* __restrict__ out, uint64_t chunk,
+                                                              int level_from_max, cssm_u128* __restrict__ pre_out,
+                                                              const PeerTable* __restrict__ peer = nullptr, int parity = 0, uint32_t seq = 0u,
+                                                              unsigned int* __restrict__ tickets = nullptr) {
+  boundary_pack_block(blockIdx.x, gridDim.x, (int)blockIdx.y, src, stride, logw, n_local, d, world, rank, cap, rec, subS, subS2, nsub, sc, out, chunk,
+                      level_from_max, pre_out, peer, parity, seq, tickets, nullptr);
 }
 
 // After the all-to-all: every segment's rows -> the slots of this rank they own.  Global cumulative weight of row i of
@@ -318,26 +357,29 @@ struct SpecHeaders {
   cssm_u128 S[64], off[64], base[64], plow[64], phigh[64];
   long long cnt[64];
   unsigned long long cnts[64][4];
-  cssm_u128 tot;
+  cssm_u128 tot, tot2;
+  unsigned long long key[64], gkey;      // the ranks' max keys, the largest of them
+  cssm_u128 S2[64];
   int all_ok;
 };
 // (the header words of rank threadIdx.x, requested by the kernel together with everything else it starts from: the verdict
 //  used to begin with three round trips one behind the other -- the sticky bits, the max keys, the headers -- and a fourth
 //  for the record's u in its middle: 3 us before a block had so much as asked for its weights)
-struct SpecHdrRegs { double w[9]; };
+struct SpecHdrRegs { double w[12]; };
 __device__ __forceinline__ SpecHdrRegs spec_load_headers(const double* __restrict__ recv, int world, long long cap, int d) {
   SpecHdrRegs g;
 #pragma unroll
-  for (int k = 0; k < 9; ++k) g.w[k] = 0.0;
+  for (int k = 0; k < 12; ++k) g.w[k] = 0.0;
   if ((int)threadIdx.x < world) {
     const double* h = recv + (size_t)threadIdx.x * spec_seg(d, cap);
     g.w[0] = ld_sys_f64(h); g.w[1] = ld_sys_f64(h + 1); g.w[2] = ld_sys_f64(h + 2); g.w[3] = ld_sys_f64(h + 6); g.w[4] = ld_sys_f64(h + 7);
     g.w[5] = ld_sys_f64(h + 8); g.w[6] = ld_sys_f64(h + 9); g.w[7] = ld_sys_f64(h + 10); g.w[8] = ld_sys_f64(h + 11);
+    g.w[9] = ld_sys_f64(h + 3); g.w[10] = ld_sys_f64(h + 4); g.w[11] = ld_sys_f64(h + 5);   // S2, the key of the rank's max
   }
   return g;
 }
-__device__ __forceinline__ bool spec_read_headers(SpecHeaders& H, const SpecHdrRegs& g, int world, int rank, long long cap, int d,
-                                                  uint64_t n_local, uint64_t n_global, const double u) {
+// stage 1: the headers into LDS, the ranks' offsets, the totals and the largest max key (all threads call; two barriers)
+__device__ __forceinline__ void spec_store_headers(SpecHeaders& H, const SpecHdrRegs& g, int world, long long cap) {
   if (threadIdx.x < 64) {
     cssm_u128 S = cssm_u128_zero(), bs = cssm_u128_zero(), pl = cssm_u128_zero(), ph = cssm_u128_zero();
     long long c = 0;
@@ -348,15 +390,25 @@ __device__ __forceinline__ bool spec_read_headers(SpecHeaders& H, const SpecHdrR
       c = (c < 0) ? 0 : ((c > cap) ? cap : c);
     }
     H.S[threadIdx.x] = S; H.base[threadIdx.x] = bs; H.plow[threadIdx.x] = pl; H.phigh[threadIdx.x] = ph; H.cnt[threadIdx.x] = c;
+    cssm_u128 S2; S2.lo = cssm_d2u(g.w[9]); S2.hi = cssm_d2u(g.w[10]);
+    H.S2[threadIdx.x] = S2; H.key[threadIdx.x] = ((int)threadIdx.x < world) ? cssm_d2u(g.w[11]) : 0ull;
   }
   __syncthreads();
   if (threadIdx.x == 0) {
-    cssm_u128 run = cssm_u128_zero();
-    for (int r = 0; r < world; ++r) { H.off[r] = run; run = cssm_u128_add(run, H.S[r]); }
-    H.tot = run;
+    cssm_u128 run = cssm_u128_zero(), run2 = cssm_u128_zero();
+    unsigned long long key = 0ull;
+    for (int r = 0; r < world; ++r) {
+      H.off[r] = run; run = cssm_u128_add(run, H.S[r]); run2 = cssm_u128_add(run2, H.S2[r]);
+      key = (H.key[r] > key) ? H.key[r] : key;
+    }
+    H.tot = run; H.tot2 = run2; H.gkey = key;
     H.all_ok = 1;
   }
   __syncthreads();
+}
+// stage 2: the verdict (all threads call)
+__device__ __forceinline__ bool spec_read_headers(SpecHeaders& H, int world, int rank, long long cap, int d,
+                                                  uint64_t n_local, uint64_t n_global, const double u) {
   const double totd = cssm_u128_to_double(H.tot);
   const bool pow2 = (n_global & (n_global - 1)) == 0;
   const double inv_n = 1.0 / (double)n_global;
@@ -470,10 +522,11 @@ __device__ __forceinline__ void expand_spec_body(SpecHeaders& H, uint32_t bid, u
 // exchange is done (disjoint slots; both read only the segment headers), and a launch costs ~5 us of latency.  Every block
 // is a k_offspring block first and then expands its share of the received rows; `optimistic` = 2 makes the offspring
 // side raise err bit 2 itself (no later kernel reads the flag).
-// EVERY block first takes the verdict of spec_read_headers.  If some rank's slots are not covered, the whole launch
-// does NOTHING on every rank except recording err bit 3 and the observation index: the state is exactly as the
-// propagate of this observation left it, every later kernel of the series returns at once (they test the bit), and
-// the host redoes this observation's exchange with a larger capacity and carries on (cssm_pf_shard_resume).
+// Block 0 takes the verdict of spec_read_headers.  If some rank's slots are not covered, the launch changes NOTHING THAT MATTERS
+// on any rank -- no scalars published, no max slots cleared; the ancestor indices the other blocks wrote are overwritten when the
+// observation's exchange is redone -- and records err bit 3 and the observation index: every later kernel of the series returns
+// at once (they test the bit), and the host redoes this observation's exchange with a larger capacity and carries on
+// (cssm_pf_shard_resume).
 #ifdef CSSM_OFF_STAMPS
 __device__ unsigned long long g_spec_stamps[2048 * 8];   // diagnostic build: clock stamps of k_offspring_expand_spec's blocks
 #define CSSM_SPEC_STAMP(k) do { if (threadIdx.x == 0 && blockIdx.x < 2048) g_spec_stamps[blockIdx.x * 8 + (k)] = __builtin_amdgcn_s_memrealtime(); } while (0)
@@ -483,9 +536,13 @@ __device__ unsigned long long g_spec_stamps[2048 * 8];   // diagnostic build: cl
 // RAWC: how the weights are stored, at compile time (2: the weights k_propagate_shard formed relative to the reference level; 0:
 // log-weights, rescaled by the level the global max gave -- LGCP, a series repeated after an outlying observation)
 template <int RAWC>
-__global__ __launch_bounds__(CSSM_BLOCK, CSSM_OFF_WAVES) void k_offspring_expand_spec(
+__device__ __forceinline__ void offspring_expand_spec_body(
     CSSM_OFFSPRING_PARAMS, uint32_t all5_stride, const double* __restrict__ recv, long long cap, int d, uint32_t n_split,
-    const cssm_u128* __restrict__ unit_pre, const unsigned int* __restrict__ peer_flags = nullptr, uint32_t peer_seq = 0u) {
+    const cssm_u128* __restrict__ unit_pre, const unsigned int* __restrict__ peer_flags, uint32_t peer_seq,
+    const uint32_t blk0, const unsigned int* __restrict__ pre_flag) {
+  // blk0 / pre_flag (the merged kernel k_exchange_offspring): this body runs in blocks blk0 .. of the launch; unit_pre is written by
+  // one of the blocks before them and announced through pre_flag
+  const uint32_t bidx = blockIdx.x - blk0, nblk = gridDim.x - blk0;
   // unit_pre (or nullptr): the exclusive prefixes of the unit sums k_boundary_pack's header block left (its pre_out)
   // peer_flags (peer-written exchange; else nullptr): this rank's flags of the window `recv` is -- one line per source rank; the
   // segment of rank r is complete once its flag holds peer_seq (PeerTable).  Every block waits for every rank's flag (thread r
@@ -493,59 +550,110 @@ __global__ __launch_bounds__(CSSM_BLOCK, CSSM_OFF_WAVES) void k_offspring_expand
   // GPU, and the series ends like one on hold.
   __shared__ SpecHeaders H;
   CSSM_SPEC_STAMP(0);
-  if (peer_flags != nullptr) {
-    __shared__ unsigned int s_late;
-    if (sc->err & (4u | 8u | 16u)) return;   // (on hold / void / a peer missing: nobody delivers, nobody waits)
+  __shared__ unsigned int s_late;
+  // thread r waits for rank r's flag (word `which` of its pair: 0 header, CSSM_PEER_FLAG_ROWS rows), thread `world` for the local
+  // flag `extra` if there is one; false: some flag did not come within the bound (err bit 4, the series ends like one on hold)
+  auto wait_flags = [&](uint32_t which, const unsigned int* extra, int r_lo, int r_hi) -> bool {
     if (threadIdx.x == 0) s_late = 0u;
     __syncthreads();
-    if ((int)threadIdx.x < world) {
-      const unsigned int* f = peer_flags + (size_t)threadIdx.x * CSSM_PEER_FLAG_STRIDE;
+    const int r = (int)threadIdx.x;
+    if ((r >= r_lo && r <= r_hi && r < world) || (r == world && extra != nullptr)) {
+      const unsigned int* f = (r < world) ? peer_flags + (size_t)r * CSSM_PEER_FLAG_STRIDE + which : extra;
       unsigned int spins = 0u;
       // (relaxed system-scope loads: each one reads the flag at the point of coherence; the window itself is read with such loads
       //  too -- ld_sys, no fence: see there -- and the next kernel's gathers start behind a kernel boundary)
       while (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != peer_seq) {
         if (++spins > CSSM_PEER_SPIN_LIMIT) { s_late = 1u; break; }
-        __builtin_amdgcn_s_sleep(8);
+        __builtin_amdgcn_s_sleep(4);
       }
     }
     __syncthreads();
     if (s_late) {
       if (threadIdx.x == 0) { atomicOr(&sc->err, 16u); atomicMin(&sc->fail_step, rec->step); }
-      return;
+      return false;
     }
+    return true;
+  };
+  double pre_w[CSSM_ITEMS];
+  const bool prefetched = peer_flags != nullptr && bidx < nunits;   // (uniform)
+  if (peer_flags != nullptr) {
+    // the block's first tile of weights is requested BEFORE the wait (it depends on nothing the peers send)
+    if (prefetched) load_tile_raw(logw, (uint64_t)bidx * sup * CSSM_TILE, n, RAWC, pre_w);
+    if (sc->err & (4u | 8u | 16u)) return;   // (on hold / void / a peer missing: nobody delivers, nobody waits)
+    if (!wait_flags(0u, pre_flag, 0, world - 1)) return;          // every rank's header (and this launch's unit-sum prefixes)
   }
   // everything the verdict starts from is requested first, tested afterwards
   const uint32_t held = sc->err;
   const double rec_ref = rec->ref, rec_u = rec->u;
-  unsigned long long key = 0ull;
-  if (optimistic) for (int r = 0; r < world; ++r) { const unsigned long long k = ld_sys_u64(all5 + (size_t)all5_stride * r + 4); key = (k > key) ? k : key; }
-  const SpecHdrRegs hregs = spec_load_headers(recv, world, cap, d);
+  const SpecHdrRegs hregs = spec_load_headers(recv, world, cap, d);   // (thread r: the 12 header words of rank r -- sums, max key, block totals)
   // (measured and dropped: the weights of the block's first tile requested here as well, ahead of the verdict -- 11.8 -> 12.3 us at
   //  2^20 per rank, eight more registers live across the verdict)
   if (held & (4u | 8u | 16u)) return;
+  spec_store_headers(H, hregs, world, cap);
   if (optimistic) {
     // the level first: sums formed relative to a reference level that the global max rules out (an outlying observation) say
     // nothing about coverage either.  Sticky bit 2 (4): every later kernel of the series returns at once, the host runs
     // the series again with the levels taken from the global max.
-    if (!(cssm_ref_choose(rec_ref, cssm_order_unkey(key)) == rec_ref)) {
-      if (blockIdx.x == 0 && threadIdx.x == 0) atomicOr(&sc->err, 4u);
+    if (!(cssm_ref_choose(rec_ref, cssm_order_unkey(H.gkey)) == rec_ref)) {
+      if (bidx == 0 && threadIdx.x == 0) atomicOr(&sc->err, 4u);
       return;
     }
   }
-  if (!spec_read_headers(H, hregs, world, rank, cap, d, n, n_global, rec_u)) {
-    if (blockIdx.x == 0 && threadIdx.x == 0) { atomicOr(&sc->err, 8u); atomicMin(&sc->fail_step, rec->step); }
+  // The coverage verdict is BLOCK 0's business alone.  What must not happen on a capacity miss is what block 0 does: publishing the
+  // observation's scalars (ll would count twice when the observation is redone) and clearing the max slots (the redone pack reads
+  // them again).  The other blocks write nothing but ancestor indices -- of slots the redone exchange writes again, all of them, before
+  // anybody gathers through them -- so they do not wait for a verdict they cannot act on: three block barriers and 4 x world exact
+  // slot counts less on the path of every block but one (round 3: 2.9 us from entry to verdict in all 1024 blocks).
+  if (bidx == 0 && !spec_read_headers(H, world, rank, cap, d, n, n_global, rec_u)) {
+    if (threadIdx.x == 0) { atomicOr(&sc->err, 8u); atomicMin(&sc->fail_step, rec->step); }
     return;
   }
   CSSM_SPEC_STAMP(1);
+  // the ranks' totals as the body wants them: read once per block above, not world x 5 times per thread
+  SpecTotals tt;
+  tt.S_off.lo = H.off[rank].lo; tt.S_off.hi = H.off[rank].hi; tt.tot.lo = H.tot.lo; tt.tot.hi = H.tot.hi;
+  tt.tot2.lo = H.tot2.lo; tt.tot2.hi = H.tot2.hi; tt.gmax = cssm_order_unkey(H.gkey);
   // (the arguments the single-collective launch has no use for are constants here: the compiler drops what hangs on them)
   (void)raw;
   offspring_body<true, false, CSSM_RESAMPLE_SYSTEMATIC, RAWC>(logw, n, sc, unitP, unitS2, rec, n_global, /*endslot=*/nullptr, anc, ntiles, sup, nunits, RAWC, slot_set,
                                                         /*ll_t=*/nullptr, /*ess_t=*/nullptr, 0u, force_exact, all5, rank, world, split, /*seed=*/0ull,
                                                         /*cum_out=*/nullptr, /*logtab=*/nullptr, optimistic, flag_out, slot_lo, slot_hi, all5_stride,
-                                                        /*s2buf=*/nullptr, 0u, -1, 0u, unit_pre);
+                                                        /*s2buf=*/nullptr, 0u, -1, 0u, unit_pre, blk0, prefetched ? pre_w : nullptr, &tt);
   CSSM_SPEC_STAMP(2);
-  expand_spec_body(H, blockIdx.x, gridDim.x, recv, world, rank, cap, d, n_split, (uint64_t)slot_lo, (uint64_t)slot_hi, n_global, rec, anc, sc);
+  // the two neighbours' rows (their flags have long been set: the rows were written while this block resampled its own particles)
+  if (peer_flags != nullptr && !wait_flags(CSSM_PEER_FLAG_ROWS, nullptr, rank - 1, rank + 1)) return;
+  expand_spec_body(H, bidx, nblk, recv, world, rank, cap, d, n_split, (uint64_t)slot_lo, (uint64_t)slot_hi, n_global, rec, anc, sc);
   CSSM_SPEC_STAMP(3);
+}
+
+template <int RAWC>
+__global__ __launch_bounds__(CSSM_BLOCK, CSSM_OFF_WAVES) void k_offspring_expand_spec(
+    CSSM_OFFSPRING_PARAMS, uint32_t all5_stride, const double* __restrict__ recv, long long cap, int d, uint32_t n_split,
+    const cssm_u128* __restrict__ unit_pre, const unsigned int* __restrict__ peer_flags = nullptr, uint32_t peer_seq = 0u) {
+  offspring_expand_spec_body<RAWC>(CSSM_OFFSPRING_FWD, all5_stride, recv, cap, d, n_split, unit_pre, peer_flags, peer_seq, 0u, nullptr);
+}
+
+// The peer-written exchange in ONE launch per weighted observation behind the propagate: the first pack_gx * world blocks of the grid
+// are k_boundary_pack's -- they write this rank's segments into the peers' windows, set the flags and leave (they wait for nothing,
+// and being the first blocks of the grid they are dispatched first: nobody who polls can keep them from running) -- and every
+// later block is a k_offspring_expand_spec block: it waits for all ranks' flags (and for the unit-sum prefixes one of the pack
+// blocks leaves), then resamples.  A dependent launch less per observation (~3 us of launch + the pack kernel's own first round trips).
+struct PackArgs {
+  const double* src; size_t stride; uint32_t nsub; uint64_t chunk; cssm_u128* pre_out;
+  const PeerTable* peer; int parity; unsigned int* tickets; unsigned int* pre_flag; uint32_t pack_gx;
+};
+template <int RAWC>
+__global__ __launch_bounds__(CSSM_BLOCK, CSSM_OFF_WAVES) void k_exchange_offspring(
+    CSSM_OFFSPRING_PARAMS, uint32_t all5_stride, const double* __restrict__ recv, long long cap, int d, uint32_t n_split,
+    const cssm_u128* __restrict__ unit_pre, const unsigned int* __restrict__ peer_flags, uint32_t peer_seq, PackArgs pk) {
+  const uint32_t blk0 = pk.pack_gx * (uint32_t)world;
+  if (blockIdx.x < blk0) {
+    boundary_pack_block(blockIdx.x % pk.pack_gx, pk.pack_gx, (int)(blockIdx.x / pk.pack_gx), pk.src, pk.stride, logw, n, d, world, rank, cap, rec,
+                        unitP, unitS2, pk.nsub, sc, nullptr, pk.chunk, /*level_from_max=*/0, pk.pre_out, pk.peer, pk.parity, peer_seq, pk.tickets,
+                        pk.pre_flag);
+    return;
+  }
+  offspring_expand_spec_body<RAWC>(CSSM_OFFSPRING_FWD, all5_stride, recv, cap, d, n_split, unit_pre, peer_flags, peer_seq, blk0, pk.pre_flag);
 }
 
 __global__ __launch_bounds__(CSSM_BLOCK) void k_expand(const uint32_t* __restrict__ cand_end, const uint32_t* __restrict__ cand_idx,

@@ -477,8 +477,9 @@ int cssm_pf_shard_series_rccl(cssm_pf* pf, void* comm, int rank, int world, size
  * a process, and for the rank itself).  k_boundary_pack writes segment (rank -> q) -- header, and for the two adjacent ranks the
  * boundary rows -- straight into q's window and, when the last of its blocks has made its stores visible at system scope, stores the
  * exchange number into q's flag (release); q's k_offspring_expand_spec polls the flags of all ranks (acquire, bounded: a rank that
- * never delivers raises a device error instead of hanging the GPU) before it reads a header.  Three launches per weighted
- * observation -- propagate, pack, offspring + expansion -- and nothing else: no RCCL launch, no host wait.  The windows hold the
+ * never delivers raises a device error instead of hanging the GPU) before it reads a header.  Two launches per weighted
+ * observation -- propagate, then pack + offspring + expansion in one (the pack blocks lead the grid) -- and nothing else: no RCCL
+ * launch, no host wait.  The windows hold the
  * capacity they were set up for; an exchange that is resumed with a larger capacity, and observations whose level comes from the
  * global max, go through the collective exchange above (the two share every kernel and produce the same bits).
  *   cssm_pf_shard_peer_setup    allocate this rank's slab for (world, cap); *mine_out = what the other ranks need to map it
@@ -500,6 +501,9 @@ int cssm_pf_shard_peer_connect(cssm_pf* pf, const cssm_peer_handle* all_handles,
 void cssm_pf_shard_peer_close(cssm_pf* pf);
 int cssm_pf_shard_pack_peer(cssm_pf* pf, int rank, int world, int64_t cap);
 int cssm_pf_shard_adopt_peer(cssm_pf* pf, int rank, int world, int64_t cap);
+/* pack + adopt in ONE launch (the pack blocks lead the grid): for a rank that has its stream to itself, i.e. one process per GPU --
+ * what cssm_pf_shard_series_peer enqueues.  Shards that share a stream use the two stage calls, every pack before any adopt. */
+int cssm_pf_shard_exchange_peer(cssm_pf* pf, int rank, int world, int64_t cap);
 int cssm_pf_shard_series_peer(cssm_pf* pf, int rank, int world, size_t s_begin, size_t s_end, const uint8_t* weighted, int64_t cap);
 
 /* ---- PMMH host loop ---------------------------------------------------------------------- */

@@ -142,7 +142,9 @@ def test_peer_exchange_world1_under_torch_distributed():
             shard.profile(False)
             assert f.last_peer and (ll, ess) == (oll, oess[-1])
             nw = int(np.sum(has[5:])) if not prec else len(t) - 5
-            assert prof["collective"][1] == 0 and prof["k_boundary_pack"][1] == nw and prof["k_offspring_expand_spec"][1] == nw
+            # no collective; the pack blocks lead the grid of the offspring launch (k_exchange_offspring); the first LGCP event of a NEW
+            # series goes through the collective exchange -- not in a continued one
+            assert prof["collective"][1] == 0 and prof["k_boundary_pack"][1] == 0 and prof["k_offspring_expand_spec"][1] == nw
             shard.close()
             f.comm.close()
     finally:

@@ -1,16 +1,17 @@
 """A/B of one library option in one process (two handles, alternating runs): usage ab_opt.py model N T option valueA valueB
-(model: c2 | c1 | d<k>).  Prints the best and median device time per observation and checks that both settings give the same bits."""
+(model: c2 | c1 | c4 (LGCP, precision 2, event times) | d<k>).  Prints the best and median device time per observation and checks that both settings give the same bits."""
 import sys, os
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, ROOT + "/tests")
 import numpy as np, cases
 from composablestatespacemodels_amd.filter import NativePf
 which, n, T, opt, va, vb = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]), int(sys.argv[5]), int(sys.argv[6])
-model = cases.c2_model() if which == "c2" else (cases.c1_model() if which == "c1" else cases.dim_model(int(which[1:])))
-t, y, has = cases.poisson_counts(T, missing=0.05)
+prec = 2 if which == "c4" else 0
+model = cases.c4_model() if which == "c4" else (cases.c2_model() if which == "c2" else (cases.c1_model() if which == "c1" else cases.dim_model(int(which[1:]))))
+t, y, has = cases.event_times(T, horizon=0.1 * T) if which == "c4" else cases.poisson_counts(T, missing=0.05)
 hs = {}
 for v in (va, vb):
-    g = NativePf(model, n, cases.SEED); g.set_option(opt, v); g.run(t[:10], y[:10], has[:10]); hs[v] = g
+    g = NativePf(model, n, cases.SEED, lgcp_precision=prec); g.set_option(opt, v); g.run(t[:10], y[:10], has[:10]); hs[v] = g
 res = {v: [] for v in hs}; out = {}
 for rep in range(5):
     for v, g in hs.items():
