@@ -57,6 +57,10 @@ int cssm_prop_items(int d) { return d <= 2 ? CSSM_PROP_IT_LO : (d <= 8 ? CSSM_PR
 
 // k_propagate blocks per 1024-particle unit on a single-GPU handle: one tile of the kernel per block below 2^20 particles
 static uint32_t auto_split(const cssm_pf* pf) {
+  // (measured and dropped: a shard of an LGCP filter on blocks of 1024 particles where a unit has 2048 -- k_propagate 71.8 -> 68.4 us at
+  //  2^21 particles per rank, one round of whole-unit blocks running in lockstep being 12 % slower per particle than the same kernel on
+  //  several rounds; but the exchange kernel's header and prefix blocks, which every block of every rank waits for, then total twice
+  //  the sums: 18.5 -> 20.4 us, the step 89.5 -> 90.3)
   if (pf->sharded || pf->sup != 1 || pf->n >= CSSM_SPLIT_MAX_N) return 1u;
   return cssm_prop_items(pf->d) == 1 ? 4u : 2u;   // one tile of the kernel: half of 1024 (two particles per thread), a quarter (one)
 }

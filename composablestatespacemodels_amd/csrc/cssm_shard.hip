@@ -444,17 +444,20 @@ static int boundary_pack_impl(cssm_pf* pf, int rank, int world, int64_t cap, dou
   if (cap < 1 || world < 1 || world > 64 || rank < 0 || rank >= world) return fail(CSSM_ESHARD, "rank %d / world %d / cap %lld", rank, world, (long long)cap);
   // !last_optimistic: the sums were formed by cssm_pf_shard_sums relative to the level chosen with the all-gathered max
   const size_t slot = last_rec_slot(pf);
-  const uint64_t chunk = (uint64_t)pf->sup * CSSM_TILE / pf->split;
+  // (the sums a propagate formed are per block -- pf->split blocks per unit; the sums of cssm_pf_shard_sums per unit)
+  const uint32_t split = pf->last_optimistic ? pf->split : 1u;
+  const uint64_t chunk = (uint64_t)pf->sup * CSSM_TILE / split;
   const uint32_t nsub = (uint32_t)((pf->n + chunk - 1) / chunk);
   const long long cnt = std::min<long long>((long long)pf->n, (long long)cap);
   const int tiles = (int)((cnt + CSSM_TILE - 1) / CSSM_TILE);
+  const bool pre = nsub <= 8u * CSSM_BLOCK;   // (the prefix block's reach)
   prof_begin(pf, CSSM_K_PACK);
   hipLaunchKernelGGL(k_boundary_pack, dim3(tiles + 2, world), dim3(CSSM_BLOCK), 0, pf->stream, pf->state[pf->cur], pf->stride, pf->logw, pf->n, pf->d,
                      world, rank, (long long)cap, pf->d_recs + slot, (const cssm_u128*)pf->tileS, (const cssm_u128*)pf->tileS2, nsub,
                      (const Scalars*)pf->sc, send_buf_dev, chunk, pf->last_optimistic ? 0 : 1,
-                     (pf->split == 1 && nsub <= 4u * CSSM_BLOCK) ? pf->unitPre : (cssm_u128*)nullptr,
+                     pre ? pf->unitPre : (cssm_u128*)nullptr,
                      peer ? (const PeerTable*)pf->peer_tab : (const PeerTable*)nullptr, (int)(pf->peer_seq & 1u), pf->peer_seq, pf->peer_tickets);
-  pf->spec_pre = (pf->split == 1 && nsub <= 4u * CSSM_BLOCK);   // (k_offspring_expand_spec reads them: cssm_pf_shard_adopt_spec)
+  pf->spec_pre = pre;   // (k_offspring_expand_spec reads them: cssm_pf_shard_adopt_spec)
   prof_end(pf);
   HIP_TRY(hipGetLastError());
   return CSSM_OK;
@@ -486,7 +489,7 @@ static int adopt_spec_impl(cssm_pf* pf, const double* recv_buf_dev, int rank, in
     const uint64_t chunk = (uint64_t)pf->sup * CSSM_TILE / pf->split;
     const uint32_t nsub = (uint32_t)((pf->n + chunk - 1) / chunk);
     const long long cnt = std::min<long long>((long long)pf->n, (long long)cap);
-    const bool pre = (pf->split == 1 && nsub <= 4u * CSSM_BLOCK);
+    const bool pre = nsub <= 8u * CSSM_BLOCK;
     PackArgs pk;
     pk.src = pf->state[pf->cur]; pk.stride = pf->stride; pk.nsub = nsub; pk.chunk = chunk;
     pk.pre_out = pre ? pf->unitPre : (cssm_u128*)nullptr;
@@ -505,7 +508,7 @@ static int adopt_spec_impl(cssm_pf* pf, const double* recv_buf_dev, int rank, in
     hipLaunchKernelGGL(k_offspring_expand_spec<2>, dim3(tgrid), dim3(CSSM_BLOCK), 0, pf->stream, pf->logw, pf->n, pf->sc,
                      (const cssm_u128*)pf->tileS, (const cssm_u128*)pf->tileS2, (const StepRec*)(pf->d_recs + slot), pf->n_global, pf->endslot,
                      pf->anc, pf->ntiles, pf->sup, pf->nunits, pf->last_optimistic ? 2 : 0, 0, (double*)nullptr, (int32_t*)nullptr, 0u, pf->opt_exact,
-                     all5, rank, world, (int)pf->split, pf->seed, (double*)nullptr, (const double*)pf->d_logtab,
+                     all5, rank, world, pf->last_optimistic ? (int)pf->split : 1, pf->seed, (double*)nullptr, (const double*)pf->d_logtab,
                      pf->last_optimistic ? 2 : 0, (unsigned long long*)(pf->d_xch + 128), (uint32_t)pf->first, (uint32_t)(pf->first + pf->n), (uint32_t)seg,
                      recv_buf_dev, (long long)cap, pf->d, n_split, pf->spec_pre ? (const cssm_u128*)pf->unitPre : (const cssm_u128*)nullptr,
                      peer_flags, peer_seq);
@@ -513,7 +516,7 @@ static int adopt_spec_impl(cssm_pf* pf, const double* recv_buf_dev, int rank, in
     hipLaunchKernelGGL(k_offspring_expand_spec<0>, dim3(tgrid), dim3(CSSM_BLOCK), 0, pf->stream, pf->logw, pf->n, pf->sc,
                      (const cssm_u128*)pf->tileS, (const cssm_u128*)pf->tileS2, (const StepRec*)(pf->d_recs + slot), pf->n_global, pf->endslot,
                      pf->anc, pf->ntiles, pf->sup, pf->nunits, pf->last_optimistic ? 2 : 0, 0, (double*)nullptr, (int32_t*)nullptr, 0u, pf->opt_exact,
-                     all5, rank, world, (int)pf->split, pf->seed, (double*)nullptr, (const double*)pf->d_logtab,
+                     all5, rank, world, pf->last_optimistic ? (int)pf->split : 1, pf->seed, (double*)nullptr, (const double*)pf->d_logtab,
                      pf->last_optimistic ? 2 : 0, (unsigned long long*)(pf->d_xch + 128), (uint32_t)pf->first, (uint32_t)(pf->first + pf->n), (uint32_t)seg,
                      recv_buf_dev, (long long)cap, pf->d, n_split, pf->spec_pre ? (const cssm_u128*)pf->unitPre : (const cssm_u128*)nullptr,
                      peer_flags, peer_seq);

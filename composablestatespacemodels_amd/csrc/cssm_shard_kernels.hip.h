@@ -99,7 +99,7 @@ __device__ __forceinline__ void boundary_pack_block(const uint32_t bx, const uin
   // bx / gx / q: the block's place in a (gx, world) grid -- blockIdx.x, gridDim.x, blockIdx.y of k_boundary_pack; the merged
   // exchange + offspring kernel of the peer-written exchange hands its first gx * world blocks through here
   // pre_flag (merged kernel; else nullptr): the prefix block announces pre_out with the exchange number (agent-scope release)
-  // pre_out (nsub <= 4 * CSSM_BLOCK, else nullptr): the header block of segment 0 also writes the EXCLUSIVE prefix of the sub-unit
+  // pre_out (nsub <= 8 * CSSM_BLOCK, else nullptr): a block of its own (segment 0's last) also writes the EXCLUSIVE prefix of the sub-unit
   // sums -- pre_out[j] = subS[0] + .. + subS[j - 1] -- which k_offspring_expand_spec's block j then reads as one word instead of
   // summing j entries itself (on average 8 KiB per block and a block-wide sum with two barriers)
   // level_from_max: the sums (subS) were formed relative to the level chosen with the GLOBAL max after an all-gather of the
@@ -163,26 +163,29 @@ __device__ __forceinline__ void boundary_pack_block(const uint32_t bx, const uin
   };
   // grid.x = tiles of the block + 2: the header has a block of its own, and so have the prefixes of the sub-unit sums (pre_out; in the
   // header block they lengthened the launch's longest latency chain by 1.6 us)
-  if (bx == gx - 1) {   // the prefix block: thread t owns the entries 4 t .. 4 t + 3
+  if (bx == gx - 1) {   // the prefix block: thread t owns the E consecutive entries from t E on (E = 4; 8 beyond 1024 sub-unit sums)
     if (pre_out == nullptr || q != 0) return;
     // (the entries are requested ahead of the hold test)
     __shared__ cssm_u128 s_p[CSSM_BLOCK / 64];
-    cssm_u128 v[4];
+    constexpr int EMAX = 8;
+    const uint32_t E = (nsub > 4u * CSSM_BLOCK) ? (uint32_t)EMAX : 4u;   // (uniform)
+    cssm_u128 v[EMAX];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) { const uint32_t i = threadIdx.x * 4u + (uint32_t)k; v[k] = (i < nsub) ? subS[i] : cssm_u128_zero(); }
-    const cssm_u128 e1 = v[0], e2 = cssm_u128_add(e1, v[1]), e3 = cssm_u128_add(e2, v[2]), own = cssm_u128_add(e3, v[3]);
+    for (int k = 0; k < EMAX; ++k) { const uint32_t i = threadIdx.x * E + (uint32_t)k; v[k] = ((uint32_t)k < E && i < nsub) ? subS[i] : cssm_u128_zero(); }
+    cssm_u128 run[EMAX];   // run[k] = v[0] + .. + v[k - 1]
+    cssm_u128 own = cssm_u128_zero();
+#pragma unroll
+    for (int k = 0; k < EMAX; ++k) { run[k] = own; own = cssm_u128_add(own, v[k]); }
     const cssm_u128 inc = wave_scan_u128(own, lane);
     if (lane == 63) s_p[wid] = inc;
     __syncthreads();
     cssm_u128 ex = inc;                                  // exclusive prefix of the thread's first entry: inc - own + the waves before
     ex.hi = inc.hi - own.hi - (inc.lo < own.lo ? 1ull : 0ull); ex.lo = inc.lo - own.lo;
     for (int w = 0; w < wid; ++w) ex = cssm_u128_add(ex, s_p[w]);
-    const uint32_t i0 = threadIdx.x * 4u;
+    const uint32_t i0 = threadIdx.x * E;
     if (held) return;
-    if (i0 < nsub) pre_out[i0] = ex;
-    if (i0 + 1u < nsub) pre_out[i0 + 1u] = cssm_u128_add(ex, e1);
-    if (i0 + 2u < nsub) pre_out[i0 + 2u] = cssm_u128_add(ex, e2);
-    if (i0 + 3u < nsub) pre_out[i0 + 3u] = cssm_u128_add(ex, e3);
+#pragma unroll
+    for (int k = 0; k < EMAX; ++k) if ((uint32_t)k < E && i0 + (uint32_t)k < nsub) pre_out[i0 + (uint32_t)k] = cssm_u128_add(ex, run[k]);
     if (pre_flag != nullptr) {   // (merged kernel: the offspring blocks of this very launch read them, behind this flag)
       __threadfence();
       __syncthreads();
