@@ -310,7 +310,20 @@ def run_multi(args, emit=print):
     sync = torch.cuda.synchronize if gpu else (lambda: None)
     dev = "cuda" if gpu else "cpu"
     # the W warm-up observations START the sharded filter ...
-    f.ll_filter(t[:Wn], y[:Wn], has[:Wn], lgcp=lgcp)
+    fallbacks = []
+    try:
+        f.ll_filter(t[:Wn], y[:Wn], has[:Wn], lgcp=lgcp)
+    except RuntimeError as e:
+        # (raised on every rank alike: libcssm_pf could not make its own RCCL communicator -- the collectives then go through
+        #  torch.distributed, and the line says so)
+        if not gpu or "CSSM_SHARD_NATIVE" not in str(e):
+            raise
+        fallbacks.append(str(e))
+        os.environ["CSSM_SHARD_NATIVE"] = "0"
+        f = ShardedFilter([shard], DistComm(device=torch.device("cuda", local)))
+        f.ll_filter(t[:Wn], y[:Wn], has[:Wn], lgcp=lgcp)
+    if getattr(f, "peer_refused", None):
+        fallbacks.append("peer-written exchange refused: " + str(f.peer_refused))
     # ... and every timed leg CONTINUES it with exactly K more (the sharded cssm_pf_ll_filter_more: records built and uploaded,
     # kernels and collectives enqueued by the library, one status read per stretch, ll / ess read back -- no new cloud, no k_init),
     # bracketed by a barrier + device synchronisation on both sides; a leg's time is the MAX over the ranks, the figure the
@@ -366,6 +379,7 @@ def run_multi(args, emit=print):
                          "collectives_issued_by": ("none per observation" if peer else
                                                    ("libcssm_pf (cssm_pf_shard_series_rccl)" if native else "torch.distributed")),
                          "all_to_all": getattr(f, "last_all_to_all", "equal split"),
+                         "fallbacks": fallbacks,
                          "rccl": shard.lib.cssm_rccl_library().decode() if gpu else None},
             "per_rank": every,
             "ll": ll, "ess_last": ess}))

@@ -657,6 +657,24 @@ extern "C" int cssm_pf_shard_peer_connect(cssm_pf* pf, const cssm_peer_handle* a
   return CSSM_OK;
 }
 
+// One empty round of the protocol across all ranks (every rank calls it at the same point, e.g. behind a barrier of the host's
+// control plane): CSSM_OK, or CSSM_ESHARD naming how many ranks' tokens did not arrive within the wait bound.
+extern "C" int cssm_pf_shard_peer_handshake(cssm_pf* pf, uint32_t token) {
+  int rc = shard_check(pf);
+  if (rc) return rc;
+  PeerState* ps = static_cast<PeerState*>(pf->peer);
+  if (!ps || !ps->connected) return fail(CSSM_ESTATE, "peer windows are not set up (cssm_pf_shard_peer_setup / _connect)");
+  if (token == 0u) return fail(CSSM_EINVAL_ARG, "the token must not be zero (the flags start there)");
+  unsigned int* res = pf->peer_tickets + 96;   // (a word of the ticket allocation nobody else uses)
+  hipLaunchKernelGGL(k_peer_handshake, dim3(1), dim3(64), 0, pf->stream, (const PeerTable*)pf->peer_tab, ps->world, ps->rank, token, res);
+  HIP_TRY(hipGetLastError());
+  unsigned int missing = 0u;
+  HIP_TRY(hipMemcpyAsync(&missing, res, sizeof missing, hipMemcpyDeviceToHost, pf->stream));
+  HIP_TRY(hipStreamSynchronize(pf->stream));
+  if (missing) return fail(CSSM_ESHARD, "peer handshake: the tokens of %u of %d ranks did not arrive in this rank's windows", missing, ps->world);
+  return CSSM_OK;
+}
+
 extern "C" void cssm_pf_shard_peer_close(cssm_pf* pf) {
   if (!pf) return;
   (void)hipSetDevice(pf->device);

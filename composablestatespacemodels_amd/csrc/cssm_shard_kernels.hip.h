@@ -83,6 +83,29 @@ struct PeerTable {
 #define CSSM_PEER_FLAG_ROWS 16
 #define CSSM_PEER_SPIN_LIMIT (1u << 22)   /* polls (~1 us each) before a reader gives up: err bit 4 (16) */
 
+#define CSSM_PEER_FLAG_HELLO 8    /* word of a source rank's flag pair that cssm_pf_shard_peer_handshake uses */
+// One round of the protocol with nothing attached, run by every rank at once right after the windows were mapped: thread q writes a
+// token where rank q looks for this rank's (system-scope release) and waits, bounded, for rank q's token in this rank's own flags.
+// result[0] = number of ranks whose token did not arrive.  A rank whose mapping, peer access or cross-GPU visibility does not work
+// shows up here, on the host, before a series depends on it.
+__global__ void k_peer_handshake(const PeerTable* __restrict__ peer, int world, int rank, uint32_t token, unsigned int* __restrict__ result) {
+  __shared__ unsigned int s_missing;
+  if (threadIdx.x == 0) s_missing = 0u;
+  __syncthreads();
+  const int q = (int)threadIdx.x;
+  if (q < world) {
+    __hip_atomic_store(peer->flag[0][q] + (size_t)rank * CSSM_PEER_FLAG_STRIDE + CSSM_PEER_FLAG_HELLO, token, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    const unsigned int* f = peer->flag[0][rank] + (size_t)q * CSSM_PEER_FLAG_STRIDE + CSSM_PEER_FLAG_HELLO;
+    unsigned int spins = 0u;
+    while (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != token) {
+      if (++spins > CSSM_PEER_SPIN_LIMIT) { atomicAdd(&s_missing, 1u); break; }
+      __builtin_amdgcn_s_sleep(16);
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) result[0] = s_missing;
+}
+
 // grid (tiles of the block + 1 for the header, destination rank); the weights are those k_propagate<SUMS> summed and stored,
 // exp(min(w - c, REF_BELOW)) -- or, with the level taken from the global max, exp(w - level) of the stored log-weights
 // peer != nullptr: the peer-written exchange -- `out` unused, segment rank -> q lands in peer->win[parity][q] + rank * seg,

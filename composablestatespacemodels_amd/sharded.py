@@ -178,6 +178,9 @@ class GpuShard:
         _abi.check(self.lib.cssm_pf_shard_peer_connect(self._h, arr, len(handles)))
         self._peer_ready = True
 
+    def peer_handshake(self, token: int):
+        _abi.check(self.lib.cssm_pf_shard_peer_handshake(self._h, int(token)))
+
     def peer_ready(self, cap: int) -> bool:
         return bool(getattr(self, "_peer_ready", False)) and getattr(self, "_peer_cap", None) == int(cap)
 
@@ -484,14 +487,40 @@ class ShardedFilter:
     def _ensure_peer(self, cap: int) -> bool:
         """Windows of every local shard set up for `cap` and every rank's mapped by every other (once per capacity)."""
         S, comm = self.shards, self.comm
-        if not all(hasattr(s, "peer_setup") for s in S):
+        if not all(hasattr(s, "peer_setup") for s in S) or getattr(self, "peer_refused", None):
             return False
         if all(s.peer_ready(cap) for s in S):
             return True
-        mine = [s.peer_setup(cap) for s in S]
+
+        def agreed(stage, action):
+            """`action` on every local shard; every rank learns whether it worked everywhere (a rank that failed must not leave the
+            others waiting in the next collective).  False: the peer-written exchange is off for this filter, on every rank alike,
+            and ``peer_refused`` says why -- the series then run on the collective exchange."""
+            err = None
+            out = []
+            for s in S:
+                try:
+                    out.append(action(s))
+                except Exception as e:          # noqa: BLE001 -- any failure of this rank is a reason for all ranks
+                    err = f"{stage}: {e}"
+                    out.append(None)
+            if comm.agree_max([1 if err else 0] * len(S)):
+                self.peer_refused = err or f"{stage}: failed on another rank"
+                for s in S:
+                    s.peer_close()
+                return None
+            return out
+
+        mine = agreed("setup", lambda s: s.peer_setup(cap))
+        if mine is None:
+            return False
         every = comm.exchange_handles(mine)
-        for s in S:
-            s.peer_connect(every)
+        if agreed("connect", lambda s: s.peer_connect(every)) is None:
+            return False
+        comm.barrier()
+        self._peer_token = getattr(self, "_peer_token", 0) + 1
+        if len(S) == 1 and agreed("handshake", lambda s: s.peer_handshake(self._peer_token)) is None:
+            return False      # (several shards of one process share a stream: a handshake kernel of one would wait for the next one's)
         comm.barrier()
         return True
 

@@ -498,6 +498,10 @@ typedef struct cssm_peer_handle {
 } cssm_peer_handle;
 int cssm_pf_shard_peer_setup(cssm_pf* pf, int rank, int world, int64_t cap, cssm_peer_handle* mine_out);
 int cssm_pf_shard_peer_connect(cssm_pf* pf, const cssm_peer_handle* all_handles, int world);
+/* One empty round of the protocol -- every rank writes a (non-zero) token into every rank's flags and waits, bounded, for everybody's
+ * in its own -- called by all ranks at the same point right after connecting: a mapping, peer access or cross-GPU visibility that does
+ * not work surfaces here, as CSSM_ESHARD on the host, before a series depends on it. */
+int cssm_pf_shard_peer_handshake(cssm_pf* pf, uint32_t token);
 void cssm_pf_shard_peer_close(cssm_pf* pf);
 int cssm_pf_shard_pack_peer(cssm_pf* pf, int rank, int world, int64_t cap);
 int cssm_pf_shard_adopt_peer(cssm_pf* pf, int rank, int world, int64_t cap);
