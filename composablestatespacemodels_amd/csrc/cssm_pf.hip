@@ -1196,6 +1196,7 @@ extern "C" int cssm_resample(int kind, const double* w, size_t n, double u, uint
   int rc = CSSM_OK;
   StepRec hrec; memset(&hrec, 0, sizeof hrec); hrec.u = u; hrec.step = step;
   Scalars hs;
+  std::vector<double> wscaled;
 #define RS_TRY(expr) do { hipError_t e__ = (expr); if (e__ != hipSuccess) { rc = fail(CSSM_EHIP, "%s: %s", #expr, hipGetErrorString(e__)); goto done; } } while (0)
   RS_TRY(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
   RS_TRY(hipMalloc(&d_w, stride * 8)); RS_TRY(hipMalloc(&d_end, stride * 4)); RS_TRY(hipMalloc(&d_anc, stride * 4));
@@ -1204,6 +1205,21 @@ extern "C" int cssm_resample(int kind, const double* w, size_t n, double u, uint
   if (kind == CSSM_RESAMPLE_MULTINOMIAL) RS_TRY(hipMalloc(&d_cum, stride * 8));
   RS_TRY(hipMemcpyAsync(d_tab, CSSM_TAB, sizeof(CSSM_TAB), hipMemcpyHostToDevice, st));
   RS_TRY(hipMemsetAsync(sc, 0, sizeof(Scalars), st));
+  {
+    // Weights of ANY scale: the reference normalises w / sum(w) (Resampling.scala:21-24) and its own property is stated over every
+    // non-empty vector in [0, 1] (SamplingTest.scala:12-22), but the contract's sums live on a 2^-96 grid -- a vector whose largest
+    // weight is below 2^-32 (inside a filter the largest is ~1) is brought up by the exact power of two that puts that weight into
+    // [0.5, 1) before it is summed.  The oracle's seam does the same (oracle/oracle.py: seam_scale).
+    double wmax = 0.0;
+    for (size_t i = 0; i < n; ++i) if (w[i] > wmax) wmax = w[i];
+    if (wmax > 0.0 && wmax < 0x1.0p-32) {
+      int e = 0;
+      (void)std::frexp(wmax, &e);
+      wscaled.resize(n);
+      for (size_t i = 0; i < n; ++i) wscaled[i] = std::ldexp(w[i], -e);
+      w = wscaled.data();
+    }
+  }
   RS_TRY(hipMemcpyAsync(d_w, w, n * 8, hipMemcpyHostToDevice, st));
   RS_TRY(hipMemcpyAsync(d_rec, &hrec, sizeof hrec, hipMemcpyHostToDevice, st));
   {

@@ -259,8 +259,19 @@ class OraclePf:
         return ll, th, acc, last
 
 
-def resample_systematic(w, u, flags=0, want_cumw=False):
+def seam_scale(w):
+    """What the stateless `Resample[A]` seam does with weights of ANY scale before they enter the fixed-point sums (2^-96 grid): the
+    reference normalises w / sum(w) (Resampling.scala:21-24), so only ratios matter -- a vector whose largest weight is below 2^-32 is
+    multiplied by the power of two that brings that weight into [0.5, 1) (exact).  Mirrors cssm_resample (csrc/cssm_pf.hip)."""
     w = np.ascontiguousarray(w, dtype=np.float64)
+    m = float(np.max(w)) if len(w) else 0.0
+    if 0.0 < m < 2.0 ** -32:
+        return np.ldexp(w, -int(np.frexp(m)[1]))
+    return w
+
+
+def resample_systematic(w, u, flags=0, want_cumw=False):
+    w = seam_scale(w) if not (flags & LITERAL_SUMS) else np.ascontiguousarray(w, dtype=np.float64)
     anc = np.zeros(len(w), dtype=np.uint32)
     Cw = np.zeros(len(w))
     rc = lib().oracle_resample_systematic(_p(w), len(w), u, _p(anc, _u32p), _p(Cw), flags)
@@ -269,12 +280,12 @@ def resample_systematic(w, u, flags=0, want_cumw=False):
 
 
 def resample_stratified(w, seed, step=0):
-    w = np.ascontiguousarray(w, dtype=np.float64); anc = np.zeros(len(w), dtype=np.uint32)
+    w = seam_scale(w); anc = np.zeros(len(w), dtype=np.uint32)
     _chk(lib().oracle_resample_stratified(_p(w), len(w), seed, step, _p(anc, _u32p), None)); return anc
 
 
 def resample_multinomial(w, seed, step=0):
-    w = np.ascontiguousarray(w, dtype=np.float64); anc = np.zeros(len(w), dtype=np.uint32)
+    w = seam_scale(w); anc = np.zeros(len(w), dtype=np.uint32)
     _chk(lib().oracle_resample_multinomial(_p(w), len(w), seed, step, _p(anc, _u32p), None)); return anc
 
 

@@ -850,18 +850,22 @@ LL_TOL_PER_OBS = 1e-9
 FLIPPED_ANCESTORS_MAX = 1e-4     # fraction of slots whose ancestor may differ after the FIRST weighted observation
 
 
-@pytest.mark.parametrize("name,n,T", [("c1_model", 1000, 100), ("c2_model", 1 << 16, 60)])
+@pytest.mark.parametrize("name,n,T", [("c1_model", 1000, 100), ("c2_model", 1 << 16, 60),
+                                      # round 4: the widest bench model (d = 9), the LGCP filter (precision 2: sub-steps, hazard sums, levels predicted
+                                      # from the previous event's max against the reference's plain max) and a "next" density (negative binomial)
+                                      ("c3_model", 1 << 14, 40), ("c4_model", 1 << 14, 25), ("negbin_model", 1 << 15, 40)])
 def test_hip_likelihood_within_stated_tolerance_of_literal_reference_arithmetic(name, n, T):
     model = getattr(cases, name)()
-    t, y, has = cases.poisson_counts(T)
-    g = NativePf(model, n, cases.SEED)
+    prec = 2 if name == "c4_model" else 0
+    t, y, has = cases.event_times(T, horizon=0.1 * T) if prec else cases.poisson_counts(T)
+    g = NativePf(model, n, cases.SEED, lgcp_precision=prec)
     gl, gl_t, gess, _ = g.run(t, y, has)
     t0 = float(np.min(t))
     s0 = int(np.argmax(has))
 
     def first_weighted_step(flags):
         g.init(t0)
-        o = oracle.OraclePf(model.descriptor(), n, cases.SEED, flags)
+        o = oracle.OraclePf(model.descriptor(prec), n, cases.SEED, flags)
         o.init(t0)
         for s in range(s0 + 1):
             g.step(t[s], y[s], bool(has[s])); o.step(t[s], y[s], bool(has[s]))
@@ -869,7 +873,7 @@ def test_hip_likelihood_within_stated_tolerance_of_literal_reference_arithmetic(
 
     # (a) literal sums + libm: the stated tolerance
     flags = oracle.LITERAL_SUMS | oracle.LIBM
-    ol, ol_t, oess, _ = oracle.OraclePf(model.descriptor(), n, cases.SEED, flags).filter(t, y, has)
+    ol, ol_t, oess, _ = oracle.OraclePf(model.descriptor(prec), n, cases.SEED, flags).filter(t, y, has)
     assert abs(gl - ol) <= LL_TOL_PER_OBS * T, (gl, ol)
     assert np.max(np.abs(gl_t - ol_t)) <= LL_TOL_PER_OBS * T
     assert np.max(np.abs(gess.astype(np.int64) - oess.astype(np.int64))) <= 1
@@ -878,7 +882,7 @@ def test_hip_likelihood_within_stated_tolerance_of_literal_reference_arithmetic(
     assert flipped <= FLIPPED_ANCESTORS_MAX
     # (b) ... + the TreeMap duplicate-key quirk
     flags |= oracle.TIE_LAST
-    tl = oracle.OraclePf(model.descriptor(), n, cases.SEED, flags).filter(t, y, has)[0]
+    tl = oracle.OraclePf(model.descriptor(prec), n, cases.SEED, flags).filter(t, y, has)[0]
     ga, oa, lw = first_weighted_step(flags)
     diff = np.nonzero(ga != oa)[0]
     w1 = np.exp(lw - lw.max())

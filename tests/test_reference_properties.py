@@ -1,0 +1,115 @@
+"""The reference's OWN test properties, restated on this build (the reference holds no golden vectors -- these
+properties are everything its tests pin on the hot path):
+
+* src/test/scala/SamplingTest.scala:12-22 -- ScalaCheck: for every non-empty vector of doubles in [0, 1], each of
+  multinomialResampling / systematicResampling / stratifiedResampling called as (w, w) returns a vector of the same length.
+  Restated with hypothesis over the CPU oracle (not gpu) and over the HIP path through the `Resample[A]` seam (gpu), plus what the
+  reference's implementation implies and its test does not say: every returned element is one of the inputs.
+* src/test/scala/ModelTest.scala:72-86 -- "Compose two models": for (linearNoNoise |+| linearNoNoise), the flattened initial state
+  has `sde.dimension` entries, a step changes the state, and the noise-free observation equals eta = link(f(x1, 1)).
+  Restated through the C ABI (gpu): the composed handle's dimension, a step of the cloud, and eta of a cloud of identical
+  particles -- its order statistics and the eta of its mean all equal f(x) = the sum of the leaves' first components.
+* Kalman known answer K4 (src/main/tut/docs/particle_filter.md:8-18) on the GPU at three cloud sizes: the Monte-Carlo
+  error of the likelihood estimate shrinks like 1/sqrt(N).
+"""
+import numpy as np
+import pytest
+from hypothesis import HealthCheck, assume, given, settings
+from hypothesis import strategies as st
+
+import cases
+from oracle import oracle
+
+# Gen.nonEmptyContainerOf[Vector, Double](Gen.choose(0.0, 1.0)), SamplingTest.scala:10-11 (lengths as ScalaCheck sizes them: up to ~100;
+# here up to 300, with length 1 and exact zeros made likely)
+weights = st.lists(st.one_of(st.floats(0.0, 1.0), st.sampled_from([0.0, 1.0, 0.5, 2.0 ** -60])), min_size=1, max_size=300)
+
+
+@settings(max_examples=60, deadline=None)
+@given(w=weights, u=st.floats(0.0, 1.0, exclude_max=True), seed=st.integers(0, 2 ** 32))
+def test_oracle_resamplers_return_the_same_length(w, u, seed):
+    """SamplingTest.scala:12-22 on the CPU restatement."""
+    assume(sum(w) > 0.0)          # (an all-zero vector divides by zero in Resampling.normalise: not what the property is about)
+    wa = np.asarray(w)
+    for anc in (oracle.resample_systematic(wa, u), oracle.resample_stratified(wa, seed), oracle.resample_multinomial(wa, seed)):
+        assert len(anc) == len(w) and anc.min() >= 0 and anc.max() < len(w)
+
+
+@pytest.mark.gpu
+@settings(max_examples=40, deadline=None, suppress_health_check=[HealthCheck.too_slow])
+@given(w=weights, u=st.floats(0.0, 1.0, exclude_max=True), seed=st.integers(0, 2 ** 31))
+def test_hip_resamplers_return_the_same_length(w, u, seed):
+    """SamplingTest.scala:12-22 on the HIP path: Resampling.*Resampling(w, w) as the reference's properties call them."""
+    from composablestatespacemodels_amd.filter import Resampling
+    assume(sum(w) > 0.0)
+    out = [Resampling.systematicResampling(w, w, u=u), Resampling.stratifiedResampling(w, w, seed=seed), Resampling.multinomialResampling(w, w, seed=seed)]
+    wa = np.asarray(w)
+    for kind, res in zip((0, 1, 2), out):
+        assert len(res) == len(w)
+        assert all(x in w for x in res)
+        if kind == 0 and u > 0.0:                # first-wins ties: no slot goes to a particle of zero weight (grid point 0 is the one
+            assert all(x > 0.0 for x in res)     #  exception: (u + 0)/n = 0 <= C_0 = 0 holds for a zero first weight, as in the reference)
+    # ... and the device agrees with the oracle on which particles (the seam is deterministic under (u | seed))
+    np.testing.assert_array_equal(Resampling.ancestors(0, w, u=u), oracle.resample_systematic(wa, u))
+    np.testing.assert_array_equal(Resampling.ancestors(1, w, seed=seed), oracle.resample_stratified(wa, seed))
+    np.testing.assert_array_equal(Resampling.ancestors(2, w, seed=seed), oracle.resample_multinomial(wa, seed))
+
+
+@pytest.mark.gpu
+def test_composed_models_have_the_summed_dimension_and_a_noise_free_observation_is_eta():
+    """ModelTest.scala:72-86."""
+    from composablestatespacemodels_amd import Model, Parameters, Sde, SdeParameter
+    from composablestatespacemodels_amd.filter import NativePf
+    single = Parameters.apply(1.0, SdeParameter.brownianParameter(1.0, 1.0, 1.0))            # ParamNode(Some(1.0), brownianParameter(1)(1)(1))
+    um = Model.linear(Sde.brownianMotion(1))
+    model = (um | um).run(single | single)
+    n = 4096
+    g = NativePf(model, n, cases.SEED)
+    assert g.d == 2                                       # x0.flatten.size == mod.sde.dimension
+    g.init(0.0)
+    x0 = g.particles()
+    g.step(1.0, None, False)                              # x1 = stepFunction(1)(x0): propagate only
+    x1 = g.particles()
+    assert x0.shape == (2, n) and np.all(x1[0] != x0[1])  # x1.getNode(0) != x0.getNode(1)
+    # y == eta for the noise-free observation: eta = link(f(x1, 1)) = sum over the leaves of the first component (Model.scala:122-128)
+    state = [0.75, -2.5]
+    g.init_from(1.0, state)
+    _, _, _, eta_of_mean, eta_lower, eta_upper = g.summary(0.975)
+    assert eta_of_mean == sum(state) and eta_lower == sum(state) and eta_upper == sum(state)
+    g.close()
+    # a seasonal leaf: f = F(t) . x with F(t) = (cos wt, sin wt, ...) (ModelTest.scala:32-44)
+    ps = Parameters.apply(1.0, SdeParameter.brownianParameter(1.0, 1.0, 1.0)) | Parameters.apply(None, SdeParameter.ouParameter(0.0, 1.0, 0.2, 0.0, 0.3))
+    ms = (um | Model.seasonal(24, 1, Sde.ouProcess(2))).run(ps)
+    gs = NativePf(ms, 1024, cases.SEED)
+    assert gs.d == 3
+    st3, tt = [0.5, 2.0, -1.0], 5.0
+    gs.init_from(tt, st3)
+    w = 2.0 * np.pi / 24.0
+    want = st3[0] + np.cos(w * tt) * st3[1] + np.sin(w * tt) * st3[2]
+    assert abs(gs.summary(0.975)[3] - want) < 1e-14
+    gs.close()
+
+
+@pytest.mark.gpu
+def test_k4_kalman_likelihood_on_the_gpu_converges_like_one_over_sqrt_n():
+    """Brownian latent + Gaussian observation (Model.linear) has an exact Kalman log-likelihood: the HIP filter's estimate must
+    approach it with an error that shrinks ~ 1/sqrt(N) over N = 2^12, 2^16, 2^20 (16 seeds each)."""
+    from composablestatespacemodels_amd.filter import NativePf
+    from test_oracle_pins import kalman_ll
+    sigma, obs_sd, m0, c0 = 0.3, 0.5, 0.5, 2.0
+    model = cases.linear_model(sigma, obs_sd, m0, c0)
+    t, y, has = cases.gaussian_series(40, sigma=sigma, obs_sd=obs_sd)
+    exact = kalman_ll(t, y, m0, c0, sigma, obs_sd)
+    sd = []
+    for n in (1 << 12, 1 << 16, 1 << 20):
+        g = NativePf(model, n, 1000)
+        lls = []
+        for r in range(16):
+            g.reseed(1000 + r)
+            lls.append(g.run(t, y, has)[0])
+        g.close()
+        sd.append(float(np.sqrt(np.mean((np.array(lls) - exact) ** 2))))
+    print("K4 on the GPU: rms error of ll at N = 2^12, 2^16, 2^20:", sd, "exact", exact)
+    assert sd[2] < 0.01 and sd[1] < 0.04
+    # a factor 16 in N is a factor 4 in the error, up to the noise of 16 replicates (accept 2.2 .. 7)
+    assert 2.2 < sd[0] / sd[1] < 7.0 and 2.2 < sd[1] / sd[2] < 7.0
