@@ -165,7 +165,7 @@ def run_single(args, emit=print):
     n = args.particles if args.particles > 0 else (N_16M if lgcp else N_PER_GPU)
     R = args.repeats if args.repeats > 0 else (3 if K >= 200 else 7)
     W = max(W, 1)                      # (the filter has to be running before K more steps can be timed)
-    model, t, y, has = build_workload(W + 2 * R * K + 8, args.model)
+    model, t, y, has = build_workload(W + 4 * R * K + 16, args.model)
     pf = NativePf(model, n, 20260101, device=0, lgcp_precision=LGCP_PRECISION if lgcp else 0)
     if args.fused is not None:
         pf.set_option(3, args.fused)   # CSSM_OPT_FUSED_SUMS (experiment switch; the default is the library's)
@@ -191,6 +191,23 @@ def run_single(args, emit=print):
     loop_ms = float(np.median(loops))
     per, pair_s, prof_raw = _kernel_profile(pf, t, y, has, K, loop_ms,
                                             legs=[(W + (R + r) * K, W + (R + r + 1) * K) for r in range(R)])
+    # the same model and legs with the structure specialisation switched off (CSSM_OPT_SPECIALISE = 0: the kernel that reads the model's
+    # structure as data, what every model outside BASELINE's configurations ran until round 4 gave each its own run-time-compiled kernel)
+    roof_generic = None
+    if not args.no_generic:
+        pf.set_option(8, 0)
+        lo = W + 2 * R * K
+        pf.run_more(t[lo:lo + 8], y[lo:lo + 8], has[lo:lo + 8])
+        lo += 8
+        gl = []
+        for r in range(R):
+            pf.run_more(t[lo + r * K:lo + (r + 1) * K], y[lo + r * K:lo + (r + 1) * K], has[lo + r * K:lo + (r + 1) * K])
+            gl.append(pf.last_loop_ms())
+        gper, gpair, _ = _kernel_profile(pf, t, y, has, K, float(np.median(gl)), legs=[(lo + (R + r) * K, lo + (R + r + 1) * K) for r in range(R)])
+        ga, gc, gr = gper["k_propagate"]
+        roof_generic = _roofline(f"k_propagate<{d},...> reading the model's structure as data (CSSM_OPT_SPECIALISE = 0), N={n}", d, n, ga, gc, gr, gpair, None)
+        roof_generic["step_us"] = float(np.median(gl)) * 1e3 / K
+        pf.set_option(8, 1)
     lib = pf.lib
     pf.close()
     # on-box streaming ceiling (plain 16-byte-per-lane copy, 1 GiB each way: far beyond the 256 MB Infinity Cache)
@@ -225,6 +242,7 @@ def run_single(args, emit=print):
                    "particles_per_gpu": n, "observations": K, "latent_dim": d, "seed": 20260101},
         "repeats": R, "value_is": "median over `repeats` timed legs of K steps each, continuing the filter the warm-up steps started (cssm_pf_ll_filter_more)", "wall_ms_each": [w * 1e3 for w in walls],
         "roofline": roof,
+        "roofline_generic": roof_generic,
         "kernels_us": kernels_us,
         "device_loop_ms": loop_ms, "ll": ll, "ess_last": int(ess_t[-1]),
     }
@@ -459,6 +477,7 @@ def main():
     ap.add_argument("--repeats", type=int, default=0, help="timed K-step series (0: 3 for K >= 200, else 7); the median is reported")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-16m", action="store_true", help="skip the roofline_16m leg")
+    ap.add_argument("--no-generic", action="store_true", help="skip the roofline_generic leg (the same kernel with the model's structure as data)")
     ap.add_argument("--fused", type=int, default=None, help="CSSM_OPT_FUSED_SUMS override (single GPU)")
     ap.add_argument("--model", default="c2", choices=["c2", "c1", "c4"], help="c2: the bench workload (BASELINE configs[1], d = 3, weak scaling); c4: BASELINE configs[3], the log-Gaussian Cox process at N = 2^24 in total (strong scaling); c1: Poisson-Brownian (configs[0], d = 1) -- profiling runs only")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="gloo: CPU rehearsal of the N-rank path with the test-only oracle shard")

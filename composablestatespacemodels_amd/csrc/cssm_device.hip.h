@@ -29,8 +29,10 @@
 // Cross-lane traffic is DPP, not ds_bpermute (5 vs 25 cycles per move on MI355X, tools/instr_rate.hip).
 #pragma once
 
+#if !defined(__HIPCC_RTC__)
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#endif
 
 #include "cssm_records.h"
 

@@ -25,7 +25,15 @@ struct PropLaunch {
   int shard_slim;      // the sharded filter's slim launch k_propagate_shard applies (cssm_pf.hip decides)
   uint32_t step;       // the observation's index (= rec->step, read from the host copy of the record: k_propagate_self / _shard use it before any load lands)
   int one;             // k_propagate_self<..., ONE>: 1 = the block's range is one tile, 2 = the same body tile after tile, 0 = software-pipelined
+  int specialise;      // 1 (default): the kernel that holds the model's structure at compile time -- an ahead-of-time instantiation where one exists
+                       //   (cssm_prop.hip: KnownStructures), else one compiled at run time (cssm_rtc.cpp); 0: the structure-as-data kernel
+  int obs_kind;        // the handle's CSSM_OBS_* (a run-time-compiled kernel holds it at compile time whichever it is; `obs` above is -1 for
+                       //   the densities the ahead-of-time kernels keep behind a switch)
 };
+
+// cssm_rtc.cpp: the fused kernel of launch `a` specialised at run time (kind 0 = k_propagate_self, 1 = k_propagate_shard, 2 = the LGCP
+// k_propagate); false = not launched, the caller falls back to the structure-as-data kernel
+bool cssm_rtc_launch(const PropLaunch& a, int kind, int D, int IT, int onev);
 
 // one per latent dimension, defined in cssm_prop.hip; returns what the kernel it chose does beyond the propagate itself
 #define CSSM_PROP_LAUNCHED_GRP 1   /* its blocks accumulate the sums of groups of units (Scalars::grp; asked for by bit 8 of slot_set) */

@@ -68,6 +68,7 @@ struct cssm_pf : HostModel {
   size_t fine_cap = 0;
   int opt_whole = 0;           // CSSM_OPT_WHOLE_TILES
   int opt_grp = 1;             // CSSM_OPT_GROUP_SUMS
+  int opt_spec = 1;            // CSSM_OPT_SPECIALISE
   bool last_grp = false;       // the last launch_propagate's blocks accumulated the sums of groups of units (Scalars::grp)
   int resampler = CSSM_RESAMPLE_SYSTEMATIC;
   double* cum = nullptr;       // multinomial: cumulative normalised weights

@@ -335,6 +335,7 @@ int cssm_launch_propagate(cssm_pf* pf, const StepRec* d_rec, double* pick_out, u
   a.step = rec_step;
   a.fsub = pf->lgcp_tdep ? pf->d_fsub : nullptr;
   a.one = (chunk == (uint64_t)CSSM_BLOCK * cssm_prop_items(pf->d)) ? 1 : (geo == GEO_LOOP ? 2 : 0);
+  a.specialise = pf->opt_spec; a.obs_kind = pf->obs_kind;
   // sharded handle on the single-collective exchange (received rows read in place: src2_stride == 0) or before its first exchange:
   // slim launch, tile after tile while a unit has at most CSSM_LOOP_MAX_TILES tiles; whole pairs per thread (d <= 8) need an even first id
   a.shard_slim = pf->sharded && do_sums && !a.lgcp && (a.src2 == nullptr || a.src2_stride == 0) && a.fsub == nullptr && pick_out == nullptr &&
@@ -904,6 +905,7 @@ extern "C" int cssm_pf_set_option(cssm_pf* pf, int option, int value) {
   if (option == CSSM_OPT_EXACT_OFFSPRING) { pf->opt_exact = (value == 2) ? 2 : (value ? 1 : 0); return CSSM_OK; }
   if (option == CSSM_OPT_FUSED_SUMS) { pf->opt_fused = value ? 1 : 0; return CSSM_OK; }
   if (option == CSSM_OPT_GROUP_SUMS) { pf->opt_grp = value ? 1 : 0; return CSSM_OK; }
+  if (option == CSSM_OPT_SPECIALISE) { pf->opt_spec = (value == 2) ? 2 : (value ? 1 : 0); return CSSM_OK; }
   if (option == CSSM_OPT_WHOLE_TILES) {   // launch geometry only: the arrays hold up to four sub-units per unit either way
     if (pf->sharded) return fail(CSSM_ESTATE, "sharded handles always run whole tiles");
     pf->opt_whole = value < 0 ? 0 : (value > 3 ? 3 : value);

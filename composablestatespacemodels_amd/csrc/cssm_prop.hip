@@ -47,11 +47,13 @@ template <int D, int IT, int ONEV, bool SHARD, int OB, int I> struct TryKnown {
     }
   }
 };
+// ... or, for every other structure (and every observation model), the instantiation compiled at run time (cssm_rtc.cpp)
 template <int D, int IT, int ONEV, bool SHARD = false> static bool launch_known(const PropLaunch& a) {
-  if (D > 12 || a.mk.d != D) return false;
-  if (a.obs == CSSM_OBS_POISSON) return TryKnown<D, IT, ONEV, SHARD, CSSM_OBS_POISSON, 0>::go(a);
-  if constexpr (D == 1) { if (a.obs == CSSM_OBS_GAUSSIAN) return TryKnown<D, IT, ONEV, SHARD, CSSM_OBS_GAUSSIAN, 0>::go(a); }   // (Model.linear on one component)
-  return false;
+  if (!a.specialise || D > 12 || a.mk.d != D) return false;
+  // (specialise == 2, a verification setting: the run-time-compiled kernel also where an ahead-of-time instantiation exists)
+  if (a.specialise != 2 && a.obs == CSSM_OBS_POISSON && TryKnown<D, IT, ONEV, SHARD, CSSM_OBS_POISSON, 0>::go(a)) return true;
+  if constexpr (D == 1) { if (a.specialise != 2 && a.obs == CSSM_OBS_GAUSSIAN && TryKnown<D, IT, ONEV, SHARD, CSSM_OBS_GAUSSIAN, 0>::go(a)) return true; }   // (Model.linear on one component)
+  return cssm_rtc_launch(a, SHARD ? 1 : 0, D, IT, ONEV);
 }
 
 // the single-tile instantiation of the small clouds (one pair per thread for d <= 8, one particle for d >= 9)
@@ -116,10 +118,11 @@ int CSSM_CAT(cssm_prop_launch_d, CSSM_PROP_D)(const PropLaunch& a) {
     // 1 / 2 = the sums formed relative to the PREDICTED level (contract v8) and the weights stored -- one GPU / a shard (both sums)
 #define PROP_LGCP(SM)                                                                                                          \
     do {                                                                                                                       \
-      if (D == 1 && a.mk.comp[0] == 0x36u)                                                                                     \
+      if (a.specialise == 1 && D == 1 && a.mk.comp[0] == 0x36u)                                                                   \
         k_propagate<D, true, IT, -1, SM, (D == 1 ? 0x36u : 0u)><<<dim3(a.grid), dim3(CSSM_BLOCK), 0, a.stream>>>(              \
             a.src, a.src_stride, a.anc, a.dst, a.dst_stride, a.logw, a.n, a.gid0, a.seed, a.rec, a.mk, a.sc, a.slot_set & 0xff, a.src2, \
             a.src2_stride, a.n_split, a.logtab, a.chunk, a.do_sums, a.subS, a.subS2, a.pick_out, a.pick_slot, a.fsub);         \
+      else if (cssm_rtc_launch(a, 2, D, IT, 0)) { /* the structure of any other LGCP model, compiled at run time */ }          \
       else                                                                                                                     \
         PROP_GO(true, -1, SM);                                                                                                 \
     } while (0)

@@ -2,7 +2,9 @@
 // cssm_prop.hip, which is compiled once per latent dimension D (the 112 instantiations built in parallel).
 #pragma once
 
+#if !defined(__HIPCC_RTC__)   /* (hipRTC -- csrc/cssm_rtc.cpp compiles this header at run time for a handle's model structure -- has no system headers) */
 #include <cstddef>
+#endif
 
 #include "cssm_device.hip.h"
 

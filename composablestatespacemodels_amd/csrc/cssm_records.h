@@ -4,9 +4,11 @@
 // cssm_device.hip.h.
 #pragma once
 
+#if !defined(__HIPCC_RTC__)
 #include <stdint.h>
 
 #include <vector>
+#endif
 
 #include "../../include/cssm_numerics.h"
 #include "../../include/cssm_pf.h"
@@ -87,4 +89,6 @@ void cssm_build_rec(const HostModel* m, double t_prev, double t, double y, int h
 // LGCP with a time-dependent f (FilterLgcp.calcWeight evaluates f at every simulated time, model/ParticleFilter.scala:193-205):
 // append the n_sub x d coefficient rows of records recs[first .. first + count) to `table` and set their fsub_off;
 // CSSM_ENOMEM if the table would exceed 1 GiB.  No-op for every other model.
+#if !defined(__HIPCC_RTC__)
 int cssm_build_fsub_table(const HostModel* m, StepRec* recs, size_t first, size_t count, std::vector<double>& table);
+#endif

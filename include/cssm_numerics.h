@@ -31,7 +31,16 @@
 #ifndef CSSM_NUMERICS_H
 #define CSSM_NUMERICS_H
 
+#if !defined(__HIPCC_RTC__)
 #include <stdint.h>
+#elif !defined(CSSM_RTC_STDINT)   /* hipRTC builds have no system headers: the fixed-width types the sources use */
+#define CSSM_RTC_STDINT 1
+typedef signed char int8_t; typedef unsigned char uint8_t; typedef short int16_t; typedef unsigned short uint16_t;
+typedef int int32_t; typedef unsigned int uint32_t; typedef long long int64_t; typedef unsigned long long uint64_t;
+#ifndef offsetof
+#define offsetof(type, member) __builtin_offsetof(type, member)
+#endif
+#endif
 
 #if defined(__HIPCC__)
 #define CSSM_HD __host__ __device__ inline

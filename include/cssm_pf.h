@@ -34,8 +34,10 @@
 #ifndef CSSM_PF_H
 #define CSSM_PF_H
 
+#if !defined(__HIPCC_RTC__)
 #include <stddef.h>
 #include <stdint.h>
+#endif
 
 #ifdef __cplusplus
 extern "C" {
@@ -240,7 +242,19 @@ int cssm_pf_last_loop_ms(cssm_pf* pf, float* ms_out);
  * of 32 units, and k_offspring's blocks read 32 group sums + the 32 unit sums of their own group instead of all 1024 unit sums
  * (16 KiB per block through the L2s).  0 = every block totals every unit sum, as before. */
 #define CSSM_OPT_GROUP_SUMS 7
+/* CSSM_OPT_SPECIALISE (default 1; results are bit-identical either way): the fused kernel holds the model's STRUCTURE -- per latent
+ * component its SDE, its place in the f map, where its leaf ends -- and its observation model at compile time, as the reference's
+ * models are composed at compile time (model/Model.scala:110-136): ahead-of-time instantiations for BASELINE's configurations, and for
+ * every other model (d <= 12) one compiled at RUN TIME with hipRTC from the library's own kernel sources (~1 s per kernel the first time
+ * a structure is seen; kept on disk afterwards: $CSSM_RTC_CACHE, else rtc_cache/ next to the library).  If the runtime compiler is
+ * unavailable one line on stderr says so and the structure-as-data kernel runs; environment CSSM_RTC=0 does the same on purpose.
+ * 0: always the structure-as-data kernel (bench.py reports its roofline fraction beside the specialised kernel's); 2 (verification):
+ * the run-time-compiled kernel also where an ahead-of-time instantiation exists (tests compare the two). */
+#define CSSM_OPT_SPECIALISE 8
 int cssm_pf_set_option(cssm_pf* pf, int option, int value);
+/* Counters of the run-time specialisation in this process: out4 = {kernels compiled, kernels loaded from the disk cache, launches of
+ * run-time-compiled kernels, failures (each reported once on stderr)}. */
+int cssm_rtc_info(uint64_t* out4);
 
 /* Per-kernel device time, measured with HIP events recorded on the handle's stream directly
  * before and after every kernel launch of the batch loop (bench.py's `roofline` figure).

@@ -1,0 +1,118 @@
+"""-m gpu: the fused kernel specialised for a model's structure at RUN TIME (csrc/cssm_rtc.cpp, CSSM_OPT_SPECIALISE): every model the
+reference's constructors can compose (model/Model.scala:44-136) gets the kernel that holds its structure and its observation model at
+compile time -- not only BASELINE's configurations, which have ahead-of-time instantiations.  Bit-identical to the oracle, as fast as
+an ahead-of-time instantiation, and never silently the other kernel."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import cases
+from composablestatespacemodels_amd import Model, Parameters, Sde, SdeParameter, _abi
+from composablestatespacemodels_amd.filter import NativePf
+from oracle import oracle
+
+pytestmark = pytest.mark.gpu
+
+OPT_SPECIALISE, OPT_WHOLE_TILES = 8, 6
+
+
+def rtc_info():
+    out = (C.c_uint64 * 4)()
+    _abi.check(_abi.load_library().cssm_rtc_info(out))
+    return dict(compiled=out[0], disk=out[1], launches=out[2], failures=out[3])
+
+
+def outside_the_table():
+    """poisson(brownianMotion(1)) |+| seasonal(24, 1, ouProcess(2)): d = 3 like the bench model, another structure word."""
+    p = (Parameters.apply(None, SdeParameter.brownianParameter(0.0, 1.0, 0.01))
+         | Parameters.apply(None, SdeParameter.ouParameter(0.0, 1.0, 0.2, [0.5, -0.25], 0.3)))
+    return (Model.poisson(Sde.brownianMotion(1)) | Model.seasonal(24, 1, Sde.ouProcess(2))).run(p)
+
+
+def negbin_c3():
+    """examples/Simulation.scala:15-28 as the reference has it: negativeBinomial(brownianMotion(1)) |+| seasonal(24, 4, ouProcess(8)), d = 9."""
+    p = (Parameters.apply(np.log(3.0), SdeParameter.brownianParameter(0.0, 1.0, 0.01))
+         | Parameters.apply(None, SdeParameter.ouParameter(0.0, 1.0, 0.2, [-1.0, -1.0, 0.0, 0.0, 0.0, 0.0, -0.125, -0.125], 0.3)))
+    return (Model.negativeBinomial(Sde.brownianMotion(1)) | Model.seasonal(24, 4, Sde.ouProcess(8))).run(p)
+
+
+@pytest.mark.parametrize("make,n,whole", [(outside_the_table, 5000, 0), (outside_the_table, 70 * 1024 + 3, 1), (outside_the_table, 9000, 2),
+                                          (negbin_c3, 4096, 0), (negbin_c3, 9 * 1024, 1), (cases.gen_brownian_seasonal_gaussian, 6000, 0),
+                                          (cases.euler_model, 3000, 0), (cases.bernoulli_model, 3000, 0)])
+def test_runtime_specialised_kernels_are_bit_identical_to_the_oracle(make, n, whole):
+    model = make()
+    t, y, has = cases.binary_series(9) if make is cases.bernoulli_model else cases.poisson_counts(9, missing=0.15)
+    o = oracle.OraclePf(model.descriptor(), n, cases.SEED)
+    ol, oll, oess, _ = o.filter(t, y, has)
+    before = rtc_info()
+    g = NativePf(model, n, cases.SEED)
+    g.set_option(OPT_WHOLE_TILES, whole)
+    gl, gll, gess, _ = g.run(t, y, has)
+    after = rtc_info()
+    assert after["failures"] == before["failures"] == 0, "the runtime compiler failed: see stderr"
+    assert after["launches"] - before["launches"] == len(t), "the structure-as-data kernel ran instead of the specialised one"
+    assert gl == ol
+    np.testing.assert_array_equal(gll, oll); np.testing.assert_array_equal(gess, oess)
+    np.testing.assert_array_equal(g.ancestors(), o.ancestors()); np.testing.assert_array_equal(g.particles(), o.particles())
+    # ... and the structure-as-data kernel gives the same bits (the switch is not a numerical one)
+    g.set_option(OPT_SPECIALISE, 0)
+    assert g.run(t, y, has)[0] == ol and rtc_info()["launches"] == after["launches"]
+    g.close()
+
+
+def test_runtime_specialised_lgcp_with_a_seasonal_leaf():
+    """An LGCP model other than configs[3]'s (a seasonal leaf: f depends on time) runs its sub-step loop on its own structure."""
+    model = cases.lgcp_seasonal_model()
+    n = 6000
+    t, y, has = cases.event_times(8, horizon=3.0)
+    o = oracle.OraclePf(model.descriptor(2), n, cases.SEED)
+    ol, _, oess, _ = o.filter(t, y, has)
+    before = rtc_info()
+    g = NativePf(model, n, cases.SEED, lgcp_precision=2)
+    gl, _, gess, _ = g.run(t, y, has)
+    after = rtc_info()
+    assert after["failures"] == 0 and after["launches"] - before["launches"] == len(t)
+    assert gl == ol
+    np.testing.assert_array_equal(gess, oess); np.testing.assert_array_equal(g.particles(), o.particles())
+    g.close()
+
+
+def _kernel_us(g, t, y, has, reps=5):
+    best = 1e30
+    for _ in range(reps):
+        g.profile(True); g.run(t, y, has); p = g.profile_read(); g.profile(False)
+        best = min(best, p["k_propagate"][0] / p["k_propagate"][1] * 1e3)
+    return best
+
+
+def test_a_model_outside_the_table_runs_as_fast_as_the_table_kernel():
+    """(i) The bench model compiled at run time against its ahead-of-time instantiation: the same source and flags, the same speed (3 %).
+    (ii) a d = 3 model OUTSIDE round 3's table (a Brownian instead of an OU first leaf) against the bench model's table kernel: it used to
+    run the structure-as-data kernel (~5-8 % slower); (iii) which that kernel still is, measured in the same process."""
+    n, T = 1 << 20, 40
+    t, y, has = cases.poisson_counts(T)
+    g = NativePf(cases.c2_model(), n, cases.SEED)
+    g.run(t, y, has)
+    aot = _kernel_us(g, t, y, has)
+    l0 = rtc_info()["launches"]
+    g.set_option(OPT_SPECIALISE, 2)
+    g.run(t, y, has)
+    assert rtc_info()["launches"] - l0 == T and rtc_info()["failures"] == 0
+    rtc = _kernel_us(g, t, y, has)
+    g.set_option(OPT_SPECIALISE, 0)
+    g.run(t, y, has)
+    generic = _kernel_us(g, t, y, has)
+    g.close()
+    h = NativePf(outside_the_table(), n, cases.SEED)
+    h.run(t, y, has)
+    other = _kernel_us(h, t, y, has)
+    h.set_option(OPT_SPECIALISE, 0)
+    h.run(t, y, has)
+    other_generic = _kernel_us(h, t, y, has)
+    h.close()
+    print(f"k_propagate at N = 2^20, d = 3 (us, best of 5, event-bracketed): table {aot:.2f}, the same structure compiled at run time {rtc:.2f}, "
+          f"structure as data {generic:.2f}; a model outside the table: run-time specialised {other:.2f}, structure as data {other_generic:.2f}")
+    assert rtc <= 1.03 * aot + 0.1
+    assert other <= 1.03 * aot + 0.1        # (a Brownian leaf does no more arithmetic than an OU leaf)
+    assert generic >= rtc                    # what the specialisation is for
