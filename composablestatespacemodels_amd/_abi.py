@@ -143,6 +143,12 @@ SYMBOLS = [
     ("cssm_pf_shard_series_peer", C.c_int, [_h, C.c_int, C.c_int, C.c_size_t, C.c_size_t, _u8p, C.c_int64]),
     ("cssm_pmmh_run", C.c_int, [_h, _descp, _dp, C.c_size_t, C.c_double, _dp, _dp, _u8p, C.c_size_t,
                                 C.c_uint64, C.c_size_t, _dp, _dp, _i32p, _dp]),
+    ("cssm_pfb_create", C.c_int, [_descp, C.c_uint64, C.c_int, C.c_int, C.POINTER(_h)]),
+    ("cssm_pfb_destroy", None, [_h]),
+    ("cssm_pfb_num_chains", C.c_int, [_h]),
+    ("cssm_pfb_chain", _h, [_h, C.c_int]),
+    ("cssm_pfb_filter", C.c_int, [_h, C.POINTER(_descp), _u64p, _dp, _dp, _u8p, C.c_size_t, _dp, _dp, C.POINTER(C.c_int)]),
+    ("cssm_pmmh_run_batched", C.c_int, [_h, _descp, _dp, C.c_size_t, C.c_double, _dp, _dp, _u8p, C.c_size_t, _u64p, C.c_size_t, _dp, _dp, _i32p, _dp]),
     ("cssm_diag_copy_ceiling", C.c_int, [C.c_int, C.c_size_t, C.c_int, _dp]),
     ("cssm_contract_eval", C.c_int, [C.c_int, C.c_int, _dp, C.c_size_t, _dp, C.c_size_t]),
     ("cssm_desc_flatten", C.c_int, [_descp, _dp, C.c_size_t, C.POINTER(C.c_size_t)]),

@@ -87,6 +87,17 @@ struct Scalars {
   cssm_u128 pend_S;          // S_tot of that observation
 };
 
+// BATCHED independent filters (cssm_batch.hip: B clouds of one model structure -- the chains of a PMMH run, a pilot grid of
+// parameters -- advanced in lockstep by ONE launch per stage, blockIdx.y = the chain): what differs between the chains of a launch.
+// The array is rewritten at the start of every batched call; everything else of a launch (sizes, parities, the record's index) is
+// common to the chains and travels as kernel arguments.
+struct ChainBase {
+  double* state[2]; double* logw; uint32_t* anc; cssm_u128* tileS; cssm_u128* tileS2; Scalars* sc; StepRec* recs;
+  cssm_u128* s2buf; double* ll_t; int32_t* ess_t; double* path; const double* m0; const double* sd0;
+  Scalars* host_sc; double* host_ll_t; int32_t* host_ess_t; uint32_t* host_done;
+  uint64_t seed; uint32_t gen, done_seq;
+};
+
 // ------------------------------------------------------------------------------------ helpers
 
 // Cross-lane traffic goes through DPP (data-parallel primitives: a VALU move whose source lane is a fixed

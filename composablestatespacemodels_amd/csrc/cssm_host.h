@@ -27,6 +27,9 @@ struct PropLaunch {
   int one;             // k_propagate_self<..., ONE>: 1 = the block's range is one tile, 2 = the same body tile after tile, 0 = software-pipelined
   int specialise;      // 1 (default): the kernel that holds the model's structure at compile time -- an ahead-of-time instantiation where one exists
                        //   (cssm_prop.hip: KnownStructures), else one compiled at run time (cssm_rtc.cpp); 0: the structure-as-data kernel
+  const void* chains;  // batched launch (cssm_batch.hip): the device array of ChainBase, nchains of them (grid.y); src / dst / anc / logw / sc /
+  int nchains;         //   rec / seed / subS / pick_* above are unused -- the chains' own come from the array
+  int cur, anc_valid, want_pick; uint32_t rec_idx;
   int obs_kind;        // the handle's CSSM_OBS_* (a run-time-compiled kernel holds it at compile time whichever it is; `obs` above is -1 for
                        //   the densities the ahead-of-time kernels keep behind a switch)
 };

@@ -191,7 +191,12 @@ int cssm_build_fsub(cssm_pf* pf, size_t first, size_t count, bool reset);   // s
 int cssm_ensure_recs(cssm_pf* pf, size_t T);
 int cssm_upload_recs(cssm_pf* pf, size_t first, size_t count, bool chain);   // records -> device (+ the predicted level of the first one: LGCP)
 int cssm_launch_init(cssm_pf* pf, double t0);
-int cssm_launch_propagate(cssm_pf* pf, const StepRec* d_rec, double* pick_out = nullptr, uint32_t pick_slot = 0);
+// batched launch (cssm_batch.hip): the chains of the launch; `pf` is chain 0, whose bookkeeping stands for all of them
+struct CssmBatchLaunch { const void* chains; int nchains; uint32_t rec_idx; int want_pick; };
+int cssm_launch_propagate(cssm_pf* pf, const StepRec* d_rec, double* pick_out = nullptr, uint32_t pick_slot = 0, const CssmBatchLaunch* batch = nullptr);
+int cssm_pf_create_on_stream(const cssm_model_desc* desc, uint64_t n_particles, uint64_t seed, int device, hipStream_t stream, cssm_pf** out);
+void cssm_batch_fresh(cssm_pf* pf, double t0);   // host-side state of a freshly drawn cloud; the call's generation and completion number
+int cssm_batch_ok(const cssm_pf* pf);            // the batched launches serve this handle's configuration
 int cssm_check_device_err(cssm_pf* pf, const Scalars& h);
 int cssm_prop_items(int d);   // PropItems<D>
 double cssm_eta_of_mean(const cssm_pf* pf, const StepRec& rec, const double* mean);

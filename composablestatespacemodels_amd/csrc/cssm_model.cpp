@@ -312,44 +312,76 @@ extern "C" int cssm_desc_flatten(const cssm_model_desc* desc, double* theta, siz
 
 // mhStep, model/PMMH.scala:68-81; init ll = -1e99 (:121); proposal Parameters.perturb(delta),
 // model/Parameters.scala:65-67; the current ll is reused, never re-estimated (:63-66).
+// One chain's state, so that the sequential driver (cssm_pmmh_run) and the batched one (cssm_pmmh_run_batched: B chains whose
+// filters of an iteration run as one batch, cssm_batch.hip) make the same proposals, key their filters alike and decide alike.
+struct cssm_pmmh_chain {
+  OwnedDesc o;
+  std::vector<double> cur, prop, cur_state;
+  double cur_ll = -1e99, sd = 0.0;
+  int32_t acc = 0;
+  uint64_t seed = 0;
+  size_t n_theta = 0;
+  int d = 0;
+};
+int cssm_pmmh_chain_create(const cssm_model_desc* desc, const double* theta0, size_t n_theta, double delta, uint64_t seed, int d, cssm_pmmh_chain** out) {
+  cssm_pmmh_chain* c = new cssm_pmmh_chain();
+  int rc = own_desc(desc, &c->o);
+  if (!rc && c->o.slots.size() != n_theta) rc = fail(CSSM_EINVAL_ARG, "theta0 has %zu entries, the descriptor flattens to %zu", n_theta, c->o.slots.size());
+  if (rc) { delete c; return rc; }
+  c->cur.assign(theta0, theta0 + n_theta); c->prop.resize(n_theta); c->cur_state.assign((size_t)d, 0.0);
+  c->sd = std::sqrt(delta); c->seed = seed; c->n_theta = n_theta; c->d = d;
+  *out = c;
+  return CSSM_OK;
+}
+void cssm_pmmh_chain_destroy(cssm_pmmh_chain* c) { delete c; }
+// propParams <- proposal(s.params) of iteration `it`: the descriptor to filter under, and the filter's Philox key
+const cssm_model_desc* cssm_pmmh_chain_propose(cssm_pmmh_chain* c, size_t it, uint64_t* key_out) {
+  for (size_t j = 0; j < c->n_theta; j += 2) {
+    double z0, z1;
+    cssm_normal_pair_of(c->seed, it, (uint32_t)(j / 2), CSSM_STREAM_HOST, 0, CSSM_LOG_TAB, &z0, &z1);
+    c->prop[j] = c->cur[j] + c->sd * z0;
+    if (j + 1 < c->n_theta) c->prop[j + 1] = c->cur[j + 1] + c->sd * z1;
+  }
+  for (size_t j = 0; j < c->n_theta; ++j) *c->o.slots[j] = c->prop[j];
+  *key_out = cssm_derive_key(c->seed, (uint64_t)it + 1);      // (never seed + it: include/cssm_numerics.h)
+  return &c->o.desc;
+}
+// accept iff log(u) < ll' - ll (:75; logTransition = prior = 0); the iteration's output row
+void cssm_pmmh_chain_decide(cssm_pmmh_chain* c, size_t it, double pll, const double* last_path_row, double* ll_out, double* theta_out, int32_t* acc_out,
+                            double* state_out) {
+  const double a = pll - c->cur_ll;
+  const cssm_u32x4 b = cssm_philox_draw(c->seed, it, 0xffffffffu, CSSM_STREAM_HOST, 1);
+  const double uu = cssm_u01_open0(b.v[0], b.v[1]);
+  if (cssm_log(uu) < a) {
+    c->cur_ll = pll; c->cur = c->prop; ++c->acc;
+    memcpy(c->cur_state.data(), last_path_row, (size_t)c->d * 8);
+  }
+  *ll_out = c->cur_ll; *acc_out = c->acc;
+  memcpy(theta_out, c->cur.data(), c->n_theta * 8);
+  memcpy(state_out, c->cur_state.data(), (size_t)c->d * 8);
+}
+
 extern "C" int cssm_pmmh_run(cssm_pf* pf, const cssm_model_desc* desc, const double* theta0, size_t n_theta, double delta,
                              const double* t, const double* y, const uint8_t* has_obs, size_t T, uint64_t seed,
                              size_t n_iters, double* ll, double* theta, int32_t* accepted, double* last_state) {
   if (!pf || !theta0 || !ll || !theta || !accepted || !last_state) return fail(CSSM_EINVAL_ARG, "null argument");
-  OwnedDesc o;
-  int rc = own_desc(desc, &o);
-  if (rc) return rc;
-  if (o.slots.size() != n_theta) return fail(CSSM_EINVAL_ARG, "theta0 has %zu entries, the descriptor flattens to %zu", n_theta, o.slots.size());
   const int d = cssm_pf_dim(pf);
-  std::vector<double> cur(theta0, theta0 + n_theta), prop(n_theta), path((T + 1) * (size_t)d), cur_state(d, 0.0);
-  double cur_ll = -1e99;
-  int32_t acc = 0;
-  const double sd = std::sqrt(delta);
-  for (size_t it = 0; it < n_iters; ++it) {
-    for (size_t j = 0; j < n_theta; j += 2) {                  // propParams <- proposal(s.params)
-      double z0, z1;
-      cssm_normal_pair_of(seed, it, (uint32_t)(j / 2), CSSM_STREAM_HOST, 0, CSSM_LOG_TAB, &z0, &z1);
-      prop[j] = cur[j] + sd * z0;
-      if (j + 1 < n_theta) prop[j + 1] = cur[j + 1] + sd * z1;
-    }
-    for (size_t j = 0; j < n_theta; ++j) *o.slots[j] = prop[j];
-    rc = cssm_pf_set_params(pf, &o.desc);
-    if (rc) return rc;
-    cssm_pf_reseed(pf, cssm_derive_key(seed, (uint64_t)it + 1));   // (never seed + it: include/cssm_numerics.h)
+  cssm_pmmh_chain* c = nullptr;
+  int rc = cssm_pmmh_chain_create(desc, theta0, n_theta, delta, seed, d, &c);
+  if (rc) return rc;
+  std::vector<double> path((T + 1) * (size_t)d);
+  for (size_t it = 0; it < n_iters && !rc; ++it) {
+    uint64_t key = 0;
+    const cssm_model_desc* pd = cssm_pmmh_chain_propose(c, it, &key);
+    rc = cssm_pf_set_params(pf, pd);
+    if (rc) break;
+    cssm_pf_reseed(pf, key);
     double pll = 0.0;
     rc = cssm_pf_filter(pf, t, y, has_obs, T, &pll, nullptr, nullptr, path.data());   // state = pf(propParams)
-    if (rc == CSSM_ENONFINITE) pll = -cssm_inf();              // a proposal the filter cannot weigh is rejected
-    else if (rc) return rc;
-    const double a = pll - cur_ll;                             // logTransition = prior = 0
-    const cssm_u32x4 b = cssm_philox_draw(seed, it, 0xffffffffu, CSSM_STREAM_HOST, 1);
-    const double uu = cssm_u01_open0(b.v[0], b.v[1]);
-    if (cssm_log(uu) < a) {                                    // :75
-      cur_ll = pll; cur = prop; ++acc;
-      memcpy(cur_state.data(), path.data() + T * (size_t)d, d * 8);
-    }
-    ll[it] = cur_ll; accepted[it] = acc;
-    memcpy(theta + it * n_theta, cur.data(), n_theta * 8);
-    memcpy(last_state + it * (size_t)d, cur_state.data(), d * 8);
+    if (rc == CSSM_ENONFINITE) { pll = -cssm_inf(); rc = CSSM_OK; }          // a proposal the filter cannot weigh is rejected
+    else if (rc) break;
+    cssm_pmmh_chain_decide(c, it, pll, path.data() + T * (size_t)d, &ll[it], theta + it * n_theta, &accepted[it], last_state + it * (size_t)d);
   }
-  return CSSM_OK;
+  cssm_pmmh_chain_destroy(c);
+  return rc;
 }

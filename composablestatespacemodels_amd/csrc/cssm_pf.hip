@@ -139,14 +139,19 @@ static int create_common(const cssm_model_desc* desc, uint64_t n_global, uint64_
   cssm_pf* pf = new cssm_pf();
   pf->device = device;
   pf->n_global = n_global; pf->first = first; pf->n = n_local; pf->seed = seed; pf->sharded = sharded;
-  if (sharded) { pf->stream = (hipStream_t)stream; pf->own_stream = false; pf->opt_fused = 1; }
-  else pf->opt_fused = 1;   // two launches per observation at every size (measured with the slim single-GPU kernels: 18.7 vs 20.0 us at
+  if (sharded || stream != nullptr) { pf->stream = (hipStream_t)stream; pf->own_stream = false; }
+  pf->opt_fused = 1;   // two launches per observation at every size (measured with the slim single-GPU kernels: 18.7 vs 20.0 us at
                             // N = 100 000, 34.0 vs 35.4 at 2^20, 336 vs 356 at 2^24); an outlying observation is redone in place
   int rc = cssm_build_model(pf, desc, false);
   if (rc == CSSM_OK) rc = alloc_handle(pf);
   if (rc != CSSM_OK) { const std::string keep = cssm_last_error(); cssm_pf_destroy(pf); return fail(rc, "%s", keep.c_str()); }
   *out = pf;
   return CSSM_OK;
+}
+
+// a single-GPU handle on a stream of the caller's (the chains of a batch share one: cssm_batch.hip)
+int cssm_pf_create_on_stream(const cssm_model_desc* desc, uint64_t n_particles, uint64_t seed, int device, hipStream_t stream, cssm_pf** out) {
+  return create_common(desc, n_particles, 0, n_particles, seed, device, stream, false, out);
 }
 
 extern "C" int cssm_pf_create(const cssm_model_desc* desc, uint64_t n_particles, uint64_t seed, int device, cssm_pf** out) {
@@ -283,7 +288,13 @@ static int large_geometry(const cssm_pf* pf) {
   return pf->d >= CSSM_FINE_MIN_D ? GEO_FINE : GEO_PIPE;
 }
 
-int cssm_launch_propagate(cssm_pf* pf, const StepRec* d_rec, double* pick_out, uint32_t pick_slot) {
+void cssm_batch_fresh(cssm_pf* pf, double t0) { fresh_host_state(pf, t0); pf->gen++; pf->done_seq++; }
+int cssm_batch_ok(const cssm_pf* pf) {
+  return pf->opt_fused && !pf->safe_sums && pf->obs_kind != CSSM_OBS_LGCP && pf->resampler == CSSM_RESAMPLE_SYSTEMATIC && !pf->sharded &&
+         large_geometry(pf) != GEO_FINE;
+}
+
+int cssm_launch_propagate(cssm_pf* pf, const StepRec* d_rec, double* pick_out, uint32_t pick_slot, const CssmBatchLaunch* batch) {
   // The observation's index travels as a kernel argument (the slim kernels use it before any load lands): every record a
   // propagate is launched on lives in the handle's record buffer, and the HOST copy of that record -- h_recs mirrors d_recs from
   // the moment a record is built until the launch that consumes it: every caller builds the record, enqueues its upload and
@@ -315,6 +326,8 @@ int cssm_launch_propagate(cssm_pf* pf, const StepRec* d_rec, double* pick_out, u
   }
   prof_begin(pf, CSSM_K_PROPAGATE);
   PropLaunch a;
+  a.chains = nullptr; a.nchains = 0; a.cur = pf->cur; a.anc_valid = pf->anc_valid ? 1 : 0; a.want_pick = 0; a.rec_idx = 0;
+  if (batch) { a.chains = batch->chains; a.nchains = batch->nchains; a.want_pick = batch->want_pick; a.rec_idx = batch->rec_idx; }
   a.grid = grid; a.stream = pf->stream;
   a.lgcp = pf->obs_kind == CSSM_OBS_LGCP;
   a.sharded = pf->sharded ? 1 : 0;

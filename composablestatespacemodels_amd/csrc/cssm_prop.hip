@@ -79,6 +79,18 @@ template <int D, int IT> struct OneTile {
 int CSSM_CAT(cssm_prop_launch_d, CSSM_PROP_D)(const PropLaunch& a) {
   constexpr int D = CSSM_PROP_D;
   constexpr int IT = PropItems<D>::value;
+  if (a.chains != nullptr) {
+    // B independent clouds (cssm_batch.hip): the fused-sums single-GPU kernels only; the model's structure and observation model at
+    // compile time through the run-time compiler, else the structure-as-data instantiation with the observation model behind its switch
+    const int onev = a.one;
+    if (a.specialise && D <= 12 && cssm_rtc_launch(a, 3, D, IT, onev)) return (a.slot_set & 0x100) ? CSSM_PROP_LAUNCHED_GRP : 0;
+#define PROP_BATCH(ONEV)                                                                                                               \
+    k_propagate_batch<D, IT, -1, ONEV><<<dim3(a.grid, a.nchains), dim3(CSSM_BLOCK), 0, a.stream>>>(                                   \
+        static_cast<const ChainBase*>(a.chains), a.cur, a.anc_valid, a.src_stride, a.n, a.rec_idx, a.mk, a.slot_set, a.logtab, a.chunk, a.want_pick, a.step)
+    if (onev == 1) PROP_BATCH(1); else if (onev == 2) PROP_BATCH(2); else PROP_BATCH(0);
+#undef PROP_BATCH
+    return (a.slot_set & 0x100) ? CSSM_PROP_LAUNCHED_GRP : 0;
+  }
 #define PROP_GO(LG, OB, SM)                                                                                               \
   k_propagate<D, LG, IT, OB, SM><<<dim3(a.grid), dim3(CSSM_BLOCK), 0, a.stream>>>(                                        \
       a.src, a.src_stride, a.anc, a.dst, a.dst_stride, a.logw, a.n, a.gid0, a.seed, a.rec, a.mk, a.sc, a.slot_set & 0xff, a.src2, \

@@ -648,6 +648,24 @@ __global__ __launch_bounds__(CSSM_BLOCK, (ONE ? 2 : PropWaves<D, SUMS>::value)) 
                                          pick_out, pick_slot, 0ull, nullptr, 0u, step_now);
 }
 
+// B independent clouds in one launch (blockIdx.y = the chain; ChainBase, cssm_device.hip.h): the body of k_propagate_self with the
+// fused sums, the chain's buffers, records, Philox key and -- for `filter` -- path taken from its ChainBase.  At N = 100 000 (the
+// PMMH configuration) one chain's launch leaves three quarters of the GPU idle; four chains fill it for the price of one.
+template <int D, int IT, int OBS, int ONE = 0, uint32_t MKW = 0u, uint32_t MKW1 = 0u, uint32_t MKW2 = 0u>
+__global__ __launch_bounds__(CSSM_BLOCK, (ONE ? 2 : PropWaves<D, 1>::value)) void k_propagate_batch(
+    const ChainBase* __restrict__ chains, int cur, int anc_valid, size_t stride, uint64_t n_arg, uint32_t rec_idx, ModelK mk, int slot_set,
+    const double* __restrict__ logtab, uint64_t chunk, int want_pick, uint32_t step_now) {
+  static_assert(MKW == 0u || D <= 12, "three structure words cover twelve components");
+  if (MKW != 0u) { mk.comp[0] = MKW; mk.comp[1] = MKW1; mk.comp[2] = MKW2; }
+  const ChainBase* __restrict__ c = chains + blockIdx.y;
+  const StepRec* __restrict__ rec = c->recs + rec_idx;
+  // (`filter`: the thread that gathers the slot sampleOne picked after the observation before records that state on the way)
+  double* pick_out = (want_pick && rec_idx >= 1u) ? c->path + (size_t)rec_idx * D : nullptr;
+  const uint32_t pick_slot = (want_pick && rec_idx >= 1u) ? c->recs[rec_idx - 1u].pick : 0u;
+  propagate_block<D, IT, OBS, 1, ONE>(c->state[cur], stride, anc_valid ? c->anc : nullptr, c->state[cur ^ 1], stride, c->logw, n_arg, c->seed, rec, mk, c->sc,
+                                      slot_set, logtab, chunk, c->tileS, c->tileS2, pick_out, pick_slot, 0ull, nullptr, 0u, step_now);
+}
+
 // The sharded filter's slim launch (single-collective exchange: the sums are always formed, the rows received from the two
 // neighbouring ranks are read in place -- src2 = the receive buffer, rows of D + 1 doubles, indices >= n_split --, max-slot set
 // 0, an even first global particle: whole pairs per thread): the same body behind 18 arguments instead of the generic

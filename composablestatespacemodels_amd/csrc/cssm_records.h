@@ -81,6 +81,13 @@ struct HostModel {
 };
 
 // ---- cssm_model.cpp (host only) ----
+// one PMMH chain's state (model/PMMH.scala:68-81): shared by the sequential and the batched driver
+struct cssm_pmmh_chain;
+int cssm_pmmh_chain_create(const cssm_model_desc* desc, const double* theta0, size_t n_theta, double delta, uint64_t seed, int d, cssm_pmmh_chain** out);
+void cssm_pmmh_chain_destroy(cssm_pmmh_chain* c);
+const cssm_model_desc* cssm_pmmh_chain_propose(cssm_pmmh_chain* c, size_t it, uint64_t* key_out);
+void cssm_pmmh_chain_decide(cssm_pmmh_chain* c, size_t it, double pll, const double* last_path_row, double* ll_out, double* theta_out, int32_t* acc_out,
+                            double* state_out);
 int cssm_fail(int code, const char* fmt, ...);   // sets the thread-local message of cssm_last_error(), returns code
 // Validate and translate a descriptor; `update`: re-parameterise -- the STRUCTURE must be the one `m` already has.
 int cssm_build_model(HostModel* m, const cssm_model_desc* desc, bool update);

@@ -210,7 +210,8 @@ hipFunction_t cssm_rtc_function(const std::string& expr) {
 // The fused kernel of launch `a` specialised for the handle's structure words and observation model; false: not launched
 // (specialisation off, latent dimension beyond the twelve components three words cover, or the runtime compiler unavailable).
 // kind: 0 = k_propagate_self<D, IT, OB, SUMS, ONEV, W..> (SUMS = a.sums ? 1 : 0), 1 = k_propagate_shard<D, IT, OB, ONEV, W..>,
-// 2 = k_propagate<D, true, IT, -1, SM, W..> (LGCP; SM = 0 / 1 / 2 as the dispatcher of cssm_prop.hip chooses).
+// 2 = k_propagate<D, true, IT, -1, SM, W..> (LGCP; SM = 0 / 1 / 2 as the dispatcher of cssm_prop.hip chooses),
+// 3 = k_propagate_batch<D, IT, OB, ONEV, W..> (B chains per launch: cssm_batch.hip).
 bool cssm_rtc_launch(const PropLaunch& a, int kind, int D, int IT, int onev) {
   if (!a.specialise || D > 12 || a.mk.d != D) return false;
   char expr[256];
@@ -218,6 +219,7 @@ bool cssm_rtc_launch(const PropLaunch& a, int kind, int D, int IT, int onev) {
   const int ob = a.obs_kind;      // the observation model at compile time, whichever it is
   if (kind == 0) snprintf(expr, sizeof expr, "k_propagate_self<%d, %d, %d, %d, %d, %uu, %uu, %uu>", D, IT, ob, a.sums ? 1 : 0, onev, w0, w1, w2);
   else if (kind == 1) snprintf(expr, sizeof expr, "k_propagate_shard<%d, %d, %d, %d, %uu, %uu, %uu>", D, IT, ob, onev, w0, w1, w2);
+  else if (kind == 3) snprintf(expr, sizeof expr, "k_propagate_batch<%d, %d, %d, %d, %uu, %uu, %uu>", D, IT, ob, onev, w0, w1, w2);
   else snprintf(expr, sizeof expr, "k_propagate<%d, true, %d, -1, %d, %uu, %uu, %uu>", D, IT, !a.sums ? 0 : (a.sharded ? 2 : 1), w0, w1, w2);
   hipFunction_t fn = cssm_rtc_function(expr);
   if (!fn) return false;
@@ -227,15 +229,20 @@ bool cssm_rtc_launch(const PropLaunch& a, int kind, int D, int IT, int onev) {
   int slot_set = a.slot_set, slot_lo = a.slot_set & 0xff; const double* src2 = a.src2; size_t src2_stride = a.src2_stride; uint32_t n_split = a.n_split;
   const double* logtab = a.logtab; uint64_t chunk = a.chunk; int do_sums = a.do_sums; cssm_u128* subS = a.subS; cssm_u128* subS2 = a.subS2;
   double* pick_out = a.pick_out; uint32_t pick_slot = a.pick_slot, step = a.step; const double* fsub = a.fsub;
+  const void* chains = a.chains; int cur = a.cur, anc_valid = a.anc_valid, want_pick = a.want_pick; uint32_t rec_idx = a.rec_idx;
+  unsigned grid_y = 1;
   std::vector<void*> args;
-  if (kind == 0)
+  if (kind == 3) {
+    args = {&chains, &cur, &anc_valid, &src_stride, &n, &rec_idx, &mk, &slot_set, &logtab, &chunk, &want_pick, &step};
+    grid_y = (unsigned)a.nchains;
+  } else if (kind == 0)
     args = {&src, &src_stride, &anc, &dst, &dst_stride, &logw, &n, &seed, &rec, &mk, &sc, &slot_set, &logtab, &chunk, &subS, &subS2, &pick_out, &pick_slot, &step};
   else if (kind == 1)
     args = {&src, &src_stride, &anc, &dst, &dst_stride, &logw, &n, &gid0, &seed, &rec, &mk, &sc, &src2, &n_split, &logtab, &chunk, &subS, &subS2, &step};
   else
     args = {&src, &src_stride, &anc, &dst, &dst_stride, &logw, &n, &gid0, &seed, &rec, &mk, &sc, &slot_lo, &src2, &src2_stride, &n_split, &logtab, &chunk,
             &do_sums, &subS, &subS2, &pick_out, &pick_slot, &fsub};
-  if (hipModuleLaunchKernel(fn, (unsigned)a.grid, 1, 1, CSSM_BLOCK, 1, 1, 0, a.stream, args.data(), nullptr) != hipSuccess) {
+  if (hipModuleLaunchKernel(fn, (unsigned)a.grid, grid_y, 1, CSSM_BLOCK, 1, 1, 0, a.stream, args.data(), nullptr) != hipSuccess) {
     (void)hipGetLastError();
     return false;
   }

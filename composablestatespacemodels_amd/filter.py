@@ -229,6 +229,59 @@ class NativePf:
 
 
 # --------------------------------------------------------------------------- Resample[A]
+class NativePfBatch:
+    """``cssm_pfb*``: B filters of one model structure advanced in lockstep, one launch per stage for all of them (the chains of a PMMH
+    run, a pilot grid of parameters -- model/Streaming.scala:38-39).  ``filter(models, seeds, t, y, has)`` = B x ``NativePf.run(...,
+    want_path=True)`` on handles reseeded with ``seeds[k]``, bit for bit."""
+
+    def __init__(self, model: Model, n: int, chains: int, device: int = 0):
+        self.lib = _abi.load_library()
+        self._h = C.c_void_p()
+        _abi.check(self.lib.cssm_pfb_create(model.descriptor().ptr(), int(n), int(chains), int(device), C.byref(self._h)))
+        self.B, self.n = int(chains), int(n)
+        self.d = int(self.lib.cssm_pf_dim(self.lib.cssm_pfb_chain(self._h, 0)))
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            self.lib.cssm_pfb_destroy(self._h)
+            self._h = C.c_void_p()
+
+    __del__ = close
+
+    def filter(self, models: Sequence[Model], seeds: Sequence[int], t, y, has=None, want_path: bool = True):
+        """(ll[B], path[B, T + 1, d] or None, rc[B]): rc[k] != 0 is chain k's own status (-5: its weights were unusable)."""
+        if len(models) != self.B or len(seeds) != self.B:
+            raise ValueError("one model and one seed per chain")
+        t = np.ascontiguousarray(t, dtype=np.float64); y = np.ascontiguousarray(y, dtype=np.float64)
+        T = len(t)
+        hp = None
+        if has is not None:
+            has = np.ascontiguousarray(has, dtype=np.uint8); hp = _p(has, C.POINTER(C.c_uint8))
+        descs = [m.descriptor() for m in models]
+        arr = (C.POINTER(_abi.ModelDesc) * self.B)(*[C.pointer(d.desc) for d in descs])
+        sd = np.ascontiguousarray([int(x) & (2**64 - 1) for x in seeds], dtype=np.uint64)
+        ll = np.zeros(self.B); rc = np.zeros(self.B, dtype=np.int32)
+        path = np.zeros((self.B, T + 1, self.d)) if want_path else None
+        _abi.check(self.lib.cssm_pfb_filter(self._h, arr, _p(sd, C.POINTER(C.c_uint64)), _p(t), _p(y), hp, T, _p(ll), _p(path) if want_path else None,
+                                            _p(rc, C.POINTER(C.c_int))))
+        return ll, path, rc
+
+    def chain(self, k: int) -> "NativePf":
+        """Chain k as a NativePf view (inspection only; the batch owns the handle)."""
+        v = _PfView.__new__(_PfView)
+        v.lib = self.lib; v._h = C.c_void_p(self.lib.cssm_pfb_chain(self._h, int(k))); v.n = self.n; v.d = self.d; v.generation = 0
+        return v
+
+
+class _PfView(NativePf):
+    """A chain of a batch seen as a NativePf: the batch owns the handle, closing the view destroys nothing."""
+
+    def close(self):
+        self._h = C.c_void_p()
+
+    __del__ = close
+
+
 class Resampling:
     """``Resampling.systematicResampling`` (Resampling.scala:63-72) on the GPU.
 

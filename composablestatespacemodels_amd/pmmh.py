@@ -159,3 +159,33 @@ def pmmh_native(unparam: UnparamModel, init: Parameters, data, n: int, delta: fl
     pf.close()
     _abi.check(rc)
     return ll, th, acc, last
+
+
+def pmmh_native_batched(unparam: UnparamModel, inits: Sequence[Parameters], data, n: int, delta: float, iters: int,
+                        seeds: Sequence[int], device: int = 0):
+    """``len(inits)`` chains in lockstep (``cssm_pmmh_run_batched``): chain k is ``pmmh_native(unparam, inits[k], ..., seed=seeds[k])`` bit
+    for bit -- what examples/DetermineParameters.scala:68-69 runs as two chains under ``mapAsync(2)`` -- but every iteration's filters
+    of all chains run as ONE batch on the GPU.  Returns (ll[B, iters], theta[B, iters, n_theta], accepted[B, iters], last_state[B, iters, d])."""
+    t, y, h = split_data(data)
+    B = len(inits)
+    if B < 1 or len(seeds) != B:
+        raise ValueError("one seed per chain")
+    model = unparam.run(inits[0])
+    desc = model.descriptor()
+    lib = _abi.load_library()
+    hb = C.c_void_p()
+    _abi.check(lib.cssm_pfb_create(desc.ptr(), int(n), B, int(device), C.byref(hb)))
+    try:
+        d = int(lib.cssm_pf_dim(lib.cssm_pfb_chain(hb, 0)))
+        theta0 = np.ascontiguousarray([p.flattenParams() for p in inits], dtype=np.float64)
+        nt = theta0.shape[1]
+        ll = np.zeros((B, iters)); th = np.zeros((B, iters, nt)); acc = np.zeros((B, iters), dtype=np.int32); last = np.zeros((B, iters, d))
+        sd = np.ascontiguousarray([int(x) & (2**64 - 1) for x in seeds], dtype=np.uint64)
+        dp = C.POINTER(C.c_double)
+        _abi.check(lib.cssm_pmmh_run_batched(hb, desc.ptr(), theta0.ctypes.data_as(dp), nt, float(delta), t.ctypes.data_as(dp), y.ctypes.data_as(dp),
+                                             h.ctypes.data_as(C.POINTER(C.c_uint8)), len(t), sd.ctypes.data_as(C.POINTER(C.c_uint64)), int(iters),
+                                             ll.ctypes.data_as(dp), th.ctypes.data_as(dp), acc.ctypes.data_as(C.POINTER(C.c_int32)), last.ctypes.data_as(dp)))
+    finally:
+        lib.cssm_pfb_destroy(hb)
+    return ll, th, acc, last
+

@@ -541,6 +541,35 @@ int cssm_pmmh_run(cssm_pf* pf, const cssm_model_desc* desc, const double* theta0
                   uint64_t seed, size_t n_iters, double* ll, double* theta, int32_t* accepted,
                   double* last_state);
 
+/* ---- batched independent filters ------------------------------------------------------------ */
+/*
+ * B filters of ONE model structure -- the chains of a PMMH run (examples/DetermineParameters.scala:68-69 runs two under mapAsync(2)),
+ * the parameter grid of a pilot run (model/Streaming.scala:38-39: mapAsyncUnordered(4)) -- advanced in lockstep: one launch per stage
+ * for all of them (grid.y = the chain), enqueued by ONE host thread.  At N = 100 000 particles a single filter leaves most of the GPU
+ * idle and a step is launch latency + one wave's dependent instruction stream; B chains cost little more than one.
+ *   cssm_pfb_create          B handles of `desc`'s structure and n_particles each, on one stream
+ *   cssm_pfb_filter          `filter` (model/ParticleFilter.scala:152-158) of chain k under descs[k] (same structure) and the Philox key
+ *                            seeds[k]: ll_out[k], path_out[k][(T + 1) * d] (may be NULL), rc_out[k] = that chain's own status
+ *                            (CSSM_ENONFINITE: its weights were unusable).  Per chain the bits of cssm_pf_reseed + cssm_pf_filter on a
+ *                            handle of its own: a chain the batched launches do not serve (an observation ruled out of its reference
+ *                            level, LGCP, another resampler) is run through that very driver.
+ *   cssm_pmmh_run_batched    cssm_pmmh_run (model/PMMH.scala:68-81,114-123) for B chains in lockstep -- chain k from theta0[k * n_theta ..]
+ *                            under seeds[k]: the same proposals, filter keys and decisions as B separate runs, every iteration's B
+ *                            filters as one batch.  Outputs chain-major: ll[k * n_iters + it], theta[(k * n_iters + it) * n_theta + j],
+ *                            accepted[k * n_iters + it], last_state[(k * n_iters + it) * d + j].
+ *   cssm_pfb_chain           chain k as an ordinary handle (inspection: particles, ancestors, summaries); owned by the batch.
+ */
+typedef struct cssm_pfb cssm_pfb;
+int cssm_pfb_create(const cssm_model_desc* desc, uint64_t n_particles, int n_chains, int device, cssm_pfb** out);
+void cssm_pfb_destroy(cssm_pfb* b);
+int cssm_pfb_num_chains(const cssm_pfb* b);
+cssm_pf* cssm_pfb_chain(cssm_pfb* b, int k);
+int cssm_pfb_filter(cssm_pfb* b, const cssm_model_desc* const* descs, const uint64_t* seeds, const double* t, const double* y,
+                    const uint8_t* has_obs, size_t T, double* ll_out, double* path_out, int* rc_out);
+int cssm_pmmh_run_batched(cssm_pfb* b, const cssm_model_desc* desc, const double* theta0, size_t n_theta, double delta, const double* t,
+                          const double* y, const uint8_t* has_obs, size_t T, const uint64_t* seeds, size_t n_iters, double* ll, double* theta,
+                          int32_t* accepted, double* last_state);
+
 /* Number of stored parameters of a descriptor and their copy-out / copy-in in flatten order. */
 int cssm_desc_flatten(const cssm_model_desc* desc, double* theta, size_t cap, size_t* n_theta);
 
