@@ -927,7 +927,9 @@ extern "C" int cssm_pf_set_option(cssm_pf* pf, int option, int value) {
   }
   if (option == CSSM_OPT_RESAMPLER) {
     if (value < CSSM_RESAMPLE_SYSTEMATIC || value > CSSM_RESAMPLE_MULTINOMIAL) return fail(CSSM_EINVAL_ARG, "unknown resampler %d", value);
-    if (pf->sharded && value != CSSM_RESAMPLE_SYSTEMATIC) return fail(CSSM_ESTATE, "sharded handles resample systematically");
+    // (a sharded multinomial resampler is another exchange altogether: slot i draws its own uniform, so a rank's slots take their
+    //  ancestors from every rank -- a general gather, not the boundary rows of two neighbours)
+    if (pf->sharded && value == CSSM_RESAMPLE_MULTINOMIAL) return fail(CSSM_ESTATE, "sharded handles resample systematically or stratified");
     pf->resampler = value;
     return CSSM_OK;
   }

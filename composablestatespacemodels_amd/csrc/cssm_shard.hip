@@ -32,14 +32,17 @@ __global__ void k_import_level(Scalars* sc, const unsigned long long* __restrict
 // range of LOCAL particles that own at least one of q's slots.  One thread per q.
 __global__ void k_send_ranges(const uint32_t* __restrict__ endslot, uint64_t n_local, const Scalars* __restrict__ sc,
                               const StepRec* __restrict__ rec, uint64_t n_global, int rank, int world, uint64_t n_per,
-                              long long* __restrict__ first, long long* __restrict__ count) {
+                              long long* __restrict__ first, long long* __restrict__ count, int rs, uint64_t seed) {
   const int q = blockIdx.x * blockDim.x + threadIdx.x;
   if (q >= world) return;
   uint64_t b_lo = (uint64_t)q * n_per, b_hi = b_lo + n_per;
   if (b_lo > n_global) b_lo = n_global;
   if (b_hi > n_global) b_hi = n_global;
   uint64_t e_before = 0;   // end slot of the last particle of the previous rank
-  if (rank > 0) e_before = cssm_sys_count(cssm_u128_to_double(sc->S_off) / cssm_u128_to_double(sc->S_tot), rec->u, n_global);
+  if (rank > 0) {
+    const double Cb = cssm_u128_to_double(sc->S_off) / cssm_u128_to_double(sc->S_tot);
+    e_before = (rs == CSSM_RESAMPLE_STRATIFIED) ? cssm_strat_count(Cb, seed, rec->step, n_global) : cssm_sys_count(Cb, rec->u, n_global);
+  }
   // j_lo = first local j with endslot[j] > b_lo
   uint64_t lo = 0, hi = n_local;
   while (lo < hi) { const uint64_t mid = (lo + hi) >> 1; if ((uint64_t)endslot[mid] > b_lo) hi = mid; else lo = mid + 1; }
@@ -241,15 +244,19 @@ extern "C" int cssm_pf_shard_offspring(cssm_pf* pf, const uint64_t* all_sums5_de
   const int optimistic = pf->last_optimistic ? 1 : 0;
   // the rank's own particles write their runs inside the rank's slots straight into anc (indexed from the first
   // own slot); the end slots are kept for the send ranges; slots owned by other ranks' particles are filled by adopt
-  hipLaunchKernelGGL((k_offspring<true, false, CSSM_RESAMPLE_SYSTEMATIC>), dim3(tgrid), dim3(CSSM_BLOCK), 0, pf->stream, pf->logw, pf->n, pf->sc,
-                     (const cssm_u128*)pf->tileS, (const cssm_u128*)pf->tileS2, pf->d_recs + slot, pf->n_global, pf->endslot,
-                     pf->anc, pf->ntiles, pf->sup, pf->nunits, optimistic ? 2 : 0, 0, (double*)nullptr, (int32_t*)nullptr, 0u, pf->opt_exact,
-                     (const unsigned long long*)all_sums5_dev, rank, world, optimistic ? (int)pf->split : 1, pf->seed, (double*)nullptr, pf->d_logtab,
-                     optimistic, (unsigned long long*)redo_flag_dev, (uint32_t)pf->first, (uint32_t)(pf->first + pf->n));
+#define SHARD_OFF_ARGS pf->logw, pf->n, pf->sc, (const cssm_u128*)pf->tileS, (const cssm_u128*)pf->tileS2, pf->d_recs + slot, pf->n_global, pf->endslot, \
+                     pf->anc, pf->ntiles, pf->sup, pf->nunits, optimistic ? 2 : 0, 0, (double*)nullptr, (int32_t*)nullptr, 0u, pf->opt_exact,            \
+                     (const unsigned long long*)all_sums5_dev, rank, world, optimistic ? (int)pf->split : 1, pf->seed, (double*)nullptr, pf->d_logtab,    \
+                     optimistic, (unsigned long long*)redo_flag_dev, (uint32_t)pf->first, (uint32_t)(pf->first + pf->n)
+  if (pf->resampler == CSSM_RESAMPLE_STRATIFIED)
+    hipLaunchKernelGGL((k_offspring<true, false, CSSM_RESAMPLE_STRATIFIED>), dim3(tgrid), dim3(CSSM_BLOCK), 0, pf->stream, SHARD_OFF_ARGS);
+  else
+    hipLaunchKernelGGL((k_offspring<true, false, CSSM_RESAMPLE_SYSTEMATIC>), dim3(tgrid), dim3(CSSM_BLOCK), 0, pf->stream, SHARD_OFF_ARGS);
+#undef SHARD_OFF_ARGS
   pf->have_level = true;
   pf->send_first_dev = (const long long*)send_first_dev; pf->send_count_dev = (const long long*)send_count_dev;
   hipLaunchKernelGGL(k_send_ranges, dim3(1), dim3(64), 0, pf->stream, pf->endslot, pf->n, pf->sc, pf->d_recs + slot, pf->n_global, rank, world,
-                     n_per, (long long*)send_first_dev, (long long*)send_count_dev);
+                     n_per, (long long*)send_first_dev, (long long*)send_count_dev, pf->resampler, pf->seed);
   HIP_TRY(hipGetLastError());
   return CSSM_OK;
 }
@@ -497,7 +504,8 @@ static int adopt_spec_impl(cssm_pf* pf, const double* recv_buf_dev, int rank, in
     pk.pre_flag = pre ? pf->peer_tickets + 64 : (unsigned int*)nullptr;
     pk.pack_gx = (uint32_t)((cnt + CSSM_TILE - 1) / CSSM_TILE) + 2u;
     pf->spec_pre = pre;
-    hipLaunchKernelGGL(k_exchange_offspring<2>, dim3(tgrid + (int)(pk.pack_gx * (uint32_t)world)), dim3(CSSM_BLOCK), 0, pf->stream, pf->logw, pf->n, pf->sc,
+    auto kx = (pf->resampler == CSSM_RESAMPLE_STRATIFIED) ? k_exchange_offspring<2, CSSM_RESAMPLE_STRATIFIED> : k_exchange_offspring<2, CSSM_RESAMPLE_SYSTEMATIC>;
+    hipLaunchKernelGGL(kx, dim3(tgrid + (int)(pk.pack_gx * (uint32_t)world)), dim3(CSSM_BLOCK), 0, pf->stream, pf->logw, pf->n, pf->sc,
                      (const cssm_u128*)pf->tileS, (const cssm_u128*)pf->tileS2, (const StepRec*)(pf->d_recs + slot), pf->n_global, pf->endslot,
                      pf->anc, pf->ntiles, pf->sup, pf->nunits, 2, 0, (double*)nullptr, (int32_t*)nullptr, 0u, pf->opt_exact,
                      all5, rank, world, (int)pf->split, pf->seed, (double*)nullptr, (const double*)pf->d_logtab,
@@ -505,7 +513,8 @@ static int adopt_spec_impl(cssm_pf* pf, const double* recv_buf_dev, int rank, in
                      recv_buf_dev, (long long)cap, pf->d, n_split, pre ? (const cssm_u128*)pf->unitPre : (const cssm_u128*)nullptr,
                      peer_flags, peer_seq, pk);
   } else if (pf->last_optimistic) {
-    hipLaunchKernelGGL(k_offspring_expand_spec<2>, dim3(tgrid), dim3(CSSM_BLOCK), 0, pf->stream, pf->logw, pf->n, pf->sc,
+    auto ke = (pf->resampler == CSSM_RESAMPLE_STRATIFIED) ? k_offspring_expand_spec<2, CSSM_RESAMPLE_STRATIFIED> : k_offspring_expand_spec<2, CSSM_RESAMPLE_SYSTEMATIC>;
+    hipLaunchKernelGGL(ke, dim3(tgrid), dim3(CSSM_BLOCK), 0, pf->stream, pf->logw, pf->n, pf->sc,
                      (const cssm_u128*)pf->tileS, (const cssm_u128*)pf->tileS2, (const StepRec*)(pf->d_recs + slot), pf->n_global, pf->endslot,
                      pf->anc, pf->ntiles, pf->sup, pf->nunits, pf->last_optimistic ? 2 : 0, 0, (double*)nullptr, (int32_t*)nullptr, 0u, pf->opt_exact,
                      all5, rank, world, pf->last_optimistic ? (int)pf->split : 1, pf->seed, (double*)nullptr, (const double*)pf->d_logtab,
@@ -513,7 +522,8 @@ static int adopt_spec_impl(cssm_pf* pf, const double* recv_buf_dev, int rank, in
                      recv_buf_dev, (long long)cap, pf->d, n_split, pf->spec_pre ? (const cssm_u128*)pf->unitPre : (const cssm_u128*)nullptr,
                      peer_flags, peer_seq);
   } else {
-    hipLaunchKernelGGL(k_offspring_expand_spec<0>, dim3(tgrid), dim3(CSSM_BLOCK), 0, pf->stream, pf->logw, pf->n, pf->sc,
+    auto ke = (pf->resampler == CSSM_RESAMPLE_STRATIFIED) ? k_offspring_expand_spec<0, CSSM_RESAMPLE_STRATIFIED> : k_offspring_expand_spec<0, CSSM_RESAMPLE_SYSTEMATIC>;
+    hipLaunchKernelGGL(ke, dim3(tgrid), dim3(CSSM_BLOCK), 0, pf->stream, pf->logw, pf->n, pf->sc,
                      (const cssm_u128*)pf->tileS, (const cssm_u128*)pf->tileS2, (const StepRec*)(pf->d_recs + slot), pf->n_global, pf->endslot,
                      pf->anc, pf->ntiles, pf->sup, pf->nunits, pf->last_optimistic ? 2 : 0, 0, (double*)nullptr, (int32_t*)nullptr, 0u, pf->opt_exact,
                      all5, rank, world, pf->last_optimistic ? (int)pf->split : 1, pf->seed, (double*)nullptr, (const double*)pf->d_logtab,

@@ -433,14 +433,19 @@ __device__ __forceinline__ void spec_store_headers(SpecHeaders& H, const SpecHdr
   __syncthreads();
 }
 // stage 2: the verdict (all threads call)
+// rs / seed / step: the resampler whose grid the slots follow -- systematic (one uniform u, model/Resampling.scala:63-72) or stratified
+// (one uniform per slot from the Philox streams of (seed, step), :78-86: the grid points are keyed by GLOBAL slot, so every rank counts
+// the same slots below a cumulative weight)
 __device__ __forceinline__ bool spec_read_headers(SpecHeaders& H, int world, int rank, long long cap, int d,
-                                                  uint64_t n_local, uint64_t n_global, const double u) {
+                                                  uint64_t n_local, uint64_t n_global, const double u, int rs = CSSM_RESAMPLE_SYSTEMATIC,
+                                                  uint64_t seed = 0, uint32_t step = 0) {
   const double totd = cssm_u128_to_double(H.tot);
   const bool pow2 = (n_global & (n_global - 1)) == 0;
   const double inv_n = 1.0 / (double)n_global;
   auto count_of = [&](cssm_u128 G) -> uint64_t {
     if (cssm_u128_is_zero(G)) return 0;   // (the globally first particle starts at slot 0, as in k_offspring)
     const double C = cssm_u128_to_double(G) / totd;
+    if (rs == CSSM_RESAMPLE_STRATIFIED) return cssm_strat_count(C, seed, step, n_global);
     return pow2 ? cssm_sys_count_pow2(C, u, n_global, inv_n) : cssm_sys_count(C, u, n_global);
   };
   // four slot counts per rank (own begin / end, reach of the lower neighbour's last block / of the upper neighbour's first
@@ -482,7 +487,8 @@ __device__ __forceinline__ bool spec_read_headers(SpecHeaders& H, int world, int
 
 __device__ __forceinline__ void expand_spec_body(SpecHeaders& H, uint32_t bid, uint32_t nblk, const double* __restrict__ recv, int world, int rank,
                                                  long long cap, int d, uint32_t n_split, uint64_t slot_lo, uint64_t slot_hi, uint64_t n_global,
-                                                 const StepRec* __restrict__ rec, uint32_t* __restrict__ anc, Scalars* __restrict__ sc) {
+                                                 const StepRec* __restrict__ rec, uint32_t* __restrict__ anc, Scalars* __restrict__ sc,
+                                                 int rs = CSSM_RESAMPLE_SYSTEMATIC, uint64_t seed = 0) {
   __shared__ uint32_t s_nheavy;
   __shared__ uint32_t s_hb[CSSM_BLOCK], s_he[CSSM_BLOCK], s_hj[CSSM_BLOCK];
   const long long R = d + 1, HD = spec_hdr(d), seg = spec_seg(d, cap);
@@ -490,9 +496,11 @@ __device__ __forceinline__ void expand_spec_body(SpecHeaders& H, uint32_t bid, u
   const double u = rec->u;
   const bool pow2 = (n_global & (n_global - 1)) == 0;
   const double inv_n = 1.0 / (double)n_global;
+  const uint32_t rstep = rec->step;
   auto count_of = [&](cssm_u128 G) -> uint64_t {
     if (cssm_u128_is_zero(G)) return 0;
     const double C = cssm_u128_to_double(G) / totd;
+    if (rs == CSSM_RESAMPLE_STRATIFIED) return cssm_strat_count(C, seed, rstep, n_global);
     return pow2 ? cssm_sys_count_pow2(C, u, n_global, inv_n) : cssm_sys_count(C, u, n_global);
   };
   if (bid == 0 && threadIdx.x < CSSM_MAXSLOTS) sc->maxslot[(size_t)threadIdx.x * CSSM_SLOT_STRIDE] = 0ull;   // set 0 for the next step
@@ -561,7 +569,7 @@ __device__ unsigned long long g_spec_stamps[2048 * 8];   // diagnostic build: cl
 #endif
 // RAWC: how the weights are stored, at compile time (2: the weights k_propagate_shard formed relative to the reference level; 0:
 // log-weights, rescaled by the level the global max gave -- LGCP, a series repeated after an outlying observation)
-template <int RAWC>
+template <int RAWC, int RS>
 __device__ __forceinline__ void offspring_expand_spec_body(
     CSSM_OFFSPRING_PARAMS, uint32_t all5_stride, const double* __restrict__ recv, long long cap, int d, uint32_t n_split,
     const cssm_u128* __restrict__ unit_pre, const unsigned int* __restrict__ peer_flags, uint32_t peer_seq,
@@ -630,7 +638,7 @@ __device__ __forceinline__ void offspring_expand_spec_body(
   // them again).  The other blocks write nothing but ancestor indices -- of slots the redone exchange writes again, all of them, before
   // anybody gathers through them -- so they do not wait for a verdict they cannot act on: three block barriers and 4 x world exact
   // slot counts less on the path of every block but one (round 3: 2.9 us from entry to verdict in all 1024 blocks).
-  if (bidx == 0 && !spec_read_headers(H, world, rank, cap, d, n, n_global, rec_u)) {
+  if (bidx == 0 && !spec_read_headers(H, world, rank, cap, d, n, n_global, rec_u, RS, seed, rec->step)) {
     if (threadIdx.x == 0) { atomicOr(&sc->err, 8u); atomicMin(&sc->fail_step, rec->step); }
     return;
   }
@@ -641,22 +649,22 @@ __device__ __forceinline__ void offspring_expand_spec_body(
   tt.tot2.lo = H.tot2.lo; tt.tot2.hi = H.tot2.hi; tt.gmax = cssm_order_unkey(H.gkey);
   // (the arguments the single-collective launch has no use for are constants here: the compiler drops what hangs on them)
   (void)raw;
-  offspring_body<true, false, CSSM_RESAMPLE_SYSTEMATIC, RAWC>(logw, n, sc, unitP, unitS2, rec, n_global, /*endslot=*/nullptr, anc, ntiles, sup, nunits, RAWC, slot_set,
-                                                        /*ll_t=*/nullptr, /*ess_t=*/nullptr, 0u, force_exact, all5, rank, world, split, /*seed=*/0ull,
+  offspring_body<true, false, RS, RAWC>(logw, n, sc, unitP, unitS2, rec, n_global, /*endslot=*/nullptr, anc, ntiles, sup, nunits, RAWC, slot_set,
+                                                        /*ll_t=*/nullptr, /*ess_t=*/nullptr, 0u, force_exact, all5, rank, world, split, seed,
                                                         /*cum_out=*/nullptr, /*logtab=*/nullptr, optimistic, flag_out, slot_lo, slot_hi, all5_stride,
                                                         /*s2buf=*/nullptr, 0u, -1, 0u, unit_pre, blk0, prefetched ? pre_w : nullptr, &tt);
   CSSM_SPEC_STAMP(2);
   // the two neighbours' rows (their flags have long been set: the rows were written while this block resampled its own particles)
   if (peer_flags != nullptr && !wait_flags(CSSM_PEER_FLAG_ROWS, nullptr, rank - 1, rank + 1)) return;
-  expand_spec_body(H, bidx, nblk, recv, world, rank, cap, d, n_split, (uint64_t)slot_lo, (uint64_t)slot_hi, n_global, rec, anc, sc);
+  expand_spec_body(H, bidx, nblk, recv, world, rank, cap, d, n_split, (uint64_t)slot_lo, (uint64_t)slot_hi, n_global, rec, anc, sc, RS, seed);
   CSSM_SPEC_STAMP(3);
 }
 
-template <int RAWC>
+template <int RAWC, int RS = CSSM_RESAMPLE_SYSTEMATIC>
 __global__ __launch_bounds__(CSSM_BLOCK, CSSM_OFF_WAVES) void k_offspring_expand_spec(
     CSSM_OFFSPRING_PARAMS, uint32_t all5_stride, const double* __restrict__ recv, long long cap, int d, uint32_t n_split,
     const cssm_u128* __restrict__ unit_pre, const unsigned int* __restrict__ peer_flags = nullptr, uint32_t peer_seq = 0u) {
-  offspring_expand_spec_body<RAWC>(CSSM_OFFSPRING_FWD, all5_stride, recv, cap, d, n_split, unit_pre, peer_flags, peer_seq, 0u, nullptr);
+  offspring_expand_spec_body<RAWC, RS>(CSSM_OFFSPRING_FWD, all5_stride, recv, cap, d, n_split, unit_pre, peer_flags, peer_seq, 0u, nullptr);
 }
 
 // The peer-written exchange in ONE launch per weighted observation behind the propagate: the first pack_gx * world blocks of the grid
@@ -668,7 +676,7 @@ struct PackArgs {
   const double* src; size_t stride; uint32_t nsub; uint64_t chunk; cssm_u128* pre_out;
   const PeerTable* peer; int parity; unsigned int* tickets; unsigned int* pre_flag; uint32_t pack_gx;
 };
-template <int RAWC>
+template <int RAWC, int RS = CSSM_RESAMPLE_SYSTEMATIC>
 __global__ __launch_bounds__(CSSM_BLOCK, CSSM_OFF_WAVES) void k_exchange_offspring(
     CSSM_OFFSPRING_PARAMS, uint32_t all5_stride, const double* __restrict__ recv, long long cap, int d, uint32_t n_split,
     const cssm_u128* __restrict__ unit_pre, const unsigned int* __restrict__ peer_flags, uint32_t peer_seq, PackArgs pk) {
@@ -679,7 +687,7 @@ __global__ __launch_bounds__(CSSM_BLOCK, CSSM_OFF_WAVES) void k_exchange_offspri
                         pk.pre_flag);
     return;
   }
-  offspring_expand_spec_body<RAWC>(CSSM_OFFSPRING_FWD, all5_stride, recv, cap, d, n_split, unit_pre, peer_flags, peer_seq, blk0, pk.pre_flag);
+  offspring_expand_spec_body<RAWC, RS>(CSSM_OFFSPRING_FWD, all5_stride, recv, cap, d, n_split, unit_pre, peer_flags, peer_seq, blk0, pk.pre_flag);
 }
 
 __global__ __launch_bounds__(CSSM_BLOCK) void k_expand(const uint32_t* __restrict__ cand_end, const uint32_t* __restrict__ cand_idx,

@@ -103,6 +103,10 @@ class GpuShard:
     def init(self, t0: float):
         _abi.check(self.lib.cssm_pf_shard_init(self._h, float(t0)))
 
+    def set_option(self, option: int, value: int):
+        """cssm_pf_set_option on the shard's handle (CSSM_OPT_RESAMPLER = 2: 0 systematic, 1 stratified -- the same on every rank)."""
+        _abi.check(self.lib.cssm_pf_set_option(self._h, int(option), int(value)))
+
     # ---- a whole series, records resident on the device
     def begin(self, t, y, has):
         t = np.ascontiguousarray(t, dtype=np.float64)

@@ -211,7 +211,9 @@ int cssm_pf_last_loop_ms(cssm_pf* pf, float* ms_out);
 /* CSSM_OPT_RESAMPLER selects the `Resample[A]` the filter was constructed with (model/ParticleFilter.scala:
  * 233-235): systematic (model/Resampling.scala:63-72, default), stratified (:78-86) or multinomial (:92-96).
  * The reference's residualResampling (:130-146) indexes `Vector.range(1, m)` with draws from [0, n) and cannot
- * run as written; it is not offered.  Sharded handles support systematic resampling only. */
+ * run as written; it is not offered.  Sharded handles support systematic and stratified resampling (the grid points of both are
+ * keyed by GLOBAL slot and ordered, so the ancestors of a rank's slots are its own particles plus its neighbours' boundary blocks);
+ * a multinomial resampler draws every slot's ancestor from the whole cloud and stays single-GPU. */
 #define CSSM_OPT_RESAMPLER 2
 #define CSSM_RESAMPLE_SYSTEMATIC 0
 #define CSSM_RESAMPLE_STRATIFIED 1

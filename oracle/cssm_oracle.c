@@ -701,6 +701,7 @@ double oracle_pf_ref_level(const oracle_pf* pf, double y) {
 }
 double oracle_c_ref_choose(double c, double max) { return cssm_ref_choose(c, max); }
 double oracle_c_ref_predict(double prev_max) { return cssm_ref_predict(prev_max); }
+uint64_t oracle_c_strat_count(double C, uint64_t seed, uint32_t step, uint64_t n) { return cssm_strat_count(C, seed, step, n); }
 uint64_t oracle_c_order_key(double x) { return cssm_order_key(x); }
 double oracle_c_order_unkey(uint64_t k) { return cssm_order_unkey(k); }
 void oracle_pf_get_ref(const oracle_pf* pf, double* ref, double* gmax) { *ref = pf->ref_last; *gmax = pf->gmax_last; }

@@ -75,6 +75,7 @@ def lib() -> C.CDLL:
             "oracle_pf_ref_level": (C.c_double, [vp, C.c_double]),
             "oracle_c_ref_choose": (C.c_double, [C.c_double, C.c_double]),
             "oracle_c_ref_predict": (C.c_double, [C.c_double]),
+            "oracle_c_strat_count": (C.c_uint64, [C.c_double, C.c_uint64, C.c_uint32, C.c_uint64]),
             "oracle_c_order_key": (C.c_uint64, [C.c_double]),
             "oracle_c_order_unkey": (C.c_double, [C.c_uint64]),
             "oracle_pf_summary": (C.c_int, [vp, C.c_double, _dp, _dp, _dp, _dp, _dp, _dp]),

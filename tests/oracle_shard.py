@@ -36,8 +36,9 @@ def _join64(lo: int, hi: int) -> int:
 
 
 class OracleShard:
-    def __init__(self, model, n_global, rank, world, seed, lgcp_precision=0):
+    def __init__(self, model, n_global, rank, world, seed, lgcp_precision=0, resampler=0):
         self.rank, self.world, self.n_global = rank, world, n_global
+        self.resampler = resampler        # 0 systematic, 1 stratified (CSSM_RESAMPLE_*): the grid the slot counts follow
         self.first, self.n = shard_bounds(n_global, world, rank)
         self.o = oracle.OraclePf(model.descriptor(lgcp_precision), self.n, seed)
         self.o.set_shard(self.first, n_global)
@@ -78,6 +79,12 @@ class OracleShard:
         else:
             self.o.set_particles(self.x1)
         self.step_idx += 1
+
+    def _cnt(self, C, u):
+        """#{ slots whose grid point is <= C }: systematic (one uniform u) or stratified (one per slot, keyed by GLOBAL slot)"""
+        if self.resampler == 1:
+            return int(oracle.lib().oracle_c_strat_count(C, self.seed, self.step_idx - 1, self.n_global))
+        return int(oracle.lib().oracle_c_sys_count(C, u, self.n_global))
 
     def o_is_lgcp(self):
         return self.o._d.desc.obs_kind == 2
@@ -122,14 +129,13 @@ class OracleShard:
         self.ess = int(np.floor(1.0 / (tot2 / (tot * tot))))
         u = oracle.lib().oracle_c_u(self.seed, self.step_idx - 1)
         totd = float(S_tot)
-        cnt = oracle.lib().oracle_c_sys_count
         run = S_off
         E = np.zeros(self.n, dtype=np.int64)
         for j, q in enumerate(self.q):
             run += q
-            E[j] = cnt(float(run) / totd, u, self.n_global)
+            E[j] = self._cnt(float(run) / totd, u)
         self.E = E
-        e_before = cnt(float(S_off) / totd, u, self.n_global) if self.rank > 0 else 0
+        e_before = self._cnt(float(S_off) / totd, u) if self.rank > 0 else 0
         per = (self.n_global + self.world - 1) // self.world
         for qd in range(self.world):
             b_lo = min(qd * per, self.n_global); b_hi = min(b_lo + per, self.n_global)
@@ -310,7 +316,7 @@ class OracleShard:
         off = [sum(S[:r]) for r in range(self.world)]
         totd = float(sum(S))
         u = oracle.lib().oracle_c_u(self.seed, self.step_idx - 1)
-        cnt_of = lambda G: 0 if G == 0 else int(oracle.lib().oracle_c_sys_count(float(G) / totd, u, self.n_global))
+        cnt_of = lambda G: 0 if G == 0 else self._cnt(float(G) / totd, u)
         # the verdict every rank reaches from the headers alone: are EVERY rank's slots covered?
         plow = [int(bits[r * seg + 8]) | (int(bits[r * seg + 9]) << 64) for r in range(self.world)]
         phigh = [int(bits[r * seg + 10]) | (int(bits[r * seg + 11]) << 64) for r in range(self.world)]

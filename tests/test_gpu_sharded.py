@@ -503,3 +503,33 @@ def test_trimmed_exchange_reads_only_headers_of_non_adjacent_segments(world, nam
     np.testing.assert_array_equal(np.concatenate([s.particles() for s in shards], axis=1), opart)
     for s in shards:
         s.close()
+
+
+@pytest.mark.parametrize("peer", [False, True])
+@pytest.mark.parametrize("world,name,n", [(2, "c2_model", 5000), (4, "c1_model", 6000), (8, "c2_model", 16000), (3, "c3_model", 4100)])
+def test_local_shards_stratified_resampling(world, name, n, peer):
+    """Resampling.stratifiedResampling (model/Resampling.scala:78-86) over shards: one uniform per slot from the Philox stream of the
+    GLOBAL slot, so the ancestors of a rank's slots are again its own particles plus its neighbours' boundary blocks -- the same
+    exchange, the stratified slot counts.  Bit-identical to the single-rank oracle with the same resampler: collective and peer-written
+    exchange, the exact exchange, a continued series."""
+    from composablestatespacemodels_amd.sharded import GpuShard, ShardedFilter
+    from local_comm import LocalComm, LocalCommPeer
+    model = getattr(cases, name)()
+    t, y, has = cases.poisson_counts(9, missing=0.15)
+    shards = [GpuShard(model, n, r, world, cases.SEED, 0) for r in range(world)]
+    for s in shards:
+        s.set_option(2, 1)                      # CSSM_OPT_RESAMPLER = CSSM_RESAMPLE_STRATIFIED
+    f = ShardedFilter(shards, (LocalCommPeer if peer else LocalComm)(world))
+    o = oracle.OraclePf(model.descriptor(), n, cases.SEED, oracle.RESAMPLE_STRATIFIED)
+    oll, _, oess, _ = o.filter(t, y, has)
+    for exact in ((False,) if peer else (False, True)):
+        ll, ess = f.ll_filter(t, y, has, exact=exact)
+        assert (ll, ess) == (oll, oess[-1]), (exact, ll, oll)
+        np.testing.assert_array_equal(np.concatenate([s.particles() for s in shards], axis=1), o.particles())
+    f.ll_filter(t[:5], y[:5], has[:5])
+    assert f.ll_filter_more(t[5:], y[5:], has[5:]) == (oll, oess[-1])
+    with pytest.raises(Exception):
+        shards[0].set_option(2, 2)              # multinomial: another exchange altogether, refused on a shard
+    for s in shards:
+        s.close()
+

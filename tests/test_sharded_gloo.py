@@ -118,6 +118,49 @@ def test_local_comm_matches_single_rank_on_cpu():
     np.testing.assert_allclose(sm["state_mean"], om, rtol=1e-12)
 
 
+def _strat_worker(rank, world, port, n, T, out_dir):
+    sys.path.insert(0, HERE)
+    sys.path.insert(0, os.path.dirname(HERE))
+    import cases as C
+    from composablestatespacemodels_amd.sharded import DistComm, ShardedFilter
+    from oracle_shard import OracleShard
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        t, y, has = C.poisson_counts(T, missing=0.1)
+        shard = OracleShard(C.c2_model(), n, rank, world, C.SEED, 0, resampler=1)
+        ll, ess = ShardedFilter([shard], DistComm()).ll_filter(t, y, has)
+        np.savez(os.path.join(out_dir, f"q{rank}.npz"), ll=ll, ess=ess, part=shard.particles())
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_stratified_resampling_matches_single_rank(tmp_path, world):
+    """Resampling.stratifiedResampling (model/Resampling.scala:78-86) over shards, orchestration rehearsed on the CPU: in one process
+    (LocalComm, 4 shards) and over gloo (`world` processes) -- the single-rank oracle's bits with the same resampler."""
+    from composablestatespacemodels_amd.sharded import ShardedFilter
+    from local_comm import LocalComm
+    from oracle_shard import OracleShard
+    model = cases.c2_model()
+    n, T = 300, 7
+    t, y, has = cases.poisson_counts(T, missing=0.1)
+    o = oracle.OraclePf(model.descriptor(), n, cases.SEED, oracle.RESAMPLE_STRATIFIED)
+    oll, _, oess, _ = o.filter(t, y, has)
+    shards = [OracleShard(model, n, r, 4, cases.SEED, 0, resampler=1) for r in range(4)]
+    assert ShardedFilter(shards, LocalComm(4)).ll_filter(t, y, has) == (oll, int(oess[-1]))
+    np.testing.assert_array_equal(np.concatenate([s.particles() for s in shards], axis=1), o.particles())
+    port = 29900 + (os.getpid() % 90) + world
+    mp.spawn(_strat_worker, args=(world, port, n, T, str(tmp_path)), nprocs=world, join=True)
+    parts = []
+    for r in range(world):
+        z = np.load(os.path.join(str(tmp_path), f"q{r}.npz"))
+        assert float(z["ll"]) == oll and int(z["ess"]) == int(oess[-1])
+        parts.append(z["part"])
+    np.testing.assert_array_equal(np.concatenate(parts, axis=1), o.particles())
+
+
 @pytest.mark.parametrize("which", ["c2", "c4"])
 def test_bench_launches_its_own_ranks_over_gloo(which):
     """`python bench.py --gpus 2` without a launcher starts its own two ranks (children, before any GPU call in the
