@@ -355,8 +355,9 @@ def run_multi(args, emit=print):
         t0 = time.perf_counter()
         ll, ess = f.ll_filter_more(t[lo:lo + K], y[lo:lo + K], has[lo:lo + K], lgcp=lgcp)
         sync()
+        t1 = time.perf_counter()     # this rank's K steps are done; the leg's time is the MAX over the ranks (below), behind the barrier
         dist.barrier()
-        wall = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
+        wall = torch.tensor([t1 - t0], dtype=torch.float64, device=dev)
         dist.all_reduce(wall, op=dist.ReduceOp.MAX)
         walls.append(float(wall.item()))
         plans.append({"plan": "max" if f.last_from_max else ("ref" if f.last_single else "exact"), "resumes": int(f.last_resumes),
