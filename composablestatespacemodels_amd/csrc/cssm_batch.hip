@@ -56,7 +56,7 @@ __global__ __launch_bounds__(CSSM_BLOCK) void k_init_batch(const ChainBase* __re
 }
 
 template <int RS, int RAWC, bool GRP>
-__global__ __attribute__((amdgpu_flat_work_group_size(CSSM_BLOCK, CSSM_BLOCK), amdgpu_waves_per_eu(CSSM_OFF_SELF_WAVES, 8))) void k_offspring_batch(
+__global__ __attribute__((amdgpu_flat_work_group_size(CSSM_BLOCK, CSSM_BLOCK), amdgpu_waves_per_eu(CSSM_OFF_WAVES, 8))) void k_offspring_batch(
     const ChainBase* __restrict__ chains, uint64_t n, uint32_t rec_idx, uint32_t ntiles, uint32_t sup, uint32_t nunits, int slot_set, int force_exact,
     int split, uint32_t s2_stride, int s2_par) {
   const ChainBase* __restrict__ c = chains + blockIdx.y;
