@@ -49,7 +49,7 @@ static __global__ __launch_bounds__(CSSM_BLOCK) void k_tile_sums(const double* _
   // resumes exactly there (cssm_pf_shard_resume)
   if (hold_mask && (sc->err & hold_mask)) return;
   __shared__ cssm_u128 s_a[CSSM_BLOCK / 64], s_b[CSSM_BLOCK / 64];
-  const double* tab = nullptr; (void)logtab;   // literal constants measured faster than an LDS constant table
+  const double* tab = nullptr; (void)logtab;   // literal constants measured faster than an LDS constant table (LABNOTES.md)
   double pre[CSSM_ITEMS];   // the block's first tile is requested before the (serial) max decode
   if (blockIdx.x < nunits) load_tile_raw(logw, (uint64_t)blockIdx.x * sup * CSSM_TILE, n, raw, pre);
   // slot_set < 0: the max was agreed elsewhere (sharded: all-reduced value at gmax_in; stateless: sc->gmax)

@@ -333,7 +333,7 @@ class Resampling:
     @staticmethod
     def residualResampling(particles: Sequence, weights: Sequence[float]):
         """Resampling.scala:130-146 cannot run as written (it hands ``Vector.range(1, m)`` with n weights to the multinomial
-        resampler and then indexes the particles with the result, :144-145): not offered, see DESIGN.md section 9."""
+        resampler and then indexes the particles with the result, :144-145): not offered, see LABNOTES.md (old section 9)."""
         raise NotImplementedError("the reference's residualResampling fails as written (model/Resampling.scala:144-145)")
 
     @staticmethod
