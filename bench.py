@@ -166,56 +166,83 @@ def run_single(args, emit=print):
     R = args.repeats if args.repeats > 0 else (3 if K >= 200 else 7)
     W = max(W, 1)                      # (the filter has to be running before K more steps can be timed)
     model, t, y, has = build_workload(W + 4 * R * K + 16, args.model)
-    pf = NativePf(model, n, 20260101, device=0, lgcp_precision=LGCP_PRECISION if lgcp else 0)
-    if args.fused is not None:
-        pf.set_option(3, args.fused)   # CSSM_OPT_FUSED_SUMS (experiment switch; the default is the library's)
-    d = pf.d
-    torch.cuda.synchronize()
-    # W untimed warm-up steps start the filter (initial cloud, allocations, clocks) ...
-    pf.run(t[:W], y[:W], has[:W])
-    # ... and the timed leg CONTINUES it: R legs of exactly K more steps each (cssm_pf_ll_filter_more: no new cloud, the series
-    # goes on), every leg bracketed by a device synchronisation on both sides; the figure is the MEDIAN leg (a short leg on a
-    # fresh box is otherwise at the mercy of one hiccup).  A leg is the whole host call: records built and uploaded, 2 K
-    # launches enqueued, ll / ess read back.
-    walls, loops = [], []
-    ll = ess_t = None
-    for r in range(R):
-        lo = W + r * K
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        ll, _, ess_t = pf.run_more(t[lo:lo + K], y[lo:lo + K], has[lo:lo + K])
-        torch.cuda.synchronize()
-        walls.append(time.perf_counter() - t0)
-        loops.append(pf.last_loop_ms())
-    wall = float(np.median(walls))
-    loop_ms = float(np.median(loops))
-    per, pair_s, prof_raw = _kernel_profile(pf, t, y, has, K, loop_ms,
-                                            legs=[(W + (R + r) * K, W + (R + r + 1) * K) for r in range(R)])
-    # the same model and legs with the structure specialisation switched off (CSSM_OPT_SPECIALISE = 0: the kernel that reads the model's
-    # structure as data, what every model outside BASELINE's configurations ran until round 4 gave each its own run-time-compiled kernel)
-    roof_generic = None
-    if not args.no_generic:
-        pf.set_option(8, 0)
-        lo = W + 2 * R * K
-        pf.run_more(t[lo:lo + 8], y[lo:lo + 8], has[lo:lo + 8])
-        lo += 8
-        gl = []
-        for r in range(R):
-            pf.run_more(t[lo + r * K:lo + (r + 1) * K], y[lo + r * K:lo + (r + 1) * K], has[lo + r * K:lo + (r + 1) * K])
-            gl.append(pf.last_loop_ms())
-        gper, gpair, _ = _kernel_profile(pf, t, y, has, K, float(np.median(gl)), legs=[(lo + (R + r) * K, lo + (R + r + 1) * K) for r in range(R)])
-        ga, gc, gr = gper["k_propagate"]
-        roof_generic = _roofline(f"k_propagate<{d},...> reading the model's structure as data (CSSM_OPT_SPECIALISE = 0), N={n}", d, n, ga, gc, gr, gpair, None)
-        roof_generic["step_us"] = float(np.median(gl)) * 1e3 / K
-        pf.set_option(8, 1)
-    lib = pf.lib
-    pf.close()
-    # on-box streaming ceiling (plain 16-byte-per-lane copy, 1 GiB each way: far beyond the 256 MB Infinity Cache)
     import ctypes as C
-    copy = C.c_double(0.0)
-    copy_gbs = None
-    if lib.cssm_diag_copy_ceiling(0, 1 << 30, 10, C.byref(copy)) == 0:
-        copy_gbs = copy.value
+
+    def handle():
+        h = NativePf(model, n, 20260101, device=0, lgcp_precision=LGCP_PRECISION if lgcp else 0)
+        if args.fused is not None:
+            h.set_option(3, args.fused)   # CSSM_OPT_FUSED_SUMS (experiment switch; the default is the library's)
+        return h
+
+    def timed_legs():
+        """The figure of merit: W untimed warm-up steps start a filter (initial cloud, allocations) and the timed leg CONTINUES it: R legs
+        of exactly K more steps each (cssm_pf_ll_filter_more: no new cloud, the series goes on), every leg bracketed by a device
+        synchronisation on both sides; the figure is the MEDIAN leg.  A leg is the whole host call: records built and sent, 2 K launches
+        enqueued, ll / ess read back."""
+        pf = handle()
+        torch.cuda.synchronize()
+        pf.run(t[:W], y[:W], has[:W])
+        walls = []
+        ll = ess_t = None
+        for r in range(R):
+            lo = W + r * K
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            ll, _, ess_t = pf.run_more(t[lo:lo + K], y[lo:lo + K], has[lo:lo + K])
+            torch.cuda.synchronize()
+            walls.append(time.perf_counter() - t0)
+        d = pf.d
+        pf.close()
+        return walls, ll, ess_t, d
+
+    def roofline_legs():
+        """Kernel times of legs of the same shape on a handle of their own: the streaming ceiling of the box, the device time of R legs (HIP
+        events around their per-observation kernels: CSSM_OPT_LOOP_EVENTS -- off in the timed legs, the two event packets cost a 20-step
+        call ~5 us), R legs with every kernel bracketed, and the same with the structure specialisation switched off."""
+        pf = handle()
+        copy = C.c_double(0.0)
+        copy_gbs = None
+        # (plain 16-byte-per-lane copy, 1 GiB each way: far beyond the 256 MB Infinity Cache)
+        if pf.lib.cssm_diag_copy_ceiling(0, 1 << 30, 10, C.byref(copy)) == 0:
+            copy_gbs = copy.value
+        pf.run(t[:W], y[:W], has[:W])
+        pf.set_option(9, 1)
+        loops = []
+        for r in range(R):
+            lo = W + r * K
+            pf.run_more(t[lo:lo + K], y[lo:lo + K], has[lo:lo + K])
+            loops.append(pf.last_loop_ms())
+        loop_ms = float(np.median(loops))
+        per, pair_s, prof_raw = _kernel_profile(pf, t, y, has, K, loop_ms, legs=[(W + (R + r) * K, W + (R + r + 1) * K) for r in range(R)])
+        # the same model and legs with the structure specialisation switched off (CSSM_OPT_SPECIALISE = 0: the kernel that reads the model's
+        # structure as data, what every model outside BASELINE's configurations ran until round 4 gave each its own run-time-compiled kernel)
+        roof_generic = None
+        if not args.no_generic:
+            pf.set_option(8, 0)
+            lo = W + 2 * R * K
+            pf.run_more(t[lo:lo + 8], y[lo:lo + 8], has[lo:lo + 8])
+            lo += 8
+            gl = []
+            for r in range(R):
+                pf.run_more(t[lo + r * K:lo + (r + 1) * K], y[lo + r * K:lo + (r + 1) * K], has[lo + r * K:lo + (r + 1) * K])
+                gl.append(pf.last_loop_ms())
+            gper, gpair, _ = _kernel_profile(pf, t, y, has, K, float(np.median(gl)), legs=[(lo + (R + r) * K, lo + (R + r + 1) * K) for r in range(R)])
+            ga, gc, gr = gper["k_propagate"]
+            roof_generic = _roofline(f"k_propagate<{pf.d},...> reading the model's structure as data (CSSM_OPT_SPECIALISE = 0), N={n}", pf.d, n, ga, gc, gr, gpair, None)
+            roof_generic["step_us"] = float(np.median(gl)) * 1e3 / K
+        pf.close()
+        return copy_gbs, loop_ms, per, pair_s, roof_generic
+
+    # Order: the roofline legs FIRST.  W = 5 warm-up steps are 0.1 ms of device work, and the legs of a process that has kept the GPU busy
+    # for a few ms in all run 5-15 % slower than every later one (leg after leg of the same handle: 522 493 461 465 468 ... 445 us, level
+    # after ~15 legs): timed first, R = 7 legs of 20 steps measure that ramp, not the filter.  BENCH_TIMED_FIRST=1 restores that order.
+    if os.environ.get("BENCH_TIMED_FIRST", "0") == "1":
+        walls, ll, ess_t, d = timed_legs()
+        copy_gbs, loop_ms, per, pair_s, roof_generic = roofline_legs()
+    else:
+        copy_gbs, loop_ms, per, pair_s, roof_generic = roofline_legs()
+        walls, ll, ess_t, d = timed_legs()
+    wall = float(np.median(walls))
     traffic, traffic_source = None, None
     tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
     if os.path.exists(tpath):
@@ -240,7 +267,7 @@ def run_single(args, emit=print):
         "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
         "config": {"workload": workload_text(args.model, n, K),
                    "particles_per_gpu": n, "observations": K, "latent_dim": d, "seed": 20260101},
-        "repeats": R, "value_is": "median over `repeats` timed legs of K steps each, continuing the filter the warm-up steps started (cssm_pf_ll_filter_more)", "wall_ms_each": [w * 1e3 for w in walls],
+        "repeats": R, "value_is": "median over `repeats` timed legs of K steps each, continuing the filter the warm-up steps started (cssm_pf_ll_filter_more); the roofline legs (a handle of their own) run before it", "wall_ms_each": [w * 1e3 for w in walls],
         "roofline": roof,
         "roofline_generic": roof_generic,
         "kernels_us": kernels_us,
@@ -268,6 +295,7 @@ def roofline_16m(NativePf, copy_gbs, fused=None, K=24):
         for variant, fz in (("", 1 if fused is None else fused), ("_lean", 0)):
             pf = NativePf(model, N_16M, 20260101, device=0)
             pf.set_option(3, fz)
+            pf.set_option(9, 1)            # CSSM_OPT_LOOP_EVENTS: these legs are timed on the device
             pf.run(t[:8], y[:8], has[:8])
             loop_ms = 1e30
             for _ in range(3):            # (the first series on a 1 GB handle is not representative: best of three)

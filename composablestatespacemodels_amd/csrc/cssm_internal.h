@@ -112,6 +112,7 @@ struct cssm_pf : HostModel {
   std::vector<Snap> snaps;     // host-side state right after the propagate of every observation of the series (cssm_pf_shard_resume)
   // host staging (pinned)
   StepRec* h_recs = nullptr;
+  StepRec* h_recs_dev = nullptr;   // the device's address of h_recs (k_fetch_recs)
   size_t h_recs_cap = 0;
   Scalars* h_sc = nullptr;     // pinned: the streaming step's scalars land here without a staging copy
   // filter state
@@ -120,7 +121,9 @@ struct cssm_pf : HostModel {
   uint32_t h_step_for_resample = 0;   // observation index of the step being resampled (Philox counter word)
   bool initialised = false;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
-  float last_ms = 0.f;
+  float last_ms = -1.f;
+  int opt_events = 0;              // CSSM_OPT_LOOP_EVENTS: the batch drivers bracket their device loop with an event pair
+  bool have_events = false;        // ... and the last call did
   // optional per-kernel timing (HIP events on the launch stream around every kernel)
   bool profile = false;
   uint32_t* h_done = nullptr; uint32_t* hd_done = nullptr; uint32_t done_seq = 0;   // k_finish's completion word (host-mapped), read_scalars polls it

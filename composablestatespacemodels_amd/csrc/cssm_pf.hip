@@ -70,6 +70,7 @@ static int alloc_handle(cssm_pf* pf) {
   if (pf->own_stream) HIP_TRY(hipStreamCreateWithFlags(&pf->stream, hipStreamNonBlocking));
   HIP_TRY(hipEventCreate(&pf->ev0));
   HIP_TRY(hipEventCreate(&pf->ev1));
+  { const char* e = getenv("CSSM_LOOP_EVENTS"); pf->opt_events = (e && e[0] == '1') ? 1 : 0; }   // (measurement scripts: the default of CSSM_OPT_LOOP_EVENTS)
   HIP_TRY(hipDeviceGetAttribute(&pf->n_cus, hipDeviceAttributeMultiprocessorCount, pf->device));
   pf->stride = (size_t)((pf->n + CSSM_TILE - 1) / CSSM_TILE) * CSSM_TILE;   // rows start 16-B aligned
   pf->ntiles = (uint32_t)((pf->n + CSSM_TILE - 1) / CSSM_TILE);
@@ -252,8 +253,25 @@ static bool may_use_sums_kernel(const cssm_pf* pf) {
 // Records [first, first + count) of the handle's host buffer -> the device.  chain (the records CONTINUE a running filter): where
 // the level is predicted from the observation before (LGCP: StepRec::predict) the first record's comes from Scalars::next_ref,
 // on the stream; later records of the call get theirs from the kernels that publish their predecessors (publish_next_level).
+// The observation records travel by a KERNEL that reads the pinned host buffer (one block per record), not by hipMemcpyAsync: a
+// 14 KB copy cost 7-11 us of host time and left the queue idle for 9 us before the first propagate (rocprofv3 timeline of 20-step
+// legs: copy 0 .. 3, first kernel at 11.6 us); a launch costs 3.5 us of host time and the records' 89 words cross PCIe in one round trip.
+// CSSM_UPLOAD_MEMCPY=1 keeps the copy (A/B).
+__global__ __launch_bounds__(128) void k_fetch_recs(const StepRec* __restrict__ host, StepRec* __restrict__ dev) {
+  static_assert(sizeof(StepRec) % 8 == 0, "records are copied in 8-byte words");
+  const unsigned long long* s = reinterpret_cast<const unsigned long long*>(host + blockIdx.x);
+  unsigned long long* d = reinterpret_cast<unsigned long long*>(dev + blockIdx.x);
+  for (uint32_t i = threadIdx.x; i < sizeof(StepRec) / 8; i += 128) d[i] = s[i];
+}
 int cssm_upload_recs(cssm_pf* pf, size_t first, size_t count, bool chain) {
-  HIP_TRY(hipMemcpyAsync(pf->d_recs + first, pf->h_recs + first, count * sizeof(StepRec), hipMemcpyHostToDevice, pf->stream));
+  static const bool by_copy = getenv("CSSM_UPLOAD_MEMCPY") != nullptr;
+  if (count == 0) return CSSM_OK;
+  if (by_copy || !pf->h_recs_dev || count > 0x7fffffffu) {
+    HIP_TRY(hipMemcpyAsync(pf->d_recs + first, pf->h_recs + first, count * sizeof(StepRec), hipMemcpyHostToDevice, pf->stream));
+  } else {
+    hipLaunchKernelGGL(k_fetch_recs, dim3((uint32_t)count), dim3(128), 0, pf->stream, (const StepRec*)(pf->h_recs_dev + first), pf->d_recs + first);
+    HIP_TRY(hipGetLastError());
+  }
   if (chain && pf->obs_kind == CSSM_OBS_LGCP) {
     hipLaunchKernelGGL(k_chain_level, dim3(1), dim3(1), 0, pf->stream, pf->d_recs + first, (const Scalars*)pf->sc);
     HIP_TRY(hipGetLastError());
@@ -498,6 +516,8 @@ int cssm_ensure_recs(cssm_pf* pf, size_t T) {
     pf->h_recs = nullptr;
     HIP_TRY(hipHostMalloc((void**)&pf->h_recs, T * sizeof(StepRec), hipHostMallocDefault));
     pf->h_recs_cap = T;
+    pf->h_recs_dev = nullptr;   // (the device's address of the pinned buffer: k_fetch_recs reads it; without one the records are copied)
+    if (hipHostGetDevicePointer((void**)&pf->h_recs_dev, pf->h_recs, 0) != hipSuccess) { (void)hipGetLastError(); pf->h_recs_dev = nullptr; }
   }
   if (pf->recs_cap < T) {
     if (pf->d_recs) (void)hipFree(pf->d_recs);
@@ -672,13 +692,27 @@ static int run_filter_once(cssm_pf* pf, const double* t, const double* y, const 
   for (size_t s = 1; s < T; ++s) if (t[s] < t0) t0 = t[s];     // data.minBy(_.t).t, model/ParticleFilter.scala:138
   const uint32_t base = cont ? pf->step : 0u;                  // index of this call's first observation in the filter's series
   double tp = cont ? pf->t : t0;
-  for (size_t s = 0; s < T; ++s) { cssm_build_rec(pf, tp, t[s], y[s], has ? has[s] : 1, base + (uint32_t)s, &pf->h_recs[s]); tp = t[s]; }
-  rc = cssm_build_fsub(pf, 0, T, true);
-  if (rc) return rc;
-  ph_rec = since(tp0);
-  rc = cssm_upload_recs(pf, 0, T, cont);
-  if (rc) return rc;
-  ph_up = since(tp0);
+  // The first observation's record goes ahead of the others (a continued call of a model without per-observation tables): the queue
+  // has its first kernels while the host is still building records 1 .. T-1 (4 us for 20 of them, on the critical path otherwise).
+  const bool head_first = cont && T > 1 && pf->obs_kind != CSSM_OBS_LGCP;
+  size_t built = 0;
+  if (head_first) {
+    cssm_build_rec(pf, tp, t[0], y[0], has ? has[0] : 1, base, &pf->h_recs[0]); tp = t[0]; built = 1;
+    rc = cssm_upload_recs(pf, 0, 1, cont);
+    if (rc) return rc;
+  }
+  bool rest_pending = head_first;
+  auto build_rest = [&]() -> int {      // records built .. T-1: built and sent (head_first: behind the first observation's launches)
+    for (size_t s = built; s < T; ++s) { cssm_build_rec(pf, tp, t[s], y[s], has ? has[s] : 1, base + (uint32_t)s, &pf->h_recs[s]); tp = t[s]; }
+    int r = cssm_build_fsub(pf, 0, T, true);
+    if (r) return r;
+    ph_rec = since(tp0);
+    r = cssm_upload_recs(pf, built, T - built, cont && built == 0);
+    ph_up = since(tp0);
+    rest_pending = false;
+    return r;
+  };
+  if (!head_first) { rc = build_rest(); if (rc) return rc; }
   if (!cont) {
     rc = cssm_launch_init(pf, t0);
     if (rc) return rc;
@@ -701,7 +735,7 @@ static int run_filter_once(cssm_pf* pf, const double* t, const double* y, const 
     hipLaunchKernelGGL(k_pick, dim3(1), dim3(64), 0, pf->stream, pf->src, pf->src_stride, (const uint32_t*)nullptr,
                        (uint64_t)pa % pf->n, d, pf->d_path);
   }
-  HIP_TRY(hipEventRecord(pf->ev0, pf->stream));
+  if (pf->opt_events) HIP_TRY(hipEventRecord(pf->ev0, pf->stream));
   // path entry s + 1 = the resampled state sampleOne picks after observation s.  With the kernels that also form the
   // sums (small handles: the PMMH case) the k_propagate of observation s + 1, which gathers exactly that state into the
   // thread of slot pick_s, records it on the way; otherwise a one-block launch per observation does.
@@ -726,6 +760,7 @@ static int run_filter_once(cssm_pf* pf, const double* t, const double* y, const 
         else hipLaunchKernelGGL(k_record, dim3(1), dim3(1), 0, pf->stream, pf->sc, pf->d_ll_t, pf->d_ess_t, (uint32_t)s);
       }
       if (rc) return rc;
+      if (rest_pending) { rc = build_rest(); if (rc) return rc; }
       folded = path && s + 1 < T && uses_sums_kernel(pf);   // (the last entry has no following propagate)
       if (path && !folded)
         hipLaunchKernelGGL(k_pick, dim3(1), dim3(64), 0, pf->stream, pf->src, pf->src_stride,
@@ -734,7 +769,7 @@ static int run_filter_once(cssm_pf* pf, const double* t, const double* y, const 
     }
     // the call's ONE synchronisation when no observation was held: results and scalars travel together
     ph_enq = since(tp0);
-    HIP_TRY(hipEventRecord(pf->ev1, pf->stream));
+    if (pf->opt_events) HIP_TRY(hipEventRecord(pf->ev1, pf->stream));
     HIP_TRY(hipGetLastError());
     if (path) HIP_TRY(hipMemcpyAsync(path, pf->d_path, (T + 1) * (size_t)d * 8, hipMemcpyDeviceToHost, pf->stream));
     rc = read_scalars(pf, (uint32_t)T, ll_t != nullptr, ess_t != nullptr, /*poll=*/path == nullptr);   // (k_finish: a pending ESS formed, results into host-mapped memory)
@@ -773,7 +808,8 @@ static int run_filter_once(cssm_pf* pf, const double* t, const double* y, const 
     for (size_t s = 0; s < T; ++s) if (!pf->h_recs[s].has_obs) ess_t[s] = s ? ess_t[s - 1] : ess0;
   }
   pf->last_ms = -1.f;            // (the event pair is read when somebody asks: cssm_pf_last_loop_ms; a query per call cost ~3 us)
-  if (timing) { HIP_TRY(hipEventSynchronize(pf->ev1)); HIP_TRY(hipEventElapsedTime(&pf->last_ms, pf->ev0, pf->ev1)); }
+  pf->have_events = pf->opt_events != 0;
+  if (timing && pf->have_events) { HIP_TRY(hipEventSynchronize(pf->ev1)); HIP_TRY(hipEventElapsedTime(&pf->last_ms, pf->ev0, pf->ev1)); }
   prof_collect(pf);
   if (timing) fprintf(stderr, "cssm call T=%zu: records built %.1f us, upload enqueued %.1f, %zu steps enqueued %.1f, results back %.1f (device loop %.1f us)\n",
                       T, ph_rec, ph_up, T, ph_enq, since(tp0), pf->last_ms * 1e3);
@@ -905,6 +941,7 @@ extern "C" int cssm_diag_copy_ceiling(int device, size_t bytes, int reps, double
 extern "C" int cssm_pf_last_loop_ms(cssm_pf* pf, float* ms_out) {
   if (!pf || !ms_out) return fail(CSSM_EINVAL_ARG, "null argument");
   if (pf->last_ms < 0.f) {       // the batch drivers leave the event pair of their device loop unread
+    if (!pf->have_events) return fail(CSSM_ESTATE, "the last batch call recorded no events: set CSSM_OPT_LOOP_EVENTS = 1 before it");
     HIP_TRY(hipSetDevice(pf->device));
     HIP_TRY(hipEventSynchronize(pf->ev1));   // (the call returned on k_finish's completion word, not on the stream)
     HIP_TRY(hipEventElapsedTime(&pf->last_ms, pf->ev0, pf->ev1));
@@ -918,6 +955,7 @@ extern "C" int cssm_pf_set_option(cssm_pf* pf, int option, int value) {
   if (option == CSSM_OPT_EXACT_OFFSPRING) { pf->opt_exact = (value == 2) ? 2 : (value ? 1 : 0); return CSSM_OK; }
   if (option == CSSM_OPT_FUSED_SUMS) { pf->opt_fused = value ? 1 : 0; return CSSM_OK; }
   if (option == CSSM_OPT_GROUP_SUMS) { pf->opt_grp = value ? 1 : 0; return CSSM_OK; }
+  if (option == CSSM_OPT_LOOP_EVENTS) { pf->opt_events = value ? 1 : 0; return CSSM_OK; }
   if (option == CSSM_OPT_SPECIALISE) { pf->opt_spec = (value == 2) ? 2 : (value ? 1 : 0); return CSSM_OK; }
   if (option == CSSM_OPT_WHOLE_TILES) {   // launch geometry only: the arrays hold up to four sub-units per unit either way
     if (pf->sharded) return fail(CSSM_ESTATE, "sharded handles always run whole tiles");

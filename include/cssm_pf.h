@@ -253,6 +253,10 @@ int cssm_pf_last_loop_ms(cssm_pf* pf, float* ms_out);
  * 0: always the structure-as-data kernel (bench.py reports its roofline fraction beside the specialised kernel's); 2 (verification):
  * the run-time-compiled kernel also where an ahead-of-time instantiation exists (tests compare the two). */
 #define CSSM_OPT_SPECIALISE 8
+/* CSSM_OPT_LOOP_EVENTS (default 0): the batch drivers record a HIP event before the first and behind the last per-observation kernel of a
+ * call, which cssm_pf_last_loop_ms then reads.  Off by default: the two event packets cost a 20-observation call about 5 us (the one
+ * between the last kernel and the call's closing kernel holds the queue for ~4 us). */
+#define CSSM_OPT_LOOP_EVENTS 9
 int cssm_pf_set_option(cssm_pf* pf, int option, int value);
 /* Counters of the run-time specialisation in this process: out4 = {kernels compiled, kernels loaded from the disk cache, launches of
  * run-time-compiled kernels, failures (each reported once on stderr)}. */

@@ -180,6 +180,9 @@ def test_batch_ll_filter_matches_oracle(name, n, T):
     model = getattr(cases, name)()
     t, y, has = cases.poisson_counts(T, missing=0.1)
     g = NativePf(model, n, cases.SEED)
+    with pytest.raises(Exception):          # (no batch call yet, and the event pair is opt-in: CSSM_OPT_LOOP_EVENTS)
+        g.last_loop_ms()
+    g.set_option(9, 1)
     o = oracle.OraclePf(model.descriptor(), n, cases.SEED)
     gl, gll, gess, gpath = g.run(t, y, has, want_path=True)
     ol, oll, oess, opath = o.filter(t, y, has, want_path=True)

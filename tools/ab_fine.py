@@ -1,6 +1,7 @@
 """A/B in one process: the single-tile propagate kernel + k_reduce_units (default for large clouds) against whole units and the
 software-pipelined kernel (CSSM_OPT_WHOLE_TILES = 2).  usage: ab_fine.py model N [T=40] [optA optB]  (model: c2 | c1 | d<k>; opt = CSSM_OPT_WHOLE_TILES value: 0 default, 1 single-tile,
 2 whole units + software-pipelined kernel, one block per unit)"""
+import os; os.environ.setdefault("CSSM_LOOP_EVENTS", "1")   # (cssm_pf_last_loop_ms needs the event pair: CSSM_OPT_LOOP_EVENTS)
 import sys, os
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, ROOT + "/tests")

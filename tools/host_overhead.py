@@ -1,5 +1,6 @@
 """Host time of one batch run beyond its device time (records built, uploaded, results read back), with and without the
 sampled path, and of one iteration of the native PMMH loop: usage host_overhead.py"""
+import os; os.environ.setdefault("CSSM_LOOP_EVENTS", "1")   # (cssm_pf_last_loop_ms needs the event pair: CSSM_OPT_LOOP_EVENTS)
 import sys, os, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, ROOT + "/tests")
