@@ -165,7 +165,7 @@ def run_single(args, emit=print):
     n = args.particles if args.particles > 0 else (N_16M if lgcp else N_PER_GPU)
     R = args.repeats if args.repeats > 0 else (3 if K >= 200 else 7)
     W = max(W, 1)                      # (the filter has to be running before K more steps can be timed)
-    model, t, y, has = build_workload(W + 4 * R * K + 16, args.model)
+    model, t, y, has = build_workload(W + 5 * R * K + 16, args.model)
     import ctypes as C
 
     def handle():
@@ -207,19 +207,24 @@ def run_single(args, emit=print):
             copy_gbs = copy.value
         pf.run(t[:W], y[:W], has[:W])
         pf.set_option(9, 1)
-        loops = []
+        # R legs nobody reads (the first legs of a process run 5-15 % slower than the ones behind them, and the bracket's cost is
+        # calibrated as a DIFFERENCE of the two passes below: both have to be taken in the same state), then the two passes
         for r in range(R):
             lo = W + r * K
             pf.run_more(t[lo:lo + K], y[lo:lo + K], has[lo:lo + K])
+        loops = []
+        for r in range(R):
+            lo = W + (R + r) * K
+            pf.run_more(t[lo:lo + K], y[lo:lo + K], has[lo:lo + K])
             loops.append(pf.last_loop_ms())
         loop_ms = float(np.median(loops))
-        per, pair_s, prof_raw = _kernel_profile(pf, t, y, has, K, loop_ms, legs=[(W + (R + r) * K, W + (R + r + 1) * K) for r in range(R)])
+        per, pair_s, prof_raw = _kernel_profile(pf, t, y, has, K, loop_ms, legs=[(W + (2 * R + r) * K, W + (2 * R + r + 1) * K) for r in range(R)])
         # the same model and legs with the structure specialisation switched off (CSSM_OPT_SPECIALISE = 0: the kernel that reads the model's
         # structure as data, what every model outside BASELINE's configurations ran until round 4 gave each its own run-time-compiled kernel)
         roof_generic = None
         if not args.no_generic:
             pf.set_option(8, 0)
-            lo = W + 2 * R * K
+            lo = W + 3 * R * K
             pf.run_more(t[lo:lo + 8], y[lo:lo + 8], has[lo:lo + 8])
             lo += 8
             gl = []
