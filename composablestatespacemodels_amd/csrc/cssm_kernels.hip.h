@@ -244,6 +244,159 @@ __device__ __forceinline__ void offspring_exact_counts(cssm_u128 run0, const dou
 #else
 #define CSSM_STAMP(k) do { } while (0)
 #endif
+// The contract's correctly rounded S_tot as a double, formed only where the exact predicate is evaluated: the single-GPU launch totals
+// the waves' sums its prologue left in LDS (s_r[1], not written again); the sharded launches hold the total already
+template <bool SELF> struct TotExact {
+  const cssm_u128* waves; double totd;
+  __device__ __forceinline__ double operator()() const {
+    if (!SELF) return totd;
+    cssm_u128 t = waves[0];
+#pragma unroll
+    for (int w = 1; w < CSSM_BLOCK / 64; ++w) t = cssm_u128_add(t, waves[w]);
+    return cssm_u128_to_double(t);
+  }
+};
+// End slot of a particle = cnt(C_j) of the contract.  Fast path: p = S_j/S_tot*N - u evaluated in fp64; whenever p is
+// farther than eps = N*2^-44 from an integer, floor(p)+1 IS the contract's count.  Otherwise (probability 2*eps per
+// particle) the exact predicate is evaluated on the exact 128-bit prefix.  Error budget of the fast path, in slots:
+//   S_j as a double: the thread's exclusive prefix is converted once (two conversions: < N*2^-52), then every particle adds
+//     its weight IN FLOATING POINT, sd += w1 * 2^96 (<= 4 roundings: < N*2^-51) -- the weight as a double, not its
+//     truncation to the 2^-96 grid: the drift is < 4 * 2^-96 / S_tot, and S_tot >= the largest weight >= exp(-32) > 2^-46.2
+//     (cssm_ref_choose admits a level at most CSSM_REF_ABOVE = 32 above the max; a level from the max itself gives 1):
+//     < N*2^-47.8.  (Round 2 converted the exact 128-bit running sum per particle: 13 instructions against 1.)
+//   quotient N / S_tot, the fma: < N*2^-51; the contract's own roundings move a decision by < N*2^-51.
+// Total < N*2^-47.2, a factor 9 inside eps.  raw == 1 (stateless resampling of arbitrary host weights: no lower bound on
+// S_tot) keeps the exact running sum.
+// The thread's CSSM_ITEMS particles: run = its exclusive prefix (exact, on the 2^-96 grid), w1 its weights; e[r] = the end slot of particle r.
+// totd_exact(): the contract's correctly rounded S_tot, called only where the exact predicate is evaluated.
+template <bool SELF, int RS>
+__device__ __forceinline__ void tile_end_slots(cssm_u128 run, const double (&w1)[CSSM_ITEMS], const int raw,
+                                               const double u, const uint64_t n_global, const bool pow2, const int force_exact, const TotExact<SELF> totd_exact,
+                                               const uint64_t seed, const uint32_t rec_step, const uint64_t base, const uint64_t n,
+                                               double* __restrict__ cum_out, uint32_t (&e)[CSSM_ITEMS],
+                                               const double scale, const double eps, const double one_minus_eps, const double one_minus_u) {
+  constexpr int resampler = RS;
+  auto fixw = [&](double w) { return (raw == 1) ? cssm_fix_from_double(w) : cssm_fix_from_unit(w); };
+  constexpr bool OUTLINED = RS == CSSM_RESAMPLE_SYSTEMATIC && CSSM_ITEMS == 4;   // (every systematic instantiation)
+  uint32_t unsafe = 0u;                                   // OUTLINED: the particles whose count the exact predicate decides
+  const cssm_u128 run0 = run;
+  double sd = cssm_fma((double)run.hi, 0x1.0p64, (double)run.lo);
+#pragma unroll
+  for (int r = 0; r < CSSM_ITEMS; ++r) {
+    if (raw == 1) {
+      run = cssm_u128_add(run, fixw(w1[r]));
+      sd = cssm_fma((double)run.hi, 0x1.0p64, (double)run.lo);
+    } else {
+      sd = cssm_fma(w1[r], 0x1.0p96, sd);
+    }
+    // p + 1 = S_j/S_tot*N + (1 - u) > 0 (1 - u is exact: u is a multiple of 2^-53 in [0, 1)): its integer part is the count,
+    // its fraction (v_fract_f64) the distance test
+    const double pp1 = cssm_fma(sd, scale, one_minus_u);
+    const double fr = cssm_fract_pos(pp1);
+    // (OUTLINED: a forced exact evaluation does not touch this path -- the particles it names join `unsafe` behind the loop)
+    const bool safe = (fr > eps) && (fr < one_minus_eps) && (OUTLINED || !force_exact) && resampler == CSSM_RESAMPLE_SYSTEMATIC;
+    if (safe) {
+      // (the count cannot exceed N -- the min is a guard for the ancestor writes below, not part of the arithmetic)
+      const uint32_t c32 = (uint32_t)pp1;
+      e[r] = (c32 > (uint32_t)n_global) ? (uint32_t)n_global : c32;
+    } else if constexpr (OUTLINED) {
+      e[r] = 0u;
+      unsafe |= 1u << r;
+    } else {
+      if (raw != 1) {                                      // the exact prefix, formed only here
+        run = run0;
+#pragma unroll
+        for (int k = 0; k < CSSM_ITEMS; ++k) if (k <= r) run = cssm_u128_add(run, fixw(w1[k]));
+      }
+      const double C = cssm_u128_to_double(run) / totd_exact();
+      if (resampler == CSSM_RESAMPLE_SYSTEMATIC) {
+        e[r] = (uint32_t)(pow2 ? cssm_sys_count_pow2(C, u, n_global, 1.0 / (double)n_global) : cssm_sys_count(C, u, n_global));
+      } else if (resampler == CSSM_RESAMPLE_STRATIFIED) {   // one uniform per slot, model/Resampling.scala:82-83
+        e[r] = (uint32_t)cssm_strat_count(C, seed, rec_step, n_global);
+      } else {                                              // multinomial: the draws are searched in C afterwards
+        const uint64_t ii = base + (uint64_t)threadIdx.x * CSSM_ITEMS + r;
+        if (ii < n) cum_out[ii] = C;
+        e[r] = 0;
+      }
+    }
+  }
+  if constexpr (OUTLINED) {
+    // CSSM_OPT_EXACT_OFFSPRING (verification): 1 = every particle through the exact predicate, 2 = every third one -- threads
+    // then hold mixed masks, as they do when the fast path hands over a single particle
+    if (force_exact) {   // (uniform)
+      uint32_t fm = 0xfu;
+      if (force_exact == 2) {
+        const uint32_t j0 = (uint32_t)base + threadIdx.x * CSSM_ITEMS;
+        fm = ((j0 % 3u == 0u) ? 1u : 0u) | (((j0 + 1u) % 3u == 0u) ? 2u : 0u) | (((j0 + 2u) % 3u == 0u) ? 4u : 0u) | (((j0 + 3u) % 3u == 0u) ? 8u : 0u);
+      }
+      unsafe |= fm;
+    }
+    if (unsafe) offspring_exact_counts(run0, w1, unsafe, totd_exact(), u, n_global, e, raw == 1);
+  }
+}
+
+// The end slot of ONE cumulative weight `toff` (a wave's exclusive prefix: the end slot of the particle before the wave's first): the fast
+// path of tile_end_slots with its scale / eps, else the exact predicate
+template <bool SELF, int RS>
+__device__ __forceinline__ uint32_t end_slot_of_prefix(const cssm_u128 toff, const double scale, const double eps, const double one_minus_eps,
+                                                       const double one_minus_u, const double u, const uint64_t n_global, const bool pow2,
+                                                       const int force_exact, const TotExact<SELF> totd_exact, const uint64_t seed, const uint32_t rec_step) {
+  constexpr int resampler = RS;
+  constexpr bool OUTLINED = RS == CSSM_RESAMPLE_SYSTEMATIC && CSSM_ITEMS == 4;
+  const double sdp = cssm_fma((double)toff.hi, 0x1.0p64, (double)toff.lo);
+  const double ppp = cssm_fma(sdp, scale, one_minus_u);
+  const double frp = cssm_fract_pos(ppp);
+  if ((frp > eps) && (frp < one_minus_eps) && !force_exact && resampler == CSSM_RESAMPLE_SYSTEMATIC) {
+    const uint32_t c32 = (uint32_t)ppp;
+    return (c32 > (uint32_t)n_global) ? (uint32_t)n_global : c32;
+  } else if constexpr (OUTLINED) {
+    const double z4[4] = {0.0, 0.0, 0.0, 0.0};
+    uint32_t p4[4] = {0u, 0u, 0u, 0u};
+    offspring_exact_counts(toff, z4, 1u, totd_exact(), u, n_global, p4);
+    return p4[0];
+  } else {
+    const double Cp = cssm_u128_to_double(toff) / totd_exact();
+    return (resampler == CSSM_RESAMPLE_STRATIFIED)
+               ? (uint32_t)cssm_strat_count(Cp, seed, rec_step, n_global)
+               : (uint32_t)(pow2 ? cssm_sys_count_pow2(Cp, u, n_global, 1.0 / (double)n_global) : cssm_sys_count(Cp, u, n_global));
+  }
+}
+
+// What the single-GPU launch's publisher block files once the sums are totalled and the level is known (all threads of the block call):
+// the ESS of the PREVIOUS weighted observation if it was still pending (ptot2 = its sum of squared weights), this observation's max /
+// level / totals / ll -- and its ESS where the squares are at hand (s2_par < 0), else the note that it is pending --, the level
+// predicted for the next observation (LGCP), and the clearing of the two slot sets this observation did not use.
+__device__ __forceinline__ void publish_observation(Scalars* __restrict__ sc, const StepRec* __restrict__ rec, const double gmax_dec, const double gmax,
+                                                    const cssm_u128 tot, const cssm_u128 tot2, const bool p_pend, const cssm_u128 ptot2,
+                                                    const int s2_par, const uint32_t nunits, const uint32_t rec_idx, const uint32_t gen,
+                                                    double* __restrict__ ll_t, int32_t* __restrict__ ess_t, const uint64_t n_global, const int slot_set) {
+  if (threadIdx.x == 0) {                              // publish the step's scalars once
+    if (p_pend) {
+      const int32_t pe = cssm_ess_of(sc->pend_S, ptot2);
+      sc->ess = pe;
+      if (ess_t && sc->pend_gen == gen) ess_t[sc->pend_idx] = pe;
+    }
+    sc->gmax = gmax_dec; sc->ref = gmax; sc->S_off = cssm_u128_zero(); sc->S_local = tot; sc->S_tot = tot;
+    publish_next_level(sc, rec, gmax_dec);
+    if (s2_par < 0) {
+      sc->S2_local = tot2; sc->S2_tot = tot2; sc->pend = 0u;
+      finish_step(sc, n_global);
+      if (ll_t) { ll_t[rec_idx] = sc->ll; ess_t[rec_idx] = sc->ess; }
+    } else {
+      sc->pend = 1u; sc->pend_buf = (uint32_t)s2_par; sc->pend_n = nunits; sc->pend_idx = rec_idx; sc->pend_gen = gen;
+      sc->pend_S = tot;
+      (void)finish_ll(sc, n_global);
+      if (ll_t) ll_t[rec_idx] = sc->ll;
+    }
+  }
+  if (threadIdx.x < 2 * 2 * CSSM_GRP_MAX) {   // ... and their group sums (two sets x two limbs x 32 groups)
+    const uint32_t tq2 = threadIdx.x;
+    sc->grp[((size_t)((slot_set + 1 + (int)(tq2 / (2 * CSSM_GRP_MAX))) % CSSM_MAXSETS) * 2 * CSSM_GRP_MAX + tq2 % (2 * CSSM_GRP_MAX)) * CSSM_SLOT_STRIDE] = 0ull;
+  }
+  if (threadIdx.x < 2 * CSSM_MAXSLOTS)   // the two sets this observation did not use
+    sc->maxslot[((size_t)((slot_set + 1 + (int)(threadIdx.x / CSSM_MAXSLOTS)) % CSSM_MAXSETS) * CSSM_MAXSLOTS + threadIdx.x % CSSM_MAXSLOTS) * CSSM_SLOT_STRIDE] = 0ull;
+}
+
 // What a sharded launch that has already read every rank's 5 words hands the body (k_offspring_expand_spec: one thread per rank
 // loads a header, the totals go through LDS -- the body's own loops over all5 are world x 5 loads in EVERY thread, and on the
 // peer-written windows each of those is a system-scope load past the caches)
@@ -440,14 +593,7 @@ __device__ __forceinline__ void offspring_body(const double* __restrict__ logw, 
   uint32_t unit = ublk;
   cssm_u128 toff_self = cssm_u128_zero();
   double scale_self = 0.0;
-  // SELF: the exact S_tot as a double, from the waves' sums the prologue left in LDS (s_r[1] is not written again)
-  auto totd_exact = [&]() -> double {
-    if (!SELF) return totd;
-    cssm_u128 t = s_r[1][0];
-#pragma unroll
-    for (int w = 1; w < CSSM_BLOCK / 64; ++w) t = cssm_u128_add(t, s_r[1][w]);
-    return cssm_u128_to_double(t);
-  };
+  // (the exact S_tot as a double, where the exact predicate needs it: TotExact)
   cssm_u128 acc2 = cssm_u128_zero();                       // SELF, s2_par >= 0: the thread's sum of squared weights
   // the weight on the 2^-96 grid (raw == 1: arbitrary host doubles, range-checked; else exp of a clamped non-positive number).
   // Not kept: the rare exact path below forms it again from w1 (16 registers live across the whole tile otherwise).
@@ -585,32 +731,8 @@ __device__ __forceinline__ void offspring_body(const double* __restrict__ logw, 
       if (!level_known()) return;
       cssm_u128 ptot2 = cssm_u128_zero();
       if (p_pend) ptot2 = block_sum_u128(pt2, s_r[2]);
-      if (threadIdx.x == 0) {                              // publish the step's scalars once
-        if (p_pend) {
-          const int32_t pe = cssm_ess_of(sc->pend_S, ptot2);
-          sc->ess = pe;
-          if (ess_t && sc->pend_gen == gen) ess_t[sc->pend_idx] = pe;
-        }
-        sc->gmax = gmax_dec; sc->ref = gmax; sc->S_off = cssm_u128_zero(); sc->S_local = tot; sc->S_tot = tot;
-        publish_next_level(sc, rec, gmax_dec);
-        if (s2_par < 0) {
-          sc->S2_local = tot2; sc->S2_tot = tot2; sc->pend = 0u;
-          finish_step(sc, n_global);
-          if (ll_t) { ll_t[rec_idx] = sc->ll; ess_t[rec_idx] = sc->ess; }
-        } else {
-          sc->pend = 1u; sc->pend_buf = (uint32_t)s2_par; sc->pend_n = nunits; sc->pend_idx = rec_idx; sc->pend_gen = gen;
-          sc->pend_S = tot;
-          (void)finish_ll(sc, n_global);
-          if (ll_t) ll_t[rec_idx] = sc->ll;
-        }
-      }
+      publish_observation(sc, rec, gmax_dec, gmax, tot, tot2, p_pend != 0u, ptot2, s2_par, nunits, rec_idx, gen, ll_t, ess_t, n_global, slot_set);
       CSSM_STAMP(7);
-      if (threadIdx.x < 2 * 2 * CSSM_GRP_MAX) {   // ... and their group sums (two sets x two limbs x 32 groups)
-        const uint32_t tq2 = threadIdx.x;
-        sc->grp[((size_t)((slot_set + 1 + (int)(tq2 / (2 * CSSM_GRP_MAX))) % CSSM_MAXSETS) * 2 * CSSM_GRP_MAX + tq2 % (2 * CSSM_GRP_MAX)) * CSSM_SLOT_STRIDE] = 0ull;
-      }
-      if (threadIdx.x < 2 * CSSM_MAXSLOTS)   // the two sets this observation did not use
-        sc->maxslot[((size_t)((slot_set + 1 + (int)(threadIdx.x / CSSM_MAXSLOTS)) % CSSM_MAXSETS) * CSSM_MAXSLOTS + threadIdx.x % CSSM_MAXSLOTS) * CSSM_SLOT_STRIDE] = 0ull;
       return;
     }
     // GRP: the first tile's weights on the grid and their wave scan while the sums' wave is at work -- nothing of that depends on
@@ -706,79 +828,15 @@ __device__ __forceinline__ void offspring_body(const double* __restrict__ logw, 
       for (int w = 0; w < wid; ++w) off = cssm_u128_add(off, s_w[w]);
       // exclusive prefix of this thread = off + the inclusive scan of the lane before (lane 0: + 0)
       cssm_u128 run = wave_excl_add_u128(inc, off);
-      // End slot of a particle = cnt(C_j) of the contract.  Fast path: p = S_j/S_tot*N - u evaluated in fp64; whenever p is
-      // farther than eps = N*2^-44 from an integer, floor(p)+1 IS the contract's count.  Otherwise (probability 2*eps per
-      // particle) the exact predicate is evaluated on the exact 128-bit prefix.  Error budget of the fast path, in slots:
-      //   S_j as a double: the thread's exclusive prefix is converted once (two conversions: < N*2^-52), then every particle adds
-      //     its weight IN FLOATING POINT, sd += w1 * 2^96 (<= 4 roundings: < N*2^-51) -- the weight as a double, not its
-      //     truncation to the 2^-96 grid: the drift is < 4 * 2^-96 / S_tot, and S_tot >= the largest weight >= exp(-32) > 2^-46.2
-      //     (cssm_ref_choose admits a level at most CSSM_REF_ABOVE = 32 above the max; a level from the max itself gives 1):
-      //     < N*2^-47.8.  (Round 2 converted the exact 128-bit running sum per particle: 13 instructions against 1.)
-      //   quotient N / S_tot, the fma: < N*2^-51; the contract's own roundings move a decision by < N*2^-51.
-      // Total < N*2^-47.2, a factor 9 inside eps.  raw == 1 (stateless resampling of arbitrary host weights: no lower bound on
-      // S_tot) keeps the exact running sum.
+      // end slots of the thread's particles (fast path in fp64, the exact predicate where the two could differ): tile_end_slots
       const double nd = (double)n_global;
       const double scale = SELF ? scale_self : nd / totd;
       const double eps = SELF ? uniform_f64(nd * 0x1.0p-44) : nd * 0x1.0p-44;
       const double one_minus_eps = SELF ? uniform_f64(1.0 - eps) : 1.0 - eps;
       const double one_minus_u = 1.0 - u;
       uint32_t e[CSSM_ITEMS];
-      constexpr bool OUTLINED = RS == CSSM_RESAMPLE_SYSTEMATIC && CSSM_ITEMS == 4;   // (every systematic instantiation)
-      uint32_t unsafe = 0u;                                   // OUTLINED: the particles whose count the exact predicate decides
-      const cssm_u128 run0 = run;
-      double sd = cssm_fma((double)run.hi, 0x1.0p64, (double)run.lo);
-#pragma unroll
-      for (int r = 0; r < CSSM_ITEMS; ++r) {
-        if (raw == 1) {
-          run = cssm_u128_add(run, fixw(w1[r]));
-          sd = cssm_fma((double)run.hi, 0x1.0p64, (double)run.lo);
-        } else {
-          sd = cssm_fma(w1[r], 0x1.0p96, sd);
-        }
-        // p + 1 = S_j/S_tot*N + (1 - u) > 0 (1 - u is exact: u is a multiple of 2^-53 in [0, 1)): its integer part is the count,
-        // its fraction (v_fract_f64) the distance test
-        const double pp1 = cssm_fma(sd, scale, one_minus_u);
-        const double fr = cssm_fract_pos(pp1);
-        // (OUTLINED: a forced exact evaluation does not touch this path -- the particles it names join `unsafe` behind the loop)
-        const bool safe = (fr > eps) && (fr < one_minus_eps) && (OUTLINED || !force_exact) && resampler == CSSM_RESAMPLE_SYSTEMATIC;
-        if (safe) {
-          // (the count cannot exceed N -- the min is a guard for the ancestor writes below, not part of the arithmetic)
-          const uint32_t c32 = (uint32_t)pp1;
-          e[r] = (c32 > (uint32_t)n_global) ? (uint32_t)n_global : c32;
-        } else if constexpr (OUTLINED) {
-          e[r] = 0u;
-          unsafe |= 1u << r;
-        } else {
-          if (raw != 1) {                                      // the exact prefix, formed only here
-            run = run0;
-#pragma unroll
-            for (int k = 0; k < CSSM_ITEMS; ++k) if (k <= r) run = cssm_u128_add(run, fixw(w1[k]));
-          }
-          const double C = cssm_u128_to_double(run) / totd_exact();
-          if (resampler == CSSM_RESAMPLE_SYSTEMATIC) {
-            e[r] = (uint32_t)(pow2 ? cssm_sys_count_pow2(C, u, n_global, 1.0 / (double)n_global) : cssm_sys_count(C, u, n_global));
-          } else if (resampler == CSSM_RESAMPLE_STRATIFIED) {   // one uniform per slot, model/Resampling.scala:82-83
-            e[r] = (uint32_t)cssm_strat_count(C, seed, rec_step, n_global);
-          } else {                                              // multinomial: the draws are searched in C afterwards
-            const uint64_t ii = base + (uint64_t)threadIdx.x * CSSM_ITEMS + r;
-            if (ii < n) cum_out[ii] = C;
-            e[r] = 0;
-          }
-        }
-      }
-      if constexpr (OUTLINED) {
-        // CSSM_OPT_EXACT_OFFSPRING (verification): 1 = every particle through the exact predicate, 2 = every third one -- threads
-        // then hold mixed masks, as they do when the fast path hands over a single particle
-        if (force_exact) {   // (uniform)
-          uint32_t fm = 0xfu;
-          if (force_exact == 2) {
-            const uint32_t j0 = (uint32_t)base + threadIdx.x * CSSM_ITEMS;
-            fm = ((j0 % 3u == 0u) ? 1u : 0u) | (((j0 + 1u) % 3u == 0u) ? 2u : 0u) | (((j0 + 2u) % 3u == 0u) ? 4u : 0u) | (((j0 + 3u) % 3u == 0u) ? 8u : 0u);
-          }
-          unsafe |= fm;
-        }
-        if (unsafe) offspring_exact_counts(run0, w1, unsafe, totd_exact(), u, n_global, e, raw == 1);
-      }
+      tile_end_slots<SELF, RS>(run, w1, raw, u, n_global, pow2, force_exact, TotExact<SELF>{s_r[1], totd}, seed, rec_step, base, n, cum_out, e,
+                               scale, eps, one_minus_eps, one_minus_u);
       const uint64_t i0 = base + (uint64_t)threadIdx.x * CSSM_ITEMS;
       constexpr bool CLIP = !SELF;
       // the EXACT exchange of the sharded filter needs the end slots themselves (k_send_ranges, k_pack); the single-collective
@@ -799,26 +857,7 @@ __device__ __forceinline__ void offspring_body(const double* __restrict__ logw, 
         uint32_t prev = dpp0<0x138 /* wave_shr:1 */, 0xf>(e[CSSM_ITEMS - 1]);
         if (lane == 0) {
           if (tile == 0 && wid == 0 && (SELF || all5 == nullptr || rank == 0)) prev = 0u;   // the globally first particle
-          else {   // the fast path of the end slots above, else the exact predicate
-            const cssm_u128 toff = off;
-            const double sdp = cssm_fma((double)toff.hi, 0x1.0p64, (double)toff.lo);
-            const double ppp = cssm_fma(sdp, scale, one_minus_u);
-            const double frp = cssm_fract_pos(ppp);
-            if ((frp > eps) && (frp < one_minus_eps) && !force_exact && resampler == CSSM_RESAMPLE_SYSTEMATIC) {
-              const uint32_t c32 = (uint32_t)ppp;
-              prev = (c32 > (uint32_t)n_global) ? (uint32_t)n_global : c32;
-            } else if constexpr (OUTLINED) {
-              const double z4[4] = {0.0, 0.0, 0.0, 0.0};
-              uint32_t p4[4] = {0u, 0u, 0u, 0u};
-              offspring_exact_counts(toff, z4, 1u, totd_exact(), u, n_global, p4);
-              prev = p4[0];
-            } else {
-              const double Cp = cssm_u128_to_double(toff) / totd_exact();
-              prev = (resampler == CSSM_RESAMPLE_STRATIFIED)
-                         ? (uint32_t)cssm_strat_count(Cp, seed, rec_step, n_global)
-                         : (uint32_t)(pow2 ? cssm_sys_count_pow2(Cp, u, n_global, 1.0 / (double)n_global) : cssm_sys_count(Cp, u, n_global));
-            }
-          }
+          else prev = end_slot_of_prefix<SELF, RS>(off, scale, eps, one_minus_eps, one_minus_u, u, n_global, pow2, force_exact, TotExact<SELF>{s_r[1], totd}, seed, rec_step);
         }
         // the slots this WAVE's 256 particles own: [start of its first particle's run, end of its last particle's run), clipped
         // to this launch's slots; their ancestors are assembled in the wave's LDS region and written as whole lines, with no
