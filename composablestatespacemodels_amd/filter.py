@@ -152,6 +152,7 @@ class NativePf:
         return ll.value, ll_t, ess_t
 
     def last_loop_ms(self) -> float:
+        """Device time of the last batch call's per-observation kernels; needs set_option(9, 1) (CSSM_OPT_LOOP_EVENTS) before that call."""
         ms = C.c_float()
         _abi.check(self.lib.cssm_pf_last_loop_ms(self._h, C.byref(ms)))
         return ms.value

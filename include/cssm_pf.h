@@ -199,7 +199,8 @@ int cssm_pf_filter(cssm_pf* pf, const double* t, const double* y, const uint8_t*
                    double* ll_out, double* ll_t, int32_t* ess_t, double* path);
 
 /* Device time of the last cssm_pf_ll_filter / cssm_pf_filter loop (HIP events on the
- * handle's stream around the T steps, init excluded), in milliseconds. */
+ * handle's stream around the T steps, init excluded), in milliseconds.  The events are recorded only
+ * with CSSM_OPT_LOOP_EVENTS = 1 (below; environment CSSM_LOOP_EVENTS=1 sets that default): CSSM_ESTATE otherwise. */
 int cssm_pf_last_loop_ms(cssm_pf* pf, float* ms_out);
 
 /* Debug/verification options.  CSSM_OPT_EXACT_OFFSPRING = 1 makes the offspring kernel evaluate the
