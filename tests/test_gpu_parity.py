@@ -1048,3 +1048,30 @@ def test_ll_filter_more_needs_a_running_filter():
     with pytest.raises(Exception):
         g.run_more(np.array([1.0]), np.array([1.0]))
     g.close()
+
+
+@pytest.mark.gpu
+def test_records_sent_by_kernel_or_by_copy_give_the_same_series():
+    """The observation records reach the device through k_fetch_recs (a kernel reading the pinned host buffer, the first record of a
+    continued call ahead of the rest) or, with CSSM_UPLOAD_MEMCPY=1, through hipMemcpyAsync as in rounds 1-3: the same bits either way
+    (a child process per setting: the library reads the variable once)."""
+    import json, os, subprocess, sys
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (
+        "import sys, json, hashlib; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+        "import numpy as np, cases\n"
+        "from composablestatespacemodels_amd.filter import NativePf\n"
+        "t, y, has = cases.poisson_counts(40, missing=0.1)\n"
+        "g = NativePf(cases.c2_model(), 6000, cases.SEED)\n"
+        "a = g.run(t[:7], y[:7], has[:7]); b = g.run_more(t[7:30], y[7:30], has[7:30]); c = g.run_more(t[30:], y[30:], has[30:])\n"
+        "s = g.step(41.0, 2.0, True)\n"
+        "h = hashlib.sha256(); [h.update(np.ascontiguousarray(x).tobytes()) for x in (b[1], b[2], c[1], c[2], g.ancestors(), g.particles())]\n"
+        "print(json.dumps({'ll': [a[0], b[0], c[0], s[0]], 'digest': h.hexdigest()}))\n"
+    ) % (ROOT, os.path.join(ROOT, "tests"))
+    outs = []
+    for extra in ({}, {"CSSM_UPLOAD_MEMCPY": "1"}):
+        env = dict(os.environ); env.pop("CSSM_UPLOAD_MEMCPY", None); env.update(extra)
+        r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append(json.loads(r.stdout.strip().splitlines()[-1]))
+    assert outs[0] == outs[1]
