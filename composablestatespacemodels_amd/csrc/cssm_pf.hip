@@ -263,10 +263,24 @@ __global__ __launch_bounds__(128) void k_fetch_recs(const StepRec* __restrict__ 
   unsigned long long* d = reinterpret_cast<unsigned long long*>(dev + blockIdx.x);
   for (uint32_t i = threadIdx.x; i < sizeof(StepRec) / 8; i += 128) d[i] = s[i];
 }
+// ONE record (a streaming step; the first observation of a continued batch call): it travels in the kernel's ARGUMENTS -- no read
+// across PCIe at all (the argument segment lives in device memory), the block copies its own kernarg bytes to the record's slot
+__global__ __launch_bounds__(128) void k_put_rec(StepRec r, StepRec* __restrict__ dev) {
+  static_assert(offsetof(StepRec, step) < sizeof(StepRec), "");
+  const unsigned long long* s = (const unsigned long long*)__builtin_amdgcn_kernarg_segment_ptr();   // (r is the first argument: offset 0)
+  unsigned long long* d = reinterpret_cast<unsigned long long*>(dev);
+  if (threadIdx.x < sizeof(StepRec) / 8) d[threadIdx.x] = s[threadIdx.x];
+  (void)r;
+}
 int cssm_upload_recs(cssm_pf* pf, size_t first, size_t count, bool chain) {
   static const bool by_copy = getenv("CSSM_UPLOAD_MEMCPY") != nullptr;
+  static const bool no_kernarg = getenv("CSSM_UPLOAD_NO_KERNARG") != nullptr;
   if (count == 0) return CSSM_OK;
-  if (by_copy || !pf->h_recs_dev || count > 0x7fffffffu) {
+  if (count == 1 && !by_copy && !no_kernarg) {
+    static_assert(sizeof(StepRec) / 8 <= 128 && sizeof(StepRec) <= 3072, "one record fits a kernel's argument segment and one block copies it");
+    hipLaunchKernelGGL(k_put_rec, dim3(1), dim3(128), 0, pf->stream, pf->h_recs[first], pf->d_recs + first);
+    HIP_TRY(hipGetLastError());
+  } else if (by_copy || !pf->h_recs_dev || count > 0x7fffffffu) {
     HIP_TRY(hipMemcpyAsync(pf->d_recs + first, pf->h_recs + first, count * sizeof(StepRec), hipMemcpyHostToDevice, pf->stream));
   } else {
     hipLaunchKernelGGL(k_fetch_recs, dim3((uint32_t)count), dim3(128), 0, pf->stream, (const StepRec*)(pf->h_recs_dev + first), pf->d_recs + first);
