@@ -593,7 +593,7 @@ extern "C" int cssm_pf_step(cssm_pf* pf, double t, double obs, int has_obs, doub
   rc = launch_step(pf, pf->d_recs, weighted, pf->step);
   if (rc) return rc;
   Scalars& h = *pf->h_sc;
-  rc = read_scalars(pf);
+  rc = read_scalars(pf, 0, false, false, /*poll=*/true);   // (the completion word, not the stream: 40.4 -> 38.0 us per streaming step at N = 2^20)
   if (rc) return rc;
   if ((h.err & 64u) && !(h.err & 3u)) {   // the max ruled the reference level out: this observation again, relative to the max
     const uint32_t cleared = h.err & ~64u, none = 0xffffffffu;
