@@ -218,7 +218,7 @@ __device__ __forceinline__ void propagate_range(
   static_assert(!ONE || (IT <= 2 && !LGCP), "ONE: one pair (d <= 8) or one particle (d >= 9) per thread, ordinary step");
   double zz[ONE ? IT * D : 1];                                    // ONE: the thread's IT * D normals (normal q -> particle q / D, component q % D)
   if (base < n) {
-    if (ONE && pre_jp != nullptr) jp[0] = *pre_jp; else load_idx(base, jp);
+    if (NJ == 1 && pre_jp != nullptr) jp[0] = *pre_jp; else load_idx(base, jp);   // (requested by the caller with its other first loads)
     if (ONE && IT == 2 && pre_jp == nullptr) {                    // (while the indices travel)
       normals_pair_half<D, 0>(seed, gid0 + base + threadIdx.x * IT, step, tab, zz);
       // the indices are consumed BEHIND these normals: an empty asm that takes both pins the order (the compiler otherwise
@@ -460,15 +460,28 @@ __global__ __launch_bounds__(CSSM_BLOCK, (PropWaves<D, SUMS>::value)) void k_pro
   // until the host resumes it (cssm_pf_shard_resume)
   // bit 3: a sharded series is on hold (capacity miss); bit 6: a single-GPU batch series waits for the redo of an outlying
   // observation; bit 2: a series enqueued ahead is void (its level was ruled out: the host repeats it) -- nothing to do
-  if (sc->err & (4u | 8u | 16u | 64u)) return;
+  // ONE round of first loads: the hold word, the contract table's three entries of this thread and the first tile's ancestor indices are
+  // requested together (they were three dependent round trips -- ~2.5 us per block, which a launch whose blocks all run in one round,
+  // an LGCP shard of 2^21 particles, pays in full)
+  const uint32_t held = sc->err;
   const uint32_t range_lo = blockIdx.x * (uint32_t)chunk;
   uint32_t n;                                                 // this block's range ends at n
   { const uint64_t range_hi = (uint64_t)range_lo + chunk; n = (uint32_t)((range_hi < n_arg) ? range_hi : n_arg); }
-  const double* tab = stage_log_table(logtab);
+  constexpr bool EARLY_IDX = (IT == 2);                        // (one packed index register: propagate_range's pre_jp)
+  unsigned long long jp_early = 0ull;
+  if (EARLY_IDX && range_lo < n) {
+    const uint32_t i0 = range_lo + threadIdx.x * IT;           // (anc holds a whole number of tiles: a partial thread's pair stays inside it)
+    jp_early = anc ? *reinterpret_cast<const unsigned long long*>(anc + i0) : ((unsigned long long)i0 | ((unsigned long long)(i0 + 1u) << 32));
+  }
+  static_assert(CSSM_BLOCK == 256, "three table entries per thread");
+  const double tv = logtab[threadIdx.x], tv1 = logtab[256 + threadIdx.x], tv2 = logtab[512 + threadIdx.x];
+  const double* tab = stage_log_table_finish(tv, tv1, tv2);
+  if (held & (4u | 8u | 16u | 64u)) return;
   __shared__ __attribute__((aligned(16))) unsigned char s_stage[PropStage<D, IT>::bytes];
   PropAcc acc;
   propagate_range<D, LGCP, IT, OBS, SUMS>(src, src_stride, anc, dst, dst_stride, logw, gid0, seed, rec, mk, src2, src2_stride,
-                                          n_split, tab, range_lo, n, do_sums_arg, pick_out, pick_slot, s_stage, acc, LGCP ? fsub : nullptr);
+                                          n_split, tab, range_lo, n, do_sums_arg, pick_out, pick_slot, s_stage, acc, LGCP ? fsub : nullptr,
+                                          (EARLY_IDX && range_lo < n) ? &jp_early : nullptr);
   const bool weighted = LGCP || rec->has_obs;
   const bool do_sums = SUMS && do_sums_arg && weighted;
   cssm_u128 accS = acc.S, accS2 = acc.S2;
