@@ -165,7 +165,7 @@ def run_single(args, emit=print):
     n = args.particles if args.particles > 0 else (N_16M if lgcp else N_PER_GPU)
     R = args.repeats if args.repeats > 0 else (3 if K >= 200 else 7)
     W = max(W, 1)                      # (the filter has to be running before K more steps can be timed)
-    model, t, y, has = build_workload(W + 5 * R * K + 16, args.model)
+    model, t, y, has = build_workload(W + 7 * R * K + 16, args.model)
     import ctypes as C
 
     def handle():
@@ -209,22 +209,23 @@ def run_single(args, emit=print):
         pf.set_option(9, 1)
         # R legs nobody reads (the first legs of a process run 5-15 % slower than the ones behind them, and the bracket's cost is
         # calibrated as a DIFFERENCE of the two passes below: both have to be taken in the same state), then the two passes
-        for r in range(R):
+        S = 3 * R if K < 200 else R      # (short legs: the per-leg times of a fresh process level off after ~15-20 legs)
+        for r in range(S):
             lo = W + r * K
             pf.run_more(t[lo:lo + K], y[lo:lo + K], has[lo:lo + K])
         loops = []
         for r in range(R):
-            lo = W + (R + r) * K
+            lo = W + (S + r) * K
             pf.run_more(t[lo:lo + K], y[lo:lo + K], has[lo:lo + K])
             loops.append(pf.last_loop_ms())
         loop_ms = float(np.median(loops))
-        per, pair_s, prof_raw = _kernel_profile(pf, t, y, has, K, loop_ms, legs=[(W + (2 * R + r) * K, W + (2 * R + r + 1) * K) for r in range(R)])
+        per, pair_s, prof_raw = _kernel_profile(pf, t, y, has, K, loop_ms, legs=[(W + (S + R + r) * K, W + (S + R + r + 1) * K) for r in range(R)])
         # the same model and legs with the structure specialisation switched off (CSSM_OPT_SPECIALISE = 0: the kernel that reads the model's
         # structure as data, what every model outside BASELINE's configurations ran until round 4 gave each its own run-time-compiled kernel)
         roof_generic = None
         if not args.no_generic:
             pf.set_option(8, 0)
-            lo = W + 3 * R * K
+            lo = W + (S + 2 * R) * K
             pf.run_more(t[lo:lo + 8], y[lo:lo + 8], has[lo:lo + 8])
             lo += 8
             gl = []
