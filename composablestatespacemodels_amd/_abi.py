@@ -133,6 +133,7 @@ SYMBOLS = [
     ("cssm_pf_shard_boundary_pack", C.c_int, [_h, C.c_int, C.c_int, C.c_int64, C.c_void_p]),
     ("cssm_pf_shard_adopt_spec", C.c_int, [_h, C.c_void_p, C.c_int, C.c_int, C.c_int64]),
     ("cssm_pf_shard_resume", C.c_int, [_h, C.POINTER(C.c_uint32)]),
+    ("cssm_pf_shard_resume_level", C.c_int, [_h, C.POINTER(C.c_uint32)]),
     ("cssm_pf_shard_peer_setup", C.c_int, [_h, C.c_int, C.c_int, C.c_int64, C.POINTER(PeerHandle)]),
     ("cssm_pf_shard_peer_connect", C.c_int, [_h, C.POINTER(PeerHandle), C.c_int]),
     ("cssm_pf_shard_peer_handshake", C.c_int, [_h, C.c_uint32]),

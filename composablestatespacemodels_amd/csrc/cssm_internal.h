@@ -110,6 +110,7 @@ struct cssm_pf : HostModel {
                                //   observation count so far after _continue
   struct Snap { int cur; const double* src; size_t src_stride; const double* src2; size_t src2_stride; uint32_t n_split; bool anc_valid, last_optimistic; uint32_t step; double t; bool have_level; };
   std::vector<Snap> snaps;     // host-side state right after the propagate of every observation of the series (cssm_pf_shard_resume)
+  std::vector<Snap> pre_snaps; // ... and right BEFORE it (cssm_pf_shard_resume_level: the observation is propagated again)
   // host staging (pinned)
   StepRec* h_recs = nullptr;
   StepRec* h_recs_dev = nullptr;   // the device's address of h_recs (k_fetch_recs)

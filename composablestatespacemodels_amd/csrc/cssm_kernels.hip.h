@@ -522,7 +522,7 @@ __device__ __forceinline__ void offspring_body(const double* __restrict__ logw, 
         if (bidx == 0 && threadIdx.x == 0) { sc->gmax = gmax_dec; atomicMin(&sc->fail_step, rec_step); atomicOr(&sc->err, 64u); }
       } else if (bidx == 0 && threadIdx.x == 0) {
         if (flag_out) *flag_out = 1ull;
-        if (optimistic == 2) atomicOr(&sc->err, 4u);   // (merged with the expansion: no later kernel reads the flag)
+        if (optimistic == 2) { atomicMin(&sc->fail_step, rec_step); atomicOr(&sc->err, 4u); }   // (merged with the expansion: no later kernel reads the flag; the series holds HERE: cssm_pf_shard_resume_level)
       }
       return false;
     }

@@ -374,6 +374,8 @@ extern "C" int cssm_pf_shard_propagate_at(cssm_pf* pf, size_t s, uint64_t* sums5
   if (rc) return rc;
   if (!pf->series || !pf->initialised) return fail(CSSM_ESTATE, "shard_propagate_at before shard_begin");
   if (s >= pf->h_recs_cap || s + pf->rec_base != pf->step) return fail(CSSM_ESTATE, "steps of a series run in order (expected %u)", pf->step - pf->rec_base);
+  if (pf->pre_snaps.size() <= s) pf->pre_snaps.resize(s + 1);
+  pf->pre_snaps[s] = {pf->cur, pf->src, pf->src_stride, pf->src2, pf->src2_stride, pf->n_split, pf->anc_valid, pf->last_optimistic, pf->step, pf->t, pf->have_level};
   rc = shard_prepare_step(pf, pf->d_recs + s, pf->h_recs[s].has_obs, sums5_dev);
   if (rc) return rc;
   pf->step++;
@@ -412,6 +414,38 @@ extern "C" int cssm_pf_shard_resume(cssm_pf* pf, uint32_t* fail_step_out) {
   pf->n_split = q.n_split; pf->anc_valid = q.anc_valid; pf->last_optimistic = q.last_optimistic; pf->step = q.step; pf->t = q.t;
   pf->have_level = q.have_level;
   pf->sums_ready = true;   // (the exchange that missed ran behind them)
+  *fail_step_out = s;
+  return CSSM_OK;
+}
+
+// An observation whose reference level its max rules out (sticky bit 4) is not the end of the series either: the launch that found
+// out resampled nothing on any rank (the verdict is a function of the segment headers), recorded the observation and every later
+// kernel returned at once.  This call rewinds the host-side state to "observation fail_step NOT yet propagated": its source cloud, the
+// ancestors and received rows of the observation before are untouched (the held propagate wrote the OTHER state buffer; the failed
+// exchange the other receive window).  The host propagates it again storing log-weights, takes its level from the all-gathered max
+// (cssm_pf_shard_propagate_at with sums5_dev, cssm_pf_shard_sums) and continues the series behind it on the ordinary plan.
+extern "C" int cssm_pf_shard_resume_level(cssm_pf* pf, uint32_t* fail_step_out) {
+  int rc = shard_check(pf);
+  if (rc) return rc;
+  if (!fail_step_out) return fail(CSSM_EINVAL_ARG, "null argument");
+  rc = bounded_sync(pf);
+  if (rc) return rc;
+  Scalars h;
+  HIP_TRY(hipMemcpyAsync(CSSM_SC_TAIL_ARGS(&h, pf->sc), hipMemcpyDeviceToHost, pf->stream));
+  HIP_TRY(hipStreamSynchronize(pf->stream));
+  if (!(h.err & 4u) || h.fail_step == 0xffffffffu || h.fail_step < pf->rec_base || h.fail_step - pf->rec_base >= pf->pre_snaps.size())
+    return fail(CSSM_ESTATE, "no observation with a ruled-out reference level is recorded");
+  if (h.err & ~4u) return fail(CSSM_ESTATE, "the series has other errors (bits %u)", h.err);
+  const uint32_t s = h.fail_step - pf->rec_base;
+  h.err &= ~4u; h.fail_step = 0xffffffffu;
+  HIP_TRY(hipMemcpyAsync(&pf->sc->err, &h.err, sizeof(uint32_t), hipMemcpyHostToDevice, pf->stream));
+  HIP_TRY(hipMemcpyAsync(&pf->sc->fail_step, &h.fail_step, sizeof(uint32_t), hipMemcpyHostToDevice, pf->stream));
+  HIP_TRY(hipStreamSynchronize(pf->stream));
+  const cssm_pf::Snap& q = pf->pre_snaps[s];
+  pf->cur = q.cur; pf->src = q.src; pf->src_stride = q.src_stride; pf->src2 = q.src2; pf->src2_stride = q.src2_stride;
+  pf->n_split = q.n_split; pf->anc_valid = q.anc_valid; pf->last_optimistic = q.last_optimistic; pf->step = q.step; pf->t = q.t;
+  pf->have_level = q.have_level;
+  pf->sums_ready = false;
   *fail_step_out = s;
   return CSSM_OK;
 }

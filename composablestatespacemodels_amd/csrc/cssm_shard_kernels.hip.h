@@ -629,7 +629,7 @@ __device__ __forceinline__ void offspring_expand_spec_body(
     // nothing about coverage either.  Sticky bit 2 (4): every later kernel of the series returns at once, the host runs
     // the series again with the levels taken from the global max.
     if (!(cssm_ref_choose(rec_ref, cssm_order_unkey(H.gkey)) == rec_ref)) {
-      if (bidx == 0 && threadIdx.x == 0) atomicOr(&sc->err, 4u);
+      if (bidx == 0 && threadIdx.x == 0) { atomicMin(&sc->fail_step, rec->step); atomicOr(&sc->err, 4u); }   // (the series holds HERE: cssm_pf_shard_resume_level)
       return;
     }
   }

@@ -211,6 +211,13 @@ class GpuShard:
         _abi.check(self.lib.cssm_pf_shard_resume(self._h, C.byref(k)))
         return int(k.value)
 
+    def resume_level(self) -> int:
+        """After an observation whose reference level its max ruled out (sticky bit 4): that observation, NOT yet propagated -- the
+        bit is cleared and the handle rewound; the host runs it again with its level from the all-gathered max."""
+        k = C.c_uint32()
+        _abi.check(self.lib.cssm_pf_shard_resume_level(self._h, C.byref(k)))
+        return int(k.value)
+
     def status(self, T: int):
         """(ll, ess, sticky bits, capacity needed per step) of the series just run."""
         ll, ess, bits = C.c_double(), C.c_int32(), C.c_uint32()
@@ -594,9 +601,9 @@ class ShardedFilter:
 
     def ll_filter_more(self, t, y, has=None, lgcp: bool = False):
         """T MORE observations of the filter ``ll_filter`` (or an earlier ``ll_filter_more``) left running: the sharded
-        cssm_pf_ll_filter_more.  Capacity misses are resumed in place as ever; an observation whose reference level the max
-        rules out cannot be handled by repeating the series (its start is gone): RuntimeError -- run such data through
-        ``ll_filter`` or as an LGCP-style series (``lgcp=True``: every level from the global max)."""
+        cssm_pf_ll_filter_more.  Capacity misses are resumed in place as ever, and so is an observation whose reference level the
+        max rules out (that one observation is run again from the global max: cssm_pf_shard_resume_level); shards without that
+        call (the CPU rehearsal's) cannot repeat a continued series from its start: RuntimeError."""
         return self.ll_filter(t, y, has, lgcp=lgcp, cont=True)
 
     def ll_filter(self, t, y, has=None, lgcp: bool = False, exact: bool = False, cont: bool = False):
@@ -640,6 +647,11 @@ class ShardedFilter:
                 native = comm.native_comm()
             mode = 2 if (self.SINGLE_MODE == 1 and os.environ.get("CSSM_SHARD_TRIM", "0") == "1") else self.SINGLE_MODE
             k, resumes, redo_exchange, redo_cap, escalated, give_up = 0, 0, False, 0, {}, False
+            redo_level, level_redos = False, 0
+            # (in place only on the peer-written exchange: its packs are gated ON THE DEVICE while the series holds, and the failed exchange
+            #  wrote the OTHER receive window -- the rows the observation is propagated from again are intact.  A collective has moved
+            #  its segments into the one receive buffer before any rank knows the verdict: there the series is repeated from the max)
+            can_redo_level = (plan == "ref") and bool(peer) and all(hasattr(s, "resume_level") for s in S)
             final_status = []
 
             def look_for_a_miss():
@@ -647,11 +659,26 @@ class ShardedFilter:
                 same verdict from the segment headers, so bit 8 needs no agreement) and every kernel behind it returned at
                 once.  Its exchange is redone with four times the capacity (again four times if it missed before); the
                 series behind it keeps the ordinary capacity."""
-                nonlocal k, resumes, redo_exchange, redo_cap, give_up
-                if all_exact or cap >= n_max or resumes >= 64:
+                nonlocal k, resumes, redo_exchange, redo_cap, give_up, redo_level, level_redos
+                if all_exact or resumes >= 64:
                     return False
                 seen = [s.status(T) for s in S]
-                if max(r[2] for r in seen) != 8:
+                bits_seen = max(r[2] for r in seen)
+                if bits_seen == 4 and can_redo_level and level_redos < 64:
+                    # An observation whose reference level its max ruled out holds the series in place just as a capacity miss does
+                    # (bit 4 is a function of the segment headers too: every rank reads it).  That ONE observation is run again from
+                    # the global max -- propagated again, its log-weights stored, an all-gather of the maxima ahead of its exchange --
+                    # and the series goes on behind it on the ordinary plan: no second pass over the series, and the only way for a
+                    # CONTINUED series, whose start is gone.
+                    ks = [s.resume_level() for s in S]
+                    kf = comm.agree_max([max(ks)] * len(S))
+                    if any(v != kf for v in ks):
+                        raise RuntimeError("ranks disagree on the observation whose level was ruled out")
+                    k = kf
+                    level_redos += 1
+                    redo_level = True
+                    return True
+                if bits_seen != 8 or cap >= n_max:
                     if k >= T:
                         final_status.extend(seen)   # (the series is complete: this look at it is the one the results are read from)
                     return False
@@ -670,7 +697,7 @@ class ShardedFilter:
                 return True
 
             while k < T and not give_up:
-                if peer and len(S) == 1 and hasattr(comm, "dist") and not redo_exchange and not (first_from_max and k == 0):
+                if peer and len(S) == 1 and hasattr(comm, "dist") and not redo_exchange and not redo_level and not (first_from_max and k == 0):
                     # one shard per process: the library enqueues propagate, pack and offspring + expansion of a whole stretch
                     kend = min(k + self.NATIVE_STRETCH, T)
                     S[0].series_peer(k, kend, weighted, cap)
@@ -682,8 +709,9 @@ class ShardedFilter:
                     # the library enqueues kernels and RCCL collectives itself, one stream, no host-language call per
                     # observation -- in stretches, so that a capacity miss is noticed (one status read per stretch) before
                     # the whole tail has been enqueued in vain
-                    fm = from_max or (first_from_max and k == 0)
-                    kend = 1 if (first_from_max and k == 0) else min(k + self.NATIVE_STRETCH, T)
+                    fm = from_max or (first_from_max and k == 0) or redo_level
+                    kend = k + 1 if (fm and not from_max) else min(k + self.NATIVE_STRETCH, T)
+                    redo_level = False
                     nb = comm.world * S[0].spec_segment(cap)
                     S[0].series_native(native, k, kend, weighted, cap, S[0].buffer("send_spec", nb)[:nb],
                                        S[0].buffer("recv_spec", nb)[:nb], single_collective=mode + (4 if fm else 0))
@@ -692,7 +720,7 @@ class ShardedFilter:
                     k = kend
                     look_for_a_miss()
                     continue
-                fm = from_max or (first_from_max and k == 0)
+                fm = from_max or (first_from_max and k == 0) or redo_level
                 if not redo_exchange:               # (after a resume the observation is already propagated)
                     for s in S:
                         s.propagate_at(k) if (all_exact or fm) else s.propagate_at(k, with_sums=False)
@@ -707,16 +735,20 @@ class ShardedFilter:
                         self._resample_peer(cap)
                     else:
                         self._resample_spec(redo_cap if redo_exchange else cap)   # (a resumed observation: its enlarged capacity)
-                redo_exchange, redo_cap = False, 0
+                redo_exchange, redo_cap, redo_level = False, 0, False
                 k += 1
                 if native is None and k == T:
                     look_for_a_miss()                # host-driven series: one look at its end
             self.last_resumes = resumes
+            self.last_level_redos = level_redos
             self.last_single = not all_exact
             self.last_from_max = from_max
             self.last_native = native is not None
             self.last_peer = bool(peer)
             if give_up:
+                if cont:
+                    raise RuntimeError("a continued sharded series met an observation no boundary capacity covers (slots owned by particles of "
+                                       "non-adjacent ranks): it needs the exact exchange from its start, which a continued series no longer has")
                 plans = ["exact"]
                 continue
             res = final_status if len(final_status) == len(S) else [s.status(T) for s in S]

@@ -464,6 +464,12 @@ int cssm_pf_shard_adopt_spec(cssm_pf* pf, const double* recv_buf_dev, int rank, 
  * "that observation propagated, not yet resampled"; the host redoes its exchange with a larger capacity (boundary_pack,
  * all-to-all, adopt_spec) and continues the series behind it. */
 int cssm_pf_shard_resume(cssm_pf* pf, uint32_t* fail_step_out);
+/* ... and so is an observation whose reference level its max rules out (sticky bit 4: an outlying datum; the launch that found out
+ * resampled nothing, recorded the observation, every later kernel returned at once).  cssm_pf_shard_resume_level returns its index,
+ * clears the bit and rewinds the handle to "that observation NOT yet propagated" (its source cloud is untouched); the host runs it
+ * again with the level taken from the all-gathered max (cssm_pf_shard_propagate_at with sums5_dev, cssm_pf_shard_sums, then the
+ * exchange) and continues behind it -- also inside a continued series, which cannot be repeated from its start. */
+int cssm_pf_shard_resume_level(cssm_pf* pf, uint32_t* fail_step_out);
 
 /* The single-collective series with its collectives driven from INSIDE the library (RCCL over xGMI, resolved at run time
  * with dlopen: the copy already in the process, else librccl.so of the ROCm installation).  Per weighted observation s in

@@ -67,11 +67,11 @@ def test_peer_exchange_lgcp(world, n, name):
 
 
 @pytest.mark.parametrize("world", [2, 3, 4])
-def test_peer_exchange_resumes_capacity_misses_and_falls_back_on_an_outlier(world):
+def test_peer_exchange_resumes_capacity_misses_and_redoes_an_outlier_in_place(world):
     """One row per pair: the exchanges miss and are resumed -- each redone through the collective exchange with a larger capacity
     while the kernels enqueued behind it (their packs and polls included) returned at once -- and the series goes on peer-written:
-    the exchange counter has moved on by the skipped exchanges, on every rank alike.  An outlying observation voids the plan
-    and the series is repeated with every level from the global max (collective exchange)."""
+    the exchange counter has moved on by the skipped exchanges, on every rank alike.  An outlying observation holds the series
+    the same way: that observation alone is run again with its level from the global max (collective exchange)."""
     model = cases.c2_model()
     n = 3000 * world
     t, y, has = cases.poisson_counts(12, missing=0.1)
@@ -85,7 +85,9 @@ def test_peer_exchange_resumes_capacity_misses_and_falls_back_on_an_outlier(worl
     y2 = y.copy(); y2[5] = 60.0; has2 = has.copy(); has2[5] = 1
     f.MIN_CAP, f.CAP_SQRT = 1024, 6.0
     ll, ess = f.ll_filter(t, y2, has2)
-    assert f.last_attempts >= 2 and not f.last_peer      # ("max", or on to "exact" where the outlier leaves whole ranks without weight)
+    # (the outlying observation is run again from the global max, in place: cssm_pf_shard_resume_level -- or the plan moves on to
+    #  "exact" where the outlier leaves whole ranks without weight)
+    assert f.last_level_redos >= 1 or f.last_attempts >= 2
     oll, oess, opart = _oracle_run(model, n, t, y2, has2)
     assert (ll, ess) == (oll, oess[-1])
     np.testing.assert_array_equal(np.concatenate([s.particles() for s in shards], axis=1), opart)
@@ -202,3 +204,42 @@ def test_peer_exchange_between_processes_sharing_the_gpu(tmp_path, world):
         assert float(z["ll2"]) == ll2 and int(z["ess2"]) == ess2
         parts.append(z["part"])
     np.testing.assert_array_equal(np.concatenate(parts, axis=1), o.particles())
+
+
+@pytest.mark.parametrize("peer", [True, False])
+@pytest.mark.parametrize("world,n", [(2, 6000), (2, 50000)])
+def test_an_outlying_observation_is_redone_in_place_also_in_a_continued_series(world, n, peer):
+    """An observation whose reference level its max rules out (sticky bit 4) holds the sharded series at that observation, on every
+    rank; cssm_pf_shard_resume_level rewinds to before its propagate and that ONE observation runs again with its level from the
+    all-gathered max -- in a series run in one call (no second pass under the "max" plan) and in a CONTINUED one, whose start is
+    gone.  On the peer-written exchange only (see ShardedFilter.ll_filter); the bits of the single-rank oracle either way.  (Two
+    ranks: a datum outlying enough to rule its level out leaves one particle with all the weight, and with three or more ranks its
+    offspring reach non-adjacent ranks -- the exact exchange, tests above.)"""
+    from composablestatespacemodels_amd.sharded import GpuShard, ShardedFilter
+    from local_comm import LocalComm, LocalCommPeer
+    model = cases.c2_model()
+    t, y, has = cases.poisson_counts(14, missing=0.1)
+    y = y.copy(); has = has.copy()
+    y[9] = 40.0; has[9] = 1                      # outlying: the level (the Poisson mode's log-density) is ruled out by the max
+    shards = [GpuShard(model, n, r, world, cases.SEED, 0) for r in range(world)]
+    f = ShardedFilter(shards, (LocalCommPeer if peer else LocalComm)(world))
+    oll, oess, opart = _oracle_run(model, n, t, y, has)
+    ll, ess = f.ll_filter(t, y, has)
+    assert (ll, ess) == (oll, oess[-1])
+    np.testing.assert_array_equal(np.concatenate([s.particles() for s in shards], axis=1), opart)
+    if peer:
+        assert f.last_level_redos == 1 and f.last_attempts == 1 and f.last_peer
+    else:
+        # (a collective has overwritten the one receive buffer -- the rows the observation would be propagated from again -- before any
+        #  rank knows the verdict: the series is repeated with every level from the max, as ever)
+        assert f.last_level_redos == 0 and f.last_attempts == 2 and f.last_from_max
+    f.ll_filter(t[:6], y[:6], has[:6])
+    if peer:
+        ll, ess = f.ll_filter_more(t[6:], y[6:], has[6:])
+        assert (ll, ess) == (oll, oess[-1]) and f.last_level_redos == 1
+        np.testing.assert_array_equal(np.concatenate([s.particles() for s in shards], axis=1), opart)
+    else:
+        with pytest.raises(RuntimeError):
+            f.ll_filter_more(t[6:], y[6:], has[6:])
+    for s in shards:
+        s.close()
