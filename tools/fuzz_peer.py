@@ -1,6 +1,6 @@
 """Ad-hoc fuzz of the sharded filter on the peer-written exchange (shards of one process: tests/local_comm.py, LocalCommPeer) against
 the single-rank CPU oracle: random world sizes, cloud sizes, models, resamplers, series with missing observations and an outlier, a
-continued part.  usage (GPU box): python tools/fuzz_peer.py [cases] [seed]"""
+continued part.  usage (GPU box): [FUZZ_COMM=peer|collective|trimmed] python tools/fuzz_peer.py [cases] [seed]"""
 import os, sys
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, R); sys.path.insert(0, os.path.join(R, "tests"))
@@ -8,7 +8,7 @@ import numpy as np
 import cases
 from oracle import oracle
 from composablestatespacemodels_amd.sharded import GpuShard, ShardedFilter
-from local_comm import LocalCommPeer
+from local_comm import LocalComm, LocalCommPeer, LocalCommTrimmed
 
 ncases = int(sys.argv[1]) if len(sys.argv) > 1 else 16
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
@@ -33,7 +33,8 @@ for c in range(ncases):
     shards = [GpuShard(model, n, r, world, cases.SEED, 0, lgcp_precision=prec) for r in range(world)]
     if strat:
         for s_ in shards: s_.set_option(2, 1)
-    f = ShardedFilter(shards, LocalCommPeer(world))
+    Comm = {"peer": LocalCommPeer, "collective": LocalComm, "trimmed": LocalCommTrimmed}[os.environ.get("FUZZ_COMM", "peer")]
+    f = ShardedFilter(shards, Comm(world))
     f.ll_filter(t[:a], y[:a], has[:a], lgcp=lg)
     try:
         ll, ess = f.ll_filter_more(t[a:], y[a:], has[a:], lgcp=lg)
