@@ -48,6 +48,37 @@ def test_scala_shim_builds_left_nested_states_and_survives_the_reference_throwin
     assert "sde.run(p).toOption" not in shim.replace("scala.util.Try(sde.run(p)).flatten.toOption", "")
 
 
+def test_jni_glue_passes_a_syntax_only_compile():
+    """gcc -fsyntax-only of the glue against tests/jni_stub/jni.h -- a TEST-ONLY prototype header written from the public JNI
+    specification (only the members the glue calls): catches arity and type slips in the calls through JNIEnv and into the C ABI.
+    Hygiene, not evidence of a binding: nothing compiled against the stub is linked or run."""
+    res = subprocess.run(["gcc", "-fsyntax-only", "-std=c11", "-Wall", "-Wextra", "-Werror", "-Wno-unused-parameter",
+                          "-I" + os.path.join(ROOT, "tests", "jni_stub"), "-I" + os.path.join(ROOT, "include"), GLUE],
+                         capture_output=True, text=True)
+    assert res.returncode == 0, res.stderr[-3000:]
+
+
+_JNI_TYPE = {"void": "void", "long": "jlong", "int": "jint", "double": "jdouble", "boolean": "jboolean", "byte": "jbyte",
+             "int[]": "jintArray", "double[]": "jdoubleArray", "byte[]": "jbyteArray", "long[]": "jlongArray"}
+
+
+def test_every_java_native_has_a_glue_function_of_the_matching_jni_signature():
+    """`public static native R name(A a, ...)` <-> `JNIEXPORT jR JNICALL Java_..._name(JNIEnv*, jclass, jA, ...)`: return type, arity and
+    every argument type (JNI specification, table 3-1 and section 3.2) -- a mismatch links and then corrupts arguments at run time."""
+    glue, native = open(GLUE).read(), open(NATIVE).read()
+    java = {m.group(2): (m.group(1), [a.strip().rsplit(" ", 1)[0] for a in m.group(3).split(",") if a.strip()])
+            for m in re.finditer(r"public static native (\S+) (\w+)\(([^)]*)\);", native)}
+    cfun = {m.group(2): (m.group(1), [a.strip() for a in m.group(3).split(",")])
+            for m in re.finditer(r"JNIEXPORT (\w+) JNICALL Java_com_github_jonnylaw_model_CssmNative_(\w+)\(([^)]*)\)", glue)}
+    assert java and set(java) == set(cfun)
+    for name, (ret, args) in java.items():
+        cret, cargs = cfun[name]
+        assert cret == _JNI_TYPE[ret], (name, ret, cret)
+        assert cargs[0].startswith("JNIEnv*") and cargs[1].startswith("jclass"), (name, cargs[:2])
+        ctypes_ = [a.rsplit(" ", 1)[0] for a in cargs[2:]]
+        assert ctypes_ == [_JNI_TYPE[a] for a in args], (name, args, ctypes_)
+
+
 def _probe_jdk():
     """(javac, java, include dir holding jni.h) or a string saying what is missing."""
     found = {}
