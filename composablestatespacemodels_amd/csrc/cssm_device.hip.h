@@ -62,6 +62,10 @@ struct Scalars {
   // instead of all 1024 unit sums (16 KiB per block, 16 MiB per launch through the L2s: doubling that traffic cost the kernel
   // 1.35 us at N = 2^20).  Cleared with the max slots.  Index: ((set * 2 + limb) * CSSM_GRP_MAX + group) * CSSM_SLOT_STRIDE.
   unsigned long long grp[CSSM_MAXSETS * 2 * CSSM_GRP_MAX * CSSM_SLOT_STRIDE];
+  // The same for the sums of SQUARED weights of a shard's units (k_propagate_shard / the sharded LGCP launch form both sums, SUMS = 2: the
+  // exchange ships them in the segment headers).  A shard's max slots stay in set 0; its group sums rotate through the three sets by
+  // weighted observation like the single GPU's (cssm_pf::wparity), and block 0 of the exchange's offspring blocks clears the two other sets.
+  unsigned long long grp2[CSSM_MAXSETS * 2 * CSSM_GRP_MAX * CSSM_SLOT_STRIDE];
   uint32_t err;              // bit0: NaN log-weight, bit1: all weights zero / max not finite,
                              // bit2: the reference level was unusable and the sums must be formed again (host retries)
                              // bit3: (sharded) the exchange capacity did not cover some rank's slots at step fail_step

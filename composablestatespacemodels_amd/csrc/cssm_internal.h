@@ -61,13 +61,15 @@ struct cssm_pf : HostModel {
   uint32_t* endslot = nullptr;
   uint32_t* anc = nullptr;
   bool anc_valid = false;
-  int wparity = 0;             // max-slot set (0 .. CSSM_MAXSETS - 1) of the next weighted step (single-GPU path)
+  int wparity = 0;             // max-slot set (0 .. CSSM_MAXSETS - 1) of the next weighted step (single-GPU path); a shard: the set of GROUP
+                               //   sums (Scalars::grp / grp2) of the next weighted observation -- its max slots stay in set 0
   int opt_exact = 0;           // CSSM_OPT_EXACT_OFFSPRING
   int opt_fused = 0;           // CSSM_OPT_FUSED_SUMS (set to 1 for sharded handles at creation)
   cssm_u128 *fineS = nullptr, *fineS2 = nullptr;   // large clouds: the sums of k_propagate's single-tile blocks (k_reduce_units folds them into tileS / tileS2)
   size_t fine_cap = 0;
   int opt_whole = 0;           // CSSM_OPT_WHOLE_TILES
   int opt_grp = 1;             // CSSM_OPT_GROUP_SUMS
+  uint32_t grp_min_units = 2u * CSSM_GRP_UNITS;   // smallest cloud (in units) whose propagate accumulates group sums (CSSM_GRP_MIN_UNITS: tests run small clouds through them)
   int opt_spec = 1;            // CSSM_OPT_SPECIALISE
   bool last_grp = false;       // the last launch_propagate's blocks accumulated the sums of groups of units (Scalars::grp)
   int resampler = CSSM_RESAMPLE_SYSTEMATIC;
@@ -108,7 +110,8 @@ struct cssm_pf : HostModel {
   bool want_path = false;      // sharded `filter`: record sampleOne's pick after every observation whose slot this rank owns
   uint32_t rec_base = 0;       // observation index (pf->step) of the resident series' first record: 0 after _begin, the filter's
                                //   observation count so far after _continue
-  struct Snap { int cur; const double* src; size_t src_stride; const double* src2; size_t src2_stride; uint32_t n_split; bool anc_valid, last_optimistic; uint32_t step; double t; bool have_level; };
+  struct Snap { int cur; const double* src; size_t src_stride; const double* src2; size_t src2_stride; uint32_t n_split; bool anc_valid, last_optimistic; uint32_t step; double t; bool have_level;
+                int wparity; bool last_grp; };   // (the set of group sums the observation's propagate added to, and whether it did)
   std::vector<Snap> snaps;     // host-side state right after the propagate of every observation of the series (cssm_pf_shard_resume)
   std::vector<Snap> pre_snaps; // ... and right BEFORE it (cssm_pf_shard_resume_level: the observation is propagated again)
   // host staging (pinned)

@@ -401,7 +401,12 @@ __device__ __forceinline__ void publish_observation(Scalars* __restrict__ sc, co
 // loads a header, the totals go through LDS -- the body's own loops over all5 are world x 5 loads in EVERY thread, and on the
 // peer-written windows each of those is a system-scope load past the caches)
 struct SpecTotals { cssm_u128 S_off, tot, tot2; double gmax; };
-template <bool FUSE, bool SELF, int RS, int RAWC = -1, bool GRP = false>
+// `Mid` (sharded launches with the group sums at hand, GRP && !SELF): what stands between the block's LOCAL work -- its first tile on the
+// grid and scanned, its prefix inside the rank from the group sums: nothing of that depends on another rank -- and the rest, which
+// needs every rank's totals: the wait for the peers' headers, the level check, block 0's coverage verdict.  bool operator()(SpecTotals&):
+// false = the block ends here (series on hold, a peer missing); contains block barriers.  Every other instantiation passes nullptr.
+struct NoMid { __device__ __forceinline__ bool operator()(SpecTotals&) const { return true; } };
+template <bool FUSE, bool SELF, int RS, int RAWC = -1, bool GRP = false, class Mid = NoMid>
 __device__ __forceinline__ void offspring_body(const double* __restrict__ logw, uint64_t n,
                                                           Scalars* __restrict__ sc,
                                                           const cssm_u128* __restrict__ unitP, const cssm_u128* __restrict__ unitS2,
@@ -416,7 +421,7 @@ __device__ __forceinline__ void offspring_body(const double* __restrict__ logw, 
                                                           uint32_t slot_lo, uint32_t slot_hi, uint32_t all5_stride,
                                                           cssm_u128* __restrict__ s2buf = nullptr, uint32_t s2_stride = 0, int s2_par_arg = -1,
                                                           uint32_t gen = 0, const cssm_u128* __restrict__ unit_pre = nullptr, const uint32_t blk0 = 0u,
-                                                          const double* pre_in = nullptr, const SpecTotals* tt = nullptr) {
+                                                          const double* pre_in = nullptr, const SpecTotals* tt = nullptr, Mid* mid = nullptr) {
   // pre_in (or nullptr): the weights of the block's first tile, requested by the caller (the merged exchange kernel asks for them
   // BEFORE it waits for the peers' flags: the wait covers their round trip)
   // blk0: blocks [0, blk0) of the launch are somebody else's (the pack blocks of the merged exchange + offspring kernel of the
@@ -427,7 +432,8 @@ __device__ __forceinline__ void offspring_body(const double* __restrict__ logw, 
   // (Scalars::grp) -- an instantiation of its own: it keeps ONE unit-sum entry per lane of one wave in flight instead of UPRE per
   // thread, and the registers that frees let the block's first tile be converted and scanned BEFORE the sums' barrier
   constexpr bool grp_on = GRP;
-  static_assert(!GRP || (SELF && RAWC == 2), "group sums: the single-GPU launch behind a fused-sums propagate");
+  static_assert(!GRP || RAWC == 2, "group sums: a launch behind a fused-sums propagate (the single GPU's, or a shard's exchange kernel)");
+  constexpr bool SHARD_GRP = GRP && !SELF;               // (the group sums are the RANK's: prefix inside the rank; totals and offset come with `mid`)
   // RAWC >= 0 (the single-GPU launches): the weight-input mode is a compile-time constant -- 2 goes with the pending ESS
   // (s2_par >= 0), 0 with the sums of squares at hand; the kernel had run out of scalar and vector registers otherwise
   const int raw = (RAWC >= 0) ? RAWC : raw_arg;
@@ -479,7 +485,7 @@ __device__ __forceinline__ void offspring_body(const double* __restrict__ logw, 
   // holds group l (four 64-bit words of 32-bit limb sums), lane 32 + j unit j of the own group
   const uint32_t wsum = (bidx + 1u) & 3u;
   const uint32_t grp_unit = is_pub ? 0u : ublk;
-  if (SELF && grp_on) {
+  if (grp_on) {
 #pragma unroll
     for (int k = 0; k < UPRE; ++k) upre[k] = cssm_u128_zero();
     if ((threadIdx.x >> 6) == wsum) {
@@ -540,7 +546,7 @@ __device__ __forceinline__ void offspring_body(const double* __restrict__ logw, 
       if (l == 0u) s_key = k;
     }
     if (held & 64u) return;
-  } else {
+  } else if (!SHARD_GRP) {
     if (tt != nullptr) {
       gmax_dec = tt->gmax;
     } else if (all5) {
@@ -552,32 +558,37 @@ __device__ __forceinline__ void offspring_body(const double* __restrict__ logw, 
     }
     if (!level_known()) return;
   }
-  if (!SELF && flag_out && bidx == 0 && threadIdx.x == 0) *flag_out = 0ull;
+  if (!SELF && !SHARD_GRP && flag_out && bidx == 0 && threadIdx.x == 0) *flag_out = 0ull;
   const bool pow2 = (n_global & (n_global - 1)) == 0;
   // (1 / N is formed where the exact predicate is evaluated: a division and two registers in every thread otherwise)
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   double totd = 0.0;
   cssm_u128 S_off = cssm_u128_zero();
-  if (!SELF) {
-    if (all5) {   // sharded: every block derives this rank's offset and the global totals from the all-gathered sums
-      cssm_u128 tot = cssm_u128_zero(), tot2 = cssm_u128_zero();
-      if (tt != nullptr) {
-        S_off = tt->S_off; tot = tt->tot; tot2 = tt->tot2;
-      } else
-      for (int r = 0; r < world; ++r) {
-        cssm_u128 a, b;
-        const unsigned long long* w5 = all5 + (size_t)all5_stride * r;   // (possibly a peer-written window: ld_sys)
-        a.lo = ld_sys_u64(w5); a.hi = ld_sys_u64(w5 + 1); b.lo = ld_sys_u64(w5 + 2); b.hi = ld_sys_u64(w5 + 3);
-        if (r < rank) S_off = cssm_u128_add(S_off, a);
-        tot = cssm_u128_add(tot, a); tot2 = cssm_u128_add(tot2, b);
-      }
-      totd = cssm_u128_to_double(tot);
-      if (bidx == 0 && threadIdx.x == 0) {
-        sc->gmax = gmax_dec; sc->ref = gmax;
-        sc->S_off = S_off; sc->S_tot = tot; sc->S2_tot = tot2;
-        finish_step(sc, n_global);
-        publish_next_level(sc, rec, gmax_dec);
-      }
+  // sharded: the rank's offset and the global totals -- from the all-gathered sums (every block totals them itself, or the caller did: tt);
+  // block 0 publishes the observation's scalars
+  auto shard_totals = [&](const SpecTotals* t) {
+    cssm_u128 tot = cssm_u128_zero(), tot2 = cssm_u128_zero();
+    if (t != nullptr) {
+      S_off = t->S_off; tot = t->tot; tot2 = t->tot2;
+    } else
+    for (int r = 0; r < world; ++r) {
+      cssm_u128 a, b;
+      const unsigned long long* w5 = all5 + (size_t)all5_stride * r;   // (possibly a peer-written window: ld_sys)
+      a.lo = ld_sys_u64(w5); a.hi = ld_sys_u64(w5 + 1); b.lo = ld_sys_u64(w5 + 2); b.hi = ld_sys_u64(w5 + 3);
+      if (r < rank) S_off = cssm_u128_add(S_off, a);
+      tot = cssm_u128_add(tot, a); tot2 = cssm_u128_add(tot2, b);
+    }
+    totd = cssm_u128_to_double(tot);
+    if (bidx == 0 && threadIdx.x == 0) {
+      sc->gmax = gmax_dec; sc->ref = gmax;
+      sc->S_off = S_off; sc->S_tot = tot; sc->S2_tot = tot2;
+      finish_step(sc, n_global);
+      publish_next_level(sc, rec, gmax_dec);
+    }
+  };
+  if (!SELF && !SHARD_GRP) {
+    if (all5) {
+      shard_totals(tt);
     } else {
       totd = cssm_u128_to_double(sc->S_tot);
       S_off = sc->S_off;
@@ -624,7 +635,7 @@ __device__ __forceinline__ void offspring_body(const double* __restrict__ logw, 
   };
   double w1_first[CSSM_ITEMS];                             // GRP: the first tile, converted ahead of the sums' barrier
   cssm_u128 inc_first = cssm_u128_zero();
-  if (SELF) {                                              // here unitP holds the unit SUMS (k_propagate / k_tile_sums output)
+  if (SELF || SHARD_GRP) {                                 // here unitP holds the unit SUMS (k_propagate / k_tile_sums output)
     // ONE wave scan of the threads' own sums gives both the total and the prefix of the entries below this block's first
     // (qlim): that prefix = inclusive scan at thread tq - 1 + the first qlim - tq E entries of thread tq, tq = qlim / E.
     // (Round 2 took two block-wide sums with eight masked 128-bit adds per thread each: a third of the kernel's
@@ -658,12 +669,14 @@ __device__ __forceinline__ void offspring_body(const double* __restrict__ logw, 
 #pragma unroll
             for (int w = 1; w < CSSM_BLOCK / 64; ++w) s_r[1][w] = cssm_u128_zero();
             s_pre[0] = cssm_u128_add(pg, pu);
-            // N / S_tot of the end slots' fast path (see below), once per block instead of once per thread behind the barrier
-            const double tf = cssm_fma((double)t.hi, 0x1.0p64, (double)t.lo);
-            double rinv = __builtin_amdgcn_rcp(tf);
-            rinv = cssm_fma(cssm_fma(-tf, rinv, 1.0), rinv, rinv);
-            rinv = cssm_fma(cssm_fma(-tf, rinv, 1.0), rinv, rinv);
-            s_scale = (double)n_global * rinv;
+            if (SELF) {   // (a shard's group sums are its own: the total that scales its end slots comes with the peers' headers)
+              // N / S_tot of the end slots' fast path (see below), once per block instead of once per thread behind the barrier
+              const double tf = cssm_fma((double)t.hi, 0x1.0p64, (double)t.lo);
+              double rinv = __builtin_amdgcn_rcp(tf);
+              rinv = cssm_fma(cssm_fma(-tf, rinv, 1.0), rinv, rinv);
+              rinv = cssm_fma(cssm_fma(-tf, rinv, 1.0), rinv, rinv);
+              s_scale = (double)n_global * rinv;
+            }
           }
         }
         __syncthreads();
@@ -739,11 +752,18 @@ __device__ __forceinline__ void offspring_body(const double* __restrict__ logw, 
     // the sums (RAWC == 2: the weights are stored as they are used); its results go through the SAME barrier (tile_front below)
     if constexpr (GRP) {
       const uint32_t t0h = ublk * sup;
-      inc_first = tile_front(t0h, true, w1_first, t0h + 1u == ((t0h + sup < ntiles) ? t0h + sup : ntiles));
+      inc_first = tile_front(t0h, true, w1_first, SELF && s2_par >= 0 && t0h + 1u == ((t0h + sup < ntiles) ? t0h + sup : ntiles));
     }
     cssm_u128 tot;
     scan_units(tot, toff_self);
     CSSM_STAMP(1);
+    if constexpr (SHARD_GRP) {
+      // everything local is done (first tile on the grid and scanned, the prefix inside the rank known): now the peers
+      SpecTotals t2;
+      if (!(*mid)(t2)) return;
+      gmax_dec = t2.gmax; gmax = rec_ref;                  // (mid checked the level: the sums were formed relative to rec_ref)
+      shard_totals(&t2);
+    } else {
     gmax_dec = cssm_order_unkey(s_key);
     if (!level_known()) return;
     // N / S_tot for the fast path of the end slots: S_tot through two conversions and an fma, its reciprocal by v_rcp_f64 and two
@@ -759,11 +779,15 @@ __device__ __forceinline__ void offspring_body(const double* __restrict__ logw, 
       rinv = cssm_fma(cssm_fma(-tf, rinv, 1.0), rinv, rinv);
       scale_self = uniform_f64((double)n_global * rinv);
     }
+    }
   }
   if (unit < nunits) do {
     const uint32_t t0 = unit * sup;
     const uint32_t t1 = (t0 + sup < ntiles) ? t0 + sup : ntiles;
     cssm_u128 toff;                                        // cumulative weight before the current tile
+    if constexpr (SHARD_GRP) {
+      toff = cssm_u128_add(S_off, toff_self);              // (one unit per block: a launch with the group sums has nunits offspring blocks)
+    } else
     if (!SELF && all5 && unit_pre != nullptr) {            // sharded, the prefixes of the unit sums at hand (k_boundary_pack's header block)
       // (the merged kernel's prefix block wrote them while this launch ran: system-scope loads, behind its flag)
       cssm_u128 up; const unsigned long long* upw = reinterpret_cast<const unsigned long long*>(unit_pre + (size_t)unit * split);
@@ -880,7 +904,7 @@ __device__ __forceinline__ void offspring_body(const double* __restrict__ logw, 
         __syncthreads();                                       // (s_w is rewritten by the next tile / the next unit)
       }
     }
-  } while (!SELF && (unit += nblk) < nunits);
+  } while (!SELF && !SHARD_GRP && (unit += nblk) < nunits);
 }
 
 #define CSSM_OFFSPRING_PARAMS                                                                                              \

@@ -71,6 +71,7 @@ static int alloc_handle(cssm_pf* pf) {
   HIP_TRY(hipEventCreate(&pf->ev0));
   HIP_TRY(hipEventCreate(&pf->ev1));
   { const char* e = getenv("CSSM_LOOP_EVENTS"); pf->opt_events = (e && e[0] == '1') ? 1 : 0; }   // (measurement scripts: the default of CSSM_OPT_LOOP_EVENTS)
+  { const char* e = getenv("CSSM_GRP_MIN_UNITS"); if (e && atoi(e) >= 1) pf->grp_min_units = (uint32_t)atoi(e); }   // (tests: small clouds through the group sums)
   HIP_TRY(hipDeviceGetAttribute(&pf->n_cus, hipDeviceAttributeMultiprocessorCount, pf->device));
   pf->stride = (size_t)((pf->n + CSSM_TILE - 1) / CSSM_TILE) * CSSM_TILE;   // rows start 16-B aligned
   pf->ntiles = (uint32_t)((pf->n + CSSM_TILE - 1) / CSSM_TILE);
@@ -370,10 +371,12 @@ int cssm_launch_propagate(cssm_pf* pf, const StepRec* d_rec, double* pick_out, u
   a.slot_set = pf->sharded ? 0 : pf->wparity;
   // one fused-sums block per unit of a single-GPU cloud: the blocks also accumulate the sums of groups of 32 units (Scalars::grp,
   // bit 8 of the set argument of k_propagate_self and k_offspring_self), which k_offspring then reads instead of every unit sum
-  pf->last_grp = !pf->sharded && do_sums && !fine && pf->split == 1 && chunk == unit_particles && pf->first == 0 && pf->n == pf->n_global &&
-                 pf->nunits >= 2u * CSSM_GRP_UNITS && pf->nunits <= (uint32_t)(CSSM_GRP_MAX * CSSM_GRP_UNITS) && unit_particles <= CSSM_GRP_MAX_UNIT && pf->opt_grp;
+  // (a shard: the same, in Scalars::grp and grp2 -- both sums travel in the exchange's headers --, the set rotating with the handle's
+  //  weighted observations while its max slots stay in set 0; the exchange kernels read 32 group sums instead of every unit sum)
+  pf->last_grp = do_sums && !fine && pf->split == 1 && chunk == unit_particles && (pf->sharded || (pf->first == 0 && pf->n == pf->n_global)) &&
+                 pf->nunits >= pf->grp_min_units && pf->nunits <= (uint32_t)(CSSM_GRP_MAX * CSSM_GRP_UNITS) && unit_particles <= CSSM_GRP_MAX_UNIT && pf->opt_grp;
   const bool want_grp = pf->last_grp;
-  if (want_grp) a.slot_set |= 0x100;
+  if (want_grp) a.slot_set |= 0x100 | (pf->wparity << 9);
   a.src2 = anc ? pf->src2 : nullptr; a.src2_stride = pf->src2_stride; a.n_split = pf->n_split; a.logtab = pf->d_logtab;
   a.chunk = chunk; a.do_sums = do_sums; a.subS = fine ? pf->fineS : pf->tileS; a.subS2 = fine ? pf->fineS2 : pf->tileS2;
   a.pick_out = pick_out; a.pick_slot = pick_slot;
@@ -384,7 +387,7 @@ int cssm_launch_propagate(cssm_pf* pf, const StepRec* d_rec, double* pick_out, u
   // sharded handle on the single-collective exchange (received rows read in place: src2_stride == 0) or before its first exchange:
   // slim launch, tile after tile while a unit has at most CSSM_LOOP_MAX_TILES tiles; whole pairs per thread (d <= 8) need an even first id
   a.shard_slim = pf->sharded && do_sums && !a.lgcp && (a.src2 == nullptr || a.src2_stride == 0) && a.fsub == nullptr && pick_out == nullptr &&
-                 ((pf->first & 1ull) == 0ull || cssm_prop_items(pf->d) == 1) && a.slot_set == 0;
+                 ((pf->first & 1ull) == 0ull || cssm_prop_items(pf->d) == 1) && (a.slot_set & 0xff) == 0;
   if (a.shard_slim && pf->sup * (uint32_t)CSSM_TILE / (uint32_t)(CSSM_BLOCK * cssm_prop_items(pf->d)) <= CSSM_LOOP_MAX_TILES) a.one = 2;
   int launched = 0;   // CSSM_PROP_LAUNCHED_* of the kernel the dispatcher chose
   switch (pf->d) {

@@ -36,7 +36,7 @@ template <int D, int IT, int ONEV, bool SHARD, int OB, int I> struct TryKnown {
         if constexpr (SHARD)
           k_propagate_shard<D, IT, OB, ONEV, W0, W1, W2><<<dim3(a.grid), dim3(CSSM_BLOCK), 0, a.stream>>>(
               a.src, a.src_stride, a.anc, a.dst, a.dst_stride, a.logw, a.n, a.gid0, a.seed, a.rec, a.mk, a.sc, a.src2, a.n_split, a.logtab, a.chunk,
-              a.subS, a.subS2, a.step);
+              a.subS, a.subS2, a.step, a.slot_set);
         else
           k_propagate_self<D, IT, OB, 1, ONEV, W0, W1, W2><<<dim3(a.grid), dim3(CSSM_BLOCK), 0, a.stream>>>(
               a.src, a.src_stride, a.anc, a.dst, a.dst_stride, a.logw, a.n, a.seed, a.rec, a.mk, a.sc, a.slot_set, a.logtab, a.chunk, a.subS, a.subS2,
@@ -93,7 +93,7 @@ int CSSM_CAT(cssm_prop_launch_d, CSSM_PROP_D)(const PropLaunch& a) {
   }
 #define PROP_GO(LG, OB, SM)                                                                                               \
   k_propagate<D, LG, IT, OB, SM><<<dim3(a.grid), dim3(CSSM_BLOCK), 0, a.stream>>>(                                        \
-      a.src, a.src_stride, a.anc, a.dst, a.dst_stride, a.logw, a.n, a.gid0, a.seed, a.rec, a.mk, a.sc, a.slot_set & 0xff, a.src2, \
+      a.src, a.src_stride, a.anc, a.dst, a.dst_stride, a.logw, a.n, a.gid0, a.seed, a.rec, a.mk, a.sc, a.slot_set, a.src2, \
       a.src2_stride, a.n_split, a.logtab, a.chunk, a.do_sums, a.subS, a.subS2, a.pick_out, a.pick_slot, a.fsub)
   // the single-GPU lean launch: nothing of the sharded filter, no fused sums, no pick, first global id 0
   const bool self = (!a.sharded || !a.sums) && !a.lgcp && a.src2 == nullptr && a.gid0 == 0 && a.fsub == nullptr && (a.sums || a.pick_out == nullptr) && (!a.sums || a.do_sums);
@@ -101,8 +101,8 @@ int CSSM_CAT(cssm_prop_launch_d, CSSM_PROP_D)(const PropLaunch& a) {
   k_propagate_self<D, IT, OB, SM><<<dim3(a.grid), dim3(CSSM_BLOCK), 0, a.stream>>>(a.src, a.src_stride, a.anc, a.dst, a.dst_stride, \
       a.logw, a.n, a.seed, a.rec, a.mk, a.sc, a.slot_set, a.logtab, a.chunk, a.subS, a.subS2, a.pick_out, a.pick_slot, a.step)
   // small clouds: one tile of the kernel per block (half a tile of 1024 for d <= 8, a quarter for d >= 9): the ONE instantiation
-  // only propagate_block with SUMS == 1 (k_propagate_self<..., 1, ...>) adds to the group sums
-  const int grp = (self && CSSM_PROP_SELF && a.sums && (a.slot_set & 0x100)) ? CSSM_PROP_LAUNCHED_GRP : 0;
+  // every kernel that forms the sums adds to the group sums where bit 8 of the set argument asks for them (one block per unit: cssm_pf.hip)
+  const int grp = (a.sums && a.do_sums && (a.slot_set & 0x100)) ? CSSM_PROP_LAUNCHED_GRP : 0;
   if (self && CSSM_PROP_SELF && a.sums && a.one) {
     OneTile<D, IT>::go(a);
   } else if (self && CSSM_PROP_SELF) {
@@ -114,7 +114,7 @@ int CSSM_CAT(cssm_prop_launch_d, CSSM_PROP_D)(const PropLaunch& a) {
     // the sharded filter (single-collective exchange): the slim launch; tile after tile while a unit has few tiles
 #define PROP_SHARD(OB, ONEV)                                                                                               \
   k_propagate_shard<D, IT, OB, ONEV><<<dim3(a.grid), dim3(CSSM_BLOCK), 0, a.stream>>>(a.src, a.src_stride, a.anc, a.dst, a.dst_stride, a.logw, \
-      a.n, a.gid0, a.seed, a.rec, a.mk, a.sc, a.src2, a.n_split, a.logtab, a.chunk, a.subS, a.subS2, a.step)
+      a.n, a.gid0, a.seed, a.rec, a.mk, a.sc, a.src2, a.n_split, a.logtab, a.chunk, a.subS, a.subS2, a.step, a.slot_set)
     if (a.one == 2 ? launch_known<D, IT, 2, true>(a) : launch_known<D, IT, 0, true>(a)) {
       /* a known structure's own instantiation */
     } else if (a.one == 2) {
@@ -132,7 +132,7 @@ int CSSM_CAT(cssm_prop_launch_d, CSSM_PROP_D)(const PropLaunch& a) {
     do {                                                                                                                       \
       if (a.specialise == 1 && D == 1 && a.mk.comp[0] == 0x36u)                                                                   \
         k_propagate<D, true, IT, -1, SM, (D == 1 ? 0x36u : 0u)><<<dim3(a.grid), dim3(CSSM_BLOCK), 0, a.stream>>>(              \
-            a.src, a.src_stride, a.anc, a.dst, a.dst_stride, a.logw, a.n, a.gid0, a.seed, a.rec, a.mk, a.sc, a.slot_set & 0xff, a.src2, \
+            a.src, a.src_stride, a.anc, a.dst, a.dst_stride, a.logw, a.n, a.gid0, a.seed, a.rec, a.mk, a.sc, a.slot_set, a.src2, \
             a.src2_stride, a.n_split, a.logtab, a.chunk, a.do_sums, a.subS, a.subS2, a.pick_out, a.pick_slot, a.fsub);         \
       else if (cssm_rtc_launch(a, 2, D, IT, 0)) { /* the structure of any other LGCP model, compiled at run time */ }          \
       else                                                                                                                     \

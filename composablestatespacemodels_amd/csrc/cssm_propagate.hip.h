@@ -441,6 +441,20 @@ __device__ __forceinline__ void propagate_range(
   acc.S = accS; acc.S2 = accS2; acc.tmax = tmax; acc.bad = bad;
 }
 
+// A unit's sum (and, squares: its sum of squared weights) added to its group's: two 56-bit limbs each, non-returning atomics on lines of
+// their own (Scalars::grp / grp2; integer sums: any order, the same bits).  One thread of the unit's block calls it.
+__device__ __forceinline__ void group_sums_add(Scalars* __restrict__ sc, int set, uint32_t group, cssm_u128 ta, cssm_u128 tb, bool squares) {
+  const size_t at = ((size_t)set * 2 * CSSM_GRP_MAX + group) * CSSM_SLOT_STRIDE;
+  unsigned long long* g = &sc->grp[at];
+  atomicAdd(g, ta.lo & ((1ull << CSSM_GRP_LIMB) - 1ull));
+  atomicAdd(g + (size_t)CSSM_GRP_MAX * CSSM_SLOT_STRIDE, (ta.lo >> CSSM_GRP_LIMB) | (ta.hi << (64 - CSSM_GRP_LIMB)));
+  if (squares) {
+    unsigned long long* g2 = &sc->grp2[at];
+    atomicAdd(g2, tb.lo & ((1ull << CSSM_GRP_LIMB) - 1ull));
+    atomicAdd(g2 + (size_t)CSSM_GRP_MAX * CSSM_SLOT_STRIDE, (tb.lo >> CSSM_GRP_LIMB) | (tb.hi << (64 - CSSM_GRP_LIMB)));
+  }
+}
+
 //
 // A block owns the CONTIGUOUS range [blockIdx.x * chunk, +chunk) (chunk a multiple of CSSM_BLOCK*IT, chosen on the
 // host so that a whole number of blocks makes one scan unit of k_offspring).  With do_sums the block also forms
@@ -450,12 +464,16 @@ template <int D, bool LGCP, int IT, int OBS, int SUMS, uint32_t MKW = 0u, uint32
 __global__ __launch_bounds__(CSSM_BLOCK, (PropWaves<D, SUMS>::value)) void k_propagate(
     const double* __restrict__ src, size_t src_stride, const uint32_t* __restrict__ anc,
     double* __restrict__ dst, size_t dst_stride, double* __restrict__ logw, uint64_t n_arg, uint64_t gid0,
-    uint64_t seed, const StepRec* __restrict__ rec, ModelK mk, Scalars* __restrict__ sc, int slot_set,
+    uint64_t seed, const StepRec* __restrict__ rec, ModelK mk, Scalars* __restrict__ sc, int slot_set_arg,
     const double* __restrict__ src2, size_t src2_stride, uint32_t n_split, const double* __restrict__ logtab,
     uint64_t chunk, int do_sums_arg, cssm_u128* __restrict__ subS, cssm_u128* __restrict__ subS2,
     double* __restrict__ pick_out, uint32_t pick_slot, const double* __restrict__ fsub) {
   __shared__ double s_max[CSSM_BLOCK / 64];
   if (MKW != 0u) { mk.comp[0] = MKW; mk.comp[1] = MKW1; mk.comp[2] = MKW2; }   // (a known structure at compile time: k_propagate_self)
+  // slot_set_arg: as in propagate_block -- bits 0-7 the set of max slots, bit 8 + bits 9-10: one block per unit, group sums wanted, their set
+  const int slot_set = slot_set_arg & 0xff;
+  const bool grp_on = (slot_set_arg & 0x100) != 0;
+  const int grp_set = (slot_set_arg >> 9) & 3;
   // (sharded series) the exchange of an earlier observation did not fit: the series is on hold and nothing may change
   // until the host resumes it (cssm_pf_shard_resume)
   // bit 3: a sharded series is on hold (capacity miss); bit 6: a single-GPU batch series waits for the redo of an outlying
@@ -503,6 +521,7 @@ __global__ __launch_bounds__(CSSM_BLOCK, (PropWaves<D, SUMS>::value)) void k_pro
       for (int w = 1; w < CSSM_BLOCK / 64; ++w) { ta = cssm_u128_add(ta, s_sa[w]); if (SUMS == 2) tb = cssm_u128_add(tb, s_sb[w]); }
       subS[blockIdx.x] = ta;
       if (SUMS == 2) subS2[blockIdx.x] = tb;
+      if (grp_on) group_sums_add(sc, grp_set, blockIdx.x / CSSM_GRP_UNITS, ta, tb, SUMS == 2);   // (uniform)
     }
   } else {
     __syncthreads();
@@ -532,10 +551,12 @@ __device__ __forceinline__ void propagate_block(
     int slot_set_arg, const double* __restrict__ logtab, uint64_t chunk,
     cssm_u128* __restrict__ subS, cssm_u128* __restrict__ subS2, double* __restrict__ pick_out, uint32_t pick_slot,
     const uint64_t gid0, const double* __restrict__ src2, const uint32_t n_split, const uint32_t step_now) {
-  // slot_set_arg: bits 0-7 the set of max slots (and of group sums); bit 8: this launch has one block per unit of a single-GPU
-  // cloud -- the blocks also accumulate the sums of groups of units (Scalars::grp)
+  // slot_set_arg: bits 0-7 the set of max slots; bit 8: this launch has one block per unit -- the blocks also accumulate the sums of
+  // groups of units (Scalars::grp; a shard's launch, SUMS == 2: Scalars::grp2 as well) in set bits 9-10 (the single GPU passes the set
+  // of its max slots there; a shard's max slots stay in set 0 while its group sums rotate)
   const int slot_set = slot_set_arg & 0xff;
   const bool grp_on = (slot_set_arg & 0x100) != 0;
+  const int grp_set = (slot_set_arg >> 9) & 3;
   // SUMS: the block also forms its fixed-point sums of exp(w - c) (subS / subS2, one entry per block) and, for `filter`,
   // records the state sampleOne picked after the previous observation (pick_out / pick_slot; see k_propagate)
   __shared__ double s_max[CSSM_BLOCK / 64];
@@ -623,11 +644,7 @@ __device__ __forceinline__ void propagate_block(
       for (int w = 1; w < CSSM_BLOCK / 64; ++w) { ta = cssm_u128_add(ta, s_sa[w]); if (SUMS == 2) tb = cssm_u128_add(tb, s_sb[w]); }
       subS[blockIdx.x] = ta;
       if (SUMS == 2) subS2[blockIdx.x] = tb;
-      if (SUMS == 1 && grp_on) {   // (uniform) the group's sum: Scalars::grp
-        unsigned long long* g = &sc->grp[((size_t)slot_set * 2 * CSSM_GRP_MAX + blockIdx.x / CSSM_GRP_UNITS) * CSSM_SLOT_STRIDE];
-        atomicAdd(g, ta.lo & ((1ull << CSSM_GRP_LIMB) - 1ull));
-        atomicAdd(g + (size_t)CSSM_GRP_MAX * CSSM_SLOT_STRIDE, (ta.lo >> CSSM_GRP_LIMB) | (ta.hi << (64 - CSSM_GRP_LIMB)));
-      }
+      if (grp_on) group_sums_add(sc, grp_set, blockIdx.x / CSSM_GRP_UNITS, ta, tb, SUMS == 2);   // (uniform) Scalars::grp / grp2
     }
   } else {
     __syncthreads();
@@ -689,8 +706,9 @@ __global__ __launch_bounds__(CSSM_BLOCK, (ONE ? 2 : PropWaves<D, 2>::value)) voi
     const double* __restrict__ src, size_t src_stride, const uint32_t* __restrict__ anc, double* __restrict__ dst, size_t dst_stride,
     double* __restrict__ logw, uint64_t n_arg, uint64_t gid0, uint64_t seed, const StepRec* __restrict__ rec, ModelK mk,
     Scalars* __restrict__ sc, const double* __restrict__ src2, uint32_t n_split, const double* __restrict__ logtab, uint64_t chunk,
-    cssm_u128* __restrict__ subS, cssm_u128* __restrict__ subS2, uint32_t step_now) {
+    cssm_u128* __restrict__ subS, cssm_u128* __restrict__ subS2, uint32_t step_now, int slot_set) {
+  // slot_set: max-slot set 0 in bits 0-7; bit 8 / bits 9-10: group sums wanted (one block per unit) and their set (propagate_block)
   if (MKW != 0u) { mk.comp[0] = MKW; mk.comp[1] = MKW1; mk.comp[2] = MKW2; }
-  propagate_block<D, IT, OBS, 2, ONE>(src, src_stride, anc, dst, dst_stride, logw, n_arg, seed, rec, mk, sc, 0, logtab, chunk, subS, subS2,
+  propagate_block<D, IT, OBS, 2, ONE>(src, src_stride, anc, dst, dst_stride, logw, n_arg, seed, rec, mk, sc, slot_set, logtab, chunk, subS, subS2,
                                       nullptr, 0u, gid0, src2, n_split, step_now);
 }

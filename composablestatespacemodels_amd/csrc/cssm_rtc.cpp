@@ -226,7 +226,7 @@ bool cssm_rtc_launch(const PropLaunch& a, int kind, int D, int IT, int onev) {
   // (copies: the argument array points at them)
   const double* src = a.src; size_t src_stride = a.src_stride; const uint32_t* anc = a.anc; double* dst = a.dst; size_t dst_stride = a.dst_stride;
   double* logw = a.logw; uint64_t n = a.n, gid0 = a.gid0, seed = a.seed; const StepRec* rec = a.rec; ModelK mk = a.mk; Scalars* sc = a.sc;
-  int slot_set = a.slot_set, slot_lo = a.slot_set & 0xff; const double* src2 = a.src2; size_t src2_stride = a.src2_stride; uint32_t n_split = a.n_split;
+  int slot_set = a.slot_set; const double* src2 = a.src2; size_t src2_stride = a.src2_stride; uint32_t n_split = a.n_split;
   const double* logtab = a.logtab; uint64_t chunk = a.chunk; int do_sums = a.do_sums; cssm_u128* subS = a.subS; cssm_u128* subS2 = a.subS2;
   double* pick_out = a.pick_out; uint32_t pick_slot = a.pick_slot, step = a.step; const double* fsub = a.fsub;
   const void* chains = a.chains; int cur = a.cur, anc_valid = a.anc_valid, want_pick = a.want_pick; uint32_t rec_idx = a.rec_idx;
@@ -238,9 +238,9 @@ bool cssm_rtc_launch(const PropLaunch& a, int kind, int D, int IT, int onev) {
   } else if (kind == 0)
     args = {&src, &src_stride, &anc, &dst, &dst_stride, &logw, &n, &seed, &rec, &mk, &sc, &slot_set, &logtab, &chunk, &subS, &subS2, &pick_out, &pick_slot, &step};
   else if (kind == 1)
-    args = {&src, &src_stride, &anc, &dst, &dst_stride, &logw, &n, &gid0, &seed, &rec, &mk, &sc, &src2, &n_split, &logtab, &chunk, &subS, &subS2, &step};
+    args = {&src, &src_stride, &anc, &dst, &dst_stride, &logw, &n, &gid0, &seed, &rec, &mk, &sc, &src2, &n_split, &logtab, &chunk, &subS, &subS2, &step, &slot_set};
   else
-    args = {&src, &src_stride, &anc, &dst, &dst_stride, &logw, &n, &gid0, &seed, &rec, &mk, &sc, &slot_lo, &src2, &src2_stride, &n_split, &logtab, &chunk,
+    args = {&src, &src_stride, &anc, &dst, &dst_stride, &logw, &n, &gid0, &seed, &rec, &mk, &sc, &slot_set, &src2, &src2_stride, &n_split, &logtab, &chunk,
             &do_sums, &subS, &subS2, &pick_out, &pick_slot, &fsub};
   if (hipModuleLaunchKernel(fn, (unsigned)a.grid, grid_y, 1, CSSM_BLOCK, 1, 1, 0, a.stream, args.data(), nullptr) != hipSuccess) {
     (void)hipGetLastError();

@@ -375,14 +375,14 @@ extern "C" int cssm_pf_shard_propagate_at(cssm_pf* pf, size_t s, uint64_t* sums5
   if (!pf->series || !pf->initialised) return fail(CSSM_ESTATE, "shard_propagate_at before shard_begin");
   if (s >= pf->h_recs_cap || s + pf->rec_base != pf->step) return fail(CSSM_ESTATE, "steps of a series run in order (expected %u)", pf->step - pf->rec_base);
   if (pf->pre_snaps.size() <= s) pf->pre_snaps.resize(s + 1);
-  pf->pre_snaps[s] = {pf->cur, pf->src, pf->src_stride, pf->src2, pf->src2_stride, pf->n_split, pf->anc_valid, pf->last_optimistic, pf->step, pf->t, pf->have_level};
+  pf->pre_snaps[s] = {pf->cur, pf->src, pf->src_stride, pf->src2, pf->src2_stride, pf->n_split, pf->anc_valid, pf->last_optimistic, pf->step, pf->t, pf->have_level, pf->wparity, pf->last_grp};
   rc = shard_prepare_step(pf, pf->d_recs + s, pf->h_recs[s].has_obs, sums5_dev);
   if (rc) return rc;
   pf->step++;
   pf->t = pf->h_recs[s].t_obs;
   if (!pf->h_recs[s].has_obs) path_after(pf, s);   // (a weighted observation: behind its resampling, cssm_pf_shard_adopt_spec / _adopt)
   if (pf->snaps.size() <= s) pf->snaps.resize(s + 1);
-  pf->snaps[s] = {pf->cur, pf->src, pf->src_stride, pf->src2, pf->src2_stride, pf->n_split, pf->anc_valid, pf->last_optimistic, pf->step, pf->t, pf->have_level};
+  pf->snaps[s] = {pf->cur, pf->src, pf->src_stride, pf->src2, pf->src2_stride, pf->n_split, pf->anc_valid, pf->last_optimistic, pf->step, pf->t, pf->have_level, pf->wparity, pf->last_grp};
   return CSSM_OK;
 }
 
@@ -412,7 +412,7 @@ extern "C" int cssm_pf_shard_resume(cssm_pf* pf, uint32_t* fail_step_out) {
   const cssm_pf::Snap& q = pf->snaps[s];
   pf->cur = q.cur; pf->src = q.src; pf->src_stride = q.src_stride; pf->src2 = q.src2; pf->src2_stride = q.src2_stride;
   pf->n_split = q.n_split; pf->anc_valid = q.anc_valid; pf->last_optimistic = q.last_optimistic; pf->step = q.step; pf->t = q.t;
-  pf->have_level = q.have_level;
+  pf->have_level = q.have_level; pf->wparity = q.wparity; pf->last_grp = q.last_grp;
   pf->sums_ready = true;   // (the exchange that missed ran behind them)
   *fail_step_out = s;
   return CSSM_OK;
@@ -444,7 +444,7 @@ extern "C" int cssm_pf_shard_resume_level(cssm_pf* pf, uint32_t* fail_step_out) 
   const cssm_pf::Snap& q = pf->pre_snaps[s];
   pf->cur = q.cur; pf->src = q.src; pf->src_stride = q.src_stride; pf->src2 = q.src2; pf->src2_stride = q.src2_stride;
   pf->n_split = q.n_split; pf->anc_valid = q.anc_valid; pf->last_optimistic = q.last_optimistic; pf->step = q.step; pf->t = q.t;
-  pf->have_level = q.have_level;
+  pf->have_level = q.have_level; pf->wparity = q.wparity; pf->last_grp = q.last_grp;
   pf->sums_ready = false;
   *fail_step_out = s;
   return CSSM_OK;
@@ -477,13 +477,16 @@ static int boundary_pack_impl(cssm_pf* pf, int rank, int world, int64_t cap, dou
   const uint32_t nsub = (uint32_t)((pf->n + chunk - 1) / chunk);
   const long long cnt = std::min<long long>((long long)pf->n, (long long)cap);
   const int tiles = (int)((cnt + CSSM_TILE - 1) / CSSM_TILE);
-  const bool pre = nsub <= 8u * CSSM_BLOCK;   // (the prefix block's reach)
+  // group sums at hand (the propagate's blocks accumulated them in set pf->wparity): the header blocks total those, and the offspring
+  // blocks of the launch behind this one take their prefixes from them -- no prefix block
+  const int grp_set = (pf->last_grp && pf->last_optimistic) ? pf->wparity : -1;
+  const bool pre = nsub <= 8u * CSSM_BLOCK && grp_set < 0;   // (the prefix block's reach)
   prof_begin(pf, CSSM_K_PACK);
   hipLaunchKernelGGL(k_boundary_pack, dim3(tiles + 2, world), dim3(CSSM_BLOCK), 0, pf->stream, pf->state[pf->cur], pf->stride, pf->logw, pf->n, pf->d,
                      world, rank, (long long)cap, pf->d_recs + slot, (const cssm_u128*)pf->tileS, (const cssm_u128*)pf->tileS2, nsub,
                      (const Scalars*)pf->sc, send_buf_dev, chunk, pf->last_optimistic ? 0 : 1,
                      pre ? pf->unitPre : (cssm_u128*)nullptr,
-                     peer ? (const PeerTable*)pf->peer_tab : (const PeerTable*)nullptr, (int)(pf->peer_seq & 1u), pf->peer_seq, pf->peer_tickets);
+                     peer ? (const PeerTable*)pf->peer_tab : (const PeerTable*)nullptr, (int)(pf->peer_seq & 1u), pf->peer_seq, pf->peer_tickets, grp_set);
   pf->spec_pre = pre;   // (k_offspring_expand_spec reads them: cssm_pf_shard_adopt_spec)
   prof_end(pf);
   HIP_TRY(hipGetLastError());
@@ -510,13 +513,17 @@ static int adopt_spec_impl(cssm_pf* pf, const double* recv_buf_dev, int rank, in
   // the 5 words of every rank are the header words 1..5 of its segment (the all-to-all delivered this rank's own too)
   const unsigned long long* all5 = reinterpret_cast<const unsigned long long*>(recv_buf_dev) + 1;
   const uint32_t n_split = (uint32_t)pf->n;
+  // the set of group sums of this observation (every exchange of the handle rotates it, whether the sums were used or not: block 0 of
+  // the offspring blocks clears the two other sets); grp: the propagate's blocks accumulated them -- the GRP instantiations
+  const int gset = pf->wparity;
+  const bool grp = pf->last_grp && pf->last_optimistic;
   prof_begin(pf, CSSM_K_EXPAND);
   if (merged) {
     if (!pf->last_optimistic) return fail(CSSM_ESTATE, "the merged peer exchange serves the propagate that formed the sums (levels known in advance)");
     const uint64_t chunk = (uint64_t)pf->sup * CSSM_TILE / pf->split;
     const uint32_t nsub = (uint32_t)((pf->n + chunk - 1) / chunk);
     const long long cnt = std::min<long long>((long long)pf->n, (long long)cap);
-    const bool pre = nsub <= 8u * CSSM_BLOCK;
+    const bool pre = nsub <= 8u * CSSM_BLOCK && !grp;
     PackArgs pk;
     pk.src = pf->state[pf->cur]; pk.stride = pf->stride; pk.nsub = nsub; pk.chunk = chunk;
     pk.pre_out = pre ? pf->unitPre : (cssm_u128*)nullptr;
@@ -524,19 +531,23 @@ static int adopt_spec_impl(cssm_pf* pf, const double* recv_buf_dev, int rank, in
     pk.pre_flag = pre ? pf->peer_tickets + 64 : (unsigned int*)nullptr;
     pk.pack_gx = (uint32_t)((cnt + CSSM_TILE - 1) / CSSM_TILE) + 2u;
     pf->spec_pre = pre;
-    auto kx = (pf->resampler == CSSM_RESAMPLE_STRATIFIED) ? k_exchange_offspring<2, CSSM_RESAMPLE_STRATIFIED> : k_exchange_offspring<2, CSSM_RESAMPLE_SYSTEMATIC>;
+    auto kx = (pf->resampler == CSSM_RESAMPLE_STRATIFIED)
+                  ? (grp ? k_exchange_offspring<2, CSSM_RESAMPLE_STRATIFIED, true> : k_exchange_offspring<2, CSSM_RESAMPLE_STRATIFIED>)
+                  : (grp ? k_exchange_offspring<2, CSSM_RESAMPLE_SYSTEMATIC, true> : k_exchange_offspring<2, CSSM_RESAMPLE_SYSTEMATIC>);
     hipLaunchKernelGGL(kx, dim3(tgrid + (int)(pk.pack_gx * (uint32_t)world)), dim3(CSSM_BLOCK), 0, pf->stream, pf->logw, pf->n, pf->sc,
                      (const cssm_u128*)pf->tileS, (const cssm_u128*)pf->tileS2, (const StepRec*)(pf->d_recs + slot), pf->n_global, pf->endslot,
-                     pf->anc, pf->ntiles, pf->sup, pf->nunits, 2, 0, (double*)nullptr, (int32_t*)nullptr, 0u, pf->opt_exact,
+                     pf->anc, pf->ntiles, pf->sup, pf->nunits, 2, gset, (double*)nullptr, (int32_t*)nullptr, 0u, pf->opt_exact,
                      all5, rank, world, (int)pf->split, pf->seed, (double*)nullptr, (const double*)pf->d_logtab,
                      2, (unsigned long long*)(pf->d_xch + 128), (uint32_t)pf->first, (uint32_t)(pf->first + pf->n), (uint32_t)seg,
                      recv_buf_dev, (long long)cap, pf->d, n_split, pre ? (const cssm_u128*)pf->unitPre : (const cssm_u128*)nullptr,
                      peer_flags, peer_seq, pk);
   } else if (pf->last_optimistic) {
-    auto ke = (pf->resampler == CSSM_RESAMPLE_STRATIFIED) ? k_offspring_expand_spec<2, CSSM_RESAMPLE_STRATIFIED> : k_offspring_expand_spec<2, CSSM_RESAMPLE_SYSTEMATIC>;
+    auto ke = (pf->resampler == CSSM_RESAMPLE_STRATIFIED)
+                  ? (grp ? k_offspring_expand_spec<2, CSSM_RESAMPLE_STRATIFIED, true> : k_offspring_expand_spec<2, CSSM_RESAMPLE_STRATIFIED>)
+                  : (grp ? k_offspring_expand_spec<2, CSSM_RESAMPLE_SYSTEMATIC, true> : k_offspring_expand_spec<2, CSSM_RESAMPLE_SYSTEMATIC>);
     hipLaunchKernelGGL(ke, dim3(tgrid), dim3(CSSM_BLOCK), 0, pf->stream, pf->logw, pf->n, pf->sc,
                      (const cssm_u128*)pf->tileS, (const cssm_u128*)pf->tileS2, (const StepRec*)(pf->d_recs + slot), pf->n_global, pf->endslot,
-                     pf->anc, pf->ntiles, pf->sup, pf->nunits, pf->last_optimistic ? 2 : 0, 0, (double*)nullptr, (int32_t*)nullptr, 0u, pf->opt_exact,
+                     pf->anc, pf->ntiles, pf->sup, pf->nunits, pf->last_optimistic ? 2 : 0, gset, (double*)nullptr, (int32_t*)nullptr, 0u, pf->opt_exact,
                      all5, rank, world, pf->last_optimistic ? (int)pf->split : 1, pf->seed, (double*)nullptr, (const double*)pf->d_logtab,
                      pf->last_optimistic ? 2 : 0, (unsigned long long*)(pf->d_xch + 128), (uint32_t)pf->first, (uint32_t)(pf->first + pf->n), (uint32_t)seg,
                      recv_buf_dev, (long long)cap, pf->d, n_split, pf->spec_pre ? (const cssm_u128*)pf->unitPre : (const cssm_u128*)nullptr,
@@ -545,7 +556,7 @@ static int adopt_spec_impl(cssm_pf* pf, const double* recv_buf_dev, int rank, in
     auto ke = (pf->resampler == CSSM_RESAMPLE_STRATIFIED) ? k_offspring_expand_spec<0, CSSM_RESAMPLE_STRATIFIED> : k_offspring_expand_spec<0, CSSM_RESAMPLE_SYSTEMATIC>;
     hipLaunchKernelGGL(ke, dim3(tgrid), dim3(CSSM_BLOCK), 0, pf->stream, pf->logw, pf->n, pf->sc,
                      (const cssm_u128*)pf->tileS, (const cssm_u128*)pf->tileS2, (const StepRec*)(pf->d_recs + slot), pf->n_global, pf->endslot,
-                     pf->anc, pf->ntiles, pf->sup, pf->nunits, pf->last_optimistic ? 2 : 0, 0, (double*)nullptr, (int32_t*)nullptr, 0u, pf->opt_exact,
+                     pf->anc, pf->ntiles, pf->sup, pf->nunits, pf->last_optimistic ? 2 : 0, gset, (double*)nullptr, (int32_t*)nullptr, 0u, pf->opt_exact,
                      all5, rank, world, pf->last_optimistic ? (int)pf->split : 1, pf->seed, (double*)nullptr, (const double*)pf->d_logtab,
                      pf->last_optimistic ? 2 : 0, (unsigned long long*)(pf->d_xch + 128), (uint32_t)pf->first, (uint32_t)(pf->first + pf->n), (uint32_t)seg,
                      recv_buf_dev, (long long)cap, pf->d, n_split, pf->spec_pre ? (const cssm_u128*)pf->unitPre : (const cssm_u128*)nullptr,
@@ -557,6 +568,7 @@ static int adopt_spec_impl(cssm_pf* pf, const double* recv_buf_dev, int rank, in
   pf->src2 = recv_buf_dev; pf->src2_stride = 0; pf->n_split = n_split; pf->anc_valid = true;   // stride 0 = rows of d + 1
   pf->wmode = pf->last_optimistic;
   pf->have_level = true;        // (its block 0 published the next observation's predicted level: LGCP)
+  pf->wparity = (pf->wparity + 1) % CSSM_MAXSETS;
   if (pf->series) path_after(pf, slot);   // (on hold after a capacity miss the slot index of a wrong row is overwritten when the observation is redone)
   return CSSM_OK;
 }

@@ -106,6 +106,12 @@ __global__ void k_peer_handshake(const PeerTable* __restrict__ peer, int world, 
   if (threadIdx.x == 0) result[0] = s_missing;
 }
 
+#ifdef CSSM_OFF_STAMPS
+__device__ unsigned long long g_spec_stamps[2048 * 8];   // diagnostic build: clock stamps of the exchange kernels' blocks (tools/exchange_stamps.py)
+#define CSSM_SPEC_STAMP(k) do { if (threadIdx.x == 0 && blockIdx.x < 2048) g_spec_stamps[blockIdx.x * 8 + (k)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define CSSM_SPEC_STAMP(k) do { } while (0)
+#endif
 // grid (tiles of the block + 1 for the header, destination rank); the weights are those k_propagate<SUMS> summed and stored,
 // exp(min(w - c, REF_BELOW)) -- or, with the level taken from the global max, exp(w - level) of the stored log-weights
 // peer != nullptr: the peer-written exchange -- `out` unused, segment rank -> q lands in peer->win[parity][q] + rank * seg,
@@ -118,7 +124,11 @@ __device__ __forceinline__ void boundary_pack_block(const uint32_t bx, const uin
                                                               const Scalars* __restrict__ sc, double* __restrict__ out, uint64_t chunk,
                                                               int level_from_max, cssm_u128* __restrict__ pre_out,
                                                               const PeerTable* __restrict__ peer, int parity, uint32_t seq,
-                                                              unsigned int* __restrict__ tickets, unsigned int* __restrict__ pre_flag) {
+                                                              unsigned int* __restrict__ tickets, unsigned int* __restrict__ pre_flag,
+                                                              const int grp_set = -1) {
+  // grp_set >= 0: k_propagate's blocks accumulated the sums (and sums of squares) of groups of 32 units in that set of Scalars::grp / grp2:
+  // the header block totals 2 x 32 group sums in ONE wave instead of 2 x nsub unit sums in four (it is the head of the exchange's critical
+  // path: every offspring block of every rank waits for it -- 3.4 us from entry to flag at 1024 units, tools/exchange_stamps.py)
   // bx / gx / q: the block's place in a (gx, world) grid -- blockIdx.x, gridDim.x, blockIdx.y of k_boundary_pack; the merged
   // exchange + offspring kernel of the peer-written exchange hands its first gx * world blocks through here
   // pre_flag (merged kernel; else nullptr): the prefix block announces pre_out with the exchange number (agent-scope release)
@@ -214,9 +224,11 @@ __device__ __forceinline__ void boundary_pack_block(const uint32_t bx, const uin
       __syncthreads();
       if (threadIdx.x == 0) __hip_atomic_store(pre_flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
     }
+    CSSM_SPEC_STAMP(6);
     return;
   }
   const bool header_block = (bx == gx - 2);
+  if (header_block) CSSM_SPEC_STAMP(4);
   if (!header_block) {
   if (cnt == 0) { if (held) return; peer_done(false); return; }
   // prefix of the tiles before this block's tile
@@ -282,6 +294,50 @@ __device__ __forceinline__ void boundary_pack_block(const uint32_t bx, const uin
   // requested before anything is summed: up to 4 sums and 4 sums of squares per thread (1024 sub-units), the max slots, the
   // boundary blocks' sub-unit sums (below).
   unsigned long long key = 0ull;
+  const long long cnt_all = ((long long)n_local < cap) ? (long long)n_local : cap;
+  cssm_u128 ptot[2];
+  {
+    // group sums at hand and both boundary blocks made of whole units: one round of loads, one wave each -- wave 0 the totals (lanes 0-31
+    // the groups' sums, lanes 32-63 their sums of squares), wave 1 the key of the max, waves 2 and 3 the boundary blocks' totals
+    const bool whole = (chunk % (uint64_t)CSSM_TILE == 0) && ((uint64_t)cnt_all % chunk == 0) && ((n_local - (uint64_t)cnt_all) % chunk == 0);
+    if (grp_set >= 0 && whole && !level_from_max) {   // (uniform)
+      static_assert(CSSM_GRP_MAX == 32, "one wave holds the groups' sums and their sums of squares");
+      __shared__ cssm_u128 s_pt[2];
+      __shared__ unsigned long long s_hkey;
+      if (wid == 0) {
+        const size_t at = ((size_t)grp_set * 2 * CSSM_GRP_MAX + (size_t)(lane & 31)) * CSSM_SLOT_STRIDE;
+        const unsigned long long* g = (lane < 32) ? &sc->grp[at] : &sc->grp2[at];
+        const unsigned long long l0 = g[0], l1 = g[(size_t)CSSM_GRP_MAX * CSSM_SLOT_STRIDE];   // the two limb sums a0, a1 (< 2^61 each) -> a0 + a1 2^56
+        cssm_u128 x, y;
+        x.lo = l0; x.hi = 0ull;
+        y.lo = l1 << CSSM_GRP_LIMB; y.hi = l1 >> (64 - CSSM_GRP_LIMB);
+        const cssm_u128 inc = wave_scan_u128(cssm_u128_add(x, y), lane);
+        cssm_u128 S, T;
+        S.lo = readlane_u64(inc.lo, 31); S.hi = readlane_u64(inc.hi, 31);
+        T.lo = readlane_u64(inc.lo, 63); T.hi = readlane_u64(inc.hi, 63);
+        if (lane == 0) {
+          cssm_u128 S2; S2.lo = T.lo - S.lo; S2.hi = T.hi - S.hi - (T.lo < S.lo ? 1ull : 0ull);
+          s_r[0][0] = S; s_r[1][0] = S2;
+#pragma unroll
+          for (int w = 1; w < CSSM_BLOCK / 64; ++w) { s_r[0][w] = cssm_u128_zero(); s_r[1][w] = cssm_u128_zero(); }
+        }
+      } else if (wid == 1) {
+        unsigned long long k = (lane < CSSM_MAXSLOTS) ? sc->maxslot[(size_t)lane * CSSM_SLOT_STRIDE] : 0ull;   // slot set 0 (sharded handles)
+        k = wave_max_u64(k);
+        if (lane == 0) s_hkey = k;
+      } else {
+        const int which = wid - 2;
+        const uint64_t bfirst = which ? n_local - (uint64_t)cnt_all : 0;
+        const uint32_t b0 = (uint32_t)(bfirst / chunk), nch = (uint32_t)((uint64_t)cnt_all / chunk);
+        cssm_u128 c = cssm_u128_zero();
+        for (uint32_t t = (uint32_t)lane; t < nch; t += 64u) c = cssm_u128_add(c, subS[b0 + t]);
+        c = wave_sum_u128(c);
+        if (lane == 0) s_pt[which] = c;
+      }
+      __syncthreads();
+      key = s_hkey;
+      ptot[0].lo = s_pt[0].lo; ptot[0].hi = s_pt[0].hi; ptot[1].lo = s_pt[1].lo; ptot[1].hi = s_pt[1].hi;
+    } else {
   if (level_from_max) {
     key = cssm_order_key(sc->gmax);                    // (the slots were exported and cleared before the all-gather)
   } else if (threadIdx.x < 64) {
@@ -294,7 +350,6 @@ __device__ __forceinline__ void boundary_pack_block(const uint32_t bx, const uin
     a4[k] = (i < nsub) ? subS[i] : cssm_u128_zero();
     b4[k] = (i < nsub) ? subS2[i] : cssm_u128_zero();
   }
-  const long long cnt_all = ((long long)n_local < cap) ? (long long)n_local : cap;
   cssm_u128 p2[2] = {cssm_u128_zero(), cssm_u128_zero()};
   bool al2[2];
 #pragma unroll
@@ -317,7 +372,6 @@ __device__ __forceinline__ void boundary_pack_block(const uint32_t bx, const uin
   if (!level_from_max && threadIdx.x < 64) key = wave_max_u64(key);
   // total weights of the rank's FIRST-cap and LAST-cap blocks (both travel in every header; the LAST one gives the base)
   const uint32_t ntile = (uint32_t)((cnt_all + CSSM_TILE - 1) / CSSM_TILE);
-  cssm_u128 ptot[2];
 #pragma unroll
   for (int which = 0; which < 2; ++which) {
     const uint64_t bfirst = which ? n_local - (uint64_t)cnt_all : 0;
@@ -342,6 +396,8 @@ __device__ __forceinline__ void boundary_pack_block(const uint32_t bx, const uin
     }
     ptot[which] = acc;
   }
+    }
+  }
   if (held) return;
   if (threadIdx.x == 0) {
     cssm_u128 S = s_r[0][0], S2 = s_r[1][0];
@@ -357,6 +413,7 @@ __device__ __forceinline__ void boundary_pack_block(const uint32_t bx, const uin
     oseg[10] = cssm_u2d(ptot[1].lo); oseg[11] = cssm_u2d(ptot[1].hi);
   }
   peer_done(true);
+  CSSM_SPEC_STAMP(5);
 }
 
 __global__ __launch_bounds__(CSSM_BLOCK) void k_boundary_pack(const double* __restrict__ src, size_t stride, const double* __restrict__ logw,
@@ -366,9 +423,9 @@ __global__ __launch_bounds__(CSSM_BLOCK) void k_boundary_pack(const double* __re
                                                               const Scalars* __restrict__ sc, double* __restrict__ out, uint64_t chunk,
                                                               int level_from_max, cssm_u128* __restrict__ pre_out,
                                                               const PeerTable* __restrict__ peer = nullptr, int parity = 0, uint32_t seq = 0u,
-                                                              unsigned int* __restrict__ tickets = nullptr) {
+                                                              unsigned int* __restrict__ tickets = nullptr, int grp_set = -1) {
   boundary_pack_block(blockIdx.x, gridDim.x, (int)blockIdx.y, src, stride, logw, n_local, d, world, rank, cap, rec, subS, subS2, nsub, sc, out, chunk,
-                      level_from_max, pre_out, peer, parity, seq, tickets, nullptr);
+                      level_from_max, pre_out, peer, parity, seq, tickets, nullptr, grp_set);
 }
 
 // After the all-to-all: every segment's rows -> the slots of this rank they own.  Global cumulative weight of row i of
@@ -488,7 +545,7 @@ __device__ __forceinline__ bool spec_read_headers(SpecHeaders& H, int world, int
 __device__ __forceinline__ void expand_spec_body(SpecHeaders& H, uint32_t bid, uint32_t nblk, const double* __restrict__ recv, int world, int rank,
                                                  long long cap, int d, uint32_t n_split, uint64_t slot_lo, uint64_t slot_hi, uint64_t n_global,
                                                  const StepRec* __restrict__ rec, uint32_t* __restrict__ anc, Scalars* __restrict__ sc,
-                                                 int rs = CSSM_RESAMPLE_SYSTEMATIC, uint64_t seed = 0) {
+                                                 int rs = CSSM_RESAMPLE_SYSTEMATIC, uint64_t seed = 0, int grp_cur = 0) {
   __shared__ uint32_t s_nheavy;
   __shared__ uint32_t s_hb[CSSM_BLOCK], s_he[CSSM_BLOCK], s_hj[CSSM_BLOCK];
   const long long R = d + 1, HD = spec_hdr(d), seg = spec_seg(d, cap);
@@ -504,6 +561,16 @@ __device__ __forceinline__ void expand_spec_body(SpecHeaders& H, uint32_t bid, u
     return pow2 ? cssm_sys_count_pow2(C, u, n_global, inv_n) : cssm_sys_count(C, u, n_global);
   };
   if (bid == 0 && threadIdx.x < CSSM_MAXSLOTS) sc->maxslot[(size_t)threadIdx.x * CSSM_SLOT_STRIDE] = 0ull;   // set 0 for the next step
+  // ... and the two sets of group sums this observation did not use (grp_cur: the set of this one; the handle's exchanges rotate through
+  // the three -- the next propagate adds to set grp_cur + 1, the one after to the set the observation before this one used)
+  if (bid == 0) {
+    static_assert(2 * 2 * CSSM_GRP_MAX <= CSSM_BLOCK, "one store per thread and array");
+    if (threadIdx.x < 2 * 2 * CSSM_GRP_MAX) {
+      const uint32_t tq2 = threadIdx.x;
+      const size_t at = ((size_t)((grp_cur + 1 + (int)(tq2 / (2 * CSSM_GRP_MAX))) % CSSM_MAXSETS) * 2 * CSSM_GRP_MAX + tq2 % (2 * CSSM_GRP_MAX)) * CSSM_SLOT_STRIDE;
+      sc->grp[at] = 0ull; sc->grp2[at] = 0ull;
+    }
+  }
   // Only the two adjacent ranks' rows can own slots of this rank: the verdict established that its slots below the own
   // particles' first one all belong to the last-cap block of rank - 1 and those above to the first-cap block of rank + 1.
   // The rows are spread evenly over ALL blocks of the launch (a share of ceil(2 cap / blocks) each, done after the
@@ -561,15 +628,12 @@ __device__ __forceinline__ void expand_spec_body(SpecHeaders& H, uint32_t bid, u
 // observation's exchange is redone -- and records err bit 3 and the observation index: every later kernel of the series returns
 // at once (they test the bit), and the host redoes this observation's exchange with a larger capacity and carries on
 // (cssm_pf_shard_resume).
-#ifdef CSSM_OFF_STAMPS
-__device__ unsigned long long g_spec_stamps[2048 * 8];   // diagnostic build: clock stamps of k_offspring_expand_spec's blocks
-#define CSSM_SPEC_STAMP(k) do { if (threadIdx.x == 0 && blockIdx.x < 2048) g_spec_stamps[blockIdx.x * 8 + (k)] = __builtin_amdgcn_s_memrealtime(); } while (0)
-#else
-#define CSSM_SPEC_STAMP(k) do { } while (0)
-#endif
 // RAWC: how the weights are stored, at compile time (2: the weights k_propagate_shard formed relative to the reference level; 0:
 // log-weights, rescaled by the level the global max gave -- LGCP, a series repeated after an outlying observation)
-template <int RAWC, int RS>
+// GRP (RAWC == 2; slot_set = the set of Scalars::grp the propagate's blocks added to): the block's prefix INSIDE the rank comes from 32 group
+// sums + the 32 unit sums of its own group (as in k_offspring_self<..., GRP>), so nothing is waited for but the peers' headers -- no prefix
+// block, no pre_flag -- and everything local (first tile on the grid and scanned, that prefix) is done BEFORE the wait.
+template <int RAWC, int RS, bool GRP = false>
 __device__ __forceinline__ void offspring_expand_spec_body(
     CSSM_OFFSPRING_PARAMS, uint32_t all5_stride, const double* __restrict__ recv, long long cap, int d, uint32_t n_split,
     const cssm_u128* __restrict__ unit_pre, const unsigned int* __restrict__ peer_flags, uint32_t peer_seq,
@@ -609,12 +673,52 @@ __device__ __forceinline__ void offspring_expand_spec_body(
     return true;
   };
   double pre_w[CSSM_ITEMS];
+  if constexpr (GRP) {
+    static_assert(RAWC == 2, "group sums: behind a propagate that formed the sums");
+    const bool pre_ok = bidx < nunits;                       // (uniform; a launch with the group sums has exactly nunits offspring blocks)
+    if (pre_ok) load_tile_raw(logw, (uint64_t)bidx * sup * CSSM_TILE, n, RAWC, pre_w);
+    const uint32_t held0 = sc->err;
+    const double rec_ref = rec->ref, rec_u = rec->u;
+    if (held0 & (4u | 8u | 16u)) return;                     // (on hold / void / a peer missing: nobody delivers, nobody waits)
+    bool mid_ok = false;                                     // (the body called mid and it said yes: this block resampled)
+    auto mid = [&](SpecTotals& tt) -> bool {
+      if (peer_flags != nullptr && !wait_flags(0u, nullptr, 0, world - 1)) return false;   // every rank's header
+      CSSM_SPEC_STAMP(7);
+      const SpecHdrRegs hregs = spec_load_headers(recv, world, cap, d);
+      spec_store_headers(H, hregs, world, cap);
+      if (optimistic && !(cssm_ref_choose(rec_ref, cssm_order_unkey(H.gkey)) == rec_ref)) {   // (see below: the level first)
+        if (bidx == 0 && threadIdx.x == 0) { atomicMin(&sc->fail_step, rec->step); atomicOr(&sc->err, 4u); }
+        return false;
+      }
+      if (bidx == 0 && !spec_read_headers(H, world, rank, cap, d, n, n_global, rec_u, RS, seed, rec->step)) {   // (block 0's business alone: see below)
+        if (threadIdx.x == 0) { atomicOr(&sc->err, 8u); atomicMin(&sc->fail_step, rec->step); }
+        return false;
+      }
+      CSSM_SPEC_STAMP(1);
+      tt.S_off.lo = H.off[rank].lo; tt.S_off.hi = H.off[rank].hi; tt.tot.lo = H.tot.lo; tt.tot.hi = H.tot.hi;
+      tt.tot2.lo = H.tot2.lo; tt.tot2.hi = H.tot2.hi; tt.gmax = cssm_order_unkey(H.gkey);
+      mid_ok = true;
+      return true;
+    };
+    (void)raw; (void)unit_pre; (void)pre_flag;
+    offspring_body<true, false, RS, RAWC, true, decltype(mid)>(logw, n, sc, unitP, unitS2, rec, n_global, /*endslot=*/nullptr, anc, ntiles, sup, nunits, RAWC, slot_set,
+                                                               /*ll_t=*/nullptr, /*ess_t=*/nullptr, 0u, force_exact, all5, rank, world, split, seed,
+                                                               /*cum_out=*/nullptr, /*logtab=*/nullptr, optimistic, flag_out, slot_lo, slot_hi, all5_stride,
+                                                               /*s2buf=*/nullptr, 0u, -1, 0u, /*unit_pre=*/nullptr, blk0, pre_ok ? pre_w : nullptr, nullptr, &mid);
+    if (!mid_ok) return;   // (the body returned without resampling -- the level ruled out, block 0's verdict, a peer missing: no tail either)
+    CSSM_SPEC_STAMP(2);
+    if (peer_flags != nullptr && !wait_flags(CSSM_PEER_FLAG_ROWS, nullptr, rank - 1, rank + 1)) return;
+    expand_spec_body(H, bidx, nblk, recv, world, rank, cap, d, n_split, (uint64_t)slot_lo, (uint64_t)slot_hi, n_global, rec, anc, sc, RS, seed, slot_set);
+    CSSM_SPEC_STAMP(3);
+    return;
+  }
   const bool prefetched = peer_flags != nullptr && bidx < nunits;   // (uniform)
   if (peer_flags != nullptr) {
     // the block's first tile of weights is requested BEFORE the wait (it depends on nothing the peers send)
     if (prefetched) load_tile_raw(logw, (uint64_t)bidx * sup * CSSM_TILE, n, RAWC, pre_w);
     if (sc->err & (4u | 8u | 16u)) return;   // (on hold / void / a peer missing: nobody delivers, nobody waits)
     if (!wait_flags(0u, pre_flag, 0, world - 1)) return;          // every rank's header (and this launch's unit-sum prefixes)
+    CSSM_SPEC_STAMP(7);
   }
   // everything the verdict starts from is requested first, tested afterwards
   const uint32_t held = sc->err;
@@ -656,15 +760,15 @@ __device__ __forceinline__ void offspring_expand_spec_body(
   CSSM_SPEC_STAMP(2);
   // the two neighbours' rows (their flags have long been set: the rows were written while this block resampled its own particles)
   if (peer_flags != nullptr && !wait_flags(CSSM_PEER_FLAG_ROWS, nullptr, rank - 1, rank + 1)) return;
-  expand_spec_body(H, bidx, nblk, recv, world, rank, cap, d, n_split, (uint64_t)slot_lo, (uint64_t)slot_hi, n_global, rec, anc, sc, RS, seed);
+  expand_spec_body(H, bidx, nblk, recv, world, rank, cap, d, n_split, (uint64_t)slot_lo, (uint64_t)slot_hi, n_global, rec, anc, sc, RS, seed, slot_set);
   CSSM_SPEC_STAMP(3);
 }
 
-template <int RAWC, int RS = CSSM_RESAMPLE_SYSTEMATIC>
+template <int RAWC, int RS = CSSM_RESAMPLE_SYSTEMATIC, bool GRP = false>
 __global__ __launch_bounds__(CSSM_BLOCK, CSSM_OFF_WAVES) void k_offspring_expand_spec(
     CSSM_OFFSPRING_PARAMS, uint32_t all5_stride, const double* __restrict__ recv, long long cap, int d, uint32_t n_split,
     const cssm_u128* __restrict__ unit_pre, const unsigned int* __restrict__ peer_flags = nullptr, uint32_t peer_seq = 0u) {
-  offspring_expand_spec_body<RAWC, RS>(CSSM_OFFSPRING_FWD, all5_stride, recv, cap, d, n_split, unit_pre, peer_flags, peer_seq, 0u, nullptr);
+  offspring_expand_spec_body<RAWC, RS, GRP>(CSSM_OFFSPRING_FWD, all5_stride, recv, cap, d, n_split, unit_pre, peer_flags, peer_seq, 0u, nullptr);
 }
 
 // The peer-written exchange in ONE launch per weighted observation behind the propagate: the first pack_gx * world blocks of the grid
@@ -676,7 +780,9 @@ struct PackArgs {
   const double* src; size_t stride; uint32_t nsub; uint64_t chunk; cssm_u128* pre_out;
   const PeerTable* peer; int parity; unsigned int* tickets; unsigned int* pre_flag; uint32_t pack_gx;
 };
-template <int RAWC, int RS = CSSM_RESAMPLE_SYSTEMATIC>
+// GRP: the group sums are at hand (slot_set = their set): the header blocks total them, the offspring blocks take their prefixes from them
+// (pk.pre_out == nullptr: the prefix block of every destination leaves at once)
+template <int RAWC, int RS = CSSM_RESAMPLE_SYSTEMATIC, bool GRP = false>
 __global__ __launch_bounds__(CSSM_BLOCK, CSSM_OFF_WAVES) void k_exchange_offspring(
     CSSM_OFFSPRING_PARAMS, uint32_t all5_stride, const double* __restrict__ recv, long long cap, int d, uint32_t n_split,
     const cssm_u128* __restrict__ unit_pre, const unsigned int* __restrict__ peer_flags, uint32_t peer_seq, PackArgs pk) {
@@ -684,10 +790,10 @@ __global__ __launch_bounds__(CSSM_BLOCK, CSSM_OFF_WAVES) void k_exchange_offspri
   if (blockIdx.x < blk0) {
     boundary_pack_block(blockIdx.x % pk.pack_gx, pk.pack_gx, (int)(blockIdx.x / pk.pack_gx), pk.src, pk.stride, logw, n, d, world, rank, cap, rec,
                         unitP, unitS2, pk.nsub, sc, nullptr, pk.chunk, /*level_from_max=*/0, pk.pre_out, pk.peer, pk.parity, peer_seq, pk.tickets,
-                        pk.pre_flag);
+                        pk.pre_flag, GRP ? slot_set : -1);
     return;
   }
-  offspring_expand_spec_body<RAWC, RS>(CSSM_OFFSPRING_FWD, all5_stride, recv, cap, d, n_split, unit_pre, peer_flags, peer_seq, blk0, pk.pre_flag);
+  offspring_expand_spec_body<RAWC, RS, GRP>(CSSM_OFFSPRING_FWD, all5_stride, recv, cap, d, n_split, unit_pre, peer_flags, peer_seq, blk0, pk.pre_flag);
 }
 
 __global__ __launch_bounds__(CSSM_BLOCK) void k_expand(const uint32_t* __restrict__ cand_end, const uint32_t* __restrict__ cand_idx,
