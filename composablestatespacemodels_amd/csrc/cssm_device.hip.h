@@ -89,6 +89,10 @@ struct Scalars {
   // batch call of generation pend_gen is still the one running), or the host when a call ends (cssm_ess_of, same arithmetic).
   uint32_t pend, pend_buf, pend_n, pend_idx, pend_gen, pad3_;
   cssm_u128 pend_S;          // S_tot of that observation
+  // (peer-written exchange) how long a reader polls for a peer's words before it gives up (err bit 4), in ticks of the constant 100 MHz
+  // clock (s_memrealtime): wall-clock time, not an iteration count -- a rank that compiles a kernel, a loaded host or a debugger may be
+  // seconds late without being dead.  Set with the scalars (reset_scalars) from the handle's CSSM_PEER_TIMEOUT_MS (default 30 s).
+  unsigned long long peer_wait_ticks;
 };
 
 // BATCHED independent filters (cssm_batch.hip: B clouds of one model structure -- the chains of a PMMH run, a pilot grid of

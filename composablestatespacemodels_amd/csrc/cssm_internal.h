@@ -105,6 +105,7 @@ struct cssm_pf : HostModel {
   size_t sm_cap = 0; int sm_blocks = 0; double sm_time = 0.0;
   // peer-written exchange (cssm_shard.hip: PeerState; the device table and the ticket counters k_boundary_pack uses)
   void* peer = nullptr; void* peer_tab = nullptr; unsigned int* peer_tickets = nullptr;
+  unsigned long long peer_wait_ticks = 3000000000ull;   // 30 s of the 100 MHz clock (CSSM_PEER_TIMEOUT_MS): Scalars::peer_wait_ticks
   uint32_t peer_seq = 0;       // number of the last exchange enqueued on the peer windows (window = seq & 1; the flags carry it)
   bool peer_packed = false;    // cssm_pf_shard_pack_peer ran, cssm_pf_shard_adopt_peer has not yet
   bool want_path = false;      // sharded `filter`: record sampleOne's pick after every observation whose slot this rank owns

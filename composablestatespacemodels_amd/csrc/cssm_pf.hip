@@ -71,6 +71,7 @@ static int alloc_handle(cssm_pf* pf) {
   HIP_TRY(hipEventCreate(&pf->ev0));
   HIP_TRY(hipEventCreate(&pf->ev1));
   { const char* e = getenv("CSSM_LOOP_EVENTS"); pf->opt_events = (e && e[0] == '1') ? 1 : 0; }   // (measurement scripts: the default of CSSM_OPT_LOOP_EVENTS)
+  { const char* e = getenv("CSSM_PEER_TIMEOUT_MS"); if (e && atof(e) > 0.0) pf->peer_wait_ticks = (unsigned long long)(atof(e) * 1e5); }
   { const char* e = getenv("CSSM_GRP_MIN_UNITS"); if (e && atoi(e) >= 1) pf->grp_min_units = (uint32_t)atoi(e); }   // (tests: small clouds through the group sums)
   HIP_TRY(hipDeviceGetAttribute(&pf->n_cus, hipDeviceAttributeMultiprocessorCount, pf->device));
   pf->stride = (size_t)((pf->n + CSSM_TILE - 1) / CSSM_TILE) * CSSM_TILE;   // rows start 16-B aligned
@@ -212,6 +213,7 @@ static int reset_scalars(cssm_pf* pf) {
   h.ess = (int32_t)(pf->n_global < 2147483647ull ? pf->n_global : 2147483647ull);
   h.fail_step = 0xffffffffu;
   h.next_ref = cssm_nan();      // (LGCP: no weighted observation yet whose max could predict a level)
+  h.peer_wait_ticks = pf->peer_wait_ticks;
   // pageable source: the copy is staged before the call returns, so a stack object is safe
   HIP_TRY(hipMemcpyAsync(pf->sc, &h, sizeof h, hipMemcpyHostToDevice, pf->stream));
   return CSSM_OK;

@@ -180,12 +180,23 @@ __device__ __forceinline__ void propagate_range(
   };
   // (every gather source is allocated with 16 spare bytes: the 16-byte fetch of the last element of a buffer stays inside it)
   auto stage_issue = [&](const uint32_t (&j)[IT]) {
+    // (sharded filter) rows received from the neighbouring ranks are gathered by the slots next to the rank's two ends only -- ancestors
+    // are monotone in the slot --: a wave none of whose indices reaches them (wave-uniform test) addresses the local cloud alone, with
+    // the row base in scalar registers, instead of forming both addresses and a select per element (~25 VALU instructions per particle
+    // at d = 3: most of what k_propagate_shard cost beyond k_propagate_self)
+    bool local_only = (src2 == nullptr);
+    if (src2 != nullptr) {
+      uint32_t jm = j[0];
+#pragma unroll
+      for (int r = 1; r < IT; ++r) jm = (j[r] > jm) ? j[r] : jm;
+      local_only = !__any(jm >= n_split);
+    }
 #pragma unroll
     for (int r = 0; r < IT; ++r)
 #pragma unroll
       for (int k = 0; k < D; ++k) {
         // (src2 == nullptr is uniform: without candidates from other ranks the row base stays in scalar registers)
-        const double* g = (src2 == nullptr) ? src + (size_t)k * src_stride + j[r] : ptr_of(j[r], k);
+        const double* g = local_only ? src + (size_t)k * src_stride + j[r] : ptr_of(j[r], k);
         const uint32_t slot = wstage_lds + (uint32_t)((r * D + k) * 64 * ES);
         if (ES == 16) {
           lds_dma16(g, slot);

@@ -713,7 +713,7 @@ extern "C" int cssm_pf_shard_peer_handshake(cssm_pf* pf, uint32_t token) {
   if (!ps || !ps->connected) return fail(CSSM_ESTATE, "peer windows are not set up (cssm_pf_shard_peer_setup / _connect)");
   if (token == 0u) return fail(CSSM_EINVAL_ARG, "the token must not be zero (the flags start there)");
   unsigned int* res = pf->peer_tickets + 96;   // (a word of the ticket allocation nobody else uses)
-  hipLaunchKernelGGL(k_peer_handshake, dim3(1), dim3(64), 0, pf->stream, (const PeerTable*)pf->peer_tab, ps->world, ps->rank, token, res);
+  hipLaunchKernelGGL(k_peer_handshake, dim3(1), dim3(64), 0, pf->stream, (const PeerTable*)pf->peer_tab, ps->world, ps->rank, token, res, pf->peer_wait_ticks);
   HIP_TRY(hipGetLastError());
   unsigned int missing = 0u;
   HIP_TRY(hipMemcpyAsync(&missing, res, sizeof missing, hipMemcpyDeviceToHost, pf->stream));

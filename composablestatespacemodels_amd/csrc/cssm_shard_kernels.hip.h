@@ -79,16 +79,50 @@ struct PeerTable {
   double* win[2][64];              // win[p][q]: base of rank q's receive window p (world segments; segment r = what rank r wrote)
   unsigned int* flag[2][64];       // flag[p][q]: rank q's flags of window p, two 64-byte lines per source rank: header, rows
 };
-#define CSSM_PEER_FLAG_STRIDE 32   /* uint32 words between the flags of consecutive source ranks (header flag at 0, rows flag at 16) */
+#define CSSM_PEER_FLAG_STRIDE 96   /* uint32 words between the flags of consecutive source ranks (header flag at 0, rows flag at 16, the header itself at 32) */
 #define CSSM_PEER_FLAG_ROWS 16
-#define CSSM_PEER_SPIN_LIMIT (1u << 22)   /* polls (~1 us each) before a reader gives up: err bit 4 (16) */
+// The header a SECOND time, as 24 self-validating 8-byte words behind the flags (word w = exchange number << 32 | half w of the 12 header
+// doubles): an 8-byte store is atomic, so a reader that sees the exchange number in a word holds its data -- no flag to wait for first and
+// no release in front of it (the header flag's system-scope release is an L2 write-back of the writing XCD).  The group-sum launches
+// read these (one round trip from "the peer's header block has stored" to "this block has the header" instead of two); the flag and the
+// header in the window stay for the readers that do not (small shards).
+#define CSSM_PEER_FLAG_LL 32
+#define CSSM_PEER_LL_WORDS 24
+// A reader polls until the word it waits for holds the exchange number or `ticks` of the constant 100 MHz clock have gone by (wall-clock
+// time: Scalars::peer_wait_ticks); the clock is read every 64th poll
+__device__ __forceinline__ bool peer_poll_u32(const unsigned int* f, unsigned int want, unsigned long long ticks) {
+  unsigned long long t0 = 0ull;
+  unsigned int polls = 0u;
+  while (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != want) {
+    if ((++polls & 63u) == 0u) {
+      const unsigned long long now = __builtin_amdgcn_s_memrealtime();
+      if (t0 == 0ull) t0 = now; else if (now - t0 > ticks) return false;
+    }
+    __builtin_amdgcn_s_sleep(4);
+  }
+  return true;
+}
+__device__ __forceinline__ bool peer_poll_ll(const unsigned long long* f, unsigned int want, unsigned long long ticks, unsigned int& half) {
+  unsigned long long t0 = 0ull, v;
+  unsigned int polls = 0u;
+  while ((unsigned int)((v = __hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)) >> 32) != want) {
+    if ((++polls & 63u) == 0u) {
+      const unsigned long long now = __builtin_amdgcn_s_memrealtime();
+      if (t0 == 0ull) t0 = now; else if (now - t0 > ticks) return false;
+    }
+    __builtin_amdgcn_s_sleep(2);
+  }
+  half = (unsigned int)v;
+  return true;
+}
 
 #define CSSM_PEER_FLAG_HELLO 8    /* word of a source rank's flag pair that cssm_pf_shard_peer_handshake uses */
 // One round of the protocol with nothing attached, run by every rank at once right after the windows were mapped: thread q writes a
 // token where rank q looks for this rank's (system-scope release) and waits, bounded, for rank q's token in this rank's own flags.
 // result[0] = number of ranks whose token did not arrive.  A rank whose mapping, peer access or cross-GPU visibility does not work
 // shows up here, on the host, before a series depends on it.
-__global__ void k_peer_handshake(const PeerTable* __restrict__ peer, int world, int rank, uint32_t token, unsigned int* __restrict__ result) {
+__global__ void k_peer_handshake(const PeerTable* __restrict__ peer, int world, int rank, uint32_t token, unsigned int* __restrict__ result,
+                                 unsigned long long wait_ticks) {
   __shared__ unsigned int s_missing;
   if (threadIdx.x == 0) s_missing = 0u;
   __syncthreads();
@@ -96,11 +130,7 @@ __global__ void k_peer_handshake(const PeerTable* __restrict__ peer, int world, 
   if (q < world) {
     __hip_atomic_store(peer->flag[0][q] + (size_t)rank * CSSM_PEER_FLAG_STRIDE + CSSM_PEER_FLAG_HELLO, token, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     const unsigned int* f = peer->flag[0][rank] + (size_t)q * CSSM_PEER_FLAG_STRIDE + CSSM_PEER_FLAG_HELLO;
-    unsigned int spins = 0u;
-    while (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != token) {
-      if (++spins > CSSM_PEER_SPIN_LIMIT) { atomicAdd(&s_missing, 1u); break; }
-      __builtin_amdgcn_s_sleep(16);
-    }
+    if (!peer_poll_u32(f, token, wait_ticks)) atomicAdd(&s_missing, 1u);
   }
   __syncthreads();
   if (threadIdx.x == 0) result[0] = s_missing;
@@ -399,18 +429,30 @@ __device__ __forceinline__ void boundary_pack_block(const uint32_t bx, const uin
     }
   }
   if (held) return;
+  __shared__ unsigned long long s_hw[12];
   if (threadIdx.x == 0) {
     cssm_u128 S = s_r[0][0], S2 = s_r[1][0];
 #pragma unroll
     for (int w = 1; w < CSSM_BLOCK / 64; ++w) { S = cssm_u128_add(S, s_r[0][w]); S2 = cssm_u128_add(S2, s_r[1][w]); }
     cssm_u128 bs = cssm_u128_zero();
     if (q > rank) { bs.lo = S.lo - ptot[1].lo; bs.hi = S.hi - ptot[1].hi - (S.lo < ptot[1].lo ? 1u : 0u); }
-    oseg[0] = (double)cnt;
-    oseg[1] = cssm_u2d(S.lo); oseg[2] = cssm_u2d(S.hi); oseg[3] = cssm_u2d(S2.lo); oseg[4] = cssm_u2d(S2.hi);
-    oseg[5] = cssm_u2d(key);
-    oseg[6] = cssm_u2d(bs.lo); oseg[7] = cssm_u2d(bs.hi);
-    oseg[8] = cssm_u2d(ptot[0].lo); oseg[9] = cssm_u2d(ptot[0].hi);
-    oseg[10] = cssm_u2d(ptot[1].lo); oseg[11] = cssm_u2d(ptot[1].hi);
+    s_hw[0] = cssm_d2u((double)cnt);
+    s_hw[1] = S.lo; s_hw[2] = S.hi; s_hw[3] = S2.lo; s_hw[4] = S2.hi;
+    s_hw[5] = key;
+    s_hw[6] = bs.lo; s_hw[7] = bs.hi;
+    s_hw[8] = ptot[0].lo; s_hw[9] = ptot[0].hi;
+    s_hw[10] = ptot[1].lo; s_hw[11] = ptot[1].hi;
+  }
+  __syncthreads();
+  if (peer != nullptr && threadIdx.x < CSSM_PEER_LL_WORDS) {   // the self-validating copy first: it is what the group-sum readers wait for
+    const unsigned long long hw = s_hw[threadIdx.x >> 1];
+    const unsigned long long half = (threadIdx.x & 1u) ? (hw >> 32) : (hw & 0xffffffffull);
+    unsigned long long* ll = reinterpret_cast<unsigned long long*>(peer->flag[parity][q] + (size_t)rank * CSSM_PEER_FLAG_STRIDE + CSSM_PEER_FLAG_LL);
+    __hip_atomic_store(ll + threadIdx.x, ((unsigned long long)seq << 32) | half, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+  if (threadIdx.x == 0) {
+#pragma unroll
+    for (int w = 0; w < 12; ++w) oseg[w] = cssm_u2d(s_hw[w]);
   }
   peer_done(true);
   CSSM_SPEC_STAMP(5);
@@ -649,6 +691,7 @@ __device__ __forceinline__ void offspring_expand_spec_body(
   __shared__ SpecHeaders H;
   CSSM_SPEC_STAMP(0);
   __shared__ unsigned int s_late;
+  const unsigned long long wait_ticks = (peer_flags != nullptr) ? sc->peer_wait_ticks : 0ull;   // (requested with the block's first loads)
   // thread r waits for rank r's flag (word `which` of its pair: 0 header, CSSM_PEER_FLAG_ROWS rows), thread `world` for the local
   // flag `extra` if there is one; false: some flag did not come within the bound (err bit 4, the series ends like one on hold)
   auto wait_flags = [&](uint32_t which, const unsigned int* extra, int r_lo, int r_hi) -> bool {
@@ -657,13 +700,9 @@ __device__ __forceinline__ void offspring_expand_spec_body(
     const int r = (int)threadIdx.x;
     if ((r >= r_lo && r <= r_hi && r < world) || (r == world && extra != nullptr)) {
       const unsigned int* f = (r < world) ? peer_flags + (size_t)r * CSSM_PEER_FLAG_STRIDE + which : extra;
-      unsigned int spins = 0u;
       // (relaxed system-scope loads: each one reads the flag at the point of coherence; the window itself is read with such loads
       //  too -- ld_sys, no fence: see there -- and the next kernel's gathers start behind a kernel boundary)
-      while (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != peer_seq) {
-        if (++spins > CSSM_PEER_SPIN_LIMIT) { s_late = 1u; break; }
-        __builtin_amdgcn_s_sleep(4);
-      }
+      if (!peer_poll_u32(f, peer_seq, wait_ticks)) s_late = 1u;
     }
     __syncthreads();
     if (s_late) {
@@ -681,10 +720,38 @@ __device__ __forceinline__ void offspring_expand_spec_body(
     const double rec_ref = rec->ref, rec_u = rec->u;
     if (held0 & (4u | 8u | 16u)) return;                     // (on hold / void / a peer missing: nobody delivers, nobody waits)
     bool mid_ok = false;                                     // (the body called mid and it said yes: this block resampled)
+    __shared__ uint32_t s_ll[64 * CSSM_PEER_LL_WORDS];      // the ranks' headers as they arrive: 24 halves per rank
     auto mid = [&](SpecTotals& tt) -> bool {
-      if (peer_flags != nullptr && !wait_flags(0u, nullptr, 0, world - 1)) return false;   // every rank's header
-      CSSM_SPEC_STAMP(7);
-      const SpecHdrRegs hregs = spec_load_headers(recv, world, cap, d);
+      SpecHdrRegs hregs;
+      if (peer_flags != nullptr) {
+        // every rank's header through its self-validating words: thread (r, w) polls word w of rank r and keeps its half
+        if (threadIdx.x == 0) s_late = 0u;
+        __syncthreads();
+        for (uint32_t i = threadIdx.x; i < (uint32_t)world * CSSM_PEER_LL_WORDS; i += CSSM_BLOCK) {
+          const uint32_t r = i / CSSM_PEER_LL_WORDS, w = i % CSSM_PEER_LL_WORDS;
+          const unsigned long long* f = reinterpret_cast<const unsigned long long*>(peer_flags + (size_t)r * CSSM_PEER_FLAG_STRIDE + CSSM_PEER_FLAG_LL) + w;
+          unsigned int half = 0u;
+          if (!peer_poll_ll(f, peer_seq, wait_ticks, half)) { s_late = 1u; break; }
+          s_ll[i] = half;
+        }
+        __syncthreads();
+        if (s_late) {
+          if (threadIdx.x == 0) { atomicOr(&sc->err, 16u); atomicMin(&sc->fail_step, rec->step); }
+          return false;
+        }
+        CSSM_SPEC_STAMP(7);
+#pragma unroll
+        for (int k = 0; k < 12; ++k) hregs.w[k] = 0.0;
+        if ((int)threadIdx.x < world) {
+          const uint32_t* h = s_ll + threadIdx.x * CSSM_PEER_LL_WORDS;
+          auto hw = [&](int k) { return cssm_u2d((unsigned long long)h[2 * k] | ((unsigned long long)h[2 * k + 1] << 32)); };
+          // (the order of spec_load_headers: count, S, base, the two block totals, S2, the key)
+          hregs.w[0] = hw(0); hregs.w[1] = hw(1); hregs.w[2] = hw(2); hregs.w[3] = hw(6); hregs.w[4] = hw(7); hregs.w[5] = hw(8); hregs.w[6] = hw(9);
+          hregs.w[7] = hw(10); hregs.w[8] = hw(11); hregs.w[9] = hw(3); hregs.w[10] = hw(4); hregs.w[11] = hw(5);
+        }
+      } else {
+        hregs = spec_load_headers(recv, world, cap, d);
+      }
       spec_store_headers(H, hregs, world, cap);
       if (optimistic && !(cssm_ref_choose(rec_ref, cssm_order_unkey(H.gkey)) == rec_ref)) {   // (see below: the level first)
         if (bidx == 0 && threadIdx.x == 0) { atomicMin(&sc->fail_step, rec->step); atomicOr(&sc->err, 4u); }
