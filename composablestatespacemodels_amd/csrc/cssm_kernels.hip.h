@@ -495,7 +495,11 @@ __device__ __forceinline__ void offspring_body(const double* __restrict__ logw, 
         upre[0].lo = g[0]; upre[0].hi = g[(size_t)CSSM_GRP_MAX * CSSM_SLOT_STRIDE];   // the two limb sums
       } else {
         const uint32_t q = (grp_unit / CSSM_GRP_UNITS) * CSSM_GRP_UNITS + (l - (uint32_t)CSSM_GRP_MAX);
-        if (q < nunits) upre[0] = unitP[q];
+        if (q < nunits) {
+          upre[0] = unitP[(size_t)q * (uint32_t)split];
+          // (a shard whose propagate ran `split` blocks per unit -- the LGCP: its sums are the blocks')
+          if (!SELF) for (uint32_t sb = 1; sb < (uint32_t)split; ++sb) upre[0] = cssm_u128_add(upre[0], unitP[(size_t)q * (uint32_t)split + sb]);
+        }
       }
     }
   } else if (SELF) {

@@ -61,7 +61,22 @@ static uint32_t auto_split(const cssm_pf* pf) {
   //  2^21 particles per rank, one round of whole-unit blocks running in lockstep being 12 % slower per particle than the same kernel on
   //  several rounds; but the exchange kernel's header and prefix blocks, which every block of every rank waits for, then total twice
   //  the sums: 18.5 -> 20.4 us, the step 89.5 -> 90.3)
-  if (pf->sharded || pf->sup != 1 || pf->n >= CSSM_SPLIT_MAX_N) return 1u;
+  if (pf->sharded) {
+    // an LGCP shard whose units have several tiles: blocks of HALF a unit -- whole-unit blocks all start together (1024 of them, one
+    // round) and run in lockstep, so every memory wait of the prologue and of the tile boundaries is exposed; half-unit blocks run in
+    // two staggered rounds (k_propagate 71.8 -> 68.4 us at 2^21 particles per rank).  The exchange kernels do not see the difference
+    // any more: they read the sums of groups of units (Scalars::grp), to which every block adds its own.  CSSM_SHARD_LGCP_SPLIT: 1, 2, 4.
+    if (pf->obs_kind != CSSM_OBS_LGCP || pf->sup < 2) return 1u;
+    uint32_t want = 2u;
+    if (const char* e = getenv("CSSM_SHARD_LGCP_SPLIT")) { const int v = atoi(e); if (v == 1 || v == 2 || v == 4) want = (uint32_t)v; }
+    // (whole tiles of 1024: the exchange's pack blocks take the prefix of a boundary block's tiles from the blocks' sums only then --
+    //  quarter-unit blocks of 512 particles at 2^21 per rank sent them down their recompute path: 39 us per exchange)
+    while (want > 1u && ((uint64_t)pf->sup * CSSM_TILE / want) % (uint64_t)CSSM_TILE != 0) want >>= 1;
+    const uint64_t unit_particles = (uint64_t)pf->sup * CSSM_TILE;
+    if (!(pf->opt_grp && pf->nunits >= pf->grp_min_units && pf->nunits <= (uint32_t)(CSSM_GRP_MAX * CSSM_GRP_UNITS) && unit_particles <= CSSM_GRP_MAX_UNIT)) want = 1u;   // (no group sums: whole units)
+    return want;
+  }
+  if (pf->sup != 1 || pf->n >= CSSM_SPLIT_MAX_N) return 1u;
   return cssm_prop_items(pf->d) == 1 ? 4u : 2u;   // one tile of the kernel: half of 1024 (two particles per thread), a quarter (one)
 }
 
@@ -375,10 +390,10 @@ int cssm_launch_propagate(cssm_pf* pf, const StepRec* d_rec, double* pick_out, u
   // bit 8 of the set argument of k_propagate_self and k_offspring_self), which k_offspring then reads instead of every unit sum
   // (a shard: the same, in Scalars::grp and grp2 -- both sums travel in the exchange's headers --, the set rotating with the handle's
   //  weighted observations while its max slots stay in set 0; the exchange kernels read 32 group sums instead of every unit sum)
-  pf->last_grp = do_sums && !fine && pf->split == 1 && chunk == unit_particles && (pf->sharded || (pf->first == 0 && pf->n == pf->n_global)) &&
+  pf->last_grp = do_sums && !fine && chunk * pf->split == unit_particles && (pf->sharded ? pf->split <= 4u : (pf->split == 1 && pf->first == 0 && pf->n == pf->n_global)) &&
                  pf->nunits >= pf->grp_min_units && pf->nunits <= (uint32_t)(CSSM_GRP_MAX * CSSM_GRP_UNITS) && unit_particles <= CSSM_GRP_MAX_UNIT && pf->opt_grp;
   const bool want_grp = pf->last_grp;
-  if (want_grp) a.slot_set |= 0x100 | (pf->wparity << 9);
+  if (want_grp) a.slot_set |= 0x100 | (pf->wparity << 9) | ((pf->split == 4u ? 2 : (pf->split == 2u ? 1 : 0)) << 11);
   a.src2 = anc ? pf->src2 : nullptr; a.src2_stride = pf->src2_stride; a.n_split = pf->n_split; a.logtab = pf->d_logtab;
   a.chunk = chunk; a.do_sums = do_sums; a.subS = fine ? pf->fineS : pf->tileS; a.subS2 = fine ? pf->fineS2 : pf->tileS2;
   a.pick_out = pick_out; a.pick_slot = pick_slot;

@@ -452,6 +452,7 @@ __device__ __forceinline__ void propagate_range(
   acc.S = accS; acc.S2 = accS2; acc.tmax = tmax; acc.bad = bad;
 }
 
+static_assert(CSSM_GRP_UNITS == 32, "group index = block >> (5 + log2(blocks per unit))");
 // A unit's sum (and, squares: its sum of squared weights) added to its group's: two 56-bit limbs each, non-returning atomics on lines of
 // their own (Scalars::grp / grp2; integer sums: any order, the same bits).  One thread of the unit's block calls it.
 __device__ __forceinline__ void group_sums_add(Scalars* __restrict__ sc, int set, uint32_t group, cssm_u128 ta, cssm_u128 tb, bool squares) {
@@ -485,6 +486,7 @@ __global__ __launch_bounds__(CSSM_BLOCK, (PropWaves<D, SUMS>::value)) void k_pro
   const int slot_set = slot_set_arg & 0xff;
   const bool grp_on = (slot_set_arg & 0x100) != 0;
   const int grp_set = (slot_set_arg >> 9) & 3;
+  const int grp_shift = 5 + ((slot_set_arg >> 11) & 3);
   // (sharded series) the exchange of an earlier observation did not fit: the series is on hold and nothing may change
   // until the host resumes it (cssm_pf_shard_resume)
   // bit 3: a sharded series is on hold (capacity miss); bit 6: a single-GPU batch series waits for the redo of an outlying
@@ -532,7 +534,7 @@ __global__ __launch_bounds__(CSSM_BLOCK, (PropWaves<D, SUMS>::value)) void k_pro
       for (int w = 1; w < CSSM_BLOCK / 64; ++w) { ta = cssm_u128_add(ta, s_sa[w]); if (SUMS == 2) tb = cssm_u128_add(tb, s_sb[w]); }
       subS[blockIdx.x] = ta;
       if (SUMS == 2) subS2[blockIdx.x] = tb;
-      if (grp_on) group_sums_add(sc, grp_set, blockIdx.x / CSSM_GRP_UNITS, ta, tb, SUMS == 2);   // (uniform)
+      if (grp_on) group_sums_add(sc, grp_set, blockIdx.x >> grp_shift, ta, tb, SUMS == 2);   // (uniform)
     }
   } else {
     __syncthreads();
@@ -568,6 +570,7 @@ __device__ __forceinline__ void propagate_block(
   const int slot_set = slot_set_arg & 0xff;
   const bool grp_on = (slot_set_arg & 0x100) != 0;
   const int grp_set = (slot_set_arg >> 9) & 3;
+  const int grp_shift = 5 + ((slot_set_arg >> 11) & 3);    // log2(blocks per group): 32 units x (1, 2 or 4 blocks per unit: bits 11-12)
   // SUMS: the block also forms its fixed-point sums of exp(w - c) (subS / subS2, one entry per block) and, for `filter`,
   // records the state sampleOne picked after the previous observation (pick_out / pick_slot; see k_propagate)
   __shared__ double s_max[CSSM_BLOCK / 64];
@@ -655,7 +658,7 @@ __device__ __forceinline__ void propagate_block(
       for (int w = 1; w < CSSM_BLOCK / 64; ++w) { ta = cssm_u128_add(ta, s_sa[w]); if (SUMS == 2) tb = cssm_u128_add(tb, s_sb[w]); }
       subS[blockIdx.x] = ta;
       if (SUMS == 2) subS2[blockIdx.x] = tb;
-      if (grp_on) group_sums_add(sc, grp_set, blockIdx.x / CSSM_GRP_UNITS, ta, tb, SUMS == 2);   // (uniform) Scalars::grp / grp2
+      if (grp_on) group_sums_add(sc, grp_set, blockIdx.x >> grp_shift, ta, tb, SUMS == 2);   // (uniform) Scalars::grp / grp2
     }
   } else {
     __syncthreads();
@@ -720,6 +723,9 @@ __global__ __launch_bounds__(CSSM_BLOCK, (ONE ? 2 : PropWaves<D, 2>::value)) voi
     cssm_u128* __restrict__ subS, cssm_u128* __restrict__ subS2, uint32_t step_now, int slot_set) {
   // slot_set: max-slot set 0 in bits 0-7; bit 8 / bits 9-10: group sums wanted (one block per unit) and their set (propagate_block)
   if (MKW != 0u) { mk.comp[0] = MKW; mk.comp[1] = MKW1; mk.comp[2] = MKW2; }
-  propagate_block<D, IT, OBS, 2, ONE>(src, src_stride, anc, dst, dst_stride, logw, n_arg, seed, rec, mk, sc, slot_set, logtab, chunk, subS, subS2,
+#ifndef CSSM_EXP_SHARD_SUMS
+#define CSSM_EXP_SHARD_SUMS 2
+#endif
+  propagate_block<D, IT, OBS, CSSM_EXP_SHARD_SUMS, ONE>(src, src_stride, anc, dst, dst_stride, logw, n_arg, seed, rec, mk, sc, slot_set, logtab, chunk, subS, subS2,
                                       nullptr, 0u, gid0, src2, n_split, step_now);
 }

@@ -111,3 +111,26 @@ def test_group_sum_shards_lgcp_and_stratified(peer):
     np.testing.assert_array_equal(np.concatenate([s.particles() for s in shards], axis=1), opart)
     for s in shards:
         s.close()
+
+
+@pytest.mark.native_threshold
+@pytest.mark.parametrize("split,peer", [("1", True), ("2", True), ("4", False), ("2", False)])
+def test_lgcp_shards_with_several_propagate_blocks_per_unit(split, peer, monkeypatch):
+    """An LGCP shard of 2^21 particles has units of two tiles; its propagate runs blocks of HALF a unit (CSSM_SHARD_LGCP_SPLIT = 2, the
+    default; 4: a quarter), every block adding its sums to its unit's group (Scalars::grp / grp2) and the exchange's offspring blocks
+    adding up their group's block sums: the same bits as whole-unit blocks and as the single-GPU handle (2 shards of 2^21 here)."""
+    from composablestatespacemodels_amd.filter import NativePf
+    monkeypatch.setenv("CSSM_SHARD_LGCP_SPLIT", split)
+    model, n, world = cases.c4_model(), 1 << 22, 2
+    t, y, has = cases.event_times(5, horizon=2.0)
+    g = NativePf(model, n, cases.SEED, lgcp_precision=2)
+    ll1, _, ess1, _ = g.run(t, y, has)
+    ref = g.particles()
+    g.close()
+    shards, f = _filters(model, n, world, peer, prec=2)
+    ll, ess = f.ll_filter(t[:3], y[:3], has[:3], lgcp=True)
+    ll, ess = f.ll_filter_more(t[3:], y[3:], has[3:], lgcp=True)
+    assert (ll, ess) == (ll1, int(ess1[-1]))
+    for s in shards:
+        np.testing.assert_array_equal(s.particles(), ref[:, s.first:s.first + s.n])
+        s.close()
