@@ -137,6 +137,7 @@ SYMBOLS = [
     ("cssm_pf_shard_peer_setup", C.c_int, [_h, C.c_int, C.c_int, C.c_int64, C.POINTER(PeerHandle)]),
     ("cssm_pf_shard_peer_connect", C.c_int, [_h, C.POINTER(PeerHandle), C.c_int]),
     ("cssm_pf_shard_peer_handshake", C.c_int, [_h, C.c_uint32]),
+    ("cssm_pf_shard_peer_probe_stale", C.c_uint32, [_h]),
     ("cssm_pf_shard_peer_close", None, [_h]),
     ("cssm_pf_shard_pack_peer", C.c_int, [_h, C.c_int, C.c_int, C.c_int64]),
     ("cssm_pf_shard_adopt_peer", C.c_int, [_h, C.c_int, C.c_int, C.c_int64]),

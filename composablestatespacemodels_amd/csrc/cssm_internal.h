@@ -107,6 +107,7 @@ struct cssm_pf : HostModel {
   void* peer = nullptr; void* peer_tab = nullptr; unsigned int* peer_tickets = nullptr;
   unsigned long long peer_wait_ticks = 3000000000ull;   // 30 s of the 100 MHz clock (CSSM_PEER_TIMEOUT_MS): Scalars::peer_wait_ticks
   uint32_t peer_seq = 0;       // number of the last exchange enqueued on the peer windows (window = seq & 1; the flags carry it)
+  uint32_t peer_probe_plain_bad = 0;   // cssm_pf_shard_peer_probe_stale
   bool peer_packed = false;    // cssm_pf_shard_pack_peer ran, cssm_pf_shard_adopt_peer has not yet
   bool want_path = false;      // sharded `filter`: record sampleOne's pick after every observation whose slot this rank owns
   uint32_t rec_base = 0;       // observation index (pf->step) of the resident series' first record: 0 after _begin, the filter's

@@ -969,8 +969,8 @@ static __global__ void k_gather(const double* __restrict__ src, size_t src_strid
   for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
     const size_t j = anc ? (size_t)anc[i] : (size_t)i;
     for (int k = 0; k < d; ++k)
-      out[(size_t)k * out_stride + i] = (src2 && j >= n_split)
-          ? (src2_stride == 0 ? src2[(size_t)(j - n_split) * (size_t)(d + 1) + k] : src2[(size_t)k * src2_stride + (j - n_split)])
+      out[(size_t)k * out_stride + i] = (src2 && j >= n_split)   // (rows received from other ranks: system-scope loads, as everywhere a window is read)
+          ? (src2_stride == 0 ? ld_sys_f64(src2 + (size_t)(j - n_split) * (size_t)(d + 1) + k) : ld_sys_f64(src2 + (size_t)k * src2_stride + (j - n_split)))
           : src[(size_t)k * src_stride + j];
   }
 }
@@ -1071,7 +1071,7 @@ __global__ __launch_bounds__(CSSM_BLOCK) void k_summary_fill(const double* __res
 #pragma unroll
     for (int k = 0; k < D; ++k) {
       x[k] = (src2 && j >= n_split)
-          ? (src2_stride == 0 ? src2[(size_t)(j - n_split) * (size_t)(D + 1) + k] : src2[(size_t)k * src2_stride + (j - n_split)])
+          ? (src2_stride == 0 ? ld_sys_f64(src2 + (size_t)(j - n_split) * (size_t)(D + 1) + k) : ld_sys_f64(src2 + (size_t)k * src2_stride + (j - n_split)))
           : src[(size_t)k * src_stride + j];
       keys[(size_t)k * kstride + i] = cssm_order_key(x[k]);
       acc[k] += x[k];

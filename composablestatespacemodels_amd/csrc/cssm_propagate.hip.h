@@ -176,7 +176,7 @@ __device__ __forceinline__ void propagate_range(
 #pragma unroll
     for (int r = 0; r < IT; ++r)
 #pragma unroll
-      for (int k = 0; k < D; ++k) x[r][k] = *ptr_of(j[r], k);
+      for (int k = 0; k < D; ++k) x[r][k] = (src2 && j[r] >= n_split) ? ld_sys_f64(ptr_of(j[r], k)) : *ptr_of(j[r], k);
   };
   // (every gather source is allocated with 16 spare bytes: the 16-byte fetch of the last element of a buffer stays inside it)
   auto stage_issue = [&](const uint32_t (&j)[IT]) {
@@ -198,6 +198,20 @@ __device__ __forceinline__ void propagate_range(
         // (src2 == nullptr is uniform: without candidates from other ranks the row base stays in scalar registers)
         const double* g = local_only ? src + (size_t)k * src_stride + j[r] : ptr_of(j[r], k);
         const uint32_t slot = wstage_lds + (uint32_t)((r * D + k) * 64 * ES);
+        if (!local_only && j[r] >= n_split) {
+          // a row another rank wrote into this rank's receive window (or an all-to-all delivered): read with a SYSTEM-scope load, like
+          // everything else that reads a window (ld_sys), and put into the lane's staging slot by hand -- what this GPU's caches may
+          // still hold of the window's previous use never answers it.  The few lanes next to the rank's ends take this path.
+          const double v = ld_sys_f64(g);
+          unsigned char* sl = wstage + (size_t)((r * D + k) * 64 * ES);
+          const uint32_t lane = threadIdx.x & 63;
+          if (ES == 16) {
+            *reinterpret_cast<double*>(sl + lane * 16) = v;
+          } else {
+            *reinterpret_cast<uint32_t*>(sl + lane * 4) = (uint32_t)cssm_d2u(v);
+            *reinterpret_cast<uint32_t*>(sl + 256 + lane * 4) = (uint32_t)(cssm_d2u(v) >> 32);
+          }
+        } else
         if (ES == 16) {
           lds_dma16(g, slot);
         } else {

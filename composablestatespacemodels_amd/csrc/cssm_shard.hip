@@ -104,7 +104,7 @@ __global__ void k_pick_shard(const double* __restrict__ src, size_t src_stride, 
   if (k >= d) return;
   const size_t j = anc ? (size_t)anc[idx] : (size_t)idx;
   out_row[k] = (src2 && j >= n_split)
-      ? (src2_stride == 0 ? src2[(size_t)(j - n_split) * (size_t)(d + 1) + k] : src2[(size_t)k * src2_stride + (j - n_split)])
+      ? (src2_stride == 0 ? ld_sys_f64(src2 + (size_t)(j - n_split) * (size_t)(d + 1) + k) : ld_sys_f64(src2 + (size_t)k * src2_stride + (j - n_split)))
       : src[(size_t)k * src_stride + j];
 }
 static int path_prepare(cssm_pf* pf, size_t T) {
@@ -408,6 +408,8 @@ extern "C" int cssm_pf_shard_resume(cssm_pf* pf, uint32_t* fail_step_out) {
   // only err and fail_step change on the device (ll, ess, sums stay what the last completed observation left)
   HIP_TRY(hipMemcpyAsync(&pf->sc->err, &h.err, sizeof(uint32_t), hipMemcpyHostToDevice, pf->stream));
   HIP_TRY(hipMemcpyAsync(&pf->sc->fail_step, &h.fail_step, sizeof(uint32_t), hipMemcpyHostToDevice, pf->stream));
+  // (pack blocks of the held launches that returned without their ticket while siblings took theirs would leave a count behind)
+  if (pf->peer_tickets) HIP_TRY(hipMemsetAsync(pf->peer_tickets, 0, 96 * sizeof(unsigned int), pf->stream));
   HIP_TRY(hipStreamSynchronize(pf->stream));
   const cssm_pf::Snap& q = pf->snaps[s];
   pf->cur = q.cur; pf->src = q.src; pf->src_stride = q.src_stride; pf->src2 = q.src2; pf->src2_stride = q.src2_stride;
@@ -440,6 +442,7 @@ extern "C" int cssm_pf_shard_resume_level(cssm_pf* pf, uint32_t* fail_step_out) 
   h.err &= ~4u; h.fail_step = 0xffffffffu;
   HIP_TRY(hipMemcpyAsync(&pf->sc->err, &h.err, sizeof(uint32_t), hipMemcpyHostToDevice, pf->stream));
   HIP_TRY(hipMemcpyAsync(&pf->sc->fail_step, &h.fail_step, sizeof(uint32_t), hipMemcpyHostToDevice, pf->stream));
+  if (pf->peer_tickets) HIP_TRY(hipMemsetAsync(pf->peer_tickets, 0, 96 * sizeof(unsigned int), pf->stream));
   HIP_TRY(hipStreamSynchronize(pf->stream));
   const cssm_pf::Snap& q = pf->pre_snaps[s];
   pf->cur = q.cur; pf->src = q.src; pf->src_stride = q.src_stride; pf->src2 = q.src2; pf->src2_stride = q.src2_stride;
@@ -686,6 +689,11 @@ extern "C" int cssm_pf_shard_peer_connect(cssm_pf* pf, const cssm_peer_handle* a
   for (int q = 0; q < world; ++q) {
     if (all[q].bytes != (uint64_t)ps->slab_bytes) return fail(CSSM_ESHARD, "rank %d set its windows up for another capacity or world (%llu bytes, %zu here)", q, (unsigned long long)all[q].bytes, ps->slab_bytes);
     void* base = nullptr;
+    // windows that another GPU or another process writes while kernels of this one run must be fine-grained memory: without it nothing
+    // says when the writes become visible here.  No silent use of plain device memory (CSSM_PEER_COARSE=1 asks for it by name: A/B on one GPU)
+    if (q != ps->rank && !ps->slab_fine && (all[q].pid != me || all[q].device != pf->device) && getenv("CSSM_PEER_COARSE") == nullptr)
+      return fail(CSSM_ESHARD, "this rank's receive windows are not fine-grained device memory (hipExtMallocWithFlags refused) and rank %d writes them from "
+                               "another %s: the peer-written exchange is refused", q, all[q].pid != me ? "process" : "device");
     if (q == ps->rank) base = ps->slab;
     else if (all[q].pid == me) base = (void*)(uintptr_t)all[q].local_ptr;       // a shard of this process
     else {
@@ -712,15 +720,25 @@ extern "C" int cssm_pf_shard_peer_handshake(cssm_pf* pf, uint32_t token) {
   PeerState* ps = static_cast<PeerState*>(pf->peer);
   if (!ps || !ps->connected) return fail(CSSM_ESTATE, "peer windows are not set up (cssm_pf_shard_peer_setup / _connect)");
   if (token == 0u) return fail(CSSM_EINVAL_ARG, "the token must not be zero (the flags start there)");
-  unsigned int* res = pf->peer_tickets + 96;   // (a word of the ticket allocation nobody else uses)
-  hipLaunchKernelGGL(k_peer_handshake, dim3(1), dim3(64), 0, pf->stream, (const PeerTable*)pf->peer_tab, ps->world, ps->rank, token, res, pf->peer_wait_ticks);
+  if (ps->seg < (size_t)CSSM_PEER_PROBE_WORDS) return fail(CSSM_ESHARD, "peer handshake: segments of %zu doubles are too small for the probe", ps->seg);
+  unsigned int* res = pf->peer_tickets + 96;   // (words of the ticket allocation nobody else uses: [0] missing tokens, [1] / [2] probe words read wrongly)
+  HIP_TRY(hipMemsetAsync(res, 0, 4 * sizeof(unsigned int), pf->stream));
+  hipLaunchKernelGGL(k_peer_handshake, dim3(1), dim3(64), 0, pf->stream, (const PeerTable*)pf->peer_tab, ps->world, ps->rank, token, res, pf->peer_wait_ticks, ps->seg);
+  // ... and, behind a kernel boundary as the propagate is behind the exchange: what the peers' handshake kernels wrote into this rank's window
+  hipLaunchKernelGGL(k_peer_verify, dim3(1), dim3(CSSM_BLOCK), 0, pf->stream, (const double*)peer_window(ps, ps->slab, 0), ps->world, token, ps->seg, res);
   HIP_TRY(hipGetLastError());
-  unsigned int missing = 0u;
-  HIP_TRY(hipMemcpyAsync(&missing, res, sizeof missing, hipMemcpyDeviceToHost, pf->stream));
+  unsigned int got[4] = {0u, 0u, 0u, 0u};
+  HIP_TRY(hipMemcpyAsync(got, res, sizeof got, hipMemcpyDeviceToHost, pf->stream));
   HIP_TRY(hipStreamSynchronize(pf->stream));
-  if (missing) return fail(CSSM_ESHARD, "peer handshake: the tokens of %u of %d ranks did not arrive in this rank's windows", missing, ps->world);
+  pf->peer_probe_plain_bad = got[2];
+  if (got[0]) return fail(CSSM_ESHARD, "peer handshake: the tokens of %u of %d ranks did not arrive in this rank's windows within the wait bound", got[0], ps->world);
+  if (got[1]) return fail(CSSM_ESHARD, "peer handshake: %u probe words the peers wrote into this rank's window read wrongly (system-scope loads behind the flag): "
+                                        "peer-written windows are not coherent on this system", got[1]);
   return CSSM_OK;
 }
+// probe words of the last handshake that PLAIN loads of the window read wrongly while system-scope loads read them right (diagnostic: the
+// library reads windows with system-scope loads only)
+extern "C" uint32_t cssm_pf_shard_peer_probe_stale(const cssm_pf* pf) { return pf ? pf->peer_probe_plain_bad : 0u; }
 
 extern "C" void cssm_pf_shard_peer_close(cssm_pf* pf) {
   if (!pf) return;

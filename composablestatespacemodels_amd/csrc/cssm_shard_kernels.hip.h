@@ -121,13 +121,26 @@ __device__ __forceinline__ bool peer_poll_ll(const unsigned long long* f, unsign
 // token where rank q looks for this rank's (system-scope release) and waits, bounded, for rank q's token in this rank's own flags.
 // result[0] = number of ranks whose token did not arrive.  A rank whose mapping, peer access or cross-GPU visibility does not work
 // shows up here, on the host, before a series depends on it.
+// ... with a PAYLOAD: before the token, thread q stores CSSM_PEER_PROBE_WORDS doubles -- a function of (token, source rank, index) --
+// at the head of segment `rank` of rank q's window 0, with the plain stores + system-scope fence + release the pack blocks use for rows;
+// k_peer_verify, a launch of its own BEHIND this one, reads what the peers left in this rank's window with the loads the propagate reads
+// rows with (system-scope) AND with plain ones, and counts what differs.  The host runs two rounds with different tokens: a line of
+// round one that some cache of this GPU kept would answer round two's plain loads with the wrong pattern (reported, not fatal: plain
+// loads of a window are not on any data path).
+#define CSSM_PEER_PROBE_WORDS 16
+__device__ __forceinline__ double peer_probe_word(uint32_t token, int src_rank, int i) {
+  return cssm_u2d(0x3ff0000000000000ull | ((unsigned long long)token << 16) | ((unsigned long long)(src_rank & 0xff) << 8) | (unsigned long long)(i & 0xff));
+}
 __global__ void k_peer_handshake(const PeerTable* __restrict__ peer, int world, int rank, uint32_t token, unsigned int* __restrict__ result,
-                                 unsigned long long wait_ticks) {
+                                 unsigned long long wait_ticks, size_t seg) {
   __shared__ unsigned int s_missing;
   if (threadIdx.x == 0) s_missing = 0u;
   __syncthreads();
   const int q = (int)threadIdx.x;
   if (q < world) {
+    double* w = peer->win[0][q] + (size_t)rank * seg;
+    for (int i = 0; i < CSSM_PEER_PROBE_WORDS; ++i) w[i] = peer_probe_word(token, rank, i);
+    __threadfence_system();
     __hip_atomic_store(peer->flag[0][q] + (size_t)rank * CSSM_PEER_FLAG_STRIDE + CSSM_PEER_FLAG_HELLO, token, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     const unsigned int* f = peer->flag[0][rank] + (size_t)q * CSSM_PEER_FLAG_STRIDE + CSSM_PEER_FLAG_HELLO;
     if (!peer_poll_u32(f, token, wait_ticks)) atomicAdd(&s_missing, 1u);
@@ -142,6 +155,17 @@ __device__ unsigned long long g_spec_stamps[2048 * 8];   // diagnostic build: cl
 #else
 #define CSSM_SPEC_STAMP(k) do { } while (0)
 #endif
+// result[1] += probe words of this rank's window 0 that system-scope loads read wrongly, result[2] += those that plain loads read wrongly
+__global__ void k_peer_verify(const double* __restrict__ win0, int world, uint32_t token, size_t seg, unsigned int* __restrict__ result) {
+  const int q = (int)(threadIdx.x / CSSM_PEER_PROBE_WORDS), i = (int)(threadIdx.x % CSSM_PEER_PROBE_WORDS);
+  for (int r = q; r < world; r += (int)(blockDim.x / CSSM_PEER_PROBE_WORDS)) {
+    const double* w = win0 + (size_t)r * seg + i;
+    const unsigned long long want = cssm_d2u(peer_probe_word(token, r, i));
+    if (cssm_d2u(ld_sys_f64(w)) != want) atomicAdd(&result[1], 1u);
+    if (cssm_d2u(*reinterpret_cast<const volatile double*>(w)) != want) atomicAdd(&result[2], 1u);
+  }
+}
+
 // grid (tiles of the block + 1 for the header, destination rank); the weights are those k_propagate<SUMS> summed and stored,
 // exp(min(w - c, REF_BELOW)) -- or, with the level taken from the global max, exp(w - level) of the stored log-weights
 // peer != nullptr: the peer-written exchange -- `out` unused, segment rank -> q lands in peer->win[parity][q] + rank * seg,

@@ -185,6 +185,10 @@ class GpuShard:
     def peer_handshake(self, token: int):
         _abi.check(self.lib.cssm_pf_shard_peer_handshake(self._h, int(token)))
 
+    def peer_probe_stale(self) -> int:
+        """Probe words of the last handshake that plain loads read wrongly while system-scope loads read them right (diagnostic)."""
+        return int(self.lib.cssm_pf_shard_peer_probe_stale(self._h))
+
     def peer_ready(self, cap: int) -> bool:
         return bool(getattr(self, "_peer_ready", False)) and getattr(self, "_peer_cap", None) == int(cap)
 
@@ -529,9 +533,14 @@ class ShardedFilter:
         if agreed("connect", lambda s: s.peer_connect(every)) is None:
             return False
         comm.barrier()
-        self._peer_token = getattr(self, "_peer_token", 0) + 1
-        if len(S) == 1 and agreed("handshake", lambda s: s.peer_handshake(self._peer_token)) is None:
-            return False      # (several shards of one process share a stream: a handshake kernel of one would wait for the next one's)
+        if len(S) == 1:       # (several shards of one process share a stream: a handshake kernel of one would wait for the next one's)
+            # two rounds with different tokens and payloads (`agreed` ends in a collective: every rank has read round one's words before
+            # anybody writes round two's): the second finds a window line that a cache kept from the first
+            for rnd in ("handshake", "handshake, second round"):
+                self._peer_token = getattr(self, "_peer_token", 0) + 1
+                if agreed(rnd, lambda s: s.peer_handshake(self._peer_token)) is None:
+                    return False
+            self.peer_probe_stale = max(s.peer_probe_stale() for s in S)
         comm.barrier()
         return True
 
@@ -545,7 +554,7 @@ class ShardedFilter:
     # library-driven series: 1 = equal-split all-to-all of whole segments (default), 2 = all-to-all-v trimmed to what is read
     # (whole segments between adjacent ranks, the 12 header words between all other pairs).  Mode 2 moves (world - 3) segments
     # fewer per rank and observation but has never run on more than one real GPU: it is opt-in (CSSM_SHARD_TRIM=1) until
-    # it has; LocalCommTrimmed (above) checks its claim -- nothing but the header of a non-adjacent segment is ever
+    # it has; LocalCommTrimmed (tests/local_comm.py) checks its claim -- nothing but the header of a non-adjacent segment is ever
     # read -- on one GPU.
     SINGLE_MODE = 1
     last_resumes = 0

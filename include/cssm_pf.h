@@ -529,6 +529,13 @@ int cssm_pf_shard_peer_connect(cssm_pf* pf, const cssm_peer_handle* all_handles,
  * in its own -- called by all ranks at the same point right after connecting: a mapping, peer access or cross-GPU visibility that does
  * not work surfaces here, as CSSM_ESHARD on the host, before a series depends on it. */
 int cssm_pf_shard_peer_handshake(cssm_pf* pf, uint32_t token);
+/* (round 5) The handshake also carries a PAYLOAD: every rank stores 16 probe words (a function of token, source rank and index) at the
+ * head of its segment in every peer's window 0 ahead of its token, the way the exchange's pack blocks store rows; a second launch behind
+ * the handshake reads what the peers left in this rank's window with system-scope loads -- what every kernel of the library reads a
+ * window with -- and CSSM_ESHARD names how many words read wrongly.  The same words read with PLAIN loads are counted too and reported
+ * here (diagnostic: a line some cache of this GPU kept from an earlier round; not on any data path).  Callers run two rounds with
+ * different tokens, a host barrier between them. */
+uint32_t cssm_pf_shard_peer_probe_stale(const cssm_pf* pf);
 void cssm_pf_shard_peer_close(cssm_pf* pf);
 int cssm_pf_shard_pack_peer(cssm_pf* pf, int rank, int world, int64_t cap);
 int cssm_pf_shard_adopt_peer(cssm_pf* pf, int rank, int world, int64_t cap);

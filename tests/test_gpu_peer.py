@@ -175,18 +175,23 @@ def _ipc_rank(rank, world, port, n, T, outdir):
     ll, ess = f.ll_filter(t, y, has)
     ll2, ess2 = f.ll_filter_more(t[-3:] + T, y[-3:], has[-3:])
     np.savez(os.path.join(outdir, f"r{rank}.npz"), ll=ll, ess=ess, ll2=ll2, ess2=ess2, part=shard.particles(), peer=int(f.last_peer),
-             resumes=int(f.last_resumes))
+             resumes=int(f.last_resumes), stale=int(getattr(f, "peer_probe_stale", -1)))
     shard.close()
     dist.barrier()
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 3])
-def test_peer_exchange_between_processes_sharing_the_gpu(tmp_path, world):
+@pytest.mark.parametrize("world,grp", [(2, False), (3, False), (2, True), (4, False), (4, True)])
+def test_peer_exchange_between_processes_sharing_the_gpu(tmp_path, world, grp, monkeypatch):
     """`world` PROCESSES, all on this GPU, each mapping the others' windows through hipIpcOpenMemHandle: the handles, the
-    device table, the flags and the window alternation as across GPUs (what one GPU cannot show is xGMI visibility).  Small
-    clouds, so that the processes' kernels fit the GPU side by side."""
+    device table, the flags (world x world of them), the self-validating header words and the window alternation as across GPUs (what
+    one GPU cannot show is xGMI visibility; the handshake's probe words are read back here too).  Small clouds, so that the processes'
+    kernels fit the GPU side by side.  grp: the exchange on the group sums (CSSM_GRP_MIN_UNITS = 1 sends these few units through them).
+    World 4 is as far as this goes: a GPU box admits six processes on its card, and the test runner is one of them -- eight ranks
+    cannot be started here (the in-process shards of LocalCommPeer cover world 8, without the IPC mapping)."""
     import torch.multiprocessing as mp
+    if grp:
+        monkeypatch.setenv("CSSM_GRP_MIN_UNITS", "1")
     n, T = 4096 * world, 9
     port = 29700 + (os.getpid() % 200) + world
     mp.spawn(_ipc_rank, args=(world, port, n, T, str(tmp_path)), nprocs=world, join=True)
@@ -199,7 +204,7 @@ def test_peer_exchange_between_processes_sharing_the_gpu(tmp_path, world):
     parts = []
     for r in range(world):
         z = np.load(os.path.join(str(tmp_path), f"r{r}.npz"))
-        assert int(z["peer"]) == 1
+        assert int(z["peer"]) == 1 and int(z["stale"]) == 0
         assert float(z["ll"]) == ll and int(z["ess"]) == int(ess_t[-1])
         assert float(z["ll2"]) == ll2 and int(z["ess2"]) == ess2
         parts.append(z["part"])
