@@ -320,6 +320,129 @@ def roofline_16m(NativePf, copy_gbs, fused=None, K=24):
 
 
 # ------------------------------------------------------------------------------------------------ N ranks
+class _Deadline:
+    """A stage of a rank that must end: if it has not after `seconds`, the rank says where it hung and leaves with a non-zero status
+    (os._exit from a watchdog thread: no cleanup can hang, nothing is exec'ed) -- the launcher (torch.distributed.run, or launch_ranks
+    below) then ends the other ranks and reports failure.  Far above anything a healthy stage takes; the device-side waits of the
+    peer-written exchange give up long before (CSSM_PEER_TIMEOUT_MS, 30 s).  ONE watchdog thread per process, started before anything is
+    timed (a thread started inside the first timed leg cost that leg 40-60 ms); entering a stage only posts its name and deadline."""
+    _stage = None          # (what, deadline on time.monotonic()) of the stage this process is in
+    _thread = None
+
+    def __init__(self, seconds, what):
+        self.seconds, self.what = seconds, what
+
+    @classmethod
+    def _watch(cls):
+        while True:
+            time.sleep(0.25)
+            st = cls._stage
+            if st is not None and time.monotonic() > st[1]:
+                sys.stderr.write(f"bench.py: rank {os.environ.get('RANK', '0')}: '{st[0]}' did not finish within {st[2]:g} s; leaving\n")
+                sys.stderr.flush()
+                os._exit(7)
+
+    def __enter__(self):
+        import threading
+        cls = _Deadline
+        if self.seconds > 0:
+            if cls._thread is None:
+                cls._thread = threading.Thread(target=cls._watch, daemon=True)
+                cls._thread.start()
+            cls._stage = (self.what, time.monotonic() + self.seconds, self.seconds)
+        return self
+
+    def __exit__(self, *exc):
+        _Deadline._stage = None
+        return False
+
+
+def preflight(f, make_filter, t, y, has, lgcp, gpu, rank, world, stage_s):
+    """Which exchange protocol the timed legs run on, decided by every rank alike BEFORE anything is timed, with the reasons:
+    peer-written windows -> collectives issued by libcssm_pf over RCCL -> collectives through torch.distributed.  A protocol is taken
+    only if (a) every rank could set it up (the library's own agreement: windows mapped, two handshake rounds with probe words read
+    back) and (b) a short series on it returns the SAME BITS (ll, ess) on every rank as the same series on the next protocol down --
+    the results of the sharded filter do not depend on how the segments travel, so any difference is a transport fault, and the walk
+    moves on instead of timing wrong numbers.  Returns (filter to use, steps): steps = [{"protocol", "ok", "why"}, ...] in walk order."""
+    import torch.distributed as dist
+    steps = []
+    Tp = min(6, len(t))
+
+    def run_series(ff):
+        ll, ess = ff.ll_filter(t[:Tp], y[:Tp], has[:Tp], lgcp=lgcp)
+        return (float(ll).hex(), int(ess))
+
+    def everyone(value):
+        box = [None] * world
+        dist.all_gather_object(box, value)
+        return box
+
+    results = {}          # protocol -> this rank's (ll bits, ess)
+    saved = {k: os.environ.get(k) for k in ("CSSM_SHARD_PEER", "CSSM_SHARD_NATIVE")}
+    order = ["peer", "rccl", "torch"]
+    usable = {}
+    for proto in order:
+        os.environ["CSSM_SHARD_PEER"] = "1" if proto == "peer" else "0"
+        os.environ["CSSM_SHARD_NATIVE"] = "0" if proto == "torch" else "1"
+        if proto == "peer" and saved["CSSM_SHARD_PEER"] == "0":
+            steps.append({"protocol": proto, "ok": False, "why": "switched off by CSSM_SHARD_PEER=0"})
+            continue
+        if proto == "rccl" and saved["CSSM_SHARD_NATIVE"] == "0":
+            steps.append({"protocol": proto, "ok": False, "why": "switched off by CSSM_SHARD_NATIVE=0"})
+            continue
+        ff = make_filter()
+        why, mine = "", None
+        try:
+            with _Deadline(stage_s, f"pre-flight series on the {proto} protocol"):
+                mine = run_series(ff)
+            if proto == "peer" and not getattr(ff, "last_peer", False):
+                why = "refused: " + str(getattr(ff, "peer_refused", None) or ("not a GPU rank" if not gpu else "the series did not run on the windows"))
+                mine = None
+            elif proto == "rccl" and not getattr(ff, "last_native", False):
+                why = "refused: " + ("backend is not RCCL" if not gpu else "no library-owned communicator")
+                mine = None
+        except RuntimeError as e:     # (raised on every rank alike: e.g. libcssm_pf could not make its own RCCL communicator)
+            why, mine = "refused: " + str(e).splitlines()[0][:300], None
+        got = everyone(mine)
+        if any(g is None for g in got):
+            steps.append({"protocol": proto, "ok": False, "why": why or "refused on another rank"})
+            continue
+        if any(g != got[0] for g in got):
+            steps.append({"protocol": proto, "ok": False, "why": f"ranks disagree on the {Tp}-observation series: {got}"})
+            continue
+        results[proto] = got[0]
+        usable[proto] = ff
+        extra = ""
+        if proto == "peer":
+            extra = f"; handshake probe words read stale by plain loads: {getattr(ff, 'peer_probe_stale', 'n/a')}"
+        steps.append({"protocol": proto, "ok": True, "why": f"{Tp}-observation series ll = {got[0][0]}, ess = {got[0][1]} on every rank" + extra})
+    # the first protocol of the walk whose bits equal those of EVERY usable protocol below it (torch.distributed is the yardstick: the
+    # plainest path); a protocol that differs is marked and skipped
+    chosen = None
+    for i, proto in enumerate(order):
+        if proto not in results:
+            continue
+        lower = [q for q in order[i + 1:] if q in results]
+        bad = [q for q in lower if results[q] != results[proto]]
+        if bad:
+            for st in steps:
+                if st["protocol"] == proto:
+                    st["ok"], st["why"] = False, f"its bits {results[proto]} differ from the {bad[0]} protocol's {results[bad[0]]}: transport fault, not used"
+            continue
+        chosen = proto
+        break
+    if chosen is None:
+        raise SystemExit("bench.py: no exchange protocol is usable on every rank: " + json.dumps(steps))
+    os.environ["CSSM_SHARD_PEER"] = "1" if chosen == "peer" else "0"
+    os.environ["CSSM_SHARD_NATIVE"] = "0" if chosen == "torch" else "1"
+    if rank == 0:
+        for st in steps:
+            sys.stderr.write(f"bench.py pre-flight: {st['protocol']:5s} {'ok    ' if st['ok'] else 'NOT ok'} {st['why']}\n")
+        sys.stderr.write(f"bench.py pre-flight: world {world}: the timed legs run on the '{chosen}' protocol\n")
+        sys.stderr.flush()
+    return usable[chosen], steps, chosen
+
+
 def run_multi(args, emit=print):
     import torch
     import torch.distributed as dist
@@ -354,28 +477,20 @@ def run_multi(args, emit=print):
     if gpu:
         from composablestatespacemodels_amd.sharded import GpuShard
         shard = GpuShard(model, n_global, rank, world, 20260101, local, lgcp_precision=prec)
-        f = ShardedFilter([shard], DistComm(device=torch.device("cuda", local)))
+        make_filter = lambda: ShardedFilter([shard], DistComm(device=torch.device("cuda", local)))   # noqa: E731
     else:
         from oracle_shard import OracleShard
         shard = OracleShard(model, n_global, rank, world, 20260101, prec)
-        f = ShardedFilter([shard], DistComm())
+        make_filter = lambda: ShardedFilter([shard], DistComm())   # noqa: E731
     sync = torch.cuda.synchronize if gpu else (lambda: None)
     dev = "cuda" if gpu else "cpu"
+    stage_s = float(args.stage_timeout)
+    # pre-flight: the protocol of the timed legs, agreed and cross-checked (peer-written -> RCCL issued by the library -> torch.distributed)
+    f, walk, protocol = preflight(make_filter(), make_filter, t, y, has, lgcp, gpu, rank, world, stage_s)
+    fallbacks = [f"{st['protocol']}: {st['why']}" for st in walk if not st["ok"]]
     # the W warm-up observations START the sharded filter ...
-    fallbacks = []
-    try:
+    with _Deadline(stage_s, "warm-up series"):
         f.ll_filter(t[:Wn], y[:Wn], has[:Wn], lgcp=lgcp)
-    except RuntimeError as e:
-        # (raised on every rank alike: libcssm_pf could not make its own RCCL communicator -- the collectives then go through
-        #  torch.distributed, and the line says so)
-        if not gpu or "CSSM_SHARD_NATIVE" not in str(e):
-            raise
-        fallbacks.append(str(e))
-        os.environ["CSSM_SHARD_NATIVE"] = "0"
-        f = ShardedFilter([shard], DistComm(device=torch.device("cuda", local)))
-        f.ll_filter(t[:Wn], y[:Wn], has[:Wn], lgcp=lgcp)
-    if getattr(f, "peer_refused", None):
-        fallbacks.append("peer-written exchange refused: " + str(f.peer_refused))
     # ... and every timed leg CONTINUES it with exactly K more (the sharded cssm_pf_ll_filter_more: records built and uploaded,
     # kernels and collectives enqueued by the library, one status read per stretch, ll / ess read back -- no new cloud, no k_init),
     # bracketed by a barrier + device synchronisation on both sides; a leg's time is the MAX over the ranks, the figure the
@@ -386,11 +501,12 @@ def run_multi(args, emit=print):
         lo = Wn + r * K
         dist.barrier()
         sync()
-        t0 = time.perf_counter()
-        ll, ess = f.ll_filter_more(t[lo:lo + K], y[lo:lo + K], has[lo:lo + K], lgcp=lgcp)
-        sync()
-        t1 = time.perf_counter()     # this rank's K steps are done; the leg's time is the MAX over the ranks (below), behind the barrier
-        dist.barrier()
+        with _Deadline(stage_s, f"timed leg {r}"):
+            t0 = time.perf_counter()
+            ll, ess = f.ll_filter_more(t[lo:lo + K], y[lo:lo + K], has[lo:lo + K], lgcp=lgcp)
+            sync()
+            t1 = time.perf_counter()     # this rank's K steps are done; the leg's time is the MAX over the ranks (below), behind the barrier
+            dist.barrier()
         wall = torch.tensor([t1 - t0], dtype=torch.float64, device=dev)
         dist.all_reduce(wall, op=dist.ReduceOp.MAX)
         walls.append(float(wall.item()))
@@ -420,8 +536,11 @@ def run_multi(args, emit=print):
             "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": w * 1e3 / K, "higher_is_better": True,
             "scaling": "strong" if lgcp else "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": workload_text(args.model, n_global, K, per_gpu, world) +
-                                   " (global systematic resampling: one all-to-all per observation carrying every rank's sum words and, between "
-                                   "adjacent ranks, its boundary particles" + ("; LGCP: every event's level predicted from the max of the event before (numerics contract v8)" if lgcp else "") + ")",
+                                   " (global systematic resampling, one exchange per observation carrying every rank's sum words and, between adjacent "
+                                   "ranks, its boundary particles -- " +
+                                   ("written by every rank straight into its peers' receive windows, no collective" if peer else
+                                    ("one RCCL all-to-all issued by the library" if native else "one all-to-all through torch.distributed")) +
+                                   ("; LGCP: every event's level predicted from the max of the event before (numerics contract v8)" if lgcp else "") + ")",
                        "particles_per_gpu": per_gpu, "particles_total": n_global, "observations": K, "latent_dim": shard.d, "seed": 20260101},
             "repeats": R, "value_is": "median over `repeats` timed legs of K steps each (max over ranks per leg), continuing the sharded filter the warm-up "
                                       "steps started (cssm_pf_shard_continue)", "wall_ms_each": [x * 1e3 for x in walls],
@@ -432,6 +551,7 @@ def run_multi(args, emit=print):
                          "collectives_issued_by": ("none per observation" if peer else
                                                    ("libcssm_pf (cssm_pf_shard_series_rccl)" if native else "torch.distributed")),
                          "all_to_all": getattr(f, "last_all_to_all", "equal split"),
+                         "preflight": walk, "chosen": protocol,
                          "fallbacks": fallbacks,
                          "rccl": shard.lib.cssm_rccl_library().decode() if gpu else None},
             "per_rank": every,
@@ -517,6 +637,7 @@ def main():
     ap.add_argument("--model", default="c2", choices=["c2", "c1", "c4"], help="c2: the bench workload (BASELINE configs[1], d = 3, weak scaling); c4: BASELINE configs[3], the log-Gaussian Cox process at N = 2^24 in total (strong scaling); c1: Poisson-Brownian (configs[0], d = 1) -- profiling runs only")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="gloo: CPU rehearsal of the N-rank path with the test-only oracle shard")
     ap.add_argument("--launch-timeout", type=float, default=1500.0, help="seconds the self-launched ranks may take")
+    ap.add_argument("--stage-timeout", type=float, default=300.0, help="N ranks: seconds one stage of a rank (a pre-flight series, the warm-up, one timed leg) may take before the rank leaves with a non-zero status")
     ap.add_argument("--sharded", action="store_true", help="diagnostic: with --gpus 1, run the SHARDED code path at world = 1 over RCCL (its kernels, its collective) instead of the single-GPU filter")
     args = ap.parse_args()
     in_launcher = "WORLD_SIZE" in os.environ and "RANK" in os.environ

@@ -800,6 +800,10 @@ extern "C" int cssm_pf_shard_series_peer(cssm_pf* pf, int rank, int world, size_
   int rc = shard_check(pf);
   if (rc) return rc;
   if (!weighted) return fail(CSSM_EINVAL_ARG, "null argument");
+  // no collective rides on this stretch: the waits behind it are plain stream waits (a communicator an EARLIER series of this handle
+  // used -- bench.py's pre-flight runs one on every protocol -- would send them through bounded_sync's polling loop: 50 us sleeps and an
+  // ncclCommGetAsyncError per poll, ~100 us per 20-observation leg)
+  pf->last_comm = nullptr;
   for (size_t s = s_begin; s < s_end; ++s) {
     rc = cssm_pf_shard_propagate_at(pf, s, nullptr);
     if (rc) return rc;

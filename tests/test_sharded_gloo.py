@@ -186,6 +186,12 @@ def test_bench_launches_its_own_ranks_over_gloo(which):
     assert j["config"]["particles_total"] == n_total and j["config"]["particles_per_gpu"] == n_total // 2
     assert j["scaling"] == ("weak" if which == "c2" else "strong")
     assert j["exchange"]["backend"] == "gloo"
+    # the pre-flight walk: peer-written windows and the library's own RCCL are refused on CPU ranks, with a reason each, WITHOUT aborting;
+    # the legs run on the torch.distributed collectives, whose short series every rank agreed on bit for bit
+    walk = j["exchange"]["preflight"]
+    assert [st["protocol"] for st in walk] == ["peer", "rccl", "torch"] and [st["ok"] for st in walk] == [False, False, True]
+    assert all(st["why"] for st in walk) and j["exchange"]["chosen"] == "torch" and len(j["exchange"]["fallbacks"]) == 2
+    assert "torch.distributed" in j["config"]["workload"]
     assert [p["rank"] for p in j["per_rank"]] == [0, 1]
     assert all(len(p["legs"]) == R and p["legs"][0]["plan"] == "ref" for p in j["per_rank"])
     sys.path.insert(0, os.path.dirname(HERE))
@@ -207,6 +213,21 @@ def test_bench_launcher_reports_a_failing_rank():
                         "--particles", "-1", "--backend", "gloo", "--launch-timeout", "120"],
                        capture_output=True, text=True, timeout=200, env=env)
     assert r.returncode != 0
+    assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+
+
+def test_bench_rank_that_hangs_in_a_stage_leaves_with_a_non_zero_status():
+    """--stage-timeout: a stage of a rank (here the first pre-flight series, with a deadline no series can meet) that does not end makes
+    the rank say where it hung and leave with a non-zero status; the launcher ends the other rank and reports failure -- no line, no hang."""
+    import subprocess
+    env = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(os.path.dirname(HERE), "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "1",
+                        "--particles", "200000", "--backend", "gloo", "--launch-timeout", "120", "--stage-timeout", "0.05"],
+                       capture_output=True, text=True, timeout=200, env=env)
+    assert r.returncode != 0
+    assert "did not finish within" in r.stderr
     assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
 
 
