@@ -47,8 +47,10 @@
 #define CSSM_MAXSLOTS 64
 #define CSSM_SLOT_STRIDE 16 /* u64 words: one 128-byte line per slot */
 #define CSSM_MAXSETS 3
-#define CSSM_GRP_UNITS 32 /* units per group */
-#define CSSM_GRP_MAX 32   /* groups: 1024 units */
+#define CSSM_GRP_UNITS 32 /* units per group, layout 1: up to 32 groups x 32 units -- ONE wave of k_offspring holds the groups' sums and its own group's units */
+#define CSSM_GRP_MAX 64   /* groups the arrays hold.  Layout 2 (single GPU, clouds of more than 1024 units: 2^23 particles and up): up to 64 groups
+                             x 64 units = 4096 units of <= 4 tiles -- one wave totals the groups, a second one the block's own group */
+#define CSSM_GRP_SMALL 32 /* groups of layout 1 */
 #define CSSM_GRP_LIMB 56  /* bits of the low limb */
 #define CSSM_GRP_MAX_UNIT (1u << 15) /* particles per unit: sum < 2^(15 + 96 + 1) = 2^112 = two 56-bit limbs */
 struct Scalars {
@@ -491,6 +493,21 @@ __device__ __forceinline__ void bulk_store2(double* p, double a, double b) {
 #else
   *reinterpret_cast<double2*>(p) = make_double2(a, b);
 #endif
+}
+
+static_assert(CSSM_GRP_UNITS == 32, "group index = block >> (5 + log2(blocks per unit))");
+// A unit's sum (and, squares: its sum of squared weights) added to its group's: two 56-bit limbs each, non-returning atomics on lines of
+// their own (Scalars::grp / grp2; integer sums: any order, the same bits).  One thread of the unit's block calls it.
+__device__ __forceinline__ void group_sums_add(Scalars* __restrict__ sc, int set, uint32_t group, cssm_u128 ta, cssm_u128 tb, bool squares) {
+  const size_t at = ((size_t)set * 2 * CSSM_GRP_MAX + group) * CSSM_SLOT_STRIDE;
+  unsigned long long* g = &sc->grp[at];
+  atomicAdd(g, ta.lo & ((1ull << CSSM_GRP_LIMB) - 1ull));
+  atomicAdd(g + (size_t)CSSM_GRP_MAX * CSSM_SLOT_STRIDE, (ta.lo >> CSSM_GRP_LIMB) | (ta.hi << (64 - CSSM_GRP_LIMB)));
+  if (squares) {
+    unsigned long long* g2 = &sc->grp2[at];
+    atomicAdd(g2, tb.lo & ((1ull << CSSM_GRP_LIMB) - 1ull));
+    atomicAdd(g2 + (size_t)CSSM_GRP_MAX * CSSM_SLOT_STRIDE, (tb.lo >> CSSM_GRP_LIMB) | (tb.hi << (64 - CSSM_GRP_LIMB)));
+  }
 }
 
 // ess = floor(1 / sum (w1/tot)^2) (model/ParticleFilter.scala:128, :431-434) from the fixed-point sums; IEEE operations only:

@@ -72,6 +72,7 @@ struct cssm_pf : HostModel {
   uint32_t grp_min_units = 2u * CSSM_GRP_UNITS;   // smallest cloud (in units) whose propagate accumulates group sums (CSSM_GRP_MIN_UNITS: tests run small clouds through them)
   int opt_spec = 1;            // CSSM_OPT_SPECIALISE
   bool last_grp = false;       // the last launch_propagate's blocks accumulated the sums of groups of units (Scalars::grp)
+  int grp_layout = 0;          // ... in layout 1 (<= 32 groups of 32 units) or 2 (<= 64 groups of 64 units); 0: not at all
   int resampler = CSSM_RESAMPLE_SYSTEMATIC;
   double* cum = nullptr;       // multinomial: cumulative normalised weights
   const long long *send_first_dev = nullptr, *send_count_dev = nullptr;   // last shard_offspring outputs (device)

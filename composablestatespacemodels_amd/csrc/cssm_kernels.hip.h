@@ -40,7 +40,11 @@ static __global__ __launch_bounds__(CSSM_BLOCK) void k_tile_sums(const double* _
                                                           uint32_t ntiles, uint32_t sup, uint32_t nunits, int raw, int slot_set,
                                                           const double* __restrict__ gmax_in, const double* __restrict__ logtab,
                                                           const StepRec* __restrict__ rec, uint32_t hold_mask,
-                                                          const unsigned long long* __restrict__ all5 = nullptr, int world = 0) {
+                                                          const unsigned long long* __restrict__ all5 = nullptr, int world = 0, int grp_arg = 0) {
+  // grp_arg (single GPU; bits as k_propagate's set argument: 8 = on, 9-10 the set, 11-12 log2(units per group / 32)): the units' sums
+  // are added to their groups' as the fused kernel does -- k_offspring_self<..., 0, GRP> then finds its prefix through them
+  const bool grp_on = (grp_arg & 0x100) != 0;
+  const int grp_set = (grp_arg >> 9) & 3, grp_shift = 5 + ((grp_arg >> 11) & 3);
   // all5 != nullptr (sharded series whose levels come from the global max, collectives issued by the library): the max is the
   // largest of the ranks' order keys (word 4 of each rank's 5 all-gathered words) -- every block decodes it itself, block 0
   // publishes it with the level it selects (k_boundary_pack and the status read find them in Scalars)
@@ -92,6 +96,7 @@ static __global__ __launch_bounds__(CSSM_BLOCK) void k_tile_sums(const double* _
 #pragma unroll
       for (int w = 1; w < CSSM_BLOCK / 64; ++w) { ta = cssm_u128_add(ta, s_a[w]); tb = cssm_u128_add(tb, s_b[w]); }
       unitS[unit] = ta; unitS2[unit] = tb;
+      if (grp_on) group_sums_add(sc, grp_set, unit >> grp_shift, ta, tb, false);
     }
     __syncthreads();
   }
@@ -406,7 +411,7 @@ struct SpecTotals { cssm_u128 S_off, tot, tot2; double gmax; };
 // needs every rank's totals: the wait for the peers' headers, the level check, block 0's coverage verdict.  bool operator()(SpecTotals&):
 // false = the block ends here (series on hold, a peer missing); contains block barriers.  Every other instantiation passes nullptr.
 struct NoMid { __device__ __forceinline__ bool operator()(SpecTotals&) const { return true; } };
-template <bool FUSE, bool SELF, int RS, int RAWC = -1, bool GRP = false, class Mid = NoMid>
+template <bool FUSE, bool SELF, int RS, int RAWC = -1, int GRPL = 0, class Mid = NoMid>
 __device__ __forceinline__ void offspring_body(const double* __restrict__ logw, uint64_t n,
                                                           Scalars* __restrict__ sc,
                                                           const cssm_u128* __restrict__ unitP, const cssm_u128* __restrict__ unitS2,
@@ -431,8 +436,16 @@ __device__ __forceinline__ void offspring_body(const double* __restrict__ logw, 
   // GRP (SELF, RAWC == 2, behind a k_propagate whose blocks accumulated them): the sums of groups of 32 units are at hand
   // (Scalars::grp) -- an instantiation of its own: it keeps ONE unit-sum entry per lane of one wave in flight instead of UPRE per
   // thread, and the registers that frees let the block's first tile be converted and scanned BEFORE the sums' barrier
+  // GRPL: 0 = no group sums; 1 = layout 1 (<= 32 groups of 32 units: one wave); 2 = layout 2 (<= 64 groups of 64 units: two waves; single GPU)
+  constexpr bool GRP = GRPL != 0;
+  constexpr bool BIG = GRPL == 2;
+  static_assert(!BIG || SELF, "layout 2: the single-GPU launch");
   constexpr bool grp_on = GRP;
-  static_assert(!GRP || RAWC == 2, "group sums: a launch behind a fused-sums propagate (the single GPU's, or a shard's exchange kernel)");
+  // EARLY: the block's first tile goes onto the grid and through its wave scan BEFORE the sums' barrier -- where the stored values are
+  // the weights themselves (RAWC == 2); behind k_tile_sums (RAWC == 0: log-weights, rescaled by a level the block decodes first) the
+  // group sums serve the prefix only
+  constexpr bool EARLY = GRP && RAWC == 2;
+  static_assert(!GRP || RAWC == 2 || (SELF && RAWC == 0), "group sums: a launch behind a fused-sums propagate (the single GPU's, or a shard's exchange kernel)");
   constexpr bool SHARD_GRP = GRP && !SELF;               // (the group sums are the RANK's: prefix inside the rank; totals and offset come with `mid`)
   // RAWC >= 0 (the single-GPU launches): the weight-input mode is a compile-time constant -- 2 goes with the pending ESS
   // (s2_par >= 0), 0 with the sums of squares at hand; the kernel had run out of scalar and vector registers otherwise
@@ -484,17 +497,29 @@ __device__ __forceinline__ void offspring_body(const double* __restrict__ logw, 
   // grp_on: ONE wave (not the one that decodes the max) totals 32 group sums + the 32 unit sums of the block's own group: lane l < 32
   // holds group l (four 64-bit words of 32-bit limb sums), lane 32 + j unit j of the own group
   const uint32_t wsum = (bidx + 1u) & 3u;
+  const uint32_t wsum2 = (bidx + 2u) & 3u;                 // (layout 2: the wave that scans the block's own group of 64 units)
   const uint32_t grp_unit = is_pub ? 0u : ublk;
-  if (grp_on) {
+  if (grp_on && BIG) {
+#pragma unroll
+    for (int k = 0; k < UPRE; ++k) upre[k] = cssm_u128_zero();
+    const uint32_t l = threadIdx.x & 63u;
+    if ((threadIdx.x >> 6) == wsum) {                      // lane l: group l (the two limb sums)
+      const unsigned long long* g = &sc->grp[((size_t)slot_set * 2 * CSSM_GRP_MAX + l) * CSSM_SLOT_STRIDE];
+      upre[0].lo = g[0]; upre[0].hi = g[(size_t)CSSM_GRP_MAX * CSSM_SLOT_STRIDE];
+    } else if ((threadIdx.x >> 6) == wsum2) {              // lane l: unit l of the own group
+      const uint32_t q = (grp_unit / 64u) * 64u + l;
+      if (q < nunits) upre[0] = unitP[q];
+    }
+  } else if (grp_on) {
 #pragma unroll
     for (int k = 0; k < UPRE; ++k) upre[k] = cssm_u128_zero();
     if ((threadIdx.x >> 6) == wsum) {
       const uint32_t l = threadIdx.x & 63u;
-      if (l < (uint32_t)CSSM_GRP_MAX) {
+      if (l < (uint32_t)CSSM_GRP_SMALL) {
         const unsigned long long* g = &sc->grp[((size_t)slot_set * 2 * CSSM_GRP_MAX + l) * CSSM_SLOT_STRIDE];
         upre[0].lo = g[0]; upre[0].hi = g[(size_t)CSSM_GRP_MAX * CSSM_SLOT_STRIDE];   // the two limb sums
       } else {
-        const uint32_t q = (grp_unit / CSSM_GRP_UNITS) * CSSM_GRP_UNITS + (l - (uint32_t)CSSM_GRP_MAX);
+        const uint32_t q = (grp_unit / CSSM_GRP_UNITS) * CSSM_GRP_UNITS + (l - (uint32_t)CSSM_GRP_SMALL);
         if (q < nunits) {
           upre[0] = unitP[(size_t)q * (uint32_t)split];
           // (a shard whose propagate ran `split` blocks per unit -- the LGCP: its sums are the blocks')
@@ -649,8 +674,41 @@ __device__ __forceinline__ void offspring_body(const double* __restrict__ logw, 
     // (uniform; E is a power of two for every cloud of a power-of-two size: a shift instead of the division's ~25 instructions)
     const uint32_t tq = ((Ed & (Ed - 1u)) == 0u) ? (qlim >> (31 - __builtin_clz(Ed))) : qlim / Ed, rq = qlim - tq * Ed;
     auto scan_units = [&](cssm_u128& tot, cssm_u128& pre) {   // (contains one block barrier)
+      if (grp_on && BIG) {                                      // (uniform) layout 2: one wave scans the 64 groups' sums, another the own group's 64 units
+        if (wid == wsum) {
+          cssm_u128 x, y;   // the two limb sums a0, a1 (< 2^62 each: 64 units of < 2^112) -> a0 + a1 2^56
+          x.lo = upre[0].lo; x.hi = 0ull;
+          y.lo = upre[0].hi << CSSM_GRP_LIMB; y.hi = upre[0].hi >> (64 - CSSM_GRP_LIMB);
+          const cssm_u128 inc = wave_scan_u128(cssm_u128_add(x, y), lane);
+          const uint32_t G = grp_unit / 64u;               // (uniform)
+          cssm_u128 t, pg = cssm_u128_zero();
+          t.lo = readlane_u64(inc.lo, 63); t.hi = readlane_u64(inc.hi, 63);
+          if (G > 0u) { pg.lo = readlane_u64(inc.lo, (int)G - 1); pg.hi = readlane_u64(inc.hi, (int)G - 1); }
+          if (lane == 0u) {
+            s_r[1][0] = t;
+#pragma unroll
+            for (int w = 1; w < CSSM_BLOCK / 64; ++w) s_r[1][w] = cssm_u128_zero();
+            s_pre[0] = pg;
+            const double tf = cssm_fma((double)t.hi, 0x1.0p64, (double)t.lo);   // N / S_tot of the end slots' fast path, as in layout 1
+            double rinv = __builtin_amdgcn_rcp(tf);
+            rinv = cssm_fma(cssm_fma(-tf, rinv, 1.0), rinv, rinv);
+            rinv = cssm_fma(cssm_fma(-tf, rinv, 1.0), rinv, rinv);
+            s_scale = (double)n_global * rinv;
+          }
+        } else if (wid == wsum2) {
+          const cssm_u128 inc = wave_scan_u128(upre[0], lane);
+          const uint32_t r = grp_unit % 64u;               // (uniform)
+          cssm_u128 pu = cssm_u128_zero();
+          if (r > 0u) { pu.lo = readlane_u64(inc.lo, (int)r - 1); pu.hi = readlane_u64(inc.hi, (int)r - 1); }
+          if (lane == 0u) s_pre[1] = pu;
+        }
+        __syncthreads();
+        tot.lo = s_r[1][0].lo; tot.hi = s_r[1][0].hi;
+        { cssm_u128 p0, p1; p0.lo = s_pre[0].lo; p0.hi = s_pre[0].hi; p1.lo = s_pre[1].lo; p1.hi = s_pre[1].hi; pre = cssm_u128_add(p0, p1); }
+        return;
+      }
       if (grp_on) {                                             // (uniform) one wave, one scan: groups in lanes 0..31, own group's units behind
-        static_assert(CSSM_GRP_MAX == 32 && CSSM_GRP_UNITS == 32, "one wave holds the groups and one group's units");
+        static_assert(CSSM_GRP_SMALL == 32 && CSSM_GRP_UNITS == 32, "one wave holds the groups and one group's units");
         if (wid == wsum) {
           cssm_u128 v = upre[0];
           if (lane < 32u) {   // the two limb sums a0, a1 (< 2^61 each) -> a0 + a1 2^56
@@ -754,7 +812,7 @@ __device__ __forceinline__ void offspring_body(const double* __restrict__ logw, 
     }
     // GRP: the first tile's weights on the grid and their wave scan while the sums' wave is at work -- nothing of that depends on
     // the sums (RAWC == 2: the weights are stored as they are used); its results go through the SAME barrier (tile_front below)
-    if constexpr (GRP) {
+    if constexpr (EARLY) {
       const uint32_t t0h = ublk * sup;
       inc_first = tile_front(t0h, true, w1_first, SELF && s2_par >= 0 && t0h + 1u == ((t0h + sup < ntiles) ? t0h + sup : ntiles));
     }
@@ -814,7 +872,7 @@ __device__ __forceinline__ void offspring_body(const double* __restrict__ logw, 
       double w1[CSSM_ITEMS];
       cssm_u128 inc;
       const bool s2_now = SELF && s2_par >= 0 && tile + 1 == t1;
-      if constexpr (GRP) {
+      if constexpr (EARLY) {
         if (tile == t0) {                                    // (converted and scanned ahead of the sums' barrier, which covered s_w too)
 #pragma unroll
           for (int r = 0; r < CSSM_ITEMS; ++r) w1[r] = w1_first[r];
@@ -930,7 +988,7 @@ __global__ __launch_bounds__(CSSM_BLOCK, CSSM_OFF_WAVES) void k_offspring(CSSM_O
 // The single-GPU filter's launch: only the arguments that path uses (the generic kernel above carries ~30, most of them the
 // sharded filter's; their scalar registers spilled into vector registers and those into scratch -- 28 bytes per thread,
 // i.e. 7 MB of scratch write-back per launch at N = 2^20, which the PMC counters showed as "wasted" write traffic).
-template <int RS, int RAWC, bool GRP = false>
+template <int RS, int RAWC, int GRP = 0>
 __global__ __attribute__((amdgpu_flat_work_group_size(CSSM_BLOCK, CSSM_BLOCK),
                           amdgpu_waves_per_eu((RS == CSSM_RESAMPLE_SYSTEMATIC && RAWC == 2) ? CSSM_OFF_SELF_WAVES : CSSM_OFF_WAVES, 8))) void k_offspring_self(
     const double* __restrict__ logw, uint64_t n, Scalars* __restrict__ sc, const cssm_u128* __restrict__ unitP,

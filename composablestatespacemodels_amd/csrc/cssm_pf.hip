@@ -73,7 +73,7 @@ static uint32_t auto_split(const cssm_pf* pf) {
     //  quarter-unit blocks of 512 particles at 2^21 per rank sent them down their recompute path: 39 us per exchange)
     while (want > 1u && ((uint64_t)pf->sup * CSSM_TILE / want) % (uint64_t)CSSM_TILE != 0) want >>= 1;
     const uint64_t unit_particles = (uint64_t)pf->sup * CSSM_TILE;
-    if (!(pf->opt_grp && pf->nunits >= pf->grp_min_units && pf->nunits <= (uint32_t)(CSSM_GRP_MAX * CSSM_GRP_UNITS) && unit_particles <= CSSM_GRP_MAX_UNIT)) want = 1u;   // (no group sums: whole units)
+    if (!(pf->opt_grp && pf->nunits >= pf->grp_min_units && pf->nunits <= (uint32_t)(CSSM_GRP_SMALL * CSSM_GRP_UNITS) && unit_particles <= CSSM_GRP_MAX_UNIT)) want = 1u;   // (no group sums: whole units)
     return want;
   }
   if (pf->sup != 1 || pf->n >= CSSM_SPLIT_MAX_N) return 1u;
@@ -92,6 +92,20 @@ static int alloc_handle(cssm_pf* pf) {
   pf->stride = (size_t)((pf->n + CSSM_TILE - 1) / CSSM_TILE) * CSSM_TILE;   // rows start 16-B aligned
   pf->ntiles = (uint32_t)((pf->n + CSSM_TILE - 1) / CSSM_TILE);
   pf->sup = (pf->ntiles + 1023u) / 1024u;
+  // Single GPU, clouds beyond 2^22 particles: units of 4 tiles while that gives at most 4096 of them (2^23: 2048 units, 2^24: 4096), larger
+  // units beyond -- instead of 1024 units of ever more tiles (16 at 2^24: 1025 k_offspring blocks walking 16 tiles each through three
+  // barriers per tile, 1024 k_propagate blocks on 1536 resident slots at d = 1).  k_offspring finds its prefix through the sums of up
+  // to 64 groups of 64 units (Scalars::grp, layout 2).  A shard keeps at most 1024 units (its exchange kernels' geometry).
+  // CSSM_UNIT_MAX_TILES (A/B): the tiles per unit to aim for (default 4; 0: the old rule).
+  if (!pf->sharded && pf->sup > 4u) {
+    uint32_t want = 4u;
+    if (const char* e = getenv("CSSM_UNIT_MAX_TILES")) want = (uint32_t)atoi(e);
+    if (want >= 1u) {
+      const uint32_t least = (pf->ntiles + (uint32_t)(CSSM_GRP_MAX * 64) - 1u) / (uint32_t)(CSSM_GRP_MAX * 64);   // at most 4096 units
+      const uint32_t sup2 = want > least ? want : least;
+      if (sup2 < pf->sup) pf->sup = sup2;
+    }
+  }
   pf->nunits = (pf->ntiles + pf->sup - 1) / pf->sup;
   {   // k_propagate: a block owns unit/split particles, a multiple of its CSSM_BLOCK * IT particles per iteration
     // (the kernel pipelines its tiles through LDS and wants several of them: one block per unit)
@@ -390,10 +404,15 @@ int cssm_launch_propagate(cssm_pf* pf, const StepRec* d_rec, double* pick_out, u
   // bit 8 of the set argument of k_propagate_self and k_offspring_self), which k_offspring then reads instead of every unit sum
   // (a shard: the same, in Scalars::grp and grp2 -- both sums travel in the exchange's headers --, the set rotating with the handle's
   //  weighted observations while its max slots stay in set 0; the exchange kernels read 32 group sums instead of every unit sum)
+  // layout 1: at most 32 groups of 32 units; layout 2 (single GPU, not the batched chains): at most 64 groups of 64 units
+  const bool big = pf->nunits > (uint32_t)(CSSM_GRP_SMALL * CSSM_GRP_UNITS);
   pf->last_grp = do_sums && !fine && chunk * pf->split == unit_particles && (pf->sharded ? pf->split <= 4u : (pf->split == 1 && pf->first == 0 && pf->n == pf->n_global)) &&
-                 pf->nunits >= pf->grp_min_units && pf->nunits <= (uint32_t)(CSSM_GRP_MAX * CSSM_GRP_UNITS) && unit_particles <= CSSM_GRP_MAX_UNIT && pf->opt_grp;
+                 pf->nunits >= pf->grp_min_units && (big ? (!pf->sharded && batch == nullptr && pf->nunits <= (uint32_t)(CSSM_GRP_MAX * 64)) : true) &&
+                 unit_particles <= CSSM_GRP_MAX_UNIT && pf->opt_grp;
+  pf->grp_layout = pf->last_grp ? (big ? 2 : 1) : 0;
   const bool want_grp = pf->last_grp;
-  if (want_grp) a.slot_set |= 0x100 | (pf->wparity << 9) | ((pf->split == 4u ? 2 : (pf->split == 2u ? 1 : 0)) << 11);
+  // bits 11-12: log2(blocks per group / 32) -- the blocks per unit of a shard's split launch, or the 64-unit groups of layout 2
+  if (want_grp) a.slot_set |= 0x100 | (pf->wparity << 9) | ((big ? 1 : (pf->split == 4u ? 2 : (pf->split == 2u ? 1 : 0))) << 11);
   a.src2 = anc ? pf->src2 : nullptr; a.src2_stride = pf->src2_stride; a.n_split = pf->n_split; a.logtab = pf->d_logtab;
   a.chunk = chunk; a.do_sums = do_sums; a.subS = fine ? pf->fineS : pf->tileS; a.subS2 = fine ? pf->fineS2 : pf->tileS2;
   a.pick_out = pick_out; a.pick_slot = pick_slot;
@@ -433,7 +452,8 @@ int cssm_launch_propagate(cssm_pf* pf, const StepRec* d_rec, double* pick_out, u
 // sums (unless k_propagate formed them) -> end slots -> ancestors, single GPU.  After a k_propagate<SUMS> the buffer holds the
 // weights themselves (raw = 2) and k_offspring forms the sum of squares on the way: that observation's ESS stays pending until
 // the next weighted observation's publisher block, or the host at the end of the call, totals the blocks' partials.
-static int launch_resample(cssm_pf* pf, const StepRec* d_rec, double* ll_t = nullptr, int32_t* ess_t = nullptr, uint32_t rec_idx = 0) {
+// (allow_grp = false: a REDONE observation -- the set of group sums it would add to still holds the sums of its first attempt)
+static int launch_resample(cssm_pf* pf, const StepRec* d_rec, double* ll_t = nullptr, int32_t* ess_t = nullptr, uint32_t rec_idx = 0, bool allow_grp = true) {
 #ifdef CSSM_OFF_STAMPS
   if (!pf->cum) { HIP_TRY(hipMalloc(&pf->cum, pf->stride * 8 + (1u << 20))); HIP_TRY(hipMemsetAsync(pf->cum, 0, 1u << 20, pf->stream)); }
 #endif
@@ -443,10 +463,18 @@ static int launch_resample(cssm_pf* pf, const StepRec* d_rec, double* ll_t = nul
   const bool optimistic = pf->last_optimistic;
   const int tgrid = (int)pf->nunits;
   const int split = optimistic ? (int)pf->split : 1;
+  // the sums as a pass of their own on a cloud of many units (systematic resampling, one GPU): k_tile_sums adds the units' sums to their
+  // groups' too, and k_offspring_self<..., 0, GRP> finds its prefix through those instead of every block reading every unit sum (at
+  // 4096 units: 64 KiB per block, 100 us per launch at N = 2^24 against 67)
+  int lean_layout = 0;
+  if (!optimistic && allow_grp && !pf->sharded && pf->opt_grp && pf->resampler == CSSM_RESAMPLE_SYSTEMATIC && pf->first == 0 && pf->n == pf->n_global &&
+      pf->nunits >= pf->grp_min_units && pf->nunits <= (uint32_t)(CSSM_GRP_MAX * 64) && (uint64_t)pf->sup * CSSM_TILE <= CSSM_GRP_MAX_UNIT)
+    lean_layout = pf->nunits > (uint32_t)(CSSM_GRP_SMALL * CSSM_GRP_UNITS) ? 2 : 1;
   if (!optimistic) {
     prof_begin(pf, CSSM_K_TILE_SUMS);
     hipLaunchKernelGGL(k_tile_sums, dim3(tgrid), dim3(CSSM_BLOCK), 0, pf->stream, pf->logw, pf->n, pf->sc, pf->tileS, pf->tileS2, pf->ntiles,
-                       pf->sup, pf->nunits, 0, pf->wparity, (const double*)nullptr, pf->d_logtab, d_rec, 0u);
+                       pf->sup, pf->nunits, 0, pf->wparity, (const double*)nullptr, pf->d_logtab, d_rec, 0u, (const unsigned long long*)nullptr, 0,
+                       lean_layout ? (0x100 | (pf->wparity << 9) | ((lean_layout == 2 ? 1 : 0) << 11)) : 0);
     prof_end(pf);
   }
   const int s2_par = optimistic ? pf->s2_par : -1;
@@ -454,9 +482,15 @@ static int launch_resample(cssm_pf* pf, const StepRec* d_rec, double* ll_t = nul
 #define OFF_ARGS pf->logw, pf->n, pf->sc, (const cssm_u128*)pf->tileS, (const cssm_u128*)pf->tileS2, d_rec, pf->anc, pf->ntiles, pf->sup, pf->nunits, \
                  pf->wparity, ll_t, ess_t, rec_idx, pf->opt_exact, split, pf->seed, pf->cum, pf->s2buf, pf->s2_stride, s2_par, pf->gen
   const int ogrid = tgrid + 1;   // one block per unit + the publisher
-#define OFF_GO(RS) do { if (optimistic && pf->last_grp && RS == CSSM_RESAMPLE_SYSTEMATIC) \
-                          hipLaunchKernelGGL((k_offspring_self<CSSM_RESAMPLE_SYSTEMATIC, 2, true>), dim3(ogrid), dim3(CSSM_BLOCK), 0, pf->stream, OFF_ARGS); \
+#define OFF_GO(RS) do { if (optimistic && pf->last_grp && pf->grp_layout == 2 && RS == CSSM_RESAMPLE_SYSTEMATIC) \
+                          hipLaunchKernelGGL((k_offspring_self<CSSM_RESAMPLE_SYSTEMATIC, 2, 2>), dim3(ogrid), dim3(CSSM_BLOCK), 0, pf->stream, OFF_ARGS); \
+                        else if (optimistic && pf->last_grp && RS == CSSM_RESAMPLE_SYSTEMATIC) \
+                          hipLaunchKernelGGL((k_offspring_self<CSSM_RESAMPLE_SYSTEMATIC, 2, 1>), dim3(ogrid), dim3(CSSM_BLOCK), 0, pf->stream, OFF_ARGS); \
                         else if (optimistic) hipLaunchKernelGGL((k_offspring_self<RS, 2>), dim3(ogrid), dim3(CSSM_BLOCK), 0, pf->stream, OFF_ARGS); \
+                        else if (lean_layout == 2 && RS == CSSM_RESAMPLE_SYSTEMATIC) \
+                          hipLaunchKernelGGL((k_offspring_self<CSSM_RESAMPLE_SYSTEMATIC, 0, 2>), dim3(ogrid), dim3(CSSM_BLOCK), 0, pf->stream, OFF_ARGS); \
+                        else if (lean_layout == 1 && RS == CSSM_RESAMPLE_SYSTEMATIC) \
+                          hipLaunchKernelGGL((k_offspring_self<CSSM_RESAMPLE_SYSTEMATIC, 0, 1>), dim3(ogrid), dim3(CSSM_BLOCK), 0, pf->stream, OFF_ARGS); \
                         else hipLaunchKernelGGL((k_offspring_self<RS, 0>), dim3(ogrid), dim3(CSSM_BLOCK), 0, pf->stream, OFF_ARGS); } while (0)
   if (pf->resampler == CSSM_RESAMPLE_STRATIFIED) OFF_GO(CSSM_RESAMPLE_STRATIFIED);
   else if (pf->resampler == CSSM_RESAMPLE_MULTINOMIAL) OFF_GO(CSSM_RESAMPLE_MULTINOMIAL);
@@ -538,7 +572,7 @@ static int redo_observation(cssm_pf* pf, const PreState& q, const StepRec* d_rec
   int rc = cssm_launch_propagate(pf, d_rec, nullptr, 0);
   pf->safe_sums = false;
   if (rc) return rc;
-  return launch_resample(pf, d_rec, ll_t, ess_t, rec_idx);
+  return launch_resample(pf, d_rec, ll_t, ess_t, rec_idx, /*allow_grp=*/false);
 }
 
 // ------------------------------------------------------------------------------------ streaming API

@@ -466,21 +466,6 @@ __device__ __forceinline__ void propagate_range(
   acc.S = accS; acc.S2 = accS2; acc.tmax = tmax; acc.bad = bad;
 }
 
-static_assert(CSSM_GRP_UNITS == 32, "group index = block >> (5 + log2(blocks per unit))");
-// A unit's sum (and, squares: its sum of squared weights) added to its group's: two 56-bit limbs each, non-returning atomics on lines of
-// their own (Scalars::grp / grp2; integer sums: any order, the same bits).  One thread of the unit's block calls it.
-__device__ __forceinline__ void group_sums_add(Scalars* __restrict__ sc, int set, uint32_t group, cssm_u128 ta, cssm_u128 tb, bool squares) {
-  const size_t at = ((size_t)set * 2 * CSSM_GRP_MAX + group) * CSSM_SLOT_STRIDE;
-  unsigned long long* g = &sc->grp[at];
-  atomicAdd(g, ta.lo & ((1ull << CSSM_GRP_LIMB) - 1ull));
-  atomicAdd(g + (size_t)CSSM_GRP_MAX * CSSM_SLOT_STRIDE, (ta.lo >> CSSM_GRP_LIMB) | (ta.hi << (64 - CSSM_GRP_LIMB)));
-  if (squares) {
-    unsigned long long* g2 = &sc->grp2[at];
-    atomicAdd(g2, tb.lo & ((1ull << CSSM_GRP_LIMB) - 1ull));
-    atomicAdd(g2 + (size_t)CSSM_GRP_MAX * CSSM_SLOT_STRIDE, (tb.lo >> CSSM_GRP_LIMB) | (tb.hi << (64 - CSSM_GRP_LIMB)));
-  }
-}
-
 //
 // A block owns the CONTIGUOUS range [blockIdx.x * chunk, +chunk) (chunk a multiple of CSSM_BLOCK*IT, chosen on the
 // host so that a whole number of blocks makes one scan unit of k_offspring).  With do_sums the block also forms

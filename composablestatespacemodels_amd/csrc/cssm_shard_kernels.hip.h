@@ -355,7 +355,7 @@ __device__ __forceinline__ void boundary_pack_block(const uint32_t bx, const uin
     // the groups' sums, lanes 32-63 their sums of squares), wave 1 the key of the max, waves 2 and 3 the boundary blocks' totals
     const bool whole = (chunk % (uint64_t)CSSM_TILE == 0) && ((uint64_t)cnt_all % chunk == 0) && ((n_local - (uint64_t)cnt_all) % chunk == 0);
     if (grp_set >= 0 && whole && !level_from_max) {   // (uniform)
-      static_assert(CSSM_GRP_MAX == 32, "one wave holds the groups' sums and their sums of squares");
+      static_assert(CSSM_GRP_SMALL == 32, "one wave holds the groups' sums and their sums of squares (a shard: layout 1, at most 32 groups)");
       __shared__ cssm_u128 s_pt[2];
       __shared__ unsigned long long s_hkey;
       if (wid == 0) {

@@ -794,20 +794,25 @@ def test_group_sums_survive_a_host_resampled_step_in_between(native_before):
     g.close()
 
 
-@pytest.mark.parametrize("n", [1 << 20, (1 << 20) + 4097, 3 << 20, (1 << 23) + 5])
-def test_group_sums_on_and_off_agree_at_full_size(n):
-    """The same at the sizes where the group sums are the default (1024 units of 1024 .. 8192 particles, a ragged cloud whose last
-    groups are short or empty): both settings of CSSM_OPT_GROUP_SUMS, bit for bit, over a series with a missing observation."""
-    model = cases.c2_model() if n != (1 << 23) + 5 else cases.c1_model()
+@pytest.mark.parametrize("n", [1 << 20, (1 << 20) + 4097, 3 << 20, (5 << 20) + 1029, (1 << 23) + 5, 1 << 24])
+def test_group_sums_on_and_off_agree_at_full_size(n, monkeypatch):
+    """The same at the sizes where the group sums are the default (1024 units of 1024 .. 4096 particles, a ragged cloud whose last
+    groups are short or empty; from 5 x 2^20 particles on units of 4 tiles -- 1281, 2049, 4096 of them -- whose sums k_offspring finds
+    through up to 64 groups of 64 units, layout 2 of Scalars::grp): both settings of CSSM_OPT_GROUP_SUMS, and the units of the rule
+    before round 5 (at most 1024 of them: CSSM_UNIT_MAX_TILES = 0), bit for bit, over a series with a missing observation."""
+    model = cases.c2_model() if n not in ((1 << 23) + 5, 1 << 24) else cases.c1_model()
     t, y, has = cases.poisson_counts(7, missing=0.2)
     out = []
-    for grp in (1, 0):
+    for grp, old_units in ((1, False), (0, False), (1, True)):
+        if old_units:
+            monkeypatch.setenv("CSSM_UNIT_MAX_TILES", "0")
         g = NativePf(model, n, cases.SEED); g.set_option(OPT_GROUP_SUMS, grp)
         ll, llt, ess, _ = g.run(t, y, has)
         out.append((ll, llt, ess, g.ancestors(), g.particles())); g.close()
-    assert out[0][0] == out[1][0]
-    for a, b in zip(out[0][1:], out[1][1:]):
-        np.testing.assert_array_equal(a, b)
+    for other in out[1:]:
+        assert out[0][0] == other[0]
+        for a, b in zip(out[0][1:], other[1:]):
+            np.testing.assert_array_equal(a, b)
 
 
 @pytest.mark.parametrize("name", ["c1", "c2", "c3", "linear", "negbin", "zip", "bernoulli", "studentt", "beta"])
