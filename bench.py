@@ -281,12 +281,35 @@ def run_single(args, emit=print):
     }
     if lgcp:
         roof["note"] = ("an LGCP step runs its ~10 sub-steps of Philox + Box-Muller + exp per particle in registers: the kernel is compute-bound by "
-                        "design (SURVEY.md 8d); the HBM fraction is reported for completeness")
+                        "design (SURVEY.md 8d); the HBM fraction is reported for completeness -- its bound is the vector-ALU issue rate: roofline_valu")
+        out["roofline_valu"] = _roofline_valu(n, avg_s)
     if not args.no_16m and not lgcp:
         out["roofline_16m"] = roofline_16m(NativePf, copy_gbs, args.fused)
     if not args.no_cpu:
         out["cpu_baseline"] = cpu_baseline()
     emit(json.dumps(out))
+
+
+def _roofline_valu(n, avg_s):
+    """configs[3]'s real bound: the LGCP kernel issues ~1000 vector-ALU instructions per particle and event (Philox-7, Box-Muller, exp and the
+    OU transition of ~10 sub-steps, all in registers) against 24 bytes of HBM traffic.  achieved = VALU wave-instructions per second -- the
+    count per particle and event from the committed PMC pass (SQ_INSTS_VALU; profiles/valu_latest.json: NOT measured in this run, the
+    instruction count of a kernel does not depend on the box), the kernel time measured live with HIP events; peak = one fp64 instruction
+    per 4.82 cycles and SIMD (profiles/r01s2_instr_rate.txt: v_fma_f64 at 8 waves per SIMD) on 256 CUs x 4 SIMDs at 2.4 GHz.  Part of the
+    stream is 32-bit integer work (Philox), which issues in 2.4 cycles: `frac` can exceed 1 -- `avg_cycles_per_inst` says where between the
+    two rates the kernel runs; both at once means the SIMDs issue back to back."""
+    vpath = os.path.join(ROOT, "profiles", "valu_latest.json")
+    if not os.path.exists(vpath):
+        return None
+    vj = json.load(open(vpath))
+    simds, clock = 256 * 4, 2.4e9
+    insts = vj["valu_wave_insts_per_particle_event"] * n
+    achieved = insts / avg_s
+    peak = simds * clock / 4.82
+    return {"bound": "valu", "kernel": vj["kernel"] + f", N={n}", "achieved": achieved / 1e9, "peak": peak / 1e9, "unit": "G wave-instructions/s",
+            "frac": achieved / peak, "avg_launch_us": avg_s * 1e6, "valu_lane_insts_per_particle_event": vj["valu_lane_insts_per_particle_event"],
+            "avg_cycles_per_inst": avg_s * clock * simds / insts, "fp64_issue_cycles": 4.82, "int32_issue_cycles": 2.4,
+            "insts_source": "NOT measured in this run: " + vj["source"]}
 
 
 def roofline_16m(NativePf, copy_gbs, fused=None, K=24):
