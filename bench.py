@@ -309,6 +309,7 @@ def _roofline_valu(n, avg_s):
     return {"bound": "valu", "kernel": vj["kernel"] + f", N={n}", "achieved": achieved / 1e9, "peak": peak / 1e9, "unit": "G wave-instructions/s",
             "frac": achieved / peak, "avg_launch_us": avg_s * 1e6, "valu_lane_insts_per_particle_event": vj["valu_lane_insts_per_particle_event"],
             "avg_cycles_per_inst": avg_s * clock * simds / insts, "fp64_issue_cycles": 4.82, "int32_issue_cycles": 2.4,
+            "frac_of_int32_rate": achieved / (simds * clock / 2.4),   # (the other end: every slot a 32-bit instruction)
             "insts_source": "NOT measured in this run: " + vj["source"]}
 
 

@@ -103,6 +103,7 @@ SYMBOLS = [
     ("cssm_pf_interpolate", C.c_int, [_h, _dp, _dp, _u8p, C.c_size_t, C.c_double, C.c_int, _dp, _dp, _dp, _dp, _dp, _dp, _dp]),
     ("cssm_resample_systematic", C.c_int, [_dp, C.c_size_t, C.c_double, _u32p, C.c_int]),
     ("cssm_resample", C.c_int, [C.c_int, _dp, C.c_size_t, C.c_double, C.c_uint64, C.c_uint32, _u32p, C.c_int]),
+    ("cssm_resample_residual", C.c_int, [_dp, C.c_size_t, C.c_uint64, C.c_uint32, C.POINTER(C.c_uint32), C.c_int]),
     ("cssm_pf_shard_init", C.c_int, [_h, C.c_double]),
     ("cssm_pf_shard_propagate", C.c_int, [_h, C.c_double, C.c_double, C.c_int, C.c_void_p]),
     ("cssm_pf_shard_sums", C.c_int, [_h, C.c_void_p, C.c_int, C.c_void_p]),

@@ -332,10 +332,26 @@ class Resampling:
         return Resampling._seeded(2, particles, weights, seed, step)
 
     @staticmethod
-    def residualResampling(particles: Sequence, weights: Sequence[float]):
-        """Resampling.scala:130-146 cannot run as written (it hands ``Vector.range(1, m)`` with n weights to the multinomial
-        resampler and then indexes the particles with the result, :144-145): not offered, see LABNOTES.md (old section 9)."""
-        raise NotImplementedError("the reference's residualResampling fails as written (model/Resampling.scala:144-145)")
+    def residualAncestors(weights: Sequence[float], seed: int = 0, step: int = 0, device: int = 0) -> np.ndarray:
+        """cssm_resample_residual (an EXTENSION, see ``residualResampling``): the particle every slot takes."""
+        w = np.ascontiguousarray(weights, dtype=np.float64)
+        anc = np.zeros(len(w), dtype=np.uint32)
+        _abi.check(_abi.load_library().cssm_resample_residual(_p(w), len(w), int(seed), int(step), _p(anc, C.POINTER(C.c_uint32)), device))
+        return anc
+
+    @staticmethod
+    def residualResampling(particles: Sequence, weights: Sequence[float], seed: Optional[int] = None, step: int = 0):
+        """EXTENSION.  The reference's residualResampling (Resampling.scala:130-146) cannot run as written: it hands ``Vector.range(1, m)``
+        with n weights to the multinomial resampler, indexes the particles with the result (:144-145) and exp-normalises weights that
+        are already exponentiated.  This is the resampler its scaladoc DESCRIBES (:124-129), as a host ``Resample[A]``: particle i
+        appears floor(n w_i / sum w) times, the remaining slots are drawn by multinomial resampling on the residual weights
+        (cssm_resample_residual).  ``weights`` are w1 = exp(w - max), as for the other resamplers.  As a ``Filter`` argument it runs
+        through the host-resampler seam (cssm_pf_propagate / cssm_pf_adopt): there is no native in-filter kernel for it."""
+        if len(particles) != len(weights):
+            raise ValueError("particles and weights differ in length")
+        if seed is None:
+            seed = int(np.random.default_rng().integers(0, 2**63))
+        return [particles[int(a)] for a in Resampling.residualAncestors(weights, seed, step)]
 
     @staticmethod
     def systematicResampling(particles: Sequence, weights: Sequence[float], u: Optional[float] = None):
@@ -393,8 +409,6 @@ class _FilterBase:
 
     def __init__(self, mod: Model, resample, n_particles: Optional[int] = None, seed: int = 20260101, device: int = 0):
         kinds = {Resampling.systematicResampling: 0, Resampling.stratifiedResampling: 1, Resampling.multinomialResampling: 2}
-        if resample is Resampling.residualResampling:
-            raise NotImplementedError("the reference's residualResampling cannot run as written (model/Resampling.scala:144-145)")
         if not callable(resample):
             raise TypeError("resample must be a Resample[A]: (samples, weights) -> samples")
         # one of the three native resamplers: the whole step stays on the device.  Any OTHER function is a host Resample[A]

@@ -362,6 +362,14 @@ int cssm_resample_systematic(const double* w, size_t n, double u, uint32_t* anc,
  * come from the Philox streams of (seed, step) -- the ancestors a filter with that seed selects at observation `step`
  * for the same weights (u unused).  The reference draws them from unseeded global generators (:66, :83, :93). */
 int cssm_resample(int kind, const double* w, size_t n, double u, uint64_t seed, uint32_t step, uint32_t* anc, int device);
+/* EXTENSION -- not a drop-in for running reference code: Resampling.residualResampling (model/Resampling.scala:130-146) cannot run as
+ * written (it hands Vector.range(1, m) with n weights to the multinomial resampler, indexes the particles with what comes back, and
+ * exp-normalises weights that stepFilter has already exponentiated).  This is the resampler its scaladoc describes (:124-129): particle
+ * i appears k_i = floor(n w_i / sum w) times, in particle order, and the remaining m = n - sum k_i slots are drawn by multinomial
+ * resampling on the residual weights n w_i / sum w - k_i (the draws of cssm_resample(CSSM_RESAMPLE_MULTINOMIAL): one uniform per slot
+ * from the Philox stream of (seed, step)).  anc[s] = the particle slot s takes: first the copies, then the m draws in draw order.
+ * Arithmetic: csrc/cssm_residual.hip; oracle twin: oracle_resample_residual. */
+int cssm_resample_residual(const double* w, size_t n, uint64_t seed, uint32_t step, uint32_t* anc, int device);
 
 /* ---- sharded filter: stage calls between which the caller runs its collectives ------------ */
 /*

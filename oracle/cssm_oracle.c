@@ -482,6 +482,45 @@ int oracle_resample_multinomial(const double* w, uint64_t n, uint64_t seed, uint
   return ORACLE_OK;
 }
 
+/* EXTENSION (not a restatement of running reference code): residual resampling in the intent its scaladoc states
+ * (model/Resampling.scala:124-129: "particle (xi, wi) appears ki = n * wi times; resample m = n - total allocated particles
+ * according to w = n * wi - ki using other resampling technique") -- the body at :130-146 cannot run (it indexes with draws of
+ * Vector.range(1, m) and exp-normalises weights that are already exponentiated).  The twin of cssm_resample_residual
+ * (csrc/cssm_residual.hip), whose header states the arithmetic: p_i = RN(RN(F_i) / RN(S)) * n, k_i = floor(p_i) copies in particle
+ * order, then m multinomial draws on the residuals r_i = p_i - k_i (contract sums, cssm_multi_uniform(seed, step, t)). */
+int oracle_resample_residual(const double* w, uint64_t n, uint64_t seed, uint32_t step, uint32_t* anc) {
+  u128 tot = 0;
+  for (uint64_t i = 0; i < n; ++i) tot += fix_from_double(w[i]);
+  if (tot == 0) return ORACLE_EEMPTY;
+  const double totd = (double)tot, nd = (double)n;
+  double* r = (double*)malloc(n * 8);
+  uint64_t K = 0;
+  for (uint64_t i = 0; i < n; ++i) {
+    const double p = ((double)fix_from_double(w[i]) / totd) * nd;
+    const uint64_t k = (p >= nd) ? n : (uint64_t)p;
+    r[i] = p - (double)k;
+    if (K + k > n) { free(r); return ORACLE_EEMPTY; }
+    for (uint64_t c = 0; c < k; ++c) anc[K++] = (uint32_t)i;
+  }
+  if (K < n) {
+    double* C = (double*)malloc(n * 8);
+    u128 rt = 0;
+    for (uint64_t i = 0; i < n; ++i) rt += fix_from_double(r[i]);
+    if (rt == 0) { free(C); free(r); return ORACLE_EEMPTY; }
+    contract_cumw(r, n, C);
+    const uint64_t m = n - K;
+    for (uint64_t t = 0; t < m; ++t) {
+      const double ut = cssm_multi_uniform(seed, step, t);
+      uint64_t lo = 0, hi = n - 1;                               /* first j with C_j >= u_t (C is non-decreasing and ends at 1) */
+      while (lo < hi) { const uint64_t mid = (lo + hi) >> 1; if (C[mid] >= ut) hi = mid; else lo = mid + 1; }
+      anc[K + t] = (uint32_t)lo;
+    }
+    free(C);
+  }
+  free(r);
+  return ORACLE_OK;
+}
+
 /* ------------------------------------------------------------------ A6/A7 sums, ll, ess */
 
 /* Tail of stepFilter after the log-weights exist: model/ParticleFilter.scala:124-130

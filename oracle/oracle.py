@@ -83,6 +83,7 @@ def lib() -> C.CDLL:
             "oracle_resample_systematic": (C.c_int, [_dp, C.c_uint64, C.c_double, _u32p, _dp, C.c_int]),
             "oracle_resample_stratified": (C.c_int, [_dp, C.c_uint64, C.c_uint64, C.c_uint32, _u32p, _dp]),
             "oracle_resample_multinomial": (C.c_int, [_dp, C.c_uint64, C.c_uint64, C.c_uint32, _u32p, _dp]),
+            "oracle_resample_residual": (C.c_int, [_dp, C.c_uint64, C.c_uint64, C.c_uint32, _u32p]),
             "oracle_logdens_poisson": (C.c_double, [C.c_double, C.c_double]),
             "oracle_logdens_gaussian": (C.c_double, [C.c_double, C.c_double, C.c_double]),
             "oracle_logdens_negbin": (C.c_double, [C.c_double, C.c_double, C.c_double]),
@@ -288,6 +289,12 @@ def resample_stratified(w, seed, step=0):
 def resample_multinomial(w, seed, step=0):
     w = seam_scale(w); anc = np.zeros(len(w), dtype=np.uint32)
     _chk(lib().oracle_resample_multinomial(_p(w), len(w), seed, step, _p(anc, _u32p), None)); return anc
+
+
+def resample_residual(w, seed, step=0):
+    """EXTENSION: residual resampling in its documented intent (oracle_resample_residual; twin of cssm_resample_residual)."""
+    w = seam_scale(w); anc = np.zeros(len(w), dtype=np.uint32)
+    _chk(lib().oracle_resample_residual(_p(w), len(w), seed, step, _p(anc, _u32p))); return anc
 
 
 def c_exp(x):

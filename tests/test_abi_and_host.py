@@ -109,14 +109,14 @@ def test_composition_is_left_nested_and_leftmost_model_observes():
     assert g.parameters().add([1.0] * len(theta)).flattenParams() == [v + 1.0 for v in theta]
 
 
-def test_filter_accepts_any_resample_function_except_the_broken_residual():
+def test_filter_accepts_any_resample_function():
     """`Resample[A]` is a function type (model/package.scala:23): the three native resamplers keep the step on the device, any
-    other function is applied on the host (cssm_pf_propagate / cssm_pf_adopt); the reference's residualResampling cannot run as
-    written (model/Resampling.scala:144-145) and is refused."""
+    other function is applied on the host (cssm_pf_propagate / cssm_pf_adopt) -- among them residualResampling, which the reference
+    cannot run as written (model/Resampling.scala:144-145) and this package offers in its documented intent, as a labelled extension."""
     f = Filter(cases.c1_model(), lambda p, w: p)
     assert f._host_resample is not None and Filter(cases.c1_model(), Resampling.systematicResampling)._host_resample is None
-    with pytest.raises(NotImplementedError):
-        Filter(cases.c1_model(), Resampling.residualResampling)
+    assert Filter(cases.c1_model(), Resampling.residualResampling)._host_resample is Resampling.residualResampling
+    assert "EXTENSION" in Resampling.residualResampling.__doc__
     with pytest.raises(TypeError):
         Filter(cases.c1_model(), 3)
     assert ParticleFilter.effectiveSampleSize([1.0, 1.0, 1.0, 1.0]) == 4      # ParticleFilter.scala:431-434

@@ -324,8 +324,38 @@ def test_stateless_stratified_and_multinomial_match_oracle(n):
     assert len(out) == n and all(w[i] > 0 for i in out)
     out = Resampling.multinomialResampling(list(range(n)), list(w))
     assert len(out) == n and all(w[i] > 0 for i in out)
-    with pytest.raises(NotImplementedError):
-        Resampling.residualResampling([1, 2], [0.5, 0.5])
+
+
+@pytest.mark.parametrize("n", [1, 4, 7, 1000, 1024, 4097, 200000, (1 << 20) + 3])
+def test_residual_resampling_extension_matches_oracle(n):
+    """cssm_resample_residual -- an EXTENSION: the resampler Resampling.scala:124-129 DESCRIBES (its body, :130-146, cannot run) --
+    against its oracle twin bit for bit, and against its definition: particle i holds floor(n w_i / sum w) slots in particle order,
+    then m multinomial draws from the residual weights; every slot is taken by a particle of positive weight, the output has n slots
+    (the reference's own property of a resampler, SamplingTest.scala:16-18)."""
+    rng = np.random.default_rng(n + 11)
+    for case in range(5):
+        if case == 0:
+            w = rng.random(n)
+        elif case == 1:
+            w = np.exp(-rng.exponential(8.0, n))
+        elif case == 2:
+            w = np.ones(n)
+        elif case == 3:
+            w = np.zeros(n); w[rng.integers(n)] = 1.0
+        else:
+            w = rng.random(n) * 2.0 ** -60; w[rng.random(n) < 0.6] = 0.0; w[rng.integers(n)] = 2.0 ** -61
+        for seed, step in ((cases.SEED, 0), (987, 5)):
+            anc = Resampling.residualAncestors(w, seed=seed, step=step)
+            np.testing.assert_array_equal(anc, oracle.resample_residual(w, seed, step), err_msg=f"case {case}")
+            assert len(anc) == n and np.all(w[anc] > 0)
+            cnt = np.bincount(anc, minlength=n)
+            k = np.floor(n * (w / w.sum()) * (1.0 - 1e-12)).astype(np.int64)      # (floor up to the last ulp of the quotient)
+            assert np.all(cnt >= np.minimum(k, cnt + (k - cnt) * (np.abs(n * w / w.sum() - np.round(n * w / w.sum())) < 1e-9)))
+            K = int(np.floor(n * (w / w.sum())).sum())
+            head = anc[:max(K - 2, 0)]
+            assert np.all(np.diff(head.astype(np.int64)) >= 0)                    # the copies come first, in particle order
+    out = Resampling.residualResampling(list(range(n)), list(w))
+    assert len(out) == n and all(w[i] > 0 for i in out)
 
 
 def test_resample_seam_returns_same_length():

@@ -324,6 +324,29 @@ def test_stratified_and_multinomial_properties():
     assert np.all(np.abs(cnt - [0.1, 0.2, 0.3, 0.4]) < 0.02) and len(big) == 4
 
 
+def test_residual_resampling_extension_hand_worked_and_unbiased():
+    """The EXTENSION (the resampler Resampling.scala:124-129 describes; its body cannot run), pinned by hand: w = (1/2, 1/4, 1/8, 1/8),
+    n = 4 -> n w = (2, 1, 1/2, 1/2): particle 0 twice, particle 1 once, one slot left, drawn from the residuals (0, 0, 1/2, 1/2):
+    particle 2 if its uniform is <= 1/2, else 3.  And its defining property over many seeds: E[count_i] = n w_i."""
+    w = np.array([0.5, 0.25, 0.125, 0.125])
+    seen = set()
+    for seed in range(40):
+        a = oracle.resample_residual(w, seed)
+        assert list(a[:3]) == [0, 0, 1] and a[3] in (2, 3)
+        seen.add(int(a[3]))
+    assert seen == {2, 3}
+    np.testing.assert_array_equal(oracle.resample_residual(np.ones(16), 3), np.arange(16))      # n w_i = 1: every particle once, no draw
+    np.testing.assert_array_equal(oracle.resample_residual(np.array([0.0, 3.0, 0.0]), 3), [1, 1, 1])
+    rng = np.random.default_rng(4)
+    w = rng.random(50)
+    cnt = np.zeros(50)
+    for seed in range(400):
+        cnt += np.bincount(oracle.resample_residual(w, seed), minlength=50)
+    expect = 50 * w / w.sum()
+    assert np.all(np.abs(cnt / 400 - expect) < 0.12)                        # unbiased: the residual part has variance < 1/4 per draw
+    assert np.all(np.bincount(oracle.resample_residual(w, 1), minlength=50) >= np.floor(expect))
+
+
 def test_filters_with_other_resamplers_estimate_the_same_likelihood():
     model = cases.linear_model()
     t, y, has = cases.gaussian_series(30)
