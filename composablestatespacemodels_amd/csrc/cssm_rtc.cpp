@@ -42,6 +42,7 @@ struct HipRtc {
   int (*GetProgramLogSize)(void*, size_t*) = nullptr;
   int (*GetProgramLog)(void*, char*) = nullptr;
   int (*DestroyProgram)(void**) = nullptr;
+  int (*Version)(int*, int*) = nullptr;   // optional
   bool ok = false;
 };
 
@@ -55,7 +56,7 @@ HipRtc* hiprtc() {
 #define SYM(field, name) api.field = reinterpret_cast<decltype(api.field)>(dlsym(api.lib, name))
     SYM(CreateProgram, "hiprtcCreateProgram"); SYM(AddNameExpression, "hiprtcAddNameExpression"); SYM(CompileProgram, "hiprtcCompileProgram");
     SYM(GetLoweredName, "hiprtcGetLoweredName"); SYM(GetCodeSize, "hiprtcGetCodeSize"); SYM(GetCode, "hiprtcGetCode");
-    SYM(GetProgramLogSize, "hiprtcGetProgramLogSize"); SYM(GetProgramLog, "hiprtcGetProgramLog"); SYM(DestroyProgram, "hiprtcDestroyProgram");
+    SYM(GetProgramLogSize, "hiprtcGetProgramLogSize"); SYM(GetProgramLog, "hiprtcGetProgramLog"); SYM(DestroyProgram, "hiprtcDestroyProgram"); SYM(Version, "hiprtcVersion");
 #undef SYM
     api.ok = api.CreateProgram && api.AddNameExpression && api.CompileProgram && api.GetLoweredName && api.GetCodeSize && api.GetCode && api.DestroyProgram;
   });
@@ -68,14 +69,39 @@ uint64_t fnv1a(const void* p, size_t n, uint64_t h = 1469598103934665603ull) {
   return h;
 }
 
-const char* kFlags[] = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-mfma"};
+// the flags of the ahead-of-time build (Makefile: CXXFLAGS; -DCSSM_RTC_ARCH / -DCSSM_RTC_EXTRA carry its ARCH and EXTRA here)
+#ifndef CSSM_RTC_ARCH
+#define CSSM_RTC_ARCH "gfx950"
+#endif
+#ifndef CSSM_RTC_EXTRA
+#define CSSM_RTC_EXTRA ""
+#endif
+std::vector<std::string> build_flags() {
+  std::vector<std::string> f = {std::string("--offload-arch=") + CSSM_RTC_ARCH, "-O3", "-std=c++17", "-ffp-contract=off", "-mfma"};
+  std::string extra = CSSM_RTC_EXTRA;          // (space-separated, as make passes it)
+  size_t p = 0;
+  while (p < extra.size()) {
+    const size_t q = extra.find(' ', p);
+    const std::string tok = extra.substr(p, q == std::string::npos ? std::string::npos : q - p);
+    if (!tok.empty()) f.push_back(tok);
+    if (q == std::string::npos) break;
+    p = q + 1;
+  }
+  return f;
+}
 const char kEntry[] = "#include \"cssm_propagate.hip.h\"\n";
 
+// what a cached code object depends on: the kernel sources, the flags, the run-time compiler's version (a new ROCm must not be
+// handed an old compiler's code) -- the architecture is part of the flags
 uint64_t sources_hash() {
   static const uint64_t h = [] {
     uint64_t x = fnv1a(kEntry, sizeof kEntry);
     for (int i = 0; i < cssm_rtc_nsources; ++i) x = fnv1a(cssm_rtc_sources[i].text, cssm_rtc_sources[i].len, x);
-    for (const char* f : kFlags) x = fnv1a(f, strlen(f), x);
+    for (const std::string& f : build_flags()) x = fnv1a(f.data(), f.size(), x);
+    int major = 0, minor = 0;
+    if (HipRtc* r = hiprtc()) if (r->Version) (void)r->Version(&major, &minor);
+    const int ver[2] = {major, minor};
+    x = fnv1a(ver, sizeof ver, x);
     return x;
   }();
   return h;
@@ -93,9 +119,14 @@ std::string cache_dir() {
       const size_t s = p.rfind('/');
       cand.push_back((s == std::string::npos ? std::string(".") : p.substr(0, s)) + "/rtc_cache");
     }
+    if (const char* x = getenv("XDG_CACHE_HOME")) { if (x[0] == '/') cand.push_back(std::string(x) + "/cssm_rtc_cache"); }
     cand.push_back("/tmp/cssm_rtc_cache_" + std::to_string((unsigned)getuid()));
+    // A directory is used only if it is a REAL directory (no symlink), owned by this user and writable by nobody else: the code
+    // objects in it are loaded and run.  (A directory somebody else created under the predictable /tmp name is passed over.)
     for (const std::string& d : cand) {
-      (void)mkdir(d.c_str(), 0755);
+      (void)mkdir(d.c_str(), 0700);
+      struct stat sb;
+      if (lstat(d.c_str(), &sb) != 0 || !S_ISDIR(sb.st_mode) || sb.st_uid != getuid() || (sb.st_mode & (S_IWGRP | S_IWOTH)) != 0) continue;
       if (access(d.c_str(), W_OK | X_OK) == 0) return d;
     }
     return std::string();
@@ -134,7 +165,10 @@ bool compile(const std::string& expr, std::vector<char>& code, std::string& lowe
   if (r->CreateProgram(&prog, kEntry, "cssm_rtc.hip", (int)texts.size(), texts.data(), names.data()) != 0) { why = "hiprtcCreateProgram failed"; return false; }
   bool ok = r->AddNameExpression(prog, expr.c_str()) == 0;
   if (!ok) why = "hiprtcAddNameExpression failed";
-  if (ok && r->CompileProgram(prog, (int)(sizeof kFlags / sizeof kFlags[0]), kFlags) != 0) {
+  const std::vector<std::string> flags = build_flags();
+  std::vector<const char*> fl;
+  for (const std::string& f : flags) fl.push_back(f.c_str());
+  if (ok && r->CompileProgram(prog, (int)fl.size(), fl.data()) != 0) {
     ok = false;
     size_t n = 0;
     std::string log;
@@ -186,10 +220,14 @@ hipFunction_t cssm_rtc_function(const std::string& expr) {
       if (f) {
         const bool w = fwrite(code.data(), 1, code.size(), f) == code.size();
         fclose(f);
-        if (w && rename(tmp.c_str(), (base + ".hsaco").c_str()) == 0) {
-          FILE* g = fopen((base + ".name").c_str(), "wb");
-          if (g) { fwrite(lowered.data(), 1, lowered.size(), g); fclose(g); }
-        } else {
+        // the lowered name first, under a temporary name and renamed like the code object: a concurrent rank finds either both
+        // files whole or no .hsaco at all (it looks for the .hsaco first) -- never half a name
+        const std::string tmpn = base + ".ntmp" + std::to_string((long)getpid());
+        FILE* g = w ? fopen(tmpn.c_str(), "wb") : nullptr;
+        const bool wn = g && fwrite(lowered.data(), 1, lowered.size(), g) == lowered.size();
+        if (g) fclose(g);
+        if (!(wn && rename(tmpn.c_str(), (base + ".name").c_str()) == 0 && rename(tmp.c_str(), (base + ".hsaco").c_str()) == 0)) {
+          (void)remove(tmpn.c_str());
           (void)remove(tmp.c_str());
         }
       }

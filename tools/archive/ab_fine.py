@@ -3,7 +3,7 @@ software-pipelined kernel (CSSM_OPT_WHOLE_TILES = 2).  usage: ab_fine.py model N
 2 whole units + software-pipelined kernel, one block per unit)"""
 import os; os.environ.setdefault("CSSM_LOOP_EVENTS", "1")   # (cssm_pf_last_loop_ms needs the event pair: CSSM_OPT_LOOP_EVENTS)
 import sys, os
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, ROOT + "/tests")
 import numpy as np, cases
 from composablestatespacemodels_amd.filter import NativePf

@@ -2,7 +2,7 @@
 sampled path, and of one iteration of the native PMMH loop: usage host_overhead.py"""
 import os; os.environ.setdefault("CSSM_LOOP_EVENTS", "1")   # (cssm_pf_last_loop_ms needs the event pair: CSSM_OPT_LOOP_EVENTS)
 import sys, os, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, ROOT + "/tests")
 import numpy as np, cases
 from composablestatespacemodels_amd.filter import NativePf

@@ -1,7 +1,7 @@
 """Per-kernel event times (us) of the per-observation kernels for a size list: kernel_probe.py [c2|c1] [sizes] [fused]"""
 import os; os.environ.setdefault("CSSM_LOOP_EVENTS", "1")   # (cssm_pf_last_loop_ms needs the event pair: CSSM_OPT_LOOP_EVENTS)
 import sys, os
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, ROOT + "/tests")
 import numpy as np, cases
 from composablestatespacemodels_amd.filter import NativePf

@@ -1,7 +1,7 @@
 """Per-kernel event times of a batch run: usage kernel_times.py model N [T=60]   (model: c2 | c1 | d<k>)"""
 import os; os.environ.setdefault("CSSM_LOOP_EVENTS", "1")   # (cssm_pf_last_loop_ms needs the event pair: CSSM_OPT_LOOP_EVENTS)
 import sys, os
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, ROOT + "/tests")
 import cases
 from composablestatespacemodels_amd.filter import NativePf

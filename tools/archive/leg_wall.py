@@ -1,6 +1,6 @@
 """Wall time of short continued legs (bench.py --steps K's timed region), events off: python tools/leg_wall.py [K] [N]"""
 import sys, os, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, ROOT + "/tests")
 import numpy as np, cases, torch
 from composablestatespacemodels_amd.filter import NativePf

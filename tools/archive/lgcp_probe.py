@@ -1,7 +1,7 @@
 """Device time per event of the single-GPU LGCP filter (configs[3]) and per observation of C1 / C2: python tools/lgcp_probe.py"""
 import os; os.environ.setdefault("CSSM_LOOP_EVENTS", "1")
 import sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, ROOT + "/tests")
 import numpy as np, cases
 from composablestatespacemodels_amd.filter import NativePf

@@ -1,6 +1,6 @@
 """Where the Python side of a timed leg goes: idle torch.cuda.synchronize(), NativePf.run_more against the bare ctypes call."""
 import sys, os, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, ROOT + "/tests")
 import ctypes as C
 import numpy as np, cases, torch

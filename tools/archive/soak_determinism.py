@@ -2,13 +2,13 @@
 sums, several dimensions) and 4 local shards with the single-collective exchange; every repetition must give the same
 bits (ll, ess trace, ancestors, particles)."""
 import hashlib, os, sys, time
-R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+R = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, R); sys.path.insert(0, os.path.join(R, "tests"))
 import numpy as np
 import cases
 from composablestatespacemodels_amd.filter import NativePf
 from composablestatespacemodels_amd.sharded import GpuShard, ShardedFilter
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests"))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "..", "tests"))
 from local_comm import LocalComm
 
 def digest(*arrs):

@@ -10,12 +10,12 @@ import sys
 
 import numpy as np
 
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests"))
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "..", "tests"))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
 import cases  # noqa: E402
 from composablestatespacemodels_amd import _abi  # noqa: E402
 from composablestatespacemodels_amd.sharded import GpuShard, ShardedFilter  # noqa: E402
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests"))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "..", "tests"))
 from local_comm import LocalComm  # noqa: E402
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 1 << 20
