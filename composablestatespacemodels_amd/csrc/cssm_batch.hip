@@ -1,7 +1,7 @@
 // cssm_batch.hip -- B independent filters of ONE model structure advanced in lockstep: one launch per stage for all of them
 // (grid.y = the chain).  The two chains of examples/DetermineParameters.scala:68-69 and the mapAsyncUnordered(4) pilot grid of
 // model/Streaming.scala:38-39 run N = 100 000 particles each: a single chain's launches leave three quarters of the GPU idle and a
-// step is launch latency + one wave's dependent instruction stream (LABNOTES.md, old section 5c); four host threads on four streams reached 510
+// step is launch latency + one wave's dependent instruction stream (LABNOTES_rounds1-3.md, section 5c); four host threads on four streams reached 510
 // iterations/s against 178 for one chain.  Here ONE host thread enqueues two launches per observation for all B chains.
 //
 // What a chain keeps to itself: its buffers, its records (the parameters differ), its Philox key -- one ChainBase each, in a

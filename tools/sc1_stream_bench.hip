@@ -1,4 +1,4 @@
-// What do agent-scope (sc1) accesses cost for BULK data on gfx950?  A persistent series kernel (LABNOTES.md, old section 5b) would
+// What do agent-scope (sc1) accesses cost for BULK data on gfx950?  A persistent series kernel (LABNOTES_rounds1-3.md, section 5b) would
 // have to move the particle state with them, since nothing else keeps the 8 L2s coherent inside a kernel.
 //   hipcc -O3 --offload-arch=gfx950 tools/sc1_stream_bench.hip -o tools/sc1_stream_bench.bin && tools/sc1_stream_bench.bin
 // Pattern of k_propagate at d = 3: read 3 rows, write 3 rows + 1 row of doubles (56 B per particle), a few flops between.
