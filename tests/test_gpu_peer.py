@@ -211,6 +211,34 @@ def test_peer_exchange_between_processes_sharing_the_gpu(tmp_path, world, grp, m
     np.testing.assert_array_equal(np.concatenate(parts, axis=1), o.particles())
 
 
+@pytest.mark.parametrize("grp", [False, True])
+def test_a_peer_that_never_delivers_ends_in_an_error_not_a_hang(monkeypatch, grp):
+    """Rank 1 maps its windows and then never runs its series: rank 0's exchange kernels wait for its header -- the header flag (small
+    shards) or the self-validating header words (group sums) -- for CSSM_PEER_TIMEOUT_MS of WALL-CLOCK time (the constant 100 MHz clock,
+    not an iteration count), raise sticky bit 16 and every kernel behind them returns at once; the status read names the cause."""
+    import time
+    from composablestatespacemodels_amd import _abi
+    from composablestatespacemodels_amd.sharded import GpuShard
+    monkeypatch.setenv("CSSM_PEER_TIMEOUT_MS", "250")
+    if grp:
+        monkeypatch.setenv("CSSM_GRP_MIN_UNITS", "1")
+    model, n, cap, T = cases.c2_model(), 12000, 1024, 4
+    shards = [GpuShard(model, n, r, 2, cases.SEED, 0) for r in range(2)]
+    handles = [s.peer_setup(cap) for s in shards]
+    for s in shards:
+        s.peer_connect(handles)
+    t, y, has = cases.poisson_counts(T)
+    shards[0].begin(t, y, has)                      # only rank 0 starts its series
+    t0 = time.time()
+    shards[0].series_peer(0, T, np.ones(T, dtype=np.uint8), cap)
+    with pytest.raises(_abi.CssmError, match="did not arrive"):
+        shards[0].status(T)
+    waited = time.time() - t0
+    assert 0.2 < waited < 15.0, waited              # the bound, once (the blocks of the first launch wait side by side; the rest return at once)
+    for s in shards:
+        s.close()
+
+
 @pytest.mark.parametrize("peer", [True, False])
 @pytest.mark.parametrize("world,n", [(2, 6000), (2, 50000)])
 def test_an_outlying_observation_is_redone_in_place_also_in_a_continued_series(world, n, peer):
