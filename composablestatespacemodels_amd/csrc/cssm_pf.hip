@@ -243,8 +243,11 @@ static int reset_scalars(cssm_pf* pf) {
   h.fail_step = 0xffffffffu;
   h.next_ref = cssm_nan();      // (LGCP: no weighted observation yet whose max could predict a level)
   h.peer_wait_ticks = pf->peer_wait_ticks;
-  // pageable source: the copy is staged before the call returns, so a stack object is safe
-  HIP_TRY(hipMemcpyAsync(pf->sc, &h, sizeof h, hipMemcpyHostToDevice, pf->stream));
+  // the slot and group-sum sets (120 KB since round 5: a PMMH chain initialises a filter per iteration) are cleared on the device; only
+  // the scalars behind them travel (pageable source: the copy is staged before the call returns, so a stack object is safe)
+  HIP_TRY(hipMemsetAsync(pf->sc, 0, offsetof(Scalars, err), pf->stream));
+  HIP_TRY(hipMemcpyAsync(reinterpret_cast<char*>(pf->sc) + CSSM_SC_TAIL_OFF, reinterpret_cast<const char*>(&h) + CSSM_SC_TAIL_OFF, sizeof(Scalars) - CSSM_SC_TAIL_OFF,
+                         hipMemcpyHostToDevice, pf->stream));
   return CSSM_OK;
 }
 
