@@ -8,7 +8,7 @@ export TMPDIR=/tmp
 cd /tmp
 run() { # name, counters...
   local name=$1; shift
-  rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d $R/gpurun_out/pmc_${TAG}_${name} -- python3 $R/bench.py --steps $K --warmup 2 --no-cpu --no-16m --repeats 1 --particles $N $EXTRA > $R/gpurun_out/pmc_${TAG}_${name}.log 2>&1
+  rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d $R/gpurun_out/pmc_${TAG}_${name} -- python3 $R/bench.py --steps $K --warmup 2 --no-cpu --no-16m --no-pmc --repeats 1 --particles $N $EXTRA > $R/gpurun_out/pmc_${TAG}_${name}.log 2>&1
 }
 run sq SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_ACTIVE_INST_VALU
 run fetch FETCH_SIZE

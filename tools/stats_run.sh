@@ -6,9 +6,9 @@ TAG=${1:-r02}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 export TMPDIR=/tmp
 cd /tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/stats_${TAG}_1M -- python3 $R/bench.py --steps 500 --warmup 20 --no-cpu --no-16m > $R/gpurun_out/stats_${TAG}_1M.log 2>&1
-rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/stats_${TAG}_16M -- python3 $R/bench.py --steps 100 --warmup 5 --no-cpu --no-16m --particles 16777216 > $R/gpurun_out/stats_${TAG}_16M.log 2>&1
-rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/stats_${TAG}_16M_d1 -- python3 $R/bench.py --steps 100 --warmup 5 --no-cpu --no-16m --particles 16777216 --model c1 > $R/gpurun_out/stats_${TAG}_16M_d1.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/stats_${TAG}_1M -- python3 $R/bench.py --steps 500 --warmup 20 --no-cpu --no-16m --no-pmc > $R/gpurun_out/stats_${TAG}_1M.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/stats_${TAG}_16M -- python3 $R/bench.py --steps 100 --warmup 5 --no-cpu --no-16m --no-pmc --particles 16777216 > $R/gpurun_out/stats_${TAG}_16M.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/stats_${TAG}_16M_d1 -- python3 $R/bench.py --steps 100 --warmup 5 --no-cpu --no-16m --no-pmc --particles 16777216 --model c1 > $R/gpurun_out/stats_${TAG}_16M_d1.log 2>&1
 cd $R
 for s in 1M 16M 16M_d1; do
   f=$(find gpurun_out/stats_${TAG}_$s -name '*kernel_stats.csv' | head -1)
