@@ -476,8 +476,8 @@ def preflight(f, make_filter, t, y, has, lgcp, gpu, rank, world, stage_s):
             elif proto == "rccl" and not getattr(ff, "last_native", False):
                 why = "refused: " + ("backend is not RCCL" if not gpu else "no library-owned communicator")
                 mine = None
-        except RuntimeError as e:     # (raised on every rank alike: e.g. libcssm_pf could not make its own RCCL communicator)
-            why, mine = "refused: " + str(e).splitlines()[0][:300], None
+        except Exception as e:        # noqa: BLE001 -- raised on every rank alike (e.g. libcssm_pf could not make its own RCCL communicator; a backend
+            why, mine = "refused: " + (str(e).splitlines() or [repr(e)])[0][:300], None   # that cannot move device buffers): the walk moves on
         got = everyone(mine)
         if any(g is None for g in got):
             steps.append({"protocol": proto, "ok": False, "why": why or "refused on another rank"})
@@ -527,12 +527,20 @@ def run_multi(args, emit=print):
     world = int(os.environ.get("WORLD_SIZE", str(args.gpus)))
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("MASTER_PORT", "29511")
-    gpu = args.backend == "nccl"
-    if gpu:
+    gpu = args.backend in ("nccl", "gloo-gpu")
+    # gloo-gpu: a REHEARSAL of the N-rank GPU path on fewer GPUs than ranks -- every rank a real GpuShard (all of them on the devices
+    # there are, rank % device count), the peers' windows mapped over hipIpc, the control plane on gloo (RCCL refuses two ranks on one
+    # device): the launcher, the pre-flight walk, the handshakes and the timed legs run as they will on a node, the figure means nothing
+    shared_gpu = args.backend == "gloo-gpu"
+    if shared_gpu:
+        local = local % max(torch.cuda.device_count(), 1)
+    if gpu and not shared_gpu:
         torch.cuda.set_device(local)
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
-    else:   # rehearsal of the launcher and of the orchestration on CPU (tests): gloo + the test-only oracle shard
+    else:   # rehearsals (tests): gloo -- with the test-only oracle shard on CPU, or (gloo-gpu) GPU shards
         dist.init_process_group("gloo", rank=rank, world_size=world)
+        if shared_gpu:
+            torch.cuda.set_device(local)
     K, W = args.steps, args.warmup
     if args.particles < 0:
         raise SystemExit("--particles must be positive (0: the configuration's default)")
@@ -552,13 +560,18 @@ def run_multi(args, emit=print):
     if gpu:
         from composablestatespacemodels_amd.sharded import GpuShard
         shard = GpuShard(model, n_global, rank, world, 20260101, local, lgcp_precision=prec)
-        make_filter = lambda: ShardedFilter([shard], DistComm(device=torch.device("cuda", local)))   # noqa: E731
+        if shared_gpu:
+            class GlooPeerComm(DistComm):          # control plane on the CPU (gloo), windows on the GPU (IPC)
+                peer = property(lambda self: os.environ.get("CSSM_SHARD_PEER", "1") != "0")
+            make_filter = lambda: ShardedFilter([shard], GlooPeerComm())   # noqa: E731
+        else:
+            make_filter = lambda: ShardedFilter([shard], DistComm(device=torch.device("cuda", local)))   # noqa: E731
     else:
         from oracle_shard import OracleShard
         shard = OracleShard(model, n_global, rank, world, 20260101, prec)
         make_filter = lambda: ShardedFilter([shard], DistComm())   # noqa: E731
     sync = torch.cuda.synchronize if gpu else (lambda: None)
-    dev = "cuda" if gpu else "cpu"
+    dev = "cuda" if (gpu and not shared_gpu) else "cpu"
     stage_s = float(args.stage_timeout)
     # pre-flight: the protocol of the timed legs, agreed and cross-checked (peer-written -> RCCL issued by the library -> torch.distributed)
     f, walk, protocol = preflight(make_filter(), make_filter, t, y, has, lgcp, gpu, rank, world, stage_s)
@@ -620,7 +633,7 @@ def run_multi(args, emit=print):
             "repeats": R, "value_is": "median over `repeats` timed legs of K steps each (max over ranks per leg), continuing the sharded filter the warm-up "
                                       "steps started (cssm_pf_shard_continue)", "wall_ms_each": [x * 1e3 for x in walls],
             "exchange": {"backend": args.backend,
-                         "shard_backend": "libcssm_pf (HIP)" if gpu else "oracle (CPU rehearsal, not a measurement)",
+                         "shard_backend": ("libcssm_pf (HIP), ranks SHARING the GPUs there are (rehearsal, not a measurement)" if shared_gpu else "libcssm_pf (HIP)") if gpu else "oracle (CPU rehearsal, not a measurement)",
                          "protocol": ("peer-written: every rank writes its segments into the other ranks' receive windows (hipIpc-mapped device memory) and "
                                       "sets a flag; no collective per observation (cssm_pf_shard_series_peer)") if peer else "collective: one all-to-all per observation",
                          "collectives_issued_by": ("none per observation" if peer else
@@ -711,7 +724,7 @@ def main():
     ap.add_argument("--no-generic", action="store_true", help="skip the roofline_generic leg (the same kernel with the model's structure as data)")
     ap.add_argument("--fused", type=int, default=None, help="CSSM_OPT_FUSED_SUMS override (single GPU)")
     ap.add_argument("--model", default="c2", choices=["c2", "c1", "c4"], help="c2: the bench workload (BASELINE configs[1], d = 3, weak scaling); c4: BASELINE configs[3], the log-Gaussian Cox process at N = 2^24 in total (strong scaling); c1: Poisson-Brownian (configs[0], d = 1) -- profiling runs only")
-    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="gloo: CPU rehearsal of the N-rank path with the test-only oracle shard")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo", "gloo-gpu"], help="gloo: CPU rehearsal of the N-rank path with the test-only oracle shard; gloo-gpu: rehearsal with real GPU shards sharing the devices there are (peer windows over hipIpc, control plane on gloo) -- not a measurement")
     ap.add_argument("--launch-timeout", type=float, default=1500.0, help="seconds the self-launched ranks may take")
     ap.add_argument("--stage-timeout", type=float, default=300.0, help="N ranks: seconds one stage of a rank (a pre-flight series, the warm-up, one timed leg) may take before the rank leaves with a non-zero status")
     ap.add_argument("--sharded", action="store_true", help="diagnostic: with --gpus 1, run the SHARDED code path at world = 1 over RCCL (its kernels, its collective) instead of the single-GPU filter")
@@ -722,7 +735,7 @@ def main():
     with _QuietStdout() as out:
         if int(os.environ.get("WORLD_SIZE", "1")) > 1 or args.sharded:
             run_multi(args, out.emit)
-        elif args.backend == "gloo":
+        elif args.backend in ("gloo", "gloo-gpu"):
             run_multi(args, out.emit)
         else:
             run_single(args, out.emit)

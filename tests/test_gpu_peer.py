@@ -211,6 +211,41 @@ def test_peer_exchange_between_processes_sharing_the_gpu(tmp_path, world, grp, m
     np.testing.assert_array_equal(np.concatenate(parts, axis=1), o.particles())
 
 
+def test_bench_n_rank_path_rehearsed_with_gpu_shards_sharing_this_gpu():
+    """`bench.py --gpus 3 --backend gloo-gpu`: what the driver will run on a node (`bench.py --gpus N` -> torch.distributed.run -> one rank
+    per GPU), rehearsed with three ranks that are real GpuShards on THIS GPU: the launcher, the pre-flight walk (windows mapped over
+    hipIpc, two handshake rounds with probe words, a 6-observation series on the windows and on the torch.distributed collectives returning
+    the same bits on every rank; the library's own RCCL refused with a reason: RCCL cannot put two ranks on one device), the timed legs
+    on the peer-written exchange, rank 0's line -- and its ll / ess equal the single-rank oracle's.  Not a measurement."""
+    import json
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    K, W, R, per = 5, 8, 2, 20000
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "3", "--backend", "gloo-gpu", "--particles", str(per), "--steps", str(K),
+                        "--warmup", str(W), "--repeats", str(R), "--launch-timeout", "300", "--stage-timeout", "120"],
+                       capture_output=True, text=True, timeout=400, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    j = json.loads(lines[0])
+    ex = j["exchange"]
+    walk = {st["protocol"]: st for st in ex["preflight"]}
+    assert ex["chosen"] == "peer" and walk["peer"]["ok"] and walk["torch"]["ok"] and not walk["rccl"]["ok"] and walk["rccl"]["why"]
+    assert "stale by plain loads: 0" in walk["peer"]["why"]
+    assert j["n_gpus"] == 3 and j["config"]["particles_total"] == 3 * per and "receive windows" in j["config"]["workload"]
+    assert all(p["legs"][0]["plan"] == "ref" for p in j["per_rank"]) and len(j["per_rank"]) == 3
+    sys.path.insert(0, root)
+    import bench
+    model, t, y, has = bench.build_workload(W + (R + 1) * K, "c2")
+    o = oracle.OraclePf(model.descriptor(), 3 * per, 20260101)
+    T = W + R * K
+    ll, _, ess_t, _ = o.filter(t[:T], y[:T], has[:T])
+    assert j["ll"] == ll and j["ess_last"] == int(ess_t[-1])
+
+
 @pytest.mark.parametrize("grp", [False, True])
 def test_a_peer_that_never_delivers_ends_in_an_error_not_a_hang(monkeypatch, grp):
     """Rank 1 maps its windows and then never runs its series: rank 0's exchange kernels wait for its header -- the header flag (small
