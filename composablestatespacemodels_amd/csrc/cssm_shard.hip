@@ -409,7 +409,10 @@ extern "C" int cssm_pf_shard_resume(cssm_pf* pf, uint32_t* fail_step_out) {
   HIP_TRY(hipMemcpyAsync(&pf->sc->err, &h.err, sizeof(uint32_t), hipMemcpyHostToDevice, pf->stream));
   HIP_TRY(hipMemcpyAsync(&pf->sc->fail_step, &h.fail_step, sizeof(uint32_t), hipMemcpyHostToDevice, pf->stream));
   // (pack blocks of the held launches that returned without their ticket while siblings took theirs would leave a count behind)
-  if (pf->peer_tickets) HIP_TRY(hipMemsetAsync(pf->peer_tickets, 0, 96 * sizeof(unsigned int), pf->stream));
+  if (pf->peer_tickets) {
+    HIP_TRY(hipMemsetAsync(pf->peer_tickets, 0, 96 * sizeof(unsigned int), pf->stream));
+    HIP_TRY(hipMemsetAsync(pf->peer_tickets + CSSM_PEER_TICKET_NEED, 0, 64 * sizeof(unsigned int), pf->stream));   // (PackNeed::need likewise)
+  }
   HIP_TRY(hipStreamSynchronize(pf->stream));
   const cssm_pf::Snap& q = pf->snaps[s];
   pf->cur = q.cur; pf->src = q.src; pf->src_stride = q.src_stride; pf->src2 = q.src2; pf->src2_stride = q.src2_stride;
@@ -442,7 +445,10 @@ extern "C" int cssm_pf_shard_resume_level(cssm_pf* pf, uint32_t* fail_step_out) 
   h.err &= ~4u; h.fail_step = 0xffffffffu;
   HIP_TRY(hipMemcpyAsync(&pf->sc->err, &h.err, sizeof(uint32_t), hipMemcpyHostToDevice, pf->stream));
   HIP_TRY(hipMemcpyAsync(&pf->sc->fail_step, &h.fail_step, sizeof(uint32_t), hipMemcpyHostToDevice, pf->stream));
-  if (pf->peer_tickets) HIP_TRY(hipMemsetAsync(pf->peer_tickets, 0, 96 * sizeof(unsigned int), pf->stream));
+  if (pf->peer_tickets) {
+    HIP_TRY(hipMemsetAsync(pf->peer_tickets, 0, 96 * sizeof(unsigned int), pf->stream));
+    HIP_TRY(hipMemsetAsync(pf->peer_tickets + CSSM_PEER_TICKET_NEED, 0, 64 * sizeof(unsigned int), pf->stream));   // (PackNeed::need likewise)
+  }
   HIP_TRY(hipStreamSynchronize(pf->stream));
   const cssm_pf::Snap& q = pf->pre_snaps[s];
   pf->cur = q.cur; pf->src = q.src; pf->src_stride = q.src_stride; pf->src2 = q.src2; pf->src2_stride = q.src2_stride;
@@ -463,14 +469,15 @@ extern "C" int64_t cssm_pf_shard_spec_segment(const cssm_pf* pf, int64_t cap) {
   return (pf && cap >= 1) ? (int64_t)spec_seg(pf->d, (long long)cap) : 0;
 }
 
-static int boundary_pack_impl(cssm_pf* pf, int rank, int world, int64_t cap, double* send_buf_dev, bool peer);
+static int boundary_pack_impl(cssm_pf* pf, int rank, int world, int64_t cap, double* send_buf_dev, bool peer, int phase = 3);
 extern "C" int cssm_pf_shard_boundary_pack(cssm_pf* pf, int rank, int world, int64_t cap, double* send_buf_dev) {
   int rc = shard_check(pf);
   if (rc) return rc;
   if (!send_buf_dev) return fail(CSSM_EINVAL_ARG, "null argument");
   return boundary_pack_impl(pf, rank, world, cap, send_buf_dev, false);
 }
-static int boundary_pack_impl(cssm_pf* pf, int rank, int world, int64_t cap, double* send_buf_dev, bool peer) {
+static int boundary_pack_impl(cssm_pf* pf, int rank, int world, int64_t cap, double* send_buf_dev, bool peer, int phase) {
+  // phase (peer): 1 = headers and unit-sum prefixes, 2 = rows, 3 = both (boundary_pack_block)
   if (cap < 1 || world < 1 || world > 64 || rank < 0 || rank >= world) return fail(CSSM_ESHARD, "rank %d / world %d / cap %lld", rank, world, (long long)cap);
   // !last_optimistic: the sums were formed by cssm_pf_shard_sums relative to the level chosen with the all-gathered max
   const size_t slot = last_rec_slot(pf);
@@ -489,7 +496,8 @@ static int boundary_pack_impl(cssm_pf* pf, int rank, int world, int64_t cap, dou
                      world, rank, (long long)cap, pf->d_recs + slot, (const cssm_u128*)pf->tileS, (const cssm_u128*)pf->tileS2, nsub,
                      (const Scalars*)pf->sc, send_buf_dev, chunk, pf->last_optimistic ? 0 : 1,
                      pre ? pf->unitPre : (cssm_u128*)nullptr,
-                     peer ? (const PeerTable*)pf->peer_tab : (const PeerTable*)nullptr, (int)(pf->peer_seq & 1u), pf->peer_seq, pf->peer_tickets, grp_set);
+                     peer ? (const PeerTable*)pf->peer_tab : (const PeerTable*)nullptr, (int)(pf->peer_seq & 1u), pf->peer_seq, pf->peer_tickets, grp_set,
+                     phase, (peer && !pf->peer_all_rows) ? 1 : 0, pf->n_global, pf->seed, pf->resampler, (uint64_t)pf->first, (uint64_t)(pf->first + pf->n));
   pf->spec_pre = pre;   // (k_offspring_expand_spec reads them: cssm_pf_shard_adopt_spec)
   prof_end(pf);
   HIP_TRY(hipGetLastError());
@@ -533,6 +541,7 @@ static int adopt_spec_impl(cssm_pf* pf, const double* recv_buf_dev, int rank, in
     pk.peer = (const PeerTable*)pf->peer_tab; pk.parity = (int)(peer_seq & 1u); pk.tickets = pf->peer_tickets;
     pk.pre_flag = pre ? pf->peer_tickets + 64 : (unsigned int*)nullptr;
     pk.pack_gx = (uint32_t)((cnt + CSSM_TILE - 1) / CSSM_TILE) + 2u;
+    pk.all_rows = pf->peer_all_rows ? 1 : 0;
     pf->spec_pre = pre;
     auto kx = (pf->resampler == CSSM_RESAMPLE_STRATIFIED)
                   ? (grp ? k_exchange_offspring<2, CSSM_RESAMPLE_STRATIFIED, true> : k_exchange_offspring<2, CSSM_RESAMPLE_STRATIFIED>)
@@ -663,8 +672,8 @@ extern "C" int cssm_pf_shard_peer_setup(cssm_pf* pf, int rank, int world, int64_
   else { (void)hipGetLastError(); if (hipMalloc(&ps->slab, ps->slab_bytes) != hipSuccess) { ps->slab = nullptr; cssm_peer_free(pf); return fail(CSSM_ENOMEM, "peer windows (%zu bytes)", ps->slab_bytes); } }
   HIP_TRY(hipMemsetAsync(ps->slab, 0, ps->slab_bytes, pf->stream));
   HIP_TRY(hipMalloc(&pf->peer_tab, sizeof(PeerTable)));
-  HIP_TRY(hipMalloc(&pf->peer_tickets, 128 * sizeof(unsigned int)));   // [0, 64): tickets per destination; [64]: the flag of the unit-sum prefixes (merged kernel)
-  HIP_TRY(hipMemsetAsync(pf->peer_tickets, 0, 128 * sizeof(unsigned int), pf->stream));
+  HIP_TRY(hipMalloc(&pf->peer_tickets, CSSM_PEER_TICKET_WORDS * sizeof(unsigned int)));   // (layout: CSSM_PEER_TICKET_WORDS in cssm_shard_kernels.hip.h)
+  HIP_TRY(hipMemsetAsync(pf->peer_tickets, 0, CSSM_PEER_TICKET_WORDS * sizeof(unsigned int), pf->stream));
   HIP_TRY(hipStreamSynchronize(pf->stream));
   memset(mine_out, 0, sizeof *mine_out);
   mine_out->pid = (uint64_t)getpid();
@@ -765,7 +774,38 @@ extern "C" int cssm_pf_shard_pack_peer(cssm_pf* pf, int rank, int world, int64_t
   if (pf->peer_packed) return fail(CSSM_ESTATE, "cssm_pf_shard_pack_peer twice without cssm_pf_shard_adopt_peer");
   pf->peer_seq++;
   pf->peer_packed = true;
-  return boundary_pack_impl(pf, rank, world, cap, nullptr, true);
+  pf->peer_rows_packed = pf->peer_all_rows;
+  // (needed rows only: the rows are a stage of their own, cssm_pf_shard_pack_rows_peer -- their blocks wait for every rank's header)
+  return boundary_pack_impl(pf, rank, world, cap, nullptr, true, pf->peer_all_rows ? 3 : 1);
+}
+// Second stage of the pack: the rows of the boundary blocks that the neighbours' slots need, once every rank's header is on its way --
+// a host that drives several shards on ONE stream calls cssm_pf_shard_pack_peer on all of them, then this on all of them, then
+// cssm_pf_shard_adopt_peer on all of them.  (CSSM_PEER_ALL_ROWS=1: the first stage wrote every row; nothing left to do here.)
+extern "C" int cssm_pf_shard_pack_rows_peer(cssm_pf* pf, int rank, int world, int64_t cap) {
+  int rc = shard_check(pf);
+  if (rc) return rc;
+  PeerState* ps = static_cast<PeerState*>(pf->peer);
+  if (!ps || !ps->connected) return fail(CSSM_ESTATE, "peer windows are not set up (cssm_pf_shard_peer_setup / _connect)");
+  if (rank != ps->rank || world != ps->world || cap != ps->cap) return fail(CSSM_ESHARD, "peer windows were set up for rank %d / world %d / cap %lld", ps->rank, ps->world, (long long)ps->cap);
+  if (!pf->peer_packed) return fail(CSSM_ESTATE, "cssm_pf_shard_pack_rows_peer without cssm_pf_shard_pack_peer");
+  if (pf->peer_rows_packed) return CSSM_OK;
+  pf->peer_rows_packed = true;
+  return boundary_pack_impl(pf, rank, world, cap, nullptr, true, 2);
+}
+// Rows the pack stages of this handle wrote for its neighbours since the windows were set up, and the number of neighbour segments they
+// went into (needed rows only; CSSM_PEER_ALL_ROWS=1 leaves both at zero: every segment then carries min(n_local, cap) rows)
+extern "C" int cssm_pf_shard_peer_rows(cssm_pf* pf, uint64_t* rows_out, uint64_t* segments_out) {
+  int rc = shard_check(pf);
+  if (rc) return rc;
+  if (!rows_out || !segments_out) return fail(CSSM_EINVAL_ARG, "null argument");
+  *rows_out = 0; *segments_out = 0;
+  if (!pf->peer_tickets) return CSSM_OK;
+  rc = bounded_sync(pf);
+  if (rc) return rc;
+  unsigned long long st[2] = {0ull, 0ull};
+  HIP_TRY(hipMemcpy(st, pf->peer_tickets + CSSM_PEER_TICKET_STAT, sizeof st, hipMemcpyDeviceToHost));
+  *rows_out = st[0]; *segments_out = st[1];
+  return CSSM_OK;
 }
 extern "C" int cssm_pf_shard_adopt_peer(cssm_pf* pf, int rank, int world, int64_t cap) {
   int rc = shard_check(pf);
@@ -774,7 +814,8 @@ extern "C" int cssm_pf_shard_adopt_peer(cssm_pf* pf, int rank, int world, int64_
   if (!ps || !ps->connected) return fail(CSSM_ESTATE, "peer windows are not set up (cssm_pf_shard_peer_setup / _connect)");
   if (rank != ps->rank || world != ps->world || cap != ps->cap) return fail(CSSM_ESHARD, "peer windows were set up for rank %d / world %d / cap %lld", ps->rank, ps->world, (long long)ps->cap);
   if (!pf->peer_packed) return fail(CSSM_ESTATE, "cssm_pf_shard_adopt_peer without cssm_pf_shard_pack_peer");
-  pf->peer_packed = false;
+  if (!pf->peer_rows_packed) return fail(CSSM_ESTATE, "cssm_pf_shard_adopt_peer without cssm_pf_shard_pack_rows_peer (the rows are the pack's second stage)");
+  pf->peer_packed = false; pf->peer_rows_packed = false;
   const int p = (int)(pf->peer_seq & 1u);
   return adopt_spec_impl(pf, peer_window(ps, ps->slab, p), rank, world, cap, peer_flagset(ps, ps->slab, p), pf->peer_seq);
 }
@@ -811,6 +852,8 @@ extern "C" int cssm_pf_shard_series_peer(cssm_pf* pf, int rank, int world, size_
     static const bool two_launches = getenv("CSSM_PEER_TWO_LAUNCHES") != nullptr;   // (A/B: pack and adopt as launches of their own)
     if (two_launches) {
       rc = cssm_pf_shard_pack_peer(pf, rank, world, cap);
+      if (rc) return rc;
+      rc = cssm_pf_shard_pack_rows_peer(pf, rank, world, cap);
       if (rc) return rc;
       rc = cssm_pf_shard_adopt_peer(pf, rank, world, cap);
     } else {

@@ -116,6 +116,112 @@ __device__ __forceinline__ bool peer_poll_ll(const unsigned long long* f, unsign
   return true;
 }
 
+// NEEDED ROWS.  A boundary block's capacity is sized for the worst observation (6 sqrt(N_global) rows: 17 408 at 8 x 2^20, 696 KB per
+// neighbour) while the neighbour's slots are owned by a few hundred of them on a typical one (median 660) -- and every row is a remote store
+// over one xGMI link.  With all headers at hand the SENDER knows which of its rows the neighbour's slots need: row i of the block for rank + 1
+// iff its end slot lies beyond this rank's last slot (a suffix of the block: end slots grow with i), row i of the block for rank - 1 iff its
+// run starts below this rank's first slot (a prefix).  The row blocks of the pack therefore wait for the headers too (the header blocks wait
+// for nothing, so nobody waits in a circle), write only those rows, and the block that takes the last ticket publishes their number in the
+// word behind the rows flag (`need`: rows [cnt - need, cnt) of the block for rank + 1, rows [0, need) of the block for rank - 1) before it
+// sets the flag.  The reader expands exactly those.  CSSM_PEER_ALL_ROWS=1: every row travels as before (need = cnt).
+#define CSSM_PEER_FLAG_NEED (CSSM_PEER_FLAG_ROWS + 1)
+// the handle's local words of the protocol (cssm_pf::peer_tickets, CSSM_PEER_TICKET_WORDS uint32): [0, 64) tickets per destination,
+// [64] the flag of the unit-sum prefixes (merged kernel), [96, 100) results of the handshake, [100, 104) PackNeed::stat, [128, 192) PackNeed::need
+#define CSSM_PEER_TICKET_WORDS 256
+#define CSSM_PEER_TICKET_STAT 100
+#define CSSM_PEER_TICKET_NEED 128
+struct SpecHeaders;
+struct PackNeed {
+  SpecHeaders* H; uint32_t* ll;          // LDS of the launch: the ranks' headers, the 24 halves per rank they arrive as
+  const unsigned int* my_flags;          // this rank's flags of the window of this exchange (the peers' headers land there)
+  unsigned int* need;                    // [q]: rows destination q needs -- max over the row blocks (device memory, zero between launches)
+  unsigned long long* stat;              // [0] += rows written for the neighbours, [1] += neighbour segments (diagnostics)
+  uint64_t n_global, seed, slot_lo, slot_hi;
+  int rs;
+};
+
+// What every block that needs the ranks' sums does first: the headers of all segments -> per-rank sums, offsets, block totals (and, in
+// the offspring blocks, the verdict "every rank's slots are covered by its own particles plus its neighbours' boundary blocks").
+struct SpecHeaders {
+  cssm_u128 S[64], off[64], base[64], plow[64], phigh[64];
+  long long cnt[64];
+  unsigned long long cnts[64][4];
+  cssm_u128 tot, tot2;
+  unsigned long long key[64], gkey;      // the ranks' max keys, the largest of them
+  cssm_u128 S2[64];
+  int all_ok;
+};
+// (the header words of rank threadIdx.x, requested by the kernel together with everything else it starts from: the verdict
+//  used to begin with three round trips one behind the other -- the sticky bits, the max keys, the headers -- and a fourth
+//  for the record's u in its middle: 3 us before a block had so much as asked for its weights)
+struct SpecHdrRegs { double w[12]; };
+__device__ __forceinline__ SpecHdrRegs spec_load_headers(const double* __restrict__ recv, int world, long long cap, int d) {
+  SpecHdrRegs g;
+#pragma unroll
+  for (int k = 0; k < 12; ++k) g.w[k] = 0.0;
+  if ((int)threadIdx.x < world) {
+    const double* h = recv + (size_t)threadIdx.x * spec_seg(d, cap);
+    g.w[0] = ld_sys_f64(h); g.w[1] = ld_sys_f64(h + 1); g.w[2] = ld_sys_f64(h + 2); g.w[3] = ld_sys_f64(h + 6); g.w[4] = ld_sys_f64(h + 7);
+    g.w[5] = ld_sys_f64(h + 8); g.w[6] = ld_sys_f64(h + 9); g.w[7] = ld_sys_f64(h + 10); g.w[8] = ld_sys_f64(h + 11);
+    g.w[9] = ld_sys_f64(h + 3); g.w[10] = ld_sys_f64(h + 4); g.w[11] = ld_sys_f64(h + 5);   // S2, the key of the rank's max
+  }
+  return g;
+}
+// stage 1: the headers into LDS, the ranks' offsets, the totals and the largest max key (all threads call; two barriers)
+__device__ __forceinline__ void spec_store_headers(SpecHeaders& H, const SpecHdrRegs& g, int world, long long cap) {
+  if (threadIdx.x < 64) {
+    cssm_u128 S = cssm_u128_zero(), bs = cssm_u128_zero(), pl = cssm_u128_zero(), ph = cssm_u128_zero();
+    long long c = 0;
+    if ((int)threadIdx.x < world) {
+      S.lo = cssm_d2u(g.w[1]); S.hi = cssm_d2u(g.w[2]); bs.lo = cssm_d2u(g.w[3]); bs.hi = cssm_d2u(g.w[4]);
+      pl.lo = cssm_d2u(g.w[5]); pl.hi = cssm_d2u(g.w[6]); ph.lo = cssm_d2u(g.w[7]); ph.hi = cssm_d2u(g.w[8]);
+      c = (long long)g.w[0];
+      c = (c < 0) ? 0 : ((c > cap) ? cap : c);
+    }
+    H.S[threadIdx.x] = S; H.base[threadIdx.x] = bs; H.plow[threadIdx.x] = pl; H.phigh[threadIdx.x] = ph; H.cnt[threadIdx.x] = c;
+    cssm_u128 S2; S2.lo = cssm_d2u(g.w[9]); S2.hi = cssm_d2u(g.w[10]);
+    H.S2[threadIdx.x] = S2; H.key[threadIdx.x] = ((int)threadIdx.x < world) ? cssm_d2u(g.w[11]) : 0ull;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    cssm_u128 run = cssm_u128_zero(), run2 = cssm_u128_zero();
+    unsigned long long key = 0ull;
+    for (int r = 0; r < world; ++r) {
+      H.off[r] = run; run = cssm_u128_add(run, H.S[r]); run2 = cssm_u128_add(run2, H.S2[r]);
+      key = (H.key[r] > key) ? H.key[r] : key;
+    }
+    H.tot = run; H.tot2 = run2; H.gkey = key;
+    H.all_ok = 1;
+  }
+  __syncthreads();
+}
+// every rank's header through its self-validating words (all threads call): thread (r, w) polls word w of rank r and keeps its half in
+// `ll`; then thread r holds rank r's 12 header words in the order of spec_load_headers.  false: a word did not come within the bound
+__device__ __forceinline__ bool peer_headers_ll(SpecHdrRegs& hregs, uint32_t* __restrict__ ll, unsigned int& s_late, const unsigned int* __restrict__ peer_flags,
+                                                uint32_t peer_seq, unsigned long long wait_ticks, int world) {
+  if (threadIdx.x == 0) s_late = 0u;
+  __syncthreads();
+  for (uint32_t i = threadIdx.x; i < (uint32_t)world * CSSM_PEER_LL_WORDS; i += CSSM_BLOCK) {
+    const uint32_t r = i / CSSM_PEER_LL_WORDS, w = i % CSSM_PEER_LL_WORDS;
+    const unsigned long long* f = reinterpret_cast<const unsigned long long*>(peer_flags + (size_t)r * CSSM_PEER_FLAG_STRIDE + CSSM_PEER_FLAG_LL) + w;
+    unsigned int half = 0u;
+    if (!peer_poll_ll(f, peer_seq, wait_ticks, half)) { s_late = 1u; break; }
+    ll[i] = half;
+  }
+  __syncthreads();
+  if (s_late) return false;
+#pragma unroll
+  for (int k = 0; k < 12; ++k) hregs.w[k] = 0.0;
+  if ((int)threadIdx.x < world) {
+    const uint32_t* h = ll + threadIdx.x * CSSM_PEER_LL_WORDS;
+    auto hw = [&](int k) { return cssm_u2d((unsigned long long)h[2 * k] | ((unsigned long long)h[2 * k + 1] << 32)); };
+    // (the order of spec_load_headers: count, S, base, the two block totals, S2, the key)
+    hregs.w[0] = hw(0); hregs.w[1] = hw(1); hregs.w[2] = hw(2); hregs.w[3] = hw(6); hregs.w[4] = hw(7); hregs.w[5] = hw(8); hregs.w[6] = hw(9);
+    hregs.w[7] = hw(10); hregs.w[8] = hw(11); hregs.w[9] = hw(3); hregs.w[10] = hw(4); hregs.w[11] = hw(5);
+  }
+  return true;
+}
+
 #define CSSM_PEER_FLAG_HELLO 8    /* word of a source rank's flag pair that cssm_pf_shard_peer_handshake uses */
 // One round of the protocol with nothing attached, run by every rank at once right after the windows were mapped: thread q writes a
 // token where rank q looks for this rank's (system-scope release) and waits, bounded, for rank q's token in this rank's own flags.
@@ -170,6 +276,7 @@ __global__ void k_peer_verify(const double* __restrict__ win0, int world, uint32
 // exp(min(w - c, REF_BELOW)) -- or, with the level taken from the global max, exp(w - level) of the stored log-weights
 // peer != nullptr: the peer-written exchange -- `out` unused, segment rank -> q lands in peer->win[parity][q] + rank * seg,
 // tickets[q] counts the finished blocks of destination q (left at zero again by the block that takes the last ticket)
+template <int RSC = -1>   // the resampler, where the launch knows it at compile time (else PackNeed::rs)
 __device__ __forceinline__ void boundary_pack_block(const uint32_t bx, const uint32_t gx, const int q,
                                                               const double* __restrict__ src, size_t stride, const double* __restrict__ logw,
                                                               uint64_t n_local, int d, int world, int rank, long long cap,
@@ -179,7 +286,12 @@ __device__ __forceinline__ void boundary_pack_block(const uint32_t bx, const uin
                                                               int level_from_max, cssm_u128* __restrict__ pre_out,
                                                               const PeerTable* __restrict__ peer, int parity, uint32_t seq,
                                                               unsigned int* __restrict__ tickets, unsigned int* __restrict__ pre_flag,
-                                                              const int grp_set = -1) {
+                                                              const int grp_set, const PackNeed& xnr, const bool need_on, const int phase) {
+  const PackNeed* xn = &xnr;
+  // need_on (peer-written exchange): only the rows the neighbours' slots need are written (PackNeed: the row blocks wait for
+  // every rank's header first).  phase: bit 0 = the header and prefix blocks work, bit 1 = the row blocks do -- shards of ONE process that
+  // share a stream launch the two phases apart, all headers before any rows: a row block of the first shard would otherwise wait for a
+  // header that a launch BEHIND it on the same stream is to write
   // grp_set >= 0: k_propagate's blocks accumulated the sums (and sums of squares) of groups of 32 units in that set of Scalars::grp / grp2:
   // the header block totals 2 x 32 group sums in ONE wave instead of 2 x nsub unit sums in four (it is the head of the exchange's critical
   // path: every offspring block of every rank waits for it -- 3.4 us from entry to flag at 1024 units, tools/exchange_stamps.py)
@@ -195,6 +307,8 @@ __device__ __forceinline__ void boundary_pack_block(const uint32_t bx, const uin
   // chunk = particles per sub-unit sum of k_propagate (subS): when the tiles of the carried block coincide with
   // sub-units, the prefix of the tiles before a block's own is read from subS instead of being recomputed
   __shared__ cssm_u128 s_w[CSSM_BLOCK / 64], s_r[2][CSSM_BLOCK / 64];
+  __shared__ unsigned int s_need, s_hlate;
+  const bool exact = need_on && peer != nullptr;
   // the series is on hold (capacity miss), void (level ruled out) or a peer is missing: nothing may change -- tested where a block is
   // about to store (everything before is loads and arithmetic: at the head of the block the test was a round trip of its own in a
   // kernel that is one latency chain, and in the merged kernel the pollers of every rank wait for that chain)
@@ -202,6 +316,9 @@ __device__ __forceinline__ void boundary_pack_block(const uint32_t bx, const uin
   const long long R = d + 1, HD = spec_hdr(d), seg = spec_seg(d, cap);
   double* oseg = peer ? peer->win[parity][q] + (size_t)rank * seg : out + (size_t)q * seg;
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  // only the two adjacent ranks can own slots of this rank's boundary particles (k_offspring_expand_spec's verdict refuses
+  // anything else), so only their segments carry rows; every other segment is its header
+  const long long cnt = (q == rank + 1 || q == rank - 1) ? ((long long)n_local < cap ? (long long)n_local : cap) : 0;
   // peer-written exchange: this block's part of segment rank -> q is done (all threads call; see PeerTable)
   auto peer_done = [&](bool header) {
     if (peer == nullptr) return;
@@ -216,18 +333,27 @@ __device__ __forceinline__ void boundary_pack_block(const uint32_t bx, const uin
       unsigned int* f = peer->flag[parity][q] + (size_t)rank * CSSM_PEER_FLAG_STRIDE;
       {
         const unsigned int nblk = gx - 2u;                // (the row blocks of this destination)
+        if (exact && cnt > 0) {                           // this block's needed rows into the destination's maximum, ahead of its ticket
+          const unsigned int mine = s_need;
+          if (mine) atomicMax(&xn->need[q], mine);
+          __threadfence();
+        }
         const unsigned int t = atomicAdd(&tickets[q], 1u);
         if (t + 1u == nblk) {
           tickets[q] = 0u;                                // (the next launch on this stream starts from zero)
+          unsigned int nn = (unsigned int)cnt;            // (every row travelled)
+          if (exact && cnt > 0) {
+            __threadfence();
+            nn = atomicExch(&xn->need[q], 0u);
+            atomicAdd(&xn->stat[0], (unsigned long long)nn); atomicAdd(&xn->stat[1], 1ull);
+          }
+          __hip_atomic_store(f + CSSM_PEER_FLAG_NEED, nn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
           __threadfence_system();
           __hip_atomic_store(f + CSSM_PEER_FLAG_ROWS, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
         }
       }
     }
   };
-  // only the two adjacent ranks can own slots of this rank's boundary particles (k_offspring_expand_spec's verdict refuses
-  // anything else), so only their segments carry rows; every other segment is its header
-  const long long cnt = (q == rank + 1 || q == rank - 1) ? ((long long)n_local < cap ? (long long)n_local : cap) : 0;
   const uint64_t first = (q < rank) ? 0 : n_local - (uint64_t)cnt;     // first particle of the block the segment carries
   const double cref = level_from_max ? sc->ref : rec->ref;
   auto tile_weights = [&](uint64_t base, cssm_u128 (&qq)[CSSM_ITEMS]) {   // particles first + base + 4 tid .. of the block
@@ -251,7 +377,7 @@ __device__ __forceinline__ void boundary_pack_block(const uint32_t bx, const uin
   // grid.x = tiles of the block + 2: the header has a block of its own, and so have the prefixes of the sub-unit sums (pre_out; in the
   // header block they lengthened the launch's longest latency chain by 1.6 us)
   if (bx == gx - 1) {   // the prefix block: thread t owns the E consecutive entries from t E on (E = 4; 8 beyond 1024 sub-unit sums)
-    if (pre_out == nullptr || q != 0) return;
+    if (pre_out == nullptr || q != 0 || !(phase & 1)) return;
     // (the entries are requested ahead of the hold test)
     __shared__ cssm_u128 s_p[CSSM_BLOCK / 64];
     constexpr int EMAX = 8;
@@ -282,9 +408,22 @@ __device__ __forceinline__ void boundary_pack_block(const uint32_t bx, const uin
     return;
   }
   const bool header_block = (bx == gx - 2);
+  if (!(phase & (header_block ? 1 : 2))) return;
   if (header_block) CSSM_SPEC_STAMP(4);
   if (!header_block) {
   if (cnt == 0) { if (held) return; peer_done(false); return; }
+  if (exact) {
+    // needed rows only: every rank's header first (the offspring blocks of this launch wait for the same words; ahead of the tile's own
+    // loads so that the header words and the tile's weights are not held in registers together)
+    if (held) return;
+    if (threadIdx.x == 0) s_need = 0u;
+    SpecHdrRegs hregs;
+    if (!peer_headers_ll(hregs, xn->ll, s_hlate, xn->my_flags, seq, sc->peer_wait_ticks, world)) {
+      if (threadIdx.x == 0) { atomicOr(&const_cast<Scalars*>(sc)->err, 16u); atomicMin(&const_cast<Scalars*>(sc)->fail_step, rec->step); }
+      return;   // (a peer's header did not come: no ticket, no rows flag -- the series ends on every rank like one on hold)
+    }
+    spec_store_headers(*xn->H, hregs, world, cap);
+  }
   // prefix of the tiles before this block's tile
   cssm_u128 toff = cssm_u128_zero();
   // The carried block starts on a boundary of the sub-units whose sums k_propagate (or k_tile_sums) formed -- chunk particles
@@ -330,15 +469,59 @@ __device__ __forceinline__ void boundary_pack_block(const uint32_t bx, const uin
   run = cssm_u128_add(run, inc);
   { cssm_u128 t; t.lo = run.lo - tsum.lo; t.hi = run.hi - tsum.hi - (run.lo < tsum.lo ? 1u : 0u); run = t; }   // exclusive prefix of the thread
   if (held) return;
+  uint32_t need_mask = 0xffffffffu;   // bit r: row r of this thread travels
+  if (exact) {
+    // the slot counts of this thread's rows as the READER forms them in expand_spec_body -- the same header words, the same arithmetic,
+    // the same numbers
+    SpecHeaders& H = *xn->H;
+    cssm_u128 off = H.off[rank];
+    if (q > rank) {
+      const cssm_u128 Sr = H.S[rank], Pr = H.phigh[rank];
+      cssm_u128 bs; bs.lo = Sr.lo - Pr.lo; bs.hi = Sr.hi - Pr.hi - (Sr.lo < Pr.lo ? 1u : 0u);
+      off = cssm_u128_add(off, bs);
+    }
+    const double totd = cssm_u128_to_double(H.tot), u = rec->u;
+    const uint64_t n_global = xn->n_global;
+    const bool pow2 = (n_global & (n_global - 1)) == 0;
+    const double inv_n = 1.0 / (double)n_global;
+    const uint32_t rstep = rec->step;
+    const int rs = (RSC >= 0) ? RSC : xn->rs;
+    auto count_of = [&](cssm_u128 G) -> uint64_t {
+      if (cssm_u128_is_zero(G)) return 0;
+      const double C = cssm_u128_to_double(G) / totd;
+      if (rs == CSSM_RESAMPLE_STRATIFIED) return cssm_strat_count(C, xn->seed, rstep, n_global);
+      return pow2 ? cssm_sys_count_pow2(C, u, n_global, inv_n) : cssm_sys_count(C, u, n_global);
+    };
+    // ONE count per thread: its four rows travel together.  Block for rank + 1 (a suffix is needed: end slots grow with the row): the
+    // thread's rows travel iff the LAST of them ends beyond this rank's last slot; block for rank - 1 (a prefix): iff the FIRST of them
+    // starts below this rank's first slot.  Up to three rows more than needed at the edge; the reader clamps their runs to nothing.
+    const uint64_t i0 = base + (uint64_t)threadIdx.x * CSSM_ITEMS;
+    const uint64_t c = count_of(cssm_u128_add(off, (q < rank) ? run : cssm_u128_add(run, tsum)));
+    unsigned int mine = 0u;
+    need_mask = 0u;
+    if (i0 < (uint64_t)cnt && ((q < rank) ? (c < xn->slot_lo) : (c > xn->slot_hi))) {
+      need_mask = 0xffffffffu;
+      const uint64_t i1 = (i0 + CSSM_ITEMS < (uint64_t)cnt) ? i0 + CSSM_ITEMS : (uint64_t)cnt;   // one past the thread's last row
+      mine = (q < rank) ? (unsigned int)i1 : (unsigned int)((uint64_t)cnt - i0);
+    }
+    mine = (unsigned int)wave_max_u64((unsigned long long)mine);
+    if (lane == 0 && mine) atomicMax(&s_need, mine);   // (peer_done's barrier stands between this and its reader)
+  }
+  // (needed rows only: the weights are read once more, through a pointer the compiler cannot identify with the first one -- four 128-bit
+  //  weights held across the counts cost the merged kernel a wave of occupancy)
+  if (need_mask) {
+    const double* lw = logw;
+    if (exact) asm volatile("" : "+v"(lw));
 #pragma unroll
-  for (int r = 0; r < CSSM_ITEMS; ++r) {
-    run = cssm_u128_add(run, qq[r]);
-    const uint64_t i = base + (uint64_t)threadIdx.x * CSSM_ITEMS + r;
-    if (i < (uint64_t)cnt) {
-      double* o = oseg + HD + (long long)i * R;
-      for (int k = 0; k < d; ++k) o[k] = src[(size_t)k * stride + (size_t)(first + i)];
-      o[d] = cssm_u2d(run.lo);
-      oseg[HD + cap * R + (long long)i] = cssm_u2d(run.hi);
+    for (int r = 0; r < CSSM_ITEMS; ++r) {
+      const uint64_t i = base + (uint64_t)threadIdx.x * CSSM_ITEMS + r;
+      if (i < (uint64_t)cnt) {
+        run = cssm_u128_add(run, cssm_fix_from_unit(level_from_max ? cssm_exp_le0(lw[first + i] - cref) : lw[first + i]));
+        double* o = oseg + HD + (long long)i * R;
+        for (int k = 0; k < d; ++k) o[k] = src[(size_t)k * stride + (size_t)(first + i)];
+        o[d] = cssm_u2d(run.lo);
+        oseg[HD + cap * R + (long long)i] = cssm_u2d(run.hi);
+      }
     }
   }
   peer_done(false);
@@ -489,9 +672,19 @@ __global__ __launch_bounds__(CSSM_BLOCK) void k_boundary_pack(const double* __re
                                                               const Scalars* __restrict__ sc, double* __restrict__ out, uint64_t chunk,
                                                               int level_from_max, cssm_u128* __restrict__ pre_out,
                                                               const PeerTable* __restrict__ peer = nullptr, int parity = 0, uint32_t seq = 0u,
-                                                              unsigned int* __restrict__ tickets = nullptr, int grp_set = -1) {
+                                                              unsigned int* __restrict__ tickets = nullptr, int grp_set = -1,
+                                                              int phase = 3, int need_rows = 0, uint64_t n_global = 0, uint64_t seed = 0, int rs = 0,
+                                                              uint64_t slot_lo = 0, uint64_t slot_hi = 0) {
+  // need_rows (peer != nullptr): only the rows the neighbours need travel (PackNeed) -- the row blocks (phase bit 1) wait for all headers
+  __shared__ SpecHeaders H;
+  __shared__ uint32_t s_ll[64 * CSSM_PEER_LL_WORDS];
+  PackNeed xn;
+  xn.H = &H; xn.ll = s_ll; xn.my_flags = (peer != nullptr) ? peer->flag[parity][rank] : nullptr;
+  xn.need = (tickets != nullptr) ? tickets + CSSM_PEER_TICKET_NEED : nullptr;
+  xn.stat = (tickets != nullptr) ? reinterpret_cast<unsigned long long*>(tickets + CSSM_PEER_TICKET_STAT) : nullptr;
+  xn.n_global = n_global; xn.seed = seed; xn.slot_lo = slot_lo; xn.slot_hi = slot_hi; xn.rs = rs;
   boundary_pack_block(blockIdx.x, gridDim.x, (int)blockIdx.y, src, stride, logw, n_local, d, world, rank, cap, rec, subS, subS2, nsub, sc, out, chunk,
-                      level_from_max, pre_out, peer, parity, seq, tickets, nullptr, grp_set);
+                      level_from_max, pre_out, peer, parity, seq, tickets, nullptr, grp_set, xn, need_rows != 0, phase);
 }
 
 // After the all-to-all: every segment's rows -> the slots of this rank they own.  Global cumulative weight of row i of
@@ -502,59 +695,6 @@ __global__ __launch_bounds__(CSSM_BLOCK) void k_boundary_pack(const double* __re
 // What every block of the launch does first: the headers of all segments -> per-rank sums, offsets, block totals, and the
 // verdict "every rank's slots are covered by its own particles plus its neighbours' boundary blocks".  The verdict is a
 // function of the headers alone, and every rank holds every header: all ranks arrive at the same verdict without talking.
-struct SpecHeaders {
-  cssm_u128 S[64], off[64], base[64], plow[64], phigh[64];
-  long long cnt[64];
-  unsigned long long cnts[64][4];
-  cssm_u128 tot, tot2;
-  unsigned long long key[64], gkey;      // the ranks' max keys, the largest of them
-  cssm_u128 S2[64];
-  int all_ok;
-};
-// (the header words of rank threadIdx.x, requested by the kernel together with everything else it starts from: the verdict
-//  used to begin with three round trips one behind the other -- the sticky bits, the max keys, the headers -- and a fourth
-//  for the record's u in its middle: 3 us before a block had so much as asked for its weights)
-struct SpecHdrRegs { double w[12]; };
-__device__ __forceinline__ SpecHdrRegs spec_load_headers(const double* __restrict__ recv, int world, long long cap, int d) {
-  SpecHdrRegs g;
-#pragma unroll
-  for (int k = 0; k < 12; ++k) g.w[k] = 0.0;
-  if ((int)threadIdx.x < world) {
-    const double* h = recv + (size_t)threadIdx.x * spec_seg(d, cap);
-    g.w[0] = ld_sys_f64(h); g.w[1] = ld_sys_f64(h + 1); g.w[2] = ld_sys_f64(h + 2); g.w[3] = ld_sys_f64(h + 6); g.w[4] = ld_sys_f64(h + 7);
-    g.w[5] = ld_sys_f64(h + 8); g.w[6] = ld_sys_f64(h + 9); g.w[7] = ld_sys_f64(h + 10); g.w[8] = ld_sys_f64(h + 11);
-    g.w[9] = ld_sys_f64(h + 3); g.w[10] = ld_sys_f64(h + 4); g.w[11] = ld_sys_f64(h + 5);   // S2, the key of the rank's max
-  }
-  return g;
-}
-// stage 1: the headers into LDS, the ranks' offsets, the totals and the largest max key (all threads call; two barriers)
-__device__ __forceinline__ void spec_store_headers(SpecHeaders& H, const SpecHdrRegs& g, int world, long long cap) {
-  if (threadIdx.x < 64) {
-    cssm_u128 S = cssm_u128_zero(), bs = cssm_u128_zero(), pl = cssm_u128_zero(), ph = cssm_u128_zero();
-    long long c = 0;
-    if ((int)threadIdx.x < world) {
-      S.lo = cssm_d2u(g.w[1]); S.hi = cssm_d2u(g.w[2]); bs.lo = cssm_d2u(g.w[3]); bs.hi = cssm_d2u(g.w[4]);
-      pl.lo = cssm_d2u(g.w[5]); pl.hi = cssm_d2u(g.w[6]); ph.lo = cssm_d2u(g.w[7]); ph.hi = cssm_d2u(g.w[8]);
-      c = (long long)g.w[0];
-      c = (c < 0) ? 0 : ((c > cap) ? cap : c);
-    }
-    H.S[threadIdx.x] = S; H.base[threadIdx.x] = bs; H.plow[threadIdx.x] = pl; H.phigh[threadIdx.x] = ph; H.cnt[threadIdx.x] = c;
-    cssm_u128 S2; S2.lo = cssm_d2u(g.w[9]); S2.hi = cssm_d2u(g.w[10]);
-    H.S2[threadIdx.x] = S2; H.key[threadIdx.x] = ((int)threadIdx.x < world) ? cssm_d2u(g.w[11]) : 0ull;
-  }
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    cssm_u128 run = cssm_u128_zero(), run2 = cssm_u128_zero();
-    unsigned long long key = 0ull;
-    for (int r = 0; r < world; ++r) {
-      H.off[r] = run; run = cssm_u128_add(run, H.S[r]); run2 = cssm_u128_add(run2, H.S2[r]);
-      key = (H.key[r] > key) ? H.key[r] : key;
-    }
-    H.tot = run; H.tot2 = run2; H.gkey = key;
-    H.all_ok = 1;
-  }
-  __syncthreads();
-}
 // stage 2: the verdict (all threads call)
 // rs / seed / step: the resampler whose grid the slots follow -- systematic (one uniform u, model/Resampling.scala:63-72) or stratified
 // (one uniform per slot from the Philox streams of (seed, step), :78-86: the grid points are keyed by GLOBAL slot, so every rank counts
@@ -611,7 +751,10 @@ __device__ __forceinline__ bool spec_read_headers(SpecHeaders& H, int world, int
 __device__ __forceinline__ void expand_spec_body(SpecHeaders& H, uint32_t bid, uint32_t nblk, const double* __restrict__ recv, int world, int rank,
                                                  long long cap, int d, uint32_t n_split, uint64_t slot_lo, uint64_t slot_hi, uint64_t n_global,
                                                  const StepRec* __restrict__ rec, uint32_t* __restrict__ anc, Scalars* __restrict__ sc,
-                                                 int rs = CSSM_RESAMPLE_SYSTEMATIC, uint64_t seed = 0, int grp_cur = 0) {
+                                                 int rs = CSSM_RESAMPLE_SYSTEMATIC, uint64_t seed = 0, int grp_cur = 0,
+                                                 const unsigned int* __restrict__ peer_flags = nullptr) {
+  // peer_flags (peer-written exchange, behind the neighbours' rows flags): the word behind a neighbour's rows flag says how many rows of
+  // its block it wrote -- the ones this rank's slots need (PackNeed); else every row of the blocks is there
   __shared__ uint32_t s_nheavy;
   __shared__ uint32_t s_hb[CSSM_BLOCK], s_he[CSSM_BLOCK], s_hj[CSSM_BLOCK];
   const long long R = d + 1, HD = spec_hdr(d), seg = spec_seg(d, cap);
@@ -641,7 +784,19 @@ __device__ __forceinline__ void expand_spec_body(SpecHeaders& H, uint32_t bid, u
   // particles' first one all belong to the last-cap block of rank - 1 and those above to the first-cap block of rank + 1.
   // The rows are spread evenly over ALL blocks of the launch (a share of ceil(2 cap / blocks) each, done after the
   // block's own tile): extra blocks for them would start a second, nearly empty round on a chip the offspring blocks fill.
-  const long long total = 2 * cap;
+  // rows of rank - 1's LAST-cap block: the last n_lo of its cnt; rows of rank + 1's FIRST-cap block: the first n_hi
+  long long n_lo = (rank > 0) ? H.cnt[rank - 1] : 0, n_hi = (rank + 1 < world) ? H.cnt[rank + 1] : 0;
+  if (peer_flags != nullptr) {
+    if (rank > 0) {
+      const long long v = (long long)__hip_atomic_load(peer_flags + (size_t)(rank - 1) * CSSM_PEER_FLAG_STRIDE + CSSM_PEER_FLAG_NEED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      n_lo = (v < n_lo) ? v : n_lo;
+    }
+    if (rank + 1 < world) {
+      const long long v = (long long)__hip_atomic_load(peer_flags + (size_t)(rank + 1) * CSSM_PEER_FLAG_STRIDE + CSSM_PEER_FLAG_NEED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      n_hi = (v < n_hi) ? v : n_hi;
+    }
+  }
+  const long long total = n_lo + n_hi;
   const long long per = (total + nblk - 1) / nblk;
   const long long row_lo = (long long)bid * per, row_hi = (row_lo + per < total) ? row_lo + per : total;
   for (long long base = row_lo; base < row_hi; base += CSSM_BLOCK) {
@@ -649,9 +804,9 @@ __device__ __forceinline__ void expand_spec_body(SpecHeaders& H, uint32_t bid, u
     __syncthreads();
     const long long idx = base + threadIdx.x;
     if (idx < row_hi) {
-      const int s = (idx < cap) ? rank - 1 : rank + 1;
-      const long long i = (idx < cap) ? idx : idx - cap;
-      if (s >= 0 && s < world && i < H.cnt[s]) {
+      const int s = (idx < n_lo) ? rank - 1 : rank + 1;
+      const long long i = (idx < n_lo) ? H.cnt[rank - 1] - n_lo + idx : idx - n_lo;
+      {
         const double* h = recv + (size_t)s * seg;
         const cssm_u128 off = cssm_u128_add(H.off[s], H.base[s]);
         cssm_u128 P; P.lo = cssm_d2u(ld_sys_f64(h + HD + i * R + d)); P.hi = cssm_d2u(ld_sys_f64(h + HD + cap * R + i));
@@ -659,6 +814,8 @@ __device__ __forceinline__ void expand_spec_body(SpecHeaders& H, uint32_t bid, u
         uint64_t b;
         if (i == 0) {
           b = count_of(off);
+        } else if (idx == 0 && s < rank) {
+          b = slot_lo;   // (the row before the first needed one was not written: its run ends at or below this rank's first slot)
         } else {
           cssm_u128 Pp; Pp.lo = cssm_d2u(ld_sys_f64(h + HD + (i - 1) * R + d)); Pp.hi = cssm_d2u(ld_sys_f64(h + HD + cap * R + (i - 1)));
           b = count_of(cssm_u128_add(off, Pp));
@@ -703,7 +860,9 @@ template <int RAWC, int RS, bool GRP = false>
 __device__ __forceinline__ void offspring_expand_spec_body(
     CSSM_OFFSPRING_PARAMS, uint32_t all5_stride, const double* __restrict__ recv, long long cap, int d, uint32_t n_split,
     const cssm_u128* __restrict__ unit_pre, const unsigned int* __restrict__ peer_flags, uint32_t peer_seq,
-    const uint32_t blk0, const unsigned int* __restrict__ pre_flag) {
+    const uint32_t blk0, const unsigned int* __restrict__ pre_flag, SpecHeaders& H, uint32_t* __restrict__ s_ll) {
+  // H / s_ll: LDS of the launch, declared by the kernel (the merged kernel's pack blocks use the same two objects: static LDS of the
+  // two halves of a kernel adds up, it does not overlap)
   // blk0 / pre_flag (the merged kernel k_exchange_offspring): this body runs in blocks blk0 .. of the launch; unit_pre is written by
   // one of the blocks before them and announced through pre_flag
   const uint32_t bidx = blockIdx.x - blk0, nblk = gridDim.x - blk0;
@@ -712,7 +871,6 @@ __device__ __forceinline__ void offspring_expand_spec_body(
   // segment of rank r is complete once its flag holds peer_seq (PeerTable).  Every block waits for every rank's flag (thread r
   // polls rank r's, system-scope acquire, bounded): a rank that never delivers raises err bit 4 (16) here instead of hanging the
   // GPU, and the series ends like one on hold.
-  __shared__ SpecHeaders H;
   CSSM_SPEC_STAMP(0);
   __shared__ unsigned int s_late;
   const unsigned long long wait_ticks = (peer_flags != nullptr) ? sc->peer_wait_ticks : 0ull;   // (requested with the block's first loads)
@@ -744,35 +902,14 @@ __device__ __forceinline__ void offspring_expand_spec_body(
     const double rec_ref = rec->ref, rec_u = rec->u;
     if (held0 & (4u | 8u | 16u)) return;                     // (on hold / void / a peer missing: nobody delivers, nobody waits)
     bool mid_ok = false;                                     // (the body called mid and it said yes: this block resampled)
-    __shared__ uint32_t s_ll[64 * CSSM_PEER_LL_WORDS];      // the ranks' headers as they arrive: 24 halves per rank
     auto mid = [&](SpecTotals& tt) -> bool {
       SpecHdrRegs hregs;
       if (peer_flags != nullptr) {
-        // every rank's header through its self-validating words: thread (r, w) polls word w of rank r and keeps its half
-        if (threadIdx.x == 0) s_late = 0u;
-        __syncthreads();
-        for (uint32_t i = threadIdx.x; i < (uint32_t)world * CSSM_PEER_LL_WORDS; i += CSSM_BLOCK) {
-          const uint32_t r = i / CSSM_PEER_LL_WORDS, w = i % CSSM_PEER_LL_WORDS;
-          const unsigned long long* f = reinterpret_cast<const unsigned long long*>(peer_flags + (size_t)r * CSSM_PEER_FLAG_STRIDE + CSSM_PEER_FLAG_LL) + w;
-          unsigned int half = 0u;
-          if (!peer_poll_ll(f, peer_seq, wait_ticks, half)) { s_late = 1u; break; }
-          s_ll[i] = half;
-        }
-        __syncthreads();
-        if (s_late) {
+        if (!peer_headers_ll(hregs, s_ll, s_late, peer_flags, peer_seq, wait_ticks, world)) {
           if (threadIdx.x == 0) { atomicOr(&sc->err, 16u); atomicMin(&sc->fail_step, rec->step); }
           return false;
         }
         CSSM_SPEC_STAMP(7);
-#pragma unroll
-        for (int k = 0; k < 12; ++k) hregs.w[k] = 0.0;
-        if ((int)threadIdx.x < world) {
-          const uint32_t* h = s_ll + threadIdx.x * CSSM_PEER_LL_WORDS;
-          auto hw = [&](int k) { return cssm_u2d((unsigned long long)h[2 * k] | ((unsigned long long)h[2 * k + 1] << 32)); };
-          // (the order of spec_load_headers: count, S, base, the two block totals, S2, the key)
-          hregs.w[0] = hw(0); hregs.w[1] = hw(1); hregs.w[2] = hw(2); hregs.w[3] = hw(6); hregs.w[4] = hw(7); hregs.w[5] = hw(8); hregs.w[6] = hw(9);
-          hregs.w[7] = hw(10); hregs.w[8] = hw(11); hregs.w[9] = hw(3); hregs.w[10] = hw(4); hregs.w[11] = hw(5);
-        }
       } else {
         hregs = spec_load_headers(recv, world, cap, d);
       }
@@ -799,7 +936,7 @@ __device__ __forceinline__ void offspring_expand_spec_body(
     if (!mid_ok) return;   // (the body returned without resampling -- the level ruled out, block 0's verdict, a peer missing: no tail either)
     CSSM_SPEC_STAMP(2);
     if (peer_flags != nullptr && !wait_flags(CSSM_PEER_FLAG_ROWS, nullptr, rank - 1, rank + 1)) return;
-    expand_spec_body(H, bidx, nblk, recv, world, rank, cap, d, n_split, (uint64_t)slot_lo, (uint64_t)slot_hi, n_global, rec, anc, sc, RS, seed, slot_set);
+    expand_spec_body(H, bidx, nblk, recv, world, rank, cap, d, n_split, (uint64_t)slot_lo, (uint64_t)slot_hi, n_global, rec, anc, sc, RS, seed, slot_set, peer_flags);
     CSSM_SPEC_STAMP(3);
     return;
   }
@@ -851,7 +988,7 @@ __device__ __forceinline__ void offspring_expand_spec_body(
   CSSM_SPEC_STAMP(2);
   // the two neighbours' rows (their flags have long been set: the rows were written while this block resampled its own particles)
   if (peer_flags != nullptr && !wait_flags(CSSM_PEER_FLAG_ROWS, nullptr, rank - 1, rank + 1)) return;
-  expand_spec_body(H, bidx, nblk, recv, world, rank, cap, d, n_split, (uint64_t)slot_lo, (uint64_t)slot_hi, n_global, rec, anc, sc, RS, seed, slot_set);
+  expand_spec_body(H, bidx, nblk, recv, world, rank, cap, d, n_split, (uint64_t)slot_lo, (uint64_t)slot_hi, n_global, rec, anc, sc, RS, seed, slot_set, peer_flags);
   CSSM_SPEC_STAMP(3);
 }
 
@@ -859,7 +996,9 @@ template <int RAWC, int RS = CSSM_RESAMPLE_SYSTEMATIC, bool GRP = false>
 __global__ __launch_bounds__(CSSM_BLOCK, CSSM_OFF_WAVES) void k_offspring_expand_spec(
     CSSM_OFFSPRING_PARAMS, uint32_t all5_stride, const double* __restrict__ recv, long long cap, int d, uint32_t n_split,
     const cssm_u128* __restrict__ unit_pre, const unsigned int* __restrict__ peer_flags = nullptr, uint32_t peer_seq = 0u) {
-  offspring_expand_spec_body<RAWC, RS, GRP>(CSSM_OFFSPRING_FWD, all5_stride, recv, cap, d, n_split, unit_pre, peer_flags, peer_seq, 0u, nullptr);
+  __shared__ SpecHeaders H;
+  __shared__ uint32_t s_ll[GRP ? 64 * CSSM_PEER_LL_WORDS : 1];   // the ranks' headers as they arrive: 24 halves per rank (GRP launches read them)
+  offspring_expand_spec_body<RAWC, RS, GRP>(CSSM_OFFSPRING_FWD, all5_stride, recv, cap, d, n_split, unit_pre, peer_flags, peer_seq, 0u, nullptr, H, s_ll);
 }
 
 // The peer-written exchange in ONE launch per weighted observation behind the propagate: the first pack_gx * world blocks of the grid
@@ -870,6 +1009,7 @@ __global__ __launch_bounds__(CSSM_BLOCK, CSSM_OFF_WAVES) void k_offspring_expand
 struct PackArgs {
   const double* src; size_t stride; uint32_t nsub; uint64_t chunk; cssm_u128* pre_out;
   const PeerTable* peer; int parity; unsigned int* tickets; unsigned int* pre_flag; uint32_t pack_gx;
+  int all_rows;   // CSSM_PEER_ALL_ROWS: every row of the boundary blocks travels (else the needed ones: PackNeed)
 };
 // GRP: the group sums are at hand (slot_set = their set): the header blocks total them, the offspring blocks take their prefixes from them
 // (pk.pre_out == nullptr: the prefix block of every destination leaves at once)
@@ -878,13 +1018,19 @@ __global__ __launch_bounds__(CSSM_BLOCK, CSSM_OFF_WAVES) void k_exchange_offspri
     CSSM_OFFSPRING_PARAMS, uint32_t all5_stride, const double* __restrict__ recv, long long cap, int d, uint32_t n_split,
     const cssm_u128* __restrict__ unit_pre, const unsigned int* __restrict__ peer_flags, uint32_t peer_seq, PackArgs pk) {
   const uint32_t blk0 = pk.pack_gx * (uint32_t)world;
+  __shared__ SpecHeaders H;
+  __shared__ uint32_t s_ll[64 * CSSM_PEER_LL_WORDS];   // the ranks' headers as they arrive: 24 halves per rank
   if (blockIdx.x < blk0) {
-    boundary_pack_block(blockIdx.x % pk.pack_gx, pk.pack_gx, (int)(blockIdx.x / pk.pack_gx), pk.src, pk.stride, logw, n, d, world, rank, cap, rec,
+    PackNeed xn;
+    xn.H = &H; xn.ll = s_ll; xn.my_flags = peer_flags; xn.need = pk.tickets + CSSM_PEER_TICKET_NEED;
+    xn.stat = reinterpret_cast<unsigned long long*>(pk.tickets + CSSM_PEER_TICKET_STAT);
+    xn.n_global = n_global; xn.seed = seed; xn.slot_lo = slot_lo; xn.slot_hi = slot_hi; xn.rs = RS;
+    boundary_pack_block<RS>(blockIdx.x % pk.pack_gx, pk.pack_gx, (int)(blockIdx.x / pk.pack_gx), pk.src, pk.stride, logw, n, d, world, rank, cap, rec,
                         unitP, unitS2, pk.nsub, sc, nullptr, pk.chunk, /*level_from_max=*/0, pk.pre_out, pk.peer, pk.parity, peer_seq, pk.tickets,
-                        pk.pre_flag, GRP ? slot_set : -1);
+                        pk.pre_flag, GRP ? slot_set : -1, xn, !pk.all_rows, 3);
     return;
   }
-  offspring_expand_spec_body<RAWC, RS, GRP>(CSSM_OFFSPRING_FWD, all5_stride, recv, cap, d, n_split, unit_pre, peer_flags, peer_seq, blk0, pk.pre_flag);
+  offspring_expand_spec_body<RAWC, RS, GRP>(CSSM_OFFSPRING_FWD, all5_stride, recv, cap, d, n_split, unit_pre, peer_flags, peer_seq, blk0, pk.pre_flag, H, s_ll);
 }
 
 __global__ __launch_bounds__(CSSM_BLOCK) void k_expand(const uint32_t* __restrict__ cand_end, const uint32_t* __restrict__ cand_idx,

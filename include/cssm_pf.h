@@ -521,7 +521,8 @@ int cssm_pf_shard_series_rccl(cssm_pf* pf, void* comm, int rank, int world, size
  *   [the host exchanges the handles: every rank receives all `world` of them, in rank order]
  *   cssm_pf_shard_peer_connect  map them, build the device table
  *   cssm_pf_shard_series_peer   observations [s_begin, s_end) of the resident series (cssm_pf_shard_begin / _continue), or stage
- *                               by stage: cssm_pf_shard_propagate_at(s, NULL), cssm_pf_shard_pack_peer, cssm_pf_shard_adopt_peer
+ *                               by stage: cssm_pf_shard_propagate_at(s, NULL), cssm_pf_shard_pack_peer, cssm_pf_shard_pack_rows_peer,
+ *                               cssm_pf_shard_adopt_peer
  *   cssm_pf_shard_peer_close    unmap and free (also done by cssm_pf_destroy)
  * model/ParticleFilter.scala:116-132 is the step whose resampling this exchange completes across GPUs. */
 typedef struct cssm_peer_handle {
@@ -546,9 +547,19 @@ int cssm_pf_shard_peer_handshake(cssm_pf* pf, uint32_t token);
 uint32_t cssm_pf_shard_peer_probe_stale(const cssm_pf* pf);
 void cssm_pf_shard_peer_close(cssm_pf* pf);
 int cssm_pf_shard_pack_peer(cssm_pf* pf, int rank, int world, int64_t cap);
+/* (round 5) NEEDED ROWS ONLY.  A boundary block holds `cap` rows (sized for the worst observation, ~6 sqrt(N_global)), a typical
+ * observation's neighbour needs a few hundred of them, and every row is a remote store over one xGMI link.  Once the headers of all ranks
+ * are there the SENDER can tell which rows the neighbour's slots need (end slot beyond its own last slot / run starting below its own
+ * first slot: the arithmetic the reader uses), so the pack's row blocks wait for the headers, write those rows only and publish their
+ * number next to the rows flag; the reader expands exactly those.  In stage-by-stage use the rows are therefore a stage of their own:
+ * cssm_pf_shard_pack_peer (headers) on every shard, cssm_pf_shard_pack_rows_peer on every shard, cssm_pf_shard_adopt_peer on every shard.
+ * CSSM_PEER_ALL_ROWS=1 (read when the handle is created) keeps the old behaviour -- every row travels, pack_rows_peer does nothing.
+ * cssm_pf_shard_peer_rows: rows written for neighbours / neighbour segments so far (diagnostics; both 0 with CSSM_PEER_ALL_ROWS=1). */
+int cssm_pf_shard_pack_rows_peer(cssm_pf* pf, int rank, int world, int64_t cap);
+int cssm_pf_shard_peer_rows(cssm_pf* pf, uint64_t* rows_out, uint64_t* segments_out);
 int cssm_pf_shard_adopt_peer(cssm_pf* pf, int rank, int world, int64_t cap);
 /* pack + adopt in ONE launch (the pack blocks lead the grid): for a rank that has its stream to itself, i.e. one process per GPU --
- * what cssm_pf_shard_series_peer enqueues.  Shards that share a stream use the two stage calls, every pack before any adopt. */
+ * what cssm_pf_shard_series_peer enqueues.  Shards that share a stream use the stage calls, every stage on all shards before the next. */
 int cssm_pf_shard_exchange_peer(cssm_pf* pf, int rank, int world, int64_t cap);
 int cssm_pf_shard_series_peer(cssm_pf* pf, int rank, int world, size_t s_begin, size_t s_end, const uint8_t* weighted, int64_t cap);
 

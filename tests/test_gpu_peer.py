@@ -49,6 +49,49 @@ def test_peer_exchange_local_shards_match_single_rank_oracle(world, name, n):
         s.close()
 
 
+@pytest.mark.parametrize("stratified", [False, True])
+@pytest.mark.parametrize("world,n", [(2, 40000), (4, 30000), (8, 100000)])
+def test_only_the_rows_a_neighbour_needs_travel(world, n, stratified, monkeypatch):
+    """The boundary blocks are sized for the worst observation (CAP_SQRT x sqrt(N) rows, at least a unit); the pack's row blocks wait for
+    every rank's header and write the rows the neighbour's slots need (cssm_pf.h: cssm_pf_shard_pack_rows_peer) -- a small part of the
+    capacity -- and the readers expand exactly those: the bits of the oracle, the bits of CSSM_PEER_ALL_ROWS=1 (every row travels)."""
+    model = cases.c2_model()
+    t, y, has = cases.poisson_counts(14, missing=0.15)
+    rs = oracle.RESAMPLE_STRATIFIED if stratified else 0
+    o = oracle.OraclePf(model.descriptor(), n, cases.SEED, rs)
+    oll, _, oess, _ = o.filter(t, y, has)
+    got = {}
+    for all_rows in (False, True):
+        if all_rows:
+            monkeypatch.setenv("CSSM_PEER_ALL_ROWS", "1")      # (read when a handle is created)
+        else:
+            monkeypatch.delenv("CSSM_PEER_ALL_ROWS", raising=False)
+        shards, f = _peer_filter(model, n, world)
+        if stratified:
+            for s in shards:
+                s.set_option(2, 1)
+        ll, ess = f.ll_filter(t, y, has)
+        assert f.last_peer and f.last_single and f.last_attempts == 1
+        assert (ll, ess) == (oll, oess[-1])
+        part = np.concatenate([s.particles() for s in shards], axis=1)
+        np.testing.assert_array_equal(part, o.particles())
+        rows = [s.peer_rows() for s in shards]
+        got[all_rows] = (ll, ess, rows, f.last_cap)
+        # ... and a continued series on the same windows
+        f.ll_filter(t[:6], y[:6], has[:6])
+        assert f.ll_filter_more(t[6:], y[6:], has[6:]) == (oll, oess[-1])
+        for s in shards:
+            s.close()
+    weighted = int(np.count_nonzero(has))
+    rows, cap = got[False][2], got[False][3]
+    assert all(r == (0, 0) for r in got[True][2])                # nothing counted when every row travels
+    for r, (nrows, nseg) in enumerate(rows):
+        neighbours = (1 if r > 0 else 0) + (1 if r + 1 < world else 0)
+        assert nseg == neighbours * weighted, (r, nseg)
+        full = neighbours * weighted * min(cap, n // world)
+        assert 0 < nrows < full // 4, (r, nrows, full)           # a fraction of what the capacity would send
+
+
 @pytest.mark.parametrize("world,n", [(2, 3000), (4, 9000), (8, 20000)])
 @pytest.mark.parametrize("name", ["c4_model", "lgcp_seasonal_model"])
 def test_peer_exchange_lgcp(world, n, name):
