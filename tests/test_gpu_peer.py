@@ -224,17 +224,24 @@ def _ipc_rank(rank, world, port, n, T, outdir):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,grp", [(2, False), (3, False), (2, True), (4, False), (4, True)])
-def test_peer_exchange_between_processes_sharing_the_gpu(tmp_path, world, grp, monkeypatch):
+@pytest.mark.parametrize("world,grp,mode", [(2, False, ""), (3, False, ""), (2, True, ""), (4, False, ""), (4, True, ""),
+                                            (3, True, "stages"), (3, False, "all_rows")])
+def test_peer_exchange_between_processes_sharing_the_gpu(tmp_path, world, grp, mode, monkeypatch):
     """`world` PROCESSES, all on this GPU, each mapping the others' windows through hipIpcOpenMemHandle: the handles, the
     device table, the flags (world x world of them), the self-validating header words and the window alternation as across GPUs (what
     one GPU cannot show is xGMI visibility; the handshake's probe words are read back here too).  Small clouds, so that the processes'
     kernels fit the GPU side by side.  grp: the exchange on the group sums (CSSM_GRP_MIN_UNITS = 1 sends these few units through them).
     World 4 is as far as this goes: a GPU box admits six processes on its card, and the test runner is one of them -- eight ranks
-    cannot be started here (the in-process shards of LocalCommPeer cover world 8, without the IPC mapping)."""
+    cannot be started here (the in-process shards of LocalCommPeer cover world 8, without the IPC mapping).
+    mode "stages": the library's series loop enqueues the exchange as its three stage launches (headers / needed rows / adopt:
+    CSSM_PEER_TWO_LAUNCHES) instead of the merged kernel; "all_rows": every row of the boundary blocks travels (CSSM_PEER_ALL_ROWS)."""
     import torch.multiprocessing as mp
     if grp:
         monkeypatch.setenv("CSSM_GRP_MIN_UNITS", "1")
+    if mode == "stages":
+        monkeypatch.setenv("CSSM_PEER_TWO_LAUNCHES", "1")
+    if mode == "all_rows":
+        monkeypatch.setenv("CSSM_PEER_ALL_ROWS", "1")
     n, T = 4096 * world, 9
     port = 29700 + (os.getpid() % 200) + world
     mp.spawn(_ipc_rank, args=(world, port, n, T, str(tmp_path)), nprocs=world, join=True)
