@@ -614,11 +614,12 @@ def run_multi(args, emit=print):
         mine["collectives_per_observation"] = round(prof["collective"][1] / max(prof["k_propagate"][1], 1), 2)
         mine["note"] = "bracketed event times include ~2 us of event-record overhead per launch; a collective's time includes waiting for the slowest peer"
         if getattr(f, "last_peer", False):
-            # what went over the links: rows this rank wrote into its neighbours' windows (the needed ones; the capacity is what
-            # CSSM_PEER_ALL_ROWS=1 would write), per neighbour segment and observation, pre-flight and warm-up included
-            nrows, nseg = shard.peer_rows()
+            # what went over the links: rows this rank wrote into its neighbours' windows -- per neighbour segment and observation the
+            # eager rows (written at once) or, where more were needed, the needed ones; pre-flight and warm-up included
+            nrows, nseg, beyond = shard.peer_rows()
             rb = (shard.d + 2) * 8
-            mine["rows_to_neighbours"] = {"rows": nrows, "segments": nseg, "mean_rows_per_segment": round(nrows / nseg, 1) if nseg else None,
+            mine["rows_to_neighbours"] = {"rows": nrows, "segments": nseg, "segments_needing_rows_beyond_the_eager_ones": beyond,
+                                          "mean_rows_per_segment": round(nrows / nseg, 1) if nseg else None,
                                           "mean_bytes_per_segment": round(nrows / nseg * rb) if nseg else None, "capacity_rows": f.last_cap,
                                           "capacity_bytes": f.last_cap * rb}
     every = [None] * world

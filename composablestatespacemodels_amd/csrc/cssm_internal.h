@@ -111,7 +111,8 @@ struct cssm_pf : HostModel {
   uint32_t peer_probe_plain_bad = 0;   // cssm_pf_shard_peer_probe_stale
   bool peer_packed = false;    // cssm_pf_shard_pack_peer ran, cssm_pf_shard_adopt_peer has not yet
   bool peer_rows_packed = false;   // ... and cssm_pf_shard_pack_rows_peer (the second stage of a pack that sends the needed rows only)
-  bool peer_all_rows = false;  // CSSM_PEER_ALL_ROWS=1: every row of the boundary blocks travels (else only the rows the neighbour's slots need)
+  bool peer_all_rows = false;  // CSSM_PEER_ALL_ROWS=1: every row of the boundary blocks travels (else the eager rows + what the neighbour's slots need beyond them)
+  long long peer_eager = 4096; // CSSM_PEER_EAGER_ROWS: rows next to the boundary that travel at once, ahead of the headers (four tiles)
   bool want_path = false;      // sharded `filter`: record sampleOne's pick after every observation whose slot this rank owns
   uint32_t rec_base = 0;       // observation index (pf->step) of the resident series' first record: 0 after _begin, the filter's
                                //   observation count so far after _continue

@@ -411,7 +411,7 @@ extern "C" int cssm_pf_shard_resume(cssm_pf* pf, uint32_t* fail_step_out) {
   // (pack blocks of the held launches that returned without their ticket while siblings took theirs would leave a count behind)
   if (pf->peer_tickets) {
     HIP_TRY(hipMemsetAsync(pf->peer_tickets, 0, 96 * sizeof(unsigned int), pf->stream));
-    HIP_TRY(hipMemsetAsync(pf->peer_tickets + CSSM_PEER_TICKET_NEED, 0, 64 * sizeof(unsigned int), pf->stream));   // (PackNeed::need likewise)
+    HIP_TRY(hipMemsetAsync(pf->peer_tickets + CSSM_PEER_TICKET_NEED, 0, 128 * sizeof(unsigned int), pf->stream));   // (PackNeed::need and the second set of tickets likewise)
   }
   HIP_TRY(hipStreamSynchronize(pf->stream));
   const cssm_pf::Snap& q = pf->snaps[s];
@@ -447,7 +447,7 @@ extern "C" int cssm_pf_shard_resume_level(cssm_pf* pf, uint32_t* fail_step_out) 
   HIP_TRY(hipMemcpyAsync(&pf->sc->fail_step, &h.fail_step, sizeof(uint32_t), hipMemcpyHostToDevice, pf->stream));
   if (pf->peer_tickets) {
     HIP_TRY(hipMemsetAsync(pf->peer_tickets, 0, 96 * sizeof(unsigned int), pf->stream));
-    HIP_TRY(hipMemsetAsync(pf->peer_tickets + CSSM_PEER_TICKET_NEED, 0, 64 * sizeof(unsigned int), pf->stream));   // (PackNeed::need likewise)
+    HIP_TRY(hipMemsetAsync(pf->peer_tickets + CSSM_PEER_TICKET_NEED, 0, 128 * sizeof(unsigned int), pf->stream));   // (PackNeed::need and the second set of tickets likewise)
   }
   HIP_TRY(hipStreamSynchronize(pf->stream));
   const cssm_pf::Snap& q = pf->pre_snaps[s];
@@ -469,7 +469,9 @@ extern "C" int64_t cssm_pf_shard_spec_segment(const cssm_pf* pf, int64_t cap) {
   return (pf && cap >= 1) ? (int64_t)spec_seg(pf->d, (long long)cap) : 0;
 }
 
-static int boundary_pack_impl(cssm_pf* pf, int rank, int world, int64_t cap, double* send_buf_dev, bool peer, int phase = 3);
+static int boundary_pack_impl(cssm_pf* pf, int rank, int world, int64_t cap, double* send_buf_dev, bool peer, int phase = 7);
+// rows next to the boundary that the peer-written exchange writes at once (>= cap: every row travels)
+static long long peer_eager_rows(const cssm_pf* pf, int64_t cap) { return pf->peer_all_rows ? (long long)cap : std::min<long long>(pf->peer_eager, (long long)cap); }
 extern "C" int cssm_pf_shard_boundary_pack(cssm_pf* pf, int rank, int world, int64_t cap, double* send_buf_dev) {
   int rc = shard_check(pf);
   if (rc) return rc;
@@ -477,7 +479,7 @@ extern "C" int cssm_pf_shard_boundary_pack(cssm_pf* pf, int rank, int world, int
   return boundary_pack_impl(pf, rank, world, cap, send_buf_dev, false);
 }
 static int boundary_pack_impl(cssm_pf* pf, int rank, int world, int64_t cap, double* send_buf_dev, bool peer, int phase) {
-  // phase (peer): 1 = headers and unit-sum prefixes, 2 = rows, 3 = both (boundary_pack_block)
+  // phase (peer): bit 0 = headers and unit-sum prefixes, bit 1 = eager rows, bit 2 = needed rows beyond them (boundary_pack_block)
   if (cap < 1 || world < 1 || world > 64 || rank < 0 || rank >= world) return fail(CSSM_ESHARD, "rank %d / world %d / cap %lld", rank, world, (long long)cap);
   // !last_optimistic: the sums were formed by cssm_pf_shard_sums relative to the level chosen with the all-gathered max
   const size_t slot = last_rec_slot(pf);
@@ -497,7 +499,7 @@ static int boundary_pack_impl(cssm_pf* pf, int rank, int world, int64_t cap, dou
                      (const Scalars*)pf->sc, send_buf_dev, chunk, pf->last_optimistic ? 0 : 1,
                      pre ? pf->unitPre : (cssm_u128*)nullptr,
                      peer ? (const PeerTable*)pf->peer_tab : (const PeerTable*)nullptr, (int)(pf->peer_seq & 1u), pf->peer_seq, pf->peer_tickets, grp_set,
-                     phase, (peer && !pf->peer_all_rows) ? 1 : 0, pf->n_global, pf->seed, pf->resampler, (uint64_t)pf->first, (uint64_t)(pf->first + pf->n));
+                     phase, peer ? peer_eager_rows(pf, cap) : (long long)cap, pf->n_global, pf->seed, pf->resampler, (uint64_t)pf->first, (uint64_t)(pf->first + pf->n));
   pf->spec_pre = pre;   // (k_offspring_expand_spec reads them: cssm_pf_shard_adopt_spec)
   prof_end(pf);
   HIP_TRY(hipGetLastError());
@@ -541,7 +543,7 @@ static int adopt_spec_impl(cssm_pf* pf, const double* recv_buf_dev, int rank, in
     pk.peer = (const PeerTable*)pf->peer_tab; pk.parity = (int)(peer_seq & 1u); pk.tickets = pf->peer_tickets;
     pk.pre_flag = pre ? pf->peer_tickets + 64 : (unsigned int*)nullptr;
     pk.pack_gx = (uint32_t)((cnt + CSSM_TILE - 1) / CSSM_TILE) + 2u;
-    pk.all_rows = pf->peer_all_rows ? 1 : 0;
+    pk.eager = peer_eager_rows(pf, cap);
     pf->spec_pre = pre;
     auto kx = (pf->resampler == CSSM_RESAMPLE_STRATIFIED)
                   ? (grp ? k_exchange_offspring<2, CSSM_RESAMPLE_STRATIFIED, true> : k_exchange_offspring<2, CSSM_RESAMPLE_STRATIFIED>)
@@ -563,7 +565,7 @@ static int adopt_spec_impl(cssm_pf* pf, const double* recv_buf_dev, int rank, in
                      all5, rank, world, pf->last_optimistic ? (int)pf->split : 1, pf->seed, (double*)nullptr, (const double*)pf->d_logtab,
                      pf->last_optimistic ? 2 : 0, (unsigned long long*)(pf->d_xch + 128), (uint32_t)pf->first, (uint32_t)(pf->first + pf->n), (uint32_t)seg,
                      recv_buf_dev, (long long)cap, pf->d, n_split, pf->spec_pre ? (const cssm_u128*)pf->unitPre : (const cssm_u128*)nullptr,
-                     peer_flags, peer_seq);
+                     peer_flags, peer_seq, peer_flags ? peer_eager_rows(pf, cap) : (long long)cap);
   } else {
     auto ke = (pf->resampler == CSSM_RESAMPLE_STRATIFIED) ? k_offspring_expand_spec<0, CSSM_RESAMPLE_STRATIFIED> : k_offspring_expand_spec<0, CSSM_RESAMPLE_SYSTEMATIC>;
     hipLaunchKernelGGL(ke, dim3(tgrid), dim3(CSSM_BLOCK), 0, pf->stream, pf->logw, pf->n, pf->sc,
@@ -572,7 +574,7 @@ static int adopt_spec_impl(cssm_pf* pf, const double* recv_buf_dev, int rank, in
                      all5, rank, world, pf->last_optimistic ? (int)pf->split : 1, pf->seed, (double*)nullptr, (const double*)pf->d_logtab,
                      pf->last_optimistic ? 2 : 0, (unsigned long long*)(pf->d_xch + 128), (uint32_t)pf->first, (uint32_t)(pf->first + pf->n), (uint32_t)seg,
                      recv_buf_dev, (long long)cap, pf->d, n_split, pf->spec_pre ? (const cssm_u128*)pf->unitPre : (const cssm_u128*)nullptr,
-                     peer_flags, peer_seq);
+                     peer_flags, peer_seq, peer_flags ? peer_eager_rows(pf, cap) : (long long)cap);
   }
   prof_end(pf);
   HIP_TRY(hipGetLastError());
@@ -774,9 +776,10 @@ extern "C" int cssm_pf_shard_pack_peer(cssm_pf* pf, int rank, int world, int64_t
   if (pf->peer_packed) return fail(CSSM_ESTATE, "cssm_pf_shard_pack_peer twice without cssm_pf_shard_adopt_peer");
   pf->peer_seq++;
   pf->peer_packed = true;
-  pf->peer_rows_packed = pf->peer_all_rows;
-  // (needed rows only: the rows are a stage of their own, cssm_pf_shard_pack_rows_peer -- their blocks wait for every rank's header)
-  return boundary_pack_impl(pf, rank, world, cap, nullptr, true, pf->peer_all_rows ? 3 : 1);
+  const bool all = peer_eager_rows(pf, cap) >= (long long)cap;
+  pf->peer_rows_packed = all;
+  // (the rows beyond the eager ones are a stage of their own, cssm_pf_shard_pack_rows_peer -- their blocks wait for every rank's header)
+  return boundary_pack_impl(pf, rank, world, cap, nullptr, true, all ? 7 : 3);
 }
 // Second stage of the pack: the rows of the boundary blocks that the neighbours' slots need, once every rank's header is on its way --
 // a host that drives several shards on ONE stream calls cssm_pf_shard_pack_peer on all of them, then this on all of them, then
@@ -790,21 +793,24 @@ extern "C" int cssm_pf_shard_pack_rows_peer(cssm_pf* pf, int rank, int world, in
   if (!pf->peer_packed) return fail(CSSM_ESTATE, "cssm_pf_shard_pack_rows_peer without cssm_pf_shard_pack_peer");
   if (pf->peer_rows_packed) return CSSM_OK;
   pf->peer_rows_packed = true;
-  return boundary_pack_impl(pf, rank, world, cap, nullptr, true, 2);
+  return boundary_pack_impl(pf, rank, world, cap, nullptr, true, 4);
 }
-// Rows the pack stages of this handle wrote for its neighbours since the windows were set up, and the number of neighbour segments they
-// went into (needed rows only; CSSM_PEER_ALL_ROWS=1 leaves both at zero: every segment then carries min(n_local, cap) rows)
-extern "C" int cssm_pf_shard_peer_rows(cssm_pf* pf, uint64_t* rows_out, uint64_t* segments_out) {
+// Rows the pack stages of this handle wrote for its neighbours since the windows were set up (per segment: the eager rows, or the needed
+// ones where they were more), the number of neighbour segments they went into, and how many of those needed rows beyond the eager ones
+// (where every row travels -- CSSM_PEER_ALL_ROWS=1 or an eager count >= the capacity -- that is the whole block per segment, none beyond)
+extern "C" int cssm_pf_shard_peer_rows(cssm_pf* pf, uint64_t* rows_out, uint64_t* segments_out, uint64_t* beyond_out) {
   int rc = shard_check(pf);
   if (rc) return rc;
   if (!rows_out || !segments_out) return fail(CSSM_EINVAL_ARG, "null argument");
   *rows_out = 0; *segments_out = 0;
+  if (beyond_out) *beyond_out = 0;
   if (!pf->peer_tickets) return CSSM_OK;
   rc = bounded_sync(pf);
   if (rc) return rc;
-  unsigned long long st[2] = {0ull, 0ull};
+  unsigned long long st[3] = {0ull, 0ull, 0ull};
   HIP_TRY(hipMemcpy(st, pf->peer_tickets + CSSM_PEER_TICKET_STAT, sizeof st, hipMemcpyDeviceToHost));
   *rows_out = st[0]; *segments_out = st[1];
+  if (beyond_out) *beyond_out = st[2];
   return CSSM_OK;
 }
 extern "C" int cssm_pf_shard_adopt_peer(cssm_pf* pf, int rank, int world, int64_t cap) {

@@ -123,20 +123,32 @@ __device__ __forceinline__ bool peer_poll_ll(const unsigned long long* f, unsign
 // run starts below this rank's first slot (a prefix).  The row blocks of the pack therefore wait for the headers too (the header blocks wait
 // for nothing, so nobody waits in a circle), write only those rows, and the block that takes the last ticket publishes their number in the
 // word behind the rows flag (`need`: rows [cnt - need, cnt) of the block for rank + 1, rows [0, need) of the block for rank - 1) before it
-// sets the flag.  The reader expands exactly those.  CSSM_PEER_ALL_ROWS=1: every row travels as before (need = cnt).
-#define CSSM_PEER_FLAG_NEED (CSSM_PEER_FLAG_ROWS + 1)
+// sets the flag.  The reader expands exactly those.
+// ... and EAGER ROWS, so that none of this lies on the reader's critical path: the `eager` rows next to the boundary (one tile by default,
+// CSSM_PEER_EAGER_ROWS; a typical observation needs a quarter of that) are written AT ONCE -- they need no header -- with a flag of their
+// own (ROWS), long set by the time the reader has resampled its own particles.  Only rows beyond them go the way described above, behind
+// a second flag (EXTRA), and the reader waits for that one only if the eager rows do not reach its first / last slot -- which it sees from
+// the eager rows themselves (the cumulative weight in front of the first eager row travels with them: PSTART).  eager >= cap is "every
+// row travels" (CSSM_PEER_ALL_ROWS=1, and what the collective exchange does); eager = 0 "needed rows only, all behind the headers".
+#define CSSM_PEER_FLAG_NEED (CSSM_PEER_FLAG_ROWS + 1)    /* rows of the block that were needed (0: none beyond the eager ones) */
+#define CSSM_PEER_FLAG_EXTRA (CSSM_PEER_FLAG_ROWS + 2)   /* exchange number: the needed rows beyond the eager ones are complete */
+#define CSSM_PEER_FLAG_PSTART (CSSM_PEER_FLAG_ROWS + 4)  /* two 8-byte words: cumulative weight in front of the first eager row (block for rank + 1) */
 // the handle's local words of the protocol (cssm_pf::peer_tickets, CSSM_PEER_TICKET_WORDS uint32): [0, 64) tickets per destination,
-// [64] the flag of the unit-sum prefixes (merged kernel), [96, 100) results of the handshake, [100, 104) PackNeed::stat, [128, 192) PackNeed::need
+// [64] the flag of the unit-sum prefixes (merged kernel), [96, 100) results of the handshake, [100, 108) PackNeed::stat, [128, 192) PackNeed::need,
+// [192, 256) tickets of the rows beyond the eager ones
 #define CSSM_PEER_TICKET_WORDS 256
 #define CSSM_PEER_TICKET_STAT 100
 #define CSSM_PEER_TICKET_NEED 128
+#define CSSM_PEER_TICKET_EXTRA 192
 struct SpecHeaders;
 struct PackNeed {
   SpecHeaders* H; uint32_t* ll;          // LDS of the launch: the ranks' headers, the 24 halves per rank they arrive as
   const unsigned int* my_flags;          // this rank's flags of the window of this exchange (the peers' headers land there)
   unsigned int* need;                    // [q]: rows destination q needs -- max over the row blocks (device memory, zero between launches)
-  unsigned long long* stat;              // [0] += rows written for the neighbours, [1] += neighbour segments (diagnostics)
+  unsigned long long* stat;              // [0] += rows written for the neighbours, [1] += neighbour segments, [2] += segments that needed rows
+                                         //   beyond the eager ones (diagnostics)
   uint64_t n_global, seed, slot_lo, slot_hi;
+  long long eager;                       // rows next to the boundary that travel at once (>= cap: all of them)
   int rs;
 };
 
@@ -288,10 +300,11 @@ __device__ __forceinline__ void boundary_pack_block(const uint32_t bx, const uin
                                                               unsigned int* __restrict__ tickets, unsigned int* __restrict__ pre_flag,
                                                               const int grp_set, const PackNeed& xnr, const bool need_on, const int phase) {
   const PackNeed* xn = &xnr;
-  // need_on (peer-written exchange): only the rows the neighbours' slots need are written (PackNeed: the row blocks wait for
-  // every rank's header first).  phase: bit 0 = the header and prefix blocks work, bit 1 = the row blocks do -- shards of ONE process that
-  // share a stream launch the two phases apart, all headers before any rows: a row block of the first shard would otherwise wait for a
-  // header that a launch BEHIND it on the same stream is to write
+  // need_on (peer-written exchange; xn.eager < cap): the eager rows travel at once, of the others those the neighbours need, behind every
+  // rank's header (PackNeed).  phase: bit 0 = the header and prefix blocks work, bit 1 = the row blocks write their eager rows, bit 2 = the
+  // row blocks write needed rows beyond them -- shards of ONE process that share a stream launch bits 0 | 1 and bit 2 apart, every shard's
+  // headers before any shard waits for them: a row block of the first shard would otherwise wait for a header that a launch BEHIND it on
+  // the same stream is to write
   // grp_set >= 0: k_propagate's blocks accumulated the sums (and sums of squares) of groups of 32 units in that set of Scalars::grp / grp2:
   // the header block totals 2 x 32 group sums in ONE wave instead of 2 x nsub unit sums in four (it is the head of the exchange's critical
   // path: every offspring block of every rank waits for it -- 3.4 us from entry to flag at 1024 units, tools/exchange_stamps.py)
@@ -308,7 +321,8 @@ __device__ __forceinline__ void boundary_pack_block(const uint32_t bx, const uin
   // sub-units, the prefix of the tiles before a block's own is read from subS instead of being recomputed
   __shared__ cssm_u128 s_w[CSSM_BLOCK / 64], s_r[2][CSSM_BLOCK / 64];
   __shared__ unsigned int s_need, s_hlate;
-  const bool exact = need_on && peer != nullptr;
+  // rows next to the boundary that travel at once (PackNeed; every row where nobody asked for less: the collective exchange, CSSM_PEER_ALL_ROWS)
+  const long long eager = (need_on && peer != nullptr) ? xn->eager : cap;
   // the series is on hold (capacity miss), void (level ruled out) or a peer is missing: nothing may change -- tested where a block is
   // about to store (everything before is loads and arithmetic: at the head of the block the test was a round trip of its own in a
   // kernel that is one latency chain, and in the merged kernel the pollers of every rank wait for that chain)
@@ -327,29 +341,41 @@ __device__ __forceinline__ void boundary_pack_block(const uint32_t bx, const uin
         __hip_atomic_store(peer->flag[parity][q] + (size_t)rank * CSSM_PEER_FLAG_STRIDE, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
       return;
     }
+  };
+  // rows this block wrote are done (all threads call).  extra = false: its EAGER rows -- the last block's ticket sets the ROWS flag;
+  // extra = true: its needed rows beyond them -- the block's count joins the destination's maximum, the last ticket publishes it (NEED) and
+  // sets the EXTRA flag
+  auto rows_done = [&](const bool extra) {
+    if (peer == nullptr) return;
     __threadfence_system();
     __syncthreads();
     if (threadIdx.x == 0) {
       unsigned int* f = peer->flag[parity][q] + (size_t)rank * CSSM_PEER_FLAG_STRIDE;
-      {
-        const unsigned int nblk = gx - 2u;                // (the row blocks of this destination)
-        if (exact && cnt > 0) {                           // this block's needed rows into the destination's maximum, ahead of its ticket
-          const unsigned int mine = s_need;
-          if (mine) atomicMax(&xn->need[q], mine);
-          __threadfence();
-        }
+      const unsigned int nblk = gx - 2u;                // (the row blocks of this destination)
+      if (!extra) {
         const unsigned int t = atomicAdd(&tickets[q], 1u);
         if (t + 1u == nblk) {
-          tickets[q] = 0u;                                // (the next launch on this stream starts from zero)
-          unsigned int nn = (unsigned int)cnt;            // (every row travelled)
-          if (exact && cnt > 0) {
-            __threadfence();
-            nn = atomicExch(&xn->need[q], 0u);
-            atomicAdd(&xn->stat[0], (unsigned long long)nn); atomicAdd(&xn->stat[1], 1ull);
+          tickets[q] = 0u;                              // (the next launch on this stream starts from zero)
+          __threadfence_system();
+          __hip_atomic_store(f + CSSM_PEER_FLAG_ROWS, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+      } else {
+        unsigned int* tk = tickets + CSSM_PEER_TICKET_EXTRA;
+        const unsigned int mine = s_need;
+        if (mine) { atomicMax(&xn->need[q], mine); __threadfence(); }
+        const unsigned int t = atomicAdd(&tk[q], 1u);
+        if (t + 1u == nblk) {
+          tk[q] = 0u;
+          __threadfence();
+          const unsigned int nn = atomicExch(&xn->need[q], 0u);
+          if (cnt > 0) {
+            const unsigned int eg = (unsigned int)((long long)cnt < eager ? (long long)cnt : eager);
+            atomicAdd(&xn->stat[0], (unsigned long long)(nn > eg ? nn : eg)); atomicAdd(&xn->stat[1], 1ull);
+            if (nn > eg) atomicAdd(&xn->stat[2], 1ull);
           }
           __hip_atomic_store(f + CSSM_PEER_FLAG_NEED, nn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
           __threadfence_system();
-          __hip_atomic_store(f + CSSM_PEER_FLAG_ROWS, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+          __hip_atomic_store(f + CSSM_PEER_FLAG_EXTRA, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
         }
       }
     }
@@ -408,22 +434,38 @@ __device__ __forceinline__ void boundary_pack_block(const uint32_t bx, const uin
     return;
   }
   const bool header_block = (bx == gx - 2);
-  if (!(phase & (header_block ? 1 : 2))) return;
+  if (header_block && !(phase & 1)) return;
   if (header_block) CSSM_SPEC_STAMP(4);
   if (!header_block) {
-  if (cnt == 0) { if (held) return; peer_done(false); return; }
-  if (exact) {
-    // needed rows only: every rank's header first (the offspring blocks of this launch wait for the same words; ahead of the tile's own
-    // loads so that the header words and the tile's weights are not held in registers together)
-    if (held) return;
-    if (threadIdx.x == 0) s_need = 0u;
+  // stage A (phase bit 1): the eager rows of this tile; stage B (bit 2): its needed rows beyond them, behind every rank's header
+  const bool do_a = (phase & 2) != 0, do_b = (phase & 4) != 0;
+  if (!do_a && !do_b) return;
+  if (held) return;
+  if (threadIdx.x == 0) s_need = 0u;
+  if (cnt == 0) return;   // (not a neighbour: no rows, and nobody waits for a rows flag of this segment)
+  // this tile's rows [base, tile_end) of the block; the eager rows are [e_lo, e_hi): the block's last E for rank + 1, its first E for rank - 1
+  const uint64_t base = (uint64_t)bx * CSSM_TILE;
+  const long long E = (eager < cnt) ? (eager > 0 ? eager : 0) : cnt;
+  const long long e_lo = (q > rank) ? cnt - E : 0, e_hi = (q > rank) ? cnt : E;
+  const long long tile_end = ((long long)base + CSSM_TILE < cnt) ? (long long)base + CSSM_TILE : cnt;
+  const bool work_a = do_a && e_lo < tile_end && (long long)base < e_hi;                                // (uniform)
+  const bool work_b = do_b && E < cnt && !(e_lo <= (long long)base && tile_end <= e_hi);                // (uniform: rows outside the eager range)
+  bool have_headers = false;
+  auto wait_headers = [&]() -> bool {   // every rank's header -> *xn->H (the offspring blocks of this launch wait for the same words)
     SpecHdrRegs hregs;
     if (!peer_headers_ll(hregs, xn->ll, s_hlate, xn->my_flags, seq, sc->peer_wait_ticks, world)) {
       if (threadIdx.x == 0) { atomicOr(&const_cast<Scalars*>(sc)->err, 16u); atomicMin(&const_cast<Scalars*>(sc)->fail_step, rec->step); }
-      return;   // (a peer's header did not come: no ticket, no rows flag -- the series ends on every rank like one on hold)
+      return false;   // (a peer's header did not come: no ticket, no flag -- the series ends on every rank like one on hold)
     }
     spec_store_headers(*xn->H, hregs, world, cap);
-  }
+    have_headers = true;
+    return true;
+  };
+  // (a tile without eager rows: the headers ahead of the tile's own loads, so that the header words and the tile's sums are not held in
+  //  registers together)
+  if (work_b && !work_a && !wait_headers()) return;
+  cssm_u128 run0 = cssm_u128_zero(), tsum = cssm_u128_zero();   // exclusive prefix of the thread's first row inside the block; sum of its rows
+  if (work_a || work_b) {
   // prefix of the tiles before this block's tile
   cssm_u128 toff = cssm_u128_zero();
   // The carried block starts on a boundary of the sub-units whose sums k_propagate (or k_tile_sums) formed -- chunk particles
@@ -453,13 +495,13 @@ __device__ __forceinline__ void boundary_pack_block(const uint32_t bx, const uin
     for (int r = 0; r < CSSM_ITEMS; ++r) a = cssm_u128_add(a, qq[r]);
     toff = cssm_u128_add(toff, block_total(a));
   }
-  // this tile: inclusive prefixes, rows
-  const uint64_t base = (uint64_t)bx * CSSM_TILE;
-  cssm_u128 qq[CSSM_ITEMS];
-  tile_weights(base, qq);
-  cssm_u128 tsum = cssm_u128_zero();
+  // this tile: the threads' exclusive prefixes
+  {
+    cssm_u128 qq[CSSM_ITEMS];
+    tile_weights(base, qq);
 #pragma unroll
-  for (int r = 0; r < CSSM_ITEMS; ++r) tsum = cssm_u128_add(tsum, qq[r]);
+    for (int r = 0; r < CSSM_ITEMS; ++r) tsum = cssm_u128_add(tsum, qq[r]);
+  }
   const cssm_u128 inc = wave_scan_u128(tsum, lane);
   __syncthreads();
   if (lane == 63) s_w[wid] = inc;
@@ -467,64 +509,79 @@ __device__ __forceinline__ void boundary_pack_block(const uint32_t bx, const uin
   cssm_u128 run = toff;
   for (int w = 0; w < wid; ++w) run = cssm_u128_add(run, s_w[w]);
   run = cssm_u128_add(run, inc);
-  { cssm_u128 t; t.lo = run.lo - tsum.lo; t.hi = run.hi - tsum.hi - (run.lo < tsum.lo ? 1u : 0u); run = t; }   // exclusive prefix of the thread
-  if (held) return;
-  uint32_t need_mask = 0xffffffffu;   // bit r: row r of this thread travels
-  if (exact) {
-    // the slot counts of this thread's rows as the READER forms them in expand_spec_body -- the same header words, the same arithmetic,
-    // the same numbers
-    SpecHeaders& H = *xn->H;
-    cssm_u128 off = H.off[rank];
-    if (q > rank) {
-      const cssm_u128 Sr = H.S[rank], Pr = H.phigh[rank];
-      cssm_u128 bs; bs.lo = Sr.lo - Pr.lo; bs.hi = Sr.hi - Pr.hi - (Sr.lo < Pr.lo ? 1u : 0u);
-      off = cssm_u128_add(off, bs);
-    }
-    const double totd = cssm_u128_to_double(H.tot), u = rec->u;
-    const uint64_t n_global = xn->n_global;
-    const bool pow2 = (n_global & (n_global - 1)) == 0;
-    const double inv_n = 1.0 / (double)n_global;
-    const uint32_t rstep = rec->step;
-    const int rs = (RSC >= 0) ? RSC : xn->rs;
-    auto count_of = [&](cssm_u128 G) -> uint64_t {
-      if (cssm_u128_is_zero(G)) return 0;
-      const double C = cssm_u128_to_double(G) / totd;
-      if (rs == CSSM_RESAMPLE_STRATIFIED) return cssm_strat_count(C, xn->seed, rstep, n_global);
-      return pow2 ? cssm_sys_count_pow2(C, u, n_global, inv_n) : cssm_sys_count(C, u, n_global);
-    };
-    // ONE count per thread: its four rows travel together.  Block for rank + 1 (a suffix is needed: end slots grow with the row): the
-    // thread's rows travel iff the LAST of them ends beyond this rank's last slot; block for rank - 1 (a prefix): iff the FIRST of them
-    // starts below this rank's first slot.  Up to three rows more than needed at the edge; the reader clamps their runs to nothing.
-    const uint64_t i0 = base + (uint64_t)threadIdx.x * CSSM_ITEMS;
-    const uint64_t c = count_of(cssm_u128_add(off, (q < rank) ? run : cssm_u128_add(run, tsum)));
-    unsigned int mine = 0u;
-    need_mask = 0u;
-    if (i0 < (uint64_t)cnt && ((q < rank) ? (c < xn->slot_lo) : (c > xn->slot_hi))) {
-      need_mask = 0xffffffffu;
-      const uint64_t i1 = (i0 + CSSM_ITEMS < (uint64_t)cnt) ? i0 + CSSM_ITEMS : (uint64_t)cnt;   // one past the thread's last row
-      mine = (q < rank) ? (unsigned int)i1 : (unsigned int)((uint64_t)cnt - i0);
-    }
-    mine = (unsigned int)wave_max_u64((unsigned long long)mine);
-    if (lane == 0 && mine) atomicMax(&s_need, mine);   // (peer_done's barrier stands between this and its reader)
+  run0.lo = run.lo - tsum.lo; run0.hi = run.hi - tsum.hi - (run.lo < tsum.lo ? 1u : 0u);
   }
-  // (needed rows only: the weights are read once more, through a pointer the compiler cannot identify with the first one -- four 128-bit
-  //  weights held across the counts cost the merged kernel a wave of occupancy)
-  if (need_mask) {
+  // rows [lo, hi) of the thread's four -> the segment (the weights are read once more, through a pointer the compiler cannot identify with
+  // the first one: four 128-bit weights held across the header wait and the counts cost the merged kernel a wave of occupancy)
+  const uint64_t i0 = base + (uint64_t)threadIdx.x * CSSM_ITEMS;
+  auto write_rows = [&](const long long lo, const long long hi, const bool pstart) {
     const double* lw = logw;
-    if (exact) asm volatile("" : "+v"(lw));
+    asm volatile("" : "+v"(lw));
+    cssm_u128 run = run0;
 #pragma unroll
     for (int r = 0; r < CSSM_ITEMS; ++r) {
-      const uint64_t i = base + (uint64_t)threadIdx.x * CSSM_ITEMS + r;
-      if (i < (uint64_t)cnt) {
-        run = cssm_u128_add(run, cssm_fix_from_unit(level_from_max ? cssm_exp_le0(lw[first + i] - cref) : lw[first + i]));
-        double* o = oseg + HD + (long long)i * R;
-        for (int k = 0; k < d; ++k) o[k] = src[(size_t)k * stride + (size_t)(first + i)];
-        o[d] = cssm_u2d(run.lo);
-        oseg[HD + cap * R + (long long)i] = cssm_u2d(run.hi);
+      const long long i = (long long)i0 + r;
+      if (i < cnt) {
+        if (pstart && i == lo && i > 0) {   // the cumulative weight in front of the first eager row (the reader's start slot of that row)
+          unsigned long long* ps = reinterpret_cast<unsigned long long*>(peer->flag[parity][q] + (size_t)rank * CSSM_PEER_FLAG_STRIDE + CSSM_PEER_FLAG_PSTART);
+          ps[0] = run.lo; ps[1] = run.hi;
+        }
+        run = cssm_u128_add(run, cssm_fix_from_unit(level_from_max ? cssm_exp_le0(lw[first + (uint64_t)i] - cref) : lw[first + (uint64_t)i]));
+        if (i >= lo && i < hi) {
+          double* o = oseg + HD + i * R;
+          for (int k = 0; k < d; ++k) o[k] = src[(size_t)k * stride + (size_t)(first + (uint64_t)i)];
+          o[d] = cssm_u2d(run.lo);
+          oseg[HD + cap * R + i] = cssm_u2d(run.hi);
+        }
       }
     }
+  };
+  if (do_a) {
+    if (work_a && (long long)i0 < e_hi && (long long)i0 + CSSM_ITEMS > e_lo) write_rows(e_lo, e_hi, peer != nullptr && q > rank);
+    rows_done(false);
   }
-  peer_done(false);
+  if (do_b) {
+    if (work_b) {
+      if (!have_headers && !wait_headers()) return;
+      // the slot counts of this thread's rows as the READER forms them in expand_spec_body -- the same header words, the same arithmetic,
+      // the same numbers
+      SpecHeaders& H = *xn->H;
+      cssm_u128 off = H.off[rank];
+      if (q > rank) {
+        const cssm_u128 Sr = H.S[rank], Pr = H.phigh[rank];
+        cssm_u128 bs; bs.lo = Sr.lo - Pr.lo; bs.hi = Sr.hi - Pr.hi - (Sr.lo < Pr.lo ? 1u : 0u);
+        off = cssm_u128_add(off, bs);
+      }
+      const double totd = cssm_u128_to_double(H.tot), u = rec->u;
+      const uint64_t n_global = xn->n_global;
+      const bool pow2 = (n_global & (n_global - 1)) == 0;
+      const double inv_n = 1.0 / (double)n_global;
+      const uint32_t rstep = rec->step;
+      const int rs = (RSC >= 0) ? RSC : xn->rs;
+      auto count_of = [&](cssm_u128 G) -> uint64_t {
+        if (cssm_u128_is_zero(G)) return 0;
+        const double C = cssm_u128_to_double(G) / totd;
+        if (rs == CSSM_RESAMPLE_STRATIFIED) return cssm_strat_count(C, xn->seed, rstep, n_global);
+        return pow2 ? cssm_sys_count_pow2(C, u, n_global, inv_n) : cssm_sys_count(C, u, n_global);
+      };
+      // ONE count per thread: its four rows travel together.  Block for rank + 1 (a suffix is needed: end slots grow with the row): the
+      // thread's rows travel iff the LAST of them ends beyond this rank's last slot; block for rank - 1 (a prefix): iff the FIRST of them
+      // starts below this rank's first slot.  Up to three rows more than needed at the edge; the reader clamps their runs to nothing.
+      const uint64_t c = count_of(cssm_u128_add(off, (q < rank) ? run0 : cssm_u128_add(run0, tsum)));
+      unsigned int mine = 0u;
+      bool need_rows = false;
+      if (i0 < (uint64_t)cnt && ((q < rank) ? (c < xn->slot_lo) : (c > xn->slot_hi))) {
+        need_rows = true;
+        const uint64_t i1 = (i0 + CSSM_ITEMS < (uint64_t)cnt) ? i0 + CSSM_ITEMS : (uint64_t)cnt;   // one past the thread's last row
+        mine = (q < rank) ? (unsigned int)i1 : (unsigned int)((uint64_t)cnt - i0);
+      }
+      mine = (unsigned int)wave_max_u64((unsigned long long)mine);
+      if (lane == 0 && mine) atomicMax(&s_need, mine);   // (rows_done's barrier stands between this and its reader)
+      // (its rows outside the eager range: the eager ones went in stage A)
+      if (need_rows) { if (q > rank) write_rows(0, e_lo, false); else write_rows(e_hi, cnt, false); }
+    }
+    rows_done(true);
+  }
   return;
   }
   // header: the rank's totals of the sub-unit sums k_propagate formed, the key of its max, base.  Everything it reads is
@@ -673,18 +730,19 @@ __global__ __launch_bounds__(CSSM_BLOCK) void k_boundary_pack(const double* __re
                                                               int level_from_max, cssm_u128* __restrict__ pre_out,
                                                               const PeerTable* __restrict__ peer = nullptr, int parity = 0, uint32_t seq = 0u,
                                                               unsigned int* __restrict__ tickets = nullptr, int grp_set = -1,
-                                                              int phase = 3, int need_rows = 0, uint64_t n_global = 0, uint64_t seed = 0, int rs = 0,
+                                                              int phase = 7, long long eager = 0, uint64_t n_global = 0, uint64_t seed = 0, int rs = 0,
                                                               uint64_t slot_lo = 0, uint64_t slot_hi = 0) {
-  // need_rows (peer != nullptr): only the rows the neighbours need travel (PackNeed) -- the row blocks (phase bit 1) wait for all headers
+  // eager < cap (peer != nullptr): the eager rows travel at once (phase bit 1), of the others those the neighbours need, behind all headers
+  // (phase bit 2: PackNeed)
   __shared__ SpecHeaders H;
   __shared__ uint32_t s_ll[64 * CSSM_PEER_LL_WORDS];
   PackNeed xn;
   xn.H = &H; xn.ll = s_ll; xn.my_flags = (peer != nullptr) ? peer->flag[parity][rank] : nullptr;
   xn.need = (tickets != nullptr) ? tickets + CSSM_PEER_TICKET_NEED : nullptr;
   xn.stat = (tickets != nullptr) ? reinterpret_cast<unsigned long long*>(tickets + CSSM_PEER_TICKET_STAT) : nullptr;
-  xn.n_global = n_global; xn.seed = seed; xn.slot_lo = slot_lo; xn.slot_hi = slot_hi; xn.rs = rs;
+  xn.n_global = n_global; xn.seed = seed; xn.slot_lo = slot_lo; xn.slot_hi = slot_hi; xn.rs = rs; xn.eager = eager;
   boundary_pack_block(blockIdx.x, gridDim.x, (int)blockIdx.y, src, stride, logw, n_local, d, world, rank, cap, rec, subS, subS2, nsub, sc, out, chunk,
-                      level_from_max, pre_out, peer, parity, seq, tickets, nullptr, grp_set, xn, need_rows != 0, phase);
+                      level_from_max, pre_out, peer, parity, seq, tickets, nullptr, grp_set, xn, peer != nullptr && eager < cap, phase);
 }
 
 // After the all-to-all: every segment's rows -> the slots of this rank they own.  Global cumulative weight of row i of
@@ -752,9 +810,10 @@ __device__ __forceinline__ void expand_spec_body(SpecHeaders& H, uint32_t bid, u
                                                  long long cap, int d, uint32_t n_split, uint64_t slot_lo, uint64_t slot_hi, uint64_t n_global,
                                                  const StepRec* __restrict__ rec, uint32_t* __restrict__ anc, Scalars* __restrict__ sc,
                                                  int rs = CSSM_RESAMPLE_SYSTEMATIC, uint64_t seed = 0, int grp_cur = 0,
-                                                 const unsigned int* __restrict__ peer_flags = nullptr) {
-  // peer_flags (peer-written exchange, behind the neighbours' rows flags): the word behind a neighbour's rows flag says how many rows of
-  // its block it wrote -- the ones this rank's slots need (PackNeed); else every row of the blocks is there
+                                                 const unsigned int* __restrict__ peer_flags = nullptr, uint32_t peer_seq = 0u, long long eager = 0) {
+  // peer_flags (peer-written exchange, behind the neighbours' ROWS flags) and eager < cap: the neighbours wrote the `eager` rows next to
+  // the boundary at once and, behind every rank's header, the rows beyond them that this rank's slots need (PackNeed); else every row of
+  // the blocks is there
   __shared__ uint32_t s_nheavy;
   __shared__ uint32_t s_hb[CSSM_BLOCK], s_he[CSSM_BLOCK], s_hj[CSSM_BLOCK];
   const long long R = d + 1, HD = spec_hdr(d), seg = spec_seg(d, cap);
@@ -784,29 +843,23 @@ __device__ __forceinline__ void expand_spec_body(SpecHeaders& H, uint32_t bid, u
   // particles' first one all belong to the last-cap block of rank - 1 and those above to the first-cap block of rank + 1.
   // The rows are spread evenly over ALL blocks of the launch (a share of ceil(2 cap / blocks) each, done after the
   // block's own tile): extra blocks for them would start a second, nearly empty round on a chip the offspring blocks fill.
-  // rows of rank - 1's LAST-cap block: the last n_lo of its cnt; rows of rank + 1's FIRST-cap block: the first n_hi
-  long long n_lo = (rank > 0) ? H.cnt[rank - 1] : 0, n_hi = (rank + 1 < world) ? H.cnt[rank + 1] : 0;
-  if (peer_flags != nullptr) {
-    if (rank > 0) {
-      const long long v = (long long)__hip_atomic_load(peer_flags + (size_t)(rank - 1) * CSSM_PEER_FLAG_STRIDE + CSSM_PEER_FLAG_NEED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-      n_lo = (v < n_lo) ? v : n_lo;
-    }
-    if (rank + 1 < world) {
-      const long long v = (long long)__hip_atomic_load(peer_flags + (size_t)(rank + 1) * CSSM_PEER_FLAG_STRIDE + CSSM_PEER_FLAG_NEED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-      n_hi = (v < n_hi) ? v : n_hi;
-    }
-  }
-  const long long total = n_lo + n_hi;
-  const long long per = (total + nblk - 1) / nblk;
-  const long long row_lo = (long long)bid * per, row_hi = (row_lo + per < total) ? row_lo + per : total;
-  for (long long base = row_lo; base < row_hi; base += CSSM_BLOCK) {
-    if (threadIdx.x == 0) s_nheavy = 0;
-    __syncthreads();
-    const long long idx = base + threadIdx.x;
-    if (idx < row_hi) {
-      const int s = (idx < n_lo) ? rank - 1 : rank + 1;
-      const long long i = (idx < n_lo) ? H.cnt[rank - 1] - n_lo + idx : idx - n_lo;
-      {
+  // EAGER rows first (all of them where nobody asked for less): the last n_lo rows of rank - 1's LAST-cap block, the first n_hi of rank + 1's
+  // FIRST-cap block, spread over the blocks
+  const long long cnt_lo = (rank > 0) ? H.cnt[rank - 1] : 0, cnt_hi = (rank + 1 < world) ? H.cnt[rank + 1] : 0;
+  const long long eg = (peer_flags != nullptr && eager < cap) ? (eager > 0 ? eager : 0) : cap;
+  const long long n_lo = (eg < cnt_lo) ? eg : cnt_lo, n_hi = (eg < cnt_hi) ? eg : cnt_hi;
+  __shared__ uint32_t s_unc;   // bit 0 / 1: the eager rows of rank - 1 / rank + 1 do not reach this rank's first / last slot
+  // rows [idx0, idx1) of the list `which` (0: the eager rows as above; 1 / 2: the rows beyond them of rank - 1 / rank + 1, x_lo of them)
+  auto expand_rows = [&](const int which, const long long idx0, const long long idx1, const long long x_n) {
+    for (long long base = idx0; base < idx1; base += CSSM_BLOCK) {
+      if (threadIdx.x == 0) s_nheavy = 0;
+      __syncthreads();
+      const long long idx = base + threadIdx.x;
+      if (idx < idx1) {
+        int s; long long i;
+        if (which == 0) { s = (idx < n_lo) ? rank - 1 : rank + 1; i = (idx < n_lo) ? cnt_lo - n_lo + idx : idx - n_lo; }
+        else if (which == 1) { s = rank - 1; i = cnt_lo - n_lo - x_n + idx; }
+        else { s = rank + 1; i = n_hi + idx; }
         const double* h = recv + (size_t)s * seg;
         const cssm_u128 off = cssm_u128_add(H.off[s], H.base[s]);
         cssm_u128 P; P.lo = cssm_d2u(ld_sys_f64(h + HD + i * R + d)); P.hi = cssm_d2u(ld_sys_f64(h + HD + cap * R + i));
@@ -814,12 +867,22 @@ __device__ __forceinline__ void expand_spec_body(SpecHeaders& H, uint32_t bid, u
         uint64_t b;
         if (i == 0) {
           b = count_of(off);
-        } else if (idx == 0 && s < rank) {
+        } else if (which == 0 && s < rank && idx == 0) {
+          // the first eager row: the cumulative weight in front of it came with the rows (PSTART).  A run that starts beyond this rank's
+          // first slot: rows in front of the eager ones own slots of this rank -- the sender writes them behind the headers (EXTRA)
+          const unsigned long long* ps = reinterpret_cast<const unsigned long long*>(peer_flags + (size_t)s * CSSM_PEER_FLAG_STRIDE + CSSM_PEER_FLAG_PSTART);
+          cssm_u128 Pp;
+          Pp.lo = __hip_atomic_load(ps, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); Pp.hi = __hip_atomic_load(ps + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+          b = count_of(cssm_u128_add(off, Pp));
+          if (b > slot_lo) atomicOr(&s_unc, 1u);
+        } else if (which == 1 && idx == 0) {
           b = slot_lo;   // (the row before the first needed one was not written: its run ends at or below this rank's first slot)
         } else {
           cssm_u128 Pp; Pp.lo = cssm_d2u(ld_sys_f64(h + HD + (i - 1) * R + d)); Pp.hi = cssm_d2u(ld_sys_f64(h + HD + cap * R + (i - 1)));
           b = count_of(cssm_u128_add(off, Pp));
         }
+        // the last eager row of rank + 1 ends below this rank's last slot and the block has more rows: they are on their way (EXTRA)
+        if (which == 0 && s > rank && i == n_hi - 1 && n_hi < cnt_hi && e < slot_hi) atomicOr(&s_unc, 2u);
         if (b < slot_lo) b = slot_lo;
         if (e > slot_hi) e = slot_hi;
         if (e > b) {
@@ -832,14 +895,52 @@ __device__ __forceinline__ void expand_spec_body(SpecHeaders& H, uint32_t bid, u
           }
         }
       }
+      __syncthreads();
+      const uint32_t nh = s_nheavy;
+      for (uint32_t hh = 0; hh < nh; ++hh) {
+        const uint32_t he = s_he[hh], hj = s_hj[hh];
+        for (uint32_t sl = s_hb[hh] + threadIdx.x; sl < he; sl += CSSM_BLOCK) anc[sl] = hj;
+      }
+      __syncthreads();
     }
-    __syncthreads();
-    const uint32_t nh = s_nheavy;
-    for (uint32_t hh = 0; hh < nh; ++hh) {
-      const uint32_t he = s_he[hh], hj = s_hj[hh];
-      for (uint32_t sl = s_hb[hh] + threadIdx.x; sl < he; sl += CSSM_BLOCK) anc[sl] = hj;
+  };
+  const long long total = n_lo + n_hi;
+  const long long per = (total + nblk - 1) / nblk;
+  const long long row_lo = (long long)bid * per, row_hi = (row_lo + per < total) ? row_lo + per : total;
+  if (row_lo >= row_hi) return;
+  if (threadIdx.x == 0) s_unc = 0u;   // (expand_rows begins with a barrier)
+  expand_rows(0, row_lo, row_hi, 0);
+  if (peer_flags == nullptr || eg >= cap) return;
+  // Rows BEYOND the eager ones (rare: the eager rows cover a typical observation several times over).  The block that expanded the first
+  // eager row of rank - 1 / the last one of rank + 1 has seen whether they reach; if not it waits, bounded, for the sender's EXTRA flag --
+  // set once the sender's row blocks have seen every header and written what this rank needs -- and expands those rows itself.
+  const uint32_t unc = s_unc;   // (behind expand_rows' closing barrier)
+  if (unc == 0u) return;
+  __shared__ unsigned int s_xlate;
+  __shared__ long long s_xneed[2];
+  __syncthreads();
+  if (threadIdx.x < 2) {
+    const int side = (int)threadIdx.x, s = side ? rank + 1 : rank - 1;
+    s_xneed[side] = 0;
+    if (threadIdx.x == 0) s_xlate = 0u;
+    if ((unc >> side) & 1u) {
+      const unsigned int* f = peer_flags + (size_t)s * CSSM_PEER_FLAG_STRIDE;
+      if (!peer_poll_u32(f + CSSM_PEER_FLAG_EXTRA, peer_seq, sc->peer_wait_ticks)) atomicOr(&s_xlate, 1u);
+      else s_xneed[side] = (long long)__hip_atomic_load(f + CSSM_PEER_FLAG_NEED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
-    __syncthreads();
+  }
+  __syncthreads();
+  if (s_xlate) {
+    if (threadIdx.x == 0) { atomicOr(&sc->err, 16u); atomicMin(&sc->fail_step, rec->step); }
+    return;
+  }
+  if (unc & 1u) {
+    long long need = s_xneed[0]; need = (need < cnt_lo) ? need : cnt_lo;
+    if (need > n_lo) expand_rows(1, 0, need - n_lo, need - n_lo);
+  }
+  if (unc & 2u) {
+    long long need = s_xneed[1]; need = (need < cnt_hi) ? need : cnt_hi;
+    if (need > n_hi) expand_rows(2, 0, need - n_hi, need - n_hi);
   }
 }
 // Offspring of the own particles and expansion of the received rows in ONE launch: the two are independent once the
@@ -860,7 +961,8 @@ template <int RAWC, int RS, bool GRP = false>
 __device__ __forceinline__ void offspring_expand_spec_body(
     CSSM_OFFSPRING_PARAMS, uint32_t all5_stride, const double* __restrict__ recv, long long cap, int d, uint32_t n_split,
     const cssm_u128* __restrict__ unit_pre, const unsigned int* __restrict__ peer_flags, uint32_t peer_seq,
-    const uint32_t blk0, const unsigned int* __restrict__ pre_flag, SpecHeaders& H, uint32_t* __restrict__ s_ll) {
+    const uint32_t blk0, const unsigned int* __restrict__ pre_flag, SpecHeaders& H, uint32_t* __restrict__ s_ll, const long long eager) {
+  // eager (peer-written exchange): rows next to the boundary that the neighbours wrote at once (PackNeed::eager; >= cap: all of them)
   // H / s_ll: LDS of the launch, declared by the kernel (the merged kernel's pack blocks use the same two objects: static LDS of the
   // two halves of a kernel adds up, it does not overlap)
   // blk0 / pre_flag (the merged kernel k_exchange_offspring): this body runs in blocks blk0 .. of the launch; unit_pre is written by
@@ -876,11 +978,11 @@ __device__ __forceinline__ void offspring_expand_spec_body(
   const unsigned long long wait_ticks = (peer_flags != nullptr) ? sc->peer_wait_ticks : 0ull;   // (requested with the block's first loads)
   // thread r waits for rank r's flag (word `which` of its pair: 0 header, CSSM_PEER_FLAG_ROWS rows), thread `world` for the local
   // flag `extra` if there is one; false: some flag did not come within the bound (err bit 4, the series ends like one on hold)
-  auto wait_flags = [&](uint32_t which, const unsigned int* extra, int r_lo, int r_hi) -> bool {
+  auto wait_flags = [&](uint32_t which, const unsigned int* extra, int r_lo, int r_hi, int skip = -1) -> bool {
     if (threadIdx.x == 0) s_late = 0u;
     __syncthreads();
     const int r = (int)threadIdx.x;
-    if ((r >= r_lo && r <= r_hi && r < world) || (r == world && extra != nullptr)) {
+    if ((r >= r_lo && r <= r_hi && r < world && r != skip) || (r == world && extra != nullptr)) {
       const unsigned int* f = (r < world) ? peer_flags + (size_t)r * CSSM_PEER_FLAG_STRIDE + which : extra;
       // (relaxed system-scope loads: each one reads the flag at the point of coherence; the window itself is read with such loads
       //  too -- ld_sys, no fence: see there -- and the next kernel's gathers start behind a kernel boundary)
@@ -935,8 +1037,8 @@ __device__ __forceinline__ void offspring_expand_spec_body(
                                                                /*s2buf=*/nullptr, 0u, -1, 0u, /*unit_pre=*/nullptr, blk0, pre_ok ? pre_w : nullptr, nullptr, &mid);
     if (!mid_ok) return;   // (the body returned without resampling -- the level ruled out, block 0's verdict, a peer missing: no tail either)
     CSSM_SPEC_STAMP(2);
-    if (peer_flags != nullptr && !wait_flags(CSSM_PEER_FLAG_ROWS, nullptr, rank - 1, rank + 1)) return;
-    expand_spec_body(H, bidx, nblk, recv, world, rank, cap, d, n_split, (uint64_t)slot_lo, (uint64_t)slot_hi, n_global, rec, anc, sc, RS, seed, slot_set, peer_flags);
+    if (peer_flags != nullptr && !wait_flags(CSSM_PEER_FLAG_ROWS, nullptr, rank - 1, rank + 1, rank)) return;
+    expand_spec_body(H, bidx, nblk, recv, world, rank, cap, d, n_split, (uint64_t)slot_lo, (uint64_t)slot_hi, n_global, rec, anc, sc, RS, seed, slot_set, peer_flags, peer_seq, eager);
     CSSM_SPEC_STAMP(3);
     return;
   }
@@ -987,18 +1089,18 @@ __device__ __forceinline__ void offspring_expand_spec_body(
                                                         /*s2buf=*/nullptr, 0u, -1, 0u, unit_pre, blk0, prefetched ? pre_w : nullptr, &tt);
   CSSM_SPEC_STAMP(2);
   // the two neighbours' rows (their flags have long been set: the rows were written while this block resampled its own particles)
-  if (peer_flags != nullptr && !wait_flags(CSSM_PEER_FLAG_ROWS, nullptr, rank - 1, rank + 1)) return;
-  expand_spec_body(H, bidx, nblk, recv, world, rank, cap, d, n_split, (uint64_t)slot_lo, (uint64_t)slot_hi, n_global, rec, anc, sc, RS, seed, slot_set, peer_flags);
+  if (peer_flags != nullptr && !wait_flags(CSSM_PEER_FLAG_ROWS, nullptr, rank - 1, rank + 1, rank)) return;
+  expand_spec_body(H, bidx, nblk, recv, world, rank, cap, d, n_split, (uint64_t)slot_lo, (uint64_t)slot_hi, n_global, rec, anc, sc, RS, seed, slot_set, peer_flags, peer_seq, eager);
   CSSM_SPEC_STAMP(3);
 }
 
 template <int RAWC, int RS = CSSM_RESAMPLE_SYSTEMATIC, bool GRP = false>
 __global__ __launch_bounds__(CSSM_BLOCK, CSSM_OFF_WAVES) void k_offspring_expand_spec(
     CSSM_OFFSPRING_PARAMS, uint32_t all5_stride, const double* __restrict__ recv, long long cap, int d, uint32_t n_split,
-    const cssm_u128* __restrict__ unit_pre, const unsigned int* __restrict__ peer_flags = nullptr, uint32_t peer_seq = 0u) {
+    const cssm_u128* __restrict__ unit_pre, const unsigned int* __restrict__ peer_flags = nullptr, uint32_t peer_seq = 0u, long long eager = 0) {
   __shared__ SpecHeaders H;
   __shared__ uint32_t s_ll[GRP ? 64 * CSSM_PEER_LL_WORDS : 1];   // the ranks' headers as they arrive: 24 halves per rank (GRP launches read them)
-  offspring_expand_spec_body<RAWC, RS, GRP>(CSSM_OFFSPRING_FWD, all5_stride, recv, cap, d, n_split, unit_pre, peer_flags, peer_seq, 0u, nullptr, H, s_ll);
+  offspring_expand_spec_body<RAWC, RS, GRP>(CSSM_OFFSPRING_FWD, all5_stride, recv, cap, d, n_split, unit_pre, peer_flags, peer_seq, 0u, nullptr, H, s_ll, eager);
 }
 
 // The peer-written exchange in ONE launch per weighted observation behind the propagate: the first pack_gx * world blocks of the grid
@@ -1009,7 +1111,7 @@ __global__ __launch_bounds__(CSSM_BLOCK, CSSM_OFF_WAVES) void k_offspring_expand
 struct PackArgs {
   const double* src; size_t stride; uint32_t nsub; uint64_t chunk; cssm_u128* pre_out;
   const PeerTable* peer; int parity; unsigned int* tickets; unsigned int* pre_flag; uint32_t pack_gx;
-  int all_rows;   // CSSM_PEER_ALL_ROWS: every row of the boundary blocks travels (else the needed ones: PackNeed)
+  long long eager;   // rows next to the boundary that travel at once (PackNeed::eager; >= cap: every row, CSSM_PEER_ALL_ROWS)
 };
 // GRP: the group sums are at hand (slot_set = their set): the header blocks total them, the offspring blocks take their prefixes from them
 // (pk.pre_out == nullptr: the prefix block of every destination leaves at once)
@@ -1024,13 +1126,13 @@ __global__ __launch_bounds__(CSSM_BLOCK, CSSM_OFF_WAVES) void k_exchange_offspri
     PackNeed xn;
     xn.H = &H; xn.ll = s_ll; xn.my_flags = peer_flags; xn.need = pk.tickets + CSSM_PEER_TICKET_NEED;
     xn.stat = reinterpret_cast<unsigned long long*>(pk.tickets + CSSM_PEER_TICKET_STAT);
-    xn.n_global = n_global; xn.seed = seed; xn.slot_lo = slot_lo; xn.slot_hi = slot_hi; xn.rs = RS;
+    xn.n_global = n_global; xn.seed = seed; xn.slot_lo = slot_lo; xn.slot_hi = slot_hi; xn.rs = RS; xn.eager = pk.eager;
     boundary_pack_block<RS>(blockIdx.x % pk.pack_gx, pk.pack_gx, (int)(blockIdx.x / pk.pack_gx), pk.src, pk.stride, logw, n, d, world, rank, cap, rec,
                         unitP, unitS2, pk.nsub, sc, nullptr, pk.chunk, /*level_from_max=*/0, pk.pre_out, pk.peer, pk.parity, peer_seq, pk.tickets,
-                        pk.pre_flag, GRP ? slot_set : -1, xn, !pk.all_rows, 3);
+                        pk.pre_flag, GRP ? slot_set : -1, xn, pk.eager < cap, 7);
     return;
   }
-  offspring_expand_spec_body<RAWC, RS, GRP>(CSSM_OFFSPRING_FWD, all5_stride, recv, cap, d, n_split, unit_pre, peer_flags, peer_seq, blk0, pk.pre_flag, H, s_ll);
+  offspring_expand_spec_body<RAWC, RS, GRP>(CSSM_OFFSPRING_FWD, all5_stride, recv, cap, d, n_split, unit_pre, peer_flags, peer_seq, blk0, pk.pre_flag, H, s_ll, pk.eager);
 }
 
 __global__ __launch_bounds__(CSSM_BLOCK) void k_expand(const uint32_t* __restrict__ cand_end, const uint32_t* __restrict__ cand_idx,

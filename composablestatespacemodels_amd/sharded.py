@@ -200,14 +200,15 @@ class GpuShard:
         _abi.check(self.lib.cssm_pf_shard_pack_peer(self._h, self.rank, self.world, int(cap)))
 
     def pack_rows_peer(self, cap: int):
-        """Second stage of the pack: the rows the neighbours' slots need (behind every shard's ``pack_peer``)."""
+        """Second stage of the pack: the rows beyond the eager ones that the neighbours' slots need (behind every shard's ``pack_peer``)."""
         _abi.check(self.lib.cssm_pf_shard_pack_rows_peer(self._h, self.rank, self.world, int(cap)))
 
     def peer_rows(self):
-        """(rows written for neighbours, neighbour segments) since the windows were set up -- diagnostics of the needed-rows pack."""
-        r, g = C.c_uint64(0), C.c_uint64(0)
-        _abi.check(self.lib.cssm_pf_shard_peer_rows(self._h, C.byref(r), C.byref(g)))
-        return int(r.value), int(g.value)
+        """(rows written for neighbours, neighbour segments, segments that needed rows beyond the eager ones) since the windows were set
+        up -- diagnostics of the peer-written exchange's pack."""
+        r, g, b = C.c_uint64(0), C.c_uint64(0), C.c_uint64(0)
+        _abi.check(self.lib.cssm_pf_shard_peer_rows(self._h, C.byref(r), C.byref(g), C.byref(b)))
+        return int(r.value), int(g.value), int(b.value)
 
     def adopt_peer(self, cap: int):
         _abi.check(self.lib.cssm_pf_shard_adopt_peer(self._h, self.rank, self.world, int(cap)))
@@ -505,9 +506,9 @@ class ShardedFilter:
         every shard resamples behind the flags (shards of ONE process share a stream: the order of the launches is the order
         of the protocol; one shard per process: the flags are)."""
         for s in self.shards:
-            s.pack_peer(cap)          # headers
+            s.pack_peer(cap)          # headers + the eager rows
         for s in self.shards:
-            s.pack_rows_peer(cap)     # the rows the neighbours need (their blocks wait for every shard's header)
+            s.pack_rows_peer(cap)     # rows beyond them that the neighbours need (their blocks wait for every shard's header)
         for s in self.shards:
             s.adopt_peer(cap)
 

@@ -547,16 +547,20 @@ int cssm_pf_shard_peer_handshake(cssm_pf* pf, uint32_t token);
 uint32_t cssm_pf_shard_peer_probe_stale(const cssm_pf* pf);
 void cssm_pf_shard_peer_close(cssm_pf* pf);
 int cssm_pf_shard_pack_peer(cssm_pf* pf, int rank, int world, int64_t cap);
-/* (round 5) NEEDED ROWS ONLY.  A boundary block holds `cap` rows (sized for the worst observation, ~6 sqrt(N_global)), a typical
- * observation's neighbour needs a few hundred of them, and every row is a remote store over one xGMI link.  Once the headers of all ranks
- * are there the SENDER can tell which rows the neighbour's slots need (end slot beyond its own last slot / run starting below its own
- * first slot: the arithmetic the reader uses), so the pack's row blocks wait for the headers, write those rows only and publish their
- * number next to the rows flag; the reader expands exactly those.  In stage-by-stage use the rows are therefore a stage of their own:
- * cssm_pf_shard_pack_peer (headers) on every shard, cssm_pf_shard_pack_rows_peer on every shard, cssm_pf_shard_adopt_peer on every shard.
- * CSSM_PEER_ALL_ROWS=1 (read when the handle is created) keeps the old behaviour -- every row travels, pack_rows_peer does nothing.
- * cssm_pf_shard_peer_rows: rows written for neighbours / neighbour segments so far (diagnostics; both 0 with CSSM_PEER_ALL_ROWS=1). */
+/* (round 5) EAGER ROWS + NEEDED ROWS.  A boundary block holds `cap` rows (sized for the worst observation, ~6 sqrt(N_global)), a typical
+ * observation's neighbour needs a few hundred of them, and every row is a remote store over one xGMI link.  The rows next to the boundary
+ * (CSSM_PEER_EAGER_ROWS, default 1024 = one tile) are written AT ONCE, with a flag of their own that is long set when the reader gets to
+ * them.  Rows beyond them travel only if the neighbour's slots need them: once the headers of all ranks are there the SENDER can tell
+ * (end slot beyond its own last slot / run starting below its own first slot: the reader's arithmetic), so the pack's row blocks wait for
+ * the headers, write those rows and publish their number behind a second flag -- which the reader waits for only when the eager rows do
+ * not reach its first / last slot (it sees that from the eager rows).  In stage-by-stage use the rows beyond the eager ones are a stage of
+ * their own: cssm_pf_shard_pack_peer (headers + eager rows) on every shard, cssm_pf_shard_pack_rows_peer on every shard,
+ * cssm_pf_shard_adopt_peer on every shard.  CSSM_PEER_ALL_ROWS=1 (read when the handle is created), or an eager count >= the capacity:
+ * every row travels at once, pack_rows_peer does nothing.
+ * cssm_pf_shard_peer_rows: rows written for neighbours / neighbour segments / segments that needed rows beyond the eager ones, so far
+ * (diagnostics; beyond_out may be NULL). */
 int cssm_pf_shard_pack_rows_peer(cssm_pf* pf, int rank, int world, int64_t cap);
-int cssm_pf_shard_peer_rows(cssm_pf* pf, uint64_t* rows_out, uint64_t* segments_out);
+int cssm_pf_shard_peer_rows(cssm_pf* pf, uint64_t* rows_out, uint64_t* segments_out, uint64_t* beyond_out);
 int cssm_pf_shard_adopt_peer(cssm_pf* pf, int rank, int world, int64_t cap);
 /* pack + adopt in ONE launch (the pack blocks lead the grid): for a rank that has its stream to itself, i.e. one process per GPU --
  * what cssm_pf_shard_series_peer enqueues.  Shards that share a stream use the stage calls, every stage on all shards before the next. */

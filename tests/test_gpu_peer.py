@@ -51,45 +51,49 @@ def test_peer_exchange_local_shards_match_single_rank_oracle(world, name, n):
 
 @pytest.mark.parametrize("stratified", [False, True])
 @pytest.mark.parametrize("world,n", [(2, 40000), (4, 30000), (8, 100000)])
-def test_only_the_rows_a_neighbour_needs_travel(world, n, stratified, monkeypatch):
-    """The boundary blocks are sized for the worst observation (CAP_SQRT x sqrt(N) rows, at least a unit); the pack's row blocks wait for
-    every rank's header and write the rows the neighbour's slots need (cssm_pf.h: cssm_pf_shard_pack_rows_peer) -- a small part of the
-    capacity -- and the readers expand exactly those: the bits of the oracle, the bits of CSSM_PEER_ALL_ROWS=1 (every row travels)."""
+def test_eager_rows_and_the_needed_rows_beyond_them(world, n, stratified, monkeypatch):
+    """The boundary blocks are sized for the worst observation (CAP_SQRT x sqrt(N) rows, at least a unit).  What travels: the `eager` rows
+    next to the boundary at once, and of the rows beyond them those the neighbour's slots need -- the pack's row blocks wait for every
+    rank's header, count, write them and say how many; the reader waits for that only when the eager rows do not reach (cssm_pf.h:
+    cssm_pf_shard_pack_rows_peer).  CSSM_PEER_EAGER_ROWS = 8 sends nearly every observation down the second path, 1 all of them, the
+    default (four tiles) hardly any; CSSM_PEER_ALL_ROWS=1 is "every row travels".  All: the bits of the oracle."""
     model = cases.c2_model()
     t, y, has = cases.poisson_counts(14, missing=0.15)
-    rs = oracle.RESAMPLE_STRATIFIED if stratified else 0
-    o = oracle.OraclePf(model.descriptor(), n, cases.SEED, rs)
+    o = oracle.OraclePf(model.descriptor(), n, cases.SEED, oracle.RESAMPLE_STRATIFIED if stratified else 0)
     oll, _, oess, _ = o.filter(t, y, has)
-    got = {}
-    for all_rows in (False, True):
-        if all_rows:
-            monkeypatch.setenv("CSSM_PEER_ALL_ROWS", "1")      # (read when a handle is created)
-        else:
-            monkeypatch.delenv("CSSM_PEER_ALL_ROWS", raising=False)
+    weighted = int(np.count_nonzero(has))
+    for mode in ("8", "1", "default", "all"):
+        monkeypatch.delenv("CSSM_PEER_ALL_ROWS", raising=False)
+        monkeypatch.delenv("CSSM_PEER_EAGER_ROWS", raising=False)
+        if mode == "all":
+            monkeypatch.setenv("CSSM_PEER_ALL_ROWS", "1")      # (both are read when a handle is created)
+        elif mode != "default":
+            monkeypatch.setenv("CSSM_PEER_EAGER_ROWS", mode)
         shards, f = _peer_filter(model, n, world)
         if stratified:
             for s in shards:
                 s.set_option(2, 1)
         ll, ess = f.ll_filter(t, y, has)
         assert f.last_peer and f.last_single and f.last_attempts == 1
-        assert (ll, ess) == (oll, oess[-1])
-        part = np.concatenate([s.particles() for s in shards], axis=1)
-        np.testing.assert_array_equal(part, o.particles())
-        rows = [s.peer_rows() for s in shards]
-        got[all_rows] = (ll, ess, rows, f.last_cap)
+        assert (ll, ess) == (oll, oess[-1]), mode
+        np.testing.assert_array_equal(np.concatenate([s.particles() for s in shards], axis=1), o.particles())
+        rows, cap = [s.peer_rows() for s in shards], f.last_cap
         # ... and a continued series on the same windows
         f.ll_filter(t[:6], y[:6], has[:6])
         assert f.ll_filter_more(t[6:], y[6:], has[6:]) == (oll, oess[-1])
         for s in shards:
             s.close()
-    weighted = int(np.count_nonzero(has))
-    rows, cap = got[False][2], got[False][3]
-    assert all(r == (0, 0) for r in got[True][2])                # nothing counted when every row travels
-    for r, (nrows, nseg) in enumerate(rows):
-        neighbours = (1 if r > 0 else 0) + (1 if r + 1 < world else 0)
-        assert nseg == neighbours * weighted, (r, nseg)
-        full = neighbours * weighted * min(cap, n // world)
-        assert 0 < nrows < full // 4, (r, nrows, full)           # a fraction of what the capacity would send
+        for r, (nrows, nseg, beyond) in enumerate(rows):
+            neighbours = (1 if r > 0 else 0) + (1 if r + 1 < world else 0)
+            assert nseg == neighbours * weighted, (mode, r, nseg)
+            full = nseg * min(cap, n // world)
+            if mode == "all":
+                assert beyond == 0 and nrows == full, (mode, r, nrows, nseg, beyond)
+            elif mode == "default":                                 # four tiles of eager rows: an observation that needs more is the exception
+                assert beyond <= nseg // 4 and nseg * min(4096, cap, n // world) <= nrows <= full, (mode, r, nrows, nseg, beyond)
+            else:
+                assert beyond > 0, (mode, r, beyond, nseg)          # the second path ran: needed rows beyond the 8 (1) eager ones
+                assert int(mode) * nseg < nrows < full // 4, (mode, r, nrows, full)   # ... and they are a fraction of the capacity
 
 
 @pytest.mark.parametrize("world,n", [(2, 3000), (4, 9000), (8, 20000)])
