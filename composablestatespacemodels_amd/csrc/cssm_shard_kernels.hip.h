@@ -978,16 +978,31 @@ __device__ __forceinline__ void offspring_expand_spec_body(
   const unsigned long long wait_ticks = (peer_flags != nullptr) ? sc->peer_wait_ticks : 0ull;   // (requested with the block's first loads)
   // thread r waits for rank r's flag (word `which` of its pair: 0 header, CSSM_PEER_FLAG_ROWS rows), thread `world` for the local
   // flag `extra` if there is one; false: some flag did not come within the bound (err bit 4, the series ends like one on hold)
-  auto wait_flags = [&](uint32_t which, const unsigned int* extra, int r_lo, int r_hi, int skip = -1) -> bool {
+  auto wait_flags = [&](uint32_t which, const unsigned int* extra, int r_lo, int r_hi) -> bool {
     if (threadIdx.x == 0) s_late = 0u;
     __syncthreads();
     const int r = (int)threadIdx.x;
-    if ((r >= r_lo && r <= r_hi && r < world && r != skip) || (r == world && extra != nullptr)) {
+    if ((r >= r_lo && r <= r_hi && r < world) || (r == world && extra != nullptr)) {
       const unsigned int* f = (r < world) ? peer_flags + (size_t)r * CSSM_PEER_FLAG_STRIDE + which : extra;
       // (relaxed system-scope loads: each one reads the flag at the point of coherence; the window itself is read with such loads
       //  too -- ld_sys, no fence: see there -- and the next kernel's gathers start behind a kernel boundary)
       if (!peer_poll_u32(f, peer_seq, wait_ticks)) s_late = 1u;
     }
+    __syncthreads();
+    if (s_late) {
+      if (threadIdx.x == 0) { atomicOr(&sc->err, 16u); atomicMin(&sc->fail_step, rec->step); }
+      return false;
+    }
+    return true;
+  };
+  // The neighbours' ROWS flags (their eager rows are complete: they left at the start of the senders' launches, the flags are long set) --
+  // thread rank - 1 / rank + 1 polls, one barrier.  s_late is zero here: the header wait that cleared it succeeded.  (Measured and dropped:
+  // a look at the flags right behind the headers, kept in a register for the tail -- 95 -> 97 VGPR, a wave of occupancy.)
+  const bool rows_thread = peer_flags != nullptr && (int)threadIdx.x < world && ((int)threadIdx.x == rank - 1 || (int)threadIdx.x == rank + 1);
+  auto wait_rows = [&]() -> bool {
+    if (peer_flags == nullptr) return true;
+    if (rows_thread &&
+        !peer_poll_u32(peer_flags + (size_t)threadIdx.x * CSSM_PEER_FLAG_STRIDE + CSSM_PEER_FLAG_ROWS, peer_seq, wait_ticks)) s_late = 1u;
     __syncthreads();
     if (s_late) {
       if (threadIdx.x == 0) { atomicOr(&sc->err, 16u); atomicMin(&sc->fail_step, rec->step); }
@@ -1037,7 +1052,7 @@ __device__ __forceinline__ void offspring_expand_spec_body(
                                                                /*s2buf=*/nullptr, 0u, -1, 0u, /*unit_pre=*/nullptr, blk0, pre_ok ? pre_w : nullptr, nullptr, &mid);
     if (!mid_ok) return;   // (the body returned without resampling -- the level ruled out, block 0's verdict, a peer missing: no tail either)
     CSSM_SPEC_STAMP(2);
-    if (peer_flags != nullptr && !wait_flags(CSSM_PEER_FLAG_ROWS, nullptr, rank - 1, rank + 1, rank)) return;
+    if (!wait_rows()) return;
     expand_spec_body(H, bidx, nblk, recv, world, rank, cap, d, n_split, (uint64_t)slot_lo, (uint64_t)slot_hi, n_global, rec, anc, sc, RS, seed, slot_set, peer_flags, peer_seq, eager);
     CSSM_SPEC_STAMP(3);
     return;
@@ -1089,7 +1104,7 @@ __device__ __forceinline__ void offspring_expand_spec_body(
                                                         /*s2buf=*/nullptr, 0u, -1, 0u, unit_pre, blk0, prefetched ? pre_w : nullptr, &tt);
   CSSM_SPEC_STAMP(2);
   // the two neighbours' rows (their flags have long been set: the rows were written while this block resampled its own particles)
-  if (peer_flags != nullptr && !wait_flags(CSSM_PEER_FLAG_ROWS, nullptr, rank - 1, rank + 1, rank)) return;
+  if (!wait_rows()) return;
   expand_spec_body(H, bidx, nblk, recv, world, rank, cap, d, n_split, (uint64_t)slot_lo, (uint64_t)slot_hi, n_global, rec, anc, sc, RS, seed, slot_set, peer_flags, peer_seq, eager);
   CSSM_SPEC_STAMP(3);
 }

@@ -115,4 +115,6 @@ def test_a_model_outside_the_table_runs_as_fast_as_the_table_kernel():
           f"structure as data {generic:.2f}; a model outside the table: run-time specialised {other:.2f}, structure as data {other_generic:.2f}")
     assert rtc <= 1.03 * aot + 0.1
     assert other <= 1.03 * aot + 0.1        # (a Brownian leaf does no more arithmetic than an OU leaf)
-    assert generic >= rtc                    # what the specialisation is for
+    # what the specialisation is for: never slower than reading the structure as data (0.5-1 us faster on most boxes of the pool, level on
+    # some: event-bracketed kernel times repeat to ~1 %)
+    assert rtc <= 1.02 * generic + 0.1
