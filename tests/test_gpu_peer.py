@@ -229,7 +229,8 @@ def _ipc_rank(rank, world, port, n, T, outdir):
 
 
 @pytest.mark.parametrize("world,grp,mode", [(2, False, ""), (3, False, ""), (2, True, ""), (4, False, ""), (4, True, ""),
-                                            (3, True, "stages"), (3, False, "all_rows")])
+                                            (3, True, "stages"), (3, False, "all_rows"), (3, True, "eager8"), (2, False, "eager8"),
+                                            (4, True, "stages+eager8")])
 def test_peer_exchange_between_processes_sharing_the_gpu(tmp_path, world, grp, mode, monkeypatch):
     """`world` PROCESSES, all on this GPU, each mapping the others' windows through hipIpcOpenMemHandle: the handles, the
     device table, the flags (world x world of them), the self-validating header words and the window alternation as across GPUs (what
@@ -238,14 +239,17 @@ def test_peer_exchange_between_processes_sharing_the_gpu(tmp_path, world, grp, m
     World 4 is as far as this goes: a GPU box admits six processes on its card, and the test runner is one of them -- eight ranks
     cannot be started here (the in-process shards of LocalCommPeer cover world 8, without the IPC mapping).
     mode "stages": the library's series loop enqueues the exchange as its three stage launches (headers / needed rows / adopt:
-    CSSM_PEER_TWO_LAUNCHES) instead of the merged kernel; "all_rows": every row of the boundary blocks travels (CSSM_PEER_ALL_ROWS)."""
+    CSSM_PEER_TWO_LAUNCHES) instead of the merged kernel; "all_rows": every row of the boundary blocks travels (CSSM_PEER_ALL_ROWS);
+    "eager8": eight eager rows, so that the rows beyond them -- written behind the headers, waited for by the reader -- carry most exchanges."""
     import torch.multiprocessing as mp
     if grp:
         monkeypatch.setenv("CSSM_GRP_MIN_UNITS", "1")
-    if mode == "stages":
+    if "stages" in mode:
         monkeypatch.setenv("CSSM_PEER_TWO_LAUNCHES", "1")
     if mode == "all_rows":
         monkeypatch.setenv("CSSM_PEER_ALL_ROWS", "1")
+    if "eager8" in mode:      # (the default eager count exceeds these shards' capacity: every row would travel at once)
+        monkeypatch.setenv("CSSM_PEER_EAGER_ROWS", "8")
     n, T = 4096 * world, 9
     port = 29700 + (os.getpid() % 200) + world
     mp.spawn(_ipc_rank, args=(world, port, n, T, str(tmp_path)), nprocs=world, join=True)
