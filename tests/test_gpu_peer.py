@@ -222,7 +222,7 @@ def _ipc_rank(rank, world, port, n, T, outdir):
     ll, ess = f.ll_filter(t, y, has)
     ll2, ess2 = f.ll_filter_more(t[-3:] + T, y[-3:], has[-3:])
     np.savez(os.path.join(outdir, f"r{rank}.npz"), ll=ll, ess=ess, ll2=ll2, ess2=ess2, part=shard.particles(), peer=int(f.last_peer),
-             resumes=int(f.last_resumes), stale=int(getattr(f, "peer_probe_stale", -1)))
+             resumes=int(f.last_resumes), stale=int(getattr(f, "peer_probe_stale", -1)), rows=np.asarray(shard.peer_rows(), dtype=np.int64))
     shard.close()
     dist.barrier()
     dist.destroy_process_group()
@@ -259,14 +259,17 @@ def test_peer_exchange_between_processes_sharing_the_gpu(tmp_path, world, grp, m
     ll, _, ess_t, _ = o.filter(t, y, has)
     for a, b, h in zip(t[-3:] + T, y[-3:], has[-3:]):
         ll2, ess2 = o.step(a, b, bool(h))
-    parts = []
+    parts, beyond = [], 0
     for r in range(world):
         z = np.load(os.path.join(str(tmp_path), f"r{r}.npz"))
         assert int(z["peer"]) == 1 and int(z["stale"]) == 0
         assert float(z["ll"]) == ll and int(z["ess"]) == int(ess_t[-1])
         assert float(z["ll2"]) == ll2 and int(z["ess2"]) == ess2
         parts.append(z["part"])
+        beyond += int(z["rows"][2])
     np.testing.assert_array_equal(np.concatenate(parts, axis=1), o.particles())
+    if "eager8" in mode:
+        assert beyond > 0          # some exchange needed rows beyond the eight eager ones: the second path ran across processes
 
 
 def test_bench_n_rank_path_rehearsed_with_gpu_shards_sharing_this_gpu():
