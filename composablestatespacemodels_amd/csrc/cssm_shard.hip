@@ -521,7 +521,7 @@ static int adopt_spec_impl(cssm_pf* pf, const double* recv_buf_dev, int rank, in
   const uint64_t n_per = (pf->n_global + (uint64_t)world - 1) / (uint64_t)world;
   if (pf->first != (uint64_t)rank * n_per) return fail(CSSM_ESHARD, "rank %d must own particles from %llu", rank, (unsigned long long)((uint64_t)rank * n_per));
   const size_t slot = last_rec_slot(pf);
-  const int tgrid = (int)pf->nunits;
+  const int tgrid = (int)pf->nunits + CSSM_SPEC_EXPAND_BLOCKS;   // (the blocks that expand the received rows lead the offspring blocks)
   const long long seg = spec_seg(pf->d, (long long)cap);
   // the 5 words of every rank are the header words 1..5 of its segment (the all-to-all delivered this rank's own too)
   const unsigned long long* all5 = reinterpret_cast<const unsigned long long*>(recv_buf_dev) + 1;

@@ -806,6 +806,23 @@ __device__ __forceinline__ bool spec_read_headers(SpecHeaders& H, int world, int
   return H.all_ok != 0;
 }
 
+// What the first offspring block leaves for the next observation (all its threads call, behind its own particles): max-slot set 0 cleared,
+// and the two sets of group sums this observation did not use (grp_cur: the set of this one; the handle's exchanges rotate through the
+// three -- the next propagate adds to set grp_cur + 1, the one after to the set the observation before this one used)
+__device__ __forceinline__ void spec_clear_sets(Scalars* __restrict__ sc, const int grp_cur) {
+  if (threadIdx.x < CSSM_MAXSLOTS) sc->maxslot[(size_t)threadIdx.x * CSSM_SLOT_STRIDE] = 0ull;
+  static_assert(2 * 2 * CSSM_GRP_MAX <= CSSM_BLOCK, "one store per thread and array");
+  if (threadIdx.x < 2 * 2 * CSSM_GRP_MAX) {
+    const uint32_t tq2 = threadIdx.x;
+    const size_t at = ((size_t)((grp_cur + 1 + (int)(tq2 / (2 * CSSM_GRP_MAX))) % CSSM_MAXSETS) * 2 * CSSM_GRP_MAX + tq2 % (2 * CSSM_GRP_MAX)) * CSSM_SLOT_STRIDE;
+    sc->grp[at] = 0ull; sc->grp2[at] = 0ull;
+  }
+}
+// The received rows are expanded by blocks of their own, the first CSSM_SPEC_EXPAND_BLOCKS behind the pack blocks: reading a window costs
+// system-scope loads, and an offspring block that expanded its share of the rows behind its own particles ran 5-6 us longer for it
+// (in-process shards, 2^20 particles each, tools/expand_cost.py: 11.7 -> 17-17.9 us) -- invisible at world 1, where there are no rows.
+// These blocks wait for the headers like every block, then for the neighbours' eager rows, and are done before the offspring blocks are.
+#define CSSM_SPEC_EXPAND_BLOCKS 64
 __device__ __forceinline__ void expand_spec_body(SpecHeaders& H, uint32_t bid, uint32_t nblk, const double* __restrict__ recv, int world, int rank,
                                                  long long cap, int d, uint32_t n_split, uint64_t slot_lo, uint64_t slot_hi, uint64_t n_global,
                                                  const StepRec* __restrict__ rec, uint32_t* __restrict__ anc, Scalars* __restrict__ sc,
@@ -816,6 +833,7 @@ __device__ __forceinline__ void expand_spec_body(SpecHeaders& H, uint32_t bid, u
   // the blocks is there
   __shared__ uint32_t s_nheavy;
   __shared__ uint32_t s_hb[CSSM_BLOCK], s_he[CSSM_BLOCK], s_hj[CSSM_BLOCK];
+  (void)grp_cur;
   const long long R = d + 1, HD = spec_hdr(d), seg = spec_seg(d, cap);
   const double totd = cssm_u128_to_double(H.tot);
   const double u = rec->u;
@@ -828,21 +846,9 @@ __device__ __forceinline__ void expand_spec_body(SpecHeaders& H, uint32_t bid, u
     if (rs == CSSM_RESAMPLE_STRATIFIED) return cssm_strat_count(C, seed, rstep, n_global);
     return pow2 ? cssm_sys_count_pow2(C, u, n_global, inv_n) : cssm_sys_count(C, u, n_global);
   };
-  if (bid == 0 && threadIdx.x < CSSM_MAXSLOTS) sc->maxslot[(size_t)threadIdx.x * CSSM_SLOT_STRIDE] = 0ull;   // set 0 for the next step
-  // ... and the two sets of group sums this observation did not use (grp_cur: the set of this one; the handle's exchanges rotate through
-  // the three -- the next propagate adds to set grp_cur + 1, the one after to the set the observation before this one used)
-  if (bid == 0) {
-    static_assert(2 * 2 * CSSM_GRP_MAX <= CSSM_BLOCK, "one store per thread and array");
-    if (threadIdx.x < 2 * 2 * CSSM_GRP_MAX) {
-      const uint32_t tq2 = threadIdx.x;
-      const size_t at = ((size_t)((grp_cur + 1 + (int)(tq2 / (2 * CSSM_GRP_MAX))) % CSSM_MAXSETS) * 2 * CSSM_GRP_MAX + tq2 % (2 * CSSM_GRP_MAX)) * CSSM_SLOT_STRIDE;
-      sc->grp[at] = 0ull; sc->grp2[at] = 0ull;
-    }
-  }
   // Only the two adjacent ranks' rows can own slots of this rank: the verdict established that its slots below the own
   // particles' first one all belong to the last-cap block of rank - 1 and those above to the first-cap block of rank + 1.
-  // The rows are spread evenly over ALL blocks of the launch (a share of ceil(2 cap / blocks) each, done after the
-  // block's own tile): extra blocks for them would start a second, nearly empty round on a chip the offspring blocks fill.
+  // The rows are spread evenly over the launch's EXPANSION blocks (bid of nblk: CSSM_SPEC_EXPAND_BLOCKS blocks that do nothing else).
   // EAGER rows first (all of them where nobody asked for less): the last n_lo rows of rank - 1's LAST-cap block, the first n_hi of rank + 1's
   // FIRST-cap block, spread over the blocks
   const long long cnt_lo = (rank > 0) ? H.cnt[rank - 1] : 0, cnt_hi = (rank + 1 < world) ? H.cnt[rank + 1] : 0;
@@ -967,7 +973,10 @@ __device__ __forceinline__ void offspring_expand_spec_body(
   // two halves of a kernel adds up, it does not overlap)
   // blk0 / pre_flag (the merged kernel k_exchange_offspring): this body runs in blocks blk0 .. of the launch; unit_pre is written by
   // one of the blocks before them and announced through pre_flag
-  const uint32_t bidx = blockIdx.x - blk0, nblk = gridDim.x - blk0;
+  // blocks blk0 .. blk0 + CSSM_SPEC_EXPAND_BLOCKS - 1 expand the received rows (below), the offspring blocks follow them
+  const bool expander = blockIdx.x - blk0 < (uint32_t)CSSM_SPEC_EXPAND_BLOCKS;
+  const uint32_t blk1 = blk0 + (uint32_t)CSSM_SPEC_EXPAND_BLOCKS;
+  const uint32_t bidx = blockIdx.x - blk1;
   // unit_pre (or nullptr): the exclusive prefixes of the unit sums k_boundary_pack's header block left (its pre_out)
   // peer_flags (peer-written exchange; else nullptr): this rank's flags of the window `recv` is -- one line per source rank; the
   // segment of rank r is complete once its flag holds peer_seq (PeerTable).  Every block waits for every rank's flag (thread r
@@ -1010,6 +1019,34 @@ __device__ __forceinline__ void offspring_expand_spec_body(
     }
     return true;
   };
+  if (expander) {
+    // an expansion block: every rank's header, the level test (block 0 of the offspring blocks records a ruled-out level; nobody expands
+    // then), the neighbours' eager rows, its share of the rows.  (The coverage verdict stays the first offspring block's business: rows
+    // expanded into slots of an exchange that is redone are written again.)
+    if (sc->err & (4u | 8u | 16u)) return;   // (on hold / void / a peer missing: nobody delivers, nobody waits)
+    const double rec_ref = rec->ref;
+    SpecHdrRegs hregs;
+    if (peer_flags != nullptr) {
+      if constexpr (GRP) {
+        if (!peer_headers_ll(hregs, s_ll, s_late, peer_flags, peer_seq, wait_ticks, world)) {
+          if (threadIdx.x == 0) { atomicOr(&sc->err, 16u); atomicMin(&sc->fail_step, rec->step); }
+          return;
+        }
+      } else {
+        if (!wait_flags(0u, nullptr, 0, world - 1)) return;
+        hregs = spec_load_headers(recv, world, cap, d);
+      }
+    } else {
+      hregs = spec_load_headers(recv, world, cap, d);
+    }
+    spec_store_headers(H, hregs, world, cap);
+    if (optimistic && !(cssm_ref_choose(rec_ref, cssm_order_unkey(H.gkey)) == rec_ref)) return;
+    if (!wait_rows()) return;
+    expand_spec_body(H, blockIdx.x - blk0, (uint32_t)CSSM_SPEC_EXPAND_BLOCKS, recv, world, rank, cap, d, n_split, (uint64_t)slot_lo, (uint64_t)slot_hi, n_global, rec, anc, sc,
+                     RS, seed, slot_set, peer_flags, peer_seq, eager);
+    CSSM_SPEC_STAMP(3);
+    return;
+  }
   double pre_w[CSSM_ITEMS];
   if constexpr (GRP) {
     static_assert(RAWC == 2, "group sums: behind a propagate that formed the sums");
@@ -1049,12 +1086,10 @@ __device__ __forceinline__ void offspring_expand_spec_body(
     offspring_body<true, false, RS, RAWC, true, decltype(mid)>(logw, n, sc, unitP, unitS2, rec, n_global, /*endslot=*/nullptr, anc, ntiles, sup, nunits, RAWC, slot_set,
                                                                /*ll_t=*/nullptr, /*ess_t=*/nullptr, 0u, force_exact, all5, rank, world, split, seed,
                                                                /*cum_out=*/nullptr, /*logtab=*/nullptr, optimistic, flag_out, slot_lo, slot_hi, all5_stride,
-                                                               /*s2buf=*/nullptr, 0u, -1, 0u, /*unit_pre=*/nullptr, blk0, pre_ok ? pre_w : nullptr, nullptr, &mid);
+                                                               /*s2buf=*/nullptr, 0u, -1, 0u, /*unit_pre=*/nullptr, blk1, pre_ok ? pre_w : nullptr, nullptr, &mid);
     if (!mid_ok) return;   // (the body returned without resampling -- the level ruled out, block 0's verdict, a peer missing: no tail either)
     CSSM_SPEC_STAMP(2);
-    if (!wait_rows()) return;
-    expand_spec_body(H, bidx, nblk, recv, world, rank, cap, d, n_split, (uint64_t)slot_lo, (uint64_t)slot_hi, n_global, rec, anc, sc, RS, seed, slot_set, peer_flags, peer_seq, eager);
-    CSSM_SPEC_STAMP(3);
+    if (bidx == 0) spec_clear_sets(sc, slot_set);
     return;
   }
   const bool prefetched = peer_flags != nullptr && bidx < nunits;   // (uniform)
@@ -1101,12 +1136,9 @@ __device__ __forceinline__ void offspring_expand_spec_body(
   offspring_body<true, false, RS, RAWC>(logw, n, sc, unitP, unitS2, rec, n_global, /*endslot=*/nullptr, anc, ntiles, sup, nunits, RAWC, slot_set,
                                                         /*ll_t=*/nullptr, /*ess_t=*/nullptr, 0u, force_exact, all5, rank, world, split, seed,
                                                         /*cum_out=*/nullptr, /*logtab=*/nullptr, optimistic, flag_out, slot_lo, slot_hi, all5_stride,
-                                                        /*s2buf=*/nullptr, 0u, -1, 0u, unit_pre, blk0, prefetched ? pre_w : nullptr, &tt);
+                                                        /*s2buf=*/nullptr, 0u, -1, 0u, unit_pre, blk1, prefetched ? pre_w : nullptr, &tt);
   CSSM_SPEC_STAMP(2);
-  // the two neighbours' rows (their flags have long been set: the rows were written while this block resampled its own particles)
-  if (!wait_rows()) return;
-  expand_spec_body(H, bidx, nblk, recv, world, rank, cap, d, n_split, (uint64_t)slot_lo, (uint64_t)slot_hi, n_global, rec, anc, sc, RS, seed, slot_set, peer_flags, peer_seq, eager);
-  CSSM_SPEC_STAMP(3);
+  if (bidx == 0) spec_clear_sets(sc, slot_set);
 }
 
 template <int RAWC, int RS = CSSM_RESAMPLE_SYSTEMATIC, bool GRP = false>
