@@ -772,18 +772,23 @@ __device__ __forceinline__ bool spec_read_headers(SpecHeaders& H, int world, int
   // four slot counts per rank (own begin / end, reach of the lower neighbour's last block / of the upper neighbour's first
   // block), one thread each: the verdict is on every block's critical path
   if ((int)threadIdx.x < 4 * world) {
+    // (ONE call of count_of for the four kinds: the exact count is a chain of dependent fp64 operations -- a division among them -- and the
+    //  four arms of a switch ran one after the other in the block's first wave: 4.3 us from headers to verdict at world 2, on the path of
+    //  the launch's last block, tools/exchange_stamps_local.py; the arms now only choose the cumulative weight)
     const int r = (int)(threadIdx.x >> 2), which = (int)(threadIdx.x & 3);
-    uint64_t v = 0;
-    if (which == 0) v = count_of(H.off[r]);
-    else if (which == 1) v = count_of(cssm_u128_add(H.off[r], H.S[r]));
-    else if (which == 2) {
-      if (r > 0) {
-        const cssm_u128 Sp = H.S[r - 1], Pp = H.phigh[r - 1];
-        cssm_u128 bse; bse.lo = Sp.lo - Pp.lo; bse.hi = Sp.hi - Pp.hi - (Sp.lo < Pp.lo ? 1u : 0u);
-        v = count_of(cssm_u128_add(H.off[r - 1], bse));
-      }
-    } else if (r + 1 < world) v = count_of(cssm_u128_add(H.off[r + 1], H.plow[r + 1]));
-    H.cnts[r][which] = v;
+    const int rr = (which == 2) ? r - 1 : ((which == 3) ? r + 1 : r);
+    const bool valid = rr >= 0 && rr < world;
+    cssm_u128 G = cssm_u128_zero();
+    if (valid) {
+      const cssm_u128 Sr = H.S[rr];
+      cssm_u128 add = cssm_u128_zero();                 // which 0: the rank's first cumulative weight
+      if (which == 1) add = Sr;                         // its last
+      else if (which == 2) { const cssm_u128 Pp = H.phigh[rr]; add.lo = Sr.lo - Pp.lo; add.hi = Sr.hi - Pp.hi - (Sr.lo < Pp.lo ? 1u : 0u); }   // in front of the lower neighbour's last block
+      else if (which == 3) add = H.plow[rr];            // behind the upper neighbour's first block
+      G = cssm_u128_add(H.off[rr], add);
+    }
+    const uint64_t v = count_of(G);
+    H.cnts[r][which] = valid ? v : 0;
   }
   __syncthreads();
   if ((int)threadIdx.x < world) {
