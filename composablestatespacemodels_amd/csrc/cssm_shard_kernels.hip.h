@@ -179,7 +179,7 @@ __device__ __forceinline__ SpecHdrRegs spec_load_headers(const double* __restric
   }
   return g;
 }
-// stage 1: the headers into LDS, the ranks' offsets, the totals and the largest max key (all threads call; two barriers)
+// stage 1: the headers into LDS, the ranks' offsets, the totals and the largest max key (all threads call; one barrier)
 __device__ __forceinline__ void spec_store_headers(SpecHeaders& H, const SpecHdrRegs& g, int world, long long cap) {
   if (threadIdx.x < 64) {
     cssm_u128 S = cssm_u128_zero(), bs = cssm_u128_zero(), pl = cssm_u128_zero(), ph = cssm_u128_zero();
@@ -192,18 +192,19 @@ __device__ __forceinline__ void spec_store_headers(SpecHeaders& H, const SpecHdr
     }
     H.S[threadIdx.x] = S; H.base[threadIdx.x] = bs; H.plow[threadIdx.x] = pl; H.phigh[threadIdx.x] = ph; H.cnt[threadIdx.x] = c;
     cssm_u128 S2; S2.lo = cssm_d2u(g.w[9]); S2.hi = cssm_d2u(g.w[10]);
-    H.S2[threadIdx.x] = S2; H.key[threadIdx.x] = ((int)threadIdx.x < world) ? cssm_d2u(g.w[11]) : 0ull;
-  }
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    cssm_u128 run = cssm_u128_zero(), run2 = cssm_u128_zero();
-    unsigned long long key = 0ull;
-    for (int r = 0; r < world; ++r) {
-      H.off[r] = run; run = cssm_u128_add(run, H.S[r]); run2 = cssm_u128_add(run2, H.S2[r]);
-      key = (H.key[r] > key) ? H.key[r] : key;
-    }
-    H.tot = run; H.tot2 = run2; H.gkey = key;
-    H.all_ok = 1;
+    const unsigned long long key = ((int)threadIdx.x < world) ? cssm_d2u(g.w[11]) : 0ull;
+    H.S2[threadIdx.x] = S2; H.key[threadIdx.x] = key;
+    // the ranks' offsets, the totals and the largest key by the wave's scans, out of the registers (the ranks beyond `world` hold zeros).
+    // (Thread 0 used to walk the ranks through LDS behind a barrier: 1.4 us from "headers seen" to "headers in LDS" at world 8 against 0.8
+    //  at world 1, in every block of the launch -- tools/exchange_stamps_local.py)
+    const int lane = (int)threadIdx.x;
+    const cssm_u128 inc = wave_scan_u128(S, lane);
+    cssm_u128 off; off.lo = inc.lo - S.lo; off.hi = inc.hi - S.hi - (inc.lo < S.lo ? 1ull : 0ull);
+    H.off[threadIdx.x] = off;
+    const cssm_u128 tot2 = wave_sum_u128(S2);
+    const unsigned long long gkey = wave_max_u64(key);
+    if (lane == 63) H.tot = inc;
+    if (lane == 0) { H.tot2 = tot2; H.gkey = gkey; H.all_ok = 1; }
   }
   __syncthreads();
 }
