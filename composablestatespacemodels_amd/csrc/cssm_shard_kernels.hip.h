@@ -102,6 +102,9 @@ __device__ __forceinline__ bool peer_poll_u32(const unsigned int* f, unsigned in
   }
   return true;
 }
+#ifndef CSSM_POLL_LL_SLEEP
+#define CSSM_POLL_LL_SLEEP 2   /* s_sleep units (64 clocks) between two polls of a header word (tools/archive/poll_sleep_experiment.sh: 2 and 8 are level) */
+#endif
 __device__ __forceinline__ bool peer_poll_ll(const unsigned long long* f, unsigned int want, unsigned long long ticks, unsigned int& half) {
   unsigned long long t0 = 0ull, v;
   unsigned int polls = 0u;
@@ -110,7 +113,7 @@ __device__ __forceinline__ bool peer_poll_ll(const unsigned long long* f, unsign
       const unsigned long long now = __builtin_amdgcn_s_memrealtime();
       if (t0 == 0ull) t0 = now; else if (now - t0 > ticks) return false;
     }
-    __builtin_amdgcn_s_sleep(2);
+    __builtin_amdgcn_s_sleep(CSSM_POLL_LL_SLEEP);
   }
   half = (unsigned int)v;
   return true;
