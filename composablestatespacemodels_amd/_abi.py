@@ -143,6 +143,7 @@ SYMBOLS = [
     ("cssm_pf_shard_pack_peer", C.c_int, [_h, C.c_int, C.c_int, C.c_int64]),
     ("cssm_pf_shard_pack_rows_peer", C.c_int, [_h, C.c_int, C.c_int, C.c_int64]),
     ("cssm_pf_shard_peer_rows", C.c_int, [_h, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
+    ("cssm_pf_shard_peer_debug", C.c_int64, [_h, C.POINTER(C.c_uint32), C.c_size_t]),
     ("cssm_pf_shard_adopt_peer", C.c_int, [_h, C.c_int, C.c_int, C.c_int64]),
     ("cssm_pf_shard_exchange_peer", C.c_int, [_h, C.c_int, C.c_int, C.c_int64]),
     ("cssm_pf_shard_series_peer", C.c_int, [_h, C.c_int, C.c_int, C.c_size_t, C.c_size_t, _u8p, C.c_int64]),

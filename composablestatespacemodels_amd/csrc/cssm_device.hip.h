@@ -89,7 +89,10 @@ struct Scalars {
   // observation was formed by k_offspring's blocks -- one partial per block in s2[pend_buf][0 .. pend_n) -- and nobody has
   // totalled it yet: the NEXT weighted observation's publisher block does (and files the value under ess_t[pend_idx] if the
   // batch call of generation pend_gen is still the one running), or the host when a call ends (cssm_ess_of, same arithmetic).
-  uint32_t pend, pend_buf, pend_n, pend_idx, pend_gen, pad3_;
+  uint32_t pend, pend_buf, pend_n, pend_idx, pend_gen;
+  uint32_t wait_code;        // (peer-written exchange, with err bit 4) WHICH wait gave up: bit 0 an offspring block's header words, 1 an expansion
+                             //   block's, 2 a pack row block's, 3 the eager rows' flag, 4 the flag of the rows beyond them, 5 a header flag
+                             //   (launches without group sums); bits 8-15: the rank whose word it was
   cssm_u128 pend_S;          // S_tot of that observation
   // (peer-written exchange) how long a reader polls for a peer's words before it gives up (err bit 4), in ticks of the constant 100 MHz
   // clock (s_memrealtime): wall-clock time, not an iteration count -- a rank that compiles a kernel, a loaded host or a debugger may be

@@ -610,7 +610,9 @@ extern "C" int cssm_pf_shard_status(cssm_pf* pf, double* ll_out, int32_t* ess_ou
   if (bits_out) *bits_out = h.err & 12u;
   h.err &= ~12u;
   if (h.err & 16u) return fail(CSSM_ESHARD, "peer-written exchange: a rank's segment of observation %u did not arrive within the wait bound "
-                                            "(a peer that died, or never enqueued its series?)", h.fail_step);
+                                            "(a peer that died, or never enqueued its series?  wait code %#x: bit 0 / 1 / 2 header words awaited by an offspring / "
+                                            "expansion / pack row block, 3 the eager rows' flag, 4 the flag of the rows beyond them, 5 a header flag; bits 8-15 the rank)",
+                                            h.fail_step, h.wait_code);
   return cssm_check_device_err(pf, h);
 }
 
@@ -794,6 +796,21 @@ extern "C" int cssm_pf_shard_pack_rows_peer(cssm_pf* pf, int rank, int world, in
   if (pf->peer_rows_packed) return CSSM_OK;
   pf->peer_rows_packed = true;
   return boundary_pack_impl(pf, rank, world, cap, nullptr, true, 4);
+}
+// Diagnostics: this rank's flag words of both windows (world x CSSM_PEER_FLAG_STRIDE uint32 each, window 0 first), its local ticket words
+// behind them (CSSM_PEER_TICKET_WORDS) and, last, the handle's exchange counter -- as they are now (no synchronisation with the stream: for
+// a series that has just ended in "a rank's segment did not arrive").  Returns the number of words written, or a negative error.
+extern "C" int64_t cssm_pf_shard_peer_debug(cssm_pf* pf, uint32_t* out, size_t nwords) {
+  if (!pf || !out) return CSSM_EINVAL_ARG;
+  PeerState* ps = static_cast<PeerState*>(pf->peer);
+  if (!ps || !ps->slab) return CSSM_ESTATE;
+  const size_t fw = (size_t)ps->world * CSSM_PEER_FLAG_STRIDE, need = 2 * fw + CSSM_PEER_TICKET_WORDS + 1;
+  if (nwords < need) return CSSM_EINVAL_ARG;
+  for (int p = 0; p < 2; ++p)
+    if (hipMemcpy(out + (size_t)p * fw, peer_flagset(ps, ps->slab, p), fw * sizeof(uint32_t), hipMemcpyDeviceToHost) != hipSuccess) { (void)hipGetLastError(); return CSSM_EHIP; }
+  if (hipMemcpy(out + 2 * fw, pf->peer_tickets, CSSM_PEER_TICKET_WORDS * sizeof(uint32_t), hipMemcpyDeviceToHost) != hipSuccess) { (void)hipGetLastError(); return CSSM_EHIP; }
+  out[2 * fw + CSSM_PEER_TICKET_WORDS] = pf->peer_seq;
+  return (int64_t)need;
 }
 // Rows the pack stages of this handle wrote for its neighbours since the windows were set up (per segment: the eager rows, or the needed
 // ones where they were more), the number of neighbour segments they went into, and how many of those needed rows beyond the eager ones

@@ -221,7 +221,7 @@ __device__ __forceinline__ bool peer_headers_ll(SpecHdrRegs& hregs, uint32_t* __
     const uint32_t r = i / CSSM_PEER_LL_WORDS, w = i % CSSM_PEER_LL_WORDS;
     const unsigned long long* f = reinterpret_cast<const unsigned long long*>(peer_flags + (size_t)r * CSSM_PEER_FLAG_STRIDE + CSSM_PEER_FLAG_LL) + w;
     unsigned int half = 0u;
-    if (!peer_poll_ll(f, peer_seq, wait_ticks, half)) { s_late = 1u; break; }
+    if (!peer_poll_ll(f, peer_seq, wait_ticks, half)) { s_late = 1u | (r << 8); break; }   // (bits 8-15: whose word it was -- Scalars::wait_code)
     ll[i] = half;
   }
   __syncthreads();
@@ -327,10 +327,17 @@ __device__ __forceinline__ void boundary_pack_block(const uint32_t bx, const uin
   __shared__ unsigned int s_need, s_hlate;
   // rows next to the boundary that travel at once (PackNeed; every row where nobody asked for less: the collective exchange, CSSM_PEER_ALL_ROWS)
   const long long eager = (need_on && peer != nullptr) ? xn->eager : cap;
-  // the series is on hold (capacity miss), void (level ruled out) or a peer is missing: nothing may change -- tested where a block is
-  // about to store (everything before is loads and arithmetic: at the head of the block the test was a round trip of its own in a
-  // kernel that is one latency chain, and in the merged kernel the pollers of every rank wait for that chain)
-  const uint32_t held = sc->err & (4u | 8u | 16u);
+  // The series is on hold (capacity miss), void (level ruled out) or a peer is missing: nothing may change -- IF THE BIT WAS THERE WHEN
+  // THIS LAUNCH BEGAN.  The first offspring block of this very launch raises such a bit as soon as it holds every rank's header (its
+  // verdict), and a pack block that saw it then returned without its header or its ticket: the rank it was for waited for words that never
+  // came.  Reading the bits at the block's entry is not enough -- the blocks of a launch start XCD by XCD, and with three processes on one
+  // GPU a header block was seen to start microseconds behind the offspring blocks of its own launch (tools/ipc_soak.py: one run in six at a
+  // capacity miss).  So the question is put so that every block of a launch answers it alike: the bits count only if the observation that
+  // raised them (Scalars::fail_step, written with them) is not this launch's own.  (fail_step still unset: the bit is being raised right
+  // now -- by this launch.)  Tested where a block is about to store: at the head it was a round trip of its own.
+  const uint32_t err_now = __hip_atomic_load(&sc->err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & (4u | 8u | 16u);
+  const uint32_t fail_now = __hip_atomic_load(&sc->fail_step, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  const uint32_t held = (err_now != 0u && fail_now != 0xffffffffu && fail_now != rec->step) ? err_now : 0u;
   const long long R = d + 1, HD = spec_hdr(d), seg = spec_seg(d, cap);
   double* oseg = peer ? peer->win[parity][q] + (size_t)rank * seg : out + (size_t)q * seg;
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
@@ -458,7 +465,10 @@ __device__ __forceinline__ void boundary_pack_block(const uint32_t bx, const uin
   auto wait_headers = [&]() -> bool {   // every rank's header -> *xn->H (the offspring blocks of this launch wait for the same words)
     SpecHdrRegs hregs;
     if (!peer_headers_ll(hregs, xn->ll, s_hlate, xn->my_flags, seq, sc->peer_wait_ticks, world)) {
-      if (threadIdx.x == 0) { atomicOr(&const_cast<Scalars*>(sc)->err, 16u); atomicMin(&const_cast<Scalars*>(sc)->fail_step, rec->step); }
+      if (threadIdx.x == 0) {
+        Scalars* scw = const_cast<Scalars*>(sc);
+        atomicOr(&scw->err, 16u); atomicMin(&scw->fail_step, rec->step); atomicOr(&scw->wait_code, 4u | (s_hlate & 0xff00u));
+      }
       return false;   // (a peer's header did not come: no ticket, no flag -- the series ends on every rank like one on hold)
     }
     spec_store_headers(*xn->H, hregs, world, cap);
@@ -940,7 +950,7 @@ __device__ __forceinline__ void expand_spec_body(SpecHeaders& H, uint32_t bid, u
     if (threadIdx.x == 0) s_xlate = 0u;
     if ((unc >> side) & 1u) {
       const unsigned int* f = peer_flags + (size_t)s * CSSM_PEER_FLAG_STRIDE;
-      if (!peer_poll_u32(f + CSSM_PEER_FLAG_EXTRA, peer_seq, sc->peer_wait_ticks)) atomicOr(&s_xlate, 1u);
+      if (!peer_poll_u32(f + CSSM_PEER_FLAG_EXTRA, peer_seq, sc->peer_wait_ticks)) { atomicOr(&s_xlate, 1u); atomicOr(&sc->wait_code, 16u | ((uint32_t)s << 8)); }
       else s_xneed[side] = (long long)__hip_atomic_load(f + CSSM_PEER_FLAG_NEED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
   }
@@ -1004,7 +1014,7 @@ __device__ __forceinline__ void offspring_expand_spec_body(
       const unsigned int* f = (r < world) ? peer_flags + (size_t)r * CSSM_PEER_FLAG_STRIDE + which : extra;
       // (relaxed system-scope loads: each one reads the flag at the point of coherence; the window itself is read with such loads
       //  too -- ld_sys, no fence: see there -- and the next kernel's gathers start behind a kernel boundary)
-      if (!peer_poll_u32(f, peer_seq, wait_ticks)) s_late = 1u;
+      if (!peer_poll_u32(f, peer_seq, wait_ticks)) { s_late = 1u; atomicOr(&sc->wait_code, 32u | ((uint32_t)r << 8)); }
     }
     __syncthreads();
     if (s_late) {
@@ -1020,7 +1030,9 @@ __device__ __forceinline__ void offspring_expand_spec_body(
   auto wait_rows = [&]() -> bool {
     if (peer_flags == nullptr) return true;
     if (rows_thread &&
-        !peer_poll_u32(peer_flags + (size_t)threadIdx.x * CSSM_PEER_FLAG_STRIDE + CSSM_PEER_FLAG_ROWS, peer_seq, wait_ticks)) s_late = 1u;
+        !peer_poll_u32(peer_flags + (size_t)threadIdx.x * CSSM_PEER_FLAG_STRIDE + CSSM_PEER_FLAG_ROWS, peer_seq, wait_ticks)) {
+      s_late = 1u; atomicOr(&sc->wait_code, 8u | (threadIdx.x << 8));
+    }
     __syncthreads();
     if (s_late) {
       if (threadIdx.x == 0) { atomicOr(&sc->err, 16u); atomicMin(&sc->fail_step, rec->step); }
@@ -1038,7 +1050,7 @@ __device__ __forceinline__ void offspring_expand_spec_body(
     if (peer_flags != nullptr) {
       if constexpr (GRP) {
         if (!peer_headers_ll(hregs, s_ll, s_late, peer_flags, peer_seq, wait_ticks, world)) {
-          if (threadIdx.x == 0) { atomicOr(&sc->err, 16u); atomicMin(&sc->fail_step, rec->step); }
+          if (threadIdx.x == 0) { atomicOr(&sc->err, 16u); atomicMin(&sc->fail_step, rec->step); atomicOr(&sc->wait_code, 2u | (s_late & 0xff00u)); }
           return;
         }
       } else {
@@ -1069,7 +1081,7 @@ __device__ __forceinline__ void offspring_expand_spec_body(
       SpecHdrRegs hregs;
       if (peer_flags != nullptr) {
         if (!peer_headers_ll(hregs, s_ll, s_late, peer_flags, peer_seq, wait_ticks, world)) {
-          if (threadIdx.x == 0) { atomicOr(&sc->err, 16u); atomicMin(&sc->fail_step, rec->step); }
+          if (threadIdx.x == 0) { atomicOr(&sc->err, 16u); atomicMin(&sc->fail_step, rec->step); atomicOr(&sc->wait_code, 1u | (s_late & 0xff00u)); }
           return false;
         }
         CSSM_SPEC_STAMP(7);

@@ -561,6 +561,10 @@ int cssm_pf_shard_pack_peer(cssm_pf* pf, int rank, int world, int64_t cap);
  * (diagnostics; beyond_out may be NULL). */
 int cssm_pf_shard_pack_rows_peer(cssm_pf* pf, int rank, int world, int64_t cap);
 int cssm_pf_shard_peer_rows(cssm_pf* pf, uint64_t* rows_out, uint64_t* segments_out, uint64_t* beyond_out);
+/* Diagnostics for a series that ended in "a rank's segment did not arrive": this rank's flag words of both windows (world x 96 uint32 each:
+ * per source rank [0] header flag, [16] eager rows flag, [17] needed rows, [18] flag of the rows beyond the eager ones, [32..79] the 24
+ * self-validating header words), its 256 local ticket words and the handle's exchange counter; returns the words written (< 0: error). */
+int64_t cssm_pf_shard_peer_debug(cssm_pf* pf, uint32_t* out, size_t nwords);
 int cssm_pf_shard_adopt_peer(cssm_pf* pf, int rank, int world, int64_t cap);
 /* pack + adopt in ONE launch (the pack blocks lead the grid): for a rank that has its stream to itself, i.e. one process per GPU --
  * what cssm_pf_shard_series_peer enqueues.  Shards that share a stream use the stage calls, every stage on all shards before the next. */

@@ -272,6 +272,58 @@ def test_peer_exchange_between_processes_sharing_the_gpu(tmp_path, world, grp, m
         assert beyond > 0          # some exchange needed rows beyond the eight eager ones: the second path ran across processes
 
 
+def _soak_rank(rank, world, port, n, T, outdir):
+    """One rank of test_a_capacity_miss_between_processes_holds_every_rank_alike (spawned; every rank on cuda:0)."""
+    import torch
+    import torch.distributed as dist
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import cases as cs
+    from composablestatespacemodels_amd.sharded import DistComm, GpuShard, ShardedFilter
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+
+    class GlooPeerComm(DistComm):
+        peer = True
+
+    torch.cuda.set_device(0)
+    t, y, has = cs.poisson_counts(T, missing=0.1)
+    shard = GpuShard(cs.c2_model(), n, rank, world, cs.SEED, 0)
+    shard.set_option(2, 1)                      # stratified: the series that met the capacity miss in tools/ipc_soak.py
+    f = ShardedFilter([shard], GlooPeerComm())
+    cut = T // 3
+    f.ll_filter(t[:cut], y[:cut], has[:cut])
+    ll, ess = f.ll_filter_more(t[cut:], y[cut:], has[cut:])
+    np.savez(os.path.join(outdir, f"r{rank}.npz"), ll=ll, ess=ess, part=shard.particles(), resumes=int(f.last_resumes))
+    shard.close()
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_a_capacity_miss_between_processes_holds_every_rank_alike(tmp_path, monkeypatch):
+    """Three processes on this GPU, a 400-observation series with eight eager rows whose observation 315 needs more rows than the capacity
+    holds: every rank's first offspring block raises the hold as soon as it has all headers -- while pack blocks of the SAME launch on
+    the same rank may not have stored yet (the blocks of a launch start XCD by XCD; with several processes on the GPU microseconds apart).
+    Those blocks must not take the hold for theirs (they did, one run in six: a header or a ticket missing, the neighbour waiting until its
+    bound): every rank holds, resumes the observation with a larger capacity, and ends on the oracle's bits.  Repeated: it is a race."""
+    import torch.multiprocessing as mp
+    monkeypatch.setenv("CSSM_GRP_MIN_UNITS", "1")
+    monkeypatch.setenv("CSSM_PEER_EAGER_ROWS", "8")
+    monkeypatch.setenv("CSSM_PEER_TIMEOUT_MS", "5000")
+    world, n, T = 3, 13312, 400
+    t, y, has = cases.poisson_counts(T, missing=0.1)
+    o = oracle.OraclePf(cases.c2_model().descriptor(), n, cases.SEED, oracle.RESAMPLE_STRATIFIED)
+    oll, _, oess, _ = o.filter(t, y, has)
+    for rep in range(4):
+        out = tmp_path / f"rep{rep}"
+        out.mkdir()
+        mp.spawn(_soak_rank, args=(world, 29850 + (os.getpid() + rep) % 40, n, T, str(out)), nprocs=world, join=True)
+        z = [np.load(os.path.join(str(out), f"r{r}.npz")) for r in range(world)]
+        assert all(float(q["ll"]) == oll and int(q["ess"]) == int(oess[-1]) for q in z)
+        assert all(int(q["resumes"]) >= 1 for q in z)      # the series did meet its capacity miss
+        np.testing.assert_array_equal(np.concatenate([q["part"] for q in z], axis=1), o.particles())
+
+
 def test_bench_n_rank_path_rehearsed_with_gpu_shards_sharing_this_gpu():
     """`bench.py --gpus 3 --backend gloo-gpu`: what the driver will run on a node (`bench.py --gpus N` -> torch.distributed.run -> one rank
     per GPU), rehearsed with three ranks that are real GpuShards on THIS GPU: the launcher, the pre-flight walk (windows mapped over

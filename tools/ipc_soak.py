@@ -1,0 +1,75 @@
+#!/usr/bin/env python3
+"""Soak of the peer-written exchange ACROSS PROCESSES sharing this GPU (windows mapped over hipIpc, control plane on gloo): long series on the
+merged launch with few eager rows, so that nearly every exchange takes the path behind the headers (rows beyond the eager ones, EXTRA flag),
+and every rank's ll / ESS / cloud against the single-rank oracle.  Timing between the processes differs from run to run: what a race in the
+flag protocol would need.  usage: ipc_soak.py [world=3] [observations=400] [rounds=3] [eager=8]"""
+import os
+import sys
+
+import numpy as np
+
+R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, R); sys.path.insert(0, os.path.join(R, "tests"))
+
+
+def rank_main(rank, world, port, n, T, outdir, stratified):
+    import torch
+    import torch.distributed as dist
+    import cases as cs
+    from composablestatespacemodels_amd.sharded import DistComm, GpuShard, ShardedFilter
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+
+    class GlooPeerComm(DistComm):
+        peer = True
+
+    torch.cuda.set_device(0)
+    model = cs.c2_model()
+    t, y, has = cs.poisson_counts(T, missing=0.1)
+    shard = GpuShard(model, n, rank, world, cs.SEED, 0)
+    if stratified:
+        shard.set_option(2, 1)
+    f = ShardedFilter([shard], GlooPeerComm())
+    cut = T // 3
+    f.ll_filter(t[:cut], y[:cut], has[:cut])
+    ll, ess = f.ll_filter_more(t[cut:], y[cut:], has[cut:])
+    np.savez(os.path.join(outdir, f"r{rank}.npz"), ll=ll, ess=ess, part=shard.particles(), peer=int(f.last_peer), resumes=int(f.last_resumes),
+             rows=np.asarray(shard.peer_rows(), dtype=np.int64))
+    shard.close()
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def main():
+    import tempfile
+    import torch.multiprocessing as mp
+    import cases
+    from oracle import oracle
+    world = int(sys.argv[1]) if len(sys.argv) > 1 else 3
+    T = int(sys.argv[2]) if len(sys.argv) > 2 else 400
+    rounds = int(sys.argv[3]) if len(sys.argv) > 3 else 3
+    os.environ["CSSM_PEER_EAGER_ROWS"] = sys.argv[4] if len(sys.argv) > 4 else "8"
+    os.environ.setdefault("CSSM_GRP_MIN_UNITS", "1")
+    model = cases.c2_model()
+    t, y, has = cases.poisson_counts(T, missing=0.1)
+    bad = 0
+    for rnd in range(rounds):
+        for stratified in (False, True):
+            n = 4096 * world + 1024 * rnd
+            o = oracle.OraclePf(model.descriptor(), n, cases.SEED, oracle.RESAMPLE_STRATIFIED if stratified else 0)
+            oll, _, oess, _ = o.filter(t, y, has)
+            with tempfile.TemporaryDirectory() as d:
+                mp.spawn(rank_main, args=(world, 29900 + (os.getpid() + rnd * 2 + int(stratified)) % 90, n, T, d, stratified), nprocs=world, join=True)
+                z = [np.load(os.path.join(d, f"r{r}.npz")) for r in range(world)]
+            ok = all(float(q["ll"]) == oll and int(q["ess"]) == int(oess[-1]) and int(q["peer"]) == 1 for q in z) and \
+                np.array_equal(np.concatenate([q["part"] for q in z], axis=1), o.particles())
+            beyond = sum(int(q["rows"][2]) for q in z); seg = sum(int(q["rows"][1]) for q in z)
+            print(f"round {rnd} world {world} N {n} T {T} stratified {stratified}: {'identical' if ok else 'DIFFERENT'}; {beyond} of {seg} neighbour segments needed rows beyond "
+                  f"the {os.environ['CSSM_PEER_EAGER_ROWS']} eager ones; resumes {[int(q['resumes']) for q in z]}", flush=True)
+            bad += 0 if ok else 1
+    print("SOAK OK" if bad == 0 else f"SOAK FAILED ({bad})")
+    sys.exit(1 if bad else 0)
+
+
+if __name__ == "__main__":
+    main()
