@@ -140,6 +140,7 @@ __device__ __forceinline__ bool peer_poll_ll(const unsigned long long* f, unsign
 // [64] the flag of the unit-sum prefixes (merged kernel), [96, 100) results of the handshake, [100, 108) PackNeed::stat, [128, 192) PackNeed::need,
 // [192, 256) tickets of the rows beyond the eager ones
 #define CSSM_PEER_TICKET_WORDS 256
+#define CSSM_PEER_TICKET_HDR_DONE 66   /* merged launch: header blocks that are done reading the max slots (the first offspring block clears them) */
 #define CSSM_PEER_TICKET_STAT 100
 #define CSSM_PEER_TICKET_NEED 128
 #define CSSM_PEER_TICKET_EXTRA 192
@@ -302,7 +303,8 @@ __device__ __forceinline__ void boundary_pack_block(const uint32_t bx, const uin
                                                               int level_from_max, cssm_u128* __restrict__ pre_out,
                                                               const PeerTable* __restrict__ peer, int parity, uint32_t seq,
                                                               unsigned int* __restrict__ tickets, unsigned int* __restrict__ pre_flag,
-                                                              const int grp_set, const PackNeed& xnr, const bool need_on, const int phase) {
+                                                              const int grp_set, const PackNeed& xnr, const bool need_on, const int phase, const bool merged = false) {
+  // merged: this block runs in the merged launch (k_exchange_offspring), next to the offspring blocks that consume what it reads
   const PackNeed* xn = &xnr;
   // need_on (peer-written exchange; xn.eager < cap): the eager rows travel at once, of the others those the neighbours need, behind every
   // rank's header (PackNeed).  phase: bit 0 = the header and prefix blocks work, bit 1 = the row blocks write their eager rows, bit 2 = the
@@ -733,6 +735,9 @@ __device__ __forceinline__ void boundary_pack_block(const uint32_t bx, const uin
     for (int w = 0; w < 12; ++w) oseg[w] = cssm_u2d(s_hw[w]);
   }
   peer_done(true);
+  // (merged launch: the first offspring block clears the max slots this block has read -- behind the count of the header blocks that are
+  //  done with them: CSSM_PEER_TICKET_HDR_DONE)
+  if (merged && tickets != nullptr && threadIdx.x == 0) atomicAdd(&tickets[CSSM_PEER_TICKET_HDR_DONE], 1u);
   CSSM_SPEC_STAMP(5);
 }
 
@@ -828,7 +833,28 @@ __device__ __forceinline__ bool spec_read_headers(SpecHeaders& H, int world, int
 // What the first offspring block leaves for the next observation (all its threads call, behind its own particles): max-slot set 0 cleared,
 // and the two sets of group sums this observation did not use (grp_cur: the set of this one; the handle's exchanges rotate through the
 // three -- the next propagate adds to set grp_cur + 1, the one after to the set the observation before this one used)
-__device__ __forceinline__ void spec_clear_sets(Scalars* __restrict__ sc, const int grp_cur) {
+// hdr_done / n_hdr (the merged launch; else nullptr): the max slots are read by the launch's OWN header blocks, one per destination rank --
+// they lead the grid, but the blocks of a launch start XCD by XCD, and with several processes on one GPU a header block was seen to run
+// behind the first offspring block's end: it read cleared slots, its destination got a header with another max than everybody else's, and
+// the ranks' levels (LGCP: predicted from the max) and likelihoods drifted apart (tools/ipc_soak.py ... lgcp, world 3).  So the clear waits,
+// bounded, for the count of header blocks that are done (usually long reached), and takes the count back to zero.
+__device__ __forceinline__ void spec_clear_sets(Scalars* __restrict__ sc, const int grp_cur, unsigned int* __restrict__ hdr_done = nullptr, const unsigned int n_hdr = 0u) {
+  if (hdr_done != nullptr) {
+    if (threadIdx.x == 0) {
+      const unsigned long long ticks = sc->peer_wait_ticks;
+      unsigned long long t0 = 0ull;
+      unsigned int polls = 0u;
+      while (__hip_atomic_load(hdr_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < n_hdr) {
+        if ((++polls & 63u) == 0u) {
+          const unsigned long long now = __builtin_amdgcn_s_memrealtime();
+          if (t0 == 0ull) t0 = now; else if (now - t0 > ticks) break;   // (a header block that never ran: the launch is beyond help; do not hang)
+        }
+        __builtin_amdgcn_s_sleep(2);
+      }
+      __hip_atomic_store(hdr_done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+  }
   if (threadIdx.x < CSSM_MAXSLOTS) sc->maxslot[(size_t)threadIdx.x * CSSM_SLOT_STRIDE] = 0ull;
   static_assert(2 * 2 * CSSM_GRP_MAX <= CSSM_BLOCK, "one store per thread and array");
   if (threadIdx.x < 2 * 2 * CSSM_GRP_MAX) {
@@ -986,7 +1012,9 @@ template <int RAWC, int RS, bool GRP = false>
 __device__ __forceinline__ void offspring_expand_spec_body(
     CSSM_OFFSPRING_PARAMS, uint32_t all5_stride, const double* __restrict__ recv, long long cap, int d, uint32_t n_split,
     const cssm_u128* __restrict__ unit_pre, const unsigned int* __restrict__ peer_flags, uint32_t peer_seq,
-    const uint32_t blk0, const unsigned int* __restrict__ pre_flag, SpecHeaders& H, uint32_t* __restrict__ s_ll, const long long eager) {
+    const uint32_t blk0, const unsigned int* __restrict__ pre_flag, SpecHeaders& H, uint32_t* __restrict__ s_ll, const long long eager,
+    unsigned int* __restrict__ hdr_done = nullptr) {
+  // hdr_done (the merged launch): the count of this launch's header blocks that are done (spec_clear_sets)
   // eager (peer-written exchange): rows next to the boundary that the neighbours wrote at once (PackNeed::eager; >= cap: all of them)
   // H / s_ll: LDS of the launch, declared by the kernel (the merged kernel's pack blocks use the same two objects: static LDS of the
   // two halves of a kernel adds up, it does not overlap)
@@ -1110,7 +1138,7 @@ __device__ __forceinline__ void offspring_expand_spec_body(
                                                                /*s2buf=*/nullptr, 0u, -1, 0u, /*unit_pre=*/nullptr, blk1, pre_ok ? pre_w : nullptr, nullptr, &mid);
     if (!mid_ok) return;   // (the body returned without resampling -- the level ruled out, block 0's verdict, a peer missing: no tail either)
     CSSM_SPEC_STAMP(2);
-    if (bidx == 0) spec_clear_sets(sc, slot_set);
+    if (bidx == 0) spec_clear_sets(sc, slot_set, hdr_done, (unsigned int)world);
     return;
   }
   const bool prefetched = peer_flags != nullptr && bidx < nunits;   // (uniform)
@@ -1159,7 +1187,7 @@ __device__ __forceinline__ void offspring_expand_spec_body(
                                                         /*cum_out=*/nullptr, /*logtab=*/nullptr, optimistic, flag_out, slot_lo, slot_hi, all5_stride,
                                                         /*s2buf=*/nullptr, 0u, -1, 0u, unit_pre, blk1, prefetched ? pre_w : nullptr, &tt);
   CSSM_SPEC_STAMP(2);
-  if (bidx == 0) spec_clear_sets(sc, slot_set);
+  if (bidx == 0) spec_clear_sets(sc, slot_set, hdr_done, (unsigned int)world);
 }
 
 template <int RAWC, int RS = CSSM_RESAMPLE_SYSTEMATIC, bool GRP = false>
@@ -1197,10 +1225,11 @@ __global__ __launch_bounds__(CSSM_BLOCK, CSSM_OFF_WAVES) void k_exchange_offspri
     xn.n_global = n_global; xn.seed = seed; xn.slot_lo = slot_lo; xn.slot_hi = slot_hi; xn.rs = RS; xn.eager = pk.eager;
     boundary_pack_block<RS>(blockIdx.x % pk.pack_gx, pk.pack_gx, (int)(blockIdx.x / pk.pack_gx), pk.src, pk.stride, logw, n, d, world, rank, cap, rec,
                         unitP, unitS2, pk.nsub, sc, nullptr, pk.chunk, /*level_from_max=*/0, pk.pre_out, pk.peer, pk.parity, peer_seq, pk.tickets,
-                        pk.pre_flag, GRP ? slot_set : -1, xn, pk.eager < cap, 7);
+                        pk.pre_flag, GRP ? slot_set : -1, xn, pk.eager < cap, 7, /*merged=*/true);
     return;
   }
-  offspring_expand_spec_body<RAWC, RS, GRP>(CSSM_OFFSPRING_FWD, all5_stride, recv, cap, d, n_split, unit_pre, peer_flags, peer_seq, blk0, pk.pre_flag, H, s_ll, pk.eager);
+  offspring_expand_spec_body<RAWC, RS, GRP>(CSSM_OFFSPRING_FWD, all5_stride, recv, cap, d, n_split, unit_pre, peer_flags, peer_seq, blk0, pk.pre_flag, H, s_ll, pk.eager,
+                                            pk.tickets + CSSM_PEER_TICKET_HDR_DONE);
 }
 
 __global__ __launch_bounds__(CSSM_BLOCK) void k_expand(const uint32_t* __restrict__ cand_end, const uint32_t* __restrict__ cand_idx,

@@ -272,8 +272,9 @@ def test_peer_exchange_between_processes_sharing_the_gpu(tmp_path, world, grp, m
         assert beyond > 0          # some exchange needed rows beyond the eight eager ones: the second path ran across processes
 
 
-def _soak_rank(rank, world, port, n, T, outdir):
-    """One rank of test_a_capacity_miss_between_processes_holds_every_rank_alike (spawned; every rank on cuda:0)."""
+def _soak_rank(rank, world, port, n, T, outdir, lgcp=False):
+    """One rank of test_a_capacity_miss_between_processes_holds_every_rank_alike / test_lgcp_between_processes_... (spawned; every rank
+    on cuda:0)."""
     import torch
     import torch.distributed as dist
     sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
@@ -287,13 +288,17 @@ def _soak_rank(rank, world, port, n, T, outdir):
         peer = True
 
     torch.cuda.set_device(0)
-    t, y, has = cs.poisson_counts(T, missing=0.1)
-    shard = GpuShard(cs.c2_model(), n, rank, world, cs.SEED, 0)
-    shard.set_option(2, 1)                      # stratified: the series that met the capacity miss in tools/ipc_soak.py
+    if lgcp:
+        t, y, has = cs.event_times(T, horizon=0.1 * T)
+        shard = GpuShard(cs.c4_model(), n, rank, world, cs.SEED, 0, lgcp_precision=2)
+    else:
+        t, y, has = cs.poisson_counts(T, missing=0.1)
+        shard = GpuShard(cs.c2_model(), n, rank, world, cs.SEED, 0)
+        shard.set_option(2, 1)                  # stratified: the series that met the capacity miss in tools/ipc_soak.py
     f = ShardedFilter([shard], GlooPeerComm())
     cut = T // 3
-    f.ll_filter(t[:cut], y[:cut], has[:cut])
-    ll, ess = f.ll_filter_more(t[cut:], y[cut:], has[cut:])
+    f.ll_filter(t[:cut], y[:cut], has[:cut], lgcp=lgcp)
+    ll, ess = f.ll_filter_more(t[cut:], y[cut:], has[cut:], lgcp=lgcp)
     np.savez(os.path.join(outdir, f"r{rank}.npz"), ll=ll, ess=ess, part=shard.particles(), resumes=int(f.last_resumes))
     shard.close()
     dist.barrier()
@@ -321,6 +326,29 @@ def test_a_capacity_miss_between_processes_holds_every_rank_alike(tmp_path, monk
         z = [np.load(os.path.join(str(out), f"r{r}.npz")) for r in range(world)]
         assert all(float(q["ll"]) == oll and int(q["ess"]) == int(oess[-1]) for q in z)
         assert all(int(q["resumes"]) >= 1 for q in z)      # the series did meet its capacity miss
+        np.testing.assert_array_equal(np.concatenate([q["part"] for q in z], axis=1), o.particles())
+
+
+def test_lgcp_between_processes_every_destination_gets_the_same_header(tmp_path, monkeypatch):
+    """Three processes on this GPU, BASELINE configs[3] (LGCP: every event's level is predicted from the max of the event before, which
+    travels in the headers), 60 events.  A rank's header blocks -- one per destination -- read the max slots that the first offspring block
+    of the SAME launch clears at its end; a header block that ran behind it (the blocks of a launch start XCD by XCD, processes take turns)
+    sent its destination a header with another max than everybody else's: levels and likelihoods drifted apart between the ranks (every
+    run of tools/ipc_soak.py ... lgcp at world 3 before the clear waited for the header blocks).  All ranks: the oracle's bits."""
+    import torch.multiprocessing as mp
+    monkeypatch.setenv("CSSM_GRP_MIN_UNITS", "1")
+    monkeypatch.setenv("CSSM_PEER_EAGER_ROWS", "8")
+    monkeypatch.setenv("CSSM_PEER_TIMEOUT_MS", "5000")
+    world, n, T = 3, 12288, 60
+    t, y, has = cases.event_times(T, horizon=0.1 * T)
+    o = oracle.OraclePf(cases.c4_model().descriptor(2), n, cases.SEED)
+    oll, _, oess, _ = o.filter(t, y, has)
+    for rep in range(2):
+        out = tmp_path / f"rep{rep}"
+        out.mkdir()
+        mp.spawn(_soak_rank, args=(world, 29810 + (os.getpid() + rep) % 30, n, T, str(out), True), nprocs=world, join=True)
+        z = [np.load(os.path.join(str(out), f"r{r}.npz")) for r in range(world)]
+        assert [float(q["ll"]) for q in z] == [oll] * world and all(int(q["ess"]) == int(oess[-1]) for q in z)
         np.testing.assert_array_equal(np.concatenate([q["part"] for q in z], axis=1), o.particles())
 
 
