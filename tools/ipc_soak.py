@@ -4,7 +4,9 @@ merged launch with few eager rows, so that nearly every exchange takes the path 
 and every rank's ll / ESS / cloud against the single-rank oracle.  Timing between the processes differs from run to run: what a race in the
 flag protocol would need.  usage: ipc_soak.py [world=3] [observations=400] [rounds=3] [eager=8] [outliers | lgcp]
 outliers (world 2): two observations outlying enough to rule their reference level out -- the series holds there on every rank and the
-observation is redone in place with its level from the all-gathered max (cssm_pf_shard_resume_level)."""
+observation is redone in place with its level from the all-gathered max (cssm_pf_shard_resume_level).  SOAK_PER_RANK=<particles per rank>
+(default 4096); CSSM_PEER_TWO_LAUNCHES=1 / CSSM_GRP_MIN_UNITS=100000 send the series through the staged launches / the launches without
+group sums."""
 import os
 import sys
 
@@ -72,7 +74,7 @@ def main():
     bad = 0
     for rnd in range(rounds):
         for stratified in (False, True):
-            n = 4096 * world + 1024 * rnd
+            n = int(os.environ.get("SOAK_PER_RANK", "4096")) * world + 1024 * rnd
             o = oracle.OraclePf(model.descriptor(2 if lgcp else 0), n, cases.SEED, oracle.RESAMPLE_STRATIFIED if stratified else 0)
             oll, _, oess, _ = o.filter(t, y, has)
             with tempfile.TemporaryDirectory() as d:
