@@ -37,7 +37,7 @@ def rank_main(rank, world, port, n, T, outdir, stratified, outliers):
     dist.init_process_group("gloo", rank=rank, world_size=world)
 
     class GlooPeerComm(DistComm):
-        peer = True
+        peer = os.environ.get("SOAK_PROTOCOL", "peer") == "peer"     # SOAK_PROTOCOL=torch: every exchange through torch.distributed (gloo)
 
     torch.cuda.set_device(0)
     lgcp = outliers == "lgcp"
@@ -80,7 +80,7 @@ def main():
             with tempfile.TemporaryDirectory() as d:
                 mp.spawn(rank_main, args=(world, 29900 + (os.getpid() + rnd * 2 + int(stratified)) % 90, n, T, d, stratified, outliers), nprocs=world, join=True)
                 z = [np.load(os.path.join(d, f"r{r}.npz")) for r in range(world)]
-            ok = all(float(q["ll"]) == oll and int(q["ess"]) == int(oess[-1]) and int(q["peer"]) == 1 for q in z) and \
+            ok = all(float(q["ll"]) == oll and int(q["ess"]) == int(oess[-1]) and int(q["peer"]) == int(os.environ.get("SOAK_PROTOCOL", "peer") == "peer") for q in z) and \
                 np.array_equal(np.concatenate([q["part"] for q in z], axis=1), o.particles())
             if not ok:
                 print(f"   oracle ll {oll!r} ess {int(oess[-1])}; ranks: " + "; ".join(f"ll {float(q['ll'])!r} ess {int(q['ess'])} peer {int(q['peer'])}" for q in z) +
