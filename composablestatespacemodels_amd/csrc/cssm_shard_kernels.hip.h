@@ -369,8 +369,7 @@ __device__ __forceinline__ void boundary_pack_block(const uint32_t bx, const uin
         const unsigned int t = atomicAdd(&tickets[q], 1u);
         if (t + 1u == nblk) {
           tickets[q] = 0u;                              // (the next launch on this stream starts from zero)
-          __threadfence_system();
-          __hip_atomic_store(f + CSSM_PEER_FLAG_ROWS, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+          __hip_atomic_store(f + CSSM_PEER_FLAG_ROWS, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);   // (the release is the fence)
         }
       } else {
         unsigned int* tk = tickets + CSSM_PEER_TICKET_EXTRA;
@@ -387,8 +386,7 @@ __device__ __forceinline__ void boundary_pack_block(const uint32_t bx, const uin
             if (nn > eg) atomicAdd(&xn->stat[2], 1ull);
           }
           __hip_atomic_store(f + CSSM_PEER_FLAG_NEED, nn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-          __threadfence_system();
-          __hip_atomic_store(f + CSSM_PEER_FLAG_EXTRA, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+          __hip_atomic_store(f + CSSM_PEER_FLAG_EXTRA, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);   // (the release orders the count in front of it)
         }
       }
     }
@@ -495,12 +493,19 @@ __device__ __forceinline__ void boundary_pack_block(const uint32_t bx, const uin
     const uint32_t c0 = (uint32_t)(first / chunk), nc = bx / per;   // sub-units wholly before this tile
     // (the kernel is one latency chain after another at the sizes it runs at -- a capacity of a few thousand rows: what can be
     //  requested together is: up to 8 sums in flight, the rest in a loop)
-    cssm_u128 pre8[8];
+    if (nc <= 8u) {   // (uniform)
+      cssm_u128 pre8[8];
 #pragma unroll
-    for (int c = 0; c < 8; ++c) pre8[c] = ((uint32_t)c < nc) ? subS[c0 + (uint32_t)c] : cssm_u128_zero();
+      for (int c = 0; c < 8; ++c) pre8[c] = ((uint32_t)c < nc) ? subS[c0 + (uint32_t)c] : cssm_u128_zero();
 #pragma unroll
-    for (int c = 0; c < 8; ++c) toff = cssm_u128_add(toff, pre8[c]);
-    for (uint32_t c = 8; c < nc; ++c) toff = cssm_u128_add(toff, subS[c0 + c]);
+      for (int c = 0; c < 8; ++c) toff = cssm_u128_add(toff, pre8[c]);
+    } else {
+      // more of them -- the LAST tiles of a boundary block of thousands of rows, i.e. the eager rows for rank + 1, whose flag the
+      // neighbour's expansion blocks wait for: one sum per thread and a block total instead of a loop of dependent loads
+      cssm_u128 v = cssm_u128_zero();
+      for (uint32_t c = threadIdx.x; c < nc; c += CSSM_BLOCK) v = cssm_u128_add(v, subS[c0 + c]);
+      toff = block_total(v);
+    }
     t_begin = nc * per;
   }
   for (uint32_t t = t_begin; t < bx; ++t) {
