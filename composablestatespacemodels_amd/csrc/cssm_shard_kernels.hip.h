@@ -293,6 +293,32 @@ __global__ void k_peer_verify(const double* __restrict__ win0, int world, uint32
 // exp(min(w - c, REF_BELOW)) -- or, with the level taken from the global max, exp(w - level) of the stored log-weights
 // peer != nullptr: the peer-written exchange -- `out` unused, segment rank -> q lands in peer->win[parity][q] + rank * seg,
 // tickets[q] counts the finished blocks of destination q (left at zero again by the block that takes the last ticket)
+// Four consecutive rows of a boundary block (one thread's) in 16-byte accesses: the states of particles p0 .. p0 + 3 (struct of arrays: two
+// loads per component), the rows (D states + the low word of the row's cumulative weight, 4 (D + 1) doubles in a row) and the four high
+// words.  The windows are fine-grained memory: every store is a transaction of its own on the way out, and 8 bytes at a time the 1024
+// rows of a tile took 4.5-5 us of the 11 between the launch's start and the eager rows' flag (tools/pack_stamps_local.py).  The caller
+// has checked that all three addresses are 16-byte aligned.
+template <int D>
+__device__ __forceinline__ void pack_rows4(const double* __restrict__ src, const size_t stride, const uint64_t p0, double* __restrict__ orow,
+                                           double* __restrict__ ohi, const cssm_u128 (&P)[4]) {
+  constexpr int R = D + 1;
+  double out[4 * R];
+#pragma unroll
+  for (int k = 0; k < D; ++k) {
+    const double2* s2 = reinterpret_cast<const double2*>(src + (size_t)k * stride + (size_t)p0);
+    const double2 a = s2[0], b = s2[1];
+    out[0 * R + k] = a.x; out[1 * R + k] = a.y; out[2 * R + k] = b.x; out[3 * R + k] = b.y;
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) out[r * R + D] = cssm_u2d(P[r].lo);
+  double2* o2 = reinterpret_cast<double2*>(orow);
+#pragma unroll
+  for (int j = 0; j < 2 * R; ++j) o2[j] = make_double2(out[2 * j], out[2 * j + 1]);
+  double2* h2 = reinterpret_cast<double2*>(ohi);
+  h2[0] = make_double2(cssm_u2d(P[0].hi), cssm_u2d(P[1].hi));
+  h2[1] = make_double2(cssm_u2d(P[2].hi), cssm_u2d(P[3].hi));
+}
+
 template <int RSC = -1>   // the resampler, where the launch knows it at compile time (else PackNeed::rs)
 __device__ __forceinline__ void boundary_pack_block(const uint32_t bx, const uint32_t gx, const int q,
                                                               const double* __restrict__ src, size_t stride, const double* __restrict__ logw,
@@ -360,8 +386,12 @@ __device__ __forceinline__ void boundary_pack_block(const uint32_t bx, const uin
   // sets the EXTRA flag
   auto rows_done = [&](const bool extra) {
     if (peer == nullptr) return;
-    __threadfence_system();
+    // every wave waits for its stores to have left it, the block meets, and ONE wave fences at system scope (a fence is a write-back of
+    // the XCD's L2: four waves each issuing their own stood 1.7-2.4 us between the last row and the ticket, tools/pack_stamps_local.py)
+    __builtin_amdgcn_s_waitcnt(0);
     __syncthreads();
+    if (threadIdx.x == 0) __threadfence_system();
+    if (!extra) CSSM_SPEC_STAMP(7);
     if (threadIdx.x == 0) {
       unsigned int* f = peer->flag[parity][q] + (size_t)rank * CSSM_PEER_FLAG_STRIDE;
       const unsigned int nblk = gx - 2u;                // (the row blocks of this destination)
@@ -369,7 +399,10 @@ __device__ __forceinline__ void boundary_pack_block(const uint32_t bx, const uin
         const unsigned int t = atomicAdd(&tickets[q], 1u);
         if (t + 1u == nblk) {
           tickets[q] = 0u;                              // (the next launch on this stream starts from zero)
-          __hip_atomic_store(f + CSSM_PEER_FLAG_ROWS, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);   // (the release is the fence)
+          // (every block fenced in front of its ticket, this one included, and the ticket's return is behind all of them: the flag needs
+          //  no release of its own -- a second write-back of this XCD's L2 on the way out)
+          __hip_atomic_store(f + CSSM_PEER_FLAG_ROWS, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+          CSSM_SPEC_STAMP(3);   // (diagnostic build: a pack block that set a destination's ROWS flag -- tools/pack_stamps_local.py)
         }
       } else {
         unsigned int* tk = tickets + CSSM_PEER_TICKET_EXTRA;
@@ -386,7 +419,8 @@ __device__ __forceinline__ void boundary_pack_block(const uint32_t bx, const uin
             if (nn > eg) atomicAdd(&xn->stat[2], 1ull);
           }
           __hip_atomic_store(f + CSSM_PEER_FLAG_NEED, nn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-          __hip_atomic_store(f + CSSM_PEER_FLAG_EXTRA, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);   // (the release orders the count in front of it)
+          __builtin_amdgcn_s_waitcnt(0);                // (the count has arrived before the flag leaves; the rows: fenced in front of the tickets)
+          __hip_atomic_store(f + CSSM_PEER_FLAG_EXTRA, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         }
       }
     }
@@ -454,6 +488,7 @@ __device__ __forceinline__ void boundary_pack_block(const uint32_t bx, const uin
   if (held) return;
   if (threadIdx.x == 0) s_need = 0u;
   if (cnt == 0) return;   // (not a neighbour: no rows, and nobody waits for a rows flag of this segment)
+  CSSM_SPEC_STAMP(0);
   // this tile's rows [base, tile_end) of the block; the eager rows are [e_lo, e_hi): the block's last E for rank + 1, its first E for rank - 1
   const uint64_t base = (uint64_t)bx * CSSM_TILE;
   const long long E = (eager < cnt) ? (eager > 0 ? eager : 0) : cnt;
@@ -539,6 +574,30 @@ __device__ __forceinline__ void boundary_pack_block(const uint32_t bx, const uin
     const double* lw = logw;
     asm volatile("" : "+v"(lw));
     cssm_u128 run = run0;
+    static_assert(CSSM_ITEMS == 4, "pack_rows4: a thread's four rows");
+    if ((long long)i0 >= lo && (long long)i0 + CSSM_ITEMS <= hi && (long long)i0 + CSSM_ITEMS <= cnt && d >= 1 && d <= 4) {
+      // all four rows travel: 16-byte loads and stores where the addresses allow (else the row-by-row path below)
+      double* orow = oseg + HD + (long long)i0 * R;
+      double* ohi = oseg + HD + cap * R + (long long)i0;
+      const uint64_t p0 = first + i0;
+      if ((((uintptr_t)orow | (uintptr_t)ohi | (uintptr_t)(src + p0) | (uintptr_t)(logw + p0) | (uintptr_t)(stride * sizeof(double))) & 15u) == 0u) {
+        if (pstart && (long long)i0 == lo && i0 > 0) {
+          unsigned long long* ps = reinterpret_cast<unsigned long long*>(peer->flag[parity][q] + (size_t)rank * CSSM_PEER_FLAG_STRIDE + CSSM_PEER_FLAG_PSTART);
+          ps[0] = run.lo; ps[1] = run.hi;
+        }
+        const double2* w2 = reinterpret_cast<const double2*>(lw + p0);
+        const double2 wa = w2[0], wb = w2[1];
+        const double wv[4] = {wa.x, wa.y, wb.x, wb.y};
+        cssm_u128 P[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { run = cssm_u128_add(run, cssm_fix_from_unit(level_from_max ? cssm_exp_le0(wv[r] - cref) : wv[r])); P[r] = run; }
+        if (d == 3) pack_rows4<3>(src, stride, p0, orow, ohi, P);
+        else if (d == 1) pack_rows4<1>(src, stride, p0, orow, ohi, P);
+        else if (d == 2) pack_rows4<2>(src, stride, p0, orow, ohi, P);
+        else pack_rows4<4>(src, stride, p0, orow, ohi, P);
+        return;
+      }
+    }
 #pragma unroll
     for (int r = 0; r < CSSM_ITEMS; ++r) {
       const long long i = (long long)i0 + r;
@@ -558,7 +617,9 @@ __device__ __forceinline__ void boundary_pack_block(const uint32_t bx, const uin
     }
   };
   if (do_a) {
+    if (work_a) CSSM_SPEC_STAMP(1);
     if (work_a && (long long)i0 < e_hi && (long long)i0 + CSSM_ITEMS > e_lo) write_rows(e_lo, e_hi, peer != nullptr && q > rank);
+    if (work_a) CSSM_SPEC_STAMP(2);
     rows_done(false);
   }
   if (do_b) {
