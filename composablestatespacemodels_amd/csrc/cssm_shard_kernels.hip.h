@@ -979,24 +979,32 @@ __device__ __forceinline__ void expand_spec_body(SpecHeaders& H, uint32_t bid, u
         else { s = rank + 1; i = n_hi + idx; }
         const double* h = recv + (size_t)s * seg;
         const cssm_u128 off = cssm_u128_add(H.off[s], H.base[s]);
-        cssm_u128 P; P.lo = cssm_d2u(ld_sys_f64(h + HD + i * R + d)); P.hi = cssm_d2u(ld_sys_f64(h + HD + cap * R + i));
+        // the row's cumulative weight AND the one in front of it are requested together -- system-scope loads, a round trip each if one
+        // waited for the other (the exact counts behind them are chains of their own): the words in front of row i come from row i - 1, or,
+        // for the first eager row of rank - 1, from the words that travelled with the rows (PSTART); none for a block's first row and for
+        // the first of the rows beyond the eager ones (its run starts at or below this rank's first slot)
+        const bool first_eager = which == 0 && s < rank && idx == 0 && i != 0;
+        const bool no_prev = i == 0 || (which == 1 && idx == 0);
+        const unsigned long long* ps = reinterpret_cast<const unsigned long long*>(peer_flags + (size_t)(first_eager ? s : 0) * CSSM_PEER_FLAG_STRIDE + CSSM_PEER_FLAG_PSTART);
+        const long long ip = (no_prev || first_eager) ? i : i - 1;     // (a row that is there, where none is needed)
+        cssm_u128 P, Pp;
+        P.lo = cssm_d2u(ld_sys_f64(h + HD + i * R + d)); P.hi = cssm_d2u(ld_sys_f64(h + HD + cap * R + i));
+        if (first_eager) {
+          Pp.lo = __hip_atomic_load(ps, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); Pp.hi = __hip_atomic_load(ps + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        } else {
+          Pp.lo = cssm_d2u(ld_sys_f64(h + HD + ip * R + d)); Pp.hi = cssm_d2u(ld_sys_f64(h + HD + cap * R + ip));
+        }
         uint64_t e = count_of(cssm_u128_add(off, P));
         uint64_t b;
         if (i == 0) {
           b = count_of(off);
-        } else if (which == 0 && s < rank && idx == 0) {
-          // the first eager row: the cumulative weight in front of it came with the rows (PSTART).  A run that starts beyond this rank's
-          // first slot: rows in front of the eager ones own slots of this rank -- the sender writes them behind the headers (EXTRA)
-          const unsigned long long* ps = reinterpret_cast<const unsigned long long*>(peer_flags + (size_t)s * CSSM_PEER_FLAG_STRIDE + CSSM_PEER_FLAG_PSTART);
-          cssm_u128 Pp;
-          Pp.lo = __hip_atomic_load(ps, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); Pp.hi = __hip_atomic_load(ps + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-          b = count_of(cssm_u128_add(off, Pp));
-          if (b > slot_lo) atomicOr(&s_unc, 1u);
         } else if (which == 1 && idx == 0) {
           b = slot_lo;   // (the row before the first needed one was not written: its run ends at or below this rank's first slot)
         } else {
-          cssm_u128 Pp; Pp.lo = cssm_d2u(ld_sys_f64(h + HD + (i - 1) * R + d)); Pp.hi = cssm_d2u(ld_sys_f64(h + HD + cap * R + (i - 1)));
           b = count_of(cssm_u128_add(off, Pp));
+          // the first eager row's run starts beyond this rank's first slot: rows in front of the eager ones own slots of this rank -- the
+          // sender writes them behind the headers (EXTRA)
+          if (first_eager && b > slot_lo) atomicOr(&s_unc, 1u);
         }
         // the last eager row of rank + 1 ends below this rank's last slot and the block has more rows: they are on their way (EXTRA)
         if (which == 0 && s > rank && i == n_hi - 1 && n_hi < cnt_hi && e < slot_hi) atomicOr(&s_unc, 2u);
