@@ -332,6 +332,7 @@ __device__ __forceinline__ void boundary_pack_block(const uint32_t bx, const uin
                                                               const int grp_set, const PackNeed& xnr, const bool need_on, const int phase, const bool merged = false) {
   // merged: this block runs in the merged launch (k_exchange_offspring), next to the offspring blocks that consume what it reads
   const PackNeed* xn = &xnr;
+  if (bx == gx - 2) CSSM_SPEC_STAMP(0);   // (diagnostic build: the header block's first instruction)
   // need_on (peer-written exchange; xn.eager < cap): the eager rows travel at once, of the others those the neighbours need, behind every
   // rank's header (PackNeed).  phase: bit 0 = the header and prefix blocks work, bit 1 = the row blocks write their eager rows, bit 2 = the
   // row blocks write needed rows beyond them -- shards of ONE process that share a stream launch bits 0 | 1 and bit 2 apart, every shard's
@@ -365,7 +366,9 @@ __device__ __forceinline__ void boundary_pack_block(const uint32_t bx, const uin
   // now -- by this launch.)  Tested where a block is about to store: at the head it was a round trip of its own.
   const uint32_t err_now = __hip_atomic_load(&sc->err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & (4u | 8u | 16u);
   const uint32_t fail_now = __hip_atomic_load(&sc->fail_step, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  const uint32_t held = (err_now != 0u && fail_now != 0xffffffffu && fail_now != rec->step) ? err_now : 0u;
+  // (asked where a block is about to store or to wait: the two loads are on their way from here, the wait for them is there -- asked here,
+  //  it stood a round trip in front of every other load of the block: 1.1 us, tools/pack_stamps_local.py)
+  auto held = [&]() -> bool { return err_now != 0u && fail_now != 0xffffffffu && fail_now != rec->step; };
   const long long R = d + 1, HD = spec_hdr(d), seg = spec_seg(d, cap);
   double* oseg = peer ? peer->win[parity][q] + (size_t)rank * seg : out + (size_t)q * seg;
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
@@ -467,7 +470,7 @@ __device__ __forceinline__ void boundary_pack_block(const uint32_t bx, const uin
     ex.hi = inc.hi - own.hi - (inc.lo < own.lo ? 1ull : 0ull); ex.lo = inc.lo - own.lo;
     for (int w = 0; w < wid; ++w) ex = cssm_u128_add(ex, s_p[w]);
     const uint32_t i0 = threadIdx.x * E;
-    if (held) return;
+    if (held()) return;
 #pragma unroll
     for (int k = 0; k < EMAX; ++k) if ((uint32_t)k < E && i0 + (uint32_t)k < nsub) pre_out[i0 + (uint32_t)k] = cssm_u128_add(ex, run[k]);
     if (pre_flag != nullptr) {   // (merged kernel: the offspring blocks of this very launch read them, behind this flag)
@@ -485,7 +488,6 @@ __device__ __forceinline__ void boundary_pack_block(const uint32_t bx, const uin
   // stage A (phase bit 1): the eager rows of this tile; stage B (bit 2): its needed rows beyond them, behind every rank's header
   const bool do_a = (phase & 2) != 0, do_b = (phase & 4) != 0;
   if (!do_a && !do_b) return;
-  if (held) return;
   if (threadIdx.x == 0) s_need = 0u;
   if (cnt == 0) return;   // (not a neighbour: no rows, and nobody waits for a rows flag of this segment)
   CSSM_SPEC_STAMP(0);
@@ -512,7 +514,7 @@ __device__ __forceinline__ void boundary_pack_block(const uint32_t bx, const uin
   };
   // (a tile without eager rows: the headers ahead of the tile's own loads, so that the header words and the tile's sums are not held in
   //  registers together)
-  if (work_b && !work_a && !wait_headers()) return;
+  if (work_b && !work_a) { if (held()) return; if (!wait_headers()) return; }
   cssm_u128 run0 = cssm_u128_zero(), tsum = cssm_u128_zero();   // exclusive prefix of the thread's first row inside the block; sum of its rows
   // the tile's own weights are requested FIRST (raw: log-weights or stored weights), ahead of the loads and barriers of the prefix of the
   // tiles before it -- one round trip instead of two on the way to the eager rows' flag.  (Stage A writing its rows from these instead
@@ -626,6 +628,7 @@ __device__ __forceinline__ void boundary_pack_block(const uint32_t bx, const uin
       }
     }
   };
+  if (held()) return;   // (on hold when the launch began: no rows, no tickets -- every block of the launch alike)
   if (do_a) {
     if (work_a) CSSM_SPEC_STAMP(1);
     if (work_a && (long long)i0 < e_hi && (long long)i0 + CSSM_ITEMS > e_lo) write_rows(e_lo, e_hi, peer != nullptr && q > rank);
@@ -721,6 +724,7 @@ __device__ __forceinline__ void boundary_pack_block(const uint32_t bx, const uin
         if (lane == 0) s_pt[which] = c;
       }
       __syncthreads();
+      CSSM_SPEC_STAMP(1);
       key = s_hkey;
       ptot[0].lo = s_pt[0].lo; ptot[0].hi = s_pt[0].hi; ptot[1].lo = s_pt[1].lo; ptot[1].hi = s_pt[1].hi;
     } else {
@@ -784,7 +788,7 @@ __device__ __forceinline__ void boundary_pack_block(const uint32_t bx, const uin
   }
     }
   }
-  if (held) return;
+  if (held()) return;
   __shared__ unsigned long long s_hw[12];
   if (threadIdx.x == 0) {
     cssm_u128 S = s_r[0][0], S2 = s_r[1][0];
@@ -806,6 +810,7 @@ __device__ __forceinline__ void boundary_pack_block(const uint32_t bx, const uin
     unsigned long long* ll = reinterpret_cast<unsigned long long*>(peer->flag[parity][q] + (size_t)rank * CSSM_PEER_FLAG_STRIDE + CSSM_PEER_FLAG_LL);
     __hip_atomic_store(ll + threadIdx.x, ((unsigned long long)seq << 32) | half, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   }
+  CSSM_SPEC_STAMP(2);
   if (threadIdx.x == 0) {
 #pragma unroll
     for (int w = 0; w < 12; ++w) oseg[w] = cssm_u2d(s_hw[w]);

@@ -51,7 +51,7 @@ gx = -(-min(cap, per) // 1024) + 2
 hb = st[gx - 2]
 t0 = int(hb[4])
 print(f"world {world}, shard {mid} of {per} particles, capacity {cap} rows = {gx - 2} row blocks per destination; us after a header block's entry")
-print(f"  a header block: entered {0.0:5.2f}, header + flag out {(hb[5] - t0) * 0.01:5.2f}")
+print(f"  a header block: first instruction {(hb[0] - t0) * 0.01:5.2f}, entered {0.0:5.2f}, sums in LDS {(hb[1] - t0) * 0.01:5.2f}, header words stored {(hb[2] - t0) * 0.01:5.2f}, header + flag out {(hb[5] - t0) * 0.01:5.2f}")
 for bx in range(gx - 2):
     r = st[bx]
     if r[0] >= t0 - 100000:
