@@ -1161,6 +1161,8 @@ __device__ __forceinline__ void offspring_expand_spec_body(
     }
     return true;
   };
+  if (expander) __builtin_amdgcn_s_setprio(1);   // (few blocks with a chain of their own: ahead of the offspring blocks they share a CU with)
+  else if (bidx == 0) __builtin_amdgcn_s_setprio(2);   // (the block with the verdict and the publication on top of its unit)
   if (expander) {
     // an expansion block: every rank's header, the level test (block 0 of the offspring blocks records a ruled-out level; nobody expands
     // then), the neighbours' eager rows, its share of the rows.  (The coverage verdict stays the first offspring block's business: rows
