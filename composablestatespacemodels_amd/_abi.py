@@ -155,6 +155,7 @@ SYMBOLS = [
     ("cssm_pfb_chain", _h, [_h, C.c_int]),
     ("cssm_pfb_filter", C.c_int, [_h, C.POINTER(_descp), _u64p, _dp, _dp, _u8p, C.c_size_t, _dp, _dp, C.POINTER(C.c_int)]),
     ("cssm_pmmh_run_batched", C.c_int, [_h, _descp, _dp, C.c_size_t, C.c_double, _dp, _dp, _u8p, C.c_size_t, _u64p, C.c_size_t, _dp, _dp, _i32p, _dp]),
+    ("cssm_pmmh_run_speculative", C.c_int, [_h, _descp, _dp, C.c_size_t, C.c_double, _dp, _dp, _u8p, C.c_size_t, C.c_uint64, C.c_size_t, _dp, _dp, _i32p, _dp]),
     ("cssm_diag_copy_ceiling", C.c_int, [C.c_int, C.c_size_t, C.c_int, _dp]),
     ("cssm_contract_eval", C.c_int, [C.c_int, C.c_int, _dp, C.c_size_t, _dp, C.c_size_t]),
     ("cssm_desc_flatten", C.c_int, [_descp, _dp, C.c_size_t, C.POINTER(C.c_size_t)]),

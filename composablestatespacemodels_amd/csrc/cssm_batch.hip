@@ -321,3 +321,63 @@ extern "C" int cssm_pmmh_run_batched(cssm_pfb* b, const cssm_model_desc* desc, c
   for (cssm_pmmh_chain* c : chains) cssm_pmmh_chain_destroy(c);
   return rc;
 }
+
+// ONE chain, two iterations per batch of three filters.  The chain is sequential -- iteration i + 1 proposes from whatever iteration i
+// leaves -- but it leaves one of two things: its proposal (accepted) or the parameters it started from (rejected).  Proposals and filter
+// keys are functions of (seed, iteration, parameters) alone (counter-based streams: cssm_pmmh_chain_propose), so BOTH candidates for
+// iteration i + 1 can be drawn and filtered before iteration i has decided: slot 0 filters iteration i's proposal, slot 1 iteration i + 1's
+// proposal from it, slot 2 iteration i + 1's proposal from the current parameters -- one batch, at N = 100 000 for little more than the
+// price of one filter (a single filter leaves most of the GPU idle) -- and the two decisions follow, the second on slot 1 or 2.  Output
+// identical to cssm_pmmh_run(seed), bit for bit; b holds at least three chains (further ones idle).  model/PMMH.scala:68-81,114-123.
+extern "C" int cssm_pmmh_run_speculative(cssm_pfb* b, const cssm_model_desc* desc, const double* theta0, size_t n_theta, double delta, const double* t,
+                                         const double* y, const uint8_t* has, size_t T, uint64_t seed, size_t n_iters, double* ll, double* theta,
+                                         int32_t* accepted, double* last_state) {
+  if (!b || !desc || !theta0 || !ll || !theta || !accepted || !last_state) return fail(CSSM_EINVAL_ARG, "null argument");
+  const int B = b->B, d = b->ch[0]->d;
+  if (B < 3) return fail(CSSM_EINVAL_ARG, "the speculative chain filters three candidates per batch: a batch of %d chains", B);
+  // the chain itself (L) and one proposer per slot; all under the chain's seed -- the proposal of iteration `it` from parameters p is the
+  // same numbers whoever draws it
+  cssm_pmmh_chain* L = nullptr;
+  std::vector<cssm_pmmh_chain*> slot((size_t)B, nullptr);
+  std::vector<const cssm_model_desc*> descs((size_t)B);
+  std::vector<uint64_t> keys((size_t)B);
+  std::vector<double> pll((size_t)B), paths((size_t)B * (T + 1) * d);
+  std::vector<int> rcs((size_t)B);
+  int rc = cssm_pmmh_chain_create(desc, theta0, n_theta, delta, seed, d, &L);
+  for (int k = 0; k < B && !rc; ++k) rc = cssm_pmmh_chain_create(desc, theta0, n_theta, delta, seed, d, &slot[(size_t)k]);
+  auto used = [&](int k, double* pl) -> int {   // the slot's likelihood as the sequential driver would have seen it
+    *pl = pll[(size_t)k];
+    if (rcs[(size_t)k] == CSSM_ENONFINITE) { *pl = -cssm_inf(); return CSSM_OK; }   // a proposal the filter cannot weigh is rejected
+    return rcs[(size_t)k];
+  };
+  for (size_t it = 0; it < n_iters && !rc; it += 2) {
+    const bool two = it + 1 < n_iters;
+    cssm_pmmh_chain_set_current(slot[0], cssm_pmmh_chain_current(L));
+    descs[0] = cssm_pmmh_chain_propose(slot[0], it, &keys[0]);
+    for (int k = 1; k < B; ++k) {
+      // slot 1: iteration it + 1 from iteration it's proposal (it is accepted); slot 2: from the current parameters (it is rejected);
+      // an odd last iteration and further slots: iteration it's proposal again
+      const bool next = two && k <= 2;
+      cssm_pmmh_chain_set_current(slot[(size_t)k], (next && k == 1) ? cssm_pmmh_chain_proposal(slot[0]) : cssm_pmmh_chain_current(L));
+      descs[(size_t)k] = cssm_pmmh_chain_propose(slot[(size_t)k], next ? it + 1 : it, &keys[(size_t)k]);
+    }
+    rc = cssm_pfb_filter(b, descs.data(), keys.data(), t, y, has, T, pll.data(), paths.data(), rcs.data());
+    if (rc) break;
+    double pl = 0.0;
+    rc = used(0, &pl);
+    if (rc) break;
+    const int32_t before = cssm_pmmh_chain_accepted(L);
+    cssm_pmmh_chain_set_proposal(L, cssm_pmmh_chain_proposal(slot[0]));
+    cssm_pmmh_chain_decide(L, it, pl, paths.data() + ((size_t)0 * (T + 1) + T) * d, &ll[it], theta + it * n_theta, &accepted[it], last_state + it * (size_t)d);
+    if (!two) break;
+    const int k = (cssm_pmmh_chain_accepted(L) > before) ? 1 : 2;
+    rc = used(k, &pl);
+    if (rc) break;
+    cssm_pmmh_chain_set_proposal(L, cssm_pmmh_chain_proposal(slot[(size_t)k]));
+    cssm_pmmh_chain_decide(L, it + 1, pl, paths.data() + ((size_t)k * (T + 1) + T) * d, &ll[it + 1], theta + (it + 1) * n_theta, &accepted[it + 1],
+                           last_state + (it + 1) * (size_t)d);
+  }
+  cssm_pmmh_chain_destroy(L);
+  for (cssm_pmmh_chain* c : slot) cssm_pmmh_chain_destroy(c);
+  return rc;
+}

@@ -334,6 +334,11 @@ int cssm_pmmh_chain_create(const cssm_model_desc* desc, const double* theta0, si
   return CSSM_OK;
 }
 void cssm_pmmh_chain_destroy(cssm_pmmh_chain* c) { delete c; }
+void cssm_pmmh_chain_set_current(cssm_pmmh_chain* c, const double* theta) { c->cur.assign(theta, theta + c->n_theta); }
+void cssm_pmmh_chain_set_proposal(cssm_pmmh_chain* c, const double* theta) { c->prop.assign(theta, theta + c->n_theta); }
+const double* cssm_pmmh_chain_current(const cssm_pmmh_chain* c) { return c->cur.data(); }
+const double* cssm_pmmh_chain_proposal(const cssm_pmmh_chain* c) { return c->prop.data(); }
+int32_t cssm_pmmh_chain_accepted(const cssm_pmmh_chain* c) { return c->acc; }
 // propParams <- proposal(s.params) of iteration `it`: the descriptor to filter under, and the filter's Philox key
 const cssm_model_desc* cssm_pmmh_chain_propose(cssm_pmmh_chain* c, size_t it, uint64_t* key_out) {
   for (size_t j = 0; j < c->n_theta; j += 2) {

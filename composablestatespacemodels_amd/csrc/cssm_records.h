@@ -88,6 +88,12 @@ void cssm_pmmh_chain_destroy(cssm_pmmh_chain* c);
 const cssm_model_desc* cssm_pmmh_chain_propose(cssm_pmmh_chain* c, size_t it, uint64_t* key_out);
 void cssm_pmmh_chain_decide(cssm_pmmh_chain* c, size_t it, double pll, const double* last_path_row, double* ll_out, double* theta_out, int32_t* acc_out,
                             double* state_out);
+// (the speculative driver, cssm_pmmh_run_speculative: proposals from a given parameter vector, the decision on a given proposal)
+void cssm_pmmh_chain_set_current(cssm_pmmh_chain* c, const double* theta);
+void cssm_pmmh_chain_set_proposal(cssm_pmmh_chain* c, const double* theta);
+const double* cssm_pmmh_chain_current(const cssm_pmmh_chain* c);
+const double* cssm_pmmh_chain_proposal(const cssm_pmmh_chain* c);
+int32_t cssm_pmmh_chain_accepted(const cssm_pmmh_chain* c);
 int cssm_fail(int code, const char* fmt, ...);   // sets the thread-local message of cssm_last_error(), returns code
 // Validate and translate a descriptor; `update`: re-parameterise -- the STRUCTURE must be the one `m` already has.
 int cssm_build_model(HostModel* m, const cssm_model_desc* desc, bool update);

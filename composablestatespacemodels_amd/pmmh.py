@@ -189,3 +189,28 @@ def pmmh_native_batched(unparam: UnparamModel, inits: Sequence[Parameters], data
         lib.cssm_pfb_destroy(hb)
     return ll, th, acc, last
 
+
+def pmmh_native_speculative(unparam: UnparamModel, init: Parameters, data, n: int, delta: float, iters: int,
+                            seed: int = 20260101, device: int = 0):
+    """``pmmh_native`` -- the same chain, bit for bit -- at two iterations per batch of three filters (``cssm_pmmh_run_speculative``):
+    iteration i's proposal and both candidates for iteration i + 1 (proposed from it, and from the current parameters) are filtered
+    together; the proposals and filter keys are functions of (seed, iteration, parameters) alone.  For clouds that leave the GPU
+    mostly idle (BASELINE configs[4]: N = 100 000).  Returns (ll[iters], theta[iters, n_theta], accepted[iters], last_state[iters, d])."""
+    t, y, h = split_data(data)
+    model = unparam.run(init)
+    desc = model.descriptor()
+    lib = _abi.load_library()
+    hb = C.c_void_p()
+    _abi.check(lib.cssm_pfb_create(desc.ptr(), int(n), 3, int(device), C.byref(hb)))
+    try:
+        d = int(lib.cssm_pf_dim(lib.cssm_pfb_chain(hb, 0)))
+        theta0 = np.ascontiguousarray(init.flattenParams(), dtype=np.float64)
+        nt = theta0.size
+        ll = np.zeros(iters); th = np.zeros((iters, nt)); acc = np.zeros(iters, dtype=np.int32); last = np.zeros((iters, d))
+        dp = C.POINTER(C.c_double)
+        _abi.check(lib.cssm_pmmh_run_speculative(hb, desc.ptr(), theta0.ctypes.data_as(dp), nt, float(delta), t.ctypes.data_as(dp), y.ctypes.data_as(dp),
+                                                 h.ctypes.data_as(C.POINTER(C.c_uint8)), len(t), int(seed) & (2**64 - 1), int(iters),
+                                                 ll.ctypes.data_as(dp), th.ctypes.data_as(dp), acc.ctypes.data_as(C.POINTER(C.c_int32)), last.ctypes.data_as(dp)))
+    finally:
+        lib.cssm_pfb_destroy(hb)
+    return ll, th, acc, last

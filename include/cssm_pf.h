@@ -616,6 +616,14 @@ int cssm_pfb_filter(cssm_pfb* b, const cssm_model_desc* const* descs, const uint
 int cssm_pmmh_run_batched(cssm_pfb* b, const cssm_model_desc* desc, const double* theta0, size_t n_theta, double delta, const double* t,
                           const double* y, const uint8_t* has_obs, size_t T, const uint64_t* seeds, size_t n_iters, double* ll, double* theta,
                           int32_t* accepted, double* last_state);
+/* (round 5) ONE chain at two iterations per batch: a batch of three filters holds iteration i's proposal and BOTH candidates for iteration
+ * i + 1 (its proposal from iteration i's proposal, and from the current parameters): the proposals and filter keys are functions of
+ * (seed, iteration, parameters) alone, so they can be drawn and filtered before iteration i has decided.  Output identical to
+ * cssm_pmmh_run(seed), bit for bit; `b` holds at least three chains.  At N = 100 000 a single filter leaves most of the GPU idle: three
+ * cost little more than one (model/PMMH.scala:68-81). */
+int cssm_pmmh_run_speculative(cssm_pfb* b, const cssm_model_desc* desc, const double* theta0, size_t n_theta, double delta, const double* t,
+                              const double* y, const uint8_t* has_obs, size_t T, uint64_t seed, size_t n_iters, double* ll, double* theta,
+                              int32_t* accepted, double* last_state);
 
 /* Number of stored parameters of a descriptor and their copy-out / copy-in in flatten order. */
 int cssm_desc_flatten(const cssm_model_desc* desc, double* theta, size_t cap, size_t* n_theta);

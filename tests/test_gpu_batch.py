@@ -114,3 +114,21 @@ def test_batched_pmmh_equals_the_chains_run_one_by_one():
         l1, t1, a1, s1 = pmmh_native(um, inits[k], data, n, 0.01, iters, seed=seeds[k])
         np.testing.assert_array_equal(ll[k], l1); np.testing.assert_array_equal(th[k], t1)
         np.testing.assert_array_equal(acc[k], a1); np.testing.assert_array_equal(last[k], s1)
+
+
+@pytest.mark.parametrize("iters,delta", [(9, 0.01), (12, 0.25), (1, 0.01)])
+def test_speculative_pmmh_is_the_sequential_chain(iters, delta):
+    """cssm_pmmh_run_speculative == cssm_pmmh_run: iteration i's proposal and both candidates for iteration i + 1 are filtered as one
+    batch of three, the decisions follow -- the chain (log-likelihoods, parameters, acceptance counts, sampled states) bit for bit; an odd
+    number of iterations, a single one, and a step size large enough that proposals are rejected wholesale (and some cannot be weighed)."""
+    from composablestatespacemodels_amd.model import TimedObservation
+    from composablestatespacemodels_amd.pmmh import pmmh_native, pmmh_native_speculative
+    um, init = cases.c2_unparam(), cases.c2_params()
+    T, n = 30, 6000
+    t, y, has = cases.poisson_counts(T, missing=0.1)
+    data = [TimedObservation(float(a), float(v) if h else None) for a, v, h in zip(t, y, has)]
+    ref = pmmh_native(um, init, data, n, delta, iters, seed=20260105)
+    got = pmmh_native_speculative(um, init, data, n, delta, iters, seed=20260105)
+    for a, b in zip(got, ref):
+        np.testing.assert_array_equal(a, b)
+    assert 0 < ref[2][-1] or iters == 1 or delta > 0.1      # (the small-step chains accept something: both branches are exercised)
