@@ -53,7 +53,14 @@ for n in (100000, 131072):
     pmmh_native(cases.c2_unparam(), cases.c2_params(), data, n, 0.05, 2, seed=7)   # (untimed: the first call of a process loads the code objects)
     t0 = time.perf_counter(); ll, th, acc, last = pmmh_native(cases.c2_unparam(), cases.c2_params(), data, n, 0.05, 20, seed=7)
     dt = time.perf_counter() - t0
+    # ... and the same chain at two iterations per batch of three filters (cssm_pmmh_run_speculative: identical output)
+    from composablestatespacemodels_amd.pmmh import pmmh_native_speculative
+    pmmh_native_speculative(cases.c2_unparam(), cases.c2_params(), data, n, 0.05, 2, seed=7)
+    t0 = time.perf_counter(); sp = pmmh_native_speculative(cases.c2_unparam(), cases.c2_params(), data, n, 0.05, 20, seed=7)
+    ds = time.perf_counter() - t0
     row = {"config": f"C5 PMMH seasonal model N={n} T=500", "iters_run": 20, "s_per_iter": dt / 20, "projected_10k_iters_s": dt / 20 * 10000,
-           "particle_steps_per_s": n * 500 * 20 / dt, "accepted": int(acc[-1]), "ll_last": float(ll[-1])}
+           "particle_steps_per_s": n * 500 * 20 / dt, "accepted": int(acc[-1]), "ll_last": float(ll[-1]),
+           "speculative_s_per_iter": ds / 20, "speculative_projected_10k_iters_s": ds / 20 * 10000,
+           "speculative_identical": bool(all(np.array_equal(a, b) for a, b in zip(sp, (ll, th, acc, last))))}
     out.append(row); print(json.dumps(row), flush=True)
 json.dump(out, open(os.path.join(R, "gpurun_out", "configs.json"), "w"), indent=1)
