@@ -30,8 +30,9 @@ def build_case(c, seed):
             s = int(rng.integers(1, T)); y[s] = 70.0; has[s] = 1
     strat = (not lg) and rng.random() < 0.3
     a = int(rng.integers(2, T - 1))
+    path = rng.random() < 0.3          # `filter`: the whole series in one call, sampleOne's pick after every observation recorded
     env = {"CSSM_PEER_EAGER_ROWS": str(int(rng.choice([1, 8, 64, 4096]))), "CSSM_GRP_MIN_UNITS": str(int(rng.choice([1, 100000])))}
-    return dict(world=world, lg=lg, name=name, n=n, T=T, t=t, y=y, has=has, strat=strat, a=a, env=env)
+    return dict(world=world, lg=lg, name=name, n=n, T=T, t=t, y=y, has=has, strat=strat, a=a, env=env, path=path)
 
 
 def rank_main(rank, world, port, c, seed, outdir):
@@ -54,15 +55,20 @@ def rank_main(rank, world, port, c, seed, outdir):
         shard.set_option(2, 1)
     f = ShardedFilter([shard], GlooPeerComm())
     t, y, has, a, lg = k["t"], k["y"], k["has"], k["a"], k["lg"]
-    f.ll_filter(t[:a], y[:a], has[:a], lgcp=lg)
-    whole = 0
-    try:
-        ll, ess = f.ll_filter_more(t[a:], y[a:], has[a:], lgcp=lg)
-    except RuntimeError:               # (a continued series that would need another plan from its start: the whole series in one call)
-        whole = 1
-        ll, ess = f.ll_filter(t, y, has, lgcp=lg)
+    whole, path = 0, np.zeros(0)
+    if k["path"]:
+        whole = 2
+        ll, path = f.filter(t, y, has, lgcp=lg)
+        ess = -1
+    else:
+        f.ll_filter(t[:a], y[:a], has[:a], lgcp=lg)
+        try:
+            ll, ess = f.ll_filter_more(t[a:], y[a:], has[a:], lgcp=lg)
+        except RuntimeError:               # (a continued series that would need another plan from its start: the whole series in one call)
+            whole = 1
+            ll, ess = f.ll_filter(t, y, has, lgcp=lg)
     np.savez(os.path.join(outdir, f"r{rank}.npz"), ll=ll, ess=ess, part=shard.particles(), peer=int(f.last_peer), resumes=int(f.last_resumes),
-             redos=int(f.last_level_redos), whole=whole)
+             redos=int(f.last_level_redos), whole=whole, path=path)
     shard.close()
     dist.barrier()
     dist.destroy_process_group()
@@ -81,13 +87,14 @@ def main():
         model = getattr(cases, k["name"])()
         prec = 2 if k["lg"] else 0
         o = oracle.OraclePf(model.descriptor(prec), k["n"], cases.SEED, oracle.RESAMPLE_STRATIFIED if k["strat"] else 0)
-        oll, _, oess, _ = o.filter(k["t"], k["y"], k["has"])
+        oll, _, oess, opath = o.filter(k["t"], k["y"], k["has"], want_path=k["path"])
         with tempfile.TemporaryDirectory() as d:
             try:
                 mp.spawn(rank_main, args=(k["world"], 29700 + (os.getpid() + c) % 90, c, seed, d), nprocs=k["world"], join=True)
                 z = [np.load(os.path.join(d, f"r{r}.npz")) for r in range(k["world"])]
-                ok = all(float(q["ll"]) == oll and int(q["ess"]) == int(oess[-1]) for q in z) and \
-                    np.array_equal(np.concatenate([q["part"] for q in z], axis=1), o.particles())
+                ok = all(float(q["ll"]) == oll and (k["path"] or int(q["ess"]) == int(oess[-1])) for q in z) and \
+                    np.array_equal(np.concatenate([q["part"] for q in z], axis=1), o.particles()) and \
+                    (not k["path"] or all(np.array_equal(q["path"], opath) for q in z))
                 info = f"peer={[int(q['peer']) for q in z]} resumes={int(z[0]['resumes'])} level redos={int(z[0]['redos'])} whole={int(z[0]['whole'])}"
             except Exception as e:      # noqa: BLE001 -- a rank that failed is the finding
                 ok, info = False, f"a rank failed: {str(e)[-300:]}"
