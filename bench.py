@@ -158,6 +158,11 @@ def _roofline(name, d, n, avg_s, cnt, raw_s, pair_s, copy_gbs, note=None):
 
 
 def run_single(args, emit=print):
+    # The host waits for the GPU by POLLING its completion signals, not by sleeping until an interrupt (a setting of the ROCm runtime for
+    # this process, read when it initialises): a short leg ends in a wait that an interrupt's wake-up lengthens by microseconds -- same-box
+    # A/B of --steps 20: 22.7-22.9 vs 22.9-23.6 us per step (tools/archive/ab_hsa_interrupt.py).  What a latency-minded host of the library
+    # would set; recorded in the line (`runtime`).  A value the caller exported wins.
+    os.environ.setdefault("HSA_ENABLE_INTERRUPT", "0")
     import torch  # first: its import takes long enough for the GPU clocks to idle down
     from composablestatespacemodels_amd.filter import NativePf
     K, W = args.steps, args.warmup
@@ -284,6 +289,7 @@ def run_single(args, emit=print):
         "roofline_generic": roof_generic,
         "kernels_us": kernels_us,
         "device_loop_ms": loop_ms, "ll": ll, "ess_last": int(ess_t[-1]),
+        "runtime": {"HSA_ENABLE_INTERRUPT": os.environ.get("HSA_ENABLE_INTERRUPT"), "note": "0 = the host polls the GPU's completion signals instead of sleeping until an interrupt"},
     }
     if lgcp:
         roof["note"] = ("an LGCP step runs its ~10 sub-steps of Philox + Box-Muller + exp per particle in registers: the kernel is compute-bound by "
