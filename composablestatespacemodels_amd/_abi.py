@@ -89,6 +89,8 @@ SYMBOLS = [
     ("cssm_pf_ll_filter_more", C.c_int, [_h, _dp, _dp, _u8p, C.c_size_t, _dp, _dp, _i32p]),
     ("cssm_pf_filter", C.c_int, [_h, _dp, _dp, _u8p, C.c_size_t, _dp, _dp, _i32p, _dp]),
     ("cssm_pf_last_loop_ms", C.c_int, [_h, C.POINTER(C.c_float)]),
+    ("cssm_pf_last_device_us", C.c_int, [_h, _dp]),
+    ("cssm_pf_stream_idle", C.c_int, [_h]),
     ("cssm_pf_set_option", C.c_int, [_h, C.c_int, C.c_int]),
     ("cssm_rtc_info", C.c_int, [_u64p]),
     ("cssm_pf_profile", C.c_int, [_h, C.c_int]),

@@ -98,6 +98,11 @@ struct Scalars {
   // clock (s_memrealtime): wall-clock time, not an iteration count -- a rank that compiles a kernel, a loaded host or a debugger may be
   // seconds late without being dead.  Set with the scalars (reset_scalars) from the handle's CSSM_PEER_TIMEOUT_MS (default 30 s).
   unsigned long long peer_wait_ticks;
+  // (measurement) the constant 100 MHz clock (s_memrealtime) when the first kernel of the running batch call started: the kernel that
+  // brings the call's first record(s) stamps it, k_finish hands it to the host next to its own stamp -- the DEVICE time of the call,
+  // first instruction to completion word, without an event packet on the queue (cssm_pf_last_device_us)
+  unsigned long long t_first;
+  unsigned long long t_last;    // k_finish's own stamp (valid in the host's mirror only)
 };
 
 // BATCHED independent filters (cssm_batch.hip: B clouds of one model structure -- the chains of a PMMH run, a pilot grid of

@@ -256,7 +256,10 @@ static __global__ __launch_bounds__(CSSM_BLOCK) void k_finish(Scalars* __restric
   constexpr uint32_t WE = (uint32_t)(offsetof(Scalars, ess) / 4), WP = (uint32_t)(offsetof(Scalars, pend) / 4);
   const uint32_t* src = reinterpret_cast<const uint32_t*>(sc);
   uint32_t* dst = reinterpret_cast<uint32_t*>(host_sc);
-  for (uint32_t w = W0 + threadIdx.x; w < W1; w += CSSM_BLOCK) dst[w] = (w == WE) ? (uint32_t)ess : ((w == WP) ? 0u : src[w]);
+  constexpr uint32_t WT = (uint32_t)(offsetof(Scalars, t_last) / 4);
+  const unsigned long long now = __builtin_amdgcn_s_memrealtime();   // (Scalars::t_last: with t_first the device time of the call)
+  for (uint32_t w = W0 + threadIdx.x; w < W1; w += CSSM_BLOCK)
+    dst[w] = (w == WE) ? (uint32_t)ess : ((w == WP) ? 0u : ((w == WT) ? (uint32_t)now : ((w == WT + 1u) ? (uint32_t)(now >> 32) : src[w])));
   // the call's completion word, behind everything above: the host polls it instead of waiting for the stream (read_scalars)
   if (host_done) {
     __threadfence_system();

@@ -294,33 +294,36 @@ static bool may_use_sums_kernel(const cssm_pf* pf) {
 // 14 KB copy cost 7-11 us of host time and left the queue idle for 9 us before the first propagate (rocprofv3 timeline of 20-step
 // legs: copy 0 .. 3, first kernel at 11.6 us); a launch costs 3.5 us of host time and the records' 89 words cross PCIe in one round trip.
 // CSSM_UPLOAD_MEMCPY=1 keeps the copy (A/B).
-__global__ __launch_bounds__(128) void k_fetch_recs(const StepRec* __restrict__ host, StepRec* __restrict__ dev) {
+__global__ __launch_bounds__(128) void k_fetch_recs(const StepRec* __restrict__ host, StepRec* __restrict__ dev, Scalars* __restrict__ sc) {
   static_assert(sizeof(StepRec) % 8 == 0, "records are copied in 8-byte words");
+  if (sc != nullptr && blockIdx.x == 0 && threadIdx.x == 0) sc->t_first = __builtin_amdgcn_s_memrealtime();   // (the call's first kernel: Scalars::t_first)
   const unsigned long long* s = reinterpret_cast<const unsigned long long*>(host + blockIdx.x);
   unsigned long long* d = reinterpret_cast<unsigned long long*>(dev + blockIdx.x);
   for (uint32_t i = threadIdx.x; i < sizeof(StepRec) / 8; i += 128) d[i] = s[i];
 }
 // ONE record (a streaming step; the first observation of a continued batch call): it travels in the kernel's ARGUMENTS -- no read
 // across PCIe at all (the argument segment lives in device memory), the block copies its own kernarg bytes to the record's slot
-__global__ __launch_bounds__(128) void k_put_rec(StepRec r, StepRec* __restrict__ dev) {
+__global__ __launch_bounds__(128) void k_put_rec(StepRec r, StepRec* __restrict__ dev, Scalars* __restrict__ sc) {
   static_assert(offsetof(StepRec, step) < sizeof(StepRec), "");
+  if (sc != nullptr && threadIdx.x == 0) sc->t_first = __builtin_amdgcn_s_memrealtime();   // (the call's first kernel: Scalars::t_first)
   const unsigned long long* s = (const unsigned long long*)__builtin_amdgcn_kernarg_segment_ptr();   // (r is the first argument: offset 0)
   unsigned long long* d = reinterpret_cast<unsigned long long*>(dev);
   if (threadIdx.x < sizeof(StepRec) / 8) d[threadIdx.x] = s[threadIdx.x];
   (void)r;
 }
 int cssm_upload_recs(cssm_pf* pf, size_t first, size_t count, bool chain) {
+  Scalars* stamp = first == 0 ? pf->sc : nullptr;   // (record 0 of a call travels with the call's first kernel)
   static const bool by_copy = getenv("CSSM_UPLOAD_MEMCPY") != nullptr;
   static const bool no_kernarg = getenv("CSSM_UPLOAD_NO_KERNARG") != nullptr;
   if (count == 0) return CSSM_OK;
   if (count == 1 && !by_copy && !no_kernarg) {
     static_assert(sizeof(StepRec) / 8 <= 128 && sizeof(StepRec) <= 3072, "one record fits a kernel's argument segment and one block copies it");
-    hipLaunchKernelGGL(k_put_rec, dim3(1), dim3(128), 0, pf->stream, pf->h_recs[first], pf->d_recs + first);
+    hipLaunchKernelGGL(k_put_rec, dim3(1), dim3(128), 0, pf->stream, pf->h_recs[first], pf->d_recs + first, stamp);
     HIP_TRY(hipGetLastError());
   } else if (by_copy || !pf->h_recs_dev || count > 0x7fffffffu) {
     HIP_TRY(hipMemcpyAsync(pf->d_recs + first, pf->h_recs + first, count * sizeof(StepRec), hipMemcpyHostToDevice, pf->stream));
   } else {
-    hipLaunchKernelGGL(k_fetch_recs, dim3((uint32_t)count), dim3(128), 0, pf->stream, (const StepRec*)(pf->h_recs_dev + first), pf->d_recs + first);
+    hipLaunchKernelGGL(k_fetch_recs, dim3((uint32_t)count), dim3(128), 0, pf->stream, (const StepRec*)(pf->h_recs_dev + first), pf->d_recs + first, stamp);
     HIP_TRY(hipGetLastError());
   }
   if (chain && pf->obs_kind == CSSM_OBS_LGCP) {
@@ -1021,6 +1024,24 @@ extern "C" int cssm_pf_last_loop_ms(cssm_pf* pf, float* ms_out) {
   }
   *ms_out = pf->last_ms;
   return CSSM_OK;
+}
+
+extern "C" int cssm_pf_last_device_us(cssm_pf* pf, double* us_out) {
+  if (!pf || !us_out) return fail(CSSM_EINVAL_ARG, "null argument");
+  if (!pf->h_sc) return fail(CSSM_ESTATE, "no call has run");
+  const unsigned long long a = pf->h_sc->t_first, b = pf->h_sc->t_last;
+  if (a == 0ull || b < a) return fail(CSSM_ESTATE, "the last call left no pair of device stamps (it drew a new cloud, or none has run)");
+  *us_out = (double)(b - a) * 1e-2;   // 100 MHz
+  return CSSM_OK;
+}
+
+extern "C" int cssm_pf_stream_idle(cssm_pf* pf) {
+  if (!pf) return fail(CSSM_EINVAL_ARG, "null handle");
+  if (hipSetDevice(pf->device) != hipSuccess) return fail(CSSM_EHIP, "hipSetDevice(%d)", pf->device);
+  const hipError_t q = hipStreamQuery(pf->stream);
+  if (q == hipSuccess) return 1;
+  if (q == hipErrorNotReady) { (void)hipGetLastError(); return 0; }
+  return fail(CSSM_EHIP, "hipStreamQuery: %s", hipGetErrorString(q));
 }
 
 extern "C" int cssm_pf_set_option(cssm_pf* pf, int option, int value) {

@@ -127,7 +127,7 @@ __device__ __forceinline__ bool peer_poll_ll(const unsigned long long* f, unsign
 // for nothing, so nobody waits in a circle), write only those rows, and the block that takes the last ticket publishes their number in the
 // word behind the rows flag (`need`: rows [cnt - need, cnt) of the block for rank + 1, rows [0, need) of the block for rank - 1) before it
 // sets the flag.  The reader expands exactly those.
-// ... and EAGER ROWS, so that none of this lies on the reader's critical path: the `eager` rows next to the boundary (one tile by default,
+// ... and EAGER ROWS, so that none of this lies on the reader's critical path: the `eager` rows next to the boundary (four tiles = 4096 rows by default,
 // CSSM_PEER_EAGER_ROWS; a typical observation needs a quarter of that) are written AT ONCE -- they need no header -- with a flag of their
 // own (ROWS), long set by the time the reader has resampled its own particles.  Only rows beyond them go the way described above, behind
 // a second flag (EXTRA), and the reader waits for that one only if the eager rows do not reach its first / last slot -- which it sees from
@@ -402,9 +402,12 @@ __device__ __forceinline__ void boundary_pack_block(const uint32_t bx, const uin
         const unsigned int t = atomicAdd(&tickets[q], 1u);
         if (t + 1u == nblk) {
           tickets[q] = 0u;                              // (the next launch on this stream starts from zero)
-          // (every block fenced in front of its ticket, this one included, and the ticket's return is behind all of them: the flag needs
-          //  no release of its own -- a second write-back of this XCD's L2 on the way out)
-          __hip_atomic_store(f + CSSM_PEER_FLAG_ROWS, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+          // (every block fenced in front of its ticket, this one included, and the ticket's return is behind all of them; the flag is a
+          //  RELEASE store all the same -- round 5 stored it relaxed and saved this block a second write-back of its XCD's L2 (~0.8 us
+          //  on a flag that is long set when its reader gets to it), but the tickets are relaxed device-scope atomics and the order
+          //  "every block's rows, then the flag" across a link has never run on two physical GPUs: the memory model's guarantee, not
+          //  an argument about when stores are acknowledged, is what a reader on another GPU gets)
+          __hip_atomic_store(f + CSSM_PEER_FLAG_ROWS, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
           CSSM_SPEC_STAMP(3);   // (diagnostic build: a pack block that set a destination's ROWS flag -- tools/pack_stamps_local.py)
         }
       } else {
@@ -423,7 +426,7 @@ __device__ __forceinline__ void boundary_pack_block(const uint32_t bx, const uin
           }
           __hip_atomic_store(f + CSSM_PEER_FLAG_NEED, nn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
           __builtin_amdgcn_s_waitcnt(0);                // (the count has arrived before the flag leaves; the rows: fenced in front of the tickets)
-          __hip_atomic_store(f + CSSM_PEER_FLAG_EXTRA, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+          __hip_atomic_store(f + CSSM_PEER_FLAG_EXTRA, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);   // (release: as the ROWS flag)
         }
       }
     }

@@ -157,6 +157,20 @@ class NativePf:
         _abi.check(self.lib.cssm_pf_last_loop_ms(self._h, C.byref(ms)))
         return ms.value
 
+    def last_device_us(self) -> float:
+        """Device time of the last continued batch call, first instruction of its first kernel to its closing kernel's results, from the GPU's
+        constant clock (cssm_pf_last_device_us: no event packets on the queue)."""
+        us = C.c_double()
+        _abi.check(self.lib.cssm_pf_last_device_us(self._h, C.byref(us)))
+        return us.value
+
+    def stream_idle(self) -> bool:
+        """Whether the runtime sees nothing queued or running on the handle's stream (cssm_pf_stream_idle; raises on a HIP error)."""
+        r = self.lib.cssm_pf_stream_idle(self._h)
+        if r < 0:
+            _abi.check(r)
+        return r == 1
+
     KERNELS = ("k_propagate", "k_tile_sums", "k_offspring", "k_reduce_units", "k_boundary_pack", "k_offspring_expand_spec", "collective")
 
     def set_option(self, option: int, value: int):

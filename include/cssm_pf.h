@@ -203,6 +203,19 @@ int cssm_pf_filter(cssm_pf* pf, const double* t, const double* y, const uint8_t*
  * with CSSM_OPT_LOOP_EVENTS = 1 (below; environment CSSM_LOOP_EVENTS=1 sets that default): CSSM_ESTATE otherwise. */
 int cssm_pf_last_loop_ms(cssm_pf* pf, float* ms_out);
 
+/* Device time of the last batch call (cssm_pf_ll_filter_more, a sharded cssm_pf_shard_continue + series + status) WITHOUT event packets:
+ * the kernel that brings the call's first record stamps the GPU's constant 100 MHz clock (s_memrealtime) at its first instruction, the
+ * call's closing kernel (k_finish) stamps it again and hands both to the host with the results.  *us_out = first instruction of the
+ * call's first kernel -> the closing kernel's copy of the results, in microseconds (resolution 10 ns).  What bench.py reports per
+ * timed leg (`device_ms_each`) beside the host's wall time.  CSSM_ESTATE if the last call left no pair of stamps (a call that drew
+ * a new cloud: the scalars are reset behind its first kernel). */
+int cssm_pf_last_device_us(cssm_pf* pf, double* us_out);
+
+/* 1 if nothing is queued or running on the handle's stream (hipStreamQuery: every launch of the calls so far has completed as the runtime
+ * sees it), 0 if work is still pending, negative on a HIP error.  The batch drivers return on their closing kernel's completion word;
+ * a caller that wants the runtime's own confirmation (bench.py does, right behind its timed region) asks here -- no wait, no packet. */
+int cssm_pf_stream_idle(cssm_pf* pf);
+
 /* Debug/verification options.  CSSM_OPT_EXACT_OFFSPRING = 1 makes the offspring kernel evaluate the
  * contract's exact predicate for every particle instead of only where its fp64 position estimate is
  * within the error band of a slot boundary; results are identical by construction (tests compare).
@@ -549,7 +562,7 @@ void cssm_pf_shard_peer_close(cssm_pf* pf);
 int cssm_pf_shard_pack_peer(cssm_pf* pf, int rank, int world, int64_t cap);
 /* (round 5) EAGER ROWS + NEEDED ROWS.  A boundary block holds `cap` rows (sized for the worst observation, ~6 sqrt(N_global)), a typical
  * observation's neighbour needs a few hundred of them, and every row is a remote store over one xGMI link.  The rows next to the boundary
- * (CSSM_PEER_EAGER_ROWS, default 1024 = one tile) are written AT ONCE, with a flag of their own that is long set when the reader gets to
+ * (CSSM_PEER_EAGER_ROWS, default 4096 = four tiles) are written AT ONCE, with a flag of their own that is long set when the reader gets to
  * them.  Rows beyond them travel only if the neighbour's slots need them: once the headers of all ranks are there the SENDER can tell
  * (end slot beyond its own last slot / run starting below its own first slot: the reader's arithmetic), so the pack's row blocks wait for
  * the headers, write those rows and publish their number behind a second flag -- which the reader waits for only when the eager rows do

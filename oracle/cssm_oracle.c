@@ -241,6 +241,18 @@ static void draw_normals_paired(const oracle_pf* pf, uint64_t gid, uint32_t step
   }
 }
 
+/* The injected random stream, dumped for the independent numpy statement of the path (tests/golden/make_literal.py: the reference draws
+ * from an unseeded global generator -- what a second witness must share with this file are the VARIATES, not the arithmetic): the d
+ * normals of every particle of this handle at (step, tag) in the handle's mode (ORACLE_LIBM: Box-Muller through libm) -- sub < 0: the
+ * pair streams of an ordinary step / the initial draw; sub >= 0: sub-step `sub` of an LGCP event.  out[n][d]. */
+void oracle_pf_dump_normals(const oracle_pf* pf, uint32_t step, int init, int sub, double* out) {
+  const uint32_t tag = init ? CSSM_STREAM_INIT : CSSM_STREAM_STEP;
+  for (uint64_t i = 0; i < pf->n; ++i) {
+    if (sub < 0) draw_normals_paired(pf, pf->first + i, step, tag, out + i * pf->d);
+    else draw_normals(pf, pf->first + i, step, tag, (uint32_t)sub, out + i * pf->d);
+  }
+}
+
 /* ------------------------------------------------------------------ A1 initial state */
 
 /* initialiseState, model/ParticleFilter.scala:105-108; initialState of the leaves:

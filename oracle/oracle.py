@@ -55,6 +55,7 @@ def lib() -> C.CDLL:
             "oracle_pf_set_params": (C.c_int, [vp, vp]),
             "oracle_pf_reseed": (None, [vp, C.c_uint64]),
             "oracle_pf_components": (C.c_int, [vp, _dp]),
+            "oracle_pf_dump_normals": (None, [vp, C.c_uint32, C.c_int, C.c_int, _dp]),
             "oracle_pf_init": (C.c_int, [vp, C.c_double]),
             "oracle_pf_init_from": (C.c_int, [vp, C.c_double, _dp]),
             "oracle_pf_step": (C.c_int, [vp, C.c_double, C.c_double, C.c_int, _dp, _i32p]),
@@ -160,6 +161,12 @@ class OraclePf:
     def components(self):
         out = np.zeros((self.d, 5))
         lib().oracle_pf_components(self._h, _p(out))
+        return out
+
+    def dump_normals(self, step, init=False, sub=-1):
+        """The d normals of every particle at (step, initial draw / ordinary step, LGCP sub-step or -1) in the handle's mode: [n][d]."""
+        out = np.zeros((self.n, self.d))
+        lib().oracle_pf_dump_normals(self._h, int(step), 1 if init else 0, int(sub), _p(out))
         return out
 
     def init(self, t0):
