@@ -176,16 +176,16 @@ def run_single(args, emit=print):
 
     def timed_legs():
         """The figure of merit: W untimed warm-up steps start a filter (initial cloud, allocations) and the timed leg CONTINUES it: R legs
-        of exactly K more steps each (cssm_pf_ll_filter_more: no new cloud, the series goes on); the figure is the MEDIAN leg.  A leg is the
-        whole host call: records built and sent, 2 K launches enqueued, ll / ess read back.  Bracket: torch.cuda.synchronize() in front; the
-        clock stops when the call returns -- it returns on the completion word its closing kernel stores BEHIND the K steps' results, so
-        the K steps are done -- and the runtime's own view is asserted right behind (hipStreamQuery: nothing queued, nothing running);
-        the torch.cuda.synchronize() that follows is timed too and reported beside it (`wall_with_sync_ms_each`: 4-6 us more, the
-        runtime observing a signal the library has already seen).  Per leg also the DEVICE time from the GPU's own clock."""
+        of exactly K more steps each (cssm_pf_ll_filter_more: no new cloud, the series goes on), every leg bracketed by a device
+        synchronisation on both sides; the figure is the MEDIAN leg.  A leg is the whole host call: records built and sent, 2 K launches
+        enqueued, ll / ess read back.  Per leg also: the host time of the call alone (it returns on the completion word its closing kernel
+        stores behind the K steps' results; the closing torch.cuda.synchronize() then waits for the runtime to see that kernel's completion
+        signal -- measured in round 6: hipStreamQuery still says "not ready" when the call returns, the end-of-kernel release of the closing
+        kernel is what the synchronise waits 4-6 us for) and the DEVICE time of the leg from the GPU's own clock."""
         pf = handle()
         torch.cuda.synchronize()
         pf.run(t[:W], y[:W], has[:W])
-        walls, devs, syncs = [], [], []
+        walls, devs, calls, idle = [], [], [], []
         ll = ess_t = None
         for r in range(R):
             lo = W + r * K
@@ -193,17 +193,17 @@ def run_single(args, emit=print):
             t0 = time.perf_counter()
             ll, _, ess_t = pf.run_more(t[lo:lo + K], y[lo:lo + K], has[lo:lo + K])
             t1 = time.perf_counter()
-            idle = pf.stream_idle()
             torch.cuda.synchronize()
             t2 = time.perf_counter()
-            if not idle:
-                raise SystemExit("bench.py: the filter's stream was not idle when cssm_pf_ll_filter_more returned: the timed region would be short")
-            walls.append(t1 - t0)
-            syncs.append(t2 - t0)
+            walls.append(t2 - t0)
+            calls.append(t1 - t0)
+            idle.append(bool(pf.stream_idle()))          # (behind the synchronise: must be true)
             devs.append(pf.last_device_us() * 1e-6)      # (read behind the timed region: the GPU's own clock, no event packets)
+        if not all(idle):
+            raise SystemExit("bench.py: the filter's stream was not idle behind torch.cuda.synchronize()")
         d = pf.d
         pf.close()
-        return walls, ll, ess_t, d, devs, syncs
+        return walls, ll, ess_t, d, devs, calls
 
     def roofline_legs():
         """Kernel times of legs of the same shape on a handle of their own: the streaming ceiling of the box, the device time of R legs (HIP
@@ -253,11 +253,11 @@ def run_single(args, emit=print):
     # for a few ms in all run 5-15 % slower than every later one (leg after leg of the same handle: 522 493 461 465 468 ... 445 us, level
     # after ~15 legs): timed first, R = 7 legs of 20 steps measure that ramp, not the filter.  BENCH_TIMED_FIRST=1 restores that order.
     if os.environ.get("BENCH_TIMED_FIRST", "0") == "1":
-        walls, ll, ess_t, d, devs, syncs = timed_legs()
+        walls, ll, ess_t, d, devs, calls = timed_legs()
         copy_gbs, loop_ms, per, pair_s, roof_generic = roofline_legs()
     else:
         copy_gbs, loop_ms, per, pair_s, roof_generic = roofline_legs()
-        walls, ll, ess_t, d, devs, syncs = timed_legs()
+        walls, ll, ess_t, d, devs, calls = timed_legs()
     wall = float(np.median(walls))
     traffic, traffic_source = None, None
     tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
@@ -295,8 +295,8 @@ def run_single(args, emit=print):
         "kernels_us": kernels_us,
         "device_ms_each": [x * 1e3 for x in devs],
         "device_ms_each_is": "per timed leg, the GPU's constant 100 MHz clock (s_memrealtime) at the first instruction of the leg's first kernel and in its closing kernel (cssm_pf_last_device_us): device time of the very legs wall_ms_each times, no event packets on the queue",
-        "wall_with_sync_ms_each": [x * 1e3 for x in syncs],
-        "wall_ms_each_is": "torch.cuda.synchronize() -> cssm_pf_ll_filter_more returns (its closing kernel's completion word: the K steps' results are in host memory), the stream asserted idle right behind (cssm_pf_stream_idle); wall_with_sync_ms_each adds a closing torch.cuda.synchronize()",
+        "call_ms_each": [x * 1e3 for x in calls],
+        "call_ms_each_is": "host time of cssm_pf_ll_filter_more alone (the K steps' results are in host memory when it returns); wall_ms_each = torch.cuda.synchronize() -> call -> torch.cuda.synchronize()",
         "host_share": 1.0 - float(np.median(devs)) / wall,
         "device_loop_ms": loop_ms, "ll": ll, "ess_last": int(ess_t[-1]),
         "runtime": {"HSA_ENABLE_INTERRUPT": os.environ.get("HSA_ENABLE_INTERRUPT"), "note": "the ROCm runtime's completion wait as the caller left it (round 5 set 0 = polling; round 6's A/B on this very command, three interleaved pairs on one box: 22.55 / 23.15 / 22.87 us per step polling, 22.79 / 23.15 / 22.48 with interrupts -- no difference, setting removed: profiles/r06_ab_hsa_interrupt.txt)"},

@@ -40,6 +40,7 @@ bool cssm_rtc_launch(const PropLaunch& a, int kind, int D, int IT, int onev);
 
 // one per latent dimension, defined in cssm_prop.hip; returns what the kernel it chose does beyond the propagate itself
 #define CSSM_PROP_LAUNCHED_GRP 1   /* its blocks accumulate the sums of groups of units (Scalars::grp; asked for by bit 8 of slot_set) */
+#define CSSM_PROP_LAUNCHED_WS 2    /* its waves own contiguous quarter units and stored their exact sums (subS2, four per block; asked for by bit 13 of slot_set) */
 #define CSSM_DECL_PROP(D) int cssm_prop_launch_d##D(const PropLaunch& a);
 CSSM_DECL_PROP(1) CSSM_DECL_PROP(2) CSSM_DECL_PROP(3) CSSM_DECL_PROP(4) CSSM_DECL_PROP(5) CSSM_DECL_PROP(6) CSSM_DECL_PROP(7) CSSM_DECL_PROP(8)
 CSSM_DECL_PROP(9) CSSM_DECL_PROP(10) CSSM_DECL_PROP(11) CSSM_DECL_PROP(12) CSSM_DECL_PROP(13) CSSM_DECL_PROP(14) CSSM_DECL_PROP(15) CSSM_DECL_PROP(16)

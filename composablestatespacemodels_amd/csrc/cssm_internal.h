@@ -73,6 +73,9 @@ struct cssm_pf : HostModel {
   int opt_spec = 1;            // CSSM_OPT_SPECIALISE
   bool last_grp = false;       // the last launch_propagate's blocks accumulated the sums of groups of units (Scalars::grp)
   int grp_layout = 0;          // ... in layout 1 (<= 32 groups of 32 units) or 2 (<= 64 groups of 64 units); 0: not at all
+  bool last_ws = false;        // ... and its waves stored the exact sums of their quarter units (tileW): k_offspring_wave may run
+  int opt_wave = 1;            // CSSM_OPT_WAVE_SUMS
+  cssm_u128* tileW = nullptr;  // four per unit: the quarter units' sums (k_propagate_self<..., SUMS = 1, ONE = 2>, bit 13 of its set argument)
   int resampler = CSSM_RESAMPLE_SYSTEMATIC;
   double* cum = nullptr;       // multinomial: cumulative normalised weights
   const long long *send_first_dev = nullptr, *send_count_dev = nullptr;   // last shard_offspring outputs (device)

@@ -12,6 +12,7 @@
 
 #include "cssm_internal.h"
 #include "cssm_kernels.hip.h"
+#include "cssm_offspring_wave.hip.h"
 
 static int upload_init_params(cssm_pf* pf) {
   double m0[CSSM_MAX_DIM], sd0[CSSM_MAX_DIM];
@@ -134,6 +135,8 @@ static int alloc_handle(cssm_pf* pf) {
   HIP_TRY(hipMalloc(&pf->tileS2, nsums * sizeof(cssm_u128)));
   HIP_TRY(hipMalloc(&pf->tileP, nsums * sizeof(cssm_u128)));
   HIP_TRY(hipMalloc(&pf->unitPre, nsums * sizeof(cssm_u128)));
+  HIP_TRY(hipMalloc(&pf->tileW, nsums * sizeof(cssm_u128)));
+  HIP_TRY(hipMemsetAsync(pf->tileW, 0, nsums * sizeof(cssm_u128), pf->stream));
   pf->s2_stride = (uint32_t)nsums;
   HIP_TRY(hipMalloc(&pf->s2buf, 2 * nsums * sizeof(cssm_u128)));
   HIP_TRY(hipMemsetAsync(pf->s2buf, 0, 2 * nsums * sizeof(cssm_u128), pf->stream));
@@ -202,7 +205,7 @@ extern "C" void cssm_pf_destroy(cssm_pf* pf) {
   (void)hipSetDevice(pf->device);
   if (pf->stream) (void)hipStreamSynchronize(pf->stream);
   cssm_peer_free(pf);
-  void* ptrs[] = {pf->sm_keys, pf->sm_partial, pf->sm_st, pf->sm_rec, pf->s2buf, pf->fineS, pf->fineS2, pf->state[0], pf->state[1], pf->logw, pf->endslot, pf->anc, pf->tileS, pf->tileS2, pf->tileP, pf->unitPre, pf->sc,
+  void* ptrs[] = {pf->sm_keys, pf->sm_partial, pf->sm_st, pf->sm_rec, pf->s2buf, pf->fineS, pf->fineS2, pf->state[0], pf->state[1], pf->logw, pf->endslot, pf->anc, pf->tileS, pf->tileS2, pf->tileP, pf->unitPre, pf->tileW, pf->sc,
                   pf->d_m0, pf->d_sd0, pf->d_logtab, pf->d_fsub, pf->cum, pf->d_recs, pf->d_ll_t, pf->d_ess_t, pf->d_path, pf->cand, pf->cand_end, pf->cand_idx, pf->d_bounds, pf->d_xch, pf->d_need};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   if (pf->h_recs) (void)hipHostFree(pf->h_recs);
@@ -421,8 +424,14 @@ int cssm_launch_propagate(cssm_pf* pf, const StepRec* d_rec, double* pick_out, u
   const bool want_grp = pf->last_grp;
   // bits 11-12: log2(blocks per group / 32) -- the blocks per unit of a shard's split launch, or the 64-unit groups of layout 2
   if (want_grp) a.slot_set |= 0x100 | (pf->wparity << 9) | ((big ? 1 : (pf->split == 4u ? 2 : (pf->split == 2u ? 1 : 0))) << 11);
+  // ... and, on the single GPU's tile-after-tile launch behind systematic resampling, the exact sums of the waves' quarter units (bit 13;
+  // the array travels in the slot of the sums of squares, which these kernels leave to k_offspring): k_offspring_wave then needs neither
+  // a conversion nor a 128-bit scan per weight (CSSM_OPT_WAVE_SUMS = 0: k_offspring_self as before)
+  const bool want_ws = want_grp && geo == GEO_LOOP && !pf->sharded && batch == nullptr && pf->resampler == CSSM_RESAMPLE_SYSTEMATIC &&
+                       pf->obs_kind != CSSM_OBS_LGCP && pick_out == nullptr && pf->opt_wave != 0 && 4 * (size_t)pf->nunits <= (size_t)pf->s2_stride;
+  if (want_ws) a.slot_set |= 0x2000;
   a.src2 = anc ? pf->src2 : nullptr; a.src2_stride = pf->src2_stride; a.n_split = pf->n_split; a.logtab = pf->d_logtab;
-  a.chunk = chunk; a.do_sums = do_sums; a.subS = fine ? pf->fineS : pf->tileS; a.subS2 = fine ? pf->fineS2 : pf->tileS2;
+  a.chunk = chunk; a.do_sums = do_sums; a.subS = fine ? pf->fineS : pf->tileS; a.subS2 = want_ws ? pf->tileW : (fine ? pf->fineS2 : pf->tileS2);
   a.pick_out = pick_out; a.pick_slot = pick_slot;
   a.step = rec_step;
   a.fsub = pf->lgcp_tdep ? pf->d_fsub : nullptr;
@@ -443,6 +452,7 @@ int cssm_launch_propagate(cssm_pf* pf, const StepRec* d_rec, double* pick_out, u
   }
   // k_offspring reads the group sums only where the kernel that ran accumulated them (the unit sums exist either way)
   pf->last_grp = want_grp && (launched & CSSM_PROP_LAUNCHED_GRP) != 0;
+  pf->last_ws = pf->last_grp && want_ws && (launched & CSSM_PROP_LAUNCHED_WS) != 0;
   prof_end(pf);
   if (fine) {   // the blocks' sums -> the units' (the kernel itself skips unweighted observations and series on hold)
     prof_begin(pf, CSSM_K_REDUCE);
@@ -490,7 +500,12 @@ static int launch_resample(cssm_pf* pf, const StepRec* d_rec, double* ll_t = nul
 #define OFF_ARGS pf->logw, pf->n, pf->sc, (const cssm_u128*)pf->tileS, (const cssm_u128*)pf->tileS2, d_rec, pf->anc, pf->ntiles, pf->sup, pf->nunits, \
                  pf->wparity, ll_t, ess_t, rec_idx, pf->opt_exact, split, pf->seed, pf->cum, pf->s2buf, pf->s2_stride, s2_par, pf->gen
   const int ogrid = tgrid + 1;   // one block per unit + the publisher
-#define OFF_GO(RS) do { if (optimistic && pf->last_grp && pf->grp_layout == 2 && RS == CSSM_RESAMPLE_SYSTEMATIC) \
+#define OFF_WAVE_ARGS pf->logw, pf->n, pf->sc, (const cssm_u128*)pf->tileS, (const cssm_u128*)pf->tileW, d_rec, pf->anc, pf->sup, pf->nunits, pf->wparity, \
+                      ll_t, ess_t, rec_idx, pf->opt_exact, pf->s2buf, pf->s2_stride, s2_par, pf->gen
+#define OFF_GO(RS) do { if (optimistic && pf->last_grp && pf->last_ws && RS == CSSM_RESAMPLE_SYSTEMATIC) { \
+                          if (pf->grp_layout == 2) hipLaunchKernelGGL((k_offspring_wave<2>), dim3(ogrid), dim3(CSSM_BLOCK), 0, pf->stream, OFF_WAVE_ARGS); \
+                          else hipLaunchKernelGGL((k_offspring_wave<1>), dim3(ogrid), dim3(CSSM_BLOCK), 0, pf->stream, OFF_WAVE_ARGS); \
+                        } else if (optimistic && pf->last_grp && pf->grp_layout == 2 && RS == CSSM_RESAMPLE_SYSTEMATIC) \
                           hipLaunchKernelGGL((k_offspring_self<CSSM_RESAMPLE_SYSTEMATIC, 2, 2>), dim3(ogrid), dim3(CSSM_BLOCK), 0, pf->stream, OFF_ARGS); \
                         else if (optimistic && pf->last_grp && RS == CSSM_RESAMPLE_SYSTEMATIC) \
                           hipLaunchKernelGGL((k_offspring_self<CSSM_RESAMPLE_SYSTEMATIC, 2, 1>), dim3(ogrid), dim3(CSSM_BLOCK), 0, pf->stream, OFF_ARGS); \
@@ -505,6 +520,7 @@ static int launch_resample(cssm_pf* pf, const StepRec* d_rec, double* ll_t = nul
   else OFF_GO(CSSM_RESAMPLE_SYSTEMATIC);
 #undef OFF_GO
 #undef OFF_ARGS
+#undef OFF_WAVE_ARGS
   if (pf->resampler == CSSM_RESAMPLE_MULTINOMIAL)
     hipLaunchKernelGGL(k_multinomial, dim3(grid_for(pf->n, 256, kGridCap)), dim3(256), 0, pf->stream, pf->cum, pf->n, pf->seed,
                        pf->h_step_for_resample, pf->anc);
@@ -1049,6 +1065,7 @@ extern "C" int cssm_pf_set_option(cssm_pf* pf, int option, int value) {
   if (option == CSSM_OPT_EXACT_OFFSPRING) { pf->opt_exact = (value == 2) ? 2 : (value ? 1 : 0); return CSSM_OK; }
   if (option == CSSM_OPT_FUSED_SUMS) { pf->opt_fused = value ? 1 : 0; return CSSM_OK; }
   if (option == CSSM_OPT_GROUP_SUMS) { pf->opt_grp = value ? 1 : 0; return CSSM_OK; }
+  if (option == CSSM_OPT_WAVE_SUMS) { pf->opt_wave = value ? 1 : 0; return CSSM_OK; }
   if (option == CSSM_OPT_LOOP_EVENTS) { pf->opt_events = value ? 1 : 0; return CSSM_OK; }
   if (option == CSSM_OPT_SPECIALISE) { pf->opt_spec = (value == 2) ? 2 : (value ? 1 : 0); return CSSM_OK; }
   if (option == CSSM_OPT_WHOLE_TILES) {   // launch geometry only: the arrays hold up to four sub-units per unit either way

@@ -103,6 +103,8 @@ int CSSM_CAT(cssm_prop_launch_d, CSSM_PROP_D)(const PropLaunch& a) {
   // small clouds: one tile of the kernel per block (half a tile of 1024 for d <= 8, a quarter for d >= 9): the ONE instantiation
   // every kernel that forms the sums adds to the group sums where bit 8 of the set argument asks for them (one block per unit: cssm_pf.hip)
   const int grp = (a.sums && a.do_sums && (a.slot_set & 0x100)) ? CSSM_PROP_LAUNCHED_GRP : 0;
+  // ... and the single GPU's tile-after-tile launch stores its waves' sums where bit 13 asks for them (propagate_block: WR)
+  const int ws = (self && CSSM_PROP_SELF && a.sums && a.do_sums && a.one == 2 && (a.slot_set & 0x2000)) ? CSSM_PROP_LAUNCHED_WS : 0;
   if (self && CSSM_PROP_SELF && a.sums && a.one) {
     OneTile<D, IT>::go(a);
   } else if (self && CSSM_PROP_SELF) {
@@ -149,7 +151,7 @@ int CSSM_CAT(cssm_prop_launch_d, CSSM_PROP_D)(const PropLaunch& a) {
   }
 #undef PROP_GO
 #undef PROP_SELF
-  return grp;
+  return grp | ws;
 }
 
 #if defined(CSSM_PROP_STAMPS)

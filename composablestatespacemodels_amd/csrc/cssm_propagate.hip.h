@@ -77,7 +77,13 @@ struct PropAcc {
 // else hides those two round trips (~1.7 us of a kernel whose whole body takes ~5).  Same arithmetic, another order.
 // (ONE = 1: the range is a single tile; ONE = 2: the same body tile after tile -- a separate instantiation: folding the loop into
 // the single-tile kernel cost it 18 VGPRs and 10 % at d = 9)
-template <int D, bool LGCP, int IT, int OBS, int SUMS, int ONE = 0>
+// WR (wave ranges; round 6): the range [range_lo, n) is ONE WAVE's -- a contiguous quarter of its block's unit, walked in tiles of 64 * IT
+// particles, lane l owning the IT particles at 64 IT tile + IT l -- instead of the whole block's (tiles of CSSM_BLOCK * IT, thread t at IT t).
+// Every particle's arithmetic depends on its global id alone and the sums are integers: the same bits either way.  What it buys: the wave's
+// sum, which the block reduction forms anyway, is the exact sum of a contiguous quarter unit -- k_offspring_wave's waves take their
+// prefixes from those sums instead of converting and scanning every weight again (cssm_offspring_wave.hip.h).  A wave's store
+// instruction covers 1 KiB contiguously as before; the block streams four ranges instead of one.
+template <int D, bool LGCP, int IT, int OBS, int SUMS, int ONE = 0, bool WR = false>
 __device__ __forceinline__ void propagate_range(
     const double* __restrict__ src, size_t src_stride, const uint32_t* __restrict__ anc,
     double* __restrict__ dst, size_t dst_stride, double* __restrict__ logw, uint64_t gid0,
@@ -116,7 +122,9 @@ __device__ __forceinline__ void propagate_range(
   double tmax = -cssm_inf();
   bool bad = false;
   // tile indices are 32-bit (the library admits n <= 2^32 - 2^16 particles per handle): half the VALU work of 64-bit
-  constexpr uint32_t stride = (uint32_t)CSSM_BLOCK * IT;      // particles per tile
+  static_assert(!WR || ONE == 2, "wave ranges: the tile-after-tile instantiation");
+  constexpr uint32_t stride = (WR ? 64u : (uint32_t)CSSM_BLOCK) * IT;      // particles per tile (WR: of the wave)
+  const uint32_t tl = WR ? (threadIdx.x & 63u) : threadIdx.x;               // the thread's place in its tile
   // Software pipeline over the block's tiles WITHOUT spending registers on it.  With 4 waves per SIMD the two
   // dependent memory round trips of a tile (ancestor index -> gathered state) are exposed: a model with that
   // latency reproduces the 3.3 TB/s the un-pipelined kernel reached for every d, and holding the next tile in VGPRs
@@ -141,7 +149,7 @@ __device__ __forceinline__ void propagate_range(
   // register copy that unpacking a vector load can need -- makes the compiler wait for the load right there.
   constexpr int NJ = (IT + 1) / 2;
   auto load_idx = [&](uint32_t base, unsigned long long (&jp)[NJ]) {
-    const uint32_t i0 = base + threadIdx.x * IT;
+    const uint32_t i0 = base + tl * IT;
     if (anc) {
       if (IT == 4) {
         const ulonglong2 a = *reinterpret_cast<const ulonglong2*>(anc + i0);
@@ -158,7 +166,7 @@ __device__ __forceinline__ void propagate_range(
   };
   // unpacked where they are consumed; what a partial thread read beyond n is replaced by a valid index
   auto unpack_idx = [&](uint32_t base, const unsigned long long (&jp)[NJ], uint32_t (&j)[IT]) {
-    const uint32_t i0 = base + threadIdx.x * IT;
+    const uint32_t i0 = base + tl * IT;
 #pragma unroll
     for (int r = 0; r < IT; ++r) {
       const uint32_t v = (uint32_t)(jp[r / 2] >> (32 * (r & 1)));
@@ -245,7 +253,7 @@ __device__ __forceinline__ void propagate_range(
   if (base < n) {
     if (NJ == 1 && pre_jp != nullptr) jp[0] = *pre_jp; else load_idx(base, jp);   // (requested by the caller with its other first loads)
     if (ONE && IT == 2 && pre_jp == nullptr) {                    // (while the indices travel)
-      normals_pair_half<D, 0>(seed, gid0 + base + threadIdx.x * IT, step, tab, zz);
+      normals_pair_half<D, 0>(seed, gid0 + base + tl * IT, step, tab, zz);
       // the indices are consumed BEHIND these normals: an empty asm that takes both pins the order (the compiler otherwise
       // hoists the address arithmetic, and with it the wait for the load, above the Philox rounds)
 #pragma unroll
@@ -260,14 +268,14 @@ __device__ __forceinline__ void propagate_range(
         if (pre_blk != nullptr) {
           normals_pair_from_blocks<D>(pre_blk, tab, zz);
         } else {
-          if (pre_jp != nullptr) normals_pair_half<D, 0>(seed, gid0 + base + threadIdx.x * IT, step, tab, zz);
-          normals_pair_half<D, 1>(seed, gid0 + base + threadIdx.x * IT, step, tab, zz);
+          if (pre_jp != nullptr) normals_pair_half<D, 0>(seed, gid0 + base + tl * IT, step, tab, zz);
+          normals_pair_half<D, 1>(seed, gid0 + base + tl * IT, step, tab, zz);
         }
 #pragma unroll
         for (int q = (pre_jp != nullptr) ? 0 : PairHalf<D>::n0; q < 2 * D; ++q) asm volatile("" : "+v"(zz[q % (ONE ? IT * D : 1)]));
       } else if (ONE) {                                           // one particle per thread: its D normals
         double z1[D];
-        draw_normals<D>(seed, gid0 + base + threadIdx.x, step, CSSM_STREAM_STEP, tab, z1);
+        draw_normals<D>(seed, gid0 + base + tl, step, CSSM_STREAM_STEP, tab, z1);
 #pragma unroll
         for (int q = 0; q < D; ++q) { zz[q % (ONE ? IT * D : 1)] = z1[q]; asm volatile("" : "+v"(zz[q % (ONE ? IT * D : 1)])); }
       }
@@ -286,7 +294,7 @@ __device__ __forceinline__ void propagate_range(
     }
   }
   for (; base < n; base += stride) {
-    const uint32_t i0 = base + threadIdx.x * IT;
+    const uint32_t i0 = base + tl * IT;
     const bool full = (i0 + IT <= n);
     // (tile after tile: the NEXT tile's ancestor indices travel while this one is computed -- one of the two dependent round trips
     //  at the tile boundary; two registers)
@@ -429,11 +437,11 @@ __device__ __forceinline__ void propagate_range(
         unpack_idx(nb, jp, jn);
         stage_issue(jn);
         if (IT == 2) {
-          normals_pair_half<D, 0>(seed, gid0 + nb + threadIdx.x * IT, step, tab, zz);
-          normals_pair_half<D, 1>(seed, gid0 + nb + threadIdx.x * IT, step, tab, zz);
+          normals_pair_half<D, 0>(seed, gid0 + nb + tl * IT, step, tab, zz);
+          normals_pair_half<D, 1>(seed, gid0 + nb + tl * IT, step, tab, zz);
         } else {
           double z1[D];
-          draw_normals<D>(seed, gid0 + nb + threadIdx.x, step, CSSM_STREAM_STEP, tab, z1);
+          draw_normals<D>(seed, gid0 + nb + tl, step, CSSM_STREAM_STEP, tab, z1);
 #pragma unroll
           for (int q = 0; q < D; ++q) zz[q % (ONE ? IT * D : 1)] = z1[q];
         }
@@ -579,16 +587,30 @@ __device__ __forceinline__ void propagate_block(
   if (ONE != 0 && IT == 2) asm volatile("" : "+s"(key_lo), "+s"(key_hi), "+s"(step_k));
   PSTAMP(0);
   const uint32_t held = sc->err;          // (tested behind the table staging: its load then overlaps the table's)
-  const uint32_t range_lo = blockIdx.x * (uint32_t)chunk;
+  // WR (the single GPU's tile-after-tile launch with the fused sums): every WAVE owns a contiguous quarter of the block's range (see
+  // propagate_range); bit 13 of the set argument: the waves' sums are wanted (subS2, unused by SUMS == 1, holds them: four per block)
+  constexpr bool WR = (ONE == 2 && SUMS == 1);
+  const bool wsum_on = WR && (slot_set_arg & 0x2000) != 0;
+  uint32_t range_lo = blockIdx.x * (uint32_t)chunk;
   uint32_t n;
   { const uint64_t range_hi = (uint64_t)range_lo + chunk; n = (uint32_t)((range_hi < n_arg) ? range_hi : n_arg); }
+  if (WR) {
+    const uint32_t qw = (uint32_t)(chunk >> 2);             // (the chunk is a whole number of tiles of 1024: a quarter is whole tiles of 64 IT)
+    const uint32_t wlo = range_lo + (threadIdx.x >> 6) * qw;
+    const uint32_t whi = ((uint64_t)wlo + qw < (uint64_t)n) ? wlo + qw : n;
+    range_lo = (wlo < n) ? wlo : n;                          // (a wave beyond the cloud's end: an empty range)
+    n = whi;
+  }
+  const uint32_t tl = WR ? (threadIdx.x & 63u) : threadIdx.x;
   // ONE: the tile's ancestor indices are requested together with the log table -- they depend on nothing but the thread's
   // position (anc holds a whole number of tiles: a partial thread's pair stays inside it)
   unsigned long long jp_early = 0ull;
   if (ONE) {
-    const uint32_t i0 = range_lo + threadIdx.x * IT;
-    if (IT == 2) jp_early = anc ? *reinterpret_cast<const unsigned long long*>(anc + i0) : ((unsigned long long)i0 | ((unsigned long long)(i0 + 1u) << 32));
-    else jp_early = anc ? (unsigned long long)anc[i0] : (unsigned long long)i0;
+    const uint32_t i0 = range_lo + tl * IT;
+    // (WR: a wave whose range is empty may stand beyond the index buffer's last tile: it requests nothing)
+    const bool in_buf = !WR || range_lo < n;
+    if (IT == 2) jp_early = (anc && in_buf) ? *reinterpret_cast<const unsigned long long*>(anc + i0) : ((unsigned long long)i0 | ((unsigned long long)(i0 + 1u) << 32));
+    else jp_early = (anc && in_buf) ? (unsigned long long)anc[i0] : (unsigned long long)i0;
   }
   // ... and so are the thread's entry of the log table and the lines of the observation's record the kernel will read: behind
   // the table's barrier the record's lines are hits in the scalar cache instead of a first touch on the critical path.  (The
@@ -618,7 +640,7 @@ __device__ __forceinline__ void propagate_block(
     // and a loaded value: the rounds cannot sink below them, the waits for the loads cannot rise above them -- scalar loads return
     // out of order, so a wait for any of them is a wait for all.)
     if (EARLY) {
-      const uint64_t stream = cssm_pair_stream(gid0 + range_lo + threadIdx.x * IT);
+      const uint64_t stream = cssm_pair_stream(gid0 + range_lo + tl * IT);
 #pragma unroll
       for (int B = 0; B < PairHalf<D>::nblk; ++B) {
         blk_early[B] = cssm_philox_draw((uint64_t)key_lo | ((uint64_t)key_hi << 32), stream, step_k, CSSM_STREAM_STEP, (uint32_t)B);
@@ -638,7 +660,7 @@ __device__ __forceinline__ void propagate_block(
   if (held & (4u | 8u | 16u | 64u)) return;
   __shared__ __attribute__((aligned(16))) unsigned char s_stage[PropStage<D, IT>::bytes];
   PropAcc acc;
-  propagate_range<D, false, IT, OBS, SUMS, ONE>(src, src_stride, anc, dst, dst_stride, logw, gid0, seed, rec, mk, src2, 0, n_split, tab,
+  propagate_range<D, false, IT, OBS, SUMS, ONE, WR>(src, src_stride, anc, dst, dst_stride, logw, gid0, seed, rec, mk, src2, 0, n_split, tab,
                                                 range_lo, n, SUMS ? 1 : 0, SUMS ? pick_out : nullptr, pick_slot, s_stage, acc,
                                                 nullptr, ONE ? &jp_early : nullptr, EARLY ? blk_early : nullptr, step_now);
   PSTAMP(6);
@@ -649,7 +671,10 @@ __device__ __forceinline__ void propagate_block(
   if (SUMS) {
     __shared__ cssm_u128 s_sa[CSSM_BLOCK / 64], s_sb[CSSM_BLOCK / 64];
     const cssm_u128 accS = wave_sum_u128(acc.S), accS2 = (SUMS == 2) ? wave_sum_u128(acc.S2) : cssm_u128_zero();
-    if ((threadIdx.x & 63) == 0) { s_sa[threadIdx.x >> 6] = accS; if (SUMS == 2) s_sb[threadIdx.x >> 6] = accS2; }
+    if ((threadIdx.x & 63) == 0) {
+      s_sa[threadIdx.x >> 6] = accS; if (SUMS == 2) s_sb[threadIdx.x >> 6] = accS2;
+      if (wsum_on) subS2[(size_t)blockIdx.x * (CSSM_BLOCK / 64) + (threadIdx.x >> 6)] = accS;   // the quarter unit's exact sum (k_offspring_wave)
+    }
     __syncthreads();
     if (threadIdx.x == 0) {
       cssm_u128 ta = s_sa[0], tb = (SUMS == 2) ? s_sb[0] : cssm_u128_zero();

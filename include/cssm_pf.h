@@ -271,6 +271,13 @@ int cssm_pf_stream_idle(cssm_pf* pf);
  * call, which cssm_pf_last_loop_ms then reads.  Off by default: the two event packets cost a 20-observation call about 5 us (the one
  * between the last kernel and the call's closing kernel holds the queue for ~4 us). */
 #define CSSM_OPT_LOOP_EVENTS 9
+/* CSSM_OPT_WAVE_SUMS (default 1; a verification switch: results are bit-identical either way).  Single GPU, systematic resampling, clouds of
+ * 2^20 particles and more on the tile-after-tile launch: every wave of the fused kernel owns a contiguous quarter of its block's unit and
+ * stores the exact fixed-point sum of its weights; the resampling kernel (k_offspring_wave) takes a wave's prefix from those sums and the
+ * group sums and runs the rest of its prefix arithmetic in fp64 -- no conversion to the 2^-96 grid and no 128-bit scan per weight, one block
+ * barrier per block; the contract's exact predicate where the fp64 estimate is within its error band of a slot boundary, as before.
+ * 0 = k_offspring_self (every weight converted and scanned in 128 bits). */
+#define CSSM_OPT_WAVE_SUMS 10
 int cssm_pf_set_option(cssm_pf* pf, int option, int value);
 /* Counters of the run-time specialisation in this process: out4 = {kernels compiled, kernels loaded from the disk cache, launches of
  * run-time-compiled kernels, failures (each reported once on stderr)}. */

@@ -10,6 +10,7 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run on the GPU box with -m gpu)")
+    config.addinivalue_line("markers", "slow: a GPU test that needs a minute or more of one-thread oracle time (full-size bit comparisons); part of -m gpu")
     config.addinivalue_line("markers", "native_threshold: (test_gpu_shard_group_sums) the library's own size threshold for the group sums, no override")
 
 
