@@ -16,9 +16,11 @@
 //     together < N 2^-47.1, a factor 8 inside eps = N 2^-44.  The fp64 sums add the weights THEMSELVES, the contract their truncation to
 //     the grid: < 2^-96 per particle, < q 2^-96 over a wave's quarter, i.e. N q 2^-96 / S_tot slots -- nothing unless S_tot is tiny (the
 //     level may sit 32 above the max: S_tot >= 2^-46.2), so eps carries the term: eps = N (2^-44 + 2 q 2^-96 / S_tot).
-//   * where a fraction falls inside the band (2 eps of the particles: 2^-19 at N = 2^24) the WAVE takes a cold path: the exact prefix of
-//     its chunk (the quarter's exact prefix + the chunk sums before it, re-read and converted), a 128-bit scan of the chunk, and
-//     offspring_exact_counts for the flagged particles -- the contract's predicate on the contract's sums, as everywhere else.
+//   * where a fraction of a chunk falls inside the band (2 eps of the particles: 2^-19 at N = 2^24, one chunk of 256 in 2^11) the WAVE notes
+//     the chunk and redoes it BEHIND its loop, where nothing of the hot path is live: the chunk's exact prefix (the quarter's exact prefix
+//     + the chunk sums before it, re-read and converted), a 128-bit scan of the chunk and offspring_exact_counts for every particle of it
+//     -- the contract's predicate on the contract's sums, as everywhere else.  (Resolved in place, inside the loop, that path's registers
+//     took the kernel from 63 vector registers to 110; as a real call its caller-saved spills were hoisted onto the hot path.)
 //   * one block barrier per block (behind the group sums' scan) instead of one + one or two per tile; the waves' sums of squared weights
 //     meet through an LDS ticket, not a barrier.
 #pragma once
@@ -43,7 +45,7 @@ __device__ __forceinline__ cssm_u128 u128_add_any(cssm_u128 a, cssm_u128 b) {
 __device__ __forceinline__ double u128_to_f64_fast(cssm_u128 a) { return cssm_fma((double)a.hi, 0x1.0p64, (double)a.lo); }
 
 #ifndef CSSM_OFFW_WAVES
-#define CSSM_OFFW_WAVES 5
+#define CSSM_OFFW_WAVES 6
 #endif
 
 // GRPL: the layout of the group sums the propagate behind this launch added to (1: <= 32 groups of 32 units, one wave scans groups and
@@ -68,18 +70,20 @@ __global__ __attribute__((amdgpu_flat_work_group_size(CSSM_BLOCK, CSSM_BLOCK), a
   const uint32_t lane = threadIdx.x & 63u, wid = threadIdx.x >> 6;
   // ======== entry: one round of loads
   const uint32_t held = sc->err;
+  // (indices are 32-bit: the library admits n <= 2^32 - 2^16 particles per handle, and a cloud's last unit ends below n + 2^15)
+  const uint32_t n32 = (uint32_t)n;
   const uint32_t q = sup * (uint32_t)(CSSM_TILE / 4);          // particles of a quarter unit: what one wave owns
-  const uint64_t w_lo = (uint64_t)ublk * sup * CSSM_TILE + (uint64_t)wid * q;   // the wave's first particle
+  const uint32_t w_lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(ublk * sup * (uint32_t)CSSM_TILE + wid * q));   // the wave's first particle
   double w1[CSSM_ITEMS];
-  auto load_chunk = [&](uint64_t base, double (&v)[CSSM_ITEMS]) {          // the wave's 256 particles from `base` on, four per lane
-    const uint64_t i0 = base + (uint64_t)lane * CSSM_ITEMS;
-    if (i0 + CSSM_ITEMS <= n) {
+  auto load_chunk = [&](uint32_t base, double (&v)[CSSM_ITEMS]) {          // the wave's 256 particles from `base` on, four per lane
+    const uint32_t i0 = base + lane * CSSM_ITEMS;
+    if (i0 + CSSM_ITEMS <= n32) {
       const double2 a = *reinterpret_cast<const double2*>(logw + i0);
       const double2 b = *reinterpret_cast<const double2*>(logw + i0 + 2);
       v[0] = a.x; v[1] = a.y; v[2] = b.x; v[3] = b.y;
     } else {
 #pragma unroll
-      for (int r = 0; r < CSSM_ITEMS; ++r) v[r] = (i0 + r < n) ? logw[i0 + r] : 0.0;
+      for (int r = 0; r < CSSM_ITEMS; ++r) v[r] = (i0 + r < n32) ? logw[i0 + r] : 0.0;
     }
   };
   if (!is_pub) load_chunk(w_lo, w1);
@@ -212,8 +216,8 @@ __global__ __attribute__((amdgpu_flat_work_group_size(CSSM_BLOCK, CSSM_BLOCK), a
     return;
   }
   // ======== the wave's quarter unit, chunk after chunk; nothing below waits for another wave
-  const double nd = (double)n;
-  const double scale = uniform_f64(s_scale) * 0x1.0p96;        // N / S_tot with S_tot in weight units
+  const double nd = (double)n32;
+  const double scale = uniform_f64(uniform_f64(s_scale) * 0x1.0p96);        // N / S_tot with S_tot in weight units
   cssm_u128 toff;                                              // exact: everything before this wave's first particle
   {
     cssm_u128 p0, p1; p0.lo = s_pre[0].lo; p0.hi = s_pre[0].hi; p1.lo = s_pre[1].lo; p1.hi = s_pre[1].hi;
@@ -225,19 +229,19 @@ __global__ __attribute__((amdgpu_flat_work_group_size(CSSM_BLOCK, CSSM_BLOCK), a
     }
     toff = uniform_u128(toff);
   }
-  const double tot_w = u128_to_f64_fast(tot) * 0x1.0p-96;
-  const double eps = uniform_f64(nd * (0x1.0p-44 + (double)(2u * q) * 0x1.0p-96 / tot_w));
-  const double one_minus_eps = 1.0 - eps;
-  const double one_minus_u = 1.0 - u;
-  const bool pow2 = (n & (n - 1)) == 0;
+  // eps = N (2^-44 + 2 q 2^-96 / S_tot): 1 / S_tot = scale / N
+  const double eps = uniform_f64(cssm_fma((double)(2u * q) * 0x1.0p-96, scale, nd * 0x1.0p-44));
+  const double one_minus_eps = uniform_f64(1.0 - eps);
+  const double one_minus_u = uniform_f64(1.0 - u);
   double pre_w = uniform_f64(u128_to_f64_fast(toff) * 0x1.0p-96);   // the running prefix of the wave's chunks, weight units
-  const uint64_t w_hi = (w_lo + q < n) ? w_lo + q : n;
-  for (uint64_t base = w_lo; base < w_hi; base += CSSM_TILE / 4) {
-    if (base != w_lo) {
-      load_chunk(base, w1);
-      inc = wave_scan_f64((w1[0] + w1[1]) + (w1[2] + w1[3]));
-      squares(w1);
-    }
+  const uint32_t w_hi = (w_lo + q < n32 && w_lo + q > w_lo) ? w_lo + q : n32;
+  uint32_t cold = 0u;                                         // bit c: chunk c of the quarter waits for the exact path (a unit has <= 32 tiles)
+  for (uint32_t base = w_lo; base < w_hi; base += CSSM_TILE / 4) {
+    // the NEXT chunk's weights travel while this one is resolved (no barrier stands between a wave's chunks any more: what hid the round
+    // trip in k_offspring_self -- the CU's other blocks -- is now worth having in flight)
+    const bool more = base + (uint32_t)(CSSM_TILE / 4) < w_hi;
+    double wn[CSSM_ITEMS];
+    if (more) load_chunk(base + (uint32_t)(CSSM_TILE / 4), wn);
     // exclusive prefix of the thread's first particle: the lane before's inclusive sum (lane 0: nothing) on the chunk's prefix
     double sd = pre_w + cssm_u2d(dpp0_u64<0x138 /* wave_shr:1 */, 0xf>(cssm_d2u(inc)));
     uint32_t e[CSSM_ITEMS];
@@ -248,7 +252,7 @@ __global__ __attribute__((amdgpu_flat_work_group_size(CSSM_BLOCK, CSSM_BLOCK), a
       const double pp1 = cssm_fma(sd, scale, one_minus_u);
       const double fr = cssm_fract_pos(pp1);
       const uint32_t c32 = (uint32_t)pp1;
-      e[r] = (c32 > (uint32_t)n) ? (uint32_t)n : c32;
+      e[r] = (c32 > n32) ? n32 : c32;
       if (!((fr > eps) && (fr < one_minus_eps))) unsafe |= 1u << r;
     }
     // the end slot of the particle before the wave's first: counted on the chunk's prefix -- the very sum that particle was counted on
@@ -256,60 +260,36 @@ __global__ __attribute__((amdgpu_flat_work_group_size(CSSM_BLOCK, CSSM_BLOCK), a
     uint32_t prev = dpp0<0x138 /* wave_shr:1 */, 0xf>(e[CSSM_ITEMS - 1]);
     bool prev_unsafe = false;
     if (lane == 0u) {
-      if (base == 0ull) prev = 0u;                             // the globally first particle
+      if (base == 0u) prev = 0u;                             // the globally first particle
       else {
         const double ppp = cssm_fma(pre_w, scale, one_minus_u);
         const double frp = cssm_fract_pos(ppp);
         const uint32_t c32 = (uint32_t)ppp;
-        prev = (c32 > (uint32_t)n) ? (uint32_t)n : c32;
+        prev = (c32 > n32) ? n32 : c32;
         prev_unsafe = !((frp > eps) && (frp < one_minus_eps));
       }
     }
-    if (force_exact) {   // CSSM_OPT_EXACT_OFFSPRING (verification): 1 = every particle through the exact predicate, 2 = every third one
-      uint32_t fm = 0xfu;
-      if (force_exact == 2) {
-        const uint32_t j0 = (uint32_t)base + lane * CSSM_ITEMS;
-        fm = ((j0 % 3u == 0u) ? 1u : 0u) | (((j0 + 1u) % 3u == 0u) ? 2u : 0u) | (((j0 + 2u) % 3u == 0u) ? 4u : 0u) | (((j0 + 3u) % 3u == 0u) ? 8u : 0u);
-      }
-      unsafe |= fm;
-      if (lane == 0u && base != 0ull) prev_unsafe = true;
-    }
-    if (__any(unsafe != 0u || prev_unsafe)) {
-      // ---- cold path (wave-uniform): the chunk's exact prefix, the threads' exact prefixes, the contract's predicate
-      cssm_u128 X = toff;
-      for (uint64_t b2 = w_lo; b2 < base; b2 += CSSM_TILE / 4) {          // the chunks of this quarter before the current one
-        double v[CSSM_ITEMS];
-        load_chunk(b2, v);
-        cssm_u128 ts = cssm_u128_zero();
-#pragma unroll
-        for (int r = 0; r < CSSM_ITEMS; ++r) ts = cssm_u128_add(ts, cssm_fix_from_unit(v[r]));
-        X = u128_add_any(X, wave_sum_u128(ts));
-      }
-      cssm_u128 ts = cssm_u128_zero();
-#pragma unroll
-      for (int r = 0; r < CSSM_ITEMS; ++r) ts = cssm_u128_add(ts, cssm_fix_from_unit(w1[r]));
-      const cssm_u128 xinc = wave_scan_u128(ts, (int)lane);
-      const cssm_u128 run0 = wave_excl_add_u128(xinc, X);
-      const double totd = cssm_u128_to_double(tot);
-      if (unsafe) offspring_exact_counts(run0, w1, unsafe, totd, u, n, e);
-      if (prev_unsafe) {
-        const double z4[4] = {0.0, 0.0, 0.0, 0.0};
-        uint32_t p4[4] = {0u, 0u, 0u, 0u};
-        offspring_exact_counts(X, z4, 1u, totd, u, n, p4);
-        prev = p4[0];
-      }
-      // (the lane behind a corrected particle read its end slot before the correction)
-      const uint32_t pv2 = dpp0<0x138 /* wave_shr:1 */, 0xf>(e[CSSM_ITEMS - 1]);
-      if (lane != 0u) prev = pv2;
-    }
+    // A chunk with a fraction inside the band (or under CSSM_OPT_EXACT_OFFSPRING, verification: every chunk) is NOT resolved here: it is
+    // noted and redone behind the loop through the contract's predicate on exact sums (see below) -- inlined at this point that path's
+    // registers (128-bit sums, a division, the counting loops) took the kernel from 63 vector registers to 110.
+    const bool deferred = force_exact != 0 || __any(unsafe != 0u || prev_unsafe);
+    if (deferred) cold |= 1u << ((base - w_lo) >> 8);
+    else {
     // the slots this wave's 256 particles own, assembled in the wave's LDS region and written as whole lines
     uint32_t wb = (uint32_t)__builtin_amdgcn_readfirstlane((int)prev);
     uint32_t we = (uint32_t)__builtin_amdgcn_readlane((int)e[CSSM_ITEMS - 1], 63);
-    we = (we > (uint32_t)n) ? (uint32_t)n : we;
+    we = (we > n32) ? n32 : we;
     wb = (wb > we) ? we : wb;
-    fill_runs_wave<CSSM_OFF_SC1 != 0, false>(prev, e, (uint32_t)(base + (uint64_t)lane * CSSM_ITEMS), wb, we, anc, 0u, (uint32_t)(n - 1), s_slot + wid * CSSM_WAVE_CHUNK);
-    // advance the running prefix by the chunk's total (the scan's last lane)
+    fill_runs_wave<CSSM_OFF_SC1 != 0, false>(prev, e, base + lane * CSSM_ITEMS, wb, we, anc, 0u, n32 - 1u, s_slot + wid * CSSM_WAVE_CHUNK);
+    }
+    // advance the running prefix by the chunk's total (the scan's last lane); the next chunk: sums, scan, squares
     pre_w = uniform_f64(pre_w + cssm_u2d(readlane_u64(cssm_d2u(inc), 63)));
+    if (more) {
+#pragma unroll
+      for (int r = 0; r < CSSM_ITEMS; ++r) w1[r] = wn[r];
+      inc = wave_scan_f64((w1[0] + w1[1]) + (w1[2] + w1[3]));
+      squares(w1);
+    }
   }
   // ======== the block's partial of the observation's sum of squared weights: the waves meet through a ticket, the last one files it
   {
@@ -325,5 +305,44 @@ __global__ __attribute__((amdgpu_flat_work_group_size(CSSM_BLOCK, CSSM_BLOCK), a
       }
     }
   }
-  (void)pow2;
+  // ======== the chunks the loop left: the contract's predicate on the contract's sums for every particle of the chunk (wave-uniform;
+  //          2 eps x 256 of the chunks: 2^-11 at N = 2^24) -- nothing of the hot path is live any more
+  while (cold != 0u) {
+    const uint32_t c = (uint32_t)__builtin_ctz(cold);
+    cold &= cold - 1u;
+    const uint32_t base = w_lo + c * (uint32_t)(CSSM_TILE / 4);
+    cssm_u128 X = toff;                                        // exact: everything before the chunk's first particle
+    for (uint32_t b2 = w_lo; b2 < base; b2 += CSSM_TILE / 4) {
+      double v[CSSM_ITEMS];
+      load_chunk(b2, v);
+      cssm_u128 ts = cssm_u128_zero();
+#pragma unroll
+      for (int r = 0; r < CSSM_ITEMS; ++r) ts = cssm_u128_add(ts, cssm_fix_from_unit(v[r]));
+      X = u128_add_any(X, wave_sum_u128(ts));
+    }
+    load_chunk(base, w1);
+    cssm_u128 ts = cssm_u128_zero();
+#pragma unroll
+    for (int r = 0; r < CSSM_ITEMS; ++r) ts = cssm_u128_add(ts, cssm_fix_from_unit(w1[r]));
+    const cssm_u128 run0 = wave_excl_add_u128(wave_scan_u128(ts, (int)lane), X);
+    cssm_u128 tote; tote.lo = s_tot.lo; tote.hi = s_tot.hi;
+    const double totd = cssm_u128_to_double(tote);
+    uint32_t e[CSSM_ITEMS] = {0u, 0u, 0u, 0u};
+    offspring_exact_counts(run0, w1, 0xfu, totd, u, (uint64_t)n32, e);
+    uint32_t prev = dpp0<0x138 /* wave_shr:1 */, 0xf>(e[CSSM_ITEMS - 1]);
+    if (lane == 0u) {
+      prev = 0u;                                               // (the globally first particle)
+      if (base != 0u) {
+        const double z4[4] = {0.0, 0.0, 0.0, 0.0};
+        uint32_t p4[4] = {0u, 0u, 0u, 0u};
+        offspring_exact_counts(X, z4, 1u, totd, u, (uint64_t)n32, p4);
+        prev = p4[0];
+      }
+    }
+    uint32_t wb = (uint32_t)__builtin_amdgcn_readfirstlane((int)prev);
+    uint32_t we = (uint32_t)__builtin_amdgcn_readlane((int)e[CSSM_ITEMS - 1], 63);
+    we = (we > n32) ? n32 : we;
+    wb = (wb > we) ? we : wb;
+    fill_runs_wave<CSSM_OFF_SC1 != 0, false>(prev, e, base + lane * CSSM_ITEMS, wb, we, anc, 0u, n32 - 1u, s_slot + wid * CSSM_WAVE_CHUNK);
+  }
 }

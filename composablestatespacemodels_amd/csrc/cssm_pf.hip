@@ -90,6 +90,7 @@ static int alloc_handle(cssm_pf* pf) {
   { const char* e = getenv("CSSM_PEER_TIMEOUT_MS"); if (e && atof(e) > 0.0) pf->peer_wait_ticks = (unsigned long long)(atof(e) * 1e5); }
   { const char* e = getenv("CSSM_PEER_ALL_ROWS"); pf->peer_all_rows = e && e[0] == '1'; }
   { const char* e = getenv("CSSM_PEER_EAGER_ROWS"); if (e && atoll(e) >= 1) pf->peer_eager = atoll(e); }
+  { const char* e = getenv("CSSM_WAVE_SUMS"); if (e) pf->opt_wave = atoi(e) ? 1 : 0; }   // (A/B: the default of CSSM_OPT_WAVE_SUMS)
   { const char* e = getenv("CSSM_GRP_MIN_UNITS"); if (e && atoi(e) >= 1) pf->grp_min_units = (uint32_t)atoi(e); }   // (tests: small clouds through the group sums)
   HIP_TRY(hipDeviceGetAttribute(&pf->n_cus, hipDeviceAttributeMultiprocessorCount, pf->device));
   pf->stride = (size_t)((pf->n + CSSM_TILE - 1) / CSSM_TILE) * CSSM_TILE;   // rows start 16-B aligned

@@ -1,0 +1,69 @@
+"""-m gpu: k_offspring_wave (round 6: the resampling kernel that takes its waves' prefixes from the exact sums the propagate's waves left and
+runs the rest in fp64, CSSM_OPT_WAVE_SUMS) against k_offspring_self (every weight converted and scanned in 128 bits) and the oracle: the same
+bits -- ll after every observation, ESS, ancestors, clouds -- on whole and ragged clouds, one and several chunks per wave, both group-sum
+layouts, with every chunk forced through the exact path, across outlying observations (redone by the old kernels in place) and
+continued calls."""
+import numpy as np
+import pytest
+
+import cases
+from composablestatespacemodels_amd.filter import NativePf
+from oracle import oracle
+
+pytestmark = pytest.mark.gpu
+OPT_EXACT, OPT_WHOLE_TILES, OPT_WAVE_SUMS = 1, 6, 10
+
+
+def _run(model, n, t, y, has, wave, exact=0, whole=0, cut=None):
+    g = NativePf(model, n, cases.SEED)
+    g.set_option(OPT_WAVE_SUMS, wave); g.set_option(OPT_EXACT, exact)
+    if whole:
+        g.set_option(OPT_WHOLE_TILES, whole)
+    if cut is None:
+        ll, ll_t, ess, _ = g.run(t, y, has)
+    else:
+        _, a, b, _ = g.run(t[:cut], y[:cut], has[:cut])
+        ll, c, d = g.run_more(t[cut:], y[cut:], has[cut:])
+        ll_t, ess = np.concatenate([a, c]), np.concatenate([b, d])
+    out = (ll, ll_t, ess, g.ancestors(), g.particles())
+    g.close()
+    return out
+
+
+def _same(a, b, what):
+    assert a[0] == b[0], what
+    np.testing.assert_array_equal(a[1], b[1], err_msg=what)
+    np.testing.assert_array_equal(a[2], b[2], err_msg=what)
+    np.testing.assert_array_equal(a[3], b[3], err_msg=what)
+    np.testing.assert_array_equal(a[4], b[4], err_msg=what)
+
+
+@pytest.mark.parametrize("name,n,whole", [("c2_model", 64 * 1024, 1), ("c2_model", 65 * 1024 + 3, 1), ("c1_model", 200 * 1024 + 511, 1),
+                                          ("c3_model", 100 * 1024 + 1, 1), ("c2_model", 1 << 20, 0), ("c1_model", (1 << 20) + 1, 0)])
+def test_wave_sums_kernel_equals_the_128_bit_kernel_and_the_oracle(name, n, whole):
+    model = getattr(cases, name)()
+    t, y, has = cases.poisson_counts(9, missing=0.2)
+    y = y.copy(); y[5] = 70.0; has[5] = 1                      # an outlying observation: held, redone relative to the max, the series goes on
+    new = _run(model, n, t, y, has, 1, whole=whole, cut=4)
+    old = _run(model, n, t, y, has, 0, whole=whole, cut=4)
+    _same(new, old, "wave sums on / off")
+    for mode in (1, 2):                                       # every chunk through the contract's exact predicate
+        _same(_run(model, n, t, y, has, 1, exact=mode, whole=whole), new, f"exact mode {mode}")
+    o = oracle.OraclePf(model.descriptor(), n, cases.SEED)
+    ol, oll, oess, _ = o.filter(t, y, has)
+    assert new[0] == ol
+    np.testing.assert_array_equal(new[1], oll)
+    np.testing.assert_array_equal(new[2], oess)
+    np.testing.assert_array_equal(new[3], o.ancestors())
+    np.testing.assert_array_equal(new[4], o.particles())
+
+
+@pytest.mark.parametrize("name,n", [("c2_model", (3 << 20) + 777), ("c1_model", (1 << 22) + 12345), ("c1_model", 1 << 23), ("c2_model", (1 << 24) - 4097)])
+def test_wave_sums_kernel_equals_the_128_bit_kernel_at_large_sizes(name, n):
+    """Several chunks per wave (units of 2 .. 4 tiles), ragged last units, layout 2 of the group sums from 2^22 + 1 particles on."""
+    model = getattr(cases, name)()
+    t, y, has = cases.poisson_counts(6, missing=0.2)
+    new = _run(model, n, t, y, has, 1, cut=3)
+    _same(new, _run(model, n, t, y, has, 0, cut=3), "wave sums on / off")
+    _same(_run(model, n, t, y, has, 1, exact=1), new, "every chunk exact")
+    assert np.all(np.diff(new[3].astype(np.int64)) >= 0)
