@@ -90,7 +90,7 @@ static int alloc_handle(cssm_pf* pf) {
   { const char* e = getenv("CSSM_PEER_TIMEOUT_MS"); if (e && atof(e) > 0.0) pf->peer_wait_ticks = (unsigned long long)(atof(e) * 1e5); }
   { const char* e = getenv("CSSM_PEER_ALL_ROWS"); pf->peer_all_rows = e && e[0] == '1'; }
   { const char* e = getenv("CSSM_PEER_EAGER_ROWS"); if (e && atoll(e) >= 1) pf->peer_eager = atoll(e); }
-  { const char* e = getenv("CSSM_WAVE_SUMS"); if (e) pf->opt_wave = atoi(e) ? 1 : 0; }   // (A/B: the default of CSSM_OPT_WAVE_SUMS)
+  { const char* e = getenv("CSSM_WAVE_SUMS"); if (e) pf->opt_wave = atoi(e) == 2 ? 2 : (atoi(e) ? 1 : 0); }   // (A/B: the default of CSSM_OPT_WAVE_SUMS)
   { const char* e = getenv("CSSM_GRP_MIN_UNITS"); if (e && atoi(e) >= 1) pf->grp_min_units = (uint32_t)atoi(e); }   // (tests: small clouds through the group sums)
   HIP_TRY(hipDeviceGetAttribute(&pf->n_cus, hipDeviceAttributeMultiprocessorCount, pf->device));
   pf->stride = (size_t)((pf->n + CSSM_TILE - 1) / CSSM_TILE) * CSSM_TILE;   // rows start 16-B aligned
@@ -429,7 +429,10 @@ int cssm_launch_propagate(cssm_pf* pf, const StepRec* d_rec, double* pick_out, u
   // the array travels in the slot of the sums of squares, which these kernels leave to k_offspring): k_offspring_wave then needs neither
   // a conversion nor a 128-bit scan per weight (CSSM_OPT_WAVE_SUMS = 0: k_offspring_self as before)
   const bool want_ws = want_grp && geo == GEO_LOOP && !pf->sharded && batch == nullptr && pf->resampler == CSSM_RESAMPLE_SYSTEMATIC &&
-                       pf->obs_kind != CSSM_OBS_LGCP && pick_out == nullptr && pf->opt_wave != 0 && 4 * (size_t)pf->nunits <= (size_t)pf->s2_stride;
+                       pf->obs_kind != CSSM_OBS_LGCP && pick_out == nullptr && 4 * (size_t)pf->nunits <= (size_t)pf->s2_stride &&
+                       // (where it pays: units of several tiles -- clouds beyond 2^20 particles; the mapping costs the propagate 2.5-3 % and at
+                       //  one tile per unit the resampling kernel gains nothing back: same-box A/B of round 6; CSSM_OPT_WAVE_SUMS = 2 forces it)
+                       (pf->opt_wave == 2 || (pf->opt_wave != 0 && pf->sup >= 2u));
   if (want_ws) a.slot_set |= 0x2000;
   a.src2 = anc ? pf->src2 : nullptr; a.src2_stride = pf->src2_stride; a.n_split = pf->n_split; a.logtab = pf->d_logtab;
   a.chunk = chunk; a.do_sums = do_sums; a.subS = fine ? pf->fineS : pf->tileS; a.subS2 = want_ws ? pf->tileW : (fine ? pf->fineS2 : pf->tileS2);
@@ -1066,7 +1069,7 @@ extern "C" int cssm_pf_set_option(cssm_pf* pf, int option, int value) {
   if (option == CSSM_OPT_EXACT_OFFSPRING) { pf->opt_exact = (value == 2) ? 2 : (value ? 1 : 0); return CSSM_OK; }
   if (option == CSSM_OPT_FUSED_SUMS) { pf->opt_fused = value ? 1 : 0; return CSSM_OK; }
   if (option == CSSM_OPT_GROUP_SUMS) { pf->opt_grp = value ? 1 : 0; return CSSM_OK; }
-  if (option == CSSM_OPT_WAVE_SUMS) { pf->opt_wave = value ? 1 : 0; return CSSM_OK; }
+  if (option == CSSM_OPT_WAVE_SUMS) { pf->opt_wave = value == 2 ? 2 : (value ? 1 : 0); return CSSM_OK; }
   if (option == CSSM_OPT_LOOP_EVENTS) { pf->opt_events = value ? 1 : 0; return CSSM_OK; }
   if (option == CSSM_OPT_SPECIALISE) { pf->opt_spec = (value == 2) ? 2 : (value ? 1 : 0); return CSSM_OK; }
   if (option == CSSM_OPT_WHOLE_TILES) {   // launch geometry only: the arrays hold up to four sub-units per unit either way

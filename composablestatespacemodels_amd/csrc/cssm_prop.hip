@@ -104,7 +104,7 @@ int CSSM_CAT(cssm_prop_launch_d, CSSM_PROP_D)(const PropLaunch& a) {
   // every kernel that forms the sums adds to the group sums where bit 8 of the set argument asks for them (one block per unit: cssm_pf.hip)
   const int grp = (a.sums && a.do_sums && (a.slot_set & 0x100)) ? CSSM_PROP_LAUNCHED_GRP : 0;
   // ... and the single GPU's tile-after-tile launch stores its waves' sums where bit 13 asks for them (propagate_block: WR)
-  const int ws = (self && CSSM_PROP_SELF && a.sums && a.do_sums && a.one == 2 && (a.slot_set & 0x2000)) ? CSSM_PROP_LAUNCHED_WS : 0;
+  const int ws = (CSSM_PROP_WR != 0 && self && CSSM_PROP_SELF && a.sums && a.do_sums && a.one == 2 && (a.slot_set & 0x2000)) ? CSSM_PROP_LAUNCHED_WS : 0;
   if (self && CSSM_PROP_SELF && a.sums && a.one) {
     OneTile<D, IT>::go(a);
   } else if (self && CSSM_PROP_SELF) {

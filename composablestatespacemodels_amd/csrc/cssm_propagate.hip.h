@@ -17,6 +17,11 @@
 #ifndef CSSM_PROP_IT_LO
 #define CSSM_PROP_IT_LO 2
 #endif
+// 1 (default): the single GPU's tile-after-tile fused-sums launch gives every wave a contiguous quarter of its block's range (propagate_block);
+// 0 (A/B builds): the block-wide tiles of rounds 1-5 -- the host then never asks for the waves' sums and k_offspring_self resamples
+#ifndef CSSM_PROP_WR
+#define CSSM_PROP_WR 1
+#endif
 template <int D> struct PropItems { static constexpr int value = (D <= 2) ? CSSM_PROP_IT_LO : (D <= 8 ? CSSM_PROP_IT_MID : 1); };
 
 
@@ -92,7 +97,7 @@ __device__ __forceinline__ void propagate_range(
     const uint32_t range_lo, const uint32_t n, int do_sums_arg,
     double* __restrict__ pick_out, uint32_t pick_slot, unsigned char* s_stage, PropAcc& acc,
     const double* __restrict__ fsub = nullptr, const unsigned long long* pre_jp = nullptr, const cssm_u32x4* pre_blk = nullptr,
-    const uint32_t step_now = 0u) {
+    const uint32_t step_now = 0u, const bool wr_on = false) {
   // pre_jp (ONE): the tile's packed ancestor indices, already requested by the caller (before it staged the log table: one
   // dependent round trip less)
   // pre_blk (ONE, pairs): the Philox blocks of the first tile's pairs, drawn by the caller while those first loads travelled
@@ -123,8 +128,9 @@ __device__ __forceinline__ void propagate_range(
   bool bad = false;
   // tile indices are 32-bit (the library admits n <= 2^32 - 2^16 particles per handle): half the VALU work of 64-bit
   static_assert(!WR || ONE == 2, "wave ranges: the tile-after-tile instantiation");
-  constexpr uint32_t stride = (WR ? 64u : (uint32_t)CSSM_BLOCK) * IT;      // particles per tile (WR: of the wave)
-  const uint32_t tl = WR ? (threadIdx.x & 63u) : threadIdx.x;               // the thread's place in its tile
+  const bool wr = WR && wr_on;                                              // (uniform: the launch's choice, propagate_block)
+  const uint32_t stride = (wr ? 64u : (uint32_t)CSSM_BLOCK) * IT;           // particles per tile (wave ranges: of the wave)
+  const uint32_t tl = wr ? (threadIdx.x & 63u) : threadIdx.x;               // the thread's place in its tile
   // Software pipeline over the block's tiles WITHOUT spending registers on it.  With 4 waves per SIMD the two
   // dependent memory round trips of a tile (ancestor index -> gathered state) are exposed: a model with that
   // latency reproduces the 3.3 TB/s the un-pipelined kernel reached for every d, and holding the next tile in VGPRs
@@ -589,26 +595,30 @@ __device__ __forceinline__ void propagate_block(
   const uint32_t held = sc->err;          // (tested behind the table staging: its load then overlaps the table's)
   // WR (the single GPU's tile-after-tile launch with the fused sums): every WAVE owns a contiguous quarter of the block's range (see
   // propagate_range); bit 13 of the set argument: the waves' sums are wanted (subS2, unused by SUMS == 1, holds them: four per block)
-  constexpr bool WR = (ONE == 2 && SUMS == 1);
+  // The mapping is the LAUNCH's choice (the same bit): measured against the block-wide tiles it costs this kernel 2.5-3 % at every size
+  // (same-box A/B, round 6) and buys k_offspring 11-13 % from 2^21 particles on, nothing at 2^20 -- the host asks for it where it pays.
+  constexpr bool WR = CSSM_PROP_WR != 0 && (ONE == 2 && SUMS == 1);
   const bool wsum_on = WR && (slot_set_arg & 0x2000) != 0;
   uint32_t range_lo = blockIdx.x * (uint32_t)chunk;
   uint32_t n;
   { const uint64_t range_hi = (uint64_t)range_lo + chunk; n = (uint32_t)((range_hi < n_arg) ? range_hi : n_arg); }
-  if (WR) {
+  if (wsum_on) {
     const uint32_t qw = (uint32_t)(chunk >> 2);             // (the chunk is a whole number of tiles of 1024: a quarter is whole tiles of 64 IT)
     const uint32_t wlo = range_lo + (threadIdx.x >> 6) * qw;
     const uint32_t whi = ((uint64_t)wlo + qw < (uint64_t)n) ? wlo + qw : n;
-    range_lo = (wlo < n) ? wlo : n;                          // (a wave beyond the cloud's end: an empty range)
-    n = whi;
+    // (wave-uniform values the compiler cannot know to be uniform: into scalar registers, or the tile loop's bounds, bases and
+    //  addresses turn into vector arithmetic -- the first version of this mapping cost the kernel 4.5 % at N = 2^20 that way)
+    range_lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)((wlo < n) ? wlo : n));   // (a wave beyond the cloud's end: an empty range)
+    n = (uint32_t)__builtin_amdgcn_readfirstlane((int)whi);
   }
-  const uint32_t tl = WR ? (threadIdx.x & 63u) : threadIdx.x;
+  const uint32_t tl = wsum_on ? (threadIdx.x & 63u) : threadIdx.x;
   // ONE: the tile's ancestor indices are requested together with the log table -- they depend on nothing but the thread's
   // position (anc holds a whole number of tiles: a partial thread's pair stays inside it)
   unsigned long long jp_early = 0ull;
   if (ONE) {
     const uint32_t i0 = range_lo + tl * IT;
     // (WR: a wave whose range is empty may stand beyond the index buffer's last tile: it requests nothing)
-    const bool in_buf = !WR || range_lo < n;
+    const bool in_buf = !wsum_on || range_lo < n;
     if (IT == 2) jp_early = (anc && in_buf) ? *reinterpret_cast<const unsigned long long*>(anc + i0) : ((unsigned long long)i0 | ((unsigned long long)(i0 + 1u) << 32));
     else jp_early = (anc && in_buf) ? (unsigned long long)anc[i0] : (unsigned long long)i0;
   }
@@ -662,7 +672,7 @@ __device__ __forceinline__ void propagate_block(
   PropAcc acc;
   propagate_range<D, false, IT, OBS, SUMS, ONE, WR>(src, src_stride, anc, dst, dst_stride, logw, gid0, seed, rec, mk, src2, 0, n_split, tab,
                                                 range_lo, n, SUMS ? 1 : 0, SUMS ? pick_out : nullptr, pick_slot, s_stage, acc,
-                                                nullptr, ONE ? &jp_early : nullptr, EARLY ? blk_early : nullptr, step_now);
+                                                nullptr, ONE ? &jp_early : nullptr, EARLY ? blk_early : nullptr, step_now, wsum_on);
   PSTAMP(6);
   if (!rec->has_obs) return;
   double tmax = wave_max(acc.tmax);

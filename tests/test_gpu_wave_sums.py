@@ -16,7 +16,7 @@ OPT_EXACT, OPT_WHOLE_TILES, OPT_WAVE_SUMS = 1, 6, 10
 
 def _run(model, n, t, y, has, wave, exact=0, whole=0, cut=None):
     g = NativePf(model, n, cases.SEED)
-    g.set_option(OPT_WAVE_SUMS, wave); g.set_option(OPT_EXACT, exact)
+    g.set_option(OPT_WAVE_SUMS, 2 if wave else 0); g.set_option(OPT_EXACT, exact)   # (2: the mapping wherever the geometry allows, also at one tile per unit)
     if whole:
         g.set_option(OPT_WHOLE_TILES, whole)
     if cut is None:
