@@ -270,7 +270,7 @@ def run_single(args, emit=print):
         except Exception:
             traffic = None
     if not args.no_pmc and not lgcp:
-        live, why = live_traffic(n, args.model)
+        live, why = live_traffic(n, args.model, fused=args.fused)
         if live is not None:
             traffic, traffic_source = live, why
         else:
@@ -312,7 +312,7 @@ def run_single(args, emit=print):
     emit(json.dumps(out))
 
 
-def live_traffic(n, model, timeout_s=150.0):
+def live_traffic(n, model, timeout_s=150.0, fused=None):
     """HBM bytes per launch of the fused kernel, MEASURED in this run: two rocprofv3 passes (FETCH_SIZE, then WRITE_SIZE: the two do not fit
     one pass on gfx950) around a short child `bench.py` of the same workload, each with `--pmc <counter> --kernel-trace` only, from /tmp.
     Bytes = 2 x FETCH_SIZE + WRITE_SIZE (both reported in KiB): the factor 2 is the gfx950 correction of MI355X_MICROARCH.md (FETCH_SIZE
@@ -334,18 +334,21 @@ def live_traffic(n, model, timeout_s=150.0):
             out = os.path.join(work, counter)
             cmd = [exe, "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", out, "--", sys.executable, os.path.abspath(__file__),
                    "--steps", "20", "--warmup", "2", "--repeats", "1", "--particles", str(n), "--model", model,
-                   "--no-cpu", "--no-16m", "--no-generic", "--no-pmc"]
+                   "--no-cpu", "--no-16m", "--no-generic", "--no-pmc"] + ([] if fused is None else ["--fused", str(fused)])   # (the kernel variant that is timed)
             try:
                 r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, text=True, timeout=timeout_s)
             except subprocess.TimeoutExpired:
                 return None, f"the {counter} pass did not finish within {timeout_s:.0f} s"
             if r.returncode != 0:
                 return None, f"the {counter} pass exited with {r.returncode}: {r.stderr.strip().splitlines()[-1][:200] if r.stderr.strip() else ''}"
-            tot, cnt = 0.0, 0
+            # the launches of the child's TIMED leg only: its last 20 k_propagate_self launches in dispatch order (its warm-up and roofline
+            # legs come first; every launch moves the same bytes, the filter makes the average mean what it says)
+            vals = []
             for path in glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True):
-                for row in csv.DictReader(open(path)):
-                    if row["Counter_Name"] == counter and "k_propagate_self<" in row["Kernel_Name"]:
-                        tot += float(row["Counter_Value"]); cnt += 1
+                rows = [r for r in csv.DictReader(open(path)) if r["Counter_Name"] == counter and "k_propagate_self<" in r["Kernel_Name"]]
+                rows.sort(key=lambda r: int(r.get("Dispatch_Id", 0) or 0))
+                vals += [float(r["Counter_Value"]) for r in rows[-20:]]
+            tot, cnt = sum(vals), len(vals)
             if cnt == 0:
                 return None, f"the {counter} pass returned no k_propagate_self row"
             got[counter] = (tot / cnt, cnt)
@@ -534,6 +537,29 @@ def preflight(f, make_filter, t, y, has, lgcp, gpu, rank, world, stage_s):
     return usable[chosen], steps, chosen
 
 
+def _rccl_transports(rank):
+    """{peer: [transports RCCL chose for its channels to that peer]} from this process's NCCL_DEBUG_FILE ("... 0[0] -> 1[1] via P2P/IPC/read"),
+    or a reason.  Written while the communicators of the pre-flight were set up (torch's and the library's own)."""
+    import glob
+    import re
+    pat = os.environ.get("NCCL_DEBUG_FILE", "")
+    if not pat:
+        return {"error": "NCCL_DEBUG_FILE is not set"}
+    paths = glob.glob(pat.replace("%h", "*").replace("%p", str(os.getpid())))
+    if not paths:
+        return {"error": "RCCL wrote no debug file (NCCL_DEBUG overridden?)"}
+    via = {}
+    try:
+        for path in paths:
+            for ln in open(path, errors="replace"):
+                m = re.search(r"(\d+)\[\w+\] -> (\d+)\[\w+\].*? via (\S+)", ln)
+                if m and int(m.group(1)) == rank:
+                    via.setdefault(m.group(2), set()).add(m.group(3))
+    except OSError as e:
+        return {"error": repr(e)}
+    return {k: sorted(v) for k, v in sorted(via.items(), key=lambda kv: int(kv[0]))} or {"note": "no channel lines in RCCL's debug output"}
+
+
 def run_multi(args, emit=print):
     import torch
     import torch.distributed as dist
@@ -552,6 +578,12 @@ def run_multi(args, emit=print):
         local = local % max(torch.cuda.device_count(), 1)
     if gpu and not shared_gpu:
         torch.cuda.set_device(local)
+        # RCCL's own account of how it reaches every peer (xGMI P2P, PCIe, host shared memory, network) goes into a per-rank file and from
+        # there into the line (exchange.preflight_transport): one run then tells a link problem from a kernel problem.  INFO logging is
+        # written while communicators are set up, nothing per collective.
+        os.environ.setdefault("NCCL_DEBUG", "INFO")
+        os.environ.setdefault("NCCL_DEBUG_SUBSYS", "INIT,GRAPH,P2P")
+        os.environ.setdefault("NCCL_DEBUG_FILE", os.path.join("/tmp", f"cssm_rccl_{os.getppid()}_rank%h_%p.log"))
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
     else:   # rehearsals (tests): gloo -- with the test-only oracle shard on CPU, or (gloo-gpu) GPU shards
         dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -592,6 +624,7 @@ def run_multi(args, emit=print):
     # pre-flight: the protocol of the timed legs, agreed and cross-checked (peer-written -> RCCL issued by the library -> torch.distributed)
     f, walk, protocol = preflight(make_filter(), make_filter, t, y, has, lgcp, gpu, rank, world, stage_s)
     fallbacks = [f"{st['protocol']}: {st['why']}" for st in walk if not st["ok"]]
+    transport = _rccl_transports(rank) if (gpu and not shared_gpu) else None
     # the W warm-up observations START the sharded filter ...
     with _Deadline(stage_s, "warm-up series"):
         f.ll_filter(t[:Wn], y[:Wn], has[:Wn], lgcp=lgcp)
@@ -619,6 +652,8 @@ def run_multi(args, emit=print):
     # a pass of its own with HIP events around every kernel and every library-issued collective of this rank's stream (the
     # event records perturb the throughput figure): what a step is made of, per rank
     mine = {"rank": rank, "legs": plans}
+    if transport is not None:
+        mine["rccl_transport"] = transport
     if gpu:
         lo = Wn + R * K
         shard.profile(True)

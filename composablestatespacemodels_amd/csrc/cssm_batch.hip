@@ -328,13 +328,14 @@ extern "C" int cssm_pmmh_run_batched(cssm_pfb* b, const cssm_model_desc* desc, c
 // iteration i + 1 can be drawn and filtered before iteration i has decided: slot 0 filters iteration i's proposal, slot 1 iteration i + 1's
 // proposal from it, slot 2 iteration i + 1's proposal from the current parameters -- one batch, at N = 100 000 for little more than the
 // price of one filter (a single filter leaves most of the GPU idle) -- and the two decisions follow, the second on slot 1 or 2.  Output
-// identical to cssm_pmmh_run(seed), bit for bit; b holds at least three chains (further ones idle).  model/PMMH.scala:68-81,114-123.
+// identical to cssm_pmmh_run(seed), bit for bit, on its error paths too (a batch that fails is redone candidate by candidate, in the
+// sequential chain's order); b holds exactly three chains.  model/PMMH.scala:68-81,114-123.
 extern "C" int cssm_pmmh_run_speculative(cssm_pfb* b, const cssm_model_desc* desc, const double* theta0, size_t n_theta, double delta, const double* t,
                                          const double* y, const uint8_t* has, size_t T, uint64_t seed, size_t n_iters, double* ll, double* theta,
                                          int32_t* accepted, double* last_state) {
   if (!b || !desc || !theta0 || !ll || !theta || !accepted || !last_state) return fail(CSSM_EINVAL_ARG, "null argument");
   const int B = b->B, d = b->ch[0]->d;
-  if (B < 3) return fail(CSSM_EINVAL_ARG, "the speculative chain filters three candidates per batch: a batch of %d chains", B);
+  if (B != 3) return fail(CSSM_EINVAL_ARG, "the speculative chain filters exactly three candidates per batch: a batch of %d chains (further slots would re-filter a proposal for nothing)", B);
   // the chain itself (L) and one proposer per slot; all under the chain's seed -- the proposal of iteration `it` from parameters p is the
   // same numbers whoever draws it
   cssm_pmmh_chain* L = nullptr;
@@ -361,7 +362,21 @@ extern "C" int cssm_pmmh_run_speculative(cssm_pfb* b, const cssm_model_desc* des
       cssm_pmmh_chain_set_current(slot[(size_t)k], (next && k == 1) ? cssm_pmmh_chain_proposal(slot[0]) : cssm_pmmh_chain_current(L));
       descs[(size_t)k] = cssm_pmmh_chain_propose(slot[(size_t)k], next ? it + 1 : it, &keys[(size_t)k]);
     }
+    // the candidate the sequential chain would filter next, alone (every slot the same proposal): the fall-back where the batch failed for a
+    // reason that may belong to a candidate the chain never evaluates -- a speculative proposal whose parameters the library refuses, say
+    auto alone = [&](int k) -> int {
+      for (int j = 0; j < B; ++j) { descs[(size_t)j] = descs[(size_t)k]; keys[(size_t)j] = keys[(size_t)k]; }
+      const int r = cssm_pfb_filter(b, descs.data(), keys.data(), t, y, has, T, pll.data(), paths.data(), rcs.data());
+      if (r) return r;
+      pll[(size_t)k] = pll[0]; rcs[(size_t)k] = rcs[0];
+      if (k) memcpy(paths.data() + (size_t)k * (T + 1) * d, paths.data(), (T + 1) * (size_t)d * 8);
+      return CSSM_OK;
+    };
+    const cssm_model_desc* d1 = descs[1]; const cssm_model_desc* d2 = descs[2];
+    const uint64_t k1 = keys[1], k2 = keys[2];
+    bool batch_ok = true;
     rc = cssm_pfb_filter(b, descs.data(), keys.data(), t, y, has, T, pll.data(), paths.data(), rcs.data());
+    if (rc) { batch_ok = false; rc = alone(0); }               // (a failure of slot 0's own candidate fails again: the sequential chain's error)
     if (rc) break;
     double pl = 0.0;
     rc = used(0, &pl);
@@ -371,6 +386,11 @@ extern "C" int cssm_pmmh_run_speculative(cssm_pfb* b, const cssm_model_desc* des
     cssm_pmmh_chain_decide(L, it, pl, paths.data() + ((size_t)0 * (T + 1) + T) * d, &ll[it], theta + it * n_theta, &accepted[it], last_state + it * (size_t)d);
     if (!two) break;
     const int k = (cssm_pmmh_chain_accepted(L) > before) ? 1 : 2;
+    if (!batch_ok) {                                           // the batch never ran: the needed candidate of iteration it + 1 on its own
+      descs[1] = d1; descs[2] = d2; keys[1] = k1; keys[2] = k2;
+      rc = alone(k);
+      if (rc) break;
+    }
     rc = used(k, &pl);
     if (rc) break;
     cssm_pmmh_chain_set_proposal(L, cssm_pmmh_chain_proposal(slot[(size_t)k]));

@@ -922,9 +922,14 @@ RcclApi* rccl_api() {   // (distinct handles may be driven from different thread
 }
 static RcclApi* rccl_api_load() {
   static RcclApi api;
+  // CSSM_RCCL_LIB: the library to take the nccl* entry points from, by path -- a particular RCCL build, or (tests/test_gpu_rccl_loopback.py)
+  // a stand-in whose ranks are threads of one process, which drives this file's series loop at world > 1 on a single GPU
+  if (const char* e = getenv("CSSM_RCCL_LIB")) {
+    if (e[0]) { api.lib = dlopen(e, RTLD_NOW | RTLD_LOCAL); if (api.lib) api.path = e; else return nullptr; }
+  }
   // the copy already mapped into this process (the host's framework usually brings one: two RCCL instances side by side
   // would each keep their own topology and IPC state), else the ROCm installation's
-  if (FILE* maps = fopen("/proc/self/maps", "r")) {
+  if (FILE* maps = api.lib ? nullptr : fopen("/proc/self/maps", "r")) {
     char line[4096];
     while (!api.lib && fgets(line, sizeof line, maps)) {
       char* path = strchr(line, '/');

@@ -360,7 +360,9 @@ class Resampling:
         are already exponentiated.  This is the resampler its scaladoc DESCRIBES (:124-129), as a host ``Resample[A]``: particle i
         appears floor(n w_i / sum w) times, the remaining slots are drawn by multinomial resampling on the residual weights
         (cssm_resample_residual).  ``weights`` are w1 = exp(w - max), as for the other resamplers.  As a ``Filter`` argument it runs
-        through the host-resampler seam (cssm_pf_propagate / cssm_pf_adopt): there is no native in-filter kernel for it."""
+        through the host-resampler seam (cssm_pf_propagate / cssm_pf_adopt): there is no native in-filter kernel for it; the filter
+        keys its draws by (the filter's seed, the number of observations it has resampled), so a seeded Filter reproduces.  Called
+        directly with seed = None it takes a fresh seed, as the reference's unseeded generators would."""
         if len(particles) != len(weights):
             raise ValueError("particles and weights differ in length")
         if seed is None:
@@ -435,6 +437,7 @@ class _FilterBase:
         self.seed = seed
         self.device = device
         self._pf: Optional[NativePf] = None
+        self._host_step = 0
         if n_particles is not None:
             self._ensure(n_particles)
 
@@ -454,6 +457,7 @@ class _FilterBase:
     def initialiseState(self, particles: int, t0: float) -> PfState:
         pf = self._ensure(particles)
         pf.init(t0)
+        self._host_step = 0                                 # weighted observations resampled on the host since the cloud was drawn
         return self._state(t0, None, 0.0, particles)
 
     # ParticleFilter.scala:116-132 (FilterLgcp: :210-226)
@@ -478,7 +482,13 @@ class _FilterBase:
         mx = float(np.max(w))                              # :124
         w1 = np.exp(w - mx)                                # :125
         cols = [x1[:, i] for i in range(pf.n)]
-        new = self._host_resample(cols, w1)                # :126
+        if self._host_resample is Resampling.residualResampling:
+            # the residual extension draws its remainder from counter-based variates: keyed by the FILTER's seed and the observation's
+            # index like the three native resamplers, so that Filter(seed = ...) reproduces (unkeyed it took a fresh seed per step)
+            new = Resampling.residualResampling(cols, w1, seed=self.seed, step=self._host_step)
+        else:
+            new = self._host_resample(cols, w1)            # :126
+        self._host_step += 1
         if len(new) != pf.n:
             raise ValueError("the resampler must return as many particles as it was given")
         ll = s.ll + mx + math.log(float(np.sum(w1)) / pf.n)   # :127

@@ -641,7 +641,7 @@ int cssm_pmmh_run_batched(cssm_pfb* b, const cssm_model_desc* desc, const double
 /* (round 5) ONE chain at two iterations per batch: a batch of three filters holds iteration i's proposal and BOTH candidates for iteration
  * i + 1 (its proposal from iteration i's proposal, and from the current parameters): the proposals and filter keys are functions of
  * (seed, iteration, parameters) alone, so they can be drawn and filtered before iteration i has decided.  Output identical to
- * cssm_pmmh_run(seed), bit for bit; `b` holds at least three chains.  At N = 100 000 a single filter leaves most of the GPU idle: three
+ * cssm_pmmh_run(seed), bit for bit; `b` holds exactly three chains (a batch that fails is redone candidate by candidate in the sequential order: the same result on the error paths too).  At N = 100 000 a single filter leaves most of the GPU idle: three
  * cost little more than one (model/PMMH.scala:68-81). */
 int cssm_pmmh_run_speculative(cssm_pfb* b, const cssm_model_desc* desc, const double* theta0, size_t n_theta, double delta, const double* t,
                               const double* y, const uint8_t* has_obs, size_t T, uint64_t seed, size_t n_iters, double* ll, double* theta,

@@ -6,7 +6,7 @@ export TMPDIR=/tmp
 [ -n "$LIB" ] && export CSSM_PF_LIB=$R/composablestatespacemodels_amd/csrc/$LIB
 cd /tmp
 for c in WRITE_SIZE FETCH_SIZE; do
-  rocprofv3 --pmc $c --kernel-trace --output-format csv -d $R/gpurun_out/pmcw_${TAG}_$c -- python3 $R/bench.py --steps 60 --warmup 2 --no-cpu --no-16m --repeats 1 > $R/gpurun_out/pmcw_${TAG}_$c.log 2>&1
+  rocprofv3 --pmc $c --kernel-trace --output-format csv -d $R/gpurun_out/pmcw_${TAG}_$c -- python3 $R/bench.py --steps 60 --warmup 2 --no-cpu --no-16m --no-pmc --repeats 1 > $R/gpurun_out/pmcw_${TAG}_$c.log 2>&1
 done
 cd $R
 python3 - "$TAG" <<'PY'
