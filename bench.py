@@ -544,7 +544,7 @@ def _rccl_transports(rank):
     import re
     pat = os.environ.get("NCCL_DEBUG_FILE", "")
     if not pat:
-        return {"error": "NCCL_DEBUG_FILE is not set"}
+        return None
     paths = glob.glob(pat.replace("%h", "*").replace("%p", str(os.getpid())))
     if not paths:
         return {"error": "RCCL wrote no debug file (NCCL_DEBUG overridden?)"}
@@ -578,12 +578,9 @@ def run_multi(args, emit=print):
         local = local % max(torch.cuda.device_count(), 1)
     if gpu and not shared_gpu:
         torch.cuda.set_device(local)
-        # RCCL's own account of how it reaches every peer (xGMI P2P, PCIe, host shared memory, network) goes into a per-rank file and from
-        # there into the line (exchange.preflight_transport): one run then tells a link problem from a kernel problem.  INFO logging is
-        # written while communicators are set up, nothing per collective.
-        os.environ.setdefault("NCCL_DEBUG", "INFO")
-        os.environ.setdefault("NCCL_DEBUG_SUBSYS", "INIT,GRAPH,P2P")
-        os.environ.setdefault("NCCL_DEBUG_FILE", os.path.join("/tmp", f"cssm_rccl_{os.getppid()}_rank%h_%p.log"))
+        # (RCCL's own account of how it reaches every peer -- xGMI P2P, PCIe, host shared memory -- is read from NCCL_DEBUG_FILE where the CALLER
+        #  has switched it on: NCCL_DEBUG=INFO NCCL_DEBUG_SUBSYS=INIT,GRAPH,P2P NCCL_DEBUG_FILE=/tmp/rccl_%h_%p.log.  Not by default: with INFO
+        #  logging on, one timed leg in seven took 60-100 ms on the test box -- measured in round 6)
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
     else:   # rehearsals (tests): gloo -- with the test-only oracle shard on CPU, or (gloo-gpu) GPU shards
         dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -624,7 +621,7 @@ def run_multi(args, emit=print):
     # pre-flight: the protocol of the timed legs, agreed and cross-checked (peer-written -> RCCL issued by the library -> torch.distributed)
     f, walk, protocol = preflight(make_filter(), make_filter, t, y, has, lgcp, gpu, rank, world, stage_s)
     fallbacks = [f"{st['protocol']}: {st['why']}" for st in walk if not st["ok"]]
-    transport = _rccl_transports(rank) if (gpu and not shared_gpu) else None
+
     # the W warm-up observations START the sharded filter ...
     with _Deadline(stage_s, "warm-up series"):
         f.ll_filter(t[:Wn], y[:Wn], has[:Wn], lgcp=lgcp)
@@ -634,6 +631,11 @@ def run_multi(args, emit=print):
     # MEDIAN leg
     walls, plans = [], []
     ll = ess = None
+    # the collectives that bracket a leg, once, untimed: a communicator sets its channels up at its first use
+    dist.barrier()
+    warm = torch.zeros(1, dtype=torch.float64, device=dev)
+    dist.all_reduce(warm, op=dist.ReduceOp.MAX)
+    sync()
     for r in range(R):
         lo = Wn + r * K
         dist.barrier()
@@ -652,8 +654,8 @@ def run_multi(args, emit=print):
     # a pass of its own with HIP events around every kernel and every library-issued collective of this rank's stream (the
     # event records perturb the throughput figure): what a step is made of, per rank
     mine = {"rank": rank, "legs": plans}
-    if transport is not None:
-        mine["rccl_transport"] = transport
+    if gpu and not shared_gpu and os.environ.get("NCCL_DEBUG_FILE"):
+        mine["rccl_transport"] = _rccl_transports(rank)       # (read at the end: RCCL sets channels up lazily, at a communicator's first use)
     if gpu:
         lo = Wn + R * K
         shard.profile(True)
