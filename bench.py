@@ -667,6 +667,11 @@ def run_multi(args, emit=print):
         mine["collectives_per_observation"] = round(prof["collective"][1] / max(prof["k_propagate"][1], 1), 2)
         mine["note"] = "bracketed event times include ~2 us of event-record overhead per launch; a collective's time includes waiting for the slowest peer"
         if getattr(f, "last_peer", False):
+            # what ONE block per exchange launch spent polling its peers (the GPU's own clock; warm-up and timed legs): at world 1 a block
+            # waits for its own launch's header block, across GPUs the link and the peers' lateness show here and not in kernels_us
+            nx, hw, xw, rw = shard.wait_stats()
+            mine["peer_waits"] = {"exchanges": nx, "header_wait_us": hw and round(hw, 2), "expansion_block_header_wait_us": xw and round(xw, 2),
+                                  "rows_wait_us": rw and round(rw, 2)}
             # what went over the links: rows this rank wrote into its neighbours' windows -- per neighbour segment and observation the
             # eager rows (written at once) or, where more were needed, the needed ones; pre-flight and warm-up included
             nrows, nseg, beyond = shard.peer_rows()

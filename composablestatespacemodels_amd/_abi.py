@@ -113,6 +113,7 @@ SYMBOLS = [
     ("cssm_pf_shard_begin", C.c_int, [_h, _dp, _dp, _u8p, C.c_size_t]),
     ("cssm_pf_shard_continue", C.c_int, [_h, _dp, _dp, _u8p, C.c_size_t]),
     ("cssm_pf_shard_propagate_at", C.c_int, [_h, C.c_size_t, C.c_void_p]),
+    ("cssm_pf_shard_wait_stats", C.c_int, [_h, _u64p]),
     ("cssm_pf_shard_status", C.c_int, [_h, _dp, _i32p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.c_size_t]),
     ("cssm_pf_shard_want_path", C.c_int, [_h, C.c_int]),
     ("cssm_pf_shard_get_path", C.c_int, [_h, _dp, C.c_size_t]),

@@ -103,6 +103,12 @@ struct Scalars {
   // first instruction to completion word, without an event packet on the queue (cssm_pf_last_device_us)
   unsigned long long t_first;
   unsigned long long t_last;    // k_finish's own stamp (valid in the host's mirror only)
+  // (measurement, peer-written exchange) what ONE block of every exchange launch spent polling its peers, in ticks of the 100 MHz clock,
+  // summed since the cloud was drawn: the first offspring block for every rank's header words, the first expansion block for the header
+  // words and then for its neighbours' eager-rows flags; xwaits = exchanges counted.  One thread of one block adds per launch (launches of
+  // a stream follow each other): plain read-modify-write.  cssm_pf_shard_wait_stats; bench.py: per_rank.header_wait_us / rows_wait_us --
+  // at world 1 the time a block needs to see its OWN header block's words; across GPUs the link shows up here, not in kernels_us.
+  unsigned long long hdr_wait_ticks, xhdr_wait_ticks, rows_wait_ticks, xwaits;
 };
 
 // BATCHED independent filters (cssm_batch.hip: B clouds of one model structure -- the chains of a PMMH run, a pilot grid of

@@ -587,6 +587,15 @@ static int adopt_spec_impl(cssm_pf* pf, const double* recv_buf_dev, int rank, in
   return CSSM_OK;
 }
 
+extern "C" int cssm_pf_shard_wait_stats(cssm_pf* pf, uint64_t* out4) {
+  int rc = shard_check(pf);
+  if (rc) return rc;
+  if (!out4) return fail(CSSM_EINVAL_ARG, "null argument");
+  if (!pf->h_sc) return fail(CSSM_ESTATE, "no status has been read");
+  out4[0] = pf->h_sc->xwaits; out4[1] = pf->h_sc->hdr_wait_ticks; out4[2] = pf->h_sc->xhdr_wait_ticks; out4[3] = pf->h_sc->rows_wait_ticks;
+  return CSSM_OK;
+}
+
 // ll, ess and the sticky bits of a series run with the single-collective exchange: bit 2 (value 4) = some observation's
 // reference level was ruled out by the max, bit 3 (value 8) = a capacity miss that was not resumed.  Either bit means the
 // numbers are not the filter's (ShardedFilter moves on to its next plan); `need` (optional, T entries): diagnostics.

@@ -1173,6 +1173,8 @@ __device__ __forceinline__ void offspring_expand_spec_body(
     if (sc->err & (4u | 8u | 16u)) return;   // (on hold / void / a peer missing: nobody delivers, nobody waits)
     const double rec_ref = rec->ref;
     SpecHdrRegs hregs;
+    const bool xstamp = peer_flags != nullptr && blockIdx.x == blk0;   // (the first expansion block keeps the time of its waits: Scalars::xhdr_wait_ticks)
+    const unsigned long long tx0 = xstamp ? __builtin_amdgcn_s_memrealtime() : 0ull;
     if (peer_flags != nullptr) {
       if constexpr (GRP) {
         if (!peer_headers_ll(hregs, s_ll, s_late, peer_flags, peer_seq, wait_ticks, world)) {
@@ -1188,7 +1190,9 @@ __device__ __forceinline__ void offspring_expand_spec_body(
     }
     spec_store_headers(H, hregs, world, cap);
     if (optimistic && !(cssm_ref_choose(rec_ref, cssm_order_unkey(H.gkey)) == rec_ref)) return;
+    const unsigned long long tx1 = xstamp ? __builtin_amdgcn_s_memrealtime() : 0ull;
     if (!wait_rows()) return;
+    if (xstamp && threadIdx.x == 0) { sc->xhdr_wait_ticks += tx1 - tx0; sc->rows_wait_ticks += __builtin_amdgcn_s_memrealtime() - tx1; }
     expand_spec_body(H, blockIdx.x - blk0, (uint32_t)CSSM_SPEC_EXPAND_BLOCKS, recv, world, rank, cap, d, n_split, (uint64_t)slot_lo, (uint64_t)slot_hi, n_global, rec, anc, sc,
                      RS, seed, slot_set, peer_flags, peer_seq, eager);
     CSSM_SPEC_STAMP(3);
@@ -1206,10 +1210,12 @@ __device__ __forceinline__ void offspring_expand_spec_body(
     auto mid = [&](SpecTotals& tt) -> bool {
       SpecHdrRegs hregs;
       if (peer_flags != nullptr) {
+        const unsigned long long tw0 = (bidx == 0) ? __builtin_amdgcn_s_memrealtime() : 0ull;
         if (!peer_headers_ll(hregs, s_ll, s_late, peer_flags, peer_seq, wait_ticks, world)) {
           if (threadIdx.x == 0) { atomicOr(&sc->err, 16u); atomicMin(&sc->fail_step, rec->step); atomicOr(&sc->wait_code, 1u | (s_late & 0xff00u)); }
           return false;
         }
+        if (bidx == 0 && threadIdx.x == 0) { sc->hdr_wait_ticks += __builtin_amdgcn_s_memrealtime() - tw0; sc->xwaits += 1ull; }   // (Scalars::hdr_wait_ticks)
         CSSM_SPEC_STAMP(7);
       } else {
         hregs = spec_load_headers(recv, world, cap, d);

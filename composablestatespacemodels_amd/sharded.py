@@ -241,6 +241,15 @@ class GpuShard:
                                                  need.ctypes.data_as(C.POINTER(C.c_uint32)), T))
         return ll.value, ess.value, bits.value, need
 
+    def wait_stats(self):
+        """(exchanges counted, mean us the first offspring block waited for every rank's header words, mean us the first expansion block
+        waited for them, mean us it then waited for its neighbours' eager-rows flags) of the peer-written exchanges since the cloud was
+        drawn, as of the last status read (cssm_pf_shard_wait_stats: the GPU's own 100 MHz clock)."""
+        out = (C.c_uint64 * 4)()
+        _abi.check(self.lib.cssm_pf_shard_wait_stats(self._h, out))
+        n = int(out[0])
+        return (n,) + tuple((float(out[k]) * 1e-2 / n) if n else None for k in (1, 2, 3))
+
     def want_path(self, on: bool):
         _abi.check(self.lib.cssm_pf_shard_want_path(self._h, 1 if on else 0))
 

@@ -431,6 +431,13 @@ int cssm_pf_shard_result(cssm_pf* pf, double* ll_out, int32_t* ess_out);
  * observation's reference level out (run the series again with the exact exchange), 8: a capacity miss that was not resumed;
  * need[s] = rows observation s needed (diagnostics). */
 int cssm_pf_shard_begin(cssm_pf* pf, const double* t, const double* y, const uint8_t* has_obs, size_t T);
+/* (measurement) What one block of every exchange launch of the peer-written exchange spent polling its peers since the cloud was drawn, as of
+ * the last cssm_pf_shard_status: out4 = {exchanges counted, ticks the first offspring block waited for every rank's header words, ticks
+ * the first expansion block waited for them, ticks it then waited for its neighbours' eager-rows flags}; ticks of the GPU's constant
+ * 100 MHz clock.  At world 1 a block waits for its own launch's header block; across GPUs a slow link or a late peer shows up here and
+ * not in the kernels' durations.  bench.py reports the per-exchange means (per_rank.header_wait_us, rows_wait_us). */
+int cssm_pf_shard_wait_stats(cssm_pf* pf, uint64_t* out4);
+
 /* T MORE observations of the sharded filter that is already running -- what cssm_pf_ll_filter_more is to a single-GPU handle
  * (Flow.scan(init)(stepFilter) handed the next T elements, model/ParticleFilter.scala:163-166): no new cloud, the first time
  * increment from the handle's clock, record s of the call = observation (observations so far + s) of the filter.  Steps,
