@@ -157,6 +157,15 @@ def _roofline(name, d, n, avg_s, cnt, raw_s, pair_s, copy_gbs, note=None):
     return r
 
 
+def _offspring_roofline(n, per):
+    """The resampling kernel against the HBM roofline: SURVEY.md 8d's K_resample = read w1 (8 B) + write anc (4 B) = 12 B per particle."""
+    if "k_offspring" not in per:
+        return None
+    t = per["k_offspring"][0]
+    return {"kernel": "k_offspring_wave / k_offspring_self (unit prefix, end slots, ancestor runs, ll, sum of squares)", "algorithmic_bytes_per_particle": 12,
+            "avg_launch_us": t * 1e6, "achieved": 12 * n / t / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": 12 * n / t / 1e9 / HBM_PEAK_GBS}
+
+
 def run_single(args, emit=print):
     import torch  # first: its import takes long enough for the GPU clocks to idle down
     from composablestatespacemodels_amd.filter import NativePf
@@ -293,6 +302,7 @@ def run_single(args, emit=print):
         "roofline": roof,
         "roofline_generic": roof_generic,
         "kernels_us": kernels_us,
+        "roofline_resampling": _offspring_roofline(n, per),
         "device_ms_each": [x * 1e3 for x in devs],
         "device_ms_each_is": "per timed leg, the GPU's constant 100 MHz clock (s_memrealtime) at the first instruction of the leg's first kernel and in its closing kernel (cssm_pf_last_device_us): device time of the very legs wall_ms_each times, no event packets on the queue",
         "call_ms_each": [x * 1e3 for x in calls],
@@ -408,6 +418,7 @@ def roofline_16m(NativePf, copy_gbs, fused=None, K=24):
             r["step_us"] = loop_ms * 1e3 / K
             r["particle_steps_per_s"] = N_16M * K / (loop_ms * 1e-3)
             r["kernels_us"] = {k: v[0] * 1e6 for k, v in per.items()}
+            r["resampling_kernel"] = _offspring_roofline(N_16M, per)
             res[key + variant] = r
             pf.close()
     return res

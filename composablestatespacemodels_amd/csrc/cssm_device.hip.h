@@ -18,7 +18,7 @@
 //   k_offspring   unit prefix + totals (every block sums the <= 1K unit sums itself), ll and ess (:127-128), per tile
 //                 a DPP wave scan -> cumulative weight C_j -> end slot cnt(C_j); every particle writes its own run of
 //                 slots into anc (single GPU), or the end slots are kept for the exchange   model/Resampling.scala:36-58,69
-//   launch geometry (single GPU; LABNOTES_rounds1-3.md, section 5c): k_propagate_self<..., ONE> has no software pipeline -- everything
+//   launch geometry (single GPU; docs/history/LABNOTES_rounds1-3.md, section 5c): k_propagate_self<..., ONE> has no software pipeline -- everything
 //                 position-dependent requested in the first round of loads, the normals drawn while the gathered rows travel.
 //                 Clouds below 2^20 particles: ONE = 1, one tile per block, one pair of sums per block (k_offspring totals up to
 //                 4096 of them); from 2^20 on a block owns a whole unit of 1024 * k particles and runs the same body tile after

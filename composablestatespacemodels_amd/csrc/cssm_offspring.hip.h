@@ -90,7 +90,7 @@ __device__ __forceinline__ void offspring_exact_counts(cssm_u128 run0, const dou
   }
 }
 
-// Diagnostic build only (-DCSSM_OFF_STAMPS, tools/offspring_stamps.py): thread 0 of every block of k_offspring_self leaves the
+// Diagnostic build only (-DCSSM_OFF_STAMPS, tools/archive/offspring_stamps.py): thread 0 of every block of k_offspring_self leaves the
 // constant 100 MHz clock at eight points of the kernel in the (otherwise unused) cumulative-weights buffer.
 #ifdef CSSM_OFF_STAMPS
 #define CSSM_STAMP(k) do { if (SELF && threadIdx.x == 0 && cum_out) reinterpret_cast<unsigned long long*>(cum_out)[(size_t)(is_pub ? gridDim.x - 1u : ublk) * 8 + (k)] = __builtin_amdgcn_s_memrealtime(); } while (0)

@@ -506,7 +506,8 @@ static int launch_resample(cssm_pf* pf, const StepRec* d_rec, double* ll_t = nul
   const int ogrid = tgrid + 1;   // one block per unit + the publisher
 #define OFF_WAVE_ARGS pf->logw, pf->n, pf->sc, (const cssm_u128*)pf->tileS, (const cssm_u128*)pf->tileW, d_rec, pf->anc, pf->sup, pf->nunits, pf->wparity, \
                       ll_t, ess_t, rec_idx, pf->opt_exact, pf->s2buf, pf->s2_stride, s2_par, pf->gen
-#define OFF_GO(RS) do { if (optimistic && pf->last_grp && pf->last_ws && RS == CSSM_RESAMPLE_SYSTEMATIC) { \
+  static const bool no_offw = getenv("CSSM_NO_OFFW") != nullptr;   // (A/B: the wave-range propagate in front of k_offspring_self)
+#define OFF_GO(RS) do { if (optimistic && pf->last_grp && pf->last_ws && !no_offw && RS == CSSM_RESAMPLE_SYSTEMATIC) { \
                           if (pf->grp_layout == 2) hipLaunchKernelGGL((k_offspring_wave<2>), dim3(ogrid), dim3(CSSM_BLOCK), 0, pf->stream, OFF_WAVE_ARGS); \
                           else hipLaunchKernelGGL((k_offspring_wave<1>), dim3(ogrid), dim3(CSSM_BLOCK), 0, pf->stream, OFF_WAVE_ARGS); \
                         } else if (optimistic && pf->last_grp && pf->grp_layout == 2 && RS == CSSM_RESAMPLE_SYSTEMATIC) \
@@ -774,7 +775,7 @@ static int run_filter_once(cssm_pf* pf, const double* t, const double* y, const 
   *retry = false;
   if (!pf || !t || !y) return fail(CSSM_EINVAL_ARG, "null argument");
   if (T < 1) return fail(CSSM_EINVAL_ARG, "empty data (the reference's minBy throws on an empty Vector)");
-  // CSSM_CALL_TIMING=1: host-side phases of the call on stderr (tools/leg_overhead.py)
+  // CSSM_CALL_TIMING=1: host-side phases of the call on stderr (tools/archive/leg_overhead.py)
   static const bool timing = getenv("CSSM_CALL_TIMING") != nullptr;
   const auto tp0 = std::chrono::steady_clock::now();
   auto since = [&](std::chrono::steady_clock::time_point a) { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - a).count(); };

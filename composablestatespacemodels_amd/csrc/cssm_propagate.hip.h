@@ -41,7 +41,7 @@ template <int D> struct PropItems { static constexpr int value = (D <= 2) ? CSSM
 // that spill 41.2 us/step at N = 2^20 and 375 us at 2^24, 3 waves without it 41.9 and 383)
 template <int D, int SUMS = 0> struct PropWaves { static constexpr int value = (D <= 4) ? (SUMS ? CSSM_PROP_WAVES_SUMS : CSSM_PROP_WAVES_LO) : 3; };
 
-// Diagnostic build only (-DCSSM_PROP_STAMPS, tools/propagate_stamps.py): lane 0 of wave 0 of every block of the slim kernels leaves the
+// Diagnostic build only (-DCSSM_PROP_STAMPS, tools/archive/propagate_stamps.py): lane 0 of wave 0 of every block of the slim kernels leaves the
 // 100 MHz clock at the points marked PSTAMP (8 words per block).
 // (Measured with these stamps and dropped: s_setprio by phase -- first tile's normals 3, its arithmetic 2, second tile's normals 1, the
 //  rest 0 -- so that the waves of a SIMD, which the arbiter otherwise serves oldest first, progress together: they do (blocks done

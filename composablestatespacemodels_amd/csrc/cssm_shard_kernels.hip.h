@@ -200,7 +200,7 @@ __device__ __forceinline__ void spec_store_headers(SpecHeaders& H, const SpecHdr
     H.S2[threadIdx.x] = S2; H.key[threadIdx.x] = key;
     // the ranks' offsets, the totals and the largest key by the wave's scans, out of the registers (the ranks beyond `world` hold zeros).
     // (Thread 0 used to walk the ranks through LDS behind a barrier: 1.4 us from "headers seen" to "headers in LDS" at world 8 against 0.8
-    //  at world 1, in every block of the launch -- tools/exchange_stamps_local.py)
+    //  at world 1, in every block of the launch -- tools/archive/exchange_stamps_local.py)
     const int lane = (int)threadIdx.x;
     const cssm_u128 inc = wave_scan_u128(S, lane);
     cssm_u128 off; off.lo = inc.lo - S.lo; off.hi = inc.hi - S.hi - (inc.lo < S.lo ? 1ull : 0ull);
@@ -273,7 +273,7 @@ __global__ void k_peer_handshake(const PeerTable* __restrict__ peer, int world, 
 }
 
 #ifdef CSSM_OFF_STAMPS
-__device__ unsigned long long g_spec_stamps[2048 * 8];   // diagnostic build: clock stamps of the exchange kernels' blocks (tools/exchange_stamps.py)
+__device__ unsigned long long g_spec_stamps[2048 * 8];   // diagnostic build: clock stamps of the exchange kernels' blocks (tools/archive/exchange_stamps.py)
 #define CSSM_SPEC_STAMP(k) do { if (threadIdx.x == 0 && blockIdx.x < 2048) g_spec_stamps[blockIdx.x * 8 + (k)] = __builtin_amdgcn_s_memrealtime(); } while (0)
 #else
 #define CSSM_SPEC_STAMP(k) do { } while (0)
@@ -296,7 +296,7 @@ __global__ void k_peer_verify(const double* __restrict__ win0, int world, uint32
 // Four consecutive rows of a boundary block (one thread's) in 16-byte accesses: the states of particles p0 .. p0 + 3 (struct of arrays: two
 // loads per component), the rows (D states + the low word of the row's cumulative weight, 4 (D + 1) doubles in a row) and the four high
 // words.  The windows are fine-grained memory: every store is a transaction of its own on the way out, and 8 bytes at a time the 1024
-// rows of a tile took 4.5-5 us of the 11 between the launch's start and the eager rows' flag (tools/pack_stamps_local.py).  The caller
+// rows of a tile took 4.5-5 us of the 11 between the launch's start and the eager rows' flag (tools/archive/pack_stamps_local.py).  The caller
 // has checked that all three addresses are 16-byte aligned.
 template <int D>
 __device__ __forceinline__ void pack_rows4(const double* __restrict__ src, const size_t stride, const uint64_t p0, double* __restrict__ orow,
@@ -340,7 +340,7 @@ __device__ __forceinline__ void boundary_pack_block(const uint32_t bx, const uin
   // the same stream is to write
   // grp_set >= 0: k_propagate's blocks accumulated the sums (and sums of squares) of groups of 32 units in that set of Scalars::grp / grp2:
   // the header block totals 2 x 32 group sums in ONE wave instead of 2 x nsub unit sums in four (it is the head of the exchange's critical
-  // path: every offspring block of every rank waits for it -- 3.4 us from entry to flag at 1024 units, tools/exchange_stamps.py)
+  // path: every offspring block of every rank waits for it -- 3.4 us from entry to flag at 1024 units, tools/archive/exchange_stamps.py)
   // bx / gx / q: the block's place in a (gx, world) grid -- blockIdx.x, gridDim.x, blockIdx.y of k_boundary_pack; the merged
   // exchange + offspring kernel of the peer-written exchange hands its first gx * world blocks through here
   // pre_flag (merged kernel; else nullptr): the prefix block announces pre_out with the exchange number (agent-scope release)
@@ -367,7 +367,7 @@ __device__ __forceinline__ void boundary_pack_block(const uint32_t bx, const uin
   const uint32_t err_now = __hip_atomic_load(&sc->err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & (4u | 8u | 16u);
   const uint32_t fail_now = __hip_atomic_load(&sc->fail_step, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   // (asked where a block is about to store or to wait: the two loads are on their way from here, the wait for them is there -- asked here,
-  //  it stood a round trip in front of every other load of the block: 1.1 us, tools/pack_stamps_local.py)
+  //  it stood a round trip in front of every other load of the block: 1.1 us, tools/archive/pack_stamps_local.py)
   auto held = [&]() -> bool { return err_now != 0u && fail_now != 0xffffffffu && fail_now != rec->step; };
   const long long R = d + 1, HD = spec_hdr(d), seg = spec_seg(d, cap);
   double* oseg = peer ? peer->win[parity][q] + (size_t)rank * seg : out + (size_t)q * seg;
@@ -390,7 +390,7 @@ __device__ __forceinline__ void boundary_pack_block(const uint32_t bx, const uin
   auto rows_done = [&](const bool extra) {
     if (peer == nullptr) return;
     // every wave waits for its stores to have left it, the block meets, and ONE wave fences at system scope (a fence is a write-back of
-    // the XCD's L2: four waves each issuing their own stood 1.7-2.4 us between the last row and the ticket, tools/pack_stamps_local.py)
+    // the XCD's L2: four waves each issuing their own stood 1.7-2.4 us between the last row and the ticket, tools/archive/pack_stamps_local.py)
     __builtin_amdgcn_s_waitcnt(0);
     __syncthreads();
     if (threadIdx.x == 0) __threadfence_system();
@@ -408,7 +408,7 @@ __device__ __forceinline__ void boundary_pack_block(const uint32_t bx, const uin
           //  "every block's rows, then the flag" across a link has never run on two physical GPUs: the memory model's guarantee, not
           //  an argument about when stores are acknowledged, is what a reader on another GPU gets)
           __hip_atomic_store(f + CSSM_PEER_FLAG_ROWS, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-          CSSM_SPEC_STAMP(3);   // (diagnostic build: a pack block that set a destination's ROWS flag -- tools/pack_stamps_local.py)
+          CSSM_SPEC_STAMP(3);   // (diagnostic build: a pack block that set a destination's ROWS flag -- tools/archive/pack_stamps_local.py)
         }
       } else {
         unsigned int* tk = tickets + CSSM_PEER_TICKET_EXTRA;
@@ -881,7 +881,7 @@ __device__ __forceinline__ bool spec_read_headers(SpecHeaders& H, int world, int
   if ((int)threadIdx.x < 4 * world) {
     // (ONE call of count_of for the four kinds: the exact count is a chain of dependent fp64 operations -- a division among them -- and the
     //  four arms of a switch ran one after the other in the block's first wave: 4.3 us from headers to verdict at world 2, on the path of
-    //  the launch's last block, tools/exchange_stamps_local.py; the arms now only choose the cumulative weight)
+    //  the launch's last block, tools/archive/exchange_stamps_local.py; the arms now only choose the cumulative weight)
     const int r = (int)(threadIdx.x >> 2), which = (int)(threadIdx.x & 3);
     const int rr = (which == 2) ? r - 1 : ((which == 3) ? r + 1 : r);
     const bool valid = rr >= 0 && rr < world;
@@ -953,7 +953,7 @@ __device__ __forceinline__ void spec_clear_sets(Scalars* __restrict__ sc, const 
 }
 // The received rows are expanded by blocks of their own, the first CSSM_SPEC_EXPAND_BLOCKS behind the pack blocks: reading a window costs
 // system-scope loads, and an offspring block that expanded its share of the rows behind its own particles ran 5-6 us longer for it
-// (in-process shards, 2^20 particles each, tools/expand_cost.py: 11.7 -> 17-17.9 us) -- invisible at world 1, where there are no rows.
+// (in-process shards, 2^20 particles each, tools/archive/expand_cost.py: 11.7 -> 17-17.9 us) -- invisible at world 1, where there are no rows.
 // These blocks wait for the headers like every block, then for the neighbours' eager rows, and are done before the offspring blocks are.
 #define CSSM_SPEC_EXPAND_BLOCKS 64
 __device__ __forceinline__ void expand_spec_body(SpecHeaders& H, uint32_t bid, uint32_t nblk, const double* __restrict__ recv, int world, int rank,

@@ -249,7 +249,7 @@ int cssm_pf_stream_idle(cssm_pf* pf);
  * blocks' sums into <= 1024 unit sums (d >= 4).  1 / 2 / 3 force that geometry at every size: the kernels of the large
  * clouds can then be checked against the oracle at sizes the oracle finishes in seconds.
  * (Options 4 and 5 of rounds 1-2 -- a persistent one-launch-per-series kernel and a one-launch-per-observation kernel, both
- * bit-identical and both measured slower than two launches per observation -- were removed in round 3; LABNOTES_rounds1-3.md (sections 5b-5c) keeps
+ * bit-identical and both measured slower than two launches per observation -- were removed in round 3; docs/history/LABNOTES_rounds1-3.md (sections 5b-5c) keeps
  * the record, git history the code.) */
 #define CSSM_OPT_WHOLE_TILES 6
 /* CSSM_OPT_GROUP_SUMS (default 1; a verification switch: results are bit-identical either way).  Where k_propagate runs one

@@ -6,7 +6,7 @@ Build (in composablestatespacemodels_amd/csrc, after `make`):
     mkdir -p build_stamps
     hipcc -O3 -std=c++17 -fPIC -ffp-contract=off -mfma --offload-arch=gfx950 -Wno-unused-function -DCSSM_OFF_STAMPS -c -o build_stamps/shard.o cssm_shard.hip
     hipcc -O3 -fPIC --offload-arch=gfx950 -shared -o build_stamps/libcssm_pf_stamps.so build/pf.o build_stamps/shard.o build/batch.o build/model.o build/rtc.o build/prop_d*.o -ldl
-Run:   CSSM_PF_LIB=.../build_stamps/libcssm_pf_stamps.so python tools/exchange_stamps.py [N] [lgcp]
+Run:   CSSM_PF_LIB=.../build_stamps/libcssm_pf_stamps.so python tools/archive/exchange_stamps.py [N] [lgcp]
 Stamps (100 MHz): pack blocks -- 4 header block entered, 5 header written + flag released, 6 unit-sum prefixes written + announced;
 offspring blocks -- 0 entry, 7 all flags seen, 1 headers in LDS + level checked, 2 own ancestors written, 3 received rows expanded."""
 import ctypes as C
@@ -15,7 +15,7 @@ import sys
 
 import numpy as np
 
-R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+R = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, R); sys.path.insert(0, os.path.join(R, "tests"))
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402

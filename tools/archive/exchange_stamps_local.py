@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Clock stamps of the adopt launch (k_offspring_expand_spec, the peer-written exchange in stages) of the LAST of `world` in-process shards:
-where a shard WITH a neighbour spends its time against world 1.  Diagnostic build as in tools/exchange_stamps.py (-DCSSM_OFF_STAMPS).
-Run:   CSSM_PF_LIB=.../build_stamps/libcssm_pf_stamps.so python tools/exchange_stamps_local.py [world=2] [particles per shard=1048576]
+where a shard WITH a neighbour spends its time against world 1.  Diagnostic build as in tools/archive/exchange_stamps.py (-DCSSM_OFF_STAMPS).
+Run:   CSSM_PF_LIB=.../build_stamps/libcssm_pf_stamps.so python tools/archive/exchange_stamps_local.py [world=2] [particles per shard=1048576]
 Stamps (100 MHz): 0 entry, 7 all headers seen, 1 headers in LDS + level checked, 2 own ancestors written (offspring blocks) / 3 rows expanded
 (the 64 expansion blocks that lead the grid)."""
 import ctypes as C
@@ -10,7 +10,7 @@ import sys
 
 import numpy as np
 
-R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+R = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, R); sys.path.insert(0, os.path.join(R, "tests"))
 import cases  # noqa: E402
 from composablestatespacemodels_amd import _abi  # noqa: E402

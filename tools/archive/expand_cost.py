@@ -3,7 +3,7 @@ stages: pack / pack rows / adopt, tests/local_comm.py), every launch bracketed b
 middle shard (two neighbours) against the same launch at world 1 (no neighbour, no rows).  Bench workload (C2).
 usage: expand_cost.py [world=4] [particles per shard=1048576] [observations=200] [lgcp]   (lgcp: BASELINE configs[3] instead of the bench workload)"""
 import os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, ROOT + "/tests")
 import numpy as np, cases
 from composablestatespacemodels_amd.sharded import GpuShard, ShardedFilter

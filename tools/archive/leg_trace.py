@@ -1,4 +1,4 @@
-"""Per-position kernel times inside short continued legs, from a rocprofv3 --kernel-trace CSV of tools/leg_overhead.py:
+"""Per-position kernel times inside short continued legs, from a rocprofv3 --kernel-trace CSV of tools/archive/leg_overhead.py:
 usage  leg_trace.py <kernel_trace.csv> [K]   -- prints, for step index 0 .. K-1 of a leg, the median duration of k_propagate and
 k_offspring and the median gap before them (a leg = the kernels between two k_finish launches)."""
 import csv, sys, statistics, re

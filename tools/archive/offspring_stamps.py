@@ -6,7 +6,7 @@ Build (in composablestatespacemodels_amd/csrc, after `make`):
     hipcc -O3 -std=c++17 -fPIC -ffp-contract=off -mfma --offload-arch=gfx950 -DCSSM_OFF_STAMPS -c -o build_stamps/pf.o cssm_pf.hip
     hipcc -O3 -fPIC --offload-arch=gfx950 -shared -o build_stamps/libcssm_pf_stamps.so build_stamps/pf.o build/shard.o build/model.o build/prop_d*.o
 Run on the GPU box:
-    CSSM_PF_LIB=composablestatespacemodels_amd/csrc/build_stamps/libcssm_pf_stamps.so python tools/offspring_stamps.py [N]
+    CSSM_PF_LIB=composablestatespacemodels_amd/csrc/build_stamps/libcssm_pf_stamps.so python tools/archive/offspring_stamps.py [N]
 
 Stamps (100 MHz constant clock, 10 ns): 0 kernel entry, 1 behind the unit-sum scan (first loads have landed, one barrier),
 2 weights on the 2^-96 grid + wave scan done, 3 behind the tile's barrier, 4 end slots known, 5 ancestors assembled and
@@ -18,8 +18,8 @@ import sys
 
 import numpy as np
 
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests"))
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "..", "tests"))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
 import cases  # noqa: E402
 from composablestatespacemodels_amd import _abi  # noqa: E402
 from composablestatespacemodels_amd.filter import NativePf  # noqa: E402
@@ -64,7 +64,7 @@ def main():
     print("  behind-scan time by XCD (block %% 8): " + " ".join("%.2f" % np.median(late[x::8]) for x in range(8)))
     q = len(late) // 8
     print("  behind-scan time by block index octile: " + " ".join("%.2f" % np.median(late[i * q:(i + 1) * q]) for i in range(8)))
-    np.save(os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "gpurun_out", "stamps.npy"), s)
+    np.save(os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "..", "gpurun_out", "stamps.npy"), s)
     print("  publisher: entry %.2f, behind scan %.2f, done %.2f" % ((pub[0] - t0) * 0.01, (pub[1] - t0) * 0.01, (pub[7] - t0) * 0.01))
     g.close()
 

@@ -1,15 +1,15 @@
 #!/usr/bin/env python3
 """When the eager rows' flag leaves: clock stamps of the pack launch (headers + eager rows) of a MIDDLE shard of `world` in-process shards --
 per destination, the block that set the ROWS flag against the header block's "header + flag out".  The last observation is driven stage by
-stage so that the middle shard's pack launch is the last one before the stamps are read.  Diagnostic build as tools/exchange_stamps.py.
-Run:   CSSM_PF_LIB=.../build_stamps/libcssm_pf_stamps.so python tools/pack_stamps_local.py [world=8] [particles per shard=1048576]"""
+stage so that the middle shard's pack launch is the last one before the stamps are read.  Diagnostic build as tools/archive/exchange_stamps.py.
+Run:   CSSM_PF_LIB=.../build_stamps/libcssm_pf_stamps.so python tools/archive/pack_stamps_local.py [world=8] [particles per shard=1048576]"""
 import ctypes as C
 import os
 import sys
 
 import numpy as np
 
-R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+R = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, R); sys.path.insert(0, os.path.join(R, "tests"))
 import cases  # noqa: E402
 from composablestatespacemodels_amd import _abi  # noqa: E402

@@ -2,7 +2,7 @@
 thread: a single chain (cssm_pmmh_run) against B chains in lockstep whose filters run as one batch (cssm_pmmh_run_batched).
 usage: pmmh_batched.py [iters=20] [B list, comma separated = 1,2,4,8]"""
 import os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, ROOT + "/tests")
 import numpy as np, cases
 from composablestatespacemodels_amd.model import TimedObservation

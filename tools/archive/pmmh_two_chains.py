@@ -2,7 +2,7 @@
 Each chain is a handle of its own on a stream of its own, driven from its own thread; at N = 100 000 a filter step is
 launch-latency bound, so the chains overlap on the GPU.  Run on the GPU box."""
 import os, sys, threading, time
-R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+R = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, R); sys.path.insert(0, os.path.join(R, "tests"))
 import cases
 from composablestatespacemodels_amd import Data

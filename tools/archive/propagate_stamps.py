@@ -7,7 +7,7 @@ Build (in composablestatespacemodels_amd/csrc, after `make`):
     hipcc -O3 -fPIC --offload-arch=gfx950 -shared -o build_stamps/libcssm_pf_pstamps.so build/pf.o build/shard.o build/model.o \
         build_stamps/prop_d3.o $(ls build/prop_d*.o | grep -v 'prop_d3\\.o')
 Run on the GPU box:
-    CSSM_PF_LIB=composablestatespacemodels_amd/csrc/build_stamps/libcssm_pf_pstamps.so python tools/propagate_stamps.py [N]
+    CSSM_PF_LIB=composablestatespacemodels_amd/csrc/build_stamps/libcssm_pf_pstamps.so python tools/archive/propagate_stamps.py [N]
 
 Stamps (100 MHz constant clock, 10 ns), wave 0 of every block: 0 kernel entry, 1 behind the table's barrier (first loads landed, the
 first tile's Philox blocks drawn), 2 the first tile's normals drawn (its rows were requested before them), 3 its rows landed,
@@ -20,8 +20,8 @@ import sys
 
 import numpy as np
 
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests"))
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "..", "tests"))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
 import cases  # noqa: E402
 from composablestatespacemodels_amd import _abi  # noqa: E402
 from composablestatespacemodels_amd.filter import NativePf  # noqa: E402

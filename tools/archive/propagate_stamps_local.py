@@ -1,14 +1,14 @@
 #!/usr/bin/env python3
 """Clock stamps of k_propagate_shard of the LAST of `world` in-process shards (a shard that gathers rows its neighbour wrote) against
-world 1: which blocks finish last.  Diagnostic build as in tools/propagate_stamps.py (-DCSSM_PROP_STAMPS -DCSSM_PROP_D=3).
-Run:   CSSM_PF_LIB=.../build_stamps/libcssm_pf_pstamps.so python tools/propagate_stamps_local.py [world=2] [particles per shard=1048576]"""
+world 1: which blocks finish last.  Diagnostic build as in tools/archive/propagate_stamps.py (-DCSSM_PROP_STAMPS -DCSSM_PROP_D=3).
+Run:   CSSM_PF_LIB=.../build_stamps/libcssm_pf_pstamps.so python tools/archive/propagate_stamps_local.py [world=2] [particles per shard=1048576]"""
 import ctypes as C
 import os
 import sys
 
 import numpy as np
 
-R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+R = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, R); sys.path.insert(0, os.path.join(R, "tests"))
 import cases  # noqa: E402
 from composablestatespacemodels_amd import _abi  # noqa: E402

@@ -3,7 +3,7 @@ are more), against the capacity of a boundary block (what CSSM_PEER_ALL_ROWS=1 s
 needed: `world` shards of ONE process on this GPU (tests/local_comm.py), the bench workload (C2).  CSSM_PEER_EAGER_ROWS=1 shows the bare need.
 usage: rows_sent.py [world=8] [particles per shard=1048576] [observations=100]"""
 import os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, ROOT + "/tests")
 import numpy as np, cases
 from composablestatespacemodels_amd.sharded import GpuShard, ShardedFilter

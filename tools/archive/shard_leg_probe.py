@@ -2,7 +2,7 @@
 """Host-side anatomy of a continued K-observation leg of the sharded filter at world = 1 (bench.py --sharded --steps K): wall time of the
 leg against K x the steady-state step, and the host time of the three library calls a leg is made of.  usage: shard_leg_probe.py [K] [N]"""
 import os, sys, time
-R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+R = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, R); sys.path.insert(0, os.path.join(R, "tests"))
 import numpy as np
 import torch, torch.distributed as dist, cases

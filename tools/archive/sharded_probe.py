@@ -1,6 +1,6 @@
 """Time the sharded (RCCL) code path at world = 1 against the single-GPU path (run on the GPU box)."""
 import os, sys, time
-R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+R = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, R); sys.path.insert(0, os.path.join(R, "tests"))
 import torch, torch.distributed as dist, cases
 from composablestatespacemodels_amd.sharded import DistComm, GpuShard, ShardedFilter

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Where k_offspring_expand_spec's time goes (sharded single-collective step, one rank): clock stamps of a diagnostic build.
 
-Build: as tools/offspring_stamps.py says, with cssm_shard.hip compiled -DCSSM_OFF_STAMPS into build_stamps/shard.o.
+Build: as tools/archive/offspring_stamps.py says, with cssm_shard.hip compiled -DCSSM_OFF_STAMPS into build_stamps/shard.o.
 Run:   CSSM_PF_LIB=.../build_stamps/libcssm_pf_stamps.so python tools/spec_stamps.py
 Stamps (100 MHz): 0 entry, 1 level + headers' verdict known, 2 own particles' ancestors written, 3 received rows expanded."""
 import ctypes as C

@@ -5,7 +5,7 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 export TMPDIR=/tmp
 export PROBE_FIXED_ONLY=1
 cd /tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/stats_sh_${TAG} -- python3 $R/tools/sharded_probe.py 1048576 > $R/gpurun_out/stats_sh_${TAG}.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/stats_sh_${TAG} -- python3 $R/tools/archive/sharded_probe.py 1048576 > $R/gpurun_out/stats_sh_${TAG}.log 2>&1
 cd $R
 f=$(find gpurun_out/stats_sh_${TAG} -name '*kernel_stats.csv' | head -1)
 python3 - "$f" <<'PY'

@@ -1,6 +1,6 @@
 """Wall time of one streaming step (cssm_pf_step: record up, two kernels, ll / ess back, one synchronisation): usage stream_latency.py"""
 import sys, os, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, ROOT + "/tests")
 import numpy as np, cases
 from composablestatespacemodels_amd.filter import NativePf
