@@ -86,7 +86,9 @@ __global__ __attribute__((amdgpu_flat_work_group_size(CSSM_BLOCK, CSSM_BLOCK), a
       for (int r = 0; r < CSSM_ITEMS; ++r) v[r] = (i0 + r < n32) ? logw[i0 + r] : 0.0;
     }
   };
+#ifdef CSSM_OFFW_WEIGHTS_FIRST
   if (!is_pub) load_chunk(w_lo, w1);
+#endif
   // the sums one wave scans for the block (which wave: round-robin over the blocks, as in k_offspring_self)
   const uint32_t wsum = (bidx + 1u) & 3u, wsum2 = (bidx + 2u) & 3u, wkey = bidx & 3u;
   const uint32_t grp_unit = is_pub ? 0u : ublk;
@@ -111,6 +113,11 @@ __global__ __attribute__((amdgpu_flat_work_group_size(CSSM_BLOCK, CSSM_BLOCK), a
   // the quarter units before this wave's (lanes 0 .. 3 hold the unit's four; one 64-byte line)
   cssm_u128 wq = cssm_u128_zero();
   if (!is_pub) wq = unitW[(size_t)ublk * 4u + (lane & 3u)];
+  // ... and only then the wave's first 256 weights: a wave's loads come back in the order they were issued, and the block's critical
+  // path is its sums' wave (loads -> 128-bit scan -> LDS -> the barrier every wave waits at)
+#ifndef CSSM_OFFW_WEIGHTS_FIRST
+  if (!is_pub) load_chunk(w_lo, w1);
+#endif
   const double rec_ref = rec->ref, u = rec->u;
   const uint32_t rec_step = rec->step;
   if (wid == wkey) {                                           // the running max: lane t reads slot t
