@@ -67,3 +67,20 @@ def test_wave_sums_kernel_equals_the_128_bit_kernel_at_large_sizes(name, n):
     _same(new, _run(model, n, t, y, has, 0, cut=3), "wave sums on / off")
     _same(_run(model, n, t, y, has, 1, exact=1), new, "every chunk exact")
     assert np.all(np.diff(new[3].astype(np.int64)) >= 0)
+
+
+@pytest.mark.parametrize("yout", [55.0, 60.0, 64.0])
+def test_wave_sums_kernel_on_a_level_far_above_the_max(yout):
+    """An observation whose reference level sits 20-32 above the largest log-weight is ACCEPTED (cssm_ref_choose): every weight is tiny, S_tot a
+    few powers of two above its floor -- the case the fp64 prefixes' error band widens for (eps = N (2^-44 + 2 q 2^-96 / S_tot))."""
+    model = cases.c2_model()
+    n = 70 * 1024 + 5
+    t, y, has = cases.poisson_counts(8)
+    y = y.copy(); y[4] = yout; has[4] = 1
+    new = _run(model, n, t, y, has, 1, whole=1)
+    _same(new, _run(model, n, t, y, has, 0, whole=1), "wave sums on / off")
+    o = oracle.OraclePf(model.descriptor(), n, cases.SEED)
+    ol, oll, oess, _ = o.filter(t, y, has)
+    assert new[0] == ol
+    np.testing.assert_array_equal(new[2], oess)
+    np.testing.assert_array_equal(new[3], o.ancestors())
