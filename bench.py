@@ -183,7 +183,7 @@ def run_single(args, emit=print):
             h.set_option(3, args.fused)   # CSSM_OPT_FUSED_SUMS (experiment switch; the default is the library's)
         return h
 
-    def timed_legs():
+    def timed_legs(timed_pf=None):
         """The figure of merit: W untimed warm-up steps start a filter (initial cloud, allocations) and the timed leg CONTINUES it: R legs
         of exactly K more steps each (cssm_pf_ll_filter_more: no new cloud, the series goes on), every leg bracketed by a device
         synchronisation on both sides; the figure is the MEDIAN leg.  A leg is the whole host call: records built and sent, 2 K launches
@@ -191,7 +191,7 @@ def run_single(args, emit=print):
         stores behind the K steps' results; the closing torch.cuda.synchronize() then waits for the runtime to see that kernel's completion
         signal -- measured in round 6: hipStreamQuery still says "not ready" when the call returns, the end-of-kernel release of the closing
         kernel is what the synchronise waits 4-6 us for) and the DEVICE time of the leg from the GPU's own clock."""
-        pf = handle()
+        pf = timed_pf if timed_pf is not None else handle()
         torch.cuda.synchronize()
         pf.run(t[:W], y[:W], has[:W])
         walls, devs, calls, idle = [], [], [], []
@@ -255,18 +255,27 @@ def run_single(args, emit=print):
             ga, gc, gr = gper["k_propagate"]
             roof_generic = _roofline(f"k_propagate<{pf.d},...> reading the model's structure as data (CSSM_OPT_SPECIALISE = 0), N={n}", pf.d, n, ga, gc, gr, gpair, None)
             roof_generic["step_us"] = float(np.median(gl)) * 1e3 / K
-        pf.close()
+        keep.append(pf)                  # (closed behind the timed legs: a hipFree is a device synchronisation and an idle gap)
         return copy_gbs, loop_ms, per, pair_s, roof_generic
 
     # Order: the roofline legs FIRST.  W = 5 warm-up steps are 0.1 ms of device work, and the legs of a process that has kept the GPU busy
     # for a few ms in all run 5-15 % slower than every later one (leg after leg of the same handle: 522 493 461 465 468 ... 445 us, level
     # after ~15 legs): timed first, R = 7 legs of 20 steps measure that ramp, not the filter.  BENCH_TIMED_FIRST=1 restores that order.
+    # ... and the timed filter's handle is CREATED ahead of them and the roofline handle closed behind the timed legs, so that no allocation, no
+    # hipFree and no idle gap stands between the roofline legs and the W warm-up steps: a GPU that has idled for a millisecond or more runs the
+    # legs 1.5-5 ms into new work up to 14 % slower before it settles (tools/leg_drift.py, device clock stamps: 434 434 445 456 467 496 491
+    # 481 472 456 448 436 ... 425 us per 20-observation leg; uncorrelated with the data, back after 2 s of idling) -- the rising legs of
+    # BENCH_r05.  The timed region is what the contract says: W warm-up steps, then R legs of exactly K.
+    keep = []
     if os.environ.get("BENCH_TIMED_FIRST", "0") == "1":
         walls, ll, ess_t, d, devs, calls = timed_legs()
         copy_gbs, loop_ms, per, pair_s, roof_generic = roofline_legs()
     else:
+        timed_pf = handle()
         copy_gbs, loop_ms, per, pair_s, roof_generic = roofline_legs()
-        walls, ll, ess_t, d, devs, calls = timed_legs()
+        walls, ll, ess_t, d, devs, calls = timed_legs(timed_pf)
+    for h in keep:
+        h.close()
     wall = float(np.median(walls))
     traffic, traffic_source = None, None
     tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
@@ -402,9 +411,13 @@ def roofline_16m(NativePf, copy_gbs, fused=None, K=24):
     res = {}
     for key, which in (("c2_d3", "c2"), ("c1_d1", "c1")):
         model, t, y, has = build_workload(K, which)
-        for variant, fz in (("", 1 if fused is None else fused), ("_lean", 0)):
+        # "" = the default path (round 6: wave ranges in the propagate + k_offspring_wave beyond 2^20 particles); "_block_tiles" = the same with
+        # CSSM_OPT_WAVE_SUMS = 0 (round 5's block-wide propagate tiles + k_offspring_self): the propagate alone is 3-4 % faster there, the step
+        # slower (profiles/r06_ab_wave_sums.txt) -- both are in the line so that one run shows the trade; "_lean" = without the fused sums
+        for variant, fz, ws in (("", 1 if fused is None else fused, 1), ("_block_tiles", 1 if fused is None else fused, 0), ("_lean", 0, 1)):
             pf = NativePf(model, N_16M, 20260101, device=0)
             pf.set_option(3, fz)
+            pf.set_option(10, ws)         # CSSM_OPT_WAVE_SUMS
             pf.set_option(9, 1)            # CSSM_OPT_LOOP_EVENTS: these legs are timed on the device
             pf.run(t[:8], y[:8], has[:8])
             loop_ms = 1e30
@@ -415,6 +428,7 @@ def roofline_16m(NativePf, copy_gbs, fused=None, K=24):
             avg_s, cnt, raw_s = per["k_propagate"]
             r = _roofline(f"k_propagate<{pf.d},...> {'with' if fz else 'without'} the fused sums, N={N_16M}", pf.d, N_16M, avg_s, cnt, raw_s, pair_s, copy_gbs)
             r["fused_sums"] = bool(fz)
+            r["wave_ranges"] = bool(ws and fz)
             r["step_us"] = loop_ms * 1e3 / K
             r["particle_steps_per_s"] = N_16M * K / (loop_ms * 1e-3)
             r["kernels_us"] = {k: v[0] * 1e6 for k, v in per.items()}
