@@ -411,10 +411,12 @@ def roofline_16m(NativePf, copy_gbs, fused=None, K=24):
     res = {}
     for key, which in (("c2_d3", "c2"), ("c1_d1", "c1")):
         model, t, y, has = build_workload(K, which)
-        # "" = the default path (round 6: wave ranges in the propagate + k_offspring_wave beyond 2^20 particles); "_block_tiles" = the same with
-        # CSSM_OPT_WAVE_SUMS = 0 (round 5's block-wide propagate tiles + k_offspring_self): the propagate alone is 3-4 % faster there, the step
-        # slower (profiles/r06_ab_wave_sums.txt) -- both are in the line so that one run shows the trade; "_lean" = without the fused sums
-        for variant, fz, ws in (("", 1 if fused is None else fused, 1), ("_block_tiles", 1 if fused is None else fused, 0), ("_lean", 0, 1)):
+        # "" = the default path; "_wave_ranges" / "_block_tiles" = the OTHER mapping of the propagate's blocks (round 6: wave ranges + k_offspring_wave
+        # against block-wide tiles + k_offspring_self; the default takes wave ranges beyond 2^20 particles at d <= 2, where the step gains:
+        # profiles/r06_ab_wave_sums.txt) -- both are in the line so that one run shows the trade; "_lean" = without the fused sums
+        fzd = 1 if fused is None else fused
+        other = ("_block_tiles", 0) if which == "c1" else ("_wave_ranges", 2)
+        for variant, fz, ws in (("", fzd, 1), (other[0], fzd, other[1]), ("_lean", 0, 1)):
             pf = NativePf(model, N_16M, 20260101, device=0)
             pf.set_option(3, fz)
             pf.set_option(10, ws)         # CSSM_OPT_WAVE_SUMS
@@ -428,7 +430,7 @@ def roofline_16m(NativePf, copy_gbs, fused=None, K=24):
             avg_s, cnt, raw_s = per["k_propagate"]
             r = _roofline(f"k_propagate<{pf.d},...> {'with' if fz else 'without'} the fused sums, N={N_16M}", pf.d, N_16M, avg_s, cnt, raw_s, pair_s, copy_gbs)
             r["fused_sums"] = bool(fz)
-            r["wave_ranges"] = bool(ws and fz)
+            r["wave_ranges"] = bool(fz and (ws == 2 or (ws == 1 and pf.d <= 2)))
             r["step_us"] = loop_ms * 1e3 / K
             r["particle_steps_per_s"] = N_16M * K / (loop_ms * 1e-3)
             r["kernels_us"] = {k: v[0] * 1e6 for k, v in per.items()}

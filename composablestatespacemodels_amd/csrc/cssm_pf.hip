@@ -430,9 +430,12 @@ int cssm_launch_propagate(cssm_pf* pf, const StepRec* d_rec, double* pick_out, u
   // a conversion nor a 128-bit scan per weight (CSSM_OPT_WAVE_SUMS = 0: k_offspring_self as before)
   const bool want_ws = want_grp && geo == GEO_LOOP && !pf->sharded && batch == nullptr && pf->resampler == CSSM_RESAMPLE_SYSTEMATIC &&
                        pf->obs_kind != CSSM_OBS_LGCP && pick_out == nullptr && 4 * (size_t)pf->nunits <= (size_t)pf->s2_stride &&
-                       // (where it pays: units of several tiles -- clouds beyond 2^20 particles; the mapping costs the propagate 2.5-3 % and at
-                       //  one tile per unit the resampling kernel gains nothing back: same-box A/B of round 6; CSSM_OPT_WAVE_SUMS = 2 forces it)
-                       (pf->opt_wave == 2 || (pf->opt_wave != 0 && pf->sup >= 2u));
+                       // (where it pays: units of several tiles -- clouds beyond 2^20 particles: at one tile per unit the resampling kernel gains
+                       //  nothing back -- and at most two latent components: a block on wave ranges streams 4 x (d rows + weights) ranges instead
+                       //  of d + 1, and from d = 3 on the propagate loses to that what the resampling kernel gains (same-box A/B of round 6: the
+                       //  step -1.2 % on slower boxes, +0-5 % on the fastest, where the block-wide propagate runs at 0.68 of the HBM peak; d = 1:
+                       //  -4.8 % .. 0).  CSSM_OPT_WAVE_SUMS = 2 forces it wherever the geometry allows.)
+                       (pf->opt_wave == 2 || (pf->opt_wave != 0 && pf->sup >= 2u && pf->d <= 2));
   if (want_ws) a.slot_set |= 0x2000;
   a.src2 = anc ? pf->src2 : nullptr; a.src2_stride = pf->src2_stride; a.n_split = pf->n_split; a.logtab = pf->d_logtab;
   a.chunk = chunk; a.do_sums = do_sums; a.subS = fine ? pf->fineS : pf->tileS; a.subS2 = want_ws ? pf->tileW : (fine ? pf->fineS2 : pf->tileS2);

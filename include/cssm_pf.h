@@ -276,9 +276,10 @@ int cssm_pf_stream_idle(cssm_pf* pf);
  * stores the exact fixed-point sum of its weights; the resampling kernel (k_offspring_wave) takes a wave's prefix from those sums and the
  * group sums and runs the rest of its prefix arithmetic in fp64 -- no conversion to the 2^-96 grid and no 128-bit scan per weight, one block
  * barrier per block; the contract's exact predicate where the fp64 estimate is within its error band of a slot boundary, as before.
- * The mapping costs the fused kernel 2.5-3 % and the resampling kernel gains 11-13 % from 2^21 particles on, nothing at 2^20 (one tile per
- * unit): 1 applies it to clouds whose units have several tiles (more than 2^20 particles), 2 (verification) wherever the geometry allows,
- * 0 = never: k_offspring_self (every weight converted and scanned in 128 bits). */
+ * The mapping costs the fused kernel 1-4 % at d <= 2 and up to 10 % at d = 3 on the fastest boxes (a block streams four ranges per row
+ * instead of one), the resampling kernel gains 14-16 % from 2^21 particles on and nothing at 2^20 (one tile per unit): 1 applies it to clouds
+ * whose units have several tiles (more than 2^20 particles) of models with at most two latent components -- where the STEP gains --, 2
+ * (verification, A/B) wherever the geometry allows, 0 = never: k_offspring_self (every weight converted and scanned in 128 bits). */
 #define CSSM_OPT_WAVE_SUMS 10
 int cssm_pf_set_option(cssm_pf* pf, int option, int value);
 /* Counters of the run-time specialisation in this process: out4 = {kernels compiled, kernels loaded from the disk cache, launches of
