@@ -47,8 +47,10 @@ def test_hip_resamplers_return_the_same_length(w, u, seed):
     for kind, res in zip((0, 1, 2), out):
         assert len(res) == len(w)
         assert all(x in w for x in res)
-        if kind == 0 and u > 0.0:                # first-wins ties: no slot goes to a particle of zero weight (grid point 0 is the one
-            assert all(x > 0.0 for x in res)     #  exception: (u + 0)/n = 0 <= C_0 = 0 holds for a zero first weight, as in the reference)
+        if kind == 0 and (u + 0.0) / len(w) > 0.0:   # first-wins ties: no slot goes to a particle of zero weight (grid point 0 is the one
+            assert all(x > 0.0 for x in res)         #  exception: (u + 0)/n = 0 <= C_0 = 0 holds for a zero first weight, as in the reference --
+                                                     #  also for a u so small that u / n ROUNDS to 0: hypothesis likes 5e-324; an intermittent
+                                                     #  failure of this test in round 6 was exactly that example)
     # ... and the device agrees with the oracle on which particles (the seam is deterministic under (u | seed))
     np.testing.assert_array_equal(Resampling.ancestors(0, w, u=u), oracle.resample_systematic(wa, u))
     np.testing.assert_array_equal(Resampling.ancestors(1, w, seed=seed), oracle.resample_stratified(wa, seed))
