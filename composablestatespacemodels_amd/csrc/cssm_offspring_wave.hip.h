@@ -27,12 +27,21 @@
 
 #include "cssm_offspring.hip.h"
 
+// A DPP move of all rows whose lanes without a source read 0 (bound_ctrl): no `old` operand to prepare -- dpp0's zero-initialised
+// destination costs two v_mov per 64-bit move, which in the six steps of a scan is a third of its instructions
+template <int CTRL>
+__device__ __forceinline__ uint64_t dppz_u64(uint64_t v) {
+  return (uint64_t)(uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)v, CTRL, 0xf, 0xf, true) |
+         ((uint64_t)(uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)(v >> 32), CTRL, 0xf, 0xf, true) << 32);
+}
 // inclusive scan of doubles across the 64 lanes (a lane without a DPP source adds +0.0)
 __device__ __forceinline__ double wave_scan_f64(double v) {
+#define CSSM_F64_STEPZ(CTRL) { const double o = cssm_u2d(dppz_u64<CTRL>(cssm_d2u(v))); v = v + o; }
 #define CSSM_F64_STEP(CTRL, RM) { const double o = cssm_u2d(dpp0_u64<CTRL, RM>(cssm_d2u(v))); v = v + o; }
-  CSSM_F64_STEP(CSSM_DPP_ROW_SHR(1), 0xf) CSSM_F64_STEP(CSSM_DPP_ROW_SHR(2), 0xf) CSSM_F64_STEP(CSSM_DPP_ROW_SHR(4), 0xf)
-  CSSM_F64_STEP(CSSM_DPP_ROW_SHR(8), 0xf) CSSM_F64_STEP(CSSM_DPP_BCAST15, 0xa) CSSM_F64_STEP(CSSM_DPP_BCAST31, 0xc)
+  CSSM_F64_STEPZ(CSSM_DPP_ROW_SHR(1)) CSSM_F64_STEPZ(CSSM_DPP_ROW_SHR(2)) CSSM_F64_STEPZ(CSSM_DPP_ROW_SHR(4))
+  CSSM_F64_STEPZ(CSSM_DPP_ROW_SHR(8)) CSSM_F64_STEP(CSSM_DPP_BCAST15, 0xa) CSSM_F64_STEP(CSSM_DPP_BCAST31, 0xc)
 #undef CSSM_F64_STEP
+#undef CSSM_F64_STEPZ
   return v;
 }
 // a + b on values the compiler may keep in scalar registers (cssm_u128_add's carry chain is vector assembly)
@@ -250,7 +259,7 @@ __global__ __attribute__((amdgpu_flat_work_group_size(CSSM_BLOCK, CSSM_BLOCK), a
     double wn[CSSM_ITEMS];
     if (more) load_chunk(base + (uint32_t)(CSSM_TILE / 4), wn);
     // exclusive prefix of the thread's first particle: the lane before's inclusive sum (lane 0: nothing) on the chunk's prefix
-    double sd = pre_w + cssm_u2d(dpp0_u64<0x138 /* wave_shr:1 */, 0xf>(cssm_d2u(inc)));
+    double sd = pre_w + cssm_u2d(dppz_u64<0x138 /* wave_shr:1 */>(cssm_d2u(inc)));
     uint32_t e[CSSM_ITEMS];
     uint32_t unsafe = 0u;
 #pragma unroll
