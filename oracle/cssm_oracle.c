@@ -13,7 +13,13 @@
  *   - closed-form transition moments and the double-logistic OU quirk,
  *   - hand-worked systematic-resampling examples that follow Resampling.scala:52-72 literally,
  *   - the exact Kalman-filter log-likelihood for Brownian + Gaussian observation,
- *   - the reference's own property (output length == input length).
+ *   - the reference's own property (output length == input length),
+ *   - and (round 6) a SECOND, independent statement of the path: tests/golden/make_literal.py restates stepFilter, the
+ *     transitions, f, the Poisson density, systematicResampling (sequential cumsum + searchsorted + the TreeMap's
+ *     last-key-wins) and the LGCP step from the Scala lines in numpy / libm arithmetic without this file or
+ *     include/cssm_numerics.h; its fixture (tests/golden/literal_runs.json) holds this file's literal mode to 1e-12 in
+ *     ll with ESS and ancestors identical (tests/test_literal_mirror.py).  Only the variates are shared
+ *     (oracle_pf_dump_normals, oracle_c_u): the reference's generators are unseeded.
  *
  * Each function cites the reference lines it follows as  model/<File>.scala:<lines>
  * (relative to src/main/scala/com/github/jonnylaw/).  Execution model is the reference's:
