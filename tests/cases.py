@@ -168,6 +168,16 @@ def golden_case(name, T, missing=0.0):
     return (mk(),) + tuple(data)
 
 
+def literal_case(name, T, missing=0.0):
+    """(model, t, y, has) of a run of the numpy witness (tests/golden/literal_runs.json): the golden cases plus the two compositions that
+    exercise the generalised Brownian motion and the trait's Euler-Maruyama step."""
+    if name == "gbsg":
+        return (gen_brownian_seasonal_gaussian(),) + tuple(gaussian_series(T))
+    if name == "euler":
+        return (euler_model(),) + tuple(poisson_counts(T, missing=missing))
+    return golden_case(name, T, missing=missing)
+
+
 def max_dim_model():
     """d = CSSM_MAX_DIM = 16 in one composition: poisson(brownian 2) |+| seasonal(12, 3, ou 6) |+| linear-leaf(genBrownian 8)."""
     p = (Parameters.apply(None, SdeParameter.brownianParameter([0.0, 0.1], 1.0, [0.01, 0.02]))

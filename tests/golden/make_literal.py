@@ -9,7 +9,8 @@ paths relative to src/main/scala/com/github/jonnylaw/model/) with numpy / libm a
 include/cssm_numerics.h nor oracle/cssm_oracle.c, shares no elementary function, no fixed-point sum, no tie rule and no clamp with them.
 Sums are the reference's sequential fp64 sums (`foldLeft`, `scanLeft`, `Seq.sum`), the ancestor search is `numpy.searchsorted(C, k,
 side='left')` for `TreeMap.from(k).head` followed by the TreeMap's duplicate-key rule (the LAST particle inserted under a key wins,
-Resampling.scala:57), the Poisson density is breeze's `-lambda + k log(lambda) - lgamma(k + 1)` with `lambda = exp(gamma)` as written.
+Resampling.scala:57), the Poisson density is breeze's `-lambda + k log(lambda) - lgamma(k + 1)` with `lambda = exp(gamma)` as written, the
+other seven observation densities are scipy.stats' norm / t / beta log-pdfs and `gammaln` forms of the Scala lines (data_likelihood).
 
 What is shared, and why.  The reference draws its variates from unseeded global generators (breeze `rand.gaussian`, `scala.util.Random`):
 no run of it can be reproduced even by itself.  A witness of the ARITHMETIC therefore needs the variates handed in: the standard normals
@@ -17,7 +18,7 @@ of every particle and the one uniform of every resampling are DUMPED from the or
 LITERAL_SUMS | LIBM | TIE_LAST mode: Philox bits through libm's log / sqrt / cos / sin) and read here as data -- `z()` and `u` of
 SURVEY.md Appendix A.  Nothing else crosses.
 
-The fixture: for BASELINE's configs[0..3] at N <= 4096 the per-observation log-likelihood and ESS, the ancestors of the first and of the
+The fixture: for BASELINE's configs[0..3] at N <= 4096, and for one run of every other observation model and transition at N = 2048, the per-observation log-likelihood and ESS, the ancestors of the first and of the
 last weighted observation and the final cloud's first component -- twice: `tie_last` is the reference's behaviour (TreeMap duplicate keys),
 `tie_first` the same statement with the canonical lower bound (the build's deviation D3: the two differ only where a weight underflowed
 to exactly 0, and are different realisations of the same estimator from the first such swap on).  tests/test_literal_mirror.py holds the CPU oracle (literal mode) and
@@ -155,7 +156,40 @@ def poisson_log_probability(gamma, y):
     return -lam + k * np.log(lam) - gammaln(k + 1.0)
 
 
-def literal_filter(leaves, lgcp_precision, t, y, has, n, normals, uniform, tie_last=True):
+def data_likelihood(kind, eta, y, scale, df):
+    """dataLikelihood of the LEFTMOST model of the composition (Model.scala:118-120,132), as the case classes write it, in numpy / scipy:
+    Poisson :269,273 -- Gaussian (LinearModel :252-258, SeasonalModel :227-233: the second argument of breeze's Gaussian is the standard
+    deviation exp(scale)) -- Student's t :155-160 (the LOG-pdf multiplied by 1/v: as written) -- negative binomial :186-195 -- zero-inflated
+    Poisson :298-307 -- Bernoulli :318-336 (link clamped at +-6, -1e99 floors) -- Beta(link, 1) :349-352 with link = exp(-gamma) :345."""
+    from scipy import stats
+    if kind == "poisson":
+        return poisson_log_probability(eta, y)
+    if kind in ("linear", "seasonal"):
+        v = math.exp(scale)
+        return stats.norm.logpdf(y, loc=eta, scale=v)                     # Gaussian(x, v).logPdf(y)
+    if kind == "studentt":
+        v = math.exp(scale)
+        return 1 / v * stats.t.logpdf((y - eta) / v, df)                  # 1/v * StudentsT(df).logPdf((y - eta) / v)
+    if kind == "negbin":
+        size, mu, k = math.exp(scale), np.exp(eta), int(y)
+        return (gammaln(size + k) - gammaln(k + 1.0) - gammaln(size) + size * np.log(size / (mu + size)) + k * np.log(mu / (mu + size)))
+    if kind == "zip":
+        p, k = math.exp(scale) / (1 + math.exp(scale)), int(y)
+        if k == 0:
+            return np.log(p + (1 - p) * np.exp(-np.exp(eta)))
+        return -math.log(1 + math.exp(scale)) + k * eta - np.exp(eta) - gammaln(k + 1.0)
+    if kind == "bernoulli":
+        link = np.where(eta > 6, 1.0, np.where(eta < -6, 0.0, 1.0 / (1 + np.exp(-eta))))
+        with np.errstate(divide="ignore"):
+            if y == 1.0:
+                return np.where(link == 0.0, -1e99, np.log(link))
+            return np.where(link == 1.0, -1e99, np.log(1 - link))
+    if kind == "beta":
+        return stats.beta.logpdf(y, np.exp(-eta), 1.0)                    # new Beta(link(gamma), 1.0).logPdf(y)
+    raise ValueError(kind)
+
+
+def literal_filter(leaves, lgcp_precision, t, y, has, n, normals, uniform, tie_last=True, obs=("poisson", None, 0)):
     """llFilter, ParticleFilter.scala:137-140 over stepFilter :116-132 (FilterLgcp.stepFilter :210-226 when lgcp_precision > 0).
     normals(step, init, sub) -> [n, d] standard normals, uniform(step) -> u: the injected variates.  Returns per-observation ll and ess,
     the ancestors of every weighted observation and the final cloud."""
@@ -187,7 +221,7 @@ def literal_filter(leaves, lgcp_precision, t, y, has, n, normals, uniform, tie_l
             xs = [lf.step(x, dt, z) for lf, x, z in zip(leaves, xs, split(normals(s, False, -1)))]   # :118
             weighted = bool(has[s])
             if weighted:
-                w = poisson_log_probability(compose_f(leaves, xs, float(t[s])), float(y[s]))          # :123
+                w = data_likelihood(obs[0], compose_f(leaves, xs, float(t[s])), float(y[s]), obs[1], obs[2])   # :123
         if weighted:
             anc, ll, ess = weigh_and_resample(w, ll, uniform(s), tie_last)
             xs = [x[anc] for x in xs]                                                                 # :130
@@ -211,11 +245,14 @@ def leaves_of(model):
     return out
 
 
-CASES = [   # (name, N, T, missing fraction): BASELINE configs[0] at its own size, configs[1..3] at sizes the witness runs in seconds
+CASES = [   # (name, N, T, missing fraction): BASELINE configs[0] at its own size, configs[1..3] at sizes the witness runs in seconds ...
     ("c1", 1000, 100, 0.0),
     ("c2", 4096, 60, 0.15),
     ("c3", 2048, 40, 0.0),
     ("c4", 2048, 24, 0.0),
+    # ... and every other observation model and transition of SURVEY.md 8f-1 / A3 (tests/cases.py: the golden cases' models)
+    ("linear", 2048, 40, 0.0), ("negbin", 2048, 40, 0.1), ("zip", 2048, 40, 0.0), ("bernoulli", 2048, 40, 0.0), ("studentt", 2048, 40, 0.0),
+    ("beta", 2048, 40, 0.0), ("gbsg", 2048, 40, 0.0), ("euler", 2048, 40, 0.1),
 ]
 
 
@@ -223,7 +260,9 @@ def run_case(name, n, T, missing):
     sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
     import cases
     from oracle import oracle
-    model, t, y, has = cases.golden_case(name, T, missing=missing)
+    model, t, y, has = cases.literal_case(name, T, missing=missing)
+    spec0, node0 = model.leaves[0][0], model.leaves[0][1]
+    obs = (spec0.obs, node0.scale, spec0.df)
     prec = 2 if name == "c4" else 0
     flags = oracle.LITERAL_SUMS | oracle.LIBM | oracle.TIE_LAST
     o = oracle.OraclePf(model.descriptor(prec), n, cases.SEED, flags)          # (only its variate dump is used here)
@@ -232,7 +271,7 @@ def run_case(name, n, T, missing):
     for key, tie_last in (("tie_last", True), ("tie_first", False)):
         ll_t, ess_t, ancs, cloud = literal_filter(leaves_of(model), prec, t, y, has, n,
                                                   lambda s, init, sub: o.dump_normals(s, init, sub),
-                                                  lambda s: float(lib.oracle_c_u(cases.SEED, s)), tie_last)
+                                                  lambda s: float(lib.oracle_c_u(cases.SEED, s)), tie_last, obs)
         out[key] = {"ll_t": [float(v).hex() for v in ll_t], "ess_t": [int(v) for v in ess_t],
                     "anc_first": [int(v) for v in ancs[0]], "anc_last": [int(v) for v in ancs[-1]],
                     "weighted": int(len(ancs)), "x0_last": [float(v).hex() for v in cloud[:, 0]]}

@@ -40,7 +40,7 @@ def _fx(r, key):
 
 
 def _data(r):
-    model, t, y, has = cases.golden_case(r["name"], r["T"], missing=r["missing"])
+    model, t, y, has = cases.literal_case(r["name"], r["T"], missing=r["missing"])
     weighted = np.ones(r["T"], dtype=bool) if r["lgcp_precision"] else has.astype(bool)
     return model, t, y, has, weighted
 
