@@ -25,6 +25,7 @@ Poisson-Brownian (d = 1), and ``cpu_baseline``: the CPU restatement of the refer
 the reference runs) on a bounded sample of the same workload.
 """
 import argparse
+import gc
 import json
 import os
 import signal
@@ -172,7 +173,7 @@ def run_single(args, emit=print):
     K, W = args.steps, args.warmup
     lgcp = args.model == "c4"
     n = args.particles if args.particles > 0 else (N_16M if lgcp else N_PER_GPU)
-    R = args.repeats if args.repeats > 0 else (3 if K >= 200 else 7)
+    R = args.repeats if args.repeats > 0 else (3 if K >= 200 else 25)
     W = max(W, 1)                      # (the filter has to be running before K more steps can be timed)
     model, t, y, has = build_workload(W + 7 * R * K + 16, args.model)
     import ctypes as C
@@ -192,6 +193,10 @@ def run_single(args, emit=print):
         signal -- measured in round 6: hipStreamQuery still says "not ready" when the call returns, the end-of-kernel release of the closing
         kernel is what the synchronise waits 4-6 us for) and the DEVICE time of the leg from the GPU's own clock."""
         pf = timed_pf if timed_pf is not None else handle()
+        gc.disable()       # (as timeit does: a full collection of a process with torch imported takes ~50 ms -- seen inside one timed leg
+        #                     of the sharded bench, always the same one; re-enabled behind the legs.  No gc.collect() here: it idles the
+        #                     GPU for those 50 ms, and legs 2-5 ms behind an idle gap run up to 15 % slower -- tried, three runs of the
+        #                     driver's command: 4.43 / 4.06 / 4.03e10 against 4.5-4.7e10 without)
         torch.cuda.synchronize()
         pf.run(t[:W], y[:W], has[:W])
         walls, devs, calls, idle = [], [], [], []
@@ -208,6 +213,7 @@ def run_single(args, emit=print):
             calls.append(t1 - t0)
             idle.append(bool(pf.stream_idle()))          # (behind the synchronise: must be true)
             devs.append(pf.last_device_us() * 1e-6)      # (read behind the timed region: the GPU's own clock, no event packets)
+        gc.enable()
         if not all(idle):
             raise SystemExit("bench.py: the filter's stream was not idle behind torch.cuda.synchronize()")
         d = pf.d
@@ -307,7 +313,7 @@ def run_single(args, emit=print):
         "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
         "config": {"workload": workload_text(args.model, n, K),
                    "particles_per_gpu": n, "observations": K, "latent_dim": d, "seed": 20260101},
-        "repeats": R, "value_is": "median over `repeats` timed legs of K steps each, continuing the filter the warm-up steps started (cssm_pf_ll_filter_more); the roofline legs (a handle of their own) run before it", "wall_ms_each": [w * 1e3 for w in walls],
+        "repeats": R, "value_is": "median over `repeats` timed legs of K steps each (every leg counts, none is discarded: the legs 2-5 ms behind the idle gap in front of the filter run slower on the DEVICE -- device_ms_each), continuing the filter the warm-up steps started (cssm_pf_ll_filter_more); the roofline legs (a handle of their own) run behind them", "wall_ms_each": [w * 1e3 for w in walls],
         "roofline": roof,
         "roofline_generic": roof_generic,
         "kernels_us": kernels_us,
@@ -623,7 +629,7 @@ def run_multi(args, emit=print):
     else:         # configs[1]: a fixed cloud per GPU (weak scaling)
         per_gpu = args.particles if args.particles > 0 else N_PER_GPU
         n_global = per_gpu * world
-    R = args.repeats if args.repeats > 0 else (3 if K >= 200 else 7)
+    R = args.repeats if args.repeats > 0 else (3 if K >= 200 else 25)
     # warm-up: allocations, RCCL channels, clocks.  At least 8 observations whatever W is: the library's own RCCL communicator and
     # the exchange buffers are created at the first observation of the first series -- that must not happen inside a timed leg
     Wn = max(W, 8) if gpu else max(W, 1)
@@ -649,6 +655,7 @@ def run_multi(args, emit=print):
     f, walk, protocol = preflight(make_filter(), make_filter, t, y, has, lgcp, gpu, rank, world, stage_s)
     fallbacks = [f"{st['protocol']}: {st['why']}" for st in walk if not st["ok"]]
 
+    gc.disable()           # (see run_single: a full collection inside a timed leg costs it ~50 ms; re-enabled behind the legs)
     # the W warm-up observations START the sharded filter ...
     with _Deadline(stage_s, "warm-up series"):
         f.ll_filter(t[:Wn], y[:Wn], has[:Wn], lgcp=lgcp)
@@ -677,7 +684,10 @@ def run_multi(args, emit=print):
         dist.all_reduce(wall, op=dist.ReduceOp.MAX)
         walls.append(float(wall.item()))
         plans.append({"plan": "max" if f.last_from_max else ("ref" if f.last_single else "exact"), "resumes": int(f.last_resumes),
-                      "capacity_rows": f.last_cap})
+                      "level_redos": int(getattr(f, "last_level_redos", 0)), "capacity_rows": f.last_cap, "wall_ms": round((t1 - t0) * 1e3, 4),
+                      # this rank's leg on the GPU's own clock, first kernel of the call to k_finish (no event packets): wall_ms - device_ms is host
+                      "device_ms": round(shard.last_device_us() * 1e-3, 4) if gpu else None})
+    gc.enable()
     # a pass of its own with HIP events around every kernel and every library-issued collective of this rank's stream (the
     # event records perturb the throughput figure): what a step is made of, per rank
     mine = {"rank": rank, "legs": plans}
@@ -811,7 +821,7 @@ def main():
     ap.add_argument("--steps", type=int, default=500)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--particles", type=int, default=0, help="particles per GPU (c2 / c1: default 2^20) or in total (c4: default 2^24)")
-    ap.add_argument("--repeats", type=int, default=0, help="timed K-step series (0: 3 for K >= 200, else 7); the median is reported")
+    ap.add_argument("--repeats", type=int, default=0, help="timed K-step series (0: 3 for K >= 200, else 25); the median is reported")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-16m", action="store_true", help="skip the roofline_16m leg")
     ap.add_argument("--no-pmc", action="store_true", help="skip the live HBM-traffic passes (two rocprofv3 --pmc child runs); roofline.traffic then comes from profiles/traffic_latest.json")

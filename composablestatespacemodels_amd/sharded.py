@@ -241,6 +241,13 @@ class GpuShard:
                                                  need.ctypes.data_as(C.POINTER(C.c_uint32)), T))
         return ll.value, ess.value, bits.value, need
 
+    def last_device_us(self) -> float:
+        """Device time of the last continued series as of its last status read, first kernel of the call to the status kernel, from the
+        GPU's constant clock (cssm_pf_last_device_us)."""
+        us = C.c_double()
+        _abi.check(self.lib.cssm_pf_last_device_us(self._h, C.byref(us)))
+        return us.value
+
     def wait_stats(self):
         """(exchanges counted, mean us the first offspring block waited for every rank's header words, mean us the first expansion block
         waited for them, mean us it then waited for its neighbours' eager-rows flags) of the peer-written exchanges since the cloud was
