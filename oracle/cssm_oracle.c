@@ -953,6 +953,13 @@ double oracle_c_u(uint64_t seed, uint32_t step) {
   cssm_u32x4 b = cssm_philox_draw(seed, 0, step, CSSM_STREAM_U, 0);
   return cssm_u01(b.v[0], b.v[1]);
 }
+/* the per-slot uniforms of the stratified grid / of the multinomial draws (dumped as data for tests/golden/make_literal.py) */
+void oracle_c_strat_u_v(uint64_t seed, uint32_t step, uint64_t n, double* out) {
+  for (uint64_t i = 0; i < n; ++i) { cssm_u32x4 b = cssm_philox_draw(seed, i, step, CSSM_STREAM_STRAT, 0); out[i] = cssm_u01(b.v[0], b.v[1]); }
+}
+void oracle_c_multi_u_v(uint64_t seed, uint32_t step, uint64_t n, double* out) {
+  for (uint64_t i = 0; i < n; ++i) out[i] = cssm_multi_uniform(seed, step, i);
+}
 /* vectorised for ulp sweeps */
 void oracle_c_exp_v(const double* x, double* y, size_t n) { for (size_t i = 0; i < n; ++i) y[i] = cssm_exp(x[i]); }
 void oracle_c_fix_v(const double* w, uint64_t* out, size_t n) {

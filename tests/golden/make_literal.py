@@ -18,12 +18,14 @@ of every particle and the one uniform of every resampling are DUMPED from the or
 LITERAL_SUMS | LIBM | TIE_LAST mode: Philox bits through libm's log / sqrt / cos / sin) and read here as data -- `z()` and `u` of
 SURVEY.md Appendix A.  Nothing else crosses.
 
-The fixture: for BASELINE's configs[0..3] at N <= 4096, and for one run of every other observation model and transition at N = 2048, the per-observation log-likelihood and ESS, the ancestors of the first and of the
+The fixture: for BASELINE's configs[0..3] at N <= 4096, for one run of every other observation model and transition at N = 2048 and for
+the filter constructed with stratifiedResampling / multinomialResampling (per-slot uniforms dumped: oracle_c_strat_u_v, oracle_c_multi_u_v), the per-observation log-likelihood and ESS, the ancestors of the first and of the
 last weighted observation and the final cloud's first component -- twice: `tie_last` is the reference's behaviour (TreeMap duplicate keys),
 `tie_first` the same statement with the canonical lower bound (the build's deviation D3: the two differ only where a weight underflowed
 to exactly 0, and are different realisations of the same estimator from the first such swap on).  tests/test_literal_mirror.py holds the CPU oracle (literal mode) and
 -- on the GPU -- the HIP path (contract mode, through the C ABI) against it, with the tolerances stated there.
 """
+import ctypes as C
 import json
 import math
 import os
@@ -137,11 +139,44 @@ def systematic_resampling(w1, u, tie_last=True):
     return last.astype(np.int64)
 
 
-def weigh_and_resample(w, ll, u, tie_last=True):
-    """stepFilter's tail, ParticleFilter.scala:124-128 (and :218-223): max, w1, ll, ess, ancestors."""
+def stratified_resampling(w1, us, tie_last=True):
+    """Resampling.stratifiedResampling, Resampling.scala:78-86: one uniform per slot, ks_i = (i + u_i) / n; the same TreeMap walk."""
+    n = len(w1)
+    ecdf_keys = np.cumsum(w1 / seq_sum(w1))                    # treeEcdf, :52-58
+    ks = (np.arange(n, dtype=np.float64) + us) / n             # Vector.range(0, n).map(i => (i + scala.util.Random.nextDouble) / n)
+    first = np.searchsorted(ecdf_keys, ks, side="left")
+    if np.any(first >= n):
+        raise LookupError("findAllInTreeMap: `.head` of an empty map")
+    if not tie_last:
+        return first.astype(np.int64)
+    return (np.searchsorted(ecdf_keys, ecdf_keys[first], side="right") - 1).astype(np.int64)
+
+
+def multinomial_resampling(w1, us):
+    """Resampling.multinomialResampling, Resampling.scala:92-96: particles.size independent draws of breeze's Multinomial(weights) --
+    third-party (breeze 0.13.x, build.sbt; not under /root/reference), its published `draw`: prob = uniform * sum, then the weights are
+    subtracted one after the other and the first index at which prob <= 0 is returned.  Stated literally (the sequential differences,
+    one row per draw); output in draw order."""
+    total = seq_sum(w1)                                        # Multinomial's `sum`
+    out = np.zeros(len(us), dtype=np.int64)
+    for i, u in enumerate(us):
+        rem = np.subtract.accumulate(np.concatenate(([u * total], w1)))[1:]   # ((prob - w_0) - w_1) - ...
+        hit = np.nonzero(rem <= 0)[0]
+        out[i] = hit[0] if len(hit) else 0                     # (`params.activeKeysIterator.next`: rounding left prob > 0 at the end)
+    return out
+
+
+def weigh_and_resample(w, ll, u, tie_last=True, resampler="systematic"):
+    """stepFilter's tail, ParticleFilter.scala:124-128 (and :218-223): max, w1, ll, ess, ancestors.  u: the one uniform of systematic
+    resampling, or the n per-slot uniforms of the other two."""
     mx = float(np.max(w))
     w1 = np.exp(w - mx)
-    anc = systematic_resampling(w1, u, tie_last)
+    if resampler == "systematic":
+        anc = systematic_resampling(w1, u, tie_last)
+    elif resampler == "stratified":
+        anc = stratified_resampling(w1, u, tie_last)
+    else:
+        anc = multinomial_resampling(w1, u)
     ll = ll + mx + math.log(seq_sum(w1) / len(w1))             # s.ll + max + log(ParticleFilter.mean(w1)), :522-524
     nw = w1 / seq_sum(w1)                                      # Resampling.normalise
     ess = int(math.floor(1 / seq_sum(nw * nw)))                # :431-434
@@ -189,7 +224,7 @@ def data_likelihood(kind, eta, y, scale, df):
     raise ValueError(kind)
 
 
-def literal_filter(leaves, lgcp_precision, t, y, has, n, normals, uniform, tie_last=True, obs=("poisson", None, 0)):
+def literal_filter(leaves, lgcp_precision, t, y, has, n, normals, uniform, tie_last=True, obs=("poisson", None, 0), resampler="systematic"):
     """llFilter, ParticleFilter.scala:137-140 over stepFilter :116-132 (FilterLgcp.stepFilter :210-226 when lgcp_precision > 0).
     normals(step, init, sub) -> [n, d] standard normals, uniform(step) -> u: the injected variates.  Returns per-observation ll and ess,
     the ancestors of every weighted observation and the final cloud."""
@@ -223,7 +258,7 @@ def literal_filter(leaves, lgcp_precision, t, y, has, n, normals, uniform, tie_l
             if weighted:
                 w = data_likelihood(obs[0], compose_f(leaves, xs, float(t[s])), float(y[s]), obs[1], obs[2])   # :123
         if weighted:
-            anc, ll, ess = weigh_and_resample(w, ll, uniform(s), tie_last)
+            anc, ll, ess = weigh_and_resample(w, ll, uniform(s), tie_last, resampler)
             xs = [x[anc] for x in xs]                                                                 # :130
             ancs.append(anc)
         now = float(t[s])
@@ -256,7 +291,13 @@ CASES = [   # (name, N, T, missing fraction): BASELINE configs[0] at its own siz
 ]
 
 
-def run_case(name, n, T, missing):
+RESAMPLER_CASES = [   # (name, N, T, missing fraction, resampler): the filter constructed with another `Resample[A]`
+    ("c1", 1000, 60, 0.0, "stratified"), ("c2", 2048, 40, 0.1, "stratified"),
+    ("c1", 1000, 40, 0.0, "multinomial"), ("c2", 1024, 30, 0.1, "multinomial"),
+]
+
+
+def run_case(name, n, T, missing, resampler="systematic"):
     sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
     import cases
     from oracle import oracle
@@ -267,11 +308,17 @@ def run_case(name, n, T, missing):
     flags = oracle.LITERAL_SUMS | oracle.LIBM | oracle.TIE_LAST
     o = oracle.OraclePf(model.descriptor(prec), n, cases.SEED, flags)          # (only its variate dump is used here)
     lib = oracle.lib()
-    out = {"name": name, "n": n, "T": T, "missing": missing, "lgcp_precision": prec, "seed": cases.SEED}
+    out = {"name": name, "n": n, "T": T, "missing": missing, "lgcp_precision": prec, "seed": cases.SEED, "resampler": resampler}
+
+    def uniforms(s):
+        if resampler == "systematic":
+            return float(lib.oracle_c_u(cases.SEED, s))
+        us = np.zeros(n)
+        (lib.oracle_c_strat_u_v if resampler == "stratified" else lib.oracle_c_multi_u_v)(cases.SEED, s, n, us.ctypes.data_as(C.POINTER(C.c_double)))
+        return us
     for key, tie_last in (("tie_last", True), ("tie_first", False)):
         ll_t, ess_t, ancs, cloud = literal_filter(leaves_of(model), prec, t, y, has, n,
-                                                  lambda s, init, sub: o.dump_normals(s, init, sub),
-                                                  lambda s: float(lib.oracle_c_u(cases.SEED, s)), tie_last, obs)
+                                                  lambda s, init, sub: o.dump_normals(s, init, sub), uniforms, tie_last, obs, resampler)
         out[key] = {"ll_t": [float(v).hex() for v in ll_t], "ess_t": [int(v) for v in ess_t],
                     "anc_first": [int(v) for v in ancs[0]], "anc_last": [int(v) for v in ancs[-1]],
                     "weighted": int(len(ancs)), "x0_last": [float(v).hex() for v in cloud[:, 0]]}
@@ -279,12 +326,12 @@ def run_case(name, n, T, missing):
 
 
 def main():
-    runs = [run_case(*c) for c in CASES]
+    runs = [run_case(*c) for c in CASES] + [run_case(*c) for c in RESAMPLER_CASES]
     out = os.path.join(HERE, "literal_runs.json")
     json.dump({"made_by": "tests/golden/make_literal.py (numpy " + np.__version__ + "): the numpy statement of the path on variates dumped from "
                           "the oracle's literal mode; doubles as C99 hex strings", "runs": runs}, open(out, "w"), indent=0)
     for r in runs:
-        print(r["name"], "N", r["n"], "T", r["T"], "ll (TreeMap ties)", float.fromhex(r["tie_last"]["ll_t"][-1]), "ll (first key wins)", float.fromhex(r["tie_first"]["ll_t"][-1]),
+        print(r["name"], r["resampler"], "N", r["n"], "T", r["T"], "ll (TreeMap ties)", float.fromhex(r["tie_last"]["ll_t"][-1]), "ll (first key wins)", float.fromhex(r["tie_first"]["ll_t"][-1]),
               "first-observation ancestors that differ between the two:", int(np.sum(np.array(r["tie_last"]["anc_first"]) != np.array(r["tie_first"]["anc_first"]))))
 
 

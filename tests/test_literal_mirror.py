@@ -4,6 +4,9 @@ sequential fp64 sums, searchsorted + the TreeMap's last-key-wins rule; no cssm_n
 shared, dumped from the oracle).  The reference holds no golden values: parity stays "unpinned by the reference", but it
 no longer rests on one C file.
 
+Runs: BASELINE's configs[0..3], one run of every other observation model and transition, and the filter constructed with the stratified
+and the multinomial `Resample[A]` (Resampling.scala:78-96; their per-slot uniforms dumped like the systematic one).
+
 Tolerances, stated:
   * oracle in LITERAL_SUMS | LIBM | TIE_LAST mode (the reference's own arithmetic) vs the numpy statement: |ll_t - fixture| <= 1e-12 at
     every observation (numpy's exp / log vs glibc's: last-bit differences, measured <= 3e-14), ESS equal, the ancestors of the first and
@@ -27,6 +30,9 @@ from oracle import oracle
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 RUNS = json.load(open(os.path.join(HERE, "golden", "literal_runs.json")))["runs"]
+IDS = [r["name"] + ("" if r.get("resampler", "systematic") == "systematic" else "-" + r["resampler"]) for r in RUNS]
+ORACLE_RESAMPLER = {"systematic": 0, "stratified": oracle.RESAMPLE_STRATIFIED, "multinomial": oracle.RESAMPLE_MULTINOMIAL}
+HIP_RESAMPLER = {"systematic": 0, "stratified": 1, "multinomial": 2}      # CSSM_OPT_RESAMPLER (include/cssm_pf.h)
 LL_TOL_LITERAL = 1e-12
 LL_TOL_PER_OBS = 1e-9      # the stated bound; measured <= 5e-13 over whole series: guarded at 1e-11 below
 FLIPPED_ANCESTORS_MAX = 1e-4
@@ -61,12 +67,15 @@ def _stepwise(f, r, t, y, has, weighted):
 
 
 @pytest.mark.parametrize("key", ["tie_last", "tie_first"])
-@pytest.mark.parametrize("r", RUNS, ids=[r["name"] for r in RUNS])
+@pytest.mark.parametrize("r", RUNS, ids=IDS)
 def test_oracle_literal_mode_equals_the_numpy_statement(r, key):
     model, t, y, has, weighted = _data(r)
     fll, fess, fa0, fa1, fx0 = _fx(r, key)
     assert r[key]["weighted"] == int(weighted.sum())
-    flags = oracle.LITERAL_SUMS | oracle.LIBM | (oracle.TIE_LAST if key == "tie_last" else 0)
+    rs = r.get("resampler", "systematic")
+    if rs != "systematic" and key == "tie_last":
+        pytest.skip("the oracle states the other resamplers with the canonical lower bound only (deviation D3); multinomial draws have no TreeMap")
+    flags = oracle.LITERAL_SUMS | oracle.LIBM | (oracle.TIE_LAST if key == "tie_last" else 0) | ORACLE_RESAMPLER[rs]
     o = oracle.OraclePf(model.descriptor(r["lgcp_precision"]), r["n"], r["seed"], flags)
     ll_t, ess_t, a0, a1 = _stepwise(o, r, t, y, has, weighted)
     assert np.max(np.abs(ll_t - fll)) <= LL_TOL_LITERAL
@@ -90,31 +99,32 @@ def _check_contract(r, ll_t, ess_t, a0):
     # weighs nothing)
     ra0 = _fx(r, "tie_last")[2]
     sw = np.nonzero(ra0 != fa0)[0]
-    assert np.all(ra0[sw] > fa0[sw])
+    assert np.all(ra0[sw] > fa0[sw])           # (multinomial: draws, no TreeMap -- the two statements are the same, sw is empty)
     return dll, differing, len(sw)
 
 
-@pytest.mark.parametrize("r", RUNS, ids=[r["name"] for r in RUNS])
+@pytest.mark.parametrize("r", RUNS, ids=IDS)
 def test_oracle_contract_mode_within_stated_tolerance_of_the_numpy_statement(r):
     model, t, y, has, weighted = _data(r)
-    o = oracle.OraclePf(model.descriptor(r["lgcp_precision"]), r["n"], r["seed"])
+    o = oracle.OraclePf(model.descriptor(r["lgcp_precision"]), r["n"], r["seed"], ORACLE_RESAMPLER[r.get("resampler", "systematic")])
     ll_t, ess_t, a0, _ = _stepwise(o, r, t, y, has, weighted)
     _check_contract(r, ll_t, ess_t, a0)
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("r", RUNS, ids=[r["name"] for r in RUNS])
+@pytest.mark.parametrize("r", RUNS, ids=IDS)
 def test_hip_path_within_stated_tolerance_of_the_numpy_statement(r):
     """The product path (HIP, through the C ABI) against the numpy statement: streaming cssm_pf_step for the first observation's ancestors,
     the batch driver for the series."""
     from composablestatespacemodels_amd.filter import NativePf
     model, t, y, has, weighted = _data(r)
     g = NativePf(model, r["n"], r["seed"], lgcp_precision=r["lgcp_precision"])
+    g.set_option(2, HIP_RESAMPLER[r.get("resampler", "systematic")])
     ll_t, ess_t, a0, _ = _stepwise(g, r, t, y, has, weighted)
     dll, differing, swaps = _check_contract(r, ll_t, ess_t, a0)
     gl, gl_t, gess, _ = g.run(t, y, has)                       # the batch driver: the same bits as the streaming steps
     np.testing.assert_array_equal(gl_t, ll_t)
     np.testing.assert_array_equal(gess.astype(np.int64), ess_t)
     g.close()
-    print(f"{r['name']} N={r['n']} T={r['T']}: HIP vs the numpy statement: max |dll_t| = {dll:.3e} (tolerance {LL_TOL_PER_OBS * r['T']:.1e}), "
+    print(f"{r['name']} {r.get('resampler', 'systematic')} N={r['n']} T={r['T']}: HIP vs the numpy statement: max |dll_t| = {dll:.3e} (tolerance {LL_TOL_PER_OBS * r['T']:.1e}), "
           f"{differing} of {r['n']} first-observation ancestors differ; {swaps} more under the reference's TreeMap duplicate-key rule (D3)")
