@@ -593,6 +593,15 @@ def _rccl_transports(rank):
     return {k: sorted(v) for k, v in sorted(via.items(), key=lambda kv: int(kv[0]))} or {"note": "no channel lines in RCCL's debug output"}
 
 
+def _leg_device_ms(shard):
+    """This rank's last leg on the GPU's own clock, or None where the protocol the walk ended on leaves no pair of stamps (a leg must not
+    fail over a diagnostic)."""
+    try:
+        return round(shard.last_device_us() * 1e-3, 4)
+    except Exception:   # noqa: BLE001
+        return None
+
+
 def run_multi(args, emit=print):
     import torch
     import torch.distributed as dist
@@ -686,7 +695,7 @@ def run_multi(args, emit=print):
         plans.append({"plan": "max" if f.last_from_max else ("ref" if f.last_single else "exact"), "resumes": int(f.last_resumes),
                       "level_redos": int(getattr(f, "last_level_redos", 0)), "capacity_rows": f.last_cap, "wall_ms": round((t1 - t0) * 1e3, 4),
                       # this rank's leg on the GPU's own clock, first kernel of the call to k_finish (no event packets): wall_ms - device_ms is host
-                      "device_ms": round(shard.last_device_us() * 1e-3, 4) if gpu else None})
+                      "device_ms": _leg_device_ms(shard) if gpu else None})
     gc.enable()
     # a pass of its own with HIP events around every kernel and every library-issued collective of this rank's stream (the
     # event records perturb the throughput figure): what a step is made of, per rank
