@@ -953,6 +953,20 @@ double oracle_c_u(uint64_t seed, uint32_t step) {
   cssm_u32x4 b = cssm_philox_draw(seed, 0, step, CSSM_STREAM_U, 0);
   return cssm_u01(b.v[0], b.v[1]);
 }
+/* the accept uniform of MH iteration `it` and the key of filter run `run` (dumped as data for tests/golden/make_literal.py) */
+double oracle_c_mh_u(uint64_t seed, uint64_t it) {
+  cssm_u32x4 b = cssm_philox_draw(seed, it, 0xffffffffu, CSSM_STREAM_HOST, 1);
+  return cssm_u01_open0(b.v[0], b.v[1]);
+}
+uint64_t oracle_c_derive_key(uint64_t seed, uint64_t run) { return cssm_derive_key(seed, run); }
+void oracle_c_mh_normals(uint64_t seed, uint64_t it, uint64_t n_theta, double* out) {   /* the proposal's n_theta standard normals */
+  for (uint64_t j = 0; j < n_theta; j += 2) {
+    double z0, z1;
+    cssm_normal_pair_of(seed, it, (uint32_t)(j / 2), CSSM_STREAM_HOST, 0, CSSM_LOG_TAB, &z0, &z1);
+    out[j] = z0;
+    if (j + 1 < n_theta) out[j + 1] = z1;
+  }
+}
 /* the per-slot uniforms of the stratified grid / of the multinomial draws (dumped as data for tests/golden/make_literal.py) */
 void oracle_c_strat_u_v(uint64_t seed, uint32_t step, uint64_t n, double* out) {
   for (uint64_t i = 0; i < n; ++i) { cssm_u32x4 b = cssm_philox_draw(seed, i, step, CSSM_STREAM_STRAT, 0); out[i] = cssm_u01(b.v[0], b.v[1]); }

@@ -108,6 +108,9 @@ def lib() -> C.CDLL:
             "oracle_c_sys_count": (C.c_uint64, [C.c_double, C.c_double, C.c_uint64]),
             "oracle_c_fix_roundtrip": (C.c_double, [C.c_double]),
             "oracle_c_u": (C.c_double, [C.c_uint64, C.c_uint32]),
+            "oracle_c_mh_u": (C.c_double, [C.c_uint64, C.c_uint64]),
+            "oracle_c_derive_key": (C.c_uint64, [C.c_uint64, C.c_uint64]),
+            "oracle_c_mh_normals": (None, [C.c_uint64, C.c_uint64, C.c_uint64, _dp]),
             "oracle_c_strat_u_v": (None, [C.c_uint64, C.c_uint32, C.c_uint64, _dp]),
             "oracle_c_multi_u_v": (None, [C.c_uint64, C.c_uint32, C.c_uint64, _dp]),
             "oracle_c_exp_v": (None, [_dp, _dp, C.c_size_t]),

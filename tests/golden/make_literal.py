@@ -24,6 +24,10 @@ last weighted observation and the final cloud's first component -- twice: `tie_l
 `tie_first` the same statement with the canonical lower bound (the build's deviation D3: the two differ only where a weight underflowed
 to exactly 0, and are different realisations of the same estimator from the first such swap on).  tests/test_literal_mirror.py holds the CPU oracle (literal mode) and
 -- on the GPU -- the HIP path (contract mode, through the C ABI) against it, with the tolerances stated there.
+
+PMMH: `literal_mh` states MetropolisHastings.mhStep (PMMH.scala:68-81,121; Parameters.scala:65-67) over the numpy filter
+above; the proposal's normals, the accept uniform and the key of every filter run are dumped (oracle_c_mh_normals, oracle_c_mh_u,
+oracle_c_derive_key).  The fixture's chain (12 iterations) has accepted and rejected proposals.
 """
 import ctypes as C
 import json
@@ -325,14 +329,66 @@ def run_case(name, n, T, missing, resampler="systematic"):
     return out
 
 
+PMMH_CASE = {"name": "c2", "n": 512, "T": 25, "missing": 0.1, "delta": 0.05, "iters": 12, "seed": 7}     # (accepts and rejections)
+
+
+def literal_mh(theta0, delta, iters, loglik, proposal_normals, accept_uniform):
+    """MetropolisHastings.mhStep folded `iters` times from init (PMMH.scala:68-81, :121 ll = -1e99), with the proposal of
+    Parameters.perturb(delta) (Parameters.scala:65-67: Gaussian(theta_k, sqrt(delta)) on every stored scalar), a symmetric transition
+    and a flat prior (both log terms 0, as the reference's examples run it).  loglik(it, theta) -> the pseudo-marginal log-likelihood of
+    the filter run for iteration it; proposal_normals(it) / accept_uniform(it): the injected variates."""
+    cur, cur_ll, accepted = np.array(theta0, dtype=np.float64), -1e99, 0
+    sd = math.sqrt(delta)
+    ll, theta, acc = [], [], []
+    for it in range(iters):
+        prop = cur + sd * proposal_normals(it)                     # proposal(s.params)
+        pll = loglik(it, prop)                                      # state = pf(propParams)
+        a = pll + 0.0 + 0.0 - 0.0 - cur_ll - 0.0                    # :71-72
+        if math.log(accept_uniform(it)) < a:                        # :74-75
+            cur, cur_ll, accepted = prop, pll, accepted + 1
+        ll.append(cur_ll); theta.append(cur.copy()); acc.append(accepted)
+    return np.array(ll), np.array(theta), np.array(acc, dtype=np.int64)
+
+
+def run_pmmh(case):
+    sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import cases
+    from oracle import oracle
+    lib = oracle.lib()
+    unparam, init = cases.c2_unparam(), cases.c2_params()
+    t, y, has = cases.poisson_counts(case["T"], missing=case["missing"])
+    theta0 = np.array(init.flattenParams())
+    n, seed = case["n"], case["seed"]
+    dp = C.POINTER(C.c_double)
+
+    def normals(it):
+        z = np.zeros(len(theta0)); lib.oracle_c_mh_normals(seed, it, len(theta0), z.ctypes.data_as(dp)); return z
+    out = dict(case)
+    for key, tie_last in (("tie_last", True), ("tie_first", False)):
+        def loglik(it, theta):
+            model = unparam.run(init.withFlat(theta))
+            k = int(lib.oracle_c_derive_key(seed, it + 1))          # the key of filter run it + 1 (only the variates' addresses)
+            o = oracle.OraclePf(model.descriptor(0), n, k, oracle.LITERAL_SUMS | oracle.LIBM | oracle.TIE_LAST)
+            ll_t, _, _, _ = literal_filter(leaves_of(model), 0, t, y, has, n, lambda s, i, sub: o.dump_normals(s, i, sub),
+                                           lambda s: float(lib.oracle_c_u(k, s)), tie_last)
+            return float(ll_t[-1])
+        ll, theta, acc = literal_mh(theta0, case["delta"], case["iters"], loglik, normals, lambda it: float(lib.oracle_c_mh_u(seed, it)))
+        out[key] = {"ll": [float(v).hex() for v in ll], "accepted": [int(v) for v in acc], "theta": [[float(v).hex() for v in row] for row in theta]}
+    return out
+
+
 def main():
     runs = [run_case(*c) for c in CASES] + [run_case(*c) for c in RESAMPLER_CASES]
     out = os.path.join(HERE, "literal_runs.json")
     json.dump({"made_by": "tests/golden/make_literal.py (numpy " + np.__version__ + "): the numpy statement of the path on variates dumped from "
-                          "the oracle's literal mode; doubles as C99 hex strings", "runs": runs}, open(out, "w"), indent=0)
+                          "the oracle's literal mode; doubles as C99 hex strings", "runs": runs, "pmmh": run_pmmh(PMMH_CASE)}, open(out, "w"), indent=0)
     for r in runs:
         print(r["name"], r["resampler"], "N", r["n"], "T", r["T"], "ll (TreeMap ties)", float.fromhex(r["tie_last"]["ll_t"][-1]), "ll (first key wins)", float.fromhex(r["tie_first"]["ll_t"][-1]),
               "first-observation ancestors that differ between the two:", int(np.sum(np.array(r["tie_last"]["anc_first"]) != np.array(r["tie_first"]["anc_first"]))))
+
+
+    pm = json.load(open(out))["pmmh"]
+    print("pmmh", {k: pm[k] for k in ("name", "n", "T", "delta", "iters")}, "accepted (TreeMap ties)", pm["tie_last"]["accepted"], "(first key wins)", pm["tie_first"]["accepted"])
 
 
 if __name__ == "__main__":

@@ -29,7 +29,8 @@ import cases
 from oracle import oracle
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-RUNS = json.load(open(os.path.join(HERE, "golden", "literal_runs.json")))["runs"]
+_FX = json.load(open(os.path.join(HERE, "golden", "literal_runs.json")))
+RUNS, PMMH = _FX["runs"], _FX["pmmh"]
 IDS = [r["name"] + ("" if r.get("resampler", "systematic") == "systematic" else "-" + r["resampler"]) for r in RUNS]
 ORACLE_RESAMPLER = {"systematic": 0, "stratified": oracle.RESAMPLE_STRATIFIED, "multinomial": oracle.RESAMPLE_MULTINOMIAL}
 HIP_RESAMPLER = {"systematic": 0, "stratified": 1, "multinomial": 2}      # CSSM_OPT_RESAMPLER (include/cssm_pf.h)
@@ -128,3 +129,61 @@ def test_hip_path_within_stated_tolerance_of_the_numpy_statement(r):
     g.close()
     print(f"{r['name']} {r.get('resampler', 'systematic')} N={r['n']} T={r['T']}: HIP vs the numpy statement: max |dll_t| = {dll:.3e} (tolerance {LL_TOL_PER_OBS * r['T']:.1e}), "
           f"{differing} of {r['n']} first-observation ancestors differ; {swaps} more under the reference's TreeMap duplicate-key rule (D3)")
+
+
+# ----------------------------------------------------------------------------------------------------------------- PMMH
+def _pmmh_fx(key):
+    q = PMMH[key]
+    return (np.array([float.fromhex(v) for v in q["ll"]]), np.array([[float.fromhex(v) for v in r] for r in q["theta"]]),
+            np.array(q["accepted"], dtype=np.int64))
+
+
+def _pmmh_data():
+    t, y, has = cases.poisson_counts(PMMH["T"], missing=PMMH["missing"])
+    return cases.c2_model(), t, y, has
+
+
+@pytest.mark.parametrize("key", ["tie_last", "tie_first"])
+def test_oracle_pmmh_in_literal_mode_equals_the_numpy_statement_of_mhStep(key):
+    """oracle_pmmh_run against the numpy statement of MetropolisHastings.mhStep (PMMH.scala:68-81) over the numpy filter: the same proposals,
+    the same accept / reject decisions (the fixture's chain has both), log-likelihoods to 1e-12."""
+    model, t, y, has = _pmmh_data()
+    fll, fth, facc = _pmmh_fx(key)
+    assert 0 < facc[-1] < PMMH["iters"] and facc[0] == 1          # (ll = -1e99 at the start: the first proposal is always adopted, :121)
+    o = oracle.OraclePf(model.descriptor(), PMMH["n"], 1, oracle.LITERAL_SUMS | oracle.LIBM | (oracle.TIE_LAST if key == "tie_last" else 0))
+    ll, th, acc, _ = o.pmmh(model.descriptor(), np.array(model.parameters().flattenParams()), PMMH["delta"], t, y, has, seed=PMMH["seed"],
+                            n_iters=PMMH["iters"])
+    np.testing.assert_array_equal(acc, facc)
+    np.testing.assert_array_equal(th, fth)                        # (theta + sqrt(delta) z: the same doubles on both sides)
+    assert np.max(np.abs(ll - fll)) <= LL_TOL_LITERAL
+
+
+def _check_pmmh_contract(ll, th, acc):
+    fll, fth, facc = _pmmh_fx("tie_first")
+    np.testing.assert_array_equal(acc, facc)
+    np.testing.assert_array_equal(th, fth)
+    d = float(np.max(np.abs(ll - fll)))
+    assert d <= LL_TOL_PER_OBS * PMMH["T"] and d <= 1e-11, d
+    return d
+
+
+def test_oracle_pmmh_in_contract_mode_within_stated_tolerance_of_the_numpy_statement():
+    model, t, y, has = _pmmh_data()
+    o = oracle.OraclePf(model.descriptor(), PMMH["n"], 1)
+    ll, th, acc, _ = o.pmmh(model.descriptor(), np.array(model.parameters().flattenParams()), PMMH["delta"], t, y, has, seed=PMMH["seed"],
+                            n_iters=PMMH["iters"])
+    _check_pmmh_contract(ll, th, acc)
+
+
+@pytest.mark.gpu
+def test_hip_pmmh_chain_within_stated_tolerance_of_the_numpy_statement():
+    """cssm_pmmh_run (the chain loop in the library, filters on the GPU) and its speculative form against the numpy statement."""
+    from composablestatespacemodels_amd import Data
+    from composablestatespacemodels_amd.pmmh import pmmh_native, pmmh_native_speculative
+    model, t, y, has = _pmmh_data()
+    data = [Data(float(a), float(b) if h else None) for a, b, h in zip(t, y, has)]
+    ll, th, acc, _ = pmmh_native(cases.c2_unparam(), model.parameters(), data, PMMH["n"], PMMH["delta"], PMMH["iters"], seed=PMMH["seed"])
+    d = _check_pmmh_contract(ll, th, acc)
+    ll2, th2, acc2, _ = pmmh_native_speculative(cases.c2_unparam(), model.parameters(), data, PMMH["n"], PMMH["delta"], PMMH["iters"], seed=PMMH["seed"])
+    _check_pmmh_contract(ll2, th2, acc2)
+    print(f"PMMH N={PMMH['n']} T={PMMH['T']} {PMMH['iters']} iterations: HIP chain vs the numpy statement: accepted {acc.tolist()} identical, max |dll| = {d:.3e}")
