@@ -84,3 +84,69 @@ def test_wave_sums_kernel_on_a_level_far_above_the_max(yout):
     assert new[0] == ol
     np.testing.assert_array_equal(new[2], oess)
     np.testing.assert_array_equal(new[3], o.ancestors())
+
+
+def _two_component_model_outside_the_table():
+    """poisson(ouProcess(2)): d = 2, a structure the library holds no ahead-of-time kernel for -- its propagate is compiled at run time."""
+    from composablestatespacemodels_amd import Model, Parameters, Sde, SdeParameter
+    return Model.poisson(Sde.ouProcess(2)).run(Parameters.apply(None, SdeParameter.ouParameter(0.0, 1.0, 0.2, [0.5, -0.25], 0.3)))
+
+
+def test_wave_ranges_in_a_runtime_compiled_propagate():
+    """The wave-range mapping is a flag of the LAUNCH, so a propagate kernel compiled at run time (hipRTC: a model outside the table) takes it
+    like the ahead-of-time ones: the DEFAULT path of a d = 2 cloud beyond 2^20 particles (k_offspring_wave behind it) against the 128-bit
+    kernel bit for bit, and -- at a size the one-thread oracle affords, the mapping forced -- against the oracle."""
+    from composablestatespacemodels_amd import _abi
+    import ctypes as C
+    model = _two_component_model_outside_the_table()
+    t, y, has = cases.poisson_counts(6, missing=0.2)
+    info = (C.c_uint64 * 4)()       # compiled, from disk, launches, failures
+    _abi.check(_abi.load_library().cssm_rtc_info(info)); before = list(info)
+    n = (1 << 21) + 4099
+
+    def run(ws):
+        g = NativePf(model, n, cases.SEED)
+        if ws is not None:
+            g.set_option(OPT_WAVE_SUMS, ws)
+        ll, ll_t, ess, _ = g.run(t, y, has)
+        out = (ll, ll_t, ess, g.ancestors(), g.particles()); g.close()
+        return out
+    default = run(None)
+    _abi.check(_abi.load_library().cssm_rtc_info(info))
+    assert info[2] - before[2] == len(t) and info[3] == before[3] == 0, "the model was expected to run on runtime-compiled kernels"
+    _same(default, run(0), "default path (wave ranges) / 128-bit kernel")
+    _same(default, run(2), "default path / wave ranges forced")
+    n2 = 70 * 1024 + 3
+    new = _run(model, n2, t, y, has, 1, whole=1)
+    o = oracle.OraclePf(model.descriptor(), n2, cases.SEED)
+    ol, oll, oess, _ = o.filter(t, y, has)
+    assert new[0] == ol
+    np.testing.assert_array_equal(new[2], oess)
+    np.testing.assert_array_equal(new[3], o.ancestors())
+    np.testing.assert_array_equal(new[4], o.particles())
+
+
+def test_streaming_steps_on_the_default_path_beyond_2_20_particles():
+    """cssm_pf_step (one observation per call, the shape of the reference's Flow.scan) at d = 1 beyond 2^20 particles takes the wave-range
+    propagate + k_offspring_wave by default: the same bits as with the mapping switched off, observation by observation."""
+    model = cases.c1_model()
+    n = (1 << 21) + 17
+    t, y, has = cases.poisson_counts(5, missing=0.2)
+
+    def run(ws):
+        g = NativePf(model, n, cases.SEED)
+        if ws is not None:
+            g.set_option(OPT_WAVE_SUMS, ws)
+        g.init(float(np.min(t)))
+        out = []
+        for s in range(len(t)):
+            ll, ess = g.step(float(t[s]), float(y[s]), bool(has[s]))
+            out.append((ll, ess, g.ancestors().copy()))
+        cloud = g.particles(); g.close()
+        return out, cloud
+    a, ca = run(None)
+    b, cb = run(0)
+    for s, (x, z) in enumerate(zip(a, b)):
+        assert x[0] == z[0] and x[1] == z[1], s
+        np.testing.assert_array_equal(x[2], z[2])
+    np.testing.assert_array_equal(ca, cb)
