@@ -266,7 +266,7 @@ def run_single(args, emit=print):
 
     # Order: the roofline legs FIRST.  W = 5 warm-up steps are 0.1 ms of device work, and the legs of a process that has kept the GPU busy
     # for a few ms in all run 5-15 % slower than every later one (leg after leg of the same handle: 522 493 461 465 468 ... 445 us, level
-    # after ~15 legs): timed first, R = 7 legs of 20 steps measure that ramp, not the filter.  BENCH_TIMED_FIRST=1 restores that order.
+    # after ~15 legs): timed first, the legs of 20 steps measure that ramp, not the filter.  BENCH_TIMED_FIRST=1 restores that order.
     # ... and the timed filter's handle is CREATED ahead of them and the roofline handle closed behind the timed legs, so that no allocation, no
     # hipFree and no idle gap stands between the roofline legs and the W warm-up steps: a GPU that has idled for a millisecond or more runs the
     # legs 1.5-5 ms into new work up to 14 % slower before it settles (tools/leg_drift.py, device clock stamps: 434 434 445 456 467 496 491
@@ -313,7 +313,7 @@ def run_single(args, emit=print):
         "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
         "config": {"workload": workload_text(args.model, n, K),
                    "particles_per_gpu": n, "observations": K, "latent_dim": d, "seed": 20260101},
-        "repeats": R, "value_is": "median over `repeats` timed legs of K steps each (every leg counts, none is discarded: the legs 2-5 ms behind the idle gap in front of the filter run slower on the DEVICE -- device_ms_each), continuing the filter the warm-up steps started (cssm_pf_ll_filter_more); the roofline legs (a handle of their own) run behind them", "wall_ms_each": [w * 1e3 for w in walls],
+        "repeats": R, "value_is": "median over `repeats` timed legs of K steps each (every leg counts, none is discarded: the legs 2-5 ms behind the idle gap in front of the filter run slower on the DEVICE -- device_ms_each), continuing the filter the warm-up steps started (cssm_pf_ll_filter_more); the roofline legs (a handle of their own) run before them, the timed filter's handle is created ahead of those and the roofline handle closed behind the timed legs (no allocation, hipFree or idle gap in front of the W warm-up steps)", "wall_ms_each": [w * 1e3 for w in walls],
         "roofline": roof,
         "roofline_generic": roof_generic,
         "kernels_us": kernels_us,
